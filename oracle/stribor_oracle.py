@@ -1,0 +1,417 @@
+"""CPU oracle for the stribor coupling-flow hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a functional restatement (torch CPU ops, fp32 or fp64 depending on the dtype of
+the tensors handed in) of the reference algorithm for the path named by BASELINE.json.  It is
+NOT part of the product: only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` may import it.  The product path (``stribor_amd``) never does.
+
+Parity pin: every function here is checked in ``tests/test_oracle_golden.py`` against vectors
+captured from the unmodified reference imported in the build container
+(``tests/golden/make_golden.py`` -> ``tests/golden/*.npz``) and against the reference's own
+known-answer test (stribor/test/test_normalizing_flow.py:45-55) and exact mask vectors
+(stribor/test/test_mask.py:4-30).
+
+The reference is a class hierarchy of nn.Modules; the oracle is deliberately a set of pure
+functions over a *flow spec*: a list of dicts, one per transform, holding plain tensors.
+
+    {'kind': 'coupling_affine', 'mask': 'ordered_right_half', 'net': NET}
+    {'kind': 'coupling_rqs',    'mask': ..., 'net': NET, 'n_bins': K, 'lower': a, 'upper': b}
+    {'kind': 'affine',          'log_scale': [1,D] or [D], 'shift': same}       (no latent_net)
+    {'kind': 'affine_lu',       'weight': [D,D], 'log_diag': [1,D], 'bias': [1,D]}
+    {'kind': 'matrix_exp',      'weight': [D,D], 'diag': [D], 'bias': [D] or None, 'log_time': bool}
+    {'kind': 'permute',         'perm': int64[D]}
+    {'kind': 'flip'}
+    NET = {'weights': [W0, W1, ...], 'biases': [b0, b1, ...], 'activation': 'Tanh'}
+
+All ``file:line`` citations are into /root/reference/stribor/.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+MIN_BIN_WIDTH = 1e-3      # util/rational_quadratic_spline.py:22
+MIN_BIN_HEIGHT = 1e-3     # util/rational_quadratic_spline.py:23
+MIN_DERIVATIVE = 1e-3     # util/rational_quadratic_spline.py:24
+SEARCH_EPS = 1e-6         # util/search_sorted.py:3
+
+
+# ----------------------------------------------------------------------------------------------
+# masks                                                                          util/mask.py:6-57
+# ----------------------------------------------------------------------------------------------
+def mask_vector(name: str, dim: int) -> Tensor:
+    """0/1 float vector; 1 = pass-through + conditioner input, 0 = transformed.
+
+    util/mask.py:6-20 (name dispatch), :22-23 (none), :35-45 (ordered), :47-57 (parity).
+    'random_half' (:25-33) is redrawn on every call in the reference (quirk Q5) and is out of
+    parity scope.
+    """
+    if name == 'none':
+        return torch.tensor([0.0])                                   # mask.py:22-23
+    if name in ('ordered_right_half', 'ordered_0', 'ordered_left_half', 'ordered_1'):
+        if dim == 1:
+            return torch.tensor([1.0])                               # mask.py:37-38
+        n_zero = int(np.clip(int(dim * 0.5), 1, dim - 1))            # mask.py:40
+        m = torch.ones(dim)
+        m[:n_zero] = 0.0                                             # mask.py:41
+        if name in ('ordered_left_half', 'ordered_1'):               # right_zero=True, mask.py:12
+            m = 1.0 - m                                              # mask.py:42-43
+        return m
+    if name in ('parity_even', 'parity_odd'):
+        if dim == 1:
+            return torch.tensor([1.0])                               # mask.py:50-51
+        m = torch.ones(dim)
+        m[::2] = 0.0                                                 # mask.py:53
+        if name == 'parity_odd':                                     # even_zero=True, mask.py:17
+            m = 1.0 - m                                              # mask.py:54-55
+        return m
+    raise NotImplementedError(name)                                  # mask.py:20
+
+
+# ----------------------------------------------------------------------------------------------
+# conditioner MLP                                                               net/mlp.py:48-65
+# ----------------------------------------------------------------------------------------------
+def mlp_forward(net: Dict, z: Tensor) -> Tensor:
+    """Linear -> (act -> Linear)*; weights are torch [out, in].  net/mlp.py:48-58, :65."""
+    act = getattr(torch.nn, net.get('activation', 'Tanh'))()         # mlp.py:38-39
+    n = len(net['weights'])
+    h = z
+    for i in range(n):
+        h = F.linear(h, net['weights'][i], net['biases'][i])
+        if i + 1 < n:
+            h = act(h)
+    return h
+
+
+# ----------------------------------------------------------------------------------------------
+# coupling glue                                                           flows/coupling.py:48-95
+# ----------------------------------------------------------------------------------------------
+def _coupling_mask(layer: Dict, x: Tensor) -> Tensor:
+    return mask_vector(layer['mask'], x.shape[-1]).to(x).expand_as(x)   # coupling.py:53
+
+
+def _conditioning(x: Tensor, m: Tensor, latent: Optional[Tensor]) -> Tensor:
+    z = x * m                                                        # coupling.py:61
+    if x.shape[-1] == 1:
+        z = z * 0                                                    # coupling.py:62-63
+    if latent is not None:
+        z = torch.cat([z, latent], -1)                               # coupling.py:64-65
+    return z
+
+
+# ----------------------------------------------------------------------------------------------
+# elementwise affine                                                   flows/affine.py:59-123
+# ----------------------------------------------------------------------------------------------
+def affine_params(layer: Dict, z: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
+    if 'net' in layer and layer['net'] is not None:
+        p = mlp_forward(layer['net'], z)
+        log_scale, shift = p.chunk(2, dim=-1)                        # affine.py:66
+        return log_scale, shift
+    return layer['log_scale'], layer['shift']                        # affine.py:63-64
+
+
+def affine_apply(x: Tensor, log_scale: Tensor, shift: Tensor, reverse: bool) -> Tensor:
+    if reverse:
+        return (x - shift) * torch.exp(-log_scale)                   # affine.py:106
+    return x * torch.exp(log_scale) + shift                          # affine.py:108
+
+
+# ----------------------------------------------------------------------------------------------
+# rational-quadratic spline            util/rational_quadratic_spline.py:11-251, search_sorted.py
+# ----------------------------------------------------------------------------------------------
+def rqs_params_from_net(p: Tensor, dim: int, n_bins: int) -> Tuple[Tensor, Tensor, Tensor]:
+    """[..., D*(3K-1)] -> w[..., D, K], h[..., D, K], d[..., D, K-1].  flows/spline.py:82-86."""
+    p = p.view(*p.shape[:-1], dim, 3 * n_bins - 1)
+    return p[..., :n_bins], p[..., n_bins:2 * n_bins], p[..., 2 * n_bins:]
+
+
+def rqs_unconstrained(x: Tensor, uw: Tensor, uh: Tensor, ud: Tensor, inverse: bool,
+                      lower: float, upper: float,
+                      left=None, right=None, bottom=None, top=None) -> Tuple[Tensor, Tensor]:
+    """Per-element restatement of unconstrained_rational_quadratic_spline + rational_quadratic_spline.
+
+    Differences from the reference, all value-preserving:
+      * no boolean compaction (:161-164) / scatter (:250): every element is evaluated with its
+        input clamped into the domain and the tails are selected at the end (:86-87);
+      * the domain check (:167-178, quirk Q1: an accidental [M] x [M,1] broadcast, O(M^2)) is
+        vacuous after the `inside` selection and is not reproduced;
+      * `assert discriminant >= 0` (:223) is kept as a check on the inside elements.
+    Returns (outputs, log-diag-Jacobian); the inverse ljd is already negated (:234).
+    """
+    if all(v is not None for v in (left, right, bottom, top)):       # :55-61
+        lo_in, hi_in = (bottom, top) if inverse else (left, right)
+    else:
+        left = bottom = lower                                        # :63-64
+        right = top = upper
+        lo_in, hi_in = lower, upper
+    # the reference turns scalar bounds into fp32 tensors (:167-172) before using them in arithmetic
+    as_t = lambda v: v.to(x) if torch.is_tensor(v) else torch.tensor(float(v), dtype=x.dtype)
+    left, right, bottom, top = as_t(left), as_t(right), as_t(bottom), as_t(top)
+    K = uw.shape[-1]
+    if MIN_BIN_WIDTH * K > 1.0:
+        raise ValueError('Minimal bin width too large for the number of bins')     # :96-97
+    if MIN_BIN_HEIGHT * K > 1.0:
+        raise ValueError('Minimal bin height too large for the number of bins')    # :98-99
+
+    uw = uw.expand(*x.shape, -1)                                     # :67-69
+    uh = uh.expand(*x.shape, -1)
+    ud = ud.expand(*x.shape, -1)
+    inside = (x >= lo_in) & (x <= hi_in)                             # :71 (closed interval)
+
+    if ud.shape[-1] == K - 1:                                        # :79-83
+        const = float(np.log(np.exp(1 - MIN_DERIVATIVE) - 1))
+        ud = F.pad(ud, pad=(1, 1))
+        ud = ud.clone()
+        ud[..., 0] = const
+        ud[..., -1] = const
+
+    w = MIN_BIN_WIDTH + (1 - MIN_BIN_WIDTH * K) * F.softmax(uw, dim=-1)     # :101-102
+    h = MIN_BIN_HEIGHT + (1 - MIN_BIN_HEIGHT * K) * F.softmax(uh, dim=-1)   # :104-105
+    d = MIN_DERIVATIVE + F.softplus(ud)                                      # :107
+
+    # knots: cumsum -> pad -> rescale -> pin ends -> re-difference             :180-192
+    cw = F.pad(torch.cumsum(w, dim=-1), pad=(1, 0), value=0.0)
+    cw = (right - left) * cw + left
+    cw[..., 0] = left
+    cw[..., -1] = right
+    w = cw[..., 1:] - cw[..., :-1]
+    ch = F.pad(torch.cumsum(h, dim=-1), pad=(1, 0), value=0.0)
+    ch = (top - bottom) * ch + bottom
+    ch[..., 0] = bottom
+    ch[..., -1] = top
+    h = ch[..., 1:] - ch[..., :-1]
+
+    xin = torch.where(inside, x, torch.full_like(x, float(lo_in)))   # keep tails finite
+    edges = (ch if inverse else cw).clone()                          # :194-197
+    edges[..., -1] += SEARCH_EPS                                     # search_sorted.py:4 (in place there)
+    b = (torch.sum(xin[..., None] >= edges, dim=-1) - 1)[..., None]  # search_sorted.py:5
+    b = b.clamp(0, K - 1)                                            # only hit by discarded tail lanes
+
+    g = lambda t: t.gather(-1, b)[..., 0]
+    cw_b, w_b = g(cw), g(w)                                          # :199-200
+    ch_b = g(ch)                                                     # :202
+    delta = h / w                                                    # :203
+    s_b = g(delta)                                                   # :204
+    d_b = g(d)                                                       # :206
+    d_b1 = g(d[..., 1:])                                             # :207
+    h_b = g(h)                                                       # :209
+
+    if inverse:
+        dy = xin - ch_b
+        q = d_b + d_b1 - 2 * s_b
+        a = dy * q + h_b * (s_b - d_b)                               # :212-215
+        bb = h_b * d_b - dy * q                                      # :216-219
+        c = -s_b * dy                                                # :220
+        disc = bb.pow(2) - 4 * a * c                                 # :222
+        if not bool((disc[inside] >= 0).all()):                      # :223
+            raise AssertionError('negative discriminant')
+        root = (2 * c) / (-bb - torch.sqrt(disc))                    # :225
+        out = root * w_b + cw_b                                      # :226
+        tomt = root * (1 - root)                                     # :228
+        den = s_b + q * tomt                                         # :229-230
+        dnum = s_b.pow(2) * (d_b1 * root.pow(2) + 2 * s_b * tomt + d_b * (1 - root).pow(2))  # :231-233
+        ljd = -torch.log(dnum) + 2 * torch.log(den)                  # :234 (sign already flipped)
+    else:
+        theta = (xin - cw_b) / w_b                                   # :236
+        tomt = theta * (1 - theta)                                   # :237
+        num = h_b * (s_b * theta.pow(2) + d_b * tomt)                # :239-240
+        den = s_b + (d_b + d_b1 - 2 * s_b) * tomt                    # :241-242
+        out = ch_b + num / den                                       # :243
+        dnum = s_b.pow(2) * (d_b1 * theta.pow(2) + 2 * s_b * tomt + d_b * (1 - theta).pow(2))  # :245-247
+        ljd = torch.log(dnum) - 2 * torch.log(den)                   # :248
+
+    out = torch.where(inside, out, x)                                # :86
+    ljd = torch.where(inside, ljd, torch.zeros_like(ljd))            # :87
+    return out, ljd
+
+
+def rqs_from_layer(layer: Dict, x: Tensor, z: Optional[Tensor], reverse: bool) -> Tuple[Tensor, Tensor]:
+    """Spline.forward_and_log_diag_jacobian, flows/spline.py:101-105."""
+    D, K = x.shape[-1], layer['n_bins']
+    if layer.get('net') is not None:
+        uw, uh, ud = rqs_params_from_net(mlp_forward(layer['net'], z), D, K)
+    else:
+        uw, uh, ud = layer['width'], layer['height'], layer['derivative']        # spline.py:78-79
+    return rqs_unconstrained(x, uw, uh, ud, reverse, layer.get('lower', 0), layer.get('upper', 1))
+
+
+# ----------------------------------------------------------------------------------------------
+# per-transform forward / inverse / log_det_jacobian                       flow.py:8-47 protocol
+# ----------------------------------------------------------------------------------------------
+def _get_time(layer: Dict, t, shape) -> Tensor:
+    if not torch.is_tensor(t):
+        t = torch.ones(*shape[:-1], 1) * t                           # affine.py:237-238
+    if layer.get('log_time', False):
+        t = torch.log1p(t.abs())                                     # affine.py:239-240
+    return t
+
+
+def _matexp_lu(layer: Dict) -> Tuple[Tensor, Tensor]:
+    W = layer['weight']
+    eye = torch.eye(W.shape[0]).to(W)
+    return torch.tril(W, diagonal=-1) + eye, torch.triu(W) + eye     # affine.py:222-226
+
+
+def transform_apply(layer: Dict, x: Tensor, reverse: bool, latent: Optional[Tensor] = None,
+                    t=1.0) -> Tensor:
+    """f(x) (reverse=False) or f.inverse(x) (reverse=True) for one transform."""
+    kind = layer['kind']
+    if kind in ('coupling_affine', 'coupling_rqs'):
+        m = _coupling_mask(layer, x)                                 # coupling.py:70
+        z = _conditioning(x, m, latent)                              # coupling.py:71
+        if kind == 'coupling_affine':
+            ls, sh = affine_params(layer, z)
+            y_ = affine_apply(x, ls, sh, reverse)                    # coupling.py:73-76
+        else:
+            y_, _ = rqs_from_layer(layer, x, z, reverse)
+        return y_ * (1 - m) + x * m                                  # coupling.py:78
+    if kind == 'affine':
+        ls, sh = affine_params(layer, latent)
+        return affine_apply(x, ls, sh, reverse)
+    if kind == 'rqs':
+        y, _ = rqs_from_layer(layer, x, latent, reverse)
+        return y
+    if kind == 'affine_lu':
+        W = layer['weight']
+        eye = torch.eye(W.shape[0]).to(W)
+        L = torch.tril(W, -1) + eye                                  # affine.py:148-150
+        U = torch.triu(W, 1) + eye * layer['log_diag'].exp()         # affine.py:152-154
+        if reverse:
+            v = x - layer['bias']                                    # affine.py:160
+            v = torch.linalg.solve_triangular(U, v, upper=True, left=False)     # :161
+            return torch.linalg.solve_triangular(L, v, upper=False, left=False)  # :162
+        return x @ (L @ U) + layer['bias']                           # affine.py:157
+    if kind == 'matrix_exp':
+        tt = _get_time(layer, t, x.shape).to(x)                      # affine.py:251
+        bias = layer.get('bias', None)
+        if reverse:
+            tt = -tt                                                 # affine.py:254
+            if bias is not None:
+                x = x - bias                                         # affine.py:255-256
+        L, U = _matexp_lu(layer)
+        v = torch.linalg.solve_triangular(L, x.unsqueeze(-1), upper=False, unitriangular=True).squeeze(-1)  # :260
+        v = torch.linalg.solve_triangular(U, v.unsqueeze(-1), upper=True, unitriangular=False).squeeze(-1)  # :261
+        v = v * (layer['diag'] * tt).exp()                           # :263
+        v = F.linear(v, U)                                           # :265
+        v = F.linear(v, L)                                           # :266
+        if not reverse and bias is not None:
+            v = v + bias                                             # :268-269
+        return v
+    if kind == 'permute':
+        perm = layer['perm']
+        if reverse:
+            inv = torch.empty_like(perm)
+            inv[perm] = torch.arange(perm.numel())                   # permute.py:67-68
+            return x[..., inv]                                       # permute.py:75
+        return x[..., perm]                                          # permute.py:71
+    if kind == 'flip':
+        return torch.flip(x, [-1])                                   # permute.py:35,38
+    raise ValueError(kind)
+
+
+def transform_ldj(layer: Dict, x: Tensor, latent: Optional[Tensor] = None, t=1.0) -> Tensor:
+    """f.log_det_jacobian(x, y): forward-direction log|det J| at x, shape [..., 1]."""
+    kind = layer['kind']
+    if kind in ('coupling_affine', 'coupling_rqs'):
+        m = _coupling_mask(layer, x)                                 # coupling.py:91
+        z = _conditioning(x, m, latent)                              # coupling.py:92 (2nd MLP call, Q2)
+        if kind == 'coupling_affine':
+            ls, _ = affine_params(layer, z)                          # affine.py:122
+            diag = ls.expand_as(x)                                   # affine.py:123
+        else:
+            _, diag = rqs_from_layer(layer, x, z, False)             # spline.py:142-143
+        return (diag * (1 - m)).sum(-1, keepdim=True)                # coupling.py:95
+    if kind == 'affine':
+        ls, _ = affine_params(layer, latent)
+        return ls.expand_as(x).sum(-1, keepdim=True)                 # affine.py:109
+    if kind == 'rqs':
+        _, diag = rqs_from_layer(layer, x, latent, False)
+        return diag.sum(-1, keepdim=True)                            # spline.py:117
+    if kind == 'affine_lu':
+        return layer['log_diag'].expand_as(x).sum(-1, keepdim=True)  # affine.py:171
+    if kind == 'matrix_exp':
+        tt = _get_time(layer, t, x.shape).to(x)
+        return layer['diag'].sum() * tt                              # affine.py:287-288
+    if kind in ('permute', 'flip'):
+        return torch.zeros_like(x[..., :1])                          # permute.py:41,78
+    raise ValueError(kind)
+
+
+def transform_inverse_and_ldj(layer: Dict, y: Tensor, latent=None, t=1.0) -> Tuple[Tensor, Tensor]:
+    """Transform.inverse_and_log_det_jacobian default, flow.py:42-47 (conditioner runs twice)."""
+    x = transform_apply(layer, y, True, latent, t)
+    return x, -transform_ldj(layer, x, latent, t)
+
+
+def transform_forward_and_ldj(layer: Dict, x: Tensor, latent=None, t=1.0) -> Tuple[Tensor, Tensor]:
+    """Transform.forward_and_log_det_jacobian default, flow.py:35-40."""
+    y = transform_apply(layer, x, False, latent, t)
+    return y, transform_ldj(layer, x, latent, t)
+
+
+# ----------------------------------------------------------------------------------------------
+# base density + flow container                                 dist/normal.py:37,52-54; flow.py
+# ----------------------------------------------------------------------------------------------
+def unit_normal_log_prob(x: Tensor) -> Tensor:
+    """Independent(Normal(0,1),1).log_prob: sum_d [-(x-0)^2/(2*1) - log(1) - log(sqrt(2pi))]."""
+    var = 1.0
+    lp = -((x - 0.0) ** 2) / (2 * var) - math.log(1.0) - math.log(math.sqrt(2 * math.pi))
+    return lp.sum(-1)
+
+
+def flow_inverse_and_ldj(spec: Sequence[Dict], y: Tensor, latent=None, t=1.0,
+                         trace: Optional[List] = None) -> Tuple[Tensor, Tensor]:
+    """NormalizingFlow.inverse_and_log_det_jacobian, flow.py:118-125."""
+    acc = 0
+    for layer in reversed(list(spec)):
+        y, ldj = transform_inverse_and_ldj(layer, y, latent, t)
+        acc = acc + ldj
+        if trace is not None:
+            trace.append((y, ldj))
+    return y, acc
+
+
+def flow_forward_and_ldj(spec: Sequence[Dict], x: Tensor, latent=None, t=1.0) -> Tuple[Tensor, Tensor]:
+    """NormalizingFlow.forward_and_log_det_jacobian, flow.py:109-116."""
+    acc = 0
+    for layer in spec:
+        x, ldj = transform_forward_and_ldj(layer, x, latent, t)
+        acc = acc + ldj
+    return x, acc
+
+
+def flow_forward(spec: Sequence[Dict], x: Tensor, latent=None, t=1.0) -> Tensor:
+    for layer in spec:                                               # flow.py:99-102
+        x = transform_apply(layer, x, False, latent, t)
+    return x
+
+
+def flow_inverse(spec: Sequence[Dict], y: Tensor, latent=None, t=1.0) -> Tensor:
+    for layer in reversed(list(spec)):                               # flow.py:104-107
+        y = transform_apply(layer, y, True, latent, t)
+    return y
+
+
+def flow_log_prob(spec: Sequence[Dict], y: Tensor, latent=None, t=1.0) -> Tensor:
+    """NormalizingFlow.log_prob with a UnitNormal base, flow.py:127-130 -> [..., 1]."""
+    x, acc = flow_inverse_and_ldj(spec, y, latent, t)
+    return unit_normal_log_prob(x).unsqueeze(-1) + acc
+
+
+def spec_to(spec: Sequence[Dict], dtype: torch.dtype) -> List[Dict]:
+    """Deep-copy a spec casting floating tensors (used for the fp64 'truth' runs)."""
+    def cv(v):
+        if torch.is_tensor(v):
+            return v.to(dtype) if v.is_floating_point() else v.clone()
+        if isinstance(v, dict):
+            return {k: cv(u) for k, u in v.items()}
+        if isinstance(v, list):
+            return [cv(u) for u in v]
+        return v
+    return [cv(l) for l in spec]
