@@ -1,0 +1,191 @@
+/*
+ * stribor_hip.h — C ABI of libstribor_hip.so: the MI355X (gfx950) kernels behind stribor's
+ * coupling-flow hot path (NormalizingFlow.log_prob / forward / inverse over Coupling(Affine|Spline),
+ * Affine, AffineLU, MatrixExponential, Permute/Flip, UnitNormal).
+ *
+ * The reference (mbilos/stribor, /root/reference) is pure Python and has NO FFI; its plugin
+ * boundary is the `Transform` class protocol (stribor/flow.py:8-69).  The entry points below are
+ * therefore what a ctypes binding inside stribor's own classes would call — each one cites the
+ * reference method whose torch-op chain it replaces.  INTEGRATION.md shows that binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`;
+ *   - the library allocates nothing, keeps no global state and never synchronises: all work is
+ *     enqueued on `stream` (a hipStream_t passed as void*; NULL = the default stream);
+ *   - tensors are row-major, rows = samples; `x`/`y` are [n_rows, dim] with element type
+ *     `dtype` (SX_F32 or SX_BF16 storage); all arithmetic is fp32; ldj / log-prob are fp32;
+ *   - every function returns 0 on success, a negative SX_E* code for a bad argument, or a
+ *     positive hipError_t; sx_last_error() gives a thread-local message;
+ *   - data-dependent error conditions of the reference (ValueError / assert inside
+ *     rational_quadratic_spline.py:175-178,223) are reported through a caller-owned device
+ *     flag word (`err_flag`, bit mask SX_FLAG_*), never by aborting.
+ */
+#ifndef STRIBOR_HIP_H
+#define STRIBOR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SX_ABI_VERSION 1
+
+/* storage dtypes of x / y */
+#define SX_F32  0
+#define SX_BF16 1
+
+/* error codes */
+#define SX_OK            0
+#define SX_E_BADARG     -1
+#define SX_E_UNSUPPORTED -2
+
+/* device error-flag bits */
+#define SX_FLAG_RQS_NEG_DISCRIMINANT 1u   /* rational_quadratic_spline.py:223 assert */
+#define SX_FLAG_NONFINITE            2u
+
+/* hidden activations of the conditioner (torch.nn names, stribor/net/mlp.py:38-39) */
+#define SX_ACT_IDENTITY  0
+#define SX_ACT_TANH      1
+#define SX_ACT_RELU      2
+#define SX_ACT_SIGMOID   3
+#define SX_ACT_ELU       4
+#define SX_ACT_SOFTPLUS  5
+#define SX_ACT_LEAKYRELU 6
+#define SX_ACT_SILU      7
+#define SX_ACT_GELU      8
+
+int         sx_abi_version(void);
+const char *sx_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Elementwise / HBM-bound kernels (params already in HBM)
+ * ------------------------------------------------------------------------------------------ */
+
+/* Permute / Flip: y[n, j] = x[n, idx[j]]   (stribor/flows/permute.py:35,38,71,75).
+ * Bit-exact byte move; elem_bytes is 2 or 4. */
+int sx_permute(const void *x, void *y, const int32_t *idx, int64_t n_rows, int32_t dim,
+               int32_t elem_bytes, void *stream);
+
+/* Affine coupling, element-wise part (stribor/flows/affine.py:104-109 + coupling.py:78,95).
+ *   params[n, 0:n_live]        = log_scale of the live (transformed, mask==0) dims
+ *   params[n, n_live:2*n_live] = shift of the live dims        (row n at params + n*params_stride;
+ *                                                               params_stride = 0 broadcasts one row)
+ *   live_idx[i] = column of x the i-th live parameter applies to; other columns are copied.
+ *   live_idx == NULL means the contiguous range [live_start, live_start + n_live) (vectorised path).
+ *   forward:  y = x*exp(ls) + sh       reverse:  y = (x - sh)*exp(-ls)
+ *   ldj (nullable, [n_rows]):  ldj[n] = (ldj_accumulate ? ldj[n] : 0) + ldj_scale * sum_i ls[n,i]
+ * Also serves st.Affine without coupling (live_idx = 0..dim-1). */
+int sx_affine_coupling(const void *x, void *y, float *ldj, const float *params, int64_t params_stride,
+                       const int32_t *live_idx, int32_t live_start, int32_t n_live, int64_t n_rows,
+                       int32_t dim, int32_t dtype, int32_t reverse, int32_t ldj_accumulate,
+                       float ldj_scale, void *stream);
+
+/* Rational-quadratic spline, element-wise part
+ * (stribor/util/rational_quadratic_spline.py:11-251, util/search_sorted.py:3-5, flows/spline.py:82-86).
+ *   params[n, i*(3K-1) + 0:K]    unnormalised widths  of live dim i
+ *   params[n, i*(3K-1) + K:2K]   unnormalised heights
+ *   params[n, i*(3K-1) + 2K:3K-1] unnormalised interior derivatives   (K = n_bins)
+ *   domain [left,right] -> codomain [bottom,top]; outside the (input-side) interval: y = x, ljd = 0.
+ *   ldiag (nullable, [n_rows, dim]): per-element log-diag-Jacobian (0 on non-live columns);
+ *   the reverse direction returns the already-negated value like the reference (:234).
+ *   ldj as in sx_affine_coupling (sum over live dims of the value written to ldiag). */
+int sx_rqs_coupling(const void *x, void *y, float *ldj, float *ldiag, const float *params,
+                    int64_t params_stride, const int32_t *live_idx, int32_t live_start, int32_t n_live, int32_t n_bins,
+                    float left, float right, float bottom, float top, int64_t n_rows, int32_t dim,
+                    int32_t dtype, int32_t reverse, int32_t ldj_accumulate, float ldj_scale,
+                    uint32_t *err_flag, void *stream);
+
+/* UnitNormal.log_prob + log-det accumulator (stribor/dist/normal.py:37,52-54; flow.py:128-129):
+ *   out[n] = sum_d( -x[n,d]^2/2 ) - dim*log(sqrt(2*pi)) + (ldj ? ldj[n] : 0) */
+int sx_unit_normal_logprob(const void *x, const float *ldj, float *out, int64_t n_rows, int32_t dim,
+                           int32_t dtype, void *stream);
+
+/* sum of an fp32 vector into ONE fp64 (block partials in fp64, one atomic per block);
+ * `*out` must be zeroed by the caller (or hold a running total). */
+int sx_sum_f64(const float *v, int64_t n, double *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * MFMA path: fragment packing + the fused flow kernel
+ * ------------------------------------------------------------------------------------------ */
+
+/* Number of floats sx_pack_linear writes for an (m_tiles*32) x (k_tiles*32) padded linear. */
+size_t sx_packed_linear_floats(int32_t m_tiles, int32_t k_tiles);
+
+/* Re-lays one nn.Linear (W: [out_dim, in_dim] row-major as torch stores it, b: [out_dim] or NULL)
+ * into v_mfma_f32_32x32x2_f32 A-operand fragment order, followed by the bias in C-fragment order.
+ *   row_idx[m_tiles*32]: output slot -> row of W, or -1 for a zero row (padding / pruned)
+ *   col_idx[k_tiles*32]: input  slot -> column of W, or -1 for a zero column
+ * Layout written (floats): A[m][kt][g][lane][e] = W[row_idx[32m + (lane&31)]][col_idx[32kt + kmap(4g+e, lane>>5)]]
+ * with kmap(s,h) = (s&3) + 8*(s>>2) + 4*h, then bias[m][h][r] = b[row_idx[32m + kmap(r,h)]]. */
+int sx_pack_linear(const float *W, const float *b, int32_t out_dim, int32_t in_dim,
+                   const int32_t *row_idx, const int32_t *col_idx, int32_t m_tiles, int32_t k_tiles,
+                   float *dst, void *stream);
+
+/* One step of a fused flow program.  The flow state lives in registers as 32-wide "tiles" of
+ * columns (tile t = state slots 32t..32t+31); slots map to columns of x through in_col/out_col. */
+#define SX_STEP_COUPLING_AFFINE 1  /* blob = pack_linear(W1) ++ pack_linear(W2 rows [ls(t0..), sh(t0..)] per tile) */
+#define SX_STEP_AFFINE_CONST    2  /* blob = ls[tiles][2][16] ++ sh[tiles][2][16] (C-fragment order)            */
+#define SX_STEP_LINEAR_TILE     3  /* blob = pack_linear(M, 1 m-tile): new tile `t0` = M[t0] . state + bias      */
+#define SX_STEP_LINEAR_COMMIT   4  /* state = new tiles                                                            */
+#define SX_STEP_MLP_HIDDEN      5  /* blob = pack_linear(W): hidden = act(W . state[c0..c0+ct) + b)               */
+#define SX_STEP_MLP_HIDDEN2     6  /* blob = pack_linear(W): hidden' = act(W . hidden + b)                         */
+#define SX_STEP_MLP_OUT_TILE    7  /* blob = pack_linear(W, 1 m-tile): out[:, 32*t0 ..] = W[t0] . hidden + b       */
+#define SX_STEP_COUPLING_RQS    8  /* reserved */
+
+#define SX_MAX_STEPS 96
+
+typedef struct sx_step {
+    int32_t  kind;        /* SX_STEP_*                                                        */
+    int32_t  c0, ct;      /* conditioner input tiles [c0, c0+ct)                              */
+    int32_t  t0, tt;      /* transformed / output tiles [t0, t0+tt)                           */
+    int32_t  reverse;     /* 1: inverse direction ((x-sh)*exp(-ls)), 0: forward               */
+    int32_t  act;         /* SX_ACT_* of the hidden layer                                     */
+    uint32_t blob_off;    /* offset of this step's blob in `blobs`, in floats (multiple of 4)  */
+    uint32_t blob_floats; /* size of the blob in floats (multiple of 4)                        */
+    float    ldj_scale;   /* coefficient of this step's sum(log_scale) in the ldj accumulator  */
+    float    ldj_const;   /* constant added to the ldj accumulator (AffineLU / MatrixExponential) */
+    int32_t  pad_;
+} sx_step;
+
+typedef struct sx_program {
+    int32_t n_steps;
+    int32_t dim;          /* D: columns of x / y                                               */
+    int32_t latent_dim;   /* columns of `latent` (0 = none); they occupy tiles after the data  */
+    int32_t x_tiles;      /* tiles holding data columns                                        */
+    int32_t tiles;        /* x_tiles + latent tiles: 1, 2 or 4                                 */
+    int32_t h_tiles;      /* hidden width / 32 rounded up to 1, 2 or 4                         */
+    int32_t identity_cols;/* 1: state slot p <-> column p (vector loads), 0: use in_col/out_col */
+    int32_t pad_;
+    sx_step steps[SX_MAX_STEPS];
+} sx_program;
+
+/* Runs a fused program over n_rows samples: the whole flow stays in registers, weights stream
+ * through LDS, the conditioner GEMMs run on v_mfma_f32_32x32x2_f32.
+ * Replaces NormalizingFlow.{forward, inverse, forward_and_log_det_jacobian,
+ * inverse_and_log_det_jacobian, log_prob} (stribor/flow.py:99-130) and, with a one-step program,
+ * Coupling.{forward, inverse, log_det_jacobian} (stribor/flows/coupling.py:69-95).
+ *   x        [n_rows, dim]  input (dtype)
+ *   latent   [n_rows, latent_dim] fp32 or NULL
+ *   in_col   int32[x_tiles*32]: state slot -> column of x (-1 = zero pad); NULL if identity_cols
+ *   out_col  int32[x_tiles*32]: state slot -> column of y (-1 = not stored); NULL if identity_cols
+ *   y        [n_rows, dim]  final state (dtype), or NULL
+ *   ldj_out  [n_rows] accumulated log-det terms, or NULL
+ *   logp_out [n_rows] UnitNormal.log_prob(final state) + accumulated log-det terms, or NULL
+ *   sum_out  one fp64: += sum_n logp_out[n] (or of ldj when logp_out is NULL); NULL to skip
+ *   mlp_out  [n_rows, mlp_out_dim] (row stride mlp_out_stride) destination of SX_STEP_MLP_OUT_TILE
+ *            steps, or NULL                                                                   */
+int sx_flow_run(const sx_program *prog_host, const float *blobs, const void *x, const float *latent,
+                const int32_t *in_col, const int32_t *out_col, void *y, float *ldj_out,
+                float *logp_out, double *sum_out, float *mlp_out, int64_t mlp_out_stride,
+                int32_t mlp_out_dim, int64_t n_rows, int32_t dtype, void *stream);
+
+/* LDS bytes and grid the launcher will use for a program (introspection for tests/bench). */
+int sx_flow_launch_info(const sx_program *prog_host, int64_t n_rows, int32_t *grid, int32_t *block,
+                        int32_t *lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STRIBOR_HIP_H */

@@ -1,0 +1,14 @@
+"""stribor_amd — MI355X-native drop-in for stribor's coupling-flow hot path.
+
+Same names and constructor signatures as ``stribor`` for the classes on the path
+(``NormalizingFlow``, ``Coupling``, ``Affine``, ``Spline``, ``AffineLU``, ``MatrixExponential``,
+``Permute``/``Flip``, ``UnitNormal``, ``net.MLP``, ``util.get_mask``); the arithmetic is hand-written
+HIP for gfx950 behind the C ABI in ``include/stribor_hip.h``.  There is no CPU fallback.
+"""
+from . import net, util
+from .dist import *          # noqa: F401,F403
+from .dist.normal import UnitNormal
+from .flow import ElementwiseTransform, NormalizingFlow, Transform
+from .flows import Affine, AffineLU, Coupling, Flip, MatrixExponential, Permute, Spline
+
+__version__ = '0.1.0'

@@ -1,0 +1,131 @@
+"""ctypes binding of libstribor_hip.so (the C ABI declared in include/stribor_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a tensor is not on a
+ROCm device, the call raises.  Build the library with ``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C stribor_amd/csrc -j8``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libstribor_hip.so')
+
+SX_F32, SX_BF16 = 0, 1
+SX_MAX_STEPS = 96
+
+STEP_COUPLING_AFFINE = 1
+STEP_AFFINE_CONST = 2
+STEP_LINEAR_TILE = 3
+STEP_LINEAR_COMMIT = 4
+STEP_MLP_HIDDEN = 5
+STEP_MLP_HIDDEN2 = 6
+STEP_MLP_OUT_TILE = 7
+STEP_COUPLING_RQS = 8
+
+ACT_CODES = {'Identity': 0, 'Tanh': 1, 'ReLU': 2, 'Sigmoid': 3, 'ELU': 4, 'Softplus': 5, 'LeakyReLU': 6,
+             'SiLU': 7, 'GELU': 8}
+
+# every symbol include/stribor_hip.h declares (tests check that the library exports all of them)
+EXPORTS = ['sx_abi_version', 'sx_last_error', 'sx_permute', 'sx_affine_coupling', 'sx_rqs_coupling',
+           'sx_unit_normal_logprob', 'sx_sum_f64', 'sx_packed_linear_floats', 'sx_pack_linear', 'sx_flow_run',
+           'sx_flow_launch_info']
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class sx_step(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('c0', C.c_int32), ('ct', C.c_int32), ('t0', C.c_int32), ('tt', C.c_int32),
+                ('reverse', C.c_int32), ('act', C.c_int32), ('blob_off', C.c_uint32), ('blob_floats', C.c_uint32),
+                ('ldj_scale', C.c_float), ('ldj_const', C.c_float), ('pad_', C.c_int32)]
+
+
+class sx_program(C.Structure):
+    _fields_ = [('n_steps', C.c_int32), ('dim', C.c_int32), ('latent_dim', C.c_int32), ('x_tiles', C.c_int32),
+                ('tiles', C.c_int32), ('h_tiles', C.c_int32), ('identity_cols', C.c_int32), ('pad_', C.c_int32),
+                ('steps', sx_step * SX_MAX_STEPS)]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def _declare(lib: C.CDLL) -> None:
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    lib.sx_abi_version.restype = i32
+    lib.sx_abi_version.argtypes = []
+    lib.sx_last_error.restype = C.c_char_p
+    lib.sx_last_error.argtypes = []
+    lib.sx_permute.restype = i32
+    lib.sx_permute.argtypes = [vp, vp, vp, i64, i32, i32, vp]
+    lib.sx_affine_coupling.restype = i32
+    lib.sx_affine_coupling.argtypes = [vp, vp, vp, vp, i64, vp, i32, i32, i64, i32, i32, i32, i32, f32, vp]
+    lib.sx_rqs_coupling.restype = i32
+    lib.sx_rqs_coupling.argtypes = [vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, f32, f32, f32, f32, i64, i32, i32,
+                                    i32, i32, f32, vp, vp]
+    lib.sx_unit_normal_logprob.restype = i32
+    lib.sx_unit_normal_logprob.argtypes = [vp, vp, vp, i64, i32, i32, vp]
+    lib.sx_sum_f64.restype = i32
+    lib.sx_sum_f64.argtypes = [vp, i64, vp, vp]
+    lib.sx_packed_linear_floats.restype = C.c_size_t
+    lib.sx_packed_linear_floats.argtypes = [i32, i32]
+    lib.sx_pack_linear.restype = i32
+    lib.sx_pack_linear.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp]
+    lib.sx_flow_run.restype = i32
+    lib.sx_flow_run.argtypes = [C.POINTER(sx_program), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i64, i32, vp]
+    lib.sx_flow_launch_info.restype = i32
+    lib.sx_flow_launch_info.argtypes = [C.POINTER(sx_program), i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+
+
+def lib() -> C.CDLL:
+    """The loaded library; raises HipLibraryMissing (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f'{LIB_PATH} not found: stribor_amd has no CPU fallback. Build it with '
+                f'`make -C {os.path.join(_HERE, "csrc")} -j8` (hipcc, --offload-arch=gfx950).')
+        l = C.CDLL(LIB_PATH)
+        _declare(l)
+        if l.sx_abi_version() != 1:
+            raise HipLibraryMissing(f'{LIB_PATH}: ABI version {l.sx_abi_version()} != 1; rebuild')
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().sx_last_error().decode(errors='replace')
+        raise RuntimeError(f'{what} failed (rc={rc}): {msg}')
+
+
+def require_device(t: torch.Tensor, name: str = 'input') -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f'stribor_amd: {name} must live on a ROCm device (got {t.device}); this package runs '
+                           f'the coupling-flow path on MI355X HIP kernels only and has no CPU fallback.')
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return SX_F32
+    if t.dtype == torch.bfloat16:
+        return SX_BF16
+    raise TypeError(f'stribor_amd: unsupported storage dtype {t.dtype} (float32 or bfloat16)')
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def packed_linear_floats(m_tiles: int, k_tiles: int) -> int:
+    # pure arithmetic (mirrors sx_packed_linear_floats) so program layout can be planned without the library
+    return m_tiles * k_tiles * 1024 + m_tiles * 32

@@ -1,0 +1,302 @@
+// HBM-bound element-wise kernels of the coupling-flow path (parameters already in HBM).
+// One pass over [n_rows, dim]: coalesced 8/16-byte accesses, per-row log-det sums by wave shuffles.
+#include "sx_common.h"
+#include <stdarg.h>
+
+// ------------------------------------------------------------------------------------------------
+// error string
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void sx_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *sx_last_error(void) { return g_err; }
+extern "C" int sx_abi_version(void) { return SX_ABI_VERSION; }
+
+static int grid_for(int64_t work_items, int block, int max_blocks = 256 * 8) {
+    int64_t g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// vector row access: 4 consecutive columns per thread
+// ------------------------------------------------------------------------------------------------
+template <bool BF16>
+__device__ __forceinline__ f32x4 load4(const void *base, int64_t elem_off) {
+    if constexpr (BF16) {
+        u16x4 v = *reinterpret_cast<const u16x4 *>(reinterpret_cast<const uint16_t *>(base) + elem_off);
+        return f32x4{bf16_to_f32(v.x), bf16_to_f32(v.y), bf16_to_f32(v.z), bf16_to_f32(v.w)};
+    } else {
+        return *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(base) + elem_off);
+    }
+}
+template <bool BF16>
+__device__ __forceinline__ void store4(void *base, int64_t elem_off, f32x4 v) {
+    if constexpr (BF16) {
+        u16x4 o{f32_to_bf16(v.x), f32_to_bf16(v.y), f32_to_bf16(v.z), f32_to_bf16(v.w)};
+        *reinterpret_cast<u16x4 *>(reinterpret_cast<uint16_t *>(base) + elem_off) = o;
+    } else {
+        *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(base) + elem_off) = v;
+    }
+}
+template <bool BF16>
+__device__ __forceinline__ float load1(const void *base, int64_t elem_off) {
+    if constexpr (BF16) return bf16_to_f32(reinterpret_cast<const uint16_t *>(base)[elem_off]);
+    else return reinterpret_cast<const float *>(base)[elem_off];
+}
+template <bool BF16>
+__device__ __forceinline__ void store1(void *base, int64_t elem_off, float v) {
+    if constexpr (BF16) reinterpret_cast<uint16_t *>(base)[elem_off] = f32_to_bf16(v);
+    else reinterpret_cast<float *>(base)[elem_off] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: affine coupling, element-wise part            (stribor/flows/affine.py:104-109, coupling.py:78,95)
+// Fast path: dim % 4 == 0, TPR = dim/4 threads per row is a power of two <= 64, live columns are
+// the contiguous 4-aligned range [l0, l0+n_live).  Each thread owns 4 columns of one row.
+// ------------------------------------------------------------------------------------------------
+template <bool BF16, bool REVERSE>
+__global__ __launch_bounds__(256) void affine_coupling_vec4_kernel(
+    const void *__restrict__ x, void *__restrict__ y, float *__restrict__ ldj,
+    const float *__restrict__ params, int64_t pstride, int l0, int n_live, int64_t n_rows, int dim,
+    int tpr_log2, int ldj_acc, float ldj_scale) {
+    const int tpr = 1 << tpr_log2;
+    const int64_t n_vec = n_rows << tpr_log2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_vec; v += stride) {
+        const int64_t row = v >> tpr_log2;
+        const int c = ((int)(v & (tpr - 1))) << 2;
+        f32x4 xv = load4<BF16>(x, row * dim + c);
+        float s = 0.f;
+        if (c >= l0 && c < l0 + n_live) {
+            const float *p = params + row * pstride + (c - l0);
+            f32x4 ls = *reinterpret_cast<const f32x4 *>(p);
+            f32x4 sh = *reinterpret_cast<const f32x4 *>(p + n_live);
+            if constexpr (REVERSE) {
+                xv.x = (xv.x - sh.x) * fast_exp(-ls.x);
+                xv.y = (xv.y - sh.y) * fast_exp(-ls.y);
+                xv.z = (xv.z - sh.z) * fast_exp(-ls.z);
+                xv.w = (xv.w - sh.w) * fast_exp(-ls.w);
+            } else {
+                xv.x = xv.x * fast_exp(ls.x) + sh.x;
+                xv.y = xv.y * fast_exp(ls.y) + sh.y;
+                xv.z = xv.z * fast_exp(ls.z) + sh.z;
+                xv.w = xv.w * fast_exp(ls.w) + sh.w;
+            }
+            s = (ls.x + ls.y) + (ls.z + ls.w);
+        }
+        store4<BF16>(y, row * dim + c, xv);
+        if (ldj != nullptr) {   // wave-uniform
+            s = group_sum_rt(s, tpr);
+            if ((v & (tpr - 1)) == 0) ldj[row] = (ldj_acc ? ldj[row] : 0.f) + ldj_scale * s;
+        }
+    }
+}
+
+// Generic path: one wave per row, lanes stride over columns; any dim / live set.
+template <bool BF16, bool REVERSE>
+__global__ __launch_bounds__(256) void affine_coupling_generic_kernel(
+    const void *__restrict__ x, void *__restrict__ y, float *__restrict__ ldj,
+    const float *__restrict__ params, int64_t pstride, const int32_t *__restrict__ live_idx, int l0,
+    int n_live, int64_t n_rows, int dim, int ldj_acc, float ldj_scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *pos = reinterpret_cast<int *>(smem);   // column -> live slot or -1
+    for (int c = threadIdx.x; c < dim; c += blockDim.x) pos[c] = -1;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_live; i += blockDim.x) pos[live_idx ? live_idx[i] : l0 + i] = i;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t row = wave; row < n_rows; row += n_waves) {
+        float s = 0.f;
+        for (int c = lane; c < dim; c += 64) {
+            float xv = load1<BF16>(x, row * dim + c);
+            int i = pos[c];
+            if (i >= 0) {
+                float ls = params[row * pstride + i];
+                float sh = params[row * pstride + n_live + i];
+                xv = REVERSE ? (xv - sh) * fast_exp(-ls) : xv * fast_exp(ls) + sh;
+                s += ls;
+            }
+            store1<BF16>(y, row * dim + c, xv);
+        }
+        if (ldj != nullptr) {
+            s = group_sum<64>(s);
+            if (lane == 0) ldj[row] = (ldj_acc ? ldj[row] : 0.f) + ldj_scale * s;
+        }
+    }
+}
+
+static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+extern "C" int sx_affine_coupling(const void *x, void *y, float *ldj, const float *params,
+                                  int64_t params_stride, const int32_t *live_idx, int32_t live_start,
+                                  int32_t n_live, int64_t n_rows, int32_t dim, int32_t dtype,
+                                  int32_t reverse, int32_t ldj_accumulate, float ldj_scale, void *stream) {
+    SX_REQUIRE(x && y && params, "sx_affine_coupling: null pointer");
+    SX_REQUIRE(dim > 0 && n_live >= 0 && n_live <= dim && n_rows >= 0, "sx_affine_coupling: bad sizes");
+    SX_REQUIRE(dtype == SX_F32 || dtype == SX_BF16, "sx_affine_coupling: bad dtype");
+    if (n_rows == 0) return SX_OK;
+    hipStream_t st = sx_stream(stream);
+    const bool fast = live_idx == nullptr && dim % 4 == 0 && pow2(dim / 4) && dim / 4 <= 64 &&
+                      live_start % 4 == 0 && n_live % 4 == 0 && params_stride % 4 == 0 &&
+                      live_start + n_live <= dim && (((uintptr_t)params) & 15) == 0 &&
+                      (((uintptr_t)x) & 15) == 0 && (((uintptr_t)y) & 15) == 0;
+    if (fast) {
+        const int tl = ilog2(dim / 4);
+        const int grid = grid_for(n_rows << tl, 256);
+#define SX_AC(BF, RV)                                                                         \
+    hipLaunchKernelGGL((affine_coupling_vec4_kernel<BF, RV>), dim3(grid), dim3(256), 0, st, x, y, ldj, \
+                       params, params_stride, live_start, n_live, n_rows, dim, tl, ldj_accumulate, ldj_scale)
+        if (dtype == SX_BF16) { if (reverse) SX_AC(true, true); else SX_AC(true, false); }
+        else { if (reverse) SX_AC(false, true); else SX_AC(false, false); }
+#undef SX_AC
+    } else {
+        const int grid = grid_for(n_rows * 64, 256);
+        const size_t lds = (size_t)dim * sizeof(int);
+#define SX_AG(BF, RV)                                                                               \
+    hipLaunchKernelGGL((affine_coupling_generic_kernel<BF, RV>), dim3(grid), dim3(256), lds, st, x, y, ldj, \
+                       params, params_stride, live_idx, live_start, n_live, n_rows, dim, ldj_accumulate, ldj_scale)
+        if (dtype == SX_BF16) { if (reverse) SX_AG(true, true); else SX_AG(true, false); }
+        else { if (reverse) SX_AG(false, true); else SX_AG(false, false); }
+#undef SX_AG
+    }
+    SX_LAUNCH_CHECK();
+    return SX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7: Permute / Flip — bit-exact column gather                 (stribor/flows/permute.py:35,38,71,75)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void permute_kernel(const T *__restrict__ x, T *__restrict__ y,
+                                                      const int32_t *__restrict__ idx, int64_t n_rows, int dim) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *sidx = reinterpret_cast<int *>(smem);
+    for (int c = threadIdx.x; c < dim; c += blockDim.x) sidx[c] = idx[c];
+    __syncthreads();
+    const int64_t total = n_rows * dim;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t row = i / dim;
+        const int j = (int)(i - row * dim);
+        y[i] = x[row * dim + sidx[j]];
+    }
+}
+
+extern "C" int sx_permute(const void *x, void *y, const int32_t *idx, int64_t n_rows, int32_t dim,
+                          int32_t elem_bytes, void *stream) {
+    SX_REQUIRE(x && y && idx, "sx_permute: null pointer");
+    SX_REQUIRE(x != y, "sx_permute: in-place permutation is not supported");
+    SX_REQUIRE(dim > 0 && n_rows >= 0, "sx_permute: bad sizes");
+    SX_REQUIRE(elem_bytes == 2 || elem_bytes == 4, "sx_permute: elem_bytes must be 2 or 4");
+    if (n_rows == 0) return SX_OK;
+    const int grid = grid_for(n_rows * dim, 256);
+    const size_t lds = (size_t)dim * sizeof(int);
+    if (elem_bytes == 2)
+        hipLaunchKernelGGL(permute_kernel<uint16_t>, dim3(grid), dim3(256), lds, sx_stream(stream),
+                           (const uint16_t *)x, (uint16_t *)y, idx, n_rows, dim);
+    else
+        hipLaunchKernelGGL(permute_kernel<uint32_t>, dim3(grid), dim3(256), lds, sx_stream(stream),
+                           (const uint32_t *)x, (uint32_t *)y, idx, n_rows, dim);
+    SX_LAUNCH_CHECK();
+    return SX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8: UnitNormal.log_prob + ldj accumulator              (stribor/dist/normal.py:37,52-54; flow.py:129)
+// ------------------------------------------------------------------------------------------------
+#define SX_HALF_LOG_2PI 0.91893853320467274178f
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void unit_normal_vec4_kernel(const void *__restrict__ x,
+                                                               const float *__restrict__ ldj,
+                                                               float *__restrict__ out, int64_t n_rows,
+                                                               int dim, int tpr_log2) {
+    const int tpr = 1 << tpr_log2;
+    const int64_t n_vec = n_rows << tpr_log2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_vec; v += stride) {
+        const int64_t row = v >> tpr_log2;
+        const int c = ((int)(v & (tpr - 1))) << 2;
+        f32x4 xv = load4<BF16>(x, row * dim + c);
+        float s = (xv.x * xv.x + xv.y * xv.y) + (xv.z * xv.z + xv.w * xv.w);
+        s = group_sum_rt(s, tpr);
+        if ((v & (tpr - 1)) == 0)
+            out[row] = -0.5f * s - (float)dim * SX_HALF_LOG_2PI + (ldj ? ldj[row] : 0.f);
+    }
+}
+template <bool BF16>
+__global__ __launch_bounds__(256) void unit_normal_generic_kernel(const void *__restrict__ x,
+                                                                  const float *__restrict__ ldj,
+                                                                  float *__restrict__ out, int64_t n_rows, int dim) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t row = wave; row < n_rows; row += n_waves) {
+        float s = 0.f;
+        for (int c = lane; c < dim; c += 64) {
+            float v = load1<BF16>(x, row * dim + c);
+            s += v * v;
+        }
+        s = group_sum<64>(s);
+        if (lane == 0) out[row] = -0.5f * s - (float)dim * SX_HALF_LOG_2PI + (ldj ? ldj[row] : 0.f);
+    }
+}
+
+extern "C" int sx_unit_normal_logprob(const void *x, const float *ldj, float *out, int64_t n_rows,
+                                      int32_t dim, int32_t dtype, void *stream) {
+    SX_REQUIRE(x && out, "sx_unit_normal_logprob: null pointer");
+    SX_REQUIRE(dim > 0 && n_rows >= 0, "sx_unit_normal_logprob: bad sizes");
+    SX_REQUIRE(dtype == SX_F32 || dtype == SX_BF16, "sx_unit_normal_logprob: bad dtype");
+    if (n_rows == 0) return SX_OK;
+    hipStream_t st = sx_stream(stream);
+    const bool fast = dim % 4 == 0 && pow2(dim / 4) && dim / 4 <= 64 && (((uintptr_t)x) & 15) == 0;
+    if (fast) {
+        const int tl = ilog2(dim / 4);
+        const int grid = grid_for(n_rows << tl, 256);
+        if (dtype == SX_BF16)
+            hipLaunchKernelGGL(unit_normal_vec4_kernel<true>, dim3(grid), dim3(256), 0, st, x, ldj, out, n_rows, dim, tl);
+        else
+            hipLaunchKernelGGL(unit_normal_vec4_kernel<false>, dim3(grid), dim3(256), 0, st, x, ldj, out, n_rows, dim, tl);
+    } else {
+        const int grid = grid_for(n_rows * 64, 256);
+        if (dtype == SX_BF16)
+            hipLaunchKernelGGL(unit_normal_generic_kernel<true>, dim3(grid), dim3(256), 0, st, x, ldj, out, n_rows, dim);
+        else
+            hipLaunchKernelGGL(unit_normal_generic_kernel<false>, dim3(grid), dim3(256), 0, st, x, ldj, out, n_rows, dim);
+    }
+    SX_LAUNCH_CHECK();
+    return SX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K9: sum of fp32 values into one fp64 (per-thread fp64 partials, one atomic per block)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sum_f64_kernel(const float *__restrict__ v, int64_t n, double *out) {
+    __shared__ double part[4];
+    double acc = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc += (double)v[i];
+    acc = wave_sum_f64(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+extern "C" int sx_sum_f64(const float *v, int64_t n, double *out, void *stream) {
+    SX_REQUIRE(v && out, "sx_sum_f64: null pointer");
+    SX_REQUIRE(n >= 0, "sx_sum_f64: bad size");
+    if (n == 0) return SX_OK;
+    const int grid = grid_for(n, 256, 1024);
+    hipLaunchKernelGGL(sum_f64_kernel, dim3(grid), dim3(256), 0, sx_stream(stream), v, n, out);
+    SX_LAUNCH_CHECK();
+    return SX_OK;
+}

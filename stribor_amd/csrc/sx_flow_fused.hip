@@ -1,0 +1,108 @@
+// Host dispatcher of the fused flow kernel (device code: sx_flow_kernel.h, one object per tile pair).
+#include "sx_flow_types.h"
+
+#define SX_ROWS_PER_BLOCK 128
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, bool *mlp_mode) {
+    SX_REQUIRE(p != nullptr, "sx_flow_run: null program");
+    SX_REQUIRE(p->n_steps >= 0 && p->n_steps <= SX_MAX_STEPS, "sx_flow_run: n_steps %d out of range", p->n_steps);
+    SX_REQUIRE(p->tiles == 1 || p->tiles == 2 || p->tiles == 4, "sx_flow_run: tiles must be 1, 2 or 4 (got %d)", p->tiles);
+    SX_REQUIRE(p->h_tiles == 1 || p->h_tiles == 2 || p->h_tiles == 4, "sx_flow_run: h_tiles must be 1, 2 or 4");
+    SX_REQUIRE(p->x_tiles >= 1 && p->x_tiles <= p->tiles, "sx_flow_run: bad x_tiles");
+    SX_REQUIRE(p->dim >= 1 && p->dim <= 32 * p->x_tiles, "sx_flow_run: dim %d does not fit %d tiles", p->dim, p->x_tiles);
+    SX_REQUIRE(p->latent_dim >= 0 && p->latent_dim <= 32 * (p->tiles - p->x_tiles), "sx_flow_run: latent_dim does not fit");
+    SX_REQUIRE(!p->identity_cols || p->dim % 4 == 0, "sx_flow_run: identity_cols needs dim %% 4 == 0");
+    d->n_steps = p->n_steps; d->dim = p->dim; d->latent_dim = p->latent_dim; d->x_tiles = p->x_tiles;
+    d->identity_cols = p->identity_cols; d->pad = 0;
+    int mx = 256;
+    *mlp_mode = false;
+    for (int i = 0; i < p->n_steps; ++i) {
+        const sx_step &s = p->steps[i];
+        SX_REQUIRE(s.blob_off % 256 == 0 && s.blob_floats % 256 == 0, "sx_flow_run: step %d blob not 1 KiB aligned", i);
+        SX_REQUIRE(s.c0 >= 0 && s.ct >= 0 && s.c0 + s.ct <= p->tiles && s.t0 >= 0 && s.tt >= 0, "sx_flow_run: step %d bad tiles", i);
+        size_t need = 0;
+        switch (s.kind) {
+            case SX_STEP_COUPLING_AFFINE: {
+                const int T = p->tiles;
+                const bool low = T >= 2 && s.c0 == 0 && s.ct == T / 2 && s.t0 == T / 2 && s.tt == T / 2;
+                const bool high = T >= 2 && s.c0 == T / 2 && s.ct == T / 2 && s.t0 == 0 && s.tt == T / 2;
+                const bool dense = s.c0 == 0 && s.ct == T && s.t0 == 0 && s.tt == T;
+                SX_REQUIRE(low || high || dense, "sx_flow_run: step %d: coupling tiles must be low/high halves or dense", i);
+            }
+                need = sx_packed_linear_floats(p->h_tiles, s.ct) + sx_packed_linear_floats(2 * s.tt, p->h_tiles);
+                break;
+            case SX_STEP_AFFINE_CONST: need = 2 * 32 * p->tiles; break;
+            case SX_STEP_MLP_HIDDEN:
+                SX_REQUIRE(s.c0 == 0 && s.ct == p->tiles, "sx_flow_run: MLP_HIDDEN must read all tiles");
+                need = sx_packed_linear_floats(p->h_tiles, p->tiles); *mlp_mode = true; break;
+            case SX_STEP_MLP_HIDDEN2: need = sx_packed_linear_floats(p->h_tiles, p->h_tiles); *mlp_mode = true; break;
+            case SX_STEP_MLP_OUT_TILE: need = sx_packed_linear_floats(1, p->h_tiles); *mlp_mode = true; break;
+            default: sx_set_error("sx_flow_run: step %d has unsupported kind %d", i, s.kind); return SX_E_UNSUPPORTED;
+        }
+        SX_REQUIRE(s.blob_floats >= need, "sx_flow_run: step %d blob too small (%u < %zu floats)", i, s.blob_floats, need);
+        if ((int)s.blob_floats > mx) mx = (int)s.blob_floats;
+        dstep &o = d->steps[i];
+        o.kind = (uint8_t)s.kind; o.c0 = (uint8_t)s.c0; o.ct = (uint8_t)s.ct; o.t0 = (uint8_t)s.t0; o.tt = (uint8_t)s.tt;
+        o.reverse = (uint8_t)(s.reverse != 0); o.act = (uint8_t)s.act; o.pad = 0;
+        o.blob_off = s.blob_off; o.blob_floats = s.blob_floats; o.ldj_scale = s.ldj_scale; o.ldj_const = s.ldj_const;
+    }
+    *buf_floats = mx;
+    SX_REQUIRE((size_t)mx * 8 <= 160 * 1024, "sx_flow_run: a step needs %d B of LDS per buffer (> 80 KiB)", mx * 4);
+    return SX_OK;
+}
+
+static int pick_grid(int64_t n_rows, int lds_bytes) {
+    int per_cu = (160 * 1024) / (lds_bytes > 0 ? lds_bytes : 1);
+    if (per_cu > 2) per_cu = 2;
+    if (per_cu < 1) per_cu = 1;
+    int64_t chunks = (n_rows + SX_ROWS_PER_BLOCK - 1) / SX_ROWS_PER_BLOCK;
+    int64_t g = 256 * per_cu;
+    if (g > chunks) g = chunks;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" int sx_flow_launch_info(const sx_program *prog_host, int64_t n_rows, int32_t *grid, int32_t *block,
+                                   int32_t *lds_bytes) {
+    dprog d; int bf; bool mm;
+    int rc = validate_and_convert(prog_host, &d, &bf, &mm);
+    if (rc) return rc;
+    if (lds_bytes) *lds_bytes = bf * 8;
+    if (block) *block = 256;
+    if (grid) *grid = pick_grid(n_rows, bf * 8);
+    return SX_OK;
+}
+
+
+extern "C" int sx_flow_run(const sx_program *prog_host, const float *blobs, const void *x, const float *latent,
+                           const int32_t *in_col, const int32_t *out_col, void *y, float *ldj_out, float *logp_out,
+                           double *sum_out, float *mlp_out, int64_t mlp_out_stride, int32_t mlp_out_dim,
+                           int64_t n_rows, int32_t dtype, void *stream) {
+    dprog d; int bf; bool mlp_mode;
+    int rc = validate_and_convert(prog_host, &d, &bf, &mlp_mode);
+    if (rc) return rc;
+    SX_REQUIRE(x != nullptr && n_rows >= 0, "sx_flow_run: bad x / n_rows");
+    SX_REQUIRE(blobs != nullptr || prog_host->n_steps == 0, "sx_flow_run: null blobs");
+    SX_REQUIRE(dtype == SX_F32 || dtype == SX_BF16, "sx_flow_run: bad dtype");
+    SX_REQUIRE(prog_host->identity_cols || (in_col != nullptr && (y == nullptr || out_col != nullptr)),
+               "sx_flow_run: in_col/out_col required when identity_cols == 0");
+    SX_REQUIRE(prog_host->latent_dim == 0 || latent != nullptr, "sx_flow_run: latent_dim > 0 but latent is NULL");
+    SX_REQUIRE(!mlp_mode || (mlp_out != nullptr && mlp_out_dim > 0), "sx_flow_run: MLP steps need mlp_out");
+    SX_REQUIRE(!prog_host->identity_cols || ((uintptr_t)x & 15) == 0, "sx_flow_run: x must be 16-byte aligned");
+    if (n_rows == 0) return SX_OK;
+    sx_flow_args a;
+    a.prog = d; a.blobs = blobs; a.x = x; a.latent = latent; a.in_col = in_col; a.out_col = out_col; a.y = y;
+    a.ldj_out = ldj_out; a.logp_out = logp_out; a.sum_out = sum_out; a.mlp_out = mlp_out;
+    a.mlp_out_stride = mlp_out_stride; a.mlp_out_dim = mlp_out_dim; a.n_rows = n_rows; a.buf_floats = bf;
+    a.bf16 = dtype == SX_BF16; a.mlp_mode = mlp_mode; a.lds = bf * 8; a.grid = pick_grid(n_rows, a.lds);
+    a.stream = sx_stream(stream);
+    const int T = prog_host->tiles, H = prog_host->h_tiles;
+#define SX_GO(TT, HH) if (T == TT && H == HH) return sx_flow_launch_t##TT##h##HH(a)
+    SX_GO(1, 1); SX_GO(1, 2); SX_GO(1, 4); SX_GO(2, 1); SX_GO(2, 2); SX_GO(2, 4); SX_GO(4, 1); SX_GO(4, 2); SX_GO(4, 4);
+#undef SX_GO
+    sx_set_error("sx_flow_run: unsupported tile configuration");
+    return SX_E_UNSUPPORTED;
+}

@@ -1,0 +1,29 @@
+// Types shared by the fused-flow host dispatcher and its per-(tiles, hidden-tiles) kernel objects.
+#pragma once
+#include "sx_common.h"
+
+// compact device-side copy of sx_step / sx_program (kernarg)
+struct dstep {
+    uint8_t kind, c0, ct, t0, tt, reverse, act, pad;
+    uint32_t blob_off, blob_floats;
+    float ldj_scale, ldj_const;
+};
+struct dprog {
+    int32_t n_steps, dim, latent_dim, x_tiles, identity_cols, pad;
+    dstep steps[SX_MAX_STEPS];
+};
+
+
+struct sx_flow_args {
+    dprog prog;
+    const float *blobs; const void *x; const float *latent; const int32_t *in_col; const int32_t *out_col;
+    void *y; float *ldj_out; float *logp_out; double *sum_out; float *mlp_out; int64_t mlp_out_stride;
+    int mlp_out_dim; int64_t n_rows; int buf_floats; int bf16; int mlp_mode; int grid; int lds; hipStream_t stream;
+};
+
+
+#define SX_DECL_FLOW(T, H) int sx_flow_launch_t##T##h##H(const sx_flow_args &a);
+SX_DECL_FLOW(1, 1) SX_DECL_FLOW(1, 2) SX_DECL_FLOW(1, 4)
+SX_DECL_FLOW(2, 1) SX_DECL_FLOW(2, 2) SX_DECL_FLOW(2, 4)
+SX_DECL_FLOW(4, 1) SX_DECL_FLOW(4, 2) SX_DECL_FLOW(4, 4)
+#undef SX_DECL_FLOW

@@ -1,0 +1,56 @@
+// Weight re-layout for the MFMA path: one nn.Linear -> v_mfma_f32_32x32x2_f32 A-operand fragments.
+//
+// v_mfma_f32_32x32x2_f32 computes D(32x32) = A(32x2) . B(2x32) + C with (cdna_hip_programming.md §3)
+//   A: lane l holds A[i = l&31][k = l>>5]        B: lane l holds B[k = l>>5][j = l&31]
+//   C/D: lane l, register r holds C[row = kmap(r, l>>5)][col = l&31],  kmap(r,h) = (r&3) + 8*(r>>2) + 4*h
+// The fused kernels keep samples on the MFMA column (lane&31) and features on the C rows, so a C tile
+// is directly the B operand of the next GEMM provided k-step s of lane-half h is matched with the
+// weight column kmap(s,h).  That permutation is baked in here, once per parameter update.
+#include "sx_common.h"
+
+__host__ __device__ static inline int sx_kmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+extern "C" size_t sx_packed_linear_floats(int32_t m_tiles, int32_t k_tiles) {
+    return (size_t)m_tiles * k_tiles * 1024 + (size_t)m_tiles * 32;
+}
+
+__global__ __launch_bounds__(256) void pack_linear_kernel(const float *__restrict__ W, const float *__restrict__ b,
+                                                          int out_dim, int in_dim,
+                                                          const int32_t *__restrict__ row_idx,
+                                                          const int32_t *__restrict__ col_idx, int m_tiles,
+                                                          int k_tiles, float *__restrict__ dst) {
+    const int n_a = m_tiles * k_tiles * 1024;
+    const int total = n_a + m_tiles * 32;
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (o < n_a) {
+            // o = (((m*k_tiles + kt)*4 + g)*64 + lane)*4 + e
+            const int e = o & 3, lane = (o >> 2) & 63, g = (o >> 8) & 3;
+            const int mk = o >> 10;
+            const int kt = mk % k_tiles, m = mk / k_tiles;
+            const int row = row_idx[32 * m + (lane & 31)];
+            const int col = col_idx[32 * kt + sx_kmap(4 * g + e, lane >> 5)];
+            if (row >= 0 && col >= 0) v = W[(int64_t)row * in_dim + col];
+        } else {
+            // bias[m][h][r]
+            const int q = o - n_a;
+            const int r = q & 15, h = (q >> 4) & 1, m = q >> 5;
+            const int row = row_idx[32 * m + sx_kmap(r, h)];
+            if (row >= 0 && b != nullptr) v = b[row];
+        }
+        dst[o] = v;
+    }
+}
+
+extern "C" int sx_pack_linear(const float *W, const float *b, int32_t out_dim, int32_t in_dim,
+                              const int32_t *row_idx, const int32_t *col_idx, int32_t m_tiles, int32_t k_tiles,
+                              float *dst, void *stream) {
+    SX_REQUIRE(W && row_idx && col_idx && dst, "sx_pack_linear: null pointer");
+    SX_REQUIRE(m_tiles > 0 && k_tiles > 0 && out_dim > 0 && in_dim > 0, "sx_pack_linear: bad sizes");
+    const int total = (int)sx_packed_linear_floats(m_tiles, k_tiles);
+    const int grid = (total + 255) / 256;
+    hipLaunchKernelGGL(pack_linear_kernel, dim3(grid > 1024 ? 1024 : grid), dim3(256), 0, sx_stream(stream), W, b,
+                       out_dim, in_dim, row_idx, col_idx, m_tiles, k_tiles, dst);
+    SX_LAUNCH_CHECK();
+    return SX_OK;
+}

@@ -1,0 +1,247 @@
+// Rational-quadratic spline, element-wise kernel (parameters already in HBM).
+//
+// Replaces unconstrained_rational_quadratic_spline + rational_quadratic_spline
+// (stribor/util/rational_quadratic_spline.py:11-251) and searchsorted (util/search_sorted.py:3-5):
+// ~30 torch passes over [M, K]-sized temporaries (boolean compaction, 2 softmax, softplus, 2 cumsum,
+// pad, rescale, pin, re-difference, bin search, 8 gathers, rational formula / quadratic root, scatter)
+// become one pass: one lane = one (row, live column) element.
+//
+// CDNA4 mapping: the 3K-1 parameters of the 64 elements a wave owns are one contiguous span of HBM
+// (64*(3K-1)*4 B = 12 KiB at K = 16).  The wave copies that span into ITS OWN slice of LDS with coalesced
+// loads, then each lane walks its element's parameters at stride 3K-1 dwords — an odd stride, so the 32
+// lanes of a ds_read_b32 group hit 32 different banks.  No compaction: tails are predicated.  The per-row
+// log-det is a shuffle sum when a row's live columns sit inside one wave, float atomics otherwise.
+#include "sx_common.h"
+
+#define RQS_MIN_BIN 1e-3f
+#define RQS_MIN_DERIV 1e-3f
+#define RQS_EPS 1e-6f
+
+extern __shared__ __attribute__((aligned(16))) float rqs_smem[];
+
+__device__ __forceinline__ float softplus_ref(float v) { return v > 20.f ? v : log1pf(expf(v)); }  // F.softplus
+
+template <bool BF16>
+__device__ __forceinline__ float rqs_load(const void *p, int64_t off) {
+    if constexpr (BF16) return bf16_to_f32(reinterpret_cast<const uint16_t *>(p)[off]);
+    else return reinterpret_cast<const float *>(p)[off];
+}
+template <bool BF16>
+__device__ __forceinline__ void rqs_store(void *p, int64_t off, float v) {
+    if constexpr (BF16) reinterpret_cast<uint16_t *>(p)[off] = f32_to_bf16(v);
+    else reinterpret_cast<float *>(p)[off] = v;
+}
+
+// copies the pass-through (mask == 1) columns: y = T(x)*(1-m) + x*m (coupling.py:78)
+template <bool BF16>
+__global__ __launch_bounds__(256) void rqs_copy_passthrough_kernel(const void *__restrict__ x, void *__restrict__ y,
+                                                                   float *__restrict__ ldiag,
+                                                                   const int32_t *__restrict__ live_idx, int l0,
+                                                                   int n_live, int64_t n_rows, int dim, int copy_x) {
+    extern __shared__ __attribute__((aligned(16))) char cp_smem[];
+    int *is_live = reinterpret_cast<int *>(cp_smem);
+    for (int c = threadIdx.x; c < dim; c += blockDim.x) is_live[c] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_live; i += blockDim.x) is_live[live_idx ? live_idx[i] : l0 + i] = 1;
+    __syncthreads();
+    const int64_t total = n_rows * dim;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % dim);
+        if (!is_live[c]) {
+            if (copy_x) rqs_store<BF16>(y, i, rqs_load<BF16>(x, i));
+            if (ldiag) ldiag[i] = 0.f;
+        }
+    }
+}
+
+template <bool BF16, bool INVERSE>
+__global__ __launch_bounds__(256) void rqs_kernel(const void *__restrict__ x, void *__restrict__ y,
+                                                  float *__restrict__ ldj, float *__restrict__ ldiag,
+                                                  const float *__restrict__ params, int64_t pstride,
+                                                  const int32_t *__restrict__ live_idx, int l0, int n_live, int K,
+                                                  float left, float right, float bottom, float top, int64_t n_rows,
+                                                  int dim, int ldj_mode /*0 none, 1 direct (group), 2 atomic*/,
+                                                  int ldj_acc, float ldj_scale, uint32_t *__restrict__ err_flag) {
+    const int P = 3 * K - 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int waves_per_block = blockDim.x >> 6;
+    float *sp = rqs_smem + (size_t)wave * 64 * P;               // this wave's staging slice
+    const int64_t n_elem = n_rows * n_live;
+    const int64_t n_groups = (n_elem + 63) >> 6;
+    const float lo_in = INVERSE ? bottom : left, hi_in = INVERSE ? top : right;
+    const float bconst = logf(expf(1.f - RQS_MIN_DERIV) - 1.f);  // :81 boundary derivative constant
+    const float norm = 1.f - RQS_MIN_BIN * (float)K;
+
+    for (int64_t grp = (int64_t)blockIdx.x * waves_per_block + wave; grp < n_groups;
+         grp += (int64_t)gridDim.x * waves_per_block) {
+        const int64_t e0 = grp << 6;
+        // ---- stage 64 elements' parameters: consecutive idx -> consecutive HBM addresses inside a row ----
+        const int n_here = (int)((n_elem - e0) < 64 ? (n_elem - e0) : 64);
+        const int total = n_here * P;
+        for (int idx = lane; idx < total; idx += 64) {
+            const int el = idx / P, q = idx - el * P;
+            const int64_t e = e0 + el;
+            const int64_t row = e / n_live;
+            const int i = (int)(e - row * n_live);
+            sp[idx] = params[row * pstride + (int64_t)i * P + q];
+        }
+        // wave-private slice: the wave's own LDS writes are ordered before its reads by lgkmcnt (no barrier)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        const int64_t e = e0 + lane;
+        const bool valid = e < n_elem;
+        const int64_t row = valid ? e / n_live : 0;
+        const int i = valid ? (int)(e - row * n_live) : 0;
+        const int col = live_idx ? live_idx[i] : l0 + i;
+        const float xv = valid ? rqs_load<BF16>(x, row * dim + col) : lo_in;
+        const bool inside = (xv >= lo_in) && (xv <= hi_in);                    // :71 closed interval
+        const float xin = inside ? xv : lo_in;
+        const float *uw = sp + (valid ? lane : 0) * P, *uh = uw + K, *ud = uh + K;
+
+        // ---- softmax normalisers (F.softmax: exp(u - max) / sum), :101,104 -------------------------------
+        float mw = uw[0], mh = uh[0];
+        for (int k = 1; k < K; ++k) { mw = fmaxf(mw, uw[k]); mh = fmaxf(mh, uh[k]); }
+        float sw = 0.f, sh = 0.f;
+        for (int k = 0; k < K; ++k) { sw += expf(uw[k] - mw); sh += expf(uh[k] - mh); }
+
+        // ---- knots (:180-192) + bin search (search_sorted.py:4-5) in one sweep ----------------------------
+        // edge_0 = lower bound <= x always; b = last j with x >= edge_j, edge_K = upper + 1e-6.
+        int b = 0;
+        float cw_b = left, ch_b = bottom, cw_n = right, ch_n = top;           // knots at b and b+1
+        bool have_next = false;
+        float csw = 0.f, csh = 0.f;
+        for (int j = 1; j <= K; ++j) {
+            const float wk = RQS_MIN_BIN + norm * (expf(uw[j - 1] - mw) / sw);   // :102
+            const float hk = RQS_MIN_BIN + norm * (expf(uh[j - 1] - mh) / sh);   // :105
+            csw += wk;                                                           // cumsum :180
+            csh += hk;                                                           // cumsum :187
+            const float kw = (j < K) ? (right - left) * csw + left : right;      // :182-184 (ends pinned)
+            const float kh = (j < K) ? (top - bottom) * csh + bottom : top;      // :189-191
+            const float edge = INVERSE ? kh : kw;
+            const bool ge = xin >= ((j < K) ? edge : edge + RQS_EPS);
+            if (ge && j < K) { b = j; cw_b = kw; ch_b = kh; }                    // j == K: clamp to last bin
+            else if (!ge && !have_next) { cw_n = kw; ch_n = kh; have_next = true; }
+        }
+        const float w_b = cw_n - cw_b;                                           // :185
+        const float h_b = ch_n - ch_b;                                           // :192
+        const float s_b = h_b / w_b;                                             // :203-204
+        const float d_b = RQS_MIN_DERIV + softplus_ref(b == 0 ? bconst : ud[b - 1]);        // :107, :206
+        const float d_n = RQS_MIN_DERIV + softplus_ref(b + 1 == K ? bconst : ud[b]);        // :207
+
+        float out, ljd;
+        if constexpr (INVERSE) {
+            const float dy = xin - ch_b;
+            const float q = d_b + d_n - 2.f * s_b;
+            const float a = dy * q + h_b * (s_b - d_b);                          // :212-215
+            const float bb = h_b * d_b - dy * q;                                 // :216-219
+            const float c = -s_b * dy;                                           // :220
+            const float disc = bb * bb - 4.f * a * c;                            // :222
+            if (valid && inside && !(disc >= 0.f) && err_flag) atomicOr(err_flag, SX_FLAG_RQS_NEG_DISCRIMINANT);
+            const float root = (2.f * c) / (-bb - sqrtf(disc));                  // :225
+            out = root * w_b + cw_b;                                             // :226
+            const float tomt = root * (1.f - root);                              // :228
+            const float den = s_b + q * tomt;                                    // :229-230
+            const float omr = 1.f - root;
+            const float dnum = (s_b * s_b) * (d_n * (root * root) + 2.f * s_b * tomt + d_b * (omr * omr));
+            ljd = -logf(dnum) + 2.f * logf(den);                                 // :234 (sign already flipped)
+        } else {
+            const float theta = (xin - cw_b) / w_b;                              // :236
+            const float tomt = theta * (1.f - theta);                            // :237
+            const float num = h_b * (s_b * (theta * theta) + d_b * tomt);        // :239-240
+            const float den = s_b + (d_b + d_n - 2.f * s_b) * tomt;              // :241-242
+            out = ch_b + num / den;                                              // :243
+            const float omt = 1.f - theta;
+            const float dnum = (s_b * s_b) * (d_n * (theta * theta) + 2.f * s_b * tomt + d_b * (omt * omt));
+            ljd = logf(dnum) - 2.f * logf(den);                                  // :248
+        }
+        if (!inside) { out = xv; ljd = 0.f; }                                    // :86-87 linear tails
+        if (valid) {
+            rqs_store<BF16>(y, row * dim + col, out);
+            if (ldiag) ldiag[row * dim + col] = ljd;
+        }
+        if (ldj_mode == 1) {                 // n_live is a power of two <= 64: a row never leaves the wave
+            float s = valid ? ljd : 0.f;
+            s = group_sum_rt(s, n_live);
+            if (valid && (lane & (n_live - 1)) == 0) ldj[row] = (ldj_acc ? ldj[row] : 0.f) + ldj_scale * s;
+        } else if (ldj_mode == 2) {
+            if (valid) atomicAdd(&ldj[row], ldj_scale * ljd);
+        }
+    }
+}
+
+static bool rqs_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+extern "C" int sx_rqs_coupling(const void *x, void *y, float *ldj, float *ldiag, const float *params,
+                               int64_t params_stride, const int32_t *live_idx, int32_t live_start, int32_t n_live,
+                               int32_t n_bins, float left, float right, float bottom, float top, int64_t n_rows,
+                               int32_t dim, int32_t dtype, int32_t reverse, int32_t ldj_accumulate, float ldj_scale,
+                               uint32_t *err_flag, void *stream) {
+    SX_REQUIRE(x && y && params, "sx_rqs_coupling: null pointer");
+    SX_REQUIRE(dim > 0 && n_live >= 0 && n_live <= dim && n_rows >= 0, "sx_rqs_coupling: bad sizes");
+    SX_REQUIRE(n_bins >= 1, "sx_rqs_coupling: n_bins must be >= 1");
+    SX_REQUIRE(dtype == SX_F32 || dtype == SX_BF16, "sx_rqs_coupling: bad dtype");
+    // rational_quadratic_spline.py:96-99
+    SX_REQUIRE(1e-3 * n_bins <= 1.0, "Minimal bin width too large for the number of bins");
+    SX_REQUIRE(right > left && top > bottom, "sx_rqs_coupling: empty domain");
+    if (n_rows == 0) return SX_OK;
+    hipStream_t st = sx_stream(stream);
+    const int P = 3 * n_bins - 1;
+    int block = 256;
+    size_t lds = (size_t)(block / 64) * 64 * P * sizeof(float);
+    if (lds > 64 * 1024) { block = 64; lds = (size_t)64 * P * sizeof(float); }
+    SX_REQUIRE(lds <= 160 * 1024, "sx_rqs_coupling: n_bins %d needs %zu B of LDS per wave", n_bins, lds);
+
+    // pass-through columns (and their zero log-diag entries)
+    if (n_live < dim && (x != y || ldiag)) {
+        int64_t g = (n_rows * dim + 255) / 256;
+        if (g > 2048) g = 2048;
+        if (dtype == SX_BF16)
+            hipLaunchKernelGGL(rqs_copy_passthrough_kernel<true>, dim3((int)g), dim3(256), dim * sizeof(int), st, x, y,
+                               ldiag, live_idx, live_start, n_live, n_rows, dim, x != y);
+        else
+            hipLaunchKernelGGL(rqs_copy_passthrough_kernel<false>, dim3((int)g), dim3(256), dim * sizeof(int), st, x, y,
+                               ldiag, live_idx, live_start, n_live, n_rows, dim, x != y);
+        SX_LAUNCH_CHECK();
+    }
+    if (n_live == 0) {
+        if (ldj && !ldj_accumulate) {
+            hipError_t e = hipMemsetAsync(ldj, 0, n_rows * sizeof(float), st);
+            if (e != hipSuccess) { sx_set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+        }
+        return SX_OK;
+    }
+    int ldj_mode = 0;
+    if (ldj) {
+        if (rqs_pow2(n_live) && n_live <= 64) ldj_mode = 1;
+        else {
+            ldj_mode = 2;
+            if (!ldj_accumulate) {
+                hipError_t e = hipMemsetAsync(ldj, 0, n_rows * sizeof(float), st);
+                if (e != hipSuccess) { sx_set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+            }
+        }
+    }
+    const int64_t n_groups = (n_rows * n_live + 63) / 64;
+    const int wpb = block / 64;
+    int64_t grid = (n_groups + wpb - 1) / wpb;
+    const int64_t max_grid = 256 * (int64_t)((160 * 1024) / (lds ? lds : 1) > 8 ? 8 : (160 * 1024) / (lds ? lds : 1));
+    if (grid > max_grid) grid = max_grid;
+    if (grid < 1) grid = 1;
+    if (lds > 48 * 1024) {
+#define SX_ATTR(BF, INV)                                                                                          \
+    hipFuncSetAttribute((const void *)rqs_kernel<BF, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+        SX_ATTR(true, true); SX_ATTR(true, false); SX_ATTR(false, true); SX_ATTR(false, false);
+#undef SX_ATTR
+    }
+#define SX_RQ(BF, INV)                                                                                           \
+    hipLaunchKernelGGL((rqs_kernel<BF, INV>), dim3((int)grid), dim3(block), lds, st, x, y, ldj, ldiag, params,    \
+                       params_stride, live_idx, live_start, n_live, n_bins, left, right, bottom, top, n_rows, dim, \
+                       ldj_mode, ldj_accumulate, ldj_scale, err_flag)
+    if (dtype == SX_BF16) { if (reverse) SX_RQ(true, true); else SX_RQ(true, false); }
+    else { if (reverse) SX_RQ(false, true); else SX_RQ(false, false); }
+#undef SX_RQ
+    SX_LAUNCH_CHECK();
+    return SX_OK;
+}

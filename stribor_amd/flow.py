@@ -1,0 +1,219 @@
+"""Plugin surface and flow container (reference: stribor/flow.py:8-152).
+
+``Transform`` / ``ElementwiseTransform`` keep the reference's abstract methods and defaulted
+``*_and_log_det_jacobian`` combinators, so third-party transforms written against stribor plug in
+unchanged.  ``NormalizingFlow`` keeps the reference's method set, but instead of looping over the
+layers in Python (flow.py:99-125) it asks every layer for its step(s) of a fused program and runs the
+whole flow — inverse pass, log-det accumulation and the UnitNormal base density (flow.py:127-130) —
+in ONE kernel launch.  Layers that cannot be fused fall back to a per-layer loop of HIP kernels.
+"""
+from abc import ABCMeta, abstractmethod
+from typing import List, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import _hip
+from .fused import CompiledProgram, ProgramBuilder
+
+__all__ = ['Transform', 'ElementwiseTransform', 'NormalizingFlow']
+
+
+def flatten_rows(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Size]:
+    """[..., D] -> contiguous [N, D] plus the leading shape (the kernels see rows = samples)."""
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, x.shape[-1])
+    return (x2 if x2.is_contiguous() else x2.contiguous()), lead
+
+
+class Transform(nn.Module, metaclass=ABCMeta):
+    """flow.py:8-47.  Subclasses may additionally implement the planner hooks
+    ``_plan_hidden_width()`` and ``_plan(builder, reverse, ldj_scale)`` to join fused programs."""
+
+    @abstractmethod
+    def forward(self, x, **kwargs):
+        ...
+
+    @abstractmethod
+    def inverse(self, y, **kwargs):
+        ...
+
+    @abstractmethod
+    def log_det_jacobian(self, x, y, **kwargs):
+        ...
+
+    def jacobian(self, x, y, **kwargs):
+        raise NotImplementedError
+
+    def forward_and_log_det_jacobian(self, x, **kwargs):
+        y = self.forward(x, **kwargs)
+        return y, self.log_det_jacobian(x, y, **kwargs)
+
+    def inverse_and_log_det_jacobian(self, y, **kwargs):
+        x = self.inverse(y, **kwargs)
+        return x, -self.log_det_jacobian(x, y, **kwargs)
+
+    # ---- fused-program hooks (default: not fusable) --------------------------------------------------
+    def _plan_hidden_width(self) -> int:
+        return 0
+
+    def _plan_first_mask(self, dim: int):
+        return None
+
+    def _plan(self, builder: ProgramBuilder, reverse: bool, ldj_scale: float) -> bool:
+        return False
+
+
+class ElementwiseTransform(Transform):
+    """flow.py:50-69."""
+
+    @abstractmethod
+    def log_diag_jacobian(self, x, y, **kwargs):
+        ...
+
+    def forward_and_log_diag_jacobian(self, x, **kwargs):
+        y = self.forward(x, **kwargs)
+        return y, self.log_diag_jacobian(x, y, **kwargs)
+
+    def inverse_and_log_diag_jacobian(self, y, **kwargs):
+        x = self.inverse(y, **kwargs)
+        return x, -self.log_diag_jacobian(x, y, **kwargs)
+
+
+class NormalizingFlow(Transform):
+    """flow.py:72-152.  ``base_dist`` needs ``log_prob / sample / rsample`` (flow.py:129,139,141)."""
+
+    def __init__(self, base_dist, transforms: List[Transform]):
+        super().__init__()
+        self.base_dist = base_dist
+        self.transforms = nn.ModuleList(transforms)
+        self._fused = {}
+
+    # ---- fused program cache -----------------------------------------------------------------------------
+    def _fused_program(self, reverse: bool, dim: int, latent_dim: int, device) -> Optional[CompiledProgram]:
+        key = (reverse, dim, latent_dim, str(device))
+        if key not in self._fused:
+            self._fused[key] = self._build_fused(reverse, dim, latent_dim, device)
+        return self._fused[key]
+
+    def _build_fused(self, reverse, dim, latent_dim, device) -> Optional[CompiledProgram]:
+        order = list(reversed(self.transforms)) if reverse else list(self.transforms)
+        try:
+            hw = max([f._plan_hidden_width() for f in order] + [1])
+            b = ProgramBuilder(dim, latent_dim, hw)
+            for f in order:
+                m = f._plan_first_mask(dim)
+                if m is not None:
+                    b.choose_layout(m)
+                    break
+            # Transform.inverse_and_log_det_jacobian negates the forward log-det (flow.py:47)
+            scale = -1.0 if reverse else 1.0
+            for f in order:
+                if not f._plan(b, reverse, scale):
+                    return None
+            return b.build(device)
+        except NotImplementedError:
+            return None
+
+    def _run(self, x, reverse: bool, latent, want_y, want_ldj, want_logp, sum_out=None, **kwargs):
+        """Returns (y, ldj[..., 1], logp[..., 1]) (None where not requested) via the fused kernel, or None
+        when the flow cannot be fused."""
+        _hip.require_device(x, 'x')
+        if kwargs:          # e.g. t= for MatrixExponential: per-layer path
+            return None
+        x2, lead = flatten_rows(x)
+        lat2 = None
+        if latent is not None:
+            lat2 = latent.reshape(-1, latent.shape[-1])
+        prog = self._fused_program(reverse, x2.shape[1], 0 if lat2 is None else lat2.shape[1], x.device)
+        if prog is None:
+            return None
+        y, ldj, logp = prog.run(x2, lat2, want_y, want_ldj, want_logp, sum_out)
+        shp = lambda t, d: None if t is None else t.reshape(*lead, d)
+        return shp(y, x2.shape[1]), shp(ldj, 1), shp(logp, 1)
+
+    # ---- reference method set -----------------------------------------------------------------------------
+    def forward(self, x, latent=None, **kwargs):
+        r = self._run(x, False, latent, True, False, False, **kwargs)
+        if r is not None:
+            return r[0]
+        kw = dict(kwargs) if latent is None else dict(kwargs, latent=latent)
+        for f in self.transforms:                                   # flow.py:99-102
+            x = f(x, **kw)
+        return x
+
+    def inverse(self, y, latent=None, **kwargs):
+        r = self._run(y, True, latent, True, False, False, **kwargs)
+        if r is not None:
+            return r[0]
+        kw = dict(kwargs) if latent is None else dict(kwargs, latent=latent)
+        for f in reversed(self.transforms):                         # flow.py:104-107
+            y = f.inverse(y, **kw)
+        return y
+
+    def forward_and_log_det_jacobian(self, x, latent=None, **kwargs):
+        r = self._run(x, False, latent, True, True, False, **kwargs)
+        if r is not None:
+            return r[0], r[1]
+        kw = dict(kwargs) if latent is None else dict(kwargs, latent=latent)
+        acc = 0
+        for f in self.transforms:                                   # flow.py:109-116
+            x, ldj = f.forward_and_log_det_jacobian(x, **kw)
+            acc = acc + ldj
+        return x, acc
+
+    def inverse_and_log_det_jacobian(self, y, latent=None, **kwargs):
+        r = self._run(y, True, latent, True, True, False, **kwargs)
+        if r is not None:
+            return r[0], r[1]
+        kw = dict(kwargs) if latent is None else dict(kwargs, latent=latent)
+        acc = 0
+        for f in reversed(self.transforms):                         # flow.py:118-125
+            y, ldj = f.inverse_and_log_det_jacobian(y, **kw)
+            acc = acc + ldj
+        return y, acc
+
+    def log_prob(self, y, latent=None, **kwargs):
+        """[..., D] -> [..., 1]   (flow.py:127-130)."""
+        from .dist.normal import UnitNormal
+        if isinstance(self.base_dist, UnitNormal):
+            r = self._run(y, True, latent, False, False, True, **kwargs)
+            if r is not None:
+                return r[2]
+        x, acc = self.inverse_and_log_det_jacobian(y, latent=latent, **kwargs)
+        if isinstance(self.base_dist, UnitNormal):
+            x2, lead = flatten_rows(x)
+            ldj = acc.reshape(-1).to(torch.float32).contiguous() if torch.is_tensor(acc) else None
+            out = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device)
+            rc = _hip.lib().sx_unit_normal_logprob(x2.data_ptr(), _hip.ptr(ldj), out.data_ptr(), x2.shape[0],
+                                                   x2.shape[1], _hip.dtype_code(x2), _hip.stream())
+            _hip.check(rc, 'sx_unit_normal_logprob')
+            return out.reshape(*lead, 1)
+        return self.base_dist.log_prob(x).unsqueeze(-1) + acc      # foreign base density: torch ops
+
+    def log_prob_sum(self, y, out: Optional[torch.Tensor] = None, latent=None) -> torch.Tensor:
+        """Sum over the batch of log_prob as ONE fp64 scalar accumulated on the device (the operand of the
+        multi-GPU all-reduce); no per-sample output is written when the flow is fused."""
+        if out is None:
+            out = torch.zeros(1, dtype=torch.float64, device=y.device)
+        from .dist.normal import UnitNormal
+        if isinstance(self.base_dist, UnitNormal):
+            r = self._run(y, True, latent, False, False, True, sum_out=out)
+            if r is not None:
+                return out
+        lp = self.log_prob(y, latent=latent).reshape(-1).contiguous()
+        _hip.check(_hip.lib().sx_sum_f64(lp.data_ptr(), lp.numel(), out.data_ptr(), _hip.stream()), 'sx_sum_f64')
+        return out
+
+    def sample(self, num_samples: Union[Tuple[int], int], *, rsample: bool = False, **kwargs):
+        if isinstance(num_samples, int):
+            num_samples = (num_samples,)
+        x = self.base_dist.rsample(num_samples) if rsample else self.base_dist.sample(num_samples)
+        return self.forward(x, **kwargs)                            # flow.py:132-143
+
+    def rsample(self, num_samples, **kwargs):
+        return self.sample(num_samples, **kwargs)                   # flow.py:145-146
+
+    def log_det_jacobian(self, x, y=None, **kwargs):
+        _, ldj = self.forward_and_log_det_jacobian(x, **kwargs)     # flow.py:148-152
+        return ldj

@@ -1,0 +1,108 @@
+"""Elementwise affine flow (reference: stribor/flows/affine.py:13-123).
+
+``Affine(dim, *, latent_net=None, scale=None, shift=None)`` — keyword-only like the reference.
+Arithmetic runs in ``sx_affine_coupling`` (one HBM pass: read x, read params, write y, wave-shuffle
+row sums for the log-det); inside a fused flow a parameter-only Affine is a constant step.
+"""
+from numbers import Number
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import _hip
+from ..flow import ElementwiseTransform, flatten_rows
+
+__all__ = ['Affine']
+
+
+def run_affine_kernel(x2, params, params_stride, live_idx, live_start, n_live, reverse, want_y, want_ldj,
+                      ldj_scale=1.0):
+    """Thin launcher of sx_affine_coupling on [N, D] rows."""
+    n, d = x2.shape
+    y = torch.empty_like(x2) if want_y else torch.empty_like(x2)     # the kernel always writes y
+    ldj = torch.empty(n, dtype=torch.float32, device=x2.device) if want_ldj else None
+    rc = _hip.lib().sx_affine_coupling(x2.data_ptr(), y.data_ptr(), _hip.ptr(ldj), params.data_ptr(), params_stride,
+                                       _hip.ptr(live_idx), live_start, n_live, n, d, _hip.dtype_code(x2),
+                                       int(reverse), 0, float(ldj_scale), _hip.stream())
+    _hip.check(rc, 'sx_affine_coupling')
+    return y, ldj
+
+
+class Affine(ElementwiseTransform):
+    def __init__(self, dim: int, *, latent_net: Optional[nn.Module] = None, scale=None, shift=None, **kwargs):
+        super().__init__()
+        self.dim = dim
+        self.latent_net = latent_net
+        if latent_net is None:
+            if scale is None:
+                self.log_scale = nn.Parameter(torch.empty(1, dim))            # affine.py:47-50
+                self.shift = nn.Parameter(torch.empty(1, dim))
+                nn.init.xavier_uniform_(self.log_scale)
+                nn.init.xavier_uniform_(self.shift)
+            else:
+                if isinstance(scale, Number):
+                    scale, shift = torch.tensor([float(scale)]), torch.tensor([float(shift)])
+                assert torch.all(scale > 0), '`scale` mush have positive values'  # affine.py:55
+                # buffers (not plain attributes, quirk Q6) so .to(device) moves them; kept out of state_dict
+                self.register_buffer('log_scale', scale.float().log(), persistent=False)
+                self.register_buffer('shift', shift.float().clone(), persistent=False)
+
+    # ---- parameters ---------------------------------------------------------------------------------------
+    def _const_params(self, device) -> torch.Tensor:
+        ls = self.log_scale.detach().reshape(-1)
+        sh = self.shift.detach().reshape(-1)
+        if ls.numel() == 1:
+            ls, sh = ls.expand(self.dim), sh.expand(self.dim)
+        return torch.cat([ls, sh]).to(device=device, dtype=torch.float32).contiguous()
+
+    def _params(self, x2, latent):
+        """-> (params [rows, 2D] fp32, row stride)"""
+        if self.latent_net is None:
+            return self._const_params(x2.device), 0
+        if latent is None:
+            raise ValueError('Affine with a latent_net needs `latent`')
+        p = self.latent_net(latent.reshape(-1, latent.shape[-1]))            # affine.py:66
+        return p, p.stride(0)
+
+    def _apply(self, x, latent, reverse, want_y, want_ldj, ldj_scale=1.0):
+        _hip.require_device(x, 'x')
+        x2, lead = flatten_rows(x)
+        d = x2.shape[1]
+        params, stride = self._params(x2, latent)
+        y, ldj = run_affine_kernel(x2, params, stride, None, 0, d, reverse, want_y, want_ldj, ldj_scale)
+        return (y.reshape(*lead, d) if want_y else None), (None if ldj is None else ldj.reshape(*lead, 1))
+
+    # ---- reference method set (affine.py:69-123) ---------------------------------------------------------
+    def forward(self, x, latent=None, **kwargs):
+        return self._apply(x, latent, False, True, False)[0]
+
+    def inverse(self, y, latent=None, **kwargs):
+        return self._apply(y, latent, True, True, False)[0]
+
+    def log_det_jacobian(self, x, y=None, latent=None, **kwargs):
+        return self._apply(x, latent, False, False, True)[1]
+
+    def forward_and_log_det_jacobian(self, x, latent=None, *, reverse: bool = False, **kwargs):
+        return self._apply(x, latent, reverse, True, True)                    # affine.py:97-109
+
+    def inverse_and_log_det_jacobian(self, y, latent=None, **kwargs):
+        return self._apply(y, latent, True, True, True, ldj_scale=-1.0)      # affine.py:111-113
+
+    def log_diag_jacobian(self, x, y=None, latent=None, **kwargs):
+        x2, lead = flatten_rows(x)
+        params, stride = self._params(x2, latent)
+        ls = params[..., :x2.shape[1]]                                        # affine.py:122-123
+        if stride == 0:
+            ls = ls.reshape(1, -1).expand(x2.shape[0], -1)
+        return ls.reshape(*lead, x2.shape[1])
+
+    # ---- fused-program hooks --------------------------------------------------------------------------------
+    def _plan_hidden_width(self):
+        return 0
+
+    def _plan(self, builder, reverse, ldj_scale):
+        if self.latent_net is not None:
+            return False
+        builder.add_affine_const(self.log_scale, self.shift, reverse, ldj_scale)
+        return True

@@ -1,0 +1,155 @@
+"""Coupling layer (reference: stribor/flows/coupling.py:10-95).
+
+``Coupling(transform, mask, set_data=False)`` wraps an elementwise transform whose ``latent_net`` maps the
+masked input (optionally concatenated with ``latent``) to the transform's parameters.
+
+* ``Coupling(Affine(latent_net=MLP))`` is ONE launch of the fused MFMA kernel per call: masked GEMM-1,
+  tanh, pruned GEMM-2, affine, blend and per-sample log-det all stay in registers; the conditioner runs
+  once even for ``*_and_log_det_jacobian`` (the reference runs it twice, quirk Q2).
+* ``Coupling(Spline(quadratic, latent_net=MLP))`` runs the conditioner with the MFMA kernel (pruned to the
+  transformed columns) and the spline in ``sx_rqs_coupling`` (parameters staged through LDS per wavefront).
+"""
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import _hip
+from ..flow import Transform, flatten_rows
+from ..fused import ProgramBuilder
+from ..net.mlp import MLP, _chunk_mlp_program
+from ..util.mask import get_mask
+from .affine import Affine
+
+__all__ = ['Coupling']
+
+
+class Coupling(Transform):
+    def __init__(self, transform, mask: str, set_data: bool = False, **kwargs):
+        super().__init__()
+        if set_data:
+            raise NotImplementedError('stribor_amd.Coupling: set_data=True (masking over a set axis) is outside '
+                                      'the coupling-flow hot path (SURVEY 8(f))')
+        self.transform = transform
+        self.mask_name = mask
+        self.mask_func = get_mask(mask)                       # raises NotImplementedError like mask.py:20
+        self.set_data = False
+        self._masks = {}
+        self._programs = {}
+
+    # ---- mask: built once per width (the reference rebuilds it from numpy every call, quirk Q4) --------
+    def mask_vector(self, dim: int) -> np.ndarray:
+        if dim not in self._masks:
+            m = self.mask_func(dim).numpy().astype(np.float64).reshape(-1)
+            self._masks[dim] = np.full(dim, m[0]) if m.size == 1 else m
+        return self._masks[dim]
+
+    def _get_mask(self, x: torch.Tensor) -> torch.Tensor:
+        return torch.from_numpy(self.mask_vector(x.shape[-1])).to(x).expand_as(x)     # coupling.py:48-53
+
+    def _net(self) -> MLP:
+        net = getattr(self.transform, 'latent_net', None)
+        if not isinstance(net, MLP):
+            raise NotImplementedError('stribor_amd.Coupling needs a transform with a stribor_amd.net.MLP latent_net')
+        return net
+
+    # ---- affine: one fused single-step program per (direction, width, latent width, device) -----------
+    def _affine_program(self, reverse: bool, ldj_scale: float, dim: int, latent_dim: int, device):
+        key = ('affine', reverse, ldj_scale, dim, latent_dim, str(device))
+        if key not in self._programs:
+            b = ProgramBuilder(dim, latent_dim, self._net().hidden_width)
+            if not self._plan(b, reverse, ldj_scale):
+                raise NotImplementedError('this coupling cannot run on the fused kernel')
+            self._programs[key] = b.build(device)
+        return self._programs[key]
+
+    def _run(self, x, latent, reverse, want_y, want_ldj, ldj_scale=1.0):
+        _hip.require_device(x, 'x')
+        x2, lead = flatten_rows(x)
+        d = x2.shape[1]
+        lat2 = None if latent is None else latent.reshape(-1, latent.shape[-1])
+        ld = 0 if lat2 is None else lat2.shape[1]
+        if isinstance(self.transform, Affine):
+            prog = self._affine_program(reverse, ldj_scale, d, ld, x.device)
+            y, ldj, _ = prog.run(x2, lat2, want_y, want_ldj, False)
+        else:
+            from .spline import Spline
+            if not isinstance(self.transform, Spline):
+                raise NotImplementedError(f'Coupling({type(self.transform).__name__}) is not on the hot path')
+            y, ldj = self._run_spline(x2, lat2, reverse, want_ldj, ldj_scale)
+        return (None if y is None else y.reshape(*lead, d)), (None if ldj is None else ldj.reshape(*lead, 1))
+
+    # ---- spline: pruned conditioner (MFMA) + LDS-staged spline kernel --------------------------------------
+    def _spline_program(self, dim: int, latent_dim: int, device):
+        key = ('rqs', dim, latent_dim, str(device))
+        if key not in self._programs:
+            net, sp = self._net(), self.transform
+            m = self.mask_vector(dim)
+            live = np.nonzero(m <= 0.5)[0]
+            cond = m > 0.5
+            if dim == 1:
+                cond = np.zeros(1, dtype=bool)                                       # coupling.py:62-63
+            P = 3 * sp.n_bins - 1
+            out_rows = (live[:, None] * P + np.arange(P)[None, :]).reshape(-1)       # spline.py:82-86, pruned
+            b = ProgramBuilder(dim, latent_dim, net.hidden_width)
+            b.add_mlp(net.linears(), net.act_code, cond, out_rows)
+            contiguous = len(live) > 0 and np.array_equal(live, np.arange(live[0], live[0] + len(live)))
+            live_idx = None if contiguous else torch.from_numpy(live.astype(np.int32)).to(device)
+            self._programs[key] = (_chunk_mlp_program(b, device), live_idx, int(live[0]) if len(live) else 0,
+                                   len(live), len(out_rows))
+        return self._programs[key]
+
+    def _run_spline(self, x2, lat2, reverse, want_ldj, ldj_scale):
+        from .spline import run_rqs_kernel
+        sp = self.transform
+        n, d = x2.shape
+        progs, live_idx, live_start, n_live, width = self._spline_program(d, 0 if lat2 is None else lat2.shape[1],
+                                                                          x2.device)
+        params = torch.empty(n, width, dtype=torch.float32, device=x2.device)
+        for p in progs:
+            p.run(x2, lat2, mlp_out=params)
+        y, ldj, _ = run_rqs_kernel(x2, params, params.stride(0), live_idx, live_start, n_live, sp.n_bins,
+                                   sp.lower, sp.upper, sp.lower, sp.upper, reverse, want_ldj, False, ldj_scale)
+        return y, ldj
+
+    # ---- reference method set (coupling.py:69-95) -----------------------------------------------------------
+    def forward(self, x, latent=None, reverse: bool = False, **kwargs):
+        return self._run(x, latent, reverse, True, False)[0]
+
+    def inverse(self, y, latent=None, **kwargs):
+        return self._run(y, latent, True, True, False)[0]                            # coupling.py:81-82 (Q3)
+
+    def log_det_jacobian(self, x, y=None, latent=None, **kwargs):
+        return self._run(x, latent, False, False, True)[1]
+
+    def forward_and_log_det_jacobian(self, x, latent=None, **kwargs):
+        return self._run(x, latent, False, True, True)
+
+    def inverse_and_log_det_jacobian(self, y, latent=None, **kwargs):
+        if isinstance(self.transform, Affine):
+            # the log-scales that invert y are the forward log-det at x (same conditioner input): one launch
+            return self._run(y, latent, True, True, True, ldj_scale=-1.0)
+        # spline: inverse kernel returns the already-negated log-diag-Jacobian (rational_quadratic_spline.py:234)
+        return self._run(y, latent, True, True, True, ldj_scale=1.0)
+
+    # ---- fused-program hooks --------------------------------------------------------------------------------
+    def _plan_hidden_width(self):
+        return self._net().hidden_width if isinstance(self.transform, Affine) else 0
+
+    def _plan_first_mask(self, dim):
+        return self.mask_vector(dim)
+
+    def _plan(self, builder: ProgramBuilder, reverse: bool, ldj_scale: float) -> bool:
+        if not isinstance(self.transform, Affine) or not isinstance(getattr(self.transform, 'latent_net', None), MLP):
+            return False
+        net = self._net()
+        lin = net.linears()
+        if len(lin) != 2:
+            return False                  # deeper conditioners take the per-layer path
+        (W1, b1), (W2, b2) = lin
+        if W1.shape[1] != builder.dim + builder.latent_dim or W2.shape[0] != 2 * builder.dim:
+            raise ValueError(f'latent_net maps {W1.shape[1]} -> {W2.shape[0]}, expected '
+                             f'{builder.dim + builder.latent_dim} -> {2 * builder.dim}')
+        builder.add_coupling_affine(W1, b1, W2, b2, self.mask_vector(builder.dim), net.act_code, reverse, ldj_scale,
+                                    W1.shape[0])
+        return True

@@ -1,0 +1,94 @@
+"""Flip / Permute (reference: stribor/flows/permute.py:11-82): bit-exact column moves, log-det 0.
+
+Stand-alone they run ``sx_permute`` (a byte gather); inside a fused flow they are free — the planner only
+relabels which column each state slot holds.  The permutation is a registered buffer (the reference
+keeps it as a plain attribute that ``state_dict`` and ``.to()`` miss, quirks Q6/Q7).
+"""
+from typing import List
+
+import numpy as np
+import torch
+
+from .. import _hip
+from ..flow import ElementwiseTransform, flatten_rows
+
+__all__ = ['Flip', 'Permute']
+
+
+def _gather_columns(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    _hip.require_device(x, 'x')
+    if x.element_size() not in (2, 4):
+        raise TypeError(f'sx_permute moves 2- or 4-byte elements (got {x.dtype})')
+    x2, lead = flatten_rows(x)
+    y = torch.empty_like(x2)
+    idx = idx.to(device=x.device, dtype=torch.int32)
+    rc = _hip.lib().sx_permute(x2.data_ptr(), y.data_ptr(), idx.data_ptr(), x2.shape[0], x2.shape[1],
+                               x2.element_size(), _hip.stream())
+    _hip.check(rc, 'sx_permute')
+    return y.reshape(*lead, x2.shape[1])
+
+
+class _ColumnShuffle(ElementwiseTransform):
+    def _perm(self, dim: int) -> torch.Tensor:
+        raise NotImplementedError
+
+    def _inv(self, dim: int) -> torch.Tensor:
+        p = self._perm(dim)
+        inv = torch.empty_like(p)
+        inv[p] = torch.arange(p.numel(), device=p.device, dtype=p.dtype)
+        return inv
+
+    def forward(self, x, **kwargs):
+        return _gather_columns(x, self._perm(x.shape[-1]))
+
+    def inverse(self, y, **kwargs):
+        return _gather_columns(y, self._inv(y.shape[-1]))
+
+    def log_det_jacobian(self, x, y=None, **kwargs):
+        return torch.zeros_like(x[..., :1])                                  # permute.py:41,78
+
+    def log_diag_jacobian(self, x, y=None, **kwargs):
+        # permute.py:44,82: log of the diagonal of a permutation matrix (0 on fixed points, -inf elsewhere)
+        p = self._perm(x.shape[-1]).to(x.device)
+        fixed = p == torch.arange(p.numel(), device=x.device)
+        d = torch.where(fixed, torch.zeros((), device=x.device), torch.full((), float('-inf'), device=x.device))
+        return d.to(x.dtype).expand_as(x)
+
+    def _plan(self, builder, reverse, ldj_scale):
+        builder.add_permutation(self._perm(builder.dim).cpu().numpy(), reverse)
+        return True
+
+
+class Flip(_ColumnShuffle):
+    def __init__(self, dims: List[int] = [-1]):
+        super().__init__()
+        if list(dims) != [-1]:
+            raise NotImplementedError('stribor_amd.Flip: only the feature axis (dims=[-1]) is on the hot path')
+        self.dims = list(dims)
+
+    def _perm(self, dim):
+        return torch.arange(dim - 1, -1, -1)
+
+
+class Permute(_ColumnShuffle):
+    def __init__(self, dim: int):
+        super().__init__()
+        self.dim = dim
+        self.register_buffer('permutation', torch.randperm(dim))              # permute.py:65
+        inv = torch.empty(dim, dtype=torch.long)
+        inv[self.permutation] = torch.arange(dim)                             # permute.py:67-68
+        self.register_buffer('inverse_permutation', inv, persistent=False)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
+        if prefix + 'permutation' in missing_keys:       # a reference checkpoint never holds it (quirk Q7)
+            missing_keys.remove(prefix + 'permutation')
+        inv = torch.empty_like(self.permutation)
+        inv[self.permutation] = torch.arange(self.dim, device=self.permutation.device)
+        self.inverse_permutation = inv
+
+    def _perm(self, dim):
+        assert dim == self.dim
+        return self.permutation

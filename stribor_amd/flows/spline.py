@@ -1,0 +1,137 @@
+"""Rational-quadratic spline flow (reference: stribor/flows/spline.py:11-143 with
+``spline_type='quadratic'`` -> stribor/util/rational_quadratic_spline.py).
+
+Same constructor as the reference.  ``spline_type='cubic'`` (the reference default, quirk Q10) is not on
+the path named by BASELINE.json and raises.  The arithmetic runs in ``sx_rqs_coupling``: one lane per
+element, the element's 3K-1 parameters staged through the wave's own LDS slice, tails predicated.
+
+Error behaviour: the reference raises ``ValueError('Minimal bin width too large ...')`` when
+``1e-3 * n_bins > 1`` (rational_quadratic_spline.py:96-99) — same here, from Python, before launch.
+Its ``assert (discriminant >= 0).all()`` (:223) becomes a device flag that ``check_errors()`` reads.
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import _hip
+from ..flow import ElementwiseTransform, flatten_rows
+
+__all__ = ['Spline', 'run_rqs_kernel']
+
+_err_flags = {}
+
+
+def _err_flag(device) -> torch.Tensor:
+    key = str(device)
+    if key not in _err_flags:
+        _err_flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _err_flags[key]
+
+
+def check_errors(device=None) -> None:
+    """Raise what the reference would have raised for data-dependent spline failures (synchronises)."""
+    for key, flag in list(_err_flags.items()):
+        if device is not None and key != str(device):
+            continue
+        v = int(flag.item())
+        if v:
+            flag.zero_()
+            if v & 1:
+                raise AssertionError('rational_quadratic_spline: negative discriminant in the inverse pass')
+
+
+def run_rqs_kernel(x2, params, params_stride, live_idx, live_start, n_live, n_bins, left, right, bottom, top,
+                   reverse, want_ldj, want_ldiag, ldj_scale=1.0):
+    """Launch sx_rqs_coupling on [N, D] rows -> (y, ldj | None, ldiag | None)."""
+    if 1e-3 * n_bins > 1.0:
+        raise ValueError('Minimal bin width too large for the number of bins')      # :96-97
+    n, d = x2.shape
+    y = torch.empty_like(x2)
+    ldj = torch.empty(n, dtype=torch.float32, device=x2.device) if want_ldj else None
+    ldiag = torch.empty(n, d, dtype=torch.float32, device=x2.device) if want_ldiag else None
+    rc = _hip.lib().sx_rqs_coupling(x2.data_ptr(), y.data_ptr(), _hip.ptr(ldj), _hip.ptr(ldiag), params.data_ptr(),
+                                    params_stride, _hip.ptr(live_idx), live_start, n_live, n_bins, float(left),
+                                    float(right), float(bottom), float(top), n, d, _hip.dtype_code(x2),
+                                    int(reverse), 0, float(ldj_scale), _err_flag(x2.device).data_ptr(),
+                                    _hip.stream())
+    _hip.check(rc, 'sx_rqs_coupling')
+    return y, ldj, ldiag
+
+
+class Spline(ElementwiseTransform):
+    def __init__(self, dim: int, n_bins: int, latent_net: Optional[nn.Module] = None, lower: Optional[float] = 0,
+                 upper: Optional[float] = 1, spline_type: Optional[str] = 'cubic', **kwargs):
+        super().__init__()
+        self.lower, self.upper = lower, upper
+        self.dim, self.n_bins = dim, n_bins
+        self.latent_net = latent_net
+        if spline_type == 'quadratic':
+            self.derivative_dim = n_bins - 1                                         # spline.py:56-57
+        elif spline_type == 'cubic':
+            raise NotImplementedError("stribor_amd.Spline: spline_type='cubic' is outside the rational-quadratic "
+                                      "hot path named by BASELINE.json; pass spline_type='quadratic'")
+        else:
+            raise ValueError('spline_type must be either `quadratic` or `cubic`')    # spline.py:63
+        if latent_net is None:
+            self.width = nn.Parameter(torch.empty(dim, n_bins))                      # spline.py:65-69
+            self.height = nn.Parameter(torch.empty(dim, n_bins))
+            self.derivative = nn.Parameter(torch.empty(dim, self.derivative_dim))
+            nn.init.xavier_uniform_(self.width)
+            nn.init.xavier_uniform_(self.height)
+            if self.derivative_dim > 0:
+                nn.init.xavier_uniform_(self.derivative)
+
+    # ---- parameters: [rows, D*(3K-1)] in the conditioner's own layout (spline.py:82-86) ----------------
+    def _params(self, x2, latent):
+        if self.latent_net is None:
+            p = torch.cat([self.width, self.height, self.derivative], dim=-1).detach()
+            return p.reshape(-1).to(device=x2.device, dtype=torch.float32).contiguous(), 0
+        if latent is None:
+            raise ValueError('Spline with a latent_net needs `latent`')
+        p = self.latent_net(latent.reshape(-1, latent.shape[-1]))
+        return p, p.stride(0)
+
+    def _bounds(self):
+        return self.lower, self.upper, self.lower, self.upper                        # left, right, bottom, top
+
+    def _apply(self, x, latent, reverse, want_ldj, want_ldiag, ldj_scale=1.0):
+        _hip.require_device(x, 'x')
+        x2, lead = flatten_rows(x)
+        d = x2.shape[1]
+        params, stride = self._params(x2, latent)
+        l, r, b, t = self._bounds()
+        y, ldj, ldiag = run_rqs_kernel(x2, params, stride, None, 0, d, self.n_bins, l, r, b, t, reverse, want_ldj,
+                                       want_ldiag, ldj_scale)
+        return (y.reshape(*lead, d), None if ldj is None else ldj.reshape(*lead, 1),
+                None if ldiag is None else ldiag.reshape(*lead, d))
+
+    # ---- reference method set (spline.py:89-143) ----------------------------------------------------------
+    def forward(self, x, latent=None, **kwargs):
+        return self._apply(x, latent, False, False, False)[0]
+
+    def inverse(self, y, latent=None, **kwargs):
+        return self._apply(y, latent, True, False, False)[0]
+
+    def forward_and_log_diag_jacobian(self, x, latent=None, *, reverse=False, **kwargs):
+        y, _, ld = self._apply(x, latent, reverse, False, True)
+        return y, ld
+
+    def inverse_and_log_diag_jacobian(self, y, latent=None, **kwargs):
+        # the inverse spline already returns the negated value (rational_quadratic_spline.py:234): no extra sign
+        x, _, ld = self._apply(y, latent, True, False, True)
+        return x, ld
+
+    def forward_and_log_det_jacobian(self, x, latent=None, **kwargs):
+        y, ldj, _ = self._apply(x, latent, False, True, False)
+        return y, ldj
+
+    def inverse_and_log_det_jacobian(self, y, latent=None, **kwargs):
+        x, ldj, _ = self._apply(y, latent, True, True, False)
+        return x, ldj
+
+    def log_det_jacobian(self, x, y=None, latent=None, **kwargs):
+        return self._apply(x, latent, False, True, False)[1]
+
+    def log_diag_jacobian(self, x, y=None, latent=None, **kwargs):
+        return self._apply(x, latent, False, False, True)[2]

@@ -1,0 +1,368 @@
+"""Host-side planner for the fused flow kernel (``sx_flow_run``).
+
+Turns a sequence of transforms (in execution order, each with a direction) into
+
+  * an ``sx_program`` (step table: which 32-column tiles condition, which are transformed, where each
+    step's weight blob lives),
+  * one device buffer of weight blobs in MFMA fragment order (written by ``sx_pack_linear`` on the
+    device; re-packed only when a parameter's version changes),
+  * the slot <-> column maps used to load / store the state.
+
+The flow state is kept in *slots* (tile t = slots 32t..32t+31).  Permute / Flip layers cost nothing:
+they only relabel which logical column a slot holds (stribor/flows/permute.py:71,75), and the
+relabelling is folded into the row / column index lists of the neighbouring layers' weights.
+Masks (stribor/util/mask.py) become tile sets: when a coupling's conditioning columns fill exactly
+the low (or high) half of the tiles, the dead half of both GEMMs is pruned (SURVEY finding 3: exact,
+zeros contribute exactly 0); otherwise the layer runs dense over all tiles with zeroed weights.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _hip
+
+ALLOWED_TILES = (1, 2, 4)
+
+
+def _ceil_div(a: int, b: int) -> int:
+    return -(-a // b)
+
+
+def _round_tiles(n: int, what: str) -> int:
+    for t in ALLOWED_TILES:
+        if n <= t:
+            return t
+    raise NotImplementedError(f'stribor_amd fused kernel: {what} needs {n} tiles of 32 (max 4, i.e. 128 columns)')
+
+
+def _kmap(r: int, h: int) -> int:
+    return (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+class _PackJob:
+    """One sx_pack_linear call: (W, b) -> blob[dst_off : dst_off + n]."""
+
+    def __init__(self, W, b, row_idx: np.ndarray, col_idx: np.ndarray, m_tiles: int, k_tiles: int, dst_off: int):
+        self.W, self.b = W, b
+        self.row_idx_host, self.col_idx_host = row_idx.astype(np.int32), col_idx.astype(np.int32)
+        self.m_tiles, self.k_tiles, self.dst_off = m_tiles, k_tiles, dst_off
+        self.row_idx = self.col_idx = None
+
+    def run(self, blobs: torch.Tensor) -> None:
+        dev = blobs.device
+        if self.row_idx is None:
+            self.row_idx = torch.from_numpy(self.row_idx_host).to(dev)
+            self.col_idx = torch.from_numpy(self.col_idx_host).to(dev)
+        W = self.W.detach()
+        b = None if self.b is None else self.b.detach()
+        if W.dtype != torch.float32 or not W.is_contiguous():
+            raise TypeError('stribor_amd: conditioner weights must be contiguous float32')
+        out_dim, in_dim = W.shape
+        rc = _hip.lib().sx_pack_linear(W.data_ptr(), _hip.ptr(b), out_dim, in_dim, self.row_idx.data_ptr(),
+                                       self.col_idx.data_ptr(), self.m_tiles, self.k_tiles,
+                                       blobs.data_ptr() + 4 * self.dst_off, _hip.stream())
+        _hip.check(rc, 'sx_pack_linear')
+
+    def params(self):
+        return [p for p in (self.W, self.b) if p is not None]
+
+
+class _ConstJob:
+    """Per-slot constants (st.Affine without latent_net): blob[dst_off:] = cat(ls, sh)[gather]."""
+
+    def __init__(self, log_scale, shift, dim: int, gather: np.ndarray, dst_off: int):
+        self.log_scale, self.shift, self.dim = log_scale, shift, dim
+        self.gather_host, self.dst_off = gather.astype(np.int64), dst_off
+        self.gather = None
+
+    def run(self, blobs: torch.Tensor) -> None:
+        dev = blobs.device
+        if self.gather is None:
+            self.gather = torch.from_numpy(self.gather_host).to(dev)
+        ls = self.log_scale.detach().to(dev, torch.float32).reshape(-1).expand(self.dim) \
+            if self.log_scale.numel() == 1 else self.log_scale.detach().to(dev, torch.float32).reshape(-1)
+        sh = self.shift.detach().to(dev, torch.float32).reshape(-1).expand(self.dim) \
+            if self.shift.numel() == 1 else self.shift.detach().to(dev, torch.float32).reshape(-1)
+        src = torch.cat([ls, sh, torch.zeros(1, device=dev)])
+        n = self.gather.numel()
+        blobs[self.dst_off:self.dst_off + n] = src[self.gather]
+
+    def params(self):
+        return [self.log_scale, self.shift]
+
+
+class CompiledProgram:
+    def __init__(self, prog: _hip.sx_program, blob_floats: int, jobs: List, in_col: Optional[np.ndarray],
+                 out_col: Optional[np.ndarray], device: torch.device, mlp_out_dim: int = 0):
+        self.prog = prog
+        self.device = device
+        self.jobs = jobs
+        self.blobs = torch.zeros(max(blob_floats, 256), dtype=torch.float32, device=device)
+        self.in_col = None if in_col is None else torch.from_numpy(in_col.astype(np.int32)).to(device)
+        self.out_col = None if out_col is None else torch.from_numpy(out_col.astype(np.int32)).to(device)
+        self.mlp_out_dim = mlp_out_dim
+        self._versions = None
+
+    # -- parameter tracking ----------------------------------------------------------------------
+    def _current_versions(self):
+        return tuple((p.data_ptr(), p._version) for j in self.jobs for p in j.params())
+
+    def refresh(self) -> None:
+        v = self._current_versions()
+        if v != self._versions:
+            for j in self.jobs:
+                j.run(self.blobs)
+            self._versions = v
+
+    # -- launch -----------------------------------------------------------------------------------
+    def run(self, x: torch.Tensor, latent: Optional[torch.Tensor] = None, want_y: bool = False,
+            want_ldj: bool = False, want_logp: bool = False, sum_out: Optional[torch.Tensor] = None,
+            mlp_out: Optional[torch.Tensor] = None):
+        """x: [N, dim] contiguous on the program's device.  Returns (y | None, ldj | None, logp | None)."""
+        _hip.require_device(x, 'x')
+        assert x.dim() == 2 and x.shape[1] == self.prog.dim, (x.shape, self.prog.dim)
+        if not x.is_contiguous():
+            x = x.contiguous()
+        self.refresh()
+        n = x.shape[0]
+        y = torch.empty_like(x) if want_y else None
+        ldj = torch.empty(n, dtype=torch.float32, device=x.device) if want_ldj else None
+        logp = torch.empty(n, dtype=torch.float32, device=x.device) if want_logp else None
+        if latent is not None:
+            _hip.require_device(latent, 'latent')
+            latent = latent.to(torch.float32).contiguous()
+            assert latent.shape == (n, self.prog.latent_dim), (latent.shape, self.prog.latent_dim)
+        elif self.prog.latent_dim:
+            raise ValueError('this transform was built for a latent input but none was given')
+        stride = mlp_out.stride(0) if mlp_out is not None else 0
+        rc = _hip.lib().sx_flow_run(C.byref(self.prog), self.blobs.data_ptr(), x.data_ptr(), _hip.ptr(latent),
+                                    _hip.ptr(self.in_col), _hip.ptr(self.out_col), _hip.ptr(y), _hip.ptr(ldj),
+                                    _hip.ptr(logp), _hip.ptr(sum_out), _hip.ptr(mlp_out), stride,
+                                    self.mlp_out_dim, n, _hip.dtype_code(x), _hip.stream())
+        _hip.check(rc, 'sx_flow_run')
+        return y, ldj, logp
+
+    def launch_info(self, n_rows: int) -> Tuple[int, int, int]:
+        g, b, l = C.c_int32(), C.c_int32(), C.c_int32()
+        _hip.check(_hip.lib().sx_flow_launch_info(C.byref(self.prog), n_rows, C.byref(g), C.byref(b), C.byref(l)),
+                   'sx_flow_launch_info')
+        return g.value, b.value, l.value
+
+
+class ProgramBuilder:
+    """Accumulates steps; tracks which logical column each state slot holds."""
+
+    def __init__(self, dim: int, latent_dim: int = 0, hidden_width: int = 32):
+        self.dim, self.latent_dim = dim, latent_dim
+        lat_tiles = _ceil_div(latent_dim, 32)
+        self.tiles = _round_tiles(_ceil_div(dim, 32) + lat_tiles, f'dim {dim} + latent {latent_dim}')
+        self.x_tiles = self.tiles - lat_tiles
+        self.h_tiles = _round_tiles(_ceil_div(hidden_width, 32), f'hidden width {hidden_width}')
+        self.n_slots = 32 * self.x_tiles
+        # slot -> logical column (-1 = padding); identity until choose_layout / permutations change it
+        self.col_of_slot = np.full(self.n_slots, -1, dtype=np.int64)
+        self.col_of_slot[:dim] = np.arange(dim)
+        self.in_col: Optional[np.ndarray] = None     # set at the first step
+        self.steps: List[dict] = []
+        self.jobs: List = []
+        self.blob_floats = 0
+        self.mlp_out_dim = 0
+
+    # -- layout ------------------------------------------------------------------------------------
+    def choose_layout(self, first_mask: Optional[np.ndarray]) -> None:
+        """Put the first coupling's conditioning columns in the low tiles and its transformed columns
+        in the high tiles when both fit, so masks that are not contiguous (parity_*) still prune."""
+        assert not self.steps
+        if first_mask is None or self.tiles < 2 or self.latent_dim or self.x_tiles != self.tiles:
+            return
+        half = 16 * self.tiles
+        cond = np.nonzero(first_mask > 0.5)[0]
+        live = np.nonzero(first_mask <= 0.5)[0]
+        if len(cond) == 0 or len(live) == 0 or len(cond) > half or len(live) > half:
+            return
+        # identity already splits along the tile halves (ordered_* masks at full tiles): keep vector loads
+        if (cond.max() < half <= live.min()) or (live.max() < half <= cond.min()):
+            return
+        lay = np.full(self.n_slots, -1, dtype=np.int64)
+        lay[:len(cond)] = cond
+        lay[half:half + len(live)] = live
+        self.col_of_slot = lay
+
+    def _freeze_input(self) -> None:
+        if self.in_col is None:
+            self.in_col = self.col_of_slot.copy()
+
+    def slot_of_col(self) -> np.ndarray:
+        s = np.full(self.dim, -1, dtype=np.int64)
+        ok = self.col_of_slot >= 0
+        s[self.col_of_slot[ok]] = np.nonzero(ok)[0]
+        return s
+
+    def _alloc(self, n_floats: int) -> Tuple[int, int]:
+        n = _ceil_div(max(n_floats, 1), 256) * 256
+        off = self.blob_floats
+        self.blob_floats += n
+        return off, n
+
+    # -- steps -------------------------------------------------------------------------------------
+    def add_permutation(self, perm: np.ndarray, reverse: bool) -> None:
+        """forward: y[j] = x[perm[j]]; inverse: x[j] = y[inv[j]]  (permute.py:71,75) — a relabelling."""
+        self._freeze_input()
+        perm = np.asarray(perm, dtype=np.int64)
+        inv = np.empty_like(perm)
+        inv[perm] = np.arange(len(perm))
+        relabel = perm if reverse else inv        # new label of the slot that held old label j
+        ok = self.col_of_slot >= 0
+        self.col_of_slot[ok] = relabel[self.col_of_slot[ok]]
+
+    def add_coupling_affine(self, W1, b1, W2, b2, mask: np.ndarray, act: int, reverse: bool, ldj_scale: float,
+                            hidden: int) -> None:
+        self._freeze_input()
+        D, T, HT = self.dim, self.tiles, self.h_tiles
+        mask = np.asarray(mask, dtype=np.float64).reshape(-1)
+        if mask.size == 1:
+            mask = np.full(D, mask[0])
+        cond_col = mask > 0.5
+        if D == 1:
+            cond_col = np.zeros(1, dtype=bool)          # z = z * 0 (coupling.py:62-63)
+        live_col = mask <= 0.5
+        col = self.col_of_slot
+        slot_cond = np.array([c >= 0 and cond_col[c] for c in col])
+        slot_live = np.array([c >= 0 and live_col[c] for c in col])
+        half = 16 * T
+        variant = 'dense'
+        if T >= 2 and self.latent_dim == 0 and self.x_tiles == T:
+            if not slot_cond[half:].any() and not slot_live[:half].any():
+                variant = 'low'
+            elif not slot_cond[:half].any() and not slot_live[half:].any():
+                variant = 'high'
+        if variant == 'low':
+            c0, ct, t0, tt = 0, T // 2, T // 2, T // 2
+        elif variant == 'high':
+            c0, ct, t0, tt = T // 2, T // 2, 0, T // 2
+        else:
+            c0, ct, t0, tt = 0, T, 0, T
+        # GEMM-1 operand: hidden rows x conditioning slots
+        k_slots = np.arange(32 * c0, 32 * (c0 + ct))
+        col_idx = np.full(len(k_slots), -1, dtype=np.int64)
+        for i, p in enumerate(k_slots):
+            if p < self.n_slots:
+                if slot_cond[p]:
+                    col_idx[i] = col[p]
+            else:
+                li = p - self.n_slots
+                if li < self.latent_dim:
+                    col_idx[i] = D + li                    # cat([z, latent]) (coupling.py:64-65)
+        row_idx = np.full(32 * HT, -1, dtype=np.int64)
+        row_idx[:hidden] = np.arange(hidden)
+        n1 = _hip.packed_linear_floats(HT, ct)
+        n2 = _hip.packed_linear_floats(2 * tt, HT)
+        off, n = self._alloc(n1 + n2)
+        self.jobs.append(_PackJob(W1, b1, row_idx, col_idx, HT, ct, off))
+        # GEMM-2 operand: per transformed tile, 32 log_scale rows then 32 shift rows (affine.py:66)
+        row2 = np.full(32 * 2 * tt, -1, dtype=np.int64)
+        for t in range(tt):
+            for i in range(32):
+                p = 32 * (t0 + t) + i
+                if p < self.n_slots and slot_live[p]:
+                    row2[32 * (2 * t) + i] = col[p]
+                    row2[32 * (2 * t + 1) + i] = D + col[p]
+        col2 = np.full(32 * HT, -1, dtype=np.int64)
+        col2[:hidden] = np.arange(hidden)
+        self.jobs.append(_PackJob(W2, b2, row2, col2, 2 * tt, HT, off + n1))
+        self.steps.append(dict(kind=_hip.STEP_COUPLING_AFFINE, c0=c0, ct=ct, t0=t0, tt=tt, reverse=int(reverse),
+                               act=act, blob_off=off, blob_floats=n, ldj_scale=ldj_scale, ldj_const=0.0))
+
+    def add_affine_const(self, log_scale, shift, reverse: bool, ldj_scale: float) -> None:
+        self._freeze_input()
+        D, T = self.dim, self.tiles
+        off, n = self._alloc(2 * 32 * T)
+        gather = np.full(2 * 32 * T, 2 * D, dtype=np.int64)    # index 2D = the appended zero
+        for t in range(self.x_tiles):
+            for h in range(2):
+                for r in range(16):
+                    c = self.col_of_slot[32 * t + _kmap(r, h)]
+                    if c >= 0:
+                        gather[t * 32 + h * 16 + r] = c
+                        gather[(T + t) * 32 + h * 16 + r] = D + c
+        self.jobs.append(_ConstJob(log_scale, shift, D, gather, off))
+        self.steps.append(dict(kind=_hip.STEP_AFFINE_CONST, c0=0, ct=0, t0=0, tt=T, reverse=int(reverse), act=0,
+                               blob_off=off, blob_floats=n, ldj_scale=ldj_scale, ldj_const=0.0))
+
+    def add_mlp(self, linears: Sequence[Tuple], act: int, in_cols_live: Optional[np.ndarray],
+                out_rows: np.ndarray) -> None:
+        """Conditioner as its own program: hidden layers then one OUT_TILE step per 32 output columns.
+
+        linears: [(W, b), ...] torch layout; in_cols_live: bool[D] (False -> that x column is zeroed,
+        the z = x*mask of coupling.py:61) or None; out_rows[i] = row of the last W written to column i."""
+        self._freeze_input()
+        assert len(linears) >= 2, 'conditioner needs at least one hidden layer'
+        D, T, HT = self.dim, self.tiles, self.h_tiles
+        col = self.col_of_slot
+        W0, b0 = linears[0]
+        col_idx = np.full(32 * T, -1, dtype=np.int64)
+        for p in range(32 * T):
+            if p < self.n_slots:
+                c = col[p]
+                if c >= 0 and (in_cols_live is None or in_cols_live[c]):
+                    col_idx[p] = c
+            else:
+                li = p - self.n_slots
+                if li < self.latent_dim:
+                    col_idx[p] = D + li
+        h_prev = W0.shape[0]
+        row_idx = np.full(32 * HT, -1, dtype=np.int64)
+        row_idx[:h_prev] = np.arange(h_prev)
+        off, n = self._alloc(_hip.packed_linear_floats(HT, T))
+        self.jobs.append(_PackJob(W0, b0, row_idx, col_idx, HT, T, off))
+        self.steps.append(dict(kind=_hip.STEP_MLP_HIDDEN, c0=0, ct=T, t0=0, tt=0, reverse=0, act=act, blob_off=off,
+                               blob_floats=n, ldj_scale=0.0, ldj_const=0.0))
+        for (W, b) in linears[1:-1]:
+            h_cur = W.shape[0]
+            r = np.full(32 * HT, -1, dtype=np.int64)
+            r[:h_cur] = np.arange(h_cur)
+            c = np.full(32 * HT, -1, dtype=np.int64)
+            c[:h_prev] = np.arange(h_prev)
+            off, n = self._alloc(_hip.packed_linear_floats(HT, HT))
+            self.jobs.append(_PackJob(W, b, r, c, HT, HT, off))
+            self.steps.append(dict(kind=_hip.STEP_MLP_HIDDEN2, c0=0, ct=0, t0=0, tt=0, reverse=0, act=act,
+                                   blob_off=off, blob_floats=n, ldj_scale=0.0, ldj_const=0.0))
+            h_prev = h_cur
+        WL, bL = linears[-1]
+        out_rows = np.asarray(out_rows, dtype=np.int64)
+        self.mlp_out_dim = len(out_rows)
+        cL = np.full(32 * HT, -1, dtype=np.int64)
+        cL[:h_prev] = np.arange(h_prev)
+        for u in range(_ceil_div(len(out_rows), 32)):
+            r = np.full(32, -1, dtype=np.int64)
+            seg = out_rows[32 * u:32 * u + 32]
+            r[:len(seg)] = seg
+            off, n = self._alloc(_hip.packed_linear_floats(1, HT))
+            self.jobs.append(_PackJob(WL, bL, r, cL, 1, HT, off))
+            self.steps.append(dict(kind=_hip.STEP_MLP_OUT_TILE, c0=0, ct=0, t0=u, tt=1, reverse=0, act=0,
+                                   blob_off=off, blob_floats=n, ldj_scale=0.0, ldj_const=0.0))
+
+    # -- finish ------------------------------------------------------------------------------------
+    def build(self, device: torch.device) -> CompiledProgram:
+        self._freeze_input()
+        if len(self.steps) > _hip.SX_MAX_STEPS:
+            raise NotImplementedError(f'fused program has {len(self.steps)} steps (max {_hip.SX_MAX_STEPS})')
+        prog = _hip.sx_program()
+        prog.n_steps = len(self.steps)
+        prog.dim, prog.latent_dim = self.dim, self.latent_dim
+        prog.x_tiles, prog.tiles, prog.h_tiles = self.x_tiles, self.tiles, self.h_tiles
+        ident = np.full(self.n_slots, -1, dtype=np.int64)
+        ident[:self.dim] = np.arange(self.dim)
+        identity = (self.dim % 4 == 0 and np.array_equal(self.in_col, ident)
+                    and np.array_equal(self.col_of_slot, ident))
+        prog.identity_cols = int(identity)
+        for i, s in enumerate(self.steps):
+            st = prog.steps[i]
+            for k, v in s.items():
+                setattr(st, k, v)
+        return CompiledProgram(prog, self.blob_floats, self.jobs, None if identity else self.in_col,
+                               None if identity else self.col_of_slot.copy(), device, self.mlp_out_dim)

@@ -1,0 +1,236 @@
+"""GPU: the HIP path (through the C ABI) against the golden vectors and the oracle.
+
+Tolerance: the north_star bound "<= 1e-5 rel for fp32 transforms" is applied as
+|got - want| <= 1e-5 + 1e-5*|want|; Permute/Flip are bit-exact.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+import flowdesc as fd
+from goldens import Golden
+from producthelp import close, product_flow, product_transform
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import stribor_oracle as orc
+
+import stribor_amd as st
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def test_f1_doc_known_answer():
+    """stribor/test/test_normalizing_flow.py:45-55 on the GPU."""
+    g = Golden('f1_doc_example')
+    flow = fd.build_flow(st, g.meta['desc'], 2)
+    flow.load_state_dict(g.state(''))
+    flow = flow.to(DEV)
+    lp = flow.log_prob(g.t('x').to(DEV))
+    assert lp.shape == (3, 1)
+    close(lp, torch.tensor([[-1.7560], [-1.7434], [-2.1792]]), rtol=0, atol=1e-4)
+    close(lp, g.t('log_prob'))
+    s = flow.forward(g.t('base_sample').to(DEV))
+    close(s, torch.tensor([[-0.5204, 0.4196]]), rtol=0, atol=1e-4)
+    close(s, g.t('sample'))
+    assert flow.sample(5).shape == (5, 2) and flow.sample(5).is_cuda
+
+
+@pytest.mark.parametrize('fixture,case', [('f3_cfg1', 'cfg1'), ('f4_cfg2', 'cfg2'), ('f7_permute', 'mixed')])
+def test_fused_flow_against_golden(fixture, case):
+    g = Golden(fixture)
+    flow = product_flow(g, case)
+    x = g.t(case + '/x').to(DEV)
+    close(flow.log_prob(x), g.t(case + '/log_prob'))
+    z, ldj = flow.inverse_and_log_det_jacobian(x)
+    close(z, g.t(case + '/inverse'))
+    close(ldj, g.t(case + '/inverse_ldj'), atol=1e-4)
+    close(flow.inverse(x), g.t(case + '/inverse'))
+    y, ldf = flow.forward_and_log_det_jacobian(x)
+    close(y, g.t(case + '/forward'))
+    close(ldf, g.t(case + '/forward_ldj'), atol=1e-4)
+    close(flow.forward(x), g.t(case + '/forward'))
+    close(flow.log_det_jacobian(x, None), g.t(case + '/forward_ldj'), atol=1e-4)
+    # vs fp64 truth: not worse than the reference's own fp32 error by more than 1e-5 rel
+    if g.has(case + '/log_prob_f64'):
+        close(flow.log_prob(x).double(), g.t(case + '/log_prob_f64'), rtol=1e-5, atol=1e-5)
+    for extra in ('bf16', 'wide'):
+        if g.has(f'{case}/{extra}/x'):
+            close(flow.log_prob(g.t(f'{case}/{extra}/x').to(DEV)), g.t(f'{case}/{extra}/log_prob'))
+
+
+@pytest.mark.parametrize('fixture,case', [('f3_cfg1', 'cfg1'), ('f4_cfg2', 'cfg2'), ('f7_permute', 'mixed')])
+def test_per_layer_api_against_golden(fixture, case):
+    """The Transform plugin surface layer by layer (flow.py:42-47 called on every transform)."""
+    g = Golden(fixture)
+    flow = product_flow(g, case)
+    cur = g.t(case + '/x').to(DEV)
+    for i in reversed(range(len(flow.transforms))):
+        f = flow.transforms[i]
+        nxt, ldj = f.inverse_and_log_det_jacobian(cur)
+        close(nxt, g.t(f'{case}/inv_x.{i}'))
+        close(ldj, g.t(f'{case}/inv_ldj.{i}'), atol=2e-5)
+        close(f.inverse(cur), g.t(f'{case}/inv_x.{i}'))
+        close(f.log_det_jacobian(nxt, cur), -g.t(f'{case}/inv_ldj.{i}'), atol=2e-5)
+        close(f.forward(nxt), cur.cpu(), atol=1e-4)                # base.py:8-11 round trip
+        cur = nxt
+
+
+def test_bf16_storage_matches_oracle_on_rounded_input():
+    """x stored bf16, arithmetic fp32, log_prob fp32 == oracle fed x.bfloat16().float()."""
+    g = Golden('f4_cfg2')
+    flow = product_flow(g, 'cfg2')
+    xb = g.t('cfg2/bf16/x')
+    lp = flow.log_prob(xb.to(DEV).bfloat16())
+    assert lp.dtype == torch.float32
+    close(lp, g.t('cfg2/bf16/log_prob'))
+    z = flow.inverse(xb.to(DEV).bfloat16())
+    assert z.dtype == torch.bfloat16
+    spec = fd.flow_spec(g.meta['cfg2']['desc'], g.state('cfg2'))
+    close(z.float(), orc.flow_inverse(spec, xb).bfloat16().float(), rtol=1e-2, atol=1e-2)
+
+
+def test_suite_shapes_coupling_affine_and_affine():
+    """stribor/test/test_coupling.py:7-26, test_affine.py:27-40 shapes incl. latent 0/1/13 and 3-D inputs."""
+    g = Golden('f8_suite')
+    n = 0
+    for case in g.cases('coupling_affine/') + g.cases('affine_latent/'):
+        f = product_transform(g, case)
+        x = g.t(case + '/x').to(DEV)
+        kw = {'latent': g.t(case + '/latent').to(DEV)} if g.has(case + '/latent') else {}
+        y = f(x, **kw)
+        close(y, g.t(case + '/y'))
+        close(f.inverse(y, **kw), g.t(case + '/x'), atol=1e-4)
+        ldj = f.log_det_jacobian(x, y, **kw)
+        close(ldj, g.t(case + '/ldj'), atol=2e-5)
+        _, l1 = f.forward_and_log_det_jacobian(x, **kw)
+        _, l2 = f.inverse_and_log_det_jacobian(y, **kw)
+        close(l1, g.t(case + '/ldj'), atol=2e-5)
+        close(-l2, g.t(case + '/ldj'), atol=1e-4)                              # base.py:14-22
+        close(ldj.reshape(-1), g.t(case + '/autograd_logdet'), atol=1e-4)      # base.py:35-44
+        n += 1
+    assert n == 4 * 3 + 4 * 2
+
+
+def test_permute_flip_bit_exact():
+    g = Golden('f7_permute')
+    p = st.Permute(64)
+    p.load_state_dict({'permutation': g.t('perm64/permutation')})
+    p = p.to(DEV)
+    x = g.t('perm64/x').to(DEV)
+    assert torch.equal(p(x).cpu(), g.t('perm64/fwd'))
+    assert torch.equal(p.inverse(x).cpu(), g.t('perm64/inv'))
+    assert torch.equal(p.inverse(p(x)), x)
+    xb = g.t('perm64/x_bf16_bits').to(DEV).view(torch.bfloat16)
+    assert torch.equal(p(xb).view(torch.int16).cpu(), g.t('perm64/fwd_bf16_bits'))
+    fl = st.Flip([-1])
+    assert torch.equal(fl(x).cpu(), g.t('flip/fwd'))
+    assert torch.equal(fl.inverse(x).cpu(), g.t('flip/inv'))
+    assert torch.equal(p.log_det_jacobian(x, x), torch.zeros(33, 1, device=DEV))
+    g8 = Golden('f8_suite')
+    for case in g8.cases('permute/') + g8.cases('flip/'):
+        f = product_transform(g8, case)
+        x = g8.t(case + '/x').to(DEV)
+        assert torch.equal(f(x).cpu(), g8.t(case + '/y'))
+        assert torch.equal(f.inverse(f(x)), x)
+
+
+def test_unit_normal_log_prob():
+    torch.manual_seed(0)
+    for shape in [(5, 64), (3, 7, 5), (1, 1), (1000, 128)]:
+        x = torch.randn(*shape)
+        got = st.UnitNormal(shape[-1]).to(DEV).log_prob(x.to(DEV))
+        close(got, orc.unit_normal_log_prob(x))
+
+
+def test_mlp_standalone_matches_oracle():
+    """net/mlp.py:65 through the fused MFMA kernel: 1 and 2 hidden layers, odd widths, every activation."""
+    torch.manual_seed(3)
+    for (i, hs, o, act) in [(64, [64], 128, 'Tanh'), (10, [13], 20, 'Tanh'), (5, [12, 7], 9, 'ReLU'),
+                            (32, [64, 64], 3008, 'Tanh'), (2, [64], 4, 'Sigmoid'), (3, [8], 5, 'ELU'),
+                            (3, [8], 5, 'Softplus'), (3, [8], 5, 'LeakyReLU'), (3, [8], 5, 'SiLU'), (3, [8], 5, 'GELU')]:
+        net = st.net.MLP(i, hs, o, activation=act)
+        x = torch.randn(77, i)
+        spec = {'weights': [w for (w, _) in net.linears()], 'biases': [b for (_, b) in net.linears()], 'activation': act}
+        with torch.no_grad():
+            want = orc.mlp_forward(spec, x)
+        got = net.to(DEV)(x.to(DEV))
+        close(got, want, rtol=1e-5, atol=2e-6)
+
+
+def test_elementwise_affine_kernel_against_oracle():
+    """sx_affine_coupling standalone (params in HBM): vector path, generic path, bf16, broadcast params."""
+    from stribor_amd.flows.affine import run_affine_kernel
+    torch.manual_seed(1)
+    for (n, d, l0, nl, bf) in [(1000, 64, 0, 32, False), (1000, 64, 32, 32, True), (33, 10, 5, 5, False),
+                               (257, 128, 64, 64, False), (5, 7, 0, 7, False)]:
+        x = torch.randn(n, d)
+        if bf:
+            x = x.bfloat16().float()
+        params = torch.randn(n, 2 * nl) * 0.5
+        ls, sh = params[:, :nl], params[:, nl:]
+        for reverse in (False, True):
+            want = x.clone()
+            want[:, l0:l0 + nl] = orc.affine_apply(x[:, l0:l0 + nl], ls, sh, reverse)
+            xin = x.to(DEV).bfloat16() if bf else x.to(DEV)
+            y, ldj = run_affine_kernel(xin, params.to(DEV), 2 * nl, None, l0, nl, reverse, True, True, -1.0)
+            if bf:
+                close(y.float(), want.bfloat16().float(), rtol=1e-2, atol=1e-2)
+            else:
+                close(y, want)
+            close(ldj, -ls.sum(-1), atol=2e-5)
+    # scattered live set -> generic kernel with live_idx
+    x = torch.randn(50, 10)
+    live = torch.tensor([1, 4, 6, 9], dtype=torch.int32)
+    params = torch.randn(50, 8) * 0.3
+    want = x.clone()
+    want[:, live.long()] = orc.affine_apply(x[:, live.long()], params[:, :4], params[:, 4:], False)
+    y, ldj = run_affine_kernel(x.to(DEV), params.to(DEV), 8, live.to(DEV), 0, 4, False, True, True)
+    close(y, want)
+    close(ldj, params[:, :4].sum(-1), atol=2e-5)
+
+
+def test_empty_and_ragged_batches():
+    g = Golden('f4_cfg2')
+    flow = product_flow(g, 'cfg2')
+    x = g.t('cfg2/x')
+    want = g.t('cfg2/log_prob')
+    assert flow.log_prob(x[:0].to(DEV)).shape == (0, 1)
+    for n in (1, 31, 33, 127, 129, 255):
+        close(flow.log_prob(x[:n].to(DEV)), want[:n])
+    # 3-D leading shape (test_coupling.py:7 uses (7, 4, 5))
+    close(flow.log_prob(x[:252].reshape(7, 36, 64).to(DEV)), want[:252].reshape(7, 36, 1))
+
+
+def test_log_prob_sum_is_sum_of_log_probs():
+    g = Golden('f4_cfg2')
+    flow = product_flow(g, 'cfg2')
+    x = g.t('cfg2/x').to(DEV)
+    s = flow.log_prob_sum(x)
+    assert s.dtype == torch.float64
+    want = g.t('cfg2/log_prob').double().sum()
+    assert abs(s.item() - want.item()) <= 1e-6 * abs(want.item())
+
+
+def test_full_size_properties():
+    """BASELINE cfg 2 at N = 2^20: inverse(forward(x)) == x, three-way log-det consistency, batch-split
+    invariance, agreement with the oracle on a slice."""
+    torch.manual_seed(0)
+    flow = fd.build_flow(st, fd.cfg2_desc(), 64).to(DEV)
+    n = 1 << 20
+    x = torch.randn(n, 64, device=DEV)
+    y, ldj_f = flow.forward_and_log_det_jacobian(x)
+    xb, ldj_i = flow.inverse_and_log_det_jacobian(y)
+    assert (xb - x).abs().max().item() < 1e-4                                  # base.py:8-11
+    assert (ldj_f + ldj_i).abs().max().item() < 1e-3                           # base.py:21-22
+    lp = flow.log_prob(x)
+    assert torch.isfinite(lp).all()
+    lp2 = torch.cat([flow.log_prob(x[:300_001]), flow.log_prob(x[300_001:])])
+    assert torch.equal(lp, lp2)                                                # rows are independent
+    spec = fd.flow_spec(fd.cfg2_desc(), {k: v.cpu() for k, v in flow.state_dict().items()})
+    sl = slice(777_000, 777_512)
+    close(lp[sl], orc.flow_log_prob(spec, x[sl].cpu()))
+    s = flow.log_prob_sum(x)
+    assert abs(s.item() - lp.double().sum().item()) <= 1e-9 * abs(s.item())

@@ -1,0 +1,153 @@
+"""CPU: host logic of the product — library ABI, constructor / state_dict surface, masks, planner."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import flowdesc as fd
+from goldens import Golden
+
+import stribor_amd as st
+from stribor_amd import _hip
+from stribor_amd.fused import ProgramBuilder
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads and exports every function include/stribor_hip.h declares."""
+    hdr = open(os.path.join(ROOT, 'include', 'stribor_hip.h')).read()
+    declared = set(re.findall(r'\b(sx_[a-z0-9_]+)\s*\(', hdr))
+    declared -= {'sx_step', 'sx_program'}
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert set(_hip.EXPORTS) == declared
+    assert _hip.lib().sx_abi_version() == 1
+    assert _hip.lib().sx_packed_linear_floats(2, 1) == _hip.packed_linear_floats(2, 1) == 2 * 1024 + 64
+
+
+def test_struct_layout_matches_header():
+    assert ctypes.sizeof(_hip.sx_step) == 48
+    assert ctypes.sizeof(_hip.sx_program) == 32 + 48 * _hip.SX_MAX_STEPS
+
+
+def test_no_cpu_fallback():
+    f = st.NormalizingFlow(st.UnitNormal(2), [st.Affine(2)])
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        f.log_prob(torch.randn(3, 2))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        st.Permute(4)(torch.randn(3, 4))
+
+
+def test_masks_exact():
+    """stribor/test/test_mask.py:4-30 + captured vectors."""
+    g = Golden('f2_masks')
+    for key in g.arrays:
+        name, d = key.split('/')
+        assert torch.equal(st.util.get_mask(name)(int(d)), g.t(key)), key
+    with pytest.raises(NotImplementedError):
+        st.util.get_mask('nope')
+    m = st.util.get_mask('random_half')(10)
+    assert m.sum() == 5 and set(m.tolist()) == {0.0, 1.0}
+
+
+@pytest.mark.parametrize('fixture,case', [('f3_cfg1', 'cfg1'), ('f4_cfg2', 'cfg2'), ('f7_permute', 'mixed')])
+def test_state_dict_keys_match_reference(fixture, case):
+    g = Golden(fixture)
+    m = g.meta[case]
+    flow = fd.build_flow(st, m['desc'], m['dim'])
+    ref_state = g.state(case)
+    assert set(flow.state_dict().keys()) == set(ref_state.keys())
+    for k, v in flow.state_dict().items():
+        assert tuple(v.shape) == tuple(ref_state[k].shape), k
+    flow.load_state_dict(ref_state)
+    # a checkpoint written by the reference has no permutation entry (quirk Q7): still loads
+    flow.load_state_dict({k: v for k, v in ref_state.items() if 'permutation' not in k})
+
+
+def test_constructor_surface():
+    """Signatures of SURVEY 8(b): keyword-only Affine args, Spline defaults, error types."""
+    with pytest.raises(TypeError):
+        st.Affine(2, st.net.MLP(2, [4], 4))                       # latent_net is keyword-only (affine.py:31-35)
+    with pytest.raises(ValueError):
+        st.Spline(2, 3, spline_type='linear')                     # spline.py:63
+    with pytest.raises(NotImplementedError):
+        st.Spline(2, 3)                                           # default 'cubic' is out of scope
+    with pytest.raises(AssertionError):
+        st.Affine(2, scale=torch.tensor([1.0, -1.0]), shift=torch.zeros(2))    # affine.py:55
+    mlp = st.net.MLP(3, [5, 7], 4)
+    assert list(mlp.state_dict().keys()) == ['net.0.weight', 'net.0.bias', 'net.2.weight', 'net.2.bias',
+                                             'net.4.weight', 'net.4.bias']
+    assert torch.all(mlp.net[4].bias == 0)                        # mlp.py:53
+    sp = st.Spline(4, 5, spline_type='quadratic')
+    assert set(sp.state_dict()) == {'width', 'height', 'derivative'} and sp.derivative.shape == (4, 4)
+
+
+def test_default_init_matches_reference_rng_stream():
+    """Same construction order under the same seed -> same weights as the reference (fixture F4)."""
+    g = Golden('f4_cfg2')
+    torch.manual_seed(g.meta['cfg2']['seed'])
+    flow = fd.build_flow(st, g.meta['cfg2']['desc'], 64)
+    for k, v in flow.state_dict().items():
+        assert torch.equal(v, g.t('cfg2/state/' + k)), k
+
+
+def test_planner_prunes_ordered_and_parity_masks():
+    def plan(masks, dim=64, hidden=64, perm_after=None):
+        torch.manual_seed(0)
+        layers = []
+        for i, mk in enumerate(masks):
+            layers.append(st.Coupling(st.Affine(dim, latent_net=st.net.MLP(dim, [hidden], 2 * dim)), mask=mk))
+            if perm_after is not None and i == perm_after:
+                layers.append(st.Permute(dim))
+        b = ProgramBuilder(dim, 0, hidden)
+        b.choose_layout(layers[0]._plan_first_mask(dim))
+        for f in layers:
+            assert f._plan(b, False, 1.0)
+        return b
+
+    b = plan(['ordered_right_half', 'ordered_left_half'] * 2)
+    assert [(s['c0'], s['ct'], s['t0'], s['tt']) for s in b.steps] == [(1, 1, 0, 1), (0, 1, 1, 1)] * 2
+    assert np.array_equal(b.col_of_slot, np.arange(64))            # identity layout -> vector loads
+    b = plan(['parity_even', 'parity_odd'])
+    assert [(s['ct'], s['tt']) for s in b.steps] == [(1, 1), (1, 1)]          # pruned via slot layout
+    assert sorted(b.col_of_slot[:32]) == list(range(1, 64, 2))
+    b = plan(['ordered_right_half', 'parity_even'])
+    assert [(s['ct'], s['tt']) for s in b.steps] == [(1, 1), (2, 2)]          # second one runs dense
+    b = plan(['ordered_right_half', 'ordered_left_half'], perm_after=0)
+    assert b.steps[1]['ct'] == 2                                               # random permutation -> dense
+    # blobs are 1 KiB aligned and large enough
+    for s in b.steps:
+        assert s['blob_off'] % 256 == 0 and s['blob_floats'] % 256 == 0
+
+
+def test_planner_permutation_relabelling_matches_gather():
+    """Folding Permute/Flip into slot labels == explicit gathers (permute.py:71,75), both directions."""
+    rng = np.random.default_rng(0)
+    for reverse in (False, True):
+        b = ProgramBuilder(10, 0, 32)
+        x = rng.standard_normal(10)
+        ref = x.copy()
+        for _ in range(3):
+            perm = rng.permutation(10)
+            inv = np.argsort(perm)
+            b.add_permutation(perm, reverse)
+            ref = ref[inv] if reverse else ref[perm]
+        state = np.zeros(32)
+        state[:10] = x                                   # slots never move
+        out = np.zeros(10)
+        for p, c in enumerate(b.col_of_slot):
+            if c >= 0:
+                out[c] = state[p]
+        assert np.array_equal(out, ref)
+
+
+def test_tile_limits_raise():
+    with pytest.raises(NotImplementedError):
+        ProgramBuilder(200, 0, 32)
+    with pytest.raises(NotImplementedError):
+        ProgramBuilder(64, 0, 300)
