@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Headline benchmark: NormalizingFlow.log_prob throughput, BASELINE.json cfg 2 (configs[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one synthetic batch per rank: log_prob of x[2^20, 64]
+(standard normal, stored bf16, resident in HBM) through 8 alternating affine couplings (H = 64) and the
+UnitNormal base density, summed to one fp64 on the device and, for N > 1, all-reduced over RCCL (the
+path's only exchange).  Weak scaling: every rank owns 2^20 rows (cfg 5 = 8 x 2^20).
+
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant (only) kernel of a step, the fused flow
+kernel, against the exact-fp32 MFMA peak; `roofline_elementwise` is the standalone HBM-bound affine
+coupling kernel (north_star: "achieved HBM GB/s on the element-wise path"); `cpu_baseline` is the oracle
+(a torch-CPU port that follows the reference op for op, incl. its double conditioner call) timed on this
+box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import torch
+import torch.distributed as dist
+
+import flowdesc as fd
+import stribor_amd as st
+from stribor_amd.sharded import ShardedLogProb
+
+DIM, LAYERS, HIDDEN = 64, 8, 64
+ROWS_PER_GPU = 1 << 20
+FLOPS_PER_ROW = LAYERS * 2 * (DIM // 2 * HIDDEN + HIDDEN * DIM)       # 98,304 (pruned)
+BYTES_PER_ROW = DIM * 2 + 4                                            # 132 B (bf16 x in, fp32 log_prob out)
+PEAK_F32_MFMA_TFLOPS = 157.3                                           # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+PEAK_HBM_GBS = 8000.0                                                  # MI355X_MICROARCH.md, HBM3E spec
+ELEMWISE_BYTES_PER_ROW = 128 + 256 + 128 + 8                           # 520 B/row/layer (bf16 x,y)
+
+
+def event_ms(fn, reps, inner=8):
+    """Average device time of one launch of `fn` by HIP events on the current stream: `reps` groups of
+    `inner` back-to-back launches, each group bracketed by two events (amortises the event overhead)."""
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    fn()
+    for a, b in evs:
+        a.record()
+        for _ in range(inner):
+            fn()
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) / inner for a, b in evs)
+    return sum(ts) / len(ts), ts[len(ts) // 2]
+
+
+def cpu_baseline(desc, state):
+    from oracle import stribor_oracle as orc
+    spec = fd.flow_spec(desc, state)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    gen = torch.Generator().manual_seed(1234)
+    with torch.no_grad():
+        x = torch.randn(1 << 16, DIM, generator=gen)
+        # torch's intra-op pool does not scale to hundreds of threads on [65536, 64] ops: probe a few
+        # thread counts and keep the fastest (that count is what `cores` reports)
+        best = None
+        for th in sorted({c for c in (8, 16, 32, 64, 128, avail) if c <= avail}):
+            torch.set_num_threads(th)
+            orc.flow_log_prob(spec, x[:4096])                          # warm-up
+            t0 = time.perf_counter()
+            orc.flow_log_prob(spec, x)
+            dt = time.perf_counter() - t0
+            if best is None or dt < best[1]:
+                best = (th, dt)
+            if dt > 8.0:
+                break
+        cores, probe = best
+        torch.set_num_threads(cores)
+        rows = 1 << 16
+        while rows < (1 << 21) and probe * (2 * rows / (1 << 16)) < 12.0:
+            rows *= 2
+        x = torch.randn(rows, DIM, generator=gen)
+        t0 = time.perf_counter()
+        orc.flow_log_prob(spec, x)
+        dt = time.perf_counter() - t0
+    return {'value': rows / dt, 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
+            'sample': f'oracle.flow_log_prob (torch CPU fp32, reference op sequence incl. double conditioner call) '
+                      f'on {rows} rows x {DIM}, 1 pass, {dt:.2f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    dev = torch.device('cuda', local_rank if world > 1 else 0)
+    assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+
+    torch.manual_seed(0)                                               # same weights on every rank
+    desc = fd.cfg2_desc(LAYERS, DIM, HIDDEN)
+    flow = fd.build_flow(st, desc, DIM)
+    state = {k: v.clone() for k, v in flow.state_dict().items()}
+    flow = flow.to(dev)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.randn(ROWS_PER_GPU, DIM, device=dev, generator=gen).bfloat16()   # resident before timing
+    sharded = ShardedLogProb(flow)
+    out = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    def step():
+        return sharded.log_prob_sum(x, out)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        total = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = t.item()
+    assert torch.isfinite(total).all()
+    total_value = total.item()
+
+    result = None
+    if rank == 0:
+        rows_total = ROWS_PER_GPU * world * args.steps
+        # dominant kernel: the fused flow kernel, one launch per step, timed alone by HIP events
+        k_avg_ms, k_med_ms = event_ms(lambda: flow.log_prob_sum(x, out), 10)
+        achieved_tflops = FLOPS_PER_ROW * ROWS_PER_GPU / (k_avg_ms * 1e-3) / 1e12
+        # standalone element-wise affine coupling kernel (params precomputed in HBM), HBM roofline
+        from stribor_amd.flows.affine import run_affine_kernel
+        params = torch.randn(ROWS_PER_GPU, DIM, device=dev) * 0.1
+        e_avg_ms, _ = event_ms(lambda: run_affine_kernel(x, params, DIM, None, 0, DIM // 2, True, True, True, -1.0), 10)
+        e_gbs = ELEMWISE_BYTES_PER_ROW * ROWS_PER_GPU / (e_avg_ms * 1e-3) / 1e9
+        result = {
+            'metric': 'log_prob samples/sec, D=64 8-layer affine-coupling',
+            'value': rows_total / elapsed,
+            'unit': 'samples/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': 'cfg2: D=64, 8 alternating st.Affine coupling layers (MLP hidden 64, Tanh), '
+                                   'batch 2^20 per GPU, x stored bf16, fp32 arithmetic, UnitNormal base, fp64 batch sum',
+                       'rows_per_gpu': ROWS_PER_GPU, 'dim': DIM, 'layers': LAYERS, 'hidden': HIDDEN,
+                       'x_storage': 'bf16', 'parallelism': f'batch-sharded x{world}, one 8-byte all-reduce per step'},
+            'roofline': {'kernel': 'flow_fused_kernel<2,2,0>', 'bound': 'mfma', 'achieved': achieved_tflops,
+                         'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved_tflops / PEAK_F32_MFMA_TFLOPS,
+                         'traffic': None, 'avg_kernel_ms': k_avg_ms, 'median_kernel_ms': k_med_ms,
+                         'algorithmic_flops_per_launch': FLOPS_PER_ROW * ROWS_PER_GPU,
+                         'algorithmic_bytes_per_launch': BYTES_PER_ROW * ROWS_PER_GPU,
+                         'hbm_frac_of_same_kernel': BYTES_PER_ROW * ROWS_PER_GPU / (k_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+            'roofline_elementwise': {'kernel': 'affine_coupling_vec4_kernel<bf16,reverse>', 'bound': 'hbm',
+                                     'achieved': e_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': e_gbs / PEAK_HBM_GBS,
+                                     'traffic': None, 'avg_kernel_ms': e_avg_ms,
+                                     'algorithmic_bytes_per_launch': ELEMWISE_BYTES_PER_ROW * ROWS_PER_GPU},
+            'log_prob_sum': total_value,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline(desc, state)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == '__main__':
+    main()

@@ -65,7 +65,7 @@ class Affine(ElementwiseTransform):
         p = self.latent_net(latent.reshape(-1, latent.shape[-1]))            # affine.py:66
         return p, p.stride(0)
 
-    def _apply(self, x, latent, reverse, want_y, want_ldj, ldj_scale=1.0):
+    def _launch(self, x, latent, reverse, want_y, want_ldj, ldj_scale=1.0):
         _hip.require_device(x, 'x')
         x2, lead = flatten_rows(x)
         d = x2.shape[1]
@@ -75,19 +75,19 @@ class Affine(ElementwiseTransform):
 
     # ---- reference method set (affine.py:69-123) ---------------------------------------------------------
     def forward(self, x, latent=None, **kwargs):
-        return self._apply(x, latent, False, True, False)[0]
+        return self._launch(x, latent, False, True, False)[0]
 
     def inverse(self, y, latent=None, **kwargs):
-        return self._apply(y, latent, True, True, False)[0]
+        return self._launch(y, latent, True, True, False)[0]
 
     def log_det_jacobian(self, x, y=None, latent=None, **kwargs):
-        return self._apply(x, latent, False, False, True)[1]
+        return self._launch(x, latent, False, False, True)[1]
 
     def forward_and_log_det_jacobian(self, x, latent=None, *, reverse: bool = False, **kwargs):
-        return self._apply(x, latent, reverse, True, True)                    # affine.py:97-109
+        return self._launch(x, latent, reverse, True, True)                    # affine.py:97-109
 
     def inverse_and_log_det_jacobian(self, y, latent=None, **kwargs):
-        return self._apply(y, latent, True, True, True, ldj_scale=-1.0)      # affine.py:111-113
+        return self._launch(y, latent, True, True, True, ldj_scale=-1.0)      # affine.py:111-113
 
     def log_diag_jacobian(self, x, y=None, latent=None, **kwargs):
         x2, lead = flatten_rows(x)

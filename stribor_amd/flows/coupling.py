@@ -103,6 +103,8 @@ class Coupling(Transform):
         from .spline import run_rqs_kernel
         sp = self.transform
         n, d = x2.shape
+        if not (self.mask_vector(d) <= 0.5).any():      # dim == 1: mask = [1], nothing is transformed (mask.py:37-38)
+            return x2.clone(), (torch.zeros(n, dtype=torch.float32, device=x2.device) if want_ldj else None)
         progs, live_idx, live_start, n_live, width = self._spline_program(d, 0 if lat2 is None else lat2.shape[1],
                                                                           x2.device)
         params = torch.empty(n, width, dtype=torch.float32, device=x2.device)

@@ -95,7 +95,7 @@ class Spline(ElementwiseTransform):
     def _bounds(self):
         return self.lower, self.upper, self.lower, self.upper                        # left, right, bottom, top
 
-    def _apply(self, x, latent, reverse, want_ldj, want_ldiag, ldj_scale=1.0):
+    def _launch(self, x, latent, reverse, want_ldj, want_ldiag, ldj_scale=1.0):
         _hip.require_device(x, 'x')
         x2, lead = flatten_rows(x)
         d = x2.shape[1]
@@ -108,30 +108,30 @@ class Spline(ElementwiseTransform):
 
     # ---- reference method set (spline.py:89-143) ----------------------------------------------------------
     def forward(self, x, latent=None, **kwargs):
-        return self._apply(x, latent, False, False, False)[0]
+        return self._launch(x, latent, False, False, False)[0]
 
     def inverse(self, y, latent=None, **kwargs):
-        return self._apply(y, latent, True, False, False)[0]
+        return self._launch(y, latent, True, False, False)[0]
 
     def forward_and_log_diag_jacobian(self, x, latent=None, *, reverse=False, **kwargs):
-        y, _, ld = self._apply(x, latent, reverse, False, True)
+        y, _, ld = self._launch(x, latent, reverse, False, True)
         return y, ld
 
     def inverse_and_log_diag_jacobian(self, y, latent=None, **kwargs):
         # the inverse spline already returns the negated value (rational_quadratic_spline.py:234): no extra sign
-        x, _, ld = self._apply(y, latent, True, False, True)
+        x, _, ld = self._launch(y, latent, True, False, True)
         return x, ld
 
     def forward_and_log_det_jacobian(self, x, latent=None, **kwargs):
-        y, ldj, _ = self._apply(x, latent, False, True, False)
+        y, ldj, _ = self._launch(x, latent, False, True, False)
         return y, ldj
 
     def inverse_and_log_det_jacobian(self, y, latent=None, **kwargs):
-        x, ldj, _ = self._apply(y, latent, True, True, False)
+        x, ldj, _ = self._launch(y, latent, True, True, False)
         return x, ldj
 
     def log_det_jacobian(self, x, y=None, latent=None, **kwargs):
-        return self._apply(x, latent, False, True, False)[1]
+        return self._launch(x, latent, False, True, False)[1]
 
     def log_diag_jacobian(self, x, y=None, latent=None, **kwargs):
-        return self._apply(x, latent, False, False, True)[2]
+        return self._launch(x, latent, False, False, True)[2]

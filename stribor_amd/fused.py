@@ -129,6 +129,10 @@ class CompiledProgram:
             x = x.contiguous()
         self.refresh()
         n = x.shape[0]
+        if n == 0:        # empty batch: nothing to launch (the reference returns empty tensors too)
+            e = lambda *shape, dt=torch.float32: torch.empty(*shape, dtype=dt, device=x.device)
+            return (e(0, x.shape[1], dt=x.dtype) if want_y else None, e(0) if want_ldj else None,
+                    e(0) if want_logp else None)
         y = torch.empty_like(x) if want_y else None
         ldj = torch.empty(n, dtype=torch.float32, device=x.device) if want_ldj else None
         logp = torch.empty(n, dtype=torch.float32, device=x.device) if want_logp else None

@@ -234,3 +234,114 @@ def test_full_size_properties():
     close(lp[sl], orc.flow_log_prob(spec, x[sl].cpu()))
     s = flow.log_prob_sum(x)
     assert abs(s.item() - lp.double().sum().item()) <= 1e-9 * abs(s.item())
+
+
+# ------------------------------------------------------------------------------------------------
+# rational-quadratic spline
+# ------------------------------------------------------------------------------------------------
+def test_suite_shapes_rqs_and_coupling_rqs():
+    """stribor/test/test_spline.py:8-33 (quadratic rows: n_bins 1/3/10, latent 0/1/13, box [0,2]) plus the
+    same protocol through Coupling."""
+    g = Golden('f8_suite')
+    n = 0
+    for case in g.cases('rqs/') + g.cases('coupling_rqs/'):
+        f = product_transform(g, case)
+        x = g.t(case + '/x').to(DEV)
+        kw = {'latent': g.t(case + '/latent').to(DEV)} if g.has(case + '/latent') else {}
+        y = f(x, **kw)
+        close(y, g.t(case + '/y'))
+        close(f.inverse(y, **kw), g.t(case + '/x'), atol=1e-4)                 # base.py:8-11
+        ldj = f.log_det_jacobian(x, y, **kw)
+        close(ldj, g.t(case + '/ldj'), atol=1e-4)                              # the suite's own atol (base.py:22)
+        _, l1 = f.forward_and_log_det_jacobian(x, **kw)
+        _, l2 = f.inverse_and_log_det_jacobian(y, **kw)
+        close(l1, g.t(case + '/ldj'), atol=1e-4)
+        close(-l2, g.t(case + '/ldj'), atol=1e-4)                              # base.py:14-22
+        close(ldj.reshape(-1), g.t(case + '/autograd_logdet'), atol=1e-4)      # base.py:35-44
+        if g.has(case + '/ldiag'):
+            close(f.log_diag_jacobian(x, y, **kw), g.t(case + '/ldiag'), atol=1e-4)
+        n += 1
+    assert n == 4 * 9 + 4 * 3
+    from stribor_amd.flows.spline import check_errors
+    check_errors()
+
+
+def test_cfg3_spline_flow_against_golden():
+    """2 RQ-spline couplings at the cfg-3 widths (D=64, K=16, H=64, box [-3,3]) incl. rows in the tails,
+    exactly on the bounds and on a grid through the knots (fixture F5)."""
+    g = Golden('f5_cfg3')
+    flow = product_flow(g, 'cfg3')
+    x = g.t('cfg3/x').to(DEV)
+    cur = x
+    for i in reversed(range(len(flow.transforms))):
+        nxt, ldj = flow.transforms[i].inverse_and_log_det_jacobian(cur)
+        close(nxt, g.t(f'cfg3/inv_x.{i}'))
+        close(ldj, g.t(f'cfg3/inv_ldj.{i}'), rtol=1e-5, atol=1e-4)
+        cur = nxt
+    close(flow.log_prob(x), g.t('cfg3/log_prob'), rtol=1e-5, atol=1e-4)
+    close(flow.forward(x), g.t('cfg3/forward'))
+    close(flow.inverse(x), g.t('cfg3/inverse'))
+    y, ldf = flow.forward_and_log_det_jacobian(x)
+    close(ldf, g.t('cfg3/forward_ldj'), rtol=1e-5, atol=1e-4)
+    close(flow.log_prob(x).double(), g.t('cfg3/log_prob_f64'), rtol=1e-5, atol=1e-4)
+
+
+def test_rqs_kernel_against_oracle_random_params():
+    """sx_rqs_coupling standalone: random parameters, both directions, asymmetric box (test_spline.py:36-52),
+    bf16 storage, scattered live columns, K from 1 to 32."""
+    from stribor_amd.flows.spline import run_rqs_kernel
+    torch.manual_seed(5)
+    for (n, d, K, box) in [(300, 8, 5, (-1.0, 1.0, -3.0, 2.0)), (64, 64, 16, (-3.0, 3.0, -3.0, 3.0)),
+                           (17, 3, 1, (0.0, 2.0, 0.0, 2.0)), (50, 6, 32, (-2.0, 2.0, -2.0, 2.0))]:
+        left, right, bottom, top = box
+        P = 3 * K - 1
+        params = torch.randn(n, d * P)
+        pv = params.view(n, d, P)
+        uw, uh, ud = pv[..., :K], pv[..., K:2 * K], pv[..., 2 * K:]
+        x = torch.rand(n, d) * (right - left) * 1.2 + left - 0.1 * (right - left)      # some rows in the tails
+        yo, lo = orc.rqs_unconstrained(x, uw, uh, ud, False, None, None, left, right, bottom, top)
+        y64, l64 = orc.rqs_unconstrained(x.double(), uw.double(), uh.double(), ud.double(), False, None, None,
+                                         left, right, bottom, top)
+        y, ldj, ldiag = run_rqs_kernel(x.to(DEV), params.to(DEV), d * P, None, 0, d, K, left, right, bottom, top,
+                                       False, True, True)
+        close(y, yo)
+        # The log-derivative divides by a bin width that the reference forms as a DIFFERENCE of two cumsum
+        # knots (rational_quadratic_spline.py:185,192): for narrow bins that cancellation amplifies fp32
+        # rounding to ~1e-4, in the reference as much as here.  Bar: 2e-4 against the reference's fp32 values
+        # AND no further from the fp64 truth than the reference's own fp32 path (x2 + 1e-5).
+        close(ldiag, lo, atol=2e-4)
+        ref_err = (lo.double() - l64).abs().max().item()
+        our_err = (ldiag.cpu().double() - l64).abs().max().item()
+        assert our_err <= 2 * ref_err + 1e-5, (our_err, ref_err)
+        close(ldj, lo.sum(-1), atol=5e-4)
+        xi = torch.rand(n, d) * (top - bottom) * 1.2 + bottom - 0.1 * (top - bottom)
+        xo, li = orc.rqs_unconstrained(xi, uw, uh, ud, True, None, None, left, right, bottom, top)
+        xg, ldj_i, ldiag_i = run_rqs_kernel(xi.to(DEV), params.to(DEV), d * P, None, 0, d, K, left, right, bottom,
+                                            top, True, True, True)
+        x64, li64 = orc.rqs_unconstrained(xi.double(), uw.double(), uh.double(), ud.double(), True, None, None,
+                                          left, right, bottom, top)
+        close(xg, xo, atol=3e-4)                       # quadratic-root cancellation, same conditioning argument
+        assert (xg.cpu().double() - x64).abs().max().item() <= 2 * (xo.double() - x64).abs().max().item() + 1e-5
+        close(ldiag_i, li, atol=5e-4)
+        assert (ldiag_i.cpu().double() - li64).abs().max().item() <= 2 * (li.double() - li64).abs().max().item() + 1e-5
+    # scattered live columns + pass-through copy
+    n, d, K = 40, 10, 4
+    P = 3 * K - 1
+    live = torch.tensor([0, 3, 4, 9], dtype=torch.int32)
+    params = torch.randn(n, 4 * P)
+    x = torch.rand(n, d) * 2 - 1
+    pv = params.view(n, 4, P)
+    yo, lo = orc.rqs_unconstrained(x[:, live.long()], pv[..., :K], pv[..., K:2 * K], pv[..., 2 * K:], False, -1., 1.)
+    want = x.clone()
+    want[:, live.long()] = yo
+    y, ldj, ldiag = run_rqs_kernel(x.to(DEV), params.to(DEV), 4 * P, live.to(DEV), 0, 4, K, -1, 1, -1, 1, False, True, True)
+    close(y, want)
+    close(ldj, lo.sum(-1), atol=3e-4)
+    wd = torch.zeros(n, d)
+    wd[:, live.long()] = lo
+    close(ldiag, wd, atol=2e-4)
+
+
+def test_spline_error_behaviour():
+    with pytest.raises(ValueError, match='Minimal bin width too large'):       # rational_quadratic_spline.py:96-97
+        st.Spline(2, 1001, spline_type='quadratic').to(DEV)(torch.rand(3, 2, device=DEV))
