@@ -127,12 +127,14 @@ int sx_pack_linear(const float *W, const float *b, int32_t out_dim, int32_t in_d
  * columns (tile t = state slots 32t..32t+31); slots map to columns of x through in_col/out_col. */
 #define SX_STEP_COUPLING_AFFINE 1  /* blob = pack_linear(W1) ++ pack_linear(W2 rows [ls(t0..), sh(t0..)] per tile) */
 #define SX_STEP_AFFINE_CONST    2  /* blob = ls[tiles][2][16] ++ sh[tiles][2][16] (C-fragment order)            */
-#define SX_STEP_LINEAR_TILE     3  /* blob = pack_linear(M, 1 m-tile): new tile `t0` = M[t0] . state + bias      */
-#define SX_STEP_LINEAR_COMMIT   4  /* state = new tiles                                                            */
+#define SX_STEP_LINEAR_TILE     3  /* blob = pack_linear(M, 1 m-tile): new tile `t0` = M[t0] . state + bias; tt != 0 on
+                                      the last slab commits the new tiles as the state                                */
+#define SX_STEP_LINEAR_COMMIT   4  /* (unused: the commit rides on the last LINEAR_TILE)                             */
 #define SX_STEP_MLP_HIDDEN      5  /* blob = pack_linear(W): hidden = act(W . state[c0..c0+ct) + b)               */
 #define SX_STEP_MLP_HIDDEN2     6  /* blob = pack_linear(W): hidden' = act(W . hidden + b)                         */
 #define SX_STEP_MLP_OUT_TILE    7  /* blob = pack_linear(W, 1 m-tile): out[:, 32*t0 ..] = W[t0] . hidden + b       */
 #define SX_STEP_COUPLING_RQS    8  /* reserved */
+#define SX_STEP_ROW_SCALE_EXP    9  /* blob = diag[tiles][2][16]: state *= exp(+-diag * t_row); t_row = row_t[n] or ldj_const */
 
 #define SX_MAX_STEPS 96
 
@@ -174,12 +176,14 @@ typedef struct sx_program {
  *   ldj_out  [n_rows] accumulated log-det terms, or NULL
  *   logp_out [n_rows] UnitNormal.log_prob(final state) + accumulated log-det terms, or NULL
  *   sum_out  one fp64: += sum_n logp_out[n] (or of ldj when logp_out is NULL); NULL to skip
+ *   row_t    [n_rows] per-sample time of SX_STEP_ROW_SCALE_EXP steps (MatrixExponential with a tensor t,
+ *            stribor/flows/affine.py:236-241), or NULL to use the step's constant
  *   mlp_out  [n_rows, mlp_out_dim] (row stride mlp_out_stride) destination of SX_STEP_MLP_OUT_TILE
  *            steps, or NULL                                                                   */
 int sx_flow_run(const sx_program *prog_host, const float *blobs, const void *x, const float *latent,
                 const int32_t *in_col, const int32_t *out_col, void *y, float *ldj_out,
                 float *logp_out, double *sum_out, float *mlp_out, int64_t mlp_out_stride,
-                int32_t mlp_out_dim, int64_t n_rows, int32_t dtype, void *stream);
+                int32_t mlp_out_dim, const float *row_t, int64_t n_rows, int32_t dtype, void *stream);
 
 /* LDS bytes and grid the launcher will use for a program (introspection for tests/bench). */
 int sx_flow_launch_info(const sx_program *prog_host, int64_t n_rows, int32_t *grid, int32_t *block,

@@ -26,6 +26,7 @@ STEP_MLP_HIDDEN = 5
 STEP_MLP_HIDDEN2 = 6
 STEP_MLP_OUT_TILE = 7
 STEP_COUPLING_RQS = 8
+STEP_ROW_SCALE_EXP = 9
 
 ACT_CODES = {'Identity': 0, 'Tanh': 1, 'ReLU': 2, 'Sigmoid': 3, 'ELU': 4, 'Softplus': 5, 'LeakyReLU': 6,
              'SiLU': 7, 'GELU': 8}
@@ -77,7 +78,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.sx_pack_linear.restype = i32
     lib.sx_pack_linear.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp]
     lib.sx_flow_run.restype = i32
-    lib.sx_flow_run.argtypes = [C.POINTER(sx_program), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i64, i32, vp]
+    lib.sx_flow_run.argtypes = [C.POINTER(sx_program), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, i64, i32, vp]
     lib.sx_flow_launch_info.restype = i32
     lib.sx_flow_launch_info.argtypes = [C.POINTER(sx_program), i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
 

@@ -6,7 +6,7 @@
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, bool *mlp_mode) {
+static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, int *mlp_mode) {
     SX_REQUIRE(p != nullptr, "sx_flow_run: null program");
     SX_REQUIRE(p->n_steps >= 0 && p->n_steps <= SX_MAX_STEPS, "sx_flow_run: n_steps %d out of range", p->n_steps);
     SX_REQUIRE(p->tiles == 1 || p->tiles == 2 || p->tiles == 4, "sx_flow_run: tiles must be 1, 2 or 4 (got %d)", p->tiles);
@@ -18,7 +18,8 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     d->n_steps = p->n_steps; d->dim = p->dim; d->latent_dim = p->latent_dim; d->x_tiles = p->x_tiles;
     d->identity_cols = p->identity_cols; d->pad = 0;
     int mx = 256;
-    *mlp_mode = false;
+    bool lin = false;
+    *mlp_mode = 0;
     for (int i = 0; i < p->n_steps; ++i) {
         const sx_step &s = p->steps[i];
         SX_REQUIRE(s.blob_off % 256 == 0 && s.blob_floats % 256 == 0, "sx_flow_run: step %d blob not 1 KiB aligned", i);
@@ -37,9 +38,13 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
             case SX_STEP_AFFINE_CONST: need = 2 * 32 * p->tiles; break;
             case SX_STEP_MLP_HIDDEN:
                 SX_REQUIRE(s.c0 == 0 && s.ct == p->tiles, "sx_flow_run: MLP_HIDDEN must read all tiles");
-                need = sx_packed_linear_floats(p->h_tiles, p->tiles); *mlp_mode = true; break;
-            case SX_STEP_MLP_HIDDEN2: need = sx_packed_linear_floats(p->h_tiles, p->h_tiles); *mlp_mode = true; break;
-            case SX_STEP_MLP_OUT_TILE: need = sx_packed_linear_floats(1, p->h_tiles); *mlp_mode = true; break;
+                need = sx_packed_linear_floats(p->h_tiles, p->tiles); *mlp_mode = 1; break;
+            case SX_STEP_MLP_HIDDEN2: need = sx_packed_linear_floats(p->h_tiles, p->h_tiles); *mlp_mode = 1; break;
+            case SX_STEP_MLP_OUT_TILE: need = sx_packed_linear_floats(1, p->h_tiles); *mlp_mode = 1; break;
+            case SX_STEP_LINEAR_TILE:
+                SX_REQUIRE(s.t0 < p->x_tiles, "sx_flow_run: step %d: linear slab %d out of range", i, s.t0);
+                need = sx_packed_linear_floats(1, p->tiles); lin = true; break;
+            case SX_STEP_ROW_SCALE_EXP: need = 32 * p->tiles; lin = true; break;
             default: sx_set_error("sx_flow_run: step %d has unsupported kind %d", i, s.kind); return SX_E_UNSUPPORTED;
         }
         SX_REQUIRE(s.blob_floats >= need, "sx_flow_run: step %d blob too small (%u < %zu floats)", i, s.blob_floats, need);
@@ -50,6 +55,8 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
         o.blob_off = s.blob_off; o.blob_floats = s.blob_floats; o.ldj_scale = s.ldj_scale; o.ldj_const = s.ldj_const;
     }
     *buf_floats = mx;
+    SX_REQUIRE(!(lin && *mlp_mode), "sx_flow_run: linear steps cannot be mixed with MLP-output steps");
+    if (lin) *mlp_mode = 2;
     SX_REQUIRE((size_t)mx * 8 <= 160 * 1024, "sx_flow_run: a step needs %d B of LDS per buffer (> 80 KiB)", mx * 4);
     return SX_OK;
 }
@@ -67,7 +74,7 @@ static int pick_grid(int64_t n_rows, int lds_bytes) {
 
 extern "C" int sx_flow_launch_info(const sx_program *prog_host, int64_t n_rows, int32_t *grid, int32_t *block,
                                    int32_t *lds_bytes) {
-    dprog d; int bf; bool mm;
+    dprog d; int bf; int mm;
     int rc = validate_and_convert(prog_host, &d, &bf, &mm);
     if (rc) return rc;
     if (lds_bytes) *lds_bytes = bf * 8;
@@ -80,8 +87,8 @@ extern "C" int sx_flow_launch_info(const sx_program *prog_host, int64_t n_rows, 
 extern "C" int sx_flow_run(const sx_program *prog_host, const float *blobs, const void *x, const float *latent,
                            const int32_t *in_col, const int32_t *out_col, void *y, float *ldj_out, float *logp_out,
                            double *sum_out, float *mlp_out, int64_t mlp_out_stride, int32_t mlp_out_dim,
-                           int64_t n_rows, int32_t dtype, void *stream) {
-    dprog d; int bf; bool mlp_mode;
+                           const float *row_t, int64_t n_rows, int32_t dtype, void *stream) {
+    dprog d; int bf; int mlp_mode;
     int rc = validate_and_convert(prog_host, &d, &bf, &mlp_mode);
     if (rc) return rc;
     SX_REQUIRE(x != nullptr && n_rows >= 0, "sx_flow_run: bad x / n_rows");
@@ -90,7 +97,7 @@ extern "C" int sx_flow_run(const sx_program *prog_host, const float *blobs, cons
     SX_REQUIRE(prog_host->identity_cols || (in_col != nullptr && (y == nullptr || out_col != nullptr)),
                "sx_flow_run: in_col/out_col required when identity_cols == 0");
     SX_REQUIRE(prog_host->latent_dim == 0 || latent != nullptr, "sx_flow_run: latent_dim > 0 but latent is NULL");
-    SX_REQUIRE(!mlp_mode || (mlp_out != nullptr && mlp_out_dim > 0), "sx_flow_run: MLP steps need mlp_out");
+    SX_REQUIRE(mlp_mode != 1 || (mlp_out != nullptr && mlp_out_dim > 0), "sx_flow_run: MLP steps need mlp_out");
     SX_REQUIRE(!prog_host->identity_cols || ((uintptr_t)x & 15) == 0, "sx_flow_run: x must be 16-byte aligned");
     if (n_rows == 0) return SX_OK;
     sx_flow_args a;
@@ -99,6 +106,7 @@ extern "C" int sx_flow_run(const sx_program *prog_host, const float *blobs, cons
     a.mlp_out_stride = mlp_out_stride; a.mlp_out_dim = mlp_out_dim; a.n_rows = n_rows; a.buf_floats = bf;
     a.bf16 = dtype == SX_BF16; a.mlp_mode = mlp_mode; a.lds = bf * 8; a.grid = pick_grid(n_rows, a.lds);
     a.stream = sx_stream(stream);
+    a.row_t = row_t;
     const int T = prog_host->tiles, H = prog_host->h_tiles;
 #define SX_GO(TT, HH) if (T == TT && H == HH) return sx_flow_launch_t##TT##h##HH(a)
     SX_GO(1, 1); SX_GO(1, 2); SX_GO(1, 4); SX_GO(2, 1); SX_GO(2, 2); SX_GO(2, 4); SX_GO(4, 1); SX_GO(4, 2); SX_GO(4, 4);

@@ -174,14 +174,15 @@ __device__ __forceinline__ void st_elem(void *p, int64_t off, float v, int bf16)
     else reinterpret_cast<float *>(p)[off] = v;
 }
 
-// MODE 0: flow programs (coupling / affine-const steps); MODE 1: + persistent hidden state (MLP programs)
+// MODE 0: flow programs (coupling / affine-const steps); MODE 1: + persistent hidden state (MLP programs);
+// MODE 2: flow programs with dense linear layers (AffineLU / MatrixExponential): + a second state tile set
 template <int TX, int HT, int MODE>
 __global__ __launch_bounds__(256, 2) void flow_fused_kernel(
     const dprog prog, const float *__restrict__ blobs, const void *__restrict__ x,
     const float *__restrict__ latent, const int32_t *__restrict__ in_col, const int32_t *__restrict__ out_col,
     void *__restrict__ y, float *__restrict__ ldj_out, float *__restrict__ logp_out, double *__restrict__ sum_out,
     float *__restrict__ mlp_out, int64_t mlp_out_stride, int mlp_out_dim, int64_t n_rows, int buf_floats,
-    int bf16) {
+    int bf16, const float *__restrict__ row_t) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int dim = prog.dim, x_tiles = prog.x_tiles, n_steps = prog.n_steps;
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(256, 2) void flow_fused_kernel(
         float ldj = 0.f;
         float ldj_c = 0.f;
         f32x16 hid[MODE == 1 ? HT : 1];
+        f32x16 xnew[MODE == 2 ? TX : 1];
 
         for (int s = 0; s < n_steps; ++s) {
             // (1) this step's weights were issued one step ago (or in the prologue): wait for MY pieces, then
@@ -309,9 +311,47 @@ __global__ __launch_bounds__(256, 2) void flow_fused_kernel(
                         }
                     }
                     break;
+                case SX_STEP_LINEAR_TILE:
+                    // one 32-row slab of y = M . x + b (AffineLU affine.py:157,159-163; MatrixExponential
+                    // affine.py:243-270 with the triangular solves folded into M on the host, in fp64)
+                    if constexpr (MODE == 2) {
+                        f32x16 acc = load_cfrag(base + TX * 1024, h);
+#pragma unroll
+                        for (int c = 0; c < TX; ++c) acc = gemm_tile(base + c * 1024, xs[c], acc, lane);
+#pragma unroll
+                        for (int t = 0; t < TX; ++t)
+                            if (t == st.t0) xnew[t] = acc;
+                        if (st.tt) {   // last slab: commit
+#pragma unroll
+                            for (int t = 0; t < TX; ++t)
+                                if (t < x_tiles) xs[t] = xnew[t];
+                        }
+                    }
+                    break;
+                case SX_STEP_ROW_SCALE_EXP:
+                    // x *= exp(+-diag * t_row)  (affine.py:263), t_row optionally log1p|t| (affine.py:239-240)
+                    if constexpr (MODE == 2) {
+                        float tr = row_t != nullptr ? row_t[lrow] : st.ldj_const;
+                        if (st.act) tr = log1pf(fabsf(tr));
+                        const float sg = st.reverse ? -tr : tr;
+                        float sd = 0.f;
+#pragma unroll
+                        for (int t = 0; t < TX; ++t) {
+                            if (t < x_tiles) {
+                                const f32x16 dg = load_cfrag(base + t * 32, h);
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    xs[t][r] *= fast_exp(dg[r] * sg);
+                                    sd += dg[r];
+                                }
+                            }
+                        }
+                        ldj += st.ldj_scale * sd * tr;
+                    }
+                    break;
                 default: break;
             }
-            ldj_c += st.ldj_const;
+            if (st.kind != SX_STEP_ROW_SCALE_EXP) ldj_c += st.ldj_const;
             cur ^= 1;
         }
 
@@ -390,9 +430,9 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
         }                                                                                                      \
         hipLaunchKernelGGL(k, dim3(a.grid), dim3(256), a.lds, a.stream, a.prog, a.blobs, a.x, a.latent, a.in_col, \
                            a.out_col, a.y, a.ldj_out, a.logp_out, a.sum_out, a.mlp_out, a.mlp_out_stride,      \
-                           a.mlp_out_dim, a.n_rows, a.buf_floats, a.bf16);                                     \
+                           a.mlp_out_dim, a.n_rows, a.buf_floats, a.bf16, a.row_t);                                     \
     } while (0)
-    if (a.mlp_mode) SX_FL(1); else SX_FL(0);
+    if (a.mlp_mode == 1) SX_FL(1); else if (a.mlp_mode == 2) SX_FL(2); else SX_FL(0);
 #undef SX_FL
     SX_LAUNCH_CHECK();
     return SX_OK;

@@ -90,17 +90,18 @@ class NormalizingFlow(Transform):
         self._fused = {}
 
     # ---- fused program cache -----------------------------------------------------------------------------
-    def _fused_program(self, reverse: bool, dim: int, latent_dim: int, device) -> Optional[CompiledProgram]:
-        key = (reverse, dim, latent_dim, str(device))
+    def _fused_program(self, reverse: bool, dim: int, latent_dim: int, device, t_kind=None) -> Optional[CompiledProgram]:
+        key = (reverse, dim, latent_dim, str(device), t_kind)
         if key not in self._fused:
-            self._fused[key] = self._build_fused(reverse, dim, latent_dim, device)
+            self._fused[key] = self._build_fused(reverse, dim, latent_dim, device, t_kind)
         return self._fused[key]
 
-    def _build_fused(self, reverse, dim, latent_dim, device) -> Optional[CompiledProgram]:
+    def _build_fused(self, reverse, dim, latent_dim, device, t_kind=None) -> Optional[CompiledProgram]:
         order = list(reversed(self.transforms)) if reverse else list(self.transforms)
         try:
             hw = max([f._plan_hidden_width() for f in order] + [1])
             b = ProgramBuilder(dim, latent_dim, hw)
+            b.t = t_kind                      # None | float | 'tensor' (MatrixExponential's time)
             for f in order:
                 m = f._plan_first_mask(dim)
                 if m is not None:
@@ -119,16 +120,19 @@ class NormalizingFlow(Transform):
         """Returns (y, ldj[..., 1], logp[..., 1]) (None where not requested) via the fused kernel, or None
         when the flow cannot be fused."""
         _hip.require_device(x, 'x')
-        if kwargs:          # e.g. t= for MatrixExponential: per-layer path
+        t = kwargs.pop('t', None)
+        if kwargs:          # unknown keyword: let the per-layer path hand it to every transform
             return None
+        t_kind = 'tensor' if torch.is_tensor(t) else (None if t is None else float(t))
         x2, lead = flatten_rows(x)
         lat2 = None
         if latent is not None:
             lat2 = latent.reshape(-1, latent.shape[-1])
-        prog = self._fused_program(reverse, x2.shape[1], 0 if lat2 is None else lat2.shape[1], x.device)
+        prog = self._fused_program(reverse, x2.shape[1], 0 if lat2 is None else lat2.shape[1], x.device, t_kind)
         if prog is None:
             return None
-        y, ldj, logp = prog.run(x2, lat2, want_y, want_ldj, want_logp, sum_out)
+        y, ldj, logp = prog.run(x2, lat2, want_y, want_ldj, want_logp, sum_out,
+                                row_t=t.reshape(-1) if t_kind == 'tensor' else None)
         shp = lambda t, d: None if t is None else t.reshape(*lead, d)
         return shp(y, x2.shape[1]), shp(ldj, 1), shp(logp, 1)
 

@@ -1,22 +1,196 @@
-"""AffineLU / MatrixExponential — filled in by the linear-layer milestone."""
-from ..flow import Transform
+"""Dense invertible linear layers (reference: stribor/flows/affine.py:126-299).
+
+``AffineLU(dim)``: ``y = x (L U) + b`` with ``L = tril(W,-1)+I``, ``U = triu(W,1)+diag(exp(log_diag))``
+(affine.py:148-157); the reference inverts by two right-side triangular solves (:159-163).
+``MatrixExponential(dim, bias, log_time)``: ``y = L U e^{diag t} U^-1 L^-1 x (+ b)`` with
+``U = triu(W)+I`` (affine.py:222-270); the reference solves two batched [N, D, 1] triangular systems
+(97 % of cfg-4 time).
+
+Here every direction is one (or, for a per-row ``t``, two) dense D x D products on the fp32 matrix cores
+inside the fused flow kernel.  The matrices — ``(LU)^T``, ``((LU)^-1)^T``, ``L U e^{diag t} (L U)^-1`` — are
+derived from the parameters in fp64 on the device once per parameter version and rounded to fp32, which is
+closer to the exact inverse than the reference's own fp32 substitution (fp32-vs-fp64 self error of the
+reference on cfg 4: 1e-6..4e-6 rel).  ``log_det_jacobian`` is parameter-only.
+"""
+import math
+from numbers import Number
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import _hip
+from ..flow import Transform, flatten_rows
+from ..fused import ProgramBuilder
 
 __all__ = ['AffineLU', 'MatrixExponential']
 
 
-class AffineLU(Transform):
-    def __init__(self, *a, **k):
-        raise NotImplementedError
+class _DenseLinear(Transform):
+    """Shared launcher: single-transform fused programs keyed by (direction, ldj sign, t kind, device)."""
 
-    def forward(self, x, **kw): ...
-    def inverse(self, y, **kw): ...
-    def log_det_jacobian(self, x, y, **kw): ...
+    def _program(self, key, build):
+        if not hasattr(self, '_programs'):
+            self._programs = {}
+        if key not in self._programs:
+            self._programs[key] = build()
+        return self._programs[key]
+
+    def _run(self, x, reverse, want_y, want_ldj, ldj_scale, t=None):
+        _hip.require_device(x, 'x')
+        x2, lead = flatten_rows(x)
+        d = x2.shape[1]
+        t_kind = 'tensor' if torch.is_tensor(t) else (None if t is None else float(t))
+        key = (reverse, ldj_scale, t_kind, d, str(x.device))
+
+        def build():
+            b = ProgramBuilder(d, 0, 32)
+            b.t = t_kind
+            assert self._plan(b, reverse, ldj_scale)
+            return b.build(x.device)
+
+        prog = self._program(key, build)
+        row_t = t.reshape(-1) if torch.is_tensor(t) else None
+        y, ldj, _ = prog.run(x2, None, want_y, want_ldj, False, row_t=row_t)
+        return (None if y is None else y.reshape(*lead, d)), (None if ldj is None else ldj.reshape(*lead, 1))
 
 
-class MatrixExponential(Transform):
-    def __init__(self, *a, **k):
-        raise NotImplementedError
+class AffineLU(_DenseLinear):
+    def __init__(self, dim: int, **kwargs):
+        super().__init__()
+        self.dim = dim
+        self.weight = nn.Parameter(torch.empty(dim, dim))
+        self.log_diag = nn.Parameter(torch.empty(1, dim))
+        self.bias = nn.Parameter(torch.empty(1, dim))
+        self.reset_parameters()
 
-    def forward(self, x, **kw): ...
-    def inverse(self, y, **kw): ...
-    def log_det_jacobian(self, x, y, **kw): ...
+    def reset_parameters(self):
+        nn.init.xavier_uniform_(self.weight)                    # affine.py:143-146
+        nn.init.xavier_uniform_(self.log_diag)
+        nn.init.xavier_uniform_(self.bias)
+
+    def _lu64(self, dev):
+        W = self.weight.detach().to(dev, torch.float64)
+        eye = torch.eye(self.dim, dtype=torch.float64, device=dev)
+        L = torch.tril(W, -1) + eye                             # affine.py:148-150
+        U = torch.triu(W, 1) + eye * self.log_diag.detach().to(dev, torch.float64).exp()    # :152-154
+        return L @ U
+
+    def _matrices(self, reverse):
+        def fn(dev):
+            A = self._lu64(dev)
+            b = self.bias.detach().to(dev, torch.float64).reshape(-1)
+            if not reverse:
+                return A.T, b                                   # y = x A + b            (:157)
+            Ainv = torch.linalg.inv(A)
+            return Ainv.T, -(b @ Ainv)                          # x = (y - b) A^-1       (:159-163)
+        return fn
+
+    def _plan(self, builder, reverse, ldj_scale):
+        ld = float(self.log_diag.detach().double().sum().item())          # affine.py:171
+        builder.add_linear([self.weight, self.log_diag, self.bias], self._matrices(reverse), ldj_scale * ld)
+        return True
+
+    def forward(self, x, **kwargs):
+        return self._run(x, False, True, False, 1.0)[0]
+
+    def inverse(self, y, **kwargs):
+        return self._run(y, True, True, False, 1.0)[0]
+
+    def log_det_jacobian(self, x, y=None, **kwargs):
+        ld = self.log_diag.detach().to(x.device, torch.float32).sum()
+        return ld.expand(*x.shape[:-1], 1).clone()                          # affine.py:171
+
+    def forward_and_log_det_jacobian(self, x, **kwargs):
+        return self._run(x, False, True, True, 1.0)
+
+    def inverse_and_log_det_jacobian(self, y, **kwargs):
+        return self._run(y, True, True, True, -1.0)
+
+    def jacobian(self, x, y=None, **kwargs):
+        A = self._lu64(x.device).to(torch.float32)
+        return A.T.expand(*x.shape[:-1], -1, -1)                             # affine.py:173-179
+
+
+class MatrixExponential(_DenseLinear):
+    def __init__(self, dim: int, bias: bool = False, log_time: bool = False, **kwargs):
+        super().__init__()
+        self.dim, self.log_time = dim, log_time
+        self._weight = nn.Parameter(torch.empty(dim, dim))
+        self.diag = nn.Parameter(torch.empty(dim))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(dim))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self._weight, a=math.sqrt(5))               # affine.py:213-220
+        fan_in, _ = nn.init._calculate_fan_in_and_fan_out(self._weight)
+        bound = 1 / math.sqrt(fan_in)
+        nn.init.uniform_(self.diag, -bound, bound)
+        if self.bias is not None:
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def _sources(self):
+        return [p for p in (self._weight, self.diag, self.bias) if p is not None]
+
+    def _lu64(self, dev):
+        W = self._weight.detach().to(dev, torch.float64)
+        eye = torch.eye(self.dim, dtype=torch.float64, device=dev)
+        return (torch.tril(W, diagonal=-1) + eye) @ (torch.triu(W) + eye)    # affine.py:222-226
+
+    def _t_eff(self, t: float) -> float:
+        return math.log1p(abs(t)) if self.log_time else t                    # affine.py:239-240
+
+    def _plan(self, builder, reverse, ldj_scale):
+        t = getattr(builder, 't', None)
+        t = 1.0 if t is None else t                                          # default t = 1.0 (affine.py:246)
+        has_bias = self.bias is not None
+        if t == 'tensor':
+            # v = (LU)^-1 (x [- b]);  v *= exp(+-diag t_n);  y = (LU) v [+ b]       (affine.py:254-269)
+            def solve(dev):
+                Ainv = torch.linalg.inv(self._lu64(dev))
+                b = -(Ainv @ self.bias.detach().to(dev, torch.float64)) if (reverse and has_bias) else None
+                return Ainv, b
+
+            def mult(dev):
+                b = self.bias.detach().to(dev, torch.float64) if (not reverse and has_bias) else None
+                return self._lu64(dev), b
+            builder.add_linear(self._sources(), solve, 0.0)
+            builder.add_row_scale_exp(self.diag, reverse, ldj_scale, self.log_time, 0.0)
+            builder.add_linear(self._sources(), mult, 0.0)
+            return True
+        te = self._t_eff(float(t))
+        sg = -te if reverse else te
+
+        def collapsed(dev):
+            A = self._lu64(dev)
+            M = (A * (self.diag.detach().to(dev, torch.float64) * sg).exp()) @ torch.linalg.inv(A)
+            if not has_bias:
+                return M, None
+            b = self.bias.detach().to(dev, torch.float64)
+            return (M, b) if not reverse else (M, -(M @ b))
+        ld = float(self.diag.detach().double().sum().item()) * te            # affine.py:287-288
+        builder.add_linear(self._sources(), collapsed, ldj_scale * ld)
+        return True
+
+    def forward(self, x, t=1.0, *, reverse: bool = False, **kwargs):
+        return self._run(x, reverse, True, False, 1.0, t)[0]
+
+    def inverse(self, y, t=1.0, **kwargs):
+        return self._run(y, True, True, False, 1.0, t)[0]                    # affine.py:272-278
+
+    def log_det_jacobian(self, x, y=None, t=1.0, **kwargs):
+        s = self.diag.detach().to(x.device, torch.float32).sum()
+        if torch.is_tensor(t):
+            tt = t.to(x.device, torch.float32)
+            tt = torch.log1p(tt.abs()) if self.log_time else tt
+            return s * tt                                                    # [..., 1]
+        return (s * self._t_eff(float(t))).expand(*x.shape[:-1], 1).clone()
+
+    def forward_and_log_det_jacobian(self, x, t=1.0, **kwargs):
+        return self._run(x, False, True, True, 1.0, t)
+
+    def inverse_and_log_det_jacobian(self, y, t=1.0, **kwargs):
+        return self._run(y, True, True, True, -1.0, t)

@@ -71,6 +71,34 @@ class _PackJob:
         return [p for p in (self.W, self.b) if p is not None]
 
 
+class _DerivedLinearJob:
+    """A dense layer whose matrix is DERIVED from parameters (AffineLU: (L U)^T or its inverse;
+    MatrixExponential: L U e^{diag t} U^-1 L^-1): `fn()` -> (W [out, in] fp32, b [out] fp32 | None) on the
+    device, recomputed (in fp64 inside fn) only when a source parameter changes, then packed slab by slab."""
+
+    def __init__(self, sources, fn, targets):
+        self.sources, self.fn, self.targets = list(sources), fn, targets   # targets: [(row_idx, col_idx, k_tiles, off)]
+        self._dev_idx = None
+        self._keep = None
+
+    def run(self, blobs: torch.Tensor) -> None:
+        dev = blobs.device
+        W, b = self.fn(dev)
+        W = W.to(torch.float32).contiguous()
+        b = None if b is None else b.to(torch.float32).contiguous()
+        self._keep = (W, b)                      # stays alive until the async pack kernels have run
+        if self._dev_idx is None:
+            self._dev_idx = [(torch.from_numpy(r.astype(np.int32)).to(dev), torch.from_numpy(c.astype(np.int32)).to(dev))
+                             for (r, c, _, _) in self.targets]
+        for (ri, ci), (_, _, k_tiles, off) in zip(self._dev_idx, self.targets):
+            rc = _hip.lib().sx_pack_linear(W.data_ptr(), _hip.ptr(b), W.shape[0], W.shape[1], ri.data_ptr(),
+                                           ci.data_ptr(), 1, k_tiles, blobs.data_ptr() + 4 * off, _hip.stream())
+            _hip.check(rc, 'sx_pack_linear')
+
+    def params(self):
+        return self.sources
+
+
 class _ConstJob:
     """Per-slot constants (st.Affine without latent_net): blob[dst_off:] = cat(ls, sh)[gather]."""
 
@@ -93,6 +121,24 @@ class _ConstJob:
 
     def params(self):
         return [self.log_scale, self.shift]
+
+
+class _VectorJob:
+    """blob[dst_off:] = cat(vec, 0)[gather] (per-slot constants in C-fragment order)."""
+
+    def __init__(self, vec, dim: int, gather: np.ndarray, dst_off: int):
+        self.vec, self.dim, self.gather_host, self.dst_off = vec, dim, gather.astype(np.int64), dst_off
+        self.gather = None
+
+    def run(self, blobs: torch.Tensor) -> None:
+        dev = blobs.device
+        if self.gather is None:
+            self.gather = torch.from_numpy(self.gather_host).to(dev)
+        src = torch.cat([self.vec.detach().to(dev, torch.float32).reshape(-1), torch.zeros(1, device=dev)])
+        blobs[self.dst_off:self.dst_off + self.gather.numel()] = src[self.gather]
+
+    def params(self):
+        return [self.vec]
 
 
 class CompiledProgram:
@@ -121,7 +167,7 @@ class CompiledProgram:
     # -- launch -----------------------------------------------------------------------------------
     def run(self, x: torch.Tensor, latent: Optional[torch.Tensor] = None, want_y: bool = False,
             want_ldj: bool = False, want_logp: bool = False, sum_out: Optional[torch.Tensor] = None,
-            mlp_out: Optional[torch.Tensor] = None):
+            mlp_out: Optional[torch.Tensor] = None, row_t: Optional[torch.Tensor] = None):
         """x: [N, dim] contiguous on the program's device.  Returns (y | None, ldj | None, logp | None)."""
         _hip.require_device(x, 'x')
         assert x.dim() == 2 and x.shape[1] == self.prog.dim, (x.shape, self.prog.dim)
@@ -143,10 +189,14 @@ class CompiledProgram:
         elif self.prog.latent_dim:
             raise ValueError('this transform was built for a latent input but none was given')
         stride = mlp_out.stride(0) if mlp_out is not None else 0
+        if row_t is not None:
+            _hip.require_device(row_t, 't')
+            row_t = row_t.reshape(-1).to(torch.float32).contiguous()
+            assert row_t.numel() == n, (row_t.shape, n)
         rc = _hip.lib().sx_flow_run(C.byref(self.prog), self.blobs.data_ptr(), x.data_ptr(), _hip.ptr(latent),
                                     _hip.ptr(self.in_col), _hip.ptr(self.out_col), _hip.ptr(y), _hip.ptr(ldj),
                                     _hip.ptr(logp), _hip.ptr(sum_out), _hip.ptr(mlp_out), stride,
-                                    self.mlp_out_dim, n, _hip.dtype_code(x), _hip.stream())
+                                    self.mlp_out_dim, _hip.ptr(row_t), n, _hip.dtype_code(x), _hip.stream())
         _hip.check(rc, 'sx_flow_run')
         return y, ldj, logp
 
@@ -296,6 +346,42 @@ class ProgramBuilder:
         self.jobs.append(_ConstJob(log_scale, shift, D, gather, off))
         self.steps.append(dict(kind=_hip.STEP_AFFINE_CONST, c0=0, ct=0, t0=0, tt=T, reverse=int(reverse), act=0,
                                blob_off=off, blob_floats=n, ldj_scale=ldj_scale, ldj_const=0.0))
+
+    def add_linear(self, sources, fn, ldj_const: float) -> None:
+        """y = W . x + b on the data columns (W, b = fn(device), torch Linear layout [out, in]); one
+        LINEAR_TILE step per 32 output slots, the last one commits."""
+        self._freeze_input()
+        D, T = self.dim, self.tiles
+        col = self.col_of_slot
+        col_idx = np.full(32 * T, -1, dtype=np.int64)
+        col_idx[:self.n_slots] = col                       # input slot -> W column (= logical column)
+        targets = []
+        first = len(self.steps)
+        for t in range(self.x_tiles):
+            row_idx = col[32 * t:32 * t + 32].copy()       # output slot keeps its logical column
+            off, n = self._alloc(_hip.packed_linear_floats(1, T))
+            targets.append((row_idx, col_idx, T, off))
+            self.steps.append(dict(kind=_hip.STEP_LINEAR_TILE, c0=0, ct=T, t0=t, tt=int(t == self.x_tiles - 1),
+                                   reverse=0, act=0, blob_off=off, blob_floats=n, ldj_scale=0.0,
+                                   ldj_const=ldj_const if t == 0 else 0.0))
+        self.jobs.append(_DerivedLinearJob(sources, fn, targets))
+
+    def add_row_scale_exp(self, diag, reverse: bool, ldj_scale: float, log_time: bool, t_const: float) -> None:
+        """state *= exp(+-diag * t_row) (MatrixExponential with a per-row time, affine.py:263)."""
+        self._freeze_input()
+        T = self.tiles
+        off, n = self._alloc(32 * T)
+        gather = np.full(32 * T, self.dim, dtype=np.int64)      # index dim = appended zero
+        for t in range(self.x_tiles):
+            for h in range(2):
+                for r in range(16):
+                    c = self.col_of_slot[32 * t + _kmap(r, h)]
+                    if c >= 0:
+                        gather[t * 32 + h * 16 + r] = c
+        self.jobs.append(_VectorJob(diag, self.dim, gather, off))
+        self.steps.append(dict(kind=_hip.STEP_ROW_SCALE_EXP, c0=0, ct=0, t0=0, tt=T, reverse=int(reverse),
+                               act=int(log_time), blob_off=off, blob_floats=n, ldj_scale=ldj_scale,
+                               ldj_const=float(t_const)))
 
     def add_mlp(self, linears: Sequence[Tuple], act: int, in_cols_live: Optional[np.ndarray],
                 out_rows: np.ndarray) -> None:

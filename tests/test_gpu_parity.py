@@ -345,3 +345,72 @@ def test_rqs_kernel_against_oracle_random_params():
 def test_spline_error_behaviour():
     with pytest.raises(ValueError, match='Minimal bin width too large'):       # rational_quadratic_spline.py:96-97
         st.Spline(2, 1001, spline_type='quadratic').to(DEV)(torch.rand(3, 2, device=DEV))
+
+
+# ------------------------------------------------------------------------------------------------
+# dense linear layers
+# ------------------------------------------------------------------------------------------------
+def test_suite_shapes_affine_lu_and_matrix_exponential():
+    """stribor/test/test_affine.py:44-80: AffineLU; MatrixExponential with bias / log_time, default t and a
+    per-row t tensor; identity at t = 0 (:77-80)."""
+    g = Golden('f8_suite')
+    n = 0
+    for case in g.cases('affine_lu/') + g.cases('matrix_exp/'):
+        f = product_transform(g, case)
+        x = g.t(case + '/x').to(DEV)
+        kw = {'t': g.t(case + '/t').to(DEV)} if g.has(case + '/t') else {}
+        y = f(x, **kw)
+        close(y, g.t(case + '/y'), rtol=2e-5, atol=2e-5)
+        close(f.inverse(y, **kw), g.t(case + '/x'), atol=1e-4)                 # base.py:8-11
+        ldj = f.log_det_jacobian(x, y, **kw)
+        close(ldj, g.t(case + '/ldj'), atol=2e-5)
+        _, l1 = f.forward_and_log_det_jacobian(x, **kw)
+        _, l2 = f.inverse_and_log_det_jacobian(y, **kw)
+        close(l1, g.t(case + '/ldj'), atol=2e-5)
+        close(-l2, g.t(case + '/ldj'), atol=1e-4)
+        close(ldj.reshape(-1), g.t(case + '/autograd_logdet'), atol=1e-4)      # base.py:35-44
+        if case.startswith('matrix_exp/') and '/b0' in case:
+            t0 = torch.zeros(*x.shape[:-1], 1, device=DEV)
+            close(f(x, t=t0), x.cpu(), atol=1e-6)                              # test_affine.py:77-80
+        n += 1
+    assert n == 4 + 4 * 4 * 2
+
+
+def test_matrix_exponential_variants():
+    g = Golden('f6_cfg4')
+    for case in g.cases('matexp_'):
+        f = product_flow(g, case).transforms[0]
+        x, t = g.t(case + '/x').to(DEV), g.t(case + '/t').to(DEV)
+        tol = dict(rtol=2e-5, atol=2e-5)
+        close(f(x, t=t), g.t(case + '/fwd_t'), **tol)
+        close(f.inverse(x, t=t), g.t(case + '/inv_t'), **tol)
+        close(f.log_det_jacobian(x, None, t=t), g.t(case + '/ldj_t'), **tol)
+        close(f(x, t=0.7), g.t(case + '/fwd_s'), **tol)
+        close(f.inverse(x, t=0.7), g.t(case + '/inv_s'), **tol)
+        close(f.log_det_jacobian(x, None, t=0.7), g.t(case + '/ldj_s'), **tol)
+        close(f(x), g.t(case + '/fwd_default'), **tol)
+
+
+def test_cfg4_flow_against_golden():
+    """D=128: [AffineLU, Coupling(Affine), MatrixExponential, Coupling(Affine)] x 2, fully fused (fixture F6).
+    The reference's own fp32-vs-fp64 error on this config is ~1e-6..4e-6 rel (triangular solves); the bar is
+    1e-5 rel against its fp32 values and against the fp64 truth."""
+    g = Golden('f6_cfg4')
+    flow = product_flow(g, 'cfg4')
+    x = g.t('cfg4/x').to(DEV)
+    assert flow._fused_program(True, 128, 0, x.device) is not None             # one launch, no per-layer fallback
+    lp = flow.log_prob(x)
+    close(lp, g.t('cfg4/log_prob'), rtol=1e-5, atol=1e-4)
+    close(lp.double(), g.t('cfg4/log_prob_f64'), rtol=1e-5, atol=1e-4)
+    z, ldj = flow.inverse_and_log_det_jacobian(x)
+    close(z, g.t('cfg4/inverse'), rtol=1e-4, atol=2e-4)
+    close(ldj, g.t('cfg4/inverse_ldj'), rtol=1e-5, atol=1e-4)
+    y, ldf = flow.forward_and_log_det_jacobian(x)
+    close(y, g.t('cfg4/forward'), rtol=1e-4, atol=2e-4)
+    close(ldf, g.t('cfg4/forward_ldj'), rtol=1e-5, atol=1e-4)
+    cur = x
+    for i in reversed(range(len(flow.transforms))):
+        nxt, l = flow.transforms[i].inverse_and_log_det_jacobian(cur)
+        close(nxt, g.t(f'cfg4/inv_x.{i}'), rtol=1e-4, atol=2e-4)
+        close(l, g.t(f'cfg4/inv_ldj.{i}'), rtol=1e-5, atol=1e-4)
+        cur = nxt
