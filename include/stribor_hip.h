@@ -55,8 +55,15 @@ extern "C" {
 #define SX_ACT_LEAKYRELU 6
 #define SX_ACT_SILU      7
 #define SX_ACT_GELU      8
+/* coupling steps only: weights packed with the tanh / exp constants folded in (see sx_pack_linear):
+ * hidden = 1/(exp2(z') + 1), scale = exp2(ls'); ldj_scale carries the 1/(+-log2 e) factor */
+#define SX_ACT_TANH_FOLDED 9
 
 int         sx_abi_version(void);
+/* GEMM arithmetic the library was built with: 0 = v_mfma_f32_32x32x2_f32 (exact fp32 fma chains),
+ * 1 = fp16 x 3 split on v_mfma_f32_32x32x16_f16 (a = a_hi + a_lo in fp16, 3 products, fp32 accumulate:
+ * ~2^-22 relative per product, fp32-grade).  sx_pack_linear writes the matching fragment layout. */
+int         sx_fragment_mode(void);
 const char *sx_last_error(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -118,10 +125,15 @@ size_t sx_packed_linear_floats(int32_t m_tiles, int32_t k_tiles);
  *   row_idx[m_tiles*32]: output slot -> row of W, or -1 for a zero row (padding / pruned)
  *   col_idx[k_tiles*32]: input  slot -> column of W, or -1 for a zero column
  * Layout written (floats): A[m][kt][g][lane][e] = W[row_idx[32m + (lane&31)]][col_idx[32kt + kmap(4g+e, lane>>5)]]
- * with kmap(s,h) = (s&3) + 8*(s>>2) + 4*h, then bias[m][h][r] = b[row_idx[32m + kmap(r,h)]]. */
+ * with kmap(s,h) = (s&3) + 8*(s>>2) + 4*h, then bias[m][h][r] = b[row_idx[32m + kmap(r,h)]].
+ * Optional exact re-parametrisation (all NULL / 0 = plain copy):
+ *   row_scale[m_tiles*32]  : A rows are multiplied by row_scale[slot]
+ *   bias_scale[m_tiles*32], fold_ones: bias' = bias_scale[slot] * (b[row] + fold_ones * sum_live_cols W[row][col])
+ * used to fold the constants of tanh(z) = 1 - 2/(exp2(2 log2(e) z) + 1) and exp(x) = exp2(log2(e) x) into the
+ * weights so the kernel spends no VALU cycles on them (SX_ACT_TANH_FOLDED). */
 int sx_pack_linear(const float *W, const float *b, int32_t out_dim, int32_t in_dim,
                    const int32_t *row_idx, const int32_t *col_idx, int32_t m_tiles, int32_t k_tiles,
-                   float *dst, void *stream);
+                   const float *row_scale, const float *bias_scale, float fold_ones, float *dst, void *stream);
 
 /* One step of a fused flow program.  The flow state lives in registers as 32-wide "tiles" of
  * columns (tile t = state slots 32t..32t+31); slots map to columns of x through in_col/out_col. */

@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libstribor_hip.so')
+LIB_PATH = os.environ.get('STRIBOR_HIP_LIB', os.path.join(_HERE, 'libstribor_hip.so'))   # override: experiments only
 
 SX_F32, SX_BF16 = 0, 1
 SX_MAX_STEPS = 96
@@ -28,11 +28,12 @@ STEP_MLP_OUT_TILE = 7
 STEP_COUPLING_RQS = 8
 STEP_ROW_SCALE_EXP = 9
 
+ACT_TANH_FOLDED = 9
 ACT_CODES = {'Identity': 0, 'Tanh': 1, 'ReLU': 2, 'Sigmoid': 3, 'ELU': 4, 'Softplus': 5, 'LeakyReLU': 6,
              'SiLU': 7, 'GELU': 8}
 
 # every symbol include/stribor_hip.h declares (tests check that the library exports all of them)
-EXPORTS = ['sx_abi_version', 'sx_last_error', 'sx_permute', 'sx_affine_coupling', 'sx_rqs_coupling',
+EXPORTS = ['sx_abi_version', 'sx_fragment_mode', 'sx_last_error', 'sx_permute', 'sx_affine_coupling', 'sx_rqs_coupling',
            'sx_unit_normal_logprob', 'sx_sum_f64', 'sx_packed_linear_floats', 'sx_pack_linear', 'sx_flow_run',
            'sx_flow_launch_info']
 
@@ -60,6 +61,8 @@ def _declare(lib: C.CDLL) -> None:
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     lib.sx_abi_version.restype = i32
     lib.sx_abi_version.argtypes = []
+    lib.sx_fragment_mode.restype = i32
+    lib.sx_fragment_mode.argtypes = []
     lib.sx_last_error.restype = C.c_char_p
     lib.sx_last_error.argtypes = []
     lib.sx_permute.restype = i32
@@ -76,7 +79,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.sx_packed_linear_floats.restype = C.c_size_t
     lib.sx_packed_linear_floats.argtypes = [i32, i32]
     lib.sx_pack_linear.restype = i32
-    lib.sx_pack_linear.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp]
+    lib.sx_pack_linear.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, f32, vp, vp]
     lib.sx_flow_run.restype = i32
     lib.sx_flow_run.argtypes = [C.POINTER(sx_program), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, i64, i32, vp]
     lib.sx_flow_launch_info.restype = i32

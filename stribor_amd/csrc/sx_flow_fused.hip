@@ -1,7 +1,7 @@
 // Host dispatcher of the fused flow kernel (device code: sx_flow_kernel.h, one object per tile pair).
 #include "sx_flow_types.h"
+#include <stdlib.h>
 
-#define SX_ROWS_PER_BLOCK 128
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -61,11 +61,17 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     return SX_OK;
 }
 
-static int pick_grid(int64_t n_rows, int lds_bytes) {
+#ifndef SX_DEFAULT_BLOCKS_PER_CU
+#define SX_DEFAULT_BLOCKS_PER_CU 2
+#endif
+static int pick_grid(int64_t n_rows, int lds_bytes, int tiles) {
     int per_cu = (160 * 1024) / (lds_bytes > 0 ? lds_bytes : 1);
-    if (per_cu > 2) per_cu = 2;
+    int max_per_cu = SX_DEFAULT_BLOCKS_PER_CU;
+    if (const char *g = getenv("SX_BLOCKS_PER_CU")) max_per_cu = atoi(g);      // experiment knob
+    if (per_cu > max_per_cu) per_cu = max_per_cu;
     if (per_cu < 1) per_cu = 1;
-    int64_t chunks = (n_rows + SX_ROWS_PER_BLOCK - 1) / SX_ROWS_PER_BLOCK;
+    const int rows_per_block = 128 * SX_NS_FOR(tiles);
+    int64_t chunks = (n_rows + rows_per_block - 1) / rows_per_block;
     int64_t g = 256 * per_cu;
     if (g > chunks) g = chunks;
     if (g < 1) g = 1;
@@ -79,7 +85,7 @@ extern "C" int sx_flow_launch_info(const sx_program *prog_host, int64_t n_rows, 
     if (rc) return rc;
     if (lds_bytes) *lds_bytes = bf * 8;
     if (block) *block = 256;
-    if (grid) *grid = pick_grid(n_rows, bf * 8);
+    if (grid) *grid = pick_grid(n_rows, bf * 8, prog_host->tiles);
     return SX_OK;
 }
 
@@ -104,7 +110,7 @@ extern "C" int sx_flow_run(const sx_program *prog_host, const float *blobs, cons
     a.prog = d; a.blobs = blobs; a.x = x; a.latent = latent; a.in_col = in_col; a.out_col = out_col; a.y = y;
     a.ldj_out = ldj_out; a.logp_out = logp_out; a.sum_out = sum_out; a.mlp_out = mlp_out;
     a.mlp_out_stride = mlp_out_stride; a.mlp_out_dim = mlp_out_dim; a.n_rows = n_rows; a.buf_floats = bf;
-    a.bf16 = dtype == SX_BF16; a.mlp_mode = mlp_mode; a.lds = bf * 8; a.grid = pick_grid(n_rows, a.lds);
+    a.bf16 = dtype == SX_BF16; a.mlp_mode = mlp_mode; a.lds = bf * 8; a.grid = pick_grid(n_rows, a.lds, prog_host->tiles);
     a.stream = sx_stream(stream);
     a.row_t = row_t;
     const int T = prog_host->tiles, H = prog_host->h_tiles;

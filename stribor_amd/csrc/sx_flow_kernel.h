@@ -5,33 +5,78 @@
 // of stribor/flows/coupling.py:48-95 + flows/affine.py:59-123 + net/mlp.py:65.
 //
 // Mapping to CDNA4 (MI355X_MICROARCH.md, cdna_hip_programming.md §3):
-//   * one wave = 32 samples.  Samples sit on the MFMA column (lane&31), features on the C rows, so the
-//     flow state x[D] of a sample is 16*D/32 VGPRs per lane in v_mfma_f32_32x32x2_f32 C-fragment order
-//     (lane half h = lane>>5 owns features kmap(r,h), r = 0..15, of every 32-wide tile);
+//   * one wave = NS x 32 samples (NS = 2 for D <= 64, 1 for D = 128).  Samples sit on the MFMA column
+//     (lane&31), features on the C rows, so the flow state x[D] of a sample is 16*D/32 VGPRs per lane in
+//     v_mfma_f32_32x32x2_f32 C-fragment order (lane half h = lane>>5 owns features kmap(r,h), r = 0..15, of
+//     every 32-wide tile);
 //   * a C tile is directly the B operand of the next GEMM (k-step s <-> feature kmap(s,h); the weights
 //     are pre-permuted by sx_pack_linear), so x -> hidden -> (log_scale, shift) -> x' never leaves
 //     registers: no LDS transposes, no HBM round trips between layers;
-//   * GEMMs run on the exact-fp32 matrix pipe (v_mfma_f32_32x32x2_f32: an fp32 fma chain, so parity
-//     with the CPU reference holds at ~1e-7); tanh/exp are v_exp_f32 + v_rcp_f32 on the VALU, which
-//     overlaps the matrix pipe of the co-resident wave;
+//   * GEMMs run on the exact-fp32 matrix pipe (v_mfma_f32_32x32x2_f32: an fp32 fma chain, so parity with
+//     the CPU reference holds at ~1e-7).  One ds_read_b128 of A operands feeds 4 k-steps x NS sample
+//     tiles = 4*NS MFMAs, and the NS accumulator chains are independent, so LDS latency and the per-step
+//     fixed costs (descriptor load, barrier, bias loads) are amortised over 2x the matrix work;
+//   * tanh / exp (v_exp_f32 + v_rcp_f32) of one tile are issued between the MFMAs of the next tile
+//     (software pipelining in program order), so the VALU work rides in the matrix pipe's shadow;
 //   * weights of one step (<= ~25 KB for D=64,H=64) stream L2 -> LDS by LDS-DMA (global_load_lds x16 B),
-//     double-buffered: step s+1 lands while step s computes; A operands come from LDS as ds_read_b128
-//     (4 k-steps per read, conflict-free: lane-linear 16 B);
-//   * 256-thread workgroups (4 waves = 128 samples per pass), persistent grid-stride over sample chunks,
-//     2 workgroups per CU so that one wave's VALU phase hides under its SIMD partner's MFMA phase;
+//     double-buffered: step s+1 lands while step s computes; the NEXT step's descriptor is fetched one
+//     step early as well;
+//   * 256-thread workgroups (4 waves = 128*NS samples per pass), persistent grid-stride over sample
+//     chunks, up to 2 workgroups per CU;
 //   * per-sample log-det / log-prob: in-lane sums + ONE cross-half shuffle; optional batch sum as fp64
 //     block partials + one atomic per workgroup (flow.py:129 + the multi-GPU all-reduce operand).
+#pragma once
 #include "sx_common.h"
 #include "sx_flow_types.h"
+#include <stdlib.h>
 
-#define SX_ROWS_PER_BLOCK 128
 #define SX_HALF_LOG_2PI 0.91893853320467274178f
+#ifndef SX_WAVES_PER_SIMD
+#define SX_WAVES_PER_SIMD 2
+#endif
 
 __host__ __device__ static inline int sx_kmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 extern __shared__ __attribute__((aligned(16))) float smem[];
 
+// Timing experiments only (tools/knob_sweep.sh): with -DSX_DEBUG_KNOBS the bits of g_sx_dbg switch parts of
+// the kernel off (results are then wrong).  The shipped .so is built without it: SX_DBG folds to 0.
+#ifdef SX_DEBUG_KNOBS
+__device__ int g_sx_dbg;   // set by the host before launch (hipMemcpyToSymbol)
+__device__ __forceinline__ int smem_dbg() { return __builtin_amdgcn_readfirstlane(g_sx_dbg); }
+#define SX_DBG(bit) (smem_dbg() & (bit))
+#else
+#define SX_DBG(bit) 0
+#endif
+
 typedef __attribute__((address_space(3))) void lds_void;
+
+// In-kernel phase stamps (diagnostic build only; MI355X guide §7 'In-kernel stamps').  prof_t is empty in the
+// shipped build, so every SX_STAMP folds away.
+#ifdef SX_DEBUG_KNOBS
+__device__ unsigned long long g_sx_prof[16];
+struct prof_t {
+    unsigned long long acc[16];
+    unsigned long long last;
+};
+__device__ __forceinline__ void sx_stamp(prof_t &p, int id) {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    p.acc[id] += t - p.last;
+    p.last = t;
+}
+#define SX_STAMP(p, id) sx_stamp(p, id)
+#else
+struct prof_t {};
+#define SX_STAMP(p, id) ((void)0)
+#endif
+
+template <int NS>
+struct tile {            // one 32-feature tile of NS x 32 samples, C-fragment order
+    f32x16 v[NS];
+};
 
 // ---- weights: L2 -> LDS by LDS-DMA, 1 KiB per wave-instruction, lane-linear -----------------------------
 __device__ __forceinline__ void stage_blob(const float *__restrict__ g, int lds_float_off, uint32_t n_floats) {
@@ -45,21 +90,108 @@ __device__ __forceinline__ void stage_blob(const float *__restrict__ g, int lds_
     }
 }
 
-// ---- one 32x32 output tile += A(32 x 32) . B(32 x 32 samples): 16 k-steps, A from LDS ------------------
-__device__ __forceinline__ f32x16 gemm_tile(int a_off, const f32x16 &b, f32x16 acc, int lane) {
+// ---- one 32x32 output tile (x NS sample tiles) += A(32 x 32) . B, A from LDS --------------------------
+// f(i), i = 0..15, is one unit of independent VALU work slotted between the MFMAs.
+#ifndef SX_F16X3
+// exact fp32: 16 k-steps of v_mfma_f32_32x32x2_f32; the B operand is the fp32 C tile itself
+template <int NS>
+using btile = tile<NS>;
+template <int NS>
+__device__ __forceinline__ const btile<NS> &make_btile(const tile<NS> &c) { return c; }
+
+template <int NS, class F>
+__device__ __forceinline__ void gemm_tile_f(int a_off, const btile<NS> &b, tile<NS> &acc, int lane, F &&f) {
+    if (SX_DBG(16)) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) f(i);
+        return;
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const f32x4 a = reinterpret_cast<const f32x4 *>(smem)[(a_off >> 2) + g * 64 + lane];   // ds_read_b128
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[4 * g + 0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[4 * g + 1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[4 * g + 2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[4 * g + 3], acc, 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NS; ++n) acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.v[n][4 * g + 0], acc.v[n], 0, 0, 0);
+        f(4 * g + 0);
+#pragma unroll
+        for (int n = 0; n < NS; ++n) acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.v[n][4 * g + 1], acc.v[n], 0, 0, 0);
+        f(4 * g + 1);
+#pragma unroll
+        for (int n = 0; n < NS; ++n) acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.v[n][4 * g + 2], acc.v[n], 0, 0, 0);
+        f(4 * g + 2);
+#pragma unroll
+        for (int n = 0; n < NS; ++n) acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.v[n][4 * g + 3], acc.v[n], 0, 0, 0);
+        f(4 * g + 3);
     }
-    return acc;
+}
+#else
+// fp16 x 3 split: a = a_hi + a_lo, b = b_hi + b_lo in fp16 (22 mantissa bits each), a.b ~= a_hi b_hi + a_hi b_lo +
+// a_lo b_hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation: 6 MFMAs x 32 cycles per 32-deep tile instead of
+// 16 x 64 cycles, and -- unlike the fp32 form, which executes on the VALU -- on the matrix pipe, beside the VALU.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int NS>
+struct btile {            // one 32-deep B operand: 2 k16-steps x (hi, lo) fragments, per sample tile
+    h8 hi[NS][2], lo[NS][2];
+};
+__device__ __forceinline__ uint32_t pk_rtz(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
+}
+__device__ __forceinline__ float lo_f(uint32_t p) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(p & 0xffffu)); }
+__device__ __forceinline__ float hi_f(uint32_t p) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(p >> 16)); }
+// C tile (fp32, 16 registers) -> B fragments: k16-step s takes registers 8s..8s+7 (cdna_hip_programming.md §3
+// 'An accumulator tile as the next MFMA's operand'); hi = rtz(v), lo = rtz(v - hi) (v - hi is exact in fp32).
+template <int NS>
+__device__ __forceinline__ btile<NS> make_btile(const tile<NS> &c) {
+    btile<NS> b;
+#pragma unroll
+    for (int n = 0; n < NS; ++n)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4 hi, lo;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v0 = c.v[n][8 * s + 2 * q], v1 = c.v[n][8 * s + 2 * q + 1];
+                const uint32_t ph = pk_rtz(v0, v1);
+                hi[q] = ph;
+                lo[q] = pk_rtz(v0 - lo_f(ph), v1 - hi_f(ph));
+            }
+            b.hi[n][s] = __builtin_bit_cast(h8, hi);
+            b.lo[n][s] = __builtin_bit_cast(h8, lo);
+        }
+    return b;
+}
+template <int NS, class F>
+__device__ __forceinline__ void gemm_tile_f(int a_off, const btile<NS> &b, tile<NS> &acc, int lane, F &&f) {
+    if (SX_DBG(16)) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) f(i);
+        return;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const u32x4 ahu = reinterpret_cast<const u32x4 *>(smem)[(a_off >> 2) + (2 * s) * 64 + lane];       // ds_read_b128
+        const u32x4 alu = reinterpret_cast<const u32x4 *>(smem)[(a_off >> 2) + (2 * s + 1) * 64 + lane];
+        const h8 ah = __builtin_bit_cast(h8, ahu), al = __builtin_bit_cast(h8, alu);
+        // smallest terms first
+#pragma unroll
+        for (int n = 0; n < NS; ++n) acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b.hi[n][s], acc.v[n], 0, 0, 0);
+        f(8 * s + 0); f(8 * s + 1); f(8 * s + 2);
+#pragma unroll
+        for (int n = 0; n < NS; ++n) acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.lo[n][s], acc.v[n], 0, 0, 0);
+        f(8 * s + 3); f(8 * s + 4); f(8 * s + 5);
+#pragma unroll
+        for (int n = 0; n < NS; ++n) acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.hi[n][s], acc.v[n], 0, 0, 0);
+        f(8 * s + 6); f(8 * s + 7);
+    }
+}
+#endif
+template <int NS>
+__device__ __forceinline__ void gemm_tile(int a_off, const btile<NS> &b, tile<NS> &acc, int lane) {
+    gemm_tile_f<NS>(a_off, b, acc, lane, [](int) {});
 }
 
-// bias / per-feature constants in C-fragment order: [h][16] floats at off
-__device__ __forceinline__ f32x16 load_cfrag(int off, int h) {
+// bias / per-feature constants in C-fragment order: [h][16] floats at off, replicated over the sample tiles
+__device__ __forceinline__ f32x16 load_cfrag1(int off, int h) {
     f32x16 v;
     const f32x4 *p = reinterpret_cast<const f32x4 *>(smem) + ((off >> 2) + h * 4);
     const f32x4 a = p[0], b = p[1], c = p[2], d = p[3];
@@ -69,9 +201,18 @@ __device__ __forceinline__ f32x16 load_cfrag(int off, int h) {
     v[12] = d.x; v[13] = d.y; v[14] = d.z; v[15] = d.w;
     return v;
 }
+template <int NS>
+__device__ __forceinline__ tile<NS> load_cfrag(int off, int h) {
+    tile<NS> t;
+    t.v[0] = load_cfrag1(off, h);
+#pragma unroll
+    for (int n = 1; n < NS; ++n) t.v[n] = t.v[0];
+    return t;
+}
 
 __device__ __forceinline__ float act_one(float v, int act) {
     switch (act) {
+        case SX_ACT_TANH: return fast_tanh(v);
         case SX_ACT_RELU: return fmaxf(v, 0.f);
         case SX_ACT_SIGMOID: return fast_rcp(1.f + fast_exp(-v));
         case SX_ACT_ELU: return v > 0.f ? v : expm1f(v);
@@ -82,87 +223,174 @@ __device__ __forceinline__ float act_one(float v, int act) {
         default: return v;
     }
 }
-__device__ __forceinline__ void activate(f32x16 &v, int act) {
+// Generic activations are rare: one out-of-line copy keeps the code (and hipcc's compile time) small.
+__device__ __attribute__((noinline)) void activate_generic(f32x16 *v, int act) {
+    f32x16 t = *v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = act_one(t[r], act);
+    *v = t;
+}
+template <int NS>
+__device__ __forceinline__ void activate(tile<NS> &t, int act) {
     if (act == SX_ACT_TANH) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = fast_tanh(v[r]);
+        for (int n = 0; n < NS; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t.v[n][r] = fast_tanh(t.v[n][r]);
     } else if (act != SX_ACT_IDENTITY) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = act_one(v[r], act);
+        for (int n = 0; n < NS; ++n) activate_generic(&t.v[n], act);
     }
 }
 
-// hidden[m] = act(W . state[C0..C0+CT) + b),  blob = pack_linear(W, HT m-tiles, CT k-tiles)
-template <int TX, int HT, int C0, int CT>
-__device__ __forceinline__ void hidden_from_state(const f32x16 (&xs)[TX], f32x16 (&hid)[HT], int base, int act,
-                                                  int lane) {
+// folded tanh (SX_ACT_TANH_FOLDED): the weights carry the constants, the kernel computes r = 1/(exp2(z') + 1)
+__device__ __forceinline__ float hid_act(float v, bool folded) {
+    return folded ? __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v) + 1.0f) : fast_tanh(v);
+}
+
+// hidden[m] = act(W . src[C0..C0+CT) + b),  blob = pack_linear(W, HT m-tiles, CT k-tiles).
+// The activation of tile m-1 is issued between the MFMAs of tile m (tanh fast path).
+template <int NS, int NSRC, int HT, int C0, int CT>
+__device__ __forceinline__ void hidden_layer(const tile<NS> (&src)[NSRC], tile<NS> (&hid)[HT], int base, int act,
+                                             int lane) {
     const int h = lane >> 5;
     const int bias = base + HT * CT * 1024;
+    btile<NS> bsrc[CT];          // B operands are formed once and reused by every output tile
 #pragma unroll
-    for (int m = 0; m < HT; ++m) {
-        f32x16 acc = load_cfrag(bias + m * 32, h);
+    for (int c = 0; c < CT; ++c) bsrc[c] = make_btile<NS>(src[C0 + c]);
+    if (act == SX_ACT_TANH || act == SX_ACT_TANH_FOLDED) {
+        const bool folded = act == SX_ACT_TANH_FOLDED;
+        tile<NS> acc = load_cfrag<NS>(bias, h);
 #pragma unroll
-        for (int c = 0; c < CT; ++c) acc = gemm_tile(base + (m * CT + c) * 1024, xs[C0 + c], acc, lane);
-        activate(acc, act);
-        hid[m] = acc;
+        for (int c = 0; c < CT; ++c) gemm_tile<NS>(base + c * 1024, bsrc[c], acc, lane);
+#pragma unroll
+        for (int m = 1; m < HT; ++m) {
+            tile<NS> nxt = load_cfrag<NS>(bias + m * 32, h);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                if (c == 0)
+                    gemm_tile_f<NS>(base + (m * CT + c) * 1024, bsrc[c], nxt, lane, [&](int i) {
+#pragma unroll
+                        for (int n = 0; n < NS; ++n) acc.v[n][i] = hid_act(acc.v[n][i], folded);
+                    });
+                else
+                    gemm_tile<NS>(base + (m * CT + c) * 1024, bsrc[c], nxt, lane);
+            }
+            hid[m - 1] = acc;
+            acc = nxt;
+        }
+        hid[HT - 1] = acc;     // NOT yet activated: the caller hides this last tanh under its own MFMAs
+    } else {
+#pragma unroll
+        for (int m = 0; m < HT; ++m) {
+            tile<NS> acc = load_cfrag<NS>(bias + m * 32, h);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) gemm_tile<NS>(base + (m * CT + c) * 1024, bsrc[c], acc, lane);
+            activate<NS>(acc, act);
+            hid[m] = acc;
+        }
     }
+}
+template <int NS>
+__device__ __forceinline__ void tanh_tile(tile<NS> &t, bool folded = false) {
+#pragma unroll
+    for (int n = 0; n < NS; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t.v[n][r] = hid_act(t.v[n][r], folded);
 }
 
 // Affine coupling step (affine.py:104-109 through coupling.py:69-95), conditioner evaluated once (quirk Q2).
-template <int TX, int HT, int C0, int CT, int T0, int TT>
-__device__ __forceinline__ void coupling_affine(f32x16 (&xs)[TX], int base, const dstep &st, float &ldj, int lane) {
+template <int NS, int TX, int HT, int C0, int CT, int T0, int TT>
+__device__ __forceinline__ void coupling_affine(tile<NS> (&xs)[TX], int base, const dstep &st, float (&ldj)[NS],
+                                                int lane, prof_t &pf) {
     const int h = lane >> 5;
-    f32x16 hid[HT];
-    hidden_from_state<TX, HT, C0, CT>(xs, hid, base, st.act, lane);
+    const bool folded = st.act == SX_ACT_TANH_FOLDED;
+    const bool tanh_path = st.act == SX_ACT_TANH || folded;
+    tile<NS> hid[HT];
+    hidden_layer<NS, TX, HT, C0, CT>(xs, hid, base, st.act, lane);
+    SX_STAMP(pf, 3);     // GEMM-1 (+ pipelined tanh)
     const int a2 = base + HT * CT * 1024 + HT * 32;   // pack_linear(W2: 2*TT m-tiles, HT k-tiles)
     const int b2 = a2 + 2 * TT * HT * 1024;
-    float s = 0.f;
+    const float sgn = folded ? 1.0f : (st.reverse ? -1.44269504088896341f : 1.44269504088896341f);
+    float s[NS];
+#pragma unroll
+    for (int n = 0; n < NS; ++n) s[n] = 0.f;
+    if (tanh_path && HT == 1) tanh_tile<NS>(hid[0], folded);
+    btile<NS> bh[HT];
+#pragma unroll
+    for (int m = 0; m + 1 < HT; ++m) bh[m] = make_btile<NS>(hid[m]);
+    if (!tanh_path || HT == 1) bh[HT - 1] = make_btile<NS>(hid[HT - 1]);
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
-        f32x16 ls = load_cfrag(b2 + (2 * t) * 32, h);
-        f32x16 sh = load_cfrag(b2 + (2 * t + 1) * 32, h);
+        tile<NS> ls = load_cfrag<NS>(b2 + (2 * t) * 32, h);
+        tile<NS> sh = load_cfrag<NS>(b2 + (2 * t + 1) * 32, h);
 #pragma unroll
-        for (int m = 0; m < HT; ++m) {
-            ls = gemm_tile(a2 + ((2 * t) * HT + m) * 1024, hid[m], ls, lane);
-            sh = gemm_tile(a2 + ((2 * t + 1) * HT + m) * 1024, hid[m], sh, lane);
+        for (int m = 0; m + 1 < HT; ++m) {
+            if (t == 0 && m == 0 && tanh_path)        // the last hidden tile's tanh rides under this k-chunk
+                gemm_tile_f<NS>(a2 + ((2 * t) * HT + m) * 1024, bh[m], ls, lane, [&](int i) {
+#pragma unroll
+                    for (int n = 0; n < NS; ++n) hid[HT - 1].v[n][i] = hid_act(hid[HT - 1].v[n][i], folded);
+                });
+            else
+                gemm_tile<NS>(a2 + ((2 * t) * HT + m) * 1024, bh[m], ls, lane);
+            gemm_tile<NS>(a2 + ((2 * t + 1) * HT + m) * 1024, bh[m], sh, lane);
         }
-        f32x16 &x = xs[T0 + t];
+        if (t == 0 && tanh_path && HT > 1) bh[HT - 1] = make_btile<NS>(hid[HT - 1]);   // its tanh just finished
+        gemm_tile<NS>(a2 + ((2 * t) * HT + (HT - 1)) * 1024, bh[HT - 1], ls, lane);
+        // exp(+-log_scale) rides under the shift tile's last k-chunk; ls is overwritten by the scale
+        gemm_tile_f<NS>(a2 + ((2 * t + 1) * HT + (HT - 1)) * 1024, bh[HT - 1], sh, lane, [&](int i) {
+#pragma unroll
+            for (int n = 0; n < NS; ++n) {
+                s[n] += ls.v[n][i];
+                ls.v[n][i] = __builtin_amdgcn_exp2f(ls.v[n][i] * sgn);
+            }
+        });
+        SX_STAMP(pf, 4);     // GEMM-2 (+ pipelined tanh / exp)
+        tile<NS> &x = xs[T0 + t];
         if (st.reverse) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) x[r] = (x[r] - sh[r]) * fast_exp(-ls[r]);
+            for (int n = 0; n < NS; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x.v[n][r] = (x.v[n][r] - sh.v[n][r]) * ls.v[n][r];
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) x[r] = x[r] * fast_exp(ls[r]) + sh[r];
-        }
+            for (int n = 0; n < NS; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s += ls[r];
+                for (int r = 0; r < 16; ++r) x.v[n][r] = x.v[n][r] * ls.v[n][r] + sh.v[n][r];
+        }
     }
-    ldj += st.ldj_scale * s;
+#pragma unroll
+    for (int n = 0; n < NS; ++n) ldj[n] += st.ldj_scale * s[n];
+    SX_STAMP(pf, 5);         // affine + log-det
 }
 
 // Elementwise affine with per-feature constants (st.Affine without latent_net, affine.py:63-64,104-109)
-template <int TX>
-__device__ __forceinline__ void affine_const(f32x16 (&xs)[TX], int base, const dstep &st, int x_tiles, float &ldj,
-                                             int lane) {
+template <int NS, int TX>
+__device__ __forceinline__ void affine_const(tile<NS> (&xs)[TX], int base, const dstep &st, int x_tiles,
+                                             float (&ldj)[NS], int lane) {
     const int h = lane >> 5;
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < TX; ++t) {
         if (t < x_tiles) {
-            const f32x16 ls = load_cfrag(base + t * 32, h);
-            const f32x16 sh = load_cfrag(base + (TX + t) * 32, h);
-            if (st.reverse) {
+            const f32x16 ls = load_cfrag1(base + t * 32, h);
+            const f32x16 sh = load_cfrag1(base + (TX + t) * 32, h);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) xs[t][r] = (xs[t][r] - sh[r]) * fast_exp(-ls[r]);
-            } else {
+            for (int n = 0; n < NS; ++n) {
+                if (st.reverse) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) xs[t][r] = xs[t][r] * fast_exp(ls[r]) + sh[r];
+                    for (int r = 0; r < 16; ++r) xs[t].v[n][r] = (xs[t].v[n][r] - sh[r]) * fast_exp(-ls[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xs[t].v[n][r] = xs[t].v[n][r] * fast_exp(ls[r]) + sh[r];
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) s += ls[r];     // padding slots carry log_scale = 0
         }
     }
-    ldj += st.ldj_scale * s;
+#pragma unroll
+    for (int n = 0; n < NS; ++n) ldj[n] += st.ldj_scale * s;
 }
 
 __device__ __forceinline__ float ld_elem(const void *p, int64_t off, int bf16) {
@@ -174,138 +402,165 @@ __device__ __forceinline__ void st_elem(void *p, int64_t off, float v, int bf16)
     else reinterpret_cast<float *>(p)[off] = v;
 }
 
+struct flow_kargs {     // everything but the program, by value in the kernarg segment
+    const float *blobs; const void *x; const float *latent; const int32_t *in_col; const int32_t *out_col;
+    void *y; float *ldj_out; float *logp_out; double *sum_out; float *mlp_out; const float *row_t;
+    int64_t mlp_out_stride; int64_t n_rows; int mlp_out_dim; int buf_floats; int bf16; int pad;
+};
+
 // MODE 0: flow programs (coupling / affine-const steps); MODE 1: + persistent hidden state (MLP programs);
 // MODE 2: flow programs with dense linear layers (AffineLU / MatrixExponential): + a second state tile set
-template <int TX, int HT, int MODE>
-__global__ __launch_bounds__(256, 2) void flow_fused_kernel(
-    const dprog prog, const float *__restrict__ blobs, const void *__restrict__ x,
-    const float *__restrict__ latent, const int32_t *__restrict__ in_col, const int32_t *__restrict__ out_col,
-    void *__restrict__ y, float *__restrict__ ldj_out, float *__restrict__ logp_out, double *__restrict__ sum_out,
-    float *__restrict__ mlp_out, int64_t mlp_out_stride, int mlp_out_dim, int64_t n_rows, int buf_floats,
-    int bf16, const float *__restrict__ row_t) {
+template <int NS, int TX, int HT, int MODE>
+__global__ __launch_bounds__(256, SX_WAVES_PER_SIMD) void flow_fused_kernel(const dprog prog, const flow_kargs k) {
+    constexpr int ROWS_PER_BLOCK = 128 * NS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int dim = prog.dim, x_tiles = prog.x_tiles, n_steps = prog.n_steps;
-    const int64_t n_chunks = (n_rows + SX_ROWS_PER_BLOCK - 1) / SX_ROWS_PER_BLOCK;
+    const int64_t n_rows = k.n_rows;
+    const int64_t n_chunks = (n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    const int bf16 = k.bf16, buf_floats = k.buf_floats;
     double block_sum = 0.0;
+    prof_t pf;
+#ifdef SX_DEBUG_KNOBS
+    for (int i = 0; i < 16; ++i) pf.acc[i] = 0;
+    pf.last = __builtin_amdgcn_s_memtime();
+#endif
 
-    // prologue: first step's weights into buffer 0
+    // prologue: first step's weights into buffer 0, first step's descriptor into registers
     int cur = 0;
-    if ((int64_t)blockIdx.x < n_chunks && n_steps > 0 && prog.steps[0].blob_floats)
-        stage_blob(blobs + prog.steps[0].blob_off, 0, prog.steps[0].blob_floats);
+    dstep st_next = prog.steps[0];
+    if ((int64_t)blockIdx.x < n_chunks && n_steps > 0 && st_next.blob_floats)
+        stage_blob(k.blobs + st_next.blob_off, 0, st_next.blob_floats);
 
     for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-        const int64_t row = chunk * SX_ROWS_PER_BLOCK + wave * 32 + j;
-        const int64_t lrow = row < n_rows ? row : n_rows - 1;      // clamp loads, mask stores
+        int64_t row[NS], lrow[NS];
+#pragma unroll
+        for (int n = 0; n < NS; ++n) {
+            row[n] = chunk * ROWS_PER_BLOCK + wave * (32 * NS) + n * 32 + j;
+            lrow[n] = row[n] < n_rows ? row[n] : n_rows - 1;      // clamp loads, mask stores
+        }
         const bool has_next_chunk = chunk + gridDim.x < n_chunks;
 
         // ---- load the state tiles in C-fragment order ---------------------------------------------------
-        f32x16 xs[TX];
+        tile<NS> xs[TX];
 #pragma unroll
-        for (int t = 0; t < TX; ++t) {
-            if (t < x_tiles) {
-                if (prog.identity_cols) {
+        for (int n = 0; n < NS; ++n) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int c = 32 * t + 8 * q + 4 * h;
-                        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                        if (c + 3 < dim) {
-                            if (bf16) {
-                                const u16x4 u = *reinterpret_cast<const u16x4 *>(
-                                    reinterpret_cast<const uint16_t *>(x) + lrow * dim + c);
-                                v = f32x4{bf16_to_f32(u.x), bf16_to_f32(u.y), bf16_to_f32(u.z), bf16_to_f32(u.w)};
-                            } else {
-                                v = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(x) + lrow * dim + c);
+            for (int t = 0; t < TX; ++t) {
+                if (t < x_tiles) {
+                    if (prog.identity_cols) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int c = 32 * t + 8 * q + 4 * h;
+                            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                            if (c + 3 < dim) {
+                                if (bf16) {
+                                    const u16x4 u = *reinterpret_cast<const u16x4 *>(
+                                        reinterpret_cast<const uint16_t *>(k.x) + lrow[n] * dim + c);
+                                    v = f32x4{bf16_to_f32(u.x), bf16_to_f32(u.y), bf16_to_f32(u.z), bf16_to_f32(u.w)};
+                                } else {
+                                    v = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(k.x) + lrow[n] * dim + c);
+                                }
                             }
+                            xs[t].v[n][4 * q + 0] = v.x; xs[t].v[n][4 * q + 1] = v.y;
+                            xs[t].v[n][4 * q + 2] = v.z; xs[t].v[n][4 * q + 3] = v.w;
                         }
-                        xs[t][4 * q + 0] = v.x; xs[t][4 * q + 1] = v.y; xs[t][4 * q + 2] = v.z; xs[t][4 * q + 3] = v.w;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int c = k.in_col[32 * t + sx_kmap(r, h)];
+                            xs[t].v[n][r] = c >= 0 ? ld_elem(k.x, lrow[n] * dim + c, bf16) : 0.f;
+                        }
                     }
-                } else {
+                } else {   // latent tiles (fp32), conditioner-only inputs (coupling.py:64-65)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int c = in_col[32 * t + sx_kmap(r, h)];
-                        xs[t][r] = c >= 0 ? ld_elem(x, lrow * dim + c, bf16) : 0.f;
+                        const int c = 32 * (t - x_tiles) + sx_kmap(r, h);
+                        xs[t].v[n][r] = (k.latent != nullptr && c < prog.latent_dim) ? k.latent[lrow[n] * prog.latent_dim + c] : 0.f;
                     }
-                }
-            } else {   // latent tiles (fp32), conditioner-only inputs (coupling.py:64-65)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int c = 32 * (t - x_tiles) + sx_kmap(r, h);
-                    xs[t][r] = (latent != nullptr && c < prog.latent_dim) ? latent[lrow * prog.latent_dim + c] : 0.f;
                 }
             }
         }
 
-        float ldj = 0.f;
+        SX_STAMP(pf, 0);     // chunk prologue: x loads issued (not yet waited for)
+        float ldj[NS];
+#pragma unroll
+        for (int n = 0; n < NS; ++n) ldj[n] = 0.f;
         float ldj_c = 0.f;
-        f32x16 hid[MODE == 1 ? HT : 1];
-        f32x16 xnew[MODE == 2 ? TX : 1];
+        tile<NS> hid[MODE == 1 ? HT : 1];
+        tile<NS> xnew[MODE == 2 ? TX : 1];
 
         for (int s = 0; s < n_steps; ++s) {
             // (1) this step's weights were issued one step ago (or in the prologue): wait for MY pieces, then
             //     the barrier makes every wave's pieces visible AND guarantees all waves left step s-1,
             //     i.e. nobody still reads buffer cur^1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            // (2) refill buffer cur^1 with the next step's weights; the DMA flies under this step's MFMAs.
+            if (!SX_DBG(2)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            SX_STAMP(pf, 1);     // wait for weights + barrier
+            // (2) refill buffer cur^1 with the next step's weights (the DMA flies under this step's MFMAs)
+            //     and fetch the next step's descriptor one step early.
+            const dstep st = st_next;
             const int nxt = (s + 1 < n_steps) ? s + 1 : 0;
-            if ((s + 1 < n_steps || has_next_chunk) && prog.steps[nxt].blob_floats)
-                stage_blob(blobs + prog.steps[nxt].blob_off, (cur ^ 1) * buf_floats, prog.steps[nxt].blob_floats);
+            st_next = prog.steps[nxt];
+            if ((s + 1 < n_steps || has_next_chunk) && st_next.blob_floats && !SX_DBG(1))
+                stage_blob(k.blobs + st_next.blob_off, (cur ^ 1) * buf_floats, st_next.blob_floats);
 
-            const dstep st = prog.steps[s];
             const int base = cur * buf_floats;
+            SX_STAMP(pf, 2);     // descriptor + DMA issue
             switch (st.kind) {
                 case SX_STEP_COUPLING_AFFINE:
                     if constexpr (TX >= 2) {
                         if (st.ct == TX / 2 && st.c0 == 0 && st.t0 == TX / 2) {          // cond = low tiles
-                            coupling_affine<TX, HT, 0, TX / 2, TX / 2, TX / 2>(xs, base, st, ldj, lane);
+                            coupling_affine<NS, TX, HT, 0, TX / 2, TX / 2, TX / 2>(xs, base, st, ldj, lane, pf);
                             break;
                         }
                         if (st.ct == TX / 2 && st.c0 == TX / 2 && st.t0 == 0) {          // cond = high tiles
-                            coupling_affine<TX, HT, TX / 2, TX / 2, 0, TX / 2>(xs, base, st, ldj, lane);
+                            coupling_affine<NS, TX, HT, TX / 2, TX / 2, 0, TX / 2>(xs, base, st, ldj, lane, pf);
                             break;
                         }
                     }
-                    coupling_affine<TX, HT, 0, TX, 0, TX>(xs, base, st, ldj, lane);       // dense
+                    coupling_affine<NS, TX, HT, 0, TX, 0, TX>(xs, base, st, ldj, lane, pf);       // dense
                     break;
                 case SX_STEP_AFFINE_CONST:
-                    affine_const<TX>(xs, base, st, x_tiles, ldj, lane);
+                    affine_const<NS, TX>(xs, base, st, x_tiles, ldj, lane);
                     break;
                 case SX_STEP_MLP_HIDDEN:
-                    if constexpr (MODE == 1) hidden_from_state<TX, HT, 0, TX>(xs, hid, base, st.act, lane);
+                    if constexpr (MODE == 1) {
+                        hidden_layer<NS, TX, HT, 0, TX>(xs, hid, base, st.act, lane);
+                        if (st.act == SX_ACT_TANH) tanh_tile<NS>(hid[HT - 1]);
+                    }
                     break;
                 case SX_STEP_MLP_HIDDEN2:
                     if constexpr (MODE == 1) {
-                        f32x16 nh[HT];
-                        const int bias = base + HT * HT * 1024;
-#pragma unroll
-                        for (int m = 0; m < HT; ++m) {
-                            f32x16 acc = load_cfrag(bias + m * 32, h);
-#pragma unroll
-                            for (int c = 0; c < HT; ++c) acc = gemm_tile(base + (m * HT + c) * 1024, hid[c], acc, lane);
-                            activate(acc, st.act);
-                            nh[m] = acc;
-                        }
+                        tile<NS> nh[HT];
+                        hidden_layer<NS, HT, HT, 0, HT>(hid, nh, base, st.act, lane);
+                        if (st.act == SX_ACT_TANH) tanh_tile<NS>(nh[HT - 1]);
 #pragma unroll
                         for (int m = 0; m < HT; ++m) hid[m] = nh[m];
                     }
                     break;
                 case SX_STEP_MLP_OUT_TILE:
                     if constexpr (MODE == 1) {
-                        f32x16 acc = load_cfrag(base + HT * 1024, h);
+                        tile<NS> acc = load_cfrag<NS>(base + HT * 1024, h);
 #pragma unroll
-                        for (int c = 0; c < HT; ++c) acc = gemm_tile(base + c * 1024, hid[c], acc, lane);
-                        if (row < n_rows) {
+                        for (int c = 0; c < HT; ++c) gemm_tile<NS>(base + c * 1024, make_btile<NS>(hid[c]), acc, lane);
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const int c = 32 * st.t0 + 8 * q + 4 * h;
-                                float *o = mlp_out + row * mlp_out_stride + c;
-                                if (c + 3 < mlp_out_dim && (mlp_out_stride & 3) == 0) {
-                                    *reinterpret_cast<f32x4 *>(o) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-                                } else {
+                        for (int n = 0; n < NS; ++n) {
+                            if (row[n] < n_rows) {
 #pragma unroll
-                                    for (int e = 0; e < 4; ++e)
-                                        if (c + e < mlp_out_dim) o[e] = acc[4 * q + e];
+                                for (int q = 0; q < 4; ++q) {
+                                    const int c = 32 * st.t0 + 8 * q + 4 * h;
+                                    float *o = k.mlp_out + row[n] * k.mlp_out_stride + c;
+                                    if (c + 3 < k.mlp_out_dim && (k.mlp_out_stride & 3) == 0) {
+                                        *reinterpret_cast<f32x4 *>(o) = f32x4{acc.v[n][4 * q], acc.v[n][4 * q + 1],
+                                                                              acc.v[n][4 * q + 2], acc.v[n][4 * q + 3]};
+                                    } else {
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e)
+                                            if (c + e < k.mlp_out_dim) o[e] = acc.v[n][4 * q + e];
+                                    }
                                 }
                             }
                         }
@@ -315,9 +570,9 @@ __global__ __launch_bounds__(256, 2) void flow_fused_kernel(
                     // one 32-row slab of y = M . x + b (AffineLU affine.py:157,159-163; MatrixExponential
                     // affine.py:243-270 with the triangular solves folded into M on the host, in fp64)
                     if constexpr (MODE == 2) {
-                        f32x16 acc = load_cfrag(base + TX * 1024, h);
+                        tile<NS> acc = load_cfrag<NS>(base + TX * 1024, h);
 #pragma unroll
-                        for (int c = 0; c < TX; ++c) acc = gemm_tile(base + c * 1024, xs[c], acc, lane);
+                        for (int c = 0; c < TX; ++c) gemm_tile<NS>(base + c * 1024, make_btile<NS>(xs[c]), acc, lane);
 #pragma unroll
                         for (int t = 0; t < TX; ++t)
                             if (t == st.t0) xnew[t] = acc;
@@ -331,109 +586,146 @@ __global__ __launch_bounds__(256, 2) void flow_fused_kernel(
                 case SX_STEP_ROW_SCALE_EXP:
                     // x *= exp(+-diag * t_row)  (affine.py:263), t_row optionally log1p|t| (affine.py:239-240)
                     if constexpr (MODE == 2) {
-                        float tr = row_t != nullptr ? row_t[lrow] : st.ldj_const;
-                        if (st.act) tr = log1pf(fabsf(tr));
-                        const float sg = st.reverse ? -tr : tr;
-                        float sd = 0.f;
 #pragma unroll
-                        for (int t = 0; t < TX; ++t) {
-                            if (t < x_tiles) {
-                                const f32x16 dg = load_cfrag(base + t * 32, h);
+                        for (int n = 0; n < NS; ++n) {
+                            float tr = k.row_t != nullptr ? k.row_t[lrow[n]] : st.ldj_const;
+                            if (st.act) tr = log1pf(fabsf(tr));
+                            const float sg = st.reverse ? -tr : tr;
+                            float sd = 0.f;
 #pragma unroll
-                                for (int r = 0; r < 16; ++r) {
-                                    xs[t][r] *= fast_exp(dg[r] * sg);
-                                    sd += dg[r];
+                            for (int t = 0; t < TX; ++t) {
+                                if (t < x_tiles) {
+                                    const f32x16 dg = load_cfrag1(base + t * 32, h);
+#pragma unroll
+                                    for (int r = 0; r < 16; ++r) {
+                                        xs[t].v[n][r] *= fast_exp(dg[r] * sg);
+                                        sd += dg[r];
+                                    }
                                 }
                             }
+                            ldj[n] += st.ldj_scale * sd * tr;
                         }
-                        ldj += st.ldj_scale * sd * tr;
                     }
                     break;
                 default: break;
             }
             if (st.kind != SX_STEP_ROW_SCALE_EXP) ldj_c += st.ldj_const;
             cur ^= 1;
+            SX_STAMP(pf, 6);     // step tail
         }
 
         // ---- epilogue: outputs -----------------------------------------------------------------------------
-        if (y != nullptr && row < n_rows) {
 #pragma unroll
-            for (int t = 0; t < TX; ++t) {
-                if (t < x_tiles) {
-                    if (prog.identity_cols) {
+        for (int n = 0; n < NS; ++n) {
+            if (k.y != nullptr && row[n] < n_rows) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int c = 32 * t + 8 * q + 4 * h;
-                            if (c + 3 < dim) {
-                                if (bf16) {
-                                    u16x4 u{f32_to_bf16(xs[t][4 * q]), f32_to_bf16(xs[t][4 * q + 1]),
-                                            f32_to_bf16(xs[t][4 * q + 2]), f32_to_bf16(xs[t][4 * q + 3])};
-                                    *reinterpret_cast<u16x4 *>(reinterpret_cast<uint16_t *>(y) + row * dim + c) = u;
-                                } else {
-                                    *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(y) + row * dim + c) =
-                                        f32x4{xs[t][4 * q], xs[t][4 * q + 1], xs[t][4 * q + 2], xs[t][4 * q + 3]};
+                for (int t = 0; t < TX; ++t) {
+                    if (t < x_tiles) {
+                        if (prog.identity_cols) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int c = 32 * t + 8 * q + 4 * h;
+                                if (c + 3 < dim) {
+                                    const f32x16 &v = xs[t].v[n];
+                                    if (bf16) {
+                                        u16x4 u{f32_to_bf16(v[4 * q]), f32_to_bf16(v[4 * q + 1]), f32_to_bf16(v[4 * q + 2]),
+                                                f32_to_bf16(v[4 * q + 3])};
+                                        *reinterpret_cast<u16x4 *>(reinterpret_cast<uint16_t *>(k.y) + row[n] * dim + c) = u;
+                                    } else {
+                                        *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(k.y) + row[n] * dim + c) =
+                                            f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+                                    }
                                 }
                             }
-                        }
-                    } else {
+                        } else {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int c = out_col[32 * t + sx_kmap(r, h)];
-                            if (c >= 0) st_elem(y, row * dim + c, xs[t][r], bf16);
+                            for (int r = 0; r < 16; ++r) {
+                                const int c = k.out_col[32 * t + sx_kmap(r, h)];
+                                if (c >= 0) st_elem(k.y, row[n] * dim + c, xs[t].v[n][r], bf16);
+                            }
                         }
                     }
                 }
             }
-        }
-        if (ldj_out != nullptr || logp_out != nullptr || sum_out != nullptr) {
-            float sq = 0.f;
-            if (logp_out != nullptr) {
+            if (k.ldj_out != nullptr || k.logp_out != nullptr || k.sum_out != nullptr) {
+                float sq = 0.f;
+                if (k.logp_out != nullptr) {
 #pragma unroll
-                for (int t = 0; t < TX; ++t)
-                    if (t < x_tiles) {
+                    for (int t = 0; t < TX; ++t)
+                        if (t < x_tiles) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) sq += xs[t][r] * xs[t][r];
-                    }
-            }
-            const float part_lp = ldj - 0.5f * sq;
-            const float tot = part_lp + __shfl_xor(part_lp, 32, 64);   // the two lane halves of one sample
-            const float ldj_tot = ldj + __shfl_xor(ldj, 32, 64) + ldj_c;
-            const float lp = tot + ldj_c - (float)dim * SX_HALF_LOG_2PI;
-            if (row < n_rows && h == 0) {
-                if (ldj_out != nullptr) ldj_out[row] = ldj_tot;
-                if (logp_out != nullptr) logp_out[row] = lp;
-                block_sum += (double)(logp_out != nullptr ? lp : ldj_tot);
+                            for (int r = 0; r < 16; ++r) sq += xs[t].v[n][r] * xs[t].v[n][r];
+                        }
+                }
+                const float part_lp = ldj[n] - 0.5f * sq;
+                const float tot = part_lp + __shfl_xor(part_lp, 32, 64);   // the two lane halves of one sample
+                const float ldj_tot = ldj[n] + __shfl_xor(ldj[n], 32, 64) + ldj_c;
+                const float lp = tot + ldj_c - (float)dim * SX_HALF_LOG_2PI;
+                if (row[n] < n_rows && h == 0) {
+                    if (k.ldj_out != nullptr) k.ldj_out[row[n]] = ldj_tot;
+                    if (k.logp_out != nullptr) k.logp_out[row[n]] = lp;
+                    block_sum += (double)(k.logp_out != nullptr ? lp : ldj_tot);
+                }
             }
         }
+        SX_STAMP(pf, 7);         // chunk epilogue
     }
 
-    if (sum_out != nullptr) {
+#ifdef SX_DEBUG_KNOBS
+    SX_STAMP(pf, 7);             // epilogue of the last chunk
+    if (blockIdx.x == 3 && threadIdx.x == 64)
+        for (int i = 0; i < 16; ++i) g_sx_prof[i] = pf.acc[i];
+#endif
+    if (k.sum_out != nullptr) {
         double *part = reinterpret_cast<double *>(smem);   // no second __shared__ object beside the DMA ring
         block_sum = wave_sum_f64(block_sum);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (lane == 0) part[wave] = block_sum;
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(sum_out, (part[0] + part[1]) + (part[2] + part[3]));
+        if (threadIdx.x == 0) atomicAdd(k.sum_out, (part[0] + part[1]) + (part[2] + part[3]));
     }
 }
 
-
 template <int TX, int HT>
 static int sx_flow_launch_impl(const sx_flow_args &a) {
+#ifdef SX_DEBUG_KNOBS
+    {
+        const char *e = getenv("SX_DBG");
+        int v = e ? atoi(e) : 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sx_dbg), &v, sizeof(int));
+    }
+#endif
+    constexpr int NS = SX_NS_FOR(TX);
+    flow_kargs k;
+    k.blobs = a.blobs; k.x = a.x; k.latent = a.latent; k.in_col = a.in_col; k.out_col = a.out_col; k.y = a.y;
+    k.ldj_out = a.ldj_out; k.logp_out = a.logp_out; k.sum_out = a.sum_out; k.mlp_out = a.mlp_out; k.row_t = a.row_t;
+    k.mlp_out_stride = a.mlp_out_stride; k.n_rows = a.n_rows; k.mlp_out_dim = a.mlp_out_dim;
+    k.buf_floats = a.buf_floats; k.bf16 = a.bf16; k.pad = 0;
 #define SX_FL(MD)                                                                                              \
     do {                                                                                                       \
-        auto k = flow_fused_kernel<TX, HT, MD>;                                                                \
+        auto kern = flow_fused_kernel<NS, TX, HT, MD>;                                                         \
         if (a.lds > 48 * 1024) {                                                                               \
-            hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, a.lds); \
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, a.lds); \
             if (e != hipSuccess) { sx_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
         }                                                                                                      \
-        hipLaunchKernelGGL(k, dim3(a.grid), dim3(256), a.lds, a.stream, a.prog, a.blobs, a.x, a.latent, a.in_col, \
-                           a.out_col, a.y, a.ldj_out, a.logp_out, a.sum_out, a.mlp_out, a.mlp_out_stride,      \
-                           a.mlp_out_dim, a.n_rows, a.buf_floats, a.bf16, a.row_t);                                     \
+        hipLaunchKernelGGL(kern, dim3(a.grid), dim3(256), a.lds, a.stream, a.prog, k);                         \
     } while (0)
     if (a.mlp_mode == 1) SX_FL(1); else if (a.mlp_mode == 2) SX_FL(2); else SX_FL(0);
 #undef SX_FL
     SX_LAUNCH_CHECK();
+#ifdef SX_DEBUG_KNOBS
+    if (getenv("SX_PROF")) {
+        (void)hipStreamSynchronize(a.stream);
+        unsigned long long p[16];
+        (void)hipMemcpyFromSymbol(p, HIP_SYMBOL(g_sx_prof), sizeof(p));
+        static const char *names[8] = {"chunk-prologue", "wait+barrier", "desc+dma-issue", "gemm1", "gemm2", "affine", "step-tail", "epilogue"};
+        unsigned long long tot = 0;
+        for (int i = 0; i < 8; ++i) tot += p[i];
+        fprintf(stderr, "[sx prof] wave 1 of block 3, cycles:");
+        for (int i = 0; i < 8; ++i) fprintf(stderr, " %s=%llu (%.1f%%)", names[i], p[i], 100.0 * p[i] / (tot ? tot : 1));
+        fprintf(stderr, " total=%llu\n", tot);
+    }
+#endif
     return SX_OK;
 }

@@ -23,6 +23,15 @@ struct sx_flow_args {
 };
 
 
+// sample tiles (of 32 rows) per wave: 2 while the state fits the register file twice over, else 1
+// (measured on cfg 2, MI355X: 2 sample tiles per wave buy nothing over 1 at 2 workgroups per CU -- 1.87e9 rows/s
+// either way -- and cost registers, so 1 is the default; -DSX_NS_OVERRIDE=2 rebuilds the 64-rows-per-wave form)
+#ifdef SX_NS_OVERRIDE
+#define SX_NS_FOR(TX) (SX_NS_OVERRIDE)
+#else
+#define SX_NS_FOR(TX) 1
+#endif
+
 #define SX_DECL_FLOW(T, H) int sx_flow_launch_t##T##h##H(const sx_flow_args &a);
 SX_DECL_FLOW(1, 1) SX_DECL_FLOW(1, 2) SX_DECL_FLOW(1, 4)
 SX_DECL_FLOW(2, 1) SX_DECL_FLOW(2, 2) SX_DECL_FLOW(2, 4)

@@ -10,6 +10,15 @@
 
 __host__ __device__ static inline int sx_kmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// 0: exact fp32 MFMA fragments; 1: fp16 x 3 split fragments (the library is built for one of them)
+extern "C" int sx_fragment_mode(void) {
+#ifdef SX_F16X3
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 extern "C" size_t sx_packed_linear_floats(int32_t m_tiles, int32_t k_tiles) {
     return (size_t)m_tiles * k_tiles * 1024 + (size_t)m_tiles * 32;
 }
@@ -18,7 +27,9 @@ __global__ __launch_bounds__(256) void pack_linear_kernel(const float *__restric
                                                           int out_dim, int in_dim,
                                                           const int32_t *__restrict__ row_idx,
                                                           const int32_t *__restrict__ col_idx, int m_tiles,
-                                                          int k_tiles, float *__restrict__ dst) {
+                                                          int k_tiles, const float *__restrict__ row_scale,
+                                                          const float *__restrict__ bias_scale, float fold_ones,
+                                                          int frag_mode, float *__restrict__ dst) {
     const int n_a = m_tiles * k_tiles * 1024;
     const int total = n_a + m_tiles * 32;
     for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gridDim.x * blockDim.x) {
@@ -30,13 +41,43 @@ __global__ __launch_bounds__(256) void pack_linear_kernel(const float *__restric
             const int kt = mk % k_tiles, m = mk / k_tiles;
             const int row = row_idx[32 * m + (lane & 31)];
             const int col = col_idx[32 * kt + sx_kmap(4 * g + e, lane >> 5)];
-            if (row >= 0 && col >= 0) v = W[(int64_t)row * in_dim + col];
+            if (frag_mode == 0) {
+                if (row >= 0 && col >= 0) v = W[(int64_t)row * in_dim + col] * (row_scale ? row_scale[32 * m + (lane & 31)] : 1.f);
+            } else {
+                // fp16 x 3 split fragments for v_mfma_f32_32x32x16_f16: [s(2)][hi,lo][lane][8 halfs];
+                // this float holds halfs j = 2q, 2q+1 of k16-step s (k slot = kmap(8s + j, lane>>5)).
+                const int q = e, part = g & 1, s16 = g >> 1;
+                uint32_t bits = 0;
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = 2 * q + jj;
+                    const int col2 = col_idx[32 * kt + sx_kmap(8 * s16 + j, lane >> 5)];
+                    float w = 0.f;
+                    if (row >= 0 && col2 >= 0) w = W[(int64_t)row * in_dim + col2] * (row_scale ? row_scale[32 * m + (lane & 31)] : 1.f);
+                    const _Float16 hi = (_Float16)w;
+                    const _Float16 lo = (_Float16)(w - (float)hi);
+                    const _Float16 pick = part ? lo : hi;
+                    bits |= (uint32_t)__builtin_bit_cast(uint16_t, pick) << (16 * jj);
+                }
+                v = __uint_as_float(bits);
+            }
         } else {
             // bias[m][h][r]
             const int q = o - n_a;
             const int r = q & 15, h = (q >> 4) & 1, m = q >> 5;
-            const int row = row_idx[32 * m + sx_kmap(r, h)];
-            if (row >= 0 && b != nullptr) v = b[row];
+            const int slot = 32 * m + sx_kmap(r, h);
+            const int row = row_idx[slot];
+            if (row >= 0) {
+                double acc = b != nullptr ? (double)b[row] : 0.0;
+                if (fold_ones != 0.f) {          // b' = b + fold * sum over the live input slots of W[row][.]
+                    double rs = 0.0;
+                    for (int c = 0; c < 32 * k_tiles; ++c) {
+                        const int col = col_idx[c];
+                        if (col >= 0) rs += (double)W[(int64_t)row * in_dim + col];
+                    }
+                    acc += (double)fold_ones * rs;
+                }
+                v = (float)(acc * (bias_scale ? (double)bias_scale[slot] : 1.0));
+            }
         }
         dst[o] = v;
     }
@@ -44,13 +85,15 @@ __global__ __launch_bounds__(256) void pack_linear_kernel(const float *__restric
 
 extern "C" int sx_pack_linear(const float *W, const float *b, int32_t out_dim, int32_t in_dim,
                               const int32_t *row_idx, const int32_t *col_idx, int32_t m_tiles, int32_t k_tiles,
-                              float *dst, void *stream) {
+                              const float *row_scale, const float *bias_scale, float fold_ones, float *dst,
+                              void *stream) {
+    const int frag_mode = sx_fragment_mode();
     SX_REQUIRE(W && row_idx && col_idx && dst, "sx_pack_linear: null pointer");
     SX_REQUIRE(m_tiles > 0 && k_tiles > 0 && out_dim > 0 && in_dim > 0, "sx_pack_linear: bad sizes");
     const int total = (int)sx_packed_linear_floats(m_tiles, k_tiles);
     const int grid = (total + 255) / 256;
     hipLaunchKernelGGL(pack_linear_kernel, dim3(grid > 1024 ? 1024 : grid), dim3(256), 0, sx_stream(stream), W, b,
-                       out_dim, in_dim, row_idx, col_idx, m_tiles, k_tiles, dst);
+                       out_dim, in_dim, row_idx, col_idx, m_tiles, k_tiles, row_scale, bias_scale, fold_ones, frag_mode, dst);
     SX_LAUNCH_CHECK();
     return SX_OK;
 }

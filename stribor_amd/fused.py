@@ -46,17 +46,27 @@ def _kmap(r: int, h: int) -> int:
 class _PackJob:
     """One sx_pack_linear call: (W, b) -> blob[dst_off : dst_off + n]."""
 
-    def __init__(self, W, b, row_idx: np.ndarray, col_idx: np.ndarray, m_tiles: int, k_tiles: int, dst_off: int):
+    def __init__(self, W, b, row_idx: np.ndarray, col_idx: np.ndarray, m_tiles: int, k_tiles: int, dst_off: int,
+                 row_scale: Optional[np.ndarray] = None, bias_scale: Optional[np.ndarray] = None,
+                 fold_ones: float = 0.0):
         self.W, self.b = W, b
         self.row_idx_host, self.col_idx_host = row_idx.astype(np.int32), col_idx.astype(np.int32)
         self.m_tiles, self.k_tiles, self.dst_off = m_tiles, k_tiles, dst_off
         self.row_idx = self.col_idx = None
+        self.row_scale_host = None if row_scale is None else row_scale.astype(np.float32)
+        self.bias_scale_host = None if bias_scale is None else bias_scale.astype(np.float32)
+        self.row_scale = self.bias_scale = None
+        self.fold_ones = float(fold_ones)
 
     def run(self, blobs: torch.Tensor) -> None:
         dev = blobs.device
         if self.row_idx is None:
             self.row_idx = torch.from_numpy(self.row_idx_host).to(dev)
             self.col_idx = torch.from_numpy(self.col_idx_host).to(dev)
+            if self.row_scale_host is not None:
+                self.row_scale = torch.from_numpy(self.row_scale_host).to(dev)
+            if self.bias_scale_host is not None:
+                self.bias_scale = torch.from_numpy(self.bias_scale_host).to(dev)
         W = self.W.detach()
         b = None if self.b is None else self.b.detach()
         if W.dtype != torch.float32 or not W.is_contiguous():
@@ -64,6 +74,7 @@ class _PackJob:
         out_dim, in_dim = W.shape
         rc = _hip.lib().sx_pack_linear(W.data_ptr(), _hip.ptr(b), out_dim, in_dim, self.row_idx.data_ptr(),
                                        self.col_idx.data_ptr(), self.m_tiles, self.k_tiles,
+                                       _hip.ptr(self.row_scale), _hip.ptr(self.bias_scale), self.fold_ones,
                                        blobs.data_ptr() + 4 * self.dst_off, _hip.stream())
         _hip.check(rc, 'sx_pack_linear')
 
@@ -92,7 +103,8 @@ class _DerivedLinearJob:
                              for (r, c, _, _) in self.targets]
         for (ri, ci), (_, _, k_tiles, off) in zip(self._dev_idx, self.targets):
             rc = _hip.lib().sx_pack_linear(W.data_ptr(), _hip.ptr(b), W.shape[0], W.shape[1], ri.data_ptr(),
-                                           ci.data_ptr(), 1, k_tiles, blobs.data_ptr() + 4 * off, _hip.stream())
+                                           ci.data_ptr(), 1, k_tiles, None, None, 0.0,
+                                           blobs.data_ptr() + 4 * off, _hip.stream())
             _hip.check(rc, 'sx_pack_linear')
 
     def params(self):
@@ -316,7 +328,28 @@ class ProgramBuilder:
         n1 = _hip.packed_linear_floats(HT, ct)
         n2 = _hip.packed_linear_floats(2 * tt, HT)
         off, n = self._alloc(n1 + n2)
-        self.jobs.append(_PackJob(W1, b1, row_idx, col_idx, HT, ct, off))
+        # Tanh hot path: fold the constants of tanh(z) = 1 - 2/(exp2(2 log2e z) + 1) and exp(x) = exp2(log2e x)
+        # into the packed weights (exact re-parametrisation; fp32 MFMA shares the VALU, so every saved VALU
+        # instruction is saved wall time):  hidden r = 1/(exp2(c z) + 1);  W2 tanh + b2 = (-2 W2) r + (b2 + W2 1).
+        folded = act == _hip.ACT_CODES['Tanh']
+        LOG2E = 1.4426950408889634
+        rs1 = bs1 = rs2 = bs2 = None
+        fold = 0.0
+        if folded:
+            kk = (-LOG2E) if reverse else LOG2E              # exp(-ls) / exp(+ls) -> exp2(kk ls)
+            rs1 = np.full(32 * HT, 2.0 * LOG2E)
+            bs1 = rs1
+            rs2 = np.empty(32 * 2 * tt)
+            bs2 = np.empty(32 * 2 * tt)
+            for t in range(tt):
+                rs2[32 * (2 * t):32 * (2 * t + 1)] = -2.0 * kk
+                bs2[32 * (2 * t):32 * (2 * t + 1)] = kk
+                rs2[32 * (2 * t + 1):32 * (2 * t + 2)] = -2.0
+                bs2[32 * (2 * t + 1):32 * (2 * t + 2)] = 1.0
+            fold = 1.0
+            act = _hip.ACT_TANH_FOLDED
+            ldj_scale = ldj_scale / kk
+        self.jobs.append(_PackJob(W1, b1, row_idx, col_idx, HT, ct, off, rs1, bs1, 0.0))
         # GEMM-2 operand: per transformed tile, 32 log_scale rows then 32 shift rows (affine.py:66)
         row2 = np.full(32 * 2 * tt, -1, dtype=np.int64)
         for t in range(tt):
@@ -327,7 +360,7 @@ class ProgramBuilder:
                     row2[32 * (2 * t + 1) + i] = D + col[p]
         col2 = np.full(32 * HT, -1, dtype=np.int64)
         col2[:hidden] = np.arange(hidden)
-        self.jobs.append(_PackJob(W2, b2, row2, col2, 2 * tt, HT, off + n1))
+        self.jobs.append(_PackJob(W2, b2, row2, col2, 2 * tt, HT, off + n1, rs2, bs2, fold))
         self.steps.append(dict(kind=_hip.STEP_COUPLING_AFFINE, c0=c0, ct=ct, t0=t0, tt=tt, reverse=int(reverse),
                                act=act, blob_off=off, blob_floats=n, ldj_scale=ldj_scale, ldj_const=0.0))
 

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Throughput of every BASELINE.json config on one MI355X (not the driver's contract bench: see bench.py).
+
+    python tools/bench_configs.py [cfg1 cfg2 cfg2_f32 cfg3 cfg4 ...] [--rows N]
+
+Prints one JSON line per config: rows/s of log_prob, ms per batch, launches per batch.
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import torch
+
+import flowdesc as fd
+import stribor_amd as st
+
+
+def timed(fn, reps=10, inner=4):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(inner):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) / inner)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+CONFIGS = {
+    'cfg1': (lambda: [{'kind': 'coupling_affine', 'dim': 2, 'hidden': [64], 'mask': 'ordered_right_half', 'latent_dim': 0}], 2, 1024, torch.float32),
+    'cfg2': (lambda: fd.cfg2_desc(), 64, 1 << 20, torch.bfloat16),
+    'cfg2_f32': (lambda: fd.cfg2_desc(), 64, 1 << 20, torch.float32),
+    'cfg3': (lambda: fd.cfg3_desc(), 64, 1 << 20, torch.float32),
+    'cfg4': (lambda: fd.cfg4_desc(), 128, 1 << 20, torch.float32),
+    'cfg2_parity': (lambda: [dict(d, mask='parity_even' if i % 2 == 0 else 'parity_odd') for i, d in enumerate(fd.cfg2_desc())], 64, 1 << 20, torch.float32),
+}
+
+
+def main():
+    names = [a for a in sys.argv[1:] if not a.startswith('--')] or list(CONFIGS)
+    rows_override = None
+    if '--rows' in sys.argv:
+        rows_override = int(sys.argv[sys.argv.index('--rows') + 1])
+    dev = torch.device('cuda', 0)
+    for name in names:
+        mk, dim, rows, dt = CONFIGS[name]
+        rows = rows_override or rows
+        torch.manual_seed(0)
+        flow = fd.build_flow(st, mk(), dim).to(dev)
+        x = torch.randn(rows, dim, device=dev).to(dt)
+        fused = flow._fused_program(True, dim, 0, dev) is not None
+        ms = timed(lambda: flow.log_prob(x))
+        lp = flow.log_prob(x)
+        print(json.dumps({'config': name, 'rows': rows, 'dim': dim, 'x_dtype': str(dt), 'fused_single_launch': fused,
+                          'ms_per_batch': ms, 'rows_per_s': rows / (ms * 1e-3), 'finite': bool(torch.isfinite(lp).all()),
+                          'mean_log_prob': lp.mean().item()}))
+
+
+if __name__ == '__main__':
+    main()
