@@ -100,7 +100,7 @@ template <int NS>
 __device__ __forceinline__ const btile<NS> &make_btile(const tile<NS> &c) { return c; }
 
 template <int NS, class F>
-__device__ __forceinline__ void gemm_tile_f(int a_off, const btile<NS> &b, tile<NS> &acc, int lane, F &&f) {
+__device__ __forceinline__ void gemm_tile_f(const char *wb, int a_off, const btile<NS> &b, tile<NS> &acc, F &&f) {
     if (SX_DBG(16)) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) f(i);
@@ -108,7 +108,7 @@ __device__ __forceinline__ void gemm_tile_f(int a_off, const btile<NS> &b, tile<
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const f32x4 a = reinterpret_cast<const f32x4 *>(smem)[(a_off >> 2) + g * 64 + lane];   // ds_read_b128
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(wb + (a_off + g * 256) * 4);   // ds_read_b128, imm offset
 #pragma unroll
         for (int n = 0; n < NS; ++n) acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.v[n][4 * g + 0], acc.v[n], 0, 0, 0);
         f(4 * g + 0);
@@ -161,7 +161,7 @@ __device__ __forceinline__ btile<NS> make_btile(const tile<NS> &c) {
     return b;
 }
 template <int NS, class F>
-__device__ __forceinline__ void gemm_tile_f(int a_off, const btile<NS> &b, tile<NS> &acc, int lane, F &&f) {
+__device__ __forceinline__ void gemm_tile_f(const char *wb, int a_off, const btile<NS> &b, tile<NS> &acc, F &&f) {
     if (SX_DBG(16)) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) f(i);
@@ -169,8 +169,8 @@ __device__ __forceinline__ void gemm_tile_f(int a_off, const btile<NS> &b, tile<
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        const u32x4 ahu = reinterpret_cast<const u32x4 *>(smem)[(a_off >> 2) + (2 * s) * 64 + lane];       // ds_read_b128
-        const u32x4 alu = reinterpret_cast<const u32x4 *>(smem)[(a_off >> 2) + (2 * s + 1) * 64 + lane];
+        const u32x4 ahu = *reinterpret_cast<const u32x4 *>(wb + (a_off + (2 * s) * 256) * 4);       // ds_read_b128, imm offset
+        const u32x4 alu = *reinterpret_cast<const u32x4 *>(wb + (a_off + (2 * s + 1) * 256) * 4);
         const h8 ah = __builtin_bit_cast(h8, ahu), al = __builtin_bit_cast(h8, alu);
         // smallest terms first
 #pragma unroll
@@ -183,17 +183,18 @@ __device__ __forceinline__ void gemm_tile_f(int a_off, const btile<NS> &b, tile<
         for (int n = 0; n < NS; ++n) acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.hi[n][s], acc.v[n], 0, 0, 0);
         f(8 * s + 6); f(8 * s + 7);
     }
+    __builtin_amdgcn_sched_barrier(0);   // keep later tiles' ds_reads from piling up ahead (register pressure)
 }
 #endif
 template <int NS>
-__device__ __forceinline__ void gemm_tile(int a_off, const btile<NS> &b, tile<NS> &acc, int lane) {
-    gemm_tile_f<NS>(a_off, b, acc, lane, [](int) {});
+__device__ __forceinline__ void gemm_tile(const char *wb, int a_off, const btile<NS> &b, tile<NS> &acc) {
+    gemm_tile_f<NS>(wb, a_off, b, acc, [](int) {});
 }
 
 // bias / per-feature constants in C-fragment order: [h][16] floats at off, replicated over the sample tiles
-__device__ __forceinline__ f32x16 load_cfrag1(int off, int h) {
+__device__ __forceinline__ f32x16 load_cfrag1(const char *cb, int off) {
     f32x16 v;
-    const f32x4 *p = reinterpret_cast<const f32x4 *>(smem) + ((off >> 2) + h * 4);
+    const f32x4 *p = reinterpret_cast<const f32x4 *>(cb + off * 4);
     const f32x4 a = p[0], b = p[1], c = p[2], d = p[3];
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
     v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
@@ -202,13 +203,16 @@ __device__ __forceinline__ f32x16 load_cfrag1(int off, int h) {
     return v;
 }
 template <int NS>
-__device__ __forceinline__ tile<NS> load_cfrag(int off, int h) {
+__device__ __forceinline__ tile<NS> load_cfrag(const char *cb, int off) {
     tile<NS> t;
-    t.v[0] = load_cfrag1(off, h);
+    t.v[0] = load_cfrag1(cb, off);
 #pragma unroll
     for (int n = 1; n < NS; ++n) t.v[n] = t.v[0];
     return t;
 }
+
+// r = 1/(exp2(z) + 1): the folded form of tanh (the weights carry its constants, see sx_pack_linear)
+__device__ __forceinline__ float fast_sig2(float v) { return __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v) + 1.0f); }
 
 __device__ __forceinline__ float act_one(float v, int act) {
     switch (act) {
@@ -243,138 +247,145 @@ __device__ __forceinline__ void activate(tile<NS> &t, int act) {
     }
 }
 
-// folded tanh (SX_ACT_TANH_FOLDED): the weights carry the constants, the kernel computes r = 1/(exp2(z') + 1)
-__device__ __forceinline__ float hid_act(float v, bool folded) {
-    return folded ? __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v) + 1.0f) : fast_tanh(v);
+// per-step LDS pointers: every weight / bias access below is `pointer + compile-time offset`, so the offsets
+// fold into the ds_read immediates and no scalar address arithmetic is issued per access
+struct wptr {
+    const char *wb;   // blob base + lane*16  (A-operand fragments, one ds_read_b128 per lane)
+    const char *cb;   // blob base + h*64     (C-fragment constants: bias, per-feature scale / shift)
+};
+__device__ __forceinline__ wptr make_wptr(int base_floats, int lane) {
+    const char *p = reinterpret_cast<const char *>(smem) + base_floats * 4;
+    return wptr{p + lane * 16, p + (lane >> 5) * 64};
 }
 
-// hidden[m] = act(W . src[C0..C0+CT) + b),  blob = pack_linear(W, HT m-tiles, CT k-tiles).
-// The activation of tile m-1 is issued between the MFMAs of tile m (tanh fast path).
-template <int NS, int NSRC, int HT, int C0, int CT>
-__device__ __forceinline__ void hidden_layer(const tile<NS> (&src)[NSRC], tile<NS> (&hid)[HT], int base, int act,
-                                             int lane) {
-    const int h = lane >> 5;
-    const int bias = base + HT * CT * 1024;
+// hidden[m] = act(W . src[C0..C0+CT) + b),  blob = pack_linear(W, HT m-tiles, CT k-tiles) at float offset OFF.
+// FOLDED: weights carry tanh's constants, the activation is r = 1/(exp2(z') + 1) (SX_ACT_TANH_FOLDED) and the
+// activation of tile m-1 is issued between the MFMAs of tile m; the LAST tile is returned un-activated so the
+// caller can hide it under its own MFMAs.  Otherwise: runtime activation `act`, applied in place.
+template <int NS, int NSRC, int HT, int C0, int CT, bool FOLDED>
+__device__ __forceinline__ void hidden_layer(const tile<NS> (&src)[NSRC], tile<NS> (&hid)[HT], const wptr w, int off,
+                                             int act) {
+    const int bias = off + HT * CT * 1024;
     btile<NS> bsrc[CT];          // B operands are formed once and reused by every output tile
 #pragma unroll
     for (int c = 0; c < CT; ++c) bsrc[c] = make_btile<NS>(src[C0 + c]);
-    if (act == SX_ACT_TANH || act == SX_ACT_TANH_FOLDED) {
-        const bool folded = act == SX_ACT_TANH_FOLDED;
-        tile<NS> acc = load_cfrag<NS>(bias, h);
+    if constexpr (FOLDED) {
+        tile<NS> acc = load_cfrag<NS>(w.cb, bias);
 #pragma unroll
-        for (int c = 0; c < CT; ++c) gemm_tile<NS>(base + c * 1024, bsrc[c], acc, lane);
+        for (int c = 0; c < CT; ++c) gemm_tile<NS>(w.wb, off + c * 1024, bsrc[c], acc);
 #pragma unroll
         for (int m = 1; m < HT; ++m) {
-            tile<NS> nxt = load_cfrag<NS>(bias + m * 32, h);
+            tile<NS> nxt = load_cfrag<NS>(w.cb, bias + m * 32);
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
                 if (c == 0)
-                    gemm_tile_f<NS>(base + (m * CT + c) * 1024, bsrc[c], nxt, lane, [&](int i) {
+                    gemm_tile_f<NS>(w.wb, off + (m * CT + c) * 1024, bsrc[c], nxt, [&](int i) {
 #pragma unroll
-                        for (int n = 0; n < NS; ++n) acc.v[n][i] = hid_act(acc.v[n][i], folded);
+                        for (int n = 0; n < NS; ++n) acc.v[n][i] = fast_sig2(acc.v[n][i]);
                     });
                 else
-                    gemm_tile<NS>(base + (m * CT + c) * 1024, bsrc[c], nxt, lane);
+                    gemm_tile<NS>(w.wb, off + (m * CT + c) * 1024, bsrc[c], nxt);
             }
             hid[m - 1] = acc;
             acc = nxt;
         }
-        hid[HT - 1] = acc;     // NOT yet activated: the caller hides this last tanh under its own MFMAs
+        hid[HT - 1] = acc;
     } else {
 #pragma unroll
         for (int m = 0; m < HT; ++m) {
-            tile<NS> acc = load_cfrag<NS>(bias + m * 32, h);
+            tile<NS> acc = load_cfrag<NS>(w.cb, bias + m * 32);
 #pragma unroll
-            for (int c = 0; c < CT; ++c) gemm_tile<NS>(base + (m * CT + c) * 1024, bsrc[c], acc, lane);
+            for (int c = 0; c < CT; ++c) gemm_tile<NS>(w.wb, off + (m * CT + c) * 1024, bsrc[c], acc);
             activate<NS>(acc, act);
             hid[m] = acc;
         }
     }
 }
-template <int NS>
-__device__ __forceinline__ void tanh_tile(tile<NS> &t, bool folded = false) {
-#pragma unroll
-    for (int n = 0; n < NS; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) t.v[n][r] = hid_act(t.v[n][r], folded);
-}
 
 // Affine coupling step (affine.py:104-109 through coupling.py:69-95), conditioner evaluated once (quirk Q2).
-template <int NS, int TX, int HT, int C0, int CT, int T0, int TT>
-__device__ __forceinline__ void coupling_affine(tile<NS> (&xs)[TX], int base, const dstep &st, float (&ldj)[NS],
-                                                int lane, prof_t &pf) {
-    const int h = lane >> 5;
-    const bool folded = st.act == SX_ACT_TANH_FOLDED;
-    const bool tanh_path = st.act == SX_ACT_TANH || folded;
+// FOLDED (the Tanh hot path): no runtime conditionals inside; REV selects (x - sh)*scale vs x*scale + sh.
+template <int NS, int TX, int HT, int C0, int CT, int T0, int TT, bool FOLDED, bool REV>
+__device__ __forceinline__ void coupling_affine(tile<NS> (&xs)[TX], const wptr w, const dstep &st, float (&ldj)[NS],
+                                                prof_t &pf) {
     tile<NS> hid[HT];
-    hidden_layer<NS, TX, HT, C0, CT>(xs, hid, base, st.act, lane);
-    SX_STAMP(pf, 3);     // GEMM-1 (+ pipelined tanh)
-    const int a2 = base + HT * CT * 1024 + HT * 32;   // pack_linear(W2: 2*TT m-tiles, HT k-tiles)
-    const int b2 = a2 + 2 * TT * HT * 1024;
-    const float sgn = folded ? 1.0f : (st.reverse ? -1.44269504088896341f : 1.44269504088896341f);
+    hidden_layer<NS, TX, HT, C0, CT, FOLDED>(xs, hid, w, 0, st.act);
+    SX_STAMP(pf, 3);     // GEMM-1 (+ pipelined activation)
+    constexpr int a2 = HT * CT * 1024 + HT * 32;   // pack_linear(W2: 2*TT m-tiles, HT k-tiles)
+    constexpr int b2 = a2 + 2 * TT * HT * 1024;
     float s[NS];
 #pragma unroll
     for (int n = 0; n < NS; ++n) s[n] = 0.f;
-    if (tanh_path && HT == 1) tanh_tile<NS>(hid[0], folded);
+    if constexpr (FOLDED && HT == 1) {
+#pragma unroll
+        for (int n = 0; n < NS; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hid[0].v[n][r] = fast_sig2(hid[0].v[n][r]);
+    }
     btile<NS> bh[HT];
 #pragma unroll
     for (int m = 0; m + 1 < HT; ++m) bh[m] = make_btile<NS>(hid[m]);
-    if (!tanh_path || HT == 1) bh[HT - 1] = make_btile<NS>(hid[HT - 1]);
+    if constexpr (!FOLDED || HT == 1) bh[HT - 1] = make_btile<NS>(hid[HT - 1]);
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
-        tile<NS> ls = load_cfrag<NS>(b2 + (2 * t) * 32, h);
-        tile<NS> sh = load_cfrag<NS>(b2 + (2 * t + 1) * 32, h);
+        tile<NS> ls = load_cfrag<NS>(w.cb, b2 + (2 * t) * 32);
+        tile<NS> sh = load_cfrag<NS>(w.cb, b2 + (2 * t + 1) * 32);
 #pragma unroll
         for (int m = 0; m + 1 < HT; ++m) {
-            if (t == 0 && m == 0 && tanh_path)        // the last hidden tile's tanh rides under this k-chunk
-                gemm_tile_f<NS>(a2 + ((2 * t) * HT + m) * 1024, bh[m], ls, lane, [&](int i) {
+            if (FOLDED && t == 0 && m == 0)        // the last hidden tile's activation rides under this k-chunk
+                gemm_tile_f<NS>(w.wb, a2 + ((2 * t) * HT + m) * 1024, bh[m], ls, [&](int i) {
 #pragma unroll
-                    for (int n = 0; n < NS; ++n) hid[HT - 1].v[n][i] = hid_act(hid[HT - 1].v[n][i], folded);
+                    for (int n = 0; n < NS; ++n) hid[HT - 1].v[n][i] = fast_sig2(hid[HT - 1].v[n][i]);
                 });
             else
-                gemm_tile<NS>(a2 + ((2 * t) * HT + m) * 1024, bh[m], ls, lane);
-            gemm_tile<NS>(a2 + ((2 * t + 1) * HT + m) * 1024, bh[m], sh, lane);
+                gemm_tile<NS>(w.wb, a2 + ((2 * t) * HT + m) * 1024, bh[m], ls);
+            gemm_tile<NS>(w.wb, a2 + ((2 * t + 1) * HT + m) * 1024, bh[m], sh);
         }
-        if (t == 0 && tanh_path && HT > 1) bh[HT - 1] = make_btile<NS>(hid[HT - 1]);   // its tanh just finished
-        gemm_tile<NS>(a2 + ((2 * t) * HT + (HT - 1)) * 1024, bh[HT - 1], ls, lane);
-        // exp(+-log_scale) rides under the shift tile's last k-chunk; ls is overwritten by the scale
-        gemm_tile_f<NS>(a2 + ((2 * t + 1) * HT + (HT - 1)) * 1024, bh[HT - 1], sh, lane, [&](int i) {
+        if (FOLDED && t == 0 && HT > 1) bh[HT - 1] = make_btile<NS>(hid[HT - 1]);   // its activation just finished
+        gemm_tile<NS>(w.wb, a2 + ((2 * t) * HT + (HT - 1)) * 1024, bh[HT - 1], ls);
+        // the scale exp(+-log_scale) rides under the shift tile's last k-chunk; ls is overwritten by it
+        const float sgn = FOLDED ? 1.0f : (REV ? -1.44269504088896341f : 1.44269504088896341f);
+        gemm_tile_f<NS>(w.wb, a2 + ((2 * t + 1) * HT + (HT - 1)) * 1024, bh[HT - 1], sh, [&](int i) {
 #pragma unroll
             for (int n = 0; n < NS; ++n) {
                 s[n] += ls.v[n][i];
-                ls.v[n][i] = __builtin_amdgcn_exp2f(ls.v[n][i] * sgn);
+                ls.v[n][i] = __builtin_amdgcn_exp2f(FOLDED ? ls.v[n][i] : ls.v[n][i] * sgn);
             }
         });
-        SX_STAMP(pf, 4);     // GEMM-2 (+ pipelined tanh / exp)
+        SX_STAMP(pf, 4);     // GEMM-2 (+ pipelined activation / exp)
         tile<NS> &x = xs[T0 + t];
-        if (st.reverse) {
 #pragma unroll
-            for (int n = 0; n < NS; ++n)
+        for (int n = 0; n < NS; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) x.v[n][r] = (x.v[n][r] - sh.v[n][r]) * ls.v[n][r];
-        } else {
-#pragma unroll
-            for (int n = 0; n < NS; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) x.v[n][r] = x.v[n][r] * ls.v[n][r] + sh.v[n][r];
-        }
+            for (int r = 0; r < 16; ++r)
+                x.v[n][r] = REV ? (x.v[n][r] - sh.v[n][r]) * ls.v[n][r] : x.v[n][r] * ls.v[n][r] + sh.v[n][r];
     }
 #pragma unroll
     for (int n = 0; n < NS; ++n) ldj[n] += st.ldj_scale * s[n];
     SX_STAMP(pf, 5);         // affine + log-det
 }
+// one runtime dispatch per step on (activation kind, direction) -> straight-line specialisations
+template <int NS, int TX, int HT, int C0, int CT, int T0, int TT>
+__device__ __forceinline__ void coupling_affine_dispatch(tile<NS> (&xs)[TX], const wptr w, const dstep &st,
+                                                         float (&ldj)[NS], prof_t &pf) {
+    if (st.act == SX_ACT_TANH_FOLDED) {
+        if (st.reverse) coupling_affine<NS, TX, HT, C0, CT, T0, TT, true, true>(xs, w, st, ldj, pf);
+        else coupling_affine<NS, TX, HT, C0, CT, T0, TT, true, false>(xs, w, st, ldj, pf);
+    } else {
+        if (st.reverse) coupling_affine<NS, TX, HT, C0, CT, T0, TT, false, true>(xs, w, st, ldj, pf);
+        else coupling_affine<NS, TX, HT, C0, CT, T0, TT, false, false>(xs, w, st, ldj, pf);
+    }
+}
 
 // Elementwise affine with per-feature constants (st.Affine without latent_net, affine.py:63-64,104-109)
 template <int NS, int TX>
-__device__ __forceinline__ void affine_const(tile<NS> (&xs)[TX], int base, const dstep &st, int x_tiles,
-                                             float (&ldj)[NS], int lane) {
-    const int h = lane >> 5;
+__device__ __forceinline__ void affine_const(tile<NS> (&xs)[TX], const wptr w, const dstep &st, int x_tiles,
+                                             float (&ldj)[NS]) {
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < TX; ++t) {
         if (t < x_tiles) {
-            const f32x16 ls = load_cfrag1(base + t * 32, h);
-            const f32x16 sh = load_cfrag1(base + (TX + t) * 32, h);
+            const f32x16 ls = load_cfrag1(w.cb, t * 32);
+            const f32x16 sh = load_cfrag1(w.cb, (TX + t) * 32);
 #pragma unroll
             for (int n = 0; n < NS; ++n) {
                 if (st.reverse) {
@@ -507,45 +518,41 @@ __global__ __launch_bounds__(256, SX_WAVES_PER_SIMD) void flow_fused_kernel(cons
             if ((s + 1 < n_steps || has_next_chunk) && st_next.blob_floats && !SX_DBG(1))
                 stage_blob(k.blobs + st_next.blob_off, (cur ^ 1) * buf_floats, st_next.blob_floats);
 
-            const int base = cur * buf_floats;
+            const wptr w = make_wptr(cur * buf_floats, lane);
             SX_STAMP(pf, 2);     // descriptor + DMA issue
             switch (st.kind) {
                 case SX_STEP_COUPLING_AFFINE:
                     if constexpr (TX >= 2) {
                         if (st.ct == TX / 2 && st.c0 == 0 && st.t0 == TX / 2) {          // cond = low tiles
-                            coupling_affine<NS, TX, HT, 0, TX / 2, TX / 2, TX / 2>(xs, base, st, ldj, lane, pf);
+                            coupling_affine_dispatch<NS, TX, HT, 0, TX / 2, TX / 2, TX / 2>(xs, w, st, ldj, pf);
                             break;
                         }
                         if (st.ct == TX / 2 && st.c0 == TX / 2 && st.t0 == 0) {          // cond = high tiles
-                            coupling_affine<NS, TX, HT, TX / 2, TX / 2, 0, TX / 2>(xs, base, st, ldj, lane, pf);
+                            coupling_affine_dispatch<NS, TX, HT, TX / 2, TX / 2, 0, TX / 2>(xs, w, st, ldj, pf);
                             break;
                         }
                     }
-                    coupling_affine<NS, TX, HT, 0, TX, 0, TX>(xs, base, st, ldj, lane, pf);       // dense
+                    coupling_affine_dispatch<NS, TX, HT, 0, TX, 0, TX>(xs, w, st, ldj, pf);       // dense
                     break;
                 case SX_STEP_AFFINE_CONST:
-                    affine_const<NS, TX>(xs, base, st, x_tiles, ldj, lane);
+                    affine_const<NS, TX>(xs, w, st, x_tiles, ldj);
                     break;
                 case SX_STEP_MLP_HIDDEN:
-                    if constexpr (MODE == 1) {
-                        hidden_layer<NS, TX, HT, 0, TX>(xs, hid, base, st.act, lane);
-                        if (st.act == SX_ACT_TANH) tanh_tile<NS>(hid[HT - 1]);
-                    }
+                    if constexpr (MODE == 1) hidden_layer<NS, TX, HT, 0, TX, false>(xs, hid, w, 0, st.act);
                     break;
                 case SX_STEP_MLP_HIDDEN2:
                     if constexpr (MODE == 1) {
                         tile<NS> nh[HT];
-                        hidden_layer<NS, HT, HT, 0, HT>(hid, nh, base, st.act, lane);
-                        if (st.act == SX_ACT_TANH) tanh_tile<NS>(nh[HT - 1]);
+                        hidden_layer<NS, HT, HT, 0, HT, false>(hid, nh, w, 0, st.act);
 #pragma unroll
                         for (int m = 0; m < HT; ++m) hid[m] = nh[m];
                     }
                     break;
                 case SX_STEP_MLP_OUT_TILE:
                     if constexpr (MODE == 1) {
-                        tile<NS> acc = load_cfrag<NS>(base + HT * 1024, h);
+                        tile<NS> acc = load_cfrag<NS>(w.cb, HT * 1024);
 #pragma unroll
-                        for (int c = 0; c < HT; ++c) gemm_tile<NS>(base + c * 1024, make_btile<NS>(hid[c]), acc, lane);
+                        for (int c = 0; c < HT; ++c) gemm_tile<NS>(w.wb, c * 1024, make_btile<NS>(hid[c]), acc);
 #pragma unroll
                         for (int n = 0; n < NS; ++n) {
                             if (row[n] < n_rows) {
@@ -570,9 +577,9 @@ __global__ __launch_bounds__(256, SX_WAVES_PER_SIMD) void flow_fused_kernel(cons
                     // one 32-row slab of y = M . x + b (AffineLU affine.py:157,159-163; MatrixExponential
                     // affine.py:243-270 with the triangular solves folded into M on the host, in fp64)
                     if constexpr (MODE == 2) {
-                        tile<NS> acc = load_cfrag<NS>(base + TX * 1024, h);
+                        tile<NS> acc = load_cfrag<NS>(w.cb, TX * 1024);
 #pragma unroll
-                        for (int c = 0; c < TX; ++c) gemm_tile<NS>(base + c * 1024, make_btile<NS>(xs[c]), acc, lane);
+                        for (int c = 0; c < TX; ++c) gemm_tile<NS>(w.wb, c * 1024, make_btile<NS>(xs[c]), acc);
 #pragma unroll
                         for (int t = 0; t < TX; ++t)
                             if (t == st.t0) xnew[t] = acc;
@@ -595,7 +602,7 @@ __global__ __launch_bounds__(256, SX_WAVES_PER_SIMD) void flow_fused_kernel(cons
 #pragma unroll
                             for (int t = 0; t < TX; ++t) {
                                 if (t < x_tiles) {
-                                    const f32x16 dg = load_cfrag1(base + t * 32, h);
+                                    const f32x16 dg = load_cfrag1(w.cb, t * 32);
 #pragma unroll
                                     for (int r = 0; r < 16; ++r) {
                                         xs[t].v[n][r] *= fast_exp(dg[r] * sg);
