@@ -11,7 +11,9 @@ UnitNormal base density, summed to one fp64 on the device and, for N > 1, all-re
 path's only exchange).  Weak scaling: every rank owns 2^20 rows (cfg 5 = 8 x 2^20).
 
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant (only) kernel of a step, the fused flow
-kernel, against the exact-fp32 MFMA peak; `roofline_elementwise` is the standalone HBM-bound affine
+kernel: algorithmic flops (98,304 per row) against the dense MFMA peak of the dtype its GEMMs
+issue in (fp16, three split products per algorithmic product; or fp32 when the library is built EXACT_F32=1);
+`roofline_elementwise` is the standalone HBM-bound affine
 coupling kernel (north_star: "achieved HBM GB/s on the element-wise path"); `cpu_baseline` is the oracle
 (a torch-CPU port that follows the reference op for op, incl. its double conditioner call) timed on this
 box's host cores on a bounded sample.
@@ -38,6 +40,7 @@ ROWS_PER_GPU = 1 << 20
 FLOPS_PER_ROW = LAYERS * 2 * (DIM // 2 * HIDDEN + HIDDEN * DIM)       # 98,304 (pruned)
 BYTES_PER_ROW = DIM * 2 + 4                                            # 132 B (bf16 x in, fp32 log_prob out)
 PEAK_F32_MFMA_TFLOPS = 157.3                                           # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+PEAK_F16_MFMA_TFLOPS = 2500.0                                          # MI355X_MICROARCH.md, dense BF16/FP16 MFMA
 PEAK_HBM_GBS = 8000.0                                                  # MI355X_MICROARCH.md, HBM3E spec
 ELEMWISE_BYTES_PER_ROW = 128 + 256 + 128 + 8                           # 520 B/row/layer (bf16 x,y)
 
@@ -148,6 +151,14 @@ def main():
         # dominant kernel: the fused flow kernel, one launch per step, timed alone by HIP events
         k_avg_ms, k_med_ms = event_ms(lambda: flow.log_prob_sum(x, out), 10)
         achieved_tflops = FLOPS_PER_ROW * ROWS_PER_GPU / (k_avg_ms * 1e-3) / 1e12
+        from stribor_amd import _hip
+        f16x3 = _hip.lib().sx_fragment_mode() == 1
+        peak = PEAK_F16_MFMA_TFLOPS if f16x3 else PEAK_F32_MFMA_TFLOPS
+        pmc = {}
+        try:      # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_cfg2.json')))
+        except Exception:
+            pass
         # standalone element-wise affine coupling kernel (params precomputed in HBM), HBM roofline
         from stribor_amd.flows.affine import run_affine_kernel
         params = torch.randn(ROWS_PER_GPU, DIM, device=dev) * 0.1
@@ -170,15 +181,25 @@ def main():
                                    'batch 2^20 per GPU, x stored bf16, fp32 arithmetic, UnitNormal base, fp64 batch sum',
                        'rows_per_gpu': ROWS_PER_GPU, 'dim': DIM, 'layers': LAYERS, 'hidden': HIDDEN,
                        'x_storage': 'bf16', 'parallelism': f'batch-sharded x{world}, one 8-byte all-reduce per step'},
-            'roofline': {'kernel': 'flow_fused_kernel<2,2,0>', 'bound': 'mfma', 'achieved': achieved_tflops,
-                         'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved_tflops / PEAK_F32_MFMA_TFLOPS,
-                         'traffic': None, 'avg_kernel_ms': k_avg_ms, 'median_kernel_ms': k_med_ms,
+            'roofline': {'kernel': 'flow_fused_kernel<NS=1,TX=2,HT=2,MODE=0>', 'bound': 'mfma',
+                         'achieved': achieved_tflops, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved_tflops / peak,
+                         'traffic': pmc.get('flow_fused_kernel', {}).get('hbm_bytes_per_launch'),
+                         'avg_kernel_ms': k_avg_ms, 'median_kernel_ms': k_med_ms,
+                         'gemm_arithmetic': ('fp16 x 3 split on v_mfma_f32_32x32x16_f16, fp32 accumulate '
+                                             '(3 MFMA products per algorithmic product)') if f16x3
+                                            else 'v_mfma_f32_32x32x2_f32 (exact fp32)',
+                         'mfma_executed_tflops': achieved_tflops * (3 if f16x3 else 1),
+                         'frac_mfma_pipe_busy': achieved_tflops * (3 if f16x3 else 1) / peak,
+                         'frac_of_exact_fp32_mfma_peak': achieved_tflops / PEAK_F32_MFMA_TFLOPS,
+                         'binding_resource': 'VALU issue (tanh/exp transcendentals + fp16 operand splitting); '
+                                             'neither HBM (3 % of peak) nor the matrix pipe binds',
                          'algorithmic_flops_per_launch': FLOPS_PER_ROW * ROWS_PER_GPU,
                          'algorithmic_bytes_per_launch': BYTES_PER_ROW * ROWS_PER_GPU,
                          'hbm_frac_of_same_kernel': BYTES_PER_ROW * ROWS_PER_GPU / (k_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
             'roofline_elementwise': {'kernel': 'affine_coupling_vec4_kernel<bf16,reverse>', 'bound': 'hbm',
                                      'achieved': e_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': e_gbs / PEAK_HBM_GBS,
-                                     'traffic': None, 'avg_kernel_ms': e_avg_ms,
+                                     'traffic': pmc.get('affine_coupling_vec4_kernel', {}).get('hbm_bytes_per_launch'),
+                                     'avg_kernel_ms': e_avg_ms,
                                      'algorithmic_bytes_per_launch': ELEMWISE_BYTES_PER_ROW * ROWS_PER_GPU},
             'log_prob_sum': total_value,
         }

@@ -61,12 +61,9 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     return SX_OK;
 }
 
-#ifndef SX_DEFAULT_BLOCKS_PER_CU
-#define SX_DEFAULT_BLOCKS_PER_CU 2
-#endif
 static int pick_grid(int64_t n_rows, int lds_bytes, int tiles) {
     int per_cu = (160 * 1024) / (lds_bytes > 0 ? lds_bytes : 1);
-    int max_per_cu = SX_DEFAULT_BLOCKS_PER_CU;
+    int max_per_cu = SX_WAVES_FOR(tiles);
     if (const char *g = getenv("SX_BLOCKS_PER_CU")) max_per_cu = atoi(g);      // experiment knob
     if (per_cu > max_per_cu) per_cu = max_per_cu;
     if (per_cu < 1) per_cu = 1;

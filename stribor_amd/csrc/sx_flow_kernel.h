@@ -422,7 +422,7 @@ struct flow_kargs {     // everything but the program, by value in the kernarg s
 // MODE 0: flow programs (coupling / affine-const steps); MODE 1: + persistent hidden state (MLP programs);
 // MODE 2: flow programs with dense linear layers (AffineLU / MatrixExponential): + a second state tile set
 template <int NS, int TX, int HT, int MODE>
-__global__ __launch_bounds__(256, SX_WAVES_PER_SIMD) void flow_fused_kernel(const dprog prog, const flow_kargs k) {
+__global__ __launch_bounds__(256, SX_WAVES_FOR(TX)) void flow_fused_kernel(const dprog prog, const flow_kargs k) {
     constexpr int ROWS_PER_BLOCK = 128 * NS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
