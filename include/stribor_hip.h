@@ -146,9 +146,14 @@ int sx_pack_linear(const float *W, const float *b, int32_t out_dim, int32_t in_d
 #define SX_STEP_MLP_HIDDEN2     6  /* blob = pack_linear(W): hidden' = act(W . hidden + b)                         */
 #define SX_STEP_MLP_OUT_TILE    7  /* blob = pack_linear(W, 1 m-tile): out[:, 32*t0 ..] = W[t0] . hidden + b       */
 #define SX_STEP_COUPLING_RQS    8  /* reserved */
+#define SX_STEP_RQS_HIDDEN      10  /* blob = pack_linear(W1, folded tanh): hidden of a spline coupling, kept for its phases */
+#define SX_STEP_RQS_PHASE       11  /* one (8-column group, parameter block) slab of a rational-quadratic spline coupling:
+                                       blob = pack_linear(W2 rows, 4 m-tiles) ++ {lo, hi}; t0 = tile, c0 = group 0..3,
+                                       ct = phase (0 search block, 1 select block, 2 derivatives + evaluate), tt = n_bins,
+                                       pad_ = live mask of the tile's 32 slots                                          */
 #define SX_STEP_ROW_SCALE_EXP    9  /* blob = diag[tiles][2][16]: state *= exp(+-diag * t_row); t_row = row_t[n] or ldj_const */
 
-#define SX_MAX_STEPS 96
+#define SX_MAX_STEPS 128
 
 typedef struct sx_step {
     int32_t  kind;        /* SX_STEP_*                                                        */

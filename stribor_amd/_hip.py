@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('STRIBOR_HIP_LIB', os.path.join(_HERE, 'libstribor_hip.so'))   # override: experiments only
 
 SX_F32, SX_BF16 = 0, 1
-SX_MAX_STEPS = 96
+SX_MAX_STEPS = 128
 
 STEP_COUPLING_AFFINE = 1
 STEP_AFFINE_CONST = 2
@@ -27,6 +27,8 @@ STEP_MLP_HIDDEN2 = 6
 STEP_MLP_OUT_TILE = 7
 STEP_COUPLING_RQS = 8
 STEP_ROW_SCALE_EXP = 9
+STEP_RQS_HIDDEN = 10
+STEP_RQS_PHASE = 11
 
 ACT_TANH_FOLDED = 9
 ACT_CODES = {'Identity': 0, 'Tanh': 1, 'ReLU': 2, 'Sigmoid': 3, 'ELU': 4, 'Softplus': 5, 'LeakyReLU': 6,

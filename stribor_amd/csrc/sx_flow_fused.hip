@@ -18,12 +18,13 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     d->n_steps = p->n_steps; d->dim = p->dim; d->latent_dim = p->latent_dim; d->x_tiles = p->x_tiles;
     d->identity_cols = p->identity_cols; d->pad = 0;
     int mx = 256;
-    bool lin = false;
+    bool lin = false, rqs = false;
     *mlp_mode = 0;
     for (int i = 0; i < p->n_steps; ++i) {
         const sx_step &s = p->steps[i];
         SX_REQUIRE(s.blob_off % 256 == 0 && s.blob_floats % 256 == 0, "sx_flow_run: step %d blob not 1 KiB aligned", i);
-        SX_REQUIRE(s.c0 >= 0 && s.ct >= 0 && s.c0 + s.ct <= p->tiles && s.t0 >= 0 && s.tt >= 0, "sx_flow_run: step %d bad tiles", i);
+        SX_REQUIRE(s.kind == SX_STEP_RQS_PHASE || (s.c0 >= 0 && s.ct >= 0 && s.c0 + s.ct <= p->tiles && s.t0 >= 0 && s.tt >= 0),
+                   "sx_flow_run: step %d bad tiles", i);
         size_t need = 0;
         switch (s.kind) {
             case SX_STEP_COUPLING_AFFINE: {
@@ -45,6 +46,18 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
                 SX_REQUIRE(s.t0 < p->x_tiles, "sx_flow_run: step %d: linear slab %d out of range", i, s.t0);
                 need = sx_packed_linear_floats(1, p->tiles); lin = true; break;
             case SX_STEP_ROW_SCALE_EXP: need = 32 * p->tiles; lin = true; break;
+            case SX_STEP_RQS_HIDDEN: {
+                const int T = p->tiles;
+                const bool low = T >= 2 && s.c0 == 0 && s.ct == T / 2;
+                const bool high = T >= 2 && s.c0 == T / 2 && s.ct == T / 2;
+                const bool dense = s.c0 == 0 && s.ct == T;
+                SX_REQUIRE(low || high || dense, "sx_flow_run: step %d: RQS conditioner tiles must be low/high halves or dense", i);
+                need = sx_packed_linear_floats(p->h_tiles, s.ct); rqs = true; break;
+            }
+            case SX_STEP_RQS_PHASE:
+                SX_REQUIRE(s.t0 < p->x_tiles && s.c0 >= 0 && s.c0 < 4 && s.ct >= 0 && s.ct < 3 && s.tt >= 1 && s.tt <= 16,
+                           "sx_flow_run: step %d: bad RQS phase (tile %d group %d phase %d bins %d)", i, s.t0, s.c0, s.ct, s.tt);
+                need = sx_packed_linear_floats(4, p->h_tiles) + 4; rqs = true; break;
             default: sx_set_error("sx_flow_run: step %d has unsupported kind %d", i, s.kind); return SX_E_UNSUPPORTED;
         }
         SX_REQUIRE(s.blob_floats >= need, "sx_flow_run: step %d blob too small (%u < %zu floats)", i, s.blob_floats, need);
@@ -53,10 +66,13 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
         o.kind = (uint8_t)s.kind; o.c0 = (uint8_t)s.c0; o.ct = (uint8_t)s.ct; o.t0 = (uint8_t)s.t0; o.tt = (uint8_t)s.tt;
         o.reverse = (uint8_t)(s.reverse != 0); o.act = (uint8_t)s.act; o.pad = 0;
         o.blob_off = s.blob_off; o.blob_floats = s.blob_floats; o.ldj_scale = s.ldj_scale; o.ldj_const = s.ldj_const;
+        o.mask = (uint32_t)s.pad_;
     }
     *buf_floats = mx;
     SX_REQUIRE(!(lin && *mlp_mode), "sx_flow_run: linear steps cannot be mixed with MLP-output steps");
     if (lin) *mlp_mode = 2;
+    SX_REQUIRE(!(rqs && (lin || *mlp_mode == 1)), "sx_flow_run: spline steps cannot be mixed with linear / MLP-output steps");
+    if (rqs) *mlp_mode = 3;
     SX_REQUIRE((size_t)mx * 8 <= 160 * 1024, "sx_flow_run: a step needs %d B of LDS per buffer (> 80 KiB)", mx * 4);
     return SX_OK;
 }

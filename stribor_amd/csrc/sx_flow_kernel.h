@@ -404,6 +404,204 @@ __device__ __forceinline__ void affine_const(tile<NS> (&xs)[TX], const wptr w, c
     for (int n = 0; n < NS; ++n) ldj[n] += st.ldj_scale * s;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Rational-quadratic spline coupling, fused (util/rational_quadratic_spline.py:11-251 + search_sorted.py).
+// A layer is 1 RQS_HIDDEN step + 12 RQS_PHASE steps per transformed tile: the tile's 32 columns are handled in
+// 4 groups of 8; per group three parameter blocks (the SEARCH block whose knots bracket the input, the SELECT
+// block evaluated at the found bin, the derivatives) arrive as 4 MFMA output tiles each, laid out so that every
+// lane receives, in 16 registers, the 16 parameters of 4 of its own elements (row 8q + 4h + i of output tile u
+// = parameter 4u + i of the lane-half-h element q): the 12 GiB [N, D*(3K-1)] parameter tensor of the
+// reference (spline.py:82-86) only ever exists 64 registers at a time.
+// ------------------------------------------------------------------------------------------------
+#define RQS_MIN 1e-3f
+struct rqs_elems {          // the 4 elements of the current group a lane owns
+    float x[4];             // input values
+    float a_b[4], a_w[4];   // searched sequence: knot at the bin, bin size
+    float c_b[4], c_w[4];   // selected sequence: knot at the bin, bin size
+    int b[4];               // bin index
+    bool in[4];             // inside the (input-side) interval
+};
+
+template <int HT>
+__device__ __forceinline__ void rqs_gemm(const wptr w, const btile<1> (&bh)[HT], tile<1> (&acc)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        acc[u] = load_cfrag<1>(w.cb, 4 * HT * 1024 + u * 32);
+#pragma unroll
+        for (int m = 0; m < HT; ++m) gemm_tile<1>(w.wb, (u * HT + m) * 1024, bh[m], acc[u]);
+    }
+}
+// parameter k (0..15) of element q: register 4q + (k & 3) of output tile k >> 2
+#define RQS_P(acc, q, k) (acc)[(k) >> 2].v[0][4 * (q) + ((k) & 3)]
+
+// softmax numerators in place + the factor that turns them into bin sizes: size_k = MIN + e_k * inv
+template <int Q>
+__device__ __forceinline__ float rqs_softmax(tile<1> (&acc)[4], int K) {
+    float mx = RQS_P(acc, Q, 0);
+#pragma unroll
+    for (int k = 1; k < 16; ++k)
+        if (k < K) mx = fmaxf(mx, RQS_P(acc, Q, k));
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (k < K) {
+            const float e = fast_exp(RQS_P(acc, Q, k) - mx);
+            RQS_P(acc, Q, k) = e;
+            sum += e;
+        }
+    return (1.f - RQS_MIN * (float)K) * fast_rcp(sum);         // :101-105
+}
+
+// phase 0: knots of the searched block (:180-192) and the bin search (search_sorted.py:4-5) in one sweep
+template <int Q>
+__device__ __forceinline__ void rqs_search(tile<1> (&acc)[4], rqs_elems &e, int K, float lo, float hi) {
+    const float xv = e.x[Q];
+    e.in[Q] = (xv >= lo) && (xv <= hi);                       // :71 closed interval
+    const float xin = e.in[Q] ? xv : lo;
+    const float inv = rqs_softmax<Q>(acc, K);
+    int b = 0;
+    float k_b = lo, k_n = hi, cs = 0.f;
+    bool have = false;
+#pragma unroll
+    for (int j = 1; j <= 16; ++j) {
+        if (j <= K) {
+            cs += RQS_MIN + RQS_P(acc, Q, j - 1) * inv;
+            const float knot = (j < K) ? (hi - lo) * cs + lo : hi;       // ends pinned
+            const bool ge = xin >= ((j < K) ? knot : knot + 1e-6f);
+            if (ge && j < K) { b = j; k_b = knot; }
+            else if (!ge && !have) { k_n = knot; have = true; }
+        }
+    }
+    e.b[Q] = b;
+    e.a_b[Q] = k_b;
+    e.a_w[Q] = k_n - k_b;
+}
+// phase 1: knots of the other block at the found bin
+template <int Q>
+__device__ __forceinline__ void rqs_select(tile<1> (&acc)[4], rqs_elems &e, int K, float lo, float hi) {
+    const float inv = rqs_softmax<Q>(acc, K);
+    const int b = e.b[Q];
+    float k_b = lo, k_n = hi, cs = 0.f;
+#pragma unroll
+    for (int j = 1; j <= 16; ++j) {
+        if (j <= K) {
+            cs += RQS_MIN + RQS_P(acc, Q, j - 1) * inv;
+            const float knot = (j < K) ? (hi - lo) * cs + lo : hi;
+            if (j == b) k_b = knot;
+            if (j == b + 1) k_n = knot;
+        }
+    }
+    e.c_b[Q] = k_b;
+    e.c_w[Q] = k_n - k_b;
+}
+__device__ __forceinline__ float rqs_softplus(float v) { return v > 20.f ? v : log1pf(expf(v)); }
+// phase 2: the two knot derivatives at the bin (:107,:206-207), then the rational-quadratic (:236-248) or its
+// inverse (:212-234; the returned log-derivative is already negated like the reference's).
+template <int Q, bool REV>
+__device__ __forceinline__ void rqs_eval(tile<1> (&acc)[4], const rqs_elems &e, int K, float &out, float &ljd) {
+    const int b = e.b[Q];
+    const float cst = logf(expf(1.f - RQS_MIN) - 1.f);          // :81 boundary derivative constant
+    float r_b = cst, r_n = cst;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) {
+        if (k < K - 1) {
+            const float v = RQS_P(acc, Q, k);
+            if (k == b - 1) r_b = v;
+            if (k == b) r_n = v;
+        }
+    }
+    const float d_b = RQS_MIN + rqs_softplus(r_b), d_n = RQS_MIN + rqs_softplus(r_n);
+    // REV: the searched block is the heights (codomain side), the selected one the widths
+    const float cw_b = REV ? e.c_b[Q] : e.a_b[Q], w_b = REV ? e.c_w[Q] : e.a_w[Q];
+    const float ch_b = REV ? e.a_b[Q] : e.c_b[Q], h_b = REV ? e.a_w[Q] : e.c_w[Q];
+    const float s_b = h_b / w_b;
+    const float xin = e.in[Q] ? e.x[Q] : (REV ? ch_b : cw_b);
+    if constexpr (REV) {
+        const float dy = xin - ch_b;
+        const float q = d_b + d_n - 2.f * s_b;
+        const float a = dy * q + h_b * (s_b - d_b);
+        const float bb = h_b * d_b - dy * q;
+        const float c = -s_b * dy;
+        const float disc = bb * bb - 4.f * a * c;
+        const float root = (2.f * c) / (-bb - sqrtf(disc));
+        out = root * w_b + cw_b;
+        const float tomt = root * (1.f - root), omr = 1.f - root;
+        const float den = s_b + q * tomt;
+        const float dnum = (s_b * s_b) * (d_n * (root * root) + 2.f * s_b * tomt + d_b * (omr * omr));
+        ljd = -logf(dnum) + 2.f * logf(den);
+    } else {
+        const float theta = (xin - cw_b) / w_b;
+        const float tomt = theta * (1.f - theta), omt = 1.f - theta;
+        const float num = h_b * (s_b * (theta * theta) + d_b * tomt);
+        const float den = s_b + (d_b + d_n - 2.f * s_b) * tomt;
+        out = ch_b + num / den;
+        const float dnum = (s_b * s_b) * (d_n * (theta * theta) + 2.f * s_b * tomt + d_b * (omt * omt));
+        ljd = logf(dnum) - 2.f * logf(den);
+    }
+    if (!e.in[Q]) { out = e.x[Q]; ljd = 0.f; }                // :86-87 linear tails
+}
+
+template <int TX, int HT>
+__device__ __forceinline__ void rqs_phase(tile<1> (&xs)[TX], const btile<1> (&bh)[HT], rqs_elems &e, const wptr w,
+                                          const dstep &st, float &ldj, int lane) {
+    const int h = lane >> 5;
+    const int g = st.c0, K = st.tt;
+    tile<1> acc[4];
+    rqs_gemm<HT>(w, bh, acc);
+    const float lo = *reinterpret_cast<const float *>(w.cb - h * 64 + (4 * HT * 1024 + 128) * 4);
+    const float hi = *reinterpret_cast<const float *>(w.cb - h * 64 + (4 * HT * 1024 + 129) * 4);
+    if (st.ct == 0) {
+        // fetch the group's 4 inputs out of the state tile (wave-uniform selects keep register indices static)
+#pragma unroll
+        for (int t = 0; t < TX; ++t)
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg)
+                if (t == st.t0 && gg == g) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) e.x[q] = xs[t].v[0][4 * gg + q];
+                }
+        rqs_search<0>(acc, e, K, lo, hi);
+        rqs_search<1>(acc, e, K, lo, hi);
+        rqs_search<2>(acc, e, K, lo, hi);
+        rqs_search<3>(acc, e, K, lo, hi);
+    } else if (st.ct == 1) {
+        rqs_select<0>(acc, e, K, lo, hi);
+        rqs_select<1>(acc, e, K, lo, hi);
+        rqs_select<2>(acc, e, K, lo, hi);
+        rqs_select<3>(acc, e, K, lo, hi);
+    } else {
+        float out[4], lj[4];
+        if (st.reverse) {
+            rqs_eval<0, true>(acc, e, K, out[0], lj[0]);
+            rqs_eval<1, true>(acc, e, K, out[1], lj[1]);
+            rqs_eval<2, true>(acc, e, K, out[2], lj[2]);
+            rqs_eval<3, true>(acc, e, K, out[3], lj[3]);
+        } else {
+            rqs_eval<0, false>(acc, e, K, out[0], lj[0]);
+            rqs_eval<1, false>(acc, e, K, out[1], lj[1]);
+            rqs_eval<2, false>(acc, e, K, out[2], lj[2]);
+            rqs_eval<3, false>(acc, e, K, out[3], lj[3]);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool live = (st.mask >> (q + 8 * g + 4 * h)) & 1u;     // slot kmap(4g+q, h) of the tile
+            if (!live) { out[q] = e.x[q]; lj[q] = 0.f; }
+            s += lj[q];
+        }
+#pragma unroll
+        for (int t = 0; t < TX; ++t)
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg)
+                if (t == st.t0 && gg == g) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xs[t].v[0][4 * gg + q] = out[q];
+                }
+        ldj += st.ldj_scale * s;
+    }
+}
+
 __device__ __forceinline__ float ld_elem(const void *p, int64_t off, int bf16) {
     if (bf16) return bf16_to_f32(reinterpret_cast<const uint16_t *>(p)[off]);
     return reinterpret_cast<const float *>(p)[off];
@@ -420,7 +618,8 @@ struct flow_kargs {     // everything but the program, by value in the kernarg s
 };
 
 // MODE 0: flow programs (coupling / affine-const steps); MODE 1: + persistent hidden state (MLP programs);
-// MODE 2: flow programs with dense linear layers (AffineLU / MatrixExponential): + a second state tile set
+// MODE 2: flow programs with dense linear layers (AffineLU / MatrixExponential): + a second state tile set;
+// MODE 3: flow programs with rational-quadratic spline couplings: + hidden B operands and the group state
 template <int NS, int TX, int HT, int MODE>
 __global__ __launch_bounds__(256, SX_WAVES_FOR(TX)) void flow_fused_kernel(const dprog prog, const flow_kargs k) {
     constexpr int ROWS_PER_BLOCK = 128 * NS;
@@ -500,6 +699,8 @@ __global__ __launch_bounds__(256, SX_WAVES_FOR(TX)) void flow_fused_kernel(const
         float ldj_c = 0.f;
         tile<NS> hid[MODE == 1 ? HT : 1];
         tile<NS> xnew[MODE == 2 ? TX : 1];
+        btile<1> rq_bh[MODE == 3 ? HT : 1];      // MODE 3 (spline couplings): hidden B operands + group state
+        rqs_elems rq_e;
 
         for (int s = 0; s < n_steps; ++s) {
             // (1) this step's weights were issued one step ago (or in the prologue): wait for MY pieces, then
@@ -589,6 +790,25 @@ __global__ __launch_bounds__(256, SX_WAVES_FOR(TX)) void flow_fused_kernel(const
                                 if (t < x_tiles) xs[t] = xnew[t];
                         }
                     }
+                    break;
+                case SX_STEP_RQS_HIDDEN:
+                    if constexpr (MODE == 3 && NS == 1) {
+                        tile<1> hd[HT];
+                        if constexpr (TX >= 2) {
+                            if (st.ct == TX / 2 && st.c0 == 0) hidden_layer<1, TX, HT, 0, TX / 2, true>(xs, hd, w, 0, st.act);
+                            else if (st.ct == TX / 2) hidden_layer<1, TX, HT, TX / 2, TX / 2, true>(xs, hd, w, 0, st.act);
+                            else hidden_layer<1, TX, HT, 0, TX, true>(xs, hd, w, 0, st.act);
+                        } else {
+                            hidden_layer<1, TX, HT, 0, TX, true>(xs, hd, w, 0, st.act);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) hd[HT - 1].v[0][r] = fast_sig2(hd[HT - 1].v[0][r]);
+#pragma unroll
+                        for (int m = 0; m < HT; ++m) rq_bh[m] = make_btile<1>(hd[m]);
+                    }
+                    break;
+                case SX_STEP_RQS_PHASE:
+                    if constexpr (MODE == 3 && NS == 1) rqs_phase<TX, HT>(xs, rq_bh, rq_e, w, st, ldj[0], lane);
                     break;
                 case SX_STEP_ROW_SCALE_EXP:
                     // x *= exp(+-diag * t_row)  (affine.py:263), t_row optionally log1p|t| (affine.py:239-240)
@@ -718,7 +938,7 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
         }                                                                                                      \
         hipLaunchKernelGGL(kern, dim3(a.grid), dim3(256), a.lds, a.stream, a.prog, k);                         \
     } while (0)
-    if (a.mlp_mode == 1) SX_FL(1); else if (a.mlp_mode == 2) SX_FL(2); else SX_FL(0);
+    if (a.mlp_mode == 1) SX_FL(1); else if (a.mlp_mode == 2) SX_FL(2); else if (a.mlp_mode == 3) SX_FL(3); else SX_FL(0);
 #undef SX_FL
     SX_LAUNCH_CHECK();
 #ifdef SX_DEBUG_KNOBS

@@ -7,6 +7,7 @@ struct dstep {
     uint8_t kind, c0, ct, t0, tt, reverse, act, pad;
     uint32_t blob_off, blob_floats;
     float ldj_scale, ldj_const;
+    uint32_t mask;      // RQS phases: live slots of the transformed tile
 };
 struct dprog {
     int32_t n_steps, dim, latent_dim, x_tiles, identity_cols, pad;

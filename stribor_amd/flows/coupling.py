@@ -136,12 +136,31 @@ class Coupling(Transform):
 
     # ---- fused-program hooks --------------------------------------------------------------------------------
     def _plan_hidden_width(self):
-        return self._net().hidden_width if isinstance(self.transform, Affine) else 0
+        return self._net().hidden_width if isinstance(getattr(self.transform, 'latent_net', None), MLP) else 0
+
+    def _plan_spline(self, builder: ProgramBuilder, reverse: bool, ldj_scale: float) -> bool:
+        sp = self.transform
+        net = getattr(sp, 'latent_net', None)
+        if not isinstance(net, MLP) or net.activation_name != 'Tanh' or sp.n_bins > 16:
+            return False
+        lin = net.linears()
+        if len(lin) != 2:
+            return False
+        (W1, b1), (W2, b2) = lin
+        if W1.shape[1] != builder.dim + builder.latent_dim or W2.shape[0] != builder.dim * (3 * sp.n_bins - 1):
+            raise ValueError(f'latent_net maps {W1.shape[1]} -> {W2.shape[0]}, expected '
+                             f'{builder.dim + builder.latent_dim} -> {builder.dim * (3 * sp.n_bins - 1)}')
+        builder.add_coupling_rqs(W1, b1, W2, b2, self.mask_vector(builder.dim), reverse, ldj_scale, W1.shape[0],
+                                 sp.n_bins, sp.lower, sp.upper, sp.lower, sp.upper)
+        return True
 
     def _plan_first_mask(self, dim):
         return self.mask_vector(dim)
 
     def _plan(self, builder: ProgramBuilder, reverse: bool, ldj_scale: float) -> bool:
+        from .spline import Spline
+        if isinstance(self.transform, Spline):
+            return self._plan_spline(builder, reverse, ldj_scale)
         if not isinstance(self.transform, Affine) or not isinstance(getattr(self.transform, 'latent_net', None), MLP):
             return False
         net = self._net()

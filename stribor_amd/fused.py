@@ -135,6 +135,20 @@ class _ConstJob:
         return [self.log_scale, self.shift]
 
 
+class _ScalarsJob:
+    """blob[dst_off : dst_off + len(values)] = values (host constants, e.g. spline bounds)."""
+
+    def __init__(self, values, dst_off: int):
+        self.values, self.dst_off = [float(v) for v in values], dst_off
+
+    def run(self, blobs: torch.Tensor) -> None:
+        blobs[self.dst_off:self.dst_off + len(self.values)] = torch.tensor(self.values, dtype=torch.float32,
+                                                                          device=blobs.device)
+
+    def params(self):
+        return []
+
+
 class _VectorJob:
     """blob[dst_off:] = cat(vec, 0)[gather] (per-slot constants in C-fragment order)."""
 
@@ -363,6 +377,95 @@ class ProgramBuilder:
         self.jobs.append(_PackJob(W2, b2, row2, col2, 2 * tt, HT, off + n1, rs2, bs2, fold))
         self.steps.append(dict(kind=_hip.STEP_COUPLING_AFFINE, c0=c0, ct=ct, t0=t0, tt=tt, reverse=int(reverse),
                                act=act, blob_off=off, blob_floats=n, ldj_scale=ldj_scale, ldj_const=0.0))
+
+    def _cond_variant(self, slot_cond, slot_live):
+        """(c0, ct, t0, tt) tile ranges: pruned low / high halves when the masks align with the tiles, else dense."""
+        T = self.tiles
+        half = 16 * T
+        if T >= 2 and self.latent_dim == 0 and self.x_tiles == T:
+            if not slot_cond[half:].any() and not slot_live[:half].any():
+                return 0, T // 2, T // 2, T // 2
+            if not slot_cond[:half].any() and not slot_live[half:].any():
+                return T // 2, T // 2, 0, T // 2
+        return 0, T, 0, T
+
+    def add_coupling_rqs(self, W1, b1, W2, b2, mask: np.ndarray, reverse: bool, ldj_scale: float, hidden: int,
+                         n_bins: int, left: float, right: float, bottom: float, top: float) -> None:
+        """Rational-quadratic spline coupling, fused: 1 hidden step + 12 phase steps per transformed tile.
+        The conditioner must be Linear-Tanh-Linear (folded tanh); n_bins <= 16."""
+        self._freeze_input()
+        D, T, HT, K = self.dim, self.tiles, self.h_tiles, n_bins
+        if K > 16:
+            raise NotImplementedError('fused spline coupling supports n_bins <= 16')
+        P = 3 * K - 1
+        mask = np.asarray(mask, dtype=np.float64).reshape(-1)
+        if mask.size == 1:
+            mask = np.full(D, mask[0])
+        cond_col = mask > 0.5
+        if D == 1:
+            cond_col = np.zeros(1, dtype=bool)
+        live_col = mask <= 0.5
+        col = self.col_of_slot
+        slot_cond = np.array([c >= 0 and cond_col[c] for c in col])
+        slot_live = np.array([c >= 0 and live_col[c] for c in col])
+        c0, ct, t0, tt = self._cond_variant(slot_cond, slot_live)
+        LOG2E = 1.4426950408889634
+        # hidden layer (folded tanh: r = 1/(exp2(2 log2e z) + 1))
+        k_slots = np.arange(32 * c0, 32 * (c0 + ct))
+        col_idx = np.full(len(k_slots), -1, dtype=np.int64)
+        for i, p in enumerate(k_slots):
+            if p < self.n_slots:
+                if slot_cond[p]:
+                    col_idx[i] = col[p]
+            else:
+                li = p - self.n_slots
+                if li < self.latent_dim:
+                    col_idx[i] = D + li
+        row_idx = np.full(32 * HT, -1, dtype=np.int64)
+        row_idx[:hidden] = np.arange(hidden)
+        off, n = self._alloc(_hip.packed_linear_floats(HT, ct))
+        sc = np.full(32 * HT, 2.0 * LOG2E)
+        self.jobs.append(_PackJob(W1, b1, row_idx, col_idx, HT, ct, off, sc, sc, 0.0))
+        self.steps.append(dict(kind=_hip.STEP_RQS_HIDDEN, c0=c0, ct=ct, t0=t0, tt=tt, reverse=int(reverse),
+                               act=_hip.ACT_TANH_FOLDED, blob_off=off, blob_floats=n, ldj_scale=0.0, ldj_const=0.0))
+        col2 = np.full(32 * HT, -1, dtype=np.int64)
+        col2[:hidden] = np.arange(hidden)
+        # forward searches the widths on [left, right], inverse the heights on [bottom, top]
+        blocks = [(K, K, bottom, top), (0, K, left, right)] if reverse else [(0, K, left, right), (K, K, bottom, top)]
+        blocks.append((2 * K, K - 1, 0.0, 0.0))
+        for t in range(t0, t0 + tt):
+            if t >= self.x_tiles:
+                continue
+            live_mask = 0
+            for i in range(32):
+                if slot_live[32 * t + i]:
+                    live_mask |= 1 << i
+            if live_mask == 0:
+                continue
+            for g in range(4):
+                if not any((live_mask >> (q + 8 * g + 4 * h)) & 1 for q in range(4) for h in range(2)):
+                    continue
+                for phase, (start, count, lo, hi) in enumerate(blocks):
+                    rows = np.full(128, -1, dtype=np.int64)
+                    for u in range(4):
+                        for q in range(4):
+                            for h in range(2):
+                                slot = 32 * t + q + 8 * g + 4 * h
+                                if not slot_live[slot]:
+                                    continue
+                                for i in range(4):
+                                    k = 4 * u + i
+                                    if k < count:
+                                        rows[32 * u + 8 * q + 4 * h + i] = col[slot] * P + start + k
+                    nlin = _hip.packed_linear_floats(4, HT)
+                    off, n = self._alloc(nlin + 4)
+                    self.jobs.append(_PackJob(W2, b2, rows, col2, 4, HT, off, np.full(128, -2.0), np.full(128, 1.0), 1.0))
+                    self.jobs.append(_ScalarsJob([lo, hi], off + nlin))
+                    s_scale = (-ldj_scale if reverse else ldj_scale) if phase == 2 else 0.0
+                    step = dict(kind=_hip.STEP_RQS_PHASE, c0=g, ct=phase, t0=t, tt=K, reverse=int(reverse), act=0,
+                                blob_off=off, blob_floats=n, ldj_scale=s_scale, ldj_const=0.0)
+                    step['pad_'] = live_mask - (1 << 32) if live_mask >= (1 << 31) else live_mask
+                    self.steps.append(step)
 
     def add_affine_const(self, log_scale, shift, reverse: bool, ldj_scale: float) -> None:
         self._freeze_input()

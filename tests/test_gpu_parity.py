@@ -272,6 +272,8 @@ def test_cfg3_spline_flow_against_golden():
     g = Golden('f5_cfg3')
     flow = product_flow(g, 'cfg3')
     x = g.t('cfg3/x').to(DEV)
+    assert flow._fused_program(True, 64, 0, x.device) is not None            # whole spline flow = one launch
+    assert flow._fused_program(False, 64, 0, x.device) is not None
     cur = x
     for i in reversed(range(len(flow.transforms))):
         nxt, ldj = flow.transforms[i].inverse_and_log_det_jacobian(cur)
