@@ -18,7 +18,7 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     d->n_steps = p->n_steps; d->dim = p->dim; d->latent_dim = p->latent_dim; d->x_tiles = p->x_tiles;
     d->identity_cols = p->identity_cols; d->pad = 0;
     int mx = 256;
-    bool lin = false, rqs = false;
+    bool lin = false, rqs = false, aff = false;
     *mlp_mode = 0;
     for (int i = 0; i < p->n_steps; ++i) {
         const sx_step &s = p->steps[i];
@@ -33,6 +33,7 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
                 const bool high = T >= 2 && s.c0 == T / 2 && s.ct == T / 2 && s.t0 == 0 && s.tt == T / 2;
                 const bool dense = s.c0 == 0 && s.ct == T && s.t0 == 0 && s.tt == T;
                 SX_REQUIRE(low || high || dense, "sx_flow_run: step %d: coupling tiles must be low/high halves or dense", i);
+                aff = true;
             }
                 need = sx_packed_linear_floats(p->h_tiles, s.ct) + sx_packed_linear_floats(2 * s.tt, p->h_tiles);
                 break;
@@ -72,14 +73,15 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     SX_REQUIRE(!(lin && *mlp_mode), "sx_flow_run: linear steps cannot be mixed with MLP-output steps");
     if (lin) *mlp_mode = 2;
     SX_REQUIRE(!(rqs && (lin || *mlp_mode == 1)), "sx_flow_run: spline steps cannot be mixed with linear / MLP-output steps");
+    SX_REQUIRE(!(rqs && aff), "sx_flow_run: spline and affine couplings cannot share one fused program");
     if (rqs) *mlp_mode = 3;
     SX_REQUIRE((size_t)mx * 8 <= 160 * 1024, "sx_flow_run: a step needs %d B of LDS per buffer (> 80 KiB)", mx * 4);
     return SX_OK;
 }
 
-static int pick_grid(int64_t n_rows, int lds_bytes, int tiles) {
+static int pick_grid(int64_t n_rows, int lds_bytes, int tiles, int mode) {
     int per_cu = (160 * 1024) / (lds_bytes > 0 ? lds_bytes : 1);
-    int max_per_cu = SX_WAVES_FOR(tiles);
+    int max_per_cu = SX_WAVES_FOR(tiles, mode);
     if (const char *g = getenv("SX_BLOCKS_PER_CU")) max_per_cu = atoi(g);      // experiment knob
     if (per_cu > max_per_cu) per_cu = max_per_cu;
     if (per_cu < 1) per_cu = 1;
@@ -98,7 +100,7 @@ extern "C" int sx_flow_launch_info(const sx_program *prog_host, int64_t n_rows, 
     if (rc) return rc;
     if (lds_bytes) *lds_bytes = bf * 8;
     if (block) *block = 256;
-    if (grid) *grid = pick_grid(n_rows, bf * 8, prog_host->tiles);
+    if (grid) *grid = pick_grid(n_rows, bf * 8, prog_host->tiles, mm);
     return SX_OK;
 }
 
@@ -123,7 +125,7 @@ extern "C" int sx_flow_run(const sx_program *prog_host, const float *blobs, cons
     a.prog = d; a.blobs = blobs; a.x = x; a.latent = latent; a.in_col = in_col; a.out_col = out_col; a.y = y;
     a.ldj_out = ldj_out; a.logp_out = logp_out; a.sum_out = sum_out; a.mlp_out = mlp_out;
     a.mlp_out_stride = mlp_out_stride; a.mlp_out_dim = mlp_out_dim; a.n_rows = n_rows; a.buf_floats = bf;
-    a.bf16 = dtype == SX_BF16; a.mlp_mode = mlp_mode; a.lds = bf * 8; a.grid = pick_grid(n_rows, a.lds, prog_host->tiles);
+    a.bf16 = dtype == SX_BF16; a.mlp_mode = mlp_mode; a.lds = bf * 8; a.grid = pick_grid(n_rows, a.lds, prog_host->tiles, mlp_mode);
     a.stream = sx_stream(stream);
     a.row_t = row_t;
     const int T = prog_host->tiles, H = prog_host->h_tiles;

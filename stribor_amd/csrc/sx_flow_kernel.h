@@ -495,13 +495,16 @@ __device__ __forceinline__ void rqs_select(tile<1> (&acc)[4], rqs_elems &e, int 
     e.c_b[Q] = k_b;
     e.c_w[Q] = k_n - k_b;
 }
-__device__ __forceinline__ float rqs_softplus(float v) { return v > 20.f ? v : log1pf(expf(v)); }
+// F.softplus(v) = log1p(exp(v)) (threshold 20) on v_exp_f32 / v_log_f32: |abs err| <~ 1e-7, far below the 1e-4
+// conditioning noise of the spline's log-derivative
+__device__ __forceinline__ float fast_log(float v) { return __builtin_amdgcn_logf(v) * 0.69314718055994531f; }
+__device__ __forceinline__ float rqs_softplus(float v) { return v > 20.f ? v : fast_log(1.f + fast_exp(v)); }
 // phase 2: the two knot derivatives at the bin (:107,:206-207), then the rational-quadratic (:236-248) or its
 // inverse (:212-234; the returned log-derivative is already negated like the reference's).
 template <int Q, bool REV>
 __device__ __forceinline__ void rqs_eval(tile<1> (&acc)[4], const rqs_elems &e, int K, float &out, float &ljd) {
     const int b = e.b[Q];
-    const float cst = logf(expf(1.f - RQS_MIN) - 1.f);          // :81 boundary derivative constant
+    const float cst = 0.5397424172369522f;                            // log(exp(1 - 1e-3) - 1), :81 boundary derivative constant
     float r_b = cst, r_n = cst;
 #pragma unroll
     for (int k = 0; k < 15; ++k) {
@@ -515,7 +518,7 @@ __device__ __forceinline__ void rqs_eval(tile<1> (&acc)[4], const rqs_elems &e, 
     // REV: the searched block is the heights (codomain side), the selected one the widths
     const float cw_b = REV ? e.c_b[Q] : e.a_b[Q], w_b = REV ? e.c_w[Q] : e.a_w[Q];
     const float ch_b = REV ? e.a_b[Q] : e.c_b[Q], h_b = REV ? e.a_w[Q] : e.c_w[Q];
-    const float s_b = h_b / w_b;
+    const float s_b = h_b * fast_rcp(w_b);
     const float xin = e.in[Q] ? e.x[Q] : (REV ? ch_b : cw_b);
     if constexpr (REV) {
         const float dy = xin - ch_b;
@@ -524,20 +527,20 @@ __device__ __forceinline__ void rqs_eval(tile<1> (&acc)[4], const rqs_elems &e, 
         const float bb = h_b * d_b - dy * q;
         const float c = -s_b * dy;
         const float disc = bb * bb - 4.f * a * c;
-        const float root = (2.f * c) / (-bb - sqrtf(disc));
+        const float root = (2.f * c) * fast_rcp(-bb - __builtin_amdgcn_sqrtf(disc));
         out = root * w_b + cw_b;
         const float tomt = root * (1.f - root), omr = 1.f - root;
         const float den = s_b + q * tomt;
         const float dnum = (s_b * s_b) * (d_n * (root * root) + 2.f * s_b * tomt + d_b * (omr * omr));
-        ljd = -logf(dnum) + 2.f * logf(den);
+        ljd = -fast_log(dnum) + 2.f * fast_log(den);
     } else {
-        const float theta = (xin - cw_b) / w_b;
+        const float theta = (xin - cw_b) * fast_rcp(w_b);
         const float tomt = theta * (1.f - theta), omt = 1.f - theta;
         const float num = h_b * (s_b * (theta * theta) + d_b * tomt);
         const float den = s_b + (d_b + d_n - 2.f * s_b) * tomt;
-        out = ch_b + num / den;
+        out = ch_b + num * fast_rcp(den);
         const float dnum = (s_b * s_b) * (d_n * (theta * theta) + 2.f * s_b * tomt + d_b * (omt * omt));
-        ljd = logf(dnum) - 2.f * logf(den);
+        ljd = fast_log(dnum) - 2.f * fast_log(den);
     }
     if (!e.in[Q]) { out = e.x[Q]; ljd = 0.f; }                // :86-87 linear tails
 }
@@ -621,7 +624,7 @@ struct flow_kargs {     // everything but the program, by value in the kernarg s
 // MODE 2: flow programs with dense linear layers (AffineLU / MatrixExponential): + a second state tile set;
 // MODE 3: flow programs with rational-quadratic spline couplings: + hidden B operands and the group state
 template <int NS, int TX, int HT, int MODE>
-__global__ __launch_bounds__(256, SX_WAVES_FOR(TX)) void flow_fused_kernel(const dprog prog, const flow_kargs k) {
+__global__ __launch_bounds__(256, SX_WAVES_FOR(TX, MODE)) void flow_fused_kernel(const dprog prog, const flow_kargs k) {
     constexpr int ROWS_PER_BLOCK = 128 * NS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -723,6 +726,7 @@ __global__ __launch_bounds__(256, SX_WAVES_FOR(TX)) void flow_fused_kernel(const
             SX_STAMP(pf, 2);     // descriptor + DMA issue
             switch (st.kind) {
                 case SX_STEP_COUPLING_AFFINE:
+                    if constexpr (MODE == 3) break;      // spline programs carry no affine couplings (register budget)
                     if constexpr (TX >= 2) {
                         if (st.ct == TX / 2 && st.c0 == 0 && st.t0 == TX / 2) {          // cond = low tiles
                             coupling_affine_dispatch<NS, TX, HT, 0, TX / 2, TX / 2, TX / 2>(xs, w, st, ldj, pf);

@@ -577,6 +577,11 @@ class ProgramBuilder:
         self._freeze_input()
         if len(self.steps) > _hip.SX_MAX_STEPS:
             raise NotImplementedError(f'fused program has {len(self.steps)} steps (max {_hip.SX_MAX_STEPS})')
+        kinds = {s['kind'] for s in self.steps}
+        rqs = kinds & {_hip.STEP_RQS_HIDDEN, _hip.STEP_RQS_PHASE}
+        if rqs and kinds & {_hip.STEP_COUPLING_AFFINE, _hip.STEP_LINEAR_TILE, _hip.STEP_ROW_SCALE_EXP}:
+            # the spline kernel variant spends its registers on the group state: mixed flows run layer by layer
+            raise NotImplementedError('spline couplings cannot share a fused program with affine couplings / linear layers')
         prog = _hip.sx_program()
         prog.n_steps = len(self.steps)
         prog.dim, prog.latent_dim = self.dim, self.latent_dim

@@ -416,3 +416,20 @@ def test_cfg4_flow_against_golden():
         close(nxt, g.t(f'cfg4/inv_x.{i}'), rtol=1e-4, atol=2e-4)
         close(l, g.t(f'cfg4/inv_ldj.{i}'), rtol=1e-5, atol=1e-4)
         cur = nxt
+
+
+def test_mixed_spline_affine_flow_falls_back_per_layer_and_matches_oracle():
+    """A flow the fused kernel cannot take whole (spline + affine couplings + AffineLU) runs layer by layer on
+    HIP kernels; checked against the oracle built from the same state_dict."""
+    torch.manual_seed(11)
+    desc = [fd.cfg3_desc(1, 16, 24, 5)[0], fd.cfg2_desc(2, 16, 24)[1], {'kind': 'affine_lu', 'dim': 16},
+            {'kind': 'permute', 'dim': 16}, fd.cfg3_desc(2, 16, 24, 5)[1]]
+    flow = fd.build_flow(st, desc, 16)
+    spec = fd.flow_spec(desc, {k: v.clone() for k, v in flow.state_dict().items()})
+    flow = flow.to(DEV)
+    x = torch.randn(300, 16)
+    assert flow._fused_program(True, 16, 0, torch.device(DEV)) is None
+    with torch.no_grad():
+        close(flow.log_prob(x.to(DEV)), orc.flow_log_prob(spec, x), rtol=1e-5, atol=1e-4)
+        close(flow.forward(x.to(DEV)), orc.flow_forward(spec, x), rtol=2e-5, atol=2e-5)
+        close(flow.inverse(x.to(DEV)), orc.flow_inverse(spec, x), rtol=2e-5, atol=2e-5)

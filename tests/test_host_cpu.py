@@ -151,3 +151,21 @@ def test_tile_limits_raise():
         ProgramBuilder(200, 0, 32)
     with pytest.raises(NotImplementedError):
         ProgramBuilder(64, 0, 300)
+
+
+def test_planner_spline_flow_and_mixed_fallback():
+    """cfg 3 plans into 8 x (1 hidden + 12 phase) steps; a flow mixing spline and affine couplings is not fused."""
+    torch.manual_seed(0)
+    flow = fd.build_flow(st, fd.cfg3_desc(), 64)
+    b = ProgramBuilder(64, 0, 64)
+    order = list(reversed(flow.transforms))
+    b.choose_layout(order[0]._plan_first_mask(64))
+    for f in order:
+        assert f._plan(b, True, -1.0)
+    assert len(b.steps) == 8 * 13
+    phases = [s for s in b.steps if s['kind'] == _hip.STEP_RQS_PHASE]
+    assert all(s['tt'] == 16 and s['pad_'] == -1 for s in phases)            # 16 bins, all 32 slots live
+    assert [s['ct'] for s in phases[:3]] == [0, 1, 2]
+    assert sum(1 for s in phases if s['ldj_scale'] != 0) == 8 * 4            # only the evaluate phases add log-det
+    mixed = st.NormalizingFlow(st.UnitNormal(64), [flow.transforms[0], fd.build_transform(st, fd.cfg2_desc(1)[0])])
+    assert mixed._build_fused(True, 64, 0, torch.device('cpu')) is None
