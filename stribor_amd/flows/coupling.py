@@ -70,14 +70,52 @@ class Coupling(Transform):
         lat2 = None if latent is None else latent.reshape(-1, latent.shape[-1])
         ld = 0 if lat2 is None else lat2.shape[1]
         if isinstance(self.transform, Affine):
-            prog = self._affine_program(reverse, ldj_scale, d, ld, x.device)
-            y, ldj, _ = prog.run(x2, lat2, want_y, want_ldj, False)
+            try:
+                prog = self._affine_program(reverse, ldj_scale, d, ld, x.device)
+            except NotImplementedError:
+                prog = None            # e.g. a conditioner with several hidden layers: MLP kernel + element-wise kernel
+            if prog is not None:
+                y, ldj, _ = prog.run(x2, lat2, want_y, want_ldj, False)
+            else:
+                y, ldj = self._run_affine_unfused(x2, lat2, reverse, want_ldj, ldj_scale)
         else:
             from .spline import Spline
             if not isinstance(self.transform, Spline):
                 raise NotImplementedError(f'Coupling({type(self.transform).__name__}) is not on the hot path')
             y, ldj = self._run_spline(x2, lat2, reverse, want_ldj, ldj_scale)
         return (None if y is None else y.reshape(*lead, d)), (None if ldj is None else ldj.reshape(*lead, 1))
+
+    # ---- affine, unfused: pruned conditioner (MFMA program) + HBM-bound element-wise kernel -----------------
+    def _affine_unfused_program(self, dim: int, latent_dim: int, device):
+        key = ('affine-unfused', dim, latent_dim, str(device))
+        if key not in self._programs:
+            net = self._net()
+            m = self.mask_vector(dim)
+            live = np.nonzero(m <= 0.5)[0]
+            cond = m > 0.5
+            if dim == 1:
+                cond = np.zeros(1, dtype=bool)
+            out_rows = np.concatenate([live, dim + live])                           # (log_scale | shift) of live columns
+            b = ProgramBuilder(dim, latent_dim, net.hidden_width)
+            b.add_mlp(net.linears(), net.act_code, cond, out_rows)
+            contiguous = len(live) > 0 and np.array_equal(live, np.arange(live[0], live[0] + len(live)))
+            live_idx = None if contiguous else torch.from_numpy(live.astype(np.int32)).to(device)
+            self._programs[key] = (_chunk_mlp_program(b, device), live_idx, int(live[0]) if len(live) else 0,
+                                   len(live))
+        return self._programs[key]
+
+    def _run_affine_unfused(self, x2, lat2, reverse, want_ldj, ldj_scale):
+        from .affine import run_affine_kernel
+        n, d = x2.shape
+        if not (self.mask_vector(d) <= 0.5).any():
+            return x2.clone(), (torch.zeros(n, dtype=torch.float32, device=x2.device) if want_ldj else None)
+        progs, live_idx, live_start, n_live = self._affine_unfused_program(d, 0 if lat2 is None else lat2.shape[1],
+                                                                           x2.device)
+        params = torch.empty(n, 2 * n_live, dtype=torch.float32, device=x2.device)
+        for p in progs:
+            p.run(x2, lat2, mlp_out=params)
+        return run_affine_kernel(x2, params, params.stride(0), live_idx, live_start, n_live, reverse, True, want_ldj,
+                                 ldj_scale)
 
     # ---- spline: pruned conditioner (MFMA) + LDS-staged spline kernel --------------------------------------
     def _spline_program(self, dim: int, latent_dim: int, device):

@@ -433,3 +433,30 @@ def test_mixed_spline_affine_flow_falls_back_per_layer_and_matches_oracle():
         close(flow.log_prob(x.to(DEV)), orc.flow_log_prob(spec, x), rtol=1e-5, atol=1e-4)
         close(flow.forward(x.to(DEV)), orc.flow_forward(spec, x), rtol=2e-5, atol=2e-5)
         close(flow.inverse(x.to(DEV)), orc.flow_inverse(spec, x), rtol=2e-5, atol=2e-5)
+
+
+def test_coupling_with_deep_conditioner_and_other_activations():
+    """Conditioners the fused coupling step does not take (two hidden layers; ReLU) still run on HIP kernels:
+    MLP program -> pruned parameters in HBM -> sx_affine_coupling."""
+    torch.manual_seed(21)
+    for hidden, act, dim, mask in [([24, 16], 'Tanh', 10, 'ordered_left_half'), ([40], 'ReLU', 64, 'ordered_right_half'),
+                                   ([32, 32], 'ELU', 7, 'parity_even')]:
+        net = st.net.MLP(dim, hidden, 2 * dim, activation=act)
+        f = st.Coupling(st.Affine(dim, latent_net=net), mask=mask)
+        lin = net.linears()
+        spec = {'kind': 'coupling_affine', 'mask': mask,
+                'net': {'weights': [w.detach().clone() for (w, _) in lin], 'biases': [b.detach().clone() for (_, b) in lin],
+                        'activation': act}}
+        f = f.to(DEV)
+        x = torch.randn(130, dim)
+        with torch.no_grad():
+            y = f(x.to(DEV))
+            close(y, orc.transform_apply(spec, x, False))
+            close(f.inverse(y), x, atol=1e-4)
+            yy, ldj = f.forward_and_log_det_jacobian(x.to(DEV))
+            close(ldj, orc.transform_ldj(spec, x), atol=2e-5)
+            xb, ldi = f.inverse_and_log_det_jacobian(y)
+            close(ldi, -orc.transform_ldj(spec, x), atol=1e-4)
+        # a flow of them: not fusable as one program -> per-layer loop
+        flow = st.NormalizingFlow(st.UnitNormal(dim), [f]).to(DEV)
+        close(flow.log_prob(x.to(DEV)), orc.flow_log_prob([spec], x), rtol=1e-5, atol=1e-4)
