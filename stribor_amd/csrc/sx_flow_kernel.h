@@ -4,25 +4,26 @@
 //   mask -> x*mask -> Linear -> Tanh -> Linear -> chunk -> (x-shift)*exp(-log_scale) -> blend -> sum
 // of stribor/flows/coupling.py:48-95 + flows/affine.py:59-123 + net/mlp.py:65.
 //
-// Mapping to CDNA4 (MI355X_MICROARCH.md, cdna_hip_programming.md §3):
-//   * one wave = NS x 32 samples (NS = 2 for D <= 64, 1 for D = 128).  Samples sit on the MFMA column
-//     (lane&31), features on the C rows, so the flow state x[D] of a sample is 16*D/32 VGPRs per lane in
-//     v_mfma_f32_32x32x2_f32 C-fragment order (lane half h = lane>>5 owns features kmap(r,h), r = 0..15, of
-//     every 32-wide tile);
-//   * a C tile is directly the B operand of the next GEMM (k-step s <-> feature kmap(s,h); the weights
-//     are pre-permuted by sx_pack_linear), so x -> hidden -> (log_scale, shift) -> x' never leaves
-//     registers: no LDS transposes, no HBM round trips between layers;
-//   * GEMMs run on the exact-fp32 matrix pipe (v_mfma_f32_32x32x2_f32: an fp32 fma chain, so parity with
-//     the CPU reference holds at ~1e-7).  One ds_read_b128 of A operands feeds 4 k-steps x NS sample
-//     tiles = 4*NS MFMAs, and the NS accumulator chains are independent, so LDS latency and the per-step
-//     fixed costs (descriptor load, barrier, bias loads) are amortised over 2x the matrix work;
-//   * tanh / exp (v_exp_f32 + v_rcp_f32) of one tile are issued between the MFMAs of the next tile
-//     (software pipelining in program order), so the VALU work rides in the matrix pipe's shadow;
-//   * weights of one step (<= ~25 KB for D=64,H=64) stream L2 -> LDS by LDS-DMA (global_load_lds x16 B),
-//     double-buffered: step s+1 lands while step s computes; the NEXT step's descriptor is fetched one
-//     step early as well;
-//   * 256-thread workgroups (4 waves = 128*NS samples per pass), persistent grid-stride over sample
-//     chunks, up to 2 workgroups per CU;
+// Mapping to CDNA4 (MI355X_MICROARCH.md, cdna_hip_programming.md §3; measurements in DESIGN.md §4.1/§6):
+//   * one wave = 32 samples.  Samples sit on the MFMA column (lane&31), features on the C rows, so the flow
+//     state x[D] of a sample is 16*D/32 VGPRs per lane in MFMA C-fragment order (lane half h = lane>>5 owns
+//     features kmap(r,h), r = 0..15, of every 32-wide tile);
+//   * a C tile is directly the B operand of the next GEMM (k-step <-> feature kmap; the weights are
+//     pre-permuted by sx_pack_linear), so x -> hidden -> (log_scale, shift) -> x' never leaves registers:
+//     no LDS transposes, no HBM round trips between layers;
+//   * GEMM arithmetic is a build-time choice.  Default (-DSX_F16X3): both operands split hi + lo in fp16, three
+//     products per 16-deep step on v_mfma_f32_32x32x16_f16 with fp32 accumulation (~2^-22 per product,
+//     fp32-grade) -- on the matrix pipe, BESIDE the VALU.  EXACT_F32=1: v_mfma_f32_32x32x2_f32, an exact fp32
+//     fma chain, which on gfx950 executes at the VALU rate ON the VALU (tools/mfma_probe.hip), so the tanh /
+//     exp work serialises behind it;
+//   * the kernel is VALU-issue bound, so VALU work is shaved: tanh's and exp's constants live in the packed
+//     weights (hidden r = 1/(exp2(z') + 1): v_exp, v_add, v_rcp), activations of one tile are issued between the
+//     MFMAs of the next, every LDS access is pointer + immediate, one runtime dispatch per step selects a
+//     straight-line specialisation;
+//   * weights of one step (<= ~33 KB) stream L2 -> LDS by LDS-DMA (global_load_lds x16 B), double-buffered:
+//     step s+1 lands while step s computes; the NEXT step's descriptor is fetched one step early as well;
+//   * 256-thread workgroups (4 waves = 128 samples per pass), persistent grid-stride over sample chunks,
+//     2 workgroups per CU for D <= 64, 1 for D = 128;
 //   * per-sample log-det / log-prob: in-lane sums + ONE cross-half shuffle; optional batch sum as fp64
 //     block partials + one atomic per workgroup (flow.py:129 + the multi-GPU all-reduce operand).
 #pragma once
@@ -269,6 +270,7 @@ __device__ __forceinline__ void hidden_layer(const tile<NS> (&src)[NSRC], tile<N
     btile<NS> bsrc[CT];          // B operands are formed once and reused by every output tile
 #pragma unroll
     for (int c = 0; c < CT; ++c) bsrc[c] = make_btile<NS>(src[C0 + c]);
+    __builtin_amdgcn_sched_barrier(0);
     if constexpr (FOLDED) {
         tile<NS> acc = load_cfrag<NS>(w.cb, bias);
 #pragma unroll
@@ -288,6 +290,7 @@ __device__ __forceinline__ void hidden_layer(const tile<NS> (&src)[NSRC], tile<N
             }
             hid[m - 1] = acc;
             acc = nxt;
+            __builtin_amdgcn_sched_barrier(0);
         }
         hid[HT - 1] = acc;
     } else {
@@ -325,6 +328,7 @@ __device__ __forceinline__ void coupling_affine(tile<NS> (&xs)[TX], const wptr w
 #pragma unroll
     for (int m = 0; m + 1 < HT; ++m) bh[m] = make_btile<NS>(hid[m]);
     if constexpr (!FOLDED || HT == 1) bh[HT - 1] = make_btile<NS>(hid[HT - 1]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
         tile<NS> ls = load_cfrag<NS>(w.cb, b2 + (2 * t) * 32);
@@ -340,7 +344,10 @@ __device__ __forceinline__ void coupling_affine(tile<NS> (&xs)[TX], const wptr w
                 gemm_tile<NS>(w.wb, a2 + ((2 * t) * HT + m) * 1024, bh[m], ls);
             gemm_tile<NS>(w.wb, a2 + ((2 * t + 1) * HT + m) * 1024, bh[m], sh);
         }
-        if (FOLDED && t == 0 && HT > 1) bh[HT - 1] = make_btile<NS>(hid[HT - 1]);   // its activation just finished
+        if (FOLDED && t == 0 && HT > 1) {
+            bh[HT - 1] = make_btile<NS>(hid[HT - 1]);   // its activation just finished
+            __builtin_amdgcn_sched_barrier(0);
+        }
         gemm_tile<NS>(w.wb, a2 + ((2 * t) * HT + (HT - 1)) * 1024, bh[HT - 1], ls);
         // the scale exp(+-log_scale) rides under the shift tile's last k-chunk; ls is overwritten by it
         const float sgn = FOLDED ? 1.0f : (REV ? -1.44269504088896341f : 1.44269504088896341f);

@@ -34,11 +34,14 @@ struct sx_flow_args {
 #endif
 
 // waves per SIMD the kernel is compiled for (= workgroups per CU): the D = 128 state (+ a second copy for the
-// dense linear layers) needs the whole 512-register file, D <= 64 fits twice
+// dense linear layers) needs the whole 512-register file; D <= 64 coupling flows run 3 per SIMD (168 VGPRs; measured
+// +7 % over 2 on cfg 2: the third wave fills issue slots the other two leave at s_waitcnt / barriers)
 #ifndef SX_RQS_WAVES
 #define SX_RQS_WAVES 2
 #endif
-#define SX_WAVES_FOR(TX, MODE) ((TX) >= 4 ? 1 : ((MODE) == 3 ? SX_RQS_WAVES : 2))
+#ifndef SX_WAVES_FOR
+#define SX_WAVES_FOR(TX, MODE) ((TX) >= 4 ? 1 : ((MODE) == 3 ? SX_RQS_WAVES : ((MODE) == 0 ? 3 : 2)))
+#endif
 
 #define SX_DECL_FLOW(T, H) int sx_flow_launch_t##T##h##H(const sx_flow_args &a);
 SX_DECL_FLOW(1, 1) SX_DECL_FLOW(1, 2) SX_DECL_FLOW(1, 4)
