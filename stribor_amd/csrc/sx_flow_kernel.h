@@ -374,6 +374,10 @@ __device__ __forceinline__ void coupling_affine(tile<NS> (&xs)[TX], const wptr w
 template <int NS, int TX, int HT, int C0, int CT, int T0, int TT>
 __device__ __forceinline__ void coupling_affine_dispatch(tile<NS> (&xs)[TX], const wptr w, const dstep &st,
                                                          float (&ldj)[NS], prof_t &pf) {
+#ifdef SX_ONLY_HOT     // ISA-inspection build: only the specialisation cfg 2's log_prob executes
+    coupling_affine<NS, TX, HT, C0, CT, T0, TT, true, true>(xs, w, st, ldj, pf);
+    return;
+#endif
     if (st.act == SX_ACT_TANH_FOLDED) {
         if (st.reverse) coupling_affine<NS, TX, HT, C0, CT, T0, TT, true, true>(xs, w, st, ldj, pf);
         else coupling_affine<NS, TX, HT, C0, CT, T0, TT, true, false>(xs, w, st, ldj, pf);
