@@ -130,10 +130,13 @@ size_t sx_packed_linear_floats(int32_t m_tiles, int32_t k_tiles);
  *   row_scale[m_tiles*32]  : A rows are multiplied by row_scale[slot]
  *   bias_scale[m_tiles*32], fold_ones: bias' = bias_scale[slot] * (b[row] + fold_ones * sum_live_cols W[row][col])
  * used to fold the constants of tanh(z) = 1 - 2/(exp2(2 log2(e) z) + 1) and exp(x) = exp2(log2(e) x) into the
- * weights so the kernel spends no VALU cycles on them (SX_ACT_TANH_FOLDED). */
+ * weights so the kernel spends no VALU cycles on them (SX_ACT_TANH_FOLDED).
+ * transpose != 0 packs W^T (row slots index W's columns, column slots W's rows; b must be NULL): the operands
+ * of the backward pass (dh = W2^T dp, dz = W1^T dh_pre). */
 int sx_pack_linear(const float *W, const float *b, int32_t out_dim, int32_t in_dim,
                    const int32_t *row_idx, const int32_t *col_idx, int32_t m_tiles, int32_t k_tiles,
-                   const float *row_scale, const float *bias_scale, float fold_ones, float *dst, void *stream);
+                   const float *row_scale, const float *bias_scale, float fold_ones, int32_t transpose,
+                   float *dst, void *stream);
 
 /* One step of a fused flow program.  The flow state lives in registers as 32-wide "tiles" of
  * columns (tile t = state slots 32t..32t+31); slots map to columns of x through in_col/out_col. */
@@ -151,6 +154,9 @@ int sx_pack_linear(const float *W, const float *b, int32_t out_dim, int32_t in_d
                                        blob = pack_linear(W2 rows, 4 m-tiles) ++ {lo, hi}; t0 = tile, c0 = group 0..3,
                                        ct = phase (0 search block, 1 select block, 2 derivatives + evaluate), tt = n_bins,
                                        pad_ = live mask of the tile's 32 slots                                          */
+#define SX_STEP_COUPLING_AFFINE_BWD 12 /* backward of one affine coupling of a log_prob pass (training): state tiles
+                                       [0,2) = x, [2,4) = dL/dx; blob = forward blob ++ pack(W2^T) ++ pack(W1^T); c0 = cond
+                                       tile, t0 = transformed tile, tt = layer slot in `side` (see sx_flow_run)        */
 #define SX_STEP_ROW_SCALE_EXP    9  /* blob = diag[tiles][2][16]: state *= exp(+-diag * t_row); t_row = row_t[n] or ldj_const */
 
 #define SX_MAX_STEPS 128
@@ -195,12 +201,16 @@ typedef struct sx_program {
  *   sum_out  one fp64: += sum_n logp_out[n] (or of ldj when logp_out is NULL); NULL to skip
  *   row_t    [n_rows] per-sample time of SX_STEP_ROW_SCALE_EXP steps (MatrixExponential with a tensor t,
  *            stribor/flows/affine.py:236-241), or NULL to use the step's constant
+ *   side     training backward only (programs of SX_STEP_COUPLING_AFFINE_BWD steps): [n_layers, n_rows, side_width]
+ *            fp32, per row [z(32) | tanh h(32*h_tiles) | dL/dh_pre(32*h_tiles) | dL/d(log_scale, shift)(64)] in slot
+ *            order, from which the caller forms the weight gradients with plain GEMMs; row_t carries dL/dlog_prob;
+ *            x is the flow's latent z, y receives dL/d(input)
  *   mlp_out  [n_rows, mlp_out_dim] (row stride mlp_out_stride) destination of SX_STEP_MLP_OUT_TILE
  *            steps, or NULL                                                                   */
 int sx_flow_run(const sx_program *prog_host, const float *blobs, const void *x, const float *latent,
                 const int32_t *in_col, const int32_t *out_col, void *y, float *ldj_out,
                 float *logp_out, double *sum_out, float *mlp_out, int64_t mlp_out_stride,
-                int32_t mlp_out_dim, const float *row_t, int64_t n_rows, int32_t dtype, void *stream);
+                int32_t mlp_out_dim, const float *row_t, float *side, int64_t n_rows, int32_t dtype, void *stream);
 
 /* LDS bytes and grid the launcher will use for a program (introspection for tests/bench). */
 int sx_flow_launch_info(const sx_program *prog_host, int64_t n_rows, int32_t *grid, int32_t *block,

@@ -29,6 +29,7 @@ STEP_COUPLING_RQS = 8
 STEP_ROW_SCALE_EXP = 9
 STEP_RQS_HIDDEN = 10
 STEP_RQS_PHASE = 11
+STEP_COUPLING_AFFINE_BWD = 12
 
 ACT_TANH_FOLDED = 9
 ACT_CODES = {'Identity': 0, 'Tanh': 1, 'ReLU': 2, 'Sigmoid': 3, 'ELU': 4, 'Softplus': 5, 'LeakyReLU': 6,
@@ -81,9 +82,9 @@ def _declare(lib: C.CDLL) -> None:
     lib.sx_packed_linear_floats.restype = C.c_size_t
     lib.sx_packed_linear_floats.argtypes = [i32, i32]
     lib.sx_pack_linear.restype = i32
-    lib.sx_pack_linear.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, f32, vp, vp]
+    lib.sx_pack_linear.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, f32, i32, vp, vp]
     lib.sx_flow_run.restype = i32
-    lib.sx_flow_run.argtypes = [C.POINTER(sx_program), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, i64, i32, vp]
+    lib.sx_flow_run.argtypes = [C.POINTER(sx_program), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, i64, i32, vp]
     lib.sx_flow_launch_info.restype = i32
     lib.sx_flow_launch_info.argtypes = [C.POINTER(sx_program), i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
 

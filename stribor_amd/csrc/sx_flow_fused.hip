@@ -18,7 +18,7 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     d->n_steps = p->n_steps; d->dim = p->dim; d->latent_dim = p->latent_dim; d->x_tiles = p->x_tiles;
     d->identity_cols = p->identity_cols; d->pad = 0;
     int mx = 256;
-    bool lin = false, rqs = false, aff = false;
+    bool lin = false, rqs = false, aff = false, bwd = false;
     *mlp_mode = 0;
     for (int i = 0; i < p->n_steps; ++i) {
         const sx_step &s = p->steps[i];
@@ -47,6 +47,12 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
                 SX_REQUIRE(s.t0 < p->x_tiles, "sx_flow_run: step %d: linear slab %d out of range", i, s.t0);
                 need = sx_packed_linear_floats(1, p->tiles); lin = true; break;
             case SX_STEP_ROW_SCALE_EXP: need = 32 * p->tiles; lin = true; break;
+            case SX_STEP_COUPLING_AFFINE_BWD:
+                SX_REQUIRE(p->tiles == 4 && p->x_tiles == 2 && s.c0 >= 0 && s.c0 < 2 && s.t0 == 1 - s.c0,
+                           "sx_flow_run: step %d: backward steps need 2 data tiles with the coupling pruned to halves", i);
+                need = sx_packed_linear_floats(p->h_tiles, 1) + sx_packed_linear_floats(2, p->h_tiles) +
+                       sx_packed_linear_floats(p->h_tiles, 2) + sx_packed_linear_floats(1, p->h_tiles);
+                bwd = true; break;
             case SX_STEP_RQS_HIDDEN: {
                 const int T = p->tiles;
                 const bool low = T >= 2 && s.c0 == 0 && s.ct == T / 2;
@@ -75,6 +81,8 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     SX_REQUIRE(!(rqs && (lin || *mlp_mode == 1)), "sx_flow_run: spline steps cannot be mixed with linear / MLP-output steps");
     SX_REQUIRE(!(rqs && aff), "sx_flow_run: spline and affine couplings cannot share one fused program");
     if (rqs) *mlp_mode = 3;
+    SX_REQUIRE(!(bwd && (rqs || lin || aff || *mlp_mode == 1)), "sx_flow_run: backward steps cannot be mixed with other step kinds");
+    if (bwd) *mlp_mode = 4;
     SX_REQUIRE((size_t)mx * 8 <= 160 * 1024, "sx_flow_run: a step needs %d B of LDS per buffer (> 80 KiB)", mx * 4);
     return SX_OK;
 }
@@ -108,7 +116,7 @@ extern "C" int sx_flow_launch_info(const sx_program *prog_host, int64_t n_rows, 
 extern "C" int sx_flow_run(const sx_program *prog_host, const float *blobs, const void *x, const float *latent,
                            const int32_t *in_col, const int32_t *out_col, void *y, float *ldj_out, float *logp_out,
                            double *sum_out, float *mlp_out, int64_t mlp_out_stride, int32_t mlp_out_dim,
-                           const float *row_t, int64_t n_rows, int32_t dtype, void *stream) {
+                           const float *row_t, float *side, int64_t n_rows, int32_t dtype, void *stream) {
     dprog d; int bf; int mlp_mode;
     int rc = validate_and_convert(prog_host, &d, &bf, &mlp_mode);
     if (rc) return rc;
@@ -119,6 +127,8 @@ extern "C" int sx_flow_run(const sx_program *prog_host, const float *blobs, cons
                "sx_flow_run: in_col/out_col required when identity_cols == 0");
     SX_REQUIRE(prog_host->latent_dim == 0 || latent != nullptr, "sx_flow_run: latent_dim > 0 but latent is NULL");
     SX_REQUIRE(mlp_mode != 1 || (mlp_out != nullptr && mlp_out_dim > 0), "sx_flow_run: MLP steps need mlp_out");
+    SX_REQUIRE(mlp_mode != 4 || (side != nullptr && row_t != nullptr && dtype == SX_F32 && prog_host->latent_dim == 0),
+               "sx_flow_run: backward programs need side, row_t (dL/dlog_prob) and fp32 state");
     SX_REQUIRE(!prog_host->identity_cols || ((uintptr_t)x & 15) == 0, "sx_flow_run: x must be 16-byte aligned");
     if (n_rows == 0) return SX_OK;
     sx_flow_args a;
@@ -128,6 +138,7 @@ extern "C" int sx_flow_run(const sx_program *prog_host, const float *blobs, cons
     a.bf16 = dtype == SX_BF16; a.mlp_mode = mlp_mode; a.lds = bf * 8; a.grid = pick_grid(n_rows, a.lds, prog_host->tiles, mlp_mode);
     a.stream = sx_stream(stream);
     a.row_t = row_t;
+    a.side = side;
     const int T = prog_host->tiles, H = prog_host->h_tiles;
 #define SX_GO(TT, HH) if (T == TT && H == HH) return sx_flow_launch_t##TT##h##HH(a)
     SX_GO(1, 1); SX_GO(1, 2); SX_GO(1, 4); SX_GO(2, 1); SX_GO(2, 2); SX_GO(2, 4); SX_GO(4, 1); SX_GO(4, 2); SX_GO(4, 4);

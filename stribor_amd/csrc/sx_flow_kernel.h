@@ -616,6 +616,98 @@ __device__ __forceinline__ void rqs_phase(tile<1> (&xs)[TX], const btile<1> (&bh
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Training: backward of one affine coupling of a log_prob pass.
+// The forward (log_prob) direction computed x_out = (x_in - sh) * exp(-ls) on the transformed tile with
+// (ls, sh) = net(x_cond) and added -sum(ls) to the log-prob.  Flows are invertible, so nothing was saved: given
+// x_out and a = dL/dx_out this step recomputes the conditioner, un-transforms the state (x_in = x_out*exp(ls) + sh)
+// and propagates the adjoint; the per-row factors of the weight gradients (z, tanh h, dL/dh_pre, dL/dparams) go to
+// HBM, where the caller contracts them over the batch with plain GEMMs.
+// State tiles: [0,2) = x, [2,4) = dL/dx.  C = conditioning x tile, T = 1 - C the transformed one.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_ctile(float *row_base, int off, const f32x16 &v, int h) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f32x4 *>(row_base + off + 8 * q + 4 * h) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+}
+template <int HT, int C>
+__device__ __forceinline__ void coupling_affine_bwd(tile<1> (&xs)[4], const wptr w, float g, float *side_row, int lane) {
+    constexpr int T = 1 - C;
+    constexpr int F1 = 0;                                   // forward pack(W1', HT x 1)
+    constexpr int F2 = HT * 1024 + HT * 32;                 // forward pack(W2', 2 x HT)
+    constexpr int B2 = F2 + 2 * HT * 1024 + 64;             // pack(W2^T, HT x 2)
+    constexpr int B1 = B2 + HT * 2 * 1024 + HT * 32;        // pack(W1^T, 1 x HT)
+    const int h = lane >> 5;
+    // 1. recompute the conditioner (folded tanh: r = (1 - tanh)/2)
+    tile<1> hid[HT];
+    hidden_layer<1, 4, HT, C, 1, true>(xs, hid, w, F1, SX_ACT_TANH_FOLDED);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hid[HT - 1].v[0][r] = fast_sig2(hid[HT - 1].v[0][r]);
+    tile<1> ls = load_cfrag<1>(w.cb, F2 + 2 * HT * 1024), sh = load_cfrag<1>(w.cb, F2 + 2 * HT * 1024 + 32);
+    {
+        btile<1> bh[HT];
+#pragma unroll
+        for (int m = 0; m < HT; ++m) bh[m] = make_btile<1>(hid[m]);
+#pragma unroll
+        for (int m = 0; m < HT; ++m) {
+            gemm_tile<1>(w.wb, F2 + m * 1024, bh[m], ls);              // rows 0..31: kk*log_scale (kk = -log2 e)
+            gemm_tile<1>(w.wb, F2 + (HT + m) * 1024, bh[m], sh);       // rows 32..63: shift
+        }
+    }
+    // 2. un-transform, adjoints of the transformed tile, parameter adjoints
+    tile<1> dls, dsh;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(ls.v[0][r]);            // exp(-log_scale)
+        const float xo = xs[T].v[0][r], al = xs[2 + T].v[0][r];
+        xs[T].v[0][r] = xo * __builtin_amdgcn_exp2f(-ls.v[0][r]) + sh.v[0][r];   // x_in
+        const float ai = al * e;                                       // dL/dx_in
+        xs[2 + T].v[0][r] = ai;
+        dsh.v[0][r] = -ai;                                             // dL/dshift
+        dls.v[0][r] = -al * xo - g;                                    // dL/dlog_scale (incl. the -sum(ls) term)
+    }
+    // 3. dh = W2^T [dls; dsh],  dh_pre = dh * (1 - tanh^2)
+    tile<1> dh[HT];
+    {
+        const btile<1> b0 = make_btile<1>(dls), b1 = make_btile<1>(dsh);
+#pragma unroll
+        for (int m = 0; m < HT; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dh[m].v[0][r] = 0.f;
+            gemm_tile<1>(w.wb, B2 + (m * 2 + 0) * 1024, b0, dh[m]);
+            gemm_tile<1>(w.wb, B2 + (m * 2 + 1) * 1024, b1, dh[m]);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < HT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float th = 1.f - 2.f * hid[m].v[0][r];               // tanh
+            hid[m].v[0][r] = th;
+            dh[m].v[0][r] *= (1.f - th * th);
+        }
+    // 4. adjoint of the conditioning tile: += W1^T dh_pre
+    tile<1> dz;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dz.v[0][r] = 0.f;
+#pragma unroll
+    for (int m = 0; m < HT; ++m) gemm_tile<1>(w.wb, B1 + m * 1024, make_btile<1>(dh[m]), dz);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xs[2 + C].v[0][r] += dz.v[0][r];
+    // 5. per-row factors of the weight gradients: [z | tanh h | dL/dh_pre | dL/dls, dL/dsh]
+    if (side_row != nullptr) {
+        store_ctile(side_row, 0, xs[C].v[0], h);
+#pragma unroll
+        for (int m = 0; m < HT; ++m) {
+            store_ctile(side_row, 32 + 32 * m, hid[m].v[0], h);
+            store_ctile(side_row, 32 + 32 * HT + 32 * m, dh[m].v[0], h);
+        }
+        store_ctile(side_row, 32 + 64 * HT, dls.v[0], h);
+        store_ctile(side_row, 64 + 64 * HT, dsh.v[0], h);
+    }
+}
+
 __device__ __forceinline__ float ld_elem(const void *p, int64_t off, int bf16) {
     if (bf16) return bf16_to_f32(reinterpret_cast<const uint16_t *>(p)[off]);
     return reinterpret_cast<const float *>(p)[off];
@@ -627,13 +719,14 @@ __device__ __forceinline__ void st_elem(void *p, int64_t off, float v, int bf16)
 
 struct flow_kargs {     // everything but the program, by value in the kernarg segment
     const float *blobs; const void *x; const float *latent; const int32_t *in_col; const int32_t *out_col;
-    void *y; float *ldj_out; float *logp_out; double *sum_out; float *mlp_out; const float *row_t;
+    void *y; float *ldj_out; float *logp_out; double *sum_out; float *mlp_out; const float *row_t; float *side;
     int64_t mlp_out_stride; int64_t n_rows; int mlp_out_dim; int buf_floats; int bf16; int pad;
 };
 
 // MODE 0: flow programs (coupling / affine-const steps); MODE 1: + persistent hidden state (MLP programs);
 // MODE 2: flow programs with dense linear layers (AffineLU / MatrixExponential): + a second state tile set;
-// MODE 3: flow programs with rational-quadratic spline couplings: + hidden B operands and the group state
+// MODE 3: flow programs with rational-quadratic spline couplings: + hidden B operands and the group state;
+// MODE 4: training backward of affine-coupling log_prob flows: tiles [0,2) = x, [2,4) = dL/dx
 template <int NS, int TX, int HT, int MODE>
 __global__ __launch_bounds__(256, SX_WAVES_FOR(TX, MODE)) void flow_fused_kernel(const dprog prog, const flow_kargs k) {
     constexpr int ROWS_PER_BLOCK = 128 * NS;
@@ -695,6 +788,13 @@ __global__ __launch_bounds__(256, SX_WAVES_FOR(TX, MODE)) void flow_fused_kernel
                             const int c = k.in_col[32 * t + sx_kmap(r, h)];
                             xs[t].v[n][r] = c >= 0 ? ld_elem(k.x, lrow[n] * dim + c, bf16) : 0.f;
                         }
+                    }
+                } else if constexpr (MODE == 4) {
+                    // adjoint tiles: dL/dz of log p = -z^2/2 + ... is -g z (g = dL/dlog_prob of the row)
+                    if constexpr (TX == 4) {
+                        const float gg = k.row_t[lrow[n]];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) xs[t].v[n][r] = -gg * xs[t - 2].v[n][r];
                     }
                 } else {   // latent tiles (fp32), conditioner-only inputs (coupling.py:64-65)
 #pragma unroll
@@ -806,6 +906,15 @@ __global__ __launch_bounds__(256, SX_WAVES_FOR(TX, MODE)) void flow_fused_kernel
                         }
                     }
                     break;
+                case SX_STEP_COUPLING_AFFINE_BWD:
+                    if constexpr (MODE == 4 && NS == 1 && TX == 4) {
+                        const float gg = k.row_t[lrow[0]];
+                        const int sw = 32 + 64 * HT + 64;
+                        float *srow = row[0] < n_rows ? k.side + ((int64_t)st.tt * n_rows + row[0]) * sw : nullptr;
+                        if (st.c0 == 0) coupling_affine_bwd<HT, 0>(xs, w, gg, srow, lane);
+                        else coupling_affine_bwd<HT, 1>(xs, w, gg, srow, lane);
+                    }
+                    break;
                 case SX_STEP_RQS_HIDDEN:
                     if constexpr (MODE == 3 && NS == 1) {
                         tile<1> hd[HT];
@@ -863,12 +972,13 @@ __global__ __launch_bounds__(256, SX_WAVES_FOR(TX, MODE)) void flow_fused_kernel
 #pragma unroll
                 for (int t = 0; t < TX; ++t) {
                     if (t < x_tiles) {
+                        const int ts = (MODE == 4 && TX == 4) ? t + 2 : t;      // backward: y receives dL/d(input)
                         if (prog.identity_cols) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 const int c = 32 * t + 8 * q + 4 * h;
                                 if (c + 3 < dim) {
-                                    const f32x16 &v = xs[t].v[n];
+                                    const f32x16 &v = xs[ts].v[n];
                                     if (bf16) {
                                         u16x4 u{f32_to_bf16(v[4 * q]), f32_to_bf16(v[4 * q + 1]), f32_to_bf16(v[4 * q + 2]),
                                                 f32_to_bf16(v[4 * q + 3])};
@@ -883,7 +993,7 @@ __global__ __launch_bounds__(256, SX_WAVES_FOR(TX, MODE)) void flow_fused_kernel
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
                                 const int c = k.out_col[32 * t + sx_kmap(r, h)];
-                                if (c >= 0) st_elem(k.y, row[n] * dim + c, xs[t].v[n][r], bf16);
+                                if (c >= 0) st_elem(k.y, row[n] * dim + c, xs[ts].v[n][r], bf16);
                             }
                         }
                     }
@@ -941,7 +1051,7 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
     constexpr int NS = SX_NS_FOR(TX);
     flow_kargs k;
     k.blobs = a.blobs; k.x = a.x; k.latent = a.latent; k.in_col = a.in_col; k.out_col = a.out_col; k.y = a.y;
-    k.ldj_out = a.ldj_out; k.logp_out = a.logp_out; k.sum_out = a.sum_out; k.mlp_out = a.mlp_out; k.row_t = a.row_t;
+    k.ldj_out = a.ldj_out; k.logp_out = a.logp_out; k.sum_out = a.sum_out; k.mlp_out = a.mlp_out; k.row_t = a.row_t; k.side = a.side;
     k.mlp_out_stride = a.mlp_out_stride; k.n_rows = a.n_rows; k.mlp_out_dim = a.mlp_out_dim;
     k.buf_floats = a.buf_floats; k.bf16 = a.bf16; k.pad = 0;
 #define SX_FL(MD)                                                                                              \
@@ -953,7 +1063,8 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
         }                                                                                                      \
         hipLaunchKernelGGL(kern, dim3(a.grid), dim3(256), a.lds, a.stream, a.prog, k);                         \
     } while (0)
-    if (a.mlp_mode == 1) SX_FL(1); else if (a.mlp_mode == 2) SX_FL(2); else if (a.mlp_mode == 3) SX_FL(3); else SX_FL(0);
+    if (a.mlp_mode == 1) SX_FL(1); else if (a.mlp_mode == 2) SX_FL(2); else if (a.mlp_mode == 3) SX_FL(3);
+    else if (a.mlp_mode == 4) SX_FL(4); else SX_FL(0);
 #undef SX_FL
     SX_LAUNCH_CHECK();
 #ifdef SX_DEBUG_KNOBS

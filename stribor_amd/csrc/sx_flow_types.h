@@ -21,6 +21,7 @@ struct sx_flow_args {
     void *y; float *ldj_out; float *logp_out; double *sum_out; float *mlp_out; int64_t mlp_out_stride;
     int mlp_out_dim; int64_t n_rows; int buf_floats; int bf16; int mlp_mode; int grid; int lds; hipStream_t stream;
     const float *row_t;
+    float *side;
 };
 
 

@@ -29,7 +29,9 @@ __global__ __launch_bounds__(256) void pack_linear_kernel(const float *__restric
                                                           const int32_t *__restrict__ col_idx, int m_tiles,
                                                           int k_tiles, const float *__restrict__ row_scale,
                                                           const float *__restrict__ bias_scale, float fold_ones,
-                                                          int frag_mode, float *__restrict__ dst) {
+                                                          int frag_mode, int transpose, float *__restrict__ dst) {
+    // transpose: the operand is W^T (row slots index W's columns, column slots index W's rows)
+    auto Wat = [&](int r, int c) -> float { return transpose ? W[(int64_t)c * in_dim + r] : W[(int64_t)r * in_dim + c]; };
     const int n_a = m_tiles * k_tiles * 1024;
     const int total = n_a + m_tiles * 32;
     for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gridDim.x * blockDim.x) {
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(256) void pack_linear_kernel(const float *__restric
             const int row = row_idx[32 * m + (lane & 31)];
             const int col = col_idx[32 * kt + sx_kmap(4 * g + e, lane >> 5)];
             if (frag_mode == 0) {
-                if (row >= 0 && col >= 0) v = W[(int64_t)row * in_dim + col] * (row_scale ? row_scale[32 * m + (lane & 31)] : 1.f);
+                if (row >= 0 && col >= 0) v = Wat(row, col) * (row_scale ? row_scale[32 * m + (lane & 31)] : 1.f);
             } else {
                 // fp16 x 3 split fragments for v_mfma_f32_32x32x16_f16: [s(2)][hi,lo][lane][8 halfs];
                 // this float holds halfs j = 2q, 2q+1 of k16-step s (k slot = kmap(8s + j, lane>>5)).
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(256) void pack_linear_kernel(const float *__restric
                     const int j = 2 * q + jj;
                     const int col2 = col_idx[32 * kt + sx_kmap(8 * s16 + j, lane >> 5)];
                     float w = 0.f;
-                    if (row >= 0 && col2 >= 0) w = W[(int64_t)row * in_dim + col2] * (row_scale ? row_scale[32 * m + (lane & 31)] : 1.f);
+                    if (row >= 0 && col2 >= 0) w = Wat(row, col2) * (row_scale ? row_scale[32 * m + (lane & 31)] : 1.f);
                     const _Float16 hi = (_Float16)w;
                     const _Float16 lo = (_Float16)(w - (float)hi);
                     const _Float16 pick = part ? lo : hi;
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void pack_linear_kernel(const float *__restric
                     double rs = 0.0;
                     for (int c = 0; c < 32 * k_tiles; ++c) {
                         const int col = col_idx[c];
-                        if (col >= 0) rs += (double)W[(int64_t)row * in_dim + col];
+                        if (col >= 0) rs += (double)Wat(row, col);
                     }
                     acc += (double)fold_ones * rs;
                 }
@@ -85,15 +87,15 @@ __global__ __launch_bounds__(256) void pack_linear_kernel(const float *__restric
 
 extern "C" int sx_pack_linear(const float *W, const float *b, int32_t out_dim, int32_t in_dim,
                               const int32_t *row_idx, const int32_t *col_idx, int32_t m_tiles, int32_t k_tiles,
-                              const float *row_scale, const float *bias_scale, float fold_ones, float *dst,
-                              void *stream) {
+                              const float *row_scale, const float *bias_scale, float fold_ones, int32_t transpose,
+                              float *dst, void *stream) {
     const int frag_mode = sx_fragment_mode();
     SX_REQUIRE(W && row_idx && col_idx && dst, "sx_pack_linear: null pointer");
     SX_REQUIRE(m_tiles > 0 && k_tiles > 0 && out_dim > 0 && in_dim > 0, "sx_pack_linear: bad sizes");
     const int total = (int)sx_packed_linear_floats(m_tiles, k_tiles);
     const int grid = (total + 255) / 256;
     hipLaunchKernelGGL(pack_linear_kernel, dim3(grid > 1024 ? 1024 : grid), dim3(256), 0, sx_stream(stream), W, b,
-                       out_dim, in_dim, row_idx, col_idx, m_tiles, k_tiles, row_scale, bias_scale, fold_ones, frag_mode, dst);
+                       out_dim, in_dim, row_idx, col_idx, m_tiles, k_tiles, row_scale, bias_scale, fold_ones, frag_mode, transpose, dst);
     SX_LAUNCH_CHECK();
     return SX_OK;
 }

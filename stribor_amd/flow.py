@@ -19,6 +19,59 @@ from .fused import CompiledProgram, ProgramBuilder
 __all__ = ['Transform', 'ElementwiseTransform', 'NormalizingFlow']
 
 
+class _FusedLogProb(torch.autograd.Function):
+    """log_prob with a hand-written backward for flows of affine couplings.
+
+    forward: the fused kernel, which also leaves the latent z in HBM.  backward: ONE launch of the backward
+    program walks the layers in the opposite order; flows are invertible, so no activation was saved -- each
+    step recomputes its conditioner from the state, un-transforms the state and propagates dL/dx; the per-row
+    factors of the weight gradients (z, tanh h, dL/dh_pre, dL/dparams) land in HBM and are contracted over the
+    batch by plain library GEMMs (torch.mm -> rocBLAS)."""
+
+    @staticmethod
+    def forward(ctx, flow, y2, *params):
+        prog = flow._fused_program(True, y2.shape[1], 0, y2.device)
+        z, _, logp = prog.run(y2, None, True, False, True)
+        ctx.flow = flow
+        ctx.save_for_backward(z)
+        ctx.need_input_grad = y2.requires_grad
+        return logp
+
+    @staticmethod
+    def backward(ctx, grad_logp):
+        flow = ctx.flow
+        (z,) = ctx.saved_tensors
+        n, d = z.shape
+        bprog, layers = flow._backward_program(d, z.device)
+        g = grad_logp.reshape(-1).to(torch.float32).contiguous()
+        width = 32 + 64 * bprog.prog.h_tiles + 64
+        side = torch.empty(len(layers), n, width, dtype=torch.float32, device=z.device)
+        gy, _, _ = bprog.run(z, None, True, False, False, row_t=g, side=side)
+        grads = {}
+        ht = 32 * bprog.prog.h_tiles
+        for slot, (cpl, info) in enumerate(layers):
+            (W1, b1), (W2, b2) = cpl._net().linears()
+            H = info['hidden']
+            sd = side[slot]
+            zz, hh, dhp, dp = sd[:, :32], sd[:, 32:32 + ht], sd[:, 32 + ht:32 + 2 * ht], sd[:, 32 + 2 * ht:]
+            dW2s = dp.t() @ hh                    # [64 slots, hidden slots]
+            dW1s = dhp.t() @ zz                   # [hidden slots, 32 cond slots]
+            rows = torch.as_tensor(info['out_rows'], device=z.device)
+            cols = torch.as_tensor(info['cond_cols'], device=z.device)
+            vr, vc = rows >= 0, cols >= 0
+            gW2 = torch.zeros_like(W2)
+            gW2[rows[vr], :H] = dW2s[vr][:, :H]
+            gb2 = torch.zeros_like(b2)
+            gb2[rows[vr]] = dp.sum(0)[vr]
+            gW1 = torch.zeros_like(W1)
+            gW1[:H, cols[vc]] = dW1s[:H][:, vc]
+            gb1 = dhp.sum(0)[:H].clone()
+            for p_, g_ in ((W1, gW1), (b1, gb1), (W2, gW2), (b2, gb2)):
+                grads[id(p_)] = g_
+        out = [grads.get(id(p_)) for p_ in flow._grad_params()]
+        return (None, gy if ctx.need_input_grad else None, *out)
+
+
 def flatten_rows(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Size]:
     """[..., D] -> contiguous [N, D] plus the leading shape (the kernels see rows = samples)."""
     lead = x.shape[:-1]
@@ -116,6 +169,61 @@ class NormalizingFlow(Transform):
         except NotImplementedError:
             return None
 
+    # ---- training (autograd) -----------------------------------------------------------------------------
+    def _grad_params(self):
+        return [p for p in self.parameters()]
+
+    def _backward_program(self, dim: int, device):
+        """The backward program of log_prob (layers in forward order) + the slot maps for the weight gradients."""
+        key = ('bwd', dim, str(device))
+        if self._fused.get(key) == 'unsupported':
+            raise NotImplementedError('training backward unsupported for this flow')
+        if key not in self._fused:
+          try:
+              from .flows.coupling import Coupling
+              from .flows.affine import Affine
+              order = list(self.transforms)
+              hw = max([f._plan_hidden_width() for f in order] + [1])
+              b = ProgramBuilder(dim, 0, hw)
+              # the backward pass starts in the slot layout the forward (log_prob) program ends in; affine-coupling
+              # flows never move columns, so that is the layout chosen from the first mask the forward pass sees
+              rev = list(reversed(order))
+              for f in rev:
+                  m = f._plan_first_mask(dim)
+                  if m is not None:
+                      b.choose_layout(m)
+                      break
+              b.enable_adjoint_tiles()
+              layers = []
+              for f in order:
+                  if not (isinstance(f, Coupling) and isinstance(f.transform, Affine)):
+                      raise NotImplementedError('training backward is implemented for flows of Coupling(Affine) layers')
+                  net = f._net()
+                  lin = net.linears()
+                  if len(lin) != 2 or net.activation_name != 'Tanh':
+                      raise NotImplementedError('training backward needs Linear-Tanh-Linear conditioners')
+                  (W1, b1), (W2, b2) = lin
+                  info = b.add_coupling_affine_bwd(W1, b1, W2, b2, f.mask_vector(dim), W1.shape[0], len(layers))
+                  layers.append((f, info))
+              self._fused[key] = (b.build(device), layers)
+          except NotImplementedError:
+            self._fused[key] = 'unsupported'
+            raise
+        return self._fused[key]
+
+    def _can_backward(self, y) -> bool:
+        try:
+            d = y.shape[-1]
+            if self._fused_program(True, d, 0, y.device) is None:
+                return False
+            self._backward_program(d, y.device)
+            return True
+        except NotImplementedError:
+            return False
+
+    def _wants_grad(self, y) -> bool:
+        return torch.is_grad_enabled() and (y.requires_grad or any(p.requires_grad for p in self.parameters()))
+
     def _run(self, x, reverse: bool, latent, want_y, want_ldj, want_logp, sum_out=None, **kwargs):
         """Returns (y, ldj[..., 1], logp[..., 1]) (None where not requested) via the fused kernel, or None
         when the flow cannot be fused."""
@@ -181,6 +289,12 @@ class NormalizingFlow(Transform):
         """[..., D] -> [..., 1]   (flow.py:127-130)."""
         from .dist.normal import UnitNormal
         if isinstance(self.base_dist, UnitNormal):
+            _hip.require_device(y, 'y')
+            if self._wants_grad(y) and latent is None and not kwargs and self._can_backward(y):
+                # differentiable path: fp32 state, hand-written backward (flows of affine couplings); every other
+                # flow evaluates without a graph, as before
+                y2, lead = flatten_rows(y.to(torch.float32))
+                return _FusedLogProb.apply(self, y2, *self._grad_params()).reshape(*lead, 1)
             r = self._run(y, True, latent, False, False, True, **kwargs)
             if r is not None:
                 return r[2]

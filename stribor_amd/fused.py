@@ -48,7 +48,8 @@ class _PackJob:
 
     def __init__(self, W, b, row_idx: np.ndarray, col_idx: np.ndarray, m_tiles: int, k_tiles: int, dst_off: int,
                  row_scale: Optional[np.ndarray] = None, bias_scale: Optional[np.ndarray] = None,
-                 fold_ones: float = 0.0):
+                 fold_ones: float = 0.0, transpose: bool = False):
+        self.transpose = int(transpose)
         self.W, self.b = W, b
         self.row_idx_host, self.col_idx_host = row_idx.astype(np.int32), col_idx.astype(np.int32)
         self.m_tiles, self.k_tiles, self.dst_off = m_tiles, k_tiles, dst_off
@@ -75,7 +76,7 @@ class _PackJob:
         rc = _hip.lib().sx_pack_linear(W.data_ptr(), _hip.ptr(b), out_dim, in_dim, self.row_idx.data_ptr(),
                                        self.col_idx.data_ptr(), self.m_tiles, self.k_tiles,
                                        _hip.ptr(self.row_scale), _hip.ptr(self.bias_scale), self.fold_ones,
-                                       blobs.data_ptr() + 4 * self.dst_off, _hip.stream())
+                                       self.transpose, blobs.data_ptr() + 4 * self.dst_off, _hip.stream())
         _hip.check(rc, 'sx_pack_linear')
 
     def params(self):
@@ -103,7 +104,7 @@ class _DerivedLinearJob:
                              for (r, c, _, _) in self.targets]
         for (ri, ci), (_, _, k_tiles, off) in zip(self._dev_idx, self.targets):
             rc = _hip.lib().sx_pack_linear(W.data_ptr(), _hip.ptr(b), W.shape[0], W.shape[1], ri.data_ptr(),
-                                           ci.data_ptr(), 1, k_tiles, None, None, 0.0,
+                                           ci.data_ptr(), 1, k_tiles, None, None, 0.0, 0,
                                            blobs.data_ptr() + 4 * off, _hip.stream())
             _hip.check(rc, 'sx_pack_linear')
 
@@ -193,7 +194,8 @@ class CompiledProgram:
     # -- launch -----------------------------------------------------------------------------------
     def run(self, x: torch.Tensor, latent: Optional[torch.Tensor] = None, want_y: bool = False,
             want_ldj: bool = False, want_logp: bool = False, sum_out: Optional[torch.Tensor] = None,
-            mlp_out: Optional[torch.Tensor] = None, row_t: Optional[torch.Tensor] = None):
+            mlp_out: Optional[torch.Tensor] = None, row_t: Optional[torch.Tensor] = None,
+            side: Optional[torch.Tensor] = None):
         """x: [N, dim] contiguous on the program's device.  Returns (y | None, ldj | None, logp | None)."""
         _hip.require_device(x, 'x')
         assert x.dim() == 2 and x.shape[1] == self.prog.dim, (x.shape, self.prog.dim)
@@ -222,7 +224,8 @@ class CompiledProgram:
         rc = _hip.lib().sx_flow_run(C.byref(self.prog), self.blobs.data_ptr(), x.data_ptr(), _hip.ptr(latent),
                                     _hip.ptr(self.in_col), _hip.ptr(self.out_col), _hip.ptr(y), _hip.ptr(ldj),
                                     _hip.ptr(logp), _hip.ptr(sum_out), _hip.ptr(mlp_out), stride,
-                                    self.mlp_out_dim, _hip.ptr(row_t), n, _hip.dtype_code(x), _hip.stream())
+                                    self.mlp_out_dim, _hip.ptr(row_t), _hip.ptr(side), n, _hip.dtype_code(x),
+                                    _hip.stream())
         _hip.check(rc, 'sx_flow_run')
         return y, ldj, logp
 
@@ -466,6 +469,55 @@ class ProgramBuilder:
                                 blob_off=off, blob_floats=n, ldj_scale=s_scale, ldj_const=0.0)
                     step['pad_'] = live_mask - (1 << 32) if live_mask >= (1 << 31) else live_mask
                     self.steps.append(step)
+
+    def enable_adjoint_tiles(self) -> None:
+        """Backward programs carry dL/dx beside x: tiles [0, x_tiles) = x, [x_tiles, 2 x_tiles) = adjoint."""
+        if self.x_tiles != 2 or self.latent_dim:
+            raise NotImplementedError('training backward is built for 33..64 columns without latent inputs')
+        self.tiles = 4
+
+    def add_coupling_affine_bwd(self, W1, b1, W2, b2, mask: np.ndarray, hidden: int, layer_slot: int) -> dict:
+        """Backward of one affine coupling of a log_prob pass; returns the slot maps the caller needs to turn the
+        kernel's per-row factors into weight gradients."""
+        self._freeze_input()
+        assert self.tiles == 4 and self.x_tiles == 2
+        D, HT = self.dim, self.h_tiles
+        mask = np.asarray(mask, dtype=np.float64).reshape(-1)
+        cond_col, live_col = mask > 0.5, mask <= 0.5
+        col = self.col_of_slot
+        slot_cond = np.array([c >= 0 and cond_col[c] for c in col])
+        slot_live = np.array([c >= 0 and live_col[c] for c in col])
+        if not slot_cond[32:].any() and not slot_live[:32].any():
+            c0 = 0
+        elif not slot_cond[:32].any() and not slot_live[32:].any():
+            c0 = 1
+        else:
+            raise NotImplementedError('training backward needs the coupling mask aligned with the 32-column tiles')
+        t0 = 1 - c0
+        LOG2E = 1.4426950408889634
+        kk = -LOG2E                                              # log_prob direction: scale = exp(-log_scale)
+        col_idx = np.array([col[p] if slot_cond[p] else -1 for p in range(32 * c0, 32 * c0 + 32)], dtype=np.int64)
+        row_h = np.full(32 * HT, -1, dtype=np.int64)
+        row_h[:hidden] = np.arange(hidden)
+        row2 = np.full(64, -1, dtype=np.int64)
+        for i in range(32):
+            p = 32 * t0 + i
+            if slot_live[p]:
+                row2[i] = col[p]
+                row2[32 + i] = D + col[p]
+        n1, n2 = _hip.packed_linear_floats(HT, 1), _hip.packed_linear_floats(2, HT)
+        n3, n4 = _hip.packed_linear_floats(HT, 2), _hip.packed_linear_floats(1, HT)
+        off, n = self._alloc(n1 + n2 + n3 + n4)
+        rs1 = np.full(32 * HT, 2.0 * LOG2E)
+        rs2 = np.concatenate([np.full(32, -2.0 * kk), np.full(32, -2.0)])
+        bs2 = np.concatenate([np.full(32, kk), np.full(32, 1.0)])
+        self.jobs.append(_PackJob(W1, b1, row_h, col_idx, HT, 1, off, rs1, rs1, 0.0))
+        self.jobs.append(_PackJob(W2, b2, row2, row_h, 2, HT, off + n1, rs2, bs2, 1.0))
+        self.jobs.append(_PackJob(W2, None, row_h, row2, HT, 2, off + n1 + n2, transpose=True))     # W2^T
+        self.jobs.append(_PackJob(W1, None, col_idx, row_h, 1, HT, off + n1 + n2 + n3, transpose=True))   # W1^T
+        self.steps.append(dict(kind=_hip.STEP_COUPLING_AFFINE_BWD, c0=c0, ct=1, t0=t0, tt=layer_slot, reverse=1,
+                               act=_hip.ACT_TANH_FOLDED, blob_off=off, blob_floats=n, ldj_scale=0.0, ldj_const=0.0))
+        return dict(cond_cols=col_idx, out_rows=row2, hidden=hidden)
 
     def add_affine_const(self, log_scale, shift, reverse: bool, ldj_scale: float) -> None:
         self._freeze_input()
