@@ -212,6 +212,14 @@ int sx_flow_run(const sx_program *prog_host, const float *blobs, const void *x, 
                 float *logp_out, double *sum_out, float *mlp_out, int64_t mlp_out_stride,
                 int32_t mlp_out_dim, const float *row_t, float *side, int64_t n_rows, int32_t dtype, void *stream);
 
+/* Weight-gradient contraction of the training backward pass:
+ *   dW[i, j] += sum_n A[n, i] * B[n, j]   (dW row stride ldw),   db[i] += sum_n A[n, i]   (db may be NULL)
+ * A = [n_rows, M], B = [n_rows, Nc] row-major fp32 with row strides lda / ldb (slices of `side`), M, Nc <= 128.
+ * dW / db are accumulated into (float atomics): zero them first.  Replaces autograd's dense matmuls over the
+ * batch axis for nn.Linear inside stribor/net/mlp.py:48-58. */
+int sx_wgrad(const float *A, int64_t lda, int32_t M, const float *B, int64_t ldb, int32_t Nc, int64_t n_rows,
+             float *dW, int64_t ldw, float *db, void *stream);
+
 /* LDS bytes and grid the launcher will use for a program (introspection for tests/bench). */
 int sx_flow_launch_info(const sx_program *prog_host, int64_t n_rows, int32_t *grid, int32_t *block,
                         int32_t *lds_bytes);

@@ -38,7 +38,7 @@ ACT_CODES = {'Identity': 0, 'Tanh': 1, 'ReLU': 2, 'Sigmoid': 3, 'ELU': 4, 'Softp
 # every symbol include/stribor_hip.h declares (tests check that the library exports all of them)
 EXPORTS = ['sx_abi_version', 'sx_fragment_mode', 'sx_last_error', 'sx_permute', 'sx_affine_coupling', 'sx_rqs_coupling',
            'sx_unit_normal_logprob', 'sx_sum_f64', 'sx_packed_linear_floats', 'sx_pack_linear', 'sx_flow_run',
-           'sx_flow_launch_info']
+           'sx_flow_launch_info', 'sx_wgrad']
 
 
 class HipLibraryMissing(RuntimeError):
@@ -85,6 +85,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.sx_pack_linear.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, f32, i32, vp, vp]
     lib.sx_flow_run.restype = i32
     lib.sx_flow_run.argtypes = [C.POINTER(sx_program), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, i64, i32, vp]
+    lib.sx_wgrad.restype = i32
+    lib.sx_wgrad.argtypes = [vp, i64, i32, vp, i64, i32, i64, vp, i64, vp, vp]
     lib.sx_flow_launch_info.restype = i32
     lib.sx_flow_launch_info.argtypes = [C.POINTER(sx_program), i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
 

@@ -54,18 +54,26 @@ class _FusedLogProb(torch.autograd.Function):
             H = info['hidden']
             sd = side[slot]
             zz, hh, dhp, dp = sd[:, :32], sd[:, 32:32 + ht], sd[:, 32 + ht:32 + 2 * ht], sd[:, 32 + 2 * ht:]
-            dW2s = dp.t() @ hh                    # [64 slots, hidden slots]
-            dW1s = dhp.t() @ zz                   # [hidden slots, 32 cond slots]
+            # contract the per-row factors over the batch (sx_wgrad: chip-wide split over rows, fp32 MFMA)
+            dW2s = torch.zeros(64, ht, dtype=torch.float32, device=z.device)       # [64 slots, hidden slots]
+            db2s = torch.zeros(64, dtype=torch.float32, device=z.device)
+            dW1s = torch.zeros(ht, 32, dtype=torch.float32, device=z.device)       # [hidden slots, 32 cond slots]
+            db1s = torch.zeros(ht, dtype=torch.float32, device=z.device)
+            lib = _hip.lib()
+            _hip.check(lib.sx_wgrad(dp.data_ptr(), width, 64, hh.data_ptr(), width, ht, n, dW2s.data_ptr(), ht,
+                                    db2s.data_ptr(), _hip.stream()), 'sx_wgrad')
+            _hip.check(lib.sx_wgrad(dhp.data_ptr(), width, ht, zz.data_ptr(), width, 32, n, dW1s.data_ptr(), 32,
+                                    db1s.data_ptr(), _hip.stream()), 'sx_wgrad')
             rows = torch.as_tensor(info['out_rows'], device=z.device)
             cols = torch.as_tensor(info['cond_cols'], device=z.device)
             vr, vc = rows >= 0, cols >= 0
             gW2 = torch.zeros_like(W2)
             gW2[rows[vr], :H] = dW2s[vr][:, :H]
             gb2 = torch.zeros_like(b2)
-            gb2[rows[vr]] = dp.sum(0)[vr]
+            gb2[rows[vr]] = db2s[vr]
             gW1 = torch.zeros_like(W1)
             gW1[:H, cols[vc]] = dW1s[:H][:, vc]
-            gb1 = dhp.sum(0)[:H].clone()
+            gb1 = db1s[:H].clone()
             for p_, g_ in ((W1, gW1), (b1, gb1), (W2, gW2), (b2, gb2)):
                 grads[id(p_)] = g_
         out = [grads.get(id(p_)) for p_ in flow._grad_params()]

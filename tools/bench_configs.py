@@ -47,7 +47,7 @@ CONFIGS = {
 
 
 def main():
-    names = [a for a in sys.argv[1:] if not a.startswith('--')] or list(CONFIGS)
+    names = [a for a in sys.argv[1:] if not a.startswith('--') and not a.isdigit()] or list(CONFIGS)
     rows_override = None
     if '--rows' in sys.argv:
         rows_override = int(sys.argv[sys.argv.index('--rows') + 1])
@@ -59,8 +59,18 @@ def main():
         flow = fd.build_flow(st, mk(), dim).to(dev)
         x = torch.randn(rows, dim, device=dev).to(dt)
         fused = flow._fused_program(True, dim, 0, dev) is not None
-        ms = timed(lambda: flow.log_prob(x))
-        lp = flow.log_prob(x)
+        with torch.no_grad():
+            ms = timed(lambda: flow.log_prob(x))
+            lp = flow.log_prob(x)
+        if name == 'cfg2_f32' and '--train' in sys.argv:
+            def train_step():
+                for p_ in flow.parameters():
+                    p_.grad = None
+                loss = -flow.log_prob(x).mean()
+                loss.backward()
+            tms = timed(train_step, reps=5, inner=2)
+            print(json.dumps({'config': 'cfg2_f32 forward+backward (loss = -mean log_prob)', 'rows': rows,
+                              'ms_per_batch': tms, 'rows_per_s': rows / (tms * 1e-3)}))
         print(json.dumps({'config': name, 'rows': rows, 'dim': dim, 'x_dtype': str(dt), 'fused_single_launch': fused,
                           'ms_per_batch': ms, 'rows_per_s': rows / (ms * 1e-3), 'finite': bool(torch.isfinite(lp).all()),
                           'mean_log_prob': lp.mean().item()}))
