@@ -446,42 +446,56 @@ __device__ __forceinline__ void rqs_gemm(const wptr w, const btile<1> (&bh)[HT],
 // parameter k (0..15) of element q: register 4q + (k & 3) of output tile k >> 2
 #define RQS_P(acc, q, k) (acc)[(k) >> 2].v[0][4 * (q) + ((k) & 3)]
 
+// The three per-element routines are written branch-free (selects only) and take the bin count as a template
+// argument: KC = 16 is the straight-line hot path of cfg 3, KC = 0 keeps K as a run-time value (k < K predicates).
+template <int KC>
+__device__ __forceinline__ bool rqs_has(int k, int K) { return KC ? (k < KC) : (k < K); }
+
 // softmax numerators in place + the factor that turns them into bin sizes: size_k = MIN + e_k * inv
-template <int Q>
+template <int Q, int KC>
 __device__ __forceinline__ float rqs_softmax(tile<1> (&acc)[4], int K) {
     float mx = RQS_P(acc, Q, 0);
 #pragma unroll
     for (int k = 1; k < 16; ++k)
-        if (k < K) mx = fmaxf(mx, RQS_P(acc, Q, k));
+        if (KC ? (k < KC) : true) mx = fmaxf(mx, rqs_has<KC>(k, K) ? RQS_P(acc, Q, k) : mx);
     float sum = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k)
-        if (k < K) {
-            const float e = fast_exp(RQS_P(acc, Q, k) - mx);
+        if (KC ? (k < KC) : true) {
+            const float e = rqs_has<KC>(k, K) ? fast_exp(RQS_P(acc, Q, k) - mx) : 0.f;
             RQS_P(acc, Q, k) = e;
             sum += e;
         }
-    return (1.f - RQS_MIN * (float)K) * fast_rcp(sum);         // :101-105
+    const float Kf = KC ? (float)KC : (float)K;
+    return (1.f - RQS_MIN * Kf) * fast_rcp(sum);         // :101-105
 }
 
-// phase 0: knots of the searched block (:180-192) and the bin search (search_sorted.py:4-5) in one sweep
-template <int Q>
+// phase 0: knots of the searched block (:180-192) and the bin search (search_sorted.py:4-5) in one sweep.
+// The knots increase and `x >= knot_j` is true for a prefix of j, so
+//   knot at the bin  = last knot with x >= knot  (running select),
+//   next knot        = min over the knots with x < knot (min with `hi` where x >= knot).
+template <int Q, int KC>
 __device__ __forceinline__ void rqs_search(tile<1> (&acc)[4], rqs_elems &e, int K, float lo, float hi) {
     const float xv = e.x[Q];
-    e.in[Q] = (xv >= lo) && (xv <= hi);                       // :71 closed interval
-    const float xin = e.in[Q] ? xv : lo;
-    const float inv = rqs_softmax<Q>(acc, K);
+    const bool in = (xv >= lo) && (xv <= hi);                       // :71 closed interval
+    e.in[Q] = in;
+    const float xin = in ? xv : lo;
+    const float inv = rqs_softmax<Q, KC>(acc, K);
+    const int Kn = KC ? KC : K;
     int b = 0;
     float k_b = lo, k_n = hi, cs = 0.f;
-    bool have = false;
 #pragma unroll
     for (int j = 1; j <= 16; ++j) {
-        if (j <= K) {
+        if (KC ? (j <= KC) : true) {
             cs += RQS_MIN + RQS_P(acc, Q, j - 1) * inv;
-            const float knot = (j < K) ? (hi - lo) * cs + lo : hi;       // ends pinned
-            const bool ge = xin >= ((j < K) ? knot : knot + 1e-6f);
-            if (ge && j < K) { b = j; k_b = knot; }
-            else if (!ge && !have) { k_n = knot; have = true; }
+            const bool last = (j == Kn);
+            const bool used = KC ? true : (j <= K);
+            const float knot = last ? hi : (hi - lo) * cs + lo;          // ends pinned
+            const bool ge = used && (xin >= (last ? knot + 1e-6f : knot));
+            const bool take = ge && !last;                               // j == K only clamps (see rqs_kernel)
+            b = take ? j : b;
+            k_b = take ? knot : k_b;
+            k_n = fminf(k_n, (ge || !used) ? hi : knot);
         }
     }
     e.b[Q] = b;
@@ -489,18 +503,20 @@ __device__ __forceinline__ void rqs_search(tile<1> (&acc)[4], rqs_elems &e, int 
     e.a_w[Q] = k_n - k_b;
 }
 // phase 1: knots of the other block at the found bin
-template <int Q>
+template <int Q, int KC>
 __device__ __forceinline__ void rqs_select(tile<1> (&acc)[4], rqs_elems &e, int K, float lo, float hi) {
-    const float inv = rqs_softmax<Q>(acc, K);
+    const float inv = rqs_softmax<Q, KC>(acc, K);
+    const int Kn = KC ? KC : K;
     const int b = e.b[Q];
     float k_b = lo, k_n = hi, cs = 0.f;
 #pragma unroll
     for (int j = 1; j <= 16; ++j) {
-        if (j <= K) {
+        if (KC ? (j < KC) : true) {                                      // knot K is `hi` (the initial k_n)
             cs += RQS_MIN + RQS_P(acc, Q, j - 1) * inv;
-            const float knot = (j < K) ? (hi - lo) * cs + lo : hi;
-            if (j == b) k_b = knot;
-            if (j == b + 1) k_n = knot;
+            const bool used = KC ? true : (j < Kn);
+            const float knot = (hi - lo) * cs + lo;
+            k_b = (used && j == b) ? knot : k_b;
+            k_n = (used && j == b + 1) ? knot : k_n;
         }
     }
     e.c_b[Q] = k_b;
@@ -512,17 +528,19 @@ __device__ __forceinline__ float fast_log(float v) { return __builtin_amdgcn_log
 __device__ __forceinline__ float rqs_softplus(float v) { return v > 20.f ? v : fast_log(1.f + fast_exp(v)); }
 // phase 2: the two knot derivatives at the bin (:107,:206-207), then the rational-quadratic (:236-248) or its
 // inverse (:212-234; the returned log-derivative is already negated like the reference's).
-template <int Q, bool REV>
+template <int Q, bool REV, int KC>
 __device__ __forceinline__ void rqs_eval(tile<1> (&acc)[4], const rqs_elems &e, int K, float &out, float &ljd) {
     const int b = e.b[Q];
-    const float cst = 0.5397424172369522f;                            // log(exp(1 - 1e-3) - 1), :81 boundary derivative constant
+    const int Kn = KC ? KC : K;
+    const float cst = 0.5397424172369522f;                      // log(exp(1 - 1e-3) - 1), :81 boundary derivative constant
     float r_b = cst, r_n = cst;
 #pragma unroll
     for (int k = 0; k < 15; ++k) {
-        if (k < K - 1) {
+        if (KC ? (k < KC - 1) : true) {
+            const bool used = KC ? true : (k < Kn - 1);
             const float v = RQS_P(acc, Q, k);
-            if (k == b - 1) r_b = v;
-            if (k == b) r_n = v;
+            r_b = (used && k == b - 1) ? v : r_b;
+            r_n = (used && k == b) ? v : r_n;
         }
     }
     const float d_b = RQS_MIN + rqs_softplus(r_b), d_n = RQS_MIN + rqs_softplus(r_n);
@@ -553,18 +571,14 @@ __device__ __forceinline__ void rqs_eval(tile<1> (&acc)[4], const rqs_elems &e, 
         const float dnum = (s_b * s_b) * (d_n * (theta * theta) + 2.f * s_b * tomt + d_b * (omt * omt));
         ljd = fast_log(dnum) - 2.f * fast_log(den);
     }
-    if (!e.in[Q]) { out = e.x[Q]; ljd = 0.f; }                // :86-87 linear tails
+    out = e.in[Q] ? out : e.x[Q];                               // :86-87 linear tails
+    ljd = e.in[Q] ? ljd : 0.f;
 }
 
-template <int TX, int HT>
-__device__ __forceinline__ void rqs_phase(tile<1> (&xs)[TX], const btile<1> (&bh)[HT], rqs_elems &e, const wptr w,
-                                          const dstep &st, float &ldj, int lane) {
-    const int h = lane >> 5;
+template <int TX, int HT, int KC>
+__device__ __forceinline__ void rqs_phase_k(tile<1> (&acc)[4], tile<1> (&xs)[TX], rqs_elems &e, const dstep &st,
+                                            float lo, float hi, float &ldj, int h) {
     const int g = st.c0, K = st.tt;
-    tile<1> acc[4];
-    rqs_gemm<HT>(w, bh, acc);
-    const float lo = *reinterpret_cast<const float *>(w.cb - h * 64 + (4 * HT * 1024 + 128) * 4);
-    const float hi = *reinterpret_cast<const float *>(w.cb - h * 64 + (4 * HT * 1024 + 129) * 4);
     if (st.ct == 0) {
         // fetch the group's 4 inputs out of the state tile (wave-uniform selects keep register indices static)
 #pragma unroll
@@ -575,34 +589,34 @@ __device__ __forceinline__ void rqs_phase(tile<1> (&xs)[TX], const btile<1> (&bh
 #pragma unroll
                     for (int q = 0; q < 4; ++q) e.x[q] = xs[t].v[0][4 * gg + q];
                 }
-        rqs_search<0>(acc, e, K, lo, hi);
-        rqs_search<1>(acc, e, K, lo, hi);
-        rqs_search<2>(acc, e, K, lo, hi);
-        rqs_search<3>(acc, e, K, lo, hi);
+        rqs_search<0, KC>(acc, e, K, lo, hi);
+        rqs_search<1, KC>(acc, e, K, lo, hi);
+        rqs_search<2, KC>(acc, e, K, lo, hi);
+        rqs_search<3, KC>(acc, e, K, lo, hi);
     } else if (st.ct == 1) {
-        rqs_select<0>(acc, e, K, lo, hi);
-        rqs_select<1>(acc, e, K, lo, hi);
-        rqs_select<2>(acc, e, K, lo, hi);
-        rqs_select<3>(acc, e, K, lo, hi);
+        rqs_select<0, KC>(acc, e, K, lo, hi);
+        rqs_select<1, KC>(acc, e, K, lo, hi);
+        rqs_select<2, KC>(acc, e, K, lo, hi);
+        rqs_select<3, KC>(acc, e, K, lo, hi);
     } else {
         float out[4], lj[4];
         if (st.reverse) {
-            rqs_eval<0, true>(acc, e, K, out[0], lj[0]);
-            rqs_eval<1, true>(acc, e, K, out[1], lj[1]);
-            rqs_eval<2, true>(acc, e, K, out[2], lj[2]);
-            rqs_eval<3, true>(acc, e, K, out[3], lj[3]);
+            rqs_eval<0, true, KC>(acc, e, K, out[0], lj[0]);
+            rqs_eval<1, true, KC>(acc, e, K, out[1], lj[1]);
+            rqs_eval<2, true, KC>(acc, e, K, out[2], lj[2]);
+            rqs_eval<3, true, KC>(acc, e, K, out[3], lj[3]);
         } else {
-            rqs_eval<0, false>(acc, e, K, out[0], lj[0]);
-            rqs_eval<1, false>(acc, e, K, out[1], lj[1]);
-            rqs_eval<2, false>(acc, e, K, out[2], lj[2]);
-            rqs_eval<3, false>(acc, e, K, out[3], lj[3]);
+            rqs_eval<0, false, KC>(acc, e, K, out[0], lj[0]);
+            rqs_eval<1, false, KC>(acc, e, K, out[1], lj[1]);
+            rqs_eval<2, false, KC>(acc, e, K, out[2], lj[2]);
+            rqs_eval<3, false, KC>(acc, e, K, out[3], lj[3]);
         }
         float s = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const bool live = (st.mask >> (q + 8 * g + 4 * h)) & 1u;     // slot kmap(4g+q, h) of the tile
-            if (!live) { out[q] = e.x[q]; lj[q] = 0.f; }
-            s += lj[q];
+            out[q] = live ? out[q] : e.x[q];
+            s += live ? lj[q] : 0.f;
         }
 #pragma unroll
         for (int t = 0; t < TX; ++t)
@@ -616,6 +630,17 @@ __device__ __forceinline__ void rqs_phase(tile<1> (&xs)[TX], const btile<1> (&bh
     }
 }
 
+template <int TX, int HT>
+__device__ __forceinline__ void rqs_phase(tile<1> (&xs)[TX], const btile<1> (&bh)[HT], rqs_elems &e, const wptr w,
+                                          const dstep &st, float &ldj, int lane) {
+    const int h = lane >> 5;
+    tile<1> acc[4];
+    rqs_gemm<HT>(w, bh, acc);
+    const float lo = *reinterpret_cast<const float *>(w.cb - h * 64 + (4 * HT * 1024 + 128) * 4);
+    const float hi = *reinterpret_cast<const float *>(w.cb - h * 64 + (4 * HT * 1024 + 129) * 4);
+    if (st.tt == 16) rqs_phase_k<TX, HT, 16>(acc, xs, e, st, lo, hi, ldj, h);
+    else rqs_phase_k<TX, HT, 0>(acc, xs, e, st, lo, hi, ldj, h);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Training: backward of one affine coupling of a log_prob pass.
