@@ -28,6 +28,8 @@ class _FusedLogProb(torch.autograd.Function):
     factors of the weight gradients (z, tanh h, dL/dh_pre, dL/dparams) land in HBM and are contracted over the
     batch by plain library GEMMs (torch.mm -> rocBLAS)."""
 
+    SIDE_BYTES = 8 << 30      # scratch for the per-row gradient factors (8 GiB of the 288 GB: 2^20-row blocks at 8 layers)
+
     @staticmethod
     def forward(ctx, flow, y2, *params):
         prog = flow._fused_program(True, y2.shape[1], 0, y2.device)
@@ -44,36 +46,47 @@ class _FusedLogProb(torch.autograd.Function):
         n, d = z.shape
         bprog, layers = flow._backward_program(d, z.device)
         g = grad_logp.reshape(-1).to(torch.float32).contiguous()
-        width = 32 + 64 * bprog.prog.h_tiles + 64
-        side = torch.empty(len(layers), n, width, dtype=torch.float32, device=z.device)
-        gy, _, _ = bprog.run(z, None, True, False, False, row_t=g, side=side)
-        grads = {}
         ht = 32 * bprog.prog.h_tiles
+        width = 32 + 2 * ht + 64
+        dev = z.device
+        # slot-ordered gradient accumulators per layer (sx_wgrad adds into them)
+        acc = [dict(W2=torch.zeros(64, ht, dtype=torch.float32, device=dev), b2=torch.zeros(64, dtype=torch.float32, device=dev),
+                    W1=torch.zeros(ht, 32, dtype=torch.float32, device=dev), b1=torch.zeros(ht, dtype=torch.float32, device=dev))
+               for _ in layers]
+        gy = torch.empty_like(z) if ctx.need_input_grad else None
+        lib = _hip.lib()
+        # the per-row factors are 224 floats per row and layer: bound the scratch by walking the batch in blocks
+        block = max(1, min(n, _FusedLogProb.SIDE_BYTES // (len(layers) * width * 4)))
+        side = torch.empty(len(layers), block, width, dtype=torch.float32, device=dev)
+        for lo in range(0, n, block):
+            m = min(block, n - lo)
+            sd_all = side if m == block else torch.empty(len(layers), m, width, dtype=torch.float32, device=dev)
+            gblk, _, _ = bprog.run(z[lo:lo + m], None, True, False, False, row_t=g[lo:lo + m], side=sd_all)
+            if gy is not None:
+                gy[lo:lo + m] = gblk
+            for slot in range(len(layers)):
+                sd = sd_all[slot]
+                zz, hh, dhp, dp = sd[:, :32], sd[:, 32:32 + ht], sd[:, 32 + ht:32 + 2 * ht], sd[:, 32 + 2 * ht:]
+                a = acc[slot]
+                _hip.check(lib.sx_wgrad(dp.data_ptr(), width, 64, hh.data_ptr(), width, ht, m, a['W2'].data_ptr(), ht,
+                                        a['b2'].data_ptr(), _hip.stream()), 'sx_wgrad')
+                _hip.check(lib.sx_wgrad(dhp.data_ptr(), width, ht, zz.data_ptr(), width, 32, m, a['W1'].data_ptr(), 32,
+                                        a['b1'].data_ptr(), _hip.stream()), 'sx_wgrad')
+        grads = {}
         for slot, (cpl, info) in enumerate(layers):
             (W1, b1), (W2, b2) = cpl._net().linears()
             H = info['hidden']
-            sd = side[slot]
-            zz, hh, dhp, dp = sd[:, :32], sd[:, 32:32 + ht], sd[:, 32 + ht:32 + 2 * ht], sd[:, 32 + 2 * ht:]
-            # contract the per-row factors over the batch (sx_wgrad: chip-wide split over rows, fp32 MFMA)
-            dW2s = torch.zeros(64, ht, dtype=torch.float32, device=z.device)       # [64 slots, hidden slots]
-            db2s = torch.zeros(64, dtype=torch.float32, device=z.device)
-            dW1s = torch.zeros(ht, 32, dtype=torch.float32, device=z.device)       # [hidden slots, 32 cond slots]
-            db1s = torch.zeros(ht, dtype=torch.float32, device=z.device)
-            lib = _hip.lib()
-            _hip.check(lib.sx_wgrad(dp.data_ptr(), width, 64, hh.data_ptr(), width, ht, n, dW2s.data_ptr(), ht,
-                                    db2s.data_ptr(), _hip.stream()), 'sx_wgrad')
-            _hip.check(lib.sx_wgrad(dhp.data_ptr(), width, ht, zz.data_ptr(), width, 32, n, dW1s.data_ptr(), 32,
-                                    db1s.data_ptr(), _hip.stream()), 'sx_wgrad')
-            rows = torch.as_tensor(info['out_rows'], device=z.device)
-            cols = torch.as_tensor(info['cond_cols'], device=z.device)
+            a = acc[slot]
+            rows = torch.as_tensor(info['out_rows'], device=dev)
+            cols = torch.as_tensor(info['cond_cols'], device=dev)
             vr, vc = rows >= 0, cols >= 0
             gW2 = torch.zeros_like(W2)
-            gW2[rows[vr], :H] = dW2s[vr][:, :H]
+            gW2[rows[vr], :H] = a['W2'][vr][:, :H]
             gb2 = torch.zeros_like(b2)
-            gb2[rows[vr]] = db2s[vr]
+            gb2[rows[vr]] = a['b2'][vr]
             gW1 = torch.zeros_like(W1)
-            gW1[:H, cols[vc]] = dW1s[:H][:, vc]
-            gb1 = db1s[:H].clone()
+            gW1[:H, cols[vc]] = a['W1'][:H][:, vc]
+            gb1 = a['b1'][:H].clone()
             for p_, g_ in ((W1, gW1), (b1, gb1), (W2, gW2), (b2, gb2)):
                 grads[id(p_)] = g_
         out = [grads.get(id(p_)) for p_ in flow._grad_params()]
