@@ -77,15 +77,13 @@ class _FusedLogProb(torch.autograd.Function):
             (W1, b1), (W2, b2) = cpl._net().linears()
             H = info['hidden']
             a = acc[slot]
-            rows = torch.as_tensor(info['out_rows'], device=dev)
-            cols = torch.as_tensor(info['cond_cols'], device=dev)
-            vr, vc = rows >= 0, cols >= 0
+            # slot order -> parameter order with index tensors prepared at plan time (no boolean masks: no syncs)
             gW2 = torch.zeros_like(W2)
-            gW2[rows[vr], :H] = a['W2'][vr][:, :H]
+            gW2[:, :H].index_copy_(0, info['row_dst'], a['W2'].index_select(0, info['row_src'])[:, :H])
             gb2 = torch.zeros_like(b2)
-            gb2[rows[vr]] = a['b2'][vr]
+            gb2.index_copy_(0, info['row_dst'], a['b2'].index_select(0, info['row_src']))
             gW1 = torch.zeros_like(W1)
-            gW1[:H, cols[vc]] = a['W1'][:H][:, vc]
+            gW1[:H].index_copy_(1, info['col_dst'], a['W1'][:H].index_select(1, info['col_src']))
             gb1 = a['b1'][:H].clone()
             for p_, g_ in ((W1, gW1), (b1, gb1), (W2, gW2), (b2, gb2)):
                 grads[id(p_)] = g_
@@ -225,6 +223,13 @@ class NormalizingFlow(Transform):
                       raise NotImplementedError('training backward needs Linear-Tanh-Linear conditioners')
                   (W1, b1), (W2, b2) = lin
                   info = b.add_coupling_affine_bwd(W1, b1, W2, b2, f.mask_vector(dim), W1.shape[0], len(layers))
+                  import numpy as np
+                  rs = np.nonzero(info['out_rows'] >= 0)[0]
+                  cs = np.nonzero(info['cond_cols'] >= 0)[0]
+                  info['row_src'] = torch.from_numpy(rs).to(device)
+                  info['row_dst'] = torch.from_numpy(info['out_rows'][rs]).to(device)
+                  info['col_src'] = torch.from_numpy(cs).to(device)
+                  info['col_dst'] = torch.from_numpy(info['cond_cols'][cs]).to(device)
                   layers.append((f, info))
               self._fused[key] = (b.build(device), layers)
           except NotImplementedError:
