@@ -191,6 +191,39 @@ __global__ __launch_bounds__(256) void permute_kernel(const T *__restrict__ x, T
     }
 }
 
+// Rows staged through LDS: every global access is a coalesced 16-byte chunk; the gather happens in LDS.
+// One 256-thread workgroup moves 4 KiB = 4096 / row_bytes whole rows per pass.
+template <typename T>
+__global__ __launch_bounds__(256) void permute_lds_kernel(const T *__restrict__ x, T *__restrict__ y,
+                                                          const int32_t *__restrict__ idx, int64_t n_rows, int dim) {
+    __shared__ __attribute__((aligned(16))) char tile[4096];
+    __shared__ int sidx[2048];
+    constexpr int EPC = 16 / sizeof(T);                       // elements per 16-byte chunk
+    const int row_bytes = dim * (int)sizeof(T);
+    const int rows_per_pass = 4096 / row_bytes;
+    const int chunks_per_row = row_bytes / 16;
+    for (int c = threadIdx.x; c < dim; c += 256) sidx[c] = idx[c];
+    const int64_t n_pass = (n_rows + rows_per_pass - 1) / rows_per_pass;
+    for (int64_t pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
+        const int64_t row0 = pass * rows_per_pass;
+        const int r = threadIdx.x / chunks_per_row, ch = threadIdx.x - r * chunks_per_row;
+        const bool ok = row0 + r < n_rows;
+        __syncthreads();                                      // previous pass's reads done (and sidx ready)
+        if (ok)
+            *reinterpret_cast<f32x4 *>(tile + threadIdx.x * 16) =
+                *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(x) + (row0 + r) * row_bytes + ch * 16);
+        __syncthreads();
+        if (ok) {
+            const T *trow = reinterpret_cast<const T *>(tile + r * row_bytes);
+            T o[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o[e] = trow[sidx[ch * EPC + e]];
+            *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(y) + (row0 + r) * row_bytes + ch * 16) =
+                *reinterpret_cast<const f32x4 *>(o);
+        }
+    }
+}
+
 extern "C" int sx_permute(const void *x, void *y, const int32_t *idx, int64_t n_rows, int32_t dim,
                           int32_t elem_bytes, void *stream) {
     SX_REQUIRE(x && y && idx, "sx_permute: null pointer");
@@ -198,6 +231,20 @@ extern "C" int sx_permute(const void *x, void *y, const int32_t *idx, int64_t n_
     SX_REQUIRE(dim > 0 && n_rows >= 0, "sx_permute: bad sizes");
     SX_REQUIRE(elem_bytes == 2 || elem_bytes == 4, "sx_permute: elem_bytes must be 2 or 4");
     if (n_rows == 0) return SX_OK;
+    const int row_bytes = dim * elem_bytes;
+    if (row_bytes % 16 == 0 && row_bytes <= 4096 && 4096 % row_bytes == 0 && dim <= 2048 &&
+        (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+        const int64_t n_pass = (n_rows + 4096 / row_bytes - 1) / (4096 / row_bytes);
+        const int g = (int)(n_pass < 256 * 8 ? n_pass : 256 * 8);
+        if (elem_bytes == 2)
+            hipLaunchKernelGGL(permute_lds_kernel<uint16_t>, dim3(g), dim3(256), 0, sx_stream(stream),
+                               (const uint16_t *)x, (uint16_t *)y, idx, n_rows, dim);
+        else
+            hipLaunchKernelGGL(permute_lds_kernel<uint32_t>, dim3(g), dim3(256), 0, sx_stream(stream),
+                               (const uint32_t *)x, (uint32_t *)y, idx, n_rows, dim);
+        SX_LAUNCH_CHECK();
+        return SX_OK;
+    }
     const int grid = grid_for(n_rows * dim, 256);
     const size_t lds = (size_t)dim * sizeof(int);
     if (elem_bytes == 2)
@@ -214,6 +261,29 @@ extern "C" int sx_permute(const void *x, void *y, const int32_t *idx, int64_t n_
 // K8: UnitNormal.log_prob + ldj accumulator              (stribor/dist/normal.py:37,52-54; flow.py:129)
 // ------------------------------------------------------------------------------------------------
 #define SX_HALF_LOG_2PI 0.91893853320467274178f
+
+// bf16 rows with 16-byte accesses: 8 columns per thread
+__global__ __launch_bounds__(256) void unit_normal_bf16x8_kernel(const void *__restrict__ x, const float *__restrict__ ldj,
+                                                                 float *__restrict__ out, int64_t n_rows, int dim,
+                                                                 int tpr_log2) {
+    typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
+    const int tpr = 1 << tpr_log2;
+    const int64_t n_vec = n_rows << tpr_log2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_vec; v += stride) {
+        const int64_t row = v >> tpr_log2;
+        const int c = ((int)(v & (tpr - 1))) << 3;
+        const u16x8 u = *reinterpret_cast<const u16x8 *>(reinterpret_cast<const uint16_t *>(x) + row * dim + c);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = bf16_to_f32(u[e]);
+            s += f * f;
+        }
+        s = group_sum_rt(s, tpr);
+        if ((v & (tpr - 1)) == 0) out[row] = -0.5f * s - (float)dim * SX_HALF_LOG_2PI + (ldj ? ldj[row] : 0.f);
+    }
+}
 
 template <bool BF16>
 __global__ __launch_bounds__(256) void unit_normal_vec4_kernel(const void *__restrict__ x,
@@ -259,7 +329,11 @@ extern "C" int sx_unit_normal_logprob(const void *x, const float *ldj, float *ou
     if (n_rows == 0) return SX_OK;
     hipStream_t st = sx_stream(stream);
     const bool fast = dim % 4 == 0 && pow2(dim / 4) && dim / 4 <= 64 && (((uintptr_t)x) & 15) == 0;
-    if (fast) {
+    if (dtype == SX_BF16 && dim % 8 == 0 && pow2(dim / 8) && dim / 8 <= 64 && (((uintptr_t)x) & 15) == 0) {
+        const int tl = ilog2(dim / 8);
+        hipLaunchKernelGGL(unit_normal_bf16x8_kernel, dim3(grid_for(n_rows << tl, 256)), dim3(256), 0, st, x, ldj, out,
+                           n_rows, dim, tl);
+    } else if (fast) {
         const int tl = ilog2(dim / 4);
         const int grid = grid_for(n_rows << tl, 256);
         if (dtype == SX_BF16)
@@ -284,7 +358,18 @@ __global__ __launch_bounds__(256) void sum_f64_kernel(const float *__restrict__ 
     __shared__ double part[4];
     double acc = 0.0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc += (double)v[i];
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((reinterpret_cast<uintptr_t>(v) & 15) == 0) {          // 16-byte loads over the aligned body, scalars for the tail
+        const int64_t n4 = n >> 2;
+        const f32x4 *v4 = reinterpret_cast<const f32x4 *>(v);
+        for (int64_t i = tid; i < n4; i += stride) {
+            const f32x4 t = v4[i];
+            acc += ((double)t.x + (double)t.y) + ((double)t.z + (double)t.w);
+        }
+        for (int64_t i = (n4 << 2) + tid; i < n; i += stride) acc += (double)v[i];
+    } else {
+        for (int64_t i = tid; i < n; i += stride) acc += (double)v[i];
+    }
     acc = wave_sum_f64(acc);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -295,7 +380,7 @@ extern "C" int sx_sum_f64(const float *v, int64_t n, double *out, void *stream) 
     SX_REQUIRE(v && out, "sx_sum_f64: null pointer");
     SX_REQUIRE(n >= 0, "sx_sum_f64: bad size");
     if (n == 0) return SX_OK;
-    const int grid = grid_for(n, 256, 1024);
+    const int grid = grid_for((n + 3) / 4, 256, 2048);
     hipLaunchKernelGGL(sum_f64_kernel, dim3(grid), dim3(256), 0, sx_stream(stream), v, n, out);
     SX_LAUNCH_CHECK();
     return SX_OK;

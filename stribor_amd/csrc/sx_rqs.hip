@@ -55,6 +55,104 @@ __global__ __launch_bounds__(256) void rqs_copy_passthrough_kernel(const void *_
     }
 }
 
+// ---- straight-line evaluation for K = 16 (the BASELINE configuration): parameters in registers, selects only ----
+__device__ __forceinline__ float rqs_fast_exp(float v) { return __builtin_amdgcn_exp2f(v * 1.44269504088896341f); }
+__device__ __forceinline__ float rqs_fast_log(float v) { return __builtin_amdgcn_logf(v) * 0.69314718055994531f; }
+__device__ __forceinline__ float rqs_fast_softplus(float v) { return v > 20.f ? v : rqs_fast_log(1.f + rqs_fast_exp(v)); }
+
+// softmax numerators in place; returns the factor turning them into bin sizes (size_k = MIN + e_k * inv), :101-105
+__device__ __forceinline__ float rqs16_softmax(float (&u)[16]) {
+    float mx = u[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) mx = fmaxf(mx, u[k]);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        u[k] = rqs_fast_exp(u[k] - mx);
+        sum += u[k];
+    }
+    return (1.f - RQS_MIN_BIN * 16.f) * __builtin_amdgcn_rcpf(sum);
+}
+
+template <bool INVERSE>
+__device__ __forceinline__ void rqs16_eval(const float *__restrict__ p, float xv, float left, float right, float bottom,
+                                           float top, float &out, float &ljd, bool &bad_disc) {
+    const float lo = INVERSE ? bottom : left, hi = INVERSE ? top : right;        // searched (input-side) interval
+    const float lo2 = INVERSE ? left : bottom, hi2 = INVERSE ? right : top;      // the other block's interval
+    const bool inside = (xv >= lo) && (xv <= hi);                                // :71
+    const float xin = inside ? xv : lo;
+    float us[16], uo[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        us[k] = p[(INVERSE ? 16 : 0) + k];      // searched block: widths forward, heights inverse
+        uo[k] = p[(INVERSE ? 0 : 16) + k];
+    }
+    // search sweep (:180-197): knots increase and x >= knot_j holds for a prefix of j
+    const float inv_s = rqs16_softmax(us);
+    int b = 0;
+    float a_b = lo, a_n = hi, cs = 0.f;
+#pragma unroll
+    for (int j = 1; j <= 16; ++j) {
+        cs += RQS_MIN_BIN + us[j - 1] * inv_s;
+        const bool last = j == 16;
+        const float knot = last ? hi : (hi - lo) * cs + lo;
+        const bool ge = xin >= (last ? knot + RQS_EPS : knot);
+        const bool take = ge && !last;
+        b = take ? j : b;
+        a_b = take ? knot : a_b;
+        a_n = fminf(a_n, ge ? hi : knot);
+    }
+    // the other block at the found bin
+    const float inv_o = rqs16_softmax(uo);
+    float c_b = lo2, c_n = hi2;
+    cs = 0.f;
+#pragma unroll
+    for (int j = 1; j < 16; ++j) {
+        cs += RQS_MIN_BIN + uo[j - 1] * inv_o;
+        const float knot = (hi2 - lo2) * cs + lo2;
+        c_b = (j == b) ? knot : c_b;
+        c_n = (j == b + 1) ? knot : c_n;
+    }
+    const float cst = 0.5397424172369522f;       // log(exp(1 - 1e-3) - 1), :81
+    float r_b = cst, r_n = cst;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) {
+        const float v = p[32 + k];
+        r_b = (k == b - 1) ? v : r_b;
+        r_n = (k == b) ? v : r_n;
+    }
+    const float d_b = RQS_MIN_DERIV + rqs_fast_softplus(r_b), d_n = RQS_MIN_DERIV + rqs_fast_softplus(r_n);
+    const float cw_b = INVERSE ? c_b : a_b, w_b = INVERSE ? c_n - c_b : a_n - a_b;
+    const float ch_b = INVERSE ? a_b : c_b, h_b = INVERSE ? a_n - a_b : c_n - c_b;
+    const float s_b = h_b * __builtin_amdgcn_rcpf(w_b);
+    bad_disc = false;
+    if constexpr (INVERSE) {
+        const float dy = xin - ch_b;
+        const float q = d_b + d_n - 2.f * s_b;
+        const float a = dy * q + h_b * (s_b - d_b);
+        const float bb = h_b * d_b - dy * q;
+        const float c = -s_b * dy;
+        const float disc = bb * bb - 4.f * a * c;
+        bad_disc = inside && !(disc >= 0.f);
+        const float root = (2.f * c) * __builtin_amdgcn_rcpf(-bb - __builtin_amdgcn_sqrtf(disc));
+        out = root * w_b + cw_b;
+        const float tomt = root * (1.f - root), omr = 1.f - root;
+        const float den = s_b + q * tomt;
+        const float dnum = (s_b * s_b) * (d_n * (root * root) + 2.f * s_b * tomt + d_b * (omr * omr));
+        ljd = -rqs_fast_log(dnum) + 2.f * rqs_fast_log(den);
+    } else {
+        const float theta = (xin - cw_b) * __builtin_amdgcn_rcpf(w_b);
+        const float tomt = theta * (1.f - theta), omt = 1.f - theta;
+        const float num = h_b * (s_b * (theta * theta) + d_b * tomt);
+        const float den = s_b + (d_b + d_n - 2.f * s_b) * tomt;
+        out = ch_b + num * __builtin_amdgcn_rcpf(den);
+        const float dnum = (s_b * s_b) * (d_n * (theta * theta) + 2.f * s_b * tomt + d_b * (omt * omt));
+        ljd = rqs_fast_log(dnum) - 2.f * rqs_fast_log(den);
+    }
+    out = inside ? out : xv;                     // :86-87
+    ljd = inside ? ljd : 0.f;
+}
+
 template <bool BF16, bool INVERSE>
 __global__ __launch_bounds__(256) void rqs_kernel(const void *__restrict__ x, void *__restrict__ y,
                                                   float *__restrict__ ldj, float *__restrict__ ldiag,
@@ -72,19 +170,53 @@ __global__ __launch_bounds__(256) void rqs_kernel(const void *__restrict__ x, vo
     const float lo_in = INVERSE ? bottom : left, hi_in = INVERSE ? top : right;
     const float bconst = logf(expf(1.f - RQS_MIN_DERIV) - 1.f);  // :81 boundary derivative constant
     const float norm = 1.f - RQS_MIN_BIN * (float)K;
+    // rows of parameters back to back (stride = n_live * P) and a 16-byte aligned base: 64 elements = 64*P floats
+    const bool contig = (pstride == (int64_t)n_live * P) && ((reinterpret_cast<uintptr_t>(params) & 15) == 0);
 
+    f32x4 pf[12];               // next group's parameter span (K = 16 contiguous case)
+    bool have_pf = false;
     for (int64_t grp = (int64_t)blockIdx.x * waves_per_block + wave; grp < n_groups;
          grp += (int64_t)gridDim.x * waves_per_block) {
         const int64_t e0 = grp << 6;
         // ---- stage 64 elements' parameters: consecutive idx -> consecutive HBM addresses inside a row ----
         const int n_here = (int)((n_elem - e0) < 64 ? (n_elem - e0) : 64);
         const int total = n_here * P;
-        for (int idx = lane; idx < total; idx += 64) {
-            const int el = idx / P, q = idx - el * P;
-            const int64_t e = e0 + el;
-            const int64_t row = e / n_live;
-            const int i = (int)(e - row * n_live);
-            sp[idx] = params[row * pstride + (int64_t)i * P + q];
+        if (contig && n_here == 64 && P == 47) {
+            // the 64 elements' parameters are one contiguous, 16-byte aligned span of 752 float4: 11.75 per lane.
+            // Software pipeline: this group's span was fetched into registers one iteration ago; park it in LDS,
+            // then fetch the NEXT group's span so its latency hides under this group's arithmetic.
+            f32x4 *dst = reinterpret_cast<f32x4 *>(sp);
+            if (!have_pf) {
+                const f32x4 *src = reinterpret_cast<const f32x4 *>(params + e0 * P);
+#pragma unroll
+                for (int t = 0; t < 12; ++t)
+                    if (t * 64 + lane < 752) pf[t] = src[t * 64 + lane];
+            }
+#pragma unroll
+            for (int t = 0; t < 12; ++t)
+                if (t * 64 + lane < 752) dst[t * 64 + lane] = pf[t];
+            const int64_t gnext = grp + (int64_t)gridDim.x * waves_per_block;
+            have_pf = gnext < n_groups && ((gnext << 6) + 64 <= n_elem);
+            if (have_pf) {
+                const f32x4 *src = reinterpret_cast<const f32x4 *>(params + (gnext << 6) * P);
+#pragma unroll
+                for (int t = 0; t < 12; ++t)
+                    if (t * 64 + lane < 752) pf[t] = src[t * 64 + lane];
+            }
+        } else if (contig && n_here == 64) {
+            have_pf = false;
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(params + e0 * P);
+            f32x4 *dst = reinterpret_cast<f32x4 *>(sp);
+            for (int idx = lane; idx < 16 * P; idx += 64) dst[idx] = src[idx];
+        } else {
+            have_pf = false;
+            for (int idx = lane; idx < total; idx += 64) {
+                const int el = idx / P, q = idx - el * P;
+                const int64_t e = e0 + el;
+                const int64_t row = e / n_live;
+                const int i = (int)(e - row * n_live);
+                sp[idx] = params[row * pstride + (int64_t)i * P + q];
+            }
         }
         // wave-private slice: the wave's own LDS writes are ordered before its reads by lgkmcnt (no barrier)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -96,6 +228,12 @@ __global__ __launch_bounds__(256) void rqs_kernel(const void *__restrict__ x, vo
         const int i = valid ? (int)(e - row * n_live) : 0;
         const int col = live_idx ? live_idx[i] : l0 + i;
         const float xv = valid ? rqs_load<BF16>(x, row * dim + col) : lo_in;
+        float out, ljd;
+        if (K == 16) {      // wave-uniform: straight-line register path
+            bool bad;
+            rqs16_eval<INVERSE>(sp + (valid ? lane : 0) * P, xv, left, right, bottom, top, out, ljd, bad);
+            if (valid && bad && err_flag) atomicOr(err_flag, SX_FLAG_RQS_NEG_DISCRIMINANT);
+        } else {
         const bool inside = (xv >= lo_in) && (xv <= hi_in);                    // :71 closed interval
         const float xin = inside ? xv : lo_in;
         const float *uw = sp + (valid ? lane : 0) * P, *uh = uw + K, *ud = uh + K;
@@ -130,7 +268,6 @@ __global__ __launch_bounds__(256) void rqs_kernel(const void *__restrict__ x, vo
         const float d_b = RQS_MIN_DERIV + softplus_ref(b == 0 ? bconst : ud[b - 1]);        // :107, :206
         const float d_n = RQS_MIN_DERIV + softplus_ref(b + 1 == K ? bconst : ud[b]);        // :207
 
-        float out, ljd;
         if constexpr (INVERSE) {
             const float dy = xin - ch_b;
             const float q = d_b + d_n - 2.f * s_b;
@@ -157,6 +294,7 @@ __global__ __launch_bounds__(256) void rqs_kernel(const void *__restrict__ x, vo
             ljd = logf(dnum) - 2.f * logf(den);                                  // :248
         }
         if (!inside) { out = xv; ljd = 0.f; }                                    // :86-87 linear tails
+        }
         if (valid) {
             rqs_store<BF16>(y, row * dim + col, out);
             if (ldiag) ldiag[row * dim + col] = ljd;
