@@ -489,3 +489,19 @@ def test_full_size_properties_spline_and_linear_flows():
         close(lp[sl], orc.flow_log_prob(spec, x[sl].cpu()), rtol=1e-5, atol=1e-4)
         s = flow.log_prob_sum(x)
         assert abs(s.item() - lp.double().sum().item()) <= 1e-9 * abs(s.item()), name
+
+
+def test_cfg5_shard_size_batch_int64_offsets():
+    """2^23 rows (the whole cfg-5 batch on one GPU, 1 GiB of bf16 x): 64-bit row offsets, persistent grid-stride;
+    bit-identical to evaluating the eight 2^20-row shards separately, and the fp64 batch sum matches."""
+    torch.manual_seed(0)
+    flow = fd.build_flow(st, fd.cfg2_desc(), 64).to(DEV)
+    n = 1 << 23
+    x = torch.randn(n, 64, device=DEV).bfloat16()
+    with torch.no_grad():
+        lp = flow.log_prob(x)
+        assert lp.shape == (n, 1) and torch.isfinite(lp).all()
+        parts = torch.cat([flow.log_prob(x[i << 20:(i + 1) << 20]) for i in range(8)])
+        assert torch.equal(lp, parts)
+        s = flow.log_prob_sum(x)
+        assert abs(s.item() - lp.double().sum().item()) <= 1e-9 * abs(s.item())
