@@ -206,17 +206,29 @@ class NormalizingFlow(Transform):
               b = ProgramBuilder(dim, 0, hw)
               # the backward pass starts in the slot layout the forward (log_prob) program ends in; affine-coupling
               # flows never move columns, so that is the layout chosen from the first mask the forward pass sees
+              from .flows.permute import _ColumnShuffle
               rev = list(reversed(order))
               for f in rev:
                   m = f._plan_first_mask(dim)
                   if m is not None:
                       b.choose_layout(m)
                       break
+              # Permute / Flip only relabel slots: replay the forward program's relabelling to find the layout it
+              # ends in (= the layout z is read back in), then undo it layer by layer on the way back
+              for f in rev:
+                  if isinstance(f, _ColumnShuffle):
+                      b.add_permutation(f._perm(dim).cpu().numpy(), True)
+              b.in_col = None                      # the backward program's input layout is the forward's final one
+              b.steps = []
               b.enable_adjoint_tiles()
               layers = []
               for f in order:
+                  if isinstance(f, _ColumnShuffle):
+                      b.add_permutation(f._perm(dim).cpu().numpy(), False)
+                      continue
                   if not (isinstance(f, Coupling) and isinstance(f.transform, Affine)):
-                      raise NotImplementedError('training backward is implemented for flows of Coupling(Affine) layers')
+                      raise NotImplementedError('training backward is implemented for flows of Coupling(Affine) layers '
+                                                'and Permute / Flip')
                   net = f._net()
                   lin = net.linears()
                   if len(lin) != 2 or net.activation_name != 'Tanh':
