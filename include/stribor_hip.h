@@ -121,11 +121,15 @@ int sx_sum_f64(const float *v, int64_t n, double *out, void *stream);
 size_t sx_packed_linear_floats(int32_t m_tiles, int32_t k_tiles);
 
 /* Re-lays one nn.Linear (W: [out_dim, in_dim] row-major as torch stores it, b: [out_dim] or NULL)
- * into v_mfma_f32_32x32x2_f32 A-operand fragment order, followed by the bias in C-fragment order.
+ * into MFMA A-operand fragment order for the library's GEMM arithmetic (sx_fragment_mode()), followed by the bias
+ * in C-fragment order.  4 KiB per 32x32 tile pair in both modes.
  *   row_idx[m_tiles*32]: output slot -> row of W, or -1 for a zero row (padding / pruned)
  *   col_idx[k_tiles*32]: input  slot -> column of W, or -1 for a zero column
- * Layout written (floats): A[m][kt][g][lane][e] = W[row_idx[32m + (lane&31)]][col_idx[32kt + kmap(4g+e, lane>>5)]]
- * with kmap(s,h) = (s&3) + 8*(s>>2) + 4*h, then bias[m][h][r] = b[row_idx[32m + kmap(r,h)]].
+ * With kmap(s,h) = (s&3) + 8*(s>>2) + 4*h (the C/D fragment row map):
+ *   mode 0 (v_mfma_f32_32x32x2_f32), floats: A[m][kt][g][lane][e] = W[row_idx[32m + (lane&31)]][col_idx[32kt + kmap(4g+e, lane>>5)]]
+ *   mode 1 (v_mfma_f32_32x32x16_f16), halfs: A[m][kt][s][p][lane][j] = part_p(W[row_idx[32m + (lane&31)]][col_idx[32kt + kmap(8s+j, lane>>5)]]),
+ *          p = 0: hi = fp16(w), p = 1: lo = fp16(w - hi)
+ *   then (floats) bias[m][h][r] = b[row_idx[32m + kmap(r,h)]].
  * Optional exact re-parametrisation (all NULL / 0 = plain copy):
  *   row_scale[m_tiles*32]  : A rows are multiplied by row_scale[slot]
  *   bias_scale[m_tiles*32], fold_ones: bias' = bias_scale[slot] * (b[row] + fold_ones * sum_live_cols W[row][col])
@@ -138,40 +142,42 @@ int sx_pack_linear(const float *W, const float *b, int32_t out_dim, int32_t in_d
                    const float *row_scale, const float *bias_scale, float fold_ones, int32_t transpose,
                    float *dst, void *stream);
 
-/* One step of a fused flow program.  The flow state lives in registers as 32-wide "tiles" of
- * columns (tile t = state slots 32t..32t+31); slots map to columns of x through in_col/out_col. */
-#define SX_STEP_COUPLING_AFFINE 1  /* blob = pack_linear(W1) ++ pack_linear(W2 rows [ls(t0..), sh(t0..)] per tile) */
-#define SX_STEP_AFFINE_CONST    2  /* blob = ls[tiles][2][16] ++ sh[tiles][2][16] (C-fragment order)            */
-#define SX_STEP_LINEAR_TILE     3  /* blob = pack_linear(M, 1 m-tile): new tile `t0` = M[t0] . state + bias; tt != 0 on
-                                      the last slab commits the new tiles as the state                                */
-#define SX_STEP_LINEAR_COMMIT   4  /* (unused: the commit rides on the last LINEAR_TILE)                             */
-#define SX_STEP_MLP_HIDDEN      5  /* blob = pack_linear(W): hidden = act(W . state[c0..c0+ct) + b)               */
-#define SX_STEP_MLP_HIDDEN2     6  /* blob = pack_linear(W): hidden' = act(W . hidden + b)                         */
-#define SX_STEP_MLP_OUT_TILE    7  /* blob = pack_linear(W, 1 m-tile): out[:, 32*t0 ..] = W[t0] . hidden + b       */
-#define SX_STEP_COUPLING_RQS    8  /* reserved */
-#define SX_STEP_RQS_HIDDEN      10  /* blob = pack_linear(W1, folded tanh): hidden of a spline coupling, kept for its phases */
-#define SX_STEP_RQS_PHASE       11  /* one (8-column group, parameter block) slab of a rational-quadratic spline coupling:
-                                       blob = pack_linear(W2 rows, 4 m-tiles) ++ {lo, hi}; t0 = tile, c0 = group 0..3,
-                                       ct = phase (0 search block, 1 select block, 2 derivatives + evaluate), tt = n_bins,
-                                       pad_ = live mask of the tile's 32 slots                                          */
-#define SX_STEP_COUPLING_AFFINE_BWD 12 /* backward of one affine coupling of a log_prob pass (training): state tiles
-                                       [0,2) = x, [2,4) = dL/dx; blob = forward blob ++ pack(W2^T) ++ pack(W1^T); c0 = cond
-                                       tile, t0 = transformed tile, tt = layer slot in `side` (see sx_flow_run)        */
-#define SX_STEP_ROW_SCALE_EXP    9  /* blob = diag[tiles][2][16]: state *= exp(+-diag * t_row); t_row = row_t[n] or ldj_const */
+/* One step of a fused flow program.  The flow state lives in registers as 32-wide "tiles" of columns (tile t =
+ * state slots 32t..32t+31); slots map to columns of x through in_col/out_col.  Field use per kind: */
+#define SX_STEP_COUPLING_AFFINE      1  /* affine coupling (coupling.py:69-95 + affine.py:104-109): conditioner tiles [c0,c0+ct),
+                                           transformed tiles [t0,t0+tt) (low / high halves or all tiles);
+                                           blob = pack_linear(W1: h_tiles x ct) ++ pack_linear(W2: per transformed tile 32 log_scale
+                                           rows then 32 shift rows, x h_tiles); act = SX_ACT_* or SX_ACT_TANH_FOLDED          */
+#define SX_STEP_AFFINE_CONST         2  /* st.Affine without latent_net: blob = ls[tiles][2][16] ++ sh[tiles][2][16] (C-fragment) */
+#define SX_STEP_LINEAR_TILE          3  /* blob = pack_linear(M, 1 m-tile x tiles): new tile t0 = M[t0] . state + bias; tt != 0 on
+                                           the last slab commits the new tiles as the state (AffineLU, MatrixExponential)        */
+#define SX_STEP_MLP_HIDDEN           5  /* blob = pack_linear(W, h_tiles x tiles): hidden = act(W . state + b)  (mlp.py:65)       */
+#define SX_STEP_MLP_HIDDEN2          6  /* blob = pack_linear(W, h_tiles x h_tiles): hidden' = act(W . hidden + b)                 */
+#define SX_STEP_MLP_OUT_TILE         7  /* blob = pack_linear(W, 1 x h_tiles): mlp_out[:, 32*t0 ..] = W[t0] . hidden + b            */
+#define SX_STEP_ROW_SCALE_EXP        9  /* blob = diag[tiles][2][16]: state *= exp(+-diag * t_row); t_row = row_t[n] or ldj_const;
+                                           act != 0 applies log1p|t| (affine.py:239-240)                                          */
+#define SX_STEP_RQS_HIDDEN          10  /* blob = pack_linear(W1, folded tanh): hidden of a spline coupling, kept for its phases    */
+#define SX_STEP_RQS_PHASE           11  /* one (8-column group, parameter block) slab of a rational-quadratic spline coupling:
+                                           blob = pack_linear(W2 rows, 4 m-tiles) ++ {lo, hi}; t0 = tile, c0 = group 0..3,
+                                           ct = phase (0 search block, 1 select block, 2 derivatives + evaluate), tt = n_bins,
+                                           pad_ = live mask of the tile's 32 slots                                               */
+#define SX_STEP_COUPLING_AFFINE_BWD 12  /* backward of one affine coupling of a log_prob pass (training): state tiles
+                                           [0,2) = x, [2,4) = dL/dx; blob = forward blob ++ pack(W2^T) ++ pack(W1^T); c0 = cond
+                                           tile, t0 = transformed tile, tt = layer slot in `side` (see sx_flow_run)             */
 
 #define SX_MAX_STEPS 128
 
 typedef struct sx_step {
     int32_t  kind;        /* SX_STEP_*                                                        */
-    int32_t  c0, ct;      /* conditioner input tiles [c0, c0+ct)                              */
-    int32_t  t0, tt;      /* transformed / output tiles [t0, t0+tt)                           */
+    int32_t  c0, ct;      /* conditioner input tiles [c0, c0+ct)    (other meanings: see the kinds)   */
+    int32_t  t0, tt;      /* transformed / output tiles [t0, t0+tt) (other meanings: see the kinds)   */
     int32_t  reverse;     /* 1: inverse direction ((x-sh)*exp(-ls)), 0: forward               */
     int32_t  act;         /* SX_ACT_* of the hidden layer                                     */
-    uint32_t blob_off;    /* offset of this step's blob in `blobs`, in floats (multiple of 4)  */
-    uint32_t blob_floats; /* size of the blob in floats (multiple of 4)                        */
+    uint32_t blob_off;    /* offset of this step's blob in `blobs`, in floats (multiple of 256) */
+    uint32_t blob_floats; /* size of the blob in floats (multiple of 256: 1 KiB LDS-DMA pieces) */
     float    ldj_scale;   /* coefficient of this step's sum(log_scale) in the ldj accumulator  */
     float    ldj_const;   /* constant added to the ldj accumulator (AffineLU / MatrixExponential) */
-    int32_t  pad_;
+    int32_t  pad_;        /* SX_STEP_RQS_PHASE: live-slot mask; else 0                         */
 } sx_step;
 
 typedef struct sx_program {
@@ -187,7 +193,9 @@ typedef struct sx_program {
 } sx_program;
 
 /* Runs a fused program over n_rows samples: the whole flow stays in registers, weights stream
- * through LDS, the conditioner GEMMs run on v_mfma_f32_32x32x2_f32.
+ * through LDS, every GEMM runs on the matrix cores (sx_fragment_mode()).  A program holds flow steps
+ * (kinds 1, 2; + 3, 9 for dense linear layers; or 10, 11 for spline couplings), or conditioner steps (5-7),
+ * or backward steps (12) -- the kernel variant is picked from the kinds present.
  * Replaces NormalizingFlow.{forward, inverse, forward_and_log_det_jacobian,
  * inverse_and_log_det_jacobian, log_prob} (stribor/flow.py:99-130) and, with a one-step program,
  * Coupling.{forward, inverse, log_det_jacobian} (stribor/flows/coupling.py:69-95).
