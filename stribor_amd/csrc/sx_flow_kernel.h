@@ -1082,9 +1082,11 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
 #define SX_FL(MD)                                                                                              \
     do {                                                                                                       \
         auto kern = flow_fused_kernel<NS, TX, HT, MD>;                                                         \
-        if (a.lds > 48 * 1024) {                                                                               \
-            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, a.lds); \
+        static int lds_allowed = 48 * 1024;      /* raised once per kernel variant and process, not per launch */ \
+        if (a.lds > lds_allowed) {                                                                             \
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             if (e != hipSuccess) { sx_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
+            lds_allowed = 160 * 1024;                                                                          \
         }                                                                                                      \
         hipLaunchKernelGGL(kern, dim3(a.grid), dim3(256), a.lds, a.stream, a.prog, k);                         \
     } while (0)
