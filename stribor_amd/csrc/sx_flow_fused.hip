@@ -6,7 +6,8 @@
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, int *mlp_mode) {
+static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, int *mlp_mode, int *side_width) {
+    *side_width = 0;
     SX_REQUIRE(p != nullptr, "sx_flow_run: null program");
     SX_REQUIRE(p->n_steps >= 0 && p->n_steps <= SX_MAX_STEPS, "sx_flow_run: n_steps %d out of range", p->n_steps);
     SX_REQUIRE(p->tiles == 1 || p->tiles == 2 || p->tiles == 4, "sx_flow_run: tiles must be 1, 2 or 4 (got %d)", p->tiles);
@@ -47,12 +48,21 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
                 SX_REQUIRE(s.t0 < p->x_tiles, "sx_flow_run: step %d: linear slab %d out of range", i, s.t0);
                 need = sx_packed_linear_floats(1, p->tiles); lin = true; break;
             case SX_STEP_ROW_SCALE_EXP: need = 32 * p->tiles; lin = true; break;
-            case SX_STEP_COUPLING_AFFINE_BWD:
-                SX_REQUIRE(p->tiles == 4 && p->x_tiles == 2 && s.c0 >= 0 && s.c0 < 2 && s.t0 == 1 - s.c0,
-                           "sx_flow_run: step %d: backward steps need 2 data tiles with the coupling pruned to halves", i);
-                need = sx_packed_linear_floats(p->h_tiles, 1) + sx_packed_linear_floats(2, p->h_tiles) +
-                       sx_packed_linear_floats(p->h_tiles, 2) + sx_packed_linear_floats(1, p->h_tiles);
+            case SX_STEP_COUPLING_AFFINE_BWD: {
+                SX_REQUIRE((p->tiles == 2 || p->tiles == 4) && p->x_tiles * 2 == p->tiles,
+                           "sx_flow_run: step %d: backward programs carry x and dL/dx: tiles = 2 * x_tiles (2 or 4)", i);
+                const int XT = p->x_tiles;
+                const bool low = XT == 2 && s.c0 == 0 && s.ct == 1 && s.t0 == 1;
+                const bool high = XT == 2 && s.c0 == 1 && s.ct == 1 && s.t0 == 0;
+                const bool dense = s.c0 == 0 && s.ct == XT && s.t0 == 0;
+                SX_REQUIRE(low || high || dense, "sx_flow_run: step %d: backward coupling tiles must be halves or dense", i);
+                const int ct = s.ct, tt = dense ? XT : 1;
+                need = sx_packed_linear_floats(p->h_tiles, ct) + sx_packed_linear_floats(2 * tt, p->h_tiles) +
+                       sx_packed_linear_floats(p->h_tiles, 2 * tt) + sx_packed_linear_floats(ct, p->h_tiles);
+                const int sw = 32 * ct + 64 * p->h_tiles + 64 * tt;
+                if (sw > *side_width) *side_width = sw;
                 bwd = true; break;
+            }
             case SX_STEP_RQS_HIDDEN: {
                 const int T = p->tiles;
                 const bool low = T >= 2 && s.c0 == 0 && s.ct == T / 2;
@@ -103,8 +113,8 @@ static int pick_grid(int64_t n_rows, int lds_bytes, int tiles, int mode) {
 
 extern "C" int sx_flow_launch_info(const sx_program *prog_host, int64_t n_rows, int32_t *grid, int32_t *block,
                                    int32_t *lds_bytes) {
-    dprog d; int bf; int mm;
-    int rc = validate_and_convert(prog_host, &d, &bf, &mm);
+    dprog d; int bf; int mm; int sw;
+    int rc = validate_and_convert(prog_host, &d, &bf, &mm, &sw);
     if (rc) return rc;
     if (lds_bytes) *lds_bytes = bf * 8;
     if (block) *block = 256;
@@ -117,8 +127,8 @@ extern "C" int sx_flow_run(const sx_program *prog_host, const float *blobs, cons
                            const int32_t *in_col, const int32_t *out_col, void *y, float *ldj_out, float *logp_out,
                            double *sum_out, float *mlp_out, int64_t mlp_out_stride, int32_t mlp_out_dim,
                            const float *row_t, float *side, int64_t n_rows, int32_t dtype, void *stream) {
-    dprog d; int bf; int mlp_mode;
-    int rc = validate_and_convert(prog_host, &d, &bf, &mlp_mode);
+    dprog d; int bf; int mlp_mode; int sw;
+    int rc = validate_and_convert(prog_host, &d, &bf, &mlp_mode, &sw);
     if (rc) return rc;
     SX_REQUIRE(x != nullptr && n_rows >= 0, "sx_flow_run: bad x / n_rows");
     SX_REQUIRE(blobs != nullptr || prog_host->n_steps == 0, "sx_flow_run: null blobs");
@@ -139,6 +149,7 @@ extern "C" int sx_flow_run(const sx_program *prog_host, const float *blobs, cons
     a.stream = sx_stream(stream);
     a.row_t = row_t;
     a.side = side;
+    a.side_width = sw;
     const int T = prog_host->tiles, H = prog_host->h_tiles;
 #define SX_GO(TT, HH) if (T == TT && H == HH) return sx_flow_launch_t##TT##h##HH(a)
     SX_GO(1, 1); SX_GO(1, 2); SX_GO(1, 4); SX_GO(2, 1); SX_GO(2, 2); SX_GO(2, 4); SX_GO(4, 1); SX_GO(4, 2); SX_GO(4, 4);

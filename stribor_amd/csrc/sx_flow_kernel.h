@@ -656,52 +656,59 @@ __device__ __forceinline__ void store_ctile(float *row_base, int off, const f32x
     for (int q = 0; q < 4; ++q)
         *reinterpret_cast<f32x4 *>(row_base + off + 8 * q + 4 * h) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
 }
-template <int HT, int C>
-__device__ __forceinline__ void coupling_affine_bwd(tile<1> (&xs)[4], const wptr w, float g, float *side_row, int lane) {
-    constexpr int T = 1 - C;
-    constexpr int F1 = 0;                                   // forward pack(W1', HT x 1)
-    constexpr int F2 = HT * 1024 + HT * 32;                 // forward pack(W2', 2 x HT)
-    constexpr int B2 = F2 + 2 * HT * 1024 + 64;             // pack(W2^T, HT x 2)
-    constexpr int B1 = B2 + HT * 2 * 1024 + HT * 32;        // pack(W1^T, 1 x HT)
+// XT data tiles (1 or 2); state tiles [0,XT) = x, [XT,2XT) = dL/dx.  Conditioner tiles [C0,C0+CT), transformed tiles
+// [T0,T0+TT) of the data tiles: pruned halves (XT = 2) or dense (any mask; zero weights outside the mask).
+template <int XT, int HT, int C0, int CT, int T0, int TT>
+__device__ __forceinline__ void coupling_affine_bwd(tile<1> (&xs)[2 * XT], const wptr w, float g, float *side_row,
+                                                    int lane) {
+    constexpr int F1 = 0;                                            // forward pack(W1', HT x CT)
+    constexpr int F2 = HT * CT * 1024 + HT * 32;                     // forward pack(W2', 2TT x HT)
+    constexpr int F2B = F2 + 2 * TT * HT * 1024;                     //   its bias
+    constexpr int B2 = F2B + 2 * TT * 32;                            // pack(W2^T, HT x 2TT)
+    constexpr int B1 = B2 + HT * 2 * TT * 1024 + HT * 32;            // pack(W1^T, CT x HT)
     const int h = lane >> 5;
     // 1. recompute the conditioner (folded tanh: r = (1 - tanh)/2)
     tile<1> hid[HT];
-    hidden_layer<1, 4, HT, C, 1, true>(xs, hid, w, F1, SX_ACT_TANH_FOLDED);
+    hidden_layer<1, 2 * XT, HT, C0, CT, true>(xs, hid, w, F1, SX_ACT_TANH_FOLDED);
 #pragma unroll
     for (int r = 0; r < 16; ++r) hid[HT - 1].v[0][r] = fast_sig2(hid[HT - 1].v[0][r]);
-    tile<1> ls = load_cfrag<1>(w.cb, F2 + 2 * HT * 1024), sh = load_cfrag<1>(w.cb, F2 + 2 * HT * 1024 + 32);
-    {
-        btile<1> bh[HT];
+    btile<1> bh[HT];
 #pragma unroll
-        for (int m = 0; m < HT; ++m) bh[m] = make_btile<1>(hid[m]);
+    for (int m = 0; m < HT; ++m) bh[m] = make_btile<1>(hid[m]);
+    // 2. per transformed tile: (kk*log_scale, shift), un-transform, adjoints
+    tile<1> dls[TT], dsh[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        tile<1> ls = load_cfrag<1>(w.cb, F2B + (2 * t) * 32), sh = load_cfrag<1>(w.cb, F2B + (2 * t + 1) * 32);
 #pragma unroll
         for (int m = 0; m < HT; ++m) {
-            gemm_tile<1>(w.wb, F2 + m * 1024, bh[m], ls);              // rows 0..31: kk*log_scale (kk = -log2 e)
-            gemm_tile<1>(w.wb, F2 + (HT + m) * 1024, bh[m], sh);       // rows 32..63: shift
+            gemm_tile<1>(w.wb, F2 + ((2 * t) * HT + m) * 1024, bh[m], ls);          // kk*log_scale, kk = -log2 e
+            gemm_tile<1>(w.wb, F2 + ((2 * t + 1) * HT + m) * 1024, bh[m], sh);      // shift
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f(ls.v[0][r]);                     // exp(-log_scale)
+            const float xo = xs[T0 + t].v[0][r], al = xs[XT + T0 + t].v[0][r];
+            xs[T0 + t].v[0][r] = xo * __builtin_amdgcn_exp2f(-ls.v[0][r]) + sh.v[0][r];      // x_in
+            const float ai = al * e;                                                // dL/dx_in
+            xs[XT + T0 + t].v[0][r] = ai;
+            dsh[t].v[0][r] = -ai;                                                   // dL/dshift
+            dls[t].v[0][r] = -al * xo - g;                                          // dL/dlog_scale (incl. -sum(ls))
         }
     }
-    // 2. un-transform, adjoints of the transformed tile, parameter adjoints
-    tile<1> dls, dsh;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(ls.v[0][r]);            // exp(-log_scale)
-        const float xo = xs[T].v[0][r], al = xs[2 + T].v[0][r];
-        xs[T].v[0][r] = xo * __builtin_amdgcn_exp2f(-ls.v[0][r]) + sh.v[0][r];   // x_in
-        const float ai = al * e;                                       // dL/dx_in
-        xs[2 + T].v[0][r] = ai;
-        dsh.v[0][r] = -ai;                                             // dL/dshift
-        dls.v[0][r] = -al * xo - g;                                    // dL/dlog_scale (incl. the -sum(ls) term)
-    }
-    // 3. dh = W2^T [dls; dsh],  dh_pre = dh * (1 - tanh^2)
+    // 3. dh = W2^T [dls_0; dsh_0; dls_1; ...],  dh_pre = dh * (1 - tanh^2)
     tile<1> dh[HT];
-    {
-        const btile<1> b0 = make_btile<1>(dls), b1 = make_btile<1>(dsh);
+#pragma unroll
+    for (int m = 0; m < HT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh[m].v[0][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        const btile<1> b0 = make_btile<1>(dls[t]), b1 = make_btile<1>(dsh[t]);
 #pragma unroll
         for (int m = 0; m < HT; ++m) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dh[m].v[0][r] = 0.f;
-            gemm_tile<1>(w.wb, B2 + (m * 2 + 0) * 1024, b0, dh[m]);
-            gemm_tile<1>(w.wb, B2 + (m * 2 + 1) * 1024, b1, dh[m]);
+            gemm_tile<1>(w.wb, B2 + (m * 2 * TT + 2 * t) * 1024, b0, dh[m]);
+            gemm_tile<1>(w.wb, B2 + (m * 2 * TT + 2 * t + 1) * 1024, b1, dh[m]);
         }
     }
 #pragma unroll
@@ -712,24 +719,36 @@ __device__ __forceinline__ void coupling_affine_bwd(tile<1> (&xs)[4], const wptr
             hid[m].v[0][r] = th;
             dh[m].v[0][r] *= (1.f - th * th);
         }
-    // 4. adjoint of the conditioning tile: += W1^T dh_pre
-    tile<1> dz;
+    // 4. adjoint of the conditioning tiles: += W1^T dh_pre
+    {
+        btile<1> bd[HT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dz.v[0][r] = 0.f;
+        for (int m = 0; m < HT; ++m) bd[m] = make_btile<1>(dh[m]);
 #pragma unroll
-    for (int m = 0; m < HT; ++m) gemm_tile<1>(w.wb, B1 + m * 1024, make_btile<1>(dh[m]), dz);
+        for (int c = 0; c < CT; ++c) {
+            tile<1> dz;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) xs[2 + C].v[0][r] += dz.v[0][r];
-    // 5. per-row factors of the weight gradients: [z | tanh h | dL/dh_pre | dL/dls, dL/dsh]
+            for (int r = 0; r < 16; ++r) dz.v[0][r] = 0.f;
+#pragma unroll
+            for (int m = 0; m < HT; ++m) gemm_tile<1>(w.wb, B1 + (c * HT + m) * 1024, bd[m], dz);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xs[XT + C0 + c].v[0][r] += dz.v[0][r];
+        }
+    }
+    // 5. per-row factors of the weight gradients: [z (CT) | tanh h (HT) | dL/dh_pre (HT) | dL/dls_t, dL/dsh_t (2TT)]
     if (side_row != nullptr) {
-        store_ctile(side_row, 0, xs[C].v[0], h);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) store_ctile(side_row, 32 * c, xs[C0 + c].v[0], h);
 #pragma unroll
         for (int m = 0; m < HT; ++m) {
-            store_ctile(side_row, 32 + 32 * m, hid[m].v[0], h);
-            store_ctile(side_row, 32 + 32 * HT + 32 * m, dh[m].v[0], h);
+            store_ctile(side_row, 32 * CT + 32 * m, hid[m].v[0], h);
+            store_ctile(side_row, 32 * CT + 32 * HT + 32 * m, dh[m].v[0], h);
         }
-        store_ctile(side_row, 32 + 64 * HT, dls.v[0], h);
-        store_ctile(side_row, 64 + 64 * HT, dsh.v[0], h);
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            store_ctile(side_row, 32 * CT + 64 * HT + 64 * t, dls[t].v[0], h);
+            store_ctile(side_row, 32 * CT + 64 * HT + 64 * t + 32, dsh[t].v[0], h);
+        }
     }
 }
 
@@ -745,7 +764,7 @@ __device__ __forceinline__ void st_elem(void *p, int64_t off, float v, int bf16)
 struct flow_kargs {     // everything but the program, by value in the kernarg segment
     const float *blobs; const void *x; const float *latent; const int32_t *in_col; const int32_t *out_col;
     void *y; float *ldj_out; float *logp_out; double *sum_out; float *mlp_out; const float *row_t; float *side;
-    int64_t mlp_out_stride; int64_t n_rows; int mlp_out_dim; int buf_floats; int bf16; int pad;
+    int64_t mlp_out_stride; int64_t n_rows; int mlp_out_dim; int buf_floats; int bf16; int side_width;
 };
 
 // MODE 0: flow programs (coupling / affine-const steps); MODE 1: + persistent hidden state (MLP programs);
@@ -816,10 +835,10 @@ __global__ __launch_bounds__(256, SX_WAVES_FOR(TX, MODE)) void flow_fused_kernel
                     }
                 } else if constexpr (MODE == 4) {
                     // adjoint tiles: dL/dz of log p = -z^2/2 + ... is -g z (g = dL/dlog_prob of the row)
-                    if constexpr (TX == 4) {
+                    if constexpr (TX == 2 || TX == 4) {
                         const float gg = k.row_t[lrow[n]];
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) xs[t].v[n][r] = -gg * xs[t - 2].v[n][r];
+                        for (int r = 0; r < 16; ++r) xs[t].v[n][r] = -gg * xs[t - TX / 2].v[n][r];
                     }
                 } else {   // latent tiles (fp32), conditioner-only inputs (coupling.py:64-65)
 #pragma unroll
@@ -932,12 +951,17 @@ __global__ __launch_bounds__(256, SX_WAVES_FOR(TX, MODE)) void flow_fused_kernel
                     }
                     break;
                 case SX_STEP_COUPLING_AFFINE_BWD:
-                    if constexpr (MODE == 4 && NS == 1 && TX == 4) {
+                    if constexpr (MODE == 4 && NS == 1 && (TX == 2 || TX == 4)) {
+                        constexpr int XT = TX / 2;
                         const float gg = k.row_t[lrow[0]];
-                        const int sw = 32 + 64 * HT + 64;
-                        float *srow = row[0] < n_rows ? k.side + ((int64_t)st.tt * n_rows + row[0]) * sw : nullptr;
-                        if (st.c0 == 0) coupling_affine_bwd<HT, 0>(xs, w, gg, srow, lane);
-                        else coupling_affine_bwd<HT, 1>(xs, w, gg, srow, lane);
+                        float *srow = row[0] < n_rows ? k.side + ((int64_t)st.tt * n_rows + row[0]) * k.side_width : nullptr;
+                        if constexpr (XT == 2) {
+                            if (st.ct == 1 && st.c0 == 0) coupling_affine_bwd<2, HT, 0, 1, 1, 1>(xs, w, gg, srow, lane);
+                            else if (st.ct == 1) coupling_affine_bwd<2, HT, 1, 1, 0, 1>(xs, w, gg, srow, lane);
+                            else coupling_affine_bwd<2, HT, 0, 2, 0, 2>(xs, w, gg, srow, lane);
+                        } else {
+                            coupling_affine_bwd<1, HT, 0, 1, 0, 1>(xs, w, gg, srow, lane);
+                        }
                     }
                     break;
                 case SX_STEP_RQS_HIDDEN:
@@ -997,7 +1021,7 @@ __global__ __launch_bounds__(256, SX_WAVES_FOR(TX, MODE)) void flow_fused_kernel
 #pragma unroll
                 for (int t = 0; t < TX; ++t) {
                     if (t < x_tiles) {
-                        const int ts = (MODE == 4 && TX == 4) ? t + 2 : t;      // backward: y receives dL/d(input)
+                        const int ts = (MODE == 4) ? t + TX / 2 : t;      // backward: y receives dL/d(input)
                         if (prog.identity_cols) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
@@ -1078,7 +1102,7 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
     k.blobs = a.blobs; k.x = a.x; k.latent = a.latent; k.in_col = a.in_col; k.out_col = a.out_col; k.y = a.y;
     k.ldj_out = a.ldj_out; k.logp_out = a.logp_out; k.sum_out = a.sum_out; k.mlp_out = a.mlp_out; k.row_t = a.row_t; k.side = a.side;
     k.mlp_out_stride = a.mlp_out_stride; k.n_rows = a.n_rows; k.mlp_out_dim = a.mlp_out_dim;
-    k.buf_floats = a.buf_floats; k.bf16 = a.bf16; k.pad = 0;
+    k.buf_floats = a.buf_floats; k.bf16 = a.bf16; k.side_width = a.side_width;
 #define SX_FL(MD)                                                                                              \
     do {                                                                                                       \
         auto kern = flow_fused_kernel<NS, TX, HT, MD>;                                                         \

@@ -22,6 +22,7 @@ struct sx_flow_args {
     int mlp_out_dim; int64_t n_rows; int buf_floats; int bf16; int mlp_mode; int grid; int lds; hipStream_t stream;
     const float *row_t;
     float *side;
+    int side_width;
 };
 
 

@@ -47,12 +47,14 @@ class _FusedLogProb(torch.autograd.Function):
         bprog, layers = flow._backward_program(d, z.device)
         g = grad_logp.reshape(-1).to(torch.float32).contiguous()
         ht = 32 * bprog.prog.h_tiles
-        width = 32 + 2 * ht + 64
+        width = max(info['side_width'] for _, info in layers)
         dev = z.device
         # slot-ordered gradient accumulators per layer (sx_wgrad adds into them)
-        acc = [dict(W2=torch.zeros(64, ht, dtype=torch.float32, device=dev), b2=torch.zeros(64, dtype=torch.float32, device=dev),
-                    W1=torch.zeros(ht, 32, dtype=torch.float32, device=dev), b1=torch.zeros(ht, dtype=torch.float32, device=dev))
-               for _ in layers]
+        acc = [dict(W2=torch.zeros(64 * info['tt'], ht, dtype=torch.float32, device=dev),
+                    b2=torch.zeros(64 * info['tt'], dtype=torch.float32, device=dev),
+                    W1=torch.zeros(ht, 32 * info['ct'], dtype=torch.float32, device=dev),
+                    b1=torch.zeros(ht, dtype=torch.float32, device=dev))
+               for _, info in layers]
         gy = torch.empty_like(z) if ctx.need_input_grad else None
         lib = _hip.lib()
         # the per-row factors are 224 floats per row and layer: bound the scratch by walking the batch in blocks
@@ -66,11 +68,14 @@ class _FusedLogProb(torch.autograd.Function):
                 gy[lo:lo + m] = gblk
             for slot in range(len(layers)):
                 sd = sd_all[slot]
-                zz, hh, dhp, dp = sd[:, :32], sd[:, 32:32 + ht], sd[:, 32 + ht:32 + 2 * ht], sd[:, 32 + 2 * ht:]
+                info = layers[slot][1]
+                zc, pc = 32 * info['ct'], 64 * info['tt']
+                zz, hh, dhp = sd[:, :zc], sd[:, zc:zc + ht], sd[:, zc + ht:zc + 2 * ht]
+                dp = sd[:, zc + 2 * ht:zc + 2 * ht + pc]
                 a = acc[slot]
-                _hip.check(lib.sx_wgrad(dp.data_ptr(), width, 64, hh.data_ptr(), width, ht, m, a['W2'].data_ptr(), ht,
+                _hip.check(lib.sx_wgrad(dp.data_ptr(), width, pc, hh.data_ptr(), width, ht, m, a['W2'].data_ptr(), ht,
                                         a['b2'].data_ptr(), _hip.stream()), 'sx_wgrad')
-                _hip.check(lib.sx_wgrad(dhp.data_ptr(), width, ht, zz.data_ptr(), width, 32, m, a['W1'].data_ptr(), 32,
+                _hip.check(lib.sx_wgrad(dhp.data_ptr(), width, ht, zz.data_ptr(), width, zc, m, a['W1'].data_ptr(), zc,
                                         a['b1'].data_ptr(), _hip.stream()), 'sx_wgrad')
         grads = {}
         for slot, (cpl, info) in enumerate(layers):

@@ -472,52 +472,58 @@ class ProgramBuilder:
 
     def enable_adjoint_tiles(self) -> None:
         """Backward programs carry dL/dx beside x: tiles [0, x_tiles) = x, [x_tiles, 2 x_tiles) = adjoint."""
-        if self.x_tiles != 2 or self.latent_dim:
-            raise NotImplementedError('training backward is built for 33..64 columns without latent inputs')
-        self.tiles = 4
+        if self.x_tiles > 2 or self.latent_dim:
+            raise NotImplementedError('training backward is built for up to 64 columns without latent inputs')
+        self.tiles = 2 * self.x_tiles
 
     def add_coupling_affine_bwd(self, W1, b1, W2, b2, mask: np.ndarray, hidden: int, layer_slot: int) -> dict:
         """Backward of one affine coupling of a log_prob pass; returns the slot maps the caller needs to turn the
         kernel's per-row factors into weight gradients."""
         self._freeze_input()
-        assert self.tiles == 4 and self.x_tiles == 2
+        XT = self.x_tiles
+        assert self.tiles == 2 * XT
         D, HT = self.dim, self.h_tiles
         mask = np.asarray(mask, dtype=np.float64).reshape(-1)
+        if mask.size == 1:
+            mask = np.full(D, mask[0])
         cond_col, live_col = mask > 0.5, mask <= 0.5
+        if D == 1:
+            cond_col = np.zeros(1, dtype=bool)
         col = self.col_of_slot
         slot_cond = np.array([c >= 0 and cond_col[c] for c in col])
         slot_live = np.array([c >= 0 and live_col[c] for c in col])
-        if not slot_cond[32:].any() and not slot_live[:32].any():
-            c0 = 0
-        elif not slot_cond[:32].any() and not slot_live[32:].any():
-            c0 = 1
+        if XT == 2 and not slot_cond[32:].any() and not slot_live[:32].any():
+            c0, ct, t0, tt = 0, 1, 1, 1
+        elif XT == 2 and not slot_cond[:32].any() and not slot_live[32:].any():
+            c0, ct, t0, tt = 1, 1, 0, 1
         else:
-            raise NotImplementedError('training backward needs the coupling mask aligned with the 32-column tiles')
-        t0 = 1 - c0
+            c0, ct, t0, tt = 0, XT, 0, XT                     # dense: any mask, zero weights outside it
         LOG2E = 1.4426950408889634
         kk = -LOG2E                                              # log_prob direction: scale = exp(-log_scale)
-        col_idx = np.array([col[p] if slot_cond[p] else -1 for p in range(32 * c0, 32 * c0 + 32)], dtype=np.int64)
+        col_idx = np.array([col[p] if slot_cond[p] else -1 for p in range(32 * c0, 32 * (c0 + ct))], dtype=np.int64)
         row_h = np.full(32 * HT, -1, dtype=np.int64)
         row_h[:hidden] = np.arange(hidden)
-        row2 = np.full(64, -1, dtype=np.int64)
-        for i in range(32):
-            p = 32 * t0 + i
-            if slot_live[p]:
-                row2[i] = col[p]
-                row2[32 + i] = D + col[p]
-        n1, n2 = _hip.packed_linear_floats(HT, 1), _hip.packed_linear_floats(2, HT)
-        n3, n4 = _hip.packed_linear_floats(HT, 2), _hip.packed_linear_floats(1, HT)
+        row2 = np.full(64 * tt, -1, dtype=np.int64)
+        for t in range(tt):
+            for i in range(32):
+                p = 32 * (t0 + t) + i
+                if slot_live[p]:
+                    row2[64 * t + i] = col[p]
+                    row2[64 * t + 32 + i] = D + col[p]
+        n1, n2 = _hip.packed_linear_floats(HT, ct), _hip.packed_linear_floats(2 * tt, HT)
+        n3, n4 = _hip.packed_linear_floats(HT, 2 * tt), _hip.packed_linear_floats(ct, HT)
         off, n = self._alloc(n1 + n2 + n3 + n4)
         rs1 = np.full(32 * HT, 2.0 * LOG2E)
-        rs2 = np.concatenate([np.full(32, -2.0 * kk), np.full(32, -2.0)])
-        bs2 = np.concatenate([np.full(32, kk), np.full(32, 1.0)])
-        self.jobs.append(_PackJob(W1, b1, row_h, col_idx, HT, 1, off, rs1, rs1, 0.0))
-        self.jobs.append(_PackJob(W2, b2, row2, row_h, 2, HT, off + n1, rs2, bs2, 1.0))
-        self.jobs.append(_PackJob(W2, None, row_h, row2, HT, 2, off + n1 + n2, transpose=True))     # W2^T
-        self.jobs.append(_PackJob(W1, None, col_idx, row_h, 1, HT, off + n1 + n2 + n3, transpose=True))   # W1^T
-        self.steps.append(dict(kind=_hip.STEP_COUPLING_AFFINE_BWD, c0=c0, ct=1, t0=t0, tt=layer_slot, reverse=1,
+        rs2 = np.concatenate([np.concatenate([np.full(32, -2.0 * kk), np.full(32, -2.0)]) for _ in range(tt)])
+        bs2 = np.concatenate([np.concatenate([np.full(32, kk), np.full(32, 1.0)]) for _ in range(tt)])
+        self.jobs.append(_PackJob(W1, b1, row_h, col_idx, HT, ct, off, rs1, rs1, 0.0))
+        self.jobs.append(_PackJob(W2, b2, row2, row_h, 2 * tt, HT, off + n1, rs2, bs2, 1.0))
+        self.jobs.append(_PackJob(W2, None, row_h, row2, HT, 2 * tt, off + n1 + n2, transpose=True))      # W2^T
+        self.jobs.append(_PackJob(W1, None, col_idx, row_h, ct, HT, off + n1 + n2 + n3, transpose=True))  # W1^T
+        self.steps.append(dict(kind=_hip.STEP_COUPLING_AFFINE_BWD, c0=c0, ct=ct, t0=t0, tt=layer_slot, reverse=1,
                                act=_hip.ACT_TANH_FOLDED, blob_off=off, blob_floats=n, ldj_scale=0.0, ldj_const=0.0))
-        return dict(cond_cols=col_idx, out_rows=row2, hidden=hidden)
+        return dict(cond_cols=col_idx, out_rows=row2, hidden=hidden, ct=ct, tt=tt,
+                    side_width=32 * ct + 64 * HT + 64 * tt)
 
     def add_affine_const(self, log_scale, shift, reverse: bool, ldj_scale: float) -> None:
         self._freeze_input()

@@ -119,3 +119,31 @@ def test_backward_through_flips_realnvp_style():
     for name, p in flow.named_parameters():
         ref = want_g[name].float()
         assert (p.grad.cpu() - ref).abs().max().item() <= 2e-4 * (ref.abs().max().item() + 1e-12) + 1e-7, name
+
+
+@pytest.mark.parametrize('dim,mask,hidden', [(64, 'parity_even', 40), (10, 'ordered_left_half', 13), (2, 'ordered_right_half', 64),
+                                              (5, 'parity_odd', 13), (40, 'ordered_right_half', 32)])
+def test_backward_dense_masks_and_small_dims(dim, mask, hidden):
+    """Masks that do not align with the 32-column tiles (parity_*) and widths below 64 (the reference suite's own
+    shapes, stribor/test/test_coupling.py:7 with check_gradients_not_nan) take the dense backward variant."""
+    torch.manual_seed(17)
+    other = {'ordered_left_half': 'ordered_right_half', 'ordered_right_half': 'ordered_left_half',
+             'parity_even': 'parity_odd', 'parity_odd': 'parity_even'}[mask]
+    desc = [{'kind': 'coupling_affine', 'dim': dim, 'hidden': [hidden], 'mask': m, 'latent_dim': 0}
+            for m in (mask, other, mask)]
+    flow = fd.build_flow(st, desc, dim)
+    state = {k: v.clone() for k, v in flow.state_dict().items()}
+    flow = flow.to(DEV)
+    x = torch.randn(333, dim)
+    want_loss, want_g, want_gx = oracle_grads(desc, state, x)
+    xg = x.to(DEV).requires_grad_(True)
+    lp = flow.log_prob(xg)
+    assert lp.requires_grad
+    loss = -lp.mean()
+    loss.backward()
+    assert abs(loss.item() - want_loss) <= 1e-5 * abs(want_loss)
+    close(xg.grad, want_gx.float(), rtol=1e-4, atol=1e-6)
+    for name, p in flow.named_parameters():
+        ref = want_g[name].float()
+        assert not torch.isnan(p.grad).any()                                     # base.py:76-81
+        assert (p.grad.cpu() - ref).abs().max().item() <= 2e-4 * (ref.abs().max().item() + 1e-12) + 1e-7, name
