@@ -97,6 +97,27 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     return SX_OK;
 }
 
+// {ticket, done} counter pair per (device, stream): launches on one stream never overlap, and the kernel's last
+// workgroup zeroes the pair again, so the pair needs no per-launch memset.  First use on a stream allocates
+// (do that outside hipGraph capture).
+#include <mutex>
+#include <vector>
+struct work_slot { int dev; hipStream_t stream; uint32_t *ptr; };
+static uint32_t *work_counters(hipStream_t stream) {
+    static std::mutex mu;
+    static std::vector<work_slot> slots;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> g(mu);
+    for (const work_slot &w : slots)
+        if (w.dev == dev && w.stream == stream) return w.ptr;
+    uint32_t *p = nullptr;
+    if (hipMalloc(&p, 2 * sizeof(uint32_t)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 2 * sizeof(uint32_t)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return nullptr; }
+    slots.push_back(work_slot{dev, stream, p});
+    return p;
+}
+
 static int pick_grid(int64_t n_rows, int lds_bytes, int tiles, int mode) {
     int per_cu = (160 * 1024) / (lds_bytes > 0 ? lds_bytes : 1);
     int max_per_cu = SX_WAVES_FOR(tiles, mode);
@@ -116,9 +137,9 @@ extern "C" int sx_flow_launch_info(const sx_program *prog_host, int64_t n_rows, 
     dprog d; int bf; int mm; int sw;
     int rc = validate_and_convert(prog_host, &d, &bf, &mm, &sw);
     if (rc) return rc;
-    if (lds_bytes) *lds_bytes = bf * 8;
+    if (lds_bytes) *lds_bytes = bf * 8 + 16;
     if (block) *block = 256;
-    if (grid) *grid = pick_grid(n_rows, bf * 8, prog_host->tiles, mm);
+    if (grid) *grid = pick_grid(n_rows, bf * 8 + 16, prog_host->tiles, mm);
     return SX_OK;
 }
 
@@ -145,11 +166,14 @@ extern "C" int sx_flow_run(const sx_program *prog_host, const float *blobs, cons
     a.prog = d; a.blobs = blobs; a.x = x; a.latent = latent; a.in_col = in_col; a.out_col = out_col; a.y = y;
     a.ldj_out = ldj_out; a.logp_out = logp_out; a.sum_out = sum_out; a.mlp_out = mlp_out;
     a.mlp_out_stride = mlp_out_stride; a.mlp_out_dim = mlp_out_dim; a.n_rows = n_rows; a.buf_floats = bf;
-    a.bf16 = dtype == SX_BF16; a.mlp_mode = mlp_mode; a.lds = bf * 8; a.grid = pick_grid(n_rows, a.lds, prog_host->tiles, mlp_mode);
+    a.bf16 = dtype == SX_BF16; a.mlp_mode = mlp_mode; a.lds = bf * 8 + 16; a.grid = pick_grid(n_rows, a.lds, prog_host->tiles, mlp_mode);
     a.stream = sx_stream(stream);
     a.row_t = row_t;
     a.side = side;
     a.side_width = sw;
+    // dynamic chunk hand-out pays once a workgroup has several chunks; it needs a barrier per chunk (>= 1 step)
+    const int64_t n_chunks = (n_rows + 128 * SX_NS_FOR(prog_host->tiles) - 1) / (128 * SX_NS_FOR(prog_host->tiles));
+    a.work = (prog_host->n_steps > 0 && n_chunks > 2 * (int64_t)a.grid && !getenv("SX_STATIC_CHUNKS")) ? work_counters(a.stream) : nullptr;
     const int T = prog_host->tiles, H = prog_host->h_tiles;
 #define SX_GO(TT, HH) if (T == TT && H == HH) return sx_flow_launch_t##TT##h##HH(a)
     SX_GO(1, 1); SX_GO(1, 2); SX_GO(1, 4); SX_GO(2, 1); SX_GO(2, 2); SX_GO(2, 4); SX_GO(4, 1); SX_GO(4, 2); SX_GO(4, 4);

@@ -42,6 +42,11 @@ extern __shared__ __attribute__((aligned(16))) float smem[];
 
 // Timing experiments only (tools/knob_sweep.sh): with -DSX_DEBUG_KNOBS the bits of g_sx_dbg switch parts of
 // the kernel off (results are then wrong).  The shipped .so is built without it: SX_DBG folds to 0.
+// Compile-time timing experiments (results wrong, straight-line code kept): -DSX_X=<bits>
+//   4 no hidden transcendentals   8 no scale exp2   16 no MFMA   32 no weight ds_read   64 no fp16 split
+#ifndef SX_X
+#define SX_X 0
+#endif
 #ifdef SX_DEBUG_KNOBS
 __device__ int g_sx_dbg;   // set by the host before launch (hipMemcpyToSymbol)
 __device__ __forceinline__ int smem_dbg() { return __builtin_amdgcn_readfirstlane(g_sx_dbg); }
@@ -56,6 +61,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 // shipped build, so every SX_STAMP folds away.
 #ifdef SX_DEBUG_KNOBS
 __device__ unsigned long long g_sx_prof[16];
+__device__ unsigned long long g_sx_span[1024][2];
 struct prof_t {
     unsigned long long acc[16];
     unsigned long long last;
@@ -81,13 +87,13 @@ struct tile {            // one 32-feature tile of NS x 32 samples, C-fragment o
 
 // ---- weights: L2 -> LDS by LDS-DMA, 1 KiB per wave-instruction, lane-linear -----------------------------
 __device__ __forceinline__ void stage_blob(const float *__restrict__ g, int lds_float_off, uint32_t n_floats) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // wave-uniform loop: scalar piece offsets (the LDS address goes through m0), one VGPR of lane offsets
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const uint32_t n_bytes = n_floats * 4u;    // multiple of 1024 (host pads blobs to 256 floats)
-    const char *gsrc = reinterpret_cast<const char *>(g);
+    const char *gsrc = reinterpret_cast<const char *>(g) + lane * 16;
     char *ldst = reinterpret_cast<char *>(smem + lds_float_off);
     for (uint32_t off = wave * 1024u; off < n_bytes; off += 4u * 1024u) {
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(gsrc + off + lane * 16),
-                                         (lds_void *)(ldst + off), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(gsrc + off), (lds_void *)(ldst + off), 16, 0, 0);
     }
 }
 
@@ -137,8 +143,16 @@ struct btile {            // one 32-deep B operand: 2 k16-steps x (hi, lo) fragm
 __device__ __forceinline__ uint32_t pk_rtz(float a, float b) {
     return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
 }
-__device__ __forceinline__ float lo_f(uint32_t p) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(p & 0xffffu)); }
-__device__ __forceinline__ float hi_f(uint32_t p) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(p >> 16)); }
+// lo halfs of a pair: rtz_f16(v - hi) straight from the packed hi register: v_fma_mix_f32 reads the fp16 source in
+// place (no v_cvt_f32_f16) and subtracts in fp32 (exact): 4 full-rate VALU instructions per pair for the whole
+// split instead of 6.  (v_fma_mixlo/mixhi_f16 would make it 3, but they issue at the transcendental rate:
+// tools/valu_cost_probe.hip.)
+__device__ __forceinline__ uint32_t pk_residual(uint32_t ph, float v0, float v1) {
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(ph), "v"(v0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(ph), "v"(v1));
+    return pk_rtz(l0, l1);
+}
 // C tile (fp32, 16 registers) -> B fragments: k16-step s takes registers 8s..8s+7 (cdna_hip_programming.md §3
 // 'An accumulator tile as the next MFMA's operand'); hi = rtz(v), lo = rtz(v - hi) (v - hi is exact in fp32).
 template <int NS>
@@ -152,9 +166,10 @@ __device__ __forceinline__ btile<NS> make_btile(const tile<NS> &c) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float v0 = c.v[n][8 * s + 2 * q], v1 = c.v[n][8 * s + 2 * q + 1];
+                if (SX_X & 64) { hi[q] = __float_as_uint(v0); lo[q] = __float_as_uint(v1); continue; }
                 const uint32_t ph = pk_rtz(v0, v1);
                 hi[q] = ph;
-                lo[q] = pk_rtz(v0 - lo_f(ph), v1 - hi_f(ph));
+                lo[q] = pk_residual(ph, v0, v1);
             }
             b.hi[n][s] = __builtin_bit_cast(h8, hi);
             b.lo[n][s] = __builtin_bit_cast(h8, lo);
@@ -170,8 +185,9 @@ __device__ __forceinline__ void gemm_tile_f(const char *wb, int a_off, const bti
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        const u32x4 ahu = *reinterpret_cast<const u32x4 *>(wb + (a_off + (2 * s) * 256) * 4);       // ds_read_b128, imm offset
-        const u32x4 alu = *reinterpret_cast<const u32x4 *>(wb + (a_off + (2 * s + 1) * 256) * 4);
+        if (SX_X & 16) { f(8 * s + 0); f(8 * s + 1); f(8 * s + 2); f(8 * s + 3); f(8 * s + 4); f(8 * s + 5); f(8 * s + 6); f(8 * s + 7); continue; }
+        const u32x4 ahu = (SX_X & 32) ? u32x4{(uint32_t)a_off, 1u, 2u, 3u} : *reinterpret_cast<const u32x4 *>(wb + (a_off + (2 * s) * 256) * 4);       // ds_read_b128, imm offset
+        const u32x4 alu = (SX_X & 32) ? u32x4{5u, (uint32_t)a_off, 2u, 3u} : *reinterpret_cast<const u32x4 *>(wb + (a_off + (2 * s + 1) * 256) * 4);
         const h8 ah = __builtin_bit_cast(h8, ahu), al = __builtin_bit_cast(h8, alu);
         // smallest terms first
 #pragma unroll
@@ -214,6 +230,63 @@ __device__ __forceinline__ tile<NS> load_cfrag(const char *cb, int off) {
 
 // r = 1/(exp2(z) + 1): the folded form of tanh (the weights carry its constants, see sx_pack_linear)
 __device__ __forceinline__ float fast_sig2(float v) { return __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v) + 1.0f); }
+// the same on registers i, i+1 of a C tile (i even; odd i is a no-op so callers can pass gemm_tile_f's unit index):
+// the +1 is one v_pk_add_f32 for the pair
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// fp32 arithmetic on register pairs.  SX_PK: 0 scalar (default: beside MFMAs a v_pk_*_f32 costs more than the two
+// scalar instructions it replaces -- MI355X_MICROARCH.md 'price of one filler beside MFMAs'; measured here
+// 0.423 vs 0.443 ms on cfg 2), 1 vector types (the compiler packs, and its pre-emit peephole un-packs again
+// whatever sits in an MFMA's shadow), 2 v_pk_*_f32 pinned by inline asm (experiments only).
+#ifndef SX_PK
+#define SX_PK 0
+#endif
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+#if SX_PK == 2
+    f32x2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+#elif SX_PK == 1
+    return a + b;
+#else
+    return f32x2{a.x + b.x, a.y + b.y};
+#endif
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+#if SX_PK == 2
+    f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
+#elif SX_PK == 1
+    return a - b;
+#else
+    return f32x2{a.x - b.x, a.y - b.y};
+#endif
+}
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) {
+#if SX_PK == 2
+    f32x2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+#elif SX_PK == 1
+    return a * b;
+#else
+    return f32x2{a.x * b.x, a.y * b.y};
+#endif
+}
+__device__ __forceinline__ f32x2 pk_add_one(f32x2 a) {
+#if SX_PK == 2
+    f32x2 r; asm("v_pk_add_f32 %0, %1, 1.0 op_sel_hi:[1,0]" : "=v"(r) : "v"(a)); return r;
+#else
+    return a + 1.0f;
+#endif
+}
+__device__ __forceinline__ void fast_sig2_pair(f32x16 &t, int i) {
+    if (i & 1) return;
+    if (SX_X & 4) { t[i] *= 0.5f; t[i + 1] *= 0.5f; return; }
+#if SX_PK == 0
+    t[i] = fast_sig2(t[i]);
+    t[i + 1] = fast_sig2(t[i + 1]);
+#else
+    f32x2 e = {__builtin_amdgcn_exp2f(t[i]), __builtin_amdgcn_exp2f(t[i + 1])};
+    e = pk_add_one(e);
+    t[i] = __builtin_amdgcn_rcpf(e.x);
+    t[i + 1] = __builtin_amdgcn_rcpf(e.y);
+#endif
+}
 
 __device__ __forceinline__ float act_one(float v, int act) {
     switch (act) {
@@ -283,7 +356,7 @@ __device__ __forceinline__ void hidden_layer(const tile<NS> (&src)[NSRC], tile<N
                 if (c == 0)
                     gemm_tile_f<NS>(w.wb, off + (m * CT + c) * 1024, bsrc[c], nxt, [&](int i) {
 #pragma unroll
-                        for (int n = 0; n < NS; ++n) acc.v[n][i] = fast_sig2(acc.v[n][i]);
+                        for (int n = 0; n < NS; ++n) fast_sig2_pair(acc.v[n], i);
                     });
                 else
                     gemm_tile<NS>(w.wb, off + (m * CT + c) * 1024, bsrc[c], nxt);
@@ -315,14 +388,14 @@ __device__ __forceinline__ void coupling_affine(tile<NS> (&xs)[TX], const wptr w
     SX_STAMP(pf, 3);     // GEMM-1 (+ pipelined activation)
     constexpr int a2 = HT * CT * 1024 + HT * 32;   // pack_linear(W2: 2*TT m-tiles, HT k-tiles)
     constexpr int b2 = a2 + 2 * TT * HT * 1024;
-    float s[NS];
+    f32x2 s[NS];         // log-det partial sums, two lanes of v_pk_add_f32
 #pragma unroll
-    for (int n = 0; n < NS; ++n) s[n] = 0.f;
+    for (int n = 0; n < NS; ++n) s[n] = f32x2{0.f, 0.f};
     if constexpr (FOLDED && HT == 1) {
 #pragma unroll
         for (int n = 0; n < NS; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) hid[0].v[n][r] = fast_sig2(hid[0].v[n][r]);
+            for (int r = 0; r < 16; r += 2) fast_sig2_pair(hid[0].v[n], r);
     }
     btile<NS> bh[HT];
 #pragma unroll
@@ -338,7 +411,7 @@ __device__ __forceinline__ void coupling_affine(tile<NS> (&xs)[TX], const wptr w
             if (FOLDED && t == 0 && m == 0)        // the last hidden tile's activation rides under this k-chunk
                 gemm_tile_f<NS>(w.wb, a2 + ((2 * t) * HT + m) * 1024, bh[m], ls, [&](int i) {
 #pragma unroll
-                    for (int n = 0; n < NS; ++n) hid[HT - 1].v[n][i] = fast_sig2(hid[HT - 1].v[n][i]);
+                    for (int n = 0; n < NS; ++n) fast_sig2_pair(hid[HT - 1].v[n], i);
                 });
             else
                 gemm_tile<NS>(w.wb, a2 + ((2 * t) * HT + m) * 1024, bh[m], ls);
@@ -352,10 +425,13 @@ __device__ __forceinline__ void coupling_affine(tile<NS> (&xs)[TX], const wptr w
         // the scale exp(+-log_scale) rides under the shift tile's last k-chunk; ls is overwritten by it
         const float sgn = FOLDED ? 1.0f : (REV ? -1.44269504088896341f : 1.44269504088896341f);
         gemm_tile_f<NS>(w.wb, a2 + ((2 * t + 1) * HT + (HT - 1)) * 1024, bh[HT - 1], sh, [&](int i) {
+            if (i & 1) return;
 #pragma unroll
             for (int n = 0; n < NS; ++n) {
-                s[n] += ls.v[n][i];
+                s[n] = pk_add(s[n], f32x2{ls.v[n][i], ls.v[n][i + 1]});
+                if (SX_X & 8) continue;
                 ls.v[n][i] = __builtin_amdgcn_exp2f(FOLDED ? ls.v[n][i] : ls.v[n][i] * sgn);
+                ls.v[n][i + 1] = __builtin_amdgcn_exp2f(FOLDED ? ls.v[n][i + 1] : ls.v[n][i + 1] * sgn);
             }
         });
         SX_STAMP(pf, 4);     // GEMM-2 (+ pipelined activation / exp)
@@ -363,11 +439,16 @@ __device__ __forceinline__ void coupling_affine(tile<NS> (&xs)[TX], const wptr w
 #pragma unroll
         for (int n = 0; n < NS; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                x.v[n][r] = REV ? (x.v[n][r] - sh.v[n][r]) * ls.v[n][r] : x.v[n][r] * ls.v[n][r] + sh.v[n][r];
+            for (int r = 0; r < 16; r += 2) {      // v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 on register pairs
+                const f32x2 xv = {x.v[n][r], x.v[n][r + 1]}, sv = {sh.v[n][r], sh.v[n][r + 1]};
+                const f32x2 ev = {ls.v[n][r], ls.v[n][r + 1]};
+                const f32x2 yv = REV ? pk_mul(pk_sub(xv, sv), ev) : pk_add(pk_mul(xv, ev), sv);
+                x.v[n][r] = yv.x;
+                x.v[n][r + 1] = yv.y;
+            }
     }
 #pragma unroll
-    for (int n = 0; n < NS; ++n) ldj[n] += st.ldj_scale * s[n];
+    for (int n = 0; n < NS; ++n) ldj[n] += st.ldj_scale * (s[n].x + s[n].y);
     SX_STAMP(pf, 5);         // affine + log-det
 }
 // one runtime dispatch per step on (activation kind, direction) -> straight-line specialisations
@@ -765,6 +846,7 @@ struct flow_kargs {     // everything but the program, by value in the kernarg s
     const float *blobs; const void *x; const float *latent; const int32_t *in_col; const int32_t *out_col;
     void *y; float *ldj_out; float *logp_out; double *sum_out; float *mlp_out; const float *row_t; float *side;
     int64_t mlp_out_stride; int64_t n_rows; int mlp_out_dim; int buf_floats; int bf16; int side_width;
+    uint32_t *work;     // {next-chunk ticket, finished workgroups}: dynamic chunk hand-out (NULL = static stride)
 };
 
 // MODE 0: flow programs (coupling / affine-const steps); MODE 1: + persistent hidden state (MLP programs);
@@ -785,6 +867,7 @@ __global__ __launch_bounds__(256, SX_WAVES_FOR(TX, MODE)) void flow_fused_kernel
 #ifdef SX_DEBUG_KNOBS
     for (int i = 0; i < 16; ++i) pf.acc[i] = 0;
     pf.last = __builtin_amdgcn_s_memtime();
+    const unsigned long long pf_t0 = pf.last, pf_w0 = wall_clock64();   // wall_clock64: 100 MHz constant clock
 #endif
 
     // prologue: first step's weights into buffer 0, first step's descriptor into registers
@@ -792,15 +875,26 @@ __global__ __launch_bounds__(256, SX_WAVES_FOR(TX, MODE)) void flow_fused_kernel
     dstep st_next = prog.steps[0];
     if ((int64_t)blockIdx.x < n_chunks && n_steps > 0 && st_next.blob_floats)
         stage_blob(k.blobs + st_next.blob_off, 0, st_next.blob_floats);
+    // the DMA fields of the step after next are fetched a step early, so the refill below never waits on a scalar load
+    uint32_t dma_off = prog.steps[n_steps > 1 ? 1 : 0].blob_off, dma_floats = prog.steps[n_steps > 1 ? 1 : 0].blob_floats;
 
-    for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    // Chunks (128 rows) are handed out dynamically: workgroups sharing a SIMD do not progress at the same rate (the
+    // issue arbiter favours the oldest wave), so a static stride leaves the last third of the kernel with CUs
+    // running one workgroup.  Thread 0 takes a ticket for the NEXT chunk in the prologue; it travels to the other
+    // waves through LDS across the first step's barrier (two slots, alternating, behind the weight ring).
+    const bool dyn = k.work != nullptr;
+    volatile uint32_t *slot = reinterpret_cast<volatile uint32_t *>(smem + 2 * buf_floats);
+    int iter = 0;
+    for (int64_t chunk = blockIdx.x; chunk < n_chunks; ++iter) {
+        uint32_t ticket = 0;
+        if (dyn && threadIdx.x == 0) ticket = atomicAdd(k.work, 1u);
+        int64_t next_chunk = chunk + gridDim.x;
         int64_t row[NS], lrow[NS];
 #pragma unroll
         for (int n = 0; n < NS; ++n) {
             row[n] = chunk * ROWS_PER_BLOCK + wave * (32 * NS) + n * 32 + j;
             lrow[n] = row[n] < n_rows ? row[n] : n_rows - 1;      // clamp loads, mask stores
         }
-        const bool has_next_chunk = chunk + gridDim.x < n_chunks;
 
         // ---- load the state tiles in C-fragment order ---------------------------------------------------
         tile<NS> xs[TX];
@@ -866,16 +960,21 @@ __global__ __launch_bounds__(256, SX_WAVES_FOR(TX, MODE)) void flow_fused_kernel
             //     i.e. nobody still reads buffer cur^1;
             if (!SX_DBG(2)) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (dyn && s == 0 && threadIdx.x == 0) slot[iter & 1] = ticket;
                 __syncthreads();
+                if (dyn && s == 0) next_chunk = (int64_t)gridDim.x + __builtin_amdgcn_readfirstlane(slot[iter & 1]);
             }
+            const bool has_next_chunk = next_chunk < n_chunks;
             SX_STAMP(pf, 1);     // wait for weights + barrier
             // (2) refill buffer cur^1 with the next step's weights (the DMA flies under this step's MFMAs)
             //     and fetch the next step's descriptor one step early.
             const dstep st = st_next;
-            const int nxt = (s + 1 < n_steps) ? s + 1 : 0;
+            if ((s + 1 < n_steps || has_next_chunk) && dma_floats && !SX_DBG(1))
+                stage_blob(k.blobs + dma_off, (cur ^ 1) * buf_floats, dma_floats);
+            const int nxt = (s + 1 < n_steps) ? s + 1 : 0, nxt2 = (nxt + 1 < n_steps) ? nxt + 1 : 0;
             st_next = prog.steps[nxt];
-            if ((s + 1 < n_steps || has_next_chunk) && st_next.blob_floats && !SX_DBG(1))
-                stage_blob(k.blobs + st_next.blob_off, (cur ^ 1) * buf_floats, st_next.blob_floats);
+            dma_off = prog.steps[nxt2].blob_off;
+            dma_floats = prog.steps[nxt2].blob_floats;
 
             const wptr w = make_wptr(cur * buf_floats, lane);
             SX_STAMP(pf, 2);     // descriptor + DMA issue
@@ -1070,12 +1169,24 @@ __global__ __launch_bounds__(256, SX_WAVES_FOR(TX, MODE)) void flow_fused_kernel
             }
         }
         SX_STAMP(pf, 7);         // chunk epilogue
+        chunk = next_chunk;
+    }
+    if (dyn && threadIdx.x == 0) {     // the last workgroup out re-arms the counters for the next launch on this stream
+        __threadfence();
+        if (atomicAdd(k.work + 1, 1u) == gridDim.x - 1) { k.work[0] = 0u; k.work[1] = 0u; }
     }
 
 #ifdef SX_DEBUG_KNOBS
     SX_STAMP(pf, 7);             // epilogue of the last chunk
-    if (blockIdx.x == 3 && threadIdx.x == 64)
-        for (int i = 0; i < 16; ++i) g_sx_prof[i] = pf.acc[i];
+    if (blockIdx.x == 3 && threadIdx.x == 64) {
+        for (int i = 0; i < 8; ++i) g_sx_prof[i] = pf.acc[i];
+        g_sx_prof[8] = __builtin_amdgcn_s_memtime() - pf_t0;
+        g_sx_prof[9] = wall_clock64() - pf_w0;
+    }
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {      // start / end time of every workgroup (100 MHz ticks)
+        g_sx_span[blockIdx.x][0] = pf_w0;
+        g_sx_span[blockIdx.x][1] = wall_clock64();
+    }
 #endif
     if (k.sum_out != nullptr) {
         double *part = reinterpret_cast<double *>(smem);   // no second __shared__ object beside the DMA ring
@@ -1095,6 +1206,8 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
         const char *e = getenv("SX_DBG");
         int v = e ? atoi(e) : 0;
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sx_dbg), &v, sizeof(int));
+        static unsigned long long zero[1024][2];
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sx_span), zero, sizeof(zero));
     }
 #endif
     constexpr int NS = SX_NS_FOR(TX);
@@ -1102,7 +1215,7 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
     k.blobs = a.blobs; k.x = a.x; k.latent = a.latent; k.in_col = a.in_col; k.out_col = a.out_col; k.y = a.y;
     k.ldj_out = a.ldj_out; k.logp_out = a.logp_out; k.sum_out = a.sum_out; k.mlp_out = a.mlp_out; k.row_t = a.row_t; k.side = a.side;
     k.mlp_out_stride = a.mlp_out_stride; k.n_rows = a.n_rows; k.mlp_out_dim = a.mlp_out_dim;
-    k.buf_floats = a.buf_floats; k.bf16 = a.bf16; k.side_width = a.side_width;
+    k.buf_floats = a.buf_floats; k.bf16 = a.bf16; k.side_width = a.side_width; k.work = a.work;
 #define SX_FL(MD)                                                                                              \
     do {                                                                                                       \
         auto kern = flow_fused_kernel<NS, TX, HT, MD>;                                                         \
@@ -1128,7 +1241,24 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
         for (int i = 0; i < 8; ++i) tot += p[i];
         fprintf(stderr, "[sx prof] wave 1 of block 3, cycles:");
         for (int i = 0; i < 8; ++i) fprintf(stderr, " %s=%llu (%.1f%%)", names[i], p[i], 100.0 * p[i] / (tot ? tot : 1));
-        fprintf(stderr, " total=%llu\n", tot);
+        fprintf(stderr, " total=%llu; wave lifetime %.1f us at %.2f GHz (s_memtime / 100 MHz wall clock)\n", tot, p[9] * 0.01,
+                p[9] ? (double)p[8] / (p[9] * 10.0) : 0.0);
+        static unsigned long long span[1024][2];
+        (void)hipMemcpyFromSymbol(span, HIP_SYMBOL(g_sx_span), sizeof(span));
+        unsigned long long s0 = ~0ull, s1 = 0, e0 = ~0ull, e1 = 0;
+        int nb = 0;
+        for (int b = 0; b < 1024 && b < a.grid; ++b) {
+            if (!span[b][1]) continue;
+            ++nb;
+            s0 = span[b][0] < s0 ? span[b][0] : s0; s1 = span[b][0] > s1 ? span[b][0] : s1;
+            e0 = span[b][1] < e0 ? span[b][1] : e0; e1 = span[b][1] > e1 ? span[b][1] : e1;
+        }
+        fprintf(stderr, "[sx prof] %d workgroups: starts spread %.1f us; first end %.1f us, last end %.1f us after the first start\n",
+                nb, (s1 - s0) * 0.01, (e0 - s0) * 0.01, (e1 - s0) * 0.01);
+        if (getenv("SX_PROF_DUMP")) {
+            for (int b = 0; b < 1024 && b < a.grid; ++b)
+                fprintf(stderr, "[sx span] %d %.2f %.2f\n", b, (span[b][0] - s0) * 0.01, (span[b][1] - s0) * 0.01);
+        }
     }
 #endif
     return SX_OK;

@@ -23,6 +23,7 @@ struct sx_flow_args {
     const float *row_t;
     float *side;
     int side_width;
+    uint32_t *work;
 };
 
 

@@ -369,7 +369,7 @@ extern "C" int sx_rqs_coupling(const void *x, void *y, float *ldj, float *ldiag,
     if (grid < 1) grid = 1;
     if (lds > 48 * 1024) {
 #define SX_ATTR(BF, INV)                                                                                          \
-    hipFuncSetAttribute((const void *)rqs_kernel<BF, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+    (void)hipFuncSetAttribute((const void *)rqs_kernel<BF, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
         SX_ATTR(true, true); SX_ATTR(true, false); SX_ATTR(false, true); SX_ATTR(false, false);
 #undef SX_ATTR
     }
