@@ -883,11 +883,15 @@ __global__ __launch_bounds__(256, SX_WAVES_FOR(TX, MODE)) void flow_fused_kernel
     // running one workgroup.  Thread 0 takes a ticket for the NEXT chunk in the prologue; it travels to the other
     // waves through LDS across the first step's barrier (two slots, alternating, behind the weight ring).
     const bool dyn = k.work != nullptr;
-    volatile uint32_t *slot = reinterpret_cast<volatile uint32_t *>(smem + 2 * buf_floats);
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    lds_u32 *slot = (lds_u32 *)(smem + 2 * buf_floats);      // ds_write_b32 / ds_read_b32, ordered by the barrier
     int iter = 0;
     for (int64_t chunk = blockIdx.x; chunk < n_chunks; ++iter) {
-        uint32_t ticket = 0;
-        if (dyn && threadIdx.x == 0) ticket = atomicAdd(k.work, 1u);
+        // lane-derived indices are re-derived per chunk from the thread id (opaque to the optimizer) instead of
+        // living in -- or being spilled from -- registers across the step loop
+        uint32_t tid_ = threadIdx.x;
+        asm volatile("" : "+v"(tid_));
+        [[maybe_unused]] const int lane = tid_ & 63, wave = tid_ >> 6, j = lane & 31, h = lane >> 5;
         int64_t next_chunk = chunk + gridDim.x;
         int64_t row[NS], lrow[NS];
 #pragma unroll
@@ -944,6 +948,10 @@ __global__ __launch_bounds__(256, SX_WAVES_FOR(TX, MODE)) void flow_fused_kernel
             }
         }
 
+        // the ticket is requested behind the x loads and, like them, first waited for at step 0's vmcnt(0)
+        // (built with the atomic optimizer off: its readfirstlane epilogue would wait right here)
+        uint32_t ticket = 0;
+        if (dyn && threadIdx.x == 0) ticket = atomicAdd(k.work, 1u);
         SX_STAMP(pf, 0);     // chunk prologue: x loads issued (not yet waited for)
         float ldj[NS];
 #pragma unroll
