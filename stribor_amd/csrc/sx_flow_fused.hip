@@ -93,6 +93,21 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     if (rqs) *mlp_mode = 3;
     SX_REQUIRE(!(bwd && (rqs || lin || aff || *mlp_mode == 1)), "sx_flow_run: backward steps cannot be mixed with other step kinds");
     if (bwd) *mlp_mode = 4;
+    // MODE 5 / 6: nothing but tanh-folded affine couplings on half the tiles conditioned on the other half, all in
+    // one direction (5 reverse, 6 forward) -- the plain RealNVP log_prob / sample program.  Its kernel carries two
+    // straight-line arms only, which keeps the state in place (no phi copies) at 130 VGPRs.
+    if (*mlp_mode == 0 && p->n_steps > 0 && p->tiles >= 2) {
+        bool pure = true;
+        const int T = p->tiles;
+        for (int i = 0; i < p->n_steps && pure; ++i) {
+            const sx_step &s = p->steps[i];
+            const bool low = s.c0 == 0 && s.ct == T / 2 && s.t0 == T / 2 && s.tt == T / 2;
+            const bool high = s.c0 == T / 2 && s.ct == T / 2 && s.t0 == 0 && s.tt == T / 2;
+            pure = s.kind == SX_STEP_COUPLING_AFFINE && s.act == SX_ACT_TANH_FOLDED && (low || high) &&
+                   (s.reverse != 0) == (p->steps[0].reverse != 0);
+        }
+        if (pure && !getenv("SX_NO_PURE_MODE")) *mlp_mode = p->steps[0].reverse ? 5 : 6;
+    }
     SX_REQUIRE((size_t)mx * 8 <= 160 * 1024, "sx_flow_run: a step needs %d B of LDS per buffer (> 80 KiB)", mx * 4);
     return SX_OK;
 }

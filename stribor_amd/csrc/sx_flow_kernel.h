@@ -857,7 +857,7 @@ template <int NS, int TX, int HT, int MODE>
 __global__ __launch_bounds__(256, SX_WAVES_FOR(TX, MODE)) void flow_fused_kernel(const dprog prog, const flow_kargs k) {
     constexpr int ROWS_PER_BLOCK = 128 * NS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = lane & 31, h = lane >> 5;
+    [[maybe_unused]] const int j = lane & 31, h = lane >> 5;
     const int dim = prog.dim, x_tiles = prog.x_tiles, n_steps = prog.n_steps;
     const int64_t n_rows = k.n_rows;
     const int64_t n_chunks = (n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
@@ -986,6 +986,13 @@ __global__ __launch_bounds__(256, SX_WAVES_FOR(TX, MODE)) void flow_fused_kernel
 
             const wptr w = make_wptr(cur * buf_floats, lane);
             SX_STAMP(pf, 2);     // descriptor + DMA issue
+            if constexpr (MODE == 5 || MODE == 6) {
+                // pure split-coupling programs (host: validate_and_convert): two straight-line arms, state in place
+                if constexpr (TX >= 2) {
+                    if (st.c0 == 0) coupling_affine<NS, TX, HT, 0, TX / 2, TX / 2, TX / 2, true, MODE == 5>(xs, w, st, ldj, pf);
+                    else coupling_affine<NS, TX, HT, TX / 2, TX / 2, 0, TX / 2, true, MODE == 5>(xs, w, st, ldj, pf);
+                }
+            } else
             switch (st.kind) {
                 case SX_STEP_COUPLING_AFFINE:
                     if constexpr (MODE == 3) break;      // spline programs carry no affine couplings (register budget)
@@ -1236,7 +1243,10 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
         hipLaunchKernelGGL(kern, dim3(a.grid), dim3(256), a.lds, a.stream, a.prog, k);                         \
     } while (0)
     if (a.mlp_mode == 1) SX_FL(1); else if (a.mlp_mode == 2) SX_FL(2); else if (a.mlp_mode == 3) SX_FL(3);
-    else if (a.mlp_mode == 4) SX_FL(4); else SX_FL(0);
+    else if (a.mlp_mode == 4) SX_FL(4);
+    else if (a.mlp_mode == 5) { if constexpr (TX >= 2) SX_FL(5); }
+    else if (a.mlp_mode == 6) { if constexpr (TX >= 2) SX_FL(6); }
+    else SX_FL(0);
 #undef SX_FL
     SX_LAUNCH_CHECK();
 #ifdef SX_DEBUG_KNOBS

@@ -43,7 +43,7 @@ struct sx_flow_args {
 #define SX_RQS_WAVES 2
 #endif
 #ifndef SX_WAVES_FOR
-#define SX_WAVES_FOR(TX, MODE) ((TX) >= 4 ? 1 : ((MODE) == 3 ? SX_RQS_WAVES : ((MODE) == 0 ? 3 : 2)))
+#define SX_WAVES_FOR(TX, MODE) ((TX) >= 4 ? 1 : ((MODE) == 3 ? SX_RQS_WAVES : ((MODE) == 0 || (MODE) >= 5 ? 3 : 2)))
 #endif
 
 #define SX_DECL_FLOW(T, H) int sx_flow_launch_t##T##h##H(const sx_flow_args &a);
