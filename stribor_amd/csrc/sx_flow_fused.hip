@@ -135,11 +135,11 @@ static uint32_t *work_counters(hipStream_t stream) {
 
 static int pick_grid(int64_t n_rows, int lds_bytes, int tiles, int mode) {
     int per_cu = (160 * 1024) / (lds_bytes > 0 ? lds_bytes : 1);
-    int max_per_cu = SX_WAVES_FOR(tiles, mode);
+    int max_per_cu = SX_BLOCKS_FOR(tiles, mode);
     if (const char *g = getenv("SX_BLOCKS_PER_CU")) max_per_cu = atoi(g);      // experiment knob
     if (per_cu > max_per_cu) per_cu = max_per_cu;
     if (per_cu < 1) per_cu = 1;
-    const int rows_per_block = 128 * SX_NS_FOR(tiles);
+    const int rows_per_block = 32 * SX_BLOCK_WAVES(tiles, mode) * SX_NS_FOR(tiles);
     int64_t chunks = (n_rows + rows_per_block - 1) / rows_per_block;
     int64_t g = 256 * per_cu;
     if (g > chunks) g = chunks;
@@ -153,7 +153,7 @@ extern "C" int sx_flow_launch_info(const sx_program *prog_host, int64_t n_rows, 
     int rc = validate_and_convert(prog_host, &d, &bf, &mm, &sw);
     if (rc) return rc;
     if (lds_bytes) *lds_bytes = bf * 8 + 16;
-    if (block) *block = 256;
+    if (block) *block = 64 * SX_BLOCK_WAVES(prog_host->tiles, mm);
     if (grid) *grid = pick_grid(n_rows, bf * 8 + 16, prog_host->tiles, mm);
     return SX_OK;
 }
@@ -187,7 +187,8 @@ extern "C" int sx_flow_run(const sx_program *prog_host, const float *blobs, cons
     a.side = side;
     a.side_width = sw;
     // dynamic chunk hand-out pays once a workgroup has several chunks; it needs a barrier per chunk (>= 1 step)
-    const int64_t n_chunks = (n_rows + 128 * SX_NS_FOR(prog_host->tiles) - 1) / (128 * SX_NS_FOR(prog_host->tiles));
+    const int rpb = 32 * SX_BLOCK_WAVES(prog_host->tiles, mlp_mode) * SX_NS_FOR(prog_host->tiles);
+    const int64_t n_chunks = (n_rows + rpb - 1) / rpb;
     a.work = (prog_host->n_steps > 0 && n_chunks > 2 * (int64_t)a.grid && !getenv("SX_STATIC_CHUNKS")) ? work_counters(a.stream) : nullptr;
     const int T = prog_host->tiles, H = prog_host->h_tiles;
 #define SX_GO(TT, HH) if (T == TT && H == HH) return sx_flow_launch_t##TT##h##HH(a)

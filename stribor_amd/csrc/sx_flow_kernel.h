@@ -86,13 +86,14 @@ struct tile {            // one 32-feature tile of NS x 32 samples, C-fragment o
 };
 
 // ---- weights: L2 -> LDS by LDS-DMA, 1 KiB per wave-instruction, lane-linear -----------------------------
+template <int WAVES>
 __device__ __forceinline__ void stage_blob(const float *__restrict__ g, int lds_float_off, uint32_t n_floats) {
     // wave-uniform loop: scalar piece offsets (the LDS address goes through m0), one VGPR of lane offsets
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const uint32_t n_bytes = n_floats * 4u;    // multiple of 1024 (host pads blobs to 256 floats)
     const char *gsrc = reinterpret_cast<const char *>(g) + lane * 16;
     char *ldst = reinterpret_cast<char *>(smem + lds_float_off);
-    for (uint32_t off = wave * 1024u; off < n_bytes; off += 4u * 1024u) {
+    for (uint32_t off = wave * 1024u; off < n_bytes; off += WAVES * 1024u) {
         __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(gsrc + off), (lds_void *)(ldst + off), 16, 0, 0);
     }
 }
@@ -854,8 +855,9 @@ struct flow_kargs {     // everything but the program, by value in the kernarg s
 // MODE 3: flow programs with rational-quadratic spline couplings: + hidden B operands and the group state;
 // MODE 4: training backward of affine-coupling log_prob flows: tiles [0,2) = x, [2,4) = dL/dx
 template <int NS, int TX, int HT, int MODE>
-__global__ __launch_bounds__(256, SX_WAVES_FOR(TX, MODE)) void flow_fused_kernel(const dprog prog, const flow_kargs k) {
-    constexpr int ROWS_PER_BLOCK = 128 * NS;
+__global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MODE)) void flow_fused_kernel(const dprog prog, const flow_kargs k) {
+    constexpr int WB = SX_BLOCK_WAVES(TX, MODE);      // waves per workgroup
+    constexpr int ROWS_PER_BLOCK = 32 * WB * NS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     [[maybe_unused]] const int j = lane & 31, h = lane >> 5;
     const int dim = prog.dim, x_tiles = prog.x_tiles, n_steps = prog.n_steps;
@@ -874,7 +876,7 @@ __global__ __launch_bounds__(256, SX_WAVES_FOR(TX, MODE)) void flow_fused_kernel
     int cur = 0;
     dstep st_next = prog.steps[0];
     if ((int64_t)blockIdx.x < n_chunks && n_steps > 0 && st_next.blob_floats)
-        stage_blob(k.blobs + st_next.blob_off, 0, st_next.blob_floats);
+        stage_blob<WB>(k.blobs + st_next.blob_off, 0, st_next.blob_floats);
     // the DMA fields of the step after next are fetched a step early, so the refill below never waits on a scalar load
     uint32_t dma_off = prog.steps[n_steps > 1 ? 1 : 0].blob_off, dma_floats = prog.steps[n_steps > 1 ? 1 : 0].blob_floats;
 
@@ -978,7 +980,7 @@ __global__ __launch_bounds__(256, SX_WAVES_FOR(TX, MODE)) void flow_fused_kernel
             //     and fetch the next step's descriptor one step early.
             const dstep st = st_next;
             if ((s + 1 < n_steps || has_next_chunk) && dma_floats && !SX_DBG(1))
-                stage_blob(k.blobs + dma_off, (cur ^ 1) * buf_floats, dma_floats);
+                stage_blob<WB>(k.blobs + dma_off, (cur ^ 1) * buf_floats, dma_floats);
             const int nxt = (s + 1 < n_steps) ? s + 1 : 0, nxt2 = (nxt + 1 < n_steps) ? nxt + 1 : 0;
             st_next = prog.steps[nxt];
             dma_off = prog.steps[nxt2].blob_off;
@@ -1210,7 +1212,12 @@ __global__ __launch_bounds__(256, SX_WAVES_FOR(TX, MODE)) void flow_fused_kernel
         __syncthreads();
         if (lane == 0) part[wave] = block_sum;
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(k.sum_out, (part[0] + part[1]) + (part[2] + part[3]));
+        if (threadIdx.x == 0) {
+            double tot = 0.0;
+#pragma unroll
+            for (int i = 0; i < WB; i += 4) tot += (part[i] + part[i + 1]) + (part[i + 2] + part[i + 3]);
+            atomicAdd(k.sum_out, tot);
+        }
     }
 }
 
@@ -1240,7 +1247,7 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
             if (e != hipSuccess) { sx_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
             lds_allowed = 160 * 1024;                                                                          \
         }                                                                                                      \
-        hipLaunchKernelGGL(kern, dim3(a.grid), dim3(256), a.lds, a.stream, a.prog, k);                         \
+        hipLaunchKernelGGL(kern, dim3(a.grid), dim3(64 * SX_BLOCK_WAVES(TX, MD)), a.lds, a.stream, a.prog, k);                         \
     } while (0)
     if (a.mlp_mode == 1) SX_FL(1); else if (a.mlp_mode == 2) SX_FL(2); else if (a.mlp_mode == 3) SX_FL(3);
     else if (a.mlp_mode == 4) SX_FL(4);
