@@ -159,6 +159,11 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_cfg2.json')))
         except Exception:
             pass
+        sq = {}
+        try:      # SQ utilisation of the fused kernel from the committed --pmc passes (tools/profile_bench.sh)
+            sq = json.load(open(os.path.join(ROOT, 'profiles', 'sq_cfg2.json')))
+        except Exception:
+            pass
         # standalone element-wise affine coupling kernel (params precomputed in HBM), HBM roofline
         from stribor_amd.flows.affine import run_affine_kernel
         params = torch.randn(ROWS_PER_GPU, DIM, device=dev) * 0.1
@@ -181,7 +186,7 @@ def main():
                                    'batch 2^20 per GPU, x stored bf16, fp32 arithmetic, UnitNormal base, fp64 batch sum',
                        'rows_per_gpu': ROWS_PER_GPU, 'dim': DIM, 'layers': LAYERS, 'hidden': HIDDEN,
                        'x_storage': 'bf16', 'parallelism': f'batch-sharded x{world}, one 8-byte all-reduce per step'},
-            'roofline': {'kernel': 'flow_fused_kernel<NS=1,TX=2,HT=2,MODE=0>', 'bound': 'mfma',
+            'roofline': {'kernel': 'flow_fused_kernel<NS=1,TX=2,HT=2,MODE=5> (pure split-coupling program, 8-wave workgroups)', 'bound': 'mfma',
                          'achieved': achieved_tflops, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved_tflops / peak,
                          'traffic': pmc.get('flow_fused_kernel', {}).get('hbm_bytes_per_launch'),
                          'avg_kernel_ms': k_avg_ms, 'median_kernel_ms': k_med_ms,
@@ -193,6 +198,9 @@ def main():
                          'frac_of_exact_fp32_mfma_peak': achieved_tflops / PEAK_F32_MFMA_TFLOPS,
                          'binding_resource': 'VALU issue (tanh/exp transcendentals + fp16 operand splitting); '
                                              'neither HBM (3 % of peak) nor the matrix pipe binds',
+                         'valu_issue_busy_frac_pmc': sq.get('valu_issue_busy_frac'),
+                         'mfma_pipe_busy_frac_pmc': sq.get('mfma_pipe_busy_frac'),
+                         'effective_clock_ghz_pmc': sq.get('effective_clock_ghz'),
                          'algorithmic_flops_per_launch': FLOPS_PER_ROW * ROWS_PER_GPU,
                          'algorithmic_bytes_per_launch': BYTES_PER_ROW * ROWS_PER_GPU,
                          'hbm_frac_of_same_kernel': BYTES_PER_ROW * ROWS_PER_GPU / (k_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
