@@ -15,7 +15,8 @@ The reference is a class hierarchy of nn.Modules; the oracle is deliberately a s
 functions over a *flow spec*: a list of dicts, one per transform, holding plain tensors.
 
     {'kind': 'coupling_affine', 'mask': 'ordered_right_half', 'net': NET}
-    {'kind': 'coupling_rqs',    'mask': ..., 'net': NET, 'n_bins': K, 'lower': a, 'upper': b}
+    {'kind': 'coupling_rqs',    'mask': ..., 'net': NET, 'n_bins': K, 'lower': a, 'upper': b,
+                                'spline_type': 'quadratic' (default here) | 'cubic'}
     {'kind': 'affine',          'log_scale': [1,D] or [D], 'shift': same}       (no latent_net)
     {'kind': 'affine_lu',       'weight': [D,D], 'log_diag': [1,D], 'bias': [1,D]}
     {'kind': 'matrix_exp',      'weight': [D,D], 'diag': [D], 'bias': [D] or None, 'log_time': bool}
@@ -231,13 +232,154 @@ def rqs_unconstrained(x: Tensor, uw: Tensor, uh: Tensor, ud: Tensor, inverse: bo
     return out, ljd
 
 
+# ----------------------------------------------------------------------------------------------
+# monotone cubic spline (spline_type='cubic', the reference's default)    util/cubic_spline.py:21-251
+# ----------------------------------------------------------------------------------------------
+CUBIC_MIN_BIN_WIDTH = 1e-2       # util/cubic_spline.py:13
+CUBIC_MIN_BIN_HEIGHT = 1e-2      # util/cubic_spline.py:14
+CUBIC_EPS = 1e-5                 # util/cubic_spline.py:15
+CUBIC_QUADRATIC_THRESHOLD = 1e-3  # util/cubic_spline.py:16
+
+
+def cubic_params_from_net(p: Tensor, dim: int, n_bins: int) -> Tuple[Tensor, Tensor, Tensor]:
+    """[..., D*(2K+2)] -> w[..., D, K], h[..., D, K], d[..., D, 2].  flows/spline.py:82-86."""
+    p = p.view(*p.shape[:-1], dim, 2 * n_bins + 2)
+    return p[..., :n_bins], p[..., n_bins:2 * n_bins], p[..., 2 * n_bins:]
+
+
+def _cbrt(x: Tensor) -> Tensor:
+    return torch.sign(x) * torch.exp(torch.log(torch.abs(x)) / 3.0)  # cubic_spline.py:18-20
+
+
+def cubic_unconstrained(x: Tensor, uw: Tensor, uh: Tensor, ud: Tensor, inverse: bool,
+                        lower: float, upper: float) -> Tuple[Tensor, Tensor]:
+    """Per-element restatement of unconstrained_cubic_spline + cubic_spline (cubic_spline.py:21-251).
+
+    The in-domain elements are compacted first, as in the reference (which makes its domain check :86-89 vacuous).
+    The inverse's root selection keeps the reference's precedence (:170-222): one-root formula where the
+    discriminant is <= 0, else the first of the three trigonometric roots (order 1, 2, 3) that lies in the bin
+    (what torch.argsort(descending=True)[..., 0] returns on CPU; root 1 if none does), both overwritten by the
+    quadratic formula where |a| < 1e-3.
+    """
+    K = uw.shape[-1]
+    if CUBIC_MIN_BIN_WIDTH * K > 1.0:
+        raise ValueError('Minimal bin width too large for the number of bins')     # :93-94
+    if CUBIC_MIN_BIN_HEIGHT * K > 1.0:
+        raise ValueError('Minimal bin height too large for the number of bins')    # :95-96
+    left = bottom = lower
+    right = top = upper
+    uw = uw.expand(*x.shape, -1)                                     # :35-36
+    uh = uh.expand(*x.shape, -1)
+    udl = ud[..., 0, None].expand(*x.shape, -1)                      # :37-38
+    udr = ud[..., 1, None].expand(*x.shape, -1)
+    inside = (x >= lower) & (x <= upper)                             # :40
+    out_full = x.clone()                                             # :43-48 linear tails: identity, ldj 0
+    ljd_full = torch.zeros_like(x)
+    if not bool(inside.any()):                                       # :52-53
+        return out_full, ljd_full
+    # boolean compaction as in the reference (:55-60): torch's vectorised CPU kernels are not position-independent
+    # to the last bit and the golden vectors pin this function bit for bit
+    xin, uw, uh, udl, udr = x[inside], uw[inside, :], uh[inside, :], udl[inside, :], udr[inside, :]
+    if inverse:
+        xin = (xin - bottom) / (top - bottom)                        # :98-99
+    else:
+        xin = (xin - left) / (right - left)                          # :100-101
+
+    w = F.softmax(uw, dim=-1)                                        # :103-104
+    w = CUBIC_MIN_BIN_WIDTH + (1 - CUBIC_MIN_BIN_WIDTH * K) * w
+    cw = torch.cumsum(w, dim=-1)                                     # :106-108
+    cw[..., -1] = 1
+    cw = F.pad(cw, pad=(1, 0), mode='constant', value=0.0)
+    h = F.softmax(uh, dim=-1)                                        # :110-111
+    h = CUBIC_MIN_BIN_HEIGHT + (1 - CUBIC_MIN_BIN_HEIGHT * K) * h
+    ch = torch.cumsum(h, dim=-1)                                     # :113-115
+    ch[..., -1] = 1
+    ch = F.pad(ch, pad=(1, 0), mode='constant', value=0.0)
+
+    slopes = h / w                                                   # :117
+    m1 = torch.min(torch.abs(slopes[..., :-1]), torch.abs(slopes[..., 1:]))            # :118-119
+    m2 = (0.5 * (w[..., 1:] * slopes[..., :-1] + w[..., :-1] * slopes[..., 1:])
+          / (w[..., :-1] + w[..., 1:]))                              # :120-123
+    ms = torch.min(m1, m2)                                           # :124
+    dl = torch.sigmoid(udl) * 3 * slopes[..., 0][..., None]          # :126
+    dr = torch.sigmoid(udr) * 3 * slopes[..., -1][..., None]         # :127
+    dv = ms * (torch.sign(slopes[..., :-1]) + torch.sign(slopes[..., 1:]))              # :129
+    dv = torch.cat([dl, dv, dr], dim=-1)                             # :130-132
+
+    a = (dv[..., :-1] + dv[..., 1:] - 2 * slopes) / w.pow(2)         # :134
+    b = (3 * slopes - 2 * dv[..., :-1] - dv[..., 1:]) / w            # :135
+    c = dv[..., :-1]                                                 # :136
+    d = ch[..., :-1]                                                 # :137
+
+    edges = (ch if inverse else cw).clone()                          # :139-142
+    edges[..., -1] += SEARCH_EPS                                     # search_sorted.py:4
+    idx = (torch.sum(xin[..., None] >= edges, dim=-1) - 1)[..., None]
+    g = lambda t: t.gather(-1, idx)[..., 0]
+    ia, ib, ic, id_ = g(a), g(b), g(c), g(d)                         # :144-147
+    lcw = g(cw)                                                      # :149
+    rcw = cw.gather(-1, idx + 1)[..., 0]                             # :150
+
+    if inverse:
+        b_ = (ib / ia) / 3.                                          # :154-156
+        c_ = (ic / ia) / 3.
+        d_ = (id_ - xin) / ia
+        delta_1 = -b_.pow(2) + c_                                    # :158-160
+        delta_2 = -c_ * b_ + d_
+        delta_3 = b_ * d_ - c_.pow(2)
+        disc = 4. * delta_1 * delta_3 - delta_2.pow(2)               # :162
+        dep1 = -2. * b_ * delta_1 + delta_2                          # :164-165
+        dep2 = delta_1
+        three = disc > 0                                             # :167-168
+        one = ~three
+        # Subsets are compacted as in the reference: torch's vectorised CPU kernels are not position-independent to
+        # the last bit, and the golden vectors pin this function bit for bit.
+        out = torch.zeros_like(xin)                                  # :170
+        sq = torch.sqrt(-disc[one])                                  # :174-175
+        pp = _cbrt((-dep1[one] + sq) / 2.)
+        qq = _cbrt((-dep1[one] - sq) / 2.)
+        out[one] = (pp + qq) - b_[one] + lcw[one]                    # :177-179
+        theta = torch.atan2(torch.sqrt(disc[three]), -dep1[three])   # :183-184
+        theta = theta / 3.
+        cr1, cr2 = torch.cos(theta), torch.sin(theta)                # :186-187
+        r1 = cr1                                                     # :189-191
+        r2 = -0.5 * cr1 - 0.5 * math.sqrt(3) * cr2
+        r3 = -0.5 * cr1 + 0.5 * math.sqrt(3) * cr2
+        scale = 2 * torch.sqrt(-dep2[three])                         # :193
+        shift = (-b_[three] + lcw[three])                            # :194
+        r1, r2, r3 = r1 * scale + shift, r2 * scale + shift, r3 * scale + shift        # :196-198
+        lo3, hi3 = lcw[three] - CUBIC_EPS, rcw[three] + CUBIC_EPS
+        k1, k2, k3 = (lo3 < r1) & (r1 < hi3), (lo3 < r2) & (r2 < hi3), (lo3 < r3) & (r3 < hi3)   # :200-207
+        # argsort(masks, descending)[..., 0] on CPU = the first root whose mask is 1, root 1 if none (:209-212)
+        out[three] = torch.where(k1, r1, torch.where(k2, r2, torch.where(k3, r3, r1)))
+        quad = ia.abs() < CUBIC_QUADRATIC_THRESHOLD                  # :216-222
+        qa, qb, qc = ib[quad], ic[quad], (id_[quad] - xin[quad])
+        alpha = (-qb + torch.sqrt(qb.pow(2) - 4 * qa * qc)) / (2 * qa)
+        out[quad] = alpha + lcw[quad]
+        sh_out = out - lcw                                           # :218
+        ljd = -torch.log(3 * ia * sh_out.pow(2) + 2 * ib * sh_out + ic)                 # :219-221
+        out = out * (right - left) + left                            # :235
+        ljd = ljd - math.log(top - bottom) + math.log(right - left)  # :236
+    else:
+        t = xin - lcw                                                # :223
+        out = ia * t.pow(3) + ib * t.pow(2) + ic * t + id_           # :224-227
+        ljd = torch.log(3 * ia * t.pow(2) + 2 * ib * t + ic)         # :229-231
+        out = out * (top - bottom) + bottom                          # :238
+        ljd = ljd + math.log(top - bottom) - math.log(right - left)  # :239
+    out_full[inside] = out                                           # :55
+    ljd_full[inside] = ljd
+    return out_full, ljd_full
+
+
 def rqs_from_layer(layer: Dict, x: Tensor, z: Optional[Tensor], reverse: bool) -> Tuple[Tensor, Tensor]:
     """Spline.forward_and_log_diag_jacobian, flows/spline.py:101-105."""
     D, K = x.shape[-1], layer['n_bins']
+    cubic = layer.get('spline_type', 'quadratic') == 'cubic'         # spline.py:56-61
     if layer.get('net') is not None:
-        uw, uh, ud = rqs_params_from_net(mlp_forward(layer['net'], z), D, K)
+        uw, uh, ud = (cubic_params_from_net if cubic else rqs_params_from_net)(mlp_forward(layer['net'], z), D, K)
     else:
         uw, uh, ud = layer['width'], layer['height'], layer['derivative']        # spline.py:78-79
+    if cubic:
+        return cubic_unconstrained(x, uw, uh, ud, reverse, layer.get('lower', 0), layer.get('upper', 1))
     return rqs_unconstrained(x, uw, uh, ud, reverse, layer.get('lower', 0), layer.get('upper', 1))
 
 

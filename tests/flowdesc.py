@@ -22,6 +22,11 @@ from typing import Dict, List
 import torch
 
 
+def _spline_params(d: Dict) -> int:
+    """parameters per element: 3K-1 (quadratic) or 2K+2 (cubic), flows/spline.py:56-61."""
+    return 2 * d['n_bins'] + 2 if d.get('spline_type', 'quadratic') == 'cubic' else 3 * d['n_bins'] - 1
+
+
 def build_transform(st, d: Dict):
     k = d['kind']
     if k == 'coupling_affine':
@@ -30,8 +35,9 @@ def build_transform(st, d: Dict):
         return st.Coupling(transform=st.Affine(dim, latent_net=net), mask=d['mask'])
     if k == 'coupling_rqs':
         dim, ld, K = d['dim'], d.get('latent_dim', 0), d['n_bins']
-        net = st.net.MLP(dim + ld, list(d['hidden']), dim * (3 * K - 1))
-        sp = st.Spline(dim, K, latent_net=net, lower=d['lower'], upper=d['upper'], spline_type='quadratic')
+        net = st.net.MLP(dim + ld, list(d['hidden']), dim * _spline_params(d))
+        sp = st.Spline(dim, K, latent_net=net, lower=d['lower'], upper=d['upper'],
+                       spline_type=d.get('spline_type', 'quadratic'))
         return st.Coupling(transform=sp, mask=d['mask'])
     if k == 'affine':
         return st.Affine(d['dim'])
@@ -39,9 +45,9 @@ def build_transform(st, d: Dict):
         return st.Affine(d['dim'], latent_net=st.net.MLP(d['latent_dim'], list(d['hidden']), 2 * d['dim']))
     if k == 'rqs':
         dim, ld, K = d['dim'], d.get('latent_dim', 0), d['n_bins']
-        net = st.net.MLP(ld, list(d['hidden']), dim * (3 * K - 1)) if ld else None
+        net = st.net.MLP(ld, list(d['hidden']), dim * _spline_params(d)) if ld else None
         return st.Spline(dim=dim, n_bins=K, latent_net=net, lower=d['lower'], upper=d['upper'],
-                         spline_type='quadratic')
+                         spline_type=d.get('spline_type', 'quadratic'))
     if k == 'affine_lu':
         return st.AffineLU(d['dim'])
     if k == 'matrix_exp':
@@ -75,13 +81,15 @@ def transform_spec(d: Dict, state: Dict[str, torch.Tensor], prefix: str) -> Dict
         return {'kind': k, 'mask': d['mask'], 'net': _net_spec(state, prefix + 'transform.latent_net.')}
     if k == 'coupling_rqs':
         return {'kind': k, 'mask': d['mask'], 'net': _net_spec(state, prefix + 'transform.latent_net.'),
-                'n_bins': d['n_bins'], 'lower': d['lower'], 'upper': d['upper']}
+                'n_bins': d['n_bins'], 'lower': d['lower'], 'upper': d['upper'],
+                'spline_type': d.get('spline_type', 'quadratic')}
     if k == 'affine':
         return {'kind': 'affine', 'log_scale': state[prefix + 'log_scale'], 'shift': state[prefix + 'shift']}
     if k == 'affine_latent':
         return {'kind': 'affine', 'net': _net_spec(state, prefix + 'latent_net.')}
     if k == 'rqs':
-        s = {'kind': 'rqs', 'n_bins': d['n_bins'], 'lower': d['lower'], 'upper': d['upper']}
+        s = {'kind': 'rqs', 'n_bins': d['n_bins'], 'lower': d['lower'], 'upper': d['upper'],
+             'spline_type': d.get('spline_type', 'quadratic')}
         if d.get('latent_dim', 0):
             s['net'] = _net_spec(state, prefix + 'latent_net.')
         else:

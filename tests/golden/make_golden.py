@@ -12,7 +12,7 @@ reference files untouched.  Bytecode writing is disabled so nothing lands in the
 Fixtures:  F1 doc known-answer, F2 masks, F3 cfg 1, F4 cfg 2 (N=256, + bf16
 rounded inputs), F5 cfg 3 (RQ-spline couplings, N=128, incl. tails / on-bound / on-knot rows),
 F6 cfg 4 (AffineLU + MatrixExponential + couplings), F7 Permute/Flip, F8 the reference test-suite
-shapes with autograd log|det J|.
+shapes with autograd log|det J|, F9 cubic splines (suite shapes + a D=64 coupling flow).
 """
 import json
 import os
@@ -365,9 +365,48 @@ def f8_suite():
     save('f8_suite', arrays, meta)
 
 
+# ------------------------------------------------------------------------------------------ F9
+def f9_cubic():
+    """Cubic splines (the reference's default spline_type): test_spline.py:8-33 cubic rows, cubic couplings on the
+    suite shapes, and a two-layer D=64, K=16 coupling flow with tail / on-bound rows (as F5)."""
+    arrays, meta = {}, {}
+    for shp in SHAPES:
+        dim = shp[-1]
+        tag = 'x'.join(map(str, shp))
+        for K in (1, 3, 10):
+            for ld in (0, 1, 13):
+                np.random.seed(123)
+                torch.manual_seed(123)
+                x = torch.rand(*shp) * 2
+                latent = torch.randn(*shp[:-1], ld) if ld else None
+                d = {'kind': 'rqs', 'dim': dim, 'n_bins': K, 'lower': 0, 'upper': 2, 'hidden': [12], 'latent_dim': ld,
+                     'spline_type': 'cubic'}
+                suite_case(f'cubic/{tag}/k{K}/l{ld}', d, dim, x, arrays, meta, latent=latent)
+        for K in (3, 10):
+            torch.manual_seed(123)
+            x = torch.rand(*shp) * 2.4 - 0.2          # some elements in the linear tails
+            d = {'kind': 'coupling_rqs', 'dim': dim, 'hidden': [12], 'mask': 'ordered_right_half', 'latent_dim': 0,
+                 'n_bins': K, 'lower': 0, 'upper': 2, 'spline_type': 'cubic'}
+            suite_case(f'coupling_cubic/{tag}/k{K}', d, dim, x, arrays, meta)
+    desc = [dict(d, spline_type='cubic') for d in fd.cfg3_desc(n_layers=2)]
+    torch.manual_seed(1009)
+    x = torch.randn(128, 64)
+    x[0, :] = 3.0
+    x[1, :] = -3.0
+    x[2, :] = 3.5
+    x[3, :] = -7.0
+    x[4, ::2] = 3.0000002
+    x[5, :] = 0.0
+    x[6, :] = torch.linspace(-3, 3, 64)
+    x[7, :] = torch.linspace(-2.999999, 2.999999, 64)
+    flow_case('cubic_flow', desc, 64, 0, x, arrays)
+    meta['cubic_flow'] = {'desc': desc, 'dim': 64, 'seed': 0}
+    save('f9_cubic', arrays, meta)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8']
+    which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9']
     table = {'f1': f1_doc_example, 'f2': f2_masks, 'f3': f3_cfg1, 'f4': f4_cfg2, 'f5': f5_cfg3,
-             'f6': f6_cfg4, 'f7': f7_permute, 'f8': f8_suite}
+             'f6': f6_cfg4, 'f7': f7_permute, 'f8': f8_suite, 'f9': f9_cubic}
     for w in which:
         table[w]()

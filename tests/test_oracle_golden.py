@@ -41,7 +41,7 @@ def test_f2_masks_exact():
 
 
 @pytest.mark.parametrize('fixture,case', [('f3_cfg1', 'cfg1'), ('f4_cfg2', 'cfg2'), ('f5_cfg3', 'cfg3'),
-                                          ('f6_cfg4', 'cfg4'), ('f7_permute', 'mixed')])
+                                          ('f6_cfg4', 'cfg4'), ('f7_permute', 'mixed'), ('f9_cubic', 'cubic_flow')])
 def test_flow_fixtures(fixture, case):
     g = Golden(fixture)
     m = g.meta[case]
@@ -126,3 +126,30 @@ def test_f8_suite_shapes():
         assert torch.allclose(l2.reshape(-1), g.t(case + '/autograd_logdet_inv'), atol=1e-4), case
         n += 1
     assert n == 112
+
+
+def test_f9_cubic_suite_shapes():
+    """Cubic splines (spline_type='cubic', the reference default; stribor/test/test_spline.py:8-33 cubic rows and
+    cubic couplings) on values captured from the reference: the oracle reproduces them bit for bit."""
+    g = Golden('f9_cubic')
+    n = 0
+    for case, m in g.meta.items():
+        if case == 'cubic_flow':
+            continue
+        d = m['desc'][0]
+        spec = fd.transform_spec(d, g.state(case), 'transforms.0.')
+        x = g.t(case + '/x')
+        latent = g.t(case + '/latent') if g.has(case + '/latent') else None
+        y = orc.transform_apply(spec, x, False, latent)
+        assert torch.equal(y, g.t(case + '/y')), case
+        xb = orc.transform_apply(spec, y, True, latent)
+        assert torch.equal(xb, g.t(case + '/x_back')), case
+        assert torch.allclose(xb, x, atol=1e-4), case                         # base.py:8-11
+        ldj = orc.transform_ldj(spec, x, latent)
+        assert torch.equal(ldj, g.t(case + '/ldj')), case
+        _, l2 = orc.transform_inverse_and_ldj(spec, y, latent)
+        assert torch.equal(l2, g.t(case + '/ldj_inv')), case
+        assert torch.allclose(ldj, -l2, atol=1e-4), case                      # base.py:21-22
+        assert torch.allclose(ldj.reshape(-1), g.t(case + '/autograd_logdet'), atol=1e-4), case
+        n += 1
+    assert n == 4 * (9 + 2)
