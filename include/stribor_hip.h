@@ -104,6 +104,17 @@ int sx_rqs_coupling(const void *x, void *y, float *ldj, float *ldiag, const floa
                     int32_t dtype, int32_t reverse, int32_t ldj_accumulate, float ldj_scale,
                     uint32_t *err_flag, void *stream);
 
+/* Monotone cubic spline, element-wise part -- spline_type='cubic', the reference's default
+ * (stribor/util/cubic_spline.py:21-251, util/search_sorted.py:3-5, flows/spline.py:59-61,82-86).
+ *   params[n, i*(2K+2) + 0:K]      unnormalised widths  of live dim i
+ *   params[n, i*(2K+2) + K:2K]     unnormalised heights
+ *   params[n, i*(2K+2) + 2K:2K+2]  unnormalised boundary derivatives (left, right)   (K = n_bins)
+ *   domain = codomain = [lower, upper]; outside it: y = x, ljd = 0.  ldiag / ldj / reverse as in sx_rqs_coupling. */
+int sx_cubic_coupling(const void *x, void *y, float *ldj, float *ldiag, const float *params,
+                      int64_t params_stride, const int32_t *live_idx, int32_t live_start, int32_t n_live, int32_t n_bins,
+                      float lower, float upper, int64_t n_rows, int32_t dim, int32_t dtype, int32_t reverse,
+                      int32_t ldj_accumulate, float ldj_scale, void *stream);
+
 /* UnitNormal.log_prob + log-det accumulator (stribor/dist/normal.py:37,52-54; flow.py:128-129):
  *   out[n] = sum_d( -x[n,d]^2/2 ) - dim*log(sqrt(2*pi)) + (ldj ? ldj[n] : 0) */
 int sx_unit_normal_logprob(const void *x, const float *ldj, float *out, int64_t n_rows, int32_t dim,

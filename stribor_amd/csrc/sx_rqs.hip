@@ -383,3 +383,234 @@ extern "C" int sx_rqs_coupling(const void *x, void *y, float *ldj, float *ldiag,
     SX_LAUNCH_CHECK();
     return SX_OK;
 }
+
+// =====================================================================================================
+// Monotone cubic spline (spline_type='cubic', the reference's default), element-wise kernel.
+//
+// Replaces unconstrained_cubic_spline + cubic_spline (stribor/util/cubic_spline.py:21-251) and searchsorted:
+// 2 softmax, 2 cumsum, pads, the Steffen-style knot derivatives (:117-132), the per-bin cubic coefficients
+// (:134-137), the bin search, 6 gathers and the forward polynomial / inverse cubic solve (one-root Cardano form,
+// three-root trigonometric form with the in-bin root picked, quadratic fallback for |a| < 1e-3) become one pass:
+// one lane = one (row, live column) element.  Same CDNA4 mapping as rqs_kernel: the wave's 64 elements own one
+// contiguous span of 64*(2K+2) parameter floats, copied coalesced into the wave's LDS slice; each lane's slice is
+// padded to an odd stride (2K+3 dwords) so the 32 lanes of a ds_read_b32 group hit 32 banks, and the lane
+// overwrites its un-normalised widths / heights with the normalised ones in place.
+// =====================================================================================================
+#define CUBIC_MIN_BIN 1e-2f          // cubic_spline.py:13-14
+#define CUBIC_EPS 1e-5f              // :15
+#define CUBIC_QUAD_THRESHOLD 1e-3f   // :16
+
+__device__ __forceinline__ float cubic_cbrt(float v) {        // :18-20  sign(x) * exp(log|x| / 3)
+    const float s = (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f);
+    return s * expf(logf(fabsf(v)) / 3.0f);
+}
+__device__ __forceinline__ float cubic_sigmoid(float v) { return 1.f / (1.f + expf(-v)); }
+
+template <bool BF16, bool INVERSE>
+__global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, void *__restrict__ y,
+                                                    float *__restrict__ ldj, float *__restrict__ ldiag,
+                                                    const float *__restrict__ params, int64_t pstride,
+                                                    const int32_t *__restrict__ live_idx, int l0, int n_live, int K,
+                                                    float lower, float upper, float log_span, int64_t n_rows, int dim,
+                                                    int ldj_mode /*0 none, 1 direct (group), 2 atomic*/, int ldj_acc,
+                                                    float ldj_scale) {
+    const int P = 2 * K + 2, PS = P | 1;                         // padded (odd) per-lane stride
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int waves_per_block = blockDim.x >> 6;
+    float *sp = rqs_smem + (size_t)wave * 64 * PS;
+    const int64_t n_elem = n_rows * n_live;
+    const int64_t n_groups = (n_elem + 63) >> 6;
+    const float norm = 1.f - CUBIC_MIN_BIN * (float)K;          // :104, :111
+    const float span = upper - lower;                            // right - left = top - bottom
+    const bool contig = pstride == (int64_t)n_live * P;
+
+    for (int64_t grp = (int64_t)blockIdx.x * waves_per_block + wave; grp < n_groups;
+         grp += (int64_t)gridDim.x * waves_per_block) {
+        const int64_t e0 = grp << 6;
+        const int n_here = (int)((n_elem - e0) < 64 ? (n_elem - e0) : 64);
+        const int total = n_here * P;
+        // ---- stage: consecutive idx -> consecutive HBM addresses (one contiguous span when rows are packed) ----
+        for (int idx = lane; idx < total; idx += 64) {
+            const int el = idx / P, q = idx - el * P;
+            float v;
+            if (contig) v = params[e0 * P + idx];
+            else {
+                const int64_t e = e0 + el;
+                const int64_t row = e / n_live;
+                v = params[row * pstride + (int64_t)(e - row * n_live) * P + q];
+            }
+            sp[el * PS + q] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        const int64_t e = e0 + lane;
+        const bool valid = e < n_elem;
+        const int64_t row = valid ? e / n_live : 0;
+        const int i = valid ? (int)(e - row * n_live) : 0;
+        const int col = live_idx ? live_idx[i] : l0 + i;
+        const float xv = valid ? rqs_load<BF16>(x, row * dim + col) : lower;
+        const bool inside = (xv >= lower) && (xv <= upper);      // :40 closed interval
+        const float xin = ((inside ? xv : lower) - lower) / span;            // :98-101
+        float *p = sp + (valid ? lane : 0) * PS;                 // [0,K) widths, [K,2K) heights, 2K / 2K+1 derivatives
+
+        // ---- softmax normalisers (F.softmax: exp(u - max) / sum), :103, :110 -----------------------------
+        float mw = p[0], mh = p[K];
+        for (int k = 1; k < K; ++k) { mw = fmaxf(mw, p[k]); mh = fmaxf(mh, p[K + k]); }
+        float sw = 0.f, sh = 0.f;
+        for (int k = 0; k < K; ++k) { sw += expf(p[k] - mw); sh += expf(p[K + k] - mh); }
+        // ---- widths / heights in place, running cumsums (:106, :113), bin search (search_sorted.py:4-5) -------
+        int b = 0;
+        float cw = 0.f, ch = 0.f, cw_b = 0.f, ch_b = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float wk = CUBIC_MIN_BIN + norm * (expf(p[k] - mw) / sw);
+            const float hk = CUBIC_MIN_BIN + norm * (expf(p[K + k] - mh) / sh);
+            p[k] = wk;
+            p[K + k] = hk;
+            if (xin >= (INVERSE ? ch : cw)) { b = k; cw_b = cw; ch_b = ch; }  // lower knot of bin k (knot 0 = 0)
+            cw += wk;
+            ch += hk;
+        }
+        // ---- knot derivatives of bin b (:117-132) and its cubic (:134-137) -----------------------------------
+        const float w_b = p[b], h_b = p[K + b];
+        const float s_b = h_b / w_b;                                                       // :117
+        const float rcw = (b == K - 1) ? 1.f : cw_b + w_b;                                 // :107 (last knot pinned)
+        float dL, dR;
+        if (b == 0) dL = cubic_sigmoid(p[2 * K]) * 3.f * s_b;                              // :126
+        else {
+            const float w_m = p[b - 1], s_m = p[K + b - 1] / w_m;
+            const float m1 = fminf(fabsf(s_m), fabsf(s_b));                               // :118-119
+            const float m2 = 0.5f * (w_b * s_m + w_m * s_b) / (w_m + w_b);                 // :120-123
+            const float sg = ((s_m > 0.f) ? 1.f : ((s_m < 0.f) ? -1.f : 0.f)) + ((s_b > 0.f) ? 1.f : ((s_b < 0.f) ? -1.f : 0.f));
+            dL = fminf(m1, m2) * sg;                                                       // :124, :129
+        }
+        if (b == K - 1) dR = cubic_sigmoid(p[2 * K + 1]) * 3.f * s_b;                      // :127
+        else {
+            const float w_p = p[b + 1], s_p = p[K + b + 1] / w_p;
+            const float m1 = fminf(fabsf(s_b), fabsf(s_p));
+            const float m2 = 0.5f * (w_p * s_b + w_b * s_p) / (w_b + w_p);
+            const float sg = ((s_b > 0.f) ? 1.f : ((s_b < 0.f) ? -1.f : 0.f)) + ((s_p > 0.f) ? 1.f : ((s_p < 0.f) ? -1.f : 0.f));
+            dR = fminf(m1, m2) * sg;
+        }
+        const float a = (dL + dR - 2.f * s_b) / (w_b * w_b);                               // :134
+        const float bb = (3.f * s_b - 2.f * dL - dR) / w_b;                                // :135
+        const float c = dL;                                                                // :136
+        const float d = ch_b;                                                              // :137
+
+        float out, ljd;
+        if constexpr (INVERSE) {
+            const float b_ = (bb / a) / 3.f;                                               // :154-156
+            const float c_ = (c / a) / 3.f;
+            const float d_ = (d - xin) / a;
+            const float delta_1 = -(b_ * b_) + c_;                                         // :158-160
+            const float delta_2 = -c_ * b_ + d_;
+            const float delta_3 = b_ * d_ - c_ * c_;
+            const float disc = 4.f * delta_1 * delta_3 - delta_2 * delta_2;                // :162
+            const float dep1 = -2.f * b_ * delta_1 + delta_2;                              // :164
+            const bool three = disc > 0.f;                                                 // :167
+            // one root (:174-179)
+            const float sq = sqrtf(three ? 0.f : -disc);
+            const float one_root = (cubic_cbrt((-dep1 + sq) / 2.f) + cubic_cbrt((-dep1 - sq) / 2.f)) - b_ + cw_b;
+            // three roots (:183-212): the first (order 1, 2, 3) that lies in the bin, root 1 if none does
+            const float theta = atan2f(sqrtf(three ? disc : 0.f), -dep1) / 3.f;
+            const float cr1 = cosf(theta), cr2 = sinf(theta);
+            const float scale = 2.f * sqrtf(three ? -delta_1 : 0.f), shift = -b_ + cw_b;
+            const float r1 = cr1 * scale + shift;
+            const float r2 = (-0.5f * cr1 - 0.5f * 1.7320508075688772f * cr2) * scale + shift;
+            const float r3 = (-0.5f * cr1 + 0.5f * 1.7320508075688772f * cr2) * scale + shift;
+            const float lo3 = cw_b - CUBIC_EPS, hi3 = rcw + CUBIC_EPS;
+            const bool k1 = (lo3 < r1) && (r1 < hi3), k2 = (lo3 < r2) && (r2 < hi3), k3 = (lo3 < r3) && (r3 < hi3);
+            const float pick = k1 ? r1 : (k2 ? r2 : (k3 ? r3 : r1));
+            float o = three ? pick : one_root;
+            // a -> 0 (:216-222)
+            if (fabsf(a) < CUBIC_QUAD_THRESHOLD) {
+                const float qc = d - xin;
+                o = (-c + sqrtf(c * c - 4.f * bb * qc)) / (2.f * bb) + cw_b;
+            }
+            const float so = o - cw_b;                                                     // :224
+            ljd = -logf(3.f * a * (so * so) + 2.f * bb * so + c);                          // :225-227
+            out = o * span + lower;                                                        // :235
+            ljd = (ljd - log_span) + log_span;                                             // :236 (two fp32 roundings there)
+        } else {
+            const float t = xin - cw_b;                                                    // :229
+            out = a * (t * t * t) + bb * (t * t) + c * t + d;                              // :230-233
+            ljd = logf(3.f * a * (t * t) + 2.f * bb * t + c);                              // :235-237
+            out = out * span + lower;                                                      // :238
+            ljd = (ljd + log_span) - log_span;                                             // :239
+        }
+        if (!inside) { out = xv; ljd = 0.f; }                                              // :46-48 linear tails
+        if (valid) {
+            rqs_store<BF16>(y, row * dim + col, out);
+            if (ldiag) ldiag[row * dim + col] = ljd;
+        }
+        if (ldj_mode == 1) {
+            float s = valid ? ljd : 0.f;
+            s = group_sum_rt(s, n_live);
+            if (valid && (lane & (n_live - 1)) == 0) ldj[row] = (ldj_acc ? ldj[row] : 0.f) + ldj_scale * s;
+        } else if (ldj_mode == 2) {
+            if (valid) atomicAdd(&ldj[row], ldj_scale * ljd);
+        }
+    }
+}
+
+extern "C" int sx_cubic_coupling(const void *x, void *y, float *ldj, float *ldiag, const float *params,
+                                 int64_t params_stride, const int32_t *live_idx, int32_t live_start, int32_t n_live,
+                                 int32_t n_bins, float lower, float upper, int64_t n_rows, int32_t dim, int32_t dtype,
+                                 int32_t reverse, int32_t ldj_accumulate, float ldj_scale, void *stream) {
+    SX_REQUIRE(x && y && params, "sx_cubic_coupling: null pointer");
+    SX_REQUIRE(dim > 0 && n_live >= 0 && n_live <= dim && n_rows >= 0, "sx_cubic_coupling: bad sizes");
+    SX_REQUIRE(n_bins >= 1, "sx_cubic_coupling: n_bins must be >= 1");
+    SX_REQUIRE(dtype == SX_F32 || dtype == SX_BF16, "sx_cubic_coupling: bad dtype");
+    SX_REQUIRE(1e-2 * n_bins <= 1.0, "Minimal bin width too large for the number of bins");       // cubic_spline.py:93-96
+    SX_REQUIRE(upper > lower, "sx_cubic_coupling: empty domain");
+    if (n_rows == 0) return SX_OK;
+    hipStream_t st = sx_stream(stream);
+    const float log_span = (float)log((double)upper - (double)lower);      // math.log(top - bottom), cast as torch does
+    const int PS = (2 * n_bins + 2) | 1;
+    int block = 256;
+    size_t lds = (size_t)(block / 64) * 64 * PS * sizeof(float);
+    if (lds > 64 * 1024) { block = 64; lds = (size_t)64 * PS * sizeof(float); }
+    SX_REQUIRE(lds <= 160 * 1024, "sx_cubic_coupling: n_bins %d needs %zu B of LDS per wave", n_bins, lds);
+    if (n_live < dim && (x != y || ldiag)) {            // pass-through columns (and their zero log-diag entries)
+        int64_t g = (n_rows * dim + 255) / 256;
+        if (g > 2048) g = 2048;
+        if (dtype == SX_BF16)
+            hipLaunchKernelGGL(rqs_copy_passthrough_kernel<true>, dim3((int)g), dim3(256), dim * sizeof(int), st, x, y,
+                               ldiag, live_idx, live_start, n_live, n_rows, dim, x != y);
+        else
+            hipLaunchKernelGGL(rqs_copy_passthrough_kernel<false>, dim3((int)g), dim3(256), dim * sizeof(int), st, x, y,
+                               ldiag, live_idx, live_start, n_live, n_rows, dim, x != y);
+        SX_LAUNCH_CHECK();
+    }
+    int ldj_mode = 0;
+    if (ldj) {
+        ldj_mode = (n_live > 0 && rqs_pow2(n_live) && n_live <= 64) ? 1 : 2;
+        if ((ldj_mode == 2 || n_live == 0) && !ldj_accumulate) {
+            hipError_t e = hipMemsetAsync(ldj, 0, n_rows * sizeof(float), st);
+            if (e != hipSuccess) { sx_set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+        }
+    }
+    if (n_live == 0) return SX_OK;
+    const int64_t n_groups = (n_rows * n_live + 63) / 64;
+    const int wpb = block / 64;
+    int64_t grid = (n_groups + wpb - 1) / wpb;
+    const int64_t per_cu = (160 * 1024) / (int64_t)lds > 8 ? 8 : (160 * 1024) / (int64_t)lds;
+    if (grid > 256 * per_cu) grid = 256 * per_cu;
+    if (grid < 1) grid = 1;
+    if (lds > 48 * 1024) {
+#define SX_ATTR(BF, INV)                                                                                          \
+    (void)hipFuncSetAttribute((const void *)cubic_kernel<BF, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+        SX_ATTR(true, true); SX_ATTR(true, false); SX_ATTR(false, true); SX_ATTR(false, false);
+#undef SX_ATTR
+    }
+#define SX_CB(BF, INV)                                                                                            \
+    hipLaunchKernelGGL((cubic_kernel<BF, INV>), dim3((int)grid), dim3(block), lds, st, x, y, ldj, ldiag, params,  \
+                       params_stride, live_idx, live_start, n_live, n_bins, lower, upper, log_span, n_rows, dim,   \
+                       ldj_mode,                                                                                  \
+                       ldj_accumulate, ldj_scale)
+    if (dtype == SX_BF16) { if (reverse) SX_CB(true, true); else SX_CB(true, false); }
+    else { if (reverse) SX_CB(false, true); else SX_CB(false, false); }
+#undef SX_CB
+    SX_LAUNCH_CHECK();
+    return SX_OK;
+}

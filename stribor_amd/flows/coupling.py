@@ -119,7 +119,7 @@ class Coupling(Transform):
 
     # ---- spline: pruned conditioner (MFMA) + LDS-staged spline kernel --------------------------------------
     def _spline_program(self, dim: int, latent_dim: int, device):
-        key = ('rqs', dim, latent_dim, str(device))
+        key = ('spline', dim, latent_dim, str(device))
         if key not in self._programs:
             net, sp = self._net(), self.transform
             m = self.mask_vector(dim)
@@ -127,7 +127,7 @@ class Coupling(Transform):
             cond = m > 0.5
             if dim == 1:
                 cond = np.zeros(1, dtype=bool)                                       # coupling.py:62-63
-            P = 3 * sp.n_bins - 1
+            P = sp.params_per_element                                                # 3K-1 quadratic, 2K+2 cubic
             out_rows = (live[:, None] * P + np.arange(P)[None, :]).reshape(-1)       # spline.py:82-86, pruned
             b = ProgramBuilder(dim, latent_dim, net.hidden_width)
             b.add_mlp(net.linears(), net.act_code, cond, out_rows)
@@ -148,8 +148,16 @@ class Coupling(Transform):
         params = torch.empty(n, width, dtype=torch.float32, device=x2.device)
         for p in progs:
             p.run(x2, lat2, mlp_out=params)
-        y, ldj, _ = run_rqs_kernel(x2, params, params.stride(0), live_idx, live_start, n_live, sp.n_bins,
-                                   sp.lower, sp.upper, sp.lower, sp.upper, reverse, want_ldj, False, ldj_scale)
+        if sp.spline_type == 'cubic':
+            from .spline import run_cubic_kernel
+            # one pass: the inverse kernel returns its own (already negated) log-derivative, like the quadratic path.
+            # (The reference evaluates MINUS the FORWARD log-det at the inverted point, flow.py:42-47; the two differ
+            # only for elements within an ulp of the domain boundary, where the log-derivative jumps to the tails' 0.)
+            y, ldj, _ = run_cubic_kernel(x2, params, params.stride(0), live_idx, live_start, n_live, sp.n_bins,
+                                         sp.lower, sp.upper, reverse, want_ldj, False, ldj_scale)
+        else:
+            y, ldj, _ = run_rqs_kernel(x2, params, params.stride(0), live_idx, live_start, n_live, sp.n_bins,
+                                       sp.lower, sp.upper, sp.lower, sp.upper, reverse, want_ldj, False, ldj_scale)
         return y, ldj
 
     # ---- reference method set (coupling.py:69-95) -----------------------------------------------------------
@@ -179,8 +187,8 @@ class Coupling(Transform):
     def _plan_spline(self, builder: ProgramBuilder, reverse: bool, ldj_scale: float) -> bool:
         sp = self.transform
         net = getattr(sp, 'latent_net', None)
-        if not isinstance(net, MLP) or net.activation_name != 'Tanh' or sp.n_bins > 16:
-            return False
+        if not isinstance(net, MLP) or net.activation_name != 'Tanh' or sp.n_bins > 16 or sp.spline_type != 'quadratic':
+            return False             # cubic-spline couplings run layer by layer (MLP program + sx_cubic_coupling)
         lin = net.linears()
         if len(lin) != 2:
             return False

@@ -1,9 +1,10 @@
-"""Rational-quadratic spline flow (reference: stribor/flows/spline.py:11-143 with
-``spline_type='quadratic'`` -> stribor/util/rational_quadratic_spline.py).
+"""Spline flows (reference: stribor/flows/spline.py:11-143): ``spline_type='quadratic'`` ->
+stribor/util/rational_quadratic_spline.py, ``spline_type='cubic'`` (the reference default) ->
+stribor/util/cubic_spline.py.
 
-Same constructor as the reference.  ``spline_type='cubic'`` (the reference default, quirk Q10) is not on
-the path named by BASELINE.json and raises.  The arithmetic runs in ``sx_rqs_coupling``: one lane per
-element, the element's 3K-1 parameters staged through the wave's own LDS slice, tails predicated.
+Same constructor as the reference.  The arithmetic runs in ``sx_rqs_coupling`` / ``sx_cubic_coupling``: one lane
+per element, the element's 3K-1 (2K+2) parameters staged through the wave's own LDS slice, tails predicated.
+Quadratic-spline couplings also join fused flow programs; cubic ones run layer by layer (MLP program + this kernel).
 
 Error behaviour: the reference raises ``ValueError('Minimal bin width too large ...')`` when
 ``1e-3 * n_bins > 1`` (rational_quadratic_spline.py:96-99) — same here, from Python, before launch.
@@ -17,7 +18,7 @@ import torch.nn as nn
 from .. import _hip
 from ..flow import ElementwiseTransform, flatten_rows
 
-__all__ = ['Spline', 'run_rqs_kernel']
+__all__ = ['Spline', 'run_rqs_kernel', 'run_cubic_kernel']
 
 _err_flags = {}
 
@@ -59,6 +60,23 @@ def run_rqs_kernel(x2, params, params_stride, live_idx, live_start, n_live, n_bi
     return y, ldj, ldiag
 
 
+def run_cubic_kernel(x2, params, params_stride, live_idx, live_start, n_live, n_bins, lower, upper, reverse, want_ldj,
+                     want_ldiag, ldj_scale=1.0):
+    """Launch sx_cubic_coupling on [N, D] rows -> (y, ldj | None, ldiag | None)."""
+    if 1e-2 * n_bins > 1.0:
+        raise ValueError('Minimal bin width too large for the number of bins')      # cubic_spline.py:93-94
+    n, d = x2.shape
+    y = torch.empty_like(x2)
+    ldj = torch.empty(n, dtype=torch.float32, device=x2.device) if want_ldj else None
+    ldiag = torch.empty(n, d, dtype=torch.float32, device=x2.device) if want_ldiag else None
+    rc = _hip.lib().sx_cubic_coupling(x2.data_ptr(), y.data_ptr(), _hip.ptr(ldj), _hip.ptr(ldiag), params.data_ptr(),
+                                      params_stride, _hip.ptr(live_idx), live_start, n_live, n_bins, float(lower),
+                                      float(upper), n, d, _hip.dtype_code(x2), int(reverse), 0, float(ldj_scale),
+                                      _hip.stream())
+    _hip.check(rc, 'sx_cubic_coupling')
+    return y, ldj, ldiag
+
+
 class Spline(ElementwiseTransform):
     def __init__(self, dim: int, n_bins: int, latent_net: Optional[nn.Module] = None, lower: Optional[float] = 0,
                  upper: Optional[float] = 1, spline_type: Optional[str] = 'cubic', **kwargs):
@@ -66,11 +84,11 @@ class Spline(ElementwiseTransform):
         self.lower, self.upper = lower, upper
         self.dim, self.n_bins = dim, n_bins
         self.latent_net = latent_net
+        self.spline_type = spline_type
         if spline_type == 'quadratic':
             self.derivative_dim = n_bins - 1                                         # spline.py:56-57
         elif spline_type == 'cubic':
-            raise NotImplementedError("stribor_amd.Spline: spline_type='cubic' is outside the rational-quadratic "
-                                      "hot path named by BASELINE.json; pass spline_type='quadratic'")
+            self.derivative_dim = 2                                                  # spline.py:59-61
         else:
             raise ValueError('spline_type must be either `quadratic` or `cubic`')    # spline.py:63
         if latent_net is None:
@@ -92,6 +110,10 @@ class Spline(ElementwiseTransform):
         p = self.latent_net(latent.reshape(-1, latent.shape[-1]))
         return p, p.stride(0)
 
+    @property
+    def params_per_element(self) -> int:
+        return 2 * self.n_bins + self.derivative_dim                                 # spline.py:83
+
     def _bounds(self):
         return self.lower, self.upper, self.lower, self.upper                        # left, right, bottom, top
 
@@ -101,8 +123,12 @@ class Spline(ElementwiseTransform):
         d = x2.shape[1]
         params, stride = self._params(x2, latent)
         l, r, b, t = self._bounds()
-        y, ldj, ldiag = run_rqs_kernel(x2, params, stride, None, 0, d, self.n_bins, l, r, b, t, reverse, want_ldj,
-                                       want_ldiag, ldj_scale)
+        if self.spline_type == 'cubic':
+            y, ldj, ldiag = run_cubic_kernel(x2, params, stride, None, 0, d, self.n_bins, self.lower, self.upper, reverse,
+                                             want_ldj, want_ldiag, ldj_scale)
+        else:
+            y, ldj, ldiag = run_rqs_kernel(x2, params, stride, None, 0, d, self.n_bins, l, r, b, t, reverse, want_ldj,
+                                           want_ldiag, ldj_scale)
         return (y.reshape(*lead, d), None if ldj is None else ldj.reshape(*lead, 1),
                 None if ldiag is None else ldiag.reshape(*lead, d))
 

@@ -75,8 +75,8 @@ def test_constructor_surface():
         st.Affine(2, st.net.MLP(2, [4], 4))                       # latent_net is keyword-only (affine.py:31-35)
     with pytest.raises(ValueError):
         st.Spline(2, 3, spline_type='linear')                     # spline.py:63
-    with pytest.raises(NotImplementedError):
-        st.Spline(2, 3)                                           # default 'cubic' is out of scope
+    spc = st.Spline(2, 3)                                         # default spline_type is 'cubic' (spline.py:46)
+    assert spc.spline_type == 'cubic' and spc.derivative.shape == (2, 2) and spc.params_per_element == 8
     with pytest.raises(AssertionError):
         st.Affine(2, scale=torch.tensor([1.0, -1.0]), shift=torch.zeros(2))    # affine.py:55
     mlp = st.net.MLP(3, [5, 7], 4)
