@@ -115,6 +115,24 @@ int sx_cubic_coupling(const void *x, void *y, float *ldj, float *ldiag, const fl
                       float lower, float upper, int64_t n_rows, int32_t dim, int32_t dtype, int32_t reverse,
                       int32_t ldj_accumulate, float ldj_scale, void *stream);
 
+/* Parameter-free element-wise flows: Sigmoid / Logit (stribor/flows/sigmoid.py:9-56), ELU / LeakyReLU
+ * (flows/activations.py:11-101), Cumsum / Diff over the last axis (flows/cumsum.py:9-92).
+ *   y (nullable for the element kinds): transformed values;  ldiag (nullable, [n_rows, dim]): per-element log-derivative;
+ *   ldj (nullable, [n_rows]): its row sum, ldj[n] = (ldj_accumulate ? ldj[n] : 0) + sum_d ldiag[n, d].
+ *   Forward kinds return the forward log-derivative at x; the *_INV kinds and LOGIT return what
+ *   Transform.inverse_and_log_det_jacobian does (flow.py:42-47): minus the forward log-derivative at the value produced.
+ *   param: LeakyReLU's negative_slope (SX_PW_LEAKY_RELU) or its reciprocal (SX_PW_LEAKY_RELU_INV); ignored otherwise. */
+#define SX_PW_SIGMOID 1
+#define SX_PW_LOGIT 2
+#define SX_PW_ELU 3
+#define SX_PW_ELU_INV 4
+#define SX_PW_LEAKY_RELU 5
+#define SX_PW_LEAKY_RELU_INV 6
+#define SX_PW_CUMSUM 7
+#define SX_PW_DIFF 8
+int sx_pointwise(const void *x, void *y, float *ldj, float *ldiag, int64_t n_rows, int32_t dim, int32_t dtype,
+                 int32_t kind, float param, int32_t ldj_accumulate, void *stream);
+
 /* UnitNormal.log_prob + log-det accumulator (stribor/dist/normal.py:37,52-54; flow.py:128-129):
  *   out[n] = sum_d( -x[n,d]^2/2 ) - dim*log(sqrt(2*pi)) + (ldj ? ldj[n] : 0) */
 int sx_unit_normal_logprob(const void *x, const float *ldj, float *out, int64_t n_rows, int32_t dim,

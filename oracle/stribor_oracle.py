@@ -384,6 +384,67 @@ def rqs_from_layer(layer: Dict, x: Tensor, z: Optional[Tensor], reverse: bool) -
 
 
 # ----------------------------------------------------------------------------------------------
+# parameter-free element-wise flows       flows/sigmoid.py, flows/activations.py:11-101, flows/cumsum.py:9-92
+#   {'kind': 'sigmoid' | 'logit' | 'elu' | 'leaky_relu' (+ 'negative_slope') | 'cumsum' | 'diff' | 'identity'}
+# ----------------------------------------------------------------------------------------------
+POINTWISE = ('sigmoid', 'logit', 'elu', 'leaky_relu', 'cumsum', 'diff', 'identity')
+
+
+def _sigmoid_fwd(x: Tensor) -> Tensor:
+    finfo = torch.finfo(x.dtype)
+    return torch.clamp(torch.sigmoid(x), min=finfo.tiny, max=1. - finfo.eps)      # sigmoid.py:21-23
+
+
+def _sigmoid_inv(y: Tensor) -> Tensor:
+    finfo = torch.finfo(y.dtype)
+    y = y.clamp(min=finfo.tiny, max=1.0 - finfo.eps)                # sigmoid.py:28-30
+    return y.log() - (-y).log1p()
+
+
+def _leaky(x: Tensor, slope: float) -> Tensor:
+    zeros = torch.zeros_like(x)
+    return torch.max(zeros, x) + slope * torch.min(zeros, x)         # activations.py:84-86
+
+
+def pointwise_apply(layer: Dict, x: Tensor, reverse: bool) -> Tensor:
+    kind = layer['kind']
+    if kind == 'identity':
+        return x                                                     # identity.py:14-18
+    if kind in ('sigmoid', 'logit'):
+        return _sigmoid_fwd(x) if (kind == 'sigmoid') != reverse else _sigmoid_inv(x)     # sigmoid.py:46-53
+    if kind == 'elu':
+        if not reverse:
+            return F.elu(x)                                          # activations.py:27
+        zero = torch.zeros_like(x)
+        return torch.max(x, zero) + torch.min(torch.log1p(x), zero)  # activations.py:34-37
+    if kind == 'leaky_relu':
+        s = layer.get('negative_slope', 0.01)
+        return _leaky(x, 1 / s if reverse else s)                    # activations.py:88-92
+    if kind in ('cumsum', 'diff'):
+        if (kind == 'cumsum') != reverse:
+            return x.cumsum(-1)                                      # cumsum.py:62
+        return x - F.pad(x, (1, 0))[..., :-1]                        # cumsum.py:33
+    raise ValueError(kind)
+
+
+def pointwise_log_diag(layer: Dict, x: Tensor, y: Optional[Tensor] = None) -> Tensor:
+    """log_diag_jacobian(x, y) of the forward transform at x (Logit evaluates it at the y it is handed)."""
+    kind = layer['kind']
+    if kind == 'sigmoid':
+        return -F.softplus(-x) - F.softplus(x)                       # sigmoid.py:44
+    if kind == 'logit':
+        if y is None:
+            y = _sigmoid_inv(x)                                      # Logit.forward
+        return -(-F.softplus(-y) - F.softplus(y))                    # sigmoid.py:56 (sign and order flipped)
+    if kind == 'elu':
+        return -F.relu(-x)                                           # activations.py:63
+    if kind == 'leaky_relu':
+        s = layer.get('negative_slope', 0.01)
+        return torch.where(x >= 0., torch.zeros_like(x), torch.ones_like(x) * math.log(s))   # activations.py:99-101
+    return torch.zeros_like(x)                                       # cumsum.py:74, identity.py:24
+
+
+# ----------------------------------------------------------------------------------------------
 # per-transform forward / inverse / log_det_jacobian                       flow.py:8-47 protocol
 # ----------------------------------------------------------------------------------------------
 def _get_time(layer: Dict, t, shape) -> Tensor:
@@ -454,11 +515,13 @@ def transform_apply(layer: Dict, x: Tensor, reverse: bool, latent: Optional[Tens
         return x[..., perm]                                          # permute.py:71
     if kind == 'flip':
         return torch.flip(x, [-1])                                   # permute.py:35,38
+    if kind in POINTWISE:
+        return pointwise_apply(layer, x, reverse)
     raise ValueError(kind)
 
 
-def transform_ldj(layer: Dict, x: Tensor, latent: Optional[Tensor] = None, t=1.0) -> Tensor:
-    """f.log_det_jacobian(x, y): forward-direction log|det J| at x, shape [..., 1]."""
+def transform_ldj(layer: Dict, x: Tensor, latent: Optional[Tensor] = None, t=1.0, y: Optional[Tensor] = None) -> Tensor:
+    """f.log_det_jacobian(x, y): forward-direction log|det J| at x, shape [..., 1] (only Logit reads y)."""
     kind = layer['kind']
     if kind in ('coupling_affine', 'coupling_rqs'):
         m = _coupling_mask(layer, x)                                 # coupling.py:91
@@ -482,19 +545,21 @@ def transform_ldj(layer: Dict, x: Tensor, latent: Optional[Tensor] = None, t=1.0
         return layer['diag'].sum() * tt                              # affine.py:287-288
     if kind in ('permute', 'flip'):
         return torch.zeros_like(x[..., :1])                          # permute.py:41,78
+    if kind in POINTWISE:
+        return pointwise_log_diag(layer, x, y).sum(-1, keepdim=True)  # sigmoid.py:36, activations.py:44,93, cumsum.py:70
     raise ValueError(kind)
 
 
 def transform_inverse_and_ldj(layer: Dict, y: Tensor, latent=None, t=1.0) -> Tuple[Tensor, Tensor]:
     """Transform.inverse_and_log_det_jacobian default, flow.py:42-47 (conditioner runs twice)."""
     x = transform_apply(layer, y, True, latent, t)
-    return x, -transform_ldj(layer, x, latent, t)
+    return x, -transform_ldj(layer, x, latent, t, y)
 
 
 def transform_forward_and_ldj(layer: Dict, x: Tensor, latent=None, t=1.0) -> Tuple[Tensor, Tensor]:
     """Transform.forward_and_log_det_jacobian default, flow.py:35-40."""
     y = transform_apply(layer, x, False, latent, t)
-    return y, transform_ldj(layer, x, latent, t)
+    return y, transform_ldj(layer, x, latent, t, y)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -2,13 +2,15 @@
 
 Same names and constructor signatures as ``stribor`` for the classes on the path
 (``NormalizingFlow``, ``Coupling``, ``Affine``, ``Spline``, ``AffineLU``, ``MatrixExponential``,
-``Permute``/``Flip``, ``UnitNormal``, ``net.MLP``, ``util.get_mask``); the arithmetic is hand-written
+``Permute``/``Flip``, ``Sigmoid``/``Logit``, ``ELU``, ``LeakyReLU``, ``Cumsum``/``Diff``, ``Identity``,
+``UnitNormal``, ``net.MLP``, ``util.get_mask``); the arithmetic is hand-written
 HIP for gfx950 behind the C ABI in ``include/stribor_hip.h``.  There is no CPU fallback.
 """
 from . import net, util
 from .dist import *          # noqa: F401,F403
 from .dist.normal import UnitNormal
 from .flow import ElementwiseTransform, NormalizingFlow, Transform
-from .flows import Affine, AffineLU, Coupling, Flip, MatrixExponential, Permute, Spline
+from .flows import (ELU, Affine, AffineLU, Coupling, Cumsum, Diff, Flip, Identity, LeakyReLU, Logit, MatrixExponential,
+                    Permute, Sigmoid, Spline)
 
 __version__ = '0.1.0'

@@ -1,0 +1,156 @@
+// Parameter-free element-wise flows of the reference: Sigmoid / Logit (stribor/flows/sigmoid.py:9-56), ELU and
+// LeakyReLU (flows/activations.py:11-101), Cumsum / Diff over the last axis (flows/cumsum.py:9-92).
+//
+// One pass over HBM: read x, write y and -- when asked -- the per-element log-derivative and / or its row sum.
+// For the inverse-direction kinds the log-derivative is the one Transform.inverse_and_log_det_jacobian returns
+// (flow.py:42-47): MINUS the forward log-derivative evaluated at the value just produced, in the same pass.
+// Element kinds: one lane per element, consecutive lanes = consecutive addresses; the row sum is a shuffle sum when a
+// row is a power-of-two group inside a wave, float atomics otherwise.  Cumsum is a sequential scan per row (one lane
+// per row, running sum in double) so that it reproduces torch.cumsum bit for bit (test_cumsum.py asserts equality).
+#include "sx_common.h"
+
+__device__ __forceinline__ float pw_softplus(float v) { return v > 20.f ? v : log1pf(expf(v)); }   // F.softplus
+
+template <bool BF16>
+__device__ __forceinline__ float pw_load(const void *p, int64_t off) {
+    if constexpr (BF16) return bf16_to_f32(reinterpret_cast<const uint16_t *>(p)[off]);
+    else return reinterpret_cast<const float *>(p)[off];
+}
+template <bool BF16>
+__device__ __forceinline__ void pw_store(void *p, int64_t off, float v) {
+    if constexpr (BF16) reinterpret_cast<uint16_t *>(p)[off] = f32_to_bf16(v);
+    else reinterpret_cast<float *>(p)[off] = v;
+}
+
+#define PW_TINY 1.17549435e-38f          // torch.finfo(float32).tiny
+#define PW_ONE_MINUS_EPS 0.99999988f     // 1 - torch.finfo(float32).eps
+
+__device__ __forceinline__ void pw_eval(int kind, float param, float log_slope, float x, float &out, float &ld) {
+    switch (kind) {
+        case SX_PW_SIGMOID: {                                          // sigmoid.py:18-23, 41-44
+            out = fminf(fmaxf(1.f / (1.f + expf(-x)), PW_TINY), PW_ONE_MINUS_EPS);
+            ld = -pw_softplus(-x) - pw_softplus(x);
+            break;
+        }
+        case SX_PW_LOGIT: {                                            // sigmoid.py:25-31; minus the forward log-derivative at out
+            const float y = fminf(fmaxf(x, PW_TINY), PW_ONE_MINUS_EPS);
+            out = logf(y) - log1pf(-y);
+            ld = pw_softplus(-out) + pw_softplus(out);
+            break;
+        }
+        case SX_PW_ELU: {                                              // activations.py:22-27, 57-63
+            out = x > 0.f ? x : expm1f(x);
+            ld = -fmaxf(-x, 0.f);
+            break;
+        }
+        case SX_PW_ELU_INV: {                                          // activations.py:29-37
+            out = fmaxf(x, 0.f) + fminf(log1pf(x), 0.f);
+            ld = fmaxf(-out, 0.f);
+            break;
+        }
+        case SX_PW_LEAKY_RELU: {                                       // activations.py:80-86, param = slope, 94-101
+            out = fmaxf(0.f, x) + param * fminf(0.f, x);
+            ld = x >= 0.f ? 0.f : log_slope;                           // math.log(negative_slope), computed on the host
+            break;
+        }
+        default: {                                                     // SX_PW_LEAKY_RELU_INV: param = 1 / slope
+            out = fmaxf(0.f, x) + param * fminf(0.f, x);
+            ld = out >= 0.f ? 0.f : -log_slope;
+            break;
+        }
+    }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void pointwise_kernel(const void *__restrict__ x, void *__restrict__ y,
+                                                        float *__restrict__ ldj, float *__restrict__ ldiag,
+                                                        int64_t n_rows, int dim, int kind, float param, float log_slope,
+                                                        int ldj_mode /*0 none, 1 group, 2 atomic*/, int ldj_acc) {
+    const int64_t total = n_rows * dim;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // the loop bound is rounded up to whole waves so that every lane of a wave reaches the shuffle sum
+    const int64_t total_up = (total + 63) & ~(int64_t)63;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_up; i += stride) {
+        const bool valid = i < total;
+        float out = 0.f, ld = 0.f;
+        if (valid) {
+            pw_eval(kind, param, log_slope, pw_load<BF16>(x, i), out, ld);
+            if (y) pw_store<BF16>(y, i, out);
+            if (ldiag) ldiag[i] = ld;
+        }
+        if (ldj_mode == 1) {            // dim is a power of two <= 64: rows are aligned lane groups
+            const float s = group_sum_rt(valid ? ld : 0.f, dim);
+            if (valid && (i & (dim - 1)) == 0) { const int64_t r = i / dim; ldj[r] = (ldj_acc ? ldj[r] : 0.f) + s; }
+        } else if (ldj_mode == 2) {
+            if (valid) atomicAdd(&ldj[i / dim], ld);
+        }
+    }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void cumsum_kernel(const void *__restrict__ x, void *__restrict__ y, int64_t n_rows,
+                                                     int dim, int diff) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
+        // cumsum.py:62: torch.cumsum on CPU keeps the running sum in double (acc_type<float>) and rounds each output;
+        // diff (:33): x - pad(x)[..., :-1]
+        double acc = 0.0;
+        float prev = 0.f;
+        for (int c = 0; c < dim; ++c) {
+            const float v = pw_load<BF16>(x, r * dim + c);
+            if (diff) { pw_store<BF16>(y, r * dim + c, v - prev); prev = v; }
+            else { acc += (double)v; pw_store<BF16>(y, r * dim + c, (float)acc); }
+        }
+    }
+}
+
+extern "C" int sx_pointwise(const void *x, void *y, float *ldj, float *ldiag, int64_t n_rows, int32_t dim,
+                            int32_t dtype, int32_t kind, float param, int32_t ldj_accumulate, void *stream) {
+    SX_REQUIRE(x != nullptr, "sx_pointwise: null x");
+    SX_REQUIRE(dim > 0 && n_rows >= 0, "sx_pointwise: bad sizes");
+    SX_REQUIRE(dtype == SX_F32 || dtype == SX_BF16, "sx_pointwise: bad dtype");
+    SX_REQUIRE(kind >= SX_PW_SIGMOID && kind <= SX_PW_DIFF, "sx_pointwise: unknown kind %d", kind);
+    if (n_rows == 0) return SX_OK;
+    hipStream_t st = sx_stream(stream);
+    if (kind == SX_PW_CUMSUM || kind == SX_PW_DIFF) {
+        SX_REQUIRE(x != y, "sx_pointwise: cumsum / diff need a separate output");
+        if (y != nullptr) {                 // y == NULL: only the (zero) log-determinants are wanted
+            int64_t g = (n_rows + 255) / 256;
+            if (g > 4096) g = 4096;
+            if (dtype == SX_BF16) hipLaunchKernelGGL(cumsum_kernel<true>, dim3((int)g), dim3(256), 0, st, x, y, n_rows, dim, kind == SX_PW_DIFF);
+            else hipLaunchKernelGGL(cumsum_kernel<false>, dim3((int)g), dim3(256), 0, st, x, y, n_rows, dim, kind == SX_PW_DIFF);
+            SX_LAUNCH_CHECK();
+        }
+        if (ldj && !ldj_accumulate) {
+            hipError_t e = hipMemsetAsync(ldj, 0, n_rows * sizeof(float), st);
+            if (e != hipSuccess) { sx_set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+        }
+        if (ldiag) {
+            hipError_t e = hipMemsetAsync(ldiag, 0, n_rows * dim * sizeof(float), st);
+            if (e != hipSuccess) { sx_set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+        }
+        return SX_OK;
+    }
+    int ldj_mode = 0;
+    if (ldj) {
+        ldj_mode = ((dim & (dim - 1)) == 0 && dim <= 64) ? 1 : 2;
+        if (ldj_mode == 2 && !ldj_accumulate) {
+            hipError_t e = hipMemsetAsync(ldj, 0, n_rows * sizeof(float), st);
+            if (e != hipSuccess) { sx_set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+        }
+    }
+    // log(negative_slope) in double like math.log (activations.py:99); the inverse kind carries 1 / slope
+    float log_slope = 0.f;
+    if (kind == SX_PW_LEAKY_RELU || kind == SX_PW_LEAKY_RELU_INV) {
+        SX_REQUIRE(param > 0.f, "sx_pointwise: LeakyReLU slope must be positive");
+        log_slope = (float)(kind == SX_PW_LEAKY_RELU ? log((double)param) : -log((double)param));
+    }
+    int64_t g = (n_rows * dim + 255) / 256;
+    if (g > 256 * 8) g = 256 * 8;
+    if (dtype == SX_BF16)
+        hipLaunchKernelGGL(pointwise_kernel<true>, dim3((int)g), dim3(256), 0, st, x, y, ldj, ldiag, n_rows, dim, kind, param, log_slope, ldj_mode, ldj_accumulate);
+    else
+        hipLaunchKernelGGL(pointwise_kernel<false>, dim3((int)g), dim3(256), 0, st, x, y, ldj, ldiag, n_rows, dim, kind, param, log_slope, ldj_mode, ldj_accumulate);
+    SX_LAUNCH_CHECK();
+    return SX_OK;
+}

@@ -22,6 +22,9 @@ from typing import Dict, List
 import torch
 
 
+POINTWISE = ('sigmoid', 'logit', 'elu', 'leaky_relu', 'cumsum', 'diff', 'identity')
+
+
 def _spline_params(d: Dict) -> int:
     """parameters per element: 3K-1 (quadratic) or 2K+2 (cubic), flows/spline.py:56-61."""
     return 2 * d['n_bins'] + 2 if d.get('spline_type', 'quadratic') == 'cubic' else 3 * d['n_bins'] - 1
@@ -56,6 +59,10 @@ def build_transform(st, d: Dict):
         return st.Permute(d['dim'])
     if k == 'flip':
         return st.Flip([-1])
+    if k in POINTWISE:
+        return {'sigmoid': st.Sigmoid, 'logit': st.Logit, 'elu': st.ELU, 'identity': st.Identity,
+                'leaky_relu': lambda: st.LeakyReLU(d.get('negative_slope', 0.01)),
+                'cumsum': lambda: st.Cumsum(-1), 'diff': lambda: st.Diff(-1)}[k]()
     raise ValueError(k)
 
 
@@ -106,6 +113,8 @@ def transform_spec(d: Dict, state: Dict[str, torch.Tensor], prefix: str) -> Dict
         return {'kind': k, 'perm': state[prefix + 'permutation'].long()}
     if k == 'flip':
         return {'kind': k}
+    if k in POINTWISE:
+        return dict(d)
     raise ValueError(k)
 
 

@@ -12,7 +12,8 @@ reference files untouched.  Bytecode writing is disabled so nothing lands in the
 Fixtures:  F1 doc known-answer, F2 masks, F3 cfg 1, F4 cfg 2 (N=256, + bf16
 rounded inputs), F5 cfg 3 (RQ-spline couplings, N=128, incl. tails / on-bound / on-knot rows),
 F6 cfg 4 (AffineLU + MatrixExponential + couplings), F7 Permute/Flip, F8 the reference test-suite
-shapes with autograd log|det J|, F9 cubic splines (suite shapes + a D=64 coupling flow).
+shapes with autograd log|det J|, F9 cubic splines (suite shapes + a D=64 coupling flow), F10 parameter-free element-wise flows + the on-path part of
+test_normalizing_flow.py's stack.
 """
 import json
 import os
@@ -404,9 +405,43 @@ def f9_cubic():
     save('f9_cubic', arrays, meta)
 
 
+# ------------------------------------------------------------------------------------------ F10
+def f10_pointwise():
+    """Parameter-free element-wise flows on the suite shapes (test_sigmoid.py, test_activations.py, test_cumsum.py)
+    and the on-path part of test_normalizing_flow.py's stack: Coupling(Affine) -> Flip -> Sigmoid ->
+    Coupling(cubic Spline) -> Logit."""
+    arrays, meta = {}, {}
+    for shp in SHAPES + [(3, 4, 5), (2, 3, 4, 5)]:
+        dim = shp[-1]
+        tag = 'x'.join(map(str, shp))
+        for kind in ('sigmoid', 'logit', 'elu', 'leaky_relu', 'cumsum', 'diff', 'identity'):
+            np.random.seed(123)
+            torch.manual_seed(123)
+            x = torch.rand(*shp) * 0.5 + 0.25 if kind == 'logit' else torch.randn(*shp)        # test_sigmoid.py:17
+            if kind == 'sigmoid' and x.numel() > 4:
+                x.view(-1)[0], x.view(-1)[1] = 30.0, -120.0                  # saturating values (clamps)
+            if kind == 'logit' and x.numel() > 4:
+                x.view(-1)[0], x.view(-1)[1] = 0.0, 1.0                      # clamped ends
+            d = {'kind': kind}
+            if kind == 'leaky_relu':
+                d['negative_slope'] = 0.01 if len(shp) == 2 else 0.3
+            suite_case(f'{kind}/{tag}', d, dim, x, arrays, meta)
+    dim, K = 2, 5
+    desc = [{'kind': 'coupling_affine', 'dim': dim, 'hidden': [32, 64], 'mask': 'ordered_1', 'latent_dim': 0},
+            {'kind': 'flip'}, {'kind': 'sigmoid'},
+            {'kind': 'coupling_rqs', 'dim': dim, 'hidden': [32, 64], 'mask': 'ordered_0', 'latent_dim': 0, 'n_bins': K,
+             'lower': 0, 'upper': 1, 'spline_type': 'cubic'},
+            {'kind': 'logit'}]
+    torch.manual_seed(77)
+    x = torch.randn(3, 4, dim)
+    flow_case('stack', desc, dim, 5, x, arrays)
+    meta['stack'] = {'desc': desc, 'dim': dim, 'seed': 5}
+    save('f10_pointwise', arrays, meta)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9']
+    which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10']
     table = {'f1': f1_doc_example, 'f2': f2_masks, 'f3': f3_cfg1, 'f4': f4_cfg2, 'f5': f5_cfg3,
-             'f6': f6_cfg4, 'f7': f7_permute, 'f8': f8_suite, 'f9': f9_cubic}
+             'f6': f6_cfg4, 'f7': f7_permute, 'f8': f8_suite, 'f9': f9_cubic, 'f10': f10_pointwise}
     for w in which:
         table[w]()

@@ -595,3 +595,50 @@ def test_cubic_kernel_against_oracle_random_params():
     close(ldj, wl.sum(-1), atol=1e-4)
     with pytest.raises(ValueError):
         st.Spline(2, 101, spline_type='cubic').to(DEV)(torch.rand(3, 2, device=DEV))
+
+
+def test_pointwise_flows_suite_shapes_and_stack():
+    """stribor/test/test_sigmoid.py, test_activations.py, test_cumsum.py shapes (fixture F10): Sigmoid / Logit (incl.
+    saturated and clamped values), ELU, LeakyReLU, Cumsum / Diff (bit-exact: sequential order), Identity; then the
+    on-path part of test_normalizing_flow.py's stack, layer by layer on the device."""
+    g = Golden('f10_pointwise')
+    n = 0
+    for case, m in g.meta.items():
+        if case == 'stack':
+            continue
+        kind = m['desc'][0]['kind']
+        f = product_transform(g, case)
+        x = g.t(case + '/x').to(DEV)
+        y = f(x)
+        exact = kind in ('cumsum', 'diff', 'identity', 'leaky_relu')
+        if exact:
+            assert torch.equal(y.cpu(), g.t(case + '/y')), case                  # test_cumsum.py:17 asserts equality
+            assert torch.equal(f.inverse(y).cpu(), g.t(case + '/x_back')), case
+        else:
+            close(y, g.t(case + '/y'))
+            close(f.inverse(g.t(case + '/y').to(DEV)), g.t(case + '/x_back'), atol=2e-5)
+        ldj = f.log_det_jacobian(x, y)
+        close(ldj, g.t(case + '/ldj'), atol=2e-5)
+        _, l1 = f.forward_and_log_det_jacobian(x)
+        _, l2 = f.inverse_and_log_det_jacobian(g.t(case + '/y').to(DEV))
+        close(l1, g.t(case + '/ldj_fwd'), atol=2e-5)
+        close(l2, g.t(case + '/ldj_inv'), atol=1e-4 if kind in ('sigmoid', 'logit') else 2e-5)
+        close(f.log_diag_jacobian(x, y), g.t(case + '/ldiag'), atol=2e-5)
+        if kind not in ('sigmoid', 'logit') or x.numel() <= 4:                   # saturated entries have no finite autograd value
+            close(ldj.reshape(-1), g.t(case + '/autograd_logdet'), atol=1e-4)    # base.py:35-44
+        n += 1
+    assert n == 6 * 7
+    # bf16 storage
+    xb = torch.randn(33, 10).to(torch.bfloat16)
+    yb = st.ELU().to(DEV)(xb.to(DEV))
+    close(yb.float(), torch.nn.functional.elu(xb.float()).to(torch.bfloat16).float(), rtol=1e-2, atol=1e-2)
+    flow = product_flow(g, 'stack')
+    x = g.t('stack/x').to(DEV)
+    close(flow.log_prob(x), g.t('stack/log_prob'), rtol=1e-5, atol=1e-4)
+    close(flow.forward(x), g.t('stack/forward'), atol=2e-5)
+    close(flow.inverse(x), g.t('stack/inverse'), atol=2e-5)
+    close(flow.log_prob(x).double(), g.t('stack/log_prob_f64'), rtol=1e-5, atol=1e-4)
+    with pytest.raises(AssertionError):
+        st.LeakyReLU(-1.0)
+    with pytest.raises(AssertionError):
+        st.Cumsum(-2)

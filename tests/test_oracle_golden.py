@@ -153,3 +153,31 @@ def test_f9_cubic_suite_shapes():
         assert torch.allclose(ldj.reshape(-1), g.t(case + '/autograd_logdet'), atol=1e-4), case
         n += 1
     assert n == 4 * (9 + 2)
+
+
+def test_f10_pointwise_flows_and_stack():
+    """Sigmoid / Logit / ELU / LeakyReLU / Cumsum / Diff / Identity on the reference suite's shapes, and the on-path part
+    of test_normalizing_flow.py's stack (affine coupling -> Flip -> Sigmoid -> cubic-spline coupling -> Logit)."""
+    g = Golden('f10_pointwise')
+    n = 0
+    for case, m in g.meta.items():
+        if case == 'stack':
+            continue
+        spec = fd.transform_spec(m['desc'][0], {}, 'transforms.0.')
+        x = g.t(case + '/x')
+        y = orc.transform_apply(spec, x, False)
+        assert torch.equal(y, g.t(case + '/y')), case
+        assert torch.equal(orc.transform_apply(spec, y, True), g.t(case + '/x_back')), case
+        ldj = orc.transform_ldj(spec, x)
+        assert torch.equal(ldj, g.t(case + '/ldj')), case
+        _, l2 = orc.transform_inverse_and_ldj(spec, y)
+        assert torch.equal(l2, g.t(case + '/ldj_inv')), case
+        assert torch.equal(orc.pointwise_log_diag(spec, x), g.t(case + '/ldiag')), case
+        n += 1
+    assert n == 6 * 7
+    m = g.meta['stack']
+    spec = fd.flow_spec(m['desc'], g.state('stack'))
+    x = g.t('stack/x')
+    assert torch.equal(orc.flow_log_prob(spec, x), g.t('stack/log_prob'))
+    assert torch.equal(orc.flow_forward(spec, x), g.t('stack/forward'))
+    assert torch.equal(orc.flow_inverse(spec, x), g.t('stack/inverse'))
