@@ -25,17 +25,34 @@ __device__ __forceinline__ void pw_store(void *p, int64_t off, float v) {
 #define PW_TINY 1.17549435e-38f          // torch.finfo(float32).tiny
 #define PW_ONE_MINUS_EPS 0.99999988f     // 1 - torch.finfo(float32).eps
 
+// exp(v) on v_exp_f32 with the product v*log2(e) carried to double-float accuracy (error ~1e-7 relative for |v| < 88)
+__device__ __forceinline__ float pw_exp(float v) {
+    const float t = v * 1.44269504088896341f;
+    const float r = __builtin_fmaf(v, 1.44269504088896341f, -t) + v * 1.92596299e-8f;   // low part of v*log2(e)
+    return __builtin_amdgcn_exp2f(t) * (1.f + r * 0.69314718055994531f);
+}
+__device__ __forceinline__ float pw_log(float v) { return __builtin_amdgcn_logf(v) * 0.69314718055994531f; }
+// softplus(-v) + softplus(v) = |v| + 2 log(1 + exp(-|v|)): one exp, one log (sigmoid.py:44 evaluates two softplus)
+__device__ __forceinline__ float pw_two_softplus(float v, float &t) {
+    const float a = fabsf(v);
+    t = pw_exp(-a);
+    return a + 2.f * pw_log(1.f + t);
+}
+
 __device__ __forceinline__ void pw_eval(int kind, float param, float log_slope, float x, float &out, float &ld) {
     switch (kind) {
         case SX_PW_SIGMOID: {                                          // sigmoid.py:18-23, 41-44
-            out = fminf(fmaxf(1.f / (1.f + expf(-x)), PW_TINY), PW_ONE_MINUS_EPS);
-            ld = -pw_softplus(-x) - pw_softplus(x);
+            float t;
+            ld = -pw_two_softplus(x, t);
+            const float r = __builtin_amdgcn_rcpf(1.f + t);            // sigmoid(|x|); sigmoid(-|x|) = t * r
+            out = fminf(fmaxf(x >= 0.f ? r : t * r, PW_TINY), PW_ONE_MINUS_EPS);
             break;
         }
         case SX_PW_LOGIT: {                                            // sigmoid.py:25-31; minus the forward log-derivative at out
             const float y = fminf(fmaxf(x, PW_TINY), PW_ONE_MINUS_EPS);
             out = logf(y) - log1pf(-y);
-            ld = pw_softplus(-out) + pw_softplus(out);
+            float t;
+            ld = pw_two_softplus(out, t);
             break;
         }
         case SX_PW_ELU: {                                              // activations.py:22-27, 57-63
@@ -68,6 +85,7 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const void *__restrict__
                                                         int ldj_mode /*0 none, 1 group, 2 atomic*/, int ldj_acc) {
     const int64_t total = n_rows * dim;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int row_shift = 31 - __builtin_clz(dim);      // used when dim is a power of two
     // the loop bound is rounded up to whole waves so that every lane of a wave reaches the shuffle sum
     const int64_t total_up = (total + 63) & ~(int64_t)63;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_up; i += stride) {
@@ -80,26 +98,58 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const void *__restrict__
         }
         if (ldj_mode == 1) {            // dim is a power of two <= 64: rows are aligned lane groups
             const float s = group_sum_rt(valid ? ld : 0.f, dim);
-            if (valid && (i & (dim - 1)) == 0) { const int64_t r = i / dim; ldj[r] = (ldj_acc ? ldj[r] : 0.f) + s; }
+            if (valid && (i & (dim - 1)) == 0) { const int64_t r = i >> row_shift; ldj[r] = (ldj_acc ? ldj[r] : 0.f) + s; }
         } else if (ldj_mode == 2) {
-            if (valid) atomicAdd(&ldj[i / dim], ld);
+            if (valid) atomicAdd(&ldj[total < (1ll << 31) ? (int64_t)((uint32_t)i / (uint32_t)dim) : i / dim], ld);
         }
     }
 }
 
+// Cumsum / Diff: a wave owns 64 consecutive rows = one contiguous span of 64*dim elements.  The span is copied into
+// the wave's LDS slice with coalesced loads (row stride dim+1 dwords: conflict-free column walks), each lane scans
+// its own row there, and the span goes back out coalesced.  Rows longer than the slice allows take the direct loop.
+extern __shared__ __attribute__((aligned(16))) float pw_smem[];
 template <bool BF16>
 __global__ __launch_bounds__(256) void cumsum_kernel(const void *__restrict__ x, void *__restrict__ y, int64_t n_rows,
-                                                     int dim, int diff) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
-        // cumsum.py:62: torch.cumsum on CPU keeps the running sum in double (acc_type<float>) and rounds each output;
-        // diff (:33): x - pad(x)[..., :-1]
-        double acc = 0.0;
-        float prev = 0.f;
-        for (int c = 0; c < dim; ++c) {
-            const float v = pw_load<BF16>(x, r * dim + c);
-            if (diff) { pw_store<BF16>(y, r * dim + c, v - prev); prev = v; }
-            else { acc += (double)v; pw_store<BF16>(y, r * dim + c, (float)acc); }
+                                                     int dim, int diff, int staged) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n_groups = (n_rows + 63) >> 6;
+    const int RS = dim + 1;
+    float *sp = pw_smem + (size_t)wave * 64 * RS;
+    for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < n_groups; grp += (int64_t)gridDim.x * 4) {
+        const int64_t r0 = grp << 6;
+        const int rows = (int)((n_rows - r0) < 64 ? (n_rows - r0) : 64);
+        const int total = rows * dim;
+        if (staged) {
+            for (int i = lane; i < total; i += 64) {
+                const int r = i / dim, c = i - r * dim;
+                sp[r * RS + c] = pw_load<BF16>(x, r0 * dim + i);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (lane < rows) {
+            // cumsum.py:62: torch.cumsum on CPU keeps the running sum in double (acc_type<float>) and rounds each
+            // output; diff (:33): x - pad(x)[..., :-1]
+            double acc = 0.0;
+            float prev = 0.f;
+            float *row = sp + lane * RS;
+            const int64_t g0 = (r0 + lane) * dim;
+            for (int c = 0; c < dim; ++c) {
+                const float v = staged ? row[c] : pw_load<BF16>(x, g0 + c);
+                float o;
+                if (diff) { o = v - prev; prev = v; }
+                else { acc += (double)v; o = (float)acc; }
+                if (staged) row[c] = o; else pw_store<BF16>(y, g0 + c, o);
+            }
+        }
+        if (staged) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int i = lane; i < total; i += 64) {
+                const int r = i / dim, c = i - r * dim;
+                pw_store<BF16>(y, r0 * dim + i, sp[r * RS + c]);
+            }
         }
     }
 }
@@ -116,9 +166,16 @@ extern "C" int sx_pointwise(const void *x, void *y, float *ldj, float *ldiag, in
         SX_REQUIRE(x != y, "sx_pointwise: cumsum / diff need a separate output");
         if (y != nullptr) {                 // y == NULL: only the (zero) log-determinants are wanted
             int64_t g = (n_rows + 255) / 256;
-            if (g > 4096) g = 4096;
-            if (dtype == SX_BF16) hipLaunchKernelGGL(cumsum_kernel<true>, dim3((int)g), dim3(256), 0, st, x, y, n_rows, dim, kind == SX_PW_DIFF);
-            else hipLaunchKernelGGL(cumsum_kernel<false>, dim3((int)g), dim3(256), 0, st, x, y, n_rows, dim, kind == SX_PW_DIFF);
+            if (g > 2048) g = 2048;
+            const size_t lds = (size_t)4 * 64 * (dim + 1) * sizeof(float);
+            const int staged = lds <= 150 * 1024;
+            const size_t dyn = staged ? lds : 0;
+            if (dyn > 48 * 1024) {
+                (void)hipFuncSetAttribute((const void *)cumsum_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void *)cumsum_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            }
+            if (dtype == SX_BF16) hipLaunchKernelGGL(cumsum_kernel<true>, dim3((int)g), dim3(256), dyn, st, x, y, n_rows, dim, kind == SX_PW_DIFF, staged);
+            else hipLaunchKernelGGL(cumsum_kernel<false>, dim3((int)g), dim3(256), dyn, st, x, y, n_rows, dim, kind == SX_PW_DIFF, staged);
             SX_LAUNCH_CHECK();
         }
         if (ldj && !ldj_accumulate) {

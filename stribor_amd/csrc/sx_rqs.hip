@@ -405,6 +405,12 @@ __device__ __forceinline__ float cubic_cbrt(float v) {        // :18-20  sign(x)
     return s * expf(logf(fabsf(v)) / 3.0f);
 }
 __device__ __forceinline__ float cubic_sigmoid(float v) { return 1.f / (1.f + expf(-v)); }
+// exp(v) on v_exp_f32 with the product v*log2(e) carried to double-float accuracy (~1e-7 relative)
+__device__ __forceinline__ float cubic_exp(float v) {
+    const float t = v * 1.44269504088896341f;
+    const float r = fmaf(v, 1.44269504088896341f, -t) + v * 1.92596299e-8f;
+    return __builtin_amdgcn_exp2f(t) * (1.f + r * 0.69314718055994531f);
+}
 
 template <bool BF16, bool INVERSE>
 __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, void *__restrict__ y,
@@ -423,6 +429,7 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
     const float norm = 1.f - CUBIC_MIN_BIN * (float)K;          // :104, :111
     const float span = upper - lower;                            // right - left = top - bottom
     const bool contig = pstride == (int64_t)n_live * P;
+    const float inv_P = 1.0f / (float)P;
 
     for (int64_t grp = (int64_t)blockIdx.x * waves_per_block + wave; grp < n_groups;
          grp += (int64_t)gridDim.x * waves_per_block) {
@@ -430,8 +437,21 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
         const int n_here = (int)((n_elem - e0) < 64 ? (n_elem - e0) : 64);
         const int total = n_here * P;
         // ---- stage: consecutive idx -> consecutive HBM addresses (one contiguous span when rows are packed) ----
+        if (contig && n_here == 64 && (P & 1) == 0 && ((reinterpret_cast<uintptr_t>(params) & 15) == 0)) {
+            // 64*P floats = 16*P float4, 16-byte aligned (P even): vector loads, scalar LDS writes into the padded rows
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(params + e0 * P);
+            for (int i4 = lane; i4 < 16 * P; i4 += 64) {
+                const f32x4 v = src[i4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int idx = 4 * i4 + c;
+                    const int el = (int)(((float)idx + 0.5f) * inv_P), q = idx - el * P;
+                    sp[el * PS + q] = v[c];
+                }
+            }
+        } else
         for (int idx = lane; idx < total; idx += 64) {
-            const int el = idx / P, q = idx - el * P;
+            const int el = (int)(((float)idx + 0.5f) * inv_P), q = idx - el * P;       // idx / P, exact for idx < 2^22
             float v;
             if (contig) v = params[e0 * P + idx];
             else {
@@ -454,31 +474,78 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
         const float xin = ((inside ? xv : lower) - lower) / span;            // :98-101
         float *p = sp + (valid ? lane : 0) * PS;                 // [0,K) widths, [K,2K) heights, 2K / 2K+1 derivatives
 
-        // ---- softmax normalisers (F.softmax: exp(u - max) / sum), :103, :110 -----------------------------
-        float mw = p[0], mh = p[K];
-        for (int k = 1; k < K; ++k) { mw = fmaxf(mw, p[k]); mh = fmaxf(mh, p[K + k]); }
-        float sw = 0.f, sh = 0.f;
-        for (int k = 0; k < K; ++k) { sw += expf(p[k] - mw); sh += expf(p[K + k] - mh); }
-        // ---- widths / heights in place, running cumsums (:106, :113), bin search (search_sorted.py:4-5) -------
+        // ---- normalised widths / heights, running cumsums (:103-115) and the bin search (search_sorted.py:4-5) in
+        //      one sweep that also keeps the widths / heights of bins b-1, b, b+1 ----------------------------------
         int b = 0;
-        float cw = 0.f, ch = 0.f, cw_b = 0.f, ch_b = 0.f;
-        for (int k = 0; k < K; ++k) {
-            const float wk = CUBIC_MIN_BIN + norm * (expf(p[k] - mw) / sw);
-            const float hk = CUBIC_MIN_BIN + norm * (expf(p[K + k] - mh) / sh);
-            p[k] = wk;
-            p[K + k] = hk;
-            if (xin >= (INVERSE ? ch : cw)) { b = k; cw_b = cw; ch_b = ch; }  // lower knot of bin k (knot 0 = 0)
-            cw += wk;
-            ch += hk;
+        float cw_b = 0.f, ch_b = 0.f, w_b = 0.f, h_b = 0.f, w_m = 1.f, h_m = 1.f, w_p = 1.f, h_p = 1.f;
+        auto sweep = [&](auto get_w, auto get_h, auto set_w, auto set_h, int KK) {
+            float mw = get_w(0), mh = get_h(0);
+            for (int k = 1; k < KK; ++k) { mw = fmaxf(mw, get_w(k)); mh = fmaxf(mh, get_h(k)); }
+            float sw = 0.f, sh = 0.f;
+            for (int k = 0; k < KK; ++k) {      // exp once per parameter (v_exp_f32 with a compensated argument)
+                const float ew = cubic_exp(get_w(k) - mw), eh = cubic_exp(get_h(k) - mh);
+                set_w(k, ew);
+                set_h(k, eh);
+                sw += ew;
+                sh += eh;
+            }
+            const float nw = norm / sw, nh = norm / sh;         // one division per softmax instead of one per bin
+            float cw = 0.f, ch = 0.f, w_last = 1.f, h_last = 1.f;
+            bool need_next = false;
+            for (int k = 0; k < KK; ++k) {
+                const float wk = CUBIC_MIN_BIN + nw * get_w(k);
+                const float hk = CUBIC_MIN_BIN + nh * get_h(k);
+                if (xin >= (INVERSE ? ch : cw)) {               // lower knot of bin k (knot 0 = 0): edges only grow
+                    b = k; cw_b = cw; ch_b = ch; w_b = wk; h_b = hk; w_m = w_last; h_m = h_last; need_next = true;
+                } else if (need_next) {
+                    w_p = wk; h_p = hk; need_next = false;
+                }
+                w_last = wk; h_last = hk;
+                cw += wk;
+                ch += hk;
+            }
+        };
+        if (K == 16) {          // wave-uniform: parameters in registers, fully unrolled, selects only
+            float rw[16], rh[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { rw[k] = p[k]; rh[k] = p[16 + k]; }
+            float mw = rw[0], mh = rh[0];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) { mw = fmaxf(mw, rw[k]); mh = fmaxf(mh, rh[k]); }
+            float sw = 0.f, sh = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                rw[k] = cubic_exp(rw[k] - mw); rh[k] = cubic_exp(rh[k] - mh);
+                sw += rw[k]; sh += rh[k];
+            }
+            const float nw = norm / sw, nh = norm / sh;
+            float cw = 0.f, ch = 0.f, w_last = 1.f, h_last = 1.f;
+            bool need_next = false;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float wk = CUBIC_MIN_BIN + nw * rw[k];
+                const float hk = CUBIC_MIN_BIN + nh * rh[k];
+                const bool ge = xin >= (INVERSE ? ch : cw);
+                const bool nx = !ge && need_next;
+                b = ge ? k : b; cw_b = ge ? cw : cw_b; ch_b = ge ? ch : ch_b; w_b = ge ? wk : w_b; h_b = ge ? hk : h_b;
+                w_m = ge ? w_last : w_m; h_m = ge ? h_last : h_m;
+                w_p = nx ? wk : w_p; h_p = nx ? hk : h_p;
+                need_next = ge;                                 // edges only grow: once false it stays false
+                w_last = wk; h_last = hk;
+                cw += wk;
+                ch += hk;
+            }
+        } else {
+            sweep([&](int k) { return p[k]; }, [&](int k) { return p[K + k]; }, [&](int k, float v) { p[k] = v; },
+                  [&](int k, float v) { p[K + k] = v; }, K);
         }
         // ---- knot derivatives of bin b (:117-132) and its cubic (:134-137) -----------------------------------
-        const float w_b = p[b], h_b = p[K + b];
         const float s_b = h_b / w_b;                                                       // :117
         const float rcw = (b == K - 1) ? 1.f : cw_b + w_b;                                 // :107 (last knot pinned)
         float dL, dR;
         if (b == 0) dL = cubic_sigmoid(p[2 * K]) * 3.f * s_b;                              // :126
         else {
-            const float w_m = p[b - 1], s_m = p[K + b - 1] / w_m;
+            const float s_m = h_m / w_m;
             const float m1 = fminf(fabsf(s_m), fabsf(s_b));                               // :118-119
             const float m2 = 0.5f * (w_b * s_m + w_m * s_b) / (w_m + w_b);                 // :120-123
             const float sg = ((s_m > 0.f) ? 1.f : ((s_m < 0.f) ? -1.f : 0.f)) + ((s_b > 0.f) ? 1.f : ((s_b < 0.f) ? -1.f : 0.f));
@@ -486,7 +553,7 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
         }
         if (b == K - 1) dR = cubic_sigmoid(p[2 * K + 1]) * 3.f * s_b;                      // :127
         else {
-            const float w_p = p[b + 1], s_p = p[K + b + 1] / w_p;
+            const float s_p = h_p / w_p;
             const float m1 = fminf(fabsf(s_b), fabsf(s_p));
             const float m2 = 0.5f * (w_p * s_b + w_b * s_p) / (w_b + w_p);
             const float sg = ((s_b > 0.f) ? 1.f : ((s_b < 0.f) ? -1.f : 0.f)) + ((s_p > 0.f) ? 1.f : ((s_p < 0.f) ? -1.f : 0.f));

@@ -38,6 +38,18 @@ params = torch.randn(N2, nl * P, device=dev)
 for rev in (False, True):
     ms = timed(lambda: run_rqs_kernel(x2, params, nl * P, None, 32, nl, K, -3., 3., -3., 3., rev, True, False))
     rec(f'rqs_kernel K=16 live=32 reverse={rev} (2^18 rows)', ms, N2 * (nl * P * 4 + 2 * D * 4 + 4))
+from stribor_amd.flows.spline import run_cubic_kernel
+Pc = 2 * K + 2
+params_c = torch.randn(N2, nl * Pc, device=dev)
+for rev in (False, True):
+    ms = timed(lambda: run_cubic_kernel(x2, params_c, nl * Pc, None, 32, nl, K, -3., 3., rev, True, False))
+    rec(f'cubic_kernel K=16 live=32 reverse={rev} (2^18 rows)', ms, N2 * (nl * Pc * 4 + 2 * D * 4 + 4))
+from stribor_amd.flows.pointwise import run_pointwise, PW_SIGMOID, PW_CUMSUM
+xs = torch.randn(N, D, device=dev)
+ms = timed(lambda: run_pointwise(xs, PW_SIGMOID, want_ldj=True))
+rec('pointwise sigmoid (+ldj) x=float32', ms, N * (2 * D * 4 + 4))
+ms = timed(lambda: run_pointwise(xs, PW_CUMSUM))
+rec('cumsum x=float32', ms, N * 2 * D * 4)
 v = torch.randn(N * 64, device=dev)
 o = torch.zeros(1, dtype=torch.float64, device=dev)
 ms = timed(lambda: _hip.check(_hip.lib().sx_sum_f64(v.data_ptr(), v.numel(), o.data_ptr(), _hip.stream()), 'sum'))
