@@ -78,29 +78,50 @@ __device__ __forceinline__ void pw_eval(int kind, float param, float log_slope, 
     }
 }
 
-template <bool BF16>
+// VEC = 4: one lane = 4 consecutive elements of one row (dim % 4 == 0): 16-byte (fp32) / 8-byte (bf16) accesses
+template <bool BF16, int VEC>
 __global__ __launch_bounds__(256) void pointwise_kernel(const void *__restrict__ x, void *__restrict__ y,
                                                         float *__restrict__ ldj, float *__restrict__ ldiag,
                                                         int64_t n_rows, int dim, int kind, float param, float log_slope,
                                                         int ldj_mode /*0 none, 1 group, 2 atomic*/, int ldj_acc) {
-    const int64_t total = n_rows * dim;
+    const int gdim = dim / VEC;                         // lanes per row
+    const int64_t total = n_rows * gdim;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int row_shift = 31 - __builtin_clz(dim);      // used when dim is a power of two
+    const int row_shift = 31 - __builtin_clz(gdim);     // used when gdim is a power of two
     // the loop bound is rounded up to whole waves so that every lane of a wave reaches the shuffle sum
     const int64_t total_up = (total + 63) & ~(int64_t)63;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_up; i += stride) {
         const bool valid = i < total;
-        float out = 0.f, ld = 0.f;
+        float ld_sum = 0.f;
         if (valid) {
-            pw_eval(kind, param, log_slope, pw_load<BF16>(x, i), out, ld);
-            if (y) pw_store<BF16>(y, i, out);
-            if (ldiag) ldiag[i] = ld;
+            float xv[VEC], out[VEC], ld[VEC];
+            if constexpr (VEC == 4) {
+                if constexpr (BF16) {
+                    const u16x4 u = reinterpret_cast<const u16x4 *>(x)[i];
+                    xv[0] = bf16_to_f32(u.x); xv[1] = bf16_to_f32(u.y); xv[2] = bf16_to_f32(u.z); xv[3] = bf16_to_f32(u.w);
+                } else {
+                    const f32x4 v = reinterpret_cast<const f32x4 *>(x)[i];
+                    xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
+                }
+            } else xv[0] = pw_load<BF16>(x, i);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) { pw_eval(kind, param, log_slope, xv[c], out[c], ld[c]); ld_sum += ld[c]; }
+            if (y) {
+                if constexpr (VEC == 4) {
+                    if constexpr (BF16) reinterpret_cast<u16x4 *>(y)[i] = u16x4{f32_to_bf16(out[0]), f32_to_bf16(out[1]), f32_to_bf16(out[2]), f32_to_bf16(out[3])};
+                    else reinterpret_cast<f32x4 *>(y)[i] = f32x4{out[0], out[1], out[2], out[3]};
+                } else pw_store<BF16>(y, i, out[0]);
+            }
+            if (ldiag) {
+                if constexpr (VEC == 4) reinterpret_cast<f32x4 *>(ldiag)[i] = f32x4{ld[0], ld[1], ld[2], ld[3]};
+                else ldiag[i] = ld[0];
+            }
         }
-        if (ldj_mode == 1) {            // dim is a power of two <= 64: rows are aligned lane groups
-            const float s = group_sum_rt(valid ? ld : 0.f, dim);
-            if (valid && (i & (dim - 1)) == 0) { const int64_t r = i >> row_shift; ldj[r] = (ldj_acc ? ldj[r] : 0.f) + s; }
+        if (ldj_mode == 1) {            // gdim is a power of two <= 64: rows are aligned lane groups
+            const float s = group_sum_rt(ld_sum, gdim);
+            if (valid && (i & (gdim - 1)) == 0) { const int64_t r = i >> row_shift; ldj[r] = (ldj_acc ? ldj[r] : 0.f) + s; }
         } else if (ldj_mode == 2) {
-            if (valid) atomicAdd(&ldj[total < (1ll << 31) ? (int64_t)((uint32_t)i / (uint32_t)dim) : i / dim], ld);
+            if (valid) atomicAdd(&ldj[total < (1ll << 31) ? (int64_t)((uint32_t)i / (uint32_t)gdim) : i / gdim], ld_sum);
         }
     }
 }
@@ -188,9 +209,13 @@ extern "C" int sx_pointwise(const void *x, void *y, float *ldj, float *ldiag, in
         }
         return SX_OK;
     }
+    const size_t esz = dtype == SX_BF16 ? 2 : 4;
+    const bool vec4 = (dim % 4 == 0) && (((uintptr_t)x % (4 * esz)) == 0) && (y == nullptr || ((uintptr_t)y % (4 * esz)) == 0) &&
+                      (ldiag == nullptr || ((uintptr_t)ldiag % 16) == 0);
+    const int gdim = vec4 ? dim / 4 : dim;
     int ldj_mode = 0;
     if (ldj) {
-        ldj_mode = ((dim & (dim - 1)) == 0 && dim <= 64) ? 1 : 2;
+        ldj_mode = ((gdim & (gdim - 1)) == 0 && gdim <= 64) ? 1 : 2;
         if (ldj_mode == 2 && !ldj_accumulate) {
             hipError_t e = hipMemsetAsync(ldj, 0, n_rows * sizeof(float), st);
             if (e != hipSuccess) { sx_set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
@@ -202,12 +227,14 @@ extern "C" int sx_pointwise(const void *x, void *y, float *ldj, float *ldiag, in
         SX_REQUIRE(param > 0.f, "sx_pointwise: LeakyReLU slope must be positive");
         log_slope = (float)(kind == SX_PW_LEAKY_RELU ? log((double)param) : -log((double)param));
     }
-    int64_t g = (n_rows * dim + 255) / 256;
+    int64_t g = (n_rows * gdim + 255) / 256;
     if (g > 256 * 8) g = 256 * 8;
-    if (dtype == SX_BF16)
-        hipLaunchKernelGGL(pointwise_kernel<true>, dim3((int)g), dim3(256), 0, st, x, y, ldj, ldiag, n_rows, dim, kind, param, log_slope, ldj_mode, ldj_accumulate);
-    else
-        hipLaunchKernelGGL(pointwise_kernel<false>, dim3((int)g), dim3(256), 0, st, x, y, ldj, ldiag, n_rows, dim, kind, param, log_slope, ldj_mode, ldj_accumulate);
+#define SX_PWL(BF, V)                                                                                             \
+    hipLaunchKernelGGL((pointwise_kernel<BF, V>), dim3((int)g), dim3(256), 0, st, x, y, ldj, ldiag, n_rows, dim, kind, \
+                       param, log_slope, ldj_mode, ldj_accumulate)
+    if (dtype == SX_BF16) { if (vec4) SX_PWL(true, 4); else SX_PWL(true, 1); }
+    else { if (vec4) SX_PWL(false, 4); else SX_PWL(false, 1); }
+#undef SX_PWL
     SX_LAUNCH_CHECK();
     return SX_OK;
 }
