@@ -104,6 +104,16 @@ int sx_rqs_coupling(const void *x, void *y, float *ldj, float *ldiag, const floa
                     int32_t dtype, int32_t reverse, int32_t ldj_accumulate, float ldj_scale,
                     uint32_t *err_flag, void *stream);
 
+/* Backward of sx_rqs_coupling(reverse = 1) -- the direction log_prob evaluates -- for training:
+ * reverse mode through rational_quadratic_spline.py:101-107,180-234.
+ *   x [n_rows, dim] fp32: the values the inverse pass was given;  gout [n_rows, dim]: dL/d(output), live columns read;
+ *   gldj [n_rows]: dL/d(row log-det), scaled by ldj_scale;  params as sx_rqs_coupling.
+ *   gx [n_rows, dim]: live columns receive dL/dx;  gparams [n_rows, n_live*(3K-1)] (packed rows): dL/dparams. */
+int sx_rqs_inverse_bwd(const float *x, const float *gout, const float *gldj, const float *params,
+                       int64_t params_stride, float *gx, float *gparams, const int32_t *live_idx, int32_t live_start,
+                       int32_t n_live, int32_t n_bins, float left, float right, float bottom, float top, int64_t n_rows,
+                       int32_t dim, float ldj_scale, void *stream);
+
 /* Monotone cubic spline, element-wise part -- spline_type='cubic', the reference's default
  * (stribor/util/cubic_spline.py:21-251, util/search_sorted.py:3-5, flows/spline.py:59-61,82-86).
  *   params[n, i*(2K+2) + 0:K]      unnormalised widths  of live dim i

@@ -13,6 +13,8 @@ from typing import List, Optional, Tuple, Union
 import torch
 import torch.nn as nn
 
+HALF_LOG_2PI = 0.9189385332046727          # log(sqrt(2 pi)), dist/normal.py:37
+
 from . import _hip
 from .fused import CompiledProgram, ProgramBuilder
 
@@ -264,6 +266,34 @@ class NormalizingFlow(Transform):
         except NotImplementedError:
             return False
 
+    # ---- training, layer by layer: flows of quadratic-spline couplings (+ Permute / Flip) ---------------------
+    def _layerwise_autograd_ok(self) -> bool:
+        from .flows.coupling import Coupling
+        from .flows.permute import _ColumnShuffle
+        ok = [isinstance(f, _ColumnShuffle) or (isinstance(f, Coupling) and f._autograd_supported())
+              for f in self.transforms]
+        return all(ok) and any(isinstance(f, Coupling) for f in self.transforms)
+
+    def _log_prob_layerwise_autograd(self, y, latent=None):
+        """log_prob with a graph for spline-coupling flows: each layer's spline (and its backward) is a HIP kernel,
+        conditioners and column shuffles are torch ops on the device.  fp32 state."""
+        from .flows.permute import _ColumnShuffle
+        y2, lead = flatten_rows(y.to(torch.float32))
+        lat2 = None if latent is None else latent.reshape(-1, latent.shape[-1]).to(torch.float32)
+        cur, total = y2, None
+        for f in reversed(self.transforms):
+            if isinstance(f, _ColumnShuffle):
+                perm = f._perm(cur.shape[1]).to(cur.device).long()
+                inv = torch.empty_like(perm)
+                inv[perm] = torch.arange(perm.numel(), device=perm.device)
+                cur = cur.index_select(1, inv)                                # permute.py:75 (inverse direction)
+                continue
+            cur, ldj = f._autograd_inverse(cur, lat2)
+            total = ldj if total is None else total + ldj
+        d = cur.shape[1]
+        lp = -0.5 * (cur * cur).sum(-1) - d * HALF_LOG_2PI + total            # dist/normal.py:37,52-54
+        return lp.reshape(*lead, 1)
+
     def _wants_grad(self, y) -> bool:
         return torch.is_grad_enabled() and (y.requires_grad or any(p.requires_grad for p in self.parameters()))
 
@@ -338,6 +368,8 @@ class NormalizingFlow(Transform):
                 # flow evaluates without a graph, as before
                 y2, lead = flatten_rows(y.to(torch.float32))
                 return _FusedLogProb.apply(self, y2, *self._grad_params()).reshape(*lead, 1)
+            if self._wants_grad(y) and not kwargs and self._layerwise_autograd_ok():
+                return self._log_prob_layerwise_autograd(y, latent)
             r = self._run(y, True, latent, False, False, True, **kwargs)
             if r is not None:
                 return r[2]

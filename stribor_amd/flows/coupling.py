@@ -160,6 +160,45 @@ class Coupling(Transform):
                                        sp.lower, sp.upper, sp.lower, sp.upper, reverse, want_ldj, False, ldj_scale)
         return y, ldj
 
+    # ---- training (autograd): spline couplings, inverse direction --------------------------------------------------
+    def _autograd_supported(self) -> bool:
+        from .spline import Spline
+        return isinstance(self.transform, Spline) and self.transform.spline_type == 'quadratic' and \
+            isinstance(getattr(self.transform, 'latent_net', None), MLP)
+
+    def _autograd_inverse(self, x2: torch.Tensor, lat2=None):
+        """inverse_and_log_det_jacobian on fp32 rows [N, D] with a graph: the conditioner runs through torch's own
+        Linear layers (rocBLAS; only the rows of the last layer that parameterise transformed columns), the spline
+        and its backward are the HIP kernels behind ``RQSInverse``.  Returns (x_out [N, D], ldj [N])."""
+        from .spline import RQSInverse
+        sp, net = self.transform, self._net()
+        n, d = x2.shape
+        m = self.mask_vector(d)
+        live = np.nonzero(m <= 0.5)[0]
+        if len(live) == 0:
+            return x2, torch.zeros(n, dtype=torch.float32, device=x2.device)
+        key = ('autograd', d, str(x2.device))
+        if key not in self._programs:
+            P = sp.params_per_element
+            rows = (live[:, None] * P + np.arange(P)[None, :]).reshape(-1)
+            contiguous = np.array_equal(live, np.arange(live[0], live[0] + len(live)))
+            self._programs[key] = (torch.from_numpy(m.astype(np.float32)).to(x2.device),
+                                   torch.from_numpy(rows.astype(np.int64)).to(x2.device),
+                                   None if contiguous else torch.from_numpy(live.astype(np.int32)).to(x2.device))
+        mask_t, rows_t, live_idx = self._programs[key]
+        z = x2 * mask_t                                                              # coupling.py:61
+        if d == 1:
+            z = z * 0                                                                # coupling.py:62-63
+        if lat2 is not None:
+            z = torch.cat([z, lat2], -1)                                             # coupling.py:64-65
+        layers = list(net.net)
+        h = z
+        for layer in layers[:-1]:
+            h = layer(h)
+        last = layers[-1]
+        params = torch.nn.functional.linear(h, last.weight.index_select(0, rows_t), last.bias.index_select(0, rows_t))
+        return RQSInverse.apply(x2, params, live_idx, int(live[0]), len(live), sp.n_bins, sp.lower, sp.upper, 1.0)
+
     # ---- reference method set (coupling.py:69-95) -----------------------------------------------------------
     def forward(self, x, latent=None, reverse: bool = False, **kwargs):
         return self._run(x, latent, reverse, True, False)[0]

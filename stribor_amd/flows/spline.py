@@ -18,7 +18,7 @@ import torch.nn as nn
 from .. import _hip
 from ..flow import ElementwiseTransform, flatten_rows
 
-__all__ = ['Spline', 'run_rqs_kernel', 'run_cubic_kernel']
+__all__ = ['Spline', 'run_rqs_kernel', 'run_cubic_kernel', 'RQSInverse']
 
 _err_flags = {}
 
@@ -58,6 +58,40 @@ def run_rqs_kernel(x2, params, params_stride, live_idx, live_start, n_live, n_bi
                                     _hip.stream())
     _hip.check(rc, 'sx_rqs_coupling')
     return y, ldj, ldiag
+
+
+class RQSInverse(torch.autograd.Function):
+    """(x_out, row log-det) = inverse rational-quadratic spline of the live columns -- the direction log_prob
+    evaluates -- as a differentiable op: forward = sx_rqs_coupling(reverse=1), backward = sx_rqs_inverse_bwd (hand-written
+    reverse mode through rational_quadratic_spline.py:101-107,180-234).  Gradients flow to the input and to the
+    per-row parameter tensor [N, n_live*(3K-1)]; whatever produced the parameters (a conditioner evaluated with torch's
+    own Linear layers, or nn.Parameters) gets its gradient from autograd."""
+
+    @staticmethod
+    def forward(ctx, x2, params, live_idx, live_start, n_live, n_bins, lower, upper, ldj_scale):
+        x2 = x2.contiguous()
+        params = params.contiguous()
+        y, ldj, _ = run_rqs_kernel(x2, params, params.stride(0), live_idx, live_start, n_live, n_bins, lower, upper,
+                                   lower, upper, True, True, False, ldj_scale)
+        ctx.save_for_backward(x2, params)
+        ctx.meta = (live_idx, live_start, n_live, n_bins, float(lower), float(upper), float(ldj_scale))
+        return y, ldj
+
+    @staticmethod
+    def backward(ctx, gy, gldj):
+        x2, params = ctx.saved_tensors
+        live_idx, live_start, n_live, n_bins, lower, upper, ldj_scale = ctx.meta
+        n, d = x2.shape
+        gy = (torch.zeros_like(x2) if gy is None else gy).to(torch.float32).contiguous()
+        gldj = (torch.zeros(n, device=x2.device) if gldj is None else gldj).to(torch.float32).contiguous()
+        gx = gy.clone()                     # pass-through columns: y = x; the kernel overwrites the live columns
+        gparams = torch.empty_like(params)
+        rc = _hip.lib().sx_rqs_inverse_bwd(x2.data_ptr(), gy.data_ptr(), gldj.data_ptr(), params.data_ptr(),
+                                           params.stride(0), gx.data_ptr(), gparams.data_ptr(), _hip.ptr(live_idx),
+                                           live_start, n_live, n_bins, lower, upper, lower, upper, n, d, ldj_scale,
+                                           _hip.stream())
+        _hip.check(rc, 'sx_rqs_inverse_bwd')
+        return gx, gparams, None, None, None, None, None, None, None
 
 
 def run_cubic_kernel(x2, params, params_stride, live_idx, live_start, n_live, n_bins, lower, upper, reverse, want_ldj,
