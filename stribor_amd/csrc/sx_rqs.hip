@@ -710,16 +710,24 @@ __global__ __launch_bounds__(256) void rqs_inverse_bwd_kernel(const float *__res
     const float bconst = logf(expf(1.f - RQS_MIN_DERIV) - 1.f);
     const float norm = 1.f - RQS_MIN_BIN * (float)K;
     const float span_w = right - left, span_h = top - bottom;
+    const bool contig = pstride == (int64_t)n_live * P;
+    const float inv_P = 1.0f / (float)P;
     for (int64_t grp = (int64_t)blockIdx.x * waves_per_block + wave; grp < n_groups;
          grp += (int64_t)gridDim.x * waves_per_block) {
         const int64_t e0 = grp << 6;
         const int n_here = (int)((n_elem - e0) < 64 ? (n_elem - e0) : 64);
         const int total = n_here * P;
-        for (int idx = lane; idx < total; idx += 64) {
-            const int el = idx / P, q = idx - el * P;
-            const int64_t e = e0 + el;
-            const int64_t row = e / n_live;
-            sp[idx] = params[row * pstride + (int64_t)(e - row * n_live) * P + q];
+        if (contig && n_here == 64 && ((reinterpret_cast<uintptr_t>(params) & 15) == 0)) {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(params + e0 * P);     // 64*P floats = 16*P float4
+            f32x4 *dst = reinterpret_cast<f32x4 *>(sp);
+            for (int i4 = lane; i4 < 16 * P; i4 += 64) dst[i4] = src[i4];
+        } else {
+            for (int idx = lane; idx < total; idx += 64) {
+                const int el = (int)(((float)idx + 0.5f) * inv_P), q = idx - el * P;  // idx / P, exact for idx < 2^22
+                const int64_t e = e0 + el;
+                const int64_t row = e / n_live;
+                sp[idx] = params[row * pstride + (int64_t)(e - row * n_live) * P + q];
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -740,14 +748,21 @@ __global__ __launch_bounds__(256) void rqs_inverse_bwd_kernel(const float *__res
         float mw = uw[0], mh = uh[0];
         for (int k = 1; k < K; ++k) { mw = fmaxf(mw, uw[k]); mh = fmaxf(mh, uh[k]); }
         float sw = 0.f, sh = 0.f;
-        for (int k = 0; k < K; ++k) { sw += expf(uw[k] - mw); sh += expf(uh[k] - mh); }
+        for (int k = 0; k < K; ++k) {          // exp once per parameter, kept in place (v_exp_f32, compensated argument)
+            const float ew = cubic_exp(uw[k] - mw), eh = cubic_exp(uh[k] - mh);
+            uw[k] = ew;
+            uh[k] = eh;
+            sw += ew;
+            sh += eh;
+        }
+        const float inv_sw = 1.f / sw, inv_sh = 1.f / sh;
         int b = 0;
         float cw_b = left, ch_b = bottom, cw_n = right, ch_n = top;
         bool have_next = false;
         float csw = 0.f, csh = 0.f;
         for (int j = 1; j <= K; ++j) {
-            const float wk = RQS_MIN_BIN + norm * (expf(uw[j - 1] - mw) / sw);
-            const float hk = RQS_MIN_BIN + norm * (expf(uh[j - 1] - mh) / sh);
+            const float wk = RQS_MIN_BIN + norm * (uw[j - 1] * inv_sw);
+            const float hk = RQS_MIN_BIN + norm * (uh[j - 1] * inv_sh);
             csw += wk;
             csh += hk;
             const float kw = (j < K) ? span_w * csw + left : right;
@@ -817,7 +832,7 @@ __global__ __launch_bounds__(256) void rqs_inverse_bwd_kernel(const float *__res
         // softmax backward: du_i = p_i (G_i - sum_j G_j p_j), G_i = norm * dL/dw_i
         float dotw = 0.f, doth = 0.f;
         for (int k = 0; k < K; ++k) {
-            const float pw = expf(uw[k] - mw) / sw, ph = expf(uh[k] - mh) / sh;
+            const float pw = uw[k] * inv_sw, ph = uh[k] * inv_sh;
             dotw += pw * (k < b ? Gw_lo : (k == b ? Gw_b : 0.f));
             doth += ph * (k < b ? Gh_lo : (k == b ? Gh_b : 0.f));
         }
@@ -825,7 +840,7 @@ __global__ __launch_bounds__(256) void rqs_inverse_bwd_kernel(const float *__res
         const float g_ub = Adb * rqs_sigmoidf(u_b), g_un = Adn * rqs_sigmoidf(u_n);   // d softplus = sigmoid
         if (valid) {                       // (idle lanes of a ragged last group point at slice 0: they must not write)
             for (int k = 0; k < K; ++k) {
-                const float pw = expf(uw[k] - mw) / sw, ph = expf(uh[k] - mh) / sh;
+                const float pw = uw[k] * inv_sw, ph = uh[k] * inv_sh;
                 uw[k] = gate * norm * pw * ((k < b ? Gw_lo : (k == b ? Gw_b : 0.f)) - dotw);
                 uh[k] = gate * norm * ph * ((k < b ? Gh_lo : (k == b ? Gh_b : 0.f)) - doth);
             }
@@ -835,7 +850,13 @@ __global__ __launch_bounds__(256) void rqs_inverse_bwd_kernel(const float *__res
 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int idx = lane; idx < total; idx += 64) gparams[e0 * P + idx] = sp[idx];      // [n_rows, n_live * P], packed
+        if (n_here == 64 && ((reinterpret_cast<uintptr_t>(gparams) & 15) == 0)) {
+            f32x4 *dst = reinterpret_cast<f32x4 *>(gparams + e0 * P);             // [n_rows, n_live * P], packed
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(sp);
+            for (int i4 = lane; i4 < 16 * P; i4 += 64) dst[i4] = src[i4];
+        } else {
+            for (int idx = lane; idx < total; idx += 64) gparams[e0 * P + idx] = sp[idx];
+        }
     }
 }
 

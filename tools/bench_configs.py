@@ -62,14 +62,14 @@ def main():
         with torch.no_grad():
             ms = timed(lambda: flow.log_prob(x))
             lp = flow.log_prob(x)
-        if name == 'cfg2_f32' and '--train' in sys.argv:
+        if name in ('cfg2_f32', 'cfg3') and '--train' in sys.argv:
             def train_step():
                 for p_ in flow.parameters():
                     p_.grad = None
                 loss = -flow.log_prob(x).mean()
                 loss.backward()
             tms = timed(train_step, reps=5, inner=2)
-            print(json.dumps({'config': 'cfg2_f32 forward+backward (loss = -mean log_prob)', 'rows': rows,
+            print(json.dumps({'config': name + ' forward+backward (loss = -mean log_prob)', 'rows': rows,
                               'ms_per_batch': tms, 'rows_per_s': rows / (tms * 1e-3)}))
         print(json.dumps({'config': name, 'rows': rows, 'dim': dim, 'x_dtype': str(dt), 'fused_single_launch': fused,
                           'ms_per_batch': ms, 'rows_per_s': rows / (ms * 1e-3), 'finite': bool(torch.isfinite(lp).all()),
