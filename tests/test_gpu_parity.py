@@ -465,6 +465,14 @@ def test_coupling_with_deep_conditioner_and_other_activations():
 def test_full_size_properties_spline_and_linear_flows():
     """BASELINE cfg 3 and cfg 4 at N = 2^18 rows (kept below 2^20 only to bound test time): round trips,
     forward/inverse log-det antisymmetry, batch-split invariance, agreement with the oracle on a slice."""
+    torch.set_grad_enabled(False)        # inference properties: with a graph, spline flows take the layer-wise training path
+    try:
+        _full_size_properties_spline_and_linear()
+    finally:
+        torch.set_grad_enabled(True)
+
+
+def _full_size_properties_spline_and_linear():
     for name, desc, dim, tol_x, tol_l in [('cfg3', fd.cfg3_desc(), 64, 2e-3, 1e-3), ('cfg4', fd.cfg4_desc(), 128, 2e-2, 5e-3)]:
         torch.manual_seed(0)
         flow = fd.build_flow(st, desc, dim).to(DEV)
