@@ -89,6 +89,14 @@ int sx_affine_coupling(const void *x, void *y, float *ldj, const float *params, 
                        int32_t dim, int32_t dtype, int32_t reverse, int32_t ldj_accumulate,
                        float ldj_scale, void *stream);
 
+/* Backward of sx_affine_coupling for training (layer-wise autograd path; the single-launch backward of whole
+ * affine-coupling flows is the SX_STEP_COUPLING_AFFINE_BWD program): x, gy [n_rows, dim] fp32, gldj [n_rows];
+ * gx: live columns receive dL/dx; gparams [n_rows, 2*n_live] = (dL/dlog_scale | dL/dshift). */
+int sx_affine_coupling_bwd(const float *x, const float *gy, const float *gldj, const float *params,
+                           int64_t params_stride, float *gx, float *gparams, const int32_t *live_idx,
+                           int32_t live_start, int32_t n_live, int64_t n_rows, int32_t dim, int32_t reverse,
+                           float ldj_scale, void *stream);
+
 /* Rational-quadratic spline, element-wise part
  * (stribor/util/rational_quadratic_spline.py:11-251, util/search_sorted.py:3-5, flows/spline.py:82-86).
  *   params[n, i*(3K-1) + 0:K]    unnormalised widths  of live dim i

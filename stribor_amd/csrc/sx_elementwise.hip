@@ -173,6 +173,58 @@ extern "C" int sx_affine_coupling(const void *x, void *y, float *ldj, const floa
 }
 
 // ------------------------------------------------------------------------------------------------
+// Backward of sx_affine_coupling (training, layer-wise path): one lane per (row, live column) element.
+//   reverse:  y = (x - sh) e^{-ls}:  dx = gy e^{-ls},  dsh = -dx,  dls = -gy y + gldj * ldj_scale
+//   forward:  y = x e^{ls} + sh:     dx = gy e^{ls},   dsh = gy,   dls = gy x e^{ls} + gldj * ldj_scale
+// gx's pass-through columns are the caller's (a copy of gy); gparams has the layout of params (packed rows).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void affine_coupling_bwd_kernel(const float *__restrict__ x, const float *__restrict__ gy,
+                                                                  const float *__restrict__ gldj,
+                                                                  const float *__restrict__ params, int64_t pstride,
+                                                                  float *__restrict__ gx, float *__restrict__ gparams,
+                                                                  const int32_t *__restrict__ live_idx, int l0, int n_live,
+                                                                  int64_t n_rows, int dim, int reverse, float ldj_scale) {
+    const int64_t total = n_rows * n_live;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t row = e / n_live;
+        const int i = (int)(e - row * n_live);
+        const int col = live_idx ? live_idx[i] : l0 + i;
+        const float ls = params[row * pstride + i], sh = params[row * pstride + n_live + i];
+        const float xv = x[row * dim + col], g = gy[row * dim + col], gl = gldj[row] * ldj_scale;
+        float dx, dsh, dls;
+        if (reverse) {
+            const float e_ = expf(-ls);
+            dx = g * e_;
+            dsh = -dx;
+            dls = -g * ((xv - sh) * e_) + gl;
+        } else {
+            const float e_ = expf(ls);
+            dx = g * e_;
+            dsh = g;
+            dls = g * (xv * e_) + gl;
+        }
+        gx[row * dim + col] = dx;
+        gparams[row * 2 * n_live + i] = dls;
+        gparams[row * 2 * n_live + n_live + i] = dsh;
+    }
+}
+
+extern "C" int sx_affine_coupling_bwd(const float *x, const float *gy, const float *gldj, const float *params,
+                                      int64_t params_stride, float *gx, float *gparams, const int32_t *live_idx,
+                                      int32_t live_start, int32_t n_live, int64_t n_rows, int32_t dim, int32_t reverse,
+                                      float ldj_scale, void *stream) {
+    SX_REQUIRE(x && gy && gldj && params && gx && gparams, "sx_affine_coupling_bwd: null pointer");
+    SX_REQUIRE(dim > 0 && n_live > 0 && n_live <= dim && n_rows >= 0, "sx_affine_coupling_bwd: bad sizes");
+    if (n_rows == 0) return SX_OK;
+    const int grid = grid_for(n_rows * n_live, 256);
+    hipLaunchKernelGGL(affine_coupling_bwd_kernel, dim3(grid), dim3(256), 0, sx_stream(stream), x, gy, gldj, params,
+                       params_stride, gx, gparams, live_idx, live_start, n_live, n_rows, dim, reverse, ldj_scale);
+    SX_LAUNCH_CHECK();
+    return SX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // K7: Permute / Flip — bit-exact column gather                 (stribor/flows/permute.py:35,38,71,75)
 // ------------------------------------------------------------------------------------------------
 template <typename T>

@@ -29,6 +29,34 @@ def run_affine_kernel(x2, params, params_stride, live_idx, live_start, n_live, r
     return y, ldj
 
 
+class AffineCouplingOp(torch.autograd.Function):
+    """(y, row log-det) of the element-wise affine map on the live columns as a differentiable op (layer-wise training
+    path): forward = sx_affine_coupling, backward = sx_affine_coupling_bwd.  params = [N, 2*n_live] (log_scale | shift)."""
+
+    @staticmethod
+    def forward(ctx, x2, params, live_idx, live_start, n_live, reverse, ldj_scale):
+        x2, params = x2.contiguous(), params.contiguous()
+        y, ldj = run_affine_kernel(x2, params, params.stride(0), live_idx, live_start, n_live, reverse, True, True, ldj_scale)
+        ctx.save_for_backward(x2, params)
+        ctx.meta = (live_idx, live_start, n_live, bool(reverse), float(ldj_scale))
+        return y, ldj
+
+    @staticmethod
+    def backward(ctx, gy, gldj):
+        x2, params = ctx.saved_tensors
+        live_idx, live_start, n_live, reverse, ldj_scale = ctx.meta
+        n, d = x2.shape
+        gy = (torch.zeros_like(x2) if gy is None else gy).to(torch.float32).contiguous()
+        gldj = (torch.zeros(n, device=x2.device) if gldj is None else gldj).to(torch.float32).contiguous()
+        gx = gy.clone()
+        gparams = torch.empty_like(params)
+        rc = _hip.lib().sx_affine_coupling_bwd(x2.data_ptr(), gy.data_ptr(), gldj.data_ptr(), params.data_ptr(),
+                                               params.stride(0), gx.data_ptr(), gparams.data_ptr(), _hip.ptr(live_idx),
+                                               live_start, n_live, n, d, int(reverse), ldj_scale, _hip.stream())
+        _hip.check(rc, 'sx_affine_coupling_bwd')
+        return gx, gparams, None, None, None, None, None
+
+
 class Affine(ElementwiseTransform):
     def __init__(self, dim: int, *, latent_net: Optional[nn.Module] = None, scale=None, shift=None, **kwargs):
         super().__init__()

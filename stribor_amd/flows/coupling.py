@@ -163,15 +163,20 @@ class Coupling(Transform):
     # ---- training (autograd): spline couplings, inverse direction --------------------------------------------------
     def _autograd_supported(self) -> bool:
         from .spline import Spline
-        return isinstance(self.transform, Spline) and self.transform.spline_type == 'quadratic' and \
-            isinstance(getattr(self.transform, 'latent_net', None), MLP)
+        if not isinstance(getattr(self.transform, 'latent_net', None), MLP):
+            return False
+        return isinstance(self.transform, Affine) or \
+            (isinstance(self.transform, Spline) and self.transform.spline_type == 'quadratic')
 
     def _autograd_inverse(self, x2: torch.Tensor, lat2=None):
         """inverse_and_log_det_jacobian on fp32 rows [N, D] with a graph: the conditioner runs through torch's own
-        Linear layers (rocBLAS; only the rows of the last layer that parameterise transformed columns), the spline
-        and its backward are the HIP kernels behind ``RQSInverse``.  Returns (x_out [N, D], ldj [N])."""
-        from .spline import RQSInverse
+        Linear layers (rocBLAS; only the rows of the last layer that parameterise transformed columns), the transform
+        and its backward are the HIP kernels behind ``RQSInverse`` / ``AffineCouplingOp``.
+        Returns (x_out [N, D], ldj [N])."""
+        from .spline import RQSInverse, Spline
+        from .affine import AffineCouplingOp
         sp, net = self.transform, self._net()
+        is_spline = isinstance(sp, Spline)
         n, d = x2.shape
         m = self.mask_vector(d)
         live = np.nonzero(m <= 0.5)[0]
@@ -179,8 +184,11 @@ class Coupling(Transform):
             return x2, torch.zeros(n, dtype=torch.float32, device=x2.device)
         key = ('autograd', d, str(x2.device))
         if key not in self._programs:
-            P = sp.params_per_element
-            rows = (live[:, None] * P + np.arange(P)[None, :]).reshape(-1)
+            if is_spline:
+                P = sp.params_per_element
+                rows = (live[:, None] * P + np.arange(P)[None, :]).reshape(-1)      # spline.py:82-86
+            else:
+                rows = np.concatenate([live, d + live])                               # affine.py:66 (log_scale | shift)
             contiguous = np.array_equal(live, np.arange(live[0], live[0] + len(live)))
             self._programs[key] = (torch.from_numpy(m.astype(np.float32)).to(x2.device),
                                    torch.from_numpy(rows.astype(np.int64)).to(x2.device),
@@ -197,7 +205,10 @@ class Coupling(Transform):
             h = layer(h)
         last = layers[-1]
         params = torch.nn.functional.linear(h, last.weight.index_select(0, rows_t), last.bias.index_select(0, rows_t))
-        return RQSInverse.apply(x2, params, live_idx, int(live[0]), len(live), sp.n_bins, sp.lower, sp.upper, 1.0)
+        if is_spline:
+            return RQSInverse.apply(x2, params, live_idx, int(live[0]), len(live), sp.n_bins, sp.lower, sp.upper, 1.0)
+        # Transform.inverse_and_log_det_jacobian: minus the forward log-det (flow.py:47)
+        return AffineCouplingOp.apply(x2, params, live_idx, int(live[0]), len(live), True, -1.0)
 
     # ---- reference method set (coupling.py:69-95) -----------------------------------------------------------
     def forward(self, x, latent=None, reverse: bool = False, **kwargs):

@@ -204,3 +204,50 @@ def test_backward_dense_masks_and_small_dims(dim, mask, hidden):
         ref = want_g[name].float()
         assert not torch.isnan(p.grad).any()                                     # base.py:76-81
         assert (p.grad.cpu() - ref).abs().max().item() <= 2e-4 * (ref.abs().max().item() + 1e-12) + 1e-7, name
+
+
+def test_layerwise_backward_conditional_and_mixed_flows():
+    """Layer-wise training path (AffineCouplingOp / RQSInverse + torch conditioners): a conditional affine flow
+    (latent input, deep conditioner), and a flow mixing affine couplings, spline couplings, Permute and Flip --
+    input, latent and parameter gradients against fp64 autograd of the oracle."""
+    torch.manual_seed(21)
+    cases = [
+        ('conditional affine', [{'kind': 'coupling_affine', 'dim': 6, 'hidden': [16, 16], 'latent_dim': 3,
+                                 'mask': 'ordered_right_half' if i % 2 == 0 else 'parity_odd'} for i in range(3)], 6, 3),
+        ('mixed', [{'kind': 'coupling_affine', 'dim': 10, 'hidden': [24], 'latent_dim': 0, 'mask': 'ordered_left_half'},
+                   {'kind': 'permute', 'dim': 10},
+                   {'kind': 'coupling_rqs', 'dim': 10, 'hidden': [24], 'n_bins': 6, 'lower': -3, 'upper': 3,
+                    'mask': 'parity_even', 'latent_dim': 0},
+                   {'kind': 'flip'},
+                   {'kind': 'coupling_affine', 'dim': 10, 'hidden': [24], 'latent_dim': 0, 'mask': 'parity_odd'}], 10, 0),
+    ]
+    for name, desc, dim, ld in cases:
+        flow = fd.build_flow(st, desc, dim)
+        state = {k: v.clone() for k, v in flow.state_dict().items()}
+        for i, (d, f) in enumerate(zip(desc, flow.transforms)):
+            if d['kind'] == 'permute':
+                state[f'transforms.{i}.permutation'] = f.permutation.clone()
+        flow = flow.to(DEV)
+        n = 200
+        x = torch.randn(n, dim) * 1.3
+        lat = torch.randn(n, ld) if ld else None
+        leaves = {k: (v.detach().double().clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in state.items()}
+        spec = fd.flow_spec(desc, leaves)
+        xin = x.double().clone().requires_grad_(True)
+        lin = None if lat is None else lat.double().clone().requires_grad_(True)
+        want_loss = -orc.flow_log_prob(spec, xin, latent=lin).mean()
+        want_loss.backward()
+        xg = x.to(DEV).requires_grad_(True)
+        lg = None if lat is None else lat.to(DEV).requires_grad_(True)
+        lp = flow.log_prob(xg) if lg is None else flow.log_prob(xg, latent=lg)
+        assert lp.requires_grad, name
+        loss = -lp.mean()
+        loss.backward()
+        assert abs(loss.item() - want_loss.item()) <= 1e-5 * abs(want_loss.item()) + 1e-5, name
+        tol = lambda ref: 3e-4 * ref.abs().max().item() + 1e-7
+        assert (xg.grad.cpu() - xin.grad.float()).abs().max().item() <= tol(xin.grad), name
+        if lg is not None:
+            assert (lg.grad.cpu() - lin.grad.float()).abs().max().item() <= tol(lin.grad), name
+        for pname, p in flow.named_parameters():
+            ref = leaves[pname].grad.float()
+            assert (p.grad.cpu() - ref).abs().max().item() <= tol(ref), (name, pname)
