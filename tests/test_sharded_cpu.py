@@ -43,6 +43,11 @@ def _worker(rank, world, port, q):
         sh = ShardedLogProb(group=None, local_sum=local_sum)
         lo, hi = sh.my_rows(x.shape[0])
         total = sh.log_prob_sum(x[lo:hi])
+        # pipelined form (bench.py): several batches in flight, each with its own result buffer
+        outs = [torch.zeros(1, dtype=torch.float64) for _ in range(3)]
+        pend = [sh.log_prob_sum_async(x[lo:hi], o) for o in outs]
+        for p in pend:
+            assert abs(p.wait().item() - total.item()) <= 1e-12 * abs(total.item())
         q.put((rank, lo, hi, total.item()))
     finally:
         dist.destroy_process_group()
