@@ -673,3 +673,21 @@ def test_pointwise_vec4_path_against_oracle():
     xb16 = torch.randn(129, 64).to(torch.bfloat16)
     yb = st.Sigmoid().to(DEV)(xb16.to(DEV))
     close(yb.float(), torch.sigmoid(xb16.float()).to(torch.bfloat16).float(), rtol=1e-2, atol=1e-2)
+
+
+def test_pure_coupling_flow_d128_against_oracle():
+    """D = 128 RealNVP (pure split-coupling program at 4 tiles: 8-wave workgroups, 2 waves per SIMD) vs the oracle,
+    both directions."""
+    torch.manual_seed(3)
+    desc = fd.cfg2_desc(6, 128, 64)
+    flow = fd.build_flow(st, desc, 128)
+    spec = fd.flow_spec(desc, {k: v.clone() for k, v in flow.state_dict().items()})
+    flow = flow.to(DEV)
+    x = torch.randn(1000, 128)
+    with torch.no_grad():
+        close(flow.log_prob(x.to(DEV)), orc.flow_log_prob(spec, x), rtol=1e-5, atol=1e-4)
+        y, ldj = flow.forward_and_log_det_jacobian(x.to(DEV))
+        wy, wl = orc.flow_forward_and_ldj(spec, x)
+        close(y, wy, rtol=1e-5, atol=2e-5)
+        close(ldj, wl, rtol=1e-5, atol=1e-4)
+        close(flow.inverse(y), x, rtol=1e-4, atol=1e-4)
