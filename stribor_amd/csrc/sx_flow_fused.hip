@@ -45,8 +45,9 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
             case SX_STEP_MLP_HIDDEN2: need = sx_packed_linear_floats(p->h_tiles, p->h_tiles); *mlp_mode = 1; break;
             case SX_STEP_MLP_OUT_TILE: need = sx_packed_linear_floats(1, p->h_tiles); *mlp_mode = 1; break;
             case SX_STEP_LINEAR_TILE:
-                SX_REQUIRE(s.t0 < p->x_tiles, "sx_flow_run: step %d: linear slab %d out of range", i, s.t0);
-                need = sx_packed_linear_floats(1, p->tiles); lin = true; break;
+                SX_REQUIRE(s.t0 >= 0 && s.act >= 0 && s.t0 + (s.act ? s.act : 1) <= p->x_tiles,
+                           "sx_flow_run: step %d: linear slabs [%d, +%d) out of range", i, s.t0, s.act ? s.act : 1);
+                need = sx_packed_linear_floats(s.act ? s.act : 1, p->tiles); lin = true; break;
             case SX_STEP_ROW_SCALE_EXP: need = 32 * p->tiles; lin = true; break;
             case SX_STEP_COUPLING_AFFINE_BWD: {
                 SX_REQUIRE((p->tiles == 2 || p->tiles == 4) && p->x_tiles * 2 == p->tiles,

@@ -1052,13 +1052,24 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                 case SX_STEP_LINEAR_TILE:
                     // one 32-row slab of y = M . x + b (AffineLU affine.py:157,159-163; MatrixExponential
                     // affine.py:243-270 with the triangular solves folded into M on the host, in fp64)
+                    // act = number of slabs in this step (0: one; the planner packs the whole layer into one step when
+                    // its matrix fits the LDS ring: one barrier and one weight refill per layer instead of per slab)
                     if constexpr (MODE == 2) {
-                        tile<NS> acc = load_cfrag<NS>(w.cb, TX * 1024);
+                        const int nsl = st.act ? st.act : 1;
+                        btile<NS> bx[TX];                   // the state's B operands, formed once for all slabs
 #pragma unroll
-                        for (int c = 0; c < TX; ++c) gemm_tile<NS>(w.wb, c * 1024, make_btile<NS>(xs[c]), acc);
+                        for (int c = 0; c < TX; ++c) bx[c] = make_btile<NS>(xs[c]);
 #pragma unroll
-                        for (int t = 0; t < TX; ++t)
-                            if (t == st.t0) xnew[t] = acc;
+                        for (int m = 0; m < TX; ++m) {
+                            if (m < nsl) {
+                                tile<NS> acc = load_cfrag<NS>(w.cb, nsl * TX * 1024 + m * 32);
+#pragma unroll
+                                for (int c = 0; c < TX; ++c) gemm_tile<NS>(w.wb, (m * TX + c) * 1024, bx[c], acc);
+#pragma unroll
+                                for (int t = 0; t < TX; ++t)
+                                    if (t == st.t0 + m) xnew[t] = acc;
+                            }
+                        }
                         if (st.tt) {   // last slab: commit
 #pragma unroll
                             for (int t = 0; t < TX; ++t)

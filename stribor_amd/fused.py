@@ -89,7 +89,7 @@ class _DerivedLinearJob:
     device, recomputed (in fp64 inside fn) only when a source parameter changes, then packed slab by slab."""
 
     def __init__(self, sources, fn, targets):
-        self.sources, self.fn, self.targets = list(sources), fn, targets   # targets: [(row_idx, col_idx, k_tiles, off)]
+        self.sources, self.fn, self.targets = list(sources), fn, targets   # targets: [(row_idx, col_idx, k_tiles, off, m_tiles)]
         self._dev_idx = None
         self._keep = None
 
@@ -101,10 +101,10 @@ class _DerivedLinearJob:
         self._keep = (W, b)                      # stays alive until the async pack kernels have run
         if self._dev_idx is None:
             self._dev_idx = [(torch.from_numpy(r.astype(np.int32)).to(dev), torch.from_numpy(c.astype(np.int32)).to(dev))
-                             for (r, c, _, _) in self.targets]
-        for (ri, ci), (_, _, k_tiles, off) in zip(self._dev_idx, self.targets):
+                             for (r, c, _, _, _) in self.targets]
+        for (ri, ci), (_, _, k_tiles, off, m_tiles) in zip(self._dev_idx, self.targets):
             rc = _hip.lib().sx_pack_linear(W.data_ptr(), _hip.ptr(b), W.shape[0], W.shape[1], ri.data_ptr(),
-                                           ci.data_ptr(), 1, k_tiles, None, None, 0.0, 0,
+                                           ci.data_ptr(), m_tiles, k_tiles, None, None, 0.0, 0,
                                            blobs.data_ptr() + 4 * off, _hip.stream())
             _hip.check(rc, 'sx_pack_linear')
 
@@ -542,22 +542,31 @@ class ProgramBuilder:
                                blob_off=off, blob_floats=n, ldj_scale=ldj_scale, ldj_const=0.0))
 
     def add_linear(self, sources, fn, ldj_const: float) -> None:
-        """y = W . x + b on the data columns (W, b = fn(device), torch Linear layout [out, in]); one
-        LINEAR_TILE step per 32 output slots, the last one commits."""
+        """y = W . x + b on the data columns (W, b = fn(device), torch Linear layout [out, in]): one LINEAR_TILE step
+        for the whole layer when its packed matrix fits the LDS ring twice, else one step per 32 output slots (the last
+        one commits)."""
         self._freeze_input()
         D, T = self.dim, self.tiles
         col = self.col_of_slot
         col_idx = np.full(32 * T, -1, dtype=np.int64)
         col_idx[:self.n_slots] = col                       # input slot -> W column (= logical column)
         targets = []
-        first = len(self.steps)
-        for t in range(self.x_tiles):
-            row_idx = col[32 * t:32 * t + 32].copy()       # output slot keeps its logical column
-            off, n = self._alloc(_hip.packed_linear_floats(1, T))
-            targets.append((row_idx, col_idx, T, off))
-            self.steps.append(dict(kind=_hip.STEP_LINEAR_TILE, c0=0, ct=T, t0=t, tt=int(t == self.x_tiles - 1),
-                                   reverse=0, act=0, blob_off=off, blob_floats=n, ldj_scale=0.0,
-                                   ldj_const=ldj_const if t == 0 else 0.0))
+        XT = self.x_tiles
+        if _hip.packed_linear_floats(XT, T) * 8 + 16 <= 150 * 1024:
+            # the whole layer in ONE step (all output slabs, one barrier / one weight refill): act = number of slabs
+            row_idx = col[:32 * XT].copy()                 # output slot keeps its logical column
+            off, n = self._alloc(_hip.packed_linear_floats(XT, T))
+            targets.append((row_idx, col_idx, T, off, XT))
+            self.steps.append(dict(kind=_hip.STEP_LINEAR_TILE, c0=0, ct=T, t0=0, tt=1, reverse=0, act=XT, blob_off=off,
+                                   blob_floats=n, ldj_scale=0.0, ldj_const=ldj_const))
+        else:
+            for t in range(XT):
+                row_idx = col[32 * t:32 * t + 32].copy()
+                off, n = self._alloc(_hip.packed_linear_floats(1, T))
+                targets.append((row_idx, col_idx, T, off, 1))
+                self.steps.append(dict(kind=_hip.STEP_LINEAR_TILE, c0=0, ct=T, t0=t, tt=int(t == XT - 1),
+                                       reverse=0, act=0, blob_off=off, blob_floats=n, ldj_scale=0.0,
+                                       ldj_const=ldj_const if t == 0 else 0.0))
         self.jobs.append(_DerivedLinearJob(sources, fn, targets))
 
     def add_row_scale_exp(self, diag, reverse: bool, ldj_scale: float, log_time: bool, t_const: float) -> None:
