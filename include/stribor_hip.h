@@ -196,9 +196,8 @@ int sx_pack_linear(const float *W, const float *b, int32_t out_dim, int32_t in_d
                                            blob = pack_linear(W1: h_tiles x ct) ++ pack_linear(W2: per transformed tile 32 log_scale
                                            rows then 32 shift rows, x h_tiles); act = SX_ACT_* or SX_ACT_TANH_FOLDED          */
 #define SX_STEP_AFFINE_CONST         2  /* st.Affine without latent_net: blob = ls[tiles][2][16] ++ sh[tiles][2][16] (C-fragment) */
-#define SX_STEP_LINEAR_TILE          3  /* blob = pack_linear(M, n m-tiles x tiles), n = act ? act : 1: new tiles t0 .. t0+n-1 =
-                                           M[slab] . state + bias; tt != 0 on the last slab commits the new tiles as the state
-                                           (AffineLU, MatrixExponential; act = x_tiles does the whole layer in one step)         */
+#define SX_STEP_LINEAR_TILE          3  /* blob = pack_linear(M, x_tiles m-tiles x tiles): state = M . state + bias, the whole layer
+                                           in one step (act = x_tiles, t0 = 0; AffineLU, MatrixExponential)                       */
 #define SX_STEP_MLP_HIDDEN           5  /* blob = pack_linear(W, h_tiles x tiles): hidden = act(W . state + b)  (mlp.py:65)       */
 #define SX_STEP_MLP_HIDDEN2          6  /* blob = pack_linear(W, h_tiles x h_tiles): hidden' = act(W . hidden + b)                 */
 #define SX_STEP_MLP_OUT_TILE         7  /* blob = pack_linear(W, 1 x h_tiles): mlp_out[:, 32*t0 ..] = W[t0] . hidden + b            */

@@ -45,9 +45,9 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
             case SX_STEP_MLP_HIDDEN2: need = sx_packed_linear_floats(p->h_tiles, p->h_tiles); *mlp_mode = 1; break;
             case SX_STEP_MLP_OUT_TILE: need = sx_packed_linear_floats(1, p->h_tiles); *mlp_mode = 1; break;
             case SX_STEP_LINEAR_TILE:
-                SX_REQUIRE(s.t0 >= 0 && s.act >= 0 && s.t0 + (s.act ? s.act : 1) <= p->x_tiles,
-                           "sx_flow_run: step %d: linear slabs [%d, +%d) out of range", i, s.t0, s.act ? s.act : 1);
-                need = sx_packed_linear_floats(s.act ? s.act : 1, p->tiles); lin = true; break;
+                SX_REQUIRE(s.t0 == 0 && s.act == p->x_tiles,
+                           "sx_flow_run: step %d: a linear step covers all %d output slabs (act = x_tiles, t0 = 0)", i, p->x_tiles);
+                need = sx_packed_linear_floats(p->x_tiles, p->tiles); lin = true; break;
             case SX_STEP_ROW_SCALE_EXP: need = 32 * p->tiles; lin = true; break;
             case SX_STEP_COUPLING_AFFINE_BWD: {
                 SX_REQUIRE((p->tiles == 2 || p->tiles == 4) && p->x_tiles * 2 == p->tiles,
@@ -97,17 +97,22 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     // MODE 5 / 6: nothing but tanh-folded affine couplings on half the tiles conditioned on the other half, all in
     // one direction (5 reverse, 6 forward) -- the plain RealNVP log_prob / sample program.  Its kernel carries two
     // straight-line arms only, which keeps the state in place (no phi copies) at 130 VGPRs.
-    if (*mlp_mode == 0 && p->n_steps > 0 && p->tiles >= 2) {
-        bool pure = true;
+    // MODE 7 / 8: the same couplings interleaved with dense linear layers (AffineLU / MatrixExponential -- cfg 4).
+    if ((*mlp_mode == 0 || *mlp_mode == 2) && p->n_steps > 0 && p->tiles >= 2) {
+        bool pure = true, any = false;
+        int dir = -1;
         const int T = p->tiles;
         for (int i = 0; i < p->n_steps && pure; ++i) {
             const sx_step &s = p->steps[i];
+            if (s.kind == SX_STEP_LINEAR_TILE || s.kind == SX_STEP_ROW_SCALE_EXP) { pure = *mlp_mode == 2; continue; }
             const bool low = s.c0 == 0 && s.ct == T / 2 && s.t0 == T / 2 && s.tt == T / 2;
             const bool high = s.c0 == T / 2 && s.ct == T / 2 && s.t0 == 0 && s.tt == T / 2;
+            if (dir < 0) dir = s.reverse != 0;
             pure = s.kind == SX_STEP_COUPLING_AFFINE && s.act == SX_ACT_TANH_FOLDED && (low || high) &&
-                   (s.reverse != 0) == (p->steps[0].reverse != 0);
+                   (s.reverse != 0) == (dir != 0);
+            any = true;
         }
-        if (pure && !getenv("SX_NO_PURE_MODE")) *mlp_mode = p->steps[0].reverse ? 5 : 6;
+        if (pure && any && !getenv("SX_NO_PURE_MODE")) *mlp_mode = (*mlp_mode == 2 ? 7 : 5) + (dir ? 0 : 1);
     }
     SX_REQUIRE((size_t)mx * 8 <= 160 * 1024, "sx_flow_run: a step needs %d B of LDS per buffer (> 80 KiB)", mx * 4);
     return SX_OK;

@@ -960,7 +960,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
         for (int n = 0; n < NS; ++n) ldj[n] = 0.f;
         float ldj_c = 0.f;
         tile<NS> hid[MODE == 1 ? HT : 1];
-        tile<NS> xnew[MODE == 2 ? TX : 1];
+        constexpr bool LIN = MODE == 2 || MODE == 7 || MODE == 8;    // programs with dense linear layers
         btile<1> rq_bh[MODE == 3 ? HT : 1];      // MODE 3 (spline couplings): hidden B operands + group state
         rqs_elems rq_e;
 
@@ -994,10 +994,16 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     if (st.c0 == 0) coupling_affine<NS, TX, HT, 0, TX / 2, TX / 2, TX / 2, true, MODE == 5>(xs, w, st, ldj, pf);
                     else coupling_affine<NS, TX, HT, TX / 2, TX / 2, 0, TX / 2, true, MODE == 5>(xs, w, st, ldj, pf);
                 }
+            } else if ((MODE == 7 || MODE == 8) && st.kind == SX_STEP_COUPLING_AFFINE) {
+                // dense linear layers + pure split couplings (cfg 4): the same two arms instead of the general dispatch
+                if constexpr (TX >= 2 && (MODE == 7 || MODE == 8)) {
+                    if (st.c0 == 0) coupling_affine<NS, TX, HT, 0, TX / 2, TX / 2, TX / 2, true, MODE == 7>(xs, w, st, ldj, pf);
+                    else coupling_affine<NS, TX, HT, TX / 2, TX / 2, 0, TX / 2, true, MODE == 7>(xs, w, st, ldj, pf);
+                }
             } else
             switch (st.kind) {
                 case SX_STEP_COUPLING_AFFINE:
-                    if constexpr (MODE == 3) break;      // spline programs carry no affine couplings (register budget)
+                    if constexpr (MODE == 3 || MODE == 7 || MODE == 8) break;   // spline programs carry no affine couplings (register budget); 7 / 8: handled above
                     if constexpr (TX >= 2) {
                         if (st.ct == TX / 2 && st.c0 == 0 && st.t0 == TX / 2) {          // cond = low tiles
                             coupling_affine_dispatch<NS, TX, HT, 0, TX / 2, TX / 2, TX / 2>(xs, w, st, ldj, pf);
@@ -1011,7 +1017,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     coupling_affine_dispatch<NS, TX, HT, 0, TX, 0, TX>(xs, w, st, ldj, pf);       // dense
                     break;
                 case SX_STEP_AFFINE_CONST:
-                    affine_const<NS, TX>(xs, w, st, x_tiles, ldj);
+                    if constexpr (MODE != 7 && MODE != 8) affine_const<NS, TX>(xs, w, st, x_tiles, ldj);
                     break;
                 case SX_STEP_MLP_HIDDEN:
                     if constexpr (MODE == 1) hidden_layer<NS, TX, HT, 0, TX, false>(xs, hid, w, 0, st.act);
@@ -1052,28 +1058,22 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                 case SX_STEP_LINEAR_TILE:
                     // one 32-row slab of y = M . x + b (AffineLU affine.py:157,159-163; MatrixExponential
                     // affine.py:243-270 with the triangular solves folded into M on the host, in fp64)
-                    // act = number of slabs in this step (0: one; the planner packs the whole layer into one step when
-                    // its matrix fits the LDS ring: one barrier and one weight refill per layer instead of per slab)
-                    if constexpr (MODE == 2) {
-                        const int nsl = st.act ? st.act : 1;
-                        btile<NS> bx[TX];                   // the state's B operands, formed once for all slabs
+                    // The whole layer is one step (its packed matrix always fits the LDS ring: <= 4 x 4 tiles): the
+                    // state's fp16 hi/lo B operands are formed once and hold the complete old state, so every output
+                    // slab is written straight over the state tile it replaces -- no second copy of the state.
+                    if constexpr (LIN) {
+                        btile<NS> bx[TX];
 #pragma unroll
                         for (int c = 0; c < TX; ++c) bx[c] = make_btile<NS>(xs[c]);
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int m = 0; m < TX; ++m) {
-                            if (m < nsl) {
-                                tile<NS> acc = load_cfrag<NS>(w.cb, nsl * TX * 1024 + m * 32);
+                            if (m < x_tiles) {
+                                tile<NS> acc = load_cfrag<NS>(w.cb, x_tiles * TX * 1024 + m * 32);
 #pragma unroll
                                 for (int c = 0; c < TX; ++c) gemm_tile<NS>(w.wb, (m * TX + c) * 1024, bx[c], acc);
-#pragma unroll
-                                for (int t = 0; t < TX; ++t)
-                                    if (t == st.t0 + m) xnew[t] = acc;
+                                xs[m] = acc;
                             }
-                        }
-                        if (st.tt) {   // last slab: commit
-#pragma unroll
-                            for (int t = 0; t < TX; ++t)
-                                if (t < x_tiles) xs[t] = xnew[t];
                         }
                     }
                     break;
@@ -1112,7 +1112,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     break;
                 case SX_STEP_ROW_SCALE_EXP:
                     // x *= exp(+-diag * t_row)  (affine.py:263), t_row optionally log1p|t| (affine.py:239-240)
-                    if constexpr (MODE == 2) {
+                    if constexpr (LIN) {
 #pragma unroll
                         for (int n = 0; n < NS; ++n) {
                             float tr = k.row_t != nullptr ? k.row_t[lrow[n]] : st.ldj_const;
@@ -1264,6 +1264,8 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
     else if (a.mlp_mode == 4) SX_FL(4);
     else if (a.mlp_mode == 5) { if constexpr (TX >= 2) SX_FL(5); }
     else if (a.mlp_mode == 6) { if constexpr (TX >= 2) SX_FL(6); }
+    else if (a.mlp_mode == 7) { if constexpr (TX >= 2) SX_FL(7); }
+    else if (a.mlp_mode == 8) { if constexpr (TX >= 2) SX_FL(8); }
     else SX_FL(0);
 #undef SX_FL
     SX_LAUNCH_CHECK();

@@ -543,30 +543,20 @@ class ProgramBuilder:
 
     def add_linear(self, sources, fn, ldj_const: float) -> None:
         """y = W . x + b on the data columns (W, b = fn(device), torch Linear layout [out, in]): one LINEAR_TILE step
-        for the whole layer when its packed matrix fits the LDS ring twice, else one step per 32 output slots (the last
-        one commits)."""
+        for the whole layer."""
         self._freeze_input()
         D, T = self.dim, self.tiles
         col = self.col_of_slot
         col_idx = np.full(32 * T, -1, dtype=np.int64)
         col_idx[:self.n_slots] = col                       # input slot -> W column (= logical column)
-        targets = []
         XT = self.x_tiles
-        if _hip.packed_linear_floats(XT, T) * 8 + 16 <= 150 * 1024:
-            # the whole layer in ONE step (all output slabs, one barrier / one weight refill): act = number of slabs
-            row_idx = col[:32 * XT].copy()                 # output slot keeps its logical column
-            off, n = self._alloc(_hip.packed_linear_floats(XT, T))
-            targets.append((row_idx, col_idx, T, off, XT))
-            self.steps.append(dict(kind=_hip.STEP_LINEAR_TILE, c0=0, ct=T, t0=0, tt=1, reverse=0, act=XT, blob_off=off,
-                                   blob_floats=n, ldj_scale=0.0, ldj_const=ldj_const))
-        else:
-            for t in range(XT):
-                row_idx = col[32 * t:32 * t + 32].copy()
-                off, n = self._alloc(_hip.packed_linear_floats(1, T))
-                targets.append((row_idx, col_idx, T, off, 1))
-                self.steps.append(dict(kind=_hip.STEP_LINEAR_TILE, c0=0, ct=T, t0=t, tt=int(t == XT - 1),
-                                       reverse=0, act=0, blob_off=off, blob_floats=n, ldj_scale=0.0,
-                                       ldj_const=ldj_const if t == 0 else 0.0))
+        # the whole layer in ONE step (all output slabs, one barrier / one weight refill; at most 4 x 4 tiles = 64 KiB,
+        # which fits the LDS ring twice): act = number of slabs
+        row_idx = col[:32 * XT].copy()                     # output slot keeps its logical column
+        off, n = self._alloc(_hip.packed_linear_floats(XT, T))
+        targets = [(row_idx, col_idx, T, off, XT)]
+        self.steps.append(dict(kind=_hip.STEP_LINEAR_TILE, c0=0, ct=T, t0=0, tt=1, reverse=0, act=XT, blob_off=off,
+                               blob_floats=n, ldj_scale=0.0, ldj_const=ldj_const))
         self.jobs.append(_DerivedLinearJob(sources, fn, targets))
 
     def add_row_scale_exp(self, diag, reverse: bool, ldj_scale: float, log_time: bool, t_const: float) -> None:
