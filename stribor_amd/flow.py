@@ -266,13 +266,12 @@ class NormalizingFlow(Transform):
         except NotImplementedError:
             return False
 
-    # ---- training, layer by layer: flows of quadratic-spline couplings (+ Permute / Flip) ---------------------
+    # ---- training, layer by layer: couplings (affine / quadratic spline), element-wise Affine / Spline, Permute / Flip ----
     def _layerwise_autograd_ok(self) -> bool:
-        from .flows.coupling import Coupling
         from .flows.permute import _ColumnShuffle
-        ok = [isinstance(f, _ColumnShuffle) or (isinstance(f, Coupling) and f._autograd_supported())
+        ok = [isinstance(f, _ColumnShuffle) or (hasattr(f, '_autograd_supported') and f._autograd_supported())
               for f in self.transforms]
-        return all(ok) and any(isinstance(f, Coupling) for f in self.transforms)
+        return all(ok) and any(not isinstance(f, _ColumnShuffle) for f in self.transforms)
 
     def _log_prob_layerwise_autograd(self, y, latent=None):
         """log_prob with a graph for spline-coupling flows: each layer's spline (and its backward) is a HIP kernel,

@@ -125,6 +125,26 @@ class Affine(ElementwiseTransform):
             ls = ls.reshape(1, -1).expand(x2.shape[0], -1)
         return ls.reshape(*lead, x2.shape[1])
 
+    # ---- training (layer-wise autograd path) ---------------------------------------------------------------------
+    def _autograd_supported(self) -> bool:
+        from ..net.mlp import MLP
+        return self.latent_net is None or isinstance(self.latent_net, MLP)
+
+    def _autograd_inverse(self, x2: torch.Tensor, lat2=None):
+        """inverse_and_log_det_jacobian on fp32 rows with a graph (AffineCouplingOp over all columns); the parameters
+        are the module's own (broadcast over the rows) or the latent_net's output through torch's Linear layers."""
+        n, d = x2.shape
+        if self.latent_net is None:
+            ls, sh = self.log_scale.reshape(-1), self.shift.reshape(-1)
+            if ls.numel() == 1:
+                ls, sh = ls.expand(d), sh.expand(d)
+            params = torch.cat([ls, sh]).to(device=x2.device, dtype=torch.float32).unsqueeze(0).expand(n, 2 * d)
+        else:
+            if lat2 is None:
+                raise ValueError('Affine with a latent_net needs `latent`')
+            params = self.latent_net.net(lat2)                                # affine.py:66
+        return AffineCouplingOp.apply(x2, params, None, 0, d, True, -1.0)     # affine.py:111-113
+
     # ---- fused-program hooks --------------------------------------------------------------------------------
     def _plan_hidden_width(self):
         return 0

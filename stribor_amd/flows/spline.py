@@ -166,6 +166,23 @@ class Spline(ElementwiseTransform):
         return (y.reshape(*lead, d), None if ldj is None else ldj.reshape(*lead, 1),
                 None if ldiag is None else ldiag.reshape(*lead, d))
 
+    # ---- training (layer-wise autograd path) ---------------------------------------------------------------------
+    def _autograd_supported(self) -> bool:
+        from ..net.mlp import MLP
+        return self.spline_type == 'quadratic' and (self.latent_net is None or isinstance(self.latent_net, MLP))
+
+    def _autograd_inverse(self, x2: torch.Tensor, lat2=None):
+        """inverse_and_log_diag_jacobian summed over the columns, on fp32 rows, with a graph (RQSInverse)."""
+        n, d = x2.shape
+        if self.latent_net is None:
+            p = torch.cat([self.width, self.height, self.derivative], dim=-1).reshape(1, -1)     # spline.py:78-79
+            params = p.to(device=x2.device, dtype=torch.float32).expand(n, p.shape[1])
+        else:
+            if lat2 is None:
+                raise ValueError('Spline with a latent_net needs `latent`')
+            params = self.latent_net.net(lat2)                                                   # spline.py:82-86
+        return RQSInverse.apply(x2, params, None, 0, d, self.n_bins, self.lower, self.upper, 1.0)
+
     # ---- reference method set (spline.py:89-143) ----------------------------------------------------------
     def forward(self, x, latent=None, **kwargs):
         return self._launch(x, latent, False, False, False)[0]

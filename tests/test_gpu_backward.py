@@ -251,3 +251,36 @@ def test_layerwise_backward_conditional_and_mixed_flows():
         for pname, p in flow.named_parameters():
             ref = leaves[pname].grad.float()
             assert (p.grad.cpu() - ref).abs().max().item() <= tol(ref), (name, pname)
+
+
+def test_layerwise_backward_elementwise_affine_and_spline_layers():
+    """Element-wise st.Affine / st.Spline layers (own parameters, or a latent_net fed by `latent`) in a trainable flow."""
+    torch.manual_seed(31)
+    dim, ld, n = 6, 4, 150
+    desc = [{'kind': 'affine', 'dim': dim},
+            {'kind': 'coupling_affine', 'dim': dim, 'hidden': [16], 'latent_dim': ld, 'mask': 'ordered_left_half'},
+            {'kind': 'rqs', 'dim': dim, 'n_bins': 4, 'lower': -3, 'upper': 3, 'hidden': [12], 'latent_dim': 0},
+            {'kind': 'affine_latent', 'dim': dim, 'hidden': [10], 'latent_dim': ld},
+            {'kind': 'rqs', 'dim': dim, 'n_bins': 5, 'lower': -4, 'upper': 4, 'hidden': [12], 'latent_dim': ld},
+            {'kind': 'flip'}]
+    flow = fd.build_flow(st, desc, dim)
+    state = {k: v.clone() for k, v in flow.state_dict().items()}
+    flow = flow.to(DEV)
+    x, lat = torch.randn(n, dim) * 1.2, torch.randn(n, ld)
+    leaves = {k: v.detach().double().clone().requires_grad_(True) for k, v in state.items()}
+    spec = fd.flow_spec(desc, leaves)
+    xin, lin = x.double().clone().requires_grad_(True), lat.double().clone().requires_grad_(True)
+    want = -orc.flow_log_prob(spec, xin, latent=lin).mean()
+    want.backward()
+    xg, lg = x.to(DEV).requires_grad_(True), lat.to(DEV).requires_grad_(True)
+    lp = flow.log_prob(xg, latent=lg)
+    assert lp.requires_grad
+    loss = -lp.mean()
+    loss.backward()
+    assert abs(loss.item() - want.item()) <= 1e-5 * abs(want.item()) + 1e-5
+    tol = lambda ref: 3e-4 * ref.abs().max().item() + 1e-7
+    assert (xg.grad.cpu() - xin.grad.float()).abs().max().item() <= tol(xin.grad)
+    assert (lg.grad.cpu() - lin.grad.float()).abs().max().item() <= tol(lin.grad)
+    for pname, p in flow.named_parameters():
+        ref = leaves[pname].grad.float()
+        assert p.grad is not None and (p.grad.cpu() - ref).abs().max().item() <= tol(ref), pname
