@@ -86,6 +86,22 @@ class AffineLU(_DenseLinear):
             return Ainv.T, -(b @ Ainv)                          # x = (y - b) A^-1       (:159-163)
         return fn
 
+    # ---- training (layer-wise autograd path): the D x D matrix is derived with differentiable torch ops in fp64, the
+    #      [N, D] x [D, D] product is a plain library GEMM --------------------------------------------------------------
+    def _autograd_supported(self) -> bool:
+        return True
+
+    def _autograd_inverse(self, x2: torch.Tensor, lat2=None):
+        dev = x2.device
+        W = self.weight.to(dev, torch.float64)
+        eye = torch.eye(self.dim, dtype=torch.float64, device=dev)
+        A = (torch.tril(W, -1) + eye) @ (torch.triu(W, 1) + eye * self.log_diag.to(dev, torch.float64).exp())
+        Ainv = torch.linalg.inv(A)
+        b = self.bias.to(dev, torch.float64).reshape(-1)
+        out = torch.nn.functional.linear(x2, Ainv.T.to(torch.float32), (-(b @ Ainv)).to(torch.float32))   # :159-163
+        ldj = (-self.log_diag.to(dev, torch.float32).sum()).expand(x2.shape[0])                            # :171, negated
+        return out, ldj
+
     def _plan(self, builder, reverse, ldj_scale):
         ld = float(self.log_diag.detach().double().sum().item())          # affine.py:171
         builder.add_linear([self.weight, self.log_diag, self.bias], self._matrices(reverse), ldj_scale * ld)
@@ -142,6 +158,23 @@ class MatrixExponential(_DenseLinear):
 
     def _t_eff(self, t: float) -> float:
         return math.log1p(abs(t)) if self.log_time else t                    # affine.py:239-240
+
+    # ---- training (layer-wise autograd path, default t = 1): as AffineLU ----------------------------------------------
+    def _autograd_supported(self) -> bool:
+        return True
+
+    def _autograd_inverse(self, x2: torch.Tensor, lat2=None):
+        dev = x2.device
+        te = self._t_eff(1.0)
+        W = self._weight.to(dev, torch.float64)
+        eye = torch.eye(self.dim, dtype=torch.float64, device=dev)
+        A = (torch.tril(W, diagonal=-1) + eye) @ (torch.triu(W) + eye)      # affine.py:222-226
+        dg = self.diag.to(dev, torch.float64)
+        M = (A * (dg * (-te)).exp()) @ torch.linalg.inv(A)                   # affine.py:254-266 with t -> -t
+        b = None if self.bias is None else (-(M @ self.bias.to(dev, torch.float64))).to(torch.float32)
+        out = torch.nn.functional.linear(x2, M.to(torch.float32), b)
+        ldj = (-(self.diag.to(dev, torch.float32).sum() * te)).expand(x2.shape[0])                         # :287-288, negated
+        return out, ldj
 
     def _plan(self, builder, reverse, ldj_scale):
         t = getattr(builder, 't', None)

@@ -62,7 +62,7 @@ def main():
         with torch.no_grad():
             ms = timed(lambda: flow.log_prob(x))
             lp = flow.log_prob(x)
-        if name in ('cfg2_f32', 'cfg3') and '--train' in sys.argv:
+        if name in ('cfg2_f32', 'cfg3', 'cfg4') and '--train' in sys.argv:
             def train_step():
                 for p_ in flow.parameters():
                     p_.grad = None
