@@ -89,6 +89,18 @@ int sx_affine_coupling(const void *x, void *y, float *ldj, const float *params, 
                        int32_t dim, int32_t dtype, int32_t reverse, int32_t ldj_accumulate,
                        float ldj_scale, void *stream);
 
+/* Time-conditioned affine coupling (ContinuousAffineCoupling, stribor/flows/coupling.py:98-213):
+ * as sx_affine_coupling, with every row's (log_scale, shift) multiplied by the time embedding of t[n] first:
+ *   ls' = ls * phi(tscale[i] t),  sh' = sh * phi(tscale[n_live + i] t),  phi = the time net (net/time_net.py). */
+#define SX_TIME_IDENTITY 0   /* TimeIdentity: t            */
+#define SX_TIME_LINEAR   1   /* TimeLinear:   s t          */
+#define SX_TIME_TANH     2   /* TimeTanh:     tanh(s t)    */
+#define SX_TIME_LOG      3   /* TimeLog:      log(e^s t+1) */
+int sx_time_affine_coupling(const void *x, void *y, float *ldj, const float *params, int64_t params_stride,
+                            const float *t, const float *tscale, int32_t time_kind, const int32_t *live_idx,
+                            int32_t live_start, int32_t n_live, int64_t n_rows, int32_t dim, int32_t dtype,
+                            int32_t reverse, int32_t ldj_accumulate, float ldj_scale, void *stream);
+
 /* Backward of sx_affine_coupling for training (layer-wise autograd path; the single-launch backward of whole
  * affine-coupling flows is the SX_STEP_COUPLING_AFFINE_BWD program): x, gy [n_rows, dim] fp32, gldj [n_rows];
  * gx: live columns receive dL/dx; gparams [n_rows, 2*n_live] = (dL/dlog_scale | dL/dshift). */

@@ -384,6 +384,56 @@ def rqs_from_layer(layer: Dict, x: Tensor, z: Optional[Tensor], reverse: bool) -
 
 
 # ----------------------------------------------------------------------------------------------
+# time-conditioned affine coupling                        flows/coupling.py:98-213, net/time_net.py:6-47
+#   {'kind': 'continuous_affine_coupling', 'mask': ..., 'net': NET, 'time_kind': 'identity'|'linear'|'tanh'|'log',
+#    'time_scale': [1, out] | None, 'concatenate_time': bool}
+# ----------------------------------------------------------------------------------------------
+def time_embed(layer: Dict, t: Tensor) -> Tensor:
+    kind, sc = layer['time_kind'], layer.get('time_scale')
+    if kind == 'identity':
+        return t.repeat_interleave(layer['time_out'], dim=-1)       # time_net.py:11
+    if kind == 'linear':
+        return sc * t                                                # time_net.py:23
+    if kind == 'tanh':
+        return torch.tanh(sc * t)                                    # time_net.py:30
+    if kind == 'log':
+        return torch.log(sc.exp() * t + 1)                           # time_net.py:38
+    raise ValueError(kind)
+
+
+def continuous_affine_coupling(layer: Dict, x: Tensor, t: Tensor, latent: Optional[Tensor], reverse: bool
+                               ) -> Tuple[Tensor, Tensor]:
+    """ContinuousAffineCoupling.forward_and_log_det_jacobian, coupling.py:184-205."""
+    m = _coupling_mask(layer, x)                                     # :192
+    z = x * m                                                        # :149-156
+    if x.shape[-1] == 1:
+        z = z * 0
+    if latent is not None:
+        z = torch.cat([z, latent], -1)
+    if layer.get('concatenate_time', True):
+        z = torch.cat([z, t], -1)
+    log_scale, shift = mlp_forward(layer['net'], z).chunk(2, dim=-1)               # :194
+    t_log_scale, t_shift = time_embed(layer, t).chunk(2, dim=-1)                   # :195
+    if reverse:
+        y = (x - shift * t_shift) * torch.exp(-log_scale * t_log_scale)            # :197
+    else:
+        y = x * torch.exp(log_scale * t_log_scale) + shift * t_shift               # :199
+    ldiag = log_scale * t_log_scale * (1 - m)                                      # :201
+    y = y * (1 - m) + x * m                                                        # :203
+    return y, ldiag.sum(-1, keepdim=True)
+
+
+def neural_flow_forward(spec: Sequence[Dict], x: Tensor, t: Tensor, t0: Optional[Tensor] = None, latent=None) -> Tensor:
+    """NeuralFlow.forward, flow.py:170-184."""
+    if t0 is not None:
+        for layer in reversed(spec):
+            x = continuous_affine_coupling(layer, x, t0, latent, True)[0]           # transform.inverse(x, t=t0)
+    for layer in spec:
+        x = continuous_affine_coupling(layer, x, t, latent, False)[0]
+    return x
+
+
+# ----------------------------------------------------------------------------------------------
 # parameter-free element-wise flows       flows/sigmoid.py, flows/activations.py:11-101, flows/cumsum.py:9-92
 #   {'kind': 'sigmoid' | 'logit' | 'elu' | 'leaky_relu' (+ 'negative_slope') | 'cumsum' | 'diff' | 'identity'}
 # ----------------------------------------------------------------------------------------------

@@ -9,8 +9,8 @@ HIP for gfx950 behind the C ABI in ``include/stribor_hip.h``.  There is no CPU f
 from . import net, util
 from .dist import *          # noqa: F401,F403
 from .dist.normal import UnitNormal
-from .flow import ElementwiseTransform, NormalizingFlow, Transform
-from .flows import (ELU, Affine, AffineLU, Coupling, Cumsum, Diff, Flip, Identity, LeakyReLU, Logit, MatrixExponential,
+from .flow import ElementwiseTransform, NeuralFlow, NormalizingFlow, Transform
+from .flows import (ELU, Affine, AffineLU, ContinuousAffineCoupling, Coupling, Cumsum, Diff, Flip, Identity, LeakyReLU, Logit, MatrixExponential,
                     Permute, Sigmoid, Spline)
 
 __version__ = '0.1.0'

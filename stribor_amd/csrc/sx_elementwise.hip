@@ -225,6 +225,100 @@ extern "C" int sx_affine_coupling_bwd(const float *x, const float *gy, const flo
 }
 
 // ------------------------------------------------------------------------------------------------
+// Time-conditioned affine coupling (ContinuousAffineCoupling, stribor/flows/coupling.py:98-213): the conditioner's
+// (log_scale, shift) are multiplied by a time embedding of the row's t before the affine map, so that the layer is
+// the identity at t = 0:   ls' = ls * phi(a_i t),  sh' = sh * phi(b_i t)   with phi = the time net
+// (net/time_net.py: TimeIdentity t, TimeLinear s t, TimeTanh tanh(s t), TimeLog log(e^s t + 1)).
+// One lane per (row, column); pass-through columns are copied; the row log-det is a shuffle sum for power-of-two
+// widths <= 64 and float atomics otherwise.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float time_embed(int kind, float s, float t) {
+    switch (kind) {
+        case SX_TIME_IDENTITY: return t;
+        case SX_TIME_LINEAR: return s * t;
+        case SX_TIME_TANH: return tanhf(s * t);
+        default: return logf(expf(s) * t + 1.f);                       // SX_TIME_LOG
+    }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void time_affine_coupling_kernel(const void *__restrict__ x, void *__restrict__ y,
+                                                                   float *__restrict__ ldj, const float *__restrict__ params,
+                                                                   int64_t pstride, const float *__restrict__ t,
+                                                                   const float *__restrict__ tscale, int time_kind,
+                                                                   const int32_t *__restrict__ live_idx, int l0, int n_live,
+                                                                   int64_t n_rows, int dim, int reverse, int ldj_mode,
+                                                                   int ldj_acc, float ldj_scale) {
+    extern __shared__ __attribute__((aligned(16))) char tc_smem[];
+    int *slot = reinterpret_cast<int *>(tc_smem);                      // column -> index among the live columns, or -1
+    for (int c = threadIdx.x; c < dim; c += blockDim.x) slot[c] = -1;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_live; i += blockDim.x) slot[live_idx ? live_idx[i] : l0 + i] = i;
+    __syncthreads();
+    const int64_t total = n_rows * dim;
+    const int64_t total_up = (total + 63) & ~(int64_t)63;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total_up; e += stride) {
+        const bool valid = e < total;
+        float ld = 0.f;
+        int64_t row = 0;
+        if (valid) {
+            row = e / dim;
+            const int col = (int)(e - row * dim);
+            const int i = slot[col];
+            float xv = BF16 ? bf16_to_f32(reinterpret_cast<const uint16_t *>(x)[e]) : reinterpret_cast<const float *>(x)[e];
+            float out = xv;
+            if (i >= 0) {
+                const float tv = t[row];
+                const float ls = params[row * pstride + i] * time_embed(time_kind, tscale ? tscale[i] : 0.f, tv);
+                const float sh = params[row * pstride + n_live + i] * time_embed(time_kind, tscale ? tscale[n_live + i] : 0.f, tv);
+                out = reverse ? (xv - sh) * expf(-ls) : xv * expf(ls) + sh;   // coupling.py:196-199
+                ld = ls;                                                       // :201
+            }
+            if (BF16) reinterpret_cast<uint16_t *>(y)[e] = f32_to_bf16(out);
+            else reinterpret_cast<float *>(y)[e] = out;
+        }
+        if (ldj_mode == 1) {
+            const float s = group_sum_rt(ld, dim);
+            if (valid && (e & (dim - 1)) == 0) ldj[row] = (ldj_acc ? ldj[row] : 0.f) + ldj_scale * s;
+        } else if (ldj_mode == 2) {
+            if (valid && ld != 0.f) atomicAdd(&ldj[row], ldj_scale * ld);
+        }
+    }
+}
+
+extern "C" int sx_time_affine_coupling(const void *x, void *y, float *ldj, const float *params, int64_t params_stride,
+                                       const float *t, const float *tscale, int32_t time_kind, const int32_t *live_idx,
+                                       int32_t live_start, int32_t n_live, int64_t n_rows, int32_t dim, int32_t dtype,
+                                       int32_t reverse, int32_t ldj_accumulate, float ldj_scale, void *stream) {
+    SX_REQUIRE(x && y && params && t, "sx_time_affine_coupling: null pointer");
+    SX_REQUIRE(dim > 0 && n_live >= 0 && n_live <= dim && n_rows >= 0, "sx_time_affine_coupling: bad sizes");
+    SX_REQUIRE(dtype == SX_F32 || dtype == SX_BF16, "sx_time_affine_coupling: bad dtype");
+    SX_REQUIRE(time_kind >= SX_TIME_IDENTITY && time_kind <= SX_TIME_LOG, "sx_time_affine_coupling: unknown time net %d", time_kind);
+    SX_REQUIRE(time_kind == SX_TIME_IDENTITY || tscale != nullptr, "sx_time_affine_coupling: this time net needs its scale vector");
+    if (n_rows == 0) return SX_OK;
+    hipStream_t st = sx_stream(stream);
+    int ldj_mode = 0;
+    if (ldj) {
+        ldj_mode = (pow2(dim) && dim <= 64) ? 1 : 2;
+        if (ldj_mode == 2 && !ldj_accumulate) {
+            hipError_t e = hipMemsetAsync(ldj, 0, n_rows * sizeof(float), st);
+            if (e != hipSuccess) { sx_set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+        }
+    }
+    const int grid = grid_for(n_rows * dim, 256);
+    const size_t lds = (size_t)dim * sizeof(int);
+    if (dtype == SX_BF16)
+        hipLaunchKernelGGL(time_affine_coupling_kernel<true>, dim3(grid), dim3(256), lds, st, x, y, ldj, params, params_stride, t,
+                           tscale, time_kind, live_idx, live_start, n_live, n_rows, dim, reverse, ldj_mode, ldj_accumulate, ldj_scale);
+    else
+        hipLaunchKernelGGL(time_affine_coupling_kernel<false>, dim3(grid), dim3(256), lds, st, x, y, ldj, params, params_stride, t,
+                           tscale, time_kind, live_idx, live_start, n_live, n_rows, dim, reverse, ldj_mode, ldj_accumulate, ldj_scale);
+    SX_LAUNCH_CHECK();
+    return SX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // K7: Permute / Flip — bit-exact column gather                 (stribor/flows/permute.py:35,38,71,75)
 // ------------------------------------------------------------------------------------------------
 template <typename T>

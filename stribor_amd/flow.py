@@ -409,3 +409,19 @@ class NormalizingFlow(Transform):
     def log_det_jacobian(self, x, y=None, **kwargs):
         _, ldj = self.forward_and_log_det_jacobian(x, **kwargs)     # flow.py:148-152
         return ldj
+
+
+class NeuralFlow(nn.Module):
+    """flow.py:155-184: transforms that are the identity at t = 0; ``forward(x, t, t0)`` first inverts at t0."""
+
+    def __init__(self, transforms: List[Transform]) -> None:
+        super().__init__()
+        self.transforms = nn.ModuleList(transforms)
+
+    def forward(self, x, t, t0=None, **kwargs):
+        if t0 is not None:
+            for transform in reversed(self.transforms):
+                x = transform.inverse(x, t=t0, **kwargs)
+        for transform in self.transforms:
+            x = transform(x, t=t, **kwargs)
+        return x

@@ -1,5 +1,5 @@
 from .affine import Affine
-from .coupling import Coupling
+from .coupling import ContinuousAffineCoupling, Coupling
 from .permute import Flip, Permute
 from .spline import Spline
 from .linear import AffineLU, MatrixExponential

@@ -13,6 +13,7 @@ from typing import Optional
 
 import numpy as np
 import torch
+import torch.nn as nn
 
 from .. import _hip
 from ..flow import Transform, flatten_rows
@@ -21,7 +22,7 @@ from ..net.mlp import MLP, _chunk_mlp_program
 from ..util.mask import get_mask
 from .affine import Affine
 
-__all__ = ['Coupling']
+__all__ = ['Coupling', 'ContinuousAffineCoupling']
 
 
 class Coupling(Transform):
@@ -270,3 +271,106 @@ class Coupling(Transform):
         builder.add_coupling_affine(W1, b1, W2, b2, self.mask_vector(builder.dim), net.act_code, reverse, ldj_scale,
                                     W1.shape[0])
         return True
+
+
+class ContinuousAffineCoupling(Transform):
+    """Time-conditioned affine coupling (reference: stribor/flows/coupling.py:98-213): identity at t = 0.
+
+    ``latent_net`` (a ``net.MLP``) sees ``cat[x * mask, latent, t]`` (``concatenate_time``) and outputs ``2 * dim``
+    values, ``time_net`` (``net.TimeIdentity / TimeLinear / TimeTanh / TimeLog``) embeds t; the conditioner runs as a pruned
+    MFMA program, the time embedding, the affine map, the blend and the masked log-det are one pass of
+    ``sx_time_affine_coupling``."""
+
+    def __init__(self, latent_net: nn.Module, time_net: nn.Module, mask: str, concatenate_time: Optional[bool] = True,
+                 **kwargs):
+        super().__init__()
+        if not isinstance(latent_net, MLP):
+            raise NotImplementedError('stribor_amd.ContinuousAffineCoupling needs a stribor_amd.net.MLP latent_net')
+        if not hasattr(time_net, 'kind'):
+            raise NotImplementedError(f'time_net {type(time_net).__name__} is not on the path '
+                                      '(TimeIdentity / TimeLinear / TimeTanh / TimeLog are)')
+        self.latent_net = latent_net
+        self.time_net = time_net
+        self.mask_func = get_mask(mask)
+        self.concatenate_time = concatenate_time
+        self._masks = {}
+        self._programs = {}
+
+    def mask_vector(self, dim: int) -> np.ndarray:
+        if dim not in self._masks:
+            m = self.mask_func(dim).numpy().astype(np.float64).reshape(-1)
+            self._masks[dim] = np.full(dim, m[0]) if m.size == 1 else m
+        return self._masks[dim]
+
+    def _program(self, dim: int, extra: int, device):
+        key = (dim, extra, str(device))
+        if key not in self._programs:
+            net = self.latent_net
+            m = self.mask_vector(dim)
+            live = np.nonzero(m <= 0.5)[0]
+            cond = m > 0.5
+            if dim == 1:
+                cond = np.zeros(1, dtype=bool)                                       # coupling.py:151-152
+            b = ProgramBuilder(dim, extra, net.hidden_width)
+            b.add_mlp(net.linears(), net.act_code, cond, np.concatenate([live, dim + live]))   # chunk(2): (ls | sh)
+            contiguous = len(live) > 0 and np.array_equal(live, np.arange(live[0], live[0] + len(live)))
+            live_idx = None if contiguous else torch.from_numpy(live.astype(np.int32)).to(device)
+            self._programs[key] = (_chunk_mlp_program(b, device), live_idx, int(live[0]) if len(live) else 0, live)
+        return self._programs[key]
+
+    def _time_scales(self, dim: int, live: np.ndarray, device):
+        """Per live column: the time net's scale for its log_scale and for its shift (chunk(2) of the embedding,
+        broadcast against [.., dim] like the reference: half-width dim or 1)."""
+        tn = self.time_net
+        if tn.kind == 0:
+            return None
+        sc = tn.scale.detach().reshape(-1).to(device=device, dtype=torch.float32)
+        half = sc.numel() // 2
+        if half not in (1, dim):
+            raise ValueError(f'time_net width {sc.numel()} does not broadcast against 2 x {dim}')
+        idx = torch.from_numpy(live.astype(np.int64)).to(device) if half == dim else torch.zeros(len(live), dtype=torch.long, device=device)
+        return torch.cat([sc[:half].index_select(0, idx), sc[half:2 * half].index_select(0, idx)]).contiguous()
+
+    def _run(self, x, t, latent, reverse, want_ldj, ldj_scale):
+        _hip.require_device(x, 'x')
+        x2, lead = flatten_rows(x)
+        n, d = x2.shape
+        t2 = t.reshape(-1).to(device=x.device, dtype=torch.float32).contiguous()
+        if t2.numel() != n:
+            t2 = t.expand(*lead, 1).reshape(-1).to(torch.float32).contiguous()
+        parts = [] if latent is None else [latent.reshape(n, -1).to(torch.float32)]
+        if self.concatenate_time:
+            parts.append(t2.reshape(n, 1))                                           # coupling.py:155-156
+        lat2 = torch.cat(parts, -1).contiguous() if parts else None
+        extra = 0 if lat2 is None else lat2.shape[1]
+        progs, live_idx, live_start, live = self._program(d, extra, x.device)
+        y = torch.empty_like(x2)
+        ldj = torch.empty(n, dtype=torch.float32, device=x.device) if want_ldj else None
+        if len(live) == 0:
+            return x2.clone().reshape(*lead, d), (torch.zeros(*lead, 1, device=x.device) if want_ldj else None)
+        params = torch.empty(n, 2 * len(live), dtype=torch.float32, device=x.device)
+        for p in progs:
+            p.run(x2, lat2, mlp_out=params)
+        tscale = self._time_scales(d, live, x.device)
+        rc = _hip.lib().sx_time_affine_coupling(x2.data_ptr(), y.data_ptr(), _hip.ptr(ldj), params.data_ptr(),
+                                                params.stride(0), t2.data_ptr(), _hip.ptr(tscale), self.time_net.kind,
+                                                _hip.ptr(live_idx), live_start, len(live), n, d, _hip.dtype_code(x2),
+                                                int(reverse), 0, float(ldj_scale), _hip.stream())
+        _hip.check(rc, 'sx_time_affine_coupling')
+        return y.reshape(*lead, d), (None if ldj is None else ldj.reshape(*lead, 1))
+
+    # ---- reference method set (coupling.py:159-213) ----------------------------------------------------------------
+    def forward(self, x, t, latent=None, **kwargs):
+        return self._run(x, t, latent, False, False, 1.0)[0]
+
+    def inverse(self, y, t, latent=None, **kwargs):
+        return self._run(y, t, latent, True, False, 1.0)[0]
+
+    def log_det_jacobian(self, x, y=None, *, t, latent=None, **kwargs):
+        return self._run(x, t, latent, False, True, 1.0)[1]
+
+    def forward_and_log_det_jacobian(self, x, t, latent=None, *, reverse: bool = False, **kwargs):
+        return self._run(x, t, latent, reverse, True, 1.0)
+
+    def inverse_and_log_det_jacobian(self, y, t, latent=None, **kwargs):
+        return self._run(y, t, latent, True, True, -1.0)                             # coupling.py:211-213

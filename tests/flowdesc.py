@@ -59,6 +59,13 @@ def build_transform(st, d: Dict):
         return st.Permute(d['dim'])
     if k == 'flip':
         return st.Flip([-1])
+    if k == 'continuous_affine_coupling':
+        dim, ld = d['dim'], d.get('latent_dim', 0)
+        cat = d.get('concatenate_time', True)
+        net = st.net.MLP(dim + ld + (1 if cat else 0), list(d['hidden']), 2 * dim)
+        tn = {'identity': st.net.TimeIdentity, 'linear': st.net.TimeLinear, 'tanh': st.net.TimeTanh,
+              'log': st.net.TimeLog}[d['time_kind']](d.get('time_out', 2 * dim))
+        return st.ContinuousAffineCoupling(latent_net=net, time_net=tn, mask=d['mask'], concatenate_time=cat)
     if k in POINTWISE:
         return {'sigmoid': st.Sigmoid, 'logit': st.Logit, 'elu': st.ELU, 'identity': st.Identity,
                 'leaky_relu': lambda: st.LeakyReLU(d.get('negative_slope', 0.01)),
@@ -115,6 +122,10 @@ def transform_spec(d: Dict, state: Dict[str, torch.Tensor], prefix: str) -> Dict
         return {'kind': k}
     if k in POINTWISE:
         return dict(d)
+    if k == 'continuous_affine_coupling':
+        return {'kind': k, 'mask': d['mask'], 'net': _net_spec(state, prefix + 'latent_net.'),
+                'time_kind': d['time_kind'], 'time_scale': state.get(prefix + 'time_net.scale'),
+                'time_out': d.get('time_out', 2 * d['dim']), 'concatenate_time': d.get('concatenate_time', True)}
     raise ValueError(k)
 
 

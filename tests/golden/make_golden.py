@@ -13,7 +13,7 @@ Fixtures:  F1 doc known-answer, F2 masks, F3 cfg 1, F4 cfg 2 (N
 rounded inputs), F5 cfg 3 (RQ-spline couplings, N=128, incl. tails / on-bound / on-knot rows),
 F6 cfg 4 (AffineLU + MatrixExponential + couplings), F7 Permute/Flip, F8 the reference test-suite
 shapes with autograd log|det J|, F9 cubic splines (suite shapes + a D=64 coupling flow), F10 parameter-free element-wise flows + the on-path part of
-test_normalizing_flow.py's stack.
+test_normalizing_flow.py's stack, F11 ContinuousAffineCoupling / NeuralFlow.
 """
 import json
 import os
@@ -439,9 +439,58 @@ def f10_pointwise():
     save('f10_pointwise', arrays, meta)
 
 
+# ------------------------------------------------------------------------------------------ F11
+def f11_continuous():
+    """ContinuousAffineCoupling (test_coupling.py:29-52: ordered_left_half, hidden [13], latent 0/1/13, TimeLinear) plus
+    the other time nets, and the on-path layer of test_neural_flow.py through NeuralFlow (t, and t = t0 round trip)."""
+    arrays, meta = {}, {}
+    for shp in SHAPES:
+        dim = shp[-1]
+        tag = 'x'.join(map(str, shp))
+        for ld in (0, 1, 13):
+            for tk in (('linear',) if ld else ('linear', 'identity', 'tanh', 'log')):
+                torch.manual_seed(123)
+                x = torch.randn(*shp)
+                latent = torch.randn(*shp[:-1], ld) if ld else None
+                t = torch.randn_like(x[..., :1]) if tk != 'log' else torch.rand_like(x[..., :1])
+                d = {'kind': 'continuous_affine_coupling', 'dim': dim, 'hidden': [13], 'mask': 'ordered_left_half',
+                     'latent_dim': ld, 'time_kind': tk}
+                case = f'cac/{tag}/l{ld}/{tk}'
+                torch.manual_seed(321)
+                f = fd.build_transform(st, d)
+                for k, v in f.state_dict().items():
+                    arrays[f'{case}/state/transforms.0.{k}'] = v
+                kw = {} if latent is None else {'latent': latent}
+                with torch.no_grad():
+                    y, ldj = f.forward_and_log_det_jacobian(x, t, **kw)
+                    xb, ldj_i = f.inverse_and_log_det_jacobian(y, t, **kw)
+                arrays[f'{case}/x'], arrays[f'{case}/t'], arrays[f'{case}/y'], arrays[f'{case}/ldj'] = x, t, y, ldj
+                arrays[f'{case}/x_back'], arrays[f'{case}/ldj_inv'] = xb, ldj_i
+                if latent is not None:
+                    arrays[f'{case}/latent'] = latent
+                meta[case] = {'desc': [d], 'dim': dim}
+    # test_neural_flow.py:9-16, the ContinuousAffineCoupling layer (concatenate_time=False, TimeLinear(dim)), stacked twice
+    dim = 2
+    desc = [{'kind': 'continuous_affine_coupling', 'dim': dim, 'hidden': [32], 'mask': m, 'latent_dim': 0,
+             'time_kind': 'linear', 'time_out': dim, 'concatenate_time': False} for m in ('ordered_0', 'ordered_1')]
+    torch.manual_seed(123)
+    nf = st.NeuralFlow([fd.build_transform(st, d) for d in desc])
+    for k, v in nf.state_dict().items():
+        arrays[f'neural_flow/state/{k}'] = v
+    x = torch.randn(10, 4, 2)
+    t, t0 = torch.randn_like(x[..., :1]), torch.randn_like(x[..., :1])
+    with torch.no_grad():
+        arrays['neural_flow/x'], arrays['neural_flow/t'], arrays['neural_flow/t0'] = x, t, t0
+        arrays['neural_flow/y_t'] = nf(x, t=t)
+        arrays['neural_flow/y_t_t0'] = nf(x, t=t, t0=t0)
+        arrays['neural_flow/y_zero'] = nf(x, t=torch.zeros_like(t))
+    meta['neural_flow'] = {'desc': desc, 'dim': dim}
+    save('f11_continuous', arrays, meta)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10']
+    which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11']
     table = {'f1': f1_doc_example, 'f2': f2_masks, 'f3': f3_cfg1, 'f4': f4_cfg2, 'f5': f5_cfg3,
-             'f6': f6_cfg4, 'f7': f7_permute, 'f8': f8_suite, 'f9': f9_cubic, 'f10': f10_pointwise}
+             'f6': f6_cfg4, 'f7': f7_permute, 'f8': f8_suite, 'f9': f9_cubic, 'f10': f10_pointwise, 'f11': f11_continuous}
     for w in which:
         table[w]()

@@ -691,3 +691,38 @@ def test_pure_coupling_flow_d128_against_oracle():
         close(y, wy, rtol=1e-5, atol=2e-5)
         close(ldj, wl, rtol=1e-5, atol=1e-4)
         close(flow.inverse(y), x, rtol=1e-4, atol=1e-4)
+
+
+def test_continuous_affine_coupling_and_neural_flow():
+    """stribor/test/test_coupling.py:29-52 shapes (latent 0/1/13, TimeLinear) plus TimeIdentity / TimeTanh / TimeLog, and
+    test_neural_flow.py's container checks (identity at t = 0, t = t0 round trip) -- fixture F11."""
+    g = Golden('f11_continuous')
+    n = 0
+    for case, m in g.meta.items():
+        if case == 'neural_flow':
+            continue
+        f = product_transform(g, case)
+        x, t = g.t(case + '/x').to(DEV), g.t(case + '/t').to(DEV)
+        kw = {'latent': g.t(case + '/latent').to(DEV)} if g.has(case + '/latent') else {}
+        y, ldj = f.forward_and_log_det_jacobian(x, t, **kw)
+        close(y, g.t(case + '/y'))
+        close(ldj, g.t(case + '/ldj'), atol=2e-5)
+        close(f(x, t, **kw), g.t(case + '/y'))
+        close(f.log_det_jacobian(x, y, t=t, **kw), g.t(case + '/ldj'), atol=2e-5)
+        xb, li = f.inverse_and_log_det_jacobian(g.t(case + '/y').to(DEV), t, **kw)
+        close(xb, g.t(case + '/x_back'), atol=2e-5)
+        close(li, g.t(case + '/ldj_inv'), atol=2e-5)
+        close(f.inverse(y, t, **kw), x, atol=1e-4)                              # base.py:8-11
+        n += 1
+    assert n == 4 * 6
+    m = g.meta['neural_flow']
+    nf = st.NeuralFlow([fd.build_transform(st, d) for d in m['desc']])
+    nf.load_state_dict(g.state('neural_flow'))
+    nf = nf.to(DEV)
+    x, t, t0 = (g.t('neural_flow/' + k).to(DEV) for k in ('x', 't', 't0'))
+    close(nf(x, t=t), g.t('neural_flow/y_t'))
+    close(nf(x, t=t, t0=t0), g.t('neural_flow/y_t_t0'), atol=2e-5)
+    assert torch.equal(nf(x, t=torch.zeros_like(t)), x)                          # test_neural_flow.py:24-27
+    close(nf(x, t=t0, t0=t0), x, atol=1e-5)                                      # :29-32
+    with pytest.raises(NotImplementedError):
+        st.net.TimeFourier(4, 8)

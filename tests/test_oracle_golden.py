@@ -181,3 +181,28 @@ def test_f10_pointwise_flows_and_stack():
     assert torch.equal(orc.flow_log_prob(spec, x), g.t('stack/log_prob'))
     assert torch.equal(orc.flow_forward(spec, x), g.t('stack/forward'))
     assert torch.equal(orc.flow_inverse(spec, x), g.t('stack/inverse'))
+
+
+def test_f11_continuous_affine_coupling_and_neural_flow():
+    """ContinuousAffineCoupling on the reference suite's shapes (test_coupling.py:29-52) with every time net on the path,
+    and the NeuralFlow container (test_neural_flow.py): bit-exact against the reference's values."""
+    g = Golden('f11_continuous')
+    n = 0
+    for case, m in g.meta.items():
+        if case == 'neural_flow':
+            continue
+        spec = fd.transform_spec(m['desc'][0], g.state(case), 'transforms.0.')
+        x, t = g.t(case + '/x'), g.t(case + '/t')
+        latent = g.t(case + '/latent') if g.has(case + '/latent') else None
+        y, ldj = orc.continuous_affine_coupling(spec, x, t, latent, False)
+        assert torch.equal(y, g.t(case + '/y')) and torch.equal(ldj, g.t(case + '/ldj')), case
+        xb, li = orc.continuous_affine_coupling(spec, y, t, latent, True)
+        assert torch.equal(xb, g.t(case + '/x_back')) and torch.equal(-li, g.t(case + '/ldj_inv')), case
+        n += 1
+    assert n == 4 * (4 + 1 + 1)
+    m = g.meta['neural_flow']
+    spec = [fd.transform_spec(d, g.state('neural_flow'), f'transforms.{i}.') for i, d in enumerate(m['desc'])]
+    x, t, t0 = g.t('neural_flow/x'), g.t('neural_flow/t'), g.t('neural_flow/t0')
+    assert torch.equal(orc.neural_flow_forward(spec, x, t), g.t('neural_flow/y_t'))
+    assert torch.equal(orc.neural_flow_forward(spec, x, t, t0), g.t('neural_flow/y_t_t0'))
+    assert torch.equal(orc.neural_flow_forward(spec, x, torch.zeros_like(t)), x)          # identity at t = 0
