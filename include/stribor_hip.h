@@ -145,6 +145,14 @@ int sx_cubic_coupling(const void *x, void *y, float *ldj, float *ldiag, const fl
                       float lower, float upper, int64_t n_rows, int32_t dim, int32_t dtype, int32_t reverse,
                       int32_t ldj_accumulate, float ldj_scale, void *stream);
 
+/* Backward of sx_cubic_coupling(reverse = 1) for training: the cubic solve is differentiated implicitly, so the kernel is
+ * handed the inverse pass's input `yin` AND its output `xout` (both [n_rows, dim] fp32); other arguments as
+ * sx_rqs_inverse_bwd, gparams [n_rows, n_live*(2K+2)]. */
+int sx_cubic_inverse_bwd(const float *yin, const float *xout, const float *gout, const float *gldj, const float *params,
+                         int64_t params_stride, float *gx, float *gparams, const int32_t *live_idx, int32_t live_start,
+                         int32_t n_live, int32_t n_bins, float lower, float upper, int64_t n_rows, int32_t dim,
+                         float ldj_scale, void *stream);
+
 /* Parameter-free element-wise flows: Sigmoid / Logit (stribor/flows/sigmoid.py:9-56), ELU / LeakyReLU
  * (flows/activations.py:11-101), Cumsum / Diff over the last axis (flows/cumsum.py:9-92).
  *   y (nullable for the element kinds): transformed values;  ldiag (nullable, [n_rows, dim]): per-element log-derivative;

@@ -887,3 +887,191 @@ extern "C" int sx_rqs_inverse_bwd(const float *x, const float *gout, const float
     SX_LAUNCH_CHECK();
     return SX_OK;
 }
+
+// =====================================================================================================
+// Backward of the monotone cubic spline in the INVERSE direction (training of spline_type='cubic' layers).
+// The inverse pass solved f(t) = y for t in bin b, f(t) = a t^3 + b t^2 + c t + d (cubic_spline.py:134-137), and returned
+// x = t + cw_b, ljd = -log f'(t).  The solve is differentiated IMPLICITLY:  dt = (dy - da t^3 - db t^2 - dc t - dd) / f'(t),
+// so the Cardano / trigonometric / quadratic root formulas of the forward never appear here; the kernel is handed the
+// forward's output.  (a, b, c, d) -> (w_b, s_b, the two Steffen knot derivatives, ch_b) -> widths / heights of bins
+// b-1, b, b+1 and the cumsums -> softmax / sigmoid, in reverse mode.  min() / sign() pick the branch the forward took.
+// Staging and layout as cubic_kernel (padded odd per-lane stride); gradients leave in the parameter tensor's layout.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void cubic_inverse_bwd_kernel(const float *__restrict__ yin, const float *__restrict__ xout,
+                                                                const float *__restrict__ gout, const float *__restrict__ gldj,
+                                                                const float *__restrict__ params, int64_t pstride,
+                                                                float *__restrict__ gx, float *__restrict__ gparams,
+                                                                const int32_t *__restrict__ live_idx, int l0, int n_live,
+                                                                int K, float lower, float upper, int64_t n_rows, int dim,
+                                                                float ldj_scale) {
+    const int P = 2 * K + 2, PS = P | 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int waves_per_block = blockDim.x >> 6;
+    float *sp = rqs_smem + (size_t)wave * 64 * PS;
+    const int64_t n_elem = n_rows * n_live;
+    const int64_t n_groups = (n_elem + 63) >> 6;
+    const float norm = 1.f - CUBIC_MIN_BIN * (float)K;
+    const float span = upper - lower;
+    const float inv_P = 1.0f / (float)P;
+    for (int64_t grp = (int64_t)blockIdx.x * waves_per_block + wave; grp < n_groups;
+         grp += (int64_t)gridDim.x * waves_per_block) {
+        const int64_t e0 = grp << 6;
+        const int n_here = (int)((n_elem - e0) < 64 ? (n_elem - e0) : 64);
+        const int total = n_here * P;
+        for (int idx = lane; idx < total; idx += 64) {
+            const int el = (int)(((float)idx + 0.5f) * inv_P), q = idx - el * P;
+            const int64_t e = e0 + el;
+            const int64_t row = e / n_live;
+            sp[el * PS + q] = params[row * pstride + (int64_t)(e - row * n_live) * P + q];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        const int64_t e = e0 + lane;
+        const bool valid = e < n_elem;
+        const int64_t row = valid ? e / n_live : 0;
+        const int i = valid ? (int)(e - row * n_live) : 0;
+        const int col = live_idx ? live_idx[i] : l0 + i;
+        const float yv = valid ? yin[row * dim + col] : lower;
+        const float xo = valid ? xout[row * dim + col] : lower;
+        const float Ao = valid ? gout[row * dim + col] : 0.f;
+        const float Al = valid ? gldj[row] * ldj_scale : 0.f;
+        const bool inside = (yv >= lower) && (yv <= upper);
+        const float yn = ((inside ? yv : lower) - lower) / span;
+        float *p = sp + (valid ? lane : 0) * PS;
+
+        // ---- forward pieces: softmax numerators in place, bin (by heights), neighbours ---------------------------
+        float mw = p[0], mh = p[K];
+        for (int k = 1; k < K; ++k) { mw = fmaxf(mw, p[k]); mh = fmaxf(mh, p[K + k]); }
+        float sw = 0.f, sh = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float ew = cubic_exp(p[k] - mw), eh = cubic_exp(p[K + k] - mh);
+            if (valid) { p[k] = ew; p[K + k] = eh; }
+            sw += ew;
+            sh += eh;
+        }
+        const float inv_sw = 1.f / sw, inv_sh = 1.f / sh;
+        int b = 0;
+        float cw = 0.f, ch = 0.f, cw_b = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float wk = CUBIC_MIN_BIN + norm * (p[k] * inv_sw), hk = CUBIC_MIN_BIN + norm * (p[K + k] * inv_sh);
+            if (yn >= ch) { b = k; cw_b = cw; }
+            cw += wk;
+            ch += hk;
+        }
+        auto W = [&](int k) { return CUBIC_MIN_BIN + norm * (p[k] * inv_sw); };
+        auto H = [&](int k) { return CUBIC_MIN_BIN + norm * (p[K + k] * inv_sh); };
+        const float w_b = W(b), h_b = H(b), s_b = h_b / w_b;
+        const bool has_m = b > 0, has_p = b < K - 1;
+        const float w_m = has_m ? W(b - 1) : 1.f, h_m = has_m ? H(b - 1) : 1.f, s_m = h_m / w_m;
+        const float w_p = has_p ? W(b + 1) : 1.f, h_p = has_p ? H(b + 1) : 1.f, s_p = h_p / w_p;
+        const float sgl = cubic_sigmoid(p[2 * K]), sgr = cubic_sigmoid(p[2 * K + 1]);
+        // knot derivatives and which branch produced them
+        float dL, dR;
+        bool L_m1 = false, L_first = false, R_m1 = false, R_first = false;
+        if (!has_m) dL = sgl * 3.f * s_b;
+        else {
+            const float m1 = fminf(s_m, s_b), m2 = 0.5f * (w_b * s_m + w_m * s_b) / (w_m + w_b);
+            L_m1 = m1 < m2; L_first = s_m < s_b;
+            dL = fminf(m1, m2) * 2.f;
+        }
+        if (!has_p) dR = sgr * 3.f * s_b;
+        else {
+            const float m1 = fminf(s_b, s_p), m2 = 0.5f * (w_p * s_b + w_b * s_p) / (w_b + w_p);
+            R_m1 = m1 < m2; R_first = s_b < s_p;
+            dR = fminf(m1, m2) * 2.f;
+        }
+        const float a = (dL + dR - 2.f * s_b) / (w_b * w_b);
+        const float bb = (3.f * s_b - 2.f * dL - dR) / w_b;
+        const float c = dL;
+        const float t = (xo - lower) / span - cw_b;
+        const float fp = 3.f * a * (t * t) + 2.f * bb * t + c, fpp = 6.f * a * t + 2.f * bb;
+
+        // ---- reverse ----------------------------------------------------------------------------------------------
+        const float Aon = Ao * span;                                   // x = out_n * span + lower
+        const float At = Aon - Al * fpp / fp;                          // out_n = t + cw_b,  ljd = -log f'(t) + const
+        const float ifp = 1.f / fp;
+        const float Ay = At * ifp / span;                              // y_n = (y - lower) / span
+        const float Aa = -At * (t * t * t) * ifp - Al * 3.f * (t * t) * ifp;
+        const float Ab = -At * (t * t) * ifp - Al * 2.f * t * ifp;
+        const float Ac = -At * t * ifp - Al * ifp;
+        const float Achb = -At * ifp;                                  // d = ch_b
+        const float Acwb = Aon;
+        float AdL = Aa / (w_b * w_b) - 2.f * Ab / w_b + Ac;
+        float AdR = Aa / (w_b * w_b) - Ab / w_b;
+        float As = -2.f * Aa / (w_b * w_b) + 3.f * Ab / w_b;
+        float Aw = -2.f * a * Aa / w_b - bb * Ab / w_b;
+        float Ah = 0.f, Awm = 0.f, Ahm = 0.f, Awp = 0.f, Ahp = 0.f, Asm = 0.f, Asp = 0.f, Audl = 0.f, Audr = 0.f;
+        if (!has_m) { Audl = AdL * 3.f * s_b * sgl * (1.f - sgl); As += AdL * 3.f * sgl; }
+        else if (L_m1) { if (L_first) Asm += 2.f * AdL; else As += 2.f * AdL; }
+        else {
+            const float Wd = w_m + w_b, N = w_b * s_m + w_m * s_b, g = AdL;          // dL = N / Wd
+            Aw += g * (s_m / Wd - N / (Wd * Wd));
+            Awm += g * (s_b / Wd - N / (Wd * Wd));
+            Asm += g * w_b / Wd;
+            As += g * w_m / Wd;
+        }
+        if (!has_p) { Audr = AdR * 3.f * s_b * sgr * (1.f - sgr); As += AdR * 3.f * sgr; }
+        else if (R_m1) { if (R_first) As += 2.f * AdR; else Asp += 2.f * AdR; }
+        else {
+            const float Wd = w_b + w_p, N = w_p * s_b + w_b * s_p, g = AdR;          // dR = N / Wd
+            Awp += g * (s_b / Wd - N / (Wd * Wd));
+            Aw += g * (s_p / Wd - N / (Wd * Wd));
+            As += g * w_p / Wd;
+            Asp += g * w_b / Wd;
+        }
+        Ah += As / w_b;  Aw += -As * s_b / w_b;
+        Ahm += Asm / w_m; Awm += -Asm * s_m / w_m;
+        Ahp += Asp / w_p; Awp += -Asp * s_p / w_p;
+        // widths / heights: direct terms at b-1, b, b+1 + the cumsums' (cw_b, ch_b) on every bin below b
+        auto Gw = [&](int k) { return (k < b ? Acwb : 0.f) + (k == b ? Aw : 0.f) + ((has_m && k == b - 1) ? Awm : 0.f) + ((has_p && k == b + 1) ? Awp : 0.f); };
+        auto Gh = [&](int k) { return (k < b ? Achb : 0.f) + (k == b ? Ah : 0.f) + ((has_m && k == b - 1) ? Ahm : 0.f) + ((has_p && k == b + 1) ? Ahp : 0.f); };
+        float dotw = 0.f, doth = 0.f;
+        for (int k = 0; k < K; ++k) { dotw += p[k] * inv_sw * Gw(k); doth += p[K + k] * inv_sh * Gh(k); }
+        const float gate = inside ? 1.f : 0.f;
+        if (valid) {
+            for (int k = 0; k < K; ++k) {
+                const float pw = p[k] * inv_sw, ph = p[K + k] * inv_sh;
+                p[k] = gate * norm * pw * (Gw(k) - dotw);
+                p[K + k] = gate * norm * ph * (Gh(k) - doth);
+            }
+            p[2 * K] = gate * Audl;
+            p[2 * K + 1] = gate * Audr;
+            gx[row * dim + col] = inside ? Ay : Ao;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int idx = lane; idx < total; idx += 64) {
+            const int el = (int)(((float)idx + 0.5f) * inv_P), q = idx - el * P;
+            gparams[e0 * P + idx] = sp[el * PS + q];
+        }
+    }
+}
+
+extern "C" int sx_cubic_inverse_bwd(const float *yin, const float *xout, const float *gout, const float *gldj,
+                                    const float *params, int64_t params_stride, float *gx, float *gparams,
+                                    const int32_t *live_idx, int32_t live_start, int32_t n_live, int32_t n_bins, float lower,
+                                    float upper, int64_t n_rows, int32_t dim, float ldj_scale, void *stream) {
+    SX_REQUIRE(yin && xout && gout && gldj && params && gx && gparams, "sx_cubic_inverse_bwd: null pointer");
+    SX_REQUIRE(dim > 0 && n_live > 0 && n_live <= dim && n_rows >= 0 && n_bins >= 1, "sx_cubic_inverse_bwd: bad sizes");
+    SX_REQUIRE(upper > lower, "sx_cubic_inverse_bwd: empty domain");
+    if (n_rows == 0) return SX_OK;
+    const int PS = (2 * n_bins + 2) | 1;
+    int block = 256;
+    size_t lds = (size_t)(block / 64) * 64 * PS * sizeof(float);
+    if (lds > 64 * 1024) { block = 64; lds = (size_t)64 * PS * sizeof(float); }
+    SX_REQUIRE(lds <= 160 * 1024, "sx_cubic_inverse_bwd: n_bins %d needs %zu B of LDS per wave", n_bins, lds);
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void *)cubic_inverse_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int64_t n_groups = (n_rows * n_live + 63) / 64;
+    const int wpb = block / 64;
+    int64_t grid = (n_groups + wpb - 1) / wpb;
+    const int64_t per_cu = (160 * 1024) / (int64_t)lds > 8 ? 8 : (160 * 1024) / (int64_t)lds;
+    if (grid > 256 * per_cu) grid = 256 * per_cu;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(cubic_inverse_bwd_kernel, dim3((int)grid), dim3(block), lds, sx_stream(stream), yin, xout, gout, gldj,
+                       params, params_stride, gx, gparams, live_idx, live_start, n_live, n_bins, lower, upper, n_rows, dim,
+                       ldj_scale);
+    SX_LAUNCH_CHECK();
+    return SX_OK;
+}

@@ -166,15 +166,14 @@ class Coupling(Transform):
         from .spline import Spline
         if not isinstance(getattr(self.transform, 'latent_net', None), MLP):
             return False
-        return isinstance(self.transform, Affine) or \
-            (isinstance(self.transform, Spline) and self.transform.spline_type == 'quadratic')
+        return isinstance(self.transform, (Affine, Spline))
 
     def _autograd_inverse(self, x2: torch.Tensor, lat2=None):
         """inverse_and_log_det_jacobian on fp32 rows [N, D] with a graph: the conditioner runs through torch's own
         Linear layers (rocBLAS; only the rows of the last layer that parameterise transformed columns), the transform
         and its backward are the HIP kernels behind ``RQSInverse`` / ``AffineCouplingOp``.
         Returns (x_out [N, D], ldj [N])."""
-        from .spline import RQSInverse, Spline
+        from .spline import CubicInverse, RQSInverse, Spline
         from .affine import AffineCouplingOp
         sp, net = self.transform, self._net()
         is_spline = isinstance(sp, Spline)
@@ -207,7 +206,8 @@ class Coupling(Transform):
         last = layers[-1]
         params = torch.nn.functional.linear(h, last.weight.index_select(0, rows_t), last.bias.index_select(0, rows_t))
         if is_spline:
-            return RQSInverse.apply(x2, params, live_idx, int(live[0]), len(live), sp.n_bins, sp.lower, sp.upper, 1.0)
+            op = CubicInverse if sp.spline_type == 'cubic' else RQSInverse
+            return op.apply(x2, params, live_idx, int(live[0]), len(live), sp.n_bins, sp.lower, sp.upper, 1.0)
         # Transform.inverse_and_log_det_jacobian: minus the forward log-det (flow.py:47)
         return AffineCouplingOp.apply(x2, params, live_idx, int(live[0]), len(live), True, -1.0)
 

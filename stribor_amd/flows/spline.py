@@ -18,7 +18,7 @@ import torch.nn as nn
 from .. import _hip
 from ..flow import ElementwiseTransform, flatten_rows
 
-__all__ = ['Spline', 'run_rqs_kernel', 'run_cubic_kernel', 'RQSInverse']
+__all__ = ['Spline', 'run_rqs_kernel', 'run_cubic_kernel', 'RQSInverse', 'CubicInverse']
 
 _err_flags = {}
 
@@ -111,6 +111,37 @@ def run_cubic_kernel(x2, params, params_stride, live_idx, live_start, n_live, n_
     return y, ldj, ldiag
 
 
+class CubicInverse(torch.autograd.Function):
+    """(x_out, row log-det) = inverse monotone cubic spline of the live columns as a differentiable op: forward =
+    sx_cubic_coupling(reverse=1), backward = sx_cubic_inverse_bwd (the cubic solve differentiated implicitly, then reverse
+    mode through cubic_spline.py:103-137).  params: [N, n_live*(2K+2)]."""
+
+    @staticmethod
+    def forward(ctx, x2, params, live_idx, live_start, n_live, n_bins, lower, upper, ldj_scale):
+        x2 = x2.contiguous()
+        params = params.contiguous()
+        y, ldj, _ = run_cubic_kernel(x2, params, params.stride(0), live_idx, live_start, n_live, n_bins, lower, upper, True,
+                                     True, False, ldj_scale)
+        ctx.save_for_backward(x2, y, params)
+        ctx.meta = (live_idx, live_start, n_live, n_bins, float(lower), float(upper), float(ldj_scale))
+        return y, ldj
+
+    @staticmethod
+    def backward(ctx, gy, gldj):
+        x2, y, params = ctx.saved_tensors
+        live_idx, live_start, n_live, n_bins, lower, upper, ldj_scale = ctx.meta
+        n, d = x2.shape
+        gy = (torch.zeros_like(x2) if gy is None else gy).to(torch.float32).contiguous()
+        gldj = (torch.zeros(n, device=x2.device) if gldj is None else gldj).to(torch.float32).contiguous()
+        gx = gy.clone()
+        gparams = torch.empty_like(params)
+        rc = _hip.lib().sx_cubic_inverse_bwd(x2.data_ptr(), y.data_ptr(), gy.data_ptr(), gldj.data_ptr(), params.data_ptr(),
+                                             params.stride(0), gx.data_ptr(), gparams.data_ptr(), _hip.ptr(live_idx),
+                                             live_start, n_live, n_bins, lower, upper, n, d, ldj_scale, _hip.stream())
+        _hip.check(rc, 'sx_cubic_inverse_bwd')
+        return gx, gparams, None, None, None, None, None, None, None
+
+
 class Spline(ElementwiseTransform):
     def __init__(self, dim: int, n_bins: int, latent_net: Optional[nn.Module] = None, lower: Optional[float] = 0,
                  upper: Optional[float] = 1, spline_type: Optional[str] = 'cubic', **kwargs):
@@ -169,7 +200,7 @@ class Spline(ElementwiseTransform):
     # ---- training (layer-wise autograd path) ---------------------------------------------------------------------
     def _autograd_supported(self) -> bool:
         from ..net.mlp import MLP
-        return self.spline_type == 'quadratic' and (self.latent_net is None or isinstance(self.latent_net, MLP))
+        return self.latent_net is None or isinstance(self.latent_net, MLP)
 
     def _autograd_inverse(self, x2: torch.Tensor, lat2=None):
         """inverse_and_log_diag_jacobian summed over the columns, on fp32 rows, with a graph (RQSInverse)."""
@@ -181,7 +212,8 @@ class Spline(ElementwiseTransform):
             if lat2 is None:
                 raise ValueError('Spline with a latent_net needs `latent`')
             params = self.latent_net.net(lat2)                                                   # spline.py:82-86
-        return RQSInverse.apply(x2, params, None, 0, d, self.n_bins, self.lower, self.upper, 1.0)
+        op = CubicInverse if self.spline_type == 'cubic' else RQSInverse
+        return op.apply(x2, params, None, 0, d, self.n_bins, self.lower, self.upper, 1.0)
 
     # ---- reference method set (spline.py:89-143) ----------------------------------------------------------
     def forward(self, x, latent=None, **kwargs):
