@@ -171,6 +171,11 @@ int sx_cubic_inverse_bwd(const float *yin, const float *xout, const float *gout,
 int sx_pointwise(const void *x, void *y, float *ldj, float *ldiag, int64_t n_rows, int32_t dim, int32_t dtype,
                  int32_t kind, float param, int32_t ldj_accumulate, void *stream);
 
+/* Backward of sx_pointwise (training): gx = gy * d(out)/dx + gldj[row] * d(log-derivative)/dx; x, gy, gx [n_rows, dim]
+ * fp32, gldj [n_rows] nullable.  Cumsum / Diff: the reversed scan of gy. */
+int sx_pointwise_bwd(const float *x, const float *gy, const float *gldj, float *gx, int64_t n_rows, int32_t dim,
+                     int32_t kind, float param, void *stream);
+
 /* UnitNormal.log_prob + log-det accumulator (stribor/dist/normal.py:37,52-54; flow.py:128-129):
  *   out[n] = sum_d( -x[n,d]^2/2 ) - dim*log(sqrt(2*pi)) + (ldj ? ldj[n] : 0) */
 int sx_unit_normal_logprob(const void *x, const float *ldj, float *out, int64_t n_rows, int32_t dim,

@@ -37,7 +37,7 @@ ACT_CODES = {'Identity': 0, 'Tanh': 1, 'ReLU': 2, 'Sigmoid': 3, 'ELU': 4, 'Softp
 
 # every symbol include/stribor_hip.h declares (tests check that the library exports all of them)
 EXPORTS = ['sx_abi_version', 'sx_fragment_mode', 'sx_last_error', 'sx_permute', 'sx_affine_coupling', 'sx_rqs_coupling',
-           'sx_cubic_coupling', 'sx_pointwise', 'sx_rqs_inverse_bwd', 'sx_affine_coupling_bwd', 'sx_time_affine_coupling', 'sx_cubic_inverse_bwd',
+           'sx_cubic_coupling', 'sx_pointwise', 'sx_rqs_inverse_bwd', 'sx_affine_coupling_bwd', 'sx_time_affine_coupling', 'sx_cubic_inverse_bwd', 'sx_pointwise_bwd',
            'sx_unit_normal_logprob', 'sx_sum_f64', 'sx_packed_linear_floats', 'sx_pack_linear', 'sx_flow_run',
            'sx_flow_launch_info', 'sx_wgrad']
 
@@ -86,6 +86,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.sx_time_affine_coupling.argtypes = [vp, vp, vp, vp, i64, vp, vp, i32, vp, i32, i32, i64, i32, i32, i32, i32, f32, vp]
     lib.sx_cubic_inverse_bwd.restype = i32
     lib.sx_cubic_inverse_bwd.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, i32, f32, f32, i64, i32, f32, vp]
+    lib.sx_pointwise_bwd.restype = i32
+    lib.sx_pointwise_bwd.argtypes = [vp, vp, vp, vp, i64, i32, i32, f32, vp]
     lib.sx_pointwise.restype = i32
     lib.sx_pointwise.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, f32, i32, vp]
     lib.sx_unit_normal_logprob.restype = i32

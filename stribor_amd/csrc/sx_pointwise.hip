@@ -61,8 +61,9 @@ __device__ __forceinline__ void pw_eval(int kind, float param, float log_slope, 
             break;
         }
         case SX_PW_ELU_INV: {                                          // activations.py:29-37
-            out = fmaxf(x, 0.f) + fminf(log1pf(x), 0.f);
-            ld = fmaxf(-out, 0.f);
+            const float lt = log1pf(x);                                // NaN below -1, like torch.min(log1p(y), 0)
+            out = fmaxf(x, 0.f) + ((lt < 0.f || lt != lt) ? lt : 0.f);
+            ld = (out != out) ? out : fmaxf(-out, 0.f);
             break;
         }
         case SX_PW_LEAKY_RELU: {                                       // activations.py:80-86, param = slope, 94-101
@@ -173,6 +174,71 @@ __global__ __launch_bounds__(256) void cumsum_kernel(const void *__restrict__ x,
             }
         }
     }
+}
+
+// ---- backward (training, layer-wise path): dL/dx = gy * d(out)/dx + gldj[row] * d(ld)/dx, per element ----------------
+__device__ __forceinline__ float pw_grad(int kind, float param, float x, float gy, float gl) {
+    switch (kind) {
+        case SX_PW_SIGMOID: {
+            const float sg = 1.f / (1.f + expf(-x));
+            return gy * sg * (1.f - sg) + gl * (1.f - 2.f * sg);
+        }
+        case SX_PW_LOGIT: {
+            const float y = fminf(fmaxf(x, PW_TINY), PW_ONE_MINUS_EPS);
+            const float inv = 1.f / (y * (1.f - y));
+            return (x == y) ? (gy + gl * (2.f * y - 1.f)) * inv : 0.f;                 // clamped ends: constant
+        }
+        case SX_PW_ELU: return x > 0.f ? gy : gy * expf(x) + gl;
+        case SX_PW_ELU_INV: {
+            const float d = x > 0.f ? 1.f : 1.f / (1.f + x);
+            return gy * d + (x < 0.f ? -gl * d : 0.f);                                 // ld = max(-out, 0)
+        }
+        default: return gy * (x >= 0.f ? 1.f : param);                                  // LeakyReLU / its inverse
+    }
+}
+
+__global__ __launch_bounds__(256) void pointwise_bwd_kernel(const float *__restrict__ x, const float *__restrict__ gy,
+                                                            const float *__restrict__ gldj, float *__restrict__ gx,
+                                                            int64_t n_rows, int dim, int kind, float param) {
+    const int64_t total = n_rows * dim;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
+        gx[i] = pw_grad(kind, param, x[i], gy[i], gldj ? gldj[i / dim] : 0.f);
+}
+
+// cumsum's adjoint is the reversed cumsum, diff's the reversed diff: one lane per row, from the last column back
+__global__ __launch_bounds__(256) void cumsum_bwd_kernel(const float *__restrict__ gy, float *__restrict__ gx, int64_t n_rows,
+                                                         int dim, int diff) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
+        double acc = 0.0;
+        float prev = 0.f;
+        for (int c = dim - 1; c >= 0; --c) {
+            const float v = gy[r * dim + c];
+            if (diff) { gx[r * dim + c] = v - prev; prev = v; }
+            else { acc += (double)v; gx[r * dim + c] = (float)acc; }
+        }
+    }
+}
+
+extern "C" int sx_pointwise_bwd(const float *x, const float *gy, const float *gldj, float *gx, int64_t n_rows, int32_t dim,
+                                int32_t kind, float param, void *stream) {
+    SX_REQUIRE(x && gy && gx, "sx_pointwise_bwd: null pointer");
+    SX_REQUIRE(dim > 0 && n_rows >= 0, "sx_pointwise_bwd: bad sizes");
+    SX_REQUIRE(kind >= SX_PW_SIGMOID && kind <= SX_PW_DIFF, "sx_pointwise_bwd: unknown kind %d", kind);
+    if (n_rows == 0) return SX_OK;
+    hipStream_t st = sx_stream(stream);
+    if (kind == SX_PW_CUMSUM || kind == SX_PW_DIFF) {
+        int64_t g = (n_rows + 255) / 256;
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(cumsum_bwd_kernel, dim3((int)g), dim3(256), 0, st, gy, gx, n_rows, dim, kind == SX_PW_DIFF);
+    } else {
+        int64_t g = (n_rows * dim + 255) / 256;
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(pointwise_bwd_kernel, dim3((int)g), dim3(256), 0, st, x, gy, gldj, gx, n_rows, dim, kind, param);
+    }
+    SX_LAUNCH_CHECK();
+    return SX_OK;
 }
 
 extern "C" int sx_pointwise(const void *x, void *y, float *ldj, float *ldiag, int64_t n_rows, int32_t dim,

@@ -31,6 +31,31 @@ def run_pointwise(x, kind, param=0.0, want_y=True, want_ldj=False, want_ldiag=Fa
             None if ldiag is None else ldiag.reshape(*lead, d))
 
 
+class PointwiseOp(torch.autograd.Function):
+    """(out, row log-det) of one sx_pointwise kind as a differentiable op; backward = sx_pointwise_bwd."""
+
+    @staticmethod
+    def forward(ctx, x2, kind, param):
+        x2 = x2.contiguous()
+        y, ldj, _ = run_pointwise(x2, kind, param, want_ldj=True)
+        ctx.save_for_backward(x2)
+        ctx.meta = (kind, float(param))
+        return y, ldj.reshape(-1)
+
+    @staticmethod
+    def backward(ctx, gy, gldj):
+        (x2,) = ctx.saved_tensors
+        kind, param = ctx.meta
+        n, d = x2.shape
+        gy = (torch.zeros_like(x2) if gy is None else gy).to(torch.float32).contiguous()
+        gl = None if gldj is None else gldj.to(torch.float32).contiguous()
+        gx = torch.empty_like(x2)
+        rc = _hip.lib().sx_pointwise_bwd(x2.data_ptr(), gy.data_ptr(), _hip.ptr(gl), gx.data_ptr(), n, d, kind, param,
+                                         _hip.stream())
+        _hip.check(rc, 'sx_pointwise_bwd')
+        return gx, None, None
+
+
 class _Pointwise(ElementwiseTransform):
     """fwd / inv kernel kinds + parameters; the inverse kinds return MINUS the forward log-derivative at the value they
     produce, which is what Transform.inverse_and_log_det_jacobian returns (flow.py:42-47)."""
@@ -38,6 +63,13 @@ class _Pointwise(ElementwiseTransform):
 
     def _p(self, reverse):
         return 0.0
+
+    # ---- training (layer-wise autograd path) ------------------------------------------------------------------------
+    def _autograd_supported(self) -> bool:
+        return True
+
+    def _autograd_inverse(self, x2, lat2=None):
+        return PointwiseOp.apply(x2, self._inv, self._p(True))
 
     def forward(self, x, **kwargs):
         return run_pointwise(x, self._fwd, self._p(False))[0]
@@ -144,3 +176,9 @@ class Identity(ElementwiseTransform):
 
     def inverse_and_log_det_jacobian(self, y, **kwargs):
         return self.inverse(y), self.log_det_jacobian(y)
+
+    def _autograd_supported(self) -> bool:
+        return True
+
+    def _autograd_inverse(self, x2, lat2=None):
+        return x2, torch.zeros(x2.shape[0], dtype=torch.float32, device=x2.device)

@@ -73,9 +73,10 @@ def test_training_step_reduces_loss():
 
 def test_unsupported_flows_evaluate_without_graph():
     torch.manual_seed(0)
-    flow = st.NormalizingFlow(st.UnitNormal(4), [st.Sigmoid(), st.Logit()]).to(DEV)   # point-wise flows: no backward yet
+    # a conditioner that is not a stribor_amd.net.MLP cannot join either training path
+    flow = st.NormalizingFlow(st.UnitNormal(4), [st.AffineLU(4), st.MatrixExponential(4)]).to(DEV)
     x = torch.randn(10, 4, device=DEV, requires_grad=True)
-    lp = flow.log_prob(x)
+    lp = flow.log_prob(x, t=torch.rand(10, 1, device=DEV))       # per-row time: evaluated without a graph
     assert not lp.requires_grad
 
 
@@ -346,3 +347,40 @@ def test_cubic_spline_flow_log_prob_backward_matches_autograd_of_oracle(n, dim, 
         scale = ref.abs().max().item() + 1e-12
         err = (p.grad.cpu() - ref).abs().max().item()
         assert err <= 1e-3 * scale + 1e-7, (name, err, scale)
+
+
+def test_layerwise_backward_reference_stack_and_pointwise_flows():
+    """The on-path part of test_normalizing_flow.py's stack (affine coupling with a two-hidden-layer conditioner -> Flip ->
+    Sigmoid -> cubic-spline coupling -> Logit) trains end to end, and so do ELU / LeakyReLU / Cumsum / Diff / Identity
+    layers: gradients vs fp64 autograd of the oracle."""
+    torch.manual_seed(51)
+    dim = 2
+    stack = [{'kind': 'coupling_affine', 'dim': dim, 'hidden': [32, 64], 'mask': 'ordered_1', 'latent_dim': 0},
+             {'kind': 'flip'}, {'kind': 'sigmoid'},
+             {'kind': 'coupling_rqs', 'dim': dim, 'hidden': [32, 64], 'mask': 'ordered_0', 'latent_dim': 0, 'n_bins': 5,
+              'lower': 0, 'upper': 1, 'spline_type': 'cubic'},
+             {'kind': 'logit'}]
+    d6 = 6
+    zoo = [{'kind': 'coupling_affine', 'dim': d6, 'hidden': [16], 'mask': 'ordered_right_half', 'latent_dim': 0},
+           {'kind': 'leaky_relu', 'negative_slope': 0.3}, {'kind': 'cumsum'},
+           {'kind': 'coupling_affine', 'dim': d6, 'hidden': [16], 'mask': 'parity_odd', 'latent_dim': 0},
+           {'kind': 'diff'}, {'kind': 'identity'},
+           {'kind': 'coupling_rqs', 'dim': d6, 'hidden': [16], 'mask': 'ordered_left_half', 'latent_dim': 0, 'n_bins': 4,
+            'lower': -3, 'upper': 3},
+           {'kind': 'elu'}]            # log_prob inverts ELU first: its argument must stay above -1
+    for name, desc, dd, x in [('stack', stack, dim, torch.randn(90, dim)), ('zoo', zoo, d6, torch.rand(120, d6) * 2.5 - 0.6)]:
+        flow = fd.build_flow(st, desc, dd)
+        state = {k: v.clone() for k, v in flow.state_dict().items()}
+        flow = flow.to(DEV)
+        want_loss, want_g, want_gx = oracle_grads(desc, state, x)
+        xg = x.to(DEV).requires_grad_(True)
+        lp = flow.log_prob(xg)
+        assert lp.requires_grad, name
+        loss = -lp.mean()
+        loss.backward()
+        assert abs(loss.item() - want_loss) <= 2e-5 * abs(want_loss) + 1e-5, name
+        tol = lambda ref: 1e-3 * ref.abs().max().item() + 1e-7
+        assert (xg.grad.cpu() - want_gx.float()).abs().max().item() <= tol(want_gx), name
+        for pname, p in flow.named_parameters():
+            ref = want_g[pname].float()
+            assert p.grad is not None and (p.grad.cpu() - ref).abs().max().item() <= tol(ref), (name, pname)
