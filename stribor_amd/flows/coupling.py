@@ -344,6 +344,32 @@ class ContinuousAffineCoupling(Transform):
         lat2 = torch.cat(parts, -1).contiguous() if parts else None
         extra = 0 if lat2 is None else lat2.shape[1]
         progs, live_idx, live_start, live = self._program(d, extra, x.device)
+        needs_graph = torch.is_grad_enabled() and (x.requires_grad or t.requires_grad or
+                                                    (latent is not None and latent.requires_grad) or
+                                                    any(p.requires_grad for p in self.parameters()))
+        if needs_graph and len(live):
+            # training: conditioner and time net through torch (library GEMMs / tiny element-wise ops), the affine map and
+            # its backward through the HIP op; same values as the kernel path
+            from .affine import AffineCouplingOp
+            m = torch.from_numpy(self.mask_vector(d).astype(np.float32)).to(x.device)
+            z = x2.to(torch.float32) * m
+            if d == 1:
+                z = z * 0
+            if lat2 is not None:
+                z = torch.cat([z, lat2], -1)
+            rows = torch.from_numpy(np.concatenate([live, d + live]).astype(np.int64)).to(x.device)
+            layers = list(self.latent_net.net)
+            h = z
+            for layer in layers[:-1]:
+                h = layer(h)
+            params = torch.nn.functional.linear(h, layers[-1].weight.index_select(0, rows), layers[-1].bias.index_select(0, rows))
+            emb = self.time_net(t2.reshape(n, 1))                                    # [n, out]
+            half = emb.shape[1] // 2
+            cols = torch.from_numpy(live.astype(np.int64)).to(x.device) if half == d else torch.zeros(len(live), dtype=torch.long, device=x.device)
+            scale = torch.cat([emb[:, :half].index_select(1, cols), emb[:, half:2 * half].index_select(1, cols)], -1)
+            y, ldj = AffineCouplingOp.apply(x2.to(torch.float32), params * scale, live_idx, live_start, len(live), bool(reverse),
+                                            float(ldj_scale))
+            return y.reshape(*lead, d), (ldj.reshape(*lead, 1) if want_ldj else None)
         y = torch.empty_like(x2)
         ldj = torch.empty(n, dtype=torch.float32, device=x.device) if want_ldj else None
         if len(live) == 0:

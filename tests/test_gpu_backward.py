@@ -384,3 +384,34 @@ def test_layerwise_backward_reference_stack_and_pointwise_flows():
         for pname, p in flow.named_parameters():
             ref = want_g[pname].float()
             assert p.grad is not None and (p.grad.cpu() - ref).abs().max().item() <= tol(ref), (name, pname)
+
+
+def test_neural_flow_forward_is_differentiable():
+    """ContinuousAffineCoupling inside NeuralFlow with a graph (conditioner + time net through torch, affine map through
+    AffineCouplingOp): gradients of an MSE objective on f(x, t) w.r.t. x, t-net scales and conditioner weights vs fp64
+    autograd of the oracle; values equal the kernel path's."""
+    torch.manual_seed(61)
+    dim, n = 4, 80
+    desc = [{'kind': 'continuous_affine_coupling', 'dim': dim, 'hidden': [16], 'mask': m, 'latent_dim': 0, 'time_kind': tk}
+            for m, tk in (('ordered_left_half', 'linear'), ('ordered_right_half', 'tanh'), ('parity_odd', 'log'))]
+    nf = st.NeuralFlow([fd.build_transform(st, d) for d in desc])
+    state = {k: v.clone() for k, v in nf.state_dict().items()}
+    nf = nf.to(DEV)
+    x, t, target = torch.randn(n, dim), torch.rand(n, 1) * 2, torch.randn(n, dim)
+    leaves = {k: v.detach().double().clone().requires_grad_(True) for k, v in state.items()}
+    spec = [fd.transform_spec(d, leaves, f'transforms.{i}.') for i, d in enumerate(desc)]
+    xin = x.double().clone().requires_grad_(True)
+    want = ((orc.neural_flow_forward(spec, xin, t.double()) - target.double()) ** 2).mean()
+    want.backward()
+    xg = x.to(DEV).requires_grad_(True)
+    out = nf(xg, t=t.to(DEV))
+    with torch.no_grad():
+        close(out, nf(x.to(DEV), t=t.to(DEV)), rtol=1e-5, atol=1e-5)
+    loss = ((out - target.to(DEV)) ** 2).mean()
+    loss.backward()
+    assert abs(loss.item() - want.item()) <= 1e-5 * abs(want.item()) + 1e-6
+    tol = lambda ref: 3e-4 * ref.abs().max().item() + 1e-7
+    assert (xg.grad.cpu() - xin.grad.float()).abs().max().item() <= tol(xin.grad)
+    for pname, p in nf.named_parameters():
+        ref = leaves[pname].grad.float()
+        assert p.grad is not None and (p.grad.cpu() - ref).abs().max().item() <= tol(ref), pname

@@ -19,6 +19,15 @@ from oracle import stribor_oracle as orc
 import stribor_amd as st
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    """Parity of the inference kernels: with a graph (parameters require grad by default) log_prob of spline / mixed flows
+    and ContinuousAffineCoupling would take the layer-wise training path instead, which tests/test_gpu_backward.py covers."""
+    with torch.no_grad():
+        yield
+
 DEV = 'cuda'
 
 
