@@ -140,12 +140,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Untimed pre-run (first launch: weight packing, module load, counters; and ~0.3 s of steps so that the device
-    # leaves its idle power state) before the W warm-up steps of the contract.
+    # Untimed pre-run (first launch: weight packing, module load, counters; then a FIXED number of steps -- the same on
+    # every rank, each step carries a collective -- so that the device leaves its idle power state) before the W warm-up
+    # steps of the contract.
     step()
     torch.cuda.synchronize()
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < 0.3:
+    for _ in range(25):
         for _ in range(20):
             step()
         torch.cuda.synchronize()
