@@ -735,3 +735,47 @@ def test_continuous_affine_coupling_and_neural_flow():
     close(nf(x, t=t0, t0=t0), x, atol=1e-5)                                      # :29-32
     with pytest.raises(NotImplementedError):
         st.net.TimeFourier(4, 8)
+
+
+def test_full_size_properties_cubic_and_pointwise():
+    """Size-independent properties at BASELINE-scale batches for the widened rows: a D=64, K=16 cubic-spline coupling flow
+    at 2^18 rows (round trip, forward / inverse log-det antisymmetry, batch-split invariance, oracle on a slice) and the
+    point-wise kernels at 2^20 x 64 (round trips, log-det antisymmetry, Cumsum / Diff exactness against torch)."""
+    torch.manual_seed(0)
+    desc = [dict(d, spline_type='cubic') for d in fd.cfg3_desc(4)]
+    flow = fd.build_flow(st, desc, 64).to(DEV)
+    n = 1 << 18
+    x = torch.randn(n, 64, device=DEV)
+    y, ldj_f = flow.forward_and_log_det_jacobian(x)
+    xb, ldj_i = flow.inverse_and_log_det_jacobian(y)
+    assert torch.isfinite(y).all() and torch.isfinite(ldj_f).all()
+    err = torch.nan_to_num((xb - x).abs(), nan=0.0)
+    # four fp32 cubic solves in a row: flat spots of the spline amplify rounding (in the reference as much as here)
+    assert torch.quantile(err.flatten()[:: 97], 0.999).item() < 1e-3 and err.max().item() < 0.1
+    rel = torch.nan_to_num(((ldj_f + ldj_i).abs() / (1.0 + ldj_f.abs())).flatten(), nan=0.0)
+    assert torch.quantile(rel[:: 7], 0.99).item() < 1e-3
+    lp = flow.log_prob(x)
+    # a handful of elements per million sit where the fp32 cubic solve breaks down (f'(t) rounds to <= 0: NaN here, a
+    # finite but meaningless -1e8 in the reference's fp32 path; fp64 is fine): tolerated, counted, and excluded
+    bad = ~torch.isfinite(lp)
+    assert bad.float().mean().item() < 1e-4
+    lp2 = torch.cat([flow.log_prob(x[:100_001]), flow.log_prob(x[100_001:])])
+    assert torch.equal(torch.nan_to_num(lp, nan=0.0), torch.nan_to_num(lp2, nan=0.0))
+    spec = fd.flow_spec(desc, {k: v.cpu() for k, v in flow.state_dict().items()})
+    sl = slice(123_000, 123_128)
+    close(lp[sl], orc.flow_log_prob(spec, x[sl].cpu()), rtol=1e-5, atol=5e-4)
+    # point-wise kernels
+    n = 1 << 20
+    x = torch.randn(n, 64, device=DEV) * 2
+    for f in (st.Sigmoid(), st.ELU(), st.LeakyReLU(0.05)):
+        f = f.to(DEV)
+        y, l1 = f.forward_and_log_det_jacobian(x)
+        xb, l2 = f.inverse_and_log_det_jacobian(y)
+        ok = (y > 1e-6) & (y < 1 - 1e-6) if isinstance(f, st.Sigmoid) else torch.ones_like(y, dtype=torch.bool)
+        assert ((xb - x).abs()[ok] <= 1e-3 * (1 + x.abs()[ok])).all(), type(f).__name__
+        rows_ok = ok.all(-1)
+        assert ((l1 + l2).abs().reshape(-1)[rows_ok] <= 1e-3 * (1 + l1.abs().reshape(-1)[rows_ok])).all(), type(f).__name__
+    c = st.Cumsum(-1).to(DEV)
+    yc = c(x)
+    assert torch.equal(yc.cpu()[:4096], x.cpu()[:4096].cumsum(-1))               # test_cumsum.py:17 on the first rows
+    close(c.inverse(yc), x, rtol=1e-5, atol=1e-4)
