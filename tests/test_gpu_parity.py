@@ -779,3 +779,37 @@ def test_full_size_properties_cubic_and_pointwise():
     yc = c(x)
     assert torch.equal(yc.cpu()[:4096], x.cpu()[:4096].cumsum(-1))               # test_cumsum.py:17 on the first rows
     close(c.inverse(yc), x, rtol=1e-5, atol=1e-4)
+
+
+def test_dynamic_chunk_handout_equals_static_and_is_stream_safe():
+    """The ticket-based chunk hand-out (per-stream counters re-armed by the last workgroup) gives bit-identical per-row
+    results to the static stride for ragged batch sizes, launch after launch, and on two streams at once."""
+    torch.manual_seed(5)
+    flow = fd.build_flow(st, fd.cfg2_desc(4, 64, 64), 64).to(DEV)
+    sizes = [1, 127, 128 * 2048 + 1, 300_007, 1 << 19, (1 << 19) + 255, 777_777]
+    for n in sizes:
+        x = torch.randn(n, 64, device=DEV)
+        a = flow.log_prob(x)
+        b = flow.log_prob(x)                       # second launch on the same stream: counters were re-armed
+        os.environ['SX_STATIC_CHUNKS'] = '1'
+        try:
+            c = flow.log_prob(x)
+        finally:
+            del os.environ['SX_STATIC_CHUNKS']
+        assert torch.equal(a, b) and torch.equal(a, c), n
+        s = flow.log_prob_sum(x)
+        assert abs(s.item() - a.double().sum().item()) <= 1e-9 * abs(s.item()) + 1e-6, n
+    x1, x2 = torch.randn(400_000, 64, device=DEV), torch.randn(500_003, 64, device=DEV)
+    want1, want2 = flow.log_prob(x1), flow.log_prob(x2)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(5):
+        with torch.cuda.stream(s1):
+            o1 = flow.log_prob(x1)
+        with torch.cuda.stream(s2):
+            o2 = flow.log_prob(x2)
+        outs.append((o1, o2))
+    torch.cuda.synchronize()
+    for o1, o2 in outs:
+        assert torch.equal(o1, want1) and torch.equal(o2, want2)
