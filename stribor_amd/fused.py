@@ -287,6 +287,11 @@ class ProgramBuilder:
 
     def _alloc(self, n_floats: int) -> Tuple[int, int]:
         n = _ceil_div(max(n_floats, 1), 256) * 256
+        # one step's weights must fit the double-buffered LDS ring (2 x n floats + the ticket slots in 160 KiB); a layer
+        # that does not (e.g. a dense-mask coupling with a 128-wide conditioner) makes the flow fall back to its
+        # layer-by-layer form, where the conditioner runs as its own program of smaller steps
+        if n * 8 + 16 > 160 * 1024:
+            raise NotImplementedError(f'a fused step would need {n * 4} B of weights per LDS buffer (> 80 KiB)')
         off = self.blob_floats
         self.blob_floats += n
         return off, n

@@ -813,3 +813,54 @@ def test_dynamic_chunk_handout_equals_static_and_is_stream_safe():
     torch.cuda.synchronize()
     for o1, o2 in outs:
         assert torch.equal(o1, want1) and torch.equal(o2, want2)
+
+
+@pytest.mark.parametrize('dim,hidden,masks', [
+    (33, 8, ('ordered_right_half', 'ordered_left_half')), (40, 33, ('ordered_left_half', 'ordered_right_half')),
+    (48, 64, ('parity_even', 'parity_odd')), (63, 100, ('ordered_right_half', 'parity_odd')),
+    (64, 128, ('ordered_right_half', 'ordered_left_half')), (65, 64, ('ordered_right_half', 'ordered_left_half')),
+    (96, 32, ('parity_odd', 'parity_even')), (100, 64, ('ordered_left_half', 'ordered_right_half')),
+    (128, 128, ('ordered_right_half', 'ordered_left_half')),
+])
+def test_affine_coupling_flows_across_widths_against_oracle(dim, hidden, masks):
+    """Tile-geometry sweep of the fused affine-coupling kernels (1 / 2 / 4 state tiles, 1 / 2 / 4 hidden tiles, pruned
+    and dense mask layouts, pure and general modes, ragged row counts) against the oracle, both directions."""
+    torch.manual_seed(dim * 131 + hidden)
+    desc = [{'kind': 'coupling_affine', 'dim': dim, 'hidden': [hidden], 'mask': masks[i % 2], 'latent_dim': 0} for i in range(5)]
+    flow = fd.build_flow(st, desc, dim)
+    spec = fd.flow_spec(desc, {k: v.clone() for k, v in flow.state_dict().items()})
+    flow = flow.to(DEV)
+    for n in (1, 257, 3000):
+        x = torch.randn(n, dim)
+        close(flow.log_prob(x.to(DEV)), orc.flow_log_prob(spec, x), rtol=1e-5, atol=1e-4)
+        y, ldj = flow.forward_and_log_det_jacobian(x.to(DEV))
+        wy, wl = orc.flow_forward_and_ldj(spec, x)
+        close(y, wy, rtol=1e-5, atol=2e-5)
+        close(ldj, wl, rtol=1e-5, atol=1e-4)
+        close(flow.inverse(y), x, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('dim,hidden,K,masks', [
+    (33, 8, 3, ('ordered_right_half', 'ordered_left_half')), (48, 64, 8, ('parity_even', 'parity_odd')),
+    (64, 128, 16, ('ordered_right_half', 'ordered_left_half')), (100, 64, 5, ('ordered_left_half', 'ordered_right_half')),
+    (128, 32, 16, ('ordered_right_half', 'parity_odd')), (20, 16, 24, ('ordered_right_half', 'ordered_left_half')),
+])
+def test_spline_coupling_flows_across_widths_against_oracle(dim, hidden, K, masks):
+    """Tile-geometry sweep of the spline-coupling path (fused programs where they fit -- K <= 16 --, layer by layer
+    otherwise) against the oracle, both directions, inputs reaching into the tails."""
+    torch.manual_seed(dim * 17 + K)
+    desc = [{'kind': 'coupling_rqs', 'dim': dim, 'hidden': [hidden], 'n_bins': K, 'lower': -2.5, 'upper': 2.5,
+             'mask': masks[i % 2], 'latent_dim': 0} for i in range(3)]
+    flow = fd.build_flow(st, desc, dim)
+    spec = fd.flow_spec(desc, {k: v.clone() for k, v in flow.state_dict().items()})
+    flow = flow.to(DEV)
+    for n in (1, 300):
+        x = torch.randn(n, dim) * 1.5
+        close(flow.log_prob(x.to(DEV)), orc.flow_log_prob(spec, x), rtol=1e-5, atol=2e-4 * max(1, dim // 32))
+        y, ldj = flow.forward_and_log_det_jacobian(x.to(DEV))
+        wy, wl = orc.flow_forward_and_ldj(spec, x)
+        close(y, wy, rtol=1e-5, atol=2e-5)
+        close(ldj, wl, rtol=1e-5, atol=2e-4 * max(1, dim // 32))
+        close(flow.inverse(y), x, rtol=1e-4, atol=1e-4)
+    from stribor_amd.flows.spline import check_errors
+    check_errors()
