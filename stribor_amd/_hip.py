@@ -30,6 +30,9 @@ STEP_ROW_SCALE_EXP = 9
 STEP_RQS_HIDDEN = 10
 STEP_RQS_PHASE = 11
 STEP_COUPLING_AFFINE_BWD = 12
+STEP_CPL_HIDDEN = 13
+STEP_CPL_HIDDEN2 = 14
+STEP_COUPLING_AFFINE_DEEP = 15
 
 ACT_TANH_FOLDED = 9
 ACT_CODES = {'Identity': 0, 'Tanh': 1, 'ReLU': 2, 'Sigmoid': 3, 'ELU': 4, 'Softplus': 5, 'LeakyReLU': 6,

@@ -19,7 +19,7 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     d->n_steps = p->n_steps; d->dim = p->dim; d->latent_dim = p->latent_dim; d->x_tiles = p->x_tiles;
     d->identity_cols = p->identity_cols; d->pad = 0;
     int mx = 256;
-    bool lin = false, rqs = false, aff = false, bwd = false;
+    bool lin = false, rqs = false, aff = false, bwd = false, deep = false;
     *mlp_mode = 0;
     for (int i = 0; i < p->n_steps; ++i) {
         const sx_step &s = p->steps[i];
@@ -49,6 +49,12 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
                            "sx_flow_run: step %d: a linear step covers all %d output slabs (act = x_tiles, t0 = 0)", i, p->x_tiles);
                 need = sx_packed_linear_floats(p->x_tiles, p->tiles); lin = true; break;
             case SX_STEP_ROW_SCALE_EXP: need = 32 * p->tiles; lin = true; break;
+            case SX_STEP_CPL_HIDDEN: need = sx_packed_linear_floats(p->h_tiles, s.ct); deep = true; break;
+            case SX_STEP_CPL_HIDDEN2: need = sx_packed_linear_floats(p->h_tiles, p->h_tiles); deep = true; break;
+            case SX_STEP_COUPLING_AFFINE_DEEP:
+                SX_REQUIRE(s.tt >= 1 && s.t0 + s.tt <= p->x_tiles, "sx_flow_run: step %d: bad transformed tiles", i);
+                need = sx_packed_linear_floats(p->h_tiles, p->h_tiles) + sx_packed_linear_floats(2 * s.tt, p->h_tiles);
+                deep = true; break;
             case SX_STEP_COUPLING_AFFINE_BWD: {
                 SX_REQUIRE((p->tiles == 2 || p->tiles == 4) && p->x_tiles * 2 == p->tiles,
                            "sx_flow_run: step %d: backward programs carry x and dL/dx: tiles = 2 * x_tiles (2 or 4)", i);
@@ -94,6 +100,8 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     if (rqs) *mlp_mode = 3;
     SX_REQUIRE(!(bwd && (rqs || lin || aff || *mlp_mode == 1)), "sx_flow_run: backward steps cannot be mixed with other step kinds");
     if (bwd) *mlp_mode = 4;
+    SX_REQUIRE(!(deep && (lin || rqs || bwd || *mlp_mode == 1)), "sx_flow_run: deep-conditioner steps only mix with affine couplings");
+    if (deep) *mlp_mode = 9;
     // MODE 5 / 6: nothing but tanh-folded affine couplings on half the tiles conditioned on the other half, all in
     // one direction (5 reverse, 6 forward) -- the plain RealNVP log_prob / sample program.  Its kernel carries two
     // straight-line arms only, which keeps the state in place (no phi copies) at 130 VGPRs.

@@ -452,6 +452,46 @@ __device__ __forceinline__ void coupling_affine(tile<NS> (&xs)[TX], const wptr w
     for (int n = 0; n < NS; ++n) ldj[n] += st.ldj_scale * (s[n].x + s[n].y);
     SX_STAMP(pf, 5);         // affine + log-det
 }
+// Deep conditioners (>= 2 hidden layers, kernel MODE 9): the earlier hidden layers ran as their own steps and left their
+// activations in `hsrc`; this step evaluates the last hidden layer from them, then the output layer and the affine map.
+template <int NS, int TX, int HT, int T0, int TT, bool REV>
+__device__ __forceinline__ void coupling_affine_deep(tile<NS> (&xs)[TX], const tile<NS> (&hsrc)[HT], const wptr w,
+                                                     const dstep &st, float (&ldj)[NS]) {
+    tile<NS> hid[HT];
+    hidden_layer<NS, HT, HT, 0, HT, false>(hsrc, hid, w, 0, st.act);
+    constexpr int a2 = HT * HT * 1024 + HT * 32;       // pack_linear(W_out: 2*TT m-tiles, HT k-tiles)
+    constexpr int b2 = a2 + 2 * TT * HT * 1024;
+    btile<NS> bh[HT];
+#pragma unroll
+    for (int m = 0; m < HT; ++m) bh[m] = make_btile<NS>(hid[m]);
+    __builtin_amdgcn_sched_barrier(0);
+    float s[NS];
+#pragma unroll
+    for (int n = 0; n < NS; ++n) s[n] = 0.f;
+    const float sgn = REV ? -1.44269504088896341f : 1.44269504088896341f;
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        tile<NS> ls = load_cfrag<NS>(w.cb, b2 + (2 * t) * 32);
+        tile<NS> sh = load_cfrag<NS>(w.cb, b2 + (2 * t + 1) * 32);
+#pragma unroll
+        for (int m = 0; m < HT; ++m) {
+            gemm_tile<NS>(w.wb, a2 + ((2 * t) * HT + m) * 1024, bh[m], ls);
+            gemm_tile<NS>(w.wb, a2 + ((2 * t + 1) * HT + m) * 1024, bh[m], sh);
+        }
+        tile<NS> &x = xs[T0 + t];
+#pragma unroll
+        for (int n = 0; n < NS; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[n] += ls.v[n][r];
+                const float e = __builtin_amdgcn_exp2f(ls.v[n][r] * sgn);
+                x.v[n][r] = REV ? (x.v[n][r] - sh.v[n][r]) * e : x.v[n][r] * e + sh.v[n][r];
+            }
+    }
+#pragma unroll
+    for (int n = 0; n < NS; ++n) ldj[n] += st.ldj_scale * s[n];
+}
+
 // one runtime dispatch per step on (activation kind, direction) -> straight-line specialisations
 template <int NS, int TX, int HT, int C0, int CT, int T0, int TT>
 __device__ __forceinline__ void coupling_affine_dispatch(tile<NS> (&xs)[TX], const wptr w, const dstep &st,
@@ -961,6 +1001,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
         float ldj_c = 0.f;
         tile<NS> hid[MODE == 1 ? HT : 1];
         constexpr bool LIN = MODE == 2 || MODE == 7 || MODE == 8;    // programs with dense linear layers
+        tile<NS> hidp[MODE == 9 ? HT : 1];                           // MODE 9: hidden state kept between deep-conditioner steps
         btile<1> rq_bh[MODE == 3 ? HT : 1];      // MODE 3 (spline couplings): hidden B operands + group state
         rqs_elems rq_e;
 
@@ -1021,6 +1062,41 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     break;
                 case SX_STEP_MLP_HIDDEN:
                     if constexpr (MODE == 1) hidden_layer<NS, TX, HT, 0, TX, false>(xs, hid, w, 0, st.act);
+                    break;
+                case SX_STEP_CPL_HIDDEN:
+                    if constexpr (MODE == 9) {
+                        if constexpr (TX >= 2) {
+                            if (st.ct == TX / 2 && st.c0 == 0) { hidden_layer<NS, TX, HT, 0, TX / 2, false>(xs, hidp, w, 0, st.act); break; }
+                            if (st.ct == TX / 2 && st.c0 == TX / 2) { hidden_layer<NS, TX, HT, TX / 2, TX / 2, false>(xs, hidp, w, 0, st.act); break; }
+                        }
+                        hidden_layer<NS, TX, HT, 0, TX, false>(xs, hidp, w, 0, st.act);
+                    }
+                    break;
+                case SX_STEP_CPL_HIDDEN2:
+                    if constexpr (MODE == 9) {
+                        tile<NS> nh[HT];
+                        hidden_layer<NS, HT, HT, 0, HT, false>(hidp, nh, w, 0, st.act);
+#pragma unroll
+                        for (int m = 0; m < HT; ++m) hidp[m] = nh[m];
+                    }
+                    break;
+                case SX_STEP_COUPLING_AFFINE_DEEP:
+                    if constexpr (MODE == 9) {
+                        if constexpr (TX >= 2) {
+                            if (st.tt == TX / 2 && st.t0 == TX / 2) {
+                                if (st.reverse) coupling_affine_deep<NS, TX, HT, TX / 2, TX / 2, true>(xs, hidp, w, st, ldj);
+                                else coupling_affine_deep<NS, TX, HT, TX / 2, TX / 2, false>(xs, hidp, w, st, ldj);
+                                break;
+                            }
+                            if (st.tt == TX / 2 && st.t0 == 0) {
+                                if (st.reverse) coupling_affine_deep<NS, TX, HT, 0, TX / 2, true>(xs, hidp, w, st, ldj);
+                                else coupling_affine_deep<NS, TX, HT, 0, TX / 2, false>(xs, hidp, w, st, ldj);
+                                break;
+                            }
+                        }
+                        if (st.reverse) coupling_affine_deep<NS, TX, HT, 0, TX, true>(xs, hidp, w, st, ldj);
+                        else coupling_affine_deep<NS, TX, HT, 0, TX, false>(xs, hidp, w, st, ldj);
+                    }
                     break;
                 case SX_STEP_MLP_HIDDEN2:
                     if constexpr (MODE == 1) {
@@ -1264,6 +1340,7 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
     else if (a.mlp_mode == 4) SX_FL(4);
     else if (a.mlp_mode == 5) { if constexpr (TX >= 2) SX_FL(5); }
     else if (a.mlp_mode == 6) { if constexpr (TX >= 2) SX_FL(6); }
+    else if (a.mlp_mode == 9) SX_FL(9);
     else if (a.mlp_mode == 7) { if constexpr (TX >= 2) SX_FL(7); }
     else if (a.mlp_mode == 8) { if constexpr (TX >= 2) SX_FL(8); }
     else SX_FL(0);

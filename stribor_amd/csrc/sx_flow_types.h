@@ -43,13 +43,13 @@ struct sx_flow_args {
 #define SX_RQS_WAVES 2
 #endif
 #ifndef SX_WAVES_FOR
-#define SX_WAVES_FOR(TX, MODE) ((MODE) >= 7 ? 2 : (MODE) >= 5 ? ((TX) >= 4 ? 2 : 4) : ((TX) >= 4 ? 1 : ((MODE) == 3 ? SX_RQS_WAVES : ((MODE) == 0 ? 3 : 2))))
+#define SX_WAVES_FOR(TX, MODE) ((MODE) == 9 ? ((TX) >= 4 ? 1 : 2) : (MODE) >= 7 ? 2 : (MODE) >= 5 ? ((TX) >= 4 ? 2 : 4) : ((TX) >= 4 ? 1 : ((MODE) == 3 ? SX_RQS_WAVES : ((MODE) == 0 ? 3 : 2))))
 #endif
 
 // waves per workgroup: the pure split-coupling kernels (MODE 5 / 6) run 8-wave workgroups -- D <= 64 (128 VGPRs): two
 // per CU = 4 waves per SIMD sharing two weight rings; D = 128 (216 VGPRs): one per CU = 2 waves per SIMD on one ring
 #ifndef SX_BLOCK_WAVES
-#define SX_BLOCK_WAVES(TX, MODE) (((MODE) == 5 || (MODE) == 6 || ((MODE) >= 7 && (TX) >= 4)) ? 8 : 4)
+#define SX_BLOCK_WAVES(TX, MODE) (((MODE) == 5 || (MODE) == 6 || (((MODE) == 7 || (MODE) == 8) && (TX) >= 4)) ? 8 : 4)
 #endif
 // workgroups per CU the kernel is compiled for
 #define SX_BLOCKS_FOR(TX, MODE) (SX_WAVES_FOR(TX, MODE) * 4 / SX_BLOCK_WAVES(TX, MODE))

@@ -262,8 +262,12 @@ class Coupling(Transform):
             return False
         net = self._net()
         lin = net.linears()
-        if len(lin) != 2:
-            return False                  # deeper conditioners take the per-layer path
+        if lin[0][0].shape[1] != builder.dim + builder.latent_dim or lin[-1][0].shape[0] != 2 * builder.dim:
+            raise ValueError(f'latent_net maps {lin[0][0].shape[1]} -> {lin[-1][0].shape[0]}, expected '
+                             f'{builder.dim + builder.latent_dim} -> {2 * builder.dim}')
+        if len(lin) >= 3:                 # two or more hidden layers: hidden state kept in registers between steps
+            builder.add_coupling_affine_deep(lin, self.mask_vector(builder.dim), net.act_code, reverse, ldj_scale)
+            return True
         (W1, b1), (W2, b2) = lin
         if W1.shape[1] != builder.dim + builder.latent_dim or W2.shape[0] != 2 * builder.dim:
             raise ValueError(f'latent_net maps {W1.shape[1]} -> {W2.shape[0]}, expected '

@@ -386,6 +386,69 @@ class ProgramBuilder:
         self.steps.append(dict(kind=_hip.STEP_COUPLING_AFFINE, c0=c0, ct=ct, t0=t0, tt=tt, reverse=int(reverse),
                                act=act, blob_off=off, blob_floats=n, ldj_scale=ldj_scale, ldj_const=0.0))
 
+    def add_coupling_affine_deep(self, linears: Sequence[Tuple], mask: np.ndarray, act: int, reverse: bool,
+                                 ldj_scale: float) -> None:
+        """Affine coupling whose conditioner has two or more hidden layers (linears = [(W1, b1), ..., (W_out, b_out)]):
+        CPL_HIDDEN (state -> hidden), CPL_HIDDEN2 for every middle layer, COUPLING_AFFINE_DEEP (last hidden layer,
+        output layer, affine map); the hidden activations stay in registers between the steps."""
+        self._freeze_input()
+        assert len(linears) >= 3
+        D, T, HT = self.dim, self.tiles, self.h_tiles
+        mask = np.asarray(mask, dtype=np.float64).reshape(-1)
+        if mask.size == 1:
+            mask = np.full(D, mask[0])
+        cond_col = mask > 0.5
+        if D == 1:
+            cond_col = np.zeros(1, dtype=bool)
+        live_col = mask <= 0.5
+        col = self.col_of_slot
+        slot_cond = np.array([c >= 0 and cond_col[c] for c in col])
+        slot_live = np.array([c >= 0 and live_col[c] for c in col])
+        c0, ct, t0, tt = self._cond_variant(slot_cond, slot_live)
+        k_slots = np.arange(32 * c0, 32 * (c0 + ct))
+        col_idx = np.full(len(k_slots), -1, dtype=np.int64)
+        for i, p in enumerate(k_slots):
+            if p < self.n_slots:
+                if slot_cond[p]:
+                    col_idx[i] = col[p]
+            else:
+                li = p - self.n_slots
+                if li < self.latent_dim:
+                    col_idx[i] = D + li
+
+        def hidden_idx(width):
+            idx = np.full(32 * HT, -1, dtype=np.int64)
+            idx[:width] = np.arange(width)
+            return idx
+
+        (W1, b1) = linears[0]
+        off, n = self._alloc(_hip.packed_linear_floats(HT, ct))
+        self.jobs.append(_PackJob(W1, b1, hidden_idx(W1.shape[0]), col_idx, HT, ct, off))
+        self.steps.append(dict(kind=_hip.STEP_CPL_HIDDEN, c0=c0, ct=ct, t0=0, tt=0, reverse=0, act=act, blob_off=off,
+                               blob_floats=n, ldj_scale=0.0, ldj_const=0.0))
+        prev = W1.shape[0]
+        for (Wk, bk) in linears[1:-2]:
+            off, n = self._alloc(_hip.packed_linear_floats(HT, HT))
+            self.jobs.append(_PackJob(Wk, bk, hidden_idx(Wk.shape[0]), hidden_idx(prev), HT, HT, off))
+            self.steps.append(dict(kind=_hip.STEP_CPL_HIDDEN2, c0=0, ct=0, t0=0, tt=0, reverse=0, act=act, blob_off=off,
+                                   blob_floats=n, ldj_scale=0.0, ldj_const=0.0))
+            prev = Wk.shape[0]
+        (WL, bL), (Wo, bo) = linears[-2], linears[-1]
+        n1 = _hip.packed_linear_floats(HT, HT)
+        n2 = _hip.packed_linear_floats(2 * tt, HT)
+        off, n = self._alloc(n1 + n2)
+        self.jobs.append(_PackJob(WL, bL, hidden_idx(WL.shape[0]), hidden_idx(prev), HT, HT, off))
+        row2 = np.full(32 * 2 * tt, -1, dtype=np.int64)
+        for t in range(tt):
+            for i in range(32):
+                p = 32 * (t0 + t) + i
+                if p < self.n_slots and slot_live[p]:
+                    row2[32 * (2 * t) + i] = col[p]                 # log_scale rows, then shift rows (affine.py:66)
+                    row2[32 * (2 * t + 1) + i] = D + col[p]
+        self.jobs.append(_PackJob(Wo, bo, row2, hidden_idx(WL.shape[0]), 2 * tt, HT, off + n1))
+        self.steps.append(dict(kind=_hip.STEP_COUPLING_AFFINE_DEEP, c0=0, ct=0, t0=t0, tt=tt, reverse=int(reverse),
+                               act=act, blob_off=off, blob_floats=n, ldj_scale=ldj_scale, ldj_const=0.0))
+
     def _cond_variant(self, slot_cond, slot_live):
         """(c0, ct, t0, tt) tile ranges: pruned low / high halves when the masks align with the tiles, else dense."""
         T = self.tiles
@@ -644,6 +707,10 @@ class ProgramBuilder:
         if rqs and kinds & {_hip.STEP_COUPLING_AFFINE, _hip.STEP_LINEAR_TILE, _hip.STEP_ROW_SCALE_EXP}:
             # the spline kernel variant spends its registers on the group state: mixed flows run layer by layer
             raise NotImplementedError('spline couplings cannot share a fused program with affine couplings / linear layers')
+        deep = kinds & {_hip.STEP_CPL_HIDDEN, _hip.STEP_CPL_HIDDEN2, _hip.STEP_COUPLING_AFFINE_DEEP}
+        if deep and (rqs or kinds & {_hip.STEP_LINEAR_TILE, _hip.STEP_ROW_SCALE_EXP, _hip.STEP_MLP_HIDDEN,
+                                      _hip.STEP_MLP_HIDDEN2, _hip.STEP_MLP_OUT_TILE, _hip.STEP_COUPLING_AFFINE_BWD}):
+            raise NotImplementedError('deep-conditioner couplings only share a fused program with affine couplings')
         prog = _hip.sx_program()
         prog.n_steps = len(self.steps)
         prog.dim, prog.latent_dim = self.dim, self.latent_dim

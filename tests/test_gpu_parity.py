@@ -445,8 +445,8 @@ def test_mixed_spline_affine_flow_falls_back_per_layer_and_matches_oracle():
 
 
 def test_coupling_with_deep_conditioner_and_other_activations():
-    """Conditioners the fused coupling step does not take (two hidden layers; ReLU) still run on HIP kernels:
-    MLP program -> pruned parameters in HBM -> sx_affine_coupling."""
+    """Conditioners beyond Linear-Tanh-Linear: two hidden layers (fused as CPL_HIDDEN -> COUPLING_AFFINE_DEEP steps,
+    hidden state in registers) and other activations (run-time activation path)."""
     torch.manual_seed(21)
     for hidden, act, dim, mask in [([24, 16], 'Tanh', 10, 'ordered_left_half'), ([40], 'ReLU', 64, 'ordered_right_half'),
                                    ([32, 32], 'ELU', 7, 'parity_even')]:
@@ -864,3 +864,30 @@ def test_spline_coupling_flows_across_widths_against_oracle(dim, hidden, K, mask
         close(flow.inverse(y), x, rtol=1e-4, atol=1e-4)
     from stribor_amd.flows.spline import check_errors
     check_errors()
+
+
+def test_deep_conditioner_flows_fuse_into_one_launch():
+    """Flows whose couplings have 2 or 3 hidden layers (different widths) plan into ONE fused program (kernel MODE 9)
+    and match the oracle in both directions; mixed with single-hidden-layer couplings and a Flip."""
+    torch.manual_seed(8)
+    for dim, hiddens in [(64, ([64, 64], [64], [32, 64], [64, 48, 64])), (10, ([13, 7], [16, 16, 16])), (128, ([64, 64], [32]))]:
+        desc = []
+        for i, h in enumerate(hiddens * 2):
+            # (D = 128 keeps to tile-aligned masks: a DENSE deep step there exceeds the LDS ring and would un-fuse the flow)
+            masks = ('ordered_right_half', 'ordered_left_half', 'parity_odd') if dim < 128 else ('ordered_right_half', 'ordered_left_half')
+            desc.append({'kind': 'coupling_affine', 'dim': dim, 'hidden': list(h), 'latent_dim': 0, 'mask': masks[i % len(masks)]})
+            if i == 2:
+                desc.append({'kind': 'flip'})
+        flow = fd.build_flow(st, desc, dim)
+        spec = fd.flow_spec(desc, {k: v.clone() for k, v in flow.state_dict().items()})
+        flow = flow.to(DEV)
+        assert flow._fused_program(True, dim, 0, torch.device(DEV)) is not None
+        assert flow._fused_program(False, dim, 0, torch.device(DEV)) is not None
+        for n in (1, 1000):
+            x = torch.randn(n, dim)
+            close(flow.log_prob(x.to(DEV)), orc.flow_log_prob(spec, x), rtol=1e-5, atol=1e-4)
+            y, ldj = flow.forward_and_log_det_jacobian(x.to(DEV))
+            wy, wl = orc.flow_forward_and_ldj(spec, x)
+            close(y, wy, rtol=1e-5, atol=2e-5)
+            close(ldj, wl, rtol=1e-5, atol=1e-4)
+            close(flow.inverse(y), x, rtol=1e-4, atol=1e-4)
