@@ -239,6 +239,7 @@ int sx_pack_linear(const float *W, const float *b, int32_t out_dim, int32_t in_d
 #define SX_STEP_CPL_HIDDEN          13  /* deep conditioners (>= 2 hidden layers): hidden = act(W1 . state[c0..c0+ct) + b1), kept in
                                            registers for the next step; blob = pack_linear(W1, h_tiles x ct)                    */
 #define SX_STEP_CPL_HIDDEN2         14  /* hidden = act(Wk . hidden + bk); blob = pack_linear(Wk, h_tiles x h_tiles)              */
+                                        /* (in spline programs SX_STEP_RQS_HIDDEN with pad_ == 1 is the LAST hidden layer, fed by these) */
 #define SX_STEP_COUPLING_AFFINE_DEEP 15 /* the coupling's last hidden layer (from the kept hidden state), output layer and affine
                                            map: blob = pack_linear(W_L, h_tiles x h_tiles) ++ pack_linear(W_out, 2*tt x h_tiles) */
 

@@ -75,8 +75,8 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
                 const bool low = T >= 2 && s.c0 == 0 && s.ct == T / 2;
                 const bool high = T >= 2 && s.c0 == T / 2 && s.ct == T / 2;
                 const bool dense = s.c0 == 0 && s.ct == T;
-                SX_REQUIRE(low || high || dense, "sx_flow_run: step %d: RQS conditioner tiles must be low/high halves or dense", i);
-                need = sx_packed_linear_floats(p->h_tiles, s.ct); rqs = true; break;
+                SX_REQUIRE(s.pad_ == 1 || low || high || dense, "sx_flow_run: step %d: RQS conditioner tiles must be low/high halves or dense", i);
+                need = sx_packed_linear_floats(p->h_tiles, s.pad_ == 1 ? p->h_tiles : s.ct); rqs = true; break;
             }
             case SX_STEP_RQS_PHASE:
                 SX_REQUIRE(s.t0 < p->x_tiles && s.c0 >= 0 && s.c0 < 4 && s.ct >= 0 && s.ct < 3 && s.tt >= 1 && s.tt <= 16,
@@ -88,7 +88,8 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
         if ((int)s.blob_floats > mx) mx = (int)s.blob_floats;
         dstep &o = d->steps[i];
         o.kind = (uint8_t)s.kind; o.c0 = (uint8_t)s.c0; o.ct = (uint8_t)s.ct; o.t0 = (uint8_t)s.t0; o.tt = (uint8_t)s.tt;
-        o.reverse = (uint8_t)(s.reverse != 0); o.act = (uint8_t)s.act; o.pad = 0;
+        o.reverse = (uint8_t)(s.reverse != 0); o.act = (uint8_t)s.act;
+        o.pad = (uint8_t)(s.kind == SX_STEP_RQS_HIDDEN && s.pad_ == 1);      // deep conditioner: source = kept hidden state
         o.blob_off = s.blob_off; o.blob_floats = s.blob_floats; o.ldj_scale = s.ldj_scale; o.ldj_const = s.ldj_const;
         o.mask = (uint32_t)s.pad_;
     }
@@ -100,8 +101,8 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     if (rqs) *mlp_mode = 3;
     SX_REQUIRE(!(bwd && (rqs || lin || aff || *mlp_mode == 1)), "sx_flow_run: backward steps cannot be mixed with other step kinds");
     if (bwd) *mlp_mode = 4;
-    SX_REQUIRE(!(deep && (lin || rqs || bwd || *mlp_mode == 1)), "sx_flow_run: deep-conditioner steps only mix with affine couplings");
-    if (deep) *mlp_mode = 9;
+    SX_REQUIRE(!(deep && (lin || bwd || *mlp_mode == 1)), "sx_flow_run: deep-conditioner steps only mix with couplings");
+    if (deep) *mlp_mode = rqs ? 10 : 9;     // 10: the spline kernel with the deep-conditioner steps
     // MODE 5 / 6: nothing but tanh-folded affine couplings on half the tiles conditioned on the other half, all in
     // one direction (5 reverse, 6 forward) -- the plain RealNVP log_prob / sample program.  Its kernel carries two
     // straight-line arms only, which keeps the state in place (no phi copies) at 130 VGPRs.

@@ -337,14 +337,12 @@ __device__ __forceinline__ wptr make_wptr(int base_floats, int lane) {
 // FOLDED: weights carry tanh's constants, the activation is r = 1/(exp2(z') + 1) (SX_ACT_TANH_FOLDED) and the
 // activation of tile m-1 is issued between the MFMAs of tile m; the LAST tile is returned un-activated so the
 // caller can hide it under its own MFMAs.  Otherwise: runtime activation `act`, applied in place.
-template <int NS, int NSRC, int HT, int C0, int CT, bool FOLDED>
-__device__ __forceinline__ void hidden_layer(const tile<NS> (&src)[NSRC], tile<NS> (&hid)[HT], const wptr w, int off,
-                                             int act) {
+// (body: the B operands `bsrc` are given -- hidden_layer forms them from state tiles, the deep-conditioner steps of the
+//  spline kernel keep the previous layer's activations in this form)
+template <int NS, int HT, int CT, bool FOLDED>
+__device__ __forceinline__ void hidden_body(const btile<NS> (&bsrc)[CT], tile<NS> (&hid)[HT], const wptr w, int off,
+                                            int act) {
     const int bias = off + HT * CT * 1024;
-    btile<NS> bsrc[CT];          // B operands are formed once and reused by every output tile
-#pragma unroll
-    for (int c = 0; c < CT; ++c) bsrc[c] = make_btile<NS>(src[C0 + c]);
-    __builtin_amdgcn_sched_barrier(0);
     if constexpr (FOLDED) {
         tile<NS> acc = load_cfrag<NS>(w.cb, bias);
 #pragma unroll
@@ -377,6 +375,16 @@ __device__ __forceinline__ void hidden_layer(const tile<NS> (&src)[NSRC], tile<N
             hid[m] = acc;
         }
     }
+}
+
+template <int NS, int NSRC, int HT, int C0, int CT, bool FOLDED>
+__device__ __forceinline__ void hidden_layer(const tile<NS> (&src)[NSRC], tile<NS> (&hid)[HT], const wptr w, int off,
+                                             int act) {
+    btile<NS> bsrc[CT];          // B operands are formed once and reused by every output tile
+#pragma unroll
+    for (int c = 0; c < CT; ++c) bsrc[c] = make_btile<NS>(src[C0 + c]);
+    __builtin_amdgcn_sched_barrier(0);
+    hidden_body<NS, HT, CT, FOLDED>(bsrc, hid, w, off, act);
 }
 
 // Affine coupling step (affine.py:104-109 through coupling.py:69-95), conditioner evaluated once (quirk Q2).
@@ -1002,7 +1010,8 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
         tile<NS> hid[MODE == 1 ? HT : 1];
         constexpr bool LIN = MODE == 2 || MODE == 7 || MODE == 8;    // programs with dense linear layers
         tile<NS> hidp[MODE == 9 ? HT : 1];                           // MODE 9: hidden state kept between deep-conditioner steps
-        btile<1> rq_bh[MODE == 3 ? HT : 1];      // MODE 3 (spline couplings): hidden B operands + group state
+        constexpr bool RQ = MODE == 3 || MODE == 10;      // spline couplings (10: + deep conditioners)
+        btile<1> rq_bh[RQ ? HT : 1];             // hidden B operands + group state
         rqs_elems rq_e;
 
         for (int s = 0; s < n_steps; ++s) {
@@ -1044,7 +1053,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
             } else
             switch (st.kind) {
                 case SX_STEP_COUPLING_AFFINE:
-                    if constexpr (MODE == 3 || MODE == 7 || MODE == 8) break;   // spline programs carry no affine couplings (register budget); 7 / 8: handled above
+                    if constexpr (RQ || MODE == 7 || MODE == 8) break;   // spline programs carry no affine couplings (register budget); 7 / 8: handled above
                     if constexpr (TX >= 2) {
                         if (st.ct == TX / 2 && st.c0 == 0 && st.t0 == TX / 2) {          // cond = low tiles
                             coupling_affine_dispatch<NS, TX, HT, 0, TX / 2, TX / 2, TX / 2>(xs, w, st, ldj, pf);
@@ -1064,6 +1073,20 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     if constexpr (MODE == 1) hidden_layer<NS, TX, HT, 0, TX, false>(xs, hid, w, 0, st.act);
                     break;
                 case SX_STEP_CPL_HIDDEN:
+                    if constexpr (MODE == 10 && NS == 1) {
+                        // spline couplings with deep conditioners: the activations wait for the next layer in split (B
+                        // operand) form in rq_bh -- the array the phases use anyway: no extra registers
+                        tile<1> hd[HT];
+                        if constexpr (TX >= 2) {
+                            if (st.ct == TX / 2 && st.c0 == 0) hidden_layer<1, TX, HT, 0, TX / 2, false>(xs, hd, w, 0, st.act);
+                            else if (st.ct == TX / 2) hidden_layer<1, TX, HT, TX / 2, TX / 2, false>(xs, hd, w, 0, st.act);
+                            else hidden_layer<1, TX, HT, 0, TX, false>(xs, hd, w, 0, st.act);
+                        } else {
+                            hidden_layer<1, TX, HT, 0, TX, false>(xs, hd, w, 0, st.act);
+                        }
+#pragma unroll
+                        for (int m = 0; m < HT; ++m) rq_bh[m] = make_btile<1>(hd[m]);
+                    }
                     if constexpr (MODE == 9) {
                         if constexpr (TX >= 2) {
                             if (st.ct == TX / 2 && st.c0 == 0) { hidden_layer<NS, TX, HT, 0, TX / 2, false>(xs, hidp, w, 0, st.act); break; }
@@ -1073,6 +1096,12 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     }
                     break;
                 case SX_STEP_CPL_HIDDEN2:
+                    if constexpr (MODE == 10 && NS == 1) {
+                        tile<1> hd[HT];
+                        hidden_body<1, HT, HT, false>(rq_bh, hd, w, 0, st.act);
+#pragma unroll
+                        for (int m = 0; m < HT; ++m) rq_bh[m] = make_btile<1>(hd[m]);
+                    }
                     if constexpr (MODE == 9) {
                         tile<NS> nh[HT];
                         hidden_layer<NS, HT, HT, 0, HT, false>(hidp, nh, w, 0, st.act);
@@ -1168,8 +1197,11 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     }
                     break;
                 case SX_STEP_RQS_HIDDEN:
-                    if constexpr (MODE == 3 && NS == 1) {
+                    if constexpr (RQ && NS == 1) {
                         tile<1> hd[HT];
+                        if (MODE == 10 && st.pad == 1) {   // deep conditioner: the last hidden layer, from the previous one's activations
+                            hidden_body<1, HT, HT, true>(rq_bh, hd, w, 0, st.act);
+                        } else
                         if constexpr (TX >= 2) {
                             if (st.ct == TX / 2 && st.c0 == 0) hidden_layer<1, TX, HT, 0, TX / 2, true>(xs, hd, w, 0, st.act);
                             else if (st.ct == TX / 2) hidden_layer<1, TX, HT, TX / 2, TX / 2, true>(xs, hd, w, 0, st.act);
@@ -1184,7 +1216,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     }
                     break;
                 case SX_STEP_RQS_PHASE:
-                    if constexpr (MODE == 3 && NS == 1) rqs_phase<TX, HT>(xs, rq_bh, rq_e, w, st, ldj[0], lane);
+                    if constexpr (RQ && NS == 1) rqs_phase<TX, HT>(xs, rq_bh, rq_e, w, st, ldj[0], lane);
                     break;
                 case SX_STEP_ROW_SCALE_EXP:
                     // x *= exp(+-diag * t_row)  (affine.py:263), t_row optionally log1p|t| (affine.py:239-240)
@@ -1341,6 +1373,7 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
     else if (a.mlp_mode == 5) { if constexpr (TX >= 2) SX_FL(5); }
     else if (a.mlp_mode == 6) { if constexpr (TX >= 2) SX_FL(6); }
     else if (a.mlp_mode == 9) SX_FL(9);
+    else if (a.mlp_mode == 10) SX_FL(10);
     else if (a.mlp_mode == 7) { if constexpr (TX >= 2) SX_FL(7); }
     else if (a.mlp_mode == 8) { if constexpr (TX >= 2) SX_FL(8); }
     else SX_FL(0);

@@ -241,14 +241,14 @@ class Coupling(Transform):
         if not isinstance(net, MLP) or net.activation_name != 'Tanh' or sp.n_bins > 16 or sp.spline_type != 'quadratic':
             return False             # cubic-spline couplings run layer by layer (MLP program + sx_cubic_coupling)
         lin = net.linears()
-        if len(lin) != 2:
+        if len(lin) < 2:
             return False
-        (W1, b1), (W2, b2) = lin
+        (W1, b1), (W2, b2) = lin[0], lin[-1]
         if W1.shape[1] != builder.dim + builder.latent_dim or W2.shape[0] != builder.dim * (3 * sp.n_bins - 1):
             raise ValueError(f'latent_net maps {W1.shape[1]} -> {W2.shape[0]}, expected '
                              f'{builder.dim + builder.latent_dim} -> {builder.dim * (3 * sp.n_bins - 1)}')
         builder.add_coupling_rqs(W1, b1, W2, b2, self.mask_vector(builder.dim), reverse, ldj_scale, W1.shape[0],
-                                 sp.n_bins, sp.lower, sp.upper, sp.lower, sp.upper)
+                                 sp.n_bins, sp.lower, sp.upper, sp.lower, sp.upper, middle=lin[1:-1])
         return True
 
     def _plan_first_mask(self, dim):

@@ -461,9 +461,11 @@ class ProgramBuilder:
         return 0, T, 0, T
 
     def add_coupling_rqs(self, W1, b1, W2, b2, mask: np.ndarray, reverse: bool, ldj_scale: float, hidden: int,
-                         n_bins: int, left: float, right: float, bottom: float, top: float) -> None:
-        """Rational-quadratic spline coupling, fused: 1 hidden step + 12 phase steps per transformed tile.
-        The conditioner must be Linear-Tanh-Linear (folded tanh); n_bins <= 16."""
+                         n_bins: int, left: float, right: float, bottom: float, top: float, middle=()) -> None:
+        """Rational-quadratic spline coupling, fused: hidden step(s) + 12 phase steps per transformed tile.
+        Tanh conditioners; with two or more hidden layers (`middle` = [(W, b), ...] between W1 and the output layer W2)
+        the earlier layers run as CPL_HIDDEN / CPL_HIDDEN2 steps and the last hidden layer (folded tanh) as the
+        RQS_HIDDEN step; n_bins <= 16."""
         self._freeze_input()
         D, T, HT, K = self.dim, self.tiles, self.h_tiles, n_bins
         if K > 16:
@@ -492,13 +494,38 @@ class ProgramBuilder:
                 li = p - self.n_slots
                 if li < self.latent_dim:
                     col_idx[i] = D + li
-        row_idx = np.full(32 * HT, -1, dtype=np.int64)
-        row_idx[:hidden] = np.arange(hidden)
-        off, n = self._alloc(_hip.packed_linear_floats(HT, ct))
+        def hidden_idx(width):
+            idx = np.full(32 * HT, -1, dtype=np.int64)
+            idx[:width] = np.arange(width)
+            return idx
+
         sc = np.full(32 * HT, 2.0 * LOG2E)
-        self.jobs.append(_PackJob(W1, b1, row_idx, col_idx, HT, ct, off, sc, sc, 0.0))
-        self.steps.append(dict(kind=_hip.STEP_RQS_HIDDEN, c0=c0, ct=ct, t0=t0, tt=tt, reverse=int(reverse),
-                               act=_hip.ACT_TANH_FOLDED, blob_off=off, blob_floats=n, ldj_scale=0.0, ldj_const=0.0))
+        if not middle:
+            off, n = self._alloc(_hip.packed_linear_floats(HT, ct))
+            self.jobs.append(_PackJob(W1, b1, hidden_idx(hidden), col_idx, HT, ct, off, sc, sc, 0.0))
+            self.steps.append(dict(kind=_hip.STEP_RQS_HIDDEN, c0=c0, ct=ct, t0=t0, tt=tt, reverse=int(reverse),
+                                   act=_hip.ACT_TANH_FOLDED, blob_off=off, blob_floats=n, ldj_scale=0.0, ldj_const=0.0))
+        else:
+            tanh = _hip.ACT_CODES['Tanh']
+            off, n = self._alloc(_hip.packed_linear_floats(HT, ct))
+            self.jobs.append(_PackJob(W1, b1, hidden_idx(W1.shape[0]), col_idx, HT, ct, off))
+            self.steps.append(dict(kind=_hip.STEP_CPL_HIDDEN, c0=c0, ct=ct, t0=0, tt=0, reverse=0, act=tanh, blob_off=off,
+                                   blob_floats=n, ldj_scale=0.0, ldj_const=0.0))
+            prev = W1.shape[0]
+            for (Wk, bk) in middle[:-1]:
+                off, n = self._alloc(_hip.packed_linear_floats(HT, HT))
+                self.jobs.append(_PackJob(Wk, bk, hidden_idx(Wk.shape[0]), hidden_idx(prev), HT, HT, off))
+                self.steps.append(dict(kind=_hip.STEP_CPL_HIDDEN2, c0=0, ct=0, t0=0, tt=0, reverse=0, act=tanh,
+                                       blob_off=off, blob_floats=n, ldj_scale=0.0, ldj_const=0.0))
+                prev = Wk.shape[0]
+            WL, bL = middle[-1]
+            hidden = WL.shape[0]
+            off, n = self._alloc(_hip.packed_linear_floats(HT, HT))
+            self.jobs.append(_PackJob(WL, bL, hidden_idx(hidden), hidden_idx(prev), HT, HT, off, sc, sc, 0.0))
+            step = dict(kind=_hip.STEP_RQS_HIDDEN, c0=0, ct=0, t0=t0, tt=tt, reverse=int(reverse),
+                        act=_hip.ACT_TANH_FOLDED, blob_off=off, blob_floats=n, ldj_scale=0.0, ldj_const=0.0)
+            step['pad_'] = 1                  # source = the hidden state kept by the CPL_HIDDEN steps
+            self.steps.append(step)
         col2 = np.full(32 * HT, -1, dtype=np.int64)
         col2[:hidden] = np.arange(hidden)
         # forward searches the widths on [left, right], inverse the heights on [bottom, top]
@@ -708,9 +735,9 @@ class ProgramBuilder:
             # the spline kernel variant spends its registers on the group state: mixed flows run layer by layer
             raise NotImplementedError('spline couplings cannot share a fused program with affine couplings / linear layers')
         deep = kinds & {_hip.STEP_CPL_HIDDEN, _hip.STEP_CPL_HIDDEN2, _hip.STEP_COUPLING_AFFINE_DEEP}
-        if deep and (rqs or kinds & {_hip.STEP_LINEAR_TILE, _hip.STEP_ROW_SCALE_EXP, _hip.STEP_MLP_HIDDEN,
-                                      _hip.STEP_MLP_HIDDEN2, _hip.STEP_MLP_OUT_TILE, _hip.STEP_COUPLING_AFFINE_BWD}):
-            raise NotImplementedError('deep-conditioner couplings only share a fused program with affine couplings')
+        if deep and kinds & {_hip.STEP_LINEAR_TILE, _hip.STEP_ROW_SCALE_EXP, _hip.STEP_MLP_HIDDEN, _hip.STEP_MLP_HIDDEN2,
+                             _hip.STEP_MLP_OUT_TILE, _hip.STEP_COUPLING_AFFINE_BWD}:
+            raise NotImplementedError('deep-conditioner couplings only share a fused program with other couplings')
         prog = _hip.sx_program()
         prog.n_steps = len(self.steps)
         prog.dim, prog.latent_dim = self.dim, self.latent_dim

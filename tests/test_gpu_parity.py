@@ -891,3 +891,27 @@ def test_deep_conditioner_flows_fuse_into_one_launch():
             close(y, wy, rtol=1e-5, atol=2e-5)
             close(ldj, wl, rtol=1e-5, atol=1e-4)
             close(flow.inverse(y), x, rtol=1e-4, atol=1e-4)
+
+
+def test_deep_conditioner_spline_flows_fuse_into_one_launch():
+    """Spline-coupling flows whose conditioners have 2 or 3 hidden layers run as ONE fused program (the earlier layers'
+    activations wait in B-operand form in the registers the spline phases use anyway) and match the oracle."""
+    torch.manual_seed(18)
+    for dim, K, hiddens in [(64, 16, ([64, 64], [64], [32, 64])), (10, 5, ([13, 7], [16, 16, 16])), (40, 8, ([64, 64, 64],))]:
+        desc = [{'kind': 'coupling_rqs', 'dim': dim, 'hidden': list(h), 'n_bins': K, 'lower': -3, 'upper': 3, 'latent_dim': 0,
+                 'mask': ('ordered_right_half', 'ordered_left_half', 'parity_odd')[i % 3]} for i, h in enumerate(hiddens * 2)]
+        flow = fd.build_flow(st, desc, dim)
+        spec = fd.flow_spec(desc, {k: v.clone() for k, v in flow.state_dict().items()})
+        flow = flow.to(DEV)
+        assert flow._fused_program(True, dim, 0, torch.device(DEV)) is not None
+        assert flow._fused_program(False, dim, 0, torch.device(DEV)) is not None
+        for n in (1, 500):
+            x = torch.randn(n, dim) * 1.6
+            close(flow.log_prob(x.to(DEV)), orc.flow_log_prob(spec, x), rtol=1e-5, atol=2e-4 * max(1, dim // 32))
+            y, ldj = flow.forward_and_log_det_jacobian(x.to(DEV))
+            wy, wl = orc.flow_forward_and_ldj(spec, x)
+            close(y, wy, rtol=1e-5, atol=2e-5)
+            close(ldj, wl, rtol=1e-5, atol=2e-4 * max(1, dim // 32))
+            close(flow.inverse(y), x, rtol=1e-4, atol=1e-4)
+    from stribor_amd.flows.spline import check_errors
+    check_errors()
