@@ -638,17 +638,23 @@ __device__ __forceinline__ void rqs_select(tile<1> (&acc)[4], rqs_elems &e, int 
     const float inv = rqs_softmax<Q, KC>(acc, K);
     const int Kn = KC ? KC : K;
     const int b = e.b[Q];
-    float k_b = lo, k_n = hi, cs = 0.f;
+    // only two knots are needed: select their cumulative sums in the sweep and rescale those two afterwards
+    float cs = 0.f, cs_b = 0.f, cs_n = 0.f;
+    bool has_b = false, has_n = false;
 #pragma unroll
     for (int j = 1; j <= 16; ++j) {
-        if (KC ? (j < KC) : true) {                                      // knot K is `hi` (the initial k_n)
+        if (KC ? (j < KC) : true) {                                      // knot K is `hi` (the default k_n)
             cs += RQS_MIN + RQS_P(acc, Q, j - 1) * inv;
             const bool used = KC ? true : (j < Kn);
-            const float knot = (hi - lo) * cs + lo;
-            k_b = (used && j == b) ? knot : k_b;
-            k_n = (used && j == b + 1) ? knot : k_n;
+            const bool is_b = used && j == b, is_n = used && j == b + 1;
+            cs_b = is_b ? cs : cs_b;
+            cs_n = is_n ? cs : cs_n;
+            has_b = has_b || is_b;
+            has_n = has_n || is_n;
         }
     }
+    const float k_b = has_b ? (hi - lo) * cs_b + lo : lo;
+    const float k_n = has_n ? (hi - lo) * cs_n + lo : hi;
     e.c_b[Q] = k_b;
     e.c_w[Q] = k_n - k_b;
 }
@@ -664,13 +670,18 @@ __device__ __forceinline__ void rqs_eval(tile<1> (&acc)[4], const rqs_elems &e, 
     const int Kn = KC ? KC : K;
     const float cst = 0.5397424172369522f;                      // log(exp(1 - 1e-3) - 1), :81 boundary derivative constant
     float r_b = cst, r_n = cst;
+    // derivative k sits between bins k and k+1: it is the RIGHT knot's of bin k and the LEFT knot's of bin k+1, so one
+    // compare per bin index serves both selections
+    bool is_prev = (b == 0);             // "bin index == k" carried to the next iteration as "bin index - 1 == k - 1"
 #pragma unroll
     for (int k = 0; k < 15; ++k) {
         if (KC ? (k < KC - 1) : true) {
             const bool used = KC ? true : (k < Kn - 1);
             const float v = RQS_P(acc, Q, k);
-            r_b = (used && k == b - 1) ? v : r_b;
-            r_n = (used && k == b) ? v : r_n;
+            const bool is_next = (b == k + 1);
+            r_n = (used && is_prev) ? v : r_n;          // k == b
+            r_b = (used && is_next) ? v : r_b;          // k == b - 1
+            is_prev = is_next;
         }
     }
     const float d_b = RQS_MIN + rqs_softplus(r_b), d_n = RQS_MIN + rqs_softplus(r_n);
