@@ -299,12 +299,15 @@ int sx_flow_run(const sx_program *prog_host, const float *blobs, const void *x, 
                 int32_t mlp_out_dim, const float *row_t, float *side, int64_t n_rows, int32_t dtype, void *stream);
 
 /* Weight-gradient contraction of the training backward pass:
- *   dW[i, j] += sum_n A[n, i] * B[n, j]   (dW row stride ldw),   db[i] += sum_n A[n, i]   (db may be NULL)
+ *   dW[rm(i), cm(j)] += sum_n A[n, i] * B[n, j]   (dW row stride ldw),   db[rm(i)] += sum_n A[n, i]   (db may be NULL)
  * A = [n_rows, M], B = [n_rows, Nc] row-major fp32 with row strides lda / ldb (slices of `side`), M, Nc <= 128.
- * dW / db are accumulated into (float atomics): zero them first.  Replaces autograd's dense matmuls over the
- * batch axis for nn.Linear inside stribor/net/mlp.py:48-58. */
+ * row_map [M] / col_map [Nc] (device int32, either may be NULL = identity) send the kernel's slot order straight
+ * to the parameter's own rows / columns; negative entries are dropped.  dW / db are accumulated into (zero them
+ * first) by one writer per element: results do not depend on scheduling.  Launches on one stream share a scratch
+ * for the per-workgroup partial tiles.  Replaces autograd's dense matmuls over the batch axis for nn.Linear
+ * inside stribor/net/mlp.py:48-58. */
 int sx_wgrad(const float *A, int64_t lda, int32_t M, const float *B, int64_t ldb, int32_t Nc, int64_t n_rows,
-             float *dW, int64_t ldw, float *db, void *stream);
+             float *dW, int64_t ldw, float *db, const int32_t *row_map, const int32_t *col_map, void *stream);
 
 /* LDS bytes and grid the launcher will use for a program (introspection for tests/bench). */
 int sx_flow_launch_info(const sx_program *prog_host, int64_t n_rows, int32_t *grid, int32_t *block,

@@ -104,7 +104,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.sx_flow_run.restype = i32
     lib.sx_flow_run.argtypes = [C.POINTER(sx_program), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, i64, i32, vp]
     lib.sx_wgrad.restype = i32
-    lib.sx_wgrad.argtypes = [vp, i64, i32, vp, i64, i32, i64, vp, i64, vp, vp]
+    lib.sx_wgrad.argtypes = [vp, i64, i32, vp, i64, i32, i64, vp, i64, vp, vp, vp, vp]
     lib.sx_flow_launch_info.restype = i32
     lib.sx_flow_launch_info.argtypes = [C.POINTER(sx_program), i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
 

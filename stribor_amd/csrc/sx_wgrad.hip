@@ -7,14 +7,20 @@
 // the row-major operands ARE the MFMA fragments: v_mfma_f32_32x32x2_f32 wants A^T[i = lane&31][k = lane>>5] and
 // B[k = lane>>5][j = lane&31] with k = the row, i.e. each lane loads one float of a row (lanes of a half read
 // 128 contiguous bytes), no transposes.  Each wave keeps the (M/32) x (Nc/32) output tiles in registers over its
-// row slice and the workgroup adds them to dW with float atomics once (rows of 128 B per lane half).
+// row slice; the waves of a workgroup then sum their tiles in LDS, the workgroup stores ONE partial
+// tile to a per-stream scratch with plain coalesced stores, and a second small kernel sums the <= 512 partials
+// per element and adds them to dW / db (one writer per element).  Global float atomics on M x Nc addresses were
+// the cost of the first version: 4096 waves x 4096 contended adds took twice as long as the data pass itself.
 #include "sx_common.h"
+#include <mutex>
+#include <vector>
 
-template <int MT, int NT>
-__global__ __launch_bounds__(256) void wgrad_kernel(const float *__restrict__ A, int64_t lda,
+template <int MT, int NT, int WB>
+__global__ __launch_bounds__(64 * WB) void wgrad_kernel(const float *__restrict__ A, int64_t lda,
                                                     const float *__restrict__ B, int64_t ldb, int64_t n_rows,
-                                                    float *__restrict__ dW, int64_t ldw, float *__restrict__ db,
-                                                    int m_valid, int n_valid) {
+                                                    float *__restrict__ part, int m_valid, int n_valid) {
+    constexpr int M32 = 32 * MT, N32 = 32 * NT;
+    __shared__ float red[M32 * N32 + M32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, kk = lane >> 5;
     f32x16 acc[MT][NT];
@@ -29,8 +35,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *__restrict__ A,
     for (int m = 0; m < MT; ++m) bsum[m] = 0.f;
 
     // rows are dealt to waves in blocks of 16 (8 MFMA k-steps of 2 rows), grid-strided
-    const int64_t n_waves = (int64_t)gridDim.x * 4;
-    const int64_t w_id = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t n_waves = (int64_t)gridDim.x * WB;
+    const int64_t w_id = (int64_t)blockIdx.x * WB + wave;
     for (int64_t r0 = w_id * 16; r0 < n_rows; r0 += n_waves * 16) {
         float a[8][MT], b[8][NT];
 #pragma unroll
@@ -53,38 +59,123 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *__restrict__ A,
             }
         }
     }
-    // C layout: lane (col j = lane&31, half) holds rows kmap(r, half)
+    // C layout: lane (col j = lane&31, half) holds rows kmap(r, half).  The waves take turns adding their tiles to
+    // the LDS copy with plain read-add-write (ds_add_f32 serialises its lanes: 64 of them per wave cost 40 us).
+    for (int w = 0; w < WB; ++w) {
+        if (wave == w) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+                for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * kk, col = 32 * n + i;
-                if (row < m_valid && col < n_valid) atomicAdd(&dW[(int64_t)row * ldw + col], acc[m][n][r]);
+                    for (int r = 0; r < 16; ++r) {
+                        const int e = (32 * m + (r & 3) + 8 * (r >> 2) + 4 * kk) * N32 + 32 * n + i;
+                        red[e] = (w == 0 ? 0.f : red[e]) + acc[m][n][r];
+                    }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const float t = bsum[m] + __shfl_xor(bsum[m], 32, 64);
+                const int e = M32 * N32 + 32 * m + i;
+                if (kk == 0) red[e] = (w == 0 ? 0.f : red[e]) + t;
             }
-    if (db != nullptr) {
+        }
+        __syncthreads();
+    }
+    float *dst = part + (int64_t)blockIdx.x * (M32 * N32 + M32);
+    for (int e = threadIdx.x; e < M32 * N32 + M32; e += 64 * WB) dst[e] = red[e];
+}
+
+// dW[rm(row)][cm(col)] += sum_p part[p][row * N32 + col]; db[rm(row)] += sum_p part[p][M32 * N32 + row], with
+// rm / cm the optional row / column maps (negative = dropped).  256 threads = 32 adjacent elements x 8 partial
+// groups (128 B coalesced reads, G / 8 independent loads per thread); one writer per element, no atomics.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int n_part, int M32, int N32,
+                                                           float *__restrict__ dW, int64_t ldw, float *__restrict__ db,
+                                                           int m_valid, int n_valid, const int32_t *__restrict__ row_map,
+                                                           const int32_t *__restrict__ col_map) {
+    __shared__ float red[8][32];
+    const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int E = M32 * N32 + M32;
+    const int e = blockIdx.x * 32 + el;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < E) {
+        const float *src = part + e;
+        int p = grp;
+        for (; p + 24 < n_part; p += 32) {
+            s0 += src[(int64_t)p * E];
+            s1 += src[(int64_t)(p + 8) * E];
+            s2 += src[(int64_t)(p + 16) * E];
+            s3 += src[(int64_t)(p + 24) * E];
+        }
+        for (; p < n_part; p += 8) s0 += src[(int64_t)p * E];
+    }
+    red[grp][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp == 0 && e < E) {
+        float t = 0.f;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const float t = bsum[m] + __shfl_xor(bsum[m], 32, 64);
-            if (kk == 0 && 32 * m + i < m_valid) atomicAdd(&db[32 * m + i], t);
+        for (int g = 0; g < 8; ++g) t += red[g][el];
+        if (e < M32 * N32) {
+            int row = e / N32, col = e % N32;
+            if (row < m_valid && col < n_valid) {
+                if (row_map != nullptr) row = row_map[row];
+                if (col_map != nullptr) col = col_map[col];
+                if (row >= 0 && col >= 0) dW[(int64_t)row * ldw + col] += t;
+            }
+        } else if (db != nullptr && e - M32 * N32 < m_valid) {
+            int row = e - M32 * N32;
+            if (row_map != nullptr) row = row_map[row];
+            if (row >= 0) db[row] += t;
         }
     }
 }
 
+// per (device, stream) scratch for the partial tiles (grow-only; calls on one stream are ordered on the device)
+struct part_slot { int dev; hipStream_t stream; float *ptr; size_t floats; };
+static float *partial_scratch(hipStream_t stream, size_t floats) {
+    static std::mutex mu;
+    static std::vector<part_slot> slots;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> g(mu);
+    for (part_slot &w : slots)
+        if (w.dev == dev && w.stream == stream) {
+            if (w.floats >= floats) return w.ptr;
+            if (hipStreamSynchronize(stream) != hipSuccess) return nullptr;      // earlier launches still read it
+            (void)hipFree(w.ptr);
+            w.ptr = nullptr; w.floats = 0;
+            if (hipMalloc(&w.ptr, floats * sizeof(float)) != hipSuccess) return nullptr;
+            w.floats = floats;
+            return w.ptr;
+        }
+    float *p = nullptr;
+    if (hipMalloc(&p, floats * sizeof(float)) != hipSuccess) return nullptr;
+    slots.push_back(part_slot{dev, stream, p, floats});
+    return p;
+}
+
 extern "C" int sx_wgrad(const float *A, int64_t lda, int32_t M, const float *B, int64_t ldb, int32_t Nc,
-                        int64_t n_rows, float *dW, int64_t ldw, float *db, void *stream) {
+                        int64_t n_rows, float *dW, int64_t ldw, float *db, const int32_t *row_map,
+                        const int32_t *col_map, void *stream) {
     SX_REQUIRE(A && B && dW, "sx_wgrad: null pointer");
     SX_REQUIRE(M >= 1 && M <= 128 && Nc >= 1 && Nc <= 128 && n_rows >= 0, "sx_wgrad: M, Nc must be in 1..128");
     if (n_rows == 0) return SX_OK;
     const int mt = (M + 31) / 32, nt = (Nc + 31) / 32;
-    int64_t g = (n_rows + 16 * 4 - 1) / (16 * 4);
-    if (g > 1024) g = 1024;
     hipStream_t st = sx_stream(stream);
+    const int E = 32 * mt * 32 * nt + 32 * mt;
+    // waves per workgroup by register budget (accumulators = 16 * MT * NT VGPRs), workgroups = what fills the CUs
 #define SX_WG(MT_, NT_)                                                                                            \
     if (mt == MT_ && nt == NT_) {                                                                                  \
-        hipLaunchKernelGGL((wgrad_kernel<MT_, NT_>), dim3((int)g), dim3(256), 0, st, A, lda, B, ldb, n_rows, dW, ldw, db, \
-                           M, Nc);                                                                                 \
+        constexpr int WB = MT_ * NT_ <= 2 ? 16 : (MT_ * NT_ <= 8 ? 8 : 4);                                         \
+        constexpr int GMAX = MT_ * NT_ <= 2 ? 256 : (MT_ * NT_ <= 4 ? 512 : 256);                                  \
+        int64_t g = (n_rows + 16 * WB - 1) / (16 * WB);                                                            \
+        if (g > GMAX) g = GMAX;                                                                                    \
+        float *part = partial_scratch(st, (size_t)GMAX * E);                                                       \
+        SX_REQUIRE(part != nullptr, "sx_wgrad: cannot allocate the partial-tile scratch");                         \
+        hipLaunchKernelGGL((wgrad_kernel<MT_, NT_, WB>), dim3((int)g), dim3(64 * WB), 0, st, A, lda, B, ldb,       \
+                           n_rows, part, M, Nc);                                                                        \
+        SX_LAUNCH_CHECK();                                                                                         \
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((E + 31) / 32), dim3(256), 0, st, part, (int)g, 32 * MT_,     \
+                           32 * NT_, dW, ldw, db, M, Nc, row_map, col_map);                                                        \
         SX_LAUNCH_CHECK();                                                                                         \
         return SX_OK;                                                                                              \
     }

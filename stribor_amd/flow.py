@@ -51,49 +51,45 @@ class _FusedLogProb(torch.autograd.Function):
         ht = 32 * bprog.prog.h_tiles
         width = max(info['side_width'] for _, info in layers)
         dev = z.device
-        # slot-ordered gradient accumulators per layer (sx_wgrad adds into them)
-        acc = [dict(W2=torch.zeros(64 * info['tt'], ht, dtype=torch.float32, device=dev),
-                    b2=torch.zeros(64 * info['tt'], dtype=torch.float32, device=dev),
-                    W1=torch.zeros(ht, 32 * info['ct'], dtype=torch.float32, device=dev),
-                    b1=torch.zeros(ht, dtype=torch.float32, device=dev))
-               for _, info in layers]
+        # the parameter gradients live in ONE zero-filled buffer; sx_wgrad adds into views of it, mapping the
+        # kernel's slot order to the parameters' own rows / columns on the way (no per-layer fills or gathers)
+        shapes = []
+        for cpl, _ in layers:
+            (W1, b1), (W2, b2) = cpl._net().linears()
+            shapes.append((W1, b1, W2, b2))
+        flat = torch.zeros(sum(p_.numel() for ps in shapes for p_ in ps), dtype=torch.float32, device=dev)
+        grads, views, off = {}, [], 0
+        for ps in shapes:
+            vs = []
+            for p_ in ps:
+                v = flat[off:off + p_.numel()].view(p_.shape)
+                off += p_.numel()
+                grads[id(p_)] = v
+                vs.append(v)
+            views.append(vs)
         gy = torch.empty_like(z) if ctx.need_input_grad else None
         lib = _hip.lib()
         # the per-row factors are 224 floats per row and layer: bound the scratch by walking the batch in blocks
         block = max(1, min(n, _FusedLogProb.SIDE_BYTES // (len(layers) * width * 4)))
         side = torch.empty(len(layers), block, width, dtype=torch.float32, device=dev)
+        st = _hip.stream()
         for lo in range(0, n, block):
             m = min(block, n - lo)
             sd_all = side if m == block else torch.empty(len(layers), m, width, dtype=torch.float32, device=dev)
             gblk, _, _ = bprog.run(z[lo:lo + m], None, True, False, False, row_t=g[lo:lo + m], side=sd_all)
             if gy is not None:
                 gy[lo:lo + m] = gblk
+            base = sd_all.data_ptr()
             for slot in range(len(layers)):
-                sd = sd_all[slot]
                 info = layers[slot][1]
+                H = info['hidden']
                 zc, pc = 32 * info['ct'], 64 * info['tt']
-                zz, hh, dhp = sd[:, :zc], sd[:, zc:zc + ht], sd[:, zc + ht:zc + 2 * ht]
-                dp = sd[:, zc + 2 * ht:zc + 2 * ht + pc]
-                a = acc[slot]
-                _hip.check(lib.sx_wgrad(dp.data_ptr(), width, pc, hh.data_ptr(), width, ht, m, a['W2'].data_ptr(), ht,
-                                        a['b2'].data_ptr(), _hip.stream()), 'sx_wgrad')
-                _hip.check(lib.sx_wgrad(dhp.data_ptr(), width, ht, zz.data_ptr(), width, zc, m, a['W1'].data_ptr(), zc,
-                                        a['b1'].data_ptr(), _hip.stream()), 'sx_wgrad')
-        grads = {}
-        for slot, (cpl, info) in enumerate(layers):
-            (W1, b1), (W2, b2) = cpl._net().linears()
-            H = info['hidden']
-            a = acc[slot]
-            # slot order -> parameter order with index tensors prepared at plan time (no boolean masks: no syncs)
-            gW2 = torch.zeros_like(W2)
-            gW2[:, :H].index_copy_(0, info['row_dst'], a['W2'].index_select(0, info['row_src'])[:, :H])
-            gb2 = torch.zeros_like(b2)
-            gb2.index_copy_(0, info['row_dst'], a['b2'].index_select(0, info['row_src']))
-            gW1 = torch.zeros_like(W1)
-            gW1[:H].index_copy_(1, info['col_dst'], a['W1'][:H].index_select(1, info['col_src']))
-            gb1 = a['b1'][:H].clone()
-            for p_, g_ in ((W1, gW1), (b1, gb1), (W2, gW2), (b2, gb2)):
-                grads[id(p_)] = g_
+                p0 = base + slot * m * width * 4                  # row: z | tanh h | dL/dh_pre | dL/dparams
+                gW1, gb1, gW2, gb2 = views[slot]
+                _hip.check(lib.sx_wgrad(p0 + 4 * (zc + 2 * ht), width, pc, p0 + 4 * zc, width, H, m, gW2.data_ptr(),
+                                        gW2.stride(0), gb2.data_ptr(), info['row_map'].data_ptr(), None, st), 'sx_wgrad')
+                _hip.check(lib.sx_wgrad(p0 + 4 * (zc + ht), width, H, p0, width, zc, m, gW1.data_ptr(),
+                                        gW1.stride(0), gb1.data_ptr(), None, info['col_map'].data_ptr(), st), 'sx_wgrad')
         out = [grads.get(id(p_)) for p_ in flow._grad_params()]
         return (None, gy if ctx.need_input_grad else None, *out)
 
@@ -243,12 +239,9 @@ class NormalizingFlow(Transform):
                   (W1, b1), (W2, b2) = lin
                   info = b.add_coupling_affine_bwd(W1, b1, W2, b2, f.mask_vector(dim), W1.shape[0], len(layers))
                   import numpy as np
-                  rs = np.nonzero(info['out_rows'] >= 0)[0]
-                  cs = np.nonzero(info['cond_cols'] >= 0)[0]
-                  info['row_src'] = torch.from_numpy(rs).to(device)
-                  info['row_dst'] = torch.from_numpy(info['out_rows'][rs]).to(device)
-                  info['col_src'] = torch.from_numpy(cs).to(device)
-                  info['col_dst'] = torch.from_numpy(info['cond_cols'][cs]).to(device)
+                  # slot order -> parameter order for sx_wgrad (negative = padding slot)
+                  info['row_map'] = torch.from_numpy(np.ascontiguousarray(info['out_rows'], dtype=np.int32)).to(device)
+                  info['col_map'] = torch.from_numpy(np.ascontiguousarray(info['cond_cols'], dtype=np.int32)).to(device)
                   layers.append((f, info))
               self._fused[key] = (b.build(device), layers)
           except NotImplementedError:

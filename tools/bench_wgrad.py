@@ -1,0 +1,43 @@
+"""Times sx_wgrad on the shapes the cfg-2 backward uses (side rows of 224 floats): prints us per call and the
+HBM rate of the operand columns it reads.  Run on an MI355X."""
+import os
+import sys
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from stribor_amd import _hip
+
+
+def time_call(fn, iters=50):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def main():
+    lib = _hip.lib()
+    dev = torch.device('cuda:0')
+    width = 224
+    for n in (1 << 14, 1 << 16, 1 << 18, 1 << 20):
+        side = torch.randn(n, width, device=dev)
+        for (M, Nc, a0, b0) in ((64, 64, 160, 32), (64, 32, 96, 0), (128, 64, 96, 32), (128, 128, 0, 96)):
+            dW = torch.zeros(M, Nc, device=dev)
+            db = torch.zeros(M, device=dev)
+            A, B = side[:, a0:a0 + M], side[:, b0:b0 + Nc]
+
+            def fn():
+                _hip.check(lib.sx_wgrad(A.data_ptr(), width, M, B.data_ptr(), width, Nc, n, dW.data_ptr(), Nc,
+                                        db.data_ptr(), None, None, _hip.stream()), 'sx_wgrad')
+            us = time_call(fn)
+            gb = n * (M + Nc) * 4 / 1e9
+            print(f'n={n:8d} M={M:3d} Nc={Nc:3d}: {us:8.1f} us  {gb / (us * 1e-6) / 1e3:6.2f} TB/s (operand columns)')
+
+
+if __name__ == '__main__':
+    main()
