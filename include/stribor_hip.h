@@ -287,9 +287,10 @@ typedef struct sx_program {
  *   sum_out  one fp64: += sum_n logp_out[n] (or of ldj when logp_out is NULL); NULL to skip
  *   row_t    [n_rows] per-sample time of SX_STEP_ROW_SCALE_EXP steps (MatrixExponential with a tensor t,
  *            stribor/flows/affine.py:236-241), or NULL to use the step's constant
- *   side     training backward only (programs of SX_STEP_COUPLING_AFFINE_BWD steps): [n_layers, n_rows, side_width]
- *            fp32, per row [z(32) | tanh h(32*h_tiles) | dL/dh_pre(32*h_tiles) | dL/d(log_scale, shift)(64)] in slot
- *            order, from which the caller forms the weight gradients with plain GEMMs; row_t carries dL/dlog_prob;
+ *   side     training backward only (programs of SX_STEP_COUPLING_AFFINE_BWD steps):
+ *            [n_layers, ceil(n_rows / 32), side_width, 32] fp32 -- 32-row groups, feature-major inside; the features
+ *            of a row are [z(32) | tanh h(32*h_tiles) | dL/dh_pre(32*h_tiles) | dL/d(log_scale, shift)(64)] in slot
+ *            order, from which sx_wgrad forms the weight gradients; row_t carries dL/dlog_prob;
  *            x is the flow's latent z, y receives dL/d(input)
  *   mlp_out  [n_rows, mlp_out_dim] (row stride mlp_out_stride) destination of SX_STEP_MLP_OUT_TILE
  *            steps, or NULL                                                                   */
@@ -300,7 +301,9 @@ int sx_flow_run(const sx_program *prog_host, const float *blobs, const void *x, 
 
 /* Weight-gradient contraction of the training backward pass:
  *   dW[rm(i), cm(j)] += sum_n A[n, i] * B[n, j]   (dW row stride ldw),   db[rm(i)] += sum_n A[n, i]   (db may be NULL)
- * A = [n_rows, M], B = [n_rows, Nc] row-major fp32 with row strides lda / ldb (slices of `side`), M, Nc <= 128.
+ * A (M features) and B (Nc features) are slices of `side` (sx_flow_run), fp32 in 32-row groups, feature-major
+ * inside: element (row n, feature i) of A is A[(n >> 5) * lda + i * 32 + (n & 31)] (lda / ldb = floats per group;
+ * 16-byte aligned; rows of the last group past n_rows are ignored).  M, Nc <= 128.
  * row_map [M] / col_map [Nc] (device int32, either may be NULL = identity) send the kernel's slot order straight
  * to the parameter's own rows / columns; negative entries are dropped.  dW / db are accumulated into (zero them
  * first) by one writer per element: results do not depend on scheduling.  Launches on one stream share a scratch

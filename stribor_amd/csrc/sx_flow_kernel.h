@@ -792,10 +792,13 @@ __device__ __forceinline__ void rqs_phase(tile<1> (&xs)[TX], const btile<1> (&bh
 // HBM, where the caller contracts them over the batch with plain GEMMs.
 // State tiles: [0,2) = x, [2,4) = dL/dx.  C = conditioning x tile, T = 1 - C the transformed one.
 // ------------------------------------------------------------------------------------------------
+// side layout: 32-row groups, feature-major inside ([feature][32 rows]): every store of a C-fragment register is two
+// 128 B runs (one per lane half) -- row-major rows would take 64 separate 16 B pieces per store, and the L2
+// write-request rate, not the bytes, then bounds the kernel (measured 2.10 -> 1.83 ms on cfg 2).  sx_wgrad reads
+// whole 4 KB feature tiles and turns them through LDS.
 __device__ __forceinline__ void store_ctile(float *row_base, int off, const f32x16 &v, int h) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<f32x4 *>(row_base + off + 8 * q + 4 * h) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    for (int r = 0; r < 16; ++r) row_base[(off + (r & 3) + 8 * (r >> 2) + 4 * h) * 32] = v[r];
 }
 // XT data tiles (1 or 2); state tiles [0,XT) = x, [XT,2XT) = dL/dx.  Conditioner tiles [C0,C0+CT), transformed tiles
 // [T0,T0+TT) of the data tiles: pruned halves (XT = 2) or dense (any mask; zero weights outside the mask).
@@ -1197,7 +1200,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     if constexpr (MODE == 4 && NS == 1 && (TX == 2 || TX == 4)) {
                         constexpr int XT = TX / 2;
                         const float gg = k.row_t[lrow[0]];
-                        float *srow = row[0] < n_rows ? k.side + ((int64_t)st.tt * n_rows + row[0]) * k.side_width : nullptr;
+                        float *srow = row[0] < n_rows ? k.side + ((int64_t)st.tt * ((n_rows + 31) >> 5) + (row[0] >> 5)) * (k.side_width * 32) + (row[0] & 31) : nullptr;
                         if constexpr (XT == 2) {
                             if (st.ct == 1 && st.c0 == 0) coupling_affine_bwd<2, HT, 0, 1, 1, 1>(xs, w, gg, srow, lane);
                             else if (st.ct == 1) coupling_affine_bwd<2, HT, 1, 1, 0, 1>(xs, w, gg, srow, lane);

@@ -1,13 +1,17 @@
 // Weight-gradient contraction of the training backward pass:  dW[i][j] += sum_n A[n][i] * B[n][j],
-// db[i] += sum_n A[n][i], with A = [n_rows, M] and B = [n_rows, Nc] row-major fp32 slices of the per-row
-// factors the backward flow kernel leaves in HBM (M, Nc <= 128; n_rows ~ 1e6).
+// db[i] += sum_n A[n][i], with A (M features) and B (Nc features) slices of the per-row factors the backward flow
+// kernel leaves in HBM (M, Nc <= 128; n_rows ~ 1e6).
 //
 // A tall-skinny "A^T B" whose reduction axis is the batch: library GEMMs run it on a handful of workgroups
-// (measured 1.5 ms per 64x64x2^20 product = 9 % of HBM rate).  Here the batch is split over the whole chip and
-// the row-major operands ARE the MFMA fragments: v_mfma_f32_32x32x2_f32 wants A^T[i = lane&31][k = lane>>5] and
-// B[k = lane>>5][j = lane&31] with k = the row, i.e. each lane loads one float of a row (lanes of a half read
-// 128 contiguous bytes), no transposes.  Each wave keeps the (M/32) x (Nc/32) output tiles in registers over its
-// row slice; the waves of a workgroup then sum their tiles in LDS, the workgroup stores ONE partial
+// (measured 1.5 ms per 64x64x2^20 product = 9 % of HBM rate).  Here the batch is split over the whole chip.  The
+// factors are stored in 32-row groups, feature-major inside (element (row n, feature f) at
+// (n >> 5) * ld + f * 32 + (n & 31): the layout the flow kernel's fragment stores coalesce in), so a 32-feature
+// tile of a group is 4 KB contiguous.  A wave reads it with four fully coalesced 16 B-per-lane loads and turns it
+// through a private LDS patch into the v_mfma_f32_32x32x2_f32 operand order -- A^T[i = lane & 31][k = lane >> 5],
+// B[k][j = lane & 31] with k = the row: lane (i, kk) ends up with rows 16 kk .. 16 kk + 15 of feature i and feeds
+// them to 16 MFMAs (the pairing of rows into k-steps is free as long as A and B agree).  Each wave keeps the
+// (M/32) x (Nc/32) output tiles in registers over its row groups; the waves of a workgroup then sum their tiles in
+// LDS, the workgroup stores ONE partial
 // tile to a per-stream scratch with plain coalesced stores, and a second small kernel sums the <= 512 partials
 // per element and adds them to dW / db (one writer per element).  Global float atomics on M x Nc addresses were
 // the cost of the first version: 4096 waves x 4096 contended adds took twice as long as the data pass itself.
@@ -15,14 +19,34 @@
 #include <mutex>
 #include <vector>
 
+constexpr int PATCH = 32 * 36;       // one 32-feature x 32-row tile, feature rows padded to 36 floats
+
+// coalesced global -> registers: instr q, lane L holds feature 8q + (L >> 3), rows 4 (L & 7) .. + 3 of the tile
+__device__ __forceinline__ void load_tile(const float *tile_base, bool ok, int lane, f32x4 (&v)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        v[q] = ok ? *reinterpret_cast<const f32x4 *>(tile_base + q * 256 + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+// registers -> LDS patch -> registers: lane (i, kk) gets rows 16 kk .. 16 kk + 15 of feature i.  DS operations of
+// one wave execute in order, so the patch is reused tile after tile without barriers.
+__device__ __forceinline__ void turn_tile(float *patch, int lane, f32x4 (&v)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4 *>(patch + (8 * q + (lane >> 3)) * 36 + 4 * (lane & 7)) = v[q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4 *>(patch + (lane & 31) * 36 + 16 * (lane >> 5) + 4 * q);
+}
+
 template <int MT, int NT, int WB>
 __global__ __launch_bounds__(64 * WB) void wgrad_kernel(const float *__restrict__ A, int64_t lda,
-                                                    const float *__restrict__ B, int64_t ldb, int64_t n_rows,
-                                                    float *__restrict__ part, int m_valid, int n_valid) {
+                                                        const float *__restrict__ B, int64_t ldb, int64_t n_rows,
+                                                        float *__restrict__ part, int m_valid, int n_valid) {
     constexpr int M32 = 32 * MT, N32 = 32 * NT;
-    __shared__ float red[M32 * N32 + M32];
+    constexpr int RED = M32 * N32 + M32;
+    __shared__ __attribute__((aligned(16))) float lds[(RED > WB * PATCH ? RED : WB * PATCH)];
+    float *red = lds;                                   // the tile sum reuses the patches after the row loop
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, kk = lane >> 5;
+    float *patch = lds + wave * PATCH;
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -34,31 +58,51 @@ __global__ __launch_bounds__(64 * WB) void wgrad_kernel(const float *__restrict_
 #pragma unroll
     for (int m = 0; m < MT; ++m) bsum[m] = 0.f;
 
-    // rows are dealt to waves in blocks of 16 (8 MFMA k-steps of 2 rows), grid-strided
+    // 32-row groups are dealt to the waves, grid-strided
     const int64_t n_waves = (int64_t)gridDim.x * WB;
     const int64_t w_id = (int64_t)blockIdx.x * WB + wave;
-    for (int64_t r0 = w_id * 16; r0 < n_rows; r0 += n_waves * 16) {
-        float a[8][MT], b[8][NT];
+    const int64_t n_groups = (n_rows + 31) >> 5;
+    // features past m_valid / n_valid: whole 8-feature slabs of a load are in or out only when the bound is a multiple
+    // of 8; otherwise mask after the turn (lane i = feature)
+    for (int64_t g = w_id; g < n_groups; g += n_waves) {
+        f32x4 a[MT][4], b[NT][4];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int64_t row = r0 + 2 * s + kk;
-            const bool ok = row < n_rows;
+        for (int m = 0; m < MT; ++m) load_tile(A + g * lda + m * 1024, true, lane, a[m]);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) a[s][m] = (ok && 32 * m + i < m_valid) ? A[row * lda + 32 * m + i] : 0.f;
+        for (int n = 0; n < NT; ++n) load_tile(B + g * ldb + n * 1024, true, lane, b[n]);
+        const int64_t rem = n_rows - 32 * g;
+        const int left = (rem < 32 ? (int)rem : 32) - 16 * kk;          // valid rows among this lane's 16
 #pragma unroll
-            for (int n = 0; n < NT; ++n) b[s][n] = (ok && 32 * n + i < n_valid) ? B[row * ldb + 32 * n + i] : 0.f;
+        for (int m = 0; m < MT; ++m) {
+            turn_tile(patch, lane, a[m]);
+            const bool f_ok = 32 * m + i < m_valid;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a[m][q][c] = (f_ok && 4 * q + c < left) ? a[m][q][c] : 0.f;
         }
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
+        for (int n = 0; n < NT; ++n) {
+            turn_tile(patch, lane, b[n]);
+            const bool f_ok = 32 * n + i < n_valid;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                bsum[m] += a[s][m];
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][m], b[s][n], acc[m][n], 0, 0, 0);
-            }
+                for (int c = 0; c < 4; ++c) b[n][q][c] = (f_ok && 4 * q + c < left) ? b[n][q][c] : 0.f;
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    bsum[m] += a[m][q][c];
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][q][c], b[n][q][c], acc[m][n], 0, 0, 0);
+                }
     }
+    __syncthreads();                                    // every wave is done with its patch
     // C layout: lane (col j = lane&31, half) holds rows kmap(r, half).  The waves take turns adding their tiles to
     // the LDS copy with plain read-add-write (ds_add_f32 serialises its lanes: 64 of them per wave cost 40 us).
     for (int w = 0; w < WB; ++w) {
@@ -158,6 +202,8 @@ extern "C" int sx_wgrad(const float *A, int64_t lda, int32_t M, const float *B, 
                         const int32_t *col_map, void *stream) {
     SX_REQUIRE(A && B && dW, "sx_wgrad: null pointer");
     SX_REQUIRE(M >= 1 && M <= 128 && Nc >= 1 && Nc <= 128 && n_rows >= 0, "sx_wgrad: M, Nc must be in 1..128");
+    SX_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && lda % 4 == 0 && ldb % 4 == 0,
+               "sx_wgrad: A, B must be 16-byte aligned row groups (ld a multiple of 4 floats)");
     if (n_rows == 0) return SX_OK;
     const int mt = (M + 31) / 32, nt = (Nc + 31) / 32;
     hipStream_t st = sx_stream(stream);
@@ -166,8 +212,8 @@ extern "C" int sx_wgrad(const float *A, int64_t lda, int32_t M, const float *B, 
 #define SX_WG(MT_, NT_)                                                                                            \
     if (mt == MT_ && nt == NT_) {                                                                                  \
         constexpr int WB = MT_ * NT_ <= 2 ? 16 : (MT_ * NT_ <= 8 ? 8 : 4);                                         \
-        constexpr int GMAX = MT_ * NT_ <= 2 ? 256 : (MT_ * NT_ <= 4 ? 512 : 256);                                  \
-        int64_t g = (n_rows + 16 * WB - 1) / (16 * WB);                                                            \
+        constexpr int GMAX = 256;                                                                                   \
+        int64_t g = (n_rows + 32 * WB - 1) / (32 * WB);                                                            \
         if (g > GMAX) g = GMAX;                                                                                    \
         float *part = partial_scratch(st, (size_t)GMAX * E);                                                       \
         SX_REQUIRE(part != nullptr, "sx_wgrad: cannot allocate the partial-tile scratch");                         \

@@ -69,26 +69,28 @@ class _FusedLogProb(torch.autograd.Function):
             views.append(vs)
         gy = torch.empty_like(z) if ctx.need_input_grad else None
         lib = _hip.lib()
-        # the per-row factors are 224 floats per row and layer: bound the scratch by walking the batch in blocks
-        block = max(1, min(n, _FusedLogProb.SIDE_BYTES // (len(layers) * width * 4)))
-        side = torch.empty(len(layers), block, width, dtype=torch.float32, device=dev)
+        # the per-row factors are 224 floats per row and layer: bound the scratch by walking the batch in blocks.
+        # Layout [layer, 32-row group, feature, 32 rows] (coalesced for the kernel's fragment stores and sx_wgrad's loads)
+        block = max(32, min(n, _FusedLogProb.SIDE_BYTES // (len(layers) * width * 4)) // 32 * 32)
+        side = torch.empty(len(layers), (min(block, n) + 31) // 32, width, 32, dtype=torch.float32, device=dev)
         st = _hip.stream()
         for lo in range(0, n, block):
             m = min(block, n - lo)
-            sd_all = side if m == block else torch.empty(len(layers), m, width, dtype=torch.float32, device=dev)
+            ng = (m + 31) // 32
+            sd_all = side if ng == side.shape[1] else torch.empty(len(layers), ng, width, 32, dtype=torch.float32, device=dev)
             gblk, _, _ = bprog.run(z[lo:lo + m], None, True, False, False, row_t=g[lo:lo + m], side=sd_all)
             if gy is not None:
                 gy[lo:lo + m] = gblk
-            base = sd_all.data_ptr()
+            base, ld = sd_all.data_ptr(), width * 32
             for slot in range(len(layers)):
                 info = layers[slot][1]
                 H = info['hidden']
                 zc, pc = 32 * info['ct'], 64 * info['tt']
-                p0 = base + slot * m * width * 4                  # row: z | tanh h | dL/dh_pre | dL/dparams
+                p0 = base + slot * ng * ld * 4                    # features: z | tanh h | dL/dh_pre | dL/dparams
                 gW1, gb1, gW2, gb2 = views[slot]
-                _hip.check(lib.sx_wgrad(p0 + 4 * (zc + 2 * ht), width, pc, p0 + 4 * zc, width, H, m, gW2.data_ptr(),
+                _hip.check(lib.sx_wgrad(p0 + 128 * (zc + 2 * ht), ld, pc, p0 + 128 * zc, ld, H, m, gW2.data_ptr(),
                                         gW2.stride(0), gb2.data_ptr(), info['row_map'].data_ptr(), None, st), 'sx_wgrad')
-                _hip.check(lib.sx_wgrad(p0 + 4 * (zc + ht), width, H, p0, width, zc, m, gW1.data_ptr(),
+                _hip.check(lib.sx_wgrad(p0 + 128 * (zc + ht), ld, H, p0, ld, zc, m, gW1.data_ptr(),
                                         gW1.stride(0), gb1.data_ptr(), None, info['col_map'].data_ptr(), st), 'sx_wgrad')
         out = [grads.get(id(p_)) for p_ in flow._grad_params()]
         return (None, gy if ctx.need_input_grad else None, *out)

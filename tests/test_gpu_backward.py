@@ -415,3 +415,43 @@ def test_neural_flow_forward_is_differentiable():
     for pname, p in nf.named_parameters():
         ref = leaves[pname].grad.float()
         assert p.grad is not None and (p.grad.cpu() - ref).abs().max().item() <= tol(ref), pname
+
+
+@pytest.mark.parametrize('n,M,Nc,width,a0,b0', [(1, 64, 64, 224, 160, 32), (1000, 50, 33, 224, 96, 0),
+                                                (4097, 128, 128, 256, 0, 128), (77, 96, 40, 224, 32, 128),
+                                                (100003, 64, 32, 224, 96, 0)])
+def test_wgrad_contracts_row_groups_with_maps(n, M, Nc, width, a0, b0):
+    """sx_wgrad on its own: feature-major 32-row groups (garbage in the ragged tail), feature counts that are not
+    multiples of 32, row / column maps with dropped entries, accumulation into non-zero dW / db; fp64 truth."""
+    from stribor_amd import _hip
+    g = torch.Generator(device='cpu').manual_seed(n + M)
+    ng = (n + 31) // 32
+    side = torch.randn(ng, width, 32, generator=g)
+    rows = side.permute(0, 2, 1).reshape(ng * 32, width)[:n]                  # [n, width] view of the valid rows
+    dirty = side.clone()                                                      # rows past n hold garbage
+    if n % 32:
+        dirty[-1, :, n % 32:] = float('nan')
+    row_map = torch.randperm(M, generator=g).to(torch.int32)
+    row_map[::7] = -1
+    col_map = torch.randperm(Nc, generator=g).to(torch.int32)
+    col_map[1::5] = -1
+    dW0, db0 = torch.randn(M, Nc, generator=g), torch.randn(M, generator=g)
+    A, B = rows[:, a0:a0 + M].double(), rows[:, b0:b0 + Nc].double()
+    full, fb = A.T @ B, A.sum(0)
+    wantW, wantb = dW0.double().clone(), db0.double().clone()
+    for i in range(M):
+        if row_map[i] < 0:
+            continue
+        wantb[row_map[i]] += fb[i]
+        for j in range(Nc):
+            if col_map[j] >= 0:
+                wantW[row_map[i], col_map[j]] += full[i, j]
+    sd = dirty.to(DEV)
+    dW, db = dW0.to(DEV), db0.to(DEV)
+    rm, cm = row_map.to(DEV), col_map.to(DEV)
+    rc = _hip.lib().sx_wgrad(sd[0, a0].data_ptr(), width * 32, M, sd[0, b0].data_ptr(), width * 32, Nc, n,
+                             dW.data_ptr(), Nc, db.data_ptr(), rm.data_ptr(), cm.data_ptr(), _hip.stream())
+    _hip.check(rc, 'sx_wgrad')
+    scale = max(1.0, float(n) ** 0.5)
+    assert (dW.cpu().double() - wantW).abs().max().item() <= 2e-5 * scale
+    assert (db.cpu().double() - wantb).abs().max().item() <= 2e-5 * scale

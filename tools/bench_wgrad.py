@@ -1,5 +1,5 @@
-"""Times sx_wgrad on the shapes the cfg-2 backward uses (side rows of 224 floats): prints us per call and the
-HBM rate of the operand columns it reads.  Run on an MI355X."""
+"""Times sx_wgrad on the shapes the cfg-2 backward uses (224 features per row, 32-row groups): prints us per call
+and the HBM rate of the operand features it reads.  Run on an MI355X."""
 import os
 import sys
 import torch
@@ -25,18 +25,18 @@ def main():
     dev = torch.device('cuda:0')
     width = 224
     for n in (1 << 14, 1 << 16, 1 << 18, 1 << 20):
-        side = torch.randn(n, width, device=dev)
+        side = torch.randn((n + 31) // 32, width, 32, device=dev)
         for (M, Nc, a0, b0) in ((64, 64, 160, 32), (64, 32, 96, 0), (128, 64, 96, 32), (128, 128, 0, 96)):
             dW = torch.zeros(M, Nc, device=dev)
             db = torch.zeros(M, device=dev)
-            A, B = side[:, a0:a0 + M], side[:, b0:b0 + Nc]
+            A, B = side[0, a0], side[0, b0]                     # feature a0 / b0 of group 0; ld = floats per group
 
             def fn():
-                _hip.check(lib.sx_wgrad(A.data_ptr(), width, M, B.data_ptr(), width, Nc, n, dW.data_ptr(), Nc,
+                _hip.check(lib.sx_wgrad(A.data_ptr(), width * 32, M, B.data_ptr(), width * 32, Nc, n, dW.data_ptr(), Nc,
                                         db.data_ptr(), None, None, _hip.stream()), 'sx_wgrad')
             us = time_call(fn)
             gb = n * (M + Nc) * 4 / 1e9
-            print(f'n={n:8d} M={M:3d} Nc={Nc:3d}: {us:8.1f} us  {gb / (us * 1e-6) / 1e3:6.2f} TB/s (operand columns)')
+            print(f'n={n:8d} M={M:3d} Nc={Nc:3d}: {us:8.1f} us  {gb / (us * 1e-6) / 1e3:6.2f} TB/s (operand features)')
 
 
 if __name__ == '__main__':
