@@ -915,3 +915,33 @@ def test_deep_conditioner_spline_flows_fuse_into_one_launch():
             close(flow.inverse(y), x, rtol=1e-4, atol=1e-4)
     from stribor_amd.flows.spline import check_errors
     check_errors()
+
+
+@pytest.mark.parametrize('make,dim,n', [('cfg2', 64, 1024), ('cfg2', 64, 300_007), ('cfg3', 64, 2048), ('cfg4', 128, 4096)])
+def test_log_prob_replays_from_a_hip_graph(make, dim, n):
+    """Launch-bound small batches: log_prob captured once into a HIP graph (torch.cuda.CUDAGraph) and replayed on new
+    input contents gives bit-identical results to eager launches -- no allocation, synchronisation or host-side state in
+    the launch path (the chunk counters are created by the warm-up on the capture stream and re-armed by the kernel)."""
+    torch.manual_seed(11)
+    desc = {'cfg2': lambda: fd.cfg2_desc(8, dim, 64), 'cfg3': lambda: fd.cfg3_desc(4, dim, 64, 16),
+            'cfg4': lambda: fd.cfg4_desc(2, dim, 64)}[make]()
+    flow = fd.build_flow(st, desc, dim).to(DEV)
+    static_x = torch.randn(n, dim, device=DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            flow.log_prob(static_x)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        static_out = flow.log_prob(static_x)
+    for seed in range(3):
+        fresh = torch.randn(n, dim, device=DEV, generator=torch.Generator(device=DEV).manual_seed(seed)) * (1 + seed)
+        static_x.copy_(fresh)
+        graph.replay()
+        torch.cuda.synchronize()
+        got = static_out.clone()
+        want = flow.log_prob(fresh)
+        assert torch.equal(got, want), (make, seed)

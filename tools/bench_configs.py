@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """Throughput of every BASELINE.json config on one MI355X (not the driver's contract bench: see bench.py).
 
-    python tools/bench_configs.py [cfg1 cfg2 cfg2_f32 cfg3 cfg4 ...] [--rows N]
+    python tools/bench_configs.py [cfg1 cfg2 cfg2_f32 cfg3 cfg4 ...] [--rows N] [--train] [--graph]
 
-Prints one JSON line per config: rows/s of log_prob, ms per batch, launches per batch.
+Prints one JSON line per config: rows/s of log_prob, ms per batch, launches per batch.  --graph adds a line with the
+same call captured once into a HIP graph (torch.cuda.CUDAGraph) and replayed: what a launch-bound small batch costs
+without the Python / ctypes launch path.
 """
 import json
 import os
@@ -64,6 +66,21 @@ def main():
         with torch.no_grad():
             ms = timed(lambda: flow.log_prob(x))
             lp = flow.log_prob(x)
+        if '--graph' in sys.argv:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(3):
+                    flow.log_prob(x)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side), torch.no_grad():
+                static_out = flow.log_prob(x)
+            gms = timed(graph.replay, reps=10, inner=50)
+            same = bool(torch.equal(static_out, lp))
+            print(json.dumps({'config': name + ' HIP-graph replay', 'rows': rows, 'ms_per_batch': gms,
+                              'rows_per_s': rows / (gms * 1e-3), 'equals_eager': same}))
         if name in ('cfg2_f32', 'cfg3', 'cfg4') and '--train' in sys.argv:
             def train_step():
                 for p_ in flow.parameters():
