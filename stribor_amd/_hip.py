@@ -149,7 +149,15 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_cur_device = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def stream() -> int:
+    """The hipStream_t of torch's current stream on the current device.  torch.cuda.current_stream() costs ~8 us of a
+    17 us small-batch call (device-index resolution in Python); the raw accessor is one C call."""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -179,10 +179,14 @@ class CompiledProgram:
         self.out_col = None if out_col is None else torch.from_numpy(out_col.astype(np.int32)).to(device)
         self.mlp_out_dim = mlp_out_dim
         self._versions = None
+        self._tracked = None
 
     # -- parameter tracking ----------------------------------------------------------------------
     def _current_versions(self):
-        return tuple((p.data_ptr(), p._version) for j in self.jobs for p in j.params())
+        ps = self._tracked
+        if ps is None:                      # the jobs are fixed once the program is built
+            ps = self._tracked = [p for j in self.jobs for p in j.params()]
+        return [(p.data_ptr(), p._version) for p in ps]
 
     def refresh(self) -> None:
         v = self._current_versions()
