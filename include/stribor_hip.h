@@ -299,18 +299,25 @@ int sx_flow_run(const sx_program *prog_host, const float *blobs, const void *x, 
                 float *logp_out, double *sum_out, float *mlp_out, int64_t mlp_out_stride,
                 int32_t mlp_out_dim, const float *row_t, float *side, int64_t n_rows, int32_t dtype, void *stream);
 
-/* Weight-gradient contraction of the training backward pass:
+/* Weight-gradient contraction over the batch axis (training):
  *   dW[rm(i), cm(j)] += sum_n A[n, i] * B[n, j]   (dW row stride ldw),   db[rm(i)] += sum_n A[n, i]   (db may be NULL)
- * A (M features) and B (Nc features) are slices of `side` (sx_flow_run), fp32 in 32-row groups, feature-major
- * inside: element (row n, feature i) of A is A[(n >> 5) * lda + i * 32 + (n & 31)] (lda / ldb = floats per group;
- * 16-byte aligned; rows of the last group past n_rows are ignored).  M, Nc <= 128.
- * row_map [M] / col_map [Nc] (device int32, either may be NULL = identity) send the kernel's slot order straight
+ * A has M features, B has Nc <= 128 features, fp32, in one of two layouts:
+ *   SX_WGRAD_ROW_MAJOR   plain [n_rows, ld] matrices (row strides lda / ldb): what autograd holds for a Linear layer
+ *                        (A = dL/d(output), B = the layer's input); M <= 2048 (128-feature slabs of A, B re-read)
+ *   SX_WGRAD_ROW_GROUPS  slices of `side` (sx_flow_run): 32-row groups, feature-major inside -- element (row n,
+ *                        feature i) of A is A[(n >> 5) * lda + i * 32 + (n & 31)] (lda / ldb = floats per group,
+ *                        16-byte aligned; whole 32-feature tiles are read, rows of the last group past n_rows are
+ *                        ignored); M <= 128
+ * row_map [M] / col_map [Nc] (device int32, either may be NULL = identity) send the operands' feature order straight
  * to the parameter's own rows / columns; negative entries are dropped.  dW / db are accumulated into (zero them
  * first) by one writer per element: results do not depend on scheduling.  Launches on one stream share a scratch
  * for the per-workgroup partial tiles.  Replaces autograd's dense matmuls over the batch axis for nn.Linear
- * inside stribor/net/mlp.py:48-58. */
+ * inside stribor/net/mlp.py:48-58 (a tall-skinny A^T B that library GEMMs run on a handful of workgroups). */
+#define SX_WGRAD_ROW_MAJOR 0
+#define SX_WGRAD_ROW_GROUPS 1
 int sx_wgrad(const float *A, int64_t lda, int32_t M, const float *B, int64_t ldb, int32_t Nc, int64_t n_rows,
-             float *dW, int64_t ldw, float *db, const int32_t *row_map, const int32_t *col_map, void *stream);
+             int32_t layout, float *dW, int64_t ldw, float *db, const int32_t *row_map, const int32_t *col_map,
+             void *stream);
 
 /* LDS bytes and grid the launcher will use for a program (introspection for tests/bench). */
 int sx_flow_launch_info(const sx_program *prog_host, int64_t n_rows, int32_t *grid, int32_t *block,

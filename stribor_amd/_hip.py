@@ -34,6 +34,8 @@ STEP_CPL_HIDDEN = 13
 STEP_CPL_HIDDEN2 = 14
 STEP_COUPLING_AFFINE_DEEP = 15
 
+WGRAD_ROW_MAJOR, WGRAD_ROW_GROUPS = 0, 1
+
 ACT_TANH_FOLDED = 9
 ACT_CODES = {'Identity': 0, 'Tanh': 1, 'ReLU': 2, 'Sigmoid': 3, 'ELU': 4, 'Softplus': 5, 'LeakyReLU': 6,
              'SiLU': 7, 'GELU': 8}
@@ -104,7 +106,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.sx_flow_run.restype = i32
     lib.sx_flow_run.argtypes = [C.POINTER(sx_program), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, i64, i32, vp]
     lib.sx_wgrad.restype = i32
-    lib.sx_wgrad.argtypes = [vp, i64, i32, vp, i64, i32, i64, vp, i64, vp, vp, vp, vp]
+    lib.sx_wgrad.argtypes = [vp, i64, i32, vp, i64, i32, i64, i32, vp, i64, vp, vp, vp, vp]
     lib.sx_flow_launch_info.restype = i32
     lib.sx_flow_launch_info.argtypes = [C.POINTER(sx_program), i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
 

@@ -36,17 +36,25 @@ __device__ __forceinline__ void turn_tile(float *patch, int lane, f32x4 (&v)[4])
     for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4 *>(patch + (lane & 31) * 36 + 16 * (lane >> 5) + 4 * q);
 }
 
-template <int MT, int NT, int WB>
+// GROUPS: operands in 32-row feature-major groups (the backward flow kernel's factors); otherwise plain row-major
+// [n_rows, ld] matrices (torch tensors: autograd's weight gradient of a Linear layer), where lane (i, kk) loads
+// element (row 2s + kk, feature i) directly -- 128 B contiguous per lane half.  blockIdx.y = 128-feature slab of A
+// (row-major only: M up to 2048, B is re-read per slab from L2 / MALL).
+template <int MT, int NT, int WB, bool GROUPS>
 __global__ __launch_bounds__(64 * WB) void wgrad_kernel(const float *__restrict__ A, int64_t lda,
                                                         const float *__restrict__ B, int64_t ldb, int64_t n_rows,
-                                                        float *__restrict__ part, int m_valid, int n_valid) {
+                                                        float *__restrict__ part, int m_total, int n_valid) {
     constexpr int M32 = 32 * MT, N32 = 32 * NT;
     constexpr int RED = M32 * N32 + M32;
-    __shared__ __attribute__((aligned(16))) float lds[(RED > WB * PATCH ? RED : WB * PATCH)];
+    constexpr int LDS_FLOATS = GROUPS ? (RED > WB * PATCH ? RED : WB * PATCH) : RED;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    A += 128 * blockIdx.y;
+    const int m_valid = m_total - 128 * (int)blockIdx.y;                 // >= M32 for all but the last slab
+    part += (int64_t)blockIdx.y * gridDim.x * RED;
     float *red = lds;                                   // the tile sum reuses the patches after the row loop
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, kk = lane >> 5;
-    float *patch = lds + wave * PATCH;
+    [[maybe_unused]] float *patch = lds + wave * PATCH;
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -66,29 +74,44 @@ __global__ __launch_bounds__(64 * WB) void wgrad_kernel(const float *__restrict_
     // of 8; otherwise mask after the turn (lane i = feature)
     for (int64_t g = w_id; g < n_groups; g += n_waves) {
         f32x4 a[MT][4], b[NT][4];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) load_tile(A + g * lda + m * 1024, true, lane, a[m]);
-#pragma unroll
-        for (int n = 0; n < NT; ++n) load_tile(B + g * ldb + n * 1024, true, lane, b[n]);
         const int64_t rem = n_rows - 32 * g;
-        const int left = (rem < 32 ? (int)rem : 32) - 16 * kk;          // valid rows among this lane's 16
+        if constexpr (GROUPS) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            turn_tile(patch, lane, a[m]);
-            const bool f_ok = 32 * m + i < m_valid;
+            for (int m = 0; m < MT; ++m) load_tile(A + g * lda + m * 1024, true, lane, a[m]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) load_tile(B + g * ldb + n * 1024, true, lane, b[n]);
+            const int left = (rem < 32 ? (int)rem : 32) - 16 * kk;      // valid rows among this lane's 16
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                turn_tile(patch, lane, a[m]);
+                const bool f_ok = 32 * m + i < m_valid;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) a[m][q][c] = (f_ok && 4 * q + c < left) ? a[m][q][c] : 0.f;
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                turn_tile(patch, lane, b[n]);
+                const bool f_ok = 32 * n + i < n_valid;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) b[n][q][c] = (f_ok && 4 * q + c < left) ? b[n][q][c] : 0.f;
+            }
+        } else {
+            const float *ra = A + (32 * g + kk) * lda + i, *rb = B + (32 * g + kk) * ldb + i;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) a[m][q][c] = (f_ok && 4 * q + c < left) ? a[m][q][c] : 0.f;
-        }
+                for (int c = 0; c < 4; ++c) {
+                    const int s = 4 * q + c;                             // k-step s pairs rows 2s, 2s + 1
+                    const bool ok = 2 * s + kk < rem;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            turn_tile(patch, lane, b[n]);
-            const bool f_ok = 32 * n + i < n_valid;
+                    for (int m = 0; m < MT; ++m) a[m][q][c] = (ok && 32 * m + i < m_valid) ? ra[2 * s * lda + 32 * m] : 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) b[n][q][c] = (f_ok && 4 * q + c < left) ? b[n][q][c] : 0.f;
+                    for (int n = 0; n < NT; ++n) b[n][q][c] = (ok && 32 * n + i < n_valid) ? rb[2 * s * ldb + 32 * n] : 0.f;
+                }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -140,6 +163,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int E = M32 * N32 + M32;
     const int e = blockIdx.x * 32 + el;
+    const int slab_row = 128 * blockIdx.y;                               // blockIdx.y = 128-row slab of dW
+    part += (int64_t)blockIdx.y * n_part * E;
+    m_valid -= slab_row;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (e < E) {
         const float *src = part + e;
@@ -161,12 +187,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
         if (e < M32 * N32) {
             int row = e / N32, col = e % N32;
             if (row < m_valid && col < n_valid) {
+                row += slab_row;
                 if (row_map != nullptr) row = row_map[row];
                 if (col_map != nullptr) col = col_map[col];
                 if (row >= 0 && col >= 0) dW[(int64_t)row * ldw + col] += t;
             }
         } else if (db != nullptr && e - M32 * N32 < m_valid) {
-            int row = e - M32 * N32;
+            int row = e - M32 * N32 + slab_row;
             if (row_map != nullptr) row = row_map[row];
             if (row >= 0) db[row] += t;
         }
@@ -198,36 +225,45 @@ static float *partial_scratch(hipStream_t stream, size_t floats) {
 }
 
 extern "C" int sx_wgrad(const float *A, int64_t lda, int32_t M, const float *B, int64_t ldb, int32_t Nc,
-                        int64_t n_rows, float *dW, int64_t ldw, float *db, const int32_t *row_map,
+                        int64_t n_rows, int32_t layout, float *dW, int64_t ldw, float *db, const int32_t *row_map,
                         const int32_t *col_map, void *stream) {
     SX_REQUIRE(A && B && dW, "sx_wgrad: null pointer");
-    SX_REQUIRE(M >= 1 && M <= 128 && Nc >= 1 && Nc <= 128 && n_rows >= 0, "sx_wgrad: M, Nc must be in 1..128");
-    SX_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && lda % 4 == 0 && ldb % 4 == 0,
+    SX_REQUIRE(layout == SX_WGRAD_ROW_MAJOR || layout == SX_WGRAD_ROW_GROUPS, "sx_wgrad: unknown layout %d", layout);
+    const bool groups = layout == SX_WGRAD_ROW_GROUPS;
+    SX_REQUIRE(M >= 1 && Nc >= 1 && Nc <= 128 && n_rows >= 0 && M <= (groups ? 128 : 2048),
+               "sx_wgrad: Nc must be in 1..128, M in 1..128 (row groups) or 1..2048 (row-major)");
+    SX_REQUIRE(!groups || (((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && lda % 4 == 0 && ldb % 4 == 0),
                "sx_wgrad: A, B must be 16-byte aligned row groups (ld a multiple of 4 floats)");
     if (n_rows == 0) return SX_OK;
-    const int mt = (M + 31) / 32, nt = (Nc + 31) / 32;
+    const int slabs = (M + 127) / 128;
+    const int mt = slabs > 1 ? 4 : (M + 31) / 32, nt = (Nc + 31) / 32;
     hipStream_t st = sx_stream(stream);
     const int E = 32 * mt * 32 * nt + 32 * mt;
-    // waves per workgroup by register budget (accumulators = 16 * MT * NT VGPRs), workgroups = what fills the CUs
-#define SX_WG(MT_, NT_)                                                                                            \
-    if (mt == MT_ && nt == NT_) {                                                                                  \
+    // waves per workgroup by register budget (accumulators = 16 * MT * NT VGPRs); 256 workgroups fill the CUs
+#define SX_WG_L(MT_, NT_, GR_)                                                                                      \
+    {                                                                                                              \
         constexpr int WB = MT_ * NT_ <= 2 ? 16 : (MT_ * NT_ <= 8 ? 8 : 4);                                         \
-        constexpr int GMAX = 256;                                                                                   \
+        constexpr int GMAX = 256;                                                                                  \
         int64_t g = (n_rows + 32 * WB - 1) / (32 * WB);                                                            \
         if (g > GMAX) g = GMAX;                                                                                    \
-        float *part = partial_scratch(st, (size_t)GMAX * E);                                                       \
+        float *part = partial_scratch(st, (size_t)GMAX * E * slabs);                                               \
         SX_REQUIRE(part != nullptr, "sx_wgrad: cannot allocate the partial-tile scratch");                         \
-        hipLaunchKernelGGL((wgrad_kernel<MT_, NT_, WB>), dim3((int)g), dim3(64 * WB), 0, st, A, lda, B, ldb,       \
-                           n_rows, part, M, Nc);                                                                        \
+        hipLaunchKernelGGL((wgrad_kernel<MT_, NT_, WB, GR_>), dim3((int)g, slabs), dim3(64 * WB), 0, st, A, lda,   \
+                           B, ldb, n_rows, part, M, Nc);                                                           \
         SX_LAUNCH_CHECK();                                                                                         \
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((E + 31) / 32), dim3(256), 0, st, part, (int)g, 32 * MT_,     \
-                           32 * NT_, dW, ldw, db, M, Nc, row_map, col_map);                                                        \
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((E + 31) / 32, slabs), dim3(256), 0, st, part, (int)g,        \
+                           32 * MT_, 32 * NT_, dW, ldw, db, M, Nc, row_map, col_map);                              \
         SX_LAUNCH_CHECK();                                                                                         \
         return SX_OK;                                                                                              \
+    }
+#define SX_WG(MT_, NT_)                                                                                            \
+    if (mt == MT_ && nt == NT_) {                                                                                  \
+        if (groups) SX_WG_L(MT_, NT_, true) else SX_WG_L(MT_, NT_, false)                                          \
     }
     SX_WG(1, 1) SX_WG(1, 2) SX_WG(2, 1) SX_WG(2, 2) SX_WG(2, 4) SX_WG(4, 2) SX_WG(4, 1) SX_WG(1, 4) SX_WG(4, 4)
     SX_WG(3, 1) SX_WG(3, 2) SX_WG(3, 3) SX_WG(3, 4) SX_WG(1, 3) SX_WG(2, 3) SX_WG(4, 3)
 #undef SX_WG
+#undef SX_WG_L
     sx_set_error("sx_wgrad: unsupported tile shape %d x %d", mt, nt);
     return SX_E_UNSUPPORTED;
 }

@@ -88,9 +88,9 @@ class _FusedLogProb(torch.autograd.Function):
                 zc, pc = 32 * info['ct'], 64 * info['tt']
                 p0 = base + slot * ng * ld * 4                    # features: z | tanh h | dL/dh_pre | dL/dparams
                 gW1, gb1, gW2, gb2 = views[slot]
-                _hip.check(lib.sx_wgrad(p0 + 128 * (zc + 2 * ht), ld, pc, p0 + 128 * zc, ld, H, m, gW2.data_ptr(),
+                _hip.check(lib.sx_wgrad(p0 + 128 * (zc + 2 * ht), ld, pc, p0 + 128 * zc, ld, H, m, _hip.WGRAD_ROW_GROUPS, gW2.data_ptr(),
                                         gW2.stride(0), gb2.data_ptr(), info['row_map'].data_ptr(), None, st), 'sx_wgrad')
-                _hip.check(lib.sx_wgrad(p0 + 128 * (zc + ht), ld, H, p0, ld, zc, m, gW1.data_ptr(),
+                _hip.check(lib.sx_wgrad(p0 + 128 * (zc + ht), ld, H, p0, ld, zc, m, _hip.WGRAD_ROW_GROUPS, gW1.data_ptr(),
                                         gW1.stride(0), gb1.data_ptr(), None, info['col_map'].data_ptr(), st), 'sx_wgrad')
         out = [grads.get(id(p_)) for p_ in flow._grad_params()]
         return (None, gy if ctx.need_input_grad else None, *out)

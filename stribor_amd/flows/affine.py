@@ -142,7 +142,7 @@ class Affine(ElementwiseTransform):
         else:
             if lat2 is None:
                 raise ValueError('Affine with a latent_net needs `latent`')
-            params = self.latent_net.net(lat2)                                # affine.py:66
+            params = self.latent_net.forward_autograd(lat2)                    # affine.py:66
         return AffineCouplingOp.apply(x2, params, None, 0, d, True, -1.0)     # affine.py:111-113
 
     # ---- fused-program hooks --------------------------------------------------------------------------------

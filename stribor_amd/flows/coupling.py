@@ -199,12 +199,7 @@ class Coupling(Transform):
             z = z * 0                                                                # coupling.py:62-63
         if lat2 is not None:
             z = torch.cat([z, lat2], -1)                                             # coupling.py:64-65
-        layers = list(net.net)
-        h = z
-        for layer in layers[:-1]:
-            h = layer(h)
-        last = layers[-1]
-        params = torch.nn.functional.linear(h, last.weight.index_select(0, rows_t), last.bias.index_select(0, rows_t))
+        params = net.forward_autograd(z, rows_t)
         if is_spline:
             op = CubicInverse if sp.spline_type == 'cubic' else RQSInverse
             return op.apply(x2, params, live_idx, int(live[0]), len(live), sp.n_bins, sp.lower, sp.upper, 1.0)
@@ -362,11 +357,7 @@ class ContinuousAffineCoupling(Transform):
             if lat2 is not None:
                 z = torch.cat([z, lat2], -1)
             rows = torch.from_numpy(np.concatenate([live, d + live]).astype(np.int64)).to(x.device)
-            layers = list(self.latent_net.net)
-            h = z
-            for layer in layers[:-1]:
-                h = layer(h)
-            params = torch.nn.functional.linear(h, layers[-1].weight.index_select(0, rows), layers[-1].bias.index_select(0, rows))
+            params = self.latent_net.forward_autograd(z, rows)
             emb = self.time_net(t2.reshape(n, 1))                                    # [n, out]
             half = emb.shape[1] // 2
             cols = torch.from_numpy(live.astype(np.int64)).to(x.device) if half == d else torch.zeros(len(live), dtype=torch.long, device=x.device)

@@ -211,7 +211,7 @@ class Spline(ElementwiseTransform):
         else:
             if lat2 is None:
                 raise ValueError('Spline with a latent_net needs `latent`')
-            params = self.latent_net.net(lat2)                                                   # spline.py:82-86
+            params = self.latent_net.forward_autograd(lat2)                                                 # spline.py:82-86
         op = CubicInverse if self.spline_type == 'cubic' else RQSInverse
         return op.apply(x2, params, None, 0, d, self.n_bins, self.lower, self.upper, 1.0)
 

@@ -450,8 +450,27 @@ def test_wgrad_contracts_row_groups_with_maps(n, M, Nc, width, a0, b0):
     dW, db = dW0.to(DEV), db0.to(DEV)
     rm, cm = row_map.to(DEV), col_map.to(DEV)
     rc = _hip.lib().sx_wgrad(sd[0, a0].data_ptr(), width * 32, M, sd[0, b0].data_ptr(), width * 32, Nc, n,
-                             dW.data_ptr(), Nc, db.data_ptr(), rm.data_ptr(), cm.data_ptr(), _hip.stream())
+                             _hip.WGRAD_ROW_GROUPS, dW.data_ptr(), Nc, db.data_ptr(), rm.data_ptr(), cm.data_ptr(), _hip.stream())
     _hip.check(rc, 'sx_wgrad')
     scale = max(1.0, float(n) ** 0.5)
     assert (dW.cpu().double() - wantW).abs().max().item() <= 2e-5 * scale
     assert (db.cpu().double() - wantb).abs().max().item() <= 2e-5 * scale
+
+
+@pytest.mark.parametrize('n,in_dim,out_dim', [(5000, 64, 64), (4097, 33, 50), (8192, 64, 1504), (6001, 128, 300)])
+def test_batch_linear_weight_gradients_match_autograd(n, in_dim, out_dim):
+    """BatchLinear (layer-wise training path): dL/dW, dL/db from sx_wgrad on row-major operands -- M up to 2048 in
+    128-row slabs, ragged n, strided dL/dy -- against torch's own Linear backward in fp64."""
+    from stribor_amd.net.mlp import BatchLinear
+    torch.manual_seed(n)
+    x = torch.randn(n, in_dim, device=DEV, requires_grad=True)
+    W = torch.randn(out_dim, in_dim, device=DEV, requires_grad=True)
+    b = torch.randn(out_dim, device=DEV, requires_grad=True)
+    weight = torch.randn(n, out_dim, device=DEV)
+    (BatchLinear.apply(x, W, b).tanh() * weight).sum().backward()
+    xd, Wd, bd = (t.detach().double().requires_grad_(True) for t in (x, W, b))
+    (torch.nn.functional.linear(xd, Wd, bd).tanh() * weight.double()).sum().backward()
+    scale = float(n) ** 0.5
+    assert (W.grad.double() - Wd.grad).abs().max().item() <= 3e-5 * scale
+    assert (b.grad.double() - bd.grad).abs().max().item() <= 3e-5 * scale
+    assert (x.grad.double() - xd.grad).abs().max().item() <= 1e-3

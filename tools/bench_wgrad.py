@@ -32,7 +32,7 @@ def main():
             A, B = side[0, a0], side[0, b0]                     # feature a0 / b0 of group 0; ld = floats per group
 
             def fn():
-                _hip.check(lib.sx_wgrad(A.data_ptr(), width * 32, M, B.data_ptr(), width * 32, Nc, n, dW.data_ptr(), Nc,
+                _hip.check(lib.sx_wgrad(A.data_ptr(), width * 32, M, B.data_ptr(), width * 32, Nc, n, _hip.WGRAD_ROW_GROUPS, dW.data_ptr(), Nc,
                                         db.data_ptr(), None, None, _hip.stream()), 'sx_wgrad')
             us = time_call(fn)
             gb = n * (M + Nc) * 4 / 1e9
