@@ -40,13 +40,38 @@ __device__ __forceinline__ void turn_tile(float *patch, int lane, f32x4 (&v)[4])
 // [n_rows, ld] matrices (torch tensors: autograd's weight gradient of a Linear layer), where lane (i, kk) loads
 // element (row 2s + kk, feature i) directly -- 128 B contiguous per lane half.  blockIdx.y = 128-feature slab of A
 // (row-major only: M up to 2048, B is re-read per slab from L2 / MALL).
-template <int MT, int NT, int WB, bool GROUPS>
+// row-major tiles (32 rows x 32 features = 32 segments of 128 B, row stride ld): instr q, lane L holds row
+// 8q + (L >> 3), features 4 (L & 7) .. + 3 -- eight whole 128 B segments per load; rows past `rows_left` read as zero
+__device__ __forceinline__ void load_tile_rows(const float *tile_base, int64_t ld, int rows_left, bool f_ok, int lane,
+                                               f32x4 (&v)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = 8 * q + (lane >> 3);
+        v[q] = (f_ok && row < rows_left) ? *reinterpret_cast<const f32x4 *>(tile_base + row * ld + 4 * (lane & 7))
+                                         : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+// the patch is written row-major (conflict-free 16 B writes) and read down its columns: lane (i, kk) gets feature i
+// of rows 16 kk .. 16 kk + 15 (lanes of a half read 32 consecutive floats)
+__device__ __forceinline__ void turn_tile_rows(float *patch, int lane, f32x4 (&v)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4 *>(patch + (8 * q + (lane >> 3)) * 36 + 4 * (lane & 7)) = v[q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[q][c] = patch[(16 * (lane >> 5) + 4 * q + c) * 36 + (lane & 31)];
+}
+
+// LAYOUT: SX_WGRAD_ROW_GROUPS (1), row-major with 16 B loads through the LDS patch (2: 16-byte aligned rows), or
+// row-major with per-element loads (0: any alignment)
+template <int MT, int NT, int WB, int LAYOUT>
 __global__ __launch_bounds__(64 * WB) void wgrad_kernel(const float *__restrict__ A, int64_t lda,
                                                         const float *__restrict__ B, int64_t ldb, int64_t n_rows,
                                                         float *__restrict__ part, int m_total, int n_valid) {
     constexpr int M32 = 32 * MT, N32 = 32 * NT;
     constexpr int RED = M32 * N32 + M32;
-    constexpr int LDS_FLOATS = GROUPS ? (RED > WB * PATCH ? RED : WB * PATCH) : RED;
+    constexpr bool GROUPS = LAYOUT == 1, VEC_ROWS = LAYOUT == 2;
+    constexpr int LDS_FLOATS = (GROUPS || VEC_ROWS) ? (RED > WB * PATCH ? RED : WB * PATCH) : RED;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     A += 128 * blockIdx.y;
     const int m_valid = m_total - 128 * (int)blockIdx.y;                 // >= M32 for all but the last slab
@@ -98,6 +123,30 @@ __global__ __launch_bounds__(64 * WB) void wgrad_kernel(const float *__restrict_
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) b[n][q][c] = (f_ok && 4 * q + c < left) ? b[n][q][c] : 0.f;
+            }
+        } else if constexpr (VEC_ROWS) {
+            const int rows_left = rem < 32 ? (int)rem : 32;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                load_tile_rows(A + 32 * g * lda + 32 * m, lda, rows_left, 32 * m + 4 * (lane & 7) < m_valid, lane, a[m]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                load_tile_rows(B + 32 * g * ldb + 32 * n, ldb, rows_left, 32 * n + 4 * (lane & 7) < n_valid, lane, b[n]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                turn_tile_rows(patch, lane, a[m]);
+                if (32 * m + i >= m_valid) {                            // a quad straddling the last feature
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                turn_tile_rows(patch, lane, b[n]);
+                if (32 * n + i >= n_valid) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) b[n][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
             }
         } else {
             const float *ra = A + (32 * g + kk) * lda + i, *rb = B + (32 * g + kk) * ldb + i;
@@ -235,6 +284,8 @@ extern "C" int sx_wgrad(const float *A, int64_t lda, int32_t M, const float *B, 
     SX_REQUIRE(!groups || (((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && lda % 4 == 0 && ldb % 4 == 0),
                "sx_wgrad: A, B must be 16-byte aligned row groups (ld a multiple of 4 floats)");
     if (n_rows == 0) return SX_OK;
+    // row-major operands whose rows are 16-byte aligned (torch tensors with a multiple of 4 features) load 16 B per lane
+    const bool vec_rows = !groups && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && lda % 4 == 0 && ldb % 4 == 0;
     const int slabs = (M + 127) / 128;
     const int mt = slabs > 1 ? 4 : (M + 31) / 32, nt = (Nc + 31) / 32;
     hipStream_t st = sx_stream(stream);
@@ -258,7 +309,7 @@ extern "C" int sx_wgrad(const float *A, int64_t lda, int32_t M, const float *B, 
     }
 #define SX_WG(MT_, NT_)                                                                                            \
     if (mt == MT_ && nt == NT_) {                                                                                  \
-        if (groups) SX_WG_L(MT_, NT_, true) else SX_WG_L(MT_, NT_, false)                                          \
+        if (groups) SX_WG_L(MT_, NT_, 1) else if (vec_rows) SX_WG_L(MT_, NT_, 2) else SX_WG_L(MT_, NT_, 0)         \
     }
     SX_WG(1, 1) SX_WG(1, 2) SX_WG(2, 1) SX_WG(2, 2) SX_WG(2, 4) SX_WG(4, 2) SX_WG(4, 1) SX_WG(1, 4) SX_WG(4, 4)
     SX_WG(3, 1) SX_WG(3, 2) SX_WG(3, 3) SX_WG(3, 4) SX_WG(1, 3) SX_WG(2, 3) SX_WG(4, 3)

@@ -474,3 +474,23 @@ def test_batch_linear_weight_gradients_match_autograd(n, in_dim, out_dim):
     assert (W.grad.double() - Wd.grad).abs().max().item() <= 3e-5 * scale
     assert (b.grad.double() - bd.grad).abs().max().item() <= 3e-5 * scale
     assert (x.grad.double() - xd.grad).abs().max().item() <= 1e-3
+
+
+@pytest.mark.parametrize('n,M,lda,Nc,ldb', [(4099, 50, 52, 33, 36), (1000, 300, 300, 128, 128), (31, 64, 64, 64, 64),
+                                            (2050, 7, 7, 5, 5)])
+def test_wgrad_row_major_layouts(n, M, lda, Nc, ldb):
+    """sx_wgrad on row-major operands: the 16-byte path (aligned rows, feature counts that end inside a quad, 128-row
+    slabs of a wide A) and the per-element path (odd strides), ragged n; fp64 truth."""
+    from stribor_amd import _hip
+    g = torch.Generator(device='cpu').manual_seed(n + M)
+    Af, Bf = torch.randn(n, lda, generator=g), torch.randn(n, ldb, generator=g)
+    want = Af[:, :M].double().T @ Bf[:, :Nc].double()
+    wantb = Af[:, :M].double().sum(0)
+    A, B = Af.to(DEV), Bf.to(DEV)
+    dW, db = torch.zeros(M, Nc, device=DEV), torch.zeros(M, device=DEV)
+    rc = _hip.lib().sx_wgrad(A.data_ptr(), lda, M, B.data_ptr(), ldb, Nc, n, _hip.WGRAD_ROW_MAJOR, dW.data_ptr(), Nc,
+                             db.data_ptr(), None, None, _hip.stream())
+    _hip.check(rc, 'sx_wgrad')
+    scale = max(1.0, float(n) ** 0.5)
+    assert (dW.cpu().double() - want).abs().max().item() <= 2e-5 * scale
+    assert (db.cpu().double() - wantb).abs().max().item() <= 2e-5 * scale
