@@ -811,6 +811,13 @@ __device__ __forceinline__ void coupling_affine_bwd(tile<1> (&xs)[2 * XT], const
     constexpr int B2 = F2B + 2 * TT * 32;                            // pack(W2^T, HT x 2TT)
     constexpr int B1 = B2 + HT * 2 * TT * 1024 + HT * 32;            // pack(W1^T, CT x HT)
     const int h = lane >> 5;
+    // The per-row factors of the weight gradients -- [z (CT) | tanh h (HT) | dL/dh_pre (HT) | dL/dls_t, dL/dsh_t (2TT)]
+    // -- are stored as soon as each is final, so that the stores drain behind the GEMM phases that follow instead
+    // of queueing up at the end of the step (one wave per SIMD: nothing else hides them).
+    if (side_row != nullptr) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) store_ctile(side_row, 32 * c, xs[C0 + c].v[0], h);
+    }
     // 1. recompute the conditioner (folded tanh: r = (1 - tanh)/2)
     tile<1> hid[HT];
     hidden_layer<1, 2 * XT, HT, C0, CT, true>(xs, hid, w, F1, SX_ACT_TANH_FOLDED);
@@ -839,6 +846,10 @@ __device__ __forceinline__ void coupling_affine_bwd(tile<1> (&xs)[2 * XT], const
             dsh[t].v[0][r] = -ai;                                                   // dL/dshift
             dls[t].v[0][r] = -al * xo - g;                                          // dL/dlog_scale (incl. -sum(ls))
         }
+        if (side_row != nullptr) {
+            store_ctile(side_row, 32 * CT + 64 * HT + 64 * t, dls[t].v[0], h);
+            store_ctile(side_row, 32 * CT + 64 * HT + 64 * t + 32, dsh[t].v[0], h);
+        }
     }
     // 3. dh = W2^T [dls_0; dsh_0; dls_1; ...],  dh_pre = dh * (1 - tanh^2)
     tile<1> dh[HT];
@@ -863,6 +874,13 @@ __device__ __forceinline__ void coupling_affine_bwd(tile<1> (&xs)[2 * XT], const
             hid[m].v[0][r] = th;
             dh[m].v[0][r] *= (1.f - th * th);
         }
+    if (side_row != nullptr) {
+#pragma unroll
+        for (int m = 0; m < HT; ++m) {
+            store_ctile(side_row, 32 * CT + 32 * m, hid[m].v[0], h);
+            store_ctile(side_row, 32 * CT + 32 * HT + 32 * m, dh[m].v[0], h);
+        }
+    }
     // 4. adjoint of the conditioning tiles: += W1^T dh_pre
     {
         btile<1> bd[HT];
@@ -877,21 +895,6 @@ __device__ __forceinline__ void coupling_affine_bwd(tile<1> (&xs)[2 * XT], const
             for (int m = 0; m < HT; ++m) gemm_tile<1>(w.wb, B1 + (c * HT + m) * 1024, bd[m], dz);
 #pragma unroll
             for (int r = 0; r < 16; ++r) xs[XT + C0 + c].v[0][r] += dz.v[0][r];
-        }
-    }
-    // 5. per-row factors of the weight gradients: [z (CT) | tanh h (HT) | dL/dh_pre (HT) | dL/dls_t, dL/dsh_t (2TT)]
-    if (side_row != nullptr) {
-#pragma unroll
-        for (int c = 0; c < CT; ++c) store_ctile(side_row, 32 * c, xs[C0 + c].v[0], h);
-#pragma unroll
-        for (int m = 0; m < HT; ++m) {
-            store_ctile(side_row, 32 * CT + 32 * m, hid[m].v[0], h);
-            store_ctile(side_row, 32 * CT + 32 * HT + 32 * m, dh[m].v[0], h);
-        }
-#pragma unroll
-        for (int t = 0; t < TT; ++t) {
-            store_ctile(side_row, 32 * CT + 64 * HT + 64 * t, dls[t].v[0], h);
-            store_ctile(side_row, 32 * CT + 64 * HT + 64 * t + 32, dsh[t].v[0], h);
         }
     }
 }
