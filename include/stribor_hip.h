@@ -319,6 +319,16 @@ int sx_wgrad(const float *A, int64_t lda, int32_t M, const float *B, int64_t ldb
              int32_t layout, float *dW, int64_t ldw, float *db, const int32_t *row_map, const int32_t *col_map,
              void *stream);
 
+/* Both weight gradients of ONE coupling layer of a backward program in one pass over its slot of `side`
+ * (32-row groups of [z (32 c_tiles) | tanh h (32 h_tiles) | dL/dh_pre (32 h_tiles) | dL/d(log_scale, shift) (64 t_tiles)],
+ * ld floats per group): dW2 [rows through row_map2, `hidden` columns] += dparams^T tanh_h, db2 += sum dparams,
+ * dW1 [`hidden` rows, columns through col_map1] += dh_pre^T z, db1 += sum dh_pre -- what two sx_wgrad calls on the
+ * slices compute, with the group streamed once.  Shapes: c_tiles = t_tiles = 1, h_tiles <= 2 (SX_E_UNSUPPORTED
+ * otherwise: use sx_wgrad). */
+int sx_wgrad_layer(const float *side, int64_t ld, int64_t n_rows, int32_t c_tiles, int32_t h_tiles, int32_t t_tiles,
+                   int32_t hidden, float *dW2, int64_t ldw2, float *db2, const int32_t *row_map2, float *dW1,
+                   int64_t ldw1, float *db1, const int32_t *col_map1, void *stream);
+
 /* LDS bytes and grid the launcher will use for a program (introspection for tests/bench). */
 int sx_flow_launch_info(const sx_program *prog_host, int64_t n_rows, int32_t *grid, int32_t *block,
                         int32_t *lds_bytes);

@@ -318,3 +318,165 @@ extern "C" int sx_wgrad(const float *A, int64_t lda, int32_t M, const float *B, 
     sx_set_error("sx_wgrad: unsupported tile shape %d x %d", mt, nt);
     return SX_E_UNSUPPORTED;
 }
+
+// Both weight gradients of one coupling layer of the backward flow program in ONE pass over its per-row factors:
+// a 32-row group holds [z (CT tiles) | tanh h (HT) | dL/dh_pre (HT) | dL/d(log_scale, shift) (2 TT)] contiguously, so a
+// wave streams the whole group (28 KB for cfg 2) instead of two strided subsets in two launches:
+//   dW2 (2 TT x HT tiles) += dparams^T tanh_h,  db2 += sum dparams;   dW1 (HT x CT tiles) += dh_pre^T z,  db1 += sum dh_pre.
+template <int CT, int HT, int TT, int WB>
+__global__ __launch_bounds__(64 * WB) void wgrad_layer_kernel(const float *__restrict__ side, int64_t ld, int64_t n_rows,
+                                                              float *__restrict__ part2, float *__restrict__ part1) {
+    constexpr int PT = 2 * TT;
+    constexpr int E2 = 32 * PT * 32 * HT + 32 * PT, E1 = 32 * HT * 32 * CT + 32 * HT;
+    constexpr int RED = E2 + E1;
+    __shared__ __attribute__((aligned(16))) float lds[(RED > WB * PATCH ? RED : WB * PATCH)];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, kk = lane >> 5;
+    float *patch = lds + wave * PATCH;
+    f32x16 acc2[PT][HT], acc1[HT][CT];
+    float bs2[PT], bs1[HT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        bs2[p] = 0.f;
+#pragma unroll
+        for (int n = 0; n < HT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[p][n][r] = 0.f;
+    }
+#pragma unroll
+    for (int m = 0; m < HT; ++m) {
+        bs1[m] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[m][c][r] = 0.f;
+    }
+    const int64_t n_waves = (int64_t)gridDim.x * WB, w_id = (int64_t)blockIdx.x * WB + wave;
+    const int64_t n_groups = (n_rows + 31) >> 5;
+    for (int64_t g = w_id; g < n_groups; g += n_waves) {
+        const float *base = side + g * ld;
+        f32x4 z[CT][4], hh[HT][4], dh[HT][4], dp[PT][4];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) load_tile(base + 1024 * c, true, lane, z[c]);
+#pragma unroll
+        for (int m = 0; m < HT; ++m) load_tile(base + 1024 * (CT + m), true, lane, hh[m]);
+#pragma unroll
+        for (int m = 0; m < HT; ++m) load_tile(base + 1024 * (CT + HT + m), true, lane, dh[m]);
+#pragma unroll
+        for (int p = 0; p < PT; ++p) load_tile(base + 1024 * (CT + 2 * HT + p), true, lane, dp[p]);
+        const int64_t rem = n_rows - 32 * g;
+        const int left = (rem < 32 ? (int)rem : 32) - 16 * kk;          // valid rows among this lane's 16
+        auto turn = [&](f32x4 (&v)[4]) {
+            turn_tile(patch, lane, v);
+            if (left < 16) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[q][c] = (4 * q + c < left) ? v[q][c] : 0.f;
+            }
+        };
+#pragma unroll
+        for (int n = 0; n < HT; ++n) turn(hh[n]);
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            turn(dp[p]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    bs2[p] += dp[p][q][c];
+#pragma unroll
+                    for (int n = 0; n < HT; ++n)
+                        acc2[p][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(dp[p][q][c], hh[n][q][c], acc2[p][n], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) turn(z[c]);
+#pragma unroll
+        for (int m = 0; m < HT; ++m) {
+            turn(dh[m]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    bs1[m] += dh[m][q][c4];
+#pragma unroll
+                    for (int c = 0; c < CT; ++c)
+                        acc1[m][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(dh[m][q][c4], z[c][q][c4], acc1[m][c], 0, 0, 0);
+                }
+        }
+    }
+    __syncthreads();                                    // every wave is done with its patch
+    float *red = lds;
+    constexpr int N2 = 32 * HT, N1 = 32 * CT;
+    for (int w = 0; w < WB; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+#pragma unroll
+                for (int n = 0; n < HT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int e = (32 * p + (r & 3) + 8 * (r >> 2) + 4 * kk) * N2 + 32 * n + i;
+                        red[e] = (w == 0 ? 0.f : red[e]) + acc2[p][n][r];
+                    }
+                const float t = bs2[p] + __shfl_xor(bs2[p], 32, 64);
+                const int e = 32 * PT * N2 + 32 * p + i;
+                if (kk == 0) red[e] = (w == 0 ? 0.f : red[e]) + t;
+            }
+#pragma unroll
+            for (int m = 0; m < HT; ++m) {
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int e = E2 + (32 * m + (r & 3) + 8 * (r >> 2) + 4 * kk) * N1 + 32 * c + i;
+                        red[e] = (w == 0 ? 0.f : red[e]) + acc1[m][c][r];
+                    }
+                const float t = bs1[m] + __shfl_xor(bs1[m], 32, 64);
+                const int e = E2 + 32 * HT * N1 + 32 * m + i;
+                if (kk == 0) red[e] = (w == 0 ? 0.f : red[e]) + t;
+            }
+        }
+        __syncthreads();
+    }
+    float *d2 = part2 + (int64_t)blockIdx.x * E2, *d1 = part1 + (int64_t)blockIdx.x * E1;
+    for (int e = threadIdx.x; e < E2; e += 64 * WB) d2[e] = red[e];
+    for (int e = threadIdx.x; e < E1; e += 64 * WB) d1[e] = red[E2 + e];
+}
+
+extern "C" int sx_wgrad_layer(const float *side, int64_t ld, int64_t n_rows, int32_t c_tiles, int32_t h_tiles,
+                              int32_t t_tiles, int32_t hidden, float *dW2, int64_t ldw2, float *db2,
+                              const int32_t *row_map2, float *dW1, int64_t ldw1, float *db1, const int32_t *col_map1,
+                              void *stream) {
+    SX_REQUIRE(side && dW2 && dW1, "sx_wgrad_layer: null pointer");
+    SX_REQUIRE(((uintptr_t)side & 15) == 0 && ld % 4 == 0 && ld >= 32 * (c_tiles + 2 * h_tiles + 2 * t_tiles) * 32,
+               "sx_wgrad_layer: side must be 16-byte aligned row groups of at least the layer's features");
+    SX_REQUIRE(hidden >= 1 && hidden <= 32 * h_tiles && n_rows >= 0, "sx_wgrad_layer: bad hidden width");
+    if (n_rows == 0) return SX_OK;
+    hipStream_t st = sx_stream(stream);
+    constexpr int WB = 8, GMAX = 256;
+    int64_t g = (n_rows + 32 * WB - 1) / (32 * WB);
+    if (g > GMAX) g = GMAX;
+#define SX_WL(CT_, HT_, TT_)                                                                                       \
+    if (c_tiles == CT_ && h_tiles == HT_ && t_tiles == TT_) {                                                      \
+        constexpr int E2 = 32 * 2 * TT_ * 32 * HT_ + 32 * 2 * TT_, E1 = 32 * HT_ * 32 * CT_ + 32 * HT_;             \
+        float *part = partial_scratch(st, (size_t)GMAX * (E2 + E1));                                               \
+        SX_REQUIRE(part != nullptr, "sx_wgrad_layer: cannot allocate the partial-tile scratch");                   \
+        float *part1 = part + (size_t)GMAX * E2;                                                                   \
+        hipLaunchKernelGGL((wgrad_layer_kernel<CT_, HT_, TT_, WB>), dim3((int)g), dim3(64 * WB), 0, st, side, ld,  \
+                           n_rows, part, part1);                                                                   \
+        SX_LAUNCH_CHECK();                                                                                         \
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((E2 + 31) / 32, 1), dim3(256), 0, st, part, (int)g,           \
+                           64 * TT_, 32 * HT_, dW2, ldw2, db2, 64 * TT_, hidden, row_map2, (const int32_t *)nullptr); \
+        SX_LAUNCH_CHECK();                                                                                         \
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((E1 + 31) / 32, 1), dim3(256), 0, st, part1, (int)g,          \
+                           32 * HT_, 32 * CT_, dW1, ldw1, db1, hidden, 32 * CT_, (const int32_t *)nullptr, col_map1); \
+        SX_LAUNCH_CHECK();                                                                                         \
+        return SX_OK;                                                                                              \
+    }
+    SX_WL(1, 1, 1) SX_WL(1, 2, 1)
+#undef SX_WL
+    sx_set_error("sx_wgrad_layer: unsupported tile shape (c %d, h %d, t %d)", c_tiles, h_tiles, t_tiles);
+    return SX_E_UNSUPPORTED;
+}

@@ -88,6 +88,12 @@ class _FusedLogProb(torch.autograd.Function):
                 zc, pc = 32 * info['ct'], 64 * info['tt']
                 p0 = base + slot * ng * ld * 4                    # features: z | tanh h | dL/dh_pre | dL/dparams
                 gW1, gb1, gW2, gb2 = views[slot]
+                if info['ct'] == 1 and info['tt'] == 1 and ht <= 64:
+                    # pruned half masks: both gradients of the layer in one pass over its 28 KB row groups
+                    _hip.check(lib.sx_wgrad_layer(p0, ld, m, 1, ht // 32, 1, H, gW2.data_ptr(), gW2.stride(0), gb2.data_ptr(),
+                                                  info['row_map'].data_ptr(), gW1.data_ptr(), gW1.stride(0), gb1.data_ptr(),
+                                                  info['col_map'].data_ptr(), st), 'sx_wgrad_layer')
+                    continue
                 _hip.check(lib.sx_wgrad(p0 + 128 * (zc + 2 * ht), ld, pc, p0 + 128 * zc, ld, H, m, _hip.WGRAD_ROW_GROUPS, gW2.data_ptr(),
                                         gW2.stride(0), gb2.data_ptr(), info['row_map'].data_ptr(), None, st), 'sx_wgrad')
                 _hip.check(lib.sx_wgrad(p0 + 128 * (zc + ht), ld, H, p0, ld, zc, m, _hip.WGRAD_ROW_GROUPS, gW1.data_ptr(),
