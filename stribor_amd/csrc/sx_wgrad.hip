@@ -1,20 +1,20 @@
-// Weight-gradient contraction of the training backward pass:  dW[i][j] += sum_n A[n][i] * B[n][j],
-// db[i] += sum_n A[n][i], with A (M features) and B (Nc features) slices of the per-row factors the backward flow
-// kernel leaves in HBM (M, Nc <= 128; n_rows ~ 1e6).
+// Weight-gradient contractions over the batch axis (training):  dW[i][j] += sum_n A[n][i] * B[n][j],
+// db[i] += sum_n A[n][i]  with n_rows ~ 1e6 and a few dozen to a few hundred features.
 //
 // A tall-skinny "A^T B" whose reduction axis is the batch: library GEMMs run it on a handful of workgroups
-// (measured 1.5 ms per 64x64x2^20 product = 9 % of HBM rate).  Here the batch is split over the whole chip.  The
-// factors are stored in 32-row groups, feature-major inside (element (row n, feature f) at
-// (n >> 5) * ld + f * 32 + (n & 31): the layout the flow kernel's fragment stores coalesce in), so a 32-feature
-// tile of a group is 4 KB contiguous.  A wave reads it with four fully coalesced 16 B-per-lane loads and turns it
-// through a private LDS patch into the v_mfma_f32_32x32x2_f32 operand order -- A^T[i = lane & 31][k = lane >> 5],
-// B[k][j = lane & 31] with k = the row: lane (i, kk) ends up with rows 16 kk .. 16 kk + 15 of feature i and feeds
-// them to 16 MFMAs (the pairing of rows into k-steps is free as long as A and B agree).  Each wave keeps the
-// (M/32) x (Nc/32) output tiles in registers over its row groups; the waves of a workgroup then sum their tiles in
-// LDS, the workgroup stores ONE partial
-// tile to a per-stream scratch with plain coalesced stores, and a second small kernel sums the <= 512 partials
-// per element and adds them to dW / db (one writer per element).  Global float atomics on M x Nc addresses were
-// the cost of the first version: 4096 waves x 4096 contended adds took twice as long as the data pass itself.
+// (measured 1.5 ms per 64 x 64 x 2^20 product = 9 % of the HBM rate).  Here the batch is split over the whole chip:
+//   * 32-row groups are dealt to the waves of 256 workgroups.  v_mfma_f32_32x32x2_f32 wants A^T[i = lane & 31][k = lane >> 5]
+//     and B[k][j = lane & 31] with k = the row, i.e. lane = feature.  A wave reads a 32-row x 32-feature tile with four
+//     coalesced 16 B-per-lane loads -- 4 KB contiguous in the backward flow kernel's row-group layout (element (row n,
+//     feature f) at (n >> 5) * ld + f * 32 + (n & 31)), eight whole 128 B segments per load for row-major torch
+//     tensors -- and turns it through a private LDS patch: lane (i, kk) ends up with rows 16 kk .. 16 kk + 15 of
+//     feature i and feeds them to 16 MFMAs (the pairing of rows into k-steps is free as long as A and B agree).
+//   * each wave keeps its (M/32) x (Nc/32) output tiles in registers over all its groups; the waves of a workgroup
+//     then sum their tiles in LDS by turns, and the workgroup stores ONE partial tile to a per-stream scratch;
+//   * a second small kernel sums the <= 256 partials per element and adds them to dW / db through optional row /
+//     column maps (one writer per element: deterministic).
+// The first version added the waves' tiles with float atomics: global (4096 waves x 4096 contended adds took twice as
+// long as the data pass) and then LDS (ds_add_f32 serialises its lanes: 40 us per launch).
 #include "sx_common.h"
 #include <mutex>
 #include <vector>
@@ -36,10 +36,6 @@ __device__ __forceinline__ void turn_tile(float *patch, int lane, f32x4 (&v)[4])
     for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4 *>(patch + (lane & 31) * 36 + 16 * (lane >> 5) + 4 * q);
 }
 
-// GROUPS: operands in 32-row feature-major groups (the backward flow kernel's factors); otherwise plain row-major
-// [n_rows, ld] matrices (torch tensors: autograd's weight gradient of a Linear layer), where lane (i, kk) loads
-// element (row 2s + kk, feature i) directly -- 128 B contiguous per lane half.  blockIdx.y = 128-feature slab of A
-// (row-major only: M up to 2048, B is re-read per slab from L2 / MALL).
 // row-major tiles (32 rows x 32 features = 32 segments of 128 B, row stride ld): instr q, lane L holds row
 // 8q + (L >> 3), features 4 (L & 7) .. + 3 -- eight whole 128 B segments per load; rows past `rows_left` read as zero
 __device__ __forceinline__ void load_tile_rows(const float *tile_base, int64_t ld, int rows_left, bool f_ok, int lane,
@@ -62,8 +58,10 @@ __device__ __forceinline__ void turn_tile_rows(float *patch, int lane, f32x4 (&v
         for (int c = 0; c < 4; ++c) v[q][c] = patch[(16 * (lane >> 5) + 4 * q + c) * 36 + (lane & 31)];
 }
 
-// LAYOUT: SX_WGRAD_ROW_GROUPS (1), row-major with 16 B loads through the LDS patch (2: 16-byte aligned rows), or
-// row-major with per-element loads (0: any alignment)
+// LAYOUT 1: SX_WGRAD_ROW_GROUPS; 2: row-major [n_rows, ld] with 16 B loads through the LDS patch (16-byte aligned rows);
+// 0: row-major with per-element loads (any alignment: lane (i, kk) loads element (row 2s + kk, feature i), 128 B
+// contiguous per lane half).  blockIdx.y = 128-feature slab of A (row-major only: M up to 2048, B is re-read per slab
+// from L2 / MALL).
 template <int MT, int NT, int WB, int LAYOUT>
 __global__ __launch_bounds__(64 * WB) void wgrad_kernel(const float *__restrict__ A, int64_t lda,
                                                         const float *__restrict__ B, int64_t ldb, int64_t n_rows,
@@ -95,8 +93,7 @@ __global__ __launch_bounds__(64 * WB) void wgrad_kernel(const float *__restrict_
     const int64_t n_waves = (int64_t)gridDim.x * WB;
     const int64_t w_id = (int64_t)blockIdx.x * WB + wave;
     const int64_t n_groups = (n_rows + 31) >> 5;
-    // features past m_valid / n_valid: whole 8-feature slabs of a load are in or out only when the bound is a multiple
-    // of 8; otherwise mask after the turn (lane i = feature)
+    // features past m_valid / n_valid and rows past n_rows are masked after the turn (lane i = feature)
     for (int64_t g = w_id; g < n_groups; g += n_waves) {
         f32x4 a[MT][4], b[NT][4];
         const int64_t rem = n_rows - 32 * g;
