@@ -329,6 +329,11 @@ int sx_wgrad_layer(const float *side, int64_t ld, int64_t n_rows, int32_t c_tile
                    int32_t hidden, float *dW2, int64_t ldw2, float *db2, const int32_t *row_map2, float *dW1,
                    int64_t ldw1, float *db1, const int32_t *col_map1, void *stream);
 
+/* out[j] += sum_n A[n, j] for a row-major fp32 [n_rows, M] matrix (row stride lda): the bias gradient of a Linear
+ * layer too wide for sx_wgrad (autograd's grad_output.sum(0) behind stribor/net/mlp.py:48-58).  Deterministic, no
+ * atomics; zero `out` first. */
+int sx_colsum(const float *A, int64_t lda, int64_t n_rows, int32_t M, float *out, void *stream);
+
 /* LDS bytes and grid the launcher will use for a program (introspection for tests/bench). */
 int sx_flow_launch_info(const sx_program *prog_host, int64_t n_rows, int32_t *grid, int32_t *block,
                         int32_t *lds_bytes);

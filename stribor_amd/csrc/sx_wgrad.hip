@@ -477,3 +477,102 @@ extern "C" int sx_wgrad_layer(const float *side, int64_t ld, int64_t n_rows, int
     sx_set_error("sx_wgrad_layer: unsupported tile shape (c %d, h %d, t %d)", c_tiles, h_tiles, t_tiles);
     return SX_E_UNSUPPORTED;
 }
+
+// Column sums of a row-major [n_rows, M] matrix (the bias gradient of a wide Linear layer: out[j] += sum_n A[n][j]).
+// Two stages like sx_wgrad: 256 row slices x column blocks are summed in registers -- a workgroup is Q column lanes
+// (16 B each when the rows are 16-byte aligned: a wave reads 1 KB of a row) x 256 / Q row lanes, folded through LDS --
+// then one writer per column.  The result does not depend on scheduling and the launch pair replays from a HIP graph
+// (torch's multi-block column sum did not on this build).
+template <bool VEC>
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ A, int64_t lda, int64_t n_rows, int M,
+                                                     int Q, float *__restrict__ part) {
+    constexpr int W = VEC ? 4 : 1;
+    __shared__ float red[256 * W];
+    const int R = 256 / Q, cl = threadIdx.x % Q, rl = threadIdx.x / Q;
+    const int c = (blockIdx.y * Q + cl) * W;
+    float s[4][W];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int w = 0; w < W; ++w) s[u][w] = 0.f;
+    if (c < M) {
+        const int64_t step = (int64_t)gridDim.x * R;
+        int64_t r = (int64_t)blockIdx.x * R + rl;
+        for (; r + 3 * step < n_rows; r += 4 * step) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float *p = A + (r + u * step) * lda + c;
+                if constexpr (VEC) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(p);
+                    s[u][0] += v.x; s[u][1] += v.y; s[u][2] += v.z; s[u][3] += v.w;
+                } else {
+                    s[u][0] += *p;
+                }
+            }
+        }
+        for (; r < n_rows; r += step) {
+            const float *p = A + r * lda + c;
+#pragma unroll
+            for (int w = 0; w < W; ++w) s[0][w] += p[w];
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < W; ++w) red[threadIdx.x * W + w] = (s[0][w] + s[1][w]) + (s[2][w] + s[3][w]);
+    __syncthreads();
+    if (rl == 0 && c < M) {
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            float t = 0.f;
+            for (int k = 0; k < R; ++k) t += red[(k * Q + cl) * W + w];
+            part[(int64_t)blockIdx.x * M + c + w] = t;
+        }
+    }
+}
+// out[c] += sum_p part[p][c]: 256 threads = 32 columns x 8 partial groups
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float *__restrict__ part, int n_part, int M,
+                                                            float *__restrict__ out) {
+    __shared__ float red[8][32];
+    const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + el;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < M) {
+        int p = grp;
+        for (; p + 24 < n_part; p += 32) {
+            s0 += part[(int64_t)p * M + c]; s1 += part[(int64_t)(p + 8) * M + c];
+            s2 += part[(int64_t)(p + 16) * M + c]; s3 += part[(int64_t)(p + 24) * M + c];
+        }
+        for (; p < n_part; p += 8) s0 += part[(int64_t)p * M + c];
+    }
+    red[grp][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp == 0 && c < M) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += red[g][el];
+        out[c] += t;
+    }
+}
+
+extern "C" int sx_colsum(const float *A, int64_t lda, int64_t n_rows, int32_t M, float *out, void *stream) {
+    SX_REQUIRE(A && out, "sx_colsum: null pointer");
+    SX_REQUIRE(M >= 1 && n_rows >= 0 && lda >= M, "sx_colsum: bad shape");
+    if (n_rows == 0) return SX_OK;
+    hipStream_t st = sx_stream(stream);
+    const bool vec = ((uintptr_t)A & 15) == 0 && lda % 4 == 0 && M % 4 == 0;
+    const int lanes = vec ? (M + 3) / 4 : M;                       // column lanes needed
+    int Q = 256;
+    while (Q > 1 && Q / 2 >= lanes) Q /= 2;                        // power of two: 256 / Q row lanes per workgroup
+    const int gy = (lanes + Q - 1) / Q;
+    int gx = 1024 / gy;
+    gx = gx < 64 ? 64 : (gx > 256 ? 256 : gx);
+    const int64_t slices = (n_rows + (256 / Q) - 1) / (256 / Q);
+    if (gx > slices) gx = (int)slices;
+    float *part = partial_scratch(st, (size_t)256 * M);
+    SX_REQUIRE(part != nullptr, "sx_colsum: cannot allocate the partial scratch");
+    if (vec) hipLaunchKernelGGL(colsum_kernel<true>, dim3(gx, gy), dim3(256), 0, st, A, lda, n_rows, (int)M, Q, part);
+    else hipLaunchKernelGGL(colsum_kernel<false>, dim3(gx, gy), dim3(256), 0, st, A, lda, n_rows, (int)M, Q, part);
+    SX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((M + 31) / 32), dim3(256), 0, st, part, gx, (int)M, out);
+    SX_LAUNCH_CHECK();
+    return SX_OK;
+}

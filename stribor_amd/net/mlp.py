@@ -16,17 +16,19 @@ from ..fused import ProgramBuilder
 
 
 class BatchLinear(torch.autograd.Function):
-    """y = x W^T + b for the layer-wise training path.  Forward and dL/dx are library GEMMs; dL/dW = (dL/dy)^T x and
-    dL/db = sum_n dL/dy are a tall-skinny contraction over the batch, which library GEMMs run on a handful of
-    workgroups (0.63 ms for a 64 x 64 gradient over 2^18 rows) -- here it is sx_wgrad (row-major operands)."""
+    """y = x W^T + b for the layer-wise training path.  Forward and dL/dx are library GEMMs.  dL/dW = (dL/dy)^T x and
+    dL/db = sum_n dL/dy contract over the batch: for narrow layers (output <= 256 features) that is a tall-skinny product
+    library GEMMs run on a handful of workgroups (0.63 ms for a 64 x 64 gradient over 2^18 rows) -- sx_wgrad computes
+    both; for wide layers (a spline conditioner's 1504 rows) the library GEMM fills the chip and keeps dL/dW, and the
+    bias gradient is sx_colsum (deterministic, and unlike torch's multi-block column sum on this build it replays
+    correctly from a HIP graph)."""
 
-    MIN_ROWS = 4096
-    MAX_OUT = 256          # wider outputs (a spline conditioner's 1504 rows): the library GEMM fills the chip and wins
+    MIN_ROWS = 4096        # below this the library's weight gradient is as fast
+    MAX_OUT = 256          # wider outputs: the library GEMM wins (measured on the 1504-wide layer)
 
     @staticmethod
     def eligible(x: torch.Tensor, W: torch.Tensor) -> bool:
-        return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and W.dtype == torch.float32
-                and x.shape[0] >= BatchLinear.MIN_ROWS and W.shape[1] <= 128 and W.shape[0] <= BatchLinear.MAX_OUT)
+        return x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and W.dtype == torch.float32
 
     @staticmethod
     def forward(ctx, x, W, b):
@@ -39,17 +41,46 @@ class BatchLinear(torch.autograd.Function):
         x, W = ctx.saved_tensors
         gx = gy @ W if ctx.needs_input_grad[0] else None
         gW = gb = None
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gy2 = gy if gy.stride(1) == 1 else gy.contiguous()
+        want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        if not (want_w or want_b):
+            return gx, None, None
+        lib, st = _hip.lib(), _hip.stream()
+        gy2 = gy if gy.stride(1) == 1 else gy.contiguous()
+        out_dim, in_dim = W.shape
+        n = x.shape[0]
+        if n >= BatchLinear.MIN_ROWS and in_dim <= 128 and out_dim <= BatchLinear.MAX_OUT:
             x2 = x if x.stride(1) == 1 else x.contiguous()
-            out_dim, in_dim = W.shape
             gW = torch.zeros(out_dim, in_dim, dtype=torch.float32, device=x.device)
             gb = torch.zeros(out_dim, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-            rc = _hip.lib().sx_wgrad(gy2.data_ptr(), gy2.stride(0), out_dim, x2.data_ptr(), x2.stride(0), in_dim,
-                                     x2.shape[0], _hip.WGRAD_ROW_MAJOR, gW.data_ptr(), in_dim, _hip.ptr(gb), None, None,
-                                     _hip.stream())
-            _hip.check(rc, 'sx_wgrad')
+            _hip.check(lib.sx_wgrad(gy2.data_ptr(), gy2.stride(0), out_dim, x2.data_ptr(), x2.stride(0), in_dim, n,
+                                    _hip.WGRAD_ROW_MAJOR, gW.data_ptr(), in_dim, _hip.ptr(gb), None, None, st), 'sx_wgrad')
+            return gx, gW, gb
+        if want_w:
+            gW = gy.t() @ x
+        if want_b:
+            gb = torch.zeros(out_dim, dtype=torch.float32, device=x.device)
+            _hip.check(lib.sx_colsum(gy2.data_ptr(), gy2.stride(0), n, out_dim, gb.data_ptr(), st), 'sx_colsum')
         return gx, gW, gb
+
+
+class SelectRows(torch.autograd.Function):
+    """p.index_select(0, rows) for DISTINCT rows, with a backward that writes (index_copy_) instead of accumulating
+    (index_add_) into the zero-filled gradient: the same values, and -- unlike autograd's own index_select backward on
+    this torch / ROCm build -- correct when the step is replayed from a HIP graph (from the second replay on the
+    accumulating form returned stale sums for the bias; reproduced with plain torch ops)."""
+
+    @staticmethod
+    def forward(ctx, p, rows):
+        ctx.save_for_backward(rows)
+        ctx.shape = p.shape
+        return p.index_select(0, rows)
+
+    @staticmethod
+    def backward(ctx, g):
+        (rows,) = ctx.saved_tensors
+        out = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
+        out.index_copy_(0, rows, g)
+        return out, None
 
 
 def batch_linear(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
@@ -109,7 +140,7 @@ class MLP(nn.Module):
         last = layers[-1]
         W, b = last.weight, last.bias
         if rows is not None:
-            W, b = W.index_select(0, rows), b.index_select(0, rows)
+            W, b = SelectRows.apply(W, rows), SelectRows.apply(b, rows)       # rows are distinct
         return batch_linear(h, W, b)
 
     # -- standalone evaluation ---------------------------------------------------------------------------

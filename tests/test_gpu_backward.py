@@ -494,3 +494,52 @@ def test_wgrad_row_major_layouts(n, M, lda, Nc, ldb):
     scale = max(1.0, float(n) ** 0.5)
     assert (dW.cpu().double() - want).abs().max().item() <= 2e-5 * scale
     assert (db.cpu().double() - wantb).abs().max().item() <= 2e-5 * scale
+
+
+@pytest.mark.parametrize('make,dim,n', [('cfg2', 64, 2048), ('cfg3', 64, 512), ('cfg4', 128, 512)])
+def test_training_step_replays_from_a_hip_graph(make, dim, n):
+    """Small-batch training is launch-bound: the whole step (forward, hand-written / layer-wise backward, parameter
+    gradients) captured once into a HIP graph and replayed on new data gives the gradients of an eager step bit for bit
+    (no allocation outside torch's graph pool, no synchronisation, scratch and counters created by the warm-up)."""
+    torch.manual_seed(3)
+    desc = {'cfg2': lambda: fd.cfg2_desc(4, dim, 64), 'cfg3': lambda: fd.cfg3_desc(2, dim, 64, 16),
+            'cfg4': lambda: fd.cfg4_desc(1, dim, 64)}[make]()
+    flow = fd.build_flow(st, desc, dim).to(DEV)
+    params = list(flow.parameters())
+    static_x = torch.randn(n, dim, device=DEV)
+
+    def step():
+        loss = -flow.log_prob(static_x).mean()
+        return (loss.detach(),) + tuple(torch.autograd.grad(loss, params))
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        static_out = step()
+    for seed in range(2):
+        fresh = torch.randn(n, dim, device=DEV, generator=torch.Generator(device=DEV).manual_seed(seed))
+        static_x.copy_(fresh)
+        graph.replay()
+        torch.cuda.synchronize()
+        got = [t.clone() for t in static_out]
+        want = step()
+        for a, b in zip(got, want):
+            assert torch.equal(a, b), (make, seed)
+
+
+@pytest.mark.parametrize('n,M,lda', [(1, 7, 7), (513, 1504, 1504), (100_003, 50, 52), (4096, 300, 300), (77, 1025, 1028)])
+def test_colsum_matches_fp64(n, M, lda):
+    from stribor_amd import _hip
+    g = torch.Generator(device='cpu').manual_seed(n + M)
+    A = torch.randn(n, lda, generator=g)
+    base = torch.randn(M, generator=g)
+    want = base.double() + A[:, :M].double().sum(0)
+    Ad, out = A.to(DEV), base.to(DEV)
+    _hip.check(_hip.lib().sx_colsum(Ad.data_ptr(), lda, n, M, out.data_ptr(), _hip.stream()), 'sx_colsum')
+    assert (out.cpu().double() - want).abs().max().item() <= 2e-6 * max(1.0, float(n) ** 0.5) * 4
