@@ -280,15 +280,21 @@ class NormalizingFlow(Transform):
         from .flows.permute import _ColumnShuffle
         y2, lead = flatten_rows(y.to(torch.float32))
         lat2 = None if latent is None else latent.reshape(-1, latent.shape[-1]).to(torch.float32)
+        from .flows.linear import derive_dense_batched
+        dense = derive_dense_batched(self.transforms, y2.device)              # AffineLU / MatrixExponential matrices, batched
         cur, total = y2, None
         for f in reversed(self.transforms):
             if isinstance(f, _ColumnShuffle):
-                perm = f._perm(cur.shape[1]).to(cur.device).long()
-                inv = torch.empty_like(perm)
-                inv[perm] = torch.arange(perm.numel(), device=perm.device)
+                key = ('inv_perm', cur.shape[1], str(cur.device))
+                inv = self._fused.get(key + (id(f),))
+                if inv is None:
+                    perm = f._perm(cur.shape[1]).to(cur.device).long()
+                    inv = torch.empty_like(perm)
+                    inv[perm] = torch.arange(perm.numel(), device=perm.device)
+                    self._fused[key + (id(f),)] = inv
                 cur = cur.index_select(1, inv)                                # permute.py:75 (inverse direction)
                 continue
-            cur, ldj = f._autograd_inverse(cur, lat2)
+            cur, ldj = f._autograd_inverse(cur, lat2, dense[id(f)]) if id(f) in dense else f._autograd_inverse(cur, lat2)
             total = ldj if total is None else total + ldj
         d = cur.shape[1]
         lp = -0.5 * (cur * cur).sum(-1) - d * HALF_LOG_2PI + total            # dist/normal.py:37,52-54

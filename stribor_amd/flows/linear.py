@@ -56,12 +56,52 @@ class _DenseLinear(Transform):
         return (None if y is None else y.reshape(*lead, d)), (None if ldj is None else ldj.reshape(*lead, 1))
 
 
-def _lu_inverse(L: torch.Tensor, U: torch.Tensor) -> torch.Tensor:
-    """(L U)^-1 = U^-1 L^-1 by two triangular solves against the identity (differentiable; the factors are already
-    triangular, so no LU factorisation -- rocSOLVER's fp64 getrf panels cost 2 ms per cfg-4 training step)."""
-    eye = torch.eye(L.shape[0], dtype=L.dtype, device=L.device)
-    Linv = torch.linalg.solve_triangular(L, eye, upper=False)
-    return torch.linalg.solve_triangular(U, Linv, upper=True)
+_TE_CACHE = {}
+
+
+def derive_dense_batched(layers, dev):
+    """The inverse-direction matrices of all AffineLU / MatrixExponential layers of a flow in a few BATCHED fp64 torch ops
+    (one launch per op for every group of same-shaped layers instead of one per layer: a training step of a cfg-4-like
+    flow is dominated by these tiny launches at small batch sizes).  -> {id(layer): (W [out, in] fp32, b fp32 | None,
+    log-det scalar tensor)} for the layers' _autograd_inverse; differentiable."""
+    out, groups = {}, {}
+    for f in layers:
+        if isinstance(f, AffineLU):
+            groups.setdefault(('lu', f.dim), []).append(f)
+        elif isinstance(f, MatrixExponential):
+            groups.setdefault(('mx', f.dim, f.bias is not None), []).append(f)
+    for key, fs in groups.items():
+        D = key[1]
+        eye = torch.eye(D, dtype=torch.float64, device=dev)
+        if key[0] == 'lu':
+            W = torch.stack([f.weight for f in fs]).to(dev, torch.float64)
+            ld = torch.stack([f.log_diag.reshape(-1) for f in fs]).to(dev, torch.float64)
+            b = torch.stack([f.bias.reshape(-1) for f in fs]).to(dev, torch.float64)
+            L, U = torch.tril(W, -1) + eye, torch.triu(W, 1) + torch.diag_embed(ld.exp())      # affine.py:148-154
+            Ainv = torch.linalg.solve_triangular(U, torch.linalg.solve_triangular(L, eye.expand_as(L), upper=False), upper=True)
+            Wm = Ainv.transpose(-1, -2).to(torch.float32).contiguous()                         # x = (y - b) A^-1 (:159-163)
+            bm = (-(b.unsqueeze(1) @ Ainv).squeeze(1)).to(torch.float32)
+            ldj = (-ld.sum(-1)).to(torch.float32)                                              # :171, negated
+            for i, f in enumerate(fs):
+                out[id(f)] = (Wm[i], bm[i], ldj[i])
+        else:
+            W = torch.stack([f._weight for f in fs]).to(dev, torch.float64)
+            dg = torch.stack([f.diag for f in fs]).to(dev, torch.float64)
+            tkey = (tuple(f._t_eff(1.0) for f in fs), str(dev))
+            te = _TE_CACHE.get(tkey)                      # constants: uploaded once (a host copy would break graph capture)
+            if te is None:
+                te = _TE_CACHE[tkey] = torch.tensor(tkey[0], dtype=torch.float64, device=dev).unsqueeze(-1)
+            L, U = torch.tril(W, diagonal=-1) + eye, torch.triu(W) + eye                       # affine.py:222-226
+            Ainv = torch.linalg.solve_triangular(U, torch.linalg.solve_triangular(L, eye.expand_as(L), upper=False), upper=True)
+            M = ((L @ U) * (dg * (-te)).exp().unsqueeze(-2)) @ Ainv                            # :254-266 with t -> -t
+            Wm = M.to(torch.float32).contiguous()
+            ldj = (-(dg.sum(-1) * te.squeeze(-1))).to(torch.float32)                           # :287-288, negated
+            if key[2]:
+                bias = torch.stack([f.bias for f in fs]).to(dev, torch.float64)
+                bm = (-(M @ bias.unsqueeze(-1)).squeeze(-1)).to(torch.float32)
+            for i, f in enumerate(fs):
+                out[id(f)] = (Wm[i], bm[i] if key[2] else None, ldj[i])
+    return out
 
 
 class AffineLU(_DenseLinear):
@@ -100,15 +140,12 @@ class AffineLU(_DenseLinear):
     def _autograd_supported(self) -> bool:
         return True
 
-    def _autograd_inverse(self, x2: torch.Tensor, lat2=None):
+    def _autograd_inverse(self, x2: torch.Tensor, lat2=None, derived=None):
         dev = x2.device
-        W = self.weight.to(dev, torch.float64)
-        eye = torch.eye(self.dim, dtype=torch.float64, device=dev)
-        Ainv = _lu_inverse(torch.tril(W, -1) + eye, torch.triu(W, 1) + eye * self.log_diag.to(dev, torch.float64).exp())
-        b = self.bias.to(dev, torch.float64).reshape(-1)
-        out = batch_linear(x2, Ainv.T.to(torch.float32).contiguous(), (-(b @ Ainv)).to(torch.float32))   # :159-163
-        ldj = (-self.log_diag.to(dev, torch.float32).sum()).expand(x2.shape[0])                            # :171, negated
-        return out, ldj
+        if derived is None:
+            derived = derive_dense_batched([self], dev)[id(self)]
+        Wm, bm, ldj = derived
+        return batch_linear(x2, Wm, bm), ldj.expand(x2.shape[0])                                           # :159-163, :171
 
     def _plan(self, builder, reverse, ldj_scale):
         ld = float(self.log_diag.detach().double().sum().item())          # affine.py:171
@@ -171,18 +208,11 @@ class MatrixExponential(_DenseLinear):
     def _autograd_supported(self) -> bool:
         return True
 
-    def _autograd_inverse(self, x2: torch.Tensor, lat2=None):
-        dev = x2.device
-        te = self._t_eff(1.0)
-        W = self._weight.to(dev, torch.float64)
-        eye = torch.eye(self.dim, dtype=torch.float64, device=dev)
-        L, U = torch.tril(W, diagonal=-1) + eye, torch.triu(W) + eye        # affine.py:222-226
-        dg = self.diag.to(dev, torch.float64)
-        M = ((L @ U) * (dg * (-te)).exp()) @ _lu_inverse(L, U)               # affine.py:254-266 with t -> -t
-        b = None if self.bias is None else (-(M @ self.bias.to(dev, torch.float64))).to(torch.float32)
-        out = batch_linear(x2, M.to(torch.float32), b)
-        ldj = (-(self.diag.to(dev, torch.float32).sum() * te)).expand(x2.shape[0])                         # :287-288, negated
-        return out, ldj
+    def _autograd_inverse(self, x2: torch.Tensor, lat2=None, derived=None):
+        if derived is None:
+            derived = derive_dense_batched([self], x2.device)[id(self)]
+        Wm, bm, ldj = derived
+        return batch_linear(x2, Wm, bm), ldj.expand(x2.shape[0])                                           # :254-266, :287-288
 
     def _plan(self, builder, reverse, ldj_scale):
         t = getattr(builder, 't', None)
