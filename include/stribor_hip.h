@@ -334,6 +334,12 @@ int sx_wgrad_layer(const float *side, int64_t ld, int64_t n_rows, int32_t c_tile
  * atomics; zero `out` first. */
 int sx_colsum(const float *A, int64_t lda, int64_t n_rows, int32_t M, float *out, void *stream);
 
+/* X[b] = T[b]^-1 for a batch of row-major fp64 D x D triangular matrices (D <= 128; lower != 0: lower triangular,
+ * else upper; unit != 0: the diagonal is taken as 1).  Entries of T outside the triangle are not read; X is written
+ * in full (zeros outside the triangle).  Parameter preprocessing of AffineLU / MatrixExponential in training: replaces
+ * the triangular solves of stribor/flows/affine.py:159-163, 254-266 against the identity. */
+int sx_tri_inverse_f64(const double *T, double *X, int32_t batch, int32_t D, int32_t lower, int32_t unit, void *stream);
+
 /* LDS bytes and grid the launcher will use for a program (introspection for tests/bench). */
 int sx_flow_launch_info(const sx_program *prog_host, int64_t n_rows, int32_t *grid, int32_t *block,
                         int32_t *lds_bytes);

@@ -44,7 +44,7 @@ ACT_CODES = {'Identity': 0, 'Tanh': 1, 'ReLU': 2, 'Sigmoid': 3, 'ELU': 4, 'Softp
 EXPORTS = ['sx_abi_version', 'sx_fragment_mode', 'sx_last_error', 'sx_permute', 'sx_affine_coupling', 'sx_rqs_coupling',
            'sx_cubic_coupling', 'sx_pointwise', 'sx_rqs_inverse_bwd', 'sx_affine_coupling_bwd', 'sx_time_affine_coupling', 'sx_cubic_inverse_bwd', 'sx_pointwise_bwd',
            'sx_unit_normal_logprob', 'sx_sum_f64', 'sx_packed_linear_floats', 'sx_pack_linear', 'sx_flow_run',
-           'sx_flow_launch_info', 'sx_wgrad', 'sx_wgrad_layer', 'sx_colsum']
+           'sx_flow_launch_info', 'sx_wgrad', 'sx_wgrad_layer', 'sx_colsum', 'sx_tri_inverse_f64']
 
 
 class HipLibraryMissing(RuntimeError):
@@ -111,6 +111,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.sx_wgrad_layer.argtypes = [vp, i64, i64, i32, i32, i32, i32, vp, i64, vp, vp, vp, i64, vp, vp, vp]
     lib.sx_colsum.restype = i32
     lib.sx_colsum.argtypes = [vp, i64, i64, i32, vp, vp]
+    lib.sx_tri_inverse_f64.restype = i32
+    lib.sx_tri_inverse_f64.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     lib.sx_flow_launch_info.restype = i32
     lib.sx_flow_launch_info.argtypes = [C.POINTER(sx_program), i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
 

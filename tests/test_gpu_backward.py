@@ -543,3 +543,26 @@ def test_colsum_matches_fp64(n, M, lda):
     Ad, out = A.to(DEV), base.to(DEV)
     _hip.check(_hip.lib().sx_colsum(Ad.data_ptr(), lda, n, M, out.data_ptr(), _hip.stream()), 'sx_colsum')
     assert (out.cpu().double() - want).abs().max().item() <= 2e-6 * max(1.0, float(n) ** 0.5) * 4
+
+
+@pytest.mark.parametrize('k,D', [(1, 1), (3, 7), (4, 128), (2, 65)])
+def test_tri_inverse_f64_and_its_backward(k, D):
+    """sx_tri_inverse_f64 (unit-lower and upper) against torch.linalg on the CPU in fp64, forward and gradient."""
+    from stribor_amd.flows.linear import TriInverse
+    g = torch.Generator(device='cpu').manual_seed(k * 1000 + D)
+    W = torch.randn(k, D, D, generator=g, dtype=torch.float64) * 0.3
+    eye = torch.eye(D, dtype=torch.float64)
+    for lower, unit in ((True, True), (False, False)):
+        def build(w):
+            e = eye.to(w.device)
+            return torch.tril(w, -1) + e if lower else torch.triu(w, 1) + e * (1.5 + torch.diagonal(w, dim1=-2, dim2=-1).tanh()).unsqueeze(-1)
+        wc = W.clone().requires_grad_(True)
+        Xc = torch.linalg.inv(build(wc))
+        G = torch.randn(k, D, D, generator=g, dtype=torch.float64)
+        (Xc * G).sum().backward()
+        wd = W.clone().to(DEV).requires_grad_(True)
+        Xd = TriInverse.apply(build(wd), lower, unit)
+        (Xd * G.to(DEV)).sum().backward()
+        scale = Xc.abs().max().item()
+        assert (Xd.detach().cpu() - Xc.detach()).abs().max().item() <= 1e-10 * scale
+        assert (wd.grad.cpu() - wc.grad).abs().max().item() <= 1e-9 * max(1.0, wc.grad.abs().max().item())
