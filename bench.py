@@ -5,6 +5,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (fresh child
+processes of `torch.distributed.run`, before this process has touched a GPU) and relays rank 0's JSON line.
+
 One "step" = one pass of the hot path over one synthetic batch per rank: log_prob of x[2^20, 64]
 (standard normal, stored bf16, resident in HBM) through 8 alternating affine couplings (H = 64) and the
 UnitNormal base density, summed to one fp64 on the device and, for N > 1, all-reduced over RCCL (the
@@ -12,28 +15,24 @@ path's only exchange).  Weak scaling: every rank owns 2^20 rows (cfg 5 = 8 x 2^2
 
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant (only) kernel of a step, the fused flow
 kernel: algorithmic flops (98,304 per row) against the dense MFMA peak of the dtype its GEMMs
-issue in (fp16, three split products per algorithmic product; or fp32 when the library is built EXACT_F32=1);
-`roofline_elementwise` is the standalone HBM-bound affine
-coupling kernel (north_star: "achieved HBM GB/s on the element-wise path"); `cpu_baseline` is the oracle
-(a torch-CPU port that follows the reference op for op, incl. its double conditioner call) timed on this
-box's host cores on a bounded sample.
+issue in (fp16, three split products per algorithmic product); `roofline_elementwise` is the standalone HBM-bound
+affine coupling kernel (north_star: "achieved HBM GB/s on the element-wise path"); `configs` (N = 1 only) carries the
+same measurement for BASELINE cfg 3 (8 rational-quadratic spline couplings) and cfg 4 (AffineLU + MatrixExponential +
+couplings, D = 128) at 2^20 rows, timed in this process after the headline; `cpu_baseline` is the oracle (a torch-CPU
+port that follows the reference op for op, incl. its double conditioner call) timed on this box's host cores on a
+bounded sample.  Fields ending in `_pmc` / `traffic` come from committed rocprofv3 --pmc passes (profiles/*.json) and
+carry the commit they were captured at.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
-
-import torch
-import torch.distributed as dist
-
-import flowdesc as fd
-import stribor_amd as st
-from stribor_amd.sharded import ShardedLogProb
 
 DIM, LAYERS, HIDDEN = 64, 8, 64
 ROWS_PER_GPU = 1 << 20
@@ -43,11 +42,30 @@ PEAK_F32_MFMA_TFLOPS = 157.3                                           # MI355X_
 PEAK_F16_MFMA_TFLOPS = 2500.0                                          # MI355X_MICROARCH.md, dense BF16/FP16 MFMA
 PEAK_HBM_GBS = 8000.0                                                  # MI355X_MICROARCH.md, HBM3E spec
 ELEMWISE_BYTES_PER_ROW = 128 + 256 + 128 + 8                           # 520 B/row/layer (bf16 x,y)
+# SURVEY 8(d) per-row figures of the other single-GPU configurations
+CFG3_FLOPS_PER_ROW, CFG3_BYTES_PER_ROW = 1572864, 260
+CFG4_FLOPS_PER_ROW, CFG4_FLOPS_PER_ROW_COLLAPSED, CFG4_BYTES_PER_ROW = 589824, 458752, 516
+
+
+def spawn_ranks(args) -> int:
+    """--gpus N > 1 without a launcher: run N fresh ranks under torch.distributed.run and relay their output.
+    Nothing in this process has initialised the GPU at this point (no exec of an initialised process either)."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__),
+           '--gpus', str(args.gpus), '--steps', str(args.steps), '--warmup', str(args.warmup)]
+    if args.no_cpu_baseline:
+        cmd.append('--no-cpu-baseline')
+    return subprocess.run(cmd, env=env).returncode
 
 
 def event_ms(fn, reps, inner=8):
     """Average device time of one launch of `fn` by HIP events on the current stream: `reps` groups of
     `inner` back-to-back launches, each group bracketed by two events (amortises the event overhead)."""
+    import torch
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     fn()
     for a, b in evs:
@@ -61,7 +79,9 @@ def event_ms(fn, reps, inner=8):
 
 
 def cpu_baseline(desc, state):
+    import torch
     from oracle import stribor_oracle as orc
+    from stribor_amd.util import flowdesc as fd
     spec = fd.flow_spec(desc, state)
     avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     gen = torch.Generator().manual_seed(1234)
@@ -94,13 +114,71 @@ def cpu_baseline(desc, state):
                       f'on {rows} rows x {DIM}, 1 pass, {dt:.2f} s'}
 
 
+def load_profile(name):
+    try:
+        return json.load(open(os.path.join(ROOT, 'profiles', name)))
+    except Exception:
+        return {}
+
+
+def time_extra_config(name, workload, flow, x, steps, warmup, flops_per_row, bytes_per_row, kernel, pmc, extra=None):
+    """One BASELINE configuration beside the headline: K steps of log_prob_sum over the resident batch, wall clock
+    around barrier-free synchronised K steps plus HIP events over the same region for the kernel's launch period."""
+    import torch
+    out = torch.zeros(1, dtype=torch.float64, device=x.device)
+
+    def step():
+        out.zero_()
+        flow.log_prob_sum(x, out)
+
+    step()
+    torch.cuda.synchronize()
+    for _ in range(max(warmup, 3)):
+        step()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert torch.isfinite(out).all(), name
+    k_ms = ev0.elapsed_time(ev1) / steps
+    rows = x.shape[0]
+    tflops = flops_per_row * rows / (k_ms * 1e-3) / 1e12
+    roof = {'kernel': kernel, 'bound': 'mfma', 'achieved': tflops, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': tflops / PEAK_F16_MFMA_TFLOPS, 'traffic': pmc.get('hbm_bytes_per_launch'),
+            'traffic_pmc_commit': pmc.get('commit'), 'avg_kernel_ms': k_ms,
+            'algorithmic_flops_per_launch': flops_per_row * rows, 'algorithmic_bytes_per_launch': bytes_per_row * rows,
+            'hbm_frac_of_same_kernel': bytes_per_row * rows / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            'mfma_executed_tflops': 3 * tflops, 'frac_mfma_pipe_busy': 3 * tflops / PEAK_F16_MFMA_TFLOPS}
+    if extra:
+        roof.update(extra(k_ms, rows))
+    return {'name': name, 'workload': workload, 'steps': steps, 'ms_per_step': elapsed / steps * 1e3,
+            'value': rows * steps / elapsed, 'unit': 'samples/s', 'dtype': 'f32', 'log_prob_sum': out.item(),
+            'roofline': roof}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra-configs', action='store_true', help='skip the cfg 3 / cfg 4 lines (N = 1)')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))
+
+    import torch
+    import torch.distributed as dist
+
+    import stribor_amd as st
+    from stribor_amd.sharded import ShardedLogProb
+    from stribor_amd.util import flowdesc as fd
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -110,7 +188,8 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     dev = torch.device('cuda', local_rank if world > 1 else 0)
-    assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    rccl_ranks = dist.get_world_size() if world > 1 else 1
 
     torch.manual_seed(0)                                               # same weights on every rank
     desc = fd.cfg2_desc(LAYERS, DIM, HIDDEN)
@@ -140,29 +219,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Untimed pre-run (first launch: weight packing, module load, counters; then a FIXED number of steps -- the same on
-    # every rank, each step carries a collective -- so that the device leaves its idle power state) before the W warm-up
-    # steps of the contract.
-    step()
-    torch.cuda.synchronize()
-    for _ in range(25):
-        for _ in range(20):
-            step()
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
+    with torch.no_grad():
+        # Untimed pre-run (first launch: weight packing, module load, counters; then a FIXED number of steps -- the same
+        # on every rank, each step carries a collective -- so that the device leaves its idle power state) before the W
+        # warm-up steps of the contract.
         step()
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()                      # HIP events on the launch stream, around exactly the K timed steps
-    for _ in range(args.steps):
-        last = step()
-    ev1.record()
-    for p in pending:                # every outstanding collective completes inside the timed region
-        if p is not None:
-            p.wait()
-    barrier()
-    elapsed = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        for _ in range(25):
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize()
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()                      # HIP events on the launch stream, around exactly the K timed steps
+        for _ in range(args.steps):
+            last = step()
+        ev1.record()
+        for p in pending:                # every outstanding collective completes inside the timed region
+            if p is not None:
+                p.wait()
+        barrier()
+        elapsed = time.perf_counter() - t0
     total = last.wait()
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -174,35 +254,28 @@ def main():
     result = None
     if rank == 0:
         rows_total = ROWS_PER_GPU * world * args.steps
-        # dominant kernel: the fused flow kernel, one launch per step, timed alone by HIP events
-        # average launch period of the fused kernel over the timed region itself (HIP events ev0 / ev1; each step also
-        # launches a 4.6 us zero-fill of the 8-byte result); the median of grouped launches afterwards is kept beside it
+        # dominant kernel: the fused flow kernel, one launch per step; average launch period over the timed region itself
+        # (HIP events ev0 / ev1; each step also launches a 4.6 us zero-fill of the 8-byte result); the median of grouped
+        # launches afterwards is kept beside it
         k_avg_ms = ev0.elapsed_time(ev1) / args.steps
-        _, k_med_ms = event_ms(lambda: flow.log_prob_sum(x, outs[0]), 10)
+        with torch.no_grad():
+            _, k_med_ms = event_ms(lambda: flow.log_prob_sum(x, outs[0]), 10)
         achieved_tflops = FLOPS_PER_ROW * ROWS_PER_GPU / (k_avg_ms * 1e-3) / 1e12
-        from stribor_amd import _hip
-        f16x3 = _hip.lib().sx_fragment_mode() == 1
-        peak = PEAK_F16_MFMA_TFLOPS if f16x3 else PEAK_F32_MFMA_TFLOPS
-        pmc = {}
-        try:      # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_cfg2.json')))
-        except Exception:
-            pass
-        sq = {}
-        try:      # SQ utilisation of the fused kernel from the committed --pmc passes (tools/profile_bench.sh)
-            sq = json.load(open(os.path.join(ROOT, 'profiles', 'sq_cfg2.json')))
-        except Exception:
-            pass
+        peak = PEAK_F16_MFMA_TFLOPS
+        pmc = load_profile('pmc_cfg2.json')
+        sq = load_profile('sq_cfg2.json')
         # standalone element-wise affine coupling kernel (params precomputed in HBM), HBM roofline
         from stribor_amd.flows.affine import run_affine_kernel
         params = torch.randn(ROWS_PER_GPU, DIM, device=dev) * 0.1
         e_avg_ms, _ = event_ms(lambda: run_affine_kernel(x, params, DIM, None, 0, DIM // 2, True, True, True, -1.0), 10)
+        del params
         e_gbs = ELEMWISE_BYTES_PER_ROW * ROWS_PER_GPU / (e_avg_ms * 1e-3) / 1e9
         result = {
             'metric': 'log_prob samples/sec, D=64 8-layer affine-coupling',
             'value': rows_total / elapsed,
             'unit': 'samples/s',
             'n_gpus': world,
+            'rccl_ranks': rccl_ranks,
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3,
@@ -218,28 +291,60 @@ def main():
             'roofline': {'kernel': 'flow_fused_kernel<NS=1,TX=2,HT=2,MODE=5> (pure split-coupling program, 8-wave workgroups)', 'bound': 'mfma',
                          'achieved': achieved_tflops, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved_tflops / peak,
                          'traffic': pmc.get('flow_fused_kernel', {}).get('hbm_bytes_per_launch'),
+                         'traffic_pmc_commit': pmc.get('commit', '5b99493 (round 1, r01_h build)'),
                          'avg_kernel_ms': k_avg_ms, 'median_kernel_ms': k_med_ms,
-                         'gemm_arithmetic': ('fp16 x 3 split on v_mfma_f32_32x32x16_f16, fp32 accumulate '
-                                             '(3 MFMA products per algorithmic product)') if f16x3
-                                            else 'v_mfma_f32_32x32x2_f32 (exact fp32)',
-                         'mfma_executed_tflops': achieved_tflops * (3 if f16x3 else 1),
-                         'frac_mfma_pipe_busy': achieved_tflops * (3 if f16x3 else 1) / peak,
+                         'gemm_arithmetic': 'fp16 x 3 split on v_mfma_f32_32x32x16_f16, fp32 accumulate '
+                                            '(3 MFMA products per algorithmic product)',
+                         'mfma_executed_tflops': achieved_tflops * 3,
+                         'frac_mfma_pipe_busy': achieved_tflops * 3 / peak,
                          'frac_of_exact_fp32_mfma_peak': achieved_tflops / PEAK_F32_MFMA_TFLOPS,
                          'binding_resource': 'VALU issue (tanh/exp transcendentals + fp16 operand splitting); '
                                              'neither HBM (3 % of peak) nor the matrix pipe binds',
                          'valu_issue_busy_frac_pmc': sq.get('valu_issue_busy_frac'),
                          'mfma_pipe_busy_frac_pmc': sq.get('mfma_pipe_busy_frac'),
                          'effective_clock_ghz_pmc': sq.get('effective_clock_ghz'),
+                         'sq_pmc_commit': sq.get('commit', '5b99493 (round 1, r01_h build)'),
                          'algorithmic_flops_per_launch': FLOPS_PER_ROW * ROWS_PER_GPU,
                          'algorithmic_bytes_per_launch': BYTES_PER_ROW * ROWS_PER_GPU,
                          'hbm_frac_of_same_kernel': BYTES_PER_ROW * ROWS_PER_GPU / (k_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
             'roofline_elementwise': {'kernel': 'affine_coupling_vec4_kernel<bf16,reverse>', 'bound': 'hbm',
                                      'achieved': e_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': e_gbs / PEAK_HBM_GBS,
                                      'traffic': pmc.get('affine_coupling_vec4_kernel', {}).get('hbm_bytes_per_launch'),
+                                     'traffic_pmc_commit': pmc.get('commit', '5b99493 (round 1, r01_h build)'),
                                      'avg_kernel_ms': e_avg_ms,
                                      'algorithmic_bytes_per_launch': ELEMWISE_BYTES_PER_ROW * ROWS_PER_GPU},
             'log_prob_sum': total_value,
         }
+        if world == 1 and not args.no_extra_configs:
+            # BASELINE cfg 3 / cfg 4 at their full 2^20 rows, fp32 storage, same process, after the headline
+            del x
+            extra_steps = max(5, min(args.steps, 20))
+            cfgs = []
+            with torch.no_grad():
+                torch.manual_seed(0)
+                f3 = fd.build_flow(st, fd.cfg3_desc(), 64).to(dev)
+                x3 = torch.randn(ROWS_PER_GPU, 64, device=dev, generator=gen)
+                cfgs.append(time_extra_config(
+                    'cfg3', 'cfg3: D=64, 8 rational-quadratic st.Spline couplings, K=16 bins on [-3, 3] (MLP hidden 64), '
+                    'batch 2^20, fp32', f3, x3, extra_steps, args.warmup, CFG3_FLOPS_PER_ROW, CFG3_BYTES_PER_ROW,
+                    'flow_fused_kernel<NS=1,TX=2,HT=2,MODE=3> (spline phases: parameters only in registers)',
+                    load_profile('pmc_cfg3.json')))
+                del f3, x3
+                torch.manual_seed(0)
+                f4 = fd.build_flow(st, fd.cfg4_desc(), 128).to(dev)
+                x4 = torch.randn(ROWS_PER_GPU, 128, device=dev, generator=gen)
+                cfgs.append(time_extra_config(
+                    'cfg4', 'cfg4: D=128, 4 x [st.AffineLU, affine coupling, st.MatrixExponential (t=1), affine coupling] '
+                    '(MLP hidden 64), batch 2^20, fp32', f4, x4, extra_steps, args.warmup, CFG4_FLOPS_PER_ROW,
+                    CFG4_BYTES_PER_ROW, 'flow_fused_kernel<NS=1,TX=4,HT=2,MODE=7> (dense linear layers + split couplings)',
+                    load_profile('pmc_cfg4.json'),
+                    extra=lambda k_ms, rows: {'frac_collapsed': CFG4_FLOPS_PER_ROW_COLLAPSED * rows / (k_ms * 1e-3) / 1e12
+                                              / PEAK_F16_MFMA_TFLOPS,
+                                              'note': 'achieved counts the reference\'s two triangular products per '
+                                                      'MatrixExponential (SURVEY 8(d): 589,824 flop/row); the kernel '
+                                                      'runs the collapsed single matrix (458,752): frac_collapsed'}))
+                del f4, x4
+            result['configs'] = cfgs
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(desc, state)
     if world > 1:

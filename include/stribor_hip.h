@@ -221,8 +221,10 @@ int sx_pack_linear(const float *W, const float *b, int32_t out_dim, int32_t in_d
                                            blob = pack_linear(W1: h_tiles x ct) ++ pack_linear(W2: per transformed tile 32 log_scale
                                            rows then 32 shift rows, x h_tiles); act = SX_ACT_* or SX_ACT_TANH_FOLDED          */
 #define SX_STEP_AFFINE_CONST         2  /* st.Affine without latent_net: blob = ls[tiles][2][16] ++ sh[tiles][2][16] (C-fragment) */
-#define SX_STEP_LINEAR_TILE          3  /* blob = pack_linear(M, x_tiles m-tiles x tiles): state = M . state + bias, the whole layer
-                                           in one step (act = x_tiles, t0 = 0; AffineLU, MatrixExponential)                       */
+#define SX_STEP_LINEAR_TILE          3  /* blob = pack_linear(M, x_tiles m-tiles x tiles) ++ {log|det M| term, 1 float}: state = M . state
+                                           + bias, ldj += blob's log-det term (already signed / scaled; it lives in the blob so
+                                           that it is refreshed together with M), the whole layer in one step (act = x_tiles,
+                                           t0 = 0; AffineLU affine.py:157-171, MatrixExponential affine.py:243-288)               */
 #define SX_STEP_MLP_HIDDEN           5  /* blob = pack_linear(W, h_tiles x tiles): hidden = act(W . state + b)  (mlp.py:65)       */
 #define SX_STEP_MLP_HIDDEN2          6  /* blob = pack_linear(W, h_tiles x h_tiles): hidden' = act(W . hidden + b)                 */
 #define SX_STEP_MLP_OUT_TILE         7  /* blob = pack_linear(W, 1 x h_tiles): mlp_out[:, 32*t0 ..] = W[t0] . hidden + b            */

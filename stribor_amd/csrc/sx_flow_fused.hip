@@ -47,7 +47,7 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
             case SX_STEP_LINEAR_TILE:
                 SX_REQUIRE(s.t0 == 0 && s.act == p->x_tiles,
                            "sx_flow_run: step %d: a linear step covers all %d output slabs (act = x_tiles, t0 = 0)", i, p->x_tiles);
-                need = sx_packed_linear_floats(p->x_tiles, p->tiles); lin = true; break;
+                need = sx_packed_linear_floats(p->x_tiles, p->tiles) + 1; lin = true; break;      // + the layer's log-det
             case SX_STEP_ROW_SCALE_EXP: need = 32 * p->tiles; lin = true; break;
             case SX_STEP_CPL_HIDDEN: need = sx_packed_linear_floats(p->h_tiles, s.ct); deep = true; break;
             case SX_STEP_CPL_HIDDEN2: need = sx_packed_linear_floats(p->h_tiles, p->h_tiles); deep = true; break;

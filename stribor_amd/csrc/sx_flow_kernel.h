@@ -1197,6 +1197,9 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                                 xs[m] = acc;
                             }
                         }
+                        // the layer's (parameter-only) log-det rides in the blob behind the bias, so a parameter update
+                        // refreshes it with the matrix (affine.py:171, 287-288)
+                        ldj_c += smem[cur * buf_floats + x_tiles * TX * 1024 + x_tiles * 32];
                     }
                     break;
                 case SX_STEP_COUPLING_AFFINE_BWD:

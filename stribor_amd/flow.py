@@ -16,7 +16,7 @@ import torch.nn as nn
 HALF_LOG_2PI = 0.9189385332046727          # log(sqrt(2 pi)), dist/normal.py:37
 
 from . import _hip
-from .fused import CompiledProgram, ProgramBuilder
+from .fused import CompiledProgram, ProgramBuilder, ProgramCache, StructureTracked
 
 __all__ = ['Transform', 'ElementwiseTransform', 'NormalizingFlow']
 
@@ -109,9 +109,11 @@ def flatten_rows(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Size]:
     return (x2 if x2.is_contiguous() else x2.contiguous()), lead
 
 
-class Transform(nn.Module, metaclass=ABCMeta):
+class Transform(StructureTracked, nn.Module, metaclass=ABCMeta):
     """flow.py:8-47.  Subclasses may additionally implement the planner hooks
-    ``_plan_hidden_width()`` and ``_plan(builder, reverse, ldj_scale)`` to join fused programs."""
+    ``_plan_hidden_width()`` and ``_plan(builder, reverse, ldj_scale)`` to join fused programs.
+    (``StructureTracked``: re-assigning a sub-module, parameter, buffer or public attribute invalidates every cached
+    program, see ``fused.ProgramCache``.)"""
 
     @abstractmethod
     def forward(self, x, **kwargs):
@@ -146,6 +148,10 @@ class Transform(nn.Module, metaclass=ABCMeta):
     def _plan(self, builder: ProgramBuilder, reverse: bool, ldj_scale: float) -> bool:
         return False
 
+    def _plan_guards(self) -> list:
+        """Buffers whose VALUES `_plan` bakes into host tables (a changed (data_ptr, _version) re-plans)."""
+        return []
+
 
 class ElementwiseTransform(Transform):
     """flow.py:50-69."""
@@ -170,14 +176,24 @@ class NormalizingFlow(Transform):
         super().__init__()
         self.base_dist = base_dist
         self.transforms = nn.ModuleList(transforms)
-        self._fused = {}
+        self._fused = ProgramCache()
 
     # ---- fused program cache -----------------------------------------------------------------------------
+    # Programs bake the transform list, every Permute's index vector and the masks into host tables; the cache entry
+    # is therefore tied to the ids of the transforms (ModuleList edits), the permutation buffers' (data_ptr, _version)
+    # (load_state_dict after a first call, permute.py:62-82) and the package-wide structure epoch.
+    def _fingerprint(self):
+        return tuple(map(id, self.transforms))
+
+    def _plan_guards(self) -> list:
+        return [g for f in self.transforms for g in f._plan_guards()]
+
+    def _cached(self, key, build):
+        return self._fused.get(key, build, self._plan_guards, self._fingerprint())
+
     def _fused_program(self, reverse: bool, dim: int, latent_dim: int, device, t_kind=None) -> Optional[CompiledProgram]:
         key = (reverse, dim, latent_dim, str(device), t_kind)
-        if key not in self._fused:
-            self._fused[key] = self._build_fused(reverse, dim, latent_dim, device, t_kind)
-        return self._fused[key]
+        return self._cached(key, lambda: self._build_fused(reverse, dim, latent_dim, device, t_kind))
 
     def _build_fused(self, reverse, dim, latent_dim, device, t_kind=None) -> Optional[CompiledProgram]:
         order = list(reversed(self.transforms)) if reverse else list(self.transforms)
@@ -205,57 +221,57 @@ class NormalizingFlow(Transform):
 
     def _backward_program(self, dim: int, device):
         """The backward program of log_prob (layers in forward order) + the slot maps for the weight gradients."""
-        key = ('bwd', dim, str(device))
-        if self._fused.get(key) == 'unsupported':
+        got = self._cached(('bwd', dim, str(device)), lambda: self._build_backward_program(dim, device))
+        if got == 'unsupported':
             raise NotImplementedError('training backward unsupported for this flow')
-        if key not in self._fused:
-          try:
-              from .flows.coupling import Coupling
-              from .flows.affine import Affine
-              order = list(self.transforms)
-              hw = max([f._plan_hidden_width() for f in order] + [1])
-              b = ProgramBuilder(dim, 0, hw)
-              # the backward pass starts in the slot layout the forward (log_prob) program ends in; affine-coupling
-              # flows never move columns, so that is the layout chosen from the first mask the forward pass sees
-              from .flows.permute import _ColumnShuffle
-              rev = list(reversed(order))
-              for f in rev:
-                  m = f._plan_first_mask(dim)
-                  if m is not None:
-                      b.choose_layout(m)
-                      break
-              # Permute / Flip only relabel slots: replay the forward program's relabelling to find the layout it
-              # ends in (= the layout z is read back in), then undo it layer by layer on the way back
-              for f in rev:
-                  if isinstance(f, _ColumnShuffle):
-                      b.add_permutation(f._perm(dim).cpu().numpy(), True)
-              b.in_col = None                      # the backward program's input layout is the forward's final one
-              b.steps = []
-              b.enable_adjoint_tiles()
-              layers = []
-              for f in order:
-                  if isinstance(f, _ColumnShuffle):
-                      b.add_permutation(f._perm(dim).cpu().numpy(), False)
-                      continue
-                  if not (isinstance(f, Coupling) and isinstance(f.transform, Affine)):
-                      raise NotImplementedError('training backward is implemented for flows of Coupling(Affine) layers '
-                                                'and Permute / Flip')
-                  net = f._net()
-                  lin = net.linears()
-                  if len(lin) != 2 or net.activation_name != 'Tanh':
-                      raise NotImplementedError('training backward needs Linear-Tanh-Linear conditioners')
-                  (W1, b1), (W2, b2) = lin
-                  info = b.add_coupling_affine_bwd(W1, b1, W2, b2, f.mask_vector(dim), W1.shape[0], len(layers))
-                  import numpy as np
-                  # slot order -> parameter order for sx_wgrad (negative = padding slot)
-                  info['row_map'] = torch.from_numpy(np.ascontiguousarray(info['out_rows'], dtype=np.int32)).to(device)
-                  info['col_map'] = torch.from_numpy(np.ascontiguousarray(info['cond_cols'], dtype=np.int32)).to(device)
-                  layers.append((f, info))
-              self._fused[key] = (b.build(device), layers)
-          except NotImplementedError:
-            self._fused[key] = 'unsupported'
-            raise
-        return self._fused[key]
+        return got
+
+    def _build_backward_program(self, dim: int, device):
+        try:
+            import numpy as np
+            from .flows.coupling import Coupling
+            from .flows.affine import Affine
+            from .flows.permute import _ColumnShuffle
+            order = list(self.transforms)
+            hw = max([f._plan_hidden_width() for f in order] + [1])
+            b = ProgramBuilder(dim, 0, hw)
+            # the backward pass starts in the slot layout the forward (log_prob) program ends in; affine-coupling
+            # flows never move columns, so that is the layout chosen from the first mask the forward pass sees
+            rev = list(reversed(order))
+            for f in rev:
+                m = f._plan_first_mask(dim)
+                if m is not None:
+                    b.choose_layout(m)
+                    break
+            # Permute / Flip only relabel slots: replay the forward program's relabelling to find the layout it
+            # ends in (= the layout z is read back in), then undo it layer by layer on the way back
+            for f in rev:
+                if isinstance(f, _ColumnShuffle):
+                    b.add_permutation(f._perm(dim).cpu().numpy(), True)
+            b.in_col = None                      # the backward program's input layout is the forward's final one
+            b.steps = []
+            b.enable_adjoint_tiles()
+            layers = []
+            for f in order:
+                if isinstance(f, _ColumnShuffle):
+                    b.add_permutation(f._perm(dim).cpu().numpy(), False)
+                    continue
+                if not (isinstance(f, Coupling) and isinstance(f.transform, Affine)):
+                    raise NotImplementedError('training backward is implemented for flows of Coupling(Affine) layers '
+                                              'and Permute / Flip')
+                net = f._net()
+                lin = net.linears()
+                if len(lin) != 2 or net.activation_name != 'Tanh':
+                    raise NotImplementedError('training backward needs Linear-Tanh-Linear conditioners')
+                (W1, b1), (W2, b2) = lin
+                info = b.add_coupling_affine_bwd(W1, b1, W2, b2, f.mask_vector(dim), W1.shape[0], len(layers))
+                # slot order -> parameter order for sx_wgrad (negative = padding slot)
+                info['row_map'] = torch.from_numpy(np.ascontiguousarray(info['out_rows'], dtype=np.int32)).to(device)
+                info['col_map'] = torch.from_numpy(np.ascontiguousarray(info['cond_cols'], dtype=np.int32)).to(device)
+                layers.append((f, info))
+            return (b.build(device), layers)
+        except NotImplementedError:
+            return 'unsupported'
 
     def _can_backward(self, y) -> bool:
         try:
@@ -285,13 +301,12 @@ class NormalizingFlow(Transform):
         cur, total = y2, None
         for f in reversed(self.transforms):
             if isinstance(f, _ColumnShuffle):
-                key = ('inv_perm', cur.shape[1], str(cur.device))
-                inv = self._fused.get(key + (id(f),))
-                if inv is None:
-                    perm = f._perm(cur.shape[1]).to(cur.device).long()
+                def build_inv(f=f, d=cur.shape[1], dev=cur.device):
+                    perm = f._perm(d).to(dev).long()
                     inv = torch.empty_like(perm)
                     inv[perm] = torch.arange(perm.numel(), device=perm.device)
-                    self._fused[key + (id(f),)] = inv
+                    return inv
+                inv = self._cached(('inv_perm', cur.shape[1], str(cur.device), id(f)), build_inv)
                 cur = cur.index_select(1, inv)                                # permute.py:75 (inverse direction)
                 continue
             cur, ldj = f._autograd_inverse(cur, lat2, dense[id(f)]) if id(f) in dense else f._autograd_inverse(cur, lat2)

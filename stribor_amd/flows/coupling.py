@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from .. import _hip
 from ..flow import Transform, flatten_rows
-from ..fused import ProgramBuilder
+from ..fused import ProgramBuilder, ProgramCache, _STRUCT_EPOCH
 from ..net.mlp import MLP, _chunk_mlp_program
 from ..util.mask import get_mask
 from .affine import Affine
@@ -36,10 +36,13 @@ class Coupling(Transform):
         self.mask_func = get_mask(mask)                       # raises NotImplementedError like mask.py:20
         self.set_data = False
         self._masks = {}
-        self._programs = {}
+        self._masks_epoch = -1
+        self._programs = ProgramCache()
 
     # ---- mask: built once per width (the reference rebuilds it from numpy every call, quirk Q4) --------
     def mask_vector(self, dim: int) -> np.ndarray:
+        if self._masks_epoch != _STRUCT_EPOCH[0]:          # mask_func / mask_name may have been re-assigned
+            self._masks, self._masks_epoch = {}, _STRUCT_EPOCH[0]
         if dim not in self._masks:
             m = self.mask_func(dim).numpy().astype(np.float64).reshape(-1)
             self._masks[dim] = np.full(dim, m[0]) if m.size == 1 else m
@@ -57,12 +60,17 @@ class Coupling(Transform):
     # ---- affine: one fused single-step program per (direction, width, latent width, device) -----------
     def _affine_program(self, reverse: bool, ldj_scale: float, dim: int, latent_dim: int, device):
         key = ('affine', reverse, ldj_scale, dim, latent_dim, str(device))
-        if key not in self._programs:
-            b = ProgramBuilder(dim, latent_dim, self._net().hidden_width)
-            if not self._plan(b, reverse, ldj_scale):
-                raise NotImplementedError('this coupling cannot run on the fused kernel')
-            self._programs[key] = b.build(device)
-        return self._programs[key]
+
+        def build():
+            try:
+                b = ProgramBuilder(dim, latent_dim, self._net().hidden_width)
+                return b.build(device) if self._plan(b, reverse, ldj_scale) else None
+            except NotImplementedError:
+                return None
+        prog = self._programs.get(key, build)
+        if prog is None:
+            raise NotImplementedError('this coupling cannot run on the fused kernel')
+        return prog
 
     def _run(self, x, latent, reverse, want_y, want_ldj, ldj_scale=1.0):
         _hip.require_device(x, 'x')
@@ -89,7 +97,8 @@ class Coupling(Transform):
     # ---- affine, unfused: pruned conditioner (MFMA program) + HBM-bound element-wise kernel -----------------
     def _affine_unfused_program(self, dim: int, latent_dim: int, device):
         key = ('affine-unfused', dim, latent_dim, str(device))
-        if key not in self._programs:
+
+        def build():
             net = self._net()
             m = self.mask_vector(dim)
             live = np.nonzero(m <= 0.5)[0]
@@ -101,9 +110,8 @@ class Coupling(Transform):
             b.add_mlp(net.linears(), net.act_code, cond, out_rows)
             contiguous = len(live) > 0 and np.array_equal(live, np.arange(live[0], live[0] + len(live)))
             live_idx = None if contiguous else torch.from_numpy(live.astype(np.int32)).to(device)
-            self._programs[key] = (_chunk_mlp_program(b, device), live_idx, int(live[0]) if len(live) else 0,
-                                   len(live))
-        return self._programs[key]
+            return (_chunk_mlp_program(b, device), live_idx, int(live[0]) if len(live) else 0, len(live))
+        return self._programs.get(key, build)
 
     def _run_affine_unfused(self, x2, lat2, reverse, want_ldj, ldj_scale):
         from .affine import run_affine_kernel
@@ -121,7 +129,8 @@ class Coupling(Transform):
     # ---- spline: pruned conditioner (MFMA) + LDS-staged spline kernel --------------------------------------
     def _spline_program(self, dim: int, latent_dim: int, device):
         key = ('spline', dim, latent_dim, str(device))
-        if key not in self._programs:
+
+        def build():
             net, sp = self._net(), self.transform
             m = self.mask_vector(dim)
             live = np.nonzero(m <= 0.5)[0]
@@ -134,9 +143,8 @@ class Coupling(Transform):
             b.add_mlp(net.linears(), net.act_code, cond, out_rows)
             contiguous = len(live) > 0 and np.array_equal(live, np.arange(live[0], live[0] + len(live)))
             live_idx = None if contiguous else torch.from_numpy(live.astype(np.int32)).to(device)
-            self._programs[key] = (_chunk_mlp_program(b, device), live_idx, int(live[0]) if len(live) else 0,
-                                   len(live), len(out_rows))
-        return self._programs[key]
+            return (_chunk_mlp_program(b, device), live_idx, int(live[0]) if len(live) else 0, len(live), len(out_rows))
+        return self._programs.get(key, build)
 
     def _run_spline(self, x2, lat2, reverse, want_ldj, ldj_scale):
         from .spline import run_rqs_kernel
@@ -183,17 +191,18 @@ class Coupling(Transform):
         if len(live) == 0:
             return x2, torch.zeros(n, dtype=torch.float32, device=x2.device)
         key = ('autograd', d, str(x2.device))
-        if key not in self._programs:
+
+        def build():
             if is_spline:
                 P = sp.params_per_element
                 rows = (live[:, None] * P + np.arange(P)[None, :]).reshape(-1)      # spline.py:82-86
             else:
                 rows = np.concatenate([live, d + live])                               # affine.py:66 (log_scale | shift)
             contiguous = np.array_equal(live, np.arange(live[0], live[0] + len(live)))
-            self._programs[key] = (torch.from_numpy(m.astype(np.float32)).to(x2.device),
-                                   torch.from_numpy(rows.astype(np.int64)).to(x2.device),
-                                   None if contiguous else torch.from_numpy(live.astype(np.int32)).to(x2.device))
-        mask_t, rows_t, live_idx = self._programs[key]
+            return (torch.from_numpy(m.astype(np.float32)).to(x2.device),
+                    torch.from_numpy(rows.astype(np.int64)).to(x2.device),
+                    None if contiguous else torch.from_numpy(live.astype(np.int32)).to(x2.device))
+        mask_t, rows_t, live_idx = self._programs.get(key, build)
         z = x2 * mask_t                                                              # coupling.py:61
         if d == 1:
             z = z * 0                                                                # coupling.py:62-63
@@ -293,9 +302,12 @@ class ContinuousAffineCoupling(Transform):
         self.mask_func = get_mask(mask)
         self.concatenate_time = concatenate_time
         self._masks = {}
-        self._programs = {}
+        self._masks_epoch = -1
+        self._programs = ProgramCache()
 
     def mask_vector(self, dim: int) -> np.ndarray:
+        if self._masks_epoch != _STRUCT_EPOCH[0]:
+            self._masks, self._masks_epoch = {}, _STRUCT_EPOCH[0]
         if dim not in self._masks:
             m = self.mask_func(dim).numpy().astype(np.float64).reshape(-1)
             self._masks[dim] = np.full(dim, m[0]) if m.size == 1 else m
@@ -303,7 +315,8 @@ class ContinuousAffineCoupling(Transform):
 
     def _program(self, dim: int, extra: int, device):
         key = (dim, extra, str(device))
-        if key not in self._programs:
+
+        def build():
             net = self.latent_net
             m = self.mask_vector(dim)
             live = np.nonzero(m <= 0.5)[0]
@@ -314,8 +327,8 @@ class ContinuousAffineCoupling(Transform):
             b.add_mlp(net.linears(), net.act_code, cond, np.concatenate([live, dim + live]))   # chunk(2): (ls | sh)
             contiguous = len(live) > 0 and np.array_equal(live, np.arange(live[0], live[0] + len(live)))
             live_idx = None if contiguous else torch.from_numpy(live.astype(np.int32)).to(device)
-            self._programs[key] = (_chunk_mlp_program(b, device), live_idx, int(live[0]) if len(live) else 0, live)
-        return self._programs[key]
+            return (_chunk_mlp_program(b, device), live_idx, int(live[0]) if len(live) else 0, live)
+        return self._programs.get(key, build)
 
     def _time_scales(self, dim: int, live: np.ndarray, device):
         """Per live column: the time net's scale for its log_scale and for its shift (chunk(2) of the embedding,

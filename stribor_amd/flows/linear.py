@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from .. import _hip
 from ..flow import Transform, flatten_rows
-from ..fused import ProgramBuilder
+from ..fused import ProgramBuilder, ProgramCache
 from ..net.mlp import batch_linear
 
 __all__ = ['AffineLU', 'MatrixExponential']
@@ -31,11 +31,10 @@ class _DenseLinear(Transform):
     """Shared launcher: single-transform fused programs keyed by (direction, ldj sign, t kind, device)."""
 
     def _program(self, key, build):
-        if not hasattr(self, '_programs'):
-            self._programs = {}
-        if key not in self._programs:
-            self._programs[key] = build()
-        return self._programs[key]
+        cache = self.__dict__.get('_programs')
+        if cache is None:
+            cache = self._programs = ProgramCache()
+        return cache.get(key, build)
 
     def _run(self, x, reverse, want_y, want_ldj, ldj_scale, t=None):
         _hip.require_device(x, 'x')
@@ -178,8 +177,8 @@ class AffineLU(_DenseLinear):
         return batch_linear(x2, Wm, bm), ldj.expand(x2.shape[0])                                           # :159-163, :171
 
     def _plan(self, builder, reverse, ldj_scale):
-        ld = float(self.log_diag.detach().double().sum().item())          # affine.py:171
-        builder.add_linear([self.weight, self.log_diag, self.bias], self._matrices(reverse), ldj_scale * ld)
+        ldj = lambda dev: ldj_scale * self.log_diag.detach().to(dev, torch.float64).sum()       # affine.py:171
+        builder.add_linear([self.weight, self.log_diag, self.bias], self._matrices(reverse), ldj)
         return True
 
     def forward(self, x, **kwargs):
@@ -258,9 +257,9 @@ class MatrixExponential(_DenseLinear):
             def mult(dev):
                 b = self.bias.detach().to(dev, torch.float64) if (not reverse and has_bias) else None
                 return self._lu64(dev), b
-            builder.add_linear(self._sources(), solve, 0.0)
+            builder.add_linear(self._sources(), solve)
             builder.add_row_scale_exp(self.diag, reverse, ldj_scale, self.log_time, 0.0)
-            builder.add_linear(self._sources(), mult, 0.0)
+            builder.add_linear(self._sources(), mult)
             return True
         te = self._t_eff(float(t))
         sg = -te if reverse else te
@@ -272,8 +271,8 @@ class MatrixExponential(_DenseLinear):
                 return M, None
             b = self.bias.detach().to(dev, torch.float64)
             return (M, b) if not reverse else (M, -(M @ b))
-        ld = float(self.diag.detach().double().sum().item()) * te            # affine.py:287-288
-        builder.add_linear(self._sources(), collapsed, ldj_scale * ld)
+        ldj = lambda dev: (ldj_scale * te) * self.diag.detach().to(dev, torch.float64).sum()    # affine.py:287-288
+        builder.add_linear(self._sources(), collapsed, ldj)
         return True
 
     def forward(self, x, t=1.0, *, reverse: bool = False, **kwargs):

@@ -92,3 +92,6 @@ class Permute(_ColumnShuffle):
     def _perm(self, dim):
         assert dim == self.dim
         return self.permutation
+
+    def _plan_guards(self):
+        return [self.permutation]          # baked into the fused programs' slot relabelling at plan time

@@ -28,6 +28,63 @@ from . import _hip
 ALLOWED_TILES = (1, 2, 4)
 
 
+# ---- validity of cached programs -------------------------------------------------------------------------------
+# A built program bakes plan-time facts into host tables: which transforms a flow holds and in which order, every
+# Permute's index vector (slot relabelling), masks, which Parameter objects feed which pack job.  Parameter VALUES are
+# tracked per job ((data_ptr, _version) -> re-pack); everything else is covered by
+#   * a process-wide structure epoch, bumped whenever a module / parameter / buffer / public attribute of one of this
+#     package's modules is (re)assigned or deleted (`StructureTracked.__setattr__`), and
+#   * guard tensors (buffers read at plan time, e.g. Permute.permutation): (data_ptr, _version) snapshots, so an
+#     in-place `load_state_dict` or a `.to()` re-plans, and
+#   * an owner-supplied fingerprint (NormalizingFlow: the ids of its transforms, which ModuleList can change without
+#     passing through any __setattr__ of ours).
+_STRUCT_EPOCH = [0]
+
+
+def bump_structure_epoch() -> None:
+    _STRUCT_EPOCH[0] += 1
+
+
+class StructureTracked:
+    """Mixin for nn.Module subclasses whose attributes are read at plan time."""
+
+    _UNTRACKED = ('training',)
+
+    def __setattr__(self, name, value):
+        if not name.startswith('_') and name not in StructureTracked._UNTRACKED:
+            _STRUCT_EPOCH[0] += 1
+        super().__setattr__(name, value)
+
+    def __delattr__(self, name):
+        _STRUCT_EPOCH[0] += 1
+        super().__delattr__(name)
+
+
+def _snap(guards):
+    return [(g.data_ptr(), g._version) for g in guards]
+
+
+class ProgramCache:
+    """key -> built value, rebuilt when the structure epoch, the owner's fingerprint or a guard tensor changed."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, key, build, guards=(), fingerprint=None):
+        ent = self._d.get(key)
+        if ent is not None:
+            epoch, fp, gs, snap, value = ent
+            if epoch == _STRUCT_EPOCH[0] and fp == fingerprint and (not gs or _snap(gs) == snap):
+                return value
+        gs = list(guards() if callable(guards) else guards)
+        value = build()
+        self._d[key] = (_STRUCT_EPOCH[0], fingerprint, gs, _snap(gs), value)
+        return value
+
+    def clear(self):
+        self._d.clear()
+
+
 def _ceil_div(a: int, b: int) -> int:
     return -(-a // b)
 
@@ -86,10 +143,13 @@ class _PackJob:
 class _DerivedLinearJob:
     """A dense layer whose matrix is DERIVED from parameters (AffineLU: (L U)^T or its inverse;
     MatrixExponential: L U e^{diag t} U^-1 L^-1): `fn()` -> (W [out, in] fp32, b [out] fp32 | None) on the
-    device, recomputed (in fp64 inside fn) only when a source parameter changes, then packed slab by slab."""
+    device, recomputed (in fp64 inside fn) only when a source parameter changes, then packed slab by slab.
+    `ldj_fn(device)` -> the layer's (signed, scaled) log-det as a 0-dim device tensor, written behind the bias of the
+    blob by a device-side copy (no host read-back), so it can never go stale against the matrix."""
 
-    def __init__(self, sources, fn, targets):
+    def __init__(self, sources, fn, targets, ldj_fn=None, ldj_off: int = 0):
         self.sources, self.fn, self.targets = list(sources), fn, targets   # targets: [(row_idx, col_idx, k_tiles, off, m_tiles)]
+        self.ldj_fn, self.ldj_off = ldj_fn, ldj_off
         self._dev_idx = None
         self._keep = None
 
@@ -107,6 +167,8 @@ class _DerivedLinearJob:
                                            ci.data_ptr(), m_tiles, k_tiles, None, None, 0.0, 0,
                                            blobs.data_ptr() + 4 * off, _hip.stream())
             _hip.check(rc, 'sx_pack_linear')
+        if self.ldj_fn is not None:
+            blobs[self.ldj_off:self.ldj_off + 1] = self.ldj_fn(dev).reshape(1).to(torch.float32)
 
     def params(self):
         return self.sources
@@ -640,9 +702,9 @@ class ProgramBuilder:
         self.steps.append(dict(kind=_hip.STEP_AFFINE_CONST, c0=0, ct=0, t0=0, tt=T, reverse=int(reverse), act=0,
                                blob_off=off, blob_floats=n, ldj_scale=ldj_scale, ldj_const=0.0))
 
-    def add_linear(self, sources, fn, ldj_const: float) -> None:
+    def add_linear(self, sources, fn, ldj_fn=None) -> None:
         """y = W . x + b on the data columns (W, b = fn(device), torch Linear layout [out, in]): one LINEAR_TILE step
-        for the whole layer."""
+        for the whole layer; ldj_fn(device) -> its log-det term (0-dim tensor, signed and scaled) or None for 0."""
         self._freeze_input()
         D, T = self.dim, self.tiles
         col = self.col_of_slot
@@ -652,11 +714,14 @@ class ProgramBuilder:
         # the whole layer in ONE step (all output slabs, one barrier / one weight refill; at most 4 x 4 tiles = 64 KiB,
         # which fits the LDS ring twice): act = number of slabs
         row_idx = col[:32 * XT].copy()                     # output slot keeps its logical column
-        off, n = self._alloc(_hip.packed_linear_floats(XT, T))
+        n_lin = _hip.packed_linear_floats(XT, T)
+        off, n = self._alloc(n_lin + 1)                    # + the log-det term behind the bias
         targets = [(row_idx, col_idx, T, off, XT)]
         self.steps.append(dict(kind=_hip.STEP_LINEAR_TILE, c0=0, ct=T, t0=0, tt=1, reverse=0, act=XT, blob_off=off,
-                               blob_floats=n, ldj_scale=0.0, ldj_const=ldj_const))
-        self.jobs.append(_DerivedLinearJob(sources, fn, targets))
+                               blob_floats=n, ldj_scale=0.0, ldj_const=0.0))
+        if ldj_fn is None:
+            ldj_fn = lambda dev: torch.zeros((), dtype=torch.float32, device=dev)
+        self.jobs.append(_DerivedLinearJob(sources, fn, targets, ldj_fn, off + n_lin))
 
     def add_row_scale_exp(self, diag, reverse: bool, ldj_scale: float, log_time: bool, t_const: float) -> None:
         """state *= exp(+-diag * t_row) (MatrixExponential with a per-row time, affine.py:263)."""

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from .. import _hip
-from ..fused import ProgramBuilder
+from ..fused import ProgramBuilder, ProgramCache, StructureTracked
 
 
 class BatchLinear(torch.autograd.Function):
@@ -90,7 +90,25 @@ def batch_linear(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor]) ->
     return torch.nn.functional.linear(x, W, b)
 
 
-class MLP(nn.Module):
+class _Linear(StructureTracked, nn.Linear):
+    """nn.Linear whose re-assigned weight / bias invalidates the programs that packed the old tensors."""
+
+
+class _Sequential(StructureTracked, nn.Sequential):
+    """nn.Sequential whose replaced layers invalidate cached programs (same state_dict keys as the reference's)."""
+
+    def __setitem__(self, idx, module):
+        from ..fused import bump_structure_epoch
+        bump_structure_epoch()
+        super().__setitem__(idx, module)
+
+    def __delitem__(self, idx):
+        from ..fused import bump_structure_epoch
+        bump_structure_epoch()
+        super().__delitem__(idx)
+
+
+class MLP(StructureTracked, nn.Module):
     def __init__(self, in_dim: int, hidden_dims: List[int], out_dim: int, activation: Union[str, Callable] = 'Tanh',
                  final_activation: Optional[str] = None, nn_linear_wrapper_func: Optional[Callable] = None, **kwargs):
         super().__init__()
@@ -110,11 +128,11 @@ class MLP(nn.Module):
         for i in range(len(widths) - 1):
             if i:
                 layers.append(act)                        # keeps the reference's indices 0, 2, 4, ...
-            layers.append(nn.Linear(widths[i], widths[i + 1]))
+            layers.append(_Linear(widths[i], widths[i + 1]))
         with torch.no_grad():
             layers[-1].bias.zero_()                       # mlp.py:53
-        self.net = nn.Sequential(*layers)
-        self._programs = {}
+        self.net = _Sequential(*layers)
+        self._programs = ProgramCache()
 
     # -- pieces the coupling / spline planners consume -------------------------------------------------
     def linears(self):
@@ -145,12 +163,11 @@ class MLP(nn.Module):
 
     # -- standalone evaluation ---------------------------------------------------------------------------
     def _program(self, device):
-        key = str(device)
-        if key not in self._programs:
+        def build():
             b = ProgramBuilder(self.in_dim, 0, self.hidden_width)
             b.add_mlp(self.linears(), self.act_code, None, np.arange(self.out_dim))
-            self._programs[key] = _chunk_mlp_program(b, device)
-        return self._programs[key]
+            return _chunk_mlp_program(b, device)
+        return self._programs.get(str(device), build)
 
     def forward(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
         _hip.require_device(x, 'MLP input')

@@ -1,0 +1,183 @@
+"""GPU: cached fused programs must follow every change made AFTER a first call.
+
+The planner bakes the transform list, Permute index vectors, masks and the Parameter objects behind each pack job
+into host tables (stribor_amd/fused.py).  Each test below evaluates once (so the program is built and cached), then
+changes something the reference would pick up on its next call (it re-reads everything every call:
+stribor/flow.py:99-130, flows/permute.py:62-82, flows/affine.py:148-171,222-288, flows/coupling.py:48-53) and checks
+the second evaluation against the oracle.
+"""
+import copy
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn as nn
+
+import flowdesc as fd
+from goldens import Golden
+from producthelp import close, product_flow
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import stribor_oracle as orc
+
+import stribor_amd as st
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    with torch.no_grad():
+        yield
+
+
+def _oracle_logp(desc, flow, x):
+    spec = fd.flow_spec(desc, {k: v.detach().cpu().clone() for k, v in flow.state_dict().items()})
+    return orc.flow_log_prob(spec, x.cpu())
+
+
+def test_permutation_loaded_after_first_call():
+    """flow.log_prob(x); flow.load_state_dict(other permutation); flow.log_prob(x)  (permute.py:62-82)."""
+    g = Golden('f7_permute')
+    m = g.meta['mixed']
+    torch.manual_seed(1234)
+    flow = fd.build_flow(st, m['desc'], m['dim']).to(DEV)          # random permutation != the fixture's
+    x = g.t('mixed/x').to(DEV)
+    first = flow.log_prob(x)
+    assert first.shape == (x.shape[0], 1)
+    flow.load_state_dict(g.state('mixed'))                          # in-place copy_ into the permutation buffer
+    close(flow.log_prob(x), g.t('mixed/log_prob'))
+    close(flow.inverse(x), g.t('mixed/inverse'))
+    close(flow.forward(x), g.t('mixed/forward'))
+    # and a permutation buffer replaced wholesale (new tensor object)
+    perm_layers = [f for f in flow.transforms if isinstance(f, st.Permute)]
+    assert perm_layers
+    p = perm_layers[0]
+    new = torch.randperm(p.dim, generator=torch.Generator().manual_seed(7)).to(DEV)
+    p.permutation = new
+    want = _oracle_logp(m['desc'], flow, x)
+    close(flow.log_prob(x), want)
+    # standalone layer path of the same module
+    close(p.forward(x), x[:, new])
+    close(p.inverse(p.forward(x)), x)
+
+
+def test_transform_list_edited_after_first_call():
+    """Swapping / replacing entries of flow.transforms re-plans (flow.py:99-107 loops over the live list)."""
+    torch.manual_seed(3)
+    desc = fd.cfg2_desc(4, 16, 32)
+    flow = fd.build_flow(st, desc, 16).to(DEV)
+    x = torch.randn(300, 16, device=DEV)
+    close(flow.log_prob(x), _oracle_logp(desc, flow, x))
+    # swap two layers (ModuleList.__setitem__ never passes through a __setattr__ of ours)
+    a, b = flow.transforms[0], flow.transforms[1]
+    flow.transforms[0], flow.transforms[1] = b, a
+    desc2 = [desc[1], desc[0]] + desc[2:]
+    close(flow.log_prob(x), _oracle_logp(desc2, flow, x))
+    close(flow.inverse(x), orc.flow_inverse(fd.flow_spec(desc2, {k: v.cpu() for k, v in flow.state_dict().items()}), x.cpu()))
+    # replace one layer by a new module, append another
+    torch.manual_seed(4)
+    flow.transforms[2] = fd.build_transform(st, desc[2]).to(DEV)
+    flow.transforms.append(fd.build_transform(st, desc[0]).to(DEV))
+    desc3 = desc2 + [desc[0]]
+    close(flow.log_prob(x), _oracle_logp(desc3, flow, x))
+
+
+def test_weight_objects_replaced_after_first_call():
+    """layer.weight = nn.Parameter(...), mlp.net[i] = nn.Linear(...), coupling.transform.latent_net = MLP(...)."""
+    torch.manual_seed(5)
+    desc = fd.cfg2_desc(2, 8, 16)
+    flow = fd.build_flow(st, desc, 8).to(DEV)
+    x = torch.randn(200, 8, device=DEV)
+    close(flow.log_prob(x), _oracle_logp(desc, flow, x))
+    net = flow.transforms[0].transform.latent_net
+    lin0 = net.net[0]
+    lin0.weight = nn.Parameter(torch.randn_like(lin0.weight) * 0.3)          # new Parameter object, old one orphaned
+    close(flow.log_prob(x), _oracle_logp(desc, flow, x))
+    net.net[2] = nn.Linear(16, 16).to(DEV)                                   # foreign nn.Linear in the Sequential
+    close(flow.log_prob(x), _oracle_logp(desc, flow, x))
+    flow.transforms[1].transform.latent_net = st.net.MLP(8, [16], 16).to(DEV)
+    close(flow.log_prob(x), _oracle_logp(desc, flow, x))
+    # in-place updates (optimizer steps) keep working through the version counters
+    with torch.no_grad():
+        for p in flow.parameters():
+            p.add_(0.01 * torch.randn_like(p))
+    close(flow.log_prob(x), _oracle_logp(desc, flow, x))
+    # the coupling's own single-layer programs follow as well
+    c = flow.transforms[0]
+    want_y, want_ldj = orc.flow_forward_and_ldj(fd.flow_spec(desc[:1], {('transforms.0.' + k): v.cpu() for k, v in c.state_dict().items()}), x.cpu())
+    y, ldj = c.forward_and_log_det_jacobian(x)
+    close(y, want_y)
+    close(ldj, want_ldj, atol=1e-4)
+    net.net[0].bias = nn.Parameter(torch.randn(16, device=DEV))
+    want_y, want_ldj = orc.flow_forward_and_ldj(fd.flow_spec(desc[:1], {('transforms.0.' + k): v.cpu() for k, v in c.state_dict().items()}), x.cpu())
+    y, ldj = c.forward_and_log_det_jacobian(x)
+    close(y, want_y)
+    close(ldj, want_ldj, atol=1e-4)
+
+
+def test_mask_changed_after_first_call():
+    torch.manual_seed(6)
+    desc = fd.cfg2_desc(2, 8, 16)
+    flow = fd.build_flow(st, desc, 8).to(DEV)
+    x = torch.randn(100, 8, device=DEV)
+    close(flow.log_prob(x), _oracle_logp(desc, flow, x))
+    flow.transforms[0].mask_func = st.util.get_mask('parity_even')
+    desc2 = copy.deepcopy(desc)
+    desc2[0]['mask'] = 'parity_even'
+    close(flow.log_prob(x), _oracle_logp(desc2, flow, x))
+    y, ldj = flow.transforms[0].forward_and_log_det_jacobian(x)
+    want_y, want_ldj = orc.flow_forward_and_ldj(fd.flow_spec(desc2[:1], {k: v.cpu() for k, v in flow.state_dict().items()}), x.cpu())
+    close(y, want_y)
+    close(ldj, want_ldj, atol=1e-4)
+
+
+@pytest.mark.parametrize('dim', [8, 128])
+def test_dense_layer_logdet_follows_parameter_updates(dim):
+    """AffineLU / MatrixExponential: log|det| is parameter-only (affine.py:171, 287-288) and must be refreshed together
+    with the matrices -- in the flow's fused program and in the layers' own programs."""
+    torch.manual_seed(7)
+    desc = [{'kind': 'affine_lu', 'dim': dim},
+            {'kind': 'coupling_affine', 'dim': dim, 'hidden': [32], 'mask': 'ordered_right_half', 'latent_dim': 0},
+            {'kind': 'matrix_exp', 'dim': dim, 'bias': True, 'log_time': False},
+            {'kind': 'coupling_affine', 'dim': dim, 'hidden': [32], 'mask': 'ordered_left_half', 'latent_dim': 0}]
+    flow = fd.build_flow(st, desc, dim).to(DEV)
+    x = torch.randn(257, dim, device=DEV)
+    first = flow.log_prob(x)
+    close(first, _oracle_logp(desc, flow, x), rtol=1e-5, atol=1e-4)
+    lu, mx = flow.transforms[0], flow.transforms[2]
+    y0, l0 = lu.forward_and_log_det_jacobian(x)          # builds the layers' own programs too
+    y1, l1 = mx.inverse_and_log_det_jacobian(x)
+    with torch.no_grad():
+        lu.log_diag.add_(0.05)                            # log-det changes by 0.05 * dim
+        mx.diag.mul_(1.5).add_(0.01)
+    second = flow.log_prob(x)
+    want = _oracle_logp(desc, flow, x)
+    close(second, want, rtol=1e-5, atol=1e-4)
+    assert (second - first).abs().max().item() > 1e-2     # the update is visible at all
+    # standalone layers against the oracle's per-layer functions
+    sd = {k: v.cpu() for k, v in flow.state_dict().items()}
+    spec = fd.flow_spec(desc, sd)
+    wy, wl = orc.flow_forward_and_ldj(spec[:1], x.cpu())
+    y, l = lu.forward_and_log_det_jacobian(x)
+    close(y, wy, rtol=1e-5, atol=1e-4)
+    close(l, wl, rtol=1e-5, atol=1e-4)
+    close(lu.log_det_jacobian(x, None), wl, rtol=1e-5, atol=1e-4)
+    wy, wl = orc.flow_inverse_and_ldj(spec[2:3], x.cpu())
+    y, l = mx.inverse_and_log_det_jacobian(x)
+    close(y, wy, rtol=1e-4, atol=2e-4)
+    close(l, wl, rtol=1e-5, atol=1e-4)
+
+
+def test_load_state_dict_after_first_call_cfg4_slice():
+    """A cfg-4 style flow evaluated, then loaded with the golden state (in-place copies), then evaluated again."""
+    g = Golden('f6_cfg4')
+    m = g.meta['cfg4']
+    torch.manual_seed(99)
+    flow = fd.build_flow(st, m['desc'], m['dim']).to(DEV)
+    x = g.t('cfg4/x').to(DEV)
+    flow.log_prob(x)
+    flow.load_state_dict(g.state('cfg4'))
+    close(flow.log_prob(x), g.t('cfg4/log_prob'))
