@@ -10,8 +10,10 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless the name ends in `_host`;
- *   - the library allocates nothing, keeps no global state and never synchronises: all work is
- *     enqueued on `stream` (a hipStream_t passed as void*; NULL = the default stream);
+ *   - the library allocates nothing, keeps no per-stream or per-device state and never synchronises:
+ *     all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the default stream) of
+ *     the CURRENT device (callers hipSetDevice / torch.cuda.device first); scratch and counters are
+ *     caller-owned (`work`, `scratch` arguments below);
  *   - tensors are row-major, rows = samples; `x`/`y` are [n_rows, dim] with element type
  *     `dtype` (SX_F32 or SX_BF16 storage); all arithmetic is fp32; ldj / log-prob are fp32;
  *   - every function returns 0 on success, a negative SX_E* code for a bad argument, or a
@@ -30,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SX_ABI_VERSION 1
+#define SX_ABI_VERSION 2
 
 /* storage dtypes of x / y */
 #define SX_F32  0
@@ -44,6 +46,16 @@ extern "C" {
 /* device error-flag bits */
 #define SX_FLAG_RQS_NEG_DISCRIMINANT 1u   /* rational_quadratic_spline.py:223 assert */
 #define SX_FLAG_NONFINITE            2u
+#define SX_FLAG_F16_RANGE            4u   /* an operand of the fp16 x 3 GEMMs exceeded 65504 (weights at pack time, flow state /
+                                             activations at run time); the affected rows were returned as NaN              */
+
+/* GEMM arithmetic of the MFMA path (both are in the library; chosen per call):
+ *   SX_GEMM_F16X3: both operands split hi + lo in fp16, three products per 16-deep step on v_mfma_f32_32x32x16_f16 with
+ *                  fp32 accumulation (~2^-22 relative per product, fp32-grade) -- on the matrix pipe, beside the VALU.
+ *                  Operands must stay within fp16's range (|v| <= 65504): see SX_FLAG_F16_RANGE.
+ *   SX_GEMM_F32:   v_mfma_f32_32x32x2_f32, an exact fp32 fma chain with no range limit (3x slower on cfg 2). */
+#define SX_GEMM_F32   0
+#define SX_GEMM_F16X3 1
 
 /* hidden activations of the conditioner (torch.nn names, stribor/net/mlp.py:38-39) */
 #define SX_ACT_IDENTITY  0
@@ -60,9 +72,7 @@ extern "C" {
 #define SX_ACT_TANH_FOLDED 9
 
 int         sx_abi_version(void);
-/* GEMM arithmetic the library was built with: 0 = v_mfma_f32_32x32x2_f32 (exact fp32 fma chains),
- * 1 = fp16 x 3 split on v_mfma_f32_32x32x16_f16 (a = a_hi + a_lo in fp16, 3 products, fp32 accumulate:
- * ~2^-22 relative per product, fp32-grade).  sx_pack_linear writes the matching fragment layout. */
+/* The library's default GEMM arithmetic (SX_GEMM_F16X3). */
 int         sx_fragment_mode(void);
 const char *sx_last_error(void);
 
@@ -193,8 +203,9 @@ int sx_sum_f64(const float *v, int64_t n, double *out, void *stream);
 size_t sx_packed_linear_floats(int32_t m_tiles, int32_t k_tiles);
 
 /* Re-lays one nn.Linear (W: [out_dim, in_dim] row-major as torch stores it, b: [out_dim] or NULL)
- * into MFMA A-operand fragment order for the library's GEMM arithmetic (sx_fragment_mode()), followed by the bias
- * in C-fragment order.  4 KiB per 32x32 tile pair in both modes.
+ * into MFMA A-operand fragment order for the GEMM arithmetic `precision` (SX_GEMM_*), followed by the bias
+ * in C-fragment order.  4 KiB per 32x32 tile pair in both modes.  With SX_GEMM_F16X3 a (scaled) weight beyond fp16's
+ * range ORs SX_FLAG_F16_RANGE into `err_flag` (nullable) and packs as inf, so every product it enters is non-finite.
  *   row_idx[m_tiles*32]: output slot -> row of W, or -1 for a zero row (padding / pruned)
  *   col_idx[k_tiles*32]: input  slot -> column of W, or -1 for a zero column
  * With kmap(s,h) = (s&3) + 8*(s>>2) + 4*h (the C/D fragment row map):
@@ -212,7 +223,7 @@ size_t sx_packed_linear_floats(int32_t m_tiles, int32_t k_tiles);
 int sx_pack_linear(const float *W, const float *b, int32_t out_dim, int32_t in_dim,
                    const int32_t *row_idx, const int32_t *col_idx, int32_t m_tiles, int32_t k_tiles,
                    const float *row_scale, const float *bias_scale, float fold_ones, int32_t transpose,
-                   float *dst, void *stream);
+                   int32_t precision, uint32_t *err_flag, float *dst, void *stream);
 
 /* One step of a fused flow program.  The flow state lives in registers as 32-wide "tiles" of columns (tile t =
  * state slots 32t..32t+31); slots map to columns of x through in_col/out_col.  Field use per kind: */
@@ -273,7 +284,8 @@ typedef struct sx_program {
 } sx_program;
 
 /* Runs a fused program over n_rows samples: the whole flow stays in registers, weights stream
- * through LDS, every GEMM runs on the matrix cores (sx_fragment_mode()).  A program holds flow steps
+ * through LDS, every GEMM runs on the matrix cores in the arithmetic `precision` (SX_GEMM_*; `blobs` must have been
+ * packed for the same one).  A program holds flow steps
  * (kinds 1, 2; + 3, 9 for dense linear layers; or 10, 11 for spline couplings), or conditioner steps (5-7),
  * or backward steps (12) -- the kernel variant is picked from the kinds present.
  * Replaces NormalizingFlow.{forward, inverse, forward_and_log_det_jacobian,
@@ -295,11 +307,18 @@ typedef struct sx_program {
  *            order, from which sx_wgrad forms the weight gradients; row_t carries dL/dlog_prob;
  *            x is the flow's latent z, y receives dL/d(input)
  *   mlp_out  [n_rows, mlp_out_dim] (row stride mlp_out_stride) destination of SX_STEP_MLP_OUT_TILE
- *            steps, or NULL                                                                   */
+ *            steps, or NULL
+ *   work     two uint32 {next-chunk ticket, finished workgroups}, zero before the first launch that uses them, owned by
+ *            the caller and private to one stream (launches on a stream never overlap): the persistent workgroups take
+ *            row chunks from it dynamically and the last one out zeroes the pair again, so launches need no memset and
+ *            replay from HIP graphs.  NULL = static chunk stride.  After a failed launch zero the pair again.
+ *   err_flag caller's flag word (device memory or host-mapped pinned memory), or NULL: SX_FLAG_F16_RANGE is OR-ed in
+ *            (system-scope atomic) when a sample's operands left the fp16 x 3 range; such rows come back as NaN      */
 int sx_flow_run(const sx_program *prog_host, const float *blobs, const void *x, const float *latent,
                 const int32_t *in_col, const int32_t *out_col, void *y, float *ldj_out,
                 float *logp_out, double *sum_out, float *mlp_out, int64_t mlp_out_stride,
-                int32_t mlp_out_dim, const float *row_t, float *side, int64_t n_rows, int32_t dtype, void *stream);
+                int32_t mlp_out_dim, const float *row_t, float *side, int64_t n_rows, int32_t dtype,
+                int32_t precision, uint32_t *work, uint32_t *err_flag, void *stream);
 
 /* Weight-gradient contraction over the batch axis (training):
  *   dW[rm(i), cm(j)] += sum_n A[n, i] * B[n, j]   (dW row stride ldw),   db[rm(i)] += sum_n A[n, i]   (db may be NULL)
@@ -312,29 +331,32 @@ int sx_flow_run(const sx_program *prog_host, const float *blobs, const void *x, 
  *                        ignored); M <= 128
  * row_map [M] / col_map [Nc] (device int32, either may be NULL = identity) send the operands' feature order straight
  * to the parameter's own rows / columns; negative entries are dropped.  dW / db are accumulated into (zero them
- * first) by one writer per element: results do not depend on scheduling.  Launches on one stream share a scratch
- * for the per-workgroup partial tiles.  Replaces autograd's dense matmuls over the batch axis for nn.Linear
+ * first) by one writer per element: results do not depend on scheduling.  `scratch` (caller-owned, at least
+ * sx_wgrad_scratch_floats(M, Nc, layout) floats, private to the stream until the call has run) holds the per-workgroup
+ * partial tiles.  Replaces autograd's dense matmuls over the batch axis for nn.Linear
  * inside stribor/net/mlp.py:48-58 (a tall-skinny A^T B that library GEMMs run on a handful of workgroups). */
 #define SX_WGRAD_ROW_MAJOR 0
 #define SX_WGRAD_ROW_GROUPS 1
+size_t sx_wgrad_scratch_floats(int32_t M, int32_t Nc, int32_t layout);
 int sx_wgrad(const float *A, int64_t lda, int32_t M, const float *B, int64_t ldb, int32_t Nc, int64_t n_rows,
              int32_t layout, float *dW, int64_t ldw, float *db, const int32_t *row_map, const int32_t *col_map,
-             void *stream);
+             float *scratch, void *stream);
 
 /* Both weight gradients of ONE coupling layer of a backward program in one pass over its slot of `side`
  * (32-row groups of [z (32 c_tiles) | tanh h (32 h_tiles) | dL/dh_pre (32 h_tiles) | dL/d(log_scale, shift) (64 t_tiles)],
  * ld floats per group): dW2 [rows through row_map2, `hidden` columns] += dparams^T tanh_h, db2 += sum dparams,
  * dW1 [`hidden` rows, columns through col_map1] += dh_pre^T z, db1 += sum dh_pre -- what two sx_wgrad calls on the
  * slices compute, with the group streamed once.  Shapes: c_tiles = t_tiles = 1, h_tiles <= 2 (SX_E_UNSUPPORTED
- * otherwise: use sx_wgrad). */
+ * otherwise: use sx_wgrad).  scratch: >= sx_wgrad_layer_scratch_floats(c_tiles, h_tiles, t_tiles) floats. */
+size_t sx_wgrad_layer_scratch_floats(int32_t c_tiles, int32_t h_tiles, int32_t t_tiles);
 int sx_wgrad_layer(const float *side, int64_t ld, int64_t n_rows, int32_t c_tiles, int32_t h_tiles, int32_t t_tiles,
                    int32_t hidden, float *dW2, int64_t ldw2, float *db2, const int32_t *row_map2, float *dW1,
-                   int64_t ldw1, float *db1, const int32_t *col_map1, void *stream);
+                   int64_t ldw1, float *db1, const int32_t *col_map1, float *scratch, void *stream);
 
 /* out[j] += sum_n A[n, j] for a row-major fp32 [n_rows, M] matrix (row stride lda): the bias gradient of a Linear
  * layer too wide for sx_wgrad (autograd's grad_output.sum(0) behind stribor/net/mlp.py:48-58).  Deterministic, no
- * atomics; zero `out` first. */
-int sx_colsum(const float *A, int64_t lda, int64_t n_rows, int32_t M, float *out, void *stream);
+ * atomics; zero `out` first.  scratch: >= 256 * M floats. */
+int sx_colsum(const float *A, int64_t lda, int64_t n_rows, int32_t M, float *out, float *scratch, void *stream);
 
 /* X[b] = T[b]^-1 for a batch of row-major fp64 D x D triangular matrices (D <= 128; lower != 0: lower triangular,
  * else upper; unit != 0: the diagonal is taken as 1).  Entries of T outside the triangle are not read; X is written

@@ -17,6 +17,9 @@ LIB_PATH = os.environ.get('STRIBOR_HIP_LIB', os.path.join(_HERE, 'libstribor_hip
 
 SX_F32, SX_BF16 = 0, 1
 SX_MAX_STEPS = 128
+SX_ABI_VERSION = 2
+GEMM_F32, GEMM_F16X3 = 0, 1
+FLAG_RQS_NEG_DISCRIMINANT, FLAG_NONFINITE, FLAG_F16_RANGE = 1, 2, 4
 
 STEP_COUPLING_AFFINE = 1
 STEP_AFFINE_CONST = 2
@@ -44,7 +47,8 @@ ACT_CODES = {'Identity': 0, 'Tanh': 1, 'ReLU': 2, 'Sigmoid': 3, 'ELU': 4, 'Softp
 EXPORTS = ['sx_abi_version', 'sx_fragment_mode', 'sx_last_error', 'sx_permute', 'sx_affine_coupling', 'sx_rqs_coupling',
            'sx_cubic_coupling', 'sx_pointwise', 'sx_rqs_inverse_bwd', 'sx_affine_coupling_bwd', 'sx_time_affine_coupling', 'sx_cubic_inverse_bwd', 'sx_pointwise_bwd',
            'sx_unit_normal_logprob', 'sx_sum_f64', 'sx_packed_linear_floats', 'sx_pack_linear', 'sx_flow_run',
-           'sx_flow_launch_info', 'sx_wgrad', 'sx_wgrad_layer', 'sx_colsum', 'sx_tri_inverse_f64']
+           'sx_flow_launch_info', 'sx_wgrad', 'sx_wgrad_layer', 'sx_colsum', 'sx_tri_inverse_f64',
+           'sx_wgrad_scratch_floats', 'sx_wgrad_layer_scratch_floats']
 
 
 class HipLibraryMissing(RuntimeError):
@@ -102,15 +106,19 @@ def _declare(lib: C.CDLL) -> None:
     lib.sx_packed_linear_floats.restype = C.c_size_t
     lib.sx_packed_linear_floats.argtypes = [i32, i32]
     lib.sx_pack_linear.restype = i32
-    lib.sx_pack_linear.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, f32, i32, vp, vp]
+    lib.sx_pack_linear.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, f32, i32, i32, vp, vp, vp]
     lib.sx_flow_run.restype = i32
-    lib.sx_flow_run.argtypes = [C.POINTER(sx_program), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, i64, i32, vp]
+    lib.sx_flow_run.argtypes = [C.POINTER(sx_program), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, i64, i32, i32, vp, vp, vp]
     lib.sx_wgrad.restype = i32
-    lib.sx_wgrad.argtypes = [vp, i64, i32, vp, i64, i32, i64, i32, vp, i64, vp, vp, vp, vp]
+    lib.sx_wgrad.argtypes = [vp, i64, i32, vp, i64, i32, i64, i32, vp, i64, vp, vp, vp, vp, vp]
+    lib.sx_wgrad_scratch_floats.restype = C.c_size_t
+    lib.sx_wgrad_scratch_floats.argtypes = [i32, i32, i32]
+    lib.sx_wgrad_layer_scratch_floats.restype = C.c_size_t
+    lib.sx_wgrad_layer_scratch_floats.argtypes = [i32, i32, i32]
     lib.sx_wgrad_layer.restype = i32
-    lib.sx_wgrad_layer.argtypes = [vp, i64, i64, i32, i32, i32, i32, vp, i64, vp, vp, vp, i64, vp, vp, vp]
+    lib.sx_wgrad_layer.argtypes = [vp, i64, i64, i32, i32, i32, i32, vp, i64, vp, vp, vp, i64, vp, vp, vp, vp]
     lib.sx_colsum.restype = i32
-    lib.sx_colsum.argtypes = [vp, i64, i64, i32, vp, vp]
+    lib.sx_colsum.argtypes = [vp, i64, i64, i32, vp, vp, vp]
     lib.sx_tri_inverse_f64.restype = i32
     lib.sx_tri_inverse_f64.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     lib.sx_flow_launch_info.restype = i32
@@ -127,8 +135,8 @@ def lib() -> C.CDLL:
                 f'`make -C {os.path.join(_HERE, "csrc")} -j8` (hipcc, --offload-arch=gfx950).')
         l = C.CDLL(LIB_PATH)
         _declare(l)
-        if l.sx_abi_version() != 1:
-            raise HipLibraryMissing(f'{LIB_PATH}: ABI version {l.sx_abi_version()} != 1; rebuild')
+        if l.sx_abi_version() != SX_ABI_VERSION:
+            raise HipLibraryMissing(f'{LIB_PATH}: ABI version {l.sx_abi_version()} != {SX_ABI_VERSION}; rebuild')
         _lib = l
     return _lib
 
@@ -167,6 +175,154 @@ def stream() -> int:
     if _raw_stream is not None and _cur_device is not None:
         return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+# ---- GEMM arithmetic of the MFMA path ---------------------------------------------------------------------------------
+# 'fast'  fp16 x 3 split on the matrix pipe (fp32-grade: ~2^-22 per product).  Operands must stay within fp16's range
+#         (|v| <= 65504): a sample whose flow state / activations leave it comes back as NaN -- never as a plausible
+#         number -- and the next call (or check_errors()) raises GemmRangeError; weights beyond it raise the same way.
+# 'exact' v_mfma_f32_32x32x2_f32 fp32 fma chains, no range limit (about 3x slower on BASELINE cfg 2).
+# 'auto'  'fast', but every call synchronises, and a call that left the range is re-run 'exact' before it returns.
+_PRECISIONS = ('fast', 'exact', 'auto')
+_precision = os.environ.get('STRIBOR_GEMM_PRECISION', 'fast')
+if _precision not in _PRECISIONS:
+    raise ValueError(f'STRIBOR_GEMM_PRECISION={_precision!r}; one of {_PRECISIONS}')
+
+
+def set_gemm_precision(mode: str) -> str:
+    """Select the conditioner-GEMM arithmetic for all later calls; returns the previous mode."""
+    global _precision
+    if mode not in _PRECISIONS:
+        raise ValueError(f'gemm precision {mode!r}; one of {_PRECISIONS}')
+    old, _precision = _precision, mode
+    return old
+
+
+def get_gemm_precision() -> str:
+    return _precision
+
+
+class GemmRangeError(OverflowError):
+    """An operand of the fp16 x 3 conditioner GEMMs exceeded fp16's range (65504)."""
+
+
+# ---- data-dependent error flags (reference: exceptions raised inside the torch ops) -----------------------------------
+# One 32-bit word per device in PINNED host memory: kernels OR SX_FLAG_* bits into it with system-scope atomics (the
+# pinned allocation is mapped into the device's address space under the same pointer), the host reads it with a plain
+# load -- no stream synchronisation, nothing that would break HIP-graph capture.  A kernel's flag becomes visible once
+# that kernel has run, so `poll_errors()` at the start of the next call reports the previous call's condition;
+# `check_errors()` synchronises first.
+_flag_words = {}
+
+
+def err_flag(device) -> int:
+    """Pointer (host == device address) of `device`'s flag word."""
+    key = torch.device(device).index or 0
+    ent = _flag_words.get(key)
+    if ent is None:
+        t = torch.zeros(1, dtype=torch.int32).pin_memory()
+        ent = _flag_words[key] = (t, t.numpy(), t.data_ptr())
+    return ent[2]
+
+
+def _raise_flags(v: int) -> None:
+    if v & FLAG_F16_RANGE:
+        raise GemmRangeError(
+            'an operand of the fp16 x 3 conditioner GEMMs (a weight, or a sample\'s flow state / hidden activation) '
+            'exceeded 65504; the affected rows were returned as NaN.  Use stribor_amd.set_gemm_precision("exact") '
+            '(fp32 MFMA, no range limit) or "auto" (re-runs such calls exactly).')
+    if v & FLAG_RQS_NEG_DISCRIMINANT:
+        raise AssertionError('rational_quadratic_spline: negative discriminant in the inverse pass')
+
+
+def poll_errors() -> None:
+    """Raise for any flag a COMPLETED kernel has set (no synchronisation)."""
+    for _, view, _ in _flag_words.values():
+        v = int(view[0])
+        if v:
+            view[0] = 0
+            _raise_flags(v)
+
+
+def check_errors(device=None) -> None:
+    """Synchronise and raise what the reference would have raised for data-dependent failures."""
+    if torch.cuda.is_available():
+        torch.cuda.synchronize(device)
+    poll_errors()
+
+
+def take_flag(device, bit: int) -> bool:
+    """Clear `bit` of the device's flag word and tell whether it was set (callers synchronised already)."""
+    ent = _flag_words.get(torch.device(device).index or 0)
+    if ent is None:
+        return False
+    v = int(ent[1][0])
+    if v & bit:
+        ent[1][0] = v & ~bit
+        return True
+    return False
+
+
+# ---- caller-owned scratch of the library (it allocates nothing itself) ------------------------------------------------
+_work = {}
+_scratch = {}
+
+
+def work_counters(device) -> torch.Tensor:
+    """The {ticket, done} pair of the fused kernel's dynamic chunk hand-out for (device, current stream)."""
+    key = (torch.device(device).index or 0, stream())
+    t = _work.get(key)
+    if t is None:
+        t = _work[key] = torch.zeros(2, dtype=torch.int32, device=device)
+    return t
+
+
+def scratch(device, n_floats: int) -> torch.Tensor:
+    """>= n_floats of fp32 scratch for (device, current stream); grown by replacement (the old block returns to torch's
+    stream-ordered allocator, so launches already queued on this stream keep valid memory)."""
+    key = (torch.device(device).index or 0, stream())
+    t = _scratch.get(key)
+    if t is None or t.numel() < n_floats:
+        t = _scratch[key] = torch.empty(max(n_floats, 1 << 20), dtype=torch.float32, device=device)
+    return t
+
+
+# ---- device guard -------------------------------------------------------------------------------------------------
+# The library launches on the CURRENT device (hipGetDevice) and `stream()` is that device's current stream, so every
+# launch runs under the device of the tensors it is given -- like torch's own ops (single-process multi-GPU use, or a
+# caller that never called set_device).
+_exchange = getattr(torch._C, '_cuda_exchangeDevice', None)
+
+
+class device_of:
+    """`with device_of(t):` makes t's device current for the block (no-op fast path when it already is)."""
+    __slots__ = ('idx', 'prev')
+
+    def __init__(self, t: torch.Tensor):
+        self.idx = t.device.index if t.is_cuda else None
+
+    def __enter__(self):
+        self.prev = -1
+        if self.idx is not None and _cur_device is not None and _cur_device() != self.idx:
+            if _exchange is not None:
+                self.prev = _exchange(self.idx)
+            else:
+                self.prev = torch.cuda.current_device()
+                torch.cuda.set_device(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            torch.cuda.set_device(self.prev)
+        return False
+
+
+def call(name: str, t: torch.Tensor, *args) -> None:
+    """lib().<name>(*args, stream) on t's device and its current stream; raises on a non-zero status."""
+    with device_of(t):
+        rc = getattr(lib(), name)(*args, stream())
+    if rc != 0:
+        check(rc, name)
 
 
 def packed_linear_floats(m_tiles: int, k_tiles: int) -> int:

@@ -2,6 +2,11 @@
 #include "sx_flow_types.h"
 #include <stdlib.h>
 
+// experiment knobs, read once per process
+static const bool g_no_pure_mode = getenv("SX_NO_PURE_MODE") != nullptr;
+static const bool g_static_chunks = getenv("SX_STATIC_CHUNKS") != nullptr;
+static const int g_blocks_per_cu = getenv("SX_BLOCKS_PER_CU") ? atoi(getenv("SX_BLOCKS_PER_CU")) : 0;
+
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -121,37 +126,16 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
                    (s.reverse != 0) == (dir != 0);
             any = true;
         }
-        if (pure && any && !getenv("SX_NO_PURE_MODE")) *mlp_mode = (*mlp_mode == 2 ? 7 : 5) + (dir ? 0 : 1);
+        if (pure && any && !g_no_pure_mode) *mlp_mode = (*mlp_mode == 2 ? 7 : 5) + (dir ? 0 : 1);
     }
     SX_REQUIRE((size_t)mx * 8 <= 160 * 1024, "sx_flow_run: a step needs %d B of LDS per buffer (> 80 KiB)", mx * 4);
     return SX_OK;
 }
 
-// {ticket, done} counter pair per (device, stream): launches on one stream never overlap, and the kernel's last
-// workgroup zeroes the pair again, so the pair needs no per-launch memset.  First use on a stream allocates
-// (do that outside hipGraph capture).
-#include <mutex>
-#include <vector>
-struct work_slot { int dev; hipStream_t stream; uint32_t *ptr; };
-static uint32_t *work_counters(hipStream_t stream) {
-    static std::mutex mu;
-    static std::vector<work_slot> slots;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> g(mu);
-    for (const work_slot &w : slots)
-        if (w.dev == dev && w.stream == stream) return w.ptr;
-    uint32_t *p = nullptr;
-    if (hipMalloc(&p, 2 * sizeof(uint32_t)) != hipSuccess) return nullptr;
-    if (hipMemset(p, 0, 2 * sizeof(uint32_t)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return nullptr; }
-    slots.push_back(work_slot{dev, stream, p});
-    return p;
-}
-
 static int pick_grid(int64_t n_rows, int lds_bytes, int tiles, int mode) {
     int per_cu = (160 * 1024) / (lds_bytes > 0 ? lds_bytes : 1);
     int max_per_cu = SX_BLOCKS_FOR(tiles, mode);
-    if (const char *g = getenv("SX_BLOCKS_PER_CU")) max_per_cu = atoi(g);      // experiment knob
+    if (g_blocks_per_cu > 0) max_per_cu = g_blocks_per_cu;      // experiment knob
     if (per_cu > max_per_cu) per_cu = max_per_cu;
     if (per_cu < 1) per_cu = 1;
     const int rows_per_block = 32 * SX_BLOCK_WAVES(tiles, mode) * SX_NS_FOR(tiles);
@@ -177,13 +161,15 @@ extern "C" int sx_flow_launch_info(const sx_program *prog_host, int64_t n_rows, 
 extern "C" int sx_flow_run(const sx_program *prog_host, const float *blobs, const void *x, const float *latent,
                            const int32_t *in_col, const int32_t *out_col, void *y, float *ldj_out, float *logp_out,
                            double *sum_out, float *mlp_out, int64_t mlp_out_stride, int32_t mlp_out_dim,
-                           const float *row_t, float *side, int64_t n_rows, int32_t dtype, void *stream) {
+                           const float *row_t, float *side, int64_t n_rows, int32_t dtype, int32_t precision,
+                           uint32_t *work, uint32_t *err_flag, void *stream) {
     dprog d; int bf; int mlp_mode; int sw;
     int rc = validate_and_convert(prog_host, &d, &bf, &mlp_mode, &sw);
     if (rc) return rc;
     SX_REQUIRE(x != nullptr && n_rows >= 0, "sx_flow_run: bad x / n_rows");
     SX_REQUIRE(blobs != nullptr || prog_host->n_steps == 0, "sx_flow_run: null blobs");
     SX_REQUIRE(dtype == SX_F32 || dtype == SX_BF16, "sx_flow_run: bad dtype");
+    SX_REQUIRE(precision == SX_GEMM_F32 || precision == SX_GEMM_F16X3, "sx_flow_run: unknown precision %d", precision);
     SX_REQUIRE(prog_host->identity_cols || (in_col != nullptr && (y == nullptr || out_col != nullptr)),
                "sx_flow_run: in_col/out_col required when identity_cols == 0");
     SX_REQUIRE(prog_host->latent_dim == 0 || latent != nullptr, "sx_flow_run: latent_dim > 0 but latent is NULL");
@@ -204,9 +190,10 @@ extern "C" int sx_flow_run(const sx_program *prog_host, const float *blobs, cons
     // dynamic chunk hand-out pays once a workgroup has several chunks; it needs a barrier per chunk (>= 1 step)
     const int rpb = 32 * SX_BLOCK_WAVES(prog_host->tiles, mlp_mode) * SX_NS_FOR(prog_host->tiles);
     const int64_t n_chunks = (n_rows + rpb - 1) / rpb;
-    a.work = (prog_host->n_steps > 0 && n_chunks > 2 * (int64_t)a.grid && !getenv("SX_STATIC_CHUNKS")) ? work_counters(a.stream) : nullptr;
+    a.work = (prog_host->n_steps > 0 && n_chunks > 2 * (int64_t)a.grid && !g_static_chunks) ? work : nullptr;
+    a.flags = err_flag;
     const int T = prog_host->tiles, H = prog_host->h_tiles;
-#define SX_GO(TT, HH) if (T == TT && H == HH) return sx_flow_launch_t##TT##h##HH(a)
+#define SX_GO(TT, HH) if (T == TT && H == HH) return precision == SX_GEMM_F16X3 ? sx_flow_launch_f16x3_t##TT##h##HH(a) : sx_flow_launch_f32x_t##TT##h##HH(a)
     SX_GO(1, 1); SX_GO(1, 2); SX_GO(1, 4); SX_GO(2, 1); SX_GO(2, 2); SX_GO(2, 4); SX_GO(4, 1); SX_GO(4, 2); SX_GO(4, 4);
 #undef SX_GO
     sx_set_error("sx_flow_run: unsupported tile configuration");

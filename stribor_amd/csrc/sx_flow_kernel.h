@@ -32,6 +32,15 @@
 #include <stdlib.h>
 
 #define SX_HALF_LOG_2PI 0.91893853320467274178f
+
+// Both GEMM arithmetics live in one library: this header is compiled twice per (tiles, hidden-tiles) pair, with and
+// without -DSX_F16X3, into its own namespace; sx_flow_run picks the variant per call (`precision`).
+#ifdef SX_F16X3
+#define SX_PREC_NS sx_f16x3
+#else
+#define SX_PREC_NS sx_f32x
+#endif
+namespace SX_PREC_NS {
 #ifndef SX_WAVES_PER_SIMD
 #define SX_WAVES_PER_SIMD 2
 #endif
@@ -85,6 +94,30 @@ struct tile {            // one 32-feature tile of NS x 32 samples, C-fragment o
     f32x16 v[NS];
 };
 
+// fp16 x 3 operand range.  hi + lo holds a value only while |v| <= 65504 (fp16's largest finite number); beyond it the
+// split saturates.  Every UNBOUNDED B operand a lane forms (flow state, gradients, activations other than the
+// tanh / sigmoid family) passes through the tracked make_btile below, which keeps the running max |v| in one register
+// (one v_max3_f32 per register pair); the chunk epilogue turns an overflow into NaN outputs for that sample and raises
+// SX_FLAG_F16_RANGE in the caller's flag word, so an out-of-range input can never come back as a plausible number.
+// (NaN inputs are not counted -- they propagate through the MFMAs by themselves.)  The exact-fp32 variant has no range
+// limit and carries no tracker.
+struct rng_t {
+    uint64_t bad;          // lanes that formed an out-of-range operand: wave-uniform, lives in SGPRs (the pure coupling kernel
+};                         // sits exactly on its 128-VGPR budget: a per-lane running max spilled)
+#define SX_F16_MAX 65504.0f
+__device__ __forceinline__ float rng_max(float m, float a, float b) {
+    return __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)));        // v_max3_f32 m, |a|, |b|
+}
+__device__ __forceinline__ void rng_note(rng_t &rg, float m) {
+#if defined(SX_F16X3) && !defined(SX_NO_RANGE_TRACK)
+    rg.bad |= __builtin_amdgcn_ballot_w64(m > SX_F16_MAX);          // v_cmp + s_or_b64
+#endif
+}
+__device__ __forceinline__ bool rng_bad_sample(const rng_t &rg, int lane) {
+    // the two lane halves hold one sample
+    return ((rg.bad >> (lane & 31)) | (rg.bad >> ((lane & 31) + 32))) & 1ull;
+}
+
 // ---- weights: L2 -> LDS by LDS-DMA, 1 KiB per wave-instruction, lane-linear -----------------------------
 template <int WAVES>
 __device__ __forceinline__ void stage_blob(const float *__restrict__ g, int lds_float_off, uint32_t n_floats) {
@@ -106,6 +139,8 @@ template <int NS>
 using btile = tile<NS>;
 template <int NS>
 __device__ __forceinline__ const btile<NS> &make_btile(const tile<NS> &c) { return c; }
+template <int NS>
+__device__ __forceinline__ const btile<NS> &make_btile(const tile<NS> &c, rng_t &) { return c; }
 
 template <int NS, class F>
 __device__ __forceinline__ void gemm_tile_f(const char *wb, int a_off, const btile<NS> &b, tile<NS> &acc, F &&f) {
@@ -156,9 +191,10 @@ __device__ __forceinline__ uint32_t pk_residual(uint32_t ph, float v0, float v1)
 }
 // C tile (fp32, 16 registers) -> B fragments: k16-step s takes registers 8s..8s+7 (cdna_hip_programming.md §3
 // 'An accumulator tile as the next MFMA's operand'); hi = rtz(v), lo = rtz(v - hi) (v - hi is exact in fp32).
-template <int NS>
-__device__ __forceinline__ btile<NS> make_btile(const tile<NS> &c) {
+template <int NS, bool TRACK>
+__device__ __forceinline__ btile<NS> make_btile_impl(const tile<NS> &c, rng_t *rg) {
     btile<NS> b;
+    [[maybe_unused]] float mx = 0.f;
 #pragma unroll
     for (int n = 0; n < NS; ++n)
 #pragma unroll
@@ -168,6 +204,7 @@ __device__ __forceinline__ btile<NS> make_btile(const tile<NS> &c) {
             for (int q = 0; q < 4; ++q) {
                 const float v0 = c.v[n][8 * s + 2 * q], v1 = c.v[n][8 * s + 2 * q + 1];
                 if (SX_X & 64) { hi[q] = __float_as_uint(v0); lo[q] = __float_as_uint(v1); continue; }
+                if constexpr (TRACK) mx = rng_max(mx, v0, v1);
                 const uint32_t ph = pk_rtz(v0, v1);
                 hi[q] = ph;
                 lo[q] = pk_residual(ph, v0, v1);
@@ -175,8 +212,15 @@ __device__ __forceinline__ btile<NS> make_btile(const tile<NS> &c) {
             b.hi[n][s] = __builtin_bit_cast(h8, hi);
             b.lo[n][s] = __builtin_bit_cast(h8, lo);
         }
+    if constexpr (TRACK) rng_note(*rg, mx);
     return b;
 }
+// bounded operands (tanh / sigmoid-family activations)
+template <int NS>
+__device__ __forceinline__ btile<NS> make_btile(const tile<NS> &c) { return make_btile_impl<NS, false>(c, nullptr); }
+// unbounded operands: tracked
+template <int NS>
+__device__ __forceinline__ btile<NS> make_btile(const tile<NS> &c, rng_t &rg) { return make_btile_impl<NS, true>(c, &rg); }
 template <int NS, class F>
 __device__ __forceinline__ void gemm_tile_f(const char *wb, int a_off, const btile<NS> &b, tile<NS> &acc, F &&f) {
     if (SX_DBG(16)) {
@@ -379,10 +423,10 @@ __device__ __forceinline__ void hidden_body(const btile<NS> (&bsrc)[CT], tile<NS
 
 template <int NS, int NSRC, int HT, int C0, int CT, bool FOLDED>
 __device__ __forceinline__ void hidden_layer(const tile<NS> (&src)[NSRC], tile<NS> (&hid)[HT], const wptr w, int off,
-                                             int act) {
+                                             int act, rng_t &rg) {
     btile<NS> bsrc[CT];          // B operands are formed once and reused by every output tile
 #pragma unroll
-    for (int c = 0; c < CT; ++c) bsrc[c] = make_btile<NS>(src[C0 + c]);
+    for (int c = 0; c < CT; ++c) bsrc[c] = make_btile<NS>(src[C0 + c], rg);
     __builtin_amdgcn_sched_barrier(0);
     hidden_body<NS, HT, CT, FOLDED>(bsrc, hid, w, off, act);
 }
@@ -391,9 +435,9 @@ __device__ __forceinline__ void hidden_layer(const tile<NS> (&src)[NSRC], tile<N
 // FOLDED (the Tanh hot path): no runtime conditionals inside; REV selects (x - sh)*scale vs x*scale + sh.
 template <int NS, int TX, int HT, int C0, int CT, int T0, int TT, bool FOLDED, bool REV>
 __device__ __forceinline__ void coupling_affine(tile<NS> (&xs)[TX], const wptr w, const dstep &st, float (&ldj)[NS],
-                                                prof_t &pf) {
+                                                prof_t &pf, rng_t &rg) {
     tile<NS> hid[HT];
-    hidden_layer<NS, TX, HT, C0, CT, FOLDED>(xs, hid, w, 0, st.act);
+    hidden_layer<NS, TX, HT, C0, CT, FOLDED>(xs, hid, w, 0, st.act, rg);
     SX_STAMP(pf, 3);     // GEMM-1 (+ pipelined activation)
     constexpr int a2 = HT * CT * 1024 + HT * 32;   // pack_linear(W2: 2*TT m-tiles, HT k-tiles)
     constexpr int b2 = a2 + 2 * TT * HT * 1024;
@@ -407,9 +451,14 @@ __device__ __forceinline__ void coupling_affine(tile<NS> (&xs)[TX], const wptr w
             for (int r = 0; r < 16; r += 2) fast_sig2_pair(hid[0].v[n], r);
     }
     btile<NS> bh[HT];
+    // folded tanh: r in (0, 1), bounded; run-time activations (ReLU, ELU, ...) are not
 #pragma unroll
-    for (int m = 0; m + 1 < HT; ++m) bh[m] = make_btile<NS>(hid[m]);
-    if constexpr (!FOLDED || HT == 1) bh[HT - 1] = make_btile<NS>(hid[HT - 1]);
+    for (int m = 0; m + 1 < HT; ++m) {
+        if constexpr (FOLDED) bh[m] = make_btile<NS>(hid[m]);
+        else bh[m] = make_btile<NS>(hid[m], rg);
+    }
+    if constexpr (!FOLDED) bh[HT - 1] = make_btile<NS>(hid[HT - 1], rg);
+    else if constexpr (HT == 1) bh[HT - 1] = make_btile<NS>(hid[HT - 1]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
@@ -464,14 +513,14 @@ __device__ __forceinline__ void coupling_affine(tile<NS> (&xs)[TX], const wptr w
 // activations in `hsrc`; this step evaluates the last hidden layer from them, then the output layer and the affine map.
 template <int NS, int TX, int HT, int T0, int TT, bool REV>
 __device__ __forceinline__ void coupling_affine_deep(tile<NS> (&xs)[TX], const tile<NS> (&hsrc)[HT], const wptr w,
-                                                     const dstep &st, float (&ldj)[NS]) {
+                                                     const dstep &st, float (&ldj)[NS], rng_t &rg) {
     tile<NS> hid[HT];
-    hidden_layer<NS, HT, HT, 0, HT, false>(hsrc, hid, w, 0, st.act);
+    hidden_layer<NS, HT, HT, 0, HT, false>(hsrc, hid, w, 0, st.act, rg);
     constexpr int a2 = HT * HT * 1024 + HT * 32;       // pack_linear(W_out: 2*TT m-tiles, HT k-tiles)
     constexpr int b2 = a2 + 2 * TT * HT * 1024;
     btile<NS> bh[HT];
 #pragma unroll
-    for (int m = 0; m < HT; ++m) bh[m] = make_btile<NS>(hid[m]);
+    for (int m = 0; m < HT; ++m) bh[m] = make_btile<NS>(hid[m], rg);
     __builtin_amdgcn_sched_barrier(0);
     float s[NS];
 #pragma unroll
@@ -503,17 +552,17 @@ __device__ __forceinline__ void coupling_affine_deep(tile<NS> (&xs)[TX], const t
 // one runtime dispatch per step on (activation kind, direction) -> straight-line specialisations
 template <int NS, int TX, int HT, int C0, int CT, int T0, int TT>
 __device__ __forceinline__ void coupling_affine_dispatch(tile<NS> (&xs)[TX], const wptr w, const dstep &st,
-                                                         float (&ldj)[NS], prof_t &pf) {
+                                                         float (&ldj)[NS], prof_t &pf, rng_t &rg) {
 #ifdef SX_ONLY_HOT     // ISA-inspection build: only the specialisation cfg 2's log_prob executes
-    coupling_affine<NS, TX, HT, C0, CT, T0, TT, true, true>(xs, w, st, ldj, pf);
+    coupling_affine<NS, TX, HT, C0, CT, T0, TT, true, true>(xs, w, st, ldj, pf, rg);
     return;
 #endif
     if (st.act == SX_ACT_TANH_FOLDED) {
-        if (st.reverse) coupling_affine<NS, TX, HT, C0, CT, T0, TT, true, true>(xs, w, st, ldj, pf);
-        else coupling_affine<NS, TX, HT, C0, CT, T0, TT, true, false>(xs, w, st, ldj, pf);
+        if (st.reverse) coupling_affine<NS, TX, HT, C0, CT, T0, TT, true, true>(xs, w, st, ldj, pf, rg);
+        else coupling_affine<NS, TX, HT, C0, CT, T0, TT, true, false>(xs, w, st, ldj, pf, rg);
     } else {
-        if (st.reverse) coupling_affine<NS, TX, HT, C0, CT, T0, TT, false, true>(xs, w, st, ldj, pf);
-        else coupling_affine<NS, TX, HT, C0, CT, T0, TT, false, false>(xs, w, st, ldj, pf);
+        if (st.reverse) coupling_affine<NS, TX, HT, C0, CT, T0, TT, false, true>(xs, w, st, ldj, pf, rg);
+        else coupling_affine<NS, TX, HT, C0, CT, T0, TT, false, false>(xs, w, st, ldj, pf, rg);
     }
 }
 
@@ -804,7 +853,7 @@ __device__ __forceinline__ void store_ctile(float *row_base, int off, const f32x
 // [T0,T0+TT) of the data tiles: pruned halves (XT = 2) or dense (any mask; zero weights outside the mask).
 template <int XT, int HT, int C0, int CT, int T0, int TT>
 __device__ __forceinline__ void coupling_affine_bwd(tile<1> (&xs)[2 * XT], const wptr w, float g, float *side_row,
-                                                    int lane) {
+                                                    int lane, rng_t &rg) {
     constexpr int F1 = 0;                                            // forward pack(W1', HT x CT)
     constexpr int F2 = HT * CT * 1024 + HT * 32;                     // forward pack(W2', 2TT x HT)
     constexpr int F2B = F2 + 2 * TT * HT * 1024;                     //   its bias
@@ -820,7 +869,7 @@ __device__ __forceinline__ void coupling_affine_bwd(tile<1> (&xs)[2 * XT], const
     }
     // 1. recompute the conditioner (folded tanh: r = (1 - tanh)/2)
     tile<1> hid[HT];
-    hidden_layer<1, 2 * XT, HT, C0, CT, true>(xs, hid, w, F1, SX_ACT_TANH_FOLDED);
+    hidden_layer<1, 2 * XT, HT, C0, CT, true>(xs, hid, w, F1, SX_ACT_TANH_FOLDED, rg);
 #pragma unroll
     for (int r = 0; r < 16; ++r) hid[HT - 1].v[0][r] = fast_sig2(hid[HT - 1].v[0][r]);
     btile<1> bh[HT];
@@ -859,7 +908,7 @@ __device__ __forceinline__ void coupling_affine_bwd(tile<1> (&xs)[2 * XT], const
         for (int r = 0; r < 16; ++r) dh[m].v[0][r] = 0.f;
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
-        const btile<1> b0 = make_btile<1>(dls[t]), b1 = make_btile<1>(dsh[t]);
+        const btile<1> b0 = make_btile<1>(dls[t], rg), b1 = make_btile<1>(dsh[t], rg);
 #pragma unroll
         for (int m = 0; m < HT; ++m) {
             gemm_tile<1>(w.wb, B2 + (m * 2 * TT + 2 * t) * 1024, b0, dh[m]);
@@ -885,7 +934,7 @@ __device__ __forceinline__ void coupling_affine_bwd(tile<1> (&xs)[2 * XT], const
     {
         btile<1> bd[HT];
 #pragma unroll
-        for (int m = 0; m < HT; ++m) bd[m] = make_btile<1>(dh[m]);
+        for (int m = 0; m < HT; ++m) bd[m] = make_btile<1>(dh[m], rg);
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             tile<1> dz;
@@ -913,6 +962,7 @@ struct flow_kargs {     // everything but the program, by value in the kernarg s
     void *y; float *ldj_out; float *logp_out; double *sum_out; float *mlp_out; const float *row_t; float *side;
     int64_t mlp_out_stride; int64_t n_rows; int mlp_out_dim; int buf_floats; int bf16; int side_width;
     uint32_t *work;     // {next-chunk ticket, finished workgroups}: dynamic chunk hand-out (NULL = static stride)
+    uint32_t *flags;    // caller's error-flag word (SX_FLAG_*; device or host-mapped memory), or NULL
 };
 
 // MODE 0: flow programs (coupling / affine-const steps); MODE 1: + persistent hidden state (MLP programs);
@@ -1024,6 +1074,8 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
 #pragma unroll
         for (int n = 0; n < NS; ++n) ldj[n] = 0.f;
         float ldj_c = 0.f;
+        rng_t rg;                                                    // fp16 x 3 operand range of this chunk's samples
+        rg.bad = 0ull;
         tile<NS> hid[MODE == 1 ? HT : 1];
         constexpr bool LIN = MODE == 2 || MODE == 7 || MODE == 8;    // programs with dense linear layers
         tile<NS> hidp[MODE == 9 ? HT : 1];                           // MODE 9: hidden state kept between deep-conditioner steps
@@ -1058,14 +1110,14 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
             if constexpr (MODE == 5 || MODE == 6) {
                 // pure split-coupling programs (host: validate_and_convert): two straight-line arms, state in place
                 if constexpr (TX >= 2) {
-                    if (st.c0 == 0) coupling_affine<NS, TX, HT, 0, TX / 2, TX / 2, TX / 2, true, MODE == 5>(xs, w, st, ldj, pf);
-                    else coupling_affine<NS, TX, HT, TX / 2, TX / 2, 0, TX / 2, true, MODE == 5>(xs, w, st, ldj, pf);
+                    if (st.c0 == 0) coupling_affine<NS, TX, HT, 0, TX / 2, TX / 2, TX / 2, true, MODE == 5>(xs, w, st, ldj, pf, rg);
+                    else coupling_affine<NS, TX, HT, TX / 2, TX / 2, 0, TX / 2, true, MODE == 5>(xs, w, st, ldj, pf, rg);
                 }
             } else if ((MODE == 7 || MODE == 8) && st.kind == SX_STEP_COUPLING_AFFINE) {
                 // dense linear layers + pure split couplings (cfg 4): the same two arms instead of the general dispatch
                 if constexpr (TX >= 2 && (MODE == 7 || MODE == 8)) {
-                    if (st.c0 == 0) coupling_affine<NS, TX, HT, 0, TX / 2, TX / 2, TX / 2, true, MODE == 7>(xs, w, st, ldj, pf);
-                    else coupling_affine<NS, TX, HT, TX / 2, TX / 2, 0, TX / 2, true, MODE == 7>(xs, w, st, ldj, pf);
+                    if (st.c0 == 0) coupling_affine<NS, TX, HT, 0, TX / 2, TX / 2, TX / 2, true, MODE == 7>(xs, w, st, ldj, pf, rg);
+                    else coupling_affine<NS, TX, HT, TX / 2, TX / 2, 0, TX / 2, true, MODE == 7>(xs, w, st, ldj, pf, rg);
                 }
             } else
             switch (st.kind) {
@@ -1073,21 +1125,21 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     if constexpr (RQ || MODE == 7 || MODE == 8) break;   // spline programs carry no affine couplings (register budget); 7 / 8: handled above
                     if constexpr (TX >= 2) {
                         if (st.ct == TX / 2 && st.c0 == 0 && st.t0 == TX / 2) {          // cond = low tiles
-                            coupling_affine_dispatch<NS, TX, HT, 0, TX / 2, TX / 2, TX / 2>(xs, w, st, ldj, pf);
+                            coupling_affine_dispatch<NS, TX, HT, 0, TX / 2, TX / 2, TX / 2>(xs, w, st, ldj, pf, rg);
                             break;
                         }
                         if (st.ct == TX / 2 && st.c0 == TX / 2 && st.t0 == 0) {          // cond = high tiles
-                            coupling_affine_dispatch<NS, TX, HT, TX / 2, TX / 2, 0, TX / 2>(xs, w, st, ldj, pf);
+                            coupling_affine_dispatch<NS, TX, HT, TX / 2, TX / 2, 0, TX / 2>(xs, w, st, ldj, pf, rg);
                             break;
                         }
                     }
-                    coupling_affine_dispatch<NS, TX, HT, 0, TX, 0, TX>(xs, w, st, ldj, pf);       // dense
+                    coupling_affine_dispatch<NS, TX, HT, 0, TX, 0, TX>(xs, w, st, ldj, pf, rg);       // dense
                     break;
                 case SX_STEP_AFFINE_CONST:
                     if constexpr (MODE != 7 && MODE != 8) affine_const<NS, TX>(xs, w, st, x_tiles, ldj);
                     break;
                 case SX_STEP_MLP_HIDDEN:
-                    if constexpr (MODE == 1) hidden_layer<NS, TX, HT, 0, TX, false>(xs, hid, w, 0, st.act);
+                    if constexpr (MODE == 1) hidden_layer<NS, TX, HT, 0, TX, false>(xs, hid, w, 0, st.act, rg);
                     break;
                 case SX_STEP_CPL_HIDDEN:
                     if constexpr (MODE == 10 && NS == 1) {
@@ -1095,21 +1147,21 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                         // operand) form in rq_bh -- the array the phases use anyway: no extra registers
                         tile<1> hd[HT];
                         if constexpr (TX >= 2) {
-                            if (st.ct == TX / 2 && st.c0 == 0) hidden_layer<1, TX, HT, 0, TX / 2, false>(xs, hd, w, 0, st.act);
-                            else if (st.ct == TX / 2) hidden_layer<1, TX, HT, TX / 2, TX / 2, false>(xs, hd, w, 0, st.act);
-                            else hidden_layer<1, TX, HT, 0, TX, false>(xs, hd, w, 0, st.act);
+                            if (st.ct == TX / 2 && st.c0 == 0) hidden_layer<1, TX, HT, 0, TX / 2, false>(xs, hd, w, 0, st.act, rg);
+                            else if (st.ct == TX / 2) hidden_layer<1, TX, HT, TX / 2, TX / 2, false>(xs, hd, w, 0, st.act, rg);
+                            else hidden_layer<1, TX, HT, 0, TX, false>(xs, hd, w, 0, st.act, rg);
                         } else {
-                            hidden_layer<1, TX, HT, 0, TX, false>(xs, hd, w, 0, st.act);
+                            hidden_layer<1, TX, HT, 0, TX, false>(xs, hd, w, 0, st.act, rg);
                         }
 #pragma unroll
-                        for (int m = 0; m < HT; ++m) rq_bh[m] = make_btile<1>(hd[m]);
+                        for (int m = 0; m < HT; ++m) rq_bh[m] = make_btile<1>(hd[m], rg);
                     }
                     if constexpr (MODE == 9) {
                         if constexpr (TX >= 2) {
-                            if (st.ct == TX / 2 && st.c0 == 0) { hidden_layer<NS, TX, HT, 0, TX / 2, false>(xs, hidp, w, 0, st.act); break; }
-                            if (st.ct == TX / 2 && st.c0 == TX / 2) { hidden_layer<NS, TX, HT, TX / 2, TX / 2, false>(xs, hidp, w, 0, st.act); break; }
+                            if (st.ct == TX / 2 && st.c0 == 0) { hidden_layer<NS, TX, HT, 0, TX / 2, false>(xs, hidp, w, 0, st.act, rg); break; }
+                            if (st.ct == TX / 2 && st.c0 == TX / 2) { hidden_layer<NS, TX, HT, TX / 2, TX / 2, false>(xs, hidp, w, 0, st.act, rg); break; }
                         }
-                        hidden_layer<NS, TX, HT, 0, TX, false>(xs, hidp, w, 0, st.act);
+                        hidden_layer<NS, TX, HT, 0, TX, false>(xs, hidp, w, 0, st.act, rg);
                     }
                     break;
                 case SX_STEP_CPL_HIDDEN2:
@@ -1117,11 +1169,11 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                         tile<1> hd[HT];
                         hidden_body<1, HT, HT, false>(rq_bh, hd, w, 0, st.act);
 #pragma unroll
-                        for (int m = 0; m < HT; ++m) rq_bh[m] = make_btile<1>(hd[m]);
+                        for (int m = 0; m < HT; ++m) rq_bh[m] = make_btile<1>(hd[m], rg);
                     }
                     if constexpr (MODE == 9) {
                         tile<NS> nh[HT];
-                        hidden_layer<NS, HT, HT, 0, HT, false>(hidp, nh, w, 0, st.act);
+                        hidden_layer<NS, HT, HT, 0, HT, false>(hidp, nh, w, 0, st.act, rg);
 #pragma unroll
                         for (int m = 0; m < HT; ++m) hidp[m] = nh[m];
                     }
@@ -1130,24 +1182,24 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     if constexpr (MODE == 9) {
                         if constexpr (TX >= 2) {
                             if (st.tt == TX / 2 && st.t0 == TX / 2) {
-                                if (st.reverse) coupling_affine_deep<NS, TX, HT, TX / 2, TX / 2, true>(xs, hidp, w, st, ldj);
-                                else coupling_affine_deep<NS, TX, HT, TX / 2, TX / 2, false>(xs, hidp, w, st, ldj);
+                                if (st.reverse) coupling_affine_deep<NS, TX, HT, TX / 2, TX / 2, true>(xs, hidp, w, st, ldj, rg);
+                                else coupling_affine_deep<NS, TX, HT, TX / 2, TX / 2, false>(xs, hidp, w, st, ldj, rg);
                                 break;
                             }
                             if (st.tt == TX / 2 && st.t0 == 0) {
-                                if (st.reverse) coupling_affine_deep<NS, TX, HT, 0, TX / 2, true>(xs, hidp, w, st, ldj);
-                                else coupling_affine_deep<NS, TX, HT, 0, TX / 2, false>(xs, hidp, w, st, ldj);
+                                if (st.reverse) coupling_affine_deep<NS, TX, HT, 0, TX / 2, true>(xs, hidp, w, st, ldj, rg);
+                                else coupling_affine_deep<NS, TX, HT, 0, TX / 2, false>(xs, hidp, w, st, ldj, rg);
                                 break;
                             }
                         }
-                        if (st.reverse) coupling_affine_deep<NS, TX, HT, 0, TX, true>(xs, hidp, w, st, ldj);
-                        else coupling_affine_deep<NS, TX, HT, 0, TX, false>(xs, hidp, w, st, ldj);
+                        if (st.reverse) coupling_affine_deep<NS, TX, HT, 0, TX, true>(xs, hidp, w, st, ldj, rg);
+                        else coupling_affine_deep<NS, TX, HT, 0, TX, false>(xs, hidp, w, st, ldj, rg);
                     }
                     break;
                 case SX_STEP_MLP_HIDDEN2:
                     if constexpr (MODE == 1) {
                         tile<NS> nh[HT];
-                        hidden_layer<NS, HT, HT, 0, HT, false>(hid, nh, w, 0, st.act);
+                        hidden_layer<NS, HT, HT, 0, HT, false>(hid, nh, w, 0, st.act, rg);
 #pragma unroll
                         for (int m = 0; m < HT; ++m) hid[m] = nh[m];
                     }
@@ -1156,7 +1208,18 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     if constexpr (MODE == 1) {
                         tile<NS> acc = load_cfrag<NS>(w.cb, HT * 1024);
 #pragma unroll
-                        for (int c = 0; c < HT; ++c) gemm_tile<NS>(w.wb, c * 1024, make_btile<NS>(hid[c]), acc);
+                        for (int c = 0; c < HT; ++c) gemm_tile<NS>(w.wb, c * 1024, make_btile<NS>(hid[c], rg), acc);
+#ifdef SX_F16X3
+                        if (rg.bad) {   // a row whose operands left the fp16 x 3 range is returned as NaN and flagged
+                            if (rng_bad_sample(rg, lane)) {
+#pragma unroll
+                                for (int n = 0; n < NS; ++n)
+#pragma unroll
+                                    for (int r = 0; r < 16; ++r) acc.v[n][r] = __builtin_nanf("");
+                                if (k.flags != nullptr) __hip_atomic_fetch_or(k.flags, SX_FLAG_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            }
+                        }
+#endif
 #pragma unroll
                         for (int n = 0; n < NS; ++n) {
                             if (row[n] < n_rows) {
@@ -1186,7 +1249,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     if constexpr (LIN) {
                         btile<NS> bx[TX];
 #pragma unroll
-                        for (int c = 0; c < TX; ++c) bx[c] = make_btile<NS>(xs[c]);
+                        for (int c = 0; c < TX; ++c) bx[c] = make_btile<NS>(xs[c], rg);
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int m = 0; m < TX; ++m) {
@@ -1208,11 +1271,11 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                         const float gg = k.row_t[lrow[0]];
                         float *srow = row[0] < n_rows ? k.side + ((int64_t)st.tt * ((n_rows + 31) >> 5) + (row[0] >> 5)) * (k.side_width * 32) + (row[0] & 31) : nullptr;
                         if constexpr (XT == 2) {
-                            if (st.ct == 1 && st.c0 == 0) coupling_affine_bwd<2, HT, 0, 1, 1, 1>(xs, w, gg, srow, lane);
-                            else if (st.ct == 1) coupling_affine_bwd<2, HT, 1, 1, 0, 1>(xs, w, gg, srow, lane);
-                            else coupling_affine_bwd<2, HT, 0, 2, 0, 2>(xs, w, gg, srow, lane);
+                            if (st.ct == 1 && st.c0 == 0) coupling_affine_bwd<2, HT, 0, 1, 1, 1>(xs, w, gg, srow, lane, rg);
+                            else if (st.ct == 1) coupling_affine_bwd<2, HT, 1, 1, 0, 1>(xs, w, gg, srow, lane, rg);
+                            else coupling_affine_bwd<2, HT, 0, 2, 0, 2>(xs, w, gg, srow, lane, rg);
                         } else {
-                            coupling_affine_bwd<1, HT, 0, 1, 0, 1>(xs, w, gg, srow, lane);
+                            coupling_affine_bwd<1, HT, 0, 1, 0, 1>(xs, w, gg, srow, lane, rg);
                         }
                     }
                     break;
@@ -1223,11 +1286,11 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                             hidden_body<1, HT, HT, true>(rq_bh, hd, w, 0, st.act);
                         } else
                         if constexpr (TX >= 2) {
-                            if (st.ct == TX / 2 && st.c0 == 0) hidden_layer<1, TX, HT, 0, TX / 2, true>(xs, hd, w, 0, st.act);
-                            else if (st.ct == TX / 2) hidden_layer<1, TX, HT, TX / 2, TX / 2, true>(xs, hd, w, 0, st.act);
-                            else hidden_layer<1, TX, HT, 0, TX, true>(xs, hd, w, 0, st.act);
+                            if (st.ct == TX / 2 && st.c0 == 0) hidden_layer<1, TX, HT, 0, TX / 2, true>(xs, hd, w, 0, st.act, rg);
+                            else if (st.ct == TX / 2) hidden_layer<1, TX, HT, TX / 2, TX / 2, true>(xs, hd, w, 0, st.act, rg);
+                            else hidden_layer<1, TX, HT, 0, TX, true>(xs, hd, w, 0, st.act, rg);
                         } else {
-                            hidden_layer<1, TX, HT, 0, TX, true>(xs, hd, w, 0, st.act);
+                            hidden_layer<1, TX, HT, 0, TX, true>(xs, hd, w, 0, st.act, rg);
                         }
 #pragma unroll
                         for (int r = 0; r < 16; ++r) hd[HT - 1].v[0][r] = fast_sig2(hd[HT - 1].v[0][r]);
@@ -1270,6 +1333,27 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
         }
 
         // ---- epilogue: outputs -----------------------------------------------------------------------------
+#if defined(SX_F16X3) && !defined(SX_NO_POISON)
+        if constexpr (MODE != 1) {
+            // a sample whose GEMM operands left the fp16 x 3 range (|v| > 65504) comes back as NaN, never as a
+            // plausible number, and SX_FLAG_F16_RANGE is raised (the two lane halves hold one sample)
+            if (rg.bad) {
+                if (rng_bad_sample(rg, lane)) {
+#pragma unroll
+                    for (int n = 0; n < NS; ++n) {
+                        ldj[n] = __builtin_nanf("");
+#ifndef SX_NO_POISON_Y
+#pragma unroll
+                        for (int t = 0; t < TX; ++t)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) xs[t].v[n][r] = __builtin_nanf("");
+#endif
+                    }
+                    if (k.flags != nullptr) __hip_atomic_fetch_or(k.flags, SX_FLAG_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
+#endif
 #pragma unroll
         for (int n = 0; n < NS; ++n) {
             if (k.y != nullptr && row[n] < n_rows) {
@@ -1372,19 +1456,21 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
     }
 #endif
     constexpr int NS = SX_NS_FOR(TX);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     flow_kargs k;
     k.blobs = a.blobs; k.x = a.x; k.latent = a.latent; k.in_col = a.in_col; k.out_col = a.out_col; k.y = a.y;
     k.ldj_out = a.ldj_out; k.logp_out = a.logp_out; k.sum_out = a.sum_out; k.mlp_out = a.mlp_out; k.row_t = a.row_t; k.side = a.side;
     k.mlp_out_stride = a.mlp_out_stride; k.n_rows = a.n_rows; k.mlp_out_dim = a.mlp_out_dim;
-    k.buf_floats = a.buf_floats; k.bf16 = a.bf16; k.side_width = a.side_width; k.work = a.work;
+    k.buf_floats = a.buf_floats; k.bf16 = a.bf16; k.side_width = a.side_width; k.work = a.work; k.flags = a.flags;
 #define SX_FL(MD)                                                                                              \
     do {                                                                                                       \
         auto kern = flow_fused_kernel<NS, TX, HT, MD>;                                                         \
-        static int lds_allowed = 48 * 1024;      /* raised once per kernel variant and process, not per launch */ \
-        if (a.lds > lds_allowed) {                                                                             \
+        static int lds_allowed[64];      /* raised once per kernel variant and DEVICE, not per launch */       \
+        if (a.lds > 48 * 1024 && !lds_allowed[dev & 63]) {                                                     \
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             if (e != hipSuccess) { sx_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
-            lds_allowed = 160 * 1024;                                                                          \
+            lds_allowed[dev & 63] = 1;                                                                         \
         }                                                                                                      \
         hipLaunchKernelGGL(kern, dim3(a.grid), dim3(64 * SX_BLOCK_WAVES(TX, MD)), a.lds, a.stream, a.prog, k);                         \
     } while (0)
@@ -1431,3 +1517,5 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
 #endif
     return SX_OK;
 }
+
+}  // namespace SX_PREC_NS

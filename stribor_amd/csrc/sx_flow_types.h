@@ -24,6 +24,7 @@ struct sx_flow_args {
     float *side;
     int side_width;
     uint32_t *work;
+    uint32_t *flags;
 };
 
 
@@ -54,7 +55,7 @@ struct sx_flow_args {
 // workgroups per CU the kernel is compiled for
 #define SX_BLOCKS_FOR(TX, MODE) (SX_WAVES_FOR(TX, MODE) * 4 / SX_BLOCK_WAVES(TX, MODE))
 
-#define SX_DECL_FLOW(T, H) int sx_flow_launch_t##T##h##H(const sx_flow_args &a);
+#define SX_DECL_FLOW(T, H) int sx_flow_launch_f16x3_t##T##h##H(const sx_flow_args &a); int sx_flow_launch_f32x_t##T##h##H(const sx_flow_args &a);
 SX_DECL_FLOW(1, 1) SX_DECL_FLOW(1, 2) SX_DECL_FLOW(1, 4)
 SX_DECL_FLOW(2, 1) SX_DECL_FLOW(2, 2) SX_DECL_FLOW(2, 4)
 SX_DECL_FLOW(4, 1) SX_DECL_FLOW(4, 2) SX_DECL_FLOW(4, 4)

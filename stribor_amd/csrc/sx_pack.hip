@@ -10,14 +10,8 @@
 
 __host__ __device__ static inline int sx_kmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// 0: exact fp32 MFMA fragments; 1: fp16 x 3 split fragments (the library is built for one of them)
-extern "C" int sx_fragment_mode(void) {
-#ifdef SX_F16X3
-    return 1;
-#else
-    return 0;
-#endif
-}
+// the library's default GEMM arithmetic (both are built in; sx_pack_linear / sx_flow_run take `precision`)
+extern "C" int sx_fragment_mode(void) { return SX_GEMM_F16X3; }
 
 extern "C" size_t sx_packed_linear_floats(int32_t m_tiles, int32_t k_tiles) {
     return (size_t)m_tiles * k_tiles * 1024 + (size_t)m_tiles * 32;
@@ -29,7 +23,8 @@ __global__ __launch_bounds__(256) void pack_linear_kernel(const float *__restric
                                                           const int32_t *__restrict__ col_idx, int m_tiles,
                                                           int k_tiles, const float *__restrict__ row_scale,
                                                           const float *__restrict__ bias_scale, float fold_ones,
-                                                          int frag_mode, int transpose, float *__restrict__ dst) {
+                                                          int frag_mode, int transpose, uint32_t *__restrict__ err_flag,
+                                                          float *__restrict__ dst) {
     // transpose: the operand is W^T (row slots index W's columns, column slots index W's rows)
     auto Wat = [&](int r, int c) -> float { return transpose ? W[(int64_t)c * in_dim + r] : W[(int64_t)r * in_dim + c]; };
     const int n_a = m_tiles * k_tiles * 1024;
@@ -55,6 +50,10 @@ __global__ __launch_bounds__(256) void pack_linear_kernel(const float *__restric
                     const int col2 = col_idx[32 * kt + sx_kmap(8 * s16 + j, lane >> 5)];
                     float w = 0.f;
                     if (row >= 0 && col2 >= 0) w = Wat(row, col2) * (row_scale ? row_scale[32 * m + (lane & 31)] : 1.f);
+                    // |w| > 65504 rounds to inf here (and inf - inf below): every product it enters is non-finite, and
+                    // the flag tells the caller why
+                    if (fabsf(w) > 65504.f && err_flag != nullptr)
+                        __hip_atomic_fetch_or(err_flag, SX_FLAG_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     const _Float16 hi = (_Float16)w;
                     const _Float16 lo = (_Float16)(w - (float)hi);
                     const _Float16 pick = part ? lo : hi;
@@ -88,14 +87,15 @@ __global__ __launch_bounds__(256) void pack_linear_kernel(const float *__restric
 extern "C" int sx_pack_linear(const float *W, const float *b, int32_t out_dim, int32_t in_dim,
                               const int32_t *row_idx, const int32_t *col_idx, int32_t m_tiles, int32_t k_tiles,
                               const float *row_scale, const float *bias_scale, float fold_ones, int32_t transpose,
-                              float *dst, void *stream) {
-    const int frag_mode = sx_fragment_mode();
+                              int32_t precision, uint32_t *err_flag, float *dst, void *stream) {
+    SX_REQUIRE(precision == SX_GEMM_F32 || precision == SX_GEMM_F16X3, "sx_pack_linear: unknown precision %d", precision);
+    const int frag_mode = precision;
     SX_REQUIRE(W && row_idx && col_idx && dst, "sx_pack_linear: null pointer");
     SX_REQUIRE(m_tiles > 0 && k_tiles > 0 && out_dim > 0 && in_dim > 0, "sx_pack_linear: bad sizes");
     const int total = (int)sx_packed_linear_floats(m_tiles, k_tiles);
     const int grid = (total + 255) / 256;
     hipLaunchKernelGGL(pack_linear_kernel, dim3(grid > 1024 ? 1024 : grid), dim3(256), 0, sx_stream(stream), W, b,
-                       out_dim, in_dim, row_idx, col_idx, m_tiles, k_tiles, row_scale, bias_scale, fold_ones, frag_mode, transpose, dst);
+                       out_dim, in_dim, row_idx, col_idx, m_tiles, k_tiles, row_scale, bias_scale, fold_ones, frag_mode, transpose, err_flag, dst);
     SX_LAUNCH_CHECK();
     return SX_OK;
 }

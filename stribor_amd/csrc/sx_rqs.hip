@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void rqs_kernel(const void *__restrict__ x, vo
         if (K == 16) {      // wave-uniform: straight-line register path
             bool bad;
             rqs16_eval<INVERSE>(sp + (valid ? lane : 0) * P, xv, left, right, bottom, top, out, ljd, bad);
-            if (valid && bad && err_flag) atomicOr(err_flag, SX_FLAG_RQS_NEG_DISCRIMINANT);
+            if (valid && bad && err_flag) __hip_atomic_fetch_or(err_flag, SX_FLAG_RQS_NEG_DISCRIMINANT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         } else {
         const bool inside = (xv >= lo_in) && (xv <= hi_in);                    // :71 closed interval
         const float xin = inside ? xv : lo_in;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void rqs_kernel(const void *__restrict__ x, vo
             const float bb = h_b * d_b - dy * q;                                 // :216-219
             const float c = -s_b * dy;                                           // :220
             const float disc = bb * bb - 4.f * a * c;                            // :222
-            if (valid && inside && !(disc >= 0.f) && err_flag) atomicOr(err_flag, SX_FLAG_RQS_NEG_DISCRIMINANT);
+            if (valid && inside && !(disc >= 0.f) && err_flag) __hip_atomic_fetch_or(err_flag, SX_FLAG_RQS_NEG_DISCRIMINANT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             const float root = (2.f * c) / (-bb - sqrtf(disc));                  // :225
             out = root * w_b + cw_b;                                             // :226
             const float tomt = root * (1.f - root);                              // :228

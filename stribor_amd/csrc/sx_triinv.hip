@@ -45,7 +45,10 @@ extern "C" int sx_tri_inverse_f64(const double *T, double *X, int32_t batch, int
     SX_REQUIRE(batch >= 0 && D >= 1 && D <= 128, "sx_tri_inverse_f64: D must be in 1..128");
     if (batch == 0) return SX_OK;
     const size_t lds = (size_t)D * D * sizeof(double);
-    static bool raised = false;                       // once per process: 128 KiB of LDS for D = 128
+    static bool raised_on[64];                        // once per device: 128 KiB of LDS for D = 128
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bool &raised = raised_on[dev & 63];
     if (lds > 48 * 1024 && !raised) {
         hipError_t e = hipFuncSetAttribute((const void *)tri_inverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { sx_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }

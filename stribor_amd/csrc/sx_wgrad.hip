@@ -246,34 +246,28 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     }
 }
 
-// per (device, stream) scratch for the partial tiles (grow-only; calls on one stream are ordered on the device)
-struct part_slot { int dev; hipStream_t stream; float *ptr; size_t floats; };
-static float *partial_scratch(hipStream_t stream, size_t floats) {
-    static std::mutex mu;
-    static std::vector<part_slot> slots;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> g(mu);
-    for (part_slot &w : slots)
-        if (w.dev == dev && w.stream == stream) {
-            if (w.floats >= floats) return w.ptr;
-            if (hipStreamSynchronize(stream) != hipSuccess) return nullptr;      // earlier launches still read it
-            (void)hipFree(w.ptr);
-            w.ptr = nullptr; w.floats = 0;
-            if (hipMalloc(&w.ptr, floats * sizeof(float)) != hipSuccess) return nullptr;
-            w.floats = floats;
-            return w.ptr;
-        }
-    float *p = nullptr;
-    if (hipMalloc(&p, floats * sizeof(float)) != hipSuccess) return nullptr;
-    slots.push_back(part_slot{dev, stream, p, floats});
-    return p;
+// The per-workgroup partial tiles go through a caller-owned scratch (sx_wgrad_scratch_floats): the library keeps no
+// per-stream state and never allocates.
+static void wgrad_shape(int32_t M, int32_t Nc, int32_t layout, int *slabs, int *mt, int *nt) {
+    *slabs = (M + 127) / 128;
+    *mt = *slabs > 1 ? 4 : (M + 31) / 32;
+    *nt = (Nc + 31) / 32;
+}
+extern "C" size_t sx_wgrad_scratch_floats(int32_t M, int32_t Nc, int32_t layout) {
+    if (M < 1 || Nc < 1) return 0;
+    int slabs, mt, nt;
+    wgrad_shape(M, Nc, layout, &slabs, &mt, &nt);
+    return (size_t)256 * (32 * mt * 32 * nt + 32 * mt) * slabs;
+}
+extern "C" size_t sx_wgrad_layer_scratch_floats(int32_t c_tiles, int32_t h_tiles, int32_t t_tiles) {
+    const size_t E2 = (size_t)32 * 2 * t_tiles * 32 * h_tiles + 32 * 2 * t_tiles, E1 = (size_t)32 * h_tiles * 32 * c_tiles + 32 * h_tiles;
+    return 256 * (E2 + E1);
 }
 
 extern "C" int sx_wgrad(const float *A, int64_t lda, int32_t M, const float *B, int64_t ldb, int32_t Nc,
                         int64_t n_rows, int32_t layout, float *dW, int64_t ldw, float *db, const int32_t *row_map,
-                        const int32_t *col_map, void *stream) {
-    SX_REQUIRE(A && B && dW, "sx_wgrad: null pointer");
+                        const int32_t *col_map, float *scratch, void *stream) {
+    SX_REQUIRE(A && B && dW && scratch, "sx_wgrad: null pointer");
     SX_REQUIRE(layout == SX_WGRAD_ROW_MAJOR || layout == SX_WGRAD_ROW_GROUPS, "sx_wgrad: unknown layout %d", layout);
     const bool groups = layout == SX_WGRAD_ROW_GROUPS;
     SX_REQUIRE(M >= 1 && Nc >= 1 && Nc <= 128 && n_rows >= 0 && M <= (groups ? 128 : 2048),
@@ -294,8 +288,7 @@ extern "C" int sx_wgrad(const float *A, int64_t lda, int32_t M, const float *B, 
         constexpr int GMAX = 256;                                                                                  \
         int64_t g = (n_rows + 32 * WB - 1) / (32 * WB);                                                            \
         if (g > GMAX) g = GMAX;                                                                                    \
-        float *part = partial_scratch(st, (size_t)GMAX * E * slabs);                                               \
-        SX_REQUIRE(part != nullptr, "sx_wgrad: cannot allocate the partial-tile scratch");                         \
+        float *part = scratch;                                                                                     \
         hipLaunchKernelGGL((wgrad_kernel<MT_, NT_, WB, GR_>), dim3((int)g, slabs), dim3(64 * WB), 0, st, A, lda,   \
                            B, ldb, n_rows, part, M, Nc);                                                           \
         SX_LAUNCH_CHECK();                                                                                         \
@@ -445,8 +438,8 @@ __global__ __launch_bounds__(64 * WB) void wgrad_layer_kernel(const float *__res
 extern "C" int sx_wgrad_layer(const float *side, int64_t ld, int64_t n_rows, int32_t c_tiles, int32_t h_tiles,
                               int32_t t_tiles, int32_t hidden, float *dW2, int64_t ldw2, float *db2,
                               const int32_t *row_map2, float *dW1, int64_t ldw1, float *db1, const int32_t *col_map1,
-                              void *stream) {
-    SX_REQUIRE(side && dW2 && dW1, "sx_wgrad_layer: null pointer");
+                              float *scratch, void *stream) {
+    SX_REQUIRE(side && dW2 && dW1 && scratch, "sx_wgrad_layer: null pointer");
     SX_REQUIRE(((uintptr_t)side & 15) == 0 && ld % 4 == 0 && ld >= 32 * (c_tiles + 2 * h_tiles + 2 * t_tiles) * 32,
                "sx_wgrad_layer: side must be 16-byte aligned row groups of at least the layer's features");
     SX_REQUIRE(hidden >= 1 && hidden <= 32 * h_tiles && n_rows >= 0, "sx_wgrad_layer: bad hidden width");
@@ -458,8 +451,7 @@ extern "C" int sx_wgrad_layer(const float *side, int64_t ld, int64_t n_rows, int
 #define SX_WL(CT_, HT_, TT_)                                                                                       \
     if (c_tiles == CT_ && h_tiles == HT_ && t_tiles == TT_) {                                                      \
         constexpr int E2 = 32 * 2 * TT_ * 32 * HT_ + 32 * 2 * TT_, E1 = 32 * HT_ * 32 * CT_ + 32 * HT_;             \
-        float *part = partial_scratch(st, (size_t)GMAX * (E2 + E1));                                               \
-        SX_REQUIRE(part != nullptr, "sx_wgrad_layer: cannot allocate the partial-tile scratch");                   \
+        float *part = scratch;                                                                                     \
         float *part1 = part + (size_t)GMAX * E2;                                                                   \
         hipLaunchKernelGGL((wgrad_layer_kernel<CT_, HT_, TT_, WB>), dim3((int)g), dim3(64 * WB), 0, st, side, ld,  \
                            n_rows, part, part1);                                                                   \
@@ -553,8 +545,8 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float *__restr
     }
 }
 
-extern "C" int sx_colsum(const float *A, int64_t lda, int64_t n_rows, int32_t M, float *out, void *stream) {
-    SX_REQUIRE(A && out, "sx_colsum: null pointer");
+extern "C" int sx_colsum(const float *A, int64_t lda, int64_t n_rows, int32_t M, float *out, float *scratch, void *stream) {
+    SX_REQUIRE(A && out && scratch, "sx_colsum: null pointer");
     SX_REQUIRE(M >= 1 && n_rows >= 0 && lda >= M, "sx_colsum: bad shape");
     if (n_rows == 0) return SX_OK;
     hipStream_t st = sx_stream(stream);
@@ -567,8 +559,7 @@ extern "C" int sx_colsum(const float *A, int64_t lda, int64_t n_rows, int32_t M,
     gx = gx < 64 ? 64 : (gx > 256 ? 256 : gx);
     const int64_t slices = (n_rows + (256 / Q) - 1) / (256 / Q);
     if (gx > slices) gx = (int)slices;
-    float *part = partial_scratch(st, (size_t)256 * M);
-    SX_REQUIRE(part != nullptr, "sx_colsum: cannot allocate the partial scratch");
+    float *part = scratch;
     if (vec) hipLaunchKernelGGL(colsum_kernel<true>, dim3(gx, gy), dim3(256), 0, st, A, lda, n_rows, (int)M, Q, part);
     else hipLaunchKernelGGL(colsum_kernel<false>, dim3(gx, gy), dim3(256), 0, st, A, lda, n_rows, (int)M, Q, part);
     SX_LAUNCH_CHECK();

@@ -23,9 +23,8 @@ class UnitNormal(nn.Module):
         assert x.shape[-1] == self.dim
         x2 = x.reshape(-1, self.dim).contiguous()
         out = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device)
-        rc = _hip.lib().sx_unit_normal_logprob(x2.data_ptr(), None, out.data_ptr(), x2.shape[0], self.dim,
-                                               _hip.dtype_code(x2), _hip.stream())
-        _hip.check(rc, 'sx_unit_normal_logprob')
+        _hip.call('sx_unit_normal_logprob', x2, x2.data_ptr(), None, out.data_ptr(), x2.shape[0], self.dim,
+                                               _hip.dtype_code(x2))
         return out.reshape(x.shape[:-1])
 
     def sample(self, sample_shape=()) -> torch.Tensor:

@@ -73,31 +73,35 @@ class _FusedLogProb(torch.autograd.Function):
         # Layout [layer, 32-row group, feature, 32 rows] (coalesced for the kernel's fragment stores and sx_wgrad's loads)
         block = max(32, min(n, _FusedLogProb.SIDE_BYTES // (len(layers) * width * 4)) // 32 * 32)
         side = torch.empty(len(layers), (min(block, n) + 31) // 32, width, 32, dtype=torch.float32, device=dev)
-        st = _hip.stream()
-        for lo in range(0, n, block):
-            m = min(block, n - lo)
-            ng = (m + 31) // 32
-            sd_all = side if ng == side.shape[1] else torch.empty(len(layers), ng, width, 32, dtype=torch.float32, device=dev)
-            gblk, _, _ = bprog.run(z[lo:lo + m], None, True, False, False, row_t=g[lo:lo + m], side=sd_all)
-            if gy is not None:
-                gy[lo:lo + m] = gblk
-            base, ld = sd_all.data_ptr(), width * 32
-            for slot in range(len(layers)):
-                info = layers[slot][1]
-                H = info['hidden']
-                zc, pc = 32 * info['ct'], 64 * info['tt']
-                p0 = base + slot * ng * ld * 4                    # features: z | tanh h | dL/dh_pre | dL/dparams
-                gW1, gb1, gW2, gb2 = views[slot]
-                if info['ct'] == 1 and info['tt'] == 1 and ht <= 64:
-                    # pruned half masks: both gradients of the layer in one pass over its 28 KB row groups
-                    _hip.check(lib.sx_wgrad_layer(p0, ld, m, 1, ht // 32, 1, H, gW2.data_ptr(), gW2.stride(0), gb2.data_ptr(),
-                                                  info['row_map'].data_ptr(), gW1.data_ptr(), gW1.stride(0), gb1.data_ptr(),
-                                                  info['col_map'].data_ptr(), st), 'sx_wgrad_layer')
-                    continue
-                _hip.check(lib.sx_wgrad(p0 + 128 * (zc + 2 * ht), ld, pc, p0 + 128 * zc, ld, H, m, _hip.WGRAD_ROW_GROUPS, gW2.data_ptr(),
-                                        gW2.stride(0), gb2.data_ptr(), info['row_map'].data_ptr(), None, st), 'sx_wgrad')
-                _hip.check(lib.sx_wgrad(p0 + 128 * (zc + ht), ld, H, p0, ld, zc, m, _hip.WGRAD_ROW_GROUPS, gW1.data_ptr(),
-                                        gW1.stride(0), gb1.data_ptr(), None, info['col_map'].data_ptr(), st), 'sx_wgrad')
+        with _hip.device_of(z):
+            st = _hip.stream()
+            for lo in range(0, n, block):
+                m = min(block, n - lo)
+                ng = (m + 31) // 32
+                sd_all = side if ng == side.shape[1] else torch.empty(len(layers), ng, width, 32, dtype=torch.float32, device=dev)
+                gblk, _, _ = bprog.run(z[lo:lo + m], None, True, False, False, row_t=g[lo:lo + m], side=sd_all)
+                if gy is not None:
+                    gy[lo:lo + m] = gblk
+                base, ld = sd_all.data_ptr(), width * 32
+                for slot in range(len(layers)):
+                    info = layers[slot][1]
+                    H = info['hidden']
+                    zc, pc = 32 * info['ct'], 64 * info['tt']
+                    p0 = base + slot * ng * ld * 4                    # features: z | tanh h | dL/dh_pre | dL/dparams
+                    gW1, gb1, gW2, gb2 = views[slot]
+                    if info['ct'] == 1 and info['tt'] == 1 and ht <= 64:
+                        # pruned half masks: both gradients of the layer in one pass over its 28 KB row groups
+                        sc = _hip.scratch(dev, lib.sx_wgrad_layer_scratch_floats(1, ht // 32, 1))
+                        _hip.check(lib.sx_wgrad_layer(p0, ld, m, 1, ht // 32, 1, H, gW2.data_ptr(), gW2.stride(0), gb2.data_ptr(),
+                                                      info['row_map'].data_ptr(), gW1.data_ptr(), gW1.stride(0), gb1.data_ptr(),
+                                                      info['col_map'].data_ptr(), sc.data_ptr(), st), 'sx_wgrad_layer')
+                        continue
+                    sc = _hip.scratch(dev, max(lib.sx_wgrad_scratch_floats(pc, H, _hip.WGRAD_ROW_GROUPS),
+                                               lib.sx_wgrad_scratch_floats(H, zc, _hip.WGRAD_ROW_GROUPS)))
+                    _hip.check(lib.sx_wgrad(p0 + 128 * (zc + 2 * ht), ld, pc, p0 + 128 * zc, ld, H, m, _hip.WGRAD_ROW_GROUPS, gW2.data_ptr(),
+                                            gW2.stride(0), gb2.data_ptr(), info['row_map'].data_ptr(), None, sc.data_ptr(), st), 'sx_wgrad')
+                    _hip.check(lib.sx_wgrad(p0 + 128 * (zc + ht), ld, H, p0, ld, zc, m, _hip.WGRAD_ROW_GROUPS, gW1.data_ptr(),
+                                            gW1.stride(0), gb1.data_ptr(), None, info['col_map'].data_ptr(), sc.data_ptr(), st), 'sx_wgrad')
         out = [grads.get(id(p_)) for p_ in flow._grad_params()]
         return (None, gy if ctx.need_input_grad else None, *out)
 
@@ -399,9 +403,8 @@ class NormalizingFlow(Transform):
             x2, lead = flatten_rows(x)
             ldj = acc.reshape(-1).to(torch.float32).contiguous() if torch.is_tensor(acc) else None
             out = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device)
-            rc = _hip.lib().sx_unit_normal_logprob(x2.data_ptr(), _hip.ptr(ldj), out.data_ptr(), x2.shape[0],
-                                                   x2.shape[1], _hip.dtype_code(x2), _hip.stream())
-            _hip.check(rc, 'sx_unit_normal_logprob')
+            _hip.call('sx_unit_normal_logprob', x2, x2.data_ptr(), _hip.ptr(ldj), out.data_ptr(), x2.shape[0],
+                                                   x2.shape[1], _hip.dtype_code(x2))
             return out.reshape(*lead, 1)
         return self.base_dist.log_prob(x).unsqueeze(-1) + acc      # foreign base density: torch ops
 
@@ -416,7 +419,7 @@ class NormalizingFlow(Transform):
             if r is not None:
                 return out
         lp = self.log_prob(y, latent=latent).reshape(-1).contiguous()
-        _hip.check(_hip.lib().sx_sum_f64(lp.data_ptr(), lp.numel(), out.data_ptr(), _hip.stream()), 'sx_sum_f64')
+        _hip.call('sx_sum_f64', lp, lp.data_ptr(), lp.numel(), out.data_ptr())
         return out
 
     def sample(self, num_samples: Union[Tuple[int], int], *, rsample: bool = False, **kwargs):

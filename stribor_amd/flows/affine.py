@@ -22,10 +22,9 @@ def run_affine_kernel(x2, params, params_stride, live_idx, live_start, n_live, r
     n, d = x2.shape
     y = torch.empty_like(x2) if want_y else torch.empty_like(x2)     # the kernel always writes y
     ldj = torch.empty(n, dtype=torch.float32, device=x2.device) if want_ldj else None
-    rc = _hip.lib().sx_affine_coupling(x2.data_ptr(), y.data_ptr(), _hip.ptr(ldj), params.data_ptr(), params_stride,
+    _hip.call('sx_affine_coupling', x2, x2.data_ptr(), y.data_ptr(), _hip.ptr(ldj), params.data_ptr(), params_stride,
                                        _hip.ptr(live_idx), live_start, n_live, n, d, _hip.dtype_code(x2),
-                                       int(reverse), 0, float(ldj_scale), _hip.stream())
-    _hip.check(rc, 'sx_affine_coupling')
+                                       int(reverse), 0, float(ldj_scale))
     return y, ldj
 
 
@@ -50,10 +49,9 @@ class AffineCouplingOp(torch.autograd.Function):
         gldj = (torch.zeros(n, device=x2.device) if gldj is None else gldj).to(torch.float32).contiguous()
         gx = gy.clone()
         gparams = torch.empty_like(params)
-        rc = _hip.lib().sx_affine_coupling_bwd(x2.data_ptr(), gy.data_ptr(), gldj.data_ptr(), params.data_ptr(),
+        _hip.call('sx_affine_coupling_bwd', x2, x2.data_ptr(), gy.data_ptr(), gldj.data_ptr(), params.data_ptr(),
                                                params.stride(0), gx.data_ptr(), gparams.data_ptr(), _hip.ptr(live_idx),
-                                               live_start, n_live, n, d, int(reverse), ldj_scale, _hip.stream())
-        _hip.check(rc, 'sx_affine_coupling_bwd')
+                                               live_start, n_live, n, d, int(reverse), ldj_scale)
         return gx, gparams, None, None, None, None, None
 
 

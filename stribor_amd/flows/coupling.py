@@ -386,11 +386,10 @@ class ContinuousAffineCoupling(Transform):
         for p in progs:
             p.run(x2, lat2, mlp_out=params)
         tscale = self._time_scales(d, live, x.device)
-        rc = _hip.lib().sx_time_affine_coupling(x2.data_ptr(), y.data_ptr(), _hip.ptr(ldj), params.data_ptr(),
+        _hip.call('sx_time_affine_coupling', x2, x2.data_ptr(), y.data_ptr(), _hip.ptr(ldj), params.data_ptr(),
                                                 params.stride(0), t2.data_ptr(), _hip.ptr(tscale), self.time_net.kind,
                                                 _hip.ptr(live_idx), live_start, len(live), n, d, _hip.dtype_code(x2),
-                                                int(reverse), 0, float(ldj_scale), _hip.stream())
-        _hip.check(rc, 'sx_time_affine_coupling')
+                                                int(reverse), 0, float(ldj_scale))
         return y.reshape(*lead, d), (None if ldj is None else ldj.reshape(*lead, 1))
 
     # ---- reference method set (coupling.py:159-213) ----------------------------------------------------------------

@@ -68,8 +68,7 @@ class TriInverse(torch.autograd.Function):
         T = T.contiguous()
         X = torch.empty_like(T)
         k, D = T.shape[0], T.shape[-1]
-        _hip.check(_hip.lib().sx_tri_inverse_f64(T.data_ptr(), X.data_ptr(), k, D, int(lower), int(unit), _hip.stream()),
-                   'sx_tri_inverse_f64')
+        _hip.call('sx_tri_inverse_f64', T, T.data_ptr(), X.data_ptr(), k, D, int(lower), int(unit))
         ctx.save_for_backward(X)
         return X
 

@@ -22,9 +22,8 @@ def _gather_columns(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     x2, lead = flatten_rows(x)
     y = torch.empty_like(x2)
     idx = idx.to(device=x.device, dtype=torch.int32)
-    rc = _hip.lib().sx_permute(x2.data_ptr(), y.data_ptr(), idx.data_ptr(), x2.shape[0], x2.shape[1],
-                               x2.element_size(), _hip.stream())
-    _hip.check(rc, 'sx_permute')
+    _hip.call('sx_permute', x2, x2.data_ptr(), y.data_ptr(), idx.data_ptr(), x2.shape[0], x2.shape[1],
+                               x2.element_size())
     return y.reshape(*lead, x2.shape[1])
 
 

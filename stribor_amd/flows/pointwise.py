@@ -24,9 +24,8 @@ def run_pointwise(x, kind, param=0.0, want_y=True, want_ldj=False, want_ldiag=Fa
     y = torch.empty_like(x2) if want_y else None
     ldj = torch.empty(n, dtype=torch.float32, device=x2.device) if want_ldj else None
     ldiag = torch.empty(n, d, dtype=torch.float32, device=x2.device) if want_ldiag else None
-    rc = _hip.lib().sx_pointwise(x2.data_ptr(), _hip.ptr(y), _hip.ptr(ldj), _hip.ptr(ldiag), n, d, _hip.dtype_code(x2),
-                                 kind, float(param), 0, _hip.stream())
-    _hip.check(rc, 'sx_pointwise')
+    _hip.call('sx_pointwise', x2, x2.data_ptr(), _hip.ptr(y), _hip.ptr(ldj), _hip.ptr(ldiag), n, d, _hip.dtype_code(x2),
+                                 kind, float(param), 0)
     return (None if y is None else y.reshape(*lead, d), None if ldj is None else ldj.reshape(*lead, 1),
             None if ldiag is None else ldiag.reshape(*lead, d))
 
@@ -50,9 +49,7 @@ class PointwiseOp(torch.autograd.Function):
         gy = (torch.zeros_like(x2) if gy is None else gy).to(torch.float32).contiguous()
         gl = None if gldj is None else gldj.to(torch.float32).contiguous()
         gx = torch.empty_like(x2)
-        rc = _hip.lib().sx_pointwise_bwd(x2.data_ptr(), gy.data_ptr(), _hip.ptr(gl), gx.data_ptr(), n, d, kind, param,
-                                         _hip.stream())
-        _hip.check(rc, 'sx_pointwise_bwd')
+        _hip.call('sx_pointwise_bwd', x2, x2.data_ptr(), gy.data_ptr(), _hip.ptr(gl), gx.data_ptr(), n, d, kind, param)
         return gx, None, None
 
 

@@ -20,26 +20,10 @@ from ..flow import ElementwiseTransform, flatten_rows
 
 __all__ = ['Spline', 'run_rqs_kernel', 'run_cubic_kernel', 'RQSInverse', 'CubicInverse']
 
-_err_flags = {}
-
-
-def _err_flag(device) -> torch.Tensor:
-    key = str(device)
-    if key not in _err_flags:
-        _err_flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
-    return _err_flags[key]
-
-
 def check_errors(device=None) -> None:
-    """Raise what the reference would have raised for data-dependent spline failures (synchronises)."""
-    for key, flag in list(_err_flags.items()):
-        if device is not None and key != str(device):
-            continue
-        v = int(flag.item())
-        if v:
-            flag.zero_()
-            if v & 1:
-                raise AssertionError('rational_quadratic_spline: negative discriminant in the inverse pass')
+    """Raise what the reference would have raised for data-dependent failures (synchronises): the spline's
+    ``assert (discriminant >= 0).all()`` (rational_quadratic_spline.py:223) -> AssertionError."""
+    _hip.check_errors(device)
 
 
 def run_rqs_kernel(x2, params, params_stride, live_idx, live_start, n_live, n_bins, left, right, bottom, top,
@@ -51,12 +35,10 @@ def run_rqs_kernel(x2, params, params_stride, live_idx, live_start, n_live, n_bi
     y = torch.empty_like(x2)
     ldj = torch.empty(n, dtype=torch.float32, device=x2.device) if want_ldj else None
     ldiag = torch.empty(n, d, dtype=torch.float32, device=x2.device) if want_ldiag else None
-    rc = _hip.lib().sx_rqs_coupling(x2.data_ptr(), y.data_ptr(), _hip.ptr(ldj), _hip.ptr(ldiag), params.data_ptr(),
+    _hip.call('sx_rqs_coupling', x2, x2.data_ptr(), y.data_ptr(), _hip.ptr(ldj), _hip.ptr(ldiag), params.data_ptr(),
                                     params_stride, _hip.ptr(live_idx), live_start, n_live, n_bins, float(left),
                                     float(right), float(bottom), float(top), n, d, _hip.dtype_code(x2),
-                                    int(reverse), 0, float(ldj_scale), _err_flag(x2.device).data_ptr(),
-                                    _hip.stream())
-    _hip.check(rc, 'sx_rqs_coupling')
+                                    int(reverse), 0, float(ldj_scale), _hip.err_flag(x2.device))
     return y, ldj, ldiag
 
 
@@ -86,11 +68,9 @@ class RQSInverse(torch.autograd.Function):
         gldj = (torch.zeros(n, device=x2.device) if gldj is None else gldj).to(torch.float32).contiguous()
         gx = gy.clone()                     # pass-through columns: y = x; the kernel overwrites the live columns
         gparams = torch.empty_like(params)
-        rc = _hip.lib().sx_rqs_inverse_bwd(x2.data_ptr(), gy.data_ptr(), gldj.data_ptr(), params.data_ptr(),
+        _hip.call('sx_rqs_inverse_bwd', x2, x2.data_ptr(), gy.data_ptr(), gldj.data_ptr(), params.data_ptr(),
                                            params.stride(0), gx.data_ptr(), gparams.data_ptr(), _hip.ptr(live_idx),
-                                           live_start, n_live, n_bins, lower, upper, lower, upper, n, d, ldj_scale,
-                                           _hip.stream())
-        _hip.check(rc, 'sx_rqs_inverse_bwd')
+                                           live_start, n_live, n_bins, lower, upper, lower, upper, n, d, ldj_scale)
         return gx, gparams, None, None, None, None, None, None, None
 
 
@@ -103,11 +83,9 @@ def run_cubic_kernel(x2, params, params_stride, live_idx, live_start, n_live, n_
     y = torch.empty_like(x2)
     ldj = torch.empty(n, dtype=torch.float32, device=x2.device) if want_ldj else None
     ldiag = torch.empty(n, d, dtype=torch.float32, device=x2.device) if want_ldiag else None
-    rc = _hip.lib().sx_cubic_coupling(x2.data_ptr(), y.data_ptr(), _hip.ptr(ldj), _hip.ptr(ldiag), params.data_ptr(),
+    _hip.call('sx_cubic_coupling', x2, x2.data_ptr(), y.data_ptr(), _hip.ptr(ldj), _hip.ptr(ldiag), params.data_ptr(),
                                       params_stride, _hip.ptr(live_idx), live_start, n_live, n_bins, float(lower),
-                                      float(upper), n, d, _hip.dtype_code(x2), int(reverse), 0, float(ldj_scale),
-                                      _hip.stream())
-    _hip.check(rc, 'sx_cubic_coupling')
+                                      float(upper), n, d, _hip.dtype_code(x2), int(reverse), 0, float(ldj_scale))
     return y, ldj, ldiag
 
 
@@ -135,10 +113,9 @@ class CubicInverse(torch.autograd.Function):
         gldj = (torch.zeros(n, device=x2.device) if gldj is None else gldj).to(torch.float32).contiguous()
         gx = gy.clone()
         gparams = torch.empty_like(params)
-        rc = _hip.lib().sx_cubic_inverse_bwd(x2.data_ptr(), y.data_ptr(), gy.data_ptr(), gldj.data_ptr(), params.data_ptr(),
+        _hip.call('sx_cubic_inverse_bwd', x2, x2.data_ptr(), y.data_ptr(), gy.data_ptr(), gldj.data_ptr(), params.data_ptr(),
                                              params.stride(0), gx.data_ptr(), gparams.data_ptr(), _hip.ptr(live_idx),
-                                             live_start, n_live, n_bins, lower, upper, n, d, ldj_scale, _hip.stream())
-        _hip.check(rc, 'sx_cubic_inverse_bwd')
+                                             live_start, n_live, n_bins, lower, upper, n, d, ldj_scale)
         return gx, gparams, None, None, None, None, None, None, None
 
 

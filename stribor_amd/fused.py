@@ -116,7 +116,7 @@ class _PackJob:
         self.row_scale = self.bias_scale = None
         self.fold_ones = float(fold_ones)
 
-    def run(self, blobs: torch.Tensor) -> None:
+    def run(self, blobs: torch.Tensor, prec: int = _hip.GEMM_F16X3) -> None:
         dev = blobs.device
         if self.row_idx is None:
             self.row_idx = torch.from_numpy(self.row_idx_host).to(dev)
@@ -130,11 +130,9 @@ class _PackJob:
         if W.dtype != torch.float32 or not W.is_contiguous():
             raise TypeError('stribor_amd: conditioner weights must be contiguous float32')
         out_dim, in_dim = W.shape
-        rc = _hip.lib().sx_pack_linear(W.data_ptr(), _hip.ptr(b), out_dim, in_dim, self.row_idx.data_ptr(),
-                                       self.col_idx.data_ptr(), self.m_tiles, self.k_tiles,
-                                       _hip.ptr(self.row_scale), _hip.ptr(self.bias_scale), self.fold_ones,
-                                       self.transpose, blobs.data_ptr() + 4 * self.dst_off, _hip.stream())
-        _hip.check(rc, 'sx_pack_linear')
+        _hip.call('sx_pack_linear', blobs, W.data_ptr(), _hip.ptr(b), out_dim, in_dim, self.row_idx.data_ptr(),
+                  self.col_idx.data_ptr(), self.m_tiles, self.k_tiles, _hip.ptr(self.row_scale), _hip.ptr(self.bias_scale),
+                  self.fold_ones, self.transpose, prec, _hip.err_flag(dev), blobs.data_ptr() + 4 * self.dst_off)
 
     def params(self):
         return [p for p in (self.W, self.b) if p is not None]
@@ -153,7 +151,7 @@ class _DerivedLinearJob:
         self._dev_idx = None
         self._keep = None
 
-    def run(self, blobs: torch.Tensor) -> None:
+    def run(self, blobs: torch.Tensor, prec: int = _hip.GEMM_F16X3) -> None:
         dev = blobs.device
         W, b = self.fn(dev)
         W = W.to(torch.float32).contiguous()
@@ -163,10 +161,9 @@ class _DerivedLinearJob:
             self._dev_idx = [(torch.from_numpy(r.astype(np.int32)).to(dev), torch.from_numpy(c.astype(np.int32)).to(dev))
                              for (r, c, _, _, _) in self.targets]
         for (ri, ci), (_, _, k_tiles, off, m_tiles) in zip(self._dev_idx, self.targets):
-            rc = _hip.lib().sx_pack_linear(W.data_ptr(), _hip.ptr(b), W.shape[0], W.shape[1], ri.data_ptr(),
-                                           ci.data_ptr(), m_tiles, k_tiles, None, None, 0.0, 0,
-                                           blobs.data_ptr() + 4 * off, _hip.stream())
-            _hip.check(rc, 'sx_pack_linear')
+            _hip.call('sx_pack_linear', blobs, W.data_ptr(), _hip.ptr(b), W.shape[0], W.shape[1], ri.data_ptr(),
+                      ci.data_ptr(), m_tiles, k_tiles, None, None, 0.0, 0, prec, _hip.err_flag(dev),
+                      blobs.data_ptr() + 4 * off)
         if self.ldj_fn is not None:
             blobs[self.ldj_off:self.ldj_off + 1] = self.ldj_fn(dev).reshape(1).to(torch.float32)
 
@@ -182,7 +179,7 @@ class _ConstJob:
         self.gather_host, self.dst_off = gather.astype(np.int64), dst_off
         self.gather = None
 
-    def run(self, blobs: torch.Tensor) -> None:
+    def run(self, blobs: torch.Tensor, prec: int = 0) -> None:
         dev = blobs.device
         if self.gather is None:
             self.gather = torch.from_numpy(self.gather_host).to(dev)
@@ -204,7 +201,7 @@ class _ScalarsJob:
     def __init__(self, values, dst_off: int):
         self.values, self.dst_off = [float(v) for v in values], dst_off
 
-    def run(self, blobs: torch.Tensor) -> None:
+    def run(self, blobs: torch.Tensor, prec: int = 0) -> None:
         blobs[self.dst_off:self.dst_off + len(self.values)] = torch.tensor(self.values, dtype=torch.float32,
                                                                           device=blobs.device)
 
@@ -219,7 +216,7 @@ class _VectorJob:
         self.vec, self.dim, self.gather_host, self.dst_off = vec, dim, gather.astype(np.int64), dst_off
         self.gather = None
 
-    def run(self, blobs: torch.Tensor) -> None:
+    def run(self, blobs: torch.Tensor, prec: int = 0) -> None:
         dev = blobs.device
         if self.gather is None:
             self.gather = torch.from_numpy(self.gather_host).to(dev)
@@ -236,12 +233,19 @@ class CompiledProgram:
         self.prog = prog
         self.device = device
         self.jobs = jobs
-        self.blobs = torch.zeros(max(blob_floats, 256), dtype=torch.float32, device=device)
+        self.blob_floats = max(blob_floats, 256)
+        # weight blobs per GEMM arithmetic (the fragment layouts differ): packed on first use / parameter change
+        self._blobs = {}
+        self._versions = {}
         self.in_col = None if in_col is None else torch.from_numpy(in_col.astype(np.int32)).to(device)
         self.out_col = None if out_col is None else torch.from_numpy(out_col.astype(np.int32)).to(device)
         self.mlp_out_dim = mlp_out_dim
-        self._versions = None
         self._tracked = None
+
+    @property
+    def blobs(self) -> torch.Tensor:
+        """The packed weights of the default arithmetic (introspection / tools)."""
+        return self.blobs_for(_hip.GEMM_F16X3)
 
     # -- parameter tracking ----------------------------------------------------------------------
     def _current_versions(self):
@@ -250,12 +254,25 @@ class CompiledProgram:
             ps = self._tracked = [p for j in self.jobs for p in j.params()]
         return [(p.data_ptr(), p._version) for p in ps]
 
+    def blobs_for(self, prec: int) -> torch.Tensor:
+        """Packed weights for arithmetic `prec`, re-packed when a tracked parameter changed."""
+        blobs = self._blobs.get(prec)
+        if blobs is None:
+            blobs = self._blobs[prec] = torch.zeros(self.blob_floats, dtype=torch.float32, device=self.device)
+        if self.jobs:
+            v = self._current_versions()
+            if v != self._versions.get(prec):
+                for j in self.jobs:
+                    j.run(blobs, prec)
+                self._versions[prec] = v
+        return blobs
+
     def refresh(self) -> None:
-        v = self._current_versions()
-        if v != self._versions:
-            for j in self.jobs:
-                j.run(self.blobs)
-            self._versions = v
+        self.blobs_for(_hip.GEMM_F16X3 if _hip.get_gemm_precision() != 'exact' else _hip.GEMM_F32)
+
+    def share_weights_of(self, other: 'CompiledProgram') -> None:
+        """Chunks of one wide MLP program: same blobs, packed once by the first chunk (which always runs first)."""
+        self._blobs, self._versions, self.jobs = other._blobs, other._versions, []
 
     # -- launch -----------------------------------------------------------------------------------
     def run(self, x: torch.Tensor, latent: Optional[torch.Tensor] = None, want_y: bool = False,
@@ -267,7 +284,7 @@ class CompiledProgram:
         assert x.dim() == 2 and x.shape[1] == self.prog.dim, (x.shape, self.prog.dim)
         if not x.is_contiguous():
             x = x.contiguous()
-        self.refresh()
+        _hip.poll_errors()                  # a data-dependent condition of an EARLIER call surfaces here
         n = x.shape[0]
         if n == 0:        # empty batch: nothing to launch (the reference returns empty tensors too)
             e = lambda *shape, dt=torch.float32: torch.empty(*shape, dtype=dt, device=x.device)
@@ -287,12 +304,33 @@ class CompiledProgram:
             _hip.require_device(row_t, 't')
             row_t = row_t.reshape(-1).to(torch.float32).contiguous()
             assert row_t.numel() == n, (row_t.shape, n)
-        rc = _hip.lib().sx_flow_run(C.byref(self.prog), self.blobs.data_ptr(), x.data_ptr(), _hip.ptr(latent),
-                                    _hip.ptr(self.in_col), _hip.ptr(self.out_col), _hip.ptr(y), _hip.ptr(ldj),
-                                    _hip.ptr(logp), _hip.ptr(sum_out), _hip.ptr(mlp_out), stride,
-                                    self.mlp_out_dim, _hip.ptr(row_t), _hip.ptr(side), n, _hip.dtype_code(x),
-                                    _hip.stream())
-        _hip.check(rc, 'sx_flow_run')
+        mode = _hip.get_gemm_precision()
+        with _hip.device_of(x):                     # the library launches on the CURRENT device's stream
+            work = _hip.work_counters(x.device)
+            flag = _hip.err_flag(x.device)
+
+            def launch(prec):
+                rc = _hip.lib().sx_flow_run(C.byref(self.prog), self.blobs_for(prec).data_ptr(), x.data_ptr(),
+                                            _hip.ptr(latent), _hip.ptr(self.in_col), _hip.ptr(self.out_col), _hip.ptr(y),
+                                            _hip.ptr(ldj), _hip.ptr(logp), _hip.ptr(sum_out), _hip.ptr(mlp_out), stride,
+                                            self.mlp_out_dim, _hip.ptr(row_t), _hip.ptr(side), n, _hip.dtype_code(x),
+                                            prec, work.data_ptr(), flag, _hip.stream())
+                if rc != 0:
+                    work.zero_()                    # a failed launch may leave the ticket pair armed
+                _hip.check(rc, 'sx_flow_run')
+
+            if mode == 'exact':
+                launch(_hip.GEMM_F32)
+            elif mode == 'fast':
+                launch(_hip.GEMM_F16X3)
+            else:                                   # 'auto': never hand back a NaN-poisoned result
+                keep = None if sum_out is None else sum_out.clone()
+                launch(_hip.GEMM_F16X3)
+                torch.cuda.current_stream().synchronize()
+                if _hip.take_flag(x.device, _hip.FLAG_F16_RANGE):
+                    if keep is not None:
+                        sum_out.copy_(keep)
+                    launch(_hip.GEMM_F32)
         return y, ldj, logp
 
     def launch_info(self, n_rows: int) -> Tuple[int, int, int]:

@@ -44,7 +44,7 @@ class BatchLinear(torch.autograd.Function):
         want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         if not (want_w or want_b):
             return gx, None, None
-        lib, st = _hip.lib(), _hip.stream()
+        lib = _hip.lib()
         gy2 = gy if gy.stride(1) == 1 else gy.contiguous()
         out_dim, in_dim = W.shape
         n = x.shape[0]
@@ -52,14 +52,18 @@ class BatchLinear(torch.autograd.Function):
             x2 = x if x.stride(1) == 1 else x.contiguous()
             gW = torch.zeros(out_dim, in_dim, dtype=torch.float32, device=x.device)
             gb = torch.zeros(out_dim, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-            _hip.check(lib.sx_wgrad(gy2.data_ptr(), gy2.stride(0), out_dim, x2.data_ptr(), x2.stride(0), in_dim, n,
-                                    _hip.WGRAD_ROW_MAJOR, gW.data_ptr(), in_dim, _hip.ptr(gb), None, None, st), 'sx_wgrad')
+            with _hip.device_of(x):
+                sc = _hip.scratch(x.device, lib.sx_wgrad_scratch_floats(out_dim, in_dim, _hip.WGRAD_ROW_MAJOR))
+                _hip.call('sx_wgrad', x, gy2.data_ptr(), gy2.stride(0), out_dim, x2.data_ptr(), x2.stride(0), in_dim, n,
+                          _hip.WGRAD_ROW_MAJOR, gW.data_ptr(), in_dim, _hip.ptr(gb), None, None, sc.data_ptr())
             return gx, gW, gb
         if want_w:
             gW = gy.t() @ x
         if want_b:
             gb = torch.zeros(out_dim, dtype=torch.float32, device=x.device)
-            _hip.check(lib.sx_colsum(gy2.data_ptr(), gy2.stride(0), n, out_dim, gb.data_ptr(), st), 'sx_colsum')
+            with _hip.device_of(x):
+                sc = _hip.scratch(x.device, 256 * out_dim)
+                _hip.call('sx_colsum', x, gy2.data_ptr(), gy2.stride(0), n, out_dim, gb.data_ptr(), sc.data_ptr())
         return gx, gW, gb
 
 
@@ -194,5 +198,5 @@ def _chunk_mlp_program(builder: ProgramBuilder, device):
     builder.steps = all_steps
     # the chunks share one set of pack jobs / one blob buffer
     for p in progs[1:]:
-        p.blobs, p.jobs = progs[0].blobs, []
+        p.share_weights_of(progs[0])
     return progs

@@ -450,7 +450,8 @@ def test_wgrad_contracts_row_groups_with_maps(n, M, Nc, width, a0, b0):
     dW, db = dW0.to(DEV), db0.to(DEV)
     rm, cm = row_map.to(DEV), col_map.to(DEV)
     rc = _hip.lib().sx_wgrad(sd[0, a0].data_ptr(), width * 32, M, sd[0, b0].data_ptr(), width * 32, Nc, n,
-                             _hip.WGRAD_ROW_GROUPS, dW.data_ptr(), Nc, db.data_ptr(), rm.data_ptr(), cm.data_ptr(), _hip.stream())
+                             _hip.WGRAD_ROW_GROUPS, dW.data_ptr(), Nc, db.data_ptr(), rm.data_ptr(), cm.data_ptr(),
+                             _hip.scratch(DEV, _hip.lib().sx_wgrad_scratch_floats(M, Nc, _hip.WGRAD_ROW_GROUPS)).data_ptr(), _hip.stream())
     _hip.check(rc, 'sx_wgrad')
     scale = max(1.0, float(n) ** 0.5)
     assert (dW.cpu().double() - wantW).abs().max().item() <= 2e-5 * scale
@@ -489,7 +490,8 @@ def test_wgrad_row_major_layouts(n, M, lda, Nc, ldb):
     A, B = Af.to(DEV), Bf.to(DEV)
     dW, db = torch.zeros(M, Nc, device=DEV), torch.zeros(M, device=DEV)
     rc = _hip.lib().sx_wgrad(A.data_ptr(), lda, M, B.data_ptr(), ldb, Nc, n, _hip.WGRAD_ROW_MAJOR, dW.data_ptr(), Nc,
-                             db.data_ptr(), None, None, _hip.stream())
+                             db.data_ptr(), None, None,
+                             _hip.scratch(DEV, _hip.lib().sx_wgrad_scratch_floats(M, Nc, _hip.WGRAD_ROW_MAJOR)).data_ptr(), _hip.stream())
     _hip.check(rc, 'sx_wgrad')
     scale = max(1.0, float(n) ** 0.5)
     assert (dW.cpu().double() - want).abs().max().item() <= 2e-5 * scale
@@ -541,7 +543,7 @@ def test_colsum_matches_fp64(n, M, lda):
     base = torch.randn(M, generator=g)
     want = base.double() + A[:, :M].double().sum(0)
     Ad, out = A.to(DEV), base.to(DEV)
-    _hip.check(_hip.lib().sx_colsum(Ad.data_ptr(), lda, n, M, out.data_ptr(), _hip.stream()), 'sx_colsum')
+    _hip.check(_hip.lib().sx_colsum(Ad.data_ptr(), lda, n, M, out.data_ptr(), _hip.scratch(DEV, 256 * M).data_ptr(), _hip.stream()), 'sx_colsum')
     assert (out.cpu().double() - want).abs().max().item() <= 2e-6 * max(1.0, float(n) ** 0.5) * 4
 
 

@@ -1,0 +1,202 @@
+"""GPU: the two GEMM arithmetics of the fused kernel and the fp16 x 3 range guard.
+
+'fast' (default): fp16 x 3 split on v_mfma_f32_32x32x16_f16.  Its operands must stay within fp16's range; a sample
+whose flow state / activations leave it comes back as NaN (never as a plausible number) and GemmRangeError is raised
+lazily; weights beyond the range raise the same way.  'exact': v_mfma_f32_32x32x2_f32, no range limit.  'auto':
+re-runs out-of-range calls exactly.  The reference computes in plain fp32 (torch addmm): every mode must either match
+it at the north_star's 1e-5 or raise.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+import flowdesc as fd
+from goldens import Golden
+from producthelp import close, product_flow
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import stribor_oracle as orc
+
+import stribor_amd as st
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(autouse=True)
+def _inference_mode_and_default_precision():
+    old = st.set_gemm_precision('fast')
+    try:
+        with torch.no_grad():
+            yield
+    finally:
+        st.set_gemm_precision(old)
+        try:
+            st.check_errors()            # leave no pending flag behind for the next test
+        except Exception:
+            pass
+
+
+def _flow_and_oracle(desc, dim, seed=0):
+    torch.manual_seed(seed)
+    flow = fd.build_flow(st, desc, dim)
+    spec = fd.flow_spec(desc, {k: v.clone() for k, v in flow.state_dict().items()})
+    return flow.to(DEV), spec
+
+
+def _rel_close(got, want, tol=1e-5):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    err = ((got - want).abs() / want.abs().clamp_min(1.0)).max().item()
+    assert err <= tol, err
+
+
+def test_inputs_beyond_fp16_range():
+    """Inputs of 1e5: exact / auto match the oracle; fast returns NaN for exactly those rows and raises."""
+    desc = fd.cfg2_desc(4, 64, 64)
+    flow, spec = _flow_and_oracle(desc, 64)
+    torch.manual_seed(1)
+    x = torch.randn(777, 64)
+    big = torch.zeros(777, dtype=torch.bool)
+    big[[3, 100, 101, 500, 776]] = True
+    x[3, 5] = 1.0e5                       # a conditioning column of layer 0
+    x[100, 40] = -2.5e5                   # a transformed column of layer 0 (conditions layer 1)
+    x[101] *= 3.0e4                       # whole row around 3e4..1e5
+    x[101, 0] = 9.0e4
+    x[500, 63] = 3.0e5
+    x[776, 31] = 65505.0                  # just beyond the largest finite fp16
+    x[10, 7] = 2.0e4                      # inside the range (also after a few layers' scaling): must stay accurate
+    x[11, 50] = -2.0e4
+    want = orc.flow_log_prob(spec, x)
+    want_z = orc.flow_inverse(spec, x)
+    xd = x.to(DEV)
+
+    st.set_gemm_precision('exact')
+    _rel_close(flow.log_prob(xd), want)
+    _rel_close(flow.inverse(xd), want_z)
+    st.check_errors()
+
+    st.set_gemm_precision('auto')
+    _rel_close(flow.log_prob(xd), want)
+    _rel_close(flow.inverse(xd), want_z)
+    tot = torch.zeros(1, dtype=torch.float64, device=DEV)
+    flow.log_prob_sum(xd, tot)
+    assert abs(tot.item() - want.double().sum().item()) <= 1e-6 * abs(want.double().sum().item())
+    st.check_errors()                     # auto consumed the flag itself
+
+    st.set_gemm_precision('fast')
+    got = flow.log_prob(xd)
+    z = flow.inverse(xd)
+    torch.cuda.synchronize()
+    bad = torch.isnan(got.reshape(-1)).cpu()
+    assert bad[big].all(), 'out-of-range rows must come back as NaN, not as plausible numbers'
+    assert not bad[~big].any()
+    assert torch.isnan(z[big.to(DEV)]).all(dim=1).all() and not torch.isnan(z[~big.to(DEV)]).any()
+    _rel_close(got.cpu()[~big], want[~big])
+    _rel_close(z.cpu()[~big], want_z[~big])
+    with pytest.raises(st.GemmRangeError):
+        st.check_errors()
+    st.check_errors()                     # raised once, then cleared
+    # the lazy form: the NEXT call reports the previous call's condition without any explicit check
+    flow.log_prob(xd)
+    torch.cuda.synchronize()
+    with pytest.raises(st.GemmRangeError):
+        flow.log_prob(xd[:8])
+
+
+def test_weights_beyond_fp16_range():
+    """Weights of 1e5: flagged at pack time in fast mode; exact / auto match the oracle."""
+    desc = fd.cfg2_desc(2, 16, 32)
+    flow, _ = _flow_and_oracle(desc, 16, seed=2)
+    with torch.no_grad():
+        w = flow.transforms[0].transform.latent_net.net[0].weight
+        w[3, 10] = 1.0e5
+        w[7, 12] = -3.0e5
+    spec = fd.flow_spec(desc, {k: v.detach().cpu().clone() for k, v in flow.state_dict().items()})
+    x = torch.randn(300, 16, generator=torch.Generator().manual_seed(3))
+    want = orc.flow_log_prob(spec, x)
+    xd = x.to(DEV)
+    st.set_gemm_precision('exact')
+    _rel_close(flow.log_prob(xd), want)
+    st.set_gemm_precision('auto')
+    _rel_close(flow.log_prob(xd), want)
+    st.check_errors()
+    st.set_gemm_precision('fast')
+    got = flow.log_prob(xd)
+    with pytest.raises(st.GemmRangeError):
+        st.check_errors()
+    assert not torch.isfinite(got).all()          # nothing plausible came back for the rows the weight touches
+
+
+def test_unbounded_activations_and_mlp_program():
+    """ReLU conditioners: hidden activations are unbounded B operands too (tracked); MLP.forward poisons its rows."""
+    torch.manual_seed(4)
+    net = st.net.MLP(8, [16, 16], 6, activation='ReLU').to(DEV)
+    x = torch.randn(64, 8)
+    x[5] *= 3.0e4
+    x[5, 0] = 2.0e5
+    x[9, 2] = 1.0e6
+    ws = [m.weight.detach().cpu() for m in net.net if isinstance(m, torch.nn.Linear)]
+    bs = [m.bias.detach().cpu() for m in net.net if isinstance(m, torch.nn.Linear)]
+    want = orc.mlp_forward({'weights': ws, 'biases': bs, 'activation': 'ReLU'}, x)
+    st.set_gemm_precision('exact')
+    _rel_close(net(x.to(DEV)), want)
+    st.set_gemm_precision('auto')
+    _rel_close(net(x.to(DEV)), want)
+    st.set_gemm_precision('fast')
+    got = net(x.to(DEV)).cpu()
+    bad = torch.isnan(got).any(1)
+    assert bad[9] and bad[5]
+    ok = ~bad
+    _rel_close(got[ok], want[ok])
+    with pytest.raises(st.GemmRangeError):
+        st.check_errors()
+
+
+@pytest.mark.parametrize('fixture,case', [('f3_cfg1', 'cfg1'), ('f4_cfg2', 'cfg2'), ('f7_permute', 'mixed'),
+                                           ('f5_cfg3', 'cfg3'), ('f6_cfg4', 'cfg4')])
+def test_exact_mode_against_golden(fixture, case):
+    """Every kernel variant of the exact-fp32 arithmetic (couplings, splines, dense layers) against the fixtures."""
+    st.set_gemm_precision('exact')
+    g = Golden(fixture)
+    flow = product_flow(g, case)
+    x = g.t(case + '/x').to(DEV)
+    close(flow.log_prob(x), g.t(case + '/log_prob'), rtol=1e-5, atol=1e-4 if case == 'cfg3' else 1e-5)
+    close(flow.inverse(x), g.t(case + '/inverse'), rtol=1e-4, atol=2e-4)
+    close(flow.forward(x), g.t(case + '/forward'), rtol=1e-4, atol=2e-4)
+    st.check_errors()
+
+
+def test_modes_agree_on_ordinary_data_and_switch_freely():
+    """Switching the mode between calls re-packs the weights in the other fragment layout (one program, two blobs)."""
+    desc = fd.cfg2_desc(8, 64, 64)
+    flow, spec = _flow_and_oracle(desc, 64, seed=5)
+    x = torch.randn(2048, 64, generator=torch.Generator().manual_seed(6))
+    want = orc.flow_log_prob(spec, x)
+    xd = x.to(DEV)
+    for mode in ('fast', 'exact', 'fast', 'auto', 'exact'):
+        st.set_gemm_precision(mode)
+        _rel_close(flow.log_prob(xd), want)
+    with torch.no_grad():
+        for p in flow.parameters():
+            p.mul_(1.01)
+    spec = fd.flow_spec(desc, {k: v.detach().cpu().clone() for k, v in flow.state_dict().items()})
+    want = orc.flow_log_prob(spec, x)
+    for mode in ('exact', 'fast'):
+        st.set_gemm_precision(mode)
+        _rel_close(flow.log_prob(xd), want)
+    st.check_errors()
+
+
+def test_second_device_guard():
+    """Tensors on cuda:1 while cuda:0 is current: launches follow the tensors' device."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs')
+    desc = fd.cfg2_desc(2, 16, 32)
+    flow, spec = _flow_and_oracle(desc, 16, seed=8)
+    flow = flow.to('cuda:1')
+    x = torch.randn(100, 16)
+    assert torch.cuda.current_device() == 0
+    _rel_close(flow.log_prob(x.to('cuda:1')), orc.flow_log_prob(spec, x))
+    assert torch.cuda.current_device() == 0

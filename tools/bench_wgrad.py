@@ -33,7 +33,7 @@ def main():
 
             def fn():
                 _hip.check(lib.sx_wgrad(A.data_ptr(), width * 32, M, B.data_ptr(), width * 32, Nc, n, _hip.WGRAD_ROW_GROUPS, dW.data_ptr(), Nc,
-                                        db.data_ptr(), None, None, _hip.stream()), 'sx_wgrad')
+                                        db.data_ptr(), None, None, _hip.scratch(dev, lib.sx_wgrad_scratch_floats(M, Nc, _hip.WGRAD_ROW_GROUPS)).data_ptr(), _hip.stream()), 'sx_wgrad')
             us = time_call(fn)
             gb = n * (M + Nc) * 4 / 1e9
             print(f'n={n:8d} M={M:3d} Nc={Nc:3d}: {us:8.1f} us  {gb / (us * 1e-6) / 1e3:6.2f} TB/s (operand features)')
