@@ -264,7 +264,7 @@ typedef struct sx_step {
     int32_t  t0, tt;      /* transformed / output tiles [t0, t0+tt) (other meanings: see the kinds)   */
     int32_t  reverse;     /* 1: inverse direction ((x-sh)*exp(-ls)), 0: forward               */
     int32_t  act;         /* SX_ACT_* of the hidden layer                                     */
-    uint32_t blob_off;    /* offset of this step's blob in `blobs`, in floats (multiple of 256) */
+    uint32_t blob_off;    /* offset of this step's blob in `blobs`, in floats (multiple of 256, >= 256) */
     uint32_t blob_floats; /* size of the blob in floats (multiple of 256: 1 KiB LDS-DMA pieces) */
     float    ldj_scale;   /* coefficient of this step's sum(log_scale) in the ldj accumulator  */
     float    ldj_const;   /* constant added to the ldj accumulator (AffineLU / MatrixExponential) */
@@ -291,6 +291,9 @@ typedef struct sx_program {
  * Replaces NormalizingFlow.{forward, inverse, forward_and_log_det_jacobian,
  * inverse_and_log_det_jacobian, log_prob} (stribor/flow.py:99-130) and, with a one-step program,
  * Coupling.{forward, inverse, log_det_jacobian} (stribor/flows/coupling.py:69-95).
+ *   blobs    the steps' packed weights (sx_step.blob_off), behind a 1 KiB header: word 0 of the header holds SX_FLAG_*
+ *            bits raised while packing (point sx_pack_linear's err_flag at it and zero it before re-packing); every
+ *            launch ORs it into err_flag, so weights beyond the fp16 x 3 range are reported by each call that uses them
  *   x        [n_rows, dim]  input (dtype)
  *   latent   [n_rows, latent_dim] fp32 or NULL
  *   in_col   int32[x_tiles*32]: state slot -> column of x (-1 = zero pad); NULL if identity_cols

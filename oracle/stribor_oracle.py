@@ -22,7 +22,8 @@ functions over a *flow spec*: a list of dicts, one per transform, holding plain 
     {'kind': 'matrix_exp',      'weight': [D,D], 'diag': [D], 'bias': [D] or None, 'log_time': bool}
     {'kind': 'permute',         'perm': int64[D]}
     {'kind': 'flip'}
-    NET = {'weights': [W0, W1, ...], 'biases': [b0, b1, ...], 'activation': 'Tanh'}
+    NET = {'weights': [W0, W1, ...], 'biases': [b0, b1, ...], 'activation': 'Tanh'}  |  {'module': nn.Module}
+    couplings may carry 'set_data': True (mask over the set axis, flows/coupling.py:49-51)
 
 All ``file:line`` citations are into /root/reference/stribor/.
 """
@@ -79,7 +80,11 @@ def mask_vector(name: str, dim: int) -> Tensor:
 # conditioner MLP                                                               net/mlp.py:48-65
 # ----------------------------------------------------------------------------------------------
 def mlp_forward(net: Dict, z: Tensor) -> Tensor:
-    """Linear -> (act -> Linear)*; weights are torch [out, in].  net/mlp.py:48-58, :65."""
+    """Linear -> (act -> Linear)*; weights are torch [out, in].  net/mlp.py:48-58, :65.
+    A conditioner that is not a stribor MLP (any nn.Module is allowed as latent_net, affine.py:59-67, spline.py:76-87)
+    rides along as {'module': <the torch module on the CPU>} and is simply called."""
+    if 'module' in net:
+        return net['module'](z)
     act = getattr(torch.nn, net.get('activation', 'Tanh'))()         # mlp.py:38-39
     n = len(net['weights'])
     h = z
@@ -94,6 +99,9 @@ def mlp_forward(net: Dict, z: Tensor) -> Tensor:
 # coupling glue                                                           flows/coupling.py:48-95
 # ----------------------------------------------------------------------------------------------
 def _coupling_mask(layer: Dict, x: Tensor) -> Tensor:
+    if layer.get('set_data', False):                                 # coupling.py:49-51: mask over the set axis N
+        *rest, N, D = x.shape
+        return mask_vector(layer['mask'], N).unsqueeze(-1).expand(*rest, N, D).to(x)
     return mask_vector(layer['mask'], x.shape[-1]).to(x).expand_as(x)   # coupling.py:53
 
 
@@ -385,7 +393,7 @@ def rqs_from_layer(layer: Dict, x: Tensor, z: Optional[Tensor], reverse: bool) -
 
 # ----------------------------------------------------------------------------------------------
 # time-conditioned affine coupling                        flows/coupling.py:98-213, net/time_net.py:6-47
-#   {'kind': 'continuous_affine_coupling', 'mask': ..., 'net': NET, 'time_kind': 'identity'|'linear'|'tanh'|'log',
+#   {'kind': 'continuous_affine_coupling', 'mask': ..., 'net': NET, 'time_kind': 'identity'|'linear'|'tanh'|'log'|'fourier'|'fourier_bounded',
 #    'time_scale': [1, out] | None, 'concatenate_time': bool}
 # ----------------------------------------------------------------------------------------------
 def time_embed(layer: Dict, t: Tensor) -> Tensor:
@@ -398,6 +406,10 @@ def time_embed(layer: Dict, t: Tensor) -> Tensor:
         return torch.tanh(sc * t)                                    # time_net.py:30
     if kind == 'log':
         return torch.log(sc.exp() * t + 1)                           # time_net.py:38
+    if kind in ('fourier', 'fourier_bounded'):                       # time_net.py:49-91
+        w, sh = layer['time_weight'], layer['time_shift']
+        scale = F.softmax(w, -1) / 2 if kind == 'fourier_bounded' else w / w.shape[-1]      # :67-71
+        return (scale * torch.sin(sh * t.unsqueeze(-1))).sum(-1)     # :73-78
     raise ValueError(kind)
 
 

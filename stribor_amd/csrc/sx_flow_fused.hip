@@ -28,7 +28,8 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     *mlp_mode = 0;
     for (int i = 0; i < p->n_steps; ++i) {
         const sx_step &s = p->steps[i];
-        SX_REQUIRE(s.blob_off % 256 == 0 && s.blob_floats % 256 == 0, "sx_flow_run: step %d blob not 1 KiB aligned", i);
+        SX_REQUIRE(s.blob_off % 256 == 0 && s.blob_floats % 256 == 0 && s.blob_off >= 256,
+                   "sx_flow_run: step %d blob not 1 KiB aligned behind the 1 KiB header", i);
         SX_REQUIRE(s.kind == SX_STEP_RQS_PHASE || (s.c0 >= 0 && s.ct >= 0 && s.c0 + s.ct <= p->tiles && s.t0 >= 0 && s.tt >= 0),
                    "sx_flow_run: step %d bad tiles", i);
         size_t need = 0;

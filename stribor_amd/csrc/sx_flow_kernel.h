@@ -987,6 +987,12 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
     const unsigned long long pf_t0 = pf.last, pf_w0 = wall_clock64();   // wall_clock64: 100 MHz constant clock
 #endif
 
+    // word 0 of the blob buffer's header: SX_FLAG_* bits raised while the weights were packed (a weight beyond the
+    // fp16 x 3 range packs as inf); every launch that uses such weights reports it
+    if (blockIdx.x == 0 && threadIdx.x == 0 && k.flags != nullptr && k.blobs != nullptr) {
+        const uint32_t wf = reinterpret_cast<const uint32_t *>(k.blobs)[0];
+        if (wf) __hip_atomic_fetch_or(k.flags, wf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     // prologue: first step's weights into buffer 0, first step's descriptor into registers
     int cur = 0;
     dstep st_next = prog.steps[0];

@@ -322,6 +322,16 @@ class NormalizingFlow(Transform):
     def _wants_grad(self, y) -> bool:
         return torch.is_grad_enabled() and (y.requires_grad or any(p.requires_grad for p in self.parameters()))
 
+    def _warn_detached(self, what: str, x) -> None:
+        """The differentiable surface is `log_prob` (all on-path flows), `MLP.forward`, `ContinuousAffineCoupling` and
+        `NeuralFlow`; everything else evaluates WITHOUT a graph.  In the reference every call is differentiable, so a
+        loss built from such a result would train with the flow silently frozen: say so, loudly, once per call site."""
+        if x.requires_grad and torch.is_grad_enabled():
+            import warnings
+            warnings.warn(f'stribor_amd: NormalizingFlow.{what} returns tensors WITHOUT an autograd graph (the input '
+                          f'requires grad); only log_prob is differentiable in this build -- see INTEGRATION.md '
+                          f'"Differentiable surface"', RuntimeWarning, stacklevel=3)
+
     def _run(self, x, reverse: bool, latent, want_y, want_ldj, want_logp, sum_out=None, **kwargs):
         """Returns (y, ldj[..., 1], logp[..., 1]) (None where not requested) via the fused kernel, or None
         when the flow cannot be fused."""
@@ -344,6 +354,7 @@ class NormalizingFlow(Transform):
 
     # ---- reference method set -----------------------------------------------------------------------------
     def forward(self, x, latent=None, **kwargs):
+        self._warn_detached('forward', x)
         r = self._run(x, False, latent, True, False, False, **kwargs)
         if r is not None:
             return r[0]
@@ -353,6 +364,7 @@ class NormalizingFlow(Transform):
         return x
 
     def inverse(self, y, latent=None, **kwargs):
+        self._warn_detached('inverse', y)
         r = self._run(y, True, latent, True, False, False, **kwargs)
         if r is not None:
             return r[0]
@@ -362,6 +374,7 @@ class NormalizingFlow(Transform):
         return y
 
     def forward_and_log_det_jacobian(self, x, latent=None, **kwargs):
+        self._warn_detached('forward_and_log_det_jacobian', x)
         r = self._run(x, False, latent, True, True, False, **kwargs)
         if r is not None:
             return r[0], r[1]
@@ -373,6 +386,7 @@ class NormalizingFlow(Transform):
         return x, acc
 
     def inverse_and_log_det_jacobian(self, y, latent=None, **kwargs):
+        self._warn_detached('inverse_and_log_det_jacobian', y)
         r = self._run(y, True, latent, True, True, False, **kwargs)
         if r is not None:
             return r[0], r[1]
@@ -395,6 +409,12 @@ class NormalizingFlow(Transform):
                 return _FusedLogProb.apply(self, y2, *self._grad_params()).reshape(*lead, 1)
             if self._wants_grad(y) and not kwargs and self._layerwise_autograd_ok():
                 return self._log_prob_layerwise_autograd(y, latent)
+            if self._wants_grad(y) and not getattr(self, '_warned_no_graph', False):
+                import warnings
+                self._warned_no_graph = True
+                warnings.warn('stribor_amd: log_prob of this flow has no backward in this build (a layer outside the '
+                              'differentiable set, or extra keyword arguments): it is evaluated WITHOUT an autograd graph. '
+                              'Wrap inference in torch.no_grad() to silence this.', RuntimeWarning, stacklevel=2)
             r = self._run(y, True, latent, False, False, True, **kwargs)
             if r is not None:
                 return r[2]

@@ -3,6 +3,15 @@
 ``Coupling(transform, mask, set_data=False)`` wraps an elementwise transform whose ``latent_net`` maps the
 masked input (optionally concatenated with ``latent``) to the transform's parameters.
 
+Three execution tiers, fastest first (the first that applies is used; all give the reference's values):
+  1. fused: ``latent_net`` is a ``stribor_amd.net.MLP`` within the fused kernel's tiles (D + latent <= 128 columns,
+     hidden <= 128, n_bins <= 16) -- the layer (or the whole flow it sits in) is ONE launch;
+  2. MLP program + element-wise kernel: same conditioner class, shapes the one-step program cannot hold;
+  3. generic: ANY ``nn.Module`` conditioner (the reference accepts one: flows/affine.py:59-67, flows/spline.py:76-87),
+     any width, any n_bins, ``set_data=True`` -- the conditioner is simply called on ``cat[x * mask, latent]``
+     (coupling.py:61-65; a wide ``net.MLP`` runs its Linear layers as library GEMMs) and the transform, the blend and
+     the masked log-det are one pass of ``sx_affine_coupling`` / ``sx_rqs_coupling`` / ``sx_cubic_coupling``.
+
 * ``Coupling(Affine(latent_net=MLP))`` is ONE launch of the fused MFMA kernel per call: masked GEMM-1,
   tanh, pruned GEMM-2, affine, blend and per-sample log-det all stay in registers; the conditioner runs
   once even for ``*_and_log_det_jacobian`` (the reference runs it twice, quirk Q2).
@@ -28,13 +37,10 @@ __all__ = ['Coupling', 'ContinuousAffineCoupling']
 class Coupling(Transform):
     def __init__(self, transform, mask: str, set_data: bool = False, **kwargs):
         super().__init__()
-        if set_data:
-            raise NotImplementedError('stribor_amd.Coupling: set_data=True (masking over a set axis) is outside '
-                                      'the coupling-flow hot path (SURVEY 8(f))')
         self.transform = transform
         self.mask_name = mask
         self.mask_func = get_mask(mask)                       # raises NotImplementedError like mask.py:20
-        self.set_data = False
+        self.set_data = bool(set_data)                        # coupling.py:49-51: the mask runs over the set axis
         self._masks = {}
         self._masks_epoch = -1
         self._programs = ProgramCache()
@@ -49,13 +55,21 @@ class Coupling(Transform):
         return self._masks[dim]
 
     def _get_mask(self, x: torch.Tensor) -> torch.Tensor:
-        return torch.from_numpy(self.mask_vector(x.shape[-1])).to(x).expand_as(x)     # coupling.py:48-53
+        if self.set_data:                                                              # coupling.py:49-51
+            *rest, N, D = x.shape
+            return torch.from_numpy(self.mask_vector(N)).to(x).unsqueeze(-1).expand(*rest, N, D)
+        return torch.from_numpy(self.mask_vector(x.shape[-1])).to(x).expand_as(x)     # coupling.py:52-53
 
     def _net(self) -> MLP:
+        """The conditioner, when it is this package's MLP (what the fused tiers consume weight by weight)."""
         net = getattr(self.transform, 'latent_net', None)
         if not isinstance(net, MLP):
-            raise NotImplementedError('stribor_amd.Coupling needs a transform with a stribor_amd.net.MLP latent_net')
+            raise NotImplementedError('this coupling\'s conditioner is not a stribor_amd.net.MLP: generic tier')
         return net
+
+    def _has_mlp(self) -> bool:
+        net = getattr(self.transform, 'latent_net', None)
+        return isinstance(net, MLP) and net.fusable()
 
     # ---- affine: one fused single-step program per (direction, width, latent width, device) -----------
     def _affine_program(self, reverse: bool, ldj_scale: float, dim: int, latent_dim: int, device):
@@ -78,7 +92,16 @@ class Coupling(Transform):
         d = x2.shape[1]
         lat2 = None if latent is None else latent.reshape(-1, latent.shape[-1])
         ld = 0 if lat2 is None else lat2.shape[1]
-        if isinstance(self.transform, Affine):
+        from .spline import Spline
+        if not isinstance(self.transform, (Affine, Spline)):
+            raise NotImplementedError(f'Coupling({type(self.transform).__name__}) is not on the hot path')
+        if self.set_data:
+            if x.dim() < 2:
+                raise ValueError('set_data=True needs inputs of shape (..., N, dim)')
+            y, ldj = self._run_set(x2, lat2, x.shape[-2], reverse, want_ldj, ldj_scale)
+        elif not self._has_mlp():
+            y, ldj = self._run_generic(x2, lat2, reverse, want_ldj, ldj_scale)
+        elif isinstance(self.transform, Affine):
             try:
                 prog = self._affine_program(reverse, ldj_scale, d, ld, x.device)
             except NotImplementedError:
@@ -86,13 +109,101 @@ class Coupling(Transform):
             if prog is not None:
                 y, ldj, _ = prog.run(x2, lat2, want_y, want_ldj, False)
             else:
-                y, ldj = self._run_affine_unfused(x2, lat2, reverse, want_ldj, ldj_scale)
+                try:
+                    y, ldj = self._run_affine_unfused(x2, lat2, reverse, want_ldj, ldj_scale)
+                except NotImplementedError:        # wider than the MLP program's tiles
+                    y, ldj = self._run_generic(x2, lat2, reverse, want_ldj, ldj_scale)
         else:
-            from .spline import Spline
-            if not isinstance(self.transform, Spline):
-                raise NotImplementedError(f'Coupling({type(self.transform).__name__}) is not on the hot path')
-            y, ldj = self._run_spline(x2, lat2, reverse, want_ldj, ldj_scale)
+            try:
+                y, ldj = self._run_spline(x2, lat2, reverse, want_ldj, ldj_scale)
+            except NotImplementedError:
+                y, ldj = self._run_generic(x2, lat2, reverse, want_ldj, ldj_scale)
         return (None if y is None else y.reshape(*lead, d)), (None if ldj is None else ldj.reshape(*lead, 1))
+
+    # ---- generic tier: any conditioner module, any width --------------------------------------------------------
+    def _transform_rows(self, x2, params_full, live, reverse, want_ldj, ldj_scale):
+        """The element-wise transform of the `live` columns of [N, D] rows given the conditioner's FULL-width output
+        ([N, 2D] affine: log_scale | shift, affine.py:66; [N, D * P] splines, spline.py:82-86) -> (y, ldj | None)."""
+        from .affine import run_affine_kernel
+        from .spline import Spline, run_cubic_kernel, run_rqs_kernel
+        sp = self.transform
+        n, d = x2.shape
+        dev = x2.device
+        if len(live) == 0:
+            return x2.clone(), (torch.zeros(n, dtype=torch.float32, device=dev) if want_ldj else None)
+        contiguous = np.array_equal(live, np.arange(live[0], live[0] + len(live)))
+        live_idx = None if contiguous else torch.from_numpy(live.astype(np.int32)).to(dev)
+        p = params_full.to(torch.float32)
+        if isinstance(sp, Affine):
+            if p.shape[-1] != 2 * d:
+                raise ValueError(f'latent_net returned {p.shape[-1]} values per row, expected {2 * d}')
+            if len(live) == d:
+                params = p.contiguous()
+            else:                                       # (log_scale | shift) of the transformed columns, adjacent
+                cols = torch.from_numpy(np.concatenate([live, d + live]).astype(np.int64)).to(dev)
+                params = p.index_select(1, cols)
+            return run_affine_kernel(x2, params, params.stride(0), live_idx, int(live[0]), len(live), reverse, True,
+                                     want_ldj, ldj_scale)
+        assert isinstance(sp, Spline)
+        P = sp.params_per_element
+        if p.shape[-1] != d * P:
+            raise ValueError(f'latent_net returned {p.shape[-1]} values per row, expected {d * P}')
+        if contiguous:
+            p = p.contiguous()
+            params, stride = p[:, int(live[0]) * P:], p.stride(0)      # the live block of every row, in place
+        else:
+            cols = torch.from_numpy((live[:, None] * P + np.arange(P)[None, :]).reshape(-1).astype(np.int64)).to(dev)
+            params = p.index_select(1, cols)
+            stride = params.stride(0)
+        if sp.spline_type == 'cubic':
+            y, ldj, _ = run_cubic_kernel(x2, params, stride, live_idx, int(live[0]), len(live), sp.n_bins, sp.lower, sp.upper,
+                                         reverse, want_ldj, False, ldj_scale)
+        else:
+            y, ldj, _ = run_rqs_kernel(x2, params, stride, live_idx, int(live[0]), len(live), sp.n_bins, sp.lower, sp.upper,
+                                       sp.lower, sp.upper, reverse, want_ldj, False, ldj_scale)
+        return y, ldj
+
+    def _run_generic(self, x2, lat2, reverse, want_ldj, ldj_scale):
+        n, d = x2.shape
+        m = self.mask_vector(d)
+        live = np.nonzero(m <= 0.5)[0]
+        if len(live) == 0:
+            return x2.clone(), (torch.zeros(n, dtype=torch.float32, device=x2.device) if want_ldj else None)
+        mask_t = self._programs.get(('mask', d, str(x2.device)),
+                                    lambda: torch.from_numpy(m.astype(np.float32)).to(x2.device))
+        z = x2.to(torch.float32) * mask_t                                              # coupling.py:61
+        if d == 1:
+            z = z * 0                                                                  # coupling.py:62-63
+        if lat2 is not None:
+            z = torch.cat([z, lat2.to(torch.float32)], -1)                             # coupling.py:64-65
+        params = self.transform.latent_net(z)                                          # affine.py:66 / spline.py:82
+        return self._transform_rows(x2, params, live, reverse, want_ldj, ldj_scale)
+
+    # ---- set_data=True: the mask selects ELEMENTS OF THE SET (rows), all columns of a selected row are transformed ------
+    def _run_set(self, x2, lat2, set_size, reverse, want_ldj, ldj_scale):
+        """x2: [B * N, D] rows of B sets of N elements.  mask[n] = 1: element n passes through (and is all its
+        conditioner would see); mask[n] = 0: z = 0 (+ latent), every column transformed (coupling.py:49-51,61,78,95)."""
+        rows, d = x2.shape
+        N = set_size
+        m = self.mask_vector(N)
+        dev = x2.device
+        y = x2.clone()
+        ldj = torch.zeros(rows, dtype=torch.float32, device=dev) if want_ldj else None
+        live_n = np.nonzero(m <= 0.5)[0]
+        if len(live_n) == 0 or rows == 0:
+            return y, ldj
+        sel = self._programs.get(('set-rows', rows, N, str(dev)), lambda: torch.from_numpy(
+            (np.arange(rows // N)[:, None] * N + live_n[None, :]).reshape(-1).astype(np.int64)).to(dev))
+        xt = x2.index_select(0, sel)                                                   # the transformed elements, compact
+        z = torch.zeros(xt.shape[0], d, dtype=torch.float32, device=dev)               # x * mask = 0 on these rows
+        if lat2 is not None:
+            z = torch.cat([z, lat2.index_select(0, sel).to(torch.float32)], -1)
+        params = self.transform.latent_net(z)
+        yt, lt = self._transform_rows(xt, params, np.arange(d), reverse, want_ldj, ldj_scale)
+        y.index_copy_(0, sel, yt)
+        if want_ldj:
+            ldj.index_copy_(0, sel, lt)
+        return y, ldj
 
     # ---- affine, unfused: pruned conditioner (MFMA program) + HBM-bound element-wise kernel -----------------
     def _affine_unfused_program(self, dim: int, latent_dim: int, device):
@@ -172,7 +283,7 @@ class Coupling(Transform):
     # ---- training (autograd): spline couplings, inverse direction --------------------------------------------------
     def _autograd_supported(self) -> bool:
         from .spline import Spline
-        if not isinstance(getattr(self.transform, 'latent_net', None), MLP):
+        if self.set_data or getattr(self.transform, 'latent_net', None) is None:
             return False
         return isinstance(self.transform, (Affine, Spline))
 
@@ -183,7 +294,7 @@ class Coupling(Transform):
         Returns (x_out [N, D], ldj [N])."""
         from .spline import CubicInverse, RQSInverse, Spline
         from .affine import AffineCouplingOp
-        sp, net = self.transform, self._net()
+        sp, net = self.transform, self.transform.latent_net
         is_spline = isinstance(sp, Spline)
         n, d = x2.shape
         m = self.mask_vector(d)
@@ -208,7 +319,10 @@ class Coupling(Transform):
             z = z * 0                                                                # coupling.py:62-63
         if lat2 is not None:
             z = torch.cat([z, lat2], -1)                                             # coupling.py:64-65
-        params = net.forward_autograd(z, rows_t)
+        if isinstance(net, MLP):
+            params = net.forward_autograd(z, rows_t)
+        else:                                                                        # any nn.Module: torch's own graph
+            params = net(z).index_select(1, rows_t)
         if is_spline:
             op = CubicInverse if sp.spline_type == 'cubic' else RQSInverse
             return op.apply(x2, params, live_idx, int(live[0]), len(live), sp.n_bins, sp.lower, sp.upper, 1.0)
@@ -237,9 +351,11 @@ class Coupling(Transform):
 
     # ---- fused-program hooks --------------------------------------------------------------------------------
     def _plan_hidden_width(self):
-        return self._net().hidden_width if isinstance(getattr(self.transform, 'latent_net', None), MLP) else 0
+        return self._net().hidden_width if self._has_mlp() else 0
 
     def _plan_spline(self, builder: ProgramBuilder, reverse: bool, ldj_scale: float) -> bool:
+        if self.set_data:
+            return False
         sp = self.transform
         net = getattr(sp, 'latent_net', None)
         if not isinstance(net, MLP) or net.activation_name != 'Tanh' or sp.n_bins > 16 or sp.spline_type != 'quadratic':
@@ -256,14 +372,14 @@ class Coupling(Transform):
         return True
 
     def _plan_first_mask(self, dim):
-        return self.mask_vector(dim)
+        return None if self.set_data else self.mask_vector(dim)
 
     def _plan(self, builder: ProgramBuilder, reverse: bool, ldj_scale: float) -> bool:
         from .spline import Spline
         if isinstance(self.transform, Spline):
             return self._plan_spline(builder, reverse, ldj_scale)
-        if not isinstance(self.transform, Affine) or not isinstance(getattr(self.transform, 'latent_net', None), MLP):
-            return False
+        if self.set_data or not isinstance(self.transform, Affine) or not self._has_mlp():
+            return False                # generic tier: the flow runs layer by layer
         net = self._net()
         lin = net.linears()
         if lin[0][0].shape[1] != builder.dim + builder.latent_dim or lin[-1][0].shape[0] != 2 * builder.dim:
@@ -292,11 +408,9 @@ class ContinuousAffineCoupling(Transform):
     def __init__(self, latent_net: nn.Module, time_net: nn.Module, mask: str, concatenate_time: Optional[bool] = True,
                  **kwargs):
         super().__init__()
-        if not isinstance(latent_net, MLP):
-            raise NotImplementedError('stribor_amd.ContinuousAffineCoupling needs a stribor_amd.net.MLP latent_net')
-        if not hasattr(time_net, 'kind'):
-            raise NotImplementedError(f'time_net {type(time_net).__name__} is not on the path '
-                                      '(TimeIdentity / TimeLinear / TimeTanh / TimeLog are)')
+        # fast tier: net.MLP conditioner (pruned MFMA program) + an in-kernel time net (TimeIdentity / TimeLinear /
+        # TimeTanh / TimeLog); anything else -- a user-written conditioner, TimeFourier(Bounded), a user-written time
+        # net -- is called as a module and its output multiplied into the parameters before the HIP affine kernel
         self.latent_net = latent_net
         self.time_net = time_net
         self.mask_func = get_mask(mask)
@@ -355,11 +469,21 @@ class ContinuousAffineCoupling(Transform):
             parts.append(t2.reshape(n, 1))                                           # coupling.py:155-156
         lat2 = torch.cat(parts, -1).contiguous() if parts else None
         extra = 0 if lat2 is None else lat2.shape[1]
-        progs, live_idx, live_start, live = self._program(d, extra, x.device)
+        fast = isinstance(self.latent_net, MLP) and self.latent_net._fits_program() and hasattr(self.time_net, 'kind')
+        if fast:
+            try:
+                progs, live_idx, live_start, live = self._program(d, extra, x.device)
+            except NotImplementedError:
+                fast = False
+        if not fast:
+            live = np.nonzero(self.mask_vector(d) <= 0.5)[0]
+            contiguous = len(live) > 0 and np.array_equal(live, np.arange(live[0], live[0] + len(live)))
+            live_idx = None if contiguous else torch.from_numpy(live.astype(np.int32)).to(x.device)
+            live_start = int(live[0]) if len(live) else 0
         needs_graph = torch.is_grad_enabled() and (x.requires_grad or t.requires_grad or
                                                     (latent is not None and latent.requires_grad) or
                                                     any(p.requires_grad for p in self.parameters()))
-        if needs_graph and len(live):
+        if (needs_graph or not fast) and len(live):
             # training: conditioner and time net through torch (library GEMMs / tiny element-wise ops), the affine map and
             # its backward through the HIP op; same values as the kernel path
             from .affine import AffineCouplingOp
@@ -370,8 +494,11 @@ class ContinuousAffineCoupling(Transform):
             if lat2 is not None:
                 z = torch.cat([z, lat2], -1)
             rows = torch.from_numpy(np.concatenate([live, d + live]).astype(np.int64)).to(x.device)
-            params = self.latent_net.forward_autograd(z, rows)
-            emb = self.time_net(t2.reshape(n, 1))                                    # [n, out]
+            if isinstance(self.latent_net, MLP):
+                params = self.latent_net.forward_autograd(z, rows)
+            else:
+                params = self.latent_net(z).index_select(1, rows)                    # coupling.py:194
+            emb = self.time_net(t2.reshape(n, 1))                                    # [n, out]  coupling.py:195
             half = emb.shape[1] // 2
             cols = torch.from_numpy(live.astype(np.int64)).to(x.device) if half == d else torch.zeros(len(live), dtype=torch.long, device=x.device)
             scale = torch.cat([emb[:, :half].index_select(1, cols), emb[:, half:2 * half].index_select(1, cols)], -1)

@@ -146,6 +146,15 @@ class AffineLU(_DenseLinear):
         nn.init.xavier_uniform_(self.log_diag)
         nn.init.xavier_uniform_(self.bias)
 
+    # parameter-level accessors of the reference (D x D tensor ops on the parameters' device, differentiable)
+    @property
+    def L(self):
+        return torch.tril(self.weight, -1) + torch.eye(self.dim).to(self.weight)                     # affine.py:148-150
+
+    @property
+    def U(self):
+        return torch.triu(self.weight, 1) + torch.eye(self.dim).to(self.weight) * self.log_diag.exp()   # affine.py:152-154
+
     def _lu64(self, dev):
         W = self.weight.detach().to(dev, torch.float64)
         eye = torch.eye(self.dim, dtype=torch.float64, device=dev)
@@ -197,8 +206,7 @@ class AffineLU(_DenseLinear):
         return self._run(y, True, True, True, -1.0)
 
     def jacobian(self, x, y=None, **kwargs):
-        A = self._lu64(x.device).to(torch.float32)
-        return A.T.expand(*x.shape[:-1], -1, -1)                             # affine.py:173-179
+        return ((self.L @ self.U).T).to(x.device).expand(*x.shape[:-1], -1, -1)   # affine.py:173-179
 
 
 class MatrixExponential(_DenseLinear):
@@ -223,6 +231,29 @@ class MatrixExponential(_DenseLinear):
 
     def _sources(self):
         return [p for p in (self._weight, self.diag, self.bias) if p is not None]
+
+    # parameter-level accessors of the reference (D x D tensor ops on the parameters' device, differentiable)
+    def lu(self):
+        eye = torch.eye(self.dim).to(self._weight)
+        return torch.tril(self._weight, diagonal=-1) + eye, torch.triu(self._weight) + eye      # affine.py:222-226
+
+    @property
+    def weight(self):
+        L, U = self.lu()
+        W = L @ U
+        return (W * self.diag) @ torch.linalg.inv(W)                                          # affine.py:228-234
+
+    def get_time(self, t, shape):
+        if isinstance(t, Number):
+            t = torch.ones(*shape[:-1], 1, device=self._weight.device) * t                     # affine.py:236-241
+        if self.log_time:
+            t = torch.log1p(t.abs())
+        return t
+
+    def jacobian(self, x, y=None, t=1.0, **kwargs):
+        t = self.get_time(t, x.shape).to(x.device)
+        W = torch.matrix_exp(self.weight.to(x.device) * t.unsqueeze(-1))                      # affine.py:290-299
+        return W.expand(*x.shape[:-1], -1, -1)
 
     def _lu64(self, dev):
         W = self._weight.detach().to(dev, torch.float64)

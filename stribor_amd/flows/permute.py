@@ -59,14 +59,41 @@ class _ColumnShuffle(ElementwiseTransform):
 
 
 class Flip(_ColumnShuffle):
+    """permute.py:11-44.  dims=[-1] (the default, what flows use between couplings) is the `sx_permute` byte gather and
+    a free relabelling inside fused programs; any other axis list moves whole rows around -- `torch.flip`, a plain
+    copy -- and such a flow runs layer by layer."""
+
     def __init__(self, dims: List[int] = [-1]):
         super().__init__()
-        if list(dims) != [-1]:
-            raise NotImplementedError('stribor_amd.Flip: only the feature axis (dims=[-1]) is on the hot path')
         self.dims = list(dims)
+
+    def _feature_only(self) -> bool:
+        return self.dims == [-1]
 
     def _perm(self, dim):
         return torch.arange(dim - 1, -1, -1)
+
+    def forward(self, x, **kwargs):
+        if self._feature_only() or (x.dim() == 1 and self.dims in ([0], [-1])):
+            return super().forward(x, **kwargs)
+        _hip.require_device(x, 'x')
+        return torch.flip(x, self.dims)                                       # permute.py:35
+
+    def inverse(self, y, **kwargs):
+        if self._feature_only() or (y.dim() == 1 and self.dims in ([0], [-1])):
+            return super().inverse(y, **kwargs)
+        _hip.require_device(y, 'y')
+        return torch.flip(y, self.dims)                                       # permute.py:38
+
+    def log_diag_jacobian(self, x, y=None, **kwargs):
+        if self._feature_only():
+            return super().log_diag_jacobian(x, y, **kwargs)
+        return torch.eye(x.shape[-1], device=x.device).flip(self.dims).diag().log().to(x.dtype).expand_as(x)   # permute.py:44
+
+    def _plan(self, builder, reverse, ldj_scale):
+        if not self._feature_only():
+            return False
+        return super()._plan(builder, reverse, ldj_scale)
 
 
 class Permute(_ColumnShuffle):

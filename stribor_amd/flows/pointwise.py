@@ -117,7 +117,7 @@ class ELU(_Pointwise):
     """activations.py:11-63."""
     _fwd, _inv = PW_ELU, PW_ELU_INV
 
-    def __init__(self, **kwargs):
+    def __init__(self, *args, **kwargs):             # the reference's ELU has no __init__ of its own: anything goes
         super().__init__()
 
 

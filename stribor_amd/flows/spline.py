@@ -137,10 +137,13 @@ class Spline(ElementwiseTransform):
             self.width = nn.Parameter(torch.empty(dim, n_bins))                      # spline.py:65-69
             self.height = nn.Parameter(torch.empty(dim, n_bins))
             self.derivative = nn.Parameter(torch.empty(dim, self.derivative_dim))
-            nn.init.xavier_uniform_(self.width)
-            nn.init.xavier_uniform_(self.height)
-            if self.derivative_dim > 0:
-                nn.init.xavier_uniform_(self.derivative)
+            self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.xavier_uniform_(self.width)                                          # spline.py:71-74
+        nn.init.xavier_uniform_(self.height)
+        if self.derivative_dim > 0:
+            nn.init.xavier_uniform_(self.derivative)
 
     # ---- parameters: [rows, D*(3K-1)] in the conditioner's own layout (spline.py:82-86) ----------------
     def _params(self, x2, latent):

@@ -132,7 +132,7 @@ class _PackJob:
         out_dim, in_dim = W.shape
         _hip.call('sx_pack_linear', blobs, W.data_ptr(), _hip.ptr(b), out_dim, in_dim, self.row_idx.data_ptr(),
                   self.col_idx.data_ptr(), self.m_tiles, self.k_tiles, _hip.ptr(self.row_scale), _hip.ptr(self.bias_scale),
-                  self.fold_ones, self.transpose, prec, _hip.err_flag(dev), blobs.data_ptr() + 4 * self.dst_off)
+                  self.fold_ones, self.transpose, prec, blobs.data_ptr(), blobs.data_ptr() + 4 * self.dst_off)
 
     def params(self):
         return [p for p in (self.W, self.b) if p is not None]
@@ -162,7 +162,7 @@ class _DerivedLinearJob:
                              for (r, c, _, _, _) in self.targets]
         for (ri, ci), (_, _, k_tiles, off, m_tiles) in zip(self._dev_idx, self.targets):
             _hip.call('sx_pack_linear', blobs, W.data_ptr(), _hip.ptr(b), W.shape[0], W.shape[1], ri.data_ptr(),
-                      ci.data_ptr(), m_tiles, k_tiles, None, None, 0.0, 0, prec, _hip.err_flag(dev),
+                      ci.data_ptr(), m_tiles, k_tiles, None, None, 0.0, 0, prec, blobs.data_ptr(),
                       blobs.data_ptr() + 4 * off)
         if self.ldj_fn is not None:
             blobs[self.ldj_off:self.ldj_off + 1] = self.ldj_fn(dev).reshape(1).to(torch.float32)
@@ -262,6 +262,8 @@ class CompiledProgram:
         if self.jobs:
             v = self._current_versions()
             if v != self._versions.get(prec):
+                if prec in self._versions:
+                    blobs[:1].zero_()              # header word 0: flags of the previous packing
                 for j in self.jobs:
                     j.run(blobs, prec)
                 self._versions[prec] = v
@@ -356,7 +358,7 @@ class ProgramBuilder:
         self.in_col: Optional[np.ndarray] = None     # set at the first step
         self.steps: List[dict] = []
         self.jobs: List = []
-        self.blob_floats = 0
+        self.blob_floats = 256             # 1 KiB header: word 0 = flags raised while packing (sx_flow_run reports them)
         self.mlp_out_dim = 0
 
     # -- layout ------------------------------------------------------------------------------------

@@ -116,25 +116,26 @@ class MLP(StructureTracked, nn.Module):
     def __init__(self, in_dim: int, hidden_dims: List[int], out_dim: int, activation: Union[str, Callable] = 'Tanh',
                  final_activation: Optional[str] = None, nn_linear_wrapper_func: Optional[Callable] = None, **kwargs):
         super().__init__()
-        if nn_linear_wrapper_func is not None:
-            raise NotImplementedError('stribor_amd.net.MLP: nn_linear_wrapper_func (spectral norm) is used by '
-                                      'IResNet only, which is outside the coupling-flow path')
-        if final_activation is not None:
-            raise NotImplementedError('stribor_amd.net.MLP: final_activation is not used on the coupling-flow path')
         act_name = activation if isinstance(activation, str) else type(activation).__name__
-        if act_name not in _hip.ACT_CODES:
-            raise NotImplementedError(f'activation {act_name!r}; supported: {sorted(_hip.ACT_CODES)}')
+        # activations / wrappers the fused kernel does not know (mlp.py:38-39 takes ANY torch.nn name, mlp.py:41-42 any
+        # nn.Linear wrapper such as spectral norm): the network then runs through its torch layers (library GEMMs)
         self.activation_name = act_name
+        self._wrapped = nn_linear_wrapper_func is not None
+        wrap = nn_linear_wrapper_func or (lambda m: m)
         self.in_dim, self.out_dim = in_dim, out_dim
         widths = [in_dim] + list(hidden_dims) + [out_dim]
-        act = getattr(nn, act_name)()
+        act = getattr(nn, act_name)() if isinstance(activation, str) else activation
         layers: List[nn.Module] = []
         for i in range(len(widths) - 1):
             if i:
                 layers.append(act)                        # keeps the reference's indices 0, 2, 4, ...
-            layers.append(_Linear(widths[i], widths[i + 1]))
+            lin = _Linear(widths[i], widths[i + 1])
+            layers.append(wrap(lin) if i else lin)        # mlp.py:46,50: the first layer is not wrapped
         with torch.no_grad():
             layers[-1].bias.zero_()                       # mlp.py:53
+        self.final_activation_name = final_activation
+        if final_activation is not None:
+            layers.append(getattr(nn, final_activation)())   # mlp.py:55-56
         self.net = _Sequential(*layers)
         self._programs = ProgramCache()
 
@@ -156,6 +157,9 @@ class MLP(StructureTracked, nn.Module):
         """The network on [N, in] rows with a graph: torch activations, `batch_linear` layers.  `rows` selects the
         output rows of the last layer (a coupling only needs the parameters of its transformed columns)."""
         layers = list(self.net)
+        tail = []
+        if self.final_activation_name is not None:                            # mlp.py:55-56
+            layers, tail = layers[:-1], layers[-1:]
         h = x2
         for layer in layers[:-1]:
             h = batch_linear(h, layer.weight, layer.bias) if isinstance(layer, nn.Linear) else layer(h)
@@ -163,7 +167,10 @@ class MLP(StructureTracked, nn.Module):
         W, b = last.weight, last.bias
         if rows is not None:
             W, b = SelectRows.apply(W, rows), SelectRows.apply(b, rows)       # rows are distinct
-        return batch_linear(h, W, b)
+        h = batch_linear(h, W, b)
+        for layer in tail:
+            h = layer(h)
+        return h
 
     # -- standalone evaluation ---------------------------------------------------------------------------
     def _program(self, device):
@@ -173,12 +180,34 @@ class MLP(StructureTracked, nn.Module):
             return _chunk_mlp_program(b, device)
         return self._programs.get(str(device), build)
 
+    def fusable(self) -> bool:
+        """The planner can consume this network weight by weight: plain Linear layers, an activation the kernel knows,
+        no final activation."""
+        return (not self._wrapped and self.final_activation_name is None and self.activation_name in _hip.ACT_CODES
+                and len(self.linears()) >= 2)
+
+    def _fits_program(self) -> bool:
+        """One launch of the fused MFMA kernel holds inputs and hidden layers of up to 128 columns."""
+        return self.fusable() and self.in_dim <= 128 and self.hidden_width <= 128
+
     def forward(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
         _hip.require_device(x, 'MLP input')
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1]).to(torch.float32).contiguous()
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return self.forward_autograd(x2).reshape(*lead, self.out_dim)      # differentiable like the reference's
+        progs = None
+        if self._fits_program():
+            try:
+                progs = self._program(x.device)
+            except NotImplementedError:
+                progs = None
+        if progs is None:
+            # wider than the fused kernel's tiles (or a final activation): the Linear layers are plain library GEMMs
+            # (rocBLAS / hipBLASLt through torch), as the kernel playbook prescribes for plain GEMMs
+            return self.net(x2).reshape(*lead, self.out_dim)
         out = torch.empty(x2.shape[0], self.out_dim, dtype=torch.float32, device=x.device)
-        for prog in self._program(x.device):
+        for prog in progs:
             prog.run(x2, mlp_out=out)
         return out.reshape(*lead, self.out_dim)
 

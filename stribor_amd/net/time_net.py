@@ -2,7 +2,7 @@
 
 Inside ``ContinuousAffineCoupling`` they are evaluated by the HIP kernel (``sx_time_affine_coupling`` takes the kind and
 the scale vector); ``forward`` / ``derivative`` here serve stand-alone calls with plain tensor ops on the caller's
-device.  ``TimeFourier`` is not on the path and raises.
+device.  ``TimeFourier`` / ``TimeFourierBounded`` (and any user-written time net) have no in-kernel form: see their docstring.
 """
 import torch
 import torch.nn as nn
@@ -61,8 +61,34 @@ class TimeLog(TimeLinear):
 
 
 class TimeFourier(nn.Module):
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError('stribor_amd.net.TimeFourier is outside the coupling-flow path')
+    """Fourier features sum_k x_k sin(s_k t) (time_net.py:49-82).  No `kind`: inside ContinuousAffineCoupling such a
+    (or any other user-written) time net is evaluated with tensor ops on the device -- [N, out] values from [N, 1]
+    times -- and multiplied into the conditioner's output before the HIP affine kernel runs."""
+
+    def __init__(self, out_dim: int, hidden_dim: int, lmbd: float = 0.5, bounded: bool = False, **kwargs):
+        super().__init__()
+        self.bounded = bounded
+        self.hidden_dim = hidden_dim
+        self.shift = nn.Parameter(-torch.log(1 - torch.rand(out_dim, hidden_dim)) / lmbd)      # time_net.py:63
+        self.weight = nn.Parameter(torch.empty(out_dim, hidden_dim))
+        nn.init.xavier_normal_(self.weight)
+
+    def get_scale(self):
+        if self.bounded:
+            return torch.softmax(self.weight, -1) / 2                                          # time_net.py:69-70
+        return self.weight / self.hidden_dim
+
+    def forward(self, t):
+        t = t.unsqueeze(-1)
+        return (self.get_scale() * torch.sin(self.shift * t)).sum(-1)                          # time_net.py:74-79
+
+    def derivative(self, t):
+        t = t.unsqueeze(-1)
+        return (self.shift * self.get_scale() * torch.cos(self.shift * t)).sum(-1)             # time_net.py:81-86
 
 
-TimeFourierBounded = TimeFourier
+class TimeFourierBounded(TimeFourier):
+    """Same as TimeFourier but between 0 and 1 (time_net.py:88-91)."""
+
+    def __init__(self, out_dim: int, hidden_dim: int, lmbd: float = 0.5, **kwargs):
+        super().__init__(out_dim, hidden_dim, lmbd, True)

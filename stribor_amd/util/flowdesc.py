@@ -25,6 +25,30 @@ import torch
 POINTWISE = ('sigmoid', 'logit', 'elu', 'leaky_relu', 'cumsum', 'diff', 'identity')
 
 
+class HandNet(torch.nn.Module):
+    """A conditioner that is NOT a stribor MLP (residual branch, LayerNorm, two activations): stands for "any nn.Module
+    latent_net" (the reference accepts one: flows/affine.py:59-67, flows/spline.py:76-87).  Plain torch, so the same
+    class serves the reference, stribor_amd and the oracle."""
+
+    def __init__(self, in_dim: int, hidden: int, out_dim: int):
+        super().__init__()
+        self.a = torch.nn.Linear(in_dim, hidden)
+        self.n = torch.nn.LayerNorm(hidden)
+        self.b = torch.nn.Linear(hidden, hidden)
+        self.c = torch.nn.Linear(hidden, out_dim)
+
+    def forward(self, z):
+        u = torch.nn.functional.silu(self.a(z))
+        u = u + torch.sin(self.b(self.n(u)))
+        return self.c(u)
+
+
+def _make_net(st, d: Dict, in_dim: int, out_dim: int):
+    if d.get('net', 'mlp') == 'hand':
+        return HandNet(in_dim, d['hidden'][0], out_dim)
+    return st.net.MLP(in_dim, list(d['hidden']), out_dim)
+
+
 def _spline_params(d: Dict) -> int:
     """parameters per element: 3K-1 (quadratic) or 2K+2 (cubic), flows/spline.py:56-61."""
     return 2 * d['n_bins'] + 2 if d.get('spline_type', 'quadratic') == 'cubic' else 3 * d['n_bins'] - 1
@@ -34,14 +58,14 @@ def build_transform(st, d: Dict):
     k = d['kind']
     if k == 'coupling_affine':
         dim, ld = d['dim'], d.get('latent_dim', 0)
-        net = st.net.MLP(dim + ld, list(d['hidden']), 2 * dim)
-        return st.Coupling(transform=st.Affine(dim, latent_net=net), mask=d['mask'])
+        net = _make_net(st, d, dim + ld, 2 * dim)
+        return st.Coupling(transform=st.Affine(dim, latent_net=net), mask=d['mask'], set_data=d.get('set_data', False))
     if k == 'coupling_rqs':
         dim, ld, K = d['dim'], d.get('latent_dim', 0), d['n_bins']
-        net = st.net.MLP(dim + ld, list(d['hidden']), dim * _spline_params(d))
+        net = _make_net(st, d, dim + ld, dim * _spline_params(d))
         sp = st.Spline(dim, K, latent_net=net, lower=d['lower'], upper=d['upper'],
                        spline_type=d.get('spline_type', 'quadratic'))
-        return st.Coupling(transform=sp, mask=d['mask'])
+        return st.Coupling(transform=sp, mask=d['mask'], set_data=d.get('set_data', False))
     if k == 'affine':
         return st.Affine(d['dim'])
     if k == 'affine_latent':
@@ -62,9 +86,13 @@ def build_transform(st, d: Dict):
     if k == 'continuous_affine_coupling':
         dim, ld = d['dim'], d.get('latent_dim', 0)
         cat = d.get('concatenate_time', True)
-        net = st.net.MLP(dim + ld + (1 if cat else 0), list(d['hidden']), 2 * dim)
-        tn = {'identity': st.net.TimeIdentity, 'linear': st.net.TimeLinear, 'tanh': st.net.TimeTanh,
-              'log': st.net.TimeLog}[d['time_kind']](d.get('time_out', 2 * dim))
+        net = _make_net(st, d, dim + ld + (1 if cat else 0), 2 * dim)
+        if d['time_kind'] in ('fourier', 'fourier_bounded'):
+            cls = st.net.TimeFourier if d['time_kind'] == 'fourier' else st.net.TimeFourierBounded
+            tn = cls(d.get('time_out', 2 * dim), d.get('time_hidden', 5))
+        else:
+            tn = {'identity': st.net.TimeIdentity, 'linear': st.net.TimeLinear, 'tanh': st.net.TimeTanh,
+                  'log': st.net.TimeLog}[d['time_kind']](d.get('time_out', 2 * dim))
         return st.ContinuousAffineCoupling(latent_net=net, time_net=tn, mask=d['mask'], concatenate_time=cat)
     if k in POINTWISE:
         return {'sigmoid': st.Sigmoid, 'logit': st.Logit, 'elu': st.ELU, 'identity': st.Identity,
@@ -77,8 +105,12 @@ def build_flow(st, desc: List[Dict], dim: int):
     return st.NormalizingFlow(st.UnitNormal(dim), [build_transform(st, d) for d in desc])
 
 
-def _net_spec(state: Dict[str, torch.Tensor], prefix: str) -> Dict:
+def _net_spec(state: Dict[str, torch.Tensor], prefix: str, d: Dict = None, in_dim: int = 0, out_dim: int = 0) -> Dict:
     """MLP state_dict keys are '<prefix>net.{0,2,4,...}.{weight,bias}' (net/mlp.py:48-58)."""
+    if d is not None and d.get('net', 'mlp') == 'hand':
+        m = HandNet(in_dim, d['hidden'][0], out_dim)
+        m.load_state_dict({k[len(prefix):]: v.detach().cpu() for k, v in state.items() if k.startswith(prefix)})
+        return {'module': m.eval()}
     ws, bs, i = [], [], 0
     while f'{prefix}net.{i}.weight' in state:
         ws.append(state[f'{prefix}net.{i}.weight'])
@@ -92,9 +124,12 @@ def transform_spec(d: Dict, state: Dict[str, torch.Tensor], prefix: str) -> Dict
     """Oracle spec of one transform from stribor-keyed state ('<prefix>...')."""
     k = d['kind']
     if k == 'coupling_affine':
-        return {'kind': k, 'mask': d['mask'], 'net': _net_spec(state, prefix + 'transform.latent_net.')}
+        return {'kind': k, 'mask': d['mask'], 'set_data': d.get('set_data', False),
+                'net': _net_spec(state, prefix + 'transform.latent_net.', d, d['dim'] + d.get('latent_dim', 0), 2 * d['dim'])}
     if k == 'coupling_rqs':
-        return {'kind': k, 'mask': d['mask'], 'net': _net_spec(state, prefix + 'transform.latent_net.'),
+        return {'kind': k, 'mask': d['mask'], 'set_data': d.get('set_data', False),
+                'net': _net_spec(state, prefix + 'transform.latent_net.', d, d['dim'] + d.get('latent_dim', 0),
+                                 d['dim'] * _spline_params(d)),
                 'n_bins': d['n_bins'], 'lower': d['lower'], 'upper': d['upper'],
                 'spline_type': d.get('spline_type', 'quadratic')}
     if k == 'affine':
@@ -123,8 +158,11 @@ def transform_spec(d: Dict, state: Dict[str, torch.Tensor], prefix: str) -> Dict
     if k in POINTWISE:
         return dict(d)
     if k == 'continuous_affine_coupling':
-        return {'kind': k, 'mask': d['mask'], 'net': _net_spec(state, prefix + 'latent_net.'),
+        cat = d.get('concatenate_time', True)
+        return {'kind': k, 'mask': d['mask'],
+                'net': _net_spec(state, prefix + 'latent_net.', d, d['dim'] + d.get('latent_dim', 0) + (1 if cat else 0), 2 * d['dim']),
                 'time_kind': d['time_kind'], 'time_scale': state.get(prefix + 'time_net.scale'),
+                'time_weight': state.get(prefix + 'time_net.weight'), 'time_shift': state.get(prefix + 'time_net.shift'),
                 'time_out': d.get('time_out', 2 * d['dim']), 'concatenate_time': d.get('concatenate_time', True)}
     raise ValueError(k)
 

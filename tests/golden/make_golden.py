@@ -13,7 +13,8 @@ Fixtures:  F1 doc known-answer, F2 masks, F3 cfg 1, F4 cfg 2 (N
 rounded inputs), F5 cfg 3 (RQ-spline couplings, N=128, incl. tails / on-bound / on-knot rows),
 F6 cfg 4 (AffineLU + MatrixExponential + couplings), F7 Permute/Flip, F8 the reference test-suite
 shapes with autograd log|det J|, F9 cubic splines (suite shapes + a D=64 coupling flow), F10 parameter-free element-wise flows + the on-path part of
-test_normalizing_flow.py's stack, F11 ContinuousAffineCoupling / NeuralFlow.
+test_normalizing_flow.py's stack, F11 ContinuousAffineCoupling / NeuralFlow, F12 Coupling(set_data=True), hand-written
+conditioners and widths beyond the fused kernel's tiles (round 2).
 """
 import json
 import os
@@ -23,6 +24,7 @@ import tempfile
 sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))          # tests/ for flowdesc
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))          # repo root: flowdesc lives in stribor_amd.util
 
 REF = '/root/reference'
 
@@ -488,9 +490,89 @@ def f11_continuous():
     save('f11_continuous', arrays, meta)
 
 
+# ----------------------------------------------------------------------------------------- F12
+def f12_wide_and_set():
+    """Round 2: the branches of Coupling the fused kernel does not cover --
+    set_data=True (coupling.py:48-51: mask over the set axis, test-suite shape (7,4,5) and a 2-D (4,5) set),
+    conditioners that are not a stribor MLP, widths beyond the fused kernel's tiles (D=200 / H=256), n_bins > 16."""
+    arrays, meta = {}, {}
+    # set_data: affine, quadratic and cubic spline couplings; with and without latent
+    for shp in [(7, 4, 5), (4, 5), (3, 2, 6, 1)]:
+        dim = shp[-1]
+        tag = 'x'.join(map(str, shp))
+        for mask in ('ordered_left_half', 'parity_even'):
+            for ld in (0, 3):
+                torch.manual_seed(321)
+                x = torch.randn(*shp)
+                latent = torch.randn(*shp[:-1], ld) if ld else None
+                d = {'kind': 'coupling_affine', 'dim': dim, 'hidden': [13], 'mask': mask, 'latent_dim': ld, 'set_data': True}
+                suite_case(f'set_affine/{tag}/{mask}/l{ld}', d, dim, x, arrays, meta, latent=latent)
+            for stype, K in (('quadratic', 5), ('cubic', 4)):
+                torch.manual_seed(321)
+                x = torch.rand(*shp) * 2
+                d = {'kind': 'coupling_rqs', 'dim': dim, 'hidden': [12], 'mask': mask, 'latent_dim': 0, 'n_bins': K,
+                     'lower': 0, 'upper': 2, 'spline_type': stype, 'set_data': True}
+                suite_case(f'set_spline/{tag}/{mask}/{stype}', d, dim, x, arrays, meta)
+    # hand-written conditioners (not a stribor MLP)
+    for shp in [(10, 6), (7, 4, 5)]:
+        dim = shp[-1]
+        tag = 'x'.join(map(str, shp))
+        for ld in (0, 2):
+            torch.manual_seed(322)
+            x = torch.randn(*shp)
+            latent = torch.randn(*shp[:-1], ld) if ld else None
+            d = {'kind': 'coupling_affine', 'dim': dim, 'hidden': [24], 'mask': 'ordered_right_half', 'latent_dim': ld, 'net': 'hand'}
+            suite_case(f'hand_affine/{tag}/l{ld}', d, dim, x, arrays, meta, latent=latent)
+        torch.manual_seed(322)
+        x = torch.rand(*shp) * 2
+        d = {'kind': 'coupling_rqs', 'dim': dim, 'hidden': [24], 'mask': 'parity_odd', 'latent_dim': 0, 'n_bins': 6,
+             'lower': 0, 'upper': 2, 'net': 'hand'}
+        suite_case(f'hand_rqs/{tag}', d, dim, x, arrays, meta)
+    # ContinuousAffineCoupling with time nets that have no in-kernel form, and a hand-written conditioner
+    for shp in [(10, 4), (7, 4, 5)]:
+        dim = shp[-1]
+        tag = 'x'.join(map(str, shp))
+        for tk, net in (('fourier', 'mlp'), ('fourier_bounded', 'mlp'), ('tanh', 'hand'), ('fourier', 'hand')):
+            torch.manual_seed(323)
+            x = torch.randn(*shp)
+            t = torch.rand(*shp[:-1], 1) * 2
+            d = {'kind': 'continuous_affine_coupling', 'dim': dim, 'hidden': [13], 'mask': 'ordered_left_half', 'latent_dim': 0,
+                 'time_kind': tk, 'time_hidden': 5, 'net': net}
+            torch.manual_seed(123)
+            f = fd.build_transform(st, d)
+            prefix = f'cac/{tag}/{tk}_{net}'
+            for k, v in f.state_dict().items():
+                arrays[f'{prefix}/state/transforms.0.{k}'] = v
+            arrays[f'{prefix}/x'], arrays[f'{prefix}/t'] = x, t
+            with torch.no_grad():
+                y, ldj = f.forward_and_log_det_jacobian(x, t)
+                xb, ldj_inv = f.inverse_and_log_det_jacobian(y, t)
+            arrays[f'{prefix}/y'], arrays[f'{prefix}/ldj'] = y, ldj
+            arrays[f'{prefix}/x_back'], arrays[f'{prefix}/ldj_inv'] = xb, ldj_inv
+            meta[prefix] = {'desc': [d], 'dim': dim}
+    save('f12_set_and_hand', arrays, meta)
+    # wide flows (kept in their own file: the weights dominate)
+    arrays, meta = {}, {}
+    desc = [{'kind': 'coupling_affine', 'dim': 200, 'hidden': [256], 'mask': 'ordered_right_half', 'latent_dim': 0},
+            {'kind': 'coupling_affine', 'dim': 200, 'hidden': [256], 'mask': 'parity_even', 'latent_dim': 0}]
+    torch.manual_seed(1200)
+    x = torch.randn(48, 200)
+    flow_case('wide_affine', desc, 200, 12, x, arrays)
+    meta['wide_affine'] = {'desc': desc, 'dim': 200, 'seed': 12}
+    desc = [{'kind': 'coupling_rqs', 'dim': 12, 'hidden': [160], 'mask': 'ordered_left_half', 'latent_dim': 0, 'n_bins': 24,
+             'lower': -3, 'upper': 3},
+            {'kind': 'coupling_rqs', 'dim': 12, 'hidden': [160], 'mask': 'ordered_right_half', 'latent_dim': 0, 'n_bins': 24,
+             'lower': -3, 'upper': 3}]
+    torch.manual_seed(1201)
+    x = torch.randn(40, 12)
+    flow_case('wide_rqs', desc, 12, 13, x, arrays)
+    meta['wide_rqs'] = {'desc': desc, 'dim': 12, 'seed': 13}
+    save('f12_wide', arrays, meta)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11']
+    which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12']
     table = {'f1': f1_doc_example, 'f2': f2_masks, 'f3': f3_cfg1, 'f4': f4_cfg2, 'f5': f5_cfg3,
-             'f6': f6_cfg4, 'f7': f7_permute, 'f8': f8_suite, 'f9': f9_cubic, 'f10': f10_pointwise, 'f11': f11_continuous}
+             'f6': f6_cfg4, 'f7': f7_permute, 'f8': f8_suite, 'f9': f9_cubic, 'f10': f10_pointwise, 'f11': f11_continuous, 'f12': f12_wide_and_set}
     for w in which:
         table[w]()

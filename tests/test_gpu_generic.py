@@ -1,0 +1,203 @@
+"""GPU: the generic tier of Coupling / ContinuousAffineCoupling and the reference surface added in round 2 --
+set_data=True (coupling.py:48-51), conditioners that are not a stribor MLP (affine.py:59-67, spline.py:76-87), widths
+beyond the fused kernel's tiles (D = 200, H = 256, n_bins = 24), Fourier time nets (time_net.py:49-91), Flip over other
+axes (permute.py:30-44), the parameter accessors of AffineLU / MatrixExponential (affine.py:148-154, 222-241, 173-179,
+290-299).  Values: fixtures F12 captured from the reference (tests/golden/make_golden.py f12) and the oracle.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+import flowdesc as fd
+from goldens import Golden
+from producthelp import close, product_flow, product_transform
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import stribor_oracle as orc
+
+import stribor_amd as st
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    with torch.no_grad():
+        yield
+
+
+def test_f12_set_data_and_hand_written_conditioners():
+    g = Golden('f12_set_and_hand')
+    n = 0
+    for case, m in g.meta.items():
+        if case.startswith('cac/'):
+            continue
+        f = product_transform(g, case)
+        x = g.t(case + '/x').to(DEV)
+        kw = {'latent': g.t(case + '/latent').to(DEV)} if g.has(case + '/latent') else {}
+        spline = m['desc'][0]['kind'] == 'coupling_rqs'
+        ltol = dict(rtol=1e-5, atol=2e-4 if spline else 1e-4)
+        y = f(x, **kw)
+        close(y, g.t(case + '/y'))
+        close(f.inverse(g.t(case + '/y').to(DEV), **kw), g.t(case + '/x_back'), rtol=1e-4, atol=1e-4)
+        close(f.log_det_jacobian(x, y, **kw), g.t(case + '/ldj'), **ltol)
+        y2, l1 = f.forward_and_log_det_jacobian(x, **kw)
+        close(y2, g.t(case + '/y'))
+        close(l1, g.t(case + '/ldj_fwd'), **ltol)
+        xb, l2 = f.inverse_and_log_det_jacobian(g.t(case + '/y').to(DEV), **kw)
+        close(xb, g.t(case + '/x_back'), rtol=1e-4, atol=1e-4)
+        close(l2, g.t(case + '/ldj_inv'), **ltol)
+        assert y.shape == x.shape and l1.shape == x.shape[:-1] + (1,)
+        n += 1
+    assert n == 30
+
+
+def test_f12_continuous_coupling_generic_time_nets_and_conditioners():
+    g = Golden('f12_set_and_hand')
+    n = 0
+    for case, m in g.meta.items():
+        if not case.startswith('cac/'):
+            continue
+        f = product_transform(g, case)
+        x, t = g.t(case + '/x').to(DEV), g.t(case + '/t').to(DEV)
+        y, ldj = f.forward_and_log_det_jacobian(x, t)
+        close(y, g.t(case + '/y'))
+        close(ldj, g.t(case + '/ldj'), rtol=1e-5, atol=1e-5)
+        xb, li = f.inverse_and_log_det_jacobian(g.t(case + '/y').to(DEV), t)
+        close(xb, g.t(case + '/x_back'), rtol=1e-5, atol=1e-5)
+        close(li, g.t(case + '/ldj_inv'), rtol=1e-5, atol=1e-5)
+        close(f(x, t), g.t(case + '/y'))
+        n += 1
+    assert n == 8
+
+
+@pytest.mark.parametrize('case', ['wide_affine', 'wide_rqs'])
+def test_f12_wide_flows(case):
+    """D = 200 / H = 256 affine couplings and n_bins = 24 / H = 160 spline couplings: beyond the fused kernel's tiles,
+    so every layer runs conditioner (library GEMMs) + element-wise HIP kernel."""
+    g = Golden('f12_wide')
+    flow = product_flow(g, case)
+    x = g.t(case + '/x').to(DEV)
+    lt = dict(rtol=1e-5, atol=2e-4 if case == 'wide_rqs' else 1e-4)
+    close(flow.log_prob(x), g.t(case + '/log_prob'), **lt)
+    close(flow.log_prob(x).double(), g.t(case + '/log_prob_f64'), **lt)
+    close(flow.inverse(x), g.t(case + '/inverse'))
+    close(flow.forward(x), g.t(case + '/forward'))
+    z, ldj = flow.inverse_and_log_det_jacobian(x)
+    close(z, g.t(case + '/inverse'))
+    close(ldj, g.t(case + '/inverse_ldj'), **lt)
+    cur = x
+    for i in reversed(range(len(flow.transforms))):
+        cur, l = flow.transforms[i].inverse_and_log_det_jacobian(cur)
+        close(cur, g.t(f'{case}/inv_x.{i}'))
+        close(l, g.t(f'{case}/inv_ldj.{i}'), **lt)
+    # a larger batch against the oracle (round trip + log_prob)
+    m = g.meta[case]
+    spec = fd.flow_spec(m['desc'], g.state(case))
+    xb = torch.randn(3000, m['dim'], generator=torch.Generator().manual_seed(5))
+    close(flow.log_prob(xb.to(DEV)), orc.flow_log_prob(spec, xb), **lt)
+    close(flow.forward(flow.inverse(xb.to(DEV))), xb, rtol=1e-4, atol=1e-4)
+
+
+def test_mlp_wide_final_activation_and_unknown_activation():
+    """net.MLP beyond the kernel's tiles, with a final activation (mlp.py:55-56) or an activation the kernel does not
+    know: library-GEMM tier, same values."""
+    torch.manual_seed(0)
+    for kw in (dict(in_dim=200, hidden_dims=[256, 300], out_dim=70),
+               dict(in_dim=10, hidden_dims=[16], out_dim=4, final_activation='Sigmoid'),
+               dict(in_dim=10, hidden_dims=[16, 16], out_dim=4, activation='Softsign'),
+               dict(in_dim=6, hidden_dims=[], out_dim=3)):
+        net = st.net.MLP(**kw)
+        x = torch.randn(50, kw['in_dim'])
+        want = net.net(x)                                   # the module's own torch layers on the CPU = mlp.py:65
+        close(net.to(DEV)(x.to(DEV)), want, rtol=1e-5, atol=1e-5)
+    # inside a coupling: a final activation makes the conditioner non-fusable -> generic tier
+    torch.manual_seed(1)
+    net = st.net.MLP(6, [16], 12, final_activation='Tanh')
+    c = st.Coupling(st.Affine(6, latent_net=net), mask='parity_even')
+    x = torch.randn(40, 6)
+    m = orc.mask_vector('parity_even', 6)
+    p = net.net(x * m)
+    ls, sh = p.chunk(2, -1)
+    want = (x * ls.exp() + sh) * (1 - m) + x * m
+    c = c.to(DEV)
+    y, ldj = c.forward_and_log_det_jacobian(x.to(DEV))
+    close(y, want)
+    close(ldj, (ls * (1 - m)).sum(-1, keepdim=True), rtol=1e-5, atol=1e-5)
+
+
+def test_flip_over_other_axes():
+    x = torch.randn(3, 4, 5)
+    for dims in ([0], [1], [0, 1], [-2], [0, 2], [-1, 0]):
+        f = st.Flip(dims)
+        y = f(x.to(DEV))
+        assert torch.equal(y.cpu(), torch.flip(x, dims)), dims
+        assert torch.equal(f.inverse(y).cpu(), x), dims
+        assert torch.equal(f.log_det_jacobian(x.to(DEV), y).cpu(), torch.zeros(3, 4, 1))
+        want = torch.eye(5).flip(dims).diag().log().expand_as(x)                 # permute.py:44
+        got = f.log_diag_jacobian(x.to(DEV), y).cpu()
+        assert torch.equal(torch.isinf(got), torch.isinf(want)) and torch.equal(got[~torch.isinf(got)], want[~torch.isinf(want)])
+    # inside a flow: such a Flip is not a feature relabelling -> the flow runs layer by layer
+    torch.manual_seed(2)
+    flow = st.NormalizingFlow(st.UnitNormal(5), [st.Affine(5), st.Flip([0]), st.Affine(5)]).to(DEV)
+    xx = torch.randn(7, 5)
+    a0, a1 = flow.transforms[0], flow.transforms[2]
+    cur = (xx - a1.shift.cpu()) * torch.exp(-a1.log_scale.cpu())
+    cur = torch.flip(cur, [0])
+    cur = (cur - a0.shift.cpu()) * torch.exp(-a0.log_scale.cpu())
+    close(flow.inverse(xx.to(DEV)), cur.detach())
+
+
+def test_dense_layer_accessors():
+    torch.manual_seed(3)
+    lu = st.AffineLU(6).to(DEV)
+    W, ld = lu.weight.detach().cpu(), lu.log_diag.detach().cpu()
+    L = torch.tril(W, -1) + torch.eye(6)
+    U = torch.triu(W, 1) + torch.eye(6) * ld.exp()
+    close(lu.L, L, rtol=1e-6, atol=1e-6)
+    close(lu.U, U, rtol=1e-6, atol=1e-6)
+    x = torch.randn(4, 3, 6, device=DEV)
+    close(lu.jacobian(x, None), ((L @ U).T).expand(4, 3, -1, -1), rtol=1e-5, atol=1e-6)
+    for log_time in (False, True):
+        mx = st.MatrixExponential(5, bias=True, log_time=log_time).to(DEV)
+        Wm, dg = mx._weight.detach().cpu(), mx.diag.detach().cpu()
+        Lm, Um = torch.tril(Wm, -1) + torch.eye(5), torch.triu(Wm) + torch.eye(5)
+        gl, gu = mx.lu()
+        close(gl, Lm, rtol=1e-6, atol=1e-6)
+        close(gu, Um, rtol=1e-6, atol=1e-6)
+        A = Lm @ Um
+        Wt = (A * dg) @ torch.linalg.inv(A)
+        close(mx.weight, Wt, rtol=1e-4, atol=1e-5)
+        t = torch.rand(4, 1) + 0.1
+        tt = torch.log1p(t.abs()) if log_time else t
+        close(mx.get_time(t.to(DEV), (4, 5)), tt, rtol=1e-6, atol=1e-6)
+        assert mx.get_time(0.5, (4, 5)).shape == (4, 1)
+        xx = torch.randn(4, 5)
+        close(mx.jacobian(xx.to(DEV), None, t=t.to(DEV)), torch.matrix_exp(Wt * tt.unsqueeze(-1)), rtol=1e-4, atol=1e-5)
+        # the Jacobian really is d forward / dx (affine.py:290-299): columns of forward(e_i) - forward(0)
+        e = torch.eye(5)
+        y = mx(torch.cat([e, torch.zeros(1, 5)]).to(DEV), t=0.7).cpu()
+        J = (y[:5] - y[5:]).T
+        close(mx.jacobian(xx[:1].to(DEV), None, t=0.7)[0], J, rtol=1e-4, atol=1e-5)
+    sp = st.Spline(4, 3, spline_type='quadratic')
+    w0 = sp.width.detach().clone()
+    sp.reset_parameters()                                                         # spline.py:71-74
+    assert not torch.equal(sp.width, w0)
+    st.ELU(1, 2, foo=3)                                                           # activations.py: no __init__ of its own
+
+
+def test_set_data_coupling_inside_a_flow():
+    """A flow holding a set_data coupling runs layer by layer; round trip + log_prob against the oracle."""
+    torch.manual_seed(4)
+    desc = [{'kind': 'coupling_affine', 'dim': 5, 'hidden': [16], 'mask': 'ordered_left_half', 'latent_dim': 0, 'set_data': True},
+            {'kind': 'coupling_affine', 'dim': 5, 'hidden': [16], 'mask': 'ordered_right_half', 'latent_dim': 0},
+            {'kind': 'coupling_affine', 'dim': 5, 'hidden': [16], 'mask': 'parity_even', 'latent_dim': 0, 'set_data': True}]
+    flow = fd.build_flow(st, desc, 5)
+    spec = fd.flow_spec(desc, {k: v.clone() for k, v in flow.state_dict().items()})
+    flow = flow.to(DEV)
+    x = torch.randn(6, 4, 5)
+    close(flow.log_prob(x.to(DEV)), orc.flow_log_prob(spec, x))
+    close(flow.forward(flow.inverse(x.to(DEV))), x, rtol=1e-4, atol=1e-4)

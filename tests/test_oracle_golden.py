@@ -206,3 +206,42 @@ def test_f11_continuous_affine_coupling_and_neural_flow():
     assert torch.equal(orc.neural_flow_forward(spec, x, t), g.t('neural_flow/y_t'))
     assert torch.equal(orc.neural_flow_forward(spec, x, t, t0), g.t('neural_flow/y_t_t0'))
     assert torch.equal(orc.neural_flow_forward(spec, x, torch.zeros_like(t)), x)          # identity at t = 0
+
+
+def test_f12_set_data_hand_nets_and_wide_flows():
+    """Round 2 fixtures: Coupling(set_data=True) (coupling.py:48-51), conditioners that are not a stribor MLP, Fourier time
+    nets, widths beyond the fused kernel's tiles (D=200 / H=256, n_bins=24) -- the oracle against the reference's values."""
+    g = Golden('f12_set_and_hand')
+    n = 0
+    for case, m in g.meta.items():
+        d = m['desc'][0]
+        spec = fd.transform_spec(d, g.state(case), 'transforms.0.')
+        x = g.t(case + '/x')
+        if case.startswith('cac/'):
+            t = g.t(case + '/t')
+            y, ldj = orc.continuous_affine_coupling(spec, x, t, None, False)
+            assert torch.allclose(y, g.t(case + '/y'), rtol=1e-6, atol=1e-6), case
+            assert torch.allclose(ldj, g.t(case + '/ldj'), rtol=1e-6, atol=1e-6), case
+            xb, li = orc.continuous_affine_coupling(spec, g.t(case + '/y'), t, None, True)
+            assert torch.allclose(xb, g.t(case + '/x_back'), rtol=1e-5, atol=1e-5), case
+            assert torch.allclose(-li, g.t(case + '/ldj_inv'), rtol=1e-6, atol=1e-6), case
+            n += 1
+            continue
+        latent = g.t(case + '/latent') if g.has(case + '/latent') else None
+        tol = dict(rtol=1e-5, atol=1e-5)
+        y = orc.transform_apply(spec, x, False, latent)
+        assert torch.allclose(y, g.t(case + '/y'), **tol), case
+        assert torch.allclose(orc.transform_apply(spec, y, True, latent), g.t(case + '/x_back'), rtol=1e-4, atol=1e-4), case
+        assert torch.allclose(orc.transform_ldj(spec, x, latent, y=y), g.t(case + '/ldj'), rtol=1e-5, atol=1e-4), case
+        _, l2 = orc.transform_inverse_and_ldj(spec, y, latent)
+        assert torch.allclose(l2, g.t(case + '/ldj_inv'), rtol=1e-5, atol=1e-4), case
+        n += 1
+    assert n == 38
+    g = Golden('f12_wide')
+    for case in ('wide_affine', 'wide_rqs'):
+        m = g.meta[case]
+        spec = fd.flow_spec(m['desc'], g.state(case))
+        x = g.t(case + '/x')
+        assert torch.allclose(orc.flow_log_prob(spec, x), g.t(case + '/log_prob'), rtol=1e-5, atol=1e-4), case
+        assert torch.allclose(orc.flow_inverse(spec, x), g.t(case + '/inverse'), rtol=1e-5, atol=1e-5), case
+        assert torch.allclose(orc.flow_forward(spec, x), g.t(case + '/forward'), rtol=1e-5, atol=1e-5), case
