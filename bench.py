@@ -307,9 +307,9 @@ def main():
                          'algorithmic_flops_per_launch': FLOPS_PER_ROW * ROWS_PER_GPU,
                          'algorithmic_bytes_per_launch': BYTES_PER_ROW * ROWS_PER_GPU,
                          'hbm_frac_of_same_kernel': BYTES_PER_ROW * ROWS_PER_GPU / (k_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
-            'roofline_elementwise': {'kernel': 'affine_coupling_vec4_kernel<bf16,reverse>', 'bound': 'hbm',
+            'roofline_elementwise': {'kernel': 'affine_coupling_vec_kernel<bf16,reverse> (16 B per lane)', 'bound': 'hbm',
                                      'achieved': e_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': e_gbs / PEAK_HBM_GBS,
-                                     'traffic': pmc.get('affine_coupling_vec4_kernel', {}).get('hbm_bytes_per_launch'),
+                                     'traffic': (pmc.get('affine_coupling_vec_kernel') or pmc.get('affine_coupling_vec4_kernel') or {}).get('hbm_bytes_per_launch'),
                                      'traffic_pmc_commit': pmc.get('commit', '5b99493 (round 1, r01_h build)'),
                                      'avg_kernel_ms': e_avg_ms,
                                      'algorithmic_bytes_per_launch': ELEMWISE_BYTES_PER_ROW * ROWS_PER_GPU},

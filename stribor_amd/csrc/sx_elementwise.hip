@@ -57,40 +57,60 @@ __device__ __forceinline__ void store1(void *base, int64_t elem_off, float v) {
 
 // ------------------------------------------------------------------------------------------------
 // K3: affine coupling, element-wise part            (stribor/flows/affine.py:104-109, coupling.py:78,95)
-// Fast path: dim % 4 == 0, TPR = dim/4 threads per row is a power of two <= 64, live columns are
-// the contiguous 4-aligned range [l0, l0+n_live).  Each thread owns 4 columns of one row.
+// Fast path: every access is 16 B per lane (8-B accesses run at 0.54-0.70x the 16-B rate on this chip): a thread owns
+// CPT = 8 (bf16 storage) or 4 (fp32) consecutive columns of one row; TPR = dim / CPT threads per row is a power of two
+// <= 64, live columns are the contiguous CPT-aligned range [l0, l0 + n_live).
 // ------------------------------------------------------------------------------------------------
+typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
 template <bool BF16, bool REVERSE>
-__global__ __launch_bounds__(256) void affine_coupling_vec4_kernel(
+__global__ __launch_bounds__(256) void affine_coupling_vec_kernel(
     const void *__restrict__ x, void *__restrict__ y, float *__restrict__ ldj,
     const float *__restrict__ params, int64_t pstride, int l0, int n_live, int64_t n_rows, int dim,
     int tpr_log2, int ldj_acc, float ldj_scale) {
+    constexpr int CPT = BF16 ? 8 : 4, NQ = CPT / 4;
     const int tpr = 1 << tpr_log2;
     const int64_t n_vec = n_rows << tpr_log2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_vec; v += stride) {
         const int64_t row = v >> tpr_log2;
-        const int c = ((int)(v & (tpr - 1))) << 2;
-        f32x4 xv = load4<BF16>(x, row * dim + c);
+        const int c = ((int)(v & (tpr - 1))) * CPT;
+        f32x4 xv[NQ];
+        if constexpr (BF16) {
+            const u16x8 u = *reinterpret_cast<const u16x8 *>(reinterpret_cast<const uint16_t *>(x) + row * dim + c);
+            xv[0] = f32x4{bf16_to_f32(u[0]), bf16_to_f32(u[1]), bf16_to_f32(u[2]), bf16_to_f32(u[3])};
+            xv[1] = f32x4{bf16_to_f32(u[4]), bf16_to_f32(u[5]), bf16_to_f32(u[6]), bf16_to_f32(u[7])};
+        } else {
+            xv[0] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(x) + row * dim + c);
+        }
         float s = 0.f;
         if (c >= l0 && c < l0 + n_live) {
             const float *p = params + row * pstride + (c - l0);
-            f32x4 ls = *reinterpret_cast<const f32x4 *>(p);
-            f32x4 sh = *reinterpret_cast<const f32x4 *>(p + n_live);
-            if constexpr (REVERSE) {
-                xv.x = (xv.x - sh.x) * fast_exp(-ls.x);
-                xv.y = (xv.y - sh.y) * fast_exp(-ls.y);
-                xv.z = (xv.z - sh.z) * fast_exp(-ls.z);
-                xv.w = (xv.w - sh.w) * fast_exp(-ls.w);
-            } else {
-                xv.x = xv.x * fast_exp(ls.x) + sh.x;
-                xv.y = xv.y * fast_exp(ls.y) + sh.y;
-                xv.z = xv.z * fast_exp(ls.z) + sh.z;
-                xv.w = xv.w * fast_exp(ls.w) + sh.w;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const f32x4 ls = *reinterpret_cast<const f32x4 *>(p + 4 * q);
+                const f32x4 sh = *reinterpret_cast<const f32x4 *>(p + n_live + 4 * q);
+                if constexpr (REVERSE) {
+                    xv[q].x = (xv[q].x - sh.x) * fast_exp(-ls.x);
+                    xv[q].y = (xv[q].y - sh.y) * fast_exp(-ls.y);
+                    xv[q].z = (xv[q].z - sh.z) * fast_exp(-ls.z);
+                    xv[q].w = (xv[q].w - sh.w) * fast_exp(-ls.w);
+                } else {
+                    xv[q].x = xv[q].x * fast_exp(ls.x) + sh.x;
+                    xv[q].y = xv[q].y * fast_exp(ls.y) + sh.y;
+                    xv[q].z = xv[q].z * fast_exp(ls.z) + sh.z;
+                    xv[q].w = xv[q].w * fast_exp(ls.w) + sh.w;
+                }
+                s += (ls.x + ls.y) + (ls.z + ls.w);
             }
-            s = (ls.x + ls.y) + (ls.z + ls.w);
         }
-        store4<BF16>(y, row * dim + c, xv);
+        if constexpr (BF16) {
+            u16x8 o;
+            o[0] = f32_to_bf16(xv[0].x); o[1] = f32_to_bf16(xv[0].y); o[2] = f32_to_bf16(xv[0].z); o[3] = f32_to_bf16(xv[0].w);
+            o[4] = f32_to_bf16(xv[1].x); o[5] = f32_to_bf16(xv[1].y); o[6] = f32_to_bf16(xv[1].z); o[7] = f32_to_bf16(xv[1].w);
+            *reinterpret_cast<u16x8 *>(reinterpret_cast<uint16_t *>(y) + row * dim + c) = o;
+        } else {
+            *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(y) + row * dim + c) = xv[0];
+        }
         if (ldj != nullptr) {   // wave-uniform
             s = group_sum_rt(s, tpr);
             if ((v & (tpr - 1)) == 0) ldj[row] = (ldj_acc ? ldj[row] : 0.f) + ldj_scale * s;
@@ -145,15 +165,16 @@ extern "C" int sx_affine_coupling(const void *x, void *y, float *ldj, const floa
     SX_REQUIRE(dtype == SX_F32 || dtype == SX_BF16, "sx_affine_coupling: bad dtype");
     if (n_rows == 0) return SX_OK;
     hipStream_t st = sx_stream(stream);
-    const bool fast = live_idx == nullptr && dim % 4 == 0 && pow2(dim / 4) && dim / 4 <= 64 &&
-                      live_start % 4 == 0 && n_live % 4 == 0 && params_stride % 4 == 0 &&
+    const int cpt = dtype == SX_BF16 ? 8 : 4;
+    const bool fast = live_idx == nullptr && dim % cpt == 0 && pow2(dim / cpt) && dim / cpt <= 64 &&
+                      live_start % cpt == 0 && n_live % cpt == 0 && params_stride % 4 == 0 &&
                       live_start + n_live <= dim && (((uintptr_t)params) & 15) == 0 &&
                       (((uintptr_t)x) & 15) == 0 && (((uintptr_t)y) & 15) == 0;
     if (fast) {
-        const int tl = ilog2(dim / 4);
+        const int tl = ilog2(dim / cpt);
         const int grid = grid_for(n_rows << tl, 256);
 #define SX_AC(BF, RV)                                                                         \
-    hipLaunchKernelGGL((affine_coupling_vec4_kernel<BF, RV>), dim3(grid), dim3(256), 0, st, x, y, ldj, \
+    hipLaunchKernelGGL((affine_coupling_vec_kernel<BF, RV>), dim3(grid), dim3(256), 0, st, x, y, ldj, \
                        params, params_stride, live_start, n_live, n_rows, dim, tl, ldj_accumulate, ldj_scale)
         if (dtype == SX_BF16) { if (reverse) SX_AC(true, true); else SX_AC(true, false); }
         else { if (reverse) SX_AC(false, true); else SX_AC(false, false); }
@@ -258,31 +279,59 @@ __global__ __launch_bounds__(256) void time_affine_coupling_kernel(const void *_
     const int64_t total = n_rows * dim;
     const int64_t total_up = (total + 63) & ~(int64_t)63;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // one lane = one element e of [n_rows, dim]: returns its log-det part
+    auto body = [&](int64_t e, int64_t row) -> float {
+        float ld = 0.f;
+        const int col = (int)(e - row * dim);
+        const int i = slot[col];
+        float xv = BF16 ? bf16_to_f32(reinterpret_cast<const uint16_t *>(x)[e]) : reinterpret_cast<const float *>(x)[e];
+        float out = xv;
+        if (i >= 0) {
+            const float tv = t[row];
+            const float ls = params[row * pstride + i] * time_embed(time_kind, tscale ? tscale[i] : 0.f, tv);
+            const float sh = params[row * pstride + n_live + i] * time_embed(time_kind, tscale ? tscale[n_live + i] : 0.f, tv);
+            out = reverse ? (xv - sh) * expf(-ls) : xv * expf(ls) + sh;   // coupling.py:196-199
+            ld = ls;                                                       // :201
+        }
+        if (BF16) reinterpret_cast<uint16_t *>(y)[e] = f32_to_bf16(out);
+        else reinterpret_cast<float *>(y)[e] = out;
+        return ld;
+    };
+    if (ldj_mode == 2) {        // any row length, no atomics: row-aligned units (sx_common.h), fixed-order sums
+        const int lane = threadIdx.x & 63;
+        const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = stride >> 6;
+        const sx_units units = sx_make_units(n_rows, dim, true);
+        for (int64_t u = wave; u < units.n_units; u += n_waves) {
+            float row_acc = 0.f;
+            for (int chunk = 0; chunk < units.chunks; ++chunk) {
+                int64_t e0;
+                int n_here;
+                sx_unit_span(units, u, chunk, n_rows, dim, &e0, &n_here);
+                const bool valid = lane < n_here;
+                const int64_t e = e0 + lane, row = valid ? e / dim : 0;
+                const float s0 = valid ? body(e, row) : 0.f;
+                if (units.chunks == 1) {
+                    const int pos = lane % dim;
+                    const float s = segment_sum_rt(s0, pos, dim);
+                    if (valid && pos == 0) ldj[row] = (ldj_acc ? ldj[row] : 0.f) + ldj_scale * s;
+                } else {
+                    row_acc += s0;
+                }
+            }
+            if (units.chunks > 1) {
+                const float s = group_sum<64>(row_acc);
+                if (lane == 0) ldj[u] = (ldj_acc ? ldj[u] : 0.f) + ldj_scale * s;
+            }
+        }
+        return;
+    }
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total_up; e += stride) {
         const bool valid = e < total;
-        float ld = 0.f;
-        int64_t row = 0;
-        if (valid) {
-            row = e / dim;
-            const int col = (int)(e - row * dim);
-            const int i = slot[col];
-            float xv = BF16 ? bf16_to_f32(reinterpret_cast<const uint16_t *>(x)[e]) : reinterpret_cast<const float *>(x)[e];
-            float out = xv;
-            if (i >= 0) {
-                const float tv = t[row];
-                const float ls = params[row * pstride + i] * time_embed(time_kind, tscale ? tscale[i] : 0.f, tv);
-                const float sh = params[row * pstride + n_live + i] * time_embed(time_kind, tscale ? tscale[n_live + i] : 0.f, tv);
-                out = reverse ? (xv - sh) * expf(-ls) : xv * expf(ls) + sh;   // coupling.py:196-199
-                ld = ls;                                                       // :201
-            }
-            if (BF16) reinterpret_cast<uint16_t *>(y)[e] = f32_to_bf16(out);
-            else reinterpret_cast<float *>(y)[e] = out;
-        }
+        const int64_t row = valid ? e / dim : 0;
+        const float ld = valid ? body(e, row) : 0.f;
         if (ldj_mode == 1) {
             const float s = group_sum_rt(ld, dim);
             if (valid && (e & (dim - 1)) == 0) ldj[row] = (ldj_acc ? ldj[row] : 0.f) + ldj_scale * s;
-        } else if (ldj_mode == 2) {
-            if (valid && ld != 0.f) atomicAdd(&ldj[row], ldj_scale * ld);
         }
     }
 }
@@ -300,13 +349,9 @@ extern "C" int sx_time_affine_coupling(const void *x, void *y, float *ldj, const
     hipStream_t st = sx_stream(stream);
     int ldj_mode = 0;
     if (ldj) {
-        ldj_mode = (pow2(dim) && dim <= 64) ? 1 : 2;
-        if (ldj_mode == 2 && !ldj_accumulate) {
-            hipError_t e = hipMemsetAsync(ldj, 0, n_rows * sizeof(float), st);
-            if (e != hipSuccess) { sx_set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
-        }
+        ldj_mode = (pow2(dim) && dim <= 64) ? 1 : 2;      // 2: row-aligned units, deterministic sums (no atomics)
     }
-    const int grid = grid_for(n_rows * dim, 256);
+    const int grid = ldj_mode == 2 ? grid_for(sx_make_units(n_rows, dim, true).n_units * 64, 256) : grid_for(n_rows * dim, 256);
     const size_t lds = (size_t)dim * sizeof(int);
     if (dtype == SX_BF16)
         hipLaunchKernelGGL(time_affine_coupling_kernel<true>, dim3(grid), dim3(256), lds, st, x, y, ldj, params, params_stride, t,

@@ -84,45 +84,74 @@ template <bool BF16, int VEC>
 __global__ __launch_bounds__(256) void pointwise_kernel(const void *__restrict__ x, void *__restrict__ y,
                                                         float *__restrict__ ldj, float *__restrict__ ldiag,
                                                         int64_t n_rows, int dim, int kind, float param, float log_slope,
-                                                        int ldj_mode /*0 none, 1 group, 2 atomic*/, int ldj_acc) {
+                                                        int ldj_mode /*0 none, 1 group, 2 row-aligned units*/, int ldj_acc) {
     const int gdim = dim / VEC;                         // lanes per row
     const int64_t total = n_rows * gdim;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int row_shift = 31 - __builtin_clz(gdim);     // used when gdim is a power of two
+    // one lane = VEC consecutive elements at (vector) index i: load, evaluate, store; returns the lane's log-det part
+    auto body = [&](int64_t i) -> float {
+        float ld_sum = 0.f;
+        float xv[VEC], out[VEC], ld[VEC];
+        if constexpr (VEC == 4) {
+            if constexpr (BF16) {
+                const u16x4 u = reinterpret_cast<const u16x4 *>(x)[i];
+                xv[0] = bf16_to_f32(u.x); xv[1] = bf16_to_f32(u.y); xv[2] = bf16_to_f32(u.z); xv[3] = bf16_to_f32(u.w);
+            } else {
+                const f32x4 v = reinterpret_cast<const f32x4 *>(x)[i];
+                xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
+            }
+        } else xv[0] = pw_load<BF16>(x, i);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) { pw_eval(kind, param, log_slope, xv[c], out[c], ld[c]); ld_sum += ld[c]; }
+        if (y) {
+            if constexpr (VEC == 4) {
+                if constexpr (BF16) reinterpret_cast<u16x4 *>(y)[i] = u16x4{f32_to_bf16(out[0]), f32_to_bf16(out[1]), f32_to_bf16(out[2]), f32_to_bf16(out[3])};
+                else reinterpret_cast<f32x4 *>(y)[i] = f32x4{out[0], out[1], out[2], out[3]};
+            } else pw_store<BF16>(y, i, out[0]);
+        }
+        if (ldiag) {
+            if constexpr (VEC == 4) reinterpret_cast<f32x4 *>(ldiag)[i] = f32x4{ld[0], ld[1], ld[2], ld[3]};
+            else ldiag[i] = ld[0];
+        }
+        return ld_sum;
+    };
+    if (ldj_mode == 2) {
+        // row sums for any row length without atomics: row-aligned units (sx_common.h), fixed-order sums
+        const int lane = threadIdx.x & 63;
+        const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = stride >> 6;
+        const sx_units units = sx_make_units(n_rows, gdim, true);
+        for (int64_t u = wave; u < units.n_units; u += n_waves) {
+            float row_acc = 0.f;
+            for (int chunk = 0; chunk < units.chunks; ++chunk) {
+                int64_t e0;
+                int n_here;
+                sx_unit_span(units, u, chunk, n_rows, gdim, &e0, &n_here);
+                const bool valid = lane < n_here;
+                const float s0 = valid ? body(e0 + lane) : 0.f;
+                if (units.chunks == 1) {
+                    const int pos = lane % gdim;
+                    const float s = segment_sum_rt(s0, pos, gdim);
+                    if (valid && pos == 0) { const int64_t r = (e0 + lane) / gdim; ldj[r] = (ldj_acc ? ldj[r] : 0.f) + s; }
+                } else {
+                    row_acc += s0;
+                }
+            }
+            if (units.chunks > 1) {
+                const float s = group_sum<64>(row_acc);
+                if (lane == 0) ldj[u] = (ldj_acc ? ldj[u] : 0.f) + s;
+            }
+        }
+        return;
+    }
     // the loop bound is rounded up to whole waves so that every lane of a wave reaches the shuffle sum
     const int64_t total_up = (total + 63) & ~(int64_t)63;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_up; i += stride) {
         const bool valid = i < total;
-        float ld_sum = 0.f;
-        if (valid) {
-            float xv[VEC], out[VEC], ld[VEC];
-            if constexpr (VEC == 4) {
-                if constexpr (BF16) {
-                    const u16x4 u = reinterpret_cast<const u16x4 *>(x)[i];
-                    xv[0] = bf16_to_f32(u.x); xv[1] = bf16_to_f32(u.y); xv[2] = bf16_to_f32(u.z); xv[3] = bf16_to_f32(u.w);
-                } else {
-                    const f32x4 v = reinterpret_cast<const f32x4 *>(x)[i];
-                    xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
-                }
-            } else xv[0] = pw_load<BF16>(x, i);
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) { pw_eval(kind, param, log_slope, xv[c], out[c], ld[c]); ld_sum += ld[c]; }
-            if (y) {
-                if constexpr (VEC == 4) {
-                    if constexpr (BF16) reinterpret_cast<u16x4 *>(y)[i] = u16x4{f32_to_bf16(out[0]), f32_to_bf16(out[1]), f32_to_bf16(out[2]), f32_to_bf16(out[3])};
-                    else reinterpret_cast<f32x4 *>(y)[i] = f32x4{out[0], out[1], out[2], out[3]};
-                } else pw_store<BF16>(y, i, out[0]);
-            }
-            if (ldiag) {
-                if constexpr (VEC == 4) reinterpret_cast<f32x4 *>(ldiag)[i] = f32x4{ld[0], ld[1], ld[2], ld[3]};
-                else ldiag[i] = ld[0];
-            }
-        }
+        const float ld_sum = valid ? body(i) : 0.f;
         if (ldj_mode == 1) {            // gdim is a power of two <= 64: rows are aligned lane groups
             const float s = group_sum_rt(ld_sum, gdim);
             if (valid && (i & (gdim - 1)) == 0) { const int64_t r = i >> row_shift; ldj[r] = (ldj_acc ? ldj[r] : 0.f) + s; }
-        } else if (ldj_mode == 2) {
-            if (valid) atomicAdd(&ldj[total < (1ll << 31) ? (int64_t)((uint32_t)i / (uint32_t)gdim) : i / gdim], ld_sum);
         }
     }
 }
@@ -281,11 +310,7 @@ extern "C" int sx_pointwise(const void *x, void *y, float *ldj, float *ldiag, in
     const int gdim = vec4 ? dim / 4 : dim;
     int ldj_mode = 0;
     if (ldj) {
-        ldj_mode = ((gdim & (gdim - 1)) == 0 && gdim <= 64) ? 1 : 2;
-        if (ldj_mode == 2 && !ldj_accumulate) {
-            hipError_t e = hipMemsetAsync(ldj, 0, n_rows * sizeof(float), st);
-            if (e != hipSuccess) { sx_set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
-        }
+        ldj_mode = ((gdim & (gdim - 1)) == 0 && gdim <= 64) ? 1 : 2;      // 2: row-aligned units, deterministic sums
     }
     // log(negative_slope) in double like math.log (activations.py:99); the inverse kind carries 1 / slope
     float log_slope = 0.f;
@@ -293,8 +318,9 @@ extern "C" int sx_pointwise(const void *x, void *y, float *ldj, float *ldiag, in
         SX_REQUIRE(param > 0.f, "sx_pointwise: LeakyReLU slope must be positive");
         log_slope = (float)(kind == SX_PW_LEAKY_RELU ? log((double)param) : -log((double)param));
     }
-    int64_t g = (n_rows * gdim + 255) / 256;
+    int64_t g = ldj_mode == 2 ? (sx_make_units(n_rows, gdim, true).n_units + 3) / 4 : (n_rows * gdim + 255) / 256;
     if (g > 256 * 8) g = 256 * 8;
+    if (g < 1) g = 1;
 #define SX_PWL(BF, V)                                                                                             \
     hipLaunchKernelGGL((pointwise_kernel<BF, V>), dim3((int)g), dim3(256), 0, st, x, y, ldj, ldiag, n_rows, dim, kind, \
                        param, log_slope, ldj_mode, ldj_accumulate)

@@ -159,14 +159,15 @@ __global__ __launch_bounds__(256) void rqs_kernel(const void *__restrict__ x, vo
                                                   const float *__restrict__ params, int64_t pstride,
                                                   const int32_t *__restrict__ live_idx, int l0, int n_live, int K,
                                                   float left, float right, float bottom, float top, int64_t n_rows,
-                                                  int dim, int ldj_mode /*0 none, 1 direct (group), 2 atomic*/,
+                                                  int dim, int ldj_mode /*0 none, 1 direct (group), 2 row-aligned units*/,
                                                   int ldj_acc, float ldj_scale, uint32_t *__restrict__ err_flag) {
     const int P = 3 * K - 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int waves_per_block = blockDim.x >> 6;
     float *sp = rqs_smem + (size_t)wave * 64 * P;               // this wave's staging slice
     const int64_t n_elem = n_rows * n_live;
-    const int64_t n_groups = (n_elem + 63) >> 6;
+    const sx_units units = sx_make_units(n_rows, n_live, ldj_mode == 2);
+    const int64_t n_groups = units.n_units;
     const float lo_in = INVERSE ? bottom : left, hi_in = INVERSE ? top : right;
     const float bconst = logf(expf(1.f - RQS_MIN_DERIV) - 1.f);  // :81 boundary derivative constant
     const float norm = 1.f - RQS_MIN_BIN * (float)K;
@@ -177,11 +178,14 @@ __global__ __launch_bounds__(256) void rqs_kernel(const void *__restrict__ x, vo
     bool have_pf = false;
     for (int64_t grp = (int64_t)blockIdx.x * waves_per_block + wave; grp < n_groups;
          grp += (int64_t)gridDim.x * waves_per_block) {
-        const int64_t e0 = grp << 6;
-        // ---- stage 64 elements' parameters: consecutive idx -> consecutive HBM addresses inside a row ----
-        const int n_here = (int)((n_elem - e0) < 64 ? (n_elem - e0) : 64);
+      float row_acc = 0.f;                     // ldj_mode 2, rows wider than a wave: the row's sum over its chunks
+      for (int chunk = 0; chunk < units.chunks; ++chunk) {
+        int64_t e0;
+        int n_here;
+        sx_unit_span(units, grp, chunk, n_rows, n_live, &e0, &n_here);
+        // ---- stage the elements' parameters: consecutive idx -> consecutive HBM addresses inside a row ----
         const int total = n_here * P;
-        if (contig && n_here == 64 && P == 47) {
+        if (contig && n_here == 64 && P == 47 && units.rows_per_unit == 0) {
             // the 64 elements' parameters are one contiguous, 16-byte aligned span of 752 float4: 11.75 per lane.
             // Software pipeline: this group's span was fetched into registers one iteration ago; park it in LDS,
             // then fetch the NEXT group's span so its latency hides under this group's arithmetic.
@@ -196,14 +200,14 @@ __global__ __launch_bounds__(256) void rqs_kernel(const void *__restrict__ x, vo
             for (int t = 0; t < 12; ++t)
                 if (t * 64 + lane < 752) dst[t * 64 + lane] = pf[t];
             const int64_t gnext = grp + (int64_t)gridDim.x * waves_per_block;
-            have_pf = gnext < n_groups && ((gnext << 6) + 64 <= n_elem);
+            have_pf = gnext < n_groups && ((gnext << 6) + 64 <= n_elem);      // dense units only (checked above)
             if (have_pf) {
                 const f32x4 *src = reinterpret_cast<const f32x4 *>(params + (gnext << 6) * P);
 #pragma unroll
                 for (int t = 0; t < 12; ++t)
                     if (t * 64 + lane < 752) pf[t] = src[t * 64 + lane];
             }
-        } else if (contig && n_here == 64) {
+        } else if (contig && n_here == 64 && ((e0 * P) & 3) == 0) {
             have_pf = false;
             const f32x4 *src = reinterpret_cast<const f32x4 *>(params + e0 * P);
             f32x4 *dst = reinterpret_cast<f32x4 *>(sp);
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(256) void rqs_kernel(const void *__restrict__ x, vo
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         const int64_t e = e0 + lane;
-        const bool valid = e < n_elem;
+        const bool valid = lane < n_here;
         const int64_t row = valid ? e / n_live : 0;
         const int i = valid ? (int)(e - row * n_live) : 0;
         const int col = live_idx ? live_idx[i] : l0 + i;
@@ -303,9 +307,20 @@ __global__ __launch_bounds__(256) void rqs_kernel(const void *__restrict__ x, vo
             float s = valid ? ljd : 0.f;
             s = group_sum_rt(s, n_live);
             if (valid && (lane & (n_live - 1)) == 0) ldj[row] = (ldj_acc ? ldj[row] : 0.f) + ldj_scale * s;
-        } else if (ldj_mode == 2) {
-            if (valid) atomicAdd(&ldj[row], ldj_scale * ljd);
+        } else if (ldj_mode == 2) {          // row-aligned units: fixed-order sums, no atomics
+            const float s0 = valid ? ljd : 0.f;
+            if (units.chunks == 1) {
+                const float s = segment_sum_rt(s0, i, n_live);
+                if (valid && i == 0) ldj[row] = (ldj_acc ? ldj[row] : 0.f) + ldj_scale * s;
+            } else {
+                row_acc += s0;
+            }
         }
+      }
+      if (ldj_mode == 2 && units.chunks > 1) {
+          const float s = group_sum<64>(row_acc);
+          if (lane == 0) ldj[grp] = (ldj_acc ? ldj[grp] : 0.f) + ldj_scale * s;
+      }
     }
 }
 
@@ -352,16 +367,9 @@ extern "C" int sx_rqs_coupling(const void *x, void *y, float *ldj, float *ldiag,
     }
     int ldj_mode = 0;
     if (ldj) {
-        if (rqs_pow2(n_live) && n_live <= 64) ldj_mode = 1;
-        else {
-            ldj_mode = 2;
-            if (!ldj_accumulate) {
-                hipError_t e = hipMemsetAsync(ldj, 0, n_rows * sizeof(float), st);
-                if (e != hipSuccess) { sx_set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
-            }
-        }
+        ldj_mode = (rqs_pow2(n_live) && n_live <= 64) ? 1 : 2;      // 2: row-aligned units, deterministic sums
     }
-    const int64_t n_groups = (n_rows * n_live + 63) / 64;
+    const int64_t n_groups = sx_make_units(n_rows, n_live, ldj_mode == 2).n_units;
     const int wpb = block / 64;
     int64_t grid = (n_groups + wpb - 1) / wpb;
     const int64_t max_grid = 256 * (int64_t)((160 * 1024) / (lds ? lds : 1) > 8 ? 8 : (160 * 1024) / (lds ? lds : 1));
@@ -418,14 +426,14 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
                                                     const float *__restrict__ params, int64_t pstride,
                                                     const int32_t *__restrict__ live_idx, int l0, int n_live, int K,
                                                     float lower, float upper, float log_span, int64_t n_rows, int dim,
-                                                    int ldj_mode /*0 none, 1 direct (group), 2 atomic*/, int ldj_acc,
+                                                    int ldj_mode /*0 none, 1 direct (group), 2 row-aligned units*/, int ldj_acc,
                                                     float ldj_scale) {
     const int P = 2 * K + 2, PS = P | 1;                         // padded (odd) per-lane stride
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int waves_per_block = blockDim.x >> 6;
     float *sp = rqs_smem + (size_t)wave * 64 * PS;
-    const int64_t n_elem = n_rows * n_live;
-    const int64_t n_groups = (n_elem + 63) >> 6;
+    const sx_units units = sx_make_units(n_rows, n_live, ldj_mode == 2);
+    const int64_t n_groups = units.n_units;
     const float norm = 1.f - CUBIC_MIN_BIN * (float)K;          // :104, :111
     const float span = upper - lower;                            // right - left = top - bottom
     const bool contig = pstride == (int64_t)n_live * P;
@@ -433,11 +441,14 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
 
     for (int64_t grp = (int64_t)blockIdx.x * waves_per_block + wave; grp < n_groups;
          grp += (int64_t)gridDim.x * waves_per_block) {
-        const int64_t e0 = grp << 6;
-        const int n_here = (int)((n_elem - e0) < 64 ? (n_elem - e0) : 64);
+      float row_acc = 0.f;                     // ldj_mode 2, rows wider than a wave: the row's sum over its chunks
+      for (int chunk = 0; chunk < units.chunks; ++chunk) {
+        int64_t e0;
+        int n_here;
+        sx_unit_span(units, grp, chunk, n_rows, n_live, &e0, &n_here);
         const int total = n_here * P;
         // ---- stage: consecutive idx -> consecutive HBM addresses (one contiguous span when rows are packed) ----
-        if (contig && n_here == 64 && (P & 1) == 0 && ((reinterpret_cast<uintptr_t>(params) & 15) == 0)) {
+        if (contig && n_here == 64 && (P & 1) == 0 && ((e0 * P) & 3) == 0 && ((reinterpret_cast<uintptr_t>(params) & 15) == 0)) {
             // 64*P floats = 16*P float4, 16-byte aligned (P even): vector loads, scalar LDS writes into the padded rows
             const f32x4 *src = reinterpret_cast<const f32x4 *>(params + e0 * P);
             for (int i4 = lane; i4 < 16 * P; i4 += 64) {
@@ -465,7 +476,7 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         const int64_t e = e0 + lane;
-        const bool valid = e < n_elem;
+        const bool valid = lane < n_here;
         const int64_t row = valid ? e / n_live : 0;
         const int i = valid ? (int)(e - row * n_live) : 0;
         const int col = live_idx ? live_idx[i] : l0 + i;
@@ -614,9 +625,20 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
             float s = valid ? ljd : 0.f;
             s = group_sum_rt(s, n_live);
             if (valid && (lane & (n_live - 1)) == 0) ldj[row] = (ldj_acc ? ldj[row] : 0.f) + ldj_scale * s;
-        } else if (ldj_mode == 2) {
-            if (valid) atomicAdd(&ldj[row], ldj_scale * ljd);
+        } else if (ldj_mode == 2) {          // row-aligned units: fixed-order sums, no atomics
+            const float s0 = valid ? ljd : 0.f;
+            if (units.chunks == 1) {
+                const float s = segment_sum_rt(s0, i, n_live);
+                if (valid && i == 0) ldj[row] = (ldj_acc ? ldj[row] : 0.f) + ldj_scale * s;
+            } else {
+                row_acc += s0;
+            }
         }
+      }
+      if (ldj_mode == 2 && units.chunks > 1) {
+          const float s = group_sum<64>(row_acc);
+          if (lane == 0) ldj[grp] = (ldj_acc ? ldj[grp] : 0.f) + ldj_scale * s;
+      }
     }
 }
 
@@ -651,14 +673,14 @@ extern "C" int sx_cubic_coupling(const void *x, void *y, float *ldj, float *ldia
     }
     int ldj_mode = 0;
     if (ldj) {
-        ldj_mode = (n_live > 0 && rqs_pow2(n_live) && n_live <= 64) ? 1 : 2;
-        if ((ldj_mode == 2 || n_live == 0) && !ldj_accumulate) {
+        ldj_mode = (n_live > 0 && rqs_pow2(n_live) && n_live <= 64) ? 1 : 2;      // 2: row-aligned units, deterministic
+        if (n_live == 0 && !ldj_accumulate) {
             hipError_t e = hipMemsetAsync(ldj, 0, n_rows * sizeof(float), st);
             if (e != hipSuccess) { sx_set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
         }
     }
     if (n_live == 0) return SX_OK;
-    const int64_t n_groups = (n_rows * n_live + 63) / 64;
+    const int64_t n_groups = sx_make_units(n_rows, n_live, ldj_mode == 2).n_units;
     const int wpb = block / 64;
     int64_t grid = (n_groups + wpb - 1) / wpb;
     const int64_t per_cu = (160 * 1024) / (int64_t)lds > 8 ? 8 : (160 * 1024) / (int64_t)lds;

@@ -33,3 +33,21 @@ def close(a, b, rtol=1e-5, atol=1e-5):
         raise AssertionError(f'max abs err {err.max().item():.3e} at {i.item()} '
                              f'(got {a.flatten()[i].item():.7g}, want {b.flatten()[i].item():.7g})')
     return True
+
+
+def close_vs_f64(got, ref32, f64, k=2.0, rtol=1e-5, atol=1e-5):
+    """The north_star bound measured against the fp64 truth: |got - f64| <= k * |ref32 - f64| + atol + rtol * |f64|
+    element-wise, i.e. never more than k times the reference's OWN fp32 error plus the 1e-5 allowance (the form the
+    spline tests use; VERDICT r1 weak #3).  `ref32`: the reference's fp32 values (fixture), `f64`: the same op in fp64."""
+    got = got.detach().double().cpu()
+    ref32, f64 = ref32.detach().double().cpu(), f64.detach().double().cpu()
+    assert got.shape == f64.shape == ref32.shape, (got.shape, ref32.shape, f64.shape)
+    bound = k * (ref32 - f64).abs() + atol + rtol * f64.abs()
+    err = (got - f64).abs()
+    bad = err > bound
+    if bad.any():
+        i = (err - bound).argmax()
+        raise AssertionError(f'{int(bad.sum())} elements beyond {k} x the reference\'s own fp32 error + {atol}: worst '
+                             f'|got - f64| = {err.flatten()[i].item():.3e}, |ref32 - f64| = '
+                             f'{(ref32 - f64).abs().flatten()[i].item():.3e} at {i.item()} (f64 {f64.flatten()[i].item():.7g})')
+    return True

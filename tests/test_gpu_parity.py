@@ -11,7 +11,7 @@ import torch
 
 import flowdesc as fd
 from goldens import Golden
-from producthelp import close, product_flow, product_transform
+from producthelp import close, close_vs_f64, product_flow, product_transform
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import stribor_oracle as orc
@@ -404,27 +404,34 @@ def test_matrix_exponential_variants():
 
 def test_cfg4_flow_against_golden():
     """D=128: [AffineLU, Coupling(Affine), MatrixExponential, Coupling(Affine)] x 2, fully fused (fixture F6).
-    The reference's own fp32-vs-fp64 error on this config is ~1e-6..4e-6 rel (triangular solves); the bar is
-    1e-5 rel against its fp32 values and against the fp64 truth."""
+    log_prob and every log-det: 1e-5 rel against the reference's fp32 values and against the fp64 truth.
+    Transformed values: this flow's default-init matrices amplify by ~1e3 per block and the reference's own fp32 result
+    (substitution order inside the triangular solves) is only 1e-6..4e-6 rel accurate, so the values are held to the
+    north_star's bound MEASURED AGAINST FP64: never more than twice the reference's own fp32 error + 1e-5 rel
+    (close_vs_f64), layer by layer and end to end."""
     g = Golden('f6_cfg4')
     flow = product_flow(g, 'cfg4')
     x = g.t('cfg4/x').to(DEV)
+    spec64 = orc.spec_to(fd.flow_spec(g.meta['cfg4']['desc'], g.state('cfg4')), torch.float64)
+    x64 = g.t('cfg4/x').double()
     assert flow._fused_program(True, 128, 0, x.device) is not None             # one launch, no per-layer fallback
     lp = flow.log_prob(x)
     close(lp, g.t('cfg4/log_prob'), rtol=1e-5, atol=1e-4)
     close(lp.double(), g.t('cfg4/log_prob_f64'), rtol=1e-5, atol=1e-4)
     z, ldj = flow.inverse_and_log_det_jacobian(x)
-    close(z, g.t('cfg4/inverse'), rtol=1e-4, atol=2e-4)
+    close_vs_f64(z, g.t('cfg4/inverse'), orc.flow_inverse(spec64, x64))
     close(ldj, g.t('cfg4/inverse_ldj'), rtol=1e-5, atol=1e-4)
     y, ldf = flow.forward_and_log_det_jacobian(x)
-    close(y, g.t('cfg4/forward'), rtol=1e-4, atol=2e-4)
+    close_vs_f64(y, g.t('cfg4/forward'), orc.flow_forward(spec64, x64))
     close(ldf, g.t('cfg4/forward_ldj'), rtol=1e-5, atol=1e-4)
-    cur = x
-    for i in reversed(range(len(flow.transforms))):
-        nxt, l = flow.transforms[i].inverse_and_log_det_jacobian(cur)
-        close(nxt, g.t(f'cfg4/inv_x.{i}'), rtol=1e-4, atol=2e-4)
+    # layer by layer, each layer fed the REFERENCE's fp32 input of that layer (so errors do not compound across layers)
+    n = len(flow.transforms)
+    for i in reversed(range(n)):
+        cur32 = g.t('cfg4/x') if i == n - 1 else g.t(f'cfg4/inv_x.{i + 1}')
+        nxt, l = flow.transforms[i].inverse_and_log_det_jacobian(cur32.to(DEV))
+        want64 = orc.transform_apply(spec64[i], cur32.double(), True)
+        close_vs_f64(nxt, g.t(f'cfg4/inv_x.{i}'), want64)
         close(l, g.t(f'cfg4/inv_ldj.{i}'), rtol=1e-5, atol=1e-4)
-        cur = nxt
 
 
 def test_mixed_spline_affine_flow_falls_back_per_layer_and_matches_oracle():
@@ -472,8 +479,8 @@ def test_coupling_with_deep_conditioner_and_other_activations():
 
 
 def test_full_size_properties_spline_and_linear_flows():
-    """BASELINE cfg 3 and cfg 4 at N = 2^18 rows (kept below 2^20 only to bound test time): round trips,
-    forward/inverse log-det antisymmetry, batch-split invariance, agreement with the oracle on a slice."""
+    """BASELINE cfg 3 and cfg 4 at their full N = 2^20 rows: round trips, forward/inverse log-det antisymmetry,
+    batch-split invariance, agreement with the oracle on a slice."""
     torch.set_grad_enabled(False)        # inference properties: with a graph, spline flows take the layer-wise training path
     try:
         _full_size_properties_spline_and_linear()
@@ -486,7 +493,7 @@ def _full_size_properties_spline_and_linear():
         torch.manual_seed(0)
         flow = fd.build_flow(st, desc, dim).to(DEV)
         assert flow._fused_program(True, dim, 0, torch.device(DEV)) is not None
-        n = 1 << 18
+        n = 1 << 20
         x = torch.randn(n, dim, device=DEV)
         y, ldj_f = flow.forward_and_log_det_jacobian(x)
         xb, ldj_i = flow.inverse_and_log_det_jacobian(y)
@@ -502,7 +509,7 @@ def _full_size_properties_spline_and_linear():
         lp2 = torch.cat([flow.log_prob(x[:100_001]), flow.log_prob(x[100_001:])])
         assert torch.equal(lp, lp2), name
         spec = fd.flow_spec(desc, {k: v.cpu() for k, v in flow.state_dict().items()})
-        sl = slice(200_000, 200_256)
+        sl = slice(900_000, 900_256)
         close(lp[sl], orc.flow_log_prob(spec, x[sl].cpu()), rtol=1e-5, atol=1e-4)
         s = flow.log_prob_sum(x)
         assert abs(s.item() - lp.double().sum().item()) <= 1e-9 * abs(s.item()), name
@@ -733,8 +740,8 @@ def test_continuous_affine_coupling_and_neural_flow():
     close(nf(x, t=t, t0=t0), g.t('neural_flow/y_t_t0'), atol=2e-5)
     assert torch.equal(nf(x, t=torch.zeros_like(t)), x)                          # test_neural_flow.py:24-27
     close(nf(x, t=t0, t0=t0), x, atol=1e-5)                                      # :29-32
-    with pytest.raises(NotImplementedError):
-        st.net.TimeFourier(4, 8)
+    tf = st.net.TimeFourier(4, 8)                                                  # round 2: built (time_net.py:49-91)
+    assert tf(torch.rand(5, 1)).shape == (5, 4)
 
 
 def test_full_size_properties_cubic_and_pointwise():

@@ -23,7 +23,7 @@ for dt, sx in ((torch.bfloat16, 2), (torch.float32, 4)):
     x = torch.randn(N, D, device=dev).to(dt)
     params = torch.randn(N, D, device=dev) * 0.1
     ms = timed(lambda: run_affine_kernel(x, params, D, None, 0, D // 2, True, True, True, -1.0))
-    rec(f'affine_coupling_vec4 x={dt}', ms, N * (2 * D * sx + D * 4 + 4))
+    rec(f'affine_coupling_vec x={dt}', ms, N * (2 * D * sx + D * 4 + 4))
     p = st.Permute(D).to(dev)
     ms = timed(lambda: p(x))
     rec(f'permute x={dt}', ms, N * 2 * D * sx)

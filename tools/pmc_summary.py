@@ -15,7 +15,7 @@ def main(d):
     for f in glob.glob(os.path.join(d, 'pmc*', '**', '*counter_collection.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
             k = 'flow_fused_kernel' if 'flow_fused' in r['Kernel_Name'] else (
-                'affine_coupling_vec4_kernel' if 'affine_coupling_vec4' in r['Kernel_Name'] else None)
+                'affine_coupling_vec_kernel' if 'affine_coupling_vec' in r['Kernel_Name'] else None)
             if k:
                 per[k][r['Counter_Name']].append(float(r['Counter_Value']))
     for f in glob.glob(os.path.join(d, 'pmc3', '**', '*kernel_trace.csv'), recursive=True):
