@@ -323,6 +323,29 @@ int sx_flow_run(const sx_program *prog_host, const float *blobs, const void *x, 
                 int32_t mlp_out_dim, const float *row_t, float *side, int64_t n_rows, int32_t dtype,
                 int32_t precision, uint32_t *work, uint32_t *err_flag, void *stream);
 
+/* Training backward of log_prob for flows of affine couplings, layer-major: one launch per layer (or pair) with the weight gradients
+ * contracted inside the kernel (the single-launch program of SX_STEP_COUPLING_AFFINE_BWD steps run through sx_flow_run
+ * writes 896 B of per-row factors per layer for sx_wgrad_layer to read back; here only the state crosses HBM between
+ * launches).  `prog_host`: 1 .. sx_flow_bwd_max_steps() SX_STEP_COUPLING_AFFINE_BWD steps (conditioner / transformed columns = the two
+ * 32-column halves, hidden <= 64), fp16 x 3 blobs.
+ *   z / frag_in   first launch: the flow's latent z [n_rows, dim] fp32 (the adjoint starts as -g z); later launches: the
+ *                 state the previous launch left in frag_out -- [ceil(n_rows / 32)][4 tiles][4][64 lanes] float4
+ *                 (x tiles 0, 1 then dL/dx tiles 0, 1; 16 KB per 32 rows)
+ *   g             [n_rows] dL/dlog_prob
+ *   frag_out / gy state for the next launch, or (last launch) dL/d(input) [n_rows, dim]
+ *   acc_out       per step part_floats * n_part floats (sx_flow_bwd_partials): n_part tiles of [64 x 32 h_tiles | 64]
+ *                 (dW2 rows: 32 log_scale then 32 shift slots; db2) followed by n_part tiles of [32 h_tiles x 32 |
+ *                 32 h_tiles] (dW1, db1): the two inputs of sx_wgrad_reduce for that layer                         */
+int sx_flow_bwd_max_steps(void);      /* layers per launch this build supports (register budget: 1) */
+int sx_flow_bwd_partials(const sx_program *prog_host, int64_t n_rows, int32_t *n_part, int64_t *part_floats);
+int sx_flow_bwd_run(const sx_program *prog_host, const float *blobs, const float *z, const float *g,
+                    const float *frag_in, float *frag_out, float *gy, float *acc_out, int64_t n_rows,
+                    uint32_t *work, uint32_t *err_flag, void *stream);
+/* dW[rm(i)][cm(j)] += sum_p part[p][i * N32 + j] (i < m_valid, j < n_valid), db[rm(i)] += sum_p part[p][M32 * N32 + i];
+ * part: n_part tiles of M32 * N32 + M32 floats; one writer per element (deterministic). */
+int sx_wgrad_reduce(const float *part, int32_t n_part, int32_t M32, int32_t N32, float *dW, int64_t ldw, float *db,
+                    int32_t m_valid, int32_t n_valid, const int32_t *row_map, const int32_t *col_map, void *stream);
+
 /* Weight-gradient contraction over the batch axis (training):
  *   dW[rm(i), cm(j)] += sum_n A[n, i] * B[n, j]   (dW row stride ldw),   db[rm(i)] += sum_n A[n, i]   (db may be NULL)
  * A has M features, B has Nc <= 128 features, fp32, in one of two layouts:

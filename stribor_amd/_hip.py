@@ -48,7 +48,8 @@ EXPORTS = ['sx_abi_version', 'sx_fragment_mode', 'sx_last_error', 'sx_permute', 
            'sx_cubic_coupling', 'sx_pointwise', 'sx_rqs_inverse_bwd', 'sx_affine_coupling_bwd', 'sx_time_affine_coupling', 'sx_cubic_inverse_bwd', 'sx_pointwise_bwd',
            'sx_unit_normal_logprob', 'sx_sum_f64', 'sx_packed_linear_floats', 'sx_pack_linear', 'sx_flow_run',
            'sx_flow_launch_info', 'sx_wgrad', 'sx_wgrad_layer', 'sx_colsum', 'sx_tri_inverse_f64',
-           'sx_wgrad_scratch_floats', 'sx_wgrad_layer_scratch_floats']
+           'sx_wgrad_scratch_floats', 'sx_wgrad_layer_scratch_floats', 'sx_flow_bwd_max_steps', 'sx_flow_bwd_partials',
+           'sx_flow_bwd_run', 'sx_wgrad_reduce']
 
 
 class HipLibraryMissing(RuntimeError):
@@ -121,6 +122,14 @@ def _declare(lib: C.CDLL) -> None:
     lib.sx_colsum.argtypes = [vp, i64, i64, i32, vp, vp, vp]
     lib.sx_tri_inverse_f64.restype = i32
     lib.sx_tri_inverse_f64.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+    lib.sx_flow_bwd_max_steps.restype = i32
+    lib.sx_flow_bwd_max_steps.argtypes = []
+    lib.sx_flow_bwd_partials.restype = i32
+    lib.sx_flow_bwd_partials.argtypes = [C.POINTER(sx_program), i64, C.POINTER(i32), C.POINTER(i64)]
+    lib.sx_flow_bwd_run.restype = i32
+    lib.sx_flow_bwd_run.argtypes = [C.POINTER(sx_program), vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp]
+    lib.sx_wgrad_reduce.restype = i32
+    lib.sx_wgrad_reduce.argtypes = [vp, i32, i32, i32, vp, i64, vp, i32, i32, vp, vp, vp]
     lib.sx_flow_launch_info.restype = i32
     lib.sx_flow_launch_info.argtypes = [C.POINTER(sx_program), i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
 

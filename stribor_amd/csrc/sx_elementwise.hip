@@ -262,7 +262,7 @@ __device__ __forceinline__ float time_embed(int kind, float s, float t) {
     }
 }
 
-template <bool BF16>
+template <bool BF16, bool ALIGNED>
 __global__ __launch_bounds__(256) void time_affine_coupling_kernel(const void *__restrict__ x, void *__restrict__ y,
                                                                    float *__restrict__ ldj, const float *__restrict__ params,
                                                                    int64_t pstride, const float *__restrict__ t,
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void time_affine_coupling_kernel(const void *_
         else reinterpret_cast<float *>(y)[e] = out;
         return ld;
     };
-    if (ldj_mode == 2) {        // any row length, no atomics: row-aligned units (sx_common.h), fixed-order sums
+    if constexpr (ALIGNED) {    // any row length, no atomics: row-aligned units (sx_common.h), fixed-order sums
         const int lane = threadIdx.x & 63;
         const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = stride >> 6;
         const sx_units units = sx_make_units(n_rows, dim, true);
@@ -353,12 +353,12 @@ extern "C" int sx_time_affine_coupling(const void *x, void *y, float *ldj, const
     }
     const int grid = ldj_mode == 2 ? grid_for(sx_make_units(n_rows, dim, true).n_units * 64, 256) : grid_for(n_rows * dim, 256);
     const size_t lds = (size_t)dim * sizeof(int);
-    if (dtype == SX_BF16)
-        hipLaunchKernelGGL(time_affine_coupling_kernel<true>, dim3(grid), dim3(256), lds, st, x, y, ldj, params, params_stride, t,
-                           tscale, time_kind, live_idx, live_start, n_live, n_rows, dim, reverse, ldj_mode, ldj_accumulate, ldj_scale);
-    else
-        hipLaunchKernelGGL(time_affine_coupling_kernel<false>, dim3(grid), dim3(256), lds, st, x, y, ldj, params, params_stride, t,
-                           tscale, time_kind, live_idx, live_start, n_live, n_rows, dim, reverse, ldj_mode, ldj_accumulate, ldj_scale);
+#define SX_TA(BF, AL)                                                                                             \
+    hipLaunchKernelGGL((time_affine_coupling_kernel<BF, AL>), dim3(grid), dim3(256), lds, st, x, y, ldj, params, params_stride, t, \
+                       tscale, time_kind, live_idx, live_start, n_live, n_rows, dim, reverse, ldj_mode, ldj_accumulate, ldj_scale)
+    if (dtype == SX_BF16) { if (ldj_mode == 2) SX_TA(true, true); else SX_TA(true, false); }
+    else { if (ldj_mode == 2) SX_TA(false, true); else SX_TA(false, false); }
+#undef SX_TA
     SX_LAUNCH_CHECK();
     return SX_OK;
 }

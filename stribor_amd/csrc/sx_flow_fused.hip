@@ -193,10 +193,67 @@ extern "C" int sx_flow_run(const sx_program *prog_host, const float *blobs, cons
     const int64_t n_chunks = (n_rows + rpb - 1) / rpb;
     a.work = (prog_host->n_steps > 0 && n_chunks > 2 * (int64_t)a.grid && !g_static_chunks) ? work : nullptr;
     a.flags = err_flag;
+    a.frag_in = nullptr; a.frag_out = nullptr; a.acc_out = nullptr;
     const int T = prog_host->tiles, H = prog_host->h_tiles;
 #define SX_GO(TT, HH) if (T == TT && H == HH) return precision == SX_GEMM_F16X3 ? sx_flow_launch_f16x3_t##TT##h##HH(a) : sx_flow_launch_f32x_t##TT##h##HH(a)
     SX_GO(1, 1); SX_GO(1, 2); SX_GO(1, 4); SX_GO(2, 1); SX_GO(2, 2); SX_GO(2, 4); SX_GO(4, 1); SX_GO(4, 2); SX_GO(4, 4);
 #undef SX_GO
     sx_set_error("sx_flow_run: unsupported tile configuration");
     return SX_E_UNSUPPORTED;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Training backward, a PAIR of affine couplings per launch, weight gradients contracted in the kernel (MODE 11).
+// ------------------------------------------------------------------------------------------------
+static int bwd_check(const sx_program *p, dprog *d, int *bf) {
+    int mm, sw;
+    int rc = validate_and_convert(p, d, bf, &mm, &sw);
+    if (rc) return rc;
+    SX_REQUIRE(mm == 4 && p->n_steps >= 1 && p->n_steps <= SX_BWD_SLOTS && p->tiles == 4 && p->x_tiles == 2 && p->h_tiles <= 2,
+               "sx_flow_bwd_run: a program of 1..%d SX_STEP_COUPLING_AFFINE_BWD steps on 2 + 2 state tiles, hidden <= 64", SX_BWD_SLOTS);
+    for (int i = 0; i < p->n_steps; ++i)
+        SX_REQUIRE(p->steps[i].ct == 1 && (p->steps[i].c0 == 0 || p->steps[i].c0 == 1) && p->steps[i].t0 == 1 - p->steps[i].c0,
+                   "sx_flow_bwd_run: step %d: conditioner and transformed columns must be the two tile halves", i);
+    return SX_OK;
+}
+
+extern "C" int sx_flow_bwd_max_steps(void) { return SX_BWD_SLOTS; }
+
+extern "C" int sx_flow_bwd_partials(const sx_program *prog_host, int64_t n_rows, int32_t *n_part, int64_t *part_floats) {
+    dprog d; int bf;
+    int rc = bwd_check(prog_host, &d, &bf);
+    if (rc) return rc;
+    const int N2 = 32 * prog_host->h_tiles;
+    if (n_part) *n_part = pick_grid(n_rows, bf * 8 + 16, prog_host->tiles, 11);
+    if (part_floats) *part_floats = (int64_t)(64 * N2 + 64) + (int64_t)(N2 * 32 + N2);
+    return SX_OK;
+}
+
+extern "C" int sx_flow_bwd_run(const sx_program *prog_host, const float *blobs, const float *z, const float *g,
+                               const float *frag_in, float *frag_out, float *gy, float *acc_out, int64_t n_rows,
+                               uint32_t *work, uint32_t *err_flag, void *stream) {
+    dprog d; int bf;
+    int rc = bwd_check(prog_host, &d, &bf);
+    if (rc) return rc;
+    SX_REQUIRE(blobs && g && acc_out && n_rows >= 0, "sx_flow_bwd_run: null pointer");
+    SX_REQUIRE((z != nullptr) != (frag_in != nullptr), "sx_flow_bwd_run: give z (first launch) or frag_in (later launches)");
+    SX_REQUIRE((gy != nullptr) != (frag_out != nullptr), "sx_flow_bwd_run: give gy (last launch) or frag_out (earlier launches)");
+    SX_REQUIRE(prog_host->identity_cols || z == nullptr, "sx_flow_bwd_run: z is read in the flow's own column order (identity_cols)");
+    SX_REQUIRE((((uintptr_t)frag_in | (uintptr_t)frag_out | (uintptr_t)z | (uintptr_t)gy) & 15) == 0, "sx_flow_bwd_run: 16-byte alignment");
+    if (n_rows == 0) return SX_OK;
+    sx_flow_args a;
+    a.prog = d; a.blobs = blobs; a.x = z ? (const void *)z : (const void *)frag_in; a.latent = nullptr; a.in_col = nullptr; a.out_col = nullptr;
+    a.y = gy; a.ldj_out = nullptr; a.logp_out = nullptr; a.sum_out = nullptr; a.mlp_out = nullptr; a.mlp_out_stride = 0;
+    a.mlp_out_dim = 0; a.n_rows = n_rows; a.buf_floats = bf; a.bf16 = 0; a.mlp_mode = 11; a.lds = bf * 8 + 16;
+    a.grid = pick_grid(n_rows, a.lds, prog_host->tiles, 11);
+    a.stream = sx_stream(stream);
+    a.row_t = g; a.side = nullptr; a.side_width = 0;
+    const int rpb = 32 * SX_BLOCK_WAVES(prog_host->tiles, 11);
+    const int64_t n_chunks = (n_rows + rpb - 1) / rpb;
+    a.work = (n_chunks > 2 * (int64_t)a.grid && !g_static_chunks) ? work : nullptr;
+    a.flags = err_flag;
+    a.frag_in = frag_in; a.frag_out = frag_out; a.acc_out = acc_out;
+    if (prog_host->h_tiles == 1) return sx_flow_launch_f16x3_t4h1(a);
+    return sx_flow_launch_f16x3_t4h2(a);
 }

@@ -431,6 +431,16 @@ __device__ __forceinline__ void hidden_layer(const tile<NS> (&src)[NSRC], tile<N
     hidden_body<NS, HT, CT, FOLDED>(bsrc, hid, w, off, act);
 }
 
+// hidden_layer that hands the B fragments of its source tiles back (the training backward contracts them again)
+template <int NS, int NSRC, int HT, int C0, int CT, bool FOLDED>
+__device__ __forceinline__ void hidden_layer_keep(const tile<NS> (&src)[NSRC], tile<NS> (&hid)[HT], btile<NS> (&bsrc)[CT],
+                                                  const wptr w, int off, int act, rng_t &rg) {
+#pragma unroll
+    for (int c = 0; c < CT; ++c) bsrc[c] = make_btile<NS>(src[C0 + c], rg);
+    __builtin_amdgcn_sched_barrier(0);
+    hidden_body<NS, HT, CT, FOLDED>(bsrc, hid, w, off, act);
+}
+
 // Affine coupling step (affine.py:104-109 through coupling.py:69-95), conditioner evaluated once (quirk Q2).
 // FOLDED (the Tanh hot path): no runtime conditionals inside; REV selects (x - sh)*scale vs x*scale + sh.
 template <int NS, int TX, int HT, int C0, int CT, int T0, int TT, bool FOLDED, bool REV>
@@ -948,6 +958,197 @@ __device__ __forceinline__ void coupling_affine_bwd(tile<1> (&xs)[2 * XT], const
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Training backward with the weight gradients contracted IN the kernel (fp16 x 3 build only).
+//
+// The single-launch backward above writes 224 floats of per-row factors per layer to HBM (7.5 GB per 2^20-row cfg-2
+// step) and sx_wgrad_layer reads them back: ~28x the step's algorithmic traffic.  Here a launch covers a PAIR of
+// layers and keeps dW2 / dW1 of both in accumulator registers over all the chunks a wave processes (2 x 6 tiles =
+// 192 registers: one wave per SIMD owns the 512-register file), so only the state (x | dL/dx) crosses HBM between
+// launches, in fragment order (1 KB per load / store instruction).
+//
+// The contraction runs over the BATCH, which sits on the MFMA lanes; an MFMA sums over registers.  The factor tiles
+// already exist as fp16 hi / lo B fragments (they feed the step's own GEMMs); used as the A operand against a 0/1
+// selection matrix, X^T . I = X^T (cdna_hip_programming.md, 'An accumulator tile as the next MFMA's operand'), the
+// matrix pipe itself turns a tile: 2 MFMAs per part, exact (fp16 x 1.0 in an fp32 accumulator), no LDS.  The turned
+// parts convert back to fp16 exactly, and dW[i][j] += sum_n A[n,i] B[n,j] is the usual 3-product split GEMM with
+// k = sample.  tanh h = 1 - 2r is never formed: sum_n dp_n (1 - 2 r_n)^T = (sum_n dp_n) 1^T - 2 sum_n dp_n r_n^T is
+// applied once per workgroup at the end.
+// ------------------------------------------------------------------------------------------------
+#ifdef SX_F16X3
+struct sel_t {                 // I_s as a B operand: lane (c, h), element j = [16 s + 8 (j >> 2) + 4 h + (j & 3) == c]
+    h8 s[2];
+};
+__device__ __forceinline__ sel_t make_sel(int lane) {
+    sel_t r;
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.s[st][j] = (16 * st + 8 * (j >> 2) + 4 * h + (j & 3) == c) ? (_Float16)1.0f : (_Float16)0.0f;
+    return r;
+}
+struct tfrag {                 // one turned tile: lane = feature, k = sample; hi / lo parts, two k16 steps
+    h8 hi[2], lo[2];
+};
+__device__ __forceinline__ void turn_part(const h8 (&p)[2], const sel_t &sel, h8 (&out)[2], float &colsum) {
+    f32x16 t;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = 0.f;
+    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(p[0], sel.s[0], t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(p[1], sel.s[1], t, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        u32x4 u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) u[q] = pk_rtz(t[8 * s + 2 * q], t[8 * s + 2 * q + 1]);     // exact: the values are fp16
+        out[s] = __builtin_bit_cast(h8, u);
+    }
+    float a = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a += t[r];
+    colsum += a;
+}
+// turned fragments of a factor tile + (optionally) the per-feature sum over this wave's samples
+__device__ __forceinline__ tfrag turn_tile(const btile<1> &b, const sel_t &sel, float &colsum) {
+    tfrag t;
+    turn_part(b.hi[0], sel, t.hi, colsum);
+    turn_part(b.lo[0], sel, t.lo, colsum);
+    return t;
+}
+// acc[i][j] += sum_n A[n, i] B[n, j]   (rows = A's features, columns = B's features)
+__device__ __forceinline__ void contract(const tfrag &a, const tfrag &b, f32x16 &acc) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.lo[s], b.hi[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi[s], b.lo[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi[s], b.hi[s], acc, 0, 0, 0);
+    }
+}
+template <int HT>
+struct wacc {                  // one layer's weight-gradient accumulators (pruned halves: CT = TT = 1)
+    f32x16 c2[2][HT];          // [dp tile (ls, sh)][hidden tile]: sum_n dp_n r_n^T
+    f32x16 c1[HT];             // [hidden tile]:                    sum_n dh_pre_n z_n^T
+    float b2[2], b1[HT];       // per-lane (= per feature) sums of dp and dh_pre over this wave's samples
+};
+template <int HT>
+__device__ __forceinline__ void wacc_zero(wacc<HT> &a) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        a.b2[p] = 0.f;
+#pragma unroll
+        for (int m = 0; m < HT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a.c2[p][m][r] = 0.f;
+    }
+#pragma unroll
+    for (int m = 0; m < HT; ++m) {
+        a.b1[m] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a.c1[m][r] = 0.f;
+    }
+}
+
+// One affine coupling of the backward pass (as coupling_affine_bwd, XT = 2, pruned halves) with its weight gradients
+// accumulated into `A`.  `live`: this lane's sample is a real row (a padded tail row contributes nothing).
+template <int HT, int C0, int T0>
+__device__ __forceinline__ void coupling_affine_bwd_acc(tile<1> (&xs)[4], const wptr w, float g, bool live, wacc<HT> &A,
+                                                        const sel_t &sel, rng_t &rg) {
+    constexpr int XT = 2, CT = 1, TT = 1;
+    constexpr int F1 = 0;
+    constexpr int F2 = HT * CT * 1024 + HT * 32;
+    constexpr int F2B = F2 + 2 * TT * HT * 1024;
+    constexpr int B2 = F2B + 2 * TT * 32;
+    constexpr int B1 = B2 + HT * 2 * TT * 1024 + HT * 32;
+    // Register budget: state 64 + two layers' accumulators 192 of the 512; every fragment below is formed as late and
+    // dropped as early as possible (z is split twice, r is rebuilt from its fp16 parts instead of being kept in fp32).
+    // 1. conditioner (folded tanh: r = (1 - tanh) / 2)
+    btile<1> bh[HT];
+    {
+        tile<1> hid[HT];
+        hidden_layer<1, 4, HT, C0, CT, true>(xs, hid, w, F1, SX_ACT_TANH_FOLDED, rg);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hid[HT - 1].v[0][r] = fast_sig2(hid[HT - 1].v[0][r]);
+#pragma unroll
+        for (int m = 0; m < HT; ++m) bh[m] = make_btile<1>(hid[m]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // 2. (kk log_scale, shift), un-transform, adjoints of the parameters
+    btile<1> b0, b1;
+    {
+        tile<1> ls = load_cfrag<1>(w.cb, F2B), sh = load_cfrag<1>(w.cb, F2B + 32);
+#pragma unroll
+        for (int m = 0; m < HT; ++m) {
+            gemm_tile<1>(w.wb, F2 + m * 1024, bh[m], ls);
+            gemm_tile<1>(w.wb, F2 + (HT + m) * 1024, bh[m], sh);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f(ls.v[0][r]);                     // exp(-log_scale)
+            const float xo = xs[T0].v[0][r], al = xs[XT + T0].v[0][r];
+            xs[T0].v[0][r] = xo * __builtin_amdgcn_exp2f(-ls.v[0][r]) + sh.v[0][r];  // x_in
+            const float ai = al * e;                                                // dL/dx_in
+            xs[XT + T0].v[0][r] = ai;
+            sh.v[0][r] = live ? -ai : 0.f;                                          // dL/dshift
+            ls.v[0][r] = live ? -al * xo - g : 0.f;                                 // dL/dlog_scale (incl. -sum(ls))
+        }
+        b0 = make_btile<1>(ls, rg);
+        b1 = make_btile<1>(sh, rg);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // 3. dW2 partial: sum_n dp_n r_n^T (turned tiles; the tanh fix-up happens once per workgroup), one hidden tile at a time
+    {
+        float dummy = 0.f;
+        const tfrag t0 = turn_tile(b0, sel, A.b2[0]), t1 = turn_tile(b1, sel, A.b2[1]);
+#pragma unroll
+        for (int m = 0; m < HT; ++m) {
+            const tfrag th = turn_tile(bh[m], sel, dummy);
+            contract(t0, th, A.c2[0][m]);
+            contract(t1, th, A.c2[1][m]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // 4. dh = W2^T [dls; dsh];  dh_pre = dh (1 - tanh^2) with tanh = 1 - 2 r, r = hi + lo of its fp16 parts
+    btile<1> bd[HT];
+#pragma unroll
+    for (int m = 0; m < HT; ++m) {
+        tile<1> dh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh.v[0][r] = 0.f;
+        gemm_tile<1>(w.wb, B2 + (m * 2) * 1024, b0, dh);
+        gemm_tile<1>(w.wb, B2 + (m * 2 + 1) * 1024, b1, dh);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float rr = (float)bh[m].hi[0][s][j] + (float)bh[m].lo[0][s][j];
+                const float th = 1.f - 2.f * rr;
+                dh.v[0][8 * s + j] *= (1.f - th * th);
+            }
+        bd[m] = make_btile<1>(dh, rg);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // 5. adjoint of the conditioning tile += W1^T dh_pre;  dW1 partial: sum_n dh_pre_n z_n^T
+    {
+        tile<1> dz;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dz.v[0][r] = 0.f;
+#pragma unroll
+        for (int m = 0; m < HT; ++m) gemm_tile<1>(w.wb, B1 + m * 1024, bd[m], dz);
+        float dummy = 0.f;
+        const tfrag tz = turn_tile(make_btile<1>(xs[C0]), sel, dummy);      // z again (the tile itself is unchanged)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xs[XT + C0].v[0][r] += dz.v[0][r];
+#pragma unroll
+        for (int m = 0; m < HT; ++m) {
+            const tfrag td = turn_tile(bd[m], sel, A.b1[m]);
+            contract(td, tz, A.c1[m]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+#endif   // SX_F16X3
+
 __device__ __forceinline__ float ld_elem(const void *p, int64_t off, int bf16) {
     if (bf16) return bf16_to_f32(reinterpret_cast<const uint16_t *>(p)[off]);
     return reinterpret_cast<const float *>(p)[off];
@@ -963,12 +1164,17 @@ struct flow_kargs {     // everything but the program, by value in the kernarg s
     int64_t mlp_out_stride; int64_t n_rows; int mlp_out_dim; int buf_floats; int bf16; int side_width;
     uint32_t *work;     // {next-chunk ticket, finished workgroups}: dynamic chunk hand-out (NULL = static stride)
     uint32_t *flags;    // caller's error-flag word (SX_FLAG_*; device or host-mapped memory), or NULL
+    // MODE 11 (training backward, weight gradients contracted in-kernel; see coupling_affine_bwd_acc)
+    const float *frag_in;   // state (x | dL/dx) of the previous launch in fragment order, or NULL: start from z (= x) and row_t
+    float *frag_out;        // state for the next launch, or NULL: y receives dL/d(input)
+    float *acc_out;         // [n_steps]{[gridDim.x][E2], [gridDim.x][E1]} per-workgroup weight-gradient partials (wgrad_reduce layout)
 };
 
 // MODE 0: flow programs (coupling / affine-const steps); MODE 1: + persistent hidden state (MLP programs);
 // MODE 2: flow programs with dense linear layers (AffineLU / MatrixExponential): + a second state tile set;
 // MODE 3: flow programs with rational-quadratic spline couplings: + hidden B operands and the group state;
 // MODE 4: training backward of affine-coupling log_prob flows: tiles [0,2) = x, [2,4) = dL/dx
+// MODE 11: the same for a pair of layers per launch with the weight gradients contracted in-kernel (fp16 x 3 build)
 template <int NS, int TX, int HT, int MODE>
 __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MODE)) void flow_fused_kernel(const dprog prog, const flow_kargs k) {
     constexpr int WB = SX_BLOCK_WAVES(TX, MODE);      // waves per workgroup
@@ -1005,6 +1211,15 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
     // issue arbiter favours the oldest wave), so a static stride leaves the last third of the kernel with CUs
     // running one workgroup.  Thread 0 takes a ticket for the NEXT chunk in the prologue; it travels to the other
     // waves through LDS across the first step's barrier (two slots, alternating, behind the weight ring).
+#ifdef SX_F16X3
+    [[maybe_unused]] wacc<HT> WA[MODE == 11 ? SX_BWD_SLOTS : 1];
+    [[maybe_unused]] sel_t sel;
+    if constexpr (MODE == 11) {
+        wacc_zero<HT>(WA[0]);
+        wacc_zero<HT>(WA[SX_BWD_SLOTS - 1]);
+        sel = make_sel(lane);
+    }
+#endif
     const bool dyn = k.work != nullptr;
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
     lds_u32 *slot = (lds_u32 *)(smem + 2 * buf_floats);      // ds_write_b32 / ds_read_b32, ordered by the barrier
@@ -1025,6 +1240,26 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
 
         // ---- load the state tiles in C-fragment order ---------------------------------------------------
         tile<NS> xs[TX];
+        bool from_frag = false;
+        if constexpr (MODE == 11) {
+            from_frag = k.frag_in != nullptr;
+            if (from_frag) {
+                // fragment-order state of the previous launch: [32-row group][tile][q][lane] float4 (1 KB per instruction)
+                const int64_t n_grp = (n_rows + 31) >> 5;
+                int64_t grp = chunk * WB + wave;
+                grp = grp < n_grp ? grp : n_grp - 1;
+                const f32x4 *fi = reinterpret_cast<const f32x4 *>(k.frag_in) + grp * (TX * 4 * 64) + lane;
+#pragma unroll
+                for (int t = 0; t < TX; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = fi[(t * 4 + q) * 64];
+                        xs[t].v[0][4 * q + 0] = v.x; xs[t].v[0][4 * q + 1] = v.y;
+                        xs[t].v[0][4 * q + 2] = v.z; xs[t].v[0][4 * q + 3] = v.w;
+                    }
+            }
+        }
+        if (!from_frag)
 #pragma unroll
         for (int n = 0; n < NS; ++n) {
 #pragma unroll
@@ -1054,7 +1289,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                             xs[t].v[n][r] = c >= 0 ? ld_elem(k.x, lrow[n] * dim + c, bf16) : 0.f;
                         }
                     }
-                } else if constexpr (MODE == 4) {
+                } else if constexpr (MODE == 4 || MODE == 11) {
                     // adjoint tiles: dL/dz of log p = -z^2/2 + ... is -g z (g = dL/dlog_prob of the row)
                     if constexpr (TX == 2 || TX == 4) {
                         const float gg = k.row_t[lrow[n]];
@@ -1119,6 +1354,21 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     if (st.c0 == 0) coupling_affine<NS, TX, HT, 0, TX / 2, TX / 2, TX / 2, true, MODE == 5>(xs, w, st, ldj, pf, rg);
                     else coupling_affine<NS, TX, HT, TX / 2, TX / 2, 0, TX / 2, true, MODE == 5>(xs, w, st, ldj, pf, rg);
                 }
+            } else if constexpr (MODE == 11) {
+#ifdef SX_F16X3
+                if constexpr (TX == 4 && NS == 1 && HT <= 2) {
+                    const float gg = k.row_t[lrow[0]];
+                    const bool live = row[0] < n_rows;
+                    // static accumulator slots (the host keeps a MODE 11 program to SX_BWD_SLOTS steps)
+                    if (SX_BWD_SLOTS == 1 || s == 0) {
+                        if (st.c0 == 0) coupling_affine_bwd_acc<HT, 0, 1>(xs, w, gg, live, WA[0], sel, rg);
+                        else coupling_affine_bwd_acc<HT, 1, 0>(xs, w, gg, live, WA[0], sel, rg);
+                    } else {
+                        if (st.c0 == 0) coupling_affine_bwd_acc<HT, 0, 1>(xs, w, gg, live, WA[SX_BWD_SLOTS - 1], sel, rg);
+                        else coupling_affine_bwd_acc<HT, 1, 0>(xs, w, gg, live, WA[SX_BWD_SLOTS - 1], sel, rg);
+                    }
+                }
+#endif
             } else if ((MODE == 7 || MODE == 8) && st.kind == SX_STEP_COUPLING_AFFINE) {
                 // dense linear layers + pure split couplings (cfg 4): the same two arms instead of the general dispatch
                 if constexpr (TX >= 2 && (MODE == 7 || MODE == 8)) {
@@ -1360,13 +1610,23 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
             }
         }
 #endif
+        if constexpr (MODE == 11) {
+            if (k.frag_out != nullptr && chunk * WB + wave < ((n_rows + 31) >> 5)) {
+                f32x4 *fo = reinterpret_cast<f32x4 *>(k.frag_out) + (chunk * WB + wave) * (TX * 4 * 64) + lane;
+#pragma unroll
+                for (int t = 0; t < TX; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        fo[(t * 4 + q) * 64] = f32x4{xs[t].v[0][4 * q], xs[t].v[0][4 * q + 1], xs[t].v[0][4 * q + 2], xs[t].v[0][4 * q + 3]};
+            }
+        }
 #pragma unroll
         for (int n = 0; n < NS; ++n) {
             if (k.y != nullptr && row[n] < n_rows) {
 #pragma unroll
                 for (int t = 0; t < TX; ++t) {
                     if (t < x_tiles) {
-                        const int ts = (MODE == 4) ? t + TX / 2 : t;      // backward: y receives dL/d(input)
+                        const int ts = (MODE == 4 || MODE == 11) ? t + TX / 2 : t;      // backward: y receives dL/d(input)
                         if (prog.identity_cols) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
@@ -1421,6 +1681,59 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
         __threadfence();
         if (atomicAdd(k.work + 1, 1u) == gridDim.x - 1) { k.work[0] = 0u; k.work[1] = 0u; }
     }
+#ifdef SX_F16X3
+    if constexpr (MODE == 11) {
+        // one partial per workgroup and layer, in wgrad_reduce_kernel's layout: [64 x 32 HT | 64] then [32 HT x 32 | 32 HT];
+        // the waves add their tiles in LDS by turns, then dW2 = (sum dp) 1^T - 2 sum dp r^T is applied and stored
+        constexpr int N2 = 32 * HT, E2 = 64 * N2 + 64, E1 = 32 * HT * 32 + 32 * HT;
+        const int i = lane & 31, kk = lane >> 5;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                    // nobody reads the weight ring any more
+        float *red = smem;
+#pragma unroll
+        for (int slot = 0; slot < SX_BWD_SLOTS; ++slot) {
+            if (slot < n_steps) {
+                const wacc<HT> &A = WA[slot];
+                for (int wv = 0; wv < WB; ++wv) {
+                    if (wave == wv) {
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                            for (int m = 0; m < HT; ++m)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    const int e = (32 * p + (r & 3) + 8 * (r >> 2) + 4 * kk) * N2 + 32 * m + i;
+                                    red[e] = (wv == 0 ? 0.f : red[e]) + A.c2[p][m][r];
+                                }
+                            const float tb = A.b2[p] + __shfl_xor(A.b2[p], 32, 64);
+                            if (kk == 0) { const int e = 64 * N2 + 32 * p + i; red[e] = (wv == 0 ? 0.f : red[e]) + tb; }
+                        }
+#pragma unroll
+                        for (int m = 0; m < HT; ++m) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int e = E2 + (32 * m + (r & 3) + 8 * (r >> 2) + 4 * kk) * 32 + i;
+                                red[e] = (wv == 0 ? 0.f : red[e]) + A.c1[m][r];
+                            }
+                            const float tb = A.b1[m] + __shfl_xor(A.b1[m], 32, 64);
+                            if (kk == 0) { const int e = E2 + 32 * HT * 32 + 32 * m + i; red[e] = (wv == 0 ? 0.f : red[e]) + tb; }
+                        }
+                    }
+                    __syncthreads();
+                }
+                // per step: [gridDim.x][E2] then [gridDim.x][E1] (two inputs of wgrad_reduce_kernel)
+                float *dst2 = k.acc_out + (int64_t)slot * gridDim.x * (E2 + E1) + (int64_t)blockIdx.x * E2;
+                float *dst1 = k.acc_out + (int64_t)slot * gridDim.x * (E2 + E1) + (int64_t)gridDim.x * E2 + (int64_t)blockIdx.x * E1;
+                for (int e = threadIdx.x; e < E2 + E1; e += 64 * WB) {
+                    float v = red[e];
+                    if (e < 64 * N2) v = red[64 * N2 + e / N2] - 2.f * v;          // tanh = 1 - 2 r
+                    if (e < E2) dst2[e] = v; else dst1[e - E2] = v;
+                }
+                __syncthreads();
+            }
+        }
+    }
+#endif
 
 #ifdef SX_DEBUG_KNOBS
     SX_STAMP(pf, 7);             // epilogue of the last chunk
@@ -1469,6 +1782,7 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
     k.ldj_out = a.ldj_out; k.logp_out = a.logp_out; k.sum_out = a.sum_out; k.mlp_out = a.mlp_out; k.row_t = a.row_t; k.side = a.side;
     k.mlp_out_stride = a.mlp_out_stride; k.n_rows = a.n_rows; k.mlp_out_dim = a.mlp_out_dim;
     k.buf_floats = a.buf_floats; k.bf16 = a.bf16; k.side_width = a.side_width; k.work = a.work; k.flags = a.flags;
+    k.frag_in = a.frag_in; k.frag_out = a.frag_out; k.acc_out = a.acc_out;
 #define SX_FL(MD)                                                                                              \
     do {                                                                                                       \
         auto kern = flow_fused_kernel<NS, TX, HT, MD>;                                                         \
@@ -1488,6 +1802,12 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
     else if (a.mlp_mode == 10) SX_FL(10);
     else if (a.mlp_mode == 7) { if constexpr (TX >= 2) SX_FL(7); }
     else if (a.mlp_mode == 8) { if constexpr (TX >= 2) SX_FL(8); }
+    else if (a.mlp_mode == 11) {
+#ifdef SX_F16X3
+        if constexpr (TX == 4 && HT <= 2) SX_FL(11); else
+#endif
+        { sx_set_error("sx_flow_bwd_run: needs 4 state tiles, hidden <= 64 and the fp16 x 3 arithmetic"); return SX_E_UNSUPPORTED; }
+    }
     else SX_FL(0);
 #undef SX_FL
     SX_LAUNCH_CHECK();

@@ -25,8 +25,18 @@ struct sx_flow_args {
     int side_width;
     uint32_t *work;
     uint32_t *flags;
+    const float *frag_in;
+    float *frag_out;
+    float *acc_out;
 };
 
+
+// Layers per launch of the training backward with in-kernel weight-gradient contraction (MODE 11): every layer keeps
+// 6 accumulator tiles (96 registers) alive over the whole launch.  With 2 the kernel needs 553 registers (984 B of
+// scratch per lane on top of the 512-register file); with 1 it fits (457, no scratch).
+#ifndef SX_BWD_SLOTS
+#define SX_BWD_SLOTS 1
+#endif
 
 // sample tiles (of 32 rows) per wave: 2 while the state fits the register file twice over, else 1
 // (measured on cfg 2, MI355X: 2 sample tiles per wave buy nothing over 1 at 2 workgroups per CU -- 1.87e9 rows/s
@@ -44,7 +54,7 @@ struct sx_flow_args {
 #define SX_RQS_WAVES 2
 #endif
 #ifndef SX_WAVES_FOR
-#define SX_WAVES_FOR(TX, MODE) ((MODE) == 10 ? ((TX) >= 4 ? 1 : SX_RQS_WAVES) : (MODE) == 9 ? ((TX) >= 4 ? 1 : 2) : (MODE) >= 7 ? 2 : (MODE) >= 5 ? ((TX) >= 4 ? 2 : 4) : ((TX) >= 4 ? 1 : ((MODE) == 3 ? SX_RQS_WAVES : ((MODE) == 0 ? 3 : 2))))
+#define SX_WAVES_FOR(TX, MODE) ((MODE) == 11 ? 1 : (MODE) == 10 ? ((TX) >= 4 ? 1 : SX_RQS_WAVES) : (MODE) == 9 ? ((TX) >= 4 ? 1 : 2) : (MODE) >= 7 ? 2 : (MODE) >= 5 ? ((TX) >= 4 ? 2 : 4) : ((TX) >= 4 ? 1 : ((MODE) == 3 ? SX_RQS_WAVES : ((MODE) == 0 ? 3 : 2))))
 #endif
 
 // waves per workgroup: the pure split-coupling kernels (MODE 5 / 6) run 8-wave workgroups -- D <= 64 (128 VGPRs): two

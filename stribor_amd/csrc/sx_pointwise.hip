@@ -80,7 +80,7 @@ __device__ __forceinline__ void pw_eval(int kind, float param, float log_slope, 
 }
 
 // VEC = 4: one lane = 4 consecutive elements of one row (dim % 4 == 0): 16-byte (fp32) / 8-byte (bf16) accesses
-template <bool BF16, int VEC>
+template <bool BF16, int VEC, bool ALIGNED>
 __global__ __launch_bounds__(256) void pointwise_kernel(const void *__restrict__ x, void *__restrict__ y,
                                                         float *__restrict__ ldj, float *__restrict__ ldiag,
                                                         int64_t n_rows, int dim, int kind, float param, float log_slope,
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const void *__restrict__
         }
         return ld_sum;
     };
-    if (ldj_mode == 2) {
+    if constexpr (ALIGNED) {
         // row sums for any row length without atomics: row-aligned units (sx_common.h), fixed-order sums
         const int lane = threadIdx.x & 63;
         const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = stride >> 6;
@@ -321,12 +321,14 @@ extern "C" int sx_pointwise(const void *x, void *y, float *ldj, float *ldiag, in
     int64_t g = ldj_mode == 2 ? (sx_make_units(n_rows, gdim, true).n_units + 3) / 4 : (n_rows * gdim + 255) / 256;
     if (g > 256 * 8) g = 256 * 8;
     if (g < 1) g = 1;
-#define SX_PWL(BF, V)                                                                                             \
-    hipLaunchKernelGGL((pointwise_kernel<BF, V>), dim3((int)g), dim3(256), 0, st, x, y, ldj, ldiag, n_rows, dim, kind, \
+#define SX_PWL2(BF, V, AL)                                                                                        \
+    hipLaunchKernelGGL((pointwise_kernel<BF, V, AL>), dim3((int)g), dim3(256), 0, st, x, y, ldj, ldiag, n_rows, dim, kind, \
                        param, log_slope, ldj_mode, ldj_accumulate)
+#define SX_PWL(BF, V) do { if (ldj_mode == 2) SX_PWL2(BF, V, true); else SX_PWL2(BF, V, false); } while (0)
     if (dtype == SX_BF16) { if (vec4) SX_PWL(true, 4); else SX_PWL(true, 1); }
     else { if (vec4) SX_PWL(false, 4); else SX_PWL(false, 1); }
 #undef SX_PWL
+#undef SX_PWL2
     SX_LAUNCH_CHECK();
     return SX_OK;
 }

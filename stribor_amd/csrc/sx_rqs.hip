@@ -153,7 +153,7 @@ __device__ __forceinline__ void rqs16_eval(const float *__restrict__ p, float xv
     ljd = inside ? ljd : 0.f;
 }
 
-template <bool BF16, bool INVERSE>
+template <bool BF16, bool INVERSE, bool ALIGNED>
 __global__ __launch_bounds__(256) void rqs_kernel(const void *__restrict__ x, void *__restrict__ y,
                                                   float *__restrict__ ldj, float *__restrict__ ldiag,
                                                   const float *__restrict__ params, int64_t pstride,
@@ -166,7 +166,9 @@ __global__ __launch_bounds__(256) void rqs_kernel(const void *__restrict__ x, vo
     const int waves_per_block = blockDim.x >> 6;
     float *sp = rqs_smem + (size_t)wave * 64 * P;               // this wave's staging slice
     const int64_t n_elem = n_rows * n_live;
-    const sx_units units = sx_make_units(n_rows, n_live, ldj_mode == 2);
+    // ALIGNED (ldj_mode 2): row-aligned work units, per-row sums without atomics; the dense variant is compiled without
+    // any of it (its software-pipelined staging sits at 163 VGPRs = 3 waves per SIMD)
+    const sx_units units = sx_make_units(n_rows, n_live, ALIGNED);
     const int64_t n_groups = units.n_units;
     const float lo_in = INVERSE ? bottom : left, hi_in = INVERSE ? top : right;
     const float bconst = logf(expf(1.f - RQS_MIN_DERIV) - 1.f);  // :81 boundary derivative constant
@@ -178,14 +180,15 @@ __global__ __launch_bounds__(256) void rqs_kernel(const void *__restrict__ x, vo
     bool have_pf = false;
     for (int64_t grp = (int64_t)blockIdx.x * waves_per_block + wave; grp < n_groups;
          grp += (int64_t)gridDim.x * waves_per_block) {
-      float row_acc = 0.f;                     // ldj_mode 2, rows wider than a wave: the row's sum over its chunks
-      for (int chunk = 0; chunk < units.chunks; ++chunk) {
+      [[maybe_unused]] float row_acc = 0.f;    // ALIGNED, rows wider than a wave: the row's sum over its chunks
+      for (int chunk = 0; chunk < (ALIGNED ? units.chunks : 1); ++chunk) {
         int64_t e0;
         int n_here;
-        sx_unit_span(units, grp, chunk, n_rows, n_live, &e0, &n_here);
+        if constexpr (ALIGNED) sx_unit_span(units, grp, chunk, n_rows, n_live, &e0, &n_here);
+        else { e0 = grp << 6; n_here = (int)((n_elem - e0) < 64 ? (n_elem - e0) : 64); }
         // ---- stage the elements' parameters: consecutive idx -> consecutive HBM addresses inside a row ----
         const int total = n_here * P;
-        if (contig && n_here == 64 && P == 47 && units.rows_per_unit == 0) {
+        if (!ALIGNED && contig && n_here == 64 && P == 47) {
             // the 64 elements' parameters are one contiguous, 16-byte aligned span of 752 float4: 11.75 per lane.
             // Software pipeline: this group's span was fetched into registers one iteration ago; park it in LDS,
             // then fetch the NEXT group's span so its latency hides under this group's arithmetic.
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(256) void rqs_kernel(const void *__restrict__ x, vo
                 for (int t = 0; t < 12; ++t)
                     if (t * 64 + lane < 752) pf[t] = src[t * 64 + lane];
             }
-        } else if (contig && n_here == 64 && ((e0 * P) & 3) == 0) {
+        } else if (contig && n_here == 64 && (!ALIGNED || ((e0 * P) & 3) == 0)) {
             have_pf = false;
             const f32x4 *src = reinterpret_cast<const f32x4 *>(params + e0 * P);
             f32x4 *dst = reinterpret_cast<f32x4 *>(sp);
@@ -307,7 +310,8 @@ __global__ __launch_bounds__(256) void rqs_kernel(const void *__restrict__ x, vo
             float s = valid ? ljd : 0.f;
             s = group_sum_rt(s, n_live);
             if (valid && (lane & (n_live - 1)) == 0) ldj[row] = (ldj_acc ? ldj[row] : 0.f) + ldj_scale * s;
-        } else if (ldj_mode == 2) {          // row-aligned units: fixed-order sums, no atomics
+        }
+        if constexpr (ALIGNED) {             // row-aligned units: fixed-order sums, no atomics
             const float s0 = valid ? ljd : 0.f;
             if (units.chunks == 1) {
                 const float s = segment_sum_rt(s0, i, n_live);
@@ -317,9 +321,11 @@ __global__ __launch_bounds__(256) void rqs_kernel(const void *__restrict__ x, vo
             }
         }
       }
-      if (ldj_mode == 2 && units.chunks > 1) {
-          const float s = group_sum<64>(row_acc);
-          if (lane == 0) ldj[grp] = (ldj_acc ? ldj[grp] : 0.f) + ldj_scale * s;
+      if constexpr (ALIGNED) {
+          if (units.chunks > 1) {
+              const float s = group_sum<64>(row_acc);
+              if (lane == 0) ldj[grp] = (ldj_acc ? ldj[grp] : 0.f) + ldj_scale * s;
+          }
       }
     }
 }
@@ -377,17 +383,20 @@ extern "C" int sx_rqs_coupling(const void *x, void *y, float *ldj, float *ldiag,
     if (grid < 1) grid = 1;
     if (lds > 48 * 1024) {
 #define SX_ATTR(BF, INV)                                                                                          \
-    (void)hipFuncSetAttribute((const void *)rqs_kernel<BF, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+    (void)hipFuncSetAttribute((const void *)rqs_kernel<BF, INV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    (void)hipFuncSetAttribute((const void *)rqs_kernel<BF, INV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
         SX_ATTR(true, true); SX_ATTR(true, false); SX_ATTR(false, true); SX_ATTR(false, false);
 #undef SX_ATTR
     }
-#define SX_RQ(BF, INV)                                                                                           \
-    hipLaunchKernelGGL((rqs_kernel<BF, INV>), dim3((int)grid), dim3(block), lds, st, x, y, ldj, ldiag, params,    \
+#define SX_RQ2(BF, INV, AL)                                                                                      \
+    hipLaunchKernelGGL((rqs_kernel<BF, INV, AL>), dim3((int)grid), dim3(block), lds, st, x, y, ldj, ldiag, params, \
                        params_stride, live_idx, live_start, n_live, n_bins, left, right, bottom, top, n_rows, dim, \
                        ldj_mode, ldj_accumulate, ldj_scale, err_flag)
+#define SX_RQ(BF, INV) do { if (ldj_mode == 2) SX_RQ2(BF, INV, true); else SX_RQ2(BF, INV, false); } while (0)
     if (dtype == SX_BF16) { if (reverse) SX_RQ(true, true); else SX_RQ(true, false); }
     else { if (reverse) SX_RQ(false, true); else SX_RQ(false, false); }
 #undef SX_RQ
+#undef SX_RQ2
     SX_LAUNCH_CHECK();
     return SX_OK;
 }
@@ -420,7 +429,7 @@ __device__ __forceinline__ float cubic_exp(float v) {
     return __builtin_amdgcn_exp2f(t) * (1.f + r * 0.69314718055994531f);
 }
 
-template <bool BF16, bool INVERSE>
+template <bool BF16, bool INVERSE, bool ALIGNED>
 __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, void *__restrict__ y,
                                                     float *__restrict__ ldj, float *__restrict__ ldiag,
                                                     const float *__restrict__ params, int64_t pstride,
@@ -432,7 +441,8 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int waves_per_block = blockDim.x >> 6;
     float *sp = rqs_smem + (size_t)wave * 64 * PS;
-    const sx_units units = sx_make_units(n_rows, n_live, ldj_mode == 2);
+    const sx_units units = sx_make_units(n_rows, n_live, ALIGNED);
+    const int64_t n_elem = n_rows * n_live;
     const int64_t n_groups = units.n_units;
     const float norm = 1.f - CUBIC_MIN_BIN * (float)K;          // :104, :111
     const float span = upper - lower;                            // right - left = top - bottom
@@ -441,14 +451,15 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
 
     for (int64_t grp = (int64_t)blockIdx.x * waves_per_block + wave; grp < n_groups;
          grp += (int64_t)gridDim.x * waves_per_block) {
-      float row_acc = 0.f;                     // ldj_mode 2, rows wider than a wave: the row's sum over its chunks
-      for (int chunk = 0; chunk < units.chunks; ++chunk) {
+      [[maybe_unused]] float row_acc = 0.f;    // ALIGNED, rows wider than a wave: the row's sum over its chunks
+      for (int chunk = 0; chunk < (ALIGNED ? units.chunks : 1); ++chunk) {
         int64_t e0;
         int n_here;
-        sx_unit_span(units, grp, chunk, n_rows, n_live, &e0, &n_here);
+        if constexpr (ALIGNED) sx_unit_span(units, grp, chunk, n_rows, n_live, &e0, &n_here);
+        else { e0 = grp << 6; n_here = (int)((n_elem - e0) < 64 ? (n_elem - e0) : 64); }
         const int total = n_here * P;
         // ---- stage: consecutive idx -> consecutive HBM addresses (one contiguous span when rows are packed) ----
-        if (contig && n_here == 64 && (P & 1) == 0 && ((e0 * P) & 3) == 0 && ((reinterpret_cast<uintptr_t>(params) & 15) == 0)) {
+        if (contig && n_here == 64 && (P & 1) == 0 && (!ALIGNED || ((e0 * P) & 3) == 0) && ((reinterpret_cast<uintptr_t>(params) & 15) == 0)) {
             // 64*P floats = 16*P float4, 16-byte aligned (P even): vector loads, scalar LDS writes into the padded rows
             const f32x4 *src = reinterpret_cast<const f32x4 *>(params + e0 * P);
             for (int i4 = lane; i4 < 16 * P; i4 += 64) {
@@ -625,7 +636,8 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
             float s = valid ? ljd : 0.f;
             s = group_sum_rt(s, n_live);
             if (valid && (lane & (n_live - 1)) == 0) ldj[row] = (ldj_acc ? ldj[row] : 0.f) + ldj_scale * s;
-        } else if (ldj_mode == 2) {          // row-aligned units: fixed-order sums, no atomics
+        }
+        if constexpr (ALIGNED) {             // row-aligned units: fixed-order sums, no atomics
             const float s0 = valid ? ljd : 0.f;
             if (units.chunks == 1) {
                 const float s = segment_sum_rt(s0, i, n_live);
@@ -635,9 +647,11 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
             }
         }
       }
-      if (ldj_mode == 2 && units.chunks > 1) {
-          const float s = group_sum<64>(row_acc);
-          if (lane == 0) ldj[grp] = (ldj_acc ? ldj[grp] : 0.f) + ldj_scale * s;
+      if constexpr (ALIGNED) {
+          if (units.chunks > 1) {
+              const float s = group_sum<64>(row_acc);
+              if (lane == 0) ldj[grp] = (ldj_acc ? ldj[grp] : 0.f) + ldj_scale * s;
+          }
       }
     }
 }
@@ -688,18 +702,21 @@ extern "C" int sx_cubic_coupling(const void *x, void *y, float *ldj, float *ldia
     if (grid < 1) grid = 1;
     if (lds > 48 * 1024) {
 #define SX_ATTR(BF, INV)                                                                                          \
-    (void)hipFuncSetAttribute((const void *)cubic_kernel<BF, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+    (void)hipFuncSetAttribute((const void *)cubic_kernel<BF, INV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    (void)hipFuncSetAttribute((const void *)cubic_kernel<BF, INV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
         SX_ATTR(true, true); SX_ATTR(true, false); SX_ATTR(false, true); SX_ATTR(false, false);
 #undef SX_ATTR
     }
-#define SX_CB(BF, INV)                                                                                            \
-    hipLaunchKernelGGL((cubic_kernel<BF, INV>), dim3((int)grid), dim3(block), lds, st, x, y, ldj, ldiag, params,  \
+#define SX_CB2(BF, INV, AL)                                                                                       \
+    hipLaunchKernelGGL((cubic_kernel<BF, INV, AL>), dim3((int)grid), dim3(block), lds, st, x, y, ldj, ldiag, params, \
                        params_stride, live_idx, live_start, n_live, n_bins, lower, upper, log_span, n_rows, dim,   \
                        ldj_mode,                                                                                  \
                        ldj_accumulate, ldj_scale)
+#define SX_CB(BF, INV) do { if (ldj_mode == 2) SX_CB2(BF, INV, true); else SX_CB2(BF, INV, false); } while (0)
     if (dtype == SX_BF16) { if (reverse) SX_CB(true, true); else SX_CB(true, false); }
     else { if (reverse) SX_CB(false, true); else SX_CB(false, false); }
 #undef SX_CB
+#undef SX_CB2
     SX_LAUNCH_CHECK();
     return SX_OK;
 }

@@ -246,6 +246,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     }
 }
 
+// Second stage on its own: sums `n_part` partial tiles ([M32 x N32 | M32] floats each, produced by sx_flow_bwd_run)
+// into a parameter's rows / columns.
+extern "C" int sx_wgrad_reduce(const float *part, int32_t n_part, int32_t M32, int32_t N32, float *dW, int64_t ldw,
+                               float *db, int32_t m_valid, int32_t n_valid, const int32_t *row_map,
+                               const int32_t *col_map, void *stream) {
+    SX_REQUIRE(part && dW && n_part >= 1 && M32 >= 1 && M32 <= 128 && N32 >= 1, "sx_wgrad_reduce: bad arguments");
+    const int E = M32 * N32 + M32;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((E + 31) / 32, 1), dim3(256), 0, sx_stream(stream), part, (int)n_part,
+                       (int)M32, (int)N32, dW, ldw, db, (int)m_valid, (int)n_valid, row_map, col_map);
+    SX_LAUNCH_CHECK();
+    return SX_OK;
+}
+
 // The per-workgroup partial tiles go through a caller-owned scratch (sx_wgrad_scratch_floats): the library keeps no
 // per-stream state and never allocates.
 static void wgrad_shape(int32_t M, int32_t Nc, int32_t layout, int *slabs, int *mt, int *nt) {

@@ -7,6 +7,8 @@ layers in Python (flow.py:99-125) it asks every layer for its step(s) of a fused
 whole flow — inverse pass, log-det accumulation and the UnitNormal base density (flow.py:127-130) —
 in ONE kernel launch.  Layers that cannot be fused fall back to a per-layer loop of HIP kernels.
 """
+import ctypes as C
+import os
 from abc import ABCMeta, abstractmethod
 from typing import List, Optional, Tuple, Union
 
@@ -69,6 +71,10 @@ class _FusedLogProb(torch.autograd.Function):
             views.append(vs)
         gy = torch.empty_like(z) if ctx.need_input_grad else None
         lib = _hip.lib()
+        if _FusedLogProb._layer_major_ok(bprog, layers, ht):
+            _FusedLogProb._backward_layer_major(bprog, layers, views, z, g, gy if gy is not None else torch.empty_like(z))
+            out = [grads.get(id(p_)) for p_ in flow._grad_params()]
+            return (None, gy if ctx.need_input_grad else None, *out)
         # the per-row factors are 224 floats per row and layer: bound the scratch by walking the batch in blocks.
         # Layout [layer, 32-row group, feature, 32 rows] (coalesced for the kernel's fragment stores and sx_wgrad's loads)
         block = max(32, min(n, _FusedLogProb.SIDE_BYTES // (len(layers) * width * 4)) // 32 * 32)
@@ -104,6 +110,65 @@ class _FusedLogProb(torch.autograd.Function):
                                             gW1.stride(0), gb1.data_ptr(), None, info['col_map'].data_ptr(), sc.data_ptr(), st), 'sx_wgrad')
         out = [grads.get(id(p_)) for p_ in flow._grad_params()]
         return (None, gy if ctx.need_input_grad else None, *out)
+
+
+def _layer_major_ok(bprog, layers, ht) -> bool:
+    """The layer-major backward (weight gradients contracted in-kernel, sx_flow_bwd_run) covers 64-column flows whose
+    couplings condition one 32-column half on the other in the flow's own column order, hidden <= 64, fp16 x 3."""
+    if os.environ.get('STRIBOR_BWD_FACTORS') or _hip.get_gemm_precision() == 'exact':
+        return False
+    p = bprog.prog
+    return (p.identity_cols == 1 and p.x_tiles == 2 and p.tiles == 4 and ht <= 64
+            and all(info['ct'] == 1 and info['tt'] == 1 for _, info in layers))
+
+
+def _backward_layer_major(bprog, layers, views, z, g, gy) -> None:
+    """One launch per coupling (forward order = the backward pass's order): the state (x | dL/dx) streams through one
+    fragment-order buffer in place (512 B per row), each launch leaves one partial of its layer's dW2 / db2 / dW1 / db1
+    per workgroup, and sx_wgrad_reduce adds them into the parameter-order gradient views."""
+    lib = _hip.lib()
+    n, dev = z.shape[0], z.device
+    L = len(layers)
+    subs = getattr(bprog, '_layer_programs', None)
+    if subs is None:                                  # one-step programs over the same blobs
+        subs = []
+        for k in range(L):
+            sp = _hip.sx_program()
+            C.memmove(C.byref(sp), C.byref(bprog.prog), C.sizeof(_hip.sx_program))
+            sp.n_steps = 1
+            sp.steps[0] = bprog.prog.steps[k]
+            subs.append(sp)
+        bprog._layer_programs = subs
+    n_part, part_floats = C.c_int32(), C.c_int64()
+    _hip.check(lib.sx_flow_bwd_partials(C.byref(subs[0]), n, C.byref(n_part), C.byref(part_floats)), 'sx_flow_bwd_partials')
+    n_part, part_floats = n_part.value, part_floats.value
+    H32 = 32 * bprog.prog.h_tiles
+    E2 = 64 * H32 + 64
+    with _hip.device_of(z):
+        blobs = bprog.blobs_for(_hip.GEMM_F16X3)
+        frag = torch.empty((n + 31) // 32 * 4096, dtype=torch.float32, device=dev) if L > 1 else None
+        acc = torch.empty(L, n_part * part_floats, dtype=torch.float32, device=dev)
+        work, flag, st = _hip.work_counters(dev), _hip.err_flag(dev), _hip.stream()
+        for k in range(L):
+            first, last = k == 0, k == L - 1
+            rc = lib.sx_flow_bwd_run(C.byref(subs[k]), blobs.data_ptr(), z.data_ptr() if first else None, g.data_ptr(),
+                                     None if first else frag.data_ptr(), None if last else frag.data_ptr(),
+                                     gy.data_ptr() if last else None, acc[k].data_ptr(), n, work.data_ptr(), flag, st)
+            if rc != 0:
+                work.zero_()
+            _hip.check(rc, 'sx_flow_bwd_run')
+        for k in range(L):
+            info = layers[k][1]
+            gW1, gb1, gW2, gb2 = views[k]
+            base = acc[k].data_ptr()
+            _hip.check(lib.sx_wgrad_reduce(base, n_part, 64, H32, gW2.data_ptr(), gW2.stride(0), gb2.data_ptr(), 64, info['hidden'],
+                                           info['row_map'].data_ptr(), None, st), 'sx_wgrad_reduce')
+            _hip.check(lib.sx_wgrad_reduce(base + 4 * n_part * E2, n_part, H32, 32, gW1.data_ptr(), gW1.stride(0), gb1.data_ptr(),
+                                           info['hidden'], 32, None, info['col_map'].data_ptr(), st), 'sx_wgrad_reduce')
+
+
+_FusedLogProb._layer_major_ok = staticmethod(_layer_major_ok)
+_FusedLogProb._backward_layer_major = staticmethod(_backward_layer_major)
 
 
 def flatten_rows(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Size]:

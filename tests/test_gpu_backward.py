@@ -568,3 +568,44 @@ def test_tri_inverse_f64_and_its_backward(k, D):
         scale = Xc.abs().max().item()
         assert (Xd.detach().cpu() - Xc.detach()).abs().max().item() <= 1e-10 * scale
         assert (wd.grad.cpu() - wc.grad).abs().max().item() <= 1e-9 * max(1.0, wc.grad.abs().max().item())
+
+
+def test_layer_major_backward_matches_factor_path_and_oracle():
+    """Round 2: the layer-major backward (sx_flow_bwd_run: one launch per coupling, weight gradients contracted in the
+    kernel through MFMA-turned factor tiles, state streamed in fragment order) against the round-1 path (per-row factors
+    in HBM + sx_wgrad_layer) on cfg-2 shaped flows -- ragged batch sizes (padded tail rows must contribute nothing),
+    hidden 64 and 40, 1 / 3 / 8 layers -- and against fp64 autograd of the oracle."""
+    import os
+    from stribor_amd.flow import _layer_major_ok
+    for layers, hidden, n in [(8, 64, 4096), (3, 40, 1000), (1, 64, 77), (2, 32, 128 * 300 + 5)]:
+        torch.manual_seed(layers)
+        desc = fd.cfg2_desc(layers, 64, hidden)
+        flow = fd.build_flow(st, desc, 64)
+        spec = fd.flow_spec(desc, {k: v.clone() for k, v in flow.state_dict().items()})
+        flow = flow.to(DEV)
+        x = torch.randn(n, 64)
+        w = torch.rand(n, 1) + 0.5                                   # non-uniform dL/dlog_prob per row
+        params = list(flow.parameters())
+
+        def grads():
+            xg = x.to(DEV).requires_grad_(True)
+            loss = -(flow.log_prob(xg) * w.to(DEV)).sum() / n
+            return torch.autograd.grad(loss, [xg] + params)
+
+        bprog, lay = flow._backward_program(64, torch.device(DEV))
+        assert _layer_major_ok(bprog, lay, 32 * bprog.prog.h_tiles)
+        new = [t.detach().clone() for t in grads()]
+        os.environ['STRIBOR_BWD_FACTORS'] = '1'
+        try:
+            old = [t.detach().clone() for t in grads()]
+        finally:
+            del os.environ['STRIBOR_BWD_FACTORS']
+        for a, b in zip(new, old):
+            scale = b.abs().max().clamp_min(1e-12)
+            assert ((a - b).abs().max() / scale).item() <= 2e-5, (layers, hidden, n)
+        # fp64 autograd of the oracle
+        spec64 = orc.spec_to(spec, torch.float64)
+        x64 = x.double().requires_grad_(True)
+        loss64 = -(orc.flow_log_prob(spec64, x64) * w.double()).sum() / n
+        gx64 = torch.autograd.grad(loss64, [x64])[0]
+        assert ((new[0].cpu().double() - gx64).abs().max() / gx64.abs().max()).item() <= 2e-4
