@@ -2,6 +2,10 @@
 // One pass over [n_rows, dim]: coalesced 8/16-byte accesses, per-row log-det sums by wave shuffles.
 #include "sx_common.h"
 #include <stdarg.h>
+#include <stdlib.h>
+#ifndef SX_AFFINE_DEFAULT_VARIANT
+#define SX_AFFINE_DEFAULT_VARIANT 10
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // error string
@@ -62,7 +66,19 @@ __device__ __forceinline__ void store1(void *base, int64_t elem_off, float v) {
 // <= 64, live columns are the contiguous CPT-aligned range [l0, l0 + n_live).
 // ------------------------------------------------------------------------------------------------
 typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
-template <bool BF16, bool REVERSE>
+// NT: streaming (non-temporal) loads of x / params and stores of y -- every byte is touched once; UNR: rows in flight
+// per thread (independent iterations issued together: more loads outstanding per lane).
+template <bool NT, typename T>
+__device__ __forceinline__ T ld_stream(const T *p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT, typename T>
+__device__ __forceinline__ void st_stream(T *p, T v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+template <bool BF16, bool REVERSE, int UNR, bool NT>
 __global__ __launch_bounds__(256) void affine_coupling_vec_kernel(
     const void *__restrict__ x, void *__restrict__ y, float *__restrict__ ldj,
     const float *__restrict__ params, int64_t pstride, int l0, int n_live, int64_t n_rows, int dim,
@@ -71,49 +87,73 @@ __global__ __launch_bounds__(256) void affine_coupling_vec_kernel(
     const int tpr = 1 << tpr_log2;
     const int64_t n_vec = n_rows << tpr_log2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_vec; v += stride) {
-        const int64_t row = v >> tpr_log2;
-        const int c = ((int)(v & (tpr - 1))) * CPT;
-        f32x4 xv[NQ];
-        if constexpr (BF16) {
-            const u16x8 u = *reinterpret_cast<const u16x8 *>(reinterpret_cast<const uint16_t *>(x) + row * dim + c);
-            xv[0] = f32x4{bf16_to_f32(u[0]), bf16_to_f32(u[1]), bf16_to_f32(u[2]), bf16_to_f32(u[3])};
-            xv[1] = f32x4{bf16_to_f32(u[4]), bf16_to_f32(u[5]), bf16_to_f32(u[6]), bf16_to_f32(u[7])};
-        } else {
-            xv[0] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(x) + row * dim + c);
-        }
-        float s = 0.f;
-        if (c >= l0 && c < l0 + n_live) {
-            const float *p = params + row * pstride + (c - l0);
+    for (int64_t v0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v0 < n_vec; v0 += stride * UNR) {
+        f32x4 xv[UNR][NQ], ls[UNR][NQ], sh[UNR][NQ];
+        bool live[UNR], ok[UNR];
+        int64_t row[UNR];
+        int c[UNR];
+        // all loads of the UNR independent rows first
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const f32x4 ls = *reinterpret_cast<const f32x4 *>(p + 4 * q);
-                const f32x4 sh = *reinterpret_cast<const f32x4 *>(p + n_live + 4 * q);
-                if constexpr (REVERSE) {
-                    xv[q].x = (xv[q].x - sh.x) * fast_exp(-ls.x);
-                    xv[q].y = (xv[q].y - sh.y) * fast_exp(-ls.y);
-                    xv[q].z = (xv[q].z - sh.z) * fast_exp(-ls.z);
-                    xv[q].w = (xv[q].w - sh.w) * fast_exp(-ls.w);
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t v = v0 + u * stride;
+            ok[u] = v < n_vec;
+            row[u] = ok[u] ? v >> tpr_log2 : 0;
+            c[u] = ((int)(v & (tpr - 1))) * CPT;
+            live[u] = ok[u] && c[u] >= l0 && c[u] < l0 + n_live;
+            if (ok[u]) {
+                if constexpr (BF16) {
+                    const u16x8 q = ld_stream<NT>(reinterpret_cast<const u16x8 *>(reinterpret_cast<const uint16_t *>(x) + row[u] * dim + c[u]));
+                    xv[u][0] = f32x4{bf16_to_f32(q[0]), bf16_to_f32(q[1]), bf16_to_f32(q[2]), bf16_to_f32(q[3])};
+                    xv[u][1] = f32x4{bf16_to_f32(q[4]), bf16_to_f32(q[5]), bf16_to_f32(q[6]), bf16_to_f32(q[7])};
                 } else {
-                    xv[q].x = xv[q].x * fast_exp(ls.x) + sh.x;
-                    xv[q].y = xv[q].y * fast_exp(ls.y) + sh.y;
-                    xv[q].z = xv[q].z * fast_exp(ls.z) + sh.z;
-                    xv[q].w = xv[q].w * fast_exp(ls.w) + sh.w;
+                    xv[u][0] = ld_stream<NT>(reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(x) + row[u] * dim + c[u]));
                 }
-                s += (ls.x + ls.y) + (ls.z + ls.w);
+            }
+            if (live[u]) {
+                const float *p = params + row[u] * pstride + (c[u] - l0);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    ls[u][q] = ld_stream<NT>(reinterpret_cast<const f32x4 *>(p + 4 * q));
+                    sh[u][q] = ld_stream<NT>(reinterpret_cast<const f32x4 *>(p + n_live + 4 * q));
+                }
             }
         }
-        if constexpr (BF16) {
-            u16x8 o;
-            o[0] = f32_to_bf16(xv[0].x); o[1] = f32_to_bf16(xv[0].y); o[2] = f32_to_bf16(xv[0].z); o[3] = f32_to_bf16(xv[0].w);
-            o[4] = f32_to_bf16(xv[1].x); o[5] = f32_to_bf16(xv[1].y); o[6] = f32_to_bf16(xv[1].z); o[7] = f32_to_bf16(xv[1].w);
-            *reinterpret_cast<u16x8 *>(reinterpret_cast<uint16_t *>(y) + row * dim + c) = o;
-        } else {
-            *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(y) + row * dim + c) = xv[0];
-        }
-        if (ldj != nullptr) {   // wave-uniform
-            s = group_sum_rt(s, tpr);
-            if ((v & (tpr - 1)) == 0) ldj[row] = (ldj_acc ? ldj[row] : 0.f) + ldj_scale * s;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            float s = 0.f;
+            if (live[u]) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    f32x4 &X = xv[u][q];
+                    const f32x4 L = ls[u][q], S = sh[u][q];
+                    if constexpr (REVERSE) {
+                        X.x = (X.x - S.x) * fast_exp(-L.x);
+                        X.y = (X.y - S.y) * fast_exp(-L.y);
+                        X.z = (X.z - S.z) * fast_exp(-L.z);
+                        X.w = (X.w - S.w) * fast_exp(-L.w);
+                    } else {
+                        X.x = X.x * fast_exp(L.x) + S.x;
+                        X.y = X.y * fast_exp(L.y) + S.y;
+                        X.z = X.z * fast_exp(L.z) + S.z;
+                        X.w = X.w * fast_exp(L.w) + S.w;
+                    }
+                    s += (L.x + L.y) + (L.z + L.w);
+                }
+            }
+            if (ok[u]) {
+                if constexpr (BF16) {
+                    u16x8 o;
+                    o[0] = f32_to_bf16(xv[u][0].x); o[1] = f32_to_bf16(xv[u][0].y); o[2] = f32_to_bf16(xv[u][0].z); o[3] = f32_to_bf16(xv[u][0].w);
+                    o[4] = f32_to_bf16(xv[u][1].x); o[5] = f32_to_bf16(xv[u][1].y); o[6] = f32_to_bf16(xv[u][1].z); o[7] = f32_to_bf16(xv[u][1].w);
+                    st_stream<NT>(reinterpret_cast<u16x8 *>(reinterpret_cast<uint16_t *>(y) + row[u] * dim + c[u]), o);
+                } else {
+                    st_stream<NT>(reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(y) + row[u] * dim + c[u]), xv[u][0]);
+                }
+            }
+            if (ldj != nullptr) {   // wave-uniform (the whole wave shares ok[u] except in the last, partial wave: tpr divides 64)
+                s = group_sum_rt(s, tpr);
+                if (ok[u] && ((v0 + u * stride) & (tpr - 1)) == 0) ldj[row[u]] = (ldj_acc ? ldj[row[u]] : 0.f) + ldj_scale * s;
+            }
         }
     }
 }
@@ -172,13 +212,29 @@ extern "C" int sx_affine_coupling(const void *x, void *y, float *ldj, const floa
                       (((uintptr_t)x) & 15) == 0 && (((uintptr_t)y) & 15) == 0;
     if (fast) {
         const int tl = ilog2(dim / cpt);
-        const int grid = grid_for(n_rows << tl, 256);
-#define SX_AC(BF, RV)                                                                         \
-    hipLaunchKernelGGL((affine_coupling_vec_kernel<BF, RV>), dim3(grid), dim3(256), 0, st, x, y, ldj, \
+        // experiment knob (read once): SX_AFFINE_VARIANT = 10 * UNR + NT
+        static const int variant = getenv("SX_AFFINE_VARIANT") ? atoi(getenv("SX_AFFINE_VARIANT")) : SX_AFFINE_DEFAULT_VARIANT;
+        static const int grid_mul = getenv("SX_AFFINE_GRID") ? atoi(getenv("SX_AFFINE_GRID")) : 8;
+        const int unr = variant / 10 < 1 ? 1 : variant / 10;
+        const int grid = grid_for((n_rows << tl) / unr + 1, 256, 256 * grid_mul);
+#define SX_AC3(BF, RV, U, N)                                                                  \
+    hipLaunchKernelGGL((affine_coupling_vec_kernel<BF, RV, U, N>), dim3(grid), dim3(256), 0, st, x, y, ldj, \
                        params, params_stride, live_start, n_live, n_rows, dim, tl, ldj_accumulate, ldj_scale)
+#define SX_AC(BF, RV)                                                                         \
+    do {                                                                                      \
+        switch (variant) {                                                                    \
+            case 11: SX_AC3(BF, RV, 1, true); break;                                          \
+            case 20: SX_AC3(BF, RV, 2, false); break;                                         \
+            case 21: SX_AC3(BF, RV, 2, true); break;                                          \
+            case 40: SX_AC3(BF, RV, 4, false); break;                                         \
+            case 41: SX_AC3(BF, RV, 4, true); break;                                          \
+            default: SX_AC3(BF, RV, 1, false); break;                                         \
+        }                                                                                     \
+    } while (0)
         if (dtype == SX_BF16) { if (reverse) SX_AC(true, true); else SX_AC(true, false); }
         else { if (reverse) SX_AC(false, true); else SX_AC(false, false); }
 #undef SX_AC
+#undef SX_AC3
     } else {
         const int grid = grid_for(n_rows * 64, 256);
         const size_t lds = (size_t)dim * sizeof(int);

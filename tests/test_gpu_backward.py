@@ -577,7 +577,7 @@ def test_layer_major_backward_matches_factor_path_and_oracle():
     hidden 64 and 40, 1 / 3 / 8 layers -- and against fp64 autograd of the oracle."""
     import os
     from stribor_amd.flow import _layer_major_ok
-    for layers, hidden, n in [(8, 64, 4096), (3, 40, 1000), (1, 64, 77), (2, 32, 128 * 300 + 5)]:
+    for layers, hidden, n in [(8, 64, 4096), (3, 40, 1000), (1, 64, 77), (2, 32, 128 * 300 + 5), (4, 64, 1 << 17)]:
         torch.manual_seed(layers)
         desc = fd.cfg2_desc(layers, 64, hidden)
         flow = fd.build_flow(st, desc, 64)
@@ -601,11 +601,36 @@ def test_layer_major_backward_matches_factor_path_and_oracle():
         finally:
             del os.environ['STRIBOR_BWD_FACTORS']
         for a, b in zip(new, old):
-            scale = b.abs().max().clamp_min(1e-12)
-            assert ((a - b).abs().max() / scale).item() <= 2e-5, (layers, hidden, n)
+            scale = b.abs().max().clamp_min(1e-30)
+            assert ((a - b).abs().max() / scale).item() <= 5e-5, (layers, hidden, n)
         # fp64 autograd of the oracle
         spec64 = orc.spec_to(spec, torch.float64)
         x64 = x.double().requires_grad_(True)
         loss64 = -(orc.flow_log_prob(spec64, x64) * w.double()).sum() / n
         gx64 = torch.autograd.grad(loss64, [x64])[0]
-        assert ((new[0].cpu().double() - gx64).abs().max() / gx64.abs().max()).item() <= 2e-4
+        # 2^17 rows of a mean loss: dL/dlog_prob ~ 1e-5 per row (the pass runs on a power-of-two multiple of it)
+        assert ((new[0].cpu().double() - gx64).abs().max() / gx64.abs().max()).item() <= 2e-4, (layers, hidden, n)
+
+
+def test_backward_is_accurate_for_tiny_loss_scales():
+    """dL/dlog_prob of 1e-9 per row (a mean over a huge batch, or a down-weighted loss term): the fp16 x 3 backward GEMMs
+    would see operands far below fp16's normal range; the pass rescales by a power of two, so the gradients keep their
+    relative accuracy against fp64 autograd of the oracle."""
+    torch.manual_seed(12)
+    desc = fd.cfg2_desc(4, 64, 64)
+    flow = fd.build_flow(st, desc, 64)
+    state = {k: v.clone() for k, v in flow.state_dict().items()}
+    flow = flow.to(DEV)
+    x = torch.randn(2000, 64)
+    for scale in (1e-9, 1.0, 3e4):
+        for p in flow.parameters():
+            p.grad = None
+        xg = x.to(DEV).requires_grad_(True)
+        (-flow.log_prob(xg).sum() * scale).backward()
+        _, want_g, want_gx = oracle_grads(desc, state, x)
+        k = scale * x.shape[0]                                 # oracle_grads uses the mean
+        ref = want_gx.float() * k
+        assert ((xg.grad.cpu() - ref).abs().max() / ref.abs().max()).item() <= 2e-4, scale
+        for name, p in flow.named_parameters():
+            ref = want_g[name].float() * k
+            assert ((p.grad.cpu() - ref).abs().max() / (ref.abs().max() + 1e-30)).item() <= 2e-4, (name, scale)
