@@ -3,9 +3,6 @@
 #include "sx_common.h"
 #include <stdarg.h>
 #include <stdlib.h>
-#ifndef SX_AFFINE_DEFAULT_VARIANT
-#define SX_AFFINE_DEFAULT_VARIANT 10
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // error string
@@ -212,9 +209,14 @@ extern "C" int sx_affine_coupling(const void *x, void *y, float *ldj, const floa
                       (((uintptr_t)x) & 15) == 0 && (((uintptr_t)y) & 15) == 0;
     if (fast) {
         const int tl = ilog2(dim / cpt);
-        // experiment knob (read once): SX_AFFINE_VARIANT = 10 * UNR + NT
-        static const int variant = getenv("SX_AFFINE_VARIANT") ? atoi(getenv("SX_AFFINE_VARIANT")) : SX_AFFINE_DEFAULT_VARIANT;
-        static const int grid_mul = getenv("SX_AFFINE_GRID") ? atoi(getenv("SX_AFFINE_GRID")) : 8;
+        // Streaming (non-temporal) accesses and, for bf16 storage, two rows in flight per thread: measured on 2^20 x 64
+        // (tools/sweep_affine.py; fraction of 8 TB/s): plain loads 0.64-0.69, nt 0.72-0.73, nt + 2 rows + 32 workgroups
+        // per CU 0.75 (bf16) / 0.70 (fp32).  SX_AFFINE_VARIANT = 10 * rows-in-flight + nt, SX_AFFINE_GRID = workgroups per
+        // CU override the choice (experiments; read once).
+        static const int variant_env = getenv("SX_AFFINE_VARIANT") ? atoi(getenv("SX_AFFINE_VARIANT")) : 0;
+        static const int grid_env = getenv("SX_AFFINE_GRID") ? atoi(getenv("SX_AFFINE_GRID")) : 0;
+        const int variant = variant_env ? variant_env : (dtype == SX_BF16 ? 21 : 11);
+        const int grid_mul = grid_env ? grid_env : (dtype == SX_BF16 ? 32 : 16);
         const int unr = variant / 10 < 1 ? 1 : variant / 10;
         const int grid = grid_for((n_rows << tl) / unr + 1, 256, 256 * grid_mul);
 #define SX_AC3(BF, RV, U, N)                                                                  \

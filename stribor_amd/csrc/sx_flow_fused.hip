@@ -225,7 +225,7 @@ extern "C" int sx_flow_bwd_partials(const sx_program *prog_host, int64_t n_rows,
     int rc = bwd_check(prog_host, &d, &bf);
     if (rc) return rc;
     const int N2 = 32 * prog_host->h_tiles;
-    if (n_part) *n_part = pick_grid(n_rows, bf * 8 + 16, prog_host->tiles, 11);
+    if (n_part) *n_part = pick_grid(n_rows, prog_host->n_steps == 1 ? bf * 4 + 4 * 16384 + 16 : bf * 8 + 16, prog_host->tiles, 11);
     if (part_floats) *part_floats = (int64_t)(64 * N2 + 64) + (int64_t)(N2 * 32 + N2);
     return SX_OK;
 }
@@ -245,7 +245,10 @@ extern "C" int sx_flow_bwd_run(const sx_program *prog_host, const float *blobs, 
     sx_flow_args a;
     a.prog = d; a.blobs = blobs; a.x = z ? (const void *)z : (const void *)frag_in; a.latent = nullptr; a.in_col = nullptr; a.out_col = nullptr;
     a.y = gy; a.ldj_out = nullptr; a.logp_out = nullptr; a.sum_out = nullptr; a.mlp_out = nullptr; a.mlp_out_stride = 0;
-    a.mlp_out_dim = 0; a.n_rows = n_rows; a.buf_floats = bf; a.bf16 = 0; a.mlp_mode = 11; a.lds = bf * 8 + 16;
+    a.mlp_out_dim = 0; a.n_rows = n_rows; a.buf_floats = bf; a.bf16 = 0; a.mlp_mode = 11;
+    // single-step programs: resident weights + a 16 KB state landing zone per wave instead of the second weight buffer
+    a.lds = prog_host->n_steps == 1 ? bf * 4 + 4 * 16384 + 16 : bf * 8 + 16;
+    SX_REQUIRE(a.lds <= 160 * 1024, "sx_flow_bwd_run: the step needs %d B of LDS", a.lds);
     a.grid = pick_grid(n_rows, a.lds, prog_host->tiles, 11);
     a.stream = sx_stream(stream);
     a.row_t = g; a.side = nullptr; a.side_width = 0;

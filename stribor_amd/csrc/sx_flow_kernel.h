@@ -1222,7 +1222,13 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
 #endif
     const bool dyn = k.work != nullptr;
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
-    lds_u32 *slot = (lds_u32 *)(smem + 2 * buf_floats);      // ds_write_b32 / ds_read_b32, ordered by the barrier
+    // MODE 11 with a single step (the default build): the step's weights stay resident in buffer 0 for the whole launch,
+    // and the second buffer's place is taken by a per-wave 16 KB landing zone into which the NEXT chunk's state is
+    // prefetched by LDS-DMA while this chunk computes (one wave per SIMD: nothing else would hide that latency)
+    const bool resident = MODE == 11 && n_steps == 1;
+    const int pf_base = buf_floats;                           // floats; WB * 4096 floats behind buffer 0
+    lds_u32 *slot = (lds_u32 *)(smem + (resident ? buf_floats + WB * 4096 : 2 * buf_floats));      // ds_write_b32 / ds_read_b32, ordered by the barrier
+    [[maybe_unused]] bool have_pf = false;
     int iter = 0;
     for (int64_t chunk = blockIdx.x; chunk < n_chunks; ++iter) {
         // lane-derived indices are re-derived per chunk from the thread id (opaque to the optimizer) instead of
@@ -1243,7 +1249,19 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
         bool from_frag = false;
         if constexpr (MODE == 11) {
             from_frag = k.frag_in != nullptr;
-            if (from_frag) {
+            if (from_frag && have_pf) {
+                // this chunk's state was prefetched into the wave's landing zone during the previous chunk
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const f32x4 *fl = reinterpret_cast<const f32x4 *>(smem + pf_base + wave * 4096) + lane;
+#pragma unroll
+                for (int t = 0; t < TX; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = fl[(t * 4 + q) * 64];
+                        xs[t].v[0][4 * q + 0] = v.x; xs[t].v[0][4 * q + 1] = v.y;
+                        xs[t].v[0][4 * q + 2] = v.z; xs[t].v[0][4 * q + 3] = v.w;
+                    }
+            } else if (from_frag) {
                 // fragment-order state of the previous launch: [32-row group][tile][q][lane] float4 (1 KB per instruction)
                 const int64_t n_grp = (n_rows + 31) >> 5;
                 int64_t grp = chunk * WB + wave;
@@ -1258,6 +1276,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                         xs[t].v[0][4 * q + 2] = v.z; xs[t].v[0][4 * q + 3] = v.w;
                     }
             }
+            have_pf = false;
         }
         if (!from_frag)
 #pragma unroll
@@ -1339,8 +1358,21 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
             // (2) refill buffer cur^1 with the next step's weights (the DMA flies under this step's MFMAs)
             //     and fetch the next step's descriptor one step early.
             const dstep st = st_next;
-            if ((s + 1 < n_steps || has_next_chunk) && dma_floats && !SX_DBG(1))
+            if ((s + 1 < n_steps || has_next_chunk) && dma_floats && !SX_DBG(1) && !resident)
                 stage_blob<WB>(k.blobs + dma_off, (cur ^ 1) * buf_floats, dma_floats);
+            if constexpr (MODE == 11) {
+                if (resident && s == 0 && k.frag_in != nullptr && has_next_chunk) {
+                    const int64_t ngrp = next_chunk * WB + wave;
+                    if (ngrp < ((n_rows + 31) >> 5)) {       // wave-uniform
+                        const char *gsrc = reinterpret_cast<const char *>(k.frag_in + ngrp * (TX * 4 * 64 * 4)) + lane * 16;
+                        char *ldst = reinterpret_cast<char *>(smem + pf_base + wave * 4096);
+#pragma unroll
+                        for (int i = 0; i < TX * 4; ++i)
+                            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(gsrc + i * 1024), (lds_void *)(ldst + i * 1024), 16, 0, 0);
+                        have_pf = true;
+                    }
+                }
+            }
             const int nxt = (s + 1 < n_steps) ? s + 1 : 0, nxt2 = (nxt + 1 < n_steps) ? nxt + 1 : 0;
             st_next = prog.steps[nxt];
             dma_off = prog.steps[nxt2].blob_off;
@@ -1584,7 +1616,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                 default: break;
             }
             if (st.kind != SX_STEP_ROW_SCALE_EXP) ldj_c += st.ldj_const;
-            cur ^= 1;
+            if (!resident) cur ^= 1;
             SX_STAMP(pf, 6);     // step tail
         }
 

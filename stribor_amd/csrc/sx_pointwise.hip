@@ -205,6 +205,58 @@ __global__ __launch_bounds__(256) void cumsum_kernel(const void *__restrict__ x,
     }
 }
 
+// Vectorised form (fp32, dim % 4 == 0, 16-byte aligned): every global access and every LDS access moves 16 B.  The
+// wave's 64 rows are one contiguous span; row stride in LDS = dim + 4 dwords: 16-byte aligned, and the 64 lanes of a
+// ds_read_b128 / ds_write_b128 column walk (lane = row) cover all 32 banks 8 times -- the minimum for 1 KiB.
+__global__ __launch_bounds__(256) void cumsum_vec_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t n_rows,
+                                                         int dim, int diff) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n_groups = (n_rows + 63) >> 6;
+    const int RS = dim + 4, Q = dim >> 2;                 // Q float4 per row
+    float *sp = pw_smem + (size_t)wave * 64 * RS;
+    const float inv_q = 1.0f / (float)Q;
+    for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < n_groups; grp += (int64_t)gridDim.x * 4) {
+        const int64_t r0 = grp << 6;
+        const int rows = (int)((n_rows - r0) < 64 ? (n_rows - r0) : 64);
+        const int total4 = rows * Q;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(x + r0 * dim);
+        for (int i = lane; i < total4; i += 64) {
+            const int r = (int)(((float)i + 0.5f) * inv_q), c4 = i - r * Q;      // i / Q, exact for i < 2^22
+            *reinterpret_cast<f32x4 *>(sp + r * RS + 4 * c4) = src[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < rows) {
+            // cumsum.py:62: torch.cumsum on CPU keeps the running sum in double (acc_type<float>) and rounds each
+            // output; diff (:33): x - pad(x)[..., :-1]
+            double acc = 0.0;
+            float prev = 0.f;
+            f32x4 *row = reinterpret_cast<f32x4 *>(sp + lane * RS);
+            for (int c4 = 0; c4 < Q; ++c4) {
+                const f32x4 v = row[c4];
+                f32x4 o;
+                if (diff) {
+                    o.x = v.x - prev; o.y = v.y - v.x; o.z = v.z - v.y; o.w = v.w - v.z;
+                    prev = v.w;
+                } else {
+                    acc += (double)v.x; o.x = (float)acc;
+                    acc += (double)v.y; o.y = (float)acc;
+                    acc += (double)v.z; o.z = (float)acc;
+                    acc += (double)v.w; o.w = (float)acc;
+                }
+                row[c4] = o;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        f32x4 *dst = reinterpret_cast<f32x4 *>(y + r0 * dim);
+        for (int i = lane; i < total4; i += 64) {
+            const int r = (int)(((float)i + 0.5f) * inv_q), c4 = i - r * Q;
+            dst[i] = *reinterpret_cast<const f32x4 *>(sp + r * RS + 4 * c4);
+        }
+    }
+}
+
 // ---- backward (training, layer-wise path): dL/dx = gy * d(out)/dx + gldj[row] * d(ld)/dx, per element ----------------
 __device__ __forceinline__ float pw_grad(int kind, float param, float x, float gy, float gl) {
     switch (kind) {
@@ -283,6 +335,19 @@ extern "C" int sx_pointwise(const void *x, void *y, float *ldj, float *ldiag, in
         if (y != nullptr) {                 // y == NULL: only the (zero) log-determinants are wanted
             int64_t g = (n_rows + 255) / 256;
             if (g > 2048) g = 2048;
+            const size_t lds4 = (size_t)4 * 64 * (dim + 4) * sizeof(float);
+            if (dtype == SX_F32 && dim % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && lds4 <= 150 * 1024 && dim <= 16384) {
+                static bool raised[64];
+                int dev = 0;
+                (void)hipGetDevice(&dev);
+                if (lds4 > 48 * 1024 && !raised[dev & 63]) {
+                    (void)hipFuncSetAttribute((const void *)cumsum_vec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    raised[dev & 63] = true;
+                }
+                hipLaunchKernelGGL(cumsum_vec_kernel, dim3((int)g), dim3(256), lds4, st, (const float *)x, (float *)y, n_rows, dim,
+                                   kind == SX_PW_DIFF);
+                SX_LAUNCH_CHECK();
+            } else {
             const size_t lds = (size_t)4 * 64 * (dim + 1) * sizeof(float);
             const int staged = lds <= 150 * 1024;
             const size_t dyn = staged ? lds : 0;
@@ -293,6 +358,7 @@ extern "C" int sx_pointwise(const void *x, void *y, float *ldj, float *ldiag, in
             if (dtype == SX_BF16) hipLaunchKernelGGL(cumsum_kernel<true>, dim3((int)g), dim3(256), dyn, st, x, y, n_rows, dim, kind == SX_PW_DIFF, staged);
             else hipLaunchKernelGGL(cumsum_kernel<false>, dim3((int)g), dim3(256), dyn, st, x, y, n_rows, dim, kind == SX_PW_DIFF, staged);
             SX_LAUNCH_CHECK();
+            }
         }
         if (ldj && !ldj_accumulate) {
             hipError_t e = hipMemsetAsync(ldj, 0, n_rows * sizeof(float), st);
