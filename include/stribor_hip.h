@@ -149,7 +149,10 @@ int sx_rqs_inverse_bwd(const float *x, const float *gout, const float *gldj, con
  *   params[n, i*(2K+2) + 0:K]      unnormalised widths  of live dim i
  *   params[n, i*(2K+2) + K:2K]     unnormalised heights
  *   params[n, i*(2K+2) + 2K:2K+2]  unnormalised boundary derivatives (left, right)   (K = n_bins)
- *   domain = codomain = [lower, upper]; outside it: y = x, ljd = 0.  ldiag / ldj / reverse as in sx_rqs_coupling. */
+ *   domain = codomain = [lower, upper]; outside it: y = x, ljd = 0.  ldiag / ldj / reverse as in sx_rqs_coupling.
+ *   reverse == 2: the inverse with the log-det the reference's Transform.inverse_and_log_det_jacobian returns
+ *   (flow.py:42-47): MINUS the FORWARD log-derivative re-evaluated at the inverted point -- identical to the inverse's own
+ *   value inside a bin, different where the inverted point rounds out of the domain (0) or into a neighbouring bin. */
 int sx_cubic_coupling(const void *x, void *y, float *ldj, float *ldiag, const float *params,
                       int64_t params_stride, const int32_t *live_idx, int32_t live_start, int32_t n_live, int32_t n_bins,
                       float lower, float upper, int64_t n_rows, int32_t dim, int32_t dtype, int32_t reverse,

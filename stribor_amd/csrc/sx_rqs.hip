@@ -429,6 +429,44 @@ __device__ __forceinline__ float cubic_exp(float v) {
     return __builtin_amdgcn_exp2f(t) * (1.f + r * 0.69314718055994531f);
 }
 
+// Forward log-derivative log f'(x) of the monotone cubic spline at normalised input `xin` from the element's
+// (exp'ed) widths / heights ew[k], eh[k] with their softmax factors nw, nh and the two raw boundary-derivative parameters
+// (cubic_spline.py:103-137, 229-237): the bin is searched by widths, as the forward pass does.  Used by the inverse
+// kernel's reference mode when the inverted point does not land in the bin it was solved in (rare).
+template <class GW, class GH>
+__device__ __forceinline__ float cubic_forward_logderiv(GW ew, GH eh, float nw, float nh, float dpar0, float dpar1, int K,
+                                                        float xin) {
+    int b = 0;
+    float cw_b = 0.f, w_b = 0.f, h_b = 0.f, w_m = 1.f, h_m = 1.f, w_p = 1.f, h_p = 1.f;
+    float cw = 0.f, w_last = 1.f, h_last = 1.f;
+    bool need_next = false;
+    for (int k = 0; k < K; ++k) {
+        const float wk = CUBIC_MIN_BIN + nw * ew(k);
+        const float hk = CUBIC_MIN_BIN + nh * eh(k);
+        if (xin >= cw) { b = k; cw_b = cw; w_b = wk; h_b = hk; w_m = w_last; h_m = h_last; need_next = true; }
+        else if (need_next) { w_p = wk; h_p = hk; need_next = false; }
+        w_last = wk; h_last = hk;
+        cw += wk;
+    }
+    const float s_b = h_b / w_b;
+    auto sgn = [](float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); };
+    float dL, dR;
+    if (b == 0) dL = cubic_sigmoid(dpar0) * 3.f * s_b;
+    else {
+        const float s_m = h_m / w_m;
+        dL = fminf(fminf(fabsf(s_m), fabsf(s_b)), 0.5f * (w_b * s_m + w_m * s_b) / (w_m + w_b)) * (sgn(s_m) + sgn(s_b));
+    }
+    if (b == K - 1) dR = cubic_sigmoid(dpar1) * 3.f * s_b;
+    else {
+        const float s_p = h_p / w_p;
+        dR = fminf(fminf(fabsf(s_b), fabsf(s_p)), 0.5f * (w_p * s_b + w_b * s_p) / (w_b + w_p)) * (sgn(s_b) + sgn(s_p));
+    }
+    const float a = (dL + dR - 2.f * s_b) / (w_b * w_b);
+    const float bb = (3.f * s_b - 2.f * dL - dR) / w_b;
+    const float t = xin - cw_b;
+    return logf(3.f * a * (t * t) + 2.f * bb * t + dL);
+}
+
 template <bool BF16, bool INVERSE, bool ALIGNED>
 __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, void *__restrict__ y,
                                                     float *__restrict__ ldj, float *__restrict__ ldiag,
@@ -436,7 +474,7 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
                                                     const int32_t *__restrict__ live_idx, int l0, int n_live, int K,
                                                     float lower, float upper, float log_span, int64_t n_rows, int dim,
                                                     int ldj_mode /*0 none, 1 direct (group), 2 row-aligned units*/, int ldj_acc,
-                                                    float ldj_scale) {
+                                                    float ldj_scale, int ref_ldj) {
     const int P = 2 * K + 2, PS = P | 1;                         // padded (odd) per-lane stride
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int waves_per_block = blockDim.x >> 6;
@@ -500,6 +538,7 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
         //      one sweep that also keeps the widths / heights of bins b-1, b, b+1 ----------------------------------
         int b = 0;
         float cw_b = 0.f, ch_b = 0.f, w_b = 0.f, h_b = 0.f, w_m = 1.f, h_m = 1.f, w_p = 1.f, h_p = 1.f;
+        float nw_k = 0.f, nh_k = 0.f;          // softmax factors, kept for the reference-mode re-evaluation
         auto sweep = [&](auto get_w, auto get_h, auto set_w, auto set_h, int KK) {
             float mw = get_w(0), mh = get_h(0);
             for (int k = 1; k < KK; ++k) { mw = fmaxf(mw, get_w(k)); mh = fmaxf(mh, get_h(k)); }
@@ -512,6 +551,7 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
                 sh += eh;
             }
             const float nw = norm / sw, nh = norm / sh;         // one division per softmax instead of one per bin
+            nw_k = nw; nh_k = nh;
             float cw = 0.f, ch = 0.f, w_last = 1.f, h_last = 1.f;
             bool need_next = false;
             for (int k = 0; k < KK; ++k) {
@@ -620,6 +660,41 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
             ljd = -logf(3.f * a * (so * so) + 2.f * bb * so + c);                          // :225-227
             out = o * span + lower;                                                        // :235
             ljd = (ljd - log_span) + log_span;                                             // :236 (two fp32 roundings there)
+            if (ref_ldj) {
+                // Reference mode (a coupling's inverse_and_log_det_jacobian): the reference does NOT use the inverse's own
+                // log-derivative -- Transform.inverse_and_log_det_jacobian (flow.py:42-47) evaluates MINUS the FORWARD
+                // log-det at the inverted point.  The two agree to rounding inside a bin, but differ where the inverted
+                // point lands an ulp outside the domain (forward: linear tail, 0) or in a neighbouring bin, and where the
+                // fp32 cubic solve breaks down.  Re-evaluate the forward log-derivative at x' = out exactly as the forward
+                // kernel would: in the solved bin when x' lies inside it (no second sweep), else by a full search.
+                const bool in2 = inside && (out >= lower) && (out <= upper);
+                const float xin2 = ((in2 ? out : lower) - lower) / span;
+                const bool same_bin = (xin2 >= cw_b) && (b == K - 1 || xin2 < cw_b + w_b);
+                float lf;
+                {
+                    const float t2 = xin2 - cw_b;
+                    lf = logf(3.f * a * (t2 * t2) + 2.f * bb * t2 + c);
+                }
+                const bool slow = valid && in2 && !same_bin;
+                if (__builtin_amdgcn_ballot_w64(slow)) {
+                    if (slow) {
+                        if (K == 16) {          // the raw parameters are still in LDS: redo the softmax factors
+                            float mw = p[0], mh = p[16];
+                            for (int k = 1; k < 16; ++k) { mw = fmaxf(mw, p[k]); mh = fmaxf(mh, p[16 + k]); }
+                            float sw = 0.f, sh = 0.f;
+                            for (int k = 0; k < 16; ++k) { sw += cubic_exp(p[k] - mw); sh += cubic_exp(p[16 + k] - mh); }
+                            lf = cubic_forward_logderiv([&](int k) { return cubic_exp(p[k] - mw); },
+                                                        [&](int k) { return cubic_exp(p[16 + k] - mh); }, norm / sw, norm / sh,
+                                                        p[32], p[33], 16, xin2);
+                        } else {                // the generic path left exp(u - max) in place of the raw widths / heights
+                            lf = cubic_forward_logderiv([&](int k) { return p[k]; }, [&](int k) { return p[K + k]; }, nw_k, nh_k,
+                                                        p[2 * K], p[2 * K + 1], K, xin2);
+                        }
+                    }
+                }
+                lf = (lf + log_span) - log_span;                                           // :239 (forward's two roundings)
+                ljd = in2 ? -lf : 0.f;                                                     // :46-48 tails; flow.py:47 negation
+            }
         } else {
             const float t = xin - cw_b;                                                    // :229
             out = a * (t * t * t) + bb * (t * t) + c * t + d;                              // :230-233
@@ -711,7 +786,7 @@ extern "C" int sx_cubic_coupling(const void *x, void *y, float *ldj, float *ldia
     hipLaunchKernelGGL((cubic_kernel<BF, INV, AL>), dim3((int)grid), dim3(block), lds, st, x, y, ldj, ldiag, params, \
                        params_stride, live_idx, live_start, n_live, n_bins, lower, upper, log_span, n_rows, dim,   \
                        ldj_mode,                                                                                  \
-                       ldj_accumulate, ldj_scale)
+                       ldj_accumulate, ldj_scale, (int)(reverse == 2))
 #define SX_CB(BF, INV) do { if (ldj_mode == 2) SX_CB2(BF, INV, true); else SX_CB2(BF, INV, false); } while (0)
     if (dtype == SX_BF16) { if (reverse) SX_CB(true, true); else SX_CB(true, false); }
     else { if (reverse) SX_CB(false, true); else SX_CB(false, false); }

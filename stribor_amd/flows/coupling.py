@@ -156,8 +156,9 @@ class Coupling(Transform):
             params = p.index_select(1, cols)
             stride = params.stride(0)
         if sp.spline_type == 'cubic':
+            # a coupling's inverse log-det is MINUS the FORWARD log-det at the inverted point (flow.py:42-47): reverse = 2
             y, ldj, _ = run_cubic_kernel(x2, params, stride, live_idx, int(live[0]), len(live), sp.n_bins, sp.lower, sp.upper,
-                                         reverse, want_ldj, False, ldj_scale)
+                                         2 if (reverse and want_ldj) else reverse, want_ldj, False, ldj_scale)
         else:
             y, ldj, _ = run_rqs_kernel(x2, params, stride, live_idx, int(live[0]), len(live), sp.n_bins, sp.lower, sp.upper,
                                        sp.lower, sp.upper, reverse, want_ldj, False, ldj_scale)
@@ -270,11 +271,11 @@ class Coupling(Transform):
             p.run(x2, lat2, mlp_out=params)
         if sp.spline_type == 'cubic':
             from .spline import run_cubic_kernel
-            # one pass: the inverse kernel returns its own (already negated) log-derivative, like the quadratic path.
-            # (The reference evaluates MINUS the FORWARD log-det at the inverted point, flow.py:42-47; the two differ
-            # only for elements within an ulp of the domain boundary, where the log-derivative jumps to the tails' 0.)
+            # one pass; in the inverse direction the kernel's reference mode (reverse = 2) returns what the reference's
+            # Transform.inverse_and_log_det_jacobian does: MINUS the FORWARD log-det re-evaluated at the inverted point
+            # (flow.py:42-47) -- so elements that round onto / across a domain bound or a knot get the reference's value
             y, ldj, _ = run_cubic_kernel(x2, params, params.stride(0), live_idx, live_start, n_live, sp.n_bins,
-                                         sp.lower, sp.upper, reverse, want_ldj, False, ldj_scale)
+                                         sp.lower, sp.upper, 2 if (reverse and want_ldj) else reverse, want_ldj, False, ldj_scale)
         else:
             y, ldj, _ = run_rqs_kernel(x2, params, params.stride(0), live_idx, live_start, n_live, sp.n_bins,
                                        sp.lower, sp.upper, sp.lower, sp.upper, reverse, want_ldj, False, ldj_scale)

@@ -564,22 +564,23 @@ def test_cubic_spline_flow_against_golden():
     flow = product_flow(g, 'cubic_flow')
     x = g.t('cubic_flow/x').to(DEV)
     # Rows 0, 1 and 6 hold elements EXACTLY on a domain bound: there the log-derivative jumps (in-domain value vs the
-    # linear tails' 0) and the reference decides by re-evaluating the forward spline at the inverted point
-    # (flow.py:42-47), i.e. by the last bit of its own inverse.  Those rows are compared on the transformed values only.
-    ok = torch.ones(x.shape[0], dtype=torch.bool)
-    ok[[0, 1, 6]] = False
+    # linear tails' 0) and the reference decides by re-evaluating the FORWARD spline at the inverted point
+    # (Transform.inverse_and_log_det_jacobian, flow.py:42-47).  The kernel's reference mode (sx_cubic_coupling reverse = 2)
+    # does the same, so every row is compared (round 1 excluded these rows).
     cur = x
     for i in reversed(range(len(flow.transforms))):
         nxt, ldj = flow.transforms[i].inverse_and_log_det_jacobian(cur)
         close(nxt, g.t(f'cubic_flow/inv_x.{i}'), atol=1e-4)      # a cubic solve: flat spots amplify fp32 rounding (as in the reference)
-        close(ldj.cpu()[ok], g.t(f'cubic_flow/inv_ldj.{i}')[ok], rtol=1e-5, atol=2e-4)
+        close(ldj, g.t(f'cubic_flow/inv_ldj.{i}'), rtol=1e-5, atol=2e-4)
         cur = nxt
-    close(flow.log_prob(x).cpu()[ok], g.t('cubic_flow/log_prob')[ok], rtol=1e-5, atol=2e-4)
+    close(flow.log_prob(x), g.t('cubic_flow/log_prob'), rtol=1e-5, atol=2e-4)
     close(flow.forward(x), g.t('cubic_flow/forward'), atol=2e-5)
     close(flow.inverse(x), g.t('cubic_flow/inverse'), atol=1e-4)
+    ok = torch.ones(x.shape[0], dtype=torch.bool)
+    ok[[0, 1, 6]] = False      # fp64 truth: on-bound rows resolve differently in fp64 than in the reference's own fp32
     close(flow.log_prob(x).double().cpu()[ok], g.t('cubic_flow/log_prob_f64')[ok], rtol=1e-5, atol=2e-4)
     yf, ldf = flow.forward_and_log_det_jacobian(x)
-    close(ldf.cpu()[ok], g.t('cubic_flow/forward_ldj')[ok], rtol=1e-5, atol=2e-4)
+    close(ldf, g.t('cubic_flow/forward_ldj'), rtol=1e-5, atol=2e-4)
 
 
 def test_cubic_kernel_against_oracle_random_params():
