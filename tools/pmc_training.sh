@@ -29,3 +29,4 @@ json.dump(out, open('$O/pmc_training_cfg2.json', 'w'), indent=1)
 print(json.dumps(out, indent=1))
 PY
 find $O -name "*kernel_trace.csv" -delete
+find $O -name "*counter_collection.csv" -delete

@@ -1,14 +1,16 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun -- 'bash tools/profile_bench.sh r01_g'): rocprofv3 kernel stats of bench.py and of every
-# config, HBM-traffic PMC passes (separate --pmc runs, no tracing domains besides --kernel-trace) and SQ counter
-# passes of the fused kernel.  Outputs land in gpurun_out/prof_<tag>/; tools/pmc_summary.py condenses them.
-TAG=${1:-r01_x}
+# Runs on the GPU box (gpurun -- 'bash tools/profile_bench.sh r02_a <commit>'): rocprofv3 kernel stats of bench.py (cfg 2
+# headline + cfg 3 / cfg 4 lines + the stand-alone affine kernel), HBM-traffic PMC passes (separate --pmc runs, no tracing
+# domains besides --kernel-trace) and SQ counter passes of the fused kernels.  Outputs land in gpurun_out/prof_<tag>/;
+# tools/pmc_summary.py condenses them into pmc_cfg{2,3,4}.json / sq_cfg{2,3,4}.json.
+TAG=${1:-r02_x}
+COMMIT=${2:-unknown}
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_stats.log 2>&1
-rocprofv3 --kernel-trace --stats -d $OUT/stats_all -o all --output-format csv -- python3 $R/tools/bench_configs.py cfg1 cfg2 cfg3 cfg4 > $OUT/all_stats.log 2>&1
+f=$(find $OUT/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/bench_kernel_stats.csv
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" \
   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
@@ -17,5 +19,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $set -d $OUT/pmc$i -o p --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/pmc$i.log 2>&1
 done
-python3 $R/tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
+python3 $R/tools/pmc_summary.py $OUT $COMMIT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
+find $OUT -name "*kernel_trace.csv" -delete
+find $OUT -name "*counter_collection.csv" -delete
