@@ -373,43 +373,78 @@ class NormalizingFlow(Transform):
               for f in self.transforms]
         return all(ok) and any(not isinstance(f, _ColumnShuffle) for f in self.transforms)
 
-    def _log_prob_layerwise_autograd(self, y, latent=None):
-        """log_prob with a graph for spline-coupling flows: each layer's spline (and its backward) is a HIP kernel,
-        conditioners and column shuffles are torch ops on the device.  fp32 state."""
+    def _layerwise_autograd(self, x, latent=None, reverse: bool = True):
+        """The flow layer by layer WITH an autograd graph: each layer's transform (and its backward) is a HIP kernel behind
+        an autograd op, conditioners and column shuffles are torch ops on the device.  fp32 state.
+        -> (rows [N, D], accumulated log-det [N]); reverse = the direction log_prob evaluates."""
         from .flows.permute import _ColumnShuffle
-        y2, lead = flatten_rows(y.to(torch.float32))
+        x2, lead = flatten_rows(x.to(torch.float32))
         lat2 = None if latent is None else latent.reshape(-1, latent.shape[-1]).to(torch.float32)
         from .flows.linear import derive_dense_batched
-        dense = derive_dense_batched(self.transforms, y2.device)              # AffineLU / MatrixExponential matrices, batched
-        cur, total = y2, None
-        for f in reversed(self.transforms):
+        dense = derive_dense_batched(self.transforms, x2.device, reverse)        # AffineLU / MatrixExponential matrices, batched
+        cur, total = x2, None
+        for f in (reversed(self.transforms) if reverse else self.transforms):
             if isinstance(f, _ColumnShuffle):
-                def build_inv(f=f, d=cur.shape[1], dev=cur.device):
+                def build_idx(f=f, d=cur.shape[1], dev=cur.device):
                     perm = f._perm(d).to(dev).long()
+                    if not reverse:
+                        return perm                                           # permute.py:71 (forward: x[..., perm])
                     inv = torch.empty_like(perm)
                     inv[perm] = torch.arange(perm.numel(), device=perm.device)
                     return inv
-                inv = self._cached(('inv_perm', cur.shape[1], str(cur.device), id(f)), build_inv)
-                cur = cur.index_select(1, inv)                                # permute.py:75 (inverse direction)
+                idx = self._cached(('perm_idx', reverse, cur.shape[1], str(cur.device), id(f)), build_idx)
+                cur = cur.index_select(1, idx)                                # permute.py:71,75
                 continue
-            cur, ldj = f._autograd_inverse(cur, lat2, dense[id(f)]) if id(f) in dense else f._autograd_inverse(cur, lat2)
+            step = f._autograd_inverse if reverse else f._autograd_forward
+            cur, ldj = step(cur, lat2, dense[id(f)]) if id(f) in dense else step(cur, lat2)
             total = ldj if total is None else total + ldj
+        if total is None:
+            total = torch.zeros(cur.shape[0], dtype=torch.float32, device=cur.device)
+        return cur, total, lead
+
+    def _log_prob_layerwise_autograd(self, y, latent=None):
+        """log_prob with a graph for spline-coupling / conditional / mixed flows (the layer-wise training path)."""
+        cur, total, lead = self._layerwise_autograd(y, latent, True)
         d = cur.shape[1]
         lp = -0.5 * (cur * cur).sum(-1) - d * HALF_LOG_2PI + total            # dist/normal.py:37,52-54
         return lp.reshape(*lead, 1)
+
+    def _transform_with_graph(self, x, latent, reverse: bool, what: str, kwargs):
+        """forward / inverse (+ log-det) as differentiable tensors when a graph is wanted, or None.  The reference's
+        methods are all differentiable (VI losses built from rsample + log-det); here the layer-wise ops provide that for
+        every layer with a backward in the wanted direction (forward: affine couplings, element-wise Affine, the point-wise
+        flows, AffineLU / MatrixExponential with the default t, Permute / Flip; inverse: also spline couplings).  Flows
+        outside that set evaluate without a graph and say so."""
+        if not self._wants_grad(x) or kwargs:
+            return None
+        from .flows.permute import _ColumnShuffle
+        ok = self._layerwise_autograd_ok() and (reverse or all(isinstance(f, _ColumnShuffle) or hasattr(f, '_autograd_forward')
+                                                               for f in self.transforms))
+        if ok:
+            try:
+                cur, total, lead = self._layerwise_autograd(x, latent, reverse)
+                return cur.reshape(*lead, cur.shape[1]).to(x.dtype if x.dtype != torch.bfloat16 else torch.float32), total.reshape(*lead, 1)
+            except NotImplementedError:
+                pass
+        self._warn_detached(what, x)
+        return None
 
     def _wants_grad(self, y) -> bool:
         return torch.is_grad_enabled() and (y.requires_grad or any(p.requires_grad for p in self.parameters()))
 
     def _warn_detached(self, what: str, x) -> None:
-        """The differentiable surface is `log_prob` (all on-path flows), `MLP.forward`, `ContinuousAffineCoupling` and
-        `NeuralFlow`; everything else evaluates WITHOUT a graph.  In the reference every call is differentiable, so a
-        loss built from such a result would train with the flow silently frozen: say so, loudly, once per call site."""
-        if x.requires_grad and torch.is_grad_enabled():
-            import warnings
-            warnings.warn(f'stribor_amd: NormalizingFlow.{what} returns tensors WITHOUT an autograd graph (the input '
-                          f'requires grad); only log_prob is differentiable in this build -- see INTEGRATION.md '
-                          f'"Differentiable surface"', RuntimeWarning, stacklevel=3)
+        """A graph was wanted (grad enabled and the input or a parameter requires grad) but this flow has a layer without a
+        backward in the wanted direction (or extra keyword arguments): the result is computed by the fused kernels WITHOUT
+        a graph.  In the reference every call is differentiable, so a loss built from such a result would train with the
+        flow silently frozen: say so -- always when the input itself requires grad, once per method otherwise."""
+        import warnings
+        seen = self.__dict__.setdefault('_warned_detached', set())
+        if x.requires_grad or what not in seen:
+            seen.add(what)
+            warnings.warn(f'stribor_amd: NormalizingFlow.{what} returns tensors WITHOUT an autograd graph for this flow '
+                          f'(a layer has no backward in that direction, or keyword arguments were given); wrap inference in '
+                          f'torch.no_grad() to silence this -- see INTEGRATION.md "Differentiable surface"',
+                          RuntimeWarning, stacklevel=4)
 
     def _run(self, x, reverse: bool, latent, want_y, want_ldj, want_logp, sum_out=None, **kwargs):
         """Returns (y, ldj[..., 1], logp[..., 1]) (None where not requested) via the fused kernel, or None
@@ -433,7 +468,9 @@ class NormalizingFlow(Transform):
 
     # ---- reference method set -----------------------------------------------------------------------------
     def forward(self, x, latent=None, **kwargs):
-        self._warn_detached('forward', x)
+        g = self._transform_with_graph(x, latent, False, 'forward', kwargs)
+        if g is not None:
+            return g[0]
         r = self._run(x, False, latent, True, False, False, **kwargs)
         if r is not None:
             return r[0]
@@ -443,7 +480,9 @@ class NormalizingFlow(Transform):
         return x
 
     def inverse(self, y, latent=None, **kwargs):
-        self._warn_detached('inverse', y)
+        g = self._transform_with_graph(y, latent, True, 'inverse', kwargs)
+        if g is not None:
+            return g[0]
         r = self._run(y, True, latent, True, False, False, **kwargs)
         if r is not None:
             return r[0]
@@ -453,7 +492,9 @@ class NormalizingFlow(Transform):
         return y
 
     def forward_and_log_det_jacobian(self, x, latent=None, **kwargs):
-        self._warn_detached('forward_and_log_det_jacobian', x)
+        g = self._transform_with_graph(x, latent, False, 'forward_and_log_det_jacobian', kwargs)
+        if g is not None:
+            return g
         r = self._run(x, False, latent, True, True, False, **kwargs)
         if r is not None:
             return r[0], r[1]
@@ -465,7 +506,9 @@ class NormalizingFlow(Transform):
         return x, acc
 
     def inverse_and_log_det_jacobian(self, y, latent=None, **kwargs):
-        self._warn_detached('inverse_and_log_det_jacobian', y)
+        g = self._transform_with_graph(y, latent, True, 'inverse_and_log_det_jacobian', kwargs)
+        if g is not None:
+            return g
         r = self._run(y, True, latent, True, True, False, **kwargs)
         if r is not None:
             return r[0], r[1]

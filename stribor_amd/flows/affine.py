@@ -125,12 +125,15 @@ class Affine(ElementwiseTransform):
 
     # ---- training (layer-wise autograd path) ---------------------------------------------------------------------
     def _autograd_supported(self) -> bool:
-        from ..net.mlp import MLP
-        return self.latent_net is None or isinstance(self.latent_net, MLP)
+        return True
 
-    def _autograd_inverse(self, x2: torch.Tensor, lat2=None):
-        """inverse_and_log_det_jacobian on fp32 rows with a graph (AffineCouplingOp over all columns); the parameters
-        are the module's own (broadcast over the rows) or the latent_net's output through torch's Linear layers."""
+    def _autograd_forward(self, x2: torch.Tensor, lat2=None):
+        return self._autograd_inverse(x2, lat2, reverse=False)
+
+    def _autograd_inverse(self, x2: torch.Tensor, lat2=None, reverse: bool = True):
+        """inverse_and_log_det_jacobian (or, reverse=False, forward_and_log_det_jacobian) on fp32 rows with a graph
+        (AffineCouplingOp over all columns); the parameters are the module's own (broadcast over the rows) or the
+        latent_net's output through torch's Linear layers."""
         n, d = x2.shape
         if self.latent_net is None:
             ls, sh = self.log_scale.reshape(-1), self.shift.reshape(-1)
@@ -140,8 +143,9 @@ class Affine(ElementwiseTransform):
         else:
             if lat2 is None:
                 raise ValueError('Affine with a latent_net needs `latent`')
-            params = self.latent_net.forward_autograd(lat2)                    # affine.py:66
-        return AffineCouplingOp.apply(x2, params, None, 0, d, True, -1.0)     # affine.py:111-113
+            net = self.latent_net
+            params = net.forward_autograd(lat2) if hasattr(net, 'forward_autograd') else net(lat2)   # affine.py:66
+        return AffineCouplingOp.apply(x2, params.contiguous(), None, 0, d, bool(reverse), -1.0 if reverse else 1.0)   # affine.py:97-113
 
     # ---- fused-program hooks --------------------------------------------------------------------------------
     def _plan_hidden_width(self):

@@ -288,7 +288,14 @@ class Coupling(Transform):
             return False
         return isinstance(self.transform, (Affine, Spline))
 
-    def _autograd_inverse(self, x2: torch.Tensor, lat2=None):
+    def _autograd_forward(self, x2: torch.Tensor, lat2=None):
+        """forward_and_log_det_jacobian with a graph (affine couplings; the spline kernels have a hand-written backward for
+        the inverse direction only)."""
+        if not isinstance(self.transform, Affine):
+            raise NotImplementedError('forward-direction autograd is built for affine couplings')
+        return self._autograd_inverse(x2, lat2, reverse=False)
+
+    def _autograd_inverse(self, x2: torch.Tensor, lat2=None, reverse: bool = True):
         """inverse_and_log_det_jacobian on fp32 rows [N, D] with a graph: the conditioner runs through torch's own
         Linear layers (rocBLAS; only the rows of the last layer that parameterise transformed columns), the transform
         and its backward are the HIP kernels behind ``RQSInverse`` / ``AffineCouplingOp``.
@@ -325,10 +332,12 @@ class Coupling(Transform):
         else:                                                                        # any nn.Module: torch's own graph
             params = net(z).index_select(1, rows_t)
         if is_spline:
+            if not reverse:
+                raise NotImplementedError('forward-direction autograd is built for affine couplings')
             op = CubicInverse if sp.spline_type == 'cubic' else RQSInverse
             return op.apply(x2, params, live_idx, int(live[0]), len(live), sp.n_bins, sp.lower, sp.upper, 1.0)
         # Transform.inverse_and_log_det_jacobian: minus the forward log-det (flow.py:47)
-        return AffineCouplingOp.apply(x2, params, live_idx, int(live[0]), len(live), True, -1.0)
+        return AffineCouplingOp.apply(x2, params, live_idx, int(live[0]), len(live), bool(reverse), -1.0 if reverse else 1.0)
 
     # ---- reference method set (coupling.py:69-95) -----------------------------------------------------------
     def forward(self, x, latent=None, reverse: bool = False, **kwargs):

@@ -87,11 +87,12 @@ def _lu_inverse_batched(L, U):
     return torch.linalg.solve_triangular(U, torch.linalg.solve_triangular(L, eye, upper=False), upper=True)
 
 
-def derive_dense_batched(layers, dev):
-    """The inverse-direction matrices of all AffineLU / MatrixExponential layers of a flow in a few BATCHED fp64 torch ops
-    (one launch per op for every group of same-shaped layers instead of one per layer: a training step of a cfg-4-like
-    flow is dominated by these tiny launches at small batch sizes).  -> {id(layer): (W [out, in] fp32, b fp32 | None,
-    log-det scalar tensor)} for the layers' _autograd_inverse; differentiable."""
+def derive_dense_batched(layers, dev, reverse: bool = True):
+    """The matrices of all AffineLU / MatrixExponential layers of a flow in a few BATCHED fp64 torch ops (one launch per op
+    for every group of same-shaped layers instead of one per layer: a training step of a cfg-4-like flow is dominated by
+    these tiny launches at small batch sizes), for the inverse direction (what log_prob evaluates) or the forward one.
+    -> {id(layer): (W [out, in] fp32, b fp32 | None, log-det scalar tensor)} for the layers' _autograd_inverse /
+    _autograd_forward; differentiable."""
     out, groups = {}, {}
     for f in layers:
         if isinstance(f, AffineLU):
@@ -106,10 +107,15 @@ def derive_dense_batched(layers, dev):
             ld = torch.stack([f.log_diag.reshape(-1) for f in fs]).to(dev, torch.float64)
             b = torch.stack([f.bias.reshape(-1) for f in fs]).to(dev, torch.float64)
             L, U = torch.tril(W, -1) + eye, torch.triu(W, 1) + torch.diag_embed(ld.exp())      # affine.py:148-154
-            Ainv = _lu_inverse_batched(L, U)
-            Wm = Ainv.transpose(-1, -2).to(torch.float32).contiguous()                         # x = (y - b) A^-1 (:159-163)
-            bm = (-(b.unsqueeze(1) @ Ainv).squeeze(1)).to(torch.float32)
-            ldj = (-ld.sum(-1)).to(torch.float32)                                              # :171, negated
+            if reverse:
+                Ainv = _lu_inverse_batched(L, U)
+                Wm = Ainv.transpose(-1, -2).to(torch.float32).contiguous()                     # x = (y - b) A^-1 (:159-163)
+                bm = (-(b.unsqueeze(1) @ Ainv).squeeze(1)).to(torch.float32)
+                ldj = (-ld.sum(-1)).to(torch.float32)                                          # :171, negated
+            else:
+                Wm = (L @ U).transpose(-1, -2).to(torch.float32).contiguous()                  # y = x (L U) + b (:157)
+                bm = b.to(torch.float32)
+                ldj = ld.sum(-1).to(torch.float32)
             for i, f in enumerate(fs):
                 out[id(f)] = (Wm[i], bm[i], ldj[i])
         else:
@@ -121,12 +127,13 @@ def derive_dense_batched(layers, dev):
                 te = _TE_CACHE[tkey] = torch.tensor(tkey[0], dtype=torch.float64, device=dev).unsqueeze(-1)
             L, U = torch.tril(W, diagonal=-1) + eye, torch.triu(W) + eye                       # affine.py:222-226
             Ainv = _lu_inverse_batched(L, U)
-            M = ((L @ U) * (dg * (-te)).exp().unsqueeze(-2)) @ Ainv                            # :254-266 with t -> -t
+            sg = -te if reverse else te
+            M = ((L @ U) * (dg * sg).exp().unsqueeze(-2)) @ Ainv                               # :254-266 (t -> -t inverse)
             Wm = M.to(torch.float32).contiguous()
-            ldj = (-(dg.sum(-1) * te.squeeze(-1))).to(torch.float32)                           # :287-288, negated
+            ldj = ((dg.sum(-1) * sg.squeeze(-1))).to(torch.float32)                            # :287-288 (negated inverse)
             if key[2]:
                 bias = torch.stack([f.bias for f in fs]).to(dev, torch.float64)
-                bm = (-(M @ bias.unsqueeze(-1)).squeeze(-1)).to(torch.float32)
+                bm = (-(M @ bias.unsqueeze(-1)).squeeze(-1)).to(torch.float32) if reverse else bias.to(torch.float32)
             for i, f in enumerate(fs):
                 out[id(f)] = (Wm[i], bm[i] if key[2] else None, ldj[i])
     return out
@@ -183,6 +190,12 @@ class AffineLU(_DenseLinear):
             derived = derive_dense_batched([self], dev)[id(self)]
         Wm, bm, ldj = derived
         return batch_linear(x2, Wm, bm), ldj.expand(x2.shape[0])                                           # :159-163, :171
+
+    def _autograd_forward(self, x2: torch.Tensor, lat2=None, derived=None):
+        if derived is None:
+            derived = derive_dense_batched([self], x2.device, reverse=False)[id(self)]
+        Wm, bm, ldj = derived
+        return batch_linear(x2, Wm, bm), ldj.expand(x2.shape[0])                                           # :157, :171
 
     def _plan(self, builder, reverse, ldj_scale):
         ldj = lambda dev: ldj_scale * self.log_diag.detach().to(dev, torch.float64).sum()       # affine.py:171
@@ -272,6 +285,12 @@ class MatrixExponential(_DenseLinear):
             derived = derive_dense_batched([self], x2.device)[id(self)]
         Wm, bm, ldj = derived
         return batch_linear(x2, Wm, bm), ldj.expand(x2.shape[0])                                           # :254-266, :287-288
+
+    def _autograd_forward(self, x2: torch.Tensor, lat2=None, derived=None):
+        if derived is None:
+            derived = derive_dense_batched([self], x2.device, reverse=False)[id(self)]
+        Wm, bm, ldj = derived
+        return batch_linear(x2, Wm, bm), ldj.expand(x2.shape[0])                                           # :243-270, :287-288
 
     def _plan(self, builder, reverse, ldj_scale):
         t = getattr(builder, 't', None)

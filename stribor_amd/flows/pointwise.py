@@ -68,6 +68,9 @@ class _Pointwise(ElementwiseTransform):
     def _autograd_inverse(self, x2, lat2=None):
         return PointwiseOp.apply(x2, self._inv, self._p(True))
 
+    def _autograd_forward(self, x2, lat2=None):
+        return PointwiseOp.apply(x2, self._fwd, self._p(False))
+
     def forward(self, x, **kwargs):
         return run_pointwise(x, self._fwd, self._p(False))[0]
 
@@ -178,4 +181,7 @@ class Identity(ElementwiseTransform):
         return True
 
     def _autograd_inverse(self, x2, lat2=None):
+        return x2, torch.zeros(x2.shape[0], dtype=torch.float32, device=x2.device)
+
+    def _autograd_forward(self, x2, lat2=None):
         return x2, torch.zeros(x2.shape[0], dtype=torch.float32, device=x2.device)
