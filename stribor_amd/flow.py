@@ -143,31 +143,33 @@ def _backward_layer_major(bprog, layers, views, z, g, gy) -> None:
     lib = _hip.lib()
     n, dev = z.shape[0], z.device
     L = len(layers)
+    G = max(1, int(lib.sx_flow_bwd_max_steps()))      # layers per launch this build's register budget allows (1)
     subs = getattr(bprog, '_layer_programs', None)
-    if subs is None:                                  # one-step programs over the same blobs
+    if subs is None or bprog._layer_group != G:       # programs of G consecutive steps over the same blobs
         subs = []
-        for k in range(L):
+        for k0 in range(0, L, G):
             sp = _hip.sx_program()
             C.memmove(C.byref(sp), C.byref(bprog.prog), C.sizeof(_hip.sx_program))
-            sp.n_steps = 1
-            sp.steps[0] = bprog.prog.steps[k]
-            subs.append(sp)
-        bprog._layer_programs = subs
+            sp.n_steps = min(G, L - k0)
+            for j in range(sp.n_steps):
+                sp.steps[j] = bprog.prog.steps[k0 + j]
+            subs.append((k0, sp))
+        bprog._layer_programs, bprog._layer_group = subs, G
     n_part, part_floats = C.c_int32(), C.c_int64()
-    _hip.check(lib.sx_flow_bwd_partials(C.byref(subs[0]), n, C.byref(n_part), C.byref(part_floats)), 'sx_flow_bwd_partials')
+    _hip.check(lib.sx_flow_bwd_partials(C.byref(subs[0][1]), n, C.byref(n_part), C.byref(part_floats)), 'sx_flow_bwd_partials')
     n_part, part_floats = n_part.value, part_floats.value
     H32 = 32 * bprog.prog.h_tiles
     E2 = 64 * H32 + 64
     with _hip.device_of(z):
         blobs = bprog.blobs_for(_hip.GEMM_F16X3)
-        frag = torch.empty((n + 31) // 32 * 4096, dtype=torch.float32, device=dev) if L > 1 else None
+        frag = torch.empty((n + 31) // 32 * 4096, dtype=torch.float32, device=dev) if len(subs) > 1 else None
         acc = torch.empty(L, n_part * part_floats, dtype=torch.float32, device=dev)
         work, flag, st = _hip.work_counters(dev), _hip.err_flag(dev), _hip.stream()
-        for k in range(L):
-            first, last = k == 0, k == L - 1
-            rc = lib.sx_flow_bwd_run(C.byref(subs[k]), blobs.data_ptr(), z.data_ptr() if first else None, g.data_ptr(),
+        for i, (k0, sp) in enumerate(subs):
+            first, last = i == 0, i == len(subs) - 1
+            rc = lib.sx_flow_bwd_run(C.byref(sp), blobs.data_ptr(), z.data_ptr() if first else None, g.data_ptr(),
                                      None if first else frag.data_ptr(), None if last else frag.data_ptr(),
-                                     gy.data_ptr() if last else None, acc[k].data_ptr(), n, work.data_ptr(), flag, st)
+                                     gy.data_ptr() if last else None, acc[k0].data_ptr(), n, work.data_ptr(), flag, st)
             if rc != 0:
                 work.zero_()
             _hip.check(rc, 'sx_flow_bwd_run')
