@@ -375,15 +375,16 @@ class NormalizingFlow(Transform):
               for f in self.transforms]
         return all(ok) and any(not isinstance(f, _ColumnShuffle) for f in self.transforms)
 
-    def _layerwise_autograd(self, x, latent=None, reverse: bool = True):
+    def _layerwise_autograd(self, x, latent=None, reverse: bool = True, t=None):
         """The flow layer by layer WITH an autograd graph: each layer's transform (and its backward) is a HIP kernel behind
         an autograd op, conditioners and column shuffles are torch ops on the device.  fp32 state.
         -> (rows [N, D], accumulated log-det [N]); reverse = the direction log_prob evaluates."""
         from .flows.permute import _ColumnShuffle
         x2, lead = flatten_rows(x.to(torch.float32))
         lat2 = None if latent is None else latent.reshape(-1, latent.shape[-1]).to(torch.float32)
-        from .flows.linear import derive_dense_batched
-        dense = derive_dense_batched(self.transforms, x2.device, reverse)        # AffineLU / MatrixExponential matrices, batched
+        from .flows.linear import MatrixExponential, derive_dense_batched
+        timed = [] if t is None else [f for f in self.transforms if isinstance(f, MatrixExponential)]
+        dense = derive_dense_batched([f for f in self.transforms if f not in timed], x2.device, reverse)   # batched fp64 ops
         cur, total = x2, None
         for f in (reversed(self.transforms) if reverse else self.transforms):
             if isinstance(f, _ColumnShuffle):
@@ -397,6 +398,10 @@ class NormalizingFlow(Transform):
                 idx = self._cached(('perm_idx', reverse, cur.shape[1], str(cur.device), id(f)), build_idx)
                 cur = cur.index_select(1, idx)                                # permute.py:71,75
                 continue
+            if any(f is g for g in timed):                                    # an explicit time (number or per-row tensor)
+                cur, ldj = f._autograd_time(cur, t, reverse)
+                total = ldj if total is None else total + ldj
+                continue
             step = f._autograd_inverse if reverse else f._autograd_forward
             cur, ldj = step(cur, lat2, dense[id(f)]) if id(f) in dense else step(cur, lat2)
             total = ldj if total is None else total + ldj
@@ -404,9 +409,9 @@ class NormalizingFlow(Transform):
             total = torch.zeros(cur.shape[0], dtype=torch.float32, device=cur.device)
         return cur, total, lead
 
-    def _log_prob_layerwise_autograd(self, y, latent=None):
+    def _log_prob_layerwise_autograd(self, y, latent=None, t=None):
         """log_prob with a graph for spline-coupling / conditional / mixed flows (the layer-wise training path)."""
-        cur, total, lead = self._layerwise_autograd(y, latent, True)
+        cur, total, lead = self._layerwise_autograd(y, latent, True, t)
         d = cur.shape[1]
         lp = -0.5 * (cur * cur).sum(-1) - d * HALF_LOG_2PI + total            # dist/normal.py:37,52-54
         return lp.reshape(*lead, 1)
@@ -417,14 +422,17 @@ class NormalizingFlow(Transform):
         every layer with a backward in the wanted direction (forward: affine couplings, element-wise Affine, the point-wise
         flows, AffineLU / MatrixExponential with the default t, Permute / Flip; inverse: also spline couplings).  Flows
         outside that set evaluate without a graph and say so."""
-        if not self._wants_grad(x) or kwargs:
+        if not self._wants_grad(x):
+            return None
+        if kwargs and set(kwargs) != {'t'}:
+            self._warn_detached(what, x)
             return None
         from .flows.permute import _ColumnShuffle
         ok = self._layerwise_autograd_ok() and (reverse or all(isinstance(f, _ColumnShuffle) or hasattr(f, '_autograd_forward')
                                                                for f in self.transforms))
         if ok:
             try:
-                cur, total, lead = self._layerwise_autograd(x, latent, reverse)
+                cur, total, lead = self._layerwise_autograd(x, latent, reverse, kwargs.get('t'))
                 return cur.reshape(*lead, cur.shape[1]).to(x.dtype if x.dtype != torch.bfloat16 else torch.float32), total.reshape(*lead, 1)
             except NotImplementedError:
                 pass
@@ -531,8 +539,8 @@ class NormalizingFlow(Transform):
                 # flow evaluates without a graph, as before
                 y2, lead = flatten_rows(y.to(torch.float32))
                 return _FusedLogProb.apply(self, y2, *self._grad_params()).reshape(*lead, 1)
-            if self._wants_grad(y) and not kwargs and self._layerwise_autograd_ok():
-                return self._log_prob_layerwise_autograd(y, latent)
+            if self._wants_grad(y) and (not kwargs or set(kwargs) == {'t'}) and self._layerwise_autograd_ok():
+                return self._log_prob_layerwise_autograd(y, latent, kwargs.get('t'))
             if self._wants_grad(y) and not getattr(self, '_warned_no_graph', False):
                 import warnings
                 self._warned_no_graph = True

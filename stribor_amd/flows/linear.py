@@ -292,6 +292,28 @@ class MatrixExponential(_DenseLinear):
         Wm, bm, ldj = derived
         return batch_linear(x2, Wm, bm), ldj.expand(x2.shape[0])                                           # :243-270, :287-288
 
+    def _autograd_time(self, x2: torch.Tensor, t, reverse: bool):
+        """forward / inverse with an explicit time (a number or a per-row tensor [N, 1]) and a graph: the three stages of
+        affine.py:254-269 -- v = (LU)^-1 (x [- b]); v *= exp(+-diag t_n); y = (LU) v [+ b] -- with the matrices derived
+        in fp64 by differentiable ops and the two [N, D] x [D, D] products through BatchLinear."""
+        dev = x2.device
+        W = self._weight.to(dev, torch.float64)
+        eye = torch.eye(self.dim, dtype=torch.float64, device=dev)
+        L, U = torch.tril(W, diagonal=-1) + eye, torch.triu(W) + eye                          # affine.py:222-226
+        A = L @ U
+        Ainv = _lu_inverse_batched(L.unsqueeze(0), U.unsqueeze(0))[0]
+        tt = t.reshape(-1, 1).to(dev, torch.float32) if torch.is_tensor(t) else torch.full((x2.shape[0], 1), float(t), device=dev)
+        if self.log_time:
+            tt = torch.log1p(tt.abs())                                                         # affine.py:239-240
+        sg = -tt if reverse else tt                                                            # :254
+        xin = x2 - self.bias.to(dev, torch.float32) if (reverse and self.bias is not None) else x2          # :255-256
+        v = batch_linear(xin, Ainv.to(torch.float32), None)                                    # :260-261
+        v = v * torch.exp(self.diag.to(dev, torch.float32) * sg)                               # :263
+        y = batch_linear(v, A.to(torch.float32), None)                                         # :265-266
+        if not reverse and self.bias is not None:
+            y = y + self.bias.to(dev, torch.float32)                                           # :268-269
+        return y, (self.diag.to(dev, torch.float32).sum() * sg).reshape(-1)                    # :287-288 (negated: flow.py:47)
+
     def _plan(self, builder, reverse, ldj_scale):
         t = getattr(builder, 't', None)
         t = 1.0 if t is None else t                                          # default t = 1.0 (affine.py:246)
