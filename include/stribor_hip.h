@@ -144,6 +144,29 @@ int sx_rqs_inverse_bwd(const float *x, const float *gout, const float *gldj, con
                        int32_t n_live, int32_t n_bins, float left, float right, float bottom, float top, int64_t n_rows,
                        int32_t dim, float ldj_scale, void *stream);
 
+/* Backward of one rational-quadratic spline COUPLING with the parameter tensor never in HBM (training of
+ * Coupling(Spline(spline_type='quadratic')), stribor/flows/coupling.py:69-95 + flows/spline.py:76-87): the spline's reverse
+ * mode (as sx_rqs_inverse_bwd) fused with the last conditioner layer  params = h W2^T + b2  and that layer's backward.
+ * A workgroup owns a slab of W2 -- the 3K-1 rows of two transformed columns -- over a range of rows (sx_rqs_slab.hip).
+ *   x, gout [n_rows, dim], gldj [n_rows]: as sx_rqs_inverse_bwd;  h [n_rows, ld_h]: last hidden activation (`hidden` <= 64
+ *   features);  n_bins <= 16.
+ *   Slots: slab s (columns live[2s], live[2s+1]) has 96 slots; slot 32 t + R (t = 0 widths, 1 heights, 2 derivatives) is
+ *   parameter (R&3) + 4 (R>>3) of column 2 s + ((R>>2)&1).  slot_rows[sx_rqs_slab_slots(n_live)]: slot -> row of W2 / b2 as
+ *   handed to the packers, or -1 (padding).
+ *   w_fwd: sx_pack_linear(W2, b2, row_idx = slot_rows, col_idx = hidden slots, m_tiles = slots/32, k_tiles = ceil(hidden/32),
+ *          SX_GEMM_F16X3);  w_bwd: the same with transpose = 1 (m_tiles = ceil(hidden/32), k_tiles = slots/32, no bias).
+ *   Outputs: gx [n_rows, dim] (transformed columns written), gh [n_rows, ld_gh] = dL/dh, dW [rows of W2, ldw] and db
+ *   (rows named by slot_rows written), all fp32.  scratch: sx_rqs_slab_scratch_floats(n_rows, n_live, hidden) floats,
+ *   16-byte aligned, caller-owned.  err_flag (nullable) receives SX_FLAG_F16_RANGE when h or a parameter gradient leaves
+ *   fp16's range (those rows' gx are NaN). */
+int32_t sx_rqs_slab_slots(int32_t n_live);
+size_t sx_rqs_slab_scratch_floats(int64_t n_rows, int32_t n_live, int32_t hidden);
+int sx_rqs_slab_bwd(const float *x, const float *gout, const float *gldj, const float *h, int64_t ld_h, int32_t hidden,
+                    const float *w_fwd, const float *w_bwd, const int32_t *slot_rows, float *gx, float *gh, int64_t ld_gh,
+                    float *dW, int64_t ldw, float *db, const int32_t *live_idx, int32_t live_start, int32_t n_live,
+                    int32_t n_bins, float left, float right, float bottom, float top, int64_t n_rows, int32_t dim,
+                    float ldj_scale, float *scratch, uint32_t *err_flag, void *stream);
+
 /* Monotone cubic spline, element-wise part -- spline_type='cubic', the reference's default
  * (stribor/util/cubic_spline.py:21-251, util/search_sorted.py:3-5, flows/spline.py:59-61,82-86).
  *   params[n, i*(2K+2) + 0:K]      unnormalised widths  of live dim i

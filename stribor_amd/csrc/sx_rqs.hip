@@ -806,7 +806,7 @@ extern "C" int sx_cubic_coupling(const void *x, void *y, float *ldj, float *ldia
 // Layout / staging as rqs_kernel; the lane overwrites its parameter slice with the gradients, which then leave
 // coalesced in the parameter tensor's own layout.  fp32 only (training state).
 // =====================================================================================================
-__device__ __forceinline__ float rqs_sigmoidf(float v) { return 1.f / (1.f + expf(-v)); }
+#include "sx_rqs_bwd.h"
 
 __global__ __launch_bounds__(256) void rqs_inverse_bwd_kernel(const float *__restrict__ x, const float *__restrict__ gout,
                                                               const float *__restrict__ gldj,
@@ -821,9 +821,6 @@ __global__ __launch_bounds__(256) void rqs_inverse_bwd_kernel(const float *__res
     float *sp = rqs_smem + (size_t)wave * 64 * P;
     const int64_t n_elem = n_rows * n_live;
     const int64_t n_groups = (n_elem + 63) >> 6;
-    const float bconst = logf(expf(1.f - RQS_MIN_DERIV) - 1.f);
-    const float norm = 1.f - RQS_MIN_BIN * (float)K;
-    const float span_w = right - left, span_h = top - bottom;
     const bool contig = pstride == (int64_t)n_live * P;
     const float inv_P = 1.0f / (float)P;
     for (int64_t grp = (int64_t)blockIdx.x * waves_per_block + wave; grp < n_groups;
@@ -854,113 +851,9 @@ __global__ __launch_bounds__(256) void rqs_inverse_bwd_kernel(const float *__res
         const float xv = valid ? x[row * dim + col] : bottom;
         const float Ao = valid ? gout[row * dim + col] : 0.f;            // dL/d out
         const float Al = valid ? gldj[row] * ldj_scale : 0.f;            // dL/d ljd (the row sum's adjoint)
-        const bool inside = (xv >= bottom) && (xv <= top);
-        const float xin = inside ? xv : bottom;
-        float *uw = sp + (valid ? lane : 0) * P, *uh = uw + K, *ud = uh + K;
-
-        // ---- forward: softmax pieces, knots, bin (heights), as rqs_kernel's generic path -----------------
-        float mw = uw[0], mh = uh[0];
-        for (int k = 1; k < K; ++k) { mw = fmaxf(mw, uw[k]); mh = fmaxf(mh, uh[k]); }
-        float sw = 0.f, sh = 0.f;
-        for (int k = 0; k < K; ++k) {          // exp once per parameter, kept in place (v_exp_f32, compensated argument)
-            const float ew = cubic_exp(uw[k] - mw), eh = cubic_exp(uh[k] - mh);
-            uw[k] = ew;
-            uh[k] = eh;
-            sw += ew;
-            sh += eh;
-        }
-        const float inv_sw = 1.f / sw, inv_sh = 1.f / sh;
-        int b = 0;
-        float cw_b = left, ch_b = bottom, cw_n = right, ch_n = top;
-        bool have_next = false;
-        float csw = 0.f, csh = 0.f;
-        for (int j = 1; j <= K; ++j) {
-            const float wk = RQS_MIN_BIN + norm * (uw[j - 1] * inv_sw);
-            const float hk = RQS_MIN_BIN + norm * (uh[j - 1] * inv_sh);
-            csw += wk;
-            csh += hk;
-            const float kw = (j < K) ? span_w * csw + left : right;
-            const float kh = (j < K) ? span_h * csh + bottom : top;
-            const bool ge = xin >= ((j < K) ? kh : kh + RQS_EPS);
-            if (ge && j < K) { b = j; cw_b = kw; ch_b = kh; }
-            else if (!ge && !have_next) { cw_n = kw; ch_n = kh; have_next = true; }
-        }
-        const float w_b = cw_n - cw_b, h_b = ch_n - ch_b, s_b = h_b / w_b;
-        const float u_b = (b == 0) ? bconst : ud[b - 1], u_n = (b + 1 == K) ? bconst : ud[b];
-        const float d_b = RQS_MIN_DERIV + softplus_ref(u_b), d_n = RQS_MIN_DERIV + softplus_ref(u_n);
-        const float dy = xin - ch_b;
-        const float q = d_b + d_n - 2.f * s_b;
-        const float a = dy * q + h_b * (s_b - d_b);
-        const float bb = h_b * d_b - dy * q;
-        const float c = -s_b * dy;
-        const float disc = bb * bb - 4.f * a * c;
-        const float sq = sqrtf(disc);
-        const float D = -bb - sq;
-        const float r = (2.f * c) / D;
-        const float tomt = r * (1.f - r), omr = 1.f - r;
-        const float den = s_b + q * tomt;
-        const float T = d_n * (r * r) + 2.f * s_b * tomt + d_b * (omr * omr);
-        const float dnum = (s_b * s_b) * T;
-
-        // ---- reverse --------------------------------------------------------------------------------------
-        const float Adnum = -Al / dnum, Aden = 2.f * Al / den;
-        float As = Adnum * (2.f * s_b * T + (s_b * s_b) * 2.f * tomt) + Aden;
-        float Adn = Adnum * (s_b * s_b) * (r * r), Adb = Adnum * (s_b * s_b) * (omr * omr);
-        float Atomt = Adnum * (s_b * s_b) * 2.f * s_b + Aden * q;
-        float Ar = Adnum * (s_b * s_b) * (2.f * d_n * r) - Adnum * (s_b * s_b) * (2.f * d_b * omr);
-        float Aq = Aden * tomt;
-        Ar += Atomt * (1.f - 2.f * r) + Ao * w_b;
-        float Awb = Ao * r, Acwb = Ao;
-        float Ac = Ar * 2.f / D;
-        const float AD = -Ar * r / D;
-        float Abb = -AD;
-        const float Adisc = (sq > 0.f) ? (-AD) / (2.f * sq) : 0.f;
-        Abb += Adisc * 2.f * bb;
-        const float Aa = -4.f * c * Adisc;
-        Ac += -4.f * a * Adisc;
-        As += -dy * Ac;
-        float Ady = -s_b * Ac;
-        float Ahb = d_b * Abb;
-        Adb += h_b * Abb;
-        Ady += -q * Abb;
-        Aq += -dy * Abb;
-        Ady += q * Aa;
-        Aq += dy * Aa;
-        Ahb += (s_b - d_b) * Aa;
-        As += h_b * Aa;
-        Adb += -h_b * Aa;
-        Adb += Aq;
-        Adn += Aq;
-        As += -2.f * Aq;
-        float Axin = Ady, Achb = -Ady;
-        Ahb += As / w_b;
-        Awb += -As * s_b / w_b;
-        float Acwn = Awb, Achn = Ahb;
-        Acwb -= Awb;
-        Achb -= Ahb;
-        // knots -> cumsums -> widths / heights:  dL/dw_i = span * ([i < b] A(kw_b) + [i < b+1 < K] A(kw_{b+1}))
-        const float Gw_lo = (b >= 1 ? span_w * Acwb : 0.f) + (b + 1 < K ? span_w * Acwn : 0.f);   // bins i < b
-        const float Gw_b = (b + 1 < K ? span_w * Acwn : 0.f);                                       // bin i == b
-        const float Gh_lo = (b >= 1 ? span_h * Achb : 0.f) + (b + 1 < K ? span_h * Achn : 0.f);
-        const float Gh_b = (b + 1 < K ? span_h * Achn : 0.f);
-        // softmax backward: du_i = p_i (G_i - sum_j G_j p_j), G_i = norm * dL/dw_i
-        float dotw = 0.f, doth = 0.f;
-        for (int k = 0; k < K; ++k) {
-            const float pw = uw[k] * inv_sw, ph = uh[k] * inv_sh;
-            dotw += pw * (k < b ? Gw_lo : (k == b ? Gw_b : 0.f));
-            doth += ph * (k < b ? Gh_lo : (k == b ? Gh_b : 0.f));
-        }
-        const float gate = inside ? 1.f : 0.f;
-        const float g_ub = Adb * rqs_sigmoidf(u_b), g_un = Adn * rqs_sigmoidf(u_n);   // d softplus = sigmoid
-        if (valid) {                       // (idle lanes of a ragged last group point at slice 0: they must not write)
-            for (int k = 0; k < K; ++k) {
-                const float pw = uw[k] * inv_sw, ph = uh[k] * inv_sh;
-                uw[k] = gate * norm * pw * ((k < b ? Gw_lo : (k == b ? Gw_b : 0.f)) - dotw);
-                uh[k] = gate * norm * ph * ((k < b ? Gh_lo : (k == b ? Gh_b : 0.f)) - doth);
-            }
-            for (int k = 0; k < K - 1; ++k) ud[k] = gate * ((k == b - 1 ? g_ub : 0.f) + (k == b ? g_un : 0.f));
-            gx[row * dim + col] = inside ? Axin : Ao;                      // tails: out = x
-        }
+        float *uw = sp + (valid ? lane : 0) * P;
+        const float gxe = rqs_inverse_bwd_element(uw, K, xv, Ao, Al, left, right, bottom, top, valid);
+        if (valid) gx[row * dim + col] = gxe;
 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

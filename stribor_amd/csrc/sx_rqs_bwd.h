@@ -1,0 +1,250 @@
+// Reverse mode of the rational-quadratic spline in the INVERSE direction (the direction log_prob evaluates), per element;
+// shared by rqs_inverse_bwd_kernel (parameters staged in LDS, any bin count) and the fused slab backward of
+// sx_rqs_slab.hip (parameters in MFMA accumulator registers, K <= 16).
+// Reverse mode through exactly the operations of the forward kernel (rational_quadratic_spline.py:101-107, 180-234):
+// quadratic root -> (a, b, c) -> (knots of bin b, its two derivatives) -> cumsum -> softmax / softplus.  The bin index is
+// piecewise constant: no gradient.  Elements in the linear tails pass dL/d(out) through and contribute nothing to the
+// parameters.  Ao = dL/d(out), Al = dL/d(log-derivative) of this element.
+#pragma once
+#ifndef RQS_MIN_BIN
+#define RQS_MIN_BIN 1e-3f
+#define RQS_MIN_DERIV 1e-3f
+#define RQS_EPS 1e-6f
+#endif
+__device__ __forceinline__ float rqsb_sigmoid(float v) { return 1.f / (1.f + expf(-v)); }
+__device__ __forceinline__ float rqsb_softplus(float v) { return v > 20.f ? v : log1pf(expf(v)); }  // F.softplus
+// exp(v) on v_exp_f32 with the product v*log2(e) carried to double-float accuracy (~1e-7 relative)
+__device__ __forceinline__ float rqsb_exp(float v) {
+    const float t = v * 1.44269504088896341f;
+    const float r = fmaf(v, 1.44269504088896341f, -t) + v * 1.92596299e-8f;
+    return __builtin_amdgcn_exp2f(t) * (1.f + r * 0.69314718055994531f);
+}
+
+// The scalar part: from the bin's geometry (knots cw_b / ch_b are only used through w_b, h_b) and the two raw derivative
+// parameters to the adjoints of the four knots, the two derivative parameters and the input.
+struct rqs_adj {
+    float Acwb, Acwn, Achb, Achn;      // dL/d(knots of the bin): widths-side left / right, heights-side left / right
+    float g_ub, g_un;                  // dL/d(raw derivative parameter at the bin's left / right knot)
+    float Axin;                        // dL/d(input)
+};
+__device__ __forceinline__ rqs_adj rqs_inverse_bwd_core(float xin, float w_b, float h_b, float ch_b, float u_b, float u_n,
+                                                        float Ao, float Al) {
+    const float s_b = h_b / w_b;
+    const float d_b = RQS_MIN_DERIV + rqsb_softplus(u_b), d_n = RQS_MIN_DERIV + rqsb_softplus(u_n);
+    const float dy = xin - ch_b;
+    const float q = d_b + d_n - 2.f * s_b;
+    const float a = dy * q + h_b * (s_b - d_b);
+    const float bb = h_b * d_b - dy * q;
+    const float c = -s_b * dy;
+    const float disc = bb * bb - 4.f * a * c;
+    const float sq = sqrtf(disc);
+    const float D = -bb - sq;
+    const float r = (2.f * c) / D;
+    const float tomt = r * (1.f - r), omr = 1.f - r;
+    const float den = s_b + q * tomt;
+    const float T = d_n * (r * r) + 2.f * s_b * tomt + d_b * (omr * omr);
+    const float dnum = (s_b * s_b) * T;
+
+    // ---- reverse ----
+    const float Adnum = -Al / dnum, Aden = 2.f * Al / den;
+    float As = Adnum * (2.f * s_b * T + (s_b * s_b) * 2.f * tomt) + Aden;
+    float Adn = Adnum * (s_b * s_b) * (r * r), Adb = Adnum * (s_b * s_b) * (omr * omr);
+    float Atomt = Adnum * (s_b * s_b) * 2.f * s_b + Aden * q;
+    float Ar = Adnum * (s_b * s_b) * (2.f * d_n * r) - Adnum * (s_b * s_b) * (2.f * d_b * omr);
+    float Aq = Aden * tomt;
+    Ar += Atomt * (1.f - 2.f * r) + Ao * w_b;
+    float Awb = Ao * r, Acwb = Ao;
+    float Ac = Ar * 2.f / D;
+    const float AD = -Ar * r / D;
+    float Abb = -AD;
+    const float Adisc = (sq > 0.f) ? (-AD) / (2.f * sq) : 0.f;
+    Abb += Adisc * 2.f * bb;
+    const float Aa = -4.f * c * Adisc;
+    Ac += -4.f * a * Adisc;
+    As += -dy * Ac;
+    float Ady = -s_b * Ac;
+    float Ahb = d_b * Abb;
+    Adb += h_b * Abb;
+    Ady += -q * Abb;
+    Aq += -dy * Abb;
+    Ady += q * Aa;
+    Aq += dy * Aa;
+    Ahb += (s_b - d_b) * Aa;
+    As += h_b * Aa;
+    Adb += -h_b * Aa;
+    Adb += Aq;
+    Adn += Aq;
+    As += -2.f * Aq;
+    float Axin = Ady, Achb = -Ady;
+    Ahb += As / w_b;
+    Awb += -As * s_b / w_b;
+    float Acwn = Awb, Achn = Ahb;
+    Acwb -= Awb;
+    Achb -= Ahb;
+    rqs_adj A;
+    A.Acwb = Acwb; A.Acwn = Acwn; A.Achb = Achb; A.Achn = Achn;
+    A.g_ub = Adb * rqsb_sigmoid(u_b);          // d softplus = sigmoid
+    A.g_un = Adn * rqsb_sigmoid(u_n);
+    A.Axin = Axin;
+    return A;
+}
+
+// Parameters in memory (LDS): the lane's 3K-1 un-normalised parameters sit at `uw` (widths, heights, derivatives back to
+// back); they are overwritten with their gradients and dL/d(input) is returned.
+__device__ __forceinline__ float rqs_inverse_bwd_element(float *uw, int K, float xv, float Ao, float Al, float left, float right,
+                                                         float bottom, float top, bool valid) {
+    const float bconst = logf(expf(1.f - RQS_MIN_DERIV) - 1.f);
+    const float norm = 1.f - RQS_MIN_BIN * (float)K;
+    const float span_w = right - left, span_h = top - bottom;
+    const bool inside = (xv >= bottom) && (xv <= top);
+    const float xin = inside ? xv : bottom;
+    float *uh = uw + K, *ud = uh + K;
+
+    // ---- forward: softmax pieces, knots, bin (heights), as rqs_kernel's generic path -----------------
+    float mw = uw[0], mh = uh[0];
+    for (int k = 1; k < K; ++k) { mw = fmaxf(mw, uw[k]); mh = fmaxf(mh, uh[k]); }
+    float sw = 0.f, sh = 0.f;
+    for (int k = 0; k < K; ++k) {          // exp once per parameter, kept in place (v_exp_f32, compensated argument)
+        const float ew = rqsb_exp(uw[k] - mw), eh = rqsb_exp(uh[k] - mh);
+        uw[k] = ew;
+        uh[k] = eh;
+        sw += ew;
+        sh += eh;
+    }
+    const float inv_sw = 1.f / sw, inv_sh = 1.f / sh;
+    int b = 0;
+    float cw_b = left, ch_b = bottom, cw_n = right, ch_n = top;
+    bool have_next = false;
+    float csw = 0.f, csh = 0.f;
+    for (int j = 1; j <= K; ++j) {
+        const float wk = RQS_MIN_BIN + norm * (uw[j - 1] * inv_sw);
+        const float hk = RQS_MIN_BIN + norm * (uh[j - 1] * inv_sh);
+        csw += wk;
+        csh += hk;
+        const float kw = (j < K) ? span_w * csw + left : right;
+        const float kh = (j < K) ? span_h * csh + bottom : top;
+        const bool ge = xin >= ((j < K) ? kh : kh + RQS_EPS);
+        if (ge && j < K) { b = j; cw_b = kw; ch_b = kh; }
+        else if (!ge && !have_next) { cw_n = kw; ch_n = kh; have_next = true; }
+    }
+    const float w_b = cw_n - cw_b, h_b = ch_n - ch_b;
+    const float u_b = (b == 0) ? bconst : ud[b - 1], u_n = (b + 1 == K) ? bconst : ud[b];
+    const rqs_adj A = rqs_inverse_bwd_core(xin, w_b, h_b, ch_b, u_b, u_n, Ao, Al);
+    // knots -> cumsums -> widths / heights:  dL/dw_i = span * ([i < b] A(kw_b) + [i < b+1 < K] A(kw_{b+1}))
+    const float Gw_lo = (b >= 1 ? span_w * A.Acwb : 0.f) + (b + 1 < K ? span_w * A.Acwn : 0.f);   // bins i < b
+    const float Gw_b = (b + 1 < K ? span_w * A.Acwn : 0.f);                                       // bin i == b
+    const float Gh_lo = (b >= 1 ? span_h * A.Achb : 0.f) + (b + 1 < K ? span_h * A.Achn : 0.f);
+    const float Gh_b = (b + 1 < K ? span_h * A.Achn : 0.f);
+    // softmax backward: du_i = p_i (G_i - sum_j G_j p_j), G_i = norm * dL/dw_i
+    float dotw = 0.f, doth = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float pw = uw[k] * inv_sw, ph = uh[k] * inv_sh;
+        dotw += pw * (k < b ? Gw_lo : (k == b ? Gw_b : 0.f));
+        doth += ph * (k < b ? Gh_lo : (k == b ? Gh_b : 0.f));
+    }
+    const float gate = inside ? 1.f : 0.f;
+    if (valid) {                       // (idle lanes of a ragged last group point at slice 0: they must not write)
+        for (int k = 0; k < K; ++k) {
+            const float pw = uw[k] * inv_sw, ph = uh[k] * inv_sh;
+            uw[k] = gate * norm * pw * ((k < b ? Gw_lo : (k == b ? Gw_b : 0.f)) - dotw);
+            uh[k] = gate * norm * ph * ((k < b ? Gh_lo : (k == b ? Gh_b : 0.f)) - doth);
+        }
+        for (int k = 0; k < K - 1; ++k) ud[k] = gate * ((k == b - 1 ? A.g_ub : 0.f) + (k == b ? A.g_un : 0.f));
+    }
+    return inside ? A.Axin : Ao;                                         // tails: out = x
+
+}
+
+// Parameters in registers (one MFMA accumulator tile per block): Wp / Hp / Dp hold the element's K widths, K heights and
+// K-1 derivative parameters in entries 0..K-1 (K <= 16; the other entries are ignored) and return their gradients (zeros
+// in the unused entries and for an element that is not `valid`).  Every index is static -- the bin is applied through
+// selects -- so the arrays never leave the register file; KC = 16 is the straight-line form, KC = 0 keeps K at run time.
+// Same operations in the same order as rqs_inverse_bwd_element.
+typedef float rqsb_f16v __attribute__((ext_vector_type(16)));
+template <int KC>
+__device__ __forceinline__ float rqs_inverse_bwd_regs(rqsb_f16v &Wp, rqsb_f16v &Hp, rqsb_f16v &Dp, int K, float xv, float Ao,
+                                                      float Al, float left, float right, float bottom, float top, bool valid) {
+    const int Kn = KC ? KC : K;
+    const float bconst = logf(expf(1.f - RQS_MIN_DERIV) - 1.f);
+    const float norm = 1.f - RQS_MIN_BIN * (float)Kn;
+    const float span_w = right - left, span_h = top - bottom;
+    const bool inside = (xv >= bottom) && (xv <= top);
+    const float xin = inside ? xv : bottom;
+    float mw = Wp[0], mh = Hp[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k)
+        if (KC ? (k < KC) : true) {
+            const bool used = KC ? true : (k < K);
+            mw = used ? fmaxf(mw, Wp[k]) : mw;
+            mh = used ? fmaxf(mh, Hp[k]) : mh;
+        }
+    float sw = 0.f, sh = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (KC ? (k < KC) : true) {
+            const bool used = KC ? true : (k < K);
+            const float ew = used ? rqsb_exp(Wp[k] - mw) : 0.f, eh = used ? rqsb_exp(Hp[k] - mh) : 0.f;
+            Wp[k] = ew;
+            Hp[k] = eh;
+            sw += ew;
+            sh += eh;
+        }
+    const float inv_sw = 1.f / sw, inv_sh = 1.f / sh;
+    int b = 0;
+    float cw_b = left, ch_b = bottom, cw_n = right, ch_n = top;
+    bool have_next = false;
+    float csw = 0.f, csh = 0.f;
+#pragma unroll
+    for (int j = 1; j <= 16; ++j)
+        if (KC ? (j <= KC) : true) {
+            const bool used = KC ? true : (j <= K);
+            const bool last = (j == Kn);
+            const float wk = RQS_MIN_BIN + norm * (Wp[j - 1] * inv_sw);
+            const float hk = RQS_MIN_BIN + norm * (Hp[j - 1] * inv_sh);
+            csw += wk;
+            csh += hk;
+            const float kw = last ? right : span_w * csw + left;
+            const float kh = last ? top : span_h * csh + bottom;
+            const bool ge = xin >= (last ? kh + RQS_EPS : kh);
+            const bool take = used && ge && !last;
+            const bool nxt = used && !ge && !have_next;
+            b = take ? j : b;
+            cw_b = take ? kw : cw_b;
+            ch_b = take ? kh : ch_b;
+            cw_n = nxt ? kw : cw_n;
+            ch_n = nxt ? kh : ch_n;
+            have_next = have_next || nxt;
+        }
+    const float w_b = cw_n - cw_b, h_b = ch_n - ch_b;
+    float u_b = bconst, u_n = bconst;
+#pragma unroll
+    for (int k = 0; k < 15; ++k)
+        if (KC ? (k < KC - 1) : true) {
+            const bool used = KC ? true : (k < Kn - 1);
+            u_n = (used && b == k) ? Dp[k] : u_n;
+            u_b = (used && b == k + 1) ? Dp[k] : u_b;
+        }
+    const rqs_adj A = rqs_inverse_bwd_core(xin, w_b, h_b, ch_b, u_b, u_n, Ao, Al);
+    const float Gw_lo = (b >= 1 ? span_w * A.Acwb : 0.f) + (b + 1 < Kn ? span_w * A.Acwn : 0.f);   // bins i < b
+    const float Gw_b = (b + 1 < Kn ? span_w * A.Acwn : 0.f);                                        // bin i == b
+    const float Gh_lo = (b >= 1 ? span_h * A.Achb : 0.f) + (b + 1 < Kn ? span_h * A.Achn : 0.f);
+    const float Gh_b = (b + 1 < Kn ? span_h * A.Achn : 0.f);
+    float dotw = 0.f, doth = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (KC ? (k < KC) : true) {
+            const float pw = Wp[k] * inv_sw, ph = Hp[k] * inv_sh;          // unused entries hold 0
+            dotw += pw * (k < b ? Gw_lo : (k == b ? Gw_b : 0.f));
+            doth += ph * (k < b ? Gh_lo : (k == b ? Gh_b : 0.f));
+        }
+    const bool on = valid && inside;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const bool used = KC ? (k < KC) : (k < K);
+        const float pw = Wp[k] * inv_sw, ph = Hp[k] * inv_sh;
+        Wp[k] = (on && used) ? norm * pw * ((k < b ? Gw_lo : (k == b ? Gw_b : 0.f)) - dotw) : 0.f;
+        Hp[k] = (on && used) ? norm * ph * ((k < b ? Gh_lo : (k == b ? Gh_b : 0.f)) - doth) : 0.f;
+        Dp[k] = (on && k < Kn - 1) ? ((k == b - 1 ? A.g_ub : 0.f) + (k == b ? A.g_un : 0.f)) : 0.f;
+    }
+    return inside ? A.Axin : Ao;                                         // tails: out = x
+}

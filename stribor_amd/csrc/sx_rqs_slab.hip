@@ -1,0 +1,318 @@
+// Training backward of one rational-quadratic SPLINE COUPLING (inverse direction, the one log_prob evaluates) with the
+// [N, n_live * (3K-1)] parameter tensor of the reference (stribor/flows/spline.py:76-87, coupling.py:69-95) never in HBM.
+//
+// The layer-wise path used to materialise the conditioner's output (1,504 floats per row on cfg 3: 1.6 GB per layer and
+// 2^18 rows) and move it five times: written by the last Linear, read by the spline forward, read + written (as gradients)
+// by the spline backward, read by each of the two library GEMMs of the Linear's backward (dW2 = dp^T h, dh = dp W2).
+// Here ONE kernel does all of that per layer, tiled the other way round:
+//
+//   * a workgroup owns a SLAB of the last Linear: the 3K-1 parameter rows of TWO transformed columns (94 rows at K = 16,
+//     padded to three 32-row MFMA tiles: widths | heights | derivatives) and walks a range of the rows.  The slab's
+//     weights sit in LDS in both orientations (W2 slab as the A operand of  p = W2 h + b2,  its transpose as the A operand
+//     of  dh = W2^T dp) for the whole launch: 48 KB at hidden = 64;
+//   * a wave takes 32 rows at a time: h (the last hidden activation, 256 B per row, the only per-row input besides x and
+//     the two adjoints) -> fp16 x 3 split -> the slab's parameters by MFMA.  Tile row R carries parameter (R&3) + 4(R>>3)
+//     of column (R>>2)&1, so in C-fragment order lane (sample, half) receives, in 3 x 16 registers, exactly the 3K-1
+//     parameters of ITS element (sample, column 2 slab + half): the spline's reverse mode (sx_rqs_bwd.h) runs on registers
+//     with static indices and leaves the parameter gradients in the same registers;
+//   * those three tiles are, unchanged, the B operand of dh_partial = W2_slab^T dp (C tile -> next MFMA's operand), and --
+//     turned by the matrix pipe against a 0/1 selection operand, as in the layer-major affine backward
+//     (sx_flow_kernel.h, `turn_tile` / `contract`) -- the A operand of dW2_slab += dp^T h, accumulated in 6 accumulator
+//     tiles (96 registers) over all the rows the wave visits.  One partial per workgroup leaves at the end.
+//   * dh is a sum over the slabs: each slab writes its partial in fragment order (1 KB per store instruction) and a small
+//     second kernel adds the n_slabs partials into the row-major dL/dh the conditioner's own backward consumes.
+//
+// HBM per row and layer: x, dL/dout (2 columns x 4 B each per slab), h 256 B (L2-resident across the slabs), and
+// 2 x n_slabs x 256 B of dh partials -- 8 KB at 16 slabs against 30 KB for the five crossings of the parameter tensor.
+#define SX_F16X3
+#include "sx_flow_kernel.h"
+#include "sx_rqs_bwd.h"
+
+namespace {
+using namespace sx_f16x3;
+
+struct slab_args {
+    const float *x, *gout, *gldj, *h;   // x, gout [N, dim]; gldj [N]; h [N, ld_h] (H valid features)
+    const float *wf;                    // sx_pack_linear(W2 rows by slot): [3 n_slabs][HT][1024] + bias [3 n_slabs][32]
+    const float *wb;                    // sx_pack_linear(transpose): [HT][3 n_slabs][1024]
+    float *gx;                          // [N, dim]: the transformed columns are written
+    float *dh_part;                     // [n_slabs][n_chunks][HT][1024], fragment order
+    float *w_part;                      // [n_slabs][n_ranges][96 * 32 HT + 96]
+    const int32_t *live_idx;
+    uint32_t *flags;
+    int64_t n_rows, ld_h;
+    int l0, n_live, K, dim, H, n_slabs, n_chunks;
+    float left, right, bottom, top, ldj_scale;
+};
+
+template <int HT, int KC>
+__global__ __launch_bounds__(256, 2) void rqs_slab_bwd_kernel(const slab_args k) {
+    constexpr int FW = 0, BW = 3 * HT * 1024, BI = 6 * HT * 1024;        // LDS float offsets: W2 slab | its transpose | bias
+    constexpr int N2 = 32 * HT, E = 96 * N2 + 96;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slab = blockIdx.x, range = blockIdx.y, n_ranges = gridDim.y;
+    {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(k.wf + (size_t)slab * 3 * HT * 1024);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(smem + FW);
+        for (int i = threadIdx.x; i < 3 * HT * 256; i += 256) dst[i] = src[i];
+#pragma unroll
+        for (int m = 0; m < HT; ++m) {
+            const f32x4 *s2 = reinterpret_cast<const f32x4 *>(k.wb + ((size_t)m * 3 * k.n_slabs + 3 * slab) * 1024);
+            f32x4 *d2 = reinterpret_cast<f32x4 *>(smem + BW + m * 3 * 1024);
+            for (int i = threadIdx.x; i < 3 * 256; i += 256) d2[i] = s2[i];
+        }
+        if (threadIdx.x < 96) smem[BI + threadIdx.x] = k.wf[(size_t)k.n_slabs * 3 * HT * 1024 + slab * 96 + threadIdx.x];
+    }
+    __syncthreads();
+    const wptr w = make_wptr(0, lane);
+    const sel_t sel = make_sel(lane);
+    const int j = lane & 31, hh = lane >> 5;
+    f32x16 A[3][HT];
+    float bsum[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int m = 0; m < HT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) A[t][m][r] = 0.f;
+    const int ci = 2 * slab + hh;                                       // this lane's transformed column (index into live)
+    const bool col_ok = ci < k.n_live;
+    const int col = col_ok ? (k.live_idx ? k.live_idx[ci] : k.l0 + ci) : 0;
+    const bool vec_h = (k.ld_h % 4 == 0) && ((reinterpret_cast<uintptr_t>(k.h) & 15) == 0);
+    uint64_t any_bad = 0;
+    const int c_begin = (int)((int64_t)k.n_chunks * range / n_ranges), c_end = (int)((int64_t)k.n_chunks * (range + 1) / n_ranges);
+    for (int c = c_begin + wave; c < c_end; c += 4) {
+        rng_t rg{0};
+        const int64_t row = (int64_t)c * 32 + j;
+        const bool row_ok = row < k.n_rows;
+        const bool valid = row_ok && col_ok;
+        // ---- h -> fp16 x 3 fragments; the slab's parameters ----------------------------------------------------------
+        btile<1> bh[HT];
+#pragma unroll
+        for (int m = 0; m < HT; ++m) {
+            tile<1> hid;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f0 = 32 * m + 8 * g + 4 * hh;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (row_ok) {
+                    const float *p = k.h + row * k.ld_h + f0;
+                    if (vec_h && f0 + 3 < k.H) v = *reinterpret_cast<const f32x4 *>(p);
+                    else {
+                        if (f0 + 0 < k.H) v.x = p[0];
+                        if (f0 + 1 < k.H) v.y = p[1];
+                        if (f0 + 2 < k.H) v.z = p[2];
+                        if (f0 + 3 < k.H) v.w = p[3];
+                    }
+                }
+                hid.v[0][4 * g + 0] = v.x; hid.v[0][4 * g + 1] = v.y; hid.v[0][4 * g + 2] = v.z; hid.v[0][4 * g + 3] = v.w;
+            }
+            bh[m] = make_btile<1>(hid, rg);
+        }
+        const float xv = valid ? k.x[row * k.dim + col] : k.bottom;
+        const float Ao = valid ? k.gout[row * k.dim + col] : 0.f;
+        const float Al = valid ? k.gldj[row] * k.ldj_scale : 0.f;
+        tile<1> acc[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            acc[t] = load_cfrag<1>(w.cb, BI + t * 32);
+#pragma unroll
+            for (int m = 0; m < HT; ++m) gemm_tile<1>(w.wb, FW + (t * HT + m) * 1024, bh[m], acc[t]);
+        }
+        // ---- the spline's reverse mode on the lane's own element: parameters -> their gradients, in place ---------------
+        const float gxe = rqs_inverse_bwd_regs<KC>(acc[0].v[0], acc[1].v[0], acc[2].v[0], k.K, xv, Ao, Al, k.left, k.right,
+                                                   k.bottom, k.top, valid);
+        btile<1> bd[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) bd[t] = make_btile<1>(acc[t], rg);
+        if (valid) k.gx[row * k.dim + col] = rng_bad_sample(rg, lane) ? __builtin_nanf("") : gxe;
+        any_bad |= rg.bad;
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- dh partial = W2_slab^T dp ---------------------------------------------------------------------------
+        {
+            float *dst = k.dh_part + ((size_t)slab * k.n_chunks + c) * (HT * 1024);
+#pragma unroll
+            for (int m = 0; m < HT; ++m) {
+                tile<1> dh;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dh.v[0][r] = 0.f;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) gemm_tile<1>(w.wb, BW + (m * 3 + t) * 1024, bd[t], dh);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = {dh.v[0][4 * g], dh.v[0][4 * g + 1], dh.v[0][4 * g + 2], dh.v[0][4 * g + 3]};
+                    reinterpret_cast<f32x4 *>(dst + m * 1024)[g * 64 + lane] = v;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- dW2_slab += dp^T h (contraction over this wave's 32 rows on the matrix pipe) --------------------------------
+        {
+            tfrag th[HT];
+            float dummy = 0.f;
+#pragma unroll
+            for (int m = 0; m < HT; ++m) th[m] = turn_tile(bh[m], sel, dummy);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const tfrag td = turn_tile(bd[t], sel, bsum[t]);
+#pragma unroll
+                for (int m = 0; m < HT; ++m) contract(td, th[m], A[t][m]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    if (any_bad != 0 && lane == 0 && k.flags != nullptr)
+        __hip_atomic_fetch_or(k.flags, SX_FLAG_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // ---- one partial per workgroup: the waves add their tiles in LDS by turns (row-major [96][32 HT] | [96]) --------------
+    __syncthreads();
+    float *red = smem;
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+#pragma unroll
+                for (int m = 0; m < HT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int e = (32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh) * N2 + 32 * m + j;
+                        red[e] = (wv == 0 ? 0.f : red[e]) + A[t][m][r];
+                    }
+                const float tb = bsum[t] + __shfl_xor(bsum[t], 32, 64);
+                if (hh == 0) { const int e = 96 * N2 + 32 * t + j; red[e] = (wv == 0 ? 0.f : red[e]) + tb; }
+            }
+        }
+        __syncthreads();
+    }
+    float *dst = k.w_part + ((size_t)slab * n_ranges + range) * E;
+    for (int e = threadIdx.x; e < E; e += 256) dst[e] = red[e];
+}
+
+// dW2 / db2 rows of the slabs: sum of the per-range partials, scattered to the parameter's rows (slot_rows < 0: padding)
+__global__ __launch_bounds__(256) void rqs_slab_w_reduce_kernel(const float *__restrict__ part, int n_ranges, int N2, int H,
+                                                                const int32_t *__restrict__ slot_rows, float *__restrict__ dW,
+                                                                int64_t ldw, float *__restrict__ db) {
+    const int E = 96 * N2 + 96;
+    const int e = blockIdx.x * 256 + threadIdx.x, slab = blockIdx.y;
+    if (e >= E) return;
+    const float *src = part + (size_t)slab * n_ranges * E + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int p = 0;
+    for (; p + 3 < n_ranges; p += 4) {
+        s0 += src[(size_t)p * E];
+        s1 += src[(size_t)(p + 1) * E];
+        s2 += src[(size_t)(p + 2) * E];
+        s3 += src[(size_t)(p + 3) * E];
+    }
+    for (; p < n_ranges; ++p) s0 += src[(size_t)p * E];
+    const float t = (s0 + s1) + (s2 + s3);
+    if (e < 96 * N2) {
+        const int row = slot_rows[slab * 96 + e / N2], colh = e % N2;
+        if (row >= 0 && colh < H) dW[(int64_t)row * ldw + colh] = t;
+    } else {
+        const int row = slot_rows[slab * 96 + (e - 96 * N2)];
+        if (row >= 0) db[row] = t;
+    }
+}
+
+// dL/dh [N, H] row-major = sum over the slabs of the fragment-order partials
+template <int HT>
+__global__ __launch_bounds__(256) void rqs_slab_dh_reduce_kernel(const float *__restrict__ part, int n_slabs, int n_chunks,
+                                                                 int64_t n_rows, int H, float *__restrict__ gh, int64_t ld) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;         // one 16 B piece: (chunk, m, g, lane)
+    const int64_t total = (int64_t)n_chunks * HT * 256;
+    if (idx >= total) return;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(part) + idx;
+    f32x4 s = src[0];
+    for (int p = 1; p < n_slabs; ++p) {
+        const f32x4 v = src[(size_t)p * total];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const int lane = (int)(idx & 63), g = (int)((idx >> 6) & 3), m = (int)((idx >> 8) % HT);
+    const int64_t c = idx / (HT * 256);
+    const int64_t row = c * 32 + (lane & 31);
+    const int f0 = 32 * m + 8 * g + 4 * (lane >> 5);
+    if (row >= n_rows) return;
+    float *dst = gh + row * ld + f0;
+    if (f0 + 0 < H) dst[0] = s.x;
+    if (f0 + 1 < H) dst[1] = s.y;
+    if (f0 + 2 < H) dst[2] = s.z;
+    if (f0 + 3 < H) dst[3] = s.w;
+}
+
+int slab_ranges(int n_slabs, int n_chunks) {
+    int r = (512 + n_slabs - 1) / n_slabs;           // ~2 workgroups per CU
+    const int cap = (n_chunks + 3) / 4;              // at least one 32-row chunk per wave where the rows allow
+    if (r > cap) r = cap;
+    return r < 1 ? 1 : r;
+}
+}  // namespace
+
+extern "C" int32_t sx_rqs_slab_slots(int32_t n_live) { return ((n_live + 1) / 2) * 96; }
+
+extern "C" size_t sx_rqs_slab_scratch_floats(int64_t n_rows, int32_t n_live, int32_t hidden) {
+    if (n_rows < 0 || n_live < 1 || hidden < 1 || hidden > 64) return 0;
+    const int n_slabs = (n_live + 1) / 2, HT = (hidden + 31) / 32;
+    const int64_t n_chunks = (n_rows + 31) / 32;
+    const int n_ranges = slab_ranges(n_slabs, (int)n_chunks);
+    return (size_t)n_slabs * (size_t)n_chunks * HT * 1024 + (size_t)n_slabs * n_ranges * (96 * 32 * HT + 96);
+}
+
+extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *gldj, const float *h, int64_t ld_h,
+                               int32_t hidden, const float *w_fwd, const float *w_bwd, const int32_t *slot_rows, float *gx,
+                               float *gh, int64_t ld_gh, float *dW, int64_t ldw, float *db, const int32_t *live_idx,
+                               int32_t live_start, int32_t n_live, int32_t n_bins, float left, float right, float bottom,
+                               float top, int64_t n_rows, int32_t dim, float ldj_scale, float *scratch, uint32_t *err_flag,
+                               void *stream) {
+    SX_REQUIRE(x && gout && gldj && h && w_fwd && w_bwd && slot_rows && gx && gh && dW && db && scratch,
+               "sx_rqs_slab_bwd: null pointer");
+    SX_REQUIRE(dim > 0 && n_live > 0 && n_live <= dim && n_rows >= 0, "sx_rqs_slab_bwd: bad sizes");
+    SX_REQUIRE(n_bins >= 1 && n_bins <= 16, "sx_rqs_slab_bwd: n_bins must be in 1..16 (got %d)", n_bins);
+    SX_REQUIRE(hidden >= 1 && hidden <= 64, "sx_rqs_slab_bwd: hidden width must be in 1..64 (got %d)", hidden);
+    SX_REQUIRE(n_rows < ((int64_t)1 << 36), "sx_rqs_slab_bwd: too many rows");
+    SX_REQUIRE(right > left && top > bottom, "sx_rqs_slab_bwd: empty domain");
+    SX_REQUIRE(((uintptr_t)w_fwd & 15) == 0 && ((uintptr_t)w_bwd & 15) == 0 && ((uintptr_t)scratch & 15) == 0,
+               "sx_rqs_slab_bwd: packed weights and scratch must be 16-byte aligned");
+    if (n_rows == 0) return SX_OK;
+    hipStream_t st = sx_stream(stream);
+    const int n_slabs = (n_live + 1) / 2, HT = (hidden + 31) / 32;
+    const int n_chunks = (int)((n_rows + 31) / 32);
+    const int n_ranges = slab_ranges(n_slabs, n_chunks);
+    slab_args k;
+    k.x = x; k.gout = gout; k.gldj = gldj; k.h = h; k.wf = w_fwd; k.wb = w_bwd; k.gx = gx;
+    k.dh_part = scratch;
+    k.w_part = scratch + (size_t)n_slabs * n_chunks * HT * 1024;
+    k.live_idx = live_idx; k.flags = err_flag; k.n_rows = n_rows; k.ld_h = ld_h; k.l0 = live_start; k.n_live = n_live;
+    k.K = n_bins; k.dim = dim; k.H = hidden; k.n_slabs = n_slabs; k.n_chunks = n_chunks;
+    k.left = left; k.right = right; k.bottom = bottom; k.top = top; k.ldj_scale = ldj_scale;
+    const size_t lds = (size_t)(6 * HT * 1024 + 128) * sizeof(float);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+#define SX_SLAB(HT_, KC_)                                                                                          \
+    do {                                                                                                           \
+        auto kern = rqs_slab_bwd_kernel<HT_, KC_>;                                                                 \
+        static int lds_allowed[64];                                                                                \
+        if (lds > 48 * 1024 && !lds_allowed[dev & 63]) {                                                           \
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) { sx_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
+            lds_allowed[dev & 63] = 1;                                                                             \
+        }                                                                                                          \
+        hipLaunchKernelGGL(kern, dim3(n_slabs, n_ranges), dim3(256), lds, st, k);                                  \
+    } while (0)
+    if (HT == 1) { if (n_bins == 16) SX_SLAB(1, 16); else SX_SLAB(1, 0); }
+    else { if (n_bins == 16) SX_SLAB(2, 16); else SX_SLAB(2, 0); }
+#undef SX_SLAB
+    SX_LAUNCH_CHECK();
+    const int N2 = 32 * HT, E = 96 * N2 + 96;
+    hipLaunchKernelGGL(rqs_slab_w_reduce_kernel, dim3((E + 255) / 256, n_slabs), dim3(256), 0, st, k.w_part, n_ranges, N2,
+                       (int)hidden, slot_rows, dW, ldw, db);
+    SX_LAUNCH_CHECK();
+    const int64_t pieces = (int64_t)n_chunks * HT * 256;
+    if (HT == 1)
+        hipLaunchKernelGGL(rqs_slab_dh_reduce_kernel<1>, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, k.dh_part,
+                           n_slabs, n_chunks, n_rows, (int)hidden, gh, ld_gh);
+    else
+        hipLaunchKernelGGL(rqs_slab_dh_reduce_kernel<2>, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, k.dh_part,
+                           n_slabs, n_chunks, n_rows, (int)hidden, gh, ld_gh);
+    SX_LAUNCH_CHECK();
+    return SX_OK;
+}

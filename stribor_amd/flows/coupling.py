@@ -18,6 +18,7 @@ Three execution tiers, fastest first (the first that applies is used; all give t
 * ``Coupling(Spline(quadratic, latent_net=MLP))`` runs the conditioner with the MFMA kernel (pruned to the
   transformed columns) and the spline in ``sx_rqs_coupling`` (parameters staged through LDS per wavefront).
 """
+import os
 from typing import Optional
 
 import numpy as np
@@ -327,6 +328,8 @@ class Coupling(Transform):
             z = z * 0                                                                # coupling.py:62-63
         if lat2 is not None:
             z = torch.cat([z, lat2], -1)                                             # coupling.py:64-65
+        if is_spline and reverse and self._slab_backward_ok(net, sp):
+            return self._autograd_inverse_slab(x2, lat2, z, rows_t, live, live_idx)
         if isinstance(net, MLP):
             params = net.forward_autograd(z, rows_t)
         else:                                                                        # any nn.Module: torch's own graph
@@ -338,6 +341,48 @@ class Coupling(Transform):
             return op.apply(x2, params, live_idx, int(live[0]), len(live), sp.n_bins, sp.lower, sp.upper, 1.0)
         # Transform.inverse_and_log_det_jacobian: minus the forward log-det (flow.py:47)
         return AffineCouplingOp.apply(x2, params, live_idx, int(live[0]), len(live), bool(reverse), -1.0 if reverse else 1.0)
+
+    # ---- spline couplings: backward fused with the conditioner's last layer (sx_rqs_slab_bwd) ----------------------------
+    def _slab_backward_ok(self, net, sp) -> bool:
+        from .spline import RQSCouplingSlab
+        if os.environ.get('STRIBOR_SPLINE_UNFUSED') == '1':                         # A/B switch: the per-row parameter path
+            return False
+        if not isinstance(net, MLP) or net._wrapped or net.final_activation_name is not None:
+            return False
+        if sp.spline_type != 'quadratic':
+            return False
+        lin = net.linears()
+        return len(lin) >= 2 and lin[-1][1] is not None and RQSCouplingSlab.eligible(lin[-1][0].shape[1], sp.n_bins)
+
+    def _inverse_rows_nograd(self, x2, lat2):
+        """inverse_and_log_det_jacobian of [N, D] fp32 rows without a graph: the one-layer fused program when the conditioner
+        fits it (parameters never in HBM), else the MLP program + spline kernel."""
+        d, ld = x2.shape[1], 0 if lat2 is None else lat2.shape[1]
+        try:
+            # planner convention: the coefficient of the FORWARD log-det (flow.py:47: the inverse returns minus it)
+            prog = self._affine_program(True, -1.0, d, ld, x2.device)
+        except NotImplementedError:
+            prog = None
+        if prog is not None:
+            y, ldj, _ = prog.run(x2, lat2, True, True, False)
+            return y, ldj
+        return self._run_spline(x2, lat2, True, True, 1.0)
+
+    def _autograd_inverse_slab(self, x2, lat2, z, rows_t, live, live_idx):
+        from .spline import RQSCouplingSlab, slab_slot_rows
+        from ..net.mlp import SelectRows
+        sp, net = self.transform, self.transform.latent_net
+        h, last, _ = net.hidden_autograd(z)
+        H = h.shape[1]
+
+        def build():
+            hid = np.full(((H + 31) // 32) * 32, -1, dtype=np.int32)
+            hid[:H] = np.arange(H)
+            return (torch.from_numpy(slab_slot_rows(len(live), sp.n_bins)).to(x2.device), torch.from_numpy(hid).to(x2.device))
+        plan = self._programs.get(('slab', x2.shape[1], H, str(x2.device)), build)
+        W2, b2 = SelectRows.apply(last.weight, rows_t), SelectRows.apply(last.bias, rows_t)
+        return RQSCouplingSlab.apply(x2, h, W2, b2, lambda xx: self._inverse_rows_nograd(xx, lat2), plan, live_idx,
+                                     int(live[0]), len(live), sp.n_bins, sp.lower, sp.upper)
 
     # ---- reference method set (coupling.py:69-95) -----------------------------------------------------------
     def forward(self, x, latent=None, reverse: bool = False, **kwargs):

@@ -18,7 +18,7 @@ import torch.nn as nn
 from .. import _hip
 from ..flow import ElementwiseTransform, flatten_rows
 
-__all__ = ['Spline', 'run_rqs_kernel', 'run_cubic_kernel', 'RQSInverse', 'CubicInverse']
+__all__ = ['Spline', 'run_rqs_kernel', 'run_cubic_kernel', 'RQSInverse', 'CubicInverse', 'RQSCouplingSlab', 'slab_slot_rows']
 
 def check_errors(device=None) -> None:
     """Raise what the reference would have raised for data-dependent failures (synchronises): the spline's
@@ -72,6 +72,79 @@ class RQSInverse(torch.autograd.Function):
                                            params.stride(0), gx.data_ptr(), gparams.data_ptr(), _hip.ptr(live_idx),
                                            live_start, n_live, n_bins, lower, upper, lower, upper, n, d, ldj_scale)
         return gx, gparams, None, None, None, None, None, None, None
+
+
+def slab_slot_rows(n_live: int, n_bins: int):
+    """sx_rqs_slab_bwd's slot -> parameter-row map (include/stribor_hip.h): slab s holds transformed columns 2s, 2s+1 in
+    three 32-slot tiles (widths | heights | derivatives); slot 32 t + R carries parameter (R&3) + 4 (R>>3) of column
+    2 s + ((R>>2)&1).  Rows index the [n_live * (3K-1)] selected rows of the conditioner's last layer (spline.py:82-86:
+    per column K widths, K heights, K-1 derivatives)."""
+    import numpy as np
+    K, P = n_bins, 3 * n_bins - 1
+    n_slabs = (n_live + 1) // 2
+    rows = np.full(n_slabs * 96, -1, dtype=np.int32)
+    for s in range(n_slabs):
+        for t in range(3):
+            for R in range(32):
+                k, ci = (R & 3) + 4 * (R >> 3), 2 * s + ((R >> 2) & 1)
+                if ci < n_live and k < (K - 1 if t == 2 else K):
+                    rows[s * 96 + 32 * t + R] = ci * P + t * K + k
+    return rows
+
+
+class RQSCouplingSlab(torch.autograd.Function):
+    """(x_out, row log-det) of an inverse quadratic-spline COUPLING as a differentiable op of (x, h, W2, b2): h [N, H] is the
+    conditioner's last hidden activation (torch graph upstream), (W2, b2) the rows of its last Linear that parameterise the
+    transformed columns.  The forward is the coupling's own no-graph evaluation (`evaluate(x2)` -> (y, ldj)); the backward is
+    sx_rqs_slab_bwd: spline reverse mode + dW2 / db2 / dL/dh in one kernel that keeps each slab of W2 in LDS, so the
+    [N, n_live * (3K-1)] parameter tensor (spline.py:82-86) and its gradient never reach HBM.  Needs H <= 64, K <= 16 and the
+    fp16 x 3 GEMM arithmetic."""
+
+    @staticmethod
+    def eligible(hidden: int, n_bins: int) -> bool:
+        return hidden <= 64 and n_bins <= 16 and _hip.get_gemm_precision() != 'exact'
+
+    @staticmethod
+    def forward(ctx, x2, h, W2, b2, evaluate, plan, live_idx, live_start, n_live, n_bins, lower, upper):
+        x2 = x2.contiguous()
+        with torch.no_grad():
+            y, ldj = evaluate(x2)
+        ctx.save_for_backward(x2, h, W2, b2)
+        ctx.meta = (plan, live_idx, live_start, n_live, n_bins, float(lower), float(upper))
+        return y, ldj
+
+    @staticmethod
+    def backward(ctx, gy, gldj):
+        x2, h, W2, b2 = ctx.saved_tensors
+        (slot_rows, hid_idx), live_idx, live_start, n_live, n_bins, lower, upper = ctx.meta
+        n, d = x2.shape
+        dev = x2.device
+        H = h.shape[1]
+        gy = (torch.zeros_like(x2) if gy is None else gy).to(torch.float32).contiguous()
+        gldj = (torch.zeros(n, device=dev) if gldj is None else gldj).to(torch.float32).contiguous()
+        h = h if h.stride(1) == 1 else h.contiguous()
+        W2, b2 = W2.detach().contiguous(), b2.detach().contiguous()
+        lib = _hip.lib()
+        slots, ht = lib.sx_rqs_slab_slots(n_live), (H + 31) // 32
+        mt = slots // 32
+        n_fwd, n_bwd = _hip.packed_linear_floats(mt, ht), ht * mt * 1024
+        packs = torch.empty(n_fwd + n_bwd + 32, dtype=torch.float32, device=dev)
+        flag = _hip.err_flag(dev)
+        _hip.call('sx_pack_linear', x2, W2.data_ptr(), b2.data_ptr(), W2.shape[0], H, slot_rows.data_ptr(), hid_idx.data_ptr(),
+                  mt, ht, None, None, 0.0, 0, _hip.GEMM_F16X3, flag, packs.data_ptr())
+        _hip.call('sx_pack_linear', x2, W2.data_ptr(), None, W2.shape[0], H, hid_idx.data_ptr(), slot_rows.data_ptr(),
+                  ht, mt, None, None, 0.0, 1, _hip.GEMM_F16X3, flag, packs.data_ptr() + 4 * n_fwd)
+        gx = gy.clone()                     # pass-through columns: y = x; the kernel overwrites the transformed columns
+        gh = torch.empty(n, H, dtype=torch.float32, device=dev)
+        gW = torch.zeros_like(W2)
+        gb = torch.zeros_like(b2)
+        with _hip.device_of(x2):
+            sc = _hip.scratch(dev, lib.sx_rqs_slab_scratch_floats(n, n_live, H))
+        _hip.call('sx_rqs_slab_bwd', x2, x2.data_ptr(), gy.data_ptr(), gldj.data_ptr(), h.data_ptr(), h.stride(0), H,
+                  packs.data_ptr(), packs.data_ptr() + 4 * n_fwd, slot_rows.data_ptr(), gx.data_ptr(), gh.data_ptr(),
+                  gh.stride(0), gW.data_ptr(), gW.stride(0), gb.data_ptr(), _hip.ptr(live_idx), live_start, n_live, n_bins,
+                  lower, upper, lower, upper, n, d, 1.0, sc.data_ptr(), flag)
+        return gx, gh, gW, gb, None, None, None, None, None, None, None, None
 
 
 def run_cubic_kernel(x2, params, params_stride, live_idx, live_start, n_live, n_bins, lower, upper, reverse, want_ldj,

@@ -153,9 +153,9 @@ class MLP(StructureTracked, nn.Module):
         return max([w.shape[0] for (w, _) in ls[:-1]] + [1])
 
     # -- differentiable evaluation (layer-wise training path) -------------------------------------------
-    def forward_autograd(self, x2: torch.Tensor, rows: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """The network on [N, in] rows with a graph: torch activations, `batch_linear` layers.  `rows` selects the
-        output rows of the last layer (a coupling only needs the parameters of its transformed columns)."""
+    def hidden_autograd(self, x2: torch.Tensor):
+        """Everything before the last Linear, with a graph -> (last hidden activation [N, H], the last Linear, the layers
+        after it (a final activation or none))."""
         layers = list(self.net)
         tail = []
         if self.final_activation_name is not None:                            # mlp.py:55-56
@@ -163,7 +163,12 @@ class MLP(StructureTracked, nn.Module):
         h = x2
         for layer in layers[:-1]:
             h = batch_linear(h, layer.weight, layer.bias) if isinstance(layer, nn.Linear) else layer(h)
-        last = layers[-1]
+        return h, layers[-1], tail
+
+    def forward_autograd(self, x2: torch.Tensor, rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The network on [N, in] rows with a graph: torch activations, `batch_linear` layers.  `rows` selects the
+        output rows of the last layer (a coupling only needs the parameters of its transformed columns)."""
+        h, last, tail = self.hidden_autograd(x2)
         W, b = last.weight, last.bias
         if rows is not None:
             W, b = SelectRows.apply(W, rows), SelectRows.apply(b, rows)       # rows are distinct

@@ -147,6 +147,48 @@ def test_spline_flow_log_prob_backward_matches_autograd_of_oracle(n, dim, hidden
         assert err <= 3e-4 * scale + 1e-7, (name, err, scale)
 
 
+@pytest.mark.parametrize('n,dim,hidden,K,latent_dim,act', [
+    (1000, 64, [64], 16, 0, 'Tanh'),            # cfg-3 layer
+    (333, 7, [10], 4, 3, 'Tanh'),               # odd live count, hidden rows not 16-byte aligned, conditional flow
+    (500, 12, [24, 40], 9, 0, 'ELU'),           # deeper conditioner, another activation (no one-layer fused forward)
+    (31, 6, [33], 16, 0, 'Tanh'),               # fewer rows than one chunk; hidden spills into a second tile
+])
+def test_spline_slab_backward_matches_per_row_parameter_path(monkeypatch, n, dim, hidden, K, latent_dim, act):
+    """sx_rqs_slab_bwd (spline backward fused with the last conditioner layer: no [N, n_live*(3K-1)] tensor) against the
+    layer-wise path it replaces (torch Linear -> sx_rqs_coupling / sx_rqs_inverse_bwd -> library GEMMs), same weights."""
+    torch.manual_seed(21)
+    P = 3 * K - 1
+    tr = [st.Coupling(st.Spline(dim, K, latent_net=st.net.MLP(dim + latent_dim, hidden, dim * P, activation=act), lower=-2.5,
+                                upper=2.5, spline_type='quadratic'),
+                      mask='ordered_right_half' if i % 2 == 0 else 'parity_even') for i in range(2)]
+    flow = st.NormalizingFlow(st.UnitNormal(dim), tr).to(DEV)
+    with torch.no_grad():
+        for p in flow.parameters():
+            p.add_(torch.randn_like(p) * 0.3)        # the last layer's bias starts at zero (mlp.py:53)
+    x = torch.randn(n, dim, device=DEV) * 1.5
+    lat = torch.randn(n, latent_dim, device=DEV) if latent_dim else None
+    wgt = torch.rand(n, 1, device=DEV) + 0.5
+
+    def grads():
+        for p in flow.parameters():
+            p.grad = None
+        xg = x.clone().requires_grad_(True)
+        lp = flow.log_prob(xg, latent=lat)
+        (-(lp * wgt).mean()).backward()
+        return lp.detach(), [xg.grad.clone()] + [p.grad.clone() for p in flow.parameters()]
+
+    lp_f, fused = grads()
+    monkeypatch.setenv('STRIBOR_SPLINE_UNFUSED', '1')
+    lp_u, unfused = grads()
+    close(lp_f, lp_u, rtol=1e-5, atol=1e-4)
+    names = ['x'] + [k for k, _ in flow.named_parameters()]
+    for name, a, b in zip(names, fused, unfused):
+        scale = b.abs().max().item() + 1e-12
+        # the two paths round the parameters differently (fp16 x 3 MFMA vs the library's fp32 GEMM) and the spline's
+        # gradient amplifies that: same bound as the fp64-oracle test above
+        assert (a - b).abs().max().item() <= 3e-4 * scale + 1e-8, (name, (a - b).abs().max().item(), scale)
+
+
 def test_spline_flow_training_step_reduces_loss():
     torch.manual_seed(0)
     flow = st.NormalizingFlow(st.UnitNormal(8), [
