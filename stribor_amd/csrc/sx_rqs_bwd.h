@@ -27,26 +27,43 @@ struct rqs_adj {
     float g_ub, g_un;                  // dL/d(raw derivative parameter at the bin's left / right knot)
     float Axin;                        // dL/d(input)
 };
+// FAST: divisions as v_rcp_f32 products, softplus / sigmoid on v_exp_f32 / v_log_f32 (~1e-7 relative, as the fused forward
+// kernel evaluates them); otherwise IEEE divisions and libm, as the element-wise kernels do.
+template <bool FAST>
+__device__ __forceinline__ float rqsb_div(float a, float b) { return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
+template <bool FAST>
+__device__ __forceinline__ float rqsb_softplus_p(float v) {
+    if constexpr (FAST) return v > 20.f ? v : __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(v * 1.44269504088896341f)) * 0.69314718055994531f;
+    else return rqsb_softplus(v);
+}
+template <bool FAST>
+__device__ __forceinline__ float rqsb_sigmoid_p(float v) {
+    if constexpr (FAST) return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f));
+    else return rqsb_sigmoid(v);
+}
+template <bool FAST = false>
 __device__ __forceinline__ rqs_adj rqs_inverse_bwd_core(float xin, float w_b, float h_b, float ch_b, float u_b, float u_n,
                                                         float Ao, float Al) {
-    const float s_b = h_b / w_b;
-    const float d_b = RQS_MIN_DERIV + rqsb_softplus(u_b), d_n = RQS_MIN_DERIV + rqsb_softplus(u_n);
+    const float inv_wb = rqsb_div<FAST>(1.f, w_b);
+    const float s_b = FAST ? h_b * inv_wb : h_b / w_b;
+    const float d_b = RQS_MIN_DERIV + rqsb_softplus_p<FAST>(u_b), d_n = RQS_MIN_DERIV + rqsb_softplus_p<FAST>(u_n);
     const float dy = xin - ch_b;
     const float q = d_b + d_n - 2.f * s_b;
     const float a = dy * q + h_b * (s_b - d_b);
     const float bb = h_b * d_b - dy * q;
     const float c = -s_b * dy;
     const float disc = bb * bb - 4.f * a * c;
-    const float sq = sqrtf(disc);
+    const float sq = FAST ? __builtin_amdgcn_sqrtf(disc) : sqrtf(disc);
     const float D = -bb - sq;
-    const float r = (2.f * c) / D;
+    const float inv_D = rqsb_div<FAST>(1.f, D);
+    const float r = FAST ? (2.f * c) * inv_D : (2.f * c) / D;
     const float tomt = r * (1.f - r), omr = 1.f - r;
     const float den = s_b + q * tomt;
     const float T = d_n * (r * r) + 2.f * s_b * tomt + d_b * (omr * omr);
     const float dnum = (s_b * s_b) * T;
 
     // ---- reverse ----
-    const float Adnum = -Al / dnum, Aden = 2.f * Al / den;
+    const float Adnum = rqsb_div<FAST>(-Al, dnum), Aden = rqsb_div<FAST>(2.f * Al, den);
     float As = Adnum * (2.f * s_b * T + (s_b * s_b) * 2.f * tomt) + Aden;
     float Adn = Adnum * (s_b * s_b) * (r * r), Adb = Adnum * (s_b * s_b) * (omr * omr);
     float Atomt = Adnum * (s_b * s_b) * 2.f * s_b + Aden * q;
@@ -54,10 +71,10 @@ __device__ __forceinline__ rqs_adj rqs_inverse_bwd_core(float xin, float w_b, fl
     float Aq = Aden * tomt;
     Ar += Atomt * (1.f - 2.f * r) + Ao * w_b;
     float Awb = Ao * r, Acwb = Ao;
-    float Ac = Ar * 2.f / D;
-    const float AD = -Ar * r / D;
+    float Ac = FAST ? Ar * 2.f * inv_D : Ar * 2.f / D;
+    const float AD = FAST ? -Ar * r * inv_D : -Ar * r / D;
     float Abb = -AD;
-    const float Adisc = (sq > 0.f) ? (-AD) / (2.f * sq) : 0.f;
+    const float Adisc = (sq > 0.f) ? rqsb_div<FAST>(-AD, 2.f * sq) : 0.f;
     Abb += Adisc * 2.f * bb;
     const float Aa = -4.f * c * Adisc;
     Ac += -4.f * a * Adisc;
@@ -76,15 +93,15 @@ __device__ __forceinline__ rqs_adj rqs_inverse_bwd_core(float xin, float w_b, fl
     Adn += Aq;
     As += -2.f * Aq;
     float Axin = Ady, Achb = -Ady;
-    Ahb += As / w_b;
-    Awb += -As * s_b / w_b;
+    Ahb += FAST ? As * inv_wb : As / w_b;
+    Awb += FAST ? -As * s_b * inv_wb : -As * s_b / w_b;
     float Acwn = Awb, Achn = Ahb;
     Acwb -= Awb;
     Achb -= Ahb;
     rqs_adj A;
     A.Acwb = Acwb; A.Acwn = Acwn; A.Achb = Achb; A.Achn = Achn;
-    A.g_ub = Adb * rqsb_sigmoid(u_b);          // d softplus = sigmoid
-    A.g_un = Adn * rqsb_sigmoid(u_n);
+    A.g_ub = Adb * rqsb_sigmoid_p<FAST>(u_b);          // d softplus = sigmoid
+    A.g_un = Adn * rqsb_sigmoid_p<FAST>(u_n);
     A.Axin = Axin;
     return A;
 }
@@ -159,13 +176,17 @@ __device__ __forceinline__ float rqs_inverse_bwd_element(float *uw, int K, float
 // K-1 derivative parameters in entries 0..K-1 (K <= 16; the other entries are ignored) and return their gradients (zeros
 // in the unused entries and for an element that is not `valid`).  Every index is static -- the bin is applied through
 // selects -- so the arrays never leave the register file; KC = 16 is the straight-line form, KC = 0 keeps K at run time.
-// Same operations in the same order as rqs_inverse_bwd_element.
+// The same mathematics as rqs_inverse_bwd_element, arranged for the VALU budget of a kernel that runs beside MFMAs
+// (~45 % of the instructions): hardware exp / rcp / log, fused multiply-adds, only the cumulative sums are selected in
+// the sweep (the four knots are formed afterwards), and the softmax-backward dot products come from the selected cumulative
+// sums:  sum_{k<b} p_k = (cs_b - b MIN) / norm,  p_b = (cs_{b+1} - cs_b - MIN) / norm.
 typedef float rqsb_f16v __attribute__((ext_vector_type(16)));
 template <int KC>
 __device__ __forceinline__ float rqs_inverse_bwd_regs(rqsb_f16v &Wp, rqsb_f16v &Hp, rqsb_f16v &Dp, int K, float xv, float Ao,
                                                       float Al, float left, float right, float bottom, float top, bool valid) {
+    constexpr float LOG2E = 1.44269504088896341f;
     const int Kn = KC ? KC : K;
-    const float bconst = logf(expf(1.f - RQS_MIN_DERIV) - 1.f);
+    const float bconst = 0.5397424172369522f;                       // log(exp(1 - 1e-3) - 1), :81 boundary derivative constant
     const float norm = 1.f - RQS_MIN_BIN * (float)Kn;
     const float span_w = right - left, span_h = top - bottom;
     const bool inside = (xv >= bottom) && (xv <= top);
@@ -183,38 +204,42 @@ __device__ __forceinline__ float rqs_inverse_bwd_regs(rqsb_f16v &Wp, rqsb_f16v &
     for (int k = 0; k < 16; ++k)
         if (KC ? (k < KC) : true) {
             const bool used = KC ? true : (k < K);
-            const float ew = used ? rqsb_exp(Wp[k] - mw) : 0.f, eh = used ? rqsb_exp(Hp[k] - mh) : 0.f;
+            const float ew = used ? __builtin_amdgcn_exp2f((Wp[k] - mw) * LOG2E) : 0.f;
+            const float eh = used ? __builtin_amdgcn_exp2f((Hp[k] - mh) * LOG2E) : 0.f;
             Wp[k] = ew;
             Hp[k] = eh;
             sw += ew;
             sh += eh;
         }
-    const float inv_sw = 1.f / sw, inv_sh = 1.f / sh;
+    const float inv_sw = __builtin_amdgcn_rcpf(sw), inv_sh = __builtin_amdgcn_rcpf(sh);
+    const float nw = norm * inv_sw, nh = norm * inv_sh;              // bin size_k = MIN + e_k * n   (:101-105)
+    // one sweep: cumulative sums; the heights' knots are compared with the input (search_sorted.py:4-5), and the cumulative
+    // sums at the bin (`take`: last knot <= input) and after it (`nxt`: first knot > input) are kept
     int b = 0;
-    float cw_b = left, ch_b = bottom, cw_n = right, ch_n = top;
+    float csw = 0.f, csh = 0.f, csw_b = 0.f, csw_n = 0.f, kh_b = bottom, kh_n = top;
     bool have_next = false;
-    float csw = 0.f, csh = 0.f;
 #pragma unroll
     for (int j = 1; j <= 16; ++j)
         if (KC ? (j <= KC) : true) {
             const bool used = KC ? true : (j <= K);
             const bool last = (j == Kn);
-            const float wk = RQS_MIN_BIN + norm * (Wp[j - 1] * inv_sw);
-            const float hk = RQS_MIN_BIN + norm * (Hp[j - 1] * inv_sh);
-            csw += wk;
-            csh += hk;
-            const float kw = last ? right : span_w * csw + left;
-            const float kh = last ? top : span_h * csh + bottom;
+            csw += fmaf(Wp[j - 1], nw, RQS_MIN_BIN);
+            csh += fmaf(Hp[j - 1], nh, RQS_MIN_BIN);
+            const float kh = last ? top : fmaf(span_h, csh, bottom);     // ends pinned (:186-192)
             const bool ge = xin >= (last ? kh + RQS_EPS : kh);
             const bool take = used && ge && !last;
             const bool nxt = used && !ge && !have_next;
             b = take ? j : b;
-            cw_b = take ? kw : cw_b;
-            ch_b = take ? kh : ch_b;
-            cw_n = nxt ? kw : cw_n;
-            ch_n = nxt ? kh : ch_n;
+            csw_b = take ? csw : csw_b;
+            kh_b = take ? kh : kh_b;
+            csw_n = nxt ? csw : csw_n;
+            kh_n = nxt ? kh : kh_n;
             have_next = have_next || nxt;
         }
+    const bool first = (b == 0), lastbin = (b + 1 == Kn);
+    const float cw_b = first ? left : fmaf(span_w, csw_b, left);
+    const float cw_n = lastbin ? right : fmaf(span_w, csw_n, left);
+    const float ch_b = kh_b, ch_n = kh_n;
     const float w_b = cw_n - cw_b, h_b = ch_n - ch_b;
     float u_b = bconst, u_n = bconst;
 #pragma unroll
@@ -224,27 +249,29 @@ __device__ __forceinline__ float rqs_inverse_bwd_regs(rqsb_f16v &Wp, rqsb_f16v &
             u_n = (used && b == k) ? Dp[k] : u_n;
             u_b = (used && b == k + 1) ? Dp[k] : u_b;
         }
-    const rqs_adj A = rqs_inverse_bwd_core(xin, w_b, h_b, ch_b, u_b, u_n, Ao, Al);
-    const float Gw_lo = (b >= 1 ? span_w * A.Acwb : 0.f) + (b + 1 < Kn ? span_w * A.Acwn : 0.f);   // bins i < b
-    const float Gw_b = (b + 1 < Kn ? span_w * A.Acwn : 0.f);                                        // bin i == b
-    const float Gh_lo = (b >= 1 ? span_h * A.Achb : 0.f) + (b + 1 < Kn ? span_h * A.Achn : 0.f);
-    const float Gh_b = (b + 1 < Kn ? span_h * A.Achn : 0.f);
-    float dotw = 0.f, doth = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-        if (KC ? (k < KC) : true) {
-            const float pw = Wp[k] * inv_sw, ph = Hp[k] * inv_sh;          // unused entries hold 0
-            dotw += pw * (k < b ? Gw_lo : (k == b ? Gw_b : 0.f));
-            doth += ph * (k < b ? Gh_lo : (k == b ? Gh_b : 0.f));
-        }
+    const rqs_adj A = rqs_inverse_bwd_core<true>(xin, w_b, h_b, ch_b, u_b, u_n, Ao, Al);
+    // knots -> cumsums -> bin sizes:  dL/dsize_i = span * ([i < b] A(knot_b) + [i < b+1 < K] A(knot_{b+1}))
+    const float Gw_b = lastbin ? 0.f : span_w * A.Acwn, Gw_lo = (first ? 0.f : span_w * A.Acwb) + Gw_b;
+    const float Gh_b = lastbin ? 0.f : span_h * A.Achn, Gh_lo = (first ? 0.f : span_h * A.Achb) + Gh_b;
+    // softmax backward: du_i = norm p_i (G_i - sum_j G_j p_j)
+    const float inv_norm = __builtin_amdgcn_rcpf(norm), bf = (float)b;
+    const float inv_spw = __builtin_amdgcn_rcpf(span_w), inv_sph = __builtin_amdgcn_rcpf(span_h);
+    const float cswb = (cw_b - left) * inv_spw, cshb = (ch_b - bottom) * inv_sph;
+    const float Sw_lo = (cswb - bf * RQS_MIN_BIN) * inv_norm, pw_b = (w_b * inv_spw - RQS_MIN_BIN) * inv_norm;
+    const float Sh_lo = (cshb - bf * RQS_MIN_BIN) * inv_norm, ph_b = (h_b * inv_sph - RQS_MIN_BIN) * inv_norm;
+    const float dotw = Gw_lo * Sw_lo + Gw_b * pw_b, doth = Gh_lo * Sh_lo + Gh_b * ph_b;
     const bool on = valid && inside;
+    const float fw = on ? nw : 0.f, fh = on ? nh : 0.f;               // norm / sum(e), gated
+    const float w_lo = fw * (Gw_lo - dotw), w_at = fw * (Gw_b - dotw), w_hi = fw * -dotw;
+    const float h_lo = fh * (Gh_lo - doth), h_at = fh * (Gh_b - doth), h_hi = fh * -doth;
+    const float g_ub = on ? A.g_ub : 0.f, g_un = on ? A.g_un : 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const bool used = KC ? (k < KC) : (k < K);
-        const float pw = Wp[k] * inv_sw, ph = Hp[k] * inv_sh;
-        Wp[k] = (on && used) ? norm * pw * ((k < b ? Gw_lo : (k == b ? Gw_b : 0.f)) - dotw) : 0.f;
-        Hp[k] = (on && used) ? norm * ph * ((k < b ? Gh_lo : (k == b ? Gh_b : 0.f)) - doth) : 0.f;
-        Dp[k] = (on && k < Kn - 1) ? ((k == b - 1 ? A.g_ub : 0.f) + (k == b ? A.g_un : 0.f)) : 0.f;
+        const bool lt = k < b, eq = k == b;
+        Wp[k] = used ? Wp[k] * (lt ? w_lo : (eq ? w_at : w_hi)) : 0.f;
+        Hp[k] = used ? Hp[k] * (lt ? h_lo : (eq ? h_at : h_hi)) : 0.f;
+        Dp[k] = (k < Kn - 1) ? (eq ? g_un : (k + 1 == b ? g_ub : 0.f)) : 0.f;
     }
     return inside ? A.Axin : Ao;                                         // tails: out = x
 }

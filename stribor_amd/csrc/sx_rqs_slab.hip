@@ -28,6 +28,11 @@
 #include "sx_flow_kernel.h"
 #include "sx_rqs_bwd.h"
 
+// Timing experiments only (results wrong): -DSX_SLAB_X=<bits>  1 no spline reverse mode  2 no dh  4 no dW2  8 no parameter GEMM
+#ifndef SX_SLAB_X
+#define SX_SLAB_X 0
+#endif
+
 namespace {
 using namespace sx_f16x3;
 
@@ -39,13 +44,15 @@ struct slab_args {
     float *dh_part;                     // [n_slabs][n_chunks][HT][1024], fragment order
     float *w_part;                      // [n_slabs][n_ranges][96 * 32 HT + 96]
     const int32_t *live_idx;
+    const float *scale;                 // {S, 1/S} or null: the adjoints are multiplied by S on the way in (see sx_rqs_slab_bwd)
     uint32_t *flags;
     int64_t n_rows, ld_h;
     int l0, n_live, K, dim, H, n_slabs, n_chunks;
     float left, right, bottom, top, ldj_scale;
 };
 
-template <int HT, int KC>
+// HFULL: h rows are 16-byte aligned and exactly 32 HT wide (vector loads, no column guards)
+template <int HT, int KC, bool HFULL>
 __global__ __launch_bounds__(256, 2) void rqs_slab_bwd_kernel(const slab_args k) {
     constexpr int FW = 0, BW = 3 * HT * 1024, BI = 6 * HT * 1024;        // LDS float offsets: W2 slab | its transpose | bias
     constexpr int N2 = 32 * HT, E = 96 * N2 + 96;
@@ -78,8 +85,8 @@ __global__ __launch_bounds__(256, 2) void rqs_slab_bwd_kernel(const slab_args k)
     const int ci = 2 * slab + hh;                                       // this lane's transformed column (index into live)
     const bool col_ok = ci < k.n_live;
     const int col = col_ok ? (k.live_idx ? k.live_idx[ci] : k.l0 + ci) : 0;
-    const bool vec_h = (k.ld_h % 4 == 0) && ((reinterpret_cast<uintptr_t>(k.h) & 15) == 0);
     uint64_t any_bad = 0;
+    const float sc_in = k.scale ? k.scale[0] : 1.f, sc_out = k.scale ? k.scale[1] : 1.f;
     const int c_begin = (int)((int64_t)k.n_chunks * range / n_ranges), c_end = (int)((int64_t)k.n_chunks * (range + 1) / n_ranges);
     for (int c = c_begin + wave; c < c_end; c += 4) {
         rng_t rg{0};
@@ -87,6 +94,9 @@ __global__ __launch_bounds__(256, 2) void rqs_slab_bwd_kernel(const slab_args k)
         const bool row_ok = row < k.n_rows;
         const bool valid = row_ok && col_ok;
         // ---- h -> fp16 x 3 fragments; the slab's parameters ----------------------------------------------------------
+        // (a row past the end reads the last row instead: its parameter gradients are forced to zero below, so whatever
+        //  finite h it carries contributes nothing, and its dh is never stored by the reduce kernel)
+        const int64_t rowc = row_ok ? row : k.n_rows - 1;
         btile<1> bh[HT];
 #pragma unroll
         for (int m = 0; m < HT; ++m) {
@@ -94,42 +104,43 @@ __global__ __launch_bounds__(256, 2) void rqs_slab_bwd_kernel(const slab_args k)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int f0 = 32 * m + 8 * g + 4 * hh;
+                const float *p = k.h + rowc * k.ld_h + f0;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (row_ok) {
-                    const float *p = k.h + row * k.ld_h + f0;
-                    if (vec_h && f0 + 3 < k.H) v = *reinterpret_cast<const f32x4 *>(p);
-                    else {
-                        if (f0 + 0 < k.H) v.x = p[0];
-                        if (f0 + 1 < k.H) v.y = p[1];
-                        if (f0 + 2 < k.H) v.z = p[2];
-                        if (f0 + 3 < k.H) v.w = p[3];
-                    }
+                if constexpr (HFULL) v = *reinterpret_cast<const f32x4 *>(p);
+                else {
+                    if (f0 + 0 < k.H) v.x = p[0];
+                    if (f0 + 1 < k.H) v.y = p[1];
+                    if (f0 + 2 < k.H) v.z = p[2];
+                    if (f0 + 3 < k.H) v.w = p[3];
                 }
                 hid.v[0][4 * g + 0] = v.x; hid.v[0][4 * g + 1] = v.y; hid.v[0][4 * g + 2] = v.z; hid.v[0][4 * g + 3] = v.w;
             }
             bh[m] = make_btile<1>(hid, rg);
         }
-        const float xv = valid ? k.x[row * k.dim + col] : k.bottom;
-        const float Ao = valid ? k.gout[row * k.dim + col] : 0.f;
-        const float Al = valid ? k.gldj[row] * k.ldj_scale : 0.f;
+        const float xl = k.x[rowc * k.dim + col], gol = k.gout[rowc * k.dim + col], gll = k.gldj[rowc];
+        const float xv = valid ? xl : k.bottom;
+        const float Ao = valid ? gol * sc_in : 0.f;
+        const float Al = valid ? gll * (k.ldj_scale * sc_in) : 0.f;
         tile<1> acc[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             acc[t] = load_cfrag<1>(w.cb, BI + t * 32);
 #pragma unroll
-            for (int m = 0; m < HT; ++m) gemm_tile<1>(w.wb, FW + (t * HT + m) * 1024, bh[m], acc[t]);
+            for (int m = 0; m < HT; ++m)
+                if (!(SX_SLAB_X & 8)) gemm_tile<1>(w.wb, FW + (t * HT + m) * 1024, bh[m], acc[t]);
         }
         // ---- the spline's reverse mode on the lane's own element: parameters -> their gradients, in place ---------------
-        const float gxe = rqs_inverse_bwd_regs<KC>(acc[0].v[0], acc[1].v[0], acc[2].v[0], k.K, xv, Ao, Al, k.left, k.right,
-                                                   k.bottom, k.top, valid);
+        const float gxe = (SX_SLAB_X & 1) ? xv + Ao + Al
+                                          : rqs_inverse_bwd_regs<KC>(acc[0].v[0], acc[1].v[0], acc[2].v[0], k.K, xv, Ao, Al, k.left,
+                                                                     k.right, k.bottom, k.top, valid);
         btile<1> bd[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) bd[t] = make_btile<1>(acc[t], rg);
-        if (valid) k.gx[row * k.dim + col] = rng_bad_sample(rg, lane) ? __builtin_nanf("") : gxe;
+        if (valid) k.gx[row * k.dim + col] = rng_bad_sample(rg, lane) ? __builtin_nanf("") : gxe * sc_out;
         any_bad |= rg.bad;
         __builtin_amdgcn_sched_barrier(0);
         // ---- dh partial = W2_slab^T dp ---------------------------------------------------------------------------
-        {
+        if (!(SX_SLAB_X & 2)) {
             float *dst = k.dh_part + ((size_t)slab * k.n_chunks + c) * (HT * 1024);
 #pragma unroll
             for (int m = 0; m < HT; ++m) {
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void rqs_slab_bwd_kernel(const slab_args k)
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- dW2_slab += dp^T h (contraction over this wave's 32 rows on the matrix pipe) --------------------------------
-        {
+        if (!(SX_SLAB_X & 4)) {
             tfrag th[HT];
             float dummy = 0.f;
 #pragma unroll
@@ -190,7 +201,8 @@ __global__ __launch_bounds__(256, 2) void rqs_slab_bwd_kernel(const slab_args k)
 // dW2 / db2 rows of the slabs: sum of the per-range partials, scattered to the parameter's rows (slot_rows < 0: padding)
 __global__ __launch_bounds__(256) void rqs_slab_w_reduce_kernel(const float *__restrict__ part, int n_ranges, int N2, int H,
                                                                 const int32_t *__restrict__ slot_rows, float *__restrict__ dW,
-                                                                int64_t ldw, float *__restrict__ db) {
+                                                                int64_t ldw, float *__restrict__ db,
+                                                                const float *__restrict__ scale) {
     const int E = 96 * N2 + 96;
     const int e = blockIdx.x * 256 + threadIdx.x, slab = blockIdx.y;
     if (e >= E) return;
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(256) void rqs_slab_w_reduce_kernel(const float *__r
         s3 += src[(size_t)(p + 3) * E];
     }
     for (; p < n_ranges; ++p) s0 += src[(size_t)p * E];
-    const float t = (s0 + s1) + (s2 + s3);
+    const float t = ((s0 + s1) + (s2 + s3)) * (scale ? scale[1] : 1.f);
     if (e < 96 * N2) {
         const int row = slot_rows[slab * 96 + e / N2], colh = e % N2;
         if (row >= 0 && colh < H) dW[(int64_t)row * ldw + colh] = t;
@@ -217,7 +229,8 @@ __global__ __launch_bounds__(256) void rqs_slab_w_reduce_kernel(const float *__r
 // dL/dh [N, H] row-major = sum over the slabs of the fragment-order partials
 template <int HT>
 __global__ __launch_bounds__(256) void rqs_slab_dh_reduce_kernel(const float *__restrict__ part, int n_slabs, int n_chunks,
-                                                                 int64_t n_rows, int H, float *__restrict__ gh, int64_t ld) {
+                                                                 int64_t n_rows, int H, float *__restrict__ gh, int64_t ld,
+                                                                 const float *__restrict__ scale) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;         // one 16 B piece: (chunk, m, g, lane)
     const int64_t total = (int64_t)n_chunks * HT * 256;
     if (idx >= total) return;
@@ -227,6 +240,8 @@ __global__ __launch_bounds__(256) void rqs_slab_dh_reduce_kernel(const float *__
         const f32x4 v = src[(size_t)p * total];
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
+    const float us = scale ? scale[1] : 1.f;
+    s.x *= us; s.y *= us; s.z *= us; s.w *= us;
     const int lane = (int)(idx & 63), g = (int)((idx >> 6) & 3), m = (int)((idx >> 8) % HT);
     const int64_t c = idx / (HT * 256);
     const int64_t row = c * 32 + (lane & 31);
@@ -261,8 +276,8 @@ extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *g
                                int32_t hidden, const float *w_fwd, const float *w_bwd, const int32_t *slot_rows, float *gx,
                                float *gh, int64_t ld_gh, float *dW, int64_t ldw, float *db, const int32_t *live_idx,
                                int32_t live_start, int32_t n_live, int32_t n_bins, float left, float right, float bottom,
-                               float top, int64_t n_rows, int32_t dim, float ldj_scale, float *scratch, uint32_t *err_flag,
-                               void *stream) {
+                               float top, int64_t n_rows, int32_t dim, float ldj_scale, const float *scale, float *scratch,
+                               uint32_t *err_flag, void *stream) {
     SX_REQUIRE(x && gout && gldj && h && w_fwd && w_bwd && slot_rows && gx && gh && dW && db && scratch,
                "sx_rqs_slab_bwd: null pointer");
     SX_REQUIRE(dim > 0 && n_live > 0 && n_live <= dim && n_rows >= 0, "sx_rqs_slab_bwd: bad sizes");
@@ -281,15 +296,15 @@ extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *g
     k.x = x; k.gout = gout; k.gldj = gldj; k.h = h; k.wf = w_fwd; k.wb = w_bwd; k.gx = gx;
     k.dh_part = scratch;
     k.w_part = scratch + (size_t)n_slabs * n_chunks * HT * 1024;
-    k.live_idx = live_idx; k.flags = err_flag; k.n_rows = n_rows; k.ld_h = ld_h; k.l0 = live_start; k.n_live = n_live;
+    k.live_idx = live_idx; k.scale = scale; k.flags = err_flag; k.n_rows = n_rows; k.ld_h = ld_h; k.l0 = live_start; k.n_live = n_live;
     k.K = n_bins; k.dim = dim; k.H = hidden; k.n_slabs = n_slabs; k.n_chunks = n_chunks;
     k.left = left; k.right = right; k.bottom = bottom; k.top = top; k.ldj_scale = ldj_scale;
     const size_t lds = (size_t)(6 * HT * 1024 + 128) * sizeof(float);
     int dev = 0;
     (void)hipGetDevice(&dev);
-#define SX_SLAB(HT_, KC_)                                                                                          \
+#define SX_SLAB(HT_, KC_, HF_)                                                                                     \
     do {                                                                                                           \
-        auto kern = rqs_slab_bwd_kernel<HT_, KC_>;                                                                 \
+        auto kern = rqs_slab_bwd_kernel<HT_, KC_, HF_>;                                                            \
         static int lds_allowed[64];                                                                                \
         if (lds > 48 * 1024 && !lds_allowed[dev & 63]) {                                                           \
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -298,21 +313,25 @@ extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *g
         }                                                                                                          \
         hipLaunchKernelGGL(kern, dim3(n_slabs, n_ranges), dim3(256), lds, st, k);                                  \
     } while (0)
-    if (HT == 1) { if (n_bins == 16) SX_SLAB(1, 16); else SX_SLAB(1, 0); }
-    else { if (n_bins == 16) SX_SLAB(2, 16); else SX_SLAB(2, 0); }
+    const bool hfull = hidden == 32 * HT && ld_h % 4 == 0 && ((uintptr_t)h & 15) == 0;
+    if (HT == 1) {
+        if (n_bins == 16 && hfull) SX_SLAB(1, 16, true); else if (hfull) SX_SLAB(1, 0, true); else SX_SLAB(1, 0, false);
+    } else {
+        if (n_bins == 16 && hfull) SX_SLAB(2, 16, true); else if (hfull) SX_SLAB(2, 0, true); else SX_SLAB(2, 0, false);
+    }
 #undef SX_SLAB
     SX_LAUNCH_CHECK();
     const int N2 = 32 * HT, E = 96 * N2 + 96;
     hipLaunchKernelGGL(rqs_slab_w_reduce_kernel, dim3((E + 255) / 256, n_slabs), dim3(256), 0, st, k.w_part, n_ranges, N2,
-                       (int)hidden, slot_rows, dW, ldw, db);
+                       (int)hidden, slot_rows, dW, ldw, db, scale);
     SX_LAUNCH_CHECK();
     const int64_t pieces = (int64_t)n_chunks * HT * 256;
     if (HT == 1)
         hipLaunchKernelGGL(rqs_slab_dh_reduce_kernel<1>, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, k.dh_part,
-                           n_slabs, n_chunks, n_rows, (int)hidden, gh, ld_gh);
+                           n_slabs, n_chunks, n_rows, (int)hidden, gh, ld_gh, scale);
     else
         hipLaunchKernelGGL(rqs_slab_dh_reduce_kernel<2>, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, k.dh_part,
-                           n_slabs, n_chunks, n_rows, (int)hidden, gh, ld_gh);
+                           n_slabs, n_chunks, n_rows, (int)hidden, gh, ld_gh, scale);
     SX_LAUNCH_CHECK();
     return SX_OK;
 }

@@ -140,10 +140,15 @@ class RQSCouplingSlab(torch.autograd.Function):
         gb = torch.zeros_like(b2)
         with _hip.device_of(x2):
             sc = _hip.scratch(dev, lib.sx_rqs_slab_scratch_floats(n, n_live, H))
+        # adjoints normalised to ~1 by a power of two (exact): the parameter gradients are fp16 x 3 GEMM operands, and
+        # dL/dlog_prob = 1/N of a mean loss would put them under fp16's normal range (no host sync: S stays on the device)
+        gmax = torch.maximum(gy.abs().max(), gldj.abs().max())
+        S = torch.exp2(-torch.floor(torch.log2(gmax.clamp(1e-30, 1e30))))
+        scale = torch.stack([S, 1.0 / S]).to(torch.float32)
         _hip.call('sx_rqs_slab_bwd', x2, x2.data_ptr(), gy.data_ptr(), gldj.data_ptr(), h.data_ptr(), h.stride(0), H,
                   packs.data_ptr(), packs.data_ptr() + 4 * n_fwd, slot_rows.data_ptr(), gx.data_ptr(), gh.data_ptr(),
                   gh.stride(0), gW.data_ptr(), gW.stride(0), gb.data_ptr(), _hip.ptr(live_idx), live_start, n_live, n_bins,
-                  lower, upper, lower, upper, n, d, 1.0, sc.data_ptr(), flag)
+                  lower, upper, lower, upper, n, d, 1.0, scale.data_ptr(), sc.data_ptr(), flag)
         return gx, gh, gW, gb, None, None, None, None, None, None, None, None
 
 

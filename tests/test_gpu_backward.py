@@ -164,7 +164,7 @@ def test_spline_slab_backward_matches_per_row_parameter_path(monkeypatch, n, dim
     flow = st.NormalizingFlow(st.UnitNormal(dim), tr).to(DEV)
     with torch.no_grad():
         for p in flow.parameters():
-            p.add_(torch.randn_like(p) * 0.3)        # the last layer's bias starts at zero (mlp.py:53)
+            p.add_(torch.randn_like(p) * 0.05)       # the last layer's bias starts at zero (mlp.py:53)
     x = torch.randn(n, dim, device=DEV) * 1.5
     lat = torch.randn(n, latent_dim, device=DEV) if latent_dim else None
     wgt = torch.rand(n, 1, device=DEV) + 0.5
