@@ -1818,11 +1818,14 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
 #define SX_FL(MD)                                                                                              \
     do {                                                                                                       \
         auto kern = flow_fused_kernel<NS, TX, HT, MD>;                                                         \
-        static int lds_allowed[64];      /* raised once per kernel variant and DEVICE, not per launch */       \
-        if (a.lds > 48 * 1024 && !lds_allowed[dev & 63]) {                                                     \
-            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        /* The attribute is set to what THIS launch needs, and only when that changes (per kernel variant and device): the  \
+           runtime sizes a workgroup's LDS allocation by the attribute, not by the launch's dynamic size, so a blanket     \
+           160 KiB would cap every variant at one workgroup per CU (measured on the spline slab backward: 1.16 vs 0.92 ms) */ \
+        static int lds_set[64];                                                                                \
+        if (a.lds > 48 * 1024 && lds_set[dev & 63] != a.lds) {                                                 \
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, a.lds); \
             if (e != hipSuccess) { sx_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
-            lds_allowed[dev & 63] = 1;                                                                         \
+            lds_set[dev & 63] = a.lds;                                                                         \
         }                                                                                                      \
         hipLaunchKernelGGL(kern, dim3(a.grid), dim3(64 * SX_BLOCK_WAVES(TX, MD)), a.lds, a.stream, a.prog, k);                         \
     } while (0)

@@ -337,12 +337,14 @@ extern "C" int sx_pointwise(const void *x, void *y, float *ldj, float *ldiag, in
             if (g > 2048) g = 2048;
             const size_t lds4 = (size_t)4 * 64 * (dim + 4) * sizeof(float);
             if (dtype == SX_F32 && dim % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && lds4 <= 150 * 1024 && dim <= 16384) {
-                static bool raised[64];
+                // the attribute is what the runtime sizes the workgroup's LDS allocation by: set it to this launch's need
+                // (a blanket 160 KiB leaves one workgroup per CU), and only when it changes
+                static size_t set_to[64];
                 int dev = 0;
                 (void)hipGetDevice(&dev);
-                if (lds4 > 48 * 1024 && !raised[dev & 63]) {
-                    (void)hipFuncSetAttribute((const void *)cumsum_vec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                    raised[dev & 63] = true;
+                if (lds4 > 48 * 1024 && set_to[dev & 63] != lds4) {
+                    (void)hipFuncSetAttribute((const void *)cumsum_vec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+                    set_to[dev & 63] = lds4;
                 }
                 hipLaunchKernelGGL(cumsum_vec_kernel, dim3((int)g), dim3(256), lds4, st, (const float *)x, (float *)y, n_rows, dim,
                                    kind == SX_PW_DIFF);
@@ -352,8 +354,8 @@ extern "C" int sx_pointwise(const void *x, void *y, float *ldj, float *ldiag, in
             const int staged = lds <= 150 * 1024;
             const size_t dyn = staged ? lds : 0;
             if (dyn > 48 * 1024) {
-                (void)hipFuncSetAttribute((const void *)cumsum_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute((const void *)cumsum_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void *)cumsum_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+                (void)hipFuncSetAttribute((const void *)cumsum_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
             }
             if (dtype == SX_BF16) hipLaunchKernelGGL(cumsum_kernel<true>, dim3((int)g), dim3(256), dyn, st, x, y, n_rows, dim, kind == SX_PW_DIFF, staged);
             else hipLaunchKernelGGL(cumsum_kernel<false>, dim3((int)g), dim3(256), dyn, st, x, y, n_rows, dim, kind == SX_PW_DIFF, staged);

@@ -36,6 +36,14 @@
 namespace {
 using namespace sx_f16x3;
 
+// Phase timing (build with -DSX_SLAB_PROF; prints from sx_rqs_slab_bwd): s_memtime deltas of one wave, per phase
+#ifdef SX_SLAB_PROF
+__device__ unsigned long long g_slab_prof[16];
+#define SLAB_T(id) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pf[id] += t_ - pt; pt = t_; } while (0)
+#else
+#define SLAB_T(id) ((void)0)
+#endif
+
 struct slab_args {
     const float *x, *gout, *gldj, *h;   // x, gout [N, dim]; gldj [N]; h [N, ld_h] (H valid features)
     const float *wf;                    // sx_pack_linear(W2 rows by slot): [3 n_slabs][HT][1024] + bias [3 n_slabs][32]
@@ -47,31 +55,63 @@ struct slab_args {
     const float *scale;                 // {S, 1/S} or null: the adjoints are multiplied by S on the way in (see sx_rqs_slab_bwd)
     uint32_t *flags;
     int64_t n_rows, ld_h;
-    int l0, n_live, K, dim, H, n_slabs, n_chunks;
+    int l0, n_live, K, dim, H, n_slabs, n_chunks, n_groups, n_ranges, xcd_map;
     float left, right, bottom, top, ldj_scale;
 };
 
-// HFULL: h rows are 16-byte aligned and exactly 32 HT wide (vector loads, no column guards)
-template <int HT, int KC, bool HFULL>
-__global__ __launch_bounds__(256, 2) void rqs_slab_bwd_kernel(const slab_args k) {
-    constexpr int FW = 0, BW = 3 * HT * 1024, BI = 6 * HT * 1024;        // LDS float offsets: W2 slab | its transpose | bias
+// Pairwise hand-over through LDS flags (monotone pass counters): the two waves of a slab pair meet once per pass to exchange
+// a dh tile; a workgroup barrier there would also tie the four independent pairs (and the two waves that share a SIMD) to
+// one another's memory latencies.
+__device__ __forceinline__ void flag_wait_ge(int *flag, int target) {
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ void flag_set(int *flag, int v) {
+    __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// HFULL: h rows are 16-byte aligned and exactly 32 HT wide (vector loads, no column guards).
+// SPW slabs per workgroup (4 waves each, the same 4 chunks of rows per pass): with SPW = 2 the two slabs' waves exchange one
+// dh tile each through LDS, so only ONE partial per slab pair goes to HBM (the dh partials are the kernel's HBM traffic).
+// Workgroup id -> (slab group, row range) is XCD-aware: ids are dealt round-robin to the 8 XCDs, so the n_groups workgroups
+// that walk the same rows (and re-read the same h / x lines) are given ids 8 apart -- the same XCD, the same L2.
+template <int HT, int KC, bool HFULL, int SPW>
+__global__ __launch_bounds__(256 * SPW, SPW == 1 ? 2 : 1) void rqs_slab_bwd_kernel(const slab_args k) {
+    constexpr int SLAB_F = 6 * HT * 1024;                               // per slab: W2 slab | its transpose (floats)
+    constexpr int FWo = 0, BWo = 3 * HT * 1024;
+    constexpr int BI = SPW * SLAB_F, XB = BI + SPW * 128;               // bias [SPW][128] | exchange [4 SPW][1024] | flags [32]
+    constexpr int FL = XB + (SPW == 2 ? 8 * 1024 : 0);
     constexpr int N2 = 32 * HT, E = 96 * N2 + 96;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int slab = blockIdx.x, range = blockIdx.y, n_ranges = gridDim.y;
+    // partners (same q, the two slabs) sit on DIFFERENT SIMDs (wave w runs on SIMD w % 4): the two waves that share a SIMD
+    // then belong to different pairs and drift apart, so one's VALU phase overlaps the other's MFMA phase
+    const int sl = SPW == 1 ? 0 : wave >> 2, q = (wave + sl) & 3;
+    int group, range;
     {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(k.wf + (size_t)slab * 3 * HT * 1024);
-        f32x4 *dst = reinterpret_cast<f32x4 *>(smem + FW);
-        for (int i = threadIdx.x; i < 3 * HT * 256; i += 256) dst[i] = src[i];
+        const int L = blockIdx.x, G = k.n_groups;
+        if (k.xcd_map) { const int i = L >> 3; group = i % G; range = (i / G) * 8 + (L & 7); }
+        else { group = L % G; range = L / G; }
+    }
+    const int slab = group * SPW + sl;
+    const bool slab_ok = slab < k.n_slabs;
+    {
+        const int tid = threadIdx.x & 255;
+        f32x4 *dst = reinterpret_cast<f32x4 *>(smem + sl * SLAB_F + FWo);
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(k.wf + (size_t)(slab_ok ? slab : 0) * 3 * HT * 1024);
+        for (int i = tid; i < 3 * HT * 256; i += 256) dst[i] = slab_ok ? src[i] : zero;
 #pragma unroll
         for (int m = 0; m < HT; ++m) {
-            const f32x4 *s2 = reinterpret_cast<const f32x4 *>(k.wb + ((size_t)m * 3 * k.n_slabs + 3 * slab) * 1024);
-            f32x4 *d2 = reinterpret_cast<f32x4 *>(smem + BW + m * 3 * 1024);
-            for (int i = threadIdx.x; i < 3 * 256; i += 256) d2[i] = s2[i];
+            const f32x4 *s2 = reinterpret_cast<const f32x4 *>(k.wb + ((size_t)m * 3 * k.n_slabs + 3 * (slab_ok ? slab : 0)) * 1024);
+            f32x4 *d2 = reinterpret_cast<f32x4 *>(smem + sl * SLAB_F + BWo + m * 3 * 1024);
+            for (int i = tid; i < 3 * 256; i += 256) d2[i] = slab_ok ? s2[i] : zero;
         }
-        if (threadIdx.x < 96) smem[BI + threadIdx.x] = k.wf[(size_t)k.n_slabs * 3 * HT * 1024 + slab * 96 + threadIdx.x];
+        if (SPW == 2 && threadIdx.x < 32) reinterpret_cast<int *>(smem + FL)[threadIdx.x] = 0;
+        if (tid < 96)
+            smem[BI + sl * 128 + tid] = slab_ok ? k.wf[(size_t)k.n_slabs * 3 * HT * 1024 + slab * 96 + tid] : 0.f;
     }
     __syncthreads();
-    const wptr w = make_wptr(0, lane);
+    const wptr w = make_wptr(sl * SLAB_F, lane);
+    const int bias_off = BI + sl * 128 - sl * SLAB_F;                   // relative to w
     const sel_t sel = make_sel(lane);
     const int j = lane & 31, hh = lane >> 5;
     f32x16 A[3][HT];
@@ -87,11 +127,17 @@ __global__ __launch_bounds__(256, 2) void rqs_slab_bwd_kernel(const slab_args k)
     const int col = col_ok ? (k.live_idx ? k.live_idx[ci] : k.l0 + ci) : 0;
     uint64_t any_bad = 0;
     const float sc_in = k.scale ? k.scale[0] : 1.f, sc_out = k.scale ? k.scale[1] : 1.f;
-    const int c_begin = (int)((int64_t)k.n_chunks * range / n_ranges), c_end = (int)((int64_t)k.n_chunks * (range + 1) / n_ranges);
-    for (int c = c_begin + wave; c < c_end; c += 4) {
+    const int c_begin = (int)((int64_t)k.n_chunks * range / k.n_ranges), c_end = (int)((int64_t)k.n_chunks * (range + 1) / k.n_ranges);
+    const int iters = (c_end - c_begin + 3) >> 2;                      // passes: uniform over the workgroup
+#ifdef SX_SLAB_PROF
+    unsigned long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt = __builtin_amdgcn_s_memtime();
+#endif
+    for (int it = 0; it < iters; ++it) {
+        const int c = c_begin + q + 4 * it;
+        const bool chunk_ok = c < c_end;
         rng_t rg{0};
         const int64_t row = (int64_t)c * 32 + j;
-        const bool row_ok = row < k.n_rows;
+        const bool row_ok = chunk_ok && row < k.n_rows;
         const bool valid = row_ok && col_ok;
         // ---- h -> fp16 x 3 fragments; the slab's parameters ----------------------------------------------------------
         // (a row past the end reads the last row instead: its parameter gradients are forced to zero below, so whatever
@@ -117,6 +163,7 @@ __global__ __launch_bounds__(256, 2) void rqs_slab_bwd_kernel(const slab_args k)
             }
             bh[m] = make_btile<1>(hid, rg);
         }
+        SLAB_T(0);      // h load + split
         const float xl = k.x[rowc * k.dim + col], gol = k.gout[rowc * k.dim + col], gll = k.gldj[rowc];
         const float xv = valid ? xl : k.bottom;
         const float Ao = valid ? gol * sc_in : 0.f;
@@ -124,39 +171,84 @@ __global__ __launch_bounds__(256, 2) void rqs_slab_bwd_kernel(const slab_args k)
         tile<1> acc[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-            acc[t] = load_cfrag<1>(w.cb, BI + t * 32);
+            acc[t] = load_cfrag<1>(w.cb, bias_off + t * 32);
 #pragma unroll
             for (int m = 0; m < HT; ++m)
-                if (!(SX_SLAB_X & 8)) gemm_tile<1>(w.wb, FW + (t * HT + m) * 1024, bh[m], acc[t]);
+                if (!(SX_SLAB_X & 8)) gemm_tile<1>(w.wb, FWo + (t * HT + m) * 1024, bh[m], acc[t]);
         }
+        SLAB_T(1);      // x / adjoint loads + parameter GEMM issue
         // ---- the spline's reverse mode on the lane's own element: parameters -> their gradients, in place ---------------
         const float gxe = (SX_SLAB_X & 1) ? xv + Ao + Al
                                           : rqs_inverse_bwd_regs<KC>(acc[0].v[0], acc[1].v[0], acc[2].v[0], k.K, xv, Ao, Al, k.left,
                                                                      k.right, k.bottom, k.top, valid);
+        SLAB_T(2);      // spline reverse mode (waits for the GEMM)
         btile<1> bd[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) bd[t] = make_btile<1>(acc[t], rg);
         if (valid) k.gx[row * k.dim + col] = rng_bad_sample(rg, lane) ? __builtin_nanf("") : gxe * sc_out;
         any_bad |= rg.bad;
         __builtin_amdgcn_sched_barrier(0);
+        SLAB_T(3);      // dp split + gx store
         // ---- dh partial = W2_slab^T dp ---------------------------------------------------------------------------
         if (!(SX_SLAB_X & 2)) {
-            float *dst = k.dh_part + ((size_t)slab * k.n_chunks + c) * (HT * 1024);
+            float *dst = k.dh_part + ((size_t)group * k.n_chunks + (chunk_ok ? c : c_begin)) * (HT * 1024);
+            tile<1> dh[HT];
 #pragma unroll
             for (int m = 0; m < HT; ++m) {
-                tile<1> dh;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dh.v[0][r] = 0.f;
+                for (int r = 0; r < 16; ++r) dh[m].v[0][r] = 0.f;
 #pragma unroll
-                for (int t = 0; t < 3; ++t) gemm_tile<1>(w.wb, BW + (m * 3 + t) * 1024, bd[t], dh);
+                for (int t = 0; t < 3; ++t) gemm_tile<1>(w.wb, BWo + (m * 3 + t) * 1024, bd[t], dh[m]);
+            }
+            if constexpr (SPW == 1) {
+                if (chunk_ok) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 v = {dh.v[0][4 * g], dh.v[0][4 * g + 1], dh.v[0][4 * g + 2], dh.v[0][4 * g + 3]};
-                    reinterpret_cast<f32x4 *>(dst + m * 1024)[g * 64 + lane] = v;
+                    for (int m = 0; m < HT; ++m)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 v = {dh[m].v[0][4 * g], dh[m].v[0][4 * g + 1], dh[m].v[0][4 * g + 2], dh[m].v[0][4 * g + 3]};
+                            reinterpret_cast<f32x4 *>(dst + m * 1024)[g * 64 + lane] = v;
+                        }
+                }
+            } else {
+                // the pair (slab 2g, slab 2g+1) of a chunk: wave `sl` hands the tile it does NOT own to its partner and owns
+                // hidden tile (sl % HT): with HT = 2 each wave adds and stores one tile, with HT = 1 the first slab's wave does
+                constexpr int OWN_SPLIT = HT == 2;
+                const int own = sl * 4 + q, oth = (1 - sl) * 4 + q;
+                f32x4 *xb = reinterpret_cast<f32x4 *>(smem + XB + own * 1024);
+                f32x4 *xp = reinterpret_cast<f32x4 *>(smem + XB + oth * 1024);
+                int *ready = reinterpret_cast<int *>(smem + FL), *ack = ready + 8;
+                const int give = OWN_SPLIT ? 1 - sl : 0;            // tile handed over (HT = 1: slab 1 gives its only tile)
+                if (OWN_SPLIT || sl == 1) {
+                    flag_wait_ge(ack + own, it);                    // the partner has read the tile of the previous pass
+#pragma unroll
+                    for (int m = 0; m < HT; ++m)
+                        if (m == give) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+                                xb[g * 64 + lane] = f32x4{dh[m].v[0][4 * g], dh[m].v[0][4 * g + 1], dh[m].v[0][4 * g + 2], dh[m].v[0][4 * g + 3]};
+                        }
+                    flag_set(ready + own, it + 1);
+                }
+                if (OWN_SPLIT || sl == 0) {
+                    flag_wait_ge(ready + oth, it + 1);
+#pragma unroll
+                    for (int m = 0; m < HT; ++m)
+                        if (m == (OWN_SPLIT ? sl : 0)) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const f32x4 o = xp[g * 64 + lane];
+                                const f32x4 v = {dh[m].v[0][4 * g] + o.x, dh[m].v[0][4 * g + 1] + o.y, dh[m].v[0][4 * g + 2] + o.z,
+                                                 dh[m].v[0][4 * g + 3] + o.w};
+                                if (chunk_ok) reinterpret_cast<f32x4 *>(dst + m * 1024)[g * 64 + lane] = v;
+                            }
+                        }
+                    flag_set(ack + oth, it + 1);
                 }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        SLAB_T(4);      // dh GEMM + exchange + store
         // ---- dW2_slab += dp^T h (contraction over this wave's 32 rows on the matrix pipe) --------------------------------
         if (!(SX_SLAB_X & 4)) {
             tfrag th[HT];
@@ -171,14 +263,21 @@ __global__ __launch_bounds__(256, 2) void rqs_slab_bwd_kernel(const slab_args k)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        SLAB_T(5);      // turns + contraction
     }
+#ifdef SX_SLAB_PROF
+    if (blockIdx.x == 9 && wave == 1 && lane == 0) {
+        for (int i = 0; i < 6; ++i) g_slab_prof[i] = pf[i];
+        g_slab_prof[6] = (unsigned long long)iters;
+    }
+#endif
     if (any_bad != 0 && lane == 0 && k.flags != nullptr)
         __hip_atomic_fetch_or(k.flags, SX_FLAG_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    // ---- one partial per workgroup: the waves add their tiles in LDS by turns (row-major [96][32 HT] | [96]) --------------
+    // ---- one partial per slab and workgroup: its 4 waves add their tiles in LDS by turns (row-major [96][32 HT] | [96]) ----
     __syncthreads();
-    float *red = smem;
+    float *red = smem + sl * SLAB_F;
     for (int wv = 0; wv < 4; ++wv) {
-        if (wave == wv) {
+        if (q == wv) {
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
 #pragma unroll
@@ -194,8 +293,10 @@ __global__ __launch_bounds__(256, 2) void rqs_slab_bwd_kernel(const slab_args k)
         }
         __syncthreads();
     }
-    float *dst = k.w_part + ((size_t)slab * n_ranges + range) * E;
-    for (int e = threadIdx.x; e < E; e += 256) dst[e] = red[e];
+    if (slab_ok) {
+        float *dst = k.w_part + ((size_t)slab * k.n_ranges + range) * E;
+        for (int e = threadIdx.x & 255; e < E; e += 256) dst[e] = red[e];
+    }
 }
 
 // dW2 / db2 rows of the slabs: sum of the per-range partials, scattered to the parameter's rows (slot_rows < 0: padding)
@@ -254,11 +355,19 @@ __global__ __launch_bounds__(256) void rqs_slab_dh_reduce_kernel(const float *__
     if (f0 + 3 < H) dst[3] = s.w;
 }
 
-int slab_ranges(int n_slabs, int n_chunks) {
-    int r = (512 + n_slabs - 1) / n_slabs;           // ~2 workgroups per CU
+// launch shape: slabs per workgroup, slab groups, row ranges (one 8-wave workgroup per CU, or two 4-wave ones)
+struct slab_shape { int spw, n_groups, n_ranges; };
+slab_shape slab_plan(int n_slabs, int n_chunks) {
+    slab_shape p;
+    static const int knob = getenv("SX_SLAB_SPW") ? atoi(getenv("SX_SLAB_SPW")) : 0;      // experiments: 1 | 2, read once
+    p.spw = knob == 1 ? 1 : (n_slabs >= 2 ? 2 : 1);
+    p.n_groups = (n_slabs + p.spw - 1) / p.spw;
+    int r = ((p.spw == 2 ? 256 : 512) + p.n_groups - 1) / p.n_groups;
     const int cap = (n_chunks + 3) / 4;              // at least one 32-row chunk per wave where the rows allow
     if (r > cap) r = cap;
-    return r < 1 ? 1 : r;
+    if (r >= 8) r &= ~7;                             // multiples of 8: the XCD-aware id mapping
+    p.n_ranges = r < 1 ? 1 : r;
+    return p;
 }
 }  // namespace
 
@@ -268,8 +377,8 @@ extern "C" size_t sx_rqs_slab_scratch_floats(int64_t n_rows, int32_t n_live, int
     if (n_rows < 0 || n_live < 1 || hidden < 1 || hidden > 64) return 0;
     const int n_slabs = (n_live + 1) / 2, HT = (hidden + 31) / 32;
     const int64_t n_chunks = (n_rows + 31) / 32;
-    const int n_ranges = slab_ranges(n_slabs, (int)n_chunks);
-    return (size_t)n_slabs * (size_t)n_chunks * HT * 1024 + (size_t)n_slabs * n_ranges * (96 * 32 * HT + 96);
+    const slab_shape p = slab_plan(n_slabs, (int)n_chunks);
+    return (size_t)p.n_groups * (size_t)n_chunks * HT * 1024 + (size_t)n_slabs * p.n_ranges * (96 * 32 * HT + 96);
 }
 
 extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *gldj, const float *h, int64_t ld_h,
@@ -291,36 +400,57 @@ extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *g
     hipStream_t st = sx_stream(stream);
     const int n_slabs = (n_live + 1) / 2, HT = (hidden + 31) / 32;
     const int n_chunks = (int)((n_rows + 31) / 32);
-    const int n_ranges = slab_ranges(n_slabs, n_chunks);
+    const slab_shape pl = slab_plan(n_slabs, n_chunks);
+    const int n_ranges = pl.n_ranges, n_groups = pl.n_groups;
     slab_args k;
     k.x = x; k.gout = gout; k.gldj = gldj; k.h = h; k.wf = w_fwd; k.wb = w_bwd; k.gx = gx;
     k.dh_part = scratch;
-    k.w_part = scratch + (size_t)n_slabs * n_chunks * HT * 1024;
+    k.w_part = scratch + (size_t)n_groups * n_chunks * HT * 1024;
     k.live_idx = live_idx; k.scale = scale; k.flags = err_flag; k.n_rows = n_rows; k.ld_h = ld_h; k.l0 = live_start; k.n_live = n_live;
-    k.K = n_bins; k.dim = dim; k.H = hidden; k.n_slabs = n_slabs; k.n_chunks = n_chunks;
+    k.K = n_bins; k.dim = dim; k.H = hidden; k.n_slabs = n_slabs; k.n_chunks = n_chunks; k.n_groups = n_groups; k.n_ranges = n_ranges;
+    static const int no_xcd = getenv("SX_SLAB_NO_XCD") != nullptr;                             // experiments, read once
+    k.xcd_map = (n_ranges % 8 == 0) && !no_xcd;
     k.left = left; k.right = right; k.bottom = bottom; k.top = top; k.ldj_scale = ldj_scale;
-    const size_t lds = (size_t)(6 * HT * 1024 + 128) * sizeof(float);
+    const size_t lds = (size_t)(pl.spw * (6 * HT * 1024 + 128) + (pl.spw == 2 ? 8 * 1024 + 32 : 0)) * sizeof(float);
     int dev = 0;
     (void)hipGetDevice(&dev);
-#define SX_SLAB(HT_, KC_, HF_)                                                                                     \
+#define SX_SLAB2(HT_, KC_, HF_, SPW_)                                                                              \
     do {                                                                                                           \
-        auto kern = rqs_slab_bwd_kernel<HT_, KC_, HF_>;                                                            \
+        auto kern = rqs_slab_bwd_kernel<HT_, KC_, HF_, SPW_>;                                                      \
+        /* the attribute is set to the launch's own need: the runtime sizes the workgroup's LDS allocation by it, */  \
+        /* so a blanket 160 KiB would leave one workgroup per CU (measured: 1.16 vs 0.92 ms at SPW = 1)           */  \
         static int lds_allowed[64];                                                                                \
         if (lds > 48 * 1024 && !lds_allowed[dev & 63]) {                                                           \
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) { sx_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
             lds_allowed[dev & 63] = 1;                                                                             \
         }                                                                                                          \
-        hipLaunchKernelGGL(kern, dim3(n_slabs, n_ranges), dim3(256), lds, st, k);                                  \
+        hipLaunchKernelGGL(kern, dim3(n_groups * n_ranges), dim3(256 * SPW_), lds, st, k);                         \
     } while (0)
+#define SX_SLAB(HT_, KC_, HF_) do { if (pl.spw == 2) SX_SLAB2(HT_, KC_, HF_, 2); else SX_SLAB2(HT_, KC_, HF_, 1); } while (0)
     const bool hfull = hidden == 32 * HT && ld_h % 4 == 0 && ((uintptr_t)h & 15) == 0;
     if (HT == 1) {
         if (n_bins == 16 && hfull) SX_SLAB(1, 16, true); else if (hfull) SX_SLAB(1, 0, true); else SX_SLAB(1, 0, false);
     } else {
         if (n_bins == 16 && hfull) SX_SLAB(2, 16, true); else if (hfull) SX_SLAB(2, 0, true); else SX_SLAB(2, 0, false);
     }
+#undef SX_SLAB2
 #undef SX_SLAB
     SX_LAUNCH_CHECK();
+#ifdef SX_SLAB_PROF
+    {
+        (void)hipStreamSynchronize(st);
+        unsigned long long p[16];
+        (void)hipMemcpyFromSymbol(p, HIP_SYMBOL(g_slab_prof), sizeof(p));
+        static const char *names[6] = {"h load+split", "x/adjoint loads+param GEMM issue", "spline reverse", "dp split+gx", "dh GEMM+exchange",
+                                       "turn+contract"};
+        unsigned long long tot = 0;
+        for (int i = 0; i < 6; ++i) tot += p[i];
+        fprintf(stderr, "[slab prof] wave 1 of block 9, %llu passes, s_memtime ticks per pass:", p[6]);
+        for (int i = 0; i < 6; ++i) fprintf(stderr, " %s=%.0f (%.1f%%)", names[i], (double)p[i] / (p[6] ? p[6] : 1), 100.0 * p[i] / (tot ? tot : 1));
+        fprintf(stderr, " total=%.0f\n", (double)tot / (p[6] ? p[6] : 1));
+    }
+#endif
     const int N2 = 32 * HT, E = 96 * N2 + 96;
     hipLaunchKernelGGL(rqs_slab_w_reduce_kernel, dim3((E + 255) / 256, n_slabs), dim3(256), 0, st, k.w_part, n_ranges, N2,
                        (int)hidden, slot_rows, dW, ldw, db, scale);
@@ -328,10 +458,10 @@ extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *g
     const int64_t pieces = (int64_t)n_chunks * HT * 256;
     if (HT == 1)
         hipLaunchKernelGGL(rqs_slab_dh_reduce_kernel<1>, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, k.dh_part,
-                           n_slabs, n_chunks, n_rows, (int)hidden, gh, ld_gh, scale);
+                           n_groups, n_chunks, n_rows, (int)hidden, gh, ld_gh, scale);
     else
         hipLaunchKernelGGL(rqs_slab_dh_reduce_kernel<2>, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, k.dh_part,
-                           n_slabs, n_chunks, n_rows, (int)hidden, gh, ld_gh, scale);
+                           n_groups, n_chunks, n_rows, (int)hidden, gh, ld_gh, scale);
     SX_LAUNCH_CHECK();
     return SX_OK;
 }
