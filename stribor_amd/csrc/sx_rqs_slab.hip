@@ -59,6 +59,18 @@ struct slab_args {
     float left, right, bottom, top, ldj_scale;
 };
 
+// A-operand fragments of one 32 x 32 tile for k16-step s (hi, lo), read from LDS
+struct afrag { h8 hi, lo; };
+__device__ __forceinline__ afrag load_afrag(const char *wb, int a_off, int s) {
+    afrag a;
+    a.hi = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4 *>(wb + (a_off + (2 * s) * 256) * 4));
+    a.lo = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4 *>(wb + (a_off + (2 * s + 1) * 256) * 4));
+    return a;
+}
+__device__ __forceinline__ f32x16 mfma(const h8 &a, const h8 &b, const f32x16 &c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
 // Pairwise hand-over through LDS flags (monotone pass counters): the two waves of a slab pair meet once per pass to exchange
 // a dh tile; a workgroup barrier there would also tie the four independent pairs (and the two waves that share a SIMD) to
 // one another's memory latencies.
@@ -81,7 +93,9 @@ __global__ __launch_bounds__(256 * SPW, SPW == 1 ? 2 : 1) void rqs_slab_bwd_kern
     constexpr int BI = SPW * SLAB_F, XB = BI + SPW * 128;               // bias [SPW][128] | exchange [4 SPW][1024] | flags [32]
     constexpr int FL = XB + (SPW == 2 ? 8 * 1024 : 0);
     constexpr int N2 = 32 * HT, E = 96 * N2 + 96;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wave index through readfirstlane: everything derived from it -- slab, chunk, base pointers, the sl branches -- is then
+    //  provably wave-uniform: scalar registers and scalar branches instead of 64-bit per-lane addresses and exec masks)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // partners (same q, the two slabs) sit on DIFFERENT SIMDs (wave w runs on SIMD w % 4): the two waves that share a SIMD
     // then belong to different pairs and drift apart, so one's VALU phase overlaps the other's MFMA phase
     const int sl = SPW == 1 ? 0 : wave >> 2, q = (wave + sl) & 3;
@@ -136,13 +150,19 @@ __global__ __launch_bounds__(256 * SPW, SPW == 1 ? 2 : 1) void rqs_slab_bwd_kern
         const int c = c_begin + q + 4 * it;
         const bool chunk_ok = c < c_end;
         rng_t rg{0};
-        const int64_t row = (int64_t)c * 32 + j;
-        const bool row_ok = chunk_ok && row < k.n_rows;
+        // chunk base pointers are wave-uniform; lanes add 32-bit offsets.  A row past the end reads the chunk's last real row
+        // instead (an absent chunk: the range's first): its parameter gradients are forced to zero below, so whatever
+        // finite h it carries contributes nothing, and its dh is never stored by the reduce kernel.
+        const int cc = chunk_ok ? c : c_begin;
+        const int64_t row0 = (int64_t)cc * 32;
+        const int n_here = (int)((k.n_rows - row0) < 32 ? (k.n_rows - row0) : 32);
+        const bool row_ok = chunk_ok && j < n_here;
         const bool valid = row_ok && col_ok;
+        const int jc = j < n_here ? j : n_here - 1;
+        const float *hb = k.h + row0 * k.ld_h;
+        const float *xb_ = k.x + row0 * k.dim, *gb_ = k.gout + row0 * k.dim, *lb_ = k.gldj + row0;
+        const uint32_t hoff = (uint32_t)jc * (uint32_t)k.ld_h + 4u * hh, xoff = (uint32_t)jc * (uint32_t)k.dim + (uint32_t)col;
         // ---- h -> fp16 x 3 fragments; the slab's parameters ----------------------------------------------------------
-        // (a row past the end reads the last row instead: its parameter gradients are forced to zero below, so whatever
-        //  finite h it carries contributes nothing, and its dh is never stored by the reduce kernel)
-        const int64_t rowc = row_ok ? row : k.n_rows - 1;
         btile<1> bh[HT];
 #pragma unroll
         for (int m = 0; m < HT; ++m) {
@@ -150,7 +170,7 @@ __global__ __launch_bounds__(256 * SPW, SPW == 1 ? 2 : 1) void rqs_slab_bwd_kern
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int f0 = 32 * m + 8 * g + 4 * hh;
-                const float *p = k.h + rowc * k.ld_h + f0;
+                const float *p = hb + (hoff + 32u * m + 8u * g);
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if constexpr (HFULL) v = *reinterpret_cast<const f32x4 *>(p);
                 else {
@@ -164,17 +184,31 @@ __global__ __launch_bounds__(256 * SPW, SPW == 1 ? 2 : 1) void rqs_slab_bwd_kern
             bh[m] = make_btile<1>(hid, rg);
         }
         SLAB_T(0);      // h load + split
-        const float xl = k.x[rowc * k.dim + col], gol = k.gout[rowc * k.dim + col], gll = k.gldj[rowc];
+        const float xl = xb_[xoff], gol = gb_[xoff], gll = lb_[jc];
         const float xv = valid ? xl : k.bottom;
         const float Ao = valid ? gol * sc_in : 0.f;
         const float Al = valid ? gll * (k.ldj_scale * sc_in) : 0.f;
+        // p = W2_slab h + b2: the three tiles (widths | heights | derivatives) are independent accumulation chains, issued
+        // round-robin -- an MFMA onto the previous one's result waits for it, and the A fragments come from LDS
         tile<1> acc[3];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            acc[t] = load_cfrag<1>(w.cb, bias_off + t * 32);
+        for (int t = 0; t < 3; ++t) acc[t] = load_cfrag<1>(w.cb, bias_off + t * 32);
+        if (!(SX_SLAB_X & 8)) {
 #pragma unroll
             for (int m = 0; m < HT; ++m)
-                if (!(SX_SLAB_X & 8)) gemm_tile<1>(w.wb, FWo + (t * HT + m) * 1024, bh[m], acc[t]);
+#pragma unroll
+                for (int sx = 0; sx < 2; ++sx) {
+                    afrag a[3];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) a[t] = load_afrag(w.wb, FWo + (t * HT + m) * 1024, sx);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) acc[t].v[0] = mfma(a[t].lo, bh[m].hi[0][sx], acc[t].v[0]);      // smallest terms first
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) acc[t].v[0] = mfma(a[t].hi, bh[m].lo[0][sx], acc[t].v[0]);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) acc[t].v[0] = mfma(a[t].hi, bh[m].hi[0][sx], acc[t].v[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
         }
         SLAB_T(1);      // x / adjoint loads + parameter GEMM issue
         // ---- the spline's reverse mode on the lane's own element: parameters -> their gradients, in place ---------------
@@ -185,21 +219,33 @@ __global__ __launch_bounds__(256 * SPW, SPW == 1 ? 2 : 1) void rqs_slab_bwd_kern
         btile<1> bd[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) bd[t] = make_btile<1>(acc[t], rg);
-        if (valid) k.gx[row * k.dim + col] = rng_bad_sample(rg, lane) ? __builtin_nanf("") : gxe * sc_out;
+        if (valid && (!(SX_SLAB_X & 64) || gxe == 1234.5f)) (k.gx + row0 * k.dim)[xoff] = rng_bad_sample(rg, lane) ? __builtin_nanf("") : gxe * sc_out;
         any_bad |= rg.bad;
         __builtin_amdgcn_sched_barrier(0);
         SLAB_T(3);      // dp split + gx store
         // ---- dh partial = W2_slab^T dp ---------------------------------------------------------------------------
         if (!(SX_SLAB_X & 2)) {
-            float *dst = k.dh_part + ((size_t)group * k.n_chunks + (chunk_ok ? c : c_begin)) * (HT * 1024);
+            float *dst = k.dh_part + ((size_t)group * k.n_chunks + cc) * (HT * 1024);
             tile<1> dh[HT];
 #pragma unroll
-            for (int m = 0; m < HT; ++m) {
+            for (int m = 0; m < HT; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dh[m].v[0][r] = 0.f;
 #pragma unroll
-                for (int t = 0; t < 3; ++t) gemm_tile<1>(w.wb, BWo + (m * 3 + t) * 1024, bd[t], dh[m]);
-            }
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int sx = 0; sx < 2; ++sx) {              // the HT chains round-robin, as in the parameter GEMM
+                    afrag a[HT];
+#pragma unroll
+                    for (int m = 0; m < HT; ++m) a[m] = load_afrag(w.wb, BWo + (m * 3 + t) * 1024, sx);
+#pragma unroll
+                    for (int m = 0; m < HT; ++m) dh[m].v[0] = mfma(a[m].lo, bd[t].hi[0][sx], dh[m].v[0]);
+#pragma unroll
+                    for (int m = 0; m < HT; ++m) dh[m].v[0] = mfma(a[m].hi, bd[t].lo[0][sx], dh[m].v[0]);
+#pragma unroll
+                    for (int m = 0; m < HT; ++m) dh[m].v[0] = mfma(a[m].hi, bd[t].hi[0][sx], dh[m].v[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             if constexpr (SPW == 1) {
                 if (chunk_ok) {
 #pragma unroll
