@@ -159,16 +159,19 @@ int sx_rqs_inverse_bwd(const float *x, const float *gout, const float *gldj, con
  *   (rows named by slot_rows written), all fp32.  scratch: sx_rqs_slab_scratch_floats(n_rows, n_live, hidden) floats,
  *   16-byte aligned, caller-owned.  err_flag (nullable) receives SX_FLAG_F16_RANGE when h or a parameter gradient leaves
  *   fp16's range (those rows' gx are NaN).
- *   scale (nullable, device, 2 floats {S, 1/S}, S a power of two): gout and gldj are multiplied by S on the way in and every
- *   output by 1/S on the way out, so the parameter gradients -- operands of the fp16 x 3 GEMMs -- sit in fp16's normal range
- *   whatever the magnitude of the loss (dL/dlog_prob = 1/N underflows fp16 for large batches). */
+ *   tanh_hidden != 0: h = tanh(a) and gh receives dL/da = dL/dh (1 - h^2) (the conditioner's last activation folded in).
+ *   scale (nullable, device, ONE float): the largest |gout| / |gldj| of this call, reduced by the caller on the device.  The
+ *   kernels multiply both adjoints by S = 2^-ilogb(scale) on the way in and every output by 1/S on the way out (exact), so
+ *   the parameter gradients -- operands of the fp16 x 3 GEMMs -- sit in fp16's normal range whatever the magnitude of the
+ *   loss (dL/dlog_prob = 1/N underflows fp16 for large batches).  No host synchronisation. */
 int32_t sx_rqs_slab_slots(int32_t n_live);
 size_t sx_rqs_slab_scratch_floats(int64_t n_rows, int32_t n_live, int32_t hidden);
 int sx_rqs_slab_bwd(const float *x, const float *gout, const float *gldj, const float *h, int64_t ld_h, int32_t hidden,
                     const float *w_fwd, const float *w_bwd, const int32_t *slot_rows, float *gx, float *gh, int64_t ld_gh,
                     float *dW, int64_t ldw, float *db, const int32_t *live_idx, int32_t live_start, int32_t n_live,
                     int32_t n_bins, float left, float right, float bottom, float top, int64_t n_rows, int32_t dim,
-                    float ldj_scale, const float *scale, float *scratch, uint32_t *err_flag, void *stream);
+                    float ldj_scale, int32_t tanh_hidden, const float *scale, float *scratch, uint32_t *err_flag,
+                    void *stream);
 
 /* Monotone cubic spline, element-wise part -- spline_type='cubic', the reference's default
  * (stribor/util/cubic_spline.py:21-251, util/search_sorted.py:3-5, flows/spline.py:59-61,82-86).

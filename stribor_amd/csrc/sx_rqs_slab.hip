@@ -52,12 +52,27 @@ struct slab_args {
     float *dh_part;                     // [n_slabs][n_chunks][HT][1024], fragment order
     float *w_part;                      // [n_slabs][n_ranges][96 * 32 HT + 96]
     const int32_t *live_idx;
-    const float *scale;                 // {S, 1/S} or null: the adjoints are multiplied by S on the way in (see sx_rqs_slab_bwd)
+    const float *scale;                 // max |adjoint| (device scalar) or null: see slab_scale_in / sx_rqs_slab_bwd
     uint32_t *flags;
     int64_t n_rows, ld_h;
     int l0, n_live, K, dim, H, n_slabs, n_chunks, n_groups, n_ranges, xcd_map;
     float left, right, bottom, top, ldj_scale;
 };
+
+// Power-of-two scale of the adjoints from their largest magnitude (a device scalar the caller reduced): S = 2^-ilogb(gmax),
+// so that S * gmax is in [1, 2).  Exact, and the same value in every kernel that derives it.
+__device__ __forceinline__ float slab_scale_in(const float *gmax) {
+    if (gmax == nullptr) return 1.f;
+    const float g = gmax[0];
+    if (!(g > 0.f) || !(g < 3.0e38f)) return 1.f;
+    return ldexpf(1.f, -ilogbf(g));
+}
+__device__ __forceinline__ float slab_scale_out(const float *gmax) {
+    if (gmax == nullptr) return 1.f;
+    const float g = gmax[0];
+    if (!(g > 0.f) || !(g < 3.0e38f)) return 1.f;
+    return ldexpf(1.f, ilogbf(g));
+}
 
 // A-operand fragments of one 32 x 32 tile for k16-step s (hi, lo), read from LDS
 struct afrag { h8 hi, lo; };
@@ -140,7 +155,7 @@ __global__ __launch_bounds__(256 * SPW, SPW == 1 ? 2 : 1) void rqs_slab_bwd_kern
     const bool col_ok = ci < k.n_live;
     const int col = col_ok ? (k.live_idx ? k.live_idx[ci] : k.l0 + ci) : 0;
     uint64_t any_bad = 0;
-    const float sc_in = k.scale ? k.scale[0] : 1.f, sc_out = k.scale ? k.scale[1] : 1.f;
+    const float sc_in = slab_scale_in(k.scale), sc_out = slab_scale_out(k.scale);
     const int c_begin = (int)((int64_t)k.n_chunks * range / k.n_ranges), c_end = (int)((int64_t)k.n_chunks * (range + 1) / k.n_ranges);
     const int iters = (c_end - c_begin + 3) >> 2;                      // passes: uniform over the workgroup
 #ifdef SX_SLAB_PROF
@@ -363,7 +378,7 @@ __global__ __launch_bounds__(256) void rqs_slab_w_reduce_kernel(const float *__r
         s3 += src[(size_t)(p + 3) * E];
     }
     for (; p < n_ranges; ++p) s0 += src[(size_t)p * E];
-    const float t = ((s0 + s1) + (s2 + s3)) * (scale ? scale[1] : 1.f);
+    const float t = ((s0 + s1) + (s2 + s3)) * slab_scale_out(scale);
     if (e < 96 * N2) {
         const int row = slot_rows[slab * 96 + e / N2], colh = e % N2;
         if (row >= 0 && colh < H) dW[(int64_t)row * ldw + colh] = t;
@@ -377,7 +392,8 @@ __global__ __launch_bounds__(256) void rqs_slab_w_reduce_kernel(const float *__r
 template <int HT>
 __global__ __launch_bounds__(256) void rqs_slab_dh_reduce_kernel(const float *__restrict__ part, int n_slabs, int n_chunks,
                                                                  int64_t n_rows, int H, float *__restrict__ gh, int64_t ld,
-                                                                 const float *__restrict__ scale) {
+                                                                 const float *__restrict__ scale, const float *__restrict__ h_tanh,
+                                                                 int64_t ld_h) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;         // one 16 B piece: (chunk, m, g, lane)
     const int64_t total = (int64_t)n_chunks * HT * 256;
     if (idx >= total) return;
@@ -387,7 +403,7 @@ __global__ __launch_bounds__(256) void rqs_slab_dh_reduce_kernel(const float *__
         const f32x4 v = src[(size_t)p * total];
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    const float us = scale ? scale[1] : 1.f;
+    const float us = slab_scale_out(scale);
     s.x *= us; s.y *= us; s.z *= us; s.w *= us;
     const int lane = (int)(idx & 63), g = (int)((idx >> 6) & 3), m = (int)((idx >> 8) % HT);
     const int64_t c = idx / (HT * 256);
@@ -395,6 +411,13 @@ __global__ __launch_bounds__(256) void rqs_slab_dh_reduce_kernel(const float *__
     const int f0 = 32 * m + 8 * g + 4 * (lane >> 5);
     if (row >= n_rows) return;
     float *dst = gh + row * ld + f0;
+    if (h_tanh != nullptr) {                    // h = tanh(a): dL/da = dL/dh (1 - h^2)
+        const float *hp = h_tanh + row * ld_h + f0;
+        if (f0 + 0 < H) s.x *= 1.f - hp[0] * hp[0];
+        if (f0 + 1 < H) s.y *= 1.f - hp[1] * hp[1];
+        if (f0 + 2 < H) s.z *= 1.f - hp[2] * hp[2];
+        if (f0 + 3 < H) s.w *= 1.f - hp[3] * hp[3];
+    }
     if (f0 + 0 < H) dst[0] = s.x;
     if (f0 + 1 < H) dst[1] = s.y;
     if (f0 + 2 < H) dst[2] = s.z;
@@ -431,8 +454,8 @@ extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *g
                                int32_t hidden, const float *w_fwd, const float *w_bwd, const int32_t *slot_rows, float *gx,
                                float *gh, int64_t ld_gh, float *dW, int64_t ldw, float *db, const int32_t *live_idx,
                                int32_t live_start, int32_t n_live, int32_t n_bins, float left, float right, float bottom,
-                               float top, int64_t n_rows, int32_t dim, float ldj_scale, const float *scale, float *scratch,
-                               uint32_t *err_flag, void *stream) {
+                               float top, int64_t n_rows, int32_t dim, float ldj_scale, int32_t tanh_hidden, const float *scale,
+                               float *scratch, uint32_t *err_flag, void *stream) {
     SX_REQUIRE(x && gout && gldj && h && w_fwd && w_bwd && slot_rows && gx && gh && dW && db && scratch,
                "sx_rqs_slab_bwd: null pointer");
     SX_REQUIRE(dim > 0 && n_live > 0 && n_live <= dim && n_rows >= 0, "sx_rqs_slab_bwd: bad sizes");
@@ -504,10 +527,10 @@ extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *g
     const int64_t pieces = (int64_t)n_chunks * HT * 256;
     if (HT == 1)
         hipLaunchKernelGGL(rqs_slab_dh_reduce_kernel<1>, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, k.dh_part,
-                           n_groups, n_chunks, n_rows, (int)hidden, gh, ld_gh, scale);
+                           n_groups, n_chunks, n_rows, (int)hidden, gh, ld_gh, scale, tanh_hidden ? h : nullptr, ld_h);
     else
         hipLaunchKernelGGL(rqs_slab_dh_reduce_kernel<2>, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, k.dh_part,
-                           n_groups, n_chunks, n_rows, (int)hidden, gh, ld_gh, scale);
+                           n_groups, n_chunks, n_rows, (int)hidden, gh, ld_gh, scale, tanh_hidden ? h : nullptr, ld_h);
     SX_LAUNCH_CHECK();
     return SX_OK;
 }

@@ -323,13 +323,13 @@ class Coupling(Transform):
                     torch.from_numpy(rows.astype(np.int64)).to(x2.device),
                     None if contiguous else torch.from_numpy(live.astype(np.int32)).to(x2.device))
         mask_t, rows_t, live_idx = self._programs.get(key, build)
+        if is_spline and reverse and self._slab_backward_ok(net, sp):
+            return self._autograd_inverse_slab(x2, lat2, mask_t, rows_t, live, live_idx)
         z = x2 * mask_t                                                              # coupling.py:61
         if d == 1:
             z = z * 0                                                                # coupling.py:62-63
         if lat2 is not None:
             z = torch.cat([z, lat2], -1)                                             # coupling.py:64-65
-        if is_spline and reverse and self._slab_backward_ok(net, sp):
-            return self._autograd_inverse_slab(x2, lat2, z, rows_t, live, live_idx)
         if isinstance(net, MLP):
             params = net.forward_autograd(z, rows_t)
         else:                                                                        # any nn.Module: torch's own graph
@@ -368,11 +368,17 @@ class Coupling(Transform):
             return y, ldj
         return self._run_spline(x2, lat2, True, True, 1.0)
 
-    def _autograd_inverse_slab(self, x2, lat2, z, rows_t, live, live_idx):
+    def _autograd_inverse_slab(self, x2, lat2, mask_t, rows_t, live, live_idx):
         from .spline import RQSCouplingSlab, slab_slot_rows
         from ..net.mlp import SelectRows
         sp, net = self.transform, self.transform.latent_net
-        h, last, _ = net.hidden_autograd(z)
+        # conditioner input cat[x * mask, latent] (coupling.py:61-65) with the mask folded into the first layer's weight
+        col_mask = mask_t * 0 if x2.shape[1] == 1 else mask_t                        # coupling.py:62-63
+        if lat2 is not None:
+            col_mask = torch.cat([col_mask, torch.ones(lat2.shape[1], dtype=torch.float32, device=x2.device)])
+        # (a Tanh right before the last Linear is applied inside the op: its backward rides on the kernel that reduces dL/dh)
+        h, last, _, pre_tanh = net.hidden_autograd(x2 if lat2 is None else torch.cat([x2, lat2], -1), col_mask, pre_tanh=True,
+                                                   want_flag=True)
         H = h.shape[1]
 
         def build():
@@ -382,7 +388,7 @@ class Coupling(Transform):
         plan = self._programs.get(('slab', x2.shape[1], H, str(x2.device)), build)
         W2, b2 = SelectRows.apply(last.weight, rows_t), SelectRows.apply(last.bias, rows_t)
         return RQSCouplingSlab.apply(x2, h, W2, b2, lambda xx: self._inverse_rows_nograd(xx, lat2), plan, live_idx,
-                                     int(live[0]), len(live), sp.n_bins, sp.lower, sp.upper)
+                                     int(live[0]), len(live), sp.n_bins, sp.lower, sp.upper, pre_tanh)
 
     # ---- reference method set (coupling.py:69-95) -----------------------------------------------------------
     def forward(self, x, latent=None, reverse: bool = False, **kwargs):

@@ -94,7 +94,8 @@ def slab_slot_rows(n_live: int, n_bins: int):
 
 class RQSCouplingSlab(torch.autograd.Function):
     """(x_out, row log-det) of an inverse quadratic-spline COUPLING as a differentiable op of (x, h, W2, b2): h [N, H] is the
-    conditioner's last hidden activation (torch graph upstream), (W2, b2) the rows of its last Linear that parameterise the
+    conditioner's last hidden activation (torch graph upstream; or, with pre_tanh, the pre-activation of a final Tanh, which the
+    op then applies and differentiates itself -- the tanh backward rides on the kernel that reduces dL/dh), (W2, b2) the rows of its last Linear that parameterise the
     transformed columns.  The forward is the coupling's own no-graph evaluation (`evaluate(x2)` -> (y, ldj)); the backward is
     sx_rqs_slab_bwd: spline reverse mode + dW2 / db2 / dL/dh in one kernel that keeps each slab of W2 in LDS, so the
     [N, n_live * (3K-1)] parameter tensor (spline.py:82-86) and its gradient never reach HBM.  Needs H <= 64, K <= 16 and the
@@ -105,18 +106,20 @@ class RQSCouplingSlab(torch.autograd.Function):
         return hidden <= 64 and n_bins <= 16 and _hip.get_gemm_precision() != 'exact'
 
     @staticmethod
-    def forward(ctx, x2, h, W2, b2, evaluate, plan, live_idx, live_start, n_live, n_bins, lower, upper):
+    def forward(ctx, x2, h, W2, b2, evaluate, plan, live_idx, live_start, n_live, n_bins, lower, upper, pre_tanh=False):
         x2 = x2.contiguous()
         with torch.no_grad():
             y, ldj = evaluate(x2)
+            if pre_tanh:                    # `h` is the pre-activation of a Tanh: applied here, differentiated in backward
+                h = torch.tanh(h)
         ctx.save_for_backward(x2, h, W2, b2)
-        ctx.meta = (plan, live_idx, live_start, n_live, n_bins, float(lower), float(upper))
+        ctx.meta = (plan, live_idx, live_start, n_live, n_bins, float(lower), float(upper), bool(pre_tanh))
         return y, ldj
 
     @staticmethod
     def backward(ctx, gy, gldj):
         x2, h, W2, b2 = ctx.saved_tensors
-        (slot_rows, hid_idx), live_idx, live_start, n_live, n_bins, lower, upper = ctx.meta
+        (slot_rows, hid_idx), live_idx, live_start, n_live, n_bins, lower, upper, pre_tanh = ctx.meta
         n, d = x2.shape
         dev = x2.device
         H = h.shape[1]
@@ -140,16 +143,16 @@ class RQSCouplingSlab(torch.autograd.Function):
         gb = torch.zeros_like(b2)
         with _hip.device_of(x2):
             sc = _hip.scratch(dev, lib.sx_rqs_slab_scratch_floats(n, n_live, H))
-        # adjoints normalised to ~1 by a power of two (exact): the parameter gradients are fp16 x 3 GEMM operands, and
-        # dL/dlog_prob = 1/N of a mean loss would put them under fp16's normal range (no host sync: S stays on the device)
-        gmax = torch.maximum(gy.abs().max(), gldj.abs().max())
-        S = torch.exp2(-torch.floor(torch.log2(gmax.clamp(1e-30, 1e30))))
-        scale = torch.stack([S, 1.0 / S]).to(torch.float32)
+        # the kernels normalise the adjoints by a power of two derived from their largest magnitude (exact): the parameter
+        # gradients are fp16 x 3 GEMM operands, and dL/dlog_prob = 1/N of a mean loss would put them under fp16's normal
+        # range.  The maximum stays on the device (no host sync).
+        inf = float('inf')
+        scale = torch.maximum(torch.linalg.vector_norm(gy, ord=inf), torch.linalg.vector_norm(gldj, ord=inf)).reshape(1)
         _hip.call('sx_rqs_slab_bwd', x2, x2.data_ptr(), gy.data_ptr(), gldj.data_ptr(), h.data_ptr(), h.stride(0), H,
                   packs.data_ptr(), packs.data_ptr() + 4 * n_fwd, slot_rows.data_ptr(), gx.data_ptr(), gh.data_ptr(),
                   gh.stride(0), gW.data_ptr(), gW.stride(0), gb.data_ptr(), _hip.ptr(live_idx), live_start, n_live, n_bins,
-                  lower, upper, lower, upper, n, d, 1.0, scale.data_ptr(), sc.data_ptr(), flag)
-        return gx, gh, gW, gb, None, None, None, None, None, None, None, None
+                  lower, upper, lower, upper, n, d, 1.0, int(pre_tanh), scale.data_ptr(), sc.data_ptr(), flag)
+        return gx, gh, gW, gb, None, None, None, None, None, None, None, None, None
 
 
 def run_cubic_kernel(x2, params, params_stride, live_idx, live_start, n_live, n_bins, lower, upper, reverse, want_ldj,

@@ -153,17 +153,32 @@ class MLP(StructureTracked, nn.Module):
         return max([w.shape[0] for (w, _) in ls[:-1]] + [1])
 
     # -- differentiable evaluation (layer-wise training path) -------------------------------------------
-    def hidden_autograd(self, x2: torch.Tensor):
+    def hidden_autograd(self, x2: torch.Tensor, col_mask: Optional[torch.Tensor] = None, pre_tanh: bool = False,
+                        want_flag: bool = False):
         """Everything before the last Linear, with a graph -> (last hidden activation [N, H], the last Linear, the layers
-        after it (a final activation or none))."""
+        after it (a final activation or none)).  `col_mask` [in_dim] (0 / 1): the first Linear sees x2 * col_mask -- applied
+        to its [H, in] weight instead of the [N, in] rows (x_j (w_ij m_j) = (x_j m_j) w_ij exactly for a 0 / 1 mask), which
+        saves a pass over the batch in the forward and another in the backward.  `pre_tanh`: when the last hidden activation is
+        Tanh, stop BEFORE it (-> the pre-activation; with want_flag the 4th result says whether that happened)."""
         layers = list(self.net)
         tail = []
         if self.final_activation_name is not None:                            # mlp.py:55-56
             layers, tail = layers[:-1], layers[-1:]
+        body = layers[:-1]
+        if pre_tanh and len(body) >= 2 and isinstance(body[-1], nn.Tanh):
+            body = body[:-1]                      # the caller applies (and differentiates) the last tanh itself
+        else:
+            pre_tanh = False
         h = x2
-        for layer in layers[:-1]:
-            h = batch_linear(h, layer.weight, layer.bias) if isinstance(layer, nn.Linear) else layer(h)
-        return h, layers[-1], tail
+        for i, layer in enumerate(body):
+            if isinstance(layer, nn.Linear):
+                W = layer.weight * col_mask if (i == 0 and col_mask is not None) else layer.weight
+                h = batch_linear(h, W, layer.bias)
+            else:
+                if i == 0 and col_mask is not None:
+                    h = h * col_mask
+                h = layer(h)
+        return (h, layers[-1], tail, pre_tanh) if want_flag else (h, layers[-1], tail)
 
     def forward_autograd(self, x2: torch.Tensor, rows: Optional[torch.Tensor] = None) -> torch.Tensor:
         """The network on [N, in] rows with a graph: torch activations, `batch_linear` layers.  `rows` selects the

@@ -49,7 +49,7 @@ def main():
     def run():
         _hip.call('sx_rqs_slab_bwd', x, x.data_ptr(), gy.data_ptr(), gl.data_ptr(), h.data_ptr(), h.stride(0), H, packs.data_ptr(),
                   packs.data_ptr() + 4 * n_fwd, slot_rows.data_ptr(), gx.data_ptr(), gh.data_ptr(), gh.stride(0), gW.data_ptr(),
-                  gW.stride(0), gb.data_ptr(), None, n_live, n_live, K, 0.0, 1.0, 0.0, 1.0, n, d, 1.0, None, sc.data_ptr(), flag)
+                  gW.stride(0), gb.data_ptr(), None, n_live, n_live, K, 0.0, 1.0, 0.0, 1.0, n, d, 1.0, 0, None, sc.data_ptr(), flag)
     for _ in range(3):
         run()
     torch.cuda.synchronize()
