@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of every BASELINE.json config on one MI355X (not the driver's contract bench: see bench.py).
 
-    python tools/bench_configs.py [cfg1 cfg2 cfg2_f32 cfg3 cfg4 ...] [--rows N] [--train] [--graph]
+    python tools/bench_configs.py [cfg1 cfg2 cfg2_f32 cfg3 cfg4 ...] [--rows N] [--train] [--train-only] [--graph]
 
 Prints one JSON line per config: rows/s of log_prob, ms per batch, launches per batch.  --graph adds a line with the
 same call captured once into a HIP graph (torch.cuda.CUDAGraph) and replayed: what a launch-bound small batch costs
@@ -64,7 +64,7 @@ def main():
         x = torch.randn(rows, dim, device=dev).to(dt)
         fused = flow._fused_program(True, dim, 0, dev) is not None
         with torch.no_grad():
-            ms = timed(lambda: flow.log_prob(x))
+            ms = float('nan') if '--train-only' in sys.argv else timed(lambda: flow.log_prob(x))
             lp = flow.log_prob(x)
         if '--graph' in sys.argv:
             side = torch.cuda.Stream()
