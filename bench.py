@@ -161,6 +161,36 @@ def time_extra_config(name, workload, flow, x, steps, warmup, flops_per_row, byt
             'roofline': roof}
 
 
+def time_training_step(name, workload, flow, x, steps, note):
+    """Training step beside the inference lines: forward + backward of loss = -log_prob(x).mean(), all
+    parameter gradients; median of `steps` event-timed steps after warm-up."""
+    import torch
+
+    def step():
+        for p_ in flow.parameters():
+            p_.grad = None
+        loss = -flow.log_prob(x).mean()
+        loss.backward()
+        return loss
+
+    for _ in range(3):
+        loss = step()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(steps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        loss = step()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    ts.sort()
+    ms = ts[len(ts) // 2]
+    finite = bool(torch.isfinite(loss).item()) and all(bool(torch.isfinite(p_.grad).all()) for p_ in flow.parameters())
+    return {'name': name, 'workload': workload, 'steps': steps, 'ms_per_step': ms, 'value': x.shape[0] / (ms * 1e-3),
+            'unit': 'samples/s', 'dtype': 'f32', 'finite': finite, 'note': note}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -345,6 +375,24 @@ def main():
                                                       'runs the collapsed single matrix (458,752): frac_collapsed'}))
                 del f4, x4
             result['configs'] = cfgs
+            # training steps (forward + backward) of the two trainable BASELINE families, same process
+            tr = []
+            torch.manual_seed(0)
+            f2 = fd.build_flow(st, fd.cfg2_desc(), 64).to(dev)
+            x2t = torch.randn(ROWS_PER_GPU, 64, device=dev, generator=gen)
+            tr.append(time_training_step('cfg2_train', 'cfg2 flow, 2^20 rows fp32: loss = -log_prob.mean(), backward to every '
+                                         'parameter', f2, x2t, 10,
+                                         'layer-major backward: weight gradients contracted in the kernel (DESIGN 4.3)'))
+            del f2, x2t
+            torch.manual_seed(0)
+            f3 = fd.build_flow(st, fd.cfg3_desc(), 64).to(dev)
+            x3t = torch.randn(ROWS_PER_GPU // 4, 64, device=dev, generator=gen)
+            tr.append(time_training_step('cfg3_train', 'cfg3 flow, 2^18 rows fp32: loss = -log_prob.mean(), backward to every '
+                                         'parameter', f3, x3t, 10,
+                                         'spline backward fused with the last conditioner layer, no [N, 1504] parameter tensor '
+                                         '(sx_rqs_slab_bwd, DESIGN 4.3.1); HBM bytes per step in profiles/pmc_training_cfg3_fused.json'))
+            del f3, x3t
+            result['training'] = tr
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(desc, state)
     if world > 1:

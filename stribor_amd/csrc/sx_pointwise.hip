@@ -8,6 +8,7 @@
 // row is a power-of-two group inside a wave, float atomics otherwise.  Cumsum is a sequential scan per row (one lane
 // per row, running sum in double) so that it reproduces torch.cumsum bit for bit (test_cumsum.py asserts equality).
 #include "sx_common.h"
+#include <stdlib.h>
 
 __device__ __forceinline__ float pw_softplus(float v) { return v > 20.f ? v : log1pf(expf(v)); }   // F.softplus
 
@@ -257,6 +258,76 @@ __global__ __launch_bounds__(256) void cumsum_vec_kernel(const float *__restrict
     }
 }
 
+// The same with the NEXT group's rows in flight while the current group is scanned (dim <= 64: the wave's 64 x dim span
+// is at most 16 float4 per lane).  A wave of cumsum_vec_kernel alternates load / scan / store phases, so only a third of the
+// resident waves have loads outstanding at any time; here every wave always has one group (16 KB at dim = 64) in flight.
+__global__ __launch_bounds__(256) void cumsum_vec_pipe_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t n_rows,
+                                                              int dim, int diff) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n_groups = (n_rows + 63) >> 6;
+    const int RS = dim + 4, Q = dim >> 2;                 // Q <= 16 float4 per row
+    float *sp = pw_smem + (size_t)wave * 64 * RS;
+    const float inv_q = 1.0f / (float)Q;
+    const int64_t step = (int64_t)gridDim.x * 4;
+    f32x4 nxt[16];
+    auto fetch = [&](int64_t grp) {
+        if (grp >= n_groups) return;
+        const int64_t r0 = grp << 6;
+        const int rows = (int)((n_rows - r0) < 64 ? (n_rows - r0) : 64);
+        const int total4 = rows * Q;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(x + r0 * dim);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const int i = lane + 64 * kk;
+            if (kk < Q && i < total4) nxt[kk] = src[i];
+        }
+    };
+    int64_t grp = (int64_t)blockIdx.x * 4 + wave;
+    fetch(grp);
+    for (; grp < n_groups; grp += step) {
+        const int64_t r0 = grp << 6;
+        const int rows = (int)((n_rows - r0) < 64 ? (n_rows - r0) : 64);
+        const int total4 = rows * Q;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const int i = lane + 64 * kk;
+            if (kk < Q && i < total4) {
+                const int r = (int)(((float)i + 0.5f) * inv_q), c4 = i - r * Q;      // i / Q, exact for i < 2^22
+                *reinterpret_cast<f32x4 *>(sp + r * RS + 4 * c4) = nxt[kk];
+            }
+        }
+        fetch(grp + step);                                   // lands during the scan and the stores below
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < rows) {
+            double acc = 0.0;                                // cumsum.py:62 (see cumsum_vec_kernel)
+            float prev = 0.f;
+            f32x4 *row = reinterpret_cast<f32x4 *>(sp + lane * RS);
+            for (int c4 = 0; c4 < Q; ++c4) {
+                const f32x4 v = row[c4];
+                f32x4 o;
+                if (diff) {
+                    o.x = v.x - prev; o.y = v.y - v.x; o.z = v.z - v.y; o.w = v.w - v.z;
+                    prev = v.w;
+                } else {
+                    acc += (double)v.x; o.x = (float)acc;
+                    acc += (double)v.y; o.y = (float)acc;
+                    acc += (double)v.z; o.z = (float)acc;
+                    acc += (double)v.w; o.w = (float)acc;
+                }
+                row[c4] = o;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        f32x4 *dst = reinterpret_cast<f32x4 *>(y + r0 * dim);
+        for (int i = lane; i < total4; i += 64) {
+            const int r = (int)(((float)i + 0.5f) * inv_q), c4 = i - r * Q;
+            dst[i] = *reinterpret_cast<const f32x4 *>(sp + r * RS + 4 * c4);
+        }
+    }
+}
+
 // ---- backward (training, layer-wise path): dL/dx = gy * d(out)/dx + gldj[row] * d(ld)/dx, per element ----------------
 __device__ __forceinline__ float pw_grad(int kind, float param, float x, float gy, float gl) {
     switch (kind) {
@@ -346,6 +417,20 @@ extern "C" int sx_pointwise(const void *x, void *y, float *ldj, float *ldiag, in
                     (void)hipFuncSetAttribute((const void *)cumsum_vec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
                     set_to[dev & 63] = lds4;
                 }
+                static const bool no_pipe = getenv("SX_CUMSUM_NO_PIPE") != nullptr;          // experiments, read once
+                if (dim <= 64 && !no_pipe) {
+                    static size_t set_p[64];
+                    if (lds4 > 48 * 1024 && set_p[dev & 63] != lds4) {
+                        (void)hipFuncSetAttribute((const void *)cumsum_vec_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+                        set_p[dev & 63] = lds4;
+                    }
+                    // persistent grid: as many workgroups as are resident at once, each streaming its share of the groups
+                    int64_t per_cu = (160 * 1024) / (int64_t)lds4;
+                    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+                    const int64_t gp = g < 256 * per_cu ? g : 256 * per_cu;
+                    hipLaunchKernelGGL(cumsum_vec_pipe_kernel, dim3((int)gp), dim3(256), lds4, st, (const float *)x, (float *)y, n_rows,
+                                       dim, kind == SX_PW_DIFF);
+                } else
                 hipLaunchKernelGGL(cumsum_vec_kernel, dim3((int)g), dim3(256), lds4, st, (const float *)x, (float *)y, n_rows, dim,
                                    kind == SX_PW_DIFF);
                 SX_LAUNCH_CHECK();
