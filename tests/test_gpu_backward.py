@@ -152,6 +152,8 @@ def test_spline_flow_log_prob_backward_matches_autograd_of_oracle(n, dim, hidden
     (333, 7, [10], 4, 3, 'Tanh'),               # odd live count, hidden rows not 16-byte aligned, conditional flow
     (500, 12, [24, 40], 9, 0, 'ELU'),           # deeper conditioner, another activation (no one-layer fused forward)
     (31, 6, [33], 16, 0, 'Tanh'),               # fewer rows than one chunk; hidden spills into a second tile
+    (700, 8, [32], 8, 0, 'Tanh'),               # one full hidden tile (vector loads), run-time bin count
+    (4100, 10, [32], 16, 2, 'Tanh'),            # one hidden tile, K = 16 straight-line form, odd number of slabs, several ranges
 ])
 def test_spline_slab_backward_matches_per_row_parameter_path(monkeypatch, n, dim, hidden, K, latent_dim, act):
     """sx_rqs_slab_bwd (spline backward fused with the last conditioner layer: no [N, n_live*(3K-1)] tensor) against the
@@ -187,6 +189,43 @@ def test_spline_slab_backward_matches_per_row_parameter_path(monkeypatch, n, dim
         # the two paths round the parameters differently (fp16 x 3 MFMA vs the library's fp32 GEMM) and the spline's
         # gradient amplifies that: same bound as the fp64-oracle test above
         assert (a - b).abs().max().item() <= 3e-4 * scale + 1e-8, (name, (a - b).abs().max().item(), scale)
+
+
+def test_spline_slab_backward_reports_fp16_range_and_exact_mode_bypasses_it():
+    """The slab backward's GEMM operands are fp16 x 3: a hidden activation beyond 65504 must not come back as a plausible
+    gradient (NaN rows + GemmRangeError at the next check), and set_gemm_precision('exact') takes the per-row path."""
+    torch.manual_seed(5)
+    dim, K = 8, 6
+    P = 3 * K - 1
+
+    def make():
+        net = st.net.MLP(dim, [16], dim * P, activation='ReLU')
+        return st.NormalizingFlow(st.UnitNormal(dim), [st.Coupling(st.Spline(dim, K, latent_net=net, lower=-3, upper=3,
+                                                                           spline_type='quadratic'), mask='ordered_right_half')]).to(DEV)
+    flow = make()
+    with torch.no_grad():
+        lin0 = flow.transforms[0].transform.latent_net.net[0]
+        lin0.weight.mul_(1e6)                              # ReLU hidden activations ~1e6
+        flow.transforms[0].transform.latent_net.net[2].weight.mul_(1e-7)
+    x = torch.randn(200, dim, device=DEV).requires_grad_(True)
+    st.set_gemm_precision('exact')
+    try:
+        lp = flow.log_prob(x)
+        (-lp.mean()).backward()
+        torch.cuda.synchronize()
+        st.check_errors()
+        g_exact = [p.grad.clone() for p in flow.parameters()]
+        assert all(torch.isfinite(g).all() for g in g_exact)
+    finally:
+        st.set_gemm_precision('fast')
+    for p in flow.parameters():
+        p.grad = None
+    x2 = x.detach().clone().requires_grad_(True)
+    with pytest.raises(st.GemmRangeError):
+        lp = flow.log_prob(x2)
+        (-lp.mean()).backward()
+        torch.cuda.synchronize()
+        st.check_errors()
 
 
 def test_spline_flow_training_step_reduces_loss():
