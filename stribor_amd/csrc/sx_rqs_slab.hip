@@ -411,7 +411,16 @@ __global__ __launch_bounds__(256) void rqs_slab_dh_reduce_kernel(const float *__
     const int f0 = 32 * m + 8 * g + 4 * (lane >> 5);
     if (row >= n_rows) return;
     float *dst = gh + row * ld + f0;
-    if (h_tanh != nullptr) {                    // h = tanh(a): dL/da = dL/dh (1 - h^2)
+    const bool vec = f0 + 3 < H && ((ld | ld_h) & 3) == 0 && ((reinterpret_cast<uintptr_t>(gh) | reinterpret_cast<uintptr_t>(h_tanh)) & 15) == 0;
+    if (vec) {                                  // whole 16-byte pieces (H a multiple of 4, aligned rows): one load, one store
+        if (h_tanh != nullptr) {                // h = tanh(a): dL/da = dL/dh (1 - h^2)
+            const f32x4 hv = *reinterpret_cast<const f32x4 *>(h_tanh + row * ld_h + f0);
+            s.x *= 1.f - hv.x * hv.x; s.y *= 1.f - hv.y * hv.y; s.z *= 1.f - hv.z * hv.z; s.w *= 1.f - hv.w * hv.w;
+        }
+        *reinterpret_cast<f32x4 *>(dst) = s;
+        return;
+    }
+    if (h_tanh != nullptr) {
         const float *hp = h_tanh + row * ld_h + f0;
         if (f0 + 0 < H) s.x *= 1.f - hp[0] * hp[0];
         if (f0 + 1 < H) s.y *= 1.f - hp[1] * hp[1];
