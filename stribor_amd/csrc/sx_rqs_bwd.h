@@ -180,10 +180,17 @@ __device__ __forceinline__ float rqs_inverse_bwd_element(float *uw, int K, float
 // (~45 % of the instructions): hardware exp / rcp / log, fused multiply-adds, only the cumulative sums are selected in
 // the sweep (the four knots are formed afterwards), and the softmax-backward dot products come from the selected cumulative
 // sums:  sum_{k<b} p_k = (cs_b - b MIN) / norm,  p_b = (cs_{b+1} - cs_b - MIN) / norm.
+// `hook(slot)`, slot = 0..47 (a constant once the loops are unrolled), is called once per iteration of the three 16-step
+// loops (exp, knot sweep, output): the software-pipelined slab kernel issues the previous chunk's MFMAs from it, ~10 VALU apart.
+struct rqsb_no_hook {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+
 typedef float rqsb_f16v __attribute__((ext_vector_type(16)));
-template <int KC>
+template <int KC, class Hook = rqsb_no_hook>
 __device__ __forceinline__ float rqs_inverse_bwd_regs(rqsb_f16v &Wp, rqsb_f16v &Hp, rqsb_f16v &Dp, int K, float xv, float Ao,
-                                                      float Al, float left, float right, float bottom, float top, bool valid) {
+                                                      float Al, float left, float right, float bottom, float top, bool valid,
+                                                      Hook &&hook = Hook{}) {
     constexpr float LOG2E = 1.44269504088896341f;
     const int Kn = KC ? KC : K;
     const float bconst = 0.5397424172369522f;                       // log(exp(1 - 1e-3) - 1), :81 boundary derivative constant
@@ -201,7 +208,7 @@ __device__ __forceinline__ float rqs_inverse_bwd_regs(rqsb_f16v &Wp, rqsb_f16v &
         }
     float sw = 0.f, sh = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k)
+    for (int k = 0; k < 16; ++k) {
         if (KC ? (k < KC) : true) {
             const bool used = KC ? true : (k < K);
             const float ew = used ? __builtin_amdgcn_exp2f((Wp[k] - mw) * LOG2E) : 0.f;
@@ -211,6 +218,8 @@ __device__ __forceinline__ float rqs_inverse_bwd_regs(rqsb_f16v &Wp, rqsb_f16v &
             sw += ew;
             sh += eh;
         }
+        hook(k);
+    }
     const float inv_sw = __builtin_amdgcn_rcpf(sw), inv_sh = __builtin_amdgcn_rcpf(sh);
     const float nw = norm * inv_sw, nh = norm * inv_sh;              // bin size_k = MIN + e_k * n   (:101-105)
     // one sweep: cumulative sums; the heights' knots are compared with the input (search_sorted.py:4-5), and the cumulative
@@ -219,7 +228,7 @@ __device__ __forceinline__ float rqs_inverse_bwd_regs(rqsb_f16v &Wp, rqsb_f16v &
     float csw = 0.f, csh = 0.f, csw_b = 0.f, csw_n = 0.f, kh_b = bottom, kh_n = top;
     bool have_next = false;
 #pragma unroll
-    for (int j = 1; j <= 16; ++j)
+    for (int j = 1; j <= 16; ++j) {
         if (KC ? (j <= KC) : true) {
             const bool used = KC ? true : (j <= K);
             const bool last = (j == Kn);
@@ -236,6 +245,8 @@ __device__ __forceinline__ float rqs_inverse_bwd_regs(rqsb_f16v &Wp, rqsb_f16v &
             kh_n = nxt ? kh : kh_n;
             have_next = have_next || nxt;
         }
+        hook(16 + j - 1);
+    }
     const bool first = (b == 0), lastbin = (b + 1 == Kn);
     const float cw_b = first ? left : fmaf(span_w, csw_b, left);
     const float cw_n = lastbin ? right : fmaf(span_w, csw_n, left);
@@ -272,6 +283,7 @@ __device__ __forceinline__ float rqs_inverse_bwd_regs(rqsb_f16v &Wp, rqsb_f16v &
         Wp[k] = used ? Wp[k] * (lt ? w_lo : (eq ? w_at : w_hi)) : 0.f;
         Hp[k] = used ? Hp[k] * (lt ? h_lo : (eq ? h_at : h_hi)) : 0.f;
         Dp[k] = (k < Kn - 1) ? (eq ? g_un : (k + 1 == b ? g_ub : 0.f)) : 0.f;
+        hook(32 + k);
     }
     return inside ? A.Axin : Ao;                                         // tails: out = x
 }
