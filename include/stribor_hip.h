@@ -155,7 +155,8 @@ int sx_rqs_inverse_bwd(const float *x, const float *gout, const float *gldj, con
  *   handed to the packers, or -1 (padding).
  *   w_fwd: sx_pack_linear(W2, b2, row_idx = slot_rows, col_idx = hidden slots, m_tiles = slots/32, k_tiles = ceil(hidden/32),
  *          SX_GEMM_F16X3);  w_bwd: the same with transpose = 1 (m_tiles = ceil(hidden/32), k_tiles = slots/32, no bias).
- *   Outputs: gx [n_rows, dim] (transformed columns written), gh [n_rows, ld_gh] = dL/dh, dW [rows of W2, ldw] and db
+ *   Outputs: gx [n_rows, dim] (transformed columns written), gh [n_rows, ld_gh] = dL/dh (NULL: the dh partials are left in
+ *   `scratch` for sx_rqs_slab_l1_bwd), dW [rows of W2, ldw] and db
  *   (rows named by slot_rows written), all fp32.  scratch: sx_rqs_slab_scratch_floats(n_rows, n_live, hidden) floats,
  *   16-byte aligned, caller-owned.  err_flag (nullable) receives SX_FLAG_F16_RANGE when h or a parameter gradient leaves
  *   fp16's range (those rows' gx are NaN).
@@ -172,6 +173,25 @@ int sx_rqs_slab_bwd(const float *x, const float *gout, const float *gldj, const 
                     int32_t n_bins, float left, float right, float bottom, float top, int64_t n_rows, int32_t dim,
                     float ldj_scale, int32_t tanh_hidden, const float *scale, float *scratch, uint32_t *err_flag,
                     void *stream);
+
+/* Backward of the conditioner's FIRST layer behind sx_rqs_slab_bwd, for Linear - Tanh - Linear conditioners without a latent
+ * input (net/mlp.py:26-58 with one hidden layer; coupling.py:61: the layer sees x * mask):  a = W1m x + b1, h = tanh(a),
+ * W1m = W1 with the mask folded into its columns.  Call sx_rqs_slab_bwd with gh = NULL (the dh partials stay in its scratch),
+ * then this on the same stream: one pass over the rows sums the partials, applies 1 - h^2, writes
+ * gx[:, conditioning columns] = gout + W1m^T da (the transformed columns of gx were written by sx_rqs_slab_bwd) and contracts
+ * dW1 += da x^T, db1 += sum da on the matrix pipe.
+ *   slab_scratch: the scratch sx_rqs_slab_bwd was given (same n_rows, n_live, hidden);  h, x, gout, gx, scale: as there.
+ *   w1t: sx_pack_linear(W1m [hidden, dim], NULL, row_idx = column slots, col_idx = hidden slots, m_tiles = ceil(dim/32),
+ *        k_tiles = ceil(hidden/32), transpose = 1, SX_GEMM_F16X3).
+ *   cond_mask: HOST pointer, 2 words: bit c of word t = column 32 t + c is a conditioning column.
+ *   dW1 [hidden, ldw] and db1 [hidden] are ACCUMULATED into (zero them); col_map[ceil(dim/32)*32]: column -> column of dW1, or -1
+ *   (transformed columns: their weights do not exist in W1m).  scratch: sx_rqs_slab_l1_scratch_floats(dim, hidden) floats.
+ *   dim, hidden <= 64. */
+size_t sx_rqs_slab_l1_scratch_floats(int32_t dim, int32_t hidden);
+int sx_rqs_slab_l1_bwd(const float *slab_scratch, const float *h, int64_t ld_h, int32_t hidden, const float *x, const float *gout,
+                       const float *w1t, const uint32_t *cond_mask, float *gx, float *dW1, int64_t ldw, float *db1,
+                       const int32_t *col_map, int32_t n_live, int64_t n_rows, int32_t dim, const float *scale, float *scratch,
+                       uint32_t *err_flag, void *stream);
 
 /* Monotone cubic spline, element-wise part -- spline_type='cubic', the reference's default
  * (stribor/util/cubic_spline.py:21-251, util/search_sorted.py:3-5, flows/spline.py:59-61,82-86).

@@ -433,6 +433,182 @@ __global__ __launch_bounds__(256) void rqs_slab_dh_reduce_kernel(const float *__
     if (f0 + 3 < H) dst[3] = s.w;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Backward of the conditioner's FIRST layer behind the slab kernel, for Linear - Tanh - Linear conditioners without a
+// latent input (cfg 3):  a = W1m x + b1 (W1m = W1 with the coupling mask folded into its columns), h = tanh(a).
+// One pass over the rows does what took a reduce kernel, a tanh backward, two library GEMMs, a weight-gradient kernel, a
+// clone and an add: per 32-row chunk it sums the slab groups' dh partials (fragment order = C tiles), applies 1 - h^2,
+// forms dz = W1m^T da by MFMA and writes  gx[:, conditioning columns] = gout + dz  (the transformed columns were written by
+// the slab kernel), and contracts dW1m += da x^T over the rows on the matrix pipe (turn / contract, as the slab kernel).
+// Everything stays in the power-of-two scaled domain of the slab kernel until it is stored.
+struct l1_args {
+    const float *part;            // [n_groups][n_chunks][HT][1024] dh partials
+    const float *h, *x, *gout;    // [N, ld_h], [N, dim], [N, dim]
+    const float *w1t;             // sx_pack_linear(W1m, transpose = 1): [XT][HT][1024]
+    float *gx;                    // [N, dim]
+    float *w_part;                // [gridDim][32 HT * 32 XT + 32 HT]
+    const float *scale;
+    uint32_t *flags;
+    int64_t n_rows, ld_h;
+    int n_groups, n_chunks, dim, H;
+    uint32_t cond_mask[2];        // bit c of word t: column 32 t + c is a conditioning column (receives gout + dz)
+};
+template <int HT, int XT>
+__global__ __launch_bounds__(256, 2) void rqs_slab_l1_bwd_kernel(const l1_args k) {
+    constexpr int N1 = 32 * XT, E1 = 32 * HT * N1 + 32 * HT;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(k.w1t);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
+        for (int i = threadIdx.x; i < XT * HT * 256; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const wptr w = make_wptr(0, lane);
+    const sel_t sel = make_sel(lane);
+    const int j = lane & 31, hh = lane >> 5;
+    f32x16 Aw[HT][XT];
+    float bsum[HT];
+#pragma unroll
+    for (int m = 0; m < HT; ++m) {
+        bsum[m] = 0.f;
+#pragma unroll
+        for (int xt = 0; xt < XT; ++xt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Aw[m][xt][r] = 0.f;
+    }
+    const float sc_out = slab_scale_out(k.scale);
+    const bool vec = (k.dim % 4 == 0) && (k.ld_h % 4 == 0) && k.H == 32 * HT && k.dim == 32 * XT &&
+                     ((reinterpret_cast<uintptr_t>(k.h) | reinterpret_cast<uintptr_t>(k.x) | reinterpret_cast<uintptr_t>(k.gout) |
+                       reinterpret_cast<uintptr_t>(k.gx)) & 15) == 0;
+    uint64_t any_bad = 0;
+    const size_t gstride = (size_t)k.n_chunks * HT * 1024;
+    for (int c = blockIdx.x * 4 + wave; c < k.n_chunks; c += gridDim.x * 4) {
+        rng_t rg{0};
+        const int64_t row0 = (int64_t)c * 32;
+        const int n_here = (int)((k.n_rows - row0) < 32 ? (k.n_rows - row0) : 32);
+        const bool row_ok = j < n_here;
+        const int jc = row_ok ? j : n_here - 1;
+        // ---- da = (sum of the groups' dh partials) (1 - h^2), C-fragment tiles (hidden x samples) ---------------------------------
+        btile<1> bga[HT];
+#pragma unroll
+        for (int m = 0; m < HT; ++m) {
+            tile<1> ga;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 *src = reinterpret_cast<const f32x4 *>(k.part + ((size_t)c * HT + m) * 1024) + g * 64 + lane;
+                f32x4 sum = src[0];
+                for (int p = 1; p < k.n_groups; ++p) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(src) + p * gstride);
+                    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+                }
+                const int f0 = 32 * m + 8 * g + 4 * hh;
+                const float *hp = k.h + (row0 + jc) * k.ld_h + f0;
+                f32x4 hv = {0.f, 0.f, 0.f, 0.f};
+                if (vec) hv = *reinterpret_cast<const f32x4 *>(hp);
+                else {
+                    if (f0 + 0 < k.H) hv.x = hp[0];
+                    if (f0 + 1 < k.H) hv.y = hp[1];
+                    if (f0 + 2 < k.H) hv.z = hp[2];
+                    if (f0 + 3 < k.H) hv.w = hp[3];
+                }
+                ga.v[0][4 * g + 0] = row_ok ? sum.x * (1.f - hv.x * hv.x) : 0.f;
+                ga.v[0][4 * g + 1] = row_ok ? sum.y * (1.f - hv.y * hv.y) : 0.f;
+                ga.v[0][4 * g + 2] = row_ok ? sum.z * (1.f - hv.z * hv.z) : 0.f;
+                ga.v[0][4 * g + 3] = row_ok ? sum.w * (1.f - hv.w * hv.w) : 0.f;
+            }
+            bga[m] = make_btile<1>(ga, rg);
+        }
+        // ---- x chunk as C tiles (columns x samples): the B side of the contraction ----------------------------------------------
+        tfrag tx[XT];
+#pragma unroll
+        for (int xt = 0; xt < XT; ++xt) {
+            tile<1> xv;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = 32 * xt + 8 * g + 4 * hh;
+                const float *xp = k.x + (row0 + jc) * k.dim + c0;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (vec) v = *reinterpret_cast<const f32x4 *>(xp);
+                else {
+                    if (c0 + 0 < k.dim) v.x = xp[0];
+                    if (c0 + 1 < k.dim) v.y = xp[1];
+                    if (c0 + 2 < k.dim) v.z = xp[2];
+                    if (c0 + 3 < k.dim) v.w = xp[3];
+                }
+                xv.v[0][4 * g + 0] = v.x; xv.v[0][4 * g + 1] = v.y; xv.v[0][4 * g + 2] = v.z; xv.v[0][4 * g + 3] = v.w;
+            }
+            float dummy = 0.f;
+            tx[xt] = turn_tile(make_btile<1>(xv, rg), sel, dummy);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- dz = W1m^T da;  gx[:, conditioning columns] = gout + dz ------------------------------------------------------------
+#pragma unroll
+        for (int xt = 0; xt < XT; ++xt) {
+            tile<1> dz;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dz.v[0][r] = 0.f;
+#pragma unroll
+            for (int m = 0; m < HT; ++m) gemm_tile<1>(w.wb, (xt * HT + m) * 1024, bga[m], dz);
+            const uint32_t cm = k.cond_mask[xt];
+            if (cm != 0u && row_ok) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c0 = 32 * xt + 8 * g + 4 * hh;
+                    const uint32_t bits = (cm >> (8 * g + 4 * hh)) & 15u;
+                    const size_t off = (size_t)(row0 + j) * k.dim + c0;
+                    const bool bad = rng_bad_sample(rg, lane);
+                    const float nanv = __builtin_nanf("");
+                    if (vec && bits == 15u) {
+                        const f32x4 go = *reinterpret_cast<const f32x4 *>(k.gout + off);
+                        f32x4 o = {go.x + dz.v[0][4 * g] * sc_out, go.y + dz.v[0][4 * g + 1] * sc_out, go.z + dz.v[0][4 * g + 2] * sc_out,
+                                   go.w + dz.v[0][4 * g + 3] * sc_out};
+                        if (bad) o = f32x4{nanv, nanv, nanv, nanv};
+                        *reinterpret_cast<f32x4 *>(k.gx + off) = o;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (((bits >> e) & 1u) && c0 + e < k.dim) k.gx[off + e] = bad ? nanv : k.gout[off + e] + dz.v[0][4 * g + e] * sc_out;
+                    }
+                }
+            }
+        }
+        any_bad |= rg.bad;
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- dW1m += da x^T, db1 += sum da (over this wave's rows) -----------------------------------------------------------------
+#pragma unroll
+        for (int m = 0; m < HT; ++m) {
+            const tfrag ta = turn_tile(bga[m], sel, bsum[m]);
+#pragma unroll
+            for (int xt = 0; xt < XT; ++xt) contract(ta, tx[xt], Aw[m][xt]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (any_bad != 0 && lane == 0 && k.flags != nullptr)
+        __hip_atomic_fetch_or(k.flags, SX_FLAG_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // ---- one partial per workgroup, wgrad_reduce_kernel's layout: [32 HT x 32 XT | 32 HT], already unscaled ------------------------
+    __syncthreads();
+    float *red = smem;
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int m = 0; m < HT; ++m) {
+#pragma unroll
+                for (int xt = 0; xt < XT; ++xt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int e = (32 * m + (r & 3) + 8 * (r >> 2) + 4 * hh) * N1 + 32 * xt + j;
+                        red[e] = (wv == 0 ? 0.f : red[e]) + Aw[m][xt][r];
+                    }
+                const float tb = bsum[m] + __shfl_xor(bsum[m], 32, 64);
+                if (hh == 0) { const int e = 32 * HT * N1 + 32 * m + j; red[e] = (wv == 0 ? 0.f : red[e]) + tb; }
+            }
+        }
+        __syncthreads();
+    }
+    float *dst = k.w_part + (size_t)blockIdx.x * E1;
+    for (int e = threadIdx.x; e < E1; e += 256) dst[e] = red[e] * sc_out;
+}
+
 // launch shape: slabs per workgroup, slab groups, row ranges (one 8-wave workgroup per CU, or two 4-wave ones)
 struct slab_shape { int spw, n_groups, n_ranges; };
 slab_shape slab_plan(int n_slabs, int n_chunks) {
@@ -465,8 +641,7 @@ extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *g
                                int32_t live_start, int32_t n_live, int32_t n_bins, float left, float right, float bottom,
                                float top, int64_t n_rows, int32_t dim, float ldj_scale, int32_t tanh_hidden, const float *scale,
                                float *scratch, uint32_t *err_flag, void *stream) {
-    SX_REQUIRE(x && gout && gldj && h && w_fwd && w_bwd && slot_rows && gx && gh && dW && db && scratch,
-               "sx_rqs_slab_bwd: null pointer");
+    SX_REQUIRE(x && gout && gldj && h && w_fwd && w_bwd && slot_rows && gx && dW && db && scratch, "sx_rqs_slab_bwd: null pointer");
     SX_REQUIRE(dim > 0 && n_live > 0 && n_live <= dim && n_rows >= 0, "sx_rqs_slab_bwd: bad sizes");
     SX_REQUIRE(n_bins >= 1 && n_bins <= 16, "sx_rqs_slab_bwd: n_bins must be in 1..16 (got %d)", n_bins);
     SX_REQUIRE(hidden >= 1 && hidden <= 64, "sx_rqs_slab_bwd: hidden width must be in 1..64 (got %d)", hidden);
@@ -533,6 +708,7 @@ extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *g
     hipLaunchKernelGGL(rqs_slab_w_reduce_kernel, dim3((E + 255) / 256, n_slabs), dim3(256), 0, st, k.w_part, n_ranges, N2,
                        (int)hidden, slot_rows, dW, ldw, db, scale);
     SX_LAUNCH_CHECK();
+    if (gh == nullptr) return SX_OK;            // the caller reduces the dh partials itself (sx_rqs_slab_l1_bwd)
     const int64_t pieces = (int64_t)n_chunks * HT * 256;
     if (HT == 1)
         hipLaunchKernelGGL(rqs_slab_dh_reduce_kernel<1>, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, k.dh_part,
@@ -542,4 +718,40 @@ extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *g
                            n_groups, n_chunks, n_rows, (int)hidden, gh, ld_gh, scale, tanh_hidden ? h : nullptr, ld_h);
     SX_LAUNCH_CHECK();
     return SX_OK;
+}
+
+extern "C" size_t sx_rqs_slab_l1_scratch_floats(int32_t dim, int32_t hidden) {
+    if (dim < 1 || dim > 64 || hidden < 1 || hidden > 64) return 0;
+    const int HT = (hidden + 31) / 32, XT = (dim + 31) / 32;
+    return (size_t)512 * (32 * HT * 32 * XT + 32 * HT);
+}
+
+extern "C" int sx_rqs_slab_l1_bwd(const float *slab_scratch, const float *h, int64_t ld_h, int32_t hidden, const float *x,
+                                  const float *gout, const float *w1t, const uint32_t *cond_mask, float *gx, float *dW1,
+                                  int64_t ldw, float *db1, const int32_t *col_map, int32_t n_live, int64_t n_rows, int32_t dim,
+                                  const float *scale, float *scratch, uint32_t *err_flag, void *stream) {
+    SX_REQUIRE(slab_scratch && h && x && gout && w1t && cond_mask && gx && dW1 && db1 && scratch, "sx_rqs_slab_l1_bwd: null pointer");
+    SX_REQUIRE(dim >= 1 && dim <= 64 && hidden >= 1 && hidden <= 64 && n_live >= 1 && n_rows >= 0,
+               "sx_rqs_slab_l1_bwd: dim and hidden must be in 1..64");
+    SX_REQUIRE(((uintptr_t)w1t & 15) == 0 && ((uintptr_t)slab_scratch & 15) == 0, "sx_rqs_slab_l1_bwd: 16-byte alignment");
+    if (n_rows == 0) return SX_OK;
+    hipStream_t st = sx_stream(stream);
+    const int HT = (hidden + 31) / 32, XT = (dim + 31) / 32;
+    const int n_slabs = (n_live + 1) / 2;
+    const int n_chunks = (int)((n_rows + 31) / 32);
+    const slab_shape pl = slab_plan(n_slabs, n_chunks);
+    l1_args k;
+    k.part = slab_scratch; k.h = h; k.x = x; k.gout = gout; k.w1t = w1t; k.gx = gx; k.w_part = scratch; k.scale = scale;
+    k.flags = err_flag; k.n_rows = n_rows; k.ld_h = ld_h; k.n_groups = pl.n_groups; k.n_chunks = n_chunks; k.dim = dim; k.H = hidden;
+    k.cond_mask[0] = cond_mask[0]; k.cond_mask[1] = cond_mask[1];
+    int grid = (n_chunks + 3) / 4;
+    if (grid > 512) grid = 512;
+    const size_t lds_need = (size_t)XT * HT * 1024 * sizeof(float);
+    const int E1 = 32 * HT * 32 * XT + 32 * HT;
+    const size_t lds = lds_need > (size_t)E1 * sizeof(float) ? lds_need : (size_t)E1 * sizeof(float);
+#define SX_L1(HT_, XT_) hipLaunchKernelGGL((rqs_slab_l1_bwd_kernel<HT_, XT_>), dim3(grid), dim3(256), lds, st, k)
+    if (HT == 1 && XT == 1) SX_L1(1, 1); else if (HT == 1) SX_L1(1, 2); else if (XT == 1) SX_L1(2, 1); else SX_L1(2, 2);
+#undef SX_L1
+    SX_LAUNCH_CHECK();
+    return sx_wgrad_reduce(scratch, grid, 32 * HT, 32 * XT, dW1, ldw, db1, hidden, dim, nullptr, col_map, stream);
 }

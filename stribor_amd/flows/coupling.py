@@ -369,26 +369,44 @@ class Coupling(Transform):
         return self._run_spline(x2, lat2, True, True, 1.0)
 
     def _autograd_inverse_slab(self, x2, lat2, mask_t, rows_t, live, live_idx):
-        from .spline import RQSCouplingSlab, slab_slot_rows
+        from .spline import RQSCouplingSlab, RQSCouplingSlabL1, slab_slot_rows
         from ..net.mlp import SelectRows
         sp, net = self.transform, self.transform.latent_net
+        d = x2.shape[1]
+        lin = net.linears()
+        H = lin[-1][0].shape[1]
+
+        def build():
+            hid = np.full(((H + 31) // 32) * 32, -1, dtype=np.int32)
+            hid[:H] = np.arange(H)
+            m = self.mask_vector(d)
+            if d == 1:
+                m = m * 0                                                            # coupling.py:62-63
+            cols = np.full(((d + 31) // 32) * 32, -1, dtype=np.int32)
+            cols[:d] = np.arange(d)
+            cmap = cols.copy()
+            cmap[:d][m <= 0.5] = -1                                                  # transformed columns: no weight in W1 * mask
+            words = [int(sum(1 << c for c in range(32) if 32 * t + c < d and m[32 * t + c] > 0.5)) for t in range(2)]
+            dev = x2.device
+            return (torch.from_numpy(slab_slot_rows(len(live), sp.n_bins)).to(dev), torch.from_numpy(hid).to(dev),
+                    torch.from_numpy(cols).to(dev), torch.from_numpy(cmap).to(dev), words)
+        plan = self._programs.get(('slab', d, H, str(x2.device)), build)
+        W2, b2 = SelectRows.apply(lin[-1][0], rows_t), SelectRows.apply(lin[-1][1], rows_t)
+        evaluate = lambda xx: self._inverse_rows_nograd(xx, lat2)
+        col_mask = mask_t * 0 if d == 1 else mask_t                                  # coupling.py:62-63
+        if (lat2 is None and len(lin) == 2 and net.activation_name == 'Tanh' and lin[0][1] is not None
+                and RQSCouplingSlabL1.eligible(d, H, sp.n_bins) and os.environ.get('STRIBOR_SPLINE_L1_TORCH') != '1'):
+            # Linear - Tanh - Linear conditioner: the first layer's backward is part of the op too
+            return RQSCouplingSlabL1.apply(x2, lin[0][0], lin[0][1], W2, b2, col_mask, evaluate, plan, live_idx, int(live[0]),
+                                           len(live), sp.n_bins, sp.lower, sp.upper)
         # conditioner input cat[x * mask, latent] (coupling.py:61-65) with the mask folded into the first layer's weight
-        col_mask = mask_t * 0 if x2.shape[1] == 1 else mask_t                        # coupling.py:62-63
         if lat2 is not None:
             col_mask = torch.cat([col_mask, torch.ones(lat2.shape[1], dtype=torch.float32, device=x2.device)])
         # (a Tanh right before the last Linear is applied inside the op: its backward rides on the kernel that reduces dL/dh)
         h, last, _, pre_tanh = net.hidden_autograd(x2 if lat2 is None else torch.cat([x2, lat2], -1), col_mask, pre_tanh=True,
                                                    want_flag=True)
-        H = h.shape[1]
-
-        def build():
-            hid = np.full(((H + 31) // 32) * 32, -1, dtype=np.int32)
-            hid[:H] = np.arange(H)
-            return (torch.from_numpy(slab_slot_rows(len(live), sp.n_bins)).to(x2.device), torch.from_numpy(hid).to(x2.device))
-        plan = self._programs.get(('slab', x2.shape[1], H, str(x2.device)), build)
-        W2, b2 = SelectRows.apply(last.weight, rows_t), SelectRows.apply(last.bias, rows_t)
-        return RQSCouplingSlab.apply(x2, h, W2, b2, lambda xx: self._inverse_rows_nograd(xx, lat2), plan, live_idx,
-                                     int(live[0]), len(live), sp.n_bins, sp.lower, sp.upper, pre_tanh)
+        return RQSCouplingSlab.apply(x2, h, W2, b2, evaluate, plan[:2], live_idx, int(live[0]), len(live), sp.n_bins, sp.lower,
+                                     sp.upper, pre_tanh)
 
     # ---- reference method set (coupling.py:69-95) -----------------------------------------------------------
     def forward(self, x, latent=None, reverse: bool = False, **kwargs):

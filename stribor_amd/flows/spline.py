@@ -18,7 +18,7 @@ import torch.nn as nn
 from .. import _hip
 from ..flow import ElementwiseTransform, flatten_rows
 
-__all__ = ['Spline', 'run_rqs_kernel', 'run_cubic_kernel', 'RQSInverse', 'CubicInverse', 'RQSCouplingSlab', 'slab_slot_rows']
+__all__ = ['Spline', 'run_rqs_kernel', 'run_cubic_kernel', 'RQSInverse', 'CubicInverse', 'RQSCouplingSlab', 'RQSCouplingSlabL1', 'slab_slot_rows']
 
 def check_errors(device=None) -> None:
     """Raise what the reference would have raised for data-dependent failures (synchronises): the spline's
@@ -128,15 +128,8 @@ class RQSCouplingSlab(torch.autograd.Function):
         h = h if h.stride(1) == 1 else h.contiguous()
         W2, b2 = W2.detach().contiguous(), b2.detach().contiguous()
         lib = _hip.lib()
-        slots, ht = lib.sx_rqs_slab_slots(n_live), (H + 31) // 32
-        mt = slots // 32
-        n_fwd, n_bwd = _hip.packed_linear_floats(mt, ht), ht * mt * 1024
-        packs = torch.empty(n_fwd + n_bwd + 32, dtype=torch.float32, device=dev)
         flag = _hip.err_flag(dev)
-        _hip.call('sx_pack_linear', x2, W2.data_ptr(), b2.data_ptr(), W2.shape[0], H, slot_rows.data_ptr(), hid_idx.data_ptr(),
-                  mt, ht, None, None, 0.0, 0, _hip.GEMM_F16X3, flag, packs.data_ptr())
-        _hip.call('sx_pack_linear', x2, W2.data_ptr(), None, W2.shape[0], H, hid_idx.data_ptr(), slot_rows.data_ptr(),
-                  ht, mt, None, None, 0.0, 1, _hip.GEMM_F16X3, flag, packs.data_ptr() + 4 * n_fwd)
+        packs, n_fwd = _slab_packs(x2, W2, b2, slot_rows, hid_idx, n_live, H)
         gx = gy.clone()                     # pass-through columns: y = x; the kernel overwrites the transformed columns
         gh = torch.empty(n, H, dtype=torch.float32, device=dev)
         gW = torch.zeros_like(W2)
@@ -153,6 +146,84 @@ class RQSCouplingSlab(torch.autograd.Function):
                   gh.stride(0), gW.data_ptr(), gW.stride(0), gb.data_ptr(), _hip.ptr(live_idx), live_start, n_live, n_bins,
                   lower, upper, lower, upper, n, d, 1.0, int(pre_tanh), scale.data_ptr(), sc.data_ptr(), flag)
         return gx, gh, gW, gb, None, None, None, None, None, None, None, None, None
+
+
+def _slab_packs(x2, W2, b2, slot_rows, hid_idx, n_live, H):
+    """The two fragment packs of the selected last-layer rows sx_rqs_slab_bwd consumes -> (buffer, float offset of the
+    transposed pack)."""
+    lib = _hip.lib()
+    slots, ht = lib.sx_rqs_slab_slots(n_live), (H + 31) // 32
+    mt = slots // 32
+    n_fwd, n_bwd = _hip.packed_linear_floats(mt, ht), ht * mt * 1024
+    packs = torch.empty(n_fwd + n_bwd + 32, dtype=torch.float32, device=x2.device)
+    flag = _hip.err_flag(x2.device)
+    _hip.call('sx_pack_linear', x2, W2.data_ptr(), b2.data_ptr(), W2.shape[0], H, slot_rows.data_ptr(), hid_idx.data_ptr(),
+              mt, ht, None, None, 0.0, 0, _hip.GEMM_F16X3, flag, packs.data_ptr())
+    _hip.call('sx_pack_linear', x2, W2.data_ptr(), None, W2.shape[0], H, hid_idx.data_ptr(), slot_rows.data_ptr(),
+              ht, mt, None, None, 0.0, 1, _hip.GEMM_F16X3, flag, packs.data_ptr() + 4 * n_fwd)
+    return packs, n_fwd
+
+
+class RQSCouplingSlabL1(torch.autograd.Function):
+    """RQSCouplingSlab with the conditioner's FIRST layer inside the op as well, for Linear - Tanh - Linear conditioners without
+    a latent input (cfg 3): a differentiable op of (x, W1, b1, W2, b2).  Forward: h = tanh(x (W1 * mask)^T + b1) (one library
+    GEMM, kept for the backward) and the coupling's no-graph evaluation.  Backward: sx_rqs_slab_bwd leaves its dh partials in
+    scratch and sx_rqs_slab_l1_bwd finishes the layer in one pass over the rows -- partial sum, tanh', dL/dx of the
+    conditioning columns (= dL/dout + W1m^T da), dW1, db1 -- so no library GEMM, clone or add is left in the backward."""
+
+    @staticmethod
+    def eligible(dim: int, hidden: int, n_bins: int) -> bool:
+        return dim <= 64 and RQSCouplingSlab.eligible(hidden, n_bins)
+
+    @staticmethod
+    def forward(ctx, x2, W1, b1, W2, b2, mask_t, evaluate, plan, live_idx, live_start, n_live, n_bins, lower, upper):
+        x2 = x2.contiguous()
+        with torch.no_grad():
+            y, ldj = evaluate(x2)
+            h = torch.tanh(torch.addmm(b1, x2, (W1 * mask_t).t()))
+        ctx.save_for_backward(x2, h, W1, W2, b2, mask_t)
+        ctx.meta = (plan, live_idx, live_start, n_live, n_bins, float(lower), float(upper))
+        return y, ldj
+
+    @staticmethod
+    def backward(ctx, gy, gldj):
+        import ctypes as C
+        x2, h, W1, W2, b2, mask_t = ctx.saved_tensors
+        (slot_rows, hid_idx, col_slots, col_map, cond_words), live_idx, live_start, n_live, n_bins, lower, upper = ctx.meta
+        n, d = x2.shape
+        dev = x2.device
+        H = h.shape[1]
+        gy = (torch.zeros_like(x2) if gy is None else gy).to(torch.float32).contiguous()
+        gldj = (torch.zeros(n, device=dev) if gldj is None else gldj).to(torch.float32).contiguous()
+        W2, b2 = W2.detach().contiguous(), b2.detach().contiguous()
+        lib = _hip.lib()
+        flag = _hip.err_flag(dev)
+        packs, n_fwd = _slab_packs(x2, W2, b2, slot_rows, hid_idx, n_live, H)
+        W1m = (W1.detach() * mask_t).contiguous()
+        ht, xt = (H + 31) // 32, (d + 31) // 32
+        w1t = torch.empty(xt * ht * 1024 + 32, dtype=torch.float32, device=dev)
+        _hip.call('sx_pack_linear', x2, W1m.data_ptr(), None, H, d, col_slots.data_ptr(), hid_idx.data_ptr(), xt, ht, None, None,
+                  0.0, 1, _hip.GEMM_F16X3, flag, w1t.data_ptr())
+        gx = torch.empty_like(gy)           # every column is written: transformed ones by the slab kernel, the rest by the l1 kernel
+        gW2, gb2 = torch.zeros_like(W2), torch.zeros_like(b2)
+        gW1 = torch.zeros(H, d, dtype=torch.float32, device=dev)
+        gb1 = torch.zeros(H, dtype=torch.float32, device=dev)
+        n_slab = lib.sx_rqs_slab_scratch_floats(n, n_live, H)
+        n_l1 = lib.sx_rqs_slab_l1_scratch_floats(d, H)
+        with _hip.device_of(x2):
+            sc = _hip.scratch(dev, n_slab + n_l1 + 64)
+        inf = float('inf')
+        scale = torch.maximum(torch.linalg.vector_norm(gy, ord=inf), torch.linalg.vector_norm(gldj, ord=inf)).reshape(1)
+        _hip.call('sx_rqs_slab_bwd', x2, x2.data_ptr(), gy.data_ptr(), gldj.data_ptr(), h.data_ptr(), h.stride(0), H,
+                  packs.data_ptr(), packs.data_ptr() + 4 * n_fwd, slot_rows.data_ptr(), gx.data_ptr(), None, 0,
+                  gW2.data_ptr(), gW2.stride(0), gb2.data_ptr(), _hip.ptr(live_idx), live_start, n_live, n_bins,
+                  lower, upper, lower, upper, n, d, 1.0, 1, scale.data_ptr(), sc.data_ptr(), flag)
+        words = (C.c_uint32 * 2)(*cond_words)
+        l1_scratch = sc.data_ptr() + 4 * ((n_slab + 3) // 4 * 4)
+        _hip.call('sx_rqs_slab_l1_bwd', x2, sc.data_ptr(), h.data_ptr(), h.stride(0), H, x2.data_ptr(), gy.data_ptr(),
+                  w1t.data_ptr(), C.cast(words, C.c_void_p), gx.data_ptr(), gW1.data_ptr(), gW1.stride(0), gb1.data_ptr(),
+                  col_map.data_ptr(), n_live, n, d, scale.data_ptr(), l1_scratch, flag)
+        return gx, gW1, gb1, gW2, gb2, None, None, None, None, None, None, None, None, None
 
 
 def run_cubic_kernel(x2, params, params_stride, live_idx, live_start, n_live, n_bins, lower, upper, reverse, want_ldj,
