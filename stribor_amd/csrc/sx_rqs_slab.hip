@@ -495,11 +495,20 @@ __global__ __launch_bounds__(256, 2) void rqs_slab_l1_bwd_kernel(const l1_args k
             tile<1> ga;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 *src = reinterpret_cast<const f32x4 *>(k.part + ((size_t)c * HT + m) * 1024) + g * 64 + lane;
-                f32x4 sum = src[0];
-                for (int p = 1; p < k.n_groups; ++p) {
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(src) + p * gstride);
-                    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+                // eight groups' pieces in flight at a time (a rolled loop would wait for each load before the next: the kernel
+                // is a stream of 64 KB per chunk and nothing else hides the latency); groups past the end re-read the last one
+                const float *src = k.part + ((size_t)c * HT + m) * 1024 + (g * 64 + lane) * 4;
+                f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+                for (int p0 = 0; p0 < k.n_groups; p0 += 8) {
+                    f32x4 v[8];
+#pragma unroll
+                    for (int pp = 0; pp < 8; ++pp) {
+                        const int p = p0 + pp < k.n_groups ? p0 + pp : k.n_groups - 1;
+                        v[pp] = *reinterpret_cast<const f32x4 *>(src + (size_t)p * gstride);
+                    }
+#pragma unroll
+                    for (int pp = 0; pp < 8; ++pp)
+                        if (p0 + pp < k.n_groups) { sum.x += v[pp].x; sum.y += v[pp].y; sum.z += v[pp].z; sum.w += v[pp].w; }
                 }
                 const int f0 = 32 * m + 8 * g + 4 * hh;
                 const float *hp = k.h + (row0 + jc) * k.ld_h + f0;
