@@ -144,6 +144,13 @@ int sx_rqs_inverse_bwd(const float *x, const float *gout, const float *gldj, con
                        int32_t n_live, int32_t n_bins, float left, float right, float bottom, float top, int64_t n_rows,
                        int32_t dim, float ldj_scale, void *stream);
 
+/* The same for sx_rqs_coupling(reverse = 0), the forward direction (forward / rsample of spline flows; reverse mode through
+ * rational_quadratic_spline.py:101-107,180-207,236-248; the bin is searched on the widths, the input lives in [left, right]). */
+int sx_rqs_forward_bwd(const float *x, const float *gout, const float *gldj, const float *params,
+                       int64_t params_stride, float *gx, float *gparams, const int32_t *live_idx, int32_t live_start,
+                       int32_t n_live, int32_t n_bins, float left, float right, float bottom, float top, int64_t n_rows,
+                       int32_t dim, float ldj_scale, void *stream);
+
 /* Backward of one rational-quadratic spline COUPLING with the parameter tensor never in HBM (training of
  * Coupling(Spline(spline_type='quadratic')), stribor/flows/coupling.py:69-95 + flows/spline.py:76-87): the spline's reverse
  * mode (as sx_rqs_inverse_bwd) fused with the last conditioner layer  params = h W2^T + b2  and that layer's backward.

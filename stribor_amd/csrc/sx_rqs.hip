@@ -808,7 +808,8 @@ extern "C" int sx_cubic_coupling(const void *x, void *y, float *ldj, float *ldia
 // =====================================================================================================
 #include "sx_rqs_bwd.h"
 
-__global__ __launch_bounds__(256) void rqs_inverse_bwd_kernel(const float *__restrict__ x, const float *__restrict__ gout,
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void rqs_bwd_kernel(const float *__restrict__ x, const float *__restrict__ gout,
                                                               const float *__restrict__ gldj,
                                                               const float *__restrict__ params, int64_t pstride,
                                                               float *__restrict__ gx, float *__restrict__ gparams,
@@ -848,11 +849,11 @@ __global__ __launch_bounds__(256) void rqs_inverse_bwd_kernel(const float *__res
         const int64_t row = valid ? e / n_live : 0;
         const int i = valid ? (int)(e - row * n_live) : 0;
         const int col = live_idx ? live_idx[i] : l0 + i;
-        const float xv = valid ? x[row * dim + col] : bottom;
+        const float xv = valid ? x[row * dim + col] : (INVERSE ? bottom : left);
         const float Ao = valid ? gout[row * dim + col] : 0.f;            // dL/d out
         const float Al = valid ? gldj[row] * ldj_scale : 0.f;            // dL/d ljd (the row sum's adjoint)
         float *uw = sp + (valid ? lane : 0) * P;
-        const float gxe = rqs_inverse_bwd_element(uw, K, xv, Ao, Al, left, right, bottom, top, valid);
+        const float gxe = rqs_bwd_element<INVERSE>(uw, K, xv, Ao, Al, left, right, bottom, top, valid);
         if (valid) gx[row * dim + col] = gxe;
 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -867,32 +868,54 @@ __global__ __launch_bounds__(256) void rqs_inverse_bwd_kernel(const float *__res
     }
 }
 
-extern "C" int sx_rqs_inverse_bwd(const float *x, const float *gout, const float *gldj, const float *params,
+static int rqs_bwd_launch(bool inverse, const float *x, const float *gout, const float *gldj, const float *params,
                                   int64_t params_stride, float *gx, float *gparams, const int32_t *live_idx,
                                   int32_t live_start, int32_t n_live, int32_t n_bins, float left, float right,
                                   float bottom, float top, int64_t n_rows, int32_t dim, float ldj_scale, void *stream) {
-    SX_REQUIRE(x && gout && gldj && params && gx && gparams, "sx_rqs_inverse_bwd: null pointer");
-    SX_REQUIRE(dim > 0 && n_live > 0 && n_live <= dim && n_rows >= 0 && n_bins >= 1, "sx_rqs_inverse_bwd: bad sizes");
-    SX_REQUIRE(right > left && top > bottom, "sx_rqs_inverse_bwd: empty domain");
+    SX_REQUIRE(x && gout && gldj && params && gx && gparams, "sx_rqs_*_bwd: null pointer");
+    SX_REQUIRE(dim > 0 && n_live > 0 && n_live <= dim && n_rows >= 0 && n_bins >= 1, "sx_rqs_*_bwd: bad sizes");
+    SX_REQUIRE(right > left && top > bottom, "sx_rqs_*_bwd: empty domain");
     if (n_rows == 0) return SX_OK;
     const int P = 3 * n_bins - 1;
     int block = 256;
     size_t lds = (size_t)(block / 64) * 64 * P * sizeof(float);
     if (lds > 64 * 1024) { block = 64; lds = (size_t)64 * P * sizeof(float); }
-    SX_REQUIRE(lds <= 160 * 1024, "sx_rqs_inverse_bwd: n_bins %d needs %zu B of LDS per wave", n_bins, lds);
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void *)rqs_inverse_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SX_REQUIRE(lds <= 160 * 1024, "sx_rqs_*_bwd: n_bins %d needs %zu B of LDS per wave", n_bins, lds);
+    if (lds > 48 * 1024) {
+        (void)hipFuncSetAttribute((const void *)rqs_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)rqs_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     const int64_t n_groups = (n_rows * n_live + 63) / 64;
     const int wpb = block / 64;
     int64_t grid = (n_groups + wpb - 1) / wpb;
     const int64_t per_cu = (160 * 1024) / (int64_t)lds > 8 ? 8 : (160 * 1024) / (int64_t)lds;
     if (grid > 256 * per_cu) grid = 256 * per_cu;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(rqs_inverse_bwd_kernel, dim3((int)grid), dim3(block), lds, sx_stream(stream), x, gout, gldj, params,
-                       params_stride, gx, gparams, live_idx, live_start, n_live, n_bins, left, right, bottom, top, n_rows,
-                       dim, ldj_scale);
+    if (inverse)
+        hipLaunchKernelGGL(rqs_bwd_kernel<true>, dim3((int)grid), dim3(block), lds, sx_stream(stream), x, gout, gldj, params,
+                           params_stride, gx, gparams, live_idx, live_start, n_live, n_bins, left, right, bottom, top, n_rows,
+                           dim, ldj_scale);
+    else
+        hipLaunchKernelGGL(rqs_bwd_kernel<false>, dim3((int)grid), dim3(block), lds, sx_stream(stream), x, gout, gldj, params,
+                           params_stride, gx, gparams, live_idx, live_start, n_live, n_bins, left, right, bottom, top, n_rows,
+                           dim, ldj_scale);
     SX_LAUNCH_CHECK();
     return SX_OK;
+}
+
+extern "C" int sx_rqs_inverse_bwd(const float *x, const float *gout, const float *gldj, const float *params,
+                                  int64_t params_stride, float *gx, float *gparams, const int32_t *live_idx,
+                                  int32_t live_start, int32_t n_live, int32_t n_bins, float left, float right,
+                                  float bottom, float top, int64_t n_rows, int32_t dim, float ldj_scale, void *stream) {
+    return rqs_bwd_launch(true, x, gout, gldj, params, params_stride, gx, gparams, live_idx, live_start, n_live, n_bins, left, right,
+                          bottom, top, n_rows, dim, ldj_scale, stream);
+}
+extern "C" int sx_rqs_forward_bwd(const float *x, const float *gout, const float *gldj, const float *params,
+                                  int64_t params_stride, float *gx, float *gparams, const int32_t *live_idx,
+                                  int32_t live_start, int32_t n_live, int32_t n_bins, float left, float right,
+                                  float bottom, float top, int64_t n_rows, int32_t dim, float ldj_scale, void *stream) {
+    return rqs_bwd_launch(false, x, gout, gldj, params, params_stride, gx, gparams, live_idx, live_start, n_live, n_bins, left, right,
+                          bottom, top, n_rows, dim, ldj_scale, stream);
 }
 
 // =====================================================================================================

@@ -106,15 +106,64 @@ __device__ __forceinline__ rqs_adj rqs_inverse_bwd_core(float xin, float w_b, fl
     return A;
 }
 
+// The same for the FORWARD direction (rational_quadratic_spline.py:236-248):  theta = (x - cw_b) / w_b,
+//   out = ch_b + h_b (s theta^2 + d_b theta(1-theta)) / (s + (d_b + d_n - 2 s) theta(1-theta)),
+//   ljd = log(s^2 (d_n theta^2 + 2 s theta(1-theta) + d_b (1-theta)^2)) - 2 log(den).
+__device__ __forceinline__ rqs_adj rqs_forward_bwd_core(float xin, float w_b, float h_b, float cw_b, float u_b, float u_n, float Ao,
+                                                        float Al) {
+    const float s_b = h_b / w_b;
+    const float d_b = RQS_MIN_DERIV + rqsb_softplus(u_b), d_n = RQS_MIN_DERIV + rqsb_softplus(u_n);
+    const float th = (xin - cw_b) / w_b, omt = 1.f - th, tomt = th * omt;
+    const float q = d_b + d_n - 2.f * s_b;
+    const float inner = s_b * (th * th) + d_b * tomt;
+    const float num = h_b * inner;
+    const float den = s_b + q * tomt;
+    const float T = d_n * (th * th) + 2.f * s_b * tomt + d_b * (omt * omt);
+    const float dnum = (s_b * s_b) * T;
+    // ---- reverse ----
+    const float Anum = Ao / den;
+    float Aden = -Ao * num / (den * den) - 2.f * Al / den;
+    const float Adnum = Al / dnum;
+    float As = Adnum * (2.f * s_b * T + (s_b * s_b) * 2.f * tomt) + Aden + Anum * h_b * (th * th);
+    float Adn = Adnum * (s_b * s_b) * (th * th);
+    float Adb = Adnum * (s_b * s_b) * (omt * omt) + Anum * h_b * tomt;
+    float Atomt = Adnum * (s_b * s_b) * 2.f * s_b + Aden * q + Anum * h_b * d_b;
+    float Ath = Adnum * (s_b * s_b) * (2.f * d_n * th - 2.f * d_b * omt) + Anum * h_b * s_b * 2.f * th;
+    float Ahb = Anum * inner;
+    const float Aq = Aden * tomt;
+    Adb += Aq;
+    Adn += Aq;
+    As += -2.f * Aq;
+    Ath += Atomt * (1.f - 2.f * th);
+    const float Axin = Ath / w_b;
+    float Acwb = -Ath / w_b;
+    float Awb = -Ath * th / w_b;
+    Ahb += As / w_b;
+    Awb += -As * s_b / w_b;
+    rqs_adj A;
+    A.Acwn = Awb;
+    A.Acwb = Acwb - Awb;
+    A.Achn = Ahb;
+    A.Achb = Ao - Ahb;                 // out = ch_b + ...
+    A.g_ub = Adb * rqsb_sigmoid(u_b);
+    A.g_un = Adn * rqsb_sigmoid(u_n);
+    A.Axin = Axin;
+    return A;
+}
+
 // Parameters in memory (LDS): the lane's 3K-1 un-normalised parameters sit at `uw` (widths, heights, derivatives back to
 // back); they are overwritten with their gradients and dL/d(input) is returned.
-__device__ __forceinline__ float rqs_inverse_bwd_element(float *uw, int K, float xv, float Ao, float Al, float left, float right,
-                                                         float bottom, float top, bool valid) {
+// INVERSE: the direction log_prob evaluates (bin searched on the heights, input in [bottom, top]); otherwise the forward
+// direction (bin searched on the widths, input in [left, right]).
+template <bool INVERSE>
+__device__ __forceinline__ float rqs_bwd_element(float *uw, int K, float xv, float Ao, float Al, float left, float right,
+                                                 float bottom, float top, bool valid) {
     const float bconst = logf(expf(1.f - RQS_MIN_DERIV) - 1.f);
     const float norm = 1.f - RQS_MIN_BIN * (float)K;
     const float span_w = right - left, span_h = top - bottom;
-    const bool inside = (xv >= bottom) && (xv <= top);
-    const float xin = inside ? xv : bottom;
+    const float lo = INVERSE ? bottom : left, hi = INVERSE ? top : right;
+    const bool inside = (xv >= lo) && (xv <= hi);
+    const float xin = inside ? xv : lo;
     float *uh = uw + K, *ud = uh + K;
 
     // ---- forward: softmax pieces, knots, bin (heights), as rqs_kernel's generic path -----------------
@@ -140,13 +189,15 @@ __device__ __forceinline__ float rqs_inverse_bwd_element(float *uw, int K, float
         csh += hk;
         const float kw = (j < K) ? span_w * csw + left : right;
         const float kh = (j < K) ? span_h * csh + bottom : top;
-        const bool ge = xin >= ((j < K) ? kh : kh + RQS_EPS);
+        const float ks = INVERSE ? kh : kw;                              // the searched side's knot (:71-73, search_sorted.py:4-5)
+        const bool ge = xin >= ((j < K) ? ks : ks + RQS_EPS);
         if (ge && j < K) { b = j; cw_b = kw; ch_b = kh; }
         else if (!ge && !have_next) { cw_n = kw; ch_n = kh; have_next = true; }
     }
     const float w_b = cw_n - cw_b, h_b = ch_n - ch_b;
     const float u_b = (b == 0) ? bconst : ud[b - 1], u_n = (b + 1 == K) ? bconst : ud[b];
-    const rqs_adj A = rqs_inverse_bwd_core(xin, w_b, h_b, ch_b, u_b, u_n, Ao, Al);
+    const rqs_adj A = INVERSE ? rqs_inverse_bwd_core(xin, w_b, h_b, ch_b, u_b, u_n, Ao, Al)
+                              : rqs_forward_bwd_core(xin, w_b, h_b, cw_b, u_b, u_n, Ao, Al);
     // knots -> cumsums -> widths / heights:  dL/dw_i = span * ([i < b] A(kw_b) + [i < b+1 < K] A(kw_{b+1}))
     const float Gw_lo = (b >= 1 ? span_w * A.Acwb : 0.f) + (b + 1 < K ? span_w * A.Acwn : 0.f);   // bins i < b
     const float Gw_b = (b + 1 < K ? span_w * A.Acwn : 0.f);                                       // bin i == b
@@ -169,7 +220,10 @@ __device__ __forceinline__ float rqs_inverse_bwd_element(float *uw, int K, float
         for (int k = 0; k < K - 1; ++k) ud[k] = gate * ((k == b - 1 ? A.g_ub : 0.f) + (k == b ? A.g_un : 0.f));
     }
     return inside ? A.Axin : Ao;                                         // tails: out = x
-
+}
+__device__ __forceinline__ float rqs_inverse_bwd_element(float *uw, int K, float xv, float Ao, float Al, float left, float right,
+                                                         float bottom, float top, bool valid) {
+    return rqs_bwd_element<true>(uw, K, xv, Ao, Al, left, right, bottom, top, valid);
 }
 
 // Parameters in registers (one MFMA accumulator tile per block): Wp / Hp / Dp hold the element's K widths, K heights and

@@ -18,7 +18,7 @@ import torch.nn as nn
 from .. import _hip
 from ..flow import ElementwiseTransform, flatten_rows
 
-__all__ = ['Spline', 'run_rqs_kernel', 'run_cubic_kernel', 'RQSInverse', 'CubicInverse', 'RQSCouplingSlab', 'RQSCouplingSlabL1', 'slab_slot_rows']
+__all__ = ['Spline', 'run_rqs_kernel', 'run_cubic_kernel', 'RQSInverse', 'RQSForward', 'CubicInverse', 'RQSCouplingSlab', 'RQSCouplingSlabL1', 'slab_slot_rows']
 
 def check_errors(device=None) -> None:
     """Raise what the reference would have raised for data-dependent failures (synchronises): the spline's
@@ -69,6 +69,35 @@ class RQSInverse(torch.autograd.Function):
         gx = gy.clone()                     # pass-through columns: y = x; the kernel overwrites the live columns
         gparams = torch.empty_like(params)
         _hip.call('sx_rqs_inverse_bwd', x2, x2.data_ptr(), gy.data_ptr(), gldj.data_ptr(), params.data_ptr(),
+                                           params.stride(0), gx.data_ptr(), gparams.data_ptr(), _hip.ptr(live_idx),
+                                           live_start, n_live, n_bins, lower, upper, lower, upper, n, d, ldj_scale)
+        return gx, gparams, None, None, None, None, None, None, None
+
+
+class RQSForward(torch.autograd.Function):
+    """(y, row log-det) = FORWARD rational-quadratic spline of the live columns as a differentiable op (forward / rsample of
+    spline flows): forward = sx_rqs_coupling(reverse=0), backward = sx_rqs_forward_bwd.  Same contract as RQSInverse."""
+
+    @staticmethod
+    def forward(ctx, x2, params, live_idx, live_start, n_live, n_bins, lower, upper, ldj_scale):
+        x2 = x2.contiguous()
+        params = params.contiguous()
+        y, ldj, _ = run_rqs_kernel(x2, params, params.stride(0), live_idx, live_start, n_live, n_bins, lower, upper,
+                                   lower, upper, False, True, False, ldj_scale)
+        ctx.save_for_backward(x2, params)
+        ctx.meta = (live_idx, live_start, n_live, n_bins, float(lower), float(upper), float(ldj_scale))
+        return y, ldj
+
+    @staticmethod
+    def backward(ctx, gy, gldj):
+        x2, params = ctx.saved_tensors
+        live_idx, live_start, n_live, n_bins, lower, upper, ldj_scale = ctx.meta
+        n, d = x2.shape
+        gy = (torch.zeros_like(x2) if gy is None else gy).to(torch.float32).contiguous()
+        gldj = (torch.zeros(n, device=x2.device) if gldj is None else gldj).to(torch.float32).contiguous()
+        gx = gy.clone()
+        gparams = torch.empty_like(params)
+        _hip.call('sx_rqs_forward_bwd', x2, x2.data_ptr(), gy.data_ptr(), gldj.data_ptr(), params.data_ptr(),
                                            params.stride(0), gx.data_ptr(), gparams.data_ptr(), _hip.ptr(live_idx),
                                            live_start, n_live, n_bins, lower, upper, lower, upper, n, d, ldj_scale)
         return gx, gparams, None, None, None, None, None, None, None
@@ -334,7 +363,7 @@ class Spline(ElementwiseTransform):
         from ..net.mlp import MLP
         return self.latent_net is None or isinstance(self.latent_net, MLP)
 
-    def _autograd_inverse(self, x2: torch.Tensor, lat2=None):
+    def _autograd_inverse(self, x2: torch.Tensor, lat2=None, reverse: bool = True):
         """inverse_and_log_diag_jacobian summed over the columns, on fp32 rows, with a graph (RQSInverse)."""
         n, d = x2.shape
         if self.latent_net is None:
@@ -344,8 +373,17 @@ class Spline(ElementwiseTransform):
             if lat2 is None:
                 raise ValueError('Spline with a latent_net needs `latent`')
             params = self.latent_net.forward_autograd(lat2)                                                 # spline.py:82-86
-        op = CubicInverse if self.spline_type == 'cubic' else RQSInverse
+        if self.spline_type == 'cubic':
+            if not reverse:
+                raise NotImplementedError('forward-direction autograd is built for quadratic splines')
+            op = CubicInverse
+        else:
+            op = RQSInverse if reverse else RQSForward
         return op.apply(x2, params, None, 0, d, self.n_bins, self.lower, self.upper, 1.0)
+
+    def _autograd_forward(self, x2: torch.Tensor, lat2=None):
+        """forward_and_log_diag_jacobian summed over the columns, with a graph (quadratic splines: RQSForward)."""
+        return self._autograd_inverse(x2, lat2, reverse=False)
 
     # ---- reference method set (spline.py:89-143) ----------------------------------------------------------
     def forward(self, x, latent=None, **kwargs):

@@ -802,9 +802,10 @@ def test_forward_and_inverse_directions_are_differentiable():
     s = flow.rsample((5,))
     assert s.shape == (5, dim) and s.requires_grad
     assert flow.forward(x.to(DEV)).requires_grad
-    # a spline flow: inverse direction differentiable, forward direction warns and returns a detached result
+    # quadratic-spline flows are differentiable in both directions (next test); a CUBIC spline coupling has a backward for the
+    # inverse direction only: its forward warns and returns a detached result
     torch.manual_seed(22)
-    sdesc = fd.cfg3_desc(2, 8, 16, 5)
+    sdesc = [dict(d, spline_type='cubic') for d in fd.cfg3_desc(2, 8, 16, 5)]
     sflow = fd.build_flow(st, sdesc, 8).to(DEV)
     xs = (torch.rand(50, 8) * 4 - 2).to(DEV).requires_grad_(True)
     z, l = sflow.inverse_and_log_det_jacobian(xs)
@@ -812,3 +813,49 @@ def test_forward_and_inverse_directions_are_differentiable():
     with pytest.warns(RuntimeWarning):
         ys = sflow.forward(xs)
     assert not ys.requires_grad
+
+
+@pytest.mark.parametrize('K,dim,hidden', [(5, 8, 16), (16, 12, 24), (1, 5, 12)])
+def test_spline_forward_direction_backward_matches_autograd_of_oracle(K, dim, hidden):
+    """forward_and_log_det_jacobian / rsample of quadratic-spline flows build a graph too (sx_rqs_forward_bwd: reverse mode
+    through the FORWARD spline, bin searched on the widths): spline couplings + an element-wise Spline, against fp64 autograd of
+    the oracle, inputs reaching into both linear tails."""
+    torch.manual_seed(31)
+    desc = [{'kind': 'coupling_rqs', 'dim': dim, 'hidden': [hidden], 'n_bins': K, 'lower': -2, 'upper': 2,
+             'mask': 'ordered_right_half', 'latent_dim': 0},
+            {'kind': 'rqs', 'dim': dim, 'n_bins': K, 'lower': -2.5, 'upper': 2.5, 'hidden': [], 'latent_dim': 0},
+            {'kind': 'flip'},
+            {'kind': 'coupling_rqs', 'dim': dim, 'hidden': [hidden], 'n_bins': K, 'lower': -2, 'upper': 2, 'mask': 'parity_odd',
+             'latent_dim': 0}]
+    flow = fd.build_flow(st, desc, dim)
+    with torch.no_grad():
+        for p in flow.parameters():
+            p.add_(torch.randn_like(p) * 0.05)
+    state = {k: v.clone() for k, v in flow.state_dict().items()}
+    flow = flow.to(DEV)
+    x = torch.randn(257, dim) * 1.4
+    w = torch.linspace(0.5, 1.5, x.shape[0]).unsqueeze(-1)
+    leaves = {k: v.detach().double().clone().requires_grad_(True) for k, v in state.items()}
+    xin = x.double().clone().requires_grad_(True)
+    y64, l64 = orc.flow_forward_and_ldj(fd.flow_spec(desc, leaves), xin)
+    want = (y64 ** 2).sum() * 0.1 + (l64 * w.double()).sum()
+    want.backward()
+    xg = x.to(DEV).requires_grad_(True)
+    y, ldj = flow.forward_and_log_det_jacobian(xg)
+    assert y.requires_grad and ldj.requires_grad and ldj.shape == (x.shape[0], 1)
+    loss = (y ** 2).sum() * 0.1 + (ldj * w.to(DEV)).sum()
+    loss.backward()
+    assert abs(loss.item() - want.item()) <= 1e-4 * abs(want.item()) + 1e-3
+    ref = xin.grad.float()
+    assert ((xg.grad.cpu() - ref).abs().max() / ref.abs().max()).item() <= 3e-4
+    for name, p in flow.named_parameters():
+        if p.numel() == 0:                       # K = 1: an element-wise Spline has no derivative parameters
+            continue
+        assert p.grad is not None, name
+        ref = leaves[name].grad.float()
+        assert ((p.grad.cpu() - ref).abs().max() / (ref.abs().max() + 1e-12)).item() <= 3e-4, name
+    with torch.no_grad():
+        yk, lk = flow.forward_and_log_det_jacobian(x.to(DEV))
+    close(y, yk, rtol=1e-5, atol=1e-5)
+    close(ldj, lk, rtol=1e-5, atol=1e-4)
+    assert flow.rsample((7,)).requires_grad
