@@ -222,6 +222,12 @@ int sx_cubic_inverse_bwd(const float *yin, const float *xout, const float *gout,
                          int32_t n_live, int32_t n_bins, float lower, float upper, int64_t n_rows, int32_t dim,
                          float ldj_scale, void *stream);
 
+/* The same for sx_cubic_coupling(reverse = 0), the forward direction (out = f(t), ljd = log f'(t), bin searched on the
+ * widths): x [n_rows, dim] the forward pass's input; no solve to differentiate. */
+int sx_cubic_forward_bwd(const float *x, const float *gout, const float *gldj, const float *params, int64_t params_stride,
+                         float *gx, float *gparams, const int32_t *live_idx, int32_t live_start, int32_t n_live,
+                         int32_t n_bins, float lower, float upper, int64_t n_rows, int32_t dim, float ldj_scale, void *stream);
+
 /* Parameter-free element-wise flows: Sigmoid / Logit (stribor/flows/sigmoid.py:9-56), ELU / LeakyReLU
  * (flows/activations.py:11-101), Cumsum / Diff over the last axis (flows/cumsum.py:9-92).
  *   y (nullable for the element kinds): transformed values;  ldiag (nullable, [n_rows, dim]): per-element log-derivative;

@@ -45,7 +45,7 @@ ACT_CODES = {'Identity': 0, 'Tanh': 1, 'ReLU': 2, 'Sigmoid': 3, 'ELU': 4, 'Softp
 
 # every symbol include/stribor_hip.h declares (tests check that the library exports all of them)
 EXPORTS = ['sx_abi_version', 'sx_fragment_mode', 'sx_last_error', 'sx_permute', 'sx_affine_coupling', 'sx_rqs_coupling',
-           'sx_cubic_coupling', 'sx_pointwise', 'sx_rqs_inverse_bwd', 'sx_rqs_forward_bwd', 'sx_affine_coupling_bwd', 'sx_time_affine_coupling', 'sx_cubic_inverse_bwd', 'sx_pointwise_bwd',
+           'sx_cubic_coupling', 'sx_pointwise', 'sx_rqs_inverse_bwd', 'sx_rqs_forward_bwd', 'sx_affine_coupling_bwd', 'sx_time_affine_coupling', 'sx_cubic_inverse_bwd', 'sx_cubic_forward_bwd', 'sx_pointwise_bwd',
            'sx_unit_normal_logprob', 'sx_sum_f64', 'sx_packed_linear_floats', 'sx_pack_linear', 'sx_flow_run',
            'sx_flow_launch_info', 'sx_wgrad', 'sx_wgrad_layer', 'sx_colsum', 'sx_tri_inverse_f64',
            'sx_wgrad_scratch_floats', 'sx_wgrad_layer_scratch_floats', 'sx_flow_bwd_max_steps', 'sx_flow_bwd_partials',
@@ -109,6 +109,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.sx_time_affine_coupling.argtypes = [vp, vp, vp, vp, i64, vp, vp, i32, vp, i32, i32, i64, i32, i32, i32, i32, f32, vp]
     lib.sx_cubic_inverse_bwd.restype = i32
     lib.sx_cubic_inverse_bwd.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, i32, f32, f32, i64, i32, f32, vp]
+    lib.sx_cubic_forward_bwd.restype = i32
+    lib.sx_cubic_forward_bwd.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, i32, f32, f32, i64, i32, f32, vp]
     lib.sx_pointwise_bwd.restype = i32
     lib.sx_pointwise_bwd.argtypes = [vp, vp, vp, vp, i64, i32, i32, f32, vp]
     lib.sx_pointwise.restype = i32

@@ -927,7 +927,10 @@ extern "C" int sx_rqs_forward_bwd(const float *x, const float *gout, const float
 // b-1, b, b+1 and the cumsums -> softmax / sigmoid, in reverse mode.  min() / sign() pick the branch the forward took.
 // Staging and layout as cubic_kernel (padded odd per-lane stride); gradients leave in the parameter tensor's layout.
 // =====================================================================================================
-__global__ __launch_bounds__(256) void cubic_inverse_bwd_kernel(const float *__restrict__ yin, const float *__restrict__ xout,
+// INVERSE = false: the FORWARD direction (x -> f(t), ljd = log f'(t), bin searched on the widths; `xout` unused): no solve, the
+// adjoints of (a, b, c, d, t) are read off the polynomial, the chain below them is the same.
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void cubic_bwd_kernel(const float *__restrict__ yin, const float *__restrict__ xout,
                                                                 const float *__restrict__ gout, const float *__restrict__ gldj,
                                                                 const float *__restrict__ params, int64_t pstride,
                                                                 float *__restrict__ gx, float *__restrict__ gparams,
@@ -963,7 +966,7 @@ __global__ __launch_bounds__(256) void cubic_inverse_bwd_kernel(const float *__r
         const int i = valid ? (int)(e - row * n_live) : 0;
         const int col = live_idx ? live_idx[i] : l0 + i;
         const float yv = valid ? yin[row * dim + col] : lower;
-        const float xo = valid ? xout[row * dim + col] : lower;
+        const float xo = (INVERSE && valid) ? xout[row * dim + col] : lower;
         const float Ao = valid ? gout[row * dim + col] : 0.f;
         const float Al = valid ? gldj[row] * ldj_scale : 0.f;
         const bool inside = (yv >= lower) && (yv <= upper);
@@ -985,7 +988,7 @@ __global__ __launch_bounds__(256) void cubic_inverse_bwd_kernel(const float *__r
         float cw = 0.f, ch = 0.f, cw_b = 0.f;
         for (int k = 0; k < K; ++k) {
             const float wk = CUBIC_MIN_BIN + norm * (p[k] * inv_sw), hk = CUBIC_MIN_BIN + norm * (p[K + k] * inv_sh);
-            if (yn >= ch) { b = k; cw_b = cw; }
+            if (yn >= (INVERSE ? ch : cw)) { b = k; cw_b = cw; }
             cw += wk;
             ch += hk;
         }
@@ -1014,19 +1017,30 @@ __global__ __launch_bounds__(256) void cubic_inverse_bwd_kernel(const float *__r
         const float a = (dL + dR - 2.f * s_b) / (w_b * w_b);
         const float bb = (3.f * s_b - 2.f * dL - dR) / w_b;
         const float c = dL;
-        const float t = (xo - lower) / span - cw_b;
+        const float t = INVERSE ? (xo - lower) / span - cw_b : yn - cw_b;
         const float fp = 3.f * a * (t * t) + 2.f * bb * t + c, fpp = 6.f * a * t + 2.f * bb;
 
         // ---- reverse ----------------------------------------------------------------------------------------------
-        const float Aon = Ao * span;                                   // x = out_n * span + lower
-        const float At = Aon - Al * fpp / fp;                          // out_n = t + cw_b,  ljd = -log f'(t) + const
+        const float Aon = Ao * span;                                   // out = out_n * span + lower
         const float ifp = 1.f / fp;
-        const float Ay = At * ifp / span;                              // y_n = (y - lower) / span
-        const float Aa = -At * (t * t * t) * ifp - Al * 3.f * (t * t) * ifp;
-        const float Ab = -At * (t * t) * ifp - Al * 2.f * t * ifp;
-        const float Ac = -At * t * ifp - Al * ifp;
-        const float Achb = -At * ifp;                                  // d = ch_b
-        const float Acwb = Aon;
+        float Ay, Aa, Ab, Ac, Achb, Acwb;
+        if constexpr (INVERSE) {
+            const float At = Aon - Al * fpp / fp;                      // out_n = t + cw_b,  ljd = -log f'(t) + const
+            Ay = At * ifp / span;                                      // y_n = (y - lower) / span
+            Aa = -At * (t * t * t) * ifp - Al * 3.f * (t * t) * ifp;
+            Ab = -At * (t * t) * ifp - Al * 2.f * t * ifp;
+            Ac = -At * t * ifp - Al * ifp;
+            Achb = -At * ifp;                                          // d = ch_b
+            Acwb = Aon;
+        } else {
+            const float At = Aon * fp + Al * fpp * ifp;                // out_n = f(t),  ljd = log f'(t),  t = x_n - cw_b
+            Ay = At / span;
+            Aa = Aon * (t * t * t) + Al * 3.f * (t * t) * ifp;
+            Ab = Aon * (t * t) + Al * 2.f * t * ifp;
+            Ac = Aon * t + Al * ifp;
+            Achb = Aon;                                                // d = ch_b
+            Acwb = -At;
+        }
         float AdL = Aa / (w_b * w_b) - 2.f * Ab / w_b + Ac;
         float AdR = Aa / (w_b * w_b) - Ab / w_b;
         float As = -2.f * Aa / (w_b * w_b) + 3.f * Ab / w_b;
@@ -1078,11 +1092,11 @@ __global__ __launch_bounds__(256) void cubic_inverse_bwd_kernel(const float *__r
     }
 }
 
-extern "C" int sx_cubic_inverse_bwd(const float *yin, const float *xout, const float *gout, const float *gldj,
+static int cubic_bwd_launch(bool inverse, const float *yin, const float *xout, const float *gout, const float *gldj,
                                     const float *params, int64_t params_stride, float *gx, float *gparams,
                                     const int32_t *live_idx, int32_t live_start, int32_t n_live, int32_t n_bins, float lower,
                                     float upper, int64_t n_rows, int32_t dim, float ldj_scale, void *stream) {
-    SX_REQUIRE(yin && xout && gout && gldj && params && gx && gparams, "sx_cubic_inverse_bwd: null pointer");
+    SX_REQUIRE(yin && (xout || !inverse) && gout && gldj && params && gx && gparams, "sx_cubic_*_bwd: null pointer");
     SX_REQUIRE(dim > 0 && n_live > 0 && n_live <= dim && n_rows >= 0 && n_bins >= 1, "sx_cubic_inverse_bwd: bad sizes");
     SX_REQUIRE(upper > lower, "sx_cubic_inverse_bwd: empty domain");
     if (n_rows == 0) return SX_OK;
@@ -1092,16 +1106,38 @@ extern "C" int sx_cubic_inverse_bwd(const float *yin, const float *xout, const f
     if (lds > 64 * 1024) { block = 64; lds = (size_t)64 * PS * sizeof(float); }
     SX_REQUIRE(lds <= 160 * 1024, "sx_cubic_inverse_bwd: n_bins %d needs %zu B of LDS per wave", n_bins, lds);
     if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void *)cubic_inverse_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        {
+        (void)hipFuncSetAttribute((const void *)cubic_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)cubic_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     const int64_t n_groups = (n_rows * n_live + 63) / 64;
     const int wpb = block / 64;
     int64_t grid = (n_groups + wpb - 1) / wpb;
     const int64_t per_cu = (160 * 1024) / (int64_t)lds > 8 ? 8 : (160 * 1024) / (int64_t)lds;
     if (grid > 256 * per_cu) grid = 256 * per_cu;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(cubic_inverse_bwd_kernel, dim3((int)grid), dim3(block), lds, sx_stream(stream), yin, xout, gout, gldj,
-                       params, params_stride, gx, gparams, live_idx, live_start, n_live, n_bins, lower, upper, n_rows, dim,
-                       ldj_scale);
+    if (inverse)
+        hipLaunchKernelGGL(cubic_bwd_kernel<true>, dim3((int)grid), dim3(block), lds, sx_stream(stream), yin, xout, gout, gldj,
+                           params, params_stride, gx, gparams, live_idx, live_start, n_live, n_bins, lower, upper, n_rows, dim,
+                           ldj_scale);
+    else
+        hipLaunchKernelGGL(cubic_bwd_kernel<false>, dim3((int)grid), dim3(block), lds, sx_stream(stream), yin, xout, gout, gldj,
+                           params, params_stride, gx, gparams, live_idx, live_start, n_live, n_bins, lower, upper, n_rows, dim,
+                           ldj_scale);
     SX_LAUNCH_CHECK();
     return SX_OK;
+}
+extern "C" int sx_cubic_inverse_bwd(const float *yin, const float *xout, const float *gout, const float *gldj,
+                                    const float *params, int64_t params_stride, float *gx, float *gparams,
+                                    const int32_t *live_idx, int32_t live_start, int32_t n_live, int32_t n_bins, float lower,
+                                    float upper, int64_t n_rows, int32_t dim, float ldj_scale, void *stream) {
+    return cubic_bwd_launch(true, yin, xout, gout, gldj, params, params_stride, gx, gparams, live_idx, live_start, n_live, n_bins,
+                            lower, upper, n_rows, dim, ldj_scale, stream);
+}
+extern "C" int sx_cubic_forward_bwd(const float *x, const float *gout, const float *gldj, const float *params,
+                                    int64_t params_stride, float *gx, float *gparams, const int32_t *live_idx,
+                                    int32_t live_start, int32_t n_live, int32_t n_bins, float lower, float upper,
+                                    int64_t n_rows, int32_t dim, float ldj_scale, void *stream) {
+    return cubic_bwd_launch(false, x, nullptr, gout, gldj, params, params_stride, gx, gparams, live_idx, live_start, n_live, n_bins,
+                            lower, upper, n_rows, dim, ldj_scale, stream);
 }

@@ -290,11 +290,7 @@ class Coupling(Transform):
         return isinstance(self.transform, (Affine, Spline))
 
     def _autograd_forward(self, x2: torch.Tensor, lat2=None):
-        """forward_and_log_det_jacobian with a graph (affine and quadratic-spline couplings; the cubic spline kernel has a
-        hand-written backward for the inverse direction only)."""
-        from .spline import Spline
-        if isinstance(self.transform, Spline) and self.transform.spline_type != 'quadratic':
-            raise NotImplementedError('forward-direction autograd is built for affine and quadratic-spline couplings')
+        """forward_and_log_det_jacobian with a graph (affine and spline couplings)."""
         return self._autograd_inverse(x2, lat2, reverse=False)
 
     def _autograd_inverse(self, x2: torch.Tensor, lat2=None, reverse: bool = True):
@@ -302,7 +298,7 @@ class Coupling(Transform):
         Linear layers (rocBLAS; only the rows of the last layer that parameterise transformed columns), the transform
         and its backward are the HIP kernels behind ``RQSInverse`` / ``AffineCouplingOp``.
         Returns (x_out [N, D], ldj [N])."""
-        from .spline import CubicInverse, RQSForward, RQSInverse, Spline
+        from .spline import CubicForward, CubicInverse, RQSForward, RQSInverse, Spline
         from .affine import AffineCouplingOp
         sp, net = self.transform, self.transform.latent_net
         is_spline = isinstance(sp, Spline)
@@ -336,9 +332,10 @@ class Coupling(Transform):
         else:                                                                        # any nn.Module: torch's own graph
             params = net(z).index_select(1, rows_t)
         if is_spline:
-            if not reverse and sp.spline_type == 'cubic':
-                raise NotImplementedError('forward-direction autograd is built for affine and quadratic-spline couplings')
-            op = CubicInverse if sp.spline_type == 'cubic' else (RQSInverse if reverse else RQSForward)
+            if sp.spline_type == 'cubic':
+                op = CubicInverse if reverse else CubicForward
+            else:
+                op = RQSInverse if reverse else RQSForward
             return op.apply(x2, params, live_idx, int(live[0]), len(live), sp.n_bins, sp.lower, sp.upper, 1.0)
         # Transform.inverse_and_log_det_jacobian: minus the forward log-det (flow.py:47)
         return AffineCouplingOp.apply(x2, params, live_idx, int(live[0]), len(live), bool(reverse), -1.0 if reverse else 1.0)

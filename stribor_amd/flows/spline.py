@@ -18,7 +18,7 @@ import torch.nn as nn
 from .. import _hip
 from ..flow import ElementwiseTransform, flatten_rows
 
-__all__ = ['Spline', 'run_rqs_kernel', 'run_cubic_kernel', 'RQSInverse', 'RQSForward', 'CubicInverse', 'RQSCouplingSlab', 'RQSCouplingSlabL1', 'slab_slot_rows']
+__all__ = ['Spline', 'run_rqs_kernel', 'run_cubic_kernel', 'RQSInverse', 'RQSForward', 'CubicInverse', 'CubicForward', 'RQSCouplingSlab', 'RQSCouplingSlabL1', 'slab_slot_rows']
 
 def check_errors(device=None) -> None:
     """Raise what the reference would have raised for data-dependent failures (synchronises): the spline's
@@ -300,6 +300,35 @@ class CubicInverse(torch.autograd.Function):
         return gx, gparams, None, None, None, None, None, None, None
 
 
+class CubicForward(torch.autograd.Function):
+    """(y, row log-det) = FORWARD monotone cubic spline of the live columns as a differentiable op: forward =
+    sx_cubic_coupling(reverse=0), backward = sx_cubic_forward_bwd (the polynomial's own derivatives, then the chain of
+    CubicInverse through the Steffen knot derivatives, cumsums and softmax)."""
+
+    @staticmethod
+    def forward(ctx, x2, params, live_idx, live_start, n_live, n_bins, lower, upper, ldj_scale):
+        x2 = x2.contiguous()
+        params = params.contiguous()
+        y, ldj, _ = run_cubic_kernel(x2, params, params.stride(0), live_idx, live_start, n_live, n_bins, lower, upper, False,
+                                     True, False, ldj_scale)
+        ctx.save_for_backward(x2, params)
+        ctx.meta = (live_idx, live_start, n_live, n_bins, float(lower), float(upper), float(ldj_scale))
+        return y, ldj
+
+    @staticmethod
+    def backward(ctx, gy, gldj):
+        x2, params = ctx.saved_tensors
+        live_idx, live_start, n_live, n_bins, lower, upper, ldj_scale = ctx.meta
+        n, d = x2.shape
+        gy = (torch.zeros_like(x2) if gy is None else gy).to(torch.float32).contiguous()
+        gldj = (torch.zeros(n, device=x2.device) if gldj is None else gldj).to(torch.float32).contiguous()
+        gx = gy.clone()
+        gparams = torch.empty_like(params)
+        _hip.call('sx_cubic_forward_bwd', x2, x2.data_ptr(), gy.data_ptr(), gldj.data_ptr(), params.data_ptr(), params.stride(0),
+                  gx.data_ptr(), gparams.data_ptr(), _hip.ptr(live_idx), live_start, n_live, n_bins, lower, upper, n, d, ldj_scale)
+        return gx, gparams, None, None, None, None, None, None, None
+
+
 class Spline(ElementwiseTransform):
     def __init__(self, dim: int, n_bins: int, latent_net: Optional[nn.Module] = None, lower: Optional[float] = 0,
                  upper: Optional[float] = 1, spline_type: Optional[str] = 'cubic', **kwargs):
@@ -374,9 +403,7 @@ class Spline(ElementwiseTransform):
                 raise ValueError('Spline with a latent_net needs `latent`')
             params = self.latent_net.forward_autograd(lat2)                                                 # spline.py:82-86
         if self.spline_type == 'cubic':
-            if not reverse:
-                raise NotImplementedError('forward-direction autograd is built for quadratic splines')
-            op = CubicInverse
+            op = CubicInverse if reverse else CubicForward
         else:
             op = RQSInverse if reverse else RQSForward
         return op.apply(x2, params, None, 0, d, self.n_bins, self.lower, self.upper, 1.0)
