@@ -243,3 +243,26 @@ def test_bench_spawns_its_own_ranks(monkeypatch):
     assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
     assert cmd[cmd.index('--gpus') + 1] == '8' and cmd[cmd.index('--steps') + 1] == '7'
     assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+
+
+@pytest.mark.parametrize('n_live,K', [(32, 16), (5, 3), (1, 1), (7, 16), (2, 9)])
+def test_slab_slot_rows_cover_every_parameter_row_once(n_live, K):
+    """sx_rqs_slab_bwd's slot map (include/stribor_hip.h): every row of the selected last conditioner layer -- per transformed
+    column K widths, K heights, K-1 derivatives (spline.py:82-86) -- sits in exactly one slot, in the tile of its block and the
+    lane half of its column; all other slots are padding."""
+    import numpy as np
+    from stribor_amd.flows.spline import slab_slot_rows
+    rows = slab_slot_rows(n_live, K)
+    P = 3 * K - 1
+    n_slabs = (n_live + 1) // 2
+    assert rows.shape == (n_slabs * 96,) and rows.dtype == np.int32
+    used = rows[rows >= 0]
+    assert sorted(used.tolist()) == list(range(n_live * P))
+    for slot, r in enumerate(rows):
+        if r < 0:
+            continue
+        s_, t, R = slot // 96, (slot % 96) // 32, slot % 32
+        ci, off = divmod(int(r), P)
+        assert ci == 2 * s_ + ((R >> 2) & 1)                         # column <-> lane half of the C fragment
+        k = (R & 3) + 4 * (R >> 3)
+        assert off == t * K + k and k < (K - 1 if t == 2 else K)     # block <-> tile, parameter <-> register
