@@ -408,8 +408,8 @@ extern "C" int sx_pointwise(const void *x, void *y, float *ldj, float *ldiag, in
             if (g > 2048) g = 2048;
             const size_t lds4 = (size_t)4 * 64 * (dim + 4) * sizeof(float);
             if (dtype == SX_F32 && dim % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && lds4 <= 150 * 1024 && dim <= 16384) {
-                // the attribute is what the runtime sizes the workgroup's LDS allocation by: set it to this launch's need
-                // (a blanket 160 KiB leaves one workgroup per CU), and only when it changes
+                // the attribute is set to this launch's need (a blanket 160 KiB cost the spline slab backward a workgroup
+                // per CU), and only when it changes
                 static size_t set_to[64];
                 int dev = 0;
                 (void)hipGetDevice(&dev);

@@ -679,8 +679,8 @@ extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *g
 #define SX_SLAB2(HT_, KC_, HF_, SPW_)                                                                              \
     do {                                                                                                           \
         auto kern = rqs_slab_bwd_kernel<HT_, KC_, HF_, SPW_>;                                                      \
-        /* the attribute is set to the launch's own need: the runtime sizes the workgroup's LDS allocation by it, */  \
-        /* so a blanket 160 KiB would leave one workgroup per CU (measured: 1.16 vs 0.92 ms at SPW = 1)           */  \
+        /* the attribute is set to the launch's own need: at a blanket 160 KiB the SPW = 1 form ran one workgroup  */  \
+        /* per CU less (measured: 1.16 vs 0.92 ms)                                                                */  \
         static int lds_allowed[64];                                                                                \
         if (lds > 48 * 1024 && !lds_allowed[dev & 63]) {                                                           \
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

@@ -17,4 +17,9 @@ a={k:sum(v)/len(v) for k,v in agg.items()}
 for k,v in sorted(a.items()): print('%-28s %.4g'%(k,v))
 cyc=a['GRBM_GUI_ACTIVE']/8; simd=cyc*1024
 print('cycles',cyc,'valu busy',4*a['SQ_ACTIVE_INST_VALU']/simd,'mfma busy',a['SQ_VALU_MFMA_BUSY_CYCLES']/simd,'waves/simd',4*a['SQ_WAVE_CYCLES']/simd)
+import json
+chunks=131072.0
+json.dump({'kernel':'rqs_slab_bwd_kernel<2,16,true,2> (2^18 rows, D=64, 32 transformed columns, H=64, K=16)','counters':a,'gpu_cycles':cyc,
+ 'valu_issue_busy_frac':4*a['SQ_ACTIVE_INST_VALU']/simd,'mfma_pipe_busy_frac':a['SQ_VALU_MFMA_BUSY_CYCLES']/simd,'waves_per_simd':4*a['SQ_WAVE_CYCLES']/simd,
+ 'valu_instructions_per_chunk_and_slab':a['SQ_INSTS_VALU']/chunks,'mfma_per_chunk_and_slab':a['SQ_INSTS_MFMA']/chunks,'wait_frac_of_wave_cycles':a['SQ_WAIT_ANY']/a['SQ_WAVE_CYCLES']},open('$O/sq_slab_bwd.json','w'),indent=1)
 PY
