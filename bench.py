@@ -163,7 +163,7 @@ def time_extra_config(name, workload, flow, x, steps, warmup, flops_per_row, byt
 
 def time_training_step(name, workload, flow, x, steps, note):
     """Training step beside the inference lines: forward + backward of loss = -log_prob(x).mean(), all
-    parameter gradients; median of `steps` event-timed steps after warm-up."""
+    parameter gradients; median over event-timed groups of 3 steps after warm-up."""
     import torch
 
     def step():
@@ -176,14 +176,15 @@ def time_training_step(name, workload, flow, x, steps, note):
     for _ in range(3):
         loss = step()
     torch.cuda.synchronize()
-    ts = []
-    for _ in range(steps):
+    ts, inner = [], 3                      # events around groups of steps: a per-step sync would expose the launch ramp-up
+    for _ in range(max(1, steps // inner)):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        loss = step()
+        for _ in range(inner):
+            loss = step()
         b.record()
         torch.cuda.synchronize()
-        ts.append(a.elapsed_time(b))
+        ts.append(a.elapsed_time(b) / inner)
     ts.sort()
     ms = ts[len(ts) // 2]
     finite = bool(torch.isfinite(loss).item()) and all(bool(torch.isfinite(p_.grad).all()) for p_ in flow.parameters())
@@ -381,14 +382,14 @@ def main():
             f2 = fd.build_flow(st, fd.cfg2_desc(), 64).to(dev)
             x2t = torch.randn(ROWS_PER_GPU, 64, device=dev, generator=gen)
             tr.append(time_training_step('cfg2_train', 'cfg2 flow, 2^20 rows fp32: loss = -log_prob.mean(), backward to every '
-                                         'parameter', f2, x2t, 10,
+                                         'parameter', f2, x2t, 12,
                                          'layer-major backward: weight gradients contracted in the kernel (DESIGN 4.3)'))
             del f2, x2t
             torch.manual_seed(0)
             f3 = fd.build_flow(st, fd.cfg3_desc(), 64).to(dev)
             x3t = torch.randn(ROWS_PER_GPU // 4, 64, device=dev, generator=gen)
             tr.append(time_training_step('cfg3_train', 'cfg3 flow, 2^18 rows fp32: loss = -log_prob.mean(), backward to every '
-                                         'parameter', f3, x3t, 10,
+                                         'parameter', f3, x3t, 12,
                                          'spline backward fused with the last conditioner layer, no [N, 1504] parameter tensor '
                                          '(sx_rqs_slab_bwd, DESIGN 4.3.1); HBM bytes per step in profiles/pmc_training_cfg3_fused.json'))
             del f3, x3t
