@@ -497,7 +497,17 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
         else { e0 = grp << 6; n_here = (int)((n_elem - e0) < 64 ? (n_elem - e0) : 64); }
         const int total = n_here * P;
         // ---- stage: consecutive idx -> consecutive HBM addresses (one contiguous span when rows are packed) ----
-        if (contig && n_here == 64 && (P & 1) == 0 && (!ALIGNED || ((e0 * P) & 3) == 0) && ((reinterpret_cast<uintptr_t>(params) & 15) == 0)) {
+        // K even (P / 2 odd): the span is copied as it is (16 B per lane in, 16 B out) and a lane reads its element's parameters
+        // as 8-byte pairs at a stride of P / 2 pairs -- odd, so the 64-bit reads are conflict-free without padding, and the
+        // 270 instructions per element of index arithmetic + scalar LDS writes of the padded form reduce to 17
+        // (forward direction only: the inverse's reference mode re-reads single parameters at the even stride, 2-way conflicts)
+        const bool lin = !INVERSE && K == 16 && contig && n_here == 64 && (!ALIGNED || ((e0 * P) & 3) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(params) & 15) == 0);
+        if (lin) {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(params + e0 * P);
+            f32x4 *dst = reinterpret_cast<f32x4 *>(sp);
+            for (int i4 = lane; i4 < 16 * P; i4 += 64) dst[i4] = src[i4];
+        } else if (contig && n_here == 64 && (P & 1) == 0 && (!ALIGNED || ((e0 * P) & 3) == 0) && ((reinterpret_cast<uintptr_t>(params) & 15) == 0)) {
             // 64*P floats = 16*P float4, 16-byte aligned (P even): vector loads, scalar LDS writes into the padded rows
             const f32x4 *src = reinterpret_cast<const f32x4 *>(params + e0 * P);
             for (int i4 = lane; i4 < 16 * P; i4 += 64) {
@@ -532,7 +542,7 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
         const float xv = valid ? rqs_load<BF16>(x, row * dim + col) : lower;
         const bool inside = (xv >= lower) && (xv <= upper);      // :40 closed interval
         const float xin = ((inside ? xv : lower) - lower) / span;            // :98-101
-        float *p = sp + (valid ? lane : 0) * PS;                 // [0,K) widths, [K,2K) heights, 2K / 2K+1 derivatives
+        float *p = sp + (valid ? lane : 0) * (lin ? P : PS);     // [0,K) widths, [K,2K) heights, 2K / 2K+1 derivatives
 
         // ---- normalised widths / heights, running cumsums (:103-115) and the bin search (search_sorted.py:4-5) in
         //      one sweep that also keeps the widths / heights of bins b-1, b, b+1 ----------------------------------
@@ -569,8 +579,17 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
         };
         if (K == 16) {          // wave-uniform: parameters in registers, fully unrolled, selects only
             float rw[16], rh[16];
+            if (lin) {                              // 8-byte aligned pairs
+                typedef float f32pair __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int k = 0; k < 16; ++k) { rw[k] = p[k]; rh[k] = p[16 + k]; }
+                for (int k = 0; k < 16; k += 2) {
+                    const f32pair a = *reinterpret_cast<const f32pair *>(p + k), c2 = *reinterpret_cast<const f32pair *>(p + 16 + k);
+                    rw[k] = a.x; rw[k + 1] = a.y; rh[k] = c2.x; rh[k + 1] = c2.y;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { rw[k] = p[k]; rh[k] = p[16 + k]; }
+            }
             float mw = rw[0], mh = rh[0];
 #pragma unroll
             for (int k = 1; k < 16; ++k) { mw = fmaxf(mw, rw[k]); mh = fmaxf(mh, rh[k]); }
