@@ -157,6 +157,9 @@ int sx_rqs_forward_bwd(const float *x, const float *gout, const float *gldj, con
  * A workgroup owns a slab of W2 -- the 3K-1 rows of two transformed columns -- over a range of rows (sx_rqs_slab.hip).
  *   x, gout [n_rows, dim], gldj [n_rows]: as sx_rqs_inverse_bwd;  h [n_rows, ld_h]: last hidden activation (`hidden` <= 64
  *   features);  n_bins <= 16.
+ *   xout: NULL for rational-quadratic splines.  Not NULL: MONOTONE CUBIC splines (cubic_spline.py:21-251; as
+ *   sx_cubic_inverse_bwd: xout [n_rows, dim] is the inverse pass's output, domain [left, right] on both sides, 2K+2 parameters
+ *   per element: slots 32 t + R of tile 2 carry the two boundary-derivative parameters at (R&3) + 4 (R>>3) = 0, 1).
  *   Slots: slab s (columns live[2s], live[2s+1]) has 96 slots; slot 32 t + R (t = 0 widths, 1 heights, 2 derivatives) is
  *   parameter (R&3) + 4 (R>>3) of column 2 s + ((R>>2)&1).  slot_rows[sx_rqs_slab_slots(n_live)]: slot -> row of W2 / b2 as
  *   handed to the packers, or -1 (padding).
@@ -174,7 +177,8 @@ int sx_rqs_forward_bwd(const float *x, const float *gout, const float *gldj, con
  *   loss (dL/dlog_prob = 1/N underflows fp16 for large batches).  No host synchronisation. */
 int32_t sx_rqs_slab_slots(int32_t n_live);
 size_t sx_rqs_slab_scratch_floats(int64_t n_rows, int32_t n_live, int32_t hidden);
-int sx_rqs_slab_bwd(const float *x, const float *gout, const float *gldj, const float *h, int64_t ld_h, int32_t hidden,
+int sx_rqs_slab_bwd(const float *x, const float *gout, const float *gldj, const float *xout, const float *h, int64_t ld_h,
+                    int32_t hidden,
                     const float *w_fwd, const float *w_bwd, const int32_t *slot_rows, float *gx, float *gh, int64_t ld_gh,
                     float *dW, int64_t ldw, float *db, const int32_t *live_idx, int32_t live_start, int32_t n_live,
                     int32_t n_bins, float left, float right, float bottom, float top, int64_t n_rows, int32_t dim,

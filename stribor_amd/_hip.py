@@ -95,7 +95,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.sx_rqs_slab_scratch_floats.restype = C.c_size_t
     lib.sx_rqs_slab_scratch_floats.argtypes = [i64, i32, i32]
     lib.sx_rqs_slab_bwd.restype = i32
-    lib.sx_rqs_slab_bwd.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, i32, i32, i32, f32, f32, f32,
+    lib.sx_rqs_slab_bwd.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, i32, i32, i32, f32, f32, f32,
                                     f32, i64, i32, f32, i32, vp, vp, vp, vp]
     lib.sx_rqs_slab_l1_scratch_floats.restype = C.c_size_t
     lib.sx_rqs_slab_l1_scratch_floats.argtypes = [i32, i32]

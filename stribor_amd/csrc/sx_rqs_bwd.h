@@ -341,3 +341,147 @@ __device__ __forceinline__ float rqs_inverse_bwd_regs(rqsb_f16v &Wp, rqsb_f16v &
     }
     return inside ? A.Axin : Ao;                                         // tails: out = x
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The monotone CUBIC spline's reverse mode (inverse direction) on registers, for the slab backward: Wp / Hp hold the element's
+// K widths / heights, Dp[0..1] its two boundary-derivative parameters (cubic_spline.py:103-137); the same mathematics as
+// cubic_bwd_kernel<true> (sx_rqs.hip: the solve differentiated implicitly at the forward's output `xo`, then reverse mode
+// through the Steffen knot derivatives, cumsums and softmax), static indices, hardware exp / rcp.
+#define CUBICB_MIN_BIN 1e-2f
+template <int KC>
+__device__ __forceinline__ float cubic_inverse_bwd_regs(rqsb_f16v &Wp, rqsb_f16v &Hp, rqsb_f16v &Dp, int K, float yv, float xo,
+                                                        float Ao, float Al, float lower, float upper, bool valid) {
+    constexpr float LOG2E = 1.44269504088896341f;
+    const int Kn = KC ? KC : K;
+    const float norm = 1.f - CUBICB_MIN_BIN * (float)Kn;
+    const float span = upper - lower, inv_span = __builtin_amdgcn_rcpf(span);
+    const bool inside = (yv >= lower) && (yv <= upper);
+    const float yn = ((inside ? yv : lower) - lower) * inv_span;
+    float mw = Wp[0], mh = Hp[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k)
+        if (KC ? (k < KC) : true) {
+            const bool used = KC ? true : (k < K);
+            mw = used ? fmaxf(mw, Wp[k]) : mw;
+            mh = used ? fmaxf(mh, Hp[k]) : mh;
+        }
+    float sw = 0.f, sh = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (KC ? (k < KC) : true) {
+            const bool used = KC ? true : (k < K);
+            const float ew = used ? __builtin_amdgcn_exp2f((Wp[k] - mw) * LOG2E) : 0.f;
+            const float eh = used ? __builtin_amdgcn_exp2f((Hp[k] - mh) * LOG2E) : 0.f;
+            Wp[k] = ew;
+            Hp[k] = eh;
+            sw += ew;
+            sh += eh;
+        }
+    const float nw = norm * __builtin_amdgcn_rcpf(sw), nh = norm * __builtin_amdgcn_rcpf(sh);
+    // one sweep: the bin (last lower edge <= y_n, by heights), its lower edge on the widths side, the sizes of bins b-1, b, b+1
+    int b = 0;
+    float cw = 0.f, ch = 0.f, cw_b = 0.f, w_b = 1.f, h_b = 1.f, w_m = 1.f, h_m = 1.f, w_p = 1.f, h_p = 1.f, w_last = 1.f, h_last = 1.f;
+    bool need_next = false;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (KC ? (k < KC) : true) {
+            const bool used = KC ? true : (k < K);
+            const float wk = fmaf(Wp[k], nw, CUBICB_MIN_BIN), hk = fmaf(Hp[k], nh, CUBICB_MIN_BIN);
+            const bool ge = used && yn >= ch;
+            const bool nx = used && !ge && need_next;
+            b = ge ? k : b;
+            cw_b = ge ? cw : cw_b;
+            w_b = ge ? wk : w_b; h_b = ge ? hk : h_b;
+            w_m = ge ? w_last : w_m; h_m = ge ? h_last : h_m;
+            w_p = nx ? wk : w_p; h_p = nx ? hk : h_p;
+            need_next = used ? ge : need_next;                   // edges only grow: once false it stays false
+            w_last = used ? wk : w_last; h_last = used ? hk : h_last;
+            cw += used ? wk : 0.f;
+            ch += used ? hk : 0.f;
+        }
+    const bool has_m = b > 0, has_p = b < Kn - 1;
+    const float s_b = h_b * __builtin_amdgcn_rcpf(w_b), s_m = h_m * __builtin_amdgcn_rcpf(w_m), s_p = h_p * __builtin_amdgcn_rcpf(w_p);
+    const float sgl = rqsb_sigmoid_p<true>(Dp[0]), sgr = rqsb_sigmoid_p<true>(Dp[1]);
+    float dL, dR;
+    bool L_m1 = false, L_first = false, R_m1 = false, R_first = false;
+    if (!has_m) dL = sgl * 3.f * s_b;                                                      // :126
+    else {
+        const float m1 = fminf(s_m, s_b), m2 = 0.5f * (w_b * s_m + w_m * s_b) * __builtin_amdgcn_rcpf(w_m + w_b);    // :118-123
+        L_m1 = m1 < m2; L_first = s_m < s_b;
+        dL = fminf(m1, m2) * 2.f;                                                          // :124, :129 (slopes are positive)
+    }
+    if (!has_p) dR = sgr * 3.f * s_b;                                                      // :127
+    else {
+        const float m1 = fminf(s_b, s_p), m2 = 0.5f * (w_p * s_b + w_b * s_p) * __builtin_amdgcn_rcpf(w_b + w_p);
+        R_m1 = m1 < m2; R_first = s_b < s_p;
+        dR = fminf(m1, m2) * 2.f;
+    }
+    const float iw = __builtin_amdgcn_rcpf(w_b), iw2 = iw * iw;
+    const float a = (dL + dR - 2.f * s_b) * iw2;                                           // :134
+    const float bb = (3.f * s_b - 2.f * dL - dR) * iw;                                     // :135
+    const float c = dL;                                                                    // :136
+    const float t = (xo - lower) * inv_span - cw_b;
+    const float fp = 3.f * a * (t * t) + 2.f * bb * t + c, fpp = 6.f * a * t + 2.f * bb;
+    // ---- reverse: the solve f(t) = y_n differentiated implicitly --------------------------------------------------------
+    const float Aon = Ao * span;                                   // x = out_n * span + lower
+    const float ifp = __builtin_amdgcn_rcpf(fp);
+    const float At = Aon - Al * fpp * ifp;                         // out_n = t + cw_b,  ljd = -log f'(t) + const
+    const float Ay = At * ifp * inv_span;                          // y_n = (y - lower) / span
+    const float Aa = -At * (t * t * t) * ifp - Al * 3.f * (t * t) * ifp;
+    const float Ab = -At * (t * t) * ifp - Al * 2.f * t * ifp;
+    const float Ac = -At * t * ifp - Al * ifp;
+    const float Achb = -At * ifp;                                  // d = ch_b
+    const float Acwb = Aon;
+    const float AdL = Aa * iw2 - 2.f * Ab * iw + Ac;
+    const float AdR = Aa * iw2 - Ab * iw;
+    float As = -2.f * Aa * iw2 + 3.f * Ab * iw;
+    float Aw = -2.f * a * Aa * iw - bb * Ab * iw;
+    float Ah = 0.f, Awm = 0.f, Ahm = 0.f, Awp = 0.f, Ahp = 0.f, Asm = 0.f, Asp = 0.f, Audl = 0.f, Audr = 0.f;
+    if (!has_m) { Audl = AdL * 3.f * s_b * sgl * (1.f - sgl); As += AdL * 3.f * sgl; }
+    else if (L_m1) { if (L_first) Asm += 2.f * AdL; else As += 2.f * AdL; }
+    else {
+        const float iWd = __builtin_amdgcn_rcpf(w_m + w_b), N = w_b * s_m + w_m * s_b;      // dL = N / Wd
+        Aw += AdL * (s_m * iWd - N * iWd * iWd);
+        Awm += AdL * (s_b * iWd - N * iWd * iWd);
+        Asm += AdL * w_b * iWd;
+        As += AdL * w_m * iWd;
+    }
+    if (!has_p) { Audr = AdR * 3.f * s_b * sgr * (1.f - sgr); As += AdR * 3.f * sgr; }
+    else if (R_m1) { if (R_first) As += 2.f * AdR; else Asp += 2.f * AdR; }
+    else {
+        const float iWd = __builtin_amdgcn_rcpf(w_b + w_p), N = w_p * s_b + w_b * s_p;      // dR = N / Wd
+        Awp += AdR * (s_b * iWd - N * iWd * iWd);
+        Aw += AdR * (s_p * iWd - N * iWd * iWd);
+        As += AdR * w_p * iWd;
+        Asp += AdR * w_b * iWd;
+    }
+    Ah += As * iw;  Aw += -As * s_b * iw;
+    { const float im = __builtin_amdgcn_rcpf(w_m); Ahm += Asm * im; Awm += -Asm * s_m * im; }
+    { const float ip = __builtin_amdgcn_rcpf(w_p); Ahp += Asp * ip; Awp += -Asp * s_p * ip; }
+    if (!has_m) { Awm = 0.f; Ahm = 0.f; }
+    if (!has_p) { Awp = 0.f; Ahp = 0.f; }
+    // bin sizes: direct terms at b-1, b, b+1 + the cumsums' (cw_b, ch_b) on every bin below b; softmax backward
+    float dotw = 0.f, doth = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (KC ? (k < KC) : true) {
+            const float gw = (k < b ? Acwb : 0.f) + (k == b ? Aw : 0.f) + (k == b - 1 ? Awm : 0.f) + (k == b + 1 ? Awp : 0.f);
+            const float gh = (k < b ? Achb : 0.f) + (k == b ? Ah : 0.f) + (k == b - 1 ? Ahm : 0.f) + (k == b + 1 ? Ahp : 0.f);
+            dotw += Wp[k] * gw;                                    // unused entries hold 0
+            doth += Hp[k] * gh;
+        }
+    const bool on = valid && inside;
+    const float fw = on ? nw : 0.f, fh = on ? nh : 0.f;            // norm / sum(e), gated
+    dotw *= nw * __builtin_amdgcn_rcpf(norm);                      // sum_k p_k G_k, p_k = e_k / sum(e)
+    doth *= nh * __builtin_amdgcn_rcpf(norm);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const bool used = KC ? (k < KC) : (k < K);
+        const float gw = (k < b ? Acwb : 0.f) + (k == b ? Aw : 0.f) + (k == b - 1 ? Awm : 0.f) + (k == b + 1 ? Awp : 0.f);
+        const float gh = (k < b ? Achb : 0.f) + (k == b ? Ah : 0.f) + (k == b - 1 ? Ahm : 0.f) + (k == b + 1 ? Ahp : 0.f);
+        Wp[k] = used ? fw * Wp[k] * (gw - dotw) : 0.f;
+        Hp[k] = used ? fh * Hp[k] * (gh - doth) : 0.f;
+        Dp[k] = k == 0 ? (on ? Audl : 0.f) : (k == 1 ? (on ? Audr : 0.f) : 0.f);
+    }
+    return inside ? Ay : Ao;                                          // tails: out = y
+}

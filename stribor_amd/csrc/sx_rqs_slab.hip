@@ -46,6 +46,7 @@ __device__ unsigned long long g_slab_prof[16];
 
 struct slab_args {
     const float *x, *gout, *gldj, *h;   // x, gout [N, dim]; gldj [N]; h [N, ld_h] (H valid features)
+    const float *xout;                  // cubic splines: the inverse pass's output [N, dim] (the solve is differentiated there)
     const float *wf;                    // sx_pack_linear(W2 rows by slot): [3 n_slabs][HT][1024] + bias [3 n_slabs][32]
     const float *wb;                    // sx_pack_linear(transpose): [HT][3 n_slabs][1024]
     float *gx;                          // [N, dim]: the transformed columns are written
@@ -101,7 +102,8 @@ __device__ __forceinline__ void flag_set(int *flag, int v) {
 // dh tile each through LDS, so only ONE partial per slab pair goes to HBM (the dh partials are the kernel's HBM traffic).
 // Workgroup id -> (slab group, row range) is XCD-aware: ids are dealt round-robin to the 8 XCDs, so the n_groups workgroups
 // that walk the same rows (and re-read the same h / x lines) are given ids 8 apart -- the same XCD, the same L2.
-template <int HT, int KC, bool HFULL, int SPW>
+// CUBIC: monotone cubic splines (2K + 2 parameters per element: widths | heights | two boundary derivatives in the third tile).
+template <int HT, int KC, bool HFULL, int SPW, bool CUBIC>
 __global__ __launch_bounds__(256 * SPW, SPW == 1 ? 2 : 1) void rqs_slab_bwd_kernel(const slab_args k) {
     constexpr int SLAB_F = 6 * HT * 1024;                               // per slab: W2 slab | its transpose (floats)
     constexpr int FWo = 0, BWo = 3 * HT * 1024;
@@ -200,6 +202,8 @@ __global__ __launch_bounds__(256 * SPW, SPW == 1 ? 2 : 1) void rqs_slab_bwd_kern
         }
         SLAB_T(0);      // h load + split
         const float xl = xb_[xoff], gol = gb_[xoff], gll = lb_[jc];
+        [[maybe_unused]] float xo = 0.f;
+        if constexpr (CUBIC) xo = (k.xout + row0 * k.dim)[xoff];
         const float xv = valid ? xl : k.bottom;
         const float Ao = valid ? gol * sc_in : 0.f;
         const float Al = valid ? gll * (k.ldj_scale * sc_in) : 0.f;
@@ -227,9 +231,13 @@ __global__ __launch_bounds__(256 * SPW, SPW == 1 ? 2 : 1) void rqs_slab_bwd_kern
         }
         SLAB_T(1);      // x / adjoint loads + parameter GEMM issue
         // ---- the spline's reverse mode on the lane's own element: parameters -> their gradients, in place ---------------
-        const float gxe = (SX_SLAB_X & 1) ? xv + Ao + Al
-                                          : rqs_inverse_bwd_regs<KC>(acc[0].v[0], acc[1].v[0], acc[2].v[0], k.K, xv, Ao, Al, k.left,
-                                                                     k.right, k.bottom, k.top, valid);
+        float gxe;
+        if constexpr (CUBIC)
+            gxe = cubic_inverse_bwd_regs<KC>(acc[0].v[0], acc[1].v[0], acc[2].v[0], k.K, xv, xo, Ao, Al, k.left, k.right, valid);
+        else
+            gxe = (SX_SLAB_X & 1) ? xv + Ao + Al
+                                  : rqs_inverse_bwd_regs<KC>(acc[0].v[0], acc[1].v[0], acc[2].v[0], k.K, xv, Ao, Al, k.left, k.right,
+                                                             k.bottom, k.top, valid);
         SLAB_T(2);      // spline reverse mode (waits for the GEMM)
         btile<1> bd[3];
 #pragma unroll
@@ -644,7 +652,7 @@ extern "C" size_t sx_rqs_slab_scratch_floats(int64_t n_rows, int32_t n_live, int
     return (size_t)p.n_groups * (size_t)n_chunks * HT * 1024 + (size_t)n_slabs * p.n_ranges * (96 * 32 * HT + 96);
 }
 
-extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *gldj, const float *h, int64_t ld_h,
+extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *gldj, const float *xout, const float *h, int64_t ld_h,
                                int32_t hidden, const float *w_fwd, const float *w_bwd, const int32_t *slot_rows, float *gx,
                                float *gh, int64_t ld_gh, float *dW, int64_t ldw, float *db, const int32_t *live_idx,
                                int32_t live_start, int32_t n_live, int32_t n_bins, float left, float right, float bottom,
@@ -665,7 +673,7 @@ extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *g
     const slab_shape pl = slab_plan(n_slabs, n_chunks);
     const int n_ranges = pl.n_ranges, n_groups = pl.n_groups;
     slab_args k;
-    k.x = x; k.gout = gout; k.gldj = gldj; k.h = h; k.wf = w_fwd; k.wb = w_bwd; k.gx = gx;
+    k.x = x; k.gout = gout; k.gldj = gldj; k.xout = xout; k.h = h; k.wf = w_fwd; k.wb = w_bwd; k.gx = gx;
     k.dh_part = scratch;
     k.w_part = scratch + (size_t)n_groups * n_chunks * HT * 1024;
     k.live_idx = live_idx; k.scale = scale; k.flags = err_flag; k.n_rows = n_rows; k.ld_h = ld_h; k.l0 = live_start; k.n_live = n_live;
@@ -678,14 +686,14 @@ extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *g
     (void)hipGetDevice(&dev);
 #define SX_SLAB2(HT_, KC_, HF_, SPW_)                                                                              \
     do {                                                                                                           \
-        auto kern = rqs_slab_bwd_kernel<HT_, KC_, HF_, SPW_>;                                                      \
+        auto kern = xout ? rqs_slab_bwd_kernel<HT_, KC_, HF_, SPW_, true> : rqs_slab_bwd_kernel<HT_, KC_, HF_, SPW_, false>;                                                      \
         /* the attribute is set to the launch's own need: at a blanket 160 KiB the SPW = 1 form ran one workgroup  */  \
         /* per CU less (measured: 1.16 vs 0.92 ms)                                                                */  \
-        static int lds_allowed[64];                                                                                \
-        if (lds > 48 * 1024 && !lds_allowed[dev & 63]) {                                                           \
+        static int lds_allowed[2][64];                                                                             \
+        if (lds > 48 * 1024 && !lds_allowed[xout != nullptr][dev & 63]) {                                          \
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) { sx_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
-            lds_allowed[dev & 63] = 1;                                                                             \
+            lds_allowed[xout != nullptr][dev & 63] = 1;                                                            \
         }                                                                                                          \
         hipLaunchKernelGGL(kern, dim3(n_groups * n_ranges), dim3(256 * SPW_), lds, st, k);                         \
     } while (0)

@@ -347,8 +347,6 @@ class Coupling(Transform):
             return False
         if not isinstance(net, MLP) or net._wrapped or net.final_activation_name is not None:
             return False
-        if sp.spline_type != 'quadratic':
-            return False
         lin = net.linears()
         return len(lin) >= 2 and lin[-1][1] is not None and RQSCouplingSlab.eligible(lin[-1][0].shape[1], sp.n_bins)
 
@@ -373,6 +371,7 @@ class Coupling(Transform):
         d = x2.shape[1]
         lin = net.linears()
         H = lin[-1][0].shape[1]
+        cubic = sp.spline_type == 'cubic'
 
         def build():
             hid = np.full(((H + 31) // 32) * 32, -1, dtype=np.int32)
@@ -386,9 +385,9 @@ class Coupling(Transform):
             cmap[:d][m <= 0.5] = -1                                                  # transformed columns: no weight in W1 * mask
             words = [int(sum(1 << c for c in range(32) if 32 * t + c < d and m[32 * t + c] > 0.5)) for t in range(2)]
             dev = x2.device
-            return (torch.from_numpy(slab_slot_rows(len(live), sp.n_bins)).to(dev), torch.from_numpy(hid).to(dev),
+            return (torch.from_numpy(slab_slot_rows(len(live), sp.n_bins, cubic)).to(dev), torch.from_numpy(hid).to(dev),
                     torch.from_numpy(cols).to(dev), torch.from_numpy(cmap).to(dev), words)
-        plan = self._programs.get(('slab', d, H, str(x2.device)), build)
+        plan = self._programs.get(('slab', d, H, cubic, str(x2.device)), build)
         W2, b2 = SelectRows.apply(lin[-1][0], rows_t), SelectRows.apply(lin[-1][1], rows_t)
         evaluate = lambda xx: self._inverse_rows_nograd(xx, lat2)
         col_mask = mask_t * 0 if d == 1 else mask_t                                  # coupling.py:62-63
@@ -396,7 +395,7 @@ class Coupling(Transform):
                 and RQSCouplingSlabL1.eligible(d, H, sp.n_bins) and os.environ.get('STRIBOR_SPLINE_L1_TORCH') != '1'):
             # Linear - Tanh - Linear conditioner: the first layer's backward is part of the op too
             return RQSCouplingSlabL1.apply(x2, lin[0][0], lin[0][1], W2, b2, col_mask, evaluate, plan, live_idx, int(live[0]),
-                                           len(live), sp.n_bins, sp.lower, sp.upper)
+                                           len(live), sp.n_bins, sp.lower, sp.upper, cubic)
         # conditioner input cat[x * mask, latent] (coupling.py:61-65) with the mask folded into the first layer's weight
         if lat2 is not None:
             col_mask = torch.cat([col_mask, torch.ones(lat2.shape[1], dtype=torch.float32, device=x2.device)])
@@ -404,7 +403,7 @@ class Coupling(Transform):
         h, last, _, pre_tanh = net.hidden_autograd(x2 if lat2 is None else torch.cat([x2, lat2], -1), col_mask, pre_tanh=True,
                                                    want_flag=True)
         return RQSCouplingSlab.apply(x2, h, W2, b2, evaluate, plan[:2], live_idx, int(live[0]), len(live), sp.n_bins, sp.lower,
-                                     sp.upper, pre_tanh)
+                                     sp.upper, pre_tanh, cubic)
 
     # ---- reference method set (coupling.py:69-95) -----------------------------------------------------------
     def forward(self, x, latent=None, reverse: bool = False, **kwargs):

@@ -103,20 +103,22 @@ class RQSForward(torch.autograd.Function):
         return gx, gparams, None, None, None, None, None, None, None
 
 
-def slab_slot_rows(n_live: int, n_bins: int):
+def slab_slot_rows(n_live: int, n_bins: int, cubic: bool = False):
     """sx_rqs_slab_bwd's slot -> parameter-row map (include/stribor_hip.h): slab s holds transformed columns 2s, 2s+1 in
     three 32-slot tiles (widths | heights | derivatives); slot 32 t + R carries parameter (R&3) + 4 (R>>3) of column
-    2 s + ((R>>2)&1).  Rows index the [n_live * (3K-1)] selected rows of the conditioner's last layer (spline.py:82-86:
-    per column K widths, K heights, K-1 derivatives)."""
+    2 s + ((R>>2)&1).  Rows index the [n_live * P] selected rows of the conditioner's last layer (spline.py:82-86): per column
+    K widths, K heights, then K-1 knot derivatives (quadratic, P = 3K-1) or the 2 boundary derivatives (cubic, P = 2K+2)."""
     import numpy as np
-    K, P = n_bins, 3 * n_bins - 1
+    K = n_bins
+    P = 2 * K + 2 if cubic else 3 * K - 1
+    n_third = 2 if cubic else K - 1
     n_slabs = (n_live + 1) // 2
     rows = np.full(n_slabs * 96, -1, dtype=np.int32)
     for s in range(n_slabs):
         for t in range(3):
             for R in range(32):
                 k, ci = (R & 3) + 4 * (R >> 3), 2 * s + ((R >> 2) & 1)
-                if ci < n_live and k < (K - 1 if t == 2 else K):
+                if ci < n_live and k < (n_third if t == 2 else K):
                     rows[s * 96 + 32 * t + R] = ci * P + t * K + k
     return rows
 
@@ -128,26 +130,28 @@ class RQSCouplingSlab(torch.autograd.Function):
     transformed columns.  The forward is the coupling's own no-graph evaluation (`evaluate(x2)` -> (y, ldj)); the backward is
     sx_rqs_slab_bwd: spline reverse mode + dW2 / db2 / dL/dh in one kernel that keeps each slab of W2 in LDS, so the
     [N, n_live * (3K-1)] parameter tensor (spline.py:82-86) and its gradient never reach HBM.  Needs H <= 64, K <= 16 and the
-    fp16 x 3 GEMM arithmetic."""
+    fp16 x 3 GEMM arithmetic.  cubic=True: monotone cubic splines (the op then also keeps the pass's output)."""
 
     @staticmethod
     def eligible(hidden: int, n_bins: int) -> bool:
         return hidden <= 64 and n_bins <= 16 and _hip.get_gemm_precision() != 'exact'
 
     @staticmethod
-    def forward(ctx, x2, h, W2, b2, evaluate, plan, live_idx, live_start, n_live, n_bins, lower, upper, pre_tanh=False):
+    def forward(ctx, x2, h, W2, b2, evaluate, plan, live_idx, live_start, n_live, n_bins, lower, upper, pre_tanh=False,
+                cubic=False):
         x2 = x2.contiguous()
         with torch.no_grad():
             y, ldj = evaluate(x2)
             if pre_tanh:                    # `h` is the pre-activation of a Tanh: applied here, differentiated in backward
                 h = torch.tanh(h)
-        ctx.save_for_backward(x2, h, W2, b2)
+        # cubic splines: the backward differentiates the solve at the pass's output
+        ctx.save_for_backward(x2, h, W2, b2, y if cubic else None)
         ctx.meta = (plan, live_idx, live_start, n_live, n_bins, float(lower), float(upper), bool(pre_tanh))
         return y, ldj
 
     @staticmethod
     def backward(ctx, gy, gldj):
-        x2, h, W2, b2 = ctx.saved_tensors
+        x2, h, W2, b2, yout = ctx.saved_tensors
         (slot_rows, hid_idx), live_idx, live_start, n_live, n_bins, lower, upper, pre_tanh = ctx.meta
         n, d = x2.shape
         dev = x2.device
@@ -170,11 +174,11 @@ class RQSCouplingSlab(torch.autograd.Function):
         # range.  The maximum stays on the device (no host sync).
         inf = float('inf')
         scale = torch.maximum(torch.linalg.vector_norm(gy, ord=inf), torch.linalg.vector_norm(gldj, ord=inf)).reshape(1)
-        _hip.call('sx_rqs_slab_bwd', x2, x2.data_ptr(), gy.data_ptr(), gldj.data_ptr(), h.data_ptr(), h.stride(0), H,
+        _hip.call('sx_rqs_slab_bwd', x2, x2.data_ptr(), gy.data_ptr(), gldj.data_ptr(), _hip.ptr(yout), h.data_ptr(), h.stride(0), H,
                   packs.data_ptr(), packs.data_ptr() + 4 * n_fwd, slot_rows.data_ptr(), gx.data_ptr(), gh.data_ptr(),
                   gh.stride(0), gW.data_ptr(), gW.stride(0), gb.data_ptr(), _hip.ptr(live_idx), live_start, n_live, n_bins,
                   lower, upper, lower, upper, n, d, 1.0, int(pre_tanh), scale.data_ptr(), sc.data_ptr(), flag)
-        return gx, gh, gW, gb, None, None, None, None, None, None, None, None, None
+        return gx, gh, gW, gb, None, None, None, None, None, None, None, None, None, None
 
 
 def _slab_packs(x2, W2, b2, slot_rows, hid_idx, n_live, H):
@@ -205,19 +209,19 @@ class RQSCouplingSlabL1(torch.autograd.Function):
         return dim <= 64 and RQSCouplingSlab.eligible(hidden, n_bins)
 
     @staticmethod
-    def forward(ctx, x2, W1, b1, W2, b2, mask_t, evaluate, plan, live_idx, live_start, n_live, n_bins, lower, upper):
+    def forward(ctx, x2, W1, b1, W2, b2, mask_t, evaluate, plan, live_idx, live_start, n_live, n_bins, lower, upper, cubic=False):
         x2 = x2.contiguous()
         with torch.no_grad():
             y, ldj = evaluate(x2)
             h = torch.tanh(torch.addmm(b1, x2, (W1 * mask_t).t()))
-        ctx.save_for_backward(x2, h, W1, W2, b2, mask_t)
+        ctx.save_for_backward(x2, h, W1, W2, b2, mask_t, y if cubic else None)
         ctx.meta = (plan, live_idx, live_start, n_live, n_bins, float(lower), float(upper))
         return y, ldj
 
     @staticmethod
     def backward(ctx, gy, gldj):
         import ctypes as C
-        x2, h, W1, W2, b2, mask_t = ctx.saved_tensors
+        x2, h, W1, W2, b2, mask_t, yout = ctx.saved_tensors
         (slot_rows, hid_idx, col_slots, col_map, cond_words), live_idx, live_start, n_live, n_bins, lower, upper = ctx.meta
         n, d = x2.shape
         dev = x2.device
@@ -243,7 +247,7 @@ class RQSCouplingSlabL1(torch.autograd.Function):
             sc = _hip.scratch(dev, n_slab + n_l1 + 64)
         inf = float('inf')
         scale = torch.maximum(torch.linalg.vector_norm(gy, ord=inf), torch.linalg.vector_norm(gldj, ord=inf)).reshape(1)
-        _hip.call('sx_rqs_slab_bwd', x2, x2.data_ptr(), gy.data_ptr(), gldj.data_ptr(), h.data_ptr(), h.stride(0), H,
+        _hip.call('sx_rqs_slab_bwd', x2, x2.data_ptr(), gy.data_ptr(), gldj.data_ptr(), _hip.ptr(yout), h.data_ptr(), h.stride(0), H,
                   packs.data_ptr(), packs.data_ptr() + 4 * n_fwd, slot_rows.data_ptr(), gx.data_ptr(), None, 0,
                   gW2.data_ptr(), gW2.stride(0), gb2.data_ptr(), _hip.ptr(live_idx), live_start, n_live, n_bins,
                   lower, upper, lower, upper, n, d, 1.0, 1, scale.data_ptr(), sc.data_ptr(), flag)
@@ -252,7 +256,7 @@ class RQSCouplingSlabL1(torch.autograd.Function):
         _hip.call('sx_rqs_slab_l1_bwd', x2, sc.data_ptr(), h.data_ptr(), h.stride(0), H, x2.data_ptr(), gy.data_ptr(),
                   w1t.data_ptr(), C.cast(words, C.c_void_p), gx.data_ptr(), gW1.data_ptr(), gW1.stride(0), gb1.data_ptr(),
                   col_map.data_ptr(), n_live, n, d, scale.data_ptr(), l1_scratch, flag)
-        return gx, gW1, gb1, gW2, gb2, None, None, None, None, None, None, None, None, None
+        return gx, gW1, gb1, gW2, gb2, None, None, None, None, None, None, None, None, None, None
 
 
 def run_cubic_kernel(x2, params, params_stride, live_idx, live_start, n_live, n_bins, lower, upper, reverse, want_ldj,

@@ -147,6 +147,7 @@ def test_spline_flow_log_prob_backward_matches_autograd_of_oracle(n, dim, hidden
         assert err <= 3e-4 * scale + 1e-7, (name, err, scale)
 
 
+@pytest.mark.parametrize('stype', ['quadratic', 'cubic'])
 @pytest.mark.parametrize('n,dim,hidden,K,latent_dim,act', [
     (1000, 64, [64], 16, 0, 'Tanh'),            # cfg-3 layer
     (333, 7, [10], 4, 3, 'Tanh'),               # odd live count, hidden rows not 16-byte aligned, conditional flow
@@ -155,13 +156,13 @@ def test_spline_flow_log_prob_backward_matches_autograd_of_oracle(n, dim, hidden
     (700, 8, [32], 8, 0, 'Tanh'),               # one full hidden tile (vector loads), run-time bin count
     (4100, 10, [32], 16, 2, 'Tanh'),            # one hidden tile, K = 16 straight-line form, odd number of slabs, several ranges
 ])
-def test_spline_slab_backward_matches_per_row_parameter_path(monkeypatch, n, dim, hidden, K, latent_dim, act):
+def test_spline_slab_backward_matches_per_row_parameter_path(monkeypatch, n, dim, hidden, K, latent_dim, act, stype):
     """sx_rqs_slab_bwd (spline backward fused with the last conditioner layer: no [N, n_live*(3K-1)] tensor) against the
     layer-wise path it replaces (torch Linear -> sx_rqs_coupling / sx_rqs_inverse_bwd -> library GEMMs), same weights."""
     torch.manual_seed(21)
-    P = 3 * K - 1
+    P = 3 * K - 1 if stype == 'quadratic' else 2 * K + 2
     tr = [st.Coupling(st.Spline(dim, K, latent_net=st.net.MLP(dim + latent_dim, hidden, dim * P, activation=act), lower=-2.5,
-                                upper=2.5, spline_type='quadratic'),
+                                upper=2.5, spline_type=stype),
                       mask='ordered_right_half' if i % 2 == 0 else 'parity_even') for i in range(2)]
     flow = st.NormalizingFlow(st.UnitNormal(dim), tr).to(DEV)
     with torch.no_grad():
@@ -182,13 +183,20 @@ def test_spline_slab_backward_matches_per_row_parameter_path(monkeypatch, n, dim
     lp_f, fused = grads()
     monkeypatch.setenv('STRIBOR_SPLINE_UNFUSED', '1')
     lp_u, unfused = grads()
-    close(lp_f, lp_u, rtol=1e-5, atol=1e-4)
+    # (cubic: the slab op's forward returns the reference's inverse log-det -- minus the forward log-det re-evaluated at the
+    #  inverted point, flow.py:42-47 -- and CubicInverse the inverse pass's own: they differ for elements on a bound or knot)
+    if stype == 'quadratic':
+        close(lp_f, lp_u, rtol=1e-5, atol=1e-4)
+    else:
+        d = (lp_f - lp_u).abs().flatten()
+        assert (d > 1e-4 + 1e-5 * lp_u.abs().flatten()).float().mean().item() < 0.02 and d.max().item() < 5e-2
     names = ['x'] + [k for k, _ in flow.named_parameters()]
     for name, a, b in zip(names, fused, unfused):
         scale = b.abs().max().item() + 1e-12
         # the two paths round the parameters differently (fp16 x 3 MFMA vs the library's fp32 GEMM) and the spline's
-        # gradient amplifies that: same bound as the fp64-oracle test above
-        assert (a - b).abs().max().item() <= 3e-4 * scale + 1e-8, (name, (a - b).abs().max().item(), scale)
+        # gradient amplifies that: same bounds as the fp64-oracle tests (cubic: 1 / w^2 of bins as narrow as 1e-2)
+        tol = 3e-4 if stype == 'quadratic' else 1e-3
+        assert (a - b).abs().max().item() <= tol * scale + 1e-8, (name, (a - b).abs().max().item(), scale)
 
 
 def test_spline_slab_backward_reports_fp16_range_and_exact_mode_bypasses_it():

@@ -245,15 +245,17 @@ def test_bench_spawns_its_own_ranks(monkeypatch):
     assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
 
 
+@pytest.mark.parametrize('cubic', [False, True])
 @pytest.mark.parametrize('n_live,K', [(32, 16), (5, 3), (1, 1), (7, 16), (2, 9)])
-def test_slab_slot_rows_cover_every_parameter_row_once(n_live, K):
+def test_slab_slot_rows_cover_every_parameter_row_once(n_live, K, cubic):
     """sx_rqs_slab_bwd's slot map (include/stribor_hip.h): every row of the selected last conditioner layer -- per transformed
-    column K widths, K heights, K-1 derivatives (spline.py:82-86) -- sits in exactly one slot, in the tile of its block and the
+    column K widths, K heights, K-1 derivatives (quadratic) or 2 (cubic) (spline.py:82-86) -- sits in exactly one slot, in the tile of its block and the
     lane half of its column; all other slots are padding."""
     import numpy as np
     from stribor_amd.flows.spline import slab_slot_rows
-    rows = slab_slot_rows(n_live, K)
-    P = 3 * K - 1
+    rows = slab_slot_rows(n_live, K, cubic)
+    P = 2 * K + 2 if cubic else 3 * K - 1
+    n_third = 2 if cubic else K - 1
     n_slabs = (n_live + 1) // 2
     assert rows.shape == (n_slabs * 96,) and rows.dtype == np.int32
     used = rows[rows >= 0]
@@ -265,4 +267,4 @@ def test_slab_slot_rows_cover_every_parameter_row_once(n_live, K):
         ci, off = divmod(int(r), P)
         assert ci == 2 * s_ + ((R >> 2) & 1)                         # column <-> lane half of the C fragment
         k = (R & 3) + 4 * (R >> 3)
-        assert off == t * K + k and k < (K - 1 if t == 2 else K)     # block <-> tile, parameter <-> register
+        assert off == t * K + k and k < (n_third if t == 2 else K)   # block <-> tile, parameter <-> register

@@ -47,7 +47,7 @@ def main():
     sc = torch.empty(lib.sx_rqs_slab_scratch_floats(n, n_live, H), dtype=torch.float32, device=dev)
 
     def run():
-        _hip.call('sx_rqs_slab_bwd', x, x.data_ptr(), gy.data_ptr(), gl.data_ptr(), h.data_ptr(), h.stride(0), H, packs.data_ptr(),
+        _hip.call('sx_rqs_slab_bwd', x, x.data_ptr(), gy.data_ptr(), gl.data_ptr(), None, h.data_ptr(), h.stride(0), H, packs.data_ptr(),
                   packs.data_ptr() + 4 * n_fwd, slot_rows.data_ptr(), gx.data_ptr(), gh.data_ptr(), gh.stride(0), gW.data_ptr(),
                   gW.stride(0), gb.data_ptr(), None, n_live, n_live, K, 0.0, 1.0, 0.0, 1.0, n, d, 1.0, 0, None, sc.data_ptr(), flag)
     for _ in range(3):
