@@ -393,6 +393,13 @@ def main():
                                          'spline backward fused with the last conditioner layer, no [N, 1504] parameter tensor '
                                          '(sx_rqs_slab_bwd, DESIGN 4.3.1); HBM bytes per step in profiles/pmc_training_cfg3_fused.json'))
             del f3, x3t
+            pt = load_profile('pmc_training_cfg3_fused.json')
+            if pt:
+                tr[-1]['hbm_MB_per_step_pmc'] = {'read': pt.get('hbm_read_MB_per_step'), 'written': pt.get('hbm_write_MB_per_step'),
+                                                 'per_row_parameter_path': load_profile('pmc_training_cfg3_unfused.json').get(
+                                                     'hbm_read_MB_per_step', 0) + load_profile(
+                                                     'pmc_training_cfg3_unfused.json').get('hbm_write_MB_per_step', 0),
+                                                 'source': 'profiles/pmc_training_cfg3_{fused,unfused}.json (builder-run rocprofv3 passes)'}
             result['training'] = tr
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(desc, state)

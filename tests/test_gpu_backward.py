@@ -199,6 +199,37 @@ def test_spline_slab_backward_matches_per_row_parameter_path(monkeypatch, n, dim
         assert (a - b).abs().max().item() <= tol * scale + 1e-8, (name, (a - b).abs().max().item(), scale)
 
 
+def test_spline_slab_backward_at_scale_matches_per_row_parameter_path(monkeypatch):
+    """65,537 rows of the cfg-3 layer shape: 32 row ranges x 8 slab pairs (XCD-aware workgroup ids, 16-17 passes per wave,
+    a ragged last chunk) -- the partitioning the small cases do not reach.  Gradients against the per-row parameter path."""
+    torch.manual_seed(23)
+    flow = fd.build_flow(st, fd.cfg3_desc(2, 64, 64, 16), 64).to(DEV)
+    n = (1 << 16) + 1
+    x = torch.randn(n, 64, device=DEV) * 1.3
+    wgt = torch.rand(n, 1, device=DEV) + 0.5
+
+    def grads():
+        for p in flow.parameters():
+            p.grad = None
+        xg = x.clone().requires_grad_(True)
+        (-(flow.log_prob(xg) * wgt).mean()).backward()
+        return [xg.grad.clone()] + [p.grad.clone() for p in flow.parameters()]
+
+    fused = grads()
+    monkeypatch.setenv('STRIBOR_SPLINE_UNFUSED', '1')
+    unfused = grads()
+    for name, a, b in zip(['x'] + [k for k, _ in flow.named_parameters()], fused, unfused):
+        scale = b.abs().max().item() + 1e-12
+        assert torch.isfinite(a).all(), name
+        if name == 'x':
+            # d(log-det)/dx jumps at the knots (the spline is C1, not C2): an input within rounding of a knot may fall into
+            # different bins on the two paths (their parameters round differently) -- a handful of the 4.2e6 elements
+            off = ((a - b).abs() > 3e-4 * scale + 1e-9).float().mean().item()
+            assert off <= 5e-5, (name, off)
+        else:
+            assert (a - b).abs().max().item() <= 3e-4 * scale + 1e-9, (name, (a - b).abs().max().item(), scale)
+
+
 def test_spline_slab_backward_reports_fp16_range_and_exact_mode_bypasses_it():
     """The slab backward's GEMM operands are fp16 x 3: a hidden activation beyond 65504 must not come back as a plausible
     gradient (NaN rows + GemmRangeError at the next check), and set_gemm_precision('exact') takes the per-row path."""
