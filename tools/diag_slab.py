@@ -15,7 +15,7 @@ DEV = 'cuda:0'
 
 
 def main():
-    n, dim, hidden, K = 1000, 64, 64, 16
+    n, dim, hidden, K = (int(sys.argv[2]) if len(sys.argv) > 2 else 1000), 64, 64, 16
     pert = float(sys.argv[1]) if len(sys.argv) > 1 else 0.3
     torch.manual_seed(21)
     desc = [{'kind': 'coupling_rqs', 'dim': dim, 'hidden': [hidden], 'n_bins': K, 'lower': -2.5, 'upper': 2.5,
@@ -45,7 +45,8 @@ def main():
     for nm, a, b, r in zip(names, fused, unfused, ref):
         sc = r.abs().max().item() + 1e-30
         print(f'{nm:28s} scale {sc:9.3e}  slab-f64 {(a - r).abs().max().item() / sc:9.2e}  unfused-f64 '
-              f'{(b - r).abs().max().item() / sc:9.2e}  slab-unfused {(a - b).abs().max().item() / sc:9.2e}')
+              f'{(b - r).abs().max().item() / sc:9.2e}  slab-unfused {(a - b).abs().max().item() / sc:9.2e}'
+              + (f'  elements off by > 3e-4 scale: slab {((a - r).abs() > 3e-4 * sc).sum().item()}, unfused {((b - r).abs() > 3e-4 * sc).sum().item()}' if nm == 'x' else ''))
 
 
 if __name__ == '__main__':
