@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256 * SPW, SPW == 1 ? 2 : 1) void rqs_slab_bwd_kern
         btile<1> bd[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) bd[t] = make_btile<1>(acc[t], rg);
-        if (valid && (!(SX_SLAB_X & 64) || gxe == 1234.5f)) (k.gx + row0 * k.dim)[xoff] = rng_bad_sample(rg, lane) ? __builtin_nanf("") : gxe * sc_out;
+        if (valid) (k.gx + row0 * k.dim)[xoff] = rng_bad_sample(rg, lane) ? __builtin_nanf("") : gxe * sc_out;
         any_bad |= rg.bad;
         __builtin_amdgcn_sched_barrier(0);
         SLAB_T(3);      // dp split + gx store
