@@ -81,10 +81,31 @@ class TriInverse(torch.autograd.Function):
 
 def _lu_inverse_batched(L, U):
     """(L U)^-1 = U^-1 L^-1 for batches of unit-lower L and upper U (fp64, on the device)."""
-    if L.is_cuda and L.dtype == torch.float64 and L.shape[-1] <= 128:
-        return TriInverse.apply(U, False, False) @ TriInverse.apply(L, True, True)
-    eye = torch.eye(L.shape[-1], dtype=L.dtype, device=L.device).expand_as(L)
-    return torch.linalg.solve_triangular(U, torch.linalg.solve_triangular(L, eye, upper=False), upper=True)
+    return _lu_inverse_multi([(L, U)])[0]
+
+
+def _lu_inverse_multi(pairs):
+    """[(L U)^-1 for (L, U) in pairs], each a batch [k_i, D, D] of unit-lower L (ones on the diagonal, explicit) and upper U.
+    The triangular inverses of ALL pairs of one width go through ONE sx_tri_inverse_f64 launch (one workgroup per matrix, the
+    launch is latency-bound: 0.3 ms whether it inverts 4 or 16 matrices): U^-1 = ((U^T)^-1)^T makes every operand lower
+    triangular with an explicit diagonal."""
+    out = [None] * len(pairs)
+    by_dim = {}
+    for i, (L, U) in enumerate(pairs):
+        if L.is_cuda and L.dtype == torch.float64 and L.shape[-1] <= 128:
+            by_dim.setdefault(L.shape[-1], []).append(i)
+        else:
+            eye = torch.eye(L.shape[-1], dtype=L.dtype, device=L.device).expand_as(L)
+            out[i] = torch.linalg.solve_triangular(U, torch.linalg.solve_triangular(L, eye, upper=False), upper=True)
+    for idx in by_dim.values():
+        stack = torch.cat([t for i in idx for t in (pairs[i][1].transpose(-1, -2), pairs[i][0])])
+        X = TriInverse.apply(stack, True, False)
+        o = 0
+        for i in idx:
+            k = pairs[i][0].shape[0]
+            out[i] = X[o:o + k].transpose(-1, -2) @ X[o + k:o + 2 * k]
+            o += 2 * k
+    return out
 
 
 def derive_dense_batched(layers, dev, reverse: bool = True):
@@ -99,6 +120,8 @@ def derive_dense_batched(layers, dev, reverse: bool = True):
             groups.setdefault(('lu', f.dim), []).append(f)
         elif isinstance(f, MatrixExponential):
             groups.setdefault(('mx', f.dim, f.bias is not None), []).append(f)
+    # pass 1: the triangular factors of every group; pass 2 (after ONE batched inverse of all of them): the matrices
+    prep = {}
     for key, fs in groups.items():
         D = key[1]
         eye = torch.eye(D, dtype=torch.float64, device=dev)
@@ -107,8 +130,20 @@ def derive_dense_batched(layers, dev, reverse: bool = True):
             ld = torch.stack([f.log_diag.reshape(-1) for f in fs]).to(dev, torch.float64)
             b = torch.stack([f.bias.reshape(-1) for f in fs]).to(dev, torch.float64)
             L, U = torch.tril(W, -1) + eye, torch.triu(W, 1) + torch.diag_embed(ld.exp())      # affine.py:148-154
+            prep[key] = (L, U, ld, b)
+        else:
+            W = torch.stack([f._weight for f in fs]).to(dev, torch.float64)
+            dg = torch.stack([f.diag for f in fs]).to(dev, torch.float64)
+            L, U = torch.tril(W, diagonal=-1) + eye, torch.triu(W) + eye                       # affine.py:222-226
+            prep[key] = (L, U, dg, None)
+    need = [key for key in groups if key[0] == 'mx' or reverse]
+    inv = dict(zip(need, _lu_inverse_multi([(prep[k][0], prep[k][1]) for k in need])))
+    for key, fs in groups.items():
+        L, U, third, b = prep[key]
+        if key[0] == 'lu':
+            ld = third
             if reverse:
-                Ainv = _lu_inverse_batched(L, U)
+                Ainv = inv[key]
                 Wm = Ainv.transpose(-1, -2).to(torch.float32).contiguous()                     # x = (y - b) A^-1 (:159-163)
                 bm = (-(b.unsqueeze(1) @ Ainv).squeeze(1)).to(torch.float32)
                 ldj = (-ld.sum(-1)).to(torch.float32)                                          # :171, negated
@@ -119,14 +154,12 @@ def derive_dense_batched(layers, dev, reverse: bool = True):
             for i, f in enumerate(fs):
                 out[id(f)] = (Wm[i], bm[i], ldj[i])
         else:
-            W = torch.stack([f._weight for f in fs]).to(dev, torch.float64)
-            dg = torch.stack([f.diag for f in fs]).to(dev, torch.float64)
+            dg = third
             tkey = (tuple(f._t_eff(1.0) for f in fs), str(dev))
             te = _TE_CACHE.get(tkey)                      # constants: uploaded once (a host copy would break graph capture)
             if te is None:
                 te = _TE_CACHE[tkey] = torch.tensor(tkey[0], dtype=torch.float64, device=dev).unsqueeze(-1)
-            L, U = torch.tril(W, diagonal=-1) + eye, torch.triu(W) + eye                       # affine.py:222-226
-            Ainv = _lu_inverse_batched(L, U)
+            Ainv = inv[key]
             sg = -te if reverse else te
             M = ((L @ U) * (dg * sg).exp().unsqueeze(-2)) @ Ainv                               # :254-266 (t -> -t inverse)
             Wm = M.to(torch.float32).contiguous()
