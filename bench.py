@@ -199,6 +199,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra-configs', action='store_true', help='skip the cfg 3 / cfg 4 lines (N = 1)')
+    ap.add_argument('--no-training', action='store_true', help='skip the training-step entries (N = 1)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -378,29 +379,31 @@ def main():
             result['configs'] = cfgs
             # training steps (forward + backward) of the two trainable BASELINE families, same process
             tr = []
-            torch.manual_seed(0)
-            f2 = fd.build_flow(st, fd.cfg2_desc(), 64).to(dev)
-            x2t = torch.randn(ROWS_PER_GPU, 64, device=dev, generator=gen)
-            tr.append(time_training_step('cfg2_train', 'cfg2 flow, 2^20 rows fp32: loss = -log_prob.mean(), backward to every '
-                                         'parameter', f2, x2t, 12,
-                                         'layer-major backward: weight gradients contracted in the kernel (DESIGN 4.3)'))
-            del f2, x2t
-            torch.manual_seed(0)
-            f3 = fd.build_flow(st, fd.cfg3_desc(), 64).to(dev)
-            x3t = torch.randn(ROWS_PER_GPU // 4, 64, device=dev, generator=gen)
-            tr.append(time_training_step('cfg3_train', 'cfg3 flow, 2^18 rows fp32: loss = -log_prob.mean(), backward to every '
-                                         'parameter', f3, x3t, 12,
-                                         'spline backward fused with the last conditioner layer, no [N, 1504] parameter tensor '
-                                         '(sx_rqs_slab_bwd, DESIGN 4.3.1); HBM bytes per step in profiles/pmc_training_cfg3_fused.json'))
-            del f3, x3t
-            pt = load_profile('pmc_training_cfg3_fused.json')
-            if pt:
-                tr[-1]['hbm_MB_per_step_pmc'] = {'read': pt.get('hbm_read_MB_per_step'), 'written': pt.get('hbm_write_MB_per_step'),
-                                                 'per_row_parameter_path': load_profile('pmc_training_cfg3_unfused.json').get(
-                                                     'hbm_read_MB_per_step', 0) + load_profile(
-                                                     'pmc_training_cfg3_unfused.json').get('hbm_write_MB_per_step', 0),
-                                                 'source': 'profiles/pmc_training_cfg3_{fused,unfused}.json (builder-run rocprofv3 passes)'}
-            result['training'] = tr
+            if not args.no_training:
+                torch.manual_seed(0)
+                f2 = fd.build_flow(st, fd.cfg2_desc(), 64).to(dev)
+                x2t = torch.randn(ROWS_PER_GPU, 64, device=dev, generator=gen)
+                tr.append(time_training_step('cfg2_train', 'cfg2 flow, 2^20 rows fp32: loss = -log_prob.mean(), backward to every '
+                                             'parameter', f2, x2t, 12,
+                                             'layer-major backward: weight gradients contracted in the kernel (DESIGN 4.3)'))
+                del f2, x2t
+                torch.manual_seed(0)
+                f3 = fd.build_flow(st, fd.cfg3_desc(), 64).to(dev)
+                x3t = torch.randn(ROWS_PER_GPU // 4, 64, device=dev, generator=gen)
+                tr.append(time_training_step('cfg3_train', 'cfg3 flow, 2^18 rows fp32: loss = -log_prob.mean(), backward to every '
+                                             'parameter', f3, x3t, 12,
+                                             'spline backward fused with the last conditioner layer, no [N, 1504] parameter tensor '
+                                             '(sx_rqs_slab_bwd, DESIGN 4.3.1); HBM bytes per step in profiles/pmc_training_cfg3_fused.json'))
+                del f3, x3t
+                pt = load_profile('pmc_training_cfg3_fused.json')
+                if pt:
+                    tr[-1]['hbm_MB_per_step_pmc'] = {'read': pt.get('hbm_read_MB_per_step'), 'written': pt.get('hbm_write_MB_per_step'),
+                                                     'per_row_parameter_path': load_profile('pmc_training_cfg3_unfused.json').get(
+                                                         'hbm_read_MB_per_step', 0) + load_profile(
+                                                         'pmc_training_cfg3_unfused.json').get('hbm_write_MB_per_step', 0),
+                                                     'source': 'profiles/pmc_training_cfg3_{fused,unfused}.json (builder-run rocprofv3 passes)'}
+            if not args.no_training:
+                result['training'] = tr
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(desc, state)
     if world > 1:

@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-training > $OUT/bench_stats.log 2>&1
 f=$(find $OUT/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/bench_kernel_stats.csv
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" \
@@ -17,7 +17,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
   "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_INSTS_VALU SQ_INSTS_MFMA" \
   "SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES SQ_INSTS_VALU_TRANS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set -d $OUT/pmc$i -o p --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/pmc$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set -d $OUT/pmc$i -o p --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-training > $OUT/pmc$i.log 2>&1
 done
 python3 $R/tools/pmc_summary.py $OUT $COMMIT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
