@@ -165,8 +165,7 @@ class RQSCouplingSlab(torch.autograd.Function):
         packs, n_fwd = _slab_packs(x2, W2, b2, slot_rows, hid_idx, n_live, H)
         gx = gy.clone()                     # pass-through columns: y = x; the kernel overwrites the transformed columns
         gh = torch.empty(n, H, dtype=torch.float32, device=dev)
-        gW = torch.zeros_like(W2)
-        gb = torch.zeros_like(b2)
+        gW, gb = torch.empty_like(W2), torch.empty_like(b2)      # every selected row sits in exactly one slot: all written
         with _hip.device_of(x2):
             sc = _hip.scratch(dev, lib.sx_rqs_slab_scratch_floats(n, n_live, H))
         # the kernels normalise the adjoints by a power of two derived from their largest magnitude (exact): the parameter
@@ -238,7 +237,7 @@ class RQSCouplingSlabL1(torch.autograd.Function):
         _hip.call('sx_pack_linear', x2, W1m.data_ptr(), None, H, d, col_slots.data_ptr(), hid_idx.data_ptr(), xt, ht, None, None,
                   0.0, 1, _hip.GEMM_F16X3, flag, w1t.data_ptr())
         gx = torch.empty_like(gy)           # every column is written: transformed ones by the slab kernel, the rest by the l1 kernel
-        gW2, gb2 = torch.zeros_like(W2), torch.zeros_like(b2)
+        gW2, gb2 = torch.empty_like(W2), torch.empty_like(b2)    # every selected row sits in exactly one slot: all written
         gW1 = torch.zeros(H, d, dtype=torch.float32, device=dev)
         gb1 = torch.zeros(H, dtype=torch.float32, device=dev)
         n_slab = lib.sx_rqs_slab_scratch_floats(n, n_live, H)
