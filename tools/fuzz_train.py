@@ -1,0 +1,95 @@
+"""Randomised differential check of the training paths: random spline / affine coupling flows (dims, widths, masks, bin counts,
+spline types, latent inputs, batch sizes) -- gradients of -log_prob.mean() from the HIP paths against fp64 autograd of the oracle.
+    python tools/fuzz_train.py [n_cases] [seed] [--forward]     (--forward: forward_and_log_det_jacobian instead of log_prob)"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import stribor_amd as st  # noqa: E402
+from stribor_amd.util import flowdesc as fd  # noqa: E402
+import stribor_oracle as orc  # noqa: E402
+
+DEV = 'cuda:0'
+MASKS = ['ordered_right_half', 'ordered_left_half', 'parity_even', 'parity_odd']
+
+
+def case(rng):
+    dim = int(rng.integers(2, 71))
+    latent = int(rng.choice([0, 0, 0, 3]))
+    layers = int(rng.integers(1, 4))
+    desc = []
+    for _ in range(layers):
+        kind = rng.choice(['rqs', 'rqs', 'cubic', 'affine'])
+        hidden = [int(rng.integers(4, 65)) for _ in range(int(rng.integers(1, 3)))]
+        d = {'dim': dim, 'hidden': hidden, 'mask': str(rng.choice(MASKS)), 'latent_dim': latent}
+        if kind == 'affine':
+            d['kind'] = 'coupling_affine'
+        else:
+            d.update(kind='coupling_rqs', n_bins=int(rng.integers(1, 17)), lower=-3.0, upper=3.0,
+                     spline_type='quadratic' if kind == 'rqs' else 'cubic')
+        desc.append(d)
+        if rng.random() < 0.3:
+            desc.append({'kind': 'flip'})
+    return desc, dim, latent, int(rng.integers(1, 700))
+
+
+def main():
+    fwd = '--forward' in sys.argv
+    args = [a for a in sys.argv[1:] if not a.startswith('--')]
+    n_cases = int(args[0]) if len(args) > 0 else 40
+    seed = int(args[1]) if len(args) > 1 else 0
+    rng = np.random.default_rng(seed)
+    worst = 0.0
+    for i in range(n_cases):
+        desc, dim, latent, n = case(rng)
+        torch.manual_seed(seed * 1000 + i)
+        flow = fd.build_flow(st, desc, dim)
+        with torch.no_grad():
+            for p in flow.parameters():
+                p.add_(torch.randn_like(p) * 0.03)
+        state = {k: v.clone() for k, v in flow.state_dict().items()}
+        flow = flow.to(DEV)
+        x = torch.randn(n, dim) * 1.4
+        lat = torch.randn(n, latent) if latent else None
+        leaves = {k: v.detach().double().clone().requires_grad_(True) for k, v in state.items()}
+        xin = x.double().clone().requires_grad_(True)
+        if fwd:
+            y64, l64 = orc.flow_forward_and_ldj(fd.flow_spec(desc, leaves), xin, None if lat is None else lat.double())
+            want = ((y64 ** 2).sum() * 0.1 + l64.sum()) / n
+        else:
+            want = -orc.flow_log_prob(fd.flow_spec(desc, leaves), xin, None if lat is None else lat.double()).mean()
+        want.backward()
+        xg = x.to(DEV).requires_grad_(True)
+        if fwd:
+            yg, lg = flow.forward_and_log_det_jacobian(xg, latent=None if lat is None else lat.to(DEV))
+            loss = ((yg ** 2).sum() * 0.1 + lg.sum()) / n
+        else:
+            loss = -flow.log_prob(xg, latent=None if lat is None else lat.to(DEV)).mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        st.check_errors()
+        cubic = any(d.get('spline_type') == 'cubic' for d in desc)
+        tol = 3e-3 if cubic else 1e-3
+        errs = {'loss': abs(loss.item() - want.item()) / (abs(want.item()) + 1e-9)}
+        ref = xin.grad.float()
+        errs['x'] = ((xg.grad.cpu() - ref).abs().max() / (ref.abs().max() + 1e-12)).item()
+        for name, p in flow.named_parameters():
+            if p.numel() == 0:
+                continue
+            ref = leaves[name].grad.float()
+            errs[name] = ((p.grad.cpu() - ref).abs().max() / (ref.abs().max() + 1e-12)).item()
+        bad = {k: v for k, v in errs.items() if not (v <= (1e-4 if k == 'loss' else tol))}
+        m = max(v for k, v in errs.items() if k != 'loss')
+        worst = max(worst, m)
+        kinds = [d['kind'] + ('/' + d['spline_type'][0] if 'spline_type' in d else '') + (f":K{d['n_bins']}" if 'n_bins' in d else '') + (f":H{d['hidden']}" if 'hidden' in d else '') for d in desc]
+        print(f'case {i:3d} dim {dim:2d} lat {latent} n {n:3d} {kinds}  max grad err {m:.2e}' + (f'  FAIL {bad}' if bad else ''), flush=True)
+    print('worst', worst)
+
+
+if __name__ == '__main__':
+    main()
