@@ -58,9 +58,10 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
             case SX_STEP_CPL_HIDDEN: need = sx_packed_linear_floats(p->h_tiles, s.ct); deep = true; break;
             case SX_STEP_CPL_HIDDEN2: need = sx_packed_linear_floats(p->h_tiles, p->h_tiles); deep = true; break;
             case SX_STEP_COUPLING_AFFINE_DEEP:
-                SX_REQUIRE(s.tt >= 1 && s.t0 + s.tt <= p->x_tiles, "sx_flow_run: step %d: bad transformed tiles", i);
+                // (dense form with a latent input: the range covers the latent tile too, whose output rows are zero weights)
+                SX_REQUIRE(s.tt >= 1 && s.t0 + s.tt <= p->tiles, "sx_flow_run: step %d: bad transformed tiles", i);
                 need = sx_packed_linear_floats(p->h_tiles, p->h_tiles) + sx_packed_linear_floats(2 * s.tt, p->h_tiles);
-                deep = true; break;
+                deep = true; aff = true; break;
             case SX_STEP_COUPLING_AFFINE_BWD: {
                 SX_REQUIRE((p->tiles == 2 || p->tiles == 4) && p->x_tiles * 2 == p->tiles,
                            "sx_flow_run: step %d: backward programs carry x and dL/dx: tiles = 2 * x_tiles (2 or 4)", i);

@@ -840,7 +840,8 @@ class ProgramBuilder:
             raise NotImplementedError(f'fused program has {len(self.steps)} steps (max {_hip.SX_MAX_STEPS})')
         kinds = {s['kind'] for s in self.steps}
         rqs = kinds & {_hip.STEP_RQS_HIDDEN, _hip.STEP_RQS_PHASE}
-        if rqs and kinds & {_hip.STEP_COUPLING_AFFINE, _hip.STEP_LINEAR_TILE, _hip.STEP_ROW_SCALE_EXP}:
+        if rqs and kinds & {_hip.STEP_COUPLING_AFFINE, _hip.STEP_COUPLING_AFFINE_DEEP, _hip.STEP_LINEAR_TILE,
+                            _hip.STEP_ROW_SCALE_EXP}:
             # the spline kernel variant spends its registers on the group state: mixed flows run layer by layer
             raise NotImplementedError('spline couplings cannot share a fused program with affine couplings / linear layers')
         deep = kinds & {_hip.STEP_CPL_HIDDEN, _hip.STEP_CPL_HIDDEN2, _hip.STEP_COUPLING_AFFINE_DEEP}

@@ -971,3 +971,38 @@ def test_log_prob_replays_from_a_hip_graph(make, dim, n):
         got = static_out.clone()
         want = flow.log_prob(fresh)
         assert torch.equal(got, want), (make, seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('second', ['rqs', 'affine'])
+def test_deep_affine_coupling_with_latent_in_one_state_tile(second):
+    """Found by tools/fuzz_train.py --infer.  (1) A conditional flow (latent) whose affine coupling has a two-hidden-layer
+    conditioner and fits one state tile (dim 10 + latent 3: x_tiles = 1, tiles = 2) plans the DENSE deep step over both tiles;
+    the launcher used to reject it ('bad transformed tiles').  (2) With a quadratic-spline coupling in the same flow the
+    planner used to put both in one program, whose spline kernel variant has no deep-affine arm: that layer was skipped
+    silently (log_prob off by 0.1-0.3 relative, round trips still consistent).  Such flows now run layer by layer and the
+    launcher refuses the mix.  Values against the oracle in fp64."""
+    torch.manual_seed(5)
+    dim, latent = 10, 3
+    desc = [{'dim': dim, 'hidden': [48, 51], 'mask': 'ordered_left_half', 'latent_dim': latent, 'kind': 'coupling_affine'},
+            {'kind': 'flip'}]
+    if second == 'rqs':
+        desc.append({'dim': dim, 'hidden': [36, 13], 'mask': 'ordered_right_half', 'latent_dim': latent, 'kind': 'coupling_rqs',
+                     'n_bins': 1, 'lower': -3.0, 'upper': 3.0, 'spline_type': 'quadratic'})
+    else:
+        desc.append({'dim': dim, 'hidden': [36, 13], 'mask': 'ordered_right_half', 'latent_dim': latent, 'kind': 'coupling_affine'})
+    flow = fd.build_flow(st, desc, dim)
+    state = {k: v.clone() for k, v in flow.state_dict().items()}
+    flow = flow.to(DEV)
+    x, lat = torch.randn(519, dim) * 1.4, torch.randn(519, latent)
+    spec = fd.flow_spec(desc, {k: v.double() for k, v in state.items()})
+    want = orc.flow_log_prob(spec, x.double(), lat.double())
+    wy, wl = orc.flow_forward_and_ldj(spec, x.double(), lat.double())
+    with torch.no_grad():
+        lp = flow.log_prob(x.to(DEV), latent=lat.to(DEV))
+        y, ldj = flow.forward_and_log_det_jacobian(x.to(DEV), latent=lat.to(DEV))
+        xr = flow.inverse(y, latent=lat.to(DEV))
+    close(lp, want.float(), rtol=1e-5, atol=1e-4)
+    close(y, wy.float(), rtol=1e-5, atol=1e-5)
+    close(ldj, wl.float(), rtol=1e-5, atol=1e-4)
+    close(xr, x, rtol=1e-4, atol=1e-4)
