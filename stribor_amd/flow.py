@@ -354,6 +354,8 @@ class NormalizingFlow(Transform):
                 info['row_map'] = torch.from_numpy(np.ascontiguousarray(info['out_rows'], dtype=np.int32)).to(device)
                 info['col_map'] = torch.from_numpy(np.ascontiguousarray(info['cond_cols'], dtype=np.int32)).to(device)
                 layers.append((f, info))
+            if not layers:
+                raise NotImplementedError('no coupling in the flow: the layer-wise path carries dL/dx')
             return (b.build(device), layers)
         except NotImplementedError:
             return 'unsupported'
@@ -373,7 +375,7 @@ class NormalizingFlow(Transform):
         from .flows.permute import _ColumnShuffle
         ok = [isinstance(f, _ColumnShuffle) or (hasattr(f, '_autograd_supported') and f._autograd_supported())
               for f in self.transforms]
-        return all(ok) and any(not isinstance(f, _ColumnShuffle) for f in self.transforms)
+        return all(ok)         # (a flow of nothing but Permute / Flip still carries dL/dx: index_select ops + the base density)
 
     def _layerwise_autograd(self, x, latent=None, reverse: bool = True, t=None):
         """The flow layer by layer WITH an autograd graph: each layer's transform (and its backward) is a HIP kernel behind

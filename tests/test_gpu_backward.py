@@ -891,3 +891,24 @@ def test_spline_forward_direction_backward_matches_autograd_of_oracle(K, dim, hi
     close(y, yk, rtol=1e-5, atol=1e-5)
     close(ldj, lk, rtol=1e-5, atol=1e-4)
     assert flow.rsample((7,)).requires_grad
+
+
+def test_flow_of_column_shuffles_only_carries_the_input_gradient():
+    """Found by tools/fuzz_train.py --mix: a flow of nothing but Permute / Flip has no parameter, but the reference's
+    log_prob is still differentiable in its input (flow.py:69-84: inverse, then the base density).  It used to be evaluated
+    without a graph (warning + `loss.backward()` raising)."""
+    torch.manual_seed(2)
+    dim = 47
+    desc = [{'kind': 'flip'}, {'kind': 'permute', 'dim': dim}, {'kind': 'flip'}]
+    flow = fd.build_flow(st, desc, dim)
+    state = {k: v.clone() for k, v in flow.state_dict().items()}
+    flow = flow.to(DEV)
+    x = torch.randn(181, dim)
+    xin = x.double().requires_grad_(True)
+    want = -orc.flow_log_prob(fd.flow_spec(desc, state), xin, None).mean()
+    want.backward()
+    xg = x.to(DEV).requires_grad_(True)
+    loss = -flow.log_prob(xg).mean()
+    loss.backward()
+    close(loss.detach().cpu(), want.detach().float(), rtol=1e-6, atol=1e-6)
+    close(xg.grad.cpu(), xin.grad.float(), rtol=1e-5, atol=1e-8)

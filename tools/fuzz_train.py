@@ -1,6 +1,7 @@
 """Randomised differential check of the training paths: random spline / affine coupling flows (dims, widths, masks, bin counts,
 spline types, latent inputs, batch sizes) -- gradients of -log_prob.mean() from the HIP paths against fp64 autograd of the oracle.
-    python tools/fuzz_train.py [n_cases] [seed] [--forward]     (--forward: forward_and_log_det_jacobian instead of log_prob)"""
+    python tools/fuzz_train.py [n_cases] [seed] [--forward] [--infer] [--mix]
+(--forward: forward_and_log_det_jacobian instead of log_prob; --infer: the no-graph paths; --mix: every transform kind)"""
 import os
 import sys
 
@@ -38,16 +39,51 @@ def case(rng):
     return desc, dim, latent, int(rng.integers(1, 700))
 
 
+def case_mix(rng):
+    """Every transform kind of the path in one flow: couplings beside element-wise affine / spline layers, dense linear
+    layers (AffineLU, MatrixExponential), Permute and Flip -- the mixes decide which fused program (or tier) a flow runs on."""
+    dim = int(rng.integers(2, 71))
+    latent = int(rng.choice([0, 0, 3]))
+    desc = []
+    for _ in range(int(rng.integers(1, 6))):
+        kind = str(rng.choice(['coupling_affine', 'coupling_affine', 'coupling_rqs', 'affine', 'affine_latent', 'rqs', 'affine_lu',
+                               'matrix_exp', 'permute', 'flip']))
+        hidden = [int(rng.integers(4, 65)) for _ in range(int(rng.integers(1, 3)))]
+        if kind == 'affine_latent' and not latent:
+            kind = 'affine'
+        if kind == 'coupling_affine':
+            d = {'dim': dim, 'hidden': hidden, 'mask': str(rng.choice(MASKS)), 'latent_dim': latent}
+        elif kind == 'coupling_rqs':
+            d = {'dim': dim, 'hidden': hidden, 'mask': str(rng.choice(MASKS)), 'latent_dim': latent,
+                 'n_bins': int(rng.integers(1, 17)), 'lower': -3.0, 'upper': 3.0,
+                 'spline_type': str(rng.choice(['quadratic', 'quadratic', 'cubic']))}
+        elif kind == 'affine':
+            d = {'dim': dim}
+        elif kind == 'affine_latent':
+            d = {'dim': dim, 'hidden': hidden, 'latent_dim': latent}
+        elif kind == 'rqs':
+            d = {'dim': dim, 'n_bins': int(rng.integers(1, 9)), 'lower': -3.0, 'upper': 3.0,
+                 'hidden': hidden if latent else None, 'latent_dim': latent}
+        elif kind == 'matrix_exp':
+            d = {'dim': dim, 'bias': bool(rng.integers(0, 2)), 'log_time': False}
+        else:
+            d = {'dim': dim}
+        d['kind'] = kind
+        desc.append(d)
+    return desc, dim, latent, int(rng.integers(1, 700))
+
+
 def main():
     fwd = '--forward' in sys.argv
     infer = '--infer' in sys.argv
+    mix = '--mix' in sys.argv
     args = [a for a in sys.argv[1:] if not a.startswith('--')]
     n_cases = int(args[0]) if len(args) > 0 else 40
     seed = int(args[1]) if len(args) > 1 else 0
     rng = np.random.default_rng(seed)
     worst = 0.0
     for i in range(n_cases):
-        desc, dim, latent, n = case(rng)
+        desc, dim, latent, n = (case_mix if mix else case)(rng)
         torch.manual_seed(seed * 1000 + i)
         flow = fd.build_flow(st, desc, dim)
         with torch.no_grad():
