@@ -19,6 +19,22 @@
 
 extern __shared__ __attribute__((aligned(16))) float rqs_smem[];
 
+// A wave's parameter span HBM -> its LDS slice by LDS-DMA (global_load_lds_dwordx4: lane-linear 1 KiB pieces, no VGPRs on the
+// way, asynchronous -- counted by vmcnt).  BYTES is a multiple of 16; the last piece runs with the upper lanes masked off.
+// The spline kernels issue the NEXT group's copy as soon as the current group's parameters sit in registers, so the HBM
+// latency of a group hides under the arithmetic of the one before it.
+typedef __attribute__((address_space(3))) void rqs_lds_void;
+template <int BYTES>
+__device__ __forceinline__ void rqs_dma_span(const float *__restrict__ g, float *lds_slice, int lane) {
+    const char *gs = reinterpret_cast<const char *>(g) + lane * 16;
+    char *ld = reinterpret_cast<char *>(lds_slice);      // wave-uniform (the LDS base of the copy travels in m0)
+#pragma unroll
+    for (int off = 0; off < BYTES; off += 1024) {
+        if (off + 1024 <= BYTES || off + lane * 16 < BYTES)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(gs + off), (rqs_lds_void *)(ld + off), 16, 0, 0);
+    }
+}
+
 __device__ __forceinline__ float softplus_ref(float v) { return v > 20.f ? v : log1pf(expf(v)); }  // F.softplus
 
 template <bool BF16>
@@ -74,19 +90,26 @@ __device__ __forceinline__ float rqs16_softmax(float (&u)[16]) {
     return (1.f - RQS_MIN_BIN * 16.f) * __builtin_amdgcn_rcpf(sum);
 }
 
+// the element's 47 parameters in registers (read up front: the LDS slice is then free for the next group's copy)
+struct rqs16_regs { float us[16], uo[16], ud[15]; };
 template <bool INVERSE>
-__device__ __forceinline__ void rqs16_eval(const float *__restrict__ p, float xv, float left, float right, float bottom,
+__device__ __forceinline__ void rqs16_load(rqs16_regs &r, const float *__restrict__ p) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        r.us[k] = p[(INVERSE ? 16 : 0) + k];      // searched block: widths forward, heights inverse
+        r.uo[k] = p[(INVERSE ? 0 : 16) + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 15; ++k) r.ud[k] = p[32 + k];
+}
+template <bool INVERSE>
+__device__ __forceinline__ void rqs16_eval(rqs16_regs &r, float xv, float left, float right, float bottom,
                                            float top, float &out, float &ljd, bool &bad_disc) {
     const float lo = INVERSE ? bottom : left, hi = INVERSE ? top : right;        // searched (input-side) interval
     const float lo2 = INVERSE ? left : bottom, hi2 = INVERSE ? right : top;      // the other block's interval
     const bool inside = (xv >= lo) && (xv <= hi);                                // :71
     const float xin = inside ? xv : lo;
-    float us[16], uo[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        us[k] = p[(INVERSE ? 16 : 0) + k];      // searched block: widths forward, heights inverse
-        uo[k] = p[(INVERSE ? 0 : 16) + k];
-    }
+    float (&us)[16] = r.us, (&uo)[16] = r.uo;
     // search sweep (:180-197): knots increase and x >= knot_j holds for a prefix of j
     const float inv_s = rqs16_softmax(us);
     int b = 0;
@@ -117,7 +140,7 @@ __device__ __forceinline__ void rqs16_eval(const float *__restrict__ p, float xv
     float r_b = cst, r_n = cst;
 #pragma unroll
     for (int k = 0; k < 15; ++k) {
-        const float v = p[32 + k];
+        const float v = r.ud[k];
         r_b = (k == b - 1) ? v : r_b;
         r_n = (k == b) ? v : r_n;
     }
@@ -164,7 +187,7 @@ __global__ __launch_bounds__(256) void rqs_kernel(const void *__restrict__ x, vo
     const int P = 3 * K - 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int waves_per_block = blockDim.x >> 6;
-    float *sp = rqs_smem + (size_t)wave * 64 * P;               // this wave's staging slice
+    float *sp = rqs_smem + (size_t)__builtin_amdgcn_readfirstlane(wave) * 64 * P;               // this wave's staging slice
     const int64_t n_elem = n_rows * n_live;
     // ALIGNED (ldj_mode 2): row-aligned work units, per-row sums without atomics; the dense variant is compiled without
     // any of it (its software-pipelined staging sits at 163 VGPRs = 3 waves per SIMD)
@@ -176,8 +199,13 @@ __global__ __launch_bounds__(256) void rqs_kernel(const void *__restrict__ x, vo
     // rows of parameters back to back (stride = n_live * P) and a 16-byte aligned base: 64 elements = 64*P floats
     const bool contig = (pstride == (int64_t)n_live * P) && ((reinterpret_cast<uintptr_t>(params) & 15) == 0);
 
-    f32x4 pf[12];               // next group's parameter span (K = 16 contiguous case)
-    bool have_pf = false;
+    bool have_pf = false;       // this group's span is already on its way into the slice (K = 16 contiguous case)
+    float x_pf = 0.f;           // ... and so is its input element (loads return in order: a load issued behind the copy would wait for it)
+    auto load_x = [&](int64_t e) {
+        const int64_t row = e / n_live;
+        const int i = (int)(e - row * n_live);
+        return rqs_load<BF16>(x, row * dim + (live_idx ? live_idx[i] : l0 + i));
+    };
     for (int64_t grp = (int64_t)blockIdx.x * waves_per_block + wave; grp < n_groups;
          grp += (int64_t)gridDim.x * waves_per_block) {
       [[maybe_unused]] float row_acc = 0.f;    // ALIGNED, rows wider than a wave: the row's sum over its chunks
@@ -188,28 +216,22 @@ __global__ __launch_bounds__(256) void rqs_kernel(const void *__restrict__ x, vo
         else { e0 = grp << 6; n_here = (int)((n_elem - e0) < 64 ? (n_elem - e0) : 64); }
         // ---- stage the elements' parameters: consecutive idx -> consecutive HBM addresses inside a row ----
         const int total = n_here * P;
-        if (!ALIGNED && contig && n_here == 64 && P == 47) {
-            // the 64 elements' parameters are one contiguous, 16-byte aligned span of 752 float4: 11.75 per lane.
-            // Software pipeline: this group's span was fetched into registers one iteration ago; park it in LDS,
-            // then fetch the NEXT group's span so its latency hides under this group's arithmetic.
-            f32x4 *dst = reinterpret_cast<f32x4 *>(sp);
-            if (!have_pf) {
-                const f32x4 *src = reinterpret_cast<const f32x4 *>(params + e0 * P);
-#pragma unroll
-                for (int t = 0; t < 12; ++t)
-                    if (t * 64 + lane < 752) pf[t] = src[t * 64 + lane];
-            }
-#pragma unroll
-            for (int t = 0; t < 12; ++t)
-                if (t * 64 + lane < 752) dst[t * 64 + lane] = pf[t];
+        [[maybe_unused]] rqs16_regs pr;
+        [[maybe_unused]] float x_dense = 0.f;
+        const bool dense16 = !ALIGNED && contig && n_here == 64 && P == 47;
+        if (dense16) {
+            // the 64 elements' parameters are one contiguous, 16-byte aligned span of 12,032 B.  Software pipeline on
+            // LDS-DMA: the span was requested one iteration ago; lift it into registers (47 conflict-free ds_read_b32 at the
+            // odd stride), then request the NEXT group's span into the same slice: its latency hides under this group's
+            // arithmetic, no VGPR holds data in flight (the register-prefetch form of round 1 sat at 163 VGPRs).
+            if (!have_pf) { x_pf = load_x(e0 + lane); rqs_dma_span<64 * 47 * 4>(params + e0 * P, sp, lane); }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            x_dense = x_pf;
+            rqs16_load<INVERSE>(pr, sp + lane * P);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int64_t gnext = grp + (int64_t)gridDim.x * waves_per_block;
             have_pf = gnext < n_groups && ((gnext << 6) + 64 <= n_elem);      // dense units only (checked above)
-            if (have_pf) {
-                const f32x4 *src = reinterpret_cast<const f32x4 *>(params + (gnext << 6) * P);
-#pragma unroll
-                for (int t = 0; t < 12; ++t)
-                    if (t * 64 + lane < 752) pf[t] = src[t * 64 + lane];
-            }
+            if (have_pf) { x_pf = load_x((gnext << 6) + lane); rqs_dma_span<64 * 47 * 4>(params + (gnext << 6) * P, sp, lane); }
         } else if (contig && n_here == 64 && (!ALIGNED || ((e0 * P) & 3) == 0)) {
             have_pf = false;
             const f32x4 *src = reinterpret_cast<const f32x4 *>(params + e0 * P);
@@ -234,11 +256,12 @@ __global__ __launch_bounds__(256) void rqs_kernel(const void *__restrict__ x, vo
         const int64_t row = valid ? e / n_live : 0;
         const int i = valid ? (int)(e - row * n_live) : 0;
         const int col = live_idx ? live_idx[i] : l0 + i;
-        const float xv = valid ? rqs_load<BF16>(x, row * dim + col) : lo_in;
+        const float xv = dense16 ? x_dense : (valid ? rqs_load<BF16>(x, row * dim + col) : lo_in);
         float out, ljd;
         if (K == 16) {      // wave-uniform: straight-line register path
             bool bad;
-            rqs16_eval<INVERSE>(sp + (valid ? lane : 0) * P, xv, left, right, bottom, top, out, ljd, bad);
+            if (!dense16) rqs16_load<INVERSE>(pr, sp + (valid ? lane : 0) * P);
+            rqs16_eval<INVERSE>(pr, xv, left, right, bottom, top, out, ljd, bad);
             if (valid && bad && err_flag) __hip_atomic_fetch_or(err_flag, SX_FLAG_RQS_NEG_DISCRIMINANT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         } else {
         const bool inside = (xv >= lo_in) && (xv <= hi_in);                    // :71 closed interval
@@ -433,21 +456,9 @@ __device__ __forceinline__ float cubic_exp(float v) {
 // (exp'ed) widths / heights ew[k], eh[k] with their softmax factors nw, nh and the two raw boundary-derivative parameters
 // (cubic_spline.py:103-137, 229-237): the bin is searched by widths, as the forward pass does.  Used by the inverse
 // kernel's reference mode when the inverted point does not land in the bin it was solved in (rare).
-template <class GW, class GH>
-__device__ __forceinline__ float cubic_forward_logderiv(GW ew, GH eh, float nw, float nh, float dpar0, float dpar1, int K,
-                                                        float xin) {
-    int b = 0;
-    float cw_b = 0.f, w_b = 0.f, h_b = 0.f, w_m = 1.f, h_m = 1.f, w_p = 1.f, h_p = 1.f;
-    float cw = 0.f, w_last = 1.f, h_last = 1.f;
-    bool need_next = false;
-    for (int k = 0; k < K; ++k) {
-        const float wk = CUBIC_MIN_BIN + nw * ew(k);
-        const float hk = CUBIC_MIN_BIN + nh * eh(k);
-        if (xin >= cw) { b = k; cw_b = cw; w_b = wk; h_b = hk; w_m = w_last; h_m = h_last; need_next = true; }
-        else if (need_next) { w_p = wk; h_p = hk; need_next = false; }
-        w_last = wk; h_last = hk;
-        cw += wk;
-    }
+// log f'(x) in bin b from the sizes of bins b-1, b, b+1 (:117-137, :235-237)
+__device__ __forceinline__ float cubic_logderiv_at(int b, int K, float cw_b, float w_b, float h_b, float w_m, float h_m, float w_p,
+                                                   float h_p, float dpar0, float dpar1, float xin) {
     const float s_b = h_b / w_b;
     auto sgn = [](float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); };
     float dL, dR;
@@ -466,6 +477,45 @@ __device__ __forceinline__ float cubic_forward_logderiv(GW ew, GH eh, float nw, 
     const float t = xin - cw_b;
     return logf(3.f * a * (t * t) + 2.f * bb * t + dL);
 }
+template <class GW, class GH>
+__device__ __forceinline__ float cubic_forward_logderiv(GW ew, GH eh, float nw, float nh, float dpar0, float dpar1, int K,
+                                                        float xin) {
+    int b = 0;
+    float cw_b = 0.f, w_b = 0.f, h_b = 0.f, w_m = 1.f, h_m = 1.f, w_p = 1.f, h_p = 1.f;
+    float cw = 0.f, w_last = 1.f, h_last = 1.f;
+    bool need_next = false;
+    for (int k = 0; k < K; ++k) {
+        const float wk = CUBIC_MIN_BIN + nw * ew(k);
+        const float hk = CUBIC_MIN_BIN + nh * eh(k);
+        if (xin >= cw) { b = k; cw_b = cw; w_b = wk; h_b = hk; w_m = w_last; h_m = h_last; need_next = true; }
+        else if (need_next) { w_p = wk; h_p = hk; need_next = false; }
+        w_last = wk; h_last = hk;
+        cw += wk;
+    }
+    return cubic_logderiv_at(b, K, cw_b, w_b, h_b, w_m, h_m, w_p, h_p, dpar0, dpar1, xin);
+}
+// the same from the K = 16 register form (exp'ed widths / heights + softmax factors): selects only
+__device__ __forceinline__ float cubic16_forward_logderiv(const float (&rw)[16], const float (&rh)[16], float nw, float nh,
+                                                          float dpar0, float dpar1, float xin) {
+    int b = 0;
+    float cw_b = 0.f, w_b = 0.f, h_b = 0.f, w_m = 1.f, h_m = 1.f, w_p = 1.f, h_p = 1.f;
+    float cw = 0.f, w_last = 1.f, h_last = 1.f;
+    bool need_next = false;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const float wk = CUBIC_MIN_BIN + nw * rw[k];
+        const float hk = CUBIC_MIN_BIN + nh * rh[k];
+        const bool ge = xin >= cw;
+        const bool nx = !ge && need_next;
+        b = ge ? k : b; cw_b = ge ? cw : cw_b; w_b = ge ? wk : w_b; h_b = ge ? hk : h_b;
+        w_m = ge ? w_last : w_m; h_m = ge ? h_last : h_m;
+        w_p = nx ? wk : w_p; h_p = nx ? hk : h_p;
+        need_next = ge;
+        w_last = wk; h_last = hk;
+        cw += wk;
+    }
+    return cubic_logderiv_at(b, 16, cw_b, w_b, h_b, w_m, h_m, w_p, h_p, dpar0, dpar1, xin);
+}
 
 template <bool BF16, bool INVERSE, bool ALIGNED>
 __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, void *__restrict__ y,
@@ -478,11 +528,18 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
     const int P = 2 * K + 2, PS = P | 1;                         // padded (odd) per-lane stride
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int waves_per_block = blockDim.x >> 6;
-    float *sp = rqs_smem + (size_t)wave * 64 * PS;
+    float *sp = rqs_smem + (size_t)__builtin_amdgcn_readfirstlane(wave) * 64 * PS;
     const sx_units units = sx_make_units(n_rows, n_live, ALIGNED);
     const int64_t n_elem = n_rows * n_live;
     const int64_t n_groups = units.n_units;
     const float norm = 1.f - CUBIC_MIN_BIN * (float)K;          // :104, :111
+    bool have_pf = false;       // dense K = 16 pipeline: this group's span and input element are already on their way
+    float x_pf = 0.f;
+    auto load_x = [&](int64_t e) {
+        const int64_t row = e / n_live;
+        const int i = (int)(e - row * n_live);
+        return rqs_load<BF16>(x, row * dim + (live_idx ? live_idx[i] : l0 + i));
+    };
     const float span = upper - lower;                            // right - left = top - bottom
     const bool contig = pstride == (int64_t)n_live * P;
     const float inv_P = 1.0f / (float)P;
@@ -500,15 +557,41 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
         // K even (P / 2 odd): the span is copied as it is (16 B per lane in, 16 B out) and a lane reads its element's parameters
         // as 8-byte pairs at a stride of P / 2 pairs -- odd, so the 64-bit reads are conflict-free without padding, and the
         // 270 instructions per element of index arithmetic + scalar LDS writes of the padded form reduce to 17
-        // (forward direction only: the inverse's reference mode re-reads single parameters at the even stride, 2-way conflicts)
-        const bool lin = !INVERSE && K == 16 && contig && n_here == 64 && (!ALIGNED || ((e0 * P) & 3) == 0) &&
+        // (both directions: the inverse's reference-mode re-evaluation works from the registers)
+        const bool lin = K == 16 && contig && n_here == 64 && (!ALIGNED || ((e0 * P) & 3) == 0) &&
                          ((reinterpret_cast<uintptr_t>(params) & 15) == 0);
-        if (lin) {
+        const bool dma16 = !ALIGNED && lin;
+        [[maybe_unused]] float rw[16], rh[16], x_dense = 0.f;
+        float dpar0 = 0.f, dpar1 = 0.f;
+        typedef float f32pair __attribute__((ext_vector_type(2)));
+        auto load16 = [&](const float *q) {                      // 8-byte aligned pairs
+#pragma unroll
+            for (int k = 0; k < 16; k += 2) {
+                const f32pair a = *reinterpret_cast<const f32pair *>(q + k), c2 = *reinterpret_cast<const f32pair *>(q + 16 + k);
+                rw[k] = a.x; rw[k + 1] = a.y; rh[k] = c2.x; rh[k + 1] = c2.y;
+            }
+            const f32pair d2 = *reinterpret_cast<const f32pair *>(q + 32);
+            dpar0 = d2.x; dpar1 = d2.y;
+        };
+        if (dma16) {
+            // software pipeline on LDS-DMA (see rqs_kernel): the span requested one iteration ago is lifted into registers,
+            // then the next group's span is requested into the same slice and lands under this group's arithmetic
+            if (!have_pf) { x_pf = load_x(e0 + lane); rqs_dma_span<64 * 34 * 4>(params + e0 * P, sp, lane); }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            x_dense = x_pf;
+            load16(sp + lane * P);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int64_t gnext = grp + (int64_t)gridDim.x * waves_per_block;
+            have_pf = gnext < n_groups && ((gnext << 6) + 64 <= n_elem);
+            if (have_pf) { x_pf = load_x((gnext << 6) + lane); rqs_dma_span<64 * 34 * 4>(params + (gnext << 6) * P, sp, lane); }
+        } else if (lin) {
+            have_pf = false;
             const f32x4 *src = reinterpret_cast<const f32x4 *>(params + e0 * P);
             f32x4 *dst = reinterpret_cast<f32x4 *>(sp);
             for (int i4 = lane; i4 < 16 * P; i4 += 64) dst[i4] = src[i4];
         } else if (contig && n_here == 64 && (P & 1) == 0 && (!ALIGNED || ((e0 * P) & 3) == 0) && ((reinterpret_cast<uintptr_t>(params) & 15) == 0)) {
             // 64*P floats = 16*P float4, 16-byte aligned (P even): vector loads, scalar LDS writes into the padded rows
+            have_pf = false;
             const f32x4 *src = reinterpret_cast<const f32x4 *>(params + e0 * P);
             for (int i4 = lane; i4 < 16 * P; i4 += 64) {
                 const f32x4 v = src[i4];
@@ -519,7 +602,8 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
                     sp[el * PS + q] = v[c];
                 }
             }
-        } else
+        } else {
+        have_pf = false;
         for (int idx = lane; idx < total; idx += 64) {
             const int el = (int)(((float)idx + 0.5f) * inv_P), q = idx - el * P;       // idx / P, exact for idx < 2^22
             float v;
@@ -531,6 +615,7 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
             }
             sp[el * PS + q] = v;
         }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
@@ -539,7 +624,7 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
         const int64_t row = valid ? e / n_live : 0;
         const int i = valid ? (int)(e - row * n_live) : 0;
         const int col = live_idx ? live_idx[i] : l0 + i;
-        const float xv = valid ? rqs_load<BF16>(x, row * dim + col) : lower;
+        const float xv = dma16 ? x_dense : (valid ? rqs_load<BF16>(x, row * dim + col) : lower);
         const bool inside = (xv >= lower) && (xv <= upper);      // :40 closed interval
         const float xin = ((inside ? xv : lower) - lower) / span;            // :98-101
         float *p = sp + (valid ? lane : 0) * (lin ? P : PS);     // [0,K) widths, [K,2K) heights, 2K / 2K+1 derivatives
@@ -578,17 +663,13 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
             }
         };
         if (K == 16) {          // wave-uniform: parameters in registers, fully unrolled, selects only
-            float rw[16], rh[16];
-            if (lin) {                              // 8-byte aligned pairs
-                typedef float f32pair __attribute__((ext_vector_type(2)));
-#pragma unroll
-                for (int k = 0; k < 16; k += 2) {
-                    const f32pair a = *reinterpret_cast<const f32pair *>(p + k), c2 = *reinterpret_cast<const f32pair *>(p + 16 + k);
-                    rw[k] = a.x; rw[k + 1] = a.y; rh[k] = c2.x; rh[k + 1] = c2.y;
-                }
+            if (dma16) {
+            } else if (lin) {
+                load16(p);
             } else {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) { rw[k] = p[k]; rh[k] = p[16 + k]; }
+                dpar0 = p[32]; dpar1 = p[33];
             }
             float mw = rw[0], mh = rh[0];
 #pragma unroll
@@ -600,6 +681,7 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
                 sw += rw[k]; sh += rh[k];
             }
             const float nw = norm / sw, nh = norm / sh;
+            nw_k = nw; nh_k = nh;
             float cw = 0.f, ch = 0.f, w_last = 1.f, h_last = 1.f;
             bool need_next = false;
 #pragma unroll
@@ -619,12 +701,13 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
         } else {
             sweep([&](int k) { return p[k]; }, [&](int k) { return p[K + k]; }, [&](int k, float v) { p[k] = v; },
                   [&](int k, float v) { p[K + k] = v; }, K);
+            dpar0 = p[2 * K]; dpar1 = p[2 * K + 1];
         }
         // ---- knot derivatives of bin b (:117-132) and its cubic (:134-137) -----------------------------------
         const float s_b = h_b / w_b;                                                       // :117
         const float rcw = (b == K - 1) ? 1.f : cw_b + w_b;                                 // :107 (last knot pinned)
         float dL, dR;
-        if (b == 0) dL = cubic_sigmoid(p[2 * K]) * 3.f * s_b;                              // :126
+        if (b == 0) dL = cubic_sigmoid(dpar0) * 3.f * s_b;                                 // :126
         else {
             const float s_m = h_m / w_m;
             const float m1 = fminf(fabsf(s_m), fabsf(s_b));                               // :118-119
@@ -632,7 +715,7 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
             const float sg = ((s_m > 0.f) ? 1.f : ((s_m < 0.f) ? -1.f : 0.f)) + ((s_b > 0.f) ? 1.f : ((s_b < 0.f) ? -1.f : 0.f));
             dL = fminf(m1, m2) * sg;                                                       // :124, :129
         }
-        if (b == K - 1) dR = cubic_sigmoid(p[2 * K + 1]) * 3.f * s_b;                      // :127
+        if (b == K - 1) dR = cubic_sigmoid(dpar1) * 3.f * s_b;                             // :127
         else {
             const float s_p = h_p / w_p;
             const float m1 = fminf(fabsf(s_b), fabsf(s_p));
@@ -697,17 +780,12 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
                 const bool slow = valid && in2 && !same_bin;
                 if (__builtin_amdgcn_ballot_w64(slow)) {
                     if (slow) {
-                        if (K == 16) {          // the raw parameters are still in LDS: redo the softmax factors
-                            float mw = p[0], mh = p[16];
-                            for (int k = 1; k < 16; ++k) { mw = fmaxf(mw, p[k]); mh = fmaxf(mh, p[16 + k]); }
-                            float sw = 0.f, sh = 0.f;
-                            for (int k = 0; k < 16; ++k) { sw += cubic_exp(p[k] - mw); sh += cubic_exp(p[16 + k] - mh); }
-                            lf = cubic_forward_logderiv([&](int k) { return cubic_exp(p[k] - mw); },
-                                                        [&](int k) { return cubic_exp(p[16 + k] - mh); }, norm / sw, norm / sh,
-                                                        p[32], p[33], 16, xin2);
+                        if (K == 16) {          // the exp'ed widths / heights are still in registers (the LDS slice may already
+                                                // be receiving the next group)
+                            lf = cubic16_forward_logderiv(rw, rh, nw_k, nh_k, dpar0, dpar1, xin2);
                         } else {                // the generic path left exp(u - max) in place of the raw widths / heights
                             lf = cubic_forward_logderiv([&](int k) { return p[k]; }, [&](int k) { return p[K + k]; }, nw_k, nh_k,
-                                                        p[2 * K], p[2 * K + 1], K, xin2);
+                                                        dpar0, dpar1, K, xin2);
                         }
                     }
                 }
