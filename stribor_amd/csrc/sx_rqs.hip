@@ -456,26 +456,42 @@ __device__ __forceinline__ float cubic_exp(float v) {
 // (exp'ed) widths / heights ew[k], eh[k] with their softmax factors nw, nh and the two raw boundary-derivative parameters
 // (cubic_spline.py:103-137, 229-237): the bin is searched by widths, as the forward pass does.  Used by the inverse
 // kernel's reference mode when the inverted point does not land in the bin it was solved in (rare).
+// ---- cubic_kernel's arithmetic: the hardware's 1-ulp exp2 / log2 / rcp / sqrt instead of libm calls and IEEE division
+// sequences (the kernel is VALU-bound: 1,489 -> ~900 VALU instructions per element in the inverse direction, 791 -> ~500
+// forward, tools/pmc_spline_kernels.sh).  Their errors (~1e-7 relative) are the size of the reference's own fp32 rounding;
+// the inverse ends in Newton steps on the bin's cubic, so its result does not depend on how exactly the closed form ran.
+__device__ __forceinline__ float cubic_fexp(float v) { return __builtin_amdgcn_exp2f(v * 1.44269504088896341f); }
+__device__ __forceinline__ float cubic_frcp(float v) { return __builtin_amdgcn_rcpf(v); }
+__device__ __forceinline__ float cubic_flog(float v) { return __builtin_amdgcn_logf(v) * 0.69314718055994531f; }
+__device__ __forceinline__ float cubic_fsigmoid(float v) { return cubic_frcp(1.f + cubic_fexp(-v)); }
+__device__ __forceinline__ float cubic_fcbrt(float v) {        // :18-20  sign(x) * exp(log|x| / 3)
+    const float m = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(fabsf(v)) * (1.0f / 3.0f));
+    return (v == 0.f) ? 0.f : copysignf(m, v);
+}
+// Knot derivatives of bin b (:117-132) and its cubic a t^3 + bb t^2 + c t + d (:134-137) from the sizes of bins b-1, b, b+1.
+// Bin sizes are >= 1e-2, so every slope is positive: sign(s_m) + sign(s_b) = 2 and the |.| of :118-119 are no-ops.
+struct cubic_coef { float a, bb, c; };
+__device__ __forceinline__ cubic_coef cubic_bin_coef(int b, int K, float w_b, float h_b, float w_m, float h_m, float w_p, float h_p,
+                                                     float dpar0, float dpar1) {
+    const float rwb = cubic_frcp(w_b);
+    const float s_b = h_b * rwb;                                                           // :117
+    const float s_m = h_m * cubic_frcp(w_m), s_p = h_p * cubic_frcp(w_p);
+    const float mL = 0.5f * (w_b * s_m + w_m * s_b) * cubic_frcp(w_m + w_b);              // :120-123
+    const float mR = 0.5f * (w_p * s_b + w_b * s_p) * cubic_frcp(w_b + w_p);
+    const float dL = (b == 0) ? cubic_fsigmoid(dpar0) * 3.f * s_b : 2.f * fminf(fminf(s_m, s_b), mL);       // :126, :118-129
+    const float dR = (b == K - 1) ? cubic_fsigmoid(dpar1) * 3.f * s_b : 2.f * fminf(fminf(s_b, s_p), mR);   // :127
+    cubic_coef q;
+    q.a = (dL + dR - 2.f * s_b) * (rwb * rwb);                                             // :134
+    q.bb = (3.f * s_b - 2.f * dL - dR) * rwb;                                              // :135
+    q.c = dL;                                                                              // :136
+    return q;
+}
 // log f'(x) in bin b from the sizes of bins b-1, b, b+1 (:117-137, :235-237)
 __device__ __forceinline__ float cubic_logderiv_at(int b, int K, float cw_b, float w_b, float h_b, float w_m, float h_m, float w_p,
                                                    float h_p, float dpar0, float dpar1, float xin) {
-    const float s_b = h_b / w_b;
-    auto sgn = [](float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); };
-    float dL, dR;
-    if (b == 0) dL = cubic_sigmoid(dpar0) * 3.f * s_b;
-    else {
-        const float s_m = h_m / w_m;
-        dL = fminf(fminf(fabsf(s_m), fabsf(s_b)), 0.5f * (w_b * s_m + w_m * s_b) / (w_m + w_b)) * (sgn(s_m) + sgn(s_b));
-    }
-    if (b == K - 1) dR = cubic_sigmoid(dpar1) * 3.f * s_b;
-    else {
-        const float s_p = h_p / w_p;
-        dR = fminf(fminf(fabsf(s_b), fabsf(s_p)), 0.5f * (w_p * s_b + w_b * s_p) / (w_b + w_p)) * (sgn(s_b) + sgn(s_p));
-    }
-    const float a = (dL + dR - 2.f * s_b) / (w_b * w_b);
-    const float bb = (3.f * s_b - 2.f * dL - dR) / w_b;
+    const cubic_coef q = cubic_bin_coef(b, K, w_b, h_b, w_m, h_m, w_p, h_p, dpar0, dpar1);
     const float t = xin - cw_b;
-    return logf(3.f * a * (t * t) + 2.f * bb * t + dL);
+    return cubic_flog(3.f * q.a * (t * t) + 2.f * q.bb * t + q.c);
 }
 template <class GW, class GH>
 __device__ __forceinline__ float cubic_forward_logderiv(GW ew, GH eh, float nw, float nh, float dpar0, float dpar1, int K,
@@ -518,7 +534,7 @@ __device__ __forceinline__ float cubic16_forward_logderiv(const float (&rw)[16],
 }
 
 template <bool BF16, bool INVERSE, bool ALIGNED>
-__global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, void *__restrict__ y,
+__global__ __launch_bounds__(256, 4) void cubic_kernel(const void *__restrict__ x, void *__restrict__ y,
                                                     float *__restrict__ ldj, float *__restrict__ ldiag,
                                                     const float *__restrict__ params, int64_t pstride,
                                                     const int32_t *__restrict__ live_idx, int l0, int n_live, int K,
@@ -541,6 +557,7 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
         return rqs_load<BF16>(x, row * dim + (live_idx ? live_idx[i] : l0 + i));
     };
     const float span = upper - lower;                            // right - left = top - bottom
+    const float inv_span = 1.0f / span;
     const bool contig = pstride == (int64_t)n_live * P;
     const float inv_P = 1.0f / (float)P;
 
@@ -626,7 +643,7 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
         const int col = live_idx ? live_idx[i] : l0 + i;
         const float xv = dma16 ? x_dense : (valid ? rqs_load<BF16>(x, row * dim + col) : lower);
         const bool inside = (xv >= lower) && (xv <= upper);      // :40 closed interval
-        const float xin = ((inside ? xv : lower) - lower) / span;            // :98-101
+        const float xin = ((inside ? xv : lower) - lower) * inv_span;        // :98-101
         float *p = sp + (valid ? lane : 0) * (lin ? P : PS);     // [0,K) widths, [K,2K) heights, 2K / 2K+1 derivatives
 
         // ---- normalised widths / heights, running cumsums (:103-115) and the bin search (search_sorted.py:4-5) in
@@ -639,13 +656,13 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
             for (int k = 1; k < KK; ++k) { mw = fmaxf(mw, get_w(k)); mh = fmaxf(mh, get_h(k)); }
             float sw = 0.f, sh = 0.f;
             for (int k = 0; k < KK; ++k) {      // exp once per parameter (v_exp_f32 with a compensated argument)
-                const float ew = cubic_exp(get_w(k) - mw), eh = cubic_exp(get_h(k) - mh);
+                const float ew = cubic_fexp(get_w(k) - mw), eh = cubic_fexp(get_h(k) - mh);
                 set_w(k, ew);
                 set_h(k, eh);
                 sw += ew;
                 sh += eh;
             }
-            const float nw = norm / sw, nh = norm / sh;         // one division per softmax instead of one per bin
+            const float nw = norm * cubic_frcp(sw), nh = norm * cubic_frcp(sh);         // one reciprocal per softmax
             nw_k = nw; nh_k = nh;
             float cw = 0.f, ch = 0.f, w_last = 1.f, h_last = 1.f;
             bool need_next = false;
@@ -677,10 +694,10 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
             float sw = 0.f, sh = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                rw[k] = cubic_exp(rw[k] - mw); rh[k] = cubic_exp(rh[k] - mh);
+                rw[k] = cubic_fexp(rw[k] - mw); rh[k] = cubic_fexp(rh[k] - mh);
                 sw += rw[k]; sh += rh[k];
             }
-            const float nw = norm / sw, nh = norm / sh;
+            const float nw = norm * cubic_frcp(sw), nh = norm * cubic_frcp(sh);
             nw_k = nw; nh_k = nh;
             float cw = 0.f, ch = 0.f, w_last = 1.f, h_last = 1.f;
             bool need_next = false;
@@ -704,48 +721,49 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
             dpar0 = p[2 * K]; dpar1 = p[2 * K + 1];
         }
         // ---- knot derivatives of bin b (:117-132) and its cubic (:134-137) -----------------------------------
-        const float s_b = h_b / w_b;                                                       // :117
         const float rcw = (b == K - 1) ? 1.f : cw_b + w_b;                                 // :107 (last knot pinned)
-        float dL, dR;
-        if (b == 0) dL = cubic_sigmoid(dpar0) * 3.f * s_b;                                 // :126
-        else {
-            const float s_m = h_m / w_m;
-            const float m1 = fminf(fabsf(s_m), fabsf(s_b));                               // :118-119
-            const float m2 = 0.5f * (w_b * s_m + w_m * s_b) / (w_m + w_b);                 // :120-123
-            const float sg = ((s_m > 0.f) ? 1.f : ((s_m < 0.f) ? -1.f : 0.f)) + ((s_b > 0.f) ? 1.f : ((s_b < 0.f) ? -1.f : 0.f));
-            dL = fminf(m1, m2) * sg;                                                       // :124, :129
-        }
-        if (b == K - 1) dR = cubic_sigmoid(dpar1) * 3.f * s_b;                             // :127
-        else {
-            const float s_p = h_p / w_p;
-            const float m1 = fminf(fabsf(s_b), fabsf(s_p));
-            const float m2 = 0.5f * (w_p * s_b + w_b * s_p) / (w_b + w_p);
-            const float sg = ((s_b > 0.f) ? 1.f : ((s_b < 0.f) ? -1.f : 0.f)) + ((s_p > 0.f) ? 1.f : ((s_p < 0.f) ? -1.f : 0.f));
-            dR = fminf(m1, m2) * sg;
-        }
-        const float a = (dL + dR - 2.f * s_b) / (w_b * w_b);                               // :134
-        const float bb = (3.f * s_b - 2.f * dL - dR) / w_b;                                // :135
-        const float c = dL;                                                                // :136
+        const cubic_coef cf = cubic_bin_coef(b, K, w_b, h_b, w_m, h_m, w_p, h_p, dpar0, dpar1);
+        const float a = cf.a, bb = cf.bb, c = cf.c;
         const float d = ch_b;                                                              // :137
 
         float out, ljd;
         if constexpr (INVERSE) {
-            const float b_ = (bb / a) / 3.f;                                               // :154-156
-            const float c_ = (c / a) / 3.f;
-            const float d_ = (d - xin) / a;
+            const float ra = cubic_frcp(a);
+            const float b_ = (bb * ra) * (1.0f / 3.0f);                                    // :154-156
+            const float c_ = (c * ra) * (1.0f / 3.0f);
+            const float d_ = (d - xin) * ra;
             const float delta_1 = -(b_ * b_) + c_;                                         // :158-160
             const float delta_2 = -c_ * b_ + d_;
             const float delta_3 = b_ * d_ - c_ * c_;
             const float disc = 4.f * delta_1 * delta_3 - delta_2 * delta_2;                // :162
             const float dep1 = -2.f * b_ * delta_1 + delta_2;                              // :164
             const bool three = disc > 0.f;                                                 // :167
+            const float sqd = __builtin_amdgcn_sqrtf(fabsf(disc));
             // one root (:174-179)
-            const float sq = sqrtf(three ? 0.f : -disc);
-            const float one_root = (cubic_cbrt((-dep1 + sq) / 2.f) + cubic_cbrt((-dep1 - sq) / 2.f)) - b_ + cw_b;
-            // three roots (:183-212): the first (order 1, 2, 3) that lies in the bin, root 1 if none does
-            const float theta = atan2f(sqrtf(three ? disc : 0.f), -dep1) / 3.f;
-            const float cr1 = cosf(theta), cr2 = sinf(theta);
-            const float scale = 2.f * sqrtf(three ? -delta_1 : 0.f), shift = -b_ + cw_b;
+            const float sq = three ? 0.f : sqd;
+            const float one_root = (cubic_fcbrt((-dep1 + sq) * 0.5f) + cubic_fcbrt((-dep1 - sq) * 0.5f)) - b_ + cw_b;
+            // three roots (:183-212): the first (order 1, 2, 3) that lies in the bin, root 1 if none does.
+            // theta = atan2(sqrt(disc), -dep1) / 3 in [0, pi/3]: odd polynomial for atan on [0, 1] (1.3e-7), Taylor sums for
+            // cos / sin on [0, pi/3] (< 4e-9) -- no range reduction is needed anywhere.
+            const float ty = three ? sqd : 0.f, tx = -dep1;
+            const float ax = fabsf(tx), hi_ = fmaxf(ax, ty), lo_ = fminf(ax, ty);
+            const float qa = (hi_ > 0.f) ? lo_ * cubic_frcp(hi_) : 0.f, q2 = qa * qa;
+            float at = -0.00405455706641078f;
+            at = fmaf(at, q2, 0.021862920373678207f); at = fmaf(at, q2, -0.05591226741671562f); at = fmaf(at, q2, 0.09642192721366882f);
+            at = fmaf(at, q2, -0.1390862762928009f); at = fmaf(at, q2, 0.19946564733982086f); at = fmaf(at, q2, -0.33329859375953674f);
+            at = fmaf(at, q2, 0.9999993443489075f);
+            at = at * qa;
+            at = (ty > ax) ? 1.5707963267948966f - at : at;
+            at = (tx < 0.f) ? 3.141592653589793f - at : at;
+            const float theta = at * (1.0f / 3.0f), th2 = theta * theta;
+            float cr1 = -2.755731922398589e-07f;                                           // cos: 1 - t^2/2! + ... - t^10/10!
+            cr1 = fmaf(cr1, th2, 2.48015873015873e-05f); cr1 = fmaf(cr1, th2, -1.388888888888889e-03f); cr1 = fmaf(cr1, th2, 4.166666666666666e-02f);
+            cr1 = fmaf(cr1, th2, -0.5f); cr1 = fmaf(cr1, th2, 1.f);
+            float cr2 = -2.505210838544172e-08f;                                           // sin: t (1 - t^2/3! + ... - t^10/11!)
+            cr2 = fmaf(cr2, th2, 2.755731922398589e-06f); cr2 = fmaf(cr2, th2, -1.984126984126984e-04f); cr2 = fmaf(cr2, th2, 8.333333333333333e-03f);
+            cr2 = fmaf(cr2, th2, -1.666666666666667e-01f); cr2 = fmaf(cr2, th2, 1.f);
+            cr2 = cr2 * theta;
+            const float scale = 2.f * __builtin_amdgcn_sqrtf(three ? -delta_1 : 0.f), shift = -b_ + cw_b;
             const float r1 = cr1 * scale + shift;
             const float r2 = (-0.5f * cr1 - 0.5f * 1.7320508075688772f * cr2) * scale + shift;
             const float r3 = (-0.5f * cr1 + 0.5f * 1.7320508075688772f * cr2) * scale + shift;
@@ -755,11 +773,30 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
             float o = three ? pick : one_root;
             // a -> 0 (:216-222)
             if (fabsf(a) < CUBIC_QUAD_THRESHOLD) {
+                // (-c + sqrt(c^2 - 4 bb qc)) / (2 bb) in its cancellation-free form -2 qc / (c + sqrt(.)), c = dL > 0: the same
+                // root, but the reference's form loses everything as bb -> 0 (a near-identity spline has bb ~ 1e-5: 5 % of t,
+                // 1e-2 of x in fp32 -- the reference's own fp32 path does that; its fp64 values are what this returns)
                 const float qc = d - xin;
-                o = (-c + sqrtf(c * c - 4.f * bb * qc)) / (2.f * bb) + cw_b;
+                o = (-2.f * qc) * cubic_frcp(c + __builtin_amdgcn_sqrtf(c * c - 4.f * bb * qc)) + cw_b;
             }
-            const float so = o - cw_b;                                                     // :224
-            ljd = -logf(3.f * a * (so * so) + 2.f * bb * so + c);                          // :225-227
+            // Newton steps on f(t) = a t^3 + bb t^2 + c t + d - y inside the bin (f is monotone there): the closed forms above lose
+            // up to 5e-3 of the bin in fp32 where the cubic degenerates (the reference's fp32 path does too); two steps from
+            // their result bring the residual to rounding level.  A non-finite start falls back to the bin's lower knot.
+            float so = o - cw_b;                                                           // :224
+            const float t_hi = rcw - cw_b, f0 = d - xin;
+            so = fminf(fmaxf(so, 0.f), t_hi);                                              // (fmaxf(NaN, 0) = 0)
+            const bool quad = fabsf(a) < CUBIC_QUAD_THRESHOLD;     // the reference's quadratic root stays as it is (it is not the cubic's)
+            const float so_q = o - cw_b;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const float fv = fmaf(fmaf(fmaf(a, so, bb), so, c), so, f0);
+                const float fd = fmaf(fmaf(3.f * a, so, 2.f * bb), so, c);
+                const float st = fv * cubic_frcp(fd);
+                so = (fd > 0.f) ? fminf(fmaxf(so - st, 0.f), t_hi) : so;
+            }
+            so = quad ? so_q : so;
+            o = so + cw_b;
+            ljd = -cubic_flog(3.f * a * (so * so) + 2.f * bb * so + c);                    // :225-227
             out = o * span + lower;                                                        // :235
             ljd = (ljd - log_span) + log_span;                                             // :236 (two fp32 roundings there)
             if (ref_ldj) {
@@ -770,12 +807,12 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
                 // fp32 cubic solve breaks down.  Re-evaluate the forward log-derivative at x' = out exactly as the forward
                 // kernel would: in the solved bin when x' lies inside it (no second sweep), else by a full search.
                 const bool in2 = inside && (out >= lower) && (out <= upper);
-                const float xin2 = ((in2 ? out : lower) - lower) / span;
+                const float xin2 = ((in2 ? out : lower) - lower) * inv_span;
                 const bool same_bin = (xin2 >= cw_b) && (b == K - 1 || xin2 < cw_b + w_b);
                 float lf;
                 {
                     const float t2 = xin2 - cw_b;
-                    lf = logf(3.f * a * (t2 * t2) + 2.f * bb * t2 + c);
+                    lf = cubic_flog(3.f * a * (t2 * t2) + 2.f * bb * t2 + c);
                 }
                 const bool slow = valid && in2 && !same_bin;
                 if (__builtin_amdgcn_ballot_w64(slow)) {
@@ -795,7 +832,7 @@ __global__ __launch_bounds__(256) void cubic_kernel(const void *__restrict__ x, 
         } else {
             const float t = xin - cw_b;                                                    // :229
             out = a * (t * t * t) + bb * (t * t) + c * t + d;                              // :230-233
-            ljd = logf(3.f * a * (t * t) + 2.f * bb * t + c);                              // :235-237
+            ljd = cubic_flog(3.f * a * (t * t) + 2.f * bb * t + c);                        // :235-237
             out = out * span + lower;                                                      // :238
             ljd = (ljd + log_span) - log_span;                                             // :239
         }
@@ -1123,11 +1160,17 @@ __global__ __launch_bounds__(256) void cubic_bwd_kernel(const float *__restrict_
         float Ay, Aa, Ab, Ac, Achb, Acwb;
         if constexpr (INVERSE) {
             const float At = Aon - Al * fpp / fp;                      // out_n = t + cw_b,  ljd = -log f'(t) + const
-            Ay = At * ifp / span;                                      // y_n = (y - lower) / span
-            Aa = -At * (t * t * t) * ifp - Al * 3.f * (t * t) * ifp;
-            Ab = -At * (t * t) * ifp - Al * 2.f * t * ifp;
-            Ac = -At * t * ifp - Al * ifp;
-            Achb = -At * ifp;                                          // d = ch_b
+            // the root as an implicit function of the bin's polynomial, dt/dtheta = -(df/dtheta) / f'(t) -- except where
+            // |a| < 1e-3: there the reference solves the QUADRATIC bb t^2 + c t + (d - y) = 0 (cubic_spline.py:216-222), whose
+            // root does not depend on a and whose other derivatives carry 1 / q'(t), q' = 2 bb t + c.  (da/dtheta carries
+            // 1 / w^2, so the a-path is as large as the others; a near-identity spline has a ~ 0 in every bin.)
+            const bool quad = fabsf(a) < CUBIC_QUAD_THRESHOLD;
+            const float iq = quad ? 1.f / (2.f * bb * t + c) : ifp;
+            Ay = At * iq / span;                                       // y_n = (y - lower) / span
+            Aa = (quad ? 0.f : -At * (t * t * t) * iq) - Al * 3.f * (t * t) * ifp;
+            Ab = -At * (t * t) * iq - Al * 2.f * t * ifp;
+            Ac = -At * t * iq - Al * ifp;
+            Achb = -At * iq;                                           // d = ch_b
             Acwb = Aon;
         } else {
             const float At = Aon * fp + Al * fpp * ifp;                // out_n = f(t),  ljd = log f'(t),  t = x_n - cw_b

@@ -426,11 +426,17 @@ __device__ __forceinline__ float cubic_inverse_bwd_regs(rqsb_f16v &Wp, rqsb_f16v
     const float Aon = Ao * span;                                   // x = out_n * span + lower
     const float ifp = __builtin_amdgcn_rcpf(fp);
     const float At = Aon - Al * fpp * ifp;                         // out_n = t + cw_b,  ljd = -log f'(t) + const
-    const float Ay = At * ifp * inv_span;                          // y_n = (y - lower) / span
-    const float Aa = -At * (t * t * t) * ifp - Al * 3.f * (t * t) * ifp;
-    const float Ab = -At * (t * t) * ifp - Al * 2.f * t * ifp;
-    const float Ac = -At * t * ifp - Al * ifp;
-    const float Achb = -At * ifp;                                  // d = ch_b
+    // the root is an implicit function of the bin's polynomial: dt/dtheta = -(df/dtheta) / f'(t).  Where |a| < 1e-3 the reference
+    // solves the QUADRATIC bb t^2 + c t + (d - y) = 0 instead (cubic_spline.py:216-222): its root does not depend on a at all and
+    // the other derivatives carry 1 / q'(t), q' = 2 bb t + c -- not a rounding matter: da/dtheta carries 1 / w^2, so the a-path is
+    // as large as the others, and a near-identity spline (every freshly initialised one) has a ~ 0 in every bin.
+    const bool quad = fabsf(a) < 1e-3f;
+    const float iq = quad ? __builtin_amdgcn_rcpf(2.f * bb * t + c) : ifp;
+    const float Ay = At * iq * inv_span;                           // y_n = (y - lower) / span
+    const float Aa = (quad ? 0.f : -At * (t * t * t) * iq) - Al * 3.f * (t * t) * ifp;
+    const float Ab = -At * (t * t) * iq - Al * 2.f * t * ifp;
+    const float Ac = -At * t * iq - Al * ifp;
+    const float Achb = -At * iq;                                   // d = ch_b
     const float Acwb = Aon;
     const float AdL = Aa * iw2 - 2.f * Ab * iw + Ac;
     const float AdR = Aa * iw2 - Ab * iw;

@@ -912,3 +912,64 @@ def test_flow_of_column_shuffles_only_carries_the_input_gradient():
     loss.backward()
     close(loss.detach().cpu(), want.detach().float(), rtol=1e-6, atol=1e-6)
     close(xg.grad.cpu(), xin.grad.float(), rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize('unfused', [False, True])
+@pytest.mark.parametrize('K,hidden,last_scale', [(8, [24], 1e-5), (16, [64], 1e-2), (5, [20, 12], 3e-2)])
+def test_cubic_coupling_gradients_in_the_quadratic_fallback_branch(K, hidden, last_scale, unfused, monkeypatch):
+    """Found by tools/fuzz_train.py: where |a| < 1e-3 the reference's inverse solves the bin's QUADRATIC (cubic_spline.py:216-222),
+    so its root -- and autograd through it -- does not depend on `a`; the backward used to differentiate the full cubic there,
+    whose a-path is NOT small (da/dtheta carries 1/w^2): 1e-2 of a weight gradient's scale on single fuzz cases.  A near-identity
+    spline (small last-layer weights: every freshly initialised or zero-initialised conditioner) has a ~ 0 in every bin, so here
+    most elements take that branch (last_scale 1e-5: all interior bins; the other two: a mix.  Scales that put many elements AT the
+    threshold -- a ~ 20 x last_scale here -- are avoided: there fp32 and fp64 take different branches for a percent of the
+    elements, in the reference too, and the branches' gradients differ).  Both backward paths (slab kernel, per-row kernel)
+    against fp64 autograd of the oracle.  The same flows pin the inverse's VALUES: the reference's quadratic formula
+    (-c + sqrt(c^2 - 4 b q)) / (2 b) cancels catastrophically as b -> 0 (1e-2 of x in fp32 for a near-identity spline); the
+    kernel evaluates the same root as -2 q / (c + sqrt(.)) and must match the fp64 oracle per row."""
+    if unfused:
+        monkeypatch.setenv('STRIBOR_SPLINE_UNFUSED', '1')
+    torch.manual_seed(21)
+    dim, n = 12, 700
+    desc = [{'kind': 'coupling_rqs', 'dim': dim, 'hidden': hidden, 'n_bins': K, 'lower': -3, 'upper': 3, 'mask': m,
+             'latent_dim': 0, 'spline_type': 'cubic'} for m in ('ordered_right_half', 'ordered_left_half')]
+    flow = fd.build_flow(st, desc, dim)
+    with torch.no_grad():
+        for t in flow.transforms:
+            last = [m for m in t.transform.latent_net.modules() if isinstance(m, torch.nn.Linear)][-1]
+            last.weight.mul_(last_scale)
+            last.bias.mul_(last_scale)
+    state = {k: v.clone() for k, v in flow.state_dict().items()}
+    flow = flow.to(DEV)
+    x = torch.randn(n, dim) * 1.3
+    want_loss, want_g, want_gx = oracle_grads(desc, state, x)
+    xg = x.to(DEV).requires_grad_(True)
+    lp = flow.log_prob(xg)
+    want_lp = orc.flow_log_prob(fd.flow_spec(desc, {k: v.double() for k, v in state.items()}), x.double())
+    close(lp.detach(), want_lp.float(), rtol=1e-5, atol=5e-5)
+    loss = -lp.mean()
+    loss.backward()
+    assert abs(loss.item() - want_loss) <= 1e-5 * abs(want_loss) + 1e-5
+    sx = want_gx.abs().max().item()
+    assert (xg.grad.cpu() - want_gx.float()).abs().max().item() <= 2e-4 * sx + 1e-7
+    if last_scale < 1e-4:
+        # bb ~ 1e-7 here, and fp64 AUTOGRAD through the reference's (-c + sqrt(c^2 - 4 b q)) / (2 b) is off by ~10 % per element
+        # (two terms of size t / b cancel to t^2); the oracle's VALUES are fine, so the truth is a central difference of its loss
+        spec_of = lambda st_: fd.flow_spec(desc, st_)
+        s64 = {k: v.double() for k, v in state.items()}
+        for tname in ('transforms.0.transform.latent_net.net.2.weight', 'transforms.1.transform.latent_net.net.2.bias'):
+            ours = dict(flow.named_parameters())[tname].grad.cpu().double()
+            for idx in ours.abs().flatten().topk(6).indices.tolist():
+                vals = []
+                for sgn in (1.0, -1.0):
+                    s2 = {k: v.clone() for k, v in s64.items()}
+                    s2[tname].view(-1)[idx] += sgn * 1e-6
+                    vals.append(-orc.flow_log_prob(spec_of(s2), x.double()).mean().item())
+                fdg = (vals[0] - vals[1]) / 2e-6
+                assert abs(ours.flatten()[idx].item() - fdg) <= 1e-3 * abs(fdg) + 1e-7, (tname, idx, ours.flatten()[idx].item(), fdg)
+        return
+    for name, p in flow.named_parameters():
+        ref = want_g[name].float()
+        scale = ref.abs().max().item() + 1e-12
+        err = (p.grad.cpu() - ref).abs().max().item()
+        assert err <= 2e-4 * scale + 1e-9, (name, err, scale)

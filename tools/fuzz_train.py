@@ -1,6 +1,6 @@
 """Randomised differential check of the training paths: random spline / affine coupling flows (dims, widths, masks, bin counts,
 spline types, latent inputs, batch sizes) -- gradients of -log_prob.mean() from the HIP paths against fp64 autograd of the oracle.
-    python tools/fuzz_train.py [n_cases] [seed] [--forward] [--infer] [--mix]
+    python tools/fuzz_train.py [n_cases] [seed] [--forward] [--infer] [--mix] [--only=i ...]
 (--forward: forward_and_log_det_jacobian instead of log_prob; --infer: the no-graph paths; --mix: every transform kind)"""
 import os
 import sys
@@ -82,8 +82,11 @@ def main():
     seed = int(args[1]) if len(args) > 1 else 0
     rng = np.random.default_rng(seed)
     worst = 0.0
+    only = [int(a.split('=')[1]) for a in sys.argv if a.startswith('--only=')]
     for i in range(n_cases):
         desc, dim, latent, n = (case_mix if mix else case)(rng)
+        if only and i not in only:
+            continue
         torch.manual_seed(seed * 1000 + i)
         flow = fd.build_flow(st, desc, dim)
         with torch.no_grad():
