@@ -47,7 +47,15 @@ def case_mix(rng):
     desc = []
     for _ in range(int(rng.integers(1, 6))):
         kind = str(rng.choice(['coupling_affine', 'coupling_affine', 'coupling_rqs', 'affine', 'affine_latent', 'rqs', 'affine_lu',
-                               'matrix_exp', 'permute', 'flip']))
+                               'matrix_exp', 'permute', 'flip', 'leaky_relu', 'cumsum', 'diff', 'identity']))
+        # (bijections of the whole real line only: ELU^-1 is undefined below -1 and logit(sigmoid(x)) saturates in fp32 beyond
+        #  |x| ~ 17 -- in the reference as much as here; those flows have their own domain-aware tests)
+        if kind in ('cumsum', 'diff', 'identity'):
+            desc.append({'kind': kind})
+            continue
+        if kind == 'leaky_relu':
+            desc.append({'kind': kind, 'negative_slope': float(rng.choice([0.01, 0.2]))})
+            continue
         hidden = [int(rng.integers(4, 65)) for _ in range(int(rng.integers(1, 3)))]
         if kind == 'affine_latent' and not latent:
             kind = 'affine'
@@ -94,8 +102,11 @@ def main():
                 p.add_(torch.randn_like(p) * 0.03)
         state = {k: v.clone() for k, v in flow.state_dict().items()}
         flow = flow.to(DEV)
-        x = torch.randn(n, dim) * 1.4
-        lat = torch.randn(n, latent) if latent else None
+        lead = (n,)
+        if mix and n % 3 == 0:                 # a second batch axis (the product flattens leading axes itself)
+            lead = (n // 3, 3)
+        x = torch.randn(*lead, dim) * 1.4
+        lat = torch.randn(*lead, latent) if latent else None
         if infer:         # no-graph paths (fused programs / tiers): log_prob, forward + log-det, inverse round trip vs fp64
             spec = fd.flow_spec(desc, {k: v.double() for k, v in state.items()})
             l64 = None if lat is None else lat.double()
