@@ -491,14 +491,14 @@ def test_cubic_spline_flow_log_prob_backward_matches_autograd_of_oracle(n, dim, 
     loss.backward()
     assert abs(loss.item() - want_loss) <= 1e-5 * abs(want_loss) + 1e-5
     sx = want_gx.abs().max().item()
-    # fp32 against fp64: the cubic's coefficients carry 1 / w^2 of bins as narrow as 1e-2, so single elements sit at
-    # ~1e-3 of the gradient scale (the quadratic spline and affine tests hold 2e-4 .. 3e-4)
-    assert (xg.grad.cpu() - want_gx.float()).abs().max().item() <= 1e-3 * sx + 1e-7
+    # (round-2 note: this bound was 1e-3 "because the cubic's coefficients carry 1 / w^2" -- it was the quadratic-fallback
+    #  branch's gradient, test_cubic_coupling_gradients_in_the_quadratic_fallback_branch; now the spline tests' 3e-4)
+    assert (xg.grad.cpu() - want_gx.float()).abs().max().item() <= 3e-4 * sx + 1e-7
     for name, p in flow.named_parameters():
         ref = want_g[name].float()
         scale = ref.abs().max().item() + 1e-12
         err = (p.grad.cpu() - ref).abs().max().item()
-        assert err <= 1e-3 * scale + 1e-7, (name, err, scale)
+        assert err <= 3e-4 * scale + 1e-7, (name, err, scale)
 
 
 def test_layerwise_backward_reference_stack_and_pointwise_flows():

@@ -775,21 +775,21 @@ def test_full_size_properties_cubic_and_pointwise():
     y, ldj_f = flow.forward_and_log_det_jacobian(x)
     xb, ldj_i = flow.inverse_and_log_det_jacobian(y)
     assert torch.isfinite(y).all() and torch.isfinite(ldj_f).all()
-    err = torch.nan_to_num((xb - x).abs(), nan=0.0)
-    # four fp32 cubic solves in a row: flat spots of the spline amplify rounding (in the reference as much as here)
-    assert torch.quantile(err.flatten()[:: 97], 0.999).item() < 1e-3 and err.max().item() < 0.1
-    rel = torch.nan_to_num(((ldj_f + ldj_i).abs() / (1.0 + ldj_f.abs())).flatten(), nan=0.0)
-    assert torch.quantile(rel[:: 7], 0.99).item() < 1e-3
+    assert torch.isfinite(xb).all() and torch.isfinite(ldj_i).all()
+    err = (xb - x).abs()
+    # four cubic solves in a row.  The reference's fp32 closed forms lose up to 5e-3 of a bin where the cubic degenerates (and
+    # f'(t) then rounds to <= 0: a handful of NaN / -1e8 rows per million in fp32); the kernel ends the solve in Newton steps on
+    # the bin's cubic, so none of that is left (measured: max 1.7e-5, 99.9 % quantile 4e-6, log-det antisymmetry max 5e-5)
+    assert torch.quantile(err.flatten()[:: 97], 0.999).item() < 2e-5 and err.max().item() < 2e-4
+    rel = ((ldj_f + ldj_i).abs() / (1.0 + ldj_f.abs())).flatten()
+    assert rel.max().item() < 5e-4
     lp = flow.log_prob(x)
-    # a handful of elements per million sit where the fp32 cubic solve breaks down (f'(t) rounds to <= 0: NaN here, a
-    # finite but meaningless -1e8 in the reference's fp32 path; fp64 is fine): tolerated, counted, and excluded
-    bad = ~torch.isfinite(lp)
-    assert bad.float().mean().item() < 1e-4
+    assert torch.isfinite(lp).all()                     # round 1 tolerated 1e-4 of the rows being NaN here
     lp2 = torch.cat([flow.log_prob(x[:100_001]), flow.log_prob(x[100_001:])])
-    assert torch.equal(torch.nan_to_num(lp, nan=0.0), torch.nan_to_num(lp2, nan=0.0))
+    assert torch.equal(lp, lp2)
     spec = fd.flow_spec(desc, {k: v.cpu() for k, v in flow.state_dict().items()})
     sl = slice(123_000, 123_128)
-    close(lp[sl], orc.flow_log_prob(spec, x[sl].cpu()), rtol=1e-5, atol=5e-4)
+    close(lp[sl], orc.flow_log_prob(spec, x[sl].cpu()), rtol=1e-5, atol=1e-4)
     # point-wise kernels
     n = 1 << 20
     x = torch.randn(n, 64, device=DEV) * 2

@@ -146,8 +146,7 @@ def main():
         loss.backward()
         torch.cuda.synchronize()
         st.check_errors()
-        cubic = any(d.get('spline_type') == 'cubic' for d in desc)
-        tol = 3e-3 if cubic else 1e-3
+        tol = 1e-3
         errs = {'loss': abs(loss.item() - want.item()) / (abs(want.item()) + 1e-9)}
         ref = xin.grad.float()
         errs['x'] = ((xg.grad.cpu() - ref).abs().max() / (ref.abs().max() + 1e-12)).item()
