@@ -24,7 +24,7 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     d->n_steps = p->n_steps; d->dim = p->dim; d->latent_dim = p->latent_dim; d->x_tiles = p->x_tiles;
     d->identity_cols = p->identity_cols; d->pad = 0;
     int mx = 256;
-    bool lin = false, rqs = false, aff = false, bwd = false, deep = false;
+    bool lin = false, rqs = false, aff = false, bwd = false, deep = false, cub = false, quadr = false;
     *mlp_mode = 0;
     for (int i = 0; i < p->n_steps; ++i) {
         const sx_step &s = p->steps[i];
@@ -88,6 +88,8 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
             case SX_STEP_RQS_PHASE:
                 SX_REQUIRE(s.t0 < p->x_tiles && s.c0 >= 0 && s.c0 < 4 && s.ct >= 0 && s.ct < 3 && s.tt >= 1 && s.tt <= 16,
                            "sx_flow_run: step %d: bad RQS phase (tile %d group %d phase %d bins %d)", i, s.t0, s.c0, s.ct, s.tt);
+                SX_REQUIRE(s.act == 0 || s.act == 1, "sx_flow_run: step %d: spline phase kind %d (0 rational-quadratic, 1 cubic)", i, s.act);
+                if (s.act == 1) cub = true; else quadr = true;
                 need = sx_packed_linear_floats(4, p->h_tiles) + 4; rqs = true; break;
             default: sx_set_error("sx_flow_run: step %d has unsupported kind %d", i, s.kind); return SX_E_UNSUPPORTED;
         }
@@ -105,11 +107,12 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     if (lin) *mlp_mode = 2;
     SX_REQUIRE(!(rqs && (lin || *mlp_mode == 1)), "sx_flow_run: spline steps cannot be mixed with linear / MLP-output steps");
     SX_REQUIRE(!(rqs && aff), "sx_flow_run: spline and affine couplings cannot share one fused program");
-    if (rqs) *mlp_mode = 3;
+    SX_REQUIRE(!(cub && quadr), "sx_flow_run: rational-quadratic and cubic spline couplings cannot share one fused program");
+    if (rqs) *mlp_mode = cub ? 12 : 3;
     SX_REQUIRE(!(bwd && (rqs || lin || aff || *mlp_mode == 1)), "sx_flow_run: backward steps cannot be mixed with other step kinds");
     if (bwd) *mlp_mode = 4;
     SX_REQUIRE(!(deep && (lin || bwd || *mlp_mode == 1)), "sx_flow_run: deep-conditioner steps only mix with couplings");
-    if (deep) *mlp_mode = rqs ? 10 : 9;     // 10: the spline kernel with the deep-conditioner steps
+    if (deep) *mlp_mode = rqs ? (cub ? 13 : 10) : 9;     // 10 / 13: the spline kernels with the deep-conditioner steps
     // MODE 5 / 6: nothing but tanh-folded affine couplings on half the tiles conditioned on the other half, all in
     // one direction (5 reverse, 6 forward) -- the plain RealNVP log_prob / sample program.  Its kernel carries two
     // straight-line arms only, which keeps the state in place (no phi copies) at 130 VGPRs.

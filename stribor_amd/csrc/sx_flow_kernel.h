@@ -29,7 +29,9 @@
 #pragma once
 #include "sx_common.h"
 #include "sx_flow_types.h"
+#include "sx_cubic_core.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #define SX_HALF_LOG_2PI 0.91893853320467274178f
 
@@ -843,6 +845,185 @@ __device__ __forceinline__ void rqs_phase(tile<1> (&xs)[TX], const btile<1> (&bh
 }
 
 // ------------------------------------------------------------------------------------------------
+// Monotone cubic spline coupling, fused (util/cubic_spline.py:21-251; the reference's default spline_type) -- kernel MODE 12
+// (13: with deep conditioners).  Same step layout as the rational-quadratic spline: per group of 8 columns three parameter
+// blocks of 4 MFMA output tiles -- the SEARCHED block (widths forward, heights inverse: bin + the sizes of bins b-1, b, b+1 and
+// the knot at b), the OTHER block (the same four numbers at the found bin), the two boundary-derivative parameters -- so the
+// [N, D(2K+2)] parameter tensor the unfused path writes and reads (4.6 GB per layer at 2^20 x 64, K = 16) never exists.
+// The arithmetic is sx_cubic_core.h's (shared with cubic_kernel).  The inverse returns what the reference's
+// Transform.inverse_and_log_det_jacobian does (flow.py:42-47): minus the forward log-derivative at the inverted point -- in
+// the solved bin (the spline is C1: at a knot both bins give the same derivative to rounding), 0 where that point leaves the
+// domain.
+// ------------------------------------------------------------------------------------------------
+struct cubic_elems {        // the 4 elements of the current group a lane owns
+    float x[4];
+    float s_k[4], s_m[4], s_b[4], s_p[4];   // searched sequence: knot at the bin, sizes of bins b-1, b, b+1
+    float o_k[4], o_m[4], o_b[4], o_p[4];   // other sequence, same
+    int b[4];
+    bool in[4];
+};
+template <int Q, int KC>
+__device__ __forceinline__ float cub_softmax(tile<1> (&acc)[4], int K) {
+    float mx = RQS_P(acc, Q, 0);
+#pragma unroll
+    for (int k = 1; k < 16; ++k)
+        if (KC ? (k < KC) : true) mx = fmaxf(mx, rqs_has<KC>(k, K) ? RQS_P(acc, Q, k) : mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (KC ? (k < KC) : true) {
+            const float e = rqs_has<KC>(k, K) ? cubic_fexp(RQS_P(acc, Q, k) - mx) : 0.f;
+            RQS_P(acc, Q, k) = e;
+            sum += e;
+        }
+    const float Kf = KC ? (float)KC : (float)K;
+    return (1.f - CUBIC_MIN_BIN * Kf) * cubic_frcp(sum);         // :103-104, :110-111
+}
+__device__ __forceinline__ float cub_norm(float xv, bool in, float lo, float hi) { return ((in ? xv : lo) - lo) * cubic_frcp(hi - lo); }   // :98-101
+// phase 0: sizes + running knots of the searched block and the bin search (search_sorted.py:4-5) in one sweep
+template <int Q, int KC>
+__device__ __forceinline__ void cub_search(tile<1> (&acc)[4], cubic_elems &e, int K, float lo, float hi) {
+    const float xv = e.x[Q];
+    const bool in = (xv >= lo) && (xv <= hi);                       // :40 closed interval
+    e.in[Q] = in;
+    const float xn = cub_norm(xv, in, lo, hi);
+    const float inv = cub_softmax<Q, KC>(acc, K);
+    int b = 0;
+    float k_b = 0.f, s_b = 0.f, s_m = 1.f, s_p = 1.f, cum = 0.f, last = 1.f;
+    bool need = false;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (KC ? (k < KC) : true) {
+            const bool used = KC ? true : (k < K);
+            const float sz = CUBIC_MIN_BIN + RQS_P(acc, Q, k) * inv;
+            const bool ge = used && (xn >= cum);                    // lower knot of bin k (knot 0 = 0): knots only grow
+            const bool nx = used && !ge && need;
+            b = ge ? k : b; k_b = ge ? cum : k_b; s_b = ge ? sz : s_b; s_m = ge ? last : s_m;
+            s_p = nx ? sz : s_p;
+            need = ge;
+            last = sz;
+            cum += sz;
+        }
+    }
+    e.b[Q] = b; e.s_k[Q] = k_b; e.s_m[Q] = s_m; e.s_b[Q] = s_b; e.s_p[Q] = s_p;
+}
+// phase 1: the other block at the found bin
+template <int Q, int KC>
+__device__ __forceinline__ void cub_select(tile<1> (&acc)[4], cubic_elems &e, int K) {
+    const float inv = cub_softmax<Q, KC>(acc, K);
+    const int b = e.b[Q];
+    float k_b = 0.f, o_b = 0.f, o_m = 1.f, o_p = 1.f, cum = 0.f;
+    bool is_prev = false;                 // b == k - 1
+    bool is_cur = (b == 0);               // b == k
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (KC ? (k < KC) : true) {
+            const bool used = KC ? true : (k < K);
+            const float sz = CUBIC_MIN_BIN + RQS_P(acc, Q, k) * inv;
+            const bool is_next = (b == k + 1);
+            k_b = (used && is_cur) ? cum : k_b;
+            o_b = (used && is_cur) ? sz : o_b;
+            o_m = (used && is_next) ? sz : o_m;     // bin k is b - 1
+            o_p = (used && is_prev) ? sz : o_p;     // bin k is b + 1
+            is_prev = is_cur;
+            is_cur = is_next;
+            cum += sz;
+        }
+    }
+    e.o_k[Q] = k_b; e.o_m[Q] = o_m; e.o_b[Q] = o_b; e.o_p[Q] = o_p;
+}
+// phase 2: knot derivatives of the bin (:117-132), its cubic (:134-137), the polynomial or its inverse
+template <int Q, bool REV>
+__device__ __forceinline__ void cub_eval(tile<1> (&acc)[4], const cubic_elems &e, int K, float lo, float hi, float &out, float &ljd) {
+    const int b = e.b[Q];
+    const float w_m = REV ? e.o_m[Q] : e.s_m[Q], w_b = REV ? e.o_b[Q] : e.s_b[Q], w_p = REV ? e.o_p[Q] : e.s_p[Q];
+    const float h_m = REV ? e.s_m[Q] : e.o_m[Q], h_b = REV ? e.s_b[Q] : e.o_b[Q], h_p = REV ? e.s_p[Q] : e.o_p[Q];
+    const float cw_b = REV ? e.o_k[Q] : e.s_k[Q], ch_b = REV ? e.s_k[Q] : e.o_k[Q];
+    const cubic_coef cf = cubic_bin_coef(b, K, w_b, h_b, w_m, h_m, w_p, h_p, RQS_P(acc, Q, 0), RQS_P(acc, Q, 1));
+    const float a = cf.a, bb = cf.bb, c = cf.c, d = ch_b;
+    const float xn = cub_norm(e.x[Q], e.in[Q], lo, hi), span = hi - lo;
+    if constexpr (REV) {
+        const float rcw = (b == K - 1) ? 1.f : cw_b + w_b;                                 // :107 (last knot pinned)
+        const float so = cubic_invert(a, bb, c, d, xn, cw_b, rcw);
+        out = (so + cw_b) * span + lo;                                                     // :235
+        const bool in2 = (out >= lo) && (out <= hi);
+        const float t2 = cub_norm(out, in2, lo, hi) - cw_b;
+        ljd = in2 ? -cubic_flog(3.f * a * (t2 * t2) + 2.f * bb * t2 + c) : 0.f;            // flow.py:42-47
+    } else {
+        const float t = xn - cw_b;                                                         // :229
+        out = (a * (t * t * t) + bb * (t * t) + c * t + d) * span + lo;                    // :230-233, :238
+        ljd = cubic_flog(3.f * a * (t * t) + 2.f * bb * t + c);                            // :235-237
+    }
+    out = e.in[Q] ? out : e.x[Q];                                                          // :46-48 linear tails
+    ljd = e.in[Q] ? ljd : 0.f;
+}
+
+template <int TX, int HT, int KC>
+__device__ __forceinline__ void cubic_phase_k(tile<1> (&acc)[4], tile<1> (&xs)[TX], cubic_elems &e, const dstep &st,
+                                              float lo, float hi, float &ldj, int h) {
+    const int g = st.c0, K = st.tt;
+    if (st.ct == 0) {
+#pragma unroll
+        for (int t = 0; t < TX; ++t)
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg)
+                if (t == st.t0 && gg == g) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) e.x[q] = xs[t].v[0][4 * gg + q];
+                }
+        cub_search<0, KC>(acc, e, K, lo, hi);
+        cub_search<1, KC>(acc, e, K, lo, hi);
+        cub_search<2, KC>(acc, e, K, lo, hi);
+        cub_search<3, KC>(acc, e, K, lo, hi);
+    } else if (st.ct == 1) {
+        cub_select<0, KC>(acc, e, K);
+        cub_select<1, KC>(acc, e, K);
+        cub_select<2, KC>(acc, e, K);
+        cub_select<3, KC>(acc, e, K);
+    } else {
+        float out[4], lj[4];
+        if (st.reverse) {
+            cub_eval<0, true>(acc, e, K, lo, hi, out[0], lj[0]);
+            cub_eval<1, true>(acc, e, K, lo, hi, out[1], lj[1]);
+            cub_eval<2, true>(acc, e, K, lo, hi, out[2], lj[2]);
+            cub_eval<3, true>(acc, e, K, lo, hi, out[3], lj[3]);
+        } else {
+            cub_eval<0, false>(acc, e, K, lo, hi, out[0], lj[0]);
+            cub_eval<1, false>(acc, e, K, lo, hi, out[1], lj[1]);
+            cub_eval<2, false>(acc, e, K, lo, hi, out[2], lj[2]);
+            cub_eval<3, false>(acc, e, K, lo, hi, out[3], lj[3]);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool live = (st.mask >> (q + 8 * g + 4 * h)) & 1u;     // slot kmap(4g+q, h) of the tile
+            out[q] = live ? out[q] : e.x[q];
+            s += live ? lj[q] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < TX; ++t)
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg)
+                if (t == st.t0 && gg == g) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xs[t].v[0][4 * gg + q] = out[q];
+                }
+        ldj += st.ldj_scale * s;
+    }
+}
+template <int TX, int HT>
+__device__ __forceinline__ void cubic_phase(tile<1> (&xs)[TX], const btile<1> (&bh)[HT], cubic_elems &e, const wptr w,
+                                            const dstep &st, float &ldj, int lane) {
+    const int h = lane >> 5;
+    tile<1> acc[4];
+    rqs_gemm<HT>(w, bh, acc);
+    const float lo = *reinterpret_cast<const float *>(w.cb - h * 64 + (4 * HT * 1024 + 128) * 4);
+    const float hi = *reinterpret_cast<const float *>(w.cb - h * 64 + (4 * HT * 1024 + 129) * 4);
+    if (st.tt == 16) cubic_phase_k<TX, HT, 16>(acc, xs, e, st, lo, hi, ldj, h);
+    else cubic_phase_k<TX, HT, 0>(acc, xs, e, st, lo, hi, ldj, h);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Training: backward of one affine coupling of a log_prob pass.
 // The forward (log_prob) direction computed x_out = (x_in - sh) * exp(-ls) on the transformed tile with
 // (ls, sh) = net(x_cond) and added -sum(ls) to the log-prob.  Flows are invertible, so nothing was saved: given
@@ -1339,9 +1520,11 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
         tile<NS> hid[MODE == 1 ? HT : 1];
         constexpr bool LIN = MODE == 2 || MODE == 7 || MODE == 8;    // programs with dense linear layers
         tile<NS> hidp[MODE == 9 ? HT : 1];                           // MODE 9: hidden state kept between deep-conditioner steps
-        constexpr bool RQ = MODE == 3 || MODE == 10;      // spline couplings (10: + deep conditioners)
+        constexpr bool CUB = MODE == 12 || MODE == 13;    // cubic-spline couplings (13: + deep conditioners)
+        constexpr bool RQ = MODE == 3 || MODE == 10 || CUB;      // spline couplings (10: + deep conditioners)
+        constexpr bool RQDEEP = MODE == 10 || MODE == 13;
         btile<1> rq_bh[RQ ? HT : 1];             // hidden B operands + group state
-        rqs_elems rq_e;
+        std::conditional_t<CUB, cubic_elems, rqs_elems> rq_e;
 
         for (int s = 0; s < n_steps; ++s) {
             // (1) this step's weights were issued one step ago (or in the prologue): wait for MY pieces, then
@@ -1430,7 +1613,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     if constexpr (MODE == 1) hidden_layer<NS, TX, HT, 0, TX, false>(xs, hid, w, 0, st.act, rg);
                     break;
                 case SX_STEP_CPL_HIDDEN:
-                    if constexpr (MODE == 10 && NS == 1) {
+                    if constexpr (RQDEEP && NS == 1) {
                         // spline couplings with deep conditioners: the activations wait for the next layer in split (B
                         // operand) form in rq_bh -- the array the phases use anyway: no extra registers
                         tile<1> hd[HT];
@@ -1453,7 +1636,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     }
                     break;
                 case SX_STEP_CPL_HIDDEN2:
-                    if constexpr (MODE == 10 && NS == 1) {
+                    if constexpr (RQDEEP && NS == 1) {
                         tile<1> hd[HT];
                         hidden_body<1, HT, HT, false>(rq_bh, hd, w, 0, st.act);
 #pragma unroll
@@ -1570,7 +1753,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                 case SX_STEP_RQS_HIDDEN:
                     if constexpr (RQ && NS == 1) {
                         tile<1> hd[HT];
-                        if (MODE == 10 && st.pad == 1) {   // deep conditioner: the last hidden layer, from the previous one's activations
+                        if (RQDEEP && st.pad == 1) {   // deep conditioner: the last hidden layer, from the previous one's activations
                             hidden_body<1, HT, HT, true>(rq_bh, hd, w, 0, st.act);
                         } else
                         if constexpr (TX >= 2) {
@@ -1587,7 +1770,8 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     }
                     break;
                 case SX_STEP_RQS_PHASE:
-                    if constexpr (RQ && NS == 1) rqs_phase<TX, HT>(xs, rq_bh, rq_e, w, st, ldj[0], lane);
+                    if constexpr (CUB && NS == 1) cubic_phase<TX, HT>(xs, rq_bh, rq_e, w, st, ldj[0], lane);
+                    else if constexpr (RQ && NS == 1) rqs_phase<TX, HT>(xs, rq_bh, rq_e, w, st, ldj[0], lane);
                     break;
                 case SX_STEP_ROW_SCALE_EXP:
                     // x *= exp(+-diag * t_row)  (affine.py:263), t_row optionally log1p|t| (affine.py:239-240)
@@ -1835,6 +2019,8 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
     else if (a.mlp_mode == 6) { if constexpr (TX >= 2) SX_FL(6); }
     else if (a.mlp_mode == 9) SX_FL(9);
     else if (a.mlp_mode == 10) SX_FL(10);
+    else if (a.mlp_mode == 12) SX_FL(12);
+    else if (a.mlp_mode == 13) SX_FL(13);
     else if (a.mlp_mode == 7) { if constexpr (TX >= 2) SX_FL(7); }
     else if (a.mlp_mode == 8) { if constexpr (TX >= 2) SX_FL(8); }
     else if (a.mlp_mode == 11) {

@@ -434,17 +434,20 @@ class Coupling(Transform):
             return False
         sp = self.transform
         net = getattr(sp, 'latent_net', None)
-        if not isinstance(net, MLP) or net.activation_name != 'Tanh' or sp.n_bins > 16 or sp.spline_type != 'quadratic':
-            return False             # cubic-spline couplings run layer by layer (MLP program + sx_cubic_coupling)
+        if not isinstance(net, MLP) or net.activation_name != 'Tanh' or sp.n_bins > 16 or \
+                sp.spline_type not in ('quadratic', 'cubic') or os.environ.get('STRIBOR_CUBIC_UNFUSED') == '1' and sp.spline_type == 'cubic':
+            return False
         lin = net.linears()
         if len(lin) < 2:
             return False
         (W1, b1), (W2, b2) = lin[0], lin[-1]
-        if W1.shape[1] != builder.dim + builder.latent_dim or W2.shape[0] != builder.dim * (3 * sp.n_bins - 1):
+        P = sp.params_per_element                                                        # 3K-1 quadratic, 2K+2 cubic
+        if W1.shape[1] != builder.dim + builder.latent_dim or W2.shape[0] != builder.dim * P:
             raise ValueError(f'latent_net maps {W1.shape[1]} -> {W2.shape[0]}, expected '
-                             f'{builder.dim + builder.latent_dim} -> {builder.dim * (3 * sp.n_bins - 1)}')
+                             f'{builder.dim + builder.latent_dim} -> {builder.dim * P}')
         builder.add_coupling_rqs(W1, b1, W2, b2, self.mask_vector(builder.dim), reverse, ldj_scale, W1.shape[0],
-                                 sp.n_bins, sp.lower, sp.upper, sp.lower, sp.upper, middle=lin[1:-1])
+                                 sp.n_bins, sp.lower, sp.upper, sp.lower, sp.upper, middle=lin[1:-1],
+                                 cubic=sp.spline_type == 'cubic')
         return True
 
     def _plan_first_mask(self, dim):

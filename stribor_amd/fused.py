@@ -567,16 +567,17 @@ class ProgramBuilder:
         return 0, T, 0, T
 
     def add_coupling_rqs(self, W1, b1, W2, b2, mask: np.ndarray, reverse: bool, ldj_scale: float, hidden: int,
-                         n_bins: int, left: float, right: float, bottom: float, top: float, middle=()) -> None:
+                         n_bins: int, left: float, right: float, bottom: float, top: float, middle=(), cubic: bool = False) -> None:
         """Rational-quadratic spline coupling, fused: hidden step(s) + 12 phase steps per transformed tile.
         Tanh conditioners; with two or more hidden layers (`middle` = [(W, b), ...] between W1 and the output layer W2)
         the earlier layers run as CPL_HIDDEN / CPL_HIDDEN2 steps and the last hidden layer (folded tanh) as the
-        RQS_HIDDEN step; n_bins <= 16."""
+        RQS_HIDDEN step; n_bins <= 16.  cubic=True: the monotone cubic spline (2K+2 parameters per element: widths, heights,
+        two boundary derivatives; phase steps with act = 1, kernel MODE 12 / 13)."""
         self._freeze_input()
         D, T, HT, K = self.dim, self.tiles, self.h_tiles, n_bins
         if K > 16:
             raise NotImplementedError('fused spline coupling supports n_bins <= 16')
-        P = 3 * K - 1
+        P = 2 * K + 2 if cubic else 3 * K - 1
         mask = np.asarray(mask, dtype=np.float64).reshape(-1)
         if mask.size == 1:
             mask = np.full(D, mask[0])
@@ -636,7 +637,7 @@ class ProgramBuilder:
         col2[:hidden] = np.arange(hidden)
         # forward searches the widths on [left, right], inverse the heights on [bottom, top]
         blocks = [(K, K, bottom, top), (0, K, left, right)] if reverse else [(0, K, left, right), (K, K, bottom, top)]
-        blocks.append((2 * K, K - 1, 0.0, 0.0))
+        blocks.append((2 * K, 2, left, right) if cubic else (2 * K, K - 1, 0.0, 0.0))      # cubic: the evaluation needs the domain
         for t in range(t0, t0 + tt):
             if t >= self.x_tiles:
                 continue
@@ -666,7 +667,7 @@ class ProgramBuilder:
                     self.jobs.append(_PackJob(W2, b2, rows, col2, 4, HT, off, np.full(128, -2.0), np.full(128, 1.0), 1.0))
                     self.jobs.append(_ScalarsJob([lo, hi], off + nlin))
                     s_scale = (-ldj_scale if reverse else ldj_scale) if phase == 2 else 0.0
-                    step = dict(kind=_hip.STEP_RQS_PHASE, c0=g, ct=phase, t0=t, tt=K, reverse=int(reverse), act=0,
+                    step = dict(kind=_hip.STEP_RQS_PHASE, c0=g, ct=phase, t0=t, tt=K, reverse=int(reverse), act=int(cubic),
                                 blob_off=off, blob_floats=n, ldj_scale=s_scale, ldj_const=0.0)
                     step['pad_'] = live_mask - (1 << 32) if live_mask >= (1 << 31) else live_mask
                     self.steps.append(step)
@@ -844,6 +845,9 @@ class ProgramBuilder:
                             _hip.STEP_ROW_SCALE_EXP}:
             # the spline kernel variant spends its registers on the group state: mixed flows run layer by layer
             raise NotImplementedError('spline couplings cannot share a fused program with affine couplings / linear layers')
+        if len({s['act'] for s in self.steps if s['kind'] == _hip.STEP_RQS_PHASE}) > 1:
+            # one kernel variant per spline type (MODE 3 / 10 rational-quadratic, 12 / 13 cubic)
+            raise NotImplementedError('rational-quadratic and cubic spline couplings cannot share a fused program')
         deep = kinds & {_hip.STEP_CPL_HIDDEN, _hip.STEP_CPL_HIDDEN2, _hip.STEP_COUPLING_AFFINE_DEEP}
         if deep and kinds & {_hip.STEP_LINEAR_TILE, _hip.STEP_ROW_SCALE_EXP, _hip.STEP_MLP_HIDDEN, _hip.STEP_MLP_HIDDEN2,
                              _hip.STEP_MLP_OUT_TILE, _hip.STEP_COUPLING_AFFINE_BWD}:
