@@ -1006,3 +1006,55 @@ def test_deep_affine_coupling_with_latent_in_one_state_tile(second):
     close(y, wy.float(), rtol=1e-5, atol=1e-5)
     close(ldj, wl.float(), rtol=1e-5, atol=1e-4)
     close(xr, x, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('dim,K,hidden,latent,masks', [
+    (64, 16, [64], 0, ('ordered_right_half', 'ordered_left_half')),           # the cfg-3 shape with the reference's default spline
+    (37, 7, [40, 24], 3, ('parity_even', 'ordered_left_half', 'parity_odd')),  # run-time K, deep conditioner (MODE 13), latent
+    (5, 1, [16], 0, ('ordered_right_half', 'parity_odd')),                     # one bin: both knot derivatives are the boundary ones
+])
+def test_fused_cubic_spline_flow_matches_oracle_and_the_unfused_path(dim, K, hidden, latent, masks, monkeypatch):
+    """Cubic-spline coupling flows run as ONE fused program (kernel MODE 12 / 13, round 2): values against the fp64 oracle in
+    all three directions, and against the layer-by-layer path (MLP program -> [N, D(2K+2)] parameters -> cubic_kernel), which
+    shares the per-element arithmetic (sx_cubic_core.h) and must agree to rounding."""
+    torch.manual_seed(31)
+    desc = []
+    for i, m in enumerate(masks):
+        desc.append({'kind': 'coupling_rqs', 'dim': dim, 'hidden': hidden, 'n_bins': K, 'lower': -3.0, 'upper': 3.0, 'mask': m,
+                     'latent_dim': latent, 'spline_type': 'cubic'})
+        if i == 0:
+            desc.append({'kind': 'flip'})
+    flow = fd.build_flow(st, desc, dim)
+    with torch.no_grad():
+        for p in flow.parameters():
+            p.add_(torch.randn_like(p) * 0.05)
+    state = {k: v.clone() for k, v in flow.state_dict().items()}
+    flow = flow.to(DEV)
+    n = 1337
+    x = torch.randn(n, dim) * 1.5                   # ~5 % of the elements in the linear tails
+    lat = torch.randn(n, latent) if latent else None
+    kw = {} if lat is None else {'latent': lat.to(DEV)}
+    assert flow._fused_program(True, dim, latent, torch.device(DEV, 0)) is not None          # really one program
+    spec = fd.flow_spec(desc, {k: v.double() for k, v in state.items()})
+    l64 = None if lat is None else lat.double()
+    want_lp = orc.flow_log_prob(spec, x.double(), l64)
+    wy, wl = orc.flow_forward_and_ldj(spec, x.double(), l64)
+    with torch.no_grad():
+        lp = flow.log_prob(x.to(DEV), **kw)
+        y, ldj = flow.forward_and_log_det_jacobian(x.to(DEV), **kw)
+        xr = flow.inverse(y, **kw)
+    close(lp, want_lp.float(), rtol=1e-5, atol=1e-4)
+    close(y, wy.float(), rtol=1e-5, atol=2e-5)
+    close(ldj, wl.float(), rtol=1e-5, atol=1e-4)
+    close(xr, x, rtol=1e-5, atol=5e-5)
+    monkeypatch.setenv('STRIBOR_CUBIC_UNFUSED', '1')
+    flow2 = fd.build_flow(st, desc, dim)
+    flow2.load_state_dict(state)
+    flow2 = flow2.to(DEV)
+    assert flow2._fused_program(True, dim, latent, torch.device(DEV, 0)) is None
+    with torch.no_grad():
+        lp2 = flow2.log_prob(x.to(DEV), **kw)
+        y2, ldj2 = flow2.forward_and_log_det_jacobian(x.to(DEV), **kw)
+    close(lp, lp2, rtol=1e-5, atol=1e-4)
+    close(y, y2, rtol=1e-5, atol=2e-5)
+    close(ldj, ldj2, rtol=1e-5, atol=1e-4)
