@@ -314,7 +314,11 @@ int sx_pack_linear(const float *W, const float *b, int32_t out_dim, int32_t in_d
 #define SX_STEP_RQS_PHASE           11  /* one (8-column group, parameter block) slab of a rational-quadratic spline coupling:
                                            blob = pack_linear(W2 rows, 4 m-tiles) ++ {lo, hi}; t0 = tile, c0 = group 0..3,
                                            ct = phase (0 search block, 1 select block, 2 derivatives + evaluate), tt = n_bins,
-                                           pad_ = live mask of the tile's 32 slots                                               */
+                                           pad_ = live mask of the tile's 32 slots.
+                                           act = 1: the monotone CUBIC spline (util/cubic_spline.py:21-251, 2K+2 parameters per
+                                           element): phase 0 = searched block (widths forward / heights inverse), 1 = the other
+                                           block, 2 = the two boundary-derivative parameters ++ {lower, upper} + evaluate; a
+                                           program holds phases of one spline type only                                          */
 #define SX_STEP_COUPLING_AFFINE_BWD 12  /* backward of one affine coupling of a log_prob pass (training): state tiles
                                            [0,2) = x, [2,4) = dL/dx; blob = forward blob ++ pack(W2^T) ++ pack(W1^T); c0 = cond
                                            tile, t0 = transformed tile, tt = layer slot in `side` (see sx_flow_run)             */
