@@ -1,6 +1,6 @@
 """Randomised differential check of the training paths: random spline / affine coupling flows (dims, widths, masks, bin counts,
 spline types, latent inputs, batch sizes) -- gradients of -log_prob.mean() from the HIP paths against fp64 autograd of the oracle.
-    python tools/fuzz_train.py [n_cases] [seed] [--forward] [--infer] [--mix] [--only=i ...]
+    python tools/fuzz_train.py [n_cases] [seed] [--forward] [--infer] [--mix] [--time] [--only=i ...]
 (--forward: forward_and_log_det_jacobian instead of log_prob; --infer: the no-graph paths; --mix: every transform kind)"""
 import os
 import sys
@@ -81,8 +81,24 @@ def case_mix(rng):
     return desc, dim, latent, int(rng.integers(1, 700))
 
 
+def case_time(rng):
+    """Time-conditioned stacks: ContinuousAffineCoupling with every time net (coupling.py:98-213, net/time_net.py:6-91) inside
+    NeuralFlow (flow.py:155-184), evaluated at per-row times t (and t0)."""
+    dim = int(rng.integers(1, 41))
+    latent = int(rng.choice([0, 0, 3]))
+    desc = []
+    for _ in range(int(rng.integers(1, 4))):
+        desc.append({'kind': 'continuous_affine_coupling', 'dim': dim,
+                     'hidden': [int(rng.integers(4, 65)) for _ in range(int(rng.integers(1, 3)))],
+                     'mask': str(rng.choice(MASKS + ['none'])) if dim > 1 else 'none', 'latent_dim': latent,
+                     'time_kind': str(rng.choice(['identity', 'linear', 'tanh', 'log', 'fourier', 'fourier_bounded'])),
+                     'concatenate_time': bool(rng.integers(0, 2))})
+    return desc, dim, latent, int(rng.integers(1, 500))
+
+
 def main():
     fwd = '--forward' in sys.argv
+    timed = '--time' in sys.argv
     infer = '--infer' in sys.argv
     mix = '--mix' in sys.argv
     args = [a for a in sys.argv[1:] if not a.startswith('--')]
@@ -92,7 +108,7 @@ def main():
     worst = 0.0
     only = [int(a.split('=')[1]) for a in sys.argv if a.startswith('--only=')]
     for i in range(n_cases):
-        desc, dim, latent, n = (case_mix if mix else case)(rng)
+        desc, dim, latent, n = (case_time if timed else case_mix if mix else case)(rng)
         if only and i not in only:
             continue
         torch.manual_seed(seed * 1000 + i)
@@ -107,16 +123,47 @@ def main():
             lead = (n // 3, 3)
         x = torch.randn(*lead, dim) * 1.4
         lat = torch.randn(*lead, latent) if latent else None
+        if timed:
+            nf = st.NeuralFlow([fd.build_transform(st, d) for d in desc])
+            with torch.no_grad():
+                for p in nf.parameters():
+                    p.add_(torch.randn_like(p) * 0.05)
+            state = {k: v.clone() for k, v in nf.state_dict().items()}
+            nf = nf.to(DEV)
+            spec = fd.flow_spec(desc, {k: v.double() for k, v in state.items()})
+            tt, t0 = torch.rand(*lead, 1) * 2.0, torch.rand(*lead, 1)
+            kw = {} if lat is None else {'latent': lat.to(DEV)}
+            l64 = None if lat is None else lat.double()
+            with torch.no_grad():
+                y1 = nf(x.to(DEV), t=tt.to(DEV), **kw).cpu().double()
+                y2 = nf(x.to(DEV), t=tt.to(DEV), t0=t0.to(DEV), **kw).cpu().double()
+                f0 = nf.transforms[0]
+                yf, lf = f0.forward_and_log_det_jacobian(x.to(DEV), tt.to(DEV), **kw)
+                xb, lb = f0.inverse_and_log_det_jacobian(yf, tt.to(DEV), **kw)
+            st.check_errors()
+            w1 = orc.neural_flow_forward(spec, x.double(), tt.double(), None, l64)
+            w2 = orc.neural_flow_forward(spec, x.double(), tt.double(), t0.double(), l64)
+            wyf, wlf = orc.continuous_affine_coupling(spec[0], x.double(), tt.double(), l64, False)
+            rel = lambda a, b: ((a - b).abs() / (1.0 + b.abs())).max().item()
+            e = [rel(y1, w1), rel(y2, w2), rel(yf.cpu().double(), wyf), rel(lf.cpu().double(), wlf),
+                 (xb.cpu().double() - x.double()).abs().max().item(), rel(-lb.cpu().double(), wlf)]
+            worst = max(worst, max(e))
+            kinds = [d['time_kind'] + ('+cat' if d['concatenate_time'] else '') + ':' + d['mask'][:8] for d in desc]
+            print(f'case {i:3d} dim {dim:2d} lat {latent} n {n:3d} {kinds} y(t) {e[0]:.1e} y(t,t0) {e[1]:.1e} layer y {e[2]:.1e} ldj {e[3]:.1e} '
+                  f'round trip {e[4]:.1e} inverse ldj {e[5]:.1e}' + ('  FAIL' if max(e) > 2e-4 else ''), flush=True)
+            continue
         if infer:         # no-graph paths (fused programs / tiers): log_prob, forward + log-det, inverse round trip vs fp64
             spec = fd.flow_spec(desc, {k: v.double() for k, v in state.items()})
             l64 = None if lat is None else lat.double()
+            kw = {} if lat is None else {'latent': lat.to(DEV)}
+            okw = {}
             with torch.no_grad():
-                lp = flow.log_prob(x.to(DEV), latent=None if lat is None else lat.to(DEV)).cpu().double()
-                y, ldj = flow.forward_and_log_det_jacobian(x.to(DEV), latent=None if lat is None else lat.to(DEV))
-                xr = flow.inverse(y, latent=None if lat is None else lat.to(DEV)).cpu().double()
+                lp = flow.log_prob(x.to(DEV), **kw).cpu().double()
+                y, ldj = flow.forward_and_log_det_jacobian(x.to(DEV), **kw)
+                xr = flow.inverse(y, **kw).cpu().double()
             st.check_errors()
-            want_lp = orc.flow_log_prob(spec, x.double(), l64)
-            wy, wl = orc.flow_forward_and_ldj(spec, x.double(), l64)
+            want_lp = orc.flow_log_prob(spec, x.double(), l64, **okw)
+            wy, wl = orc.flow_forward_and_ldj(spec, x.double(), l64, **okw)
             e1 = ((lp - want_lp).abs() / (1.0 + want_lp.abs())).max().item()
             e2 = ((y.cpu().double() - wy).abs() / (1.0 + wy.abs())).max().item()
             e3 = ((ldj.cpu().double() - wl).abs() / (1.0 + wl.abs())).max().item()
