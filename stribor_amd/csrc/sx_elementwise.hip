@@ -611,10 +611,23 @@ __global__ __launch_bounds__(256) void sum_f64_kernel(const float *__restrict__ 
     if ((reinterpret_cast<uintptr_t>(v) & 15) == 0) {          // 16-byte loads over the aligned body, scalars for the tail
         const int64_t n4 = n >> 2;
         const f32x4 *v4 = reinterpret_cast<const f32x4 *>(v);
-        for (int64_t i = tid; i < n4; i += stride) {
-            const f32x4 t = v4[i];
-            acc += ((double)t.x + (double)t.y) + ((double)t.z + (double)t.w);
+        // four independent 16-byte loads in flight per lane (one load per trip left the memory pipe idle for most of its
+        // latency); the partial sums are added in a fixed order, so the result does not depend on timing
+        int64_t i = tid;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        for (; i + 3 * stride < n4; i += 4 * stride) {
+            const f32x4 t0 = __builtin_nontemporal_load(v4 + i), t1 = __builtin_nontemporal_load(v4 + i + stride);
+            const f32x4 t2 = __builtin_nontemporal_load(v4 + i + 2 * stride), t3 = __builtin_nontemporal_load(v4 + i + 3 * stride);
+            a0 += ((double)t0.x + (double)t0.y) + ((double)t0.z + (double)t0.w);
+            a1 += ((double)t1.x + (double)t1.y) + ((double)t1.z + (double)t1.w);
+            a2 += ((double)t2.x + (double)t2.y) + ((double)t2.z + (double)t2.w);
+            a3 += ((double)t3.x + (double)t3.y) + ((double)t3.z + (double)t3.w);
         }
+        for (; i < n4; i += stride) {
+            const f32x4 t = __builtin_nontemporal_load(v4 + i);
+            a0 += ((double)t.x + (double)t.y) + ((double)t.z + (double)t.w);
+        }
+        acc = (a0 + a1) + (a2 + a3);
         for (int64_t i = (n4 << 2) + tid; i < n; i += stride) acc += (double)v[i];
     } else {
         for (int64_t i = tid; i < n; i += stride) acc += (double)v[i];

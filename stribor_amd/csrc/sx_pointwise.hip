@@ -96,10 +96,10 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const void *__restrict__
         float xv[VEC], out[VEC], ld[VEC];
         if constexpr (VEC == 4) {
             if constexpr (BF16) {
-                const u16x4 u = reinterpret_cast<const u16x4 *>(x)[i];
+                const u16x4 u = __builtin_nontemporal_load(reinterpret_cast<const u16x4 *>(x) + i);     // every byte is touched once
                 xv[0] = bf16_to_f32(u.x); xv[1] = bf16_to_f32(u.y); xv[2] = bf16_to_f32(u.z); xv[3] = bf16_to_f32(u.w);
             } else {
-                const f32x4 v = reinterpret_cast<const f32x4 *>(x)[i];
+                const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(x) + i);
                 xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
             }
         } else xv[0] = pw_load<BF16>(x, i);
@@ -107,8 +107,8 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const void *__restrict__
         for (int c = 0; c < VEC; ++c) { pw_eval(kind, param, log_slope, xv[c], out[c], ld[c]); ld_sum += ld[c]; }
         if (y) {
             if constexpr (VEC == 4) {
-                if constexpr (BF16) reinterpret_cast<u16x4 *>(y)[i] = u16x4{f32_to_bf16(out[0]), f32_to_bf16(out[1]), f32_to_bf16(out[2]), f32_to_bf16(out[3])};
-                else reinterpret_cast<f32x4 *>(y)[i] = f32x4{out[0], out[1], out[2], out[3]};
+                if constexpr (BF16) __builtin_nontemporal_store(u16x4{f32_to_bf16(out[0]), f32_to_bf16(out[1]), f32_to_bf16(out[2]), f32_to_bf16(out[3])}, reinterpret_cast<u16x4 *>(y) + i);
+                else __builtin_nontemporal_store(f32x4{out[0], out[1], out[2], out[3]}, reinterpret_cast<f32x4 *>(y) + i);
             } else pw_store<BF16>(y, i, out[0]);
         }
         if (ldiag) {
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void cumsum_vec_pipe_kernel(const float *__res
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const int i = lane + 64 * kk;
-            if (kk < Q && i < total4) nxt[kk] = src[i];
+            if (kk < Q && i < total4) nxt[kk] = __builtin_nontemporal_load(src + i);     // every byte is touched once
         }
     };
     int64_t grp = (int64_t)blockIdx.x * 4 + wave;
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void cumsum_vec_pipe_kernel(const float *__res
         f32x4 *dst = reinterpret_cast<f32x4 *>(y + r0 * dim);
         for (int i = lane; i < total4; i += 64) {
             const int r = (int)(((float)i + 0.5f) * inv_q), c4 = i - r * Q;
-            dst[i] = *reinterpret_cast<const f32x4 *>(sp + r * RS + 4 * c4);
+            __builtin_nontemporal_store(*reinterpret_cast<const f32x4 *>(sp + r * RS + 4 * c4), dst + i);
         }
     }
 }
