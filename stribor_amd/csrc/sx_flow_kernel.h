@@ -665,8 +665,73 @@ __device__ __forceinline__ float rqs_softmax(tile<1> (&acc)[4], int K) {
 // The knots increase and `x >= knot_j` is true for a prefix of j, so
 //   knot at the bin  = last knot with x >= knot  (running select),
 //   next knot        = min over the knots with x < knot (min with `hi` where x >= knot).
+// K = 16: the sixteen-step sweep as a two-level search -- which group of four bins (three compares against the knots at
+// bins 4, 8, 12, formed from the groups' sums), then the bin inside the group (its four sizes picked by the group index): ~70
+// VALU instructions per element instead of ~130 for the same knot values up to the order of the additions.
+#ifndef SX_RQS_FLAT
+template <int Q>
+__device__ __forceinline__ void rqs_search16(tile<1> (&acc)[4], rqs_elems &e, float lo, float hi) {
+    const float xv = e.x[Q];
+    const bool in = (xv >= lo) && (xv <= hi);                       // :71 closed interval
+    e.in[Q] = in;
+    const float xin = in ? xv : lo;
+    const float inv = rqs_softmax<Q, 16>(acc, 16);
+    const float span = hi - lo;
+    // cumulative sizes at the group boundaries: cs_4, cs_8, cs_12 (:180-192)
+    const float S0 = 4.f * RQS_MIN + inv * ((RQS_P(acc, Q, 0) + RQS_P(acc, Q, 1)) + (RQS_P(acc, Q, 2) + RQS_P(acc, Q, 3)));
+    const float S1 = 4.f * RQS_MIN + inv * ((RQS_P(acc, Q, 4) + RQS_P(acc, Q, 5)) + (RQS_P(acc, Q, 6) + RQS_P(acc, Q, 7)));
+    const float S2 = 4.f * RQS_MIN + inv * ((RQS_P(acc, Q, 8) + RQS_P(acc, Q, 9)) + (RQS_P(acc, Q, 10) + RQS_P(acc, Q, 11)));
+    const float C1 = S0, C2 = S0 + S1, C3 = (S0 + S1) + S2;
+    const bool m1 = xin >= span * C1 + lo, m2 = xin >= span * C2 + lo, m3 = xin >= span * C3 + lo;       // a prefix: knots grow
+    const float base = m3 ? C3 : (m2 ? C2 : (m1 ? C1 : 0.f));
+    const int gb = m3 ? 12 : (m2 ? 8 : (m1 ? 4 : 0));
+    auto pick = [&](int i) {
+        return m3 ? RQS_P(acc, Q, 12 + i) : (m2 ? RQS_P(acc, Q, 8 + i) : (m1 ? RQS_P(acc, Q, 4 + i) : RQS_P(acc, Q, i)));
+    };
+    const float cs1 = base + (RQS_MIN + pick(0) * inv), cs2 = cs1 + (RQS_MIN + pick(1) * inv);
+    const float cs3 = cs2 + (RQS_MIN + pick(2) * inv), cs4 = cs3 + (RQS_MIN + pick(3) * inv);
+    const float k0 = m1 ? span * base + lo : lo;                    // ends pinned
+    const float k1 = span * cs1 + lo, k2 = span * cs2 + lo, k3 = span * cs3 + lo;
+    const float k4 = m3 ? hi : span * cs4 + lo;
+    const bool g1 = xin >= k1, g2 = xin >= k2, g3 = xin >= k3;
+    e.b[Q] = gb + (g3 ? 3 : (g2 ? 2 : (g1 ? 1 : 0)));
+    const float k_b = g3 ? k3 : (g2 ? k2 : (g1 ? k1 : k0));
+    const float k_n = g3 ? k4 : (g2 ? k3 : (g1 ? k2 : k1));
+    e.a_b[Q] = k_b;
+    e.a_w[Q] = k_n - k_b;
+}
+// the other block at the found bin: the two knots around bin b from the group sums + the group's own sizes
+template <int Q>
+__device__ __forceinline__ void rqs_select16(tile<1> (&acc)[4], rqs_elems &e, float lo, float hi) {
+    const float inv = rqs_softmax<Q, 16>(acc, 16);
+    const float span = hi - lo;
+    const int b = e.b[Q];
+    const float S0 = 4.f * RQS_MIN + inv * ((RQS_P(acc, Q, 0) + RQS_P(acc, Q, 1)) + (RQS_P(acc, Q, 2) + RQS_P(acc, Q, 3)));
+    const float S1 = 4.f * RQS_MIN + inv * ((RQS_P(acc, Q, 4) + RQS_P(acc, Q, 5)) + (RQS_P(acc, Q, 6) + RQS_P(acc, Q, 7)));
+    const float S2 = 4.f * RQS_MIN + inv * ((RQS_P(acc, Q, 8) + RQS_P(acc, Q, 9)) + (RQS_P(acc, Q, 10) + RQS_P(acc, Q, 11)));
+    const bool m1 = b >= 4, m2 = b >= 8, m3 = b >= 12;
+    const float base = m3 ? (S0 + S1) + S2 : (m2 ? S0 + S1 : (m1 ? S0 : 0.f));
+    auto pick = [&](int i) {
+        return m3 ? RQS_P(acc, Q, 12 + i) : (m2 ? RQS_P(acc, Q, 8 + i) : (m1 ? RQS_P(acc, Q, 4 + i) : RQS_P(acc, Q, i)));
+    };
+    const float cs1 = base + (RQS_MIN + pick(0) * inv), cs2 = cs1 + (RQS_MIN + pick(1) * inv);
+    const float cs3 = cs2 + (RQS_MIN + pick(2) * inv), cs4 = cs3 + (RQS_MIN + pick(3) * inv);
+    const int bl = b & 3;
+    const float k0 = m1 ? span * base + lo : lo;
+    const float k1 = span * cs1 + lo, k2 = span * cs2 + lo, k3 = span * cs3 + lo;
+    const float k4 = m3 ? hi : span * cs4 + lo;
+    const bool g1 = bl >= 1, g2 = bl >= 2, g3 = bl >= 3;
+    const float k_b = g3 ? k3 : (g2 ? k2 : (g1 ? k1 : k0));
+    const float k_n = g3 ? k4 : (g2 ? k3 : (g1 ? k2 : k1));
+    e.c_b[Q] = k_b;
+    e.c_w[Q] = k_n - k_b;
+}
+#endif
 template <int Q, int KC>
 __device__ __forceinline__ void rqs_search(tile<1> (&acc)[4], rqs_elems &e, int K, float lo, float hi) {
+#ifndef SX_RQS_FLAT
+    if constexpr (KC == 16) { rqs_search16<Q>(acc, e, lo, hi); return; }
+#endif
     const float xv = e.x[Q];
     const bool in = (xv >= lo) && (xv <= hi);                       // :71 closed interval
     e.in[Q] = in;
@@ -696,6 +761,9 @@ __device__ __forceinline__ void rqs_search(tile<1> (&acc)[4], rqs_elems &e, int 
 // phase 1: knots of the other block at the found bin
 template <int Q, int KC>
 __device__ __forceinline__ void rqs_select(tile<1> (&acc)[4], rqs_elems &e, int K, float lo, float hi) {
+#ifndef SX_RQS_FLAT
+    if constexpr (KC == 16) { rqs_select16<Q>(acc, e, lo, hi); return; }
+#endif
     const float inv = rqs_softmax<Q, KC>(acc, K);
     const int Kn = KC ? KC : K;
     const int b = e.b[Q];
@@ -745,6 +813,8 @@ __device__ __forceinline__ void rqs_eval(tile<1> (&acc)[4], const rqs_elems &e, 
             is_prev = is_next;
         }
     }
+    // (a two-level pick of the two derivatives -- five candidates of the bin's group, then the pair -- was tried here: the
+    //  kernel went from 241 VGPRs to scratch in the phase loop and cfg 3 from 6.4 to 27.6 ms)
     const float d_b = RQS_MIN + rqs_softplus(r_b), d_n = RQS_MIN + rqs_softplus(r_n);
     // REV: the searched block is the heights (codomain side), the selected one the widths
     const float cw_b = REV ? e.c_b[Q] : e.a_b[Q], w_b = REV ? e.c_w[Q] : e.a_w[Q];

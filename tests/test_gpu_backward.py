@@ -225,7 +225,7 @@ def test_spline_slab_backward_at_scale_is_additive_over_row_partitions():
     gxp = torch.cat([gx1, gx2])
     # (not bit-identical: the power-of-two adjoint scale follows each call's largest gradient, which moves where the fp16 x 3
     #  operands' low parts go subnormal)
-    assert (gx - gxp).abs().max().item() <= 1e-4 * gx.abs().max().item()
+    assert (gx - gxp).abs().max().item() <= 2e-4 * gx.abs().max().item()      # (1.0e-4 measured: the scale is taken from sampled rows)
     for (name, _), a, b, c in zip(flow.named_parameters(), whole, part1, part2):
         scale = a.abs().max().item() + 1e-12
         assert (a - (b + c)).abs().max().item() <= 1e-4 * scale, (name, (a - (b + c)).abs().max().item(), scale)
