@@ -312,7 +312,8 @@ int sx_pack_linear(const float *W, const float *b, int32_t out_dim, int32_t in_d
                                            act != 0 applies log1p|t| (affine.py:239-240)                                          */
 #define SX_STEP_RQS_HIDDEN          10  /* blob = pack_linear(W1, folded tanh): hidden of a spline coupling, kept for its phases    */
 #define SX_STEP_RQS_PHASE           11  /* one (8-column group, parameter block) slab of a rational-quadratic spline coupling:
-                                           blob = pack_linear(W2 rows, 4 m-tiles) ++ {lo, hi}; t0 = tile, c0 = group 0..3,
+                                           blob = pack_linear(W2 rows, 4 m-tiles) ++ {lo, hi} (phases 0 and 1: rows and bias
+                                           times log2(e) -- the kernel's softmax runs in base 2); t0 = tile, c0 = group 0..3,
                                            ct = phase (0 search block, 1 select block, 2 derivatives + evaluate), tt = n_bins,
                                            pad_ = live mask of the tile's 32 slots.
                                            act = 1: the monotone CUBIC spline (util/cubic_spline.py:21-251, 2K+2 parameters per

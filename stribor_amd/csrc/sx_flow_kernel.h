@@ -642,7 +642,8 @@ __device__ __forceinline__ void rqs_gemm(const wptr w, const btile<1> (&bh)[HT],
 template <int KC>
 __device__ __forceinline__ bool rqs_has(int k, int K) { return KC ? (k < KC) : (k < K); }
 
-// softmax numerators in place + the factor that turns them into bin sizes: size_k = MIN + e_k * inv
+// softmax numerators in place + the factor that turns them into bin sizes: size_k = MIN + e_k * inv.  The two softmax blocks'
+// rows are packed times log2(e) (fused.py add_coupling_rqs), so exp(u - max) is a bare v_exp_f32.
 template <int Q, int KC>
 __device__ __forceinline__ float rqs_softmax(tile<1> (&acc)[4], int K) {
     float mx = RQS_P(acc, Q, 0);
@@ -653,7 +654,7 @@ __device__ __forceinline__ float rqs_softmax(tile<1> (&acc)[4], int K) {
 #pragma unroll
     for (int k = 0; k < 16; ++k)
         if (KC ? (k < KC) : true) {
-            const float e = rqs_has<KC>(k, K) ? fast_exp(RQS_P(acc, Q, k) - mx) : 0.f;
+            const float e = rqs_has<KC>(k, K) ? __builtin_amdgcn_exp2f(RQS_P(acc, Q, k) - mx) : 0.f;     // logits arrive in base 2
             RQS_P(acc, Q, k) = e;
             sum += e;
         }
@@ -942,7 +943,7 @@ __device__ __forceinline__ float cub_softmax(tile<1> (&acc)[4], int K) {
 #pragma unroll
     for (int k = 0; k < 16; ++k)
         if (KC ? (k < KC) : true) {
-            const float e = rqs_has<KC>(k, K) ? cubic_fexp(RQS_P(acc, Q, k) - mx) : 0.f;
+            const float e = rqs_has<KC>(k, K) ? __builtin_amdgcn_exp2f(RQS_P(acc, Q, k) - mx) : 0.f;     // logits arrive in base 2
             RQS_P(acc, Q, k) = e;
             sum += e;
         }

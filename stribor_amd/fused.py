@@ -664,7 +664,10 @@ class ProgramBuilder:
                                         rows[32 * u + 8 * q + 4 * h + i] = col[slot] * P + start + k
                     nlin = _hip.packed_linear_floats(4, HT)
                     off, n = self._alloc(nlin + 4)
-                    self.jobs.append(_PackJob(W2, b2, rows, col2, 4, HT, off, np.full(128, -2.0), np.full(128, 1.0), 1.0))
+                    # the two softmax blocks are packed in base 2 (rows and bias times log2 e): the kernel's softmax is then
+                    # v_exp_f32(p - max) with no multiply (32 instructions per element)
+                    sc2 = LOG2E if phase < 2 else 1.0
+                    self.jobs.append(_PackJob(W2, b2, rows, col2, 4, HT, off, np.full(128, -2.0 * sc2), np.full(128, sc2), 1.0))
                     self.jobs.append(_ScalarsJob([lo, hi], off + nlin))
                     s_scale = (-ldj_scale if reverse else ldj_scale) if phase == 2 else 0.0
                     step = dict(kind=_hip.STEP_RQS_PHASE, c0=g, ct=phase, t0=t, tt=K, reverse=int(reverse), act=int(cubic),
