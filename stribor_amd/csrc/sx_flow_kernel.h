@@ -802,6 +802,27 @@ __device__ __forceinline__ void rqs_eval(tile<1> (&acc)[4], const rqs_elems &e, 
     float r_b = cst, r_n = cst;
     // derivative k sits between bins k and k+1: it is the RIGHT knot's of bin k and the LEFT knot's of bin k+1, so one
     // compare per bin index serves both selections
+#ifndef SX_RQS_FLAT
+    if constexpr (KC == 16) {
+        // two-level pick (see rqs_search16): D[-1] = D[15] = cst, r_b = D[b - 1], r_n = D[b]; the five candidates D[4g-1 .. 4g+3]
+        // of the bin's group first, then the pair inside it.  (Scalars and macros on purpose: the same code with a float[5] and
+        // a lambda became a stack object -- scratch in the phase loop, cfg 3 6.4 -> 27.6 ms.)
+        const bool m1 = b >= 4, m2 = b >= 8, m3 = b >= 12;
+        // (named copies first: a select between two array elements is canonicalised into a select of ADDRESSES, which keeps
+        //  the accumulator tiles in memory -- 384 B of scratch)
+        const float d0 = RQS_P(acc, Q, 0), d1 = RQS_P(acc, Q, 1), d2 = RQS_P(acc, Q, 2), d3 = RQS_P(acc, Q, 3), d4 = RQS_P(acc, Q, 4);
+        const float d5 = RQS_P(acc, Q, 5), d6 = RQS_P(acc, Q, 6), d7 = RQS_P(acc, Q, 7), d8 = RQS_P(acc, Q, 8), d9 = RQS_P(acc, Q, 9);
+        const float d10 = RQS_P(acc, Q, 10), d11 = RQS_P(acc, Q, 11), d12 = RQS_P(acc, Q, 12), d13 = RQS_P(acc, Q, 13), d14 = RQS_P(acc, Q, 14);
+        const float v0 = m3 ? d11 : (m2 ? d7 : (m1 ? d3 : cst)), v1 = m3 ? d12 : (m2 ? d8 : (m1 ? d4 : d0));
+        const float v2 = m3 ? d13 : (m2 ? d9 : (m1 ? d5 : d1)), v3 = m3 ? d14 : (m2 ? d10 : (m1 ? d6 : d2));
+        const float v4 = m3 ? cst : (m2 ? d11 : (m1 ? d7 : d3));
+        const int bl = b & 3;
+        const bool g1 = bl >= 1, g2 = bl >= 2, g3 = bl >= 3;
+        r_b = g3 ? v3 : (g2 ? v2 : (g1 ? v1 : v0));
+        r_n = g3 ? v4 : (g2 ? v3 : (g1 ? v2 : v1));
+    } else
+#endif
+    {
     bool is_prev = (b == 0);             // "bin index == k" carried to the next iteration as "bin index - 1 == k - 1"
 #pragma unroll
     for (int k = 0; k < 15; ++k) {
@@ -814,8 +835,7 @@ __device__ __forceinline__ void rqs_eval(tile<1> (&acc)[4], const rqs_elems &e, 
             is_prev = is_next;
         }
     }
-    // (a two-level pick of the two derivatives -- five candidates of the bin's group, then the pair -- was tried here: the
-    //  kernel went from 241 VGPRs to scratch in the phase loop and cfg 3 from 6.4 to 27.6 ms)
+    }
     const float d_b = RQS_MIN + rqs_softplus(r_b), d_n = RQS_MIN + rqs_softplus(r_n);
     // REV: the searched block is the heights (codomain side), the selected one the widths
     const float cw_b = REV ? e.c_b[Q] : e.a_b[Q], w_b = REV ? e.c_w[Q] : e.a_w[Q];
@@ -951,9 +971,57 @@ __device__ __forceinline__ float cub_softmax(tile<1> (&acc)[4], int K) {
     return (1.f - CUBIC_MIN_BIN * Kf) * cubic_frcp(sum);         // :103-104, :110-111
 }
 __device__ __forceinline__ float cub_norm(float xv, bool in, float lo, float hi) { return ((in ? xv : lo) - lo) * cubic_frcp(hi - lo); }   // :98-101
+#ifndef SX_CUB_FLAT
+// K = 16: two-level forms of the two sweeps below (see rqs_search16): the group of four bins from the groups' sums, then the six
+// sizes around it (bins 4g-1 .. 4g+4) picked by the group index, the bin and its neighbours inside them
+#define CUB_CL(k) ((k) < 0 ? 0 : ((k) > 15 ? 15 : (k)))        /* (the out-of-range neighbours are never used) */
+#define CUB_Z(i) (CUBIC_MIN_BIN + inv * (m3 ? RQS_P(acc, Q, CUB_CL(11 + (i))) : (m2 ? RQS_P(acc, Q, CUB_CL(7 + (i))) : \
+                                        (m1 ? RQS_P(acc, Q, CUB_CL(3 + (i))) : RQS_P(acc, Q, CUB_CL((i) - 1))))))
+#define CUB_GROUP_SUMS()                                                                                                        \
+    const float S0 = 4.f * CUBIC_MIN_BIN + inv * ((RQS_P(acc, Q, 0) + RQS_P(acc, Q, 1)) + (RQS_P(acc, Q, 2) + RQS_P(acc, Q, 3)));    \
+    const float S1 = 4.f * CUBIC_MIN_BIN + inv * ((RQS_P(acc, Q, 4) + RQS_P(acc, Q, 5)) + (RQS_P(acc, Q, 6) + RQS_P(acc, Q, 7)));    \
+    const float S2 = 4.f * CUBIC_MIN_BIN + inv * ((RQS_P(acc, Q, 8) + RQS_P(acc, Q, 9)) + (RQS_P(acc, Q, 10) + RQS_P(acc, Q, 11)))
+template <int Q>
+__device__ __forceinline__ void cub_search16(tile<1> (&acc)[4], cubic_elems &e, float lo, float hi) {
+    const float xv = e.x[Q];
+    const bool in = (xv >= lo) && (xv <= hi);                       // :40 closed interval
+    e.in[Q] = in;
+    const float xn = cub_norm(xv, in, lo, hi);
+    const float inv = cub_softmax<Q, 16>(acc, 16);
+    CUB_GROUP_SUMS();
+    const bool m1 = xn >= S0, m2 = xn >= S0 + S1, m3 = xn >= (S0 + S1) + S2;
+    const float k0 = m3 ? (S0 + S1) + S2 : (m2 ? S0 + S1 : (m1 ? S0 : 0.f));
+    const float z0 = CUB_Z(0), z1 = CUB_Z(1), z2 = CUB_Z(2), z3 = CUB_Z(3), z4 = CUB_Z(4), z5 = CUB_Z(5);
+    const float k1 = k0 + z1, k2 = k1 + z2, k3 = k2 + z3;
+    const bool g1 = xn >= k1, g2 = xn >= k2, g3 = xn >= k3;
+    e.b[Q] = (m3 ? 12 : (m2 ? 8 : (m1 ? 4 : 0))) + (g3 ? 3 : (g2 ? 2 : (g1 ? 1 : 0)));
+    e.s_k[Q] = g3 ? k3 : (g2 ? k2 : (g1 ? k1 : k0));
+    e.s_m[Q] = g3 ? z3 : (g2 ? z2 : (g1 ? z1 : z0));
+    e.s_b[Q] = g3 ? z4 : (g2 ? z3 : (g1 ? z2 : z1));
+    e.s_p[Q] = g3 ? z5 : (g2 ? z4 : (g1 ? z3 : z2));
+}
+template <int Q>
+__device__ __forceinline__ void cub_select16(tile<1> (&acc)[4], cubic_elems &e) {
+    const float inv = cub_softmax<Q, 16>(acc, 16);
+    const int b = e.b[Q], bl = b & 3;
+    CUB_GROUP_SUMS();
+    const bool m1 = b >= 4, m2 = b >= 8, m3 = b >= 12;
+    const float k0 = m3 ? (S0 + S1) + S2 : (m2 ? S0 + S1 : (m1 ? S0 : 0.f));
+    const float z0 = CUB_Z(0), z1 = CUB_Z(1), z2 = CUB_Z(2), z3 = CUB_Z(3), z4 = CUB_Z(4), z5 = CUB_Z(5);
+    const float k1 = k0 + z1, k2 = k1 + z2, k3 = k2 + z3;
+    const bool g1 = bl >= 1, g2 = bl >= 2, g3 = bl >= 3;
+    e.o_k[Q] = g3 ? k3 : (g2 ? k2 : (g1 ? k1 : k0));
+    e.o_m[Q] = g3 ? z3 : (g2 ? z2 : (g1 ? z1 : z0));
+    e.o_b[Q] = g3 ? z4 : (g2 ? z3 : (g1 ? z2 : z1));
+    e.o_p[Q] = g3 ? z5 : (g2 ? z4 : (g1 ? z3 : z2));
+}
+#endif
 // phase 0: sizes + running knots of the searched block and the bin search (search_sorted.py:4-5) in one sweep
 template <int Q, int KC>
 __device__ __forceinline__ void cub_search(tile<1> (&acc)[4], cubic_elems &e, int K, float lo, float hi) {
+#ifndef SX_CUB_FLAT
+    if constexpr (KC == 16) { cub_search16<Q>(acc, e, lo, hi); return; }
+#endif
     const float xv = e.x[Q];
     const bool in = (xv >= lo) && (xv <= hi);                       // :40 closed interval
     e.in[Q] = in;
@@ -981,6 +1049,9 @@ __device__ __forceinline__ void cub_search(tile<1> (&acc)[4], cubic_elems &e, in
 // phase 1: the other block at the found bin
 template <int Q, int KC>
 __device__ __forceinline__ void cub_select(tile<1> (&acc)[4], cubic_elems &e, int K) {
+#ifndef SX_CUB_FLAT
+    if constexpr (KC == 16) { cub_select16<Q>(acc, e); return; }
+#endif
     const float inv = cub_softmax<Q, KC>(acc, K);
     const int b = e.b[Q];
     float k_b = 0.f, o_b = 0.f, o_m = 1.f, o_p = 1.f, cum = 0.f;
@@ -1042,14 +1113,15 @@ __device__ __forceinline__ void cubic_phase_k(tile<1> (&acc)[4], tile<1> (&xs)[T
 #pragma unroll
                     for (int q = 0; q < 4; ++q) e.x[q] = xs[t].v[0][4 * gg + q];
                 }
-        cub_search<0, KC>(acc, e, K, lo, hi);
-        cub_search<1, KC>(acc, e, K, lo, hi);
-        cub_search<2, KC>(acc, e, K, lo, hi);
+        // (one element at a time: interleaving the four two-level searches keeps 4 x 12 picked values alive at once -- scratch)
+        cub_search<0, KC>(acc, e, K, lo, hi); __builtin_amdgcn_sched_barrier(0);
+        cub_search<1, KC>(acc, e, K, lo, hi); __builtin_amdgcn_sched_barrier(0);
+        cub_search<2, KC>(acc, e, K, lo, hi); __builtin_amdgcn_sched_barrier(0);
         cub_search<3, KC>(acc, e, K, lo, hi);
     } else if (st.ct == 1) {
-        cub_select<0, KC>(acc, e, K);
-        cub_select<1, KC>(acc, e, K);
-        cub_select<2, KC>(acc, e, K);
+        cub_select<0, KC>(acc, e, K); __builtin_amdgcn_sched_barrier(0);
+        cub_select<1, KC>(acc, e, K); __builtin_amdgcn_sched_barrier(0);
+        cub_select<2, KC>(acc, e, K); __builtin_amdgcn_sched_barrier(0);
         cub_select<3, KC>(acc, e, K);
     } else {
         float out[4], lj[4];
