@@ -172,6 +172,35 @@ def test_planner_spline_flow_and_mixed_fallback():
     assert mixed._build_fused(True, 64, 0, torch.device('cpu')) is None
 
 
+def test_planner_cubic_spline_flow_and_spline_mix_rules():
+    """Round 2: cubic-spline couplings plan into the same hidden + 12-phase layout with act = 1 (kernel MODE 12 / 13); the planner
+    refuses the mixes the kernel variants cannot run -- quadratic with cubic splines, any spline with a two-hidden-layer affine
+    coupling (which the spline kernel variant used to skip silently, tools/fuzz_train.py --infer) -- so such flows run layer
+    by layer instead of producing a wrong fused program."""
+    torch.manual_seed(0)
+    dev = torch.device('cpu')
+    cubic = [dict(d, spline_type='cubic') for d in fd.cfg3_desc(2)]
+    flow = fd.build_flow(st, cubic, 64)
+    b = ProgramBuilder(64, 0, 64)
+    order = list(reversed(flow.transforms))
+    b.choose_layout(order[0]._plan_first_mask(64))
+    for f in order:
+        assert f._plan(b, True, -1.0)
+    phases = [s for s in b.steps if s['kind'] == _hip.STEP_RQS_PHASE]
+    assert len(b.steps) == 2 * 13 and all(s['act'] == 1 and s['tt'] == 16 for s in phases)
+    assert flow._build_fused(True, 64, 0, dev) is not None
+    quad = fd.build_flow(st, fd.cfg3_desc(1), 64).transforms[0]
+    assert st.NormalizingFlow(st.UnitNormal(64), [flow.transforms[0], quad])._build_fused(True, 64, 0, dev) is None
+    deep_affine = fd.build_transform(st, {'kind': 'coupling_affine', 'dim': 64, 'hidden': [48, 40], 'mask': 'ordered_left_half',
+                                          'latent_dim': 0})
+    assert st.NormalizingFlow(st.UnitNormal(64), [deep_affine])._build_fused(True, 64, 0, dev) is not None
+    for spline in (quad, flow.transforms[0]):
+        assert st.NormalizingFlow(st.UnitNormal(64), [deep_affine, spline])._build_fused(True, 64, 0, dev) is None
+    wide = fd.build_transform(st, {'kind': 'coupling_rqs', 'dim': 64, 'hidden': [64], 'n_bins': 20, 'lower': -3, 'upper': 3,
+                                   'mask': 'ordered_left_half', 'latent_dim': 0, 'spline_type': 'cubic'})
+    assert st.NormalizingFlow(st.UnitNormal(64), [wide])._build_fused(True, 64, 0, dev) is None        # n_bins > 16: layer-wise tier
+
+
 # ---- round 2: program-cache validity (host logic only; no GPU) -----------------------------------------------------
 def test_program_cache_epoch_guards_and_fingerprint():
     from stribor_amd.fused import ProgramCache, _STRUCT_EPOCH, bump_structure_epoch
