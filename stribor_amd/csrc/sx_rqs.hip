@@ -438,10 +438,6 @@ extern "C" int sx_rqs_coupling(const void *x, void *y, float *ldj, float *ldiag,
 // =====================================================================================================
 #include "sx_cubic_core.h"
 
-__device__ __forceinline__ float cubic_cbrt(float v) {        // :18-20  sign(x) * exp(log|x| / 3)
-    const float s = (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f);
-    return s * expf(logf(fabsf(v)) / 3.0f);
-}
 __device__ __forceinline__ float cubic_sigmoid(float v) { return 1.f / (1.f + expf(-v)); }
 // exp(v) on v_exp_f32 with the product v*log2(e) carried to double-float accuracy (~1e-7 relative)
 __device__ __forceinline__ float cubic_exp(float v) {
