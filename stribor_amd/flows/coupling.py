@@ -362,7 +362,10 @@ class Coupling(Transform):
         if prog is not None:
             y, ldj, _ = prog.run(x2, lat2, True, True, False)
             return y, ldj
-        return self._run_spline(x2, lat2, True, True, 1.0)
+        try:
+            return self._run_spline(x2, lat2, True, True, 1.0)
+        except NotImplementedError:          # beyond the MLP program's tiles too (dim + latent > 4 tiles of 32): generic tier, as _run
+            return self._run_generic(x2, lat2, True, True, 1.0)
 
     def _autograd_inverse_slab(self, x2, lat2, mask_t, rows_t, live, live_idx):
         from .spline import RQSCouplingSlab, RQSCouplingSlabL1, slab_slot_rows

@@ -973,3 +973,31 @@ def test_cubic_coupling_gradients_in_the_quadratic_fallback_branch(K, hidden, la
         scale = ref.abs().max().item() + 1e-12
         err = (p.grad.cpu() - ref).abs().max().item()
         assert err <= 2e-4 * scale + 1e-9, (name, err, scale)
+
+
+@pytest.mark.parametrize('stype', ['quadratic', 'cubic'])
+def test_spline_training_beyond_the_program_tiles(stype):
+    """Found by tools/fuzz_train.py --wide: 121 columns + 3 latent inputs need five tiles of 32; inference falls back to the
+    generic tier, but the training path's no-grad evaluation called the MLP-program tier directly and raised
+    NotImplementedError.  Gradients against fp64 autograd of the oracle."""
+    torch.manual_seed(17)
+    dim, latent, n = 121, 3, 150
+    desc = [{'kind': 'coupling_rqs', 'dim': dim, 'hidden': [40], 'n_bins': 6, 'lower': -3.0, 'upper': 3.0, 'mask': 'ordered_left_half',
+             'latent_dim': latent, 'spline_type': stype}]
+    flow = fd.build_flow(st, desc, dim)
+    state = {k: v.clone() for k, v in flow.state_dict().items()}
+    flow = flow.to(DEV)
+    x, lat = torch.randn(n, dim) * 1.3, torch.randn(n, latent)
+    leaves = {k: v.detach().double().clone().requires_grad_(True) for k, v in state.items()}
+    xin = x.double().clone().requires_grad_(True)
+    want = -orc.flow_log_prob(fd.flow_spec(desc, leaves), xin, lat.double()).mean()
+    want.backward()
+    xg = x.to(DEV).requires_grad_(True)
+    loss = -flow.log_prob(xg, latent=lat.to(DEV)).mean()
+    loss.backward()
+    assert abs(loss.item() - want.item()) <= 1e-5 * abs(want.item()) + 1e-5
+    sx = xin.grad.abs().max().item()
+    assert (xg.grad.cpu().double() - xin.grad).abs().max().item() <= 3e-4 * sx + 1e-8
+    for name, p in flow.named_parameters():
+        ref = leaves[name].grad
+        assert (p.grad.cpu().double() - ref).abs().max().item() <= 3e-4 * ref.abs().max().item() + 1e-8, name

@@ -1,6 +1,6 @@
 """Randomised differential check of the training paths: random spline / affine coupling flows (dims, widths, masks, bin counts,
 spline types, latent inputs, batch sizes) -- gradients of -log_prob.mean() from the HIP paths against fp64 autograd of the oracle.
-    python tools/fuzz_train.py [n_cases] [seed] [--forward] [--infer] [--mix] [--time] [--only=i ...]
+    python tools/fuzz_train.py [n_cases] [seed] [--forward] [--infer] [--mix] [--time] [--wide] [--only=i ...]
 (--forward: forward_and_log_det_jacobian instead of log_prob; --infer: the no-graph paths; --mix: every transform kind)"""
 import os
 import sys
@@ -19,8 +19,11 @@ DEV = 'cuda:0'
 MASKS = ['ordered_right_half', 'ordered_left_half', 'parity_even', 'parity_odd']
 
 
+WIDE = '--wide' in sys.argv          # 65 .. 125 columns: the four-tile kernel variants (one wave per SIMD)
+
+
 def case(rng):
-    dim = int(rng.integers(2, 71))
+    dim = int(rng.integers(65, 126)) if WIDE else int(rng.integers(2, 71))
     latent = int(rng.choice([0, 0, 0, 3]))
     layers = int(rng.integers(1, 4))
     desc = []
