@@ -33,6 +33,9 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
         SX_REQUIRE(s.kind == SX_STEP_RQS_PHASE || (s.c0 >= 0 && s.ct >= 0 && s.c0 + s.ct <= p->tiles && s.t0 >= 0 && s.tt >= 0),
                    "sx_flow_run: step %d bad tiles", i);
         size_t need = 0;
+        // the device step keeps these in 8 bits
+        SX_REQUIRE(s.c0 >= 0 && s.c0 < 256 && s.ct >= 0 && s.ct < 256 && s.t0 >= 0 && s.t0 < 256 && s.tt >= 0 && s.tt < 256 && s.act >= 0 && s.act < 256,
+                   "sx_flow_run: step %d: tile fields out of range (c0 %d ct %d t0 %d tt %d act %d; each < 256)", i, s.c0, s.ct, s.t0, s.tt, s.act);
         switch (s.kind) {
             case SX_STEP_COUPLING_AFFINE: {
                 const int T = p->tiles;

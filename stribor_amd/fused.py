@@ -240,6 +240,7 @@ class CompiledProgram:
         self.in_col = None if in_col is None else torch.from_numpy(in_col.astype(np.int32)).to(device)
         self.out_col = None if out_col is None else torch.from_numpy(out_col.astype(np.int32)).to(device)
         self.mlp_out_dim = mlp_out_dim
+        self.mlp_col0 = 0                       # first output column of this launch's window (chunked MLP programs)
         self._tracked = None
 
     @property
@@ -314,7 +315,8 @@ class CompiledProgram:
             def launch(prec):
                 rc = _hip.lib().sx_flow_run(C.byref(self.prog), self.blobs_for(prec).data_ptr(), x.data_ptr(),
                                             _hip.ptr(latent), _hip.ptr(self.in_col), _hip.ptr(self.out_col), _hip.ptr(y),
-                                            _hip.ptr(ldj), _hip.ptr(logp), _hip.ptr(sum_out), _hip.ptr(mlp_out), stride,
+                                            _hip.ptr(ldj), _hip.ptr(logp), _hip.ptr(sum_out),
+                                            None if mlp_out is None else mlp_out.data_ptr() + 4 * self.mlp_col0, stride,
                                             self.mlp_out_dim, _hip.ptr(row_t), _hip.ptr(side), n, _hip.dtype_code(x),
                                             prec, work.data_ptr(), flag, _hip.stream())
                 if rc != 0:

@@ -241,10 +241,20 @@ def _chunk_mlp_program(builder: ProgramBuilder, device):
     room = _hip.SX_MAX_STEPS - n_hidden
     progs = []
     all_steps = builder.steps
+    total_out = builder.mlp_out_dim
     for i in range(0, max(len(outs), 1), room):
-        builder.steps = head + outs[i:i + room]
-        progs.append(builder.build(device))
+        chunk = outs[i:i + room]
+        # each launch writes its own window of the output: tile indices restart at 0 (the device step keeps them in 8 bits --
+        # a 348-tile output, e.g. 121 columns x 92 spline parameters, used to wrap at tile 256 and leave the columns beyond
+        # 8192 unwritten: tools/fuzz_train.py --fat --wide)
+        first = chunk[0]['t0'] if chunk else 0
+        builder.steps = head + [dict(s, t0=s['t0'] - first) for s in chunk]
+        builder.mlp_out_dim = min(32 * len(chunk), total_out - 32 * first) if chunk else total_out
+        prog = builder.build(device)
+        prog.mlp_col0 = 32 * first
+        progs.append(prog)
     builder.steps = all_steps
+    builder.mlp_out_dim = total_out
     # the chunks share one set of pack jobs / one blob buffer
     for p in progs[1:]:
         p.share_weights_of(progs[0])

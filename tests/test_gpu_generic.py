@@ -235,3 +235,18 @@ def test_row_sums_are_bit_reproducible_for_any_row_length():
         b = run_pointwise(xs, PW_SIGMOID, want_ldj=True, want_ldiag=True)
         assert torch.equal(a[1], b[1]), n_live
         assert ((a[1].reshape(-1).double() - a[2].double().sum(-1)).abs() <= 1e-5 + 1e-6 * a[2].double().abs().sum(-1)).all()
+
+
+def test_mlp_program_with_more_than_256_output_tiles():
+    """Found by tools/fuzz_train.py --fat --wide: an MLP program writes its output in tiles of 32 columns whose index the device
+    step keeps in 8 bits; outputs beyond 8192 columns (e.g. 121 columns x 92 spline parameters = 348 tiles) wrapped -- the
+    columns past 8192 were never written and the first ones were overwritten.  Each chunk launch now writes its own window."""
+    torch.manual_seed(9)
+    net = st.net.MLP(20, [48], 8192 + 2 * 4032 + 77).to(DEV)          # 511 tiles: five launches
+    x = torch.randn(333, 20, device=DEV)
+    with torch.no_grad():
+        got = net(x)
+        lin = [m for m in net.modules() if isinstance(m, torch.nn.Linear)]
+        h = torch.tanh(torch.nn.functional.linear(x.double(), lin[0].weight.double(), lin[0].bias.double()))
+        want = torch.nn.functional.linear(h, lin[1].weight.double(), lin[1].bias.double())
+    close(got, want.float(), rtol=1e-5, atol=1e-5)

@@ -1,6 +1,6 @@
 """Randomised differential check of the training paths: random spline / affine coupling flows (dims, widths, masks, bin counts,
 spline types, latent inputs, batch sizes) -- gradients of -log_prob.mean() from the HIP paths against fp64 autograd of the oracle.
-    python tools/fuzz_train.py [n_cases] [seed] [--forward] [--infer] [--mix] [--time] [--wide] [--only=i ...]
+    python tools/fuzz_train.py [n_cases] [seed] [--forward] [--infer] [--mix] [--time] [--wide] [--fat] [--only=i ...]
 (--forward: forward_and_log_det_jacobian instead of log_prob; --infer: the no-graph paths; --mix: every transform kind)"""
 import os
 import sys
@@ -20,6 +20,7 @@ MASKS = ['ordered_right_half', 'ordered_left_half', 'parity_even', 'parity_odd']
 
 
 WIDE = '--wide' in sys.argv          # 65 .. 125 columns: the four-tile kernel variants (one wave per SIMD)
+FAT = '--fat' in sys.argv            # hidden widths 65 .. 200 and up to 32 bins: the four-hidden-tile variants and the tiers beyond them
 
 
 def case(rng):
@@ -29,12 +30,12 @@ def case(rng):
     desc = []
     for _ in range(layers):
         kind = rng.choice(['rqs', 'rqs', 'cubic', 'affine'])
-        hidden = [int(rng.integers(4, 65)) for _ in range(int(rng.integers(1, 3)))]
+        hidden = [int(rng.integers(65, 201) if FAT else rng.integers(4, 65)) for _ in range(int(rng.integers(1, 3)))]
         d = {'dim': dim, 'hidden': hidden, 'mask': str(rng.choice(MASKS)), 'latent_dim': latent}
         if kind == 'affine':
             d['kind'] = 'coupling_affine'
         else:
-            d.update(kind='coupling_rqs', n_bins=int(rng.integers(1, 17)), lower=-3.0, upper=3.0,
+            d.update(kind='coupling_rqs', n_bins=int(rng.integers(1, 33 if FAT else 17)), lower=-3.0, upper=3.0,
                      spline_type='quadratic' if kind == 'rqs' else 'cubic')
         desc.append(d)
         if rng.random() < 0.3:
