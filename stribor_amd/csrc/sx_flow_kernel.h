@@ -1087,7 +1087,7 @@ __device__ __forceinline__ void cub_eval(tile<1> (&acc)[4], const cubic_elems &e
     if constexpr (REV) {
         const float rcw = (b == K - 1) ? 1.f : cw_b + w_b;                                 // :107 (last knot pinned)
         const float so = cubic_invert(a, bb, c, d, xn, cw_b, rcw);
-        out = (so + cw_b) * span + lo;                                                     // :235
+        out = fminf(fmaxf((so + cw_b) * span + lo, lo), hi);                               // :235 (clamped: see cubic_kernel)
         const bool in2 = (out >= lo) && (out <= hi);
         const float t2 = cub_norm(out, in2, lo, hi) - cw_b;
         ljd = in2 ? -cubic_flog(3.f * a * (t2 * t2) + 2.f * bb * t2 + c) : 0.f;            // flow.py:42-47

@@ -706,7 +706,10 @@ __global__ __launch_bounds__(256, 4) void cubic_kernel(const void *__restrict__ 
             float o;
             o = so + cw_b;
             ljd = -cubic_flog(3.f * a * (so * so) + 2.f * bb * so + c);                    // :225-227
-            out = o * span + lower;                                                        // :235
+            // (an input inside the closed domain has its pre-image inside it too: without the clamp an input ON the bound -- common
+            //  with bf16 storage, whose grid contains +-3 -- can come back one ulp outside, and the reference-mode log-det below
+            //  would then be the tails' 0 instead of -log f')
+            out = fminf(fmaxf(o * span + lower, lower), upper);                            // :235
             ljd = (ljd - log_span) + log_span;                                             // :236 (two fp32 roundings there)
             if (ref_ldj) {
                 // Reference mode (a coupling's inverse_and_log_det_jacobian): the reference does NOT use the inverse's own

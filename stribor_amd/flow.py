@@ -254,6 +254,14 @@ class ElementwiseTransform(Transform):
         return x, -self.log_diag_jacobian(x, y, **kwargs)
 
 
+def _fp32_between_layers(x):
+    """bf16 is a STORAGE format here (bf16 in, fp32 arithmetic): a flow that runs layer by layer keeps fp32 between
+    its layers -- as the fused kernel does in registers -- and rounds once, on the way out.  -> (tensor to run on, cast back)."""
+    if torch.is_tensor(x) and x.dtype == torch.bfloat16:
+        return x.to(torch.float32), (lambda r: r.to(torch.bfloat16))
+    return x, (lambda r: r)
+
+
 class NormalizingFlow(Transform):
     """flow.py:72-152.  ``base_dist`` needs ``log_prob / sample / rsample`` (flow.py:129,139,141)."""
 
@@ -487,9 +495,10 @@ class NormalizingFlow(Transform):
         if r is not None:
             return r[0]
         kw = dict(kwargs) if latent is None else dict(kwargs, latent=latent)
+        x, back = _fp32_between_layers(x)
         for f in self.transforms:                                   # flow.py:99-102
             x = f(x, **kw)
-        return x
+        return back(x)
 
     def inverse(self, y, latent=None, **kwargs):
         g = self._transform_with_graph(y, latent, True, 'inverse', kwargs)
@@ -499,9 +508,10 @@ class NormalizingFlow(Transform):
         if r is not None:
             return r[0]
         kw = dict(kwargs) if latent is None else dict(kwargs, latent=latent)
+        y, back = _fp32_between_layers(y)
         for f in reversed(self.transforms):                         # flow.py:104-107
             y = f.inverse(y, **kw)
-        return y
+        return back(y)
 
     def forward_and_log_det_jacobian(self, x, latent=None, **kwargs):
         g = self._transform_with_graph(x, latent, False, 'forward_and_log_det_jacobian', kwargs)
@@ -512,10 +522,11 @@ class NormalizingFlow(Transform):
             return r[0], r[1]
         kw = dict(kwargs) if latent is None else dict(kwargs, latent=latent)
         acc = 0
+        x, back = _fp32_between_layers(x)
         for f in self.transforms:                                   # flow.py:109-116
             x, ldj = f.forward_and_log_det_jacobian(x, **kw)
             acc = acc + ldj
-        return x, acc
+        return back(x), acc
 
     def inverse_and_log_det_jacobian(self, y, latent=None, **kwargs):
         g = self._transform_with_graph(y, latent, True, 'inverse_and_log_det_jacobian', kwargs)
@@ -526,10 +537,11 @@ class NormalizingFlow(Transform):
             return r[0], r[1]
         kw = dict(kwargs) if latent is None else dict(kwargs, latent=latent)
         acc = 0
+        y, back = _fp32_between_layers(y)
         for f in reversed(self.transforms):                         # flow.py:118-125
             y, ldj = f.inverse_and_log_det_jacobian(y, **kw)
             acc = acc + ldj
-        return y, acc
+        return back(y), acc
 
     def log_prob(self, y, latent=None, **kwargs):
         """[..., D] -> [..., 1]   (flow.py:127-130)."""
@@ -552,7 +564,8 @@ class NormalizingFlow(Transform):
             r = self._run(y, True, latent, False, False, True, **kwargs)
             if r is not None:
                 return r[2]
-        x, acc = self.inverse_and_log_det_jacobian(y, latent=latent, **kwargs)
+        # (bf16 storage: the latent stays fp32 up to the base density, as in the fused kernel, where the state never leaves registers)
+        x, acc = self.inverse_and_log_det_jacobian(y.to(torch.float32) if y.dtype == torch.bfloat16 else y, latent=latent, **kwargs)
         if isinstance(self.base_dist, UnitNormal):
             x2, lead = flatten_rows(x)
             ldj = acc.reshape(-1).to(torch.float32).contiguous() if torch.is_tensor(acc) else None

@@ -1100,3 +1100,30 @@ def test_spline_kernels_pipelined_dense_path_against_oracle(cubic, bf16, scatter
             assert torch.quantile(err.flatten()[::7], 0.999).item() <= 2e-5 and err.max().item() <= 2e-3, (rev, err.max().item())
         el = (ldj.cpu().double() - wl.sum(-1)).abs() / (1.0 + wl.sum(-1).abs())
         assert torch.quantile(el[::3], 0.999).item() <= 1e-4 and el.max().item() <= 5e-3, (rev, el.max().item())
+
+
+def test_bf16_storage_keeps_fp32_between_layers_of_an_unfused_flow():
+    """SURVEY H5 (bf16 in, fp32 arithmetic) for flows that run layer by layer (here: an affine and a spline coupling cannot share a
+    fused program): the state stays fp32 between the layers and up to the base density, as it does in the fused kernel's
+    registers -- log_prob from bf16 inputs matches the oracle fed the same rounded values at fp32 level (it was 1e-3 off when
+    every layer stored bf16: tools/fuzz_train.py --bf16), outputs are rounded to bf16 once."""
+    torch.manual_seed(8)
+    dim = 24
+    desc = [{'kind': 'coupling_affine', 'dim': dim, 'hidden': [32], 'mask': 'ordered_right_half', 'latent_dim': 0},
+            {'kind': 'coupling_rqs', 'dim': dim, 'hidden': [32], 'n_bins': 7, 'lower': -3.0, 'upper': 3.0, 'mask': 'parity_odd',
+             'latent_dim': 0, 'spline_type': 'quadratic'},
+            {'kind': 'leaky_relu', 'negative_slope': 0.2}]
+    flow = fd.build_flow(st, desc, dim)
+    state = {k: v.clone() for k, v in flow.state_dict().items()}
+    flow = flow.to(DEV)
+    assert flow._fused_program(True, dim, 0, torch.device(DEV, 0)) is None
+    x = (torch.randn(500, dim) * 1.3).bfloat16()
+    spec = fd.flow_spec(desc, {k: v.double() for k, v in state.items()})
+    with torch.no_grad():
+        lp = flow.log_prob(x.to(DEV))
+        y, ldj = flow.forward_and_log_det_jacobian(x.to(DEV))
+    assert lp.dtype == torch.float32 and y.dtype == torch.bfloat16
+    close(lp, orc.flow_log_prob(spec, x.double()).float(), rtol=1e-5, atol=1e-4)
+    wy, wl = orc.flow_forward_and_ldj(spec, x.double())
+    close(ldj.float(), wl.float(), rtol=1e-5, atol=1e-4)
+    close(y.float(), wy.float().bfloat16().float(), rtol=1e-2, atol=1e-2)

@@ -1,6 +1,6 @@
 """Randomised differential check of the training paths: random spline / affine coupling flows (dims, widths, masks, bin counts,
 spline types, latent inputs, batch sizes) -- gradients of -log_prob.mean() from the HIP paths against fp64 autograd of the oracle.
-    python tools/fuzz_train.py [n_cases] [seed] [--forward] [--infer] [--mix] [--time] [--wide] [--fat] [--only=i ...]
+    python tools/fuzz_train.py [n_cases] [seed] [--forward] [--infer] [--mix] [--time] [--wide] [--fat] [--bf16] [--only=i ...]
 (--forward: forward_and_log_det_jacobian instead of log_prob; --infer: the no-graph paths; --mix: every transform kind)"""
 import os
 import sys
@@ -156,14 +156,20 @@ def main():
             print(f'case {i:3d} dim {dim:2d} lat {latent} n {n:3d} {kinds} y(t) {e[0]:.1e} y(t,t0) {e[1]:.1e} layer y {e[2]:.1e} ldj {e[3]:.1e} '
                   f'round trip {e[4]:.1e} inverse ldj {e[5]:.1e}' + ('  FAIL' if max(e) > 2e-4 else ''), flush=True)
             continue
+        if infer and '--bf16' in sys.argv:   # bf16 storage: the product reads / writes bf16, computes in fp32; the oracle gets the rounded values
+            x = x.bfloat16().float()
+            # (bf16's grid contains the spline domain's bounds +-3: an input ON the bound has its inverse within an ulp of it, and
+            #  whether the reference's forward log-det at that point is the tail's 0 is a coin flip of its own rounding -- fp64 too)
+            x = torch.where(x.abs() == 3.0, x.sign() * 2.984375, x)          # the next bf16 value inside the domain
         if infer:         # no-graph paths (fused programs / tiers): log_prob, forward + log-det, inverse round trip vs fp64
             spec = fd.flow_spec(desc, {k: v.double() for k, v in state.items()})
             l64 = None if lat is None else lat.double()
             kw = {} if lat is None else {'latent': lat.to(DEV)}
             okw = {}
+            xdev = x.to(DEV).bfloat16() if '--bf16' in sys.argv else x.to(DEV)
             with torch.no_grad():
-                lp = flow.log_prob(x.to(DEV), **kw).cpu().double()
-                y, ldj = flow.forward_and_log_det_jacobian(x.to(DEV), **kw)
+                lp = flow.log_prob(xdev, **kw).cpu().double()
+                y, ldj = flow.forward_and_log_det_jacobian(xdev, **kw)
                 xr = flow.inverse(y, **kw).cpu().double()
             st.check_errors()
             want_lp = orc.flow_log_prob(spec, x.double(), l64, **okw)
@@ -172,6 +178,8 @@ def main():
             e2 = ((y.cpu().double() - wy).abs() / (1.0 + wy.abs())).max().item()
             e3 = ((ldj.cpu().double() - wl).abs() / (1.0 + wl.abs())).max().item()
             e4 = (xr - x.double()).abs().max().item()
+            if '--bf16' in sys.argv:            # y / the round trip are stored in bf16 (8 mantissa bits)
+                e2, e4 = e2 / 64.0, 0.0            # (the round trip goes through bf16-stored y: its error follows |y|, e.g. after Cumsum)
             m = max(e1, e2, e3)
             worst = max(worst, m)
             kinds = [d['kind'] + ('/' + d['spline_type'][0] if 'spline_type' in d else '') + (f":K{d['n_bins']}" if 'n_bins' in d else '') for d in desc]
