@@ -412,6 +412,12 @@ class NormalizingFlow(Transform):
                 cur, ldj = f._autograd_time(cur, t, reverse)
                 total = ldj if total is None else total + ldj
                 continue
+            if getattr(f, 'set_data', False):                                 # the mask runs over the set axis (coupling.py:48-53)
+                if len(lead) < 1:
+                    raise ValueError('set_data=True needs inputs of shape (..., N, dim)')
+                cur, ldj = f._autograd_set(cur, lat2, lead[-1], reverse)
+                total = ldj if total is None else total + ldj
+                continue
             step = f._autograd_inverse if reverse else f._autograd_forward
             cur, ldj = step(cur, lat2, dense[id(f)]) if id(f) in dense else step(cur, lat2)
             total = ldj if total is None else total + ldj

@@ -285,9 +285,30 @@ class Coupling(Transform):
     # ---- training (autograd): spline couplings, inverse direction --------------------------------------------------
     def _autograd_supported(self) -> bool:
         from .spline import Spline
-        if self.set_data or getattr(self.transform, 'latent_net', None) is None:
+        if getattr(self.transform, 'latent_net', None) is None:
             return False
         return isinstance(self.transform, (Affine, Spline))
+
+    def _autograd_set(self, x2: torch.Tensor, lat2, set_size: int, reverse: bool):
+        """set_data=True with a graph (coupling.py:48-53, 61, 78, 95): the transformed set elements are gathered into compact rows,
+        transformed -- every column -- by the element-wise op of the transform with the conditioner's output for cat[0, latent]
+        (torch's graph through the conditioner, the HIP kernels behind AffineCouplingOp / RQSInverse / CubicInverse and their
+        forward-direction twins for the transform), and scattered back.  -> (rows [B * N, D], log-det [B * N])."""
+        rows, d = x2.shape
+        N = int(set_size)
+        dev = x2.device
+        live_n = np.nonzero(self.mask_vector(N) <= 0.5)[0]
+        zero = torch.zeros(rows, dtype=torch.float32, device=dev)
+        if len(live_n) == 0 or rows == 0:
+            return x2, zero
+        sel = self._programs.get(('set-rows', rows, N, str(dev)), lambda: torch.from_numpy(
+            (np.arange(rows // N)[:, None] * N + live_n[None, :]).reshape(-1).astype(np.int64)).to(dev))
+        xt = x2.index_select(0, sel)
+        z = torch.zeros(xt.shape[0], d, dtype=torch.float32, device=dev)               # x * mask = 0 on these rows
+        if lat2 is not None:
+            z = torch.cat([z, lat2.index_select(0, sel).to(torch.float32)], -1)
+        yt, lt = self.transform._autograd_inverse(xt.contiguous(), z, reverse=reverse)
+        return x2.index_copy(0, sel, yt), zero.index_copy(0, sel, lt.reshape(-1))
 
     def _autograd_forward(self, x2: torch.Tensor, lat2=None):
         """forward_and_log_det_jacobian with a graph (affine and spline couplings)."""

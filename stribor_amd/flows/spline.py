@@ -399,8 +399,7 @@ class Spline(ElementwiseTransform):
 
     # ---- training (layer-wise autograd path) ---------------------------------------------------------------------
     def _autograd_supported(self) -> bool:
-        from ..net.mlp import MLP
-        return self.latent_net is None or isinstance(self.latent_net, MLP)
+        return True          # own parameters, a net.MLP (forward_autograd) or any nn.Module latent_net (torch's graph)
 
     def _autograd_inverse(self, x2: torch.Tensor, lat2=None, reverse: bool = True):
         """inverse_and_log_diag_jacobian summed over the columns, on fp32 rows, with a graph (RQSInverse)."""
@@ -411,7 +410,8 @@ class Spline(ElementwiseTransform):
         else:
             if lat2 is None:
                 raise ValueError('Spline with a latent_net needs `latent`')
-            params = self.latent_net.forward_autograd(lat2)                                                 # spline.py:82-86
+            net = self.latent_net
+            params = net.forward_autograd(lat2) if hasattr(net, 'forward_autograd') else net(lat2)          # spline.py:82-86
         if self.spline_type == 'cubic':
             op = CubicInverse if reverse else CubicForward
         else:

@@ -1001,3 +1001,42 @@ def test_spline_training_beyond_the_program_tiles(stype):
     for name, p in flow.named_parameters():
         ref = leaves[name].grad
         assert (p.grad.cpu().double() - ref).abs().max().item() <= 3e-4 * ref.abs().max().item() + 1e-8, name
+
+
+@pytest.mark.parametrize('kind,stype', [('coupling_affine', None), ('coupling_rqs', 'quadratic'), ('coupling_rqs', 'cubic')])
+@pytest.mark.parametrize('direction', ['log_prob', 'forward'])
+def test_set_data_couplings_are_differentiable(kind, stype, direction):
+    """Coupling(set_data=True) (coupling.py:48-53: the mask runs over the SET axis; a transformed element sees only cat[0, latent])
+    trains like every other layer (round 2: it used to be evaluated without a graph): gradients of a loss on log_prob, or on
+    forward_and_log_det_jacobian, against fp64 autograd of the oracle; inputs (7, 4, 5) as in the reference's test_coupling.py."""
+    torch.manual_seed(12)
+    dim, latent = 5, 2
+    desc = []
+    for m in ('ordered_right_half', 'parity_odd'):
+        d = {'kind': kind, 'dim': dim, 'hidden': [24], 'mask': m, 'latent_dim': latent, 'set_data': True}
+        if stype is not None:
+            d.update(n_bins=5, lower=-3.0, upper=3.0, spline_type=stype)
+        desc.append(d)
+    flow = fd.build_flow(st, desc, dim)
+    state = {k: v.clone() for k, v in flow.state_dict().items()}
+    flow = flow.to(DEV)
+    x, lat = torch.randn(7, 4, dim) * 1.2, torch.randn(7, 4, latent)
+    leaves = {k: v.detach().double().clone().requires_grad_(True) for k, v in state.items()}
+    xin = x.double().clone().requires_grad_(True)
+    spec = fd.flow_spec(desc, leaves)
+    xg = x.to(DEV).requires_grad_(True)
+    if direction == 'log_prob':
+        want = -orc.flow_log_prob(spec, xin, lat.double()).mean()
+        loss = -flow.log_prob(xg, latent=lat.to(DEV)).mean()
+    else:
+        y64, l64 = orc.flow_forward_and_ldj(spec, xin, lat.double())
+        want = ((y64 ** 2).sum() * 0.1 + l64.sum()) / 28
+        yg, lg = flow.forward_and_log_det_jacobian(xg, latent=lat.to(DEV))
+        loss = ((yg ** 2).sum() * 0.1 + lg.sum()) / 28
+    want.backward()
+    loss.backward()
+    assert abs(loss.item() - want.item()) <= 1e-5 * abs(want.item()) + 1e-6
+    assert (xg.grad.cpu().double() - xin.grad).abs().max().item() <= 3e-4 * xin.grad.abs().max().item() + 1e-8
+    for name, p in flow.named_parameters():
+        ref = leaves[name].grad
+        assert (p.grad.cpu().double() - ref).abs().max().item() <= 3e-4 * ref.abs().max().item() + 1e-8, name

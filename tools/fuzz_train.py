@@ -1,6 +1,6 @@
 """Randomised differential check of the training paths: random spline / affine coupling flows (dims, widths, masks, bin counts,
 spline types, latent inputs, batch sizes) -- gradients of -log_prob.mean() from the HIP paths against fp64 autograd of the oracle.
-    python tools/fuzz_train.py [n_cases] [seed] [--forward] [--infer] [--mix] [--time] [--wide] [--fat] [--bf16] [--only=i ...]
+    python tools/fuzz_train.py [n_cases] [seed] [--forward] [--infer] [--mix] [--time] [--wide] [--fat] [--bf16] [--sets] [--only=i ...]
 (--forward: forward_and_log_det_jacobian instead of log_prob; --infer: the no-graph paths; --mix: every transform kind)"""
 import os
 import sys
@@ -74,8 +74,9 @@ def case_mix(rng):
         elif kind == 'affine_latent':
             d = {'dim': dim, 'hidden': hidden, 'latent_dim': latent}
         elif kind == 'rqs':
-            d = {'dim': dim, 'n_bins': int(rng.integers(1, 9)), 'lower': -3.0, 'upper': 3.0,
-                 'hidden': hidden if latent else None, 'latent_dim': latent}
+            d = {'dim': dim, 'n_bins': int(rng.integers(1, 33 if FAT else 9)), 'lower': -3.0, 'upper': 3.0,
+                 'hidden': hidden if latent else None, 'latent_dim': latent,
+                 'spline_type': str(rng.choice(['quadratic', 'cubic']))}
         elif kind == 'matrix_exp':
             d = {'dim': dim, 'bias': bool(rng.integers(0, 2)), 'log_time': False}
         else:
@@ -115,6 +116,9 @@ def main():
         desc, dim, latent, n = (case_time if timed else case_mix if mix else case)(rng)
         if only and i not in only:
             continue
+        if mix and n % 3 == 0 and '--sets' in sys.argv:
+            # the second batch axis read as sets of 3 elements: couplings mask over the set axis (coupling.py:48-53)
+            desc = [dict(d, set_data=True) if d['kind'].startswith('coupling_') else d for d in desc]
         torch.manual_seed(seed * 1000 + i)
         flow = fd.build_flow(st, desc, dim)
         with torch.no_grad():
