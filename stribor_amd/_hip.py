@@ -290,6 +290,7 @@ def take_flag(device, bit: int) -> bool:
 # ---- caller-owned scratch of the library (it allocates nothing itself) ------------------------------------------------
 _work = {}
 _scratch = {}
+_POISON_SCRATCH = os.environ.get('STRIBOR_POISON_SCRATCH') == '1'
 
 
 def work_counters(device) -> torch.Tensor:
@@ -308,6 +309,8 @@ def scratch(device, n_floats: int) -> torch.Tensor:
     t = _scratch.get(key)
     if t is None or t.numel() < n_floats:
         t = _scratch[key] = torch.empty(max(n_floats, 1 << 20), dtype=torch.float32, device=device)
+    if _POISON_SCRATCH:          # debug: every hand-out starts as NaN, so a kernel reading what this op never wrote shows up
+        t.fill_(float('nan'))
     return t
 
 

@@ -194,8 +194,12 @@ def _slab_packs(x2, W2, b2, slot_rows, hid_idx, n_live, H):
     lib = _hip.lib()
     slots, ht = lib.sx_rqs_slab_slots(n_live), (H + 31) // 32
     mt = slots // 32
-    n_fwd, n_bwd = _hip.packed_linear_floats(mt, ht), ht * mt * 1024
-    packs = torch.empty(n_fwd + n_bwd + 32, dtype=torch.float32, device=x2.device)
+    # (the transposed pack carries its own -- unused, zero -- bias block of 32 ht floats behind the tiles: reserving 32 for it
+    #  let hidden widths above 32 write 128 B past the buffer; where the block size left no padding that zeroed the start of
+    #  the next tensor in memory, e.g. the incoming log-det adjoints: tools/fuzz_train.py found it as a sequence-dependent
+    #  1e-1 gradient error)
+    n_fwd, n_bwd = _hip.packed_linear_floats(mt, ht), _hip.packed_linear_floats(ht, mt)
+    packs = torch.empty(n_fwd + n_bwd, dtype=torch.float32, device=x2.device)
     flag = _hip.err_flag(x2.device)
     _hip.call('sx_pack_linear', x2, W2.data_ptr(), b2.data_ptr(), W2.shape[0], H, slot_rows.data_ptr(), hid_idx.data_ptr(),
               mt, ht, None, None, 0.0, 0, _hip.GEMM_F16X3, flag, packs.data_ptr())
@@ -241,7 +245,7 @@ class RQSCouplingSlabL1(torch.autograd.Function):
         packs, n_fwd = _slab_packs(x2, W2, b2, slot_rows, hid_idx, n_live, H)
         W1m = (W1.detach() * mask_t).contiguous()
         ht, xt = (H + 31) // 32, (d + 31) // 32
-        w1t = torch.empty(xt * ht * 1024 + 32, dtype=torch.float32, device=dev)
+        w1t = torch.empty(_hip.packed_linear_floats(xt, ht), dtype=torch.float32, device=dev)       # tiles + the pack's bias block
         _hip.call('sx_pack_linear', x2, W1m.data_ptr(), None, H, d, col_slots.data_ptr(), hid_idx.data_ptr(), xt, ht, None, None,
                   0.0, 1, _hip.GEMM_F16X3, flag, w1t.data_ptr())
         gx = torch.empty_like(gy)           # every column is written: transformed ones by the slab kernel, the rest by the l1 kernel

@@ -1040,3 +1040,35 @@ def test_set_data_couplings_are_differentiable(kind, stype, direction):
     for name, p in flow.named_parameters():
         ref = leaves[name].grad
         assert (p.grad.cpu().double() - ref).abs().max().item() <= 3e-4 * ref.abs().max().item() + 1e-8, name
+
+
+@pytest.mark.parametrize('n_live,H', [(33, 48), (32, 64), (5, 20), (61, 64)])
+def test_slab_packs_stay_inside_their_buffer(n_live, H, monkeypatch):
+    """Found by tools/fuzz_train.py as a SEQUENCE-dependent 1e-1 gradient error: the transposed pack of the slab backward carries a
+    bias block of 32 * ceil(H / 32) floats, 32 had been reserved -- for H > 32 the pack kernel wrote 128 B past the buffer, and where
+    the allocator's block size left no padding (n_live = 33, H = 48) that zeroed the start of the next tensor in memory (the incoming
+    log-det adjoints).  The buffers are handed out here from inside a canary region that must come back untouched."""
+    from stribor_amd.flows import spline as sp_mod
+    torch.manual_seed(0)
+    K = 12
+    P = 3 * K - 1
+    W2, b2 = torch.randn(n_live * P, H, device=DEV), torch.randn(n_live * P, device=DEV)
+    x2 = torch.randn(64, 2 * n_live, device=DEV)
+    slot_rows = torch.from_numpy(sp_mod.slab_slot_rows(n_live, K, False)).to(DEV)
+    hid = torch.full((((H + 31) // 32) * 32,), -1, dtype=torch.int32, device=DEV)
+    hid[:H] = torch.arange(H, dtype=torch.int32, device=DEV)
+    real_empty, canaries = torch.empty, []
+
+    def guarded_empty(*size, **kw):
+        n = int(size[0]) if len(size) == 1 and not isinstance(size[0], (tuple, list)) else None
+        if n is None or kw.get('dtype', torch.float32) != torch.float32:
+            return real_empty(*size, **kw)
+        buf = torch.full((n + 1024,), float('nan'), dtype=torch.float32, device=kw.get('device'))
+        canaries.append(buf[n:])
+        return buf[:n]
+    monkeypatch.setattr(torch, 'empty', guarded_empty)
+    packs, n_fwd = sp_mod._slab_packs(x2, W2, b2, slot_rows, hid, n_live, H)
+    monkeypatch.setattr(torch, 'empty', real_empty)
+    torch.cuda.synchronize()
+    assert canaries and all(torch.isnan(c).all().item() for c in canaries)
+    assert torch.isfinite(packs).all()

@@ -1,6 +1,6 @@
 """Randomised differential check of the training paths: random spline / affine coupling flows (dims, widths, masks, bin counts,
 spline types, latent inputs, batch sizes) -- gradients of -log_prob.mean() from the HIP paths against fp64 autograd of the oracle.
-    python tools/fuzz_train.py [n_cases] [seed] [--forward] [--infer] [--mix] [--time] [--wide] [--fat] [--bf16] [--sets] [--only=i ...]
+    python tools/fuzz_train.py [n_cases] [seed] [--forward] [--infer] [--mix] [--time] [--wide] [--fat] [--bf16] [--sets] [--poison] [--only=i ...]
 (--forward: forward_and_log_det_jacobian instead of log_prob; --infer: the no-graph paths; --mix: every transform kind)"""
 import os
 import sys
@@ -101,7 +101,20 @@ def case_time(rng):
     return desc, dim, latent, int(rng.integers(1, 500))
 
 
+def _poison_empty():
+    """--poison: torch.empty / empty_like hand out NaN-filled float tensors: an op that reads what it never wrote shows up as NaN
+    instead of depending on what the caching allocator happens to return."""
+    e0, el0 = torch.empty, torch.empty_like
+
+    def fill(t):
+        return t.fill_(float('nan')) if t.is_floating_point() and t.is_cuda else t
+    torch.empty = lambda *a, **k: fill(e0(*a, **k))
+    torch.empty_like = lambda *a, **k: fill(el0(*a, **k))
+
+
 def main():
+    if '--poison' in sys.argv:
+        _poison_empty()
     fwd = '--forward' in sys.argv
     timed = '--time' in sys.argv
     infer = '--infer' in sys.argv
@@ -119,6 +132,28 @@ def main():
         if mix and n % 3 == 0 and '--sets' in sys.argv:
             # the second batch axis read as sets of 3 elements: couplings mask over the set axis (coupling.py:48-53)
             desc = [dict(d, set_data=True) if d['kind'].startswith('coupling_') else d for d in desc]
+        for a in sys.argv:                         # --shift=k: k live 8-byte tensors ahead of the case (moves the small-block layout)
+            if a.startswith('--shift='):
+                _keep = [torch.zeros(2, dtype=torch.int32, device=DEV) for _ in range(int(a.split('=')[1]))]
+        for a in sys.argv:                         # --reset=scratch|work|alloc|te|flags: drop one piece of process-wide state before each case
+            if a.startswith('--reset='):
+                from stribor_amd import _hip as _h
+                what = a.split('=')[1]
+                if what == 'scratch': _h._scratch.clear()
+                if what == 'work': _h._work.clear()
+                if what == 'flags': _h._flag_words.clear()
+                if what == 'alloc': torch.cuda.empty_cache()
+                if what == 'te':
+                    from stribor_amd.flows import linear as _l
+                    _l._TE_CACHE.clear()
+        if '--poison' in sys.argv:
+            # the caching allocator hands freed blocks to the next torch.empty: fill a few with NaN first, so that a kernel
+            # reading memory it (or an earlier kernel of the step) never wrote shows up as NaN instead of depending on history
+            junk = [torch.full((1 << k,), float('nan'), device=DEV) for k in range(10, 27)]
+            del junk
+            from stribor_amd import _hip as _h
+            for t_ in list(_h._scratch.values()):          # ... and the library's persistent scratch (partials of earlier launches)
+                (t_[0] if isinstance(t_, (tuple, list)) else t_).fill_(float('nan'))
         torch.manual_seed(seed * 1000 + i)
         flow = fd.build_flow(st, desc, dim)
         with torch.no_grad():
@@ -223,6 +258,10 @@ def main():
         worst = max(worst, m)
         kinds = [d['kind'] + ('/' + d['spline_type'][0] if 'spline_type' in d else '') + (f":K{d['n_bins']}" if 'n_bins' in d else '') + (f":H{d['hidden']}" if 'hidden' in d else '') for d in desc]
         print(f'case {i:3d} dim {dim:2d} lat {latent} n {n:3d} {kinds}  max grad err {m:.2e}' + (f'  FAIL {bad}' if bad else ''), flush=True)
+        if '--show-work' in sys.argv:
+            from stribor_amd import _hip as _h
+            torch.cuda.synchronize()
+            print('   work counters after the case:', {k: v.tolist() for k, v in _h._work.items()}, flush=True)
     print('worst', worst)
 
 
