@@ -22,3 +22,25 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+if os.environ.get('STRIBOR_TEST_POISON') == '1':
+    # opt-in memory hygiene run of the whole suite: torch.empty / empty_like hand out NaN-filled float tensors on the GPU (set
+    # STRIBOR_POISON_SCRATCH=1 as well for the library's scratch), so an op that reads what it never wrote turns a test red
+    # instead of depending on what the caching allocator returns
+    import torch as _torch
+    _e0, _el0 = _torch.empty, _torch.empty_like
+
+    def _fill(t):
+        return t.fill_(float('nan')) if t.is_floating_point() and t.is_cuda else t
+    _torch.empty = lambda *a, **k: _fill(_e0(*a, **k))
+    _torch.empty_like = lambda *a, **k: _fill(_el0(*a, **k))
+
+    @pytest.fixture(autouse=True)
+    def _no_pending_device_flag():
+        """(poison runs) a range / discriminant flag left behind by a test would surface in a later one: name the culprit"""
+        yield
+        if _torch.cuda.is_available():
+            import stribor_amd as _st
+            _torch.cuda.synchronize()
+            _st.check_errors()
