@@ -1,6 +1,6 @@
 """Randomised differential check of the training paths: random spline / affine coupling flows (dims, widths, masks, bin counts,
 spline types, latent inputs, batch sizes) -- gradients of -log_prob.mean() from the HIP paths against fp64 autograd of the oracle.
-    python tools/fuzz_train.py [n_cases] [seed] [--forward] [--infer] [--mix] [--time] [--wide] [--fat] [--bf16] [--sets] [--poison] [--only=i ...]
+    python tools/fuzz_train.py [n_cases] [seed] [--forward] [--infer] [--mix] [--time] [--wide] [--fat] [--bf16] [--sets] [--k16] [--poison] [--only=i ...]
 (--forward: forward_and_log_det_jacobian instead of log_prob; --infer: the no-graph paths; --mix: every transform kind)"""
 import os
 import sys
@@ -35,7 +35,7 @@ def case(rng):
         if kind == 'affine':
             d['kind'] = 'coupling_affine'
         else:
-            d.update(kind='coupling_rqs', n_bins=int(rng.integers(1, 33 if FAT else 17)), lower=-3.0, upper=3.0,
+            d.update(kind='coupling_rqs', n_bins=16 if '--k16' in sys.argv else int(rng.integers(1, 33 if FAT else 17)), lower=-3.0, upper=3.0,
                      spline_type='quadratic' if kind == 'rqs' else 'cubic')
         desc.append(d)
         if rng.random() < 0.3:
