@@ -201,6 +201,21 @@ def test_planner_cubic_spline_flow_and_spline_mix_rules():
     assert st.NormalizingFlow(st.UnitNormal(64), [wide])._build_fused(True, 64, 0, dev) is None        # n_bins > 16: layer-wise tier
 
 
+def test_wide_mlp_program_chunks_write_their_own_windows():
+    """An MLP program keeps its output-tile index in 8 bits: a 511-tile output is split over launches whose tile indices
+    restart at 0, each with the column offset of its window (round 2: indices past 255 used to wrap on the device)."""
+    net = st.net.MLP(20, [48], 8192 + 2 * 4032 + 77)
+    progs = net._program(torch.device('cpu'))
+    assert len(progs) >= 5
+    col = 0
+    for pr in progs:
+        outs = [pr.prog.steps[i] for i in range(pr.prog.n_steps) if pr.prog.steps[i].kind == _hip.STEP_MLP_OUT_TILE]
+        assert [o.t0 for o in outs] == list(range(len(outs))) and len(outs) < 256
+        assert pr.mlp_col0 == col and pr.mlp_out_dim == min(32 * len(outs), net.out_dim - col)
+        col += 32 * len(outs)
+    assert col >= net.out_dim
+
+
 # ---- round 2: program-cache validity (host logic only; no GPU) -----------------------------------------------------
 def test_program_cache_epoch_guards_and_fingerprint():
     from stribor_amd.fused import ProgramCache, _STRUCT_EPOCH, bump_structure_epoch
