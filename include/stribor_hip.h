@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SX_ABI_VERSION 2
+#define SX_ABI_VERSION 3
 
 /* storage dtypes of x / y */
 #define SX_F32  0
@@ -137,16 +137,18 @@ int sx_rqs_coupling(const void *x, void *y, float *ldj, float *ldiag, const floa
 /* Backward of sx_rqs_coupling(reverse = 1) -- the direction log_prob evaluates -- for training:
  * reverse mode through rational_quadratic_spline.py:101-107,180-234.
  *   x [n_rows, dim] fp32: the values the inverse pass was given;  gout [n_rows, dim]: dL/d(output), live columns read;
- *   gldj [n_rows]: dL/d(row log-det), scaled by ldj_scale;  params as sx_rqs_coupling.
+ *   gldj [n_rows] (nullable): dL/d(row log-det), scaled by ldj_scale;  gldiag [n_rows, dim] (nullable; ABI v3): dL/d of the
+ *   per-element log-derivative (the ldiag output: Spline.log_diag_jacobian, flows/spline.py:120-143, differentiated), added to
+ *   the row adjoint of its element;  params as sx_rqs_coupling.
  *   gx [n_rows, dim]: live columns receive dL/dx;  gparams [n_rows, n_live*(3K-1)] (packed rows): dL/dparams. */
-int sx_rqs_inverse_bwd(const float *x, const float *gout, const float *gldj, const float *params,
+int sx_rqs_inverse_bwd(const float *x, const float *gout, const float *gldj, const float *gldiag, const float *params,
                        int64_t params_stride, float *gx, float *gparams, const int32_t *live_idx, int32_t live_start,
                        int32_t n_live, int32_t n_bins, float left, float right, float bottom, float top, int64_t n_rows,
                        int32_t dim, float ldj_scale, void *stream);
 
 /* The same for sx_rqs_coupling(reverse = 0), the forward direction (forward / rsample of spline flows; reverse mode through
  * rational_quadratic_spline.py:101-107,180-207,236-248; the bin is searched on the widths, the input lives in [left, right]). */
-int sx_rqs_forward_bwd(const float *x, const float *gout, const float *gldj, const float *params,
+int sx_rqs_forward_bwd(const float *x, const float *gout, const float *gldj, const float *gldiag, const float *params,
                        int64_t params_stride, float *gx, float *gparams, const int32_t *live_idx, int32_t live_start,
                        int32_t n_live, int32_t n_bins, float left, float right, float bottom, float top, int64_t n_rows,
                        int32_t dim, float ldj_scale, void *stream);
@@ -221,14 +223,16 @@ int sx_cubic_coupling(const void *x, void *y, float *ldj, float *ldiag, const fl
 /* Backward of sx_cubic_coupling(reverse = 1) for training: the cubic solve is differentiated implicitly, so the kernel is
  * handed the inverse pass's input `yin` AND its output `xout` (both [n_rows, dim] fp32); other arguments as
  * sx_rqs_inverse_bwd, gparams [n_rows, n_live*(2K+2)]. */
-int sx_cubic_inverse_bwd(const float *yin, const float *xout, const float *gout, const float *gldj, const float *params,
+int sx_cubic_inverse_bwd(const float *yin, const float *xout, const float *gout, const float *gldj, const float *gldiag,
+                         const float *params,
                          int64_t params_stride, float *gx, float *gparams, const int32_t *live_idx, int32_t live_start,
                          int32_t n_live, int32_t n_bins, float lower, float upper, int64_t n_rows, int32_t dim,
                          float ldj_scale, void *stream);
 
 /* The same for sx_cubic_coupling(reverse = 0), the forward direction (out = f(t), ljd = log f'(t), bin searched on the
  * widths): x [n_rows, dim] the forward pass's input; no solve to differentiate. */
-int sx_cubic_forward_bwd(const float *x, const float *gout, const float *gldj, const float *params, int64_t params_stride,
+int sx_cubic_forward_bwd(const float *x, const float *gout, const float *gldj, const float *gldiag, const float *params,
+                         int64_t params_stride,
                          float *gx, float *gparams, const int32_t *live_idx, int32_t live_start, int32_t n_live,
                          int32_t n_bins, float lower, float upper, int64_t n_rows, int32_t dim, float ldj_scale, void *stream);
 
@@ -251,8 +255,9 @@ int sx_pointwise(const void *x, void *y, float *ldj, float *ldiag, int64_t n_row
                  int32_t kind, float param, int32_t ldj_accumulate, void *stream);
 
 /* Backward of sx_pointwise (training): gx = gy * d(out)/dx + gldj[row] * d(log-derivative)/dx; x, gy, gx [n_rows, dim]
- * fp32, gldj [n_rows] nullable.  Cumsum / Diff: the reversed scan of gy. */
-int sx_pointwise_bwd(const float *x, const float *gy, const float *gldj, float *gx, int64_t n_rows, int32_t dim,
+ * fp32, gldj [n_rows] nullable, gldiag [n_rows, dim] nullable (the adjoint of the per-element log-derivative, ABI v3).
+ * Cumsum / Diff: the reversed scan of gy. */
+int sx_pointwise_bwd(const float *x, const float *gy, const float *gldj, const float *gldiag, float *gx, int64_t n_rows, int32_t dim,
                      int32_t kind, float param, void *stream);
 
 /* UnitNormal.log_prob + log-det accumulator (stribor/dist/normal.py:37,52-54; flow.py:128-129):

@@ -17,18 +17,16 @@ LIB_PATH = os.environ.get('STRIBOR_HIP_LIB', os.path.join(_HERE, 'libstribor_hip
 
 SX_F32, SX_BF16 = 0, 1
 SX_MAX_STEPS = 128
-SX_ABI_VERSION = 2
+SX_ABI_VERSION = 3
 GEMM_F32, GEMM_F16X3 = 0, 1
 FLAG_RQS_NEG_DISCRIMINANT, FLAG_NONFINITE, FLAG_F16_RANGE = 1, 2, 4
 
 STEP_COUPLING_AFFINE = 1
 STEP_AFFINE_CONST = 2
 STEP_LINEAR_TILE = 3
-STEP_LINEAR_COMMIT = 4
 STEP_MLP_HIDDEN = 5
 STEP_MLP_HIDDEN2 = 6
 STEP_MLP_OUT_TILE = 7
-STEP_COUPLING_RQS = 8
 STEP_ROW_SCALE_EXP = 9
 STEP_RQS_HIDDEN = 10
 STEP_RQS_PHASE = 11
@@ -89,7 +87,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.sx_cubic_coupling.restype = i32
     lib.sx_cubic_coupling.argtypes = [vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, f32, f32, i64, i32, i32, i32, i32, f32, vp]
     lib.sx_rqs_inverse_bwd.restype = i32
-    lib.sx_rqs_inverse_bwd.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, i64, i32, f32, vp]
+    lib.sx_rqs_inverse_bwd.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, i64, i32, f32, vp]
     lib.sx_rqs_slab_slots.restype = i32
     lib.sx_rqs_slab_slots.argtypes = [i32]
     lib.sx_rqs_slab_scratch_floats.restype = C.c_size_t
@@ -108,11 +106,11 @@ def _declare(lib: C.CDLL) -> None:
     lib.sx_time_affine_coupling.restype = i32
     lib.sx_time_affine_coupling.argtypes = [vp, vp, vp, vp, i64, vp, vp, i32, vp, i32, i32, i64, i32, i32, i32, i32, f32, vp]
     lib.sx_cubic_inverse_bwd.restype = i32
-    lib.sx_cubic_inverse_bwd.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, i32, f32, f32, i64, i32, f32, vp]
+    lib.sx_cubic_inverse_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, i32, f32, f32, i64, i32, f32, vp]
     lib.sx_cubic_forward_bwd.restype = i32
-    lib.sx_cubic_forward_bwd.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, i32, f32, f32, i64, i32, f32, vp]
+    lib.sx_cubic_forward_bwd.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, i32, f32, f32, i64, i32, f32, vp]
     lib.sx_pointwise_bwd.restype = i32
-    lib.sx_pointwise_bwd.argtypes = [vp, vp, vp, vp, i64, i32, i32, f32, vp]
+    lib.sx_pointwise_bwd.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, f32, vp]
     lib.sx_pointwise.restype = i32
     lib.sx_pointwise.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, f32, i32, vp]
     lib.sx_unit_normal_logprob.restype = i32

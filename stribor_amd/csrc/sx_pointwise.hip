@@ -350,12 +350,12 @@ __device__ __forceinline__ float pw_grad(int kind, float param, float x, float g
 }
 
 __global__ __launch_bounds__(256) void pointwise_bwd_kernel(const float *__restrict__ x, const float *__restrict__ gy,
-                                                            const float *__restrict__ gldj, float *__restrict__ gx,
-                                                            int64_t n_rows, int dim, int kind, float param) {
+                                                            const float *__restrict__ gldj, const float *__restrict__ gldiag,
+                                                            float *__restrict__ gx, int64_t n_rows, int dim, int kind, float param) {
     const int64_t total = n_rows * dim;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
-        gx[i] = pw_grad(kind, param, x[i], gy[i], gldj ? gldj[i / dim] : 0.f);
+        gx[i] = pw_grad(kind, param, x[i], gy[i], (gldj ? gldj[i / dim] : 0.f) + (gldiag ? gldiag[i] : 0.f));
 }
 
 // cumsum's adjoint is the reversed cumsum, diff's the reversed diff: one lane per row, from the last column back
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void cumsum_bwd_kernel(const float *__restrict
     }
 }
 
-extern "C" int sx_pointwise_bwd(const float *x, const float *gy, const float *gldj, float *gx, int64_t n_rows, int32_t dim,
+extern "C" int sx_pointwise_bwd(const float *x, const float *gy, const float *gldj, const float *gldiag, float *gx, int64_t n_rows, int32_t dim,
                                 int32_t kind, float param, void *stream) {
     SX_REQUIRE(x && gy && gx, "sx_pointwise_bwd: null pointer");
     SX_REQUIRE(dim > 0 && n_rows >= 0, "sx_pointwise_bwd: bad sizes");
@@ -387,7 +387,7 @@ extern "C" int sx_pointwise_bwd(const float *x, const float *gy, const float *gl
     } else {
         int64_t g = (n_rows * dim + 255) / 256;
         if (g > 2048) g = 2048;
-        hipLaunchKernelGGL(pointwise_bwd_kernel, dim3((int)g), dim3(256), 0, st, x, gy, gldj, gx, n_rows, dim, kind, param);
+        hipLaunchKernelGGL(pointwise_bwd_kernel, dim3((int)g), dim3(256), 0, st, x, gy, gldj, gldiag, gx, n_rows, dim, kind, param);
     }
     SX_LAUNCH_CHECK();
     return SX_OK;

@@ -857,6 +857,7 @@ extern "C" int sx_cubic_coupling(const void *x, void *y, float *ldj, float *ldia
 template <bool INVERSE>
 __global__ __launch_bounds__(256) void rqs_bwd_kernel(const float *__restrict__ x, const float *__restrict__ gout,
                                                               const float *__restrict__ gldj,
+                                                              const float *__restrict__ gldiag,
                                                               const float *__restrict__ params, int64_t pstride,
                                                               float *__restrict__ gx, float *__restrict__ gparams,
                                                               const int32_t *__restrict__ live_idx, int l0, int n_live,
@@ -897,7 +898,8 @@ __global__ __launch_bounds__(256) void rqs_bwd_kernel(const float *__restrict__ 
         const int col = live_idx ? live_idx[i] : l0 + i;
         const float xv = valid ? x[row * dim + col] : (INVERSE ? bottom : left);
         const float Ao = valid ? gout[row * dim + col] : 0.f;            // dL/d out
-        const float Al = valid ? gldj[row] * ldj_scale : 0.f;            // dL/d ljd (the row sum's adjoint)
+        // dL/d ljd: the row sum's adjoint (+ the element's own, when the caller differentiates log_diag_jacobian)
+        const float Al = valid ? ((gldj ? gldj[row] : 0.f) + (gldiag ? gldiag[row * dim + col] : 0.f)) * ldj_scale : 0.f;
         float *uw = sp + (valid ? lane : 0) * P;
         const float gxe = rqs_bwd_element<INVERSE>(uw, K, xv, Ao, Al, left, right, bottom, top, valid);
         if (valid) gx[row * dim + col] = gxe;
@@ -914,11 +916,11 @@ __global__ __launch_bounds__(256) void rqs_bwd_kernel(const float *__restrict__ 
     }
 }
 
-static int rqs_bwd_launch(bool inverse, const float *x, const float *gout, const float *gldj, const float *params,
+static int rqs_bwd_launch(bool inverse, const float *x, const float *gout, const float *gldj, const float *gldiag, const float *params,
                                   int64_t params_stride, float *gx, float *gparams, const int32_t *live_idx,
                                   int32_t live_start, int32_t n_live, int32_t n_bins, float left, float right,
                                   float bottom, float top, int64_t n_rows, int32_t dim, float ldj_scale, void *stream) {
-    SX_REQUIRE(x && gout && gldj && params && gx && gparams, "sx_rqs_*_bwd: null pointer");
+    SX_REQUIRE(x && gout && (gldj || gldiag) && params && gx && gparams, "sx_rqs_*_bwd: null pointer");
     SX_REQUIRE(dim > 0 && n_live > 0 && n_live <= dim && n_rows >= 0 && n_bins >= 1, "sx_rqs_*_bwd: bad sizes");
     SX_REQUIRE(right > left && top > bottom, "sx_rqs_*_bwd: empty domain");
     if (n_rows == 0) return SX_OK;
@@ -938,29 +940,29 @@ static int rqs_bwd_launch(bool inverse, const float *x, const float *gout, const
     if (grid > 256 * per_cu) grid = 256 * per_cu;
     if (grid < 1) grid = 1;
     if (inverse)
-        hipLaunchKernelGGL(rqs_bwd_kernel<true>, dim3((int)grid), dim3(block), lds, sx_stream(stream), x, gout, gldj, params,
+        hipLaunchKernelGGL(rqs_bwd_kernel<true>, dim3((int)grid), dim3(block), lds, sx_stream(stream), x, gout, gldj, gldiag, params,
                            params_stride, gx, gparams, live_idx, live_start, n_live, n_bins, left, right, bottom, top, n_rows,
                            dim, ldj_scale);
     else
-        hipLaunchKernelGGL(rqs_bwd_kernel<false>, dim3((int)grid), dim3(block), lds, sx_stream(stream), x, gout, gldj, params,
+        hipLaunchKernelGGL(rqs_bwd_kernel<false>, dim3((int)grid), dim3(block), lds, sx_stream(stream), x, gout, gldj, gldiag, params,
                            params_stride, gx, gparams, live_idx, live_start, n_live, n_bins, left, right, bottom, top, n_rows,
                            dim, ldj_scale);
     SX_LAUNCH_CHECK();
     return SX_OK;
 }
 
-extern "C" int sx_rqs_inverse_bwd(const float *x, const float *gout, const float *gldj, const float *params,
+extern "C" int sx_rqs_inverse_bwd(const float *x, const float *gout, const float *gldj, const float *gldiag, const float *params,
                                   int64_t params_stride, float *gx, float *gparams, const int32_t *live_idx,
                                   int32_t live_start, int32_t n_live, int32_t n_bins, float left, float right,
                                   float bottom, float top, int64_t n_rows, int32_t dim, float ldj_scale, void *stream) {
-    return rqs_bwd_launch(true, x, gout, gldj, params, params_stride, gx, gparams, live_idx, live_start, n_live, n_bins, left, right,
+    return rqs_bwd_launch(true, x, gout, gldj, gldiag, params, params_stride, gx, gparams, live_idx, live_start, n_live, n_bins, left, right,
                           bottom, top, n_rows, dim, ldj_scale, stream);
 }
-extern "C" int sx_rqs_forward_bwd(const float *x, const float *gout, const float *gldj, const float *params,
+extern "C" int sx_rqs_forward_bwd(const float *x, const float *gout, const float *gldj, const float *gldiag, const float *params,
                                   int64_t params_stride, float *gx, float *gparams, const int32_t *live_idx,
                                   int32_t live_start, int32_t n_live, int32_t n_bins, float left, float right,
                                   float bottom, float top, int64_t n_rows, int32_t dim, float ldj_scale, void *stream) {
-    return rqs_bwd_launch(false, x, gout, gldj, params, params_stride, gx, gparams, live_idx, live_start, n_live, n_bins, left, right,
+    return rqs_bwd_launch(false, x, gout, gldj, gldiag, params, params_stride, gx, gparams, live_idx, live_start, n_live, n_bins, left, right,
                           bottom, top, n_rows, dim, ldj_scale, stream);
 }
 
@@ -978,6 +980,7 @@ extern "C" int sx_rqs_forward_bwd(const float *x, const float *gout, const float
 template <bool INVERSE>
 __global__ __launch_bounds__(256) void cubic_bwd_kernel(const float *__restrict__ yin, const float *__restrict__ xout,
                                                                 const float *__restrict__ gout, const float *__restrict__ gldj,
+                                                                const float *__restrict__ gldiag,
                                                                 const float *__restrict__ params, int64_t pstride,
                                                                 float *__restrict__ gx, float *__restrict__ gparams,
                                                                 const int32_t *__restrict__ live_idx, int l0, int n_live,
@@ -1014,7 +1017,7 @@ __global__ __launch_bounds__(256) void cubic_bwd_kernel(const float *__restrict_
         const float yv = valid ? yin[row * dim + col] : lower;
         const float xo = (INVERSE && valid) ? xout[row * dim + col] : lower;
         const float Ao = valid ? gout[row * dim + col] : 0.f;
-        const float Al = valid ? gldj[row] * ldj_scale : 0.f;
+        const float Al = valid ? ((gldj ? gldj[row] : 0.f) + (gldiag ? gldiag[row * dim + col] : 0.f)) * ldj_scale : 0.f;
         const bool inside = (yv >= lower) && (yv <= upper);
         const float yn = ((inside ? yv : lower) - lower) / span;
         float *p = sp + (valid ? lane : 0) * PS;
@@ -1144,11 +1147,11 @@ __global__ __launch_bounds__(256) void cubic_bwd_kernel(const float *__restrict_
     }
 }
 
-static int cubic_bwd_launch(bool inverse, const float *yin, const float *xout, const float *gout, const float *gldj,
+static int cubic_bwd_launch(bool inverse, const float *yin, const float *xout, const float *gout, const float *gldj, const float *gldiag,
                                     const float *params, int64_t params_stride, float *gx, float *gparams,
                                     const int32_t *live_idx, int32_t live_start, int32_t n_live, int32_t n_bins, float lower,
                                     float upper, int64_t n_rows, int32_t dim, float ldj_scale, void *stream) {
-    SX_REQUIRE(yin && (xout || !inverse) && gout && gldj && params && gx && gparams, "sx_cubic_*_bwd: null pointer");
+    SX_REQUIRE(yin && (xout || !inverse) && gout && (gldj || gldiag) && params && gx && gparams, "sx_cubic_*_bwd: null pointer");
     SX_REQUIRE(dim > 0 && n_live > 0 && n_live <= dim && n_rows >= 0 && n_bins >= 1, "sx_cubic_inverse_bwd: bad sizes");
     SX_REQUIRE(upper > lower, "sx_cubic_inverse_bwd: empty domain");
     if (n_rows == 0) return SX_OK;
@@ -1169,27 +1172,27 @@ static int cubic_bwd_launch(bool inverse, const float *yin, const float *xout, c
     if (grid > 256 * per_cu) grid = 256 * per_cu;
     if (grid < 1) grid = 1;
     if (inverse)
-        hipLaunchKernelGGL(cubic_bwd_kernel<true>, dim3((int)grid), dim3(block), lds, sx_stream(stream), yin, xout, gout, gldj,
+        hipLaunchKernelGGL(cubic_bwd_kernel<true>, dim3((int)grid), dim3(block), lds, sx_stream(stream), yin, xout, gout, gldj, gldiag,
                            params, params_stride, gx, gparams, live_idx, live_start, n_live, n_bins, lower, upper, n_rows, dim,
                            ldj_scale);
     else
-        hipLaunchKernelGGL(cubic_bwd_kernel<false>, dim3((int)grid), dim3(block), lds, sx_stream(stream), yin, xout, gout, gldj,
+        hipLaunchKernelGGL(cubic_bwd_kernel<false>, dim3((int)grid), dim3(block), lds, sx_stream(stream), yin, xout, gout, gldj, gldiag,
                            params, params_stride, gx, gparams, live_idx, live_start, n_live, n_bins, lower, upper, n_rows, dim,
                            ldj_scale);
     SX_LAUNCH_CHECK();
     return SX_OK;
 }
-extern "C" int sx_cubic_inverse_bwd(const float *yin, const float *xout, const float *gout, const float *gldj,
+extern "C" int sx_cubic_inverse_bwd(const float *yin, const float *xout, const float *gout, const float *gldj, const float *gldiag,
                                     const float *params, int64_t params_stride, float *gx, float *gparams,
                                     const int32_t *live_idx, int32_t live_start, int32_t n_live, int32_t n_bins, float lower,
                                     float upper, int64_t n_rows, int32_t dim, float ldj_scale, void *stream) {
-    return cubic_bwd_launch(true, yin, xout, gout, gldj, params, params_stride, gx, gparams, live_idx, live_start, n_live, n_bins,
+    return cubic_bwd_launch(true, yin, xout, gout, gldj, gldiag, params, params_stride, gx, gparams, live_idx, live_start, n_live, n_bins,
                             lower, upper, n_rows, dim, ldj_scale, stream);
 }
-extern "C" int sx_cubic_forward_bwd(const float *x, const float *gout, const float *gldj, const float *params,
+extern "C" int sx_cubic_forward_bwd(const float *x, const float *gout, const float *gldj, const float *gldiag, const float *params,
                                     int64_t params_stride, float *gx, float *gparams, const int32_t *live_idx,
                                     int32_t live_start, int32_t n_live, int32_t n_bins, float lower, float upper,
                                     int64_t n_rows, int32_t dim, float ldj_scale, void *stream) {
-    return cubic_bwd_launch(false, x, nullptr, gout, gldj, params, params_stride, gx, gparams, live_idx, live_start, n_live, n_bins,
+    return cubic_bwd_launch(false, x, nullptr, gout, gldj, gldiag, params, params_stride, gx, gparams, live_idx, live_start, n_live, n_bins,
                             lower, upper, n_rows, dim, ldj_scale, stream);
 }

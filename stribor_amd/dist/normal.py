@@ -21,6 +21,9 @@ class UnitNormal(nn.Module):
         """[..., dim] -> [...]  (sum_d -x^2/2 - dim*log(sqrt(2*pi)), dist/normal.py:37)."""
         _hip.require_device(x, 'x')
         assert x.shape[-1] == self.dim
+        if torch.is_grad_enabled() and x.requires_grad:       # differentiable like torch's Independent(Normal) (normal.py:37)
+            xf = x.to(torch.float32)
+            return -0.5 * (xf * xf).sum(-1) - self.dim * 0.9189385332046727
         x2 = x.reshape(-1, self.dim).contiguous()
         out = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device)
         _hip.call('sx_unit_normal_logprob', x2, x2.data_ptr(), None, out.data_ptr(), x2.shape[0], self.dim,

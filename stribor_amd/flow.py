@@ -20,7 +20,7 @@ HALF_LOG_2PI = 0.9189385332046727          # log(sqrt(2 pi)), dist/normal.py:37
 from . import _hip
 from .fused import CompiledProgram, ProgramBuilder, ProgramCache, StructureTracked
 
-__all__ = ['Transform', 'ElementwiseTransform', 'NormalizingFlow']
+__all__ = ['Transform', 'ElementwiseTransform', 'NormalizingFlow', 'graph_wanted', 'graph_rows']
 
 
 class _FusedLogProb(torch.autograd.Function):
@@ -187,6 +187,26 @@ _FusedLogProb._layer_major_ok = staticmethod(_layer_major_ok)
 _FusedLogProb._backward_layer_major = staticmethod(_backward_layer_major)
 
 
+def graph_wanted(module, *tensors) -> bool:
+    """Does this call have to build an autograd graph?  In the reference every Transform method is differentiable
+    (flow.py:35-47, coupling.py:69-95; its own harness differentiates stand-alone f and f.inverse, test/base.py:24-33), so a
+    stand-alone layer call under grad mode whose input (latent, t) or parameters require grad runs through the layer's autograd
+    ops (HIP kernels with hand-written backwards) instead of the no-graph kernels."""
+    if not torch.is_grad_enabled():
+        return False
+    for t in tensors:
+        if torch.is_tensor(t) and t.requires_grad:
+            return True
+    return module is not None and any(p.requires_grad for p in module.parameters())
+
+
+def graph_rows(x, latent=None):
+    """[..., D] (any storage dtype) -> fp32 rows for the autograd ops: (x2 [N, D], lat2 [N, Ld] | None, lead shape)."""
+    x2, lead = flatten_rows(x.to(torch.float32))
+    lat2 = None if latent is None else latent.reshape(-1, latent.shape[-1]).to(torch.float32)
+    return x2, lat2, lead
+
+
 def flatten_rows(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Size]:
     """[..., D] -> contiguous [N, D] plus the leading shape (the kernels see rows = samples)."""
     lead = x.shape[:-1]
@@ -340,6 +360,8 @@ class NormalizingFlow(Transform):
             # ends in (= the layout z is read back in), then undo it layer by layer on the way back
             for f in rev:
                 if isinstance(f, _ColumnShuffle):
+                    if not f._feature_only():
+                        raise NotImplementedError('Flip over a non-feature axis moves rows: layer-wise path')
                     b.add_permutation(f._perm(dim).cpu().numpy(), True)
             b.in_col = None                      # the backward program's input layout is the forward's final one
             b.steps = []
@@ -397,6 +419,11 @@ class NormalizingFlow(Transform):
         dense = derive_dense_batched([f for f in self.transforms if f not in timed], x2.device, reverse)   # batched fp64 ops
         cur, total = x2, None
         for f in (reversed(self.transforms) if reverse else self.transforms):
+            if isinstance(f, _ColumnShuffle) and not f._feature_only():
+                # Flip over other axes moves whole rows (permute.py:35,38): torch.flip on the unflattened state, which is
+                # differentiable and its own inverse -- NOT the column reversal f._perm describes
+                cur = torch.flip(cur.reshape(*lead, cur.shape[1]), f.dims).reshape(-1, cur.shape[1])
+                continue
             if isinstance(f, _ColumnShuffle):
                 def build_idx(f=f, d=cur.shape[1], dev=cur.device):
                     perm = f._perm(d).to(dev).long()

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .. import _hip
-from ..flow import ElementwiseTransform, flatten_rows
+from ..flow import ElementwiseTransform, flatten_rows, graph_rows, graph_wanted
 
 __all__ = ['Affine']
 
@@ -99,24 +99,51 @@ class Affine(ElementwiseTransform):
         y, ldj = run_affine_kernel(x2, params, stride, None, 0, d, reverse, want_y, want_ldj, ldj_scale)
         return (y.reshape(*lead, d) if want_y else None), (None if ldj is None else ldj.reshape(*lead, 1))
 
-    # ---- reference method set (affine.py:69-123) ---------------------------------------------------------
+    # ---- reference method set (affine.py:69-123): differentiable like the reference's (see flow.graph_wanted) -----------
+    def _graph(self, x, latent, reverse: bool):
+        _hip.require_device(x, 'x')
+        x2, lat2, lead = graph_rows(x, latent)
+        y, ldj = self._autograd_inverse(x2, lat2, reverse=reverse)
+        return y.reshape(*lead, x2.shape[1]), ldj.reshape(*lead, 1)
+
     def forward(self, x, latent=None, **kwargs):
+        if graph_wanted(self, x, latent):
+            return self._graph(x, latent, False)[0]
         return self._launch(x, latent, False, True, False)[0]
 
     def inverse(self, y, latent=None, **kwargs):
+        if graph_wanted(self, y, latent):
+            return self._graph(y, latent, True)[0]
         return self._launch(y, latent, True, True, False)[0]
 
     def log_det_jacobian(self, x, y=None, latent=None, **kwargs):
+        if graph_wanted(self, x, latent):
+            return self.log_diag_jacobian(x, y, latent=latent).sum(-1, keepdim=True)      # affine.py:119-120
         return self._launch(x, latent, False, False, True)[1]
 
     def forward_and_log_det_jacobian(self, x, latent=None, *, reverse: bool = False, **kwargs):
+        if graph_wanted(self, x, latent):
+            y, ldj = self._graph(x, latent, reverse)
+            return y, (-ldj if reverse else ldj)                               # affine.py:97-109: +sum(log_scale) either way
         return self._launch(x, latent, reverse, True, True)                    # affine.py:97-109
 
     def inverse_and_log_det_jacobian(self, y, latent=None, **kwargs):
+        if graph_wanted(self, y, latent):
+            return self._graph(y, latent, True)
         return self._launch(y, latent, True, True, True, ldj_scale=-1.0)      # affine.py:111-113
 
     def log_diag_jacobian(self, x, y=None, latent=None, **kwargs):
         x2, lead = flatten_rows(x)
+        if graph_wanted(self, x, latent):                                     # the parameters keep their graph
+            d = x2.shape[1]
+            if self.latent_net is None:
+                ls = self.log_scale.reshape(-1)
+                ls = (ls.expand(d) if ls.numel() == 1 else ls).to(x.device, torch.float32).expand(x2.shape[0], d)
+            else:
+                if latent is None:
+                    raise ValueError('Affine with a latent_net needs `latent`')
+                ls = self.latent_net(latent.reshape(-1, latent.shape[-1]))[..., :d]       # affine.py:66,122-123
+            return ls.reshape(*lead, d)
         params, stride = self._params(x2, latent)
         ls = params[..., :x2.shape[1]]                                        # affine.py:122-123
         if stride == 0:
@@ -129,6 +156,12 @@ class Affine(ElementwiseTransform):
 
     def _autograd_forward(self, x2: torch.Tensor, lat2=None):
         return self._autograd_inverse(x2, lat2, reverse=False)
+
+    def _autograd_from_params(self, x2: torch.Tensor, params: torch.Tensor, reverse: bool):
+        """(out, log-det [N]) of every column from a per-row parameter tensor [N, 2D] (log_scale | shift, affine.py:66) with a
+        graph: inverse_and_log_det_jacobian (reverse) or forward_and_log_det_jacobian (affine.py:97-113)."""
+        return AffineCouplingOp.apply(x2, params.to(torch.float32).contiguous(), None, 0, x2.shape[1], bool(reverse),
+                                      -1.0 if reverse else 1.0)
 
     def _autograd_inverse(self, x2: torch.Tensor, lat2=None, reverse: bool = True):
         """inverse_and_log_det_jacobian (or, reverse=False, forward_and_log_det_jacobian) on fp32 rows with a graph
@@ -145,7 +178,7 @@ class Affine(ElementwiseTransform):
                 raise ValueError('Affine with a latent_net needs `latent`')
             net = self.latent_net
             params = net.forward_autograd(lat2) if hasattr(net, 'forward_autograd') else net(lat2)   # affine.py:66
-        return AffineCouplingOp.apply(x2, params.contiguous(), None, 0, d, bool(reverse), -1.0 if reverse else 1.0)   # affine.py:97-113
+        return self._autograd_from_params(x2, params, reverse)
 
     # ---- fused-program hooks --------------------------------------------------------------------------------
     def _plan_hidden_width(self):

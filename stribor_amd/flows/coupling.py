@@ -26,7 +26,7 @@ import torch
 import torch.nn as nn
 
 from .. import _hip
-from ..flow import Transform, flatten_rows
+from ..flow import Transform, flatten_rows, graph_rows, graph_wanted
 from ..fused import ProgramBuilder, ProgramCache, _STRUCT_EPOCH
 from ..net.mlp import MLP, _chunk_mlp_program
 from ..util.mask import get_mask
@@ -197,15 +197,35 @@ class Coupling(Transform):
         sel = self._programs.get(('set-rows', rows, N, str(dev)), lambda: torch.from_numpy(
             (np.arange(rows // N)[:, None] * N + live_n[None, :]).reshape(-1).astype(np.int64)).to(dev))
         xt = x2.index_select(0, sel)                                                   # the transformed elements, compact
-        z = torch.zeros(xt.shape[0], d, dtype=torch.float32, device=dev)               # x * mask = 0 on these rows
-        if lat2 is not None:
-            z = torch.cat([z, lat2.index_select(0, sel).to(torch.float32)], -1)
-        params = self.transform.latent_net(z)
+        params = self._set_params(x2, lat2, N, m, sel)
         yt, lt = self._transform_rows(xt, params, np.arange(d), reverse, want_ldj, ldj_scale)
         y.index_copy_(0, sel, yt)
         if want_ldj:
             ldj.index_copy_(0, sel, lt)
         return y, ldj
+
+    def _set_params(self, x2, lat2, N: int, m: np.ndarray, sel: torch.Tensor) -> torch.Tensor:
+        """The conditioner's output for the transformed set elements (rows `sel` of the [B * N, .] rows).  A row-wise conditioner
+        (net.MLP) only ever sees z = cat[0, latent] on those rows, so it is called on the compact rows.  Any other module may look
+        ACROSS the set (DeepSets / attention conditioners pool over the N axis, which is what set_data is for): it gets exactly
+        the reference's z = cat[x * mask, latent] of shape (B, N, .) -- pass-through elements included -- in ONE call
+        (coupling.py:49-51,61-65), and the transformed elements' rows of its output are selected afterwards."""
+        rows, d = x2.shape
+        dev = x2.device
+        net = self.transform.latent_net
+        if isinstance(net, MLP):
+            z = torch.zeros(sel.numel(), d, dtype=torch.float32, device=dev)           # x * mask = 0 on these rows
+            if lat2 is not None:
+                z = torch.cat([z, lat2.index_select(0, sel).to(torch.float32)], -1)
+            return net(z)
+        mask_t = self._programs.get(('set-mask', N, str(dev)), lambda: torch.from_numpy(m.astype(np.float32)).to(dev).reshape(N, 1))
+        z = x2.to(torch.float32).reshape(rows // N, N, d) * mask_t                     # coupling.py:49-51,61
+        if d == 1:
+            z = z * 0                                                                  # coupling.py:62-63
+        if lat2 is not None:
+            z = torch.cat([z, lat2.to(torch.float32).reshape(rows // N, N, -1)], -1)   # coupling.py:64-65
+        out = net(z)
+        return out.reshape(rows, out.shape[-1]).index_select(0, sel)
 
     # ---- affine, unfused: pruned conditioner (MFMA program) + HBM-bound element-wise kernel -----------------
     def _affine_unfused_program(self, dim: int, latent_dim: int, device):
@@ -304,10 +324,15 @@ class Coupling(Transform):
         sel = self._programs.get(('set-rows', rows, N, str(dev)), lambda: torch.from_numpy(
             (np.arange(rows // N)[:, None] * N + live_n[None, :]).reshape(-1).astype(np.int64)).to(dev))
         xt = x2.index_select(0, sel)
-        z = torch.zeros(xt.shape[0], d, dtype=torch.float32, device=dev)               # x * mask = 0 on these rows
-        if lat2 is not None:
-            z = torch.cat([z, lat2.index_select(0, sel).to(torch.float32)], -1)
-        yt, lt = self.transform._autograd_inverse(xt.contiguous(), z, reverse=reverse)
+        net = self.transform.latent_net
+        if isinstance(net, MLP):
+            z = torch.zeros(xt.shape[0], d, dtype=torch.float32, device=dev)           # x * mask = 0 on these rows
+            if lat2 is not None:
+                z = torch.cat([z, lat2.index_select(0, sel).to(torch.float32)], -1)
+            yt, lt = self.transform._autograd_inverse(xt.contiguous(), z, reverse=reverse)
+        else:                       # a set-aware conditioner sees the whole set (coupling.py:61-65): torch's graph through it
+            params = self._set_params(x2, lat2, N, self.mask_vector(N), sel)
+            yt, lt = self.transform._autograd_from_params(xt.contiguous(), params, reverse)
         return x2.index_copy(0, sel, yt), zero.index_copy(0, sel, lt.reshape(-1))
 
     def _autograd_forward(self, x2: torch.Tensor, lat2=None):
@@ -430,19 +455,47 @@ class Coupling(Transform):
                                      sp.upper, pre_tanh, cubic)
 
     # ---- reference method set (coupling.py:69-95) -----------------------------------------------------------
+    # Every method is differentiable like the reference's: when a graph is wanted (grad mode and the input, the latent or a
+    # parameter requires grad) the call runs through the layer's autograd ops (`_graph`), otherwise through the no-graph tiers.
+    def _graph(self, x, latent, reverse: bool):
+        """(out [..., D], log-det [..., 1]) WITH a graph: forward_and_log_det_jacobian, or -- reverse -- what
+        inverse_and_log_det_jacobian returns (flow.py:42-47)."""
+        _hip.require_device(x, 'x')
+        from .spline import Spline
+        if not isinstance(self.transform, (Affine, Spline)) or getattr(self.transform, 'latent_net', None) is None:
+            raise NotImplementedError(f'Coupling({type(self.transform).__name__}) is not on the hot path')
+        x2, lat2, lead = graph_rows(x, latent)
+        if self.set_data:
+            if x.dim() < 2:
+                raise ValueError('set_data=True needs inputs of shape (..., N, dim)')
+            y, ldj = self._autograd_set(x2, lat2, x.shape[-2], reverse)
+        else:
+            y, ldj = self._autograd_inverse(x2, lat2, reverse=reverse)
+        return y.reshape(*lead, x2.shape[1]), ldj.reshape(*lead, 1)
+
     def forward(self, x, latent=None, reverse: bool = False, **kwargs):
+        if graph_wanted(self, x, latent):
+            return self._graph(x, latent, reverse)[0]
         return self._run(x, latent, reverse, True, False)[0]
 
     def inverse(self, y, latent=None, **kwargs):
+        if graph_wanted(self, y, latent):
+            return self._graph(y, latent, True)[0]
         return self._run(y, latent, True, True, False)[0]                            # coupling.py:81-82 (Q3)
 
     def log_det_jacobian(self, x, y=None, latent=None, **kwargs):
+        if graph_wanted(self, x, latent):
+            return self._graph(x, latent, False)[1]
         return self._run(x, latent, False, False, True)[1]
 
     def forward_and_log_det_jacobian(self, x, latent=None, **kwargs):
+        if graph_wanted(self, x, latent):
+            return self._graph(x, latent, False)
         return self._run(x, latent, False, True, True)
 
     def inverse_and_log_det_jacobian(self, y, latent=None, **kwargs):
+        if graph_wanted(self, y, latent):
+            return self._graph(y, latent, True)
         if isinstance(self.transform, Affine):
             # the log-scales that invert y are the forward log-det at x (same conditioner input): one launch
             return self._run(y, latent, True, True, True, ldj_scale=-1.0)

@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from .. import _hip
-from ..flow import Transform, flatten_rows
+from ..flow import Transform, flatten_rows, graph_rows, graph_wanted
 from ..fused import ProgramBuilder, ProgramCache
 from ..net.mlp import batch_linear
 
@@ -235,20 +235,37 @@ class AffineLU(_DenseLinear):
         builder.add_linear([self.weight, self.log_diag, self.bias], self._matrices(reverse), ldj)
         return True
 
+    # ---- reference method set (affine.py:156-179): differentiable like the reference's (see flow.graph_wanted) -------
+    def _graph(self, x, reverse: bool):
+        _hip.require_device(x, 'x')
+        x2, _, lead = graph_rows(x)
+        y, ldj = (self._autograd_inverse if reverse else self._autograd_forward)(x2)
+        return y.reshape(*lead, x2.shape[1]), ldj.reshape(*lead, 1)
+
     def forward(self, x, **kwargs):
+        if graph_wanted(self, x):
+            return self._graph(x, False)[0]
         return self._run(x, False, True, False, 1.0)[0]
 
     def inverse(self, y, **kwargs):
+        if graph_wanted(self, y):
+            return self._graph(y, True)[0]
         return self._run(y, True, True, False, 1.0)[0]
 
     def log_det_jacobian(self, x, y=None, **kwargs):
+        if graph_wanted(self, x):
+            return self.log_diag.to(x.device, torch.float32).sum().expand(*x.shape[:-1], 1)     # affine.py:171, with its graph
         ld = self.log_diag.detach().to(x.device, torch.float32).sum()
         return ld.expand(*x.shape[:-1], 1).clone()                          # affine.py:171
 
     def forward_and_log_det_jacobian(self, x, **kwargs):
+        if graph_wanted(self, x):
+            return self._graph(x, False)
         return self._run(x, False, True, True, 1.0)
 
     def inverse_and_log_det_jacobian(self, y, **kwargs):
+        if graph_wanted(self, y):
+            return self._graph(y, True)
         return self._run(y, True, True, True, -1.0)
 
     def jacobian(self, x, y=None, **kwargs):
@@ -379,22 +396,42 @@ class MatrixExponential(_DenseLinear):
         builder.add_linear(self._sources(), collapsed, ldj)
         return True
 
+    # ---- reference method set (affine.py:243-288): differentiable like the reference's (see flow.graph_wanted) -------
+    def _graph(self, x, t, reverse: bool):
+        _hip.require_device(x, 'x')
+        x2, _, lead = graph_rows(x)
+        if torch.is_tensor(t) or float(t) != 1.0:
+            y, ldj = self._autograd_time(x2, t, reverse)
+        else:
+            y, ldj = (self._autograd_inverse if reverse else self._autograd_forward)(x2)
+        return y.reshape(*lead, x2.shape[1]), ldj.reshape(*lead, 1)
+
     def forward(self, x, t=1.0, *, reverse: bool = False, **kwargs):
+        if graph_wanted(self, x, t):
+            return self._graph(x, t, reverse)[0]
         return self._run(x, reverse, True, False, 1.0, t)[0]
 
     def inverse(self, y, t=1.0, **kwargs):
+        if graph_wanted(self, y, t):
+            return self._graph(y, t, True)[0]
         return self._run(y, True, True, False, 1.0, t)[0]                    # affine.py:272-278
 
     def log_det_jacobian(self, x, y=None, t=1.0, **kwargs):
-        s = self.diag.detach().to(x.device, torch.float32).sum()
+        graph = graph_wanted(self, x, t)
+        s = (self.diag if graph else self.diag.detach()).to(x.device, torch.float32).sum()
         if torch.is_tensor(t):
             tt = t.to(x.device, torch.float32)
             tt = torch.log1p(tt.abs()) if self.log_time else tt
             return s * tt                                                    # [..., 1]
-        return (s * self._t_eff(float(t))).expand(*x.shape[:-1], 1).clone()
+        out = (s * self._t_eff(float(t))).expand(*x.shape[:-1], 1)
+        return out if graph else out.clone()
 
     def forward_and_log_det_jacobian(self, x, t=1.0, **kwargs):
+        if graph_wanted(self, x, t):
+            return self._graph(x, t, False)
         return self._run(x, False, True, True, 1.0, t)
 
     def inverse_and_log_det_jacobian(self, y, t=1.0, **kwargs):
+        if graph_wanted(self, y, t):
+            return self._graph(y, t, True)
         return self._run(y, True, True, True, -1.0, t)

@@ -10,13 +10,15 @@ import numpy as np
 import torch
 
 from .. import _hip
-from ..flow import ElementwiseTransform, flatten_rows
+from ..flow import ElementwiseTransform, flatten_rows, graph_wanted
 
 __all__ = ['Flip', 'Permute']
 
 
 def _gather_columns(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     _hip.require_device(x, 'x')
+    if graph_wanted(None, x):            # differentiable like the reference's x[..., perm] (permute.py:71,75)
+        return x.index_select(-1, idx.to(device=x.device, dtype=torch.long))
     if x.element_size() not in (2, 4):
         raise TypeError(f'sx_permute moves 2- or 4-byte elements (got {x.dtype})')
     x2, lead = flatten_rows(x)
@@ -30,6 +32,10 @@ def _gather_columns(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 class _ColumnShuffle(ElementwiseTransform):
     def _perm(self, dim: int) -> torch.Tensor:
         raise NotImplementedError
+
+    def _feature_only(self) -> bool:
+        """The layer only moves columns (what `_perm` describes); Flip over other axes overrides this."""
+        return True
 
     def _inv(self, dim: int) -> torch.Tensor:
         p = self._perm(dim)

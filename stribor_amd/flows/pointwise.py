@@ -9,7 +9,7 @@ import math
 import torch
 
 from .. import _hip
-from ..flow import ElementwiseTransform, flatten_rows
+from ..flow import ElementwiseTransform, flatten_rows, graph_rows, graph_wanted
 
 __all__ = ['Sigmoid', 'Logit', 'ELU', 'LeakyReLU', 'Cumsum', 'Diff', 'Identity']
 
@@ -31,31 +31,36 @@ def run_pointwise(x, kind, param=0.0, want_y=True, want_ldj=False, want_ldiag=Fa
 
 
 class PointwiseOp(torch.autograd.Function):
-    """(out, row log-det) of one sx_pointwise kind as a differentiable op; backward = sx_pointwise_bwd."""
+    """(out, row log-det[, per-element log-derivative]) of one sx_pointwise kind as a differentiable op; backward =
+    sx_pointwise_bwd (the adjoint of the per-element output rides on it as `gldiag`, ABI v3)."""
 
     @staticmethod
-    def forward(ctx, x2, kind, param):
+    def forward(ctx, x2, kind, param, want_ldiag=False):
         x2 = x2.contiguous()
-        y, ldj, _ = run_pointwise(x2, kind, param, want_ldj=True)
+        y, ldj, ldiag = run_pointwise(x2, kind, param, want_ldj=True, want_ldiag=bool(want_ldiag))
         ctx.save_for_backward(x2)
         ctx.meta = (kind, float(param))
+        if want_ldiag:
+            return y, ldj.reshape(-1), ldiag
         return y, ldj.reshape(-1)
 
     @staticmethod
-    def backward(ctx, gy, gldj):
+    def backward(ctx, gy, gldj, gldiag=None):
         (x2,) = ctx.saved_tensors
         kind, param = ctx.meta
         n, d = x2.shape
         gy = (torch.zeros_like(x2) if gy is None else gy).to(torch.float32).contiguous()
         gl = None if gldj is None else gldj.to(torch.float32).contiguous()
+        gd = None if gldiag is None else gldiag.to(torch.float32).contiguous()
         gx = torch.empty_like(x2)
-        _hip.call('sx_pointwise_bwd', x2, x2.data_ptr(), gy.data_ptr(), _hip.ptr(gl), gx.data_ptr(), n, d, kind, param)
-        return gx, None, None
+        _hip.call('sx_pointwise_bwd', x2, x2.data_ptr(), gy.data_ptr(), _hip.ptr(gl), _hip.ptr(gd), gx.data_ptr(), n, d, kind, param)
+        return gx, None, None, None
 
 
 class _Pointwise(ElementwiseTransform):
     """fwd / inv kernel kinds + parameters; the inverse kinds return MINUS the forward log-derivative at the value they
-    produce, which is what Transform.inverse_and_log_det_jacobian returns (flow.py:42-47)."""
+    produce, which is what Transform.inverse_and_log_det_jacobian returns (flow.py:42-47).  Every method is differentiable like
+    the reference's (see flow.graph_wanted): with a graph wanted the call is PointwiseOp."""
     _fwd = _inv = None
 
     def _p(self, reverse):
@@ -71,31 +76,57 @@ class _Pointwise(ElementwiseTransform):
     def _autograd_forward(self, x2, lat2=None):
         return PointwiseOp.apply(x2, self._fwd, self._p(False))
 
+    def _graph(self, x, reverse: bool, want_ldiag: bool = False):
+        """(out [..., D], log-det [..., 1], log-diag [..., D] | None) with a graph."""
+        _hip.require_device(x, 'x')
+        x2, _, lead = graph_rows(x)
+        d = x2.shape[1]
+        out = PointwiseOp.apply(x2, self._inv if reverse else self._fwd, self._p(reverse), want_ldiag)
+        return out[0].reshape(*lead, d), out[1].reshape(*lead, 1), (out[2].reshape(*lead, d) if want_ldiag else None)
+
     def forward(self, x, **kwargs):
+        if graph_wanted(None, x):
+            return self._graph(x, False)[0]
         return run_pointwise(x, self._fwd, self._p(False))[0]
 
     def inverse(self, y, **kwargs):
+        if graph_wanted(None, y):
+            return self._graph(y, True)[0]
         return run_pointwise(y, self._inv, self._p(True))[0]
 
     def log_diag_jacobian(self, x, y=None, **kwargs):
+        if graph_wanted(None, x):
+            return self._graph(x, False, True)[2]
         return run_pointwise(x, self._fwd, self._p(False), want_y=False, want_ldiag=True)[2]
 
     def log_det_jacobian(self, x, y=None, **kwargs):
+        if graph_wanted(None, x):
+            return self._graph(x, False)[1]
         return run_pointwise(x, self._fwd, self._p(False), want_y=False, want_ldj=True)[1]
 
     def forward_and_log_det_jacobian(self, x, **kwargs):
+        if graph_wanted(None, x):
+            return self._graph(x, False)[:2]
         y, ldj, _ = run_pointwise(x, self._fwd, self._p(False), want_ldj=True)
         return y, ldj
 
     def inverse_and_log_det_jacobian(self, y, **kwargs):
+        if graph_wanted(None, y):
+            return self._graph(y, True)[:2]
         x, ldj, _ = run_pointwise(y, self._inv, self._p(True), want_ldj=True)
         return x, ldj
 
     def forward_and_log_diag_jacobian(self, x, **kwargs):
+        if graph_wanted(None, x):
+            y, _, ld = self._graph(x, False, True)
+            return y, ld
         y, _, ld = run_pointwise(x, self._fwd, self._p(False), want_ldiag=True)
         return y, ld
 
     def inverse_and_log_diag_jacobian(self, y, **kwargs):
+        if graph_wanted(None, y):
+            x, _, ld = self._graph(y, True, True)
+            return x, ld
         x, _, ld = run_pointwise(y, self._inv, self._p(True), want_ldiag=True)
         return x, ld
 

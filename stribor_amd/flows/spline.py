@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from .. import _hip
-from ..flow import ElementwiseTransform, flatten_rows
+from ..flow import ElementwiseTransform, flatten_rows, graph_rows, graph_wanted
 
 __all__ = ['Spline', 'run_rqs_kernel', 'run_cubic_kernel', 'RQSInverse', 'RQSForward', 'CubicInverse', 'CubicForward', 'RQSCouplingSlab', 'RQSCouplingSlabL1', 'slab_slot_rows']
 
@@ -42,65 +42,76 @@ def run_rqs_kernel(x2, params, params_stride, live_idx, live_start, n_live, n_bi
     return y, ldj, ldiag
 
 
-class RQSInverse(torch.autograd.Function):
-    """(x_out, row log-det) = inverse rational-quadratic spline of the live columns -- the direction log_prob
-    evaluates -- as a differentiable op: forward = sx_rqs_coupling(reverse=1), backward = sx_rqs_inverse_bwd (hand-written
-    reverse mode through rational_quadratic_spline.py:101-107,180-234).  Gradients flow to the input and to the
-    per-row parameter tensor [N, n_live*(3K-1)]; whatever produced the parameters (a conditioner evaluated with torch's
-    own Linear layers, or nn.Parameters) gets its gradient from autograd."""
+class _SplineElementOp(torch.autograd.Function):
+    """(out, row log-det[, per-element log-derivative]) of the spline of the live columns as a differentiable op -- one class for
+    the four (spline type, direction) pairs: forward = sx_rqs_coupling / sx_cubic_coupling, backward = sx_rqs_inverse_bwd /
+    sx_rqs_forward_bwd / sx_cubic_inverse_bwd / sx_cubic_forward_bwd (hand-written reverse mode through
+    rational_quadratic_spline.py:101-107,180-248 resp. cubic_spline.py:103-247; the cubic solve is differentiated implicitly, so
+    that op also keeps its output).  Gradients flow to the input and to the per-row parameter tensor [N, n_live * P]; whatever
+    produced the parameters (a conditioner evaluated with torch's own Linear layers, or nn.Parameters) gets its gradient from
+    autograd.  `want_ldiag`: a third output [N, D] (Spline.log_diag_jacobian with a graph; its adjoint rides on the same
+    backward kernel as `gldiag`, ABI v3)."""
 
     @staticmethod
-    def forward(ctx, x2, params, live_idx, live_start, n_live, n_bins, lower, upper, ldj_scale):
+    def forward(ctx, x2, params, cubic, reverse, live_idx, live_start, n_live, n_bins, lower, upper, ldj_scale, want_ldiag):
         x2 = x2.contiguous()
         params = params.contiguous()
-        y, ldj, _ = run_rqs_kernel(x2, params, params.stride(0), live_idx, live_start, n_live, n_bins, lower, upper,
-                                   lower, upper, True, True, False, ldj_scale)
-        ctx.save_for_backward(x2, params)
-        ctx.meta = (live_idx, live_start, n_live, n_bins, float(lower), float(upper), float(ldj_scale))
+        if cubic:
+            y, ldj, ldiag = run_cubic_kernel(x2, params, params.stride(0), live_idx, live_start, n_live, n_bins, lower, upper,
+                                             bool(reverse), True, bool(want_ldiag), ldj_scale)
+        else:
+            y, ldj, ldiag = run_rqs_kernel(x2, params, params.stride(0), live_idx, live_start, n_live, n_bins, lower, upper,
+                                           lower, upper, bool(reverse), True, bool(want_ldiag), ldj_scale)
+        ctx.save_for_backward(x2, params, y if (cubic and reverse) else None)
+        ctx.meta = (bool(cubic), bool(reverse), live_idx, live_start, n_live, n_bins, float(lower), float(upper), float(ldj_scale))
+        if want_ldiag:
+            return y, ldj, ldiag
         return y, ldj
 
     @staticmethod
-    def backward(ctx, gy, gldj):
-        x2, params = ctx.saved_tensors
-        live_idx, live_start, n_live, n_bins, lower, upper, ldj_scale = ctx.meta
+    def backward(ctx, gy, gldj, gldiag=None):
+        x2, params, yout = ctx.saved_tensors
+        cubic, reverse, live_idx, live_start, n_live, n_bins, lower, upper, ldj_scale = ctx.meta
         n, d = x2.shape
         gy = (torch.zeros_like(x2) if gy is None else gy).to(torch.float32).contiguous()
         gldj = (torch.zeros(n, device=x2.device) if gldj is None else gldj).to(torch.float32).contiguous()
+        gldiag = None if gldiag is None else gldiag.to(torch.float32).contiguous()
         gx = gy.clone()                     # pass-through columns: y = x; the kernel overwrites the live columns
         gparams = torch.empty_like(params)
-        _hip.call('sx_rqs_inverse_bwd', x2, x2.data_ptr(), gy.data_ptr(), gldj.data_ptr(), params.data_ptr(),
-                                           params.stride(0), gx.data_ptr(), gparams.data_ptr(), _hip.ptr(live_idx),
-                                           live_start, n_live, n_bins, lower, upper, lower, upper, n, d, ldj_scale)
-        return gx, gparams, None, None, None, None, None, None, None
+        if cubic and reverse:
+            _hip.call('sx_cubic_inverse_bwd', x2, x2.data_ptr(), yout.data_ptr(), gy.data_ptr(), gldj.data_ptr(), _hip.ptr(gldiag),
+                      params.data_ptr(), params.stride(0), gx.data_ptr(), gparams.data_ptr(), _hip.ptr(live_idx), live_start,
+                      n_live, n_bins, lower, upper, n, d, ldj_scale)
+        elif cubic:
+            _hip.call('sx_cubic_forward_bwd', x2, x2.data_ptr(), gy.data_ptr(), gldj.data_ptr(), _hip.ptr(gldiag), params.data_ptr(),
+                      params.stride(0), gx.data_ptr(), gparams.data_ptr(), _hip.ptr(live_idx), live_start, n_live, n_bins, lower,
+                      upper, n, d, ldj_scale)
+        else:
+            _hip.call('sx_rqs_inverse_bwd' if reverse else 'sx_rqs_forward_bwd', x2, x2.data_ptr(), gy.data_ptr(), gldj.data_ptr(),
+                      _hip.ptr(gldiag), params.data_ptr(), params.stride(0), gx.data_ptr(), gparams.data_ptr(), _hip.ptr(live_idx),
+                      live_start, n_live, n_bins, lower, upper, lower, upper, n, d, ldj_scale)
+        return (gx, gparams) + (None,) * 10
 
 
-class RQSForward(torch.autograd.Function):
-    """(y, row log-det) = FORWARD rational-quadratic spline of the live columns as a differentiable op (forward / rsample of
-    spline flows): forward = sx_rqs_coupling(reverse=0), backward = sx_rqs_forward_bwd.  Same contract as RQSInverse."""
+class _SplineOpAlias:
+    """`X.apply(x2, params, live_idx, live_start, n_live, n_bins, lower, upper, ldj_scale[, want_ldiag])` -> (out, row log-det[,
+    ldiag]): the historical per-(type, direction) op names over _SplineElementOp."""
+    cubic = reverse = False
 
-    @staticmethod
-    def forward(ctx, x2, params, live_idx, live_start, n_live, n_bins, lower, upper, ldj_scale):
-        x2 = x2.contiguous()
-        params = params.contiguous()
-        y, ldj, _ = run_rqs_kernel(x2, params, params.stride(0), live_idx, live_start, n_live, n_bins, lower, upper,
-                                   lower, upper, False, True, False, ldj_scale)
-        ctx.save_for_backward(x2, params)
-        ctx.meta = (live_idx, live_start, n_live, n_bins, float(lower), float(upper), float(ldj_scale))
-        return y, ldj
+    @classmethod
+    def apply(cls, x2, params, live_idx, live_start, n_live, n_bins, lower, upper, ldj_scale, want_ldiag=False):
+        return _SplineElementOp.apply(x2, params, cls.cubic, cls.reverse, live_idx, live_start, n_live, n_bins, lower, upper,
+                                      ldj_scale, want_ldiag)
 
-    @staticmethod
-    def backward(ctx, gy, gldj):
-        x2, params = ctx.saved_tensors
-        live_idx, live_start, n_live, n_bins, lower, upper, ldj_scale = ctx.meta
-        n, d = x2.shape
-        gy = (torch.zeros_like(x2) if gy is None else gy).to(torch.float32).contiguous()
-        gldj = (torch.zeros(n, device=x2.device) if gldj is None else gldj).to(torch.float32).contiguous()
-        gx = gy.clone()
-        gparams = torch.empty_like(params)
-        _hip.call('sx_rqs_forward_bwd', x2, x2.data_ptr(), gy.data_ptr(), gldj.data_ptr(), params.data_ptr(),
-                                           params.stride(0), gx.data_ptr(), gparams.data_ptr(), _hip.ptr(live_idx),
-                                           live_start, n_live, n_bins, lower, upper, lower, upper, n, d, ldj_scale)
-        return gx, gparams, None, None, None, None, None, None, None
+
+class RQSInverse(_SplineOpAlias):
+    """inverse rational-quadratic spline -- the direction log_prob evaluates (sx_rqs_coupling(reverse=1) / sx_rqs_inverse_bwd)."""
+    cubic, reverse = False, True
+
+
+class RQSForward(_SplineOpAlias):
+    """FORWARD rational-quadratic spline (forward / rsample of spline flows; sx_rqs_forward_bwd)."""
+    cubic, reverse = False, False
 
 
 def _adjoint_scale(gy, gldj):
@@ -284,63 +295,16 @@ def run_cubic_kernel(x2, params, params_stride, live_idx, live_start, n_live, n_
     return y, ldj, ldiag
 
 
-class CubicInverse(torch.autograd.Function):
-    """(x_out, row log-det) = inverse monotone cubic spline of the live columns as a differentiable op: forward =
-    sx_cubic_coupling(reverse=1), backward = sx_cubic_inverse_bwd (the cubic solve differentiated implicitly, then reverse
-    mode through cubic_spline.py:103-137).  params: [N, n_live*(2K+2)]."""
-
-    @staticmethod
-    def forward(ctx, x2, params, live_idx, live_start, n_live, n_bins, lower, upper, ldj_scale):
-        x2 = x2.contiguous()
-        params = params.contiguous()
-        y, ldj, _ = run_cubic_kernel(x2, params, params.stride(0), live_idx, live_start, n_live, n_bins, lower, upper, True,
-                                     True, False, ldj_scale)
-        ctx.save_for_backward(x2, y, params)
-        ctx.meta = (live_idx, live_start, n_live, n_bins, float(lower), float(upper), float(ldj_scale))
-        return y, ldj
-
-    @staticmethod
-    def backward(ctx, gy, gldj):
-        x2, y, params = ctx.saved_tensors
-        live_idx, live_start, n_live, n_bins, lower, upper, ldj_scale = ctx.meta
-        n, d = x2.shape
-        gy = (torch.zeros_like(x2) if gy is None else gy).to(torch.float32).contiguous()
-        gldj = (torch.zeros(n, device=x2.device) if gldj is None else gldj).to(torch.float32).contiguous()
-        gx = gy.clone()
-        gparams = torch.empty_like(params)
-        _hip.call('sx_cubic_inverse_bwd', x2, x2.data_ptr(), y.data_ptr(), gy.data_ptr(), gldj.data_ptr(), params.data_ptr(),
-                                             params.stride(0), gx.data_ptr(), gparams.data_ptr(), _hip.ptr(live_idx),
-                                             live_start, n_live, n_bins, lower, upper, n, d, ldj_scale)
-        return gx, gparams, None, None, None, None, None, None, None
+class CubicInverse(_SplineOpAlias):
+    """inverse monotone cubic spline (sx_cubic_coupling(reverse=1) / sx_cubic_inverse_bwd: the solve differentiated implicitly,
+    then reverse mode through cubic_spline.py:103-137).  params: [N, n_live*(2K+2)]."""
+    cubic, reverse = True, True
 
 
-class CubicForward(torch.autograd.Function):
-    """(y, row log-det) = FORWARD monotone cubic spline of the live columns as a differentiable op: forward =
-    sx_cubic_coupling(reverse=0), backward = sx_cubic_forward_bwd (the polynomial's own derivatives, then the chain of
-    CubicInverse through the Steffen knot derivatives, cumsums and softmax)."""
-
-    @staticmethod
-    def forward(ctx, x2, params, live_idx, live_start, n_live, n_bins, lower, upper, ldj_scale):
-        x2 = x2.contiguous()
-        params = params.contiguous()
-        y, ldj, _ = run_cubic_kernel(x2, params, params.stride(0), live_idx, live_start, n_live, n_bins, lower, upper, False,
-                                     True, False, ldj_scale)
-        ctx.save_for_backward(x2, params)
-        ctx.meta = (live_idx, live_start, n_live, n_bins, float(lower), float(upper), float(ldj_scale))
-        return y, ldj
-
-    @staticmethod
-    def backward(ctx, gy, gldj):
-        x2, params = ctx.saved_tensors
-        live_idx, live_start, n_live, n_bins, lower, upper, ldj_scale = ctx.meta
-        n, d = x2.shape
-        gy = (torch.zeros_like(x2) if gy is None else gy).to(torch.float32).contiguous()
-        gldj = (torch.zeros(n, device=x2.device) if gldj is None else gldj).to(torch.float32).contiguous()
-        gx = gy.clone()
-        gparams = torch.empty_like(params)
-        _hip.call('sx_cubic_forward_bwd', x2, x2.data_ptr(), gy.data_ptr(), gldj.data_ptr(), params.data_ptr(), params.stride(0),
-                  gx.data_ptr(), gparams.data_ptr(), _hip.ptr(live_idx), live_start, n_live, n_bins, lower, upper, n, d, ldj_scale)
-        return gx, gparams, None, None, None, None, None, None, None
+class CubicForward(_SplineOpAlias):
+    """FORWARD monotone cubic spline (sx_cubic_forward_bwd: the polynomial's own derivatives, then the chain of CubicInverse
+    through the Steffen knot derivatives, cumsums and softmax)."""
+    cubic, reverse = True, False
 
 
 class Spline(ElementwiseTransform):
@@ -405,7 +369,16 @@ class Spline(ElementwiseTransform):
     def _autograd_supported(self) -> bool:
         return True          # own parameters, a net.MLP (forward_autograd) or any nn.Module latent_net (torch's graph)
 
-    def _autograd_inverse(self, x2: torch.Tensor, lat2=None, reverse: bool = True):
+    def _autograd_from_params(self, x2: torch.Tensor, params: torch.Tensor, reverse: bool, want_ldiag: bool = False):
+        """(out, log-det [N][, log-diag [N, D]]) of every column from a per-row parameter tensor [N, D * P] (spline.py:82-86)
+        with a graph; reverse: the inverse spline and its own (negated) log-derivative (rational_quadratic_spline.py:234)."""
+        if self.spline_type == 'cubic':
+            op = CubicInverse if reverse else CubicForward
+        else:
+            op = RQSInverse if reverse else RQSForward
+        return op.apply(x2, params.to(torch.float32), None, 0, x2.shape[1], self.n_bins, self.lower, self.upper, 1.0, want_ldiag)
+
+    def _autograd_inverse(self, x2: torch.Tensor, lat2=None, reverse: bool = True, want_ldiag: bool = False):
         """inverse_and_log_diag_jacobian summed over the columns, on fp32 rows, with a graph (RQSInverse)."""
         n, d = x2.shape
         if self.latent_net is None:
@@ -416,42 +389,60 @@ class Spline(ElementwiseTransform):
                 raise ValueError('Spline with a latent_net needs `latent`')
             net = self.latent_net
             params = net.forward_autograd(lat2) if hasattr(net, 'forward_autograd') else net(lat2)          # spline.py:82-86
-        if self.spline_type == 'cubic':
-            op = CubicInverse if reverse else CubicForward
-        else:
-            op = RQSInverse if reverse else RQSForward
-        return op.apply(x2, params, None, 0, d, self.n_bins, self.lower, self.upper, 1.0)
+        return self._autograd_from_params(x2, params, reverse, want_ldiag)
 
     def _autograd_forward(self, x2: torch.Tensor, lat2=None):
         """forward_and_log_diag_jacobian summed over the columns, with a graph (quadratic splines: RQSForward)."""
         return self._autograd_inverse(x2, lat2, reverse=False)
 
-    # ---- reference method set (spline.py:89-143) ----------------------------------------------------------
+    # ---- reference method set (spline.py:89-143): differentiable like the reference's (see flow.graph_wanted) -----------
+    def _graph(self, x, latent, reverse: bool, want_ldiag: bool = False):
+        """(out [..., D], log-det [..., 1], log-diag [..., D] | None) with a graph."""
+        _hip.require_device(x, 'x')
+        x2, lat2, lead = graph_rows(x, latent)
+        d = x2.shape[1]
+        out = self._autograd_inverse(x2, lat2, reverse=reverse, want_ldiag=want_ldiag)
+        return out[0].reshape(*lead, d), out[1].reshape(*lead, 1), (out[2].reshape(*lead, d) if want_ldiag else None)
+
     def forward(self, x, latent=None, **kwargs):
+        if graph_wanted(self, x, latent):
+            return self._graph(x, latent, False)[0]
         return self._launch(x, latent, False, False, False)[0]
 
     def inverse(self, y, latent=None, **kwargs):
+        if graph_wanted(self, y, latent):
+            return self._graph(y, latent, True)[0]
         return self._launch(y, latent, True, False, False)[0]
 
     def forward_and_log_diag_jacobian(self, x, latent=None, *, reverse=False, **kwargs):
+        if graph_wanted(self, x, latent):
+            y, _, ld = self._graph(x, latent, reverse, True)
+            return y, ld
         y, _, ld = self._launch(x, latent, reverse, False, True)
         return y, ld
 
     def inverse_and_log_diag_jacobian(self, y, latent=None, **kwargs):
         # the inverse spline already returns the negated value (rational_quadratic_spline.py:234): no extra sign
-        x, _, ld = self._launch(y, latent, True, False, True)
-        return x, ld
+        return self.forward_and_log_diag_jacobian(y, latent, reverse=True)
 
     def forward_and_log_det_jacobian(self, x, latent=None, **kwargs):
+        if graph_wanted(self, x, latent):
+            return self._graph(x, latent, False)[:2]
         y, ldj, _ = self._launch(x, latent, False, True, False)
         return y, ldj
 
     def inverse_and_log_det_jacobian(self, y, latent=None, **kwargs):
+        if graph_wanted(self, y, latent):
+            return self._graph(y, latent, True)[:2]
         x, ldj, _ = self._launch(y, latent, True, True, False)
         return x, ldj
 
     def log_det_jacobian(self, x, y=None, latent=None, **kwargs):
+        if graph_wanted(self, x, latent):
+            return self._graph(x, latent, False)[1]
         return self._launch(x, latent, False, True, False)[1]
 
     def log_diag_jacobian(self, x, y=None, latent=None, **kwargs):
+        if graph_wanted(self, x, latent):
+            return self._graph(x, latent, False, True)[2]
         return self._launch(x, latent, False, False, True)[2]

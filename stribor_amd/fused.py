@@ -65,7 +65,11 @@ def _snap(guards):
 
 
 class ProgramCache:
-    """key -> built value, rebuilt when the structure epoch, the owner's fingerprint or a guard tensor changed."""
+    """key -> built value, rebuilt when the structure epoch, the owner's fingerprint or a guard tensor changed.  Bounded: keys
+    may carry call-dependent sizes (e.g. the row count of a set_data batch), so the least recently BUILT entries beyond
+    `MAX_ENTRIES` are dropped (dict order = insertion order; a hit does not reorder -- the bound only has to stop growth)."""
+
+    MAX_ENTRIES = 256
 
     def __init__(self):
         self._d = {}
@@ -78,7 +82,10 @@ class ProgramCache:
                 return value
         gs = list(guards() if callable(guards) else guards)
         value = build()
+        self._d.pop(key, None)
         self._d[key] = (_STRUCT_EPOCH[0], fingerprint, gs, _snap(gs), value)
+        while len(self._d) > ProgramCache.MAX_ENTRIES:
+            self._d.pop(next(iter(self._d)))
         return value
 
     def clear(self):
@@ -242,6 +249,7 @@ class CompiledProgram:
         self.mlp_out_dim = mlp_out_dim
         self.mlp_col0 = 0                       # first output column of this launch's window (chunked MLP programs)
         self._tracked = None
+        self._owner = None
 
     @property
     def blobs(self) -> torch.Tensor:
@@ -257,6 +265,8 @@ class CompiledProgram:
 
     def blobs_for(self, prec: int) -> torch.Tensor:
         """Packed weights for arithmetic `prec`, re-packed when a tracked parameter changed."""
+        if self._owner is not None:                 # a later chunk of a wide MLP program: the first chunk owns the pack jobs
+            return self._owner.blobs_for(prec)
         blobs = self._blobs.get(prec)
         if blobs is None:
             blobs = self._blobs[prec] = torch.zeros(self.blob_floats, dtype=torch.float32, device=self.device)
@@ -274,8 +284,9 @@ class CompiledProgram:
         self.blobs_for(_hip.GEMM_F16X3 if _hip.get_gemm_precision() != 'exact' else _hip.GEMM_F32)
 
     def share_weights_of(self, other: 'CompiledProgram') -> None:
-        """Chunks of one wide MLP program: same blobs, packed once by the first chunk (which always runs first)."""
-        self._blobs, self._versions, self.jobs = other._blobs, other._versions, []
+        """Chunks of one wide MLP program: same blobs; every request for them goes through the first chunk, which owns the
+        pack jobs (so a precision first asked for by a later chunk -- 'auto' re-running one launch exactly -- is packed too)."""
+        self._owner, self.jobs = other, []
 
     # -- launch -----------------------------------------------------------------------------------
     def run(self, x: torch.Tensor, latent: Optional[torch.Tensor] = None, want_y: bool = False,
@@ -329,6 +340,8 @@ class CompiledProgram:
                 launch(_hip.GEMM_F16X3)
             else:                                   # 'auto': never hand back a NaN-poisoned result
                 keep = None if sum_out is None else sum_out.clone()
+                torch.cuda.current_stream().synchronize()
+                _hip.poll_errors()                  # a flag an EARLIER call left behind is that call's: raise it, do not swallow it
                 launch(_hip.GEMM_F16X3)
                 torch.cuda.current_stream().synchronize()
                 if _hip.take_flag(x.device, _hip.FLAG_F16_RANGE):

@@ -200,3 +200,70 @@ def test_second_device_guard():
     assert torch.cuda.current_device() == 0
     _rel_close(flow.log_prob(x.to('cuda:1')), orc.flow_log_prob(spec, x))
     assert torch.cuda.current_device() == 0
+
+
+def _scale_close(got, want, tol=1e-5):
+    """|got - want| <= tol * (|want| + max|want|): the 1e-5 bound relative to the tensor's OWN scale (tiny data stays tiny)."""
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    bound = tol * (want.abs() + want.abs().max())
+    err = (got - want).abs()
+    assert (err <= bound).all(), (err.max().item(), want.abs().max().item())
+
+
+@pytest.mark.parametrize('x_exp,w_exp,all_layers', [(-12, -8, False), (-8, -12, False), (-16, -10, True), (-14, 0, False)])
+def test_small_magnitude_side_of_the_fp16x3_split(x_exp, w_exp, all_layers):
+    """hi + lo of a value below 2^-14 * 2^10 leaves the `lo` half an fp16 denormal (absolute floor ~3e-8).
+    cfg-2-shaped flow with inputs x 2^x_exp and first-layer weights x 2^w_exp (and the transposed pairing): 'fast' against the
+    fp64 oracle on EVERY per-layer output and log-det, at the 1e-5 bound relative to each tensor's own scale."""
+    desc = fd.cfg2_desc(8, 64, 64)
+    torch.manual_seed(12)
+    flow = fd.build_flow(st, desc, 64)
+    with torch.no_grad():
+        for i, f in enumerate(flow.transforms):
+            lin = [m for m in f.transform.latent_net.net if isinstance(m, torch.nn.Linear)]
+            if i == 0 or all_layers:
+                lin[0].weight.mul_(2.0 ** w_exp)
+            lin[1].bias.normal_(0, 0.05)          # off the zero init (mlp.py:53): the layers do something
+    state = {k: v.clone() for k, v in flow.state_dict().items()}
+    spec64 = orc.spec_to(fd.flow_spec(desc, state), torch.float64)
+    flow = flow.to(DEV)
+    x = torch.randn(512, 64, generator=torch.Generator().manual_seed(13)) * 2.0 ** x_exp
+    cur64, cur = x.double(), x.to(DEV)
+    for i in reversed(range(8)):                               # the log_prob direction, layer by layer (one launch each)
+        nxt64, ldj64 = orc.transform_inverse_and_ldj(spec64[i], cur64)
+        nxt, ldj = flow.transforms[i].inverse_and_log_det_jacobian(cur64.float().to(DEV))
+        _scale_close(nxt, nxt64)
+        _scale_close(ldj, ldj64)
+        y, ldf = flow.transforms[i].forward_and_log_det_jacobian(nxt64.float().to(DEV))
+        _scale_close(y, cur64)
+        _scale_close(ldf, -ldj64)
+        cur64 = nxt64
+    _rel_close(flow.log_prob(x.to(DEV)), orc.flow_log_prob(spec64, x.double()))
+    _scale_close(flow.inverse(x.to(DEV)), orc.flow_inverse(spec64, x.double()))
+    st.check_errors()
+
+
+def test_nan_inputs_propagate_to_their_own_rows_only():
+    """The reference propagates NaN through torch ops: a NaN anywhere in a row makes that row's log_prob NaN and leaves every
+    other row untouched.  Same here, in both arithmetics, for affine, spline and dense-linear programs."""
+    for desc, dim in ((fd.cfg2_desc(4, 64, 64), 64), (fd.cfg3_desc(2, 16, 32, 8), 16), (fd.cfg4_desc(1, 32, 32), 32)):
+        flow, spec = _flow_and_oracle(desc, dim, seed=21)
+        x = torch.randn(200, dim, generator=torch.Generator().manual_seed(22))
+        want = orc.flow_log_prob(spec, x)
+        x[5, 3] = float('nan')                       # conditioning column of some layers, transformed column of others
+        x[77, dim - 1] = float('nan')
+        x[130] = float('nan')
+        bad = torch.zeros(200, dtype=torch.bool)
+        bad[[5, 77, 130]] = True
+        for mode in ('fast', 'exact'):
+            st.set_gemm_precision(mode)
+            got = flow.log_prob(x.to(DEV)).cpu().reshape(-1)
+            z = flow.inverse(x.to(DEV)).cpu()
+            assert torch.isnan(got[bad]).all(), mode
+            assert torch.isfinite(got[~bad]).all() and torch.isfinite(z[~bad]).all(), mode
+            assert torch.isnan(z[bad]).any(dim=1).all(), mode
+            _rel_close(got[~bad], want.reshape(-1)[~bad], 1e-5 if desc[0]['kind'] != 'coupling_rqs' else 1e-4)
+            try:
+                st.check_errors()
+            except st.GemmRangeError:             # a NaN operand may be reported as out of range; it must not go unnoticed as a number
+                pass

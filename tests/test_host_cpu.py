@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), name
     assert set(_hip.EXPORTS) == declared
-    assert _hip.lib().sx_abi_version() == _hip.SX_ABI_VERSION == 2
+    assert _hip.lib().sx_abi_version() == _hip.SX_ABI_VERSION == 3
     assert _hip.lib().sx_packed_linear_floats(2, 1) == _hip.packed_linear_floats(2, 1) == 2 * 1024 + 64
 
 
