@@ -75,6 +75,9 @@ int         sx_abi_version(void);
 /* The library's default GEMM arithmetic (SX_GEMM_F16X3). */
 int         sx_fragment_mode(void);
 const char *sx_last_error(void);
+/* 16 hex digits identifying the sources this library was built from (sha256 over csrc/ + this header): measurement
+ * files under profiles/ record it so that counter-derived figures are only quoted for the build they were taken on. */
+const char *sx_build_id(void);
 
 /* ------------------------------------------------------------------------------------------
  * Elementwise / HBM-bound kernels (params already in HBM)

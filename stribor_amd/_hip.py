@@ -42,7 +42,7 @@ ACT_CODES = {'Identity': 0, 'Tanh': 1, 'ReLU': 2, 'Sigmoid': 3, 'ELU': 4, 'Softp
              'SiLU': 7, 'GELU': 8}
 
 # every symbol include/stribor_hip.h declares (tests check that the library exports all of them)
-EXPORTS = ['sx_abi_version', 'sx_fragment_mode', 'sx_last_error', 'sx_permute', 'sx_affine_coupling', 'sx_rqs_coupling',
+EXPORTS = ['sx_abi_version', 'sx_fragment_mode', 'sx_last_error', 'sx_build_id', 'sx_permute', 'sx_affine_coupling', 'sx_rqs_coupling',
            'sx_cubic_coupling', 'sx_pointwise', 'sx_rqs_inverse_bwd', 'sx_rqs_forward_bwd', 'sx_affine_coupling_bwd', 'sx_time_affine_coupling', 'sx_cubic_inverse_bwd', 'sx_cubic_forward_bwd', 'sx_pointwise_bwd',
            'sx_unit_normal_logprob', 'sx_sum_f64', 'sx_packed_linear_floats', 'sx_pack_linear', 'sx_flow_run',
            'sx_flow_launch_info', 'sx_wgrad', 'sx_wgrad_layer', 'sx_colsum', 'sx_tri_inverse_f64',
@@ -77,6 +77,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.sx_fragment_mode.argtypes = []
     lib.sx_last_error.restype = C.c_char_p
     lib.sx_last_error.argtypes = []
+    lib.sx_build_id.restype = C.c_char_p
+    lib.sx_build_id.argtypes = []
     lib.sx_permute.restype = i32
     lib.sx_permute.argtypes = [vp, vp, vp, i64, i32, i32, vp]
     lib.sx_affine_coupling.restype = i32
@@ -161,6 +163,11 @@ def lib() -> C.CDLL:
             raise HipLibraryMissing(f'{LIB_PATH}: ABI version {l.sx_abi_version()} != {SX_ABI_VERSION}; rebuild')
         _lib = l
     return _lib
+
+
+def build_id() -> str:
+    """sha256[:16] of the sources the loaded library was built from (Makefile rule sx_build_id.inc)."""
+    return lib().sx_build_id().decode()
 
 
 def check(rc: int, what: str) -> None:

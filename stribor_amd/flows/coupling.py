@@ -352,7 +352,14 @@ class Coupling(Transform):
         m = self.mask_vector(d)
         live = np.nonzero(m <= 0.5)[0]
         if len(live) == 0:
-            return x2, torch.zeros(n, dtype=torch.float32, device=x2.device)
+            # nothing is transformed (dim 1: mask = [1], mask.py:37-38).  The reference still evaluates the conditioner and
+            # multiplies its transform by (1 - mask) = 0 (coupling.py:71-78,94-95): the outputs carry a graph in which every
+            # conditioner parameter has a ZERO gradient (base.py:76-81 calls backward on exactly this) -- keep that
+            z = x2 * 0 if d == 1 else x2 * torch.from_numpy(m.astype(np.float32)).to(x2.device)     # coupling.py:61-63
+            if lat2 is not None:
+                z = torch.cat([z, lat2], -1)
+            tie = (net.forward_autograd(z) if isinstance(net, MLP) else net(z)).sum() * 0
+            return x2 + tie, torch.zeros(n, dtype=torch.float32, device=x2.device) + tie
         key = ('autograd', d, str(x2.device))
 
         def build():

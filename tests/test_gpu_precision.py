@@ -202,10 +202,13 @@ def test_second_device_guard():
     assert torch.cuda.current_device() == 0
 
 
-def _scale_close(got, want, tol=1e-5):
-    """|got - want| <= tol * (|want| + max|want|): the 1e-5 bound relative to the tensor's OWN scale (tiny data stays tiny)."""
+def _scale_close(got, want, tol=1e-5, operands=None, atol=0.0):
+    """|got - want| <= tol * (|want| + scale), scale = the largest magnitude among the result and the layer's operands: the 1e-5
+    bound relative to the data's OWN scale (tiny data stays tiny; a result that is a small difference of O(scale) operands --
+    the round trip back to a tiny input -- is held to the operands' scale, as fp32 itself would be)."""
     got, want = got.detach().cpu().double(), want.detach().cpu().double()
-    bound = tol * (want.abs() + want.abs().max())
+    scale = want.abs().max() if operands is None else max(want.abs().max(), operands.detach().abs().max().double().cpu())
+    bound = tol * (want.abs() + scale) + atol
     err = (got - want).abs()
     assert (err <= bound).all(), (err.max().item(), want.abs().max().item())
 
@@ -233,10 +236,12 @@ def test_small_magnitude_side_of_the_fp16x3_split(x_exp, w_exp, all_layers):
         nxt64, ldj64 = orc.transform_inverse_and_ldj(spec64[i], cur64)
         nxt, ldj = flow.transforms[i].inverse_and_log_det_jacobian(cur64.float().to(DEV))
         _scale_close(nxt, nxt64)
-        _scale_close(ldj, ldj64)
+        # a row's log-det sums 32 log-scales, each an O(|W2|_1) GEMM result: the per-layer absolute floor the suite uses elsewhere
+        # (test_per_layer_api_against_golden: 2e-5) -- it does not grow as the data shrinks, which is what this test pins
+        _scale_close(ldj, ldj64, atol=2e-5)
         y, ldf = flow.transforms[i].forward_and_log_det_jacobian(nxt64.float().to(DEV))
-        _scale_close(y, cur64)
-        _scale_close(ldf, -ldj64)
+        _scale_close(y, cur64, operands=nxt64)
+        _scale_close(ldf, -ldj64, atol=2e-5)
         cur64 = nxt64
     _rel_close(flow.log_prob(x.to(DEV)), orc.flow_log_prob(spec64, x.double()))
     _scale_close(flow.inverse(x.to(DEV)), orc.flow_inverse(spec64, x.double()))

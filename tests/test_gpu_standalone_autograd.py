@@ -49,7 +49,8 @@ def check_log_det_jacobian(f, x, jacobian, reverse=False, **kwargs):
         _, got = f.inverse_and_log_det_jacobian(y, **kwargs)
     else:
         _, got = f.forward_and_log_det_jacobian(x, **kwargs)
-    assert got.requires_grad or not any(p.requires_grad for p in f.parameters())
+    # (a coupling over ONE column transforms nothing -- mask.py:37-38 -- and its log-det is the constant 0)
+    assert got.requires_grad or x.shape[-1] == 1 or not any(p.requires_grad for p in f.parameters())
     assert torch.allclose(want, got.squeeze(-1), atol=ATOL), ('Jacobian determinant is incorrect', (want - got.squeeze(-1)).abs().max())
     return want
 
@@ -153,8 +154,15 @@ def test_reference_autograd_harness_on_product_transforms_f10_pointwise(family):
     for case in g.cases(family):
         f = fd.build_transform(st, g.meta[case]['desc'][0]).to(DEV)
         x = g.t(case + '/x').to(DEV)
-        if x.numel() > 200:                     # the (2,3,4,5) / (7,4,5) Jacobians are [N D, N D]: keep the small shapes
-            x = x.reshape(-1, x.shape[-1])[:12]
+        x = x.reshape(-1, x.shape[-1])
+        # the fixture also holds rows far in the saturated / clamped ends (|x| = 30, 120; sigmoid.py clamps there and the round
+        # trip is then not the identity in the reference either): the Jacobian harness runs on the ordinary rows, like the
+        # reference's own randn / rand inputs (test_sigmoid.py, test_activations.py)
+        x = x[(x.abs() < 8).all(-1)]
+        if family == 'logit/':
+            x = x[((x > 1e-3) & (x < 1 - 1e-3)).all(-1)]
+        x = x[:12]                              # the (2,3,4,5) / (7,4,5) Jacobians are [N D, N D]: keep them small
+        assert x.shape[0] >= 1, case
         run_reference_harness(f, x, None)
 
 
