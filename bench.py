@@ -78,90 +78,198 @@ def event_ms(fn, reps, inner=8):
     return sum(ts) / len(ts), ts[len(ts) // 2]
 
 
-def cpu_baseline(desc, state):
+def cpu_baseline(desc, state, dim=DIM, budget_s=12.0, max_rows=1 << 21, what='cfg2'):
+    """The oracle (torch-CPU port of the reference's op sequence, incl. its double conditioner call; spline flows WITHOUT the
+    reference's O(M^2) domain-check broadcast, SURVEY App. B Q1 -- with it the reference cannot run these sizes at all) timed on
+    this box's host cores on a bounded sample: thread count probed, then one pass sized to ~budget_s."""
     import torch
     from oracle import stribor_oracle as orc
     from stribor_amd.util import flowdesc as fd
     spec = fd.flow_spec(desc, state)
     avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     gen = torch.Generator().manual_seed(1234)
+    probe_rows = 1 << 16 if what == 'cfg2' else 1 << 12
     with torch.no_grad():
-        x = torch.randn(1 << 16, DIM, generator=gen)
-        # torch's intra-op pool does not scale to hundreds of threads on [65536, 64] ops: probe a few
+        x = torch.randn(probe_rows, dim, generator=gen)
+        # torch's intra-op pool does not scale to hundreds of threads on these ops: probe a few
         # thread counts and keep the fastest (that count is what `cores` reports)
         best = None
         for th in sorted({c for c in (8, 16, 32, 64, 128, avail) if c <= avail}):
             torch.set_num_threads(th)
-            orc.flow_log_prob(spec, x[:4096])                          # warm-up
+            orc.flow_log_prob(spec, x[:max(256, probe_rows // 16)])    # warm-up
             t0 = time.perf_counter()
             orc.flow_log_prob(spec, x)
             dt = time.perf_counter() - t0
             if best is None or dt < best[1]:
                 best = (th, dt)
-            if dt > 8.0:
+            if dt > 0.7 * budget_s:
                 break
         cores, probe = best
         torch.set_num_threads(cores)
-        rows = 1 << 16
-        while rows < (1 << 21) and probe * (2 * rows / (1 << 16)) < 12.0:
+        rows = probe_rows
+        while rows < max_rows and probe * (2 * rows / probe_rows) < budget_s:
             rows *= 2
-        x = torch.randn(rows, DIM, generator=gen)
+        x = torch.randn(rows, dim, generator=gen)
         t0 = time.perf_counter()
         orc.flow_log_prob(spec, x)
         dt = time.perf_counter() - t0
+    note = '' if what == 'cfg2' or what == 'cfg4' else ', O(M^2) domain-check broadcast of rational_quadratic_spline.py:167-178 omitted'
     return {'value': rows / dt, 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
-            'sample': f'oracle.flow_log_prob (torch CPU fp32, reference op sequence incl. double conditioner call) '
-                      f'on {rows} rows x {DIM}, 1 pass, {dt:.2f} s'}
+            'sample': f'oracle.flow_log_prob (torch CPU fp32, reference op sequence incl. double conditioner call{note}) '
+                      f'on {rows} rows x {dim}, 1 pass, {dt:.2f} s'}
 
 
 def load_profile(name):
+    """A committed rocprofv3 summary (profiles/*.json), or {} when it was captured on a DIFFERENT build of the library than the
+    one being timed (sx_build_id: sha256 over the library's sources): counter-derived fields are then reported as null
+    rather than as observations of this run."""
     try:
-        return json.load(open(os.path.join(ROOT, 'profiles', name)))
+        prof = json.load(open(os.path.join(ROOT, 'profiles', name)))
     except Exception:
         return {}
+    try:
+        from stribor_amd import _hip
+        if prof.get('build_id') != _hip.build_id():
+            return {'stale_profile': name, 'profile_build_id': prof.get('build_id'), 'library_build_id': _hip.build_id()}
+    except Exception:
+        return {}
+    return prof
 
 
-def time_extra_config(name, workload, flow, x, steps, warmup, flops_per_row, bytes_per_row, kernel, pmc, extra=None):
+def time_extra_config(name, workload, flow, x, steps, warmup, flops_per_row, bytes_per_row, kernel, pmc, extra=None, exact=False):
     """One BASELINE configuration beside the headline: K steps of log_prob_sum over the resident batch, wall clock
-    around barrier-free synchronised K steps plus HIP events over the same region for the kernel's launch period."""
+    around barrier-free synchronised K steps plus HIP events over the same region for the kernel's launch period.
+    exact: the v_mfma_f32_32x32x2_f32 arithmetic (stribor_amd.set_gemm_precision('exact')), priced against the fp32 MFMA peak."""
     import torch
+    import stribor_amd as st
     out = torch.zeros(1, dtype=torch.float64, device=x.device)
 
     def step():
         out.zero_()
         flow.log_prob_sum(x, out)
 
-    step()
-    torch.cuda.synchronize()
-    for _ in range(max(warmup, 3)):
+    old_prec = st.set_gemm_precision('exact' if exact else 'fast')
+    try:
         step()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(steps):
-        step()
-    ev1.record()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        for _ in range(max(warmup, 3)):
+            step()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(steps):
+            step()
+        ev1.record()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    finally:
+        st.set_gemm_precision(old_prec)
     assert torch.isfinite(out).all(), name
     k_ms = ev0.elapsed_time(ev1) / steps
     rows = x.shape[0]
     tflops = flops_per_row * rows / (k_ms * 1e-3) / 1e12
-    roof = {'kernel': kernel, 'bound': 'mfma', 'achieved': tflops, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': tflops / PEAK_F16_MFMA_TFLOPS, 'traffic': pmc.get('hbm_bytes_per_launch'),
-            'traffic_pmc_commit': pmc.get('commit'), 'avg_kernel_ms': k_ms,
+    peak = PEAK_F32_MFMA_TFLOPS if exact else PEAK_F16_MFMA_TFLOPS
+    roof = {'kernel': kernel, 'bound': 'mfma', 'achieved': tflops, 'peak': peak, 'unit': 'TFLOP/s',
+            'frac': tflops / peak, 'traffic': pmc.get('hbm_bytes_per_launch'),
+            'traffic_pmc_build_id': pmc.get('build_id'), 'traffic_stale_profile': pmc.get('stale_profile'), 'avg_kernel_ms': k_ms,
             'algorithmic_flops_per_launch': flops_per_row * rows, 'algorithmic_bytes_per_launch': bytes_per_row * rows,
-            'hbm_frac_of_same_kernel': bytes_per_row * rows / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-            'mfma_executed_tflops': 3 * tflops, 'frac_mfma_pipe_busy': 3 * tflops / PEAK_F16_MFMA_TFLOPS}
+            'hbm_frac_of_same_kernel': bytes_per_row * rows / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
+    if exact:
+        roof['gemm_arithmetic'] = 'v_mfma_f32_32x32x2_f32 (exact fp32 fma chain, no operand range limit)'
+    else:
+        roof.update({'mfma_executed_tflops': 3 * tflops, 'frac_mfma_pipe_busy': 3 * tflops / PEAK_F16_MFMA_TFLOPS})
     if extra:
         roof.update(extra(k_ms, rows))
     return {'name': name, 'workload': workload, 'steps': steps, 'ms_per_step': elapsed / steps * 1e3,
-            'value': rows * steps / elapsed, 'unit': 'samples/s', 'dtype': 'f32', 'log_prob_sum': out.item(),
-            'roofline': roof}
+            'value': rows * steps / elapsed, 'unit': 'samples/s', 'dtype': 'f32', 'precision': 'exact' if exact else 'fast',
+            'log_prob_sum': out.item(), 'roofline': roof}
+
+
+def extra_flow_entries(st, fd, dev, gen, steps):
+    """Perf lines of the on-path families beyond the BASELINE configurations, 2^20 rows, D = 64:
+      * the reference's flagship stack (test_normalizing_flow.py:13-35 without the CNF layer): affine coupling -> Flip -> Sigmoid ->
+        cubic-spline coupling -> Logit, as one fused launch against the same flow evaluated layer by layer;
+      * a NeuralFlow of 4 ContinuousAffineCoupling layers (coupling.py:98-213, flow.py:155-184): forward(x, t)."""
+    import torch
+    out = []
+    rows = ROWS_PER_GPU
+
+    def timed(fn, reps=steps):
+        fn()
+        torch.cuda.synchronize()
+        for _ in range(3):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
+
+    try:
+        torch.manual_seed(0)
+        D, H, K = 64, 64, 16
+        stack = st.NormalizingFlow(st.UnitNormal(D), [
+            st.Coupling(st.Affine(D, latent_net=st.net.MLP(D, [H], 2 * D)), mask='ordered_1'),
+            st.Flip(dims=[-1]),
+            st.Sigmoid(),
+            st.Coupling(st.Spline(D, n_bins=K, latent_net=st.net.MLP(D, [H], D * (2 * K + 2)), spline_type='cubic'), mask='ordered_0'),
+            st.Logit()]).to(dev)
+        x = torch.randn(rows, D, device=dev, generator=gen)
+        fused = stack._fused_program(True, D, 0, dev) is not None
+        ms = timed(lambda: stack.log_prob(x))
+
+        def layerwise():
+            cur, acc = x, 0
+            for f in reversed(stack.transforms):
+                cur, l = f.inverse_and_log_det_jacobian(cur)
+                acc = acc + l
+            return stack.base_dist.log_prob(cur).unsqueeze(-1) + acc
+        ms_l = timed(layerwise, max(3, steps // 4))
+        out.append({'name': 'reference_stack', 'workload': 'affine coupling -> Flip -> Sigmoid -> cubic-spline coupling (K=16) -> Logit, D=64, '
+                    '2^20 rows fp32, log_prob (stribor/test/test_normalizing_flow.py:13-35 without the CNF layer)',
+                    'one_fused_launch': bool(fused), 'ms_per_step': ms, 'value': rows / (ms * 1e-3), 'unit': 'samples/s',
+                    'ms_per_step_layer_by_layer': ms_l, 'speedup_vs_layer_by_layer': ms_l / ms})
+        del stack, x
+    except Exception as e:                                   # a perf line must not take the headline down
+        out.append({'name': 'reference_stack', 'error': repr(e)})
+    try:
+        torch.manual_seed(0)
+        D, H = 64, 64
+        layers = [st.ContinuousAffineCoupling(latent_net=st.net.MLP(D + 1, [H], 2 * D), time_net=st.net.TimeTanh(2 * D),
+                                              mask='ordered_0' if i % 2 == 0 else 'ordered_1') for i in range(4)]
+        nf = st.NeuralFlow(layers).to(dev)
+        x = torch.randn(rows, D, device=dev, generator=gen)
+        t = torch.rand(rows, 1, device=dev, generator=gen)
+        ms = timed(lambda: nf(x, t), max(3, steps // 2))
+        out.append({'name': 'neural_flow', 'workload': 'NeuralFlow of 4 ContinuousAffineCoupling(MLP(65,[64],128), TimeTanh), D=64, 2^20 rows '
+                    'fp32, forward(x, t) (flow.py:155-184, coupling.py:98-213)', 'ms_per_step': ms, 'value': rows / (ms * 1e-3),
+                    'unit': 'samples/s', 'launches': 'see DESIGN 4.5'})
+        del nf, x, t
+    except Exception as e:
+        out.append({'name': 'neural_flow', 'error': repr(e)})
+    return out
 
 
 def time_training_step(name, workload, flow, x, steps, note):
+    """`_time_training_step`, but a failing entry (e.g. a GemmRangeError of the fp16 x 3 arithmetic on some initialisation) is
+    recorded as such instead of taking the headline line down with it."""
+    import torch
+    try:
+        return _time_training_step(name, workload, flow, x, steps, note)
+    except Exception as e:
+        torch.cuda.synchronize()
+        try:
+            import stribor_amd as st
+            st.check_errors()
+        except Exception:
+            pass
+        return {'name': name, 'workload': workload, 'error': repr(e)[:300], 'finite': False, 'ms_per_step': None}
+
+
+def _time_training_step(name, workload, flow, x, steps, note):
     """Training step beside the inference lines: forward + backward of loss = -log_prob(x).mean(), all
     parameter gradients; median over event-timed groups of 3 steps after warm-up."""
     import torch
@@ -209,6 +317,7 @@ def main():
     import torch.distributed as dist
 
     import stribor_amd as st
+    from stribor_amd import _hip
     from stribor_amd.sharded import ShardedLogProb
     from stribor_amd.util import flowdesc as fd
 
@@ -323,7 +432,8 @@ def main():
             'roofline': {'kernel': 'flow_fused_kernel<NS=1,TX=2,HT=2,MODE=5> (pure split-coupling program, 8-wave workgroups)', 'bound': 'mfma',
                          'achieved': achieved_tflops, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved_tflops / peak,
                          'traffic': pmc.get('flow_fused_kernel', {}).get('hbm_bytes_per_launch'),
-                         'traffic_pmc_commit': pmc.get('commit', '5b99493 (round 1, r01_h build)'),
+                         'traffic_pmc_build_id': pmc.get('build_id'), 'traffic_stale_profile': pmc.get('stale_profile'),
+                         'library_build_id': _hip.build_id(),
                          'avg_kernel_ms': k_avg_ms, 'median_kernel_ms': k_med_ms,
                          'gemm_arithmetic': 'fp16 x 3 split on v_mfma_f32_32x32x16_f16, fp32 accumulate '
                                             '(3 MFMA products per algorithmic product)',
@@ -335,35 +445,46 @@ def main():
                          'valu_issue_busy_frac_pmc': sq.get('valu_issue_busy_frac'),
                          'mfma_pipe_busy_frac_pmc': sq.get('mfma_pipe_busy_frac'),
                          'effective_clock_ghz_pmc': sq.get('effective_clock_ghz'),
-                         'sq_pmc_commit': sq.get('commit', '5b99493 (round 1, r01_h build)'),
+                         'sq_pmc_build_id': sq.get('build_id'), 'sq_stale_profile': sq.get('stale_profile'),
                          'algorithmic_flops_per_launch': FLOPS_PER_ROW * ROWS_PER_GPU,
                          'algorithmic_bytes_per_launch': BYTES_PER_ROW * ROWS_PER_GPU,
                          'hbm_frac_of_same_kernel': BYTES_PER_ROW * ROWS_PER_GPU / (k_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
             'roofline_elementwise': {'kernel': 'affine_coupling_vec_kernel<bf16,reverse> (16 B per lane)', 'bound': 'hbm',
                                      'achieved': e_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': e_gbs / PEAK_HBM_GBS,
                                      'traffic': (pmc.get('affine_coupling_vec_kernel') or pmc.get('affine_coupling_vec4_kernel') or {}).get('hbm_bytes_per_launch'),
-                                     'traffic_pmc_commit': pmc.get('commit', '5b99493 (round 1, r01_h build)'),
+                                     'traffic_pmc_build_id': pmc.get('build_id'),
                                      'avg_kernel_ms': e_avg_ms,
                                      'algorithmic_bytes_per_launch': ELEMWISE_BYTES_PER_ROW * ROWS_PER_GPU},
             'log_prob_sum': total_value,
         }
         if world == 1 and not args.no_extra_configs:
-            # BASELINE cfg 3 / cfg 4 at their full 2^20 rows, fp32 storage, same process, after the headline
-            del x
+            # BASELINE cfg 3 / cfg 4 at their full 2^20 rows, fp32 storage, same process, after the headline; beside each its own
+            # CPU baseline (the oracle on this box's cores, bounded sample), and cfg 2 once more in the exact-fp32 arithmetic
             extra_steps = max(5, min(args.steps, 20))
             cfgs = []
             with torch.no_grad():
+                cfgs.append(time_extra_config(
+                    'cfg2_exact', 'cfg2 (headline workload, x stored bf16) in the exact arithmetic: set_gemm_precision("exact")',
+                    flow, x, extra_steps, args.warmup, FLOPS_PER_ROW, BYTES_PER_ROW,
+                    'flow_fused_kernel<NS=1,TX=2,HT=2,MODE=5>, sx_f32x build (v_mfma_f32_32x32x2_f32)', {}, exact=True))
+                del x
                 torch.manual_seed(0)
-                f3 = fd.build_flow(st, fd.cfg3_desc(), 64).to(dev)
+                f3 = fd.build_flow(st, fd.cfg3_desc(), 64)
+                s3 = {k_: v_.clone() for k_, v_ in f3.state_dict().items()}
+                f3 = f3.to(dev)
                 x3 = torch.randn(ROWS_PER_GPU, 64, device=dev, generator=gen)
                 cfgs.append(time_extra_config(
                     'cfg3', 'cfg3: D=64, 8 rational-quadratic st.Spline couplings, K=16 bins on [-3, 3] (MLP hidden 64), '
                     'batch 2^20, fp32', f3, x3, extra_steps, args.warmup, CFG3_FLOPS_PER_ROW, CFG3_BYTES_PER_ROW,
                     'flow_fused_kernel<NS=1,TX=2,HT=2,MODE=3> (spline phases: parameters only in registers)',
                     load_profile('pmc_cfg3.json')))
+                if not args.no_cpu_baseline:
+                    cfgs[-1]['cpu_baseline'] = cpu_baseline(fd.cfg3_desc(), s3, 64, budget_s=6.0, max_rows=1 << 16, what='cfg3')
                 del f3, x3
                 torch.manual_seed(0)
-                f4 = fd.build_flow(st, fd.cfg4_desc(), 128).to(dev)
+                f4 = fd.build_flow(st, fd.cfg4_desc(), 128)
+                s4 = {k_: v_.clone() for k_, v_ in f4.state_dict().items()}
+                f4 = f4.to(dev)
                 x4 = torch.randn(ROWS_PER_GPU, 128, device=dev, generator=gen)
                 cfgs.append(time_extra_config(
                     'cfg4', 'cfg4: D=128, 4 x [st.AffineLU, affine coupling, st.MatrixExponential (t=1), affine coupling] '
@@ -375,9 +496,12 @@ def main():
                                               'note': 'achieved counts the reference\'s two triangular products per '
                                                       'MatrixExponential (SURVEY 8(d): 589,824 flop/row); the kernel '
                                                       'runs the collapsed single matrix (458,752): frac_collapsed'}))
+                if not args.no_cpu_baseline:
+                    cfgs[-1]['cpu_baseline'] = cpu_baseline(fd.cfg4_desc(), s4, 128, budget_s=6.0, max_rows=1 << 16, what='cfg4')
                 del f4, x4
+                cfgs += extra_flow_entries(st, fd, dev, gen, extra_steps)
             result['configs'] = cfgs
-            # training steps (forward + backward) of the two trainable BASELINE families, same process
+            # training steps (forward + backward) of the trainable BASELINE families, same process
             tr = []
             if not args.no_training:
                 torch.manual_seed(0)
@@ -394,14 +518,29 @@ def main():
                                              'parameter', f3, x3t, 12,
                                              'spline backward fused with the last conditioner layer, no [N, 1504] parameter tensor '
                                              '(sx_rqs_slab_bwd, DESIGN 4.3.1); HBM bytes per step in profiles/pmc_training_cfg3_fused.json'))
-                del f3, x3t
+                del f3
                 pt = load_profile('pmc_training_cfg3_fused.json')
-                if pt:
+                if pt and not pt.get('stale_profile'):
                     tr[-1]['hbm_MB_per_step_pmc'] = {'read': pt.get('hbm_read_MB_per_step'), 'written': pt.get('hbm_write_MB_per_step'),
-                                                     'per_row_parameter_path': load_profile('pmc_training_cfg3_unfused.json').get(
-                                                         'hbm_read_MB_per_step', 0) + load_profile(
-                                                         'pmc_training_cfg3_unfused.json').get('hbm_write_MB_per_step', 0),
-                                                     'source': 'profiles/pmc_training_cfg3_{fused,unfused}.json (builder-run rocprofv3 passes)'}
+                                                     'source': 'profiles/pmc_training_cfg3_fused.json (builder-run rocprofv3 passes, same build id)'}
+                torch.manual_seed(0)
+                cub = [dict(d_, spline_type='cubic') for d_ in fd.cfg3_desc()]
+                f3c = fd.build_flow(st, cub, 64).to(dev)
+                tr.append(time_training_step('cfg3_cubic_train', 'cfg3 shape with spline_type="cubic" (the reference\'s default), 2^18 rows '
+                                             'fp32: loss = -log_prob.mean(), backward to every parameter', f3c, x3t, 9,
+                                             'fused MODE 12 forward + cubic slab backward (DESIGN 4.3.1)'))
+                del f3c, x3t
+                torch.manual_seed(0)
+                f4 = fd.build_flow(st, fd.cfg4_desc(), 128).to(dev)
+                for rows_ in (ROWS_PER_GPU // 4, ROWS_PER_GPU):
+                    x4t = torch.randn(rows_, 128, device=dev, generator=gen)
+                    tr.append(time_training_step(f'cfg4_train_2^{rows_.bit_length() - 1}', f'cfg4 flow, {rows_} rows fp32: loss = -log_prob.mean(), '
+                                                 'backward to every parameter', f4, x4t, 9 if rows_ < ROWS_PER_GPU else 6,
+                                                 'single-launch backward program on 4 + 4 tiles (SX_STEP_LINEAR_BWD / COUPLING_AFFINE_BWD_A / _B), '
+                                                 'weight gradients by sx_wgrad on the stored factors, D x D parameter algebra in batched fp64 '
+                                                 'torch ops: no library GEMM (DESIGN 4.3.2)'))
+                    del x4t
+                del f4
             if not args.no_training:
                 result['training'] = tr
         if world == 1 and not args.no_cpu_baseline:

@@ -331,6 +331,17 @@ int sx_pack_linear(const float *W, const float *b, int32_t out_dim, int32_t in_d
 #define SX_STEP_COUPLING_AFFINE_BWD 12  /* backward of one affine coupling of a log_prob pass (training): state tiles
                                            [0,2) = x, [2,4) = dL/dx; blob = forward blob ++ pack(W2^T) ++ pack(W1^T); c0 = cond
                                            tile, t0 = transformed tile, tt = layer slot in `side` (see sx_flow_run)             */
+#define SX_STEP_COUPLING_AFFINE_BWD_A 16 /* 128-column flows (x_tiles = 4, tiles = 8): the backward of one affine coupling in two steps, since
+                                         * its four packed operands do not fit the LDS ring together.  A: blob = pack(W1') ++ pack(W2') (as
+                                         * kind 12's first two): conditioner, un-transform, dL/d(log_scale, shift) (kept in registers for B);
+                                         * c0 = first conditioner tile (0 or 2; the transformed tiles are the other half), tt = layer slot
+                                         * of the side buffer.                                                                          */
+#define SX_STEP_COUPLING_AFFINE_BWD_B 17 /* B: blob = pack(W2^T) ++ pack(W1^T): dL/dh, dL/dh_pre, adjoint of the conditioning tiles; same c0 / tt */
+#define SX_STEP_LINEAR_BWD          18  /* dense linear layer of a backward program (AffineLU / MatrixExponential, affine.py:156-171,243-288):
+                                         * tiles [c0, c0 + 4) <- M . tiles + b, blob = pack_linear(M, 4 x 4) (c0 = 0: the x tiles, M = the
+                                         * layer's forward matrix; c0 = 4: the adjoint tiles, M = W^T of the matrix log_prob applied).  The
+                                         * factors of dL/dW = sum_n dL/du_n v_n^T are stored to the side buffer of layer slot tt at feature
+                                         * offset 32 * t0: before the step when reverse = 1 (the adjoint), after it otherwise (v).        */
 #define SX_STEP_CPL_HIDDEN          13  /* deep conditioners (>= 2 hidden layers): hidden = act(W1 . state[c0..c0+ct) + b1), kept in
                                            registers for the next step; blob = pack_linear(W1, h_tiles x ct)                    */
 #define SX_STEP_CPL_HIDDEN2         14  /* hidden = act(Wk . hidden + bk); blob = pack_linear(Wk, h_tiles x h_tiles)              */
@@ -358,7 +369,7 @@ typedef struct sx_program {
     int32_t dim;          /* D: columns of x / y                                               */
     int32_t latent_dim;   /* columns of `latent` (0 = none); they occupy tiles after the data  */
     int32_t x_tiles;      /* tiles holding data columns                                        */
-    int32_t tiles;        /* x_tiles + latent tiles: 1, 2 or 4                                 */
+    int32_t tiles;        /* x_tiles + latent tiles: 1, 2 or 4 (8: backward programs of 128-column flows) */
     int32_t h_tiles;      /* hidden width / 32 rounded up to 1, 2 or 4                         */
     int32_t identity_cols;/* 1: state slot p <-> column p (vector loads), 0: use in_col/out_col */
     int32_t pad_;

@@ -34,6 +34,9 @@ STEP_COUPLING_AFFINE_BWD = 12
 STEP_CPL_HIDDEN = 13
 STEP_CPL_HIDDEN2 = 14
 STEP_COUPLING_AFFINE_DEEP = 15
+STEP_COUPLING_AFFINE_BWD_A = 16
+STEP_COUPLING_AFFINE_BWD_B = 17
+STEP_LINEAR_BWD = 18
 
 WGRAD_ROW_MAJOR, WGRAD_ROW_GROUPS = 0, 1
 

@@ -15,8 +15,10 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     *side_width = 0;
     SX_REQUIRE(p != nullptr, "sx_flow_run: null program");
     SX_REQUIRE(p->n_steps >= 0 && p->n_steps <= SX_MAX_STEPS, "sx_flow_run: n_steps %d out of range", p->n_steps);
-    SX_REQUIRE(p->tiles == 1 || p->tiles == 2 || p->tiles == 4, "sx_flow_run: tiles must be 1, 2 or 4 (got %d)", p->tiles);
+    SX_REQUIRE(p->tiles == 1 || p->tiles == 2 || p->tiles == 4 || (p->tiles == 8 && p->x_tiles == 4),
+               "sx_flow_run: tiles must be 1, 2 or 4 (8 = 4 data + 4 adjoint tiles of a backward program; got %d)", p->tiles);
     SX_REQUIRE(p->h_tiles == 1 || p->h_tiles == 2 || p->h_tiles == 4, "sx_flow_run: h_tiles must be 1, 2 or 4");
+    SX_REQUIRE(p->tiles != 8 || p->h_tiles <= 2, "sx_flow_run: backward programs of 128-column flows are built for hidden <= 64");
     SX_REQUIRE(p->x_tiles >= 1 && p->x_tiles <= p->tiles, "sx_flow_run: bad x_tiles");
     SX_REQUIRE(p->dim >= 1 && p->dim <= 32 * p->x_tiles, "sx_flow_run: dim %d does not fit %d tiles", p->dim, p->x_tiles);
     SX_REQUIRE(p->latent_dim >= 0 && p->latent_dim <= 32 * (p->tiles - p->x_tiles), "sx_flow_run: latent_dim does not fit");
@@ -25,6 +27,7 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     d->identity_cols = p->identity_cols; d->pad = 0;
     int mx = 256;
     bool lin = false, rqs = false, aff = false, bwd = false, deep = false, cub = false, quadr = false;
+    int n_bwd128 = 0;
     *mlp_mode = 0;
     for (int i = 0; i < p->n_steps; ++i) {
         const sx_step &s = p->steps[i];
@@ -67,7 +70,7 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
                 deep = true; aff = true; break;
             case SX_STEP_COUPLING_AFFINE_BWD: {
                 SX_REQUIRE((p->tiles == 2 || p->tiles == 4) && p->x_tiles * 2 == p->tiles,
-                           "sx_flow_run: step %d: backward programs carry x and dL/dx: tiles = 2 * x_tiles (2 or 4)", i);
+                           "sx_flow_run: step %d: backward programs carry x and dL/dx: tiles = 2 * x_tiles (2 or 4; 128-column flows use kinds 16 - 18)", i);
                 const int XT = p->x_tiles;
                 const bool low = XT == 2 && s.c0 == 0 && s.ct == 1 && s.t0 == 1;
                 const bool high = XT == 2 && s.c0 == 1 && s.ct == 1 && s.t0 == 0;
@@ -79,6 +82,28 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
                 const int sw = 32 * ct + 64 * p->h_tiles + 64 * tt;
                 if (sw > *side_width) *side_width = sw;
                 bwd = true; break;
+            }
+            case SX_STEP_COUPLING_AFFINE_BWD_A:
+            case SX_STEP_COUPLING_AFFINE_BWD_B: {
+                SX_REQUIRE(p->tiles == 8 && p->x_tiles == 4, "sx_flow_run: step %d: kinds 16 / 17 belong to backward programs on 4 + 4 tiles", i);
+                SX_REQUIRE((s.c0 == 0 || s.c0 == 2) && s.ct == 2, "sx_flow_run: step %d: conditioner tiles must be one half of the data tiles", i);
+                SX_REQUIRE(s.kind == SX_STEP_COUPLING_AFFINE_BWD_A || (i > 0 && p->steps[i - 1].kind == SX_STEP_COUPLING_AFFINE_BWD_A &&
+                                                                      p->steps[i - 1].c0 == s.c0 && p->steps[i - 1].tt == s.tt),
+                           "sx_flow_run: step %d: a BWD_B step follows its BWD_A step", i);
+                need = s.kind == SX_STEP_COUPLING_AFFINE_BWD_A
+                           ? sx_packed_linear_floats(p->h_tiles, 2) + sx_packed_linear_floats(4, p->h_tiles)
+                           : sx_packed_linear_floats(p->h_tiles, 4) + sx_packed_linear_floats(2, p->h_tiles);
+                const int sw = 32 * 2 + 64 * p->h_tiles + 64 * 2;
+                if (sw > *side_width) *side_width = sw;
+                bwd = true; ++n_bwd128; break;
+            }
+            case SX_STEP_LINEAR_BWD: {
+                SX_REQUIRE(p->tiles == 8 && p->x_tiles == 4, "sx_flow_run: step %d: kind 18 belongs to backward programs on 4 + 4 tiles", i);
+                SX_REQUIRE((s.c0 == 0 || s.c0 == 4) && s.t0 >= 0 && s.t0 + 4 <= 16, "sx_flow_run: step %d: bad tiles / side offset", i);
+                need = sx_packed_linear_floats(4, 4);
+                const int sw = 32 * (s.t0 + 4);
+                if (sw > *side_width) *side_width = sw;
+                bwd = true; ++n_bwd128; break;
             }
             case SX_STEP_RQS_HIDDEN: {
                 const int T = p->tiles;
@@ -114,6 +139,7 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     if (rqs) *mlp_mode = cub ? 12 : 3;
     SX_REQUIRE(!(bwd && (rqs || lin || aff || *mlp_mode == 1)), "sx_flow_run: backward steps cannot be mixed with other step kinds");
     if (bwd) *mlp_mode = 4;
+    SX_REQUIRE(p->tiles != 8 || (bwd && n_bwd128 == p->n_steps), "sx_flow_run: 8 state tiles carry backward steps (kinds 16 - 18) only");
     SX_REQUIRE(!(deep && (lin || bwd || *mlp_mode == 1)), "sx_flow_run: deep-conditioner steps only mix with couplings");
     if (deep) *mlp_mode = rqs ? (cub ? 13 : 10) : 9;     // 10 / 13: the spline kernels with the deep-conditioner steps
     // MODE 5 / 6: nothing but tanh-folded affine couplings on half the tiles conditioned on the other half, all in
@@ -204,6 +230,7 @@ extern "C" int sx_flow_run(const sx_program *prog_host, const float *blobs, cons
     const int T = prog_host->tiles, H = prog_host->h_tiles;
 #define SX_GO(TT, HH) if (T == TT && H == HH) return precision == SX_GEMM_F16X3 ? sx_flow_launch_f16x3_t##TT##h##HH(a) : sx_flow_launch_f32x_t##TT##h##HH(a)
     SX_GO(1, 1); SX_GO(1, 2); SX_GO(1, 4); SX_GO(2, 1); SX_GO(2, 2); SX_GO(2, 4); SX_GO(4, 1); SX_GO(4, 2); SX_GO(4, 4);
+    SX_GO(8, 1); SX_GO(8, 2);
 #undef SX_GO
     sx_set_error("sx_flow_run: unsupported tile configuration");
     return SX_E_UNSUPPORTED;

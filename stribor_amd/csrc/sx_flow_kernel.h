@@ -1283,6 +1283,134 @@ __device__ __forceinline__ void coupling_affine_bwd(tile<1> (&xs)[2 * XT], const
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same backward step for 128-column flows (XT = 4 data tiles + 4 adjoint tiles, cfg 4), in TWO steps: all four packed
+// operands of a D = 128 coupling (W1', W2', W2^T, W1^T: 100 KB) do not fit the double-buffered LDS ring, so step A carries the
+// forward operands (recompute the conditioner, un-transform, parameter adjoints) and step B the transposed ones (dh, dh_pre,
+// adjoint of the conditioning tiles); r = (1 - tanh h) / 2 and dL/d(log_scale, shift) wait for step B in registers (`keep`).
+// Side features of a row: [z (32 CT) | tanh h (32 HT) | dL/dh_pre (32 HT) | per transformed tile dL/dls (32), dL/dsh (32)].
+// ------------------------------------------------------------------------------------------------
+template <int XT, int HT, int C0, int CT, int T0, int TT>
+__device__ __forceinline__ void coupling_affine_bwd_a(tile<1> (&xs)[2 * XT], const wptr w, float g, float *side_row, int lane,
+                                                      rng_t &rg, tile<1> (&keep)[HT + 2 * TT]) {
+    constexpr int F1 = 0;                                            // pack(W1', HT x CT)
+    constexpr int F2 = HT * CT * 1024 + HT * 32;                     // pack(W2', 2TT x HT)
+    constexpr int F2B = F2 + 2 * TT * HT * 1024;                     //   its bias
+    const int h = lane >> 5;
+    if (side_row != nullptr) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) store_ctile(side_row, 32 * c, xs[C0 + c].v[0], h);
+    }
+    tile<1> hid[HT];
+    hidden_layer<1, 2 * XT, HT, C0, CT, true>(xs, hid, w, F1, SX_ACT_TANH_FOLDED, rg);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hid[HT - 1].v[0][r] = fast_sig2(hid[HT - 1].v[0][r]);
+    btile<1> bh[HT];
+#pragma unroll
+    for (int m = 0; m < HT; ++m) { bh[m] = make_btile<1>(hid[m]); keep[m] = hid[m]; }
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        tile<1> ls = load_cfrag<1>(w.cb, F2B + (2 * t) * 32), sh = load_cfrag<1>(w.cb, F2B + (2 * t + 1) * 32);
+#pragma unroll
+        for (int m = 0; m < HT; ++m) {
+            gemm_tile<1>(w.wb, F2 + ((2 * t) * HT + m) * 1024, bh[m], ls);          // kk*log_scale, kk = -log2 e
+            gemm_tile<1>(w.wb, F2 + ((2 * t + 1) * HT + m) * 1024, bh[m], sh);      // shift
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f(ls.v[0][r]);                     // exp(-log_scale)
+            const float xo = xs[T0 + t].v[0][r], al = xs[XT + T0 + t].v[0][r];
+            xs[T0 + t].v[0][r] = xo * __builtin_amdgcn_exp2f(-ls.v[0][r]) + sh.v[0][r];      // x_in
+            const float ai = al * e;                                                // dL/dx_in
+            xs[XT + T0 + t].v[0][r] = ai;
+            keep[HT + 2 * t + 1].v[0][r] = -ai;                                     // dL/dshift
+            keep[HT + 2 * t].v[0][r] = -al * xo - g;                                // dL/dlog_scale (incl. -sum(ls))
+        }
+        if (side_row != nullptr) {
+            store_ctile(side_row, 32 * CT + 64 * HT + 64 * t, keep[HT + 2 * t].v[0], h);
+            store_ctile(side_row, 32 * CT + 64 * HT + 64 * t + 32, keep[HT + 2 * t + 1].v[0], h);
+        }
+    }
+}
+template <int XT, int HT, int C0, int CT, int T0, int TT>
+__device__ __forceinline__ void coupling_affine_bwd_b(tile<1> (&xs)[2 * XT], const wptr w, float *side_row, int lane, rng_t &rg,
+                                                      tile<1> (&keep)[HT + 2 * TT]) {
+    constexpr int B2 = 0;                                            // pack(W2^T, HT x 2TT)
+    constexpr int B1 = HT * 2 * TT * 1024 + HT * 32;                 // pack(W1^T, CT x HT)
+    const int h = lane >> 5;
+    tile<1> dh[HT];
+#pragma unroll
+    for (int m = 0; m < HT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh[m].v[0][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        const btile<1> b0 = make_btile<1>(keep[HT + 2 * t], rg), b1 = make_btile<1>(keep[HT + 2 * t + 1], rg);
+#pragma unroll
+        for (int m = 0; m < HT; ++m) {
+            gemm_tile<1>(w.wb, B2 + (m * 2 * TT + 2 * t) * 1024, b0, dh[m]);
+            gemm_tile<1>(w.wb, B2 + (m * 2 * TT + 2 * t + 1) * 1024, b1, dh[m]);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < HT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float th = 1.f - 2.f * keep[m].v[0][r];              // tanh
+            keep[m].v[0][r] = th;
+            dh[m].v[0][r] *= (1.f - th * th);
+        }
+    if (side_row != nullptr) {
+#pragma unroll
+        for (int m = 0; m < HT; ++m) {
+            store_ctile(side_row, 32 * CT + 32 * m, keep[m].v[0], h);
+            store_ctile(side_row, 32 * CT + 32 * HT + 32 * m, dh[m].v[0], h);
+        }
+    }
+    btile<1> bd[HT];
+#pragma unroll
+    for (int m = 0; m < HT; ++m) bd[m] = make_btile<1>(dh[m], rg);
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        tile<1> dz;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dz.v[0][r] = 0.f;
+#pragma unroll
+        for (int m = 0; m < HT; ++m) gemm_tile<1>(w.wb, B1 + (c * HT + m) * 1024, bd[m], dz);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xs[XT + C0 + c].v[0][r] += dz.v[0][r];
+    }
+}
+// Dense linear layer of the backward pass (AffineLU / MatrixExponential, affine.py:156-171,243-288), one step per half of the
+// state: tiles [T0, T0 + XT) <- M . tiles + b (blob = pack_linear(M, XT x XT) + bias).  On the x tiles M is the layer's FORWARD
+// matrix (the log_prob pass applied its inverse: u = W v + c; the step recovers v), on the adjoint tiles it is W^T (dL/dv = W^T
+// dL/du).  The factors of dL/dW = sum_n dL/du_n v_n^T go to the side buffer: the adjoint tiles BEFORE their step (store_before),
+// the x tiles AFTER theirs, at feature offset `soff`.
+template <int XT, int T0>
+__device__ __forceinline__ void linear_bwd_half(tile<1> (&xs)[2 * XT], const wptr w, float *side_row, int soff, bool store_before,
+                                                int lane, rng_t &rg) {
+    const int h = lane >> 5;
+    if (side_row != nullptr && store_before) {
+#pragma unroll
+        for (int c = 0; c < XT; ++c) store_ctile(side_row, soff + 32 * c, xs[T0 + c].v[0], h);
+    }
+    btile<1> bx[XT];
+#pragma unroll
+    for (int c = 0; c < XT; ++c) bx[c] = make_btile<1>(xs[T0 + c], rg);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < XT; ++m) {
+        tile<1> acc = load_cfrag<1>(w.cb, XT * XT * 1024 + m * 32);
+#pragma unroll
+        for (int c = 0; c < XT; ++c) gemm_tile<1>(w.wb, (m * XT + c) * 1024, bx[c], acc);
+        xs[T0 + m] = acc;
+    }
+    if (side_row != nullptr && !store_before) {
+#pragma unroll
+        for (int c = 0; c < XT; ++c) store_ctile(side_row, soff + 32 * c, xs[T0 + c].v[0], h);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Training backward with the weight gradients contracted IN the kernel (fp16 x 3 build only).
 //
 // The single-launch backward above writes 224 floats of per-row factors per layer to HBM (7.5 GB per 2^20-row cfg-2
@@ -1634,7 +1762,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     }
                 } else if constexpr (MODE == 4 || MODE == 11) {
                     // adjoint tiles: dL/dz of log p = -z^2/2 + ... is -g z (g = dL/dlog_prob of the row)
-                    if constexpr (TX == 2 || TX == 4) {
+                    if constexpr (TX == 2 || TX == 4 || TX == 8) {
                         const float gg = k.row_t[lrow[n]];
 #pragma unroll
                         for (int r = 0; r < 16; ++r) xs[t].v[n][r] = -gg * xs[t - TX / 2].v[n][r];
@@ -1663,6 +1791,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
         tile<NS> hid[MODE == 1 ? HT : 1];
         constexpr bool LIN = MODE == 2 || MODE == 7 || MODE == 8;    // programs with dense linear layers
         tile<NS> hidp[MODE == 9 ? HT : 1];                           // MODE 9: hidden state kept between deep-conditioner steps
+        tile<1> bkeep[(MODE == 4 && TX == 8) ? HT + TX / 2 : 1];     // MODE 4, D = 128: r and dL/d(ls, sh) between steps A and B
         constexpr bool CUB = MODE == 12 || MODE == 13;    // cubic-spline couplings (13: + deep conditioners)
         constexpr bool RQ = MODE == 3 || MODE == 10 || CUB;      // spline couplings (10: + deep conditioners)
         constexpr bool RQDEEP = MODE == 10 || MODE == 13;
@@ -1732,6 +1861,35 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                 if constexpr (TX >= 2 && (MODE == 7 || MODE == 8)) {
                     if (st.c0 == 0) coupling_affine<NS, TX, HT, 0, TX / 2, TX / 2, TX / 2, true, MODE == 7>(xs, w, st, ldj, pf, rg);
                     else coupling_affine<NS, TX, HT, TX / 2, TX / 2, 0, TX / 2, true, MODE == 7>(xs, w, st, ldj, pf, rg);
+                }
+            } else if constexpr (MODE == 4 && TX == 8) {
+                // training backward of 128-column flows: these three step kinds only (the general switch below would instantiate
+                // every coupling variant on eight tiles)
+                if constexpr (NS == 1) {
+                    float *srow = row[0] < n_rows ? k.side + ((int64_t)st.tt * ((n_rows + 31) >> 5) + (row[0] >> 5)) * (k.side_width * 32) + (row[0] & 31) : nullptr;
+#ifdef SX_EXP_NOSIDE
+                    srow = nullptr;     // timing experiment: no factor stores (gradients wrong)
+#endif
+                    // ONE arm per step kind: a coupling whose conditioner sits in the high tiles (c0 = 2) swaps the halves of x and of
+                    // the adjoint in registers (64 v_swap) before its A step and back after its B step; the adjoint half of a dense
+                    // layer (c0 = 4) swaps x <-> adjoint around the step.  (With one template arm per (kind, c0) pair the register
+                    // allocator merged six versions of the 128-register state: 848 B of scratch per lane.)
+                    auto swap_tiles = [&](int a, int b) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { const float t_ = xs[a].v[0][r]; xs[a].v[0][r] = xs[b].v[0][r]; xs[b].v[0][r] = t_; }
+                    };
+                    if (st.kind == SX_STEP_COUPLING_AFFINE_BWD_A) {
+                        const float gg = k.row_t[lrow[0]];
+                        if (st.c0 != 0) { swap_tiles(0, 2); swap_tiles(1, 3); swap_tiles(4, 6); swap_tiles(5, 7); }
+                        coupling_affine_bwd_a<4, HT, 0, 2, 2, 2>(xs, w, gg, srow, lane, rg, bkeep);
+                    } else if (st.kind == SX_STEP_COUPLING_AFFINE_BWD_B) {
+                        coupling_affine_bwd_b<4, HT, 0, 2, 2, 2>(xs, w, srow, lane, rg, bkeep);
+                        if (st.c0 != 0) { swap_tiles(0, 2); swap_tiles(1, 3); swap_tiles(4, 6); swap_tiles(5, 7); }
+                    } else if (st.kind == SX_STEP_LINEAR_BWD) {
+                        if (st.c0 != 0) { swap_tiles(0, 4); swap_tiles(1, 5); swap_tiles(2, 6); swap_tiles(3, 7); }
+                        linear_bwd_half<4, 0>(xs, w, srow, 32 * st.t0, st.reverse != 0, lane, rg);
+                        if (st.c0 != 0) { swap_tiles(0, 4); swap_tiles(1, 5); swap_tiles(2, 6); swap_tiles(3, 7); }
+                    }
                 }
             } else
             switch (st.kind) {
@@ -2156,6 +2314,10 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
         }                                                                                                      \
         hipLaunchKernelGGL(kern, dim3(a.grid), dim3(64 * SX_BLOCK_WAVES(TX, MD)), a.lds, a.stream, a.prog, k);                         \
     } while (0)
+    if constexpr (TX == 8) {            // 4 data + 4 adjoint tiles: the training backward of 128-column flows only
+        if (a.mlp_mode == 4) SX_FL(4);
+        else { sx_set_error("sx_flow_run: 8 state tiles are the backward program's (mode %d)", a.mlp_mode); return SX_E_UNSUPPORTED; }
+    } else
     if (a.mlp_mode == 1) SX_FL(1); else if (a.mlp_mode == 2) SX_FL(2); else if (a.mlp_mode == 3) SX_FL(3);
     else if (a.mlp_mode == 4) SX_FL(4);
     else if (a.mlp_mode == 5) { if constexpr (TX >= 2) SX_FL(5); }

@@ -54,8 +54,11 @@ class _FusedLogProb(torch.autograd.Function):
         # loss over 2^20 rows makes g ~ 1e-6: below fp16's normal range, where the fp16 x 3 split keeps only a few bits.
         # So the pass runs on g * S, S = the power of two that brings max |g| to [1, 2), and every result is multiplied
         # by 1 / S afterwards -- exact (powers of two), all on the device (no host read-back).
-        gmax = g.abs().max()
-        S = torch.where(gmax > 0, torch.exp2(-torch.floor(torch.log2(gmax.clamp_min(1e-38)))), torch.ones_like(gmax))
+        # (the adjoints start at -g z and grow through the layers -- by the gain of the dense layers' matrices in cfg-4-like flows,
+        #  orders of magnitude in their worst directions -- so S leaves headroom: max |g| max(1, max |z|) lands in [1/2, 1) of a
+        #  range that reaches 65504 upwards and keeps 22 bits down to 0.125, 14 bits at 1e-3)
+        gmax = g.abs().max() * z.abs().max().clamp_min(1.0)
+        S = torch.where(gmax > 0, torch.exp2(-torch.floor(torch.log2(gmax.clamp_min(1e-38))) - 1.0), torch.ones_like(gmax))
         g = g * S
         inv_S = 1.0 / S
         ht = 32 * bprog.prog.h_tiles
@@ -64,9 +67,20 @@ class _FusedLogProb(torch.autograd.Function):
         # the parameter gradients live in ONE zero-filled buffer; sx_wgrad adds into views of it, mapping the
         # kernel's slot order to the parameters' own rows / columns on the way (no per-layer fills or gathers)
         shapes = []
-        for cpl, _ in layers:
+        dense_layers = [f for f, info in layers if info.get('kind') == 'dense']
+        for cpl, info in layers:
+            if info.get('kind') == 'dense':       # dL/d(matrix, bias) of the map log_prob applied; the parameters get theirs below
+                shapes.append((torch.empty(d, d, device='meta'), torch.empty(d, device='meta')))
+                continue
             (W1, b1), (W2, b2) = cpl._net().linears()
             shapes.append((W1, b1, W2, b2))
+        dense_graph = None
+        if dense_layers:
+            # the D x D algebra (LU products, inverses, matrix exponential) WITH a graph: the kernels produce dL/d(matrix), autograd
+            # of these batched fp64 ops carries it to the parameters; the backward program packs the same tensors (detached)
+            deriver = flow._dense_deriver()
+            dense_graph = deriver.get(z.device, True, graph=True)
+            deriver.get(z.device, False)
         flat = torch.zeros(sum(p_.numel() for ps in shapes for p_ in ps), dtype=torch.float32, device=dev)
         grads, views, off = {}, [], 0
         for ps in shapes:
@@ -74,18 +88,35 @@ class _FusedLogProb(torch.autograd.Function):
             for p_ in ps:
                 v = flat[off:off + p_.numel()].view(p_.shape)
                 off += p_.numel()
-                grads[id(p_)] = v
+                if not p_.is_meta:
+                    grads[id(p_)] = v
                 vs.append(v)
             views.append(vs)
+
+        def finish():
+            flat.mul_(inv_S)
+            if gy is not None:
+                gy.mul_(inv_S)
+            if dense_graph is not None:
+                outs, gouts = [], []
+                gsum = grad_logp.reshape(-1).to(torch.float32).sum()
+                for (f, info), vs in zip(layers, views):
+                    if info.get('kind') != 'dense':
+                        continue
+                    Wm, bm, ldj = dense_graph[id(f)]
+                    outs += [Wm, ldj] + ([bm] if bm is not None and bm.requires_grad else [])
+                    gouts += [vs[0], gsum.to(ldj.dtype)] + ([vs[1]] if bm is not None and bm.requires_grad else [])
+                ps = [p_ for f in dense_layers for p_ in f.parameters() if p_.requires_grad]
+                for p_, gp in zip(ps, torch.autograd.grad(outs, ps, gouts, allow_unused=True)):
+                    if gp is not None:
+                        grads[id(p_)] = gp if id(p_) not in grads else grads[id(p_)] + gp
+            out = [grads.get(id(p_)) for p_ in flow._grad_params()]
+            return (None, gy if ctx.need_input_grad else None, *out)
         gy = torch.empty_like(z) if ctx.need_input_grad else None
         lib = _hip.lib()
         if _FusedLogProb._layer_major_ok(bprog, layers, ht):
             _FusedLogProb._backward_layer_major(bprog, layers, views, z, g, gy if gy is not None else torch.empty_like(z))
-            flat.mul_(inv_S)
-            if gy is not None:
-                gy.mul_(inv_S)
-            out = [grads.get(id(p_)) for p_ in flow._grad_params()]
-            return (None, gy if ctx.need_input_grad else None, *out)
+            return finish()
         # the per-row factors are 224 floats per row and layer: bound the scratch by walking the batch in blocks.
         # Layout [layer, 32-row group, feature, 32 rows] (coalesced for the kernel's fragment stores and sx_wgrad's loads)
         block = max(32, min(n, _FusedLogProb.SIDE_BYTES // (len(layers) * width * 4)) // 32 * 32)
@@ -102,9 +133,18 @@ class _FusedLogProb(torch.autograd.Function):
                 base, ld = sd_all.data_ptr(), width * 32
                 for slot in range(len(layers)):
                     info = layers[slot][1]
+                    p0 = base + slot * ng * ld * 4
+                    if info.get('kind') == 'dense':
+                        # dL/dW[out, in] = sum_n dL/du_n v_n^T, dL/dc = sum_n dL/du_n of u = W v + c: features [0, 128) = dL/du,
+                        # [128, 256) = v, both in slot order (slot -> logical column through the maps)
+                        gWm, gbm = views[slot]
+                        sc = _hip.scratch(dev, lib.sx_wgrad_scratch_floats(128, 128, _hip.WGRAD_ROW_GROUPS))
+                        _hip.check(lib.sx_wgrad(p0, ld, 128, p0 + 128 * 128, ld, 128, m, _hip.WGRAD_ROW_GROUPS, gWm.data_ptr(),
+                                                gWm.stride(0), gbm.data_ptr(), info['slot_map'].data_ptr(), info['slot_map'].data_ptr(),
+                                                sc.data_ptr(), st), 'sx_wgrad')
+                        continue
                     H = info['hidden']
-                    zc, pc = 32 * info['ct'], 64 * info['tt']
-                    p0 = base + slot * ng * ld * 4                    # features: z | tanh h | dL/dh_pre | dL/dparams
+                    zc, pc = 32 * info['ct'], 64 * info['tt']                  # features: z | tanh h | dL/dh_pre | dL/dparams
                     gW1, gb1, gW2, gb2 = views[slot]
                     if info['ct'] == 1 and info['tt'] == 1 and ht <= 64:
                         # pruned half masks: both gradients of the layer in one pass over its 28 KB row groups
@@ -119,11 +159,7 @@ class _FusedLogProb(torch.autograd.Function):
                                             gW2.stride(0), gb2.data_ptr(), info['row_map'].data_ptr(), None, sc.data_ptr(), st), 'sx_wgrad')
                     _hip.check(lib.sx_wgrad(p0 + 128 * (zc + ht), ld, H, p0, ld, zc, m, _hip.WGRAD_ROW_GROUPS, gW1.data_ptr(),
                                             gW1.stride(0), gb1.data_ptr(), None, info['col_map'].data_ptr(), sc.data_ptr(), st), 'sx_wgrad')
-        flat.mul_(inv_S)
-        if gy is not None:
-            gy.mul_(inv_S)
-        out = [grads.get(id(p_)) for p_ in flow._grad_params()]
-        return (None, gy if ctx.need_input_grad else None, *out)
+        return finish()
 
 
 def _layer_major_ok(bprog, layers, ht) -> bool:
@@ -314,6 +350,7 @@ class NormalizingFlow(Transform):
             hw = max([f._plan_hidden_width() for f in order] + [1])
             b = ProgramBuilder(dim, latent_dim, hw)
             b.t = t_kind                      # None | float | 'tensor' (MatrixExponential's time)
+            b.dense_deriver = self._dense_deriver()      # AffineLU / MatrixExponential matrices: one batched fp64 derivation
             for f in order:
                 m = f._plan_first_mask(dim)
                 if m is not None:
@@ -327,6 +364,10 @@ class NormalizingFlow(Transform):
             return b.build(device)
         except NotImplementedError:
             return None
+
+    def _dense_deriver(self):
+        from .flows.linear import DenseDeriver
+        return self._cached(('dense-deriver',), lambda: DenseDeriver(list(self.transforms)))
 
     # ---- training (autograd) -----------------------------------------------------------------------------
     def _grad_params(self):
@@ -345,9 +386,13 @@ class NormalizingFlow(Transform):
             from .flows.coupling import Coupling
             from .flows.affine import Affine
             from .flows.permute import _ColumnShuffle
+            from .flows.linear import AffineLU, MatrixExponential
             order = list(self.transforms)
             hw = max([f._plan_hidden_width() for f in order] + [1])
-            b = ProgramBuilder(dim, 0, hw)
+            has_dense = any(isinstance(f, (AffineLU, MatrixExponential)) for f in order)
+            # dense linear layers (and flows wider than 64 columns) run the 4 + 4 tile form of the backward program
+            b = ProgramBuilder(dim, 0, hw, min_x_tiles=4 if (has_dense or dim > 64) else 1)
+            deriver = self._dense_deriver()
             # the backward pass starts in the slot layout the forward (log_prob) program ends in; affine-coupling
             # flows never move columns, so that is the layout chosen from the first mask the forward pass sees
             rev = list(reversed(order))
@@ -371,9 +416,15 @@ class NormalizingFlow(Transform):
                 if isinstance(f, _ColumnShuffle):
                     b.add_permutation(f._perm(dim).cpu().numpy(), False)
                     continue
-                if not (isinstance(f, Coupling) and isinstance(f.transform, Affine)):
-                    raise NotImplementedError('training backward is implemented for flows of Coupling(Affine) layers '
-                                              'and Permute / Flip')
+                if isinstance(f, (AffineLU, MatrixExponential)):
+                    fwd, adj = f._bwd_matrices(deriver)
+                    info = b.add_linear_bwd(list(f.parameters()), fwd, adj, len(layers))
+                    info['slot_map'] = torch.from_numpy(np.ascontiguousarray(info['slot_cols'], dtype=np.int32)).to(device)
+                    layers.append((f, info))
+                    continue
+                if not (isinstance(f, Coupling) and isinstance(f.transform, Affine)) or f.set_data:
+                    raise NotImplementedError('training backward is implemented for flows of Coupling(Affine), AffineLU / '
+                                              'MatrixExponential layers and Permute / Flip')
                 net = f._net()
                 lin = net.linears()
                 if len(lin) != 2 or net.activation_name != 'Tanh':
@@ -384,7 +435,7 @@ class NormalizingFlow(Transform):
                 info['row_map'] = torch.from_numpy(np.ascontiguousarray(info['out_rows'], dtype=np.int32)).to(device)
                 info['col_map'] = torch.from_numpy(np.ascontiguousarray(info['cond_cols'], dtype=np.int32)).to(device)
                 layers.append((f, info))
-            if not layers:
+            if not any(info.get('kind', 'coupling') == 'coupling' for _, info in layers):
                 raise NotImplementedError('no coupling in the flow: the layer-wise path carries dL/dx')
             return (b.build(device), layers)
         except NotImplementedError:
@@ -609,8 +660,9 @@ class NormalizingFlow(Transform):
         return self.base_dist.log_prob(x).unsqueeze(-1) + acc      # foreign base density: torch ops
 
     def log_prob_sum(self, y, out: Optional[torch.Tensor] = None, latent=None) -> torch.Tensor:
-        """Sum over the batch of log_prob as ONE fp64 scalar accumulated on the device (the operand of the
-        multi-GPU all-reduce); no per-sample output is written when the flow is fused."""
+        """Sum over the batch of log_prob as ONE fp64 scalar accumulated on the device (the operand of the multi-GPU
+        all-reduce).  The per-sample log_prob [N] is still written (fp32, 4 B per row: `CompiledProgram.run` allocates it and the
+        kernel's epilogue stores it beside the fp64 block sums) -- the bench's algorithmic bytes count it."""
         if out is None:
             out = torch.zeros(1, dtype=torch.float64, device=y.device)
         from .dist.normal import UnitNormal

@@ -24,7 +24,7 @@ from ..flow import Transform, flatten_rows, graph_rows, graph_wanted
 from ..fused import ProgramBuilder, ProgramCache
 from ..net.mlp import batch_linear
 
-__all__ = ['AffineLU', 'MatrixExponential']
+__all__ = ['AffineLU', 'MatrixExponential', 'DenseDeriver']
 
 
 class _DenseLinear(Transform):
@@ -172,6 +172,34 @@ def derive_dense_batched(layers, dev, reverse: bool = True):
     return out
 
 
+class DenseDeriver:
+    """The matrices of ALL AffineLU / MatrixExponential (default t) layers of one flow from a few batched fp64 ops
+    (`derive_dense_batched`), cached per parameter version and direction.  Fused programs built inside a flow take their packed
+    matrices from here (one batched derivation per parameter update instead of a chain of tiny fp64 launches -- and an LU
+    factorisation -- per layer), and the fused training backward asks for the same tensors WITH a graph so that dL/d(matrix)
+    reaches the parameters through autograd of the D x D algebra."""
+
+    def __init__(self, layers):
+        self.layers = [f for f in layers if isinstance(f, (AffineLU, MatrixExponential))]
+        self._cache = {}
+
+    def _versions(self):
+        return tuple((p.data_ptr(), p._version) for f in self.layers for p in f.parameters())
+
+    def get(self, dev, reverse: bool, graph: bool = False):
+        """-> {id(layer): (W [out, in] fp32, b fp32 | None, log-det 0-dim)} for the direction (reverse = what log_prob applies)."""
+        key = (str(dev), bool(reverse))
+        v = self._versions()
+        ent = self._cache.get(key)
+        if ent is not None and ent[0] == v and not graph:
+            return ent[1]
+        with (torch.enable_grad() if graph else torch.no_grad()):
+            out = derive_dense_batched(self.layers, dev, reverse)
+        # the cache keeps detached tensors (a cached graph would outlive the step that built it)
+        self._cache[key] = (v, {k: tuple(None if t is None else t.detach() for t in ts) for k, ts in out.items()} if graph else out)
+        return out
+
+
 class AffineLU(_DenseLinear):
     def __init__(self, dim: int, **kwargs):
         super().__init__()
@@ -232,8 +260,19 @@ class AffineLU(_DenseLinear):
 
     def _plan(self, builder, reverse, ldj_scale):
         ldj = lambda dev: ldj_scale * self.log_diag.detach().to(dev, torch.float64).sum()       # affine.py:171
-        builder.add_linear([self.weight, self.log_diag, self.bias], self._matrices(reverse), ldj)
+        fn = self._matrices(reverse)
+        deriver = getattr(builder, 'dense_deriver', None)
+        if deriver is not None and any(f is self for f in deriver.layers):
+            fn = lambda dev: tuple(t.detach() if t is not None else None for t in deriver.get(dev, reverse)[id(self)][:2])
+        builder.add_linear([self.weight, self.log_diag, self.bias], fn, ldj)
         return True
+
+    def _bwd_matrices(self, deriver):
+        """(fn_fwd, fn_adj) of the fused backward program's two SX_STEP_LINEAR_BWD steps: v = A^T-form u + b (affine.py:157) on the
+        x tiles, dL/dv = W^T dL/du on the adjoint tiles, W = the matrix log_prob applied ((LU)^-1 in Linear layout)."""
+        fwd = lambda dev: tuple(t.detach() if t is not None else None for t in deriver.get(dev, False)[id(self)][:2])
+        adj = lambda dev: (deriver.get(dev, True)[id(self)][0].detach().t().contiguous(), None)
+        return fwd, adj
 
     # ---- reference method set (affine.py:156-179): differentiable like the reference's (see flow.graph_wanted) -------
     def _graph(self, x, reverse: bool):
@@ -393,8 +432,17 @@ class MatrixExponential(_DenseLinear):
             b = self.bias.detach().to(dev, torch.float64)
             return (M, b) if not reverse else (M, -(M @ b))
         ldj = lambda dev: (ldj_scale * te) * self.diag.detach().to(dev, torch.float64).sum()    # affine.py:287-288
+        deriver = getattr(builder, 'dense_deriver', None)
+        if deriver is not None and float(t) == 1.0 and any(f is self for f in deriver.layers):
+            collapsed = lambda dev: tuple(x.detach() if x is not None else None for x in deriver.get(dev, reverse)[id(self)][:2])
         builder.add_linear(self._sources(), collapsed, ldj)
         return True
+
+    def _bwd_matrices(self, deriver):
+        """As AffineLU._bwd_matrices, for the collapsed matrix at the default t = 1 (affine.py:243-270)."""
+        fwd = lambda dev: tuple(t.detach() if t is not None else None for t in deriver.get(dev, False)[id(self)][:2])
+        adj = lambda dev: (deriver.get(dev, True)[id(self)][0].detach().t().contiguous(), None)
+        return fwd, adj
 
     # ---- reference method set (affine.py:243-288): differentiable like the reference's (see flow.graph_wanted) -------
     def _graph(self, x, t, reverse: bool):

@@ -360,10 +360,10 @@ class CompiledProgram:
 class ProgramBuilder:
     """Accumulates steps; tracks which logical column each state slot holds."""
 
-    def __init__(self, dim: int, latent_dim: int = 0, hidden_width: int = 32):
+    def __init__(self, dim: int, latent_dim: int = 0, hidden_width: int = 32, min_x_tiles: int = 1):
         self.dim, self.latent_dim = dim, latent_dim
         lat_tiles = _ceil_div(latent_dim, 32)
-        self.tiles = _round_tiles(_ceil_div(dim, 32) + lat_tiles, f'dim {dim} + latent {latent_dim}')
+        self.tiles = _round_tiles(max(_ceil_div(dim, 32), min_x_tiles) + lat_tiles, f'dim {dim} + latent {latent_dim}')
         self.x_tiles = self.tiles - lat_tiles
         self.h_tiles = _round_tiles(_ceil_div(hidden_width, 32), f'hidden width {hidden_width}')
         self.n_slots = 32 * self.x_tiles
@@ -692,8 +692,10 @@ class ProgramBuilder:
 
     def enable_adjoint_tiles(self) -> None:
         """Backward programs carry dL/dx beside x: tiles [0, x_tiles) = x, [x_tiles, 2 x_tiles) = adjoint."""
-        if self.x_tiles > 2 or self.latent_dim:
-            raise NotImplementedError('training backward is built for up to 64 columns without latent inputs')
+        if self.x_tiles > 4 or self.latent_dim:
+            raise NotImplementedError('training backward is built for up to 128 columns without latent inputs')
+        if self.x_tiles == 4 and self.h_tiles > 2:
+            raise NotImplementedError('the backward program of 128-column flows is built for hidden widths up to 64')
         self.tiles = 2 * self.x_tiles
 
     def add_coupling_affine_bwd(self, W1, b1, W2, b2, mask: np.ndarray, hidden: int, layer_slot: int) -> dict:
@@ -712,10 +714,11 @@ class ProgramBuilder:
         col = self.col_of_slot
         slot_cond = np.array([c >= 0 and cond_col[c] for c in col])
         slot_live = np.array([c >= 0 and live_col[c] for c in col])
-        if XT == 2 and not slot_cond[32:].any() and not slot_live[:32].any():
-            c0, ct, t0, tt = 0, 1, 1, 1
-        elif XT == 2 and not slot_cond[:32].any() and not slot_live[32:].any():
-            c0, ct, t0, tt = 1, 1, 0, 1
+        half = 16 * XT
+        if XT >= 2 and not slot_cond[half:].any() and not slot_live[:half].any():
+            c0, ct, t0, tt = 0, XT // 2, XT // 2, XT // 2
+        elif XT >= 2 and not slot_cond[:half].any() and not slot_live[half:].any():
+            c0, ct, t0, tt = XT // 2, XT // 2, 0, XT // 2
         else:
             c0, ct, t0, tt = 0, XT, 0, XT                     # dense: any mask, zero weights outside it
         LOG2E = 1.4426950408889634
@@ -732,18 +735,52 @@ class ProgramBuilder:
                     row2[64 * t + 32 + i] = D + col[p]
         n1, n2 = _hip.packed_linear_floats(HT, ct), _hip.packed_linear_floats(2 * tt, HT)
         n3, n4 = _hip.packed_linear_floats(HT, 2 * tt), _hip.packed_linear_floats(ct, HT)
-        off, n = self._alloc(n1 + n2 + n3 + n4)
         rs1 = np.full(32 * HT, 2.0 * LOG2E)
         rs2 = np.concatenate([np.concatenate([np.full(32, -2.0 * kk), np.full(32, -2.0)]) for _ in range(tt)])
         bs2 = np.concatenate([np.concatenate([np.full(32, kk), np.full(32, 1.0)]) for _ in range(tt)])
+        if XT == 4:
+            # 128-column flows: the four operands (100 KB) do not fit the double-buffered LDS ring together -> two steps, the
+            # forward operands (BWD_A) and the transposed ones (BWD_B); halves only (a dense mask would need 8 x 8 tiles)
+            if (ct, tt) != (2, 2):
+                raise NotImplementedError('backward of 128-column couplings: conditioner / transformed columns must be the tile halves')
+            offa, na = self._alloc(n1 + n2)
+            self.jobs.append(_PackJob(W1, b1, row_h, col_idx, HT, ct, offa, rs1, rs1, 0.0))
+            self.jobs.append(_PackJob(W2, b2, row2, row_h, 2 * tt, HT, offa + n1, rs2, bs2, 1.0))
+            offb, nb = self._alloc(n3 + n4)
+            self.jobs.append(_PackJob(W2, None, row_h, row2, HT, 2 * tt, offb, transpose=True))            # W2^T
+            self.jobs.append(_PackJob(W1, None, col_idx, row_h, ct, HT, offb + n3, transpose=True))        # W1^T
+            for kind, off, n in ((_hip.STEP_COUPLING_AFFINE_BWD_A, offa, na), (_hip.STEP_COUPLING_AFFINE_BWD_B, offb, nb)):
+                self.steps.append(dict(kind=kind, c0=c0, ct=ct, t0=t0, tt=layer_slot, reverse=1, act=_hip.ACT_TANH_FOLDED,
+                                       blob_off=off, blob_floats=n, ldj_scale=0.0, ldj_const=0.0))
+            return dict(kind='coupling', cond_cols=col_idx, out_rows=row2, hidden=hidden, ct=ct, tt=tt,
+                        side_width=32 * ct + 64 * HT + 64 * tt)
+        off, n = self._alloc(n1 + n2 + n3 + n4)
         self.jobs.append(_PackJob(W1, b1, row_h, col_idx, HT, ct, off, rs1, rs1, 0.0))
         self.jobs.append(_PackJob(W2, b2, row2, row_h, 2 * tt, HT, off + n1, rs2, bs2, 1.0))
         self.jobs.append(_PackJob(W2, None, row_h, row2, HT, 2 * tt, off + n1 + n2, transpose=True))      # W2^T
         self.jobs.append(_PackJob(W1, None, col_idx, row_h, ct, HT, off + n1 + n2 + n3, transpose=True))  # W1^T
         self.steps.append(dict(kind=_hip.STEP_COUPLING_AFFINE_BWD, c0=c0, ct=ct, t0=t0, tt=layer_slot, reverse=1,
                                act=_hip.ACT_TANH_FOLDED, blob_off=off, blob_floats=n, ldj_scale=0.0, ldj_const=0.0))
-        return dict(cond_cols=col_idx, out_rows=row2, hidden=hidden, ct=ct, tt=tt,
+        return dict(kind='coupling', cond_cols=col_idx, out_rows=row2, hidden=hidden, ct=ct, tt=tt,
                     side_width=32 * ct + 64 * HT + 64 * tt)
+
+    def add_linear_bwd(self, sources, fn_fwd, fn_adj, layer_slot: int) -> dict:
+        """Backward of one dense linear layer (AffineLU / MatrixExponential) of a log_prob pass on 4 + 4 tiles: the x tiles
+        recover the layer's input, v = M_fwd u + b_fwd (fn_fwd(device) -> (W [out, in], b)), the adjoint tiles become
+        dL/dv = W^T dL/du (fn_adj(device) -> (W^T as a Linear weight, None)); the factors dL/du (side features [0, 128)) and v
+        ([128, 256)) are what sx_wgrad contracts into dL/dW of the matrix log_prob applied, in slot order (see the maps)."""
+        self._freeze_input()
+        XT = self.x_tiles
+        if XT != 4 or self.tiles != 8:
+            raise NotImplementedError('dense layers in a backward program need the 4 + 4 tile form')
+        col = self.col_of_slot[:32 * XT].copy()
+        n_lin = _hip.packed_linear_floats(XT, XT)
+        for c0, fn, t0, rev in ((0, fn_fwd, 4, 0), (4, fn_adj, 0, 1)):
+            off, n = self._alloc(n_lin)
+            self.jobs.append(_DerivedLinearJob(sources, fn, [(col, col, XT, off, XT)]))
+            self.steps.append(dict(kind=_hip.STEP_LINEAR_BWD, c0=c0, ct=XT, t0=t0, tt=layer_slot, reverse=rev, act=0,
+                                   blob_off=off, blob_floats=n, ldj_scale=0.0, ldj_const=0.0))
+        return dict(kind='dense', slot_cols=col, side_width=256)
 
     def add_affine_const(self, log_scale, shift, reverse: bool, ldj_scale: float) -> None:
         self._freeze_input()
