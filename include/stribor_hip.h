@@ -456,6 +456,10 @@ int sx_wgrad_reduce(const float *part, int32_t n_part, int32_t M32, int32_t N32,
  * inside stribor/net/mlp.py:48-58 (a tall-skinny A^T B that library GEMMs run on a handful of workgroups). */
 #define SX_WGRAD_ROW_MAJOR 0
 #define SX_WGRAD_ROW_GROUPS 1
+/* the row-group layout with the contraction on v_mfma_f32_32x32x16_f16 (operands split hi + lo in fp16, three products, fp32
+ * accumulate: ~2^-22 per product).  For the factors a backward program stored: they are fp16 x 3 GEMM operands of that program
+ * already (within fp16's range, or flagged by it); 5x fewer matrix-pipe cycles than the fp32 MFMA form. */
+#define SX_WGRAD_ROW_GROUPS_F16X3 3
 size_t sx_wgrad_scratch_floats(int32_t M, int32_t Nc, int32_t layout);
 int sx_wgrad(const float *A, int64_t lda, int32_t M, const float *B, int64_t ldb, int32_t Nc, int64_t n_rows,
              int32_t layout, float *dW, int64_t ldw, float *db, const int32_t *row_map, const int32_t *col_map,

@@ -38,7 +38,7 @@ STEP_COUPLING_AFFINE_BWD_A = 16
 STEP_COUPLING_AFFINE_BWD_B = 17
 STEP_LINEAR_BWD = 18
 
-WGRAD_ROW_MAJOR, WGRAD_ROW_GROUPS = 0, 1
+WGRAD_ROW_MAJOR, WGRAD_ROW_GROUPS, WGRAD_ROW_GROUPS_F16X3 = 0, 1, 3
 
 ACT_TANH_FOLDED = 9
 ACT_CODES = {'Identity': 0, 'Tanh': 1, 'ReLU': 2, 'Sigmoid': 3, 'ELU': 4, 'Softplus': 5, 'LeakyReLU': 6,

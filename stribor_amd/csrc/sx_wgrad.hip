@@ -21,6 +21,43 @@
 
 constexpr int PATCH = 32 * 36;       // one 32-feature x 32-row tile, feature rows padded to 36 floats
 
+// ---- fp16 x 3 contraction (SX_WGRAD_ROW_GROUPS_F16X3): the operands of a backward program are fp16 x 3 GEMM operands already
+// (scaled into fp16's range, range-tracked by the kernel that wrote them), so the batch contraction can run on the matrix pipe as
+// well: a lane's 16 rows of a feature split hi + lo (hi = rtz(v), lo = rtz(v - hi)), two 16-row steps of
+// v_mfma_f32_32x32x16_f16 with three products each -- 6 MFMAs x 32 cycles per tile pair and 32 rows instead of 16 x 64.
+typedef _Float16 wg_h8 __attribute__((ext_vector_type(8)));
+typedef uint32_t wg_u4 __attribute__((ext_vector_type(4)));
+struct wg_split { wg_h8 hi[2], lo[2]; };
+__device__ __forceinline__ uint32_t wg_pk(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b)); }
+__device__ __forceinline__ wg_split wg_make(const f32x4 (&v)[4]) {
+    wg_split o;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        wg_u4 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float v0 = v[2 * s + (q >> 1)][2 * (q & 1)], v1 = v[2 * s + (q >> 1)][2 * (q & 1) + 1];
+            const uint32_t ph = wg_pk(v0, v1);
+            float l0, l1;
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(ph), "v"(v0));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(ph), "v"(v1));
+            hi[q] = ph;
+            lo[q] = wg_pk(l0, l1);
+        }
+        o.hi[s] = __builtin_bit_cast(wg_h8, hi);
+        o.lo[s] = __builtin_bit_cast(wg_h8, lo);
+    }
+    return o;
+}
+__device__ __forceinline__ void wg_contract(const wg_split &a, const wg_split &b, f32x16 &acc) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.lo[s], b.hi[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi[s], b.lo[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi[s], b.hi[s], acc, 0, 0, 0);
+    }
+}
+
 // coalesced global -> registers: instr q, lane L holds feature 8q + (L >> 3), rows 4 (L & 7) .. + 3 of the tile
 __device__ __forceinline__ void load_tile(const float *tile_base, bool ok, int lane, f32x4 (&v)[4]) {
 #pragma unroll
@@ -68,7 +105,7 @@ __global__ __launch_bounds__(64 * WB) void wgrad_kernel(const float *__restrict_
                                                         float *__restrict__ part, int m_total, int n_valid) {
     constexpr int M32 = 32 * MT, N32 = 32 * NT;
     constexpr int RED = M32 * N32 + M32;
-    constexpr bool GROUPS = LAYOUT == 1, VEC_ROWS = LAYOUT == 2;
+    constexpr bool GROUPS = LAYOUT == 1 || LAYOUT == 3, VEC_ROWS = LAYOUT == 2, F16 = LAYOUT == 3;
     constexpr int LDS_FLOATS = (GROUPS || VEC_ROWS) ? (RED > WB * PATCH ? RED : WB * PATCH) : RED;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     A += 128 * blockIdx.y;
@@ -159,6 +196,19 @@ __global__ __launch_bounds__(64 * WB) void wgrad_kernel(const float *__restrict_
                     for (int n = 0; n < NT; ++n) b[n][q][c] = (ok && 32 * n + i < n_valid) ? rb[2 * s * ldb + 32 * n] : 0.f;
                 }
         }
+        if constexpr (F16) {
+            wg_split bs[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bs[n] = wg_make(b[n]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bsum[m] += (a[m][q][0] + a[m][q][1]) + (a[m][q][2] + a[m][q][3]);
+                const wg_split as = wg_make(a[m]);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) wg_contract(as, bs[n], acc[m][n]);
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -170,6 +220,7 @@ __global__ __launch_bounds__(64 * WB) void wgrad_kernel(const float *__restrict_
                     for (int n = 0; n < NT; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][q][c], b[n][q][c], acc[m][n], 0, 0, 0);
                 }
+        }
     }
     __syncthreads();                                    // every wave is done with its patch
     // C layout: lane (col j = lane&31, half) holds rows kmap(r, half).  The waves take turns adding their tiles to
@@ -281,8 +332,10 @@ extern "C" int sx_wgrad(const float *A, int64_t lda, int32_t M, const float *B, 
                         int64_t n_rows, int32_t layout, float *dW, int64_t ldw, float *db, const int32_t *row_map,
                         const int32_t *col_map, float *scratch, void *stream) {
     SX_REQUIRE(A && B && dW && scratch, "sx_wgrad: null pointer");
-    SX_REQUIRE(layout == SX_WGRAD_ROW_MAJOR || layout == SX_WGRAD_ROW_GROUPS, "sx_wgrad: unknown layout %d", layout);
-    const bool groups = layout == SX_WGRAD_ROW_GROUPS;
+    SX_REQUIRE(layout == SX_WGRAD_ROW_MAJOR || layout == SX_WGRAD_ROW_GROUPS || layout == SX_WGRAD_ROW_GROUPS_F16X3,
+               "sx_wgrad: unknown layout %d", layout);
+    const bool f16 = layout == SX_WGRAD_ROW_GROUPS_F16X3;
+    const bool groups = layout == SX_WGRAD_ROW_GROUPS || f16;
     SX_REQUIRE(M >= 1 && Nc >= 1 && Nc <= 128 && n_rows >= 0 && M <= (groups ? 128 : 2048),
                "sx_wgrad: Nc must be in 1..128, M in 1..128 (row groups) or 1..2048 (row-major)");
     SX_REQUIRE(!groups || (((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && lda % 4 == 0 && ldb % 4 == 0),
@@ -312,7 +365,7 @@ extern "C" int sx_wgrad(const float *A, int64_t lda, int32_t M, const float *B, 
     }
 #define SX_WG(MT_, NT_)                                                                                            \
     if (mt == MT_ && nt == NT_) {                                                                                  \
-        if (groups) SX_WG_L(MT_, NT_, 1) else if (vec_rows) SX_WG_L(MT_, NT_, 2) else SX_WG_L(MT_, NT_, 0)         \
+        if (f16) SX_WG_L(MT_, NT_, 3) else if (groups) SX_WG_L(MT_, NT_, 1) else if (vec_rows) SX_WG_L(MT_, NT_, 2) else SX_WG_L(MT_, NT_, 0) \
     }
     SX_WG(1, 1) SX_WG(1, 2) SX_WG(2, 1) SX_WG(2, 2) SX_WG(2, 4) SX_WG(4, 2) SX_WG(4, 1) SX_WG(1, 4) SX_WG(4, 4)
     SX_WG(3, 1) SX_WG(3, 2) SX_WG(3, 3) SX_WG(3, 4) SX_WG(1, 3) SX_WG(2, 3) SX_WG(4, 3)

@@ -37,6 +37,10 @@ class _FusedLogProb(torch.autograd.Function):
     @staticmethod
     def forward(ctx, flow, y2, *params):
         prog = flow._fused_program(True, y2.shape[1], 0, y2.device)
+        # dense layers: ONE batched fp64 derivation of their matrices per step, with a graph (kept for backward); the forward
+        # program's pack jobs (and later the backward program's) pick up the same tensors, detached
+        deriver = flow._dense_deriver()
+        ctx.dense_graph = deriver.get(y2.device, True, graph=True) if deriver.layers else None
         z, _, logp = prog.run(y2, None, True, False, True)
         ctx.flow = flow
         ctx.save_for_backward(z)
@@ -78,9 +82,8 @@ class _FusedLogProb(torch.autograd.Function):
         if dense_layers:
             # the D x D algebra (LU products, inverses, matrix exponential) WITH a graph: the kernels produce dL/d(matrix), autograd
             # of these batched fp64 ops carries it to the parameters; the backward program packs the same tensors (detached)
-            deriver = flow._dense_deriver()
-            dense_graph = deriver.get(z.device, True, graph=True)
-            deriver.get(z.device, False)
+            dense_graph = ctx.dense_graph
+            flow._dense_deriver().get(z.device, False)
         flat = torch.zeros(sum(p_.numel() for ps in shapes for p_ in ps), dtype=torch.float32, device=dev)
         grads, views, off = {}, [], 0
         for ps in shapes:
@@ -121,6 +124,8 @@ class _FusedLogProb(torch.autograd.Function):
         # Layout [layer, 32-row group, feature, 32 rows] (coalesced for the kernel's fragment stores and sx_wgrad's loads)
         block = max(32, min(n, _FusedLogProb.SIDE_BYTES // (len(layers) * width * 4)) // 32 * 32)
         side = torch.empty(len(layers), (min(block, n) + 31) // 32, width, 32, dtype=torch.float32, device=dev)
+        # the factors are fp16 x 3 GEMM operands of the backward program already: contract them on the matrix pipe too
+        wl = _hip.WGRAD_ROW_GROUPS if _hip.get_gemm_precision() == 'exact' else _hip.WGRAD_ROW_GROUPS_F16X3
         with _hip.device_of(z):
             st = _hip.stream()
             for lo in range(0, n, block):
@@ -139,7 +144,7 @@ class _FusedLogProb(torch.autograd.Function):
                         # [128, 256) = v, both in slot order (slot -> logical column through the maps)
                         gWm, gbm = views[slot]
                         sc = _hip.scratch(dev, lib.sx_wgrad_scratch_floats(128, 128, _hip.WGRAD_ROW_GROUPS))
-                        _hip.check(lib.sx_wgrad(p0, ld, 128, p0 + 128 * 128, ld, 128, m, _hip.WGRAD_ROW_GROUPS, gWm.data_ptr(),
+                        _hip.check(lib.sx_wgrad(p0, ld, 128, p0 + 128 * 128, ld, 128, m, wl, gWm.data_ptr(),
                                                 gWm.stride(0), gbm.data_ptr(), info['slot_map'].data_ptr(), info['slot_map'].data_ptr(),
                                                 sc.data_ptr(), st), 'sx_wgrad')
                         continue
@@ -155,9 +160,9 @@ class _FusedLogProb(torch.autograd.Function):
                         continue
                     sc = _hip.scratch(dev, max(lib.sx_wgrad_scratch_floats(pc, H, _hip.WGRAD_ROW_GROUPS),
                                                lib.sx_wgrad_scratch_floats(H, zc, _hip.WGRAD_ROW_GROUPS)))
-                    _hip.check(lib.sx_wgrad(p0 + 128 * (zc + 2 * ht), ld, pc, p0 + 128 * zc, ld, H, m, _hip.WGRAD_ROW_GROUPS, gW2.data_ptr(),
+                    _hip.check(lib.sx_wgrad(p0 + 128 * (zc + 2 * ht), ld, pc, p0 + 128 * zc, ld, H, m, wl, gW2.data_ptr(),
                                             gW2.stride(0), gb2.data_ptr(), info['row_map'].data_ptr(), None, sc.data_ptr(), st), 'sx_wgrad')
-                    _hip.check(lib.sx_wgrad(p0 + 128 * (zc + ht), ld, H, p0, ld, zc, m, _hip.WGRAD_ROW_GROUPS, gW1.data_ptr(),
+                    _hip.check(lib.sx_wgrad(p0 + 128 * (zc + ht), ld, H, p0, ld, zc, m, wl, gW1.data_ptr(),
                                             gW1.stride(0), gb1.data_ptr(), None, info['col_map'].data_ptr(), sc.data_ptr(), st), 'sx_wgrad')
         return finish()
 

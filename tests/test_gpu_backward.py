@@ -572,10 +572,13 @@ def test_neural_flow_forward_is_differentiable():
 @pytest.mark.parametrize('n,M,Nc,width,a0,b0', [(1, 64, 64, 224, 160, 32), (1000, 50, 33, 224, 96, 0),
                                                 (4097, 128, 128, 256, 0, 128), (77, 96, 40, 224, 32, 128),
                                                 (100003, 64, 32, 224, 96, 0)])
-def test_wgrad_contracts_row_groups_with_maps(n, M, Nc, width, a0, b0):
+@pytest.mark.parametrize('f16', [False, True])
+def test_wgrad_contracts_row_groups_with_maps(n, M, Nc, width, a0, b0, f16):
     """sx_wgrad on its own: feature-major 32-row groups (garbage in the ragged tail), feature counts that are not
-    multiples of 32, row / column maps with dropped entries, accumulation into non-zero dW / db; fp64 truth."""
+    multiples of 32, row / column maps with dropped entries, accumulation into non-zero dW / db; fp64 truth.  f16: the same
+    contraction on the matrix pipe (SX_WGRAD_ROW_GROUPS_F16X3, operands split hi + lo in fp16)."""
     from stribor_amd import _hip
+    layout = _hip.WGRAD_ROW_GROUPS_F16X3 if f16 else _hip.WGRAD_ROW_GROUPS
     g = torch.Generator(device='cpu').manual_seed(n + M)
     ng = (n + 31) // 32
     side = torch.randn(ng, width, 32, generator=g)
@@ -602,8 +605,8 @@ def test_wgrad_contracts_row_groups_with_maps(n, M, Nc, width, a0, b0):
     dW, db = dW0.to(DEV), db0.to(DEV)
     rm, cm = row_map.to(DEV), col_map.to(DEV)
     rc = _hip.lib().sx_wgrad(sd[0, a0].data_ptr(), width * 32, M, sd[0, b0].data_ptr(), width * 32, Nc, n,
-                             _hip.WGRAD_ROW_GROUPS, dW.data_ptr(), Nc, db.data_ptr(), rm.data_ptr(), cm.data_ptr(),
-                             _hip.scratch(DEV, _hip.lib().sx_wgrad_scratch_floats(M, Nc, _hip.WGRAD_ROW_GROUPS)).data_ptr(), _hip.stream())
+                             layout, dW.data_ptr(), Nc, db.data_ptr(), rm.data_ptr(), cm.data_ptr(),
+                             _hip.scratch(DEV, _hip.lib().sx_wgrad_scratch_floats(M, Nc, layout)).data_ptr(), _hip.stream())
     _hip.check(rc, 'sx_wgrad')
     scale = max(1.0, float(n) ** 0.5)
     assert (dW.cpu().double() - wantW).abs().max().item() <= 2e-5 * scale
