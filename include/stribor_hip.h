@@ -342,6 +342,16 @@ int sx_pack_linear(const float *W, const float *b, int32_t out_dim, int32_t in_d
                                          * layer's forward matrix; c0 = 4: the adjoint tiles, M = W^T of the matrix log_prob applied).  The
                                          * factors of dL/dW = sum_n dL/du_n v_n^T are stored to the side buffer of layer slot tt at feature
                                          * offset 32 * t0: before the step when reverse = 1 (the adjoint), after it otherwise (v).        */
+#define SX_STEP_POINTWISE           19  /* point-wise flow on the data tiles (Sigmoid / Logit sigmoid.py:9-56, ELU / LeakyReLU activations.py:11-101):
+                                         * act = SX_PW_* kind (the direction is the kind), ldj_const = param (LeakyReLU slope or its reciprocal),
+                                         * blob = live-slot mask [tiles][2][16] (C-fragment order: 1 = column, 0 = padding) ++ {log-slope};
+                                         * the accumulator receives ldj_scale * (the kind's own log-derivative sum, as sx_pointwise).     */
+#define SX_STEP_COUPLING_TIME       20  /* time-conditioned affine coupling (ContinuousAffineCoupling, coupling.py:184-213): conditioner over ALL tiles
+                                         * (ct = tiles; the two slots behind the latent columns hold t and t0, filled from row_t and -- programs of
+                                         * this kind only -- from `side`, read as a second [n_rows] time vector), transformed tiles [0, tt) = the data
+                                         * tiles; blob = pack(W1, h_tiles x tiles) ++ pack(W2, 2 tt x h_tiles) ++ the time net's per-column constants
+                                         * (see sx_flow_kernel.h); pad_ = time kind (0 identity, 1 linear, 2 tanh, 3 log, 4 fourier) | (which time
+                                         * the embedding uses: 0 row_t, 1 side) << 8 | (fourier features) << 16.  Programs of these steps only.   */
 #define SX_STEP_CPL_HIDDEN          13  /* deep conditioners (>= 2 hidden layers): hidden = act(W1 . state[c0..c0+ct) + b1), kept in
                                            registers for the next step; blob = pack_linear(W1, h_tiles x ct)                    */
 #define SX_STEP_CPL_HIDDEN2         14  /* hidden = act(Wk . hidden + bk); blob = pack_linear(Wk, h_tiles x h_tiles)              */

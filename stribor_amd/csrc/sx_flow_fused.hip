@@ -28,6 +28,7 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     int mx = 256;
     bool lin = false, rqs = false, aff = false, bwd = false, deep = false, cub = false, quadr = false;
     int n_bwd128 = 0;
+    bool pw = false, timed = false;
     *mlp_mode = 0;
     for (int i = 0; i < p->n_steps; ++i) {
         const sx_step &s = p->steps[i];
@@ -105,6 +106,19 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
                 if (sw > *side_width) *side_width = sw;
                 bwd = true; ++n_bwd128; break;
             }
+            case SX_STEP_COUPLING_TIME: {
+                const int kind = s.pad_ & 0xff, K = (s.pad_ >> 16) & 0xff;
+                SX_REQUIRE(s.c0 == 0 && s.ct == p->tiles && s.t0 == 0 && s.tt >= 1 &&
+                           (s.tt == p->tiles || s.tt * 2 == p->tiles || s.tt * 4 == p->tiles),
+                           "sx_flow_run: step %d: a time coupling conditions on all tiles and transforms the data tiles (tt = tiles, tiles/2 or tiles/4)", i);
+                SX_REQUIRE(kind >= 0 && kind <= 4 && (kind != 4 || (K >= 1 && K <= 64)), "sx_flow_run: step %d: time kind %d / %d fourier features", i, kind, K);
+                need = sx_packed_linear_floats(p->h_tiles, p->tiles) + sx_packed_linear_floats(2 * s.tt, p->h_tiles) +
+                       (kind == 0 ? 0 : (kind == 4 ? (size_t)s.tt * K * 128 : (size_t)s.tt * 64));
+                timed = true; break;
+            }
+            case SX_STEP_POINTWISE:
+                SX_REQUIRE(s.act >= SX_PW_SIGMOID && s.act <= SX_PW_LEAKY_RELU_INV, "sx_flow_run: step %d: point-wise kind %d (1..6)", i, s.act);
+                need = 32 * p->tiles + 1; pw = true; break;
             case SX_STEP_RQS_HIDDEN: {
                 const int T = p->tiles;
                 const bool low = T >= 2 && s.c0 == 0 && s.ct == T / 2;
@@ -134,14 +148,17 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     SX_REQUIRE(!(lin && *mlp_mode), "sx_flow_run: linear steps cannot be mixed with MLP-output steps");
     if (lin) *mlp_mode = 2;
     SX_REQUIRE(!(rqs && (lin || *mlp_mode == 1)), "sx_flow_run: spline steps cannot be mixed with linear / MLP-output steps");
-    SX_REQUIRE(!(rqs && aff), "sx_flow_run: spline and affine couplings cannot share one fused program");
-    SX_REQUIRE(!(cub && quadr), "sx_flow_run: rational-quadratic and cubic spline couplings cannot share one fused program");
-    if (rqs) *mlp_mode = cub ? 12 : 3;
+    // mixed programs (kernel MODE 14): spline couplings beside affine couplings / point-wise steps, or both spline types
+    const bool mixed = rqs && (aff || pw || (cub && quadr));
+    SX_REQUIRE(!(pw && (lin || *mlp_mode == 1 || bwd || (deep && !mixed))), "sx_flow_run: point-wise steps mix with couplings and element-wise affines only");
+    if (rqs) *mlp_mode = mixed ? 14 : (cub ? 12 : 3);
     SX_REQUIRE(!(bwd && (rqs || lin || aff || *mlp_mode == 1)), "sx_flow_run: backward steps cannot be mixed with other step kinds");
     if (bwd) *mlp_mode = 4;
+    SX_REQUIRE(!(timed && (rqs || lin || aff || bwd || deep || pw || *mlp_mode == 1)), "sx_flow_run: time couplings form programs of their own");
+    if (timed) *mlp_mode = 15;
     SX_REQUIRE(p->tiles != 8 || (bwd && n_bwd128 == p->n_steps), "sx_flow_run: 8 state tiles carry backward steps (kinds 16 - 18) only");
     SX_REQUIRE(!(deep && (lin || bwd || *mlp_mode == 1)), "sx_flow_run: deep-conditioner steps only mix with couplings");
-    if (deep) *mlp_mode = rqs ? (cub ? 13 : 10) : 9;     // 10 / 13: the spline kernels with the deep-conditioner steps
+    if (deep && !mixed) *mlp_mode = rqs ? (cub ? 13 : 10) : 9;     // 10 / 13: the spline kernels with the deep-conditioner steps
     // MODE 5 / 6: nothing but tanh-folded affine couplings on half the tiles conditioned on the other half, all in
     // one direction (5 reverse, 6 forward) -- the plain RealNVP log_prob / sample program.  Its kernel carries two
     // straight-line arms only, which keeps the state in place (no phi copies) at 130 VGPRs.

@@ -30,6 +30,7 @@
 #include "sx_common.h"
 #include "sx_flow_types.h"
 #include "sx_cubic_core.h"
+#include "sx_pointwise_core.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -561,6 +562,131 @@ __device__ __forceinline__ void coupling_affine_deep(tile<NS> (&xs)[TX], const t
     for (int n = 0; n < NS; ++n) ldj[n] += st.ldj_scale * s[n];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Time-conditioned affine coupling (ContinuousAffineCoupling, stribor/flows/coupling.py:184-213; kernel MODE 15):
+//   (log_scale, shift) = net(cat[x * mask, latent, t]);  (e_ls, e_sh) = time_net(t).chunk(2)      (net/time_net.py:6-91)
+//   y = x exp(log_scale e_ls) + shift e_sh   |   x = (y - shift e_sh) exp(-log_scale e_ls);   log-det = sum log_scale e_ls (1 - mask)
+// One step = conditioner GEMM-1 over ALL tiles (data, latent and the time slots: t and t0 sit in the two slots behind the latent
+// columns and are filled from row_t / row_t2), GEMM-2 onto the TT data tiles, the time embedding per element and the affine map.
+// blob = pack(W1, HT x TX) ++ pack(W2, 2 TT x HT) ++ time constants in C-fragment order per data tile:
+//   kinds 1 - 3 (TimeLinear / TimeTanh / TimeLog): [c_ls (32) | c_sh (32)]  (the per-column scale; exp(scale) for TimeLog)
+//   kind 4 (TimeFourier(Bounded), K features): K x [w_ls | s_ls | w_sh | s_sh]   (e = sum_k w_k sin(s_k t))
+// step.pad_ = time kind | (time select: 0 = row_t, 1 = row_t2) << 8 | K << 16.
+// ------------------------------------------------------------------------------------------------
+#define SX_TIME_IDENTITY 0
+#define SX_TIME_LINEAR 1
+#define SX_TIME_TANH 2
+#define SX_TIME_LOG 3
+#define SX_TIME_FOURIER 4
+// sin(x) on v_sin_f32 (argument in revolutions): x / 2 pi carried to double-float accuracy, reduced to [-1/2, 1/2) first
+// (libm's sinf keeps a Payne-Hanek table in scratch memory: 448 B per lane in this kernel)
+__device__ __forceinline__ float time_sin(float x) {
+    const float hi = x * 0.15915494309189535f;
+    const float lo = __builtin_fmaf(x, 0.15915494309189535f, -hi) + x * 6.4206383e-9f;      // 1 / (2 pi) = fp32(0.15915494) + 6.42e-9
+    const float fr = (hi - __builtin_rintf(hi)) + lo;
+    return __builtin_amdgcn_sinf(fr);
+}
+template <int NS, int TT>
+__device__ __forceinline__ void time_embed(const char *cb, int toff, uint32_t code, const float (&tv)[NS], int t,
+                                           f32x16 (&els)[NS], f32x16 (&esh)[NS]) {
+    const int kind = code & 0xff, K = (code >> 16) & 0xff;
+    if (kind == SX_TIME_IDENTITY) {
+#pragma unroll
+        for (int n = 0; n < NS; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { els[n][r] = tv[n]; esh[n][r] = tv[n]; }
+    } else if (kind == SX_TIME_FOURIER) {
+#pragma unroll
+        for (int n = 0; n < NS; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { els[n][r] = 0.f; esh[n][r] = 0.f; }
+        for (int kf = 0; kf < K; ++kf) {
+            const int o = toff + (t * K + kf) * 128;
+            const f32x16 wl = load_cfrag1(cb, o), sl = load_cfrag1(cb, o + 32), ws = load_cfrag1(cb, o + 64), ss = load_cfrag1(cb, o + 96);
+#pragma unroll
+            for (int n = 0; n < NS; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    els[n][r] += wl[r] * time_sin(sl[r] * tv[n]);
+                    esh[n][r] += ws[r] * time_sin(ss[r] * tv[n]);
+                }
+        }
+    } else {
+        const f32x16 cl = load_cfrag1(cb, toff + t * 64), cs = load_cfrag1(cb, toff + t * 64 + 32);
+#pragma unroll
+        for (int n = 0; n < NS; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float a = cl[r] * tv[n], b = cs[r] * tv[n];
+                if (kind == SX_TIME_LINEAR) { els[n][r] = a; esh[n][r] = b; }
+                else if (kind == SX_TIME_TANH) { els[n][r] = fast_tanh(a); esh[n][r] = fast_tanh(b); }
+                else { els[n][r] = logf(a + 1.f); esh[n][r] = logf(b + 1.f); }       // TimeLog: c = exp(scale)
+            }
+    }
+}
+template <int NS, int TX, int HT, int TT, bool FOLDED, bool REV>
+__device__ __forceinline__ void coupling_time_affine(tile<NS> (&xs)[TX], const wptr w, const dstep &st, float (&ldj)[NS],
+                                                     rng_t &rg, const float (&tv)[NS]) {
+    tile<NS> hid[HT];
+    hidden_layer<NS, TX, HT, 0, TX, FOLDED>(xs, hid, w, 0, st.act, rg);
+    if constexpr (FOLDED) {
+#pragma unroll
+        for (int n = 0; n < NS; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) fast_sig2_pair(hid[HT - 1].v[n], r);
+    }
+    btile<NS> bh[HT];
+#pragma unroll
+    for (int m = 0; m < HT; ++m) {
+        if constexpr (FOLDED) bh[m] = make_btile<NS>(hid[m]);
+        else bh[m] = make_btile<NS>(hid[m], rg);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int a2 = HT * TX * 1024 + HT * 32;       // pack_linear(W2: 2 TT m-tiles, HT k-tiles)
+    constexpr int b2 = a2 + 2 * TT * HT * 1024;
+    constexpr int toff = b2 + 2 * TT * 32;
+    float s[NS];
+#pragma unroll
+    for (int n = 0; n < NS; ++n) s[n] = 0.f;
+    const float sgn = FOLDED ? 1.0f : (REV ? -1.44269504088896341f : 1.44269504088896341f);
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        tile<NS> ls = load_cfrag<NS>(w.cb, b2 + (2 * t) * 32);
+        tile<NS> sh = load_cfrag<NS>(w.cb, b2 + (2 * t + 1) * 32);
+#pragma unroll
+        for (int m = 0; m < HT; ++m) {
+            gemm_tile<NS>(w.wb, a2 + ((2 * t) * HT + m) * 1024, bh[m], ls);
+            gemm_tile<NS>(w.wb, a2 + ((2 * t + 1) * HT + m) * 1024, bh[m], sh);
+        }
+        f32x16 els[NS], esh[NS];
+        time_embed<NS, TT>(w.cb, toff, st.mask, tv, t, els, esh);
+        tile<NS> &x = xs[t];
+#pragma unroll
+        for (int n = 0; n < NS; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float l = ls.v[n][r] * els[n][r];            // FOLDED: kk log_scale e_ls, kk = +-log2 e (the pack folds it in)
+                s[n] += l;
+                const float e = __builtin_amdgcn_exp2f(FOLDED ? l : l * sgn);
+                const float shv = sh.v[n][r] * esh[n][r];
+                x.v[n][r] = REV ? (x.v[n][r] - shv) * e : x.v[n][r] * e + shv;
+            }
+    }
+#pragma unroll
+    for (int n = 0; n < NS; ++n) ldj[n] += st.ldj_scale * s[n];
+}
+template <int NS, int TX, int HT, int TT>
+__device__ __forceinline__ void coupling_time_dispatch(tile<NS> (&xs)[TX], const wptr w, const dstep &st, float (&ldj)[NS],
+                                                       rng_t &rg, const float (&tv)[NS]) {
+    if (st.act == SX_ACT_TANH_FOLDED) {
+        if (st.reverse) coupling_time_affine<NS, TX, HT, TT, true, true>(xs, w, st, ldj, rg, tv);
+        else coupling_time_affine<NS, TX, HT, TT, true, false>(xs, w, st, ldj, rg, tv);
+    } else {
+        if (st.reverse) coupling_time_affine<NS, TX, HT, TT, false, true>(xs, w, st, ldj, rg, tv);
+        else coupling_time_affine<NS, TX, HT, TT, false, false>(xs, w, st, ldj, rg, tv);
+    }
+}
+
 // one runtime dispatch per step on (activation kind, direction) -> straight-line specialisations
 template <int NS, int TX, int HT, int C0, int CT, int T0, int TT>
 __device__ __forceinline__ void coupling_affine_dispatch(tile<NS> (&xs)[TX], const wptr w, const dstep &st,
@@ -606,6 +732,49 @@ __device__ __forceinline__ void affine_const(tile<NS> (&xs)[TX], const wptr w, c
     for (int n = 0; n < NS; ++n) ldj[n] += st.ldj_scale * s;
 }
 
+
+// Point-wise flows inside a fused program (Sigmoid / Logit sigmoid.py:9-56, ELU / LeakyReLU activations.py:11-101): the
+// arithmetic of the stand-alone kernel (sx_pointwise_core.h) on the state tiles.  blob = live-slot mask in C-fragment order
+// (1 = the slot holds a column, 0 = padding: stays 0 and adds nothing) ++ {log-slope of the LeakyReLU kinds}.  The *_INV kinds
+// and LOGIT return MINUS the forward log-derivative at the value produced, like the stand-alone kernel (flow.py:42-47); the
+// step's ldj_scale carries the sign that turns it into the program's convention.
+template <int NS, int TX, int KIND>
+__device__ __forceinline__ void pointwise_tiles(tile<NS> (&xs)[TX], const wptr w, const dstep &st, int x_tiles, int mask_tiles,
+                                                float (&ldj)[NS]) {
+    const float param = st.ldj_const;
+    const float log_slope = *reinterpret_cast<const float *>(w.cb - ((threadIdx.x & 63) >> 5) * 64 + 32 * mask_tiles * 4);
+#pragma unroll
+    for (int t = 0; t < TX; ++t) {
+        if (t < x_tiles) {
+            const f32x16 live = load_cfrag1(w.cb, t * 32);
+#pragma unroll
+            for (int n = 0; n < NS; ++n) {
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float out, ld;
+                    pw_eval(KIND, param, log_slope, xs[t].v[n][r], out, ld);
+                    const bool on = live[r] != 0.f;
+                    xs[t].v[n][r] = on ? out : xs[t].v[n][r];
+                    s += on ? ld : 0.f;
+                }
+                ldj[n] += st.ldj_scale * s;
+            }
+        }
+    }
+}
+template <int NS, int TX>
+__device__ __forceinline__ void pointwise_step(tile<NS> (&xs)[TX], const wptr w, const dstep &st, int x_tiles, int mask_tiles,
+                                               float (&ldj)[NS]) {
+    switch (st.act) {
+        case SX_PW_SIGMOID: pointwise_tiles<NS, TX, SX_PW_SIGMOID>(xs, w, st, x_tiles, mask_tiles, ldj); break;
+        case SX_PW_LOGIT: pointwise_tiles<NS, TX, SX_PW_LOGIT>(xs, w, st, x_tiles, mask_tiles, ldj); break;
+        case SX_PW_ELU: pointwise_tiles<NS, TX, SX_PW_ELU>(xs, w, st, x_tiles, mask_tiles, ldj); break;
+        case SX_PW_ELU_INV: pointwise_tiles<NS, TX, SX_PW_ELU_INV>(xs, w, st, x_tiles, mask_tiles, ldj); break;
+        case SX_PW_LEAKY_RELU: pointwise_tiles<NS, TX, SX_PW_LEAKY_RELU>(xs, w, st, x_tiles, mask_tiles, ldj); break;
+        default: pointwise_tiles<NS, TX, SX_PW_LEAKY_RELU_INV>(xs, w, st, x_tiles, mask_tiles, ldj); break;
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // Rational-quadratic spline coupling, fused (util/rational_quadratic_spline.py:11-251 + search_sorted.py).
@@ -1771,7 +1940,12 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int c = 32 * (t - x_tiles) + sx_kmap(r, h);
-                        xs[t].v[n][r] = (k.latent != nullptr && c < prog.latent_dim) ? k.latent[lrow[n] * prog.latent_dim + c] : 0.f;
+                        float v = (k.latent != nullptr && c < prog.latent_dim) ? k.latent[lrow[n] * prog.latent_dim + c] : 0.f;
+                        if constexpr (MODE == 15) {      // the two slots behind the latent columns: t and t0 (coupling.py:155-156)
+                            if (c == prog.latent_dim && k.row_t != nullptr) v = k.row_t[lrow[n]];
+                            if (c == prog.latent_dim + 1 && k.side != nullptr) v = k.side[lrow[n]];
+                        }
+                        xs[t].v[n][r] = v;
                     }
                 }
             }
@@ -1790,13 +1964,18 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
         rg.bad = 0ull;
         tile<NS> hid[MODE == 1 ? HT : 1];
         constexpr bool LIN = MODE == 2 || MODE == 7 || MODE == 8;    // programs with dense linear layers
-        tile<NS> hidp[MODE == 9 ? HT : 1];                           // MODE 9: hidden state kept between deep-conditioner steps
+        tile<NS> hidp[(MODE == 9 || MODE == 14) ? HT : 1];           // MODE 9 / 14: hidden state kept between deep-conditioner steps
         tile<1> bkeep[(MODE == 4 && TX == 8) ? HT + TX / 2 : 1];     // MODE 4, D = 128: r and dL/d(ls, sh) between steps A and B
         constexpr bool CUB = MODE == 12 || MODE == 13;    // cubic-spline couplings (13: + deep conditioners)
         constexpr bool RQ = MODE == 3 || MODE == 10 || CUB;      // spline couplings (10: + deep conditioners)
         constexpr bool RQDEEP = MODE == 10 || MODE == 13;
-        btile<1> rq_bh[RQ ? HT : 1];             // hidden B operands + group state
+        // MODE 14: MIXED programs -- affine couplings, spline couplings of either type, point-wise steps and element-wise affines
+        // in one launch (the reference's flagship stack, test_normalizing_flow.py:13-35: affine coupling -> Flip -> Sigmoid ->
+        // cubic-spline coupling -> Logit).  One wave per SIMD: both splines' group states and the coupling arms share the file.
+        constexpr bool MIX = MODE == 14;
+        btile<1> rq_bh[(RQ || MIX) ? HT : 1];             // hidden B operands + group state
         std::conditional_t<CUB, cubic_elems, rqs_elems> rq_e;
+        [[maybe_unused]] std::conditional_t<MIX, cubic_elems, int> rq_ec;     // MODE 14 keeps both kinds of group state
 
         for (int s = 0; s < n_steps; ++s) {
             // (1) this step's weights were issued one step ago (or in the prologue): wait for MY pieces, then
@@ -1862,6 +2041,18 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     if (st.c0 == 0) coupling_affine<NS, TX, HT, 0, TX / 2, TX / 2, TX / 2, true, MODE == 7>(xs, w, st, ldj, pf, rg);
                     else coupling_affine<NS, TX, HT, TX / 2, TX / 2, 0, TX / 2, true, MODE == 7>(xs, w, st, ldj, pf, rg);
                 }
+            } else if constexpr (MODE == 15) {
+                // programs of time-conditioned affine couplings (ContinuousAffineCoupling / NeuralFlow)
+                if (st.kind == SX_STEP_COUPLING_TIME) {
+                    float tv[NS];
+#pragma unroll
+                    for (int n = 0; n < NS; ++n) tv[n] = ((st.mask >> 8) & 1u) ? k.side[lrow[n]] : k.row_t[lrow[n]];
+                    if (st.tt == TX) coupling_time_dispatch<NS, TX, HT, TX>(xs, w, st, ldj, rg, tv);
+                    else if constexpr (TX >= 2) {
+                        if (st.tt == TX / 2) coupling_time_dispatch<NS, TX, HT, TX / 2>(xs, w, st, ldj, rg, tv);
+                        else if constexpr (TX >= 4) { if (st.tt == TX / 4) coupling_time_dispatch<NS, TX, HT, TX / 4>(xs, w, st, ldj, rg, tv); }
+                    }
+                }
             } else if constexpr (MODE == 4 && TX == 8) {
                 // training backward of 128-column flows: these three step kinds only (the general switch below would instantiate
                 // every coupling variant on eight tiles)
@@ -1894,7 +2085,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
             } else
             switch (st.kind) {
                 case SX_STEP_COUPLING_AFFINE:
-                    if constexpr (RQ || MODE == 7 || MODE == 8) break;   // spline programs carry no affine couplings (register budget); 7 / 8: handled above
+                    if constexpr (RQ || MODE == 7 || MODE == 8) break;   // pure spline programs carry no affine couplings (register budget; mixed: MODE 14); 7 / 8: handled above
                     if constexpr (TX >= 2) {
                         if (st.ct == TX / 2 && st.c0 == 0 && st.t0 == TX / 2) {          // cond = low tiles
                             coupling_affine_dispatch<NS, TX, HT, 0, TX / 2, TX / 2, TX / 2>(xs, w, st, ldj, pf, rg);
@@ -1914,6 +2105,20 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     if constexpr (MODE == 1) hidden_layer<NS, TX, HT, 0, TX, false>(xs, hid, w, 0, st.act, rg);
                     break;
                 case SX_STEP_CPL_HIDDEN:
+                    if constexpr (MIX && NS == 1) {
+                        // mixed programs: the deep-conditioner steps serve affine couplings (fp32 tiles in hidp) and spline
+                        // couplings (B-operand form in rq_bh) alike -- keep both forms
+                        if constexpr (TX >= 2) {
+                            if (st.ct == TX / 2 && st.c0 == 0) hidden_layer<1, TX, HT, 0, TX / 2, false>(xs, hidp, w, 0, st.act, rg);
+                            else if (st.ct == TX / 2) hidden_layer<1, TX, HT, TX / 2, TX / 2, false>(xs, hidp, w, 0, st.act, rg);
+                            else hidden_layer<1, TX, HT, 0, TX, false>(xs, hidp, w, 0, st.act, rg);
+                        } else {
+                            hidden_layer<1, TX, HT, 0, TX, false>(xs, hidp, w, 0, st.act, rg);
+                        }
+#pragma unroll
+                        for (int m = 0; m < HT; ++m) rq_bh[m] = make_btile<1>(hidp[m], rg);
+                        break;
+                    }
                     if constexpr (RQDEEP && NS == 1) {
                         // spline couplings with deep conditioners: the activations wait for the next layer in split (B
                         // operand) form in rq_bh -- the array the phases use anyway: no extra registers
@@ -1937,6 +2142,13 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     }
                     break;
                 case SX_STEP_CPL_HIDDEN2:
+                    if constexpr (MIX && NS == 1) {
+                        tile<1> nh[HT];
+                        hidden_body<1, HT, HT, false>(rq_bh, nh, w, 0, st.act);
+#pragma unroll
+                        for (int m = 0; m < HT; ++m) { hidp[m] = nh[m]; rq_bh[m] = make_btile<1>(nh[m], rg); }
+                        break;
+                    }
                     if constexpr (RQDEEP && NS == 1) {
                         tile<1> hd[HT];
                         hidden_body<1, HT, HT, false>(rq_bh, hd, w, 0, st.act);
@@ -1951,7 +2163,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     }
                     break;
                 case SX_STEP_COUPLING_AFFINE_DEEP:
-                    if constexpr (MODE == 9) {
+                    if constexpr (MODE == 9 || MIX) {
                         if constexpr (TX >= 2) {
                             if (st.tt == TX / 2 && st.t0 == TX / 2) {
                                 if (st.reverse) coupling_affine_deep<NS, TX, HT, TX / 2, TX / 2, true>(xs, hidp, w, st, ldj, rg);
@@ -2051,10 +2263,13 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                         }
                     }
                     break;
+                case SX_STEP_POINTWISE:
+                    if constexpr (MODE == 0 || MIX) pointwise_step<NS, TX>(xs, w, st, x_tiles, TX, ldj);
+                    break;
                 case SX_STEP_RQS_HIDDEN:
-                    if constexpr (RQ && NS == 1) {
+                    if constexpr ((RQ || MIX) && NS == 1) {
                         tile<1> hd[HT];
-                        if (RQDEEP && st.pad == 1) {   // deep conditioner: the last hidden layer, from the previous one's activations
+                        if ((RQDEEP || MIX) && st.pad == 1) {   // deep conditioner: the last hidden layer, from the previous one's activations
                             hidden_body<1, HT, HT, true>(rq_bh, hd, w, 0, st.act);
                         } else
                         if constexpr (TX >= 2) {
@@ -2071,6 +2286,10 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     }
                     break;
                 case SX_STEP_RQS_PHASE:
+                    if constexpr (MIX && NS == 1) {
+                        if (st.act == 1) cubic_phase<TX, HT>(xs, rq_bh, rq_ec, w, st, ldj[0], lane);
+                        else rqs_phase<TX, HT>(xs, rq_bh, rq_e, w, st, ldj[0], lane);
+                    } else
                     if constexpr (CUB && NS == 1) cubic_phase<TX, HT>(xs, rq_bh, rq_e, w, st, ldj[0], lane);
                     else if constexpr (RQ && NS == 1) rqs_phase<TX, HT>(xs, rq_bh, rq_e, w, st, ldj[0], lane);
                     break;
@@ -2100,7 +2319,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     break;
                 default: break;
             }
-            if (st.kind != SX_STEP_ROW_SCALE_EXP) ldj_c += st.ldj_const;
+            if (st.kind != SX_STEP_ROW_SCALE_EXP && st.kind != SX_STEP_POINTWISE) ldj_c += st.ldj_const;      // (those two keep a parameter there)
             if (!resident) cur ^= 1;
             SX_STAMP(pf, 6);     // step tail
         }
@@ -2326,6 +2545,8 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
     else if (a.mlp_mode == 10) SX_FL(10);
     else if (a.mlp_mode == 12) SX_FL(12);
     else if (a.mlp_mode == 13) SX_FL(13);
+    else if (a.mlp_mode == 14) SX_FL(14);
+    else if (a.mlp_mode == 15) SX_FL(15);
     else if (a.mlp_mode == 7) { if constexpr (TX >= 2) SX_FL(7); }
     else if (a.mlp_mode == 8) { if constexpr (TX >= 2) SX_FL(8); }
     else if (a.mlp_mode == 11) {

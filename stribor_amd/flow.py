@@ -700,7 +700,45 @@ class NeuralFlow(nn.Module):
         super().__init__()
         self.transforms = nn.ModuleList(transforms)
 
+    def _fused(self, dim: int, latent_dim: int, with_t0: bool, device):
+        """The whole flow -- the inverse pass at t0 (when given) and the forward pass at t -- as ONE program of
+        SX_STEP_COUPLING_TIME steps, or None when a transform is not a fusable ContinuousAffineCoupling."""
+        from .flows.coupling import ContinuousAffineCoupling
+        cache = self.__dict__.setdefault('_programs', ProgramCache())
+        key = (dim, latent_dim, bool(with_t0), str(device))
+
+        def build():
+            fs = list(self.transforms)
+            if not fs or not all(isinstance(f, ContinuousAffineCoupling) and f._fusable() for f in fs):
+                return None
+            try:
+                b = ProgramBuilder(dim, latent_dim, max(f.latent_net.hidden_width for f in fs), time_slots=2 if with_t0 else 1)
+                if with_t0:
+                    for f in reversed(fs):                                  # flow.py:178-180: x = f.inverse(x, t=t0)
+                        if not f._plan_time(b, True, 0.0, 1):
+                            return None
+                for f in fs:                                                # flow.py:181-182: x = f(x, t=t)
+                    if not f._plan_time(b, False, 0.0, 0):
+                        return None
+                return b.build(device)
+            except NotImplementedError:
+                return None
+        return cache.get(key, build, fingerprint=tuple(map(id, self.transforms)))
+
     def forward(self, x, t, t0=None, **kwargs):
+        latent = kwargs.get('latent')
+        plain = set(kwargs) <= {'latent'} and torch.is_tensor(t) and (t0 is None or torch.is_tensor(t0))
+        if plain and x.is_cuda and not graph_wanted(self, x, t, t0, latent) and x.numel() > 0:
+            x2, lead = flatten_rows(x)
+            n, d = x2.shape
+            lat2 = None if latent is None else latent.reshape(n, -1).to(torch.float32).contiguous()
+            prog = self._fused(d, 0 if lat2 is None else lat2.shape[1], t0 is not None, x.device)
+            if prog is not None:
+                def rows(v):
+                    v = v.to(device=x.device, dtype=torch.float32)
+                    return (v.expand(*lead, 1) if v.numel() != n else v).reshape(-1).contiguous()
+                y, _, _ = prog.run(x2, lat2, True, False, False, row_t=rows(t), side=None if t0 is None else rows(t0))
+                return y.reshape(*lead, d)
         if t0 is not None:
             for transform in reversed(self.transforms):
                 x = transform.inverse(x, t=t0, **kwargs)

@@ -607,6 +607,37 @@ class ContinuousAffineCoupling(Transform):
             return (_chunk_mlp_program(b, device), live_idx, int(live[0]) if len(live) else 0, live)
         return self._programs.get(key, build)
 
+    # ---- fused tier (round 3): the whole layer -- conditioner, time embedding, affine map, log-det -- is ONE step ---------------
+    def _fusable(self) -> bool:
+        net, tn = self.latent_net, self.time_net
+        return (isinstance(net, MLP) and net.fusable() and len(net.linears()) == 2 and net.hidden_width <= 128
+                and getattr(tn, 'kind', None) in (0, 1, 2, 3, 4) and (tn.kind != 4 or tn.hidden_dim <= 64))
+
+    def _plan_time(self, builder: ProgramBuilder, reverse: bool, ldj_scale: float, time_sel: int) -> bool:
+        """One SX_STEP_COUPLING_TIME step; `time_sel`: which of the program's time slots (0: t, 1: t0) this pass reads."""
+        if not self._fusable():
+            return False
+        net = self.latent_net
+        (W1, b1), (W2, b2) = net.linears()
+        D, L = builder.dim, builder.latent_dim
+        want_in = D + L + (1 if self.concatenate_time else 0)
+        if W1.shape[1] != want_in or W2.shape[0] != 2 * D:
+            raise ValueError(f'latent_net maps {W1.shape[1]} -> {W2.shape[0]}, expected {want_in} -> {2 * D}')
+        builder.add_coupling_time(W1, b1, W2, b2, self.mask_vector(D), net.act_code, reverse, ldj_scale, W1.shape[0],
+                                  D + L if self.concatenate_time else None, time_sel, self.time_net)
+        return True
+
+    def _fused_program(self, reverse: bool, ldj_scale: float, dim: int, latent_dim: int, device):
+        key = ('time-fused', bool(reverse), float(ldj_scale), dim, latent_dim, str(device))
+
+        def build():
+            try:
+                b = ProgramBuilder(dim, latent_dim, self.latent_net.hidden_width, time_slots=1)
+                return b.build(device) if self._plan_time(b, reverse, ldj_scale, 0) else None
+            except NotImplementedError:
+                return None
+        return self._programs.get(key, build)
+
     def _time_scales(self, dim: int, live: np.ndarray, device):
         """Per live column: the time net's scale for its log_scale and for its shift (chunk(2) of the embedding,
         broadcast against [.., dim] like the reference: half-width dim or 1)."""
@@ -627,12 +658,22 @@ class ContinuousAffineCoupling(Transform):
         t2 = t.reshape(-1).to(device=x.device, dtype=torch.float32).contiguous()
         if t2.numel() != n:
             t2 = t.expand(*lead, 1).reshape(-1).to(torch.float32).contiguous()
+        needs_graph = torch.is_grad_enabled() and (x.requires_grad or t.requires_grad or
+                                                    (latent is not None and latent.requires_grad) or
+                                                    any(p.requires_grad for p in self.parameters()))
+        if not needs_graph and self._fusable() and n > 0:
+            # ONE launch, no torch op: the kernel reads t straight into the conditioner's time slot and the embedding
+            lat_only = None if latent is None else latent.reshape(n, -1).to(torch.float32).contiguous()
+            prog = self._fused_program(reverse, ldj_scale, d, 0 if lat_only is None else lat_only.shape[1], x.device)
+            if prog is not None:
+                y, ldj, _ = prog.run(x2, lat_only, True, want_ldj, False, row_t=t2)
+                return y.reshape(*lead, d), (None if ldj is None else ldj.reshape(*lead, 1))
         parts = [] if latent is None else [latent.reshape(n, -1).to(torch.float32)]
         if self.concatenate_time:
             parts.append(t2.reshape(n, 1))                                           # coupling.py:155-156
         lat2 = torch.cat(parts, -1).contiguous() if parts else None
         extra = 0 if lat2 is None else lat2.shape[1]
-        fast = isinstance(self.latent_net, MLP) and self.latent_net._fits_program() and hasattr(self.time_net, 'kind')
+        fast = isinstance(self.latent_net, MLP) and self.latent_net._fits_program() and getattr(self.time_net, 'kind', 9) <= 3
         if fast:
             try:
                 progs, live_idx, live_start, live = self._program(d, extra, x.device)
@@ -643,9 +684,6 @@ class ContinuousAffineCoupling(Transform):
             contiguous = len(live) > 0 and np.array_equal(live, np.arange(live[0], live[0] + len(live)))
             live_idx = None if contiguous else torch.from_numpy(live.astype(np.int32)).to(x.device)
             live_start = int(live[0]) if len(live) else 0
-        needs_graph = torch.is_grad_enabled() and (x.requires_grad or t.requires_grad or
-                                                    (latent is not None and latent.requires_grad) or
-                                                    any(p.requires_grad for p in self.parameters()))
         if (needs_graph or not fast) and len(live):
             # training: conditioner and time net through torch (library GEMMs / tiny element-wise ops), the affine map and
             # its backward through the HIP op; same values as the kernel path

@@ -76,6 +76,23 @@ class _Pointwise(ElementwiseTransform):
     def _autograd_forward(self, x2, lat2=None):
         return PointwiseOp.apply(x2, self._fwd, self._p(False))
 
+    # ---- fused-program hook: one SX_STEP_POINTWISE step (Cumsum / Diff mix columns: they stay out) -----------------------
+    def _plan(self, builder, reverse, ldj_scale):
+        kind = self._inv if reverse else self._fwd
+        if kind in (PW_CUMSUM, PW_DIFF):
+            return False
+        param = self._p(reverse)
+        log_slope = 0.0
+        if kind == PW_LEAKY:
+            log_slope = math.log(param)
+        elif kind == PW_LEAKY_INV:
+            log_slope = -math.log(param)                 # param = 1 / slope (sx_pointwise: log of the forward slope)
+        # every kind's own log-derivative is that of the function it applies.  ldj_scale is the coefficient of the layer's FORWARD
+        # log-det (flow.py:47: -1 for a flow's inverse pass); on the inverse pass the kind applied is the layer's inverse, whose
+        # log-derivative is minus the layer's forward one at the value produced
+        builder.add_pointwise(kind, param, log_slope, -ldj_scale if reverse else ldj_scale)
+        return True
+
     def _graph(self, x, reverse: bool, want_ldiag: bool = False):
         """(out [..., D], log-det [..., 1], log-diag [..., D] | None) with a graph."""
         _hip.require_device(x, 'x')

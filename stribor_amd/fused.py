@@ -234,6 +234,58 @@ class _VectorJob:
         return [self.vec]
 
 
+class _TimeConstJob:
+    """Per-column constants of a time net (net/time_net.py:6-91) in the SX_STEP_COUPLING_TIME layout: per data tile [c_ls (32) |
+    c_sh (32)] in C-fragment order for TimeLinear / TimeTanh (the scale) / TimeLog (exp(scale)); for TimeFourier(Bounded) per tile
+    and feature k [w_ls | s_ls | w_sh | s_sh].  The embedding's first half scales log_scale, the second the shift (coupling.py:195),
+    each `dim` wide or 1 wide (broadcast)."""
+
+    def __init__(self, time_net, kind: int, K: int, dim: int, x_tiles: int, ls_col: np.ndarray, dst_off: int):
+        self.time_net, self.kind, self.K, self.dim, self.x_tiles, self.dst_off = time_net, kind, K, dim, x_tiles, dst_off
+        # slot (in C-fragment order per tile) -> column, -1 = not transformed
+        order = np.full(32 * x_tiles, -1, dtype=np.int64)
+        for t in range(x_tiles):
+            for h in range(2):
+                for r in range(16):
+                    order[t * 32 + h * 16 + r] = ls_col[32 * t + _kmap(r, h)]
+        self.order_host = order
+        self._idx = None
+
+    def params(self):
+        return [p for p in self.time_net.parameters()]
+
+    def run(self, blobs: torch.Tensor, prec: int = 0) -> None:
+        dev = blobs.device
+        tn = self.time_net
+        with torch.no_grad():
+            if self.kind == 4:
+                S, P = tn.get_scale().to(dev, torch.float32), tn.shift.detach().to(dev, torch.float32)      # [out, K]
+            else:
+                sc = tn.scale.detach().reshape(-1, 1).to(dev, torch.float32)                               # [out, 1]
+                S, P = (sc.exp() if self.kind == 3 else sc), None
+            out = S.shape[0]
+            half = out // 2
+            if half not in (1, self.dim):
+                raise ValueError(f'time_net width {out} does not broadcast against 2 x {self.dim}')
+            if self._idx is None or self._idx[0].device != dev:
+                o = self.order_host
+                ls = np.where(o >= 0, o if half == self.dim else 0, out)                # `out` = the appended zero row
+                sh = np.where(o >= 0, half + (o if half == self.dim else 0), out)
+                self._idx = (torch.from_numpy(ls).to(dev), torch.from_numpy(sh).to(dev))
+            ls_i, sh_i = self._idx
+            zrow = torch.zeros(1, S.shape[1], dtype=torch.float32, device=dev)
+            Sz = torch.cat([S, zrow])
+            if self.kind == 4:
+                Pz = torch.cat([P, zrow])
+                X, K = self.x_tiles, self.K
+                parts = [Sz[ls_i], Pz[ls_i], Sz[sh_i], Pz[sh_i]]                            # each [X * 32, K]
+                val = torch.stack([q.reshape(X, 32, K).permute(0, 2, 1) for q in parts], dim=2)   # [X, K, 4, 32]
+            else:
+                val = torch.stack([Sz[ls_i].reshape(self.x_tiles, 32), Sz[sh_i].reshape(self.x_tiles, 32)], dim=1)   # [X, 2, 32]
+            val = val.reshape(-1).contiguous()
+            blobs[self.dst_off:self.dst_off + val.numel()] = val
+
+
 class CompiledProgram:
     def __init__(self, prog: _hip.sx_program, blob_floats: int, jobs: List, in_col: Optional[np.ndarray],
                  out_col: Optional[np.ndarray], device: torch.device, mlp_out_dim: int = 0):
@@ -360,9 +412,12 @@ class CompiledProgram:
 class ProgramBuilder:
     """Accumulates steps; tracks which logical column each state slot holds."""
 
-    def __init__(self, dim: int, latent_dim: int = 0, hidden_width: int = 32, min_x_tiles: int = 1):
+    def __init__(self, dim: int, latent_dim: int = 0, hidden_width: int = 32, min_x_tiles: int = 1, time_slots: int = 0):
         self.dim, self.latent_dim = dim, latent_dim
-        lat_tiles = _ceil_div(latent_dim, 32)
+        # time-conditioned programs (ContinuousAffineCoupling / NeuralFlow): t and t0 take the `time_slots` (0..2) slots behind the
+        # latent columns in the latent tiles; the kernel fills them from row_t / the second time vector
+        self.time_slots = time_slots
+        lat_tiles = _ceil_div(latent_dim + time_slots, 32)
         self.tiles = _round_tiles(max(_ceil_div(dim, 32), min_x_tiles) + lat_tiles, f'dim {dim} + latent {latent_dim}')
         self.x_tiles = self.tiles - lat_tiles
         self.h_tiles = _round_tiles(_ceil_div(hidden_width, 32), f'hidden width {hidden_width}')
@@ -798,6 +853,98 @@ class ProgramBuilder:
         self.steps.append(dict(kind=_hip.STEP_AFFINE_CONST, c0=0, ct=0, t0=0, tt=T, reverse=int(reverse), act=0,
                                blob_off=off, blob_floats=n, ldj_scale=ldj_scale, ldj_const=0.0))
 
+    def add_coupling_time(self, W1, b1, W2, b2, mask: np.ndarray, act: int, reverse: bool, ldj_scale: float, hidden: int,
+                          time_col: Optional[int], time_sel: int, time_net) -> None:
+        """ContinuousAffineCoupling (coupling.py:184-213) as one SX_STEP_COUPLING_TIME step: the conditioner reads ALL tiles
+        (x * mask | latent | the time slot `time_sel`, through column `time_col` of W1 when time is concatenated), the affine map
+        with the time embedding acts on the data tiles.  time_net: a net.Time* module with an in-kernel `kind`."""
+        self._freeze_input()
+        D, T, HT, L = self.dim, self.tiles, self.h_tiles, self.latent_dim
+        # transformed tiles [0, XT): the tiles that hold data columns, rounded up to what the kernel dispatches on (all, half or
+        # a quarter of the tiles; a latent / padding tile inside the range has zero weights: exp(0) x + 0)
+        XT = next(c for c in (max(T // 4, 1), max(T // 2, 1), T) if c >= _ceil_div(D, 32))
+        if time_sel >= self.time_slots and time_col is not None:
+            raise NotImplementedError('time coupling: no slot for this time')
+        mask = np.asarray(mask, dtype=np.float64).reshape(-1)
+        if mask.size == 1:
+            mask = np.full(D, mask[0])
+        cond_col, live_col = mask > 0.5, mask <= 0.5
+        if D == 1:
+            cond_col = np.zeros(1, dtype=bool)                # coupling.py:151-152
+        col = self.col_of_slot
+        col_idx = np.full(32 * T, -1, dtype=np.int64)
+        for p in range(32 * T):
+            if p < self.n_slots:
+                if col[p] >= 0 and cond_col[col[p]]:
+                    col_idx[p] = col[p]
+            else:
+                li = p - self.n_slots
+                if li < L:
+                    col_idx[p] = D + li                       # cat([z, latent]) (coupling.py:153-154)
+                elif li == L + time_sel and time_col is not None:
+                    col_idx[p] = time_col                     # cat([z, t]) (coupling.py:155-156)
+        row_idx = np.full(32 * HT, -1, dtype=np.int64)
+        row_idx[:hidden] = np.arange(hidden)
+        kind = int(time_net.kind)
+        K = int(time_net.hidden_dim) if kind == 4 else 0
+        if kind == 4 and not (1 <= K <= 64):
+            raise NotImplementedError('in-kernel Fourier time nets hold up to 64 features')
+        n1 = _hip.packed_linear_floats(HT, T)
+        n2 = _hip.packed_linear_floats(2 * XT, HT)
+        n3 = 0 if kind == 0 else (XT * K * 128 if kind == 4 else XT * 64)
+        off, n = self._alloc(n1 + n2 + n3)
+        folded = act == _hip.ACT_CODES['Tanh']
+        LOG2E = 1.4426950408889634
+        rs1 = bs1 = rs2 = bs2 = None
+        fold = 0.0
+        if folded:                                            # as add_coupling_affine: tanh's and exp's constants live in the weights
+            kk = (-LOG2E) if reverse else LOG2E
+            rs1 = np.full(32 * HT, 2.0 * LOG2E)
+            bs1 = rs1
+            rs2, bs2 = np.empty(64 * XT), np.empty(64 * XT)
+            for t in range(XT):
+                rs2[64 * t:64 * t + 32], bs2[64 * t:64 * t + 32] = -2.0 * kk, kk
+                rs2[64 * t + 32:64 * t + 64], bs2[64 * t + 32:64 * t + 64] = -2.0, 1.0
+            fold = 1.0
+            act = _hip.ACT_TANH_FOLDED
+            ldj_scale = ldj_scale / kk
+        self.jobs.append(_PackJob(W1, b1, row_idx, col_idx, HT, T, off, rs1, bs1, 0.0))
+        row2 = np.full(64 * XT, -1, dtype=np.int64)
+        ls_col = np.full(32 * XT, -1, dtype=np.int64)         # per data slot: its column when transformed (else -1)
+        for t in range(XT):
+            for i in range(32):
+                p = 32 * t + i
+                if p < self.n_slots and col[p] >= 0 and live_col[col[p]]:
+                    row2[64 * t + i] = col[p]                 # log_scale rows, then shift rows (coupling.py:194 chunk(2))
+                    row2[64 * t + 32 + i] = D + col[p]
+                    ls_col[p] = col[p]
+        col2 = np.full(32 * HT, -1, dtype=np.int64)
+        col2[:hidden] = np.arange(hidden)
+        self.jobs.append(_PackJob(W2, b2, row2, col2, 2 * XT, HT, off + n1, rs2, bs2, fold))
+        if kind != 0:
+            self.jobs.append(_TimeConstJob(time_net, kind, K, D, XT, ls_col, off + n1 + n2))
+        step = dict(kind=_hip.STEP_COUPLING_TIME, c0=0, ct=T, t0=0, tt=XT, reverse=int(reverse), act=act, blob_off=off,
+                    blob_floats=n, ldj_scale=ldj_scale, ldj_const=0.0)
+        step['pad_'] = kind | (int(time_sel) << 8) | (K << 16)
+        self.steps.append(step)
+
+    def add_pointwise(self, kind: int, param: float, log_slope: float, ldj_coeff: float) -> None:
+        """One point-wise flow on the data columns (sigmoid.py:9-56, activations.py:11-101): `kind` = the sx_pointwise kind for the
+        direction taken; the step adds ldj_coeff * (that kind's own log-derivative sum) to the accumulator."""
+        self._freeze_input()
+        T = self.tiles
+        off, n = self._alloc(32 * T + 1)
+        vals = np.zeros(32 * T + 1, dtype=np.float64)
+        for t in range(self.x_tiles):
+            for h in range(2):
+                for r in range(16):
+                    if self.col_of_slot[32 * t + _kmap(r, h)] >= 0:
+                        vals[t * 32 + h * 16 + r] = 1.0
+        vals[32 * T] = log_slope
+        self.jobs.append(_ScalarsJob(vals, off))
+        self.steps.append(dict(kind=_hip.STEP_POINTWISE, c0=0, ct=0, t0=0, tt=T, reverse=0, act=int(kind), blob_off=off,
+                               blob_floats=n, ldj_scale=float(ldj_coeff), ldj_const=float(param)))
+
     def add_linear(self, sources, fn, ldj_fn=None) -> None:
         """y = W . x + b on the data columns (W, b = fn(device), torch Linear layout [out, in]): one LINEAR_TILE step
         for the whole layer; ldj_fn(device) -> its log-det term (0-dim tensor, signed and scaled) or None for 0."""
@@ -896,14 +1043,18 @@ class ProgramBuilder:
             raise NotImplementedError(f'fused program has {len(self.steps)} steps (max {_hip.SX_MAX_STEPS})')
         kinds = {s['kind'] for s in self.steps}
         rqs = kinds & {_hip.STEP_RQS_HIDDEN, _hip.STEP_RQS_PHASE}
-        if rqs and kinds & {_hip.STEP_COUPLING_AFFINE, _hip.STEP_COUPLING_AFFINE_DEEP, _hip.STEP_LINEAR_TILE,
-                            _hip.STEP_ROW_SCALE_EXP}:
-            # the spline kernel variant spends its registers on the group state: mixed flows run layer by layer
-            raise NotImplementedError('spline couplings cannot share a fused program with affine couplings / linear layers')
-        if len({s['act'] for s in self.steps if s['kind'] == _hip.STEP_RQS_PHASE}) > 1:
-            # one kernel variant per spline type (MODE 3 / 10 rational-quadratic, 12 / 13 cubic)
-            raise NotImplementedError('rational-quadratic and cubic spline couplings cannot share a fused program')
+        dense = kinds & {_hip.STEP_LINEAR_TILE, _hip.STEP_ROW_SCALE_EXP}
         deep = kinds & {_hip.STEP_CPL_HIDDEN, _hip.STEP_CPL_HIDDEN2, _hip.STEP_COUPLING_AFFINE_DEEP}
+        pointwise = _hip.STEP_POINTWISE in kinds
+        if rqs and dense:
+            raise NotImplementedError('spline couplings cannot share a fused program with dense linear layers')
+        # spline couplings beside affine couplings / point-wise steps, or both spline types: the MIXED kernel (MODE 14)
+        mixed = bool(rqs) and (bool(kinds & {_hip.STEP_COUPLING_AFFINE, _hip.STEP_COUPLING_AFFINE_DEEP}) or pointwise or
+                               len({s['act'] for s in self.steps if s['kind'] == _hip.STEP_RQS_PHASE}) > 1)
+        if _hip.STEP_COUPLING_TIME in kinds and len(kinds) > 1:
+            raise NotImplementedError('time-conditioned couplings form fused programs of their own')
+        if pointwise and (dense or (deep and not mixed) or kinds & {_hip.STEP_MLP_HIDDEN, _hip.STEP_MLP_HIDDEN2, _hip.STEP_MLP_OUT_TILE}):
+            raise NotImplementedError('point-wise steps share fused programs with couplings and element-wise affines only')
         if deep and kinds & {_hip.STEP_LINEAR_TILE, _hip.STEP_ROW_SCALE_EXP, _hip.STEP_MLP_HIDDEN, _hip.STEP_MLP_HIDDEN2,
                              _hip.STEP_MLP_OUT_TILE, _hip.STEP_COUPLING_AFFINE_BWD}:
             raise NotImplementedError('deep-conditioner couplings only share a fused program with other couplings')

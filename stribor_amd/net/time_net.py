@@ -1,8 +1,9 @@
 """Time embeddings (reference: stribor/net/time_net.py:6-47): ``TimeIdentity``, ``TimeLinear``, ``TimeTanh``, ``TimeLog``.
 
 Inside ``ContinuousAffineCoupling`` they are evaluated by the HIP kernel (``sx_time_affine_coupling`` takes the kind and
-the scale vector); ``forward`` / ``derivative`` here serve stand-alone calls with plain tensor ops on the caller's
-device.  ``TimeFourier`` / ``TimeFourierBounded`` (and any user-written time net) have no in-kernel form: see their docstring.
+the scale vector, or -- in the fused SX_STEP_COUPLING_TIME step -- the per-column constants in the step's blob); ``forward`` /
+``derivative`` here serve stand-alone calls with plain tensor ops on the caller's device.  ``TimeFourier`` /
+``TimeFourierBounded`` are an in-kernel kind too (round 3); a user-written time net is called as a module.
 """
 import torch
 import torch.nn as nn
@@ -61,9 +62,10 @@ class TimeLog(TimeLinear):
 
 
 class TimeFourier(nn.Module):
-    """Fourier features sum_k x_k sin(s_k t) (time_net.py:49-82).  No `kind`: inside ContinuousAffineCoupling such a
-    (or any other user-written) time net is evaluated with tensor ops on the device -- [N, out] values from [N, 1]
-    times -- and multiplied into the conditioner's output before the HIP affine kernel runs."""
+    """Fourier features sum_k x_k sin(s_k t) (time_net.py:49-82).  Inside a fused ContinuousAffineCoupling / NeuralFlow program
+    the sum is evaluated in the kernel (time kind 4: per-column weights and frequencies ride in the step's blob, hidden_dim <= 64);
+    `forward` / `derivative` here serve stand-alone calls and the autograd path with tensor ops."""
+    kind = 4                                                     # SX_TIME_FOURIER
 
     def __init__(self, out_dim: int, hidden_dim: int, lmbd: float = 0.5, bounded: bool = False, **kwargs):
         super().__init__()

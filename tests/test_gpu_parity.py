@@ -739,6 +739,8 @@ def test_continuous_affine_coupling_and_neural_flow():
         f = product_transform(g, case)
         x, t = g.t(case + '/x').to(DEV), g.t(case + '/t').to(DEV)
         kw = {'latent': g.t(case + '/latent').to(DEV)} if g.has(case + '/latent') else {}
+        # round 3: conditioner + time embedding + affine map + log-det are ONE fused step (SX_STEP_COUPLING_TIME)
+        assert f._fused_program(False, 1.0, x.shape[-1], kw['latent'].shape[-1] if kw else 0, x.device) is not None, case
         y, ldj = f.forward_and_log_det_jacobian(x, t, **kw)
         close(y, g.t(case + '/y'))
         close(ldj, g.t(case + '/ldj'), atol=2e-5)
@@ -755,6 +757,7 @@ def test_continuous_affine_coupling_and_neural_flow():
     nf.load_state_dict(g.state('neural_flow'))
     nf = nf.to(DEV)
     x, t, t0 = (g.t('neural_flow/' + k).to(DEV) for k in ('x', 't', 't0'))
+    assert nf._fused(x.shape[-1], 0, True, x.device) is not None and nf._fused(x.shape[-1], 0, False, x.device) is not None
     close(nf(x, t=t), g.t('neural_flow/y_t'))
     close(nf(x, t=t, t0=t0), g.t('neural_flow/y_t_t0'), atol=2e-5)
     assert torch.equal(nf(x, t=torch.zeros_like(t)), x)                          # test_neural_flow.py:24-27
@@ -1103,8 +1106,8 @@ def test_spline_kernels_pipelined_dense_path_against_oracle(cubic, bf16, scatter
 
 
 def test_bf16_storage_keeps_fp32_between_layers_of_an_unfused_flow():
-    """SURVEY H5 (bf16 in, fp32 arithmetic) for flows that run layer by layer (here: an affine and a spline coupling cannot share a
-    fused program): the state stays fp32 between the layers and up to the base density, as it does in the fused kernel's
+    """SURVEY H5 (bf16 in, fp32 arithmetic) for flows that run layer by layer (here: Diff mixes columns, which no fused program
+    does): the state stays fp32 between the layers and up to the base density, as it does in the fused kernel's
     registers -- log_prob from bf16 inputs matches the oracle fed the same rounded values at fp32 level (it was 1e-3 off when
     every layer stored bf16: tools/fuzz_train.py --bf16), outputs are rounded to bf16 once."""
     torch.manual_seed(8)
@@ -1112,7 +1115,7 @@ def test_bf16_storage_keeps_fp32_between_layers_of_an_unfused_flow():
     desc = [{'kind': 'coupling_affine', 'dim': dim, 'hidden': [32], 'mask': 'ordered_right_half', 'latent_dim': 0},
             {'kind': 'coupling_rqs', 'dim': dim, 'hidden': [32], 'n_bins': 7, 'lower': -3.0, 'upper': 3.0, 'mask': 'parity_odd',
              'latent_dim': 0, 'spline_type': 'quadratic'},
-            {'kind': 'leaky_relu', 'negative_slope': 0.2}]
+            {'kind': 'leaky_relu', 'negative_slope': 0.2}, {'kind': 'diff'}]
     flow = fd.build_flow(st, desc, dim)
     state = {k: v.clone() for k, v in flow.state_dict().items()}
     flow = flow.to(DEV)
@@ -1127,3 +1130,124 @@ def test_bf16_storage_keeps_fp32_between_layers_of_an_unfused_flow():
     wy, wl = orc.flow_forward_and_ldj(spec, x.double())
     close(ldj.float(), wl.float(), rtol=1e-5, atol=1e-4)
     close(y.float(), wy.float().bfloat16().float(), rtol=1e-2, atol=1e-2)
+
+
+def _mixed_desc(dim, hidden, K, lo, hi):
+    """affine coupling -> Flip -> Sigmoid -> cubic coupling on [0, 1] -> Logit -> rq-spline coupling -> LeakyReLU -> affine coupling
+    -> ELU -> element-wise affine (the reference's flagship stack, test_normalizing_flow.py:13-35, and then some)."""
+    return [{'kind': 'coupling_affine', 'dim': dim, 'hidden': [hidden], 'mask': 'ordered_1', 'latent_dim': 0},
+            {'kind': 'flip'},
+            {'kind': 'sigmoid'},
+            {'kind': 'coupling_rqs', 'dim': dim, 'hidden': [hidden], 'mask': 'ordered_0', 'latent_dim': 0, 'n_bins': K, 'lower': 0,
+             'upper': 1, 'spline_type': 'cubic'},
+            {'kind': 'logit'},
+            {'kind': 'coupling_rqs', 'dim': dim, 'hidden': [hidden], 'mask': 'parity_even', 'latent_dim': 0, 'n_bins': K, 'lower': lo,
+             'upper': hi},
+            {'kind': 'leaky_relu', 'negative_slope': 0.3},
+            {'kind': 'coupling_affine', 'dim': dim, 'hidden': [hidden], 'mask': 'parity_odd', 'latent_dim': 0},
+            {'kind': 'elu'},
+            {'kind': 'affine', 'dim': dim}]
+
+
+def test_reference_stack_plans_as_one_launch_and_matches_golden():
+    """the on-path part of stribor/test/test_normalizing_flow.py:13-35 (affine coupling -> Flip -> Sigmoid ->
+    cubic-spline coupling -> Logit; fixture f10 'stack', captured from the reference) is ONE fused program (kernel MODE 14)."""
+    g = Golden('f10_pointwise')
+    flow = product_flow(g, 'stack')
+    x = g.t('stack/x').to(DEV)
+    for reverse in (True, False):
+        prog = flow._fused_program(reverse, x.shape[-1], 0, x.device)
+        assert prog is not None, 'the reference stack must plan as one fused launch'
+        kinds = {prog.prog.steps[i].kind for i in range(prog.prog.n_steps)}
+        from stribor_amd import _hip
+        assert {_hip.STEP_POINTWISE, _hip.STEP_RQS_PHASE} <= kinds and kinds & {_hip.STEP_COUPLING_AFFINE, _hip.STEP_COUPLING_AFFINE_DEEP}
+    close(flow.log_prob(x), g.t('stack/log_prob'), rtol=1e-5, atol=1e-4)
+    close(flow.forward(x), g.t('stack/forward'), atol=2e-5)
+    close(flow.inverse(x), g.t('stack/inverse'), atol=2e-5)
+    z, ldj = flow.inverse_and_log_det_jacobian(x)
+    cur, acc = x, 0
+    for f in reversed(flow.transforms):                     # the same flow layer by layer through HBM (flow.py:118-125)
+        cur, l = f.inverse_and_log_det_jacobian(cur)
+        acc = acc + l
+    close(z, cur, atol=2e-5)
+    close(ldj, acc, atol=1e-4)
+
+
+@pytest.mark.parametrize('dim,hidden,K,n', [(64, 64, 16, 1000), (10, 12, 5, 257), (2, 13, 3, 100), (48, 40, 16, 300)])
+def test_mixed_fused_programs_against_oracle(dim, hidden, K, n):
+    """Affine couplings, both spline types, Sigmoid / Logit / LeakyReLU / ELU, Flip and an element-wise affine in ONE program
+    (kernel MODE 14), both directions, against the oracle; and against the same flow evaluated layer by layer."""
+    torch.manual_seed(61)
+    desc = _mixed_desc(dim, hidden, K, -4.0, 4.0)
+    flow = fd.build_flow(st, desc, dim)
+    with torch.no_grad():
+        for p in flow.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    spec = fd.flow_spec(desc, {k: v.clone() for k, v in flow.state_dict().items()})
+    flow = flow.to(DEV)
+    spec64 = orc.spec_to(spec, torch.float64)
+    # inputs of the inverse pass: points of the flow's range (ELU's inverse is only defined above -1)
+    x = orc.flow_forward(spec64, torch.randn(n, dim, dtype=torch.float64) * 0.8).float()
+    xd = x.to(DEV)
+    assert flow._fused_program(True, dim, 0, xd.device) is not None and flow._fused_program(False, dim, 0, xd.device) is not None
+    want_lp, want_lp64 = orc.flow_log_prob(spec, x), orc.flow_log_prob(spec64, x.double())
+    got_lp = flow.log_prob(xd)
+    close_vs_f64(got_lp, want_lp, want_lp64, k=2.0, rtol=1e-5, atol=1e-4)
+    zi, li = flow.inverse_and_log_det_jacobian(xd)
+    wz, wl = orc.flow_inverse_and_ldj(spec64, x.double())
+    close_vs_f64(zi, orc.flow_inverse(spec, x), wz, k=2.0, rtol=1e-5, atol=2e-5)
+    close(li, wl.float(), rtol=1e-5, atol=2e-4)
+    # forward direction from a point in the flow's range: the oracle's forward of the latent
+    zf = torch.randn(n, dim) * 0.7
+    wy, wlf = orc.flow_forward_and_ldj(spec64, zf.double())
+    gy, glf = flow.forward_and_log_det_jacobian(zf.to(DEV))
+    close_vs_f64(gy, orc.flow_forward(spec, zf), wy, k=2.0, rtol=1e-5, atol=2e-5)
+    close(glf, wlf.float(), rtol=1e-5, atol=2e-4)
+    # the fused launch agrees with the layer-by-layer evaluation of the same modules
+    cur, acc = xd, 0
+    for f in reversed(flow.transforms):
+        cur, l = f.inverse_and_log_det_jacobian(cur)
+        acc = acc + l
+    close(zi, cur, rtol=1e-5, atol=2e-5)
+    close(li, acc, rtol=1e-5, atol=2e-4)
+    st.check_errors()
+
+
+@pytest.mark.parametrize('dim,hidden,latent_dim,time_kind,n', [
+    (64, 64, 0, 'tanh', 1000), (64, 64, 5, 'linear', 513), (10, 12, 0, 'log', 257), (33, 40, 2, 'fourier', 300),
+    (8, 16, 0, 'fourier_bounded', 200), (96, 32, 0, 'identity', 129), (1, 8, 3, 'linear', 64)])
+def test_fused_time_couplings_and_neural_flow_against_oracle(dim, hidden, latent_dim, time_kind, n):
+    """ContinuousAffineCoupling (coupling.py:98-213) as ONE fused step and NeuralFlow.forward(x, t, t0) (flow.py:155-184) as ONE
+    launch -- every time net incl. TimeFourier(Bounded) in the kernel, latent inputs, D up to 96 -- against the oracle."""
+    torch.manual_seed(71)
+    masks = ['ordered_0', 'ordered_1', 'parity_even', 'parity_odd'] if dim > 1 else ['none'] * 4
+    desc = [{'kind': 'continuous_affine_coupling', 'dim': dim, 'hidden': [hidden], 'mask': m, 'latent_dim': latent_dim,
+             'time_kind': time_kind, 'time_hidden': 7} for m in masks]
+    fs = [fd.build_transform(st, d) for d in desc]
+    nf = st.NeuralFlow(fs)
+    with torch.no_grad():
+        for p in nf.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    state = {k: v.clone() for k, v in nf.state_dict().items()}
+    spec = [fd.transform_spec(d, state, f'transforms.{i}.') for i, d in enumerate(desc)]
+    nf = nf.to(DEV)
+    x, t, t0 = torch.randn(n, dim), torch.rand(n, 1) * 2, torch.rand(n, 1)
+    latent = torch.randn(n, latent_dim) if latent_dim else None
+    kw = {} if latent is None else {'latent': latent.to(DEV)}
+    okw = {} if latent is None else {'latent': latent}
+    assert nf._fused(dim, latent_dim, True, torch.device(DEV, 0)) is not None
+    close(nf(x.to(DEV), t.to(DEV), **kw), orc.neural_flow_forward(spec, x, t, **okw), rtol=1e-5, atol=2e-5)
+    close(nf(x.to(DEV), t.to(DEV), t0.to(DEV), **kw), orc.neural_flow_forward(spec, x, t, t0, **okw), rtol=1e-5, atol=5e-5)
+    if time_kind not in ('fourier', 'fourier_bounded', 'log') or True:
+        z = torch.zeros(n, 1)
+        got0 = nf(x.to(DEV), z.to(DEV), **kw)
+        close(got0, x, rtol=0, atol=1e-6)                                           # identity at t = 0 (test_neural_flow.py:24-27)
+    f0 = nf.transforms[0]
+    y, ldj = f0.forward_and_log_det_jacobian(x.to(DEV), t.to(DEV), **kw)
+    wy, wl = orc.continuous_affine_coupling(spec[0], x, t, latent, False)
+    close(y, wy, rtol=1e-5, atol=2e-5)
+    close(ldj, wl, rtol=1e-5, atol=2e-5)
+    xb, li = f0.inverse_and_log_det_jacobian(y, t.to(DEV), **kw)
+    close(xb, x, rtol=1e-5, atol=5e-5)
+    close(li, -wl, rtol=1e-5, atol=2e-5)
+    st.check_errors()

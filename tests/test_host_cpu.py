@@ -168,15 +168,23 @@ def test_planner_spline_flow_and_mixed_fallback():
     assert all(s['tt'] == 16 and s['pad_'] == -1 for s in phases)            # 16 bins, all 32 slots live
     assert [s['ct'] for s in phases[:3]] == [0, 1, 2]
     assert sum(1 for s in phases if s['ldj_scale'] != 0) == 8 * 4            # only the evaluate phases add log-det
-    mixed = st.NormalizingFlow(st.UnitNormal(64), [flow.transforms[0], fd.build_transform(st, fd.cfg2_desc(1)[0])])
-    assert mixed._build_fused(True, 64, 0, torch.device('cpu')) is None
+    # round 3: a flow mixing spline and affine couplings is ONE mixed program (kernel MODE 14)
+    mixed = st.NormalizingFlow(st.UnitNormal(64), [flow.transforms[0], fd.build_transform(st, fd.cfg2_desc(1)[0]), st.Sigmoid()])
+    prog = mixed._build_fused(True, 64, 0, torch.device('cpu'))
+    assert prog is not None
+    kinds = [prog.prog.steps[i].kind for i in range(prog.prog.n_steps)]
+    assert kinds[0] == _hip.STEP_POINTWISE and _hip.STEP_COUPLING_AFFINE in kinds and _hip.STEP_RQS_PHASE in kinds
+    assert prog.prog.steps[0].act == 2                                           # Sigmoid's inverse pass runs the LOGIT kind
+    # dense layers and Cumsum stay out of fused spline programs: layer by layer
+    assert st.NormalizingFlow(st.UnitNormal(64), [flow.transforms[0], st.AffineLU(64)])._build_fused(True, 64, 0, torch.device('cpu')) is None
+    assert st.NormalizingFlow(st.UnitNormal(64), [flow.transforms[0], st.Cumsum(-1)])._build_fused(True, 64, 0, torch.device('cpu')) is None
 
 
 def test_planner_cubic_spline_flow_and_spline_mix_rules():
     """Round 2: cubic-spline couplings plan into the same hidden + 12-phase layout with act = 1 (kernel MODE 12 / 13); the planner
-    refuses the mixes the kernel variants cannot run -- quadratic with cubic splines, any spline with a two-hidden-layer affine
-    coupling (which the spline kernel variant used to skip silently, tools/fuzz_train.py --infer) -- so such flows run layer
-    by layer instead of producing a wrong fused program."""
+    sends the mixes the pure spline kernel variants cannot run -- quadratic with cubic splines, any spline with a two-hidden-layer
+    affine coupling (which the spline kernel variant used to skip silently, tools/fuzz_train.py --infer) -- to the mixed program
+    (kernel MODE 14, round 3) instead of producing a wrong fused program."""
     torch.manual_seed(0)
     dev = torch.device('cpu')
     cubic = [dict(d, spline_type='cubic') for d in fd.cfg3_desc(2)]
@@ -190,12 +198,12 @@ def test_planner_cubic_spline_flow_and_spline_mix_rules():
     assert len(b.steps) == 2 * 13 and all(s['act'] == 1 and s['tt'] == 16 for s in phases)
     assert flow._build_fused(True, 64, 0, dev) is not None
     quad = fd.build_flow(st, fd.cfg3_desc(1), 64).transforms[0]
-    assert st.NormalizingFlow(st.UnitNormal(64), [flow.transforms[0], quad])._build_fused(True, 64, 0, dev) is None
+    assert st.NormalizingFlow(st.UnitNormal(64), [flow.transforms[0], quad])._build_fused(True, 64, 0, dev) is not None     # round 3: mixed program
     deep_affine = fd.build_transform(st, {'kind': 'coupling_affine', 'dim': 64, 'hidden': [48, 40], 'mask': 'ordered_left_half',
                                           'latent_dim': 0})
     assert st.NormalizingFlow(st.UnitNormal(64), [deep_affine])._build_fused(True, 64, 0, dev) is not None
-    for spline in (quad, flow.transforms[0]):
-        assert st.NormalizingFlow(st.UnitNormal(64), [deep_affine, spline])._build_fused(True, 64, 0, dev) is None
+    for spline in (quad, flow.transforms[0]):          # round 3: the mixed program (kernel MODE 14) carries deep conditioners too
+        assert st.NormalizingFlow(st.UnitNormal(64), [deep_affine, spline])._build_fused(True, 64, 0, dev) is not None
     wide = fd.build_transform(st, {'kind': 'coupling_rqs', 'dim': 64, 'hidden': [64], 'n_bins': 20, 'lower': -3, 'upper': 3,
                                    'mask': 'ordered_left_half', 'latent_dim': 0, 'spline_type': 'cubic'})
     assert st.NormalizingFlow(st.UnitNormal(64), [wide])._build_fused(True, 64, 0, dev) is None        # n_bins > 16: layer-wise tier
