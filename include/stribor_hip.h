@@ -263,6 +263,11 @@ int sx_pointwise(const void *x, void *y, float *ldj, float *ldiag, int64_t n_row
 int sx_pointwise_bwd(const float *x, const float *gy, const float *gldj, const float *gldiag, float *gx, int64_t n_rows, int32_t dim,
                      int32_t kind, float param, void *stream);
 
+/* out[0] = max(out[0], max |a[0..na)|, max |b[0..nb)|) (b nullable; fp32; `out` holds a non-negative value, e.g. 0, on entry): the
+ * magnitude of a backward pass's incoming adjoints (dL/dy [n_rows, dim] and dL/dlog-det [n_rows]), from which sx_rqs_slab_bwd
+ * derives its power-of-two normalisation; one launch over every element. */
+int sx_absmax2(const float *a, int64_t na, const float *b, int64_t nb, float *out, void *stream);
+
 /* UnitNormal.log_prob + log-det accumulator (stribor/dist/normal.py:37,52-54; flow.py:128-129):
  *   out[n] = sum_d( -x[n,d]^2/2 ) - dim*log(sqrt(2*pi)) + (ldj ? ldj[n] : 0) */
 int sx_unit_normal_logprob(const void *x, const float *ldj, float *out, int64_t n_rows, int32_t dim,

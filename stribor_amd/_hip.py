@@ -47,7 +47,7 @@ ACT_CODES = {'Identity': 0, 'Tanh': 1, 'ReLU': 2, 'Sigmoid': 3, 'ELU': 4, 'Softp
              'SiLU': 7, 'GELU': 8}
 
 # every symbol include/stribor_hip.h declares (tests check that the library exports all of them)
-EXPORTS = ['sx_abi_version', 'sx_fragment_mode', 'sx_last_error', 'sx_build_id', 'sx_permute', 'sx_affine_coupling', 'sx_rqs_coupling',
+EXPORTS = ['sx_abi_version', 'sx_fragment_mode', 'sx_last_error', 'sx_build_id', 'sx_absmax2', 'sx_permute', 'sx_affine_coupling', 'sx_rqs_coupling',
            'sx_cubic_coupling', 'sx_pointwise', 'sx_rqs_inverse_bwd', 'sx_rqs_forward_bwd', 'sx_affine_coupling_bwd', 'sx_time_affine_coupling', 'sx_cubic_inverse_bwd', 'sx_cubic_forward_bwd', 'sx_pointwise_bwd',
            'sx_unit_normal_logprob', 'sx_sum_f64', 'sx_packed_linear_floats', 'sx_pack_linear', 'sx_flow_run',
            'sx_flow_launch_info', 'sx_wgrad', 'sx_wgrad_layer', 'sx_colsum', 'sx_tri_inverse_f64',
@@ -120,6 +120,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.sx_pointwise_bwd.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, f32, vp]
     lib.sx_pointwise.restype = i32
     lib.sx_pointwise.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, f32, i32, vp]
+    lib.sx_absmax2.restype = i32
+    lib.sx_absmax2.argtypes = [vp, i64, vp, i64, vp, vp]
     lib.sx_unit_normal_logprob.restype = i32
     lib.sx_unit_normal_logprob.argtypes = [vp, vp, vp, i64, i32, i32, vp]
     lib.sx_sum_f64.restype = i32

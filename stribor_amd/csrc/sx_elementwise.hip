@@ -652,3 +652,44 @@ extern "C" int sx_sum_f64(const float *v, int64_t n, double *out, void *stream) 
     SX_LAUNCH_CHECK();
     return SX_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// out[0] = max(out[0], max |a|, max |b|) over two fp32 arrays (b may be NULL): the magnitude of a backward pass's incoming
+// adjoints, from which the slab kernels derive their power-of-two normalisation -- ONE launch over ALL elements (the torch form
+// was two strided-sample reductions + a maximum).  Non-negative floats order like their bit patterns: one atomicMax per block;
+// NaNs are skipped.  `out` must hold a non-negative value (zero) on entry.
+__global__ __launch_bounds__(256) void absmax2_kernel(const float *__restrict__ a, int64_t na, const float *__restrict__ b,
+                                                      int64_t nb, float *__restrict__ out) {
+    float m = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < na; i += stride) {
+        if (i + 3 < na && ((reinterpret_cast<uintptr_t>(a) & 15) == 0)) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(a + i);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        } else {
+            for (int64_t j = i; j < na && j < i + 4; ++j) m = fmaxf(m, fabsf(a[j]));
+        }
+    }
+    if (b != nullptr)
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(b[i]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        atomicMax(reinterpret_cast<unsigned int *>(out), __float_as_uint(m));
+    }
+}
+extern "C" int sx_absmax2(const float *a, int64_t na, const float *b, int64_t nb, float *out, void *stream) {
+    SX_REQUIRE(a && out && na >= 0 && nb >= 0, "sx_absmax2: bad arguments");
+    if (na == 0 && (b == nullptr || nb == 0)) return SX_OK;
+    int64_t g = (na / 4 + 255) / 256;
+    if (g > 1024) g = 1024;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(absmax2_kernel, dim3((int)g), dim3(256), 0, sx_stream(stream), a, na, b, b ? nb : 0, out);
+    SX_LAUNCH_CHECK();
+    return SX_OK;
+}

@@ -2283,6 +2283,25 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                         for (int r = 0; r < 16; ++r) hd[HT - 1].v[0][r] = fast_sig2(hd[HT - 1].v[0][r]);
 #pragma unroll
                         for (int m = 0; m < HT; ++m) rq_bh[m] = make_btile<1>(hd[m]);
+                        // optional side output for the training backward (sx_rqs_slab_bwd keeps the conditioner's last hidden
+                        // activation): tanh h = 1 - 2 r, row-major [n_rows, mlp_out_dim] -- instead of a library GEMM + tanh
+                        if (k.mlp_out != nullptr && row[0] < n_rows) {
+#pragma unroll
+                            for (int m = 0; m < HT; ++m)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const int c = 32 * m + 8 * q + 4 * h;
+                                    float *o = k.mlp_out + row[0] * k.mlp_out_stride + c;
+                                    const f32x4 tv = {1.f - 2.f * hd[m].v[0][4 * q], 1.f - 2.f * hd[m].v[0][4 * q + 1],
+                                                      1.f - 2.f * hd[m].v[0][4 * q + 2], 1.f - 2.f * hd[m].v[0][4 * q + 3]};
+                                    if (c + 3 < k.mlp_out_dim && (k.mlp_out_stride & 3) == 0) *reinterpret_cast<f32x4 *>(o) = tv;
+                                    else {
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e)
+                                            if (c + e < k.mlp_out_dim) o[e] = tv[e];
+                                    }
+                                }
+                        }
                     }
                     break;
                 case SX_STEP_RQS_PHASE:

@@ -61,8 +61,10 @@ class _FusedLogProb(torch.autograd.Function):
         # (the adjoints start at -g z and grow through the layers -- by the gain of the dense layers' matrices in cfg-4-like flows,
         #  orders of magnitude in their worst directions -- so S leaves headroom: max |g| max(1, max |z|) lands in [1/2, 1) of a
         #  range that reaches 65504 upwards and keeps 22 bits down to 0.125, 14 bits at 1e-3)
-        gmax = g.abs().max() * z.abs().max().clamp_min(1.0)
-        S = torch.where(gmax > 0, torch.exp2(-torch.floor(torch.log2(gmax.clamp_min(1e-38))) - 1.0), torch.ones_like(gmax))
+        gmax = g.abs().max()
+        if any(info.get('kind') == 'dense' for _, info in layers):
+            gmax = gmax * (2.0 * z.abs().max().clamp_min(1.0))       # (pure coupling flows: max |g| -> [1, 2), as before)
+        S = torch.where(gmax > 0, torch.exp2(-torch.floor(torch.log2(gmax.clamp_min(1e-38)))), torch.ones_like(gmax))
         g = g * S
         inv_S = 1.0 / S
         ht = 32 * bprog.prog.h_tiles

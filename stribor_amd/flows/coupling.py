@@ -403,9 +403,10 @@ class Coupling(Transform):
         lin = net.linears()
         return len(lin) >= 2 and lin[-1][1] is not None and RQSCouplingSlab.eligible(lin[-1][0].shape[1], sp.n_bins)
 
-    def _inverse_rows_nograd(self, x2, lat2):
+    def _inverse_rows_nograd(self, x2, lat2, h_out=None):
         """inverse_and_log_det_jacobian of [N, D] fp32 rows without a graph: the one-layer fused program when the conditioner
-        fits it (parameters never in HBM), else the MLP program + spline kernel."""
+        fits it (parameters never in HBM), else the MLP program + spline kernel.  h_out [N, H] (optional): receives the
+        conditioner's last hidden activation from the fused program -> (y, ldj, True); (y, ldj) / (y, ldj, False) otherwise."""
         d, ld = x2.shape[1], 0 if lat2 is None else lat2.shape[1]
         try:
             # planner convention: the coefficient of the FORWARD log-det (flow.py:47: the inverse returns minus it)
@@ -413,6 +414,9 @@ class Coupling(Transform):
         except NotImplementedError:
             prog = None
         if prog is not None:
+            if h_out is not None and _hip.get_gemm_precision() != 'auto':
+                y, ldj, _ = prog.run(x2, lat2, True, True, False, mlp_out=h_out)
+                return y, ldj, True
             y, ldj, _ = prog.run(x2, lat2, True, True, False)
             return y, ldj
         try:
@@ -445,7 +449,7 @@ class Coupling(Transform):
                     torch.from_numpy(cols).to(dev), torch.from_numpy(cmap).to(dev), words)
         plan = self._programs.get(('slab', d, H, cubic, str(x2.device)), build)
         W2, b2 = SelectRows.apply(lin[-1][0], rows_t), SelectRows.apply(lin[-1][1], rows_t)
-        evaluate = lambda xx: self._inverse_rows_nograd(xx, lat2)
+        evaluate = lambda xx, h_out=None: self._inverse_rows_nograd(xx, lat2, h_out)
         col_mask = mask_t * 0 if d == 1 else mask_t                                  # coupling.py:62-63
         if (lat2 is None and len(lin) == 2 and net.activation_name == 'Tanh' and lin[0][1] is not None
                 and RQSCouplingSlabL1.eligible(d, H, sp.n_bins) and os.environ.get('STRIBOR_SPLINE_L1_TORCH') != '1'):

@@ -115,12 +115,12 @@ class RQSForward(_SplineOpAlias):
 
 
 def _adjoint_scale(gy, gldj):
-    """max |adjoint| on the device, for the slab kernels' power-of-two normalisation of their fp16 x 3 operands.  Only the order
-    of magnitude matters (the normalised values have four decades of headroom below fp16's 65504 and full precision down to
-    6e-5), so big batches are sampled every 16th row: the full scan of gy was 23 us per layer and 2^18 rows."""
-    inf = float('inf')
-    g = gy[::16] if gy.shape[0] >= 4096 else gy
-    return torch.maximum(torch.linalg.vector_norm(g, ord=inf), torch.linalg.vector_norm(gldj, ord=inf)).reshape(1)
+    """max |adjoint| on the device, for the slab kernels' power-of-two normalisation of their fp16 x 3 operands: ONE launch of
+    sx_absmax2 over EVERY element (adjoints are row-local: a loss with strongly non-uniform row weights can hide its largest
+    rows from any strided sample -- ADVICE r2 -- and the sampled torch form took four launches)."""
+    out = torch.zeros(1, dtype=torch.float32, device=gy.device)
+    _hip.call('sx_absmax2', gy, gy.data_ptr(), gy.numel(), gldj.data_ptr(), gldj.numel(), out.data_ptr())
+    return out
 
 
 def slab_slot_rows(n_live: int, n_bins: int, cubic: bool = False):
@@ -234,8 +234,15 @@ class RQSCouplingSlabL1(torch.autograd.Function):
     def forward(ctx, x2, W1, b1, W2, b2, mask_t, evaluate, plan, live_idx, live_start, n_live, n_bins, lower, upper, cubic=False):
         x2 = x2.contiguous()
         with torch.no_grad():
-            y, ldj = evaluate(x2)
-            h = torch.tanh(torch.addmm(b1, x2, (W1 * mask_t).t()))
+            # h = tanh(x (W1 * mask)^T + b1) comes out of the forward program itself (side output of its hidden step) when the
+            # coupling runs as one fused program; otherwise one library GEMM + tanh
+            h = torch.empty(x2.shape[0], W1.shape[0], dtype=torch.float32, device=x2.device)
+            got = evaluate(x2, h)
+            if len(got) == 3 and got[2]:
+                y, ldj = got[0], got[1]
+            else:
+                y, ldj = got[0], got[1]
+                h = torch.tanh(torch.addmm(b1, x2, (W1 * mask_t).t()))
         ctx.save_for_backward(x2, h, W1, W2, b2, mask_t, y if cubic else None)
         ctx.meta = (plan, live_idx, live_start, n_live, n_bins, float(lower), float(upper))
         return y, ldj

@@ -325,10 +325,14 @@ class CompiledProgram:
         if self.jobs:
             v = self._current_versions()
             if v != self._versions.get(prec):
-                if prec in self._versions:
+                first = prec not in self._versions
+                if not first:
                     blobs[:1].zero_()              # header word 0: flags of the previous packing
                 for j in self.jobs:
-                    j.run(blobs, prec)
+                    # constants (spline bounds, live-slot masks: no parameter behind them) are written once per blob buffer; a
+                    # training step re-packs the weights only (each constant was a host-to-device copy per step before)
+                    if first or j.params():
+                        j.run(blobs, prec)
                 self._versions[prec] = v
         return blobs
 
@@ -366,6 +370,8 @@ class CompiledProgram:
         elif self.prog.latent_dim:
             raise ValueError('this transform was built for a latent input but none was given')
         stride = mlp_out.stride(0) if mlp_out is not None else 0
+        # (spline-coupling programs: an optional side output, the conditioner's last hidden activation [N, H] -- see SX_STEP_RQS_HIDDEN)
+        mlp_dim = self.mlp_out_dim if (self.mlp_out_dim or mlp_out is None) else mlp_out.shape[1]
         if row_t is not None:
             _hip.require_device(row_t, 't')
             row_t = row_t.reshape(-1).to(torch.float32).contiguous()
@@ -380,7 +386,7 @@ class CompiledProgram:
                                             _hip.ptr(latent), _hip.ptr(self.in_col), _hip.ptr(self.out_col), _hip.ptr(y),
                                             _hip.ptr(ldj), _hip.ptr(logp), _hip.ptr(sum_out),
                                             None if mlp_out is None else mlp_out.data_ptr() + 4 * self.mlp_col0, stride,
-                                            self.mlp_out_dim, _hip.ptr(row_t), _hip.ptr(side), n, _hip.dtype_code(x),
+                                            mlp_dim, _hip.ptr(row_t), _hip.ptr(side), n, _hip.dtype_code(x),
                                             prec, work.data_ptr(), flag, _hip.stream())
                 if rc != 0:
                     work.zero_()                    # a failed launch may leave the ticket pair armed

@@ -10,6 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d $O/$c -o p --output-format csv -- python3 $R/tools/bench_configs.py --train cfg3 --rows 262144 --train-only > $O/$c.log 2>&1
 done
+BID=$(python3 -c "import sys; sys.path.insert(0, '$R'); from stribor_amd import _hip; print(_hip.build_id())")
 python3 - <<PY
 import csv, glob, collections, json
 per = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -23,7 +24,7 @@ for f in glob.glob('$O/*/**/*counter_collection.csv', recursive=True):
         per[k][r['Counter_Name']] += float(r['Counter_Value'])
         calls[k][r['Counter_Name']] += 1
 steps = 11.0          # bench_configs.py --train: 1 warm-up + 5 x 2 timed steps
-out = {'rows': 262144, 'steps_profiled': steps, 'path': '$TAG', 'kernels': {}}
+out = {'rows': 262144, 'steps_profiled': steps, 'path': '$TAG', 'build_id': '$BID', 'kernels': {}}
 tot_r = tot_w = 0.0
 for k, a in per.items():
     rd = 2 * a.get('FETCH_SIZE', 0) * 1024 / 1e6 / steps

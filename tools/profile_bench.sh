@@ -19,7 +19,8 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $set -d $OUT/pmc$i -o p --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-training > $OUT/pmc$i.log 2>&1
 done
-python3 $R/tools/pmc_summary.py $OUT $COMMIT > $OUT/summary.txt 2>&1
+BID=$(python3 -c "import sys; sys.path.insert(0, '$R'); from stribor_amd import _hip; print(_hip.build_id())")
+python3 $R/tools/pmc_summary.py $OUT $COMMIT $BID > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*counter_collection.csv" -delete
