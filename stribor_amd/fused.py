@@ -52,7 +52,13 @@ class StructureTracked:
 
     def __setattr__(self, name, value):
         if not name.startswith('_') and name not in StructureTracked._UNTRACKED:
-            _STRUCT_EPOCH[0] += 1
+            # a plain tensor (not a Parameter) assigned to a name that is neither a registered parameter nor a buffer is a value a
+            # forward pre-hook recomputes on every call (torch's spectral_norm: setattr(module, 'weight', w / sigma)); such wrapped
+            # layers never join fused programs, and bumping the process-wide epoch per forward would re-plan every flow each step
+            hook_value = (torch.is_tensor(value) and not isinstance(value, torch.nn.Parameter)
+                          and name not in self.__dict__.get('_parameters', ()) and name not in self.__dict__.get('_buffers', ()))
+            if not hook_value:
+                _STRUCT_EPOCH[0] += 1
         super().__setattr__(name, value)
 
     def __delattr__(self, name):

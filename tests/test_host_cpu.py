@@ -320,3 +320,26 @@ def test_slab_slot_rows_cover_every_parameter_row_once(n_live, K, cubic):
         assert ci == 2 * s_ + ((R >> 2) & 1)                         # column <-> lane half of the C fragment
         k = (R & 3) + 4 * (R >> 3)
         assert off == t * K + k and k < (n_third if t == 2 else K)   # block <-> tile, parameter <-> register
+
+
+def test_hook_computed_tensors_do_not_invalidate_every_cached_program():
+    """torch's spectral_norm recomputes `module.weight` (a plain tensor) in a forward pre-hook on every call; that
+    assignment must not bump the process-wide structure epoch (every flow would re-plan and re-pack each step), while replacing a
+    parameter, a buffer or a plain attribute still does."""
+    from stribor_amd.fused import _STRUCT_EPOCH
+    net = st.net.MLP(4, [8], 6, nn_linear_wrapper_func=torch.nn.utils.spectral_norm)
+    wrapped = net.net[2]
+    assert 'weight' not in wrapped._parameters and 'weight_orig' in wrapped._parameters
+    e0 = _STRUCT_EPOCH[0]
+    setattr(wrapped, 'weight', torch.randn(6, 8))                  # what the hook does
+    assert _STRUCT_EPOCH[0] == e0
+    wrapped.bias = torch.nn.Parameter(torch.zeros(6))              # a parameter replaced: plans must go
+    assert _STRUCT_EPOCH[0] == e0 + 1
+    p = st.Permute(5)
+    e1 = _STRUCT_EPOCH[0]
+    p.permutation = torch.randperm(5)                              # a registered buffer re-assigned
+    assert _STRUCT_EPOCH[0] == e1 + 1
+    c = st.Coupling(st.Affine(4, latent_net=st.net.MLP(4, [8], 8)), mask='ordered_0')
+    e2 = _STRUCT_EPOCH[0]
+    c.set_data = True                                              # a plain attribute the planner reads
+    assert _STRUCT_EPOCH[0] == e2 + 1
