@@ -151,7 +151,7 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     // mixed programs (kernel MODE 14): spline couplings beside affine couplings / point-wise steps, or both spline types
     const bool mixed = rqs && (aff || pw || (cub && quadr));
     SX_REQUIRE(!(pw && (lin || *mlp_mode == 1 || bwd || (deep && !mixed))), "sx_flow_run: point-wise steps mix with couplings and element-wise affines only");
-    if (rqs) *mlp_mode = mixed ? ((cub && !quadr) ? 16 : 14) : (cub ? 12 : 3);      // 16: mixed programs whose splines are all cubic
+    if (rqs) *mlp_mode = mixed ? ((cub && !quadr) ? 16 : (quadr && !cub) ? 17 : 14) : (cub ? 12 : 3);      // 16 / 17: mixed programs with one spline type
     SX_REQUIRE(!(bwd && (rqs || lin || aff || *mlp_mode == 1)), "sx_flow_run: backward steps cannot be mixed with other step kinds");
     if (bwd) *mlp_mode = 4;
     SX_REQUIRE(!(timed && (rqs || lin || aff || bwd || deep || pw || *mlp_mode == 1)), "sx_flow_run: time couplings form programs of their own");

@@ -1964,7 +1964,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
         rg.bad = 0ull;
         tile<NS> hid[MODE == 1 ? HT : 1];
         constexpr bool LIN = MODE == 2 || MODE == 7 || MODE == 8;    // programs with dense linear layers
-        tile<NS> hidp[(MODE == 9 || MODE == 14 || MODE == 16) ? HT : 1];   // MODE 9 / 14 / 16: hidden state kept between deep-conditioner steps
+        tile<NS> hidp[(MODE == 9 || MODE == 14 || MODE == 16 || MODE == 17) ? HT : 1];   // MODE 9 / 14 / 16 / 17: hidden state kept between deep-conditioner steps
         tile<1> bkeep[(MODE == 4 && TX == 8) ? HT + TX / 2 : 1];     // MODE 4, D = 128: r and dL/d(ls, sh) between steps A and B
         constexpr bool CUB = MODE == 12 || MODE == 13;    // cubic-spline couplings (13: + deep conditioners)
         constexpr bool RQ = MODE == 3 || MODE == 10 || CUB;      // spline couplings (10: + deep conditioners)
@@ -1974,11 +1974,12 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
         // cubic-spline coupling -> Logit).  One wave per SIMD: both splines' group states and the coupling arms share the file.
         // MODE 16: the same with cubic splines as the only spline type (the reference's default, and its flagship stack): one group
         // state instead of two, two waves per SIMD up to 64 columns
-        constexpr bool MIX = MODE == 14 || MODE == 16;
-        constexpr bool MIXC = MODE == 16;
+        // MODE 17: the same with rational-quadratic splines only
+        constexpr bool MIX = MODE == 14 || MODE == 16 || MODE == 17;
+        constexpr bool MIXC = MODE == 16, MIXQ = MODE == 17;
         btile<1> rq_bh[(RQ || MIX) ? HT : 1];             // hidden B operands + group state
         std::conditional_t<(CUB || MIXC), cubic_elems, rqs_elems> rq_e;
-        [[maybe_unused]] std::conditional_t<(MIX && !MIXC), cubic_elems, int> rq_ec;     // MODE 14 keeps both kinds of group state
+        [[maybe_unused]] std::conditional_t<(MODE == 14), cubic_elems, int> rq_ec;     // MODE 14 keeps both kinds of group state
 
         for (int s = 0; s < n_steps; ++s) {
             // (1) this step's weights were issued one step ago (or in the prologue): wait for MY pieces, then
@@ -2309,6 +2310,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     break;
                 case SX_STEP_RQS_PHASE:
                     if constexpr (MIXC && NS == 1) cubic_phase<TX, HT>(xs, rq_bh, rq_e, w, st, ldj[0], lane);
+                    else if constexpr (MIXQ && NS == 1) rqs_phase<TX, HT>(xs, rq_bh, rq_e, w, st, ldj[0], lane);
                     else if constexpr (MIX && NS == 1) {
                         if (st.act == 1) cubic_phase<TX, HT>(xs, rq_bh, rq_ec, w, st, ldj[0], lane);
                         else rqs_phase<TX, HT>(xs, rq_bh, rq_e, w, st, ldj[0], lane);
@@ -2571,6 +2573,7 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
     else if (a.mlp_mode == 14) SX_FL(14);
     else if (a.mlp_mode == 15) SX_FL(15);
     else if (a.mlp_mode == 16) SX_FL(16);
+    else if (a.mlp_mode == 17) SX_FL(17);
     else if (a.mlp_mode == 7) { if constexpr (TX >= 2) SX_FL(7); }
     else if (a.mlp_mode == 8) { if constexpr (TX >= 2) SX_FL(8); }
     else if (a.mlp_mode == 11) {
