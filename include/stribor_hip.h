@@ -320,7 +320,8 @@ int sx_pack_linear(const float *W, const float *b, int32_t out_dim, int32_t in_d
                                            t0 = 0; AffineLU affine.py:157-171, MatrixExponential affine.py:243-288)               */
 #define SX_STEP_MLP_HIDDEN           5  /* blob = pack_linear(W, h_tiles x tiles): hidden = act(W . state + b)  (mlp.py:65)       */
 #define SX_STEP_MLP_HIDDEN2          6  /* blob = pack_linear(W, h_tiles x h_tiles): hidden' = act(W . hidden + b)                 */
-#define SX_STEP_MLP_OUT_TILE         7  /* blob = pack_linear(W, 1 x h_tiles): mlp_out[:, 32*t0 ..] = W[t0] . hidden + b            */
+#define SX_STEP_MLP_OUT_TILE         7  /* blob = pack_linear(W, 1 x h_tiles): mlp_out[:, 32*t0 ..] = W[t0] . hidden + b (reverse = 1: += -- a later
+                                         * hidden-unit chunk of a conditioner wider than the hidden tiles)                             */
 #define SX_STEP_ROW_SCALE_EXP        9  /* blob = diag[tiles][2][16]: state *= exp(+-diag * t_row); t_row = row_t[n] or ldj_const;
                                            act != 0 applies log1p|t| (affine.py:239-240)                                          */
 #define SX_STEP_RQS_HIDDEN          10  /* blob = pack_linear(W1, folded tanh): hidden of a spline coupling, kept for its phases    */
@@ -387,7 +388,7 @@ typedef struct sx_program {
     int32_t tiles;        /* x_tiles + latent tiles: 1, 2 or 4 (8: backward programs of 128-column flows) */
     int32_t h_tiles;      /* hidden width / 32 rounded up to 1, 2 or 4                         */
     int32_t identity_cols;/* 1: state slot p <-> column p (vector loads), 0: use in_col/out_col */
-    int32_t pad_;
+    int32_t pad_;         /* 0, or the row stride of x in elements (>= dim; needs in_col): the program reads a column subset of wider rows */
     sx_step steps[SX_MAX_STEPS];
 } sx_program;
 

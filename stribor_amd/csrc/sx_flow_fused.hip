@@ -24,7 +24,10 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     SX_REQUIRE(p->latent_dim >= 0 && p->latent_dim <= 32 * (p->tiles - p->x_tiles), "sx_flow_run: latent_dim does not fit");
     SX_REQUIRE(!p->identity_cols || p->dim % 4 == 0, "sx_flow_run: identity_cols needs dim %% 4 == 0");
     d->n_steps = p->n_steps; d->dim = p->dim; d->latent_dim = p->latent_dim; d->x_tiles = p->x_tiles;
-    d->identity_cols = p->identity_cols; d->pad = 0;
+    // pad_: row stride of x in elements when the program reads a column subset of wider rows (MLP programs of couplings wider than
+    // the state tiles: in_col then holds columns of the wide row); 0 = dim
+    SX_REQUIRE(p->pad_ == 0 || (p->pad_ >= p->dim && !p->identity_cols), "sx_flow_run: x row stride %d needs in_col and >= dim", p->pad_);
+    d->identity_cols = p->identity_cols; d->pad = p->pad_;
     int mx = 256;
     bool lin = false, rqs = false, aff = false, bwd = false, deep = false, cub = false, quadr = false;
     int n_bwd128 = 0;

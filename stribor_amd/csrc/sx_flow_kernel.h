@@ -1926,7 +1926,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int c = k.in_col[32 * t + sx_kmap(r, h)];
-                            xs[t].v[n][r] = c >= 0 ? ld_elem(k.x, lrow[n] * dim + c, bf16) : 0.f;
+                            xs[t].v[n][r] = c >= 0 ? ld_elem(k.x, lrow[n] * (prog.pad ? prog.pad : dim) + c, bf16) : 0.f;      // prog.pad: row stride of x when the program reads a column subset of wider rows
                         }
                     }
                 } else if constexpr (MODE == 4 || MODE == 11) {
@@ -2197,6 +2197,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                         tile<NS> acc = load_cfrag<NS>(w.cb, HT * 1024);
 #pragma unroll
                         for (int c = 0; c < HT; ++c) gemm_tile<NS>(w.wb, c * 1024, make_btile<NS>(hid[c], rg), acc);
+                        const bool accumulate = st.reverse != 0;     // a later hidden chunk of a wide conditioner: mlp_out += (see add_mlp)
 #ifdef SX_F16X3
                         if (rg.bad) {   // a row whose operands left the fp16 x 3 range is returned as NaN and flagged
                             if (rng_bad_sample(rg, lane)) {
@@ -2216,12 +2217,13 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                                     const int c = 32 * st.t0 + 8 * q + 4 * h;
                                     float *o = k.mlp_out + row[n] * k.mlp_out_stride + c;
                                     if (c + 3 < k.mlp_out_dim && (k.mlp_out_stride & 3) == 0) {
-                                        *reinterpret_cast<f32x4 *>(o) = f32x4{acc.v[n][4 * q], acc.v[n][4 * q + 1],
-                                                                              acc.v[n][4 * q + 2], acc.v[n][4 * q + 3]};
+                                        f32x4 v = f32x4{acc.v[n][4 * q], acc.v[n][4 * q + 1], acc.v[n][4 * q + 2], acc.v[n][4 * q + 3]};
+                                        if (accumulate) v += *reinterpret_cast<const f32x4 *>(o);
+                                        *reinterpret_cast<f32x4 *>(o) = v;
                                     } else {
 #pragma unroll
                                         for (int e = 0; e < 4; ++e)
-                                            if (c + e < k.mlp_out_dim) o[e] = acc.v[n][4 * q + e];
+                                            if (c + e < k.mlp_out_dim) o[e] = accumulate ? o[e] + acc.v[n][4 * q + e] : acc.v[n][4 * q + e];
                                     }
                                 }
                             }

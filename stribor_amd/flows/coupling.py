@@ -35,6 +35,10 @@ from .affine import Affine
 __all__ = ['Coupling', 'ContinuousAffineCoupling']
 
 
+def _ceil32(n: int) -> int:
+    return -(-n // 32)
+
+
 class Coupling(Transform):
     def __init__(self, transform, mask: str, set_data: bool = False, **kwargs):
         super().__init__()
@@ -227,6 +231,39 @@ class Coupling(Transform):
         out = net(z)
         return out.reshape(rows, out.shape[-1]).index_select(0, sel)
 
+    def _conditioner_programs(self, dim: int, latent_dim: int, device, cond: np.ndarray, out_rows: np.ndarray):
+        """The conditioner (net.MLP) as MFMA programs writing the selected output rows [N, len(out_rows)]: one program (chunked
+        over output windows) when inputs and hidden layers fit the kernel's tiles; for single-hidden-layer conditioners also
+        (round 3, the tier that flattens the width cliffs)
+          * couplings wider than 128 columns: the program reads only the CONDITIONING columns of the wide rows (a column-subset
+            program: <= 128 of them incl. the latent), and
+          * hidden layers wider than 128: one program per chunk of 128 hidden units, later chunks accumulating into the output
+            (W2 tanh(W1 z + b1) is a sum over hidden-unit chunks).
+        -> list of CompiledProgram, to be run in order with the same mlp_out."""
+        net = self._net()
+        lin = net.linears()
+        H = net.hidden_width
+        wide_in = _ceil32(dim) + _ceil32(latent_dim) > 4
+        if len(lin) != 2 or (H <= 128 and not wide_in):
+            b = ProgramBuilder(dim, latent_dim, H)
+            b.add_mlp(lin, net.act_code, cond, out_rows)
+            return _chunk_mlp_program(b, device)
+        cols = np.nonzero(cond)[0]
+        if wide_in and (len(cols) == 0 or _ceil32(len(cols)) + _ceil32(latent_dim) > 4):
+            raise NotImplementedError('more than 128 conditioning columns: generic tier')
+        progs = []
+        for h0 in range(0, H, 128):
+            hsel = np.arange(h0, min(h0 + 128, H))
+            if wide_in:
+                b = ProgramBuilder(len(cols), latent_dim, len(hsel))
+                b.x_cols, b.x_stride = cols, dim
+                b.add_mlp(lin, net.act_code, None, out_rows, hidden_rows=hsel, accumulate=h0 > 0, w1_cols=cols, w1_latent_base=dim)
+            else:
+                b = ProgramBuilder(dim, latent_dim, len(hsel))
+                b.add_mlp(lin, net.act_code, cond, out_rows, hidden_rows=hsel, accumulate=h0 > 0)
+            progs += _chunk_mlp_program(b, device)
+        return progs
+
     # ---- affine, unfused: pruned conditioner (MFMA program) + HBM-bound element-wise kernel -----------------
     def _affine_unfused_program(self, dim: int, latent_dim: int, device):
         key = ('affine-unfused', dim, latent_dim, str(device))
@@ -239,11 +276,10 @@ class Coupling(Transform):
             if dim == 1:
                 cond = np.zeros(1, dtype=bool)
             out_rows = np.concatenate([live, dim + live])                           # (log_scale | shift) of live columns
-            b = ProgramBuilder(dim, latent_dim, net.hidden_width)
-            b.add_mlp(net.linears(), net.act_code, cond, out_rows)
+            progs = self._conditioner_programs(dim, latent_dim, device, cond, out_rows)
             contiguous = len(live) > 0 and np.array_equal(live, np.arange(live[0], live[0] + len(live)))
             live_idx = None if contiguous else torch.from_numpy(live.astype(np.int32)).to(device)
-            return (_chunk_mlp_program(b, device), live_idx, int(live[0]) if len(live) else 0, len(live))
+            return (progs, live_idx, int(live[0]) if len(live) else 0, len(live))
         return self._programs.get(key, build)
 
     def _run_affine_unfused(self, x2, lat2, reverse, want_ldj, ldj_scale):
@@ -272,11 +308,10 @@ class Coupling(Transform):
                 cond = np.zeros(1, dtype=bool)                                       # coupling.py:62-63
             P = sp.params_per_element                                                # 3K-1 quadratic, 2K+2 cubic
             out_rows = (live[:, None] * P + np.arange(P)[None, :]).reshape(-1)       # spline.py:82-86, pruned
-            b = ProgramBuilder(dim, latent_dim, net.hidden_width)
-            b.add_mlp(net.linears(), net.act_code, cond, out_rows)
+            progs = self._conditioner_programs(dim, latent_dim, device, cond, out_rows)
             contiguous = len(live) > 0 and np.array_equal(live, np.arange(live[0], live[0] + len(live)))
             live_idx = None if contiguous else torch.from_numpy(live.astype(np.int32)).to(device)
-            return (_chunk_mlp_program(b, device), live_idx, int(live[0]) if len(live) else 0, len(live), len(out_rows))
+            return (progs, live_idx, int(live[0]) if len(live) else 0, len(live), len(out_rows))
         return self._programs.get(key, build)
 
     def _run_spline(self, x2, lat2, reverse, want_ldj, ldj_scale):

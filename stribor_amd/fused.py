@@ -357,7 +357,7 @@ class CompiledProgram:
             side: Optional[torch.Tensor] = None):
         """x: [N, dim] contiguous on the program's device.  Returns (y | None, ldj | None, logp | None)."""
         _hip.require_device(x, 'x')
-        assert x.dim() == 2 and x.shape[1] == self.prog.dim, (x.shape, self.prog.dim)
+        assert x.dim() == 2 and x.shape[1] == (self.prog.pad_ or self.prog.dim), (x.shape, self.prog.dim, self.prog.pad_)
         if not x.is_contiguous():
             x = x.contiguous()
         _hip.poll_errors()                  # a data-dependent condition of an EARLIER call surfaces here
@@ -442,6 +442,10 @@ class ProgramBuilder:
         self.jobs: List = []
         self.blob_floats = 256             # 1 KiB header: word 0 = flags raised while packing (sx_flow_run reports them)
         self.mlp_out_dim = 0
+        # conditioner programs of couplings wider than the state tiles read a COLUMN SUBSET of the wide rows: `x_cols` (column of
+        # x per state column of this program) and the rows' stride
+        self.x_cols: Optional[np.ndarray] = None
+        self.x_stride = 0
 
     # -- layout ------------------------------------------------------------------------------------
     def choose_layout(self, first_mask: Optional[np.ndarray]) -> None:
@@ -996,29 +1000,37 @@ class ProgramBuilder:
                                ldj_const=float(t_const)))
 
     def add_mlp(self, linears: Sequence[Tuple], act: int, in_cols_live: Optional[np.ndarray],
-                out_rows: np.ndarray) -> None:
+                out_rows: np.ndarray, hidden_rows: Optional[np.ndarray] = None, accumulate: bool = False,
+                w1_cols: Optional[np.ndarray] = None, w1_latent_base: Optional[int] = None) -> None:
         """Conditioner as its own program: hidden layers then one OUT_TILE step per 32 output columns.
 
         linears: [(W, b), ...] torch layout; in_cols_live: bool[D] (False -> that x column is zeroed,
-        the z = x*mask of coupling.py:61) or None; out_rows[i] = row of the last W written to column i."""
+        the z = x*mask of coupling.py:61) or None; out_rows[i] = row of the last W written to column i.
+        Conditioners wider than the tiles (one hidden layer only): `hidden_rows` = the hidden units this program covers (the
+        network's output is a SUM over hidden-unit chunks: W2 tanh(W1 z + b1) = sum_c W2[:, c] tanh(W1[c] z + b1[c])); `accumulate`:
+        this chunk adds to what an earlier one wrote (and leaves the output bias to it); `w1_cols[c]` = column of W1 that state
+        column c of this (column-subset) program feeds, `w1_latent_base` = W1's first latent column."""
         self._freeze_input()
         assert len(linears) >= 2, 'conditioner needs at least one hidden layer'
+        assert hidden_rows is None or len(linears) == 2
         D, T, HT = self.dim, self.tiles, self.h_tiles
         col = self.col_of_slot
         W0, b0 = linears[0]
+        lat0 = D if w1_latent_base is None else w1_latent_base
         col_idx = np.full(32 * T, -1, dtype=np.int64)
         for p in range(32 * T):
             if p < self.n_slots:
                 c = col[p]
                 if c >= 0 and (in_cols_live is None or in_cols_live[c]):
-                    col_idx[p] = c
+                    col_idx[p] = c if w1_cols is None else w1_cols[c]
             else:
                 li = p - self.n_slots
                 if li < self.latent_dim:
-                    col_idx[p] = D + li
-        h_prev = W0.shape[0]
+                    col_idx[p] = lat0 + li
+        hsel = np.arange(W0.shape[0]) if hidden_rows is None else np.asarray(hidden_rows, dtype=np.int64)
+        h_prev = len(hsel)
         row_idx = np.full(32 * HT, -1, dtype=np.int64)
-        row_idx[:h_prev] = np.arange(h_prev)
+        row_idx[:h_prev] = hsel
         off, n = self._alloc(_hip.packed_linear_floats(HT, T))
         self.jobs.append(_PackJob(W0, b0, row_idx, col_idx, HT, T, off))
         self.steps.append(dict(kind=_hip.STEP_MLP_HIDDEN, c0=0, ct=T, t0=0, tt=0, reverse=0, act=act, blob_off=off,
@@ -1038,14 +1050,14 @@ class ProgramBuilder:
         out_rows = np.asarray(out_rows, dtype=np.int64)
         self.mlp_out_dim = len(out_rows)
         cL = np.full(32 * HT, -1, dtype=np.int64)
-        cL[:h_prev] = np.arange(h_prev)
+        cL[:h_prev] = hsel if hidden_rows is not None else np.arange(h_prev)
         for u in range(_ceil_div(len(out_rows), 32)):
             r = np.full(32, -1, dtype=np.int64)
             seg = out_rows[32 * u:32 * u + 32]
             r[:len(seg)] = seg
             off, n = self._alloc(_hip.packed_linear_floats(1, HT))
-            self.jobs.append(_PackJob(WL, bL, r, cL, 1, HT, off))
-            self.steps.append(dict(kind=_hip.STEP_MLP_OUT_TILE, c0=0, ct=0, t0=u, tt=1, reverse=0, act=0,
+            self.jobs.append(_PackJob(WL, None if accumulate else bL, r, cL, 1, HT, off))
+            self.steps.append(dict(kind=_hip.STEP_MLP_OUT_TILE, c0=0, ct=0, t0=u, tt=1, reverse=int(accumulate), act=0,
                                    blob_off=off, blob_floats=n, ldj_scale=0.0, ldj_const=0.0))
 
     # -- finish ------------------------------------------------------------------------------------
@@ -1077,11 +1089,16 @@ class ProgramBuilder:
         ident = np.full(self.n_slots, -1, dtype=np.int64)
         ident[:self.dim] = np.arange(self.dim)
         identity = (self.dim % 4 == 0 and np.array_equal(self.in_col, ident)
-                    and np.array_equal(self.col_of_slot, ident))
+                    and np.array_equal(self.col_of_slot, ident)) and self.x_cols is None
         prog.identity_cols = int(identity)
+        in_col = self.in_col
+        if self.x_cols is not None:                   # state column c of this program = column x_cols[c] of rows x_stride wide
+            xc = np.asarray(self.x_cols, dtype=np.int64)
+            in_col = np.where(self.in_col >= 0, xc[np.clip(self.in_col, 0, len(xc) - 1)], -1)
+            prog.pad_ = int(self.x_stride)
         for i, s in enumerate(self.steps):
             st = prog.steps[i]
             for k, v in s.items():
                 setattr(st, k, v)
-        return CompiledProgram(prog, self.blob_floats, self.jobs, None if identity else self.in_col,
+        return CompiledProgram(prog, self.blob_floats, self.jobs, None if identity else in_col,
                                None if identity else self.col_of_slot.copy(), device, self.mlp_out_dim)
