@@ -1912,11 +1912,18 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                             f32x4 v = {0.f, 0.f, 0.f, 0.f};
                             if (c + 3 < dim) {
                                 if (bf16) {
+                                    // (plain loads: a lane takes 8 B of a 128-B row per instruction, eight instructions share a line -- with
+                                    //  the streaming policy the line was re-fetched between them: FETCH_SIZE 69 -> 164 MKiB per launch)
                                     const u16x4 u = *reinterpret_cast<const u16x4 *>(
                                         reinterpret_cast<const uint16_t *>(k.x) + lrow[n] * dim + c);
                                     v = f32x4{bf16_to_f32(u.x), bf16_to_f32(u.y), bf16_to_f32(u.z), bf16_to_f32(u.w)};
                                 } else {
-                                    v = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(k.x) + lrow[n] * dim + c);
+                                    // spline programs (96 steps, 3.2 MB of blobs that every chunk re-reads from L2): x is read once and
+                                    // kept out of their way by the streaming policy (cfg 3: FETCH_SIZE 318 -> 154 MKiB per launch, same
+                                    // time); elsewhere plain loads (cfg 4 measured 2 % slower with it)
+                                    constexpr bool NT_X = MODE == 3 || MODE == 10 || MODE == 12 || MODE == 13;
+                                    if constexpr (NT_X) v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(k.x) + lrow[n] * dim + c));
+                                    else v = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(k.x) + lrow[n] * dim + c);
                                 }
                             }
                             xs[t].v[n][4 * q + 0] = v.x; xs[t].v[n][4 * q + 1] = v.y;

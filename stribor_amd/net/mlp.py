@@ -195,9 +195,20 @@ class MLP(StructureTracked, nn.Module):
     # -- standalone evaluation ---------------------------------------------------------------------------
     def _program(self, device):
         def build():
-            b = ProgramBuilder(self.in_dim, 0, self.hidden_width)
-            b.add_mlp(self.linears(), self.act_code, None, np.arange(self.out_dim))
-            return _chunk_mlp_program(b, device)
+            H = self.hidden_width
+            if H <= 128:
+                b = ProgramBuilder(self.in_dim, 0, H)
+                b.add_mlp(self.linears(), self.act_code, None, np.arange(self.out_dim))
+                return _chunk_mlp_program(b, device)
+            # one hidden layer wider than the kernel's four hidden tiles: one program per chunk of 128 hidden units, later chunks
+            # accumulating into the output (W2 act(W1 x + b1) + b2 is a sum over hidden-unit chunks)
+            progs = []
+            for h0 in range(0, H, 128):
+                hsel = np.arange(h0, min(h0 + 128, H))
+                b = ProgramBuilder(self.in_dim, 0, len(hsel))
+                b.add_mlp(self.linears(), self.act_code, None, np.arange(self.out_dim), hidden_rows=hsel, accumulate=h0 > 0)
+                progs += _chunk_mlp_program(b, device)
+            return progs
         return self._programs.get(str(device), build)
 
     def fusable(self) -> bool:
@@ -207,8 +218,9 @@ class MLP(StructureTracked, nn.Module):
                 and len(self.linears()) >= 2)
 
     def _fits_program(self) -> bool:
-        """One launch of the fused MFMA kernel holds inputs and hidden layers of up to 128 columns."""
-        return self.fusable() and self.in_dim <= 128 and self.hidden_width <= 128
+        """One launch of the fused MFMA kernel holds inputs and hidden layers of up to 128 columns; a single hidden layer of any
+        width runs as one launch per 128 hidden units."""
+        return self.fusable() and self.in_dim <= 128 and (self.hidden_width <= 128 or len(self.linears()) == 2)
 
     def forward(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
         _hip.require_device(x, 'MLP input')

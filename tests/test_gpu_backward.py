@@ -1158,3 +1158,33 @@ def test_fused_backward_of_dense_linear_flows_blocks_and_trains(monkeypatch):
     assert losses[-1] < losses[0], losses
     with torch.no_grad():
         assert torch.isfinite(flow.log_prob(x)).all()
+
+
+def test_fused_backward_of_dense_linear_flows_in_the_exact_arithmetic():
+    """The same backward program through the sx_f32x kernels (set_gemm_precision('exact'): v_mfma_f32_32x32x2_f32, fp32 sx_wgrad)."""
+    old = st.set_gemm_precision('exact')
+    try:
+        torch.manual_seed(53)
+        dim, n = 128, 150
+        desc = _cfg4_like(dim, 64, 1, True, False)
+        flow = fd.build_flow(st, desc, dim)
+        with torch.no_grad():
+            for p in flow.parameters():
+                p.add_(0.02 * torch.randn_like(p))
+        state = {k: v.clone() for k, v in flow.state_dict().items()}
+        flow = flow.to(DEV)
+        x = torch.randn(n, dim)
+        want_loss, want_g, want_gx = oracle_grads(desc, state, x)
+        xg = x.to(DEV).requires_grad_(True)
+        assert flow._can_backward(xg)
+        loss = -flow.log_prob(xg).mean()
+        loss.backward()
+        assert abs(loss.item() - want_loss) <= 1e-5 * abs(want_loss) + 1e-5
+        tol = lambda ref: 3e-4 * ref.abs().max().item() + 1e-7
+        assert (xg.grad.cpu() - want_gx.float()).abs().max().item() <= tol(want_gx)
+        for pname, p in flow.named_parameters():
+            ref = want_g[pname].float()
+            assert p.grad is not None and (p.grad.cpu() - ref).abs().max().item() <= tol(ref), pname
+        st.check_errors()
+    finally:
+        st.set_gemm_precision(old)

@@ -250,3 +250,41 @@ def test_mlp_program_with_more_than_256_output_tiles():
         h = torch.tanh(torch.nn.functional.linear(x.double(), lin[0].weight.double(), lin[0].bias.double()))
         want = torch.nn.functional.linear(h, lin[1].weight.double(), lin[1].bias.double())
     close(got, want.float(), rtol=1e-5, atol=1e-5)
+
+
+def test_wide_hidden_layers_and_wide_couplings_run_as_chunked_mfma_programs():
+    """Round 3 (tier 2 widened): a single hidden layer of any width runs as one MFMA program per 128 hidden units (later chunks
+    accumulate into the output), and a coupling wider than 128 columns whose conditioning columns fit the tiles reads them as a
+    column subset of the wide rows -- no library GEMM; values against the oracle."""
+    torch.manual_seed(33)
+    net = st.net.MLP(20, [300], 70).to(DEV)
+    with torch.no_grad():
+        net.net[2].bias.normal_()
+        x = torch.randn(517, 20, device=DEV)
+        progs = net._program(torch.device(DEV, 0))
+        assert len(progs) >= 3                                     # 300 hidden units = 3 chunks (x output windows)
+        ws = [m.weight.detach().cpu() for m in net.net if isinstance(m, torch.nn.Linear)]
+        bs = [m.bias.detach().cpu() for m in net.net if isinstance(m, torch.nn.Linear)]
+        close(net(x), orc.mlp_forward({'weights': ws, 'biases': bs, 'activation': 'Tanh'}, x.cpu()), rtol=1e-5, atol=2e-5)
+    for dim, hidden, kind in ((160, 200, 'coupling_affine'), (136, 64, 'coupling_rqs'), (40, 160, 'coupling_rqs')):
+        d = {'kind': kind, 'dim': dim, 'hidden': [hidden], 'mask': 'ordered_left_half', 'latent_dim': 3}
+        if kind == 'coupling_rqs':
+            d.update(n_bins=5, lower=-3.0, upper=3.0)
+        f = fd.build_transform(st, d)
+        with torch.no_grad():
+            for p in f.parameters():
+                p.add_(0.03 * torch.randn_like(p))
+        spec = fd.transform_spec(d, {'T.' + k: v.clone() for k, v in f.state_dict().items()}, 'T.')
+        f = f.to(DEV)
+        x, lat = torch.randn(300, dim), torch.randn(300, 3)
+        with torch.no_grad():
+            progs = (f._affine_unfused_program if kind == 'coupling_affine' else f._spline_program)(dim, 3, torch.device(DEV, 0))[0]
+            assert len(progs) >= (2 if hidden > 128 else 1)
+            y, ldj = f.forward_and_log_det_jacobian(x.to(DEV), latent=lat.to(DEV))
+            wy, wl = orc.transform_forward_and_ldj(spec, x, latent=lat)
+            close(y, wy, rtol=1e-5, atol=2e-5)
+            close(ldj, wl, rtol=1e-5, atol=2e-4)
+            xb, li = f.inverse_and_log_det_jacobian(y, latent=lat.to(DEV))
+            close(xb, x, rtol=1e-4, atol=1e-4)
+            close(li, -wl, rtol=1e-5, atol=2e-4)
+    st.check_errors()
