@@ -342,12 +342,14 @@ int sx_pack_linear(const float *W, const float *b, int32_t out_dim, int32_t in_d
                                          * kind 12's first two): conditioner, un-transform, dL/d(log_scale, shift) (kept in registers for B);
                                          * c0 = first conditioner tile (0 or 2; the transformed tiles are the other half), tt = layer slot
                                          * of the side buffer.                                                                          */
-#define SX_STEP_COUPLING_AFFINE_BWD_B 17 /* B: blob = pack(W2^T) ++ pack(W1^T): dL/dh, dL/dh_pre, adjoint of the conditioning tiles; same c0 / tt */
+#define SX_STEP_COUPLING_AFFINE_BWD_B 17 /* B: blob = pack(W2^T) ++ pack(W1^T): dL/dh, dL/dh_pre, adjoint of the conditioning tiles; same c0 / tt;
+                                         * directly behind its A step (the kernel runs the pair in one iteration of its step loop)       */
 #define SX_STEP_LINEAR_BWD          18  /* dense linear layer of a backward program (AffineLU / MatrixExponential, affine.py:156-171,243-288):
                                          * tiles [c0, c0 + 4) <- M . tiles + b, blob = pack_linear(M, 4 x 4) (c0 = 0: the x tiles, M = the
                                          * layer's forward matrix; c0 = 4: the adjoint tiles, M = W^T of the matrix log_prob applied).  The
                                          * factors of dL/dW = sum_n dL/du_n v_n^T are stored to the side buffer of layer slot tt at feature
-                                         * offset 32 * t0: before the step when reverse = 1 (the adjoint), after it otherwise (v).        */
+                                         * offset 32 * t0: before the step when reverse = 1 (the adjoint), after it otherwise (v).  The two
+                                         * steps of a layer come back to back, c0 = 0 first.                                             */
 #define SX_STEP_POINTWISE           19  /* point-wise flow on the data tiles (Sigmoid / Logit sigmoid.py:9-56, ELU / LeakyReLU activations.py:11-101):
                                          * act = SX_PW_* kind (the direction is the kind), ldj_const = param (LeakyReLU slope or its reciprocal),
                                          * blob = live-slot mask [tiles][2][16] (C-fragment order: 1 = column, 0 = padding) ++ {log-slope};

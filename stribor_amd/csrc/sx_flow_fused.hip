@@ -94,6 +94,9 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
                 SX_REQUIRE(s.kind == SX_STEP_COUPLING_AFFINE_BWD_A || (i > 0 && p->steps[i - 1].kind == SX_STEP_COUPLING_AFFINE_BWD_A &&
                                                                       p->steps[i - 1].c0 == s.c0 && p->steps[i - 1].tt == s.tt),
                            "sx_flow_run: step %d: a BWD_B step follows its BWD_A step", i);
+                // (the kernel runs A and B inside one iteration of its step loop)
+                SX_REQUIRE(s.kind != SX_STEP_COUPLING_AFFINE_BWD_A || (i + 1 < p->n_steps && p->steps[i + 1].kind == SX_STEP_COUPLING_AFFINE_BWD_B),
+                           "sx_flow_run: step %d: a BWD_A step is followed by its BWD_B step", i);
                 need = s.kind == SX_STEP_COUPLING_AFFINE_BWD_A
                            ? sx_packed_linear_floats(p->h_tiles, 2) + sx_packed_linear_floats(4, p->h_tiles)
                            : sx_packed_linear_floats(p->h_tiles, 4) + sx_packed_linear_floats(2, p->h_tiles);
@@ -104,6 +107,10 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
             case SX_STEP_LINEAR_BWD: {
                 SX_REQUIRE(p->tiles == 8 && p->x_tiles == 4, "sx_flow_run: step %d: kind 18 belongs to backward programs on 4 + 4 tiles", i);
                 SX_REQUIRE((s.c0 == 0 || s.c0 == 4) && s.t0 >= 0 && s.t0 + 4 <= 16, "sx_flow_run: step %d: bad tiles / side offset", i);
+                // the two halves of a dense layer come back to back, x tiles first (one iteration of the kernel's step loop)
+                SX_REQUIRE(s.c0 == 0 ? (i + 1 < p->n_steps && p->steps[i + 1].kind == SX_STEP_LINEAR_BWD && p->steps[i + 1].c0 == 4)
+                                     : (i > 0 && p->steps[i - 1].kind == SX_STEP_LINEAR_BWD && p->steps[i - 1].c0 == 0),
+                           "sx_flow_run: step %d: SX_STEP_LINEAR_BWD steps come in pairs (x tiles, then adjoint tiles)", i);
                 need = sx_packed_linear_floats(4, 4);
                 const int sw = 32 * (s.t0 + 4);
                 if (sw > *side_width) *side_width = sw;

@@ -1770,10 +1770,6 @@ __device__ __forceinline__ void coupling_affine_bwd_acc(tile<1> (&xs)[4], const 
 }
 #endif   // SX_F16X3
 
-__device__ __forceinline__ float ld_elem(const void *p, int64_t off, int bf16) {
-    if (bf16) return bf16_to_f32(reinterpret_cast<const uint16_t *>(p)[off]);
-    return reinterpret_cast<const float *>(p)[off];
-}
 __device__ __forceinline__ void st_elem(void *p, int64_t off, float v, int bf16) {
     if (bf16) reinterpret_cast<uint16_t *>(p)[off] = f32_to_bf16(v);
     else reinterpret_cast<float *>(p)[off] = v;
@@ -1930,10 +1926,24 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                             xs[t].v[n][4 * q + 2] = v.z; xs[t].v[n][4 * q + 3] = v.w;
                         }
                     } else {
+                        // gathered columns (Flip / Permute relabelling, ragged widths): all 16 indices, then all 16 elements -- a
+                        // load under `c >= 0` is a branch with its own s_waitcnt vmcnt(0), i.e. 32 dependent round trips per tile
+                        int cidx[16];
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int c = k.in_col[32 * t + sx_kmap(r, h)];
-                            xs[t].v[n][r] = c >= 0 ? ld_elem(k.x, lrow[n] * (prog.pad ? prog.pad : dim) + c, bf16) : 0.f;      // prog.pad: row stride of x when the program reads a column subset of wider rows
+                        for (int r = 0; r < 16; ++r) cidx[r] = k.in_col[32 * t + sx_kmap(r, h)];
+                        const int64_t rb = lrow[n] * (prog.pad ? prog.pad : dim);      // prog.pad: row stride of x when the program reads a column subset of wider rows
+                        if (bf16) {
+                            uint16_t u[16];
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) u[r] = reinterpret_cast<const uint16_t *>(k.x)[rb + (cidx[r] >= 0 ? cidx[r] : 0)];
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) xs[t].v[n][r] = cidx[r] >= 0 ? bf16_to_f32(u[r]) : 0.f;
+                        } else {
+                            float u[16];
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) u[r] = reinterpret_cast<const float *>(k.x)[rb + (cidx[r] >= 0 ? cidx[r] : 0)];
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) xs[t].v[n][r] = cidx[r] >= 0 ? u[r] : 0.f;
                         }
                     }
                 } else if constexpr (MODE == 4 || MODE == 11) {
@@ -1972,7 +1982,6 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
         tile<NS> hid[MODE == 1 ? HT : 1];
         constexpr bool LIN = MODE == 2 || MODE == 7 || MODE == 8;    // programs with dense linear layers
         tile<NS> hidp[(MODE == 9 || MODE == 14 || MODE == 16 || MODE == 17) ? HT : 1];   // MODE 9 / 14 / 16 / 17: hidden state kept between deep-conditioner steps
-        tile<1> bkeep[(MODE == 4 && TX == 8) ? HT + TX / 2 : 1];     // MODE 4, D = 128: r and dL/d(ls, sh) between steps A and B
         constexpr bool CUB = MODE == 12 || MODE == 13;    // cubic-spline couplings (13: + deep conditioners)
         constexpr bool RQ = MODE == 3 || MODE == 10 || CUB;      // spline couplings (10: + deep conditioners)
         constexpr bool RQDEEP = MODE == 10 || MODE == 13;
@@ -2072,25 +2081,57 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
 #ifdef SX_EXP_NOSIDE
                     srow = nullptr;     // timing experiment: no factor stores (gradients wrong)
 #endif
-                    // ONE arm per step kind: a coupling whose conditioner sits in the high tiles (c0 = 2) swaps the halves of x and of
-                    // the adjoint in registers (64 v_swap) before its A step and back after its B step; the adjoint half of a dense
-                    // layer (c0 = 4) swaps x <-> adjoint around the step.  (With one template arm per (kind, c0) pair the register
-                    // allocator merged six versions of the 128-register state: 848 B of scratch per lane.)
                     auto swap_tiles = [&](int a, int b) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) { const float t_ = xs[a].v[0][r]; xs[a].v[0][r] = xs[b].v[0][r]; xs[b].v[0][r] = t_; }
                     };
+                    // Both halves of a layer run inside ONE loop iteration (the host plans them back to back and the launcher checks
+                    // it): the ring advance of the loop head in the middle of the arm.  As separate iterations, r and dL/d(ls, sh) of
+                    // a coupling were loop-carried state (a `keep` array beside xs) that had to survive the dense-layer arm, and the
+                    // adjoint half of a dense layer ran on swapped registers: each arm fits the register file on its own, the three
+                    // together took 548 B of scratch per lane -- and every scratch reload is a vector-memory operation that waits,
+                    // in order, behind all factor stores issued before it (1.5 of the kernel's 3.0 ms).
+                    // the state's home at the head of every iteration is the VGPR file: without it the allocator gives the arms
+                    // different homes for parts of xs and pays the difference in scratch (116 B; 433 registers and none with it)
+#pragma unroll
+                    for (int t = 0; t < TX; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(xs[t].v[0][r]));
+                    dstep stb;
+                    wptr wb_ = w;
+                    float *srow_b = nullptr;
+                    auto second_half = [&]() {
+                        cur ^= 1;
+                        ++s;
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __syncthreads();
+                        stb = st_next;
+                        if ((s + 1 < n_steps || has_next_chunk) && dma_floats) stage_blob<WB>(k.blobs + dma_off, (cur ^ 1) * buf_floats, dma_floats);
+                        const int nb = (s + 1 < n_steps) ? s + 1 : 0, nb2 = (nb + 1 < n_steps) ? nb + 1 : 0;
+                        st_next = prog.steps[nb];
+                        dma_off = prog.steps[nb2].blob_off;
+                        dma_floats = prog.steps[nb2].blob_floats;
+                        wb_ = make_wptr(cur * buf_floats, lane);
+                        srow_b = row[0] < n_rows ? k.side + ((int64_t)stb.tt * ((n_rows + 31) >> 5) + (row[0] >> 5)) * (k.side_width * 32) + (row[0] & 31) : nullptr;
+#ifdef SX_EXP_NOSIDE
+                        srow_b = nullptr;
+#endif
+                    };
                     if (st.kind == SX_STEP_COUPLING_AFFINE_BWD_A) {
+                        // a coupling whose conditioner sits in the high tiles (c0 = 2) swaps the halves of x and of the adjoint in
+                        // registers (64 v_swap) before step A and back after step B
                         const float gg = k.row_t[lrow[0]];
-                        if (st.c0 != 0) { swap_tiles(0, 2); swap_tiles(1, 3); swap_tiles(4, 6); swap_tiles(5, 7); }
-                        coupling_affine_bwd_a<4, HT, 0, 2, 2, 2>(xs, w, gg, srow, lane, rg, bkeep);
-                    } else if (st.kind == SX_STEP_COUPLING_AFFINE_BWD_B) {
-                        coupling_affine_bwd_b<4, HT, 0, 2, 2, 2>(xs, w, srow, lane, rg, bkeep);
-                        if (st.c0 != 0) { swap_tiles(0, 2); swap_tiles(1, 3); swap_tiles(4, 6); swap_tiles(5, 7); }
+                        const bool high = st.c0 != 0;
+                        if (high) { swap_tiles(0, 2); swap_tiles(1, 3); swap_tiles(4, 6); swap_tiles(5, 7); }
+                        tile<1> keep[HT + 4];
+                        coupling_affine_bwd_a<4, HT, 0, 2, 2, 2>(xs, w, gg, srow, lane, rg, keep);
+                        second_half();
+                        coupling_affine_bwd_b<4, HT, 0, 2, 2, 2>(xs, wb_, srow_b, lane, rg, keep);
+                        if (high) { swap_tiles(0, 2); swap_tiles(1, 3); swap_tiles(4, 6); swap_tiles(5, 7); }
                     } else if (st.kind == SX_STEP_LINEAR_BWD) {
-                        if (st.c0 != 0) { swap_tiles(0, 4); swap_tiles(1, 5); swap_tiles(2, 6); swap_tiles(3, 7); }
-                        linear_bwd_half<4, 0>(xs, w, srow, 32 * st.t0, st.reverse != 0, lane, rg);
-                        if (st.c0 != 0) { swap_tiles(0, 4); swap_tiles(1, 5); swap_tiles(2, 6); swap_tiles(3, 7); }
+                        linear_bwd_half<4, 0>(xs, w, srow, 32 * st.t0, st.reverse != 0, lane, rg);          // x tiles: v = M u + b
+                        second_half();
+                        linear_bwd_half<4, 4>(xs, wb_, srow_b, 32 * stb.t0, stb.reverse != 0, lane, rg);    // adjoint tiles: W^T dL/du
                     }
                 }
             } else
@@ -2414,11 +2455,12 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                                 }
                             }
                         } else {
+                            int cidx[16];                  // all indices first: one wait instead of one per element
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int c = k.out_col[32 * t + sx_kmap(r, h)];
-                                if (c >= 0) st_elem(k.y, row[n] * dim + c, xs[ts].v[n][r], bf16);
-                            }
+                            for (int r = 0; r < 16; ++r) cidx[r] = k.out_col[32 * t + sx_kmap(r, h)];
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                if (cidx[r] >= 0) st_elem(k.y, row[n] * dim + cidx[r], xs[ts].v[n][r], bf16);
                         }
                     }
                 }
