@@ -2609,6 +2609,10 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
         }                                                                                                      \
         hipLaunchKernelGGL(kern, dim3(a.grid), dim3(64 * SX_BLOCK_WAVES(TX, MD)), a.lds, a.stream, a.prog, k);                         \
     } while (0)
+#ifdef SX_ONLY_MODE      // resource / ISA studies of one variant (tools/rescheck.sh TX HT -DSX_ONLY_MODE=11): seconds instead of minutes
+    if (a.mlp_mode == SX_ONLY_MODE) SX_FL(SX_ONLY_MODE);
+    else { sx_set_error("built with SX_ONLY_MODE"); return SX_E_UNSUPPORTED; }
+#else
     if constexpr (TX == 8) {            // 4 data + 4 adjoint tiles: the training backward of 128-column flows only
         if (a.mlp_mode == 4) SX_FL(4);
         else { sx_set_error("sx_flow_run: 8 state tiles are the backward program's (mode %d)", a.mlp_mode); return SX_E_UNSUPPORTED; }
@@ -2634,6 +2638,7 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
         { sx_set_error("sx_flow_bwd_run: needs 4 state tiles, hidden <= 64 and the fp16 x 3 arithmetic"); return SX_E_UNSUPPORTED; }
     }
     else SX_FL(0);
+#endif
 #undef SX_FL
     SX_LAUNCH_CHECK();
 #ifdef SX_DEBUG_KNOBS

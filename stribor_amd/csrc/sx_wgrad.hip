@@ -131,14 +131,30 @@ __global__ __launch_bounds__(64 * WB) void wgrad_kernel(const float *__restrict_
     const int64_t w_id = (int64_t)blockIdx.x * WB + wave;
     const int64_t n_groups = (n_rows + 31) >> 5;
     // features past m_valid / n_valid and rows past n_rows are masked after the turn (lane i = feature)
+    // fp16 x 3 form: the tiles of a wave's NEXT group are requested as soon as the current ones have been split (their
+    // registers are free from then on), so the loads fly under the current group's MFMAs -- with 128 .. 256 accumulator
+    // registers a SIMD holds one or two waves, and load -> wait -> compute in turn left HBM idle two thirds of the time
+    // (128 x 128 outputs: 256 accumulator registers; the last two B tiles of a group are loaded at its start instead)
+    constexpr int PFB = MT * NT == 16 ? 2 : NT;
+    f32x4 a[MT][4], b[NT][4];
+    if constexpr (F16) {
+        const bool first = w_id < n_groups;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) load_tile(A + w_id * lda + m * 1024, first, lane, a[m]);
+#pragma unroll
+        for (int n = 0; n < PFB; ++n) load_tile(B + w_id * ldb + n * 1024, first, lane, b[n]);
+    }
     for (int64_t g = w_id; g < n_groups; g += n_waves) {
-        f32x4 a[MT][4], b[NT][4];
         const int64_t rem = n_rows - 32 * g;
+        [[maybe_unused]] const int64_t gn = g + n_waves;
+        [[maybe_unused]] const bool more = gn < n_groups;
         if constexpr (GROUPS) {
+            if constexpr (!F16) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) load_tile(A + g * lda + m * 1024, true, lane, a[m]);
+                for (int m = 0; m < MT; ++m) load_tile(A + g * lda + m * 1024, true, lane, a[m]);
+            }
 #pragma unroll
-            for (int n = 0; n < NT; ++n) load_tile(B + g * ldb + n * 1024, true, lane, b[n]);
+            for (int n = F16 ? PFB : 0; n < NT; ++n) load_tile(B + g * ldb + n * 1024, true, lane, b[n]);
             const int left = (rem < 32 ? (int)rem : 32) - 16 * kk;      // valid rows among this lane's 16
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -199,12 +215,16 @@ __global__ __launch_bounds__(64 * WB) void wgrad_kernel(const float *__restrict_
         if constexpr (F16) {
             wg_split bs[NT];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) bs[n] = wg_make(b[n]);
+            for (int n = 0; n < NT; ++n) {
+                bs[n] = wg_make(b[n]);
+                if (n < PFB) load_tile(B + gn * ldb + n * 1024, more, lane, b[n]);
+            }
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) bsum[m] += (a[m][q][0] + a[m][q][1]) + (a[m][q][2] + a[m][q][3]);
                 const wg_split as = wg_make(a[m]);
+                load_tile(A + gn * lda + m * 1024, more, lane, a[m]);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) wg_contract(as, bs[n], acc[m][n]);
             }
@@ -350,7 +370,8 @@ extern "C" int sx_wgrad(const float *A, int64_t lda, int32_t M, const float *B, 
     // waves per workgroup by register budget (accumulators = 16 * MT * NT VGPRs); 256 workgroups fill the CUs
 #define SX_WG_L(MT_, NT_, GR_)                                                                                      \
     {                                                                                                              \
-        constexpr int WB = MT_ * NT_ <= 2 ? 16 : (MT_ * NT_ <= 8 ? 8 : 4);                                         \
+        constexpr int WB = GR_ == 3 ? ((MT_ * NT_ <= 4 && MT_ + NT_ <= 4) ? 8 : 4)                                   \
+                                    : (MT_ * NT_ <= 2 ? 16 : (MT_ * NT_ <= 8 ? 8 : 4));                            \
         constexpr int GMAX = 256;                                                                                  \
         int64_t g = (n_rows + 32 * WB - 1) / (32 * WB);                                                            \
         if (g > GMAX) g = GMAX;                                                                                    \
