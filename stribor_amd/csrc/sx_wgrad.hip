@@ -25,6 +25,7 @@ constexpr int PATCH = 32 * 36;       // one 32-feature x 32-row tile, feature ro
 // (scaled into fp16's range, range-tracked by the kernel that wrote them), so the batch contraction can run on the matrix pipe as
 // well: a lane's 16 rows of a feature split hi + lo (hi = rtz(v), lo = rtz(v - hi)), two 16-row steps of
 // v_mfma_f32_32x32x16_f16 with three products each -- 6 MFMAs x 32 cycles per tile pair and 32 rows instead of 16 x 64.
+typedef __attribute__((address_space(3))) void lds_void;
 typedef _Float16 wg_h8 __attribute__((ext_vector_type(8)));
 typedef uint32_t wg_u4 __attribute__((ext_vector_type(4)));
 struct wg_split { wg_h8 hi[2], lo[2]; };
@@ -57,6 +58,9 @@ __device__ __forceinline__ void wg_contract(const wg_split &a, const wg_split &b
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi[s], b.hi[s], acc, 0, 0, 0);
     }
 }
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // coalesced global -> registers: instr q, lane L holds feature 8q + (L >> 3), rows 4 (L & 7) .. + 3 of the tile
 __device__ __forceinline__ void load_tile(const float *tile_base, bool ok, int lane, f32x4 (&v)[4]) {
@@ -106,13 +110,25 @@ __global__ __launch_bounds__(64 * WB) void wgrad_kernel(const float *__restrict_
     constexpr int M32 = 32 * MT, N32 = 32 * NT;
     constexpr int RED = M32 * N32 + M32;
     constexpr bool GROUPS = LAYOUT == 1 || LAYOUT == 3, VEC_ROWS = LAYOUT == 2, F16 = LAYOUT == 3;
-    constexpr int LDS_FLOATS = (GROUPS || VEC_ROWS) ? (RED > WB * PATCH ? RED : WB * PATCH) : RED;
+    // fp16 x 3 form: the next group's tiles come by LDS-DMA while the current group's MFMAs run (MT + NT tiles of 4 KB per
+    // wave; no patch, no register staging -- 256 accumulator registers of a 128 x 128 output leave no room for one).
+    // All vector-memory traffic of the loop is then LDS-DMA with COUNTED waits: beside an LDS-DMA in flight the compiler
+    // waits vmcnt(0) for any ordinary load, i.e. it would drain the prefetch at the first use of a tile.
+    constexpr bool DMA_B = F16;
+    constexpr int STAGE = DMA_B ? WB * (MT + NT) * 1024 : WB * PATCH;
+    // epilogue: the waves' accumulator tiles meet in LDS in C-FRAGMENT order (one ds_write_b128 per four registers), in as many
+    // separate regions as fit (NREG): the first NREG waves only write, later turns add in place, the last pass sums the regions
+    constexpr int FRAG = MT * NT * 1024;
+    constexpr int NREG = WB * FRAG <= 34816 ? WB : (2 * FRAG <= 34816 ? 2 : 1);          // 136 KB of tiles at most
+    constexpr int EPI = NREG * FRAG + WB * M32;                                            // + the waves' bias sums
+    constexpr int LDS_FLOATS = ((GROUPS || VEC_ROWS) && STAGE > EPI) ? STAGE : EPI;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     A += 128 * blockIdx.y;
     const int m_valid = m_total - 128 * (int)blockIdx.y;                 // >= M32 for all but the last slab
     part += (int64_t)blockIdx.y * gridDim.x * RED;
-    float *red = lds;                                   // the tile sum reuses the patches after the row loop
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wave index through readfirstlane: group indices and tile base pointers are then provably wave-uniform -- scalar
+    //  registers and scalar-base loads instead of a 64-bit address pair per lane and tile)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, kk = lane >> 5;
     [[maybe_unused]] float *patch = lds + wave * PATCH;
     f32x16 acc[MT][NT];
@@ -134,15 +150,39 @@ __global__ __launch_bounds__(64 * WB) void wgrad_kernel(const float *__restrict_
     // fp16 x 3 form: the tiles of a wave's NEXT group are requested as soon as the current ones have been split (their
     // registers are free from then on), so the loads fly under the current group's MFMAs -- with 128 .. 256 accumulator
     // registers a SIMD holds one or two waves, and load -> wait -> compute in turn left HBM idle two thirds of the time
-    // (128 x 128 outputs: 256 accumulator registers; the last two B tiles of a group are loaded at its start instead)
-    constexpr int PFB = MT * NT == 16 ? 2 : NT;
+    constexpr int PFB = DMA_B ? 0 : NT;
     f32x4 a[MT][4], b[NT][4];
+    // LDS-DMA of a B tile: lane L of instruction q fills 16-byte slot 64 q + L of the tile's 4 KB -- and FETCHES the chunk that
+    // belongs there: (feature f, 4-row chunk rc) lives in slot 8 f + ((rc + f) & 7).  The rotation makes the turned read
+    // (lane = feature, its 16 rows = 4 chunks) conflict-free: eight neighbouring features hit eight different 16-byte columns.
+    [[maybe_unused]] float *aland = lds + wave * ((MT + NT) * 1024), *bland = aland + MT * 1024;     // wave-uniform (m0)
+    [[maybe_unused]] auto issue_tile = [&](const float *gtile, float *ltile) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int f = 8 * q + (lane >> 3), rc = ((lane & 7) - f) & 7;
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(gtile + f * 32 + rc * 4), (lds_void *)(ltile + q * 256), 16, 0, 0);
+        }
+    };
+    // the turned read: lane (feature i, half kk) takes rows 16 kk .. 16 kk + 15 of its feature = chunks 4 kk .. 4 kk + 3
+    [[maybe_unused]] auto read_tile = [&](const float *ltile, f32x4 (&v)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4 *>(ltile + i * 32 + (((4 * kk + q) + i) & 7) * 4);
+    };
     if constexpr (F16) {
         const bool first = w_id < n_groups;
+        if constexpr (DMA_B) {
+            if (first) {            // B tiles first, then A, as in the loop (the counted waits below rely on the order)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) load_tile(A + w_id * lda + m * 1024, first, lane, a[m]);
+                for (int n = 0; n < NT; ++n) issue_tile(B + w_id * ldb + n * 1024, bland + n * 1024);
 #pragma unroll
-        for (int n = 0; n < PFB; ++n) load_tile(B + w_id * ldb + n * 1024, first, lane, b[n]);
+                for (int m = 0; m < MT; ++m) issue_tile(A + w_id * lda + m * 1024, aland + m * 1024);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) load_tile(A + w_id * lda + m * 1024, first, lane, a[m]);
+#pragma unroll
+            for (int n = 0; n < PFB; ++n) load_tile(B + w_id * ldb + n * 1024, first, lane, b[n]);
+        }
     }
     for (int64_t g = w_id; g < n_groups; g += n_waves) {
         const int64_t rem = n_rows - 32 * g;
@@ -153,21 +193,36 @@ __global__ __launch_bounds__(64 * WB) void wgrad_kernel(const float *__restrict_
 #pragma unroll
                 for (int m = 0; m < MT; ++m) load_tile(A + g * lda + m * 1024, true, lane, a[m]);
             }
+            if constexpr (!DMA_B) {
 #pragma unroll
-            for (int n = F16 ? PFB : 0; n < NT; ++n) load_tile(B + g * ldb + n * 1024, true, lane, b[n]);
+                for (int n = F16 ? PFB : 0; n < NT; ++n) load_tile(B + g * ldb + n * 1024, true, lane, b[n]);
+            } else {
+                // this group's B tiles have landed: vector-memory operations retire in order, and the only younger ones are the
+                // 4 MT DMAs of this group's A tiles (each is waited for where the m loop reads it)
+                wait_vm<4 * MT>();
+            }
             const int left = (rem < 32 ? (int)rem : 32) - 16 * kk;      // valid rows among this lane's 16
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
+            // (fp16 x 3 form: an A tile is turned right before its split, in the m loop below -- the tile requested last is then
+            //  also needed last, a whole iteration later)
+            auto turn_a = [&](int m) {
                 turn_tile(patch, lane, a[m]);
                 const bool f_ok = 32 * m + i < m_valid;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) a[m][q][c] = (f_ok && 4 * q + c < left) ? a[m][q][c] : 0.f;
+            };
+            if constexpr (!F16) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) turn_a(m);
             }
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                turn_tile(patch, lane, b[n]);
+                if constexpr (DMA_B) {
+                    read_tile(bland + n * 1024, b[n]);
+                } else {
+                    turn_tile(patch, lane, b[n]);
+                }
                 const bool f_ok = 32 * n + i < n_valid;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -219,12 +274,44 @@ __global__ __launch_bounds__(64 * WB) void wgrad_kernel(const float *__restrict_
                 bs[n] = wg_make(b[n]);
                 if (n < PFB) load_tile(B + gn * ldb + n * 1024, more, lane, b[n]);
             }
+            if constexpr (DMA_B) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // every read of the landing tiles has returned
+                if (more) {
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) issue_tile(B + gn * ldb + n * 1024, bland + n * 1024);
+                }
+            }
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
+                if constexpr (GROUPS) {
+                    const int left = (rem < 32 ? (int)rem : 32) - 16 * kk;
+                    if constexpr (DMA_B) {
+                        // tile m of this group: younger operations are the rest of this group's A tiles, the next group's B tiles
+                        // and the next group's A tiles issued so far -- 4 (MT - 1 + NT) in the steady state, 4 (MT - 1 - m) in a wave's last group
+                        if (more) wait_vm<4 * (MT - 1) + 4 * NT>();
+                        else if (m == 0) wait_vm<4 * (MT - 1)>();
+                        else if (m == 1) wait_vm<(MT > 2 ? 4 * (MT - 2) : 0)>();
+                        else if (m == 2) wait_vm<(MT > 3 ? 4 * (MT - 3) : 0)>();
+                        else wait_vm<0>();
+                        read_tile(aland + m * 1024, a[m]);
+                    } else {
+                        turn_tile(patch, lane, a[m]);
+                    }
+                    const bool f_ok = 32 * m + i < m_valid;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) a[m][q][c] = (f_ok && 4 * q + c < left) ? a[m][q][c] : 0.f;
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) bsum[m] += (a[m][q][0] + a[m][q][1]) + (a[m][q][2] + a[m][q][3]);
                 const wg_split as = wg_make(a[m]);
-                load_tile(A + gn * lda + m * 1024, more, lane, a[m]);
+                if constexpr (DMA_B) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (more) issue_tile(A + gn * lda + m * 1024, aland + m * 1024);
+                } else {
+                    load_tile(A + gn * lda + m * 1024, more, lane, a[m]);
+                }
 #pragma unroll
                 for (int n = 0; n < NT; ++n) wg_contract(as, bs[n], acc[m][n]);
             }
@@ -242,31 +329,52 @@ __global__ __launch_bounds__(64 * WB) void wgrad_kernel(const float *__restrict_
                 }
         }
     }
-    __syncthreads();                                    // every wave is done with its patch
-    // C layout: lane (col j = lane&31, half) holds rows kmap(r, half).  The waves take turns adding their tiles to
-    // the LDS copy with plain read-add-write (ds_add_f32 serialises its lanes: 64 of them per wave cost 40 us).
-    for (int w = 0; w < WB; ++w) {
-        if (wave == w) {
+    __syncthreads();                                    // every wave is done with its patch / landing tiles
+    // C layout: lane (col j = lane & 31, half kk) holds rows kmap(r, kk) of a tile in register r; four registers = one 16-byte
+    // LDS slot [tile][r / 4][lane].  (Round 2 added element by element, one wave after the other: read - add - write round trips
+    // of 4 bytes per lane, 37 us of a 128 x 128 launch regardless of the row count.)
+    {
+        float *reg = lds + (wave % NREG) * FRAG;
+        for (int turn = 0; turn < WB / NREG; ++turn) {
+            if (wave / NREG == turn) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+                for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
+                    for (int n = 0; n < NT; ++n)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int e = (32 * m + (r & 3) + 8 * (r >> 2) + 4 * kk) * N32 + 32 * n + i;
-                        red[e] = (w == 0 ? 0.f : red[e]) + acc[m][n][r];
-                    }
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const float t = bsum[m] + __shfl_xor(bsum[m], 32, 64);
-                const int e = M32 * N32 + 32 * m + i;
-                if (kk == 0) red[e] = (w == 0 ? 0.f : red[e]) + t;
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4 *slot = reinterpret_cast<f32x4 *>(reg + (m * NT + n) * 1024 + g * 256 + lane * 4);
+                            f32x4 v = {acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
+                            if (turn > 0) { const f32x4 o = *slot; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                            *slot = v;
+                        }
             }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const float t = bsum[m] + __shfl_xor(bsum[m], 32, 64);
+            if (kk == 0) lds[NREG * FRAG + wave * M32 + 32 * m + i] = t;
         }
         __syncthreads();
     }
     float *dst = part + (int64_t)blockIdx.x * (M32 * N32 + M32);
-    for (int e = threadIdx.x; e < M32 * N32 + M32; e += 64 * WB) dst[e] = red[e];
+    for (int e = threadIdx.x; e < M32 * N32; e += 64 * WB) {
+        const int row = e / N32, col = e - row * N32;
+        const int m = row >> 5, rr = row & 31, n = col >> 5, j = col & 31;
+        const int hk = (rr >> 2) & 1, r = (rr & 3) + 4 * (rr >> 3);               // rr = (r & 3) + 8 (r >> 2) + 4 hk
+        const int f = (m * NT + n) * 1024 + (r >> 2) * 256 + (j + 32 * hk) * 4 + (r & 3);
+        float v = lds[f];
+#pragma unroll
+        for (int q = 1; q < NREG; ++q) v += lds[q * FRAG + f];
+        dst[e] = v;
+    }
+    for (int e = threadIdx.x; e < M32; e += 64 * WB) {
+        float v = lds[NREG * FRAG + e];
+#pragma unroll
+        for (int q = 1; q < WB; ++q) v += lds[NREG * FRAG + q * M32 + e];
+        dst[M32 * N32 + e] = v;
+    }
 }
 
 // dW[rm(row)][cm(col)] += sum_p part[p][row * N32 + col]; db[rm(row)] += sum_p part[p][M32 * N32 + row], with

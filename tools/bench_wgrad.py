@@ -1,43 +1,38 @@
-"""Times sx_wgrad on the shapes the cfg-2 backward uses (224 features per row, 32-row groups): prints us per call
-and the HBM rate of the operand features it reads.  Run on an MI355X."""
-import os
-import sys
+"""Timing of sx_wgrad (fp16 x 3 row-group layout) on the cfg-4 training shapes: (M, Nc) = (128, 128) dense layers,
+(128, 64) dW2 and (64, 64) dW1 of a coupling, group stride 320 features as in the backward program's side buffer."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from stribor_amd import _hip
 
-
-def time_call(fn, iters=50):
-    for _ in range(5):
-        fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e3
-
-
-def main():
-    lib = _hip.lib()
-    dev = torch.device('cuda:0')
-    width = 224
-    for n in (1 << 14, 1 << 16, 1 << 18, 1 << 20):
-        side = torch.randn((n + 31) // 32, width, 32, device=dev)
-        for (M, Nc, a0, b0) in ((64, 64, 160, 32), (64, 32, 96, 0), (128, 64, 96, 32), (128, 128, 0, 96)):
-            dW = torch.zeros(M, Nc, device=dev)
-            db = torch.zeros(M, device=dev)
-            A, B = side[0, a0], side[0, b0]                     # feature a0 / b0 of group 0; ld = floats per group
-
-            def fn():
-                _hip.check(lib.sx_wgrad(A.data_ptr(), width * 32, M, B.data_ptr(), width * 32, Nc, n, _hip.WGRAD_ROW_GROUPS, dW.data_ptr(), Nc,
-                                        db.data_ptr(), None, None, _hip.scratch(dev, lib.sx_wgrad_scratch_floats(M, Nc, _hip.WGRAD_ROW_GROUPS)).data_ptr(), _hip.stream()), 'sx_wgrad')
-            us = time_call(fn)
-            gb = n * (M + Nc) * 4 / 1e9
-            print(f'n={n:8d} M={M:3d} Nc={Nc:3d}: {us:8.1f} us  {gb / (us * 1e-6) / 1e3:6.2f} TB/s (operand features)')
-
-
-if __name__ == '__main__':
-    main()
+dev = 'cuda'
+lib = _hip.lib()
+width = 320
+for rows in (1 << 14, 1 << 16, 1 << 18, 1 << 20):
+    ng = (rows + 31) // 32
+    side = torch.randn(ng, width, 32, device=dev) * 0.1
+    ld = width * 32
+    for M, Nc, offA, offB in ((128, 128, 0, 128), (128, 64, 192, 64), (64, 64, 128, 0)):
+        dW = torch.zeros(M, Nc, device=dev)
+        db = torch.zeros(M, device=dev)
+        sc = _hip.scratch(dev, lib.sx_wgrad_scratch_floats(M, Nc, _hip.WGRAD_ROW_GROUPS))
+        p0 = side.data_ptr()
+        def run():
+            _hip.check(lib.sx_wgrad(p0 + 128 * offA, ld, M, p0 + 128 * offB, ld, Nc, rows, _hip.WGRAD_ROW_GROUPS_F16X3, dW.data_ptr(),
+                                    dW.stride(0), db.data_ptr(), None, None, sc.data_ptr(), _hip.stream()), 'sx_wgrad')
+        for _ in range(3):
+            run()
+        dW.zero_(); run()
+        A = side[:, offA:offA + M, :].permute(0, 2, 1).reshape(-1, M)[:rows].double()
+        Bm = side[:, offB:offB + Nc, :].permute(0, 2, 1).reshape(-1, Nc)[:rows].double()
+        want = A.T @ Bm
+        err = ((dW.double() - want).abs().max() / want.abs().max()).item()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        mb = rows * (M + Nc) * 4 / 1e6
+        print(f'rows 2^{rows.bit_length() - 1} {M:3d} x {Nc:3d}: {us:7.1f} us (both kernels), {mb / us * 1e-6 * 1e6 / 1e6 * 1e3:6.2f} GB/ms = {mb / us / 1e3:5.2f} TB/s, rel err {err:.1e}')
