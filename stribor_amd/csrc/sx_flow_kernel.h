@@ -1775,6 +1775,22 @@ __device__ __forceinline__ void st_elem(void *p, int64_t off, float v, int bf16)
     else reinterpret_cast<float *>(p)[off] = v;
 }
 
+// A step descriptor out of the kernarg segment, as DWORDS: the eight byte-sized fields of dstep otherwise come through vector
+// byte loads (no scalar sub-dword load on gfx9) -- and a vector load's s_waitcnt vmcnt(0) right behind the next step's
+// LDS-DMA issue waits for that DMA and for every store still in flight (vector-memory operations retire in order).
+__device__ __forceinline__ dstep load_step(const dprog &prog, int idx) {
+    static_assert(sizeof(dstep) == 28, "dstep layout");
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(&prog.steps[idx]);
+    const uint32_t w0 = p[0], w1 = p[1];
+    dstep s;
+    s.kind = (uint8_t)(w0 & 0xffu); s.c0 = (uint8_t)((w0 >> 8) & 0xffu); s.ct = (uint8_t)((w0 >> 16) & 0xffu); s.t0 = (uint8_t)(w0 >> 24);
+    s.tt = (uint8_t)(w1 & 0xffu); s.reverse = (uint8_t)((w1 >> 8) & 0xffu); s.act = (uint8_t)((w1 >> 16) & 0xffu); s.pad = (uint8_t)(w1 >> 24);
+    s.blob_off = p[2]; s.blob_floats = p[3];
+    s.ldj_scale = __builtin_bit_cast(float, p[4]); s.ldj_const = __builtin_bit_cast(float, p[5]);
+    s.mask = p[6];
+    return s;
+}
+
 struct flow_kargs {     // everything but the program, by value in the kernarg segment
     const float *blobs; const void *x; const float *latent; const int32_t *in_col; const int32_t *out_col;
     void *y; float *ldj_out; float *logp_out; double *sum_out; float *mlp_out; const float *row_t; float *side;
@@ -1818,7 +1834,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
     }
     // prologue: first step's weights into buffer 0, first step's descriptor into registers
     int cur = 0;
-    dstep st_next = prog.steps[0];
+    dstep st_next = load_step(prog, 0);
     if ((int64_t)blockIdx.x < n_chunks && n_steps > 0 && st_next.blob_floats)
         stage_blob<WB>(k.blobs + st_next.blob_off, 0, st_next.blob_floats);
     // the DMA fields of the step after next are fetched a step early, so the refill below never waits on a scalar load
@@ -1861,6 +1877,16 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
             lrow[n] = row[n] < n_rows ? row[n] : n_rows - 1;      // clamp loads, mask stores
         }
 
+        // MODE 4 on 4 + 4 tiles: the row's dL/dlog_prob once per chunk (a load inside the step loop is waited for with vmcnt(0):
+        // behind the weight DMA just issued and every factor store in flight), and whether this wave stores factors at all
+        [[maybe_unused]] float gg_chunk = 0.f;
+        [[maybe_unused]] bool stores_young = false;
+        if constexpr (MODE == 4 && TX == 8 && NS == 1) {
+            gg_chunk = k.row_t[lrow[0]];
+#ifndef SX_EXP_NOSIDE
+            stores_young = k.side != nullptr && __builtin_amdgcn_readfirstlane((int)(row[0] - j < n_rows)) != 0;
+#endif
+        }
         // ---- load the state tiles in C-fragment order ---------------------------------------------------
         tile<NS> xs[TX];
         bool from_frag = false;
@@ -2002,7 +2028,14 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
             //     the barrier makes every wave's pieces visible AND guarantees all waves left step s-1,
             //     i.e. nobody still reads buffer cur^1;
             if (!SX_DBG(2)) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if constexpr (MODE == 4 && TX == 8) {
+                    // the weights (LDS-DMA issued one half-step ago) are OLDER than the >= 64 factor stores of that half-step:
+                    // a counted wait leaves the stores in flight (vector-memory operations retire in order)
+                    if (s > 0 && stores_young) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 if (dyn && s == 0 && threadIdx.x == 0) slot[iter & 1] = ticket;
                 __syncthreads();
                 if (dyn && s == 0) next_chunk = (int64_t)gridDim.x + __builtin_amdgcn_readfirstlane(slot[iter & 1]);
@@ -2028,7 +2061,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                 }
             }
             const int nxt = (s + 1 < n_steps) ? s + 1 : 0, nxt2 = (nxt + 1 < n_steps) ? nxt + 1 : 0;
-            st_next = prog.steps[nxt];
+            st_next = load_step(prog, nxt);
             dma_off = prog.steps[nxt2].blob_off;
             dma_floats = prog.steps[nxt2].blob_floats;
 
@@ -2103,12 +2136,16 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     auto second_half = [&]() {
                         cur ^= 1;
                         ++s;
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __syncthreads();
+                        if (stores_young) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        // (the raw barrier: __syncthreads()'s fence drains the vector-memory counter while the compiler believes an
+                        //  LDS-DMA to be in flight -- the one issued at the head of this iteration, waited for just above)
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
                         stb = st_next;
                         if ((s + 1 < n_steps || has_next_chunk) && dma_floats) stage_blob<WB>(k.blobs + dma_off, (cur ^ 1) * buf_floats, dma_floats);
                         const int nb = (s + 1 < n_steps) ? s + 1 : 0, nb2 = (nb + 1 < n_steps) ? nb + 1 : 0;
-                        st_next = prog.steps[nb];
+                        st_next = load_step(prog, nb);
                         dma_off = prog.steps[nb2].blob_off;
                         dma_floats = prog.steps[nb2].blob_floats;
                         wb_ = make_wptr(cur * buf_floats, lane);
@@ -2120,7 +2157,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     if (st.kind == SX_STEP_COUPLING_AFFINE_BWD_A) {
                         // a coupling whose conditioner sits in the high tiles (c0 = 2) swaps the halves of x and of the adjoint in
                         // registers (64 v_swap) before step A and back after step B
-                        const float gg = k.row_t[lrow[0]];
+                        const float gg = gg_chunk;
                         const bool high = st.c0 != 0;
                         if (high) { swap_tiles(0, 2); swap_tiles(1, 3); swap_tiles(4, 6); swap_tiles(5, 7); }
                         tile<1> keep[HT + 4];
