@@ -1862,6 +1862,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
     const int pf_base = buf_floats;                           // floats; WB * 4096 floats behind buffer 0
     lds_u32 *slot = (lds_u32 *)(smem + (resident ? buf_floats + WB * 4096 : 2 * buf_floats));      // ds_write_b32 / ds_read_b32, ordered by the barrier
     [[maybe_unused]] bool have_pf = false;
+    [[maybe_unused]] float gg_next = 0.f;                     // MODE 11: dL/dlog_prob of the prefetched chunk's row
     int iter = 0;
     for (int64_t chunk = blockIdx.x; chunk < n_chunks; ++iter) {
         // lane-derived indices are re-derived per chunk from the thread id (opaque to the optimizer) instead of
@@ -1890,11 +1891,15 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
         // ---- load the state tiles in C-fragment order ---------------------------------------------------
         tile<NS> xs[TX];
         bool from_frag = false;
+        [[maybe_unused]] float gg11 = 0.f;
         if constexpr (MODE == 11) {
             from_frag = k.frag_in != nullptr;
+            // (a row's dL/dlog_prob travels with its prefetched state: an ordinary load inside the step would be waited for with
+            //  vmcnt(0) -- behind the LDS-DMA just issued for the next chunk)
+            gg11 = (from_frag && have_pf) ? gg_next : k.row_t[lrow[0]];
             if (from_frag && have_pf) {
-                // this chunk's state was prefetched into the wave's landing zone during the previous chunk
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // this chunk's state was prefetched into the wave's landing zone during the previous chunk, and waited for at
+                // the END of that chunk, before its stores: a wait here would sit behind those stores (in-order retirement)
                 const f32x4 *fl = reinterpret_cast<const f32x4 *>(smem + pf_base + wave * 4096) + lane;
 #pragma unroll
                 for (int t = 0; t < TX; ++t)
@@ -2027,7 +2032,10 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
             // (1) this step's weights were issued one step ago (or in the prologue): wait for MY pieces, then
             //     the barrier makes every wave's pieces visible AND guarantees all waves left step s-1,
             //     i.e. nobody still reads buffer cur^1;
-            if (!SX_DBG(2)) {
+            // MODE 11 with resident weights and static chunks: after the first chunk a wave needs nothing from the others (weights
+            // are read-only, landing zones private): no wait, no barrier -- the waves of a workgroup drift freely
+            const bool free_run = MODE == 11 && resident && !dyn && iter > 0;
+            if (!SX_DBG(2) && !free_run) {
                 if constexpr (MODE == 4 && TX == 8) {
                     // the weights (LDS-DMA issued one half-step ago) are OLDER than the >= 64 factor stores of that half-step:
                     // a counted wait leaves the stores in flight (vector-memory operations retire in order)
@@ -2056,6 +2064,8 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
 #pragma unroll
                         for (int i = 0; i < TX * 4; ++i)
                             __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(gsrc + i * 1024), (lds_void *)(ldst + i * 1024), 16, 0, 0);
+                        const int64_t nrow = ngrp * 32 + (lane & 31);
+                        gg_next = k.row_t[nrow < n_rows ? nrow : n_rows - 1];
                         have_pf = true;
                     }
                 }
@@ -2076,7 +2086,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
             } else if constexpr (MODE == 11) {
 #ifdef SX_F16X3
                 if constexpr (TX == 4 && NS == 1 && HT <= 2) {
-                    const float gg = k.row_t[lrow[0]];
+                    const float gg = gg11;
                     const bool live = row[0] < n_rows;
                     // static accumulator slots (the host keeps a MODE 11 program to SX_BWD_SLOTS steps)
                     if (SX_BWD_SLOTS == 1 || s == 0) {
@@ -2434,6 +2444,12 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
             if (st.kind != SX_STEP_ROW_SCALE_EXP && st.kind != SX_STEP_POINTWISE) ldj_c += st.ldj_const;      // (those two keep a parameter there)
             if (!resident) cur ^= 1;
             SX_STAMP(pf, 6);     // step tail
+        }
+        if constexpr (MODE == 11) {
+            // E: the next chunk's state (LDS-DMA) and dL/dlog_prob were requested a whole step ago: waiting for them HERE, in
+            // front of this chunk's stores, costs nothing; the stores then drain under the next chunk's arithmetic.  (The
+            // "+v" operand makes the compiler's own wait for gg_next land here too, not behind the stores.)
+            if (have_pf) asm volatile("s_waitcnt vmcnt(0)" : "+v"(gg_next) : : "memory");
         }
 
         // ---- epilogue: outputs -----------------------------------------------------------------------------
