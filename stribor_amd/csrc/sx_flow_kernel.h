@@ -2053,6 +2053,11 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
             // (2) refill buffer cur^1 with the next step's weights (the DMA flies under this step's MFMAs)
             //     and fetch the next step's descriptor one step early.
             const dstep st = st_next;
+            // this step's LDS read offsets are formed BEFORE the DMA goes out (the empty asm pins them there): in the variants that
+            // keep lane-derived values in scratch, a reload behind the DMA is a vector-memory load whose s_waitcnt vmcnt(0)
+            // waits for the DMA itself -- the refill then no longer flies under the step's arithmetic
+            int wb_off = cur * buf_floats * 4 + lane * 16, cb_off = cur * buf_floats * 4 + (lane >> 5) * 64;
+            asm volatile("" : "+v"(wb_off), "+v"(cb_off));
             if ((s + 1 < n_steps || has_next_chunk) && dma_floats && !SX_DBG(1) && !resident)
                 stage_blob<WB>(k.blobs + dma_off, (cur ^ 1) * buf_floats, dma_floats);
             if constexpr (MODE == 11) {
@@ -2075,7 +2080,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
             dma_off = prog.steps[nxt2].blob_off;
             dma_floats = prog.steps[nxt2].blob_floats;
 
-            const wptr w = make_wptr(cur * buf_floats, lane);
+            const wptr w = wptr{reinterpret_cast<const char *>(smem) + wb_off, reinterpret_cast<const char *>(smem) + cb_off};
             SX_STAMP(pf, 2);     // descriptor + DMA issue
             if constexpr (MODE == 5 || MODE == 6) {
                 // pure split-coupling programs (host: validate_and_convert): two straight-line arms, state in place

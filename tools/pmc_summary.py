@@ -86,6 +86,20 @@ def main(d, commit, build_id=None):
             for c in ('SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_ACTIVE_INST_LDS', 'SQ_ACTIVE_INST_SCA'):
                 if c in a and 'SQ_WAVE_CYCLES' in a:
                     sq[c.lower() + '_frac_of_wave_cycles'] = a[c] / a['SQ_WAVE_CYCLES']
+        if 'SQ_INSTS_VALU_FMA_F32' in a and 'SQ_INSTS_VALU' in a:
+            # VALU instruction mix per wave and layer (a wave = 32 rows; bench.py launches 2^20 rows; cfg 2 / 3: 8 layers, cfg 4: 16):
+            # the classes are the SQ counters'; `other` = SQ_INSTS_VALU minus the named classes and the MFMAs: moves, selects,
+            # compares, min / max, bit operations.  cfg 3: a lane evaluates 16 spline elements per layer.
+            wl = (1 << 20) / 32 * {'cfg2': 8, 'cfg3': 8, 'cfg4': 16}[cfg]
+            named = ['SQ_INSTS_VALU_ADD_F32', 'SQ_INSTS_VALU_MUL_F32', 'SQ_INSTS_VALU_FMA_F32', 'SQ_INSTS_VALU_TRANS_F32', 'SQ_INSTS_VALU_CVT',
+                     'SQ_INSTS_VALU_INT32', 'SQ_INSTS_VALU_INT64']
+            mix = {c[len('SQ_INSTS_VALU_'):].lower(): a.get(c, 0.0) / wl for c in named}
+            mix['mfma'] = a.get('SQ_INSTS_MFMA', 0.0) / wl
+            mix['other'] = (a['SQ_INSTS_VALU'] - sum(a.get(c, 0.0) for c in named) - a.get('SQ_INSTS_MFMA', 0.0)) / wl
+            mix['valu_total'] = a['SQ_INSTS_VALU'] / wl
+            mix['salu'] = a.get('SQ_INSTS_SALU', 0.0) / wl
+            mix['lds'] = a.get('SQ_INSTS_LDS', 0.0) / wl
+            sq['valu_mix_per_wave_layer'] = {k_: round(v, 1) for k_, v in mix.items()}
         json.dump(sq, open(os.path.join(d, 'sq_%s.json' % cfg), 'w'), indent=1)
         out[cfg] = {'traffic': (t or {}).get('hbm_bytes_per_launch'),
                     'sq': {k: v for k, v in sq.items() if k not in ('counters_avg_per_launch',)}}
