@@ -1896,19 +1896,26 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
             from_frag = k.frag_in != nullptr;
             // (a row's dL/dlog_prob travels with its prefetched state: an ordinary load inside the step would be waited for with
             //  vmcnt(0) -- behind the LDS-DMA just issued for the next chunk)
-            gg11 = (from_frag && have_pf) ? gg_next : k.row_t[lrow[0]];
-            if (from_frag && have_pf) {
+            gg11 = have_pf ? gg_next : k.row_t[lrow[0]];
+            if (have_pf) {
                 // this chunk's state was prefetched into the wave's landing zone during the previous chunk, and waited for at
-                // the END of that chunk, before its stores: a wait here would sit behind those stores (in-order retirement)
+                // the END of that chunk, before its stores: a wait here would sit behind those stores (in-order retirement).
+                // First launch (z, row-major): the x tiles only; the adjoint tiles start at -g z as below.
                 const f32x4 *fl = reinterpret_cast<const f32x4 *>(smem + pf_base + wave * 4096) + lane;
 #pragma unroll
                 for (int t = 0; t < TX; ++t)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const f32x4 v = fl[(t * 4 + q) * 64];
-                        xs[t].v[0][4 * q + 0] = v.x; xs[t].v[0][4 * q + 1] = v.y;
-                        xs[t].v[0][4 * q + 2] = v.z; xs[t].v[0][4 * q + 3] = v.w;
+                        if (t < TX / 2 || from_frag) {
+                            const f32x4 v = fl[(t * 4 + q) * 64];
+                            xs[t].v[0][4 * q + 0] = v.x; xs[t].v[0][4 * q + 1] = v.y;
+                            xs[t].v[0][4 * q + 2] = v.z; xs[t].v[0][4 * q + 3] = v.w;
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) xs[t].v[0][4 * q + c] = -gg11 * xs[t - TX / 2].v[0][4 * q + c];
+                        }
                     }
+                from_frag = true;            // (= the state is loaded: skip the row-major loads below)
             } else if (from_frag) {
                 // fragment-order state of the previous launch: [32-row group][tile][q][lane] float4 (1 KB per instruction)
                 const int64_t n_grp = (n_rows + 31) >> 5;
@@ -2071,6 +2078,21 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                             __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(gsrc + i * 1024), (lds_void *)(ldst + i * 1024), 16, 0, 0);
                         const int64_t nrow = ngrp * 32 + (lane & 31);
                         gg_next = k.row_t[nrow < n_rows ? nrow : n_rows - 1];
+                        have_pf = true;
+                    }
+                } else if (resident && s == 0 && k.frag_in == nullptr && has_next_chunk && dim == 32 * (TX / 2)) {
+                    // first launch: the next chunk's rows of z (row-major, whole tiles) into the same landing order -- an LDS-DMA lane
+                    // fetches from any address: lane (row j, half h) of piece (t, q) takes columns 32 t + 8 q + 4 h .. + 3 of its row
+                    const int64_t ngrp = next_chunk * WB + wave;
+                    if (ngrp < ((n_rows + 31) >> 5)) {       // wave-uniform
+                        const int64_t nrow = ngrp * 32 + (lane & 31), nr = nrow < n_rows ? nrow : n_rows - 1;
+                        const char *gsrc = reinterpret_cast<const char *>(reinterpret_cast<const float *>(k.x) + nr * dim + 4 * (lane >> 5));
+                        char *ldst = reinterpret_cast<char *>(smem + pf_base + wave * 4096);
+#pragma unroll
+                        for (int i = 0; i < (TX / 2) * 4; ++i)
+                            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(gsrc + ((i >> 2) * 32 + (i & 3) * 8) * 4),
+                                                             (lds_void *)(ldst + i * 1024), 16, 0, 0);
+                        gg_next = k.row_t[nr];
                         have_pf = true;
                     }
                 }
