@@ -571,7 +571,10 @@ def test_neural_flow_forward_is_differentiable():
 
 @pytest.mark.parametrize('n,M,Nc,width,a0,b0', [(1, 64, 64, 224, 160, 32), (1000, 50, 33, 224, 96, 0),
                                                 (4097, 128, 128, 256, 0, 128), (77, 96, 40, 224, 32, 128),
-                                                (100003, 64, 32, 224, 96, 0)])
+                                                (100003, 64, 32, 224, 96, 0),
+                                                # several groups per wave: the steady state of the LDS-DMA prefetch and its counted
+                                                # waits (fp16 x 3 form), 128 x 128 / 128 x 64 / 96 x 128 outputs
+                                                (70001, 128, 128, 256, 0, 128), (70001, 128, 64, 320, 192, 64), (66000, 96, 128, 320, 0, 160)])
 @pytest.mark.parametrize('f16', [False, True])
 def test_wgrad_contracts_row_groups_with_maps(n, M, Nc, width, a0, b0, f16):
     """sx_wgrad on its own: feature-major 32-row groups (garbage in the ragged tail), feature counts that are not
