@@ -498,6 +498,63 @@ __global__ __launch_bounds__(256, 2) void rqs_slab_l1_bwd_kernel(const l1_args k
         const int jc = row_ok ? j : n_here - 1;
         // ---- da = (sum of the groups' dh partials) (1 - h^2), C-fragment tiles (hidden x samples) ---------------------------------
         btile<1> bga[HT];
+        if (k.n_groups <= 8) {
+            // up to eight groups (cfg 3: exactly eight): the 4 HT batches of a chunk -- one 16-byte piece of every group's partial
+            // plus the matching piece of h -- are software-pipelined: batch b + 1 is requested before batch b is summed, so two
+            // batches (16 KB per wave) are always in flight instead of one with a full drain in between (the kernel is a stream
+            // of 64 KB per chunk; 0.196 -> see DESIGN.md 4.3.1)
+            // GROUP-major: a group's partial tile of this chunk is 4 HT KB contiguous -- a half-batch is four of its 1 KB pieces
+            // (one DRAM-friendly run instead of one piece from each of eight tiles 64 MB apart), summed into 4 HT running pieces;
+            // the next half-batch is requested before the current one is added (no drain between them)
+            constexpr int NP = 4 * HT;                         // 16-byte pieces per lane and group tile
+            f32x4 v[2][4], sum[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) sum[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float *src0 = k.part + (size_t)c * HT * 1024 + lane * 4;
+            auto issue = [&](int hb, f32x4 (&vv)[4]) {          // hb = p * (NP / 4) + quarter
+                const int p = hb / (NP / 4), q0 = 4 * (hb % (NP / 4));
+                const float *src = src0 + (size_t)(p < k.n_groups ? p : k.n_groups - 1) * gstride;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) vv[qq] = *reinterpret_cast<const f32x4 *>(src + (q0 + qq) * 256);
+            };
+            constexpr int NHB = 8 * (NP / 4);
+            issue(0, v[0]);
+#pragma unroll
+            for (int hb = 0; hb < NHB; ++hb) {
+                if (hb + 1 < NHB) issue(hb + 1, v[(hb + 1) & 1]);
+                const int p = hb / (NP / 4), q0 = 4 * (hb % (NP / 4));
+                if (p < k.n_groups) {
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        sum[q0 + qq].x += v[hb & 1][qq].x; sum[q0 + qq].y += v[hb & 1][qq].y;
+                        sum[q0 + qq].z += v[hb & 1][qq].z; sum[q0 + qq].w += v[hb & 1][qq].w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < HT; ++m) {
+                tile<1> ga;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int f0 = 32 * m + 8 * g + 4 * hh;
+                    const float *hp = k.h + (row0 + jc) * k.ld_h + f0;
+                    f32x4 hv = {0.f, 0.f, 0.f, 0.f};
+                    if (vec) hv = *reinterpret_cast<const f32x4 *>(hp);
+                    else {
+                        if (f0 + 0 < k.H) hv.x = hp[0];
+                        if (f0 + 1 < k.H) hv.y = hp[1];
+                        if (f0 + 2 < k.H) hv.z = hp[2];
+                        if (f0 + 3 < k.H) hv.w = hp[3];
+                    }
+                    const f32x4 sm = sum[4 * m + g];
+                    ga.v[0][4 * g + 0] = row_ok ? sm.x * (1.f - hv.x * hv.x) : 0.f;
+                    ga.v[0][4 * g + 1] = row_ok ? sm.y * (1.f - hv.y * hv.y) : 0.f;
+                    ga.v[0][4 * g + 2] = row_ok ? sm.z * (1.f - hv.z * hv.z) : 0.f;
+                    ga.v[0][4 * g + 3] = row_ok ? sm.w * (1.f - hv.w * hv.w) : 0.f;
+                }
+                bga[m] = make_btile<1>(ga, rg);
+            }
+        } else
 #pragma unroll
         for (int m = 0; m < HT; ++m) {
             tile<1> ga;
