@@ -100,11 +100,9 @@ def _lu_inverse_multi(pairs):
     for idx in by_dim.values():
         stack = torch.cat([t for i in idx for t in (pairs[i][1].transpose(-1, -2), pairs[i][0])])
         X = TriInverse.apply(stack, True, False)
-        o = 0
-        for i in idx:
-            k = pairs[i][0].shape[0]
-            out[i] = X[o:o + k].transpose(-1, -2) @ X[o + k:o + 2 * k]
-            o += 2 * k
+        parts = X.split([pairs[i][0].shape[0] for i in idx for _ in (0, 1)])        # (one cat in the backward, not a zero-fill per slice)
+        for n, i in enumerate(idx):
+            out[i] = parts[2 * n].transpose(-1, -2) @ parts[2 * n + 1]
     return out
 
 
@@ -151,8 +149,10 @@ def derive_dense_batched(layers, dev, reverse: bool = True):
                 Wm = (L @ U).transpose(-1, -2).to(torch.float32).contiguous()                  # y = x (L U) + b (:157)
                 bm = b.to(torch.float32)
                 ldj = ld.sum(-1).to(torch.float32)
-            for i, f in enumerate(fs):
-                out[id(f)] = (Wm[i], bm[i], ldj[i])
+            # (unbind, not [i]: the backward of k selects is k zero-filled [k, D, D] tensors and k copies -- 40 launches per cfg-4
+            #  step; UnbindBackward stacks the pieces once)
+            for f, Wi, bi, li in zip(fs, Wm.unbind(0), bm.unbind(0), ldj.unbind(0)):
+                out[id(f)] = (Wi, bi, li)
         else:
             dg = third
             tkey = (tuple(f._t_eff(1.0) for f in fs), str(dev))
@@ -167,8 +167,9 @@ def derive_dense_batched(layers, dev, reverse: bool = True):
             if key[2]:
                 bias = torch.stack([f.bias for f in fs]).to(dev, torch.float64)
                 bm = (-(M @ bias.unsqueeze(-1)).squeeze(-1)).to(torch.float32) if reverse else bias.to(torch.float32)
-            for i, f in enumerate(fs):
-                out[id(f)] = (Wm[i], bm[i] if key[2] else None, ldj[i])
+            bms = bm.unbind(0) if key[2] else [None] * len(fs)
+            for f, Wi, bi, li in zip(fs, Wm.unbind(0), bms, ldj.unbind(0)):
+                out[id(f)] = (Wi, bi, li)
     return out
 
 
