@@ -324,7 +324,11 @@ int sx_pack_linear(const float *W, const float *b, int32_t out_dim, int32_t in_d
                                          * hidden-unit chunk of a conditioner wider than the hidden tiles)                             */
 #define SX_STEP_ROW_SCALE_EXP        9  /* blob = diag[tiles][2][16]: state *= exp(+-diag * t_row); t_row = row_t[n] or ldj_const;
                                            act != 0 applies log1p|t| (affine.py:239-240)                                          */
-#define SX_STEP_RQS_HIDDEN          10  /* blob = pack_linear(W1, folded tanh): hidden of a spline coupling, kept for its phases    */
+#define SX_STEP_RQS_HIDDEN          10  /* blob = pack_linear(W1, folded tanh): hidden of a spline coupling, kept for its phases.
+                                         * pad_ bits 8..15 = the layer's ordinal L among the program's spline couplings: with mlp_out given the
+                                         * step writes tanh h to rows [L n_rows, (L + 1) n_rows) of mlp_out, and with `side` given (programs
+                                         * without a backward step) the state it received to rows [(L - 1) n_rows, L n_rows) of `side`
+                                         * ([., dim] fp32, L >= 1): the saved tensors of a layer-by-layer backward from one forward launch */
 #define SX_STEP_RQS_PHASE           11  /* one (8-column group, parameter block) slab of a rational-quadratic spline coupling:
                                            blob = pack_linear(W2 rows, 4 m-tiles) ++ {lo, hi} (phases 0 and 1: rows and bias
                                            times log2(e) -- the kernel's softmax runs in base 2); t0 = tile, c0 = group 0..3,

@@ -134,8 +134,9 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
                 const bool low = T >= 2 && s.c0 == 0 && s.ct == T / 2;
                 const bool high = T >= 2 && s.c0 == T / 2 && s.ct == T / 2;
                 const bool dense = s.c0 == 0 && s.ct == T;
-                SX_REQUIRE(s.pad_ == 1 || low || high || dense, "sx_flow_run: step %d: RQS conditioner tiles must be low/high halves or dense", i);
-                need = sx_packed_linear_floats(p->h_tiles, s.pad_ == 1 ? p->h_tiles : s.ct); rqs = true; break;
+                const bool deep = (s.pad_ & 0xff) == 1;          // (bits 8..15 of pad_: the layer's ordinal, see SX_STEP_RQS_HIDDEN)
+                SX_REQUIRE(deep || low || high || dense, "sx_flow_run: step %d: RQS conditioner tiles must be low/high halves or dense", i);
+                need = sx_packed_linear_floats(p->h_tiles, deep ? p->h_tiles : s.ct); rqs = true; break;
             }
             case SX_STEP_RQS_PHASE:
                 SX_REQUIRE(s.t0 < p->x_tiles && s.c0 >= 0 && s.c0 < 4 && s.ct >= 0 && s.ct < 3 && s.tt >= 1 && s.tt <= 16,
@@ -150,7 +151,7 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
         dstep &o = d->steps[i];
         o.kind = (uint8_t)s.kind; o.c0 = (uint8_t)s.c0; o.ct = (uint8_t)s.ct; o.t0 = (uint8_t)s.t0; o.tt = (uint8_t)s.tt;
         o.reverse = (uint8_t)(s.reverse != 0); o.act = (uint8_t)s.act;
-        o.pad = (uint8_t)(s.kind == SX_STEP_RQS_HIDDEN && s.pad_ == 1);      // deep conditioner: source = kept hidden state
+        o.pad = (uint8_t)(s.kind == SX_STEP_RQS_HIDDEN && (s.pad_ & 0xff) == 1);      // deep conditioner: source = kept hidden state
         o.blob_off = s.blob_off; o.blob_floats = s.blob_floats; o.ldj_scale = s.ldj_scale; o.ldj_const = s.ldj_const;
         o.mask = (uint32_t)s.pad_;
     }

@@ -2413,13 +2413,35 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                         for (int m = 0; m < HT; ++m) rq_bh[m] = make_btile<1>(hd[m]);
                         // optional side output for the training backward (sx_rqs_slab_bwd keeps the conditioner's last hidden
                         // activation): tanh h = 1 - 2 r, row-major [n_rows, mlp_out_dim] -- instead of a library GEMM + tanh
+                        // (bits 8..15 of the step's mask = the layer's ordinal among the program's spline couplings: a whole-flow program
+                        //  leaves one [n_rows, H] block per layer, and -- `side` given -- the state each layer but the first received,
+                        //  row-major [n_rows, dim] blocks: what the per-layer training backward needs from ONE forward launch)
+                        const int slot = (int)((st.mask >> 8) & 0xffu);
+                        if (k.side != nullptr && slot > 0 && row[0] < n_rows) {
+                            float *so = k.side + ((int64_t)(slot - 1) * n_rows + row[0]) * dim;
+#pragma unroll
+                            for (int t = 0; t < TX; ++t)
+                                if (t < x_tiles) {
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) {
+                                        const int c = 32 * t + 8 * q + 4 * h;
+                                        const f32x4 sv = {xs[t].v[0][4 * q], xs[t].v[0][4 * q + 1], xs[t].v[0][4 * q + 2], xs[t].v[0][4 * q + 3]};
+                                        if (c + 3 < dim && (dim & 3) == 0) *reinterpret_cast<f32x4 *>(so + c) = sv;
+                                        else {
+#pragma unroll
+                                            for (int e = 0; e < 4; ++e)
+                                                if (c + e < dim) so[c + e] = sv[e];
+                                        }
+                                    }
+                                }
+                        }
                         if (k.mlp_out != nullptr && row[0] < n_rows) {
 #pragma unroll
                             for (int m = 0; m < HT; ++m)
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) {
                                     const int c = 32 * m + 8 * q + 4 * h;
-                                    float *o = k.mlp_out + row[0] * k.mlp_out_stride + c;
+                                    float *o = k.mlp_out + ((int64_t)slot * n_rows + row[0]) * k.mlp_out_stride + c;
                                     const f32x4 tv = {1.f - 2.f * hd[m].v[0][4 * q], 1.f - 2.f * hd[m].v[0][4 * q + 1],
                                                       1.f - 2.f * hd[m].v[0][4 * q + 2], 1.f - 2.f * hd[m].v[0][4 * q + 3]};
                                     if (c + 3 < k.mlp_out_dim && (k.mlp_out_stride & 3) == 0) *reinterpret_cast<f32x4 *>(o) = tv;

@@ -484,7 +484,17 @@ class NormalizingFlow(Transform):
         timed = [] if t is None else [f for f in self.transforms if isinstance(f, MatrixExponential)]
         dense = derive_dense_batched([f for f in self.transforms if f not in timed], x2.device, reverse)   # batched fp64 ops
         cur, total = x2, None
-        for f in (reversed(self.transforms) if reverse else self.transforms):
+        pre = self._spline_forward_once(x2) if (reverse and lat2 is None and t is None) else None
+        for li, f in enumerate(reversed(self.transforms) if reverse else self.transforms):
+            if pre is not None:
+                # (the whole flow already ran as one launch: each layer's op takes its saved tensors from it and launches nothing)
+                f._pre = pre[li]
+                try:
+                    cur, ldj = f._autograd_inverse(cur, None)
+                finally:
+                    f._pre = None
+                total = ldj if total is None else total + ldj
+                continue
             if isinstance(f, _ColumnShuffle) and not f._feature_only():
                 # Flip over other axes moves whole rows (permute.py:35,38): torch.flip on the unflattened state, which is
                 # differentiable and its own inverse -- NOT the column reversal f._perm describes
@@ -517,6 +527,38 @@ class NormalizingFlow(Transform):
         if total is None:
             total = torch.zeros(cur.shape[0], dtype=torch.float32, device=cur.device)
         return cur, total, lead
+
+    def _spline_forward_once(self, x2):
+        """Training forward of a flow of spline couplings as ONE launch: the whole-flow fused program (the one inference uses) with
+        side outputs -- tanh h of every layer's conditioner and the state every layer but the first received -- instead of one
+        program launch per layer.  -> per layer, in evaluation order, (output rows, log-det share, tanh h), or None when the flow
+        is not of that kind.  (The log-det is additive: the last layer carries the flow's whole sum, the others zeros -- every
+        layer's op still receives dL/dlog-det, which is all its backward needs.)"""
+        from .flows.coupling import Coupling
+        if os.environ.get('STRIBOR_SPLINE_FORWARD_PER_LAYER') == '1' or x2.dtype != torch.float32 or x2.shape[0] == 0:
+            return None
+        fs = list(reversed(self.transforms))
+        n, d = x2.shape
+        if not fs or not all(isinstance(f, Coupling) and f._slab_l1_ok(d) for f in fs):
+            return None
+        Hs = {f.transform.latent_net.linears()[0][0].shape[0] for f in fs}
+        if len(Hs) != 1:
+            return None
+        prog = self._fused_program(True, d, 0, x2.device)
+        if prog is None or not prog.prog.identity_cols or prog.prog.pad_:
+            return None
+        steps = [prog.prog.steps[i] for i in range(prog.prog.n_steps)]
+        hidden = [s_ for s_ in steps if s_.kind == _hip.STEP_RQS_HIDDEN]
+        if len(hidden) != len(fs) or [(s_.pad_ >> 8) & 0xff for s_ in hidden] != list(range(len(fs))) \
+                or any(s_.kind not in (_hip.STEP_RQS_HIDDEN, _hip.STEP_RQS_PHASE) for s_ in steps):
+            return None
+        H, L = Hs.pop(), len(fs)
+        hbuf = torch.empty(L * n, H, dtype=torch.float32, device=x2.device)
+        side = torch.empty(max(L - 1, 1) * n, d, dtype=torch.float32, device=x2.device)
+        with torch.no_grad():
+            y, ldj, _ = prog.run(x2.contiguous(), None, True, True, False, mlp_out=hbuf, side=side if L > 1 else None)
+        zeros = torch.zeros(max(L - 1, 1), n, dtype=torch.float32, device=x2.device)      # (one tensor OBJECT per op output)
+        return [(side[l * n:(l + 1) * n] if l < L - 1 else y, ldj if l == L - 1 else zeros[l], hbuf[l * n:(l + 1) * n]) for l in range(L)]
 
     def _log_prob_layerwise_autograd(self, y, latent=None, t=None):
         """log_prob with a graph for spline-coupling / conditional / mixed flows (the layer-wise training path)."""

@@ -438,6 +438,20 @@ class Coupling(Transform):
         lin = net.linears()
         return len(lin) >= 2 and lin[-1][1] is not None and RQSCouplingSlab.eligible(lin[-1][0].shape[1], sp.n_bins)
 
+    def _slab_l1_ok(self, d: int) -> bool:
+        """Does log_prob's graph path run this layer through RQSCouplingSlabL1 (Linear - Tanh - Linear conditioner without a latent
+        input)?  NormalizingFlow._layerwise_autograd uses it to decide on the one-launch forward."""
+        from .spline import RQSCouplingSlabL1, Spline
+        sp = self.transform
+        net = getattr(sp, 'latent_net', None)
+        if self.set_data or not isinstance(sp, Spline) or net is None or not self._slab_backward_ok(net, sp):
+            return False
+        if os.environ.get('STRIBOR_SPLINE_L1_TORCH') == '1' or d < 2 or not np.any(self.mask_vector(d) <= 0.5):
+            return False
+        lin = net.linears()
+        return (len(lin) == 2 and net.activation_name == 'Tanh' and lin[0][1] is not None and lin[0][0].shape[1] == d
+                and RQSCouplingSlabL1.eligible(d, lin[-1][0].shape[1], sp.n_bins))
+
     def _inverse_rows_nograd(self, x2, lat2, h_out=None):
         """inverse_and_log_det_jacobian of [N, D] fp32 rows without a graph: the one-layer fused program when the conditioner
         fits it (parameters never in HBM), else the MLP program + spline kernel.  h_out [N, H] (optional): receives the
@@ -485,12 +499,15 @@ class Coupling(Transform):
         plan = self._programs.get(('slab', d, H, cubic, str(x2.device)), build)
         W2, b2 = SelectRows.apply(lin[-1][0], rows_t), SelectRows.apply(lin[-1][1], rows_t)
         evaluate = lambda xx, h_out=None: self._inverse_rows_nograd(xx, lat2, h_out)
+        evaluate.precomputed, self._pre = getattr(self, '_pre', None), None          # (one-launch forward of a whole spline flow)
         col_mask = mask_t * 0 if d == 1 else mask_t                                  # coupling.py:62-63
         if (lat2 is None and len(lin) == 2 and net.activation_name == 'Tanh' and lin[0][1] is not None
                 and RQSCouplingSlabL1.eligible(d, H, sp.n_bins) and os.environ.get('STRIBOR_SPLINE_L1_TORCH') != '1'):
             # Linear - Tanh - Linear conditioner: the first layer's backward is part of the op too
             return RQSCouplingSlabL1.apply(x2, lin[0][0], lin[0][1], W2, b2, col_mask, evaluate, plan, live_idx, int(live[0]),
                                            len(live), sp.n_bins, sp.lower, sp.upper, cubic)
+        if evaluate.precomputed is not None:
+            raise RuntimeError('stribor_amd: a precomputed forward reached a coupling outside the Linear-Tanh-Linear slab path')
         # conditioner input cat[x * mask, latent] (coupling.py:61-65) with the mask folded into the first layer's weight
         if lat2 is not None:
             col_mask = torch.cat([col_mask, torch.ones(lat2.shape[1], dtype=torch.float32, device=x2.device)])

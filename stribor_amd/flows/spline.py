@@ -233,7 +233,13 @@ class RQSCouplingSlabL1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2, W1, b1, W2, b2, mask_t, evaluate, plan, live_idx, live_start, n_live, n_bins, lower, upper, cubic=False):
         x2 = x2.contiguous()
-        with torch.no_grad():
+        pre = getattr(evaluate, 'precomputed', None)
+        if pre is not None:
+            # the whole flow ran as ONE fused program that left every layer's output, log-det share and tanh h behind
+            # (NormalizingFlow._layerwise_autograd): nothing to launch here, the backward below is the same
+            y, ldj, h = pre
+        else:
+          with torch.no_grad():
             # h = tanh(x (W1 * mask)^T + b1) comes out of the forward program itself (side output of its hidden step) when the
             # coupling runs as one fused program; otherwise one library GEMM + tanh
             h = torch.empty(x2.shape[0], W1.shape[0], dtype=torch.float32, device=x2.device)

@@ -429,6 +429,7 @@ class ProgramBuilder:
         # time-conditioned programs (ContinuousAffineCoupling / NeuralFlow): t and t0 take the `time_slots` (0..2) slots behind the
         # latent columns in the latent tiles; the kernel fills them from row_t / the second time vector
         self.time_slots = time_slots
+        self._spline_layers = 0          # spline couplings added so far (ordinal of the next one's side outputs)
         lat_tiles = _ceil_div(latent_dim + time_slots, 32)
         self.tiles = _round_tiles(max(_ceil_div(dim, 32), min_x_tiles) + lat_tiles, f'dim {dim} + latent {latent_dim}')
         self.x_tiles = self.tiles - lat_tiles
@@ -696,8 +697,10 @@ class ProgramBuilder:
         if not middle:
             off, n = self._alloc(_hip.packed_linear_floats(HT, ct))
             self.jobs.append(_PackJob(W1, b1, hidden_idx(hidden), col_idx, HT, ct, off, sc, sc, 0.0))
-            self.steps.append(dict(kind=_hip.STEP_RQS_HIDDEN, c0=c0, ct=ct, t0=t0, tt=tt, reverse=int(reverse),
-                                   act=_hip.ACT_TANH_FOLDED, blob_off=off, blob_floats=n, ldj_scale=0.0, ldj_const=0.0))
+            step = dict(kind=_hip.STEP_RQS_HIDDEN, c0=c0, ct=ct, t0=t0, tt=tt, reverse=int(reverse),
+                        act=_hip.ACT_TANH_FOLDED, blob_off=off, blob_floats=n, ldj_scale=0.0, ldj_const=0.0)
+            step['pad_'] = self._spline_layers << 8          # the layer's ordinal (side outputs of a whole-flow program)
+            self.steps.append(step)
         else:
             tanh = _hip.ACT_CODES['Tanh']
             off, n = self._alloc(_hip.packed_linear_floats(HT, ct))
@@ -717,7 +720,7 @@ class ProgramBuilder:
             self.jobs.append(_PackJob(WL, bL, hidden_idx(hidden), hidden_idx(prev), HT, HT, off, sc, sc, 0.0))
             step = dict(kind=_hip.STEP_RQS_HIDDEN, c0=0, ct=0, t0=t0, tt=tt, reverse=int(reverse),
                         act=_hip.ACT_TANH_FOLDED, blob_off=off, blob_floats=n, ldj_scale=0.0, ldj_const=0.0)
-            step['pad_'] = 1                  # source = the hidden state kept by the CPL_HIDDEN steps
+            step['pad_'] = 1 | (self._spline_layers << 8)    # 1: source = the hidden state kept by the CPL_HIDDEN steps
             self.steps.append(step)
         col2 = np.full(32 * HT, -1, dtype=np.int64)
         col2[:hidden] = np.arange(hidden)
@@ -760,6 +763,8 @@ class ProgramBuilder:
                                 blob_off=off, blob_floats=n, ldj_scale=s_scale, ldj_const=0.0)
                     step['pad_'] = live_mask - (1 << 32) if live_mask >= (1 << 31) else live_mask
                     self.steps.append(step)
+
+        self._spline_layers += 1
 
     def enable_adjoint_tiles(self) -> None:
         """Backward programs carry dL/dx beside x: tiles [0, x_tiles) = x, [x_tiles, 2 x_tiles) = adjoint."""
