@@ -328,7 +328,9 @@ int sx_pack_linear(const float *W, const float *b, int32_t out_dim, int32_t in_d
                                          * pad_ bits 8..15 = the layer's ordinal L among the program's spline couplings: with mlp_out given the
                                          * step writes tanh h to rows [L n_rows, (L + 1) n_rows) of mlp_out, and with `side` given (programs
                                          * without a backward step) the state it received to rows [(L - 1) n_rows, L n_rows) of `side`
-                                         * ([., dim] fp32, L >= 1): the saved tensors of a layer-by-layer backward from one forward launch */
+                                         * ([., dim] fp32, L >= 1): the saved tensors of a layer-by-layer backward from one forward launch.
+                                         * Side outputs exist for pure spline programs with one hidden layer per conditioner (they run
+                                         * their own kernel instances, so that the inference kernels carry none of that code).            */
 #define SX_STEP_RQS_PHASE           11  /* one (8-column group, parameter block) slab of a rational-quadratic spline coupling:
                                            blob = pack_linear(W2 rows, 4 m-tiles) ++ {lo, hi} (phases 0 and 1: rows and bias
                                            times log2(e) -- the kernel's softmax runs in base 2); t0 = tile, c0 = group 0..3,

@@ -228,6 +228,11 @@ extern "C" int sx_flow_run(const sx_program *prog_host, const float *blobs, cons
     dprog d; int bf; int mlp_mode; int sw;
     int rc = validate_and_convert(prog_host, &d, &bf, &mlp_mode, &sw);
     if (rc) return rc;
+    // pure single-hidden-layer spline programs asked for their side outputs (tanh h, layer states: the training forward) run the
+    // instances that carry that code
+    if ((mlp_out != nullptr || side != nullptr) && (mlp_mode == 3 || mlp_mode == 12)) mlp_mode = mlp_mode == 3 ? 18 : 19;
+    SX_REQUIRE(mlp_out == nullptr || mlp_mode == 1 || mlp_mode == 18 || mlp_mode == 19,
+               "sx_flow_run: mlp_out is the output of MLP programs and the tanh-h side output of pure spline programs with one hidden layer (kernel mode %d has neither)", mlp_mode);
     SX_REQUIRE(x != nullptr && n_rows >= 0, "sx_flow_run: bad x / n_rows");
     SX_REQUIRE(blobs != nullptr || prog_host->n_steps == 0, "sx_flow_run: null blobs");
     SX_REQUIRE(dtype == SX_F32 || dtype == SX_BF16, "sx_flow_run: bad dtype");

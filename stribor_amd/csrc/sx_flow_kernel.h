@@ -1955,7 +1955,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                                     // spline programs (96 steps, 3.2 MB of blobs that every chunk re-reads from L2): x is read once and
                                     // kept out of their way by the streaming policy (cfg 3: FETCH_SIZE 318 -> 154 MKiB per launch, same
                                     // time); elsewhere plain loads (cfg 4 measured 2 % slower with it)
-                                    constexpr bool NT_X = MODE == 3 || MODE == 10 || MODE == 12 || MODE == 13;
+                                    constexpr bool NT_X = MODE == 3 || MODE == 10 || MODE == 12 || MODE == 13 || MODE == 18 || MODE == 19;
                                     if constexpr (NT_X) v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(k.x) + lrow[n] * dim + c));
                                     else v = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(k.x) + lrow[n] * dim + c);
                                 }
@@ -2020,8 +2020,11 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
         tile<NS> hid[MODE == 1 ? HT : 1];
         constexpr bool LIN = MODE == 2 || MODE == 7 || MODE == 8;    // programs with dense linear layers
         tile<NS> hidp[(MODE == 9 || MODE == 14 || MODE == 16 || MODE == 17) ? HT : 1];   // MODE 9 / 14 / 16 / 17: hidden state kept between deep-conditioner steps
-        constexpr bool CUB = MODE == 12 || MODE == 13;    // cubic-spline couplings (13: + deep conditioners)
-        constexpr bool RQ = MODE == 3 || MODE == 10 || CUB;      // spline couplings (10: + deep conditioners)
+        // MODE 18 / 19 = MODE 3 / 12 with the training forward's side outputs (tanh h per layer, the state each layer received):
+        // their own instances, so that the inference kernels carry none of that code (it cost cfg 3 0.7 % when it shared MODE 3)
+        constexpr bool SIDE_OUT = MODE == 18 || MODE == 19;
+        constexpr bool CUB = MODE == 12 || MODE == 13 || MODE == 19;    // cubic-spline couplings (13: + deep conditioners)
+        constexpr bool RQ = MODE == 3 || MODE == 10 || MODE == 18 || CUB;      // spline couplings (10: + deep conditioners)
         constexpr bool RQDEEP = MODE == 10 || MODE == 13;
         // MODE 14: MIXED programs -- affine couplings, spline couplings of either type, point-wise steps and element-wise affines
         // in one launch (the reference's flagship stack, test_normalizing_flow.py:13-35: affine coupling -> Flip -> Sigmoid ->
@@ -2416,8 +2419,11 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                         // (bits 8..15 of the step's mask = the layer's ordinal among the program's spline couplings: a whole-flow program
                         //  leaves one [n_rows, H] block per layer, and -- `side` given -- the state each layer but the first received,
                         //  row-major [n_rows, dim] blocks: what the per-layer training backward needs from ONE forward launch)
-                        const int slot = (int)((st.mask >> 8) & 0xffu);
-                        if (k.side != nullptr && slot > 0 && row[0] < n_rows) {
+                        // (the deep and mixed instances keep the h block they always had -- never requested there, sx_flow_run refuses
+                        //  it, but their register allocation is fragile: MODE 16 ran 7 % slower without it)
+                        if constexpr (SIDE_OUT || MIX || RQDEEP) {
+                        const int slot = SIDE_OUT ? (int)((st.mask >> 8) & 0xffu) : 0;
+                        if (SIDE_OUT && k.side != nullptr && slot > 0 && row[0] < n_rows) {
                             float *so = k.side + ((int64_t)(slot - 1) * n_rows + row[0]) * dim;
 #pragma unroll
                             for (int t = 0; t < TX; ++t)
@@ -2452,6 +2458,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                                     }
                                 }
                         }
+                        }   // SIDE_OUT
                     }
                     break;
                 case SX_STEP_RQS_PHASE:
@@ -2726,6 +2733,8 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
     else if (a.mlp_mode == 9) SX_FL(9);
     else if (a.mlp_mode == 10) SX_FL(10);
     else if (a.mlp_mode == 12) SX_FL(12);
+    else if (a.mlp_mode == 18) SX_FL(18);
+    else if (a.mlp_mode == 19) SX_FL(19);
     else if (a.mlp_mode == 13) SX_FL(13);
     else if (a.mlp_mode == 14) SX_FL(14);
     else if (a.mlp_mode == 15) SX_FL(15);
