@@ -497,17 +497,26 @@ class Coupling(Transform):
             return (torch.from_numpy(slab_slot_rows(len(live), sp.n_bins, cubic)).to(dev), torch.from_numpy(hid).to(dev),
                     torch.from_numpy(cols).to(dev), torch.from_numpy(cmap).to(dev), words)
         plan = self._programs.get(('slab', d, H, cubic, str(x2.device)), build)
-        W2, b2 = SelectRows.apply(lin[-1][0], rows_t), SelectRows.apply(lin[-1][1], rows_t)
         evaluate = lambda xx, h_out=None: self._inverse_rows_nograd(xx, lat2, h_out)
         evaluate.precomputed, self._pre = getattr(self, '_pre', None), None          # (one-launch forward of a whole spline flow)
         col_mask = mask_t * 0 if d == 1 else mask_t                                  # coupling.py:62-63
         if (lat2 is None and len(lin) == 2 and net.activation_name == 'Tanh' and lin[0][1] is not None
                 and RQSCouplingSlabL1.eligible(d, H, sp.n_bins) and os.environ.get('STRIBOR_SPLINE_L1_TORCH') != '1'):
-            # Linear - Tanh - Linear conditioner: the first layer's backward is part of the op too
-            return RQSCouplingSlabL1.apply(x2, lin[0][0], lin[0][1], W2, b2, col_mask, evaluate, plan, live_idx, int(live[0]),
-                                           len(live), sp.n_bins, sp.lower, sp.upper, cubic)
+            # Linear - Tanh - Linear conditioner: the first layer's backward is part of the op too.  The op takes the WHOLE last
+            # layer and a slot map into its rows (no gather of the live parameters' rows on the way in, no zero-fill + scatter of
+            # their gradients on the way out: 4 launches per layer and step)
+            def build_full():
+                rel = slab_slot_rows(len(live), sp.n_bins, cubic)
+                P = sp.params_per_element
+                rows_np = (np.asarray(live)[:, None] * P + np.arange(P)[None, :]).reshape(-1)
+                glob = np.where(rel >= 0, rows_np[np.clip(rel, 0, len(rows_np) - 1)], -1).astype(np.int32)
+                return (torch.from_numpy(glob).to(x2.device),) + tuple(plan[1:]) + (True,)
+            plan_full = self._programs.get(('slab_full', d, H, cubic, str(x2.device)), build_full)
+            return RQSCouplingSlabL1.apply(x2, lin[0][0], lin[0][1], lin[-1][0], lin[-1][1], col_mask, evaluate, plan_full, live_idx,
+                                           int(live[0]), len(live), sp.n_bins, sp.lower, sp.upper, cubic)
         if evaluate.precomputed is not None:
             raise RuntimeError('stribor_amd: a precomputed forward reached a coupling outside the Linear-Tanh-Linear slab path')
+        W2, b2 = SelectRows.apply(lin[-1][0], rows_t), SelectRows.apply(lin[-1][1], rows_t)
         # conditioner input cat[x * mask, latent] (coupling.py:61-65) with the mask folded into the first layer's weight
         if lat2 is not None:
             col_mask = torch.cat([col_mask, torch.ones(lat2.shape[1], dtype=torch.float32, device=x2.device)])

@@ -257,7 +257,9 @@ class RQSCouplingSlabL1(torch.autograd.Function):
     def backward(ctx, gy, gldj):
         import ctypes as C
         x2, h, W1, W2, b2, mask_t, yout = ctx.saved_tensors
-        (slot_rows, hid_idx, col_slots, col_map, cond_words), live_idx, live_start, n_live, n_bins, lower, upper = ctx.meta
+        plan, live_idx, live_start, n_live, n_bins, lower, upper = ctx.meta
+        slot_rows, hid_idx, col_slots, col_map, cond_words = plan[:5]
+        full_w2 = len(plan) > 5 and plan[5]          # W2 / b2 are the conditioner's WHOLE last layer, slot_rows indexes its rows
         n, d = x2.shape
         dev = x2.device
         H = h.shape[1]
@@ -273,7 +275,9 @@ class RQSCouplingSlabL1(torch.autograd.Function):
         _hip.call('sx_pack_linear', x2, W1m.data_ptr(), None, H, d, col_slots.data_ptr(), hid_idx.data_ptr(), xt, ht, None, None,
                   0.0, 1, _hip.GEMM_F16X3, flag, w1t.data_ptr())
         gx = torch.empty_like(gy)           # every column is written: transformed ones by the slab kernel, the rest by the l1 kernel
-        gW2, gb2 = torch.empty_like(W2), torch.empty_like(b2)    # every selected row sits in exactly one slot: all written
+        # every selected row sits in exactly one slot: all written; the whole layer's other rows (parameters of the columns the
+        # coupling leaves alone) have a zero gradient
+        gW2, gb2 = (torch.zeros_like(W2), torch.zeros_like(b2)) if full_w2 else (torch.empty_like(W2), torch.empty_like(b2))
         gW1 = torch.zeros(H, d, dtype=torch.float32, device=dev)
         gb1 = torch.zeros(H, dtype=torch.float32, device=dev)
         n_slab = lib.sx_rqs_slab_scratch_floats(n, n_live, H)
