@@ -287,6 +287,10 @@ def main():
 
         errs, row_err = compare(x, lat)
         note = ''
+        if errs['x'] > tol and x.dim() == 3 and '--sets' not in sys.argv:
+            # a second batch axis without set semantics: rows are independent, classify on the flattened rows
+            x, lat = x.reshape(-1, x.shape[-1]), (None if lat is None else lat.reshape(-1, lat.shape[-1]))
+            errs, row_err = compare(x, lat)
         if errs['x'] > tol and x.dim() == 2:
             suspects = torch.nonzero(row_err > tol).flatten().tolist()
             if 0 < len(suspects) <= 4:
