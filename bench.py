@@ -59,6 +59,8 @@ def spawn_ranks(args) -> int:
            '--gpus', str(args.gpus), '--steps', str(args.steps), '--warmup', str(args.warmup)]
     if args.no_cpu_baseline:
         cmd.append('--no-cpu-baseline')
+    if getattr(args, 'backend', 'nccl') != 'nccl':
+        cmd += ['--backend', args.backend]
     return subprocess.run(cmd, env=env).returncode
 
 
@@ -311,6 +313,11 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra-configs', action='store_true', help='skip the cfg 3 / cfg 4 lines (N = 1)')
     ap.add_argument('--no-training', action='store_true', help='skip the training-step entries (N = 1)')
+    ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl',
+                    help='collective backend of the N > 1 run.  nccl (= RCCL over xGMI) is the product path: one rank per GPU.  gloo '
+                         'exists so that the WHOLE multi-rank control path (rank spawn, rendezvous, the async all-reduce ring, the '
+                         'MAX over ranks of the elapsed time, rank 0\'s line) can run on a box with fewer GPUs than ranks: ranks share '
+                         'GPUs round-robin and the numbers are a plumbing check, not a measurement')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -327,11 +334,18 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dev_index = 0
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    dev = torch.device('cuda', local_rank if world > 1 else 0)
+        if args.backend == 'nccl':
+            dev_index = local_rank
+            torch.cuda.set_device(dev_index)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
+        else:
+            dev_index = local_rank % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(dev_index)
+            dist.init_process_group('gloo')
+    dev = torch.device('cuda', dev_index)
     assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     rccl_ranks = dist.get_world_size() if world > 1 else 1
 
@@ -419,7 +433,9 @@ def main():
             'value': rows_total / elapsed,
             'unit': 'samples/s',
             'n_gpus': world,
-            'rccl_ranks': rccl_ranks,
+            'rccl_ranks': rccl_ranks if args.backend == 'nccl' else 0,
+            'collective_backend': args.backend if world > 1 else None,
+            'collective_ranks': rccl_ranks,
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3,

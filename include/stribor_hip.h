@@ -306,6 +306,14 @@ int sx_pack_linear(const float *W, const float *b, int32_t out_dim, int32_t in_d
                    const int32_t *row_idx, const int32_t *col_idx, int32_t m_tiles, int32_t k_tiles,
                    const float *row_scale, const float *bias_scale, float fold_ones, int32_t transpose,
                    int32_t precision, uint32_t *err_flag, float *dst, void *stream);
+/* The same, and the bound the spline phases' softmax relies on (replaces the running maximum of torch.softmax in
+ * stribor/util/rational_quadratic_spline.py:101-105): *bound_out = max(*bound_out, max over the packed rows of the largest |output|
+ * the row can produce from inputs in [0, 1]^k), i.e. |bias' + sum of the positive (negative) packed weights|.  bound_out: one device
+ * float, zeroed once by the caller; it only grows (a re-pack after a parameter update keeps the larger value: conservative). */
+int sx_pack_linear_bound(const float *W, const float *b, int32_t out_dim, int32_t in_dim,
+                         const int32_t *row_idx, const int32_t *col_idx, int32_t m_tiles, int32_t k_tiles,
+                         const float *row_scale, const float *bias_scale, float fold_ones, int32_t transpose,
+                         int32_t precision, uint32_t *err_flag, float *dst, float *bound_out, void *stream);
 
 /* One step of a fused flow program.  The flow state lives in registers as 32-wide "tiles" of columns (tile t =
  * state slots 32t..32t+31); slots map to columns of x through in_col/out_col.  Field use per kind: */

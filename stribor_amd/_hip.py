@@ -49,7 +49,7 @@ ACT_CODES = {'Identity': 0, 'Tanh': 1, 'ReLU': 2, 'Sigmoid': 3, 'ELU': 4, 'Softp
 # every symbol include/stribor_hip.h declares (tests check that the library exports all of them)
 EXPORTS = ['sx_abi_version', 'sx_fragment_mode', 'sx_last_error', 'sx_build_id', 'sx_absmax2', 'sx_permute', 'sx_affine_coupling', 'sx_rqs_coupling',
            'sx_cubic_coupling', 'sx_pointwise', 'sx_rqs_inverse_bwd', 'sx_rqs_forward_bwd', 'sx_affine_coupling_bwd', 'sx_time_affine_coupling', 'sx_cubic_inverse_bwd', 'sx_cubic_forward_bwd', 'sx_pointwise_bwd',
-           'sx_unit_normal_logprob', 'sx_sum_f64', 'sx_packed_linear_floats', 'sx_pack_linear', 'sx_flow_run',
+           'sx_unit_normal_logprob', 'sx_sum_f64', 'sx_packed_linear_floats', 'sx_pack_linear', 'sx_pack_linear_bound', 'sx_flow_run',
            'sx_flow_launch_info', 'sx_wgrad', 'sx_wgrad_layer', 'sx_colsum', 'sx_tri_inverse_f64',
            'sx_wgrad_scratch_floats', 'sx_wgrad_layer_scratch_floats', 'sx_flow_bwd_max_steps', 'sx_flow_bwd_partials',
            'sx_flow_bwd_run', 'sx_wgrad_reduce', 'sx_rqs_slab_slots', 'sx_rqs_slab_scratch_floats', 'sx_rqs_slab_bwd', 'sx_rqs_slab_l1_scratch_floats', 'sx_rqs_slab_l1_bwd']
@@ -130,6 +130,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.sx_packed_linear_floats.argtypes = [i32, i32]
     lib.sx_pack_linear.restype = i32
     lib.sx_pack_linear.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, f32, i32, i32, vp, vp, vp]
+    lib.sx_pack_linear_bound.restype = i32
+    lib.sx_pack_linear_bound.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, f32, i32, i32, vp, vp, vp, vp]
     lib.sx_flow_run.restype = i32
     lib.sx_flow_run.argtypes = [C.POINTER(sx_program), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, i64, i32, i32, vp, vp, vp]
     lib.sx_wgrad.restype = i32

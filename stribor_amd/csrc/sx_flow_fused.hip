@@ -143,6 +143,14 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
                            "sx_flow_run: step %d: bad RQS phase (tile %d group %d phase %d bins %d)", i, s.t0, s.c0, s.ct, s.tt);
                 SX_REQUIRE(s.act == 0 || s.act == 1, "sx_flow_run: step %d: spline phase kind %d (0 rational-quadratic, 1 cubic)", i, s.act);
                 if (s.act == 1) cub = true; else quadr = true;
+                // the three parameter blocks of a group come back to back (search, select, evaluate): the kernels whose programs hold
+                // spline couplings of one type run a triple inside ONE iteration of their step loop (the group's state is then local to it)
+                SX_REQUIRE(s.ct == 0 ? (i + 2 < p->n_steps && p->steps[i + 1].kind == SX_STEP_RQS_PHASE && p->steps[i + 1].ct == 1 &&
+                                        p->steps[i + 2].kind == SX_STEP_RQS_PHASE && p->steps[i + 2].ct == 2)
+                                     : (i >= s.ct && p->steps[i - s.ct].kind == SX_STEP_RQS_PHASE && p->steps[i - s.ct].ct == 0 &&
+                                        p->steps[i - s.ct].t0 == s.t0 && p->steps[i - s.ct].c0 == s.c0 && p->steps[i - s.ct].tt == s.tt &&
+                                        p->steps[i - s.ct].act == s.act && (p->steps[i - s.ct].reverse != 0) == (s.reverse != 0)),
+                           "sx_flow_run: step %d: spline phases come in triples (blocks 0, 1, 2 of one tile / group / bin count / direction)", i);
                 need = sx_packed_linear_floats(4, p->h_tiles) + 4; rqs = true; break;
             default: sx_set_error("sx_flow_run: step %d has unsupported kind %d", i, s.kind); return SX_E_UNSUPPORTED;
         }

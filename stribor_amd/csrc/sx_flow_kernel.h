@@ -897,6 +897,124 @@ __device__ __forceinline__ void rqs_select16(tile<1> (&acc)[4], rqs_elems &e, fl
     e.c_w[Q] = k_n - k_b;
 }
 #endif
+// ------------------------------------------------------------------------------------------------
+// K = 16, BOUNDED logits (round 4): the lean form of the three phases above.  What changed and why (profiles/sq_cfg3.json: 256 of
+// the 545 vector instructions per element were selects, compares and moves; 256 VGPRs + 68 B of scratch):
+//   * no running maximum.  The softmax is shift-invariant and the shift only guards exp against overflow; the packer leaves a bound
+//     on |logit| of the step's rows behind the spline bounds (sx_pack_linear_bound: |b'| + sum |w'| -- the hidden activations are
+//     tanh's), and below RQS16_BOUND the phases run e_k = exp2(u_k) directly: 8 v_max3 + 16 v_sub per block and the
+//     canonicalising v_max pairs go away.  Above it (never seen with trained conditioners; 2^96 per bin) the KC = 0 sweep with the
+//     maximum runs instead;
+//   * the sums of a group of four bins are formed left to right, so the three partial sums ARE the group's inner prefixes: the knots
+//     inside the found group come from one pick of four prefixes each (12 selects) and one fma each, with the bounds folded into
+//     per-phase constants (knot = c_span_inv * prefix + (k0 + i * span * MIN));
+//   * every select takes named values computed on both sides (a conditional EXPRESSION with arithmetic in an arm is a branch to
+//     the front end: the old code ran s_and_saveexec / s_cbranch_execz diamonds inside the element code), one element at a time
+//     (sched_barrier between elements: four interleaved elements kept 4 x 16 picked values and 24 lane masks alive -- the SGPR
+//     spills of the old form were those masks).
+// Arithmetic: the same knots up to the order of the additions (the reference: cumsum of MIN + (1 - K MIN) softmax, times the span,
+// plus the lower bound, ends pinned -- rational_quadratic_spline.py:180-192).
+// ------------------------------------------------------------------------------------------------
+#define RQS16_BOUND 96.0f
+struct rqs16_c {            // per-phase constants (uniform; one set per phase step, shared by the lane's four elements)
+    float lo, hi;
+    float cs;               // (1 - 16 MIN) (hi - lo)
+    float sm1, sm2, sm3;    // i MIN (hi - lo)
+    float l4, l8, l12;      // lo + 4 j MIN (hi - lo): the group boundaries' constant part
+};
+__device__ __forceinline__ rqs16_c rqs16_consts(float lo, float hi) {
+    rqs16_c c;
+    const float span = hi - lo, sm = RQS_MIN * span;
+    c.lo = lo; c.hi = hi; c.cs = (1.f - 16.f * RQS_MIN) * span;
+    c.sm1 = sm; c.sm2 = 2.f * sm; c.sm3 = 3.f * sm;
+    c.l4 = lo + 4.f * sm; c.l8 = lo + 8.f * sm; c.l12 = lo + 12.f * sm;
+    return c;
+}
+// exp2 of the 16 logits in place, the groups' inner prefixes, the prefix sums of the groups and span (1 - 16 MIN) / sum
+struct rqs16_s {            // (named scalars on purpose: a select between two ARRAY elements is canonicalised into a select of
+    float a1, a2, a3;       //  addresses -- the array then lives in scratch and every pick is a scratch load)
+    float b1, b2, b3;       // group j: e_{4j}+e_{4j+1}, +e_{4j+2}, +e_{4j+3} (= the group's sum)
+    float c1, c2, c3;
+    float d1, d2, d3;
+    float G2, G3;           // g0 + g1, g0 + g1 + g2
+    float sinv;
+};
+#define RQS16_GROUP(J, x1, x2, x3)                                                                                         \
+    {                                                                                                                      \
+        const float e0 = __builtin_amdgcn_exp2f(RQS_P(acc, Q, 4 * J)), e1 = __builtin_amdgcn_exp2f(RQS_P(acc, Q, 4 * J + 1)); \
+        const float e2 = __builtin_amdgcn_exp2f(RQS_P(acc, Q, 4 * J + 2)), e3 = __builtin_amdgcn_exp2f(RQS_P(acc, Q, 4 * J + 3)); \
+        RQS_P(acc, Q, 4 * J) = e0;          /* (only the group's first size is read again: a prefix of one) */             \
+        x1 = e0 + e1; x2 = x1 + e2; x3 = x2 + e3;                                                                          \
+    }
+template <int Q>
+__device__ __forceinline__ rqs16_s rqs16_sums(tile<1> (&acc)[4], const rqs16_c &c) {
+    rqs16_s s;
+    RQS16_GROUP(0, s.a1, s.a2, s.a3)
+    RQS16_GROUP(1, s.b1, s.b2, s.b3)
+    RQS16_GROUP(2, s.c1, s.c2, s.c3)
+    RQS16_GROUP(3, s.d1, s.d2, s.d3)
+    s.G2 = s.a3 + s.b3;
+    s.G3 = s.G2 + s.c3;
+    s.sinv = c.cs * fast_rcp(s.G3 + s.d3);
+    return s;
+}
+// the five knots k0..k4 around the group chosen by the nested masks m1 >= m2 >= m3 (group >= 1, 2, 3)
+// (a function taking VALUES: `c ? a : b` on two lvalues is an lvalue -- the front end selects the ADDRESS and loads through it,
+//  which pins the operands to memory: 128 B of scratch and a scratch load per pick)
+__device__ __forceinline__ float rqs16_pick(bool m1, bool m2, bool m3, float v0, float v1, float v2, float v3) {
+    return m3 ? v3 : (m2 ? v2 : (m1 ? v1 : v0));
+}
+#define RQS16_PICK(m1, m2, m3, v0, v1, v2, v3) rqs16_pick(m1, m2, m3, v0, v1, v2, v3)
+template <int Q>
+__device__ __forceinline__ void rqs16_group_knots(tile<1> (&acc)[4], const rqs16_s &s, const rqs16_c &c, float T1, float T2, float T3,
+                                                   bool m1, bool m2, bool m3, float &k0, float &k1, float &k2, float &k3, float &k4) {
+    const float e_0 = RQS_P(acc, Q, 0), e_4 = RQS_P(acc, Q, 4), e_8 = RQS_P(acc, Q, 8), e_12 = RQS_P(acc, Q, 12);
+    const float p1 = RQS16_PICK(m1, m2, m3, e_0, e_4, e_8, e_12);
+    const float p2 = RQS16_PICK(m1, m2, m3, s.a1, s.b1, s.c1, s.d1);
+    const float p3 = RQS16_PICK(m1, m2, m3, s.a2, s.b2, s.c2, s.d2);
+    const float p4 = RQS16_PICK(m1, m2, m3, s.a3, s.b3, s.c3, s.d3);
+    const float lo_ = c.lo;
+    k0 = RQS16_PICK(m1, m2, m3, lo_, T1, T2, T3);
+    const float k4c = __builtin_fmaf(s.sinv, p4, k0 + c.sm1 * 4.f);
+    k1 = __builtin_fmaf(s.sinv, p1, k0 + c.sm1);
+    k2 = __builtin_fmaf(s.sinv, p2, k0 + c.sm2);
+    k3 = __builtin_fmaf(s.sinv, p3, k0 + c.sm3);
+    const float hi_ = c.hi;
+    k4 = m3 ? hi_ : k4c;                                                // ends pinned (:189-192)
+}
+template <int Q>
+__device__ __forceinline__ void rqs16_search(tile<1> (&acc)[4], rqs_elems &e, const rqs16_c &c) {
+    const float xv = e.x[Q];
+    const bool in = (xv >= c.lo) && (xv <= c.hi);                       // :71 closed interval
+    e.in[Q] = in;
+    const float xin = in ? xv : c.lo;
+    const rqs16_s s = rqs16_sums<Q>(acc, c);
+    // knots at bins 4, 8, 12
+    const float T1 = __builtin_fmaf(s.sinv, s.a3, c.l4), T2 = __builtin_fmaf(s.sinv, s.G2, c.l8), T3 = __builtin_fmaf(s.sinv, s.G3, c.l12);
+    const bool m1 = xin >= T1, m2 = xin >= T2, m3 = xin >= T3;          // a prefix: the knots grow
+    float k0, k1, k2, k3, k4;
+    rqs16_group_knots<Q>(acc, s, c, T1, T2, T3, m1, m2, m3, k0, k1, k2, k3, k4);
+    const bool g1 = xin >= k1, g2 = xin >= k2, g3 = xin >= k3;
+    e.b[Q] = 4 * ((int)m1 + (int)m2 + (int)m3) + ((int)g1 + (int)g2 + (int)g3);
+    const float k_b = g3 ? k3 : (g2 ? k2 : (g1 ? k1 : k0));
+    const float k_n = g3 ? k4 : (g2 ? k3 : (g1 ? k2 : k1));
+    e.a_b[Q] = k_b;
+    e.a_w[Q] = k_n - k_b;
+}
+template <int Q>
+__device__ __forceinline__ void rqs16_select(tile<1> (&acc)[4], rqs_elems &e, const rqs16_c &c) {
+    const rqs16_s s = rqs16_sums<Q>(acc, c);
+    const int b = e.b[Q], bl = b & 3;
+    const float T1 = __builtin_fmaf(s.sinv, s.a3, c.l4), T2 = __builtin_fmaf(s.sinv, s.G2, c.l8), T3 = __builtin_fmaf(s.sinv, s.G3, c.l12);
+    const bool m1 = b >= 4, m2 = b >= 8, m3 = b >= 12;
+    float k0, k1, k2, k3, k4;
+    rqs16_group_knots<Q>(acc, s, c, T1, T2, T3, m1, m2, m3, k0, k1, k2, k3, k4);
+    const bool g1 = bl >= 1, g2 = bl >= 2, g3 = bl >= 3;
+    const float k_b = g3 ? k3 : (g2 ? k2 : (g1 ? k1 : k0));
+    const float k_n = g3 ? k4 : (g2 ? k3 : (g1 ? k2 : k1));
+    e.c_b[Q] = k_b;
+    e.c_w[Q] = k_n - k_b;
+}
 template <int Q, int KC>
 __device__ __forceinline__ void rqs_search(tile<1> (&acc)[4], rqs_elems &e, int K, float lo, float hi) {
 #ifndef SX_RQS_FLAT
@@ -1051,15 +1169,37 @@ __device__ __forceinline__ void rqs_phase_k(tile<1> (&acc)[4], tile<1> (&xs)[TX]
 #pragma unroll
                     for (int q = 0; q < 4; ++q) e.x[q] = xs[t].v[0][4 * gg + q];
                 }
+#if !defined(SX_RQS_FLAT) && !defined(SX_RQS_OLD16)
+        if constexpr (KC == 16) {
+            const rqs16_c c = rqs16_consts(lo, hi);
+            rqs16_search<0>(acc, e, c); __builtin_amdgcn_sched_barrier(0);
+            rqs16_search<1>(acc, e, c); __builtin_amdgcn_sched_barrier(0);
+            rqs16_search<2>(acc, e, c); __builtin_amdgcn_sched_barrier(0);
+            rqs16_search<3>(acc, e, c);
+        } else
+#endif
+        {
         rqs_search<0, KC>(acc, e, K, lo, hi);
         rqs_search<1, KC>(acc, e, K, lo, hi);
         rqs_search<2, KC>(acc, e, K, lo, hi);
         rqs_search<3, KC>(acc, e, K, lo, hi);
+        }
     } else if (st.ct == 1) {
+#if !defined(SX_RQS_FLAT) && !defined(SX_RQS_OLD16)
+        if constexpr (KC == 16) {
+            const rqs16_c c = rqs16_consts(lo, hi);
+            rqs16_select<0>(acc, e, c); __builtin_amdgcn_sched_barrier(0);
+            rqs16_select<1>(acc, e, c); __builtin_amdgcn_sched_barrier(0);
+            rqs16_select<2>(acc, e, c); __builtin_amdgcn_sched_barrier(0);
+            rqs16_select<3>(acc, e, c);
+        } else
+#endif
+        {
         rqs_select<0, KC>(acc, e, K, lo, hi);
         rqs_select<1, KC>(acc, e, K, lo, hi);
         rqs_select<2, KC>(acc, e, K, lo, hi);
         rqs_select<3, KC>(acc, e, K, lo, hi);
+        }
     } else {
         float out[4], lj[4];
         if (st.reverse) {
@@ -1100,8 +1240,119 @@ __device__ __forceinline__ void rqs_phase(tile<1> (&xs)[TX], const btile<1> (&bh
     rqs_gemm<HT>(w, bh, acc);
     const float lo = *reinterpret_cast<const float *>(w.cb - h * 64 + (4 * HT * 1024 + 128) * 4);
     const float hi = *reinterpret_cast<const float *>(w.cb - h * 64 + (4 * HT * 1024 + 129) * 4);
-    if (st.tt == 16) rqs_phase_k<TX, HT, 16>(acc, xs, e, st, lo, hi, ldj, h);
+    // the straight-line K = 16 code needs the step's logits bounded (no running maximum in its softmax: see rqs16_sums); the
+    // packer leaves the bound of the rows it packed behind the spline bounds (the derivative block's slot stays 0)
+    const float bound = *reinterpret_cast<const float *>(w.cb - h * 64 + (4 * HT * 1024 + 130) * 4);
+    const bool lean = __builtin_amdgcn_readfirstlane((int)(bound < RQS16_BOUND)) != 0;
+    if (st.tt == 16 && lean) rqs_phase_k<TX, HT, 16>(acc, xs, e, st, lo, hi, ldj, h);
     else rqs_phase_k<TX, HT, 0>(acc, xs, e, st, lo, hi, ldj, h);
+}
+
+// The three phases of one group inside ONE iteration of the step loop (kernels whose programs hold rational-quadratic couplings
+// only: MODE 3 / 10 / 18).  `advance()` ends the current step and begins the next one in place (weight-ring flip, wait + barrier,
+// refill, descriptor fetch) and returns that step's descriptor and LDS pointers.  As three iterations, the group's state (28
+// registers) was loop-carried beside the flow state and the B fragments, every arm of the step switch had to agree with every
+// other on where all of it lives (some 60 register moves at the head of each phase), and the group's four inputs were fetched /
+// stored by 32 wave-uniform selects over the whole state; here the group state is local, the phase kind is not a branch, and
+// the four inputs move through a scalar switch on (tile, group).
+#define RQS_GROUP_CASES(OP)                                                                                              \
+    switch (tg) {                                                                                                        \
+        default: OP(0, 0) break;                                                                                         \
+        case 1: OP(0, 1) break;                                                                                          \
+        case 2: OP(0, 2) break;                                                                                          \
+        case 3: OP(0, 3) break;                                                                                          \
+        case 4: if constexpr (TX > 1) { OP(1, 0) } break;                                                                \
+        case 5: if constexpr (TX > 1) { OP(1, 1) } break;                                                                \
+        case 6: if constexpr (TX > 1) { OP(1, 2) } break;                                                                \
+        case 7: if constexpr (TX > 1) { OP(1, 3) } break;                                                                \
+        case 8: if constexpr (TX > 2) { OP(2, 0) } break;                                                                \
+        case 9: if constexpr (TX > 2) { OP(2, 1) } break;                                                                \
+        case 10: if constexpr (TX > 2) { OP(2, 2) } break;                                                               \
+        case 11: if constexpr (TX > 2) { OP(2, 3) } break;                                                               \
+        case 12: if constexpr (TX > 3) { OP(3, 0) } break;                                                               \
+        case 13: if constexpr (TX > 3) { OP(3, 1) } break;                                                               \
+        case 14: if constexpr (TX > 3) { OP(3, 2) } break;                                                               \
+        case 15: if constexpr (TX > 3) { OP(3, 3) } break;                                                               \
+    }
+// (the empty asm keeps each arm a real scalar branch: folded into selects the switch is the 32-select form again)
+#define RQS_FETCH(T, G) { asm volatile("" ::: "memory"); _Pragma("unroll") for (int q = 0; q < 4; ++q) e.x[q] = xs[T].v[0][4 * G + q]; }
+#define RQS_STORE(T, G) { asm volatile("" ::: "memory"); _Pragma("unroll") for (int q = 0; q < 4; ++q) xs[T].v[0][4 * G + q] = out[q]; }
+template <int HT>
+__device__ __forceinline__ void rqs_block(const wptr w, const btile<1> (&bh)[HT], tile<1> (&acc)[4], int h, float &lo, float &hi, bool &lean) {
+    rqs_gemm<HT>(w, bh, acc);
+    lo = *reinterpret_cast<const float *>(w.cb - h * 64 + (4 * HT * 1024 + 128) * 4);
+    hi = *reinterpret_cast<const float *>(w.cb - h * 64 + (4 * HT * 1024 + 129) * 4);
+    const float bound = *reinterpret_cast<const float *>(w.cb - h * 64 + (4 * HT * 1024 + 130) * 4);
+    lean = __builtin_amdgcn_readfirstlane((int)(bound < RQS16_BOUND)) != 0;
+}
+template <int TX, int HT, class ADV>
+__device__ __forceinline__ void rqs_triple(tile<1> (&xs)[TX], const btile<1> (&bh)[HT], const wptr w0, const dstep &st0, float &ldj,
+                                           int lane, ADV &&advance) {
+    const int h = lane >> 5;
+    const int K = st0.tt, tg = 4 * st0.t0 + st0.c0;
+    rqs_elems e;
+    tile<1> acc[4];
+    float lo, hi;
+    bool lean;
+    // block 0: the searched sequence
+    rqs_block<HT>(w0, bh, acc, h, lo, hi, lean);
+    RQS_GROUP_CASES(RQS_FETCH)
+    if (K == 16 && lean) {
+        const rqs16_c c = rqs16_consts(lo, hi);
+        rqs16_search<0>(acc, e, c); __builtin_amdgcn_sched_barrier(0);
+        rqs16_search<1>(acc, e, c); __builtin_amdgcn_sched_barrier(0);
+        rqs16_search<2>(acc, e, c); __builtin_amdgcn_sched_barrier(0);
+        rqs16_search<3>(acc, e, c);
+    } else {
+        rqs_search<0, 0>(acc, e, K, lo, hi); rqs_search<1, 0>(acc, e, K, lo, hi);
+        rqs_search<2, 0>(acc, e, K, lo, hi); rqs_search<3, 0>(acc, e, K, lo, hi);
+    }
+    // block 1: the other sequence at the found bin
+    dstep st;
+    wptr w;
+    advance(st, w);
+    rqs_block<HT>(w, bh, acc, h, lo, hi, lean);
+    if (K == 16 && lean) {
+        const rqs16_c c = rqs16_consts(lo, hi);
+        rqs16_select<0>(acc, e, c); __builtin_amdgcn_sched_barrier(0);
+        rqs16_select<1>(acc, e, c); __builtin_amdgcn_sched_barrier(0);
+        rqs16_select<2>(acc, e, c); __builtin_amdgcn_sched_barrier(0);
+        rqs16_select<3>(acc, e, c);
+    } else {
+        rqs_select<0, 0>(acc, e, K, lo, hi); rqs_select<1, 0>(acc, e, K, lo, hi);
+        rqs_select<2, 0>(acc, e, K, lo, hi); rqs_select<3, 0>(acc, e, K, lo, hi);
+    }
+    // block 2: the derivatives, the rational-quadratic and the group's outputs
+    advance(st, w);
+    rqs_gemm<HT>(w, bh, acc);
+    float out[4], lj[4];
+    if (K == 16) {
+        if (st.reverse) {
+            rqs_eval<0, true, 16>(acc, e, K, out[0], lj[0]); rqs_eval<1, true, 16>(acc, e, K, out[1], lj[1]);
+            rqs_eval<2, true, 16>(acc, e, K, out[2], lj[2]); rqs_eval<3, true, 16>(acc, e, K, out[3], lj[3]);
+        } else {
+            rqs_eval<0, false, 16>(acc, e, K, out[0], lj[0]); rqs_eval<1, false, 16>(acc, e, K, out[1], lj[1]);
+            rqs_eval<2, false, 16>(acc, e, K, out[2], lj[2]); rqs_eval<3, false, 16>(acc, e, K, out[3], lj[3]);
+        }
+    } else {
+        if (st.reverse) {
+            rqs_eval<0, true, 0>(acc, e, K, out[0], lj[0]); rqs_eval<1, true, 0>(acc, e, K, out[1], lj[1]);
+            rqs_eval<2, true, 0>(acc, e, K, out[2], lj[2]); rqs_eval<3, true, 0>(acc, e, K, out[3], lj[3]);
+        } else {
+            rqs_eval<0, false, 0>(acc, e, K, out[0], lj[0]); rqs_eval<1, false, 0>(acc, e, K, out[1], lj[1]);
+            rqs_eval<2, false, 0>(acc, e, K, out[2], lj[2]); rqs_eval<3, false, 0>(acc, e, K, out[3], lj[3]);
+        }
+    }
+    float sl = 0.f;
+    const int g = st0.c0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const bool live = (st.mask >> (q + 8 * g + 4 * h)) & 1u;     // slot kmap(4g+q, h) of the tile
+        out[q] = live ? out[q] : e.x[q];
+        sl += live ? lj[q] : 0.f;
+    }
+    RQS_GROUP_CASES(RQS_STORE)
+    ldj += st.ldj_scale * sl;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1882,6 +2133,9 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
         // behind the weight DMA just issued and every factor store in flight), and whether this wave stores factors at all
         [[maybe_unused]] float gg_chunk = 0.f;
         [[maybe_unused]] bool stores_young = false;
+        // the counted wait at the loop head is only sound when the SECOND half of the previous iteration issued >= 64 factor
+        // stores behind its weight DMA: a dense layer's adjoint half stores 4 tiles (64), a coupling's step B 2 HT tiles (32 HT)
+        [[maybe_unused]] bool head_counted = false;
         if constexpr (MODE == 4 && TX == 8 && NS == 1) {
             gg_chunk = k.row_t[lrow[0]];
 #ifndef SX_EXP_NOSIDE
@@ -2048,8 +2302,9 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
             if (!SX_DBG(2) && !free_run) {
                 if constexpr (MODE == 4 && TX == 8) {
                     // the weights (LDS-DMA issued one half-step ago) are OLDER than the >= 64 factor stores of that half-step:
-                    // a counted wait leaves the stores in flight (vector-memory operations retire in order)
-                    if (s > 0 && stores_young) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+                    // a counted wait leaves the stores in flight (vector-memory operations retire in order).  vmcnt cannot count
+                    // beyond 63, so with fewer than 64 stores behind the DMA (hidden <= 32: step B stores 32) the wait is a full one
+                    if (s > 0 && stores_young && head_counted) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2106,6 +2361,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
             dma_floats = prog.steps[nxt2].blob_floats;
 
             const wptr w = wptr{reinterpret_cast<const char *>(smem) + wb_off, reinterpret_cast<const char *>(smem) + cb_off};
+            [[maybe_unused]] float st_cur_const = st.ldj_const;      // (a spline triple moves on to its next steps inside the iteration)
             SX_STAMP(pf, 2);     // descriptor + DMA issue
             if constexpr (MODE == 5 || MODE == 6) {
                 // pure split-coupling programs (host: validate_and_convert): two straight-line arms, state in place
@@ -2205,10 +2461,12 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                         second_half();
                         coupling_affine_bwd_b<4, HT, 0, 2, 2, 2>(xs, wb_, srow_b, lane, rg, keep);
                         if (high) { swap_tiles(0, 2); swap_tiles(1, 3); swap_tiles(4, 6); swap_tiles(5, 7); }
+                        head_counted = HT >= 2;
                     } else if (st.kind == SX_STEP_LINEAR_BWD) {
                         linear_bwd_half<4, 0>(xs, w, srow, 32 * st.t0, st.reverse != 0, lane, rg);          // x tiles: v = M u + b
                         second_half();
                         linear_bwd_half<4, 4>(xs, wb_, srow_b, 32 * stb.t0, stb.reverse != 0, lane, rg);    // adjoint tiles: W^T dL/du
+                        head_counted = true;
                     }
                 }
             } else
@@ -2469,7 +2727,28 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                         else rqs_phase<TX, HT>(xs, rq_bh, rq_e, w, st, ldj[0], lane);
                     } else
                     if constexpr (CUB && NS == 1) cubic_phase<TX, HT>(xs, rq_bh, rq_e, w, st, ldj[0], lane);
-                    else if constexpr (RQ && NS == 1) rqs_phase<TX, HT>(xs, rq_bh, rq_e, w, st, ldj[0], lane);
+                    else if constexpr (RQ && NS == 1) {
+                        // the group's three blocks in this one iteration (the host plans them back to back, the launcher checks it)
+                        auto advance = [&](dstep &stn, wptr &wn) {
+                            ldj_c += st_cur_const;
+                            cur ^= 1;
+                            ++s;
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_s_barrier();
+                            stn = st_next;
+                            st_cur_const = stn.ldj_const;
+                            int wb2 = cur * buf_floats * 4 + lane * 16, cb2 = cur * buf_floats * 4 + (lane >> 5) * 64;
+                            asm volatile("" : "+v"(wb2), "+v"(cb2));
+                            if ((s + 1 < n_steps || has_next_chunk) && dma_floats) stage_blob<WB>(k.blobs + dma_off, (cur ^ 1) * buf_floats, dma_floats);
+                            const int nb = (s + 1 < n_steps) ? s + 1 : 0, nb2 = (nb + 1 < n_steps) ? nb + 1 : 0;
+                            st_next = load_step(prog, nb);
+                            dma_off = prog.steps[nb2].blob_off;
+                            dma_floats = prog.steps[nb2].blob_floats;
+                            wn = wptr{reinterpret_cast<const char *>(smem) + wb2, reinterpret_cast<const char *>(smem) + cb2};
+                        };
+                        rqs_triple<TX, HT>(xs, rq_bh, w, st, ldj[0], lane, advance);
+                    }
                     break;
                 case SX_STEP_ROW_SCALE_EXP:
                     // x *= exp(+-diag * t_row)  (affine.py:263), t_row optionally log1p|t| (affine.py:239-240)
@@ -2497,7 +2776,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     break;
                 default: break;
             }
-            if (st.kind != SX_STEP_ROW_SCALE_EXP && st.kind != SX_STEP_POINTWISE) ldj_c += st.ldj_const;      // (those two keep a parameter there)
+            if (st.kind != SX_STEP_ROW_SCALE_EXP && st.kind != SX_STEP_POINTWISE) ldj_c += st_cur_const;      // (those two keep a parameter there)
             if (!resident) cur ^= 1;
             SX_STAMP(pf, 6);     // step tail
         }

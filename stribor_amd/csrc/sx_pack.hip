@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void pack_linear_kernel(const float *__restric
                                                           int k_tiles, const float *__restrict__ row_scale,
                                                           const float *__restrict__ bias_scale, float fold_ones,
                                                           int frag_mode, int transpose, uint32_t *__restrict__ err_flag,
-                                                          float *__restrict__ dst) {
+                                                          float *__restrict__ dst, uint32_t *__restrict__ bound_out) {
     // transpose: the operand is W^T (row slots index W's columns, column slots index W's rows)
     auto Wat = [&](int r, int c) -> float { return transpose ? W[(int64_t)c * in_dim + r] : W[(int64_t)r * in_dim + c]; };
     const int n_a = m_tiles * k_tiles * 1024;
@@ -69,14 +69,27 @@ __global__ __launch_bounds__(256) void pack_linear_kernel(const float *__restric
             const int row = row_idx[slot];
             if (row >= 0) {
                 double acc = b != nullptr ? (double)b[row] : 0.0;
-                if (fold_ones != 0.f) {          // b' = b + fold * sum over the live input slots of W[row][.]
-                    double rs = 0.0;
+                if (fold_ones != 0.f || bound_out != nullptr) {          // b' = b + fold * sum over the live input slots of W[row][.]
+                    double rs = 0.0, pos = 0.0, neg = 0.0;
+                    const double rsc = row_scale ? (double)row_scale[slot] : 1.0;
                     for (int c = 0; c < 32 * k_tiles; ++c) {
                         const int col = col_idx[c];
-                        if (col >= 0) rs += (double)Wat(row, col);
+                        if (col >= 0) {
+                            const double wv = (double)Wat(row, col);
+                            rs += wv;
+                            if (wv * rsc > 0.0) pos += wv * rsc; else neg += wv * rsc;
+                        }
                     }
                     acc += (double)fold_ones * rs;
-                }
+                    v = (float)(acc * (bias_scale ? (double)bias_scale[slot] : 1.0));
+                    if (bound_out != nullptr) {
+                        // the largest |output| of this packed row over inputs in [0, 1]^k (the folded tanh r = (1 - tanh) / 2 that
+                        // feeds the spline phases): bias' + the positive (negative) packed weights; kept as the running maximum of
+                        // every row packed into this slot (non-negative floats order like their bit patterns; NaN -> inf)
+                        const float bd = (float)fmax(fabs((double)v + pos), fabs((double)v + neg));
+                        atomicMax(bound_out, __float_as_uint(bd == bd ? bd : __builtin_inff()));
+                    }
+                } else
                 v = (float)(acc * (bias_scale ? (double)bias_scale[slot] : 1.0));
             }
         }
@@ -84,10 +97,10 @@ __global__ __launch_bounds__(256) void pack_linear_kernel(const float *__restric
     }
 }
 
-extern "C" int sx_pack_linear(const float *W, const float *b, int32_t out_dim, int32_t in_dim,
+static int pack_linear_impl(const float *W, const float *b, int32_t out_dim, int32_t in_dim,
                               const int32_t *row_idx, const int32_t *col_idx, int32_t m_tiles, int32_t k_tiles,
                               const float *row_scale, const float *bias_scale, float fold_ones, int32_t transpose,
-                              int32_t precision, uint32_t *err_flag, float *dst, void *stream) {
+                              int32_t precision, uint32_t *err_flag, float *dst, float *bound_out, void *stream) {
     SX_REQUIRE(precision == SX_GEMM_F32 || precision == SX_GEMM_F16X3, "sx_pack_linear: unknown precision %d", precision);
     const int frag_mode = precision;
     SX_REQUIRE(W && row_idx && col_idx && dst, "sx_pack_linear: null pointer");
@@ -95,7 +108,25 @@ extern "C" int sx_pack_linear(const float *W, const float *b, int32_t out_dim, i
     const int total = (int)sx_packed_linear_floats(m_tiles, k_tiles);
     const int grid = (total + 255) / 256;
     hipLaunchKernelGGL(pack_linear_kernel, dim3(grid > 1024 ? 1024 : grid), dim3(256), 0, sx_stream(stream), W, b,
-                       out_dim, in_dim, row_idx, col_idx, m_tiles, k_tiles, row_scale, bias_scale, fold_ones, frag_mode, transpose, err_flag, dst);
+                       out_dim, in_dim, row_idx, col_idx, m_tiles, k_tiles, row_scale, bias_scale, fold_ones, frag_mode, transpose, err_flag, dst,
+                       reinterpret_cast<uint32_t *>(bound_out));
     SX_LAUNCH_CHECK();
     return SX_OK;
+}
+
+extern "C" int sx_pack_linear(const float *W, const float *b, int32_t out_dim, int32_t in_dim,
+                              const int32_t *row_idx, const int32_t *col_idx, int32_t m_tiles, int32_t k_tiles,
+                              const float *row_scale, const float *bias_scale, float fold_ones, int32_t transpose,
+                              int32_t precision, uint32_t *err_flag, float *dst, void *stream) {
+    return pack_linear_impl(W, b, out_dim, in_dim, row_idx, col_idx, m_tiles, k_tiles, row_scale, bias_scale, fold_ones, transpose,
+                            precision, err_flag, dst, nullptr, stream);
+}
+
+extern "C" int sx_pack_linear_bound(const float *W, const float *b, int32_t out_dim, int32_t in_dim,
+                                    const int32_t *row_idx, const int32_t *col_idx, int32_t m_tiles, int32_t k_tiles,
+                                    const float *row_scale, const float *bias_scale, float fold_ones, int32_t transpose,
+                                    int32_t precision, uint32_t *err_flag, float *dst, float *bound_out, void *stream) {
+    SX_REQUIRE(bound_out != nullptr, "sx_pack_linear_bound: null bound_out");
+    return pack_linear_impl(W, b, out_dim, in_dim, row_idx, col_idx, m_tiles, k_tiles, row_scale, bias_scale, fold_ones, transpose,
+                            precision, err_flag, dst, bound_out, stream);
 }

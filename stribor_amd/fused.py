@@ -118,8 +118,10 @@ class _PackJob:
 
     def __init__(self, W, b, row_idx: np.ndarray, col_idx: np.ndarray, m_tiles: int, k_tiles: int, dst_off: int,
                  row_scale: Optional[np.ndarray] = None, bias_scale: Optional[np.ndarray] = None,
-                 fold_ones: float = 0.0, transpose: bool = False):
+                 fold_ones: float = 0.0, transpose: bool = False, bound_off: Optional[int] = None):
         self.transpose = int(transpose)
+        # blob slot that keeps the running bound on |output| of the packed rows (sx_pack_linear_bound), or None
+        self.bound_off = bound_off
         self.W, self.b = W, b
         self.row_idx_host, self.col_idx_host = row_idx.astype(np.int32), col_idx.astype(np.int32)
         self.m_tiles, self.k_tiles, self.dst_off = m_tiles, k_tiles, dst_off
@@ -143,6 +145,12 @@ class _PackJob:
         if W.dtype != torch.float32 or not W.is_contiguous():
             raise TypeError('stribor_amd: conditioner weights must be contiguous float32')
         out_dim, in_dim = W.shape
+        if self.bound_off is not None:
+            _hip.call('sx_pack_linear_bound', blobs, W.data_ptr(), _hip.ptr(b), out_dim, in_dim, self.row_idx.data_ptr(),
+                      self.col_idx.data_ptr(), self.m_tiles, self.k_tiles, _hip.ptr(self.row_scale), _hip.ptr(self.bias_scale),
+                      self.fold_ones, self.transpose, prec, blobs.data_ptr(), blobs.data_ptr() + 4 * self.dst_off,
+                      blobs.data_ptr() + 4 * self.bound_off)
+            return
         _hip.call('sx_pack_linear', blobs, W.data_ptr(), _hip.ptr(b), out_dim, in_dim, self.row_idx.data_ptr(),
                   self.col_idx.data_ptr(), self.m_tiles, self.k_tiles, _hip.ptr(self.row_scale), _hip.ptr(self.bias_scale),
                   self.fold_ones, self.transpose, prec, blobs.data_ptr(), blobs.data_ptr() + 4 * self.dst_off)
@@ -756,7 +764,11 @@ class ProgramBuilder:
                     # the two softmax blocks are packed in base 2 (rows and bias times log2 e): the kernel's softmax is then
                     # v_exp_f32(p - max) with no multiply (32 instructions per element)
                     sc2 = LOG2E if phase < 2 else 1.0
-                    self.jobs.append(_PackJob(W2, b2, rows, col2, 4, HT, off, np.full(128, -2.0 * sc2), np.full(128, sc2), 1.0))
+                    # (the two softmax blocks also leave the bound on their logits in the slot behind (lo, hi): the K = 16 phases
+                    #  run without a running maximum below it -- sx_flow_kernel.h rqs16_sums; the blob buffer starts zeroed and
+                    #  the slot only grows)
+                    self.jobs.append(_PackJob(W2, b2, rows, col2, 4, HT, off, np.full(128, -2.0 * sc2), np.full(128, sc2), 1.0,
+                                              bound_off=(off + nlin + 2) if (phase < 2 and not cubic) else None))
                     self.jobs.append(_ScalarsJob([lo, hi], off + nlin))
                     s_scale = (-ldj_scale if reverse else ldj_scale) if phase == 2 else 0.0
                     step = dict(kind=_hip.STEP_RQS_PHASE, c0=g, ct=phase, t0=t, tt=K, reverse=int(reverse), act=int(cubic),

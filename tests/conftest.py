@@ -9,8 +9,52 @@ for p in (ROOT, os.path.join(ROOT, 'tests')):
         sys.path.insert(0, p)
 
 
+_LAUNCHER = None
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # Multi-process GPU tests run their ranks through a launcher process started HERE, before this process touches the GPU
+    # (tests/launcher.py: a GPU-initialised process must not fork + exec on the GPU boxes).  device_count() does not initialise.
+    global _LAUNCHER
+    try:
+        import torch
+        have_gpu = torch.cuda.device_count() > 0
+    except Exception:
+        have_gpu = False
+    if have_gpu and _LAUNCHER is None:
+        import subprocess
+        _LAUNCHER = subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'launcher.py')], stdin=subprocess.PIPE,
+                                     stdout=subprocess.PIPE, text=True, bufsize=1)
+
+
+def pytest_unconfigure(config):
+    global _LAUNCHER
+    if _LAUNCHER is not None:
+        try:
+            _LAUNCHER.stdin.write('{"quit": true}\n')
+            _LAUNCHER.stdin.flush()
+            _LAUNCHER.wait(timeout=10)
+        except Exception:
+            _LAUNCHER.kill()
+        _LAUNCHER = None
+
+
+@pytest.fixture
+def run_child():
+    """run_child(cmd, env=None, unset=(), timeout=1200) -> dict(rc, stdout, stderr): the command runs as a child of the launcher."""
+    import json
+
+    def run(cmd, env=None, unset=(), timeout=1200):
+        if _LAUNCHER is None:
+            pytest.skip('no launcher process (no GPU at configure time)')
+        _LAUNCHER.stdin.write(json.dumps({'cmd': list(cmd), 'env': env or {}, 'unset': list(unset), 'timeout': timeout, 'cwd': ROOT}) + '\n')
+        _LAUNCHER.stdin.flush()
+        line = _LAUNCHER.stdout.readline()
+        if not line:
+            raise RuntimeError('launcher process died')
+        return json.loads(line)
+    return run
 
 
 def pytest_collection_modifyitems(config, items):

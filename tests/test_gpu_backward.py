@@ -1236,3 +1236,41 @@ def test_spline_flow_training_runs_its_forward_as_one_launch(monkeypatch, stype,
     #  have one-sided gradients, DESIGN.md 2.1, and a mean loss over a few thousand rows shows each of them at 1e-3 of a parameter's)
     want = orc.flow_log_prob(fd.flow_spec(desc, {k: v.double() for k, v in state.items()}), x.double())
     assert ((lp1.double().reshape(-1) - want.reshape(-1)).abs() / (1.0 + want.reshape(-1).abs())).max().item() <= 2e-5
+
+
+def test_fused_backward_of_dense_linear_flows_with_narrow_hidden_layers_at_scale():
+    """Hidden <= 32 (one hidden tile) on the 4 + 4 tile backward program, at a size where the weight DMA of the next step is still
+    in flight when a half-step ends: a coupling's step B then issues only 32 factor stores behind that DMA, fewer than the counted
+    wait (`vmcnt(63)`) needs to cover it, so the wait at the loop head must be a full one.  A race shows as
+    run-to-run differences and as a gap between the two GEMM arithmetics; both are checked over repeats."""
+    torch.manual_seed(54)
+    dim, n = 128, 1 << 18
+    flow = fd.build_flow(st, _cfg4_like(dim, 32, 2), dim)
+    with torch.no_grad():
+        for p in flow.parameters():
+            p.add_(0.02 * torch.randn_like(p))
+    flow = flow.to(DEV)
+    x = torch.randn(n, dim, device=DEV)
+
+    def grads():
+        for p in flow.parameters():
+            p.grad = None
+        xg = x.clone().requires_grad_(True)
+        assert flow._can_backward(xg)
+        (-flow.log_prob(xg).mean()).backward()
+        return [xg.grad.clone()] + [p.grad.clone() for p in flow.parameters()]
+
+    fast = [grads() for _ in range(4)]
+    for rep in fast[1:]:
+        for a, b in zip(fast[0], rep):
+            # the weight gradients are reduced with float atomics in a run-dependent order: equal to rounding, not bit for bit
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-6 + 1e-5 * a.abs().max().item())
+    assert torch.equal(fast[0][0], fast[1][0]), 'dL/dx has no cross-row reduction: repeats must agree bit for bit'
+    old = st.set_gemm_precision('exact')
+    try:
+        exact = grads()
+    finally:
+        st.set_gemm_precision(old)
+    for a, b in zip(fast[0], exact):
+        assert (a - b).abs().max().item() <= 3e-4 * b.abs().max().item() + 1e-7
+    st.check_errors()

@@ -1251,3 +1251,51 @@ def test_fused_time_couplings_and_neural_flow_against_oracle(dim, hidden, latent
     close(xb, x, rtol=1e-5, atol=5e-5)
     close(li, -wl, rtol=1e-5, atol=2e-5)
     st.check_errors()
+
+
+@pytest.mark.parametrize('scale', [1.0, 40.0])
+def test_spline_k16_large_logits_take_the_guarded_sweep(scale):
+    """The straight-line K = 16 spline phases run their softmax without a running maximum, which is only sound while the logits are
+    bounded; the packer leaves the bound (largest |logit| the step's rows can produce from the folded tanh) behind the spline bounds
+    and the kernel falls back to the sweep that keeps the maximum beyond it.  Output-layer weights scaled by 40 push the bound past
+    the limit (and single logits past +-100, where exp2 without the shift would overflow the sum): both forms against the oracle
+    (reference: torch.softmax, rational_quadratic_spline.py:101-105)."""
+    torch.manual_seed(5)
+    dim, hidden, K = 64, 64, 16
+    desc = [{'kind': 'coupling_rqs', 'dim': dim, 'hidden': [hidden], 'n_bins': K, 'lower': -3.0, 'upper': 3.0,
+             'mask': ('ordered_right_half', 'ordered_left_half')[i % 2], 'latent_dim': 0} for i in range(2)]
+    flow = fd.build_flow(st, desc, dim)
+    sd = flow.state_dict()
+    for k in sd:
+        if k.endswith('net.2.weight') or k.endswith('net.2.bias'):      # the conditioners' output layers
+            sd[k] = sd[k] * scale
+    flow.load_state_dict(sd)
+    spec = fd.flow_spec(desc, {k: v.clone() for k, v in flow.state_dict().items()})
+    flow = flow.to(DEV)
+    x = torch.randn(500, dim) * 1.5
+    got = flow.log_prob(x.to(DEV))
+    prog = flow._fused_program(True, dim, 0, torch.device(DEV, torch.cuda.current_device()))
+    assert prog is not None
+    # the bound slots: phase steps of the two softmax blocks carry a positive bound, below the limit only for the default init
+    import numpy as np
+    from stribor_amd import _hip
+    blobs = prog.blobs.cpu().numpy()
+    bounds = []
+    for i in range(prog.prog.n_steps):
+        s = prog.prog.steps[i]
+        if s.kind == _hip.STEP_RQS_PHASE and s.ct < 2:
+            bounds.append(blobs[s.blob_off + _hip.packed_linear_floats(4, 2) + 2])
+    assert len(bounds) == 2 * 4 * 2 and min(bounds) > 0.0
+    assert (max(bounds) < 96.0) == (scale == 1.0), (min(bounds), max(bounds))
+    want = orc.flow_log_prob(spec, x)
+    if scale == 1.0:
+        close(got, want, rtol=1e-5, atol=2e-4)
+    else:
+        # sharply peaked bins: the reference's own fp32 result is conditioned like the logits (|d log p| ~ |logit| eps); hold the
+        # product to the fp64 truth within a few times that
+        spec64 = fd.flow_spec(desc, {k: v.cpu().double() for k, v in flow.state_dict().items()})
+        f64 = orc.flow_log_prob(spec64, x.double())
+        assert torch.isfinite(got).all()
+        close_vs_f64(got, want, f64, k=4.0, rtol=1e-5, atol=5e-3)
+    y, ldj = flow.forward_and_log_det_jacobian(x.to(DEV))
+    close(flow.inverse(y), x, rtol=1e-4, atol=2e-4 if scale == 1.0 else 2e-3)

@@ -295,6 +295,9 @@ def test_bench_spawns_its_own_ranks(monkeypatch):
     assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
     assert cmd[cmd.index('--gpus') + 1] == '8' and cmd[cmd.index('--steps') + 1] == '7'
     assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    assert '--backend' not in cmd                      # nccl (RCCL) is the default and the product path
+    bench.spawn_ranks(argparse.Namespace(gpus=2, steps=3, warmup=1, no_cpu_baseline=True, backend='gloo'))
+    assert seen['cmd'][seen['cmd'].index('--backend') + 1] == 'gloo'
 
 
 @pytest.mark.parametrize('cubic', [False, True])
