@@ -13,6 +13,6 @@ from .flow import ElementwiseTransform, NeuralFlow, NormalizingFlow, Transform
 from .flows import (ELU, Affine, AffineLU, ContinuousAffineCoupling, Coupling, Cumsum, Diff, Flip, Identity, LeakyReLU, Logit, MatrixExponential,
                     Permute, Sigmoid, Spline)
 
-from ._hip import GemmRangeError, check_errors, get_gemm_precision, set_gemm_precision
+from ._hip import GemmRangeError, check_errors, get_gemm_precision, set_gemm_precision, set_sync_errors
 
 __version__ = '0.2.0'

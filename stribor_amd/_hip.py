@@ -245,22 +245,39 @@ class GemmRangeError(OverflowError):
 
 
 # ---- data-dependent error flags (reference: exceptions raised inside the torch ops) -----------------------------------
-# One 32-bit word per device in PINNED host memory: kernels OR SX_FLAG_* bits into it with system-scope atomics (the
+# One 32-bit word per (device, stream) in PINNED host memory: kernels OR SX_FLAG_* bits into it with system-scope atomics (the
 # pinned allocation is mapped into the device's address space under the same pointer), the host reads it with a plain
 # load -- no stream synchronisation, nothing that would break HIP-graph capture.  A kernel's flag becomes visible once
-# that kernel has run, so `poll_errors()` at the start of the next call reports the previous call's condition;
-# `check_errors()` synchronises first.
+# that kernel has run, so `poll_errors()` at the start of the next call ON THE SAME STREAM reports the previous call's
+# condition (work queued on another stream -- another flow, another thread -- neither sees nor clears it); `check_errors()`
+# synchronises the device and raises whatever any of its streams left behind.
+# STRIBOR_SYNC_ERRORS=1 (or set_sync_errors(True)): every launch is followed by a stream synchronisation and the poll, so
+# the exception leaves the FAILING call like the reference's (stribor/util/rational_quadratic_spline.py:175-178,223) -- at
+# the price of one synchronisation per launch; not usable under HIP-graph capture.
 _flag_words = {}
+_sync_errors = os.environ.get('STRIBOR_SYNC_ERRORS', '0') not in ('', '0')
 
 
-def err_flag(device) -> int:
-    """Pointer (host == device address) of `device`'s flag word."""
-    key = torch.device(device).index or 0
+def set_sync_errors(on: bool) -> bool:
+    """Raise data-dependent errors inside the failing call (synchronises after every launch); returns the previous setting."""
+    global _sync_errors
+    old, _sync_errors = _sync_errors, bool(on)
+    return old
+
+
+def _flag_entry(device):
+    key = (torch.device(device).index or 0, stream())
     ent = _flag_words.get(key)
     if ent is None:
         t = torch.zeros(1, dtype=torch.int32).pin_memory()
         ent = _flag_words[key] = (t, t.numpy(), t.data_ptr())
-    return ent[2]
+    return ent
+
+
+def err_flag(device) -> int:
+    """Pointer (host == device address) of the flag word of (`device`, its current stream)."""
+    with device_of_index(torch.device(device).index):
+        return _flag_entry(device)[2]
 
 
 def _raise_flags(v: int) -> None:
@@ -273,25 +290,41 @@ def _raise_flags(v: int) -> None:
         raise AssertionError('rational_quadratic_spline: negative discriminant in the inverse pass')
 
 
-def poll_errors() -> None:
-    """Raise for any flag a COMPLETED kernel has set (no synchronisation)."""
-    for _, view, _ in _flag_words.values():
+def poll_errors(all_streams: bool = False) -> None:
+    """Raise for any flag a COMPLETED kernel of the current device's current stream has set (no synchronisation);
+    all_streams: of any stream of any device (what check_errors() does after synchronising)."""
+    if all_streams:
+        words = list(_flag_words.values())
+    else:
+        if not _flag_words:
+            return
+        ent = _flag_words.get(((_cur_device() if _cur_device is not None else torch.cuda.current_device()), stream()))
+        words = [] if ent is None else [ent]
+    for _, view, _ in words:
         v = int(view[0])
         if v:
             view[0] = 0
             _raise_flags(v)
 
 
+def after_launch() -> None:
+    """STRIBOR_SYNC_ERRORS: wait for the launch just queued and raise its data-dependent error now."""
+    if _sync_errors:
+        torch.cuda.current_stream().synchronize()
+        poll_errors()
+
+
 def check_errors(device=None) -> None:
-    """Synchronise and raise what the reference would have raised for data-dependent failures."""
+    """Synchronise and raise what the reference would have raised for data-dependent failures (any stream)."""
     if torch.cuda.is_available():
         torch.cuda.synchronize(device)
-    poll_errors()
+    poll_errors(all_streams=True)
 
 
 def take_flag(device, bit: int) -> bool:
-    """Clear `bit` of the device's flag word and tell whether it was set (callers synchronised already)."""
-    ent = _flag_words.get(torch.device(device).index or 0)
+    """Clear `bit` of the flag word of (device, current stream) and tell whether it was set (callers synchronised already)."""
+    with device_of_index(torch.device(device).index):
+        ent = _flag_words.get((torch.device(device).index or 0, stream()))
     if ent is None:
         return False
     v = int(ent[1][0])
@@ -358,10 +391,20 @@ class device_of:
         return False
 
 
+class device_of_index(device_of):
+    """`with device_of_index(i):` -- the same for a device index (None: leave the current device)."""
+    __slots__ = ()
+
+    def __init__(self, idx):
+        self.idx = idx
+
+
 def call(name: str, t: torch.Tensor, *args) -> None:
     """lib().<name>(*args, stream) on t's device and its current stream; raises on a non-zero status."""
     with device_of(t):
         rc = getattr(lib(), name)(*args, stream())
+        if rc == 0 and _sync_errors:
+            after_launch()
     if rc != 0:
         check(rc, name)
 

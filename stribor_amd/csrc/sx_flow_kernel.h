@@ -255,6 +255,26 @@ template <int NS>
 __device__ __forceinline__ void gemm_tile(const char *wb, int a_off, const btile<NS> &b, tile<NS> &acc) {
     gemm_tile_f<NS>(wb, a_off, b, acc, [](int) {});
 }
+// the same without the scheduling fence behind it: the caller interleaves the MFMAs with independent VALU work of its own
+template <int NS>
+__device__ __forceinline__ void gemm_tile_open(const char *wb, int a_off, const btile<NS> &b, tile<NS> &acc) {
+#ifdef SX_F16X3
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const u32x4 ahu = *reinterpret_cast<const u32x4 *>(wb + (a_off + (2 * s) * 256) * 4);       // ds_read_b128, imm offset
+        const u32x4 alu = *reinterpret_cast<const u32x4 *>(wb + (a_off + (2 * s + 1) * 256) * 4);
+        const h8 ah = __builtin_bit_cast(h8, ahu), al = __builtin_bit_cast(h8, alu);
+#pragma unroll
+        for (int n = 0; n < NS; ++n) acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b.hi[n][s], acc.v[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NS; ++n) acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.lo[n][s], acc.v[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NS; ++n) acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.hi[n][s], acc.v[n], 0, 0, 0);
+    }
+#else
+    gemm_tile_f<NS>(wb, a_off, b, acc, [](int) {});
+#endif
+}
 
 // bias / per-feature constants in C-fragment order: [h][16] floats at off, replicated over the sample tiles
 __device__ __forceinline__ f32x16 load_cfrag1(const char *cb, int off) {
@@ -781,18 +801,19 @@ __device__ __forceinline__ void pointwise_step(tile<NS> (&xs)[TX], const wptr w,
 // A layer is 1 RQS_HIDDEN step + 12 RQS_PHASE steps per transformed tile: the tile's 32 columns are handled in
 // 4 groups of 8; per group three parameter blocks (the SEARCH block whose knots bracket the input, the SELECT
 // block evaluated at the found bin, the derivatives) arrive as 4 MFMA output tiles each, laid out so that every
-// lane receives, in 16 registers, the 16 parameters of 4 of its own elements (row 8q + 4h + i of output tile u
-// = parameter 4u + i of the lane-half-h element q): the 12 GiB [N, D*(3K-1)] parameter tensor of the
-// reference (spline.py:82-86) only ever exists 64 registers at a time.
+// lane receives, in the 16 registers of output tile q, the 16 parameters of its element q (row kmap(k, h) of tile q = parameter k
+// of the lane-half-h element q; round 4: before, tile u held parameters 4u..4u+3 of all four elements, so no element could start
+// before all four tiles were done): the 12 GiB [N, D*(3K-1)] parameter tensor of the reference (spline.py:82-86) only ever
+// exists 64 registers at a time, and an element's arithmetic can run beside the MFMAs of the next element's tile.
 // ------------------------------------------------------------------------------------------------
 #define RQS_MIN 1e-3f
 struct rqs_elems {          // the 4 elements of the current group a lane owns
     float x[4];             // input values
     float a_b[4], a_w[4];   // searched sequence: knot at the bin, bin size
     float c_b[4], c_w[4];   // selected sequence: knot at the bin, bin size
-    int b[4];               // bin index
-    bool in[4];             // inside the (input-side) interval
-};
+    int b[4];               // bin index; + RQS_OUT when the input is outside the (input-side) interval (a bool here is a lane mask
+};                          //  in SGPRs, carried across the blocks through v_writelane / v_readlane spills)
+#define RQS_OUT 64
 
 template <int HT>
 __device__ __forceinline__ void rqs_gemm(const wptr w, const btile<1> (&bh)[HT], tile<1> (&acc)[4]) {
@@ -803,8 +824,8 @@ __device__ __forceinline__ void rqs_gemm(const wptr w, const btile<1> (&bh)[HT],
         for (int m = 0; m < HT; ++m) gemm_tile<1>(w.wb, (u * HT + m) * 1024, bh[m], acc[u]);
     }
 }
-// parameter k (0..15) of element q: register 4q + (k & 3) of output tile k >> 2
-#define RQS_P(acc, q, k) (acc)[(k) >> 2].v[0][4 * (q) + ((k) & 3)]
+// parameter k (0..15) of element q: register k of output tile q
+#define RQS_P(acc, q, k) (acc)[q].v[0][k]
 
 // The three per-element routines are written branch-free (selects only) and take the bin count as a template
 // argument: KC = 16 is the straight-line hot path of cfg 3, KC = 0 keeps K as a run-time value (k < K predicates).
@@ -843,7 +864,6 @@ template <int Q>
 __device__ __forceinline__ void rqs_search16(tile<1> (&acc)[4], rqs_elems &e, float lo, float hi) {
     const float xv = e.x[Q];
     const bool in = (xv >= lo) && (xv <= hi);                       // :71 closed interval
-    e.in[Q] = in;
     const float xin = in ? xv : lo;
     const float inv = rqs_softmax<Q, 16>(acc, 16);
     const float span = hi - lo;
@@ -864,7 +884,7 @@ __device__ __forceinline__ void rqs_search16(tile<1> (&acc)[4], rqs_elems &e, fl
     const float k1 = span * cs1 + lo, k2 = span * cs2 + lo, k3 = span * cs3 + lo;
     const float k4 = m3 ? hi : span * cs4 + lo;
     const bool g1 = xin >= k1, g2 = xin >= k2, g3 = xin >= k3;
-    e.b[Q] = gb + (g3 ? 3 : (g2 ? 2 : (g1 ? 1 : 0)));
+    e.b[Q] = gb + (g3 ? 3 : (g2 ? 2 : (g1 ? 1 : 0))) + (in ? 0 : RQS_OUT);
     const float k_b = g3 ? k3 : (g2 ? k2 : (g1 ? k1 : k0));
     const float k_n = g3 ? k4 : (g2 ? k3 : (g1 ? k2 : k1));
     e.a_b[Q] = k_b;
@@ -875,7 +895,7 @@ template <int Q>
 __device__ __forceinline__ void rqs_select16(tile<1> (&acc)[4], rqs_elems &e, float lo, float hi) {
     const float inv = rqs_softmax<Q, 16>(acc, 16);
     const float span = hi - lo;
-    const int b = e.b[Q];
+    const int b = e.b[Q] & (RQS_OUT - 1);
     const float S0 = 4.f * RQS_MIN + inv * ((RQS_P(acc, Q, 0) + RQS_P(acc, Q, 1)) + (RQS_P(acc, Q, 2) + RQS_P(acc, Q, 3)));
     const float S1 = 4.f * RQS_MIN + inv * ((RQS_P(acc, Q, 4) + RQS_P(acc, Q, 5)) + (RQS_P(acc, Q, 6) + RQS_P(acc, Q, 7)));
     const float S2 = 4.f * RQS_MIN + inv * ((RQS_P(acc, Q, 8) + RQS_P(acc, Q, 9)) + (RQS_P(acc, Q, 10) + RQS_P(acc, Q, 11)));
@@ -901,17 +921,18 @@ __device__ __forceinline__ void rqs_select16(tile<1> (&acc)[4], rqs_elems &e, fl
 // K = 16, BOUNDED logits (round 4): the lean form of the three phases above.  What changed and why (profiles/sq_cfg3.json: 256 of
 // the 545 vector instructions per element were selects, compares and moves; 256 VGPRs + 68 B of scratch):
 //   * no running maximum.  The softmax is shift-invariant and the shift only guards exp against overflow; the packer leaves a bound
-//     on |logit| of the step's rows behind the spline bounds (sx_pack_linear_bound: |b'| + sum |w'| -- the hidden activations are
-//     tanh's), and below RQS16_BOUND the phases run e_k = exp2(u_k) directly: 8 v_max3 + 16 v_sub per block and the
-//     canonicalising v_max pairs go away.  Above it (never seen with trained conditioners; 2^96 per bin) the KC = 0 sweep with the
-//     maximum runs instead;
+//     on |logit| of the step's rows behind the spline bounds (sx_pack_linear_bound: |b' + the positive (negative) packed weights| --
+//     the hidden activations are the folded tanh, in [0, 1]), and below RQS16_BOUND the phases run e_k = exp2(u_k) directly: 8
+//     v_max3 + 16 v_sub per block and the canonicalising v_max pairs go away.  Above it (2^96 per bin: not seen with trained
+//     conditioners) the KC = 0 sweep with the maximum runs instead;
 //   * the sums of a group of four bins are formed left to right, so the three partial sums ARE the group's inner prefixes: the knots
 //     inside the found group come from one pick of four prefixes each (12 selects) and one fma each, with the bounds folded into
 //     per-phase constants (knot = c_span_inv * prefix + (k0 + i * span * MIN));
-//   * every select takes named values computed on both sides (a conditional EXPRESSION with arithmetic in an arm is a branch to
-//     the front end: the old code ran s_and_saveexec / s_cbranch_execz diamonds inside the element code), one element at a time
-//     (sched_barrier between elements: four interleaved elements kept 4 x 16 picked values and 24 lane masks alive -- the SGPR
-//     spills of the old form were those masks).
+//   * every select takes named VALUES computed on both sides (a conditional EXPRESSION with arithmetic in an arm is a branch to
+//     the front end -- the old code ran s_and_saveexec / s_cbranch_execz diamonds inside the element code --, and `c ? a : b` on
+//     two lvalues selects the ADDRESS, which pins the operands to scratch);
+//   * an element's 16 parameters are ONE output tile (RQS_P), so element q's arithmetic runs beside the MFMAs of tile q + 1
+//     (rqs16_block): the matrix pipe and the VALU overlap inside the wave instead of only across the two waves of a SIMD.
 // Arithmetic: the same knots up to the order of the additions (the reference: cumsum of MIN + (1 - K MIN) softmax, times the span,
 // plus the lower bound, ends pinned -- rational_quadratic_spline.py:180-192).
 // ------------------------------------------------------------------------------------------------
@@ -919,101 +940,159 @@ __device__ __forceinline__ void rqs_select16(tile<1> (&acc)[4], rqs_elems &e, fl
 struct rqs16_c {            // per-phase constants (uniform; one set per phase step, shared by the lane's four elements)
     float lo, hi;
     float cs;               // (1 - 16 MIN) (hi - lo)
-    float sm1, sm2, sm3;    // i MIN (hi - lo)
+    float sm1, sm2, sm3, sm4;    // i MIN (hi - lo)
     float l4, l8, l12;      // lo + 4 j MIN (hi - lo): the group boundaries' constant part
 };
 __device__ __forceinline__ rqs16_c rqs16_consts(float lo, float hi) {
     rqs16_c c;
     const float span = hi - lo, sm = RQS_MIN * span;
     c.lo = lo; c.hi = hi; c.cs = (1.f - 16.f * RQS_MIN) * span;
-    c.sm1 = sm; c.sm2 = 2.f * sm; c.sm3 = 3.f * sm;
+    c.sm1 = sm; c.sm2 = 2.f * sm; c.sm3 = 3.f * sm; c.sm4 = 4.f * sm;
     c.l4 = lo + 4.f * sm; c.l8 = lo + 8.f * sm; c.l12 = lo + 12.f * sm;
     return c;
 }
-// exp2 of the 16 logits in place, the groups' inner prefixes, the prefix sums of the groups and span (1 - 16 MIN) / sum
-struct rqs16_s {            // (named scalars on purpose: a select between two ARRAY elements is canonicalised into a select of
-    float a1, a2, a3;       //  addresses -- the array then lives in scratch and every pick is a scratch load)
-    float b1, b2, b3;       // group j: e_{4j}+e_{4j+1}, +e_{4j+2}, +e_{4j+3} (= the group's sum)
-    float c1, c2, c3;
-    float d1, d2, d3;
-    float G2, G3;           // g0 + g1, g0 + g1 + g2
-    float sinv;
-};
-#define RQS16_GROUP(J, x1, x2, x3)                                                                                         \
-    {                                                                                                                      \
-        const float e0 = __builtin_amdgcn_exp2f(RQS_P(acc, Q, 4 * J)), e1 = __builtin_amdgcn_exp2f(RQS_P(acc, Q, 4 * J + 1)); \
-        const float e2 = __builtin_amdgcn_exp2f(RQS_P(acc, Q, 4 * J + 2)), e3 = __builtin_amdgcn_exp2f(RQS_P(acc, Q, 4 * J + 3)); \
-        RQS_P(acc, Q, 4 * J) = e0;          /* (only the group's first size is read again: a prefix of one) */             \
-        x1 = e0 + e1; x2 = x1 + e2; x3 = x2 + e3;                                                                          \
-    }
-template <int Q>
-__device__ __forceinline__ rqs16_s rqs16_sums(tile<1> (&acc)[4], const rqs16_c &c) {
-    rqs16_s s;
-    RQS16_GROUP(0, s.a1, s.a2, s.a3)
-    RQS16_GROUP(1, s.b1, s.b2, s.b3)
-    RQS16_GROUP(2, s.c1, s.c2, s.c3)
-    RQS16_GROUP(3, s.d1, s.d2, s.d3)
-    s.G2 = s.a3 + s.b3;
-    s.G3 = s.G2 + s.c3;
-    s.sinv = c.cs * fast_rcp(s.G3 + s.d3);
-    return s;
-}
-// the five knots k0..k4 around the group chosen by the nested masks m1 >= m2 >= m3 (group >= 1, 2, 3)
-// (a function taking VALUES: `c ? a : b` on two lvalues is an lvalue -- the front end selects the ADDRESS and loads through it,
-//  which pins the operands to memory: 128 B of scratch and a scratch load per pick)
+// (a function taking VALUES: see above)
 __device__ __forceinline__ float rqs16_pick(bool m1, bool m2, bool m3, float v0, float v1, float v2, float v3) {
     return m3 ? v3 : (m2 ? v2 : (m1 ? v1 : v0));
 }
-#define RQS16_PICK(m1, m2, m3, v0, v1, v2, v3) rqs16_pick(m1, m2, m3, v0, v1, v2, v3)
-template <int Q>
-__device__ __forceinline__ void rqs16_group_knots(tile<1> (&acc)[4], const rqs16_s &s, const rqs16_c &c, float T1, float T2, float T3,
-                                                   bool m1, bool m2, bool m3, float &k0, float &k1, float &k2, float &k3, float &k4) {
-    const float e_0 = RQS_P(acc, Q, 0), e_4 = RQS_P(acc, Q, 4), e_8 = RQS_P(acc, Q, 8), e_12 = RQS_P(acc, Q, 12);
-    const float p1 = RQS16_PICK(m1, m2, m3, e_0, e_4, e_8, e_12);
-    const float p2 = RQS16_PICK(m1, m2, m3, s.a1, s.b1, s.c1, s.d1);
-    const float p3 = RQS16_PICK(m1, m2, m3, s.a2, s.b2, s.c2, s.d2);
-    const float p4 = RQS16_PICK(m1, m2, m3, s.a3, s.b3, s.c3, s.d3);
-    const float lo_ = c.lo;
-    k0 = RQS16_PICK(m1, m2, m3, lo_, T1, T2, T3);
-    const float k4c = __builtin_fmaf(s.sinv, p4, k0 + c.sm1 * 4.f);
+// ---- the MFMAs of the NEXT element's tile, issued from inside an element's arithmetic -------------------------------------------
+// An element routine below calls hk.pt<0>() .. hk.pt<11>() at twelve points about eight vector instructions apart; a tile pipe
+// issues its 6 HT MFMAs spread over those points (each followed by a scheduling fence, so the compiler keeps the interleave), the
+// A fragments of k16-step T + 1 requested at the first MFMA of step T (two fragment buffers).  The prescriptive alternative,
+// sched_group_barrier groups over one fenced region, was tried first: the solver honoured the first four MFMA / VALU groups and
+// left the other eight MFMAs back to back in front of sixty vector instructions.
+struct rqs_nohook {
+    template <int P> __device__ __forceinline__ void pt() {}
+};
+template <int HT, int U>
+struct rqs_tile_pipe {
+    const char *wb, *cb;
+    const btile<1> (&bh)[HT];
+    tile<1> &acc;
+#ifdef SX_F16X3
+    u32x4 fh[2], fl[2];
+#endif
+    __device__ __forceinline__ rqs_tile_pipe(const wptr w, const btile<1> (&bh_)[HT], tile<1> &acc_) : wb(w.wb), cb(w.cb), bh(bh_), acc(acc_) {}
+#ifdef SX_F16X3
+    template <int T> __device__ __forceinline__ void load() {       // fragments of k16-step T (k-tile T / 2, half T % 2)
+        constexpr int a_off = (U * HT + T / 2) * 1024, s2 = T % 2;
+        fh[T & 1] = *reinterpret_cast<const u32x4 *>(wb + (a_off + (2 * s2) * 256) * 4);
+        fl[T & 1] = *reinterpret_cast<const u32x4 *>(wb + (a_off + (2 * s2 + 1) * 256) * 4);
+    }
+    template <int J> __device__ __forceinline__ void mfma() {
+        constexpr int T = J / 3, k = J % 3, m = T / 2, s2 = T % 2;
+        if constexpr (k == 0 && T + 1 < 2 * HT) load<T + 1>();
+        const h8 ah = __builtin_bit_cast(h8, fh[T & 1]), al = __builtin_bit_cast(h8, fl[T & 1]);
+        if constexpr (k == 0) acc.v[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[m].hi[0][s2], acc.v[0], 0, 0, 0);      // smallest terms first
+        else if constexpr (k == 1) acc.v[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[m].lo[0][s2], acc.v[0], 0, 0, 0);
+        else acc.v[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[m].hi[0][s2], acc.v[0], 0, 0, 0);
+    }
+    template <int J, int JE> __device__ __forceinline__ void run() {
+        if constexpr (J < JE) { mfma<J>(); run<J + 1, JE>(); }
+    }
+    __device__ __forceinline__ void start() {
+        acc = load_cfrag<1>(cb, 4 * HT * 1024 + U * 32);
+        load<0>();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    template <int P> __device__ __forceinline__ void pt() {
+        constexpr int N = 6 * HT;
+        __builtin_amdgcn_sched_barrier(0);
+        run<P * N / 12, (P + 1) * N / 12>();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#else
+    // exact fp32: v_mfma_f32_32x32x2_f32 executes on the VALU itself -- nothing to overlap: the tile's GEMM up front
+    __device__ __forceinline__ void start() {
+        acc = load_cfrag<1>(cb, 4 * HT * 1024 + U * 32);
+#pragma unroll
+        for (int m = 0; m < HT; ++m) gemm_tile<1>(wb, (U * HT + m) * 1024, bh[m], acc);
+    }
+    template <int P> __device__ __forceinline__ void pt() {}
+#endif
+};
+// exp2 of a tile's 16 logits, the groups' inner prefixes (e0, e0+e1, e0+e1+e2, the group's sum), the group boundaries' knots
+struct rqs16_s {
+    float a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3, d0, d1, d2, d3;
+    float T1, T2, T3;       // knots at bins 4, 8, 12
+    float sinv;             // span (1 - 16 MIN) / sum
+};
+template <class H>
+__device__ __forceinline__ rqs16_s rqs16_sums(const f32x16 &u, const rqs16_c &c, H &hk) {
+    rqs16_s s;
+    hk.template pt<0>();
+    s.a0 = __builtin_amdgcn_exp2f(u[0]); s.a1 = s.a0 + __builtin_amdgcn_exp2f(u[1]); s.a2 = s.a1 + __builtin_amdgcn_exp2f(u[2]); s.a3 = s.a2 + __builtin_amdgcn_exp2f(u[3]);
+    hk.template pt<1>();
+    s.b0 = __builtin_amdgcn_exp2f(u[4]); s.b1 = s.b0 + __builtin_amdgcn_exp2f(u[5]); s.b2 = s.b1 + __builtin_amdgcn_exp2f(u[6]); s.b3 = s.b2 + __builtin_amdgcn_exp2f(u[7]);
+    hk.template pt<2>();
+    s.c0 = __builtin_amdgcn_exp2f(u[8]); s.c1 = s.c0 + __builtin_amdgcn_exp2f(u[9]); s.c2 = s.c1 + __builtin_amdgcn_exp2f(u[10]); s.c3 = s.c2 + __builtin_amdgcn_exp2f(u[11]);
+    hk.template pt<3>();
+    s.d0 = __builtin_amdgcn_exp2f(u[12]); s.d1 = s.d0 + __builtin_amdgcn_exp2f(u[13]); s.d2 = s.d1 + __builtin_amdgcn_exp2f(u[14]); s.d3 = s.d2 + __builtin_amdgcn_exp2f(u[15]);
+    hk.template pt<4>();
+    const float G2 = s.a3 + s.b3, G3 = G2 + s.c3;
+    s.sinv = c.cs * fast_rcp(G3 + s.d3);
+    s.T1 = __builtin_fmaf(s.sinv, s.a3, c.l4);
+    s.T2 = __builtin_fmaf(s.sinv, G2, c.l8);
+    s.T3 = __builtin_fmaf(s.sinv, G3, c.l12);
+    return s;
+}
+// the knots around the group chosen by the nested masks m1 >= m2 >= m3 (group >= 1, 2, 3); points 6 .. 8
+template <class H>
+__device__ __forceinline__ void rqs16_knots(const rqs16_s &s, const rqs16_c &c, bool m1, bool m2, bool m3, float &k0, float &k1, float &k2,
+                                            float &k3, float &k4, H &hk) {
+    k0 = rqs16_pick(m1, m2, m3, c.lo, s.T1, s.T2, s.T3);
+    const float p1 = rqs16_pick(m1, m2, m3, s.a0, s.b0, s.c0, s.d0);
+    hk.template pt<6>();
+    const float p2 = rqs16_pick(m1, m2, m3, s.a1, s.b1, s.c1, s.d1);
+    const float p3 = rqs16_pick(m1, m2, m3, s.a2, s.b2, s.c2, s.d2);
     k1 = __builtin_fmaf(s.sinv, p1, k0 + c.sm1);
     k2 = __builtin_fmaf(s.sinv, p2, k0 + c.sm2);
+    hk.template pt<7>();
+    const float p4 = rqs16_pick(m1, m2, m3, s.a3, s.b3, s.c3, s.d3);
     k3 = __builtin_fmaf(s.sinv, p3, k0 + c.sm3);
+    const float k4c = __builtin_fmaf(s.sinv, p4, k0 + c.sm4);
     const float hi_ = c.hi;
     k4 = m3 ? hi_ : k4c;                                                // ends pinned (:189-192)
+    hk.template pt<8>();
 }
-template <int Q>
-__device__ __forceinline__ void rqs16_search(tile<1> (&acc)[4], rqs_elems &e, const rqs16_c &c) {
+template <int Q, class H>
+__device__ __forceinline__ void rqs16_search(const f32x16 &u, rqs_elems &e, const rqs16_c &c, H &hk) {
+    const rqs16_s s = rqs16_sums(u, c, hk);
+    hk.template pt<5>();
     const float xv = e.x[Q];
     const bool in = (xv >= c.lo) && (xv <= c.hi);                       // :71 closed interval
-    e.in[Q] = in;
-    const float xin = in ? xv : c.lo;
-    const rqs16_s s = rqs16_sums<Q>(acc, c);
-    // knots at bins 4, 8, 12
-    const float T1 = __builtin_fmaf(s.sinv, s.a3, c.l4), T2 = __builtin_fmaf(s.sinv, s.G2, c.l8), T3 = __builtin_fmaf(s.sinv, s.G3, c.l12);
-    const bool m1 = xin >= T1, m2 = xin >= T2, m3 = xin >= T3;          // a prefix: the knots grow
+    const float lo_ = c.lo;
+    const float xin = in ? xv : lo_;
+    const bool m1 = xin >= s.T1, m2 = xin >= s.T2, m3 = xin >= s.T3;    // a prefix: the knots grow
     float k0, k1, k2, k3, k4;
-    rqs16_group_knots<Q>(acc, s, c, T1, T2, T3, m1, m2, m3, k0, k1, k2, k3, k4);
+    rqs16_knots(s, c, m1, m2, m3, k0, k1, k2, k3, k4, hk);
     const bool g1 = xin >= k1, g2 = xin >= k2, g3 = xin >= k3;
-    e.b[Q] = 4 * ((int)m1 + (int)m2 + (int)m3) + ((int)g1 + (int)g2 + (int)g3);
+    const int bg = 4 * ((int)m1 + (int)m2 + (int)m3) + (in ? 0 : RQS_OUT);
+    hk.template pt<9>();
+    e.b[Q] = bg + ((int)g1 + (int)g2 + (int)g3);
     const float k_b = g3 ? k3 : (g2 ? k2 : (g1 ? k1 : k0));
+    hk.template pt<10>();
     const float k_n = g3 ? k4 : (g2 ? k3 : (g1 ? k2 : k1));
     e.a_b[Q] = k_b;
     e.a_w[Q] = k_n - k_b;
+    hk.template pt<11>();
 }
-template <int Q>
-__device__ __forceinline__ void rqs16_select(tile<1> (&acc)[4], rqs_elems &e, const rqs16_c &c) {
-    const rqs16_s s = rqs16_sums<Q>(acc, c);
-    const int b = e.b[Q], bl = b & 3;
-    const float T1 = __builtin_fmaf(s.sinv, s.a3, c.l4), T2 = __builtin_fmaf(s.sinv, s.G2, c.l8), T3 = __builtin_fmaf(s.sinv, s.G3, c.l12);
+template <int Q, class H>
+__device__ __forceinline__ void rqs16_select(const f32x16 &u, rqs_elems &e, const rqs16_c &c, H &hk) {
+    const rqs16_s s = rqs16_sums(u, c, hk);
+    hk.template pt<5>();
+    const int b = e.b[Q] & (RQS_OUT - 1), bl = b & 3;
     const bool m1 = b >= 4, m2 = b >= 8, m3 = b >= 12;
     float k0, k1, k2, k3, k4;
-    rqs16_group_knots<Q>(acc, s, c, T1, T2, T3, m1, m2, m3, k0, k1, k2, k3, k4);
+    rqs16_knots(s, c, m1, m2, m3, k0, k1, k2, k3, k4, hk);
     const bool g1 = bl >= 1, g2 = bl >= 2, g3 = bl >= 3;
+    hk.template pt<9>();
     const float k_b = g3 ? k3 : (g2 ? k2 : (g1 ? k1 : k0));
+    hk.template pt<10>();
     const float k_n = g3 ? k4 : (g2 ? k3 : (g1 ? k2 : k1));
     e.c_b[Q] = k_b;
     e.c_w[Q] = k_n - k_b;
+    hk.template pt<11>();
 }
 template <int Q, int KC>
 __device__ __forceinline__ void rqs_search(tile<1> (&acc)[4], rqs_elems &e, int K, float lo, float hi) {
@@ -1022,7 +1101,6 @@ __device__ __forceinline__ void rqs_search(tile<1> (&acc)[4], rqs_elems &e, int 
 #endif
     const float xv = e.x[Q];
     const bool in = (xv >= lo) && (xv <= hi);                       // :71 closed interval
-    e.in[Q] = in;
     const float xin = in ? xv : lo;
     const float inv = rqs_softmax<Q, KC>(acc, K);
     const int Kn = KC ? KC : K;
@@ -1042,7 +1120,7 @@ __device__ __forceinline__ void rqs_search(tile<1> (&acc)[4], rqs_elems &e, int 
             k_n = fminf(k_n, (ge || !used) ? hi : knot);
         }
     }
-    e.b[Q] = b;
+    e.b[Q] = b + (in ? 0 : RQS_OUT);
     e.a_b[Q] = k_b;
     e.a_w[Q] = k_n - k_b;
 }
@@ -1054,7 +1132,7 @@ __device__ __forceinline__ void rqs_select(tile<1> (&acc)[4], rqs_elems &e, int 
 #endif
     const float inv = rqs_softmax<Q, KC>(acc, K);
     const int Kn = KC ? KC : K;
-    const int b = e.b[Q];
+    const int b = e.b[Q] & (RQS_OUT - 1);
     // only two knots are needed: select their cumulative sums in the sweep and rescale those two afterwards
     float cs = 0.f, cs_b = 0.f, cs_n = 0.f;
     bool has_b = false, has_n = false;
@@ -1081,9 +1159,11 @@ __device__ __forceinline__ float fast_log(float v) { return __builtin_amdgcn_log
 __device__ __forceinline__ float rqs_softplus(float v) { return v > 20.f ? v : fast_log(1.f + fast_exp(v)); }
 // phase 2: the two knot derivatives at the bin (:107,:206-207), then the rational-quadratic (:236-248) or its
 // inverse (:212-234; the returned log-derivative is already negated like the reference's).
-template <int Q, bool REV, int KC>
-__device__ __forceinline__ void rqs_eval(tile<1> (&acc)[4], const rqs_elems &e, int K, float &out, float &ljd) {
-    const int b = e.b[Q];
+template <int Q, bool REV, int KC, class H>
+__device__ __forceinline__ void rqs_eval(const f32x16 &u, const rqs_elems &e, int K, float &out, float &ljd, H &hk) {
+    hk.template pt<0>();
+    const int b = e.b[Q] & (RQS_OUT - 1);
+    const bool in = e.b[Q] < RQS_OUT;
     const int Kn = KC ? KC : K;
     const float cst = 0.5397424172369522f;                      // log(exp(1 - 1e-3) - 1), :81 boundary derivative constant
     float r_b = cst, r_n = cst;
@@ -1097,16 +1177,19 @@ __device__ __forceinline__ void rqs_eval(tile<1> (&acc)[4], const rqs_elems &e, 
         const bool m1 = b >= 4, m2 = b >= 8, m3 = b >= 12;
         // (named copies first: a select between two array elements is canonicalised into a select of ADDRESSES, which keeps
         //  the accumulator tiles in memory -- 384 B of scratch)
-        const float d0 = RQS_P(acc, Q, 0), d1 = RQS_P(acc, Q, 1), d2 = RQS_P(acc, Q, 2), d3 = RQS_P(acc, Q, 3), d4 = RQS_P(acc, Q, 4);
-        const float d5 = RQS_P(acc, Q, 5), d6 = RQS_P(acc, Q, 6), d7 = RQS_P(acc, Q, 7), d8 = RQS_P(acc, Q, 8), d9 = RQS_P(acc, Q, 9);
-        const float d10 = RQS_P(acc, Q, 10), d11 = RQS_P(acc, Q, 11), d12 = RQS_P(acc, Q, 12), d13 = RQS_P(acc, Q, 13), d14 = RQS_P(acc, Q, 14);
+        const float d0 = u[0], d1 = u[1], d2 = u[2], d3 = u[3], d4 = u[4];
+        const float d5 = u[5], d6 = u[6], d7 = u[7], d8 = u[8], d9 = u[9];
+        const float d10 = u[10], d11 = u[11], d12 = u[12], d13 = u[13], d14 = u[14];
         const float v0 = m3 ? d11 : (m2 ? d7 : (m1 ? d3 : cst)), v1 = m3 ? d12 : (m2 ? d8 : (m1 ? d4 : d0));
+        hk.template pt<1>();
         const float v2 = m3 ? d13 : (m2 ? d9 : (m1 ? d5 : d1)), v3 = m3 ? d14 : (m2 ? d10 : (m1 ? d6 : d2));
         const float v4 = m3 ? cst : (m2 ? d11 : (m1 ? d7 : d3));
+        hk.template pt<2>();
         const int bl = b & 3;
         const bool g1 = bl >= 1, g2 = bl >= 2, g3 = bl >= 3;
         r_b = g3 ? v3 : (g2 ? v2 : (g1 ? v1 : v0));
         r_n = g3 ? v4 : (g2 ? v3 : (g1 ? v2 : v1));
+        hk.template pt<3>();
     } else
 #endif
     {
@@ -1115,7 +1198,7 @@ __device__ __forceinline__ void rqs_eval(tile<1> (&acc)[4], const rqs_elems &e, 
     for (int k = 0; k < 15; ++k) {
         if (KC ? (k < KC - 1) : true) {
             const bool used = KC ? true : (k < Kn - 1);
-            const float v = RQS_P(acc, Q, k);
+            const float v = u[k];
             const bool is_next = (b == k + 1);
             r_n = (used && is_prev) ? v : r_n;          // k == b
             r_b = (used && is_next) ? v : r_b;          // k == b - 1
@@ -1123,36 +1206,57 @@ __device__ __forceinline__ void rqs_eval(tile<1> (&acc)[4], const rqs_elems &e, 
         }
     }
     }
-    const float d_b = RQS_MIN + rqs_softplus(r_b), d_n = RQS_MIN + rqs_softplus(r_n);
+    const float d_b = RQS_MIN + rqs_softplus(r_b);
+    hk.template pt<4>();
+    const float d_n = RQS_MIN + rqs_softplus(r_n);
+    hk.template pt<5>();
     // REV: the searched block is the heights (codomain side), the selected one the widths
     const float cw_b = REV ? e.c_b[Q] : e.a_b[Q], w_b = REV ? e.c_w[Q] : e.a_w[Q];
     const float ch_b = REV ? e.a_b[Q] : e.c_b[Q], h_b = REV ? e.a_w[Q] : e.c_w[Q];
     const float s_b = h_b * fast_rcp(w_b);
-    const float xin = e.in[Q] ? e.x[Q] : (REV ? ch_b : cw_b);
+    const float xin = in ? e.x[Q] : (REV ? ch_b : cw_b);
     if constexpr (REV) {
         const float dy = xin - ch_b;
         const float q = d_b + d_n - 2.f * s_b;
+        hk.template pt<6>();
         const float a = dy * q + h_b * (s_b - d_b);
         const float bb = h_b * d_b - dy * q;
         const float c = -s_b * dy;
         const float disc = bb * bb - 4.f * a * c;
-        const float root = (2.f * c) * fast_rcp(-bb - __builtin_amdgcn_sqrtf(disc));
+        hk.template pt<7>();
+        // (disc >= 0 in exact arithmetic -- the spline is monotone --; rounding can leave it a few ulps below zero where the root
+        //  sits on a knot and the reference's own fp32 evaluation stays at or above it: clamp instead of returning NaN, :223)
+        const float root = (2.f * c) * fast_rcp(-bb - __builtin_amdgcn_sqrtf(__builtin_fmaxf(disc, 0.f)));
         out = root * w_b + cw_b;
+        hk.template pt<8>();
         const float tomt = root * (1.f - root), omr = 1.f - root;
         const float den = s_b + q * tomt;
+        hk.template pt<9>();
         const float dnum = (s_b * s_b) * (d_n * (root * root) + 2.f * s_b * tomt + d_b * (omr * omr));
+        hk.template pt<10>();
         ljd = -fast_log(dnum) + 2.f * fast_log(den);
     } else {
         const float theta = (xin - cw_b) * fast_rcp(w_b);
+        hk.template pt<6>();
         const float tomt = theta * (1.f - theta), omt = 1.f - theta;
         const float num = h_b * (s_b * (theta * theta) + d_b * tomt);
+        hk.template pt<7>();
         const float den = s_b + (d_b + d_n - 2.f * s_b) * tomt;
         out = ch_b + num * fast_rcp(den);
+        hk.template pt<8>();
         const float dnum = (s_b * s_b) * (d_n * (theta * theta) + 2.f * s_b * tomt + d_b * (omt * omt));
+        hk.template pt<9>();
+        hk.template pt<10>();
         ljd = fast_log(dnum) - 2.f * fast_log(den);
     }
-    out = e.in[Q] ? out : e.x[Q];                               // :86-87 linear tails
-    ljd = e.in[Q] ? ljd : 0.f;
+    out = in ? out : e.x[Q];                                    // :86-87 linear tails
+    ljd = in ? ljd : 0.f;
+    hk.template pt<11>();
+}
+template <int Q, bool REV, int KC>
+__device__ __forceinline__ void rqs_eval(const f32x16 &u, const rqs_elems &e, int K, float &out, float &ljd) {
+    rqs_nohook nh;
+    rqs_eval<Q, REV, KC>(u, e, K, out, ljd, nh);
 }
 
 template <int TX, int HT, int KC>
@@ -1172,10 +1276,11 @@ __device__ __forceinline__ void rqs_phase_k(tile<1> (&acc)[4], tile<1> (&xs)[TX]
 #if !defined(SX_RQS_FLAT) && !defined(SX_RQS_OLD16)
         if constexpr (KC == 16) {
             const rqs16_c c = rqs16_consts(lo, hi);
-            rqs16_search<0>(acc, e, c); __builtin_amdgcn_sched_barrier(0);
-            rqs16_search<1>(acc, e, c); __builtin_amdgcn_sched_barrier(0);
-            rqs16_search<2>(acc, e, c); __builtin_amdgcn_sched_barrier(0);
-            rqs16_search<3>(acc, e, c);
+            rqs_nohook nh16;
+            rqs16_search<0>(acc[0].v[0], e, c, nh16); __builtin_amdgcn_sched_barrier(0);
+            rqs16_search<1>(acc[1].v[0], e, c, nh16); __builtin_amdgcn_sched_barrier(0);
+            rqs16_search<2>(acc[2].v[0], e, c, nh16); __builtin_amdgcn_sched_barrier(0);
+            rqs16_search<3>(acc[3].v[0], e, c, nh16);
         } else
 #endif
         {
@@ -1188,10 +1293,11 @@ __device__ __forceinline__ void rqs_phase_k(tile<1> (&acc)[4], tile<1> (&xs)[TX]
 #if !defined(SX_RQS_FLAT) && !defined(SX_RQS_OLD16)
         if constexpr (KC == 16) {
             const rqs16_c c = rqs16_consts(lo, hi);
-            rqs16_select<0>(acc, e, c); __builtin_amdgcn_sched_barrier(0);
-            rqs16_select<1>(acc, e, c); __builtin_amdgcn_sched_barrier(0);
-            rqs16_select<2>(acc, e, c); __builtin_amdgcn_sched_barrier(0);
-            rqs16_select<3>(acc, e, c);
+            rqs_nohook nh16;
+            rqs16_select<0>(acc[0].v[0], e, c, nh16); __builtin_amdgcn_sched_barrier(0);
+            rqs16_select<1>(acc[1].v[0], e, c, nh16); __builtin_amdgcn_sched_barrier(0);
+            rqs16_select<2>(acc[2].v[0], e, c, nh16); __builtin_amdgcn_sched_barrier(0);
+            rqs16_select<3>(acc[3].v[0], e, c, nh16);
         } else
 #endif
         {
@@ -1203,15 +1309,15 @@ __device__ __forceinline__ void rqs_phase_k(tile<1> (&acc)[4], tile<1> (&xs)[TX]
     } else {
         float out[4], lj[4];
         if (st.reverse) {
-            rqs_eval<0, true, KC>(acc, e, K, out[0], lj[0]);
-            rqs_eval<1, true, KC>(acc, e, K, out[1], lj[1]);
-            rqs_eval<2, true, KC>(acc, e, K, out[2], lj[2]);
-            rqs_eval<3, true, KC>(acc, e, K, out[3], lj[3]);
+            rqs_eval<0, true, KC>(acc[0].v[0], e, K, out[0], lj[0]);
+            rqs_eval<1, true, KC>(acc[1].v[0], e, K, out[1], lj[1]);
+            rqs_eval<2, true, KC>(acc[2].v[0], e, K, out[2], lj[2]);
+            rqs_eval<3, true, KC>(acc[3].v[0], e, K, out[3], lj[3]);
         } else {
-            rqs_eval<0, false, KC>(acc, e, K, out[0], lj[0]);
-            rqs_eval<1, false, KC>(acc, e, K, out[1], lj[1]);
-            rqs_eval<2, false, KC>(acc, e, K, out[2], lj[2]);
-            rqs_eval<3, false, KC>(acc, e, K, out[3], lj[3]);
+            rqs_eval<0, false, KC>(acc[0].v[0], e, K, out[0], lj[0]);
+            rqs_eval<1, false, KC>(acc[1].v[0], e, K, out[1], lj[1]);
+            rqs_eval<2, false, KC>(acc[2].v[0], e, K, out[2], lj[2]);
+            rqs_eval<3, false, KC>(acc[3].v[0], e, K, out[3], lj[3]);
         }
         float s = 0.f;
 #pragma unroll
@@ -1234,7 +1340,7 @@ __device__ __forceinline__ void rqs_phase_k(tile<1> (&acc)[4], tile<1> (&xs)[TX]
 
 template <int TX, int HT>
 __device__ __forceinline__ void rqs_phase(tile<1> (&xs)[TX], const btile<1> (&bh)[HT], rqs_elems &e, const wptr w,
-                                          const dstep &st, float &ldj, int lane) {
+                                          const dstep &st, float &ldj, int lane, bool &group_lean) {
     const int h = lane >> 5;
     tile<1> acc[4];
     rqs_gemm<HT>(w, bh, acc);
@@ -1242,8 +1348,10 @@ __device__ __forceinline__ void rqs_phase(tile<1> (&xs)[TX], const btile<1> (&bh
     const float hi = *reinterpret_cast<const float *>(w.cb - h * 64 + (4 * HT * 1024 + 129) * 4);
     // the straight-line K = 16 code needs the step's logits bounded (no running maximum in its softmax: see rqs16_sums); the
     // packer leaves the bound of the rows it packed behind the spline bounds (the derivative block's slot stays 0)
+    // (one bound per group, in its FIRST block's blob: the decision made there holds for the group's select block as well)
     const float bound = *reinterpret_cast<const float *>(w.cb - h * 64 + (4 * HT * 1024 + 130) * 4);
-    const bool lean = __builtin_amdgcn_readfirstlane((int)(bound < RQS16_BOUND)) != 0;
+    if (st.ct == 0) group_lean = __builtin_amdgcn_readfirstlane((int)(bound < RQS16_BOUND)) != 0;
+    const bool lean = st.ct == 2 || group_lean;
     if (st.tt == 16 && lean) rqs_phase_k<TX, HT, 16>(acc, xs, e, st, lo, hi, ldj, h);
     else rqs_phase_k<TX, HT, 0>(acc, xs, e, st, lo, hi, ldj, h);
 }
@@ -1277,82 +1385,116 @@ __device__ __forceinline__ void rqs_phase(tile<1> (&xs)[TX], const btile<1> (&bh
 // (the empty asm keeps each arm a real scalar branch: folded into selects the switch is the 32-select form again)
 #define RQS_FETCH(T, G) { asm volatile("" ::: "memory"); _Pragma("unroll") for (int q = 0; q < 4; ++q) e.x[q] = xs[T].v[0][4 * G + q]; }
 #define RQS_STORE(T, G) { asm volatile("" ::: "memory"); _Pragma("unroll") for (int q = 0; q < 4; ++q) xs[T].v[0][4 * G + q] = out[q]; }
+// lo, hi and the logit bound of a block's blob
 template <int HT>
-__device__ __forceinline__ void rqs_block(const wptr w, const btile<1> (&bh)[HT], tile<1> (&acc)[4], int h, float &lo, float &hi, bool &lean) {
-    rqs_gemm<HT>(w, bh, acc);
+__device__ __forceinline__ void rqs_block_scalars(const wptr w, int h, float &lo, float &hi, bool &lean) {
     lo = *reinterpret_cast<const float *>(w.cb - h * 64 + (4 * HT * 1024 + 128) * 4);
     hi = *reinterpret_cast<const float *>(w.cb - h * 64 + (4 * HT * 1024 + 129) * 4);
     const float bound = *reinterpret_cast<const float *>(w.cb - h * 64 + (4 * HT * 1024 + 130) * 4);
     lean = __builtin_amdgcn_readfirstlane((int)(bound < RQS16_BOUND)) != 0;
 }
+// One block of the K = 16 hot path, software-pipelined over the four elements: the MFMAs of element q + 1's tile are issued from
+// inside the arithmetic of element q (rqs_tile_pipe; two accumulator tiles alternate).  PH: 0 search, 1 select, 2 evaluate.
+// (A pipeline over the whole group -- the next block's first tile beside this block's last element, with the step advance in
+//  between, and the bias / first fragments of tile q + 2 requested from element q -- was built and measured: the in-kernel stamps
+//  moved (first tiles 25 % -> 8 % of the wave cycles, last elements 8 % -> 4 %) but the kernel did not (5.31 -> 5.36 ms per 2^20
+//  rows): what one wave leaves idle the SIMD's other wave was already using.  It cost 41 registers and is not kept.)
+template <int PH, bool REV, int Q, class H>
+__device__ __forceinline__ void rqs16_unit(const f32x16 &u, rqs_elems &e, const rqs16_c &c, float (&out)[4], float (&lj)[4], H &hk) {
+    if constexpr (PH == 0) rqs16_search<Q>(u, e, c, hk);
+    else if constexpr (PH == 1) rqs16_select<Q>(u, e, c, hk);
+    else rqs_eval<Q, REV, 16>(u, e, 16, out[Q], lj[Q], hk);
+}
+template <int HT, int PH, bool REV>
+__device__ __forceinline__ void rqs16_block(const wptr w, const btile<1> (&bh)[HT], rqs_elems &e, const rqs16_c &c, float (&out)[4],
+                                            float (&lj)[4], prof_t &pf) {
+    tile<1> A, B;
+    {   // tile 0: nothing to run beside it yet
+        A = load_cfrag<1>(w.cb, 4 * HT * 1024);
+#pragma unroll
+        for (int m = 0; m < HT; ++m) gemm_tile<1>(w.wb, m * 1024, bh[m], A);
+    }
+    SX_STAMP(pf, 3);     // a block's first tile (not overlapped)
+    { rqs_tile_pipe<HT, 1> p(w, bh, B); p.start(); rqs16_unit<PH, REV, 0>(A.v[0], e, c, out, lj, p); }
+    { rqs_tile_pipe<HT, 2> p(w, bh, A); p.start(); rqs16_unit<PH, REV, 1>(B.v[0], e, c, out, lj, p); }
+    { rqs_tile_pipe<HT, 3> p(w, bh, B); p.start(); rqs16_unit<PH, REV, 2>(A.v[0], e, c, out, lj, p); }
+    SX_STAMP(pf, 4);     // three (tile GEMM, element) pairs
+    { rqs_nohook nh; rqs16_unit<PH, REV, 3>(B.v[0], e, c, out, lj, nh); }
+    SX_STAMP(pf, 5);     // the last element (no MFMAs beside it)
+}
 template <int TX, int HT, class ADV>
 __device__ __forceinline__ void rqs_triple(tile<1> (&xs)[TX], const btile<1> (&bh)[HT], const wptr w0, const dstep &st0, float &ldj,
-                                           int lane, ADV &&advance) {
+                                           int lane, ADV &&advance, prof_t &pf) {
     const int h = lane >> 5;
     const int K = st0.tt, tg = 4 * st0.t0 + st0.c0;
     rqs_elems e;
-    tile<1> acc[4];
-    float lo, hi;
+    float lo, hi, out[4], lj[4];
     bool lean;
-    // block 0: the searched sequence
-    rqs_block<HT>(w0, bh, acc, h, lo, hi, lean);
+    uint32_t live_mask;     // of the group's last step (the evaluation): scalars, not the descriptor -- a struct merged from the two
+    float ldj_scale;        // paths below is a stack object
     RQS_GROUP_CASES(RQS_FETCH)
+    rqs_block_scalars<HT>(w0, h, lo, hi, lean);     // (the bound in the first block's blob covers both softmax blocks of the group)
     if (K == 16 && lean) {
-        const rqs16_c c = rqs16_consts(lo, hi);
-        rqs16_search<0>(acc, e, c); __builtin_amdgcn_sched_barrier(0);
-        rqs16_search<1>(acc, e, c); __builtin_amdgcn_sched_barrier(0);
-        rqs16_search<2>(acc, e, c); __builtin_amdgcn_sched_barrier(0);
-        rqs16_search<3>(acc, e, c);
+        wptr w;
+        dstep st;
+        rqs16_block<HT, 0, false>(w0, bh, e, rqs16_consts(lo, hi), out, lj, pf);
+        advance(st, w);
+        rqs_block_scalars<HT>(w, h, lo, hi, lean);
+        const rqs16_c c1 = rqs16_consts(lo, hi);
+        rqs16_block<HT, 1, false>(w, bh, e, c1, out, lj, pf);
+        advance(st, w);
+        if (st.reverse) rqs16_block<HT, 2, true>(w, bh, e, c1, out, lj, pf);
+        else rqs16_block<HT, 2, false>(w, bh, e, c1, out, lj, pf);
+        live_mask = st.mask; ldj_scale = st.ldj_scale;
     } else {
-        rqs_search<0, 0>(acc, e, K, lo, hi); rqs_search<1, 0>(acc, e, K, lo, hi);
-        rqs_search<2, 0>(acc, e, K, lo, hi); rqs_search<3, 0>(acc, e, K, lo, hi);
-    }
-    // block 1: the other sequence at the found bin
-    dstep st;
-    wptr w;
-    advance(st, w);
-    rqs_block<HT>(w, bh, acc, h, lo, hi, lean);
-    if (K == 16 && lean) {
-        const rqs16_c c = rqs16_consts(lo, hi);
-        rqs16_select<0>(acc, e, c); __builtin_amdgcn_sched_barrier(0);
-        rqs16_select<1>(acc, e, c); __builtin_amdgcn_sched_barrier(0);
-        rqs16_select<2>(acc, e, c); __builtin_amdgcn_sched_barrier(0);
-        rqs16_select<3>(acc, e, c);
-    } else {
-        rqs_select<0, 0>(acc, e, K, lo, hi); rqs_select<1, 0>(acc, e, K, lo, hi);
-        rqs_select<2, 0>(acc, e, K, lo, hi); rqs_select<3, 0>(acc, e, K, lo, hi);
-    }
-    // block 2: the derivatives, the rational-quadratic and the group's outputs
-    advance(st, w);
-    rqs_gemm<HT>(w, bh, acc);
-    float out[4], lj[4];
-    if (K == 16) {
+        // any bin count, softmax with its running maximum: block by block, one element at a time (interleaved by the scheduler the
+        // four sweeps keep ~60 lane masks alive: hundreds of SGPR spills and nine VGPRs of spill lanes in the whole kernel)
+        // (the empty asm pins each element's results where they are computed: without it the optimizer sinks all four sweeps of a
+        //  block below the step advance that follows, and the register allocation of the whole kernel pays for that)
+#define RQS_PIN3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); __builtin_amdgcn_sched_barrier(0)
+#define RQS_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b)); __builtin_amdgcn_sched_barrier(0)
+        wptr w;
+        dstep st;
+        tile<1> acc[4];
+        rqs_gemm<HT>(w0, bh, acc);
+        rqs_search<0, 0>(acc, e, K, lo, hi); RQS_PIN3(e.b[0], e.a_b[0], e.a_w[0]);
+        rqs_search<1, 0>(acc, e, K, lo, hi); RQS_PIN3(e.b[1], e.a_b[1], e.a_w[1]);
+        rqs_search<2, 0>(acc, e, K, lo, hi); RQS_PIN3(e.b[2], e.a_b[2], e.a_w[2]);
+        rqs_search<3, 0>(acc, e, K, lo, hi); RQS_PIN3(e.b[3], e.a_b[3], e.a_w[3]);
+        advance(st, w);
+        rqs_block_scalars<HT>(w, h, lo, hi, lean);
+        rqs_gemm<HT>(w, bh, acc);
+        rqs_select<0, 0>(acc, e, K, lo, hi); RQS_PIN2(e.c_b[0], e.c_w[0]);
+        rqs_select<1, 0>(acc, e, K, lo, hi); RQS_PIN2(e.c_b[1], e.c_w[1]);
+        rqs_select<2, 0>(acc, e, K, lo, hi); RQS_PIN2(e.c_b[2], e.c_w[2]);
+        rqs_select<3, 0>(acc, e, K, lo, hi); RQS_PIN2(e.c_b[3], e.c_w[3]);
+        advance(st, w);
+        rqs_gemm<HT>(w, bh, acc);
         if (st.reverse) {
-            rqs_eval<0, true, 16>(acc, e, K, out[0], lj[0]); rqs_eval<1, true, 16>(acc, e, K, out[1], lj[1]);
-            rqs_eval<2, true, 16>(acc, e, K, out[2], lj[2]); rqs_eval<3, true, 16>(acc, e, K, out[3], lj[3]);
+            rqs_eval<0, true, 0>(acc[0].v[0], e, K, out[0], lj[0]); RQS_PIN2(out[0], lj[0]);
+            rqs_eval<1, true, 0>(acc[1].v[0], e, K, out[1], lj[1]); RQS_PIN2(out[1], lj[1]);
+            rqs_eval<2, true, 0>(acc[2].v[0], e, K, out[2], lj[2]); RQS_PIN2(out[2], lj[2]);
+            rqs_eval<3, true, 0>(acc[3].v[0], e, K, out[3], lj[3]);
         } else {
-            rqs_eval<0, false, 16>(acc, e, K, out[0], lj[0]); rqs_eval<1, false, 16>(acc, e, K, out[1], lj[1]);
-            rqs_eval<2, false, 16>(acc, e, K, out[2], lj[2]); rqs_eval<3, false, 16>(acc, e, K, out[3], lj[3]);
+            rqs_eval<0, false, 0>(acc[0].v[0], e, K, out[0], lj[0]); RQS_PIN2(out[0], lj[0]);
+            rqs_eval<1, false, 0>(acc[1].v[0], e, K, out[1], lj[1]); RQS_PIN2(out[1], lj[1]);
+            rqs_eval<2, false, 0>(acc[2].v[0], e, K, out[2], lj[2]); RQS_PIN2(out[2], lj[2]);
+            rqs_eval<3, false, 0>(acc[3].v[0], e, K, out[3], lj[3]);
         }
-    } else {
-        if (st.reverse) {
-            rqs_eval<0, true, 0>(acc, e, K, out[0], lj[0]); rqs_eval<1, true, 0>(acc, e, K, out[1], lj[1]);
-            rqs_eval<2, true, 0>(acc, e, K, out[2], lj[2]); rqs_eval<3, true, 0>(acc, e, K, out[3], lj[3]);
-        } else {
-            rqs_eval<0, false, 0>(acc, e, K, out[0], lj[0]); rqs_eval<1, false, 0>(acc, e, K, out[1], lj[1]);
-            rqs_eval<2, false, 0>(acc, e, K, out[2], lj[2]); rqs_eval<3, false, 0>(acc, e, K, out[3], lj[3]);
-        }
+#undef RQS_PIN3
+#undef RQS_PIN2
+        live_mask = st.mask; ldj_scale = st.ldj_scale;
     }
     float sl = 0.f;
     const int g = st0.c0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const bool live = (st.mask >> (q + 8 * g + 4 * h)) & 1u;     // slot kmap(4g+q, h) of the tile
+        const bool live = (live_mask >> (q + 8 * g + 4 * h)) & 1u;     // slot kmap(4g+q, h) of the tile
         out[q] = live ? out[q] : e.x[q];
         sl += live ? lj[q] : 0.f;
     }
     RQS_GROUP_CASES(RQS_STORE)
-    ldj += st.ldj_scale * sl;
+    ldj += ldj_scale * sl;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2291,6 +2433,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
         btile<1> rq_bh[(RQ || MIX) ? HT : 1];             // hidden B operands + group state
         std::conditional_t<(CUB || MIXC), cubic_elems, rqs_elems> rq_e;
         [[maybe_unused]] std::conditional_t<(MODE == 14), cubic_elems, int> rq_ec;     // MODE 14 keeps both kinds of group state
+        [[maybe_unused]] bool rq_lean = true;             // mixed programs: the current rational-quadratic group runs the bounded-logit code
 
         for (int s = 0; s < n_steps; ++s) {
             // (1) this step's weights were issued one step ago (or in the prologue): wait for MY pieces, then
@@ -2721,21 +2864,23 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     break;
                 case SX_STEP_RQS_PHASE:
                     if constexpr (MIXC && NS == 1) cubic_phase<TX, HT>(xs, rq_bh, rq_e, w, st, ldj[0], lane);
-                    else if constexpr (MIXQ && NS == 1) rqs_phase<TX, HT>(xs, rq_bh, rq_e, w, st, ldj[0], lane);
-                    else if constexpr (MIX && NS == 1) {
+                    else if constexpr (MODE == 14 && NS == 1) {
                         if (st.act == 1) cubic_phase<TX, HT>(xs, rq_bh, rq_ec, w, st, ldj[0], lane);
-                        else rqs_phase<TX, HT>(xs, rq_bh, rq_e, w, st, ldj[0], lane);
+                        else rqs_phase<TX, HT>(xs, rq_bh, rq_e, w, st, ldj[0], lane, rq_lean);
                     } else
                     if constexpr (CUB && NS == 1) cubic_phase<TX, HT>(xs, rq_bh, rq_e, w, st, ldj[0], lane);
+                    else if constexpr (MIXQ && NS == 1) rqs_phase<TX, HT>(xs, rq_bh, rq_e, w, st, ldj[0], lane, rq_lean);     // (the triple form below was tried here: 320 B of scratch instead of 128)
                     else if constexpr (RQ && NS == 1) {
                         // the group's three blocks in this one iteration (the host plans them back to back, the launcher checks it)
                         auto advance = [&](dstep &stn, wptr &wn) {
+                            SX_STAMP(pf, 6);
                             ldj_c += st_cur_const;
                             cur ^= 1;
                             ++s;
                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                             __builtin_amdgcn_s_barrier();
+                            SX_STAMP(pf, 1);     // wait for weights + barrier
                             stn = st_next;
                             st_cur_const = stn.ldj_const;
                             int wb2 = cur * buf_floats * 4 + lane * 16, cb2 = cur * buf_floats * 4 + (lane >> 5) * 64;
@@ -2746,8 +2891,9 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                             dma_off = prog.steps[nb2].blob_off;
                             dma_floats = prog.steps[nb2].blob_floats;
                             wn = wptr{reinterpret_cast<const char *>(smem) + wb2, reinterpret_cast<const char *>(smem) + cb2};
+                            SX_STAMP(pf, 2);     // descriptor + DMA issue
                         };
-                        rqs_triple<TX, HT>(xs, rq_bh, w, st, ldj[0], lane, advance);
+                        rqs_triple<TX, HT>(xs, rq_bh, w, st, ldj[0], lane, advance, pf);
                     }
                     break;
                 case SX_STEP_ROW_SCALE_EXP:
@@ -3036,7 +3182,7 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
         (void)hipStreamSynchronize(a.stream);
         unsigned long long p[16];
         (void)hipMemcpyFromSymbol(p, HIP_SYMBOL(g_sx_prof), sizeof(p));
-        static const char *names[8] = {"chunk-prologue", "wait+barrier", "desc+dma-issue", "gemm1", "gemm2", "affine", "step-tail", "epilogue"};
+        static const char *names[8] = {"chunk-prologue", "wait+barrier", "desc+dma-issue", "gemm1 / spline block: first tile", "gemm2 / spline block: 3 pairs", "affine / spline block: last element", "step-tail", "epilogue"};
         unsigned long long tot = 0;
         for (int i = 0; i < 8; ++i) tot += p[i];
         fprintf(stderr, "[sx prof] wave 1 of block 3, cycles:");

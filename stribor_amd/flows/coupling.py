@@ -98,8 +98,7 @@ class Coupling(Transform):
         lat2 = None if latent is None else latent.reshape(-1, latent.shape[-1])
         ld = 0 if lat2 is None else lat2.shape[1]
         from .spline import Spline
-        if not isinstance(self.transform, (Affine, Spline)):
-            raise NotImplementedError(f'Coupling({type(self.transform).__name__}) is not on the hot path')
+        assert isinstance(self.transform, (Affine, Spline))            # (anything else: the `_wrapped` tier, see forward)
         if self.set_data:
             if x.dim() < 2:
                 raise ValueError('set_data=True needs inputs of shape (..., N, dim)')
@@ -339,10 +338,9 @@ class Coupling(Transform):
 
     # ---- training (autograd): spline couplings, inverse direction --------------------------------------------------
     def _autograd_supported(self) -> bool:
-        from .spline import Spline
-        if getattr(self.transform, 'latent_net', None) is None:
-            return False
-        return isinstance(self.transform, (Affine, Spline))
+        if self._wraps_other():            # the wrapped transform's own ops carry the graph (see _wrapped)
+            return isinstance(self.transform, torch.nn.Module) and not self.set_data
+        return True
 
     def _autograd_set(self, x2: torch.Tensor, lat2, set_size: int, reverse: bool):
         """set_data=True with a graph (coupling.py:48-53, 61, 78, 95): the transformed set elements are gathered into compact rows,
@@ -381,6 +379,9 @@ class Coupling(Transform):
         Returns (x_out [N, D], ldj [N])."""
         from .spline import CubicForward, CubicInverse, RQSForward, RQSInverse, Spline
         from .affine import AffineCouplingOp
+        if self._wraps_other():
+            y, ldj = self._wrapped(x2, lat2, reverse, True, True, reverse)
+            return y, ldj.reshape(-1)
         sp, net = self.transform, self.transform.latent_net
         is_spline = isinstance(sp, Spline)
         n, d = x2.shape
@@ -545,27 +546,73 @@ class Coupling(Transform):
             y, ldj = self._autograd_inverse(x2, lat2, reverse=reverse)
         return y.reshape(*lead, x2.shape[1]), ldj.reshape(*lead, 1)
 
+    # ---- any other ElementwiseTransform (coupling.py:10-46,74-76,94): the reference's op sequence around the wrapped transform --
+    def _wraps_other(self) -> bool:
+        """The wrapped transform is not an Affine / Spline driven by a conditioner: e.g. Coupling(st.Sigmoid(), mask) or
+        Coupling(st.Affine(dim), mask) without a latent_net.  The reference calls transform(x, latent=z), transform.inverse(x,
+        latent=z) and transform.log_diag_jacobian(x, y, latent=z) on whatever it wraps; so does this tier: the wrapped transform runs
+        its own kernels (sx_pointwise, sx_affine_coupling, ...), the mask blend is three element-wise torch ops, and the whole of
+        it is differentiable through the wrapped transform's own autograd ops."""
+        from .spline import Spline
+        return not isinstance(self.transform, (Affine, Spline)) or getattr(self.transform, 'latent_net', None) is None
+
+    def _wrapped(self, x, latent, reverse: bool, want_y: bool, want_ldj: bool, negate: bool, **kwargs):
+        _hip.require_device(x, 'x')
+        if self.set_data and x.dim() < 2:
+            raise ValueError('set_data=True needs inputs of shape (..., N, dim)')
+        mask = self._get_mask(x)                                                       # coupling.py:48-53
+
+        def conditioning(v):
+            z = v * mask                                                               # coupling.py:61
+            if v.shape[-1] == 1:
+                z = z * 0                                                              # coupling.py:62-63
+            return z if latent is None else torch.cat([z, latent.to(z.dtype)], -1)     # coupling.py:64-65
+        z = conditioning(x)
+        t = self.transform
+        if not want_y:                                                                 # log_det_jacobian(x, y): y is never read
+            ld = t.log_diag_jacobian(x, None, latent=z, **kwargs)                      # coupling.py:94
+            return None, (ld * (1 - mask)).sum(-1, keepdim=True)
+        y_ = t.inverse(x, latent=z, **kwargs) if reverse else t(x, latent=z, **kwargs)     # coupling.py:74-76
+        y = y_ * (1 - mask) + x * mask                                                 # coupling.py:78
+        if not want_ldj:
+            return y, None
+        # forward: log_det_jacobian(x, y); inverse: flow.py:42-47 -- x = inverse(y), then log_det_jacobian(x, y), negated
+        a, b = (y, x) if reverse else (x, y)
+        ld = t.log_diag_jacobian(a, b, latent=conditioning(a) if reverse else z, **kwargs)
+        ldj = (ld * (1 - mask)).sum(-1, keepdim=True)
+        return y, (-ldj if negate else ldj)
+
     def forward(self, x, latent=None, reverse: bool = False, **kwargs):
+        if self._wraps_other():
+            return self._wrapped(x, latent, reverse, True, False, False, **kwargs)[0]
         if graph_wanted(self, x, latent):
             return self._graph(x, latent, reverse)[0]
         return self._run(x, latent, reverse, True, False)[0]
 
     def inverse(self, y, latent=None, **kwargs):
+        if self._wraps_other():
+            return self._wrapped(y, latent, True, True, False, False, **kwargs)[0]
         if graph_wanted(self, y, latent):
             return self._graph(y, latent, True)[0]
         return self._run(y, latent, True, True, False)[0]                            # coupling.py:81-82 (Q3)
 
     def log_det_jacobian(self, x, y=None, latent=None, **kwargs):
+        if self._wraps_other():
+            return self._wrapped(x, latent, False, False, True, False, **kwargs)[1]
         if graph_wanted(self, x, latent):
             return self._graph(x, latent, False)[1]
         return self._run(x, latent, False, False, True)[1]
 
     def forward_and_log_det_jacobian(self, x, latent=None, **kwargs):
+        if self._wraps_other():
+            return self._wrapped(x, latent, False, True, True, False, **kwargs)
         if graph_wanted(self, x, latent):
             return self._graph(x, latent, False)
         return self._run(x, latent, False, True, True)
 
     def inverse_and_log_det_jacobian(self, y, latent=None, **kwargs):
+        if self._wraps_other():
+            return self._wrapped(y, latent, True, True, True, True, **kwargs)
         if graph_wanted(self, y, latent):
             return self._graph(y, latent, True)
         if isinstance(self.transform, Affine):

@@ -23,6 +23,8 @@ from typing import Callable, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
+from abc import ABCMeta
+
 from . import _hip
 
 ALLOWED_TILES = (1, 2, 4)
@@ -32,12 +34,16 @@ ALLOWED_TILES = (1, 2, 4)
 # A built program bakes plan-time facts into host tables: which transforms a flow holds and in which order, every
 # Permute's index vector (slot relabelling), masks, which Parameter objects feed which pack job.  Parameter VALUES are
 # tracked per job ((data_ptr, _version) -> re-pack); everything else is covered by
-#   * a process-wide structure epoch, bumped whenever a module / parameter / buffer / public attribute of one of this
-#     package's modules is (re)assigned or deleted (`StructureTracked.__setattr__`), and
+#   * a process-wide structure epoch, bumped whenever a module / parameter / buffer of one of this package's modules is
+#     (re)assigned or deleted, or an attribute the module's constructor DECLARED is re-assigned (`StructureTracked.__setattr__`:
+#     mask names, bin counts, bounds, flags -- whatever __init__ set is what a planner may have read), and
 #   * guard tensors (buffers read at plan time, e.g. Permute.permutation): (data_ptr, _version) snapshots, so an
 #     in-place `load_state_dict` or a `.to()` re-plans, and
 #   * an owner-supplied fingerprint (NormalizingFlow: the ids of its transforms, which ModuleList can change without
 #     passing through any __setattr__ of ours).
+# Structure events are rare (model surgery), so one process-wide counter keeps the per-call validity check at one integer
+# compare; what is NOT an event: attributes a user hangs on a module after construction (`flow.step = i` in a training loop
+# used to re-plan every flow of the process on every call) and tensors a forward pre-hook recomputes.
 _STRUCT_EPOCH = [0]
 
 
@@ -45,24 +51,43 @@ def bump_structure_epoch() -> None:
     _STRUCT_EPOCH[0] += 1
 
 
-class StructureTracked:
+class _TrackedMeta(ABCMeta):
+    """Records, once __init__ has returned, which plain attributes the constructor declared (`_sx_declared`)."""
+
+    def __call__(cls, *args, **kwargs):
+        obj = super().__call__(*args, **kwargs)
+        object.__setattr__(obj, '_sx_declared', frozenset(k for k in obj.__dict__ if not k.startswith('_')))
+        return obj
+
+
+class StructureTracked(metaclass=_TrackedMeta):
     """Mixin for nn.Module subclasses whose attributes are read at plan time."""
 
     _UNTRACKED = ('training',)
 
     def __setattr__(self, name, value):
         if not name.startswith('_') and name not in StructureTracked._UNTRACKED:
-            # a plain tensor (not a Parameter) assigned to a name that is neither a registered parameter nor a buffer is a value a
-            # forward pre-hook recomputes on every call (torch's spectral_norm: setattr(module, 'weight', w / sigma)); such wrapped
-            # layers never join fused programs, and bumping the process-wide epoch per forward would re-plan every flow each step
-            hook_value = (torch.is_tensor(value) and not isinstance(value, torch.nn.Parameter)
-                          and name not in self.__dict__.get('_parameters', ()) and name not in self.__dict__.get('_buffers', ()))
-            if not hook_value:
+            d = self.__dict__
+            registered = name in d.get('_parameters', ()) or name in d.get('_buffers', ()) or name in d.get('_modules', ())
+            if torch.is_tensor(value) or isinstance(value, torch.nn.Module):
+                # a plain tensor (not a Parameter) assigned to a name that is neither a registered parameter nor a buffer is a value
+                # a forward pre-hook recomputes on every call (torch's spectral_norm: setattr(module, 'weight', w / sigma)); such
+                # wrapped layers never join fused programs
+                hook_value = torch.is_tensor(value) and not isinstance(value, torch.nn.Parameter) and not registered
+                if not hook_value:
+                    _STRUCT_EPOCH[0] += 1
+            elif registered or name in d.get('_sx_declared', ()) or '_sx_declared' not in d and name in d:
+                # a registered slot set to None / replaced by a non-tensor, or a declared attribute re-assigned
+                # (during __init__ itself nothing can have been planned from this object yet, but a re-assignment inside a
+                #  constructor of an attribute the BASE class set is kept an event: cheap, and obviously safe)
                 _STRUCT_EPOCH[0] += 1
         super().__setattr__(name, value)
 
     def __delattr__(self, name):
-        _STRUCT_EPOCH[0] += 1
+        d = self.__dict__
+        if (name in d.get('_parameters', ()) or name in d.get('_buffers', ()) or name in d.get('_modules', ())
+                or name in d.get('_sx_declared', ()) or '_sx_declared' not in d):
+            _STRUCT_EPOCH[0] += 1
         super().__delattr__(name)
 
 
@@ -314,6 +339,7 @@ class CompiledProgram:
         self.out_col = None if out_col is None else torch.from_numpy(out_col.astype(np.int32)).to(device)
         self.mlp_out_dim = mlp_out_dim
         self.mlp_col0 = 0                       # first output column of this launch's window (chunked MLP programs)
+        self.accumulates = False                # the launch adds into mlp_out instead of writing it
         self._tracked = None
         self._owner = None
 
@@ -405,6 +431,8 @@ class CompiledProgram:
                 if rc != 0:
                     work.zero_()                    # a failed launch may leave the ticket pair armed
                 _hip.check(rc, 'sx_flow_run')
+                if mode != 'auto':
+                    _hip.after_launch()             # STRIBOR_SYNC_ERRORS: the data-dependent error leaves THIS call
 
             if mode == 'exact':
                 launch(_hip.GEMM_F32)
@@ -412,6 +440,9 @@ class CompiledProgram:
                 launch(_hip.GEMM_F16X3)
             else:                                   # 'auto': never hand back a NaN-poisoned result
                 keep = None if sum_out is None else sum_out.clone()
+                # an accumulating launch (mlp_out += chunk) is not idempotent: the exact re-run must start from what the output
+                # held BEFORE the fp16 x 3 attempt, or the unflagged rows get the chunk's contribution twice
+                keep_out = mlp_out.clone() if (self.accumulates and mlp_out is not None) else None
                 torch.cuda.current_stream().synchronize()
                 _hip.poll_errors()                  # a flag an EARLIER call left behind is that call's: raise it, do not swallow it
                 launch(_hip.GEMM_F16X3)
@@ -419,6 +450,8 @@ class CompiledProgram:
                 if _hip.take_flag(x.device, _hip.FLAG_F16_RANGE):
                     if keep is not None:
                         sum_out.copy_(keep)
+                    if keep_out is not None:
+                        mlp_out.copy_(keep_out)
                     launch(_hip.GEMM_F32)
         return y, ldj, logp
 
@@ -747,28 +780,30 @@ class ProgramBuilder:
             for g in range(4):
                 if not any((live_mask >> (q + 8 * g + 4 * h)) & 1 for q in range(4) for h in range(2)):
                     continue
+                bound_slot = None
                 for phase, (start, count, lo, hi) in enumerate(blocks):
+                    # output tile q of the step = the 16 parameters of the lane's element q (slot q + 8 g + 4 h of the state tile):
+                    # register k of lane half h is row kmap(k, h) of the tile (sx_flow_kernel.h RQS_P)
                     rows = np.full(128, -1, dtype=np.int64)
-                    for u in range(4):
-                        for q in range(4):
-                            for h in range(2):
-                                slot = 32 * t + q + 8 * g + 4 * h
-                                if not slot_live[slot]:
-                                    continue
-                                for i in range(4):
-                                    k = 4 * u + i
-                                    if k < count:
-                                        rows[32 * u + 8 * q + 4 * h + i] = col[slot] * P + start + k
+                    for q in range(4):
+                        for h in range(2):
+                            slot = 32 * t + q + 8 * g + 4 * h
+                            if not slot_live[slot]:
+                                continue
+                            for k in range(min(count, 16)):
+                                rows[32 * q + _kmap(k, h)] = col[slot] * P + start + k
                     nlin = _hip.packed_linear_floats(4, HT)
                     off, n = self._alloc(nlin + 4)
                     # the two softmax blocks are packed in base 2 (rows and bias times log2 e): the kernel's softmax is then
                     # v_exp_f32(p - max) with no multiply (32 instructions per element)
                     sc2 = LOG2E if phase < 2 else 1.0
-                    # (the two softmax blocks also leave the bound on their logits in the slot behind (lo, hi): the K = 16 phases
-                    #  run without a running maximum below it -- sx_flow_kernel.h rqs16_sums; the blob buffer starts zeroed and
-                    #  the slot only grows)
+                    # (the two softmax blocks of a group leave the bound on their logits in the slot behind (lo, hi) of the FIRST
+                    #  block's blob: the K = 16 phases run without a running maximum below it -- sx_flow_kernel.h rqs16_sums --
+                    #  and the kernel decides once per group; the blob buffer starts zeroed and the slot only grows)
+                    if phase == 0:
+                        bound_slot = off + nlin + 2
                     self.jobs.append(_PackJob(W2, b2, rows, col2, 4, HT, off, np.full(128, -2.0 * sc2), np.full(128, sc2), 1.0,
-                                              bound_off=(off + nlin + 2) if (phase < 2 and not cubic) else None))
+                                              bound_off=bound_slot if (phase < 2 and not cubic) else None))
                     self.jobs.append(_ScalarsJob([lo, hi], off + nlin))
                     s_scale = (-ldj_scale if reverse else ldj_scale) if phase == 2 else 0.0
                     step = dict(kind=_hip.STEP_RQS_PHASE, c0=g, ct=phase, t0=t, tt=K, reverse=int(reverse), act=int(cubic),
@@ -1117,5 +1152,8 @@ class ProgramBuilder:
             st = prog.steps[i]
             for k, v in s.items():
                 setattr(st, k, v)
-        return CompiledProgram(prog, self.blob_floats, self.jobs, None if identity else in_col,
-                               None if identity else self.col_of_slot.copy(), device, self.mlp_out_dim)
+        cp = CompiledProgram(prog, self.blob_floats, self.jobs, None if identity else in_col,
+                             None if identity else self.col_of_slot.copy(), device, self.mlp_out_dim)
+        # a later hidden chunk of a wide conditioner ADDS into mlp_out (add_mlp(accumulate=True))
+        cp.accumulates = any(s['kind'] == _hip.STEP_MLP_OUT_TILE and s.get('reverse') for s in self.steps)
+        return cp

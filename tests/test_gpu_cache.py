@@ -181,3 +181,100 @@ def test_load_state_dict_after_first_call_cfg4_slice():
     flow.log_prob(x)
     flow.load_state_dict(g.state('cfg4'))
     close(flow.log_prob(x), g.t('cfg4/log_prob'))
+
+
+def test_bookkeeping_attributes_do_not_replan_and_declared_ones_do():
+    """`flow.step = i` in a training loop bumped the process-wide structure epoch, so every flow of the process
+    re-planned on every call.  Attributes a user hangs on a module after construction are not structure; attributes the constructor
+    declared (a coupling's set_data, a spline's bin count ...), sub-modules, parameters and buffers still are."""
+    from stribor_amd import fused
+    torch.manual_seed(0)
+    flow = fd.build_flow(st, fd.cfg2_desc(2, 8, 16), 8).to(DEV)
+    x = torch.randn(33, 8, device=DEV)
+    with torch.no_grad():
+        want = flow.log_prob(x).clone()
+        prog = flow._fused_program(True, 8, 0, x.device)
+        e0 = fused._STRUCT_EPOCH[0]
+        for i in range(5):
+            flow.step = i                                   # new public attribute on the flow
+            flow.transforms[0].note = ('epoch', i)          # ... on a layer
+            flow.transforms[0].transform.latent_net.tag = i
+            assert flow._fused_program(True, 8, 0, x.device) is prog
+        assert fused._STRUCT_EPOCH[0] == e0
+        assert torch.equal(flow.log_prob(x), want)
+        # a declared attribute: re-plans (and the result follows it)
+        flow.transforms[0].mask_func = st.util.mask.get_mask('ordered_left_half')
+        assert fused._STRUCT_EPOCH[0] > e0
+        assert flow._fused_program(True, 8, 0, x.device) is not prog
+        got = flow.log_prob(x)
+        assert not torch.allclose(got, want)
+        # a parameter replaced by a new Parameter object: re-plans
+        e1 = fused._STRUCT_EPOCH[0]
+        lin = flow.transforms[1].transform.latent_net.net[0]
+        lin.weight = torch.nn.Parameter(lin.weight.detach() * 0.5)
+        assert fused._STRUCT_EPOCH[0] > e1
+
+
+def test_error_flags_are_per_stream():
+    """One flag word per (device, stream): a flow that leaves the fp16 x 3 range on one stream is reported to the next call on THAT
+    stream (or to check_errors()), never to work queued on another stream (one word per device let flow A's
+    condition surface in flow B's next call)."""
+    torch.manual_seed(1)
+    fa = fd.build_flow(st, fd.cfg2_desc(2, 16, 32), 16).to(DEV)
+    fb = fd.build_flow(st, fd.cfg2_desc(2, 16, 32), 16).to(DEV)
+    xa = torch.randn(64, 16, device=DEV)
+    xa[5, 3] = 3.0e5                                        # beyond fp16's range: flow A's rows 5 come back NaN and flag
+    xb = torch.randn(64, 16, device=DEV)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        with torch.cuda.stream(sa):
+            ya = fa.log_prob(xa)
+        sa.synchronize()
+        assert torch.isnan(ya[5]).all()
+        with torch.cuda.stream(sb):
+            for _ in range(3):
+                yb = fb.log_prob(xb)                        # polls stream B's word only: nothing to report
+            sb.synchronize()
+        assert torch.isfinite(yb).all()
+        fb.log_prob(xb)                                     # default stream: its own word, clean as well
+        with torch.cuda.stream(sa):
+            with pytest.raises(st.GemmRangeError):
+                fa.log_prob(xa[:8])                         # the next call on stream A reports it (and clears it)
+            fa.log_prob(xb)                                 # clean now
+        sa.synchronize()
+        # check_errors() sees every stream's word
+        with torch.cuda.stream(sb):
+            fb.log_prob(xa)
+        with pytest.raises(st.GemmRangeError):
+            st.check_errors()
+        st.check_errors()
+
+
+def test_sync_errors_mode_raises_inside_the_failing_call():
+    """set_sync_errors(True) / STRIBOR_SYNC_ERRORS=1: the data-dependent error leaves the call that caused it, like the reference's
+    (rational_quadratic_spline.py:175-178,223) -- a script that ends right after the failing call still sees it."""
+    from stribor_amd import _hip
+    torch.manual_seed(2)
+    flow = fd.build_flow(st, fd.cfg2_desc(2, 16, 32), 16).to(DEV)
+    x = torch.randn(64, 16, device=DEV)
+    x[7, 1] = -4.0e5
+    old = _hip.set_sync_errors(True)
+    try:
+        with torch.no_grad():
+            with pytest.raises(st.GemmRangeError):
+                flow.log_prob(x)
+            st.check_errors()                               # raised once, nothing left behind
+            assert torch.isfinite(flow.log_prob(x[:5])).all()
+            net = st.net.MLP(8, [16], 4, activation='ReLU').to(DEV)
+            z = torch.randn(32, 8, device=DEV)
+            z[3, 0] = 1.0e6
+            with pytest.raises(st.GemmRangeError):
+                net(z)
+    finally:
+        _hip.set_sync_errors(old)
+    with torch.no_grad():
+        flow.log_prob(x)                                    # lazy again: no raise here ...
+        torch.cuda.synchronize()
+        with pytest.raises(st.GemmRangeError):
+            flow.log_prob(x[:5])                            # ... the next call reports it

@@ -272,3 +272,44 @@ def test_nan_inputs_propagate_to_their_own_rows_only():
                 st.check_errors()
             except st.GemmRangeError:             # a NaN operand may be reported as out of range; it must not go unnoticed as a number
                 pass
+
+
+def test_auto_mode_with_wide_hidden_layers_accumulating_chunks():
+    """Hidden layers wider than 128 run as one launch per 128 hidden units, the later ones ADDING into the output.  'auto' re-runs a
+    flagged launch in the exact arithmetic: an accumulating launch must be re-run from the output it started from, or the rows that
+    were fine in fp16 x 3 get the chunk twice and the flagged rows stay NaN.  Stand-alone MLP and a coupling
+    whose conditioner has 300 hidden units, inputs with rows beyond fp16's range."""
+    torch.manual_seed(9)
+    net = st.net.MLP(12, [300], 20).to(DEV)
+    x = torch.randn(200, 12)
+    x[7, 3] = 2.0e5
+    x[150] *= 4.0e4
+    x[150, 1] = 1.5e5
+    ws = [m.weight.detach().cpu() for m in net.net if isinstance(m, torch.nn.Linear)]
+    bs = [m.bias.detach().cpu() for m in net.net if isinstance(m, torch.nn.Linear)]
+    want = orc.mlp_forward({'weights': ws, 'biases': bs, 'activation': 'Tanh'}, x)
+    with torch.no_grad():
+        assert len(net._program(torch.device(DEV, torch.cuda.current_device()))) >= 3 and net._fits_program()
+        st.set_gemm_precision('auto')
+        got = net(x.to(DEV))
+        assert torch.isfinite(got).all()
+        _rel_close(got, want)
+        st.check_errors()
+        st.set_gemm_precision('fast')
+        with pytest.raises(st.GemmRangeError):      # (a multi-launch call may report its first launch's condition before it returns)
+            bad = torch.isnan(net(x.to(DEV))).any(1).cpu()
+            assert bad[7] and bad[150] and bad.sum() == 2
+            st.check_errors()
+        try:
+            st.check_errors()                       # (launches queued behind the one that raised may have flagged as well)
+        except st.GemmRangeError:
+            pass
+        # the same through a coupling's conditioner programs (unfused tier: hidden > 128)
+        desc = [{'kind': 'coupling_affine', 'dim': 16, 'hidden': [260], 'mask': 'ordered_right_half', 'latent_dim': 0}]
+        flow, spec = _flow_and_oracle(desc, 16, seed=10)
+        xx = torch.randn(150, 16)
+        xx[3, 12] = 3.0e5                  # a conditioning column
+        wantl = orc.flow_log_prob(spec, xx)
+        st.set_gemm_precision('auto')
+        _rel_close(flow.log_prob(xx.to(DEV)), wantl)
+        st.check_errors()
