@@ -119,7 +119,8 @@ def cpu_baseline(desc, state, dim=DIM, budget_s=10.0, max_rows=1 << 21, what='cf
         orc.flow_log_prob(spec, x)
         dt = time.perf_counter() - t0
     note = '' if what == 'cfg2' or what == 'cfg4' else ', O(M^2) domain-check broadcast of rational_quadratic_spline.py:167-178 omitted'
-    return {'value': rows / dt, 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
+    return {'value': rows / dt, 'unit': 'samples/s', 'cores': cores, 'host_cores': os.cpu_count(), 'host_cores_available': avail,
+            'kind': 'port',
             'sample': f'oracle.flow_log_prob (torch CPU fp32, reference op sequence incl. double conditioner call{note}) '
                       f'on {rows} rows x {dim}, 1 pass, {dt:.2f} s'}
 
@@ -308,7 +309,7 @@ def _time_training_step(name, workload, flow, x, steps, note):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra-configs', action='store_true', help='skip the cfg 3 / cfg 4 lines (N = 1)')
@@ -520,6 +521,12 @@ def main():
                 del f4, x4
                 cfgs += extra_flow_entries(st, fd, dev, gen, extra_steps)
             result['configs'] = cfgs
+            # first-level scalars (the driver's record keeps those): the other single-GPU BASELINE configurations of this run
+            for c_ in cfgs:
+                if c_.get('name') in ('cfg2_exact', 'cfg3', 'cfg4') and 'value' in c_:
+                    result['value_' + c_['name']] = c_['value']
+                    result['ms_per_step_' + c_['name']] = c_['ms_per_step']
+                    result['roofline_frac_' + c_['name']] = c_['roofline']['frac']
             # training steps (forward + backward) of the trainable BASELINE families, same process
             tr = []
             if not args.no_training:
@@ -562,6 +569,9 @@ def main():
                 del f4
             if not args.no_training:
                 result['training'] = tr
+                for t_ in tr:
+                    if t_.get('ms_per_step') is not None:
+                        result['train_ms_' + t_['name']] = t_['ms_per_step']
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(desc, state)
     if world > 1:

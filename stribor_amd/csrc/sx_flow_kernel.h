@@ -1512,8 +1512,7 @@ struct cubic_elems {        // the 4 elements of the current group a lane owns
     float x[4];
     float s_k[4], s_m[4], s_b[4], s_p[4];   // searched sequence: knot at the bin, sizes of bins b-1, b, b+1
     float o_k[4], o_m[4], o_b[4], o_p[4];   // other sequence, same
-    int b[4];
-    bool in[4];
+    int b[4];               // bin index (+ RQS_OUT: the input is outside the domain; see rqs_elems)
 };
 template <int Q, int KC>
 __device__ __forceinline__ float cub_softmax(tile<1> (&acc)[4], int K) {
@@ -1547,7 +1546,6 @@ template <int Q>
 __device__ __forceinline__ void cub_search16(tile<1> (&acc)[4], cubic_elems &e, float lo, float hi) {
     const float xv = e.x[Q];
     const bool in = (xv >= lo) && (xv <= hi);                       // :40 closed interval
-    e.in[Q] = in;
     const float xn = cub_norm(xv, in, lo, hi);
     const float inv = cub_softmax<Q, 16>(acc, 16);
     CUB_GROUP_SUMS();
@@ -1556,7 +1554,7 @@ __device__ __forceinline__ void cub_search16(tile<1> (&acc)[4], cubic_elems &e, 
     const float z0 = CUB_Z(0), z1 = CUB_Z(1), z2 = CUB_Z(2), z3 = CUB_Z(3), z4 = CUB_Z(4), z5 = CUB_Z(5);
     const float k1 = k0 + z1, k2 = k1 + z2, k3 = k2 + z3;
     const bool g1 = xn >= k1, g2 = xn >= k2, g3 = xn >= k3;
-    e.b[Q] = (m3 ? 12 : (m2 ? 8 : (m1 ? 4 : 0))) + (g3 ? 3 : (g2 ? 2 : (g1 ? 1 : 0)));
+    e.b[Q] = (m3 ? 12 : (m2 ? 8 : (m1 ? 4 : 0))) + (g3 ? 3 : (g2 ? 2 : (g1 ? 1 : 0))) + (in ? 0 : RQS_OUT);
     e.s_k[Q] = g3 ? k3 : (g2 ? k2 : (g1 ? k1 : k0));
     e.s_m[Q] = g3 ? z3 : (g2 ? z2 : (g1 ? z1 : z0));
     e.s_b[Q] = g3 ? z4 : (g2 ? z3 : (g1 ? z2 : z1));
@@ -1565,7 +1563,7 @@ __device__ __forceinline__ void cub_search16(tile<1> (&acc)[4], cubic_elems &e, 
 template <int Q>
 __device__ __forceinline__ void cub_select16(tile<1> (&acc)[4], cubic_elems &e) {
     const float inv = cub_softmax<Q, 16>(acc, 16);
-    const int b = e.b[Q], bl = b & 3;
+    const int b = e.b[Q] & (RQS_OUT - 1), bl = b & 3;
     CUB_GROUP_SUMS();
     const bool m1 = b >= 4, m2 = b >= 8, m3 = b >= 12;
     const float k0 = m3 ? (S0 + S1) + S2 : (m2 ? S0 + S1 : (m1 ? S0 : 0.f));
@@ -1586,7 +1584,6 @@ __device__ __forceinline__ void cub_search(tile<1> (&acc)[4], cubic_elems &e, in
 #endif
     const float xv = e.x[Q];
     const bool in = (xv >= lo) && (xv <= hi);                       // :40 closed interval
-    e.in[Q] = in;
     const float xn = cub_norm(xv, in, lo, hi);
     const float inv = cub_softmax<Q, KC>(acc, K);
     int b = 0;
@@ -1606,7 +1603,7 @@ __device__ __forceinline__ void cub_search(tile<1> (&acc)[4], cubic_elems &e, in
             cum += sz;
         }
     }
-    e.b[Q] = b; e.s_k[Q] = k_b; e.s_m[Q] = s_m; e.s_b[Q] = s_b; e.s_p[Q] = s_p;
+    e.b[Q] = b + (in ? 0 : RQS_OUT); e.s_k[Q] = k_b; e.s_m[Q] = s_m; e.s_b[Q] = s_b; e.s_p[Q] = s_p;
 }
 // phase 1: the other block at the found bin
 template <int Q, int KC>
@@ -1615,7 +1612,7 @@ __device__ __forceinline__ void cub_select(tile<1> (&acc)[4], cubic_elems &e, in
     if constexpr (KC == 16) { cub_select16<Q>(acc, e); return; }
 #endif
     const float inv = cub_softmax<Q, KC>(acc, K);
-    const int b = e.b[Q];
+    const int b = e.b[Q] & (RQS_OUT - 1);
     float k_b = 0.f, o_b = 0.f, o_m = 1.f, o_p = 1.f, cum = 0.f;
     bool is_prev = false;                 // b == k - 1
     bool is_cur = (b == 0);               // b == k
@@ -1637,29 +1634,222 @@ __device__ __forceinline__ void cub_select(tile<1> (&acc)[4], cubic_elems &e, in
     e.o_k[Q] = k_b; e.o_m[Q] = o_m; e.o_b[Q] = o_b; e.o_p[Q] = o_p;
 }
 // phase 2: knot derivatives of the bin (:117-132), its cubic (:134-137), the polynomial or its inverse
-template <int Q, bool REV>
-__device__ __forceinline__ void cub_eval(tile<1> (&acc)[4], const cubic_elems &e, int K, float lo, float hi, float &out, float &ljd) {
-    const int b = e.b[Q];
+template <int Q, bool REV, class H>
+__device__ __forceinline__ void cub_eval(const f32x16 &u, const cubic_elems &e, int K, float lo, float hi, float &out, float &ljd, H &hk) {
+    hk.template pt<0>();
+    const int b = e.b[Q] & (RQS_OUT - 1);
+    const bool in = e.b[Q] < RQS_OUT;
     const float w_m = REV ? e.o_m[Q] : e.s_m[Q], w_b = REV ? e.o_b[Q] : e.s_b[Q], w_p = REV ? e.o_p[Q] : e.s_p[Q];
     const float h_m = REV ? e.s_m[Q] : e.o_m[Q], h_b = REV ? e.s_b[Q] : e.o_b[Q], h_p = REV ? e.s_p[Q] : e.o_p[Q];
     const float cw_b = REV ? e.o_k[Q] : e.s_k[Q], ch_b = REV ? e.s_k[Q] : e.o_k[Q];
-    const cubic_coef cf = cubic_bin_coef(b, K, w_b, h_b, w_m, h_m, w_p, h_p, RQS_P(acc, Q, 0), RQS_P(acc, Q, 1));
+    const cubic_coef cf = cubic_bin_coef(b, K, w_b, h_b, w_m, h_m, w_p, h_p, u[0], u[1]);
+    hk.template pt<1>(); hk.template pt<2>();
     const float a = cf.a, bb = cf.bb, c = cf.c, d = ch_b;
-    const float xn = cub_norm(e.x[Q], e.in[Q], lo, hi), span = hi - lo;
+    const float xn = cub_norm(e.x[Q], in, lo, hi), span = hi - lo;
     if constexpr (REV) {
         const float rcw = (b == K - 1) ? 1.f : cw_b + w_b;                                 // :107 (last knot pinned)
+        hk.template pt<3>(); hk.template pt<4>(); hk.template pt<5>();
         const float so = cubic_invert(a, bb, c, d, xn, cw_b, rcw);
+        hk.template pt<6>(); hk.template pt<7>(); hk.template pt<8>(); hk.template pt<9>();
         out = fminf(fmaxf((so + cw_b) * span + lo, lo), hi);                               // :235 (clamped: see cubic_kernel)
         const bool in2 = (out >= lo) && (out <= hi);
         const float t2 = cub_norm(out, in2, lo, hi) - cw_b;
+        hk.template pt<10>();
         ljd = in2 ? -cubic_flog(3.f * a * (t2 * t2) + 2.f * bb * t2 + c) : 0.f;            // flow.py:42-47
     } else {
+        hk.template pt<3>(); hk.template pt<4>(); hk.template pt<5>();
         const float t = xn - cw_b;                                                         // :229
         out = (a * (t * t * t) + bb * (t * t) + c * t + d) * span + lo;                    // :230-233, :238
+        hk.template pt<6>(); hk.template pt<7>(); hk.template pt<8>(); hk.template pt<9>(); hk.template pt<10>();
         ljd = cubic_flog(3.f * a * (t * t) + 2.f * bb * t + c);                            // :235-237
     }
-    out = e.in[Q] ? out : e.x[Q];                                                          // :46-48 linear tails
-    ljd = e.in[Q] ? ljd : 0.f;
+    out = in ? out : e.x[Q];                                                               // :46-48 linear tails
+    ljd = in ? ljd : 0.f;
+    hk.template pt<11>();
+}
+template <int Q, bool REV>
+__device__ __forceinline__ void cub_eval(tile<1> (&acc)[4], const cubic_elems &e, int K, float lo, float hi, float &out, float &ljd) {
+    rqs_nohook nh;
+    cub_eval<Q, REV>(acc[Q].v[0], e, K, lo, hi, out, ljd, nh);
+}
+
+// ---- K = 16, bounded logits: the lean forms of the two sweeps (as rqs16_*: no running maximum below the packed logit bound, value
+// selects, one element = one output tile, the next tile's MFMAs issued from the element's twelve points).  Normalised coordinates:
+// knot_j = j MIN + inv P_j on [0, 1] (:103-111); a bin's neighbours b - 1 / b + 1 are needed beside it (:117-132), so the SIZES of
+// the six bins around the found group are picked (18 selects) instead of RQ's four prefixes.
+struct cub16_s {
+    float e[16];            // exp2 of the logits (named through the accessors below only with constant indices)
+    float T1, T2, T3;       // knots at bins 4, 8, 12
+    float inv;              // (1 - 16 MIN) / sum
+};
+template <class H>
+__device__ __forceinline__ void cub16_sums(const f32x16 &u, float (&ev)[16], float &T1, float &T2, float &T3, float &inv, H &hk) {
+    hk.template pt<0>();
+    ev[0] = __builtin_amdgcn_exp2f(u[0]); ev[1] = __builtin_amdgcn_exp2f(u[1]); ev[2] = __builtin_amdgcn_exp2f(u[2]); ev[3] = __builtin_amdgcn_exp2f(u[3]);
+    const float g0 = (ev[0] + ev[1]) + (ev[2] + ev[3]);
+    hk.template pt<1>();
+    ev[4] = __builtin_amdgcn_exp2f(u[4]); ev[5] = __builtin_amdgcn_exp2f(u[5]); ev[6] = __builtin_amdgcn_exp2f(u[6]); ev[7] = __builtin_amdgcn_exp2f(u[7]);
+    const float g1 = (ev[4] + ev[5]) + (ev[6] + ev[7]);
+    hk.template pt<2>();
+    ev[8] = __builtin_amdgcn_exp2f(u[8]); ev[9] = __builtin_amdgcn_exp2f(u[9]); ev[10] = __builtin_amdgcn_exp2f(u[10]); ev[11] = __builtin_amdgcn_exp2f(u[11]);
+    const float g2 = (ev[8] + ev[9]) + (ev[10] + ev[11]);
+    hk.template pt<3>();
+    ev[12] = __builtin_amdgcn_exp2f(u[12]); ev[13] = __builtin_amdgcn_exp2f(u[13]); ev[14] = __builtin_amdgcn_exp2f(u[14]); ev[15] = __builtin_amdgcn_exp2f(u[15]);
+    const float g3 = (ev[12] + ev[13]) + (ev[14] + ev[15]);
+    hk.template pt<4>();
+    const float G2 = g0 + g1, G3 = G2 + g2;
+    inv = (1.f - 16.f * CUBIC_MIN_BIN) * cubic_frcp(G3 + g3);
+    T1 = __builtin_fmaf(inv, g0, 4.f * CUBIC_MIN_BIN);
+    T2 = __builtin_fmaf(inv, G2, 8.f * CUBIC_MIN_BIN);
+    T3 = __builtin_fmaf(inv, G3, 12.f * CUBIC_MIN_BIN);
+}
+// the group's start knot k0, its three inner knots and the sizes z0..z5 of bins 4g-1 .. 4g+4 (the out-of-range neighbours of the
+// first and the last group are never used: any finite value)
+template <class H>
+__device__ __forceinline__ void cub16_group(const float (&ev)[16], float T1, float T2, float T3, float inv, bool m1, bool m2, bool m3,
+                                            float &k0, float &k1, float &k2, float &k3, float (&z)[6], H &hk) {
+    k0 = rqs16_pick(m1, m2, m3, 0.f, T1, T2, T3);
+    const float q0 = rqs16_pick(m1, m2, m3, ev[0], ev[3], ev[7], ev[11]);
+    const float q1 = rqs16_pick(m1, m2, m3, ev[0], ev[4], ev[8], ev[12]);
+    hk.template pt<6>();
+    const float q2 = rqs16_pick(m1, m2, m3, ev[1], ev[5], ev[9], ev[13]);
+    const float q3 = rqs16_pick(m1, m2, m3, ev[2], ev[6], ev[10], ev[14]);
+    z[0] = __builtin_fmaf(inv, q0, CUBIC_MIN_BIN); z[1] = __builtin_fmaf(inv, q1, CUBIC_MIN_BIN);
+    hk.template pt<7>();
+    const float q4 = rqs16_pick(m1, m2, m3, ev[3], ev[7], ev[11], ev[15]);
+    const float q5 = rqs16_pick(m1, m2, m3, ev[4], ev[8], ev[12], ev[15]);
+    z[2] = __builtin_fmaf(inv, q2, CUBIC_MIN_BIN); z[3] = __builtin_fmaf(inv, q3, CUBIC_MIN_BIN);
+    hk.template pt<8>();
+    z[4] = __builtin_fmaf(inv, q4, CUBIC_MIN_BIN); z[5] = __builtin_fmaf(inv, q5, CUBIC_MIN_BIN);
+    k1 = k0 + z[1]; k2 = k1 + z[2]; k3 = k2 + z[3];
+}
+__device__ __forceinline__ float cub16_pick4(bool g1, bool g2, bool g3, float v0, float v1, float v2, float v3) {
+    return g3 ? v3 : (g2 ? v2 : (g1 ? v1 : v0));
+}
+template <int Q, class H>
+__device__ __forceinline__ void cub16_search(const f32x16 &u, cubic_elems &e, float lo, float hi, H &hk) {
+    float ev[16], T1, T2, T3, inv;
+    cub16_sums(u, ev, T1, T2, T3, inv, hk);
+    hk.template pt<5>();
+    const float xv = e.x[Q];
+    const bool in = (xv >= lo) && (xv <= hi);                       // :40 closed interval
+    const float xn = cub_norm(xv, in, lo, hi);
+    const bool m1 = xn >= T1, m2 = xn >= T2, m3 = xn >= T3;
+    float k0, k1, k2, k3, z[6];
+    cub16_group(ev, T1, T2, T3, inv, m1, m2, m3, k0, k1, k2, k3, z, hk);
+    const bool g1 = xn >= k1, g2 = xn >= k2, g3 = xn >= k3;
+    const int bg = 4 * ((int)m1 + (int)m2 + (int)m3) + (in ? 0 : RQS_OUT);
+    hk.template pt<9>();
+    e.b[Q] = bg + ((int)g1 + (int)g2 + (int)g3);
+    e.s_k[Q] = cub16_pick4(g1, g2, g3, k0, k1, k2, k3);
+    e.s_m[Q] = cub16_pick4(g1, g2, g3, z[0], z[1], z[2], z[3]);
+    hk.template pt<10>();
+    e.s_b[Q] = cub16_pick4(g1, g2, g3, z[1], z[2], z[3], z[4]);
+    e.s_p[Q] = cub16_pick4(g1, g2, g3, z[2], z[3], z[4], z[5]);
+    hk.template pt<11>();
+}
+template <int Q, class H>
+__device__ __forceinline__ void cub16_select(const f32x16 &u, cubic_elems &e, H &hk) {
+    float ev[16], T1, T2, T3, inv;
+    cub16_sums(u, ev, T1, T2, T3, inv, hk);
+    hk.template pt<5>();
+    const int b = e.b[Q] & (RQS_OUT - 1), bl = b & 3;
+    const bool m1 = b >= 4, m2 = b >= 8, m3 = b >= 12;
+    float k0, k1, k2, k3, z[6];
+    cub16_group(ev, T1, T2, T3, inv, m1, m2, m3, k0, k1, k2, k3, z, hk);
+    const bool g1 = bl >= 1, g2 = bl >= 2, g3 = bl >= 3;
+    hk.template pt<9>();
+    e.o_k[Q] = cub16_pick4(g1, g2, g3, k0, k1, k2, k3);
+    e.o_m[Q] = cub16_pick4(g1, g2, g3, z[0], z[1], z[2], z[3]);
+    hk.template pt<10>();
+    e.o_b[Q] = cub16_pick4(g1, g2, g3, z[1], z[2], z[3], z[4]);
+    e.o_p[Q] = cub16_pick4(g1, g2, g3, z[2], z[3], z[4], z[5]);
+    hk.template pt<11>();
+}
+template <int PH, bool REV, int Q, class H>
+__device__ __forceinline__ void cub16_unit(const f32x16 &u, cubic_elems &e, float lo, float hi, float (&out)[4], float (&lj)[4], H &hk) {
+    if constexpr (PH == 0) cub16_search<Q>(u, e, lo, hi, hk);
+    else if constexpr (PH == 1) cub16_select<Q>(u, e, hk);
+    else cub_eval<Q, REV>(u, e, 16, lo, hi, out[Q], lj[Q], hk);
+}
+template <int HT, int PH, bool REV>
+__device__ __forceinline__ void cub16_block(const wptr w, const btile<1> (&bh)[HT], cubic_elems &e, float lo, float hi, float (&out)[4],
+                                            float (&lj)[4]) {
+    tile<1> A, B;
+    {
+        A = load_cfrag<1>(w.cb, 4 * HT * 1024);
+#pragma unroll
+        for (int m = 0; m < HT; ++m) gemm_tile<1>(w.wb, m * 1024, bh[m], A);
+    }
+    { rqs_tile_pipe<HT, 1> p(w, bh, B); p.start(); cub16_unit<PH, REV, 0>(A.v[0], e, lo, hi, out, lj, p); }
+    { rqs_tile_pipe<HT, 2> p(w, bh, A); p.start(); cub16_unit<PH, REV, 1>(B.v[0], e, lo, hi, out, lj, p); }
+    { rqs_tile_pipe<HT, 3> p(w, bh, B); p.start(); cub16_unit<PH, REV, 2>(A.v[0], e, lo, hi, out, lj, p); }
+    { rqs_nohook nh; cub16_unit<PH, REV, 3>(B.v[0], e, lo, hi, out, lj, nh); }
+}
+// The three blocks of a group in one iteration of the step loop (see rqs_triple)
+#define CUB_FETCH(T, G) { asm volatile("" ::: "memory"); _Pragma("unroll") for (int q = 0; q < 4; ++q) e.x[q] = xs[T].v[0][4 * G + q]; }
+template <int TX, int HT, class ADV>
+__device__ __forceinline__ void cubic_triple(tile<1> (&xs)[TX], const btile<1> (&bh)[HT], const wptr w0, const dstep &st0, float &ldj,
+                                             int lane, ADV &&advance) {
+    const int h = lane >> 5;
+    const int K = st0.tt, tg = 4 * st0.t0 + st0.c0;
+    cubic_elems e;
+    float lo, hi, out[4], lj[4];
+    bool lean;
+    uint32_t live_mask;
+    float ldj_scale;
+    RQS_GROUP_CASES(CUB_FETCH)
+    rqs_block_scalars<HT>(w0, h, lo, hi, lean);
+    if (K == 16 && lean) {
+        wptr w;
+        dstep st;
+        cub16_block<HT, 0, false>(w0, bh, e, lo, hi, out, lj);
+        advance(st, w);
+        cub16_block<HT, 1, false>(w, bh, e, lo, hi, out, lj);
+        advance(st, w);
+        rqs_block_scalars<HT>(w, h, lo, hi, lean);
+        if (st.reverse) cub16_block<HT, 2, true>(w, bh, e, lo, hi, out, lj);
+        else cub16_block<HT, 2, false>(w, bh, e, lo, hi, out, lj);
+        live_mask = st.mask; ldj_scale = st.ldj_scale;
+    } else {
+#define CUB_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); __builtin_amdgcn_sched_barrier(0)
+        wptr w;
+        dstep st;
+        tile<1> acc[4];
+        rqs_gemm<HT>(w0, bh, acc);
+        cub_search<0, 0>(acc, e, K, lo, hi); CUB_PIN4(e.b[0], e.s_k[0], e.s_m[0], e.s_b[0]);
+        cub_search<1, 0>(acc, e, K, lo, hi); CUB_PIN4(e.b[1], e.s_k[1], e.s_m[1], e.s_b[1]);
+        cub_search<2, 0>(acc, e, K, lo, hi); CUB_PIN4(e.b[2], e.s_k[2], e.s_m[2], e.s_b[2]);
+        cub_search<3, 0>(acc, e, K, lo, hi); CUB_PIN4(e.b[3], e.s_k[3], e.s_m[3], e.s_b[3]);
+        advance(st, w);
+        rqs_gemm<HT>(w, bh, acc);
+        cub_select<0, 0>(acc, e, K); CUB_PIN4(e.o_k[0], e.o_m[0], e.o_b[0], e.o_p[0]);
+        cub_select<1, 0>(acc, e, K); CUB_PIN4(e.o_k[1], e.o_m[1], e.o_b[1], e.o_p[1]);
+        cub_select<2, 0>(acc, e, K); CUB_PIN4(e.o_k[2], e.o_m[2], e.o_b[2], e.o_p[2]);
+        cub_select<3, 0>(acc, e, K); CUB_PIN4(e.o_k[3], e.o_m[3], e.o_b[3], e.o_p[3]);
+        advance(st, w);
+        rqs_block_scalars<HT>(w, h, lo, hi, lean);
+        rqs_gemm<HT>(w, bh, acc);
+        if (st.reverse) {
+            cub_eval<0, true>(acc, e, K, lo, hi, out[0], lj[0]); cub_eval<1, true>(acc, e, K, lo, hi, out[1], lj[1]);
+            cub_eval<2, true>(acc, e, K, lo, hi, out[2], lj[2]); cub_eval<3, true>(acc, e, K, lo, hi, out[3], lj[3]);
+        } else {
+            cub_eval<0, false>(acc, e, K, lo, hi, out[0], lj[0]); cub_eval<1, false>(acc, e, K, lo, hi, out[1], lj[1]);
+            cub_eval<2, false>(acc, e, K, lo, hi, out[2], lj[2]); cub_eval<3, false>(acc, e, K, lo, hi, out[3], lj[3]);
+        }
+#undef CUB_PIN4
+        live_mask = st.mask; ldj_scale = st.ldj_scale;
+    }
+    float sl = 0.f;
+    const int g = st0.c0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const bool live = (live_mask >> (q + 8 * g + 4 * h)) & 1u;
+        out[q] = live ? out[q] : e.x[q];
+        sl += live ? lj[q] : 0.f;
+    }
+    RQS_GROUP_CASES(RQS_STORE)
+    ldj += ldj_scale * sl;
 }
 
 template <int TX, int HT, int KC>
@@ -2868,8 +3058,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                         if (st.act == 1) cubic_phase<TX, HT>(xs, rq_bh, rq_ec, w, st, ldj[0], lane);
                         else rqs_phase<TX, HT>(xs, rq_bh, rq_e, w, st, ldj[0], lane, rq_lean);
                     } else
-                    if constexpr (CUB && NS == 1) cubic_phase<TX, HT>(xs, rq_bh, rq_e, w, st, ldj[0], lane);
-                    else if constexpr (MIXQ && NS == 1) rqs_phase<TX, HT>(xs, rq_bh, rq_e, w, st, ldj[0], lane, rq_lean);     // (the triple form below was tried here: 320 B of scratch instead of 128)
+                    if constexpr (MIXQ && NS == 1) rqs_phase<TX, HT>(xs, rq_bh, rq_e, w, st, ldj[0], lane, rq_lean);     // (the triple form below was tried here: 320 B of scratch instead of 128)
                     else if constexpr (RQ && NS == 1) {
                         // the group's three blocks in this one iteration (the host plans them back to back, the launcher checks it)
                         auto advance = [&](dstep &stn, wptr &wn) {
@@ -2893,7 +3082,8 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                             wn = wptr{reinterpret_cast<const char *>(smem) + wb2, reinterpret_cast<const char *>(smem) + cb2};
                             SX_STAMP(pf, 2);     // descriptor + DMA issue
                         };
-                        rqs_triple<TX, HT>(xs, rq_bh, w, st, ldj[0], lane, advance, pf);
+                        if constexpr (CUB) cubic_triple<TX, HT>(xs, rq_bh, w, st, ldj[0], lane, advance);
+                        else rqs_triple<TX, HT>(xs, rq_bh, w, st, ldj[0], lane, advance, pf);
                     }
                     break;
                 case SX_STEP_ROW_SCALE_EXP:

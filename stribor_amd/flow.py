@@ -26,11 +26,13 @@ __all__ = ['Transform', 'ElementwiseTransform', 'NormalizingFlow', 'graph_wanted
 class _FusedLogProb(torch.autograd.Function):
     """log_prob with a hand-written backward for flows of affine couplings.
 
-    forward: the fused kernel, which also leaves the latent z in HBM.  backward: ONE launch of the backward
-    program walks the layers in the opposite order; flows are invertible, so no activation was saved -- each
-    step recomputes its conditioner from the state, un-transforms the state and propagates dL/dx; the per-row
-    factors of the weight gradients (z, tanh h, dL/dh_pre, dL/dparams) land in HBM and are contracted over the
-    batch by plain library GEMMs (torch.mm -> rocBLAS)."""
+    forward: the fused kernel, which also leaves the latent z in HBM.  backward: flows are invertible, so no activation
+    was saved -- each step recomputes its conditioner from the state, un-transforms the state and propagates dL/dx.
+    Two forms: the layer-major one (`_backward_layer_major`: one launch per coupling, the weight gradients
+    contracted over the batch INSIDE the kernel, `sx_wgrad_reduce` adds the per-workgroup partials) where the shape allows
+    it (64-column split couplings, hidden <= 64); otherwise ONE launch of the backward program walks the layers in the
+    opposite order and leaves the per-row factors of the weight gradients (z, tanh h, dL/dh_pre, dL/dparams; dense layers:
+    dL/du, v) in HBM, which `sx_wgrad_layer` / `sx_wgrad` contract over the batch on the matrix pipe.  No library GEMM."""
 
     SIDE_BYTES = 8 << 30      # scratch for the per-row gradient factors (8 GiB of the 288 GB: 2^20-row blocks at 8 layers)
 

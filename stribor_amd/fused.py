@@ -803,7 +803,7 @@ class ProgramBuilder:
                     if phase == 0:
                         bound_slot = off + nlin + 2
                     self.jobs.append(_PackJob(W2, b2, rows, col2, 4, HT, off, np.full(128, -2.0 * sc2), np.full(128, sc2), 1.0,
-                                              bound_off=bound_slot if (phase < 2 and not cubic) else None))
+                                              bound_off=bound_slot if phase < 2 else None))
                     self.jobs.append(_ScalarsJob([lo, hi], off + nlin))
                     s_scale = (-ldj_scale if reverse else ldj_scale) if phase == 2 else 0.0
                     step = dict(kind=_hip.STEP_RQS_PHASE, c0=g, ct=phase, t0=t, tt=K, reverse=int(reverse), act=int(cubic),

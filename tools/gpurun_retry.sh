@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/gpurun_retry.sh <timeout_s> '<command>'   -- retries while the pool has no free slot (exit 3)
 T=$1; shift
-for i in $(seq 1 40); do
+for i in $(seq 1 10); do
   /usr/local/graft/bin/gpurun --timeout "$T" -- "$@"
   rc=$?
   if [ $rc -ne 3 ]; then exit $rc; fi
