@@ -374,6 +374,11 @@ int sx_pack_linear_bound(const float *W, const float *b, int32_t out_dim, int32_
                                          * tiles; blob = pack(W1, h_tiles x tiles) ++ pack(W2, 2 tt x h_tiles) ++ the time net's per-column constants
                                          * (see sx_flow_kernel.h); pad_ = time kind (0 identity, 1 linear, 2 tanh, 3 log, 4 fourier) | (which time
                                          * the embedding uses: 0 row_t, 1 side) << 8 | (fourier features) << 16.  Programs of these steps only.   */
+#define SX_STEP_COUPLING_AFFINE_HC  21  /* one hidden-unit CHUNK of an affine coupling whose hidden layer is wider than the program's hidden tiles
+                                        * (coupling.py:69-95 + mlp.py:65 with hidden > 32 h_tiles; Tanh conditioners): tiles as
+                                        * SX_STEP_COUPLING_AFFINE; blob = pack(W1 rows of the chunk) ++ pack(W2 columns of the chunk, bias = b2
+                                        * in the first chunk); pad_ bit 0 = first chunk, bit 1 = last chunk (applies the affine map).  The
+                                        * chunks of a coupling come back to back. */
 #define SX_STEP_CPL_HIDDEN          13  /* deep conditioners (>= 2 hidden layers): hidden = act(W1 . state[c0..c0+ct) + b1), kept in
                                            registers for the next step; blob = pack_linear(W1, h_tiles x ct)                    */
 #define SX_STEP_CPL_HIDDEN2         14  /* hidden = act(Wk . hidden + bk); blob = pack_linear(Wk, h_tiles x h_tiles)              */

@@ -39,6 +39,7 @@ STEP_COUPLING_AFFINE_BWD_B = 17
 STEP_LINEAR_BWD = 18
 STEP_POINTWISE = 19
 STEP_COUPLING_TIME = 20
+STEP_COUPLING_AFFINE_HC = 21
 
 WGRAD_ROW_MAJOR, WGRAD_ROW_GROUPS, WGRAD_ROW_GROUPS_F16X3 = 0, 1, 3
 

@@ -31,7 +31,7 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     int mx = 256;
     bool lin = false, rqs = false, aff = false, bwd = false, deep = false, cub = false, quadr = false;
     int n_bwd128 = 0;
-    bool pw = false, timed = false;
+    bool pw = false, timed = false, wide_rq = false, hc = false;
     *mlp_mode = 0;
     for (int i = 0; i < p->n_steps; ++i) {
         const sx_step &s = p->steps[i];
@@ -54,6 +54,24 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
             }
                 need = sx_packed_linear_floats(p->h_tiles, s.ct) + sx_packed_linear_floats(2 * s.tt, p->h_tiles);
                 break;
+            case SX_STEP_COUPLING_AFFINE_HC: {
+                const int T = p->tiles;
+                const bool low = T >= 2 && s.c0 == 0 && s.ct == T / 2 && s.t0 == T / 2 && s.tt == T / 2;
+                const bool high = T >= 2 && s.c0 == T / 2 && s.ct == T / 2 && s.t0 == 0 && s.tt == T / 2;
+                SX_REQUIRE(low || high, "sx_flow_run: step %d: hidden-chunk couplings condition one half of the tiles on the other", i);
+                SX_REQUIRE(s.act == SX_ACT_TANH_FOLDED, "sx_flow_run: step %d: hidden-chunk steps carry the folded tanh", i);
+                const int first = s.pad_ & 1, last = (s.pad_ >> 1) & 1;
+                // the chunks of one coupling come back to back, same tiles and direction: first ... last
+                SX_REQUIRE(first || (i > 0 && p->steps[i - 1].kind == SX_STEP_COUPLING_AFFINE_HC && !((p->steps[i - 1].pad_ >> 1) & 1) &&
+                                     p->steps[i - 1].c0 == s.c0 && p->steps[i - 1].ct == s.ct && p->steps[i - 1].t0 == s.t0 &&
+                                     (p->steps[i - 1].reverse != 0) == (s.reverse != 0)),
+                           "sx_flow_run: step %d: a hidden-chunk step that is not the first follows the previous chunk of its coupling", i);
+                SX_REQUIRE(last || (i + 1 < p->n_steps && p->steps[i + 1].kind == SX_STEP_COUPLING_AFFINE_HC && !(p->steps[i + 1].pad_ & 1)),
+                           "sx_flow_run: step %d: a hidden-chunk step that is not the last is followed by the next chunk", i);
+                aff = true; hc = true;
+                need = sx_packed_linear_floats(p->h_tiles, s.ct) + sx_packed_linear_floats(2 * s.tt, p->h_tiles);
+                break;
+            }
             case SX_STEP_AFFINE_CONST: need = 2 * 32 * p->tiles; break;
             case SX_STEP_MLP_HIDDEN:
                 SX_REQUIRE(s.c0 == 0 && s.ct == p->tiles, "sx_flow_run: MLP_HIDDEN must read all tiles");
@@ -139,9 +157,14 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
                 need = sx_packed_linear_floats(p->h_tiles, deep ? p->h_tiles : s.ct); rqs = true; break;
             }
             case SX_STEP_RQS_PHASE:
-                SX_REQUIRE(s.t0 < p->x_tiles && s.c0 >= 0 && s.c0 < 4 && s.ct >= 0 && s.ct < 3 && s.tt >= 1 && s.tt <= 16,
+                // bins: up to 16 (one output tile per element, four elements per step); rational-quadratic splines also 17 .. 32
+                // (two tiles per element, two elements per step: act bit 1 = which pair of the lane's four elements)
+                SX_REQUIRE(s.t0 < p->x_tiles && s.c0 >= 0 && s.c0 < 4 && s.ct >= 0 && s.ct < 3 && s.tt >= 1 && s.tt <= 32,
                            "sx_flow_run: step %d: bad RQS phase (tile %d group %d phase %d bins %d)", i, s.t0, s.c0, s.ct, s.tt);
-                SX_REQUIRE(s.act == 0 || s.act == 1, "sx_flow_run: step %d: spline phase kind %d (0 rational-quadratic, 1 cubic)", i, s.act);
+                SX_REQUIRE(s.act == 0 || s.act == 1 || (s.act == 2 && s.tt > 16),
+                           "sx_flow_run: step %d: spline phase kind %d (0 rational-quadratic, 1 cubic, 2 rational-quadratic second element pair of a 17..32-bin group)", i, s.act);
+                SX_REQUIRE(s.tt <= 16 || s.act != 1, "sx_flow_run: step %d: cubic-spline phases carry up to 16 bins (got %d)", i, s.tt);
+                if (s.tt > 16) wide_rq = true;
                 if (s.act == 1) cub = true; else quadr = true;
                 // the three parameter blocks of a group come back to back (search, select, evaluate): the kernels whose programs hold
                 // spline couplings of one type run a triple inside ONE iteration of their step loop (the group's state is then local to it)
@@ -160,6 +183,7 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
         o.kind = (uint8_t)s.kind; o.c0 = (uint8_t)s.c0; o.ct = (uint8_t)s.ct; o.t0 = (uint8_t)s.t0; o.tt = (uint8_t)s.tt;
         o.reverse = (uint8_t)(s.reverse != 0); o.act = (uint8_t)s.act;
         o.pad = (uint8_t)(s.kind == SX_STEP_RQS_HIDDEN && (s.pad_ & 0xff) == 1);      // deep conditioner: source = kept hidden state
+        if (s.kind == SX_STEP_COUPLING_AFFINE_HC) o.pad = (uint8_t)(s.pad_ & 3);        // first / last chunk
         o.blob_off = s.blob_off; o.blob_floats = s.blob_floats; o.ldj_scale = s.ldj_scale; o.ldj_const = s.ldj_const;
         o.mask = (uint32_t)s.pad_;
     }
@@ -169,6 +193,7 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     SX_REQUIRE(!(rqs && (lin || *mlp_mode == 1)), "sx_flow_run: spline steps cannot be mixed with linear / MLP-output steps");
     // mixed programs (kernel MODE 14): spline couplings beside affine couplings / point-wise steps, or both spline types
     const bool mixed = rqs && (aff || pw || (cub && quadr));
+    SX_REQUIRE(!(wide_rq && mixed), "sx_flow_run: spline couplings of 17..32 bins run in programs of rational-quadratic couplings only");
     SX_REQUIRE(!(pw && (lin || *mlp_mode == 1 || bwd || (deep && !mixed))), "sx_flow_run: point-wise steps mix with couplings and element-wise affines only");
     if (rqs) *mlp_mode = mixed ? ((cub && !quadr) ? 16 : (quadr && !cub) ? 17 : 14) : (cub ? 12 : 3);      // 16 / 17: mixed programs with one spline type
     SX_REQUIRE(!(bwd && (rqs || lin || aff || *mlp_mode == 1)), "sx_flow_run: backward steps cannot be mixed with other step kinds");
@@ -178,6 +203,9 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     SX_REQUIRE(p->tiles != 8 || (bwd && n_bwd128 == p->n_steps), "sx_flow_run: 8 state tiles carry backward steps (kinds 16 - 18) only");
     SX_REQUIRE(!(deep && (lin || bwd || *mlp_mode == 1)), "sx_flow_run: deep-conditioner steps only mix with couplings");
     if (deep && !mixed) *mlp_mode = rqs ? (cub ? 13 : 10) : 9;     // 10 / 13: the spline kernels with the deep-conditioner steps
+    // MODE 20: affine couplings whose hidden layer runs as chunk steps (beside ordinary affine couplings / element-wise affines)
+    SX_REQUIRE(!(hc && (rqs || lin || deep || bwd || timed || pw || *mlp_mode == 1)), "sx_flow_run: hidden-chunk couplings share a program with affine couplings and element-wise affines only");
+    if (hc) *mlp_mode = 20;
     // MODE 5 / 6: nothing but tanh-folded affine couplings on half the tiles conditioned on the other half, all in
     // one direction (5 reverse, 6 forward) -- the plain RealNVP log_prob / sample program.  Its kernel carries two
     // straight-line arms only, which keeps the state in place (no phi copies) at 130 VGPRs.

@@ -582,6 +582,66 @@ __device__ __forceinline__ void coupling_affine_deep(tile<NS> (&xs)[TX], const t
     for (int n = 0; n < NS; ++n) ldj[n] += st.ldj_scale * s[n];
 }
 
+// Hidden layers wider than the program's hidden tiles (round 4: hidden 128 -> 160 used to cost 6x, the layer left the fused tier):
+// W2 tanh(W1 z + b1) + b2 is a SUM over hidden-unit chunks, so a coupling is a run of CHUNK steps -- each evaluates its 32 HT
+// hidden units (folded tanh) and adds its share of (kk log_scale, shift) to accumulator tiles that live in registers across the
+// steps (`pacc`: 2 TT tiles, kernel MODE 9); the first chunk's bias carries b2, every chunk's its own share of the folded
+// constant W2 1; the last chunk applies the affine map.  step.pad: bit 0 first, bit 1 last chunk.
+template <int NS, int TX, int HT, int C0, int CT, int T0, int TT, bool REV, int PN>
+__device__ __forceinline__ void coupling_affine_chunk(tile<NS> (&xs)[TX], tile<NS> (&pacc)[PN], const wptr w, const dstep &st,
+                                                      float (&ldj)[NS], rng_t &rg) {
+    tile<NS> hid[HT];
+    hidden_layer<NS, TX, HT, C0, CT, true>(xs, hid, w, 0, SX_ACT_TANH_FOLDED, rg);
+#pragma unroll
+    for (int n = 0; n < NS; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) fast_sig2_pair(hid[HT - 1].v[n], r);        // (the layer returns its last tile un-activated)
+    btile<NS> bh[HT];
+#pragma unroll
+    for (int m = 0; m < HT; ++m) bh[m] = make_btile<NS>(hid[m]);
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int a2 = HT * CT * 1024 + HT * 32;       // pack_linear(W2 chunk: 2 TT m-tiles, HT k-tiles)
+    constexpr int b2 = a2 + 2 * TT * HT * 1024;
+    const bool first = st.pad & 1, last = st.pad & 2;
+#pragma unroll
+    for (int t = 0; t < 2 * TT; ++t) {
+        tile<NS> acc = load_cfrag<NS>(w.cb, b2 + t * 32);
+        if (!first) {
+#pragma unroll
+            for (int n = 0; n < NS; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc.v[n][r] += pacc[t].v[n][r];
+        }
+#pragma unroll
+        for (int m = 0; m < HT; ++m) gemm_tile<NS>(w.wb, a2 + (t * HT + m) * 1024, bh[m], acc);
+        pacc[t] = acc;
+    }
+    if (last) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            tile<NS> &x = xs[T0 + t];
+#pragma unroll
+            for (int n = 0; n < NS; ++n) {
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float l = pacc[2 * t].v[n][r], sh = pacc[2 * t + 1].v[n][r];       // l = kk log_scale (the pack folds kk in)
+                    s += l;
+                    const float e = __builtin_amdgcn_exp2f(l);
+                    x.v[n][r] = REV ? (x.v[n][r] - sh) * e : x.v[n][r] * e + sh;
+                }
+                ldj[n] += st.ldj_scale * s;
+            }
+        }
+    }
+}
+template <int NS, int TX, int HT, int C0, int CT, int T0, int TT, int PN>
+__device__ __forceinline__ void coupling_affine_chunk_dispatch(tile<NS> (&xs)[TX], tile<NS> (&pacc)[PN], const wptr w, const dstep &st,
+                                                               float (&ldj)[NS], rng_t &rg) {
+    if (st.reverse) coupling_affine_chunk<NS, TX, HT, C0, CT, T0, TT, true>(xs, pacc, w, st, ldj, rg);
+    else coupling_affine_chunk<NS, TX, HT, C0, CT, T0, TT, false>(xs, pacc, w, st, ldj, rg);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Time-conditioned affine coupling (ContinuousAffineCoupling, stribor/flows/coupling.py:184-213; kernel MODE 15):
 //   (log_scale, shift) = net(cat[x * mask, latent, t]);  (e_ls, e_sh) = time_net(t).chunk(2)      (net/time_net.py:6-91)
@@ -834,18 +894,20 @@ __device__ __forceinline__ bool rqs_has(int k, int K) { return KC ? (k < KC) : (
 
 // softmax numerators in place + the factor that turns them into bin sizes: size_k = MIN + e_k * inv.  The two softmax blocks'
 // rows are packed times log2(e) (fused.py add_coupling_rqs), so exp(u - max) is a bare v_exp_f32.
-template <int Q, int KC>
+// (W: output tiles per element -- 1: up to 16 bins; 2: up to 32 bins, element Q of the step's two = tiles 2Q, 2Q+1)
+#define RQS_PW(acc, q, k) (acc)[W * (q) + ((k) >> 4)].v[0][(k) & 15]
+template <int Q, int KC, int W = 1>
 __device__ __forceinline__ float rqs_softmax(tile<1> (&acc)[4], int K) {
-    float mx = RQS_P(acc, Q, 0);
+    float mx = RQS_PW(acc, Q, 0);
 #pragma unroll
-    for (int k = 1; k < 16; ++k)
-        if (KC ? (k < KC) : true) mx = fmaxf(mx, rqs_has<KC>(k, K) ? RQS_P(acc, Q, k) : mx);
+    for (int k = 1; k < 16 * W; ++k)
+        if (KC ? (k < KC) : true) mx = fmaxf(mx, rqs_has<KC>(k, K) ? RQS_PW(acc, Q, k) : mx);
     float sum = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k)
+    for (int k = 0; k < 16 * W; ++k)
         if (KC ? (k < KC) : true) {
-            const float e = rqs_has<KC>(k, K) ? __builtin_amdgcn_exp2f(RQS_P(acc, Q, k) - mx) : 0.f;     // logits arrive in base 2
-            RQS_P(acc, Q, k) = e;
+            const float e = rqs_has<KC>(k, K) ? __builtin_amdgcn_exp2f(RQS_PW(acc, Q, k) - mx) : 0.f;     // logits arrive in base 2
+            RQS_PW(acc, Q, k) = e;
             sum += e;
         }
     const float Kf = KC ? (float)KC : (float)K;
@@ -1094,22 +1156,22 @@ __device__ __forceinline__ void rqs16_select(const f32x16 &u, rqs_elems &e, cons
     e.c_w[Q] = k_n - k_b;
     hk.template pt<11>();
 }
-template <int Q, int KC>
+template <int Q, int KC, int W = 1>
 __device__ __forceinline__ void rqs_search(tile<1> (&acc)[4], rqs_elems &e, int K, float lo, float hi) {
 #ifndef SX_RQS_FLAT
-    if constexpr (KC == 16) { rqs_search16<Q>(acc, e, lo, hi); return; }
+    if constexpr (KC == 16 && W == 1) { rqs_search16<Q>(acc, e, lo, hi); return; }
 #endif
     const float xv = e.x[Q];
     const bool in = (xv >= lo) && (xv <= hi);                       // :71 closed interval
     const float xin = in ? xv : lo;
-    const float inv = rqs_softmax<Q, KC>(acc, K);
+    const float inv = rqs_softmax<Q, KC, W>(acc, K);
     const int Kn = KC ? KC : K;
     int b = 0;
     float k_b = lo, k_n = hi, cs = 0.f;
 #pragma unroll
-    for (int j = 1; j <= 16; ++j) {
+    for (int j = 1; j <= 16 * W; ++j) {
         if (KC ? (j <= KC) : true) {
-            cs += RQS_MIN + RQS_P(acc, Q, j - 1) * inv;
+            cs += RQS_MIN + RQS_PW(acc, Q, j - 1) * inv;
             const bool last = (j == Kn);
             const bool used = KC ? true : (j <= K);
             const float knot = last ? hi : (hi - lo) * cs + lo;          // ends pinned
@@ -1125,21 +1187,21 @@ __device__ __forceinline__ void rqs_search(tile<1> (&acc)[4], rqs_elems &e, int 
     e.a_w[Q] = k_n - k_b;
 }
 // phase 1: knots of the other block at the found bin
-template <int Q, int KC>
+template <int Q, int KC, int W = 1>
 __device__ __forceinline__ void rqs_select(tile<1> (&acc)[4], rqs_elems &e, int K, float lo, float hi) {
 #ifndef SX_RQS_FLAT
-    if constexpr (KC == 16) { rqs_select16<Q>(acc, e, lo, hi); return; }
+    if constexpr (KC == 16 && W == 1) { rqs_select16<Q>(acc, e, lo, hi); return; }
 #endif
-    const float inv = rqs_softmax<Q, KC>(acc, K);
+    const float inv = rqs_softmax<Q, KC, W>(acc, K);
     const int Kn = KC ? KC : K;
     const int b = e.b[Q] & (RQS_OUT - 1);
     // only two knots are needed: select their cumulative sums in the sweep and rescale those two afterwards
     float cs = 0.f, cs_b = 0.f, cs_n = 0.f;
     bool has_b = false, has_n = false;
 #pragma unroll
-    for (int j = 1; j <= 16; ++j) {
+    for (int j = 1; j <= 16 * W; ++j) {
         if (KC ? (j < KC) : true) {                                      // knot K is `hi` (the default k_n)
-            cs += RQS_MIN + RQS_P(acc, Q, j - 1) * inv;
+            cs += RQS_MIN + RQS_PW(acc, Q, j - 1) * inv;
             const bool used = KC ? true : (j < Kn);
             const bool is_b = used && j == b, is_n = used && j == b + 1;
             cs_b = is_b ? cs : cs_b;
@@ -1159,6 +1221,57 @@ __device__ __forceinline__ float fast_log(float v) { return __builtin_amdgcn_log
 __device__ __forceinline__ float rqs_softplus(float v) { return v > 20.f ? v : fast_log(1.f + fast_exp(v)); }
 // phase 2: the two knot derivatives at the bin (:107,:206-207), then the rational-quadratic (:236-248) or its
 // inverse (:212-234; the returned log-derivative is already negated like the reference's).
+// the evaluation behind the derivative pick: softplus of the two picked parameters (:107), the rational-quadratic (:236-248) or its
+// inverse (:212-234; the returned log-derivative is already negated like the reference's), the linear tails (:86-87)
+template <int Q, bool REV, class H>
+__device__ __forceinline__ void rqs_eval_core(float r_b, float r_n, bool in, const rqs_elems &e, float &out, float &ljd, H &hk) {
+    const float d_b = RQS_MIN + rqs_softplus(r_b);
+    hk.template pt<4>();
+    const float d_n = RQS_MIN + rqs_softplus(r_n);
+    hk.template pt<5>();
+    // REV: the searched block is the heights (codomain side), the selected one the widths
+    const float cw_b = REV ? e.c_b[Q] : e.a_b[Q], w_b = REV ? e.c_w[Q] : e.a_w[Q];
+    const float ch_b = REV ? e.a_b[Q] : e.c_b[Q], h_b = REV ? e.a_w[Q] : e.c_w[Q];
+    const float s_b = h_b * fast_rcp(w_b);
+    const float xin = in ? e.x[Q] : (REV ? ch_b : cw_b);
+    if constexpr (REV) {
+        const float dy = xin - ch_b;
+        const float q = d_b + d_n - 2.f * s_b;
+        hk.template pt<6>();
+        const float a = dy * q + h_b * (s_b - d_b);
+        const float bb = h_b * d_b - dy * q;
+        const float c = -s_b * dy;
+        const float disc = bb * bb - 4.f * a * c;
+        hk.template pt<7>();
+        // (disc >= 0 in exact arithmetic -- the spline is monotone --; rounding can leave it a few ulps below zero where the root
+        //  sits on a knot and the reference's own fp32 evaluation stays at or above it: clamp instead of returning NaN, :223)
+        const float root = (2.f * c) * fast_rcp(-bb - __builtin_amdgcn_sqrtf(__builtin_fmaxf(disc, 0.f)));
+        out = root * w_b + cw_b;
+        hk.template pt<8>();
+        const float tomt = root * (1.f - root), omr = 1.f - root;
+        const float den = s_b + q * tomt;
+        hk.template pt<9>();
+        const float dnum = (s_b * s_b) * (d_n * (root * root) + 2.f * s_b * tomt + d_b * (omr * omr));
+        hk.template pt<10>();
+        ljd = -fast_log(dnum) + 2.f * fast_log(den);
+    } else {
+        const float theta = (xin - cw_b) * fast_rcp(w_b);
+        hk.template pt<6>();
+        const float tomt = theta * (1.f - theta), omt = 1.f - theta;
+        const float num = h_b * (s_b * (theta * theta) + d_b * tomt);
+        hk.template pt<7>();
+        const float den = s_b + (d_b + d_n - 2.f * s_b) * tomt;
+        out = ch_b + num * fast_rcp(den);
+        hk.template pt<8>();
+        const float dnum = (s_b * s_b) * (d_n * (theta * theta) + 2.f * s_b * tomt + d_b * (omt * omt));
+        hk.template pt<9>();
+        hk.template pt<10>();
+        ljd = fast_log(dnum) - 2.f * fast_log(den);
+    }
+    out = in ? out : e.x[Q];                                    // :86-87 linear tails
+    ljd = in ? ljd : 0.f;
+    hk.template pt<11>();
+}
 template <int Q, bool REV, int KC, class H>
 __device__ __forceinline__ void rqs_eval(const f32x16 &u, const rqs_elems &e, int K, float &out, float &ljd, H &hk) {
     hk.template pt<0>();
@@ -1206,52 +1319,27 @@ __device__ __forceinline__ void rqs_eval(const f32x16 &u, const rqs_elems &e, in
         }
     }
     }
-    const float d_b = RQS_MIN + rqs_softplus(r_b);
-    hk.template pt<4>();
-    const float d_n = RQS_MIN + rqs_softplus(r_n);
-    hk.template pt<5>();
-    // REV: the searched block is the heights (codomain side), the selected one the widths
-    const float cw_b = REV ? e.c_b[Q] : e.a_b[Q], w_b = REV ? e.c_w[Q] : e.a_w[Q];
-    const float ch_b = REV ? e.a_b[Q] : e.c_b[Q], h_b = REV ? e.a_w[Q] : e.c_w[Q];
-    const float s_b = h_b * fast_rcp(w_b);
-    const float xin = in ? e.x[Q] : (REV ? ch_b : cw_b);
-    if constexpr (REV) {
-        const float dy = xin - ch_b;
-        const float q = d_b + d_n - 2.f * s_b;
-        hk.template pt<6>();
-        const float a = dy * q + h_b * (s_b - d_b);
-        const float bb = h_b * d_b - dy * q;
-        const float c = -s_b * dy;
-        const float disc = bb * bb - 4.f * a * c;
-        hk.template pt<7>();
-        // (disc >= 0 in exact arithmetic -- the spline is monotone --; rounding can leave it a few ulps below zero where the root
-        //  sits on a knot and the reference's own fp32 evaluation stays at or above it: clamp instead of returning NaN, :223)
-        const float root = (2.f * c) * fast_rcp(-bb - __builtin_amdgcn_sqrtf(__builtin_fmaxf(disc, 0.f)));
-        out = root * w_b + cw_b;
-        hk.template pt<8>();
-        const float tomt = root * (1.f - root), omr = 1.f - root;
-        const float den = s_b + q * tomt;
-        hk.template pt<9>();
-        const float dnum = (s_b * s_b) * (d_n * (root * root) + 2.f * s_b * tomt + d_b * (omr * omr));
-        hk.template pt<10>();
-        ljd = -fast_log(dnum) + 2.f * fast_log(den);
-    } else {
-        const float theta = (xin - cw_b) * fast_rcp(w_b);
-        hk.template pt<6>();
-        const float tomt = theta * (1.f - theta), omt = 1.f - theta;
-        const float num = h_b * (s_b * (theta * theta) + d_b * tomt);
-        hk.template pt<7>();
-        const float den = s_b + (d_b + d_n - 2.f * s_b) * tomt;
-        out = ch_b + num * fast_rcp(den);
-        hk.template pt<8>();
-        const float dnum = (s_b * s_b) * (d_n * (theta * theta) + 2.f * s_b * tomt + d_b * (omt * omt));
-        hk.template pt<9>();
-        hk.template pt<10>();
-        ljd = fast_log(dnum) - 2.f * fast_log(den);
+    rqs_eval_core<Q, REV>(r_b, r_n, in, e, out, ljd, hk);
+}
+// 17..32 bins: the fifteen-step pick above over the element's two tiles
+template <int Q, bool REV>
+__device__ __forceinline__ void rqs_eval_wide(const f32x16 &u0, const f32x16 &u1, const rqs_elems &e, int K, float &out, float &ljd) {
+    const int b = e.b[Q] & (RQS_OUT - 1);
+    const bool in = e.b[Q] < RQS_OUT;
+    const float cst = 0.5397424172369522f;
+    float r_b = cst, r_n = cst;
+    bool is_prev = (b == 0);
+#pragma unroll
+    for (int k = 0; k < 31; ++k) {
+        const bool used = k < K - 1;
+        const float v = k < 16 ? u0[k & 15] : u1[k & 15];
+        const bool is_next = (b == k + 1);
+        r_n = (used && is_prev) ? v : r_n;          // k == b
+        r_b = (used && is_next) ? v : r_b;          // k == b - 1
+        is_prev = is_next;
     }
-    out = in ? out : e.x[Q];                                    // :86-87 linear tails
-    ljd = in ? ljd : 0.f;
-    hk.template pt<11>();
+    rqs_nohook nh;
+    rqs_eval_core<Q, REV>(r_b, r_n, in, e, out, ljd, nh);
 }
 template <int Q, bool REV, int KC>
 __device__ __forceinline__ void rqs_eval(const f32x16 &u, const rqs_elems &e, int K, float &out, float &ljd) {
@@ -1446,8 +1534,39 @@ __device__ __forceinline__ void rqs_triple(tile<1> (&xs)[TX], const btile<1> (&b
         if (st.reverse) rqs16_block<HT, 2, true>(w, bh, e, c1, out, lj, pf);
         else rqs16_block<HT, 2, false>(w, bh, e, c1, out, lj, pf);
         live_mask = st.mask; ldj_scale = st.ldj_scale;
+    } else if (K > 16) {
+        // 17 .. 32 bins (round 4: the one-launch tier used to stop at 16 and such layers ran conditioner program + element-wise kernel
+        // through HBM, 8x slower): an element's parameters are TWO output tiles, so a step carries two of the lane's four elements
+        // and a group is two triples (step.act bit 1 = which pair); the sweeps with the running maximum, over 32 slots
+        const int half = st0.act >> 1;
+        rqs_elems e2;
+        e2.x[0] = half ? e.x[2] : e.x[0]; e2.x[1] = half ? e.x[3] : e.x[1];
+        wptr w;
+        dstep st;
+        tile<1> acc[4];
+        rqs_gemm<HT>(w0, bh, acc);
+        rqs_search<0, 0, 2>(acc, e2, K, lo, hi); asm volatile("" : "+v"(e2.b[0]), "+v"(e2.a_b[0]), "+v"(e2.a_w[0])); __builtin_amdgcn_sched_barrier(0);
+        rqs_search<1, 0, 2>(acc, e2, K, lo, hi); asm volatile("" : "+v"(e2.b[1]), "+v"(e2.a_b[1]), "+v"(e2.a_w[1])); __builtin_amdgcn_sched_barrier(0);
+        advance(st, w);
+        rqs_block_scalars<HT>(w, h, lo, hi, lean);
+        rqs_gemm<HT>(w, bh, acc);
+        rqs_select<0, 0, 2>(acc, e2, K, lo, hi); asm volatile("" : "+v"(e2.c_b[0]), "+v"(e2.c_w[0])); __builtin_amdgcn_sched_barrier(0);
+        rqs_select<1, 0, 2>(acc, e2, K, lo, hi); asm volatile("" : "+v"(e2.c_b[1]), "+v"(e2.c_w[1])); __builtin_amdgcn_sched_barrier(0);
+        advance(st, w);
+        rqs_gemm<HT>(w, bh, acc);
+        float o0, o1, l0, l1;
+        if (st.reverse) {
+            rqs_eval_wide<0, true>(acc[0].v[0], acc[1].v[0], e2, K, o0, l0); __builtin_amdgcn_sched_barrier(0);
+            rqs_eval_wide<1, true>(acc[2].v[0], acc[3].v[0], e2, K, o1, l1);
+        } else {
+            rqs_eval_wide<0, false>(acc[0].v[0], acc[1].v[0], e2, K, o0, l0); __builtin_amdgcn_sched_barrier(0);
+            rqs_eval_wide<1, false>(acc[2].v[0], acc[3].v[0], e2, K, o1, l1);
+        }
+        out[0] = half ? e.x[0] : o0; out[1] = half ? e.x[1] : o1; out[2] = half ? o0 : e.x[2]; out[3] = half ? o1 : e.x[3];
+        lj[0] = half ? 0.f : l0; lj[1] = half ? 0.f : l1; lj[2] = half ? l0 : 0.f; lj[3] = half ? l1 : 0.f;
+        live_mask = st.mask; ldj_scale = st.ldj_scale;
     } else {
-        // any bin count, softmax with its running maximum: block by block, one element at a time (interleaved by the scheduler the
+        // up to 16 bins, softmax with its running maximum: block by block, one element at a time (interleaved by the scheduler the
         // four sweeps keep ~60 lane masks alive: hundreds of SGPR spills and nine VGPRs of spill lanes in the whole kernel)
         // (the empty asm pins each element's results where they are computed: without it the optimizer sinks all four sweeps of a
         //  block below the step advance that follows, and the register allocation of the whole kernel pays for that)
@@ -2606,6 +2725,10 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
         tile<NS> hid[MODE == 1 ? HT : 1];
         constexpr bool LIN = MODE == 2 || MODE == 7 || MODE == 8;    // programs with dense linear layers
         tile<NS> hidp[(MODE == 9 || MODE == 14 || MODE == 16 || MODE == 17) ? HT : 1];   // MODE 9 / 14 / 16 / 17: hidden state kept between deep-conditioner steps
+        // MODE 20: programs with hidden-chunk couplings (split masks: TX / 2 transformed tiles): their (log_scale, shift) accumulators.
+        // (An own kernel instance: as part of MODE 9 the loop-carried tiles took its deep-conditioner programs from 54 to 205 spilled
+        //  registers at 64 columns.)
+        [[maybe_unused]] tile<NS> pacc[(MODE == 20 && TX >= 2) ? TX : 1];
         // MODE 18 / 19 = MODE 3 / 12 with the training forward's side outputs (tanh h per layer, the state each layer received):
         // their own instances, so that the inference kernels carry none of that code (it cost cfg 3 0.7 % when it shared MODE 3)
         constexpr bool SIDE_OUT = MODE == 18 || MODE == 19;
@@ -2898,6 +3021,12 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                         }
                         if (st.reverse) coupling_affine_deep<NS, TX, HT, 0, TX, true>(xs, hidp, w, st, ldj, rg);
                         else coupling_affine_deep<NS, TX, HT, 0, TX, false>(xs, hidp, w, st, ldj, rg);
+                    }
+                    break;
+                case SX_STEP_COUPLING_AFFINE_HC:
+                    if constexpr (MODE == 20 && TX >= 2) {
+                        if (st.c0 == 0) coupling_affine_chunk_dispatch<NS, TX, HT, 0, TX / 2, TX / 2, TX / 2>(xs, pacc, w, st, ldj, rg);       // cond = low tiles
+                        else coupling_affine_chunk_dispatch<NS, TX, HT, TX / 2, TX / 2, 0, TX / 2>(xs, pacc, w, st, ldj, rg);               // cond = high tiles
                     }
                     break;
                 case SX_STEP_MLP_HIDDEN2:
@@ -3355,6 +3484,7 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
     else if (a.mlp_mode == 15) SX_FL(15);
     else if (a.mlp_mode == 16) SX_FL(16);
     else if (a.mlp_mode == 17) SX_FL(17);
+    else if (a.mlp_mode == 20) { if constexpr (TX >= 2) SX_FL(20); }
     else if (a.mlp_mode == 7) { if constexpr (TX >= 2) SX_FL(7); }
     else if (a.mlp_mode == 8) { if constexpr (TX >= 2) SX_FL(8); }
     else if (a.mlp_mode == 11) {

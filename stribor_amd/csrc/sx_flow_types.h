@@ -57,7 +57,7 @@ struct sx_flow_args {
 #define SX_MODE_BASE(MODE) ((MODE) == 18 ? 3 : ((MODE) == 19 ? 12 : (MODE)))
 #ifndef SX_WAVES_FOR
 #define SX_WAVES_FOR(TX, MODE) SX_WAVES_FOR_(TX, SX_MODE_BASE(MODE))
-#define SX_WAVES_FOR_(TX, MODE) ((MODE) == 11 || (MODE) == 14 ? 1 : ((MODE) == 15 || (MODE) == 16 || (MODE) == 17) ? ((TX) >= 4 ? 1 : 2) : ((MODE) == 10 || (MODE) == 12 || (MODE) == 13) ? ((TX) >= 4 ? 1 : SX_RQS_WAVES) : (MODE) == 9 ? ((TX) >= 4 ? 1 : 2) : (MODE) >= 7 ? 2 : (MODE) >= 5 ? ((TX) >= 4 ? 2 : 4) : ((TX) >= 4 ? 1 : ((MODE) == 3 ? SX_RQS_WAVES : ((MODE) == 0 ? 3 : 2))))
+#define SX_WAVES_FOR_(TX, MODE) ((MODE) == 11 || (MODE) == 14 ? 1 : (MODE) == 20 ? ((TX) >= 4 ? 1 : 2) : ((MODE) == 15 || (MODE) == 16 || (MODE) == 17) ? ((TX) >= 4 ? 1 : 2) : ((MODE) == 10 || (MODE) == 12 || (MODE) == 13) ? ((TX) >= 4 ? 1 : SX_RQS_WAVES) : (MODE) == 9 ? ((TX) >= 4 ? 1 : 2) : (MODE) >= 7 ? 2 : (MODE) >= 5 ? ((TX) >= 4 ? 2 : 4) : ((TX) >= 4 ? 1 : ((MODE) == 3 ? SX_RQS_WAVES : ((MODE) == 0 ? 3 : 2))))
 #endif
 
 // waves per workgroup: the pure split-coupling kernels (MODE 5 / 6) run 8-wave workgroups -- D <= 64 (128 VGPRs): two

@@ -382,6 +382,46 @@ class NormalizingFlow(Transform):
         except NotImplementedError:
             return None
 
+    def _fused_segments(self, reverse: bool, dim: int, latent_dim: int, device, t_kind=None):
+        key = ('segments', reverse, dim, latent_dim, str(device), t_kind)
+        return self._cached(key, lambda: self._build_segments(reverse, dim, latent_dim, device, t_kind))
+
+    def _build_segments(self, reverse, dim, latent_dim, device, t_kind=None):
+        """The flow as a SEQUENCE of fused programs over contiguous runs of layers, for flows whose steps do not fit one program
+        (SX_MAX_STEPS = 128 steps travel in the kernel's argument segment: 16 spline couplings of 16 bins are 208, one of 24 bins is
+        25).  The state crosses HBM once per segment -- not once or twice per LAYER plus the conditioner's output, as on the
+        layer-by-layer path -- and the log-dets of the segments are added on the device.  None when a layer cannot be planned at all."""
+        order = list(reversed(self.transforms)) if reverse else list(self.transforms)
+        scale = -1.0 if reverse else 1.0
+        try:
+            hw = max([f._plan_hidden_width() for f in order] + [1])
+            segs, i = [], 0
+            while i < len(order):
+                b = ProgramBuilder(dim, latent_dim, hw)
+                b.t = t_kind
+                b.dense_deriver = self._dense_deriver()
+                for f in order[i:]:
+                    m = f._plan_first_mask(dim)
+                    if m is not None:
+                        b.choose_layout(m)
+                        break
+                j = i
+                while j < len(order):
+                    snap = b.snapshot()
+                    if not order[j]._plan(b, reverse, scale):
+                        return None
+                    if len(b.steps) > _hip.SX_MAX_STEPS:
+                        b.restore(snap)
+                        break
+                    j += 1
+                if j == i:
+                    return None                     # a single layer beyond the program size
+                segs.append(b.build(device))
+                i = j
+            return segs if len(segs) > 1 else None
+        except NotImplementedError:
+            return None
+
     def _dense_deriver(self):
         from .flows.linear import DenseDeriver
         return self._cached(('dense-deriver',), lambda: DenseDeriver(list(self.transforms)))
@@ -621,13 +661,36 @@ class NormalizingFlow(Transform):
         lat2 = None
         if latent is not None:
             lat2 = latent.reshape(-1, latent.shape[-1])
-        prog = self._fused_program(reverse, x2.shape[1], 0 if lat2 is None else lat2.shape[1], x.device, t_kind)
-        if prog is None:
-            return None
-        y, ldj, logp = prog.run(x2, lat2, want_y, want_ldj, want_logp, sum_out,
-                                row_t=t.reshape(-1) if t_kind == 'tensor' else None)
+        ld = 0 if lat2 is None else lat2.shape[1]
+        row_t = t.reshape(-1) if t_kind == 'tensor' else None
         shp = lambda t, d: None if t is None else t.reshape(*lead, d)
-        return shp(y, x2.shape[1]), shp(ldj, 1), shp(logp, 1)
+        prog = self._fused_program(reverse, x2.shape[1], ld, x.device, t_kind)
+        if prog is not None:
+            y, ldj, logp = prog.run(x2, lat2, want_y, want_ldj, want_logp, sum_out, row_t=row_t)
+            return shp(y, x2.shape[1]), shp(ldj, 1), shp(logp, 1)
+        segs = self._fused_segments(reverse, x2.shape[1], ld, x.device, t_kind)
+        if segs is None:
+            return None
+        # several launches: fp32 state between them (a bf16 batch is rounded once, on the way out, like the one-launch path whose
+        # state never leaves registers), log-dets added on the device; sum_out collects every segment's block sums
+        cur = x2.to(torch.float32) if x2.dtype == torch.bfloat16 else x2
+        need_l = want_ldj or want_logp
+        acc = None
+        for i, p in enumerate(segs):
+            last = i == len(segs) - 1
+            y, ldj, logp = p.run(cur, lat2, want_y or not last, need_l and not (last and want_logp and not want_ldj),
+                                 want_logp and last, sum_out, row_t=row_t)
+            if not last or want_y:
+                cur = y
+            if ldj is not None:
+                acc = ldj if acc is None else acc + ldj
+            if last and logp is not None and not want_ldj:
+                logp = logp if acc is None else logp + acc
+            elif last and logp is not None:
+                # (both asked for: the last segment's logp misses the earlier segments' log-dets, its ldj is part of `acc`)
+                logp = logp + (acc - ldj)
+        y = cur.to(x2.dtype) if want_y else None
+        return shp(y, x2.shape[1]), shp(acc if want_ldj else None, 1), shp(logp if want_logp else None, 1)
 
     # ---- reference method set -----------------------------------------------------------------------------
     def forward(self, x, latent=None, **kwargs):

@@ -630,7 +630,7 @@ class Coupling(Transform):
             return False
         sp = self.transform
         net = getattr(sp, 'latent_net', None)
-        if not isinstance(net, MLP) or net.activation_name != 'Tanh' or sp.n_bins > 16 or \
+        if not isinstance(net, MLP) or net.activation_name != 'Tanh' or sp.n_bins > (32 if sp.spline_type == 'quadratic' else 16) or \
                 sp.spline_type not in ('quadratic', 'cubic') or os.environ.get('STRIBOR_CUBIC_UNFUSED') == '1' and sp.spline_type == 'cubic':
             return False
         lin = net.linears()

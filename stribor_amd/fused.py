@@ -474,7 +474,11 @@ class ProgramBuilder:
         lat_tiles = _ceil_div(latent_dim + time_slots, 32)
         self.tiles = _round_tiles(max(_ceil_div(dim, 32), min_x_tiles) + lat_tiles, f'dim {dim} + latent {latent_dim}')
         self.x_tiles = self.tiles - lat_tiles
-        self.h_tiles = _round_tiles(_ceil_div(hidden_width, 32), f'hidden width {hidden_width}')
+        # hidden layers wider than four tiles: single-hidden-layer Tanh couplings run as CHUNK steps (add_coupling_affine: the
+        # conditioner's output is a sum over hidden-unit chunks, accumulated in registers across the steps); the chunk is as wide
+        # as one step's weights allow in the LDS ring (128 hidden units up to 64 columns, 64 beyond)
+        ht = _ceil_div(hidden_width, 32)
+        self.h_tiles = _round_tiles(ht, f'hidden width {hidden_width}') if ht <= 4 else (2 if self.tiles >= 4 else 4)
         self.n_slots = 32 * self.x_tiles
         # slot -> logical column (-1 = padding); identity until choose_layout / permutations change it
         self.col_of_slot = np.full(self.n_slots, -1, dtype=np.int64)
@@ -488,6 +492,15 @@ class ProgramBuilder:
         # x per state column of this program) and the rows' stride
         self.x_cols: Optional[np.ndarray] = None
         self.x_stride = 0
+
+    # -- planning a flow in segments: a layer that would not fit the program is taken back ---------------------------
+    def snapshot(self):
+        return (list(self.steps), list(self.jobs), self.blob_floats, self.col_of_slot.copy(),
+                None if self.in_col is None else self.in_col.copy(), self._spline_layers, self.mlp_out_dim)
+
+    def restore(self, snap) -> None:
+        self.steps, self.jobs, self.blob_floats, self.col_of_slot, self.in_col, self._spline_layers, self.mlp_out_dim = (
+            list(snap[0]), list(snap[1]), snap[2], snap[3].copy(), None if snap[4] is None else snap[4].copy(), snap[5], snap[6])
 
     # -- layout ------------------------------------------------------------------------------------
     def choose_layout(self, first_mask: Optional[np.ndarray]) -> None:
@@ -579,11 +592,11 @@ class ProgramBuilder:
                 li = p - self.n_slots
                 if li < self.latent_dim:
                     col_idx[i] = D + li                    # cat([z, latent]) (coupling.py:64-65)
-        row_idx = np.full(32 * HT, -1, dtype=np.int64)
-        row_idx[:hidden] = np.arange(hidden)
         n1 = _hip.packed_linear_floats(HT, ct)
         n2 = _hip.packed_linear_floats(2 * tt, HT)
-        off, n = self._alloc(n1 + n2)
+        wide = hidden > 32 * HT
+        if wide and (act != _hip.ACT_CODES['Tanh'] or variant == 'dense'):
+            raise NotImplementedError('hidden layers wider than the program\'s hidden tiles: Tanh conditioners, masks that split the tiles')
         # Tanh hot path: fold the constants of tanh(z) = 1 - 2/(exp2(2 log2e z) + 1) and exp(x) = exp2(log2e x)
         # into the packed weights (exact re-parametrisation; fp32 MFMA shares the VALU, so every saved VALU
         # instruction is saved wall time):  hidden r = 1/(exp2(c z) + 1);  W2 tanh + b2 = (-2 W2) r + (b2 + W2 1).
@@ -605,7 +618,6 @@ class ProgramBuilder:
             fold = 1.0
             act = _hip.ACT_TANH_FOLDED
             ldj_scale = ldj_scale / kk
-        self.jobs.append(_PackJob(W1, b1, row_idx, col_idx, HT, ct, off, rs1, bs1, 0.0))
         # GEMM-2 operand: per transformed tile, 32 log_scale rows then 32 shift rows (affine.py:66)
         row2 = np.full(32 * 2 * tt, -1, dtype=np.int64)
         for t in range(tt):
@@ -614,11 +626,26 @@ class ProgramBuilder:
                 if p < self.n_slots and slot_live[p]:
                     row2[32 * (2 * t) + i] = col[p]
                     row2[32 * (2 * t + 1) + i] = D + col[p]
-        col2 = np.full(32 * HT, -1, dtype=np.int64)
-        col2[:hidden] = np.arange(hidden)
-        self.jobs.append(_PackJob(W2, b2, row2, col2, 2 * tt, HT, off + n1, rs2, bs2, fold))
-        self.steps.append(dict(kind=_hip.STEP_COUPLING_AFFINE, c0=c0, ct=ct, t0=t0, tt=tt, reverse=int(reverse),
-                               act=act, blob_off=off, blob_floats=n, ldj_scale=ldj_scale, ldj_const=0.0))
+        # one step per chunk of 32 HT hidden units (one chunk = the whole layer up to that width).  W2 tanh(W1 z + b1) + b2 is a SUM
+        # over hidden-unit chunks: a chunk step evaluates its slice of the hidden layer and adds its share of (log_scale, shift) to
+        # accumulator tiles that live in registers across the steps (kernel MODE 9); the first chunk carries b2, every chunk its own
+        # share of the folded constant W2 1 (the packer folds over the chunk's columns), the last one applies the affine map
+        chunk = 32 * HT
+        n_chunks = _ceil_div(hidden, chunk)
+        for c in range(n_chunks):
+            hsel = np.arange(c * chunk, min(hidden, (c + 1) * chunk))
+            row_idx = np.full(32 * HT, -1, dtype=np.int64)
+            row_idx[:len(hsel)] = hsel
+            col2 = np.full(32 * HT, -1, dtype=np.int64)
+            col2[:len(hsel)] = hsel
+            off, n = self._alloc(n1 + n2)
+            self.jobs.append(_PackJob(W1, b1, row_idx, col_idx, HT, ct, off, rs1, bs1, 0.0))
+            self.jobs.append(_PackJob(W2, b2 if c == 0 else None, row2, col2, 2 * tt, HT, off + n1, rs2, bs2, fold))
+            step = dict(kind=_hip.STEP_COUPLING_AFFINE_HC if wide else _hip.STEP_COUPLING_AFFINE, c0=c0, ct=ct, t0=t0, tt=tt,
+                        reverse=int(reverse), act=act, blob_off=off, blob_floats=n, ldj_scale=ldj_scale, ldj_const=0.0)
+            if wide:
+                step['pad_'] = int(c == 0) | (int(c == n_chunks - 1) << 1)
+            self.steps.append(step)
 
     def add_coupling_affine_deep(self, linears: Sequence[Tuple], mask: np.ndarray, act: int, reverse: bool,
                                  ldj_scale: float) -> None:
@@ -628,6 +655,8 @@ class ProgramBuilder:
         self._freeze_input()
         assert len(linears) >= 3
         D, T, HT = self.dim, self.tiles, self.h_tiles
+        if max(W.shape[0] for (W, _) in linears[:-1]) > 32 * HT:
+            raise NotImplementedError('conditioners with several hidden layers fuse up to 128 units per layer')
         mask = np.asarray(mask, dtype=np.float64).reshape(-1)
         if mask.size == 1:
             mask = np.full(D, mask[0])
@@ -703,8 +732,10 @@ class ProgramBuilder:
         two boundary derivatives; phase steps with act = 1, kernel MODE 12 / 13)."""
         self._freeze_input()
         D, T, HT, K = self.dim, self.tiles, self.h_tiles, n_bins
-        if K > 16:
-            raise NotImplementedError('fused spline coupling supports n_bins <= 16')
+        if max([hidden] + [Wk.shape[0] for (Wk, _) in middle]) > 32 * HT:
+            raise NotImplementedError('spline couplings fuse with hidden layers of up to 128 units')
+        if K > (16 if cubic else 32):
+            raise NotImplementedError('fused spline coupling supports n_bins <= 16 (cubic) / 32 (rational-quadratic)')
         P = 2 * K + 2 if cubic else 3 * K - 1
         mask = np.asarray(mask, dtype=np.float64).reshape(-1)
         if mask.size == 1:
@@ -780,36 +811,44 @@ class ProgramBuilder:
             for g in range(4):
                 if not any((live_mask >> (q + 8 * g + 4 * h)) & 1 for q in range(4) for h in range(2)):
                     continue
-                bound_slot = None
-                for phase, (start, count, lo, hi) in enumerate(blocks):
-                    # output tile q of the step = the 16 parameters of the lane's element q (slot q + 8 g + 4 h of the state tile):
-                    # register k of lane half h is row kmap(k, h) of the tile (sx_flow_kernel.h RQS_P)
-                    rows = np.full(128, -1, dtype=np.int64)
-                    for q in range(4):
-                        for h in range(2):
-                            slot = 32 * t + q + 8 * g + 4 * h
-                            if not slot_live[slot]:
-                                continue
-                            for k in range(min(count, 16)):
-                                rows[32 * q + _kmap(k, h)] = col[slot] * P + start + k
-                    nlin = _hip.packed_linear_floats(4, HT)
-                    off, n = self._alloc(nlin + 4)
-                    # the two softmax blocks are packed in base 2 (rows and bias times log2 e): the kernel's softmax is then
-                    # v_exp_f32(p - max) with no multiply (32 instructions per element)
-                    sc2 = LOG2E if phase < 2 else 1.0
-                    # (the two softmax blocks of a group leave the bound on their logits in the slot behind (lo, hi) of the FIRST
-                    #  block's blob: the K = 16 phases run without a running maximum below it -- sx_flow_kernel.h rqs16_sums --
-                    #  and the kernel decides once per group; the blob buffer starts zeroed and the slot only grows)
-                    if phase == 0:
-                        bound_slot = off + nlin + 2
-                    self.jobs.append(_PackJob(W2, b2, rows, col2, 4, HT, off, np.full(128, -2.0 * sc2), np.full(128, sc2), 1.0,
-                                              bound_off=bound_slot if phase < 2 else None))
-                    self.jobs.append(_ScalarsJob([lo, hi], off + nlin))
-                    s_scale = (-ldj_scale if reverse else ldj_scale) if phase == 2 else 0.0
-                    step = dict(kind=_hip.STEP_RQS_PHASE, c0=g, ct=phase, t0=t, tt=K, reverse=int(reverse), act=int(cubic),
-                                blob_off=off, blob_floats=n, ldj_scale=s_scale, ldj_const=0.0)
-                    step['pad_'] = live_mask - (1 << 32) if live_mask >= (1 << 31) else live_mask
-                    self.steps.append(step)
+                # up to 16 bins: one triple of steps per group, an element's parameters = ONE output tile (four elements per step);
+                # 17 .. 32 bins (rational-quadratic only): TWO tiles per element, so a group is two triples of two elements each
+                # (step.act bit 1 = which pair)
+                wide = K > 16
+                for half in ((0, 1) if wide else (0,)):
+                    elems = (2 * half, 2 * half + 1) if wide else (0, 1, 2, 3)
+                    if wide and not any((live_mask >> (q + 8 * g + 4 * h)) & 1 for q in elems for h in range(2)):
+                        continue
+                    bound_slot = None
+                    for phase, (start, count, lo, hi) in enumerate(blocks):
+                        # output tile of the step -> register k of lane half h = row kmap(k, h) of the tile (sx_flow_kernel.h RQS_P)
+                        rows = np.full(128, -1, dtype=np.int64)
+                        for qi, q in enumerate(elems):
+                            for h in range(2):
+                                slot = 32 * t + q + 8 * g + 4 * h
+                                if not slot_live[slot]:
+                                    continue
+                                for k in range(min(count, 32 if wide else 16)):
+                                    tile = (2 * qi + (k >> 4)) if wide else q
+                                    rows[32 * tile + _kmap(k & 15, h)] = col[slot] * P + start + k
+                        nlin = _hip.packed_linear_floats(4, HT)
+                        off, n = self._alloc(nlin + 4)
+                        # the two softmax blocks are packed in base 2 (rows and bias times log2 e): the kernel's softmax is then
+                        # v_exp_f32(p - max) with no multiply (32 instructions per element)
+                        sc2 = LOG2E if phase < 2 else 1.0
+                        # (the two softmax blocks of a group leave the bound on their logits in the slot behind (lo, hi) of the FIRST
+                        #  block's blob: the K = 16 phases run without a running maximum below it -- sx_flow_kernel.h rqs16_sums --
+                        #  and the kernel decides once per group; the blob buffer starts zeroed and the slot only grows)
+                        if phase == 0:
+                            bound_slot = off + nlin + 2
+                        self.jobs.append(_PackJob(W2, b2, rows, col2, 4, HT, off, np.full(128, -2.0 * sc2), np.full(128, sc2), 1.0,
+                                                  bound_off=bound_slot if phase < 2 else None))
+                        self.jobs.append(_ScalarsJob([lo, hi], off + nlin))
+                        s_scale = (-ldj_scale if reverse else ldj_scale) if phase == 2 else 0.0
+                        step = dict(kind=_hip.STEP_RQS_PHASE, c0=g, ct=phase, t0=t, tt=K, reverse=int(reverse),
+                                    act=int(cubic) | (half << 1), blob_off=off, blob_floats=n, ldj_scale=s_scale, ldj_const=0.0)
+                        step['pad_'] = live_mask - (1 << 32) if live_mask >= (1 << 31) else live_mask
+                        self.steps.append(step)
 
         self._spline_layers += 1
 
@@ -927,6 +966,8 @@ class ProgramBuilder:
         (x * mask | latent | the time slot `time_sel`, through column `time_col` of W1 when time is concatenated), the affine map
         with the time embedding acts on the data tiles.  time_net: a net.Time* module with an in-kernel `kind`."""
         self._freeze_input()
+        if hidden > 32 * self.h_tiles:
+            raise NotImplementedError('time-conditioned couplings fuse with hidden layers of up to 128 units')
         D, T, HT, L = self.dim, self.tiles, self.h_tiles, self.latent_dim
         # transformed tiles [0, XT): the tiles that hold data columns, rounded up to what the kernel dispatches on (all, half or
         # a quarter of the tiles; a latent / padding tile inside the range has zero weights: exp(0) x + 0)
@@ -1122,11 +1163,16 @@ class ProgramBuilder:
         dense = kinds & {_hip.STEP_LINEAR_TILE, _hip.STEP_ROW_SCALE_EXP}
         deep = kinds & {_hip.STEP_CPL_HIDDEN, _hip.STEP_CPL_HIDDEN2, _hip.STEP_COUPLING_AFFINE_DEEP}
         pointwise = _hip.STEP_POINTWISE in kinds
+        if _hip.STEP_COUPLING_AFFINE_HC in kinds and (rqs or dense or pointwise or deep or _hip.STEP_COUPLING_TIME in kinds or
+                                                      kinds & {_hip.STEP_MLP_HIDDEN, _hip.STEP_MLP_HIDDEN2, _hip.STEP_MLP_OUT_TILE}):
+            raise NotImplementedError('couplings with chunked hidden layers fuse with affine couplings / element-wise affines only')
         if rqs and dense:
             raise NotImplementedError('spline couplings cannot share a fused program with dense linear layers')
         # spline couplings beside affine couplings / point-wise steps, or both spline types: the MIXED kernel (MODE 14)
         mixed = bool(rqs) and (bool(kinds & {_hip.STEP_COUPLING_AFFINE, _hip.STEP_COUPLING_AFFINE_DEEP}) or pointwise or
-                               len({s['act'] for s in self.steps if s['kind'] == _hip.STEP_RQS_PHASE}) > 1)
+                               len({s['act'] & 1 for s in self.steps if s['kind'] == _hip.STEP_RQS_PHASE}) > 1)
+        if mixed and any(s['kind'] == _hip.STEP_RQS_PHASE and s['tt'] > 16 for s in self.steps):
+            raise NotImplementedError('spline couplings of 17..32 bins fuse in programs of rational-quadratic couplings only')
         if _hip.STEP_COUPLING_TIME in kinds and len(kinds) > 1:
             raise NotImplementedError('time-conditioned couplings form fused programs of their own')
         if pointwise and (dense or (deep and not mixed) or kinds & {_hip.STEP_MLP_HIDDEN, _hip.STEP_MLP_HIDDEN2, _hip.STEP_MLP_OUT_TILE}):

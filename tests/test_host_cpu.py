@@ -149,9 +149,20 @@ def test_planner_permutation_relabelling_matches_gather():
 
 def test_tile_limits_raise():
     with pytest.raises(NotImplementedError):
-        ProgramBuilder(200, 0, 32)
+        ProgramBuilder(300, 0, 32)
+    # round 4: hidden layers beyond four tiles plan as chunk steps (affine couplings, Tanh, split masks); everything else still refuses
+    b = ProgramBuilder(64, 0, 300)
+    assert b.h_tiles == 4
+    torch.manual_seed(0)
+    lin1, lin2 = torch.nn.Linear(64, 300), torch.nn.Linear(300, 128)
+    m = np.zeros(64)
+    m[32:] = 1
+    b.add_coupling_affine(lin1.weight, lin1.bias, lin2.weight, lin2.bias, m, _hip.ACT_CODES['Tanh'], True, -1.0, 300)
+    assert [s['kind'] for s in b.steps] == [_hip.STEP_COUPLING_AFFINE_HC] * 3 and [s['pad_'] for s in b.steps] == [1, 0, 2]
     with pytest.raises(NotImplementedError):
-        ProgramBuilder(64, 0, 300)
+        ProgramBuilder(64, 0, 300).add_coupling_affine(lin1.weight, lin1.bias, lin2.weight, lin2.bias, m, _hip.ACT_CODES['ReLU'], True, -1.0, 300)
+    with pytest.raises(NotImplementedError):
+        ProgramBuilder(64, 0, 300).add_coupling_rqs(lin1.weight, lin1.bias, lin2.weight, lin2.bias, m, True, -1.0, 300, 4, -1, 1, -1, 1)
 
 
 def test_planner_spline_flow_and_mixed_fallback():

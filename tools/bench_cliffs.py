@@ -32,7 +32,8 @@ def main():
     cases = []
     for dim, hidden in ((64, 64), (64, 128), (64, 160), (64, 256), (128, 64), (160, 64), (200, 64)):
         cases.append(('affine', dim, hidden, 0))
-    for K in (16, 24):
+    cases.append(('affine', 128, 160, 0))
+    for K in (16, 24, 32):
         cases.append(('rqs', 64, 64, K))
     cases.append(('rqs', 64, 160, 16))
     with torch.no_grad():
