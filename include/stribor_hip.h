@@ -379,6 +379,11 @@ int sx_pack_linear_bound(const float *W, const float *b, int32_t out_dim, int32_
                                         * SX_STEP_COUPLING_AFFINE; blob = pack(W1 rows of the chunk) ++ pack(W2 columns of the chunk, bias = b2
                                         * in the first chunk); pad_ bit 0 = first chunk, bit 1 = last chunk (applies the affine map).  The
                                         * chunks of a coupling come back to back. */
+#define SX_STEP_WIDE_HIDDEN         22  /* programs on EIGHT state tiles (129 .. 256 columns; tiles = x_tiles = 8): the hidden layer of an affine coupling
+                                        * whose mask splits the tiles, r = folded tanh(W1' . tiles [c0, c0 + 4) + b1') (c0 = 0 or 4, ct = 4), kept in
+                                        * registers for the SX_STEP_WIDE_AFFINE_TILE steps behind it; blob = pack(W1', h_tiles x 4) */
+#define SX_STEP_WIDE_AFFINE_TILE    23  /* ... and ONE transformed tile t0 of that coupling: (kk log_scale, shift) = W2'[rows of the tile] . r + b2', the
+                                        * affine map (coupling.py:69-95, affine.py:104-109), the log-det; blob = pack(W2' rows, 2 x h_tiles) */
 #define SX_STEP_CPL_HIDDEN          13  /* deep conditioners (>= 2 hidden layers): hidden = act(W1 . state[c0..c0+ct) + b1), kept in
                                            registers for the next step; blob = pack_linear(W1, h_tiles x ct)                    */
 #define SX_STEP_CPL_HIDDEN2         14  /* hidden = act(Wk . hidden + bk); blob = pack_linear(Wk, h_tiles x h_tiles)              */

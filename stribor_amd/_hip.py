@@ -40,6 +40,8 @@ STEP_LINEAR_BWD = 18
 STEP_POINTWISE = 19
 STEP_COUPLING_TIME = 20
 STEP_COUPLING_AFFINE_HC = 21
+STEP_WIDE_HIDDEN = 22
+STEP_WIDE_AFFINE_TILE = 23
 
 WGRAD_ROW_MAJOR, WGRAD_ROW_GROUPS, WGRAD_ROW_GROUPS_F16X3 = 0, 1, 3
 

@@ -15,10 +15,10 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     *side_width = 0;
     SX_REQUIRE(p != nullptr, "sx_flow_run: null program");
     SX_REQUIRE(p->n_steps >= 0 && p->n_steps <= SX_MAX_STEPS, "sx_flow_run: n_steps %d out of range", p->n_steps);
-    SX_REQUIRE(p->tiles == 1 || p->tiles == 2 || p->tiles == 4 || (p->tiles == 8 && p->x_tiles == 4),
-               "sx_flow_run: tiles must be 1, 2 or 4 (8 = 4 data + 4 adjoint tiles of a backward program; got %d)", p->tiles);
+    SX_REQUIRE(p->tiles == 1 || p->tiles == 2 || p->tiles == 4 || (p->tiles == 8 && (p->x_tiles == 4 || p->x_tiles == 8)),
+               "sx_flow_run: tiles must be 1, 2 or 4 (8 = 4 data + 4 adjoint tiles of a backward program, or 8 data tiles of a hidden-chunk program; got %d)", p->tiles);
     SX_REQUIRE(p->h_tiles == 1 || p->h_tiles == 2 || p->h_tiles == 4, "sx_flow_run: h_tiles must be 1, 2 or 4");
-    SX_REQUIRE(p->tiles != 8 || p->h_tiles <= 2, "sx_flow_run: backward programs of 128-column flows are built for hidden <= 64");
+    SX_REQUIRE(p->tiles != 8 || p->x_tiles == 8 || p->h_tiles <= 2, "sx_flow_run: backward programs of 128-column flows are built for hidden <= 64");
     SX_REQUIRE(p->x_tiles >= 1 && p->x_tiles <= p->tiles, "sx_flow_run: bad x_tiles");
     SX_REQUIRE(p->dim >= 1 && p->dim <= 32 * p->x_tiles, "sx_flow_run: dim %d does not fit %d tiles", p->dim, p->x_tiles);
     SX_REQUIRE(p->latent_dim >= 0 && p->latent_dim <= 32 * (p->tiles - p->x_tiles), "sx_flow_run: latent_dim does not fit");
@@ -32,6 +32,7 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     bool lin = false, rqs = false, aff = false, bwd = false, deep = false, cub = false, quadr = false;
     int n_bwd128 = 0;
     bool pw = false, timed = false, wide_rq = false, hc = false;
+    int n_hc8 = 0;
     *mlp_mode = 0;
     for (int i = 0; i < p->n_steps; ++i) {
         const sx_step &s = p->steps[i];
@@ -58,7 +59,7 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
                 const int T = p->tiles;
                 const bool low = T >= 2 && s.c0 == 0 && s.ct == T / 2 && s.t0 == T / 2 && s.tt == T / 2;
                 const bool high = T >= 2 && s.c0 == T / 2 && s.ct == T / 2 && s.t0 == 0 && s.tt == T / 2;
-                SX_REQUIRE(low || high, "sx_flow_run: step %d: hidden-chunk couplings condition one half of the tiles on the other", i);
+                SX_REQUIRE(T <= 4 && (low || high), "sx_flow_run: step %d: hidden-chunk couplings condition one half of up to four tiles on the other", i);
                 SX_REQUIRE(s.act == SX_ACT_TANH_FOLDED, "sx_flow_run: step %d: hidden-chunk steps carry the folded tanh", i);
                 const int first = s.pad_ & 1, last = (s.pad_ >> 1) & 1;
                 // the chunks of one coupling come back to back, same tiles and direction: first ... last
@@ -72,7 +73,22 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
                 need = sx_packed_linear_floats(p->h_tiles, s.ct) + sx_packed_linear_floats(2 * s.tt, p->h_tiles);
                 break;
             }
-            case SX_STEP_AFFINE_CONST: need = 2 * 32 * p->tiles; break;
+            case SX_STEP_WIDE_HIDDEN:
+                SX_REQUIRE(p->tiles == 8 && p->x_tiles == 8, "sx_flow_run: step %d: kind 22 belongs to programs on eight data tiles", i);
+                SX_REQUIRE((s.c0 == 0 || s.c0 == 4) && s.ct == 4 && s.act == SX_ACT_TANH_FOLDED, "sx_flow_run: step %d: the hidden layer reads one half of the tiles (folded tanh)", i);
+                SX_REQUIRE(i + 1 < p->n_steps && p->steps[i + 1].kind == SX_STEP_WIDE_AFFINE_TILE, "sx_flow_run: step %d: a WIDE_HIDDEN step is followed by its coupling's tile steps", i);
+                need = sx_packed_linear_floats(p->h_tiles, 4); aff = true; hc = true; ++n_hc8; break;
+            case SX_STEP_WIDE_AFFINE_TILE: {
+                SX_REQUIRE(p->tiles == 8 && p->x_tiles == 8, "sx_flow_run: step %d: kind 23 belongs to programs on eight data tiles", i);
+                SX_REQUIRE(s.t0 >= 0 && s.t0 < 8 && s.tt == 1, "sx_flow_run: step %d: one transformed tile per step", i);
+                // the tile steps of a coupling follow its hidden step, all on the other half of the tiles
+                int j = i - 1;
+                while (j >= 0 && p->steps[j].kind == SX_STEP_WIDE_AFFINE_TILE) --j;
+                SX_REQUIRE(j >= 0 && p->steps[j].kind == SX_STEP_WIDE_HIDDEN && (p->steps[j].c0 == 0) == (s.t0 >= 4),
+                           "sx_flow_run: step %d: a tile step follows the hidden step of its coupling and transforms a tile of the other half", i);
+                need = sx_packed_linear_floats(2, p->h_tiles); aff = true; hc = true; ++n_hc8; break;
+            }
+            case SX_STEP_AFFINE_CONST: need = 2 * 32 * p->tiles; ++n_hc8; break;
             case SX_STEP_MLP_HIDDEN:
                 SX_REQUIRE(s.c0 == 0 && s.ct == p->tiles, "sx_flow_run: MLP_HIDDEN must read all tiles");
                 need = sx_packed_linear_floats(p->h_tiles, p->tiles); *mlp_mode = 1; break;
@@ -200,7 +216,8 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
     if (bwd) *mlp_mode = 4;
     SX_REQUIRE(!(timed && (rqs || lin || aff || bwd || deep || pw || *mlp_mode == 1)), "sx_flow_run: time couplings form programs of their own");
     if (timed) *mlp_mode = 15;
-    SX_REQUIRE(p->tiles != 8 || (bwd && n_bwd128 == p->n_steps), "sx_flow_run: 8 state tiles carry backward steps (kinds 16 - 18) only");
+    SX_REQUIRE(p->tiles != 8 || (p->x_tiles == 4 && bwd && n_bwd128 == p->n_steps) || (p->x_tiles == 8 && hc && n_hc8 == p->n_steps),
+               "sx_flow_run: 8 state tiles carry backward steps (kinds 16 - 18; 4 data + 4 adjoint tiles) or the couplings of kinds 22 / 23 and element-wise affines (8 data tiles) only");
     SX_REQUIRE(!(deep && (lin || bwd || *mlp_mode == 1)), "sx_flow_run: deep-conditioner steps only mix with couplings");
     if (deep && !mixed) *mlp_mode = rqs ? (cub ? 13 : 10) : 9;     // 10 / 13: the spline kernels with the deep-conditioner steps
     // MODE 20: affine couplings whose hidden layer runs as chunk steps (beside ordinary affine couplings / element-wise affines)
@@ -299,7 +316,7 @@ extern "C" int sx_flow_run(const sx_program *prog_host, const float *blobs, cons
     const int T = prog_host->tiles, H = prog_host->h_tiles;
 #define SX_GO(TT, HH) if (T == TT && H == HH) return precision == SX_GEMM_F16X3 ? sx_flow_launch_f16x3_t##TT##h##HH(a) : sx_flow_launch_f32x_t##TT##h##HH(a)
     SX_GO(1, 1); SX_GO(1, 2); SX_GO(1, 4); SX_GO(2, 1); SX_GO(2, 2); SX_GO(2, 4); SX_GO(4, 1); SX_GO(4, 2); SX_GO(4, 4);
-    SX_GO(8, 1); SX_GO(8, 2);
+    SX_GO(8, 1); SX_GO(8, 2); SX_GO(8, 4);
 #undef SX_GO
     sx_set_error("sx_flow_run: unsupported tile configuration");
     return SX_E_UNSUPPORTED;

@@ -642,6 +642,51 @@ __device__ __forceinline__ void coupling_affine_chunk_dispatch(tile<NS> (&xs)[TX
     else coupling_affine_chunk<NS, TX, HT, C0, CT, T0, TT, false>(xs, pacc, w, st, ldj, rg);
 }
 
+// 129 .. 256 columns (round 4: D 128 -> 160 used to cost 12x, the flow left the fused tier): eight state tiles at one wave per SIMD
+// (kernel MODE 20, TX = 8).  A coupling whose mask splits the tiles is 1 + 4 steps -- the weights of a whole coupling (48 HT KB) do not
+// fit the LDS ring, those of its pieces do:
+//   WIDE_HIDDEN       r = folded tanh(W1' . the four conditioning tiles + b1'), kept as B fragments (`bhp`) across the steps (16 HT KB);
+//   WIDE_AFFINE_TILE  one transformed tile: (kk log_scale, shift) = W2'[the tile's rows] . r + b2', the affine map, the log-det (8 HT KB).
+template <int TX, int HT, int C0>
+__device__ __forceinline__ void wide_hidden(tile<1> (&xs)[TX], btile<1> (&bhp)[HT], const wptr w, rng_t &rg) {
+    tile<1> hid[HT];
+    hidden_layer<1, TX, HT, C0, TX / 2, true>(xs, hid, w, 0, SX_ACT_TANH_FOLDED, rg);
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) fast_sig2_pair(hid[HT - 1].v[0], r);
+#pragma unroll
+    for (int m = 0; m < HT; ++m) bhp[m] = make_btile<1>(hid[m]);
+}
+template <int TX, int HT>
+__device__ __forceinline__ void wide_affine_tile(tile<1> (&xs)[TX], const btile<1> (&bhp)[HT], const wptr w, const dstep &st, float &ldj) {
+    tile<1> ls = load_cfrag<1>(w.cb, 2 * HT * 1024), sh = load_cfrag<1>(w.cb, 2 * HT * 1024 + 32);
+#pragma unroll
+    for (int m = 0; m < HT; ++m) {
+        gemm_tile<1>(w.wb, m * 1024, bhp[m], ls);
+        gemm_tile<1>(w.wb, (HT + m) * 1024, bhp[m], sh);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        s += ls.v[0][r];
+        ls.v[0][r] = __builtin_amdgcn_exp2f(ls.v[0][r]);          // exp(+-log_scale): the pack folds kk = +-log2 e in
+    }
+    const bool rev = st.reverse != 0;
+#define WIDE_APPLY(T) { asm volatile("" ::: "memory"); _Pragma("unroll") for (int r = 0; r < 16; ++r) \
+        xs[T].v[0][r] = rev ? (xs[T].v[0][r] - sh.v[0][r]) * ls.v[0][r] : xs[T].v[0][r] * ls.v[0][r] + sh.v[0][r]; }
+    switch (st.t0) {            // (scalar branches: the tile's registers are static in every arm)
+        default: WIDE_APPLY(0) break;
+        case 1: if constexpr (TX > 1) WIDE_APPLY(1) break;
+        case 2: if constexpr (TX > 2) WIDE_APPLY(2) break;
+        case 3: if constexpr (TX > 3) WIDE_APPLY(3) break;
+        case 4: if constexpr (TX > 4) WIDE_APPLY(4) break;
+        case 5: if constexpr (TX > 5) WIDE_APPLY(5) break;
+        case 6: if constexpr (TX > 6) WIDE_APPLY(6) break;
+        case 7: if constexpr (TX > 7) WIDE_APPLY(7) break;
+    }
+#undef WIDE_APPLY
+    ldj += st.ldj_scale * s;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Time-conditioned affine coupling (ContinuousAffineCoupling, stribor/flows/coupling.py:184-213; kernel MODE 15):
 //   (log_scale, shift) = net(cat[x * mask, latent, t]);  (e_ls, e_sh) = time_net(t).chunk(2)      (net/time_net.py:6-91)
@@ -2728,7 +2773,8 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
         // MODE 20: programs with hidden-chunk couplings (split masks: TX / 2 transformed tiles): their (log_scale, shift) accumulators.
         // (An own kernel instance: as part of MODE 9 the loop-carried tiles took its deep-conditioner programs from 54 to 205 spilled
         //  registers at 64 columns.)
-        [[maybe_unused]] tile<NS> pacc[(MODE == 20 && TX >= 2) ? TX : 1];
+        [[maybe_unused]] tile<NS> pacc[(MODE == 20 && TX >= 2 && TX <= 4) ? TX : 1];
+        [[maybe_unused]] btile<1> bhp[(MODE == 20 && TX == 8) ? HT : 1];        // eight-tile programs: the coupling's hidden activations (B fragments)
         // MODE 18 / 19 = MODE 3 / 12 with the training forward's side outputs (tanh h per layer, the state each layer received):
         // their own instances, so that the inference kernels carry none of that code (it cost cfg 3 0.7 % when it shared MODE 3)
         constexpr bool SIDE_OUT = MODE == 18 || MODE == 19;
@@ -2928,7 +2974,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
             } else
             switch (st.kind) {
                 case SX_STEP_COUPLING_AFFINE:
-                    if constexpr (RQ || MODE == 7 || MODE == 8) break;   // pure spline programs carry no affine couplings (register budget; mixed: MODE 14); 7 / 8: handled above
+                    if constexpr (RQ || MODE == 7 || MODE == 8 || TX == 8) break;   // pure spline programs carry no affine couplings (register budget; mixed: MODE 14); 7 / 8: handled above; 8 tiles: chunk steps only
                     if constexpr (TX >= 2) {
                         if (st.ct == TX / 2 && st.c0 == 0 && st.t0 == TX / 2) {          // cond = low tiles
                             coupling_affine_dispatch<NS, TX, HT, 0, TX / 2, TX / 2, TX / 2>(xs, w, st, ldj, pf, rg);
@@ -3023,8 +3069,17 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                         else coupling_affine_deep<NS, TX, HT, 0, TX, false>(xs, hidp, w, st, ldj, rg);
                     }
                     break;
+                case SX_STEP_WIDE_HIDDEN:
+                    if constexpr (MODE == 20 && TX == 8 && NS == 1) {
+                        if (st.c0 == 0) wide_hidden<TX, HT, 0>(xs, bhp, w, rg);
+                        else wide_hidden<TX, HT, TX / 2>(xs, bhp, w, rg);
+                    }
+                    break;
+                case SX_STEP_WIDE_AFFINE_TILE:
+                    if constexpr (MODE == 20 && TX == 8 && NS == 1) wide_affine_tile<TX, HT>(xs, bhp, w, st, ldj[0]);
+                    break;
                 case SX_STEP_COUPLING_AFFINE_HC:
-                    if constexpr (MODE == 20 && TX >= 2) {
+                    if constexpr (MODE == 20 && TX >= 2 && TX <= 4) {
                         if (st.c0 == 0) coupling_affine_chunk_dispatch<NS, TX, HT, 0, TX / 2, TX / 2, TX / 2>(xs, pacc, w, st, ldj, rg);       // cond = low tiles
                         else coupling_affine_chunk_dispatch<NS, TX, HT, TX / 2, TX / 2, 0, TX / 2>(xs, pacc, w, st, ldj, rg);               // cond = high tiles
                     }
@@ -3466,9 +3521,10 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
     if (a.mlp_mode == SX_ONLY_MODE) SX_FL(SX_ONLY_MODE);
     else { sx_set_error("built with SX_ONLY_MODE"); return SX_E_UNSUPPORTED; }
 #else
-    if constexpr (TX == 8) {            // 4 data + 4 adjoint tiles: the training backward of 128-column flows only
-        if (a.mlp_mode == 4) SX_FL(4);
-        else { sx_set_error("sx_flow_run: 8 state tiles are the backward program's (mode %d)", a.mlp_mode); return SX_E_UNSUPPORTED; }
+    if constexpr (TX == 8) {            // 4 data + 4 adjoint tiles: the training backward of 128-column flows; 8 data tiles: hidden-chunk programs
+        if (a.mlp_mode == 4) { if constexpr (HT <= 2) SX_FL(4); else { sx_set_error("sx_flow_run: backward programs on 4 + 4 tiles are built for hidden <= 64"); return SX_E_UNSUPPORTED; } }
+        else if (a.mlp_mode == 20) SX_FL(20);
+        else { sx_set_error("sx_flow_run: 8 state tiles are the backward program's or a hidden-chunk program's (mode %d)", a.mlp_mode); return SX_E_UNSUPPORTED; }
     } else
     if (a.mlp_mode == 1) SX_FL(1); else if (a.mlp_mode == 2) SX_FL(2); else if (a.mlp_mode == 3) SX_FL(3);
     else if (a.mlp_mode == 4) SX_FL(4);

@@ -72,5 +72,5 @@ struct sx_flow_args {
 SX_DECL_FLOW(1, 1) SX_DECL_FLOW(1, 2) SX_DECL_FLOW(1, 4)
 SX_DECL_FLOW(2, 1) SX_DECL_FLOW(2, 2) SX_DECL_FLOW(2, 4)
 SX_DECL_FLOW(4, 1) SX_DECL_FLOW(4, 2) SX_DECL_FLOW(4, 4)
-SX_DECL_FLOW(8, 1) SX_DECL_FLOW(8, 2)      // 4 data + 4 adjoint tiles: backward programs of 128-column flows (MODE 4 only)
+SX_DECL_FLOW(8, 1) SX_DECL_FLOW(8, 2) SX_DECL_FLOW(8, 4)      // 4 data + 4 adjoint tiles: backward programs of 128-column flows (MODE 4); 8 data tiles: MODE 20
 #undef SX_DECL_FLOW

@@ -472,13 +472,19 @@ class ProgramBuilder:
         self.time_slots = time_slots
         self._spline_layers = 0          # spline couplings added so far (ordinal of the next one's side outputs)
         lat_tiles = _ceil_div(latent_dim + time_slots, 32)
-        self.tiles = _round_tiles(max(_ceil_div(dim, 32), min_x_tiles) + lat_tiles, f'dim {dim} + latent {latent_dim}')
+        need = max(_ceil_div(dim, 32), min_x_tiles) + lat_tiles
+        # 129 .. 256 columns (round 4): eight state tiles at one wave per SIMD.  Only affine couplings whose masks split the tiles
+        # fuse at that width, as hidden-chunk steps of 32 units (the only step whose weights fit the LDS ring there: 48 KB), beside
+        # element-wise affines and column shuffles; everything else keeps its layer-by-layer tier.
+        self.wide_state = 4 < need <= 8 and lat_tiles == 0
+        self.tiles = 8 if self.wide_state else _round_tiles(need, f'dim {dim} + latent {latent_dim}')
         self.x_tiles = self.tiles - lat_tiles
         # hidden layers wider than four tiles: single-hidden-layer Tanh couplings run as CHUNK steps (add_coupling_affine: the
         # conditioner's output is a sum over hidden-unit chunks, accumulated in registers across the steps); the chunk is as wide
         # as one step's weights allow in the LDS ring (128 hidden units up to 64 columns, 64 beyond)
         ht = _ceil_div(hidden_width, 32)
         self.h_tiles = _round_tiles(ht, f'hidden width {hidden_width}') if ht <= 4 else (2 if self.tiles >= 4 else 4)
+
         self.n_slots = 32 * self.x_tiles
         # slot -> logical column (-1 = padding); identity until choose_layout / permutations change it
         self.col_of_slot = np.full(self.n_slots, -1, dtype=np.int64)
@@ -525,6 +531,10 @@ class ProgramBuilder:
     def _freeze_input(self) -> None:
         if self.in_col is None:
             self.in_col = self.col_of_slot.copy()
+
+    def _narrow_only(self, what: str) -> None:
+        if self.wide_state:
+            raise NotImplementedError(f'{what} fuse up to 128 columns (129 .. 256: affine couplings with split masks only)')
 
     def slot_of_col(self) -> np.ndarray:
         s = np.full(self.dim, -1, dtype=np.int64)
@@ -595,7 +605,7 @@ class ProgramBuilder:
         n1 = _hip.packed_linear_floats(HT, ct)
         n2 = _hip.packed_linear_floats(2 * tt, HT)
         wide = hidden > 32 * HT
-        if wide and (act != _hip.ACT_CODES['Tanh'] or variant == 'dense'):
+        if (wide or self.wide_state) and (act != _hip.ACT_CODES['Tanh'] or variant == 'dense'):
             raise NotImplementedError('hidden layers wider than the program\'s hidden tiles: Tanh conditioners, masks that split the tiles')
         # Tanh hot path: fold the constants of tanh(z) = 1 - 2/(exp2(2 log2e z) + 1) and exp(x) = exp2(log2e x)
         # into the packed weights (exact re-parametrisation; fp32 MFMA shares the VALU, so every saved VALU
@@ -626,6 +636,27 @@ class ProgramBuilder:
                 if p < self.n_slots and slot_live[p]:
                     row2[32 * (2 * t) + i] = col[p]
                     row2[32 * (2 * t + 1) + i] = D + col[p]
+        if self.wide_state:
+            # eight state tiles: hidden step + one step per transformed tile (sx_flow_kernel.h wide_hidden / wide_affine_tile)
+            if wide:
+                raise NotImplementedError('129 .. 256 columns: hidden layers of up to 128 units')
+            row_idx = np.full(32 * HT, -1, dtype=np.int64)
+            row_idx[:hidden] = np.arange(hidden)
+            col2 = np.full(32 * HT, -1, dtype=np.int64)
+            col2[:hidden] = np.arange(hidden)
+            off, n = self._alloc(n1)
+            self.jobs.append(_PackJob(W1, b1, row_idx, col_idx, HT, ct, off, rs1, bs1, 0.0))
+            self.steps.append(dict(kind=_hip.STEP_WIDE_HIDDEN, c0=c0, ct=ct, t0=t0, tt=tt, reverse=int(reverse), act=act, blob_off=off,
+                                   blob_floats=n, ldj_scale=0.0, ldj_const=0.0))
+            nt = _hip.packed_linear_floats(2, HT)
+            for t in range(tt):
+                if not (row2[64 * t:64 * t + 64] >= 0).any():
+                    continue                              # a tile of padding only
+                off, n = self._alloc(nt)
+                self.jobs.append(_PackJob(W2, b2, row2[64 * t:64 * t + 64], col2, 2, HT, off, rs2[64 * t:64 * t + 64], bs2[64 * t:64 * t + 64], fold))
+                self.steps.append(dict(kind=_hip.STEP_WIDE_AFFINE_TILE, c0=0, ct=0, t0=t0 + t, tt=1, reverse=int(reverse), act=act,
+                                       blob_off=off, blob_floats=n, ldj_scale=ldj_scale, ldj_const=0.0))
+            return
         # one step per chunk of 32 HT hidden units (one chunk = the whole layer up to that width).  W2 tanh(W1 z + b1) + b2 is a SUM
         # over hidden-unit chunks: a chunk step evaluates its slice of the hidden layer and adds its share of (log_scale, shift) to
         # accumulator tiles that live in registers across the steps (kernel MODE 9); the first chunk carries b2, every chunk its own
@@ -652,6 +683,7 @@ class ProgramBuilder:
         """Affine coupling whose conditioner has two or more hidden layers (linears = [(W1, b1), ..., (W_out, b_out)]):
         CPL_HIDDEN (state -> hidden), CPL_HIDDEN2 for every middle layer, COUPLING_AFFINE_DEEP (last hidden layer,
         output layer, affine map); the hidden activations stay in registers between the steps."""
+        self._narrow_only('deep conditioners')
         self._freeze_input()
         assert len(linears) >= 3
         D, T, HT = self.dim, self.tiles, self.h_tiles
@@ -730,6 +762,7 @@ class ProgramBuilder:
         the earlier layers run as CPL_HIDDEN / CPL_HIDDEN2 steps and the last hidden layer (folded tanh) as the
         RQS_HIDDEN step; n_bins <= 16.  cubic=True: the monotone cubic spline (2K+2 parameters per element: widths, heights,
         two boundary derivatives; phase steps with act = 1, kernel MODE 12 / 13)."""
+        self._narrow_only('spline couplings')
         self._freeze_input()
         D, T, HT, K = self.dim, self.tiles, self.h_tiles, n_bins
         if max([hidden] + [Wk.shape[0] for (Wk, _) in middle]) > 32 * HT:
@@ -854,6 +887,7 @@ class ProgramBuilder:
 
     def enable_adjoint_tiles(self) -> None:
         """Backward programs carry dL/dx beside x: tiles [0, x_tiles) = x, [x_tiles, 2 x_tiles) = adjoint."""
+        self._narrow_only('backward programs')
         if self.x_tiles > 4 or self.latent_dim:
             raise NotImplementedError('training backward is built for up to 128 columns without latent inputs')
         if self.x_tiles == 4 and self.h_tiles > 2:
@@ -863,6 +897,7 @@ class ProgramBuilder:
     def add_coupling_affine_bwd(self, W1, b1, W2, b2, mask: np.ndarray, hidden: int, layer_slot: int) -> dict:
         """Backward of one affine coupling of a log_prob pass; returns the slot maps the caller needs to turn the
         kernel's per-row factors into weight gradients."""
+        self._narrow_only('backward programs')
         self._freeze_input()
         XT = self.x_tiles
         assert self.tiles == 2 * XT
@@ -931,6 +966,7 @@ class ProgramBuilder:
         recover the layer's input, v = M_fwd u + b_fwd (fn_fwd(device) -> (W [out, in], b)), the adjoint tiles become
         dL/dv = W^T dL/du (fn_adj(device) -> (W^T as a Linear weight, None)); the factors dL/du (side features [0, 128)) and v
         ([128, 256)) are what sx_wgrad contracts into dL/dW of the matrix log_prob applied, in slot order (see the maps)."""
+        self._narrow_only('backward programs')
         self._freeze_input()
         XT = self.x_tiles
         if XT != 4 or self.tiles != 8:
@@ -965,6 +1001,7 @@ class ProgramBuilder:
         """ContinuousAffineCoupling (coupling.py:184-213) as one SX_STEP_COUPLING_TIME step: the conditioner reads ALL tiles
         (x * mask | latent | the time slot `time_sel`, through column `time_col` of W1 when time is concatenated), the affine map
         with the time embedding acts on the data tiles.  time_net: a net.Time* module with an in-kernel `kind`."""
+        self._narrow_only('time-conditioned couplings')
         self._freeze_input()
         if hidden > 32 * self.h_tiles:
             raise NotImplementedError('time-conditioned couplings fuse with hidden layers of up to 128 units')
@@ -1040,6 +1077,7 @@ class ProgramBuilder:
     def add_pointwise(self, kind: int, param: float, log_slope: float, ldj_coeff: float) -> None:
         """One point-wise flow on the data columns (sigmoid.py:9-56, activations.py:11-101): `kind` = the sx_pointwise kind for the
         direction taken; the step adds ldj_coeff * (that kind's own log-derivative sum) to the accumulator."""
+        self._narrow_only('point-wise flows')
         self._freeze_input()
         T = self.tiles
         off, n = self._alloc(32 * T + 1)
@@ -1057,6 +1095,7 @@ class ProgramBuilder:
     def add_linear(self, sources, fn, ldj_fn=None) -> None:
         """y = W . x + b on the data columns (W, b = fn(device), torch Linear layout [out, in]): one LINEAR_TILE step
         for the whole layer; ldj_fn(device) -> its log-det term (0-dim tensor, signed and scaled) or None for 0."""
+        self._narrow_only('dense linear layers')
         self._freeze_input()
         D, T = self.dim, self.tiles
         col = self.col_of_slot
@@ -1077,6 +1116,7 @@ class ProgramBuilder:
 
     def add_row_scale_exp(self, diag, reverse: bool, ldj_scale: float, log_time: bool, t_const: float) -> None:
         """state *= exp(+-diag * t_row) (MatrixExponential with a per-row time, affine.py:263)."""
+        self._narrow_only('dense linear layers')
         self._freeze_input()
         T = self.tiles
         off, n = self._alloc(32 * T)
@@ -1103,6 +1143,7 @@ class ProgramBuilder:
         network's output is a SUM over hidden-unit chunks: W2 tanh(W1 z + b1) = sum_c W2[:, c] tanh(W1[c] z + b1[c])); `accumulate`:
         this chunk adds to what an earlier one wrote (and leaves the output bias to it); `w1_cols[c]` = column of W1 that state
         column c of this (column-subset) program feeds, `w1_latent_base` = W1's first latent column."""
+        self._narrow_only('MLP programs')
         self._freeze_input()
         assert len(linears) >= 2, 'conditioner needs at least one hidden layer'
         assert hidden_rows is None or len(linears) == 2
