@@ -12,6 +12,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
 
 void sx_set_error(const char *fmt, ...);
+// experiment knobs (environment, by declared name only): csrc/sx_build_id.cpp
+extern "C" int sx_debug_knob(const char *name, int dflt);
 
 #define SX_REQUIRE(cond, ...)                                   \
     do {                                                        \

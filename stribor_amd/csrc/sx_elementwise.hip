@@ -213,8 +213,8 @@ extern "C" int sx_affine_coupling(const void *x, void *y, float *ldj, const floa
         // (tools/sweep_affine.py; fraction of 8 TB/s): plain loads 0.64-0.69, nt 0.72-0.73, nt + 2 rows + 32 workgroups
         // per CU 0.75 (bf16) / 0.70 (fp32).  SX_AFFINE_VARIANT = 10 * rows-in-flight + nt, SX_AFFINE_GRID = workgroups per
         // CU override the choice (experiments; read once).
-        static const int variant_env = getenv("SX_AFFINE_VARIANT") ? atoi(getenv("SX_AFFINE_VARIANT")) : 0;
-        static const int grid_env = getenv("SX_AFFINE_GRID") ? atoi(getenv("SX_AFFINE_GRID")) : 0;
+        static const int variant_env = sx_debug_knob("SX_AFFINE_VARIANT", 0);
+        static const int grid_env = sx_debug_knob("SX_AFFINE_GRID", 0);
         const int variant = variant_env ? variant_env : (dtype == SX_BF16 ? 21 : 11);
         const int grid_mul = grid_env ? grid_env : (dtype == SX_BF16 ? 32 : 16);
         const int unr = variant / 10 < 1 ? 1 : variant / 10;

@@ -3,9 +3,9 @@
 #include <stdlib.h>
 
 // experiment knobs, read once per process
-static const bool g_no_pure_mode = getenv("SX_NO_PURE_MODE") != nullptr;
-static const bool g_static_chunks = getenv("SX_STATIC_CHUNKS") != nullptr;
-static const int g_blocks_per_cu = getenv("SX_BLOCKS_PER_CU") ? atoi(getenv("SX_BLOCKS_PER_CU")) : 0;
+static const bool g_no_pure_mode = sx_debug_knob("SX_NO_PURE_MODE", 0) != 0;
+static const bool g_static_chunks = sx_debug_knob("SX_STATIC_CHUNKS", 0) != 0;
+static const int g_blocks_per_cu = sx_debug_knob("SX_BLOCKS_PER_CU", 0);
 
 
 // ------------------------------------------------------------------------------------------------

@@ -1290,7 +1290,9 @@ __device__ __forceinline__ void rqs_eval_core(float r_b, float r_n, bool in, con
         hk.template pt<7>();
         // (disc >= 0 in exact arithmetic -- the spline is monotone --; rounding can leave it a few ulps below zero where the root
         //  sits on a knot and the reference's own fp32 evaluation stays at or above it: clamp instead of returning NaN, :223)
-        const float root = (2.f * c) * fast_rcp(-bb - __builtin_amdgcn_sqrtf(__builtin_fmaxf(disc, 0.f)));
+        // the root is a position inside the bin: rounding can also leave it an ulp outside [0, 1], where a steep bin next
+        // to a flat one (slope ~1e3, knot derivative ~1e-3) turns the derivative's numerator negative and its log into NaN
+        const float root = __builtin_amdgcn_fmed3f((2.f * c) * fast_rcp(-bb - __builtin_amdgcn_sqrtf(__builtin_fmaxf(disc, 0.f))), 0.f, 1.f);
         out = root * w_b + cw_b;
         hk.template pt<8>();
         const float tomt = root * (1.f - root), omr = 1.f - root;
@@ -2634,9 +2636,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
         [[maybe_unused]] bool head_counted = false;
         if constexpr (MODE == 4 && TX == 8 && NS == 1) {
             gg_chunk = k.row_t[lrow[0]];
-#ifndef SX_EXP_NOSIDE
             stores_young = k.side != nullptr && __builtin_amdgcn_readfirstlane((int)(row[0] - j < n_rows)) != 0;
-#endif
         }
         // ---- load the state tiles in C-fragment order ---------------------------------------------------
         tile<NS> xs[TX];
@@ -2909,9 +2909,6 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                 // every coupling variant on eight tiles)
                 if constexpr (NS == 1) {
                     float *srow = row[0] < n_rows ? k.side + ((int64_t)st.tt * ((n_rows + 31) >> 5) + (row[0] >> 5)) * (k.side_width * 32) + (row[0] & 31) : nullptr;
-#ifdef SX_EXP_NOSIDE
-                    srow = nullptr;     // timing experiment: no factor stores (gradients wrong)
-#endif
                     auto swap_tiles = [&](int a, int b) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) { const float t_ = xs[a].v[0][r]; xs[a].v[0][r] = xs[b].v[0][r]; xs[b].v[0][r] = t_; }
@@ -2948,9 +2945,6 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                         dma_floats = prog.steps[nb2].blob_floats;
                         wb_ = make_wptr(cur * buf_floats, lane);
                         srow_b = row[0] < n_rows ? k.side + ((int64_t)stb.tt * ((n_rows + 31) >> 5) + (row[0] >> 5)) * (k.side_width * 32) + (row[0] & 31) : nullptr;
-#ifdef SX_EXP_NOSIDE
-                        srow_b = nullptr;
-#endif
                     };
                     if (st.kind == SX_STEP_COUPLING_AFFINE_BWD_A) {
                         // a coupling whose conditioner sits in the high tiles (c0 = 2) swaps the halves of x and of the adjoint in

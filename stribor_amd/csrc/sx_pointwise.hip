@@ -362,7 +362,7 @@ extern "C" int sx_pointwise(const void *x, void *y, float *ldj, float *ldiag, in
                     (void)hipFuncSetAttribute((const void *)cumsum_vec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
                     set_to[dev & 63] = lds4;
                 }
-                static const bool no_pipe = getenv("SX_CUMSUM_NO_PIPE") != nullptr;          // experiments, read once
+                static const bool no_pipe = sx_debug_knob("SX_CUMSUM_NO_PIPE", 0) != 0;          // experiments, read once
                 if (dim <= 64 && !no_pipe) {
                     static size_t set_p[64];
                     if (lds4 > 48 * 1024 && set_p[dev & 63] != lds4) {

@@ -687,7 +687,7 @@ __global__ __launch_bounds__(256, 2) void rqs_slab_l1_bwd_kernel(const l1_args k
 struct slab_shape { int spw, n_groups, n_ranges; };
 slab_shape slab_plan(int n_slabs, int n_chunks) {
     slab_shape p;
-    static const int knob = getenv("SX_SLAB_SPW") ? atoi(getenv("SX_SLAB_SPW")) : 0;      // experiments: 1 | 2, read once
+    static const int knob = sx_debug_knob("SX_SLAB_SPW", 0);      // experiments: 1 | 2, read once
     p.spw = knob == 1 ? 1 : (n_slabs >= 2 ? 2 : 1);
     p.n_groups = (n_slabs + p.spw - 1) / p.spw;
     int r = ((p.spw == 2 ? 256 : 512) + p.n_groups - 1) / p.n_groups;
@@ -735,7 +735,7 @@ extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *g
     k.w_part = scratch + (size_t)n_groups * n_chunks * HT * 1024;
     k.live_idx = live_idx; k.scale = scale; k.flags = err_flag; k.n_rows = n_rows; k.ld_h = ld_h; k.l0 = live_start; k.n_live = n_live;
     k.K = n_bins; k.dim = dim; k.H = hidden; k.n_slabs = n_slabs; k.n_chunks = n_chunks; k.n_groups = n_groups; k.n_ranges = n_ranges;
-    static const int no_xcd = getenv("SX_SLAB_NO_XCD") != nullptr;                             // experiments, read once
+    static const int no_xcd = sx_debug_knob("SX_SLAB_NO_XCD", 0);                             // experiments, read once
     k.xcd_map = (n_ranges % 8 == 0) && !no_xcd;
     k.left = left; k.right = right; k.bottom = bottom; k.top = top; k.ldj_scale = ldj_scale;
     const size_t lds = (size_t)(pl.spw * (6 * HT * 1024 + 128) + (pl.spw == 2 ? 8 * 1024 + 32 : 0)) * sizeof(float);

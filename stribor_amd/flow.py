@@ -17,7 +17,7 @@ import torch.nn as nn
 
 HALF_LOG_2PI = 0.9189385332046727          # log(sqrt(2 pi)), dist/normal.py:37
 
-from . import _hip
+from . import _hip, debug
 from .fused import CompiledProgram, ProgramBuilder, ProgramCache, StructureTracked
 
 __all__ = ['Transform', 'ElementwiseTransform', 'NormalizingFlow', 'graph_wanted', 'graph_rows']
@@ -182,7 +182,7 @@ class _FusedLogProb(torch.autograd.Function):
 def _layer_major_ok(bprog, layers, ht) -> bool:
     """The layer-major backward (weight gradients contracted in-kernel, sx_flow_bwd_run) covers 64-column flows whose
     couplings condition one 32-column half on the other in the flow's own column order, hidden <= 64, fp16 x 3."""
-    if os.environ.get('STRIBOR_BWD_FACTORS') or _hip.get_gemm_precision() == 'exact':
+    if debug.on('STRIBOR_BWD_FACTORS') or _hip.get_gemm_precision() == 'exact':
         return False
     p = bprog.prog
     return (p.identity_cols == 1 and p.x_tiles == 2 and p.tiles == 4 and ht <= 64
@@ -577,7 +577,7 @@ class NormalizingFlow(Transform):
         is not of that kind.  (The log-det is additive: the last layer carries the flow's whole sum, the others zeros -- every
         layer's op still receives dL/dlog-det, which is all its backward needs.)"""
         from .flows.coupling import Coupling
-        if os.environ.get('STRIBOR_SPLINE_FORWARD_PER_LAYER') == '1' or x2.dtype != torch.float32 or x2.shape[0] == 0:
+        if debug.on('STRIBOR_SPLINE_FORWARD_PER_LAYER') or x2.dtype != torch.float32 or x2.shape[0] == 0:
             return None
         fs = list(reversed(self.transforms))
         n, d = x2.shape

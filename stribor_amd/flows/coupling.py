@@ -25,7 +25,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import _hip
+from .. import _hip, debug
 from ..flow import Transform, flatten_rows, graph_rows, graph_wanted
 from ..fused import ProgramBuilder, ProgramCache, _STRUCT_EPOCH
 from ..net.mlp import MLP, _chunk_mlp_program
@@ -432,7 +432,7 @@ class Coupling(Transform):
     # ---- spline couplings: backward fused with the conditioner's last layer (sx_rqs_slab_bwd) ----------------------------
     def _slab_backward_ok(self, net, sp) -> bool:
         from .spline import RQSCouplingSlab
-        if os.environ.get('STRIBOR_SPLINE_UNFUSED') == '1':                         # A/B switch: the per-row parameter path
+        if debug.on('STRIBOR_SPLINE_UNFUSED'):                         # A/B switch: the per-row parameter path
             return False
         if not isinstance(net, MLP) or net._wrapped or net.final_activation_name is not None:
             return False
@@ -447,7 +447,7 @@ class Coupling(Transform):
         net = getattr(sp, 'latent_net', None)
         if self.set_data or not isinstance(sp, Spline) or net is None or not self._slab_backward_ok(net, sp):
             return False
-        if os.environ.get('STRIBOR_SPLINE_L1_TORCH') == '1' or d < 2 or not np.any(self.mask_vector(d) <= 0.5):
+        if debug.on('STRIBOR_SPLINE_L1_TORCH') or d < 2 or not np.any(self.mask_vector(d) <= 0.5):
             return False
         lin = net.linears()
         return (len(lin) == 2 and net.activation_name == 'Tanh' and lin[0][1] is not None and lin[0][0].shape[1] == d
@@ -502,7 +502,7 @@ class Coupling(Transform):
         evaluate.precomputed, self._pre = getattr(self, '_pre', None), None          # (one-launch forward of a whole spline flow)
         col_mask = mask_t * 0 if d == 1 else mask_t                                  # coupling.py:62-63
         if (lat2 is None and len(lin) == 2 and net.activation_name == 'Tanh' and lin[0][1] is not None
-                and RQSCouplingSlabL1.eligible(d, H, sp.n_bins) and os.environ.get('STRIBOR_SPLINE_L1_TORCH') != '1'):
+                and RQSCouplingSlabL1.eligible(d, H, sp.n_bins) and not debug.on('STRIBOR_SPLINE_L1_TORCH')):
             # Linear - Tanh - Linear conditioner: the first layer's backward is part of the op too.  The op takes the WHOLE last
             # layer and a slot map into its rows (no gather of the live parameters' rows on the way in, no zero-fill + scatter of
             # their gradients on the way out: 4 launches per layer and step)
@@ -631,7 +631,7 @@ class Coupling(Transform):
         sp = self.transform
         net = getattr(sp, 'latent_net', None)
         if not isinstance(net, MLP) or net.activation_name != 'Tanh' or sp.n_bins > (32 if sp.spline_type == 'quadratic' else 16) or \
-                sp.spline_type not in ('quadratic', 'cubic') or os.environ.get('STRIBOR_CUBIC_UNFUSED') == '1' and sp.spline_type == 'cubic':
+                sp.spline_type not in ('quadratic', 'cubic') or debug.on('STRIBOR_CUBIC_UNFUSED') and sp.spline_type == 'cubic':
             return False
         lin = net.linears()
         if len(lin) < 2:

@@ -1253,12 +1253,14 @@ def test_fused_time_couplings_and_neural_flow_against_oracle(dim, hidden, latent
     st.check_errors()
 
 
-@pytest.mark.parametrize('scale', [1.0, 20.0])
+@pytest.mark.parametrize('scale', [1.0, 20.0, 40.0])
 def test_spline_k16_large_logits_take_the_guarded_sweep(scale):
     """The straight-line K = 16 spline phases run their softmax without a running maximum, which is only sound while the logits are
     bounded; the packer leaves the bound (largest |logit| the step's rows can produce from the folded tanh) behind the spline bounds
     and the kernel falls back to the sweep that keeps the maximum beyond it.  Output-layer weights scaled by 20 push the bound past
-    the limit (and single logits past +-100, where exp2 without the shift would overflow the sum): both forms against the oracle
+    the limit (and single logits past +-100, where exp2 without the shift would overflow the sum): both forms against the oracle.
+    Scale 40 is the regime where an inverse root lands an ulp outside its bin next to a knot derivative of 1e-3: the log-determinant
+    was NaN on 3 of 500 rows before the root was clamped into the bin (tools/experiments/dbg_nan40.py)
     (reference: torch.softmax, rational_quadratic_spline.py:101-105)."""
     torch.manual_seed(5)
     dim, hidden, K = 64, 64, 16
