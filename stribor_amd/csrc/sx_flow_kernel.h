@@ -20,7 +20,7 @@
 //     weights (hidden r = 1/(exp2(z') + 1): v_exp, v_add, v_rcp), activations of one tile are issued between the
 //     MFMAs of the next, every LDS access is pointer + immediate, one runtime dispatch per step selects a
 //     straight-line specialisation;
-//   * weights of one step (<= ~33 KB) stream L2 -> LDS by LDS-DMA (global_load_lds x16 B), double-buffered:
+//   * weights of one step (<= ~33 KB) stream L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), double-buffered:
 //     step s+1 lands while step s computes; the NEXT step's descriptor is fetched one step early as well;
 //   * 256-thread workgroups (4 waves = 128 samples per pass), persistent grid-stride over sample chunks,
 //     2 workgroups per CU for D <= 64, 1 for D = 128;
@@ -125,12 +125,16 @@ __device__ __forceinline__ bool rng_bad_sample(const rng_t &rg, int lane) {
 template <int WAVES>
 __device__ __forceinline__ void stage_blob(const float *__restrict__ g, int lds_float_off, uint32_t n_floats) {
     // wave-uniform loop: scalar piece offsets (the LDS address goes through m0), one VGPR of lane offsets
+    // The MUBUF form (buffer_load_dwordx4 ... lds), not global_load_lds: the compiler's wait-count pass books a FLAT-encoded
+    // LDS-DMA as "may touch both memories" and, while one is in flight, turns EVERY later wait into a full one -- each
+    // s_waitcnt lgkmcnt(N) in front of an MFMA became lgkmcnt(0), so a wave could never keep the next tile's ds_reads in flight
+    // across the current tile's MFMAs (found on cfg 4: 64 exposed LDS round trips per dense layer).
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const uint32_t n_bytes = n_floats * 4u;    // multiple of 1024 (host pads blobs to 256 floats)
-    const char *gsrc = reinterpret_cast<const char *>(g) + lane * 16;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g), 0, n_bytes, 0x00020000);
     char *ldst = reinterpret_cast<char *>(smem + lds_float_off);
     for (uint32_t off = wave * 1024u; off < n_bytes; off += WAVES * 1024u) {
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(gsrc + off), (lds_void *)(ldst + off), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(ldst + off), 16, lane * 16, off, 0, 0);
     }
 }
 
@@ -542,6 +546,141 @@ __device__ __forceinline__ void coupling_affine(tile<NS> (&xs)[TX], const wptr w
     for (int n = 0; n < NS; ++n) ldj[n] += st.ldj_scale * (s[n].x + s[n].y);
     SX_STAMP(pf, 5);         // affine + log-det
 }
+#ifdef SX_F16X3
+// ---- the same step with the A fragments one tile ahead ------------------------------------------------------------------------
+// Two waves per SIMD (the 128-column kernels, MODE 7 / 8) cannot cover a wave's LDS round trips with other waves' work: here the
+// four ds_read_b128 of tile i + 1 go out BEFORE the six MFMAs of tile i (two register sets), through the hidden layer, the output
+// layer and across the VALU sections between them, so a wave waits for LDS once per step.  (Counted lgkmcnt waits are what makes
+// this work: see stage_blob.)
+struct afr { u32x4 q[4]; };
+__device__ __forceinline__ afr afr_load(const char *wb, int a_off) {
+    afr a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a.q[i] = *reinterpret_cast<const u32x4 *>(wb + (a_off + i * 256) * 4);
+    return a;
+}
+// one tile: request tile `next_off` (< 0: none), then the MFMAs on `cur` with the riders f(0..15) between them, then cur = next
+template <int NS, class F>
+__device__ __forceinline__ void gemm_tile_pf(const char *wb, afr &cur, int next_off, const btile<NS> &b, tile<NS> &acc, F &&f) {
+    afr nxt = cur;
+    if (next_off >= 0) nxt = afr_load(wb, next_off);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const h8 ah = __builtin_bit_cast(h8, cur.q[2 * s]), al = __builtin_bit_cast(h8, cur.q[2 * s + 1]);
+#pragma unroll
+        for (int n = 0; n < NS; ++n) acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b.hi[n][s], acc.v[n], 0, 0, 0);
+        f(8 * s + 0); f(8 * s + 1); f(8 * s + 2);
+#pragma unroll
+        for (int n = 0; n < NS; ++n) acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.lo[n][s], acc.v[n], 0, 0, 0);
+        f(8 * s + 3); f(8 * s + 4); f(8 * s + 5);
+#pragma unroll
+        for (int n = 0; n < NS; ++n) acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.hi[n][s], acc.v[n], 0, 0, 0);
+        f(8 * s + 6); f(8 * s + 7);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    cur = nxt;
+}
+template <int NS, int TX, int HT, int C0, int CT, int T0, int TT, bool REV>
+__device__ __forceinline__ void coupling_affine_pf(tile<NS> (&xs)[TX], const wptr w, const dstep &st, float (&ldj)[NS],
+                                                   prof_t &pf, rng_t &rg) {
+    constexpr int a2 = HT * CT * 1024 + HT * 32;   // pack_linear(W2: 2*TT m-tiles, HT k-tiles)
+    constexpr int b2 = a2 + 2 * TT * HT * 1024;
+    constexpr int bias1 = HT * CT * 1024;
+    auto none = [](int) {};
+    afr cur = afr_load(w.wb, 0);                   // the first tile's fragments fly under the split of the source tiles
+    btile<NS> bsrc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) bsrc[c] = make_btile<NS>(xs[C0 + c], rg);
+    tile<NS> hid[HT];
+    {   // hidden layer: tile m - 1's folded tanh rides between the MFMAs of tile m's first k-chunk
+        tile<NS> acc = load_cfrag<NS>(w.cb, bias1);
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+            gemm_tile_pf<NS>(w.wb, cur, (HT > 1 || c + 1 < CT) ? (c + 1) * 1024 : a2, bsrc[c], acc, none);
+#pragma unroll
+        for (int m = 1; m < HT; ++m) {
+            tile<NS> nxt = load_cfrag<NS>(w.cb, bias1 + m * 32);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const int no = (m * CT + c + 1 < HT * CT) ? (m * CT + c + 1) * 1024 : a2;
+                if (c == 0)
+                    gemm_tile_pf<NS>(w.wb, cur, no, bsrc[c], nxt, [&](int i) {
+#pragma unroll
+                        for (int n = 0; n < NS; ++n) fast_sig2_pair(acc.v[n], i);
+                    });
+                else
+                    gemm_tile_pf<NS>(w.wb, cur, no, bsrc[c], nxt, none);
+            }
+            hid[m - 1] = acc;
+            acc = nxt;
+        }
+        hid[HT - 1] = acc;
+    }
+    SX_STAMP(pf, 3);     // GEMM-1 (+ pipelined activation)
+    f32x2 s[NS];         // log-det partial sums
+#pragma unroll
+    for (int n = 0; n < NS; ++n) s[n] = f32x2{0.f, 0.f};
+    if constexpr (HT == 1) {
+#pragma unroll
+        for (int n = 0; n < NS; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) fast_sig2_pair(hid[0].v[n], r);
+    }
+    btile<NS> bh[HT];
+#pragma unroll
+    for (int m = 0; m + 1 < HT; ++m) bh[m] = make_btile<NS>(hid[m]);
+    if constexpr (HT == 1) bh[0] = make_btile<NS>(hid[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        tile<NS> ls = load_cfrag<NS>(w.cb, b2 + (2 * t) * 32);
+        tile<NS> sh = load_cfrag<NS>(w.cb, b2 + (2 * t + 1) * 32);
+        auto o2 = [&](int row, int m) { return a2 + (row * HT + m) * 1024; };
+#pragma unroll
+        for (int m = 0; m + 1 < HT; ++m) {
+            if (t == 0 && m == 0)        // the last hidden tile's activation rides under this k-chunk
+                gemm_tile_pf<NS>(w.wb, cur, o2(2 * t + 1, m), bh[m], ls, [&](int i) {
+#pragma unroll
+                    for (int n = 0; n < NS; ++n) fast_sig2_pair(hid[HT - 1].v[n], i);
+                });
+            else
+                gemm_tile_pf<NS>(w.wb, cur, o2(2 * t + 1, m), bh[m], ls, none);
+            gemm_tile_pf<NS>(w.wb, cur, o2(2 * t, m + 1), bh[m], sh, none);
+        }
+        if (t == 0 && HT > 1) {
+            bh[HT - 1] = make_btile<NS>(hid[HT - 1]);   // its activation just finished
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        gemm_tile_pf<NS>(w.wb, cur, o2(2 * t + 1, HT - 1), bh[HT - 1], ls, none);
+        // the scale exp2(log_scale') rides under the shift tile's last k-chunk; ls is overwritten by it
+        gemm_tile_pf<NS>(w.wb, cur, t + 1 < TT ? o2(2 * t + 2, 0) : -1, bh[HT - 1], sh, [&](int i) {
+            if (i & 1) return;
+#pragma unroll
+            for (int n = 0; n < NS; ++n) {
+                s[n] = pk_add(s[n], f32x2{ls.v[n][i], ls.v[n][i + 1]});
+                ls.v[n][i] = __builtin_amdgcn_exp2f(ls.v[n][i]);
+                ls.v[n][i + 1] = __builtin_amdgcn_exp2f(ls.v[n][i + 1]);
+            }
+        });
+        SX_STAMP(pf, 4);     // GEMM-2 (+ pipelined activation / exp)
+        tile<NS> &x = xs[T0 + t];
+#pragma unroll
+        for (int n = 0; n < NS; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 xv = {x.v[n][r], x.v[n][r + 1]}, sv = {sh.v[n][r], sh.v[n][r + 1]};
+                const f32x2 ev = {ls.v[n][r], ls.v[n][r + 1]};
+                const f32x2 yv = REV ? pk_mul(pk_sub(xv, sv), ev) : pk_add(pk_mul(xv, ev), sv);
+                x.v[n][r] = yv.x;
+                x.v[n][r + 1] = yv.y;
+            }
+    }
+#pragma unroll
+    for (int n = 0; n < NS; ++n) ldj[n] += st.ldj_scale * (s[n].x + s[n].y);
+    SX_STAMP(pf, 5);         // affine + log-det
+}
+#endif
 // Deep conditioners (>= 2 hidden layers, kernel MODE 9): the earlier hidden layers ran as their own steps and left their
 // activations in `hsrc`; this step evaluates the last hidden layer from them, then the output layer and the affine map.
 template <int NS, int TX, int HT, int T0, int TT, bool REV>
@@ -2831,11 +2970,13 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                 if (resident && s == 0 && k.frag_in != nullptr && has_next_chunk) {
                     const int64_t ngrp = next_chunk * WB + wave;
                     if (ngrp < ((n_rows + 31) >> 5)) {       // wave-uniform
-                        const char *gsrc = reinterpret_cast<const char *>(k.frag_in + ngrp * (TX * 4 * 64 * 4)) + lane * 16;
-                        char *ldst = reinterpret_cast<char *>(smem + pf_base + wave * 4096);
+                        // (MUBUF LDS-DMA: see stage_blob -- this prefetch is in flight for the whole chunk)
+                        const int64_t ngrp_s = __builtin_amdgcn_readfirstlane((int)ngrp);
+                        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(k.frag_in + ngrp_s * (TX * 4 * 64 * 4)), 0, TX * 4 * 1024, 0x00020000);
+                        char *ldst = reinterpret_cast<char *>(smem + pf_base + __builtin_amdgcn_readfirstlane(wave) * 4096);
 #pragma unroll
                         for (int i = 0; i < TX * 4; ++i)
-                            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(gsrc + i * 1024), (lds_void *)(ldst + i * 1024), 16, 0, 0);
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(ldst + i * 1024), 16, lane * 16, i * 1024, 0, 0);
                         const int64_t nrow = ngrp * 32 + (lane & 31);
                         gg_next = k.row_t[nrow < n_rows ? nrow : n_rows - 1];
                         have_pf = true;
@@ -2846,12 +2987,13 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     const int64_t ngrp = next_chunk * WB + wave;
                     if (ngrp < ((n_rows + 31) >> 5)) {       // wave-uniform
                         const int64_t nrow = ngrp * 32 + (lane & 31), nr = nrow < n_rows ? nrow : n_rows - 1;
-                        const char *gsrc = reinterpret_cast<const char *>(reinterpret_cast<const float *>(k.x) + nr * dim + 4 * (lane >> 5));
-                        char *ldst = reinterpret_cast<char *>(smem + pf_base + wave * 4096);
+                        const int64_t ngrp_s = __builtin_amdgcn_readfirstlane((int)ngrp);
+                        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(reinterpret_cast<const float *>(k.x) + ngrp_s * 32 * dim), 0, 0x7fffffff, 0x00020000);
+                        const int voff = ((int)(nr - ngrp_s * 32) * dim + 4 * (lane >> 5)) * 4;
+                        char *ldst = reinterpret_cast<char *>(smem + pf_base + __builtin_amdgcn_readfirstlane(wave) * 4096);
 #pragma unroll
                         for (int i = 0; i < (TX / 2) * 4; ++i)
-                            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(gsrc + ((i >> 2) * 32 + (i & 3) * 8) * 4),
-                                                             (lds_void *)(ldst + i * 1024), 16, 0, 0);
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(ldst + i * 1024), 16, voff, ((i >> 2) * 32 + (i & 3) * 8) * 4, 0, 0);
                         gg_next = k.row_t[nr];
                         have_pf = true;
                     }
@@ -2889,6 +3031,12 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
             } else if ((MODE == 7 || MODE == 8) && st.kind == SX_STEP_COUPLING_AFFINE) {
                 // dense linear layers + pure split couplings (cfg 4): the same two arms instead of the general dispatch
                 if constexpr (TX >= 2 && (MODE == 7 || MODE == 8)) {
+#ifdef SX_F16X3
+                    if constexpr (TX >= 4) {        // two waves per SIMD: A fragments one tile ahead
+                        if (st.c0 == 0) coupling_affine_pf<NS, TX, HT, 0, TX / 2, TX / 2, TX / 2, MODE == 7>(xs, w, st, ldj, pf, rg);
+                        else coupling_affine_pf<NS, TX, HT, TX / 2, TX / 2, 0, TX / 2, MODE == 7>(xs, w, st, ldj, pf, rg);
+                    } else
+#endif
                     if (st.c0 == 0) coupling_affine<NS, TX, HT, 0, TX / 2, TX / 2, TX / 2, true, MODE == 7>(xs, w, st, ldj, pf, rg);
                     else coupling_affine<NS, TX, HT, TX / 2, TX / 2, 0, TX / 2, true, MODE == 7>(xs, w, st, ldj, pf, rg);
                 }
@@ -3135,6 +3283,39 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
 #pragma unroll
                         for (int c = 0; c < TX; ++c) bx[c] = make_btile<NS>(xs[c], rg);
                         __builtin_amdgcn_sched_barrier(0);
+                        SX_STAMP(pf, 5);
+#ifdef SX_F16X3
+                        if (x_tiles == TX) {
+                            // full-width layers: the A fragments of tile t + 1 are requested before the MFMAs of tile t go out (two
+                            // register sets), so a wave waits for LDS once per layer instead of four times per tile
+                            u32x4 a[2][4];
+                            auto fetch = [&](int t, u32x4 (&d)[4]) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) d[i] = *reinterpret_cast<const u32x4 *>(w.wb + (t * 1024 + i * 256) * 4);
+                            };
+                            fetch(0, a[0]);
+                            tile<NS> acc;
+#pragma unroll
+                            for (int t = 0; t < TX * TX; ++t) {
+                                const int m = t / TX, c = t % TX;
+                                if (c == 0) acc = load_cfrag<NS>(w.cb, TX * TX * 1024 + m * 32);
+                                if (t + 1 < TX * TX) fetch(t + 1, a[(t + 1) & 1]);
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int sx = 0; sx < 2; ++sx) {
+                                    const h8 ah = __builtin_bit_cast(h8, a[t & 1][2 * sx]), al = __builtin_bit_cast(h8, a[t & 1][2 * sx + 1]);
+#pragma unroll
+                                    for (int n = 0; n < NS; ++n) acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bx[c].hi[n][sx], acc.v[n], 0, 0, 0);
+#pragma unroll
+                                    for (int n = 0; n < NS; ++n) acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bx[c].lo[n][sx], acc.v[n], 0, 0, 0);
+#pragma unroll
+                                    for (int n = 0; n < NS; ++n) acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bx[c].hi[n][sx], acc.v[n], 0, 0, 0);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (c == TX - 1) xs[m] = acc;
+                            }
+                        } else
+#endif
 #pragma unroll
                         for (int m = 0; m < TX; ++m) {
                             if (m < x_tiles) {
@@ -3451,7 +3632,10 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
 
 #ifdef SX_DEBUG_KNOBS
     SX_STAMP(pf, 7);             // epilogue of the last chunk
-    if (blockIdx.x == 3 && threadIdx.x == 64) {
+#ifndef SX_PROF_THREAD
+#define SX_PROF_THREAD 64       // (wave 1; -DSX_PROF_THREAD=320 stamps its SIMD partner in an 8-wave workgroup)
+#endif
+    if (blockIdx.x == 3 && threadIdx.x == SX_PROF_THREAD) {
         for (int i = 0; i < 8; ++i) g_sx_prof[i] = pf.acc[i];
         g_sx_prof[8] = __builtin_amdgcn_s_memtime() - pf_t0;
         g_sx_prof[9] = wall_clock64() - pf_w0;

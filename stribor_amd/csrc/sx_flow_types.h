@@ -55,15 +55,19 @@ struct sx_flow_args {
 #endif
 // MODE 18 / 19: MODE 3 / 12 with the training forward's side outputs (same occupancy)
 #define SX_MODE_BASE(MODE) ((MODE) == 18 ? 3 : ((MODE) == 19 ? 12 : (MODE)))
+// waves per SIMD of the 128-column linear / split-coupling kernels (MODE 7 / 8 on four tiles): one workgroup of 4 x this per CU
+#ifndef SX_M7_WAVES
+#define SX_M7_WAVES 2
+#endif
 #ifndef SX_WAVES_FOR
 #define SX_WAVES_FOR(TX, MODE) SX_WAVES_FOR_(TX, SX_MODE_BASE(MODE))
-#define SX_WAVES_FOR_(TX, MODE) ((MODE) == 11 || (MODE) == 14 ? 1 : (MODE) == 20 ? ((TX) >= 4 ? 1 : 2) : ((MODE) == 15 || (MODE) == 16 || (MODE) == 17) ? ((TX) >= 4 ? 1 : 2) : ((MODE) == 10 || (MODE) == 12 || (MODE) == 13) ? ((TX) >= 4 ? 1 : SX_RQS_WAVES) : (MODE) == 9 ? ((TX) >= 4 ? 1 : 2) : (MODE) >= 7 ? 2 : (MODE) >= 5 ? ((TX) >= 4 ? 2 : 4) : ((TX) >= 4 ? 1 : ((MODE) == 3 ? SX_RQS_WAVES : ((MODE) == 0 ? 3 : 2))))
+#define SX_WAVES_FOR_(TX, MODE) ((MODE) == 11 || (MODE) == 14 ? 1 : (MODE) == 20 ? ((TX) >= 4 ? 1 : 2) : ((MODE) == 15 || (MODE) == 16 || (MODE) == 17) ? ((TX) >= 4 ? 1 : 2) : ((MODE) == 10 || (MODE) == 12 || (MODE) == 13) ? ((TX) >= 4 ? 1 : SX_RQS_WAVES) : (MODE) == 9 ? ((TX) >= 4 ? 1 : 2) : (MODE) >= 7 ? ((TX) >= 4 ? SX_M7_WAVES : 2) : (MODE) >= 5 ? ((TX) >= 4 ? 2 : 4) : ((TX) >= 4 ? 1 : ((MODE) == 3 ? SX_RQS_WAVES : ((MODE) == 0 ? 3 : 2))))
 #endif
 
 // waves per workgroup: the pure split-coupling kernels (MODE 5 / 6) run 8-wave workgroups -- D <= 64 (128 VGPRs): two
 // per CU = 4 waves per SIMD sharing two weight rings; D = 128 (216 VGPRs): one per CU = 2 waves per SIMD on one ring
 #ifndef SX_BLOCK_WAVES
-#define SX_BLOCK_WAVES(TX, MODE) (((MODE) == 5 || (MODE) == 6 || (((MODE) == 7 || (MODE) == 8) && (TX) >= 4)) ? 8 : 4)
+#define SX_BLOCK_WAVES(TX, MODE) ((((MODE) == 7 || (MODE) == 8) && (TX) >= 4) ? 4 * SX_M7_WAVES : ((MODE) == 5 || (MODE) == 6) ? 8 : 4)
 #endif
 // workgroups per CU the kernel is compiled for
 #define SX_BLOCKS_FOR(TX, MODE) (SX_WAVES_FOR(TX, MODE) * 4 / SX_BLOCK_WAVES(TX, MODE))

@@ -157,10 +157,12 @@ __global__ __launch_bounds__(64 * WB) void wgrad_kernel(const float *__restrict_
     // (lane = feature, its 16 rows = 4 chunks) conflict-free: eight neighbouring features hit eight different 16-byte columns.
     [[maybe_unused]] float *aland = lds + wave * ((MT + NT) * 1024), *bland = aland + MT * 1024;     // wave-uniform (m0)
     [[maybe_unused]] auto issue_tile = [&](const float *gtile, float *ltile) {
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(gtile), 0, 4096, 0x00020000);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int f = 8 * q + (lane >> 3), rc = ((lane & 7) - f) & 7;
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(gtile + f * 32 + rc * 4), (lds_void *)(ltile + q * 256), 16, 0, 0);
+            // (MUBUF form: a FLAT-encoded LDS-DMA in flight turns every compiler-placed wait into a full one, sx_flow_kernel.h stage_blob)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(ltile + q * 256), 16, (f * 32 + rc * 4) * 4, 0, 0, 0);
         }
     };
     // the turned read: lane (feature i, half kk) takes rows 16 kk .. 16 kk + 15 of its feature = chunks 4 kk .. 4 kk + 3
