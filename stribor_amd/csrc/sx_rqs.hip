@@ -157,7 +157,7 @@ __device__ __forceinline__ void rqs16_eval(rqs16_regs &r, float xv, float left, 
         const float c = -s_b * dy;
         const float disc = bb * bb - 4.f * a * c;
         bad_disc = inside && !(disc >= 0.f);
-        // (clamped to the bin like the fused kernel's, sx_flow_kernel.h rqs_eval_core)
+        // (clamped to the bin like the fused kernel's, sx_flow_spline.h rqs_eval_core)
         const float root = __builtin_amdgcn_fmed3f((2.f * c) * __builtin_amdgcn_rcpf(-bb - __builtin_amdgcn_sqrtf(__builtin_fmaxf(disc, 0.f))), 0.f, 1.f);
         out = root * w_b + cw_b;
         const float tomt = root * (1.f - root), omr = 1.f - root;

@@ -854,7 +854,7 @@ class ProgramBuilder:
                         continue
                     bound_slot = None
                     for phase, (start, count, lo, hi) in enumerate(blocks):
-                        # output tile of the step -> register k of lane half h = row kmap(k, h) of the tile (sx_flow_kernel.h RQS_P)
+                        # output tile of the step -> register k of lane half h = row kmap(k, h) of the tile (sx_flow_spline.h RQS_P)
                         rows = np.full(128, -1, dtype=np.int64)
                         for qi, q in enumerate(elems):
                             for h in range(2):
@@ -870,7 +870,7 @@ class ProgramBuilder:
                         # v_exp_f32(p - max) with no multiply (32 instructions per element)
                         sc2 = LOG2E if phase < 2 else 1.0
                         # (the two softmax blocks of a group leave the bound on their logits in the slot behind (lo, hi) of the FIRST
-                        #  block's blob: the K = 16 phases run without a running maximum below it -- sx_flow_kernel.h rqs16_sums --
+                        #  block's blob: the K = 16 phases run without a running maximum below it -- sx_flow_spline.h rqs16_sums --
                         #  and the kernel decides once per group; the blob buffer starts zeroed and the slot only grows)
                         if phase == 0:
                             bound_slot = off + nlin + 2
@@ -902,6 +902,8 @@ class ProgramBuilder:
         XT = self.x_tiles
         assert self.tiles == 2 * XT
         D, HT = self.dim, self.h_tiles
+        if hidden > 32 * HT:         # (h_tiles of a builder for > 128 hidden units is the forward's chunk width: no backward chunk steps)
+            raise NotImplementedError(f'backward programs hold hidden layers of up to {32 * HT} units')
         mask = np.asarray(mask, dtype=np.float64).reshape(-1)
         if mask.size == 1:
             mask = np.full(D, mask[0])
@@ -1163,6 +1165,10 @@ class ProgramBuilder:
                     col_idx[p] = lat0 + li
         hsel = np.arange(W0.shape[0]) if hidden_rows is None else np.asarray(hidden_rows, dtype=np.int64)
         h_prev = len(hsel)
+        # (a builder made for a hidden width beyond four tiles carries the CHUNK width of add_coupling_affine in h_tiles: an MLP
+        #  program has no chunk steps -- its caller splits single-hidden-layer conditioners itself, deeper ones take the next tier)
+        if max([h_prev] + [W.shape[0] for (W, _) in linears[1:-1]]) > 32 * HT:
+            raise NotImplementedError(f'MLP programs hold hidden layers of up to {32 * HT} units here')
         row_idx = np.full(32 * HT, -1, dtype=np.int64)
         row_idx[:h_prev] = hsel
         off, n = self._alloc(_hip.packed_linear_floats(HT, T))

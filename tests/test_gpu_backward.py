@@ -1274,3 +1274,40 @@ def test_fused_backward_of_dense_linear_flows_with_narrow_hidden_layers_at_scale
     for a, b in zip(fast[0], exact):
         assert (a - b).abs().max().item() <= 3e-4 * b.abs().max().item() + 1e-7
     st.check_errors()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('desc_kind', ['affine_140', 'spline_150_69', 'affine_128_190'])
+def test_training_and_inference_with_hidden_layers_beyond_128(desc_kind):
+    """Found by tools/fuzz_train.py --fat in round 4: a ProgramBuilder made for a hidden width beyond four tiles carries the CHUNK
+    width of the forward's hidden-chunk steps in h_tiles; the backward-program builder and the MLP-program builder indexed their
+    32 * h_tiles tables with the full width (ValueError) instead of leaving the layer to the next tier.  Values and gradients
+    against fp64 autograd of the oracle."""
+    torch.manual_seed(23)
+    dim, n = 24, 180
+    if desc_kind == 'affine_140':
+        desc = [{'kind': 'coupling_affine', 'dim': dim, 'hidden': [140], 'mask': 'ordered_right_half', 'latent_dim': 0},
+                {'kind': 'coupling_affine', 'dim': dim, 'hidden': [140], 'mask': 'ordered_left_half', 'latent_dim': 0}]
+    elif desc_kind == 'affine_128_190':
+        desc = [{'kind': 'coupling_affine', 'dim': dim, 'hidden': [128, 190], 'mask': 'ordered_right_half', 'latent_dim': 0}]
+    else:
+        desc = [{'kind': 'coupling_rqs', 'dim': dim, 'hidden': [150, 69], 'n_bins': 9, 'lower': -3.0, 'upper': 3.0,
+                 'mask': 'parity_even', 'latent_dim': 0, 'spline_type': 'quadratic'}]
+    flow = fd.build_flow(st, desc, dim)
+    state = {k: v.clone() for k, v in flow.state_dict().items()}
+    flow = flow.to(DEV)
+    x = torch.randn(n, dim) * 1.2
+    want_loss, want_g, want_gx = oracle_grads(desc, state, x)
+    with torch.no_grad():
+        lp = flow.log_prob(x.to(DEV))
+    spec = fd.flow_spec(desc, {k: v.double() for k, v in state.items()})
+    close(lp, orc.flow_log_prob(spec, x.double()).float(), rtol=1e-5, atol=2e-4)
+    xg = x.to(DEV).requires_grad_(True)
+    loss = -flow.log_prob(xg).mean()
+    loss.backward()
+    assert abs(loss.item() - want_loss) <= 1e-5 * abs(want_loss) + 1e-5
+    close(xg.grad, want_gx.float(), rtol=3e-4, atol=1e-6)
+    for name, p in flow.named_parameters():
+        ref = want_g[name].float()
+        assert (p.grad.cpu() - ref).abs().max().item() <= 3e-4 * (ref.abs().max().item() + 1e-12) + 1e-7, name
+    st.check_errors()

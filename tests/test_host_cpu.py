@@ -163,6 +163,16 @@ def test_tile_limits_raise():
         ProgramBuilder(64, 0, 300).add_coupling_affine(lin1.weight, lin1.bias, lin2.weight, lin2.bias, m, _hip.ACT_CODES['ReLU'], True, -1.0, 300)
     with pytest.raises(NotImplementedError):
         ProgramBuilder(64, 0, 300).add_coupling_rqs(lin1.weight, lin1.bias, lin2.weight, lin2.bias, m, True, -1.0, 300, 4, -1, 1, -1, 1)
+    # (found by tools/fuzz_train.py --infer --fat in round 4: a builder for a 150-wide hidden layer carries the chunk width in
+    #  h_tiles, and an MLP program of a two-hidden-layer conditioner indexed past it instead of leaving the layer to the next tier)
+    lin_a, lin_b, lin_c = torch.nn.Linear(64, 150), torch.nn.Linear(150, 69), torch.nn.Linear(69, 94)
+    with pytest.raises(NotImplementedError):
+        ProgramBuilder(64, 0, 150).add_mlp([(lin_a.weight, lin_a.bias), (lin_b.weight, lin_b.bias), (lin_c.weight, lin_c.bias)],
+                                           _hip.ACT_CODES['Tanh'], None, np.arange(94))
+    bb = ProgramBuilder(64, 0, 150, min_x_tiles=1)
+    bb.enable_adjoint_tiles()
+    with pytest.raises(NotImplementedError):
+        bb.add_coupling_affine_bwd(lin_a.weight, lin_a.bias, torch.nn.Linear(150, 128).weight, torch.zeros(128), m, 150, 0)
 
 
 def test_planner_spline_flow_and_mixed_fallback():
