@@ -1,6 +1,6 @@
 """Randomised differential check of the training paths: random spline / affine coupling flows (dims, widths, masks, bin counts,
 spline types, latent inputs, batch sizes) -- gradients of -log_prob.mean() from the HIP paths against fp64 autograd of the oracle.
-    python tools/fuzz_train.py [n_cases] [seed] [--forward] [--infer] [--mix] [--time] [--wide] [--fat] [--bf16] [--sets] [--k16] [--poison] [--only=i ...]
+    python tools/fuzz_train.py [n_cases] [seed] [--forward] [--infer] [--mix] [--time] [--wide] [--xwide] [--long] [--fat] [--bf16] [--sets] [--k16] [--poison] [--only=i ...]
 (--forward: forward_and_log_det_jacobian instead of log_prob; --infer: the no-graph paths; --mix: every transform kind)"""
 import os
 import sys
@@ -21,15 +21,17 @@ MASKS = ['ordered_right_half', 'ordered_left_half', 'parity_even', 'parity_odd']
 
 WIDE = '--wide' in sys.argv          # 65 .. 125 columns: the four-tile kernel variants (one wave per SIMD)
 FAT = '--fat' in sys.argv            # hidden widths 65 .. 200 and up to 32 bins: the four-hidden-tile variants and the tiers beyond them
+XWIDE = '--xwide' in sys.argv        # 129 .. 256 columns: affine couplings on eight state tiles (kernel MODE 20), everything else layer by layer
+LONG = '--long' in sys.argv          # 10 .. 40 layers: flows beyond one 128-step program run as segments
 
 
 def case(rng):
-    dim = int(rng.integers(65, 126)) if WIDE else int(rng.integers(2, 71))
-    latent = int(rng.choice([0, 0, 0, 3]))
-    layers = int(rng.integers(1, 4))
+    dim = int(rng.integers(129, 257)) if XWIDE else int(rng.integers(65, 126)) if WIDE else int(rng.integers(2, 71))
+    latent = 0 if XWIDE else int(rng.choice([0, 0, 0, 3]))
+    layers = int(rng.integers(10, 41)) if LONG else int(rng.integers(1, 4))
     desc = []
     for _ in range(layers):
-        kind = rng.choice(['rqs', 'rqs', 'cubic', 'affine'])
+        kind = rng.choice(['affine', 'affine', 'affine', 'rqs'] if XWIDE else ['rqs', 'rqs', 'cubic', 'affine'])
         hidden = [int(rng.integers(65, 201) if FAT else rng.integers(4, 65)) for _ in range(int(rng.integers(1, 3)))]
         d = {'dim': dim, 'hidden': hidden, 'mask': str(rng.choice(MASKS)), 'latent_dim': latent}
         if kind == 'affine':
