@@ -122,7 +122,7 @@ class _FusedLogProb(torch.autograd.Function):
                     outs += [Wm, ldj] + ([bm] if bm is not None and bm.requires_grad else [])
                     gouts += [vs[0], gsum.to(ldj.dtype)] + ([vs[1]] if bm is not None and bm.requires_grad else [])
                 ps = [p_ for f in dense_layers for p_ in f.parameters() if p_.requires_grad]
-                for p_, gp in zip(ps, torch.autograd.grad(outs, ps, gouts, allow_unused=True)):
+                for p_, gp in zip(ps, torch.autograd.grad(outs, ps, gouts, allow_unused=True, retain_graph=True)):
                     if gp is not None:
                         grads[id(p_)] = gp if id(p_) not in grads else grads[id(p_)] + gp
             out = [grads.get(id(p_)) for p_ in flow._grad_params()]
@@ -530,11 +530,7 @@ class NormalizingFlow(Transform):
         for li, f in enumerate(reversed(self.transforms) if reverse else self.transforms):
             if pre is not None:
                 # (the whole flow already ran as one launch: each layer's op takes its saved tensors from it and launches nothing)
-                f._pre = pre[li]
-                try:
-                    cur, ldj = f._autograd_inverse(cur, None)
-                finally:
-                    f._pre = None
+                cur, ldj = f._autograd_inverse(cur, None, pre=pre[li])
                 total = ldj if total is None else total + ldj
                 continue
             if isinstance(f, _ColumnShuffle) and not f._feature_only():

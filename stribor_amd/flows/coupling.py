@@ -372,10 +372,13 @@ class Coupling(Transform):
         """forward_and_log_det_jacobian with a graph (affine and spline couplings)."""
         return self._autograd_inverse(x2, lat2, reverse=False)
 
-    def _autograd_inverse(self, x2: torch.Tensor, lat2=None, reverse: bool = True):
+    def _autograd_inverse(self, x2: torch.Tensor, lat2=None, reverse: bool = True, pre=None):
         """inverse_and_log_det_jacobian on fp32 rows [N, D] with a graph: the conditioner runs through torch's own
         Linear layers (rocBLAS; only the rows of the last layer that parameterise transformed columns), the transform
         and its backward are the HIP kernels behind ``RQSInverse`` / ``AffineCouplingOp``.
+        `pre`: this layer's (output rows, log-det share, tanh h) from a one-launch forward of the whole flow
+        (NormalizingFlow._spline_forward_once) -- an argument of the call, not state on the module: the same Coupling may sit in two
+        flows, or twice in one.  Only the slab path can use it; any other routing with `pre` given is a planning error.
         Returns (x_out [N, D], ldj [N])."""
         from .spline import CubicForward, CubicInverse, RQSForward, RQSInverse, Spline
         from .affine import AffineCouplingOp
@@ -410,7 +413,9 @@ class Coupling(Transform):
                     None if contiguous else torch.from_numpy(live.astype(np.int32)).to(x2.device))
         mask_t, rows_t, live_idx = self._programs.get(key, build)
         if is_spline and reverse and self._slab_backward_ok(net, sp):
-            return self._autograd_inverse_slab(x2, lat2, mask_t, rows_t, live, live_idx)
+            return self._autograd_inverse_slab(x2, lat2, mask_t, rows_t, live, live_idx, pre)
+        if pre is not None:
+            raise RuntimeError('stribor_amd: a precomputed forward was handed to a coupling that does not train on the slab path')
         z = x2 * mask_t                                                              # coupling.py:61
         if d == 1:
             z = z * 0                                                                # coupling.py:62-63
@@ -474,7 +479,7 @@ class Coupling(Transform):
         except NotImplementedError:          # beyond the MLP program's tiles too (dim + latent > 4 tiles of 32): generic tier, as _run
             return self._run_generic(x2, lat2, True, True, 1.0)
 
-    def _autograd_inverse_slab(self, x2, lat2, mask_t, rows_t, live, live_idx):
+    def _autograd_inverse_slab(self, x2, lat2, mask_t, rows_t, live, live_idx, pre=None):
         from .spline import RQSCouplingSlab, RQSCouplingSlabL1, slab_slot_rows
         from ..net.mlp import SelectRows
         sp, net = self.transform, self.transform.latent_net
@@ -499,7 +504,7 @@ class Coupling(Transform):
                     torch.from_numpy(cols).to(dev), torch.from_numpy(cmap).to(dev), words)
         plan = self._programs.get(('slab', d, H, cubic, str(x2.device)), build)
         evaluate = lambda xx, h_out=None: self._inverse_rows_nograd(xx, lat2, h_out)
-        evaluate.precomputed, self._pre = getattr(self, '_pre', None), None          # (one-launch forward of a whole spline flow)
+        evaluate.precomputed = pre                                                   # (one-launch forward of a whole spline flow)
         col_mask = mask_t * 0 if d == 1 else mask_t                                  # coupling.py:62-63
         if (lat2 is None and len(lin) == 2 and net.activation_name == 'Tanh' and lin[0][1] is not None
                 and RQSCouplingSlabL1.eligible(d, H, sp.n_bins) and not debug.on('STRIBOR_SPLINE_L1_TORCH')):

@@ -1311,3 +1311,59 @@ def test_training_and_inference_with_hidden_layers_beyond_128(desc_kind):
         ref = want_g[name].float()
         assert (p.grad.cpu() - ref).abs().max().item() <= 3e-4 * (ref.abs().max().item() + 1e-12) + 1e-7, name
     st.check_errors()
+
+
+def test_second_backward_through_a_dense_flow_with_retain_graph():
+    """the fused log_prob op of a dense-linear flow keeps the graph of its D x D fp64 derivation for the
+    backward; autograd.grad on it without retain_graph made `loss.backward(retain_graph=True)` followed by another backward
+    raise 'backward through the graph a second time'.  The second pass adds the same gradients again."""
+    torch.manual_seed(52)
+    dim, n = 24, 150
+    desc = _cfg4_like(dim, 16, 1, True, False)
+    flow = fd.build_flow(st, desc, dim).to(DEV)
+    xg = (torch.randn(n, dim) * 0.8).to(DEV).requires_grad_(True)
+    loss = -flow.log_prob(xg).mean()
+    loss.backward(retain_graph=True)
+    once = {k: p.grad.clone() for k, p in flow.named_parameters()}
+    gx = xg.grad.clone()
+    loss.backward()
+    close(xg.grad, 2 * gx, rtol=1e-6, atol=1e-9)
+    for k, p in flow.named_parameters():
+        close(p.grad, 2 * once[k], rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize('stype', ['quadratic', 'cubic'])
+def test_one_coupling_module_twice_in_a_spline_flow_trains(stype):
+    """the one-launch training forward handed every layer its precomputed tensors through an attribute of the
+    (shared) module; they travel as an argument of the call now.  The same Coupling twice in one flow: gradients of the shared
+    parameters are the sum over both positions, against fp64 autograd of the oracle on the equivalent three-layer description."""
+    torch.manual_seed(53)
+    dim, n, K = 16, 220, 8
+    d = {'kind': 'coupling_rqs', 'dim': dim, 'hidden': [32], 'n_bins': K, 'lower': -3.0, 'upper': 3.0, 'mask': 'ordered_right_half',
+         'latent_dim': 0, 'spline_type': stype}
+    desc = [d, {'kind': 'flip'}, d]
+    built = fd.build_flow(st, desc, dim)
+    shared = built.transforms[0]
+    flow = st.NormalizingFlow(st.UnitNormal(dim), [shared, built.transforms[1], shared])
+    state = {k: v.clone() for k, v in flow.state_dict().items()}
+    assert any(k.startswith('transforms.2.') for k in state)
+    flow = flow.to(DEV)
+    x = torch.randn(n, dim) * 1.2
+    leaves = {k: v.detach().double().clone().requires_grad_(True) for k, v in state.items() if k.startswith('transforms.0.')}
+    both = dict(leaves)
+    both.update({k.replace('transforms.0.', 'transforms.2.'): v for k, v in leaves.items()})
+    for k, v in state.items():
+        if k not in both:
+            both[k] = v.double()
+    xin = x.double().clone().requires_grad_(True)
+    want = -orc.flow_log_prob(fd.flow_spec(desc, both), xin).mean()
+    want.backward()
+    xg = x.to(DEV).requires_grad_(True)
+    loss = -flow.log_prob(xg).mean()
+    loss.backward()
+    assert abs(loss.item() - want.item()) <= 1e-5 * abs(want.item()) + 1e-5
+    tol = 3e-4 if stype == 'quadratic' else 2e-3
+    assert (xg.grad.cpu().double() - xin.grad).abs().max().item() <= tol * xin.grad.abs().max().item() + 1e-8
+    for name, p in shared.named_parameters():
+        ref = leaves['transforms.0.' + name].grad
+        assert (p.grad.cpu().double() - ref).abs().max().item() <= tol * ref.abs().max().item() + 1e-8, name
