@@ -367,3 +367,16 @@ def test_hook_computed_tensors_do_not_invalidate_every_cached_program():
     e2 = _STRUCT_EPOCH[0]
     c.set_data = True                                              # a plain attribute the planner reads
     assert _STRUCT_EPOCH[0] == e2 + 1
+
+
+def test_fused_kernel_stages_weights_with_mubuf_lds_dma():
+    """Round 4: a FLAT-encoded LDS-DMA (global_load_lds) in flight makes hipcc's wait-count pass emit every later s_waitcnt as a full
+    one, so no ds_read of the fused kernel could stay in flight across an MFMA group (cfg 3 -3.7 % from the switch alone).
+    The fused kernel's headers and sx_wgrad must keep the MUBUF form (buffer_load ... lds)."""
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'stribor_amd', 'csrc')
+    for name in ('sx_flow_kernel.h', 'sx_flow_spline.h', 'sx_flow_bwd.h', 'sx_wgrad.hip'):
+        src = open(os.path.join(root, name)).read()
+        code = re.sub(r'//[^\n]*', '', src)                      # (comments may name the instruction)
+        assert '__builtin_amdgcn_global_load_lds' not in code, name
+    assert '__builtin_amdgcn_raw_ptr_buffer_load_lds' in open(os.path.join(root, 'sx_flow_kernel.h')).read()
