@@ -27,7 +27,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize('backend,world', [('gloo', 2), ('gloo', 3), ('nccl', 2), ('nccl', 8)])
+# (('nccl', 1): one rank over RCCL on the one GPU of the test box -- communicator set-up and the fp64 all-reduce through the real
+#  backend, which the gloo runs cannot show; the multi-rank RCCL cases need their GPUs)
+@pytest.mark.parametrize('backend,world', [('gloo', 2), ('gloo', 3), ('nccl', 1), ('nccl', 2), ('nccl', 8)])
 def test_sharded_sum_matches_single_gpu(backend, world, run_child):
     if backend == 'nccl' and torch.cuda.device_count() < world:
         pytest.skip(f'needs {world} GPUs')
