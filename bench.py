@@ -80,24 +80,15 @@ def event_ms(fn, reps, inner=8):
     return sum(ts) / len(ts), ts[len(ts) // 2]
 
 
-def cpu_baseline(desc, state, dim=DIM, budget_s=10.0, max_rows=1 << 21, what='cfg2'):
-    """The oracle (torch-CPU port of the reference's op sequence, incl. its double conditioner call; spline flows WITHOUT the
-    reference's O(M^2) domain-check broadcast, SURVEY App. B Q1 -- with it the reference cannot run these sizes at all) timed on
-    this box's host cores on a bounded sample: thread count probed, then one pass sized to ~budget_s."""
+def _oracle_probe(spec, dim, probe_rows, avail, budget_s):
+    """Thread count of ONE oracle process: torch's intra-op pool gets slower beyond a few dozen threads on these shapes (256
+    threads measured 50x slower than 16), so walk up from 8 and stop at the first count that is not faster."""
     import torch
     from oracle import stribor_oracle as orc
-    from stribor_amd.util import flowdesc as fd
-    spec = fd.flow_spec(desc, state)
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     gen = torch.Generator().manual_seed(1234)
-    probe_rows = 1 << 16 if what == 'cfg2' else 1 << 12
+    best = None
     with torch.no_grad():
         x = torch.randn(probe_rows, dim, generator=gen)
-        # torch's intra-op pool does not scale to hundreds of threads on these ops: probe a few
-        # thread counts and keep the fastest (that count is what `cores` reports)
-        # (torch's intra-op pool gets SLOWER beyond a few dozen threads on these shapes -- 256 threads measured 50x slower than
-        #  16 -- so the probe walks up from 8 and stops at the first count that is not faster)
-        best = None
         for th in [c for c in (8, 16, 32, 64) if c <= avail] or [avail]:
             torch.set_num_threads(th)
             orc.flow_log_prob(spec, x[:max(256, probe_rows // 16)])    # warm-up
@@ -109,20 +100,161 @@ def cpu_baseline(desc, state, dim=DIM, budget_s=10.0, max_rows=1 << 21, what='cf
             best = (th, dt)
             if dt > 0.5 * budget_s:
                 break
-        cores, probe = best
+    return best
+
+
+def cpu_worker(argv):
+    """`bench.py --cpu-worker <spec.pt> <mode> ...` (never touches the GPU).  mode `probe`: print the best thread count of one
+    process; mode `run <threads> <rows> <passes> <first_core>`: pin to `threads` cores, warm up, print READY, wait for a line on
+    stdin, run `passes` passes of oracle.flow_log_prob over `rows` rows, print the elapsed time."""
+    import torch
+    from oracle import stribor_oracle as orc
+    from stribor_amd.util import flowdesc as fd
+    job = torch.load(argv[0])
+    spec = fd.flow_spec(job['desc'], job['state'])
+    dim = job['dim']
+    avail = sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else list(range(os.cpu_count() or 1))
+    if argv[1] == 'probe':
+        probe_rows, budget_s = int(argv[2]), float(argv[3])
+        th, dt = _oracle_probe(spec, dim, probe_rows, len(avail), budget_s)
+        print(json.dumps({'threads': th, 'dt': dt, 'rows': probe_rows}), flush=True)
+        return 0
+    threads, rows, passes, first = int(argv[2]), int(argv[3]), int(argv[4]), int(argv[5])
+    if hasattr(os, 'sched_setaffinity') and first >= 0:
+        os.sched_setaffinity(0, set(avail[first:first + threads]) or set(avail))
+    torch.set_num_threads(threads)
+    gen = torch.Generator().manual_seed(1234 + max(first, 0))
+    with torch.no_grad():
+        x = torch.randn(rows, dim, generator=gen)
+        orc.flow_log_prob(spec, x[:max(256, rows // 16)])
+        print('READY', flush=True)
+        sys.stdin.readline()
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            orc.flow_log_prob(spec, x)
+        dt = time.perf_counter() - t0
+    print(json.dumps({'dt': dt, 'rows': rows * passes}), flush=True)
+    return 0
+
+
+def cpu_pool(_argv):
+    """`bench.py --cpu-pool`: started by main() BEFORE the bench process touches the GPU (a GPU-initialised process must not fork +
+    exec on the GPU boxes); imports no torch, answers one JSON request per stdin line by running oracle workers as its own children:
+    a thread-count probe in one process, then floor(available cores / threads) pinned worker processes over disjoint row blocks,
+    released together; the answer carries the aggregate rows/s between the release and the last worker's end."""
+    me = os.path.abspath(__file__)
+    for line in sys.stdin:
+        line = line.strip()
+        if not line:
+            continue
+        req = json.loads(line)
+        if req.get('quit'):
+            break
+        try:
+            avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+            base = [sys.executable, me, '--cpu-worker', req['spec']]
+            pr = json.loads(subprocess.run(base + ['probe', str(req['probe_rows']), str(req['budget_s'])], capture_output=True, text=True,
+                                           timeout=600, check=True).stdout.strip().splitlines()[-1])
+            th = pr['threads']
+            rate1 = pr['rows'] / pr['dt']                                       # one process, best thread count
+            rows = min(req['rows_per_pass'], max(256, 1 << int(rate1 * req['budget_s']).bit_length() - 1))
+            passes = max(1, int(rate1 * req['budget_s'] / rows))
+            workers = max(1, avail // th)
+            try:                                                                 # stay far from the box's memory: ~40 fp32 [rows, dim]-sized
+                import psutil                                                    # temporaries per worker is a generous bound
+                per_worker = 40 * rows * req['dim'] * 4 * req.get('mem_factor', 1) + (600 << 20)
+                workers = max(1, min(workers, int(0.5 * psutil.virtual_memory().available / per_worker)))
+            except Exception:
+                pass
+            procs = [subprocess.Popen(base + ['run', str(th), str(rows), str(passes), str(i * th)], stdin=subprocess.PIPE,
+                                      stdout=subprocess.PIPE, text=True, bufsize=1) for i in range(workers)]
+            for p_ in procs:
+                assert p_.stdout.readline().strip() == 'READY'
+            t0 = time.perf_counter()
+            for p_ in procs:
+                p_.stdin.write('go\n')
+                p_.stdin.flush()
+            outs = [json.loads(p_.stdout.readline()) for p_ in procs]
+            wall = time.perf_counter() - t0
+            for p_ in procs:
+                p_.wait(timeout=60)
+            ans = {'ok': True, 'workers': workers, 'threads': th, 'rows_per_worker': rows * passes, 'rows_per_pass': rows, 'passes': passes,
+                   'wall_s': wall, 'worker_s': [o['dt'] for o in outs], 'value': workers * rows * passes / wall,
+                   'one_process_value': rate1, 'avail': avail}
+        except Exception as e:                                                  # noqa: BLE001 -- answer, never die
+            ans = {'ok': False, 'error': repr(e)[:300]}
+        sys.stdout.write(json.dumps(ans) + '\n')
+        sys.stdout.flush()
+    return 0
+
+
+def start_cpu_pool():
+    """The pool process (see cpu_pool), or None when it cannot be started (e.g. under a profiler whose preloaded library has
+    already initialised the GPU: cpu_baseline then falls back to one in-process oracle)."""
+    if 'rocprof' in os.environ.get('LD_PRELOAD', '') or os.environ.get('ROCPROFILER_REGISTER_FORCE_LOAD'):
+        return None
+    try:
+        return subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-pool'], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                text=True, bufsize=1)
+    except Exception:
+        return None
+
+
+def cpu_baseline(desc, state, dim=DIM, budget_s=10.0, max_rows=1 << 21, what='cfg2', pool=None):
+    """The oracle (torch-CPU port of the reference's op sequence, incl. its double conditioner call; spline flows WITHOUT the
+    reference's O(M^2) domain-check broadcast, SURVEY App. B Q1 -- with it the reference cannot run these sizes at all) timed on
+    this box's host cores on a bounded sample.  One torch process stops scaling at a few dozen threads, so the all-core figure is
+    floor(cores / best thread count) pinned oracle PROCESSES over disjoint row blocks, released together (`pool`: cpu_pool, started
+    before this process touched the GPU); `value` = all rows / wall time from the release to the last worker's end, `cores` = threads x
+    processes.  Without a pool: one process at its best thread count."""
+    import tempfile
+    import torch
+    note = '' if what == 'cfg2' or what == 'cfg4' else ', O(M^2) domain-check broadcast of rational_quadratic_spline.py:167-178 omitted'
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    probe_rows = 1 << 16 if what == 'cfg2' else 1 << 12
+    if pool is not None:
+        path = None
+        try:
+            fd_, path = tempfile.mkstemp(suffix='.pt', prefix='stribor_cpu_baseline_')
+            os.close(fd_)
+            torch.save({'desc': desc, 'state': {k: v.detach().cpu() for k, v in state.items()}, 'dim': dim}, path)
+            pool.stdin.write(json.dumps({'spec': path, 'dim': dim, 'probe_rows': probe_rows, 'budget_s': budget_s,
+                                         'rows_per_pass': min(max_rows, 1 << 18 if what == 'cfg2' else 1 << 14),
+                                         'mem_factor': 1 if what != 'cfg3' else 24}) + '\n')
+            pool.stdin.flush()
+            ans = json.loads(pool.stdout.readline())
+        except Exception as e:                                                  # noqa: BLE001
+            ans = {'ok': False, 'error': repr(e)[:300]}
+        finally:
+            if path and os.path.exists(path):
+                os.unlink(path)
+        if ans.get('ok'):
+            return {'value': ans['value'], 'unit': 'samples/s', 'cores': ans['workers'] * ans['threads'], 'processes': ans['workers'],
+                    'threads_per_process': ans['threads'], 'host_cores': os.cpu_count(), 'host_cores_available': avail,
+                    'one_process_value': ans['one_process_value'], 'kind': 'port',
+                    'sample': f'oracle.flow_log_prob (torch CPU fp32, reference op sequence incl. double conditioner call{note}): '
+                              f'{ans["workers"]} pinned processes x {ans["threads"]} threads, each {ans["passes"]} passes over its own '
+                              f'{ans["rows_per_pass"]} rows x {dim}, released together, {ans["wall_s"]:.2f} s wall'}
+        pool_error = ans.get('error')
+    else:
+        pool_error = 'no worker pool (started under a profiler or pool start failed)'
+    from oracle import stribor_oracle as orc
+    from stribor_amd.util import flowdesc as fd
+    spec = fd.flow_spec(desc, state)
+    cores, probe = _oracle_probe(spec, dim, probe_rows, avail, budget_s)
+    with torch.no_grad():
         torch.set_num_threads(cores)
         rows = probe_rows
         while rows < max_rows and probe * (2 * rows / probe_rows) < budget_s:
             rows *= 2
-        x = torch.randn(rows, dim, generator=gen)
+        x = torch.randn(rows, dim, generator=torch.Generator().manual_seed(1234))
         t0 = time.perf_counter()
         orc.flow_log_prob(spec, x)
         dt = time.perf_counter() - t0
-    note = '' if what == 'cfg2' or what == 'cfg4' else ', O(M^2) domain-check broadcast of rational_quadratic_spline.py:167-178 omitted'
-    return {'value': rows / dt, 'unit': 'samples/s', 'cores': cores, 'host_cores': os.cpu_count(), 'host_cores_available': avail,
-            'kind': 'port',
+    return {'value': rows / dt, 'unit': 'samples/s', 'cores': cores, 'processes': 1, 'threads_per_process': cores,
+            'host_cores': os.cpu_count(), 'host_cores_available': avail, 'kind': 'port', 'all_core_run_missing_because': pool_error,
             'sample': f'oracle.flow_log_prob (torch CPU fp32, reference op sequence incl. double conditioner call{note}) '
-                      f'on {rows} rows x {dim}, 1 pass, {dt:.2f} s'}
+                      f'on {rows} rows x {dim}, 1 pass, {dt:.2f} s, ONE process'}
 
 
 def load_profile(name):
@@ -307,6 +439,10 @@ def _time_training_step(name, workload, flow, x, steps, note):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == '--cpu-pool':
+        sys.exit(cpu_pool(sys.argv[2:]))
+    if len(sys.argv) > 1 and sys.argv[1] == '--cpu-worker':
+        sys.exit(cpu_worker(sys.argv[2:]))
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
@@ -323,6 +459,8 @@ def main():
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args))
+    # the CPU baseline's worker pool starts HERE, before anything below touches the GPU (see cpu_pool)
+    pool = start_cpu_pool() if args.gpus == 1 and 'WORLD_SIZE' not in os.environ and not args.no_cpu_baseline else None
 
     import torch
     import torch.distributed as dist
@@ -499,7 +637,7 @@ def main():
                     'flow_fused_kernel<NS=1,TX=2,HT=2,MODE=3> (spline phases: parameters only in registers)',
                     load_profile('pmc_cfg3.json')))
                 if not args.no_cpu_baseline:
-                    cfgs[-1]['cpu_baseline'] = cpu_baseline(fd.cfg3_desc(), s3, 64, budget_s=4.0, max_rows=1 << 16, what='cfg3')
+                    cfgs[-1]['cpu_baseline'] = cpu_baseline(fd.cfg3_desc(), s3, 64, budget_s=4.0, max_rows=1 << 16, what='cfg3', pool=pool)
                 del f3, x3
                 torch.manual_seed(0)
                 f4 = fd.build_flow(st, fd.cfg4_desc(), 128)
@@ -517,16 +655,10 @@ def main():
                                                       'MatrixExponential (SURVEY 8(d): 589,824 flop/row); the kernel '
                                                       'runs the collapsed single matrix (458,752): frac_collapsed'}))
                 if not args.no_cpu_baseline:
-                    cfgs[-1]['cpu_baseline'] = cpu_baseline(fd.cfg4_desc(), s4, 128, budget_s=4.0, max_rows=1 << 16, what='cfg4')
+                    cfgs[-1]['cpu_baseline'] = cpu_baseline(fd.cfg4_desc(), s4, 128, budget_s=4.0, max_rows=1 << 16, what='cfg4', pool=pool)
                 del f4, x4
                 cfgs += extra_flow_entries(st, fd, dev, gen, extra_steps)
             result['configs'] = cfgs
-            # first-level scalars (the driver's record keeps those): the other single-GPU BASELINE configurations of this run
-            for c_ in cfgs:
-                if c_.get('name') in ('cfg2_exact', 'cfg3', 'cfg4') and 'value' in c_:
-                    result['value_' + c_['name']] = c_['value']
-                    result['ms_per_step_' + c_['name']] = c_['ms_per_step']
-                    result['roofline_frac_' + c_['name']] = c_['roofline']['frac']
             # training steps (forward + backward) of the trainable BASELINE families, same process
             tr = []
             if not args.no_training:
@@ -573,7 +705,21 @@ def main():
                     if t_.get('ms_per_step') is not None:
                         result['train_ms_' + t_['name']] = t_['ms_per_step']
         if world == 1 and not args.no_cpu_baseline:
-            result['cpu_baseline'] = cpu_baseline(desc, state)
+            result['cpu_baseline'] = cpu_baseline(desc, state, pool=pool)
+        # LAST keys of the line (the driver's record keeps the tail of stdout): first-level scalars of the other single-GPU BASELINE
+        # configurations of this run -- rows/s, ms per step and fraction of the dense fp16 MFMA peak (cfg2_exact: of the fp32 MFMA peak)
+        for c_ in result.get('configs', []):
+            if c_.get('name') in ('cfg2_exact', 'cfg3', 'cfg4') and 'value' in c_:
+                result['value_' + c_['name']] = float('%.4g' % c_['value'])
+                result['ms_per_step_' + c_['name']] = round(c_['ms_per_step'], 4)
+                result['roofline_frac_' + c_['name']] = round(c_['roofline']['frac'], 4)
+    if pool is not None:
+        try:
+            pool.stdin.write('{"quit": true}\n')
+            pool.stdin.flush()
+            pool.wait(timeout=10)
+        except Exception:
+            pool.kill()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -272,9 +272,28 @@ def _flag_entry(device):
     key = (torch.device(device).index or 0, stream())
     ent = _flag_words.get(key)
     if ent is None:
+        if len(_flag_words) >= _MAX_FLAG_WORDS:
+            _evict_flag_words()
         t = torch.zeros(1, dtype=torch.int32).pin_memory()
         ent = _flag_words[key] = (t, t.numpy(), t.data_ptr())
     return ent
+
+
+_MAX_FLAG_WORDS = 64
+
+
+def _evict_flag_words() -> None:
+    """A program that keeps creating streams would grow the table by one pinned word per stream: beyond 64 entries, wait for the
+    devices (no kernel may still hold a word's address), report what is pending and drop every word -- live streams get a new one at
+    their next launch.  (A HIP graph captured earlier keeps the address of a dropped word; the pinned allocation itself stays with
+    torch's caching host allocator, so a replay writes into memory that is still mapped, and its flag is lost -- INTEGRATION.md.)"""
+    torch.cuda.synchronize()
+    pending = 0
+    for _, view, _ in _flag_words.values():
+        pending |= int(view[0])
+    _flag_words.clear()
+    if pending:
+        _raise_flags(pending)
 
 
 def err_flag(device) -> int:
@@ -293,15 +312,19 @@ def _raise_flags(v: int) -> None:
         raise AssertionError('rational_quadratic_spline: negative discriminant in the inverse pass')
 
 
-def poll_errors(all_streams: bool = False) -> None:
-    """Raise for any flag a COMPLETED kernel of the current device's current stream has set (no synchronisation);
-    all_streams: of any stream of any device (what check_errors() does after synchronising)."""
+def poll_errors(all_streams: bool = False, device=None) -> None:
+    """Raise for any flag a COMPLETED kernel of the current stream of `device` (default: the current device) has set (no
+    synchronisation); all_streams: of any stream of any device (what check_errors() does after synchronising)."""
     if all_streams:
         words = list(_flag_words.values())
     else:
         if not _flag_words:
             return
-        ent = _flag_words.get(((_cur_device() if _cur_device is not None else torch.cuda.current_device()), stream()))
+        if device is not None and torch.device(device).index is not None:
+            with device_of_index(torch.device(device).index):          # the flag of x's device, not of whichever is current
+                ent = _flag_words.get((torch.device(device).index, stream()))
+        else:
+            ent = _flag_words.get(((_cur_device() if _cur_device is not None else torch.cuda.current_device()), stream()))
         words = [] if ent is None else [ent]
     for _, view, _ in words:
         v = int(view[0])

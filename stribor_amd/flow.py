@@ -18,7 +18,7 @@ import torch.nn as nn
 HALF_LOG_2PI = 0.9189385332046727          # log(sqrt(2 pi)), dist/normal.py:37
 
 from . import _hip, debug
-from .fused import CompiledProgram, ProgramBuilder, ProgramCache, StructureTracked
+from .fused import CompiledProgram, ProgramBuilder, ProgramCache, ProgramTooLong, StructureTracked
 
 __all__ = ['Transform', 'ElementwiseTransform', 'NormalizingFlow', 'graph_wanted', 'graph_rows']
 
@@ -343,6 +343,7 @@ class NormalizingFlow(Transform):
         self.base_dist = base_dist
         self.transforms = nn.ModuleList(transforms)
         self._fused = ProgramCache()
+        self._too_long = set()           # keys of _fused_program whose plan exceeded SX_MAX_STEPS (see _fused_segments)
 
     # ---- fused program cache -----------------------------------------------------------------------------
     # Programs bake the transform list, every Permute's index vector and the masks into host tables; the cache entry
@@ -379,10 +380,17 @@ class NormalizingFlow(Transform):
                 if not f._plan(b, reverse, scale):
                     return None
             return b.build(device)
+        except ProgramTooLong:
+            self._too_long.add((reverse, dim, latent_dim, str(device), t_kind))         # plans, but needs segments
+            return None
         except NotImplementedError:
             return None
 
     def _fused_segments(self, reverse: bool, dim: int, latent_dim: int, device, t_kind=None):
+        # only a flow whose one-program plan failed on the STEP LIMIT is planned a second time (any other refusal -- layer kinds,
+        # mixing rules -- would refuse every segment too); called after _fused_program returned None for the same key
+        if (reverse, dim, latent_dim, str(device), t_kind) not in self._too_long:
+            return None
         key = ('segments', reverse, dim, latent_dim, str(device), t_kind)
         return self._cached(key, lambda: self._build_segments(reverse, dim, latent_dim, device, t_kind))
 

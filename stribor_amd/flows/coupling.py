@@ -48,6 +48,8 @@ class Coupling(Transform):
         self.set_data = bool(set_data)                        # coupling.py:49-51: the mask runs over the set axis
         self._masks = {}
         self._masks_epoch = -1
+        self._mask_tensors = {}                               # (length, device, dtype) -> mask on the device (wrapped tier)
+        self._mask_tensors_epoch = -1
         self._programs = ProgramCache()
 
     # ---- mask: built once per width (the reference rebuilds it from numpy every call, quirk Q4) --------
@@ -60,10 +62,18 @@ class Coupling(Transform):
         return self._masks[dim]
 
     def _get_mask(self, x: torch.Tensor) -> torch.Tensor:
+        def vec(n):                          # one host-to-device copy per (length, device, dtype), not per call
+            key = (n, x.device, x.dtype)
+            if self._mask_tensors_epoch != _STRUCT_EPOCH[0]:
+                self._mask_tensors, self._mask_tensors_epoch = {}, _STRUCT_EPOCH[0]
+            m = self._mask_tensors.get(key)
+            if m is None:
+                m = self._mask_tensors[key] = torch.from_numpy(self.mask_vector(n)).to(x)
+            return m
         if self.set_data:                                                              # coupling.py:49-51
             *rest, N, D = x.shape
-            return torch.from_numpy(self.mask_vector(N)).to(x).unsqueeze(-1).expand(*rest, N, D)
-        return torch.from_numpy(self.mask_vector(x.shape[-1])).to(x).expand_as(x)     # coupling.py:52-53
+            return vec(N).unsqueeze(-1).expand(*rest, N, D)
+        return vec(x.shape[-1]).expand_as(x)                                           # coupling.py:52-53
 
     def _net(self) -> MLP:
         """The conditioner, when it is this package's MLP (what the fused tiers consume weight by weight)."""
@@ -561,7 +571,7 @@ class Coupling(Transform):
         from .spline import Spline
         return not isinstance(self.transform, (Affine, Spline)) or getattr(self.transform, 'latent_net', None) is None
 
-    def _wrapped(self, x, latent, reverse: bool, want_y: bool, want_ldj: bool, negate: bool, **kwargs):
+    def _wrapped(self, x, latent, reverse: bool, want_y: bool, want_ldj: bool, negate: bool, y=None, **kwargs):
         _hip.require_device(x, 'x')
         if self.set_data and x.dim() < 2:
             raise ValueError('set_data=True needs inputs of shape (..., N, dim)')
@@ -574,8 +584,8 @@ class Coupling(Transform):
             return z if latent is None else torch.cat([z, latent.to(z.dtype)], -1)     # coupling.py:64-65
         z = conditioning(x)
         t = self.transform
-        if not want_y:                                                                 # log_det_jacobian(x, y): y is never read
-            ld = t.log_diag_jacobian(x, None, latent=z, **kwargs)                      # coupling.py:94
+        if not want_y:                                                                 # log_det_jacobian(x, y): the caller's y goes
+            ld = t.log_diag_jacobian(x, y, latent=z, **kwargs)                         # to the wrapped transform (coupling.py:94)
             return None, (ld * (1 - mask)).sum(-1, keepdim=True)
         y_ = t.inverse(x, latent=z, **kwargs) if reverse else t(x, latent=z, **kwargs)     # coupling.py:74-76
         y = y_ * (1 - mask) + x * mask                                                 # coupling.py:78
@@ -603,7 +613,7 @@ class Coupling(Transform):
 
     def log_det_jacobian(self, x, y=None, latent=None, **kwargs):
         if self._wraps_other():
-            return self._wrapped(x, latent, False, False, True, False, **kwargs)[1]
+            return self._wrapped(x, latent, False, False, True, False, y=y, **kwargs)[1]
         if graph_wanted(self, x, latent):
             return self._graph(x, latent, False)[1]
         return self._run(x, latent, False, False, True)[1]

@@ -394,7 +394,7 @@ class CompiledProgram:
         assert x.dim() == 2 and x.shape[1] == (self.prog.pad_ or self.prog.dim), (x.shape, self.prog.dim, self.prog.pad_)
         if not x.is_contiguous():
             x = x.contiguous()
-        _hip.poll_errors()                  # a data-dependent condition of an EARLIER call surfaces here
+        _hip.poll_errors(device=x.device)   # a data-dependent condition of an EARLIER call on x's device (its current stream) surfaces here
         n = x.shape[0]
         if n == 0:        # empty batch: nothing to launch (the reference returns empty tensors too)
             e = lambda *shape, dt=torch.float32: torch.empty(*shape, dtype=dt, device=x.device)
@@ -462,6 +462,10 @@ class CompiledProgram:
         return g.value, b.value, l.value
 
 
+class ProgramTooLong(NotImplementedError):
+    """The flow plans, but its steps do not fit one program (SX_MAX_STEPS): the one failure a run of SEGMENTS can cure."""
+
+
 class ProgramBuilder:
     """Accumulates steps; tracks which logical column each state slot holds."""
 
@@ -501,12 +505,22 @@ class ProgramBuilder:
 
     # -- planning a flow in segments: a layer that would not fit the program is taken back ---------------------------
     def snapshot(self):
-        return (list(self.steps), list(self.jobs), self.blob_floats, self.col_of_slot.copy(),
-                None if self.in_col is None else self.in_col.copy(), self._spline_layers, self.mlp_out_dim)
+        """Every field of the builder (shallow copy of __dict__; lists, arrays and dicts copied one level deep), so that a field a
+        _plan starts to mutate in a later round is covered without touching this method."""
+        snap = {}
+        for k, v in self.__dict__.items():
+            if isinstance(v, np.ndarray):
+                snap[k] = v.copy()
+            elif isinstance(v, (list, dict, set)):
+                snap[k] = type(v)(v)
+            else:
+                snap[k] = v
+        return snap
 
     def restore(self, snap) -> None:
-        self.steps, self.jobs, self.blob_floats, self.col_of_slot, self.in_col, self._spline_layers, self.mlp_out_dim = (
-            list(snap[0]), list(snap[1]), snap[2], snap[3].copy(), None if snap[4] is None else snap[4].copy(), snap[5], snap[6])
+        self.__dict__.clear()
+        for k, v in snap.items():
+            self.__dict__[k] = v.copy() if isinstance(v, np.ndarray) else type(v)(v) if isinstance(v, (list, dict, set)) else v
 
     # -- layout ------------------------------------------------------------------------------------
     def choose_layout(self, first_mask: Optional[np.ndarray]) -> None:
@@ -1204,8 +1218,14 @@ class ProgramBuilder:
     def build(self, device: torch.device) -> CompiledProgram:
         self._freeze_input()
         if len(self.steps) > _hip.SX_MAX_STEPS:
-            raise NotImplementedError(f'fused program has {len(self.steps)} steps (max {_hip.SX_MAX_STEPS})')
+            raise ProgramTooLong(f'fused program has {len(self.steps)} steps (max {_hip.SX_MAX_STEPS})')
         kinds = {s['kind'] for s in self.steps}
+        if self.wide_state and not (_hip.STEP_WIDE_HIDDEN in kinds and
+                                    kinds <= {_hip.STEP_WIDE_HIDDEN, _hip.STEP_WIDE_AFFINE_TILE, _hip.STEP_AFFINE_CONST}):
+            # sx_flow_run's rule for eight data tiles (sx_flow_fused.hip: `x_tiles == 8 && hc && n_hc8 == n_steps`): such a program
+            # exists for the couplings of kinds 22 / 23; a flow (or a segment) of that width made of element-wise affines and
+            # column shuffles alone -- or an empty one -- has no kernel to run in and keeps its layer-by-layer tier
+            raise NotImplementedError('programs on eight state tiles (129 .. 256 columns) carry at least one affine coupling')
         rqs = kinds & {_hip.STEP_RQS_HIDDEN, _hip.STEP_RQS_PHASE}
         dense = kinds & {_hip.STEP_LINEAR_TILE, _hip.STEP_ROW_SCALE_EXP}
         deep = kinds & {_hip.STEP_CPL_HIDDEN, _hip.STEP_CPL_HIDDEN2, _hip.STEP_COUPLING_AFFINE_DEEP}

@@ -50,6 +50,13 @@ def run_child():
             pytest.skip('no launcher process (no GPU at configure time)')
         _LAUNCHER.stdin.write(json.dumps({'cmd': list(cmd), 'env': env or {}, 'unset': list(unset), 'timeout': timeout, 'cwd': ROOT}) + '\n')
         _LAUNCHER.stdin.flush()
+        # a deadline on the answer: the launcher kills a command's process group at `timeout`, so an answer later than that plus a
+        # grace period means the launcher itself is stuck -- fail this test instead of hanging the session
+        import select
+        ready, _, _ = select.select([_LAUNCHER.stdout], [], [], timeout + 120)
+        if not ready:
+            _LAUNCHER.kill()
+            raise RuntimeError(f'launcher process gave no answer within {timeout + 120} s: killed')
         line = _LAUNCHER.stdout.readline()
         if not line:
             raise RuntimeError('launcher process died')

@@ -14,7 +14,8 @@ rounded inputs), F5 cfg 3 (RQ-spline couplings, N=128, incl. tails / on-bound / 
 F6 cfg 4 (AffineLU + MatrixExponential + couplings), F7 Permute/Flip, F8 the reference test-suite
 shapes with autograd log|det J|, F9 cubic splines (suite shapes + a D=64 coupling flow), F10 parameter-free element-wise flows + the on-path part of
 test_normalizing_flow.py's stack, F11 ContinuousAffineCoupling / NeuralFlow, F12 Coupling(set_data=True), hand-written
-conditioners and widths beyond the fused kernel's tiles (round 2).
+conditioners and widths beyond the fused kernel's tiles (round 2), F13 cfg 3 and cfg 4 at their FULL depth (8 spline couplings at N=64,
+16 layers at N=256; round 5: pins the oracle to the reference at the depth the benchmark runs).
 """
 import json
 import os
@@ -86,17 +87,30 @@ def trace_flow(flow, y, **kw):
     return out
 
 
-def flow_case(prefix, desc, dim, seed, x, arrays, extra_inputs=None, **kw):
+def tensor_sha(t):
+    import hashlib
+    a = np.ascontiguousarray(npy(t))
+    return hashlib.sha256(str(a.dtype).encode() + str(a.shape).encode() + a.tobytes()).hexdigest()
+
+
+def flow_case(prefix, desc, dim, seed, x, arrays, extra_inputs=None, state_hashes=None, trace_every=1, **kw):
+    """state_hashes: a dict that receives {key: sha256} of every state tensor INSTEAD of the tensors (large flows: the weights are
+    the reference's default init under `seed`, which the host classes reproduce draw for draw -- the test rebuilds them and holds
+    every tensor to the hash captured here, so the fixture stays small and the state is still the reference's, bit for bit)."""
     torch.manual_seed(seed)
     flow = fd.build_flow(st, desc, dim)
     state = full_state(flow, desc)
     for k, v in state.items():
-        arrays[f'{prefix}/state/{k}'] = v
+        if state_hashes is None:
+            arrays[f'{prefix}/state/{k}'] = v
+        else:
+            state_hashes[k] = tensor_sha(v)
     arrays[f'{prefix}/x'] = x
     with torch.no_grad():
         arrays[f'{prefix}/log_prob'] = flow.log_prob(x, **kw)
         for k, v in trace_flow(flow, x, **kw).items():
-            arrays[f'{prefix}/{k}'] = v
+            if int(k.rsplit('.', 1)[1]) % trace_every == 0 or k.startswith('inv_ldj'):
+                arrays[f'{prefix}/{k}'] = v
         z, ldj_inv = flow.inverse_and_log_det_jacobian(x, **kw)
         arrays[f'{prefix}/inverse'] = z
         arrays[f'{prefix}/inverse_ldj'] = ldj_inv
@@ -570,9 +584,31 @@ def f12_wide_and_set():
     save('f12_wide', arrays, meta)
 
 
+# ------------------------------------------------------------------------------------------ F13
+def f13_full_depth():
+    """BASELINE cfg 3 and cfg 4 at the depth bench.py times them (flow.py:127-130 walks every layer): all 8 spline couplings at
+    N = 64 (the reference's O(M^2) domain check, quirk Q1, allows no more on this container) and all 16 layers of cfg 4 at N = 256,
+    with per-layer values and the fp64 log_prob of the same flow."""
+    arrays, meta = {}, {}
+    desc3 = fd.cfg3_desc()
+    torch.manual_seed(1013)
+    x3 = torch.randn(64, 64)
+    x3[0, :] = torch.linspace(-3.5, 3.5, 64)      # both tails and the interior in one row
+    h3 = {}
+    flow_case('cfg3_full', desc3, 64, 0, x3, arrays, state_hashes=h3)
+    meta['cfg3_full'] = {'desc': desc3, 'dim': 64, 'seed': 0, 'state_sha256': h3}
+    desc4 = fd.cfg4_desc()
+    torch.manual_seed(1014)
+    x4 = torch.randn(256, 128)
+    h4 = {}
+    flow_case('cfg4_full', desc4, 128, 0, x4, arrays, state_hashes=h4, trace_every=4)
+    meta['cfg4_full'] = {'desc': desc4, 'dim': 128, 'seed': 0, 'state_sha256': h4}
+    save('f13_full_depth', arrays, meta)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12']
+    which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12', 'f13']
     table = {'f1': f1_doc_example, 'f2': f2_masks, 'f3': f3_cfg1, 'f4': f4_cfg2, 'f5': f5_cfg3,
-             'f6': f6_cfg4, 'f7': f7_permute, 'f8': f8_suite, 'f9': f9_cubic, 'f10': f10_pointwise, 'f11': f11_continuous, 'f12': f12_wide_and_set}
+             'f6': f6_cfg4, 'f7': f7_permute, 'f8': f8_suite, 'f9': f9_cubic, 'f10': f10_pointwise, 'f11': f11_continuous, 'f12': f12_wide_and_set, 'f13': f13_full_depth}
     for w in which:
         table[w]()

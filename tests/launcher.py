@@ -7,6 +7,7 @@ touches the GPU; it never imports torch, waits for one JSON request per line on 
 """
 import json
 import os
+import signal
 import subprocess
 import sys
 
@@ -24,12 +25,24 @@ def main():
             env.pop(k, None)
         env.update(req.get('env', {}))
         try:
-            out = subprocess.run(req['cmd'], env=env, capture_output=True, text=True, timeout=req.get('timeout', 1200),
-                                 cwd=req.get('cwd'))
-            ans = {'rc': out.returncode, 'stdout': out.stdout[-200000:], 'stderr': out.stderr[-20000:]}
-        except subprocess.TimeoutExpired as e:
-            ans = {'rc': -9, 'stdout': (e.stdout or b'').decode(errors='replace')[-20000:] if isinstance(e.stdout, bytes) else (e.stdout or ''),
-                   'stderr': 'timeout'}
+            # the command (python -m torch.distributed.run ...) has grandchildren -- the ranks -- that inherit the pipes, hold the GPU
+            # and the rendezvous port: run it in a session of its own and, on a timeout, kill the whole process GROUP before
+            # draining the pipes (killing only the direct child would leave communicate() blocked on pipes the ranks keep open)
+            proc = subprocess.Popen(req['cmd'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=req.get('cwd'),
+                                    start_new_session=True)
+            try:
+                so, se = proc.communicate(timeout=req.get('timeout', 1200))
+                ans = {'rc': proc.returncode, 'stdout': so[-200000:], 'stderr': se[-20000:]}
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                try:
+                    so, se = proc.communicate(timeout=30)
+                except subprocess.TimeoutExpired:
+                    so, se = '', ''
+                ans = {'rc': -9, 'stdout': (so or '')[-20000:], 'stderr': 'timeout: process group killed\n' + (se or '')[-4000:]}
         except Exception as e:                      # noqa: BLE001 -- report, never die
             ans = {'rc': -1, 'stdout': '', 'stderr': repr(e)}
         sys.stdout.write(json.dumps(ans) + '\n')

@@ -434,6 +434,45 @@ def test_cfg4_flow_against_golden():
         close(l, g.t(f'cfg4/inv_ldj.{i}'), rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize('case,dim', [('cfg3_full', 64), ('cfg4_full', 128)])
+def test_f13_full_depth_flows_against_golden(case, dim):
+    """BASELINE cfg 3 (all 8 spline couplings, N=64) and cfg 4 (all 16 layers, N=256) as ONE fused launch against the reference's own
+    values at full depth (fixture F13, flow.py:118-130): log_prob, inverse / forward with log-dets, and the per-layer log-dets.
+    cfg 3: 1e-5 rel on values, 1e-4 abs on the log-dets of 8 x 32 spline elements; cfg 4: values against fp64 (close_vs_f64, as
+    test_cfg4_flow_against_golden: the reference's own fp32 error at this init is 1e-6..4e-6 rel per block)."""
+    g = Golden('f13_full_depth')
+    m = g.meta[case]
+    state = g.seeded_state(case)
+    flow = fd.build_flow(st, m['desc'], dim)
+    flow.load_state_dict(state)
+    flow = flow.to(DEV)
+    x = g.t(case + '/x').to(DEV)
+    assert flow._fused_program(True, dim, 0, x.device) is not None
+    assert flow._fused_program(False, dim, 0, x.device) is not None
+    spec64 = orc.spec_to(fd.flow_spec(m['desc'], state), torch.float64)
+    x64 = g.t(case + '/x').double()
+    lp = flow.log_prob(x)
+    close(lp, g.t(case + '/log_prob'), rtol=1e-5, atol=2e-4)
+    close(lp.double(), g.t(case + '/log_prob_f64'), rtol=1e-5, atol=2e-4)
+    z, ldj = flow.inverse_and_log_det_jacobian(x)
+    y, ldf = flow.forward_and_log_det_jacobian(x)
+    close(ldj, g.t(case + '/inverse_ldj'), rtol=1e-5, atol=2e-4)
+    close(ldf, g.t(case + '/forward_ldj'), rtol=1e-5, atol=2e-4)
+    close_vs_f64(z, g.t(case + '/inverse'), orc.flow_inverse(spec64, x64))
+    close_vs_f64(y, g.t(case + '/forward'), orc.flow_forward(spec64, x64))
+    # per-layer log-dets along the reference's own trajectory (each layer fed the reference's fp32 input where the fixture holds it)
+    n = len(flow.transforms)
+    cur = x
+    for i in reversed(range(n)):
+        nxt, l = flow.transforms[i].inverse_and_log_det_jacobian(cur)
+        if g.has(f'{case}/inv_x.{i}'):
+            cur = g.t(f'{case}/inv_x.{i}').to(DEV)            # re-anchor on the reference's trajectory
+        else:
+            cur = nxt
+        if g.has(f'{case}/inv_x.{i + 1}') or i == n - 1:
+            close(l, g.t(f'{case}/inv_ldj.{i}'), rtol=1e-5, atol=1e-4)
+
+
 def test_mixed_spline_affine_flow_falls_back_per_layer_and_matches_oracle():
     """A flow the fused kernel cannot take whole (spline + affine couplings + AffineLU) runs layer by layer on
     HIP kernels; checked against the oracle built from the same state_dict."""
@@ -1419,6 +1458,39 @@ def test_affine_couplings_with_hidden_layers_beyond_128_fuse(dim, hidden, masks,
         close(flow.log_prob(x.to(DEV)), orc.flow_log_prob(spec, x), rtol=1e-5, atol=1e-5 * max(1, dim // 32))
     finally:
         st.set_gemm_precision(old)
+    st.check_errors()
+
+
+@pytest.mark.parametrize('dim', [130, 160, 256])
+def test_coupling_free_flows_of_129_to_256_columns(dim):
+    """a flow of that width made ONLY of element-wise Affine / Flip / Permute layers has no eight-tile program
+    (sx_flow_run: eight data tiles carry at least one coupling of kinds 22 / 23) -- the planner must refuse it at plan time so the flow
+    answers layer by layer, not with a RuntimeError from the launcher.  log_prob / forward / inverse / log-dets against the oracle."""
+    torch.manual_seed(dim)
+    desc = [{'kind': 'affine', 'dim': dim}, {'kind': 'flip'}, {'kind': 'permute', 'dim': dim}, {'kind': 'affine', 'dim': dim}]
+    flow = fd.build_flow(st, desc, dim)
+    with torch.no_grad():
+        for name, p in flow.named_parameters():
+            p.copy_(torch.randn_like(p) * 0.3)
+    state = {k: v.clone() for k, v in flow.state_dict().items()}
+    state['transforms.2.permutation'] = flow.transforms[2].permutation.clone()
+    spec = fd.flow_spec(desc, state)
+    flow = flow.to(DEV)
+    dev = torch.device(DEV, torch.cuda.current_device())
+    assert flow._fused_program(True, dim, 0, dev) is None and flow._fused_program(False, dim, 0, dev) is None
+    assert flow._fused_segments(True, dim, 0, dev) is None
+    assert st.NormalizingFlow(st.UnitNormal(dim), [])._fused_program(True, dim, 0, dev) is None          # the empty program
+    for n in (1, 257):
+        x = torch.randn(n, dim)
+        close(flow.log_prob(x.to(DEV)), orc.flow_log_prob(spec, x), rtol=1e-5, atol=1e-5 * (dim // 32))
+        y, ldj = flow.forward_and_log_det_jacobian(x.to(DEV))
+        wy, wl = orc.flow_forward_and_ldj(spec, x)
+        close(y, wy)
+        close(ldj, wl, rtol=1e-5, atol=1e-5 * (dim // 32))
+        z, li = flow.inverse_and_log_det_jacobian(x.to(DEV))
+        wz, wli = orc.flow_inverse_and_ldj(spec, x)
+        close(z, wz)
+        close(li, wli, rtol=1e-5, atol=1e-5 * (dim // 32))
     st.check_errors()
 
 

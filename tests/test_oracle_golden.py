@@ -245,3 +245,35 @@ def test_f12_set_data_hand_nets_and_wide_flows():
         assert torch.allclose(orc.flow_log_prob(spec, x), g.t(case + '/log_prob'), rtol=1e-5, atol=1e-4), case
         assert torch.allclose(orc.flow_inverse(spec, x), g.t(case + '/inverse'), rtol=1e-5, atol=1e-5), case
         assert torch.allclose(orc.flow_forward(spec, x), g.t(case + '/forward'), rtol=1e-5, atol=1e-5), case
+
+
+@pytest.mark.parametrize('case', ['cfg3_full', 'cfg4_full'])
+def test_f13_full_depth_flows(case):
+    """BASELINE cfg 3 (8 spline couplings) and cfg 4 (16 layers) at the depth bench.py times, against the reference's per-layer
+    values, forward pass and fp64 log_prob (flow.py:118-130); weights = the reference's seeded default init, held to its hashes."""
+    g = Golden('f13_full_depth')
+    m = g.meta[case]
+    spec = fd.flow_spec(m['desc'], g.seeded_state(case))
+    x = g.t(case + '/x')
+    trace = []
+    z, acc = orc.flow_inverse_and_ldj(spec, x, trace=trace)
+    n = len(spec)
+    assert n == (8 if case == 'cfg3_full' else 16)
+    loose = case == 'cfg4_full'
+    tol = dict(rtol=2e-5, atol=2e-5) if loose else TIGHT
+    seen = 0
+    for step, (xo, ldj) in enumerate(trace):
+        i = n - 1 - step
+        if g.has(f'{case}/inv_x.{i}'):
+            assert torch.allclose(xo, g.t(f'{case}/inv_x.{i}'), **tol), (case, i)
+            seen += 1
+        assert torch.allclose(ldj, g.t(f'{case}/inv_ldj.{i}'), **tol), (case, i)
+    assert seen >= 4
+    assert torch.allclose(z, g.t(case + '/inverse'), **tol)
+    lp = orc.flow_log_prob(spec, x)
+    assert torch.allclose(lp, g.t(case + '/log_prob'), rtol=1e-5 if loose else 1e-6, atol=1e-5)
+    yf, lf = orc.flow_forward_and_ldj(spec, x)
+    assert torch.allclose(yf, g.t(case + '/forward'), **(tol if loose else dict(rtol=1e-5, atol=1e-5)))
+    assert torch.allclose(lf, g.t(case + '/forward_ldj'), rtol=1e-5, atol=1e-4)
+    lp64 = orc.flow_log_prob(orc.spec_to(spec, torch.float64), x.double())
+    assert torch.allclose(lp64, g.t(case + '/log_prob_f64'), rtol=1e-10, atol=1e-9)
