@@ -80,6 +80,25 @@ def event_ms(fn, reps, inner=8):
     return sum(ts) / len(ts), ts[len(ts) // 2]
 
 
+def usable_cores():
+    """Cores this process may actually keep busy: its affinity mask, capped by the cgroup's CPU quota (a container that sees 256
+    cores but holds a quota of N is throttled once more than N threads spin)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = max(1, min(n, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def _oracle_probe(spec, dim, probe_rows, avail, budget_s):
     """Thread count of ONE oracle process: torch's intra-op pool gets slower beyond a few dozen threads on these shapes (256
     threads measured 50x slower than 16), so walk up from 8 and stop at the first count that is not faster."""
@@ -116,7 +135,7 @@ def cpu_worker(argv):
     avail = sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else list(range(os.cpu_count() or 1))
     if argv[1] == 'probe':
         probe_rows, budget_s = int(argv[2]), float(argv[3])
-        th, dt = _oracle_probe(spec, dim, probe_rows, len(avail), budget_s)
+        th, dt = _oracle_probe(spec, dim, probe_rows, min(len(avail), usable_cores()), budget_s)
         print(json.dumps({'threads': th, 'dt': dt, 'rows': probe_rows}), flush=True)
         return 0
     threads, rows, passes, first = int(argv[2]), int(argv[3]), int(argv[4]), int(argv[5])
@@ -151,10 +170,12 @@ def cpu_pool(_argv):
         if req.get('quit'):
             break
         try:
-            avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+            avail = usable_cores()
             base = [sys.executable, me, '--cpu-worker', req['spec']]
+            t_req = time.perf_counter()
             pr = json.loads(subprocess.run(base + ['probe', str(req['probe_rows']), str(req['budget_s'])], capture_output=True, text=True,
-                                           timeout=600, check=True).stdout.strip().splitlines()[-1])
+                                           timeout=120, check=True).stdout.strip().splitlines()[-1])
+            print(f'[cpu pool] probe: {pr} ({time.perf_counter() - t_req:.1f} s), usable cores {avail}', file=sys.stderr, flush=True)
             th = pr['threads']
             rate1 = pr['rows'] / pr['dt']                                       # one process, best thread count
             rows = min(req['rows_per_pass'], max(256, 1 << int(rate1 * req['budget_s']).bit_length() - 1))
@@ -170,6 +191,8 @@ def cpu_pool(_argv):
                                       stdout=subprocess.PIPE, text=True, bufsize=1) for i in range(workers)]
             for p_ in procs:
                 assert p_.stdout.readline().strip() == 'READY'
+            print(f'[cpu pool] {workers} workers x {th} threads ready ({time.perf_counter() - t_req:.1f} s): {passes} passes x {rows} rows each',
+                  file=sys.stderr, flush=True)
             t0 = time.perf_counter()
             for p_ in procs:
                 p_.stdin.write('go\n')
@@ -178,6 +201,7 @@ def cpu_pool(_argv):
             wall = time.perf_counter() - t0
             for p_ in procs:
                 p_.wait(timeout=60)
+            print(f'[cpu pool] done: {wall:.1f} s wall', file=sys.stderr, flush=True)
             ans = {'ok': True, 'workers': workers, 'threads': th, 'rows_per_worker': rows * passes, 'rows_per_pass': rows, 'passes': passes,
                    'wall_s': wall, 'worker_s': [o['dt'] for o in outs], 'value': workers * rows * passes / wall,
                    'one_process_value': rate1, 'avail': avail}
@@ -195,9 +219,28 @@ def start_cpu_pool():
         return None
     try:
         return subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-pool'], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
-                                text=True, bufsize=1)
+                                text=True, bufsize=1, start_new_session=True)       # own process group: stop_cpu_pool can end all of it
     except Exception:
         return None
+
+
+def stop_cpu_pool(pool, hard=False):
+    """End the pool (politely; `hard`: its whole process group at once -- a request that overran its deadline)."""
+    import signal
+    if pool is None or pool.poll() is not None:
+        return
+    try:
+        if hard:
+            os.killpg(pool.pid, signal.SIGKILL)
+        else:
+            pool.stdin.write('{"quit": true}\n')
+            pool.stdin.flush()
+        pool.wait(timeout=10)
+    except Exception:
+        try:
+            os.killpg(pool.pid, signal.SIGKILL)
+        except Exception:
+            pass
 
 
 def cpu_baseline(desc, state, dim=DIM, budget_s=10.0, max_rows=1 << 21, what='cfg2', pool=None):
@@ -210,9 +253,9 @@ def cpu_baseline(desc, state, dim=DIM, budget_s=10.0, max_rows=1 << 21, what='cf
     import tempfile
     import torch
     note = '' if what == 'cfg2' or what == 'cfg4' else ', O(M^2) domain-check broadcast of rational_quadratic_spline.py:167-178 omitted'
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    avail = usable_cores()
     probe_rows = 1 << 16 if what == 'cfg2' else 1 << 12
-    if pool is not None:
+    if pool is not None and pool.poll() is None:
         path = None
         try:
             fd_, path = tempfile.mkstemp(suffix='.pt', prefix='stribor_cpu_baseline_')
@@ -222,6 +265,14 @@ def cpu_baseline(desc, state, dim=DIM, budget_s=10.0, max_rows=1 << 21, what='cf
                                          'rows_per_pass': min(max_rows, 1 << 18 if what == 'cfg2' else 1 << 14),
                                          'mem_factor': 1 if what != 'cfg3' else 24}) + '\n')
             pool.stdin.flush()
+            # a deadline on the answer (probe + worker start-up + the sample, with a wide margin for a loaded box): a pool that
+            # overruns it is ended with all its workers and this configuration falls back to the one-process figure
+            import select
+            deadline = 90.0 + 8.0 * budget_s
+            ready, _, _ = select.select([pool.stdout], [], [], deadline)
+            if not ready:
+                stop_cpu_pool(pool, hard=True)
+                raise TimeoutError(f'the worker pool gave no answer within {deadline:.0f} s')
             ans = json.loads(pool.stdout.readline())
         except Exception as e:                                                  # noqa: BLE001
             ans = {'ok': False, 'error': repr(e)[:300]}
@@ -237,7 +288,7 @@ def cpu_baseline(desc, state, dim=DIM, budget_s=10.0, max_rows=1 << 21, what='cf
                               f'{ans["rows_per_pass"]} rows x {dim}, released together, {ans["wall_s"]:.2f} s wall'}
         pool_error = ans.get('error')
     else:
-        pool_error = 'no worker pool (started under a profiler or pool start failed)'
+        pool_error = 'no worker pool (started under a profiler, pool start failed, or an earlier request overran its deadline)'
     from oracle import stribor_oracle as orc
     from stribor_amd.util import flowdesc as fd
     spec = fd.flow_spec(desc, state)
@@ -713,13 +764,7 @@ def main():
                 result['value_' + c_['name']] = float('%.4g' % c_['value'])
                 result['ms_per_step_' + c_['name']] = round(c_['ms_per_step'], 4)
                 result['roofline_frac_' + c_['name']] = round(c_['roofline']['frac'], 4)
-    if pool is not None:
-        try:
-            pool.stdin.write('{"quit": true}\n')
-            pool.stdin.flush()
-            pool.wait(timeout=10)
-        except Exception:
-            pool.kill()
+    stop_cpu_pool(pool)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -38,12 +38,13 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
         const sx_step &s = p->steps[i];
         SX_REQUIRE(s.blob_off % 256 == 0 && s.blob_floats % 256 == 0 && s.blob_off >= 256,
                    "sx_flow_run: step %d blob not 1 KiB aligned behind the 1 KiB header", i);
-        SX_REQUIRE(s.kind == SX_STEP_RQS_PHASE || (s.c0 >= 0 && s.ct >= 0 && s.c0 + s.ct <= p->tiles && s.t0 >= 0 && s.tt >= 0),
-                   "sx_flow_run: step %d bad tiles", i);
-        size_t need = 0;
+        // (first: the sums below must not overflow -- found by the host sanitizer job with c0 = INT_MAX)
         // the device step keeps these in 8 bits
         SX_REQUIRE(s.c0 >= 0 && s.c0 < 256 && s.ct >= 0 && s.ct < 256 && s.t0 >= 0 && s.t0 < 256 && s.tt >= 0 && s.tt < 256 && s.act >= 0 && s.act < 256,
                    "sx_flow_run: step %d: tile fields out of range (c0 %d ct %d t0 %d tt %d act %d; each < 256)", i, s.c0, s.ct, s.t0, s.tt, s.act);
+        SX_REQUIRE(s.kind == SX_STEP_RQS_PHASE || (s.c0 >= 0 && s.ct >= 0 && s.c0 + s.ct <= p->tiles && s.t0 >= 0 && s.tt >= 0),
+                   "sx_flow_run: step %d bad tiles", i);
+        size_t need = 0;
         switch (s.kind) {
             case SX_STEP_COUPLING_AFFINE: {
                 const int T = p->tiles;
@@ -194,6 +195,8 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
             default: sx_set_error("sx_flow_run: step %d has unsupported kind %d", i, s.kind); return SX_E_UNSUPPORTED;
         }
         SX_REQUIRE(s.blob_floats >= need, "sx_flow_run: step %d blob too small (%u < %zu floats)", i, s.blob_floats, need);
+        // (one step's weights must fit one LDS buffer; checked here so that no size below is formed from an unbounded field)
+        SX_REQUIRE((size_t)s.blob_floats * 8 <= 160 * 1024, "sx_flow_run: step %d needs %zu B of LDS per buffer (> 80 KiB)", i, (size_t)s.blob_floats * 4);
         if ((int)s.blob_floats > mx) mx = (int)s.blob_floats;
         dstep &o = d->steps[i];
         o.kind = (uint8_t)s.kind; o.c0 = (uint8_t)s.c0; o.ct = (uint8_t)s.ct; o.t0 = (uint8_t)s.t0; o.tt = (uint8_t)s.tt;

@@ -52,44 +52,23 @@ __host__ __device__ static inline int sx_kmap(int r, int h) { return (r & 3) + 8
 
 extern __shared__ __attribute__((aligned(16))) float smem[];
 
-// Timing experiments only (tools/knob_sweep.sh): with -DSX_DEBUG_KNOBS the bits of g_sx_dbg switch parts of
-// the kernel off (results are then wrong).  The shipped .so is built without it: SX_DBG folds to 0.
-// Compile-time timing experiments (results wrong, straight-line code kept): -DSX_X=<bits>
-//   4 no hidden transcendentals   8 no scale exp2   16 no MFMA   32 no weight ds_read   64 no fp16 split
-#ifndef SX_X
-#define SX_X 0
-#endif
-#ifdef SX_DEBUG_KNOBS
-__device__ int g_sx_dbg;   // set by the host before launch (hipMemcpyToSymbol)
-__device__ __forceinline__ int smem_dbg() { return __builtin_amdgcn_readfirstlane(g_sx_dbg); }
-#define SX_DBG(bit) (smem_dbg() & (bit))
-#else
-#define SX_DBG(bit) 0
-#endif
-
 typedef __attribute__((address_space(3))) void lds_void;
 
-// In-kernel phase stamps (diagnostic build only; MI355X guide §7 'In-kernel stamps').  prof_t is empty in the
-// shipped build, so every SX_STAMP folds away.
-#ifdef SX_DEBUG_KNOBS
-__device__ unsigned long long g_sx_prof[16];
-__device__ unsigned long long g_sx_span[1024][2];
-struct prof_t {
-    unsigned long long acc[16];
-    unsigned long long last;
-};
-__device__ __forceinline__ void sx_stamp(prof_t &p, int id) {
-    unsigned long long t;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    p.acc[id] += t - p.last;
-    p.last = t;
-}
-#define SX_STAMP(p, id) sx_stamp(p, id)
+// Experiment hooks.  The product build knows none of the timing experiments: SX_X (compile-time ablations), SX_DBG (run-time
+// ablation bits), SX_STAMP (in-kernel phase stamps) and the SX_EXP_* hooks all fold to nothing below.  A build with -DSX_EXPERIMENTS
+// (tools/knob_sweep.sh, tools/experiments/*.sh -- results are then WRONG or stamped, never shipped) pulls their code in from
+// sx_flow_experiments.h.
+#ifdef SX_EXPERIMENTS
+#include "sx_flow_experiments.h"
 #else
+#define SX_X 0
+#define SX_DBG(bit) 0
 struct prof_t {};
 #define SX_STAMP(p, id) ((void)0)
+#define SX_EXP_KERNEL_BEGIN(pf) ((void)0)
+#define SX_EXP_KERNEL_END(pf) ((void)0)
+#define SX_EXP_BEFORE_LAUNCH() ((void)0)
+#define SX_EXP_AFTER_LAUNCH(a) ((void)0)
 #endif
 
 template <int NS>
@@ -109,7 +88,11 @@ struct rng_t {
 };                         // sits exactly on its 128-VGPR budget: a per-lane running max spilled)
 #define SX_F16_MAX 65504.0f
 __device__ __forceinline__ float rng_max(float m, float a, float b) {
-    return __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)));        // v_max3_f32 m, |a|, |b|
+    // ONE v_max3_f32 m, |a|, |b|.  Written as fmaxf(m, fmaxf(fabsf(a), fabsf(b))) the compiler canonicalises each operand first
+    // (v_max_f32 |a|, |a| ...): four vector instructions per register pair, a seventh of cfg 4's vector work (round-5 ISA reading).
+    float r;
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
 }
 __device__ __forceinline__ void rng_note(rng_t &rg, float m) {
 #if defined(SX_F16X3) && !defined(SX_NO_RANGE_TRACK)
@@ -148,6 +131,9 @@ template <int NS>
 __device__ __forceinline__ const btile<NS> &make_btile(const tile<NS> &c) { return c; }
 template <int NS>
 __device__ __forceinline__ const btile<NS> &make_btile(const tile<NS> &c, rng_t &) { return c; }
+template <int NS>
+__device__ __forceinline__ const btile<NS> &make_btile_mx(const tile<NS> &c, float &) { return c; }      // (no operand range in this arithmetic)
+__device__ __forceinline__ bool rng_over(float) { return false; }
 
 template <int NS, class F>
 __device__ __forceinline__ void gemm_tile_f(const char *wb, int a_off, const btile<NS> &b, tile<NS> &acc, F &&f) {
@@ -221,6 +207,59 @@ __device__ __forceinline__ btile<NS> make_btile_impl(const tile<NS> &c, rng_t *r
         }
     if constexpr (TRACK) rng_note(*rg, mx);
     return b;
+}
+// ---- operands beyond fp16's range: a per-sample power of two (round 5) ------------------------------------------------------------
+// The reference takes any finite fp32 (net/mlp.py:65, flows/affine.py:104-109, 156-163).  The conditioner inputs and the dense layers'
+// inputs -- the flow STATE, the one unbounded operand of the forward kernels -- are therefore rescaled when a sample leaves the range:
+// the tracked split hands its running max |v| back, one ballot says whether ANY lane of the wave is beyond 65504 (wave-uniform, not
+// taken in practice), and only then the layer is evaluated once more for the whole wave with every sample's operands multiplied by
+// 2^-e (e from the sample's own maximum: both lane halves), the products accumulated from zero and the result restored as
+// bias + 2^e . acc -- exact scalings, the same three fp16 products.  The fast path pays one v_cmp + s_cbranch per layer.
+// split of a tile that also returns the lane's running max |v| (no flag: the caller decides)
+template <int NS>
+__device__ __forceinline__ btile<NS> make_btile_mx(const tile<NS> &c, float &mx) {
+    btile<NS> b;
+#pragma unroll
+    for (int n = 0; n < NS; ++n)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4 hi, lo;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v0 = c.v[n][8 * s + 2 * q], v1 = c.v[n][8 * s + 2 * q + 1];
+                mx = rng_max(mx, v0, v1);
+                const uint32_t ph = pk_rtz(v0, v1);
+                hi[q] = ph;
+                lo[q] = pk_residual(ph, v0, v1);
+            }
+            b.hi[n][s] = __builtin_bit_cast(h8, hi);
+            b.lo[n][s] = __builtin_bit_cast(h8, lo);
+        }
+    return b;
+}
+__device__ __forceinline__ bool rng_over(float mx) {
+#ifndef SX_NO_RANGE_TRACK
+    return __builtin_amdgcn_ballot_w64(mx > SX_F16_MAX) != 0ull;
+#else
+    return false;
+#endif
+}
+struct rng_pow2 { float sc, inv; };
+// 2^-e / 2^e with |v| 2^-e < 2^15 for every operand of the sample (its max over BOTH lane halves); e = 0 inside the range
+__device__ __forceinline__ rng_pow2 rng_pow2_of(float mx) {
+    const float m = __builtin_fmaxf(mx, __shfl_xor(mx, 32, 64));
+    int e = (int)((__float_as_uint(m) >> 23) & 0xffu) - (127 + 14);
+    e = e < 0 ? 0 : (e > 110 ? 110 : e);          // (inf / NaN: the products become inf / NaN like the reference's)
+    return rng_pow2{__uint_as_float((uint32_t)(127 - e) << 23), __uint_as_float((uint32_t)(127 + e) << 23)};
+}
+template <int NS>
+__device__ __forceinline__ btile<NS> make_btile_scaled(const tile<NS> &c, float sc) {
+    tile<NS> t;
+#pragma unroll
+    for (int n = 0; n < NS; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t.v[n][r] = c.v[n][r] * sc;
+    return make_btile_impl<NS, false>(t, nullptr);
 }
 // bounded operands (tanh / sigmoid-family activations)
 template <int NS>
@@ -448,14 +487,57 @@ __device__ __forceinline__ void hidden_body(const btile<NS> (&bsrc)[CT], tile<NS
     }
 }
 
+#ifdef SX_F16X3
+// hidden_body's results once more, with the samples' operands brought inside fp16's range (see rng_pow2_of): hid[m] = act(bias +
+// 2^e . (W . 2^-e src)); FOLDED: the last tile is left un-activated like hidden_body's
+template <int NS, int NSRC, int HT, int C0, int CT, bool FOLDED>
+__device__ __forceinline__ void hidden_rescaled(const tile<NS> (&src)[NSRC], tile<NS> (&hid)[HT], const wptr w, int off, int act, float mx) {
+    const rng_pow2 p = rng_pow2_of(mx);
+    btile<NS> bs[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) bs[c] = make_btile_scaled<NS>(src[C0 + c], p.sc);
+    const int bias = off + HT * CT * 1024;
+#pragma unroll
+    for (int m = 0; m < HT; ++m) {
+        tile<NS> acc;
+#pragma unroll
+        for (int n = 0; n < NS; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc.v[n][r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) gemm_tile<NS>(w.wb, off + (m * CT + c) * 1024, bs[c], acc);
+        const tile<NS> b = load_cfrag<NS>(w.cb, bias + m * 32);
+#pragma unroll
+        for (int n = 0; n < NS; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc.v[n][r] = __builtin_fmaf(acc.v[n][r], p.inv, b.v[n][r]);
+        if constexpr (FOLDED) {
+            if (m + 1 < HT) {
+#pragma unroll
+                for (int n = 0; n < NS; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) fast_sig2_pair(acc.v[n], r);
+            }
+        } else {
+            activate<NS>(acc, act);
+        }
+        hid[m] = acc;
+    }
+}
+#endif
+
 template <int NS, int NSRC, int HT, int C0, int CT, bool FOLDED>
 __device__ __forceinline__ void hidden_layer(const tile<NS> (&src)[NSRC], tile<NS> (&hid)[HT], const wptr w, int off,
                                              int act, rng_t &rg) {
     btile<NS> bsrc[CT];          // B operands are formed once and reused by every output tile
+    [[maybe_unused]] float mx = 0.f;
 #pragma unroll
-    for (int c = 0; c < CT; ++c) bsrc[c] = make_btile<NS>(src[C0 + c], rg);
+    for (int c = 0; c < CT; ++c) bsrc[c] = make_btile_mx<NS>(src[C0 + c], mx);
     __builtin_amdgcn_sched_barrier(0);
     hidden_body<NS, HT, CT, FOLDED>(bsrc, hid, w, off, act);
+#ifdef SX_F16X3
+    if (rng_over(mx)) hidden_rescaled<NS, NSRC, HT, C0, CT, FOLDED>(src, hid, w, off, act, mx);      // wave-uniform, rare
+#endif
 }
 
 // hidden_layer that hands the B fragments of its source tiles back (the training backward contracts them again)
@@ -556,10 +638,16 @@ struct afr { u32x4 q[4]; };
 __device__ __forceinline__ afr afr_load(const char *wb, int a_off) {
     afr a;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a.q[i] = *reinterpret_cast<const u32x4 *>(wb + (a_off + i * 256) * 4);
+    for (int i = 0; i < 4; ++i) {
+        if (SX_X & 32) a.q[i] = u32x4{(uint32_t)a_off, 0x3c003c00u, (uint32_t)i, 0x38003800u};      // timing experiment: no fragment reads
+        else a.q[i] = *reinterpret_cast<const u32x4 *>(wb + (a_off + i * 256) * 4);
+    }
     return a;
 }
 // one tile: request tile `next_off` (< 0: none), then the MFMAs on `cur` with the riders f(0..15) between them, then cur = next
+// (an MFMA is a pure instruction too: without a use at its place in the chain of volatile statements, instruction selection sinks the
+//  MFMAs of a tile whose result nothing needs yet below all its riders -- the accumulator passes through an empty volatile asm)
+#define SX_PIN_ACC(a) asm volatile("" : "+v"(a))
 template <int NS, class F>
 __device__ __forceinline__ void gemm_tile_pf(const char *wb, afr &cur, int next_off, const btile<NS> &b, tile<NS> &acc, F &&f) {
     afr nxt = cur;
@@ -569,116 +657,182 @@ __device__ __forceinline__ void gemm_tile_pf(const char *wb, afr &cur, int next_
     for (int s = 0; s < 2; ++s) {
         const h8 ah = __builtin_bit_cast(h8, cur.q[2 * s]), al = __builtin_bit_cast(h8, cur.q[2 * s + 1]);
 #pragma unroll
-        for (int n = 0; n < NS; ++n) acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b.hi[n][s], acc.v[n], 0, 0, 0);
+        for (int n = 0; n < NS; ++n) { acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b.hi[n][s], acc.v[n], 0, 0, 0); SX_PIN_ACC(acc.v[n]); }
         f(8 * s + 0); f(8 * s + 1); f(8 * s + 2);
+        __builtin_amdgcn_sched_barrier(0);       // the riders stay in THIS MFMA's shadow (unfenced, the scheduler gathers them in front of the tile)
 #pragma unroll
-        for (int n = 0; n < NS; ++n) acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.lo[n][s], acc.v[n], 0, 0, 0);
+        for (int n = 0; n < NS; ++n) { acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.lo[n][s], acc.v[n], 0, 0, 0); SX_PIN_ACC(acc.v[n]); }
         f(8 * s + 3); f(8 * s + 4); f(8 * s + 5);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int n = 0; n < NS; ++n) acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.hi[n][s], acc.v[n], 0, 0, 0);
+        for (int n = 0; n < NS; ++n) { acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.hi[n][s], acc.v[n], 0, 0, 0); SX_PIN_ACC(acc.v[n]); }
         f(8 * s + 6); f(8 * s + 7);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
     cur = nxt;
 }
+// ---- vector work spread BETWEEN the MFMAs (round 5) ------------------------------------------------------------------------------
+// tools/coexec_probe.hip, two waves per SIMD, each step = 32 split pairs + 48 MFMAs (a dense half-layer), cycles per step and SIMD
+// (matrix-pipe floor 3,072): phases [split][MFMAs] in lockstep behind the barrier 4,223 -- the round-4 structure; the same with
+// waves 4..7 running the complementary phase (a "stagger": built here first, with a three-deep weight ring, and measured on cfg 4
+// at 1.383 vs 1.384 ms: tools/experiments/cfg4_stagger_three_deep_ring.patch) 4,633; s_setprio around the MFMAs 4,229; the vector
+// instructions of the SAME wave placed between its MFMAs 3,385.  A SIMD overlaps a wave's vector instructions with the matrix pipe
+// when they sit in the shadow of that wave's own MFMAs, and hardly at all across waves in coarse phases.  So: the fp16 split of source
+// tile c + 1 rides between the MFMAs of k-tile c (dense layers: k-major over four live accumulators), a hidden tile's sigmoid and
+// split ride under the next tile's MFMAs, the scale's exp2 and the affine map of tile t under the MFMAs of tile t + 1.
+// one pair (registers 2p, 2p + 1) of a C tile -> element p of the B operand's hi / lo fragments
+// A rider's inputs pass through an empty VOLATILE asm at the point where the rider stands: instruction selection orders pure vector
+// instructions by register pressure, not by source position -- unpinned, the sixteen exp2 / rcp of a tile's sigmoid gather in front of
+// the tile's first MFMA and the scheduling fences (which only bind the later machine scheduler) find nothing left to hold in place.
+__device__ __forceinline__ float pinned(float v) { asm volatile("" : "+v"(v)); return v; }
+template <int NS, bool TRACK>
+__device__ __forceinline__ void split_pair(const tile<NS> &c, u32x4 (&hi)[NS][2], u32x4 (&lo)[NS][2], int p, float &mx) {
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+        const float v0 = c.v[n][2 * p], v1 = c.v[n][2 * p + 1];
+        if constexpr (TRACK) mx = rng_max(mx, v0, v1);
+        const uint32_t ph = pk_rtz(v0, v1);
+        hi[n][p >> 2][p & 3] = ph;
+        lo[n][p >> 2][p & 3] = pk_residual(ph, v0, v1);
+    }
+}
+template <int NS>
+__device__ __forceinline__ btile<NS> btile_of(const u32x4 (&hi)[NS][2], const u32x4 (&lo)[NS][2]) {
+    btile<NS> b;
+#pragma unroll
+    for (int n = 0; n < NS; ++n)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { b.hi[n][s] = __builtin_bit_cast(h8, hi[n][s]); b.lo[n][s] = __builtin_bit_cast(h8, lo[n][s]); }
+    return b;
+}
+// Split coupling on 2 + 2 tiles, folded tanh.  Order of the twelve (HT = 2) gemm tiles and what rides between their MFMAs:
+//   [split src 0]  h0.k0 {split src 1}  h0.k1  h1.k0 {sigmoid h0}  h1.k1 {split h0}
+//   ls0.k0 {sigmoid h1}  sh0.k0 {split h1, pairs 0..3}  ls1.k0 {split h1, pairs 4..7}  sh1.k0
+//   ls0.k1  sh0.k1 {exp2 ls0, log-det}  ls1.k1 {affine map of tile 0}  sh1.k1 {exp2 ls1, log-det}   [affine map of tile 1]
+// ([..] = not covered by MFMAs of this wave.)  The output layer runs k-major over four live accumulators.
 template <int NS, int TX, int HT, int C0, int CT, int T0, int TT, bool REV>
 __device__ __forceinline__ void coupling_affine_pf(tile<NS> (&xs)[TX], const wptr w, const dstep &st, float (&ldj)[NS],
                                                    prof_t &pf, rng_t &rg) {
+    static_assert(CT == 2 && HT <= 2, "coupling_affine_pf: two conditioner tiles, hidden <= 64");
     constexpr int a2 = HT * CT * 1024 + HT * 32;   // pack_linear(W2: 2*TT m-tiles, HT k-tiles)
     constexpr int b2 = a2 + 2 * TT * HT * 1024;
     constexpr int bias1 = HT * CT * 1024;
+    constexpr int NH = HT * CT, NO = 2 * TT * HT;
+    // offset of the q-th gemm tile in execution order: hidden m-major, output k-major
+    auto off_of = [](int q) { return q < NH ? q * 1024 : (q < NH + NO ? a2 + (((q - NH) % (2 * TT)) * HT + (q - NH) / (2 * TT)) * 1024 : -1); };
     auto none = [](int) {};
-    afr cur = afr_load(w.wb, 0);                   // the first tile's fragments fly under the split of the source tiles
-    btile<NS> bsrc[CT];
-#pragma unroll
-    for (int c = 0; c < CT; ++c) bsrc[c] = make_btile<NS>(xs[C0 + c], rg);
+    afr cur = afr_load(w.wb, 0);                   // the first tile's fragments fly under the split of the first source tile
+    float mx = 0.f;
+    u32x4 shi[NS][2], slo[NS][2];
+    btile<NS> bsrc0 = make_btile_mx<NS>(xs[C0], mx);
     tile<NS> hid[HT];
-    {   // hidden layer: tile m - 1's folded tanh rides between the MFMAs of tile m's first k-chunk
+    int q = 0;
+    {
         tile<NS> acc = load_cfrag<NS>(w.cb, bias1);
+        gemm_tile_pf<NS>(w.wb, cur, off_of(q + 1), bsrc0, acc, [&](int i) { if (!(i & 1)) split_pair<NS, true>(xs[C0 + 1], shi, slo, i >> 1, mx); });
+        ++q;
+        const bool over = rng_over(mx);            // a sample's conditioner input beyond fp16's range (wave-uniform; see rng_pow2_of)
+        const btile<NS> bsrc1 = btile_of<NS>(shi, slo);
+        gemm_tile_pf<NS>(w.wb, cur, off_of(q + 1), bsrc1, acc, none);
+        ++q;
+        hid[0] = acc;
+        if constexpr (HT == 2) {
+            tile<NS> acc1 = load_cfrag<NS>(w.cb, bias1 + 32);
+            gemm_tile_pf<NS>(w.wb, cur, off_of(q + 1), bsrc0, acc1, [&](int i) {
+                if (i & 1) return;
 #pragma unroll
-        for (int c = 0; c < CT; ++c)
-            gemm_tile_pf<NS>(w.wb, cur, (HT > 1 || c + 1 < CT) ? (c + 1) * 1024 : a2, bsrc[c], acc, none);
-#pragma unroll
-        for (int m = 1; m < HT; ++m) {
-            tile<NS> nxt = load_cfrag<NS>(w.cb, bias1 + m * 32);
-#pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                const int no = (m * CT + c + 1 < HT * CT) ? (m * CT + c + 1) * 1024 : a2;
-                if (c == 0)
-                    gemm_tile_pf<NS>(w.wb, cur, no, bsrc[c], nxt, [&](int i) {
-#pragma unroll
-                        for (int n = 0; n < NS; ++n) fast_sig2_pair(acc.v[n], i);
-                    });
-                else
-                    gemm_tile_pf<NS>(w.wb, cur, no, bsrc[c], nxt, none);
-            }
-            hid[m - 1] = acc;
-            acc = nxt;
+                for (int n = 0; n < NS; ++n) { hid[0].v[n][i] = pinned(fast_sig2(hid[0].v[n][i])); hid[0].v[n][i + 1] = pinned(fast_sig2(hid[0].v[n][i + 1])); }
+            });
+            ++q;
+            gemm_tile_pf<NS>(w.wb, cur, off_of(q + 1), bsrc1, acc1, [&](int i) { if (!(i & 1)) split_pair<NS, false>(hid[0], shi, slo, i >> 1, mx); });
+            ++q;
+            hid[1] = acc1;
         }
-        hid[HT - 1] = acc;
-    }
-    SX_STAMP(pf, 3);     // GEMM-1 (+ pipelined activation)
-    f32x2 s[NS];         // log-det partial sums
+        if (over) {
+            // the hidden layer once more with the samples' inputs rescaled, brought to the state the pipelined code leaves behind:
+            // tile 0 activated and split (HT = 2), the last tile raw
+            hidden_rescaled<NS, TX, HT, C0, CT, true>(xs, hid, w, 0, 0, mx);
+            if constexpr (HT == 2) {
 #pragma unroll
-    for (int n = 0; n < NS; ++n) s[n] = f32x2{0.f, 0.f};
+                for (int pr = 0; pr < 8; ++pr) split_pair<NS, false>(hid[0], shi, slo, pr, mx);
+            }
+        }
+    }
+    SX_STAMP(pf, 3);     // hidden layer
+    btile<NS> bh[HT];
     if constexpr (HT == 1) {
 #pragma unroll
         for (int n = 0; n < NS; ++n)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) fast_sig2_pair(hid[0].v[n], r);
+        bh[0] = make_btile<NS>(hid[0]);
+    } else {
+        bh[0] = btile_of<NS>(shi, slo);
     }
-    btile<NS> bh[HT];
+    f32x2 s[NS];         // log-det partial sums
 #pragma unroll
-    for (int m = 0; m + 1 < HT; ++m) bh[m] = make_btile<NS>(hid[m]);
-    if constexpr (HT == 1) bh[0] = make_btile<NS>(hid[0]);
-    __builtin_amdgcn_sched_barrier(0);
+    for (int n = 0; n < NS; ++n) s[n] = f32x2{0.f, 0.f};
+    tile<NS> out[2 * TT];
 #pragma unroll
-    for (int t = 0; t < TT; ++t) {
-        tile<NS> ls = load_cfrag<NS>(w.cb, b2 + (2 * t) * 32);
-        tile<NS> sh = load_cfrag<NS>(w.cb, b2 + (2 * t + 1) * 32);
-        auto o2 = [&](int row, int m) { return a2 + (row * HT + m) * 1024; };
+    for (int r = 0; r < 2 * TT; ++r) out[r] = load_cfrag<NS>(w.cb, b2 + r * 32);
+    auto exp_rider = [&](tile<NS> &ls, int i) {
+        if (i & 1) return;
 #pragma unroll
-        for (int m = 0; m + 1 < HT; ++m) {
-            if (t == 0 && m == 0)        // the last hidden tile's activation rides under this k-chunk
-                gemm_tile_pf<NS>(w.wb, cur, o2(2 * t + 1, m), bh[m], ls, [&](int i) {
-#pragma unroll
-                    for (int n = 0; n < NS; ++n) fast_sig2_pair(hid[HT - 1].v[n], i);
-                });
-            else
-                gemm_tile_pf<NS>(w.wb, cur, o2(2 * t + 1, m), bh[m], ls, none);
-            gemm_tile_pf<NS>(w.wb, cur, o2(2 * t, m + 1), bh[m], sh, none);
+        for (int n = 0; n < NS; ++n) {
+            // (results pinned too: a pure instruction may also SINK -- the last tile's exp2 and the whole log-det chain otherwise end up
+            //  behind the step's last MFMA)
+            const float l0 = ls.v[n][i], l1 = ls.v[n][i + 1];
+            s[n].x = pinned(s[n].x + l0);
+            s[n].y = pinned(s[n].y + l1);
+            ls.v[n][i] = pinned(__builtin_amdgcn_exp2f(l0));
+            ls.v[n][i + 1] = pinned(__builtin_amdgcn_exp2f(l1));
         }
-        if (t == 0 && HT > 1) {
-            bh[HT - 1] = make_btile<NS>(hid[HT - 1]);   // its activation just finished
-            __builtin_amdgcn_sched_barrier(0);
+    };
+    auto affine_rider = [&](tile<NS> &x, const tile<NS> &e, const tile<NS> &sh, int i) {
+        if (i & 1) return;
+#pragma unroll
+        for (int n = 0; n < NS; ++n) {
+            const f32x2 xv = {x.v[n][i], x.v[n][i + 1]}, sv = {sh.v[n][i], sh.v[n][i + 1]}, ev = {e.v[n][i], e.v[n][i + 1]};
+            const f32x2 yv = REV ? pk_mul(pk_sub(xv, sv), ev) : pk_add(pk_mul(xv, ev), sv);
+            x.v[n][i] = pinned(yv.x);
+            x.v[n][i + 1] = pinned(yv.y);
         }
-        gemm_tile_pf<NS>(w.wb, cur, o2(2 * t + 1, HT - 1), bh[HT - 1], ls, none);
-        // the scale exp2(log_scale') rides under the shift tile's last k-chunk; ls is overwritten by it
-        gemm_tile_pf<NS>(w.wb, cur, t + 1 < TT ? o2(2 * t + 2, 0) : -1, bh[HT - 1], sh, [&](int i) {
-            if (i & 1) return;
+    };
 #pragma unroll
-            for (int n = 0; n < NS; ++n) {
-                s[n] = pk_add(s[n], f32x2{ls.v[n][i], ls.v[n][i + 1]});
-                ls.v[n][i] = __builtin_amdgcn_exp2f(ls.v[n][i]);
-                ls.v[n][i + 1] = __builtin_amdgcn_exp2f(ls.v[n][i + 1]);
-            }
-        });
-        SX_STAMP(pf, 4);     // GEMM-2 (+ pipelined activation / exp)
-        tile<NS> &x = xs[T0 + t];
+    for (int k = 0; k < HT; ++k) {
 #pragma unroll
-        for (int n = 0; n < NS; ++n)
+        for (int r = 0; r < 2 * TT; ++r) {
+            const bool last_k = k == HT - 1;
+            gemm_tile_pf<NS>(w.wb, cur, off_of(q + 1), bh[k], out[r], [&](int i) {
+                if (HT == 2 && k == 0) {
+                    // the last hidden tile: its sigmoid under the first tile of this k-chunk, its split under the next two
+                    if (r == 0) {
+                        if (!(i & 1)) {
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2 xv = {x.v[n][r], x.v[n][r + 1]}, sv = {sh.v[n][r], sh.v[n][r + 1]};
-                const f32x2 ev = {ls.v[n][r], ls.v[n][r + 1]};
-                const f32x2 yv = REV ? pk_mul(pk_sub(xv, sv), ev) : pk_add(pk_mul(xv, ev), sv);
-                x.v[n][r] = yv.x;
-                x.v[n][r + 1] = yv.y;
-            }
+                            for (int n = 0; n < NS; ++n) {
+                                hid[HT - 1].v[n][i] = pinned(fast_sig2(hid[HT - 1].v[n][i]));
+                                hid[HT - 1].v[n][i + 1] = pinned(fast_sig2(hid[HT - 1].v[n][i + 1]));
+                            }
+                        }
+                    } else if (r <= 2) {
+                        if ((i & 3) == 0) split_pair<NS, false>(hid[HT - 1], shi, slo, 4 * (r - 1) + (i >> 2), mx);
+                    }
+                }
+                if (last_k) {
+                    if (r & 1) exp_rider(out[r - 1], i);                                          // sh_t's MFMAs: exp2 of ls_t
+                    else if (r >= 2) affine_rider(xs[T0 + r / 2 - 1], out[r - 2], out[r - 1], i);  // ls_t's MFMAs: the map of tile t - 1
+                }
+            });
+            ++q;
+            if (HT == 2 && k == 0 && r == 2) bh[1] = btile_of<NS>(shi, slo);
+        }
     }
+    SX_STAMP(pf, 4);     // output layer (+ exp2, affine map of all tiles but the last)
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) affine_rider(xs[T0 + TT - 1], out[2 * TT - 2], out[2 * TT - 1], i);
 #pragma unroll
     for (int n = 0; n < NS; ++n) ldj[n] += st.ldj_scale * (s[n].x + s[n].y);
-    SX_STAMP(pf, 5);         // affine + log-det
+    SX_STAMP(pf, 5);         // last tile's affine map + log-det
 }
 #endif
 // Deep conditioners (>= 2 hidden layers, kernel MODE 9): the earlier hidden layers ran as their own steps and left their
@@ -1093,11 +1247,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
     const int bf16 = k.bf16, buf_floats = k.buf_floats;
     double block_sum = 0.0;
     prof_t pf;
-#ifdef SX_DEBUG_KNOBS
-    for (int i = 0; i < 16; ++i) pf.acc[i] = 0;
-    pf.last = __builtin_amdgcn_s_memtime();
-    const unsigned long long pf_t0 = pf.last, pf_w0 = wall_clock64();   // wall_clock64: 100 MHz constant clock
-#endif
+    SX_EXP_KERNEL_BEGIN(pf);
 
     // word 0 of the blob buffer's header: SX_FLAG_* bits raised while the weights were packed (a weight beyond the
     // fp16 x 3 range packs as inf); every launch that uses such weights reports it
@@ -1325,7 +1475,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
             // MODE 11 with resident weights and static chunks: after the first chunk a wave needs nothing from the others (weights
             // are read-only, landing zones private): no wait, no barrier -- the waves of a workgroup drift freely
             const bool free_run = MODE == 11 && resident && !dyn && iter > 0;
-            if (!SX_DBG(2) && !free_run) {
+            if (!SX_DBG(2) && !free_run && !((SX_X & 128) && s > 0)) {      // (SX_X & 128: timing experiment without the per-step wait + barrier)
                 if constexpr (MODE == 4 && TX == 8) {
                     // the weights (LDS-DMA issued one half-step ago) are OLDER than the >= 64 factor stores of that half-step:
                     // a counted wait leaves the stores in flight (vector-memory operations retire in order).  vmcnt cannot count
@@ -1349,6 +1499,13 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
             // waits for the DMA itself -- the refill then no longer flies under the step's arithmetic
             int wb_off = cur * buf_floats * 4 + lane * 16, cb_off = cur * buf_floats * 4 + (lane >> 5) * 64;
             asm volatile("" : "+v"(wb_off), "+v"(cb_off));
+            // MODE 7 / 8 on four tiles (8-wave workgroups): the refill is the OLDER half's job (SX_M7_DMA_WHO, sx_flow_types.h)
+            constexpr int DMA_WHO = ((MODE == 7 || MODE == 8) && WB == 8) ? SX_M7_DMA_WHO : 0;
+            [[maybe_unused]] const uint32_t dma_off_now = dma_off, dma_floats_now = ((s + 1 < n_steps || has_next_chunk) && !SX_DBG(1)) ? dma_floats : 0u;
+            if constexpr (DMA_WHO == 1) {
+                if (dma_floats_now && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) < WB / 2)
+                    stage_blob<WB / 2>(k.blobs + dma_off_now, (cur ^ 1) * buf_floats, dma_floats_now);
+            } else if constexpr (DMA_WHO == 0)
             if ((s + 1 < n_steps || has_next_chunk) && dma_floats && !SX_DBG(1) && !resident)
                 stage_blob<WB>(k.blobs + dma_off, (cur ^ 1) * buf_floats, dma_floats);
             if constexpr (MODE == 11) {
@@ -1417,7 +1574,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                 // dense linear layers + pure split couplings (cfg 4): the same two arms instead of the general dispatch
                 if constexpr (TX >= 2 && (MODE == 7 || MODE == 8)) {
 #ifdef SX_F16X3
-                    if constexpr (TX >= 4) {        // two waves per SIMD: A fragments one tile ahead
+                    if constexpr (TX == 4 && HT <= 2) {        // two waves per SIMD: A fragments one tile ahead, vector work between the MFMAs
                         if (st.c0 == 0) coupling_affine_pf<NS, TX, HT, 0, TX / 2, TX / 2, TX / 2, MODE == 7>(xs, w, st, ldj, pf, rg);
                         else coupling_affine_pf<NS, TX, HT, TX / 2, TX / 2, 0, TX / 2, MODE == 7>(xs, w, st, ldj, pf, rg);
                     } else
@@ -1622,8 +1779,26 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                 case SX_STEP_MLP_OUT_TILE:
                     if constexpr (MODE == 1) {
                         tile<NS> acc = load_cfrag<NS>(w.cb, HT * 1024);
+                        [[maybe_unused]] float mxo = 0.f;
 #pragma unroll
-                        for (int c = 0; c < HT; ++c) gemm_tile<NS>(w.wb, c * 1024, make_btile<NS>(hid[c], rg), acc);
+                        for (int c = 0; c < HT; ++c) gemm_tile<NS>(w.wb, c * 1024, make_btile_mx<NS>(hid[c], mxo), acc);
+#ifdef SX_F16X3
+                        if (rng_over(mxo)) {      // hidden activations beyond fp16's range (run-time activations are unbounded): rng_pow2_of
+                            const rng_pow2 p2 = rng_pow2_of(mxo);
+                            tile<NS> a0;
+#pragma unroll
+                            for (int n = 0; n < NS; ++n)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) a0.v[n][r] = 0.f;
+#pragma unroll
+                            for (int c = 0; c < HT; ++c) gemm_tile<NS>(w.wb, c * 1024, make_btile_scaled<NS>(hid[c], p2.sc), a0);
+                            const tile<NS> b = load_cfrag<NS>(w.cb, HT * 1024);
+#pragma unroll
+                            for (int n = 0; n < NS; ++n)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) acc.v[n][r] = __builtin_fmaf(a0.v[n][r], p2.inv, b.v[n][r]);
+                        }
+#endif
                         const bool accumulate = st.reverse != 0;     // a later hidden chunk of a wide conditioner: mlp_out += (see add_mlp)
 #ifdef SX_F16X3
                         if (rg.bad) {   // a row whose operands left the fp16 x 3 range is returned as NaN and flagged
@@ -1664,51 +1839,109 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     // state's fp16 hi/lo B operands are formed once and hold the complete old state, so every output
                     // slab is written straight over the state tile it replaces -- no second copy of the state.
                     if constexpr (LIN) {
-                        btile<NS> bx[TX];
+#ifdef SX_F16X3
+                        if (x_tiles == TX && TX >= 2) {
+                            // full-width layers, K-MAJOR over TX live accumulators: the fp16 split of source tile c + 1 rides between the
+                            // MFMAs of k-tile c (see coupling_affine_pf), so only the first tile's split is not covered; the A fragments
+                            // of the next gemm tile are requested before the MFMAs of the current one go out (two register sets).
+                            // (Known cost: the state has ONE home in the register file across the step loop, so the compiler copies it away
+                            //  in front of the layer -- 32 v_mov_b64 -- and accumulates in place.  Handing the accumulators over inside the last
+                            //  k-tile's MFMA shadows was tried two ways, a pinned assignment and an explicit v_mov_b64 per pair: the
+                            //  allocator renames the first away and coalesces the second into a self-move; the copies stay where they are.)
+                            tile<NS> acc[TX];
 #pragma unroll
-                        for (int c = 0; c < TX; ++c) bx[c] = make_btile<NS>(xs[c], rg);
+                            for (int m = 0; m < TX; ++m) acc[m] = load_cfrag<NS>(w.cb, TX * TX * 1024 + m * 32);
+                            afr cura = afr_load(w.wb, 0);
+                            float mx = 0.f;
+                            btile<NS> bcur = make_btile_mx<NS>(xs[0], mx);
+                            __builtin_amdgcn_sched_barrier(0);
+                            SX_STAMP(pf, 5);
+                            u32x4 nhi[NS][2], nlo[NS][2];
+                            constexpr int PPM = 8 / TX;            // split pairs of the next source tile per gemm tile (TX = 4: two)
+#pragma unroll
+                            for (int c = 0; c < TX; ++c) {
+#pragma unroll
+                                for (int m = 0; m < TX; ++m) {
+                                    const int qn = c * TX + m + 1;                                     // next gemm tile in k-major order
+                                    const int next_off = qn < TX * TX ? ((qn % TX) * TX + qn / TX) * 1024 : -1;
+                                    gemm_tile_pf<NS>(w.wb, cura, next_off, bcur, acc[m], [&](int i) {
+                                        if (c + 1 < TX) {
+                                            // PPM pairs, each right behind an MFMA: units 0, 8 (PPM = 2) or 0, 3, 8, 11 (PPM = 4)
+                                            if (PPM == 2) { if (i == 0 || i == 8) split_pair<NS, true>(xs[c + 1 < TX ? c + 1 : 0], nhi, nlo, PPM * m + (i >> 3), mx); }
+                                            else { if (i == 0 || i == 3 || i == 8 || i == 11) split_pair<NS, true>(xs[c + 1 < TX ? c + 1 : 0], nhi, nlo, PPM * m + (i >> 3) * 2 + ((i & 7) != 0), mx); }
+                                        }
+                                    });
+                                }
+                                if (c + 1 < TX) bcur = btile_of<NS>(nhi, nlo);
+                            }
+                            if (rng_over(mx)) {
+                                // a sample's state beyond fp16's range (wave-uniform, rare; rng_pow2_of): the layer once more, m-major, from the
+                                // state tiles (intact until the hand-over below), operands times 2^-e, result bias + 2^e . acc
+                                const rng_pow2 p2 = rng_pow2_of(mx);
+                                btile<NS> bs[TX];
+#pragma unroll
+                                for (int c = 0; c < TX; ++c) bs[c] = make_btile_scaled<NS>(xs[c], p2.sc);
+#pragma unroll
+                                for (int m = 0; m < TX; ++m) {
+                                    tile<NS> a0;
+#pragma unroll
+                                    for (int n = 0; n < NS; ++n)
+#pragma unroll
+                                        for (int r = 0; r < 16; ++r) a0.v[n][r] = 0.f;
+#pragma unroll
+                                    for (int c = 0; c < TX; ++c) gemm_tile<NS>(w.wb, (m * TX + c) * 1024, bs[c], a0);
+                                    const tile<NS> b = load_cfrag<NS>(w.cb, TX * TX * 1024 + m * 32);
+#pragma unroll
+                                    for (int n = 0; n < NS; ++n)
+#pragma unroll
+                                        for (int r = 0; r < 16; ++r) acc[m].v[n][r] = __builtin_fmaf(a0.v[n][r], p2.inv, b.v[n][r]);
+                                }
+                            }
+#pragma unroll
+                            for (int m = 0; m < TX; ++m) xs[m] = acc[m];
+                        } else
+#endif
+                        {
+                        btile<NS> bx[TX];
+                        [[maybe_unused]] float mx = 0.f;
+#pragma unroll
+                        for (int c = 0; c < TX; ++c) bx[c] = make_btile_mx<NS>(xs[c], mx);
                         __builtin_amdgcn_sched_barrier(0);
                         SX_STAMP(pf, 5);
+                        [[maybe_unused]] float sc_ = 1.f, inv_ = 1.f;
 #ifdef SX_F16X3
-                        if (x_tiles == TX) {
-                            // full-width layers: the A fragments of tile t + 1 are requested before the MFMAs of tile t go out (two
-                            // register sets), so a wave waits for LDS once per layer instead of four times per tile
-                            u32x4 a[2][4];
-                            auto fetch = [&](int t, u32x4 (&d)[4]) {
+                        const bool over = rng_over(mx);
+                        if (over) {          // (wave-uniform, rare: rng_pow2_of) operands times 2^-e, accumulated from zero, restored below
+                            const rng_pow2 p2 = rng_pow2_of(mx);
+                            sc_ = p2.sc; inv_ = p2.inv;
 #pragma unroll
-                                for (int i = 0; i < 4; ++i) d[i] = *reinterpret_cast<const u32x4 *>(w.wb + (t * 1024 + i * 256) * 4);
-                            };
-                            fetch(0, a[0]);
-                            tile<NS> acc;
-#pragma unroll
-                            for (int t = 0; t < TX * TX; ++t) {
-                                const int m = t / TX, c = t % TX;
-                                if (c == 0) acc = load_cfrag<NS>(w.cb, TX * TX * 1024 + m * 32);
-                                if (t + 1 < TX * TX) fetch(t + 1, a[(t + 1) & 1]);
-                                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                                for (int sx = 0; sx < 2; ++sx) {
-                                    const h8 ah = __builtin_bit_cast(h8, a[t & 1][2 * sx]), al = __builtin_bit_cast(h8, a[t & 1][2 * sx + 1]);
-#pragma unroll
-                                    for (int n = 0; n < NS; ++n) acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bx[c].hi[n][sx], acc.v[n], 0, 0, 0);
-#pragma unroll
-                                    for (int n = 0; n < NS; ++n) acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bx[c].lo[n][sx], acc.v[n], 0, 0, 0);
-#pragma unroll
-                                    for (int n = 0; n < NS; ++n) acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bx[c].hi[n][sx], acc.v[n], 0, 0, 0);
-                                }
-                                __builtin_amdgcn_sched_barrier(0);
-                                if (c == TX - 1) xs[m] = acc;
-                            }
-                        } else
+                            for (int c = 0; c < TX; ++c) bx[c] = make_btile_scaled<NS>(xs[c], sc_);
+                        }
 #endif
 #pragma unroll
                         for (int m = 0; m < TX; ++m) {
                             if (m < x_tiles) {
                                 tile<NS> acc = load_cfrag<NS>(w.cb, x_tiles * TX * 1024 + m * 32);
+#ifdef SX_F16X3
+                                if (over) {
+                                    tile<NS> a0;
+#pragma unroll
+                                    for (int n = 0; n < NS; ++n)
+#pragma unroll
+                                        for (int r = 0; r < 16; ++r) a0.v[n][r] = 0.f;
+#pragma unroll
+                                    for (int c = 0; c < TX; ++c) gemm_tile<NS>(w.wb, (m * TX + c) * 1024, bx[c], a0);
+#pragma unroll
+                                    for (int n = 0; n < NS; ++n)
+#pragma unroll
+                                        for (int r = 0; r < 16; ++r) acc.v[n][r] = __builtin_fmaf(a0.v[n][r], inv_, acc.v[n][r]);
+                                } else
+#endif
 #pragma unroll
                                 for (int c = 0; c < TX; ++c) gemm_tile<NS>(w.wb, (m * TX + c) * 1024, bx[c], acc);
                                 xs[m] = acc;
                             }
+                        }
                         }
                         // the layer's (parameter-only) log-det rides in the blob behind the bias, so a parameter update
                         // refreshes it with the matrix (affine.py:171, 287-288)
@@ -1857,6 +2090,11 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                 default: break;
             }
             if (st.kind != SX_STEP_ROW_SCALE_EXP && st.kind != SX_STEP_POINTWISE) ldj_c += st_cur_const;      // (those two keep a parameter there)
+            if constexpr (DMA_WHO == 2) {
+                // (buffer cur ^ 1 has been free since this step's barrier; the pieces land while the younger half finishes the step)
+                if (dma_floats_now && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) < WB / 2)
+                    stage_blob<WB / 2>(k.blobs + dma_off_now, (cur ^ 1) * buf_floats, dma_floats_now);
+            }
             if (!resident) cur ^= 1;
             SX_STAMP(pf, 6);     // step tail
         }
@@ -2015,21 +2253,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
     }
 #endif
 
-#ifdef SX_DEBUG_KNOBS
-    SX_STAMP(pf, 7);             // epilogue of the last chunk
-#ifndef SX_PROF_THREAD
-#define SX_PROF_THREAD 64       // (wave 1; -DSX_PROF_THREAD=320 stamps its SIMD partner in an 8-wave workgroup)
-#endif
-    if (blockIdx.x == 3 && threadIdx.x == SX_PROF_THREAD) {
-        for (int i = 0; i < 8; ++i) g_sx_prof[i] = pf.acc[i];
-        g_sx_prof[8] = __builtin_amdgcn_s_memtime() - pf_t0;
-        g_sx_prof[9] = wall_clock64() - pf_w0;
-    }
-    if (threadIdx.x == 0 && blockIdx.x < 1024) {      // start / end time of every workgroup (100 MHz ticks)
-        g_sx_span[blockIdx.x][0] = pf_w0;
-        g_sx_span[blockIdx.x][1] = wall_clock64();
-    }
-#endif
+    SX_EXP_KERNEL_END(pf);
     if (k.sum_out != nullptr) {
         double *part = reinterpret_cast<double *>(smem);   // no second __shared__ object beside the DMA ring
         block_sum = wave_sum_f64(block_sum);
@@ -2048,15 +2272,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
 
 template <int TX, int HT>
 static int sx_flow_launch_impl(const sx_flow_args &a) {
-#ifdef SX_DEBUG_KNOBS
-    {
-        const char *e = getenv("SX_DBG");
-        int v = e ? atoi(e) : 0;
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sx_dbg), &v, sizeof(int));
-        static unsigned long long zero[1024][2];
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sx_span), zero, sizeof(zero));
-    }
-#endif
+    SX_EXP_BEFORE_LAUNCH();
     constexpr int NS = SX_NS_FOR(TX);
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -2116,36 +2332,7 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
 #endif
 #undef SX_FL
     SX_LAUNCH_CHECK();
-#ifdef SX_DEBUG_KNOBS
-    if (getenv("SX_PROF")) {
-        (void)hipStreamSynchronize(a.stream);
-        unsigned long long p[16];
-        (void)hipMemcpyFromSymbol(p, HIP_SYMBOL(g_sx_prof), sizeof(p));
-        static const char *names[8] = {"chunk-prologue", "wait+barrier", "desc+dma-issue", "gemm1 / spline block: first tile", "gemm2 / spline block: 3 pairs", "affine / spline block: last element", "step-tail", "epilogue"};
-        unsigned long long tot = 0;
-        for (int i = 0; i < 8; ++i) tot += p[i];
-        fprintf(stderr, "[sx prof] wave 1 of block 3, cycles:");
-        for (int i = 0; i < 8; ++i) fprintf(stderr, " %s=%llu (%.1f%%)", names[i], p[i], 100.0 * p[i] / (tot ? tot : 1));
-        fprintf(stderr, " total=%llu; wave lifetime %.1f us at %.2f GHz (s_memtime / 100 MHz wall clock)\n", tot, p[9] * 0.01,
-                p[9] ? (double)p[8] / (p[9] * 10.0) : 0.0);
-        static unsigned long long span[1024][2];
-        (void)hipMemcpyFromSymbol(span, HIP_SYMBOL(g_sx_span), sizeof(span));
-        unsigned long long s0 = ~0ull, s1 = 0, e0 = ~0ull, e1 = 0;
-        int nb = 0;
-        for (int b = 0; b < 1024 && b < a.grid; ++b) {
-            if (!span[b][1]) continue;
-            ++nb;
-            s0 = span[b][0] < s0 ? span[b][0] : s0; s1 = span[b][0] > s1 ? span[b][0] : s1;
-            e0 = span[b][1] < e0 ? span[b][1] : e0; e1 = span[b][1] > e1 ? span[b][1] : e1;
-        }
-        fprintf(stderr, "[sx prof] %d workgroups: starts spread %.1f us; first end %.1f us, last end %.1f us after the first start\n",
-                nb, (s1 - s0) * 0.01, (e0 - s0) * 0.01, (e1 - s0) * 0.01);
-        if (getenv("SX_PROF_DUMP")) {
-            for (int b = 0; b < 1024 && b < a.grid; ++b)
-                fprintf(stderr, "[sx span] %d %.2f %.2f\n", b, (span[b][0] - s0) * 0.01, (span[b][1] - s0) * 0.01);
-        }
-    }
-#endif
+    SX_EXP_AFTER_LAUNCH(a);
     return SX_OK;
 }
 

@@ -59,6 +59,13 @@ struct sx_flow_args {
 #ifndef SX_M7_WAVES
 #define SX_M7_WAVES 2
 #endif
+// MODE 7 / 8 on four tiles: who issues a step's weight DMA, and when.  0: every wave, behind the step's barrier (as everywhere else);
+// 1: waves 0..3 only, behind the barrier; 2: waves 0..3 only, at the END of their step -- the older half of an 8-wave workgroup wins the
+// SIMD's issue arbitration, finishes a step at ~65 % of its duration and waits at the next barrier: the refill then costs the younger
+// half (the critical path) nothing
+#ifndef SX_M7_DMA_WHO
+#define SX_M7_DMA_WHO 2
+#endif
 #ifndef SX_WAVES_FOR
 #define SX_WAVES_FOR(TX, MODE) SX_WAVES_FOR_(TX, SX_MODE_BASE(MODE))
 #define SX_WAVES_FOR_(TX, MODE) ((MODE) == 11 || (MODE) == 14 ? 1 : (MODE) == 20 ? ((TX) >= 4 ? 1 : 2) : ((MODE) == 15 || (MODE) == 16 || (MODE) == 17) ? ((TX) >= 4 ? 1 : 2) : ((MODE) == 10 || (MODE) == 12 || (MODE) == 13) ? ((TX) >= 4 ? 1 : SX_RQS_WAVES) : (MODE) == 9 ? ((TX) >= 4 ? 1 : 2) : (MODE) >= 7 ? ((TX) >= 4 ? SX_M7_WAVES : 2) : (MODE) >= 5 ? ((TX) >= 4 ? 2 : 4) : ((TX) >= 4 ? 1 : ((MODE) == 3 ? SX_RQS_WAVES : ((MODE) == 0 ? 3 : 2))))

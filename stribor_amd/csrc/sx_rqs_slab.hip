@@ -699,10 +699,12 @@ slab_shape slab_plan(int n_slabs, int n_chunks) {
 }
 }  // namespace
 
-extern "C" int32_t sx_rqs_slab_slots(int32_t n_live) { return ((n_live + 1) / 2) * 96; }
+// (a size query takes any argument: 0 outside the widths a slab pass exists for -- the host sanitizer job found the int overflow at
+//  n_live = INT_MAX)
+extern "C" int32_t sx_rqs_slab_slots(int32_t n_live) { return (n_live < 1 || n_live > (1 << 20)) ? 0 : ((n_live + 1) / 2) * 96; }
 
 extern "C" size_t sx_rqs_slab_scratch_floats(int64_t n_rows, int32_t n_live, int32_t hidden) {
-    if (n_rows < 0 || n_live < 1 || hidden < 1 || hidden > 64) return 0;
+    if (n_rows < 0 || n_rows >= ((int64_t)1 << 36) || n_live < 1 || n_live > (1 << 20) || hidden < 1 || hidden > 64) return 0;
     const int n_slabs = (n_live + 1) / 2, HT = (hidden + 31) / 32;
     const int64_t n_chunks = (n_rows + 31) / 32;
     const slab_shape p = slab_plan(n_slabs, (int)n_chunks);

@@ -220,10 +220,11 @@ def test_error_flags_are_per_stream():
     stream (or to check_errors()), never to work queued on another stream (one word per device let flow A's
     condition surface in flow B's next call)."""
     torch.manual_seed(1)
-    fa = fd.build_flow(st, fd.cfg2_desc(2, 16, 32), 16).to(DEV)
-    fb = fd.build_flow(st, fd.cfg2_desc(2, 16, 32), 16).to(DEV)
+    from producthelp import relu_flow
+    fa = relu_flow()                                        # (ReLU conditioners: see relu_flow)
+    fb = relu_flow()
     xa = torch.randn(64, 16, device=DEV)
-    xa[5, 3] = 3.0e5                                        # beyond fp16's range: flow A's rows 5 come back NaN and flag
+    xa[5] *= 1.0e7                                          # relu(W1 x) beyond fp16's range: flow A's row 5 comes back NaN and flags
     xb = torch.randn(64, 16, device=DEV)
     sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
     torch.cuda.synchronize()
@@ -256,9 +257,10 @@ def test_sync_errors_mode_raises_inside_the_failing_call():
     (rational_quadratic_spline.py:175-178,223) -- a script that ends right after the failing call still sees it."""
     from stribor_amd import _hip
     torch.manual_seed(2)
-    flow = fd.build_flow(st, fd.cfg2_desc(2, 16, 32), 16).to(DEV)
+    from producthelp import relu_flow
+    flow = relu_flow()
     x = torch.randn(64, 16, device=DEV)
-    x[7, 1] = -4.0e5
+    x[7] *= -1.0e7
     old = _hip.set_sync_errors(True)
     try:
         with torch.no_grad():
@@ -266,11 +268,11 @@ def test_sync_errors_mode_raises_inside_the_failing_call():
                 flow.log_prob(x)
             st.check_errors()                               # raised once, nothing left behind
             assert torch.isfinite(flow.log_prob(x[:5])).all()
+            # a stand-alone MLP rescales every layer's operands per sample: no error, finite values
             net = st.net.MLP(8, [16], 4, activation='ReLU').to(DEV)
             z = torch.randn(32, 8, device=DEV)
             z[3, 0] = 1.0e6
-            with pytest.raises(st.GemmRangeError):
-                net(z)
+            assert torch.isfinite(net(z)).all()
     finally:
         _hip.set_sync_errors(old)
     with torch.no_grad():

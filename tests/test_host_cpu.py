@@ -380,3 +380,19 @@ def test_fused_kernel_stages_weights_with_mubuf_lds_dma():
         code = re.sub(r'//[^\n]*', '', src)                      # (comments may name the instruction)
         assert '__builtin_amdgcn_global_load_lds' not in code, name
     assert '__builtin_amdgcn_raw_ptr_buffer_load_lds' in open(os.path.join(root, 'sx_flow_kernel.h')).read()
+
+
+def test_host_code_under_address_and_ub_sanitizers():
+    """SURVEY 5, sanitizer row: `make asan` builds the library's HOST code (every launcher and argument validator, --offload-host-only,
+    no device code) with -fsanitize=address,undefined and links tests/asan_driver.cpp, which drives every sx_* entry point's argument
+    validation without a GPU: plain bad arguments, every single-field mutation of valid cfg 2 / 3 / 4 / backward / wide / MLP programs
+    with the out-of-range values the round-3 fuzz found, and 60,000 random programs.  No sanitizer report, no accepted bad call."""
+    import subprocess
+    csrc = os.path.join(ROOT, 'stribor_amd', 'csrc')
+    b = subprocess.run(['make', '-C', csrc, '-j', str(min(8, os.cpu_count() or 1)), 'asan'], capture_output=True, text=True, timeout=900)
+    assert b.returncode == 0, b.stdout[-2000:] + b.stderr[-2000:]
+    env = dict(os.environ, ASAN_OPTIONS='detect_leaks=0:abort_on_error=0', UBSAN_OPTIONS='print_stacktrace=1')
+    r = subprocess.run([os.path.join(csrc, 'asan', 'asan_driver')], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert 'runtime error' not in r.stderr and 'AddressSanitizer' not in r.stderr, r.stderr[-3000:]
+    assert ' 0 failures' in r.stdout, r.stdout[-1500:]

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Variant build of the library for A/B timing on ONE box (boxes differ by 3 - 8 %: never compare across gpurun calls).
+#   tools/build_variant.sh <name> <TX_HT pair, e.g. 4_2> "<extra hipcc flags>"
+# copies csrc + include to /tmp/v_<name>, rebuilds only sx_flow_x_<pair>.o and the host dispatcher with the extra flags (e.g.
+# "-DSX_ONLY_MODE=7" for a seconds-long single-kernel build, "-DSX_EXPERIMENTS -DSX_DEBUG_KNOBS" for the in-kernel stamps,
+# "-DSX_EXPERIMENTS -DSX_X=32" for an ablation) and leaves build_variants/libstribor_hip_<name>.so (git-ignored; it travels with gpurun).
+# STRIBOR_HIP_LIB=$PWD/build_variants/libstribor_hip_<name>.so selects it; tools/experiments/cfg4_ab.sh runs all of them interleaved.
+set -e
+NAME=$1; PAIR=$2; EXTRA=$3
+R=$(cd "$(dirname "$0")/.." && pwd)
+V=/tmp/v_$NAME
+rm -rf $V && mkdir -p $V/stribor_amd && cp -a $R/stribor_amd/csrc $V/stribor_amd/ && cp -a $R/include $V/
+cd $V/stribor_amd/csrc
+rm -f sx_flow_x_$PAIR.o sx_flow_fused.o ../libstribor_hip.so
+make -j8 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $EXTRA" 2>&1 | grep -v hipcc | tail -3
+mkdir -p $R/build_variants && cp $V/stribor_amd/libstribor_hip.so $R/build_variants/libstribor_hip_$NAME.so

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/pmcq_${CFG}_$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 i=0
-for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+for set in "SQ_WAVE_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32" \
            "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_INT64 SQ_WAVES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"; do
   i=$((i+1))
@@ -41,6 +41,7 @@ for k, cs in per.items():
     if simd:
         d['valu_issue_busy_frac'] = 4 * a.get('SQ_ACTIVE_INST_VALU', 0) / simd
         d['mfma_pipe_busy_frac'] = a.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / simd
+        d['valu_mfma_coexec_frac'] = a.get('SQ_VALU_MFMA_COEXEC_CYCLES', 0) / simd
         d['waves_per_simd_avg'] = 4 * a.get('SQ_WAVE_CYCLES', 0) / simd
         wc = a.get('SQ_WAVE_CYCLES', 0) or 1
         d['sq_wait_any_frac_of_wave_cycles'] = a.get('SQ_WAIT_ANY', 0) / wc
