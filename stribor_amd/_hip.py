@@ -285,15 +285,20 @@ _MAX_FLAG_WORDS = 64
 def _evict_flag_words() -> None:
     """A program that keeps creating streams would grow the table by one pinned word per stream: beyond 64 entries, wait for the
     devices (no kernel may still hold a word's address), report what is pending and drop every word -- live streams get a new one at
-    their next launch.  (A HIP graph captured earlier keeps the address of a dropped word; the pinned allocation itself stays with
-    torch's caching host allocator, so a replay writes into memory that is still mapped, and its flag is lost -- INTEGRATION.md.)"""
+    their next launch.  (A HIP graph captured earlier keeps the address of a dropped word: the words are retired, never freed, so a
+    replay writes into memory nobody else owns; its flag is no longer polled -- INTEGRATION.md.)"""
     torch.cuda.synchronize()
     pending = 0
-    for _, view, _ in _flag_words.values():
-        pending |= int(view[0])
+    for ent in _flag_words.values():
+        pending |= int(ent[1][0])
+        ent[1][0] = 0
+        _retired_words.append(ent[0])          # never handed back to the allocator: a captured graph may still write there
     _flag_words.clear()
     if pending:
         _raise_flags(pending)
+
+
+_retired_words = []
 
 
 def err_flag(device) -> int:

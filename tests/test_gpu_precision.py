@@ -358,3 +358,52 @@ def test_auto_mode_with_wide_hidden_layers_accumulating_chunks():
             st.set_gemm_precision(mode)
             _rel_close(flow.log_prob(xx.to(DEV)), wantl)
             st.check_errors()
+
+
+def test_rescale_is_exact_for_linear_maps():
+    """The in-kernel rescale multiplies a sample's operands by 2^-e, runs the same three fp16 products and restores bias + 2^e . acc:
+    for a LINEAR map without bias the result for 2^k x must therefore equal 2^k times the result for x BIT FOR BIT (same mantissas in
+    every split, same accumulation order), whether or not 2^k x leaves fp16's range -- the logic check the tolerance-based range tests
+    cannot give.  One dense layer (MatrixExponential without bias: the k-major arm at 128 and 64 columns, the m-major arm at 80) on
+    inputs that are multiples of 1/8 (exact in one fp16: no low part that could underflow differently in the two runs); deeper stacks
+    and an Identity-activation MLP with zero biases to 2e-6 of the row's largest value (small intermediate values lose low-part bits
+    to fp16's subnormals in the UNSCALED run only)."""
+    st.set_gemm_precision('fast')
+    for dim in (128, 64, 80):
+        for depth in (1, 3):
+            torch.manual_seed(dim + depth)
+            desc = [{'kind': 'matrix_exp', 'dim': dim, 'bias': False, 'log_time': False} for _ in range(depth)]
+            flow = fd.build_flow(st, desc, dim)
+            with torch.no_grad():
+                for p_ in flow.parameters():
+                    if p_.dim() == 2:
+                        p_.mul_(0.05)
+            flow = flow.to(DEV)
+            x = (torch.randn(300, dim, device=DEV) * 50.0 * 8.0).round() / 8.0           # |x| up to ~250: inside the range
+            base, _ = flow.inverse_and_log_det_jacobian(x)
+            fbase = flow.forward(x)
+            for k in (12, 15):                                   # 2^12 x ~ 1e6: far beyond it
+                big, _ = flow.inverse_and_log_det_jacobian(x * float(2 ** k))
+                fb = flow.forward(x * float(2 ** k))
+                if depth == 1:
+                    assert torch.equal(big, base * float(2 ** k)), (dim, k, (big - base * float(2 ** k)).abs().max().item())
+                    assert torch.equal(fb, fbase * float(2 ** k)), (dim, k)
+                else:
+                    for got, ref in ((big, base), (fb, fbase)):
+                        err = (got / float(2 ** k) - ref).abs().amax(1) / ref.abs().amax(1)
+                        assert err.max().item() <= 2e-6, (dim, k, err.max().item())
+    st.check_errors()
+    torch.manual_seed(7)
+    net = st.net.MLP(24, [48, 40], 10, activation='Identity')
+    with torch.no_grad():
+        for m in net.net:
+            if isinstance(m, torch.nn.Linear):
+                m.bias.zero_()
+    net = net.to(DEV)
+    z = (torch.randn(200, 24, device=DEV) * 30.0 * 8.0).round() / 8.0
+    base = net(z)
+    for k in (11, 14):
+        got = net(z * float(2 ** k)) / float(2 ** k)
+        err = (got - base).abs().amax(1) / base.abs().amax(1)
+        assert err.max().item() <= 2e-6, (k, err.max().item())
+    st.check_errors()
