@@ -13,6 +13,23 @@
 // exists 64 registers at a time, and an element's arithmetic can run beside the MFMAs of the next element's tile.
 // ------------------------------------------------------------------------------------------------
 #define RQS_MIN 1e-3f
+// One iteration of a K-generic sweep ends here: the running results pass through an empty volatile asm and a scheduling fence, so that
+// an iteration's compares are consumed by its own selects (VCC) instead of being hoisted sixteen or thirty-two deep -- interleaved, the
+// sweeps keep ~60 lane masks alive and the allocator spills them to VGPR lanes (v_writelane / v_readlane: vector instructions; the
+// spline object reported 501 SGPR spills, round 5)
+// The bin index of an element is the same value in its select and its evaluate block, and both compare it with every bin number: the
+// optimizer shares those compares -- up to 2 x 31 lane masks kept alive across the step advance between the blocks, i.e. spilled to
+// lanes and read back two v_readlane per select.  Each block takes the index through an empty asm instead and compares again.
+#ifndef SX_NO_SWEEP_FENCE
+#define SX_OPAQUE(v) asm volatile("" : "+v"(v))
+#else
+#define SX_OPAQUE(v) ((void)0)
+#endif
+#ifndef SX_NO_SWEEP_FENCE
+#define SX_SWEEP_FENCE(a, b, c) do { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SX_SWEEP_FENCE(a, b, c) ((void)0)
+#endif
 struct rqs_elems {          // the 4 elements of the current group a lane owns
     float x[4];             // input values
     float a_b[4], a_w[4];   // searched sequence: knot at the bin, bin size
@@ -326,6 +343,7 @@ __device__ __forceinline__ void rqs_search(tile<1> (&acc)[4], rqs_elems &e, int 
             b = take ? j : b;
             k_b = take ? knot : k_b;
             k_n = fminf(k_n, (ge || !used) ? hi : knot);
+            SX_SWEEP_FENCE(b, k_b, k_n);
         }
     }
     e.b[Q] = b + (in ? 0 : RQS_OUT);
@@ -340,7 +358,8 @@ __device__ __forceinline__ void rqs_select(tile<1> (&acc)[4], rqs_elems &e, int 
 #endif
     const float inv = rqs_softmax<Q, KC, W>(acc, K);
     const int Kn = KC ? KC : K;
-    const int b = e.b[Q] & (RQS_OUT - 1);
+    int b = e.b[Q] & (RQS_OUT - 1);
+    SX_OPAQUE(b);       // (see SX_OPAQUE)
     // only two knots are needed: select their cumulative sums in the sweep and rescale those two afterwards
     float cs = 0.f, cs_b = 0.f, cs_n = 0.f;
     bool has_b = false, has_n = false;
@@ -354,6 +373,7 @@ __device__ __forceinline__ void rqs_select(tile<1> (&acc)[4], rqs_elems &e, int 
             cs_n = is_n ? cs : cs_n;
             has_b = has_b || is_b;
             has_n = has_n || is_n;
+            SX_SWEEP_FENCE(cs_b, cs_n, cs);
         }
     }
     const float k_b = has_b ? (hi - lo) * cs_b + lo : lo;
@@ -423,7 +443,8 @@ __device__ __forceinline__ void rqs_eval_core(float r_b, float r_n, bool in, con
 template <int Q, bool REV, int KC, class H>
 __device__ __forceinline__ void rqs_eval(const f32x16 &u, const rqs_elems &e, int K, float &out, float &ljd, H &hk) {
     hk.template pt<0>();
-    const int b = e.b[Q] & (RQS_OUT - 1);
+    int b = e.b[Q] & (RQS_OUT - 1);
+    if constexpr (KC != 16) SX_OPAQUE(b);
     const bool in = e.b[Q] < RQS_OUT;
     const int Kn = KC ? KC : K;
     const float cst = 0.5397424172369522f;                      // log(exp(1 - 1e-3) - 1), :81 boundary derivative constant
@@ -472,7 +493,8 @@ __device__ __forceinline__ void rqs_eval(const f32x16 &u, const rqs_elems &e, in
 // 17..32 bins: the fifteen-step pick above over the element's two tiles
 template <int Q, bool REV>
 __device__ __forceinline__ void rqs_eval_wide(const f32x16 &u0, const f32x16 &u1, const rqs_elems &e, int K, float &out, float &ljd) {
-    const int b = e.b[Q] & (RQS_OUT - 1);
+    int b = e.b[Q] & (RQS_OUT - 1);
+    SX_OPAQUE(b);
     const bool in = e.b[Q] < RQS_OUT;
     const float cst = 0.5397424172369522f;
     float r_b = cst, r_n = cst;
@@ -485,6 +507,7 @@ __device__ __forceinline__ void rqs_eval_wide(const f32x16 &u0, const f32x16 &u1
         r_n = (used && is_prev) ? v : r_n;          // k == b
         r_b = (used && is_next) ? v : r_b;          // k == b - 1
         is_prev = is_next;
+        SX_SWEEP_FENCE(r_n, r_b, r_b);
     }
     rqs_nohook nh;
     rqs_eval_core<Q, REV>(r_b, r_n, in, e, out, ljd, nh);
