@@ -135,7 +135,46 @@ __device__ __forceinline__ void coupling_affine_bwd_a(tile<1> (&xs)[2 * XT], con
         for (int c = 0; c < CT; ++c) store_ctile(side_row, 32 * c, xs[C0 + c].v[0], h);
     }
     tile<1> hid[HT];
+#if defined(SX_F16X3) && !defined(SX_BWD_MMAJOR)
+    // (one wave per SIMD: the A fragments of gemm tile q + 1 are requested before the MFMAs of tile q -- gemm_tile_pf -- through the
+    //  hidden layer and the output layer; the sigmoid of hidden tile m - 1 rides between the MFMAs of tile m's first k-chunk)
+    constexpr int NHT = HT * CT, NOT_ = 2 * TT * HT;
+    auto off_of = [](int q) {            // q-th gemm tile: hidden m-major, then per transformed tile t and hidden tile m: log_scale, shift
+        if (q < NHT) return F1 + q * 1024;
+        const int o = q - NHT;
+        if (o >= NOT_) return -1;
+        const int t = o / (2 * HT), m = (o / 2) % HT, which = o & 1;
+        return F2 + ((2 * t + which) * HT + m) * 1024;
+    };
+    auto none = [](int) {};
+    afr cura = afr_load(w.wb, off_of(0));
+    int q = 0;
+    {
+        btile<1> bsrc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) bsrc[c] = make_btile<1>(xs[C0 + c], rg);
+        __builtin_amdgcn_sched_barrier(0);
+        const int bias = F1 + HT * CT * 1024;
+#pragma unroll
+        for (int m = 0; m < HT; ++m) {
+            tile<1> acc = load_cfrag<1>(w.cb, bias + m * 32);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                if (m > 0 && c == 0)
+                    gemm_tile_pf<1, false>(w.wb, cura, off_of(q + 1), bsrc[c], acc, [&](int i) {
+                        if (!(i & 1)) { hid[m > 0 ? m - 1 : 0].v[0][i] = pinned(fast_sig2(hid[m > 0 ? m - 1 : 0].v[0][i]));
+                                        hid[m > 0 ? m - 1 : 0].v[0][i + 1] = pinned(fast_sig2(hid[m > 0 ? m - 1 : 0].v[0][i + 1])); }
+                    });
+                else
+                    gemm_tile_pf<1, false>(w.wb, cura, off_of(q + 1), bsrc[c], acc, none);
+                ++q;
+            }
+            hid[m] = acc;
+        }
+    }
+#else
     hidden_layer<1, 2 * XT, HT, C0, CT, true>(xs, hid, w, F1, SX_ACT_TANH_FOLDED, rg);
+#endif
 #pragma unroll
     for (int r = 0; r < 16; ++r) hid[HT - 1].v[0][r] = fast_sig2(hid[HT - 1].v[0][r]);
     btile<1> bh[HT];
@@ -146,8 +185,13 @@ __device__ __forceinline__ void coupling_affine_bwd_a(tile<1> (&xs)[2 * XT], con
         tile<1> ls = load_cfrag<1>(w.cb, F2B + (2 * t) * 32), sh = load_cfrag<1>(w.cb, F2B + (2 * t + 1) * 32);
 #pragma unroll
         for (int m = 0; m < HT; ++m) {
+#if defined(SX_F16X3) && !defined(SX_BWD_MMAJOR)
+            gemm_tile_pf<1, false>(w.wb, cura, off_of(q + 1), bh[m], ls, none); ++q;       // kk*log_scale, kk = -log2 e
+            gemm_tile_pf<1, false>(w.wb, cura, off_of(q + 1), bh[m], sh, none); ++q;       // shift
+#else
             gemm_tile<1>(w.wb, F2 + ((2 * t) * HT + m) * 1024, bh[m], ls);          // kk*log_scale, kk = -log2 e
             gemm_tile<1>(w.wb, F2 + ((2 * t + 1) * HT + m) * 1024, bh[m], sh);      // shift
+#endif
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -176,13 +220,29 @@ __device__ __forceinline__ void coupling_affine_bwd_b(tile<1> (&xs)[2 * XT], con
     for (int m = 0; m < HT; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dh[m].v[0][r] = 0.f;
+#if defined(SX_F16X3) && !defined(SX_BWD_MMAJOR)
+    constexpr int NDH = 2 * TT * HT, NDZ = CT * HT;
+    auto off_of = [](int q) {            // q-th gemm tile: dh per (t, m): the log_scale and the shift adjoint's; then dz per (c, m)
+        if (q < NDH) { const int t = q / (2 * HT), m = (q / 2) % HT, which = q & 1; return B2 + (m * 2 * TT + 2 * t + which) * 1024; }
+        const int o = q - NDH;
+        return o < NDZ ? B1 + o * 1024 : -1;
+    };
+    auto none = [](int) {};
+    afr cura = afr_load(w.wb, off_of(0));
+    int q = 0;
+#endif
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
         const btile<1> b0 = make_btile<1>(keep[HT + 2 * t], rg), b1 = make_btile<1>(keep[HT + 2 * t + 1], rg);
 #pragma unroll
         for (int m = 0; m < HT; ++m) {
+#if defined(SX_F16X3) && !defined(SX_BWD_MMAJOR)
+            gemm_tile_pf<1, false>(w.wb, cura, off_of(q + 1), b0, dh[m], none); ++q;
+            gemm_tile_pf<1, false>(w.wb, cura, off_of(q + 1), b1, dh[m], none); ++q;
+#else
             gemm_tile<1>(w.wb, B2 + (m * 2 * TT + 2 * t) * 1024, b0, dh[m]);
             gemm_tile<1>(w.wb, B2 + (m * 2 * TT + 2 * t + 1) * 1024, b1, dh[m]);
+#endif
         }
     }
 #pragma unroll
@@ -209,7 +269,13 @@ __device__ __forceinline__ void coupling_affine_bwd_b(tile<1> (&xs)[2 * XT], con
 #pragma unroll
         for (int r = 0; r < 16; ++r) dz.v[0][r] = 0.f;
 #pragma unroll
-        for (int m = 0; m < HT; ++m) gemm_tile<1>(w.wb, B1 + (c * HT + m) * 1024, bd[m], dz);
+        for (int m = 0; m < HT; ++m) {
+#if defined(SX_F16X3) && !defined(SX_BWD_MMAJOR)
+            gemm_tile_pf<1, false>(w.wb, cura, off_of(q + 1), bd[m], dz, none); ++q;
+#else
+            gemm_tile<1>(w.wb, B1 + (c * HT + m) * 1024, bd[m], dz);
+#endif
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) xs[XT + C0 + c].v[0][r] += dz.v[0][r];
     }
@@ -227,6 +293,40 @@ __device__ __forceinline__ void linear_bwd_half(tile<1> (&xs)[2 * XT], const wpt
 #pragma unroll
         for (int c = 0; c < XT; ++c) store_ctile(side_row, soff + 32 * c, xs[T0 + c].v[0], h);
     }
+#if defined(SX_F16X3) && !defined(SX_BWD_MMAJOR)
+    {
+        // k-major over XT live accumulators, as the forward layer (sx_flow_kernel.h, SX_STEP_LINEAR_TILE): the fp16 split of source
+        // tile c + 1 rides between the MFMAs of k-tile c, the A fragments of the next gemm tile are requested before the MFMAs of the
+        // current one.  This kernel runs ONE wave per SIMD: nothing else covers a tile's LDS round trip or its split (round 5)
+        tile<1> acc[XT];
+#pragma unroll
+        for (int m = 0; m < XT; ++m) acc[m] = load_cfrag<1>(w.cb, XT * XT * 1024 + m * 32);
+        afr cura = afr_load(w.wb, 0);
+        float mx = 0.f;
+        btile<1> bcur = make_btile_mx<1>(xs[T0], mx);
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4 nhi[1][2], nlo[1][2];
+        constexpr int PPM = 8 / XT;
+#pragma unroll
+        for (int c = 0; c < XT; ++c) {
+#pragma unroll
+            for (int m = 0; m < XT; ++m) {
+                const int qn = c * XT + m + 1;
+                const int next_off = qn < XT * XT ? ((qn % XT) * XT + qn / XT) * 1024 : -1;
+                gemm_tile_pf<1, false>(w.wb, cura, next_off, bcur, acc[m], [&](int i) {
+                    if (c + 1 < XT) {
+                        if (PPM == 2) { if (i == 0 || i == 8) split_pair<1, true>(xs[T0 + (c + 1 < XT ? c + 1 : 0)], nhi, nlo, PPM * m + (i >> 3), mx); }
+                        else { if (i == 0 || i == 3 || i == 8 || i == 11) split_pair<1, true>(xs[T0 + (c + 1 < XT ? c + 1 : 0)], nhi, nlo, PPM * m + (i >> 3) * 2 + ((i & 7) != 0), mx); }
+                    }
+                });
+            }
+            if (c + 1 < XT) bcur = btile_of<1>(nhi, nlo);
+        }
+        rng_note(rg, mx);
+#pragma unroll
+        for (int m = 0; m < XT; ++m) xs[T0 + m] = acc[m];
+    }
+#else
     btile<1> bx[XT];
 #pragma unroll
     for (int c = 0; c < XT; ++c) bx[c] = make_btile<1>(xs[T0 + c], rg);
@@ -238,6 +338,7 @@ __device__ __forceinline__ void linear_bwd_half(tile<1> (&xs)[2 * XT], const wpt
         for (int c = 0; c < XT; ++c) gemm_tile<1>(w.wb, (m * XT + c) * 1024, bx[c], acc);
         xs[T0 + m] = acc;
     }
+#endif
     if (side_row != nullptr && !store_before) {
 #pragma unroll
         for (int c = 0; c < XT; ++c) store_ctile(side_row, soff + 32 * c, xs[T0 + c].v[0], h);

@@ -648,7 +648,9 @@ __device__ __forceinline__ afr afr_load(const char *wb, int a_off) {
 // (an MFMA is a pure instruction too: without a use at its place in the chain of volatile statements, instruction selection sinks the
 //  MFMAs of a tile whose result nothing needs yet below all its riders -- the accumulator passes through an empty volatile asm)
 #define SX_PIN_ACC(a) asm volatile("" : "+v"(a))
-template <int NS, class F>
+// (PIN = false: kernels that own the whole 512-entry file keep accumulators in AGPRs, where a "+v" pin costs a v_accvgpr read and write
+//  per register and MFMA -- the 128-column backward ran 21 ms instead of 13 with them)
+template <int NS, bool PIN = true, class F>
 __device__ __forceinline__ void gemm_tile_pf(const char *wb, afr &cur, int next_off, const btile<NS> &b, tile<NS> &acc, F &&f) {
     afr nxt = cur;
     if (next_off >= 0) nxt = afr_load(wb, next_off);
@@ -657,15 +659,15 @@ __device__ __forceinline__ void gemm_tile_pf(const char *wb, afr &cur, int next_
     for (int s = 0; s < 2; ++s) {
         const h8 ah = __builtin_bit_cast(h8, cur.q[2 * s]), al = __builtin_bit_cast(h8, cur.q[2 * s + 1]);
 #pragma unroll
-        for (int n = 0; n < NS; ++n) { acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b.hi[n][s], acc.v[n], 0, 0, 0); SX_PIN_ACC(acc.v[n]); }
+        for (int n = 0; n < NS; ++n) { acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b.hi[n][s], acc.v[n], 0, 0, 0); if constexpr (PIN) SX_PIN_ACC(acc.v[n]); }
         f(8 * s + 0); f(8 * s + 1); f(8 * s + 2);
         __builtin_amdgcn_sched_barrier(0);       // the riders stay in THIS MFMA's shadow (unfenced, the scheduler gathers them in front of the tile)
 #pragma unroll
-        for (int n = 0; n < NS; ++n) { acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.lo[n][s], acc.v[n], 0, 0, 0); SX_PIN_ACC(acc.v[n]); }
+        for (int n = 0; n < NS; ++n) { acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.lo[n][s], acc.v[n], 0, 0, 0); if constexpr (PIN) SX_PIN_ACC(acc.v[n]); }
         f(8 * s + 3); f(8 * s + 4); f(8 * s + 5);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int n = 0; n < NS; ++n) { acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.hi[n][s], acc.v[n], 0, 0, 0); SX_PIN_ACC(acc.v[n]); }
+        for (int n = 0; n < NS; ++n) { acc.v[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.hi[n][s], acc.v[n], 0, 0, 0); if constexpr (PIN) SX_PIN_ACC(acc.v[n]); }
         f(8 * s + 6); f(8 * s + 7);
         __builtin_amdgcn_sched_barrier(0);
     }

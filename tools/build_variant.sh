@@ -11,6 +11,8 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 V=/tmp/v_$NAME
 rm -rf $V && mkdir -p $V/stribor_amd && cp -a $R/stribor_amd/csrc $V/stribor_amd/ && cp -a $R/include $V/
 cd $V/stribor_amd/csrc
+# every other object counts as up to date (a header edited since the last full build would otherwise rebuild all of them with $EXTRA)
+touch *.o sx_build_id.inc 2>/dev/null
 rm -f sx_flow_x_$PAIR.o sx_flow_fused.o ../libstribor_hip.so
 make -j8 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $EXTRA" 2>&1 | grep -v hipcc | tail -3
 mkdir -p $R/build_variants && cp $V/stribor_amd/libstribor_hip.so $R/build_variants/libstribor_hip_$NAME.so
