@@ -945,7 +945,37 @@ __device__ __forceinline__ void coupling_affine_chunk_dispatch(tile<NS> (&xs)[TX
 template <int TX, int HT, int C0>
 __device__ __forceinline__ void wide_hidden(tile<1> (&xs)[TX], btile<1> (&bhp)[HT], const wptr w, rng_t &rg) {
     tile<1> hid[HT];
+#ifdef SX_F16X3
+    // One wave per SIMD (eight state tiles): nothing covers a gemm tile's LDS round trips but the wave itself -- the in-kernel stamps put
+    // 70 % of the wave's lifetime in these arms at ~17 % matrix-pipe use (round 5).  The A fragments of gemm tile q + 1 are requested
+    // before the MFMAs of tile q (gemm_tile_pf, unpinned: the accumulators of a 512-register kernel live in AGPRs), hidden tile m - 1's
+    // sigmoid rides under tile m; operands beyond fp16's range take hidden_layer's rescale afterwards.
+    constexpr int CT = TX / 2;
+    float mx = 0.f;
+    btile<1> bsrc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) bsrc[c] = make_btile_mx<1>(xs[C0 + c], mx);
+    __builtin_amdgcn_sched_barrier(0);
+    afr cura = afr_load(w.wb, 0);
+    constexpr int bias = HT * CT * 1024;
+#pragma unroll
+    for (int m = 0; m < HT; ++m) {
+        tile<1> acc = load_cfrag<1>(w.cb, bias + m * 32);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int qn = m * CT + c + 1;
+            const int next_off = qn < HT * CT ? qn * 1024 : -1;
+            if (m > 0 && c == 0)
+                gemm_tile_pf<1, false>(w.wb, cura, next_off, bsrc[c], acc, [&](int i) { fast_sig2_pair(hid[m > 0 ? m - 1 : 0].v[0], i); });
+            else
+                gemm_tile_pf<1, false>(w.wb, cura, next_off, bsrc[c], acc, [](int) {});
+        }
+        hid[m] = acc;
+    }
+    if (rng_over(mx)) hidden_rescaled<1, TX, HT, C0, CT, true>(xs, hid, w, 0, SX_ACT_TANH_FOLDED, mx);
+#else
     hidden_layer<1, TX, HT, C0, TX / 2, true>(xs, hid, w, 0, SX_ACT_TANH_FOLDED, rg);
+#endif
 #pragma unroll
     for (int r = 0; r < 16; r += 2) fast_sig2_pair(hid[HT - 1].v[0], r);
 #pragma unroll
@@ -954,11 +984,20 @@ __device__ __forceinline__ void wide_hidden(tile<1> (&xs)[TX], btile<1> (&bhp)[H
 template <int TX, int HT>
 __device__ __forceinline__ void wide_affine_tile(tile<1> (&xs)[TX], const btile<1> (&bhp)[HT], const wptr w, const dstep &st, float &ldj) {
     tile<1> ls = load_cfrag<1>(w.cb, 2 * HT * 1024), sh = load_cfrag<1>(w.cb, 2 * HT * 1024 + 32);
+#ifdef SX_F16X3
+    afr cura = afr_load(w.wb, 0);
+#pragma unroll
+    for (int m = 0; m < HT; ++m) {
+        gemm_tile_pf<1, false>(w.wb, cura, (HT + m) * 1024, bhp[m], ls, [](int) {});
+        gemm_tile_pf<1, false>(w.wb, cura, m + 1 < HT ? (m + 1) * 1024 : -1, bhp[m], sh, [](int) {});
+    }
+#else
 #pragma unroll
     for (int m = 0; m < HT; ++m) {
         gemm_tile<1>(w.wb, m * 1024, bhp[m], ls);
         gemm_tile<1>(w.wb, (HT + m) * 1024, bhp[m], sh);
     }
+#endif
     float s = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -1759,10 +1798,11 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     if constexpr (MODE == 20 && TX == 8 && NS == 1) {
                         if (st.c0 == 0) wide_hidden<TX, HT, 0>(xs, bhp, w, rg);
                         else wide_hidden<TX, HT, TX / 2>(xs, bhp, w, rg);
+                        SX_STAMP(pf, 3);
                     }
                     break;
                 case SX_STEP_WIDE_AFFINE_TILE:
-                    if constexpr (MODE == 20 && TX == 8 && NS == 1) wide_affine_tile<TX, HT>(xs, bhp, w, st, ldj[0]);
+                    if constexpr (MODE == 20 && TX == 8 && NS == 1) { wide_affine_tile<TX, HT>(xs, bhp, w, st, ldj[0]); SX_STAMP(pf, 4); }
                     break;
                 case SX_STEP_COUPLING_AFFINE_HC:
                     if constexpr (MODE == 20 && TX >= 2 && TX <= 4) {
