@@ -219,9 +219,11 @@ def stream() -> int:
 
 
 # ---- GEMM arithmetic of the MFMA path ---------------------------------------------------------------------------------
-# 'fast'  fp16 x 3 split on the matrix pipe (fp32-grade: ~2^-22 per product).  Operands must stay within fp16's range
-#         (|v| <= 65504): a sample whose flow state / activations leave it comes back as NaN -- never as a plausible
-#         number -- and the next call (or check_errors()) raises GemmRangeError; weights beyond it raise the same way.
+# 'fast'  fp16 x 3 split on the matrix pipe (fp32-grade: ~2^-22 per product).  A sample whose flow state or Tanh-conditioner
+#         input leaves fp16's range (|v| > 65504) is rescaled by an exact power of two inside the kernel (round 5).
+#         What still must stay within the range: WEIGHTS, hidden activations of non-Tanh coupling conditioners, operands of the
+#         training backward -- such a sample comes back as NaN, never as a plausible number, and the next call (or
+#         check_errors()) raises GemmRangeError.
 # 'exact' v_mfma_f32_32x32x2_f32 fp32 fma chains, no range limit (about 3x slower on BASELINE cfg 2).
 # 'auto'  'fast', but every call synchronises, and a call that left the range is re-run 'exact' before it returns.
 _PRECISIONS = ('fast', 'exact', 'auto')
