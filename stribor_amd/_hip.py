@@ -256,18 +256,49 @@ class GemmRangeError(OverflowError):
 # that kernel has run, so `poll_errors()` at the start of the next call ON THE SAME STREAM reports the previous call's
 # condition (work queued on another stream -- another flow, another thread -- neither sees nor clears it); `check_errors()`
 # synchronises the device and raises whatever any of its streams left behind.
-# STRIBOR_SYNC_ERRORS=1 (or set_sync_errors(True)): every launch is followed by a stream synchronisation and the poll, so
-# the exception leaves the FAILING call like the reference's (stribor/util/rational_quadratic_spline.py:175-178,223) -- at
-# the price of one synchronisation per launch; not usable under HIP-graph capture.
+# Three reporting modes (STRIBOR_SYNC_ERRORS / set_sync_errors):
+#   'grad' (default)  a NormalizingFlow call that builds an autograd graph (grad enabled, a parameter or the input requires it) of a
+#                     flow that holds a rational-quadratic spline -- the reference op that asserts on its data
+#                     (stribor/util/rational_quadratic_spline.py:175-178,223) -- synchronises its stream ONCE before it returns and
+#                     raises what its kernels flagged: in a training loop the exception leaves the failing call like the reference's,
+#                     at +2 .. 3 % of a cfg-3 training step (tools/experiments/sync_mode_cost.sh).  Flows without that op (the same
+#                     rule would cost cfg 2 13 .. 24 % of a step), calls without a graph (inference, torch.no_grad()) and stream
+#                     capture keep the deferred report of '0'.
+#   '1' / True        every LAUNCH is followed by a stream synchronisation and the poll -- the debugging mode; not usable under
+#                     HIP-graph capture.
+#   '0' / False       never synchronise: the next call on the stream (or check_errors()) reports.
 _flag_words = {}
-_sync_errors = os.environ.get('STRIBOR_SYNC_ERRORS', '0') not in ('', '0')
 
 
-def set_sync_errors(on: bool) -> bool:
-    """Raise data-dependent errors inside the failing call (synchronises after every launch); returns the previous setting."""
-    global _sync_errors
-    old, _sync_errors = _sync_errors, bool(on)
+def _parse_sync_mode(v) -> str:
+    if isinstance(v, str):
+        v = v.strip().lower()
+        if v in ('grad', 'train'):
+            return 'grad'
+        return '0' if v in ('', '0', 'false', 'off', 'never') else '1'
+    return '1' if v else '0'
+
+
+_sync_mode = _parse_sync_mode(os.environ.get('STRIBOR_SYNC_ERRORS', 'grad'))
+_sync_errors = _sync_mode == '1'          # per-launch synchronisation (read by call() / after_launch())
+
+
+def set_sync_errors(on) -> str:
+    """Select how data-dependent errors are reported: True / '1' inside the failing launch (synchronises after every launch), 'grad'
+    at the end of every graph-building flow call (the default), False / '0' by the next call; returns the previous setting."""
+    global _sync_errors, _sync_mode
+    old = _sync_mode
+    _sync_mode = _parse_sync_mode(on)
+    _sync_errors = _sync_mode == '1'
     return old
+
+
+def end_of_flow_call(x) -> None:
+    """'grad' mode: called by NormalizingFlow's outermost public call when it built a graph -- wait for the stream and raise."""
+    if _sync_mode == 'grad' and x.is_cuda and not torch.cuda.is_current_stream_capturing():
+        with device_of(x):
+            torch.cuda.current_stream().synchronize()
+            poll_errors(device=x.device)
 
 
 def _flag_entry(device):

@@ -388,7 +388,7 @@ __device__ __forceinline__ void turn_part(const h8 (&p)[2], const sel_t &sel, h8
     for (int s = 0; s < 2; ++s) {
         u32x4 u;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) u[q] = pk_rtz(t[8 * s + 2 * q], t[8 * s + 2 * q + 1]);     // exact: the values are fp16
+        for (int q = 0; q < 4; ++q) u[q] = pk_f16(t[8 * s + 2 * q], t[8 * s + 2 * q + 1]);     // exact: the values are fp16
         out[s] = __builtin_bit_cast(h8, u);
     }
     float a = 0.f;

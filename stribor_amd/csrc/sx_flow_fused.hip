@@ -317,10 +317,13 @@ extern "C" int sx_flow_run(const sx_program *prog_host, const float *blobs, cons
     a.flags = err_flag;
     a.frag_in = nullptr; a.frag_out = nullptr; a.acc_out = nullptr;
     const int T = prog_host->tiles, H = prog_host->h_tiles;
-#define SX_GO(TT, HH) if (T == TT && H == HH) return precision == SX_GEMM_F16X3 ? sx_flow_launch_f16x3_t##TT##h##HH(a) : sx_flow_launch_f32x_t##TT##h##HH(a)
+    const int fam = SX_MODE_FAMILY(mlp_mode);       // one object per kernel-MODE family (sx_flow_types.h)
+#define SX_GOF(TT, HH, F) (precision == SX_GEMM_F16X3 ? sx_flow_launch_f16x3_t##TT##h##HH##_f##F(a) : sx_flow_launch_f32x_t##TT##h##HH##_f##F(a))
+#define SX_GO(TT, HH) if (T == TT && H == HH) return fam == 0 ? SX_GOF(TT, HH, 0) : fam == 1 ? SX_GOF(TT, HH, 1) : SX_GOF(TT, HH, 2)
     SX_GO(1, 1); SX_GO(1, 2); SX_GO(1, 4); SX_GO(2, 1); SX_GO(2, 2); SX_GO(2, 4); SX_GO(4, 1); SX_GO(4, 2); SX_GO(4, 4);
     SX_GO(8, 1); SX_GO(8, 2); SX_GO(8, 4);
 #undef SX_GO
+#undef SX_GOF
     sx_set_error("sx_flow_run: unsupported tile configuration");
     return SX_E_UNSUPPORTED;
 }
@@ -382,6 +385,6 @@ extern "C" int sx_flow_bwd_run(const sx_program *prog_host, const float *blobs, 
     a.work = (prog_host->n_steps != 1 && n_chunks > 2 * (int64_t)a.grid && !g_static_chunks) ? work : nullptr;
     a.flags = err_flag;
     a.frag_in = frag_in; a.frag_out = frag_out; a.acc_out = acc_out;
-    if (prog_host->h_tiles == 1) return sx_flow_launch_f16x3_t4h1(a);
-    return sx_flow_launch_f16x3_t4h2(a);
+    if (prog_host->h_tiles == 1) return sx_flow_launch_f16x3_t4h1_f2(a);
+    return sx_flow_launch_f16x3_t4h2_f2(a);
 }

@@ -169,10 +169,22 @@ template <int NS>
 struct btile {            // one 32-deep B operand: 2 k16-steps x (hi, lo) fragments, per sample tile
     h8 hi[NS][2], lo[NS][2];
 };
-__device__ __forceinline__ uint32_t pk_rtz(float a, float b) {
+// Two fp32 -> one register of two fp16, round to NEAREST even: gfx950's v_cvt_pk_f16_f32.  (Rounds 1-4 used v_cvt_pkrtz_f16_f32, the
+// only packed conversion of gfx942: truncation leaves |v - hi - lo| up to 2^-20 |v|, always towards zero -- a BIAS that adds up
+// over a sum; nearest leaves 2^-22 |v| without a sign preference.  Same instruction count, same time on cfg 2 / 3 / 4
+// (tools/experiments/cfg4_ab.sh, three interleaved rounds); against the fp64 oracle on 8,192 rows
+// (tools/experiments/split_accuracy.py): cfg 2 log_prob rms 1.9e-7 -> 1.2e-7, mean signed error +1.1e-7 -> +1.7e-8 (the reference's own
+// fp32 sequence: 8.6e-8, +6.8e-9); cfg 4 rms 1.8e-6 -> 8.3e-7, mean +1.6e-6 -> +6e-8 (fp32 sequence: 1.2e-6).  -DSX_SPLIT_RTZ: the old split.)
+__device__ __forceinline__ uint32_t pk_f16(float a, float b) {
+#ifndef SX_SPLIT_RTZ
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2v){a, b}, f16x2v));
+#else
     return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
+#endif
 }
-// lo halfs of a pair: rtz_f16(v - hi) straight from the packed hi register: v_fma_mix_f32 reads the fp16 source in
+// lo halfs of a pair: f16(v - hi) straight from the packed hi register: v_fma_mix_f32 reads the fp16 source in
 // place (no v_cvt_f32_f16) and subtracts in fp32 (exact): 4 full-rate VALU instructions per pair for the whole
 // split instead of 6.  (v_fma_mixlo/mixhi_f16 would make it 3, but they issue at the transcendental rate:
 // tools/valu_cost_probe.hip.)
@@ -180,10 +192,10 @@ __device__ __forceinline__ uint32_t pk_residual(uint32_t ph, float v0, float v1)
     float l0, l1;
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(ph), "v"(v0));
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(ph), "v"(v1));
-    return pk_rtz(l0, l1);
+    return pk_f16(l0, l1);
 }
 // C tile (fp32, 16 registers) -> B fragments: k16-step s takes registers 8s..8s+7 (cdna_hip_programming.md §3
-// 'An accumulator tile as the next MFMA's operand'); hi = rtz(v), lo = rtz(v - hi) (v - hi is exact in fp32).
+// 'An accumulator tile as the next MFMA's operand'); hi = f16(v), lo = f16(v - hi) (v - hi is exact in fp32), both to nearest.
 template <int NS, bool TRACK>
 __device__ __forceinline__ btile<NS> make_btile_impl(const tile<NS> &c, rng_t *rg) {
     btile<NS> b;
@@ -198,7 +210,7 @@ __device__ __forceinline__ btile<NS> make_btile_impl(const tile<NS> &c, rng_t *r
                 const float v0 = c.v[n][8 * s + 2 * q], v1 = c.v[n][8 * s + 2 * q + 1];
                 if (SX_X & 64) { hi[q] = __float_as_uint(v0); lo[q] = __float_as_uint(v1); continue; }
                 if constexpr (TRACK) mx = rng_max(mx, v0, v1);
-                const uint32_t ph = pk_rtz(v0, v1);
+                const uint32_t ph = pk_f16(v0, v1);
                 hi[q] = ph;
                 lo[q] = pk_residual(ph, v0, v1);
             }
@@ -228,7 +240,7 @@ __device__ __forceinline__ btile<NS> make_btile_mx(const tile<NS> &c, float &mx)
             for (int q = 0; q < 4; ++q) {
                 const float v0 = c.v[n][8 * s + 2 * q], v1 = c.v[n][8 * s + 2 * q + 1];
                 mx = rng_max(mx, v0, v1);
-                const uint32_t ph = pk_rtz(v0, v1);
+                const uint32_t ph = pk_f16(v0, v1);
                 hi[q] = ph;
                 lo[q] = pk_residual(ph, v0, v1);
             }
@@ -693,7 +705,7 @@ __device__ __forceinline__ void split_pair(const tile<NS> &c, u32x4 (&hi)[NS][2]
     for (int n = 0; n < NS; ++n) {
         const float v0 = c.v[n][2 * p], v1 = c.v[n][2 * p + 1];
         if constexpr (TRACK) mx = rng_max(mx, v0, v1);
-        const uint32_t ph = pk_rtz(v0, v1);
+        const uint32_t ph = pk_f16(v0, v1);
         hi[n][p >> 2][p & 3] = ph;
         lo[n][p >> 2][p & 3] = pk_residual(ph, v0, v1);
     }
@@ -2312,6 +2324,13 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
     }
 }
 
+// (a template so that the `if constexpr` around a MODE's launch is value-dependent: the discarded MODEs are never instantiated)
+#ifndef SX_FAMILY
+#define SX_FAMILY -1
+#endif
+template <int TX>
+constexpr bool in_family(int f) { return SX_FAMILY < 0 || SX_FAMILY == f; }
+
 template <int TX, int HT>
 static int sx_flow_launch_impl(const sx_flow_args &a) {
     SX_EXP_BEFORE_LAUNCH();
@@ -2342,35 +2361,38 @@ static int sx_flow_launch_impl(const sx_flow_args &a) {
     if (a.mlp_mode == SX_ONLY_MODE) SX_FL(SX_ONLY_MODE);
     else { sx_set_error("built with SX_ONLY_MODE"); return SX_E_UNSUPPORTED; }
 #else
+    // SX_FM(MD): the MODE is instantiated in the object of its family only (-DSX_FAMILY: sx_flow_types.h; none: every MODE)
+#define SX_FM(MD) do { if constexpr (in_family<TX>(SX_MODE_FAMILY(MD))) SX_FL(MD); else { sx_set_error("sx_flow_run: mode %d is not in this object's family", MD); return SX_E_UNSUPPORTED; } } while (0)
     if constexpr (TX == 8) {            // 4 data + 4 adjoint tiles: the training backward of 128-column flows; 8 data tiles: hidden-chunk programs
-        if (a.mlp_mode == 4) { if constexpr (HT <= 2) SX_FL(4); else { sx_set_error("sx_flow_run: backward programs on 4 + 4 tiles are built for hidden <= 64"); return SX_E_UNSUPPORTED; } }
-        else if (a.mlp_mode == 20) SX_FL(20);
+        if (a.mlp_mode == 4) { if constexpr (HT <= 2) SX_FM(4); else { sx_set_error("sx_flow_run: backward programs on 4 + 4 tiles are built for hidden <= 64"); return SX_E_UNSUPPORTED; } }
+        else if (a.mlp_mode == 20) SX_FM(20);
         else { sx_set_error("sx_flow_run: 8 state tiles are the backward program's or a hidden-chunk program's (mode %d)", a.mlp_mode); return SX_E_UNSUPPORTED; }
     } else
-    if (a.mlp_mode == 1) SX_FL(1); else if (a.mlp_mode == 2) SX_FL(2); else if (a.mlp_mode == 3) SX_FL(3);
-    else if (a.mlp_mode == 4) SX_FL(4);
-    else if (a.mlp_mode == 5) { if constexpr (TX >= 2) SX_FL(5); }
-    else if (a.mlp_mode == 6) { if constexpr (TX >= 2) SX_FL(6); }
-    else if (a.mlp_mode == 9) SX_FL(9);
-    else if (a.mlp_mode == 10) SX_FL(10);
-    else if (a.mlp_mode == 12) SX_FL(12);
-    else if (a.mlp_mode == 18) SX_FL(18);
-    else if (a.mlp_mode == 19) SX_FL(19);
-    else if (a.mlp_mode == 13) SX_FL(13);
-    else if (a.mlp_mode == 14) SX_FL(14);
-    else if (a.mlp_mode == 15) SX_FL(15);
-    else if (a.mlp_mode == 16) SX_FL(16);
-    else if (a.mlp_mode == 17) SX_FL(17);
-    else if (a.mlp_mode == 20) { if constexpr (TX >= 2) SX_FL(20); }
-    else if (a.mlp_mode == 7) { if constexpr (TX >= 2) SX_FL(7); }
-    else if (a.mlp_mode == 8) { if constexpr (TX >= 2) SX_FL(8); }
+    if (a.mlp_mode == 1) SX_FM(1); else if (a.mlp_mode == 2) SX_FM(2); else if (a.mlp_mode == 3) SX_FM(3);
+    else if (a.mlp_mode == 4) SX_FM(4);
+    else if (a.mlp_mode == 5) { if constexpr (TX >= 2) SX_FM(5); }
+    else if (a.mlp_mode == 6) { if constexpr (TX >= 2) SX_FM(6); }
+    else if (a.mlp_mode == 9) SX_FM(9);
+    else if (a.mlp_mode == 10) SX_FM(10);
+    else if (a.mlp_mode == 12) SX_FM(12);
+    else if (a.mlp_mode == 18) SX_FM(18);
+    else if (a.mlp_mode == 19) SX_FM(19);
+    else if (a.mlp_mode == 13) SX_FM(13);
+    else if (a.mlp_mode == 14) SX_FM(14);
+    else if (a.mlp_mode == 15) SX_FM(15);
+    else if (a.mlp_mode == 16) SX_FM(16);
+    else if (a.mlp_mode == 17) SX_FM(17);
+    else if (a.mlp_mode == 20) { if constexpr (TX >= 2) SX_FM(20); }
+    else if (a.mlp_mode == 7) { if constexpr (TX >= 2) SX_FM(7); }
+    else if (a.mlp_mode == 8) { if constexpr (TX >= 2) SX_FM(8); }
     else if (a.mlp_mode == 11) {
 #ifdef SX_F16X3
-        if constexpr (TX == 4 && HT <= 2) SX_FL(11); else
+        if constexpr (TX == 4 && HT <= 2) SX_FM(11); else
 #endif
         { sx_set_error("sx_flow_bwd_run: needs 4 state tiles, hidden <= 64 and the fp16 x 3 arithmetic"); return SX_E_UNSUPPORTED; }
     }
-    else SX_FL(0);
+    else SX_FM(0);
+#undef SX_FM
 #endif
 #undef SX_FL
     SX_LAUNCH_CHECK();

@@ -79,9 +79,17 @@ struct sx_flow_args {
 // workgroups per CU the kernel is compiled for
 #define SX_BLOCKS_FOR(TX, MODE) (SX_WAVES_FOR(TX, MODE) * 4 / SX_BLOCK_WAVES(TX, MODE))
 
-#define SX_DECL_FLOW(T, H) int sx_flow_launch_f16x3_t##T##h##H(const sx_flow_args &a); int sx_flow_launch_f32x_t##T##h##H(const sx_flow_args &a);
+// Kernel-MODE families, one object per (tiles, hidden tiles, arithmetic, family) -- VERDICT r4 #8c: every object used to instantiate
+// all twenty MODEs of its pair, so a one-line spline edit rebuilt everything:
+//   0  affine / dense / MLP / time-conditioned inference programs (MODE 0, 1, 2, 5 .. 10, 15, 20)
+//   1  spline, cubic-spline and mixed programs (MODE 3, 12, 13, 14, 16 .. 19): the only objects that depend on sx_flow_spline.h
+//   2  training backward programs (MODE 4, 11): the only objects that depend on sx_flow_bwd.h
+#define SX_MODE_FAMILY(MODE) ((MODE) == 4 || (MODE) == 11 ? 2 : ((MODE) == 3 || (MODE) == 12 || (MODE) == 13 || (MODE) == 14 || ((MODE) >= 16 && (MODE) <= 19)) ? 1 : 0)
+#define SX_DECL_FLOW_F(T, H, F) int sx_flow_launch_f16x3_t##T##h##H##_f##F(const sx_flow_args &a); int sx_flow_launch_f32x_t##T##h##H##_f##F(const sx_flow_args &a);
+#define SX_DECL_FLOW(T, H) SX_DECL_FLOW_F(T, H, 0) SX_DECL_FLOW_F(T, H, 1) SX_DECL_FLOW_F(T, H, 2)
 SX_DECL_FLOW(1, 1) SX_DECL_FLOW(1, 2) SX_DECL_FLOW(1, 4)
 SX_DECL_FLOW(2, 1) SX_DECL_FLOW(2, 2) SX_DECL_FLOW(2, 4)
 SX_DECL_FLOW(4, 1) SX_DECL_FLOW(4, 2) SX_DECL_FLOW(4, 4)
 SX_DECL_FLOW(8, 1) SX_DECL_FLOW(8, 2) SX_DECL_FLOW(8, 4)      // 4 data + 4 adjoint tiles: backward programs of 128-column flows (MODE 4); 8 data tiles: MODE 20
 #undef SX_DECL_FLOW
+#undef SX_DECL_FLOW_F

@@ -23,13 +23,17 @@ constexpr int PATCH = 32 * 36;       // one 32-feature x 32-row tile, feature ro
 
 // ---- fp16 x 3 contraction (SX_WGRAD_ROW_GROUPS_F16X3): the operands of a backward program are fp16 x 3 GEMM operands already
 // (scaled into fp16's range, range-tracked by the kernel that wrote them), so the batch contraction can run on the matrix pipe as
-// well: a lane's 16 rows of a feature split hi + lo (hi = rtz(v), lo = rtz(v - hi)), two 16-row steps of
+// well: a lane's 16 rows of a feature split hi + lo (hi = f16(v), lo = f16(v - hi), to nearest: sx_flow_kernel.h pk_f16), two 16-row steps of
 // v_mfma_f32_32x32x16_f16 with three products each -- 6 MFMAs x 32 cycles per tile pair and 32 rows instead of 16 x 64.
 typedef __attribute__((address_space(3))) void lds_void;
 typedef _Float16 wg_h8 __attribute__((ext_vector_type(8)));
 typedef uint32_t wg_u4 __attribute__((ext_vector_type(4)));
 struct wg_split { wg_h8 hi[2], lo[2]; };
-__device__ __forceinline__ uint32_t wg_pk(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b)); }
+__device__ __forceinline__ uint32_t wg_pk(float a, float b) {      // v_cvt_pk_f16_f32, round to nearest even (a truncating split biases a sum over 2^20 rows)
+    typedef float wg_f2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 wg_h2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((wg_f2){a, b}, wg_h2));
+}
 __device__ __forceinline__ wg_split wg_make(const f32x4 (&v)[4]) {
     wg_split o;
 #pragma unroll

@@ -8,7 +8,9 @@ whole flow — inverse pass, log-det accumulation and the UnitNormal base densit
 in ONE kernel launch.  Layers that cannot be fused fall back to a per-layer loop of HIP kernels.
 """
 import ctypes as C
+import functools
 import os
+import threading
 from abc import ABCMeta, abstractmethod
 from typing import List, Optional, Tuple, Union
 
@@ -327,6 +329,34 @@ class ElementwiseTransform(Transform):
         return x, -self.log_diag_jacobian(x, y, **kwargs)
 
 
+_call_depth = threading.local()
+
+
+def _errors_leave_the_call(fn):
+    """The reference raises a data-dependent failure inside the failing op: the rational-quadratic spline's inverse asserts its
+    discriminant synchronously (rational_quadratic_spline.py:175-178,223).  Here kernels flag it and a later poll raises.  A call
+    that builds an autograd graph -- a training step -- of a flow that HOLDS such a spline ends with one stream synchronisation + poll
+    (`_hip.end_of_flow_call`; mode 'grad', the default), so the exception leaves THIS call; only the outermost of nested public calls
+    (log_prob -> inverse_and_log_det_jacobian) pays it.  Measured (tools/experiments/sync_mode_cost.sh): +2 .. 3 % on the cfg-3
+    training step; the same rule on flows without that op would cost cfg 2 +13 .. 24 % and cfg 4 +11 .. 14 % of a step for an
+    exception the reference does not raise there, so they -- and every inference call -- stay asynchronous."""
+    @functools.wraps(fn)
+    def wrapped(self, x, *args, **kwargs):
+        if (_hip._sync_mode != 'grad' or not torch.is_tensor(x) or not x.is_cuda or not self._wants_grad(x)
+                or not self._holds_asserting_op()):
+            return fn(self, x, *args, **kwargs)
+        depth = getattr(_call_depth, 'n', 0)
+        _call_depth.n = depth + 1
+        try:
+            out = fn(self, x, *args, **kwargs)
+        finally:
+            _call_depth.n = depth
+        if depth == 0:
+            _hip.end_of_flow_call(x)
+        return out
+    return wrapped
+
+
 def _fp32_between_layers(x):
     """bf16 is a STORAGE format here (bf16 in, fp32 arithmetic): a flow that runs layer by layer keeps fp32 between
     its layers -- as the fused kernel does in registers -- and rounds once, on the way out.  -> (tensor to run on, cast back)."""
@@ -354,6 +384,13 @@ class NormalizingFlow(Transform):
 
     def _plan_guards(self) -> list:
         return [g for f in self.transforms for g in f._plan_guards()]
+
+    def _holds_asserting_op(self) -> bool:
+        """Does a layer evaluate the reference op that asserts on its data (the rational-quadratic spline; see _errors_leave_the_call)?"""
+        def build():
+            from .flows.spline import Spline
+            return any(isinstance(m, Spline) and m.spline_type == 'quadratic' for f in self.transforms for m in f.modules())
+        return self._cached(('asserting-op',), build)
 
     def _cached(self, key, build):
         return self._fused.get(key, build, self._plan_guards, self._fingerprint())
@@ -697,6 +734,7 @@ class NormalizingFlow(Transform):
         return shp(y, x2.shape[1]), shp(acc if want_ldj else None, 1), shp(logp if want_logp else None, 1)
 
     # ---- reference method set -----------------------------------------------------------------------------
+    @_errors_leave_the_call
     def forward(self, x, latent=None, **kwargs):
         g = self._transform_with_graph(x, latent, False, 'forward', kwargs)
         if g is not None:
@@ -710,6 +748,7 @@ class NormalizingFlow(Transform):
             x = f(x, **kw)
         return back(x)
 
+    @_errors_leave_the_call
     def inverse(self, y, latent=None, **kwargs):
         g = self._transform_with_graph(y, latent, True, 'inverse', kwargs)
         if g is not None:
@@ -723,6 +762,7 @@ class NormalizingFlow(Transform):
             y = f.inverse(y, **kw)
         return back(y)
 
+    @_errors_leave_the_call
     def forward_and_log_det_jacobian(self, x, latent=None, **kwargs):
         g = self._transform_with_graph(x, latent, False, 'forward_and_log_det_jacobian', kwargs)
         if g is not None:
@@ -738,6 +778,7 @@ class NormalizingFlow(Transform):
             acc = acc + ldj
         return back(x), acc
 
+    @_errors_leave_the_call
     def inverse_and_log_det_jacobian(self, y, latent=None, **kwargs):
         g = self._transform_with_graph(y, latent, True, 'inverse_and_log_det_jacobian', kwargs)
         if g is not None:
@@ -753,6 +794,7 @@ class NormalizingFlow(Transform):
             acc = acc + ldj
         return back(y), acc
 
+    @_errors_leave_the_call
     def log_prob(self, y, latent=None, **kwargs):
         """[..., D] -> [..., 1]   (flow.py:127-130)."""
         from .dist.normal import UnitNormal

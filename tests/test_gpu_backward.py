@@ -985,7 +985,13 @@ def test_cubic_coupling_gradients_in_the_quadratic_fallback_branch(K, hidden, la
 def test_spline_training_beyond_the_program_tiles(stype):
     """Found by tools/fuzz_train.py --wide: 121 columns + 3 latent inputs need five tiles of 32; inference falls back to the
     generic tier, but the training path's no-grad evaluation called the MLP-program tier directly and raised
-    NotImplementedError.  Gradients against fp64 autograd of the oracle."""
+    NotImplementedError.  Gradients against fp64 autograd of the oracle.
+
+    d log|f'(x)| / dx = f'' / f' JUMPS at a spline's knots (the splines are C1), and the knots come out of the conditioner: an element
+    within rounding of a knot takes either side, and one such row moves the parameter gradients by percents (round 5: the nearest-rounding
+    operand split moved row 20 of this batch across one; the reference's own fp32 autograd is off by 50 % of the x-gradient scale on
+    another row: tools/experiments/dbg_cubic121.py).  Such rows are first shown to BE knot rows -- the fp64 oracle's gradient at
+    x -+ 1e-5 brackets the product's -- and then left out of the batch the gradients are compared on."""
     torch.manual_seed(17)
     dim, latent, n = 121, 3, 150
     desc = [{'kind': 'coupling_rqs', 'dim': dim, 'hidden': [40], 'n_bins': 6, 'lower': -3.0, 'upper': 3.0, 'mask': 'ordered_left_half',
@@ -993,19 +999,48 @@ def test_spline_training_beyond_the_program_tiles(stype):
     flow = fd.build_flow(st, desc, dim)
     state = {k: v.clone() for k, v in flow.state_dict().items()}
     flow = flow.to(DEV)
-    x, lat = torch.randn(n, dim) * 1.3, torch.randn(n, latent)
-    leaves = {k: v.detach().double().clone().requires_grad_(True) for k, v in state.items()}
-    xin = x.double().clone().requires_grad_(True)
-    want = -orc.flow_log_prob(fd.flow_spec(desc, leaves), xin, lat.double()).mean()
-    want.backward()
-    xg = x.to(DEV).requires_grad_(True)
-    loss = -flow.log_prob(xg, latent=lat.to(DEV)).mean()
-    loss.backward()
+    x_all, lat_all = torch.randn(n, dim) * 1.3, torch.randn(n, latent)
+
+    def oracle(x, lat, scale=1.0):
+        leaves = {k: v.detach().double().clone().requires_grad_(True) for k, v in state.items()}
+        xin = x.double().clone().requires_grad_(True)
+        want = -orc.flow_log_prob(fd.flow_spec(desc, leaves), xin, lat.double()).sum() * scale
+        want.backward()
+        return want, xin.grad, {k: v.grad for k, v in leaves.items()}
+
+    def product(x, lat):
+        for p in flow.parameters():
+            p.grad = None
+        xg = x.to(DEV).requires_grad_(True)
+        loss = -flow.log_prob(xg, latent=lat.to(DEV)).mean()
+        loss.backward()
+        return loss, xg.grad.cpu().double()
+
+    want, gx, _ = oracle(x_all, lat_all, 1.0 / n)
+    loss, ours = product(x_all, lat_all)
+    sx = gx.abs().max().item()
+    bad = torch.nonzero((ours - gx).abs() > 3e-4 * sx + 1e-8)
+    knot_rows = sorted({int(r) for r, _ in bad.tolist()})
+    assert len(knot_rows) <= 2, bad.tolist()
+    for r in knot_rows:         # the row's worst element sits at the knot; its other elements (the conditioner's inputs) follow from it
+        c = int((ours[r] - gx[r]).abs().argmax())
+        sides = []
+        for d in (1e-5, -1e-5):
+            xr = x_all[r:r + 1].clone()
+            xr[0, c] += d
+            sides.append(oracle(xr, lat_all[r:r + 1], 1.0 / n)[1][0, c].item())
+        lo_, hi_ = min(sides + [gx[r, c].item()]), max(sides + [gx[r, c].item()])
+        assert lo_ - 3e-4 * sx <= ours[r, c].item() <= hi_ + 3e-4 * sx and hi_ - lo_ > 3e-4 * sx, \
+            ('not a knot row', r, c, ours[r, c].item(), gx[r, c].item(), sides)
+    keep = torch.tensor([i for i in range(n) if i not in knot_rows])
+    x, lat = x_all[keep], lat_all[keep]
+    want, gx, gp = oracle(x, lat, 1.0 / len(keep))
+    loss, ours = product(x, lat)
     assert abs(loss.item() - want.item()) <= 1e-5 * abs(want.item()) + 1e-5
-    sx = xin.grad.abs().max().item()
-    assert (xg.grad.cpu().double() - xin.grad).abs().max().item() <= 3e-4 * sx + 1e-8
+    sx = gx.abs().max().item()
+    assert (ours - gx).abs().max().item() <= 3e-4 * sx + 1e-8
     for name, p in flow.named_parameters():
-        ref = leaves[name].grad
+        ref = gp[name]
         assert (p.grad.cpu().double() - ref).abs().max().item() <= 3e-4 * ref.abs().max().item() + 1e-8, name
 
 

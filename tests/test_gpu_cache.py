@@ -252,6 +252,62 @@ def test_error_flags_are_per_stream():
         st.check_errors()
 
 
+def test_training_calls_of_spline_flows_raise_inside_the_failing_call_by_default(monkeypatch):
+    """Mode 'grad' (the default): a graph-building call of a flow that holds a rational-quadratic spline -- the reference op that
+    asserts on its data, rational_quadratic_spline.py:175-178,223 -- synchronises once before it returns and raises what its kernels
+    flagged; the same call under no_grad(), and flows without that op, stay asynchronous.  (The flag is set from the host here, the way
+    a kernel's system-scope atomic would: the forward kernels of a training step have no condition a test can provoke at will.)"""
+    import warnings
+    from stribor_amd import _hip
+    from producthelp import relu_flow
+    assert _hip._sync_mode == 'grad'
+    torch.manual_seed(5)
+    dim, K = 8, 6
+    flow = st.NormalizingFlow(st.UnitNormal(dim), [st.Coupling(st.Spline(dim, K, latent_net=st.net.MLP(dim, [16], dim * (3 * K - 1)),
+                                                                         lower=-3, upper=3, spline_type='quadratic'),
+                                                               mask='ordered_right_half')]).to(DEV)
+    x = torch.randn(200, dim, device=DEV)
+    with torch.no_grad():
+        want = flow.log_prob(x)
+    st.check_errors()
+    calls = []
+    real = _hip.end_of_flow_call
+
+    def flagged_end(t, flag=True):
+        calls.append(1)
+        if flag:
+            _hip._flag_entry(t.device)[1][0] |= _hip.FLAG_RQS_NEG_DISCRIMINANT      # "a kernel of this call found a negative discriminant"
+        return real(t)
+    monkeypatch.setattr(_hip, 'end_of_flow_call', flagged_end)
+    with warnings.catch_warnings(), torch.enable_grad():    # (this file's tests run under no_grad: the training form needs grad mode)
+        warnings.simplefilter('ignore')
+        with pytest.raises(AssertionError, match='discriminant'):
+            flow.log_prob(x)                                # parameters require grad: the training form of the call
+        assert len(calls) == 1                              # log_prob -> inverse_and_log_det_jacobian: the outermost call only
+        st.check_errors()                                   # raised once, nothing left behind
+        monkeypatch.setattr(_hip, 'end_of_flow_call', lambda t: flagged_end(t, False))
+        lp = flow.log_prob(x)                               # a clean training call: one synchronisation, the same values, a graph
+        assert len(calls) == 2 and lp.requires_grad and torch.allclose(lp.detach(), want, rtol=1e-5, atol=1e-5)
+        with pytest.raises(AssertionError, match='discriminant'):
+            with torch.no_grad():
+                flow.log_prob(x)                            # inference: no synchronisation ...
+                assert len(calls) == 2
+                _hip._flag_entry(x.device)[1][0] |= _hip.FLAG_RQS_NEG_DISCRIMINANT
+                flow.log_prob(x[:5])                        # ... a flag is reported by the next call on the stream
+        old = _hip.set_sync_errors(False)
+        try:
+            assert old == 'grad'
+            flow.log_prob(x)                                # mode '0': no synchronisation under grad either
+            assert len(calls) == 2
+        finally:
+            _hip.set_sync_errors(old)
+        # a flow without the asserting op stays asynchronous under grad (the rule would cost cfg 2 13 .. 24 % of a training step)
+        aff = relu_flow()
+        lp = aff.log_prob(torch.randn(64, 16, device=DEV))
+        assert len(calls) == 2 and torch.isfinite(lp).all()
+    st.check_errors()
+
+
 def test_sync_errors_mode_raises_inside_the_failing_call():
     """set_sync_errors(True) / STRIBOR_SYNC_ERRORS=1: the data-dependent error leaves the call that caused it, like the reference's
     (rational_quadratic_spline.py:175-178,223) -- a script that ends right after the failing call still sees it."""
