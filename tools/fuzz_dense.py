@@ -20,8 +20,9 @@ import stribor_oracle as orc  # noqa: E402
 
 DEV = 'cuda:0'
 # allowance in units of the fp32 oracle's own error against fp64 (per row): 16 on ordinary data; rows of 1e4 .. 1e6 (--big) make the
-# conditioners' pre-activations cancelling sums of huge terms, where the fp16 x 3 products (2 x 11-bit operands, three products) are
-# measured at up to ~50 x fp32's error -- both far above 1e-5 there; 'exact' stays at fp32's level
+# conditioners' pre-activations cancelling sums of huge terms.  Where such a sum lands inside tanh's linear range (|pre| < 3: a few rows
+# per hundred cases) the fp16 x 3 weights' ABSOLUTE resolution (3e-8: the low half of a weight below 0.125 is an fp16 subnormal) times a
+# state entry of 1e5 shows: 20 .. 170 x fp32's error on that row (tools/experiments/dbg_big_layers.py); 'exact' stays at fp32's
 KREF = 64.0 if ('--big' in sys.argv and '--exact' not in sys.argv) else 16.0
 BIG = '--big' in sys.argv
 BF16 = '--bf16' in sys.argv
