@@ -20,8 +20,12 @@ affine coupling kernel (north_star: "achieved HBM GB/s on the element-wise path"
 same measurement for BASELINE cfg 3 (8 rational-quadratic spline couplings) and cfg 4 (AffineLU + MatrixExponential +
 couplings, D = 128) at 2^20 rows, timed in this process after the headline; `cpu_baseline` is the oracle (a torch-CPU
 port that follows the reference op for op, incl. its double conditioner call) timed on this box's host cores on a
-bounded sample.  Fields ending in `_pmc` / `traffic` come from committed rocprofv3 --pmc passes (profiles/*.json) and
-carry the commit they were captured at.
+bounded sample: a pool of floor(usable cores / best thread count) worker PROCESSES, pinned to disjoint cores, each over its own
+row block, released together (`cores` = processes x threads; `host_cores_available` = the affinity mask capped by the cgroup
+CPU quota -- the GPU box shows 256 CPUs and grants 16).  The pool is started before this process touches the GPU and sits
+idle during the timed region.  Fields ending in `_pmc` / `traffic` come from committed rocprofv3 --pmc passes
+(profiles/*.json) and are quoted only when their build id equals the library's.  The LAST keys of the line are the first-level
+scalars `value_* / ms_per_step_* / roofline_frac_*` of cfg2_exact, cfg3 and cfg4 (they must survive a 2,000-character tail).
 """
 import argparse
 import json

@@ -341,14 +341,15 @@ def _errors_leave_the_call(fn):
     training step; the same rule on flows without that op would cost cfg 2 +13 .. 24 % and cfg 4 +11 .. 14 % of a step for an
     exception the reference does not raise there, so they -- and every inference call -- stay asynchronous."""
     @functools.wraps(fn)
-    def wrapped(self, x, *args, **kwargs):
+    def wrapped(self, *args, **kwargs):
+        x = args[0] if args else kwargs.get('x', kwargs.get('y'))          # the data argument, however the caller spelled it
         if (_hip._sync_mode != 'grad' or not torch.is_tensor(x) or not x.is_cuda or not self._wants_grad(x)
                 or not self._holds_asserting_op()):
-            return fn(self, x, *args, **kwargs)
+            return fn(self, *args, **kwargs)
         depth = getattr(_call_depth, 'n', 0)
         _call_depth.n = depth + 1
         try:
-            out = fn(self, x, *args, **kwargs)
+            out = fn(self, *args, **kwargs)
         finally:
             _call_depth.n = depth
         if depth == 0:

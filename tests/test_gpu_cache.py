@@ -288,23 +288,25 @@ def test_training_calls_of_spline_flows_raise_inside_the_failing_call_by_default
         monkeypatch.setattr(_hip, 'end_of_flow_call', lambda t: flagged_end(t, False))
         lp = flow.log_prob(x)                               # a clean training call: one synchronisation, the same values, a graph
         assert len(calls) == 2 and lp.requires_grad and torch.allclose(lp.detach(), want, rtol=1e-5, atol=1e-5)
+        flow.inverse_and_log_det_jacobian(y=x)              # the data argument by keyword falls under the same rule
+        assert len(calls) == 3
         with pytest.raises(AssertionError, match='discriminant'):
             with torch.no_grad():
                 flow.log_prob(x)                            # inference: no synchronisation ...
-                assert len(calls) == 2
+                assert len(calls) == 3
                 _hip._flag_entry(x.device)[1][0] |= _hip.FLAG_RQS_NEG_DISCRIMINANT
                 flow.log_prob(x[:5])                        # ... a flag is reported by the next call on the stream
         old = _hip.set_sync_errors(False)
         try:
             assert old == 'grad'
             flow.log_prob(x)                                # mode '0': no synchronisation under grad either
-            assert len(calls) == 2
+            assert len(calls) == 3
         finally:
             _hip.set_sync_errors(old)
         # a flow without the asserting op stays asynchronous under grad (the rule would cost cfg 2 13 .. 24 % of a training step)
         aff = relu_flow()
         lp = aff.log_prob(torch.randn(64, 16, device=DEV))
-        assert len(calls) == 2 and torch.isfinite(lp).all()
+        assert len(calls) == 3 and torch.isfinite(lp).all()
     st.check_errors()
 
 
