@@ -396,3 +396,54 @@ def test_host_code_under_address_and_ub_sanitizers():
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     assert 'runtime error' not in r.stderr and 'AddressSanitizer' not in r.stderr, r.stderr[-3000:]
     assert ' 0 failures' in r.stdout, r.stdout[-1500:]
+
+
+def test_error_reporting_modes_and_the_asserting_op_rule():
+    """STRIBOR_SYNC_ERRORS / set_sync_errors: 'grad' (default), '1' (every launch), '0' (never); only flows that hold the reference's
+    asserting op (the rational-quadratic spline, rational_quadratic_spline.py:175-178,223) synchronise at the end of a training call."""
+    from stribor_amd import _hip
+    assert _hip._parse_sync_mode('grad') == 'grad' and _hip._parse_sync_mode(' Train ') == 'grad'
+    assert _hip._parse_sync_mode('0') == '0' and _hip._parse_sync_mode('') == '0' and _hip._parse_sync_mode(False) == '0'
+    assert _hip._parse_sync_mode('1') == '1' and _hip._parse_sync_mode(True) == '1' and _hip._parse_sync_mode('yes') == '1'
+    old = _hip.set_sync_errors(True)
+    try:
+        assert _hip._sync_errors and _hip._sync_mode == '1'
+        assert _hip.set_sync_errors('grad') == '1' and not _hip._sync_errors and _hip._sync_mode == 'grad'
+        assert _hip.set_sync_errors(False) == 'grad' and _hip._sync_mode == '0'
+    finally:
+        _hip.set_sync_errors(old)
+    dim = 6
+    rq = st.NormalizingFlow(st.UnitNormal(dim), [st.Coupling(st.Spline(dim, 4, latent_net=st.net.MLP(dim, [8], dim * 11), lower=-3, upper=3,
+                                                                       spline_type='quadratic'), mask='ordered_right_half'), st.Flip()])
+    cub = st.NormalizingFlow(st.UnitNormal(dim), [st.Coupling(st.Spline(dim, 4, latent_net=st.net.MLP(dim, [8], dim * 10), lower=-3, upper=3,
+                                                                        spline_type='cubic'), mask='ordered_right_half')])
+    aff = st.NormalizingFlow(st.UnitNormal(dim), [st.Coupling(st.Affine(dim, latent_net=st.net.MLP(dim, [8], 2 * dim)), mask='ordered_left_half')])
+    assert rq._holds_asserting_op() and not cub._holds_asserting_op() and not aff._holds_asserting_op()
+    aff.transforms.append(rq.transforms[0])                     # a structure edit re-evaluates the cached answer
+    assert aff._holds_asserting_op()
+
+
+def test_kernel_mode_families_cover_every_mode_once():
+    """csrc/sx_flow_types.h: SX_MODE_FAMILY splits the kernel MODEs over three objects per (tiles, hidden tiles, arithmetic); the
+    dispatcher (sx_flow_fused.hip) and every launcher (sx_flow_kernel.h: SX_FM) go through the same macro, and the Makefile builds the
+    three families."""
+    import re
+    csrc = os.path.join(ROOT, 'stribor_amd', 'csrc')
+    types = open(os.path.join(csrc, 'sx_flow_types.h')).read()
+    m = re.search(r'#define SX_MODE_FAMILY\(MODE\) (.*)', types)
+    assert m, 'SX_MODE_FAMILY'
+    fam = {}
+    for M in range(0, 21):
+        spline = M in (3, 12, 13, 14, 16, 17, 18, 19)
+        fam[M] = 2 if M in (4, 11) else 1 if spline else 0
+    kernel = open(os.path.join(csrc, 'sx_flow_kernel.h')).read()
+    launched = sorted({int(v) for v in re.findall(r'SX_FM\((\d+)\)', kernel)})
+    assert launched == [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20], launched
+    # the macro's three clauses, literally
+    assert '(MODE) == 4 || (MODE) == 11 ? 2' in m.group(1)
+    assert '(MODE) == 3 || (MODE) == 12 || (MODE) == 13 || (MODE) == 14 || ((MODE) >= 16 && (MODE) <= 19)) ? 1 : 0' in m.group(1)
+    assert [fam[M] for M in launched].count(2) == 2 and [fam[M] for M in launched].count(1) == 8
+    mk = open(os.path.join(csrc, 'Makefile')).read()
+    assert 'FAMS    := 0 1 2' in mk and '-DSX_FAMILY=$(1)' in mk
+    fused = open(os.path.join(csrc, 'sx_flow_fused.hip')).read()
+    assert 'SX_MODE_FAMILY(mlp_mode)' in fused and '_f2(a)' in fused
