@@ -209,6 +209,25 @@ int sx_rqs_slab_l1_bwd(const float *slab_scratch, const float *h, int64_t ld_h, 
                        const int32_t *col_map, int32_t n_live, int64_t n_rows, int32_t dim, const float *scale, float *scratch,
                        uint32_t *err_flag, void *stream);
 
+/* One rational-quadratic spline COUPLING evaluated from the conditioner's LAST HIDDEN ACTIVATION, the parameter tensor never in HBM
+ * (Coupling(Spline(spline_type='quadratic')).forward / inverse with their log-dets, stribor/flows/coupling.py:69-95 +
+ * flows/spline.py:76-143 + util/rational_quadratic_spline.py:11-251, for conditioners whose last Linear is
+ * params = h W2^T + b2 with up to 256 hidden units -- net/mlp.py:48-58 takes any width): the forward counterpart of sx_rqs_slab_bwd,
+ * same slabs, same slots, same w_fwd pack (k_tiles = ceil(hidden/32) <= 8).
+ *   x [n_rows, dim] fp32, h [n_rows, ld_h] fp32 (`hidden` <= 256 valid features), n_bins <= 16;
+ *   y [n_rows, dim]: ONLY the transformed columns (live_idx / live_start, n_live as sx_rqs_coupling) are written -- the caller
+ *   fills the pass-through columns (y = x there);
+ *   reverse = 0: forward (bin searched on the widths, x in [left, right]), 1: inverse (heights, [bottom, top]);
+ *   ldj (nullable) [n_rows] = (ldj_accumulate ? ldj : 0) + ldj_scale * sum over the transformed columns of log|d y / d x|
+ *   (reverse: of the inverse map, as rational_quadratic_spline.py:232-234 returns it), summed in slab order;
+ *   scratch: sx_rqs_slab_fwd_scratch_floats(n_rows, n_live) floats (needed when ldj is not NULL), caller-owned;
+ *   err_flag (nullable) receives SX_FLAG_F16_RANGE when |h| leaves fp16's range (those rows' outputs are NaN). */
+size_t sx_rqs_slab_fwd_scratch_floats(int64_t n_rows, int32_t n_live);
+int sx_rqs_slab_fwd(const float *x, const float *h, int64_t ld_h, int32_t hidden, const float *w_fwd, float *y, float *ldj,
+                    const int32_t *live_idx, int32_t live_start, int32_t n_live, int32_t n_bins, float left, float right,
+                    float bottom, float top, int64_t n_rows, int32_t dim, int32_t reverse, float ldj_scale, int32_t ldj_accumulate,
+                    float *scratch, uint32_t *err_flag, void *stream);
+
 /* Monotone cubic spline, element-wise part -- spline_type='cubic', the reference's default
  * (stribor/util/cubic_spline.py:21-251, util/search_sorted.py:3-5, flows/spline.py:59-61,82-86).
  *   params[n, i*(2K+2) + 0:K]      unnormalised widths  of live dim i

@@ -683,6 +683,238 @@ __global__ __launch_bounds__(256, 2) void rqs_slab_l1_bwd_kernel(const l1_args k
     for (int e = threadIdx.x; e < E1; e += 256) dst[e] = red[e] * sc_out;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// FORWARD slab pass (inference and the training forward): (y, row log-det) of a rational-quadratic spline COUPLING from the
+// conditioner's last hidden activation h [N, H], H <= 256 -- the tier that answers where the one-launch flow program does not reach
+// (hidden layers beyond 128 units: stribor/net/mlp.py:48-58 and flows/spline.py:76-87 take any width).  The layer-by-layer tier
+// materialised the [N, n_live (3K-1)] parameter tensor (1.6 GB per layer and 2^18 rows on a cfg-3-shaped coupling: written by one MLP
+// program, read and re-written by the program of the next hidden chunk, read by the spline kernel: 1.7 ms per layer); here, tiled like
+// the slab backward above, it never exists:
+//   * a workgroup (8 waves, two per SIMD) owns a SLAB -- the 3K-1 parameter rows of TWO transformed columns, three 32-row MFMA tiles
+//     (widths | heights | derivatives) x HT hidden tiles, 12 KB x HT of LDS for the whole launch -- and walks a range of the rows;
+//   * a wave takes 32 rows at a time and streams h through the k loop one 32-unit tile at a time (load -> fp16 x 3 split -> 18 MFMAs
+//     into the three accumulator tiles; the next tile's loads are issued before the current tile's MFMAs), so the hidden width is a
+//     RUN-TIME loop count: one kernel for every width;
+//   * in C-fragment order lane (sample, half) then holds exactly the 3K-1 parameters of its element (sample, column 2 slab + half)
+//     and evaluates the spline on registers with static indices (the forward part of rqs_inverse_bwd_regs' arithmetic: hardware
+//     exp / rcp / log, selects for the bin; rational_quadratic_spline.py:101-107,180-248, search_sorted.py:4-5);
+//   * the row's log-det is a sum over the slabs: each slab writes one partial per row, a second kernel adds them in slab order
+//     (deterministic; n_slabs x 4 B per row).
+// HBM per row and layer: h (128 B x HT, L2-resident across the slabs of an XCD), x and y of the transformed columns, 4 B per slab.
+struct slabf_args {
+    const float *x, *h;                 // x [N, dim]; h [N, ld_h] (H valid features)
+    const float *wf;                    // sx_pack_linear(W2 rows by slot): [3 n_slabs][HT][1024] + bias [3 n_slabs][32]
+    float *y;                           // [N, dim]: the transformed columns are written
+    float *ldj_part;                    // [n_slabs][N] or null
+    const int32_t *live_idx;
+    uint32_t *flags;
+    int64_t n_rows, ld_h;
+    int l0, n_live, K, dim, H, HT, n_slabs, n_chunks, n_ranges, xcd_map;
+    float left, right, bottom, top;
+};
+
+// One element on registers: Sp = the SEARCHED side's K bin parameters (REV: heights, else widths), Op = the other side's, Dp the
+// K - 1 knot derivatives; [slo, shi] / [olo, ohi] the two sides' intervals.  -> out, log|d out / d in| (REV: of the inverse).
+template <int KC, bool REV>
+__device__ __forceinline__ void rqs_slab_eval(rqsb_f16v &Sp, rqsb_f16v &Op, const rqsb_f16v &Dp, int K, float xv, float slo, float shi,
+                                              float olo, float ohi, float &out, float &ljd) {
+    constexpr float LOG2E = 1.44269504088896341f, LN2 = 0.69314718055994531f;
+    const int Kn = KC ? KC : K;
+    const float bconst = 0.5397424172369522f;                       // log(exp(1 - 1e-3) - 1), :81 boundary derivative constant
+    const float norm = 1.f - RQS_MIN_BIN * (float)Kn;
+    const float span_s = shi - slo, span_o = ohi - olo;
+    const bool inside = (xv >= slo) && (xv <= shi);                 // :71 closed interval
+    const float xin = inside ? xv : slo;
+    float ms = Sp[0], mo = Op[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k)
+        if (KC ? (k < KC) : true) {
+            const bool used = KC ? true : (k < K);
+            ms = used ? fmaxf(ms, Sp[k]) : ms;
+            mo = used ? fmaxf(mo, Op[k]) : mo;
+        }
+    float ss = 0.f, so = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (KC ? (k < KC) : true) {
+            const bool used = KC ? true : (k < K);
+            const float es = used ? __builtin_amdgcn_exp2f((Sp[k] - ms) * LOG2E) : 0.f;
+            const float eo = used ? __builtin_amdgcn_exp2f((Op[k] - mo) * LOG2E) : 0.f;
+            Sp[k] = es;
+            Op[k] = eo;
+            ss += es;
+            so += eo;
+        }
+    const float ns = norm * __builtin_amdgcn_rcpf(ss), no = norm * __builtin_amdgcn_rcpf(so);    // bin size_k = MIN + e_k n (:101-105)
+    // one sweep over the knots: the searched side's are compared with the input (search_sorted.py:4-5: the last knot carries + eps),
+    // both sides' cumulative sums at the bin (last knot <= input) and behind it (first knot > input) are kept
+    int b = 0;
+    float cs = 0.f, co = 0.f, co_b = 0.f, co_n = 0.f, ks_b = slo, ks_n = shi;
+    bool have_next = false;
+#pragma unroll
+    for (int j = 1; j <= 16; ++j)
+        if (KC ? (j <= KC) : true) {
+            const bool used = KC ? true : (j <= K);
+            const bool last = (j == Kn);
+            cs += fmaf(Sp[j - 1], ns, RQS_MIN_BIN);
+            co += fmaf(Op[j - 1], no, RQS_MIN_BIN);
+            const float ks = last ? shi : fmaf(span_s, cs, slo);    // ends pinned (:186-192)
+            const bool ge = xin >= (last ? ks + RQS_EPS : ks);
+            const bool take = used && ge && !last;
+            const bool nxt = used && !ge && !have_next;
+            b = take ? j : b;
+            co_b = take ? co : co_b;
+            ks_b = take ? ks : ks_b;
+            co_n = nxt ? co : co_n;
+            ks_n = nxt ? ks : ks_n;
+            have_next = have_next || nxt;
+        }
+    const bool first = (b == 0), lastbin = (b + 1 == Kn);
+    const float ko_b = first ? olo : fmaf(span_o, co_b, olo);
+    const float ko_n = lastbin ? ohi : fmaf(span_o, co_n, olo);
+    float u_b = bconst, u_n = bconst;
+#pragma unroll
+    for (int k = 0; k < 15; ++k)
+        if (KC ? (k < KC - 1) : true) {
+            const bool used = KC ? true : (k < Kn - 1);
+            u_n = (used && b == k) ? Dp[k] : u_n;
+            u_b = (used && b == k + 1) ? Dp[k] : u_b;
+        }
+    const float d_b = RQS_MIN_DERIV + rqsb_softplus_p<true>(u_b), d_n = RQS_MIN_DERIV + rqsb_softplus_p<true>(u_n);     // :107
+    const float cw_b = REV ? ko_b : ks_b, w_b = REV ? ko_n - ko_b : ks_n - ks_b;
+    const float ch_b = REV ? ks_b : ko_b, h_b = REV ? ks_n - ks_b : ko_n - ko_b;
+    const float s_b = h_b * __builtin_amdgcn_rcpf(w_b);
+    float o, l;
+    if constexpr (REV) {                                            // :212-234
+        const float dy = xin - ch_b;
+        const float q = d_b + d_n - 2.f * s_b;
+        const float a = dy * q + h_b * (s_b - d_b);
+        const float bb = h_b * d_b - dy * q;
+        const float c = -s_b * dy;
+        const float disc = bb * bb - 4.f * a * c;
+        // (the clamps of the one-launch tier, sx_flow_spline.h rqs_eval_core: rounding can leave the discriminant a few ulps below
+        //  zero and the root an ulp outside its bin where the reference's own fp32 evaluation stays inside)
+        const float root = __builtin_amdgcn_fmed3f((2.f * c) * __builtin_amdgcn_rcpf(-bb - __builtin_amdgcn_sqrtf(__builtin_fmaxf(disc, 0.f))), 0.f, 1.f);
+        o = root * w_b + cw_b;
+        const float tomt = root * (1.f - root), omr = 1.f - root;
+        const float den = s_b + q * tomt;
+        const float dnum = (s_b * s_b) * (d_n * (root * root) + 2.f * s_b * tomt + d_b * (omr * omr));
+        l = (2.f * __builtin_amdgcn_logf(den) - __builtin_amdgcn_logf(dnum)) * LN2;
+    } else {                                                        // :236-248
+        const float theta = (xin - cw_b) * __builtin_amdgcn_rcpf(w_b);
+        const float tomt = theta * (1.f - theta), omt = 1.f - theta;
+        const float num = h_b * (s_b * (theta * theta) + d_b * tomt);
+        const float den = s_b + (d_b + d_n - 2.f * s_b) * tomt;
+        o = ch_b + num * __builtin_amdgcn_rcpf(den);
+        const float dnum = (s_b * s_b) * (d_n * (theta * theta) + 2.f * s_b * tomt + d_b * (omt * omt));
+        l = (__builtin_amdgcn_logf(dnum) - 2.f * __builtin_amdgcn_logf(den)) * LN2;
+    }
+    out = inside ? o : xv;                                          // :86-87 linear tails
+    ljd = inside ? l : 0.f;
+}
+
+template <int KC, bool HFULL, bool REV>
+__global__ __launch_bounds__(512, 1) void rqs_slab_fwd_kernel(const slabf_args k) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int HT = k.HT;
+    int slab, range;
+    {
+        const int L = blockIdx.x, G = k.n_slabs;
+        if (k.xcd_map) { const int i = L >> 3; slab = i % G; range = (i / G) * 8 + (L & 7); }
+        else { slab = L % G; range = L / G; }
+    }
+    const int BI = 3 * HT * 1024;                                    // bias [96] behind the slab's tiles
+    {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(k.wf + (size_t)slab * 3 * HT * 1024);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
+        for (int i = threadIdx.x; i < 3 * HT * 256; i += 512) dst[i] = src[i];
+        if (threadIdx.x < 96) smem[BI + threadIdx.x] = k.wf[(size_t)k.n_slabs * 3 * HT * 1024 + slab * 96 + threadIdx.x];
+    }
+    __syncthreads();
+    const wptr w = make_wptr(0, lane);
+    const int j = lane & 31, hh = lane >> 5;
+    const int ci = 2 * slab + hh;                                       // this lane's transformed column (index into live)
+    const bool col_ok = ci < k.n_live;
+    const int col = col_ok ? (k.live_idx ? k.live_idx[ci] : k.l0 + ci) : 0;
+    uint64_t any_bad = 0;
+    const int c_begin = (int)((int64_t)k.n_chunks * range / k.n_ranges), c_end = (int)((int64_t)k.n_chunks * (range + 1) / k.n_ranges);
+    for (int c = c_begin + wave; c < c_end; c += 8) {
+        rng_t rg{0};
+        const int64_t row0 = (int64_t)c * 32;
+        const int n_here = (int)((k.n_rows - row0) < 32 ? (k.n_rows - row0) : 32);
+        const bool valid = j < n_here && col_ok;
+        const int jc = j < n_here ? j : n_here - 1;                     // a row past the end reads the chunk's last real row
+        const float *hb = k.h + row0 * k.ld_h;
+        const uint32_t hoff = (uint32_t)jc * (uint32_t)k.ld_h + 4u * hh, xoff = (uint32_t)jc * (uint32_t)k.dim + (uint32_t)col;
+        const float xl = (k.x + row0 * k.dim)[xoff];
+        auto load_h = [&](int m, f32x4 (&v)[4]) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f0 = 32 * m + 8 * g + 4 * hh;
+                const float *p = hb + (hoff + 32u * m + 8u * g);
+                v[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (HFULL) v[g] = *reinterpret_cast<const f32x4 *>(p);
+                else {
+                    if (f0 + 0 < k.H) v[g].x = p[0];
+                    if (f0 + 1 < k.H) v[g].y = p[1];
+                    if (f0 + 2 < k.H) v[g].z = p[2];
+                    if (f0 + 3 < k.H) v[g].w = p[3];
+                }
+            }
+        };
+        // p = W2_slab h + b2: three independent accumulation chains (widths | heights | derivatives), issued round-robin
+        tile<1> acc[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[t] = load_cfrag<1>(w.cb, BI + t * 32);
+        f32x4 hv[4];
+        load_h(0, hv);
+        for (int m = 0; m < HT; ++m) {
+            tile<1> hid;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { hid.v[0][4 * g + 0] = hv[g].x; hid.v[0][4 * g + 1] = hv[g].y; hid.v[0][4 * g + 2] = hv[g].z; hid.v[0][4 * g + 3] = hv[g].w; }
+            if (m + 1 < HT) load_h(m + 1, hv);                          // in flight across this tile's split and MFMAs
+            const btile<1> bh = make_btile<1>(hid, rg);
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                afrag a[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) a[t] = load_afrag(w.wb, (t * HT + m) * 1024, sx);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc[t].v[0] = mfma(a[t].lo, bh.hi[0][sx], acc[t].v[0]);      // smallest terms first
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc[t].v[0] = mfma(a[t].hi, bh.lo[0][sx], acc[t].v[0]);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc[t].v[0] = mfma(a[t].hi, bh.hi[0][sx], acc[t].v[0]);
+            }
+        }
+        const float xv = valid ? xl : (REV ? k.bottom : k.left);
+        float out, ljd;
+        if constexpr (REV) rqs_slab_eval<KC, true>(acc[1].v[0], acc[0].v[0], acc[2].v[0], k.K, xv, k.bottom, k.top, k.left, k.right, out, ljd);
+        else rqs_slab_eval<KC, false>(acc[0].v[0], acc[1].v[0], acc[2].v[0], k.K, xv, k.left, k.right, k.bottom, k.top, out, ljd);
+        const bool bad = rng_bad_sample(rg, lane);
+        any_bad |= rg.bad;
+        if (valid) (k.y + row0 * k.dim)[xoff] = bad ? __builtin_nanf("") : out;
+        if (k.ldj_part != nullptr) {
+            float lsum = valid ? ljd : 0.f;
+            lsum += __shfl_xor(lsum, 32, 64);
+            if (hh == 0 && j < n_here) k.ldj_part[(size_t)slab * k.n_rows + row0 + j] = bad ? __builtin_nanf("") : lsum;
+        }
+    }
+    if (any_bad != 0 && lane == 0 && k.flags != nullptr)
+        __hip_atomic_fetch_or(k.flags, SX_FLAG_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// row log-det = ldj_scale * (sum of the slabs' partials, in slab order) [+ what ldj already holds]
+__global__ __launch_bounds__(256) void rqs_slab_ldj_reduce_kernel(const float *__restrict__ part, int n_slabs, int64_t n_rows,
+                                                                  float ldj_scale, int accumulate, float *__restrict__ ldj) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_rows) return;
+    float s = 0.f;
+    for (int p = 0; p < n_slabs; ++p) s += part[(size_t)p * n_rows + i];
+    s *= ldj_scale;
+    ldj[i] = accumulate ? ldj[i] + s : s;
+}
+
 // launch shape: slabs per workgroup, slab groups, row ranges (one 8-wave workgroup per CU, or two 4-wave ones)
 struct slab_shape { int spw, n_groups, n_ranges; };
 slab_shape slab_plan(int n_slabs, int n_chunks) {
@@ -793,6 +1025,69 @@ extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *g
         hipLaunchKernelGGL(rqs_slab_dh_reduce_kernel<2>, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, k.dh_part,
                            n_groups, n_chunks, n_rows, (int)hidden, gh, ld_gh, scale, tanh_hidden ? h : nullptr, ld_h);
     SX_LAUNCH_CHECK();
+    return SX_OK;
+}
+
+extern "C" size_t sx_rqs_slab_fwd_scratch_floats(int64_t n_rows, int32_t n_live) {
+    if (n_rows < 0 || n_rows >= ((int64_t)1 << 36) || n_live < 1 || n_live > (1 << 20)) return 0;
+    return (size_t)((n_live + 1) / 2) * (size_t)n_rows;
+}
+
+extern "C" int sx_rqs_slab_fwd(const float *x, const float *h, int64_t ld_h, int32_t hidden, const float *w_fwd, float *y, float *ldj,
+                               const int32_t *live_idx, int32_t live_start, int32_t n_live, int32_t n_bins, float left, float right,
+                               float bottom, float top, int64_t n_rows, int32_t dim, int32_t reverse, float ldj_scale,
+                               int32_t ldj_accumulate, float *scratch, uint32_t *err_flag, void *stream) {
+    SX_REQUIRE(x && h && w_fwd && y, "sx_rqs_slab_fwd: null pointer");
+    SX_REQUIRE(ldj == nullptr || scratch != nullptr, "sx_rqs_slab_fwd: the row log-det needs the scratch buffer");
+    SX_REQUIRE(dim > 0 && n_live > 0 && n_live <= dim && n_rows >= 0, "sx_rqs_slab_fwd: bad sizes");
+    SX_REQUIRE(n_bins >= 1 && n_bins <= 16, "sx_rqs_slab_fwd: n_bins must be in 1..16 (got %d)", n_bins);
+    SX_REQUIRE(hidden >= 1 && hidden <= 256, "sx_rqs_slab_fwd: hidden width must be in 1..256 (got %d)", hidden);
+    SX_REQUIRE(ld_h >= hidden, "sx_rqs_slab_fwd: ld_h < hidden");
+    SX_REQUIRE(n_rows < ((int64_t)1 << 36), "sx_rqs_slab_fwd: too many rows");
+    SX_REQUIRE(right > left && top > bottom, "sx_rqs_slab_fwd: empty domain");
+    SX_REQUIRE(((uintptr_t)w_fwd & 15) == 0, "sx_rqs_slab_fwd: packed weights must be 16-byte aligned");
+    if (n_rows == 0) return SX_OK;
+    hipStream_t st = sx_stream(stream);
+    const int n_slabs = (n_live + 1) / 2, HT = (hidden + 31) / 32;
+    const int n_chunks = (int)((n_rows + 31) / 32);
+    // one 8-wave workgroup per CU at a time; two rounds of them so that the tail of the launch is short
+    int r = (512 + n_slabs - 1) / n_slabs;
+    const int cap = (n_chunks + 7) / 8;              // at least one 32-row chunk per wave where the rows allow
+    if (r > cap) r = cap;
+    if (r >= 8) r &= ~7;                             // multiples of 8: the XCD-aware id mapping
+    const int n_ranges = r < 1 ? 1 : r;
+    slabf_args k;
+    k.x = x; k.h = h; k.wf = w_fwd; k.y = y; k.ldj_part = ldj ? scratch : nullptr; k.live_idx = live_idx; k.flags = err_flag;
+    k.n_rows = n_rows; k.ld_h = ld_h; k.l0 = live_start; k.n_live = n_live; k.K = n_bins; k.dim = dim; k.H = hidden; k.HT = HT;
+    k.n_slabs = n_slabs; k.n_chunks = n_chunks; k.n_ranges = n_ranges; k.xcd_map = (n_ranges % 8 == 0);
+    k.left = left; k.right = right; k.bottom = bottom; k.top = top;
+    const size_t lds = (size_t)(3 * HT * 1024 + 128) * sizeof(float);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const bool hfull = hidden == 32 * HT && ld_h % 4 == 0 && ((uintptr_t)h & 15) == 0;
+#define SX_SLABF(KC_, HF_, REV_, ID_)                                                                              \
+    do {                                                                                                           \
+        auto kern = rqs_slab_fwd_kernel<KC_, HF_, REV_>;                                                           \
+        static int lds_allowed[8][64];                                                                             \
+        if (lds > 48 * 1024 && lds_allowed[ID_][dev & 63] < (int)lds) {                                            \
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) { sx_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
+            lds_allowed[ID_][dev & 63] = (int)lds;                                                                 \
+        }                                                                                                          \
+        hipLaunchKernelGGL(kern, dim3(n_slabs * n_ranges), dim3(512), lds, st, k);                                 \
+    } while (0)
+    if (reverse) {
+        if (n_bins == 16 && hfull) SX_SLABF(16, true, true, 0); else if (hfull) SX_SLABF(0, true, true, 1); else SX_SLABF(0, false, true, 2);
+    } else {
+        if (n_bins == 16 && hfull) SX_SLABF(16, true, false, 3); else if (hfull) SX_SLABF(0, true, false, 4); else SX_SLABF(0, false, false, 5);
+    }
+#undef SX_SLABF
+    SX_LAUNCH_CHECK();
+    if (ldj != nullptr) {
+        hipLaunchKernelGGL(rqs_slab_ldj_reduce_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, scratch, n_slabs,
+                           n_rows, ldj_scale, (int)(ldj_accumulate != 0), ldj);
+        SX_LAUNCH_CHECK();
+    }
     return SX_OK;
 }
 

