@@ -214,19 +214,29 @@ int sx_rqs_slab_l1_bwd(const float *slab_scratch, const float *h, int64_t ld_h, 
  * flows/spline.py:76-143 + util/rational_quadratic_spline.py:11-251, for conditioners whose last Linear is
  * params = h W2^T + b2 with up to 256 hidden units -- net/mlp.py:48-58 takes any width): the forward counterpart of sx_rqs_slab_bwd,
  * same slabs, same slots, same w_fwd pack (k_tiles = ceil(hidden/32) <= 8).
- *   x [n_rows, dim] fp32, h [n_rows, ld_h] fp32 (`hidden` <= 256 valid features), n_bins <= 16;
+ *   x [n_rows, dim] fp32, n_bins <= 16;
+ *   h, h_fragments = 0: [n_rows, ld_h] fp32, `hidden` <= 256 valid features (any conditioner: whatever produced its last hidden
+ *   activation); h_fragments = 1: the fragments sx_rqs_slab_hidden wrote (ld_h ignored) -- every slab re-reads h, and in this form
+ *   it is neither split into fp16 parts nor range-checked again;
  *   y [n_rows, dim]: ONLY the transformed columns (live_idx / live_start, n_live as sx_rqs_coupling) are written -- the caller
  *   fills the pass-through columns (y = x there);
  *   reverse = 0: forward (bin searched on the widths, x in [left, right]), 1: inverse (heights, [bottom, top]);
  *   ldj (nullable) [n_rows] = (ldj_accumulate ? ldj : 0) + ldj_scale * sum over the transformed columns of log|d y / d x|
  *   (reverse: of the inverse map, as rational_quadratic_spline.py:232-234 returns it), summed in slab order;
  *   scratch: sx_rqs_slab_fwd_scratch_floats(n_rows, n_live) floats (needed when ldj is not NULL), caller-owned;
- *   err_flag (nullable) receives SX_FLAG_F16_RANGE when |h| leaves fp16's range (those rows' outputs are NaN). */
+ *   err_flag (nullable) receives SX_FLAG_F16_RANGE when |h| leaves fp16's range (those rows' outputs are NaN).
+ * sx_rqs_slab_hidden: the hidden layer of a single-hidden-layer conditioner (net/mlp.py:48-58; coupling.py:61-65: it sees
+ * cat[x * mask, latent]),  h = act(W1 z + b1), as fp16 hi / lo MFMA fragments: h_frag [sx_rqs_slab_hidden_floats(n_rows, hidden)].
+ *   w1: sx_pack_linear(W1, b1, row_idx = hidden slots, col_idx = input slots (slot q = column q of x, then of latent; -1 = masked),
+ *   m_tiles = ceil(hidden/32), k_tiles = ceil((dim + latent_dim)/32), SX_GEMM_F16X3);  dim + latent_dim <= 128;  act: SX_ACT_*. */
+size_t sx_rqs_slab_hidden_floats(int64_t n_rows, int32_t hidden);
+int sx_rqs_slab_hidden(const float *x, const float *latent, const float *w1, float *h_frag, int64_t n_rows, int32_t dim,
+                       int32_t latent_dim, int32_t hidden, int32_t act, uint32_t *err_flag, void *stream);
 size_t sx_rqs_slab_fwd_scratch_floats(int64_t n_rows, int32_t n_live);
 int sx_rqs_slab_fwd(const float *x, const float *h, int64_t ld_h, int32_t hidden, const float *w_fwd, float *y, float *ldj,
                     const int32_t *live_idx, int32_t live_start, int32_t n_live, int32_t n_bins, float left, float right,
                     float bottom, float top, int64_t n_rows, int32_t dim, int32_t reverse, float ldj_scale, int32_t ldj_accumulate,
-                    float *scratch, uint32_t *err_flag, void *stream);
+                    int32_t h_fragments, float *scratch, uint32_t *err_flag, void *stream);
 
 /* Monotone cubic spline, element-wise part -- spline_type='cubic', the reference's default
  * (stribor/util/cubic_spline.py:21-251, util/search_sorted.py:3-5, flows/spline.py:59-61,82-86).

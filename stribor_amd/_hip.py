@@ -56,7 +56,7 @@ EXPORTS = ['sx_abi_version', 'sx_fragment_mode', 'sx_last_error', 'sx_build_id',
            'sx_flow_launch_info', 'sx_wgrad', 'sx_wgrad_layer', 'sx_colsum', 'sx_tri_inverse_f64',
            'sx_wgrad_scratch_floats', 'sx_wgrad_layer_scratch_floats', 'sx_flow_bwd_max_steps', 'sx_flow_bwd_partials',
            'sx_flow_bwd_run', 'sx_wgrad_reduce', 'sx_rqs_slab_slots', 'sx_rqs_slab_scratch_floats', 'sx_rqs_slab_bwd', 'sx_rqs_slab_l1_scratch_floats', 'sx_rqs_slab_l1_bwd',
-           'sx_rqs_slab_fwd_scratch_floats', 'sx_rqs_slab_fwd']
+           'sx_rqs_slab_fwd_scratch_floats', 'sx_rqs_slab_fwd', 'sx_rqs_slab_hidden_floats', 'sx_rqs_slab_hidden']
 
 
 class HipLibraryMissing(RuntimeError):
@@ -113,7 +113,11 @@ def _declare(lib: C.CDLL) -> None:
     lib.sx_rqs_slab_fwd_scratch_floats.restype = C.c_size_t
     lib.sx_rqs_slab_fwd_scratch_floats.argtypes = [i64, i32]
     lib.sx_rqs_slab_fwd.restype = i32
-    lib.sx_rqs_slab_fwd.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, i64, i32, i32, f32, i32, vp, vp, vp]
+    lib.sx_rqs_slab_fwd.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, i64, i32, i32, f32, i32, i32, vp, vp, vp]
+    lib.sx_rqs_slab_hidden_floats.restype = C.c_size_t
+    lib.sx_rqs_slab_hidden_floats.argtypes = [i64, i32]
+    lib.sx_rqs_slab_hidden.restype = i32
+    lib.sx_rqs_slab_hidden.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp]
     lib.sx_rqs_forward_bwd.restype = i32
     lib.sx_rqs_forward_bwd.argtypes = lib.sx_rqs_inverse_bwd.argtypes
     lib.sx_affine_coupling_bwd.restype = i32

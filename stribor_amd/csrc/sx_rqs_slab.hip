@@ -813,7 +813,10 @@ __device__ __forceinline__ void rqs_slab_eval(rqsb_f16v &Sp, rqsb_f16v &Op, cons
     ljd = inside ? l : 0.f;
 }
 
-template <int KC, bool HFULL, bool REV>
+// HFRAG: h arrives as fp16 hi / lo B fragments ([chunk][hidden tile][2 k16-step + (hi, lo)][64 lanes] x 16 B, written by
+// rqs_slab_hidden_kernel): four 1 KB loads per tile, no split here -- every slab re-reads h, so the split's 36 vector instructions
+// per tile were paid n_slabs times (a third of this kernel's vector work at 160 hidden units).
+template <int KC, bool HFULL, bool REV, bool HFRAG>
 __global__ __launch_bounds__(512, 1) void rqs_slab_fwd_kernel(const slabf_args k) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int HT = k.HT;
@@ -866,6 +869,34 @@ __global__ __launch_bounds__(512, 1) void rqs_slab_fwd_kernel(const slabf_args k
         tile<1> acc[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) acc[t] = load_cfrag<1>(w.cb, BI + t * 32);
+        if constexpr (HFRAG) {
+            const u32x4 *hf = reinterpret_cast<const u32x4 *>(k.h) + ((size_t)c * HT) * 256 + lane;
+            u32x4 fr[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) fr[p] = hf[p * 64];
+            for (int m = 0; m < HT; ++m) {
+                u32x4 cu[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) cu[p] = fr[p];
+                if (m + 1 < HT) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) fr[p] = hf[(m + 1) * 256 + p * 64];     // in flight across this tile's MFMAs
+                }
+#pragma unroll
+                for (int sx = 0; sx < 2; ++sx) {
+                    const h8 bhi = __builtin_bit_cast(h8, cu[2 * sx]), blo = __builtin_bit_cast(h8, cu[2 * sx + 1]);
+                    afrag a[3];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) a[t] = load_afrag(w.wb, (t * HT + m) * 1024, sx);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) acc[t].v[0] = mfma(a[t].lo, bhi, acc[t].v[0]);      // smallest terms first
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) acc[t].v[0] = mfma(a[t].hi, blo, acc[t].v[0]);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) acc[t].v[0] = mfma(a[t].hi, bhi, acc[t].v[0]);
+                }
+            }
+        } else {
         f32x4 hv[4];
         load_h(0, hv);
         for (int m = 0; m < HT; ++m) {
@@ -887,11 +918,14 @@ __global__ __launch_bounds__(512, 1) void rqs_slab_fwd_kernel(const slabf_args k
                 for (int t = 0; t < 3; ++t) acc[t].v[0] = mfma(a[t].hi, bh.hi[0][sx], acc[t].v[0]);
             }
         }
+        }
         const float xv = valid ? xl : (REV ? k.bottom : k.left);
+        const bool nan_h = acc[0].v[0][0] != acc[0].v[0][0];
         float out, ljd;
         if constexpr (REV) rqs_slab_eval<KC, true>(acc[1].v[0], acc[0].v[0], acc[2].v[0], k.K, xv, k.bottom, k.top, k.left, k.right, out, ljd);
         else rqs_slab_eval<KC, false>(acc[0].v[0], acc[1].v[0], acc[2].v[0], k.K, xv, k.left, k.right, k.bottom, k.top, out, ljd);
-        const bool bad = rng_bad_sample(rg, lane);
+        // (HFRAG: a row whose h left fp16's range carries NaN fragments -- flagged by the kernel that wrote them)
+        const bool bad = HFRAG ? nan_h : rng_bad_sample(rg, lane);
         any_bad |= rg.bad;
         if (valid) (k.y + row0 * k.dim)[xoff] = bad ? __builtin_nanf("") : out;
         if (k.ldj_part != nullptr) {
@@ -899,6 +933,83 @@ __global__ __launch_bounds__(512, 1) void rqs_slab_fwd_kernel(const slabf_args k
             lsum += __shfl_xor(lsum, 32, 64);
             if (hh == 0 && j < n_here) k.ldj_part[(size_t)slab * k.n_rows + row0 + j] = bad ? __builtin_nanf("") : lsum;
         }
+    }
+    if (any_bad != 0 && lane == 0 && k.flags != nullptr)
+        __hip_atomic_fetch_or(k.flags, SX_FLAG_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// The conditioner's hidden layer for the forward slab pass, single-hidden-layer conditioners (net/mlp.py:48-58 with one hidden
+// layer; coupling.py:61-65: the layer sees cat[x * mask, latent]):  h = act(W1 z + b1), written ONCE as the fp16 hi / lo B fragments
+// the slab kernel's MFMAs consume (4 B per value, like fp32; 1 KB per store).  The mask is folded into the pack (a masked column has
+// no slot).  Input slot q: column q of x (q < dim), then column q - dim of latent.  A row whose input or hidden activation leaves
+// fp16's range gets NaN fragments and raises SX_FLAG_F16_RANGE.
+struct slabh_args {
+    const float *x, *latent;            // [N, dim], [N, latent_dim] | null
+    const float *w1;                    // sx_pack_linear(W1, b1, hidden slots, input slots, m_tiles = HT, k_tiles = CT)
+    float *hfrag;                       // [n_chunks][HT][1024]
+    uint32_t *flags;
+    int64_t n_rows;
+    int dim, latent_dim, HT, act, n_chunks;
+};
+template <int CT>
+__global__ __launch_bounds__(256) void rqs_slab_hidden_kernel(const slabh_args k) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int HT = k.HT;
+    {
+        const int n4 = (HT * CT * 1024 + HT * 32) / 4;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(k.w1);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
+        for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const wptr w = make_wptr(0, lane);
+    const int j = lane & 31, hh = lane >> 5;
+    const int bias = HT * CT * 1024;
+    const bool xvec = (k.dim % 4 == 0) && ((reinterpret_cast<uintptr_t>(k.x) & 15) == 0);
+    uint64_t any_bad = 0;
+    for (int c = blockIdx.x * 4 + wave; c < k.n_chunks; c += gridDim.x * 4) {
+        rng_t rg{0};
+        const int64_t row0 = (int64_t)c * 32;
+        const int n_here = (int)((k.n_rows - row0) < 32 ? (k.n_rows - row0) : 32);
+        const int64_t row = row0 + (j < n_here ? j : n_here - 1);
+        btile<1> bx[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            tile<1> z;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int q0 = 32 * ct + 8 * g + 4 * hh;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (xvec && q0 + 3 < k.dim) v = *reinterpret_cast<const f32x4 *>(k.x + row * k.dim + q0);
+                else {
+                    float e[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int q = q0 + i;
+                        e[i] = q < k.dim ? k.x[row * k.dim + q] : (q < k.dim + k.latent_dim ? k.latent[row * k.latent_dim + (q - k.dim)] : 0.f);
+                    }
+                    v = f32x4{e[0], e[1], e[2], e[3]};
+                }
+                z.v[0][4 * g + 0] = v.x; z.v[0][4 * g + 1] = v.y; z.v[0][4 * g + 2] = v.z; z.v[0][4 * g + 3] = v.w;
+            }
+            bx[ct] = make_btile<1>(z, rg);
+        }
+        u32x4 *dst = reinterpret_cast<u32x4 *>(k.hfrag) + ((size_t)c * HT) * 256 + lane;
+        for (int m = 0; m < HT; ++m) {
+            tile<1> acc = load_cfrag<1>(w.cb, bias + m * 32);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) gemm_tile<1>(w.wb, (m * CT + ct) * 1024, bx[ct], acc);
+            activate<1>(acc, k.act);
+            const btile<1> bh = make_btile<1>(acc, rg);
+            const bool bad = rng_bad_sample(rg, lane);
+            const u32x4 nanv = {0x7e007e00u, 0x7e007e00u, 0x7e007e00u, 0x7e007e00u};
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                dst[m * 256 + (2 * sx) * 64] = bad ? nanv : __builtin_bit_cast(u32x4, bh.hi[0][sx]);
+                dst[m * 256 + (2 * sx + 1) * 64] = bad ? nanv : __builtin_bit_cast(u32x4, bh.lo[0][sx]);
+            }
+        }
+        any_bad |= rg.bad;
     }
     if (any_bad != 0 && lane == 0 && k.flags != nullptr)
         __hip_atomic_fetch_or(k.flags, SX_FLAG_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1036,13 +1147,14 @@ extern "C" size_t sx_rqs_slab_fwd_scratch_floats(int64_t n_rows, int32_t n_live)
 extern "C" int sx_rqs_slab_fwd(const float *x, const float *h, int64_t ld_h, int32_t hidden, const float *w_fwd, float *y, float *ldj,
                                const int32_t *live_idx, int32_t live_start, int32_t n_live, int32_t n_bins, float left, float right,
                                float bottom, float top, int64_t n_rows, int32_t dim, int32_t reverse, float ldj_scale,
-                               int32_t ldj_accumulate, float *scratch, uint32_t *err_flag, void *stream) {
+                               int32_t ldj_accumulate, int32_t h_fragments, float *scratch, uint32_t *err_flag, void *stream) {
     SX_REQUIRE(x && h && w_fwd && y, "sx_rqs_slab_fwd: null pointer");
+    SX_REQUIRE(!h_fragments || ((uintptr_t)h & 15) == 0, "sx_rqs_slab_fwd: h fragments must be 16-byte aligned");
     SX_REQUIRE(ldj == nullptr || scratch != nullptr, "sx_rqs_slab_fwd: the row log-det needs the scratch buffer");
     SX_REQUIRE(dim > 0 && n_live > 0 && n_live <= dim && n_rows >= 0, "sx_rqs_slab_fwd: bad sizes");
     SX_REQUIRE(n_bins >= 1 && n_bins <= 16, "sx_rqs_slab_fwd: n_bins must be in 1..16 (got %d)", n_bins);
     SX_REQUIRE(hidden >= 1 && hidden <= 256, "sx_rqs_slab_fwd: hidden width must be in 1..256 (got %d)", hidden);
-    SX_REQUIRE(ld_h >= hidden, "sx_rqs_slab_fwd: ld_h < hidden");
+    SX_REQUIRE(h_fragments || ld_h >= hidden, "sx_rqs_slab_fwd: ld_h < hidden");
     SX_REQUIRE(n_rows < ((int64_t)1 << 36), "sx_rqs_slab_fwd: too many rows");
     SX_REQUIRE(right > left && top > bottom, "sx_rqs_slab_fwd: empty domain");
     SX_REQUIRE(((uintptr_t)w_fwd & 15) == 0, "sx_rqs_slab_fwd: packed weights must be 16-byte aligned");
@@ -1065,10 +1177,11 @@ extern "C" int sx_rqs_slab_fwd(const float *x, const float *h, int64_t ld_h, int
     int dev = 0;
     (void)hipGetDevice(&dev);
     const bool hfull = hidden == 32 * HT && ld_h % 4 == 0 && ((uintptr_t)h & 15) == 0;
-#define SX_SLABF(KC_, HF_, REV_, ID_)                                                                              \
+#define SX_SLABF(KC_, HF_, REV_, ID_) do { if (h_fragments) SX_SLABF2(KC_, true, REV_, true, ID_ + 6); else SX_SLABF2(KC_, HF_, REV_, false, ID_); } while (0)
+#define SX_SLABF2(KC_, HF_, REV_, FR_, ID_)                                                                        \
     do {                                                                                                           \
-        auto kern = rqs_slab_fwd_kernel<KC_, HF_, REV_>;                                                           \
-        static int lds_allowed[8][64];                                                                             \
+        auto kern = rqs_slab_fwd_kernel<KC_, HF_, REV_, FR_>;                                                      \
+        static int lds_allowed[12][64];                                                                            \
         if (lds > 48 * 1024 && lds_allowed[ID_][dev & 63] < (int)lds) {                                            \
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) { sx_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
@@ -1082,12 +1195,56 @@ extern "C" int sx_rqs_slab_fwd(const float *x, const float *h, int64_t ld_h, int
         if (n_bins == 16 && hfull) SX_SLABF(16, true, false, 3); else if (hfull) SX_SLABF(0, true, false, 4); else SX_SLABF(0, false, false, 5);
     }
 #undef SX_SLABF
+#undef SX_SLABF2
     SX_LAUNCH_CHECK();
     if (ldj != nullptr) {
         hipLaunchKernelGGL(rqs_slab_ldj_reduce_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, scratch, n_slabs,
                            n_rows, ldj_scale, (int)(ldj_accumulate != 0), ldj);
         SX_LAUNCH_CHECK();
     }
+    return SX_OK;
+}
+
+extern "C" size_t sx_rqs_slab_hidden_floats(int64_t n_rows, int32_t hidden) {
+    if (n_rows < 0 || n_rows >= ((int64_t)1 << 36) || hidden < 1 || hidden > 256) return 0;
+    return (size_t)((n_rows + 31) / 32) * (size_t)((hidden + 31) / 32) * 1024;
+}
+
+extern "C" int sx_rqs_slab_hidden(const float *x, const float *latent, const float *w1, float *h_frag, int64_t n_rows, int32_t dim,
+                                  int32_t latent_dim, int32_t hidden, int32_t act, uint32_t *err_flag, void *stream) {
+    SX_REQUIRE(x && w1 && h_frag, "sx_rqs_slab_hidden: null pointer");
+    SX_REQUIRE(dim > 0 && latent_dim >= 0 && dim + latent_dim <= 128 && n_rows >= 0, "sx_rqs_slab_hidden: bad sizes (inputs of up to 128 columns)");
+    SX_REQUIRE(latent_dim == 0 || latent != nullptr, "sx_rqs_slab_hidden: null latent");
+    SX_REQUIRE(hidden >= 1 && hidden <= 256, "sx_rqs_slab_hidden: hidden width must be in 1..256 (got %d)", hidden);
+    SX_REQUIRE(act >= 0 && act <= SX_ACT_GELU, "sx_rqs_slab_hidden: unknown activation %d", act);
+    SX_REQUIRE(n_rows < ((int64_t)1 << 36), "sx_rqs_slab_hidden: too many rows");
+    SX_REQUIRE(((uintptr_t)w1 & 15) == 0 && ((uintptr_t)h_frag & 15) == 0, "sx_rqs_slab_hidden: packed weights and h must be 16-byte aligned");
+    if (n_rows == 0) return SX_OK;
+    hipStream_t st = sx_stream(stream);
+    const int HT = (hidden + 31) / 32, CT = (dim + latent_dim + 31) / 32;
+    const int n_chunks = (int)((n_rows + 31) / 32);
+    slabh_args k;
+    k.x = x; k.latent = latent; k.w1 = w1; k.hfrag = h_frag; k.flags = err_flag; k.n_rows = n_rows; k.dim = dim; k.latent_dim = latent_dim;
+    k.HT = HT; k.act = act; k.n_chunks = n_chunks;
+    const size_t lds = (size_t)(HT * CT * 1024 + HT * 32) * sizeof(float);
+    int grid = (n_chunks + 3) / 4;
+    if (grid > 1024) grid = 1024;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+#define SX_SLABH(CT_)                                                                                              \
+    do {                                                                                                           \
+        auto kern = rqs_slab_hidden_kernel<CT_>;                                                                   \
+        static int lds_allowed[64];                                                                                \
+        if (lds > 48 * 1024 && lds_allowed[dev & 63] < (int)lds) {                                                 \
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) { sx_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
+            lds_allowed[dev & 63] = (int)lds;                                                                      \
+        }                                                                                                          \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, k);                                               \
+    } while (0)
+    switch (CT) { case 1: SX_SLABH(1); break; case 2: SX_SLABH(2); break; case 3: SX_SLABH(3); break; default: SX_SLABH(4); break; }
+#undef SX_SLABH
+    SX_LAUNCH_CHECK();
     return SX_OK;
 }
 

@@ -353,11 +353,12 @@ class Coupling(Transform):
     # ---- spline, slab tier: hidden activation (MFMA program) + sx_rqs_slab_fwd; the parameter tensor never exists ---------------
     def _spline_slab_plan(self, dim: int, latent_dim: int, device):
         """Rational-quadratic couplings whose conditioner the one-launch program cannot hold (hidden layers of 129 .. 256 units;
-        spline.py:76-87 and net/mlp.py:48-58 take any width): everything before the last Linear runs as MLP programs that leave the
-        last hidden activation h [N, H] in HBM (640 B per row at H = 160 -- against 6 KB per row of spline parameters), and
-        sx_rqs_slab_fwd evaluates  params = h W2^T + b2  and the spline slab by slab on the matrix pipe.
-        -> (hidden programs [(program, first column of h)], slot -> row of the last Linear, hidden slots, live_idx, live_start,
-            n_live, H, pack cache)."""
+        spline.py:76-87 and net/mlp.py:48-58 take any width): everything before the last Linear leaves the last hidden activation h
+        in HBM (640 B per row at H = 160 -- against 6 KB per row of spline parameters; one hidden layer: sx_rqs_slab_hidden writes
+        it as MFMA fragments, deeper conditioners: MLP programs, row-major), and sx_rqs_slab_fwd evaluates  params = h W2^T + b2
+        and the spline slab by slab on the matrix pipe.
+        -> (MLP programs [(program, first column of h)], input slots of the hidden kernel | None, slot -> row of the last Linear,
+            hidden slots, live_idx, live_start, n_live, H, pack cache)."""
         key = ('spline-slab', dim, latent_dim, str(device))
 
         def build():
@@ -368,7 +369,8 @@ class Coupling(Transform):
             widths = [w.shape[0] for (w, _) in lin[:-1]]
             if sp.spline_type == 'cubic' or sp.n_bins > 16 or H > 256:
                 raise NotImplementedError('slab tier: rational-quadratic splines of up to 16 bins behind up to 256 hidden units')
-            if _ceil32(dim) + _ceil32(latent_dim) > 4 or (max(widths) > 128 and len(lin) != 2):
+            one_hidden = len(lin) == 2 and lin[0][1] is not None
+            if dim + latent_dim > 128 if one_hidden else (_ceil32(dim) + _ceil32(latent_dim) > 4 or max(widths) > 128):
                 raise NotImplementedError('slab tier: conditioner inputs of up to 128 columns; deep conditioners of up to 128 units')
             m = self.mask_vector(dim)
             live = np.nonzero(m <= 0.5)[0]
@@ -381,23 +383,25 @@ class Coupling(Transform):
             glob = np.where(rel >= 0, rows_np[np.clip(rel, 0, len(rows_np) - 1)], -1).astype(np.int32)
             hid = np.full(_ceil32(H) * 32, -1, dtype=np.int32)
             hid[:H] = np.arange(H)
-            # h = everything before the last Linear: the same MLP programs as the conditioner's, with the identity as last layer
-            eye = torch.eye(H, dtype=torch.float32, device=device)
-            hlin = list(lin[:-1]) + [(eye, None)]
-            progs = []
-            if max(widths) <= 128:
+            progs, in_slots = [], None
+            if one_hidden:
+                # one hidden layer: sx_rqs_slab_hidden writes h as the fp16 fragments the slab kernel consumes.  Input slot q = column
+                # q of cat[x, latent]; the masked columns have no slot (coupling.py:61: x * mask)
+                q = np.full(_ceil32(dim + latent_dim) * 32, -1, dtype=np.int32)
+                q[:dim] = np.where(cond, np.arange(dim), -1)
+                q[dim:dim + latent_dim] = dim + np.arange(latent_dim)
+                in_slots = torch.from_numpy(q).to(device)
+            else:
+                # deeper conditioners: everything before the last Linear as the conditioner's own MLP programs with the identity as
+                # last layer -> h [N, H] fp32, row-major
+                eye = torch.eye(H, dtype=torch.float32, device=device)
+                hlin = list(lin[:-1]) + [(eye, None)]
                 b = ProgramBuilder(dim, latent_dim, max(widths))
                 b.add_mlp(hlin, net.act_code, cond, np.arange(H))
                 progs = [(p, 0) for p in _chunk_mlp_program(b, device)]
-            else:
-                for h0 in range(0, H, 128):
-                    hsel = np.arange(h0, min(h0 + 128, H))
-                    b = ProgramBuilder(dim, latent_dim, len(hsel))
-                    b.add_mlp(hlin, net.act_code, cond, hsel, hidden_rows=hsel)
-                    progs += [(p, h0) for p in _chunk_mlp_program(b, device)]
             contiguous = np.array_equal(live, np.arange(live[0], live[0] + len(live)))
             live_idx = None if contiguous else torch.from_numpy(live.astype(np.int32)).to(device)
-            return (progs, torch.from_numpy(glob).to(device), torch.from_numpy(hid).to(device), live_idx, int(live[0]), len(live), H, {})
+            return (progs, in_slots, torch.from_numpy(glob).to(device), torch.from_numpy(hid).to(device), live_idx, int(live[0]), len(live), H, {})
         return self._programs.get(key, build)
 
     def _run_spline_slab(self, x2, lat2, reverse, want_ldj, ldj_scale):
@@ -408,34 +412,53 @@ class Coupling(Transform):
             raise ValueError('Minimal bin width too large for the number of bins')      # rational_quadratic_spline.py:96-97
         n, d = x2.shape
         dev = x2.device
-        progs, slot_rows, hid_idx, live_idx, live_start, n_live, H, cache = self._spline_slab_plan(
-            d, 0 if lat2 is None else lat2.shape[1], dev)
-        W2, b2 = self._net().linears()[-1]
+        ld = 0 if lat2 is None else lat2.shape[1]
+        progs, in_slots, slot_rows, hid_idx, live_idx, live_start, n_live, H, cache = self._spline_slab_plan(d, ld, dev)
+        net = self._net()
+        lin = net.linears()
+        W2, b2 = lin[-1]
         if b2 is None:
             raise NotImplementedError('slab tier: the last Linear carries a bias')
         x2 = x2.contiguous()
+        lat2 = None if lat2 is None else lat2.to(torch.float32).contiguous()
         lib = _hip.lib()
         flag = _hip.err_flag(dev)
-        # the slabs' fragment pack of the last Linear, re-made when the parameters change
-        stamp = (W2.data_ptr(), W2._version, b2.data_ptr(), b2._version)
-        packs = cache.get('packs')
-        if packs is None or cache.get('stamp') != stamp:
+        # the fragment packs of the conditioner's Linear layers, re-made when the parameters change
+        ps = [W2, b2] + ([lin[0][0], lin[0][1]] if in_slots is not None else [])
+        stamp = tuple((p.data_ptr(), p._version) for p in ps)
+        if cache.get('stamp') != stamp:
             mt, ht = lib.sx_rqs_slab_slots(n_live) // 32, _ceil32(H)
             packs = torch.empty(_hip.packed_linear_floats(mt, ht), dtype=torch.float32, device=dev)
             Wc, bc = W2.detach().contiguous(), b2.detach().contiguous()
             _hip.call('sx_pack_linear', x2, Wc.data_ptr(), bc.data_ptr(), Wc.shape[0], H, slot_rows.data_ptr(), hid_idx.data_ptr(),
                       mt, ht, None, None, 0.0, 0, _hip.GEMM_F16X3, flag, packs.data_ptr())
-            cache['packs'], cache['stamp'] = packs, stamp
-        h = torch.empty(n, H, dtype=torch.float32, device=dev)
-        for p, h0 in progs:
-            p.run(x2, lat2, mlp_out=h[:, h0:])
+            cache['packs'] = packs
+            if in_slots is not None:
+                ct = _ceil32(d + ld)
+                w1 = torch.empty(_hip.packed_linear_floats(ht, ct), dtype=torch.float32, device=dev)
+                W1c, b1c = lin[0][0].detach().contiguous(), lin[0][1].detach().contiguous()
+                _hip.call('sx_pack_linear', x2, W1c.data_ptr(), b1c.data_ptr(), H, d + ld, hid_idx.data_ptr(), in_slots.data_ptr(),
+                          ht, ct, None, None, 0.0, 0, _hip.GEMM_F16X3, flag, w1.data_ptr())
+                cache['w1'] = w1
+            cache['stamp'] = stamp
+        packs = cache['packs']
+        if in_slots is not None:
+            h = torch.empty(lib.sx_rqs_slab_hidden_floats(n, H), dtype=torch.float32, device=dev)
+            _hip.call('sx_rqs_slab_hidden', x2, x2.data_ptr(), _hip.ptr(lat2), cache['w1'].data_ptr(), h.data_ptr(), n, d, ld, H,
+                      net.act_code, flag)
+            ld_h, frag = 0, 1
+        else:
+            h = torch.empty(n, H, dtype=torch.float32, device=dev)
+            for p, h0 in progs:
+                p.run(x2, lat2, mlp_out=h[:, h0:])
+            ld_h, frag = h.stride(0), 0
         y = x2.clone()                                   # pass-through columns; the kernel writes the transformed ones
         ldj = torch.empty(n, dtype=torch.float32, device=dev) if want_ldj else None
         with _hip.device_of(x2):
             sc = _hip.scratch(dev, lib.sx_rqs_slab_fwd_scratch_floats(n, n_live)) if want_ldj else None
-        _hip.call('sx_rqs_slab_fwd', x2, x2.data_ptr(), h.data_ptr(), h.stride(0), H, packs.data_ptr(), y.data_ptr(), _hip.ptr(ldj),
+        _hip.call('sx_rqs_slab_fwd', x2, x2.data_ptr(), h.data_ptr(), ld_h, H, packs.data_ptr(), y.data_ptr(), _hip.ptr(ldj),
                   _hip.ptr(live_idx), live_start, n_live, sp.n_bins, float(sp.lower), float(sp.upper), float(sp.lower),
-                  float(sp.upper), n, d, int(bool(reverse)), float(ldj_scale), 0, _hip.ptr(sc), flag)
+                  float(sp.upper), n, d, int(bool(reverse)), float(ldj_scale), 0, frag, _hip.ptr(sc), flag)
         return y, ldj
 
     # ---- training (autograd): spline couplings, inverse direction --------------------------------------------------

@@ -1586,3 +1586,27 @@ def test_spline_couplings_with_hidden_layers_beyond_128_take_the_slab_forward(di
             close(got, ref.cpu(), rtol=1e-5, atol=2e-4 * max(1, dim // 32))
     from stribor_amd.flows.spline import check_errors
     check_errors()
+
+
+@pytest.mark.parametrize('hidden,act', [([40, 72], 'Tanh'), ([128, 96], 'ReLU'), ([50], 'ELU'), ([200], 'Softplus')])
+def test_slab_forward_tier_behind_deep_conditioners_and_other_activations(hidden, act):
+    """The slab forward pass takes the last hidden activation of ANY net.MLP conditioner (deeper ones: their MLP programs leave it
+    row-major in HBM; one hidden layer: sx_rqs_slab_hidden, any activation): called directly -- also on couplings the one-launch
+    tier would answer -- against the oracle, both directions, with a latent input and scattered transformed columns."""
+    torch.manual_seed(len(hidden) * 7 + hidden[-1])
+    dim, K, L, mask = 40, 9, 5, 'parity_odd'
+    net = st.net.MLP(dim + L, hidden, dim * (3 * K - 1), activation=act)
+    cpl = st.Coupling(st.Spline(dim, K, latent_net=net, lower=-2.0, upper=2.0, spline_type='quadratic'), mask=mask)
+    lin = net.linears()
+    spec = [{'kind': 'coupling_rqs', 'mask': mask, 'n_bins': K, 'lower': -2.0, 'upper': 2.0,
+             'net': {'weights': [w.detach().clone() for (w, _) in lin], 'biases': [b.detach().clone() for (_, b) in lin],
+                     'activation': act}}]
+    cpl = cpl.to(DEV)
+    x, lat = torch.randn(777, dim) * 1.4, torch.randn(777, L)
+    xd, latd = x.to(DEV), lat.to(DEV)
+    for reverse in (True, False):
+        y, ldj = cpl._run_spline_slab(xd, latd, reverse, True, 1.0)
+        wy, wl = orc.flow_inverse_and_ldj(spec, x, lat) if reverse else orc.flow_forward_and_ldj(spec, x, lat)
+        close(y, wy, rtol=1e-5, atol=2e-5)
+        close(ldj.reshape(-1, 1), wl, rtol=1e-5, atol=2e-4)
+    st.check_errors()
