@@ -25,6 +25,7 @@
 // HBM per row and layer: x, dL/dout (2 columns x 4 B each per slab), h 256 B (L2-resident across the slabs), and
 // 2 x n_slabs x 256 B of dh partials -- 8 KB at 16 slabs against 30 KB for the five crossings of the parameter tensor.
 #define SX_F16X3
+#include <type_traits>
 #include "sx_flow_kernel.h"
 #include "sx_rqs_bwd.h"
 
@@ -715,9 +716,30 @@ struct slabf_args {
 
 // One element on registers: Sp = the SEARCHED side's K bin parameters (REV: heights, else widths), Op = the other side's, Dp the
 // K - 1 knot derivatives; [slo, shi] / [olo, ohi] the two sides' intervals.  -> out, log|d out / d in| (REV: of the inverse).
-template <int KC, bool REV>
+// `hk.at<H>(ties...)`, H = 0..49, is called every ~8 vector instructions (three times in the max loop, once per exp and per knot, five
+// times in the derivative pick, ten times in the rational-quadratic itself): the pipelined kernel issues ONE MFMA of the NEXT chunk's
+// parameter GEMM -- 32 cycles of the matrix pipe = 8 vector issue slots -- from each, and the MFMAs the evaluation cannot cover
+// behind it.  (An MFMA that finds the matrix pipe busy holds the SIMD's vector issue port until the pipe frees -- for the other wave of
+// the SIMD as well --, so MFMAs issued back to back with vector work behind them overlap with a third of it at best: SLABF_NE.)
+#define SLABF_NE 50
+// (`tie`: a value the evaluation has just produced.  It passes through an empty volatile asm in front of the unit's MFMAs and the
+//  accumulators through one behind them: volatile asms keep their order, so neither the optimizer nor the scheduler can gather the
+//  MFMAs into one clump and the vector work into another -- which is what both do with independent instruction streams.)
+struct slabf_nohook {
+    template <int H, class... T> __device__ __forceinline__ void at(T &...) {}
+};
+template <int N, class Hook>
+struct slabf_hook_seq {           // hk.at<B>(), hk.at<B + 1>() ... from an unrolled loop (the index must be a constant expression)
+    template <int B, class... T> static __device__ __forceinline__ void call(Hook &hk, int k, T &...tie) {
+        if constexpr (N > 0) {
+            if (k == 0) hk.template at<B>(tie...);
+            else slabf_hook_seq<N - 1, Hook>::template call<B + 1>(hk, k - 1, tie...);
+        }
+    }
+};
+template <int KC, bool REV, class Hook>
 __device__ __forceinline__ void rqs_slab_eval(rqsb_f16v &Sp, rqsb_f16v &Op, const rqsb_f16v &Dp, int K, float xv, float slo, float shi,
-                                              float olo, float ohi, float &out, float &ljd) {
+                                              float olo, float ohi, float &out, float &ljd, Hook &hk) {
     constexpr float LOG2E = 1.44269504088896341f, LN2 = 0.69314718055994531f;
     const int Kn = KC ? KC : K;
     const float bconst = 0.5397424172369522f;                       // log(exp(1 - 1e-3) - 1), :81 boundary derivative constant
@@ -732,6 +754,7 @@ __device__ __forceinline__ void rqs_slab_eval(rqsb_f16v &Sp, rqsb_f16v &Op, cons
             const bool used = KC ? true : (k < K);
             ms = used ? fmaxf(ms, Sp[k]) : ms;
             mo = used ? fmaxf(mo, Op[k]) : mo;
+            if (k % 5 == 0) slabf_hook_seq<3, Hook>::template call<0>(hk, k / 5 - 1, ms, mo);
         }
     float ss = 0.f, so = 0.f;
 #pragma unroll
@@ -744,6 +767,7 @@ __device__ __forceinline__ void rqs_slab_eval(rqsb_f16v &Sp, rqsb_f16v &Op, cons
             Op[k] = eo;
             ss += es;
             so += eo;
+            slabf_hook_seq<16, Hook>::template call<3>(hk, k, ss, so);
         }
     const float ns = norm * __builtin_amdgcn_rcpf(ss), no = norm * __builtin_amdgcn_rcpf(so);    // bin size_k = MIN + e_k n (:101-105)
     // one sweep over the knots: the searched side's are compared with the input (search_sorted.py:4-5: the last knot carries + eps),
@@ -768,6 +792,7 @@ __device__ __forceinline__ void rqs_slab_eval(rqsb_f16v &Sp, rqsb_f16v &Op, cons
             co_n = nxt ? co : co_n;
             ks_n = nxt ? ks : ks_n;
             have_next = have_next || nxt;
+            slabf_hook_seq<16, Hook>::template call<19>(hk, j - 1, cs, co, co_b, ks_b, co_n, ks_n, b);
         }
     const bool first = (b == 0), lastbin = (b + 1 == Kn);
     const float ko_b = first ? olo : fmaf(span_o, co_b, olo);
@@ -779,11 +804,16 @@ __device__ __forceinline__ void rqs_slab_eval(rqsb_f16v &Sp, rqsb_f16v &Op, cons
             const bool used = KC ? true : (k < Kn - 1);
             u_n = (used && b == k) ? Dp[k] : u_n;
             u_b = (used && b == k + 1) ? Dp[k] : u_b;
+            if (k % 3 == 2) slabf_hook_seq<5, Hook>::template call<35>(hk, k / 3, u_n, u_b);
         }
-    const float d_b = RQS_MIN_DERIV + rqsb_softplus_p<true>(u_b), d_n = RQS_MIN_DERIV + rqsb_softplus_p<true>(u_n);     // :107
+    float d_b = RQS_MIN_DERIV + rqsb_softplus_p<true>(u_b);                                                              // :107
+    hk.template at<40>(d_b);
+    float d_n = RQS_MIN_DERIV + rqsb_softplus_p<true>(u_n);
+    hk.template at<41>(d_n);
     const float cw_b = REV ? ko_b : ks_b, w_b = REV ? ko_n - ko_b : ks_n - ks_b;
     const float ch_b = REV ? ks_b : ko_b, h_b = REV ? ks_n - ks_b : ko_n - ko_b;
-    const float s_b = h_b * __builtin_amdgcn_rcpf(w_b);
+    float s_b = h_b * __builtin_amdgcn_rcpf(w_b);
+    hk.template at<42>(s_b);
     float o, l;
     if constexpr (REV) {                                            // :212-234
         const float dy = xin - ch_b;
@@ -791,32 +821,125 @@ __device__ __forceinline__ void rqs_slab_eval(rqsb_f16v &Sp, rqsb_f16v &Op, cons
         const float a = dy * q + h_b * (s_b - d_b);
         const float bb = h_b * d_b - dy * q;
         const float c = -s_b * dy;
-        const float disc = bb * bb - 4.f * a * c;
+        float disc = bb * bb - 4.f * a * c;
+        hk.template at<43>(disc);
         // (the clamps of the one-launch tier, sx_flow_spline.h rqs_eval_core: rounding can leave the discriminant a few ulps below
         //  zero and the root an ulp outside its bin where the reference's own fp32 evaluation stays inside)
-        const float root = __builtin_amdgcn_fmed3f((2.f * c) * __builtin_amdgcn_rcpf(-bb - __builtin_amdgcn_sqrtf(__builtin_fmaxf(disc, 0.f))), 0.f, 1.f);
+        float root = __builtin_amdgcn_fmed3f((2.f * c) * __builtin_amdgcn_rcpf(-bb - __builtin_amdgcn_sqrtf(__builtin_fmaxf(disc, 0.f))), 0.f, 1.f);
+        hk.template at<44>(root);
         o = root * w_b + cw_b;
         const float tomt = root * (1.f - root), omr = 1.f - root;
-        const float den = s_b + q * tomt;
-        const float dnum = (s_b * s_b) * (d_n * (root * root) + 2.f * s_b * tomt + d_b * (omr * omr));
-        l = (2.f * __builtin_amdgcn_logf(den) - __builtin_amdgcn_logf(dnum)) * LN2;
+        float den = s_b + q * tomt;
+        hk.template at<45>(den);
+        float dnum = (s_b * s_b) * (d_n * (root * root) + 2.f * s_b * tomt + d_b * (omr * omr));
+        hk.template at<46>(dnum);
+        float l1 = __builtin_amdgcn_logf(den);
+        hk.template at<47>(l1);
+        float l2 = __builtin_amdgcn_logf(dnum);
+        hk.template at<48>(l2);
+        l = (2.f * l1 - l2) * LN2;
     } else {                                                        // :236-248
-        const float theta = (xin - cw_b) * __builtin_amdgcn_rcpf(w_b);
+        float theta = (xin - cw_b) * __builtin_amdgcn_rcpf(w_b);
+        hk.template at<43>(theta);
         const float tomt = theta * (1.f - theta), omt = 1.f - theta;
-        const float num = h_b * (s_b * (theta * theta) + d_b * tomt);
-        const float den = s_b + (d_b + d_n - 2.f * s_b) * tomt;
+        float num = h_b * (s_b * (theta * theta) + d_b * tomt);
+        hk.template at<44>(num);
+        float den = s_b + (d_b + d_n - 2.f * s_b) * tomt;
+        hk.template at<45>(den);
         o = ch_b + num * __builtin_amdgcn_rcpf(den);
-        const float dnum = (s_b * s_b) * (d_n * (theta * theta) + 2.f * s_b * tomt + d_b * (omt * omt));
-        l = (__builtin_amdgcn_logf(dnum) - 2.f * __builtin_amdgcn_logf(den)) * LN2;
+        float dnum = (s_b * s_b) * (d_n * (theta * theta) + 2.f * s_b * tomt + d_b * (omt * omt));
+        hk.template at<46>(dnum);
+        float l1 = __builtin_amdgcn_logf(dnum);
+        hk.template at<47>(l1);
+        float l2 = __builtin_amdgcn_logf(den);
+        hk.template at<48>(l2);
+        l = (l1 - 2.f * l2) * LN2;
     }
+    hk.template at<49>(l);
     out = inside ? o : xv;                                          // :86-87 linear tails
     ljd = inside ? l : 0.f;
 }
 
+// The NEXT chunk's parameter GEMM, issued one MFMA per hook of the current chunk's evaluation -- a wave's vector work only overlaps
+// the matrix pipe between its OWN MFMAs (profiles/r05_coexec_probe.txt: two waves of a SIMD in different phases do not).  MFMA H:
+// hidden tile H / 18, k16-step (H % 18) / 9, fp16 product term (H % 9) / 3, accumulator tile H % 3: every operand register and LDS
+// offset is static; `H < total` (18 HT, or 0 without a next chunk) is the one run-time test.  Fragments of even / odd tiles and the
+// A fragments of the two k16-steps alternate between two register sets, requested nine to eighteen MFMAs ahead of their first use.
+struct slabf_pipe {
+    const u32x4 *hf;            // the next chunk's fragments (+ lane)
+    const char *wb;             // A operands (LDS, + lane * 16)
+    int HT;
+    u32x4 f0[4], f1[4];
+    afrag a0[3], a1[3];
+    f32x16 acc[3];
+    // (loads never sit behind a branch: a tile index past the end is clamped to the last tile -- a redundant load of valid memory --, so
+    //  the compiler's wait counts stay exact; a load behind `if (m + 1 < HT)` made every later s_waitcnt a full one)
+    __device__ __forceinline__ void begin(const u32x4 *frags, const char *wbase, const char *cbase, int ht, int bias_off) {
+        hf = frags; wb = wbase; HT = ht;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[t] = load_cfrag1(cbase, bias_off + t * 32);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) f0[p] = hf[p * 64];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) a0[t] = load_afrag(wb, (t * HT) * 1024, 0);
+    }
+    // MFMA H of the chunk (no guard: the caller knows that hidden tile H / 18 exists)
+    template <int H> __device__ __forceinline__ void mfma_at() {
+        constexpr int m = H / 18, v = H % 18, sx = v / 9, ph = (v % 9) / 3, t = v % 3;
+        if constexpr (v == 0) {
+            const int mn = m + 1 < HT ? m + 1 : HT - 1;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if constexpr ((m + 1) & 1) f1[p] = hf[mn * 256 + p * 64]; else f0[p] = hf[mn * 256 + p * 64];
+            }
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt) a1[tt] = load_afrag(wb, (tt * HT + m) * 1024, 1);
+        }
+        if constexpr (v == 9) {
+            const int mn = m + 1 < HT ? m + 1 : HT - 1;
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt) a0[tt] = load_afrag(wb, (tt * HT + mn) * 1024, 0);
+        }
+        const h8 bhi = __builtin_bit_cast(h8, (m & 1) ? f1[2 * sx] : f0[2 * sx]);
+        const h8 blo = __builtin_bit_cast(h8, (m & 1) ? f1[2 * sx + 1] : f0[2 * sx + 1]);
+        const afrag &a = sx ? a1[t] : a0[t];
+        if constexpr (ph == 0) acc[t] = mfma(a.lo, bhi, acc[t]);          // smallest terms first
+        else if constexpr (ph == 1) acc[t] = mfma(a.hi, blo, acc[t]);
+        else acc[t] = mfma(a.hi, bhi, acc[t]);
+        asm volatile("" : "+v"(acc[t]));
+    }
+    // hook of the evaluation: MFMAs 0 .. SLABF_NE - 1 (hidden tiles 0 .. 2: the pipelined stage runs for HT >= 3)
+    template <int H, class... T> __device__ __forceinline__ void at(T &...tie) {
+        (tie_one(tie), ...);
+        mfma_at<H>();
+    }
+    template <class T> static __device__ __forceinline__ void tie_one(T &v) { asm volatile("" : "+v"(v)); }
+    template <int H, int END> __device__ __forceinline__ void run() {          // MFMAs H .. END - 1, back to back
+        if constexpr (H < END) {
+            mfma_at<H>();
+            run<H + 1, END>();
+        }
+    }
+    // what the evaluation's hooks did not reach: the rest of tile 2, then ONE test per further hidden tile
+    template <int M = 3> __device__ __forceinline__ void drain_tiles() {
+        if constexpr (M < 8) {
+            if (M < HT) {
+                run<18 * M, 18 * M + 18>();
+                drain_tiles<M + 1>();
+            }
+        }
+    }
+    __device__ __forceinline__ void drain() {
+        run<SLABF_NE, 54>();
+        drain_tiles<3>();
+    }
+};
+
 // HFRAG: h arrives as fp16 hi / lo B fragments ([chunk][hidden tile][2 k16-step + (hi, lo)][64 lanes] x 16 B, written by
 // rqs_slab_hidden_kernel): four 1 KB loads per tile, no split here -- every slab re-reads h, so the split's 36 vector instructions
 // per tile were paid n_slabs times (a third of this kernel's vector work at 160 hidden units).
-template <int KC, bool HFULL, bool REV, bool HFRAG>
+// PIPE (HFRAG only, HT >= 3: the evaluation's hooks reach into hidden tile 2): the software-pipelined chunk loop.
+template <int KC, bool HFULL, bool REV, bool HFRAG, bool PIPE>
 __global__ __launch_bounds__(512, 1) void rqs_slab_fwd_kernel(const slabf_args k) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int HT = k.HT;
@@ -841,6 +964,55 @@ __global__ __launch_bounds__(512, 1) void rqs_slab_fwd_kernel(const slabf_args k
     const int col = col_ok ? (k.live_idx ? k.live_idx[ci] : k.l0 + ci) : 0;
     uint64_t any_bad = 0;
     const int c_begin = (int)((int64_t)k.n_chunks * range / k.n_ranges), c_end = (int)((int64_t)k.n_chunks * (range + 1) / k.n_ranges);
+    if constexpr (PIPE) {
+        // software pipeline over the wave's chunks: while chunk c is evaluated (vector pipe) the parameters of chunk c + 8 are formed
+        // (matrix pipe), one MFMA per hook of the evaluation.  The first pass evaluates nothing real (no chunk yet): its stores
+        // are masked.
+        slabf_pipe pp;
+        const u32x4 *hf0 = reinterpret_cast<const u32x4 *>(k.h) + lane;
+        int ce = -1, cn = c_begin + wave;
+        // every pass evaluates one chunk and prepares the next.  The first pass has no chunk to evaluate (its stores are masked), the
+        // last prepares the range's first chunk once more (valid memory, result unused): one extra pass in ~64, no guard in the code
+        auto stage = [&](f32x16 (&accE)[3]) {
+            const bool have = ce >= 0;
+            const int cc = have ? ce : c_begin;
+            const int64_t row0 = (int64_t)cc * 32;
+            const int n_here = (int)((k.n_rows - row0) < 32 ? (k.n_rows - row0) : 32);
+            const bool valid = have && j < n_here && col_ok;
+            const int jc = j < n_here ? j : n_here - 1;
+            const uint32_t xoff = (uint32_t)jc * (uint32_t)k.dim + (uint32_t)col;
+            const float xl = (k.x + row0 * k.dim)[xoff];
+            const bool has_next = cn < c_end;
+            pp.begin(hf0 + ((size_t)(has_next ? cn : c_begin) * HT) * 256, w.wb, w.cb, HT, BI);
+            const float xv = valid ? xl : (REV ? k.bottom : k.left);
+            const bool nan_h = accE[0][0] != accE[0][0];
+            float out, ljd;
+            if constexpr (REV) rqs_slab_eval<KC, true>(accE[1], accE[0], accE[2], k.K, xv, k.bottom, k.top, k.left, k.right, out, ljd, pp);
+            else rqs_slab_eval<KC, false>(accE[0], accE[1], accE[2], k.K, xv, k.left, k.right, k.bottom, k.top, out, ljd, pp);
+            pp.drain();
+            if (valid) (k.y + row0 * k.dim)[xoff] = nan_h ? __builtin_nanf("") : out;
+            if (k.ldj_part != nullptr) {
+                float lsum = valid ? ljd : 0.f;
+                lsum += __shfl_xor(lsum, 32, 64);
+                if (have && hh == 0 && j < n_here) k.ldj_part[(size_t)slab * k.n_rows + row0 + j] = nan_h ? __builtin_nanf("") : lsum;
+            }
+            ce = has_next ? cn : -1;
+            cn += 8;
+        };
+        f32x16 accA[3], accB[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) accA[t] = load_cfrag1(w.cb, BI + t * 32);
+        while (true) {
+            stage(accA);                      // evaluates accA (chunk ce), forms the next chunk's parameters in pp.acc
+            if (ce < 0) break;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) accB[t] = pp.acc[t];
+            stage(accB);
+            if (ce < 0) break;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) accA[t] = pp.acc[t];
+        }
+    } else {
     for (int c = c_begin + wave; c < c_end; c += 8) {
         rng_t rg{0};
         const int64_t row0 = (int64_t)c * 32;
@@ -869,7 +1041,7 @@ __global__ __launch_bounds__(512, 1) void rqs_slab_fwd_kernel(const slabf_args k
         tile<1> acc[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) acc[t] = load_cfrag<1>(w.cb, BI + t * 32);
-        if constexpr (HFRAG) {
+        if constexpr (HFRAG) {      // (fewer than three hidden tiles: no pipeline)
             const u32x4 *hf = reinterpret_cast<const u32x4 *>(k.h) + ((size_t)c * HT) * 256 + lane;
             u32x4 fr[4];
 #pragma unroll
@@ -922,8 +1094,9 @@ __global__ __launch_bounds__(512, 1) void rqs_slab_fwd_kernel(const slabf_args k
         const float xv = valid ? xl : (REV ? k.bottom : k.left);
         const bool nan_h = acc[0].v[0][0] != acc[0].v[0][0];
         float out, ljd;
-        if constexpr (REV) rqs_slab_eval<KC, true>(acc[1].v[0], acc[0].v[0], acc[2].v[0], k.K, xv, k.bottom, k.top, k.left, k.right, out, ljd);
-        else rqs_slab_eval<KC, false>(acc[0].v[0], acc[1].v[0], acc[2].v[0], k.K, xv, k.left, k.right, k.bottom, k.top, out, ljd);
+        slabf_nohook nh;
+        if constexpr (REV) rqs_slab_eval<KC, true>(acc[1].v[0], acc[0].v[0], acc[2].v[0], k.K, xv, k.bottom, k.top, k.left, k.right, out, ljd, nh);
+        else rqs_slab_eval<KC, false>(acc[0].v[0], acc[1].v[0], acc[2].v[0], k.K, xv, k.left, k.right, k.bottom, k.top, out, ljd, nh);
         // (HFRAG: a row whose h left fp16's range carries NaN fragments -- flagged by the kernel that wrote them)
         const bool bad = HFRAG ? nan_h : rng_bad_sample(rg, lane);
         any_bad |= rg.bad;
@@ -933,6 +1106,7 @@ __global__ __launch_bounds__(512, 1) void rqs_slab_fwd_kernel(const slabf_args k
             lsum += __shfl_xor(lsum, 32, 64);
             if (hh == 0 && j < n_here) k.ldj_part[(size_t)slab * k.n_rows + row0 + j] = bad ? __builtin_nanf("") : lsum;
         }
+    }
     }
     if (any_bad != 0 && lane == 0 && k.flags != nullptr)
         __hip_atomic_fetch_or(k.flags, SX_FLAG_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -952,14 +1126,14 @@ struct slabh_args {
     int dim, latent_dim, HT, act, n_chunks;
 };
 template <int CT>
-__global__ __launch_bounds__(256) void rqs_slab_hidden_kernel(const slabh_args k) {
+__global__ __launch_bounds__(512) void rqs_slab_hidden_kernel(const slabh_args k) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int HT = k.HT;
     {
         const int n4 = (HT * CT * 1024 + HT * 32) / 4;
         const f32x4 *src = reinterpret_cast<const f32x4 *>(k.w1);
         f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
-        for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
+        for (int i = threadIdx.x; i < n4; i += 512) dst[i] = src[i];
     }
     __syncthreads();
     const wptr w = make_wptr(0, lane);
@@ -967,7 +1141,7 @@ __global__ __launch_bounds__(256) void rqs_slab_hidden_kernel(const slabh_args k
     const int bias = HT * CT * 1024;
     const bool xvec = (k.dim % 4 == 0) && ((reinterpret_cast<uintptr_t>(k.x) & 15) == 0);
     uint64_t any_bad = 0;
-    for (int c = blockIdx.x * 4 + wave; c < k.n_chunks; c += gridDim.x * 4) {
+    for (int c = blockIdx.x * 8 + wave; c < k.n_chunks; c += gridDim.x * 8) {
         rng_t rg{0};
         const int64_t row0 = (int64_t)c * 32;
         const int n_here = (int)((k.n_rows - row0) < 32 ? (k.n_rows - row0) : 32);
@@ -1177,11 +1351,11 @@ extern "C" int sx_rqs_slab_fwd(const float *x, const float *h, int64_t ld_h, int
     int dev = 0;
     (void)hipGetDevice(&dev);
     const bool hfull = hidden == 32 * HT && ld_h % 4 == 0 && ((uintptr_t)h & 15) == 0;
-#define SX_SLABF(KC_, HF_, REV_, ID_) do { if (h_fragments) SX_SLABF2(KC_, true, REV_, true, ID_ + 6); else SX_SLABF2(KC_, HF_, REV_, false, ID_); } while (0)
-#define SX_SLABF2(KC_, HF_, REV_, FR_, ID_)                                                                        \
+#define SX_SLABF(KC_, HF_, REV_, ID_) do { if (h_fragments && HT >= 3) SX_SLABF2(KC_, true, REV_, true, true, ID_ + 12); else if (h_fragments) SX_SLABF2(KC_, true, REV_, true, false, ID_ + 6); else SX_SLABF2(KC_, HF_, REV_, false, false, ID_); } while (0)
+#define SX_SLABF2(KC_, HF_, REV_, FR_, PI_, ID_)                                                                   \
     do {                                                                                                           \
-        auto kern = rqs_slab_fwd_kernel<KC_, HF_, REV_, FR_>;                                                      \
-        static int lds_allowed[12][64];                                                                            \
+        auto kern = rqs_slab_fwd_kernel<KC_, HF_, REV_, FR_, PI_>;                                                 \
+        static int lds_allowed[18][64];                                                                            \
         if (lds > 48 * 1024 && lds_allowed[ID_][dev & 63] < (int)lds) {                                            \
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) { sx_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
@@ -1227,8 +1401,9 @@ extern "C" int sx_rqs_slab_hidden(const float *x, const float *latent, const flo
     k.x = x; k.latent = latent; k.w1 = w1; k.hfrag = h_frag; k.flags = err_flag; k.n_rows = n_rows; k.dim = dim; k.latent_dim = latent_dim;
     k.HT = HT; k.act = act; k.n_chunks = n_chunks;
     const size_t lds = (size_t)(HT * CT * 1024 + HT * 32) * sizeof(float);
-    int grid = (n_chunks + 3) / 4;
-    if (grid > 1024) grid = 1024;
+    // two 8-wave workgroups per CU (one copy of the layer in LDS each), several chunks per wave
+    int grid = (n_chunks + 7) / 8;
+    if (grid > 512) grid = 512;
     int dev = 0;
     (void)hipGetDevice(&dev);
 #define SX_SLABH(CT_)                                                                                              \
@@ -1240,7 +1415,7 @@ extern "C" int sx_rqs_slab_hidden(const float *x, const float *latent, const flo
             if (e != hipSuccess) { sx_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
             lds_allowed[dev & 63] = (int)lds;                                                                      \
         }                                                                                                          \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, k);                                               \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, k);                                               \
     } while (0)
     switch (CT) { case 1: SX_SLABH(1); break; case 2: SX_SLABH(2); break; case 3: SX_SLABH(3); break; default: SX_SLABH(4); break; }
 #undef SX_SLABH
