@@ -104,8 +104,10 @@ __device__ __forceinline__ void flag_set(int *flag, int v) {
 // Workgroup id -> (slab group, row range) is XCD-aware: ids are dealt round-robin to the 8 XCDs, so the n_groups workgroups
 // that walk the same rows (and re-read the same h / x lines) are given ids 8 apart -- the same XCD, the same L2.
 // CUBIC: monotone cubic splines (2K + 2 parameters per element: widths | heights | two boundary derivatives in the third tile).
+// HT = 3, 4 (hidden layers of 65 .. 128 units, round 5): the 3 HT accumulator tiles of dW2 (144 / 192 registers) leave no room for two
+// waves per SIMD -- SPW = 1, one 4-wave workgroup per CU, the whole 512-register file per wave; 72 / 96 KB of LDS.
 template <int HT, int KC, bool HFULL, int SPW, bool CUBIC>
-__global__ __launch_bounds__(256 * SPW, SPW == 1 ? 2 : 1) void rqs_slab_bwd_kernel(const slab_args k) {
+__global__ __launch_bounds__(256 * SPW, (SPW == 1 && HT <= 2) ? 2 : 1) void rqs_slab_bwd_kernel(const slab_args k) {
     constexpr int SLAB_F = 6 * HT * 1024;                               // per slab: W2 slab | its transpose (floats)
     constexpr int FWo = 0, BWo = 3 * HT * 1024;
     constexpr int BI = SPW * SLAB_F, XB = BI + SPW * 128;               // bias [SPW][128] | exchange [4 SPW][1024] | flags [32]
@@ -1202,12 +1204,12 @@ __global__ __launch_bounds__(256) void rqs_slab_ldj_reduce_kernel(const float *_
 
 // launch shape: slabs per workgroup, slab groups, row ranges (one 8-wave workgroup per CU, or two 4-wave ones)
 struct slab_shape { int spw, n_groups, n_ranges; };
-slab_shape slab_plan(int n_slabs, int n_chunks) {
+slab_shape slab_plan(int n_slabs, int n_chunks, int ht = 2) {
     slab_shape p;
     static const int knob = sx_debug_knob("SX_SLAB_SPW", 0);      // experiments: 1 | 2, read once
-    p.spw = knob == 1 ? 1 : (n_slabs >= 2 ? 2 : 1);
+    p.spw = (knob == 1 || ht > 2) ? 1 : (n_slabs >= 2 ? 2 : 1);
     p.n_groups = (n_slabs + p.spw - 1) / p.spw;
-    int r = ((p.spw == 2 ? 256 : 512) + p.n_groups - 1) / p.n_groups;
+    int r = ((p.spw == 2 || ht > 2 ? 256 : 512) + p.n_groups - 1) / p.n_groups;      // workgroups per CU: 1 (8 waves, or HT > 2) | 2
     const int cap = (n_chunks + 3) / 4;              // at least one 32-row chunk per wave where the rows allow
     if (r > cap) r = cap;
     if (r >= 8) r &= ~7;                             // multiples of 8: the XCD-aware id mapping
@@ -1221,10 +1223,10 @@ slab_shape slab_plan(int n_slabs, int n_chunks) {
 extern "C" int32_t sx_rqs_slab_slots(int32_t n_live) { return (n_live < 1 || n_live > (1 << 20)) ? 0 : ((n_live + 1) / 2) * 96; }
 
 extern "C" size_t sx_rqs_slab_scratch_floats(int64_t n_rows, int32_t n_live, int32_t hidden) {
-    if (n_rows < 0 || n_rows >= ((int64_t)1 << 36) || n_live < 1 || n_live > (1 << 20) || hidden < 1 || hidden > 64) return 0;
+    if (n_rows < 0 || n_rows >= ((int64_t)1 << 36) || n_live < 1 || n_live > (1 << 20) || hidden < 1 || hidden > 128) return 0;
     const int n_slabs = (n_live + 1) / 2, HT = (hidden + 31) / 32;
     const int64_t n_chunks = (n_rows + 31) / 32;
-    const slab_shape p = slab_plan(n_slabs, (int)n_chunks);
+    const slab_shape p = slab_plan(n_slabs, (int)n_chunks, HT);
     return (size_t)p.n_groups * (size_t)n_chunks * HT * 1024 + (size_t)n_slabs * p.n_ranges * (96 * 32 * HT + 96);
 }
 
@@ -1237,7 +1239,8 @@ extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *g
     SX_REQUIRE(x && gout && gldj && h && w_fwd && w_bwd && slot_rows && gx && dW && db && scratch, "sx_rqs_slab_bwd: null pointer");
     SX_REQUIRE(dim > 0 && n_live > 0 && n_live <= dim && n_rows >= 0, "sx_rqs_slab_bwd: bad sizes");
     SX_REQUIRE(n_bins >= 1 && n_bins <= 16, "sx_rqs_slab_bwd: n_bins must be in 1..16 (got %d)", n_bins);
-    SX_REQUIRE(hidden >= 1 && hidden <= 64, "sx_rqs_slab_bwd: hidden width must be in 1..64 (got %d)", hidden);
+    SX_REQUIRE(hidden >= 1 && hidden <= 128, "sx_rqs_slab_bwd: hidden width must be in 1..128 (got %d)", hidden);
+    SX_REQUIRE(gh != nullptr || hidden <= 64, "sx_rqs_slab_bwd: sx_rqs_slab_l1_bwd (gh = NULL) holds hidden layers of up to 64 units");
     SX_REQUIRE(n_rows < ((int64_t)1 << 36), "sx_rqs_slab_bwd: too many rows");
     SX_REQUIRE(right > left && top > bottom, "sx_rqs_slab_bwd: empty domain");
     SX_REQUIRE(((uintptr_t)w_fwd & 15) == 0 && ((uintptr_t)w_bwd & 15) == 0 && ((uintptr_t)scratch & 15) == 0,
@@ -1246,7 +1249,7 @@ extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *g
     hipStream_t st = sx_stream(stream);
     const int n_slabs = (n_live + 1) / 2, HT = (hidden + 31) / 32;
     const int n_chunks = (int)((n_rows + 31) / 32);
-    const slab_shape pl = slab_plan(n_slabs, n_chunks);
+    const slab_shape pl = slab_plan(n_slabs, n_chunks, HT);
     const int n_ranges = pl.n_ranges, n_groups = pl.n_groups;
     slab_args k;
     k.x = x; k.gout = gout; k.gldj = gldj; k.xout = xout; k.h = h; k.wf = w_fwd; k.wb = w_bwd; k.gx = gx;
@@ -1277,8 +1280,12 @@ extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *g
     const bool hfull = hidden == 32 * HT && ld_h % 4 == 0 && ((uintptr_t)h & 15) == 0;
     if (HT == 1) {
         if (n_bins == 16 && hfull) SX_SLAB(1, 16, true); else if (hfull) SX_SLAB(1, 0, true); else SX_SLAB(1, 0, false);
-    } else {
+    } else if (HT == 2) {
         if (n_bins == 16 && hfull) SX_SLAB(2, 16, true); else if (hfull) SX_SLAB(2, 0, true); else SX_SLAB(2, 0, false);
+    } else if (HT == 3) {           // (one workgroup shape, two bin-count forms: the wide kernels are long compiles)
+        if (n_bins == 16 && hfull) SX_SLAB2(3, 16, true, 1); else SX_SLAB2(3, 0, false, 1);
+    } else {
+        if (n_bins == 16 && hfull) SX_SLAB2(4, 16, true, 1); else SX_SLAB2(4, 0, false, 1);
     }
 #undef SX_SLAB2
 #undef SX_SLAB
@@ -1303,12 +1310,10 @@ extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *g
     SX_LAUNCH_CHECK();
     if (gh == nullptr) return SX_OK;            // the caller reduces the dh partials itself (sx_rqs_slab_l1_bwd)
     const int64_t pieces = (int64_t)n_chunks * HT * 256;
-    if (HT == 1)
-        hipLaunchKernelGGL(rqs_slab_dh_reduce_kernel<1>, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, k.dh_part,
-                           n_groups, n_chunks, n_rows, (int)hidden, gh, ld_gh, scale, tanh_hidden ? h : nullptr, ld_h);
-    else
-        hipLaunchKernelGGL(rqs_slab_dh_reduce_kernel<2>, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, k.dh_part,
-                           n_groups, n_chunks, n_rows, (int)hidden, gh, ld_gh, scale, tanh_hidden ? h : nullptr, ld_h);
+#define SX_DHRED(HT_) hipLaunchKernelGGL(rqs_slab_dh_reduce_kernel<HT_>, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, k.dh_part, \
+                                         n_groups, n_chunks, n_rows, (int)hidden, gh, ld_gh, scale, tanh_hidden ? h : nullptr, ld_h)
+    switch (HT) { case 1: SX_DHRED(1); break; case 2: SX_DHRED(2); break; case 3: SX_DHRED(3); break; default: SX_DHRED(4); break; }
+#undef SX_DHRED
     SX_LAUNCH_CHECK();
     return SX_OK;
 }
