@@ -1127,7 +1127,9 @@ struct slabh_args {
     int64_t n_rows;
     int dim, latent_dim, HT, act, n_chunks;
 };
-template <int CT>
+// TANH: the activation inline (the generic one is an out-of-line call on the tile's ADDRESS: the tile then lives in scratch, 8 KB of
+// scratch traffic per tile and wave -- measured as 100 MB of extra HBM writes per launch)
+template <int CT, bool TANH>
 __global__ __launch_bounds__(512) void rqs_slab_hidden_kernel(const slabh_args k) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int HT = k.HT;
@@ -1175,7 +1177,10 @@ __global__ __launch_bounds__(512) void rqs_slab_hidden_kernel(const slabh_args k
             tile<1> acc = load_cfrag<1>(w.cb, bias + m * 32);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) gemm_tile<1>(w.wb, (m * CT + ct) * 1024, bx[ct], acc);
-            activate<1>(acc, k.act);
+            if constexpr (TANH) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc.v[0][r] = fast_tanh(acc.v[0][r]);
+            } else activate<1>(acc, k.act);
             const btile<1> bh = make_btile<1>(acc, rg);
             const bool bad = rng_bad_sample(rg, lane);
             const u32x4 nanv = {0x7e007e00u, 0x7e007e00u, 0x7e007e00u, 0x7e007e00u};
@@ -1413,10 +1418,11 @@ extern "C" int sx_rqs_slab_hidden(const float *x, const float *latent, const flo
     (void)hipGetDevice(&dev);
 #define SX_SLABH(CT_)                                                                                              \
     do {                                                                                                           \
-        auto kern = rqs_slab_hidden_kernel<CT_>;                                                                   \
+        auto kern = act == SX_ACT_TANH ? rqs_slab_hidden_kernel<CT_, true> : rqs_slab_hidden_kernel<CT_, false>;          \
         static int lds_allowed[64];                                                                                \
         if (lds > 48 * 1024 && lds_allowed[dev & 63] < (int)lds) {                                                 \
-            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipError_t e = hipFuncSetAttribute((const void *)rqs_slab_hidden_kernel<CT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void *)rqs_slab_hidden_kernel<CT_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) { sx_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
             lds_allowed[dev & 63] = (int)lds;                                                                      \
         }                                                                                                          \

@@ -36,6 +36,7 @@ def main():
     for K in (16, 24, 32):
         cases.append(('rqs', 64, 64, K))
     cases.append(('rqs', 64, 160, 16))
+    cases.append(('rqs', 64, 256, 16))
     with torch.no_grad():
         for kind, dim, hidden, K in cases:
             torch.manual_seed(0)
@@ -48,9 +49,16 @@ def main():
             flow = fd.build_flow(st, desc, dim).to(dev)
             x = torch.randn(ROWS, dim, device=dev)
             fused = flow._fused_program(True, dim, 0, dev) is not None
+            tier = 'one launch' if fused else 'layer by layer'
+            if not fused and kind == 'rqs':
+                try:                            # the slab forward tier (hidden layers beyond 128 units): two launches per layer
+                    flow.transforms[0]._spline_slab_plan(dim, 0, dev)
+                    tier = 'slab forward'
+                except NotImplementedError:
+                    pass
             ms = timed(lambda: flow.log_prob(x))
             print(json.dumps({'coupling': kind, 'dim': dim, 'hidden': hidden, 'n_bins': K, 'layers': 4, 'rows': ROWS,
-                              'one_fused_launch': fused, 'ms': ms, 'rows_per_s': ROWS / ms * 1e3}), flush=True)
+                              'one_fused_launch': fused, 'tier': tier, 'ms': ms, 'rows_per_s': ROWS / ms * 1e3}), flush=True)
             del flow, x
 
 
