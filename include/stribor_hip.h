@@ -224,7 +224,10 @@ int sx_rqs_slab_l1_bwd(const float *slab_scratch, const float *h, int64_t ld_h, 
  *   ldj (nullable) [n_rows] = (ldj_accumulate ? ldj : 0) + ldj_scale * sum over the transformed columns of log|d y / d x|
  *   (reverse: of the inverse map, as rational_quadratic_spline.py:232-234 returns it), summed in slab order;
  *   scratch: sx_rqs_slab_fwd_scratch_floats(n_rows, n_live) floats (needed when ldj is not NULL), caller-owned;
- *   err_flag (nullable) receives SX_FLAG_F16_RANGE when |h| leaves fp16's range (those rows' outputs are NaN).
+ *   err_flag (nullable) receives SX_FLAG_F16_RANGE when |h| leaves fp16's range (those rows' outputs are NaN);
+ *   cubic != 0: MONOTONE CUBIC splines (util/cubic_spline.py:21-251, spline_type='cubic', the reference's default; as
+ *   sx_cubic_coupling: domain [left, right] on both sides, 2K+2 parameters per element, slots as sx_rqs_slab_bwd's xout form;
+ *   reverse = 2: the inverse with MINUS the forward log-det re-evaluated at the inverted point, flow.py:42-47).
  * sx_rqs_slab_hidden: the hidden layer of a single-hidden-layer conditioner (net/mlp.py:48-58; coupling.py:61-65: it sees
  * cat[x * mask, latent]),  h = act(W1 z + b1), as fp16 hi / lo MFMA fragments: h_frag [sx_rqs_slab_hidden_floats(n_rows, hidden)].
  *   w1: sx_pack_linear(W1, b1, row_idx = hidden slots, col_idx = input slots (slot q = column q of x, then of latent; -1 = masked),
@@ -236,7 +239,7 @@ size_t sx_rqs_slab_fwd_scratch_floats(int64_t n_rows, int32_t n_live);
 int sx_rqs_slab_fwd(const float *x, const float *h, int64_t ld_h, int32_t hidden, const float *w_fwd, float *y, float *ldj,
                     const int32_t *live_idx, int32_t live_start, int32_t n_live, int32_t n_bins, float left, float right,
                     float bottom, float top, int64_t n_rows, int32_t dim, int32_t reverse, float ldj_scale, int32_t ldj_accumulate,
-                    int32_t h_fragments, float *scratch, uint32_t *err_flag, void *stream);
+                    int32_t h_fragments, int32_t cubic, float *scratch, uint32_t *err_flag, void *stream);
 
 /* Monotone cubic spline, element-wise part -- spline_type='cubic', the reference's default
  * (stribor/util/cubic_spline.py:21-251, util/search_sorted.py:3-5, flows/spline.py:59-61,82-86).

@@ -28,6 +28,7 @@
 #include <type_traits>
 #include "sx_flow_kernel.h"
 #include "sx_rqs_bwd.h"
+#include "sx_cubic_core.h"
 
 // Timing experiments only (results wrong): -DSX_SLAB_X=<bits>  1 no spline reverse mode  2 no dh  4 no dW2  8 no parameter GEMM
 #ifndef SX_SLAB_X
@@ -712,8 +713,8 @@ struct slabf_args {
     const int32_t *live_idx;
     uint32_t *flags;
     int64_t n_rows, ld_h;
-    int l0, n_live, K, dim, H, HT, n_slabs, n_chunks, n_ranges, xcd_map;
-    float left, right, bottom, top;
+    int l0, n_live, K, dim, H, HT, n_slabs, n_chunks, n_ranges, xcd_map, ref_ldj;
+    float left, right, bottom, top, log_span;
 };
 
 // One element on registers: Sp = the SEARCHED side's K bin parameters (REV: heights, else widths), Op = the other side's, Dp the
@@ -862,6 +863,112 @@ __device__ __forceinline__ void rqs_slab_eval(rqsb_f16v &Sp, rqsb_f16v &Op, cons
     ljd = inside ? l : 0.f;
 }
 
+// The monotone CUBIC spline (util/cubic_spline.py:21-251, the reference's default spline_type) of one element on registers: Wp / Hp
+// hold its K widths / heights (K <= 16, entries beyond K ignored), Dp[0..1] its two boundary-derivative parameters -- cubic_kernel's
+// arithmetic (sx_rqs.hip, sx_cubic_core.h) with the parameters in MFMA accumulators: one sweep with selects keeps the sizes of
+// bins b - 1, b, b + 1 (the Steffen slopes need the neighbours, :117-132), then the bin's cubic forward or its inverse (closed forms +
+// Newton steps).  ref_ldj (a coupling's inverse_and_log_det_jacobian): the log-det is MINUS the FORWARD log-derivative re-evaluated
+// at the inverted point (flow.py:42-47), as cubic_kernel's reference mode.
+__device__ __forceinline__ float cubic_regs_forward_logderiv(const rqsb_f16v &ew, const rqsb_f16v &eh, float nw, float nh, float dpar0,
+                                                             float dpar1, int K, float xin) {
+    int b = 0;
+    float cw_b = 0.f, w_b = 0.f, h_b = 0.f, w_m = 1.f, h_m = 1.f, w_p = 1.f, h_p = 1.f;
+    float cw = 0.f, w_last = 1.f, h_last = 1.f;
+    bool need_next = false;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const bool used = k < K;
+        const float wk = CUBIC_MIN_BIN + nw * ew[k];
+        const float hk = CUBIC_MIN_BIN + nh * eh[k];
+        const bool ge = used && xin >= cw;
+        const bool nx = used && !ge && need_next;
+        b = ge ? k : b; cw_b = ge ? cw : cw_b; w_b = ge ? wk : w_b; h_b = ge ? hk : h_b;
+        w_m = ge ? w_last : w_m; h_m = ge ? h_last : h_m;
+        w_p = nx ? wk : w_p; h_p = nx ? hk : h_p;
+        need_next = used ? ge : need_next;
+        w_last = wk; h_last = hk;
+        cw += wk;
+    }
+    const cubic_coef q = cubic_bin_coef(b, K, w_b, h_b, w_m, h_m, w_p, h_p, dpar0, dpar1);
+    const float t = xin - cw_b;
+    return cubic_flog(3.f * q.a * (t * t) + 2.f * q.bb * t + q.c);
+}
+template <bool REV>
+__device__ __forceinline__ void cubic_slab_eval(rqsb_f16v &Wp, rqsb_f16v &Hp, const rqsb_f16v &Dp, int K, float xv, float lower, float upper,
+                                                float log_span, bool ref_ldj, bool valid, float &out, float &ljd) {
+    const float norm = 1.f - CUBIC_MIN_BIN * (float)K;          // :104, :111
+    const float span = upper - lower, inv_span = 1.0f / span;
+    const bool inside = (xv >= lower) && (xv <= upper);          // :40 closed interval
+    const float xin = ((inside ? xv : lower) - lower) * inv_span;        // :98-101
+    float mw = Wp[0], mh = Hp[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+        const bool used = k < K;
+        mw = used ? fmaxf(mw, Wp[k]) : mw;
+        mh = used ? fmaxf(mh, Hp[k]) : mh;
+    }
+    float sw = 0.f, sh = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const bool used = k < K;
+        const float ew = used ? cubic_fexp(Wp[k] - mw) : 0.f, eh = used ? cubic_fexp(Hp[k] - mh) : 0.f;
+        Wp[k] = ew; Hp[k] = eh;
+        sw += ew; sh += eh;
+    }
+    const float nw = norm * cubic_frcp(sw), nh = norm * cubic_frcp(sh);
+    // normalised sizes, running cumsums (:103-115) and the bin search (search_sorted.py:4-5) in one sweep that also keeps the sizes of
+    // bins b - 1, b, b + 1: the lower knot of bin k is compared (knot 0 = 0: the knots only grow)
+    int b = 0;
+    float cw_b = 0.f, ch_b = 0.f, w_b = 0.f, h_b = 0.f, w_m = 1.f, h_m = 1.f, w_p = 1.f, h_p = 1.f;
+    float cw = 0.f, ch = 0.f, w_last = 1.f, h_last = 1.f;
+    bool need_next = false;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const bool used = k < K;
+        const float wk = CUBIC_MIN_BIN + nw * Wp[k];
+        const float hk = CUBIC_MIN_BIN + nh * Hp[k];
+        const bool ge = used && xin >= (REV ? ch : cw);
+        const bool nx = used && !ge && need_next;
+        b = ge ? k : b; cw_b = ge ? cw : cw_b; ch_b = ge ? ch : ch_b; w_b = ge ? wk : w_b; h_b = ge ? hk : h_b;
+        w_m = ge ? w_last : w_m; h_m = ge ? h_last : h_m;
+        w_p = nx ? wk : w_p; h_p = nx ? hk : h_p;
+        need_next = used ? ge : need_next;
+        w_last = wk; h_last = hk;
+        cw += wk; ch += hk;
+    }
+    const float dpar0 = Dp[0], dpar1 = Dp[1];
+    const float rcw = (b == K - 1) ? 1.f : cw_b + w_b;                                     // :107 (last knot pinned)
+    const cubic_coef cf = cubic_bin_coef(b, K, w_b, h_b, w_m, h_m, w_p, h_p, dpar0, dpar1);
+    const float a = cf.a, bb = cf.bb, c = cf.c, d = ch_b;                                  // :134-137
+    if constexpr (REV) {
+        const float so = cubic_invert(a, bb, c, d, xin, cw_b, rcw);
+        const float o = so + cw_b;
+        ljd = -cubic_flog(3.f * a * (so * so) + 2.f * bb * so + c);                        // :225-227
+        out = fminf(fmaxf(o * span + lower, lower), upper);                                // :235 (see cubic_kernel)
+        ljd = (ljd - log_span) + log_span;                                                 // :236
+        if (ref_ldj) {
+            const bool in2 = inside && (out >= lower) && (out <= upper);
+            const float xin2 = ((in2 ? out : lower) - lower) * inv_span;
+            const bool same_bin = (xin2 >= cw_b) && (b == K - 1 || xin2 < cw_b + w_b);
+            const float t2 = xin2 - cw_b;
+            float lf = cubic_flog(3.f * a * (t2 * t2) + 2.f * bb * t2 + c);
+            const bool slow = valid && in2 && !same_bin;
+            if (__builtin_amdgcn_ballot_w64(slow)) {
+                if (slow) lf = cubic_regs_forward_logderiv(Wp, Hp, nw, nh, dpar0, dpar1, K, xin2);
+            }
+            lf = (lf + log_span) - log_span;                                               // :239
+            ljd = in2 ? -lf : 0.f;                                                         // :46-48 tails; flow.py:47 negation
+        }
+    } else {
+        const float t = xin - cw_b;                                                        // :229
+        out = a * (t * t * t) + bb * (t * t) + c * t + d;                                  // :230-233
+        ljd = cubic_flog(3.f * a * (t * t) + 2.f * bb * t + c);                            // :235-237
+        out = out * span + lower;                                                          // :238
+        ljd = (ljd + log_span) - log_span;                                                 // :239
+    }
+    if (!inside) { out = xv; ljd = 0.f; }                                                  // :46-48 linear tails
+}
+
 // The NEXT chunk's parameter GEMM, issued one MFMA per hook of the current chunk's evaluation -- a wave's vector work only overlaps
 // the matrix pipe between its OWN MFMAs (profiles/r05_coexec_probe.txt: two waves of a SIMD in different phases do not).  MFMA H:
 // hidden tile H / 18, k16-step (H % 18) / 9, fp16 product term (H % 9) / 3, accumulator tile H % 3: every operand register and LDS
@@ -941,7 +1048,8 @@ struct slabf_pipe {
 // rqs_slab_hidden_kernel): four 1 KB loads per tile, no split here -- every slab re-reads h, so the split's 36 vector instructions
 // per tile were paid n_slabs times (a third of this kernel's vector work at 160 hidden units).
 // PIPE (HFRAG only, HT >= 3: the evaluation's hooks reach into hidden tile 2): the software-pipelined chunk loop.
-template <int KC, bool HFULL, bool REV, bool HFRAG, bool PIPE>
+// CUBIC: monotone cubic splines (2K + 2 parameters per element, the two boundary derivatives in the third tile), unpipelined.
+template <int KC, bool HFULL, bool REV, bool HFRAG, bool PIPE, bool CUBIC>
 __global__ __launch_bounds__(512, 1) void rqs_slab_fwd_kernel(const slabf_args k) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int HT = k.HT;
@@ -1097,7 +1205,8 @@ __global__ __launch_bounds__(512, 1) void rqs_slab_fwd_kernel(const slabf_args k
         const bool nan_h = acc[0].v[0][0] != acc[0].v[0][0];
         float out, ljd;
         slabf_nohook nh;
-        if constexpr (REV) rqs_slab_eval<KC, true>(acc[1].v[0], acc[0].v[0], acc[2].v[0], k.K, xv, k.bottom, k.top, k.left, k.right, out, ljd, nh);
+        if constexpr (CUBIC) cubic_slab_eval<REV>(acc[0].v[0], acc[1].v[0], acc[2].v[0], k.K, xv, k.left, k.right, k.log_span, k.ref_ldj != 0, valid, out, ljd);
+        else if constexpr (REV) rqs_slab_eval<KC, true>(acc[1].v[0], acc[0].v[0], acc[2].v[0], k.K, xv, k.bottom, k.top, k.left, k.right, out, ljd, nh);
         else rqs_slab_eval<KC, false>(acc[0].v[0], acc[1].v[0], acc[2].v[0], k.K, xv, k.left, k.right, k.bottom, k.top, out, ljd, nh);
         // (HFRAG: a row whose h left fp16's range carries NaN fragments -- flagged by the kernel that wrote them)
         const bool bad = HFRAG ? nan_h : rng_bad_sample(rg, lane);
@@ -1331,7 +1440,8 @@ extern "C" size_t sx_rqs_slab_fwd_scratch_floats(int64_t n_rows, int32_t n_live)
 extern "C" int sx_rqs_slab_fwd(const float *x, const float *h, int64_t ld_h, int32_t hidden, const float *w_fwd, float *y, float *ldj,
                                const int32_t *live_idx, int32_t live_start, int32_t n_live, int32_t n_bins, float left, float right,
                                float bottom, float top, int64_t n_rows, int32_t dim, int32_t reverse, float ldj_scale,
-                               int32_t ldj_accumulate, int32_t h_fragments, float *scratch, uint32_t *err_flag, void *stream) {
+                               int32_t ldj_accumulate, int32_t h_fragments, int32_t cubic, float *scratch, uint32_t *err_flag,
+                               void *stream) {
     SX_REQUIRE(x && h && w_fwd && y, "sx_rqs_slab_fwd: null pointer");
     SX_REQUIRE(!h_fragments || ((uintptr_t)h & 15) == 0, "sx_rqs_slab_fwd: h fragments must be 16-byte aligned");
     SX_REQUIRE(ldj == nullptr || scratch != nullptr, "sx_rqs_slab_fwd: the row log-det needs the scratch buffer");
@@ -1341,6 +1451,8 @@ extern "C" int sx_rqs_slab_fwd(const float *x, const float *h, int64_t ld_h, int
     SX_REQUIRE(h_fragments || ld_h >= hidden, "sx_rqs_slab_fwd: ld_h < hidden");
     SX_REQUIRE(n_rows < ((int64_t)1 << 36), "sx_rqs_slab_fwd: too many rows");
     SX_REQUIRE(right > left && top > bottom, "sx_rqs_slab_fwd: empty domain");
+    SX_REQUIRE(reverse >= 0 && reverse <= (cubic ? 2 : 1), "sx_rqs_slab_fwd: reverse must be 0 | 1 (cubic: | 2)");
+    SX_REQUIRE(!cubic || (left == bottom && right == top), "sx_rqs_slab_fwd: cubic splines map [left, right] onto itself");
     SX_REQUIRE(((uintptr_t)w_fwd & 15) == 0, "sx_rqs_slab_fwd: packed weights must be 16-byte aligned");
     if (n_rows == 0) return SX_OK;
     hipStream_t st = sx_stream(stream);
@@ -1357,15 +1469,17 @@ extern "C" int sx_rqs_slab_fwd(const float *x, const float *h, int64_t ld_h, int
     k.n_rows = n_rows; k.ld_h = ld_h; k.l0 = live_start; k.n_live = n_live; k.K = n_bins; k.dim = dim; k.H = hidden; k.HT = HT;
     k.n_slabs = n_slabs; k.n_chunks = n_chunks; k.n_ranges = n_ranges; k.xcd_map = (n_ranges % 8 == 0);
     k.left = left; k.right = right; k.bottom = bottom; k.top = top;
+    k.log_span = logf(right - left); k.ref_ldj = reverse == 2;
     const size_t lds = (size_t)(3 * HT * 1024 + 128) * sizeof(float);
     int dev = 0;
     (void)hipGetDevice(&dev);
     const bool hfull = hidden == 32 * HT && ld_h % 4 == 0 && ((uintptr_t)h & 15) == 0;
-#define SX_SLABF(KC_, HF_, REV_, ID_) do { if (h_fragments && HT >= 3) SX_SLABF2(KC_, true, REV_, true, true, ID_ + 12); else if (h_fragments) SX_SLABF2(KC_, true, REV_, true, false, ID_ + 6); else SX_SLABF2(KC_, HF_, REV_, false, false, ID_); } while (0)
-#define SX_SLABF2(KC_, HF_, REV_, FR_, PI_, ID_)                                                                   \
+#define SX_SLABF(KC_, HF_, REV_, ID_) do { if (h_fragments && HT >= 3) SX_SLABF2(KC_, true, REV_, true, true, false, ID_ + 12); else if (h_fragments) SX_SLABF2(KC_, true, REV_, true, false, false, ID_ + 6); else SX_SLABF2(KC_, HF_, REV_, false, false, false, ID_); } while (0)
+#define SX_SLABC(REV_, ID_) do { if (h_fragments) SX_SLABF2(0, true, REV_, true, false, true, ID_); else SX_SLABF2(0, false, REV_, false, false, true, ID_ + 1); } while (0)
+#define SX_SLABF2(KC_, HF_, REV_, FR_, PI_, CU_, ID_)                                                              \
     do {                                                                                                           \
-        auto kern = rqs_slab_fwd_kernel<KC_, HF_, REV_, FR_, PI_>;                                                 \
-        static int lds_allowed[18][64];                                                                            \
+        auto kern = rqs_slab_fwd_kernel<KC_, HF_, REV_, FR_, PI_, CU_>;                                            \
+        static int lds_allowed[22][64];                                                                            \
         if (lds > 48 * 1024 && lds_allowed[ID_][dev & 63] < (int)lds) {                                            \
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) { sx_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
@@ -1373,11 +1487,14 @@ extern "C" int sx_rqs_slab_fwd(const float *x, const float *h, int64_t ld_h, int
         }                                                                                                          \
         hipLaunchKernelGGL(kern, dim3(n_slabs * n_ranges), dim3(512), lds, st, k);                                 \
     } while (0)
-    if (reverse) {
+    if (cubic) {
+        if (reverse) SX_SLABC(true, 18); else SX_SLABC(false, 20);
+    } else if (reverse) {
         if (n_bins == 16 && hfull) SX_SLABF(16, true, true, 0); else if (hfull) SX_SLABF(0, true, true, 1); else SX_SLABF(0, false, true, 2);
     } else {
         if (n_bins == 16 && hfull) SX_SLABF(16, true, false, 3); else if (hfull) SX_SLABF(0, true, false, 4); else SX_SLABF(0, false, false, 5);
     }
+#undef SX_SLABC
 #undef SX_SLABF
 #undef SX_SLABF2
     SX_LAUNCH_CHECK();

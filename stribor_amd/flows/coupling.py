@@ -332,7 +332,7 @@ class Coupling(Transform):
         try:
             return self._run_spline_slab(x2, lat2, reverse, want_ldj, ldj_scale)
         except NotImplementedError:
-            pass                                        # cubic splines, > 16 bins, > 256 hidden units, bf16 rows, 'exact' / 'auto': below
+            pass                                        # > 16 bins, > 256 hidden units, bf16 rows, 'exact' / 'auto': below
         progs, live_idx, live_start, n_live, width = self._spline_program(d, 0 if lat2 is None else lat2.shape[1],
                                                                           x2.device)
         params = torch.empty(n, width, dtype=torch.float32, device=x2.device)
@@ -367,8 +367,9 @@ class Coupling(Transform):
             lin = net.linears()
             H = lin[-1][0].shape[1]
             widths = [w.shape[0] for (w, _) in lin[:-1]]
-            if sp.spline_type == 'cubic' or sp.n_bins > 16 or H > 256:
-                raise NotImplementedError('slab tier: rational-quadratic splines of up to 16 bins behind up to 256 hidden units')
+            cubic = sp.spline_type == 'cubic'
+            if sp.n_bins > 16 or H > 256:
+                raise NotImplementedError('slab tier: splines of up to 16 bins behind up to 256 hidden units')
             one_hidden = len(lin) == 2 and lin[0][1] is not None
             if dim + latent_dim > 128 if one_hidden else (_ceil32(dim) + _ceil32(latent_dim) > 4 or max(widths) > 128):
                 raise NotImplementedError('slab tier: conditioner inputs of up to 128 columns; deep conditioners of up to 128 units')
@@ -378,7 +379,7 @@ class Coupling(Transform):
             if dim == 1:
                 cond = np.zeros(1, dtype=bool)                                       # coupling.py:62-63
             P = sp.params_per_element
-            rel = slab_slot_rows(len(live), sp.n_bins, False)                        # slot -> row of the compact (live) parameter block
+            rel = slab_slot_rows(len(live), sp.n_bins, cubic)                        # slot -> row of the compact (live) parameter block
             rows_np = (live[:, None] * P + np.arange(P)[None, :]).reshape(-1)        # spline.py:82-86
             glob = np.where(rel >= 0, rows_np[np.clip(rel, 0, len(rows_np) - 1)], -1).astype(np.int32)
             hid = np.full(_ceil32(H) * 32, -1, dtype=np.int32)
@@ -408,8 +409,9 @@ class Coupling(Transform):
         sp = self.transform
         if debug.on('STRIBOR_SPLINE_NO_SLAB_FWD') or _hip.get_gemm_precision() != 'fast' or x2.dtype != torch.float32:
             raise NotImplementedError('slab tier: fp32 rows, the default arithmetic')
-        if 1e-3 * sp.n_bins > 1.0:
-            raise ValueError('Minimal bin width too large for the number of bins')      # rational_quadratic_spline.py:96-97
+        cubic = sp.spline_type == 'cubic'
+        if (1e-2 if cubic else 1e-3) * sp.n_bins > 1.0:
+            raise ValueError('Minimal bin width too large for the number of bins')      # rational_quadratic_spline.py:96-97, cubic_spline.py:93-96
         n, d = x2.shape
         dev = x2.device
         ld = 0 if lat2 is None else lat2.shape[1]
@@ -458,9 +460,11 @@ class Coupling(Transform):
         ldj = torch.empty(n, dtype=torch.float32, device=dev) if want_ldj else None
         with _hip.device_of(x2):
             sc = _hip.scratch(dev, lib.sx_rqs_slab_fwd_scratch_floats(n, n_live)) if want_ldj else None
+        # cubic splines: a coupling's inverse log-det is MINUS the FORWARD log-det at the inverted point (flow.py:42-47): reverse = 2
+        rev = (2 if (cubic and want_ldj) else 1) if reverse else 0
         _hip.call('sx_rqs_slab_fwd', x2, x2.data_ptr(), h.data_ptr(), ld_h, H, packs.data_ptr(), y.data_ptr(), _hip.ptr(ldj),
                   _hip.ptr(live_idx), live_start, n_live, sp.n_bins, float(sp.lower), float(sp.upper), float(sp.lower),
-                  float(sp.upper), n, d, int(bool(reverse)), float(ldj_scale), 0, frag, _hip.ptr(sc), flag)
+                  float(sp.upper), n, d, rev, float(ldj_scale), 0, frag, int(cubic), _hip.ptr(sc), flag)
         return y, ldj
 
     # ---- training (autograd): spline couplings, inverse direction --------------------------------------------------

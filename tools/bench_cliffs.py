@@ -37,6 +37,8 @@ def main():
         cases.append(('rqs', 64, 64, K))
     cases.append(('rqs', 64, 160, 16))
     cases.append(('rqs', 64, 256, 16))
+    cases.append(('cubic', 64, 64, 16))
+    cases.append(('cubic', 64, 160, 16))
     with torch.no_grad():
         for kind, dim, hidden, K in cases:
             torch.manual_seed(0)
@@ -45,12 +47,12 @@ def main():
                 desc = [{'kind': 'coupling_affine', 'dim': dim, 'hidden': [hidden], 'mask': m, 'latent_dim': 0} for m in masks]
             else:
                 desc = [{'kind': 'coupling_rqs', 'dim': dim, 'hidden': [hidden], 'mask': m, 'latent_dim': 0, 'n_bins': K, 'lower': -3,
-                         'upper': 3} for m in masks]
+                         'upper': 3, 'spline_type': 'cubic' if kind == 'cubic' else 'quadratic'} for m in masks]
             flow = fd.build_flow(st, desc, dim).to(dev)
             x = torch.randn(ROWS, dim, device=dev)
             fused = flow._fused_program(True, dim, 0, dev) is not None
             tier = 'one launch' if fused else 'layer by layer'
-            if not fused and kind == 'rqs':
+            if not fused and kind in ('rqs', 'cubic'):
                 try:                            # the slab forward tier (hidden layers beyond 128 units): two launches per layer
                     flow.transforms[0]._spline_slab_plan(dim, 0, dev)
                     tier = 'slab forward'
