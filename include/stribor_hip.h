@@ -161,7 +161,7 @@ int sx_rqs_forward_bwd(const float *x, const float *gout, const float *gldj, con
  * mode (as sx_rqs_inverse_bwd) fused with the last conditioner layer  params = h W2^T + b2  and that layer's backward.
  * A workgroup owns a slab of W2 -- the 3K-1 rows of two transformed columns -- over a range of rows (sx_rqs_slab.hip).
  *   x, gout [n_rows, dim], gldj [n_rows]: as sx_rqs_inverse_bwd;  h [n_rows, ld_h]: last hidden activation (`hidden` <= 128
- *   features; beyond 64 a workgroup holds one slab and runs one wave per SIMD, and gh must not be NULL);  n_bins <= 16.
+ *   features; beyond 64 a workgroup holds one slab and runs one wave per SIMD);  n_bins <= 16.
  *   xout: NULL for rational-quadratic splines.  Not NULL: MONOTONE CUBIC splines (cubic_spline.py:21-251; as
  *   sx_cubic_inverse_bwd: xout [n_rows, dim] is the inverse pass's output, domain [left, right] on both sides, 2K+2 parameters
  *   per element: slots 32 t + R of tile 2 carry the two boundary-derivative parameters at (R&3) + 4 (R>>3) = 0, 1).
@@ -202,7 +202,7 @@ int sx_rqs_slab_bwd(const float *x, const float *gout, const float *gldj, const 
  *   cond_mask: HOST pointer, 2 words: bit c of word t = column 32 t + c is a conditioning column.
  *   dW1 [hidden, ldw] and db1 [hidden] are ACCUMULATED into (zero them); col_map[ceil(dim/32)*32]: column -> column of dW1, or -1
  *   (transformed columns: their weights do not exist in W1m).  scratch: sx_rqs_slab_l1_scratch_floats(dim, hidden) floats.
- *   dim, hidden <= 64. */
+ *   dim <= 64, hidden <= 128. */
 size_t sx_rqs_slab_l1_scratch_floats(int32_t dim, int32_t hidden);
 int sx_rqs_slab_l1_bwd(const float *slab_scratch, const float *h, int64_t ld_h, int32_t hidden, const float *x, const float *gout,
                        const float *w1t, const uint32_t *cond_mask, float *gx, float *dW1, int64_t ldw, float *db1,

@@ -465,8 +465,9 @@ struct l1_args {
     int n_groups, n_chunks, dim, H;
     uint32_t cond_mask[2];        // bit c of word t: column 32 t + c is a conditioning column (receives gout + dz)
 };
+// (HT = 3, 4: the HT x XT accumulator tiles + the partial sums need more than 256 registers -- one workgroup per CU)
 template <int HT, int XT>
-__global__ __launch_bounds__(256, 2) void rqs_slab_l1_bwd_kernel(const l1_args k) {
+__global__ __launch_bounds__(256, HT <= 2 ? 2 : 1) void rqs_slab_l1_bwd_kernel(const l1_args k) {
     constexpr int N1 = 32 * XT, E1 = 32 * HT * N1 + 32 * HT;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     {
@@ -1354,7 +1355,6 @@ extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *g
     SX_REQUIRE(dim > 0 && n_live > 0 && n_live <= dim && n_rows >= 0, "sx_rqs_slab_bwd: bad sizes");
     SX_REQUIRE(n_bins >= 1 && n_bins <= 16, "sx_rqs_slab_bwd: n_bins must be in 1..16 (got %d)", n_bins);
     SX_REQUIRE(hidden >= 1 && hidden <= 128, "sx_rqs_slab_bwd: hidden width must be in 1..128 (got %d)", hidden);
-    SX_REQUIRE(gh != nullptr || hidden <= 64, "sx_rqs_slab_bwd: sx_rqs_slab_l1_bwd (gh = NULL) holds hidden layers of up to 64 units");
     SX_REQUIRE(n_rows < ((int64_t)1 << 36), "sx_rqs_slab_bwd: too many rows");
     SX_REQUIRE(right > left && top > bottom, "sx_rqs_slab_bwd: empty domain");
     SX_REQUIRE(((uintptr_t)w_fwd & 15) == 0 && ((uintptr_t)w_bwd & 15) == 0 && ((uintptr_t)scratch & 15) == 0,
@@ -1552,7 +1552,7 @@ extern "C" int sx_rqs_slab_hidden(const float *x, const float *latent, const flo
 }
 
 extern "C" size_t sx_rqs_slab_l1_scratch_floats(int32_t dim, int32_t hidden) {
-    if (dim < 1 || dim > 64 || hidden < 1 || hidden > 64) return 0;
+    if (dim < 1 || dim > 64 || hidden < 1 || hidden > 128) return 0;
     const int HT = (hidden + 31) / 32, XT = (dim + 31) / 32;
     return (size_t)512 * (32 * HT * 32 * XT + 32 * HT);
 }
@@ -1562,15 +1562,15 @@ extern "C" int sx_rqs_slab_l1_bwd(const float *slab_scratch, const float *h, int
                                   int64_t ldw, float *db1, const int32_t *col_map, int32_t n_live, int64_t n_rows, int32_t dim,
                                   const float *scale, float *scratch, uint32_t *err_flag, void *stream) {
     SX_REQUIRE(slab_scratch && h && x && gout && w1t && cond_mask && gx && dW1 && db1 && scratch, "sx_rqs_slab_l1_bwd: null pointer");
-    SX_REQUIRE(dim >= 1 && dim <= 64 && hidden >= 1 && hidden <= 64 && n_live >= 1 && n_rows >= 0,
-               "sx_rqs_slab_l1_bwd: dim and hidden must be in 1..64");
+    SX_REQUIRE(dim >= 1 && dim <= 64 && hidden >= 1 && hidden <= 128 && n_live >= 1 && n_rows >= 0,
+               "sx_rqs_slab_l1_bwd: dim must be in 1..64, hidden in 1..128");
     SX_REQUIRE(((uintptr_t)w1t & 15) == 0 && ((uintptr_t)slab_scratch & 15) == 0, "sx_rqs_slab_l1_bwd: 16-byte alignment");
     if (n_rows == 0) return SX_OK;
     hipStream_t st = sx_stream(stream);
     const int HT = (hidden + 31) / 32, XT = (dim + 31) / 32;
     const int n_slabs = (n_live + 1) / 2;
     const int n_chunks = (int)((n_rows + 31) / 32);
-    const slab_shape pl = slab_plan(n_slabs, n_chunks);
+    const slab_shape pl = slab_plan(n_slabs, n_chunks, HT);
     l1_args k;
     k.part = slab_scratch; k.h = h; k.x = x; k.gout = gout; k.w1t = w1t; k.gx = gx; k.w_part = scratch; k.scale = scale;
     k.flags = err_flag; k.n_rows = n_rows; k.ld_h = ld_h; k.n_groups = pl.n_groups; k.n_chunks = n_chunks; k.dim = dim; k.H = hidden;
@@ -1581,7 +1581,8 @@ extern "C" int sx_rqs_slab_l1_bwd(const float *slab_scratch, const float *h, int
     const int E1 = 32 * HT * 32 * XT + 32 * HT;
     const size_t lds = lds_need > (size_t)E1 * sizeof(float) ? lds_need : (size_t)E1 * sizeof(float);
 #define SX_L1(HT_, XT_) hipLaunchKernelGGL((rqs_slab_l1_bwd_kernel<HT_, XT_>), dim3(grid), dim3(256), lds, st, k)
-    if (HT == 1 && XT == 1) SX_L1(1, 1); else if (HT == 1) SX_L1(1, 2); else if (XT == 1) SX_L1(2, 1); else SX_L1(2, 2);
+    if (HT == 1 && XT == 1) SX_L1(1, 1); else if (HT == 1) SX_L1(1, 2); else if (HT == 2 && XT == 1) SX_L1(2, 1); else if (HT == 2) SX_L1(2, 2);
+    else if (HT == 3 && XT == 1) SX_L1(3, 1); else if (HT == 3) SX_L1(3, 2); else if (XT == 1) SX_L1(4, 1); else SX_L1(4, 2);
 #undef SX_L1
     SX_LAUNCH_CHECK();
     return sx_wgrad_reduce(scratch, grid, 32 * HT, 32 * XT, dW1, ldw, db1, hidden, dim, nullptr, col_map, stream);

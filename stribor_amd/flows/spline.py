@@ -228,7 +228,7 @@ class RQSCouplingSlabL1(torch.autograd.Function):
 
     @staticmethod
     def eligible(dim: int, hidden: int, n_bins: int) -> bool:
-        return dim <= 64 and hidden <= 64 and RQSCouplingSlab.eligible(hidden, n_bins)
+        return dim <= 64 and RQSCouplingSlab.eligible(hidden, n_bins)
 
     @staticmethod
     def forward(ctx, x2, W1, b1, W2, b2, mask_t, evaluate, plan, live_idx, live_start, n_live, n_bins, lower, upper, cubic=False):
