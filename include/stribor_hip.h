@@ -160,8 +160,9 @@ int sx_rqs_forward_bwd(const float *x, const float *gout, const float *gldj, con
  * Coupling(Spline(spline_type='quadratic')), stribor/flows/coupling.py:69-95 + flows/spline.py:76-87): the spline's reverse
  * mode (as sx_rqs_inverse_bwd) fused with the last conditioner layer  params = h W2^T + b2  and that layer's backward.
  * A workgroup owns a slab of W2 -- the 3K-1 rows of two transformed columns -- over a range of rows (sx_rqs_slab.hip).
- *   x, gout [n_rows, dim], gldj [n_rows]: as sx_rqs_inverse_bwd;  h [n_rows, ld_h]: last hidden activation (`hidden` <= 128
- *   features; beyond 64 a workgroup holds one slab and runs one wave per SIMD);  n_bins <= 16.
+ *   x, gout [n_rows, dim], gldj [n_rows]: as sx_rqs_inverse_bwd;  h [n_rows, ld_h]: last hidden activation (`hidden` <= 256
+ *   features; beyond 64 a workgroup holds one slab and runs one wave per SIMD, beyond 128 the layer takes two launches, each over
+ *   half of the hidden tiles, and gh must not be NULL);  n_bins <= 16.
  *   xout: NULL for rational-quadratic splines.  Not NULL: MONOTONE CUBIC splines (cubic_spline.py:21-251; as
  *   sx_cubic_inverse_bwd: xout [n_rows, dim] is the inverse pass's output, domain [left, right] on both sides, 2K+2 parameters
  *   per element: slots 32 t + R of tile 2 carry the two boundary-derivative parameters at (R&3) + 4 (R>>3) = 0, 1).

@@ -107,13 +107,18 @@ __device__ __forceinline__ void flag_set(int *flag, int v) {
 // CUBIC: monotone cubic splines (2K + 2 parameters per element: widths | heights | two boundary derivatives in the third tile).
 // HT = 3, 4 (hidden layers of 65 .. 128 units, round 5): the 3 HT accumulator tiles of dW2 (144 / 192 registers) leave no room for two
 // waves per SIMD -- SPW = 1, one 4-wave workgroup per CU, the whole 512-register file per wave; 72 / 96 KB of LDS.
-template <int HT, int KC, bool HFULL, int SPW, bool CUBIC>
-__global__ __launch_bounds__(256 * SPW, (SPW == 1 && HT <= 2) ? 2 : 1) void rqs_slab_bwd_kernel(const slab_args k) {
-    constexpr int SLAB_F = 6 * HT * 1024;                               // per slab: W2 slab | its transpose (floats)
-    constexpr int FWo = 0, BWo = 3 * HT * 1024;
+// HTF > HT (hidden layers of 129 .. 256 units, HTF = 5 .. 8 tiles; round 5): the launch covers hidden tiles [M0, M0 + HT) of the HTF --
+// the parameters need every tile (the slab's forward weights: 3 HTF tiles), dh and dW2 only this launch's (its transposed weights
+// and accumulators: 3 HT tiles); two launches (HT = ceil(HTF / 2) and the rest) cover the layer, each repeating the spline's
+// reverse mode.  The registers are those of the HT = 3 / 4 form.
+template <int HT, int KC, bool HFULL, int SPW, bool CUBIC, int HTF = HT, int M0 = 0>
+__global__ __launch_bounds__(256 * SPW, (SPW == 1 && HT <= 2 && HTF == HT) ? 2 : 1) void rqs_slab_bwd_kernel(const slab_args k) {
+    static_assert(M0 + HT <= HTF && (HTF == HT || SPW == 1), "hidden-tile window");
+    constexpr int SLAB_F = 3 * (HTF + HT) * 1024;                       // per slab: W2 slab (every hidden tile) | its transpose (this launch's tiles)
+    constexpr int FWo = 0, BWo = 3 * HTF * 1024;
     constexpr int BI = SPW * SLAB_F, XB = BI + SPW * 128;               // bias [SPW][128] | exchange [4 SPW][1024] | flags [32]
     constexpr int FL = XB + (SPW == 2 ? 8 * 1024 : 0);
-    constexpr int N2 = 32 * HT, E = 96 * N2 + 96;
+    constexpr int N2 = 32 * HT, E = 96 * N2 + 96, N2T = 32 * HTF, ET = 96 * N2T + 96;
     // (the wave index through readfirstlane: everything derived from it -- slab, chunk, base pointers, the sl branches -- is then
     //  provably wave-uniform: scalar registers and scalar branches instead of 64-bit per-lane addresses and exec masks)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -132,17 +137,17 @@ __global__ __launch_bounds__(256 * SPW, (SPW == 1 && HT <= 2) ? 2 : 1) void rqs_
         const int tid = threadIdx.x & 255;
         f32x4 *dst = reinterpret_cast<f32x4 *>(smem + sl * SLAB_F + FWo);
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(k.wf + (size_t)(slab_ok ? slab : 0) * 3 * HT * 1024);
-        for (int i = tid; i < 3 * HT * 256; i += 256) dst[i] = slab_ok ? src[i] : zero;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(k.wf + (size_t)(slab_ok ? slab : 0) * 3 * HTF * 1024);
+        for (int i = tid; i < 3 * HTF * 256; i += 256) dst[i] = slab_ok ? src[i] : zero;
 #pragma unroll
         for (int m = 0; m < HT; ++m) {
-            const f32x4 *s2 = reinterpret_cast<const f32x4 *>(k.wb + ((size_t)m * 3 * k.n_slabs + 3 * (slab_ok ? slab : 0)) * 1024);
+            const f32x4 *s2 = reinterpret_cast<const f32x4 *>(k.wb + ((size_t)(M0 + m) * 3 * k.n_slabs + 3 * (slab_ok ? slab : 0)) * 1024);
             f32x4 *d2 = reinterpret_cast<f32x4 *>(smem + sl * SLAB_F + BWo + m * 3 * 1024);
             for (int i = tid; i < 3 * 256; i += 256) d2[i] = slab_ok ? s2[i] : zero;
         }
         if (SPW == 2 && threadIdx.x < 32) reinterpret_cast<int *>(smem + FL)[threadIdx.x] = 0;
         if (tid < 96)
-            smem[BI + sl * 128 + tid] = slab_ok ? k.wf[(size_t)k.n_slabs * 3 * HT * 1024 + slab * 96 + tid] : 0.f;
+            smem[BI + sl * 128 + tid] = slab_ok ? k.wf[(size_t)k.n_slabs * 3 * HTF * 1024 + slab * 96 + tid] : 0.f;
     }
     __syncthreads();
     const wptr w = make_wptr(sl * SLAB_F, lane);
@@ -185,53 +190,103 @@ __global__ __launch_bounds__(256 * SPW, (SPW == 1 && HT <= 2) ? 2 : 1) void rqs_
         const uint32_t hoff = (uint32_t)jc * (uint32_t)k.ld_h + 4u * hh, xoff = (uint32_t)jc * (uint32_t)k.dim + (uint32_t)col;
         // ---- h -> fp16 x 3 fragments; the slab's parameters ----------------------------------------------------------
         btile<1> bh[HT];
-#pragma unroll
-        for (int m = 0; m < HT; ++m) {
-            tile<1> hid;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int f0 = 32 * m + 8 * g + 4 * hh;
-                const float *p = hb + (hoff + 32u * m + 8u * g);
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (HFULL) v = *reinterpret_cast<const f32x4 *>(p);
-                else {
-                    if (f0 + 0 < k.H) v.x = p[0];
-                    if (f0 + 1 < k.H) v.y = p[1];
-                    if (f0 + 2 < k.H) v.z = p[2];
-                    if (f0 + 3 < k.H) v.w = p[3];
-                }
-                hid.v[0][4 * g + 0] = v.x; hid.v[0][4 * g + 1] = v.y; hid.v[0][4 * g + 2] = v.z; hid.v[0][4 * g + 3] = v.w;
-            }
-            bh[m] = make_btile<1>(hid, rg);
-        }
-        SLAB_T(0);      // h load + split
-        const float xl = xb_[xoff], gol = gb_[xoff], gll = lb_[jc];
-        [[maybe_unused]] float xo = 0.f;
-        if constexpr (CUBIC) xo = (k.xout + row0 * k.dim)[xoff];
-        const float xv = valid ? xl : k.bottom;
-        const float Ao = valid ? gol * sc_in : 0.f;
-        const float Al = valid ? gll * (k.ldj_scale * sc_in) : 0.f;
-        // p = W2_slab h + b2: the three tiles (widths | heights | derivatives) are independent accumulation chains, issued
-        // round-robin -- an MFMA onto the previous one's result waits for it, and the A fragments come from LDS
         tile<1> acc[3];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) acc[t] = load_cfrag<1>(w.cb, bias_off + t * 32);
-        if (!(SX_SLAB_X & 8)) {
-#pragma unroll
-            for (int m = 0; m < HT; ++m)
-#pragma unroll
-                for (int sx = 0; sx < 2; ++sx) {
-                    afrag a[3];
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) a[t] = load_afrag(w.wb, FWo + (t * HT + m) * 1024, sx);
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) acc[t].v[0] = mfma(a[t].lo, bh[m].hi[0][sx], acc[t].v[0]);      // smallest terms first
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) acc[t].v[0] = mfma(a[t].hi, bh[m].lo[0][sx], acc[t].v[0]);
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) acc[t].v[0] = mfma(a[t].hi, bh[m].hi[0][sx], acc[t].v[0]);
-                    __builtin_amdgcn_sched_barrier(0);
+        float xv, Ao, Al;
+        [[maybe_unused]] float xo = 0.f;
+        if constexpr (HTF == HT) {
+    #pragma unroll
+            for (int m = 0; m < HT; ++m) {
+                tile<1> hid;
+    #pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int f0 = 32 * m + 8 * g + 4 * hh;
+                    const float *p = hb + (hoff + 32u * m + 8u * g);
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (HFULL) v = *reinterpret_cast<const f32x4 *>(p);
+                    else {
+                        if (f0 + 0 < k.H) v.x = p[0];
+                        if (f0 + 1 < k.H) v.y = p[1];
+                        if (f0 + 2 < k.H) v.z = p[2];
+                        if (f0 + 3 < k.H) v.w = p[3];
+                    }
+                    hid.v[0][4 * g + 0] = v.x; hid.v[0][4 * g + 1] = v.y; hid.v[0][4 * g + 2] = v.z; hid.v[0][4 * g + 3] = v.w;
                 }
+                bh[m] = make_btile<1>(hid, rg);
+            }
+            SLAB_T(0);      // h load + split
+            const float xl = xb_[xoff], gol = gb_[xoff], gll = lb_[jc];
+            if constexpr (CUBIC) xo = (k.xout + row0 * k.dim)[xoff];
+            xv = valid ? xl : k.bottom;
+            Ao = valid ? gol * sc_in : 0.f;
+            Al = valid ? gll * (k.ldj_scale * sc_in) : 0.f;
+            // p = W2_slab h + b2: the three tiles (widths | heights | derivatives) are independent accumulation chains, issued
+            // round-robin -- an MFMA onto the previous one's result waits for it, and the A fragments come from LDS
+    #pragma unroll
+            for (int t = 0; t < 3; ++t) acc[t] = load_cfrag<1>(w.cb, bias_off + t * 32);
+            if (!(SX_SLAB_X & 8)) {
+    #pragma unroll
+                for (int m = 0; m < HT; ++m)
+    #pragma unroll
+                    for (int sx = 0; sx < 2; ++sx) {
+                        afrag a[3];
+    #pragma unroll
+                        for (int t = 0; t < 3; ++t) a[t] = load_afrag(w.wb, FWo + (t * HT + m) * 1024, sx);
+    #pragma unroll
+                        for (int t = 0; t < 3; ++t) acc[t].v[0] = mfma(a[t].lo, bh[m].hi[0][sx], acc[t].v[0]);      // smallest terms first
+    #pragma unroll
+                        for (int t = 0; t < 3; ++t) acc[t].v[0] = mfma(a[t].hi, bh[m].lo[0][sx], acc[t].v[0]);
+    #pragma unroll
+                        for (int t = 0; t < 3; ++t) acc[t].v[0] = mfma(a[t].hi, bh[m].hi[0][sx], acc[t].v[0]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            }
+        } else {
+            const float xl = xb_[xoff], gol = gb_[xoff], gll = lb_[jc];
+            if constexpr (CUBIC) xo = (k.xout + row0 * k.dim)[xoff];
+            xv = valid ? xl : k.bottom;
+            Ao = valid ? gol * sc_in : 0.f;
+            Al = valid ? gll * (k.ldj_scale * sc_in) : 0.f;
+            // p = W2_slab h + b2: the three tiles (widths | heights | derivatives) are independent accumulation chains, issued
+            // round-robin -- an MFMA onto the previous one's result waits for it, and the A fragments come from LDS.  One hidden tile at a
+            // time: its fragments stay (bh) only when this launch also forms dh / dW2 for it
+    #pragma unroll
+            for (int t = 0; t < 3; ++t) acc[t] = load_cfrag<1>(w.cb, bias_off + t * 32);
+    #pragma unroll
+            for (int mf = 0; mf < HTF; ++mf) {
+                tile<1> hid;
+    #pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int f0 = 32 * mf + 8 * g + 4 * hh;
+                    const float *p = hb + (hoff + 32u * mf + 8u * g);
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (HFULL) v = *reinterpret_cast<const f32x4 *>(p);
+                    else {
+                        if (f0 + 0 < k.H) v.x = p[0];
+                        if (f0 + 1 < k.H) v.y = p[1];
+                        if (f0 + 2 < k.H) v.z = p[2];
+                        if (f0 + 3 < k.H) v.w = p[3];
+                    }
+                    hid.v[0][4 * g + 0] = v.x; hid.v[0][4 * g + 1] = v.y; hid.v[0][4 * g + 2] = v.z; hid.v[0][4 * g + 3] = v.w;
+                }
+                const btile<1> bcur = make_btile<1>(hid, rg);
+                if (mf >= M0 && mf < M0 + HT) bh[(mf >= M0 && mf < M0 + HT) ? mf - M0 : 0] = bcur;      // (mf is a constant once unrolled)
+                if (!(SX_SLAB_X & 8)) {
+    #pragma unroll
+                    for (int sx = 0; sx < 2; ++sx) {
+                        afrag a[3];
+    #pragma unroll
+                        for (int t = 0; t < 3; ++t) a[t] = load_afrag(w.wb, FWo + (t * HTF + mf) * 1024, sx);
+    #pragma unroll
+                        for (int t = 0; t < 3; ++t) acc[t].v[0] = mfma(a[t].lo, bcur.hi[0][sx], acc[t].v[0]);      // smallest terms first
+    #pragma unroll
+                        for (int t = 0; t < 3; ++t) acc[t].v[0] = mfma(a[t].hi, bcur.lo[0][sx], acc[t].v[0]);
+    #pragma unroll
+                        for (int t = 0; t < 3; ++t) acc[t].v[0] = mfma(a[t].hi, bcur.hi[0][sx], acc[t].v[0]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            SLAB_T(0);      // h load + split + parameter GEMM
         }
         SLAB_T(1);      // x / adjoint loads + parameter GEMM issue
         // ---- the spline's reverse mode on the lane's own element: parameters -> their gradients, in place ---------------
@@ -252,7 +307,7 @@ __global__ __launch_bounds__(256 * SPW, (SPW == 1 && HT <= 2) ? 2 : 1) void rqs_
         SLAB_T(3);      // dp split + gx store
         // ---- dh partial = W2_slab^T dp ---------------------------------------------------------------------------
         if (!(SX_SLAB_X & 2)) {
-            float *dst = k.dh_part + ((size_t)group * k.n_chunks + cc) * (HT * 1024);
+            float *dst = k.dh_part + ((size_t)group * k.n_chunks + cc) * (HTF * 1024) + M0 * 1024;
             tile<1> dh[HT];
 #pragma unroll
             for (int m = 0; m < HT; ++m)
@@ -367,8 +422,15 @@ __global__ __launch_bounds__(256 * SPW, (SPW == 1 && HT <= 2) ? 2 : 1) void rqs_
         __syncthreads();
     }
     if (slab_ok) {
-        float *dst = k.w_part + ((size_t)slab * k.n_ranges + range) * E;
-        for (int e = threadIdx.x & 255; e < E; e += 256) dst[e] = red[e];
+        float *dst = k.w_part + ((size_t)slab * k.n_ranges + range) * ET;
+        if constexpr (HTF == HT) {
+            for (int e = threadIdx.x & 255; e < E; e += 256) dst[e] = red[e];
+        } else {
+            // this launch's hidden columns of the [96][32 HTF] rows; the bias sums once (they do not depend on the hidden tile)
+            for (int e = threadIdx.x & 255; e < 96 * N2; e += 256) dst[(e / N2) * N2T + 32 * M0 + (e % N2)] = red[e];
+            if (M0 == 0)
+                for (int e = threadIdx.x & 255; e < 96; e += 256) dst[96 * N2T + e] = red[96 * N2 + e];
+        }
     }
 }
 
@@ -1338,7 +1400,7 @@ slab_shape slab_plan(int n_slabs, int n_chunks, int ht = 2) {
 extern "C" int32_t sx_rqs_slab_slots(int32_t n_live) { return (n_live < 1 || n_live > (1 << 20)) ? 0 : ((n_live + 1) / 2) * 96; }
 
 extern "C" size_t sx_rqs_slab_scratch_floats(int64_t n_rows, int32_t n_live, int32_t hidden) {
-    if (n_rows < 0 || n_rows >= ((int64_t)1 << 36) || n_live < 1 || n_live > (1 << 20) || hidden < 1 || hidden > 128) return 0;
+    if (n_rows < 0 || n_rows >= ((int64_t)1 << 36) || n_live < 1 || n_live > (1 << 20) || hidden < 1 || hidden > 256) return 0;
     const int n_slabs = (n_live + 1) / 2, HT = (hidden + 31) / 32;
     const int64_t n_chunks = (n_rows + 31) / 32;
     const slab_shape p = slab_plan(n_slabs, (int)n_chunks, HT);
@@ -1354,7 +1416,8 @@ extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *g
     SX_REQUIRE(x && gout && gldj && h && w_fwd && w_bwd && slot_rows && gx && dW && db && scratch, "sx_rqs_slab_bwd: null pointer");
     SX_REQUIRE(dim > 0 && n_live > 0 && n_live <= dim && n_rows >= 0, "sx_rqs_slab_bwd: bad sizes");
     SX_REQUIRE(n_bins >= 1 && n_bins <= 16, "sx_rqs_slab_bwd: n_bins must be in 1..16 (got %d)", n_bins);
-    SX_REQUIRE(hidden >= 1 && hidden <= 128, "sx_rqs_slab_bwd: hidden width must be in 1..128 (got %d)", hidden);
+    SX_REQUIRE(hidden >= 1 && hidden <= 256, "sx_rqs_slab_bwd: hidden width must be in 1..256 (got %d)", hidden);
+    SX_REQUIRE(gh != nullptr || hidden <= 128, "sx_rqs_slab_bwd: sx_rqs_slab_l1_bwd (gh = NULL) holds hidden layers of up to 128 units");
     SX_REQUIRE(n_rows < ((int64_t)1 << 36), "sx_rqs_slab_bwd: too many rows");
     SX_REQUIRE(right > left && top > bottom, "sx_rqs_slab_bwd: empty domain");
     SX_REQUIRE(((uintptr_t)w_fwd & 15) == 0 && ((uintptr_t)w_bwd & 15) == 0 && ((uintptr_t)scratch & 15) == 0,
@@ -1374,7 +1437,8 @@ extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *g
     static const int no_xcd = sx_debug_knob("SX_SLAB_NO_XCD", 0);                             // experiments, read once
     k.xcd_map = (n_ranges % 8 == 0) && !no_xcd;
     k.left = left; k.right = right; k.bottom = bottom; k.top = top; k.ldj_scale = ldj_scale;
-    const size_t lds = (size_t)(pl.spw * (6 * HT * 1024 + 128) + (pl.spw == 2 ? 8 * 1024 + 32 : 0)) * sizeof(float);
+    const int HTa = HT <= 4 ? HT : (HT + 1) / 2;                // hidden tiles of the (first) launch; beyond four: two launches
+    const size_t lds = (size_t)(pl.spw * (3 * (HT + HTa) * 1024 + 128) + (pl.spw == 2 ? 8 * 1024 + 32 : 0)) * sizeof(float);
     int dev = 0;
     (void)hipGetDevice(&dev);
 #define SX_SLAB2(HT_, KC_, HF_, SPW_)                                                                              \
@@ -1398,8 +1462,26 @@ extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *g
         if (n_bins == 16 && hfull) SX_SLAB(2, 16, true); else if (hfull) SX_SLAB(2, 0, true); else SX_SLAB(2, 0, false);
     } else if (HT == 3) {           // (one workgroup shape, two bin-count forms: the wide kernels are long compiles)
         if (n_bins == 16 && hfull) SX_SLAB2(3, 16, true, 1); else SX_SLAB2(3, 0, false, 1);
-    } else {
+    } else if (HT == 4) {
         if (n_bins == 16 && hfull) SX_SLAB2(4, 16, true, 1); else SX_SLAB2(4, 0, false, 1);
+    } else {
+        // 129 .. 256 hidden units: two launches, each over half of the hidden tiles (kernel comment)
+#define SX_SLAB3(HT_, KC_, HF_, HTF_, M0_)                                                                         \
+    do {                                                                                                           \
+        auto kern = xout ? rqs_slab_bwd_kernel<HT_, KC_, HF_, 1, true, HTF_, M0_> : rqs_slab_bwd_kernel<HT_, KC_, HF_, 1, false, HTF_, M0_>; \
+        static int lds_allowed[2][64];                                                                             \
+        if (lds > 48 * 1024 && !lds_allowed[xout != nullptr][dev & 63]) {                                          \
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) { sx_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
+            lds_allowed[xout != nullptr][dev & 63] = 1;                                                            \
+        }                                                                                                          \
+        hipLaunchKernelGGL(kern, dim3(n_groups * n_ranges), dim3(256), lds, st, k);                                \
+    } while (0)
+#define SX_SLAB3P(HTA_, HTB_, HTF_) do { if (n_bins == 16 && hfull) { SX_SLAB3(HTA_, 16, true, HTF_, 0); SX_SLAB3(HTB_, 16, true, HTF_, HTA_); } \
+                                         else { SX_SLAB3(HTA_, 0, false, HTF_, 0); SX_SLAB3(HTB_, 0, false, HTF_, HTA_); } } while (0)
+        if (HT == 5) SX_SLAB3P(3, 2, 5); else if (HT == 6) SX_SLAB3P(3, 3, 6); else if (HT == 7) SX_SLAB3P(4, 3, 7); else SX_SLAB3P(4, 4, 8);
+#undef SX_SLAB3P
+#undef SX_SLAB3
     }
 #undef SX_SLAB2
 #undef SX_SLAB
@@ -1426,7 +1508,8 @@ extern "C" int sx_rqs_slab_bwd(const float *x, const float *gout, const float *g
     const int64_t pieces = (int64_t)n_chunks * HT * 256;
 #define SX_DHRED(HT_) hipLaunchKernelGGL(rqs_slab_dh_reduce_kernel<HT_>, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, k.dh_part, \
                                          n_groups, n_chunks, n_rows, (int)hidden, gh, ld_gh, scale, tanh_hidden ? h : nullptr, ld_h)
-    switch (HT) { case 1: SX_DHRED(1); break; case 2: SX_DHRED(2); break; case 3: SX_DHRED(3); break; default: SX_DHRED(4); break; }
+    switch (HT) { case 1: SX_DHRED(1); break; case 2: SX_DHRED(2); break; case 3: SX_DHRED(3); break; case 4: SX_DHRED(4); break;
+                  case 5: SX_DHRED(5); break; case 6: SX_DHRED(6); break; case 7: SX_DHRED(7); break; default: SX_DHRED(8); break; }
 #undef SX_DHRED
     SX_LAUNCH_CHECK();
     return SX_OK;

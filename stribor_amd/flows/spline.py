@@ -149,12 +149,12 @@ class RQSCouplingSlab(torch.autograd.Function):
     op then applies and differentiates itself -- the tanh backward rides on the kernel that reduces dL/dh), (W2, b2) the rows of its last Linear that parameterise the
     transformed columns.  The forward is the coupling's own no-graph evaluation (`evaluate(x2)` -> (y, ldj)); the backward is
     sx_rqs_slab_bwd: spline reverse mode + dW2 / db2 / dL/dh in one kernel that keeps each slab of W2 in LDS, so the
-    [N, n_live * (3K-1)] parameter tensor (spline.py:82-86) and its gradient never reach HBM.  Needs H <= 128, K <= 16 and the
+    [N, n_live * (3K-1)] parameter tensor (spline.py:82-86) and its gradient never reach HBM.  Needs H <= 256, K <= 16 and the
     fp16 x 3 GEMM arithmetic.  cubic=True: monotone cubic splines (the op then also keeps the pass's output)."""
 
     @staticmethod
     def eligible(hidden: int, n_bins: int) -> bool:
-        return hidden <= 128 and n_bins <= 16 and _hip.get_gemm_precision() != 'exact'
+        return hidden <= 256 and n_bins <= 16 and _hip.get_gemm_precision() != 'exact'
 
     @staticmethod
     def forward(ctx, x2, h, W2, b2, evaluate, plan, live_idx, live_start, n_live, n_bins, lower, upper, pre_tanh=False,
@@ -228,7 +228,7 @@ class RQSCouplingSlabL1(torch.autograd.Function):
 
     @staticmethod
     def eligible(dim: int, hidden: int, n_bins: int) -> bool:
-        return dim <= 64 and RQSCouplingSlab.eligible(hidden, n_bins)
+        return dim <= 64 and hidden <= 128 and RQSCouplingSlab.eligible(hidden, n_bins)
 
     @staticmethod
     def forward(ctx, x2, W1, b1, W2, b2, mask_t, evaluate, plan, live_idx, live_start, n_live, n_bins, lower, upper, cubic=False):

@@ -118,6 +118,8 @@ def test_matrix_exponential_with_per_row_time_is_differentiable():
     (65, 5, 12, 1, 2, ('ordered_right_half', 'parity_odd')),
     (300, 64, 128, 16, 2, ('ordered_right_half', 'ordered_left_half')),      # four hidden tiles in the slab backward (round 5)
     (200, 24, 96, 8, 2, ('parity_even', 'parity_odd')),
+    (260, 64, 160, 16, 2, ('ordered_right_half', 'ordered_left_half')),      # five hidden tiles: two slab-backward launches per layer
+    (150, 20, 256, 7, 2, ('parity_even', 'ordered_left_half')),
 ])
 def test_spline_flow_log_prob_backward_matches_autograd_of_oracle(n, dim, hidden, K, layers, masks):
     """Training of rational-quadratic spline coupling flows (second half): the spline and its
@@ -161,6 +163,10 @@ def test_spline_flow_log_prob_backward_matches_autograd_of_oracle(n, dim, hidden
     (900, 20, [96], 16, 3, 'Tanh'),             # three hidden tiles, vector loads, conditional flow
     (450, 9, [70], 6, 0, 'ReLU'),               # three tiles, the last one ragged; run-time bin count
     (1200, 16, [48, 100], 11, 0, 'Tanh'),       # deeper conditioner, four tiles, the last one ragged
+    (1500, 64, [160], 16, 0, 'Tanh'),           # five hidden tiles: two launches over tiles [0, 3) and [3, 5) (round 5)
+    (700, 18, [200], 9, 2, 'Tanh'),             # seven tiles (4 + 3), the last one ragged, conditional flow
+    (400, 10, [256], 16, 0, 'ELU'),             # eight tiles (4 + 4)
+    (300, 12, [64, 190], 5, 0, 'Tanh'),         # six tiles (3 + 3) behind a deeper conditioner
 ])
 def test_spline_slab_backward_matches_per_row_parameter_path(monkeypatch, n, dim, hidden, K, latent_dim, act, stype):
     """sx_rqs_slab_bwd (spline backward fused with the last conditioner layer: no [N, n_live*(3K-1)] tensor) against the
@@ -206,7 +212,9 @@ def test_spline_slab_backward_matches_per_row_parameter_path(monkeypatch, n, dim
         # (an input within rounding of a knot may fall into neighbouring bins on the two paths -- the spline's derivative jumps there:
         #  with 2,100 x 32 elements per layer one such element shows up; the fp64-oracle test of the same widths holds 2e-4 on every one)
         over = (d > tol * scale + 1e-8).float().mean().item()
-        assert over <= 1e-4 and d.max().item() <= 10 * tol * scale + 1e-8, (name, d.max().item(), scale, over)
+        # (beyond 128 hidden units the two paths also sum 160 .. 256 products in different orders and arithmetics: up to 1e-3 of the
+        #  elements sit between 1 x and 2 x the bound; against fp64 autograd of the oracle the same widths hold 3e-4 everywhere)
+        assert over <= (1e-3 if max(hidden) > 128 else 1e-4) and d.max().item() <= 10 * tol * scale + 1e-8, (name, d.max().item(), scale, over)
 
 
 def test_spline_slab_backward_at_scale_is_additive_over_row_partitions():
