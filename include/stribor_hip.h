@@ -219,8 +219,8 @@ int sx_rqs_slab_l1_bwd(const float *slab_scratch, const float *h, int64_t ld_h, 
  *   h, h_fragments = 0: [n_rows, ld_h] fp32, `hidden` <= 256 valid features (any conditioner: whatever produced its last hidden
  *   activation); h_fragments = 1: the fragments sx_rqs_slab_hidden wrote (ld_h ignored) -- every slab re-reads h, and in this form
  *   it is neither split into fp16 parts nor range-checked again;
- *   y [n_rows, dim]: ONLY the transformed columns (live_idx / live_start, n_live as sx_rqs_coupling) are written -- the caller
- *   fills the pass-through columns (y = x there);
+ *   y [n_rows, dim]: the transformed columns (live_idx / live_start, n_live as sx_rqs_coupling) are written, and y = x in the
+ *   n_pass columns pass_idx names (device array; the columns the coupling leaves alone; n_pass = 0: the caller fills them);
  *   reverse = 0: forward (bin searched on the widths, x in [left, right]), 1: inverse (heights, [bottom, top]);
  *   ldj (nullable) [n_rows] = (ldj_accumulate ? ldj : 0) + ldj_scale * sum over the transformed columns of log|d y / d x|
  *   (reverse: of the inverse map, as rational_quadratic_spline.py:232-234 returns it), summed in slab order;
@@ -238,7 +238,8 @@ int sx_rqs_slab_hidden(const float *x, const float *latent, const float *w1, flo
                        int32_t latent_dim, int32_t hidden, int32_t act, uint32_t *err_flag, void *stream);
 size_t sx_rqs_slab_fwd_scratch_floats(int64_t n_rows, int32_t n_live);
 int sx_rqs_slab_fwd(const float *x, const float *h, int64_t ld_h, int32_t hidden, const float *w_fwd, float *y, float *ldj,
-                    const int32_t *live_idx, int32_t live_start, int32_t n_live, int32_t n_bins, float left, float right,
+                    const int32_t *live_idx, int32_t live_start, int32_t n_live, const int32_t *pass_idx, int32_t n_pass,
+                    int32_t n_bins, float left, float right,
                     float bottom, float top, int64_t n_rows, int32_t dim, int32_t reverse, float ldj_scale, int32_t ldj_accumulate,
                     int32_t h_fragments, int32_t cubic, float *scratch, uint32_t *err_flag, void *stream);
 

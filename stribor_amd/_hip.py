@@ -113,7 +113,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.sx_rqs_slab_fwd_scratch_floats.restype = C.c_size_t
     lib.sx_rqs_slab_fwd_scratch_floats.argtypes = [i64, i32]
     lib.sx_rqs_slab_fwd.restype = i32
-    lib.sx_rqs_slab_fwd.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, i64, i32, i32, f32, i32, i32, i32, vp, vp, vp]
+    lib.sx_rqs_slab_fwd.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, i32, i32, vp, i32, i32, f32, f32, f32, f32, i64, i32, i32, f32, i32, i32, i32, vp, vp, vp]
     lib.sx_rqs_slab_hidden_floats.restype = C.c_size_t
     lib.sx_rqs_slab_hidden_floats.argtypes = [i64, i32]
     lib.sx_rqs_slab_hidden.restype = i32

@@ -774,9 +774,10 @@ struct slabf_args {
     float *y;                           // [N, dim]: the transformed columns are written
     float *ldj_part;                    // [n_slabs][N] or null
     const int32_t *live_idx;
+    const int32_t *pass_idx;            // the n_pass columns the coupling leaves alone (y = x there), or null: the caller fills them
     uint32_t *flags;
     int64_t n_rows, ld_h;
-    int l0, n_live, K, dim, H, HT, n_slabs, n_chunks, n_ranges, xcd_map, ref_ldj;
+    int l0, n_live, n_pass, K, dim, H, HT, n_slabs, n_chunks, n_ranges, xcd_map, ref_ldj;
     float left, right, bottom, top, log_span;
 };
 
@@ -1155,6 +1156,13 @@ __global__ __launch_bounds__(512, 1) void rqs_slab_fwd_kernel(const slabf_args k
             const int jc = j < n_here ? j : n_here - 1;
             const uint32_t xoff = (uint32_t)jc * (uint32_t)k.dim + (uint32_t)col;
             const float xl = (k.x + row0 * k.dim)[xoff];
+            // pass-through columns: lane (row, half) of slab s copies columns pass_idx[2 s + half], + 2 n_slabs, ... of its row (the row's
+            // lines are in L2 for the slabs of this range anyway; a separate streaming copy of x was 20 us per layer)
+            // The first one is loaded here and stored with the chunk's results (a store right behind its load would expose the load's
+            // latency); masks with more pass-through than transformed columns: the rest in a loop at the end.
+            const bool pdo = k.pass_idx != nullptr && have && j < n_here && ci < k.n_pass;
+            const uint32_t po = pdo ? (uint32_t)j * (uint32_t)k.dim + (uint32_t)k.pass_idx[ci] : 0u;
+            const float pv = pdo ? (k.x + row0 * k.dim)[po] : 0.f;
             const bool has_next = cn < c_end;
             pp.begin(hf0 + ((size_t)(has_next ? cn : c_begin) * HT) * 256, w.wb, w.cb, HT, BI);
             const float xv = valid ? xl : (REV ? k.bottom : k.left);
@@ -1164,6 +1172,13 @@ __global__ __launch_bounds__(512, 1) void rqs_slab_fwd_kernel(const slabf_args k
             else rqs_slab_eval<KC, false>(accE[0], accE[1], accE[2], k.K, xv, k.left, k.right, k.bottom, k.top, out, ljd, pp);
             pp.drain();
             if (valid) (k.y + row0 * k.dim)[xoff] = nan_h ? __builtin_nanf("") : out;
+            if (pdo) {
+                (k.y + row0 * k.dim)[po] = pv;
+                for (int q = ci + 2 * k.n_slabs; q < k.n_pass; q += 2 * k.n_slabs) {
+                    const uint32_t pq = (uint32_t)j * (uint32_t)k.dim + (uint32_t)k.pass_idx[q];
+                    (k.y + row0 * k.dim)[pq] = (k.x + row0 * k.dim)[pq];
+                }
+            }
             if (k.ldj_part != nullptr) {
                 float lsum = valid ? ljd : 0.f;
                 lsum += __shfl_xor(lsum, 32, 64);
@@ -1195,6 +1210,9 @@ __global__ __launch_bounds__(512, 1) void rqs_slab_fwd_kernel(const slabf_args k
         const float *hb = k.h + row0 * k.ld_h;
         const uint32_t hoff = (uint32_t)jc * (uint32_t)k.ld_h + 4u * hh, xoff = (uint32_t)jc * (uint32_t)k.dim + (uint32_t)col;
         const float xl = (k.x + row0 * k.dim)[xoff];
+        const bool pdo = k.pass_idx != nullptr && j < n_here && ci < k.n_pass;      // pass-through columns: see the pipelined loop
+        const uint32_t po = pdo ? (uint32_t)j * (uint32_t)k.dim + (uint32_t)k.pass_idx[ci] : 0u;
+        const float pv = pdo ? (k.x + row0 * k.dim)[po] : 0.f;
         auto load_h = [&](int m, f32x4 (&v)[4]) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -1275,6 +1293,13 @@ __global__ __launch_bounds__(512, 1) void rqs_slab_fwd_kernel(const slabf_args k
         const bool bad = HFRAG ? nan_h : rng_bad_sample(rg, lane);
         any_bad |= rg.bad;
         if (valid) (k.y + row0 * k.dim)[xoff] = bad ? __builtin_nanf("") : out;
+        if (pdo) {
+            (k.y + row0 * k.dim)[po] = pv;
+            for (int q = ci + 2 * k.n_slabs; q < k.n_pass; q += 2 * k.n_slabs) {
+                const uint32_t pq = (uint32_t)j * (uint32_t)k.dim + (uint32_t)k.pass_idx[q];
+                (k.y + row0 * k.dim)[pq] = (k.x + row0 * k.dim)[pq];
+            }
+        }
         if (k.ldj_part != nullptr) {
             float lsum = valid ? ljd : 0.f;
             lsum += __shfl_xor(lsum, 32, 64);
@@ -1521,7 +1546,8 @@ extern "C" size_t sx_rqs_slab_fwd_scratch_floats(int64_t n_rows, int32_t n_live)
 }
 
 extern "C" int sx_rqs_slab_fwd(const float *x, const float *h, int64_t ld_h, int32_t hidden, const float *w_fwd, float *y, float *ldj,
-                               const int32_t *live_idx, int32_t live_start, int32_t n_live, int32_t n_bins, float left, float right,
+                               const int32_t *live_idx, int32_t live_start, int32_t n_live, const int32_t *pass_idx, int32_t n_pass,
+                               int32_t n_bins, float left, float right,
                                float bottom, float top, int64_t n_rows, int32_t dim, int32_t reverse, float ldj_scale,
                                int32_t ldj_accumulate, int32_t h_fragments, int32_t cubic, float *scratch, uint32_t *err_flag,
                                void *stream) {
@@ -1529,6 +1555,7 @@ extern "C" int sx_rqs_slab_fwd(const float *x, const float *h, int64_t ld_h, int
     SX_REQUIRE(!h_fragments || ((uintptr_t)h & 15) == 0, "sx_rqs_slab_fwd: h fragments must be 16-byte aligned");
     SX_REQUIRE(ldj == nullptr || scratch != nullptr, "sx_rqs_slab_fwd: the row log-det needs the scratch buffer");
     SX_REQUIRE(dim > 0 && n_live > 0 && n_live <= dim && n_rows >= 0, "sx_rqs_slab_fwd: bad sizes");
+    SX_REQUIRE(n_pass >= 0 && n_pass <= dim - n_live && (n_pass == 0 || pass_idx != nullptr), "sx_rqs_slab_fwd: bad pass-through columns");
     SX_REQUIRE(n_bins >= 1 && n_bins <= 16, "sx_rqs_slab_fwd: n_bins must be in 1..16 (got %d)", n_bins);
     SX_REQUIRE(hidden >= 1 && hidden <= 256, "sx_rqs_slab_fwd: hidden width must be in 1..256 (got %d)", hidden);
     SX_REQUIRE(h_fragments || ld_h >= hidden, "sx_rqs_slab_fwd: ld_h < hidden");
@@ -1548,8 +1575,8 @@ extern "C" int sx_rqs_slab_fwd(const float *x, const float *h, int64_t ld_h, int
     if (r >= 8) r &= ~7;                             // multiples of 8: the XCD-aware id mapping
     const int n_ranges = r < 1 ? 1 : r;
     slabf_args k;
-    k.x = x; k.h = h; k.wf = w_fwd; k.y = y; k.ldj_part = ldj ? scratch : nullptr; k.live_idx = live_idx; k.flags = err_flag;
-    k.n_rows = n_rows; k.ld_h = ld_h; k.l0 = live_start; k.n_live = n_live; k.K = n_bins; k.dim = dim; k.H = hidden; k.HT = HT;
+    k.x = x; k.h = h; k.wf = w_fwd; k.y = y; k.ldj_part = ldj ? scratch : nullptr; k.live_idx = live_idx; k.pass_idx = n_pass > 0 ? pass_idx : nullptr; k.flags = err_flag;
+    k.n_rows = n_rows; k.ld_h = ld_h; k.l0 = live_start; k.n_live = n_live; k.n_pass = n_pass; k.K = n_bins; k.dim = dim; k.H = hidden; k.HT = HT;
     k.n_slabs = n_slabs; k.n_chunks = n_chunks; k.n_ranges = n_ranges; k.xcd_map = (n_ranges % 8 == 0);
     k.left = left; k.right = right; k.bottom = bottom; k.top = top;
     k.log_span = logf(right - left); k.ref_ldj = reverse == 2;

@@ -402,7 +402,9 @@ class Coupling(Transform):
                 progs = [(p, 0) for p in _chunk_mlp_program(b, device)]
             contiguous = np.array_equal(live, np.arange(live[0], live[0] + len(live)))
             live_idx = None if contiguous else torch.from_numpy(live.astype(np.int32)).to(device)
-            return (progs, in_slots, torch.from_numpy(glob).to(device), torch.from_numpy(hid).to(device), live_idx, int(live[0]), len(live), H, {})
+            passthru = np.nonzero(m > 0.5)[0].astype(np.int32)               # y = x there: copied by the slab kernel
+            cache = {'pass_idx': torch.from_numpy(passthru).to(device) if len(passthru) else None, 'n_pass': len(passthru)}
+            return (progs, in_slots, torch.from_numpy(glob).to(device), torch.from_numpy(hid).to(device), live_idx, int(live[0]), len(live), H, cache)
         return self._programs.get(key, build)
 
     def _run_spline_slab(self, x2, lat2, reverse, want_ldj, ldj_scale):
@@ -454,16 +456,18 @@ class Coupling(Transform):
             for p, h0 in progs:
                 p.run(x2, lat2, mlp_out=h[:, h0:])
             ld_h, frag = h.stride(0), 0
-        # pass-through columns; the kernel writes the transformed ones.  (A copy made by the hidden-layer kernel, whose registers the
-        # rows pass through anyway, measured slower: its 16-byte pieces 256 B apart cost more than a streaming copy: 102 vs 70 + 19 us)
-        y = x2.clone()
+        # every column is written by the slab kernel: the transformed ones, and y = x in the rest (pass_idx).  (A copy made by the
+        # hidden-layer kernel, whose registers the rows pass through, measured slower than a streaming clone -- 16-byte pieces 256 B apart:
+        # 102 vs 70 + 19 us; the slab kernel's lanes copy one more element each beside the one they transform: no measurable cost.)
+        y = torch.empty_like(x2)
         ldj = torch.empty(n, dtype=torch.float32, device=dev) if want_ldj else None
         with _hip.device_of(x2):
             sc = _hip.scratch(dev, lib.sx_rqs_slab_fwd_scratch_floats(n, n_live)) if want_ldj else None
         # cubic splines: a coupling's inverse log-det is MINUS the FORWARD log-det at the inverted point (flow.py:42-47): reverse = 2
         rev = (2 if (cubic and want_ldj) else 1) if reverse else 0
         _hip.call('sx_rqs_slab_fwd', x2, x2.data_ptr(), h.data_ptr(), ld_h, H, packs.data_ptr(), y.data_ptr(), _hip.ptr(ldj),
-                  _hip.ptr(live_idx), live_start, n_live, sp.n_bins, float(sp.lower), float(sp.upper), float(sp.lower),
+                  _hip.ptr(live_idx), live_start, n_live, _hip.ptr(cache['pass_idx']), cache['n_pass'], sp.n_bins, float(sp.lower),
+                  float(sp.upper), float(sp.lower),
                   float(sp.upper), n, d, rev, float(ldj_scale), 0, frag, int(cubic), _hip.ptr(sc), flag)
         return y, ldj
 

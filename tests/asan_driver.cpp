@@ -206,18 +206,20 @@ int main() {
     (void)sx_rqs_slab_l1_scratch_floats(64, 64); (void)sx_rqs_slab_l1_scratch_floats(-1, 1 << 30);
     (void)sx_rqs_slab_fwd_scratch_floats(0, 32); (void)sx_rqs_slab_fwd_scratch_floats((int64_t)1 << 40, 32); (void)sx_rqs_slab_fwd_scratch_floats(-1, INT_MAX);
     // the forward slab pass: every argument rule, then an empty batch (no launch)
-    EXPECT_BAD(sx_rqs_slab_fwd(nullptr, f, 64, 64, f, f, f, nullptr, 32, 32, 16, -3.f, 3.f, -3.f, 3.f, 4, 64, 1, 1.f, 0, 0, 0, f, nullptr, nullptr));
-    EXPECT_BAD(sx_rqs_slab_fwd(f, f, 64, 64, f, f, f, nullptr, 32, 32, 16, -3.f, 3.f, -3.f, 3.f, 4, 64, 1, 1.f, 0, 0, 0, nullptr, nullptr, nullptr));   // ldj without scratch
-    EXPECT_BAD(sx_rqs_slab_fwd(f, f, 64, 64, f, f, nullptr, nullptr, 32, 32, 17, -3.f, 3.f, -3.f, 3.f, 4, 64, 1, 1.f, 0, 0, 0, nullptr, nullptr, nullptr));   // bins
-    EXPECT_BAD(sx_rqs_slab_fwd(f, f, 320, 257, f, f, nullptr, nullptr, 32, 32, 16, -3.f, 3.f, -3.f, 3.f, 4, 64, 1, 1.f, 0, 0, 0, nullptr, nullptr, nullptr)); // hidden
-    EXPECT_BAD(sx_rqs_slab_fwd(f, f, 32, 64, f, f, nullptr, nullptr, 32, 32, 16, -3.f, 3.f, -3.f, 3.f, 4, 64, 1, 1.f, 0, 0, 0, nullptr, nullptr, nullptr));   // ld_h < hidden
-    EXPECT_BAD(sx_rqs_slab_fwd(f, f, 64, 64, f, f, nullptr, nullptr, 32, 65, 16, -3.f, 3.f, -3.f, 3.f, 4, 64, 1, 1.f, 0, 0, 0, nullptr, nullptr, nullptr));   // n_live > dim
-    EXPECT_BAD(sx_rqs_slab_fwd(f, f, 64, 64, f, f, nullptr, nullptr, 32, 32, 16, 3.f, -3.f, -3.f, 3.f, 4, 64, 1, 1.f, 0, 0, 0, nullptr, nullptr, nullptr));   // empty domain
-    EXPECT_BAD(sx_rqs_slab_fwd(f, f, 64, 64, f, f, nullptr, nullptr, 32, 32, 16, -3.f, 3.f, -3.f, 3.f, -1, 64, 1, 1.f, 0, 0, 0, nullptr, nullptr, nullptr));  // n_rows < 0
-    EXPECT_BAD(sx_rqs_slab_fwd(f, f, 64, 64, f, f, nullptr, nullptr, 32, 32, 16, -3.f, 3.f, -3.f, 3.f, 4, 64, 2, 1.f, 0, 0, 0, nullptr, nullptr, nullptr));   // reverse = 2 is the cubic splines' reference mode
-    EXPECT_BAD(sx_rqs_slab_fwd(f, f, 64, 64, f, f, nullptr, nullptr, 32, 32, 16, -3.f, 3.f, -2.f, 3.f, 4, 64, 1, 1.f, 0, 0, 1, nullptr, nullptr, nullptr));   // cubic: one domain
-    EXPECT_OK(sx_rqs_slab_fwd(f, f, 64, 64, f, f, nullptr, nullptr, 32, 32, 16, -3.f, 3.f, -3.f, 3.f, 0, 64, 1, 1.f, 0, 0, 0, nullptr, nullptr, nullptr));
-    EXPECT_OK(sx_rqs_slab_fwd(f, f, 64, 64, f, f, nullptr, nullptr, 32, 32, 16, -3.f, 3.f, -3.f, 3.f, 0, 64, 2, 1.f, 0, 0, 1, nullptr, nullptr, nullptr));
+    EXPECT_BAD(sx_rqs_slab_fwd(nullptr, f, 64, 64, f, f, f, nullptr, 32, 32, nullptr, 0, 16, -3.f, 3.f, -3.f, 3.f, 4, 64, 1, 1.f, 0, 0, 0, f, nullptr, nullptr));
+    EXPECT_BAD(sx_rqs_slab_fwd(f, f, 64, 64, f, f, f, nullptr, 32, 32, nullptr, 0, 16, -3.f, 3.f, -3.f, 3.f, 4, 64, 1, 1.f, 0, 0, 0, nullptr, nullptr, nullptr));   // ldj without scratch
+    EXPECT_BAD(sx_rqs_slab_fwd(f, f, 64, 64, f, f, nullptr, nullptr, 32, 32, nullptr, 0, 17, -3.f, 3.f, -3.f, 3.f, 4, 64, 1, 1.f, 0, 0, 0, nullptr, nullptr, nullptr));   // bins
+    EXPECT_BAD(sx_rqs_slab_fwd(f, f, 320, 257, f, f, nullptr, nullptr, 32, 32, nullptr, 0, 16, -3.f, 3.f, -3.f, 3.f, 4, 64, 1, 1.f, 0, 0, 0, nullptr, nullptr, nullptr)); // hidden
+    EXPECT_BAD(sx_rqs_slab_fwd(f, f, 32, 64, f, f, nullptr, nullptr, 32, 32, nullptr, 0, 16, -3.f, 3.f, -3.f, 3.f, 4, 64, 1, 1.f, 0, 0, 0, nullptr, nullptr, nullptr));   // ld_h < hidden
+    EXPECT_BAD(sx_rqs_slab_fwd(f, f, 64, 64, f, f, nullptr, nullptr, 32, 65, nullptr, 0, 16, -3.f, 3.f, -3.f, 3.f, 4, 64, 1, 1.f, 0, 0, 0, nullptr, nullptr, nullptr));   // n_live > dim
+    EXPECT_BAD(sx_rqs_slab_fwd(f, f, 64, 64, f, f, nullptr, nullptr, 32, 32, nullptr, 0, 16, 3.f, -3.f, -3.f, 3.f, 4, 64, 1, 1.f, 0, 0, 0, nullptr, nullptr, nullptr));   // empty domain
+    EXPECT_BAD(sx_rqs_slab_fwd(f, f, 64, 64, f, f, nullptr, nullptr, 32, 32, nullptr, 0, 16, -3.f, 3.f, -3.f, 3.f, -1, 64, 1, 1.f, 0, 0, 0, nullptr, nullptr, nullptr));  // n_rows < 0
+    EXPECT_BAD(sx_rqs_slab_fwd(f, f, 64, 64, f, f, nullptr, nullptr, 32, 32, nullptr, 0, 16, -3.f, 3.f, -3.f, 3.f, 4, 64, 2, 1.f, 0, 0, 0, nullptr, nullptr, nullptr));   // reverse = 2 is the cubic splines' reference mode
+    EXPECT_BAD(sx_rqs_slab_fwd(f, f, 64, 64, f, f, nullptr, nullptr, 32, 32, nullptr, 0, 16, -3.f, 3.f, -2.f, 3.f, 4, 64, 1, 1.f, 0, 0, 1, nullptr, nullptr, nullptr));   // cubic: one domain
+    EXPECT_BAD(sx_rqs_slab_fwd(f, f, 64, 64, f, f, nullptr, nullptr, 32, 32, nullptr, 5, 16, -3.f, 3.f, -3.f, 3.f, 4, 64, 1, 1.f, 0, 0, 0, nullptr, nullptr, nullptr));   // pass-through columns without their list
+    EXPECT_BAD(sx_rqs_slab_fwd(f, f, 64, 64, f, f, nullptr, nullptr, 32, 32, (const int32_t *)f, 33, 16, -3.f, 3.f, -3.f, 3.f, 4, 64, 1, 1.f, 0, 0, 0, nullptr, nullptr, nullptr));   // more than dim - n_live
+    EXPECT_OK(sx_rqs_slab_fwd(f, f, 64, 64, f, f, nullptr, nullptr, 32, 32, nullptr, 0, 16, -3.f, 3.f, -3.f, 3.f, 0, 64, 1, 1.f, 0, 0, 0, nullptr, nullptr, nullptr));
+    EXPECT_OK(sx_rqs_slab_fwd(f, f, 64, 64, f, f, nullptr, nullptr, 32, 32, nullptr, 0, 16, -3.f, 3.f, -3.f, 3.f, 0, 64, 2, 1.f, 0, 0, 1, nullptr, nullptr, nullptr));
     (void)sx_rqs_slab_hidden_floats(0, 64); (void)sx_rqs_slab_hidden_floats((int64_t)1 << 40, 64); (void)sx_rqs_slab_hidden_floats(-1, INT_MAX);
     EXPECT_BAD(sx_rqs_slab_hidden(nullptr, nullptr, f, f, 4, 64, 0, 160, 1, nullptr, nullptr));
     EXPECT_BAD(sx_rqs_slab_hidden(f, nullptr, f, f, 4, 64, 8, 160, 1, nullptr, nullptr));        // latent_dim without latent
