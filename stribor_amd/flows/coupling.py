@@ -332,7 +332,7 @@ class Coupling(Transform):
         try:
             return self._run_spline_slab(x2, lat2, reverse, want_ldj, ldj_scale)
         except NotImplementedError:
-            pass                                        # > 16 bins, > 256 hidden units, bf16 rows, 'exact' / 'auto': below
+            pass                                        # > 16 bins, > 256 hidden units, bf16 rows, 'exact' (and 'auto' after a range flag): below
         progs, live_idx, live_start, n_live, width = self._spline_program(d, 0 if lat2 is None else lat2.shape[1],
                                                                           x2.device)
         params = torch.empty(n, width, dtype=torch.float32, device=x2.device)
@@ -409,8 +409,12 @@ class Coupling(Transform):
 
     def _run_spline_slab(self, x2, lat2, reverse, want_ldj, ldj_scale):
         sp = self.transform
-        if debug.on('STRIBOR_SPLINE_NO_SLAB_FWD') or _hip.get_gemm_precision() != 'fast' or x2.dtype != torch.float32:
-            raise NotImplementedError('slab tier: fp32 rows, the default arithmetic')
+        mode = _hip.get_gemm_precision()
+        if debug.on('STRIBOR_SPLINE_NO_SLAB_FWD') or mode == 'exact' or x2.dtype != torch.float32:
+            raise NotImplementedError('slab tier: fp32 rows, the fp16 x 3 arithmetic')
+        if mode == 'auto':                          # a flag an EARLIER call left behind is that call's: raise it, do not swallow it
+            torch.cuda.current_stream(x2.device).synchronize()
+            _hip.poll_errors()
         cubic = sp.spline_type == 'cubic'
         if (1e-2 if cubic else 1e-3) * sp.n_bins > 1.0:
             raise ValueError('Minimal bin width too large for the number of bins')      # rational_quadratic_spline.py:96-97, cubic_spline.py:93-96
@@ -469,6 +473,11 @@ class Coupling(Transform):
                   _hip.ptr(live_idx), live_start, n_live, _hip.ptr(cache['pass_idx']), cache['n_pass'], sp.n_bins, float(sp.lower),
                   float(sp.upper), float(sp.lower),
                   float(sp.upper), n, d, rev, float(ldj_scale), 0, frag, int(cubic), _hip.ptr(sc), flag)
+        if mode == 'auto':                          # never hand back a NaN-poisoned result: the tier below re-runs the layer exactly
+            torch.cuda.current_stream(dev).synchronize()
+            with _hip.device_of(x2):
+                if _hip.take_flag(dev, _hip.FLAG_F16_RANGE):
+                    raise NotImplementedError('slab tier: an operand left the fp16 x 3 range')
         return y, ldj
 
     # ---- training (autograd): spline couplings, inverse direction --------------------------------------------------

@@ -1652,3 +1652,32 @@ def test_slab_forward_tier_behind_deep_conditioners_and_other_activations(hidden
         close(y, wy, rtol=1e-5, atol=2e-5)
         close(ldj.reshape(-1, 1), wl, rtol=1e-5, atol=2e-4)
     st.check_errors()
+
+
+def test_slab_forward_tier_in_auto_mode_hands_out_of_range_rows_to_the_exact_arithmetic():
+    """'auto' on the slab forward tier: rows whose conditioner input leaves fp16's range raise the flag in the hidden-layer kernel, the
+    tier steps aside and the layer is re-evaluated by the tier below in the exact arithmetic -- values against the oracle, no error
+    left behind; 'fast' reports the same rows as NaN + GemmRangeError (never a plausible number)."""
+    torch.manual_seed(5)
+    dim, hidden, K = 16, 160, 8
+    desc = [{'kind': 'coupling_rqs', 'dim': dim, 'hidden': [hidden], 'n_bins': K, 'lower': -3.0, 'upper': 3.0, 'mask': 'ordered_right_half',
+             'latent_dim': 0}]
+    flow = fd.build_flow(st, desc, dim)
+    spec = fd.flow_spec(desc, {k: v.clone() for k, v in flow.state_dict().items()})
+    flow = flow.to(DEV)
+    x = torch.randn(200, dim)
+    x[7, 0] = 9.0e4                                  # a conditioning column beyond 65504 (the transformed ones sit in the linear tail)
+    x[150, 3] = -2.0e5
+    want = orc.flow_log_prob(spec, x)
+    old = st.set_gemm_precision('auto')
+    try:
+        close(flow.log_prob(x.to(DEV)), want, rtol=1e-5, atol=2e-4)
+        st.check_errors()
+    finally:
+        st.set_gemm_precision(old)
+    got = flow.log_prob(x.to(DEV))
+    with pytest.raises(st.GemmRangeError):
+        st.check_errors()
+    assert torch.isnan(got[7]).all() and torch.isnan(got[150]).all()
+    ok = torch.ones(200, dtype=torch.bool); ok[7] = ok[150] = False
+    close(got[ok.to(got.device)], want[ok], rtol=1e-5, atol=2e-4)
