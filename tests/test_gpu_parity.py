@@ -989,14 +989,20 @@ def test_deep_conditioner_spline_flows_fuse_into_one_launch():
     check_errors()
 
 
-@pytest.mark.parametrize('make,dim,n', [('cfg2', 64, 1024), ('cfg2', 64, 300_007), ('cfg3', 64, 2048), ('cfg4', 128, 4096)])
+@pytest.mark.parametrize('make,dim,n', [('cfg2', 64, 1024), ('cfg2', 64, 300_007), ('cfg3', 64, 2048), ('cfg4', 128, 4096),
+                                         ('rqs160', 64, 1500), ('cubic160', 40, 700)])
 def test_log_prob_replays_from_a_hip_graph(make, dim, n):
     """Launch-bound small batches: log_prob captured once into a HIP graph (torch.cuda.CUDAGraph) and replayed on new
     input contents gives bit-identical results to eager launches -- no allocation, synchronisation or host-side state in
     the launch path (the chunk counters are created by the warm-up on the capture stream and re-armed by the kernel)."""
     torch.manual_seed(11)
     desc = {'cfg2': lambda: fd.cfg2_desc(8, dim, 64), 'cfg3': lambda: fd.cfg3_desc(4, dim, 64, 16),
-            'cfg4': lambda: fd.cfg4_desc(2, dim, 64)}[make]()
+            'cfg4': lambda: fd.cfg4_desc(2, dim, 64),
+            # (the slab forward tier: two kernels + a reduction per layer, buffers from torch's allocator and the library scratch)
+            'rqs160': lambda: [{'kind': 'coupling_rqs', 'dim': dim, 'hidden': [160], 'n_bins': 16, 'lower': -3, 'upper': 3, 'latent_dim': 0,
+                                'mask': m} for m in ('ordered_right_half', 'ordered_left_half')],
+            'cubic160': lambda: [{'kind': 'coupling_rqs', 'dim': dim, 'hidden': [200], 'n_bins': 9, 'lower': -3, 'upper': 3, 'latent_dim': 0,
+                                  'mask': m, 'spline_type': 'cubic'} for m in ('parity_even', 'ordered_left_half')]}[make]()
     flow = fd.build_flow(st, desc, dim).to(DEV)
     static_x = torch.randn(n, dim, device=DEV)
     side = torch.cuda.Stream()
