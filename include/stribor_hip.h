@@ -232,10 +232,14 @@ int sx_rqs_slab_l1_bwd(const float *slab_scratch, const float *h, int64_t ld_h, 
  * sx_rqs_slab_hidden: the hidden layer of a single-hidden-layer conditioner (net/mlp.py:48-58; coupling.py:61-65: it sees
  * cat[x * mask, latent]),  h = act(W1 z + b1), as fp16 hi / lo MFMA fragments: h_frag [sx_rqs_slab_hidden_floats(n_rows, hidden)].
  *   w1: sx_pack_linear(W1, b1, row_idx = hidden slots, col_idx = input slots (slot q = column q of x, then of latent; -1 = masked),
- *   m_tiles = ceil(hidden/32), k_tiles = ceil((dim + latent_dim)/32), SX_GEMM_F16X3);  dim + latent_dim <= 128;  act: SX_ACT_*. */
+ *   m_tiles = ceil(hidden/32), k_tiles = ceil((dim + latent_dim)/32), SX_GEMM_F16X3);  dim + latent_dim <= 128;  act: SX_ACT_*;
+ *   cond_mask (HOST pointer, nullable = every slot): four 32-bit words, bit q = input slot q feeds the layer.  The other inputs are
+ *   zeroed before the fp16 x 3 split -- coupling.py:61 multiplies them by mask = 0, whatever their magnitude --, and a sample whose
+ *   conditioning input is beyond fp16's range is rescaled by a power of two inside the kernel: any finite fp32 row is valid
+ *   (net/mlp.py:65).  err_flag receives SX_FLAG_F16_RANGE only for a hidden ACTIVATION beyond 65504 (unbounded activations). */
 size_t sx_rqs_slab_hidden_floats(int64_t n_rows, int32_t hidden);
-int sx_rqs_slab_hidden(const float *x, const float *latent, const float *w1, float *h_frag, int64_t n_rows, int32_t dim,
-                       int32_t latent_dim, int32_t hidden, int32_t act, uint32_t *err_flag, void *stream);
+int sx_rqs_slab_hidden(const float *x, const float *latent, const float *w1, const uint32_t *cond_mask, float *h_frag,
+                       int64_t n_rows, int32_t dim, int32_t latent_dim, int32_t hidden, int32_t act, uint32_t *err_flag, void *stream);
 size_t sx_rqs_slab_fwd_scratch_floats(int64_t n_rows, int32_t n_live);
 int sx_rqs_slab_fwd(const float *x, const float *h, int64_t ld_h, int32_t hidden, const float *w_fwd, float *y, float *ldj,
                     const int32_t *live_idx, int32_t live_start, int32_t n_live, const int32_t *pass_idx, int32_t n_pass,
@@ -491,6 +495,26 @@ int sx_flow_run(const sx_program *prog_host, const float *blobs, const void *x, 
                 float *logp_out, double *sum_out, float *mlp_out, int64_t mlp_out_stride,
                 int32_t mlp_out_dim, const float *row_t, float *side, int64_t n_rows, int32_t dtype,
                 int32_t precision, uint32_t *work, uint32_t *err_flag, void *stream);
+
+/* sx_flow_run with the EXACT REDO PASS (round 6): any finite fp32 through the default arithmetic at fp32-grade error
+ * (net/mlp.py:65, flows/affine.py:104-109,156-163 take any finite value; stribor has no operand range).
+ *   blobs        packed for SX_GEMM_F16X3, blobs_exact the same program's weights packed for SX_GEMM_F32 (same offsets);
+ *   redo         caller-owned DEVICE scratch of sx_flow_redo_words(n_rows) 32-bit words, zeroed once; the call leaves it zeroed
+ *                (one list per stream: launches that share a list must be ordered).
+ * precision must be SX_GEMM_F16X3.  The fp16 x 3 kernel does not flag a sample whose operand (flow state, conditioner input, an
+ * unbounded hidden activation) is beyond fp16's range -- and does not rescale it either: fp16 hi + lo weights carry too few bits
+ * against entries of 1e5 (sx_flow_kernel.h, rng_note) --: it appends the sample's 32-row group and a per-sample mask to `redo`,
+ * and a second launch of the same program on the exact-fp32 kernel evaluates, stores (y, ldj_out, logp_out, mlp_out) and sums
+ * (sum_out) exactly those samples.  On ordinary data the second launch reads one word per workgroup and ends.
+ * Not for programs with side outputs (`side`).  MLP programs that ACCUMULATE into mlp_out (later hidden chunks) leave the named
+ * samples' rows to the exact pass, which adds the chunk's exact contribution.
+ * blobs_exact = redo = NULL: sx_flow_run (such samples come back as NaN + SX_FLAG_F16_RANGE). */
+size_t sx_flow_redo_words(int64_t n_rows);
+int sx_flow_run2(const sx_program *prog_host, const float *blobs, const float *blobs_exact, uint32_t *redo, const void *x,
+                 const float *latent, const int32_t *in_col, const int32_t *out_col, void *y, float *ldj_out,
+                 float *logp_out, double *sum_out, float *mlp_out, int64_t mlp_out_stride, int32_t mlp_out_dim,
+                 const float *row_t, float *side, int64_t n_rows, int32_t dtype, int32_t precision,
+                 uint32_t *work, uint32_t *err_flag, void *stream);
 
 /* Training backward of log_prob for flows of affine couplings, layer-major: one launch per layer (or pair) with the weight gradients
  * contracted inside the kernel (the single-launch program of SX_STEP_COUPLING_AFFINE_BWD steps run through sx_flow_run

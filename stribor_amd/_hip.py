@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Optional
 
 import torch
@@ -52,7 +53,7 @@ ACT_CODES = {'Identity': 0, 'Tanh': 1, 'ReLU': 2, 'Sigmoid': 3, 'ELU': 4, 'Softp
 # every symbol include/stribor_hip.h declares (tests check that the library exports all of them)
 EXPORTS = ['sx_abi_version', 'sx_fragment_mode', 'sx_last_error', 'sx_build_id', 'sx_absmax2', 'sx_permute', 'sx_affine_coupling', 'sx_rqs_coupling',
            'sx_cubic_coupling', 'sx_pointwise', 'sx_rqs_inverse_bwd', 'sx_rqs_forward_bwd', 'sx_affine_coupling_bwd', 'sx_time_affine_coupling', 'sx_cubic_inverse_bwd', 'sx_cubic_forward_bwd', 'sx_pointwise_bwd',
-           'sx_unit_normal_logprob', 'sx_sum_f64', 'sx_packed_linear_floats', 'sx_pack_linear', 'sx_pack_linear_bound', 'sx_flow_run',
+           'sx_unit_normal_logprob', 'sx_sum_f64', 'sx_packed_linear_floats', 'sx_pack_linear', 'sx_pack_linear_bound', 'sx_flow_run', 'sx_flow_run2', 'sx_flow_redo_words',
            'sx_flow_launch_info', 'sx_wgrad', 'sx_wgrad_layer', 'sx_colsum', 'sx_tri_inverse_f64',
            'sx_wgrad_scratch_floats', 'sx_wgrad_layer_scratch_floats', 'sx_flow_bwd_max_steps', 'sx_flow_bwd_partials',
            'sx_flow_bwd_run', 'sx_wgrad_reduce', 'sx_rqs_slab_slots', 'sx_rqs_slab_scratch_floats', 'sx_rqs_slab_bwd', 'sx_rqs_slab_l1_scratch_floats', 'sx_rqs_slab_l1_bwd',
@@ -117,7 +118,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.sx_rqs_slab_hidden_floats.restype = C.c_size_t
     lib.sx_rqs_slab_hidden_floats.argtypes = [i64, i32]
     lib.sx_rqs_slab_hidden.restype = i32
-    lib.sx_rqs_slab_hidden.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp]
+    lib.sx_rqs_slab_hidden.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp]
     lib.sx_rqs_forward_bwd.restype = i32
     lib.sx_rqs_forward_bwd.argtypes = lib.sx_rqs_inverse_bwd.argtypes
     lib.sx_affine_coupling_bwd.restype = i32
@@ -146,6 +147,10 @@ def _declare(lib: C.CDLL) -> None:
     lib.sx_pack_linear_bound.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, f32, i32, i32, vp, vp, vp, vp]
     lib.sx_flow_run.restype = i32
     lib.sx_flow_run.argtypes = [C.POINTER(sx_program), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, i64, i32, i32, vp, vp, vp]
+    lib.sx_flow_run2.restype = i32
+    lib.sx_flow_run2.argtypes = [C.POINTER(sx_program), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, i64, i32, i32, vp, vp, vp]
+    lib.sx_flow_redo_words.restype = C.c_size_t
+    lib.sx_flow_redo_words.argtypes = [i64]
     lib.sx_wgrad.restype = i32
     lib.sx_wgrad.argtypes = [vp, i64, i32, vp, i64, i32, i64, i32, vp, i64, vp, vp, vp, vp, vp]
     lib.sx_wgrad_scratch_floats.restype = C.c_size_t
@@ -329,7 +334,8 @@ def _evict_flag_words() -> None:
     devices (no kernel may still hold a word's address), report what is pending and drop every word -- live streams get a new one at
     their next launch.  (A HIP graph captured earlier keeps the address of a dropped word: the words are retired, never freed, so a
     replay writes into memory nobody else owns; its flag is no longer polled -- INTEGRATION.md.)"""
-    torch.cuda.synchronize()
+    for idx in sorted({k[0] for k in _flag_words}):          # EVERY device that owns a word (torch.cuda.synchronize() alone waits for
+        torch.cuda.synchronize(idx)                          # the current one: a pending flag elsewhere was read early and lost)
     pending = 0
     for ent in _flag_words.values():
         pending |= int(ent[1][0])
@@ -420,6 +426,37 @@ def work_counters(device) -> torch.Tensor:
     if t is None:
         t = _work[key] = torch.zeros(2, dtype=torch.int32, device=device)
     return t
+
+
+_redo = {}
+_redo_off = threading.local()
+
+
+def redo_list(device, n_rows: int) -> torch.Tensor:
+    """The redo list of sx_flow_run2 for (device, current stream): sx_flow_redo_words(n_rows) zeroed 32-bit words; every call leaves
+    it zeroed, so one buffer serves all launches of the stream (grown by replacement, like `scratch`)."""
+    key = (torch.device(device).index or 0, stream())
+    need = 2 + 2 * ((n_rows + 31) // 32)
+    t = _redo.get(key)
+    if t is None or t.numel() < need:
+        t = _redo[key] = torch.zeros(max(need, 1 << 12), dtype=torch.int32, device=device)
+    return t
+
+
+class no_redo:
+    """`with no_redo():` -- launches inside run without the exact redo pass (a graph-building flow call: a training step re-packs the
+    weights every step, and the pass needs them packed a second time, for the exact kernels; such a call reports out-of-range samples
+    through the flag word as before)."""
+
+    def __enter__(self):
+        _redo_off.n = getattr(_redo_off, 'n', 0) + 1
+
+    def __exit__(self, *exc):
+        _redo_off.n -= 1
+
+
+def redo_allowed() -> bool:
+    return getattr(_redo_off, 'n', 0) == 0 and os.environ.get('STRIBOR_NO_REDO', '0') in ('', '0')
 
 
 def scratch(device, n_floats: int) -> torch.Tensor:

@@ -22,6 +22,7 @@ __device__ __forceinline__ void store_ctile(float *row_base, int off, const f32x
 template <int XT, int HT, int C0, int CT, int T0, int TT>
 __device__ __forceinline__ void coupling_affine_bwd(tile<1> (&xs)[2 * XT], const wptr w, float g, float *side_row,
                                                     int lane, rng_t &rg) {
+    SX_DEP_MARK_BWD;
     constexpr int F1 = 0;                                            // forward pack(W1', HT x CT)
     constexpr int F2 = HT * CT * 1024 + HT * 32;                     // forward pack(W2', 2TT x HT)
     constexpr int F2B = F2 + 2 * TT * HT * 1024;                     //   its bias
@@ -126,6 +127,7 @@ __device__ __forceinline__ void coupling_affine_bwd(tile<1> (&xs)[2 * XT], const
 template <int XT, int HT, int C0, int CT, int T0, int TT>
 __device__ __forceinline__ void coupling_affine_bwd_a(tile<1> (&xs)[2 * XT], const wptr w, float g, float *side_row, int lane,
                                                       rng_t &rg, tile<1> (&keep)[HT + 2 * TT]) {
+    SX_DEP_MARK_BWD;
     constexpr int F1 = 0;                                            // pack(W1', HT x CT)
     constexpr int F2 = HT * CT * 1024 + HT * 32;                     // pack(W2', 2TT x HT)
     constexpr int F2B = F2 + 2 * TT * HT * 1024;                     //   its bias
@@ -212,6 +214,7 @@ __device__ __forceinline__ void coupling_affine_bwd_a(tile<1> (&xs)[2 * XT], con
 template <int XT, int HT, int C0, int CT, int T0, int TT>
 __device__ __forceinline__ void coupling_affine_bwd_b(tile<1> (&xs)[2 * XT], const wptr w, float *side_row, int lane, rng_t &rg,
                                                       tile<1> (&keep)[HT + 2 * TT]) {
+    SX_DEP_MARK_BWD;
     constexpr int B2 = 0;                                            // pack(W2^T, HT x 2TT)
     constexpr int B1 = HT * 2 * TT * 1024 + HT * 32;                 // pack(W1^T, CT x HT)
     const int h = lane >> 5;
@@ -288,6 +291,7 @@ __device__ __forceinline__ void coupling_affine_bwd_b(tile<1> (&xs)[2 * XT], con
 template <int XT, int T0>
 __device__ __forceinline__ void linear_bwd_half(tile<1> (&xs)[2 * XT], const wptr w, float *side_row, int soff, bool store_before,
                                                 int lane, rng_t &rg) {
+    SX_DEP_MARK_BWD;
     const int h = lane >> 5;
     if (side_row != nullptr && store_before) {
 #pragma unroll
@@ -420,6 +424,7 @@ struct wacc {                  // one layer's weight-gradient accumulators (prun
 };
 template <int HT>
 __device__ __forceinline__ void wacc_zero(wacc<HT> &a) {
+    SX_DEP_MARK_BWD;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         a.b2[p] = 0.f;
@@ -441,6 +446,7 @@ __device__ __forceinline__ void wacc_zero(wacc<HT> &a) {
 template <int HT, int C0, int T0>
 __device__ __forceinline__ void coupling_affine_bwd_acc(tile<1> (&xs)[4], const wptr w, float g, bool live, wacc<HT> &A,
                                                         const sel_t &sel, rng_t &rg) {
+    SX_DEP_MARK_BWD;
     constexpr int XT = 2, CT = 1, TT = 1;
     constexpr int F1 = 0;
     constexpr int F2 = HT * CT * 1024 + HT * 32;

@@ -276,11 +276,25 @@ extern "C" int sx_flow_launch_info(const sx_program *prog_host, int64_t n_rows, 
 }
 
 
+extern "C" size_t sx_flow_redo_words(int64_t n_rows) {
+    if (n_rows < 0 || n_rows >= ((int64_t)1 << 36)) return 0;
+    return (size_t)(2 + 2 * ((n_rows + 31) / 32));
+}
+
 extern "C" int sx_flow_run(const sx_program *prog_host, const float *blobs, const void *x, const float *latent,
                            const int32_t *in_col, const int32_t *out_col, void *y, float *ldj_out, float *logp_out,
                            double *sum_out, float *mlp_out, int64_t mlp_out_stride, int32_t mlp_out_dim,
                            const float *row_t, float *side, int64_t n_rows, int32_t dtype, int32_t precision,
                            uint32_t *work, uint32_t *err_flag, void *stream) {
+    return sx_flow_run2(prog_host, blobs, nullptr, nullptr, x, latent, in_col, out_col, y, ldj_out, logp_out, sum_out, mlp_out, mlp_out_stride,
+                        mlp_out_dim, row_t, side, n_rows, dtype, precision, work, err_flag, stream);
+}
+
+extern "C" int sx_flow_run2(const sx_program *prog_host, const float *blobs, const float *blobs_exact, uint32_t *redo, const void *x,
+                            const float *latent, const int32_t *in_col, const int32_t *out_col, void *y, float *ldj_out,
+                            float *logp_out, double *sum_out, float *mlp_out, int64_t mlp_out_stride, int32_t mlp_out_dim,
+                            const float *row_t, float *side, int64_t n_rows, int32_t dtype, int32_t precision,
+                            uint32_t *work, uint32_t *err_flag, void *stream) {
     dprog d; int bf; int mlp_mode; int sw;
     int rc = validate_and_convert(prog_host, &d, &bf, &mlp_mode, &sw);
     if (rc) return rc;
@@ -293,6 +307,9 @@ extern "C" int sx_flow_run(const sx_program *prog_host, const float *blobs, cons
     SX_REQUIRE(blobs != nullptr || prog_host->n_steps == 0, "sx_flow_run: null blobs");
     SX_REQUIRE(dtype == SX_F32 || dtype == SX_BF16, "sx_flow_run: bad dtype");
     SX_REQUIRE(precision == SX_GEMM_F32 || precision == SX_GEMM_F16X3, "sx_flow_run: unknown precision %d", precision);
+    SX_REQUIRE((blobs_exact == nullptr) == (redo == nullptr), "sx_flow_run2: blobs_exact and redo come together");
+    SX_REQUIRE(redo == nullptr || precision == SX_GEMM_F16X3, "sx_flow_run2: the redo pass belongs to the fp16 x 3 arithmetic");
+    SX_REQUIRE(redo == nullptr || (((uintptr_t)redo & 3) == 0 && side == nullptr), "sx_flow_run2: redo must be 4-byte aligned; programs with side outputs have no redo pass");
     SX_REQUIRE(prog_host->identity_cols || (in_col != nullptr && (y == nullptr || out_col != nullptr)),
                "sx_flow_run: in_col/out_col required when identity_cols == 0");
     SX_REQUIRE(prog_host->latent_dim == 0 || latent != nullptr, "sx_flow_run: latent_dim > 0 but latent is NULL");
@@ -316,16 +333,31 @@ extern "C" int sx_flow_run(const sx_program *prog_host, const float *blobs, cons
     a.work = (prog_host->n_steps > 0 && n_chunks > 2 * (int64_t)a.grid && !g_static_chunks) ? work : nullptr;
     a.flags = err_flag;
     a.frag_in = nullptr; a.frag_out = nullptr; a.acc_out = nullptr;
+    a.redo = redo; a.redo_pass = 0;
     const int T = prog_host->tiles, H = prog_host->h_tiles;
     const int fam = SX_MODE_FAMILY(mlp_mode);       // one object per kernel-MODE family (sx_flow_types.h)
-#define SX_GOF(TT, HH, F) (precision == SX_GEMM_F16X3 ? sx_flow_launch_f16x3_t##TT##h##HH##_f##F(a) : sx_flow_launch_f32x_t##TT##h##HH##_f##F(a))
-#define SX_GO(TT, HH) if (T == TT && H == HH) return fam == 0 ? SX_GOF(TT, HH, 0) : fam == 1 ? SX_GOF(TT, HH, 1) : SX_GOF(TT, HH, 2)
-    SX_GO(1, 1); SX_GO(1, 2); SX_GO(1, 4); SX_GO(2, 1); SX_GO(2, 2); SX_GO(2, 4); SX_GO(4, 1); SX_GO(4, 2); SX_GO(4, 4);
-    SX_GO(8, 1); SX_GO(8, 2); SX_GO(8, 4);
+    // One launch -- or, with a redo list, two: the fp16 x 3 kernel names the samples whose operands left fp16's range (32-row group +
+    // per-sample mask, appended to the list) instead of flagging them, and the SAME program on the exact-fp32 kernel, fed with the
+    // exact blobs, then evaluates, stores and sums exactly those samples (sx_flow_kernel.h: flow_kargs::redo).  The second launch
+    // finds an empty list on ordinary data: its workgroups read one word and leave (a few microseconds per call).
+    for (int pass = 0; pass < (redo != nullptr ? 2 : 1); ++pass) {
+        const int prec = pass == 0 ? precision : SX_GEMM_F32;
+        if (pass == 1) {
+            a.blobs = blobs_exact; a.redo_pass = 1; a.work = nullptr; a.flags = err_flag;
+            if (a.grid > 256) a.grid = 256;        // (the list is short, or empty)
+        }
+        int rc2 = SX_E_UNSUPPORTED;
+        bool found = false;
+#define SX_GOF(TT, HH, F) (prec == SX_GEMM_F16X3 ? sx_flow_launch_f16x3_t##TT##h##HH##_f##F(a) : sx_flow_launch_f32x_t##TT##h##HH##_f##F(a))
+#define SX_GO(TT, HH) if (!found && T == TT && H == HH) { found = true; rc2 = fam == 0 ? SX_GOF(TT, HH, 0) : fam == 1 ? SX_GOF(TT, HH, 1) : SX_GOF(TT, HH, 2); }
+        SX_GO(1, 1); SX_GO(1, 2); SX_GO(1, 4); SX_GO(2, 1); SX_GO(2, 2); SX_GO(2, 4); SX_GO(4, 1); SX_GO(4, 2); SX_GO(4, 4);
+        SX_GO(8, 1); SX_GO(8, 2); SX_GO(8, 4);
 #undef SX_GO
 #undef SX_GOF
-    sx_set_error("sx_flow_run: unsupported tile configuration");
-    return SX_E_UNSUPPORTED;
+        if (!found) { sx_set_error("sx_flow_run: unsupported tile configuration"); return SX_E_UNSUPPORTED; }
+        if (rc2 != SX_OK) return rc2;
+    }
+    return SX_OK;
 }
 
 

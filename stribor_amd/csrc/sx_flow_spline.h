@@ -162,18 +162,31 @@ __device__ __forceinline__ void rqs_select16(tile<1> (&acc)[4], rqs_elems &e, fl
 // plus the lower bound, ends pinned -- rational_quadratic_spline.py:180-192).
 // ------------------------------------------------------------------------------------------------
 #define RQS16_BOUND 96.0f
+// Round 6: the same code for ANY K <= 16 (`GEN`; K = 16 keeps its own instance).  K = 8 used to run 1.6 x SLOWER than K = 16 -- every
+// bin count but sixteen took the K-generic sweeps.  The packer parks the unused slots of a tile where they cost nothing
+// (fused.py add_coupling_rqs: logits of bins >= K at -1e30, so exp2 is 0 and every prefix sum is unchanged; derivative rows >= K - 1
+// at the boundary constant, so D[K - 1] needs no select), and what is left for the kernel is the reference's end handling:
+//   * knots of index >= K are never compared (rational_quadratic_spline.py:185-192 pins knot K to `hi` and search_sorted.py adds
+//     1e-6 to it, so x = hi falls in bin K - 1): a group boundary 4 j >= K gets the constant +inf (free: it is the fma's addend);
+//     inside the LAST reachable group the compares with local knots i >= K - 4 glast are masked (lane-mask and-not: scalar);
+//   * the right knot of bin K - 1 is `hi` exactly: one compare of the bin index with K - 1 and one select per softmax block.
 struct rqs16_c {            // per-phase constants (uniform; one set per phase step, shared by the lane's four elements)
     float lo, hi;
-    float cs;               // (1 - 16 MIN) (hi - lo)
+    float cs;               // (1 - K MIN) (hi - lo)
     float sm1, sm2, sm3, sm4;    // i MIN (hi - lo)
-    float l4, l8, l12;      // lo + 4 j MIN (hi - lo): the group boundaries' constant part
+    float l4, l8, l12;      // lo + 4 j MIN (hi - lo): the group boundaries' constant part (GEN: +inf where 4 j >= K)
+    int Km1, glast;         // GEN: K - 1; the last reachable group (K - 1) / 4
+    bool u1, u2, u3;        // GEN: local knot i of the last group has index >= K
 };
-__device__ __forceinline__ rqs16_c rqs16_consts(float lo, float hi) {
+__device__ __forceinline__ rqs16_c rqs16_consts(float lo, float hi, int K = 16) {
     rqs16_c c;
-    const float span = hi - lo, sm = RQS_MIN * span;
-    c.lo = lo; c.hi = hi; c.cs = (1.f - 16.f * RQS_MIN) * span;
+    const float span = hi - lo, sm = RQS_MIN * span, inf = __builtin_inff();
+    c.lo = lo; c.hi = hi; c.cs = (1.f - (float)K * RQS_MIN) * span;
     c.sm1 = sm; c.sm2 = 2.f * sm; c.sm3 = 3.f * sm; c.sm4 = 4.f * sm;
-    c.l4 = lo + 4.f * sm; c.l8 = lo + 8.f * sm; c.l12 = lo + 12.f * sm;
+    c.l4 = 4 < K ? lo + 4.f * sm : inf; c.l8 = 8 < K ? lo + 8.f * sm : inf; c.l12 = 12 < K ? lo + 12.f * sm : inf;
+    c.Km1 = K - 1; c.glast = (K - 1) >> 2;
+    const int iK = K - 4 * c.glast;             // 1 .. 4: the local index of knot K in the last group
+    c.u1 = 1 >= iK; c.u2 = 2 >= iK; c.u3 = 3 >= iK;
     return c;
 }
 // (a function taking VALUES: see above)
@@ -186,8 +199,17 @@ __device__ __forceinline__ float rqs16_pick(bool m1, bool m2, bool m3, float v0,
 // A fragments of k16-step T + 1 requested at the first MFMA of step T (two fragment buffers).  The prescriptive alternative,
 // sched_group_barrier groups over one fenced region, was tried first: the solver honoured the first four MFMA / VALU groups and
 // left the other eight MFMAs back to back in front of sixty vector instructions.
+// (`tie...`: values the element's arithmetic has produced since the previous point.  Each passes through an empty volatile asm in
+//  front of the point's MFMAs and the accumulator through one behind each MFMA: volatile asms keep their order, so the element's
+//  vector work stays BETWEEN the MFMAs.  Round 6: with scheduling fences alone the optimizer sank the whole search and select
+//  arithmetic of a group -- pure code whose results are first read by the evaluate block -- into that third block, kept all eight raw
+//  logit tiles alive (128 registers) and left the first two blocks' 96 MFMAs bare: the ISA of <1,2,2,3>, LBB0_213 / 217 / 221.)
 struct rqs_nohook {
-    template <int P> __device__ __forceinline__ void pt() {}
+    template <int P, class... T> __device__ __forceinline__ void pt(T &...) {}
+};
+template <class T> __device__ __forceinline__ void rqs_tie_one(T &v) { asm volatile("" : "+v"(v)); }
+struct rqs_pinhook {        // a block's LAST element: no MFMAs to issue, but its arithmetic stays in its block all the same
+    template <int P, class... T> __device__ __forceinline__ void pt(T &...tie) { (rqs_tie_one(tie), ...); }
 };
 template <int HT, int U>
 struct rqs_tile_pipe {
@@ -211,6 +233,7 @@ struct rqs_tile_pipe {
         if constexpr (k == 0) acc.v[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[m].hi[0][s2], acc.v[0], 0, 0, 0);      // smallest terms first
         else if constexpr (k == 1) acc.v[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[m].lo[0][s2], acc.v[0], 0, 0, 0);
         else acc.v[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[m].hi[0][s2], acc.v[0], 0, 0, 0);
+        asm volatile("" : "+v"(acc.v[0]));
     }
     template <int J, int JE> __device__ __forceinline__ void run() {
         if constexpr (J < JE) { mfma<J>(); run<J + 1, JE>(); }
@@ -220,8 +243,9 @@ struct rqs_tile_pipe {
         load<0>();
         __builtin_amdgcn_sched_barrier(0);
     }
-    template <int P> __device__ __forceinline__ void pt() {
+    template <int P, class... T> __device__ __forceinline__ void pt(T &...tie) {
         constexpr int N = 6 * HT;
+        (rqs_tie_one(tie), ...);
         __builtin_amdgcn_sched_barrier(0);
         run<P * N / 12, (P + 1) * N / 12>();
         __builtin_amdgcn_sched_barrier(0);
@@ -233,7 +257,7 @@ struct rqs_tile_pipe {
 #pragma unroll
         for (int m = 0; m < HT; ++m) gemm_tile<1>(wb, (U * HT + m) * 1024, bh[m], acc);
     }
-    template <int P> __device__ __forceinline__ void pt() {}
+    template <int P, class... T> __device__ __forceinline__ void pt(T &...) {}
 #endif
 };
 // exp2 of a tile's 16 logits, the groups' inner prefixes (e0, e0+e1, e0+e1+e2, the group's sum), the group boundaries' knots
@@ -247,13 +271,13 @@ __device__ __forceinline__ rqs16_s rqs16_sums(const f32x16 &u, const rqs16_c &c,
     rqs16_s s;
     hk.template pt<0>();
     s.a0 = __builtin_amdgcn_exp2f(u[0]); s.a1 = s.a0 + __builtin_amdgcn_exp2f(u[1]); s.a2 = s.a1 + __builtin_amdgcn_exp2f(u[2]); s.a3 = s.a2 + __builtin_amdgcn_exp2f(u[3]);
-    hk.template pt<1>();
+    hk.template pt<1>(s.a3);
     s.b0 = __builtin_amdgcn_exp2f(u[4]); s.b1 = s.b0 + __builtin_amdgcn_exp2f(u[5]); s.b2 = s.b1 + __builtin_amdgcn_exp2f(u[6]); s.b3 = s.b2 + __builtin_amdgcn_exp2f(u[7]);
-    hk.template pt<2>();
+    hk.template pt<2>(s.b3);
     s.c0 = __builtin_amdgcn_exp2f(u[8]); s.c1 = s.c0 + __builtin_amdgcn_exp2f(u[9]); s.c2 = s.c1 + __builtin_amdgcn_exp2f(u[10]); s.c3 = s.c2 + __builtin_amdgcn_exp2f(u[11]);
-    hk.template pt<3>();
+    hk.template pt<3>(s.c3);
     s.d0 = __builtin_amdgcn_exp2f(u[12]); s.d1 = s.d0 + __builtin_amdgcn_exp2f(u[13]); s.d2 = s.d1 + __builtin_amdgcn_exp2f(u[14]); s.d3 = s.d2 + __builtin_amdgcn_exp2f(u[15]);
-    hk.template pt<4>();
+    hk.template pt<4>(s.d3);
     const float G2 = s.a3 + s.b3, G3 = G2 + s.c3;
     s.sinv = c.cs * fast_rcp(G3 + s.d3);
     s.T1 = __builtin_fmaf(s.sinv, s.a3, c.l4);
@@ -262,62 +286,69 @@ __device__ __forceinline__ rqs16_s rqs16_sums(const f32x16 &u, const rqs16_c &c,
     return s;
 }
 // the knots around the group chosen by the nested masks m1 >= m2 >= m3 (group >= 1, 2, 3); points 6 .. 8
-template <class H>
+template <bool GEN, class H>
 __device__ __forceinline__ void rqs16_knots(const rqs16_s &s, const rqs16_c &c, bool m1, bool m2, bool m3, float &k0, float &k1, float &k2,
                                             float &k3, float &k4, H &hk) {
     k0 = rqs16_pick(m1, m2, m3, c.lo, s.T1, s.T2, s.T3);
-    const float p1 = rqs16_pick(m1, m2, m3, s.a0, s.b0, s.c0, s.d0);
-    hk.template pt<6>();
+    float p1 = rqs16_pick(m1, m2, m3, s.a0, s.b0, s.c0, s.d0);
+    hk.template pt<6>(k0, p1);
     const float p2 = rqs16_pick(m1, m2, m3, s.a1, s.b1, s.c1, s.d1);
-    const float p3 = rqs16_pick(m1, m2, m3, s.a2, s.b2, s.c2, s.d2);
+    float p3 = rqs16_pick(m1, m2, m3, s.a2, s.b2, s.c2, s.d2);
     k1 = __builtin_fmaf(s.sinv, p1, k0 + c.sm1);
     k2 = __builtin_fmaf(s.sinv, p2, k0 + c.sm2);
-    hk.template pt<7>();
+    hk.template pt<7>(k1, k2, p3);
     const float p4 = rqs16_pick(m1, m2, m3, s.a3, s.b3, s.c3, s.d3);
     k3 = __builtin_fmaf(s.sinv, p3, k0 + c.sm3);
     const float k4c = __builtin_fmaf(s.sinv, p4, k0 + c.sm4);
     const float hi_ = c.hi;
-    k4 = m3 ? hi_ : k4c;                                                // ends pinned (:189-192)
-    hk.template pt<8>();
+    k4 = GEN ? k4c : (m3 ? hi_ : k4c);                                  // ends pinned (:189-192; GEN: by the bin index, below)
+    hk.template pt<8>(k3, k4);
 }
-template <int Q, class H>
+template <int Q, bool GEN, class H>
 __device__ __forceinline__ void rqs16_search(const f32x16 &u, rqs_elems &e, const rqs16_c &c, H &hk) {
-    const rqs16_s s = rqs16_sums(u, c, hk);
-    hk.template pt<5>();
+    rqs16_s s = rqs16_sums(u, c, hk);
+    hk.template pt<5>(s.T1, s.T2, s.T3);
     const float xv = e.x[Q];
     const bool in = (xv >= c.lo) && (xv <= c.hi);                       // :71 closed interval
     const float lo_ = c.lo;
     const float xin = in ? xv : lo_;
     const bool m1 = xin >= s.T1, m2 = xin >= s.T2, m3 = xin >= s.T3;    // a prefix: the knots grow
     float k0, k1, k2, k3, k4;
-    rqs16_knots(s, c, m1, m2, m3, k0, k1, k2, k3, k4, hk);
-    const bool g1 = xin >= k1, g2 = xin >= k2, g3 = xin >= k3;
-    const int bg = 4 * ((int)m1 + (int)m2 + (int)m3) + (in ? 0 : RQS_OUT);
-    hk.template pt<9>();
+    rqs16_knots<GEN>(s, c, m1, m2, m3, k0, k1, k2, k3, k4, hk);
+    bool g1 = xin >= k1, g2 = xin >= k2, g3 = xin >= k3;
+    if constexpr (GEN) {
+        // groups beyond glast are unreachable (their boundaries are +inf), so "in the last group" is the mask of boundary glast
+        const bool last = c.glast == 0 ? true : (c.glast == 1 ? m1 : (c.glast == 2 ? m2 : m3));
+        g1 = g1 && !(last && c.u1); g2 = g2 && !(last && c.u2); g3 = g3 && !(last && c.u3);
+    }
+    int bg = 4 * ((int)m1 + (int)m2 + (int)m3) + (in ? 0 : RQS_OUT);
+    hk.template pt<9>(bg);
     e.b[Q] = bg + ((int)g1 + (int)g2 + (int)g3);
-    const float k_b = g3 ? k3 : (g2 ? k2 : (g1 ? k1 : k0));
-    hk.template pt<10>();
-    const float k_n = g3 ? k4 : (g2 ? k3 : (g1 ? k2 : k1));
+    float k_b = g3 ? k3 : (g2 ? k2 : (g1 ? k1 : k0));
+    hk.template pt<10>(k_b, e.b[Q]);
+    float k_n = g3 ? k4 : (g2 ? k3 : (g1 ? k2 : k1));
+    if constexpr (GEN) { const float hi_ = c.hi; k_n = e.b[Q] == c.Km1 ? hi_ : k_n; }     // (an outside input's index carries RQS_OUT: its knots are unused)
     e.a_b[Q] = k_b;
     e.a_w[Q] = k_n - k_b;
-    hk.template pt<11>();
+    hk.template pt<11>(e.a_b[Q], e.a_w[Q]);
 }
-template <int Q, class H>
+template <int Q, bool GEN, class H>
 __device__ __forceinline__ void rqs16_select(const f32x16 &u, rqs_elems &e, const rqs16_c &c, H &hk) {
-    const rqs16_s s = rqs16_sums(u, c, hk);
-    hk.template pt<5>();
+    rqs16_s s = rqs16_sums(u, c, hk);
+    hk.template pt<5>(s.T1, s.T2, s.T3);
     const int b = e.b[Q] & (RQS_OUT - 1), bl = b & 3;
     const bool m1 = b >= 4, m2 = b >= 8, m3 = b >= 12;
     float k0, k1, k2, k3, k4;
-    rqs16_knots(s, c, m1, m2, m3, k0, k1, k2, k3, k4, hk);
+    rqs16_knots<GEN>(s, c, m1, m2, m3, k0, k1, k2, k3, k4, hk);
     const bool g1 = bl >= 1, g2 = bl >= 2, g3 = bl >= 3;
     hk.template pt<9>();
-    const float k_b = g3 ? k3 : (g2 ? k2 : (g1 ? k1 : k0));
-    hk.template pt<10>();
-    const float k_n = g3 ? k4 : (g2 ? k3 : (g1 ? k2 : k1));
+    float k_b = g3 ? k3 : (g2 ? k2 : (g1 ? k1 : k0));
+    hk.template pt<10>(k_b);
+    float k_n = g3 ? k4 : (g2 ? k3 : (g1 ? k2 : k1));
+    if constexpr (GEN) { const float hi_ = c.hi; k_n = b == c.Km1 ? hi_ : k_n; }
     e.c_b[Q] = k_b;
     e.c_w[Q] = k_n - k_b;
-    hk.template pt<11>();
+    hk.template pt<11>(e.c_b[Q], e.c_w[Q]);
 }
 template <int Q, int KC, int W = 1>
 __device__ __forceinline__ void rqs_search(tile<1> (&acc)[4], rqs_elems &e, int K, float lo, float hi) {
@@ -391,10 +422,10 @@ __device__ __forceinline__ float rqs_softplus(float v) { return v > 20.f ? v : f
 // inverse (:212-234; the returned log-derivative is already negated like the reference's), the linear tails (:86-87)
 template <int Q, bool REV, class H>
 __device__ __forceinline__ void rqs_eval_core(float r_b, float r_n, bool in, const rqs_elems &e, float &out, float &ljd, H &hk) {
-    const float d_b = RQS_MIN + rqs_softplus(r_b);
-    hk.template pt<4>();
-    const float d_n = RQS_MIN + rqs_softplus(r_n);
-    hk.template pt<5>();
+    float d_b = RQS_MIN + rqs_softplus(r_b);
+    hk.template pt<4>(d_b);
+    float d_n = RQS_MIN + rqs_softplus(r_n);
+    hk.template pt<5>(d_n);
     // REV: the searched block is the heights (codomain side), the selected one the widths
     const float cw_b = REV ? e.c_b[Q] : e.a_b[Q], w_b = REV ? e.c_w[Q] : e.a_w[Q];
     const float ch_b = REV ? e.a_b[Q] : e.c_b[Q], h_b = REV ? e.a_w[Q] : e.c_w[Q];
@@ -402,43 +433,43 @@ __device__ __forceinline__ void rqs_eval_core(float r_b, float r_n, bool in, con
     const float xin = in ? e.x[Q] : (REV ? ch_b : cw_b);
     if constexpr (REV) {
         const float dy = xin - ch_b;
-        const float q = d_b + d_n - 2.f * s_b;
-        hk.template pt<6>();
+        float q = d_b + d_n - 2.f * s_b;
+        hk.template pt<6>(q);
         const float a = dy * q + h_b * (s_b - d_b);
         const float bb = h_b * d_b - dy * q;
         const float c = -s_b * dy;
-        const float disc = bb * bb - 4.f * a * c;
-        hk.template pt<7>();
+        float disc = bb * bb - 4.f * a * c;
+        hk.template pt<7>(disc);
         // (disc >= 0 in exact arithmetic -- the spline is monotone --; rounding can leave it a few ulps below zero where the root
         //  sits on a knot and the reference's own fp32 evaluation stays at or above it: clamp instead of returning NaN, :223)
         // the root is a position inside the bin: rounding can also leave it an ulp outside [0, 1], where a steep bin next
         // to a flat one (slope ~1e3, knot derivative ~1e-3) turns the derivative's numerator negative and its log into NaN
         const float root = __builtin_amdgcn_fmed3f((2.f * c) * fast_rcp(-bb - __builtin_amdgcn_sqrtf(__builtin_fmaxf(disc, 0.f))), 0.f, 1.f);
         out = root * w_b + cw_b;
-        hk.template pt<8>();
+        hk.template pt<8>(out);
         const float tomt = root * (1.f - root), omr = 1.f - root;
-        const float den = s_b + q * tomt;
-        hk.template pt<9>();
-        const float dnum = (s_b * s_b) * (d_n * (root * root) + 2.f * s_b * tomt + d_b * (omr * omr));
-        hk.template pt<10>();
+        float den = s_b + q * tomt;
+        hk.template pt<9>(den);
+        float dnum = (s_b * s_b) * (d_n * (root * root) + 2.f * s_b * tomt + d_b * (omr * omr));
+        hk.template pt<10>(dnum);
         ljd = -fast_log(dnum) + 2.f * fast_log(den);
     } else {
-        const float theta = (xin - cw_b) * fast_rcp(w_b);
-        hk.template pt<6>();
+        float theta = (xin - cw_b) * fast_rcp(w_b);
+        hk.template pt<6>(theta);
         const float tomt = theta * (1.f - theta), omt = 1.f - theta;
-        const float num = h_b * (s_b * (theta * theta) + d_b * tomt);
-        hk.template pt<7>();
-        const float den = s_b + (d_b + d_n - 2.f * s_b) * tomt;
+        float num = h_b * (s_b * (theta * theta) + d_b * tomt);
+        hk.template pt<7>(num);
+        float den = s_b + (d_b + d_n - 2.f * s_b) * tomt;
         out = ch_b + num * fast_rcp(den);
-        hk.template pt<8>();
-        const float dnum = (s_b * s_b) * (d_n * (theta * theta) + 2.f * s_b * tomt + d_b * (omt * omt));
-        hk.template pt<9>();
+        hk.template pt<8>(out, den);
+        float dnum = (s_b * s_b) * (d_n * (theta * theta) + 2.f * s_b * tomt + d_b * (omt * omt));
+        hk.template pt<9>(dnum);
         hk.template pt<10>();
         ljd = fast_log(dnum) - 2.f * fast_log(den);
     }
     out = in ? out : e.x[Q];                                    // :86-87 linear tails
     ljd = in ? ljd : 0.f;
-    hk.template pt<11>();
+    hk.template pt<11>(out, ljd);
 }
 template <int Q, bool REV, int KC, class H>
 __device__ __forceinline__ void rqs_eval(const f32x16 &u, const rqs_elems &e, int K, float &out, float &ljd, H &hk) {
@@ -462,16 +493,16 @@ __device__ __forceinline__ void rqs_eval(const f32x16 &u, const rqs_elems &e, in
         const float d0 = u[0], d1 = u[1], d2 = u[2], d3 = u[3], d4 = u[4];
         const float d5 = u[5], d6 = u[6], d7 = u[7], d8 = u[8], d9 = u[9];
         const float d10 = u[10], d11 = u[11], d12 = u[12], d13 = u[13], d14 = u[14];
-        const float v0 = m3 ? d11 : (m2 ? d7 : (m1 ? d3 : cst)), v1 = m3 ? d12 : (m2 ? d8 : (m1 ? d4 : d0));
-        hk.template pt<1>();
-        const float v2 = m3 ? d13 : (m2 ? d9 : (m1 ? d5 : d1)), v3 = m3 ? d14 : (m2 ? d10 : (m1 ? d6 : d2));
-        const float v4 = m3 ? cst : (m2 ? d11 : (m1 ? d7 : d3));
-        hk.template pt<2>();
+        float v0 = m3 ? d11 : (m2 ? d7 : (m1 ? d3 : cst)), v1 = m3 ? d12 : (m2 ? d8 : (m1 ? d4 : d0));
+        hk.template pt<1>(v0, v1);
+        float v2 = m3 ? d13 : (m2 ? d9 : (m1 ? d5 : d1)), v3 = m3 ? d14 : (m2 ? d10 : (m1 ? d6 : d2));
+        float v4 = m3 ? cst : (m2 ? d11 : (m1 ? d7 : d3));
+        hk.template pt<2>(v2, v3, v4);
         const int bl = b & 3;
         const bool g1 = bl >= 1, g2 = bl >= 2, g3 = bl >= 3;
         r_b = g3 ? v3 : (g2 ? v2 : (g1 ? v1 : v0));
         r_n = g3 ? v4 : (g2 ? v3 : (g1 ? v2 : v1));
-        hk.template pt<3>();
+        hk.template pt<3>(r_b, r_n);
     } else
 #endif
     {
@@ -536,10 +567,10 @@ __device__ __forceinline__ void rqs_phase_k(tile<1> (&acc)[4], tile<1> (&xs)[TX]
         if constexpr (KC == 16) {
             const rqs16_c c = rqs16_consts(lo, hi);
             rqs_nohook nh16;
-            rqs16_search<0>(acc[0].v[0], e, c, nh16); __builtin_amdgcn_sched_barrier(0);
-            rqs16_search<1>(acc[1].v[0], e, c, nh16); __builtin_amdgcn_sched_barrier(0);
-            rqs16_search<2>(acc[2].v[0], e, c, nh16); __builtin_amdgcn_sched_barrier(0);
-            rqs16_search<3>(acc[3].v[0], e, c, nh16);
+            rqs16_search<0, false>(acc[0].v[0], e, c, nh16); __builtin_amdgcn_sched_barrier(0);
+            rqs16_search<1, false>(acc[1].v[0], e, c, nh16); __builtin_amdgcn_sched_barrier(0);
+            rqs16_search<2, false>(acc[2].v[0], e, c, nh16); __builtin_amdgcn_sched_barrier(0);
+            rqs16_search<3, false>(acc[3].v[0], e, c, nh16);
         } else
 #endif
         {
@@ -553,10 +584,10 @@ __device__ __forceinline__ void rqs_phase_k(tile<1> (&acc)[4], tile<1> (&xs)[TX]
         if constexpr (KC == 16) {
             const rqs16_c c = rqs16_consts(lo, hi);
             rqs_nohook nh16;
-            rqs16_select<0>(acc[0].v[0], e, c, nh16); __builtin_amdgcn_sched_barrier(0);
-            rqs16_select<1>(acc[1].v[0], e, c, nh16); __builtin_amdgcn_sched_barrier(0);
-            rqs16_select<2>(acc[2].v[0], e, c, nh16); __builtin_amdgcn_sched_barrier(0);
-            rqs16_select<3>(acc[3].v[0], e, c, nh16);
+            rqs16_select<0, false>(acc[0].v[0], e, c, nh16); __builtin_amdgcn_sched_barrier(0);
+            rqs16_select<1, false>(acc[1].v[0], e, c, nh16); __builtin_amdgcn_sched_barrier(0);
+            rqs16_select<2, false>(acc[2].v[0], e, c, nh16); __builtin_amdgcn_sched_barrier(0);
+            rqs16_select<3, false>(acc[3].v[0], e, c, nh16);
         } else
 #endif
         {
@@ -600,6 +631,7 @@ __device__ __forceinline__ void rqs_phase_k(tile<1> (&acc)[4], tile<1> (&xs)[TX]
 template <int TX, int HT>
 __device__ __forceinline__ void rqs_phase(tile<1> (&xs)[TX], const btile<1> (&bh)[HT], rqs_elems &e, const wptr w,
                                           const dstep &st, float &ldj, int lane, bool &group_lean) {
+    SX_DEP_MARK_SPLINE;
     const int h = lane >> 5;
     tile<1> acc[4];
     rqs_gemm<HT>(w, bh, acc);
@@ -658,11 +690,11 @@ __device__ __forceinline__ void rqs_block_scalars(const wptr w, int h, float &lo
 //  between, and the bias / first fragments of tile q + 2 requested from element q -- was built and measured: the in-kernel stamps
 //  moved (first tiles 25 % -> 8 % of the wave cycles, last elements 8 % -> 4 %) but the kernel did not (5.31 -> 5.36 ms per 2^20
 //  rows): what one wave leaves idle the SIMD's other wave was already using.  It cost 41 registers and is not kept.)
-template <int PH, bool REV, int Q, class H>
+template <int PH, bool REV, int Q, bool GEN = false, class H>
 __device__ __forceinline__ void rqs16_unit(const f32x16 &u, rqs_elems &e, const rqs16_c &c, float (&out)[4], float (&lj)[4], H &hk) {
-    if constexpr (PH == 0) rqs16_search<Q>(u, e, c, hk);
-    else if constexpr (PH == 1) rqs16_select<Q>(u, e, c, hk);
-    else rqs_eval<Q, REV, 16>(u, e, 16, out[Q], lj[Q], hk);
+    if constexpr (PH == 0) rqs16_search<Q, GEN>(u, e, c, hk);
+    else if constexpr (PH == 1) rqs16_select<Q, GEN>(u, e, c, hk);
+    else rqs_eval<Q, REV, 16>(u, e, 16, out[Q], lj[Q], hk);       // (K < 16: rows >= K - 1 of the derivative tile hold the boundary constant)
 }
 template <int HT, int PH, bool REV>
 __device__ __forceinline__ void rqs16_block(const wptr w, const btile<1> (&bh)[HT], rqs_elems &e, const rqs16_c &c, float (&out)[4],
@@ -678,12 +710,53 @@ __device__ __forceinline__ void rqs16_block(const wptr w, const btile<1> (&bh)[H
     { rqs_tile_pipe<HT, 2> p(w, bh, A); p.start(); rqs16_unit<PH, REV, 1>(B.v[0], e, c, out, lj, p); }
     { rqs_tile_pipe<HT, 3> p(w, bh, B); p.start(); rqs16_unit<PH, REV, 2>(A.v[0], e, c, out, lj, p); }
     SX_STAMP(pf, 4);     // three (tile GEMM, element) pairs
-    { rqs_nohook nh; rqs16_unit<PH, REV, 3>(B.v[0], e, c, out, lj, nh); }
+    { rqs_pinhook nh; rqs16_unit<PH, REV, 3>(B.v[0], e, c, out, lj, nh); }
     SX_STAMP(pf, 5);     // the last element (no MFMAs beside it)
+}
+// elements 0 .. 2 of a block beside its tiles 1 .. 3 (tile 0 is in A on entry, tile 3 in B on exit)
+template <int HT, int PH, bool REV, bool GEN>
+__device__ __forceinline__ void rqs16_mid(const wptr w, const btile<1> (&bh)[HT], rqs_elems &e, const rqs16_c &c, float (&out)[4],
+                                          float (&lj)[4], tile<1> &A, tile<1> &B) {
+    { rqs_tile_pipe<HT, 1> p(w, bh, B); p.start(); rqs16_unit<PH, REV, 0, GEN>(A.v[0], e, c, out, lj, p); }
+    { rqs_tile_pipe<HT, 2> p(w, bh, A); p.start(); rqs16_unit<PH, REV, 1, GEN>(B.v[0], e, c, out, lj, p); }
+    { rqs_tile_pipe<HT, 3> p(w, bh, B); p.start(); rqs16_unit<PH, REV, 2, GEN>(A.v[0], e, c, out, lj, p); }
+}
+// the lean form of a whole group (three blocks, two step advances): see rqs_triple
+template <int HT, bool GEN, class ADV>
+__device__ __forceinline__ void rqs16_group(const wptr w0, const btile<1> (&bh)[HT], rqs_elems &e, int K, float lo, float hi, int h,
+                                            ADV &&advance, float (&out)[4], float (&lj)[4], uint32_t &live_mask, float &ldj_scale) {
+    wptr w;
+    dstep st;
+    bool lean;
+    // round 6: the pipeline runs over the whole group -- a block's LAST element is evaluated beside the NEXT block's first tile
+    // (behind the step advance: that tile's weights are the next step's), so of a group's twelve (tile, element) pairs only the
+    // first tile and the last element stand alone
+    tile<1> A, B;
+    A = load_cfrag<1>(w0.cb, 4 * HT * 1024);
+#pragma unroll
+    for (int m = 0; m < HT; ++m) gemm_tile<1>(w0.wb, m * 1024, bh[m], A);
+    const rqs16_c c0 = rqs16_consts(lo, hi, GEN ? K : 16);
+    rqs16_mid<HT, 0, false, GEN>(w0, bh, e, c0, out, lj, A, B);
+    advance(st, w);
+    rqs_block_scalars<HT>(w, h, lo, hi, lean);
+    const rqs16_c c1 = rqs16_consts(lo, hi, GEN ? K : 16);
+    { rqs_tile_pipe<HT, 0> p(w, bh, A); p.start(); rqs16_unit<0, false, 3, GEN>(B.v[0], e, c0, out, lj, p); }
+    rqs16_mid<HT, 1, false, GEN>(w, bh, e, c1, out, lj, A, B);
+    advance(st, w);
+    { rqs_tile_pipe<HT, 0> p(w, bh, A); p.start(); rqs16_unit<1, false, 3, GEN>(B.v[0], e, c1, out, lj, p); }
+    if (st.reverse) {
+        rqs16_mid<HT, 2, true, GEN>(w, bh, e, c1, out, lj, A, B);
+        rqs_pinhook nh; rqs16_unit<2, true, 3, GEN>(B.v[0], e, c1, out, lj, nh);
+    } else {
+        rqs16_mid<HT, 2, false, GEN>(w, bh, e, c1, out, lj, A, B);
+        rqs_pinhook nh; rqs16_unit<2, false, 3, GEN>(B.v[0], e, c1, out, lj, nh);
+    }
+    live_mask = st.mask; ldj_scale = st.ldj_scale;
 }
 template <int TX, int HT, class ADV>
 __device__ __forceinline__ void rqs_triple(tile<1> (&xs)[TX], const btile<1> (&bh)[HT], const wptr w0, const dstep &st0, float &ldj,
                                            int lane, ADV &&advance, prof_t &pf) {
+    SX_DEP_MARK_SPLINE;
     const int h = lane >> 5;
     const int K = st0.tt, tg = 4 * st0.t0 + st0.c0;
     rqs_elems e;
@@ -693,7 +766,11 @@ __device__ __forceinline__ void rqs_triple(tile<1> (&xs)[TX], const btile<1> (&b
     float ldj_scale;        // paths below is a stack object
     RQS_GROUP_CASES(RQS_FETCH)
     rqs_block_scalars<HT>(w0, h, lo, hi, lean);     // (the bound in the first block's blob covers both softmax blocks of the group)
-    if (K == 16 && lean) {
+    if (K <= 16 && lean) {
+#ifndef SX_RQS_NO_CHAIN
+        if (K == 16) rqs16_group<HT, false>(w0, bh, e, K, lo, hi, h, advance, out, lj, live_mask, ldj_scale);
+        else rqs16_group<HT, true>(w0, bh, e, K, lo, hi, h, advance, out, lj, live_mask, ldj_scale);
+#else
         wptr w;
         dstep st;
         rqs16_block<HT, 0, false>(w0, bh, e, rqs16_consts(lo, hi), out, lj, pf);
@@ -705,6 +782,7 @@ __device__ __forceinline__ void rqs_triple(tile<1> (&xs)[TX], const btile<1> (&b
         if (st.reverse) rqs16_block<HT, 2, true>(w, bh, e, c1, out, lj, pf);
         else rqs16_block<HT, 2, false>(w, bh, e, c1, out, lj, pf);
         live_mask = st.mask; ldj_scale = st.ldj_scale;
+#endif
     } else if (K > 16) {
         // 17 .. 32 bins (round 4: the one-launch tier used to stop at 16 and such layers ran conditioner program + element-wise kernel
         // through HBM, 8x slower): an element's parameters are TWO output tiles, so a step carries two of the lane's four elements
@@ -932,30 +1010,30 @@ __device__ __forceinline__ void cub_eval(const f32x16 &u, const cubic_elems &e, 
     const float w_m = REV ? e.o_m[Q] : e.s_m[Q], w_b = REV ? e.o_b[Q] : e.s_b[Q], w_p = REV ? e.o_p[Q] : e.s_p[Q];
     const float h_m = REV ? e.s_m[Q] : e.o_m[Q], h_b = REV ? e.s_b[Q] : e.o_b[Q], h_p = REV ? e.s_p[Q] : e.o_p[Q];
     const float cw_b = REV ? e.o_k[Q] : e.s_k[Q], ch_b = REV ? e.s_k[Q] : e.o_k[Q];
-    const cubic_coef cf = cubic_bin_coef(b, K, w_b, h_b, w_m, h_m, w_p, h_p, u[0], u[1]);
-    hk.template pt<1>(); hk.template pt<2>();
+    cubic_coef cf = cubic_bin_coef(b, K, w_b, h_b, w_m, h_m, w_p, h_p, u[0], u[1]);
+    hk.template pt<1>(cf.a, cf.bb, cf.c); hk.template pt<2>();
     const float a = cf.a, bb = cf.bb, c = cf.c, d = ch_b;
     const float xn = cub_norm(e.x[Q], in, lo, hi), span = hi - lo;
     if constexpr (REV) {
-        const float rcw = (b == K - 1) ? 1.f : cw_b + w_b;                                 // :107 (last knot pinned)
-        hk.template pt<3>(); hk.template pt<4>(); hk.template pt<5>();
-        const float so = cubic_invert(a, bb, c, d, xn, cw_b, rcw);
-        hk.template pt<6>(); hk.template pt<7>(); hk.template pt<8>(); hk.template pt<9>();
+        float rcw = (b == K - 1) ? 1.f : cw_b + w_b;                                       // :107 (last knot pinned)
+        hk.template pt<3>(rcw); hk.template pt<4>(); hk.template pt<5>();
+        float so = cubic_invert(a, bb, c, d, xn, cw_b, rcw);
+        hk.template pt<6>(so); hk.template pt<7>(); hk.template pt<8>(); hk.template pt<9>();
         out = fminf(fmaxf((so + cw_b) * span + lo, lo), hi);                               // :235 (clamped: see cubic_kernel)
         const bool in2 = (out >= lo) && (out <= hi);
-        const float t2 = cub_norm(out, in2, lo, hi) - cw_b;
-        hk.template pt<10>();
+        float t2 = cub_norm(out, in2, lo, hi) - cw_b;
+        hk.template pt<10>(t2);
         ljd = in2 ? -cubic_flog(3.f * a * (t2 * t2) + 2.f * bb * t2 + c) : 0.f;            // flow.py:42-47
     } else {
         hk.template pt<3>(); hk.template pt<4>(); hk.template pt<5>();
-        const float t = xn - cw_b;                                                         // :229
+        float t = xn - cw_b;                                                               // :229
         out = (a * (t * t * t) + bb * (t * t) + c * t + d) * span + lo;                    // :230-233, :238
-        hk.template pt<6>(); hk.template pt<7>(); hk.template pt<8>(); hk.template pt<9>(); hk.template pt<10>();
+        hk.template pt<6>(out, t); hk.template pt<7>(); hk.template pt<8>(); hk.template pt<9>(); hk.template pt<10>();
         ljd = cubic_flog(3.f * a * (t * t) + 2.f * bb * t + c);                            // :235-237
     }
     out = in ? out : e.x[Q];                                                               // :46-48 linear tails
     ljd = in ? ljd : 0.f;
-    hk.template pt<11>();
+    hk.template pt<11>(out, ljd);
 }
 template <int Q, bool REV>
 __device__ __forceinline__ void cub_eval(tile<1> (&acc)[4], const cubic_elems &e, int K, float lo, float hi, float &out, float &ljd) {
@@ -972,26 +1050,44 @@ struct cub16_s {
     float T1, T2, T3;       // knots at bins 4, 8, 12
     float inv;              // (1 - 16 MIN) / sum
 };
+// (any K <= 16, round 6: as rqs16_c -- the packer parks the logits of bins >= K at -1e30; group boundaries 4 j >= K get +inf, the
+//  compares with local knots of index >= K in the last reachable group are masked; cubic_bin_coef / cub_eval take K itself)
+struct cub16_c {
+    float cK;               // 1 - K MIN
+    float t4, t8, t12;      // 4 j MIN (GEN: +inf where 4 j >= K)
+    int K, glast;
+    bool u1, u2, u3;
+};
+__device__ __forceinline__ cub16_c cub16_consts(int K = 16) {
+    cub16_c c;
+    const float inf = __builtin_inff();
+    c.cK = 1.f - (float)K * CUBIC_MIN_BIN;
+    c.t4 = 4 < K ? 4.f * CUBIC_MIN_BIN : inf; c.t8 = 8 < K ? 8.f * CUBIC_MIN_BIN : inf; c.t12 = 12 < K ? 12.f * CUBIC_MIN_BIN : inf;
+    c.K = K; c.glast = (K - 1) >> 2;
+    const int iK = K - 4 * c.glast;
+    c.u1 = 1 >= iK; c.u2 = 2 >= iK; c.u3 = 3 >= iK;
+    return c;
+}
 template <class H>
-__device__ __forceinline__ void cub16_sums(const f32x16 &u, float (&ev)[16], float &T1, float &T2, float &T3, float &inv, H &hk) {
+__device__ __forceinline__ void cub16_sums(const f32x16 &u, const cub16_c &cc, float (&ev)[16], float &T1, float &T2, float &T3, float &inv, H &hk) {
     hk.template pt<0>();
     ev[0] = __builtin_amdgcn_exp2f(u[0]); ev[1] = __builtin_amdgcn_exp2f(u[1]); ev[2] = __builtin_amdgcn_exp2f(u[2]); ev[3] = __builtin_amdgcn_exp2f(u[3]);
-    const float g0 = (ev[0] + ev[1]) + (ev[2] + ev[3]);
-    hk.template pt<1>();
+    float g0 = (ev[0] + ev[1]) + (ev[2] + ev[3]);
+    hk.template pt<1>(g0);
     ev[4] = __builtin_amdgcn_exp2f(u[4]); ev[5] = __builtin_amdgcn_exp2f(u[5]); ev[6] = __builtin_amdgcn_exp2f(u[6]); ev[7] = __builtin_amdgcn_exp2f(u[7]);
-    const float g1 = (ev[4] + ev[5]) + (ev[6] + ev[7]);
-    hk.template pt<2>();
+    float g1 = (ev[4] + ev[5]) + (ev[6] + ev[7]);
+    hk.template pt<2>(g1);
     ev[8] = __builtin_amdgcn_exp2f(u[8]); ev[9] = __builtin_amdgcn_exp2f(u[9]); ev[10] = __builtin_amdgcn_exp2f(u[10]); ev[11] = __builtin_amdgcn_exp2f(u[11]);
-    const float g2 = (ev[8] + ev[9]) + (ev[10] + ev[11]);
-    hk.template pt<3>();
+    float g2 = (ev[8] + ev[9]) + (ev[10] + ev[11]);
+    hk.template pt<3>(g2);
     ev[12] = __builtin_amdgcn_exp2f(u[12]); ev[13] = __builtin_amdgcn_exp2f(u[13]); ev[14] = __builtin_amdgcn_exp2f(u[14]); ev[15] = __builtin_amdgcn_exp2f(u[15]);
-    const float g3 = (ev[12] + ev[13]) + (ev[14] + ev[15]);
-    hk.template pt<4>();
+    float g3 = (ev[12] + ev[13]) + (ev[14] + ev[15]);
+    hk.template pt<4>(g3);
     const float G2 = g0 + g1, G3 = G2 + g2;
-    inv = (1.f - 16.f * CUBIC_MIN_BIN) * cubic_frcp(G3 + g3);
-    T1 = __builtin_fmaf(inv, g0, 4.f * CUBIC_MIN_BIN);
-    T2 = __builtin_fmaf(inv, G2, 8.f * CUBIC_MIN_BIN);
-    T3 = __builtin_fmaf(inv, G3, 12.f * CUBIC_MIN_BIN);
+    inv = cc.cK * cubic_frcp(G3 + g3);
+    T1 = __builtin_fmaf(inv, g0, cc.t4);
+    T2 = __builtin_fmaf(inv, G2, cc.t8);
+    T3 = __builtin_fmaf(inv, G3, cc.t12);
 }
 // the group's start knot k0, its three inner knots and the sizes z0..z5 of bins 4g-1 .. 4g+4 (the out-of-range neighbours of the
 // first and the last group are never used: any finite value)
@@ -999,88 +1095,130 @@ template <class H>
 __device__ __forceinline__ void cub16_group(const float (&ev)[16], float T1, float T2, float T3, float inv, bool m1, bool m2, bool m3,
                                             float &k0, float &k1, float &k2, float &k3, float (&z)[6], H &hk) {
     k0 = rqs16_pick(m1, m2, m3, 0.f, T1, T2, T3);
-    const float q0 = rqs16_pick(m1, m2, m3, ev[0], ev[3], ev[7], ev[11]);
-    const float q1 = rqs16_pick(m1, m2, m3, ev[0], ev[4], ev[8], ev[12]);
-    hk.template pt<6>();
-    const float q2 = rqs16_pick(m1, m2, m3, ev[1], ev[5], ev[9], ev[13]);
-    const float q3 = rqs16_pick(m1, m2, m3, ev[2], ev[6], ev[10], ev[14]);
+    float q0 = rqs16_pick(m1, m2, m3, ev[0], ev[3], ev[7], ev[11]);
+    float q1 = rqs16_pick(m1, m2, m3, ev[0], ev[4], ev[8], ev[12]);
+    hk.template pt<6>(k0, q0, q1);
+    float q2 = rqs16_pick(m1, m2, m3, ev[1], ev[5], ev[9], ev[13]);
+    float q3 = rqs16_pick(m1, m2, m3, ev[2], ev[6], ev[10], ev[14]);
     z[0] = __builtin_fmaf(inv, q0, CUBIC_MIN_BIN); z[1] = __builtin_fmaf(inv, q1, CUBIC_MIN_BIN);
-    hk.template pt<7>();
+    hk.template pt<7>(z[0], z[1], q2, q3);
     const float q4 = rqs16_pick(m1, m2, m3, ev[3], ev[7], ev[11], ev[15]);
     const float q5 = rqs16_pick(m1, m2, m3, ev[4], ev[8], ev[12], ev[15]);
     z[2] = __builtin_fmaf(inv, q2, CUBIC_MIN_BIN); z[3] = __builtin_fmaf(inv, q3, CUBIC_MIN_BIN);
-    hk.template pt<8>();
+    hk.template pt<8>(z[2], z[3]);
     z[4] = __builtin_fmaf(inv, q4, CUBIC_MIN_BIN); z[5] = __builtin_fmaf(inv, q5, CUBIC_MIN_BIN);
     k1 = k0 + z[1]; k2 = k1 + z[2]; k3 = k2 + z[3];
 }
 __device__ __forceinline__ float cub16_pick4(bool g1, bool g2, bool g3, float v0, float v1, float v2, float v3) {
     return g3 ? v3 : (g2 ? v2 : (g1 ? v1 : v0));
 }
-template <int Q, class H>
-__device__ __forceinline__ void cub16_search(const f32x16 &u, cubic_elems &e, float lo, float hi, H &hk) {
+template <int Q, bool GEN, class H>
+__device__ __forceinline__ void cub16_search(const f32x16 &u, cubic_elems &e, const cub16_c &cc, float lo, float hi, H &hk) {
     float ev[16], T1, T2, T3, inv;
-    cub16_sums(u, ev, T1, T2, T3, inv, hk);
-    hk.template pt<5>();
+    cub16_sums(u, cc, ev, T1, T2, T3, inv, hk);
+    hk.template pt<5>(T1, T2, T3);
     const float xv = e.x[Q];
     const bool in = (xv >= lo) && (xv <= hi);                       // :40 closed interval
     const float xn = cub_norm(xv, in, lo, hi);
     const bool m1 = xn >= T1, m2 = xn >= T2, m3 = xn >= T3;
     float k0, k1, k2, k3, z[6];
     cub16_group(ev, T1, T2, T3, inv, m1, m2, m3, k0, k1, k2, k3, z, hk);
-    const bool g1 = xn >= k1, g2 = xn >= k2, g3 = xn >= k3;
-    const int bg = 4 * ((int)m1 + (int)m2 + (int)m3) + (in ? 0 : RQS_OUT);
-    hk.template pt<9>();
+    bool g1 = xn >= k1, g2 = xn >= k2, g3 = xn >= k3;
+    if constexpr (GEN) {
+        const bool last = cc.glast == 0 ? true : (cc.glast == 1 ? m1 : (cc.glast == 2 ? m2 : m3));
+        g1 = g1 && !(last && cc.u1); g2 = g2 && !(last && cc.u2); g3 = g3 && !(last && cc.u3);
+    }
+    int bg = 4 * ((int)m1 + (int)m2 + (int)m3) + (in ? 0 : RQS_OUT);
+    hk.template pt<9>(bg, z[4], z[5]);
     e.b[Q] = bg + ((int)g1 + (int)g2 + (int)g3);
     e.s_k[Q] = cub16_pick4(g1, g2, g3, k0, k1, k2, k3);
     e.s_m[Q] = cub16_pick4(g1, g2, g3, z[0], z[1], z[2], z[3]);
-    hk.template pt<10>();
+    hk.template pt<10>(e.b[Q], e.s_k[Q], e.s_m[Q]);
     e.s_b[Q] = cub16_pick4(g1, g2, g3, z[1], z[2], z[3], z[4]);
     e.s_p[Q] = cub16_pick4(g1, g2, g3, z[2], z[3], z[4], z[5]);
-    hk.template pt<11>();
+    hk.template pt<11>(e.s_b[Q], e.s_p[Q]);
 }
 template <int Q, class H>
-__device__ __forceinline__ void cub16_select(const f32x16 &u, cubic_elems &e, H &hk) {
+__device__ __forceinline__ void cub16_select(const f32x16 &u, cubic_elems &e, const cub16_c &cc, H &hk) {
     float ev[16], T1, T2, T3, inv;
-    cub16_sums(u, ev, T1, T2, T3, inv, hk);
-    hk.template pt<5>();
+    cub16_sums(u, cc, ev, T1, T2, T3, inv, hk);
+    hk.template pt<5>(T1, T2, T3);
     const int b = e.b[Q] & (RQS_OUT - 1), bl = b & 3;
     const bool m1 = b >= 4, m2 = b >= 8, m3 = b >= 12;
     float k0, k1, k2, k3, z[6];
     cub16_group(ev, T1, T2, T3, inv, m1, m2, m3, k0, k1, k2, k3, z, hk);
     const bool g1 = bl >= 1, g2 = bl >= 2, g3 = bl >= 3;
-    hk.template pt<9>();
+    hk.template pt<9>(z[4], z[5]);
     e.o_k[Q] = cub16_pick4(g1, g2, g3, k0, k1, k2, k3);
     e.o_m[Q] = cub16_pick4(g1, g2, g3, z[0], z[1], z[2], z[3]);
-    hk.template pt<10>();
+    hk.template pt<10>(e.o_k[Q], e.o_m[Q]);
     e.o_b[Q] = cub16_pick4(g1, g2, g3, z[1], z[2], z[3], z[4]);
     e.o_p[Q] = cub16_pick4(g1, g2, g3, z[2], z[3], z[4], z[5]);
-    hk.template pt<11>();
+    hk.template pt<11>(e.o_b[Q], e.o_p[Q]);
 }
-template <int PH, bool REV, int Q, class H>
-__device__ __forceinline__ void cub16_unit(const f32x16 &u, cubic_elems &e, float lo, float hi, float (&out)[4], float (&lj)[4], H &hk) {
-    if constexpr (PH == 0) cub16_search<Q>(u, e, lo, hi, hk);
-    else if constexpr (PH == 1) cub16_select<Q>(u, e, hk);
-    else cub_eval<Q, REV>(u, e, 16, lo, hi, out[Q], lj[Q], hk);
+template <int PH, bool REV, int Q, bool GEN, class H>
+__device__ __forceinline__ void cub16_unit(const f32x16 &u, cubic_elems &e, const cub16_c &cc, float lo, float hi, float (&out)[4], float (&lj)[4], H &hk) {
+    if constexpr (PH == 0) cub16_search<Q, GEN>(u, e, cc, lo, hi, hk);
+    else if constexpr (PH == 1) cub16_select<Q>(u, e, cc, hk);
+    else cub_eval<Q, REV>(u, e, GEN ? cc.K : 16, lo, hi, out[Q], lj[Q], hk);
 }
 template <int HT, int PH, bool REV>
 __device__ __forceinline__ void cub16_block(const wptr w, const btile<1> (&bh)[HT], cubic_elems &e, float lo, float hi, float (&out)[4],
                                             float (&lj)[4]) {
+    const cub16_c cc = cub16_consts();
     tile<1> A, B;
     {
         A = load_cfrag<1>(w.cb, 4 * HT * 1024);
 #pragma unroll
         for (int m = 0; m < HT; ++m) gemm_tile<1>(w.wb, m * 1024, bh[m], A);
     }
-    { rqs_tile_pipe<HT, 1> p(w, bh, B); p.start(); cub16_unit<PH, REV, 0>(A.v[0], e, lo, hi, out, lj, p); }
-    { rqs_tile_pipe<HT, 2> p(w, bh, A); p.start(); cub16_unit<PH, REV, 1>(B.v[0], e, lo, hi, out, lj, p); }
-    { rqs_tile_pipe<HT, 3> p(w, bh, B); p.start(); cub16_unit<PH, REV, 2>(A.v[0], e, lo, hi, out, lj, p); }
-    { rqs_nohook nh; cub16_unit<PH, REV, 3>(B.v[0], e, lo, hi, out, lj, nh); }
+    { rqs_tile_pipe<HT, 1> p(w, bh, B); p.start(); cub16_unit<PH, REV, 0, false>(A.v[0], e, cc, lo, hi, out, lj, p); }
+    { rqs_tile_pipe<HT, 2> p(w, bh, A); p.start(); cub16_unit<PH, REV, 1, false>(B.v[0], e, cc, lo, hi, out, lj, p); }
+    { rqs_tile_pipe<HT, 3> p(w, bh, B); p.start(); cub16_unit<PH, REV, 2, false>(A.v[0], e, cc, lo, hi, out, lj, p); }
+    { rqs_pinhook nh; cub16_unit<PH, REV, 3, false>(B.v[0], e, cc, lo, hi, out, lj, nh); }
+}
+template <int HT, int PH, bool REV, bool GEN>
+__device__ __forceinline__ void cub16_mid(const wptr w, const btile<1> (&bh)[HT], cubic_elems &e, const cub16_c &cc, float lo, float hi,
+                                          float (&out)[4], float (&lj)[4], tile<1> &A, tile<1> &B) {
+    { rqs_tile_pipe<HT, 1> p(w, bh, B); p.start(); cub16_unit<PH, REV, 0, GEN>(A.v[0], e, cc, lo, hi, out, lj, p); }
+    { rqs_tile_pipe<HT, 2> p(w, bh, A); p.start(); cub16_unit<PH, REV, 1, GEN>(B.v[0], e, cc, lo, hi, out, lj, p); }
+    { rqs_tile_pipe<HT, 3> p(w, bh, B); p.start(); cub16_unit<PH, REV, 2, GEN>(A.v[0], e, cc, lo, hi, out, lj, p); }
+}
+template <int HT, bool GEN, class ADV>
+__device__ __forceinline__ void cub16_group(const wptr w0, const btile<1> (&bh)[HT], cubic_elems &e, int K, float lo, float hi, int h,
+                                            ADV &&advance, float (&out)[4], float (&lj)[4], uint32_t &live_mask, float &ldj_scale) {
+    // (the group-long pipeline of rqs16_group)
+    wptr w;
+    dstep st;
+    bool lean;
+    const cub16_c cc = cub16_consts(GEN ? K : 16);
+    tile<1> A, B;
+    A = load_cfrag<1>(w0.cb, 4 * HT * 1024);
+#pragma unroll
+    for (int m = 0; m < HT; ++m) gemm_tile<1>(w0.wb, m * 1024, bh[m], A);
+    const float lo0 = lo, hi0 = hi;
+    cub16_mid<HT, 0, false, GEN>(w0, bh, e, cc, lo0, hi0, out, lj, A, B);
+    advance(st, w);
+    { rqs_tile_pipe<HT, 0> p(w, bh, A); p.start(); cub16_unit<0, false, 3, GEN>(B.v[0], e, cc, lo0, hi0, out, lj, p); }
+    cub16_mid<HT, 1, false, GEN>(w, bh, e, cc, lo0, hi0, out, lj, A, B);
+    advance(st, w);
+    rqs_block_scalars<HT>(w, h, lo, hi, lean);
+    { rqs_tile_pipe<HT, 0> p(w, bh, A); p.start(); cub16_unit<1, false, 3, GEN>(B.v[0], e, cc, lo0, hi0, out, lj, p); }
+    if (st.reverse) {
+        cub16_mid<HT, 2, true, GEN>(w, bh, e, cc, lo, hi, out, lj, A, B);
+        rqs_pinhook nh; cub16_unit<2, true, 3, GEN>(B.v[0], e, cc, lo, hi, out, lj, nh);
+    } else {
+        cub16_mid<HT, 2, false, GEN>(w, bh, e, cc, lo, hi, out, lj, A, B);
+        rqs_pinhook nh; cub16_unit<2, false, 3, GEN>(B.v[0], e, cc, lo, hi, out, lj, nh);
+    }
+    live_mask = st.mask; ldj_scale = st.ldj_scale;
 }
 // The three blocks of a group in one iteration of the step loop (see rqs_triple)
 #define CUB_FETCH(T, G) { asm volatile("" ::: "memory"); _Pragma("unroll") for (int q = 0; q < 4; ++q) e.x[q] = xs[T].v[0][4 * G + q]; }
 template <int TX, int HT, class ADV>
 __device__ __forceinline__ void cubic_triple(tile<1> (&xs)[TX], const btile<1> (&bh)[HT], const wptr w0, const dstep &st0, float &ldj,
                                              int lane, ADV &&advance) {
+    SX_DEP_MARK_SPLINE;
     const int h = lane >> 5;
     const int K = st0.tt, tg = 4 * st0.t0 + st0.c0;
     cubic_elems e;
@@ -1090,7 +1228,11 @@ __device__ __forceinline__ void cubic_triple(tile<1> (&xs)[TX], const btile<1> (
     float ldj_scale;
     RQS_GROUP_CASES(CUB_FETCH)
     rqs_block_scalars<HT>(w0, h, lo, hi, lean);
-    if (K == 16 && lean) {
+    if (K <= 16 && lean) {
+#ifndef SX_RQS_NO_CHAIN
+        if (K == 16) cub16_group<HT, false>(w0, bh, e, K, lo, hi, h, advance, out, lj, live_mask, ldj_scale);
+        else cub16_group<HT, true>(w0, bh, e, K, lo, hi, h, advance, out, lj, live_mask, ldj_scale);
+#else
         wptr w;
         dstep st;
         cub16_block<HT, 0, false>(w0, bh, e, lo, hi, out, lj);
@@ -1101,6 +1243,7 @@ __device__ __forceinline__ void cubic_triple(tile<1> (&xs)[TX], const btile<1> (
         if (st.reverse) cub16_block<HT, 2, true>(w, bh, e, lo, hi, out, lj);
         else cub16_block<HT, 2, false>(w, bh, e, lo, hi, out, lj);
         live_mask = st.mask; ldj_scale = st.ldj_scale;
+#endif
     } else {
 #define CUB_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); __builtin_amdgcn_sched_barrier(0)
         wptr w;
@@ -1199,6 +1342,7 @@ __device__ __forceinline__ void cubic_phase_k(tile<1> (&acc)[4], tile<1> (&xs)[T
 template <int TX, int HT>
 __device__ __forceinline__ void cubic_phase(tile<1> (&xs)[TX], const btile<1> (&bh)[HT], cubic_elems &e, const wptr w,
                                             const dstep &st, float &ldj, int lane) {
+    SX_DEP_MARK_SPLINE;
     const int h = lane >> 5;
     tile<1> acc[4];
     rqs_gemm<HT>(w, bh, acc);

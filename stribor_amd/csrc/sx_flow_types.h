@@ -28,6 +28,8 @@ struct sx_flow_args {
     const float *frag_in;
     float *frag_out;
     float *acc_out;
+    uint32_t *redo;         // sx_flow_run2: the redo list (sx_flow_kernel.h, flow_kargs), or NULL
+    int redo_pass;          // 1: this launch is the exact pass over the listed groups
 };
 
 
@@ -81,10 +83,27 @@ struct sx_flow_args {
 
 // Kernel-MODE families, one object per (tiles, hidden tiles, arithmetic, family) -- VERDICT r4 #8c: every object used to instantiate
 // all twenty MODEs of its pair, so a one-line spline edit rebuilt everything:
-//   0  affine / dense / MLP / time-conditioned inference programs (MODE 0, 1, 2, 5 .. 10, 15, 20)
-//   1  spline, cubic-spline and mixed programs (MODE 3, 12, 13, 14, 16 .. 19): the only objects that depend on sx_flow_spline.h
+//   0  affine / dense / MLP / time-conditioned inference programs (MODE 0, 1, 2, 5 .. 9, 15, 20)
+//   1  spline, cubic-spline and mixed programs (MODE 3, 10, 12, 13, 14, 16 .. 19): the only objects that depend on sx_flow_spline.h
+//      and sx_cubic_core.h (round 6, ADVICE r5: MODE 10 -- rational-quadratic couplings behind deep conditioners -- sat in family 0,
+//      whose prerequisite list has neither header: a spline edit left stale MODE 10 kernels behind an up-to-date build id.  The
+//      lists are checked, not trusted: `make depcheck` recompiles one family-0 and one family-2 object with a changed constant in
+//      every header their lists omit and compares the ISA)
 //   2  training backward programs (MODE 4, 11): the only objects that depend on sx_flow_bwd.h
-#define SX_MODE_FAMILY(MODE) ((MODE) == 4 || (MODE) == 11 ? 2 : ((MODE) == 3 || (MODE) == 12 || (MODE) == 13 || (MODE) == 14 || ((MODE) >= 16 && (MODE) <= 19)) ? 1 : 0)
+#define SX_MODE_FAMILY(MODE) ((MODE) == 4 || (MODE) == 11 ? 2 : ((MODE) == 3 || (MODE) == 10 || (MODE) == 12 || (MODE) == 13 || (MODE) == 14 || ((MODE) >= 16 && (MODE) <= 19)) ? 1 : 0)
+// `make depcheck` (Makefile): -DSX_DEPCHECK=<family> plants an instruction in every entry point of the headers that family's FASTDEPS
+// prerequisite list omits -- the kernels call into sx_flow_spline.h (which is where sx_cubic_core.h is used) and sx_flow_bwd.h only
+// through rqs_phase / rqs_triple / cubic_phase / cubic_triple and coupling_affine_bwd* / linear_bwd_half / wacc_zero
+#if defined(SX_DEPCHECK) && (SX_DEPCHECK == 0 || SX_DEPCHECK == 2)
+#define SX_DEP_MARK_SPLINE asm volatile("s_nop 3")
+#else
+#define SX_DEP_MARK_SPLINE ((void)0)
+#endif
+#if defined(SX_DEPCHECK) && (SX_DEPCHECK == 0 || SX_DEPCHECK == 1)
+#define SX_DEP_MARK_BWD asm volatile("s_nop 3")
+#else
+#define SX_DEP_MARK_BWD ((void)0)
+#endif
 #define SX_DECL_FLOW_F(T, H, F) int sx_flow_launch_f16x3_t##T##h##H##_f##F(const sx_flow_args &a); int sx_flow_launch_f32x_t##T##h##H##_f##F(const sx_flow_args &a);
 #define SX_DECL_FLOW(T, H) SX_DECL_FLOW_F(T, H, 0) SX_DECL_FLOW_F(T, H, 1) SX_DECL_FLOW_F(T, H, 2)
 SX_DECL_FLOW(1, 1) SX_DECL_FLOW(1, 2) SX_DECL_FLOW(1, 4)

@@ -1314,8 +1314,14 @@ __global__ __launch_bounds__(512, 1) void rqs_slab_fwd_kernel(const slabf_args k
 // The conditioner's hidden layer for the forward slab pass, single-hidden-layer conditioners (net/mlp.py:48-58 with one hidden
 // layer; coupling.py:61-65: the layer sees cat[x * mask, latent]):  h = act(W1 z + b1), written ONCE as the fp16 hi / lo B fragments
 // the slab kernel's MFMAs consume (4 B per value, like fp32; 1 KB per store).  The mask is folded into the pack (a masked column has
-// no slot).  Input slot q: column q of x (q < dim), then column q - dim of latent.  A row whose input or hidden activation leaves
-// fp16's range gets NaN fragments and raises SX_FLAG_F16_RANGE.
+// no slot).  Input slot q: column q of x (q < dim), then column q - dim of latent.
+// Operand range (round 6; ADVICE r5, VERDICT r5 #4c): the reference takes any finite fp32 here (net/mlp.py:65; coupling.py:61
+// multiplies the transformed columns by mask = 0).  The inputs a slot's mask bit rules out are ZEROED before the fp16 split (they
+// used to enter it raw: a transformed column of 1e6 -- weight 0 in the pack -- turned the row into NaN), and a sample whose
+// conditioning input leaves fp16's range is rescaled by a power of two like the fused tier's hidden layer (rng_pow2_of: the wave
+// evaluates the layer once more with every sample's inputs times 2^-e, accumulated from zero, restored as bias + 2^e acc -- exact
+// scalings, wave-uniform, never taken on ordinary data).  What still gives NaN fragments + SX_FLAG_F16_RANGE: a hidden ACTIVATION
+// beyond 65504 (unbounded activations only: the fragments are fp16 pairs).
 struct slabh_args {
     const float *x, *latent;            // [N, dim], [N, latent_dim] | null
     const float *w1;                    // sx_pack_linear(W1, b1, hidden slots, input slots, m_tiles = HT, k_tiles = CT)
@@ -1323,6 +1329,7 @@ struct slabh_args {
     uint32_t *flags;
     int64_t n_rows;
     int dim, latent_dim, HT, act, n_chunks;
+    uint32_t cmask[4];                  // bit q: input slot q feeds the layer (a conditioning column / a latent column)
 };
 // TANH: the activation inline (the generic one is an out-of-line call on the tile's ADDRESS: the tile then lives in scratch, 8 KB of
 // scratch traffic per tile and wave -- measured as 100 MB of extra HBM writes per launch)
@@ -1348,9 +1355,11 @@ __global__ __launch_bounds__(512) void rqs_slab_hidden_kernel(const slabh_args k
         const int n_here = (int)((k.n_rows - row0) < 32 ? (k.n_rows - row0) : 32);
         const int64_t row = row0 + (j < n_here ? j : n_here - 1);
         btile<1> bx[CT];
+        tile<1> zs[CT];
+        float mx = 0.f;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-            tile<1> z;
+            tile<1> &z = zs[ct];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int q0 = 32 * ct + 8 * g + 4 * hh;
@@ -1365,15 +1374,34 @@ __global__ __launch_bounds__(512) void rqs_slab_hidden_kernel(const slabh_args k
                     }
                     v = f32x4{e[0], e[1], e[2], e[3]};
                 }
-                z.v[0][4 * g + 0] = v.x; z.v[0][4 * g + 1] = v.y; z.v[0][4 * g + 2] = v.z; z.v[0][4 * g + 3] = v.w;
+                const uint32_t live = (k.cmask[ct] >> (8 * g + 4 * hh)) & 15u;          // slots q0 .. q0 + 3
+                z.v[0][4 * g + 0] = (live & 1u) ? v.x : 0.f; z.v[0][4 * g + 1] = (live & 2u) ? v.y : 0.f;
+                z.v[0][4 * g + 2] = (live & 4u) ? v.z : 0.f; z.v[0][4 * g + 3] = (live & 8u) ? v.w : 0.f;
             }
-            bx[ct] = make_btile<1>(z, rg);
+            bx[ct] = make_btile_mx<1>(z, mx);
+        }
+        const bool over = rng_over(mx);                 // wave-uniform; see slabh_args
+        rng_pow2 p2{1.f, 1.f};
+        if (over) {
+            p2 = rng_pow2_of(mx);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) bx[ct] = make_btile_scaled<1>(zs[ct], p2.sc);
         }
         u32x4 *dst = reinterpret_cast<u32x4 *>(k.hfrag) + ((size_t)c * HT) * 256 + lane;
         for (int m = 0; m < HT; ++m) {
             tile<1> acc = load_cfrag<1>(w.cb, bias + m * 32);
+            if (!over) {
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) gemm_tile<1>(w.wb, (m * CT + ct) * 1024, bx[ct], acc);
+                for (int ct = 0; ct < CT; ++ct) gemm_tile<1>(w.wb, (m * CT + ct) * 1024, bx[ct], acc);
+            } else {
+                tile<1> a0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a0.v[0][r] = 0.f;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) gemm_tile<1>(w.wb, (m * CT + ct) * 1024, bx[ct], a0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc.v[0][r] = __builtin_fmaf(a0.v[0][r], p2.inv, acc.v[0][r]);
+            }
             if constexpr (TANH) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc.v[0][r] = fast_tanh(acc.v[0][r]);
@@ -1621,8 +1649,9 @@ extern "C" size_t sx_rqs_slab_hidden_floats(int64_t n_rows, int32_t hidden) {
     return (size_t)((n_rows + 31) / 32) * (size_t)((hidden + 31) / 32) * 1024;
 }
 
-extern "C" int sx_rqs_slab_hidden(const float *x, const float *latent, const float *w1, float *h_frag, int64_t n_rows, int32_t dim,
-                                  int32_t latent_dim, int32_t hidden, int32_t act, uint32_t *err_flag, void *stream) {
+extern "C" int sx_rqs_slab_hidden(const float *x, const float *latent, const float *w1, const uint32_t *cond_mask, float *h_frag,
+                                  int64_t n_rows, int32_t dim, int32_t latent_dim, int32_t hidden, int32_t act, uint32_t *err_flag,
+                                  void *stream) {
     SX_REQUIRE(x && w1 && h_frag, "sx_rqs_slab_hidden: null pointer");
     SX_REQUIRE(dim > 0 && latent_dim >= 0 && dim + latent_dim <= 128 && n_rows >= 0, "sx_rqs_slab_hidden: bad sizes (inputs of up to 128 columns)");
     SX_REQUIRE(latent_dim == 0 || latent != nullptr, "sx_rqs_slab_hidden: null latent");
@@ -1637,6 +1666,7 @@ extern "C" int sx_rqs_slab_hidden(const float *x, const float *latent, const flo
     slabh_args k;
     k.x = x; k.latent = latent; k.w1 = w1; k.hfrag = h_frag; k.flags = err_flag; k.n_rows = n_rows; k.dim = dim; k.latent_dim = latent_dim;
     k.HT = HT; k.act = act; k.n_chunks = n_chunks;
+    for (int i = 0; i < 4; ++i) k.cmask[i] = cond_mask ? cond_mask[i] : 0xffffffffu;      // (host words: read here, passed by value)
     const size_t lds = (size_t)(HT * CT * 1024 + HT * 32) * sizeof(float);
     // two 8-wave workgroups per CU (one copy of the layer in LDS each), several chunks per wave
     int grid = (n_chunks + 7) / 8;

@@ -343,8 +343,16 @@ def _errors_leave_the_call(fn):
     @functools.wraps(fn)
     def wrapped(self, *args, **kwargs):
         x = args[0] if args else kwargs.get('x', kwargs.get('y'))          # the data argument, however the caller spelled it
-        if (_hip._sync_mode != 'grad' or not torch.is_tensor(x) or not x.is_cuda or not self._wants_grad(x)
-                or not self._holds_asserting_op()):
+        wants = torch.is_tensor(x) and x.is_cuda and self._wants_grad(x)
+        if wants:
+            # a graph-building call: its launches run without the exact redo pass (`_hip.no_redo`: the pass needs the weights packed
+            # a second time, and a training step re-packs them every step)
+            with _hip.no_redo():
+                return wrapped_inner(self, x, *args, **kwargs)
+        return fn(self, *args, **kwargs)
+
+    def wrapped_inner(self, x, *args, **kwargs):
+        if _hip._sync_mode != 'grad' or not self._holds_asserting_op():
             return fn(self, *args, **kwargs)
         depth = getattr(_call_depth, 'n', 0)
         _call_depth.n = depth + 1

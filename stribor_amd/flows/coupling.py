@@ -68,7 +68,10 @@ class Coupling(Transform):
                 self._mask_tensors, self._mask_tensors_epoch = {}, _STRUCT_EPOCH[0]
             m = self._mask_tensors.get(key)
             if m is None:
-                m = self._mask_tensors[key] = torch.from_numpy(self.mask_vector(n)).to(x)
+                # (built outside inference mode: an inference tensor cached by a first no-grad call could not be saved for the
+                #  backward of a later training call -- "Inference tensors cannot be saved for backward")
+                with torch.inference_mode(False):
+                    m = self._mask_tensors[key] = torch.from_numpy(self.mask_vector(n)).to(device=x.device, dtype=x.dtype)
             return m
         if self.set_data:                                                              # coupling.py:49-51
             *rest, N, D = x.shape
@@ -384,7 +387,7 @@ class Coupling(Transform):
             glob = np.where(rel >= 0, rows_np[np.clip(rel, 0, len(rows_np) - 1)], -1).astype(np.int32)
             hid = np.full(_ceil32(H) * 32, -1, dtype=np.int32)
             hid[:H] = np.arange(H)
-            progs, in_slots = [], None
+            progs, in_slots, cond_words = [], None, None
             if one_hidden:
                 # one hidden layer: sx_rqs_slab_hidden writes h as the fp16 fragments the slab kernel consumes.  Input slot q = column
                 # q of cat[x, latent]; the masked columns have no slot (coupling.py:61: x * mask)
@@ -392,6 +395,12 @@ class Coupling(Transform):
                 q[:dim] = np.where(cond, np.arange(dim), -1)
                 q[dim:dim + latent_dim] = dim + np.arange(latent_dim)
                 in_slots = torch.from_numpy(q).to(device)
+                # the same map as four host words for the kernel: inputs without a slot are zeroed before the fp16 split (a transformed
+                # column's magnitude must not matter: the reference multiplies it by mask = 0)
+                words = [0, 0, 0, 0]
+                for i in np.nonzero(q >= 0)[0]:
+                    words[int(i) >> 5] |= 1 << (int(i) & 31)
+                cond_words = tuple(words)
             else:
                 # deeper conditioners: everything before the last Linear as the conditioner's own MLP programs with the identity as
                 # last layer -> h [N, H] fp32, row-major
@@ -403,7 +412,7 @@ class Coupling(Transform):
             contiguous = np.array_equal(live, np.arange(live[0], live[0] + len(live)))
             live_idx = None if contiguous else torch.from_numpy(live.astype(np.int32)).to(device)
             passthru = np.nonzero(m > 0.5)[0].astype(np.int32)               # y = x there: copied by the slab kernel
-            cache = {'pass_idx': torch.from_numpy(passthru).to(device) if len(passthru) else None, 'n_pass': len(passthru)}
+            cache = {'pass_idx': torch.from_numpy(passthru).to(device) if len(passthru) else None, 'n_pass': len(passthru), 'cond_words': cond_words}
             return (progs, in_slots, torch.from_numpy(glob).to(device), torch.from_numpy(hid).to(device), live_idx, int(live[0]), len(live), H, cache)
         return self._programs.get(key, build)
 
@@ -414,7 +423,7 @@ class Coupling(Transform):
             raise NotImplementedError('slab tier: fp32 rows, the fp16 x 3 arithmetic')
         if mode == 'auto':                          # a flag an EARLIER call left behind is that call's: raise it, do not swallow it
             torch.cuda.current_stream(x2.device).synchronize()
-            _hip.poll_errors()
+            _hip.poll_errors(device=x2.device)      # the flag word of x's device (and its current stream), not of whichever is current
         cubic = sp.spline_type == 'cubic'
         if (1e-2 if cubic else 1e-3) * sp.n_bins > 1.0:
             raise ValueError('Minimal bin width too large for the number of bins')      # rational_quadratic_spline.py:96-97, cubic_spline.py:93-96
@@ -452,8 +461,10 @@ class Coupling(Transform):
         packs = cache['packs']
         if in_slots is not None:
             h = torch.empty(lib.sx_rqs_slab_hidden_floats(n, H), dtype=torch.float32, device=dev)
-            _hip.call('sx_rqs_slab_hidden', x2, x2.data_ptr(), _hip.ptr(lat2), cache['w1'].data_ptr(), h.data_ptr(), n, d, ld, H,
-                      net.act_code, flag)
+            import ctypes as C
+            words = (C.c_uint32 * 4)(*cache['cond_words'])
+            _hip.call('sx_rqs_slab_hidden', x2, x2.data_ptr(), _hip.ptr(lat2), cache['w1'].data_ptr(), C.cast(words, C.c_void_p), h.data_ptr(),
+                      n, d, ld, H, net.act_code, flag)
             ld_h, frag = 0, 1
         else:
             h = torch.empty(n, H, dtype=torch.float32, device=dev)

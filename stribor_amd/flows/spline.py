@@ -12,6 +12,8 @@ Its ``assert (discriminant >= 0).all()`` (:223) becomes a device flag that ``che
 """
 from typing import Optional
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -143,6 +145,21 @@ def slab_slot_rows(n_live: int, n_bins: int, cubic: bool = False):
     return rows
 
 
+# The slab backward's scratch grows with the rows of ONE call (dh partials: n_groups x n_chunks x HT KiB-tiles -- 10.7 GB for 2^20
+# rows at 160 hidden units, more than the parameter tensor the tier exists to avoid) and `_hip.scratch` keeps the
+# block for the life of the (device, stream).  Calls are therefore cut into row blocks whose scratch stays under a budget
+# (STRIBOR_SLAB_SCRATCH_MB, default 2048): dW / db of the blocks add up, everything else is per row.  The BASELINE shapes (cfg 3,
+# 2^18 .. 2^20 rows at 64 hidden units: 0.5 .. 2 GB) stay one call.
+_SLAB_SCRATCH_BUDGET = int(os.environ.get('STRIBOR_SLAB_SCRATCH_MB', '2048')) << 20
+
+
+def _slab_row_blocks(lib, n: int, n_live: int, H: int):
+    rows = n
+    while rows > 8192 and lib.sx_rqs_slab_scratch_floats(rows, n_live, H) * 4 > _SLAB_SCRATCH_BUDGET:
+        rows = ((rows + 1) // 2 + 127) // 128 * 128
+    return [(r0, min(n, r0 + rows)) for r0 in range(0, n, rows)] if n > 0 else [(0, 0)]
+
+
 class RQSCouplingSlab(torch.autograd.Function):
     """(x_out, row log-det) of an inverse quadratic-spline COUPLING as a differentiable op of (x, h, W2, b2): h [N, H] is the
     conditioner's last hidden activation (torch graph upstream; or, with pre_tanh, the pre-activation of a final Tanh, which the
@@ -186,16 +203,23 @@ class RQSCouplingSlab(torch.autograd.Function):
         gx = gy.clone()                     # pass-through columns: y = x; the kernel overwrites the transformed columns
         gh = torch.empty(n, H, dtype=torch.float32, device=dev)
         gW, gb = torch.empty_like(W2), torch.empty_like(b2)      # every selected row sits in exactly one slot: all written
-        with _hip.device_of(x2):
-            sc = _hip.scratch(dev, lib.sx_rqs_slab_scratch_floats(n, n_live, H))
         # the kernels normalise the adjoints by a power of two derived from their largest magnitude (exact): the parameter
         # gradients are fp16 x 3 GEMM operands, and dL/dlog_prob = 1/N of a mean loss would put them under fp16's normal
         # range.  The maximum stays on the device (no host sync).
         scale = _adjoint_scale(gy, gldj)
-        _hip.call('sx_rqs_slab_bwd', x2, x2.data_ptr(), gy.data_ptr(), gldj.data_ptr(), _hip.ptr(yout), h.data_ptr(), h.stride(0), H,
-                  packs.data_ptr(), packs.data_ptr() + 4 * n_fwd, slot_rows.data_ptr(), gx.data_ptr(), gh.data_ptr(),
-                  gh.stride(0), gW.data_ptr(), gW.stride(0), gb.data_ptr(), _hip.ptr(live_idx), live_start, n_live, n_bins,
-                  lower, upper, lower, upper, n, d, 1.0, int(pre_tanh), scale.data_ptr(), sc.data_ptr(), flag)
+        blocks = _slab_row_blocks(lib, n, n_live, H)
+        for i, (r0, r1) in enumerate(blocks):
+            gWb, gbb = (gW, gb) if i == 0 else (torch.empty_like(W2), torch.empty_like(b2))
+            with _hip.device_of(x2):
+                sc = _hip.scratch(dev, lib.sx_rqs_slab_scratch_floats(r1 - r0, n_live, H))
+            _hip.call('sx_rqs_slab_bwd', x2, x2[r0:r1].data_ptr(), gy[r0:r1].data_ptr(), gldj[r0:r1].data_ptr(),
+                      None if yout is None else yout[r0:r1].data_ptr(), h[r0:r1].data_ptr(), h.stride(0), H,
+                      packs.data_ptr(), packs.data_ptr() + 4 * n_fwd, slot_rows.data_ptr(), gx[r0:r1].data_ptr(), gh[r0:r1].data_ptr(),
+                      gh.stride(0), gWb.data_ptr(), gWb.stride(0), gbb.data_ptr(), _hip.ptr(live_idx), live_start, n_live, n_bins,
+                      lower, upper, lower, upper, r1 - r0, d, 1.0, int(pre_tanh), scale.data_ptr(), sc.data_ptr(), flag)
+            if i:
+                gW += gWb
+                gb += gbb
         return gx, gh, gW, gb, None, None, None, None, None, None, None, None, None, None
 
 
@@ -280,20 +304,28 @@ class RQSCouplingSlabL1(torch.autograd.Function):
         gW2, gb2 = (torch.zeros_like(W2), torch.zeros_like(b2)) if full_w2 else (torch.empty_like(W2), torch.empty_like(b2))
         gW1 = torch.zeros(H, d, dtype=torch.float32, device=dev)
         gb1 = torch.zeros(H, dtype=torch.float32, device=dev)
-        n_slab = lib.sx_rqs_slab_scratch_floats(n, n_live, H)
         n_l1 = lib.sx_rqs_slab_l1_scratch_floats(d, H)
-        with _hip.device_of(x2):
-            sc = _hip.scratch(dev, n_slab + n_l1 + 64)
         scale = _adjoint_scale(gy, gldj)
-        _hip.call('sx_rqs_slab_bwd', x2, x2.data_ptr(), gy.data_ptr(), gldj.data_ptr(), _hip.ptr(yout), h.data_ptr(), h.stride(0), H,
-                  packs.data_ptr(), packs.data_ptr() + 4 * n_fwd, slot_rows.data_ptr(), gx.data_ptr(), None, 0,
-                  gW2.data_ptr(), gW2.stride(0), gb2.data_ptr(), _hip.ptr(live_idx), live_start, n_live, n_bins,
-                  lower, upper, lower, upper, n, d, 1.0, 1, scale.data_ptr(), sc.data_ptr(), flag)
         words = (C.c_uint32 * 2)(*cond_words)
-        l1_scratch = sc.data_ptr() + 4 * ((n_slab + 3) // 4 * 4)
-        _hip.call('sx_rqs_slab_l1_bwd', x2, sc.data_ptr(), h.data_ptr(), h.stride(0), H, x2.data_ptr(), gy.data_ptr(),
-                  w1t.data_ptr(), C.cast(words, C.c_void_p), gx.data_ptr(), gW1.data_ptr(), gW1.stride(0), gb1.data_ptr(),
-                  col_map.data_ptr(), n_live, n, d, scale.data_ptr(), l1_scratch, flag)
+        blocks = _slab_row_blocks(lib, n, n_live, H)
+        for i, (r0, r1) in enumerate(blocks):
+            # (dW2 / db2 are written per call, dW1 / db1 accumulated by the first-layer kernel: the blocks' shares add up)
+            gW2b, gb2b = (gW2, gb2) if i == 0 else (torch.zeros_like(W2), torch.zeros_like(b2)) if full_w2 else (torch.empty_like(W2), torch.empty_like(b2))
+            n_slab = lib.sx_rqs_slab_scratch_floats(r1 - r0, n_live, H)
+            with _hip.device_of(x2):
+                sc = _hip.scratch(dev, n_slab + n_l1 + 64)
+            _hip.call('sx_rqs_slab_bwd', x2, x2[r0:r1].data_ptr(), gy[r0:r1].data_ptr(), gldj[r0:r1].data_ptr(),
+                      None if yout is None else yout[r0:r1].data_ptr(), h[r0:r1].data_ptr(), h.stride(0), H,
+                      packs.data_ptr(), packs.data_ptr() + 4 * n_fwd, slot_rows.data_ptr(), gx[r0:r1].data_ptr(), None, 0,
+                      gW2b.data_ptr(), gW2b.stride(0), gb2b.data_ptr(), _hip.ptr(live_idx), live_start, n_live, n_bins,
+                      lower, upper, lower, upper, r1 - r0, d, 1.0, 1, scale.data_ptr(), sc.data_ptr(), flag)
+            l1_scratch = sc.data_ptr() + 4 * ((n_slab + 3) // 4 * 4)
+            _hip.call('sx_rqs_slab_l1_bwd', x2, sc.data_ptr(), h[r0:r1].data_ptr(), h.stride(0), H, x2[r0:r1].data_ptr(), gy[r0:r1].data_ptr(),
+                      w1t.data_ptr(), C.cast(words, C.c_void_p), gx[r0:r1].data_ptr(), gW1.data_ptr(), gW1.stride(0), gb1.data_ptr(),
+                      col_map.data_ptr(), n_live, r1 - r0, d, scale.data_ptr(), l1_scratch, flag)
+            if i:
+                gW2 += gW2b
+                gb2 += gb2b
         return gx, gW1, gb1, gW2, gb2, None, None, None, None, None, None, None, None, None, None
 
 

@@ -18,6 +18,7 @@ zeros contribute exactly 0); otherwise the layer runs dense over all tiles with 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -255,6 +256,24 @@ class _ScalarsJob:
         return []
 
 
+class _PadJob:
+    """blob[offsets] = values, re-applied whenever `W` is re-packed (the pack job of its rows writes 0 into the bias slots of rows
+    it does not map: the parked values of a K < 16 spline tile sit in exactly those slots).  One scatter per layer."""
+
+    def __init__(self, W, offsets: np.ndarray, values: np.ndarray):
+        self.W, self.offsets_host, self.values_host = W, offsets, values
+        self.offsets = self.values = None
+
+    def run(self, blobs: torch.Tensor, prec: int = 0) -> None:
+        if self.offsets is None or self.offsets.device != blobs.device:
+            self.offsets = torch.from_numpy(self.offsets_host).to(blobs.device)
+            self.values = torch.from_numpy(self.values_host).to(blobs.device)
+        blobs.index_copy_(0, self.offsets, self.values)
+
+    def params(self):
+        return [self.W]
+
+
 class _VectorJob:
     """blob[dst_off:] = cat(vec, 0)[gather] (per-slot constants in C-fragment order)."""
 
@@ -374,7 +393,27 @@ class CompiledProgram:
                     if first or j.params():
                         j.run(blobs, prec)
                 self._versions[prec] = v
+                if prec == _hip.GEMM_F16X3:
+                    self._f16_overflow = None       # unknown for this weight version (weights_beyond_fp16)
         return blobs
+
+    def weights_beyond_fp16(self) -> bool:
+        """Do the weights of the current version exceed what fp16 x 3 fragments can hold (|w'| > 65504 after the folded constants)?
+        sx_pack_linear raises SX_FLAG_F16_RANGE in header word 0 of the blob it packs; this reads that word ONCE per weight version
+        (a 4-byte device-to-host copy: one synchronisation when weights change, none on the calls that follow) so that a 'fast' call
+        can take the exact-fp32 objects for such a program instead of returning NaN rows + GemmRangeError -- the reference takes any
+        finite weight (net/mlp.py:65, flows/affine.py:156-163).  Not asked while a graph is being built or captured (training steps
+        re-pack every step: there the flag is reported as before)."""
+        if self._owner is not None:
+            return self._owner.weights_beyond_fp16()
+        blobs = self.blobs_for(_hip.GEMM_F16X3)
+        if getattr(self, '_f16_overflow', None) is None:
+            word = int(blobs[:1].view(torch.int32).item())
+            self._f16_overflow = bool(word & _hip.FLAG_F16_RANGE)
+        return self._f16_overflow
+
+    def jobs_or_owner(self) -> bool:
+        return bool(self.jobs) or self._owner is not None
 
     def refresh(self) -> None:
         self.blobs_for(_hip.GEMM_F16X3 if _hip.get_gemm_precision() != 'exact' else _hip.GEMM_F32)
@@ -421,13 +460,18 @@ class CompiledProgram:
             work = _hip.work_counters(x.device)
             flag = _hip.err_flag(x.device)
 
-            def launch(prec):
-                rc = _hip.lib().sx_flow_run(C.byref(self.prog), self.blobs_for(prec).data_ptr(), x.data_ptr(),
-                                            _hip.ptr(latent), _hip.ptr(self.in_col), _hip.ptr(self.out_col), _hip.ptr(y),
-                                            _hip.ptr(ldj), _hip.ptr(logp), _hip.ptr(sum_out),
-                                            None if mlp_out is None else mlp_out.data_ptr() + 4 * self.mlp_col0, stride,
-                                            mlp_dim, _hip.ptr(row_t), _hip.ptr(side), n, _hip.dtype_code(x),
-                                            prec, work.data_ptr(), flag, _hip.stream())
+            def launch(prec, redo=False):
+                # redo: the fp16 x 3 launch names the samples whose operands left fp16's range and the exact-fp32 kernel evaluates
+                # them in a second launch (sx_flow_run2) -- any finite fp32 row at fp32-grade error, no flag, no synchronisation
+                redo = redo and prec == _hip.GEMM_F16X3 and side is None and _hip.redo_allowed()
+                rc = _hip.lib().sx_flow_run2(C.byref(self.prog), self.blobs_for(prec).data_ptr(),
+                                             self.blobs_for(_hip.GEMM_F32).data_ptr() if redo else None,
+                                             _hip.redo_list(x.device, n).data_ptr() if redo else None, x.data_ptr(),
+                                             _hip.ptr(latent), _hip.ptr(self.in_col), _hip.ptr(self.out_col), _hip.ptr(y),
+                                             _hip.ptr(ldj), _hip.ptr(logp), _hip.ptr(sum_out),
+                                             None if mlp_out is None else mlp_out.data_ptr() + 4 * self.mlp_col0, stride,
+                                             mlp_dim, _hip.ptr(row_t), _hip.ptr(side), n, _hip.dtype_code(x),
+                                             prec, work.data_ptr(), flag, _hip.stream())
                 if rc != 0:
                     work.zero_()                    # a failed launch may leave the ticket pair armed
                 _hip.check(rc, 'sx_flow_run')
@@ -437,14 +481,17 @@ class CompiledProgram:
             if mode == 'exact':
                 launch(_hip.GEMM_F32)
             elif mode == 'fast':
-                launch(_hip.GEMM_F16X3)
+                # (weights beyond fp16's range: the same program on the exact-fp32 objects, silently -- a parameter's magnitude is not
+                #  an error in the reference.  Decided from the pack's own flag, once per weight version, on calls without a graph.)
+                quiet = not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing()
+                launch(_hip.GEMM_F32 if (quiet and self.jobs_or_owner() and self.weights_beyond_fp16()) else _hip.GEMM_F16X3, redo=True)
             else:                                   # 'auto': never hand back a NaN-poisoned result
                 keep = None if sum_out is None else sum_out.clone()
                 # an accumulating launch (mlp_out += chunk) is not idempotent: the exact re-run must start from what the output
                 # held BEFORE the fp16 x 3 attempt, or the unflagged rows get the chunk's contribution twice
                 keep_out = mlp_out.clone() if (self.accumulates and mlp_out is not None) else None
                 torch.cuda.current_stream().synchronize()
-                _hip.poll_errors()                  # a flag an EARLIER call left behind is that call's: raise it, do not swallow it
+                _hip.poll_errors(device=x.device)   # a flag an EARLIER call left behind is that call's: raise it, do not swallow it
                 launch(_hip.GEMM_F16X3)
                 torch.cuda.current_stream().synchronize()
                 if _hip.take_flag(x.device, _hip.FLAG_F16_RANGE):
@@ -846,6 +893,7 @@ class ProgramBuilder:
         # forward searches the widths on [left, right], inverse the heights on [bottom, top]
         blocks = [(K, K, bottom, top), (0, K, left, right)] if reverse else [(0, K, left, right), (K, K, bottom, top)]
         blocks.append((2 * K, 2, left, right) if cubic else (2 * K, K - 1, 0.0, 0.0))      # cubic: the evaluation needs the domain
+        pad_off, pad_val = [], []           # bias slots of unused tile registers (K < 16), written behind the layer's pack jobs
         for t in range(t0, t0 + tt):
             if t >= self.x_tiles:
                 continue
@@ -891,12 +939,27 @@ class ProgramBuilder:
                         self.jobs.append(_PackJob(W2, b2, rows, col2, 4, HT, off, np.full(128, -2.0 * sc2), np.full(128, sc2), 1.0,
                                                   bound_off=bound_slot if phase < 2 else None))
                         self.jobs.append(_ScalarsJob([lo, hi], off + nlin))
+                        if not wide and K < 16 and (phase < 2 or not cubic):
+                            # Fewer than 16 bins: the unused registers of an element's tile are parked where the K <= 16 code of
+                            # the kernel needs no predicate for them (sx_flow_spline.h, rqs16_c): logits of bins >= K at -1e30
+                            # (exp2 = 0: every sum is that of the K bins), derivative rows >= K - 1 at the boundary-derivative
+                            # constant log(exp(1 - 1e-3) - 1) of rational_quadratic_spline.py:81 (D[K - 1] then needs no select).
+                            # Bias block of the pack: [tile][lane half][register] behind the 4 x HT fragment tiles.
+                            first, pad = (K, -1e30) if phase < 2 else (K - 1, 0.5397424172369522)
+                            for q in elems:
+                                for h in range(2):
+                                    if slot_live[32 * t + q + 8 * g + 4 * h]:
+                                        base = off + 4 * HT * 1024 + 32 * q + 16 * h
+                                        pad_off += list(range(base + first, base + 16))
+                                        pad_val += [pad] * (16 - first)
                         s_scale = (-ldj_scale if reverse else ldj_scale) if phase == 2 else 0.0
                         step = dict(kind=_hip.STEP_RQS_PHASE, c0=g, ct=phase, t0=t, tt=K, reverse=int(reverse),
                                     act=int(cubic) | (half << 1), blob_off=off, blob_floats=n, ldj_scale=s_scale, ldj_const=0.0)
                         step['pad_'] = live_mask - (1 << 32) if live_mask >= (1 << 31) else live_mask
                         self.steps.append(step)
 
+        if pad_off:
+            self.jobs.append(_PadJob(W2, np.asarray(pad_off, dtype=np.int64), np.asarray(pad_val, dtype=np.float32)))
         self._spline_layers += 1
 
     def enable_adjoint_tiles(self) -> None:

@@ -220,14 +220,18 @@ int main() {
     EXPECT_BAD(sx_rqs_slab_fwd(f, f, 64, 64, f, f, nullptr, nullptr, 32, 32, (const int32_t *)f, 33, 16, -3.f, 3.f, -3.f, 3.f, 4, 64, 1, 1.f, 0, 0, 0, nullptr, nullptr, nullptr));   // more than dim - n_live
     EXPECT_OK(sx_rqs_slab_fwd(f, f, 64, 64, f, f, nullptr, nullptr, 32, 32, nullptr, 0, 16, -3.f, 3.f, -3.f, 3.f, 0, 64, 1, 1.f, 0, 0, 0, nullptr, nullptr, nullptr));
     EXPECT_OK(sx_rqs_slab_fwd(f, f, 64, 64, f, f, nullptr, nullptr, 32, 32, nullptr, 0, 16, -3.f, 3.f, -3.f, 3.f, 0, 64, 2, 1.f, 0, 0, 1, nullptr, nullptr, nullptr));
+    // sx_flow_run2 (round 6): the exact redo pass's arguments come together, and only with the fp16 x 3 arithmetic
+    (void)sx_flow_redo_words(0); (void)sx_flow_redo_words(-1); (void)sx_flow_redo_words((int64_t)1 << 40);
+    if (sx_flow_redo_words(64) != 2 + 2 * 2) { fprintf(stderr, "sx_flow_redo_words(64)\n"); return 1; }
     (void)sx_rqs_slab_hidden_floats(0, 64); (void)sx_rqs_slab_hidden_floats((int64_t)1 << 40, 64); (void)sx_rqs_slab_hidden_floats(-1, INT_MAX);
-    EXPECT_BAD(sx_rqs_slab_hidden(nullptr, nullptr, f, f, 4, 64, 0, 160, 1, nullptr, nullptr));
-    EXPECT_BAD(sx_rqs_slab_hidden(f, nullptr, f, f, 4, 64, 8, 160, 1, nullptr, nullptr));        // latent_dim without latent
-    EXPECT_BAD(sx_rqs_slab_hidden(f, f, f, f, 4, 100, 29, 160, 1, nullptr, nullptr));            // more than 128 input columns
-    EXPECT_BAD(sx_rqs_slab_hidden(f, nullptr, f, f, 4, 64, 0, 257, 1, nullptr, nullptr));        // hidden
-    EXPECT_BAD(sx_rqs_slab_hidden(f, nullptr, f, f, 4, 64, 0, 160, 77, nullptr, nullptr));       // activation
-    EXPECT_BAD(sx_rqs_slab_hidden(f, nullptr, f, f, -4, 64, 0, 160, 1, nullptr, nullptr));
-    EXPECT_OK(sx_rqs_slab_hidden(f, nullptr, f, f, 0, 64, 0, 160, 1, nullptr, nullptr));
+    EXPECT_BAD(sx_rqs_slab_hidden(nullptr, nullptr, f, nullptr, f, 4, 64, 0, 160, 1, nullptr, nullptr));
+    EXPECT_BAD(sx_rqs_slab_hidden(f, nullptr, f, nullptr, f, 4, 64, 8, 160, 1, nullptr, nullptr));        // latent_dim without latent
+    EXPECT_BAD(sx_rqs_slab_hidden(f, f, f, nullptr, f, 4, 100, 29, 160, 1, nullptr, nullptr));            // more than 128 input columns
+    EXPECT_BAD(sx_rqs_slab_hidden(f, nullptr, f, nullptr, f, 4, 64, 0, 257, 1, nullptr, nullptr));        // hidden
+    EXPECT_BAD(sx_rqs_slab_hidden(f, nullptr, f, nullptr, f, 4, 64, 0, 160, 77, nullptr, nullptr));       // activation
+    EXPECT_BAD(sx_rqs_slab_hidden(f, nullptr, f, nullptr, f, -4, 64, 0, 160, 1, nullptr, nullptr));
+    EXPECT_OK(sx_rqs_slab_hidden(f, nullptr, f, nullptr, f, 0, 64, 0, 160, 1, nullptr, nullptr));
+    { uint32_t cm[4] = {0xffffu, 0, 0, 0}; EXPECT_OK(sx_rqs_slab_hidden(f, nullptr, f, cm, f, 0, 64, 0, 160, 1, nullptr, nullptr)); }
     (void)sx_flow_bwd_max_steps();
 
     // ---- 2. valid programs: accepted; every single-field mutation: a status, no crash ---------------------------------------------

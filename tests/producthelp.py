@@ -57,9 +57,11 @@ def close_vs_f64(got, ref32, f64, k=2.0, rtol=1e-5, atol=1e-5, row_scale=False):
 
 
 def relu_flow(dim=16, hidden=32, layers=2, device='cuda'):
-    """A coupling flow whose conditioners use ReLU: their hidden activations are UNBOUNDED fp16 x 3 operands, the one data-dependent
-    way left to raise GemmRangeError in the default arithmetic (inputs beyond fp16's range are rescaled inside the kernels since
-    round 5; a row scaled by 1e7 drives relu(W1 x) far beyond 65504).  Used by the tests of the error-flag plumbing."""
+    """A coupling flow whose conditioners use ReLU: their hidden activations are UNBOUNDED fp16 x 3 operands (a row scaled by 1e7
+    drives relu(W1 x) far beyond 65504).  Used by the tests of the error-flag plumbing, which run their launches under
+    `stribor_amd._hip.no_redo()`: since round 6 an inference call hands such samples to the exact-fp32 kernel in a second launch
+    (sx_flow_run2) and nothing is flagged; without the redo pass -- a training step, a C-ABI caller of sx_flow_run -- they come back
+    as NaN + GemmRangeError."""
     masks = ('ordered_right_half', 'ordered_left_half')
     return st.NormalizingFlow(st.UnitNormal(dim), [
         st.Coupling(st.Affine(dim, latent_net=st.net.MLP(dim, [hidden], 2 * dim, activation='ReLU')), mask=masks[i % 2])

@@ -249,6 +249,45 @@ def test_spline_slab_backward_at_scale_is_additive_over_row_partitions():
         assert (a - (b + c)).abs().max().item() <= 1e-4 * scale, (name, (a - (b + c)).abs().max().item(), scale)
 
 
+@pytest.mark.parametrize('hidden', [64, 160])
+def test_spline_slab_backward_in_row_blocks_under_a_scratch_budget(monkeypatch, hidden):
+    """the slab backward's dh-partial scratch grows with the rows of one call (10.7 GB at 2^20 rows and 160 hidden
+    units).  Under a budget the op cuts the batch into row blocks (`flows/spline.py: _slab_row_blocks`): same gradients as the
+    one-call form -- hidden 64 goes through RQSCouplingSlabL1 (first layer inside the op), hidden 160 through RQSCouplingSlab --,
+    and the library scratch stays under the budget."""
+    import stribor_amd.flows.spline as spl
+    from stribor_amd import _hip
+    torch.manual_seed(5)
+    flow = fd.build_flow(st, fd.cfg3_desc(2, 64, hidden, 16), 64).to(DEV)
+    n = (1 << 16) + 77                  # (blocks are never cut below 8192 rows)
+    x = torch.randn(n, 64, device=DEV) * 1.2
+
+    def grads():
+        for p in flow.parameters():
+            p.grad = None
+        xg = x.clone().requires_grad_(True)
+        (-flow.log_prob(xg).sum() * 1e-4).backward()
+        return xg.grad.clone(), [p.grad.clone() for p in flow.parameters()]
+
+    gx, whole = grads()
+    lib = _hip.lib()
+    one_call = lib.sx_rqs_slab_scratch_floats(n, 32, hidden) * 4
+    monkeypatch.setattr(spl, '_SLAB_SCRATCH_BUDGET', one_call // 3)
+    blocks = spl._slab_row_blocks(lib, n, 32, hidden)
+    assert len(blocks) >= 3 and blocks[0][0] == 0 and blocks[-1][1] == n and all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+    assert all(lib.sx_rqs_slab_scratch_floats(r1 - r0, 32, hidden) * 4 <= one_call // 3 for r0, r1 in blocks)
+    _hip._scratch.clear()
+    gxb, parts = grads()
+    # (the same per-stream block also serves the first-layer kernel and the weight-gradient reductions: + 16 MB)
+    assert max(t.numel() for t in _hip._scratch.values()) * 4 <= max(one_call // 3, 4 << 20) + (16 << 20)
+    # per-row arithmetic is the same in both runs (the adjoint scale is the whole batch's in both): input gradients agree row by
+    # row; parameter gradients up to fp32 summation order
+    assert (gx - gxb).abs().max().item() <= 1e-6 * gx.abs().max().item()
+    for (name, _), a, b in zip(flow.named_parameters(), whole, parts):
+        scale = a.abs().max().item() + 1e-12
+        assert (a - b).abs().max().item() <= 1e-4 * scale, (name, (a - b).abs().max().item(), scale)
+
+
 def test_spline_slab_backward_reports_fp16_range_and_exact_mode_bypasses_it():
     """The slab backward's GEMM operands are fp16 x 3: a hidden activation beyond 65504 must not come back as a plausible
     gradient (NaN rows + GemmRangeError at the next check), and set_gemm_precision('exact') takes the per-row path."""

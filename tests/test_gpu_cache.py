@@ -228,7 +228,8 @@ def test_error_flags_are_per_stream():
     xb = torch.randn(64, 16, device=DEV)
     sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
     torch.cuda.synchronize()
-    with torch.no_grad():
+    from stribor_amd import _hip
+    with torch.no_grad(), _hip.no_redo():                   # (the flag path: see relu_flow)
         with torch.cuda.stream(sa):
             ya = fa.log_prob(xa)
         sa.synchronize()
@@ -321,19 +322,22 @@ def test_sync_errors_mode_raises_inside_the_failing_call():
     x[7] *= -1.0e7
     old = _hip.set_sync_errors(True)
     try:
-        with torch.no_grad():
+        with torch.no_grad(), _hip.no_redo():               # (the flag path: see relu_flow)
             with pytest.raises(st.GemmRangeError):
                 flow.log_prob(x)
             st.check_errors()                               # raised once, nothing left behind
             assert torch.isfinite(flow.log_prob(x[:5])).all()
-            # a stand-alone MLP rescales every layer's operands per sample: no error, finite values
+        with torch.no_grad():
+            # with the redo pass (the default for an inference call) nothing is flagged: finite values
             net = st.net.MLP(8, [16], 4, activation='ReLU').to(DEV)
             z = torch.randn(32, 8, device=DEV)
             z[3, 0] = 1.0e6
             assert torch.isfinite(net(z)).all()
+            flow.log_prob(x)                                # (row 7 overflows exp() in the reference as well: no flag is what matters)
+            st.check_errors()
     finally:
         _hip.set_sync_errors(old)
-    with torch.no_grad():
+    with torch.no_grad(), _hip.no_redo():
         flow.log_prob(x)                                    # lazy again: no raise here ...
         torch.cuda.synchronize()
         with pytest.raises(st.GemmRangeError):

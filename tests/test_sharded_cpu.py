@@ -53,7 +53,7 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 8])
 def test_sharded_sum_matches_unsharded(world):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()

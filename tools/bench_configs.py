@@ -46,6 +46,9 @@ CONFIGS = {
     'cfg4': (lambda: fd.cfg4_desc(), 128, 1 << 20, torch.float32),
     'cfg2_deep': (lambda: [dict(d, hidden=[64, 64]) for d in fd.cfg2_desc()], 64, 1 << 20, torch.float32),
     'cfg3_deep': (lambda: [dict(d, hidden=[64, 64]) for d in fd.cfg3_desc()], 64, 1 << 20, torch.float32),
+    'cfg3_cubic': (lambda: [dict(d, spline_type='cubic') for d in fd.cfg3_desc()], 64, 1 << 20, torch.float32),
+    'cfg3_k24': (lambda: fd.cfg3_desc(n_layers=4, n_bins=24), 64, 1 << 18, torch.float32),
+    'cfg3_k8': (lambda: fd.cfg3_desc(n_layers=4, n_bins=8), 64, 1 << 18, torch.float32),
     'cfg2_parity': (lambda: [dict(d, mask='parity_even' if i % 2 == 0 else 'parity_odd') for i, d in enumerate(fd.cfg2_desc())], 64, 1 << 20, torch.float32),
 }
 
