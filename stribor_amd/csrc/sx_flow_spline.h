@@ -696,6 +696,222 @@ __device__ __forceinline__ void rqs16_unit(const f32x16 &u, rqs_elems &e, const 
     else if constexpr (PH == 1) rqs16_select<Q, GEN>(u, e, c, hk);
     else rqs_eval<Q, REV, 16>(u, e, 16, out[Q], lj[Q], hk);       // (K < 16: rows >= K - 1 of the derivative tile hold the boundary constant)
 }
+// ------------------------------------------------------------------------------------------------
+// 17 .. 32 bins, bounded logits (round 6; VERDICT r5 #1: K 16 -> 24 cost 2.4 x, the sweeps over 32 slots carried ~60 lane masks and the
+// allocator spilled them to VGPR lanes -- v_writelane / v_readlane, vector instructions).  The K <= 16 form one level up: an element's
+// parameters are TWO output tiles (32 slots), eight groups of four bins; the group comes from seven compares against the group
+// boundaries' knots (a prefix: the knots grow), the five values around the group from seven-deep select chains on those masks, the
+// bin inside the group as before.  The packer parks slots >= K (logits -1e30, derivative rows >= K - 1 at the boundary constant);
+// boundaries 4 j >= K get +inf, local knots of index >= K in the last reachable group are masked, the last bin's right knot is the
+// bound itself (rqs16_c).  ~145 vector instructions per softmax block and element, no lane mask outlives its select chain.
+// ------------------------------------------------------------------------------------------------
+struct rqs32_c {
+    float lo, hi, cs, sm1, sm2, sm3, sm4;
+    float l[7];             // lo + 4 j MIN (hi - lo), j = 1 .. 7 (+inf where 4 j >= K)
+    int Km1, glast;
+    bool u1, u2, u3;
+};
+__device__ __forceinline__ rqs32_c rqs32_consts(float lo, float hi, int K) {
+    rqs32_c c;
+    const float span = hi - lo, sm = RQS_MIN * span, inf = __builtin_inff();
+    c.lo = lo; c.hi = hi; c.cs = (1.f - (float)K * RQS_MIN) * span;
+    c.sm1 = sm; c.sm2 = 2.f * sm; c.sm3 = 3.f * sm; c.sm4 = 4.f * sm;
+#pragma unroll
+    for (int j = 1; j <= 7; ++j) c.l[j - 1] = 4 * j < K ? lo + 4.f * (float)j * sm : inf;
+    c.Km1 = K - 1; c.glast = (K - 1) >> 2;
+    const int iK = K - 4 * c.glast;
+    c.u1 = 1 >= iK; c.u2 = 2 >= iK; c.u3 = 3 >= iK;
+    return c;
+}
+struct rqs32_s {
+    float p[8][4];          // the groups' inner prefixes: e0, e0 + e1, e0 + e1 + e2, the group's sum
+    float T[7];             // knots at bins 4, 8, .. 28
+    float sinv;
+};
+// v0 .. v7 by the nested masks m[0] >= m[1] >= .. >= m[6] (group >= 1 .. 7): a chain of seven selects (VALUES: see rqs16_pick)
+__device__ __forceinline__ float rqs32_pick(const bool (&m)[7], float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
+    float v = m[0] ? v1 : v0;
+    v = m[1] ? v2 : v; v = m[2] ? v3 : v; v = m[3] ? v4 : v; v = m[4] ? v5 : v; v = m[5] ? v6 : v; v = m[6] ? v7 : v;
+    return v;
+}
+template <class H>
+__device__ __forceinline__ void rqs32_sums(const f32x16 &u0, const f32x16 &u1, const rqs32_c &c, rqs32_s &s, H &hk) {
+    hk.template pt<0>();
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const f32x16 &u = g < 4 ? u0 : u1;
+        const int o = 4 * (g & 3);
+        s.p[g][0] = __builtin_amdgcn_exp2f(u[o]);
+        s.p[g][1] = s.p[g][0] + __builtin_amdgcn_exp2f(u[o + 1]);
+        s.p[g][2] = s.p[g][1] + __builtin_amdgcn_exp2f(u[o + 2]);
+        s.p[g][3] = s.p[g][2] + __builtin_amdgcn_exp2f(u[o + 3]);
+        if (g == 1) hk.template pt<1>(s.p[0][3], s.p[1][3]);
+        if (g == 3) hk.template pt<2>(s.p[2][3], s.p[3][3]);
+        if (g == 5) hk.template pt<3>(s.p[4][3], s.p[5][3]);
+        if (g == 7) hk.template pt<4>(s.p[6][3], s.p[7][3]);
+    }
+    float G[8];
+    G[0] = s.p[0][3];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) G[g] = G[g - 1] + s.p[g][3];
+    s.sinv = c.cs * fast_rcp(G[7]);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) s.T[j] = __builtin_fmaf(s.sinv, G[j], c.l[j]);
+    hk.template pt<5>(s.T[0], s.T[3], s.T[6]);
+}
+template <class H>
+__device__ __forceinline__ void rqs32_knots(const rqs32_s &s, const rqs32_c &c, const bool (&m)[7], float &k0, float &k1, float &k2, float &k3,
+                                            float &k4, H &hk) {
+    k0 = rqs32_pick(m, c.lo, s.T[0], s.T[1], s.T[2], s.T[3], s.T[4], s.T[5], s.T[6]);
+    float p1 = rqs32_pick(m, s.p[0][0], s.p[1][0], s.p[2][0], s.p[3][0], s.p[4][0], s.p[5][0], s.p[6][0], s.p[7][0]);
+    hk.template pt<6>(k0, p1);
+    float p2 = rqs32_pick(m, s.p[0][1], s.p[1][1], s.p[2][1], s.p[3][1], s.p[4][1], s.p[5][1], s.p[6][1], s.p[7][1]);
+    k1 = __builtin_fmaf(s.sinv, p1, k0 + c.sm1);
+    hk.template pt<7>(k1, p2);
+    float p3 = rqs32_pick(m, s.p[0][2], s.p[1][2], s.p[2][2], s.p[3][2], s.p[4][2], s.p[5][2], s.p[6][2], s.p[7][2]);
+    k2 = __builtin_fmaf(s.sinv, p2, k0 + c.sm2);
+    hk.template pt<8>(k2, p3);
+    const float p4 = rqs32_pick(m, s.p[0][3], s.p[1][3], s.p[2][3], s.p[3][3], s.p[4][3], s.p[5][3], s.p[6][3], s.p[7][3]);
+    k3 = __builtin_fmaf(s.sinv, p3, k0 + c.sm3);
+    k4 = __builtin_fmaf(s.sinv, p4, k0 + c.sm4);
+    hk.template pt<9>(k3, k4);
+}
+template <int Q, class H>
+__device__ __forceinline__ void rqs32_search(const f32x16 &u0, const f32x16 &u1, rqs_elems &e, const rqs32_c &c, H &hk) {
+    rqs32_s s;
+    rqs32_sums(u0, u1, c, s, hk);
+    const float xv = e.x[Q];
+    const bool in = (xv >= c.lo) && (xv <= c.hi);                       // :71 closed interval
+    const float lo_ = c.lo;
+    const float xin = in ? xv : lo_;
+    bool m[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) m[j] = xin >= s.T[j];                   // a prefix: the knots grow (boundaries 4 j >= K are +inf)
+    float k0, k1, k2, k3, k4;
+    rqs32_knots(s, c, m, k0, k1, k2, k3, k4, hk);
+    bool g1 = xin >= k1, g2 = xin >= k2, g3 = xin >= k3;
+    // groups beyond glast are unreachable, so "in the last group" is the mask of boundary glast
+    const bool last = c.glast <= 4 ? m[3] : (c.glast == 5 ? m[4] : (c.glast == 6 ? m[5] : m[6]));      // (17 .. 32 bins: glast = 4 .. 7)
+    g1 = g1 && !(last && c.u1); g2 = g2 && !(last && c.u2); g3 = g3 && !(last && c.u3);
+    int bg = in ? 0 : RQS_OUT;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) bg += m[j] ? 4 : 0;
+    hk.template pt<10>(bg);
+    e.b[Q] = bg + ((int)g1 + (int)g2 + (int)g3);
+    float k_b = g3 ? k3 : (g2 ? k2 : (g1 ? k1 : k0));
+    float k_n = g3 ? k4 : (g2 ? k3 : (g1 ? k2 : k1));
+    const float hi_ = c.hi;
+    k_n = e.b[Q] == c.Km1 ? hi_ : k_n;                                  // ends pinned (:189-192)
+    e.a_b[Q] = k_b;
+    e.a_w[Q] = k_n - k_b;
+    hk.template pt<11>(e.b[Q], e.a_b[Q], e.a_w[Q]);
+}
+template <int Q, class H>
+__device__ __forceinline__ void rqs32_select(const f32x16 &u0, const f32x16 &u1, rqs_elems &e, const rqs32_c &c, H &hk) {
+    rqs32_s s;
+    rqs32_sums(u0, u1, c, s, hk);
+    const int b = e.b[Q] & (RQS_OUT - 1), bl = b & 3;
+    bool m[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) m[j] = b >= 4 * (j + 1);
+    float k0, k1, k2, k3, k4;
+    rqs32_knots(s, c, m, k0, k1, k2, k3, k4, hk);
+    const bool g1 = bl >= 1, g2 = bl >= 2, g3 = bl >= 3;
+    hk.template pt<10>();
+    float k_b = g3 ? k3 : (g2 ? k2 : (g1 ? k1 : k0));
+    float k_n = g3 ? k4 : (g2 ? k3 : (g1 ? k2 : k1));
+    const float hi_ = c.hi;
+    k_n = b == c.Km1 ? hi_ : k_n;
+    e.c_b[Q] = k_b;
+    e.c_w[Q] = k_n - k_b;
+    hk.template pt<11>(e.c_b[Q], e.c_w[Q]);
+}
+// the two knot derivatives of the bin: D[-1] = D[K - 1] = the boundary constant (the packer parks it in the rows >= K - 1), r_b = D[b - 1],
+// r_n = D[b]; the five candidates D[4g - 1 .. 4g + 3] of the bin's group by the eight-way chains, then the pair inside it
+template <int Q, bool REV, class H>
+__device__ __forceinline__ void rqs32_eval(const f32x16 &u0, const f32x16 &u1, const rqs_elems &e, float &out, float &ljd, H &hk) {
+    hk.template pt<0>();
+    const int b = e.b[Q] & (RQS_OUT - 1), bl = b & 3;
+    const bool in = e.b[Q] < RQS_OUT;
+    const float cst = 0.5397424172369522f;                      // log(exp(1 - 1e-3) - 1), :81 boundary derivative constant
+    bool m[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) m[j] = b >= 4 * (j + 1);
+#define RQS32_D(k) ((k) < 0 ? cst : ((k) < 16 ? u0[(k) & 15] : ((k) < 32 ? u1[(k) & 15] : cst)))
+    // (named copies: a select between two vector elements is canonicalised into a select of ADDRESSES -- rqs_eval)
+    float d[33];
+#pragma unroll
+    for (int k = -1; k < 32; ++k) d[k + 1] = RQS32_D(k);
+#undef RQS32_D
+    float v0 = rqs32_pick(m, d[0], d[4], d[8], d[12], d[16], d[20], d[24], d[28]);
+    float v1 = rqs32_pick(m, d[1], d[5], d[9], d[13], d[17], d[21], d[25], d[29]);
+    hk.template pt<1>(v0, v1);
+    float v2 = rqs32_pick(m, d[2], d[6], d[10], d[14], d[18], d[22], d[26], d[30]);
+    float v3 = rqs32_pick(m, d[3], d[7], d[11], d[15], d[19], d[23], d[27], d[31]);
+    hk.template pt<2>(v2, v3);
+    float v4 = rqs32_pick(m, d[4], d[8], d[12], d[16], d[20], d[24], d[28], d[32]);
+    const bool g1 = bl >= 1, g2 = bl >= 2, g3 = bl >= 3;
+    float r_b = g3 ? v3 : (g2 ? v2 : (g1 ? v1 : v0));
+    float r_n = g3 ? v4 : (g2 ? v3 : (g1 ? v2 : v1));
+    hk.template pt<3>(r_b, r_n);
+    rqs_eval_core<Q, REV>(r_b, r_n, in, e, out, ljd, hk);
+}
+// two tiles' MFMAs from one element's twelve points
+template <int HT, int UA, int UB>
+struct rqs_pair_pipe {
+    rqs_tile_pipe<HT, UA> a;
+    rqs_tile_pipe<HT, UB> b;
+    __device__ __forceinline__ rqs_pair_pipe(const wptr w, const btile<1> (&bh)[HT], tile<1> &ta, tile<1> &tb) : a(w, bh, ta), b(w, bh, tb) {}
+    __device__ __forceinline__ void start() { a.start(); b.start(); }
+    template <int P, class... T> __device__ __forceinline__ void pt(T &...tie) {
+        a.template pt<P>(tie...);
+        b.template pt<P>();
+    }
+};
+template <int PH, bool REV, int Q, class H>
+__device__ __forceinline__ void rqs32_unit(const f32x16 &u0, const f32x16 &u1, rqs_elems &e, const rqs32_c &c, float (&out)[4], float (&lj)[4], H &hk) {
+    if constexpr (PH == 0) rqs32_search<Q>(u0, u1, e, c, hk);
+    else if constexpr (PH == 1) rqs32_select<Q>(u0, u1, e, c, hk);
+    else rqs32_eval<Q, REV>(u0, u1, e, out[Q], lj[Q], hk);
+}
+// a step's two elements (tiles 0, 1 and 2, 3): element 0 beside the MFMAs of tiles 2, 3 (tiles 0, 1 are in A0 / A1 on entry), element 1
+// is left to the caller (beside the next step's first two tiles, or alone at the end of the group)
+template <int HT, int PH, bool REV>
+__device__ __forceinline__ void rqs32_first(const wptr w, const btile<1> (&bh)[HT], rqs_elems &e, const rqs32_c &c, float (&out)[4], float (&lj)[4],
+                                            tile<1> &A0, tile<1> &A1, tile<1> &B0, tile<1> &B1) {
+    rqs_pair_pipe<HT, 2, 3> p(w, bh, B0, B1);
+    p.start();
+    rqs32_unit<PH, REV, 0>(A0.v[0], A1.v[0], e, c, out, lj, p);
+}
+template <int HT, bool GEN_UNUSED, class ADV>
+__device__ __forceinline__ void rqs32_group(const wptr w0, const btile<1> (&bh)[HT], rqs_elems &e, int K, float lo, float hi, int h,
+                                            ADV &&advance, float (&out)[4], float (&lj)[4], uint32_t &live_mask, float &ldj_scale) {
+    wptr w;
+    dstep st;
+    bool lean;
+    tile<1> A0, A1, B0, B1;
+    A0 = load_cfrag<1>(w0.cb, 4 * HT * 1024);
+    A1 = load_cfrag<1>(w0.cb, 4 * HT * 1024 + 32);
+#pragma unroll
+    for (int m = 0; m < HT; ++m) { gemm_tile<1>(w0.wb, m * 1024, bh[m], A0); gemm_tile<1>(w0.wb, (HT + m) * 1024, bh[m], A1); }
+    const rqs32_c c0 = rqs32_consts(lo, hi, K);
+    rqs32_first<HT, 0, false>(w0, bh, e, c0, out, lj, A0, A1, B0, B1);
+    advance(st, w);
+    rqs_block_scalars<HT>(w, h, lo, hi, lean);
+    const rqs32_c c1 = rqs32_consts(lo, hi, K);
+    { rqs_pair_pipe<HT, 0, 1> p(w, bh, A0, A1); p.start(); rqs32_unit<0, false, 1>(B0.v[0], B1.v[0], e, c0, out, lj, p); }
+    rqs32_first<HT, 1, false>(w, bh, e, c1, out, lj, A0, A1, B0, B1);
+    advance(st, w);
+    { rqs_pair_pipe<HT, 0, 1> p(w, bh, A0, A1); p.start(); rqs32_unit<1, false, 1>(B0.v[0], B1.v[0], e, c1, out, lj, p); }
+    if (st.reverse) {
+        rqs32_first<HT, 2, true>(w, bh, e, c1, out, lj, A0, A1, B0, B1);
+        rqs_pinhook nh; rqs32_unit<2, true, 1>(B0.v[0], B1.v[0], e, c1, out, lj, nh);
+    } else {
+        rqs32_first<HT, 2, false>(w, bh, e, c1, out, lj, A0, A1, B0, B1);
+        rqs_pinhook nh; rqs32_unit<2, false, 1>(B0.v[0], B1.v[0], e, c1, out, lj, nh);
+    }
+    live_mask = st.mask; ldj_scale = st.ldj_scale;
+}
 template <int HT, int PH, bool REV>
 __device__ __forceinline__ void rqs16_block(const wptr w, const btile<1> (&bh)[HT], rqs_elems &e, const rqs16_c &c, float (&out)[4],
                                             float (&lj)[4], prof_t &pf) {
@@ -790,6 +1006,13 @@ __device__ __forceinline__ void rqs_triple(tile<1> (&xs)[TX], const btile<1> (&b
         const int half = st0.act >> 1;
         rqs_elems e2;
         e2.x[0] = half ? e.x[2] : e.x[0]; e2.x[1] = half ? e.x[3] : e.x[1];
+        float o0, o1, l0, l1;
+        if (lean) {
+            // bounded logits (the packed bound of the group's two softmax blocks): the two-level form, pipelined over the triple
+            float o2[4], l2[4];
+            rqs32_group<HT, true>(w0, bh, e2, K, lo, hi, h, advance, o2, l2, live_mask, ldj_scale);
+            o0 = o2[0]; o1 = o2[1]; l0 = l2[0]; l1 = l2[1];
+        } else {
         wptr w;
         dstep st;
         tile<1> acc[4];
@@ -803,7 +1026,6 @@ __device__ __forceinline__ void rqs_triple(tile<1> (&xs)[TX], const btile<1> (&b
         rqs_select<1, 0, 2>(acc, e2, K, lo, hi); asm volatile("" : "+v"(e2.c_b[1]), "+v"(e2.c_w[1])); __builtin_amdgcn_sched_barrier(0);
         advance(st, w);
         rqs_gemm<HT>(w, bh, acc);
-        float o0, o1, l0, l1;
         if (st.reverse) {
             rqs_eval_wide<0, true>(acc[0].v[0], acc[1].v[0], e2, K, o0, l0); __builtin_amdgcn_sched_barrier(0);
             rqs_eval_wide<1, true>(acc[2].v[0], acc[3].v[0], e2, K, o1, l1);
@@ -811,9 +1033,10 @@ __device__ __forceinline__ void rqs_triple(tile<1> (&xs)[TX], const btile<1> (&b
             rqs_eval_wide<0, false>(acc[0].v[0], acc[1].v[0], e2, K, o0, l0); __builtin_amdgcn_sched_barrier(0);
             rqs_eval_wide<1, false>(acc[2].v[0], acc[3].v[0], e2, K, o1, l1);
         }
+        live_mask = st.mask; ldj_scale = st.ldj_scale;
+        }
         out[0] = half ? e.x[0] : o0; out[1] = half ? e.x[1] : o1; out[2] = half ? o0 : e.x[2]; out[3] = half ? o1 : e.x[3];
         lj[0] = half ? 0.f : l0; lj[1] = half ? 0.f : l1; lj[2] = half ? l0 : 0.f; lj[3] = half ? l1 : 0.f;
-        live_mask = st.mask; ldj_scale = st.ldj_scale;
     } else {
         // up to 16 bins, softmax with its running maximum: block by block, one element at a time (interleaved by the scheduler the
         // four sweeps keep ~60 lane masks alive: hundreds of SGPR spills and nine VGPRs of spill lanes in the whole kernel)

@@ -24,6 +24,11 @@ extern __shared__ __attribute__((aligned(16))) float rqs_smem[];
 // The spline kernels issue the NEXT group's copy as soon as the current group's parameters sit in registers, so the HBM
 // latency of a group hides under the arithmetic of the one before it.
 typedef __attribute__((address_space(3))) void rqs_lds_void;
+// cache policy of the parameter stream's LDS-DMA (aux bits of global_load_lds: 0 default, 2 = nt): the [N, n_live (3K-1)] tensor is read
+// exactly once (MI355X_MICROARCH.md, nt-weights: once-read streams land 18 % sooner under nt) -- measured in DESIGN 6
+#ifndef SX_RQS_DMA_AUX
+#define SX_RQS_DMA_AUX 2
+#endif
 template <int BYTES>
 __device__ __forceinline__ void rqs_dma_span(const float *__restrict__ g, float *lds_slice, int lane) {
     const char *gs = reinterpret_cast<const char *>(g) + lane * 16;
@@ -31,7 +36,7 @@ __device__ __forceinline__ void rqs_dma_span(const float *__restrict__ g, float 
 #pragma unroll
     for (int off = 0; off < BYTES; off += 1024) {
         if (off + 1024 <= BYTES || off + lane * 16 < BYTES)
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(gs + off), (rqs_lds_void *)(ld + off), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(gs + off), (rqs_lds_void *)(ld + off), 16, 0, SX_RQS_DMA_AUX);
     }
 }
 

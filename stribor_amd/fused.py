@@ -483,7 +483,9 @@ class CompiledProgram:
             elif mode == 'fast':
                 # (weights beyond fp16's range: the same program on the exact-fp32 objects, silently -- a parameter's magnitude is not
                 #  an error in the reference.  Decided from the pack's own flag, once per weight version, on calls without a graph.)
-                quiet = not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing()
+                # (`redo_allowed`: not inside a graph-building flow call -- autograd runs a Function's forward with grad mode off, so
+                #  grad mode alone would let every training step pay this read-back)
+                quiet = _hip.redo_allowed() and not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing()
                 launch(_hip.GEMM_F32 if (quiet and self.jobs_or_owner() and self.weights_beyond_fp16()) else _hip.GEMM_F16X3, redo=True)
             else:                                   # 'auto': never hand back a NaN-poisoned result
                 keep = None if sum_out is None else sum_out.clone()
@@ -939,19 +941,25 @@ class ProgramBuilder:
                         self.jobs.append(_PackJob(W2, b2, rows, col2, 4, HT, off, np.full(128, -2.0 * sc2), np.full(128, sc2), 1.0,
                                                   bound_off=bound_slot if phase < 2 else None))
                         self.jobs.append(_ScalarsJob([lo, hi], off + nlin))
-                        if not wide and K < 16 and (phase < 2 or not cubic):
-                            # Fewer than 16 bins: the unused registers of an element's tile are parked where the K <= 16 code of
-                            # the kernel needs no predicate for them (sx_flow_spline.h, rqs16_c): logits of bins >= K at -1e30
-                            # (exp2 = 0: every sum is that of the K bins), derivative rows >= K - 1 at the boundary-derivative
-                            # constant log(exp(1 - 1e-3) - 1) of rational_quadratic_spline.py:81 (D[K - 1] then needs no select).
+                        if (K < (32 if wide else 16) and phase < 2) or (phase == 2 and not cubic):
+                            # The unused registers of an element's tile (16 slots; 32 for 17 .. 32 bins) are parked where the
+                            # straight-line code of the kernel needs no predicate for them (sx_flow_spline.h, rqs16_c / rqs32_c): logits
+                            # of bins >= K at -1e30 (exp2 = 0: every sum is that of the K bins), derivative rows >= K - 1 -- there is
+                            # always at least one -- at the boundary-derivative constant log(exp(1 - 1e-3) - 1) of
+                            # rational_quadratic_spline.py:81 (D[K - 1] then needs no select).
                             # Bias block of the pack: [tile][lane half][register] behind the 4 x HT fragment tiles.
                             first, pad = (K, -1e30) if phase < 2 else (K - 1, 0.5397424172369522)
-                            for q in elems:
+                            for qi, q in enumerate(elems):
                                 for h in range(2):
                                     if slot_live[32 * t + q + 8 * g + 4 * h]:
-                                        base = off + 4 * HT * 1024 + 32 * q + 16 * h
-                                        pad_off += list(range(base + first, base + 16))
-                                        pad_val += [pad] * (16 - first)
+                                        if wide:        # 17 .. 32 bins: parameter k of the step's element qi = register k & 15 of tile 2 qi + (k >> 4)
+                                            for k in range(first, 32):
+                                                pad_off.append(off + 4 * HT * 1024 + 32 * (2 * qi + (k >> 4)) + 16 * h + (k & 15))
+                                                pad_val.append(pad)
+                                        else:
+                                            base = off + 4 * HT * 1024 + 32 * q + 16 * h
+                                            pad_off += list(range(base + first, base + 16))
+                                            pad_val += [pad] * (16 - first)
                         s_scale = (-ldj_scale if reverse else ldj_scale) if phase == 2 else 0.0
                         step = dict(kind=_hip.STEP_RQS_PHASE, c0=g, ct=phase, t0=t, tt=K, reverse=int(reverse),
                                     act=int(cubic) | (half << 1), blob_off=off, blob_floats=n, ldj_scale=s_scale, ldj_const=0.0)

@@ -33,10 +33,11 @@ def main():
     for dim, hidden in ((64, 64), (64, 128), (64, 160), (64, 256), (128, 64), (160, 64), (200, 64)):
         cases.append(('affine', dim, hidden, 0))
     cases.append(('affine', 128, 160, 0))
-    for K in (16, 24, 32):
+    for K in (4, 8, 12, 16, 17, 24, 32):      # (round 6: every K <= 16 on the straight-line phases; 17 .. 32 on their two-tile form)
         cases.append(('rqs', 64, 64, K))
     cases.append(('rqs', 64, 160, 16))
     cases.append(('rqs', 64, 256, 16))
+    cases.append(('cubic', 64, 64, 8))
     cases.append(('cubic', 64, 64, 16))
     cases.append(('cubic', 64, 160, 16))
     with torch.no_grad():
