@@ -626,7 +626,8 @@ def main():
     if rank == 0:
         rows_total = ROWS_PER_GPU * world * args.steps
         # dominant kernel: the fused flow kernel, one launch per step; average launch period over the timed region itself
-        # (HIP events ev0 / ev1; each step also launches a 4.6 us zero-fill of the 8-byte result); the median of grouped
+        # (HIP events ev0 / ev1; each step also launches a 4.6 us zero-fill of the 8-byte result and, since round 6, the exact
+        # redo pass of sx_flow_run2 -- on this data an empty list: its workgroups read one word and leave); the median of grouped
         # launches afterwards is kept beside it
         k_avg_ms = ev0.elapsed_time(ev1) / args.steps
         with torch.no_grad():
