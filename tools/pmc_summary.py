@@ -18,6 +18,11 @@ VARIANTS = {'cfg2': (1, 2, 2, 5), 'cfg3': (1, 2, 2, 3), 'cfg4': (1, 4, 2, 7)}
 def kernel_key(name):
     if 'affine_coupling_vec' in name:
         return 'affine_coupling_vec_kernel'
+    # (round 6: every no-graph call is followed by the exact redo pass of sx_flow_run2 -- the SAME template instance in the sx_f32x
+    #  namespace, on ordinary data an empty launch -- and bench.py's cfg2_exact entry runs that namespace's kernels too: the counters of
+    #  a config are those of its fp16 x 3 kernel only)
+    if 'sx_f32x' in name:
+        return None
     m = re.search(r'flow_fused_kernel<\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+)\s*>', name)
     if not m:
         m = re.search(r'flow_fused_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E', name)

@@ -15,6 +15,7 @@ for f in glob.glob('$O/*/**/*counter_collection.csv', recursive=True):
         n = r['Kernel_Name']
         k = ('layer-major backward flow_fused_kernel<1,4,2,11>' if 'Li4ELi2ELi11E' in n or '<1, 4, 2, 11>' in n else
              'backward program flow_fused_kernel<1,4,2,4>' if 'Li4ELi2ELi4E' in n or '<1, 4, 2, 4>' in n else
+             'exact redo pass (sx_f32x; empty list)' if 'sx_f32x' in n else
              'forward flow_fused_kernel<1,2,2,5>' if 'flow_fused' in n else
              'wgrad_layer_kernel<1,2,1,8>' if 'wgrad_layer' in n else
              'wgrad_reduce_kernel' if 'wgrad_reduce' in n else None)

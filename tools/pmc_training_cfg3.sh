@@ -19,6 +19,7 @@ for f in glob.glob('$O/*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         n = r['Kernel_Name']
         k = ('rqs_slab_bwd_kernel' if 'rqs_slab_bwd' in n else 'rqs_slab_dh_reduce_kernel' if 'dh_reduce' in n else
+             'exact redo pass (sx_f32x; empty list)' if 'sx_f32x' in n else
              'flow_fused_kernel (per-layer forward)' if 'flow_fused' in n else 'rqs_inverse_bwd_kernel' if 'rqs_inverse_bwd' in n else
              'rqs_kernel (forward)' if 'rqs_kernel' in n else 'library GEMM (Cijk)' if n.startswith('Cijk') else 'other')
         per[k][r['Counter_Name']] += float(r['Counter_Value'])

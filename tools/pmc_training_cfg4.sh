@@ -18,6 +18,7 @@ for f in glob.glob('$O/*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         n = r['Kernel_Name']
         k = ('flow_fused_kernel<1,8,2,4> (backward program)' if 'flow_fused_kernel<1, 8' in n else
+             'exact redo pass (sx_f32x; empty list)' if 'sx_f32x' in n else
              'flow_fused_kernel (forward)' if 'flow_fused' in n else 'wgrad_kernel<4,4>' if 'wgrad_kernel<4, 4' in n else
              'wgrad_kernel<4,2>' if 'wgrad_kernel<4, 2' in n else 'wgrad_kernel<2,2>' if 'wgrad_kernel<2, 2' in n else
              'wgrad_reduce_kernel' if 'wgrad_reduce' in n else 'tri_inverse_kernel' if 'tri_inverse' in n else
