@@ -422,6 +422,10 @@ int sx_pack_linear_bound(const float *W, const float *b, int32_t out_dim, int32_
                                         * registers for the SX_STEP_WIDE_AFFINE_TILE steps behind it; blob = pack(W1', h_tiles x 4) */
 #define SX_STEP_WIDE_AFFINE_TILE    23  /* ... and ONE transformed tile t0 of that coupling: (kk log_scale, shift) = W2'[rows of the tile] . r + b2', the
                                         * affine map (coupling.py:69-95, affine.py:104-109), the log-det; blob = pack(W2' rows, 2 x h_tiles) */
+#define SX_STEP_MLP_INPUT           24  /* MLP programs (round 6): hidden = state -- the program's input tiles ARE the operand of its
+                                         * SX_STEP_MLP_OUT_TILE steps, i.e. ONE nn.Linear y = W x + b (net/mlp.py:48-58 layer by layer, the
+                                         * [N, D] x [D, D] products of the layer-wise training path) as a hand-written MFMA program
+                                         * instead of a library GEMM; tiles <= h_tiles; first step of its program; blob: unused (>= 256 floats) */
 #define SX_STEP_CPL_HIDDEN          13  /* deep conditioners (>= 2 hidden layers): hidden = act(W1 . state[c0..c0+ct) + b1), kept in
                                            registers for the next step; blob = pack_linear(W1, h_tiles x ct)                    */
 #define SX_STEP_CPL_HIDDEN2         14  /* hidden = act(Wk . hidden + bk); blob = pack_linear(Wk, h_tiles x h_tiles)              */

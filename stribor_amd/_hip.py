@@ -43,6 +43,7 @@ STEP_COUPLING_TIME = 20
 STEP_COUPLING_AFFINE_HC = 21
 STEP_WIDE_HIDDEN = 22
 STEP_WIDE_AFFINE_TILE = 23
+STEP_MLP_INPUT = 24
 
 WGRAD_ROW_MAJOR, WGRAD_ROW_GROUPS, WGRAD_ROW_GROUPS_F16X3 = 0, 1, 3
 

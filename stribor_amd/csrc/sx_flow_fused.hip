@@ -93,6 +93,9 @@ static int validate_and_convert(const sx_program *p, dprog *d, int *buf_floats, 
             case SX_STEP_MLP_HIDDEN:
                 SX_REQUIRE(s.c0 == 0 && s.ct == p->tiles, "sx_flow_run: MLP_HIDDEN must read all tiles");
                 need = sx_packed_linear_floats(p->h_tiles, p->tiles); *mlp_mode = 1; break;
+            case SX_STEP_MLP_INPUT:
+                SX_REQUIRE(i == 0 && p->tiles <= p->h_tiles && p->tiles <= 4, "sx_flow_run: MLP_INPUT is the first step of its program and needs tiles <= h_tiles");
+                need = 0; *mlp_mode = 1; break;
             case SX_STEP_MLP_HIDDEN2: need = sx_packed_linear_floats(p->h_tiles, p->h_tiles); *mlp_mode = 1; break;
             case SX_STEP_MLP_OUT_TILE: need = sx_packed_linear_floats(1, p->h_tiles); *mlp_mode = 1; break;
             case SX_STEP_LINEAR_TILE:
@@ -269,9 +272,9 @@ extern "C" int sx_flow_launch_info(const sx_program *prog_host, int64_t n_rows, 
     dprog d; int bf; int mm; int sw;
     int rc = validate_and_convert(prog_host, &d, &bf, &mm, &sw);
     if (rc) return rc;
-    if (lds_bytes) *lds_bytes = bf * 8 + 16;
+    if (lds_bytes) *lds_bytes = bf * 8 + 16 + ((mm == 5 || mm == 6) ? 64 * SX_BLOCK_WAVES(prog_host->tiles, mm) * 8 : 0);
     if (block) *block = 64 * SX_BLOCK_WAVES(prog_host->tiles, mm);
-    if (grid) *grid = pick_grid(n_rows, bf * 8 + 16, prog_host->tiles, mm);
+    if (grid) *grid = pick_grid(n_rows, bf * 8 + 16 + ((mm == 5 || mm == 6) ? 64 * SX_BLOCK_WAVES(prog_host->tiles, mm) * 8 : 0), prog_host->tiles, mm);
     return SX_OK;
 }
 
@@ -322,7 +325,9 @@ extern "C" int sx_flow_run2(const sx_program *prog_host, const float *blobs, con
     a.prog = d; a.blobs = blobs; a.x = x; a.latent = latent; a.in_col = in_col; a.out_col = out_col; a.y = y;
     a.ldj_out = ldj_out; a.logp_out = logp_out; a.sum_out = sum_out; a.mlp_out = mlp_out;
     a.mlp_out_stride = mlp_out_stride; a.mlp_out_dim = mlp_out_dim; a.n_rows = n_rows; a.buf_floats = bf;
-    a.bf16 = dtype == SX_BF16; a.mlp_mode = mlp_mode; a.lds = bf * 8 + 16; a.grid = pick_grid(n_rows, a.lds, prog_host->tiles, mlp_mode);
+    // (MODE 5 / 6: + one fp64 slot per lane for the running batch sum, behind the ring and the ticket slots: sx_flow_kernel.h, LDS_SUM)
+    a.bf16 = dtype == SX_BF16; a.mlp_mode = mlp_mode; a.lds = bf * 8 + 16 + ((mlp_mode == 5 || mlp_mode == 6) ? 64 * SX_BLOCK_WAVES(prog_host->tiles, mlp_mode) * 8 : 0);
+    a.grid = pick_grid(n_rows, a.lds, prog_host->tiles, mlp_mode);
     a.stream = sx_stream(stream);
     a.row_t = row_t;
     a.side = side;

@@ -1297,6 +1297,13 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
     const int64_t n_chunks = redo_pass ? (int64_t)((redo_count + WB * NS - 1) / (WB * NS)) : (n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     const int bf16 = k.bf16, buf_floats = k.buf_floats;
     double block_sum = 0.0;
+    // MODE 5 / 6 (the pure split-coupling kernels sit exactly on their 128-register budget): the lane's running fp64 sum lives in LDS
+    // (one slot per lane behind the weight ring and the ticket slots: sx_flow_run adds the bytes), not in a register pair carried
+    // across the step loop -- round 6's range tracking made the allocator spill that pair to scratch (2 x 4096 chunks x 512 lanes x
+    // 12 B = +9 MB of HBM writes per cfg-2 launch: pmc_cfg2.json 145.6 -> 159.2 MB); two LDS instructions per chunk instead
+    constexpr bool LDS_SUM = MODE == 5 || MODE == 6;
+    [[maybe_unused]] double *lds_sum = reinterpret_cast<double *>(smem + 2 * k.buf_floats + 4) + threadIdx.x;
+    if constexpr (LDS_SUM) *lds_sum = 0.0;
     prof_t pf;
     SX_EXP_KERNEL_BEGIN(pf);
 
@@ -1740,6 +1747,21 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     break;
                 case SX_STEP_MLP_HIDDEN:
                     if constexpr (MODE == 1) hidden_layer<NS, TX, HT, 0, TX, false>(xs, hid, w, 0, st.act, rg);
+                    break;
+                case SX_STEP_MLP_INPUT:
+                    // a single Linear: the output tiles contract the program's INPUT (tiles <= h_tiles: checked by the launcher)
+                    if constexpr (MODE == 1 && TX <= HT) {
+#pragma unroll
+                        for (int m = 0; m < HT; ++m) {
+                            if (m < TX) hid[m] = xs[m];
+                            else {
+#pragma unroll
+                                for (int n = 0; n < NS; ++n)
+#pragma unroll
+                                    for (int r = 0; r < 16; ++r) hid[m].v[n][r] = 0.f;
+                            }
+                        }
+                    }
                     break;
                 case SX_STEP_CPL_HIDDEN:
                     if constexpr (MIX && NS == 1) {
@@ -2211,7 +2233,8 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                 if (row[n] < n_rows && h == 0) {
                     if (k.ldj_out != nullptr) k.ldj_out[row[n]] = ldj_tot;
                     if (k.logp_out != nullptr) k.logp_out[row[n]] = lp;
-                    block_sum += (double)(k.logp_out != nullptr ? lp : ldj_tot);
+                    if constexpr (LDS_SUM) *lds_sum += (double)(k.logp_out != nullptr ? lp : ldj_tot);
+                    else block_sum += (double)(k.logp_out != nullptr ? lp : ldj_tot);
                 }
             }
         }
@@ -2283,6 +2306,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
     SX_EXP_KERNEL_END(pf);
     if (k.sum_out != nullptr) {
         double *part = reinterpret_cast<double *>(smem);   // no second __shared__ object beside the DMA ring
+        if constexpr (LDS_SUM) block_sum = *lds_sum;
         block_sum = wave_sum_f64(block_sum);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

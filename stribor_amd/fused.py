@@ -427,8 +427,9 @@ class CompiledProgram:
     def run(self, x: torch.Tensor, latent: Optional[torch.Tensor] = None, want_y: bool = False,
             want_ldj: bool = False, want_logp: bool = False, sum_out: Optional[torch.Tensor] = None,
             mlp_out: Optional[torch.Tensor] = None, row_t: Optional[torch.Tensor] = None,
-            side: Optional[torch.Tensor] = None):
-        """x: [N, dim] contiguous on the program's device.  Returns (y | None, ldj | None, logp | None)."""
+            side: Optional[torch.Tensor] = None, exact: bool = False):
+        """x: [N, dim] contiguous on the program's device.  Returns (y | None, ldj | None, logp | None).
+        exact: run on the exact-fp32 objects whatever the global arithmetic (HBM-bound single layers: net/mlp.py BatchLinear)."""
         _hip.require_device(x, 'x')
         assert x.dim() == 2 and x.shape[1] == (self.prog.pad_ or self.prog.dim), (x.shape, self.prog.dim, self.prog.pad_)
         if not x.is_contiguous():
@@ -455,7 +456,7 @@ class CompiledProgram:
             _hip.require_device(row_t, 't')
             row_t = row_t.reshape(-1).to(torch.float32).contiguous()
             assert row_t.numel() == n, (row_t.shape, n)
-        mode = _hip.get_gemm_precision()
+        mode = 'exact' if exact else _hip.get_gemm_precision()
         with _hip.device_of(x):                     # the library launches on the CURRENT device's stream
             work = _hip.work_counters(x.device)
             flag = _hip.err_flag(x.device)
@@ -474,6 +475,8 @@ class CompiledProgram:
                                              prec, work.data_ptr(), flag, _hip.stream())
                 if rc != 0:
                     work.zero_()                    # a failed launch may leave the ticket pair armed
+                    if redo:
+                        _hip.redo_list(x.device, n).zero_()      # ... and, where the second launch did not happen, a list that is not empty
                 _hip.check(rc, 'sx_flow_run')
                 if mode != 'auto':
                     _hip.after_launch()             # STRIBOR_SYNC_ERRORS: the data-dependent error leaves THIS call
@@ -1283,6 +1286,31 @@ class ProgramBuilder:
             off, n = self._alloc(_hip.packed_linear_floats(1, HT))
             self.jobs.append(_PackJob(WL, None if accumulate else bL, r, cL, 1, HT, off))
             self.steps.append(dict(kind=_hip.STEP_MLP_OUT_TILE, c0=0, ct=0, t0=u, tt=1, reverse=int(accumulate), act=0,
+                                   blob_off=off, blob_floats=n, ldj_scale=0.0, ldj_const=0.0))
+
+    def add_single_linear(self, W, b, out_rows: np.ndarray, transpose: bool = False) -> None:
+        """ONE nn.Linear as a program (round 6, VERDICT r5 #7: the layer-wise training path's `F.linear` / `gy @ W` were library
+        GEMMs): an SX_STEP_MLP_INPUT step (hidden = the program's input tiles) and one OUT_TILE step per 32 output columns.
+        y[:, i] = sum_c W[out_rows[i], c] x[:, c] + b[out_rows[i]];  transpose: the operand is W^T (y = x W: the input gradient of a
+        Linear; b must be None).  Input width <= 128 (the builder was made with hidden_width = dim, so h_tiles >= tiles)."""
+        self._narrow_only('MLP programs')
+        self._freeze_input()
+        T, HT = self.tiles, self.h_tiles
+        assert T <= HT and self.latent_dim == 0, (T, HT)
+        off, n = self._alloc(256)
+        self.steps.append(dict(kind=_hip.STEP_MLP_INPUT, c0=0, ct=T, t0=0, tt=0, reverse=0, act=0, blob_off=off, blob_floats=n,
+                               ldj_scale=0.0, ldj_const=0.0))
+        out_rows = np.asarray(out_rows, dtype=np.int64)
+        self.mlp_out_dim = len(out_rows)
+        cL = np.full(32 * HT, -1, dtype=np.int64)
+        cL[:self.n_slots] = self.col_of_slot
+        for u in range(_ceil_div(len(out_rows), 32)):
+            r = np.full(32, -1, dtype=np.int64)
+            seg = out_rows[32 * u:32 * u + 32]
+            r[:len(seg)] = seg
+            off, n = self._alloc(_hip.packed_linear_floats(1, HT))
+            self.jobs.append(_PackJob(W, b, r, cL, 1, HT, off, transpose=transpose))
+            self.steps.append(dict(kind=_hip.STEP_MLP_OUT_TILE, c0=0, ct=0, t0=u, tt=1, reverse=0, act=0,
                                    blob_off=off, blob_floats=n, ldj_scale=0.0, ldj_const=0.0))
 
     # -- finish ------------------------------------------------------------------------------------

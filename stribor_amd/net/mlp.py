@@ -16,7 +16,8 @@ from ..fused import ProgramBuilder, ProgramCache, StructureTracked
 
 
 class BatchLinear(torch.autograd.Function):
-    """y = x W^T + b for the layer-wise training path.  Forward and dL/dx are library GEMMs.  dL/dW = (dL/dy)^T x and
+    """y = x W^T + b for the layer-wise training path.  Forward and dL/dx: MFMA programs up to 128 x 256 features (round 6), library
+    GEMMs beyond.  dL/dW = (dL/dy)^T x and
     dL/db = sum_n dL/dy contract over the batch: for narrow layers (output <= 256 features) that is a tall-skinny product
     library GEMMs run on a handful of workgroups (0.63 ms for a 64 x 64 gradient over 2^18 rows) -- sx_wgrad computes
     both; for wide layers (a spline conditioner's 1504 rows) the library GEMM fills the chip and keeps dL/dW, and the
@@ -30,16 +31,47 @@ class BatchLinear(torch.autograd.Function):
     def eligible(x: torch.Tensor, W: torch.Tensor) -> bool:
         return x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and W.dtype == torch.float32
 
+    # Round 6: forward and dL/dx as hand-written MFMA programs too (SX_STEP_MLP_INPUT: the output tiles contract the
+    # program's input; v_mfma_f32_32x32x2_f32) where one launch holds the layer -- up to 128 input and 256 output features; the pack is one small launch per 32
+    # output columns (the weights of a training step are new every step), so wider outputs (a spline conditioner's 1504 rows) keep
+    # the library GEMM, which fills the chip there.
+    PROGRAM_MAX_IN, PROGRAM_MAX_OUT = 128, 256
+
+    @staticmethod
+    def _program_linear(x, W, b, transpose: bool):
+        """x [N, K] @ (W^T | W) + b as one fused-kernel launch, or None where the shape is not the program's."""
+        out_dim, in_dim = (W.shape[1], W.shape[0]) if transpose else W.shape
+        if (x.shape[0] < BatchLinear.MIN_ROWS or in_dim > BatchLinear.PROGRAM_MAX_IN or out_dim > BatchLinear.PROGRAM_MAX_OUT
+                or not x.is_contiguous() or not W.is_contiguous()):
+            return None
+        try:
+            bld = ProgramBuilder(in_dim, 0, in_dim)
+            bld.add_single_linear(W.detach(), None if b is None else b.detach(), np.arange(out_dim), transpose=transpose)
+            prog = bld.build(x.device)
+        except NotImplementedError:
+            return None
+        y = torch.empty(x.shape[0], out_dim, dtype=torch.float32, device=x.device)
+        # (the exact-fp32 arithmetic: a single [N, <= 128] x [<= 128, <= 256] layer is HBM-bound either way -- 400 MB against 17 Gflop
+        #  at 2^18 rows --, fp32 MFMA has no operand range and is torch's own arithmetic for this op)
+        prog.run(x, mlp_out=y, exact=True)
+        return y
+
     @staticmethod
     def forward(ctx, x, W, b):
         ctx.save_for_backward(x, W)
         ctx.has_bias = b is not None
-        return torch.nn.functional.linear(x, W, b)
+        y = BatchLinear._program_linear(x, W, b, False)
+        return y if y is not None else torch.nn.functional.linear(x, W, b)
 
     @staticmethod
     def backward(ctx, gy):
         x, W = ctx.saved_tensors
-        gx = gy @ W if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gyc = gy if gy.is_contiguous() else gy.contiguous()
+            gx = BatchLinear._program_linear(gyc, W, None, True)
+            if gx is None:
+                gx = gy @ W
         gW = gb = None
         want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         if not (want_w or want_b):

@@ -692,6 +692,36 @@ def test_batch_linear_weight_gradients_match_autograd(n, in_dim, out_dim):
     assert (x.grad.double() - xd.grad).abs().max().item() <= 1e-3
 
 
+@pytest.mark.parametrize('n,in_dim,out_dim', [(4096, 64, 64), (5000, 128, 256), (4099, 33, 7), (8192, 100, 130), (4096, 1, 1)])
+def test_batch_linear_forward_and_input_gradient_run_as_programs(n, in_dim, out_dim, monkeypatch):
+    """Round 6: up to 128 input and 256 output features `BatchLinear`'s forward and dL/dx are ONE fused-kernel launch
+    each (SX_STEP_MLP_INPUT + OUT_TILE steps, v_mfma_f32_32x32x2_f32) instead of library GEMMs (net/mlp.py:48-58 layer by layer;
+    flows/affine.py:157-163): no torch `linear` / `matmul` is called, values against fp64, rows of 1e6 included (the exact
+    arithmetic has no operand range)."""
+    from stribor_amd.net.mlp import BatchLinear
+    torch.manual_seed(n + in_dim)
+    x = torch.randn(n, in_dim, device=DEV)
+    x[3] *= 1.0e6
+    x.requires_grad_(True)
+    W = torch.randn(out_dim, in_dim, device=DEV, requires_grad=True)
+    b = torch.randn(out_dim, device=DEV, requires_grad=True)
+    weight = torch.randn(n, out_dim, device=DEV)
+    calls = []
+    real_linear = torch.nn.functional.linear
+    monkeypatch.setattr(torch.nn.functional, 'linear', lambda *a, **k: (calls.append('linear'), real_linear(*a, **k))[1])
+    y = BatchLinear.apply(x, W, b)
+    (y * weight).sum().backward()
+    monkeypatch.undo()
+    assert not calls
+    xd, Wd, bd = (t.detach().double().requires_grad_(True) for t in (x, W, b))
+    yd = torch.nn.functional.linear(xd, Wd, bd)
+    (yd * weight.double()).sum().backward()
+    row_scale = xd.detach().abs().amax(1, keepdim=True).clamp_min(1.0) * float(in_dim) ** 0.5
+    assert ((y.double() - yd).abs() / row_scale).max().item() <= 2e-6
+    assert (x.grad.double() - xd.grad).abs().max().item() <= 2e-5 * float(out_dim) ** 0.5
+    st.check_errors()
+
+
 @pytest.mark.parametrize('n,M,lda,Nc,ldb', [(4099, 50, 52, 33, 36), (1000, 300, 300, 128, 128), (31, 64, 64, 64, 64),
                                             (2050, 7, 7, 5, 5)])
 def test_wgrad_row_major_layouts(n, M, lda, Nc, ldb):
