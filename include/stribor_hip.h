@@ -353,6 +353,24 @@ int sx_pack_linear_bound(const float *W, const float *b, int32_t out_dim, int32_
                          const float *row_scale, const float *bias_scale, float fold_ones, int32_t transpose,
                          int32_t precision, uint32_t *err_flag, float *dst, float *bound_out, void *stream);
 
+/* A table of sx_pack_linear / sx_pack_linear_bound calls in ONE launch (a training step re-packs every Linear of a flow -- 13 per
+ * spline coupling -- after each optimizer step; net/mlp.py:48-66 has no such step, it is the price of the fragment layout).  `jobs`:
+ * DEVICE array of n_jobs records, every pointer a device pointer with the meaning of the same-named sx_pack_linear argument
+ * (bound_out NULL = no bound); the records are read when the kernel runs, i.e. the table must stay alive and unchanged until then.
+ * max_floats = the largest sx_packed_linear_floats(m_tiles, k_tiles) in the table.  Sizes and pointers inside the table are the
+ * caller's contract (the kernel cannot report them): build it from the same values the single calls would take. */
+typedef struct sx_pack_job {
+    const float *W, *b;
+    const int32_t *row_idx, *col_idx;
+    const float *row_scale, *bias_scale;
+    float *dst;
+    float *bound_out;
+    int32_t out_dim, in_dim, m_tiles, k_tiles, transpose;
+    float fold_ones;
+} sx_pack_job;
+int sx_pack_linear_batch(const sx_pack_job *jobs, int32_t n_jobs, int32_t max_floats, int32_t precision, uint32_t *err_flag,
+                         void *stream);
+
 /* One step of a fused flow program.  The flow state lives in registers as 32-wide "tiles" of columns (tile t =
  * state slots 32t..32t+31); slots map to columns of x through in_col/out_col.  Field use per kind: */
 #define SX_STEP_COUPLING_AFFINE      1  /* affine coupling (coupling.py:69-95 + affine.py:104-109): conditioner tiles [c0,c0+ct),
@@ -542,6 +560,17 @@ int sx_flow_bwd_run(const sx_program *prog_host, const float *blobs, const float
  * part: n_part tiles of M32 * N32 + M32 floats; one writer per element (deterministic). */
 int sx_wgrad_reduce(const float *part, int32_t n_part, int32_t M32, int32_t N32, float *dW, int64_t ldw, float *db,
                     int32_t m_valid, int32_t n_valid, const int32_t *row_map, const int32_t *col_map, void *stream);
+/* A table of such reductions in ONE launch (the 2 L reductions that close a layer-major backward pass of L couplings).  `jobs`:
+ * DEVICE array; a record's part / dW / db are FLOAT OFFSETS from part_base / out_base (db_off < 0: no bias), so a table built once
+ * serves every step whatever buffers the step allocated; M32 <= 128; every record sums the same number of partials n_part;
+ * max_elems = the largest M32 * N32 + M32 of the table.  The table must stay alive and unchanged until the kernel has run. */
+typedef struct sx_reduce_job {
+    int64_t part_off, dW_off, db_off, ldw;
+    const int32_t *row_map, *col_map;
+    int32_t M32, N32, m_valid, n_valid;
+} sx_reduce_job;
+int sx_wgrad_reduce_batch(const float *part_base, float *out_base, const sx_reduce_job *jobs, int32_t n_jobs, int32_t n_part,
+                          int32_t max_elems, void *stream);
 
 /* Weight-gradient contraction over the batch axis (training):
  *   dW[rm(i), cm(j)] += sum_n A[n, i] * B[n, j]   (dW row stride ldw),   db[rm(i)] += sum_n A[n, i]   (db may be NULL)

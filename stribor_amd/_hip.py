@@ -54,15 +54,27 @@ ACT_CODES = {'Identity': 0, 'Tanh': 1, 'ReLU': 2, 'Sigmoid': 3, 'ELU': 4, 'Softp
 # every symbol include/stribor_hip.h declares (tests check that the library exports all of them)
 EXPORTS = ['sx_abi_version', 'sx_fragment_mode', 'sx_last_error', 'sx_build_id', 'sx_absmax2', 'sx_permute', 'sx_affine_coupling', 'sx_rqs_coupling',
            'sx_cubic_coupling', 'sx_pointwise', 'sx_rqs_inverse_bwd', 'sx_rqs_forward_bwd', 'sx_affine_coupling_bwd', 'sx_time_affine_coupling', 'sx_cubic_inverse_bwd', 'sx_cubic_forward_bwd', 'sx_pointwise_bwd',
-           'sx_unit_normal_logprob', 'sx_sum_f64', 'sx_packed_linear_floats', 'sx_pack_linear', 'sx_pack_linear_bound', 'sx_flow_run', 'sx_flow_run2', 'sx_flow_redo_words',
+           'sx_unit_normal_logprob', 'sx_sum_f64', 'sx_packed_linear_floats', 'sx_pack_linear', 'sx_pack_linear_bound', 'sx_pack_linear_batch', 'sx_flow_run', 'sx_flow_run2', 'sx_flow_redo_words',
            'sx_flow_launch_info', 'sx_wgrad', 'sx_wgrad_layer', 'sx_colsum', 'sx_tri_inverse_f64',
            'sx_wgrad_scratch_floats', 'sx_wgrad_layer_scratch_floats', 'sx_flow_bwd_max_steps', 'sx_flow_bwd_partials',
-           'sx_flow_bwd_run', 'sx_wgrad_reduce', 'sx_rqs_slab_slots', 'sx_rqs_slab_scratch_floats', 'sx_rqs_slab_bwd', 'sx_rqs_slab_l1_scratch_floats', 'sx_rqs_slab_l1_bwd',
+           'sx_flow_bwd_run', 'sx_wgrad_reduce', 'sx_wgrad_reduce_batch', 'sx_rqs_slab_slots', 'sx_rqs_slab_scratch_floats', 'sx_rqs_slab_bwd', 'sx_rqs_slab_l1_scratch_floats', 'sx_rqs_slab_l1_bwd',
            'sx_rqs_slab_fwd_scratch_floats', 'sx_rqs_slab_fwd', 'sx_rqs_slab_hidden_floats', 'sx_rqs_slab_hidden']
 
 
 class HipLibraryMissing(RuntimeError):
     pass
+
+
+class sx_reduce_job(C.Structure):
+    _fields_ = [('part_off', C.c_int64), ('dW_off', C.c_int64), ('db_off', C.c_int64), ('ldw', C.c_int64), ('row_map', C.c_void_p),
+                ('col_map', C.c_void_p), ('M32', C.c_int32), ('N32', C.c_int32), ('m_valid', C.c_int32), ('n_valid', C.c_int32)]
+
+
+class sx_pack_job(C.Structure):
+    _fields_ = [('W', C.c_void_p), ('b', C.c_void_p), ('row_idx', C.c_void_p), ('col_idx', C.c_void_p), ('row_scale', C.c_void_p),
+                ('bias_scale', C.c_void_p), ('dst', C.c_void_p), ('bound_out', C.c_void_p), ('out_dim', C.c_int32),
+                ('in_dim', C.c_int32), ('m_tiles', C.c_int32), ('k_tiles', C.c_int32), ('transpose', C.c_int32),
+                ('fold_ones', C.c_float)]
 
 
 class sx_step(C.Structure):
@@ -146,6 +158,10 @@ def _declare(lib: C.CDLL) -> None:
     lib.sx_pack_linear.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, f32, i32, i32, vp, vp, vp]
     lib.sx_pack_linear_bound.restype = i32
     lib.sx_pack_linear_bound.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, f32, i32, i32, vp, vp, vp, vp]
+    lib.sx_pack_linear_batch.restype = i32
+    lib.sx_pack_linear_batch.argtypes = [vp, i32, i32, i32, vp, vp]
+    lib.sx_wgrad_reduce_batch.restype = i32
+    lib.sx_wgrad_reduce_batch.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     lib.sx_flow_run.restype = i32
     lib.sx_flow_run.argtypes = [C.POINTER(sx_program), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, i64, i32, i32, vp, vp, vp]
     lib.sx_flow_run2.restype = i32
@@ -518,6 +534,39 @@ def call(name: str, t: torch.Tensor, *args) -> None:
             after_launch()
     if rc != 0:
         check(rc, name)
+
+
+class PackTable:
+    """sx_pack_linear_batch: a table of packs run as ONE launch.  `run(records, ...)` takes one tuple per pack,
+    (W, b, out_dim, in_dim, row_idx, col_idx, m_tiles, k_tiles, row_scale, bias_scale, fold_ones, transpose, dst, bound_out) with device
+    addresses (ints, 0 / None = NULL); the device copy of the table is rebuilt only when a record changes (parameters keep their
+    storage across optimizer steps, so a training loop uploads it once)."""
+
+    def __init__(self):
+        self._key = None
+        self._table = None          # device bytes of the records
+        self._max_floats = 0
+
+    def run(self, t: torch.Tensor, records, prec: int, flag_ptr) -> None:
+        """on t's device and current stream; `t` only selects the device."""
+        if not records:
+            return
+        key = tuple(records)
+        if key != self._key or self._table is None or self._table.device != t.device:
+            arr = (sx_pack_job * len(records))()
+            mx = 0
+            names = ('W', 'b', 'out_dim', 'in_dim', 'row_idx', 'col_idx', 'm_tiles', 'k_tiles', 'row_scale', 'bias_scale', 'fold_ones',
+                     'transpose', 'dst', 'bound_out')
+            pointers = {'W', 'b', 'row_idx', 'col_idx', 'row_scale', 'bias_scale', 'dst', 'bound_out'}
+            for a, r in zip(arr, records):
+                for name, v in zip(names, r):
+                    setattr(a, name, (v or None) if name in pointers else v)
+                mx = max(mx, packed_linear_floats(r[6], r[7]))
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            # (a fresh device buffer per version: a launch already queued may still read the previous one)
+            self._table = host.to(t.device)
+            self._key, self._max_floats = key, mx
+        call('sx_pack_linear_batch', t, self._table.data_ptr(), len(records), self._max_floats, prec, flag_ptr)
 
 
 def packed_linear_floats(m_tiles: int, k_tiles: int) -> int:

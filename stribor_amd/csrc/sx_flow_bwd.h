@@ -490,7 +490,7 @@ __device__ __forceinline__ void coupling_affine_bwd_acc(tile<1> (&xs)[4], const 
     }
     __builtin_amdgcn_sched_barrier(0);
     // 3. dW2 partial: sum_n dp_n r_n^T (turned tiles; the tanh fix-up happens once per workgroup), one hidden tile at a time
-    {
+    if (!(SX_X & 512)) {        // (SX_X & 512: timing experiment without the weight-gradient contraction)
         float dummy = 0.f;
         const tfrag t0 = turn_tile(b0, sel, A.b2[0]), t1 = turn_tile(b1, sel, A.b2[1]);
 #pragma unroll
@@ -528,10 +528,11 @@ __device__ __forceinline__ void coupling_affine_bwd_acc(tile<1> (&xs)[4], const 
         for (int r = 0; r < 16; ++r) dz.v[0][r] = 0.f;
 #pragma unroll
         for (int m = 0; m < HT; ++m) gemm_tile<1>(w.wb, B1 + m * 1024, bd[m], dz);
-        float dummy = 0.f;
-        const tfrag tz = turn_tile(make_btile<1>(xs[C0]), sel, dummy);      // z again (the tile itself is unchanged)
 #pragma unroll
         for (int r = 0; r < 16; ++r) xs[XT + C0].v[0][r] += dz.v[0][r];
+        float dummy = 0.f;
+        if (SX_X & 512) return;
+        const tfrag tz = turn_tile(make_btile<1>(xs[C0]), sel, dummy);      // z again (the tile itself is unchanged)
 #pragma unroll
         for (int m = 0; m < HT; ++m) {
             const tfrag td = turn_tile(bd[m], sel, A.b1[m]);

@@ -4,7 +4,8 @@
 //
 //   -DSX_X=<bits>        compile-time ablations that keep the code straight-line (results WRONG, only the time matters):
 //                          4 no hidden transcendentals   8 no scale exp2   16 no MFMA (gemm_tile_f)   32 no weight ds_read
-//                          64 no fp16 split   128 no per-step wait + barrier
+//                          64 no fp16 split   128 no per-step wait + barrier   256 MODE 11: the state's loads / stores folded onto 4 MB
+//                          512 MODE 11: no weight-gradient contraction (turn + contract)
 //   -DSX_DEBUG_KNOBS     run-time ablation bits (environment SX_DBG: 1 no weight re-staging, 2 no per-step wait + barrier, 16 no MFMA) and
 //                        the in-kernel phase stamps (SX_PROF=1 prints them for one wave: -DSX_PROF_THREAD=<thread of workgroup 3>)
 #pragma once

@@ -1584,7 +1584,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
                     const int64_t ngrp = next_chunk * WB + wave;
                     if (ngrp < ((n_rows + 31) >> 5)) {       // wave-uniform
                         // (MUBUF LDS-DMA: see stage_blob -- this prefetch is in flight for the whole chunk)
-                        const int64_t ngrp_s = __builtin_amdgcn_readfirstlane((int)ngrp);
+                        const int64_t ngrp_s = (SX_X & 256) ? (__builtin_amdgcn_readfirstlane((int)ngrp) & 255) : __builtin_amdgcn_readfirstlane((int)ngrp);      // (SX_X & 256: state traffic folded onto 4 MB -- the launch's time without HBM)
                         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(k.frag_in + ngrp_s * (TX * 4 * 64 * 4)), 0, TX * 4 * 1024, 0x00020000);
                         char *ldst = reinterpret_cast<char *>(smem + pf_base + __builtin_amdgcn_readfirstlane(wave) * 4096);
 #pragma unroll
@@ -2174,7 +2174,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
 #endif
         if constexpr (MODE == 11) {
             if (k.frag_out != nullptr && chunk * WB + wave < ((n_rows + 31) >> 5)) {
-                f32x4 *fo = reinterpret_cast<f32x4 *>(k.frag_out) + (chunk * WB + wave) * (TX * 4 * 64) + lane;
+                f32x4 *fo = reinterpret_cast<f32x4 *>(k.frag_out) + ((SX_X & 256) ? ((chunk * WB + wave) & 255) : (chunk * WB + wave)) * (TX * 4 * 64) + lane;
 #pragma unroll
                 for (int t = 0; t < TX; ++t)
 #pragma unroll

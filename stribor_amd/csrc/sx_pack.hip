@@ -17,19 +17,20 @@ extern "C" size_t sx_packed_linear_floats(int32_t m_tiles, int32_t k_tiles) {
     return (size_t)m_tiles * k_tiles * 1024 + (size_t)m_tiles * 32;
 }
 
-__global__ __launch_bounds__(256) void pack_linear_kernel(const float *__restrict__ W, const float *__restrict__ b,
-                                                          int out_dim, int in_dim,
-                                                          const int32_t *__restrict__ row_idx,
-                                                          const int32_t *__restrict__ col_idx, int m_tiles,
-                                                          int k_tiles, const float *__restrict__ row_scale,
-                                                          const float *__restrict__ bias_scale, float fold_ones,
-                                                          int frag_mode, int transpose, uint32_t *__restrict__ err_flag,
-                                                          float *__restrict__ dst, uint32_t *__restrict__ bound_out) {
+// one pack: the floats o = first, first + stride, ... of the blob (workgroups of one launch, or of one job's row of a batched launch)
+__device__ __forceinline__ void pack_linear_body(const float *__restrict__ W, const float *__restrict__ b,
+                                                 int out_dim, int in_dim,
+                                                 const int32_t *__restrict__ row_idx,
+                                                 const int32_t *__restrict__ col_idx, int m_tiles,
+                                                 int k_tiles, const float *__restrict__ row_scale,
+                                                 const float *__restrict__ bias_scale, float fold_ones,
+                                                 int frag_mode, int transpose, uint32_t *__restrict__ err_flag,
+                                                 float *__restrict__ dst, uint32_t *__restrict__ bound_out, int first, int stride) {
     // transpose: the operand is W^T (row slots index W's columns, column slots index W's rows)
     auto Wat = [&](int r, int c) -> float { return transpose ? W[(int64_t)c * in_dim + r] : W[(int64_t)r * in_dim + c]; };
     const int n_a = m_tiles * k_tiles * 1024;
     const int total = n_a + m_tiles * 32;
-    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gridDim.x * blockDim.x) {
+    for (int o = first; o < total; o += stride) {
         float v = 0.f;
         if (o < n_a) {
             // o = (((m*k_tiles + kt)*4 + g)*64 + lane)*4 + e
@@ -96,6 +97,25 @@ __global__ __launch_bounds__(256) void pack_linear_kernel(const float *__restric
         dst[o] = v;
     }
 }
+__global__ __launch_bounds__(256) void pack_linear_kernel(const float *__restrict__ W, const float *__restrict__ b,
+                                                          int out_dim, int in_dim,
+                                                          const int32_t *__restrict__ row_idx,
+                                                          const int32_t *__restrict__ col_idx, int m_tiles,
+                                                          int k_tiles, const float *__restrict__ row_scale,
+                                                          const float *__restrict__ bias_scale, float fold_ones,
+                                                          int frag_mode, int transpose, uint32_t *__restrict__ err_flag,
+                                                          float *__restrict__ dst, uint32_t *__restrict__ bound_out) {
+    pack_linear_body(W, b, out_dim, in_dim, row_idx, col_idx, m_tiles, k_tiles, row_scale, bias_scale, fold_ones, frag_mode, transpose,
+                     err_flag, dst, bound_out, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+// a table of packs in ONE launch: blockIdx.y = job (a training step re-packs every weight of a flow: 100+ launches of 3 - 9 us before)
+__global__ __launch_bounds__(256) void pack_linear_batch_kernel(const sx_pack_job *__restrict__ jobs, int frag_mode,
+                                                                uint32_t *__restrict__ err_flag) {
+    const sx_pack_job j = jobs[blockIdx.y];
+    pack_linear_body(j.W, j.b, j.out_dim, j.in_dim, j.row_idx, j.col_idx, j.m_tiles, j.k_tiles, j.row_scale, j.bias_scale, j.fold_ones,
+                     frag_mode, j.transpose, err_flag, j.dst, reinterpret_cast<uint32_t *>(j.bound_out),
+                     blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
 
 static int pack_linear_impl(const float *W, const float *b, int32_t out_dim, int32_t in_dim,
                               const int32_t *row_idx, const int32_t *col_idx, int32_t m_tiles, int32_t k_tiles,
@@ -129,4 +149,16 @@ extern "C" int sx_pack_linear_bound(const float *W, const float *b, int32_t out_
     SX_REQUIRE(bound_out != nullptr, "sx_pack_linear_bound: null bound_out");
     return pack_linear_impl(W, b, out_dim, in_dim, row_idx, col_idx, m_tiles, k_tiles, row_scale, bias_scale, fold_ones, transpose,
                             precision, err_flag, dst, bound_out, stream);
+}
+
+extern "C" int sx_pack_linear_batch(const sx_pack_job *jobs, int32_t n_jobs, int32_t max_floats, int32_t precision,
+                                    uint32_t *err_flag, void *stream) {
+    SX_REQUIRE(precision == SX_GEMM_F32 || precision == SX_GEMM_F16X3, "sx_pack_linear_batch: unknown precision %d", precision);
+    SX_REQUIRE(jobs != nullptr && n_jobs > 0 && n_jobs <= 65535, "sx_pack_linear_batch: 1 .. 65535 jobs (got %d)", n_jobs);
+    SX_REQUIRE(max_floats > 0, "sx_pack_linear_batch: max_floats = the largest sx_packed_linear_floats of the table");
+    const int gx = (max_floats + 255) / 256;
+    hipLaunchKernelGGL(pack_linear_batch_kernel, dim3(gx > 64 ? 64 : gx, n_jobs), dim3(256), 0, sx_stream(stream), jobs, (int)precision,
+                       err_flag);
+    SX_LAUNCH_CHECK();
+    return SX_OK;
 }

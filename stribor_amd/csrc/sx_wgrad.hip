@@ -386,16 +386,16 @@ __global__ __launch_bounds__(64 * WB) void wgrad_kernel(const float *__restrict_
 // dW[rm(row)][cm(col)] += sum_p part[p][row * N32 + col]; db[rm(row)] += sum_p part[p][M32 * N32 + row], with
 // rm / cm the optional row / column maps (negative = dropped).  256 threads = 32 adjacent elements x 8 partial
 // groups (128 B coalesced reads, G / 8 independent loads per thread); one writer per element, no atomics.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int n_part, int M32, int N32,
-                                                           float *__restrict__ dW, int64_t ldw, float *__restrict__ db,
-                                                           int m_valid, int n_valid, const int32_t *__restrict__ row_map,
-                                                           const int32_t *__restrict__ col_map) {
+__device__ __forceinline__ void wgrad_reduce_body(const float *__restrict__ part, int n_part, int M32, int N32,
+                                                  float *__restrict__ dW, int64_t ldw, float *__restrict__ db,
+                                                  int m_valid, int n_valid, const int32_t *__restrict__ row_map,
+                                                  const int32_t *__restrict__ col_map, int slab) {
     __shared__ float red[8][32];
     const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int E = M32 * N32 + M32;
     const int e = blockIdx.x * 32 + el;
-    const int slab_row = 128 * blockIdx.y;                               // blockIdx.y = 128-row slab of dW
-    part += (int64_t)blockIdx.y * n_part * E;
+    const int slab_row = 128 * slab;                                     // 128-row slab of dW
+    part += (int64_t)slab * n_part * E;
     m_valid -= slab_row;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (e < E) {
@@ -429,6 +429,30 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
             if (row >= 0) db[row] += t;
         }
     }
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int n_part, int M32, int N32,
+                                                           float *__restrict__ dW, int64_t ldw, float *__restrict__ db,
+                                                           int m_valid, int n_valid, const int32_t *__restrict__ row_map,
+                                                           const int32_t *__restrict__ col_map) {
+    wgrad_reduce_body(part, n_part, M32, N32, dW, ldw, db, m_valid, n_valid, row_map, col_map, blockIdx.y);      // blockIdx.y = slab
+}
+// a table of reductions in one launch (blockIdx.y = job): the 2 L reductions of a layer-major backward pass
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const float *__restrict__ part_base, float *__restrict__ out_base,
+                                                                 const sx_reduce_job *__restrict__ jobs, int n_part) {
+    const sx_reduce_job j = jobs[blockIdx.y];
+    if ((int)blockIdx.x * 32 >= j.M32 * j.N32 + j.M32) return;          // (uniform per workgroup: before the barrier of the body)
+    wgrad_reduce_body(part_base + j.part_off, n_part, j.M32, j.N32, out_base + j.dW_off, j.ldw, j.db_off >= 0 ? out_base + j.db_off : nullptr,
+                      j.m_valid, j.n_valid, j.row_map, j.col_map, 0);
+}
+
+extern "C" int sx_wgrad_reduce_batch(const float *part_base, float *out_base, const sx_reduce_job *jobs, int32_t n_jobs,
+                                     int32_t n_part, int32_t max_elems, void *stream) {
+    SX_REQUIRE(part_base && out_base && jobs && n_jobs >= 1 && n_jobs <= 65535 && n_part >= 1 && max_elems >= 1,
+               "sx_wgrad_reduce_batch: bad arguments");
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((max_elems + 31) / 32, n_jobs), dim3(256), 0, sx_stream(stream), part_base,
+                       out_base, jobs, (int)n_part);
+    SX_LAUNCH_CHECK();
+    return SX_OK;
 }
 
 // Second stage on its own: sums `n_part` partial tiles ([M32 x N32 | M32] floats each, produced by sx_flow_bwd_run)

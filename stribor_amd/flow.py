@@ -228,14 +228,25 @@ def _backward_layer_major(bprog, layers, views, z, g, gy) -> None:
             if rc != 0:
                 work.zero_()
             _hip.check(rc, 'sx_flow_bwd_run')
-        for k in range(L):
-            info = layers[k][1]
-            gW1, gb1, gW2, gb2 = views[k]
-            base = acc[k].data_ptr()
-            _hip.check(lib.sx_wgrad_reduce(base, n_part, 64, H32, gW2.data_ptr(), gW2.stride(0), gb2.data_ptr(), 64, info['hidden'],
-                                           info['row_map'].data_ptr(), None, st), 'sx_wgrad_reduce')
-            _hip.check(lib.sx_wgrad_reduce(base + 4 * n_part * E2, n_part, H32, 32, gW1.data_ptr(), gW1.stride(0), gb1.data_ptr(),
-                                           info['hidden'], 32, None, info['col_map'].data_ptr(), st), 'sx_wgrad_reduce')
+        # the 2 L reductions in ONE launch: the table holds offsets into `acc` and into the flat gradient buffer the views
+        # partition (the same in every step), so it is uploaded once per backward program
+        out0 = views[0][0].data_ptr()
+        table = getattr(bprog, '_reduce_table', None)
+        if table is None or table[1] != (n_part, part_floats) or table[0].device != dev:
+            jobs = (_hip.sx_reduce_job * (2 * L))()
+            for k in range(L):
+                info = layers[k][1]
+                gW1, gb1, gW2, gb2 = views[k]
+                off = lambda v: (v.data_ptr() - out0) // 4
+                j2, j1 = jobs[2 * k], jobs[2 * k + 1]
+                (j2.part_off, j2.dW_off, j2.db_off, j2.ldw, j2.row_map, j2.col_map, j2.M32, j2.N32, j2.m_valid, j2.n_valid) = (
+                    k * n_part * part_floats, off(gW2), off(gb2), gW2.stride(0), info['row_map'].data_ptr(), None, 64, H32, 64, info['hidden'])
+                (j1.part_off, j1.dW_off, j1.db_off, j1.ldw, j1.row_map, j1.col_map, j1.M32, j1.N32, j1.m_valid, j1.n_valid) = (
+                    k * n_part * part_floats + n_part * E2, off(gW1), off(gb1), gW1.stride(0), None, info['col_map'].data_ptr(), H32, 32,
+                    info['hidden'], 32)
+            table = bprog._reduce_table = (torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev), (n_part, part_floats))
+        _hip.check(lib.sx_wgrad_reduce_batch(acc.data_ptr(), out0, table[0].data_ptr(), 2 * L, n_part, max(E2, H32 * 32 + H32), st),
+                   'sx_wgrad_reduce_batch')
 
 
 _FusedLogProb._layer_major_ok = staticmethod(_layer_major_ok)

@@ -671,7 +671,7 @@ class Coupling(Transform):
                 P = sp.params_per_element
                 rows_np = (np.asarray(live)[:, None] * P + np.arange(P)[None, :]).reshape(-1)
                 glob = np.where(rel >= 0, rows_np[np.clip(rel, 0, len(rows_np) - 1)], -1).astype(np.int32)
-                return (torch.from_numpy(glob).to(x2.device),) + tuple(plan[1:]) + (True,)
+                return (torch.from_numpy(glob).to(x2.device),) + tuple(plan[1:]) + (True, {})      # {}: the layer's pack cache (RQSCouplingSlabL1.backward)
             plan_full = self._programs.get(('slab_full', d, H, cubic, str(x2.device)), build_full)
             return RQSCouplingSlabL1.apply(x2, lin[0][0], lin[0][1], lin[-1][0], lin[-1][1], col_mask, evaluate, plan_full, live_idx,
                                            int(live[0]), len(live), sp.n_bins, sp.lower, sp.upper, cubic)

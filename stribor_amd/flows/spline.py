@@ -292,12 +292,35 @@ class RQSCouplingSlabL1(torch.autograd.Function):
         W2, b2 = W2.detach().contiguous(), b2.detach().contiguous()
         lib = _hip.lib()
         flag = _hip.err_flag(dev)
-        packs, n_fwd = _slab_packs(x2, W2, b2, slot_rows, hid_idx, n_live, H)
-        W1m = (W1.detach() * mask_t).contiguous()
         ht, xt = (H + 31) // 32, (d + 31) // 32
-        w1t = torch.empty(_hip.packed_linear_floats(xt, ht), dtype=torch.float32, device=dev)       # tiles + the pack's bias block
-        _hip.call('sx_pack_linear', x2, W1m.data_ptr(), None, H, d, col_slots.data_ptr(), hid_idx.data_ptr(), xt, ht, None, None,
-                  0.0, 1, _hip.GEMM_F16X3, flag, w1t.data_ptr())
+        cache = plan[6] if len(plan) > 6 else None
+        if cache is None:
+            packs, n_fwd = _slab_packs(x2, W2, b2, slot_rows, hid_idx, n_live, H)
+            W1m = (W1.detach() * mask_t).contiguous()
+            w1t = torch.empty(_hip.packed_linear_floats(xt, ht), dtype=torch.float32, device=dev)       # tiles + the pack's bias block
+            _hip.call('sx_pack_linear', x2, W1m.data_ptr(), None, H, d, col_slots.data_ptr(), hid_idx.data_ptr(), xt, ht, None, None,
+                      0.0, 1, _hip.GEMM_F16X3, flag, w1t.data_ptr())
+        else:
+            # the layer's three fragment packs (W2 slabs, their transpose, (W1 * mask)^T) live with the layer's plan and are re-made --
+            # ONE sx_pack_linear_batch launch into the same buffers -- when a parameter changed (3 launches + a product per call before)
+            stamp = tuple((p_.data_ptr(), p_._version) for p_ in (W1, W2, b2, mask_t))
+            mt = lib.sx_rqs_slab_slots(n_live) // 32
+            n_fwd, n_bwd = _hip.packed_linear_floats(mt, ht), _hip.packed_linear_floats(ht, mt)
+            if cache.get('stamp') != stamp or cache['packs'].device != dev:
+                if 'packs' not in cache or cache['packs'].device != dev:
+                    cache['packs'] = torch.empty(n_fwd + n_bwd, dtype=torch.float32, device=dev)
+                    cache['w1t'] = torch.empty(_hip.packed_linear_floats(xt, ht), dtype=torch.float32, device=dev)
+                    cache['W1m'] = torch.empty(H, d, dtype=torch.float32, device=dev)
+                    cache['table'] = _hip.PackTable()
+                torch.mul(W1.detach(), mask_t, out=cache['W1m'])
+                pk, sr, hi = cache['packs'].data_ptr(), slot_rows.data_ptr(), hid_idx.data_ptr()
+                cache['table'].run(x2, [
+                    (W2.data_ptr(), b2.data_ptr(), W2.shape[0], H, sr, hi, mt, ht, 0, 0, 0.0, 0, pk, 0),
+                    (W2.data_ptr(), 0, W2.shape[0], H, hi, sr, ht, mt, 0, 0, 0.0, 1, pk + 4 * n_fwd, 0),
+                    (cache['W1m'].data_ptr(), 0, H, d, col_slots.data_ptr(), hi, xt, ht, 0, 0, 0.0, 1, cache['w1t'].data_ptr(), 0)],
+                    _hip.GEMM_F16X3, flag)
+                cache['stamp'] = stamp
+            packs, w1t = cache['packs'], cache['w1t']
         gx = torch.empty_like(gy)           # every column is written: transformed ones by the slab kernel, the rest by the l1 kernel
         # every selected row sits in exactly one slot: all written; the whole layer's other rows (parameters of the columns the
         # coupling leaves alone) have a zero gradient

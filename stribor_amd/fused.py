@@ -157,8 +157,7 @@ class _PackJob:
         self.row_scale = self.bias_scale = None
         self.fold_ones = float(fold_ones)
 
-    def run(self, blobs: torch.Tensor, prec: int = _hip.GEMM_F16X3) -> None:
-        dev = blobs.device
+    def _operands(self, dev):
         if self.row_idx is None:
             self.row_idx = torch.from_numpy(self.row_idx_host).to(dev)
             self.col_idx = torch.from_numpy(self.col_idx_host).to(dev)
@@ -170,6 +169,18 @@ class _PackJob:
         b = None if self.b is None else self.b.detach()
         if W.dtype != torch.float32 or not W.is_contiguous():
             raise TypeError('stribor_amd: conditioner weights must be contiguous float32')
+        return W, b
+
+    def record(self, blobs: torch.Tensor):
+        """This pack as one record of a _hip.PackTable (sx_pack_linear_batch)."""
+        W, b = self._operands(blobs.device)
+        out_dim, in_dim = W.shape
+        return (W.data_ptr(), _hip.ptr(b) or 0, out_dim, in_dim, self.row_idx.data_ptr(), self.col_idx.data_ptr(), self.m_tiles,
+                self.k_tiles, _hip.ptr(self.row_scale) or 0, _hip.ptr(self.bias_scale) or 0, self.fold_ones, self.transpose,
+                blobs.data_ptr() + 4 * self.dst_off, 0 if self.bound_off is None else blobs.data_ptr() + 4 * self.bound_off)
+
+    def run(self, blobs: torch.Tensor, prec: int = _hip.GEMM_F16X3) -> None:
+        W, b = self._operands(blobs.device)
         out_dim, in_dim = W.shape
         if self.bound_off is not None:
             _hip.call('sx_pack_linear_bound', blobs, W.data_ptr(), _hip.ptr(b), out_dim, in_dim, self.row_idx.data_ptr(),
@@ -198,21 +209,37 @@ class _DerivedLinearJob:
         self._dev_idx = None
         self._keep = None
 
-    def run(self, blobs: torch.Tensor, prec: int = _hip.GEMM_F16X3) -> None:
-        dev = blobs.device
+    def _derive(self, dev):
+        """fn() into this job's own fp32 operands (the same storage at every re-pack: the records of a PackTable stay valid)."""
         W, b = self.fn(dev)
-        W = W.to(torch.float32).contiguous()
-        b = None if b is None else b.to(torch.float32).contiguous()
-        self._keep = (W, b)                      # stays alive until the async pack kernels have run
+        if self._keep is None or self._keep[0].shape != W.shape or self._keep[0].device != W.device or (self._keep[1] is None) != (b is None):
+            self._keep = (torch.empty(W.shape, dtype=torch.float32, device=W.device),
+                          None if b is None else torch.empty(b.shape, dtype=torch.float32, device=W.device))
+        self._keep[0].copy_(W)
+        if b is not None:
+            self._keep[1].copy_(b)
         if self._dev_idx is None:
             self._dev_idx = [(torch.from_numpy(r.astype(np.int32)).to(dev), torch.from_numpy(c.astype(np.int32)).to(dev))
                              for (r, c, _, _, _) in self.targets]
+        return self._keep
+
+    def records(self, blobs: torch.Tensor):
+        """Derive the matrix, then this layer's packs as records of a _hip.PackTable (sx_pack_linear_batch)."""
+        W, b = self._derive(blobs.device)
+        return [(W.data_ptr(), _hip.ptr(b) or 0, W.shape[0], W.shape[1], ri.data_ptr(), ci.data_ptr(), m_tiles, k_tiles, 0, 0, 0.0, 0,
+                 blobs.data_ptr() + 4 * off, 0) for (ri, ci), (_, _, k_tiles, off, m_tiles) in zip(self._dev_idx, self.targets)]
+
+    def write_ldj(self, blobs: torch.Tensor) -> None:
+        if self.ldj_fn is not None:
+            blobs[self.ldj_off:self.ldj_off + 1] = self.ldj_fn(blobs.device).reshape(1).to(torch.float32)
+
+    def run(self, blobs: torch.Tensor, prec: int = _hip.GEMM_F16X3) -> None:
+        W, b = self._derive(blobs.device)
         for (ri, ci), (_, _, k_tiles, off, m_tiles) in zip(self._dev_idx, self.targets):
             _hip.call('sx_pack_linear', blobs, W.data_ptr(), _hip.ptr(b), W.shape[0], W.shape[1], ri.data_ptr(),
                       ci.data_ptr(), m_tiles, k_tiles, None, None, 0.0, 0, prec, blobs.data_ptr(),
                       blobs.data_ptr() + 4 * off)
-        if self.ldj_fn is not None:
-            blobs[self.ldj_off:self.ldj_off + 1] = self.ldj_fn(dev).reshape(1).to(torch.float32)
+        self.write_ldj(blobs)
 
     def params(self):
         return self.sources
@@ -354,6 +381,7 @@ class CompiledProgram:
         # weight blobs per GEMM arithmetic (the fragment layouts differ): packed on first use / parameter change
         self._blobs = {}
         self._versions = {}
+        self._pack_tables = {}
         self.in_col = None if in_col is None else torch.from_numpy(in_col.astype(np.int32)).to(device)
         self.out_col = None if out_col is None else torch.from_numpy(out_col.astype(np.int32)).to(device)
         self.mlp_out_dim = mlp_out_dim
@@ -387,10 +415,26 @@ class CompiledProgram:
                 first = prec not in self._versions
                 if not first:
                     blobs[:1].zero_()              # header word 0: flags of the previous packing
+                # every Linear of the program in ONE launch (sx_pack_linear_batch; 13 packs per spline coupling, re-run after each
+                # optimizer step), then the other jobs in their order (a _PadJob follows the pack whose bias slots it overwrites)
+                batched = sum(1 if type(j) is _PackJob else len(j.targets) if type(j) is _DerivedLinearJob else 0 for j in self.jobs) > 1
+                if batched:
+                    records = []
+                    for j in self.jobs:
+                        if type(j) is _PackJob:
+                            records.append(j.record(blobs))
+                        elif type(j) is _DerivedLinearJob:      # (the layer's matrix is derived here, into the job's own operands)
+                            records += j.records(blobs)
+                    table = self._pack_tables.get(prec)
+                    if table is None:
+                        table = self._pack_tables[prec] = _hip.PackTable()
+                    table.run(blobs, records, prec, blobs.data_ptr())
                 for j in self.jobs:
                     # constants (spline bounds, live-slot masks: no parameter behind them) are written once per blob buffer; a
                     # training step re-packs the weights only (each constant was a host-to-device copy per step before)
-                    if first or j.params():
+                    if batched and type(j) is _DerivedLinearJob:
+                        j.write_ldj(blobs)
+                    elif (first or j.params()) and not (batched and type(j) is _PackJob):
                         j.run(blobs, prec)
                 self._versions[prec] = v
                 if prec == _hip.GEMM_F16X3:

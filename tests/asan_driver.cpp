@@ -185,6 +185,18 @@ int main() {
     EXPECT_BAD(sx_pack_linear(f, f, 4, 4, ix, ix, 0, 1, nullptr, nullptr, 0.f, 0, SX_GEMM_F16X3, nullptr, f, nullptr));
     EXPECT_BAD(sx_pack_linear(f, f, 4, 4, ix, ix, 1, 1, nullptr, nullptr, 0.f, 0, 42, nullptr, f, nullptr));
     EXPECT_BAD(sx_pack_linear_bound(f, f, 4, 4, ix, ix, 1, 1, nullptr, nullptr, 0.f, 0, SX_GEMM_F16X3, nullptr, f, nullptr, nullptr));
+    {
+        sx_pack_job pj{};
+        EXPECT_BAD(sx_pack_linear_batch(nullptr, 1, 1056, SX_GEMM_F16X3, nullptr, nullptr));
+        EXPECT_BAD(sx_pack_linear_batch(&pj, 0, 1056, SX_GEMM_F16X3, nullptr, nullptr));
+        EXPECT_BAD(sx_pack_linear_batch(&pj, 1, 0, SX_GEMM_F16X3, nullptr, nullptr));
+        EXPECT_BAD(sx_pack_linear_batch(&pj, 1, 1056, 42, nullptr, nullptr));
+        sx_reduce_job rj{};
+        EXPECT_BAD(sx_wgrad_reduce_batch(nullptr, f, &rj, 1, 1, 1056, nullptr));
+        EXPECT_BAD(sx_wgrad_reduce_batch(f, f, nullptr, 1, 1, 1056, nullptr));
+        EXPECT_BAD(sx_wgrad_reduce_batch(f, f, &rj, 0, 1, 1056, nullptr));
+        EXPECT_BAD(sx_wgrad_reduce_batch(f, f, &rj, 1, 0, 1056, nullptr));
+    }
     EXPECT_BAD(sx_wgrad_reduce(nullptr, 1, 32, 32, f, 32, f, 32, 32, nullptr, nullptr, nullptr));
     EXPECT_BAD(sx_wgrad_reduce(f, 0, 32, 32, f, 32, f, 32, 32, nullptr, nullptr, nullptr));
     EXPECT_BAD(sx_wgrad_reduce(f, 1, 129, 32, f, 32, f, 32, 32, nullptr, nullptr, nullptr));

@@ -673,6 +673,101 @@ def test_wgrad_contracts_row_groups_with_maps(n, M, Nc, width, a0, b0, f16):
     assert (db.cpu().double() - wantb).abs().max().item() <= 2e-5 * scale
 
 
+@pytest.mark.parametrize('prec', ['f16x3', 'f32'])
+def test_pack_table_writes_what_the_single_packs_write(prec):
+    """sx_pack_linear_batch (one launch for every Linear of a program after an optimizer step) against sx_pack_linear /
+    sx_pack_linear_bound one by one: plain, transposed, scaled rows + folded bias, with a bound slot, ragged maps with dropped
+    slots, different tile shapes in one table.  Bit-identical blobs, flag word and bounds; the table is re-used unchanged on the
+    second run and re-uploaded when a record changes."""
+    from stribor_amd import _hip
+    code = _hip.GEMM_F16X3 if prec == 'f16x3' else _hip.GEMM_F32
+    g = torch.Generator(device='cpu').manual_seed(5)
+    specs = [  # out, in, m_tiles, k_tiles, transpose, scaled, bound
+        (64, 32, 2, 1, 0, False, False), (94, 64, 3, 2, 0, True, True), (64, 47, 2, 2, 1, False, False),
+        (128, 128, 4, 4, 0, True, False), (20, 10, 1, 1, 0, False, True), (1504, 64, 4, 2, 0, True, True)]
+    total = sum(_hip.packed_linear_floats(m, k) + 4 for (_, _, m, k, _, _, _) in specs)
+    keep, records, singles, off = [], [], [], 1
+    blob_a = torch.zeros(total + 1, dtype=torch.float32, device=DEV)
+    blob_b = torch.zeros(total + 1, dtype=torch.float32, device=DEV)
+    for (out, inn, m, k, tr, scaled, bound) in specs:
+        W = torch.randn(out, inn, generator=g).to(DEV)
+        W[0, 0] = 7.0e4 if (out, inn) == (64, 32) else W[0, 0]                  # one weight beyond fp16: the flag word
+        b = None if tr else torch.randn(out, generator=g).to(DEV)
+        n_rows, n_cols = (inn, out) if tr else (out, inn)                       # transposed: row slots index W's columns
+        ri = torch.full((32 * m,), -1, dtype=torch.int32)
+        sel = torch.randperm(n_rows, generator=g)[:min(n_rows, 32 * m)].to(torch.int32)
+        ri[torch.randperm(32 * m, generator=g)[:sel.numel()]] = sel
+        ci = torch.full((32 * k,), -1, dtype=torch.int32)
+        selc = torch.randperm(n_cols, generator=g)[:min(n_cols, 32 * k)].to(torch.int32)
+        ci[torch.randperm(32 * k, generator=g)[:selc.numel()]] = selc
+        ri, ci = ri.to(DEV), ci.to(DEV)
+        rs = (torch.rand(32 * m, generator=g) + 0.5).to(DEV) if scaled else None
+        bs = (torch.rand(32 * m, generator=g) + 0.5).to(DEV) if scaled else None
+        fold = 1.0 if scaled else 0.0
+        nlin = _hip.packed_linear_floats(m, k)
+        keep += [W, b, ri, ci, rs, bs]
+        rec = lambda blob: (W.data_ptr(), _hip.ptr(b) or 0, out, inn, ri.data_ptr(), ci.data_ptr(), m, k, _hip.ptr(rs) or 0,
+                            _hip.ptr(bs) or 0, fold, tr, blob.data_ptr() + 4 * off, (blob.data_ptr() + 4 * (off + nlin)) if bound else 0)
+        records.append(rec(blob_a))
+        singles.append(rec(blob_b))
+        off += nlin + 4
+    table = _hip.PackTable()
+    table.run(blob_a, records, code, blob_a.data_ptr())
+    first_table = table._table
+    for r in singles:
+        name = 'sx_pack_linear_bound' if r[13] else 'sx_pack_linear'
+        args = [r[0], r[1] or None, r[2], r[3], r[4], r[5], r[6], r[7], r[8] or None, r[9] or None, r[10], r[11], code, blob_b.data_ptr(),
+                r[12]] + ([r[13]] if r[13] else [])
+        _hip.call(name, blob_b, *args)
+    torch.cuda.synchronize()
+    assert torch.equal(blob_a.view(torch.int32), blob_b.view(torch.int32))
+    assert (int(blob_a[:1].view(torch.int32).item()) & _hip.FLAG_F16_RANGE != 0) == (prec == 'f16x3')
+    table.run(blob_a, records, code, blob_a.data_ptr())
+    assert table._table is first_table                                           # unchanged records: no upload
+    blob_c = torch.zeros_like(blob_a)
+    moved = [r[:12] + (r[12] - blob_a.data_ptr() + blob_c.data_ptr(), (r[13] - blob_a.data_ptr() + blob_c.data_ptr()) if r[13] else 0)
+             for r in records]
+    table.run(blob_c, moved, code, blob_c.data_ptr())
+    torch.cuda.synchronize()
+    assert table._table is not first_table and torch.equal(blob_c.view(torch.int32), blob_b.view(torch.int32))
+
+
+def test_wgrad_reduce_table_adds_what_the_single_reductions_add():
+    """sx_wgrad_reduce_batch (the 2 L reductions that close a layer-major backward pass, one launch) against sx_wgrad_reduce per
+    job: different tile shapes, maps with dropped entries, a job without bias, accumulation into non-zero gradients."""
+    import ctypes as C
+    from stribor_amd import _hip
+    lib = _hip.lib()
+    g = torch.Generator(device='cpu').manual_seed(11)
+    n_part = 37
+    shapes = [(64, 64, 64, 50, True, False, True), (64, 32, 50, 32, False, True, True), (32, 32, 20, 31, True, True, False),
+              (128, 32, 128, 32, False, False, True)]        # M32, N32, m_valid, n_valid, row map?, col map?, bias?
+    part = torch.randn(sum(n_part * (M * N + M) for (M, N, *_rest) in shapes), generator=g).to(DEV)
+    out_a = torch.randn(sum(128 * 64 + 128 for _ in shapes), generator=g).to(DEV)
+    out_b = out_a.clone()
+    jobs = (_hip.sx_reduce_job * len(shapes))()
+    keep, po, oo = [], 0, 0
+    for j, (M, N, mv, nv, rmap, cmap, bias) in zip(jobs, shapes):
+        rm = torch.randperm(128, generator=g)[:M].to(torch.int32)
+        rm[::5] = -1
+        cm = torch.randperm(64, generator=g)[:N].to(torch.int32)
+        cm[1::4] = -1
+        rm, cm = rm.to(DEV), cm.to(DEV)
+        keep += [rm, cm]
+        (j.part_off, j.dW_off, j.db_off, j.ldw, j.row_map, j.col_map, j.M32, j.N32, j.m_valid, j.n_valid) = (
+            po, oo, (oo + 128 * 64) if bias else -1, 64, rm.data_ptr() if rmap else None, cm.data_ptr() if cmap else None, M, N, mv, nv)
+        _hip.check(lib.sx_wgrad_reduce(part.data_ptr() + 4 * po, n_part, M, N, out_b.data_ptr() + 4 * oo, 64,
+                                       (out_b.data_ptr() + 4 * (oo + 128 * 64)) if bias else None, mv, nv,
+                                       rm.data_ptr() if rmap else None, cm.data_ptr() if cmap else None, _hip.stream()), 'sx_wgrad_reduce')
+        po += n_part * (M * N + M)
+        oo += 128 * 64 + 128
+    table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(DEV)
+    _hip.check(lib.sx_wgrad_reduce_batch(part.data_ptr(), out_a.data_ptr(), table.data_ptr(), len(shapes), n_part,
+                                         max(M * N + M for (M, N, *_r) in shapes), _hip.stream()), 'sx_wgrad_reduce_batch')
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b)
+
+
 @pytest.mark.parametrize('n,in_dim,out_dim', [(5000, 64, 64), (4097, 33, 50), (8192, 64, 1504), (6001, 128, 300)])
 def test_batch_linear_weight_gradients_match_autograd(n, in_dim, out_dim):
     """BatchLinear (layer-wise training path): dL/dW, dL/db from sx_wgrad on row-major operands -- M up to 2048 in

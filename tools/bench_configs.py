@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of every BASELINE.json config on one MI355X (not the driver's contract bench: see bench.py).
 
-    python tools/bench_configs.py [cfg1 cfg2 cfg2_f32 cfg3 cfg4 ...] [--rows N] [--train] [--train-only] [--graph]
+    python tools/bench_configs.py [cfg1 cfg2 cfg2_f32 cfg3 cfg4 ...] [--rows N] [--train] [--train-only] [--optim] [--graph]
 
 Prints one JSON line per config: rows/s of log_prob, ms per batch, launches per batch.  --graph adds a line with the
 same call captured once into a HIP graph (torch.cuda.CUDAGraph) and replayed: what a launch-bound small batch costs
@@ -85,13 +85,19 @@ def main():
             print(json.dumps({'config': name + ' HIP-graph replay', 'rows': rows, 'ms_per_batch': gms,
                               'rows_per_s': rows / (gms * 1e-3), 'equals_eager': same}))
         if name in ('cfg2_f32', 'cfg3', 'cfg4') and '--train' in sys.argv:
+            # --optim: with an optimizer step (SGD, lr = 0: the weights keep their values, their versions move -- every Linear of
+            # the flow is re-laid into fragments before the next forward, as in a real training loop)
+            opt = torch.optim.SGD(flow.parameters(), lr=0.0) if '--optim' in sys.argv else None
+
             def train_step():
                 for p_ in flow.parameters():
                     p_.grad = None
                 loss = -flow.log_prob(x).mean()
                 loss.backward()
+                if opt is not None:
+                    opt.step()
             tms = timed(train_step, reps=5, inner=2)
-            print(json.dumps({'config': name + ' forward+backward (loss = -mean log_prob)', 'rows': rows,
+            print(json.dumps({'config': name + (' forward+backward+SGD step' if opt is not None else ' forward+backward (loss = -mean log_prob)'), 'rows': rows,
                               'ms_per_batch': tms, 'rows_per_s': rows / (tms * 1e-3)}))
         print(json.dumps({'config': name, 'rows': rows, 'dim': dim, 'x_dtype': str(dt), 'fused_single_launch': fused,
                           'ms_per_batch': ms, 'rows_per_s': rows / (ms * 1e-3), 'finite': bool(torch.isfinite(lp).all()),
