@@ -245,8 +245,8 @@ def _slab_packs(x2, W2, b2, slot_rows, hid_idx, n_live, H):
 
 class RQSCouplingSlabL1(torch.autograd.Function):
     """RQSCouplingSlab with the conditioner's FIRST layer inside the op as well, for Linear - Tanh - Linear conditioners without
-    a latent input (cfg 3): a differentiable op of (x, W1, b1, W2, b2).  Forward: h = tanh(x (W1 * mask)^T + b1) (one library
-    GEMM, kept for the backward) and the coupling's no-graph evaluation.  Backward: sx_rqs_slab_bwd leaves its dh partials in
+    a latent input (cfg 3): a differentiable op of (x, W1, b1, W2, b2).  Forward: h = tanh(x (W1 * mask)^T + b1) (an MFMA program launch
+    of net/mlp.py, kept for the backward) and the coupling's no-graph evaluation.  Backward: sx_rqs_slab_bwd leaves its dh partials in
     scratch and sx_rqs_slab_l1_bwd finishes the layer in one pass over the rows -- partial sum, tanh', dL/dx of the
     conditioning columns (= dL/dout + W1m^T da), dW1, db1 -- so no library GEMM, clone or add is left in the backward."""
 
@@ -265,14 +265,16 @@ class RQSCouplingSlabL1(torch.autograd.Function):
         else:
           with torch.no_grad():
             # h = tanh(x (W1 * mask)^T + b1) comes out of the forward program itself (side output of its hidden step) when the
-            # coupling runs as one fused program; otherwise one library GEMM + tanh
+            # coupling runs as one fused program; otherwise one Linear program (net/mlp.py BatchLinear) + tanh
             h = torch.empty(x2.shape[0], W1.shape[0], dtype=torch.float32, device=x2.device)
             got = evaluate(x2, h)
             if len(got) == 3 and got[2]:
                 y, ldj = got[0], got[1]
             else:
                 y, ldj = got[0], got[1]
-                h = torch.tanh(torch.addmm(b1, x2, (W1 * mask_t).t()))
+                from ..net.mlp import BatchLinear
+                h = BatchLinear._program_linear(x2, (W1 * mask_t).contiguous(), b1, False)       # (an MFMA program: net/mlp.py)
+                h = torch.tanh(h if h is not None else torch.addmm(b1, x2, (W1 * mask_t).t()))     # (fewer than 4096 rows: the library)
         ctx.save_for_backward(x2, h, W1, W2, b2, mask_t, y if cubic else None)
         ctx.meta = (plan, live_idx, live_start, n_live, n_bins, float(lower), float(upper))
         return y, ldj

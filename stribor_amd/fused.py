@@ -1332,11 +1332,13 @@ class ProgramBuilder:
             self.steps.append(dict(kind=_hip.STEP_MLP_OUT_TILE, c0=0, ct=0, t0=u, tt=1, reverse=int(accumulate), act=0,
                                    blob_off=off, blob_floats=n, ldj_scale=0.0, ldj_const=0.0))
 
-    def add_single_linear(self, W, b, out_rows: np.ndarray, transpose: bool = False) -> None:
+    def add_single_linear(self, W, b, out_rows: np.ndarray, transpose: bool = False, k0: int = 0, accumulate: bool = False) -> None:
         """ONE nn.Linear as a program (round 6, VERDICT r5 #7: the layer-wise training path's `F.linear` / `gy @ W` were library
         GEMMs): an SX_STEP_MLP_INPUT step (hidden = the program's input tiles) and one OUT_TILE step per 32 output columns.
-        y[:, i] = sum_c W[out_rows[i], c] x[:, c] + b[out_rows[i]];  transpose: the operand is W^T (y = x W: the input gradient of a
-        Linear; b must be None).  Input width <= 128 (the builder was made with hidden_width = dim, so h_tiles >= tiles)."""
+        y[:, i] = sum_c W[out_rows[i], k0 + c] x[:, c] + b[out_rows[i]];  transpose: the operand is W^T (y = x W: the input gradient
+        of a Linear; b must be None).  Input width <= 128 per program (the builder was made with hidden_width = dim, so h_tiles >=
+        tiles): a wider contraction is one program per 128 input columns -- `k0` = the first, the builder's x_cols / x_stride select
+        them from the wide rows -- with `accumulate` on every program but the first (the output tiles ADD into y)."""
         self._narrow_only('MLP programs')
         self._freeze_input()
         T, HT = self.tiles, self.h_tiles
@@ -1347,14 +1349,14 @@ class ProgramBuilder:
         out_rows = np.asarray(out_rows, dtype=np.int64)
         self.mlp_out_dim = len(out_rows)
         cL = np.full(32 * HT, -1, dtype=np.int64)
-        cL[:self.n_slots] = self.col_of_slot
+        cL[:self.n_slots] = np.where(self.col_of_slot >= 0, self.col_of_slot + k0, -1)
         for u in range(_ceil_div(len(out_rows), 32)):
             r = np.full(32, -1, dtype=np.int64)
             seg = out_rows[32 * u:32 * u + 32]
             r[:len(seg)] = seg
             off, n = self._alloc(_hip.packed_linear_floats(1, HT))
             self.jobs.append(_PackJob(W, b, r, cL, 1, HT, off, transpose=transpose))
-            self.steps.append(dict(kind=_hip.STEP_MLP_OUT_TILE, c0=0, ct=0, t0=u, tt=1, reverse=0, act=0,
+            self.steps.append(dict(kind=_hip.STEP_MLP_OUT_TILE, c0=0, ct=0, t0=u, tt=1, reverse=int(accumulate), act=0,
                                    blob_off=off, blob_floats=n, ldj_scale=0.0, ldj_const=0.0))
 
     # -- finish ------------------------------------------------------------------------------------

@@ -5,6 +5,7 @@ Same constructor, same ``state_dict`` keys (``net.{0,2,...}.{weight,bias}``), la
 (hidden activations never reach HBM); inside a Coupling the network is not called at all — its
 weights are consumed directly by the coupling kernel.
 """
+from collections import OrderedDict
 from typing import Callable, List, Optional, Union
 
 import numpy as np
@@ -16,8 +17,8 @@ from ..fused import ProgramBuilder, ProgramCache, StructureTracked
 
 
 class BatchLinear(torch.autograd.Function):
-    """y = x W^T + b for the layer-wise training path.  Forward and dL/dx: MFMA programs up to 128 x 256 features (round 6), library
-    GEMMs beyond.  dL/dW = (dL/dy)^T x and
+    """y = x W^T + b for the layer-wise training path.  Forward and dL/dx: MFMA programs (round 6; up to 128 contracted and 4064
+    output features, library GEMMs beyond).  dL/dW = (dL/dy)^T x and
     dL/db = sum_n dL/dy contract over the batch: for narrow layers (output <= 256 features) that is a tall-skinny product
     library GEMMs run on a handful of workgroups (0.63 ms for a 64 x 64 gradient over 2^18 rows) -- sx_wgrad computes
     both; for wide layers (a spline conditioner's 1504 rows) the library GEMM fills the chip and keeps dL/dW, and the
@@ -32,28 +33,55 @@ class BatchLinear(torch.autograd.Function):
         return x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and W.dtype == torch.float32
 
     # Round 6: forward and dL/dx as hand-written MFMA programs too (SX_STEP_MLP_INPUT: the output tiles contract the
-    # program's input; v_mfma_f32_32x32x2_f32) where one launch holds the layer -- up to 128 input and 256 output features; the pack is one small launch per 32
-    # output columns (the weights of a training step are new every step), so wider outputs (a spline conditioner's 1504 rows) keep
-    # the library GEMM, which fills the chip there.
-    PROGRAM_MAX_IN, PROGRAM_MAX_OUT = 128, 256
+    # program's input; v_mfma_f32_32x32x2_f32).  One launch holds 128 contracted features and up to 127 output tiles (a spline
+    # conditioner's 64 -> 1504 layer: 0.61 ms, the library's 0.61); every pack of a program is ONE sx_pack_linear_batch launch, and the
+    # programs of a weight are kept (LRU) and re-packed when its version moves.  A wider contraction runs as one launch per 128 columns,
+    # the later ones adding into y (tested: PROGRAM_MAX_IN = 2048) -- but measures 2.4 - 4.3 x the library GEMM at 2^18 rows (200 -> 64:
+    # 0.30 vs 0.09 ms; dL/dx of 64 -> 1504: 1.94 vs 0.45 ms; tools/experiments/linear_program_vs_library.py), so by default contractions
+    # beyond 128 columns stay with the library.
+    PROGRAM_MAX_IN, PROGRAM_MAX_OUT = 128, 127 * 32
+    _programs = OrderedDict()          # (weight storage, shape, orientation, bias storage, device) -> programs, least recently used first
+    _PROGRAMS_KEPT = 64
+
+    @staticmethod
+    def _linear_programs(W, b, transpose: bool, device):
+        key = (W.data_ptr(), tuple(W.shape), bool(transpose), None if b is None else b.data_ptr(), str(device))
+        progs = BatchLinear._programs.get(key)
+        if progs is not None:
+            BatchLinear._programs.move_to_end(key)
+            return progs
+        out_dim, in_dim = (W.shape[1], W.shape[0]) if transpose else W.shape
+        progs = []
+        for k0 in range(0, in_dim, 128):
+            kw = min(128, in_dim - k0)
+            bld = ProgramBuilder(kw, 0, kw)
+            if in_dim > 128:
+                bld.x_cols, bld.x_stride = np.arange(k0, k0 + kw), in_dim
+            bld.add_single_linear(W, b if k0 == 0 else None, np.arange(out_dim), transpose=transpose, k0=k0, accumulate=k0 > 0)
+            progs.append(bld.build(device))
+        # (the pack jobs keep `W` / `b` alive, so their storage cannot be handed to another tensor while the entry exists)
+        BatchLinear._programs[key] = progs
+        while len(BatchLinear._programs) > BatchLinear._PROGRAMS_KEPT:
+            BatchLinear._programs.popitem(last=False)
+        return progs
 
     @staticmethod
     def _program_linear(x, W, b, transpose: bool):
-        """x [N, K] @ (W^T | W) + b as one fused-kernel launch, or None where the shape is not the program's."""
+        """x [N, K] @ (W^T | W) + b as fused-kernel launches (one per 128 input features), or None where the shape is not the
+        programs'."""
         out_dim, in_dim = (W.shape[1], W.shape[0]) if transpose else W.shape
         if (x.shape[0] < BatchLinear.MIN_ROWS or in_dim > BatchLinear.PROGRAM_MAX_IN or out_dim > BatchLinear.PROGRAM_MAX_OUT
-                or not x.is_contiguous() or not W.is_contiguous()):
+                or not x.is_contiguous() or not W.is_contiguous() or x.shape[1] != in_dim):
             return None
         try:
-            bld = ProgramBuilder(in_dim, 0, in_dim)
-            bld.add_single_linear(W.detach(), None if b is None else b.detach(), np.arange(out_dim), transpose=transpose)
-            prog = bld.build(x.device)
+            progs = BatchLinear._linear_programs(W.detach(), None if b is None else b.detach(), transpose, x.device)
         except NotImplementedError:
             return None
         y = torch.empty(x.shape[0], out_dim, dtype=torch.float32, device=x.device)
-        # (the exact-fp32 arithmetic: a single [N, <= 128] x [<= 128, <= 256] layer is HBM-bound either way -- 400 MB against 17 Gflop
-        #  at 2^18 rows --, fp32 MFMA has no operand range and is torch's own arithmetic for this op)
-        prog.run(x, mlp_out=y, exact=True)
+        # (the exact-fp32 arithmetic: a single layer is HBM-bound either way -- 400 MB against 17 Gflop for [2^18, 128] x [128, 256]
+        #  --, fp32 MFMA has no operand range and is torch's own arithmetic for this op)
+        for prog in progs:
+            prog.run(x, mlp_out=y, exact=True)
         return y
 
     @staticmethod

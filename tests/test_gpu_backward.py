@@ -787,13 +787,18 @@ def test_batch_linear_weight_gradients_match_autograd(n, in_dim, out_dim):
     assert (x.grad.double() - xd.grad).abs().max().item() <= 1e-3
 
 
-@pytest.mark.parametrize('n,in_dim,out_dim', [(4096, 64, 64), (5000, 128, 256), (4099, 33, 7), (8192, 100, 130), (4096, 1, 1)])
+@pytest.mark.parametrize('n,in_dim,out_dim', [(4096, 64, 64), (5000, 128, 256), (4099, 33, 7), (8192, 100, 130), (4096, 1, 1),
+                                              # a spline conditioner's last layer (dL/dx contracts 1504 columns: 12 accumulating launches),
+                                              # inputs beyond 128 columns, ragged everything
+                                              (4100, 64, 1504), (4097, 200, 64), (4096, 300, 333)])
 def test_batch_linear_forward_and_input_gradient_run_as_programs(n, in_dim, out_dim, monkeypatch):
-    """Round 6: up to 128 input and 256 output features `BatchLinear`'s forward and dL/dx are ONE fused-kernel launch
-    each (SX_STEP_MLP_INPUT + OUT_TILE steps, v_mfma_f32_32x32x2_f32) instead of library GEMMs (net/mlp.py:48-58 layer by layer;
-    flows/affine.py:157-163): no torch `linear` / `matmul` is called, values against fp64, rows of 1e6 included (the exact
-    arithmetic has no operand range)."""
+    """Round 6: `BatchLinear`'s forward and dL/dx are fused-kernel launches (SX_STEP_MLP_INPUT + OUT_TILE steps,
+    v_mfma_f32_32x32x2_f32; one launch per 128 contracted columns, the later ones adding into the output) instead of library GEMMs
+    (net/mlp.py:48-58 layer by layer; flows/affine.py:157-163): no torch `linear` / `matmul` is called, values against fp64, rows
+    of 1e6 included (the exact arithmetic has no operand range).  A second call after an in-place weight update re-packs the kept
+    programs."""
     from stribor_amd.net.mlp import BatchLinear
+    monkeypatch.setattr(BatchLinear, 'PROGRAM_MAX_IN', 2048)       # (the default keeps contractions beyond 128 columns with the library: slower here)
     torch.manual_seed(n + in_dim)
     x = torch.randn(n, in_dim, device=DEV)
     x[3] *= 1.0e6
@@ -804,15 +809,25 @@ def test_batch_linear_forward_and_input_gradient_run_as_programs(n, in_dim, out_
     calls = []
     real_linear = torch.nn.functional.linear
     monkeypatch.setattr(torch.nn.functional, 'linear', lambda *a, **k: (calls.append('linear'), real_linear(*a, **k))[1])
+    real_matmul = torch.Tensor.__matmul__
+    monkeypatch.setattr(torch.Tensor, '__matmul__', lambda *a: (calls.append('matmul'), real_matmul(*a))[1])
     y = BatchLinear.apply(x, W, b)
     (y * weight).sum().backward()
+    kept = len(BatchLinear._programs)
+    with torch.no_grad():
+        W.mul_(0.5)                                                                  # same storage, next version: the kept programs re-pack
+    y2 = BatchLinear.apply(x.detach(), W, b)
     monkeypatch.undo()
-    assert not calls
+    assert calls == (['matmul'] if out_dim > BatchLinear.MAX_OUT or in_dim > 128 else []), calls     # (a wide layer's dL/dW stays the library's: mlp.py)
+    assert len(BatchLinear._programs) == kept
+    y2d = torch.nn.functional.linear(x.detach().double(), W.detach().double(), b.detach().double())
+    W.data.mul_(2.0)
     xd, Wd, bd = (t.detach().double().requires_grad_(True) for t in (x, W, b))
     yd = torch.nn.functional.linear(xd, Wd, bd)
     (yd * weight.double()).sum().backward()
     row_scale = xd.detach().abs().amax(1, keepdim=True).clamp_min(1.0) * float(in_dim) ** 0.5
     assert ((y.double() - yd).abs() / row_scale).max().item() <= 2e-6
+    assert ((y2.double() - y2d).abs() / row_scale).max().item() <= 2e-6
     assert (x.grad.double() - xd.grad).abs().max().item() <= 2e-5 * float(out_dim) ** 0.5
     st.check_errors()
 
