@@ -83,10 +83,23 @@ struct tile {            // one 32-feature tile of NS x 32 samples, C-fragment o
 // SX_FLAG_F16_RANGE in the caller's flag word, so an out-of-range input can never come back as a plausible number.
 // (NaN inputs are not counted -- they propagate through the MFMAs by themselves.)  The exact-fp32 variant has no range
 // limit and carries no tracker.
+#define SX_F16_MAX 65504.0f
+// With a redo list (sx_flow_run2) a sample is NAMED -- and evaluated by the exact-fp32 kernel -- as soon as one of its tracked operands
+// exceeds SX_REDO_ABOVE, well inside fp16's range.  A weight below 0.125 is held as hi + lo only to an ABSOLUTE 2^-25 (fp16's subnormal
+// quantum bounds its low half): an error of 3e-8 |x| sqrt(K) in the pre-activation, about 0.5 / |w| (~ 7 for nn.Linear's default
+// initialisation) times the fp32 sequence's own rounding whatever |x| is -- invisible against O(1) pre-activations at |x| ~ 1, but it
+// grows with |x| while the sensitive range of tanh does not: rows of |x| ~ 6e4, inside fp16's range, came out 27 x the fp32 sequence's
+// error (tools/fuzz_dense.py 120 914 --big, case 85).  At 256 the term is ~ 1e-7 |x| <= 2.6e-5 relative in the worst (cancelling) case.
+// Ordinary (normalised) data never reaches it; data that does is evaluated exactly, at the exact kernel's speed.
+// Without a list (graph-building calls, plain sx_flow_run) the limit stays fp16's own: beyond it NaN + SX_FLAG_F16_RANGE.
+#ifndef SX_REDO_ABOVE
+#define SX_REDO_ABOVE 256.0f
+#endif
 struct rng_t {
     uint64_t bad;          // lanes that formed an out-of-range operand: wave-uniform, lives in SGPRs (the pure coupling kernel
-};                         // sits exactly on its 128-VGPR budget: a per-lane running max spilled)
-#define SX_F16_MAX 65504.0f
+                           // sits exactly on its 128-VGPR budget: a per-lane running max spilled)
+    float thr = SX_F16_MAX;    // wave-uniform (an SGPR): SX_REDO_ABOVE in launches that carry a redo list
+};
 __device__ __forceinline__ float rng_max(float m, float a, float b) {
     // ONE v_max3_f32 m, |a|, |b|.  Written as fmaxf(m, fmaxf(fabsf(a), fabsf(b))) the compiler canonicalises each operand first
     // (v_max_f32 |a|, |a| ...): four vector instructions per register pair, a seventh of cfg 4's vector work (round-5 ISA reading).
@@ -96,7 +109,7 @@ __device__ __forceinline__ float rng_max(float m, float a, float b) {
 }
 __device__ __forceinline__ void rng_note(rng_t &rg, float m) {
 #if defined(SX_F16X3) && !defined(SX_NO_RANGE_TRACK)
-    rg.bad |= __builtin_amdgcn_ballot_w64(m > SX_F16_MAX);          // v_cmp + s_or_b64
+    rg.bad |= __builtin_amdgcn_ballot_w64(m > rg.thr);              // v_cmp + s_or_b64
 #endif
 }
 // one (32-row group, bad-sample mask) pair per sample tile of the wave onto the redo list (flow_kargs::redo)
@@ -1512,6 +1525,7 @@ __global__ __launch_bounds__(64 * SX_BLOCK_WAVES(TX, MODE), SX_WAVES_FOR(TX, MOD
         float ldj_c = 0.f;
         rng_t rg;                                                    // fp16 x 3 operand range of this chunk's samples
         rg.bad = 0ull;
+        rg.thr = k.redo != nullptr ? SX_REDO_ABOVE : SX_F16_MAX;
         tile<NS> hid[MODE == 1 ? HT : 1];
         constexpr bool LIN = MODE == 2 || MODE == 7 || MODE == 8;    // programs with dense linear layers
         tile<NS> hidp[(MODE == 9 || MODE == 14 || MODE == 16 || MODE == 17) ? HT : 1];   // MODE 9 / 14 / 16 / 17: hidden state kept between deep-conditioner steps

@@ -462,6 +462,44 @@ def test_auto_mode_with_wide_hidden_layers_accumulating_chunks():
             st.check_errors()
 
 
+def test_rows_beyond_256_go_to_the_exact_kernel_long_before_fp16_ends():
+    """SX_REDO_ABOVE (sx_flow_kernel.h; found by tools/fuzz_dense.py 120 914 --big, case 85: a row of 6.4e4 -- inside fp16's range -- at
+    27 x the fp32 sequence's error).  A weight below 0.125 is held to an absolute 3e-8, an error that grows with the entries it
+    multiplies: with a redo list a sample is named from |operand| > 256 on.  Rows of 300 .. 6e4 in 'fast' equal the 'exact' arithmetic
+    bit for bit; rows up to 250 stay on the fp16 x 3 kernel (equal to the same rows in a batch without the large ones); WITHOUT a list
+    (graph-building calls, plain sx_flow_run) the limit is still fp16's own: the same rows are finite, unflagged fp16 x 3 results."""
+    from stribor_amd import _hip
+    torch.manual_seed(3)
+    for desc, dim in ((fd.cfg2_desc(4, 64, 64), 64), (fd.cfg4_desc(1, 128, 64), 128)):
+        flow = fd.build_flow(st, desc, dim).to(DEV)
+        n = 4096 + 5
+        x = torch.randn(n, dim, device=DEV)
+        mid = {3: 300.0, 40: 1.0e3, 41: 2.0e4, 4100: 6.0e4}
+        for r, v in mid.items():
+            x[r] *= v / x[r].abs().max()
+        x[7] *= 250.0 / x[7].abs().max()                     # just below the threshold (the state may cross it later in the flow: not asserted)
+        named = torch.zeros(n, dtype=torch.bool, device=DEV)
+        named[list(mid)] = True
+        calm = x.clone()
+        calm[named] = torch.randn(len(mid), dim, device=DEV)
+        with torch.no_grad():
+            st.set_gemm_precision('exact')
+            exact = flow.log_prob(x)
+            st.set_gemm_precision('fast')
+            fast, fast_calm = flow.log_prob(x), flow.log_prob(calm)
+            st.check_errors()
+            assert torch.equal(fast[named], exact[named])
+            quiet = ~named
+            quiet[7] = False
+            assert torch.equal(fast[quiet], fast_calm[quiet])
+            if dim == 64:       # (pure coupling flow: the state stays of the input's magnitude; cfg 4's dense layers amplify it beyond 65504)
+                with _hip.no_redo():
+                    bare = flow.log_prob(x)
+                    st.check_errors()                        # nothing beyond 65504: no flag
+                assert torch.isfinite(bare).all() and torch.equal(bare[quiet], fast[quiet])
+                assert not torch.equal(bare[named], exact[named])
+
+
 def test_rescale_is_exact_for_linear_maps():
     """Samples beyond fp16's range are evaluated by the exact-fp32 kernel (round 6: the redo pass; round 5 rescaled them by a power of
     two on the fp16 weights).  The logic check the tolerance-based range tests cannot give: for a LINEAR map without bias the exact

@@ -4,7 +4,7 @@ hidden 4 .. 64, split or parity masks (the split-mask stacks are the pure MODE 5
 rows, optionally rows scaled to 1e4 .. 1e6 (beyond fp16's range: the rescale paths) and bf16 storage -- log_prob, inverse + log-det and
 forward + log-det of the HIP path against the fp64 oracle.  Values that went through dense layers are held relative to the row's
 largest entry; an out-of-range row to 16 x the fp32 oracle's own error (tests/test_gpu_precision.py).
-    python tools/fuzz_dense.py [n_cases] [seed] [--big] [--bf16] [--exact]"""
+    python tools/fuzz_dense.py [n_cases] [seed] [--big] [--mid] [--bf16] [--exact] [--detail]"""
 import os
 import sys
 
@@ -27,6 +27,9 @@ DEV = 'cuda:0'
 #  them to the same 16 x as --exact; round 5's 64 x was the allowance for the fp16 weights' low halves against entries of 1e5)
 KREF = 16.0
 BIG = '--big' in sys.argv
+MID = '--mid' in sys.argv      # rows of 30 .. 6e4: INSIDE fp16's range, either side of SX_REDO_ABOVE = 256 (round 6: the fp16 weights' absolute
+                               # resolution times a large entry -- 27 x fp32's error on a row of 6.4e4, seed 914 case 85 -- is why rows are
+                               # named from 256 on, not from 65504)
 BF16 = '--bf16' in sys.argv
 
 
@@ -75,6 +78,13 @@ def main():
         flow = flow.to(DEV)
         x = torch.randn(n, dim) * 1.3
         big_rows = torch.zeros(n, dtype=torch.bool)
+        if MID:
+            for r in rng.choice(n, size=min(n, int(rng.integers(1, 9))), replace=False):
+                if rng.random() < 0.5:
+                    x[r] *= float(10.0 ** rng.uniform(1.5, 4.8)) / x[r].abs().max()
+                else:
+                    x[r, int(rng.integers(0, dim))] = float(10.0 ** rng.uniform(1.5, 4.8)) * (1 if rng.random() < 0.5 else -1)
+                big_rows[r] = True
         if BIG:
             for r in rng.choice(n, size=min(n, int(rng.integers(1, 5))), replace=False):
                 if rng.random() < 0.5:
