@@ -415,6 +415,7 @@ extern "C" int sx_flow_bwd_run(const sx_program *prog_host, const float *blobs, 
     a.grid = pick_grid(n_rows, a.lds, prog_host->tiles, 11);
     a.stream = sx_stream(stream);
     a.row_t = g; a.side = nullptr; a.side_width = 0;
+    a.redo = nullptr; a.redo_pass = 0;          // (the backward has no redo pass: an operand beyond fp16's range is flagged)
     const int rpb = 32 * SX_BLOCK_WAVES(prog_host->tiles, 11);
     const int64_t n_chunks = (n_rows + rpb - 1) / rpb;
     // single-step programs hand their chunks out statically: one workgroup per CU, every chunk the same work -- and without
