@@ -524,9 +524,9 @@ int sx_flow_run(const sx_program *prog_host, const float *blobs, const void *x, 
  *   redo         caller-owned DEVICE scratch of sx_flow_redo_words(n_rows) 32-bit words, zeroed once; the call leaves it zeroed
  *                (one list per stream: launches that share a list must be ordered).
  * precision must be SX_GEMM_F16X3.  The fp16 x 3 kernel does not flag a sample whose operand (flow state, conditioner input, an
- * unbounded hidden activation) exceeds 256 (SX_REDO_ABOVE, sx_flow_kernel.h: far inside fp16's range -- a weight below 0.125 is held
- * to an absolute 3e-8 only, an error that grows with the entries it multiplies; from 256 on it would pass 1e-5 relative) -- and does
- * not rescale it either --: it appends the sample's 32-row group and a per-sample mask to `redo`,
+ * unbounded hidden activation) exceeds 2048 (SX_REDO_ABOVE, sx_flow_kernel.h: far inside fp16's range -- a weight below 0.125 is held
+ * to an absolute 3e-8 only, an error that grows with the entries it multiplies: 1.4e-4 relative measured on a row of 6.4e4, 4.5e-6 at
+ * 2048) -- and does not rescale it either --: it appends the sample's 32-row group and a per-sample mask to `redo`,
  * and a second launch of the same program on the exact-fp32 kernel evaluates, stores (y, ldj_out, logp_out, mlp_out) and sums
  * (sum_out) exactly those samples.  On ordinary data the second launch reads one word per workgroup and ends.
  * Not for programs with side outputs (`side`).  MLP programs that ACCUMULATE into mlp_out (later hidden chunks) leave the named

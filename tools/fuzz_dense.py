@@ -27,9 +27,9 @@ DEV = 'cuda:0'
 #  them to the same 16 x as --exact; round 5's 64 x was the allowance for the fp16 weights' low halves against entries of 1e5)
 KREF = 16.0
 BIG = '--big' in sys.argv
-MID = '--mid' in sys.argv      # rows of 30 .. 6e4: INSIDE fp16's range, either side of SX_REDO_ABOVE = 256 (round 6: the fp16 weights' absolute
+MID = '--mid' in sys.argv      # rows of 30 .. 6e4: INSIDE fp16's range, either side of SX_REDO_ABOVE = 2048 (round 6: the fp16 weights' absolute
                                # resolution times a large entry -- 27 x fp32's error on a row of 6.4e4, seed 914 case 85 -- is why rows are
-                               # named from 256 on, not from 65504)
+                               # named from 2048 on, not from 65504)
 BF16 = '--bf16' in sys.argv
 
 
