@@ -36,6 +36,35 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_hip.sx_program) == 32 + 48 * _hip.SX_MAX_STEPS
 
 
+def test_ctypes_records_match_the_header_as_a_c_compiler_lays_it_out():
+    """include/stribor_hip.h compiled as plain C (gcc): size and every field offset of the structs a binding fills -- sx_step,
+    sx_program, and the device-table records of sx_pack_linear_batch / sx_wgrad_reduce_batch (a mismatch there would not fail a
+    call: the kernel would read shifted pointers) -- against the ctypes mirrors in stribor_amd/_hip.py."""
+    import subprocess
+    import tempfile
+    structs = {'sx_step': _hip.sx_step, 'sx_program': _hip.sx_program, 'sx_pack_job': _hip.sx_pack_job, 'sx_reduce_job': _hip.sx_reduce_job}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "stribor_hip.h"', 'int main(void) {']
+    for name, cls in structs.items():
+        lines.append('  printf("%s %%zu", sizeof(%s));' % (name, name))
+        for field, _ in cls._fields_:
+            lines.append('  printf(" %%zu", offsetof(%s, %s));' % (name, field))
+        lines.append('  printf("\\n");')
+    lines += ['  return 0;', '}']
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, 'layout.c')
+        with open(src, 'w') as f:
+            f.write('\n'.join(lines) + '\n')
+        subprocess.run(['gcc', '-std=c99', '-I', os.path.join(ROOT, 'include'), src, '-o', os.path.join(td, 'layout')], check=True)
+        out = subprocess.run([os.path.join(td, 'layout')], check=True, capture_output=True, text=True).stdout
+    seen = {}
+    for line in out.strip().splitlines():
+        name, *nums = line.split()
+        seen[name] = [int(v) for v in nums]
+    for name, cls in structs.items():
+        want = [ctypes.sizeof(cls)] + [getattr(cls, field).offset for field, _ in cls._fields_]
+        assert seen[name] == want, (name, seen[name], want)
+
+
 def test_no_cpu_fallback():
     f = st.NormalizingFlow(st.UnitNormal(2), [st.Affine(2)])
     with pytest.raises(RuntimeError, match='no CPU fallback'):
