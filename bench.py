@@ -465,12 +465,12 @@ def extra_flow_entries(st, fd, dev, gen, steps):
     return out
 
 
-def time_training_step(name, workload, flow, x, steps, note):
+def time_training_step(name, workload, flow, x, steps, note, optimizer=False):
     """`_time_training_step`, but a failing entry (e.g. a GemmRangeError of the fp16 x 3 arithmetic on some initialisation) is
     recorded as such instead of taking the headline line down with it."""
     import torch
     try:
-        return _time_training_step(name, workload, flow, x, steps, note)
+        return _time_training_step(name, workload, flow, x, steps, note, optimizer)
     except Exception as e:
         torch.cuda.synchronize()
         try:
@@ -481,16 +481,21 @@ def time_training_step(name, workload, flow, x, steps, note):
         return {'name': name, 'workload': workload, 'error': repr(e)[:300], 'finite': False, 'ms_per_step': None}
 
 
-def _time_training_step(name, workload, flow, x, steps, note):
+def _time_training_step(name, workload, flow, x, steps, note, optimizer=False):
     """Training step beside the inference lines: forward + backward of loss = -log_prob(x).mean(), all
-    parameter gradients; median over event-timed groups of 3 steps after warm-up."""
+    parameter gradients; median over event-timed groups of 3 steps after warm-up.  optimizer: + an SGD step (lr = 0: the values
+    stay, the parameter versions move, so every Linear of the flow is re-laid into MFMA fragments before the next forward -- what
+    a training LOOP pays and the plain step does not)."""
     import torch
+    opt = torch.optim.SGD(flow.parameters(), lr=0.0) if optimizer else None
 
     def step():
         for p_ in flow.parameters():
             p_.grad = None
         loss = -flow.log_prob(x).mean()
         loss.backward()
+        if opt is not None:
+            opt.step()
         return loss
 
     for _ in range(3):
@@ -751,10 +756,14 @@ def main():
                                              'parameter', f3, x3t, 12,
                                              'spline backward fused with the last conditioner layer, no [N, 1504] parameter tensor '
                                              '(sx_rqs_slab_bwd, DESIGN 4.3.1); HBM bytes per step in profiles/pmc_training_cfg3_fused.json'))
+                tr.append(time_training_step('cfg3_train_sgd', 'cfg3 flow, 2^18 rows fp32: the same step + an SGD optimizer step (every weight '
+                                             're-packed into fragments before the next forward)', f3, x3t, 9,
+                                             'one sx_pack_linear_batch launch per re-packed program (104 + 24 single pack launches per step before '
+                                             'round 6: 10.6 -> 9.3 ms on one box, profiles/r06_ab_head_training_optim.txt)', optimizer=True))
                 del f3
                 pt = load_profile('pmc_training_cfg3_fused.json')
                 if pt and not pt.get('stale_profile'):
-                    tr[-1]['hbm_MB_per_step_pmc'] = {'read': pt.get('hbm_read_MB_per_step'), 'written': pt.get('hbm_write_MB_per_step'),
+                    tr[-2]['hbm_MB_per_step_pmc'] = {'read': pt.get('hbm_read_MB_per_step'), 'written': pt.get('hbm_write_MB_per_step'),
                                                      'source': 'profiles/pmc_training_cfg3_fused.json (builder-run rocprofv3 passes, same build id)'}
                 torch.manual_seed(0)
                 cub = [dict(d_, spline_type='cubic') for d_ in fd.cfg3_desc()]
